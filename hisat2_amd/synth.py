@@ -1,0 +1,138 @@
+"""Seeded synthetic genomes and reads.
+
+The reference's own simulator (hisat2_simulate_reads.py) crashes under Python 3 for
+arbitrary contig names, so workloads are generated here: uniform-random genomes (optionally
+with N-gaps and planted repeats) and reads drawn from them with i.i.d. substitutions
+(default 0.5 %/base), optional short indels, strand ~ Bernoulli(1/2).  Everything is a pure
+function of the seed so the GPU box regenerates byte-identical inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_ALPHA = np.frombuffer(b"ACGTN", dtype=np.uint8)
+_COMP = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+
+
+def make_genome(contig_lens, seed, n_gaps=0, gap_len=500, repeats=0, repeat_len=400):
+    """Return list of uint8 arrays (codes 0..4) — one per contig."""
+    rng = np.random.default_rng(seed)
+    contigs = []
+    for L in contig_lens:
+        g = rng.integers(0, 4, size=L, dtype=np.uint8)
+        for _ in range(repeats):
+            if L > 4 * repeat_len:
+                a = int(rng.integers(0, L - repeat_len))
+                b = int(rng.integers(0, L - repeat_len))
+                g[b:b + repeat_len] = g[a:a + repeat_len]
+        for _ in range(n_gaps):
+            if L > 4 * gap_len:
+                a = int(rng.integers(gap_len, L - 2 * gap_len))
+                g[a:a + gap_len] = 4
+        contigs.append(g)
+    return contigs
+
+
+def write_fasta(path, contigs, names=None, width=60):
+    with open(path, "wb") as f:
+        for i, g in enumerate(contigs):
+            name = names[i] if names else f"chr{i + 1}"
+            f.write(b">" + name.encode() + b"\n")
+            s = _ALPHA[g].tobytes()
+            for k in range(0, len(s), width):
+                f.write(s[k:k + width] + b"\n")
+
+
+def make_reads(contigs, n, rdlen, seed, sub_rate=0.005, indel_rate=0.0, n_rate=0.0):
+    """Draw n reads of length rdlen.  Returns (codes[n, rdlen] uint8, truth[n,3] = contig,pos,fw)."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    ok = lens > rdlen + 8
+    w = np.where(ok, lens - rdlen - 8, 0).astype(np.float64)
+    w /= w.sum()
+    ci = rng.choice(len(contigs), size=n, p=w)
+    reads = np.empty((n, rdlen), dtype=np.uint8)
+    truth = np.empty((n, 3), dtype=np.int64)
+    for c in range(len(contigs)):
+        idx = np.nonzero(ci == c)[0]
+        if idx.size == 0:
+            continue
+        g = contigs[c]
+        pos = rng.integers(0, lens[c] - rdlen - 8, size=idx.size)
+        win = g[pos[:, None] + np.arange(rdlen + 8)[None, :]]
+        # redraw windows containing N (bounded retries)
+        for _ in range(8):
+            bad = (win[:, :rdlen] > 3).any(axis=1)
+            if not bad.any():
+                break
+            pos[bad] = rng.integers(0, lens[c] - rdlen - 8, size=int(bad.sum()))
+            win[bad] = g[pos[bad][:, None] + np.arange(rdlen + 8)[None, :]]
+        r = win[:, :rdlen].copy()
+        if indel_rate > 0:
+            for k in np.nonzero(rng.random(idx.size) < indel_rate * rdlen)[0]:
+                p = int(rng.integers(10, rdlen - 10))
+                ln = int(rng.integers(1, 4))
+                if rng.random() < 0.5:   # deletion from read (ref gap in read)
+                    r[k, p:] = win[k, p + ln:p + ln + rdlen - p]
+                else:                    # insertion into read
+                    ins = rng.integers(0, 4, size=ln, dtype=np.uint8)
+                    r[k, p + ln:] = win[k, p:rdlen - ln]
+                    r[k, p:p + ln] = ins
+        sub = rng.random((idx.size, rdlen)) < sub_rate
+        shift = rng.integers(1, 4, size=(idx.size, rdlen), dtype=np.uint8)
+        r = np.where(sub & (r < 4), (r + shift) & 3, r).astype(np.uint8)
+        if n_rate > 0:
+            r = np.where(rng.random((idx.size, rdlen)) < n_rate, np.uint8(4), r)
+        fw = rng.random(idx.size) < 0.5
+        rc = _COMP[r[:, ::-1]]
+        r = np.where(fw[:, None], r, rc)
+        reads[idx] = r
+        truth[idx, 0] = c
+        truth[idx, 1] = pos
+        truth[idx, 2] = fw
+    return reads, truth
+
+
+def make_pairs(contigs, n, rdlen, seed, frag_mean=300, frag_sd=30, sub_rate=0.005):
+    """--fr pairs: mate1 fw at fragment start, mate2 rc at fragment end (or the mirror)."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    fl = np.clip(np.rint(rng.normal(frag_mean, frag_sd, size=n)), max(150, rdlen), 600).astype(np.int64)
+    w = np.where(lens > 700, lens - 700, 0).astype(np.float64)
+    w /= w.sum()
+    ci = rng.choice(len(contigs), size=n, p=w)
+    m1 = np.empty((n, rdlen), dtype=np.uint8)
+    m2 = np.empty((n, rdlen), dtype=np.uint8)
+    for c in range(len(contigs)):
+        idx = np.nonzero(ci == c)[0]
+        if idx.size == 0:
+            continue
+        g = contigs[c]
+        pos = rng.integers(0, lens[c] - 700, size=idx.size)
+        a = g[pos[:, None] + np.arange(rdlen)[None, :]]
+        b = g[(pos + fl[idx] - rdlen)[:, None] + np.arange(rdlen)[None, :]]
+        for arr in (a, b):
+            sub = rng.random(arr.shape) < sub_rate
+            shift = rng.integers(1, 4, size=arr.shape, dtype=np.uint8)
+            arr[...] = np.where(sub & (arr < 4), (arr + shift) & 3, arr)
+        brc = _COMP[b[:, ::-1]]
+        flip = rng.random(idx.size) < 0.5
+        m1[idx] = np.where(flip[:, None], brc, a)
+        m2[idx] = np.where(flip[:, None], a, brc)
+    return m1, m2
+
+
+def write_reads_fasta(path, reads, start_id=0):
+    n, L = reads.shape
+    with open(path, "wb") as f:
+        txt = _ALPHA[reads]
+        for i in range(n):
+            f.write(b">%d\n" % (start_id + i))
+            f.write(txt[i].tobytes() + b"\n")
+
+
+def flatten_reads(reads):
+    """(codes flat uint8, offsets uint32[n+1]) layout used by the C-ABI."""
+    n, L = reads.shape
+    offs = (np.arange(n + 1, dtype=np.uint64) * L).astype(np.uint32)
+    return np.ascontiguousarray(reads.reshape(-1)), offs

@@ -1,0 +1,729 @@
+/*
+ * h2o.c — CPU ORACLE (test infrastructure; see h2o.h).  Plain C restatement of the
+ * HISAT2 2.2.3 seed-and-extend hot path; every function cites the reference lines it
+ * follows.  Pinned by tests/test_oracle_golden.py against vectors produced by the real
+ * reference classes (oracle/ref_probe.cpp).
+ */
+#include "h2o.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ file helpers */
+typedef struct { uint8_t* d; size_t n, pos; } rbuf;
+
+static int slurp(const char* base, const char* ext, rbuf* b) {
+	char fn[4096];
+	snprintf(fn, sizeof fn, "%s.%s", base, ext);
+	FILE* f = fopen(fn, "rb");
+	if(!f) return -1;
+	fseek(f, 0, SEEK_END);
+	long n = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	b->d = (uint8_t*)malloc((size_t)n + 16);
+	b->n = (size_t)n;
+	b->pos = 0;
+	if(fread(b->d, 1, (size_t)n, f) != (size_t)n) { fclose(f); return -1; }
+	fclose(f);
+	return 0;
+}
+static uint32_t rd_u32(rbuf* b) { uint32_t v; memcpy(&v, b->d + b->pos, 4); b->pos += 4; return v; }
+static uint32_t rd_u16(rbuf* b) { uint16_t v; memcpy(&v, b->d + b->pos, 2); b->pos += 2; return v; }
+static uint32_t rd_w(rbuf* b, int wsz) { return wsz == 4 ? rd_u32(b) : rd_u16(b); }
+static uint32_t* rd_arr(rbuf* b, int wsz, size_t n) {
+	uint32_t* a = (uint32_t*)malloc((n + 1) * sizeof(uint32_t));
+	for(size_t i = 0; i < n; i++) a[i] = rd_w(b, wsz);
+	return a;
+}
+
+/* GFMParams::init  gfm.h:138-185 */
+static void params_init(h2o_params* p, uint32_t len, uint32_t gbwtLen, uint32_t numNodes,
+                        int32_t lineRate, int32_t offRate, int32_t ftabChars, uint32_t eftabLen, int wsz)
+{
+	memset(p, 0, sizeof *p);
+	p->wsz = wsz;
+	uint32_t wmax = wsz == 4 ? 0xffffffffu : 0xffffu;
+	p->linear = ((uint32_t)((len + 1) & wmax) == gbwtLen || gbwtLen == 0);
+	p->len = len;
+	p->gbwtLen = gbwtLen == 0 ? len + 1 : gbwtLen;
+	p->numNodes = numNodes == 0 ? len + 1 : numNodes;
+	uint32_t gbwtSz = p->linear ? p->gbwtLen / 4 + 1 : p->gbwtLen / 2 + 1;
+	p->lineRate = lineRate; p->offRate = offRate; p->ftabChars = ftabChars; p->eftabLen = eftabLen;
+	p->offMask = (wmax << offRate) & wmax;
+	p->ftabLen = (1u << (ftabChars * 2)) + 1;
+	p->offsLen = (p->numNodes + (1u << offRate) - 1) >> offRate;
+	p->sideSz = 1u << lineRate;
+	if(p->linear) { p->sideGbwtSz = p->sideSz - wsz * 4; p->sideGbwtLen = p->sideGbwtSz << 2; }
+	else          { p->sideGbwtSz = p->sideSz - wsz * 6; p->sideGbwtLen = p->sideGbwtSz << 1; }
+	p->numSides = (gbwtSz + p->sideGbwtSz - 1) / p->sideGbwtSz;
+	p->gbwtTotLen = p->numSides * p->sideSz;
+}
+
+/* body shared by GFM::readIntoMemory gfm.h:6039-6332 and LocalGFM::readIntoMemory hgfm.h:1150-1400 */
+static void read_gfm_body(rbuf* b, h2o_gfm* g, int wsz) {
+	g->nPat = rd_w(b, wsz);
+	g->plen = rd_arr(b, wsz, g->nPat);
+	g->nFrag = rd_w(b, wsz);
+	g->rstarts = rd_arr(b, wsz, (size_t)g->nFrag * 3);
+	g->gfm = (uint8_t*)malloc(g->p.gbwtTotLen + 16);
+	memcpy(g->gfm, b->d + b->pos, g->p.gbwtTotLen);
+	b->pos += g->p.gbwtTotLen;
+	g->nZ = rd_w(b, wsz);
+	g->zOffs = rd_arr(b, wsz, g->nZ);
+	for(int i = 0; i < 5; i++) g->fchr[i] = rd_w(b, wsz);
+	g->ftab = rd_arr(b, wsz, g->p.ftabLen);
+	g->eftab = rd_arr(b, wsz, g->p.eftabLen);
+}
+
+int h2o_index_load(const char* base, h2o_index** out) {
+	h2o_index* ix = (h2o_index*)calloc(1, sizeof *ix);
+	rbuf b1, b2, b3, b4, b5, b6;
+	if(slurp(base, "1.ht2", &b1) || slurp(base, "2.ht2", &b2) || slurp(base, "3.ht2", &b3) ||
+	   slurp(base, "4.ht2", &b4)) { free(ix); return -1; }
+	/* .1.ht2 header  gfm.h:5917-6000 */
+	if(rd_u32(&b1) != 1) return -2;          /* endianness sentinel */
+	rd_u32(&b1);                             /* version */
+	uint32_t len = rd_u32(&b1), gbwtLen = rd_u32(&b1), numNodes = rd_u32(&b1);
+	int32_t lineRate = (int32_t)rd_u32(&b1); rd_u32(&b1);
+	int32_t offRate = (int32_t)rd_u32(&b1), ftabChars = (int32_t)rd_u32(&b1);
+	uint32_t eftabLen = rd_u32(&b1); rd_u32(&b1); /* flags */
+	params_init(&ix->g.p, len, gbwtLen, numNodes, lineRate, offRate, ftabChars, eftabLen, 4);
+	read_gfm_body(&b1, &ix->g, 4);
+	/* names  gfm.h:6317-6332 */
+	ix->names = (char**)calloc(ix->g.nPat + 1, sizeof(char*));
+	{
+		uint32_t k = 0;
+		size_t s = b1.pos;
+		while(b1.pos < b1.n && k < ix->g.nPat) {
+			char c = (char)b1.d[b1.pos];
+			if(c == '\n' || c == '\0') {
+				size_t l = b1.pos - s;
+				ix->names[k] = (char*)malloc(l + 1);
+				memcpy(ix->names[k], b1.d + s, l);
+				ix->names[k][l] = 0;
+				k++;
+				s = b1.pos + 1;
+				if(c == '\0') break;
+			}
+			b1.pos++;
+		}
+	}
+	/* .2.ht2  gfm.h:6334-6432 */
+	rd_u32(&b2);
+	ix->g.offs = rd_arr(&b2, 4, ix->g.p.offsLen);
+	/* .3.ht2 / .4.ht2  reference.cpp:101-190 */
+	h2o_ref* r = &ix->r;
+	if(rd_u32(&b3) != 1) return -2;
+	r->nrecs = rd_u32(&b3);
+	r->rec_off = (uint32_t*)malloc(4 * (r->nrecs + 1));
+	r->rec_len = (uint32_t*)malloc(4 * (r->nrecs + 1));
+	r->rec_first = (uint8_t*)malloc(r->nrecs + 1);
+	r->refRecOffs = (uint32_t*)malloc(4 * (r->nrecs + 2));
+	r->refOffs = (uint32_t*)malloc(4 * (r->nrecs + 2));
+	r->refLens = (uint32_t*)malloc(4 * (r->nrecs + 2));
+	uint64_t cumsz = 0, cumlen = 0;
+	for(uint32_t i = 0; i < r->nrecs; i++) {
+		r->rec_off[i] = rd_u32(&b3);
+		r->rec_len[i] = rd_u32(&b3);
+		r->rec_first[i] = b3.d[b3.pos++] ? 1 : 0;
+		if(r->rec_first[i]) {
+			r->refRecOffs[r->nrefs] = i;
+			r->refOffs[r->nrefs] = (uint32_t)cumsz;
+			if(r->nrefs > 0) r->refLens[r->nrefs - 1] = (uint32_t)cumlen;
+			cumlen = 0;
+			r->nrefs++;
+		}
+		cumsz += r->rec_len[i];
+		cumlen += r->rec_off[i];
+		cumlen += r->rec_len[i];
+	}
+	r->refRecOffs[r->nrefs] = r->nrecs;
+	r->refOffs[r->nrefs] = (uint32_t)cumsz;
+	r->refLens[r->nrefs - 1] = (uint32_t)cumlen;
+	r->bufSz = cumsz;
+	r->buf = b4.d; /* keep */
+	/* .5/.6.ht2  hgfm.h:2560-2640, 1130-1400 */
+	if(slurp(base, "5.ht2", &b5) == 0 && slurp(base, "6.ht2", &b6) == 0) {
+		rd_u32(&b5); rd_u32(&b6);
+		ix->nlocal = rd_u32(&b5);
+		int32_t llr = (int32_t)rd_u32(&b5); rd_u32(&b5);
+		int32_t lor = (int32_t)rd_u32(&b5), lfc = (int32_t)rd_u32(&b5); rd_u32(&b5);
+		ix->local = (h2o_gfm*)calloc(ix->nlocal + 1, sizeof(h2o_gfm));
+		ix->local_first = (uint32_t*)calloc(ix->g.nPat + 2, 4);
+		uint32_t ntext = 0;
+		for(uint32_t i = 0; i < ix->nlocal; i++) {
+			h2o_gfm* l = &ix->local[i];
+			l->tidx = rd_u32(&b5); l->localOffset = rd_u32(&b5); l->joinedOffset = rd_u32(&b5);
+			uint32_t llen = rd_u16(&b5), lgl = rd_u16(&b5), lnn = rd_u16(&b5), lel = rd_u16(&b5);
+			params_init(&l->p, llen, lgl, lnn, llr, lor, lfc, lel, 2);
+			while(ntext <= l->tidx) ix->local_first[ntext++] = i;
+			if(llen == 0) continue;
+			read_gfm_body(&b5, l, 2);
+			l->offs = rd_arr(&b6, 2, l->p.offsLen);
+		}
+		while(ntext <= ix->g.nPat) ix->local_first[ntext++] = ix->nlocal;
+		free(b5.d); free(b6.d);
+	}
+	/* _minK  hi_aligner.h:3979-3984 */
+	{ uint32_t gl = ix->g.p.len; ix->minK = 0; while(gl > 0) { gl >>= 2; ix->minK++; } }
+	free(b1.d); free(b2.d); free(b3.d);
+	*out = ix;
+	return 0;
+}
+
+void h2o_index_free(h2o_index* ix) { (void)ix; /* test-lifetime object */ }
+
+void h2o_scoring_default(h2o_scoring* s) { /* scoring.h:29-87 */
+	s->mmpMax = 6; s->mmpMin = 2; s->nPen = 1; s->rdGapConst = 5; s->rdGapLinear = 3;
+	s->rfGapConst = 5; s->rfGapLinear = 3; s->scMax = 2; s->scMin = 1; s->matchBonus = 0;
+}
+
+/* ------------------------------------------------------------------ rank (a3-a5) */
+static const uint64_t c_table[4] = { /* gfm.h:75-80 */
+	0xffffffffffffffffull, 0xaaaaaaaaaaaaaaaaull, 0x5555555555555555ull, 0x0000000000000000ull };
+
+static inline int countInU64(int c, uint64_t dw) { /* gfm.h:566-578 */
+	uint64_t x0 = dw ^ c_table[c];
+	uint64_t x1 = x0 >> 1;
+	uint64_t x2 = x1 & 0x5555555555555555ull;
+	uint64_t x3 = x0 & x2;
+	return __builtin_popcountll(x3);
+}
+
+/* countUpTo, POPCNT path  gfm.h:3166-3201 */
+static uint32_t countUpTo(const uint8_t* side, int by_, int bp, int c) {
+	uint32_t cCnt = 0;
+	int i = 0;
+	int by = by_ + (bp > 0 ? 1 : 0);
+	for(; i < by; i += 8) {
+		uint64_t w;
+		memcpy(&w, side + i, 8);
+		if(i + 8 < by) {
+			cCnt += countInU64(c, w);
+		} else {
+			uint32_t by_shift = 8 - (by - i);
+			uint32_t bp_shift = (bp > 0 ? 4 - bp : 0);
+			uint32_t shift = (by_shift << 3) + (bp_shift << 1);
+			w <<= shift;
+			uint32_t add = countInU64(c, w);
+			if(c == 0) add -= (shift >> 1);
+			cCnt += add;
+			break;
+		}
+	}
+	return cCnt;
+}
+
+uint32_t h2o_rank(const h2o_gfm* g, uint32_t row, int c) { /* SideLocus::initFromRow gfm.h:376-393; countBt2Side gfm.h:2958-3001 */
+	const h2o_params* p = &g->p;
+	uint32_t sideNum = row / p->sideGbwtLen, charOff = row % p->sideGbwtLen;
+	const uint8_t* side = g->gfm + (size_t)sideNum * p->sideSz;
+	int by = charOff >> 2, bp = charOff & 3;
+	uint32_t cCnt = countUpTo(side, by, bp, c);
+	if(c == 0) {
+		for(uint32_t i = 0; i < g->nZ; i++) { /* '$' stored as A: gfm.h:2967-2979 with postReadInit :2783 */
+			uint32_t zs = g->zOffs[i] / p->sideGbwtLen, zc = g->zOffs[i] % p->sideGbwtLen;
+			if(zs == sideNum && zc < charOff) cCnt--;
+		}
+	}
+	const uint8_t* acgt8 = side + p->sideGbwtSz + (p->linear ? 0 : 2 * p->wsz);
+	uint32_t occ;
+	if(p->wsz == 4) { memcpy(&occ, acgt8 + 4 * c, 4); }
+	else { uint16_t o; memcpy(&o, acgt8 + 2 * c, 2); occ = o; }
+	return occ + cCnt + g->fchr[c];
+}
+
+int h2o_rowL(const h2o_gfm* g, uint32_t row) { /* gfm.h:3615-3630 */
+	const h2o_params* p = &g->p;
+	uint32_t sideNum = row / p->sideGbwtLen, charOff = row % p->sideGbwtLen;
+	const uint8_t* side = g->gfm + (size_t)sideNum * p->sideSz;
+	return (side[charOff >> 2] >> ((charOff & 3) * 2)) & 3;
+}
+
+/* ------------------------------------------------------------------ ftab (a10) */
+static uint32_t ftabHi(const h2o_gfm* g, uint32_t i) { /* gfm.h:2618-2634 */
+	uint32_t lim = g->p.linear ? g->p.len : g->p.gbwtLen;
+	uint32_t wmax = g->p.wsz == 4 ? 0xffffffffu : 0xffffu;
+	if(g->ftab[i] <= lim) return g->ftab[i];
+	uint32_t ef = g->ftab[i] ^ wmax;
+	return g->eftab[ef * 2 + 1];
+}
+static uint32_t ftabLo(const h2o_gfm* g, uint32_t i) { /* gfm.h:2696-2712 */
+	uint32_t lim = g->p.linear ? g->p.len : g->p.gbwtLen;
+	uint32_t wmax = g->p.wsz == 4 ? 0xffffffffu : 0xffffu;
+	if(g->ftab[i] <= lim) return g->ftab[i];
+	uint32_t ef = g->ftab[i] ^ wmax;
+	return g->eftab[ef * 2];
+}
+int h2o_ftab_lohi(const h2o_gfm* g, const uint8_t* seq, uint32_t off, uint32_t* top, uint32_t* bot) {
+	/* ftabSeqToInt (fw index, rev=false) gfm.h:2569-2594; ftabLoHi gfm.h:2670-2685 */
+	uint32_t fi = 0;
+	for(int i = 0; i < g->p.ftabChars; i++) {
+		int c = seq[off + i];
+		if(c > 3) return 0;
+		fi = (fi << 2) | (uint32_t)c;
+	}
+	*top = ftabHi(g, fi);
+	*bot = ftabLo(g, fi + 1);
+	return 1;
+}
+
+/* ------------------------------------------------------------------ SA offset (a14) */
+static int is_zoff(const h2o_gfm* g, uint32_t row) {
+	for(uint32_t i = 0; i < g->nZ; i++) if(row == g->zOffs[i]) return 1;
+	return 0;
+}
+/* Linear-index meaning of GWState::init/advance + tryOffset (group_walk.h:509-560, 1035-1336;
+ * gfm.h:2719-2733) == getOffset (gfm.h:5682-5716): walk LF until a sampled row or '$'. */
+uint32_t h2o_get_offset(const h2o_gfm* g, uint32_t row, uint32_t* steps) {
+	uint32_t jumps = 0;
+	while(1) {
+		if(is_zoff(g, row)) break;
+		if((row & g->p.offMask) == row) {
+			uint32_t off = g->offs[row >> g->p.offRate];
+			uint32_t wmax = g->p.wsz == 4 ? 0xffffffffu : 0xffffu;
+			if(off != wmax) { if(steps) *steps = jumps; return off + jumps; }
+		}
+		int c = h2o_rowL(g, row);
+		row = h2o_rank(g, row, c);
+		jumps++;
+	}
+	if(steps) *steps = jumps;
+	return jumps;
+}
+
+int h2o_joined_to_text(const h2o_gfm* g, uint32_t qlen, uint32_t off, uint32_t* tidx, uint32_t* textoff,
+                       uint32_t* tlen, int rejectStraddle, int* straddled) /* gfm.h:5527-5600 */
+{
+	uint32_t top = 0, bot = g->nFrag, elt = H2O_MAX;
+	while(1) {
+		uint32_t oldelt = elt;
+		elt = top + ((bot - top) >> 1);
+		if(oldelt == elt) { *tidx = H2O_MAX; return 0; }
+		uint32_t lower = g->rstarts[elt * 3];
+		uint32_t upper = (elt == g->nFrag - 1) ? g->p.len : g->rstarts[(elt + 1) * 3];
+		if(lower <= off) {
+			if(upper > off) {
+				if(off + qlen > upper) {
+					*straddled = 1;
+					if(rejectStraddle) { *tidx = H2O_MAX; return 0; }
+				}
+				*tidx = g->rstarts[elt * 3 + 1];
+				uint32_t fragoff = off - g->rstarts[elt * 3];
+				*textoff = fragoff + g->rstarts[elt * 3 + 2];
+				break;
+			} else top = elt;
+		} else bot = elt;
+	}
+	*tlen = g->plen[*tidx];
+	return 1;
+}
+
+/* ------------------------------------------------------------------ reference (a17) */
+/* Meaning of BitPairReference::getStretch reference.cpp:486-650 (== getStretchNaive :404-470):
+ * dest[i] = base of text tidx at toff+i (0..3), 4 for N / outside the sequence. */
+void h2o_get_stretch(const h2o_ref* r, uint32_t tidx, int64_t toff, uint32_t count, uint8_t* dest) {
+	memset(dest, 4, count);
+	uint64_t reci = r->refRecOffs[tidx], recf = r->refRecOffs[tidx + 1];
+	uint64_t bufOff = r->refOffs[tidx];
+	int64_t off = 0;
+	for(uint64_t i = reci; i < recf; i++) {
+		off += r->rec_off[i];
+		int64_t lo = off, hi = off + r->rec_len[i];     /* unambiguous stretch [lo,hi) */
+		int64_t a = toff > lo ? toff : lo, b = toff + count < hi ? toff + (int64_t)count : hi;
+		for(int64_t t = a; t < b; t++) {
+			uint64_t bo = bufOff + (uint64_t)(t - lo);
+			dest[t - toff] = (r->buf[bo >> 2] >> ((bo & 3) << 1)) & 3;
+		}
+		bufOff += r->rec_len[i];
+		off = hi;
+		if(off >= toff + (int64_t)count) break;
+	}
+}
+
+/* ------------------------------------------------------------------ partialSearch (a11) */
+void h2o_partial_search(const h2o_index* ix, const uint8_t* seq, uint32_t len, uint32_t cur_in,
+                        int pseudogeneStop_in, int anchorStop_in, uint32_t khits, h2o_bwthit* o)
+{ /* hi_aligner.h:6361-6600, linear index (mapLF gfm.h:3739; mapGLF1 linear branch gfm.h:3957-3972; mapLF1 :3892) */
+	const h2o_gfm* g = &ix->g;
+	const uint32_t ftabLen = (uint32_t)g->p.ftabChars, minK = ix->minK;
+	int pseudogeneStop_ = pseudogeneStop_in, anchorStop_ = anchorStop_in;
+	int pseudogeneStop = 0, anchorStop = 0;
+	memset(o, 0, sizeof *o);
+	o->top = o->bot = o->node_top = o->node_bot = H2O_MAX;
+	o->hit_type = H2O_CANDIDATE_HIT;
+	o->numPartialSearch = 1;
+	uint32_t cur = cur_in, offset = cur_in, dep = cur_in;
+	uint32_t left = len - dep;
+	o->bwoff = offset;
+	if(left < ftabLen + 1) {                                  /* :6403-6417 */
+		cur = len; o->len = cur - offset; o->cur = cur; o->done = 1; return;
+	}
+	for(uint32_t i = 0; i < ftabLen; i++) {                  /* :6419-6437 */
+		int c = seq[len - dep - 1 - i];
+		if(c > 3) {
+			cur += (i + 1); o->len = cur - offset; o->cur = cur; if(cur >= len) o->done = 1; return;
+		}
+	}
+	uint32_t top = 0, bot = 0;
+	h2o_ftab_lohi(g, seq, len - dep - ftabLen, &top, &bot);  /* :6440 */
+	dep += ftabLen;
+	if(top >= bot) {                                         /* :6442-6457 */
+		cur = dep; o->len = cur - offset; o->cur = cur; if(cur >= len) o->done = 1; return;
+	}
+	uint32_t same_range = 0, similar_range = 0;
+	uint32_t ntop = 0, nbot = 0;                              /* node_range, initially (0,0) */
+	uint32_t last_side[2] = { H2O_MAX, H2O_MAX };
+	while(dep < len) {                                       /* :6459-6539 */
+		int c = seq[len - dep - 1];
+		uint32_t ttop = 0, tbot = 0;
+		if(c <= 3) {
+			if(bot - top > 1) {                               /* bloc.valid(): mapLF on both loci */
+				o->nrank += 2;
+				uint32_t s0 = top / g->p.sideGbwtLen, s1 = bot / g->p.sideGbwtLen;
+				o->nside += (s0 == s1) ? 1 : 2;
+				ttop = h2o_rank(g, top, c);
+				tbot = h2o_rank(g, bot, c);
+			} else {                                         /* mapGLF1 -> mapLF1 */
+				o->nrank += 1;
+				o->nside += 1;
+				if(h2o_rowL(g, top) == c && !is_zoff(g, top)) {
+					ttop = h2o_rank(g, top, c);
+					tbot = ttop + 1;
+				}
+			}
+			(void)last_side;
+		}
+		if(ttop >= tbot) break;
+		uint32_t nt = tbot - ttop, no = nbot - ntop;         /* linear: node range == row range */
+		if(pseudogeneStop_) {                                /* :6488-6503 */
+			if(nt < no && no <= (5u < khits ? 5u : khits)) {
+				if(dep - offset >= minK + 6 && similar_range >= 5) {
+					o->numUniqueSearch++; pseudogeneStop = 1; break;
+				}
+			}
+			if(nt != 1) {
+				if(nt + 2 >= no) similar_range++;
+				else if(nt + 4 < no) similar_range = 0;
+			} else pseudogeneStop_ = 0;
+		}
+		if(anchorStop_) {                                    /* :6505-6519 */
+			if(nt != 1 && no == nt) {
+				same_range++;
+				if(same_range >= 5) anchorStop_ = 0;
+			} else same_range = 0;
+			if(dep - offset >= minK + 8 && nt >= 4) anchorStop_ = 0;
+		}
+		top = ttop; bot = tbot; ntop = ttop; nbot = tbot;
+		dep++;
+		if(anchorStop_) {                                    /* :6530-6536 */
+			if(dep - offset >= minK + 12 && bot - top == 1) {
+				o->numUniqueSearch++; anchorStop = 1; break;
+			}
+		}
+	}
+	if(top < bot) {                                          /* :6542-6598 */
+		uint32_t hit_type = H2O_CANDIDATE_HIT;
+		if(anchorStop) hit_type = H2O_ANCHOR_HIT;
+		else if(pseudogeneStop) hit_type = H2O_PSEUDOGENE_HIT;
+		int report = ntop < nbot;   /* no LF step taken => node_range (0,0) => not reported */
+		if(report) { o->top = top; o->bot = bot; o->node_top = ntop; o->node_bot = nbot; }
+		o->len = dep - offset;
+		o->hit_type = hit_type;
+		cur = dep;
+		if(cur >= len) {
+			if(hit_type == H2O_CANDIDATE_HIT) o->numUniqueSearch++;
+			o->done = 1;
+		}
+		o->cur = cur;
+	} else {
+		/* unreachable: range only shrinks to empty through the break above, which keeps
+		 * the previous non-empty range */
+		o->cur = cur;
+	}
+	o->pseudogeneStop = pseudogeneStop;
+	o->anchorStop = anchorStop;
+}
+
+/* ------------------------------------------------------------------ getGenomeCoords (a14) */
+int h2o_genome_coords(const h2o_index* ix, uint32_t top, uint32_t bot, uint32_t maxelt, uint32_t rdlen,
+                      int rejectStraddle, h2o_coord* coords, uint32_t* ncoords, int* straddled, uint32_t* nsteps)
+{ /* hi_aligner.h:5774-5855 (linear: node range == [top,bot)) */
+	*straddled = 0;
+	uint32_t nelt = bot - top;
+	if(nelt > maxelt) nelt = maxelt;
+	uint32_t n = *ncoords;
+	for(uint32_t e = 0; e < nelt; e++) {
+		uint32_t st = 0;
+		uint32_t joff = h2o_get_offset(&ix->g, top + e, &st);
+		if(nsteps) *nsteps += st;
+		uint32_t tidx = 0, toff = 0, tlen = 0;
+		int st2 = 0;
+		h2o_joined_to_text(&ix->g, rdlen, joff, &tidx, &toff, &tlen, rejectStraddle, &st2);
+		*straddled |= st2;
+		if(tidx == H2O_MAX) { *ncoords = n; return 0; }
+		coords[n].tidx = st2 ? H2O_MAX : tidx;
+		coords[n].toff = toff;
+		coords[n].joinedOff = joff;
+		n++;
+	}
+	*ncoords = n;
+	return 1;
+}
+
+/* ------------------------------------------------------------------ extend (a18, a19) */
+static int mm_pen(const h2o_scoring* sc, int q) { /* Scoring::initPens COST_MODEL_QUAL scoring.h:117-124 */
+	if(q < 0) q = 0;
+	int ii = q < 40 ? q : 40;
+	float frac = (float)ii / 40.0f;
+	return sc->mmpMin + (int)(frac * (sc->mmpMax - sc->mmpMin));
+}
+
+static int sc_pen(const h2o_scoring* sc, int q) { /* scoring.h:312-318 */
+	if(q <= 33) return sc->scMin;
+	q -= 33;
+	if(q > 40) q = 40;
+	return (int)((q / 40.0f) * (sc->scMax - sc->scMin) + sc->scMin);
+}
+
+int64_t h2o_calculate_score(const h2o_scoring* sc, const char* qual, h2o_ghit* h) { /* hi_aligner.h:3711-3891 (no splice edits) */
+	int64_t score = 0;
+	uint32_t mm = 0;
+	for(uint32_t i = 0; i < h->nedits; i++) {
+		const h2o_edit* e = &h->edits[i];
+		if(e->type == H2O_EDIT_MM) {
+			int q = qual[h->rdoff + e->pos] - 33;
+			/* Scoring::score(rdc, refm, q) scoring.h:259-269 */
+			int rdc = e->qchr == 'A' ? 0 : e->qchr == 'C' ? 1 : e->qchr == 'G' ? 2 : e->qchr == 'T' ? 3 : 4;
+			if(rdc > 3) score -= sc->nPen;
+			else if(e->chr == 'N') score += sc->matchBonus;   /* mask 15 contains every base */
+			else score -= mm_pen(sc, q);
+			mm++;
+		} else if(e->type == H2O_EDIT_READ_GAP) {
+			int open = !(i > 0 && h->edits[i - 1].type == H2O_EDIT_READ_GAP && h->edits[i - 1].pos == e->pos);
+			score -= open ? (sc->rdGapConst + sc->rdGapLinear) : sc->rdGapLinear;
+		} else if(e->type == H2O_EDIT_REF_GAP) {
+			int open = !(i > 0 && h->edits[i - 1].type == H2O_EDIT_REF_GAP && h->edits[i - 1].pos + 1 == e->pos);
+			score -= open ? (sc->rfGapConst + sc->rfGapLinear) : sc->rfGapLinear;
+		}
+	}
+	/* soft-clip penalty :3868-3874 — Scoring::sc(q) scoring.h:312-318 (takes the raw quality char) */
+	for(uint32_t i = 0; i < h->trim5; i++) score -= sc_pen(sc, qual[i]);
+	for(uint32_t i = 0; i < h->trim3; i++) score -= sc_pen(sc, qual[i]);
+	score += (int64_t)(h->len - mm) * sc->matchBonus;
+	h->score = score;
+	return score;
+}
+
+static void edits_insert_front(h2o_edit* e, uint32_t* n, h2o_edit x) {
+	if(*n >= H2O_MAX_EDITS) return;
+	memmove(e + 1, e, *n * sizeof *e);
+	e[0] = x; (*n)++;
+}
+
+/* alignWithALTs (hi_aligner.h:683-783) + alignWithALTs_recur without ALTs (:2763-2853 left, :3168-3216 right) */
+static uint32_t align_no_alts(const h2o_index* ix, uint32_t joinedOff, const uint8_t* rdseq, uint32_t base_rdoff,
+                              uint32_t rdoff, uint32_t rdlen, uint32_t tidx, int rfoff, uint32_t rflen, int left,
+                              h2o_edit* edits, uint32_t* nedits_io, uint32_t mm, uint32_t* numNs)
+{
+	(void)joinedOff;
+	int best_rdoff = (int)rdoff;
+	if(numNs) *numNs = 0;
+	uint32_t nedits = *nedits_io;
+	h2o_edit tmp[H2O_MAX_EDITS];
+	uint32_t ntmp = nedits;
+	memcpy(tmp, edits, nedits * sizeof *tmp);
+	uint32_t rdoff_add = rdoff - base_rdoff;
+	do { /* _recur, dep 0 */
+		if(rfoff < -16) break;
+		uint32_t contig_len = ix->r.refLens[tidx];
+		if(rfoff >= (int64_t)contig_len) break;
+		if(rfoff >= 0 && (uint64_t)rfoff + rflen > contig_len) rflen = contig_len - rfoff;
+		else if(rfoff < 0 && rflen > contig_len) rflen = contig_len;
+		if(rflen == 0) break;
+		uint8_t rfbuf[1100];
+		if(rflen > 1024) rflen = 1024;
+		{
+			/* rfseq = raw_refbuf + 16 + off + min(rfoff,0) over a buffer pre-filled with 4 */
+			memset(rfbuf, 4, sizeof rfbuf);
+			int s = rfoff > 0 ? rfoff : 0;
+			uint32_t cnt = rfoff > 0 ? rflen : rflen + rfoff;
+			h2o_get_stretch(&ix->r, tidx, s, cnt, rfbuf + 32);
+		}
+		const uint8_t* rfseq = rfbuf + 32 + (rfoff < 0 ? rfoff : 0);
+		if(left) {
+			uint32_t tmp_mm = 0, mm_tmp_numNs = 0;
+			int mm_min_rd_i = (int)rdoff;
+			for(int rf_i = (int)rflen - 1; rf_i >= 0 && mm_min_rd_i >= 0; rf_i--, mm_min_rd_i--) {
+				int rf_bp = rfseq[rf_i], rd_bp = rdseq[mm_min_rd_i];
+				if(rf_bp != rd_bp || rd_bp == 4) {
+					if(tmp_mm >= mm) break;
+					tmp_mm++;
+					h2o_edit e = { (uint32_t)mm_min_rd_i, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0 };
+					edits_insert_front(tmp, &ntmp, e);
+				}
+				if(rf_bp == 4) mm_tmp_numNs++;
+			}
+			if(mm_min_rd_i < best_rdoff) {
+				best_rdoff = mm_min_rd_i;
+				memcpy(edits, tmp, ntmp * sizeof *tmp); *nedits_io = ntmp;
+				if(numNs) *numNs = mm_tmp_numNs;
+			}
+		} else {
+			uint32_t tmp_mm = 0, mm_max_rd_i = 0;
+			for(uint32_t rf_i = 0; rf_i < rflen && mm_max_rd_i < rdlen; rf_i++, mm_max_rd_i++) {
+				int rf_bp = rfseq[rf_i], rd_bp = rdseq[rdoff + mm_max_rd_i];
+				if(rf_bp != rd_bp || rd_bp == 4) {
+					if(tmp_mm >= mm) break;
+					tmp_mm++;
+					if(ntmp < H2O_MAX_EDITS) {
+						h2o_edit e = { mm_max_rd_i + rdoff_add, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0 };
+						tmp[ntmp++] = e;
+					}
+				}
+			}
+			if((int)(mm_max_rd_i + rdoff) > best_rdoff) {
+				best_rdoff = (int)(mm_max_rd_i + rdoff);
+				memcpy(edits, tmp, ntmp * sizeof *tmp); *nedits_io = ntmp;
+			}
+		}
+	} while(0);
+	uint32_t extlen = left ? rdoff - best_rdoff : best_rdoff - rdoff;   /* :741-750 */
+	uint32_t ne = *nedits_io;
+	if(extlen > 0 && ne > 0) {                                            /* :751-779 */
+		const h2o_edit* f = &edits[0];
+		if(f->pos + extlen == base_rdoff + 1) {
+			if(f->type == H2O_EDIT_READ_GAP || f->type == H2O_EDIT_REF_GAP) extlen = 0;
+			if(f->type == H2O_EDIT_MM && f->chr == 'N') extlen = 0;
+		}
+		const h2o_edit* b = &edits[ne - 1];
+		if(extlen > 0 && b->pos == rdoff - base_rdoff + extlen - 1) {
+			if(b->type == H2O_EDIT_READ_GAP || b->type == H2O_EDIT_REF_GAP) extlen = 0;
+		}
+		if(extlen == 0 && ne > nedits) {
+			if(left) memmove(edits, edits + (ne - nedits), nedits * sizeof *edits);
+			*nedits_io = nedits;
+		}
+	}
+	return extlen;
+}
+
+int h2o_extend(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq, const char* qual, uint32_t rdlen,
+               h2o_ghit* h, uint32_t* leftext, uint32_t* rightext, uint32_t mm)
+{ /* GenomeHit::extend hi_aligner.h:2031-2232 */
+	uint32_t max_leftext = *leftext, max_rightext = *rightext;
+	*leftext = 0; *rightext = 0;
+	if(max_leftext > 0 && h->rdoff > 0) {
+		if(h->toff <= 0) return 0;
+		int rl = (int)h->toff - (int)h->rdoff;
+		uint32_t reflen = h->rdoff + 10;
+		rl -= (int)(reflen - h->rdoff);
+		if(rl < 0) { reflen += rl; rl = 0; }
+		uint32_t numNs = 0, num_prev = h->nedits;
+		uint32_t best_ext = align_no_alts(ix, h->joinedOff, seq, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx,
+		                                  rl, reflen, 1, h->edits, &h->nedits, mm, &numNs);
+		if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return 0; }
+		if(best_ext > 0) {
+			*leftext = best_ext;
+			uint32_t added = h->nedits - num_prev;
+			int ref_ext = (int)best_ext;
+			for(uint32_t i = 0; i < added; i++) {
+				if(h->edits[i].type == H2O_EDIT_REF_GAP) ref_ext--;
+				else if(h->edits[i].type == H2O_EDIT_READ_GAP) ref_ext++;
+			}
+			h->rdoff -= best_ext;
+			h->toff -= ref_ext;
+			h->len += best_ext;
+			h->joinedOff -= (ref_ext - (int)numNs);
+			for(uint32_t i = 0; i < h->nedits; i++) {
+				if(i < added) h->edits[i].pos -= h->rdoff;
+				else h->edits[i].pos += best_ext;
+			}
+		}
+	}
+	if(max_rightext > 0 && h->rdoff + h->len < rdlen) {
+		/* getRight :962-1000 without gap/splice edits: whole hit */
+		uint32_t right_rdoff = h->rdoff, right_len = h->len, right_toff = h->toff;
+		for(int i = (int)h->nedits - 1; i >= 0; i--) {
+			const h2o_edit* e = &h->edits[i];
+			if(e->type == H2O_EDIT_READ_GAP || e->type == H2O_EDIT_REF_GAP) {
+				right_rdoff = h->rdoff + e->pos;
+				right_len = h->len - e->pos;
+				if(e->type == H2O_EDIT_REF_GAP) { right_rdoff++; right_len--; }
+				uint32_t roff = h->toff + h->len; /* getRightOff :1020-1035 */
+				for(uint32_t k = 0; k < h->nedits; k++) {
+					if(h->edits[k].type == H2O_EDIT_READ_GAP) roff++;
+					else if(h->edits[k].type == H2O_EDIT_REF_GAP) roff--;
+				}
+				right_toff = roff - right_len;
+				break;
+			}
+		}
+		uint32_t rl = right_toff + right_len;
+		uint32_t rr = rdlen - (right_rdoff + right_len);
+		uint32_t tlen = ix->r.refLens[h->tidx];
+		if(rl < tlen) {
+			uint32_t reflen = rr + 10;
+			if(rl + reflen > tlen) reflen = tlen - rl;
+			int ref_ext = (int)h->len;
+			for(uint32_t ei = 0; ei < h->nedits; ei++) {
+				const h2o_edit* e = &h->edits[ei];
+				if(e->type == H2O_EDIT_REF_GAP) ref_ext--;
+				else if(e->type == H2O_EDIT_READ_GAP) ref_ext++;
+				else if(e->type == H2O_EDIT_MM && e->chr == 'N') ref_ext--;
+			}
+			uint32_t best_ext = align_no_alts(ix, h->joinedOff + ref_ext, seq, h->rdoff, h->rdoff + h->len,
+			                                  rdlen - (h->rdoff + h->len), h->tidx, (int)rl, reflen, 0,
+			                                  h->edits, &h->nedits, mm, NULL);
+			if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return 0; }
+			if(best_ext > 0) { *rightext = best_ext; h->len += best_ext; }
+		}
+	}
+	h2o_calculate_score(sc, qual, h);
+	return *leftext > 0 || *rightext > 0;
+}
+
+/* ------------------------------------------------------------------ batch baseline */
+uint64_t h2o_seed_extend_batch(const h2o_index* ix, const uint8_t* seqs, const uint32_t* offs, uint32_t nreads,
+                               int pseudogeneStop, uint32_t khits, uint64_t* counters)
+{
+	h2o_scoring sc;
+	h2o_scoring_default(&sc);
+	uint64_t sum = 0, nrank = 0, nsteps = 0, next = 0;
+	uint8_t rc[1024];
+	char qual[1024];
+	memset(qual, 'I', sizeof qual);
+	for(uint32_t r = 0; r < nreads; r++) {
+		const uint8_t* fwseq = seqs + offs[r];
+		uint32_t len = offs[r + 1] - offs[r];
+		if(len > 1000) continue;
+		for(uint32_t i = 0; i < len; i++) { uint8_t c = fwseq[len - 1 - i]; rc[i] = c < 4 ? 3 - c : 4; }
+		for(int fwi = 0; fwi < 2; fwi++) {
+			const uint8_t* seq = fwi == 0 ? fwseq : rc;
+			h2o_bwthit bh;
+			h2o_partial_search(ix, seq, len, 0, pseudogeneStop, 1, khits, &bh);
+			nrank += bh.nrank;
+			sum = sum * 1000003u + bh.top + 31 * bh.bot + 977 * bh.len + bh.hit_type;
+			if(bh.top == H2O_MAX || bh.bot - bh.top > 16 || bh.len <= ix->minK + 2) continue;
+			h2o_coord co[16];
+			uint32_t nco = 0, st = 0;
+			int straddled = 0;
+			h2o_genome_coords(ix, bh.top, bh.bot, bh.bot - bh.top, bh.len, 0, co, &nco, &straddled, &st);
+			nsteps += st;
+			for(uint32_t k = 0; k < nco; k++) {
+				sum = sum * 1000003u + co[k].tidx + 7 * co[k].toff;
+				if(co[k].tidx == H2O_MAX) continue;
+				h2o_ghit gh;
+				memset(&gh, 0, sizeof gh);
+				gh.fw = fwi == 0; gh.rdoff = len - bh.bwoff - bh.len; gh.len = bh.len;
+				gh.tidx = co[k].tidx; gh.toff = co[k].toff; gh.joinedOff = co[k].joinedOff;
+				uint32_t le = H2O_MAX, re = H2O_MAX;
+				h2o_extend(ix, &sc, seq, qual, len, &gh, &le, &re, 0);
+				next++;
+				sum = sum * 1000003u + gh.rdoff + 3 * gh.len + 5 * gh.toff;
+			}
+		}
+	}
+	if(counters) { counters[0] = nrank; counters[1] = nsteps; counters[2] = next; }
+	return sum;
+}

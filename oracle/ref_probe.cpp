@@ -1,0 +1,311 @@
+/*
+ * ref_probe — TEST INFRASTRUCTURE.  Drives the *real* reference classes
+ * (compiled from /root/reference where it lies; nothing copied) to emit golden
+ * vectors for the hot-path primitives of SURVEY.md §8(a):
+ *
+ *   rank     GFM::mapLF(SideLocus, c)            gfm.h:3712  (a5)  + rowL gfm.h:3615
+ *   ftab     GFM::ftabLoHi                       gfm.h:2670  (a10)
+ *   offset   GFM::tryOffset / getOffset walk     gfm.h:2719, group_walk.h (a14)
+ *   j2t      GFM::joinedToTextOff                gfm.h:5527  (a15)
+ *   stretch  BitPairReference::getStretch        reference.cpp:486 (a17)
+ *   psearch  HI_Aligner::partialSearch           hi_aligner.h:6361 (a11)
+ *   coords   HI_Aligner::getGenomeCoords         hi_aligner.h:5774 (a14)
+ *   extend   GenomeHit::extend                   hi_aligner.h:2031 (a18/a19)
+ *
+ * Built by oracle/Makefile.ref into oracle/_ref/ref_probe (git-ignored).  Output is
+ * line-oriented text on stdout; tests/gen_golden.py turns it into tests/golden/.
+ * Never linked into, called by, or shipped with the product library.
+ */
+#include <iostream>
+#include <fstream>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdint.h>
+
+#include "alphabet.h"
+#include "assert_helpers.h"
+#include "endian_swap.h"
+#include "hgfm.h"
+#include "rfm.h"
+#include "reference.h"
+#include "read.h"
+#include "scoring.h"
+#include "aln_sink.h"
+#include "hi_aligner.h"
+#include "spliced_aligner.h"
+#include "splice_site.h"
+#include "aligner_sw.h"
+#include "tp.h"
+#include "gp.h"
+
+using namespace std;
+
+typedef uint32_t index_t;
+typedef uint16_t local_index_t;
+
+// Globals the reference expects its main program to define (hisat2.cpp).
+MemoryTally gMemTally;
+bool gMate1fw = true, gMate2fw = false, gColor = false;
+int gTrim3 = 0, gTrim5 = 0;
+extern void initializeCntLut();
+extern void initializeCntBit();
+
+static uint64_t splitmix64(uint64_t& s) {
+	uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+struct Probe {
+	ALTDB<index_t>* altdb;
+	RepeatDB<index_t>* repeatdb;
+	HGFM<index_t, local_index_t>* gfm;
+	BitPairReference* ref;
+	Probe(const string& base) {
+		altdb = new ALTDB<index_t>();
+		repeatdb = new RepeatDB<index_t>();
+		gfm = new HGFM<index_t, local_index_t>(
+			base, altdb, NULL, NULL, -1, true, -1, 0, false, false, false,
+			true, true, true, true, false, false, false, false, false, false);
+		gfm->loadIntoMemory(-1, true, true, true, true, false);
+		ref = new BitPairReference(base, NULL, false, false, NULL, NULL, false,
+		                           false, false, false, false, false);
+	}
+};
+
+static Scoring* makeScoring(SimpleFunc& scoreMin, SimpleFunc& nCeil,
+                            SimpleFunc& canIL, SimpleFunc& noncanIL, bool nospliced)
+{
+	scoreMin.init(SIMPLE_FUNC_LINEAR, 0.0f, -0.2f);
+	nCeil.init(SIMPLE_FUNC_LINEAR, 0.0f, std::numeric_limits<double>::max(), 2.0f, 0.1f);
+	if(nospliced) {
+		canIL.init(SIMPLE_FUNC_LOG, -8, 1);
+		noncanIL.init(SIMPLE_FUNC_LOG, -8, 1);
+	} else {
+		canIL.init(SIMPLE_FUNC_LOG, -8, 1);
+		noncanIL.init(SIMPLE_FUNC_LOG, -8, 1);
+	}
+	return new Scoring(
+		DEFAULT_MATCH_BONUS, DEFAULT_MM_PENALTY_TYPE, DEFAULT_MM_PENALTY_MAX,
+		DEFAULT_MM_PENALTY_MIN, DEFAULT_SC_PENALTY_MAX, DEFAULT_SC_PENALTY_MIN,
+		scoreMin, nCeil, DEFAULT_N_PENALTY_TYPE, DEFAULT_N_PENALTY, DEFAULT_N_CAT_PAIR,
+		DEFAULT_READ_GAP_CONST, DEFAULT_REF_GAP_CONST, DEFAULT_READ_GAP_LINEAR,
+		DEFAULT_REF_GAP_LINEAR, 4, 0, 12, 1000000, &canIL, &noncanIL);
+}
+
+/** Parse a FASTA file of reads into Read objects (names = text after '>'). */
+static void loadReads(const char* fn, vector<Read*>& rds) {
+	ifstream in(fn);
+	string line, name, seq;
+	uint64_t id = 0;
+	while(true) {
+		bool ok = (bool)getline(in, line);
+		if(!ok || (!line.empty() && line[0] == '>')) {
+			if(!seq.empty()) {
+				Read* r = new Read();
+				r->name.install(name.c_str());
+				r->patFw.installChars(seq.c_str(), seq.size());
+				string q(seq.size(), 'I');
+				r->qual.install(q.c_str(), q.size());
+				r->rdid = id++;
+				r->mate = 0;
+				r->finalize();
+				rds.push_back(r);
+			}
+			if(!ok) break;
+			name = line.substr(1);
+			seq.clear();
+		} else {
+			seq += line;
+		}
+	}
+}
+
+int main(int argc, char** argv) {
+	if(argc < 3) {
+		cerr << "usage: ref_probe <cmd> <index_base> [args]" << endl;
+		return 2;
+	}
+	string cmd = argv[1], base = argv[2];
+	initializeCntLut();
+	initializeCntBit();
+	Probe p(base);
+	const GFM<index_t>& gfm = *p.gfm;
+	const GFMParams<index_t>& gh = gfm.gh();
+	if(cmd == "params") {
+		printf("len %u gbwtLen %u numNodes %u lineRate %d offRate %d ftabChars %d eftabLen %u linear %d sideSz %u sideGbwtSz %u sideGbwtLen %u numSides %u offsLen %u nPat %u nFrag %u\n",
+		       gh._len, gh._gbwtLen, gh._numNodes, gh._lineRate, gh._offRate, gh._ftabChars,
+		       gh._eftabLen, (int)gh.linearFM(), gh._sideSz, gh._sideGbwtSz, gh._sideGbwtLen,
+		       gh._numSides, gh._offsLen, (unsigned)gfm.nPat(), (unsigned)gfm.nFrag());
+		return 0;
+	}
+	if(cmd == "rank") {
+		// rank <base> <n> <seed>: rows ~ U[0,gbwtLen), c = hash&3 -> mapLF(row,c), rowL(row)
+		uint64_t n = strtoull(argv[3], NULL, 10), s = strtoull(argv[4], NULL, 10);
+		for(uint64_t i = 0; i < n; i++) {
+			uint64_t h = splitmix64(s);
+			index_t row = (index_t)(h % gh._gbwtLen);
+			int c = (int)((h >> 40) & 3);
+			SideLocus<index_t> l;
+			l.initFromRow(row, gh, gfm.gfm());
+			index_t r = gfm.mapLF(l, c);
+			int rl = gfm.rowL(l);
+			printf("%u %d %u %d\n", row, c, r, rl);
+		}
+		return 0;
+	}
+	if(cmd == "ftab") {
+		// ftab <base> <n> <seed>: random k-mers (some with N) -> ftabLoHi
+		uint64_t n = strtoull(argv[3], NULL, 10), s = strtoull(argv[4], NULL, 10);
+		int fc = gh._ftabChars;
+		for(uint64_t i = 0; i < n; i++) {
+			BTDnaString seq;
+			string txt;
+			uint64_t h = splitmix64(s);
+			for(int j = 0; j < fc; j++) {
+				int c = (int)((h >> (2 * j)) & 3);
+				if(((h >> 50) & 63) == 0 && j == (int)((h >> 56) % fc)) c = 4;
+				seq.append(c);
+				txt += "ACGTN"[c];
+			}
+			index_t top = 0, bot = 0;
+			bool ok = gfm.ftabLoHi(seq, 0, false, top, bot);
+			printf("%s %d %u %u\n", txt.c_str(), (int)ok, top, bot);
+		}
+		return 0;
+	}
+	if(cmd == "offset") {
+		// offset <base> <n> <seed>: random rows -> text offset in joined string + joinedToTextOff(len 20)
+		uint64_t n = strtoull(argv[3], NULL, 10), s = strtoull(argv[4], NULL, 10);
+		for(uint64_t i = 0; i < n; i++) {
+			uint64_t h = splitmix64(s);
+			index_t row = (index_t)(h % gh._gbwtLen);
+			index_t off = gfm.getOffset(row, row);
+			index_t tidx = 0, toff = 0, tlen = 0;
+			bool straddled = false;
+			index_t qlen = (index_t)((h >> 40) % 120) + 1;
+			bool ok = false;
+			if(off != (index_t)INDEX_MAX && off < gh._len)
+				ok = gfm.joinedToTextOff(qlen, off, tidx, toff, tlen, false, straddled);
+			printf("%u %u %u %d %u %u %u %d\n", row, off, qlen, (int)ok, tidx, toff, tlen, (int)straddled);
+		}
+		return 0;
+	}
+	if(cmd == "stretch") {
+		// stretch <base> <n> <seed>: random windows -> bases 0..4
+		uint64_t n = strtoull(argv[3], NULL, 10), s = strtoull(argv[4], NULL, 10);
+		SStringExpandable<char> buf;
+		SStringExpandable<uint32_t> destU32;
+		for(uint64_t i = 0; i < n; i++) {
+			uint64_t h = splitmix64(s);
+			index_t tidx = (index_t)((h >> 48) % gfm.nPat());
+			index_t tlen = gfm.plen()[tidx];
+			index_t toff = (index_t)(h % (tlen + 40));
+			if(((h >> 44) & 15) == 0) toff = (index_t)((h >> 20) % 64);
+			index_t cnt = (index_t)((h >> 32) % 150) + 1;
+			buf.resize(cnt + 32);
+			buf.fill(4);
+			int off = p.ref->getStretch(reinterpret_cast<uint32_t*>(buf.wbuf()), tidx, toff, cnt
+			                            ASSERT_ONLY(, destU32));
+			printf("%u %u %u ", tidx, toff, cnt);
+			for(index_t j = 0; j < cnt; j++) putchar("ACGTN"[(int)buf.wbuf()[off + j]]);
+			putchar('\n');
+		}
+		return 0;
+	}
+	if(cmd == "psearch" || cmd == "coords" || cmd == "extend") {
+		// <cmd> <base> <reads.fa> <nospliced:0|1>
+		vector<Read*> rds;
+		loadReads(argv[3], rds);
+		bool nospliced = (argc > 4) ? atoi(argv[4]) != 0 : true;
+		SimpleFunc scoreMin, nCeil, canIL, noncanIL;
+		Scoring* sc = makeScoring(scoreMin, nCeil, canIL, noncanIL, nospliced);
+		bool linear = gh.linearFM();
+		int khits = linear ? 5 : 10;
+		ReportingParams rp(khits, std::max(5, khits * 2), 0, 0, true, true, true,
+		                   false, false, 0, false, false);
+		HI_Aligner<index_t, local_index_t> al(gfm, true, 0);
+		RandomSource rnd;
+		rnd.init(0);
+		WalkMetrics wlm;
+		PerReadMetrics prm;
+		HIMetrics him;
+		TranscriptomePolicy tpol(20, 500000, 7, 14, nospliced, false, false, false, false);
+		GraphPolicy gpol(16, false, false, false);
+		EList<string> refnames;
+		SpliceSiteDB ssdb(*p.ref, refnames, false, false, false);
+		SwAligner swa;
+		SwMetrics swm;
+		SharedTempVars<index_t> sharedVars;
+		for(size_t ri = 0; ri < rds.size(); ri++) {
+			Read& rd = *rds[ri];
+			index_t rdlen = (index_t)rd.length();
+			TAlScore minsc = (TAlScore)scoreMin.f<double>((double)rdlen);
+			if(minsc > 0) minsc = 0;
+			for(int fwi = 0; fwi < 2; fwi++) {
+				bool fw = fwi == 0;
+				ReadBWTHit<index_t> hit;
+				hit.init(fw, rdlen);
+				size_t mineFw = 0, mineRc = 0;
+				bool pseudogeneStop = linear && !nospliced, anchorStop = true;
+				al.partialSearch(gfm, rd, *sc, rp, fw, 0, mineFw, mineRc, hit, rnd,
+				                 pseudogeneStop, anchorStop);
+				BWTHit<index_t>& ph = hit.getPartialHit(hit.offsetSize() - 1);
+				if(cmd == "psearch") {
+					printf("%llu %d %u %u %u %u %u %u %u %u %d %u %u %d %d\n",
+					       (unsigned long long)rd.rdid, (int)fw, ph._top, ph._bot, ph._node_top,
+					       ph._node_bot, ph._bwoff, ph._len, ph._hit_type, hit._cur,
+					       (int)hit._done, hit._numPartialSearch, hit._numUniqueSearch,
+					       (int)pseudogeneStop, (int)anchorStop);
+					continue;
+				}
+				if(ph.empty() || ph._bot - ph._top > 16) continue;
+				EList<Coord> coords;
+				bool straddled = false;
+				index_t rdoff = hit._len - ph._bwoff - ph._len;
+				al.getGenomeCoords(gfm, *p.altdb, *p.ref, rnd, ph._top, ph._bot, ph._node_top,
+				                   ph._node_bot, ph._node_iedge_count, fw, ph._bot - ph._top,
+				                   rdoff, ph._len, coords, wlm, prm, him, false, straddled);
+				if(cmd == "coords") {
+					printf("%llu %d %u %u %u %u %d %u", (unsigned long long)rd.rdid, (int)fw,
+					       ph._top, ph._bot, rdoff, ph._len, (int)straddled, (unsigned)coords.size());
+					for(size_t k = 0; k < coords.size(); k++)
+						printf(" %lld:%lld:%llu", (long long)(int32_t)coords[k].ref(), (long long)coords[k].off(),
+						       (unsigned long long)coords[k].joinedOff());
+					putchar('\n');
+					continue;
+				}
+				// extend: for each coordinate, a GenomeHit extended with mm = 0, 1, 2, 3
+				for(size_t k = 0; k < coords.size(); k++) {
+					if(coords[k].ref() == (TRefId)std::numeric_limits<index_t>::max()) continue;
+					for(index_t mm = 0; mm < 4; mm++) {
+						GenomeHit<index_t> gh_;
+						gh_.init(fw, rdoff, ph._len, 0, 0, (index_t)coords[k].ref(),
+						         (index_t)coords[k].off(), (index_t)coords[k].joinedOff(), sharedVars);
+						index_t leftext = (index_t)INDEX_MAX, rightext = (index_t)INDEX_MAX;
+						bool ext = gh_.extend(rd, gfm, *p.ref, *p.altdb, *p.repeatdb, ssdb, swa, swm, prm,
+						                      *sc, minsc, rnd, (index_t)8, tpol, gpol, leftext, rightext, mm);
+						printf("%llu %d %u %u %u %u %u %u -> %d %u %u %u %u %u %u %lld %u",
+						       (unsigned long long)rd.rdid, (int)fw, rdoff, ph._len,
+						       (unsigned)coords[k].ref(), (unsigned)coords[k].off(),
+						       (unsigned)coords[k].joinedOff(), mm,
+						       (int)ext, gh_.rdoff(), gh_.len(), gh_.refoff(), gh_._joinedOff,
+						       leftext, rightext, (long long)gh_.score(), (unsigned)gh_.edits().size());
+						for(size_t e = 0; e < gh_.edits().size(); e++) {
+							const Edit& ed = gh_.edits()[e];
+							printf(" %u:%c>%c", ed.pos, (char)ed.chr, (char)ed.qchr);
+						}
+						putchar('\n');
+					}
+				}
+			}
+		}
+		return 0;
+	}
+	cerr << "unknown command " << cmd << endl;
+	return 2;
+}

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/ from the REAL reference (run in the build container only).
+
+Needs oracle/_ref/{hisat2-build-s,hisat2-align-s,ref_probe} (make -C oracle ref).  Produces,
+for a small seeded genome ("g1"):
+  g1.fa.gz, g1.{1..8}.ht2.gz      genome + index written by the reference's hisat2-build-s
+  reads_se.fa.gz                  400 x 101 bp reads (subs, a few Ns and indels)
+  probe_{rank,ftab,offset,stretch,psearch,coords,extend}.txt.gz
+                                  outputs of the reference classes via oracle/ref_probe.cpp
+  ref_se_nospliced.sam.gz         hisat2-align-s -f -p 1 --no-spliced-alignment (minus @PG)
+  ref_se_spliced.sam.gz           hisat2-align-s -f -p 1 (default), minus @PG
+Everything is deterministic (seeds below); the fixtures are committed.
+"""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from hisat2_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(HERE, "golden")
+SEED = 20260925
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def gz_write(path, data: bytes):
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(data)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="h2gold")
+    contigs = synth.make_genome([60000, 45000, 30000], SEED, n_gaps=1, gap_len=500, repeats=2, repeat_len=400)
+    fa = os.path.join(tmp, "g1.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g1")
+    run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base])
+    gz_write(os.path.join(GOLD, "g1.fa.gz"), open(fa, "rb").read())
+    for k in range(1, 9):
+        gz_write(os.path.join(GOLD, f"g1.{k}.ht2.gz"), open(f"{base}.{k}.ht2", "rb").read())
+    reads, _ = synth.make_reads(contigs, 400, 101, SEED + 1, sub_rate=0.01, indel_rate=0.0005, n_rate=0.0005)
+    rfa = os.path.join(tmp, "reads_se.fa")
+    synth.write_reads_fasta(rfa, reads)
+    gz_write(os.path.join(GOLD, "reads_se.fa.gz"), open(rfa, "rb").read())
+    probe = os.path.join(REF, "ref_probe")
+    for cmd, args in [("params", []), ("rank", ["4000", "11"]), ("ftab", ["3000", "12"]), ("offset", ["2000", "13"]),
+                      ("stretch", ["1500", "14"]), ("psearch", [rfa, "1"]), ("coords", [rfa, "1"]),
+                      ("extend", [rfa, "1"])]:
+        out = run([probe, cmd, base] + args).stdout
+        gz_write(os.path.join(GOLD, f"probe_{cmd}.txt.gz"), out)
+        print(cmd, len(out.splitlines()), "lines")
+    # spliced-mode partial search (pseudogeneStop on linear indexes)
+    out = run([probe, "psearch", base, rfa, "0"]).stdout
+    gz_write(os.path.join(GOLD, "probe_psearch_spliced.txt.gz"), out)
+    for name, extra in [("ref_se_nospliced", ["--no-spliced-alignment"]), ("ref_se_spliced", [])]:
+        sam = os.path.join(tmp, name + ".sam")
+        run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "-x", base, "-U", rfa, "-S", sam] + extra)
+        lines = [l for l in open(sam, "rb").read().splitlines(True) if not l.startswith(b"@PG")]
+        gz_write(os.path.join(GOLD, name + ".sam.gz"), b"".join(lines))
+    shutil.rmtree(tmp)
+    tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    print("golden bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+"""CPU tests: the C oracle (oracle/h2o.c) against vectors emitted by the REAL reference
+classes (oracle/ref_probe.cpp run on the reference-built index of genome g1)."""
+import ctypes as C
+
+import numpy as np
+
+import h2o_py as H
+
+
+def test_params(oracle_lib, g1_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1_index)
+    kv = H.glines(golden_dir, "probe_params.txt.gz")[0].split()
+    d = dict(zip(kv[0::2], map(int, kv[1::2])))
+    p = ix.contents.g.p
+    for k in ("len", "gbwtLen", "numNodes", "lineRate", "offRate", "ftabChars", "eftabLen", "linear", "sideSz",
+              "sideGbwtSz", "sideGbwtLen", "numSides", "offsLen"):
+        assert getattr(p, k) == d[k], k
+    assert ix.contents.g.nPat == d["nPat"] and ix.contents.g.nFrag == d["nFrag"]
+
+
+def test_rank_rowL(oracle_lib, g1_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1_index)
+    g = C.byref(ix.contents.g)
+    for l in H.glines(golden_dir, "probe_rank.txt.gz"):
+        row, c, r, rl = map(int, l.split())
+        assert oracle_lib.h2o_rank(g, row, c) == r
+        assert oracle_lib.h2o_rowL(g, row) == rl
+
+
+def test_ftab(oracle_lib, g1_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1_index)
+    g = C.byref(ix.contents.g)
+    nhit = 0
+    for l in H.glines(golden_dir, "probe_ftab.txt.gz"):
+        s, ok, top, bot = l.split()
+        seq = H.encode(s.encode())
+        t, b = C.c_uint32(0), C.c_uint32(0)
+        got = oracle_lib.h2o_ftab_lohi(g, seq.ctypes.data, 0, C.byref(t), C.byref(b))
+        assert got == int(ok)
+        if got:
+            assert (t.value, b.value) == (int(top), int(bot))
+            nhit += int(bot) > int(top)
+    assert nhit > 50
+
+
+def test_offset_and_joined_to_text(oracle_lib, g1_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1_index)
+    g = C.byref(ix.contents.g)
+    for l in H.glines(golden_dir, "probe_offset.txt.gz"):
+        row, off, qlen, ok, tidx, toff, tlen, strad = map(int, l.split())
+        st = C.c_uint32(0)
+        assert oracle_lib.h2o_get_offset(g, row, C.byref(st)) == off
+        if off < ix.contents.g.p.len:
+            a, b, c_, s = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+            got = oracle_lib.h2o_joined_to_text(g, qlen, off, C.byref(a), C.byref(b), C.byref(c_), 0, C.byref(s))
+            assert (got, a.value, b.value, c_.value, s.value) == (ok, tidx, toff, tlen, strad)
+
+
+def test_stretch(oracle_lib, g1_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1_index)
+    r = C.byref(ix.contents.r)
+    for l in H.glines(golden_dir, "probe_stretch.txt.gz"):
+        tidx, toff, cnt, s = l.split()
+        buf = np.zeros(int(cnt), dtype=np.uint8)
+        oracle_lib.h2o_get_stretch(r, int(tidx), int(toff), int(cnt), buf.ctypes.data)
+        assert bytes(b"ACGTN"[x] for x in buf) == s.encode()
+
+
+def _reads(golden_dir):
+    import os
+    return H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
+
+
+def _psearch(oracle_lib, golden_dir, g1_index, fn, pseudo):
+    ix = H.load_index(oracle_lib, g1_index)
+    _, seqs = _reads(golden_dir)
+    n = 0
+    for l in H.glines(golden_dir, fn):
+        v = list(map(int, l.split()))
+        rid, fw = v[0], v[1]
+        seq = seqs[rid] if fw else H.revcomp(seqs[rid])
+        seq = np.ascontiguousarray(seq)
+        o = H.BwtHit()
+        oracle_lib.h2o_partial_search(ix, seq.ctypes.data, len(seq), 0, pseudo, 1, 5, C.byref(o))
+        got = [o.top, o.bot, o.node_top, o.node_bot, o.bwoff, o.len, o.hit_type, o.cur, o.done,
+               o.numPartialSearch, o.numUniqueSearch, o.pseudogeneStop, o.anchorStop]
+        assert got == v[2:], (rid, fw, got, v[2:])
+        n += 1
+    assert n == 800
+
+
+def test_partial_search(oracle_lib, g1_index, golden_dir):
+    _psearch(oracle_lib, golden_dir, g1_index, "probe_psearch.txt.gz", 0)
+
+
+def test_partial_search_pseudogene_stop(oracle_lib, g1_index, golden_dir):
+    _psearch(oracle_lib, golden_dir, g1_index, "probe_psearch_spliced.txt.gz", 1)
+
+
+def test_genome_coords(oracle_lib, g1_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1_index)
+    for l in H.glines(golden_dir, "probe_coords.txt.gz"):
+        f = l.split()
+        top, bot, rdoff, hlen, strad, n = map(int, f[2:8])
+        co = (H.Coord * 32)()
+        nco, st, steps = C.c_uint32(0), C.c_int(0), C.c_uint32(0)
+        oracle_lib.h2o_genome_coords(ix, top, bot, bot - top, hlen, 0, co, C.byref(nco), C.byref(st), C.byref(steps))
+        assert nco.value == n and st.value == strad
+        for k in range(n):
+            t, o, j = map(int, f[8 + k].split(":"))
+            t &= 0xFFFFFFFF
+            assert (co[k].tidx, co[k].toff, co[k].joinedOff) == (t, o, j)
+
+
+def test_extend(oracle_lib, g1_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1_index)
+    _, seqs = _reads(golden_dir)
+    sc = H.Scoring()
+    oracle_lib.h2o_scoring_default(C.byref(sc))
+    n = 0
+    for l in H.glines(golden_dir, "probe_extend.txt.gz"):
+        lhs, rhs = l.split(" -> ")
+        rid, fw, rdoff, hlen, tidx, toff, joff, mm = map(int, lhs.split())
+        r = rhs.split()
+        seq = np.ascontiguousarray(seqs[rid] if fw else H.revcomp(seqs[rid]))
+        h = H.GHit()
+        h.fw, h.rdoff, h.len, h.tidx, h.toff, h.joinedOff = fw, rdoff, hlen, tidx, toff, joff
+        le, re = C.c_uint32(H.MAX), C.c_uint32(H.MAX)
+        qual = b"I" * len(seq)
+        ext = oracle_lib.h2o_extend(ix, C.byref(sc), seq.ctypes.data, qual, len(seq), C.byref(h), C.byref(le),
+                                    C.byref(re), mm)
+        got = [ext, h.rdoff, h.len, h.toff, h.joinedOff, le.value, re.value, h.score, h.nedits]
+        assert got == list(map(int, r[:9])), (l, got)
+        eds = [f"{h.edits[k].pos}:{chr(h.edits[k].chr)}>{chr(h.edits[k].qchr)}" for k in range(h.nedits)]
+        assert eds == r[9:], (l, eds)
+        n += 1
+    assert n > 1000
