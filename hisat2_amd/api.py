@@ -1,0 +1,257 @@
+"""ctypes mirror of include/h2g.h (libh2g.so) — the host-side view used by tests and bench.py.
+
+There is no fallback: if the HIP library is missing or no GPU is usable, loading / the first call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libh2g.so")
+MAX = 0xFFFFFFFF
+MAX_EDITS = 48
+SEED_CAP = 5
+
+u32, u8, i32, u64, i64 = C.c_uint32, C.c_uint8, C.c_int32, C.c_uint64, C.c_int64
+
+
+class LoadOpts(C.Structure):
+    _fields_ = [("device", i32), ("load_local", i32)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("len", u32), ("gbwtLen", u32), ("numNodes", u32), ("lineRate", i32), ("offRate", i32),
+                ("ftabChars", i32), ("eftabLen", u32), ("linear", u32), ("sideSz", u32), ("sideGbwtSz", u32),
+                ("sideGbwtLen", u32), ("numSides", u32), ("offsLen", u32), ("ftabLen", u32), ("nPat", u32),
+                ("nFrag", u32), ("nZ", u32), ("minK", u32), ("nLocal", u32), ("nRefRecs", u32), ("device_bytes", u64)]
+
+
+class FmQuery(C.Structure):
+    _fields_ = [("read", u32), ("offset", u32), ("fw", u8), ("mode", u8), ("pseudogeneStop", u8), ("anchorStop", u8)]
+
+
+FM_HIT_FIELDS = ("top", "bot", "node_top", "node_bot", "bwoff", "len", "hit_type", "cur", "done", "numPartialSearch",
+                 "numUniqueSearch", "pseudogeneStop", "anchorStop", "nrank", "nside")
+
+
+class FmHit(C.Structure):
+    _fields_ = [(n, u32) for n in FM_HIT_FIELDS]
+
+
+class SaQuery(C.Structure):
+    _fields_ = [("top", u32), ("bot", u32), ("maxelt", u32), ("len", u32), ("rejectStraddle", u32)]
+
+
+class Coord(C.Structure):
+    _fields_ = [("tidx", u32), ("toff", u32), ("joinedOff", u32)]
+
+
+class SaResult(C.Structure):
+    _fields_ = [("ok", u32), ("ncoords", u32), ("straddled", u32), ("nsteps", u32)]
+
+
+class Edit(C.Structure):
+    _fields_ = [("pos", u32), ("chr", u8), ("qchr", u8), ("type", u8), ("pad", u8)]
+
+
+class GHit(C.Structure):
+    _fields_ = [("read", u32), ("fw", u32), ("rdoff", u32), ("len", u32), ("trim5", u32), ("trim3", u32),
+                ("tidx", u32), ("toff", u32), ("joinedOff", u32), ("score", i64), ("nedits", u32), ("overflow", u32),
+                ("edits", Edit * MAX_EDITS)]
+
+
+class ExtArgs(C.Structure):
+    _fields_ = [("mm", u32), ("max_leftext", u32), ("max_rightext", u32)]
+
+
+class ExtResult(C.Structure):
+    _fields_ = [("extended", u32), ("leftext", u32), ("rightext", u32)]
+
+
+class SeedExt(C.Structure):
+    _fields_ = [("tidx", u32), ("toff", u32), ("joinedOff", u32), ("rdoff", u32), ("len", u32), ("score", i32)]
+
+
+class SeedResult(C.Structure):
+    _fields_ = [("hit", FmHit), ("ncoords", u32), ("straddled", u32), ("nsteps", u32), ("pad", u32),
+                ("ext", SeedExt * SEED_CAP)]
+
+
+class SeedParams(C.Structure):
+    _fields_ = [("pseudogeneStop", u32), ("anchorStop", u32), ("khits", u32), ("search_variant", u32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_rank", u64), ("n_side", u64), ("n_sa_steps", u64), ("n_ext", u64), ("n_ref_bytes", u64),
+                ("n_queries", u64), ("ms_search", C.c_float), ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float)]
+
+
+# numpy views of the result structs (same memory layout)
+FM_HIT_DTYPE = np.dtype([(n, np.uint32) for n in FM_HIT_FIELDS])
+SEED_EXT_DTYPE = np.dtype([("tidx", np.uint32), ("toff", np.uint32), ("joinedOff", np.uint32), ("rdoff", np.uint32),
+                           ("len", np.uint32), ("score", np.int32)])
+SEED_RESULT_DTYPE = np.dtype([("hit", FM_HIT_DTYPE), ("ncoords", np.uint32), ("straddled", np.uint32),
+                              ("nsteps", np.uint32), ("pad", np.uint32), ("ext", SEED_EXT_DTYPE, (SEED_CAP,))])
+assert SEED_RESULT_DTYPE.itemsize == C.sizeof(SeedResult)
+
+EXPORTS = [
+    "h2g_load_opts_init", "h2g_index_load", "h2g_index_get_info", "h2g_index_synth_sides", "h2g_index_free",
+    "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_set_reads",
+    "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
+    "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
+]
+
+
+class H2GError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libh2g.so (built by hisat2_amd/csrc/Makefile).  Raises if it is not there: no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise H2GError(f"{LIB_PATH} not built (run __graft_entry__.build()); hisat2_amd has no CPU path")
+    L = C.CDLL(LIB_PATH)
+    P, vp = C.POINTER, C.c_void_p
+    L.h2g_last_error.restype = C.c_char_p
+    L.h2g_index_load.argtypes = [C.c_char_p, P(LoadOpts), P(vp)]
+    L.h2g_index_get_info.argtypes = [vp, P(IndexInfo)]
+    L.h2g_index_synth_sides.argtypes = [u64, u64, C.c_int, P(vp)]
+    L.h2g_index_free.argtypes = [vp]
+    L.h2g_index_free.restype = None
+    L.h2g_stream_create.argtypes = [vp, C.c_size_t, C.c_size_t, P(vp)]
+    L.h2g_stream_free.argtypes = [vp]
+    L.h2g_stream_free.restype = None
+    L.h2g_stream_hip.argtypes = [vp]
+    L.h2g_stream_hip.restype = vp
+    L.h2g_stream_sync.argtypes = [vp]
+    L.h2g_set_reads.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.h2g_rank_bench.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int, C.c_int, C.c_int, P(C.c_float)]
+    L.h2g_rank_bench_synth.argtypes = [vp, C.c_size_t, u64, C.c_int, C.c_int, P(C.c_float), P(u64)]
+    L.h2g_fm_search.argtypes = [vp, vp, C.c_size_t, u32, vp]
+    L.h2g_sa_resolve.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
+    L.h2g_extend.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.h2g_seed_params_init.argtypes = [P(SeedParams), vp, C.c_int]
+    L.h2g_seed_params_init.restype = None
+    L.h2g_seed_extend_run.argtypes = [vp, P(SeedParams)]
+    L.h2g_seed_extend_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+    L.h2g_get_counters.argtypes = [vp, P(Counters)]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        msg = lib().h2g_last_error()
+        raise H2GError(f"{what} failed: status {rc} ({msg.decode() if msg else ''})")
+
+
+class Index:
+    def __init__(self, base=None, device=0, synth_sides=None, seed=20260925):
+        L = lib()
+        self.h = C.c_void_p()
+        if synth_sides is not None:
+            _chk(L.h2g_index_synth_sides(int(synth_sides), int(seed), int(device), C.byref(self.h)), "h2g_index_synth_sides")
+        else:
+            o = LoadOpts(device, 1)
+            _chk(L.h2g_index_load(base.encode(), C.byref(o), C.byref(self.h)), "h2g_index_load")
+        self.info = IndexInfo()
+        _chk(L.h2g_index_get_info(self.h, C.byref(self.info)), "h2g_index_get_info")
+
+    def close(self):
+        if self.h:
+            lib().h2g_index_free(self.h)
+            self.h = C.c_void_p()
+
+
+class Stream:
+    def __init__(self, index: Index, max_reads=0, max_bases=0):
+        self.ix = index
+        self.h = C.c_void_p()
+        _chk(lib().h2g_stream_create(index.h, max_reads, max_bases, C.byref(self.h)), "h2g_stream_create")
+        self.n_reads = 0
+
+    def close(self):
+        if self.h:
+            lib().h2g_stream_free(self.h)
+            self.h = C.c_void_p()
+
+    def set_reads(self, codes: np.ndarray, offs: np.ndarray, quals=None):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint32)
+        n = len(offs) - 1
+        q = None
+        if quals is not None:
+            q = np.ascontiguousarray(quals, dtype=np.uint8).ctypes.data
+        _chk(lib().h2g_set_reads(self.h, codes.ctypes.data, offs.ctypes.data, q, n), "h2g_set_reads")
+        self.n_reads = n
+
+    def rank(self, rows, cs, variant=0, repeats=1):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        cs = np.ascontiguousarray(cs, dtype=np.uint8)
+        out = np.empty(len(rows), dtype=np.uint32)
+        ms = C.c_float(0)
+        _chk(lib().h2g_rank_bench(self.h, rows.ctypes.data, cs.ctypes.data, len(rows), out.ctypes.data, variant, 0,
+                                  repeats, C.byref(ms)), "h2g_rank_bench")
+        return out, ms.value
+
+    def rank_synth(self, n, seed, variant=0, repeats=1):
+        ms, ck = C.c_float(0), u64(0)
+        _chk(lib().h2g_rank_bench_synth(self.h, n, seed, variant, repeats, C.byref(ms), C.byref(ck)), "h2g_rank_bench_synth")
+        return ms.value, ck.value
+
+    def fm_search(self, queries, khits=5):
+        n = len(queries)
+        q = (FmQuery * n)(*queries)
+        out = (FmHit * n)()
+        _chk(lib().h2g_fm_search(self.h, q, n, khits, out), "h2g_fm_search")
+        return out
+
+    def sa_resolve(self, queries, cap=16):
+        n = len(queries)
+        q = (SaQuery * n)(*queries)
+        co = (Coord * (n * cap))()
+        res = (SaResult * n)()
+        _chk(lib().h2g_sa_resolve(self.h, q, n, cap, co, res), "h2g_sa_resolve")
+        return co, res
+
+    def extend(self, hits, args):
+        n = len(hits)
+        h = (GHit * n)(*hits)
+        a = (ExtArgs * n)(*args)
+        res = (ExtResult * n)()
+        _chk(lib().h2g_extend(self.h, h, a, n, res), "h2g_extend")
+        return h, res
+
+    def seed_params(self, no_spliced=True):
+        p = SeedParams()
+        lib().h2g_seed_params_init(C.byref(p), self.ix.h, 1 if no_spliced else 0)
+        return p
+
+    def seed_extend_run(self, params):
+        _chk(lib().h2g_seed_extend_run(self.h, C.byref(params)), "h2g_seed_extend_run")
+
+    def sync(self):
+        _chk(lib().h2g_stream_sync(self.h), "h2g_stream_sync")
+
+    def seed_extend_fetch(self, first=0, n=None):
+        n = self.n_reads - first if n is None else n
+        out = np.zeros(n * 2, dtype=SEED_RESULT_DTYPE)
+        _chk(lib().h2g_seed_extend_fetch(self.h, out.ctypes.data, first, n), "h2g_seed_extend_fetch")
+        return out
+
+    def counters(self):
+        c = Counters()
+        _chk(lib().h2g_get_counters(self.h, C.byref(c)), "h2g_get_counters")
+        return c
+
+    def hip_stream(self):
+        return lib().h2g_stream_hip(self.h)

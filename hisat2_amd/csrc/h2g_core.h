@@ -1,0 +1,608 @@
+// h2g_core.h — per-item device functions of the HISAT2 hot path (gfx950), shared by every kernel.
+//
+// Every function is `__host__ __device__` so that the identical source can be instantiated on the host
+// by tests/emul (logic tests in the GPU-less build container).  The product library only ever launches
+// the __global__ wrappers in h2g_kernels.hip; it contains no host execution path.
+//
+// Reference semantics (HISAT2 2.2.3) are cited per function as file:line.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "../../include/h2g.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define H2G_HD __host__ __device__ __forceinline__
+#else
+#define H2G_HD inline
+#endif
+
+namespace h2g {
+
+// ------------------------------------------------------------------------------------------ device views
+struct DGfm {   // one linear 32-bit GFM resident in HBM (sides exactly as on disk)
+	const uint8_t*  sides;
+	const uint32_t* ftab;
+	const uint32_t* eftab;
+	const uint32_t* offs;
+	const uint32_t* rstarts;
+	const uint32_t* plen;
+	uint32_t fchr[5];
+	uint32_t len, gbwtLen, ftabLim, sideGbwtLen, sideGbwtSz, lineRate, offRate, offMask, ftabChars;
+	uint32_t nFrag, nPat, nZ, zoff, minK, linear;
+};
+
+struct DRef {   // BitPairReference: records sorted by (text, offset); buf 2 bit/base
+	const uint8_t*  buf;
+	const uint32_t* rec_start;
+	const uint32_t* rec_len;
+	const uint32_t* rec_bufoff;
+	const uint32_t* refRecOffs;
+	const uint32_t* refLens;
+	uint32_t nrefs;
+};
+
+struct DReads {
+	const uint8_t*  codes;   // 0..4 per base, forward strand
+	const uint32_t* offs;    // [n+1]
+	const char*     quals;   // phred+33 or nullptr (FASTA => 'I')
+	uint32_t n;
+};
+
+struct DScoring {  // Scoring defaults scoring.h:29-87 / hisat2.cpp:425-441
+	int mmpMax = 6, mmpMin = 2, nPen = 1, rdGapConst = 5, rdGapLinear = 3, rfGapConst = 5, rfGapLinear = 3;
+	int scMax = 2, scMin = 1, matchBonus = 0;
+};
+
+// Read in search orientation: fw -> patFw, !fw -> patRc (Read::constructRevComps read.h:138)
+struct SeqView {
+	const uint8_t* fwc;
+	const char*    q;
+	uint32_t       len;
+	bool           fw;
+	H2G_HD int at(uint32_t i) const {
+		if(fw) return fwc[i];
+		int c = fwc[len - 1 - i];
+		return c < 4 ? 3 - c : 4;
+	}
+	H2G_HD int qual(uint32_t i) const {   // qual / qualRev
+		if(q == nullptr) return 'I';
+		return fw ? q[i] : q[len - 1 - i];
+	}
+};
+
+H2G_HD SeqView seq_view(const DReads& r, uint32_t read, bool fw) {
+	SeqView s;
+	uint32_t a = r.offs[read];
+	s.fwc = r.codes + a;
+	s.q = r.quals ? r.quals + a : nullptr;
+	s.len = r.offs[read + 1] - a;
+	s.fw = fw;
+	return s;
+}
+
+// ------------------------------------------------------------------------------------------ Occ-rank (a3-a5)
+// One linear side = 64 B = 8 x u64: words 0..5 hold 192 symbols (2 bit, LSB-first, pack_2b_in_8b
+// gfm.h:4888), word 6 = occ[A] | occ[C] << 32, word 7 = occ[G] | occ[T] << 32 (gfm.h:2953-2957).
+struct Side64 { uint64_t w[8]; };
+
+H2G_HD Side64 load_side64(const uint8_t* p) {
+	Side64 s;
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint4* q = reinterpret_cast<const uint4*>(p);   // 4 x global_load_dwordx4, one 64 B line
+	uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+	s.w[0] = a.x | ((uint64_t)a.y << 32); s.w[1] = a.z | ((uint64_t)a.w << 32);
+	s.w[2] = b.x | ((uint64_t)b.y << 32); s.w[3] = b.z | ((uint64_t)b.w << 32);
+	s.w[4] = c.x | ((uint64_t)c.y << 32); s.w[5] = c.z | ((uint64_t)c.w << 32);
+	s.w[6] = d.x | ((uint64_t)d.y << 32); s.w[7] = d.z | ((uint64_t)d.w << 32);
+#else
+	memcpy(s.w, p, 64);
+#endif
+	return s;
+}
+
+// occurrences of symbol c among the first n (0..32) symbols of one u64 — the countInU64 bit trick
+// (gfm.h:566-578: x = dw ^ c_table[c]; x & (x >> 1) & 0x55..) with the tail masked instead of shifted
+H2G_HD uint32_t count_word(uint64_t w, int c, int n) {
+	const uint64_t ct = (c & 2 ? 0ull : 0xaaaaaaaaaaaaaaaaull) | (c & 1 ? 0ull : 0x5555555555555555ull);
+	uint64_t x = w ^ ct;
+	uint64_t x3 = x & (x >> 1) & 0x5555555555555555ull;
+	uint64_t mask = n >= 32 ? ~0ull : ((1ull << (2 * (n < 0 ? 0 : n))) - 1ull);
+	return (uint32_t)__builtin_popcountll(x3 & mask);
+}
+
+// countBt2Side (gfm.h:2958-3001) on an already loaded linear side; charOff = row % 192
+H2G_HD uint32_t rank_in_side64(const DGfm& g, const Side64& s, uint32_t sideNum, uint32_t charOff, int c) {
+	uint32_t cnt = 0;
+#pragma unroll
+	for(int k = 0; k < 6; k++) cnt += count_word(s.w[k], c, (int)charOff - 32 * k);
+	// '$' is stored as 'A' (gfm.h:2967-2979; one zOff on a linear index, gfm.h:5400)
+	if(c == 0 && g.nZ) {
+		uint32_t zs = g.zoff / 192u, zc = g.zoff - zs * 192u;
+		if(zs == sideNum && zc < charOff) cnt--;
+	}
+	const uint64_t ow = (c & 2) ? s.w[7] : s.w[6];       // selects, not dynamic indexing: keeps the side in VGPRs
+	const uint32_t occ = (c & 1) ? (uint32_t)(ow >> 32) : (uint32_t)ow;
+	const uint32_t fc = c == 0 ? g.fchr[0] : c == 1 ? g.fchr[1] : c == 2 ? g.fchr[2] : g.fchr[3];
+	return occ + cnt + fc;
+}
+
+H2G_HD int rowL_in_side64(const Side64& s, uint32_t charOff) {   // rowL gfm.h:3615
+	const uint32_t k = charOff >> 5;
+	const uint64_t a = (k & 1) ? s.w[1] : s.w[0], b = (k & 1) ? s.w[3] : s.w[2], c = (k & 1) ? s.w[5] : s.w[4];
+	const uint64_t w = k >= 4 ? c : (k >= 2 ? b : a);
+	return (int)((w >> ((charOff & 31) * 2)) & 3);
+}
+
+H2G_HD uint32_t rank64(const DGfm& g, uint32_t row, int c) {   // SideLocus::initFromRow gfm.h:376 + mapLF :3712
+	uint32_t sideNum = row / 192u, charOff = row - sideNum * 192u;
+	Side64 s = load_side64(g.sides + (size_t)sideNum * 64);
+	return rank_in_side64(g, s, sideNum, charOff, c);
+}
+
+// ------------------------------------------------------------------------------------------ ftab (a10)
+H2G_HD uint32_t ftab_hi(const DGfm& g, uint32_t i) {   // gfm.h:2618-2634
+	uint32_t v = g.ftab[i];
+	if(v <= g.ftabLim) return v;
+	return g.eftab[(v ^ H2G_MAX) * 2 + 1];
+}
+H2G_HD uint32_t ftab_lo(const DGfm& g, uint32_t i) {   // gfm.h:2696-2712
+	uint32_t v = g.ftab[i];
+	if(v <= g.ftabLim) return v;
+	return g.eftab[(v ^ H2G_MAX) * 2];
+}
+
+// ------------------------------------------------------------------------------------------ partialSearch (a11)
+// hi_aligner.h:6361-6600 for a linear index: mapLF on (tloc,bloc) gfm.h:3739, single-row mapGLF1/mapLF1
+// gfm.h:3957-3972 / :3892-3919.  One work item = one (read, strand, offset).
+H2G_HD void partial_search_item(const DGfm& g, const SeqView& seq, uint32_t cur_in, bool pseudogeneStopIn,
+                                bool anchorStopIn, uint32_t khits, h2g_fm_hit* o)
+{
+	const uint32_t len = seq.len, ftabLen = g.ftabChars, minK = g.minK;
+	bool pseudogeneStop_ = pseudogeneStopIn, anchorStop_ = anchorStopIn;
+	bool pseudogeneStop = false, anchorStop = false;
+	h2g_fm_hit h;
+	h.top = h.bot = h.node_top = h.node_bot = H2G_MAX;
+	h.hit_type = H2G_CANDIDATE_HIT;
+	h.numPartialSearch = 1; h.numUniqueSearch = 0; h.done = 0; h.nrank = 0; h.nside = 0;
+	h.pseudogeneStop = 0; h.anchorStop = 0;
+	uint32_t cur = cur_in, offset = cur_in, dep = cur_in;
+	h.bwoff = offset;
+	const uint32_t left = len - dep;
+	bool finished = false;
+	if(left < ftabLen + 1) {                       // :6403
+		cur = len; h.len = cur - offset; h.done = 1; finished = true;
+	}
+	uint32_t top = 0, bot = 0;
+	if(!finished) {
+		uint32_t fi = 0;
+		for(uint32_t i = 0; i < ftabLen; i++) {    // N in the ftab window :6419; k-mer packed left-to-right
+			int c = seq.at(len - dep - 1 - i);     // (ftabSeqToInt gfm.h:2569, fw index)
+			if(c > 3) {
+				cur += (i + 1); h.len = cur - offset; if(cur >= len) h.done = 1; finished = true;
+				break;
+			}
+			fi |= (uint32_t)c << (2 * i);
+		}
+		if(!finished) {
+			top = ftab_hi(g, fi);                  // ftabLoHi gfm.h:2670
+			bot = ftab_lo(g, fi + 1);
+			dep += ftabLen;
+			if(top >= bot) {                       // :6442
+				cur = dep; h.len = cur - offset; if(cur >= len) h.done = 1; finished = true;
+			}
+		}
+	}
+	if(!finished) {
+		uint32_t same_range = 0, similar_range = 0, ntop = 0, nbot = 0;
+		while(dep < len) {                         // :6459
+			int c = seq.at(len - dep - 1);
+			uint32_t ttop = 0, tbot = 0;
+			if(c <= 3) {
+				uint32_t s0 = top / 192u, c0 = top - s0 * 192u;
+				Side64 sd = load_side64(g.sides + (size_t)s0 * 64);
+				if(bot - top > 1) {                // HIER_INIT_LOCS :5453 -> mapLF(tloc, bloc, c)
+					h.nrank += 2;
+					ttop = rank_in_side64(g, sd, s0, c0, c);
+					uint32_t spread = bot - top;
+					if(c0 + spread < 192u) {       // SideLocus::initFromTopBot gfm.h:347-370: same side
+						tbot = rank_in_side64(g, sd, s0, c0 + spread, c);
+						h.nside += 1;
+					} else {
+						tbot = rank64(g, bot, c);
+						h.nside += 2;
+					}
+				} else {                           // mapGLF1 -> mapLF1: rowL must equal c, row must not be '$'
+					h.nrank += 1; h.nside += 1;
+					if(rowL_in_side64(sd, c0) == c && !(g.nZ && top == g.zoff)) {
+						ttop = rank_in_side64(g, sd, s0, c0, c);
+						tbot = ttop + 1;
+					}
+				}
+			}
+			if(ttop >= tbot) break;
+			const uint32_t nt = tbot - ttop, no = nbot - ntop;
+			if(pseudogeneStop_) {                  // :6488-6503
+				if(nt < no && no <= (khits < 5u ? khits : 5u)) {
+					if(dep - offset >= minK + 6 && similar_range >= 5) {
+						h.numUniqueSearch++; pseudogeneStop = true; break;
+					}
+				}
+				if(nt != 1) {
+					if(nt + 2 >= no) similar_range++;
+					else if(nt + 4 < no) similar_range = 0;
+				} else pseudogeneStop_ = false;
+			}
+			if(anchorStop_) {                      // :6505-6519
+				if(nt != 1 && no == nt) { if(++same_range >= 5) anchorStop_ = false; }
+				else same_range = 0;
+				if(dep - offset >= minK + 8 && nt >= 4) anchorStop_ = false;
+			}
+			top = ttop; bot = tbot; ntop = ttop; nbot = tbot;
+			dep++;
+			if(anchorStop_ && dep - offset >= minK + 12 && bot - top == 1) {   // :6530
+				h.numUniqueSearch++; anchorStop = true; break;
+			}
+		}
+		// :6542-6598 (top < bot always holds here)
+		uint32_t hit_type = anchorStop ? H2G_ANCHOR_HIT : (pseudogeneStop ? H2G_PSEUDOGENE_HIT : H2G_CANDIDATE_HIT);
+		if(ntop < nbot) { h.top = top; h.bot = bot; h.node_top = ntop; h.node_bot = nbot; }
+		h.len = dep - offset;
+		h.hit_type = hit_type;
+		cur = dep;
+		if(cur >= len) {
+			if(hit_type == H2G_CANDIDATE_HIT) h.numUniqueSearch++;
+			h.done = 1;
+		}
+	}
+	h.cur = cur;
+	h.pseudogeneStop = pseudogeneStop;
+	h.anchorStop = anchorStop;
+	*o = h;
+}
+
+// ------------------------------------------------------------------------------------------ SA resolve (a14, a15)
+// Linear-index meaning of GWState::init/advance (group_walk.h:509-560, 1035-1336) with GFM::tryOffset
+// (gfm.h:2719): walk LF until a sampled row ((row & offMask) == row) or the '$' row; off = sample + steps.
+H2G_HD uint32_t sa_walk(const DGfm& g, uint32_t row, uint32_t* steps) {
+	uint32_t jumps = 0;
+	while(true) {
+		if(g.nZ && row == g.zoff) break;
+		if((row & g.offMask) == row) {
+			uint32_t off = g.offs[row >> g.offRate];
+			if(off != H2G_MAX) { *steps += jumps; return off + jumps; }
+		}
+		uint32_t s0 = row / 192u, c0 = row - s0 * 192u;
+		Side64 sd = load_side64(g.sides + (size_t)s0 * 64);
+		int c = rowL_in_side64(sd, c0);
+		row = rank_in_side64(g, sd, s0, c0, c);
+		jumps++;
+	}
+	*steps += jumps;
+	return jumps;
+}
+
+// GFM::joinedToTextOff gfm.h:5527-5600 (forward index)
+H2G_HD bool joined_to_text(const DGfm& g, uint32_t qlen, uint32_t off, uint32_t* tidx, uint32_t* textoff,
+                           bool rejectStraddle, bool* straddled)
+{
+	uint32_t top = 0, bot = g.nFrag, elt = H2G_MAX;
+	while(true) {
+		uint32_t oldelt = elt;
+		elt = top + ((bot - top) >> 1);
+		if(oldelt == elt) { *tidx = H2G_MAX; return false; }
+		uint32_t lower = g.rstarts[elt * 3];
+		uint32_t upper = (elt == g.nFrag - 1) ? g.len : g.rstarts[(elt + 1) * 3];
+		if(lower <= off) {
+			if(upper > off) {
+				if(off + qlen > upper) {
+					*straddled = true;
+					if(rejectStraddle) { *tidx = H2G_MAX; return false; }
+				}
+				*tidx = g.rstarts[elt * 3 + 1];
+				*textoff = (off - lower) + g.rstarts[elt * 3 + 2];
+				return true;
+			}
+			top = elt;
+		} else bot = elt;
+	}
+}
+
+// HI_Aligner::getGenomeCoords hi_aligner.h:5774-5855
+H2G_HD bool genome_coords_item(const DGfm& g, uint32_t top, uint32_t bot, uint32_t maxelt, uint32_t len,
+                               bool rejectStraddle, h2g_coord* coords, uint32_t cap, h2g_sa_result* res)
+{
+	uint32_t nelt = bot - top;
+	if(nelt > maxelt) nelt = maxelt;
+	if(nelt > cap) nelt = cap;
+	res->ok = 1; res->ncoords = 0; res->straddled = 0; res->nsteps = 0;
+	for(uint32_t e = 0; e < nelt; e++) {
+		uint32_t joff = sa_walk(g, top + e, &res->nsteps);
+		uint32_t tidx = 0, toff = 0;
+		bool st2 = false;
+		joined_to_text(g, len, joff, &tidx, &toff, rejectStraddle, &st2);
+		if(st2) res->straddled = 1;
+		if(tidx == H2G_MAX) { res->ok = 0; return false; }
+		coords[e].tidx = st2 ? H2G_MAX : tidx;
+		coords[e].toff = toff;
+		coords[e].joinedOff = joff;
+		res->ncoords = e + 1;
+	}
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------ reference (a17)
+// Meaning of BitPairReference::getStretch (reference.cpp:486-650): base of text `tidx` at `pos`, 4 for an
+// ambiguous / out-of-range position.  A cursor caches the record (or gap) interval last resolved, so the
+// sequential scans of the extension touch the record table once and then stream the 2-bit payload.
+struct RefCursor {
+	const DRef* r;
+	uint32_t reci, recf;
+	int64_t lo, hi;        // cached interval [lo, hi)
+	uint32_t bufbase;      // buf offset of lo when inside a record
+	bool inrec;
+	H2G_HD void init(const DRef* r_, uint32_t tidx) {
+		r = r_; reci = r->refRecOffs[tidx]; recf = r->refRecOffs[tidx + 1];
+		lo = 0; hi = 0; bufbase = 0; inrec = false;
+	}
+	H2G_HD void locate(int64_t pos) {
+		// last record whose start <= pos
+		uint32_t a = reci, b = recf;
+		while(a < b) {
+			uint32_t m = a + ((b - a) >> 1);
+			if((int64_t)r->rec_start[m] <= pos) a = m + 1; else b = m;
+		}
+		if(a == reci) {   // before the first stretch
+			lo = INT64_MIN / 2; hi = (int64_t)r->rec_start[reci]; inrec = false;
+			if(reci == recf) hi = INT64_MAX / 2;
+			return;
+		}
+		uint32_t k = a - 1;
+		int64_t s = r->rec_start[k], e = s + (int64_t)r->rec_len[k];
+		if(pos < e) { lo = s; hi = e; bufbase = r->rec_bufoff[k]; inrec = true; }
+		else { lo = e; hi = (k + 1 < recf) ? (int64_t)r->rec_start[k + 1] : INT64_MAX / 2; inrec = false; }
+	}
+	H2G_HD int get(int64_t pos) {
+		if(pos < lo || pos >= hi) locate(pos);
+		if(!inrec) return 4;
+		uint64_t bo = (uint64_t)bufbase + (uint64_t)(pos - lo);
+		return (r->buf[bo >> 2] >> ((bo & 3) << 1)) & 3;
+	}
+};
+
+// ------------------------------------------------------------------------------------------ scoring (a19, a26)
+H2G_HD int mm_penalty(const DScoring& sc, int q) {   // Scoring::initPens COST_MODEL_QUAL scoring.h:117-124
+	if(q < 0) q = 0;
+	int ii = q < 40 ? q : 40;
+	float frac = (float)ii / 40.0f;
+	return sc.mmpMin + (int)(frac * (float)(sc.mmpMax - sc.mmpMin));
+}
+H2G_HD int sc_penalty(const DScoring& sc, int q) {   // Scoring::sc scoring.h:312-318
+	if(q <= 33) return sc.scMin;
+	q -= 33;
+	if(q > 40) q = 40;
+	return (int)(((float)q / 40.0f) * (float)(sc.scMax - sc.scMin) + (float)sc.scMin);
+}
+
+// GenomeHit::calculateScore hi_aligner.h:3711-3891 (mismatch / gap / soft-clip terms; no splice edits)
+H2G_HD int64_t calculate_score(const DScoring& sc, const SeqView& seq, h2g_ghit* h) {
+	int64_t score = 0;
+	uint32_t mm = 0;
+	for(uint32_t i = 0; i < h->nedits; i++) {
+		const h2g_edit e = h->edits[i];
+		if(e.type == H2G_EDIT_MM) {
+			int q = seq.qual(h->rdoff + e.pos) - 33;
+			if(e.qchr == 'N') score -= sc.nPen;            // Scoring::score scoring.h:259-269: rdc > 3
+			else if(e.chr == 'N') score += sc.matchBonus;  // ref mask 15 contains every base
+			else score -= mm_penalty(sc, q);
+			mm++;
+		} else if(e.type == H2G_EDIT_READ_GAP) {
+			bool open = !(i > 0 && h->edits[i - 1].type == H2G_EDIT_READ_GAP && h->edits[i - 1].pos == e.pos);
+			score -= open ? (sc.rdGapConst + sc.rdGapLinear) : sc.rdGapLinear;
+		} else if(e.type == H2G_EDIT_REF_GAP) {
+			bool open = !(i > 0 && h->edits[i - 1].type == H2G_EDIT_REF_GAP && h->edits[i - 1].pos + 1 == e.pos);
+			score -= open ? (sc.rfGapConst + sc.rfGapLinear) : sc.rfGapLinear;
+		}
+	}
+	for(uint32_t i = 0; i < h->trim5; i++) score -= sc_penalty(sc, seq.qual(i));   // :3868-3874 (qual[i] both times)
+	for(uint32_t i = 0; i < h->trim3; i++) score -= sc_penalty(sc, seq.qual(i));
+	score += (int64_t)(h->len - mm) * sc.matchBonus;
+	h->score = score;
+	return score;
+}
+
+// ------------------------------------------------------------------------------------------ extend (a18)
+#define H2G_NEW_EDITS 24
+H2G_HD uint8_t base_char(int c) { return (uint8_t)("ACGTN"[c]); }
+H2G_HD bool is_gap(uint8_t t) { return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
+
+// alignWithALTs (hi_aligner.h:683-783) over alignWithALTs_recur without ALTs (:2763-2853 left,
+// :3168-3216 right).  Edits are committed in place instead of through a scratch copy.
+H2G_HD uint32_t align_no_alts(const DRef& ref, const SeqView& seq, uint32_t base_rdoff, uint32_t rdoff,
+                              uint32_t rdlen, uint32_t tidx, int rfoff, uint32_t rflen, bool left, h2g_ghit* h,
+                              uint32_t mm, uint32_t* numNs)
+{
+	if(numNs) *numNs = 0;
+	const uint32_t n_old = h->nedits;
+	h2g_edit ne[H2G_NEW_EDITS];
+	uint32_t tmp_mm = 0, nNs = 0;
+	bool updated = false;
+	uint32_t extlen = 0;
+	const uint32_t contig_len = ref.refLens[tidx];
+	bool run = !(rfoff < -16) && !((int64_t)rfoff >= (int64_t)contig_len);
+	if(run) {
+		if(rfoff >= 0 && (uint64_t)rfoff + rflen > contig_len) rflen = contig_len - (uint32_t)rfoff;
+		else if(rfoff < 0 && rflen > contig_len) rflen = contig_len;
+		if(rflen == 0) run = false;
+	}
+	if(run) {
+		RefCursor rc;
+		rc.init(&ref, tidx);
+		const uint32_t rdoff_add = rdoff - base_rdoff;
+		if(left) {
+			int i = (int)rdoff;
+			for(int rf_i = (int)rflen - 1; rf_i >= 0 && i >= 0; rf_i--, i--) {
+				int64_t p = (int64_t)rfoff + rf_i;
+				int rf_bp = p < 0 ? 4 : rc.get(p), rd_bp = seq.at((uint32_t)i);
+				if(rf_bp != rd_bp || rd_bp == 4) {
+					if(tmp_mm >= mm) break;
+					if(tmp_mm < H2G_NEW_EDITS) {
+						ne[tmp_mm].pos = (uint32_t)i; ne[tmp_mm].chr = base_char(rf_bp); ne[tmp_mm].qchr = base_char(rd_bp);
+						ne[tmp_mm].type = H2G_EDIT_MM; ne[tmp_mm].pad = 0;
+					} else h->overflow = 1;
+					tmp_mm++;
+				}
+				if(rf_bp == 4) nNs++;
+			}
+			if(i < (int)rdoff) { updated = true; extlen = rdoff - (uint32_t)i; if(numNs) *numNs = nNs; }
+		} else {
+			uint32_t i = 0;
+			for(uint32_t rf_i = 0; rf_i < rflen && i < rdlen; rf_i++, i++) {
+				int64_t p = (int64_t)rfoff + rf_i;
+				int rf_bp = p < 0 ? 4 : rc.get(p), rd_bp = seq.at(rdoff + i);
+				if(rf_bp != rd_bp || rd_bp == 4) {
+					if(tmp_mm >= mm) break;
+					if(tmp_mm < H2G_NEW_EDITS) {
+						ne[tmp_mm].pos = i + rdoff_add; ne[tmp_mm].chr = base_char(rf_bp); ne[tmp_mm].qchr = base_char(rd_bp);
+						ne[tmp_mm].type = H2G_EDIT_MM; ne[tmp_mm].pad = 0;
+					} else h->overflow = 1;
+					tmp_mm++;
+				}
+			}
+			if(i > 0) { updated = true; extlen = i; }
+		}
+	}
+	if(!updated) tmp_mm = 0;
+	if(tmp_mm > H2G_NEW_EDITS) tmp_mm = H2G_NEW_EDITS;
+	const uint32_t total = n_old + tmp_mm;
+	if(extlen > 0 && total > 0) {   // :751-779
+		// front()/back() of the list the reference would hold after `edits = tmp_edits`
+		h2g_edit f, b;
+		if(left) { f = tmp_mm ? ne[tmp_mm - 1] : h->edits[0]; b = n_old ? h->edits[n_old - 1] : ne[0]; }
+		else     { f = n_old ? h->edits[0] : ne[0];            b = tmp_mm ? ne[tmp_mm - 1] : h->edits[n_old - 1]; }
+		if(f.pos + extlen == base_rdoff + 1) {
+			if(is_gap(f.type)) extlen = 0;
+			if(f.type == H2G_EDIT_MM && f.chr == 'N') extlen = 0;
+		}
+		if(extlen > 0 && b.pos == rdoff - base_rdoff + extlen - 1) {
+			if(is_gap(b.type)) extlen = 0;
+		}
+	}
+	if(extlen > 0 && tmp_mm > 0) {   // commit the new edits
+		if(total > H2G_MAX_EDITS) { h->overflow = 1; return extlen; }
+		if(left) {                   // new edits go to the front, in increasing read position
+			for(int k = (int)n_old - 1; k >= 0; k--) h->edits[k + tmp_mm] = h->edits[k];
+			for(uint32_t k = 0; k < tmp_mm; k++) h->edits[k] = ne[tmp_mm - 1 - k];
+		} else {
+			for(uint32_t k = 0; k < tmp_mm; k++) h->edits[n_old + k] = ne[k];
+		}
+		h->nedits = total;
+	}
+	if(extlen == 0 && numNs) *numNs = updated ? nNs : 0;
+	return extlen;
+}
+
+// GenomeHit::getRight hi_aligner.h:962-1000 (+ getRightOff :1020) for MM / gap edit lists
+H2G_HD void hit_get_right(const h2g_ghit* h, uint32_t* rdoff, uint32_t* len, uint32_t* toff) {
+	*rdoff = h->rdoff; *len = h->len; *toff = h->toff;
+	for(int i = (int)h->nedits - 1; i >= 0; i--) {
+		const h2g_edit e = h->edits[i];
+		if(is_gap(e.type)) {
+			*rdoff = h->rdoff + e.pos;
+			*len = h->len - e.pos;
+			if(e.type == H2G_EDIT_REF_GAP) { (*rdoff)++; (*len)--; }
+			uint32_t roff = h->toff + h->len;
+			for(uint32_t k = 0; k < h->nedits; k++) {
+				if(h->edits[k].type == H2G_EDIT_READ_GAP) roff++;
+				else if(h->edits[k].type == H2G_EDIT_REF_GAP) roff--;
+			}
+			*toff = roff - *len;
+			return;
+		}
+	}
+}
+
+// GenomeHit::extend hi_aligner.h:2031-2232
+H2G_HD bool extend_item(const DRef& ref, const DScoring& sc, const SeqView& seq, h2g_ghit* h, uint32_t mm,
+                        uint32_t max_leftext, uint32_t max_rightext, uint32_t* leftext, uint32_t* rightext)
+{
+	const uint32_t rdlen = seq.len;
+	*leftext = 0; *rightext = 0;
+	if(max_leftext > 0 && h->rdoff > 0) {
+		if(h->toff <= 0) return false;
+		int rl = (int)h->toff - (int)h->rdoff;
+		uint32_t reflen = h->rdoff + 10;
+		rl -= (int)(reflen - h->rdoff);
+		if(rl < 0) { reflen += rl; rl = 0; }
+		uint32_t numNs = 0;
+		const uint32_t n_prev = h->nedits;
+		uint32_t best_ext = align_no_alts(ref, seq, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx, rl, reflen, true,
+		                                  h, mm, &numNs);
+		if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return false; }
+		if(best_ext > 0) {
+			*leftext = best_ext;
+			const uint32_t added = h->nedits - n_prev;
+			int ref_ext = (int)best_ext;
+			for(uint32_t i = 0; i < added; i++) {
+				if(h->edits[i].type == H2G_EDIT_REF_GAP) ref_ext--;
+				else if(h->edits[i].type == H2G_EDIT_READ_GAP) ref_ext++;
+			}
+			h->rdoff -= best_ext;
+			h->toff -= (uint32_t)ref_ext;
+			h->len += best_ext;
+			h->joinedOff -= (uint32_t)(ref_ext - (int)numNs);
+			for(uint32_t i = 0; i < h->nedits; i++) {
+				if(i < added) h->edits[i].pos -= h->rdoff;
+				else h->edits[i].pos += best_ext;
+			}
+		}
+	}
+	if(max_rightext > 0 && h->rdoff + h->len < rdlen) {
+		uint32_t r_rdoff, r_len, r_toff;
+		hit_get_right(h, &r_rdoff, &r_len, &r_toff);
+		const uint32_t rl = r_toff + r_len;
+		const uint32_t rr = rdlen - (r_rdoff + r_len);
+		const uint32_t tlen = ref.refLens[h->tidx];
+		if(rl < tlen) {
+			uint32_t reflen = rr + 10;
+			if(rl + reflen > tlen) reflen = tlen - rl;
+			uint32_t best_ext = align_no_alts(ref, seq, h->rdoff, h->rdoff + h->len, rdlen - (h->rdoff + h->len),
+			                                  h->tidx, (int)rl, reflen, false, h, mm, nullptr);
+			if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return false; }
+			if(best_ext > 0) { *rightext = best_ext; h->len += best_ext; }
+		}
+	}
+	calculate_score(sc, seq, h);
+	return *leftext > 0 || *rightext > 0;
+}
+
+// ------------------------------------------------------------------------------------------ fused seed stage
+// One (read, strand): coordinates of the partial hit (getAnchorHits hi_aligner.h:5007: only hits longer
+// than minK + 2; here the first H2G_SEED_CAP rows of the range) and their 0-mismatch extension
+// (hybridSearch spliced_aligner.h:139-163).
+H2G_HD void resolve_extend_item(const DGfm& g, const DRef& ref, const DScoring& sc, const SeqView& seq,
+                                h2g_seed_result* out, h2g_ghit* scratch)
+{
+	const h2g_fm_hit hit = out->hit;
+	out->ncoords = 0; out->straddled = 0; out->nsteps = 0; out->pad = 0;
+	if(hit.top == H2G_MAX || hit.bot <= hit.top || hit.len <= g.minK + 2) return;
+	h2g_coord co[H2G_SEED_CAP];
+	h2g_sa_result res;
+	genome_coords_item(g, hit.top, hit.bot, hit.bot - hit.top, hit.len, false, co, H2G_SEED_CAP, &res);
+	out->ncoords = res.ncoords; out->straddled = res.straddled; out->nsteps = res.nsteps;
+	for(uint32_t k = 0; k < res.ncoords; k++) {
+		out->ext[k].tidx = co[k].tidx; out->ext[k].toff = co[k].toff; out->ext[k].joinedOff = co[k].joinedOff;
+		out->ext[k].rdoff = seq.len - hit.bwoff - hit.len; out->ext[k].len = hit.len; out->ext[k].score = 0;
+		if(co[k].tidx == H2G_MAX) continue;
+		h2g_ghit* h = scratch;
+		h->read = 0; h->fw = seq.fw; h->rdoff = seq.len - hit.bwoff - hit.len; h->len = hit.len; h->trim5 = 0; h->trim3 = 0;
+		h->tidx = co[k].tidx; h->toff = co[k].toff; h->joinedOff = co[k].joinedOff; h->score = 0; h->nedits = 0;
+		h->overflow = 0;
+		uint32_t le, re;
+		extend_item(ref, sc, seq, h, 0, H2G_MAX, H2G_MAX, &le, &re);
+		out->ext[k].toff = h->toff; out->ext[k].joinedOff = h->joinedOff; out->ext[k].rdoff = h->rdoff;
+		out->ext[k].len = h->len; out->ext[k].score = (int32_t)h->score;
+	}
+}
+
+}  // namespace h2g

@@ -1,0 +1,200 @@
+// h2g_host_index.h — host-side parse of the on-disk .ht2 index (format unchanged from the reference).
+//
+// Layout facts follow GFM::readIntoMemory (gfm.h:5917-6332), the SA sample file (.2, gfm.h:6334-6432),
+// HGFM/LocalGFM::readIntoMemory (hgfm.h:2560-2640, 1105-1400; 16-bit words) and BitPairReference
+// (reference.cpp:101-190; RefRecord ref_read.h:73-103).  Nothing is re-encoded: sides are uploaded as
+// they are on disk, because a 64 B (linear) / 128 B (graph) side already is the HBM transaction unit and
+// keeps the Occ checkpoint in the same line as the BWT payload.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace h2g {
+
+struct GfmParams {  // GFMParams::init gfm.h:138-185
+	uint32_t len = 0, gbwtLen = 0, numNodes = 0;
+	int32_t lineRate = 0, offRate = 0, ftabChars = 0;
+	uint32_t eftabLen = 0;
+	bool linear = true;
+	uint32_t offMask = 0, ftabLen = 0, offsLen = 0, sideSz = 0, sideGbwtSz = 0, sideGbwtLen = 0, numSides = 0;
+	uint64_t gbwtTotLen = 0;
+	int wsz = 4;
+	void init(uint32_t len_, uint32_t gbwtLen_, uint32_t numNodes_, int32_t lineRate_, int32_t offRate_,
+	          int32_t ftabChars_, uint32_t eftabLen_, int wsz_) {
+		wsz = wsz_;
+		const uint32_t wmax = wsz == 4 ? 0xffffffffu : 0xffffu;
+		linear = (((len_ + 1) & wmax) == gbwtLen_ || gbwtLen_ == 0);
+		len = len_;
+		gbwtLen = gbwtLen_ == 0 ? len_ + 1 : gbwtLen_;
+		numNodes = numNodes_ == 0 ? len_ + 1 : numNodes_;
+		const uint32_t gbwtSz = linear ? gbwtLen / 4 + 1 : gbwtLen / 2 + 1;
+		lineRate = lineRate_; offRate = offRate_; ftabChars = ftabChars_; eftabLen = eftabLen_;
+		offMask = (wmax << offRate) & wmax;
+		ftabLen = (1u << (ftabChars * 2)) + 1;
+		offsLen = (numNodes + (1u << offRate) - 1) >> offRate;
+		sideSz = 1u << lineRate;
+		sideGbwtSz = sideSz - wsz * (linear ? 4 : 6);
+		sideGbwtLen = linear ? sideGbwtSz << 2 : sideGbwtSz << 1;
+		numSides = (gbwtSz + sideGbwtSz - 1) / sideGbwtSz;
+		gbwtTotLen = (uint64_t)numSides * sideSz;
+	}
+};
+
+struct HostGfm {
+	GfmParams p;
+	std::vector<uint32_t> plen, rstarts, zOffs, ftab, eftab, offs;   // widened to u32 for local indexes
+	std::vector<uint8_t> sides;
+	uint32_t fchr[5] = {0, 0, 0, 0, 0};
+	uint32_t nPat = 0, nFrag = 0;
+	uint32_t tidx = 0, localOffset = 0, joinedOffset = 0;           // LocalGFM only
+};
+
+struct HostRef {  // BitPairReference
+	std::vector<uint32_t> rec_start;    // text offset where record i's unambiguous stretch begins
+	std::vector<uint32_t> rec_len;      // its length
+	std::vector<uint32_t> rec_bufoff;   // unambiguous bases preceding it in buf (cumUnambig_)
+	std::vector<uint32_t> refRecOffs;   // [nrefs+1]
+	std::vector<uint32_t> refLens;      // [nrefs] approxLen (excludes trailing Ns)
+	std::vector<uint8_t> buf;           // .4.ht2: 2 bit/base, LSB-first
+	uint32_t nrefs = 0;
+};
+
+struct HostIndex {
+	HostGfm g;
+	HostRef r;
+	std::vector<HostGfm> local;
+	std::vector<uint32_t> local_first;  // [nPat+1]
+	std::vector<std::string> names;
+	uint32_t minK = 0;
+};
+
+class Reader {
+public:
+	std::vector<uint8_t> d;
+	size_t pos = 0;
+	bool open(const std::string& fn) {
+		FILE* f = fopen(fn.c_str(), "rb");
+		if(!f) return false;
+		fseek(f, 0, SEEK_END);
+		long n = ftell(f);
+		fseek(f, 0, SEEK_SET);
+		d.resize((size_t)n);
+		bool ok = n == 0 || fread(d.data(), 1, (size_t)n, f) == (size_t)n;
+		fclose(f);
+		return ok;
+	}
+	bool has(size_t n) const { return pos + n <= d.size(); }
+	uint32_t u32() { uint32_t v = 0; if(has(4)) memcpy(&v, &d[pos], 4); else bad = true; pos += 4; return v; }
+	uint32_t u16() { uint16_t v = 0; if(has(2)) memcpy(&v, &d[pos], 2); else bad = true; pos += 2; return v; }
+	uint32_t w(int wsz) { return wsz == 4 ? u32() : u16(); }
+	void arr(std::vector<uint32_t>& a, int wsz, size_t n) {
+		a.resize(n);
+		if(!has(n * wsz)) { bad = true; return; }
+		if(wsz == 4) { if(n) memcpy(a.data(), &d[pos], n * 4); pos += n * 4; }
+		else for(size_t i = 0; i < n; i++) a[i] = u16();
+	}
+	bool bad = false;
+};
+
+inline bool read_gfm_body(Reader& b, HostGfm& g) {
+	const int wsz = g.p.wsz;
+	g.nPat = b.w(wsz);
+	b.arr(g.plen, wsz, g.nPat);
+	g.nFrag = b.w(wsz);
+	b.arr(g.rstarts, wsz, (size_t)g.nFrag * 3);
+	if(!b.has(g.p.gbwtTotLen)) return false;
+	g.sides.assign(b.d.begin() + b.pos, b.d.begin() + b.pos + g.p.gbwtTotLen);
+	b.pos += g.p.gbwtTotLen;
+	uint32_t nZ = b.w(wsz);
+	b.arr(g.zOffs, wsz, nZ);
+	for(int i = 0; i < 5; i++) g.fchr[i] = b.w(wsz);
+	b.arr(g.ftab, wsz, g.p.ftabLen);
+	b.arr(g.eftab, wsz, g.p.eftabLen);
+	return !b.bad;
+}
+
+// returns 0 ok, -1 io, -2 format
+inline int load_host_index(const std::string& base, bool load_local, HostIndex& ix) {
+	Reader b1, b2, b3, b4;
+	if(!b1.open(base + ".1.ht2") || !b2.open(base + ".2.ht2") || !b3.open(base + ".3.ht2") ||
+	   !b4.open(base + ".4.ht2")) return -1;
+	if(b1.u32() != 1) return -2;
+	b1.u32();  // version
+	uint32_t len = b1.u32(), gbwtLen = b1.u32(), numNodes = b1.u32();
+	int32_t lineRate = (int32_t)b1.u32(); b1.u32();
+	int32_t offRate = (int32_t)b1.u32(), ftabChars = (int32_t)b1.u32();
+	uint32_t eftabLen = b1.u32(); b1.u32();
+	if(lineRate < 6 || lineRate > 8 || ftabChars < 1 || ftabChars > 14 || offRate < 0 || offRate > 16) return -2;
+	ix.g.p.init(len, gbwtLen, numNodes, lineRate, offRate, ftabChars, eftabLen, 4);
+	if(!read_gfm_body(b1, ix.g)) return -2;
+	{   // reference names, '\n'-separated, '\0'-terminated
+		std::string cur;
+		while(b1.pos < b1.d.size()) {
+			char c = (char)b1.d[b1.pos++];
+			if(c == '\0') { if(!cur.empty()) ix.names.push_back(cur); break; }
+			if(c == '\n') { ix.names.push_back(cur); cur.clear(); } else cur.push_back(c);
+		}
+	}
+	b2.u32();
+	b2.arr(ix.g.offs, 4, ix.g.p.offsLen);
+	if(b2.bad) return -2;
+	// reference records
+	if(b3.u32() != 1) return -2;
+	uint32_t nrecs = b3.u32();
+	HostRef& r = ix.r;
+	uint64_t cumsz = 0, cumlen = 0;
+	for(uint32_t i = 0; i < nrecs; i++) {
+		uint32_t off = b3.u32(), rlen = b3.u32();
+		if(!b3.has(1)) return -2;
+		bool first = b3.d[b3.pos++] != 0;
+		if(first) {
+			r.refRecOffs.push_back(i);
+			if(r.nrefs > 0) r.refLens.push_back((uint32_t)cumlen);
+			cumlen = 0;
+			r.nrefs++;
+		} else if(i == 0) return -2;
+		cumlen += off;
+		r.rec_start.push_back((uint32_t)cumlen);
+		r.rec_len.push_back(rlen);
+		r.rec_bufoff.push_back((uint32_t)cumsz);
+		cumsz += rlen;
+		cumlen += rlen;
+	}
+	if(b3.bad || r.nrefs == 0) return -2;
+	r.refRecOffs.push_back(nrecs);
+	r.refLens.push_back((uint32_t)cumlen);
+	r.buf.swap(b4.d);
+	r.buf.resize(r.buf.size() + 16, 0);
+	if(load_local) {
+		Reader b5, b6;
+		if(b5.open(base + ".5.ht2") && b6.open(base + ".6.ht2")) {
+			b5.u32(); b6.u32();
+			uint32_t nlocal = b5.u32();
+			int32_t llr = (int32_t)b5.u32(); b5.u32();
+			int32_t lor = (int32_t)b5.u32(), lfc = (int32_t)b5.u32(); b5.u32();
+			ix.local.resize(nlocal);
+			ix.local_first.clear();
+			for(uint32_t i = 0; i < nlocal; i++) {
+				HostGfm& l = ix.local[i];
+				l.tidx = b5.u32(); l.localOffset = b5.u32(); l.joinedOffset = b5.u32();
+				uint32_t llen = b5.u16(), lgl = b5.u16(), lnn = b5.u16(), lel = b5.u16();
+				l.p.init(llen, lgl, lnn, llr, lor, lfc, lel, 2);
+				while(ix.local_first.size() <= l.tidx) ix.local_first.push_back(i);
+				if(llen == 0) continue;
+				if(!read_gfm_body(b5, l)) return -2;
+				b6.arr(l.offs, 2, l.p.offsLen);
+				if(b6.bad) return -2;
+			}
+			while(ix.local_first.size() <= ix.g.nPat) ix.local_first.push_back(nlocal);
+		}
+	}
+	uint32_t gl = ix.g.p.len;
+	ix.minK = 0;
+	while(gl > 0) { gl >>= 2; ix.minK++; }   // hi_aligner.h:3979-3984
+	return 0;
+}
+
+}  // namespace h2g

@@ -1,0 +1,619 @@
+// h2g_kernels.hip — gfx950 kernels and the C ABI of libh2g.so (include/h2g.h).
+//
+// Integer / byte work bound by random 64 B HBM reads: no MFMA anywhere.  Launch geometry: 256-thread
+// workgroups (4 waves of 64), grids of >= 8 blocks per CU x 256 CUs so all 8 XCDs stay busy; sides are
+// read with 16 B-per-lane vector loads so one side = one 64 B request.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+#include "h2g_core.h"
+#include "h2g_host_index.h"
+
+using namespace h2g;
+
+// ------------------------------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+static int set_err(const char* what, hipError_t e) {
+	snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+	return H2G_ERR_DEVICE;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return set_err(#call, e_); } while(0)
+
+extern "C" const char* h2g_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ handles
+struct h2g_index {
+	HostIndex host;
+	bool synthetic = false;
+	int device = 0;
+	DGfm dg;
+	DRef dr;
+	std::vector<void*> allocs;
+	uint64_t device_bytes = 0;
+};
+
+struct h2g_stream {
+	h2g_index* ix = nullptr;
+	hipStream_t st = nullptr;
+	size_t max_reads = 0, max_bases = 0, n_reads = 0;
+	uint8_t* d_codes = nullptr;
+	uint32_t* d_offs = nullptr;
+	char* d_quals = nullptr;
+	bool has_quals = false;
+	h2g_seed_result* d_seed = nullptr;
+	unsigned long long* d_counters = nullptr;   // [8]
+	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
+	size_t tmp_sz[4] = {0, 0, 0, 0};
+	hipEvent_t ev[6];
+	h2g_counters last;
+};
+
+template <typename T>
+static int upload(h2g_index* ix, const std::vector<T>& v, const T** out, size_t pad = 64) {
+	void* p = nullptr;
+	size_t bytes = v.size() * sizeof(T) + pad;
+	HIPCHK(hipMalloc(&p, bytes));
+	HIPCHK(hipMemset(p, 0, bytes));
+	if(!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+	ix->allocs.push_back(p);
+	ix->device_bytes += bytes;
+	*out = (const T*)p;
+	return H2G_OK;
+}
+
+extern "C" void h2g_load_opts_init(h2g_load_opts* o) { o->device = 0; o->load_local = 1; }
+
+static void fill_dgfm(const HostGfm& g, uint32_t minK, DGfm* d) {
+	for(int i = 0; i < 5; i++) d->fchr[i] = g.fchr[i];
+	d->len = g.p.len; d->gbwtLen = g.p.gbwtLen; d->ftabLim = g.p.linear ? g.p.len : g.p.gbwtLen;
+	d->sideGbwtLen = g.p.sideGbwtLen; d->sideGbwtSz = g.p.sideGbwtSz; d->lineRate = g.p.lineRate;
+	d->offRate = g.p.offRate; d->offMask = g.p.offMask; d->ftabChars = g.p.ftabChars;
+	d->nFrag = g.nFrag; d->nPat = g.nPat; d->nZ = (uint32_t)g.zOffs.size();
+	d->zoff = g.zOffs.empty() ? H2G_MAX : g.zOffs[0];
+	d->minK = minK; d->linear = g.p.linear;
+}
+
+extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts, h2g_index** out) {
+	if(!base || !out) return H2G_ERR_ARG;
+	h2g_load_opts o;
+	h2g_load_opts_init(&o);
+	if(opts) o = *opts;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if(e != hipSuccess || ndev <= 0) { snprintf(g_err, sizeof g_err, "no HIP device (libh2g has no CPU path)"); return H2G_ERR_DEVICE; }
+	if(o.device < 0 || o.device >= ndev) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(o.device));
+	h2g_index* ix = new h2g_index();
+	ix->device = o.device;
+	int rc = load_host_index(base, o.load_local != 0, ix->host);
+	if(rc != 0) { delete ix; snprintf(g_err, sizeof g_err, "cannot read index %s", base); return rc == -1 ? H2G_ERR_IO : H2G_ERR_FORMAT; }
+	const HostGfm& g = ix->host.g;
+	fill_dgfm(g, ix->host.minK, &ix->dg);
+	int s = H2G_OK;
+	if((s = upload(ix, g.sides, &ix->dg.sides, 256)) || (s = upload(ix, g.ftab, &ix->dg.ftab)) ||
+	   (s = upload(ix, g.eftab, &ix->dg.eftab)) || (s = upload(ix, g.offs, &ix->dg.offs)) ||
+	   (s = upload(ix, g.rstarts, &ix->dg.rstarts)) || (s = upload(ix, g.plen, &ix->dg.plen))) { h2g_index_free(ix); return s; }
+	const HostRef& r = ix->host.r;
+	ix->dr.nrefs = r.nrefs;
+	if((s = upload(ix, r.buf, &ix->dr.buf)) || (s = upload(ix, r.rec_start, &ix->dr.rec_start)) ||
+	   (s = upload(ix, r.rec_len, &ix->dr.rec_len)) || (s = upload(ix, r.rec_bufoff, &ix->dr.rec_bufoff)) ||
+	   (s = upload(ix, r.refRecOffs, &ix->dr.refRecOffs)) || (s = upload(ix, r.refLens, &ix->dr.refLens))) { h2g_index_free(ix); return s; }
+	*out = ix;
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_index_get_info(const h2g_index* ix, h2g_index_info* o) {
+	if(!ix || !o) return H2G_ERR_ARG;
+	const GfmParams& p = ix->host.g.p;
+	o->len = p.len; o->gbwtLen = p.gbwtLen; o->numNodes = p.numNodes; o->lineRate = p.lineRate; o->offRate = p.offRate;
+	o->ftabChars = p.ftabChars; o->eftabLen = p.eftabLen; o->linear = p.linear; o->sideSz = p.sideSz;
+	o->sideGbwtSz = p.sideGbwtSz; o->sideGbwtLen = p.sideGbwtLen; o->numSides = p.numSides; o->offsLen = p.offsLen;
+	o->ftabLen = p.ftabLen; o->nPat = ix->host.g.nPat; o->nFrag = ix->host.g.nFrag; o->nZ = (uint32_t)ix->host.g.zOffs.size();
+	o->minK = ix->host.minK; o->nLocal = (uint32_t)ix->host.local.size(); o->nRefRecs = (uint32_t)ix->host.r.rec_len.size();
+	o->device_bytes = ix->device_bytes;
+	return H2G_OK;
+}
+
+extern "C" void h2g_index_free(h2g_index* ix) {
+	if(!ix) return;
+	for(void* p : ix->allocs) (void)hipFree(p);
+	delete ix;
+}
+
+// ------------------------------------------------------------------------------------------ synthetic sides
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+	x += 0x9E3779B97F4A7C15ull;
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+	return x ^ (x >> 31);
+}
+
+// fills payloads with random symbols; per-side symbol counts go to cnt[side*4 + c]
+__global__ void k_synth_fill(uint8_t* sides, uint32_t* cnt, uint64_t nsides, uint64_t seed) {
+	uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+	if(s >= nsides) return;
+	uint64_t* w = reinterpret_cast<uint64_t*>(sides + s * 64);
+	uint32_t c[4] = {0, 0, 0, 0};
+	for(int k = 0; k < 6; k++) {
+		uint64_t v = splitmix64(seed + s * 8 + k);
+		w[k] = v;
+		for(int cc = 0; cc < 4; cc++) c[cc] += count_word(v, cc, 32);
+	}
+	for(int cc = 0; cc < 4; cc++) cnt[s * 4 + cc] = c[cc];
+}
+// exclusive prefix over sides, one thread per symbol (sequential: run once at set-up)
+__global__ void k_synth_prefix(uint8_t* sides, const uint32_t* cnt, uint64_t nsides, uint32_t* totals) {
+	int c = threadIdx.x;
+	if(c >= 4) return;
+	uint32_t run = 0;
+	for(uint64_t s = 0; s < nsides; s++) {
+		reinterpret_cast<uint32_t*>(sides + s * 64 + 48)[c] = run;
+		run += cnt[s * 4 + c];
+	}
+	totals[c] = run;
+}
+
+extern "C" h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out) {
+	if(!out || num_sides == 0 || num_sides * 192ull >= 0xffffffffull) return H2G_ERR_ARG;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { snprintf(g_err, sizeof g_err, "no HIP device"); return H2G_ERR_DEVICE; }
+	HIPCHK(hipSetDevice(device));
+	h2g_index* ix = new h2g_index();
+	ix->synthetic = true;
+	ix->device = device;
+	void *sides = nullptr, *cnt = nullptr, *tot = nullptr;
+	HIPCHK(hipMalloc(&sides, num_sides * 64 + 256));
+	HIPCHK(hipMalloc(&cnt, num_sides * 16));
+	HIPCHK(hipMalloc(&tot, 16));
+	ix->allocs.push_back(sides);
+	ix->device_bytes = num_sides * 64;
+	hipLaunchKernelGGL(k_synth_fill, dim3((unsigned)((num_sides + 255) / 256)), dim3(256), 0, 0, (uint8_t*)sides, (uint32_t*)cnt, num_sides, seed);
+	hipLaunchKernelGGL(k_synth_prefix, dim3(1), dim3(64), 0, 0, (uint8_t*)sides, (const uint32_t*)cnt, num_sides, (uint32_t*)tot);
+	uint32_t totals[4];
+	HIPCHK(hipMemcpy(totals, tot, 16, hipMemcpyDeviceToHost));
+	(void)hipFree(cnt); (void)hipFree(tot);
+	GfmParams& p = ix->host.g.p;
+	uint32_t len = (uint32_t)(num_sides * 192 - 1);
+	p.init(len, len + 1, len + 1, 6, 4, 10, 0, 4);
+	p.numSides = (uint32_t)num_sides;
+	ix->host.g.fchr[0] = 0;
+	for(int c = 0; c < 4; c++) ix->host.g.fchr[c + 1] = ix->host.g.fchr[c] + totals[c];
+	fill_dgfm(ix->host.g, 16, &ix->dg);
+	ix->dg.sides = (const uint8_t*)sides;
+	ix->dg.nZ = 0;
+	*out = ix;
+	return H2G_OK;
+}
+
+// ------------------------------------------------------------------------------------------ stream
+extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t max_bases, h2g_stream** out) {
+	if(!ix || !out) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(ix->device));
+	h2g_stream* s = new h2g_stream();
+	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
+	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+	for(int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&s->ev[i]));
+	HIPCHK(hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
+	if(max_reads) {
+		HIPCHK(hipMalloc((void**)&s->d_codes, max_bases + 64));
+		HIPCHK(hipMalloc((void**)&s->d_quals, max_bases + 64));
+		HIPCHK(hipMalloc((void**)&s->d_offs, (max_reads + 1) * 4));
+		HIPCHK(hipMalloc((void**)&s->d_seed, max_reads * 2 * sizeof(h2g_seed_result)));
+	}
+	memset(&s->last, 0, sizeof s->last);
+	*out = s;
+	return H2G_OK;
+}
+
+extern "C" void h2g_stream_free(h2g_stream* s) {
+	if(!s) return;
+	(void)hipStreamSynchronize(s->st);
+	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
+	(void)hipFree(s->d_counters);
+	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
+	for(int i = 0; i < 6; i++) (void)hipEventDestroy(s->ev[i]);
+	(void)hipStreamDestroy(s->st);
+	delete s;
+}
+
+extern "C" void* h2g_stream_hip(h2g_stream* s) { return s ? (void*)s->st : nullptr; }
+extern "C" h2g_status h2g_stream_sync(h2g_stream* s) {
+	if(!s) return H2G_ERR_ARG;
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+static int tmp_buf(h2g_stream* s, int slot, size_t bytes, void** out) {
+	if(s->tmp_sz[slot] < bytes) {
+		(void)hipFree(s->d_tmp[slot]);
+		s->d_tmp[slot] = nullptr; s->tmp_sz[slot] = 0;
+		HIPCHK(hipMalloc(&s->d_tmp[slot], bytes + 256));
+		s->tmp_sz[slot] = bytes;
+	}
+	*out = s->d_tmp[slot];
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_set_reads(h2g_stream* s, const uint8_t* codes, const uint32_t* offs, const char* quals, size_t n) {
+	if(!s || !codes || !offs || n > s->max_reads) return H2G_ERR_ARG;
+	size_t nb = offs[n];
+	if(nb > s->max_bases) return H2G_ERR_ARG;
+	HIPCHK(hipMemcpyAsync(s->d_codes, codes, nb, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(s->d_offs, offs, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
+	s->has_quals = quals != nullptr;
+	if(quals) HIPCHK(hipMemcpyAsync(s->d_quals, quals, nb, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	s->n_reads = n;
+	return H2G_OK;
+}
+
+static DReads dreads(const h2g_stream* s) {
+	DReads r;
+	r.codes = s->d_codes; r.offs = s->d_offs; r.quals = s->has_quals ? s->d_quals : nullptr; r.n = (uint32_t)s->n_reads;
+	return r;
+}
+
+static unsigned grid_for(size_t n, unsigned block) {
+	size_t g = (n + block - 1) / block;
+	const size_t cap = 256 * 16;   // >= 8 resident blocks per CU plus slack; grid-stride above that
+	return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------ rank kernels
+// variant 0: one lane per query, 4 x dwordx4 per side
+__global__ __launch_bounds__(256) void k_rank_v0(DGfm g, const uint32_t* rows, const uint8_t* cs, uint32_t* out,
+                                                 size_t n, uint64_t seed, int synth)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		uint32_t row; int c;
+		if(synth) { uint64_t h = splitmix64(seed + i); row = (uint32_t)(h % g.gbwtLen); c = (int)((h >> 40) & 3); }
+		else { row = rows[i]; c = cs[i]; }
+		out[i] = rank64(g, row, c);
+	}
+}
+
+// variant 1: four lanes per side — one dwordx4 per lane => one fully coalesced 64 B request per query;
+// lanes 0-2 popcount two payload words each, lane 3 holds the four Occ words; 2-step butterfly reduce.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_rank_v1(DGfm g, const uint32_t* rows, const uint8_t* cs, uint32_t* out,
+                                                 size_t n, uint64_t seed, int synth)
+{
+	const unsigned lane = threadIdx.x & 63, sub = lane & 3;
+	const size_t ngroups = ((size_t)gridDim.x * blockDim.x) >> 2;
+	const size_t gid = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 2;
+	for(size_t base = gid * UNROLL; base < n; base += ngroups * UNROLL) {
+		uint32_t row[UNROLL], sideNum[UNROLL], charOff[UNROLL]; int c[UNROLL]; uint4 v[UNROLL];
+#pragma unroll
+		for(int u = 0; u < UNROLL; u++) {
+			size_t i = base + u;
+			bool ok = i < n;
+			if(synth) { uint64_t h = splitmix64(seed + (ok ? i : 0)); row[u] = (uint32_t)(h % g.gbwtLen); c[u] = (int)((h >> 40) & 3); }
+			else { row[u] = ok ? rows[i] : 0; c[u] = ok ? cs[i] : 0; }
+			sideNum[u] = row[u] / 192u; charOff[u] = row[u] - sideNum[u] * 192u;
+			v[u] = reinterpret_cast<const uint4*>(g.sides + (size_t)sideNum[u] * 64)[sub];
+		}
+#pragma unroll
+		for(int u = 0; u < UNROLL; u++) {
+			uint64_t w0 = v[u].x | ((uint64_t)v[u].y << 32), w1 = v[u].z | ((uint64_t)v[u].w << 32);
+			int n0 = (int)charOff[u] - 64 * (int)sub;
+			uint32_t cnt = sub < 3 ? count_word(w0, c[u], n0) + count_word(w1, c[u], n0 - 32) : 0u;
+			uint32_t occsel = c[u] == 0 ? v[u].x : c[u] == 1 ? v[u].y : c[u] == 2 ? v[u].z : v[u].w;
+			uint32_t part = sub == 3 ? occsel : cnt;
+			part += __shfl_xor(part, 1);
+			part += __shfl_xor(part, 2);
+			if(c[u] == 0 && g.nZ) {
+				uint32_t zs = g.zoff / 192u, zc = g.zoff - zs * 192u;
+				if(zs == sideNum[u] && zc < charOff[u]) part--;
+			}
+			if(sub == 0 && base + u < n) out[base + u] = part + (c[u] == 0 ? g.fchr[0] : c[u] == 1 ? g.fchr[1] : c[u] == 2 ? g.fchr[2] : g.fchr[3]);
+		}
+	}
+}
+
+// variant 2: eight lanes per side, one u64 per lane
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_rank_v2(DGfm g, const uint32_t* rows, const uint8_t* cs, uint32_t* out,
+                                                 size_t n, uint64_t seed, int synth)
+{
+	const unsigned lane = threadIdx.x & 63, sub = lane & 7;
+	const size_t ngroups = ((size_t)gridDim.x * blockDim.x) >> 3;
+	const size_t gid = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3;
+	for(size_t base = gid * UNROLL; base < n; base += ngroups * UNROLL) {
+		uint32_t row[UNROLL], sideNum[UNROLL], charOff[UNROLL]; int c[UNROLL]; uint64_t w[UNROLL];
+#pragma unroll
+		for(int u = 0; u < UNROLL; u++) {
+			size_t i = base + u;
+			bool ok = i < n;
+			if(synth) { uint64_t h = splitmix64(seed + (ok ? i : 0)); row[u] = (uint32_t)(h % g.gbwtLen); c[u] = (int)((h >> 40) & 3); }
+			else { row[u] = ok ? rows[i] : 0; c[u] = ok ? cs[i] : 0; }
+			sideNum[u] = row[u] / 192u; charOff[u] = row[u] - sideNum[u] * 192u;
+			w[u] = reinterpret_cast<const uint64_t*>(g.sides + (size_t)sideNum[u] * 64)[sub];
+		}
+#pragma unroll
+		for(int u = 0; u < UNROLL; u++) {
+			uint32_t cnt = sub < 6 ? count_word(w[u], c[u], (int)charOff[u] - 32 * (int)sub) : 0u;
+			uint32_t occ = (sub == 6 + (unsigned)(c[u] >> 1)) ? (uint32_t)(w[u] >> ((c[u] & 1) * 32)) : 0u;
+			uint32_t part = cnt + occ;
+			part += __shfl_xor(part, 1);
+			part += __shfl_xor(part, 2);
+			part += __shfl_xor(part, 4);
+			if(c[u] == 0 && g.nZ) {
+				uint32_t zs = g.zoff / 192u, zc = g.zoff - zs * 192u;
+				if(zs == sideNum[u] && zc < charOff[u]) part--;
+			}
+			if(sub == 0 && base + u < n) out[base + u] = part + (c[u] == 0 ? g.fchr[0] : c[u] == 1 ? g.fchr[1] : c[u] == 2 ? g.fchr[2] : g.fchr[3]);
+		}
+	}
+}
+
+__global__ void k_checksum(const uint32_t* v, size_t n, unsigned long long* out) {
+	unsigned long long acc = 0;
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride)
+		acc += (unsigned long long)v[i] * (unsigned long long)((i & 1023) + 1);
+	for(int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+	if((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+static int launch_rank(h2g_stream* s, const uint32_t* d_rows, const uint8_t* d_cs, uint32_t* d_out, size_t n,
+                       uint64_t seed, int synth, int variant, int repeats, float* ms)
+{
+	const DGfm& g = s->ix->dg;
+	if(!g.linear || g.lineRate != 6) { snprintf(g_err, sizeof g_err, "rank kernels: linear 64 B sides only"); return H2G_ERR_UNSUPPORTED; }
+	if(repeats < 1) repeats = 1;
+	HIPCHK(hipEventRecord(s->ev[0], s->st));
+	for(int r = 0; r < repeats; r++) {
+		if(variant == 0) {
+			hipLaunchKernelGGL(k_rank_v0, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
+		} else if(variant == 1) {
+			hipLaunchKernelGGL(k_rank_v1<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
+		} else if(variant == 2) {
+			hipLaunchKernelGGL(k_rank_v2<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
+		} else return H2G_ERR_ARG;
+	}
+	HIPCHK(hipEventRecord(s->ev[1], s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(hipGetLastError());
+	float t = 0;
+	HIPCHK(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+	s->last.ms_rank = t / repeats;
+	if(ms) *ms = t / repeats;
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_rank_bench(h2g_stream* s, const uint32_t* rows, const uint8_t* cs, size_t n, uint32_t* out,
+                                     int variant, int device_ptrs, int repeats, float* kernel_ms)
+{
+	if(!s || !rows || !cs || !out || n == 0) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	if(device_ptrs) return launch_rank(s, rows, cs, out, n, 0, 0, variant, repeats, kernel_ms);
+	void *dr, *dc, *dout;
+	int rc;
+	if((rc = tmp_buf(s, 0, n * 4, &dr)) || (rc = tmp_buf(s, 1, n, &dc)) || (rc = tmp_buf(s, 2, n * 4, &dout))) return rc;
+	HIPCHK(hipMemcpyAsync(dr, rows, n * 4, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(dc, cs, n, hipMemcpyHostToDevice, s->st));
+	rc = launch_rank(s, (const uint32_t*)dr, (const uint8_t*)dc, (uint32_t*)dout, n, 0, 0, variant, repeats, kernel_ms);
+	if(rc) return rc;
+	HIPCHK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_rank_bench_synth(h2g_stream* s, size_t n, uint64_t seed, int variant, int repeats,
+                                           float* kernel_ms, uint64_t* checksum)
+{
+	if(!s || n == 0) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	void* dout;
+	int rc;
+	if((rc = tmp_buf(s, 2, n * 4, &dout))) return rc;
+	rc = launch_rank(s, nullptr, nullptr, (uint32_t*)dout, n, seed, 1, variant, repeats, kernel_ms);
+	if(rc) return rc;
+	if(checksum) {
+		HIPCHK(hipMemsetAsync(s->d_counters + 7, 0, 8, s->st));
+		hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, s->st, (const uint32_t*)dout, n, s->d_counters + 7);
+		unsigned long long v = 0;
+		HIPCHK(hipMemcpyAsync(&v, s->d_counters + 7, 8, hipMemcpyDeviceToHost, s->st));
+		HIPCHK(hipStreamSynchronize(s->st));
+		*checksum = v;
+	}
+	return H2G_OK;
+}
+
+// ------------------------------------------------------------------------------------------ primitive kernels
+__global__ __launch_bounds__(256) void k_fm_search(DGfm g, DReads rd, const h2g_fm_query* q, size_t n, uint32_t khits,
+                                                   h2g_fm_hit* out)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		h2g_fm_query qq = q[i];
+		SeqView sv = seq_view(rd, qq.read, qq.fw != 0);
+		partial_search_item(g, sv, qq.offset, qq.pseudogeneStop != 0, qq.anchorStop != 0, khits, &out[i]);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sa_resolve(DGfm g, const h2g_sa_query* q, size_t n, uint32_t cap, h2g_coord* coords,
+                                                    h2g_sa_result* res)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		h2g_sa_query qq = q[i];
+		genome_coords_item(g, qq.top, qq.bot, qq.maxelt, qq.len, qq.rejectStraddle != 0, coords + i * cap, cap, &res[i]);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_extend(DRef ref, DReads rd, DScoring sc, h2g_ghit* hits, const h2g_ext_args* args,
+                                                size_t n, h2g_ext_result* res)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		h2g_ghit* h = &hits[i];
+		SeqView sv = seq_view(rd, h->read, h->fw != 0);
+		uint32_t le = 0, re = 0;
+		bool ext = extend_item(ref, sc, sv, h, args[i].mm, args[i].max_leftext, args[i].max_rightext, &le, &re);
+		res[i].extended = ext; res[i].leftext = le; res[i].rightext = re;
+	}
+}
+
+static int need_reads(h2g_stream* s) {
+	if(s->n_reads == 0) { snprintf(g_err, sizeof g_err, "no read batch set (h2g_set_reads)"); return H2G_ERR_ARG; }
+	return H2G_OK;
+}
+static int need_linear(h2g_stream* s) {
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	if(!s->ix->dg.linear || s->ix->dg.lineRate != 6) { snprintf(g_err, sizeof g_err, "graph (GFM) indexes: not built yet"); return H2G_ERR_UNSUPPORTED; }
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_fm_search(h2g_stream* s, const h2g_fm_query* q, size_t n, uint32_t khits, h2g_fm_hit* out) {
+	if(!s || !q || !out || n == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	for(size_t i = 0; i < n; i++) {
+		if(q[i].read >= s->n_reads) return H2G_ERR_ARG;
+		if(q[i].mode != H2G_FM_PARTIAL) { snprintf(g_err, sizeof g_err, "fm_search: only H2G_FM_PARTIAL built"); return H2G_ERR_UNSUPPORTED; }
+	}
+	HIPCHK(hipSetDevice(s->ix->device));
+	void *dq, *dout;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * sizeof *out, &dout))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	hipLaunchKernelGGL(k_fm_search, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), (const h2g_fm_query*)dq, n, khits, (h2g_fm_hit*)dout);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_sa_resolve(h2g_stream* s, const h2g_sa_query* q, size_t n, uint32_t cap, h2g_coord* coords,
+                                     h2g_sa_result* res)
+{
+	if(!s || !q || !coords || !res || n == 0 || cap == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_linear(s))) return rc;
+	const uint32_t glen = s->ix->dg.gbwtLen;
+	for(size_t i = 0; i < n; i++) if(q[i].top >= q[i].bot || q[i].bot > glen) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	void *dq, *dco, *dres;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * cap * sizeof *coords, &dco)) ||
+	   (rc = tmp_buf(s, 2, n * sizeof *res, &dres))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemsetAsync(dco, 0xff, n * cap * sizeof *coords, s->st));
+	hipLaunchKernelGGL(k_sa_resolve, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, (const h2g_sa_query*)dq, n, cap, (h2g_coord*)dco, (h2g_sa_result*)dres);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(coords, dco, n * cap * sizeof *coords, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_extend(h2g_stream* s, h2g_ghit* hits, const h2g_ext_args* args, size_t n, h2g_ext_result* res) {
+	if(!s || !hits || !args || !res || n == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	for(size_t i = 0; i < n; i++) {
+		if(hits[i].read >= s->n_reads || hits[i].tidx >= s->ix->dr.nrefs || hits[i].nedits > H2G_MAX_EDITS) return H2G_ERR_ARG;
+	}
+	HIPCHK(hipSetDevice(s->ix->device));
+	void *dh, *da, *dres;
+	if((rc = tmp_buf(s, 0, n * sizeof *hits, &dh)) || (rc = tmp_buf(s, 1, n * sizeof *args, &da)) ||
+	   (rc = tmp_buf(s, 2, n * sizeof *res, &dres))) return rc;
+	HIPCHK(hipMemcpyAsync(dh, hits, n * sizeof *hits, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(da, args, n * sizeof *args, hipMemcpyHostToDevice, s->st));
+	DScoring sc;
+	hipLaunchKernelGGL(k_extend, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dr, dreads(s), sc, (h2g_ghit*)dh, (const h2g_ext_args*)da, n, (h2g_ext_result*)dres);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(hits, dh, n * sizeof *hits, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+// ------------------------------------------------------------------------------------------ fused seed stage
+__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
+	for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	if((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+// K1: every (read, strand) runs partialSearch from offset 0 (one lane per item)
+__global__ __launch_bounds__(256) void k_seed_search(DGfm g, DReads rd, h2g_seed_params p, h2g_seed_result* out,
+                                                     unsigned long long* counters)
+{
+	const size_t n = (size_t)rd.n * 2;
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	unsigned long long nrank = 0, nside = 0;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		SeqView sv = seq_view(rd, (uint32_t)(i >> 1), (i & 1) == 0);
+		h2g_fm_hit h;
+		partial_search_item(g, sv, 0, p.pseudogeneStop != 0, p.anchorStop != 0, p.khits, &h);
+		out[i].hit = h;
+		nrank += h.nrank; nside += h.nside;
+	}
+	wave_add(counters + 0, nrank);
+	wave_add(counters + 1, nside);
+}
+
+// K2: coordinates + 0-mismatch extension for every partial hit
+__global__ __launch_bounds__(256) void k_seed_resolve_extend(DGfm g, DRef ref, DReads rd, DScoring sc, h2g_seed_result* out,
+                                                             unsigned long long* counters)
+{
+	const size_t n = (size_t)rd.n * 2;
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	unsigned long long nsteps = 0, next = 0;
+	h2g_ghit scratch;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		SeqView sv = seq_view(rd, (uint32_t)(i >> 1), (i & 1) == 0);
+		resolve_extend_item(g, ref, sc, sv, &out[i], &scratch);
+		nsteps += out[i].nsteps; next += out[i].ncoords;
+	}
+	wave_add(counters + 2, nsteps);
+	wave_add(counters + 3, next);
+}
+
+extern "C" void h2g_seed_params_init(h2g_seed_params* p, const h2g_index* ix, int no_spliced) {
+	// nextBWT hi_aligner.h:4669-4670: pseudogeneStop = linearFM && !no_spliced_alignment; anchorStop = !repeat index
+	p->pseudogeneStop = (ix && ix->dg.linear && !no_spliced) ? 1 : 0;
+	p->anchorStop = 1;
+	p->khits = (ix && !ix->dg.linear) ? 10 : 5;   // -k default hisat2.cpp:3903-3906
+	p->search_variant = 0;
+}
+
+extern "C" h2g_status h2g_seed_extend_run(h2g_stream* s, const h2g_seed_params* p) {
+	if(!s || !p) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	HIPCHK(hipSetDevice(s->ix->device));
+	const size_t n = s->n_reads * 2;
+	HIPCHK(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), s->st));
+	DScoring sc;
+	HIPCHK(hipEventRecord(s->ev[2], s->st));
+	hipLaunchKernelGGL(k_seed_search, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), *p, s->d_seed, s->d_counters);
+	HIPCHK(hipEventRecord(s->ev[3], s->st));
+	hipLaunchKernelGGL(k_seed_resolve_extend, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dr, dreads(s), sc, s->d_seed, s->d_counters);
+	HIPCHK(hipEventRecord(s->ev[4], s->st));
+	HIPCHK(hipGetLastError());
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_seed_extend_fetch(h2g_stream* s, h2g_seed_result* out, size_t first_read, size_t n_reads) {
+	if(!s || !out || first_read + n_reads > s->n_reads) return H2G_ERR_ARG;
+	HIPCHK(hipMemcpyAsync(out, s->d_seed + first_read * 2, n_reads * 2 * sizeof *out, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
+	if(!s || !c) return H2G_ERR_ARG;
+	HIPCHK(hipStreamSynchronize(s->st));
+	unsigned long long v[4] = {0, 0, 0, 0};
+	HIPCHK(hipMemcpy(v, s->d_counters, sizeof v, hipMemcpyDeviceToHost));
+	s->last.n_rank = v[0]; s->last.n_side = v[1]; s->last.n_sa_steps = v[2]; s->last.n_ext = v[3];
+	s->last.n_queries = s->n_reads * 2;
+	float t = 0;
+	if(hipEventElapsedTime(&t, s->ev[2], s->ev[3]) == hipSuccess) s->last.ms_search = t;
+	if(hipEventElapsedTime(&t, s->ev[3], s->ev[4]) == hipSuccess) s->last.ms_resolve_extend = t;
+	*c = s->last;
+	return H2G_OK;
+}

@@ -1,0 +1,168 @@
+/*
+ * h2g.h — C ABI of the MI355X-native HISAT2 seed-and-extend hot path (libh2g.so).
+ *
+ * The reference (HISAT2 2.2.3) has no FFI for this path: the hot path is header-template
+ * code called from the per-thread worker loop (hisat2.cpp:3276-3644 -> HI_Aligner::go,
+ * hi_aligner.h:4048).  This header is the boundary a maintainer binds instead; each entry
+ * point names the reference function whose semantics it reproduces bit-exactly.  Conventions
+ * follow the reference's only C ABI, hisat2lib/ht2.h:30-150: opaque handles, `int` status
+ * (0 = OK, <0 = error), option structs initialised by a function, no exceptions across the
+ * boundary, caller-owned buffers with explicit capacities.
+ *
+ * Plain pointers and sizes only; no torch / C++ types.  All kernels are hand-written HIP for
+ * gfx950; there is NO CPU fallback — every entry point returns H2G_ERR_DEVICE without a GPU.
+ */
+#ifndef H2G_H_
+#define H2G_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2G_EXPORT __attribute__((visibility("default")))   /* cf. hisat2lib/ht2_handle.h:23-27 */
+
+typedef struct h2g_index  h2g_index;    /* immutable device-resident .ht2 index; shareable across streams      */
+typedef struct h2g_stream h2g_stream;   /* per-host-thread batch context: device scratch + one hipStream_t     */
+typedef int h2g_status;
+
+enum {
+	H2G_OK = 0,
+	H2G_ERR_IO = -1,          /* index file missing / short read                                        */
+	H2G_ERR_FORMAT = -2,      /* not a little-endian .ht2 (32-bit offsets) index                         */
+	H2G_ERR_DEVICE = -3,      /* no usable HIP device / HIP runtime error (see h2g_last_error)           */
+	H2G_ERR_ARG = -4,         /* bad argument / capacity exceeded                                        */
+	H2G_ERR_UNSUPPORTED = -5, /* feature of the reference not built yet (e.g. graph index in a kernel)   */
+	H2G_ERR_NOMEM = -6
+};
+
+#define H2G_MAX 0xffffffffu     /* INDEX_MAX of the 32-bit (-s) binaries, btypes.h:24-46 */
+
+/* ---- index ------------------------------------------------------------------------------------------ */
+typedef struct {
+	int32_t device;            /* HIP device ordinal */
+	int32_t load_local;        /* also upload the local (.5/.6) indexes */
+} h2g_load_opts;
+
+/* GFMParams gfm.h:115-199 + hi_aligner.h:3979 (_minK) */
+typedef struct {
+	uint32_t len, gbwtLen, numNodes;
+	int32_t  lineRate, offRate, ftabChars;
+	uint32_t eftabLen, linear;
+	uint32_t sideSz, sideGbwtSz, sideGbwtLen, numSides, offsLen, ftabLen;
+	uint32_t nPat, nFrag, nZ, minK, nLocal, nRefRecs;
+	uint64_t device_bytes;     /* bytes resident in HBM */
+} h2g_index_info;
+
+H2G_EXPORT void       h2g_load_opts_init(h2g_load_opts*);
+/* Parses <base>.1-.6.ht2 exactly like GFM::readIntoMemory (gfm.h:5823-6453), HGFM::readIntoMemory
+ * (hgfm.h:2453-2651) and BitPairReference (reference.cpp:30-380) and uploads them to HBM. */
+H2G_EXPORT h2g_status h2g_index_load(const char* ht2_base, const h2g_load_opts*, h2g_index** out);
+H2G_EXPORT h2g_status h2g_index_get_info(const h2g_index*, h2g_index_info* out);
+/* Roofline helper: a device-only index whose sides hold `num_sides` random linear sides with
+ * consistent Occ checkpoints (GRCh38 scale = 15.3 M sides ~ 0.98 GB); only rank queries are valid. */
+H2G_EXPORT h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out);
+H2G_EXPORT void       h2g_index_free(h2g_index*);
+H2G_EXPORT const char* h2g_last_error(void);
+
+/* ---- stream / reads ---------------------------------------------------------------------------------- */
+H2G_EXPORT h2g_status h2g_stream_create(h2g_index*, size_t max_reads, size_t max_bases, h2g_stream** out);
+H2G_EXPORT void       h2g_stream_free(h2g_stream*);
+H2G_EXPORT void*      h2g_stream_hip(h2g_stream*);   /* the hipStream_t every kernel of this context runs on */
+H2G_EXPORT h2g_status h2g_stream_sync(h2g_stream*);
+
+/* Reads as the worker loop holds them after parsing (read.h:325, Read::patFw): one byte per base,
+ * codes A,C,G,T,N = 0..4; read i = codes[offs[i] .. offs[i+1]).  quals = ASCII (phred+33) or NULL for
+ * FASTA input (all 'I', pat.cpp).  Copied to HBM; the reverse complement (patRc) is derived on device. */
+H2G_EXPORT h2g_status h2g_set_reads(h2g_stream*, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                    size_t n_reads);
+
+/* ---- primitives (batched; semantics == the reference function named) ---------------------------------- */
+
+/* GFM::mapLF(SideLocus(row), c) -> countBt2Side (gfm.h:3712, :2958): the Occ-rank micro-kernel.
+ * variant: 0 = one lane per side, 1 = 4 lanes per side (16 B each + DPP reduce), 2 = 8 lanes per side.
+ * rows/cs/out are HOST arrays unless device_ptrs != 0.  *kernel_ms = HIP-event time of the kernel. */
+H2G_EXPORT h2g_status h2g_rank_bench(h2g_stream*, const uint32_t* rows, const uint8_t* cs, size_t n, uint32_t* out,
+                                     int variant, int device_ptrs, int repeats, float* kernel_ms);
+/* generates the SURVEY §8(d) query set on device: row ~ U[0,gbwtLen) from splitmix64(seed), c = hash&3 */
+H2G_EXPORT h2g_status h2g_rank_bench_synth(h2g_stream*, size_t n, uint64_t seed, int variant, int repeats,
+                                           float* kernel_ms, uint64_t* checksum);
+
+enum { H2G_FM_PARTIAL = 0, H2G_FM_GLOBAL = 1, H2G_FM_LOCAL = 2 };
+enum { H2G_CANDIDATE_HIT = 1, H2G_PSEUDOGENE_HIT = 2, H2G_ANCHOR_HIT = 3 };   /* hi_aligner.h:96-100 */
+
+typedef struct {
+	uint32_t read;             /* index into the batch set by h2g_set_reads */
+	uint32_t offset;           /* ReadBWTHit::_cur: bases already consumed from the 3' end */
+	uint8_t  fw;               /* 1: patFw, 0: patRc */
+	uint8_t  mode;             /* H2G_FM_* */
+	uint8_t  pseudogeneStop;   /* hi_aligner.h:4669 */
+	uint8_t  anchorStop;       /* hi_aligner.h:4670 */
+} h2g_fm_query;
+
+/* the BWTHit appended by partialSearch (hi_aligner.h:6361-6600) + the ReadBWTHit counters it updates */
+typedef struct {
+	uint32_t top, bot, node_top, node_bot, bwoff, len, hit_type;
+	uint32_t cur, done, numPartialSearch, numUniqueSearch, pseudogeneStop, anchorStop;
+	uint32_t nrank;            /* rank calls (HI_Aligner::bwops_) */
+	uint32_t nside;            /* unique sides visited = algorithmic bytes / sideSz */
+} h2g_fm_hit;
+
+H2G_EXPORT h2g_status h2g_fm_search(h2g_stream*, const h2g_fm_query* q, size_t n, uint32_t khits, h2g_fm_hit* out);
+
+/* HI_Aligner::getGenomeCoords (hi_aligner.h:5774-5855): GroupWalk2S::advanceElement + GFM::joinedToTextOff */
+typedef struct { uint32_t top, bot, maxelt, len; uint32_t rejectStraddle; } h2g_sa_query;
+typedef struct { uint32_t tidx, toff, joinedOff; } h2g_coord;          /* tidx == H2G_MAX: straddles */
+typedef struct { uint32_t ok, ncoords, straddled, nsteps; } h2g_sa_result;
+H2G_EXPORT h2g_status h2g_sa_resolve(h2g_stream*, const h2g_sa_query* q, size_t n, uint32_t cap_per_query,
+                                     h2g_coord* coords /* [n*cap] */, h2g_sa_result* res /* [n] */);
+
+/* GenomeHit::extend (hi_aligner.h:2031-2232) incl. alignWithALTs (:683) and calculateScore (:3711) */
+#define H2G_MAX_EDITS 48
+enum { H2G_EDIT_READ_GAP = 1, H2G_EDIT_REF_GAP = 2, H2G_EDIT_MM = 3 };  /* edit.h:37-39 */
+typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; } h2g_edit;   /* Edit, edit.h */
+typedef struct {
+	uint32_t read;
+	uint32_t fw, rdoff, len, trim5, trim3, tidx, toff, joinedOff;
+	int64_t  score;
+	uint32_t nedits;
+	uint32_t overflow;         /* edit list exceeded H2G_MAX_EDITS: caller must take its own path */
+	h2g_edit edits[H2G_MAX_EDITS];
+} h2g_ghit;
+typedef struct { uint32_t mm, max_leftext, max_rightext; } h2g_ext_args;
+typedef struct { uint32_t extended, leftext, rightext; } h2g_ext_result;
+H2G_EXPORT h2g_status h2g_extend(h2g_stream*, h2g_ghit* hits /* in/out */, const h2g_ext_args* args, size_t n,
+                                 h2g_ext_result* res);
+
+/* ---- fused seed-and-extend stage over the resident read batch ------------------------------------------ */
+/* For every read and both strands: partialSearch from offset 0 (nextBWT hi_aligner.h:4644-4760) ->
+ * getAnchorHits coordinate resolution (:5007, ranges up to H2G_SEED_CAP rows) -> 0-mismatch extend
+ * (hybridSearch spliced_aligner.h:139-163).  Results stay in HBM until h2g_seed_extend_fetch. */
+#define H2G_SEED_CAP 5
+typedef struct {
+	h2g_fm_hit hit;
+	uint32_t   ncoords, straddled, nsteps, pad;
+	struct { uint32_t tidx, toff, joinedOff, rdoff, len; int32_t score; } ext[H2G_SEED_CAP];
+} h2g_seed_result;                         /* one per (read, strand): index 2*read + (fw ? 0 : 1) */
+
+typedef struct {
+	uint32_t pseudogeneStop, anchorStop, khits;
+	uint32_t search_variant;   /* 0 = lane-per-query search kernel, 1 = cooperative 8-lane kernel */
+} h2g_seed_params;
+
+H2G_EXPORT void       h2g_seed_params_init(h2g_seed_params*, const h2g_index*, int no_spliced_alignment);
+H2G_EXPORT h2g_status h2g_seed_extend_run(h2g_stream*, const h2g_seed_params*);     /* async on the stream */
+H2G_EXPORT h2g_status h2g_seed_extend_fetch(h2g_stream*, h2g_seed_result* out, size_t first_read, size_t n_reads);
+
+/* ---- counters (roofline numerators) ------------------------------------------------- */
+typedef struct {
+	uint64_t n_rank, n_side, n_sa_steps, n_ext, n_ref_bytes, n_queries;
+	float    ms_search, ms_resolve_extend, ms_rank;   /* HIP-event durations of the last launches */
+} h2g_counters;
+H2G_EXPORT h2g_status h2g_get_counters(h2g_stream*, h2g_counters*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2G_H_ */

@@ -1,0 +1,99 @@
+// h2g_emul.cpp — TEST-ONLY host instantiation of the per-item device functions (hisat2_amd/csrc/h2g_core.h).
+//
+// The build container has no GPU, so the `__host__ __device__` item functions that the HIP kernels wrap are
+// also compiled here with g++ and driven item-by-item, to check the kernel logic against the golden vectors in
+// `-m "not gpu"` runs.  This library lives under tests/, is never shipped with or loaded by hisat2_amd, and
+// is not a fallback: libh2g.so has no host execution path.
+#include <vector>
+#include "../../hisat2_amd/csrc/h2g_core.h"
+#include "../../hisat2_amd/csrc/h2g_host_index.h"
+
+using namespace h2g;
+
+struct Emu {
+	HostIndex host;
+	DGfm dg;
+	DRef dr;
+	std::vector<uint8_t> codes;
+	std::vector<uint32_t> offs;
+	std::vector<char> quals;
+	bool has_quals = false;
+	DReads reads() const {
+		DReads r;
+		r.codes = codes.data(); r.offs = offs.data(); r.quals = has_quals ? quals.data() : nullptr;
+		r.n = (uint32_t)offs.size() - 1;
+		return r;
+	}
+};
+
+extern "C" {
+
+int h2gemu_load(const char* base, Emu** out) {
+	Emu* e = new Emu();
+	int rc = load_host_index(base, true, e->host);
+	if(rc) { delete e; return rc; }
+	const HostGfm& g = e->host.g;
+	DGfm& d = e->dg;
+	d.sides = g.sides.data(); d.ftab = g.ftab.data(); d.eftab = g.eftab.data(); d.offs = g.offs.data();
+	d.rstarts = g.rstarts.data(); d.plen = g.plen.data();
+	for(int i = 0; i < 5; i++) d.fchr[i] = g.fchr[i];
+	d.len = g.p.len; d.gbwtLen = g.p.gbwtLen; d.ftabLim = g.p.linear ? g.p.len : g.p.gbwtLen;
+	d.sideGbwtLen = g.p.sideGbwtLen; d.sideGbwtSz = g.p.sideGbwtSz; d.lineRate = g.p.lineRate; d.offRate = g.p.offRate;
+	d.offMask = g.p.offMask; d.ftabChars = g.p.ftabChars; d.nFrag = g.nFrag; d.nPat = g.nPat;
+	d.nZ = (uint32_t)g.zOffs.size(); d.zoff = g.zOffs.empty() ? H2G_MAX : g.zOffs[0]; d.minK = e->host.minK;
+	d.linear = g.p.linear;
+	const HostRef& r = e->host.r;
+	e->dr.buf = r.buf.data(); e->dr.rec_start = r.rec_start.data(); e->dr.rec_len = r.rec_len.data();
+	e->dr.rec_bufoff = r.rec_bufoff.data(); e->dr.refRecOffs = r.refRecOffs.data(); e->dr.refLens = r.refLens.data();
+	e->dr.nrefs = r.nrefs;
+	*out = e;
+	return 0;
+}
+
+void h2gemu_set_reads(Emu* e, const uint8_t* codes, const uint32_t* offs, const char* quals, size_t n) {
+	e->codes.assign(codes, codes + offs[n]);
+	e->offs.assign(offs, offs + n + 1);
+	e->has_quals = quals != nullptr;
+	if(quals) e->quals.assign(quals, quals + offs[n]);
+}
+
+void h2gemu_rank(Emu* e, const uint32_t* rows, const uint8_t* cs, size_t n, uint32_t* out) {
+	for(size_t i = 0; i < n; i++) out[i] = rank64(e->dg, rows[i], cs[i]);
+}
+
+void h2gemu_fm_search(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, h2g_fm_hit* out) {
+	DReads rd = e->reads();
+	for(size_t i = 0; i < n; i++) {
+		SeqView sv = seq_view(rd, q[i].read, q[i].fw != 0);
+		partial_search_item(e->dg, sv, q[i].offset, q[i].pseudogeneStop != 0, q[i].anchorStop != 0, khits, &out[i]);
+	}
+}
+
+void h2gemu_sa_resolve(Emu* e, const h2g_sa_query* q, size_t n, uint32_t cap, h2g_coord* coords, h2g_sa_result* res) {
+	for(size_t i = 0; i < n; i++)
+		genome_coords_item(e->dg, q[i].top, q[i].bot, q[i].maxelt, q[i].len, q[i].rejectStraddle != 0, coords + i * cap, cap, &res[i]);
+}
+
+void h2gemu_extend(Emu* e, h2g_ghit* hits, const h2g_ext_args* args, size_t n, h2g_ext_result* res) {
+	DReads rd = e->reads();
+	DScoring sc;
+	for(size_t i = 0; i < n; i++) {
+		SeqView sv = seq_view(rd, hits[i].read, hits[i].fw != 0);
+		uint32_t le = 0, re = 0;
+		bool ext = extend_item(e->dr, sc, sv, &hits[i], args[i].mm, args[i].max_leftext, args[i].max_rightext, &le, &re);
+		res[i].extended = ext; res[i].leftext = le; res[i].rightext = re;
+	}
+}
+
+void h2gemu_seed_extend(Emu* e, uint32_t pseudogeneStop, uint32_t khits, h2g_seed_result* out) {
+	DReads rd = e->reads();
+	DScoring sc;
+	h2g_ghit scratch;
+	for(size_t i = 0; i < (size_t)rd.n * 2; i++) {
+		SeqView sv = seq_view(rd, (uint32_t)(i >> 1), (i & 1) == 0);
+		partial_search_item(e->dg, sv, 0, pseudogeneStop != 0, true, khits, &out[i].hit);
+		resolve_extend_item(e->dg, e->dr, sc, sv, &out[i], &scratch);
+	}
+}
+
+}

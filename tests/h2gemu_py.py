@@ -1,0 +1,70 @@
+"""ctypes binding of tests/emul/libh2gemu.so — host instantiation of the device item functions (tests only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hisat2_amd import api
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Emu:
+    def __init__(self, base):
+        subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emul")], check=True)
+        self.L = C.CDLL(os.path.join(HERE, "emul", "libh2gemu.so"))
+        vp = C.c_void_p
+        self.L.h2gemu_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        self.L.h2gemu_set_reads.argtypes = [vp, vp, vp, vp, C.c_size_t]
+        self.L.h2gemu_rank.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        self.L.h2gemu_fm_search.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
+        self.L.h2gemu_sa_resolve.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
+        self.L.h2gemu_extend.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        self.L.h2gemu_seed_extend.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+        self.h = vp()
+        rc = self.L.h2gemu_load(base.encode(), C.byref(self.h))
+        assert rc == 0, rc
+        self.n_reads = 0
+
+    def set_reads(self, codes, offs, quals=None):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint32)
+        self._keep = (codes, offs)
+        self.n_reads = len(offs) - 1
+        self.L.h2gemu_set_reads(self.h, codes.ctypes.data, offs.ctypes.data, None, self.n_reads)
+
+    def rank(self, rows, cs):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        cs = np.ascontiguousarray(cs, dtype=np.uint8)
+        out = np.empty(len(rows), dtype=np.uint32)
+        self.L.h2gemu_rank(self.h, rows.ctypes.data, cs.ctypes.data, len(rows), out.ctypes.data)
+        return out
+
+    def fm_search(self, queries, khits=5):
+        n = len(queries)
+        q = (api.FmQuery * n)(*queries)
+        out = (api.FmHit * n)()
+        self.L.h2gemu_fm_search(self.h, q, n, khits, out)
+        return out
+
+    def sa_resolve(self, queries, cap=16):
+        n = len(queries)
+        q = (api.SaQuery * n)(*queries)
+        co = (api.Coord * (n * cap))()
+        res = (api.SaResult * n)()
+        self.L.h2gemu_sa_resolve(self.h, q, n, cap, co, res)
+        return co, res
+
+    def extend(self, hits, args):
+        n = len(hits)
+        h = (api.GHit * n)(*hits)
+        a = (api.ExtArgs * n)(*args)
+        res = (api.ExtResult * n)()
+        self.L.h2gemu_extend(self.h, h, a, n, res)
+        return h, res
+
+    def seed_extend(self, pseudogeneStop=0, khits=5):
+        out = np.zeros(self.n_reads * 2, dtype=api.SEED_RESULT_DTYPE)
+        self.L.h2gemu_seed_extend(self.h, pseudogeneStop, khits, out.ctypes.data)
+        return out

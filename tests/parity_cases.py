@@ -1,0 +1,138 @@
+"""Shared parity checks: run a backend exposing the h2g primitive API (the HIP library on a GPU, or the host
+instantiation of the same device functions on CPU) against the golden vectors of the real reference and
+against the C oracle.  Used by test_emul_golden.py (CPU) and test_gpu_parity.py (GPU)."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+import h2o_py as H
+from hisat2_amd import api
+
+
+def load_reads(golden_dir):
+    names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
+    L = len(seqs[0])
+    arr = np.stack(seqs)
+    offs = (np.arange(len(seqs) + 1, dtype=np.uint64) * L).astype(np.uint32)
+    return arr, offs
+
+
+def load_contigs(golden_dir, name="g1.fa.gz"):
+    contigs, cur = [], []
+    with gzip.open(os.path.join(golden_dir, name), "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if cur:
+                    contigs.append(H.encode(b"".join(cur)))
+                cur = []
+            else:
+                cur.append(line.strip())
+    contigs.append(H.encode(b"".join(cur)))
+    return contigs
+
+
+def check_rank(backend_rank, golden_dir):
+    rows, cs, want = [], [], []
+    for l in H.glines(golden_dir, "probe_rank.txt.gz"):
+        row, c, r, _ = map(int, l.split())
+        rows.append(row); cs.append(c); want.append(r)
+    got = backend_rank(np.array(rows, dtype=np.uint32), np.array(cs, dtype=np.uint8))
+    assert np.array_equal(got, np.array(want, dtype=np.uint32))
+
+
+def check_fm_search(be, golden_dir, fn, pseudo):
+    qs, want = [], []
+    for l in H.glines(golden_dir, fn):
+        v = list(map(int, l.split()))
+        qs.append(api.FmQuery(v[0], 0, v[1], 0, pseudo, 1))
+        want.append(v[2:])
+    out = be.fm_search(qs, khits=5)
+    for o, w, q in zip(out, want, qs):
+        got = [getattr(o, f) for f in api.FM_HIT_FIELDS[:13]]
+        assert got == w, (q.read, q.fw, got, w)
+    return len(qs)
+
+
+def check_coords(be, golden_dir):
+    qs, want = [], []
+    for l in H.glines(golden_dir, "probe_coords.txt.gz"):
+        f = l.split()
+        top, bot, rdoff, hlen, strad, n = map(int, f[2:8])
+        qs.append(api.SaQuery(top, bot, bot - top, hlen, 0))
+        want.append((strad, [tuple(int(x) & 0xFFFFFFFF for x in f[8 + k].split(":")) for k in range(n)]))
+    cap = 16
+    co, res = be.sa_resolve(qs, cap=cap)
+    for i, (strad, cs) in enumerate(want):
+        assert res[i].ok == 1 and res[i].ncoords == len(cs) and res[i].straddled == strad
+        for k, c in enumerate(cs):
+            g = co[i * cap + k]
+            assert (g.tidx, g.toff, g.joinedOff) == c
+    return len(qs)
+
+
+def check_extend(be, golden_dir):
+    hits, args, want = [], [], []
+    for l in H.glines(golden_dir, "probe_extend.txt.gz"):
+        lhs, rhs = l.split(" -> ")
+        rid, fw, rdoff, hlen, tidx, toff, joff, mm = map(int, lhs.split())
+        h = api.GHit()
+        h.read, h.fw, h.rdoff, h.len, h.tidx, h.toff, h.joinedOff = rid, fw, rdoff, hlen, tidx, toff, joff
+        hits.append(h)
+        args.append(api.ExtArgs(mm, api.MAX, api.MAX))
+        want.append(rhs.split())
+    out, res = be.extend(hits, args)
+    for h, r, w in zip(out, res, want):
+        got = [r.extended, h.rdoff, h.len, h.toff, h.joinedOff, r.leftext, r.rightext, h.score, h.nedits]
+        assert got == list(map(int, w[:9])), (got, w)
+        eds = [f"{h.edits[k].pos}:{chr(h.edits[k].chr)}>{chr(h.edits[k].qchr)}" for k in range(h.nedits)]
+        assert eds == w[9:] and h.overflow == 0
+    return len(hits)
+
+
+def oracle_seed_extend(olib, oix, reads, pseudo, khits=5, cap=api.SEED_CAP):
+    """The fused stage (partialSearch both strands -> coords of the first `cap` rows -> 0-mm extend) computed
+    by the C oracle, as a SEED_RESULT_DTYPE array."""
+    n, L = reads.shape
+    out = np.zeros(n * 2, dtype=api.SEED_RESULT_DTYPE)
+    sc = H.Scoring()
+    olib.h2o_scoring_default(C.byref(sc))
+    minK = oix.contents.minK
+    qual = b"I" * L
+    for r in range(n):
+        for fwi in range(2):
+            seq = np.ascontiguousarray(reads[r] if fwi == 0 else H.revcomp(reads[r]))
+            o = H.BwtHit()
+            olib.h2o_partial_search(oix, seq.ctypes.data, L, 0, pseudo, 1, khits, C.byref(o))
+            rec = out[2 * r + fwi]
+            for f in api.FM_HIT_FIELDS:
+                rec["hit"][f] = getattr(o, f)
+            if o.top == H.MAX or o.bot <= o.top or o.len <= minK + 2:
+                continue
+            co = (H.Coord * 64)()
+            nco, st, steps = C.c_uint32(0), C.c_int(0), C.c_uint32(0)
+            olib.h2o_genome_coords(oix, o.top, o.bot, min(o.bot - o.top, cap), o.len, 0, co, C.byref(nco), C.byref(st),
+                                   C.byref(steps))
+            rec["ncoords"], rec["straddled"], rec["nsteps"] = nco.value, st.value, steps.value
+            for k in range(nco.value):
+                e = rec["ext"][k]
+                e["tidx"], e["toff"], e["joinedOff"] = co[k].tidx, co[k].toff, co[k].joinedOff
+                e["rdoff"], e["len"], e["score"] = L - o.bwoff - o.len, o.len, 0
+                if co[k].tidx == H.MAX:
+                    continue
+                h = H.GHit()
+                h.fw, h.rdoff, h.len, h.tidx, h.toff, h.joinedOff = 1 - fwi, L - o.bwoff - o.len, o.len, co[k].tidx, co[k].toff, co[k].joinedOff
+                le, re = C.c_uint32(H.MAX), C.c_uint32(H.MAX)
+                olib.h2o_extend(oix, C.byref(sc), seq.ctypes.data, qual, L, C.byref(h), C.byref(le), C.byref(re), 0)
+                e["toff"], e["joinedOff"], e["rdoff"], e["len"], e["score"] = h.toff, h.joinedOff, h.rdoff, h.len, h.score
+    return out
+
+
+def assert_seed_equal(got, want):
+    for f in ("ncoords", "straddled", "nsteps"):
+        assert np.array_equal(got[f], want[f]), f
+    for f in api.FM_HIT_FIELDS:
+        assert np.array_equal(got["hit"][f], want["hit"][f]), f
+    for f in ("tidx", "toff", "joinedOff", "rdoff", "len", "score"):
+        assert np.array_equal(got["ext"][f], want["ext"][f]), f

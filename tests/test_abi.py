@@ -1,0 +1,62 @@
+"""CPU tests of the boundary: libh2g.so loads, exports every symbol include/h2g.h declares, its structs have
+the layout the ctypes mirror assumes, and it refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from hisat2_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "h2g.h")
+
+
+def _declared():
+    txt = open(HDR).read()
+    return re.findall(r"H2G_EXPORT\s+[\w\s\*]+?\b(h2g_\w+)\s*\(", txt)
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 18
+    L = api.lib()
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(names) == sorted(api.EXPORTS)
+
+
+def test_struct_layouts_match_header(tmp_path):
+    structs = {"h2g_load_opts": api.LoadOpts, "h2g_index_info": api.IndexInfo, "h2g_fm_query": api.FmQuery,
+               "h2g_fm_hit": api.FmHit, "h2g_sa_query": api.SaQuery, "h2g_coord": api.Coord,
+               "h2g_sa_result": api.SaResult, "h2g_edit": api.Edit, "h2g_ghit": api.GHit, "h2g_ext_args": api.ExtArgs,
+               "h2g_ext_result": api.ExtResult, "h2g_seed_result": api.SeedResult, "h2g_seed_params": api.SeedParams,
+               "h2g_counters": api.Counters}
+    src = tmp_path / "sz.c"
+    body = "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in structs)
+    src.write_text(f'#include <stdio.h>\n#include "{HDR}"\nint main(void){{{body}return 0;}}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True)   # header is plain C
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        n, sz = line.split()
+        assert C.sizeof(structs[n]) == int(sz), n
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="GPU present")
+def test_no_cpu_fallback(g1_index):
+    """Without a HIP device every entry point fails loudly instead of computing on the host."""
+    with pytest.raises(api.H2GError) as e:
+        api.Index(g1_index)
+    assert "-3" in str(e.value)   # H2G_ERR_DEVICE
+    with pytest.raises(api.H2GError):
+        api.Index(synth_sides=1024)
