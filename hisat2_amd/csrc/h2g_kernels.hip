@@ -143,16 +143,33 @@ __global__ void k_synth_fill(uint8_t* sides, uint32_t* cnt, uint64_t nsides, uin
 	}
 	for(int cc = 0; cc < 4; cc++) cnt[s * 4 + cc] = c[cc];
 }
-// exclusive prefix over sides, one thread per symbol (sequential: run once at set-up)
-__global__ void k_synth_prefix(uint8_t* sides, const uint32_t* cnt, uint64_t nsides, uint32_t* totals) {
+// exclusive prefix over sides in three passes: per-chunk sums, scan of the chunk sums, write-back
+#define SYNTH_CHUNKS 16384
+__global__ void k_synth_chunk_sum(const uint32_t* cnt, uint64_t nsides, uint32_t* chunk) {
+	uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+	if(t >= SYNTH_CHUNKS) return;
+	uint64_t per = (nsides + SYNTH_CHUNKS - 1) / SYNTH_CHUNKS, a = t * per, b = a + per < nsides ? a + per : nsides;
+	uint32_t c[4] = {0, 0, 0, 0};
+	for(uint64_t s = a; s < b; s++) for(int k = 0; k < 4; k++) c[k] += cnt[s * 4 + k];
+	for(int k = 0; k < 4; k++) chunk[t * 4 + k] = c[k];
+}
+__global__ void k_synth_chunk_scan(uint32_t* chunk, uint32_t* totals) {
 	int c = threadIdx.x;
 	if(c >= 4) return;
 	uint32_t run = 0;
-	for(uint64_t s = 0; s < nsides; s++) {
-		reinterpret_cast<uint32_t*>(sides + s * 64 + 48)[c] = run;
-		run += cnt[s * 4 + c];
-	}
+	for(uint32_t t = 0; t < SYNTH_CHUNKS; t++) { uint32_t v = chunk[t * 4 + c]; chunk[t * 4 + c] = run; run += v; }
 	totals[c] = run;
+}
+__global__ void k_synth_write(uint8_t* sides, const uint32_t* cnt, uint64_t nsides, const uint32_t* chunk) {
+	uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+	if(t >= SYNTH_CHUNKS) return;
+	uint64_t per = (nsides + SYNTH_CHUNKS - 1) / SYNTH_CHUNKS, a = t * per, b = a + per < nsides ? a + per : nsides;
+	uint32_t run[4];
+	for(int k = 0; k < 4; k++) run[k] = chunk[t * 4 + k];
+	for(uint64_t s = a; s < b; s++) {
+		uint32_t* occ = reinterpret_cast<uint32_t*>(sides + s * 64 + 48);
+		for(int k = 0; k < 4; k++) { occ[k] = run[k]; run[k] += cnt[s * 4 + k]; }
+	}
 }
 
 extern "C" h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out) {
@@ -164,16 +181,25 @@ extern "C" h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, i
 	ix->synthetic = true;
 	ix->device = device;
 	void *sides = nullptr, *cnt = nullptr, *tot = nullptr;
-	HIPCHK(hipMalloc(&sides, num_sides * 64 + 256));
+	{   // measurement knob: H2G_SIDES_MTYPE=uncached|finegrained allocates the side array with that memory type
+		const char* mt = getenv("H2G_SIDES_MTYPE");
+		if(mt && !strcmp(mt, "uncached")) HIPCHK(hipExtMallocWithFlags(&sides, num_sides * 64 + 256, hipDeviceMallocUncached));
+		else if(mt && !strcmp(mt, "finegrained")) HIPCHK(hipExtMallocWithFlags(&sides, num_sides * 64 + 256, hipDeviceMallocFinegrained));
+		else HIPCHK(hipMalloc(&sides, num_sides * 64 + 256));
+	}
 	HIPCHK(hipMalloc(&cnt, num_sides * 16));
 	HIPCHK(hipMalloc(&tot, 16));
 	ix->allocs.push_back(sides);
 	ix->device_bytes = num_sides * 64;
 	hipLaunchKernelGGL(k_synth_fill, dim3((unsigned)((num_sides + 255) / 256)), dim3(256), 0, 0, (uint8_t*)sides, (uint32_t*)cnt, num_sides, seed);
-	hipLaunchKernelGGL(k_synth_prefix, dim3(1), dim3(64), 0, 0, (uint8_t*)sides, (const uint32_t*)cnt, num_sides, (uint32_t*)tot);
+	void* chunk = nullptr;
+	HIPCHK(hipMalloc(&chunk, SYNTH_CHUNKS * 16));
+	hipLaunchKernelGGL(k_synth_chunk_sum, dim3(SYNTH_CHUNKS / 256), dim3(256), 0, 0, (const uint32_t*)cnt, num_sides, (uint32_t*)chunk);
+	hipLaunchKernelGGL(k_synth_chunk_scan, dim3(1), dim3(64), 0, 0, (uint32_t*)chunk, (uint32_t*)tot);
+	hipLaunchKernelGGL(k_synth_write, dim3(SYNTH_CHUNKS / 256), dim3(256), 0, 0, (uint8_t*)sides, (const uint32_t*)cnt, num_sides, (const uint32_t*)chunk);
 	uint32_t totals[4];
 	HIPCHK(hipMemcpy(totals, tot, 16, hipMemcpyDeviceToHost));
-	(void)hipFree(cnt); (void)hipFree(tot);
+	(void)hipFree(cnt); (void)hipFree(tot); (void)hipFree(chunk);
 	GfmParams& p = ix->host.g.p;
 	uint32_t len = (uint32_t)(num_sides * 192 - 1);
 	p.init(len, len + 1, len + 1, 6, 4, 10, 0, 4);
@@ -350,6 +376,40 @@ __global__ __launch_bounds__(256) void k_rank_v2(DGfm g, const uint32_t* rows, c
 	}
 }
 
+// ---- measurement-only variants (same results as variant 0; they probe the memory system) ----
+// 3: also loads the partner half of the 128 B line (is the fetch unit 64 B or 128 B?)
+// 4: nontemporal loads (no L2/MALL allocation)       5: two independent queries in flight per lane
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rank_exp(DGfm g, uint32_t* out, size_t n, uint64_t seed) {
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride * (MODE == 5 ? 2 : 1)) {
+		uint64_t h = splitmix64(seed + i);
+		uint32_t row = (uint32_t)(h % g.gbwtLen); int c = (int)((h >> 40) & 3);
+		if(MODE == 3) {
+			uint32_t sideNum = row / 192u;
+			const uint4* q = reinterpret_cast<const uint4*>(g.sides + (size_t)(sideNum ^ 1u) * 64);
+			uint4 x = q[0];
+			asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+			out[i] = rank64(g, row, c);
+		} else if(MODE == 4) {
+			uint32_t sideNum = row / 192u, charOff = row - sideNum * 192u;
+			const uint64_t* q = reinterpret_cast<const uint64_t*>(g.sides + (size_t)sideNum * 64);
+			Side64 s;
+#pragma unroll
+			for(int k = 0; k < 8; k++) s.w[k] = __builtin_nontemporal_load(q + k);
+			out[i] = rank_in_side64(g, s, sideNum, charOff, c);
+		} else {
+			size_t j = i + stride;
+			uint64_t h2 = splitmix64(seed + (j < n ? j : i));
+			uint32_t row2 = (uint32_t)(h2 % g.gbwtLen); int c2 = (int)((h2 >> 40) & 3);
+			uint32_t s1 = row / 192u, s2 = row2 / 192u;
+			Side64 a = load_side64(g.sides + (size_t)s1 * 64), b = load_side64(g.sides + (size_t)s2 * 64);
+			out[i] = rank_in_side64(g, a, s1, row - s1 * 192u, c);
+			if(j < n) out[j] = rank_in_side64(g, b, s2, row2 - s2 * 192u, c2);
+		}
+	}
+}
+
 __global__ void k_checksum(const uint32_t* v, size_t n, unsigned long long* out) {
 	unsigned long long acc = 0;
 	size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -373,6 +433,12 @@ static int launch_rank(h2g_stream* s, const uint32_t* d_rows, const uint8_t* d_c
 			hipLaunchKernelGGL(k_rank_v1<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
 		} else if(variant == 2) {
 			hipLaunchKernelGGL(k_rank_v2<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
+		} else if(variant == 3 && synth) {
+			hipLaunchKernelGGL(k_rank_exp<3>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed);
+		} else if(variant == 4 && synth) {
+			hipLaunchKernelGGL(k_rank_exp<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed);
+		} else if(variant == 5 && synth) {
+			hipLaunchKernelGGL(k_rank_exp<5>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed);
 		} else return H2G_ERR_ARG;
 	}
 	HIPCHK(hipEventRecord(s->ev[1], s->st));

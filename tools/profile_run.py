@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Short GPU run for rocprofv3 passes: 3 launches of the fused seed stage on the bench workload and one launch
+of each Occ-rank variant at GRCh38 scale.  (bench.py is the timed harness; this only keeps profiler passes short.)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+from hisat2_amd import api, synth  # noqa: E402
+
+nreads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 26
+base, contigs = bench.build_index(os.path.join(ROOT, ".bench_cache"), 4_900_000)
+reads, _ = synth.make_reads(contigs, nreads, 101, bench.SEED + 1000, sub_rate=0.005)
+codes, offs = synth.flatten_reads(reads)
+ix = api.Index(base)
+st = api.Stream(ix, max_reads=nreads, max_bases=codes.size)
+st.set_reads(codes, offs)
+p = st.seed_params(True)
+for _ in range(3):
+    st.seed_extend_run(p)
+st.sync()
+c = st.counters()
+print("seed stage: search %.3f ms, resolve+extend %.3f ms, n_side %d n_sa_steps %d" % (c.ms_search, c.ms_resolve_extend, c.n_side, c.n_sa_steps))
+rix = api.Index(synth_sides=15_300_000, seed=bench.SEED)
+rst = api.Stream(rix)
+for v in (0, 1, 2):
+    ms, ck = rst.rank_synth(nq, bench.SEED, variant=v, repeats=1)
+    print("rank variant %d: %.3f ms  %.1f GB/s" % (v, ms, nq * 64 / ms / 1e6))
