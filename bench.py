@@ -143,15 +143,10 @@ def main():
         dt = float(t.item())
     # final alignment-count reduction over RCCL/xGMI (the only collective on this path)
     got = st.seed_extend_fetch()
-    valid = np.arange(api.SEED_CAP)[None, :] < got["ncoords"][:, None]
-    full = ((got["ext"]["len"] == 101) & (got["ext"]["score"] == 0) & valid).any(axis=1)          # per (read, strand)
-    anchored = got["ncoords"] > 0
-    summ = np.array([int(anchored.reshape(-1, 2).any(axis=1).sum()), int(full.reshape(-1, 2).any(axis=1).sum()),
-                     int(cnt.n_rank), int(cnt.n_side), int(cnt.n_sa_steps), int(cnt.n_ext)], dtype=np.int64)
-    if dist is not None:
-        tt = torch.from_numpy(summ).cuda()
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        summ = tt.cpu().numpy()
+    from hisat2_amd import shard
+    sm = shard.summarize(got, read_len=101)    # [reads, anchored, fully extended, n_rank, n_side, n_sa_steps, n_ext]
+    sm = shard.all_reduce_sum(sm, dist, device="cuda")
+    summ = np.array([sm[1], sm[2], sm[3], sm[4], sm[5], sm[6]], dtype=np.int64)
 
     if rank == 0:
         total_reads = a.reads * world
