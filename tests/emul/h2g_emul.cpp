@@ -7,6 +7,8 @@
 #include <vector>
 #include "../../hisat2_amd/csrc/h2g_core.h"
 #include "../../hisat2_amd/csrc/h2g_host_index.h"
+#include "../../hisat2_amd/csrc/h2g_align.h"
+#include "../../hisat2_amd/csrc/h2g_local_pack.h"
 
 using namespace h2g;
 
@@ -18,6 +20,8 @@ struct Emu {
 	std::vector<uint32_t> offs;
 	std::vector<char> quals;
 	bool has_quals = false;
+	LocalPack lp;
+	DLocalSet dls;
 	DReads reads() const {
 		DReads r;
 		r.codes = codes.data(); r.offs = offs.data(); r.quals = has_quals ? quals.data() : nullptr;
@@ -46,6 +50,8 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dr.buf = r.buf.data(); e->dr.rec_start = r.rec_start.data(); e->dr.rec_len = r.rec_len.data();
 	e->dr.rec_bufoff = r.rec_bufoff.data(); e->dr.refRecOffs = r.refRecOffs.data(); e->dr.refLens = r.refLens.data();
 	e->dr.nrefs = r.nrefs;
+	pack_local(e->host, e->lp);
+	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data());
 	*out = e;
 	return 0;
 }
@@ -94,6 +100,23 @@ void h2gemu_seed_extend(Emu* e, uint32_t pseudogeneStop, uint32_t khits, h2g_see
 		partial_search_item(e->dg, sv, 0, pseudogeneStop != 0, true, khits, &out[i].hit);
 		resolve_extend_item(e->dg, e->dr, sc, sv, &out[i], &scratch);
 	}
+}
+
+
+// HI_Aligner::go + selection for every read of the batch (names: '\0'-free bytes + offsets)
+void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, AlnRec* recs) {
+	DReads rd = e->reads();
+	AlnParams P;
+	P.khits = 5; P.kseeds = 10; P.no_spliced = no_spliced; P.secondary = 0;
+	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
+	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1;
+	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
+	AlignWS* ws = new AlignWS();
+	for(uint32_t i = 0; i < rd.n; i++) {
+		al_read(C, rd, i, names + name_offs[i], name_offs[i + 1] - name_offs[i], ws, &outs[i]);
+		for(uint32_t k = 0; k < ws->nres; k++) recs[(size_t)i * AL_MAX_RESULTS + k] = ws->res[k];
+	}
+	delete ws;
 }
 
 }

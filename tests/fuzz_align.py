@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Development fuzzer (build container only): host instantiation of the go() state machine vs the real reference
+binary on freshly generated genomes/reads.  usage: fuzz_align.py <seed> <nreads> <rdlen> <sub> <indel> <nrate> [genome spec]"""
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import sam_util as SU  # noqa: E402
+from h2gemu_align import emu_align  # noqa: E402
+from hisat2_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=()):
+    tmp = tempfile.mkdtemp(prefix="h2fuzz")
+    contigs = synth.make_genome(list(lens), seed, n_gaps=gaps, gap_len=300, repeats=repeats, repeat_len=500)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads, _ = synth.make_reads(contigs, nreads, rdlen, seed + 1, sub_rate=sub, indel_rate=indel, n_rate=nrate)
+    rfa = os.path.join(tmp, "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    sam = os.path.join(tmp, "ref.sam")
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-U", rfa, "-S", sam] + list(extra),
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    refnames, want = SU.parse_sam(sam)
+    qnames = [str(i) for i in range(nreads)]
+    outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames)
+    got = SU.render(outs, recs, refnames, [rdlen] * nreads, qnames)
+    bad = ovf = setbad = 0
+    maxdep = 0
+    for i, q in enumerate(qnames):
+        ovf += 1 if outs[i].overflow else 0
+        ovfbits = ovfbits | outs[i].overflow if 'ovfbits' in dir() else outs[i].overflow
+        maxdep = max(maxdep, outs[i].depth)
+        if got[q] != want[q]:
+            bad += 1
+            if sorted((f & ~256, r, p, c, a) for f, r, p, c, a in got[q]) != sorted((f & ~256, r, p, c, a) for f, r, p, c, a in want[q]):
+                setbad += 1
+            if bad <= verbose:
+                print(" read", q, ("ovf%d" % outs[i].overflow) if outs[i].overflow else "", "\n   GOT ", got[q], "\n   WANT", want[q])
+    naln = sum(1 for q in qnames if want[q][0][0] != 4)
+    print(f"seed {seed} n {nreads} len {rdlen} sub {sub} indel {indel} N {nrate}: aligned(ref) {naln}  mismatching {bad} (set-level {setbad})  overflow {ovf}  max depth {maxdep}  tmp {tmp}")
+    return bad, tmp
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    run_case(int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]), float(a[5]))

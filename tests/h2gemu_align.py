@@ -1,0 +1,22 @@
+"""Driver for the host instantiation of the go() state machine (tests only)."""
+import ctypes as C
+
+import numpy as np
+
+import sam_util as SU
+from h2gemu_py import Emu
+
+
+def emu_align(base, reads_list, qnames, no_spliced=1):
+    e = Emu(base)
+    codes = np.concatenate(reads_list).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads_list])]).astype(np.uint32)
+    e.set_reads(codes, offs)
+    nb = "".join(qnames).encode()
+    noffs = np.concatenate([[0], np.cumsum([len(q) for q in qnames])]).astype(np.uint32)
+    n = len(reads_list)
+    outs = (SU.ReadOut * n)()
+    recs = (SU.AlnRec * (n * SU.AL_MAX_RESULTS))()
+    e.L.h2gemu_align.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    e.L.h2gemu_align(e.h, no_spliced, nb, noffs.ctypes.data, outs, recs)
+    return outs, recs

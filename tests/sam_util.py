@@ -1,0 +1,87 @@
+"""SAM helpers for the go()-level parity tests: parse the reference's SAM and render the records returned by the
+hot path (AlnRec = what reportHit hands to AlnRes::init) into FLAG / RNAME / POS / CIGAR / AS:i."""
+import ctypes as C
+import gzip
+
+import numpy as np
+
+from hisat2_amd import api
+
+AL_MAX_RESULTS = 32
+
+
+class AlnRec(C.Structure):
+    _fields_ = [("fw", C.c_uint32), ("tidx", C.c_uint32), ("toff", C.c_uint32), ("len", C.c_uint32), ("trim5", C.c_uint32),
+                ("trim3", C.c_uint32), ("nedits", C.c_uint32), ("pad", C.c_uint32), ("score", C.c_int64),
+                ("edits", api.Edit * api.MAX_EDITS)]
+
+
+class ReadOut(C.Structure):
+    _fields_ = [("nres", C.c_uint32), ("nselect", C.c_uint32), ("overflow", C.c_uint32), ("nrank", C.c_uint32),
+                ("nsteps", C.c_uint32), ("depth", C.c_uint32), ("select", C.c_uint8 * AL_MAX_RESULTS)]
+
+
+def parse_sam(path):
+    """-> (refnames, {qname: [(flag, rname, pos, cigar, AS), ...] in file order})"""
+    op = gzip.open if path.endswith(".gz") else open
+    names, recs = [], {}
+    with op(path, "rt") as f:
+        for line in f:
+            if line.startswith("@"):
+                if line.startswith("@SQ"):
+                    names.append(line.split("\t")[1][3:])
+                continue
+            t = line.rstrip("\n").split("\t")
+            a = None
+            for x in t[11:]:
+                if x.startswith("AS:i:"):
+                    a = int(x[5:])
+            recs.setdefault(t[0], []).append((int(t[1]), t[2], int(t[3]), t[5], a))
+    return names, recs
+
+
+def cigar_of(rec: AlnRec, rdlen):
+    """CIGAR in reference-forward orientation from the stored edit list (5'-relative, inverted when !fw)."""
+    eds = [(rec.edits[k].pos, rec.edits[k].type) for k in range(rec.nedits)]
+    if not rec.fw:   # undo Edit::invertPoss
+        eds = [((rdlen - p) if t == 1 else (rdlen - p - 1), t) for p, t in reversed(eds)]
+    eds = [(p - rec.trim5, t) for p, t in eds]
+    ops = []
+
+    def add(op, n=1):
+        if n <= 0:
+            return
+        if ops and ops[-1][0] == op:
+            ops[-1][1] += n
+        else:
+            ops.append([op, n])
+    add("S", rec.trim5)
+    ei = 0
+    for i in range(rec.len):
+        isins = False
+        while ei < len(eds) and eds[ei][0] == i:
+            t = eds[ei][1]
+            if t == 1:
+                add("D")
+            elif t == 2:
+                isins = True
+            ei += 1
+        add("I" if isins else "M")
+    add("S", rec.trim3)
+    return "".join(f"{n}{op}" for op, n in ops)
+
+
+def render(outs, recs, names, rdlens, qnames):
+    """-> {qname: [(flag, rname, pos, cigar, AS)]} in print order (primary first)"""
+    res = {}
+    for i, q in enumerate(qnames):
+        o = outs[i]
+        lst = []
+        if o.nselect == 0:
+            lst.append((4, "*", 0, "*", None))
+        for k in range(o.nselect):
+            r = recs[i * AL_MAX_RESULTS + o.select[k]]
+            flag = (0 if r.fw else 16) | (256 if k > 0 else 0)
+            lst.append((flag, names[r.tidx], r.toff + 1, cigar_of(r, rdlens[i]), int(r.score)))
+        res[q] = lst
+    return res
