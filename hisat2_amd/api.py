@@ -86,7 +86,27 @@ class SeedParams(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("n_rank", u64), ("n_side", u64), ("n_sa_steps", u64), ("n_ext", u64), ("n_ref_bytes", u64),
-                ("n_queries", u64), ("ms_search", C.c_float), ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float)]
+                ("n_queries", u64), ("n_aligned", u64), ("n_overflow", u64), ("ms_search", C.c_float),
+                ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float)]
+
+
+ALN_CAP = 8
+
+
+class AlnRes(C.Structure):
+    _fields_ = [("fw", u32), ("tidx", u32), ("toff", u32), ("len", u32), ("trim5", u32), ("trim3", u32), ("nedits", u32),
+                ("pad", u32), ("score", i64), ("edits", Edit * MAX_EDITS)]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("nres", u32), ("nselect", u32), ("overflow", u32), ("nrank", u32), ("nsteps", u32), ("depth", u32)]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("khits", u32), ("kseeds", u32), ("no_spliced_alignment", u32), ("secondary", u32)]
+
+
+READ_RESULT_DTYPE = np.dtype([(n, np.uint32) for n in ("nres", "nselect", "overflow", "nrank", "nsteps", "depth")])
 
 
 # numpy views of the result structs (same memory layout)
@@ -102,6 +122,7 @@ EXPORTS = [
     "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_set_reads",
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
+    "h2g_align_params_init", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
 ]
 
 
@@ -144,6 +165,11 @@ def lib():
     L.h2g_seed_extend_run.argtypes = [vp, P(SeedParams)]
     L.h2g_seed_extend_fetch.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
     L.h2g_get_counters.argtypes = [vp, P(Counters)]
+    L.h2g_align_params_init.argtypes = [P(AlignParams), vp]
+    L.h2g_align_params_init.restype = None
+    L.h2g_set_read_names.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    L.h2g_align_run.argtypes = [vp, P(AlignParams)]
+    L.h2g_align_fetch.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
     _lib = L
     return L
 
@@ -252,6 +278,27 @@ class Stream:
         c = Counters()
         _chk(lib().h2g_get_counters(self.h, C.byref(c)), "h2g_get_counters")
         return c
+
+    def set_read_names(self, qnames):
+        nb = "".join(qnames).encode()
+        offs = np.concatenate([[0], np.cumsum([len(q) for q in qnames])]).astype(np.uint32)
+        _chk(lib().h2g_set_read_names(self.h, nb, offs.ctypes.data, len(qnames)), "h2g_set_read_names")
+
+    def align_params(self):
+        p = AlignParams()
+        lib().h2g_align_params_init(C.byref(p), self.ix.h)
+        return p
+
+    def align_run(self, params=None):
+        params = params or self.align_params()
+        _chk(lib().h2g_align_run(self.h, C.byref(params)), "h2g_align_run")
+
+    def align_fetch(self, first=0, n=None, with_alignments=True):
+        n = self.n_reads - first if n is None else n
+        res = np.zeros(n, dtype=READ_RESULT_DTYPE)
+        aln = (AlnRes * (n * ALN_CAP))() if with_alignments else None
+        _chk(lib().h2g_align_fetch(self.h, res.ctypes.data, aln, first, n), "h2g_align_fetch")
+        return res, aln
 
     def hip_stream(self):
         return lib().h2g_stream_hip(self.h)

@@ -18,8 +18,8 @@ namespace h2g {
 #define AL_MAX_GHITS    10    // max(khits, kseeds) for linear indexes (hisat2.cpp:3174-3176, 3903-3906)
 #define AL_MAX_SEARCHED 64
 #define AL_MAX_RESULTS  32
-#define AL_MAX_DEPTH    48
-#define AL_MAX_LOCALHITS 8
+#define AL_MAX_DEPTH    40
+#define AL_MAX_LOCALHITS 6
 #define AL_MAX_COORDS   12
 
 // ---------------------------------------------------------------------------------------- local indexes (a13)

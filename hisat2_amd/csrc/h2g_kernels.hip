@@ -10,6 +10,8 @@
 #include <vector>
 #include "h2g_core.h"
 #include "h2g_host_index.h"
+#include "h2g_align.h"
+#include "h2g_local_pack.h"
 
 using namespace h2g;
 
@@ -30,6 +32,8 @@ struct h2g_index {
 	int device = 0;
 	DGfm dg;
 	DRef dr;
+	DLocalSet dls;
+	bool has_local = false;
 	std::vector<void*> allocs;
 	uint64_t device_bytes = 0;
 };
@@ -43,10 +47,19 @@ struct h2g_stream {
 	char* d_quals = nullptr;
 	bool has_quals = false;
 	h2g_seed_result* d_seed = nullptr;
+	char* d_names = nullptr;
+	uint32_t* d_name_offs = nullptr;
+	size_t names_cap = 0;
+	bool has_names = false;
+	AlignWS* d_ws = nullptr;
+	size_t ws_threads = 0;
+	ReadOut* d_rout = nullptr;
+	h2g_alnres* d_aln = nullptr;
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t tmp_sz[4] = {0, 0, 0, 0};
-	hipEvent_t ev[6];
+	hipEvent_t ev[8];
+	bool ran_seed = false, ran_align = false;
 	h2g_counters last;
 };
 
@@ -100,6 +113,16 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	if((s = upload(ix, r.buf, &ix->dr.buf)) || (s = upload(ix, r.rec_start, &ix->dr.rec_start)) ||
 	   (s = upload(ix, r.rec_len, &ix->dr.rec_len)) || (s = upload(ix, r.rec_bufoff, &ix->dr.rec_bufoff)) ||
 	   (s = upload(ix, r.refRecOffs, &ix->dr.refRecOffs)) || (s = upload(ix, r.refLens, &ix->dr.refLens))) { h2g_index_free(ix); return s; }
+	memset(&ix->dls, 0, sizeof ix->dls);
+	if(o.load_local && !ix->host.local.empty() && g.p.linear) {
+		LocalPack lp;
+		pack_local(ix->host, lp);
+		const DLocalDesc* dd; const uint8_t* ds; const uint16_t* dw; const uint32_t* df;
+		if((s = upload(ix, lp.desc, &dd)) || (s = upload(ix, lp.sides, &ds, 256)) || (s = upload(ix, lp.words, &dw)) ||
+		   (s = upload(ix, lp.first, &df))) { h2g_index_free(ix); return s; }
+		ix->dls = lp.view(dd, ds, dw, df);
+		ix->has_local = true;
+	}
 	*out = ix;
 	return H2G_OK;
 }
@@ -220,7 +243,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	h2g_stream* s = new h2g_stream();
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-	for(int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&s->ev[i]));
+	for(int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&s->ev[i]));
 	HIPCHK(hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
 	if(max_reads) {
@@ -238,9 +261,10 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters);
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws);
+	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
-	for(int i = 0; i < 6; i++) (void)hipEventDestroy(s->ev[i]);
+	for(int i = 0; i < 8; i++) (void)hipEventDestroy(s->ev[i]);
 	(void)hipStreamDestroy(s->st);
 	delete s;
 }
@@ -273,6 +297,7 @@ extern "C" h2g_status h2g_set_reads(h2g_stream* s, const uint8_t* codes, const u
 	if(quals) HIPCHK(hipMemcpyAsync(s->d_quals, quals, nb, hipMemcpyHostToDevice, s->st));
 	HIPCHK(hipStreamSynchronize(s->st));
 	s->n_reads = n;
+	s->has_names = false;
 	return H2G_OK;
 }
 
@@ -660,6 +685,7 @@ extern "C" h2g_status h2g_seed_extend_run(h2g_stream* s, const h2g_seed_params* 
 	hipLaunchKernelGGL(k_seed_resolve_extend, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dr, dreads(s), sc, s->d_seed, s->d_counters);
 	HIPCHK(hipEventRecord(s->ev[4], s->st));
 	HIPCHK(hipGetLastError());
+	s->ran_seed = true;
 	return H2G_OK;
 }
 
@@ -670,16 +696,134 @@ extern "C" h2g_status h2g_seed_extend_fetch(h2g_stream* s, h2g_seed_result* out,
 	return H2G_OK;
 }
 
+// ------------------------------------------------------------------------------------------ go() for the batch
+static_assert(sizeof(h2g_alnres) == sizeof(AlnRec), "h2g_alnres must mirror AlnRec");
+static_assert(sizeof(h2g_read_result) == 24, "h2g_read_result layout");
+
+// One lane = one read at a time (grid-stride); each lane owns one AlignWS in HBM (explicit recursion stack,
+// sink, searched list).  Selected alignments are written in print order.
+__global__ __launch_bounds__(256) void k_align(DGfm g, DRef ref, DLocalSet ls, DReads rd, AlnParams P, const char* names,
+                                               const uint32_t* name_offs, AlignWS* pool, ReadOut* outs, h2g_alnres* aln,
+                                               unsigned long long* counters)
+{
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	AlignWS* ws = pool + tid;
+	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
+	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0;
+	for(size_t i = tid; i < rd.n; i += stride) {
+		ReadOut o;
+		const uint32_t a = name_offs[i], b = name_offs[i + 1];
+		al_read(C, rd, (uint32_t)i, names + a, b - a, ws, &o);
+		outs[i] = o;
+		for(uint32_t k = 0; k < o.nselect && k < H2G_ALN_CAP; k++) {
+			const AlnRec& r = ws->res[o.select[k]];
+			h2g_alnres& d = aln[i * H2G_ALN_CAP + k];
+			d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
+			d.nedits = r.nedits; d.pad = 0; d.score = r.score;
+			for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
+		}
+		nrank += o.nrank; nsteps += o.nsteps; naln += o.nselect > 0; novf += o.overflow != 0;
+	}
+	wave_add(counters + 0, nrank);
+	wave_add(counters + 2, nsteps);
+	wave_add(counters + 4, naln);
+	wave_add(counters + 5, novf);
+}
+
+extern "C" void h2g_align_params_init(h2g_align_params* p, const h2g_index* ix) {
+	const bool linear = !ix || ix->dg.linear;
+	p->khits = linear ? 5 : 10;                       // hisat2.cpp:3903-3906
+	p->kseeds = p->khits * 2 > 5 ? p->khits * 2 : 5;  // --max-seeds default hisat2.cpp:3174-3176
+	p->no_spliced_alignment = 1;
+	p->secondary = 0;
+}
+
+extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const uint32_t* offs, size_t n) {
+	if(!s || !bytes || !offs || n != s->n_reads || n == 0) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	size_t nb = offs[n];
+	if(s->names_cap < nb || !s->d_name_offs) {
+		(void)hipFree(s->d_names); (void)hipFree(s->d_name_offs);
+		s->d_names = nullptr; s->d_name_offs = nullptr;
+		HIPCHK(hipMalloc((void**)&s->d_names, nb + 64));
+		HIPCHK(hipMalloc((void**)&s->d_name_offs, (s->max_reads + 1) * 4));
+		s->names_cap = nb;
+	}
+	HIPCHK(hipMemcpyAsync(s->d_names, bytes, nb, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(s->d_name_offs, offs, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	s->has_names = true;
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
+	if(!s || !p) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
+	if(!s->has_names) { snprintf(g_err, sizeof g_err, "align: read names not set (h2g_set_read_names)"); return H2G_ERR_ARG; }
+	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
+	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > AL_MAX_GHITS || p->kseeds < p->khits) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	// 2 waves per SIMD on every CU: enough lanes to cover HBM latency, bounded workspace (sizeof(AlignWS) each)
+	const unsigned block = 256;
+	size_t want = (s->n_reads + block - 1) / block;
+	const size_t maxblocks = 256 * 2;
+	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
+	const size_t nthreads = (size_t)grid * block;
+	if(s->ws_threads < nthreads) {
+		(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_threads = 0;
+		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * sizeof(AlignWS)));
+		s->ws_threads = nthreads;
+	}
+	if(!s->d_rout) {
+		HIPCHK(hipMalloc((void**)&s->d_rout, s->max_reads * sizeof(ReadOut)));
+		HIPCHK(hipMalloc((void**)&s->d_aln, s->max_reads * (size_t)H2G_ALN_CAP * sizeof(h2g_alnres)));
+	}
+	AlnParams P;
+	P.khits = p->khits; P.kseeds = p->kseeds; P.no_spliced = 1; P.secondary = p->secondary;
+	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
+	P.pseudogeneStop = 0; P.anchorStop = 1;
+	(void)hipGetLastError();
+	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
+	HIPCHK(hipEventRecord(s->ev[5], s->st));
+	hipLaunchKernelGGL(k_align, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
+	                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters);
+	HIPCHK(hipEventRecord(s->ev[6], s->st));
+	HIPCHK(hipGetLastError());
+	s->ran_align = true;
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t first, size_t n) {
+	if(!s || !res || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
+	std::vector<ReadOut> tmp(n);
+	HIPCHK(hipMemcpyAsync(tmp.data(), s->d_rout + first, n * sizeof(ReadOut), hipMemcpyDeviceToHost, s->st));
+	if(aln) HIPCHK(hipMemcpyAsync(aln, s->d_aln + first * H2G_ALN_CAP, n * H2G_ALN_CAP * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	for(size_t i = 0; i < n; i++) {
+		res[i].nres = tmp[i].nres; res[i].nselect = tmp[i].nselect; res[i].overflow = tmp[i].overflow;
+		res[i].nrank = tmp[i].nrank; res[i].nsteps = tmp[i].nsteps; res[i].depth = tmp[i].depth;
+	}
+	return H2G_OK;
+}
+
 extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	if(!s || !c) return H2G_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(s->st));
-	unsigned long long v[4] = {0, 0, 0, 0};
+	unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	HIPCHK(hipMemcpy(v, s->d_counters, sizeof v, hipMemcpyDeviceToHost));
 	s->last.n_rank = v[0]; s->last.n_side = v[1]; s->last.n_sa_steps = v[2]; s->last.n_ext = v[3];
+	s->last.n_aligned = v[4]; s->last.n_overflow = v[5];
 	s->last.n_queries = s->n_reads * 2;
 	float t = 0;
-	if(hipEventElapsedTime(&t, s->ev[2], s->ev[3]) == hipSuccess) s->last.ms_search = t;
-	if(hipEventElapsedTime(&t, s->ev[3], s->ev[4]) == hipSuccess) s->last.ms_resolve_extend = t;
+	if(s->ran_seed) {
+		if(hipEventElapsedTime(&t, s->ev[2], s->ev[3]) == hipSuccess) s->last.ms_search = t;
+		if(hipEventElapsedTime(&t, s->ev[3], s->ev[4]) == hipSuccess) s->last.ms_resolve_extend = t;
+	}
+	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[6]) == hipSuccess) s->last.ms_align = t;
+	(void)hipGetLastError();
 	*c = s->last;
 	return H2G_OK;
 }

@@ -155,10 +155,39 @@ H2G_EXPORT void       h2g_seed_params_init(h2g_seed_params*, const h2g_index*, i
 H2G_EXPORT h2g_status h2g_seed_extend_run(h2g_stream*, const h2g_seed_params*);     /* async on the stream */
 H2G_EXPORT h2g_status h2g_seed_extend_fetch(h2g_stream*, h2g_seed_result* out, size_t first_read, size_t n_reads);
 
+/* ---- the coarse entry: HI_Aligner::go for every read of the resident batch ---------------------------------- */
+/* Semantics == one iteration of the worker loop body (hisat2.cpp:3380-3640) for an unpaired read that passed the
+ * filters: rnd.init(genRandSeed(read)) (pat.h:55), splicedAligner.go(...) (hi_aligner.h:4048), and the selection
+ * half of AlnSinkWrap::finishRead (aln_sink.h:1939 -> selectByScore :2680).  Built so far: linear (HFM) indexes,
+ * unpaired reads, --no-spliced-alignment, default scoring, bowtie2_dp = 0. */
+#define H2G_ALN_CAP 8              /* alignments returned per read (>= -k) */
+typedef struct {                   /* == the arguments reportHit (hi_aligner.h:6064-6166) passes to AlnRes::init */
+	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, pad;
+	int64_t  score;                /* AS:i */
+	h2g_edit edits[H2G_MAX_EDITS]; /* 5'-relative read positions, inverted for !fw, as stored in the AlnRes */
+} h2g_alnres;
+typedef struct {
+	uint32_t nres;                 /* alignments reported to the sink (rs1u_) */
+	uint32_t nselect;              /* alignments to print, best first; [0] is the primary */
+	uint32_t overflow;             /* !=0: a fixed-capacity list overflowed -> caller runs this read through its own go() */
+	uint32_t nrank, nsteps, depth; /* work counters: rank calls, SA-walk steps, deepest recursion frame */
+} h2g_read_result;
+typedef struct {
+	uint32_t khits, kseeds;        /* -k, --max-seeds */
+	uint32_t no_spliced_alignment; /* must be 1 for now */
+	uint32_t secondary;
+} h2g_align_params;
+H2G_EXPORT void       h2g_align_params_init(h2g_align_params*, const h2g_index*);
+/* read names (needed by genRandSeed): name i = bytes[offs[i] .. offs[i+1]) */
+H2G_EXPORT h2g_status h2g_set_read_names(h2g_stream*, const char* bytes, const uint32_t* offs, size_t n_reads);
+H2G_EXPORT h2g_status h2g_align_run(h2g_stream*, const h2g_align_params*);           /* async on the stream */
+H2G_EXPORT h2g_status h2g_align_fetch(h2g_stream*, h2g_read_result* res /* [n] */, h2g_alnres* aln /* [n*H2G_ALN_CAP] or NULL */,
+                                      size_t first_read, size_t n_reads);
+
 /* ---- counters (roofline numerators) ------------------------------------------------- */
 typedef struct {
-	uint64_t n_rank, n_side, n_sa_steps, n_ext, n_ref_bytes, n_queries;
-	float    ms_search, ms_resolve_extend, ms_rank;   /* HIP-event durations of the last launches */
+	uint64_t n_rank, n_side, n_sa_steps, n_ext, n_ref_bytes, n_queries, n_aligned, n_overflow;
+	float    ms_search, ms_resolve_extend, ms_rank, ms_align;   /* HIP-event durations of the last launches */
 } h2g_counters;
 H2G_EXPORT h2g_status h2g_get_counters(h2g_stream*, h2g_counters*);
 

@@ -17,7 +17,7 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=()):
+def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=(), backend=None):
     tmp = tempfile.mkdtemp(prefix="h2fuzz")
     contigs = synth.make_genome(list(lens), seed, n_gaps=gaps, gap_len=300, repeats=repeats, repeat_len=500)
     fa = os.path.join(tmp, "g.fa")
@@ -32,8 +32,11 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refnames, want = SU.parse_sam(sam)
     qnames = [str(i) for i in range(nreads)]
-    outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames)
-    got = SU.render(outs, recs, refnames, [rdlen] * nreads, qnames)
+    if backend is None:
+        outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames)
+        got = SU.render(outs, recs, refnames, [rdlen] * nreads, qnames)
+    else:   # backend(base, reads, qnames) -> (outs with .overflow/.depth, rendered dict)
+        outs, got = backend(base, reads, qnames, refnames)
     bad = ovf = setbad = 0
     maxdep = 0
     for i, q in enumerate(qnames):

@@ -85,3 +85,20 @@ def render(outs, recs, names, rdlens, qnames):
             lst.append((flag, names[r.tidx], r.toff + 1, cigar_of(r, rdlens[i]), int(r.score)))
         res[q] = lst
     return res
+
+
+def render_selected(res, aln, names, rdlens, qnames, cap=api.ALN_CAP):
+    """Same as render() for the C-ABI output (h2g_align_fetch): `aln` already holds the selected alignments in
+    print order, `cap` slots per read."""
+    out = {}
+    for i, q in enumerate(qnames):
+        lst = []
+        nsel = int(res[i]["nselect"])
+        if nsel == 0:
+            lst.append((4, "*", 0, "*", None))
+        for k in range(min(nsel, cap)):
+            r = aln[i * cap + k]
+            flag = (0 if r.fw else 16) | (256 if k > 0 else 0)
+            lst.append((flag, names[r.tidx], r.toff + 1, cigar_of(r, rdlens[i]), int(r.score)))
+        out[q] = lst
+    return out

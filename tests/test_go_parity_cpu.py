@@ -1,0 +1,36 @@
+"""CPU go()-level parity: the device state machine (hisat2_amd/csrc/h2g_align.h), instantiated on the host by
+tests/emul, against SAM written by the REAL reference binary (hisat2-align-s -p 1 --no-spliced-alignment): FLAG
+(incl. the primary/secondary choice, which replays the per-read PRNG), RNAME, POS, CIGAR and AS:i of every line."""
+import os
+
+import pytest
+
+import h2o_py as H
+import sam_util as SU
+from h2gemu_align import emu_align
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_golden_sam(g1_index, golden_dir):
+    names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
+    outs, recs = emu_align(g1_index, seqs, names)
+    refnames, want = SU.parse_sam(os.path.join(golden_dir, "ref_se_nospliced.sam.gz"))
+    got = SU.render(outs, recs, refnames, [len(s) for s in seqs], names)
+    assert sum(1 for q in names if want[q][0][0] != 4) > 300
+    for i, q in enumerate(names):
+        assert outs[i].overflow == 0
+        assert got[q] == want[q], q
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("case", [
+    dict(seed=101, nreads=3000, rdlen=101, sub=0.02, indel=0.002, nrate=0.002),
+    dict(seed=102, nreads=2000, rdlen=60, sub=0.01, indel=0.001, nrate=0.0),
+    dict(seed=103, nreads=2000, rdlen=101, sub=0.003, indel=0.0, nrate=0.0, lens=(120000,), repeats=300, gaps=0),
+])
+def test_live_reference(case):
+    """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""
+    import fuzz_align as F
+    bad, _ = F.run_case(verbose=3, **case)
+    assert bad == 0

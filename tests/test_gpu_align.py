@@ -1,0 +1,84 @@
+"""GPU go()-level parity (run with -m gpu): h2g_align_run / h2g_align_fetch through the C ABI against SAM written by
+the REAL reference binary — committed golden SAM, and live oracle/_ref runs on fresh genomes when available."""
+import os
+
+import numpy as np
+import pytest
+
+import h2o_py as H
+import sam_util as SU
+from hisat2_amd import api
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gpu_align(base, reads, qnames):
+    """reads: (n, L) uint8 array or list of arrays"""
+    lst = [np.asarray(r, dtype=np.uint8) for r in reads]
+    codes = np.concatenate(lst)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in lst])]).astype(np.uint32)
+    ix = api.Index(base, device=0)
+    st = api.Stream(ix, max_reads=len(lst), max_bases=codes.size)
+    st.set_reads(codes, offs)
+    st.set_read_names(qnames)
+    st.align_run()
+    res, aln = st.align_fetch()
+    c = st.counters()
+    st.close()
+    ix.close()
+    return res, aln, c
+
+
+def test_golden_sam(g1_index, golden_dir):
+    names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
+    res, aln, c = gpu_align(g1_index, seqs, names)
+    refnames, want = SU.parse_sam(os.path.join(golden_dir, "ref_se_nospliced.sam.gz"))
+    got = SU.render_selected(res, aln, refnames, [len(s) for s in seqs], names)
+    assert (res["overflow"] == 0).all()
+    for q in names:
+        assert got[q] == want[q], q
+    assert c.n_aligned == sum(1 for q in names if want[q][0][0] != 4)
+    assert c.n_rank == int(res["nrank"].sum())
+
+
+class _Out:
+    def __init__(self, r):
+        self.overflow, self.depth = int(r["overflow"]), int(r["depth"])
+
+
+def _backend(base, reads, qnames, refnames):
+    res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames)
+    got = SU.render_selected(res, aln, refnames, [reads.shape[1]] * len(reads), qnames)
+    return [_Out(r) for r in res], got
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("case", [
+    dict(seed=201, nreads=20000, rdlen=101, sub=0.02, indel=0.002, nrate=0.002),
+    dict(seed=202, nreads=10000, rdlen=150, sub=0.01, indel=0.001, nrate=0.001),
+    dict(seed=203, nreads=10000, rdlen=101, sub=0.003, indel=0.0, nrate=0.0, lens=(120000,), repeats=300, gaps=0),
+    dict(seed=204, nreads=5000, rdlen=36, sub=0.01, indel=0.0, nrate=0.0),
+])
+def test_live_reference(case):
+    import fuzz_align as F
+    bad, _ = F.run_case(verbose=3, backend=_backend, **case)
+    assert bad == 0
+
+
+def test_align_requires_names_and_nospliced(g1_index, golden_dir):
+    names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
+    codes = np.concatenate(seqs)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in seqs])]).astype(np.uint32)
+    ix = api.Index(g1_index)
+    st = api.Stream(ix, max_reads=len(seqs), max_bases=codes.size)
+    st.set_reads(codes, offs)
+    with pytest.raises(api.H2GError):
+        st.align_run()                      # names missing
+    st.set_read_names(names)
+    p = st.align_params()
+    p.no_spliced_alignment = 0
+    with pytest.raises(api.H2GError):
+        st.align_run(p)                     # spliced mode not built: refused, not approximated
+    st.close()
+    ix.close()
