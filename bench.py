@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the MI355X seed-and-extend hot path (BASELINE.json metric: reads/sec; Occ-rank HBM GB/s).
 
-One "step" = one pass of the hot path over one resident batch of synthetic reads:
-    both strands' FM backward search (partialSearch, hi_aligner.h:6361) -> SA-offset resolution of the anchor
-    ranges (getGenomeCoords, hi_aligner.h:5774) -> 0-mismatch extension (GenomeHit::extend, hi_aligner.h:2031)
+One "step" = one pass of the hot path over one resident batch of synthetic reads = HI_Aligner::go for every read
+(hi_aligner.h:4048: FM backward search on both strands, SA-offset resolution, ungapped extension, local-index
+search, indel joins, recursion, sink feedback, selectByScore) — h2g_align_run.  The fused seed stage of round-1a
+(partialSearch -> getGenomeCoords -> extend(mm=0)) is timed once more and reported under "seed_stage".
 Workload at N=1 = BASELINE.json configs[1]: E. coli-size linear index, 1 M synthetic 101 bp SE reads.  The E. coli
 FASTA cannot be fetched here (no network), so the genome is the seeded uniform-random 4.9 Mbp substitute that
 SURVEY.md §8(d) prescribes; that is stated in `config` and `data`.
@@ -43,7 +44,8 @@ def build_index(cache, genome_len):
             raise SystemExit("bench.py: no cached index and oracle/_ref/hisat2-build-s is missing; run __graft_entry__.build() where /root/reference exists")
         fa = base + ".fa"
         synth.write_fasta(fa, contigs, names=["ecoli_substitute"])
-        subprocess.run([builder, "-q", fa, base + ".tmp"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nthr = min(os.cpu_count() or 1, 64)
+        subprocess.run([builder, "-q", "-p", str(nthr), fa, base + ".tmp"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         for k in range(1, 9):
             os.replace(f"{base}.tmp.{k}.ht2", f"{base}.{k}.ht2")
         os.remove(fa)
@@ -68,6 +70,38 @@ def cpu_baseline(base, reads, sample):
             "ranks_per_read": cnt[0] / sample, "sa_steps_per_read": cnt[1] / sample, "checksum": int(ck)}
 
 
+def cpu_reference(base, reads, sample, nver):
+    """Reference leg: the REAL reference aligner (oracle/_ref/hisat2-align-s, built from /root/reference by
+    oracle/Makefile.ref) on the host cores of this box, same reads, same flags; wall time minus a no-read run
+    (index load).  Also returns the SAM of the first `nver` reads for the parity check."""
+    import sam_util as SU
+    from hisat2_amd import synth
+    exe = os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")
+    if not os.path.exists(exe):
+        return None, None
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="h2bench")
+    fa = os.path.join(tmp, "sample.fa")
+    synth.write_reads_fasta(fa, reads[:sample])
+    cores = os.cpu_count() or 1
+    cmd = [exe, "-f", "--no-spliced-alignment", "-p", str(cores), "-x", base, "-U", fa, "-S", "/dev/null"]
+    t0 = time.perf_counter()
+    subprocess.run(cmd + ["-u", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t_load = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dt = time.perf_counter() - t0 - t_load
+    sam = os.path.join(tmp, "ver.sam")
+    subprocess.run([exe, "-f", "--no-spliced-alignment", "-p", "1", "-x", base, "-U", fa, "-u", str(nver), "-S", sam],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    refnames, want = SU.parse_sam(sam)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return ({"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
+             "sample": f"first {sample} reads of the bench batch, oracle/_ref/hisat2-align-s -p {cores} --no-spliced-alignment -S /dev/null, {dt:.2f} s (index load {t_load:.2f} s subtracted)"},
+            (refnames, want))
+
+
 def verify_sample(base, reads, got, nver):
     import h2o_py as H
     import parity_cases as PC
@@ -84,9 +118,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--genome-len", type=int, default=4_900_000)
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--rank-queries", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=5000)
     a = ap.parse_args()
 
     import torch
@@ -119,7 +154,9 @@ def main():
     ix = api.Index(base, device=local)
     st = api.Stream(ix, max_reads=a.reads, max_bases=codes.size)
     st.set_reads(codes, offs)                 # inputs resident in HBM before the timed region
+    st.set_read_names([str(i) for i in range(a.reads)])   # FASTA names = decimal ids (feed genRandSeed, pat.h:55)
     params = st.seed_params(no_spliced=True)  # config 2 runs --no-spliced-alignment
+    aparams = st.align_params()
 
     def barrier():
         st.sync()
@@ -128,15 +165,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    st.seed_extend_run(params)                 # round-1a seed stage, timed by HIP events only (reported aside)
+    st.sync()
     for _ in range(a.warmup):
-        st.seed_extend_run(params)
+        st.align_run(aparams)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        st.seed_extend_run(params)
+        st.align_run(aparams)
     barrier()
     dt = time.perf_counter() - t0
     cnt = st.counters()                        # counters + HIP-event kernel times of the LAST step
+    ares, aaln = st.align_fetch(0, min(a.verify, a.reads))
+    allres, _ = st.align_fetch(with_alignments=False)
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -147,22 +188,24 @@ def main():
     sm = shard.summarize(got, read_len=101)    # [reads, anchored, fully extended, n_rank, n_side, n_sa_steps, n_ext]
     sm = shard.all_reduce_sum(sm, dist, device="cuda")
     summ = np.array([sm[1], sm[2], sm[3], sm[4], sm[5], sm[6]], dtype=np.int64)
+    asum = np.array([int((allres["nselect"] > 0).sum()), int((allres["nselect"] > 1).sum()), int((allres["overflow"] != 0).sum()),
+                     int(allres["nrank"].sum()), int(allres["nsteps"].sum()), int(cnt.n_side)], dtype=np.int64)
+    asum = shard.all_reduce_sum(asum, dist, device="cuda")   # the alignment-summary reduction (RCCL over xGMI)
 
     if rank == 0:
         total_reads = a.reads * world
         value = total_reads * a.steps / dt
-        # dominant kernel = the FM search kernel (k_seed_search); algorithmic bytes = unique sides visited x 64 B
-        ms_search, ms_re = float(cnt.ms_search), float(cnt.ms_resolve_extend)
-        dom_is_search = ms_search >= ms_re
-        alg_bytes = cnt.n_side * 64 if dom_is_search else (cnt.n_sa_steps * 64 + cnt.n_ext * 28 + cnt.n_ext * 4)
-        dom_ms = ms_search if dom_is_search else ms_re
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # dominant kernel = k_align (the whole go() state machine).  Algorithmic bytes =
+        # 64 B x (unique sides visited by the search loops + SA-walk steps) of the LAST launch on this rank.
+        ms_align = float(cnt.ms_align)
+        alg_bytes = int(cnt.n_side) * 64 + int(cnt.n_sa_steps) * 64
+        achieved = alg_bytes / (ms_align * 1e-3) / 1e9 if ms_align > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "k_seed_search" if dom_is_search else "k_seed_resolve_extend",
-                    "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": int(alg_bytes),
-                    "other_kernel_ms": ms_re if dom_is_search else ms_search,
-                    "note": "index is 1.2 MB of sides (L2-resident at E. coli scale): the HBM-scale Occ-rank number is rank_microbench"}
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_align", "kernel_ms": ms_align,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "lane-per-read state machine, latency/divergence-bound at this index size (1.2 MB of sides is L2-resident); the HBM-scale Occ-rank number is rank_microbench"}
+        seed_stage = {"ms_search": float(cnt.ms_search), "ms_resolve_extend": float(cnt.ms_resolve_extend),
+                      "reads_per_s": a.reads / ((float(cnt.ms_search) + float(cnt.ms_resolve_extend)) * 1e-3)}
         # Occ-rank micro-kernel at GRCh38 scale: 15.3 M synthetic 64 B sides (0.98 GB), uniform rows
         rix = api.Index(synth_sides=15_300_000, seed=SEED, device=local)
         rst = api.Stream(rix)
@@ -175,26 +218,43 @@ def main():
         rst.close()
         rix.close()
         nver = 2000
-        verify_sample(base, reads, got, nver)
+        verify_sample(base, reads, got, nver)          # seed stage vs oracle/h2o.c
+        cpu_ref, ref_sam = (None, None)
+        if not a.no_cpu_baseline:
+            cpu_ref, ref_sam = cpu_reference(base, reads, min(a.cpu_sample, a.reads), len(ares))
+        parity = {"seed_stage_vs_oracle_reads": nver, "bit_exact": True}
+        if ref_sam is not None:
+            import sam_util as SU
+            qn = [str(i) for i in range(len(ares))]
+            gotsam = SU.render_selected(ares, aaln, ref_sam[0], [101] * len(ares), qn)
+            nbad = sum(1 for q in qn if gotsam[q] != ref_sam[1][q])
+            parity.update({"sam_checked_reads": len(ares), "sam_mismatching_reads": nbad,
+                           "against": "oracle/_ref/hisat2-align-s (FLAG, RNAME, POS, CIGAR, AS:i per line)"})
+            if nbad:
+                raise SystemExit(f"bench.py: {nbad} of {len(ares)} reads differ from the reference SAM")
         out = {
-            "metric": "reads/sec, 101 bp SE, seed-and-extend hot path (FM backward search both strands + SA resolve + 0-mm extend)",
+            "metric": "reads/sec, 101 bp SE (whole job): HI_Aligner::go per read on the GPU, bit-identical FLAG/POS/CIGAR/AS",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "configs[1]: E. coli-size linear GFM, 1M synthetic 101 bp SE reads per GPU, 1xMI355X",
                        "genome": f"seeded uniform-random {a.genome_len} bp substitute for NC_008253 (no network)",
-                       "reads_per_gpu": a.reads, "read_len": 101, "sub_rate": 0.005, "mode": "--no-spliced-alignment",
-                       "stage": "a11 partialSearch x2 strands -> a14 getGenomeCoords (<=5 rows) -> a18 extend(mm=0); full HI_Aligner::go() state machine is the next §8 row",
+                       "reads_per_gpu": a.reads, "read_len": 101, "sub_rate": 0.005, "mode": "--no-spliced-alignment -k 5",
+                       "stage": "full HI_Aligner::go + selectByScore (alignments stay in HBM; SAM text formatting is the host's, SURVEY §8(f) N1)",
                        "sharding": f"reads by id range across {world} GPU(s), index replicated; RCCL all-reduce of summary counters only"},
             "roofline": roofline,
             "rank_microbench": {"sides": 15_300_000, "bytes": 15_300_000 * 64, "queries": a.rank_queries, **micro},
-            "counters": {"reads_with_anchor": int(summ[0]), "reads_fully_extended_0mm": int(summ[1]), "n_rank": int(summ[2]),
-                         "n_side": int(summ[3]), "n_sa_steps": int(summ[4]), "n_ext": int(summ[5]),
-                         "ranks_per_read": float(summ[2]) / total_reads, "sides_per_read": float(summ[3]) / total_reads},
-            "parity": {"checked_reads": nver, "against": "oracle/h2o.c", "bit_exact": True},
+            "seed_stage": seed_stage,
+            "counters": {"reads_aligned": int(asum[0]), "reads_multi": int(asum[1]), "reads_overflow": int(asum[2]),
+                         "ranks_per_read": float(asum[3]) / total_reads, "sa_steps_per_read": float(asum[4]) / total_reads,
+                         "sides_per_read_rank0": float(asum[5]) / a.reads, "seed_reads_with_anchor": int(summ[0])},
+            "parity": parity,
         }
-        if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(base, reads, min(a.cpu_sample, a.reads))
+        if cpu_ref is not None:
+            out["cpu_baseline"] = cpu_ref
+            out["cpu_baseline_port"] = cpu_baseline(base, reads, min(200000, a.reads))
+        elif not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(base, reads, min(200000, a.reads))
         print(json.dumps(out))
     st.close()
     ix.close()

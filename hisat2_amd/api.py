@@ -87,7 +87,7 @@ class SeedParams(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("n_rank", u64), ("n_side", u64), ("n_sa_steps", u64), ("n_ext", u64), ("n_ref_bytes", u64),
                 ("n_queries", u64), ("n_aligned", u64), ("n_overflow", u64), ("ms_search", C.c_float),
-                ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float)]
+                ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_align_kernel", C.c_float)]
 
 
 ALN_CAP = 8

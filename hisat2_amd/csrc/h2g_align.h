@@ -12,6 +12,12 @@
 //   selectByScore aln_sink.h:2680   RandomSource random_source.h:33
 #pragma once
 #include "h2g_core.h"
+#if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+#include <stdio.h>
+#define AL_TRACE(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define AL_TRACE(...) do {} while(0)
+#endif
 
 namespace h2g {
 
@@ -47,6 +53,7 @@ struct GIdx {
 	H2G_HD bool is_zoff(uint32_t row) const { return g->nZ && row == g->zoff; }
 	H2G_HD void lohi(uint32_t fi, uint32_t* top, uint32_t* bot) const { *top = ftab_hi(*g, fi); *bot = ftab_lo(*g, fi + 1); }
 	H2G_HD uint32_t rank(uint32_t row, int c) const { return rank64(*g, row, c); }
+	H2G_HD uint32_t side_of(uint32_t row) const { return row / 192u; }
 	H2G_HD int rowL(uint32_t row) const {
 		uint32_t s0 = row / 192u;
 		return rowL_in_side64(load_side64(g->sides + (size_t)s0 * 64), row - s0 * 192u);
@@ -57,6 +64,7 @@ struct LIdx {
 	const DLocalDesc* d;
 	H2G_HD uint32_t ftabChars() const { return ls->ftabChars; }
 	H2G_HD bool is_zoff(uint32_t row) const { return d->nZ && row == d->zoff; }
+	H2G_HD uint32_t side_of(uint32_t row) const { return row / 224u; }
 	H2G_HD uint32_t fh(uint32_t i) const {   // ftabHi gfm.h:2618 with 16-bit words
 		uint32_t v = ls->words[d->ftab_off + i];
 		if(v <= d->len) return v;
@@ -93,7 +101,7 @@ struct LIdx {
 template <typename IDX>
 H2G_HD uint32_t gfm_search(const IDX& ix, const SeqView& seq, uint32_t rdoff, uint32_t* hitlen, uint32_t* top_o,
                            uint32_t* bot_o, bool* uniqueStop, uint32_t minUniqueLen, uint32_t maxHitLen, uint32_t maxHits,
-                           bool local, uint32_t* nrank)
+                           bool local, uint32_t* nrank /* [0] rank calls, [1] unique sides */)
 {
 	const bool uniqueStop_ = *uniqueStop;
 	*uniqueStop = false;
@@ -118,9 +126,9 @@ H2G_HD uint32_t gfm_search(const IDX& ix, const SeqView& seq, uint32_t rdoff, ui
 		int c = seq.at(len - dep - 1);
 		uint32_t ttop = 0, tbot = 0;
 		if(c <= 3) {
-			if(bot - top > 1) { *nrank += 2; ttop = ix.rank(top, c); tbot = ix.rank(bot, c); }
+			if(bot - top > 1) { nrank[0] += 2; nrank[1] += ix.side_of(top) == ix.side_of(bot) ? 1 : 2; ttop = ix.rank(top, c); tbot = ix.rank(bot, c); }
 			else {
-				*nrank += 1;
+				nrank[0] += 1; nrank[1] += 1;
 				if(ix.rowL(top) == c && !ix.is_zoff(top)) { ttop = ix.rank(top, c); tbot = ttop + 1; }
 			}
 		}
@@ -484,6 +492,7 @@ struct AlnParams {
 	uint32_t khits, kseeds, no_spliced, secondary;
 	uint32_t minIntronLen, maxIntronLen, minAnchorLen, minAnchorLen_noncan, minK_local;
 	uint32_t pseudogeneStop, anchorStop;
+	uint32_t maxFragLen;     // PairedEndPolicy::maxFragLen = -X (hisat2.cpp:345)
 	DScoring sc;
 };
 
@@ -516,19 +525,29 @@ struct RBHit {               // ReadBWTHit hi_aligner.h:216
 	PartialHit partial[AL_MAX_PARTIAL];
 };
 
+#define AL_MAX_PAIRS 32
+struct MateWS {              // per-mate state of HI_Aligner + the per-mate half of AlnSinkWrap
+	RBHit      rb[2];                            // _hits[rdi][fwi]
+	h2g_ghit   searched[AL_MAX_SEARCHED];        // _hits_searched[rdi]
+	uint32_t   nsearched;
+	AlnRec     res[AL_MAX_RESULTS];              // AlnSinkWrap rs1u_ / rs2u_
+	uint32_t   nres;
+	int64_t    bestUnp, best2Unp;                // bestUnp1_/bestUnp2_, best2Unp*_
+	int64_t    minsc;
+};
+
 struct AlignWS {
-	RBHit      rb[2];                            // _hits[0][fwi]
+	MateWS     m[2];
 	h2g_ghit   ghits[AL_MAX_GHITS];              // _genomeHits (hitcount lives in .read)
 	uint32_t   nghits;
 	uint8_t    ghit_done[AL_MAX_GHITS];
-	h2g_ghit   searched[AL_MAX_SEARCHED];        // _hits_searched[0]
-	uint32_t   nsearched;
-	AlnRec     res[AL_MAX_RESULTS];              // AlnSinkWrap rs1u_
-	uint32_t   nres;
-	int64_t    bestUnp1, best2Unp1;
+	// concordant pairs (AlnSinkWrap rs1_/rs2_ as indexes into m[0].res / m[1].res)
+	uint8_t    pair_i[AL_MAX_PAIRS], pair_j[AL_MAX_PAIRS];
+	uint32_t   npairs, insp_i, insp_j;           // _concordantIdxInspected
+	int64_t    bestPair, best2Pair;
 	uint64_t   localindexatts, max_localindexatts;
 	uint32_t   overflow;
-	uint32_t   nrank, nsteps, nframes_max;
+	uint32_t   nrank, nside, nsteps, nframes_max;   // nrank, nside adjacent: gfm_search updates both through &nrank
 	h2g_ghit   tmp, tmp2;                        // scratch hits
 	int64_t    sc1[256], sc2[256];               // combineWith temp_scores
 	Frame      stack[AL_MAX_DEPTH];
@@ -543,7 +562,7 @@ H2G_HD h2g_edit inverted_edit(const h2g_ghit* h, uint32_t k, uint32_t sz, uint32
 }
 
 // redundant hi_aligner.h:6311-6351
-H2G_HD bool al_redundant(const AlignWS* ws, const h2g_ghit* hit, uint32_t rdlen) {
+H2G_HD bool al_redundant(const MateWS* ws, const h2g_ghit* hit, uint32_t rdlen) {
 	for(uint32_t i = 0; i < ws->nres; i++) {
 		const AlnRec& r = ws->res[i];
 		if(r.tidx != hit->tidx || r.toff != hit->toff || r.fw != hit->fw) continue;
@@ -559,20 +578,21 @@ H2G_HD bool al_redundant(const AlignWS* ws, const h2g_ghit* hit, uint32_t rdlen)
 	return false;
 }
 
-H2G_HD bool al_is_searched(const AlignWS* ws, const h2g_ghit* hit) {
+H2G_HD bool al_is_searched(const MateWS* ws, const h2g_ghit* hit) {
 	for(uint32_t i = 0; i < ws->nsearched; i++) if(hit_equal(&ws->searched[i], hit)) return true;
 	return false;
 }
-H2G_HD void al_add_searched(AlignWS* ws, const h2g_ghit* hit) {
-	if(ws->nsearched >= AL_MAX_SEARCHED) { ws->overflow |= 2; return; }
+H2G_HD void al_add_searched(AlignWS* aw, MateWS* ws, const h2g_ghit* hit) {
+	if(ws->nsearched >= AL_MAX_SEARCHED) { aw->overflow |= 2; return; }
 	hit_copy(&ws->searched[ws->nsearched++], hit);
 }
 
 // reportHit hi_aligner.h:6064-6166 + AlnSinkWrap::report aln_sink.h:2565-2650 (unpaired mate 1)
-H2G_HD bool al_report(AlignWS* ws, const h2g_ghit* hit, uint32_t rdlen, int64_t minsc) {
+H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdlen, int64_t minsc) {
 	if(hit->rdoff - hit->trim5 > 0 || hit->len + hit->trim5 + hit->trim3 < rdlen) return false;
 	if(hit->score < minsc) return false;
-	if(ws->nres >= AL_MAX_RESULTS) { ws->overflow |= 4; return false; }
+	if(ws->nres >= AL_MAX_RESULTS) { aw->overflow |= 4; return false; }
+	AL_TRACE("  REPORT fw %u tidx %u toff %u len %u trim %u/%u score %lld nedits %u\n", hit->fw, hit->tidx, hit->toff, hit->len, hit->trim5, hit->trim3, (long long)hit->score, hit->nedits);
 	AlnRec& r = ws->res[ws->nres++];
 	r.fw = hit->fw; r.tidx = hit->tidx; r.toff = hit->toff; r.len = hit->len; r.trim5 = hit->trim5; r.trim3 = hit->trim3;
 	r.nedits = hit->nedits; r.pad = 0; r.score = hit->score;
@@ -580,8 +600,8 @@ H2G_HD bool al_report(AlignWS* ws, const h2g_ghit* hit, uint32_t rdlen, int64_t 
 		if(hit->fw) { r.edits[k] = hit->edits[k]; r.edits[k].pos += hit->trim5; }
 		else r.edits[k] = inverted_edit(hit, k, rdlen, hit->trim5);
 	}
-	if(hit->score > ws->bestUnp1) { ws->best2Unp1 = ws->bestUnp1; ws->bestUnp1 = hit->score; }
-	else if(hit->score > ws->best2Unp1) ws->best2Unp1 = hit->score;
+	if(hit->score > ws->bestUnp) { ws->best2Unp = ws->bestUnp; ws->bestUnp = hit->score; }
+	else if(hit->score > ws->best2Unp) ws->best2Unp = hit->score;
 	return true;
 }
 
@@ -589,8 +609,8 @@ H2G_HD bool al_report(AlignWS* ws, const h2g_ghit* hit, uint32_t rdlen, int64_t 
 H2G_HD bool ph_empty(const PartialHit& p) { return p.bot <= p.top; }
 
 // hi_aligner.h:5007-5193 for one (read, strand)
-H2G_HD uint32_t al_get_anchor_hits(const DGfm& g, const AlnParams& P, const SeqView& seq, AlignWS* ws, int fwi, Rng* rnd) {
-	RBHit& hit = ws->rb[fwi];
+H2G_HD uint32_t al_get_anchor_hits(const DGfm& g, const AlnParams& P, const SeqView& seq, AlignWS* ws, MateWS* mw, int fwi, Rng* rnd) {
+	RBHit& hit = mw->rb[fwi];
 	const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
 	const uint32_t minK = g.minK;
 	ws->nghits = 0;
@@ -720,14 +740,15 @@ H2G_HD void sort_coords(h2g_coord* c, uint32_t n) {   // Coord::operator< ref_co
 }
 
 // Runs hybridSearch_recur(hit, hitoff, hitlen) to completion; returns maxsc.
-H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, AlignWS* ws, const h2g_ghit* root, uint32_t hitoff0,
-                                      uint32_t hitlen0, int64_t minsc)
+H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, AlignWS* ws, MateWS* mw, const h2g_ghit* root,
+                                      uint32_t hitoff0, uint32_t hitlen0, int64_t minsc, bool alignMate)
 {
 	const AlnParams& P = *C.P;
 	const DScoring& sc = P.sc;
 	const uint32_t rdlen = seq.len, minK = C.g->minK, minK_local = P.minK_local;
 	const bool no_spliced = P.no_spliced != 0;
-	const int64_t cushion = 0;   // alignMate == false
+	// spliced_aligner.h:363-366: cushion = alignMate ? rdlen * 0.03 * sc.mm(255) : 0 (no_spliced_alignment only)
+	const int64_t cushion = (no_spliced && alignMate) ? (int64_t)((double)rdlen * 0.03 * (double)sc.mmpMax) : 0;
 	int sp = 0;
 	int64_t ret = INT64_MIN;
 	{
@@ -742,7 +763,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 		       if((uint32_t)sp + 1 > ws->nframes_max) ws->nframes_max = sp + 1; } \
 		goto next_iter; } while(0)
 #define AL_RET(V) do { ret = (V); sp--; goto next_iter; } while(0)
-#define AL_MINSC_LIVE(M) do { if(!P.secondary) { int64_t b_ = ws->bestUnp1 - cushion; if(b_ > (M)) (M) = b_; } } while(0)
+#define AL_MINSC_LIVE(M) do { if(!P.secondary) { int64_t b_ = mw->bestUnp - cushion; if(b_ > (M)) (M) = b_; } } while(0)
 
 	while(sp >= 0) {
 		{
@@ -752,16 +773,17 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 		const uint32_t dep = (uint32_t)sp;
 		switch(f.state) {
 		case ST_ENTRY: {
+			AL_TRACE("   recur dep %u fw %u hitoff %u hitlen %u (rdoff %u len %u) toff %u score %lld nedits %u mate %d\n", dep, hit.fw, hitoff, hitlen, hit.rdoff, hit.len, hit.toff, (long long)hit.score, hit.nedits, (int)alignMate);
 			f.maxsc = INT64_MIN;
 			if(hit.score + cushion < minsc) AL_RET(f.maxsc);
 			if(dep >= 128) AL_RET(f.maxsc);
 			if(hitoff == hit.rdoff - hit.trim5 && hitlen == hit.len + hit.trim5 + hit.trim3) {
-				if(al_is_searched(ws, &hit)) AL_RET(f.maxsc);
-				al_add_searched(ws, &hit);
+				if(al_is_searched(mw, &hit)) AL_RET(f.maxsc);
+				al_add_searched(ws, mw, &hit);
 			}
 			if(hitoff == 0 && hitlen == rdlen) {
-				if(!al_redundant(ws, &hit, rdlen)) {
-					al_report(ws, &hit, rdlen, minsc);
+				if(!al_redundant(mw, &hit, rdlen)) {
+					al_report(ws, mw, &hit, rdlen, minsc);
 					if(hit.score > f.maxsc) f.maxsc = hit.score;
 				}
 				AL_RET(f.maxsc);
@@ -1121,7 +1143,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 	return ret;
 }
 
-// ---------------------------------------------------------------------------------------- go() for one unpaired read
+// ---------------------------------------------------------------------------------------- go()
 // ReadBWTHit::searchScore hi_aligner.h:320-334
 H2G_HD int64_t rb_search_score(const RBHit& h, uint32_t minK) {
 	int64_t score = 0;
@@ -1132,110 +1154,276 @@ H2G_HD int64_t rb_search_score(const RBHit& h, uint32_t minK) {
 	return score;
 }
 
-// hi_aligner.h:4048 (go) / :4644 (nextBWT) / :4868 (pickNextReadToSearch) / :5484 (align) /
-// spliced_aligner.h:112 (hybridSearch), bowtie2_dp = 0.
-H2G_HD void al_go_unpaired(const AlnCtx& C, const DReads& rd, uint32_t read, int64_t minsc, AlignWS* ws, Rng* rndp)
+// reference extent of a reported alignment (AlnRes::refExtent): aligned read bases + read gaps - ref gaps
+H2G_HD uint32_t rec_ref_extent(const AlnRec& r) {
+	uint32_t ext = r.len;
+	for(uint32_t k = 0; k < r.nedits; k++) {
+		if(r.edits[k].type == H2G_EDIT_READ_GAP) ext++;
+		else if(r.edits[k].type == H2G_EDIT_REF_GAP) ext--;
+	}
+	return ext;
+}
+
+// PairedEndPolicy::peClassifyPair pe.cpp:38-133 with the hisat2 defaults (hisat2.cpp:344-352, 3239): --fr,
+// -I 0 -X 1000, no dovetail, containment and overlap allowed, expand-to-fit.  Returns true unless PE_ALS_DISCORD.
+H2G_HD bool pe_concordant(int64_t off1, uint32_t len1, bool fw1, int64_t off2, uint32_t len2, bool fw2, uint32_t maxfrag_) {
+	uint64_t maxfrag = maxfrag_;
+	if(len1 > maxfrag) maxfrag = len1;
+	if(len2 > maxfrag) maxfrag = len2;
+	const uint64_t minfrag = 1;
+	if(fw1 == fw2) return false;                 // PE_POLICY_FR
+	const bool oneLeft = fw1;
+	const int64_t fraglo = off1 < off2 ? off1 : off2;
+	const int64_t h1 = off1 + len1, h2 = off2 + len2;
+	const int64_t fraghi = h1 > h2 ? h1 : h2;
+	const uint64_t frag = (uint64_t)(fraghi - fraglo);
+	if(frag > maxfrag || frag < minfrag) return false;
+	const int64_t lo1 = off1, hi1 = off1 + len1 - 1, lo2 = off2, hi2 = off2 + len2 - 1;
+	const bool containment = (lo1 >= lo2 && hi1 <= hi2) || (lo2 >= lo1 && hi2 <= hi1);
+	const bool olap = (lo1 <= lo2 && hi1 >= lo2) || (lo1 <= hi2 && hi1 >= hi2) || containment;
+	if(!olap) { if((oneLeft && lo2 < lo1) || (!oneLeft && lo1 < lo2)) return false; }
+	if((oneLeft && (hi1 > hi2 || lo2 < lo1)) || (!oneLeft && (hi2 > hi1 || lo1 < lo2))) return false;   // dovetail not allowed
+	return true;
+}
+
+// pairReads hi_aligner.h:5948-6055 (non-repeat alignments, gMate1fw = true, gMate2fw = false)
+H2G_HD void al_pair_reads(const AlnParams& P, AlignWS* ws, uint32_t rdlen1, uint32_t rdlen2) {
+	MateWS& m1 = ws->m[0];
+	MateWS& m2 = ws->m[1];
+	const uint32_t start_i = ws->insp_i, start_j = ws->insp_j;
+	ws->insp_i = m1.nres; ws->insp_j = m2.nres;
+	for(uint32_t i = 0; i < m1.nres; i++) {
+		for(uint32_t j = (i >= start_i ? 0 : start_j); j < m2.nres; j++) {
+			const AlnRec& r1 = m1.res[i];
+			const AlnRec& r2 = m2.res[j];
+			if(r1.tidx != r2.tidx) continue;
+			const uint32_t e1 = rec_ref_extent(r1), e2 = rec_ref_extent(r2);
+			int64_t l = r1.toff, r = (int64_t)r1.toff + e1 - 1, l2 = r2.toff, rr2 = (int64_t)r2.toff + e2 - 1;
+			if(r1.fw) { if(r2.fw) continue; }
+			else {
+				if(!r2.fw) continue;
+				int64_t t = l; l = l2; l2 = t; t = r; r = rr2; rr2 = t;
+			}
+			if(l > l2) continue;
+			if(r > rr2) continue;
+			if(r + (int64_t)P.maxIntronLen < l2) continue;
+			bool pass = true;
+			if(P.no_spliced) {
+				if(r1.toff < r2.toff) pass = pe_concordant(r1.toff, e1, r1.fw != 0, r2.toff, e2, r2.fw != 0, P.maxFragLen);
+				else                  pass = pe_concordant(r2.toff, e2, r2.fw != 0, r1.toff, e1, r1.fw != 0, P.maxFragLen);
+			}
+			if(!P.no_spliced || pass) {
+				int64_t threshold = ws->bestPair;
+				if(m1.bestUnp >= m1.minsc && m2.bestUnp >= m2.minsc) {
+					int64_t tmp = (int64_t)((double)(m1.bestUnp + m2.bestUnp) - (double)(rdlen1 + rdlen2) * 0.03 * (double)P.sc.mmpMax);
+					if(tmp > threshold) threshold = tmp;
+				}
+				const int64_t score = r1.score + r2.score;
+				if(score >= threshold || P.secondary) {   // sink.report(0, &r1, &r2) aln_sink.h:2590-2612
+					if(ws->npairs < AL_MAX_PAIRS) { ws->pair_i[ws->npairs] = (uint8_t)i; ws->pair_j[ws->npairs] = (uint8_t)j; ws->npairs++; }
+					else ws->overflow |= 128;
+					if(score > ws->bestPair) { ws->best2Pair = ws->bestPair; ws->bestPair = score; }
+					else if(score > ws->best2Pair) ws->best2Pair = score;
+				}
+			}
+		}
+	}
+}
+
+// hybridSearch spliced_aligner.h:112-322 (bowtie2_dp = 0) over ws->ghits
+H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw) {
+	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
+		uint32_t le = H2G_MAX, re = H2G_MAX;
+		extend_item(*C.ref, C.P->sc, sv, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
+		ws->ghit_done[hi] = 0;
+	}
+	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
+		uint32_t hj = 0;
+		for(; hj < ws->nghits; hj++) if(!ws->ghit_done[hj]) break;
+		if(hj >= ws->nghits) break;
+		for(uint32_t hk = hj + 1; hk < ws->nghits; hk++) {
+			if(ws->ghit_done[hk]) continue;
+			const h2g_ghit& a = ws->ghits[hj];
+			const h2g_ghit& b = ws->ghits[hk];
+			if(b.read > a.read || (b.read == a.read && b.len > a.len)) hj = hk;
+		}
+		al_hybrid_search_recur(C, sv, ws, mw, &ws->ghits[hj], ws->ghits[hj].rdoff, ws->ghits[hj].len, mw->minsc, false);
+		ws->ghit_done[hj] = 1;
+	}
+}
+
+// align hi_aligner.h:5484-5573
+H2G_HD bool al_align(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw, int fwi, Rng* rnd) {
+	const AlnParams& P = *C.P;
+	RBHit& hit = mw->rb[fwi];
+	bool any = false;
+	for(uint32_t i = 0; i < hit.npartial; i++) if(!ph_empty(hit.partial[i])) { any = true; break; }
+	if(!any) return false;                                    // minWidth() == max
+	int64_t bestScore = mw->bestUnp;
+	if(bestScore < mw->minsc) bestScore = mw->minsc;
+	const uint32_t maxmm = (uint32_t)((-bestScore + P.sc.mmpMax - 1) / P.sc.mmpMax);
+	const uint32_t nact = hit.numPartialSearch - hit.numUniqueSearch;
+	if(!P.secondary && nact > maxmm + 0 + 1) return true;
+	uint32_t numHits = al_get_anchor_hits(*C.g, P, sv, ws, mw, fwi, rnd);
+	if(numHits == 0) return false;
+	uint64_t add = (uint64_t)((-mw->minsc) / P.sc.mmpMax) * numHits * (P.secondary ? 2 : 1);
+	ws->max_localindexatts = ws->localindexatts + (add > 10 ? add : 10);
+	al_hybrid_search(C, sv, ws, mw);
+	return true;
+}
+
+// alignMate hi_aligner.h:5579-5770: anchor the OTHER mate (ordi) near (tidx, toff) through the local index
+H2G_HD void al_align_mate(const AlnCtx& C, const SeqView& ord, AlignWS* ws, MateWS* omw, bool fw, uint32_t tidx, uint32_t toff, Rng* rnd) {
+	const AlnParams& P = *C.P;
+	const uint32_t rdlen = ord.len, minK_local = P.minK_local;
+	ws->nghits = 0;
+	uint32_t lidx = local_index_of(*C.ls, tidx, toff);
+	bool first = true;
+	uint32_t count = 0, max_hitlen = 0;
+	while(count++ < 2) {
+		if(first) first = false;
+		else {
+			if(ws->nghits > 0) break;
+			if(lidx != H2G_MAX) lidx = fw ? local_index_next(*C.ls, lidx) : local_index_prev(*C.ls, lidx);
+			if(lidx == H2G_MAX || C.ls->desc[lidx].len == 0) break;
+		}
+		if(lidx == H2G_MAX) break;
+		LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
+		uint32_t hitoff = rdlen - 1;
+		while(hitoff >= minK_local - 1) {
+			uint32_t hitlen = 0, top = H2G_MAX, bot = H2G_MAX;
+			bool uniqueStop = false;
+			uint32_t nelt = C.ls->desc[lidx].len == 0 ? 0 :
+			                gfm_search(lx, ord, hitoff, &hitlen, &top, &bot, &uniqueStop, minK_local, 0xffffu, P.kseeds, true, &ws->nrank);
+			if(nelt > 0 && nelt <= P.kseeds && hitlen > max_hitlen) {
+				h2g_coord co[AL_MAX_COORDS];
+				uint32_t nco = 0;
+				genome_coords_local(lx, top, bot, hitoff - hitlen + 1, hitlen, co, AL_MAX_COORDS, &nco, &ws->nsteps);
+				ws->nghits = 0;
+				for(uint32_t ri = 0; ri < nco; ri++) {
+					if(P.no_spliced) {
+						if((uint64_t)co[ri].toff + (uint64_t)P.maxFragLen * 2 < toff || (uint64_t)toff + (uint64_t)P.maxFragLen * 2 < co[ri].toff) continue;
+					}
+					if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], ord.fw, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff);
+					else ws->overflow |= 64;
+				}
+				max_hitlen = hitlen;
+			}
+			if(hitlen > 0) hitoff -= (hitlen - 1);
+			if(hitoff > 0) hitoff -= 1;
+		}
+	}
+	// (genomeHits never exceeds kseeds here: nelt <= kseeds)
+	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
+		uint32_t le = H2G_MAX, re = H2G_MAX;
+		extend_item(*C.ref, P.sc, ord, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
+		hit_copy(&ws->tmp2, &ws->ghits[hi]);
+		al_hybrid_search_recur(C, ord, ws, omw, &ws->tmp2, ws->tmp2.rdoff, ws->tmp2.len, omw->minsc, true);
+	}
+	(void)rnd;
+}
+
+// hi_aligner.h:4048 (go) / :4644 (nextBWT) / :4868 (pickNextReadToSearch); rds[1] == nullptr for an unpaired read
+H2G_HD void al_go(const AlnCtx& C, const DReads* const rds[2], uint32_t read, AlignWS* ws, Rng* rndp, int slot0 = 0)
 {
 	const AlnParams& P = *C.P;
-	SeqView fwv = seq_view(rd, read, true);
+	const bool paired = rds[1] != nullptr;
+	const int nm = paired ? 2 : 1;
 	const uint32_t minK = C.g->minK;
 	Rng& rnd = *rndp;
-	ws->nghits = 0; ws->nsearched = 0; ws->nres = 0; ws->overflow = 0; ws->nrank = 0; ws->nsteps = 0; ws->nframes_max = 0;
-	ws->bestUnp1 = INT64_MIN; ws->best2Unp1 = INT64_MIN;
+	ws->nghits = 0; ws->overflow = 0; ws->nrank = 0; ws->nside = 0; ws->nsteps = 0; ws->nframes_max = 0;
+	ws->npairs = 0; ws->insp_i = 0; ws->insp_j = 0; ws->bestPair = INT64_MIN; ws->best2Pair = INT64_MIN;
 	ws->localindexatts = 0; ws->max_localindexatts = 0;
-	for(int k = 0; k < 2; k++) {
-		RBHit& h = ws->rb[k];
-		h.len = fwv.len; h.cur = 0; h.done = 0; h.numPartialSearch = 0; h.numUniqueSearch = 0; h.npartial = 0;
+	uint32_t rdlens[2] = {0, 0};
+	for(int r = 0; r < 2; r++) {
+		MateWS& mw = ws->m[r ^ slot0];
+		mw.nsearched = 0; mw.nres = 0; mw.bestUnp = INT64_MIN; mw.best2Unp = INT64_MIN; mw.minsc = INT64_MAX;
+		if(r < nm) {
+			SeqView v = seq_view(*rds[r], read, true);
+			rdlens[r] = v.len;
+			// scoreMin.f<TAlScore>(len), SIMPLE_FUNC_LINEAR 0, -0.2 (hisat2.cpp:440, simple_func.h:88)
+			int64_t minsc = (int64_t)(0.0 + (double)(-0.2f) * (double)v.len);
+			if(minsc > 0) minsc = 0;
+			mw.minsc = minsc;
+			for(int k = 0; k < 2; k++) {
+				RBHit& h = mw.rb[k];
+				h.len = v.len; h.cur = 0; h.done = 0; h.numPartialSearch = 0; h.numUniqueSearch = 0; h.npartial = 0;
+			}
+		}
 	}
-	bool found[2] = {true, true};
+	bool found[2][2] = {{true, true}, {paired, paired}};
 	while(true) {
 		// ---------------- nextBWT ----------------
-		int sel = -1;
+		int sel_r = -1, sel_f = -1;
 		while(true) {
-			// pickNextReadToSearch
-			int fwi = -1;
+			int rdi = -1, fwi = -1;
 			int64_t maxScore = INT64_MIN;
-			for(int k = 0; k < 2; k++) {
-				if(ws->rb[k].done) continue;
-				int64_t cs = rb_search_score(ws->rb[k], minK);
-				if(ws->rb[k].cur == 0) cs = INT64_MAX;
-				if(cs > maxScore) { maxScore = cs; fwi = k; }
+			for(int r = 0; r < nm; r++) for(int k = 0; k < 2; k++) {
+				const RBHit& h = ws->m[r ^ slot0].rb[k];
+				if(h.done) continue;
+				int64_t cs = rb_search_score(h, minK);
+				if(h.cur == 0) cs = INT64_MAX;
+				if(cs > maxScore) { maxScore = cs; rdi = r; fwi = k; }
 			}
-			if(fwi < 0) break;
-			RBHit& hit = ws->rb[fwi];
-			RBHit& rchit = ws->rb[1 - fwi];
+			if(rdi < 0) break;
+			MateWS& mw = ws->m[rdi ^ slot0];
+			MateWS& ow = ws->m[(1 - rdi) ^ slot0];
+			RBHit& hit = mw.rb[fwi];
+			RBHit& rchit = mw.rb[1 - fwi];
+			bool ret_false = false, cont = false;
 			if(!P.secondary) {
 				const uint32_t numSearched = hit.numPartialSearch - hit.numUniqueSearch;
-				const int64_t bestScore = ws->bestUnp1;
-				if(bestScore >= minsc) {
+				const int64_t bestScore = mw.bestUnp;
+				if(bestScore >= mw.minsc) {
 					const uint32_t maxmm = (uint32_t)((-bestScore + P.sc.mmpMax - 1) / P.sc.mmpMax);
-					if(numSearched > maxmm + 0 + 1) { hit.done = 1; break; }               // return false
+					if(numSearched > maxmm + 0 + 1) {
+						hit.done = 1;
+						if(paired) { if(ow.bestUnp >= ow.minsc && ws->npairs > 0) ret_false = true; else cont = true; }
+						else ret_false = true;
+					}
 				}
-				if(rchit.done && bestScore < minsc) {
-					if(numSearched > (rchit.numPartialSearch - rchit.numUniqueSearch) + (P.anchorStop ? 1u : 0u)) { hit.done = 1; break; }
+				if(!ret_false && !cont && rchit.done && bestScore < mw.minsc) {
+					if(numSearched > (rchit.numPartialSearch - rchit.numUniqueSearch) + (P.anchorStop ? 1u : 0u)) { hit.done = 1; ret_false = true; }
 				}
 			}
-			SeqView sv = seq_view(rd, read, fwi == 0);
+			if(ret_false) break;
+			if(cont) continue;
+			SeqView sv = seq_view(*rds[rdi], read, fwi == 0);
 			h2g_fm_hit fh;
 			partial_search_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &fh);
-			ws->nrank += fh.nrank;
+			AL_TRACE("  psearch rdi %d fwi %d cur %u -> top %u bot %u len %u type %u cur %u done %u anchor %u\n", rdi, fwi, hit.cur, fh.top, fh.bot, fh.len, fh.hit_type, fh.cur, fh.done, fh.anchorStop);
+			ws->nrank += fh.nrank; ws->nside += fh.nside;
 			hit.numPartialSearch += 1; hit.numUniqueSearch += fh.numUniqueSearch; hit.cur = fh.cur;
 			if(hit.npartial < AL_MAX_PARTIAL) {
 				PartialHit& p = hit.partial[hit.npartial++];
 				p.top = fh.top; p.bot = fh.bot; p.bwoff = fh.bwoff; p.len = fh.len; p.hit_type = fh.hit_type; p.ncoords = 0;
 			} else { ws->overflow |= 32; hit.done = 1; break; }
-			if(fh.done) { hit.done = 1; sel = fwi; break; }
+			if(fh.done) { hit.done = 1; sel_r = rdi; sel_f = fwi; break; }
 			if(!fh.pseudogeneStop) { if(hit.cur + 1 < hit.len) hit.cur++; }
-			if(fh.anchorStop) { hit.done = 1; sel = fwi; break; }
+			if(fh.anchorStop) { hit.done = 1; sel_r = rdi; sel_f = fwi; break; }
 		}
-		if(sel < 0) break;
-		const int fwi = sel;
-		SeqView sv = seq_view(rd, read, fwi == 0);
-		// ---------------- align (hi_aligner.h:5484-5573) ----------------
-		bool fnd;
-		{
-			RBHit& hit = ws->rb[fwi];
-			bool any = false;
-			for(uint32_t i = 0; i < hit.npartial; i++) if(!ph_empty(hit.partial[i])) { any = true; break; }
-			if(!any) fnd = false;                                    // minWidth() == max
-			else {
-				int64_t bestScore = ws->bestUnp1;
-				if(bestScore < minsc) bestScore = minsc;
-				const uint32_t maxmm = (uint32_t)((-bestScore + P.sc.mmpMax - 1) / P.sc.mmpMax);
-				const uint32_t nact = hit.numPartialSearch - hit.numUniqueSearch;
-				if(!P.secondary && nact > maxmm + 0 + 1) fnd = true;
-				else {
-					uint32_t numHits = al_get_anchor_hits(*C.g, P, sv, ws, fwi, &rnd);
-					if(numHits == 0) fnd = false;
-					else {
-						uint64_t add = (uint64_t)((-minsc) / P.sc.mmpMax) * numHits * (P.secondary ? 2 : 1);
-						ws->max_localindexatts = ws->localindexatts + (add > 10 ? add : 10);
-						// hybridSearch spliced_aligner.h:112-322
-						for(uint32_t hi = 0; hi < ws->nghits; hi++) {
-							uint32_t le = H2G_MAX, re = H2G_MAX;
-							extend_item(*C.ref, P.sc, sv, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
-							ws->ghit_done[hi] = 0;
-						}
-						for(uint32_t hi = 0; hi < ws->nghits; hi++) {
-							uint32_t hj = 0;
-							for(; hj < ws->nghits; hj++) if(!ws->ghit_done[hj]) break;
-							if(hj >= ws->nghits) break;
-							for(uint32_t hk = hj + 1; hk < ws->nghits; hk++) {
-								if(ws->ghit_done[hk]) continue;
-								const h2g_ghit& a = ws->ghits[hj];
-								const h2g_ghit& b = ws->ghits[hk];
-								if(b.read > a.read || (b.read == a.read && b.len > a.len)) hj = hk;
-							}
-							al_hybrid_search_recur(C, sv, ws, &ws->ghits[hj], ws->ghits[hj].rdoff, ws->ghits[hj].len, minsc);
-							ws->ghit_done[hj] = 1;
-						}
-						fnd = true;
-					}
-				}
+		if(sel_r < 0) break;
+		SeqView sv = seq_view(*rds[sel_r], read, sel_f == 0);
+		found[sel_r][sel_f] = al_align(C, sv, ws, &ws->m[sel_r ^ slot0], sel_f, &rnd);
+		AL_TRACE(" align rdi %d fwi %d -> found %d nghits %u\n", sel_r, sel_f, (int)found[sel_r][sel_f], ws->nghits);
+		if(!found[0][0] && !found[0][1] && !found[1][0] && !found[1][1]) break;
+		if(paired) al_pair_reads(P, ws, rdlens[0], rdlens[1]);
+	}
+	// no concordant pair: use each mate's alignments as anchors for the other mate (hi_aligner.h:4092-4148)
+	if(paired && ws->npairs == 0 && (ws->m[0].bestUnp >= ws->m[0].minsc || ws->m[1].bestUnp >= ws->m[1].minsc)) {
+		bool mate_found = false;
+		const uint32_t rs_size[2] = {ws->m[0].nres, ws->m[1].nres};
+		for(int i = 0; i < 2; i++) {
+			for(uint32_t j = 0; j < rs_size[i]; j++) {
+				const bool fw = ws->m[i].res[j].fw != 0;
+				const uint32_t tidx = ws->m[i].res[j].tidx, toff = ws->m[i].res[j].toff;
+				SeqView ord = seq_view(*rds[1 - i], read, !fw);   // ofw = (fw == gMate2fw ? gMate1fw : gMate2fw) = !fw
+				AL_TRACE(" alignMate anchor mate %d res %u fw %d toff %u\n", i, j, (int)fw, toff);
+				al_align_mate(C, ord, ws, &ws->m[1 - i], fw, tidx, toff, &rnd);
+				mate_found = true;
 			}
 		}
-		found[fwi] = fnd;
-		if(!found[0] && !found[1]) break;
+		if(mate_found) al_pair_reads(P, ws, rdlens[0], rdlens[1]);
 	}
 }
 
@@ -1250,7 +1438,7 @@ H2G_HD int64_t hisat2_score(const AlnRec& r) {   // AlnScore::calculate_hisat2_s
 	return (int64_t)((uint64_t)score << 32) | (0ll << 28) | (0ll << 24) | (255ll << 16) | trim;
 }
 
-H2G_HD uint32_t al_select(const AlignWS* ws, const AlnParams& P, Rng* rnd, uint8_t* select) {
+H2G_HD uint32_t al_select(const MateWS* ws, const AlnParams& P, Rng* rnd, uint8_t* select) {
 	const uint32_t sz = ws->nres;
 	if(sz < 1) return 0;
 	uint32_t num = P.khits < sz ? P.khits : sz;
@@ -1292,20 +1480,55 @@ H2G_HD uint32_t al_select(const AlignWS* ws, const AlnParams& P, Rng* rnd, uint8
 // Whole per-read pipeline of the worker loop body (hisat2.cpp:3380-3640) for an unpaired read that passed
 // the filters: seed the PRNG, go(), select.
 struct ReadOut {
-	uint32_t nres, nselect, overflow, nrank, nsteps, depth;
+	uint32_t nres, nselect, overflow, nrank, nsteps, depth, nside;
 	uint8_t  select[AL_MAX_RESULTS];
 };
 
+// Scoring::nFilter scoring.cpp:104 with the effective default nCeil = L,0,0.15 (SeedAlignmentPolicy::parseString
+// aligner_seed_policy.cpp:294-296 overrides hisat2.cpp:443) + the length filter (hisat2.cpp:3413)
+H2G_HD bool read_passes_filters(const SeqView& v) {
+	if(v.len < 2) return false;
+	const uint32_t maxns = (uint32_t)(0.0 + (double)0.15f * (double)v.len);
+	uint32_t ns = 0;
+	for(uint32_t i = 0; i < v.len; i++) if(v.fwc[i] == 4) { if(++ns > maxns) return false; }
+	return true;
+}
+
 H2G_HD void al_read(const AlnCtx& C, const DReads& rd, uint32_t read, const char* name, uint32_t namelen, AlignWS* ws, ReadOut* out) {
 	SeqView fwv = seq_view(rd, read, true);
-	// scoreMin.f<TAlScore>(len), SIMPLE_FUNC_LINEAR 0, -0.2 (hisat2.cpp:440, simple_func.h:88)
-	int64_t minsc = (int64_t)(0.0 + (double)(-0.2f) * (double)fwv.len);
-	if(minsc > 0) minsc = 0;
 	Rng rnd;
-	rnd.init(gen_rand_seed(fwv, name, namelen, 0));
-	al_go_unpaired(C, rd, read, minsc, ws, &rnd);
-	out->nres = ws->nres; out->overflow = ws->overflow; out->nrank = ws->nrank; out->nsteps = ws->nsteps; out->depth = ws->nframes_max;
-	out->nselect = al_select(ws, *C.P, &rnd, out->select);
+	rnd.init(gen_rand_seed(fwv, name, namelen, 0));                // rnd.init(ps->bufa().seed) hisat2.cpp:3468
+	const DReads* rds[2] = {&rd, nullptr};
+	if(!read_passes_filters(fwv)) {                                // filt[0] false: go() is skipped (hisat2.cpp:3518)
+		ws->m[0].nres = 0; ws->overflow = 0; ws->nrank = 0; ws->nsteps = 0; ws->nframes_max = 0; ws->nside = 0;
+	} else
+	al_go(C, rds, read, ws, &rnd);
+	out->nres = ws->m[0].nres; out->overflow = ws->overflow; out->nrank = ws->nrank; out->nsteps = ws->nsteps; out->depth = ws->nframes_max; out->nside = ws->nside;
+	out->nselect = al_select(&ws->m[0], *C.P, &rnd, out->select);
+}
+
+// Paired read: rnd.init(seedA ^ seedB) (hisat2.cpp:3464-3466), go() with both mates.  The concordant /
+// discordant / unpaired classification and selection of finishRead stay on the host: the
+// caller replays the returned report events into its sink and continues the PRNG from `rnd_state`.
+struct PairOut {
+	uint32_t nres[2], npairs, overflow, nrank, nsteps, depth, nside, rnd_state, pad;
+	uint8_t  pair_i[AL_MAX_PAIRS], pair_j[AL_MAX_PAIRS];
+};
+
+H2G_HD void al_pair(const AlnCtx& C, const DReads& rd1, const DReads& rd2, uint32_t read, const char* name1, uint32_t namelen1,
+                    const char* name2, uint32_t namelen2, AlignWS* ws, PairOut* out) {
+	SeqView v1 = seq_view(rd1, read, true), v2 = seq_view(rd2, read, true);
+	Rng rnd;
+	const bool f1 = read_passes_filters(v1), f2 = read_passes_filters(v2);
+	const uint32_t s1 = gen_rand_seed(v1, name1, namelen1, 0), s2 = gen_rand_seed(v2, name2, namelen2, 0);
+	rnd.init((f1 && f2) ? (s1 ^ s2) : s1);                       // hisat2.cpp:3463-3468
+	ws->m[0].nres = 0; ws->m[1].nres = 0; ws->npairs = 0; ws->overflow = 0; ws->nrank = 0; ws->nsteps = 0; ws->nframes_max = 0; ws->nside = 0;
+	if(f1 && f2) { const DReads* rds[2] = {&rd1, &rd2}; al_go(C, rds, read, ws, &rnd); }
+	else if(f1)  { const DReads* rds[2] = {&rd1, nullptr}; al_go(C, rds, read, ws, &rnd, 0); }     // initRead(rds[0]) hisat2.cpp:3522
+	else if(f2)  { const DReads* rds[2] = {&rd2, nullptr}; al_go(C, rds, read, ws, &rnd, 1); }     // initRead(rds[1], rightendonly) :3524
+	out->nres[0] = ws->m[0].nres; out->nres[1] = ws->m[1].nres; out->npairs = ws->npairs; out->overflow = ws->overflow;
+	out->nrank = ws->nrank; out->nsteps = ws->nsteps; out->depth = ws->nframes_max; out->nside = ws->nside; out->rnd_state = rnd.last; out->pad = 0;
+	for(uint32_t k = 0; k < ws->npairs; k++) { out->pair_i[k] = ws->pair_i[k]; out->pair_j[k] = ws->pair_j[k]; }
 }
 
 }  // namespace h2g

@@ -47,7 +47,13 @@ struct DReads {
 	const uint32_t* offs;    // [n+1]
 	const char*     quals;   // phred+33 or nullptr (FASTA => 'I')
 	uint32_t n;
+	// optional per-lane LDS copy of ONE read (k_align): H2G_PK_WORDS 2-bit words then H2G_PK_WORDS/2 N-mask words,
+	// word k of this lane at pk[k * pk_stride] (lane-interleaved => conflict-free ds_read_b32)
+	const uint32_t* pk = nullptr;
+	uint32_t pk_stride = 0, pk_read = 0xffffffffu;
 };
+#define H2G_PK_WORDS 16          // 256 bases
+#define H2G_PK_MAXLEN (H2G_PK_WORDS * 16)
 
 struct DScoring {  // Scoring defaults scoring.h:29-87 / hisat2.cpp:425-441
 	int mmpMax = 6, mmpMin = 2, nPen = 1, rdGapConst = 5, rdGapLinear = 3, rfGapConst = 5, rfGapLinear = 3;
@@ -60,9 +66,16 @@ struct SeqView {
 	const char*    q;
 	uint32_t       len;
 	bool           fw;
+	const uint32_t* pk = nullptr;
+	uint32_t       pk_stride = 0;
 	H2G_HD int at(uint32_t i) const {
-		if(fw) return fwc[i];
-		int c = fwc[len - 1 - i];
+		const uint32_t j = fw ? i : len - 1 - i;
+		int c;
+		if(pk) {
+			c = (int)((pk[(j >> 4) * pk_stride] >> ((j & 15) * 2)) & 3u);
+			if((pk[(H2G_PK_WORDS + (j >> 5)) * pk_stride] >> (j & 31)) & 1u) c = 4;
+		} else c = fwc[j];
+		if(fw) return c;
 		return c < 4 ? 3 - c : 4;
 	}
 	H2G_HD int qual(uint32_t i) const {   // qual / qualRev
@@ -78,6 +91,7 @@ H2G_HD SeqView seq_view(const DReads& r, uint32_t read, bool fw) {
 	s.q = r.quals ? r.quals + a : nullptr;
 	s.len = r.offs[read + 1] - a;
 	s.fw = fw;
+	if(r.pk && r.pk_read == read) { s.pk = r.pk; s.pk_stride = r.pk_stride; }
 	return s;
 }
 
@@ -341,9 +355,11 @@ struct RefCursor {
 	int64_t lo, hi;        // cached interval [lo, hi)
 	uint32_t bufbase;      // buf offset of lo when inside a record
 	bool inrec;
+	uint64_t cw;           // 32 cached bases (one aligned 8 B word of the 2-bit payload)
+	uint64_t cblk;
 	H2G_HD void init(const DRef* r_, uint32_t tidx) {
 		r = r_; reci = r->refRecOffs[tidx]; recf = r->refRecOffs[tidx + 1];
-		lo = 0; hi = 0; bufbase = 0; inrec = false;
+		lo = 0; hi = 0; bufbase = 0; inrec = false; cw = 0; cblk = ~0ull;
 	}
 	H2G_HD void locate(int64_t pos) {
 		// last record whose start <= pos
@@ -365,8 +381,10 @@ struct RefCursor {
 	H2G_HD int get(int64_t pos) {
 		if(pos < lo || pos >= hi) locate(pos);
 		if(!inrec) return 4;
-		uint64_t bo = (uint64_t)bufbase + (uint64_t)(pos - lo);
-		return (r->buf[bo >> 2] >> ((bo & 3) << 1)) & 3;
+		const uint64_t bo = (uint64_t)bufbase + (uint64_t)(pos - lo);
+		const uint64_t blk = bo >> 5;
+		if(blk != cblk) { memcpy(&cw, r->buf + blk * 8, 8); cblk = blk; }   // buf is 256 B-aligned and padded
+		return (int)((cw >> ((bo & 31) << 1)) & 3);
 	}
 };
 

@@ -244,8 +244,8 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
 	for(int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&s->ev[i]));
-	HIPCHK(hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(s->d_counters, 0, 8 * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&s->d_counters, 16 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->d_counters, 0, 16 * sizeof(unsigned long long)));
 	if(max_reads) {
 		HIPCHK(hipMalloc((void**)&s->d_codes, max_bases + 64));
 		HIPCHK(hipMalloc((void**)&s->d_quals, max_bases + 64));
@@ -702,19 +702,81 @@ static_assert(sizeof(h2g_read_result) == 24, "h2g_read_result layout");
 
 // One lane = one read at a time (grid-stride); each lane owns one AlignWS in HBM (explicit recursion stack,
 // sink, searched list).  Selected alignments are written in print order.
-__global__ __launch_bounds__(256) void k_align(DGfm g, DRef ref, DLocalSet ls, DReads rd, AlnParams P, const char* names,
+#define H2G_NCLASS 96
+// Outcome class of one read from the seed stage (2 strands x {no anchor, anchored + full-length 0-mismatch extension,
+// anchored + partial extension (bucketed by length)}).
+__device__ __forceinline__ uint32_t seed_class(const h2g_seed_result* r, uint32_t rdlen) {
+	uint32_t key = 0;
+	for(int k = 0; k < 2; k++) {
+		uint32_t c = 0;
+		if(r[k].ncoords > 0) {
+			const uint32_t len = r[k].ext[0].len;
+			if(len == rdlen && r[k].ext[0].score == 0 && r[k].ncoords == 1) c = 1;
+			else c = 2 + (r[k].ncoords > 1 ? 4 : 0) + (len * 4 / (rdlen + 1));   // 2..9
+		}
+		key = key * 10 + c;
+	}
+	return key < H2G_NCLASS ? key : H2G_NCLASS - 1;
+}
+__global__ void k_classify(const h2g_seed_result* seed, const uint32_t* offs, uint32_t n, uint8_t* keys, uint32_t* hist) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	uint32_t k = seed_class(seed + 2 * (size_t)i, offs[i + 1] - offs[i]);
+	keys[i] = (uint8_t)k;
+	atomicAdd(&hist[k], 1u);
+}
+__global__ void k_class_scan(uint32_t* hist) {   // exclusive scan of H2G_NCLASS counters -> bucket cursors
+	if(threadIdx.x != 0) return;
+	uint32_t run = 0;
+	for(int k = 0; k < H2G_NCLASS; k++) { uint32_t v = hist[k]; hist[k] = run; run += v; }
+}
+__global__ void k_class_scatter(const uint8_t* keys, uint32_t n, uint32_t* cursor, uint32_t* perm) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	perm[atomicAdd(&cursor[keys[i]], 1u)] = i;
+}
+
+// `perm` (optional) lists read ids bucketed by the outcome class of the seed stage, so that the 64 lanes of a
+// wave walk similar control flow (k_classify below); results are written by read id, so order is irrelevant.
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref, DLocalSet ls, DReads rd, AlnParams P, const char* names,
                                                const uint32_t* name_offs, AlignWS* pool, ReadOut* outs, h2g_alnres* aln,
-                                               unsigned long long* counters)
+                                               unsigned long long* counters, const uint32_t* perm)
 {
 	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	AlignWS* ws = pool + tid;
 	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
-	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0;
-	for(size_t i = tid; i < rd.n; i += stride) {
+	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0, nside = 0;
+	// per-lane packed copy of the current read in LDS: the byte-per-base global reads of the search / extension
+	// loops become conflict-free ds_read_b32 (word k of lane t at [k][t])
+	__shared__ uint32_t s_pk[(H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256];
+	DReads rdl = rd;
+	rdl.pk = s_pk + threadIdx.x;
+	rdl.pk_stride = 256;
+	for(size_t j = tid; j < rd.n; j += stride) {
+		const size_t i = perm ? perm[j] : j;
 		ReadOut o;
 		const uint32_t a = name_offs[i], b = name_offs[i + 1];
-		al_read(C, rd, (uint32_t)i, names + a, b - a, ws, &o);
+		{
+			const uint32_t ro = rd.offs[i], rl = rd.offs[i + 1] - ro;
+			rdl.pk_read = 0xffffffffu;
+			if(rl <= H2G_PK_MAXLEN) {
+				for(uint32_t w = 0; w < (rl + 15) / 16; w++) {
+					uint32_t bits = 0, mask = 0;
+					for(uint32_t k = 0; k < 16 && w * 16 + k < rl; k++) {
+						const uint32_t c = rd.codes[ro + w * 16 + k];
+						bits |= (c & 3u) << (2 * k);
+						mask |= (c > 3u ? 1u : 0u) << k;
+					}
+					s_pk[w * 256 + threadIdx.x] = bits;
+					uint32_t& mw = s_pk[(H2G_PK_WORDS + (w >> 1)) * 256 + threadIdx.x];
+					mw = (w & 1) ? (mw | (mask << 16)) : mask;
+				}
+				rdl.pk_read = (uint32_t)i;
+			}
+		}
+		al_read(C, rdl, (uint32_t)i, names + a, b - a, ws, &o);
 		outs[i] = o;
 		for(uint32_t k = 0; k < o.nselect && k < H2G_ALN_CAP; k++) {
 			const AlnRec& r = ws->res[o.select[k]];
@@ -723,9 +785,10 @@ __global__ __launch_bounds__(256) void k_align(DGfm g, DRef ref, DLocalSet ls, D
 			d.nedits = r.nedits; d.pad = 0; d.score = r.score;
 			for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
 		}
-		nrank += o.nrank; nsteps += o.nsteps; naln += o.nselect > 0; novf += o.overflow != 0;
+		nrank += o.nrank; nsteps += o.nsteps; naln += o.nselect > 0; novf += o.overflow != 0; nside += o.nside;
 	}
 	wave_add(counters + 0, nrank);
+	wave_add(counters + 1, nside);
 	wave_add(counters + 2, nsteps);
 	wave_add(counters + 4, naln);
 	wave_add(counters + 5, novf);
@@ -769,7 +832,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	// 2 waves per SIMD on every CU: enough lanes to cover HBM latency, bounded workspace (sizeof(AlignWS) each)
 	const unsigned block = 256;
 	size_t want = (s->n_reads + block - 1) / block;
-	const size_t maxblocks = 256 * 2;
+	const size_t maxblocks = 256 * (size_t)(getenv("H2G_ALIGN_OCC") ? (atoi(getenv("H2G_ALIGN_OCC")) >= 4 ? 4 : atoi(getenv("H2G_ALIGN_OCC")) == 3 ? 3 : 2) : 4);
 	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	const size_t nthreads = (size_t)grid * block;
 	if(s->ws_threads < nthreads) {
@@ -788,8 +851,36 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	(void)hipGetLastError();
 	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
-	hipLaunchKernelGGL(k_align, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-	                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters);
+	const uint32_t* perm = nullptr;
+	static const int sort_mode = getenv("H2G_ALIGN_SORT") ? atoi(getenv("H2G_ALIGN_SORT")) : 0;
+	static const int occ_mode = getenv("H2G_ALIGN_OCC") ? atoi(getenv("H2G_ALIGN_OCC")) : 4;
+	if(sort_mode) {
+		// seed stage (partialSearch both strands from offset 0 -> coordinates -> 0-mm extension) as a classifier
+		h2g_seed_params sp;
+		sp.pseudogeneStop = 0; sp.anchorStop = 1; sp.khits = p->khits; sp.search_variant = 0;
+		const size_t n2 = s->n_reads * 2;
+		void *dkeys, *dhist, *dperm;
+		if((rc = tmp_buf(s, 0, s->n_reads, &dkeys)) || (rc = tmp_buf(s, 1, H2G_NCLASS * 4, &dhist)) || (rc = tmp_buf(s, 2, s->n_reads * 4, &dperm))) return rc;
+		DScoring sc;
+		hipLaunchKernelGGL(k_seed_search, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), sp, s->d_seed, s->d_counters + 6);
+		hipLaunchKernelGGL(k_seed_resolve_extend, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dr, dreads(s), sc, s->d_seed, s->d_counters + 6);
+		HIPCHK(hipMemsetAsync(dhist, 0, H2G_NCLASS * 4, s->st));
+		const unsigned cg = (unsigned)((s->n_reads + 255) / 256);
+		hipLaunchKernelGGL(k_classify, dim3(cg), dim3(256), 0, s->st, (const h2g_seed_result*)s->d_seed, (const uint32_t*)s->d_offs, (uint32_t)s->n_reads, (uint8_t*)dkeys, (uint32_t*)dhist);
+		hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s->st, (uint32_t*)dhist);
+		hipLaunchKernelGGL(k_class_scatter, dim3(cg), dim3(256), 0, s->st, (const uint8_t*)dkeys, (uint32_t)s->n_reads, (uint32_t*)dhist, (uint32_t*)dperm);
+		perm = (const uint32_t*)dperm;
+	}
+	HIPCHK(hipEventRecord(s->ev[7], s->st));
+	if(occ_mode >= 4)
+		hipLaunchKernelGGL(k_align<4>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm);
+	else if(occ_mode == 3)
+		hipLaunchKernelGGL(k_align<3>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm);
+	else
+		hipLaunchKernelGGL(k_align<2>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm);
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;
@@ -823,6 +914,7 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 		if(hipEventElapsedTime(&t, s->ev[3], s->ev[4]) == hipSuccess) s->last.ms_resolve_extend = t;
 	}
 	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[6]) == hipSuccess) s->last.ms_align = t;
+	if(s->ran_align && hipEventElapsedTime(&t, s->ev[7], s->ev[6]) == hipSuccess) s->last.ms_align_kernel = t;
 	(void)hipGetLastError();
 	*c = s->last;
 	return H2G_OK;

@@ -188,6 +188,7 @@ H2G_EXPORT h2g_status h2g_align_fetch(h2g_stream*, h2g_read_result* res /* [n] *
 typedef struct {
 	uint64_t n_rank, n_side, n_sa_steps, n_ext, n_ref_bytes, n_queries, n_aligned, n_overflow;
 	float    ms_search, ms_resolve_extend, ms_rank, ms_align;   /* HIP-event durations of the last launches */
+	float    ms_align_kernel;                                   /* k_align alone (ms_align includes the classifier stage) */
 } h2g_counters;
 H2G_EXPORT h2g_status h2g_get_counters(h2g_stream*, h2g_counters*);
 

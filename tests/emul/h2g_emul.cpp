@@ -109,12 +109,33 @@ void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t
 	AlnParams P;
 	P.khits = 5; P.kseeds = 10; P.no_spliced = no_spliced; P.secondary = 0;
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
-	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1;
+	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
 	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
 	AlignWS* ws = new AlignWS();
 	for(uint32_t i = 0; i < rd.n; i++) {
 		al_read(C, rd, i, names + name_offs[i], name_offs[i + 1] - name_offs[i], ws, &outs[i]);
-		for(uint32_t k = 0; k < ws->nres; k++) recs[(size_t)i * AL_MAX_RESULTS + k] = ws->res[k];
+		for(uint32_t k = 0; k < ws->m[0].nres; k++) recs[(size_t)i * AL_MAX_RESULTS + k] = ws->m[0].res[k];
+	}
+	delete ws;
+}
+
+
+// paired go(): mate 2 passed separately; names1/names2 as in the FASTA files
+void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, const uint32_t* offs2, const char* names1,
+                        const uint32_t* noffs1, const char* names2, const uint32_t* noffs2, PairOut* outs, AlnRec* recs1, AlnRec* recs2) {
+	DReads rd1 = e->reads();
+	DReads rd2 = rd1;
+	rd2.codes = codes2; rd2.offs = offs2; rd2.quals = nullptr;
+	AlnParams P;
+	P.khits = 5; P.kseeds = 10; P.no_spliced = no_spliced; P.secondary = 0;
+	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
+	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
+	AlignWS* ws = new AlignWS();
+	for(uint32_t i = 0; i < rd1.n; i++) {
+		al_pair(C, rd1, rd2, i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &outs[i]);
+		for(uint32_t k = 0; k < ws->m[0].nres; k++) recs1[(size_t)i * AL_MAX_RESULTS + k] = ws->m[0].res[k];
+		for(uint32_t k = 0; k < ws->m[1].nres; k++) recs2[(size_t)i * AL_MAX_RESULTS + k] = ws->m[1].res[k];
 	}
 	delete ws;
 }

@@ -22,7 +22,12 @@ p = st.seed_params(True)
 for _ in range(3):
     st.seed_extend_run(p)
 st.sync()
+st.set_read_names([str(i) for i in range(nreads)])
+for _ in range(2):
+    st.align_run()
+st.sync()
 c = st.counters()
+print("align: %.3f ms, n_rank %d n_side %d n_sa_steps %d aligned %d overflow %d" % (c.ms_align, c.n_rank, c.n_side, c.n_sa_steps, c.n_aligned, c.n_overflow))
 print("seed stage: search %.3f ms, resolve+extend %.3f ms, n_side %d n_sa_steps %d" % (c.ms_search, c.ms_resolve_extend, c.n_side, c.n_sa_steps))
 rix = api.Index(synth_sides=15_300_000, seed=bench.SEED)
 rst = api.Stream(rix)
