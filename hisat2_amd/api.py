@@ -106,6 +106,15 @@ class AlignParams(C.Structure):
     _fields_ = [("khits", u32), ("kseeds", u32), ("no_spliced_alignment", u32), ("secondary", u32)]
 
 
+PAIR_RES_CAP = 16
+PAIR_CAP = 32
+
+
+class PairResult(C.Structure):
+    _fields_ = [("nres", u32 * 2), ("npairs", u32), ("overflow", u32), ("nrank", u32), ("nsteps", u32), ("depth", u32),
+                ("nside", u32), ("rnd_state", u32), ("pad", u32), ("pair_i", u8 * PAIR_CAP), ("pair_j", u8 * PAIR_CAP)]
+
+
 READ_RESULT_DTYPE = np.dtype([(n, np.uint32) for n in ("nres", "nselect", "overflow", "nrank", "nsteps", "depth")])
 
 
@@ -123,6 +132,7 @@ EXPORTS = [
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_align_params_init", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
+    "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch",
 ]
 
 
@@ -170,6 +180,9 @@ def lib():
     L.h2g_set_read_names.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.h2g_align_run.argtypes = [vp, P(AlignParams)]
     L.h2g_align_fetch.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
+    L.h2g_set_mates.argtypes = [vp, vp, vp, vp, C.c_char_p, vp, C.c_size_t]
+    L.h2g_align_pairs_run.argtypes = [vp, P(AlignParams)]
+    L.h2g_align_pairs_fetch.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t]
     _lib = L
     return L
 
@@ -299,6 +312,26 @@ class Stream:
         aln = (AlnRes * (n * ALN_CAP))() if with_alignments else None
         _chk(lib().h2g_align_fetch(self.h, res.ctypes.data, aln, first, n), "h2g_align_fetch")
         return res, aln
+
+    def set_mates(self, codes2, offs2, qnames2, quals2=None):
+        codes2 = np.ascontiguousarray(codes2, dtype=np.uint8)
+        offs2 = np.ascontiguousarray(offs2, dtype=np.uint32)
+        nb = "".join(qnames2).encode()
+        noffs = np.concatenate([[0], np.cumsum([len(q) for q in qnames2])]).astype(np.uint32)
+        q = None if quals2 is None else np.ascontiguousarray(quals2, dtype=np.uint8).ctypes.data
+        _chk(lib().h2g_set_mates(self.h, codes2.ctypes.data, offs2.ctypes.data, q, nb, noffs.ctypes.data, len(offs2) - 1), "h2g_set_mates")
+
+    def align_pairs_run(self, params=None):
+        params = params or self.align_params()
+        _chk(lib().h2g_align_pairs_run(self.h, C.byref(params)), "h2g_align_pairs_run")
+
+    def align_pairs_fetch(self, first=0, n=None, with_alignments=True):
+        n = self.n_reads - first if n is None else n
+        res = (PairResult * n)()
+        a1 = (AlnRes * (n * PAIR_RES_CAP))() if with_alignments else None
+        a2 = (AlnRes * (n * PAIR_RES_CAP))() if with_alignments else None
+        _chk(lib().h2g_align_pairs_fetch(self.h, res, a1, a2, first, n), "h2g_align_pairs_fetch")
+        return res, a1, a2
 
     def hip_stream(self):
         return lib().h2g_stream_hip(self.h)

@@ -500,7 +500,7 @@ struct AlnParams {
 struct AlnRec {
 	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, pad;
 	int64_t  score;
-	h2g_edit edits[H2G_MAX_EDITS];   // as stored in the AlnRes: pos += trim5; positions inverted when !fw
+	h2g_edit edits[H2G_MAX_EDITS];   // as stored in the AlnRes: 5'-to-3' positions of the ORIGINAL read relative to the first aligned base
 };
 
 struct Frame {
@@ -596,9 +596,13 @@ H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdl
 	AlnRec& r = ws->res[ws->nres++];
 	r.fw = hit->fw; r.tidx = hit->tidx; r.toff = hit->toff; r.len = hit->len; r.trim5 = hit->trim5; r.trim3 = hit->trim3;
 	r.nedits = hit->nedits; r.pad = 0; r.score = hit->score;
+	// reportHit shifts by trim5 and inverts for !fw (hi_aligner.h:6093-6101); AlnRes::setShape then shifts the
+	// stored copy by the 5' trim in read orientation (aligner_result.cpp:110-118)
+	const uint32_t trim5p = hit->fw ? hit->trim5 : hit->trim3;
 	for(uint32_t k = 0; k < hit->nedits; k++) {
 		if(hit->fw) { r.edits[k] = hit->edits[k]; r.edits[k].pos += hit->trim5; }
 		else r.edits[k] = inverted_edit(hit, k, rdlen, hit->trim5);
+		r.edits[k].pos -= trim5p;
 	}
 	if(hit->score > ws->bestUnp) { ws->best2Unp = ws->bestUnp; ws->bestUnp = hit->score; }
 	else if(hit->score > ws->best2Unp) ws->best2Unp = hit->score;

@@ -55,6 +55,14 @@ struct h2g_stream {
 	size_t ws_threads = 0;
 	ReadOut* d_rout = nullptr;
 	h2g_alnres* d_aln = nullptr;
+	uint8_t* d_codes2 = nullptr;
+	uint32_t* d_offs2 = nullptr;
+	char* d_quals2 = nullptr;
+	char* d_names2 = nullptr;
+	uint32_t* d_name_offs2 = nullptr;
+	bool has_mates = false, has_quals2 = false;
+	PairOut* d_pout = nullptr;
+	h2g_alnres* d_paln[2] = {nullptr, nullptr};
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t tmp_sz[4] = {0, 0, 0, 0};
@@ -262,7 +270,8 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws);
-	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln);
+	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
+	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 8; i++) (void)hipEventDestroy(s->ev[i]);
 	(void)hipStreamDestroy(s->st);
@@ -298,6 +307,7 @@ extern "C" h2g_status h2g_set_reads(h2g_stream* s, const uint8_t* codes, const u
 	HIPCHK(hipStreamSynchronize(s->st));
 	s->n_reads = n;
 	s->has_names = false;
+	s->has_mates = false;
 	return H2G_OK;
 }
 
@@ -779,7 +789,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref,
 		al_read(C, rdl, (uint32_t)i, names + a, b - a, ws, &o);
 		outs[i] = o;
 		for(uint32_t k = 0; k < o.nselect && k < H2G_ALN_CAP; k++) {
-			const AlnRec& r = ws->res[o.select[k]];
+			const AlnRec& r = ws->m[0].res[o.select[k]];
 			h2g_alnres& d = aln[i * H2G_ALN_CAP + k];
 			d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
 			d.nedits = r.nedits; d.pad = 0; d.score = r.score;
@@ -847,7 +857,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	AlnParams P;
 	P.khits = p->khits; P.kseeds = p->kseeds; P.no_spliced = 1; P.secondary = p->secondary;
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
-	P.pseudogeneStop = 0; P.anchorStop = 1;
+	P.pseudogeneStop = 0; P.anchorStop = 1; P.maxFragLen = 1000;
 	(void)hipGetLastError();
 	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
@@ -897,6 +907,144 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 		res[i].nres = tmp[i].nres; res[i].nselect = tmp[i].nselect; res[i].overflow = tmp[i].overflow;
 		res[i].nrank = tmp[i].nrank; res[i].nsteps = tmp[i].nsteps; res[i].depth = tmp[i].depth;
 	}
+	return H2G_OK;
+}
+
+// ------------------------------------------------------------------------------------------ paired go()
+static_assert(sizeof(h2g_pair_result) == sizeof(PairOut), "h2g_pair_result must mirror PairOut");
+static_assert(H2G_PAIR_CAP == AL_MAX_PAIRS, "pair capacity");
+
+// lane = one read pair; both mates are packed into LDS (mate 2 behind mate 1)
+__global__ __launch_bounds__(256, 3) void k_align_pairs(DGfm g, DRef ref, DLocalSet ls, DReads rd1, DReads rd2, AlnParams P,
+                                                        const char* names1, const uint32_t* noffs1, const char* names2,
+                                                        const uint32_t* noffs2, AlignWS* pool, PairOut* outs, h2g_alnres* aln1,
+                                                        h2g_alnres* aln2, unsigned long long* counters)
+{
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	AlignWS* ws = pool + tid;
+	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
+	unsigned long long nrank = 0, nsteps = 0, npair = 0, novf = 0, nside = 0;
+	__shared__ uint32_t s_pk[2 * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256];
+	DReads rl[2] = {rd1, rd2};
+	for(int m = 0; m < 2; m++) { rl[m].pk = s_pk + m * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256 + threadIdx.x; rl[m].pk_stride = 256; }
+	for(size_t i = tid; i < rd1.n; i += stride) {
+		for(int m = 0; m < 2; m++) {
+			const DReads& rd = m == 0 ? rd1 : rd2;
+			uint32_t* pk = s_pk + m * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256;
+			const uint32_t ro = rd.offs[i], rlen = rd.offs[i + 1] - ro;
+			rl[m].pk_read = 0xffffffffu;
+			if(rlen <= H2G_PK_MAXLEN) {
+				for(uint32_t w = 0; w < (rlen + 15) / 16; w++) {
+					uint32_t bits = 0, mask = 0;
+					for(uint32_t k = 0; k < 16 && w * 16 + k < rlen; k++) {
+						const uint32_t c = rd.codes[ro + w * 16 + k];
+						bits |= (c & 3u) << (2 * k);
+						mask |= (c > 3u ? 1u : 0u) << k;
+					}
+					pk[w * 256 + threadIdx.x] = bits;
+					uint32_t& mw = pk[(H2G_PK_WORDS + (w >> 1)) * 256 + threadIdx.x];
+					mw = (w & 1) ? (mw | (mask << 16)) : mask;
+				}
+				rl[m].pk_read = (uint32_t)i;
+			}
+		}
+		PairOut o;
+		al_pair(C, rl[0], rl[1], (uint32_t)i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &o);
+		outs[i] = o;
+		for(int m = 0; m < 2; m++) {
+			h2g_alnres* dst = (m == 0 ? aln1 : aln2) + i * H2G_PAIR_RES_CAP;
+			const uint32_t n = o.nres[m] < H2G_PAIR_RES_CAP ? o.nres[m] : H2G_PAIR_RES_CAP;
+			for(uint32_t k = 0; k < n; k++) {
+				const AlnRec& r = ws->m[m].res[k];
+				h2g_alnres& d = dst[k];
+				d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
+				d.nedits = r.nedits; d.pad = 0; d.score = r.score;
+				for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
+			}
+		}
+		nrank += o.nrank; nsteps += o.nsteps; npair += o.npairs > 0; nside += o.nside;
+		novf += (o.overflow != 0 || o.nres[0] > H2G_PAIR_RES_CAP || o.nres[1] > H2G_PAIR_RES_CAP);
+	}
+	wave_add(counters + 0, nrank);
+	wave_add(counters + 1, nside);
+	wave_add(counters + 2, nsteps);
+	wave_add(counters + 4, npair);
+	wave_add(counters + 5, novf);
+}
+
+extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const uint32_t* offs2, const char* quals2,
+                                    const char* nb2, const uint32_t* noffs2, size_t n)
+{
+	if(!s || !codes2 || !offs2 || !nb2 || !noffs2 || n != s->n_reads || n == 0) return H2G_ERR_ARG;
+	if(offs2[n] > s->max_bases) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	if(!s->d_codes2) {
+		HIPCHK(hipMalloc((void**)&s->d_codes2, s->max_bases + 64));
+		HIPCHK(hipMalloc((void**)&s->d_quals2, s->max_bases + 64));
+		HIPCHK(hipMalloc((void**)&s->d_offs2, (s->max_reads + 1) * 4));
+		HIPCHK(hipMalloc((void**)&s->d_name_offs2, (s->max_reads + 1) * 4));
+	}
+	(void)hipFree(s->d_names2); s->d_names2 = nullptr;
+	HIPCHK(hipMalloc((void**)&s->d_names2, noffs2[n] + 64));
+	HIPCHK(hipMemcpyAsync(s->d_codes2, codes2, offs2[n], hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(s->d_offs2, offs2, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
+	s->has_quals2 = quals2 != nullptr;
+	if(quals2) HIPCHK(hipMemcpyAsync(s->d_quals2, quals2, offs2[n], hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(s->d_names2, nb2, noffs2[n], hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(s->d_name_offs2, noffs2, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	s->has_mates = true;
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params* p) {
+	if(!s || !p) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
+	if(!s->has_names || !s->has_mates) { snprintf(g_err, sizeof g_err, "align_pairs: names (h2g_set_read_names) and mates (h2g_set_mates) required"); return H2G_ERR_ARG; }
+	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
+	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > AL_MAX_GHITS || p->kseeds < p->khits) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	const unsigned block = 256;
+	size_t want = (s->n_reads + block - 1) / block;
+	const size_t maxblocks = 256 * 3;
+	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
+	const size_t nthreads = (size_t)grid * block;
+	if(s->ws_threads < nthreads) {
+		(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_threads = 0;
+		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * sizeof(AlignWS)));
+		s->ws_threads = nthreads;
+	}
+	if(!s->d_pout) {
+		HIPCHK(hipMalloc((void**)&s->d_pout, s->max_reads * sizeof(PairOut)));
+		for(int m = 0; m < 2; m++) HIPCHK(hipMalloc((void**)&s->d_paln[m], s->max_reads * (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres)));
+	}
+	AlnParams P;
+	P.khits = p->khits; P.kseeds = p->kseeds; P.no_spliced = 1; P.secondary = p->secondary;
+	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
+	P.pseudogeneStop = 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	DReads r1 = dreads(s), r2 = r1;
+	r2.codes = s->d_codes2; r2.offs = s->d_offs2; r2.quals = s->has_quals2 ? s->d_quals2 : nullptr;
+	(void)hipGetLastError();
+	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
+	HIPCHK(hipEventRecord(s->ev[5], s->st));
+	HIPCHK(hipEventRecord(s->ev[7], s->st));
+	hipLaunchKernelGGL(k_align_pairs, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
+	                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters);
+	HIPCHK(hipEventRecord(s->ev[6], s->st));
+	HIPCHK(hipGetLastError());
+	s->ran_align = true;
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) {
+	if(!s || !res || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
+	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
+	if(aln1) HIPCHK(hipMemcpyAsync(aln1, s->d_paln[0] + first * H2G_PAIR_RES_CAP, n * H2G_PAIR_RES_CAP * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
+	if(aln2) HIPCHK(hipMemcpyAsync(aln2, s->d_paln[1] + first * H2G_PAIR_RES_CAP, n * H2G_PAIR_RES_CAP * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
 	return H2G_OK;
 }
 

@@ -164,7 +164,8 @@ H2G_EXPORT h2g_status h2g_seed_extend_fetch(h2g_stream*, h2g_seed_result* out, s
 typedef struct {                   /* == the arguments reportHit (hi_aligner.h:6064-6166) passes to AlnRes::init */
 	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, pad;
 	int64_t  score;                /* AS:i */
-	h2g_edit edits[H2G_MAX_EDITS]; /* 5'-relative read positions, inverted for !fw, as stored in the AlnRes */
+	h2g_edit edits[H2G_MAX_EDITS]; /* as stored in the AlnRes (aligner_result.cpp:110-118): positions along the original read
+	                                * 5'->3', relative to its first aligned (non-soft-clipped) base */
 } h2g_alnres;
 typedef struct {
 	uint32_t nres;                 /* alignments reported to the sink (rs1u_) */
@@ -183,6 +184,26 @@ H2G_EXPORT h2g_status h2g_set_read_names(h2g_stream*, const char* bytes, const u
 H2G_EXPORT h2g_status h2g_align_run(h2g_stream*, const h2g_align_params*);           /* async on the stream */
 H2G_EXPORT h2g_status h2g_align_fetch(h2g_stream*, h2g_read_result* res /* [n] */, h2g_alnres* aln /* [n*H2G_ALN_CAP] or NULL */,
                                       size_t first_read, size_t n_reads);
+
+/* ---- paired-end: HI_Aligner::go with both mates (initReads hi_aligner.h:4019; pairReads :5948; alignMate :5579) -- */
+/* Mate 2 of every read of the batch (same count as h2g_set_reads); names2 feed genRandSeed of mate 2. */
+H2G_EXPORT h2g_status h2g_set_mates(h2g_stream*, const uint8_t* codes2, const uint32_t* offs2, const char* quals2,
+                                    const char* name_bytes2, const uint32_t* name_offs2, size_t n_reads);
+#define H2G_PAIR_RES_CAP 16       /* unpaired alignments returned per mate */
+#define H2G_PAIR_CAP 32           /* concordant pairs returned per read pair */
+typedef struct {
+	uint32_t nres[2];              /* sink.report(mate) events per mate, in report order (rs1u_/rs2u_) */
+	uint32_t npairs;               /* sink.report(r1, r2) events, in report order (rs1_/rs2_) */
+	uint32_t overflow, nrank, nsteps, depth, nside;
+	uint32_t rnd_state;            /* RandomSource::last after go(): the sink's selectByScore continues from it */
+	uint32_t pad;
+	uint8_t  pair_i[H2G_PAIR_CAP], pair_j[H2G_PAIR_CAP];   /* indexes into the two per-mate lists */
+} h2g_pair_result;
+/* The concordant / discordant / unpaired decision, -k selection, MAPQ and SAM stay in the caller's AlnSinkWrap
+ * (aln_sink.h:1939): it replays these events through msinkwrap.report() and calls finishRead(). */
+H2G_EXPORT h2g_status h2g_align_pairs_run(h2g_stream*, const h2g_align_params*);
+H2G_EXPORT h2g_status h2g_align_pairs_fetch(h2g_stream*, h2g_pair_result* res /* [n] */, h2g_alnres* aln1 /* [n*H2G_PAIR_RES_CAP] */,
+                                            h2g_alnres* aln2 /* [n*H2G_PAIR_RES_CAP] */, size_t first_read, size_t n_reads);
 
 /* ---- counters (roofline numerators) ------------------------------------------------- */
 typedef struct {

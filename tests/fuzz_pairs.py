@@ -54,7 +54,7 @@ def parse_pe_sam(path):
 
 
 def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, gaps=2, frag_mean=300, frag_sd=30, verbose=6,
-             backend=None):
+             backend=None, stride=16):
     tmp = tempfile.mkdtemp(prefix="h2pe")
     contigs = synth.make_genome(list(lens), seed, n_gaps=gaps, gap_len=300, repeats=repeats, repeat_len=500)
     fa = os.path.join(tmp, "g.fa")
@@ -74,7 +74,7 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     bad = ovf = setbad = 0
     ncon = 0
     for i in range(npairs):
-        got = PS.finish_pair(outs[i], r1, r2, i * SU.AL_MAX_RESULTS, refnames, (rdlen, rdlen))
+        got = PS.finish_pair(outs[i], r1, r2, i * (stride if backend else SU.AL_MAX_RESULTS), refnames, (rdlen, rdlen))
         w = want[q[i]]
         ncon += 1 if (w[0][0] & 2) else 0
         ovf += 1 if outs[i].overflow else 0

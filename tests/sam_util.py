@@ -43,9 +43,8 @@ def parse_sam(path):
 def cigar_of(rec: AlnRec, rdlen):
     """CIGAR in reference-forward orientation from the stored edit list (5'-relative, inverted when !fw)."""
     eds = [(rec.edits[k].pos, rec.edits[k].type) for k in range(rec.nedits)]
-    if not rec.fw:   # undo Edit::invertPoss
-        eds = [((rdlen - p) if t == 1 else (rdlen - p - 1), t) for p, t in reversed(eds)]
-    eds = [(p - rec.trim5, t) for p, t in eds]
+    if not rec.fw:   # stored 5'->3' along the original read, relative to the first aligned base: mirror within len
+        eds = [((rec.len - p) if t == 1 else (rec.len - p - 1), t) for p, t in reversed(eds)]
     ops = []
 
     def add(op, n=1):

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header(tmp_path):
                "h2g_sa_result": api.SaResult, "h2g_edit": api.Edit, "h2g_ghit": api.GHit, "h2g_ext_args": api.ExtArgs,
                "h2g_ext_result": api.ExtResult, "h2g_seed_result": api.SeedResult, "h2g_seed_params": api.SeedParams,
                "h2g_counters": api.Counters, "h2g_alnres": api.AlnRes, "h2g_read_result": api.ReadResult,
-               "h2g_align_params": api.AlignParams}
+               "h2g_align_params": api.AlignParams, "h2g_pair_result": api.PairResult}
     src = tmp_path / "sz.c"
     body = "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in structs)
     src.write_text(f'#include <stdio.h>\n#include "{HDR}"\nint main(void){{{body}return 0;}}\n')

@@ -1,0 +1,39 @@
+"""GPU paired-end go() parity (-m gpu): h2g_align_pairs_run through the C ABI; the report events are fed to the
+host-side finishRead mirror (tests/pe_sink.py) and every SAM line (FLAG incl. pairing bits, RNAME, POS, CIGAR, AS:i,
+line order) is compared with oracle/_ref/hisat2-align-s -1/-2 output."""
+import os
+
+import pytest
+
+import fuzz_pairs as F
+from hisat2_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _backend(base, m1, m2, q1, q2):
+    c1, o1 = synth.flatten_reads(m1)
+    c2, o2 = synth.flatten_reads(m2)
+    ix = api.Index(base, device=0)
+    st = api.Stream(ix, max_reads=len(m1), max_bases=c1.size)
+    st.set_reads(c1, o1)
+    st.set_read_names(q1)
+    st.set_mates(c2, o2, q2)
+    st.align_pairs_run()
+    res, a1, a2 = st.align_pairs_fetch()
+    st.close()
+    ix.close()
+    return res, a1, a2
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("case", [
+    dict(seed=301, npairs=20000, rdlen=101, sub=0.01),
+    dict(seed=302, npairs=8000, rdlen=101, sub=0.04),
+    dict(seed=303, npairs=8000, rdlen=75, sub=0.02, frag_mean=400, frag_sd=250),
+    dict(seed=304, npairs=6000, rdlen=150, sub=0.02, lens=(200000, 80000), repeats=150, gaps=4),
+])
+def test_live_reference_pairs(case):
+    bad, _ = F.run_case(verbose=3, backend=_backend, stride=api.PAIR_RES_CAP, **case)
+    assert bad == 0
