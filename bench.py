@@ -83,22 +83,31 @@ def cpu_reference(base, reads, sample, nver):
     tmp = tempfile.mkdtemp(prefix="h2bench")
     fa = os.path.join(tmp, "sample.fa")
     synth.write_reads_fasta(fa, reads[:sample])
-    cores = os.cpu_count() or 1
-    cmd = [exe, "-f", "--no-spliced-alignment", "-p", str(cores), "-x", base, "-U", fa, "-S", "/dev/null"]
-    t0 = time.perf_counter()
-    subprocess.run(cmd + ["-u", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    t_load = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    dt = time.perf_counter() - t0 - t_load
+    ncpu = os.cpu_count() or 1
+    # the reference's reader/writer locks stop scaling long before 256 threads (127 k reads/s at -p 8 on
+    # a cache-resident index), so scan a few thread counts on the bounded sample and report the best one
+    scan = {}
+    best = None
+    for pth in [t for t in (1, 4, 16, 64) if t <= ncpu]:
+        cmd = [exe, "-f", "--no-spliced-alignment", "-p", str(pth), "-x", base, "-U", fa, "-S", "/dev/null"]
+        t0 = time.perf_counter()
+        subprocess.run(cmd + ["-u", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_load = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = max(time.perf_counter() - t0 - t_load, 1e-6)
+        scan[str(pth)] = sample / dt
+        if best is None or sample / dt > best[0]:
+            best = (sample / dt, pth, dt, t_load)
+    cores, dt, t_load = best[1], best[2], best[3]
     sam = os.path.join(tmp, "ver.sam")
     subprocess.run([exe, "-f", "--no-spliced-alignment", "-p", "1", "-x", base, "-U", fa, "-u", str(nver), "-S", sam],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refnames, want = SU.parse_sam(sam)
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
-    return ({"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
-             "sample": f"first {sample} reads of the bench batch, oracle/_ref/hisat2-align-s -p {cores} --no-spliced-alignment -S /dev/null, {dt:.2f} s (index load {t_load:.2f} s subtracted)"},
+    return ({"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "reference", "host_cpus": ncpu, "threads_scan_reads_per_s": scan,
+             "sample": f"first {sample} reads of the bench batch, oracle/_ref/hisat2-align-s -p {cores} --no-spliced-alignment -S /dev/null, {dt:.2f} s (index load {t_load:.2f} s subtracted); best of the thread counts scanned"},
             (refnames, want))
 
 
@@ -118,10 +127,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--genome-len", type=int, default=4_900_000)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--rank-queries", type=int, default=1 << 26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=5000)
+    ap.add_argument("--pairs", type=int, default=500_000)
     a = ap.parse_args()
 
     import torch
@@ -232,6 +242,43 @@ def main():
                            "against": "oracle/_ref/hisat2-align-s (FLAG, RNAME, POS, CIGAR, AS:i per line)"})
             if nbad:
                 raise SystemExit(f"bench.py: {nbad} of {len(ares)} reads differ from the reference SAM")
+        # paired-end extra (BASELINE north star is PE): 500 k pairs = the same 1 M reads, HI_Aligner::go with pairReads /
+        # alignMate on the GPU; the first 2000 pairs are checked line-by-line against the reference's -1/-2 SAM
+        pe = None
+        if a.pairs > 0:
+            import fuzz_pairs as FP
+            import pe_sink as PS
+            m1, m2 = synth.make_pairs(contigs, a.pairs, 101, SEED + 77, sub_rate=0.005)
+            c1, o1 = synth.flatten_reads(m1)
+            c2, o2 = synth.flatten_reads(m2)
+            qn = [str(i) for i in range(a.pairs)]
+            pst = api.Stream(ix, max_reads=a.pairs, max_bases=c1.size)
+            pst.set_reads(c1, o1); pst.set_read_names(qn); pst.set_mates(c2, o2, qn)
+            pst.align_pairs_run(); pst.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                pst.align_pairs_run()
+            pst.sync()
+            pdt = (time.perf_counter() - t0) / 3
+            pc = pst.counters()
+            pe = {"pairs": a.pairs, "ms_per_step": pdt * 1e3, "pairs_per_s": a.pairs / pdt, "reads_per_s": 2 * a.pairs / pdt,
+                  "kernel_ms": float(pc.ms_align), "pairs_with_concordant": int(pc.n_aligned), "pairs_overflow": int(pc.n_overflow)}
+            exe = os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")
+            if os.path.exists(exe) and not a.no_cpu_baseline:
+                import tempfile, shutil
+                nv = min(2000, a.pairs)
+                tmp = tempfile.mkdtemp(prefix="h2benchpe")
+                synth.write_reads_fasta(os.path.join(tmp, "1.fa"), m1[:nv]); synth.write_reads_fasta(os.path.join(tmp, "2.fa"), m2[:nv])
+                subprocess.run([exe, "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", os.path.join(tmp, "1.fa"), "-2",
+                                os.path.join(tmp, "2.fa"), "-S", os.path.join(tmp, "pe.sam")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                rn, want = FP.parse_pe_sam(os.path.join(tmp, "pe.sam"))
+                pres, pa1, pa2 = pst.align_pairs_fetch(0, nv)
+                nbad = sum(1 for i in range(nv) if PS.finish_pair(pres[i], pa1, pa2, i * api.PAIR_RES_CAP, rn, (101, 101)) != want[str(i)])
+                shutil.rmtree(tmp, ignore_errors=True)
+                pe.update({"sam_checked_pairs": nv, "sam_mismatching_pairs": nbad})
+                if nbad:
+                    raise SystemExit(f"bench.py: {nbad} of {nv} pairs differ from the reference SAM")
+            pst.close()
         out = {
             "metric": "reads/sec, 101 bp SE (whole job): HI_Aligner::go per read on the GPU, bit-identical FLAG/POS/CIGAR/AS",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -245,6 +292,7 @@ def main():
             "roofline": roofline,
             "rank_microbench": {"sides": 15_300_000, "bytes": 15_300_000 * 64, "queries": a.rank_queries, **micro},
             "seed_stage": seed_stage,
+            "paired_end": pe,
             "counters": {"reads_aligned": int(asum[0]), "reads_multi": int(asum[1]), "reads_overflow": int(asum[2]),
                          "ranks_per_read": float(asum[3]) / total_reads, "sa_steps_per_read": float(asum[4]) / total_reads,
                          "sides_per_read_rank0": float(asum[5]) / a.reads, "seed_reads_with_anchor": int(summ[0])},

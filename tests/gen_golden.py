@@ -9,6 +9,7 @@ for a small seeded genome ("g1"):
                                   outputs of the reference classes via oracle/ref_probe.cpp
   ref_se_nospliced.sam.gz         hisat2-align-s -f -p 1 --no-spliced-alignment (minus @PG)
   ref_se_spliced.sam.gz           hisat2-align-s -f -p 1 (default), minus @PG
+  reads_pe_{1,2}.fa.gz, ref_pe_nospliced.sam.gz   300 pairs and their -1/-2 --no-spliced-alignment SAM
 Everything is deterministic (seeds below); the fixtures are committed.
 """
 import gzip
@@ -67,6 +68,17 @@ def main():
         run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "-x", base, "-U", rfa, "-S", sam] + extra)
         lines = [l for l in open(sam, "rb").read().splitlines(True) if not l.startswith(b"@PG")]
         gz_write(os.path.join(GOLD, name + ".sam.gz"), b"".join(lines))
+    # paired-end: 300 pairs, some with a mate that fails / contains Ns
+    m1, m2 = synth.make_pairs(contigs, 300, 101, SEED + 7, frag_mean=320, frag_sd=120, sub_rate=0.015)
+    f1, f2 = os.path.join(tmp, "reads_pe_1.fa"), os.path.join(tmp, "reads_pe_2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    gz_write(os.path.join(GOLD, "reads_pe_1.fa.gz"), open(f1, "rb").read())
+    gz_write(os.path.join(GOLD, "reads_pe_2.fa.gz"), open(f2, "rb").read())
+    sam = os.path.join(tmp, "pe.sam")
+    run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam])
+    lines = [l for l in open(sam, "rb").read().splitlines(True) if not l.startswith(b"@PG")]
+    gz_write(os.path.join(GOLD, "ref_pe_nospliced.sam.gz"), b"".join(lines))
     shutil.rmtree(tmp)
     tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print("golden bytes:", tot)

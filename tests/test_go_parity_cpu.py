@@ -34,3 +34,27 @@ def test_live_reference(case):
     import fuzz_align as F
     bad, _ = F.run_case(verbose=3, **case)
     assert bad == 0
+
+
+def test_golden_pairs_sam(g1_index, golden_dir):
+    """Paired go() (pairReads, alignMate, lone mates, N filter) + the host-side finishRead mirror vs the
+    reference's -1/-2 SAM: every line, in order."""
+    import numpy as np
+    import fuzz_pairs as F
+    import pe_sink as PS
+    _, s1 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_1.fa.gz"))
+    _, s2 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_2.fa.gz"))
+    import gzip, tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".sam", delete=False) as t:
+        t.write(gzip.open(os.path.join(golden_dir, "ref_pe_nospliced.sam.gz"), "rt").read())
+    refnames, want = F.parse_pe_sam(t.name)
+    os.unlink(t.name)
+    q = [str(i) for i in range(len(s1))]
+    outs, r1, r2 = F.emu_pairs(g1_index, np.stack(s1), np.stack(s2), q, q)
+    kinds = set()
+    for i in range(len(s1)):
+        got = PS.finish_pair(outs[i], r1, r2, i * SU.AL_MAX_RESULTS, refnames, (101, 101))
+        assert outs[i].overflow == 0
+        assert got == want[q[i]], i
+        kinds.add(got[0][0] & 0xF)
+    assert len(kinds) >= 2   # concordant and at least one other outcome class are exercised

@@ -37,3 +37,24 @@ def _backend(base, m1, m2, q1, q2):
 def test_live_reference_pairs(case):
     bad, _ = F.run_case(verbose=3, backend=_backend, stride=api.PAIR_RES_CAP, **case)
     assert bad == 0
+
+
+def test_golden_pairs_sam(g1_index, golden_dir):
+    import gzip
+    import tempfile
+
+    import numpy as np
+
+    import h2o_py as H
+    import pe_sink as PS
+    _, s1 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_1.fa.gz"))
+    _, s2 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_2.fa.gz"))
+    with tempfile.NamedTemporaryFile("w", suffix=".sam", delete=False) as t:
+        t.write(gzip.open(os.path.join(golden_dir, "ref_pe_nospliced.sam.gz"), "rt").read())
+    refnames, want = F.parse_pe_sam(t.name)
+    os.unlink(t.name)
+    q = [str(i) for i in range(len(s1))]
+    res, a1, a2 = _backend(g1_index, np.stack(s1), np.stack(s2), q, q)
+    for i in range(len(s1)):
+        assert res[i].overflow == 0
+        assert PS.finish_pair(res[i], a1, a2, i * api.PAIR_RES_CAP, refnames, (101, 101)) == want[q[i]], i
