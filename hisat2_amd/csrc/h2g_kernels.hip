@@ -712,38 +712,65 @@ static_assert(sizeof(h2g_read_result) == 24, "h2g_read_result layout");
 
 // One lane = one read at a time (grid-stride); each lane owns one AlignWS in HBM (explicit recursion stack,
 // sink, searched list).  Selected alignments are written in print order.
-#define H2G_NCLASS 96
-// Outcome class of one read from the seed stage (2 strands x {no anchor, anchored + full-length 0-mismatch extension,
-// anchored + partial extension (bucketed by length)}).
-__device__ __forceinline__ uint32_t seed_class(const h2g_seed_result* r, uint32_t rdlen) {
-	uint32_t key = 0;
-	for(int k = 0; k < 2; k++) {
-		uint32_t c = 0;
-		if(r[k].ncoords > 0) {
-			const uint32_t len = r[k].ext[0].len;
-			if(len == rdlen && r[k].ext[0].score == 0 && r[k].ncoords == 1) c = 1;
-			else c = 2 + (r[k].ncoords > 1 ? 4 : 0) + (len * 4 / (rdlen + 1));   // 2..9
-		}
-		key = key * 10 + c;
+#define H2G_NCLASS 8
+// Expected-cost class of one read for scheduling k_align (results do not depend on it): Hamming distance between
+// the whole read and the reference at the position implied by its first anchor coordinate, on the better strand.
+// 0 = >= 4 mismatches / indel-like (heaviest), 1 = 3, 2 = 2, 3 = several anchor coordinates, 4 = no anchor on either
+// strand, 5 = 1 mismatch, 6 = perfect.  Buckets are processed in this order (longest-processing-time first).
+__device__ __forceinline__ uint32_t read_hamming(const DRef& ref, const SeqView& sv, const h2g_seed_result& r) {
+	if(r.ncoords == 0 || r.ext[0].tidx == H2G_MAX) return 0xffffu;
+	const int64_t start = (int64_t)r.ext[0].toff - (int64_t)r.ext[0].rdoff;
+	RefCursor rc;
+	rc.init(&ref, r.ext[0].tidx);
+	uint32_t mm = 0;
+	for(uint32_t i = 0; i < sv.len; i++) {
+		const int64_t p = start + i;
+		const int rf = p < 0 ? 4 : rc.get(p);
+		if(rf != sv.at(i)) { if(++mm >= 8) break; }
 	}
-	return key < H2G_NCLASS ? key : H2G_NCLASS - 1;
+	return mm;
 }
-__global__ void k_classify(const h2g_seed_result* seed, const uint32_t* offs, uint32_t n, uint8_t* keys, uint32_t* hist) {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i >= n) return;
-	uint32_t k = seed_class(seed + 2 * (size_t)i, offs[i + 1] - offs[i]);
-	keys[i] = (uint8_t)k;
-	atomicAdd(&hist[k], 1u);
+__global__ __launch_bounds__(256) void k_classify(DRef ref, DReads rd, const h2g_seed_result* seed, uint8_t* keys, uint32_t* blockhist) {
+	__shared__ uint32_t hist[H2G_NCLASS];
+	if(threadIdx.x < H2G_NCLASS) hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < rd.n) {
+		const h2g_seed_result* r = seed + 2 * (size_t)i;
+		uint32_t best = 0xffffu, multi = 0;
+		for(int k = 0; k < 2; k++) {
+			if(r[k].ncoords > 1) multi = 1;
+			uint32_t h = read_hamming(ref, seq_view(rd, i, k == 0), r[k]);
+			if(h < best) best = h;
+		}
+		uint32_t key = best == 0xffffu ? 4u : multi ? 3u : best == 0 ? 6u : best == 1 ? 5u : best == 2 ? 2u : best == 3 ? 1u : 0u;
+		keys[i] = (uint8_t)key;
+		atomicAdd(&hist[key], 1u);
+	}
+	__syncthreads();
+	if(threadIdx.x < H2G_NCLASS) blockhist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];   // class-major
 }
-__global__ void k_class_scan(uint32_t* hist) {   // exclusive scan of H2G_NCLASS counters -> bucket cursors
-	if(threadIdx.x != 0) return;
-	uint32_t run = 0;
-	for(int k = 0; k < H2G_NCLASS; k++) { uint32_t v = hist[k]; hist[k] = run; run += v; }
+// exclusive scan of the class-major (class, block) histogram: one wave, chunked
+__global__ void k_class_scan(uint32_t* blockhist, uint32_t total) {
+	__shared__ uint32_t carry;
+	if(threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for(uint32_t base = 0; base < total; base += 64) {
+		const uint32_t i = base + threadIdx.x;
+		uint32_t v = i < total ? blockhist[i] : 0, x = v;
+		for(int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if((int)threadIdx.x >= o) x += y; }
+		if(i < total) blockhist[i] = carry + x - v;
+		__syncthreads();
+		if(threadIdx.x == 63) carry += x;
+		__syncthreads();
+	}
 }
-__global__ void k_class_scatter(const uint8_t* keys, uint32_t n, uint32_t* cursor, uint32_t* perm) {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i >= n) return;
-	perm[atomicAdd(&cursor[keys[i]], 1u)] = i;
+__global__ __launch_bounds__(256) void k_class_scatter(const uint8_t* keys, uint32_t n, const uint32_t* blockoff, uint32_t* perm) {
+	__shared__ uint32_t cur[H2G_NCLASS];
+	if(threadIdx.x < H2G_NCLASS) cur[threadIdx.x] = blockoff[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+	__syncthreads();
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n) perm[atomicAdd(&cur[keys[i]], 1u)] = i;
 }
 
 // `perm` (optional) lists read ids bucketed by the outcome class of the seed stage, so that the 64 lanes of a
@@ -751,7 +778,7 @@ __global__ void k_class_scatter(const uint8_t* keys, uint32_t n, uint32_t* curso
 template <int WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref, DLocalSet ls, DReads rd, AlnParams P, const char* names,
                                                const uint32_t* name_offs, AlignWS* pool, ReadOut* outs, h2g_alnres* aln,
-                                               unsigned long long* counters, const uint32_t* perm)
+                                               unsigned long long* counters, const uint32_t* perm, unsigned long long* work)
 {
 	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -764,7 +791,12 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref,
 	DReads rdl = rd;
 	rdl.pk = s_pk + threadIdx.x;
 	rdl.pk_stride = 256;
-	for(size_t j = tid; j < rd.n; j += stride) {
+	// scheduling knob (work != nullptr): a lane that finishes a read takes the next one of the work list instead of
+	// waiting for its wave's round (measured: no gain, the kernel is issue-bound under divergence)
+	for(size_t jj = tid;; jj += stride) {
+		size_t j = jj;
+		if(work) j = (size_t)atomicAdd(work, 1ull);
+		if(j >= rd.n) break;
 		const size_t i = perm ? perm[j] : j;
 		ReadOut o;
 		const uint32_t a = name_offs[i], b = name_offs[i + 1];
@@ -863,34 +895,35 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
 	const uint32_t* perm = nullptr;
 	static const int sort_mode = getenv("H2G_ALIGN_SORT") ? atoi(getenv("H2G_ALIGN_SORT")) : 0;
+	static const int dyn_mode = getenv("H2G_ALIGN_DYN") ? atoi(getenv("H2G_ALIGN_DYN")) : 0;
 	static const int occ_mode = getenv("H2G_ALIGN_OCC") ? atoi(getenv("H2G_ALIGN_OCC")) : 4;
 	if(sort_mode) {
-		// seed stage (partialSearch both strands from offset 0 -> coordinates -> 0-mm extension) as a classifier
+		// seed stage (partialSearch both strands from offset 0 -> coordinates -> 0-mm extension) + Hamming distance
+		// of the whole read as a cost classifier; bucket read ids by class, heaviest first
 		h2g_seed_params sp;
 		sp.pseudogeneStop = 0; sp.anchorStop = 1; sp.khits = p->khits; sp.search_variant = 0;
 		const size_t n2 = s->n_reads * 2;
-		void *dkeys, *dhist, *dperm;
-		if((rc = tmp_buf(s, 0, s->n_reads, &dkeys)) || (rc = tmp_buf(s, 1, H2G_NCLASS * 4, &dhist)) || (rc = tmp_buf(s, 2, s->n_reads * 4, &dperm))) return rc;
-		DScoring sc;
-		hipLaunchKernelGGL(k_seed_search, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), sp, s->d_seed, s->d_counters + 6);
-		hipLaunchKernelGGL(k_seed_resolve_extend, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dr, dreads(s), sc, s->d_seed, s->d_counters + 6);
-		HIPCHK(hipMemsetAsync(dhist, 0, H2G_NCLASS * 4, s->st));
 		const unsigned cg = (unsigned)((s->n_reads + 255) / 256);
-		hipLaunchKernelGGL(k_classify, dim3(cg), dim3(256), 0, s->st, (const h2g_seed_result*)s->d_seed, (const uint32_t*)s->d_offs, (uint32_t)s->n_reads, (uint8_t*)dkeys, (uint32_t*)dhist);
-		hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s->st, (uint32_t*)dhist);
-		hipLaunchKernelGGL(k_class_scatter, dim3(cg), dim3(256), 0, s->st, (const uint8_t*)dkeys, (uint32_t)s->n_reads, (uint32_t*)dhist, (uint32_t*)dperm);
+		void *dkeys, *dhist, *dperm;
+		if((rc = tmp_buf(s, 0, s->n_reads, &dkeys)) || (rc = tmp_buf(s, 1, (size_t)H2G_NCLASS * cg * 4, &dhist)) || (rc = tmp_buf(s, 2, s->n_reads * 4, &dperm))) return rc;
+		DScoring sc;
+		hipLaunchKernelGGL(k_seed_search, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), sp, s->d_seed, s->d_counters + 8);
+		hipLaunchKernelGGL(k_seed_resolve_extend, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dr, dreads(s), sc, s->d_seed, s->d_counters + 8);
+		hipLaunchKernelGGL(k_classify, dim3(cg), dim3(256), 0, s->st, s->ix->dr, dreads(s), (const h2g_seed_result*)s->d_seed, (uint8_t*)dkeys, (uint32_t*)dhist);
+		hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s->st, (uint32_t*)dhist, (uint32_t)(H2G_NCLASS * cg));
+		hipLaunchKernelGGL(k_class_scatter, dim3(cg), dim3(256), 0, s->st, (const uint8_t*)dkeys, (uint32_t)s->n_reads, (const uint32_t*)dhist, (uint32_t*)dperm);
 		perm = (const uint32_t*)dperm;
 	}
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
 	if(occ_mode >= 4)
 		hipLaunchKernelGGL(k_align<4>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm);
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr);
 	else if(occ_mode == 3)
 		hipLaunchKernelGGL(k_align<3>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm);
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr);
 	else
 		hipLaunchKernelGGL(k_align<2>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm);
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr);
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;
