@@ -33,6 +33,65 @@ def make_genome(contig_lens, seed, n_gaps=0, gap_len=500, repeats=0, repeat_len=
     return contigs
 
 
+def make_snps(contigs, seed, every=250, names=None):
+    """Seeded variant set for a graph index (hisat2-build --snp): list of
+    (id, type, chrom, pos, data) with type in single|deletion|insertion, >= 12 bp apart, away from Ns."""
+    rng = np.random.default_rng(seed)
+    out, sid = [], 0
+    for ci, g in enumerate(contigs):
+        L = len(g)
+        if L < 200:
+            continue
+        pos = np.sort(rng.choice(np.arange(50, L - 50), size=max(1, L // every), replace=False))
+        last = -100
+        name = names[ci] if names else f"chr{ci + 1}"
+        for p in pos:
+            p = int(p)
+            if p - last < 12 or (g[p - 6:p + 8] > 3).any():
+                continue
+            last = p
+            sid += 1
+            t = rng.random()
+            if t < 0.86:
+                alt = (int(g[p]) + int(rng.integers(1, 4))) & 3
+                out.append((f"rs{sid}", "single", name, p, "ACGT"[alt]))
+            elif t < 0.93:
+                out.append((f"rs{sid}", "deletion", name, p, str(int(rng.integers(1, 4)))))
+            else:
+                ins = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(1, 4))))
+                out.append((f"rs{sid}", "insertion", name, p, ins))
+    return out
+
+
+def write_snps(path, snps):
+    with open(path, "w") as f:
+        for s in snps:
+            f.write("\t".join(map(str, s)) + "\n")
+
+
+def apply_snps(contigs, snps, names=None):
+    """Alternate haplotype carrying every variant of `snps` (they never overlap)."""
+    idx = {(names[i] if names else f"chr{i + 1}"): i for i in range(len(contigs))}
+    per = {i: [] for i in range(len(contigs))}
+    for s in snps:
+        per[idx[s[2]]].append(s)
+    out = []
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    for i, g in enumerate(contigs):
+        parts, cur = [], 0
+        for _, typ, _, p, data in sorted(per[i], key=lambda x: x[3]):
+            if typ == "single":
+                parts.append(g[cur:p]); parts.append(np.array([code[data]], dtype=np.uint8)); cur = p + 1
+            elif typ == "deletion":
+                parts.append(g[cur:p]); cur = p + int(data)
+            else:
+                parts.append(g[cur:p]); parts.append(np.array([code[c] for c in data], dtype=np.uint8))
+                cur = p
+        parts.append(g[cur:])
+        out.append(np.concatenate(parts))
+    return out
+
+
 def write_fasta(path, contigs, names=None, width=60):
     with open(path, "wb") as f:
         for i, g in enumerate(contigs):

@@ -240,6 +240,137 @@ int h2o_rowL(const h2o_gfm* g, uint32_t row) { /* gfm.h:3615-3630 */
 	return (side[charOff >> 2] >> ((charOff & 3) * 2)) & 3;
 }
 
+/* ------------------------------------------------------------------ graph index (a2/a7/a9) */
+/* 128 B graph side (gfm.h:160-176, 6204): [0,52) 2-bit gbwt chars (208), [52,78) F bits, [78,104) M bits,
+ * then index_t F_loc, M_occ, occ[A,C,G,T].  Bit j of byte i is position 8*i+j. */
+static uint32_t pop64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+static uint32_t countUpTo_bits(const uint8_t* bits, int by, int bp) { /* gfm.h:3384-3449 */
+	uint32_t cCnt = 0;
+	int n = by + (bp > 0 ? 1 : 0);
+	for(int i = 0; i < n; i += 8) {
+		uint64_t w;
+		memcpy(&w, bits + i, 8);
+		if(i + 8 < n) cCnt += pop64(w);
+		else {
+			uint32_t by_shift = 8 - (n - i);
+			uint32_t bp_shift = (bp > 0 ? 8 - bp : 0);
+			w <<= (by_shift << 3) + bp_shift;
+			cCnt += pop64(w);
+			break;
+		}
+	}
+	return cCnt;
+}
+static uint32_t side_u32(const h2o_gfm* g, uint32_t sideNum, uint32_t k) { /* k: 0 F_loc, 1 M_occ */
+	uint32_t v;
+	memcpy(&v, g->gfm + (size_t)sideNum * g->p.sideSz + g->p.sideGbwtSz + 4 * k, 4);
+	return v;
+}
+uint32_t h2o_rank_M(const h2o_gfm* g, uint32_t row) { /* initFromRow_bit gfm.h:428; rank_M :4100; countMSide :3146 */
+	const h2o_params* p = &g->p;
+	uint32_t sideNum = row / p->sideGbwtLen, charOff = row % p->sideGbwtLen;
+	const uint8_t* side = g->gfm + (size_t)sideNum * p->sideSz;
+	const uint8_t* M = side + (p->sideGbwtSz - (p->sideGbwtSz >> 2));
+	return countUpTo_bits(M, (int)(charOff >> 3), (int)(charOff & 7)) + side_u32(g, sideNum, 1);
+}
+uint32_t h2o_select_F(const h2o_gfm* g, uint32_t row, uint32_t count) { /* gfm.h:4113-4167 */
+	const h2o_params* p = &g->p;
+	uint32_t sideNum = row / p->sideGbwtLen, charOff = row % p->sideGbwtLen;
+	const uint32_t bitsPerSide = p->sideGbwtSz << 1;
+	while(1) {
+		const uint8_t* F = g->gfm + (size_t)sideNum * p->sideSz + (p->sideGbwtSz >> 1);
+		uint32_t by = charOff >> 3, bp = charOff & 7;
+		uint32_t remaining = bitsPerSide - charOff;
+		uint32_t minSide = count < remaining ? count : remaining;
+		uint64_t bits;
+		memcpy(&bits, F + by, 8);
+		uint32_t advance = 64;
+		if(bp > 0) { bits >>= bp; advance -= bp; }
+		if(minSide < advance) { advance = minSide; bits <<= (64 - minSide); }
+		count -= pop64(bits);
+		if(count == 0) { charOff += advance - 1; break; }
+		if(charOff + advance == bitsPerSide) { sideNum++; charOff = 0; }
+		else charOff += advance;
+	}
+	return sideNum * p->sideGbwtLen + charOff;
+}
+uint32_t h2o_in_edge_count(const h2o_gfm* g, uint32_t top, uint32_t bot, uint32_t* iedges, uint32_t cap)
+{ /* gfm.h:4172-4213: (node index relative to the first node, extra in-edges) for nodes with >1 in-edge */
+	const h2o_params* p = &g->p;
+	uint32_t n = 0, curr_node = 0, num0s = 0;
+	int first = 1;
+	for(uint32_t row = top; row < bot; row++) {
+		if(first) first = 0;
+		else {
+			uint32_t sideNum = row / p->sideGbwtLen, charOff = row % p->sideGbwtLen;
+			const uint8_t* F = g->gfm + (size_t)sideNum * p->sideSz + (p->sideGbwtSz >> 1);
+			int bit = (F[charOff >> 3] >> (charOff & 7)) & 1;
+			if(bit) { curr_node++; num0s = 0; }
+			else {
+				num0s++;
+				if(num0s == 1) { if(n < cap) iedges[2 * n] = curr_node; n++; }
+				if(n <= cap) iedges[2 * (n - 1) + 1] = num0s;
+			}
+		}
+	}
+	return n;
+}
+/* F-row of node `node` (0-based) given a row whose side seeds the backward scan over the (F_loc, M_occ) side
+ * headers; shared by mapGLF :3785-3810 and mapGLF1 :3975-3998 */
+static uint32_t node_to_Frow(const h2o_gfm* g, uint32_t locRow, uint32_t node, uint32_t* F_loc_out, uint32_t* M_occ_out) {
+	uint32_t sideNum = locRow / g->p.sideGbwtLen;
+	uint32_t F_loc, M_occ;
+	while(1) {
+		F_loc = side_u32(g, sideNum, 0);
+		M_occ = side_u32(g, sideNum, 1);
+		if(M_occ <= node) break;
+		sideNum--;
+	}
+	if(M_occ > 0) F_loc++;
+	*F_loc_out = F_loc; *M_occ_out = M_occ;
+	if(node + 1 > M_occ) return h2o_select_F(g, F_loc, node + 1 - M_occ);
+	return F_loc;
+}
+/* mapGLF gfm.h:3759-3837.  Returns 0 (and top=bot=0) when the range is empty. */
+int h2o_map_glf(const h2o_gfm* g, uint32_t top, uint32_t bot, int c, uint32_t k, uint32_t* otop, uint32_t* obot,
+                uint32_t* ontop, uint32_t* onbot, uint32_t* iedges, uint32_t cap, uint32_t* niedges)
+{
+	uint32_t t = h2o_rank(g, top, c), b = h2o_rank(g, bot, c);
+	*niedges = 0;
+	if(g->p.linear) { *otop = *ontop = t; *obot = *onbot = b; return t < b; }
+	*otop = *obot = 0;
+	if(t + 1 >= g->p.gbwtLen || t >= b) return 0;
+	uint32_t node_top = h2o_rank_M(g, t + 1) - 1;
+	uint32_t F_loc, M_occ;
+	uint32_t ft = node_to_Frow(g, t + 1, node_top, &F_loc, &M_occ);
+	uint32_t node_bot = h2o_rank_M(g, b);
+	/* :3812-3827 — the bottom uses the side of `bot` directly (no backward scan) */
+	uint32_t bs = b / g->p.sideGbwtLen;
+	uint32_t bF = side_u32(g, bs, 0), bM = side_u32(g, bs, 1);
+	if(bM > 0) bF++;
+	uint32_t fb = (node_bot + 1 > bM) ? h2o_select_F(g, bF, node_bot + 1 - bM) : bF;
+	*otop = ft; *obot = fb; *ontop = node_top; *onbot = node_bot;
+	if(iedges && node_bot - node_top <= k && node_bot - node_top < fb - ft)
+		*niedges = h2o_in_edge_count(g, ft, fb, iedges, cap);
+	return 1;
+}
+/* mapGLF1 gfm.h:3957-4028 (mapLF1 :3892).  Returns 0 when the row cannot be extended by c. */
+int h2o_map_glf1(const h2o_gfm* g, uint32_t row, int c, uint32_t* otop, uint32_t* obot, uint32_t* ontop, uint32_t* onbot)
+{
+	*otop = *obot = 0;
+	if(h2o_rowL(g, row) != c) return 0;
+	for(uint32_t i = 0; i < g->nZ; i++) if(row == g->zOffs[i]) return 0;
+	uint32_t t = h2o_rank(g, row, c);
+	if(g->p.linear) { *otop = *ontop = t; *obot = *onbot = t + 1; return 1; }
+	uint32_t node_top = h2o_rank_M(g, t + 1) - 1;
+	uint32_t F_loc, M_occ;
+	uint32_t ft = node_to_Frow(g, t + 1, node_top, &F_loc, &M_occ);
+	uint32_t node_bot = node_top + 1;
+	uint32_t fb = (node_bot + 1 > M_occ) ? h2o_select_F(g, F_loc, node_bot + 1 - M_occ) : F_loc;
+	*otop = ft; *obot = fb; *ontop = node_top; *onbot = node_bot;
+	return 1;
+}
+
 /* ------------------------------------------------------------------ ftab (a10) */
 static uint32_t ftabHi(const h2o_gfm* g, uint32_t i) { /* gfm.h:2618-2634 */
 	uint32_t lim = g->p.linear ? g->p.len : g->p.gbwtLen;
@@ -344,7 +475,20 @@ void h2o_get_stretch(const h2o_ref* r, uint32_t tidx, int64_t toff, uint32_t cou
 /* ------------------------------------------------------------------ partialSearch (a11) */
 void h2o_partial_search(const h2o_index* ix, const uint8_t* seq, uint32_t len, uint32_t cur_in,
                         int pseudogeneStop_in, int anchorStop_in, uint32_t khits, h2o_bwthit* o)
-{ /* hi_aligner.h:6361-6600, linear index (mapLF gfm.h:3739; mapGLF1 linear branch gfm.h:3957-3972; mapLF1 :3892) */
+{
+	uint32_t n = 0;
+	h2o_partial_search_graph(ix, seq, len, cur_in, pseudogeneStop_in, anchorStop_in, khits,
+	                         5 > khits * 2 ? 5 : khits * 2, o, NULL, 0, &n);
+}
+
+/* hi_aligner.h:6361-6600 for linear and graph indexes; iedges[2*cap] receives BWTHit::_node_iedge_count */
+void h2o_partial_search_graph(const h2o_index* ix, const uint8_t* seq, uint32_t len, uint32_t cur_in,
+                              int pseudogeneStop_in, int anchorStop_in, uint32_t khits, uint32_t kseeds,
+                              h2o_bwthit* o, uint32_t* iedges, uint32_t cap, uint32_t* niedges)
+{ /* mapLF gfm.h:3739; mapGLF :3759; mapGLF1 :3957; mapLF1 :3892 */
+	enum { IE_CAP = 64 };
+	uint32_t tmp_ie[2 * IE_CAP], cur_ie[2 * IE_CAP], tmp_n = 0, cur_n = 0;
+	*niedges = 0;
 	const h2o_gfm* g = &ix->g;
 	const uint32_t ftabLen = (uint32_t)g->p.ftabChars, minK = ix->minK;
 	int pseudogeneStop_ = pseudogeneStop_in, anchorStop_ = anchorStop_in;
@@ -373,29 +517,31 @@ void h2o_partial_search(const h2o_index* ix, const uint8_t* seq, uint32_t len, u
 	}
 	uint32_t same_range = 0, similar_range = 0;
 	uint32_t ntop = 0, nbot = 0;                              /* node_range, initially (0,0) */
-	uint32_t last_side[2] = { H2O_MAX, H2O_MAX };
 	while(dep < len) {                                       /* :6459-6539 */
 		int c = seq[len - dep - 1];
-		uint32_t ttop = 0, tbot = 0;
+		uint32_t ttop = 0, tbot = 0, tntop = 0, tnbot = 0;
+		tmp_n = 0;
 		if(c <= 3) {
-			if(bot - top > 1) {                               /* bloc.valid(): mapLF on both loci */
+			if(bot - top > 1) {                               /* bloc.valid(): mapLF / mapGLF on both loci */
 				o->nrank += 2;
 				uint32_t s0 = top / g->p.sideGbwtLen, s1 = bot / g->p.sideGbwtLen;
 				o->nside += (s0 == s1) ? 1 : 2;
-				ttop = h2o_rank(g, top, c);
-				tbot = h2o_rank(g, bot, c);
+				if(g->p.linear) {
+					ttop = tntop = h2o_rank(g, top, c);
+					tbot = tnbot = h2o_rank(g, bot, c);
+				} else {
+					h2o_map_glf(g, top, bot, c, kseeds, &ttop, &tbot, &tntop, &tnbot, tmp_ie, IE_CAP, &tmp_n);
+				}
 			} else {                                         /* mapGLF1 -> mapLF1 */
 				o->nrank += 1;
 				o->nside += 1;
-				if(h2o_rowL(g, top) == c && !is_zoff(g, top)) {
-					ttop = h2o_rank(g, top, c);
-					tbot = ttop + 1;
+				if(h2o_map_glf1(g, top, c, &ttop, &tbot, &tntop, &tnbot)) {
+					if(ttop + 1 < tbot) { tmp_ie[0] = 0; tmp_ie[1] = tbot - ttop - 1; tmp_n = 1; } /* :6476-6482 */
 				}
 			}
-			(void)last_side;
 		}
 		if(ttop >= tbot) break;
-		uint32_t nt = tbot - ttop, no = nbot - ntop;         /* linear: node range == row range */
+		uint32_t nt = tnbot - tntop, no = nbot - ntop;
 		if(pseudogeneStop_) {                                /* :6488-6503 */
 			if(nt < no && no <= (5u < khits ? 5u : khits)) {
 				if(dep - offset >= minK + 6 && similar_range >= 5) {
@@ -414,7 +560,9 @@ void h2o_partial_search(const h2o_index* ix, const uint8_t* seq, uint32_t len, u
 			} else same_range = 0;
 			if(dep - offset >= minK + 8 && nt >= 4) anchorStop_ = 0;
 		}
-		top = ttop; bot = tbot; ntop = ttop; nbot = tbot;
+		top = ttop; bot = tbot; ntop = tntop; nbot = tnbot;
+		cur_n = tmp_n;                                       /* :6522-6527 */
+		memcpy(cur_ie, tmp_ie, sizeof(uint32_t) * 2 * (tmp_n < IE_CAP ? tmp_n : IE_CAP));
 		dep++;
 		if(anchorStop_) {                                    /* :6530-6536 */
 			if(dep - offset >= minK + 12 && bot - top == 1) {
@@ -427,7 +575,12 @@ void h2o_partial_search(const h2o_index* ix, const uint8_t* seq, uint32_t len, u
 		if(anchorStop) hit_type = H2O_ANCHOR_HIT;
 		else if(pseudogeneStop) hit_type = H2O_PSEUDOGENE_HIT;
 		int report = ntop < nbot;   /* no LF step taken => node_range (0,0) => not reported */
-		if(report) { o->top = top; o->bot = bot; o->node_top = ntop; o->node_bot = nbot; }
+		if(nbot - ntop < bot - top && cur_n == 0) report = 0;  /* :6551-6553 */
+		if(report) {
+			o->top = top; o->bot = bot; o->node_top = ntop; o->node_bot = nbot;
+			*niedges = cur_n;
+			for(uint32_t e = 0; e < cur_n && e < cap; e++) { iedges[2 * e] = cur_ie[2 * e]; iedges[2 * e + 1] = cur_ie[2 * e + 1]; }
+		}
 		o->len = dep - offset;
 		o->hit_type = hit_type;
 		cur = dep;

@@ -114,6 +114,18 @@ void     h2o_get_stretch(const h2o_ref*, uint32_t tidx, int64_t toff, uint32_t c
 /* partialSearch hi_aligner.h:6361.  seq = read as 0..4 codes in the searched orientation. */
 void h2o_partial_search(const h2o_index*, const uint8_t* seq, uint32_t len, uint32_t cur,
                         int pseudogeneStop, int anchorStop, uint32_t khits, h2o_bwthit* out);
+/* same for linear AND graph indexes; iedges[2*cap] <- BWTHit::_node_iedge_count (hi_aligner.h:199) */
+void h2o_partial_search_graph(const h2o_index*, const uint8_t* seq, uint32_t len, uint32_t cur,
+                              int pseudogeneStop, int anchorStop, uint32_t khits, uint32_t kseeds,
+                              h2o_bwthit* out, uint32_t* iedges, uint32_t cap, uint32_t* niedges);
+/* graph index primitives (gfm.h): rank over the M bit-vector, select over F, in-edge counts, graph LF */
+uint32_t h2o_rank_M(const h2o_gfm*, uint32_t row);                              /* gfm.h:4100 */
+uint32_t h2o_select_F(const h2o_gfm*, uint32_t row, uint32_t count);            /* gfm.h:4113 */
+uint32_t h2o_in_edge_count(const h2o_gfm*, uint32_t top, uint32_t bot, uint32_t* iedges, uint32_t cap); /* gfm.h:4172 */
+int h2o_map_glf(const h2o_gfm*, uint32_t top, uint32_t bot, int c, uint32_t k, uint32_t* otop, uint32_t* obot,
+                uint32_t* ontop, uint32_t* onbot, uint32_t* iedges, uint32_t cap, uint32_t* niedges); /* gfm.h:3759 */
+int h2o_map_glf1(const h2o_gfm*, uint32_t row, int c, uint32_t* otop, uint32_t* obot,
+                 uint32_t* ontop, uint32_t* onbot);                             /* gfm.h:3957 */
 /* getGenomeCoords hi_aligner.h:5774 (linear index): coords for rows [top, top+nelt) */
 int  h2o_genome_coords(const h2o_index*, uint32_t top, uint32_t bot, uint32_t maxelt, uint32_t rdlen,
                        int rejectStraddle, h2o_coord* coords, uint32_t* ncoords, int* straddled, uint32_t* nsteps);

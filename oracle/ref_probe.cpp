@@ -217,6 +217,40 @@ int main(int argc, char** argv) {
 		}
 		return 0;
 	}
+	if(cmd == "glf" || cmd == "glf1") {
+		// glf  <base> <n> <seed>: random ranges [top, top+spread) and c -> mapGLF (graph LF on a range, gfm.h:3759)
+		// glf1 <base> <n> <seed>: random row and c -> mapGLF1 (gfm.h:3957)
+		uint64_t n = strtoull(argv[3], NULL, 10), s = strtoull(argv[4], NULL, 10);
+		EList<pair<index_t, index_t> > iedges;
+		for(uint64_t i = 0; i < n; i++) {
+			uint64_t h = splitmix64(s);
+			index_t top = (index_t)(h % (gh._gbwtLen - 1));
+			int c = (int)((h >> 40) & 3);
+			if(cmd == "glf1") {
+				SideLocus<index_t> l;
+				l.initFromRow(top, gh, gfm.gfm());
+				if(((h >> 50) & 7) != 0) c = gfm.rowL(l);
+				pair<index_t, index_t> nr(0, 0);
+				pair<index_t, index_t> r = gfm.mapGLF1(top, l, c, &nr);
+				printf("%u %d %u %u %u %u\n", top, c, r.first, r.second, nr.first, nr.second);
+				continue;
+			}
+			index_t spread = (index_t)((h >> 44) % 400) + 2;
+			if(((h >> 60) & 3) == 0) spread = (index_t)((h >> 44) % 6) + 2;
+			index_t bot = top + spread;
+			if(bot > gh._gbwtLen) bot = gh._gbwtLen;
+			if(bot <= top + 1) continue;
+			SideLocus<index_t> tl, bl;
+			SideLocus<index_t>::initFromTopBot(top, bot, gh, gfm.gfm(), tl, bl);
+			pair<index_t, index_t> nr(0, 0);
+			iedges.clear();
+			pair<index_t, index_t> r = gfm.mapGLF(tl, bl, c, &nr, &iedges, 10);
+			printf("%u %u %d %u %u %u %u %u", top, bot, c, r.first, r.second, nr.first, nr.second, (unsigned)iedges.size());
+			for(size_t e = 0; e < iedges.size(); e++) printf(" %u:%u", iedges[e].first, iedges[e].second);
+			putchar('\n');
+		}
+		return 0;
+	}
 	if(cmd == "psearch" || cmd == "coords" || cmd == "extend") {
 		// <cmd> <base> <reads.fa> <nospliced:0|1>
 		vector<Read*> rds;
@@ -256,11 +290,16 @@ int main(int argc, char** argv) {
 				                 pseudogeneStop, anchorStop);
 				BWTHit<index_t>& ph = hit.getPartialHit(hit.offsetSize() - 1);
 				if(cmd == "psearch") {
-					printf("%llu %d %u %u %u %u %u %u %u %u %d %u %u %d %d\n",
+					printf("%llu %d %u %u %u %u %u %u %u %u %d %u %u %d %d",
 					       (unsigned long long)rd.rdid, (int)fw, ph._top, ph._bot, ph._node_top,
 					       ph._node_bot, ph._bwoff, ph._len, ph._hit_type, hit._cur,
 					       (int)hit._done, hit._numPartialSearch, hit._numUniqueSearch,
 					       (int)pseudogeneStop, (int)anchorStop);
+					if(!linear) {   // graph index: in-edge list of the hit
+						printf(" %u", (unsigned)ph._node_iedge_count.size());
+						for(size_t e = 0; e < ph._node_iedge_count.size(); e++) printf(" %u:%u", ph._node_iedge_count[e].first, ph._node_iedge_count[e].second);
+					}
+					putchar('\n');
 					continue;
 				}
 				if(ph.empty() || ph._bot - ph._top > 16) continue;

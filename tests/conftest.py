@@ -32,6 +32,16 @@ def g1_index(tmp_path_factory, golden_dir):
 
 
 @pytest.fixture(scope="session")
+def g1s_index(tmp_path_factory, golden_dir):
+    """The reference-built GRAPH index (g1 + ~500 seeded variants, hisat2-build-s --snp)."""
+    d = tmp_path_factory.mktemp("g1s")
+    for k in range(1, 9):
+        with gzip.open(os.path.join(golden_dir, f"g1s.{k}.ht2.gz"), "rb") as f, open(d / f"g1s.{k}.ht2", "wb") as o:
+            shutil.copyfileobj(f, o)
+    return str(d / "g1s")
+
+
+@pytest.fixture(scope="session")
 def oracle_lib():
     """Build (if needed) and load the CPU oracle.  Test infrastructure only."""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)

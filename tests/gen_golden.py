@@ -10,6 +10,10 @@ for a small seeded genome ("g1"):
   ref_se_nospliced.sam.gz         hisat2-align-s -f -p 1 --no-spliced-alignment (minus @PG)
   ref_se_spliced.sam.gz           hisat2-align-s -f -p 1 (default), minus @PG
   reads_pe_{1,2}.fa.gz, ref_pe_nospliced.sam.gz   300 pairs and their -1/-2 --no-spliced-alignment SAM
+`gen_golden.py graph` adds the GRAPH index fixtures without touching the above:
+  g1s.snp.gz, g1s.{1..8}.ht2.gz   ~500 seeded variants of g1 and the hisat2-build-s --snp graph index
+  reads_snp.fa.gz                 300 reads drawn from the alternate haplotype (all variants applied)
+  probe_g1s_{params,rank,glf,glf1,psearch,psearch_spliced}.txt.gz   reference GFM graph-LF outputs
 Everything is deterministic (seeds below); the fixtures are committed.
 """
 import gzip
@@ -84,5 +88,39 @@ def main():
     print("golden bytes:", tot)
 
 
+def main_graph():
+    import numpy as np
+    tmp = tempfile.mkdtemp(prefix="h2goldg")
+    fa = os.path.join(tmp, "g1.fa")
+    open(fa, "wb").write(gzip.open(os.path.join(GOLD, "g1.fa.gz")).read())
+    contigs = synth.make_genome([60000, 45000, 30000], SEED, n_gaps=1, gap_len=500, repeats=2, repeat_len=400)
+    snps = synth.make_snps(contigs, SEED + 11)
+    snpf = os.path.join(tmp, "g1s.snp")
+    synth.write_snps(snpf, snps)
+    gz_write(os.path.join(GOLD, "g1s.snp.gz"), open(snpf, "rb").read())
+    base = os.path.join(tmp, "g1s")
+    run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", snpf, fa, base])
+    for k in range(1, 9):
+        gz_write(os.path.join(GOLD, f"g1s.{k}.ht2.gz"), open(f"{base}.{k}.ht2", "rb").read())
+    alt = synth.apply_snps(contigs, snps)
+    reads, _ = synth.make_reads(alt, 300, 101, SEED + 12, sub_rate=0.004)
+    rfa = os.path.join(tmp, "reads_snp.fa")
+    synth.write_reads_fasta(rfa, reads)
+    gz_write(os.path.join(GOLD, "reads_snp.fa.gz"), open(rfa, "rb").read())
+    probe = os.path.join(REF, "ref_probe")
+    for name, cmd, args in [("params", "params", []), ("rank", "rank", ["3000", "21"]), ("glf", "glf", ["12000", "22"]),
+                            ("glf1", "glf1", ["6000", "23"]), ("psearch", "psearch", [rfa, "1"]),
+                            ("psearch_spliced", "psearch", [rfa, "0"])]:
+        out = run([probe, cmd, base] + args).stdout
+        gz_write(os.path.join(GOLD, f"probe_g1s_{name}.txt.gz"), out)
+        print(name, len(out.splitlines()), "lines")
+    shutil.rmtree(tmp)
+    tot = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    print("golden bytes:", tot)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "graph":
+        main_graph()
+    else:
+        main()

@@ -82,6 +82,18 @@ def load():
     lib.h2o_partial_search.argtypes = [P(Index), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
                                        P(BwtHit)]
     lib.h2o_partial_search.restype = None
+    u32 = C.c_uint32
+    lib.h2o_partial_search_graph.argtypes = [P(Index), C.c_void_p, u32, u32, C.c_int, C.c_int, u32, u32, P(BwtHit),
+                                             P(u32), u32, P(u32)]
+    lib.h2o_partial_search_graph.restype = None
+    lib.h2o_rank_M.argtypes = [P(Gfm), u32]
+    lib.h2o_rank_M.restype = u32
+    lib.h2o_select_F.argtypes = [P(Gfm), u32, u32]
+    lib.h2o_select_F.restype = u32
+    lib.h2o_map_glf.argtypes = [P(Gfm), u32, u32, C.c_int, u32] + [P(u32)] * 4 + [P(u32), u32, P(u32)]
+    lib.h2o_map_glf.restype = C.c_int
+    lib.h2o_map_glf1.argtypes = [P(Gfm), u32, C.c_int] + [P(u32)] * 4
+    lib.h2o_map_glf1.restype = C.c_int
     lib.h2o_genome_coords.argtypes = [P(Index), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, P(Coord),
                                       P(C.c_uint32), P(C.c_int), P(C.c_uint32)]
     lib.h2o_genome_coords.restype = C.c_int

@@ -1,6 +1,7 @@
 """CPU tests: the C oracle (oracle/h2o.c) against vectors emitted by the REAL reference
 classes (oracle/ref_probe.cpp run on the reference-built index of genome g1)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -135,3 +136,96 @@ def test_extend(oracle_lib, g1_index, golden_dir):
         assert eds == r[9:], (l, eds)
         n += 1
     assert n > 1000
+
+
+# ---------------------------------------------------------------- graph index (g1s): a2 / a7 / a9
+def parse_glf_line(l):
+    f = l.split()
+    top, bot, c = int(f[0]), int(f[1]), int(f[2])
+    exp = tuple(map(int, f[3:7]))
+    ie = [tuple(map(int, x.split(":"))) for x in f[8:]]
+    assert len(ie) == int(f[7])
+    return top, bot, c, exp, ie
+
+
+def test_graph_params_and_rank(oracle_lib, g1s_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1s_index)
+    p = ix.contents.g.p
+    kv = H.glines(golden_dir, "probe_g1s_params.txt.gz")[0].split()
+    d = dict(zip(kv[0::2], map(int, kv[1::2])))
+    assert not p.linear and d["linear"] == 0
+    for k in ("len", "gbwtLen", "numNodes", "sideSz", "sideGbwtSz", "sideGbwtLen", "numSides", "offsLen"):
+        assert getattr(p, k) == d[k], k
+    g = C.byref(ix.contents.g)
+    for l in H.glines(golden_dir, "probe_g1s_rank.txt.gz"):
+        r, c, v, rl = map(int, l.split())
+        assert oracle_lib.h2o_rank(g, r, c) == v and oracle_lib.h2o_rowL(g, r) == rl
+
+
+def test_graph_map_glf(oracle_lib, g1s_index, golden_dir):
+    """mapGLF on ranges (rank_M, select_F, getInEdgeCount) against the reference GFM"""
+    ix = H.load_index(oracle_lib, g1s_index)
+    g = C.byref(ix.contents.g)
+    u32 = C.c_uint32
+    nie = 0
+    for l in H.glines(golden_dir, "probe_g1s_glf.txt.gz"):
+        top, bot, c, exp, ie = parse_glf_line(l)
+        a, b, na, nb, n = u32(), u32(), u32(), u32(), u32()
+        buf = (u32 * 128)()
+        ok = oracle_lib.h2o_map_glf(g, top, bot, c, 10, a, b, na, nb, buf, 64, n)
+        if exp[0] == 0 and exp[1] == 0:
+            assert not ok and a.value == 0 and b.value == 0, l
+            continue
+        assert ok and (a.value, b.value, na.value, nb.value) == exp, l
+        assert [(buf[2 * i], buf[2 * i + 1]) for i in range(n.value)] == ie, l
+        nie += bool(ie)
+    assert nie >= 20
+
+
+def test_graph_map_glf1(oracle_lib, g1s_index, golden_dir):
+    ix = H.load_index(oracle_lib, g1s_index)
+    g = C.byref(ix.contents.g)
+    u32 = C.c_uint32
+    wide = 0
+    for l in H.glines(golden_dir, "probe_g1s_glf1.txt.gz"):
+        row, c, t, b, nt, nb = map(int, l.split())
+        a, bb, na, nbb = u32(), u32(), u32(), u32()
+        ok = oracle_lib.h2o_map_glf1(g, row, c, a, bb, na, nbb)
+        if t == 0 and b == 0:
+            assert not ok, l
+        else:
+            assert ok and (a.value, bb.value, na.value, nbb.value) == (t, b, nt, nb), l
+            wide += (b - t) > 1
+    assert wide >= 5
+
+
+def _psearch_graph(oracle_lib, golden_dir, g1s_index, fn, pseudo):
+    ix = H.load_index(oracle_lib, g1s_index)
+    _, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_snp.fa.gz"))
+    u32 = C.c_uint32
+    n = 0
+    for l in H.glines(golden_dir, fn):
+        f = l.split()
+        v = list(map(int, f[:15]))
+        ie = [tuple(map(int, x.split(":"))) for x in f[16:]]
+        rid, fw = v[0], v[1]
+        seq = np.ascontiguousarray(seqs[rid] if fw else H.revcomp(seqs[rid]))
+        o = H.BwtHit()
+        buf = (u32 * 128)()
+        nie = u32()
+        oracle_lib.h2o_partial_search_graph(ix, seq.ctypes.data, len(seq), 0, pseudo, 1, 10, 20, C.byref(o), buf, 64, nie)
+        got = [o.top, o.bot, o.node_top, o.node_bot, o.bwoff, o.len, o.hit_type, o.cur, o.done,
+               o.numPartialSearch, o.numUniqueSearch, o.pseudogeneStop, o.anchorStop]
+        assert got == v[2:], (rid, fw, got, v[2:])
+        assert [(buf[2 * i], buf[2 * i + 1]) for i in range(nie.value)] == ie
+        n += 1
+    assert n == 600
+
+
+def test_graph_partial_search(oracle_lib, g1s_index, golden_dir):
+    _psearch_graph(oracle_lib, golden_dir, g1s_index, "probe_g1s_psearch.txt.gz", 0)
+
+
+def test_graph_partial_search_spliced_mode(oracle_lib, g1s_index, golden_dir):
+    # pseudogeneStop is only ever armed on linear indexes (hi_aligner.h:4669), so spliced mode == no-spliced here
+    _psearch_graph(oracle_lib, golden_dir, g1s_index, "probe_g1s_psearch_spliced.txt.gz", 0)
