@@ -227,6 +227,17 @@ def main():
             micro[name] = {"ms": ms, "GB/s": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "checksum": int(ck)}
         rst.close()
         rix.close()
+        # same micro-kernel on GRAPH sides (128 B = one L2 line): 7.65 M synthetic sides = the same 0.98 GB
+        gix = api.Index(synth_sides=7_650_000, seed=SEED, device=local, graph=True)
+        gst = api.Stream(gix)
+        micro_g = {}
+        for v, name in ((0, "lane_per_side"), (1, "8_lanes_per_side")):
+            gst.rank_synth(a.rank_queries, SEED, variant=v, repeats=1)
+            ms, ck = gst.rank_synth(a.rank_queries, SEED, variant=v, repeats=3)
+            gbs = a.rank_queries * 128 / (ms * 1e-3) / 1e9
+            micro_g[name] = {"ms": ms, "GB/s": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "checksum": int(ck)}
+        gst.close()
+        gix.close()
         nver = 2000
         verify_sample(base, reads, got, nver)          # seed stage vs oracle/h2o.c
         cpu_ref, ref_sam = (None, None)
@@ -291,6 +302,7 @@ def main():
                        "sharding": f"reads by id range across {world} GPU(s), index replicated; RCCL all-reduce of summary counters only"},
             "roofline": roofline,
             "rank_microbench": {"sides": 15_300_000, "bytes": 15_300_000 * 64, "queries": a.rank_queries, **micro},
+            "rank_microbench_graph": {"sides": 7_650_000, "bytes": 7_650_000 * 128, "queries": a.rank_queries, **micro_g},
             "seed_stage": seed_stage,
             "paired_end": pe,
             "counters": {"reads_aligned": int(asum[0]), "reads_multi": int(asum[1]), "reads_overflow": int(asum[2]),

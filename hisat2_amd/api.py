@@ -41,6 +41,24 @@ class FmHit(C.Structure):
     _fields_ = [(n, u32) for n in FM_HIT_FIELDS]
 
 
+H2G_IEDGE_CAP = 24
+
+
+class IEdges(C.Structure):           # h2g_iedges
+    _fields_ = [("n", u32), ("e", (u32 * 2) * H2G_IEDGE_CAP)]
+
+    def pairs(self):
+        return [(self.e[i][0], self.e[i][1]) for i in range(min(self.n, H2G_IEDGE_CAP))]
+
+
+class GlfQuery(C.Structure):         # h2g_glf_query
+    _fields_ = [("top", u32), ("bot", u32), ("c", C.c_uint8), ("single", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
+class GlfResult(C.Structure):        # h2g_glf_result
+    _fields_ = [("ok", u32), ("top", u32), ("bot", u32), ("node_top", u32), ("node_bot", u32)]
+
+
 class SaQuery(C.Structure):
     _fields_ = [("top", u32), ("bot", u32), ("maxelt", u32), ("len", u32), ("rejectStraddle", u32)]
 
@@ -133,6 +151,7 @@ EXPORTS = [
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_align_params_init", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
     "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch",
+    "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides",
 ]
 
 
@@ -169,6 +188,9 @@ def lib():
     L.h2g_rank_bench_synth.argtypes = [vp, C.c_size_t, u64, C.c_int, C.c_int, P(C.c_float), P(u64)]
     L.h2g_fm_search.argtypes = [vp, vp, C.c_size_t, u32, vp]
     L.h2g_sa_resolve.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
+    L.h2g_graph_lf.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
+    L.h2g_fm_search_graph.argtypes = [vp, vp, C.c_size_t, u32, u32, vp, vp]
+    L.h2g_index_synth_graph_sides.argtypes = [u64, u64, C.c_int, P(vp)]
     L.h2g_extend.argtypes = [vp, vp, vp, C.c_size_t, vp]
     L.h2g_seed_params_init.argtypes = [P(SeedParams), vp, C.c_int]
     L.h2g_seed_params_init.restype = None
@@ -194,10 +216,13 @@ def _chk(rc, what):
 
 
 class Index:
-    def __init__(self, base=None, device=0, synth_sides=None, seed=20260925):
+    def __init__(self, base=None, device=0, synth_sides=None, seed=20260925, graph=False):
         L = lib()
         self.h = C.c_void_p()
-        if synth_sides is not None:
+        if synth_sides is not None and graph:
+            _chk(L.h2g_index_synth_graph_sides(int(synth_sides), int(seed), int(device), C.byref(self.h)),
+                 "h2g_index_synth_graph_sides")
+        elif synth_sides is not None:
             _chk(L.h2g_index_synth_sides(int(synth_sides), int(seed), int(device), C.byref(self.h)), "h2g_index_synth_sides")
         else:
             o = LoadOpts(device, 1)
@@ -253,6 +278,23 @@ class Stream:
         out = (FmHit * n)()
         _chk(lib().h2g_fm_search(self.h, q, n, khits, out), "h2g_fm_search")
         return out
+
+    def graph_lf(self, queries, k=10):
+        """GFM::mapGLF / mapGLF1 on a graph index -> (results, in-edge lists)"""
+        n = len(queries)
+        q = (GlfQuery * n)(*queries)
+        res = (GlfResult * n)()
+        ie = (IEdges * n)()
+        _chk(lib().h2g_graph_lf(self.h, q, n, k, res, ie), "h2g_graph_lf")
+        return res, ie
+
+    def fm_search_graph(self, queries, khits=10, kseeds=20):
+        n = len(queries)
+        q = (FmQuery * n)(*queries)
+        out = (FmHit * n)()
+        ie = (IEdges * n)()
+        _chk(lib().h2g_fm_search_graph(self.h, q, n, khits, kseeds, out, ie), "h2g_fm_search_graph")
+        return out, ie
 
     def sa_resolve(self, queries, cap=16):
         n = len(queries)

@@ -20,13 +20,14 @@
 namespace h2g {
 
 // ------------------------------------------------------------------------------------------ device views
-struct DGfm {   // one linear 32-bit GFM resident in HBM (sides exactly as on disk)
+struct DGfm {   // one 32-bit GFM resident in HBM (sides exactly as on disk: 64 B linear / 128 B graph)
 	const uint8_t*  sides;
 	const uint32_t* ftab;
 	const uint32_t* eftab;
 	const uint32_t* offs;
 	const uint32_t* rstarts;
 	const uint32_t* plen;
+	const uint32_t* zoffs;   // all '$' rows (graph indexes may hold several; zoff == zoffs[0])
 	uint32_t fchr[5];
 	uint32_t len, gbwtLen, ftabLim, sideGbwtLen, sideGbwtSz, lineRate, offRate, offMask, ftabChars;
 	uint32_t nFrag, nPat, nZ, zoff, minK, linear;

@@ -11,6 +11,7 @@
 #include "h2g_core.h"
 #include "h2g_host_index.h"
 #include "h2g_align.h"
+#include "h2g_graph.h"
 #include "h2g_local_pack.h"
 
 using namespace h2g;
@@ -115,7 +116,8 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	int s = H2G_OK;
 	if((s = upload(ix, g.sides, &ix->dg.sides, 256)) || (s = upload(ix, g.ftab, &ix->dg.ftab)) ||
 	   (s = upload(ix, g.eftab, &ix->dg.eftab)) || (s = upload(ix, g.offs, &ix->dg.offs)) ||
-	   (s = upload(ix, g.rstarts, &ix->dg.rstarts)) || (s = upload(ix, g.plen, &ix->dg.plen))) { h2g_index_free(ix); return s; }
+	   (s = upload(ix, g.rstarts, &ix->dg.rstarts)) || (s = upload(ix, g.plen, &ix->dg.plen)) ||
+	   (s = upload(ix, g.zOffs, &ix->dg.zoffs))) { h2g_index_free(ix); return s; }
 	const HostRef& r = ix->host.r;
 	ix->dr.nrefs = r.nrefs;
 	if((s = upload(ix, r.buf, &ix->dr.buf)) || (s = upload(ix, r.rec_start, &ix->dr.rec_start)) ||
@@ -162,15 +164,21 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 // fills payloads with random symbols; per-side symbol counts go to cnt[side*4 + c]
-__global__ void k_synth_fill(uint8_t* sides, uint32_t* cnt, uint64_t nsides, uint64_t seed) {
+// (sideSz 64: 6 payload words, occ at +48; sideSz 128: 6.5 payload words, random F/M bits, zero headers, occ at +112)
+__global__ void k_synth_fill(uint8_t* sides, uint32_t* cnt, uint64_t nsides, uint64_t seed, uint32_t sideSz) {
 	uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
 	if(s >= nsides) return;
-	uint64_t* w = reinterpret_cast<uint64_t*>(sides + s * 64);
+	uint64_t* w = reinterpret_cast<uint64_t*>(sides + s * sideSz);
 	uint32_t c[4] = {0, 0, 0, 0};
 	for(int k = 0; k < 6; k++) {
-		uint64_t v = splitmix64(seed + s * 8 + k);
+		uint64_t v = splitmix64(seed + s * 16 + k);
 		w[k] = v;
 		for(int cc = 0; cc < 4; cc++) c[cc] += count_word(v, cc, 32);
+	}
+	if(sideSz == 128) {
+		for(int k = 6; k < 13; k++) w[k] = splitmix64(seed + s * 16 + k);
+		w[13] = 0;
+		for(int cc = 0; cc < 4; cc++) c[cc] += count_word(w[6], cc, 16);
 	}
 	for(int cc = 0; cc < 4; cc++) cnt[s * 4 + cc] = c[cc];
 }
@@ -191,20 +199,21 @@ __global__ void k_synth_chunk_scan(uint32_t* chunk, uint32_t* totals) {
 	for(uint32_t t = 0; t < SYNTH_CHUNKS; t++) { uint32_t v = chunk[t * 4 + c]; chunk[t * 4 + c] = run; run += v; }
 	totals[c] = run;
 }
-__global__ void k_synth_write(uint8_t* sides, const uint32_t* cnt, uint64_t nsides, const uint32_t* chunk) {
+__global__ void k_synth_write(uint8_t* sides, const uint32_t* cnt, uint64_t nsides, const uint32_t* chunk, uint32_t sideSz) {
 	uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
 	if(t >= SYNTH_CHUNKS) return;
 	uint64_t per = (nsides + SYNTH_CHUNKS - 1) / SYNTH_CHUNKS, a = t * per, b = a + per < nsides ? a + per : nsides;
 	uint32_t run[4];
 	for(int k = 0; k < 4; k++) run[k] = chunk[t * 4 + k];
 	for(uint64_t s = a; s < b; s++) {
-		uint32_t* occ = reinterpret_cast<uint32_t*>(sides + s * 64 + 48);
+		uint32_t* occ = reinterpret_cast<uint32_t*>(sides + s * sideSz + sideSz - 16);
 		for(int k = 0; k < 4; k++) { occ[k] = run[k]; run[k] += cnt[s * 4 + k]; }
 	}
 }
 
-extern "C" h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out) {
-	if(!out || num_sides == 0 || num_sides * 192ull >= 0xffffffffull) return H2G_ERR_ARG;
+static h2g_status synth_sides(uint64_t num_sides, uint64_t seed, int device, uint32_t sideSz, h2g_index** out) {
+	const uint32_t syms = sideSz == 64 ? 192u : H2G_GSIDE_SYMS;
+	if(!out || num_sides == 0 || num_sides * (uint64_t)syms >= 0xffffffffull) return H2G_ERR_ARG;
 	int ndev = 0;
 	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { snprintf(g_err, sizeof g_err, "no HIP device"); return H2G_ERR_DEVICE; }
 	HIPCHK(hipSetDevice(device));
@@ -212,28 +221,30 @@ extern "C" h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, i
 	ix->synthetic = true;
 	ix->device = device;
 	void *sides = nullptr, *cnt = nullptr, *tot = nullptr;
+	const size_t bytes = num_sides * sideSz + 256;
 	{   // measurement knob: H2G_SIDES_MTYPE=uncached|finegrained allocates the side array with that memory type
 		const char* mt = getenv("H2G_SIDES_MTYPE");
-		if(mt && !strcmp(mt, "uncached")) HIPCHK(hipExtMallocWithFlags(&sides, num_sides * 64 + 256, hipDeviceMallocUncached));
-		else if(mt && !strcmp(mt, "finegrained")) HIPCHK(hipExtMallocWithFlags(&sides, num_sides * 64 + 256, hipDeviceMallocFinegrained));
-		else HIPCHK(hipMalloc(&sides, num_sides * 64 + 256));
+		if(mt && !strcmp(mt, "uncached")) HIPCHK(hipExtMallocWithFlags(&sides, bytes, hipDeviceMallocUncached));
+		else if(mt && !strcmp(mt, "finegrained")) HIPCHK(hipExtMallocWithFlags(&sides, bytes, hipDeviceMallocFinegrained));
+		else HIPCHK(hipMalloc(&sides, bytes));
 	}
 	HIPCHK(hipMalloc(&cnt, num_sides * 16));
 	HIPCHK(hipMalloc(&tot, 16));
 	ix->allocs.push_back(sides);
-	ix->device_bytes = num_sides * 64;
-	hipLaunchKernelGGL(k_synth_fill, dim3((unsigned)((num_sides + 255) / 256)), dim3(256), 0, 0, (uint8_t*)sides, (uint32_t*)cnt, num_sides, seed);
+	ix->device_bytes = num_sides * sideSz;
+	hipLaunchKernelGGL(k_synth_fill, dim3((unsigned)((num_sides + 255) / 256)), dim3(256), 0, 0, (uint8_t*)sides, (uint32_t*)cnt, num_sides, seed, sideSz);
 	void* chunk = nullptr;
 	HIPCHK(hipMalloc(&chunk, SYNTH_CHUNKS * 16));
 	hipLaunchKernelGGL(k_synth_chunk_sum, dim3(SYNTH_CHUNKS / 256), dim3(256), 0, 0, (const uint32_t*)cnt, num_sides, (uint32_t*)chunk);
 	hipLaunchKernelGGL(k_synth_chunk_scan, dim3(1), dim3(64), 0, 0, (uint32_t*)chunk, (uint32_t*)tot);
-	hipLaunchKernelGGL(k_synth_write, dim3(SYNTH_CHUNKS / 256), dim3(256), 0, 0, (uint8_t*)sides, (const uint32_t*)cnt, num_sides, (const uint32_t*)chunk);
+	hipLaunchKernelGGL(k_synth_write, dim3(SYNTH_CHUNKS / 256), dim3(256), 0, 0, (uint8_t*)sides, (const uint32_t*)cnt, num_sides, (const uint32_t*)chunk, sideSz);
 	uint32_t totals[4];
 	HIPCHK(hipMemcpy(totals, tot, 16, hipMemcpyDeviceToHost));
 	(void)hipFree(cnt); (void)hipFree(tot); (void)hipFree(chunk);
 	GfmParams& p = ix->host.g.p;
-	uint32_t len = (uint32_t)(num_sides * 192 - 1);
-	p.init(len, len + 1, len + 1, 6, 4, 10, 0, 4);
+	uint32_t len = (uint32_t)(num_sides * syms - 1);
+	if(sideSz == 64) p.init(len, len + 1, len + 1, 6, 4, 10, 0, 4);
+	else p.init(len - 1000, len + 1, len - 500, 7, 4, 10, 0, 4);   // gbwtLen != len + 1 => graph (gfm.h:139)
 	p.numSides = (uint32_t)num_sides;
 	ix->host.g.fchr[0] = 0;
 	for(int c = 0; c < 4; c++) ix->host.g.fchr[c + 1] = ix->host.g.fchr[c] + totals[c];
@@ -242,6 +253,12 @@ extern "C" h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, i
 	ix->dg.nZ = 0;
 	*out = ix;
 	return H2G_OK;
+}
+extern "C" h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out) {
+	return synth_sides(num_sides, seed, device, 64, out);
+}
+extern "C" h2g_status h2g_index_synth_graph_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out) {
+	return synth_sides(num_sides, seed, device, 128, out);
 }
 
 // ------------------------------------------------------------------------------------------ stream
@@ -445,6 +462,65 @@ __global__ __launch_bounds__(256) void k_rank_exp(DGfm g, uint32_t* out, size_t 
 	}
 }
 
+// ---- graph sides (128 B = one L2 line) --------------------------------------------------------------------
+// g0: one lane per query, 8 x dwordx4
+__global__ __launch_bounds__(256) void k_rank_g0(DGfm g, const uint32_t* rows, const uint8_t* cs, uint32_t* out,
+                                                 size_t n, uint64_t seed, int synth)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		uint32_t row; int c;
+		if(synth) { uint64_t h = splitmix64(seed + i); row = (uint32_t)(h % g.gbwtLen); c = (int)((h >> 40) & 3); }
+		else { row = rows[i]; c = cs[i]; }
+		out[i] = rank128(g, row, c);
+	}
+}
+// g1: eight lanes per side, one dwordx4 each => one fully coalesced 128 B request per query.  Lanes 0..3 hold
+// the symbols (lane 3 only 16 of them), lane 7 the Occ words; 3-step butterfly reduce within the 8-lane group.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_rank_g1(DGfm g, const uint32_t* rows, const uint8_t* cs, uint32_t* out,
+                                                 size_t n, uint64_t seed, int synth)
+{
+	const uint32_t lane = threadIdx.x & 63, sub = lane & 7, grp = lane >> 3;
+	const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	for(size_t base = wave * 8 * UNROLL; base < n; base += nwaves * 8 * UNROLL) {
+		uint4 v[UNROLL]; uint32_t off[UNROLL], sn[UNROLL]; int cc[UNROLL]; bool ok[UNROLL];
+#pragma unroll
+		for(int u = 0; u < UNROLL; u++) {
+			const size_t i = base + (size_t)u * 8 + grp;
+			ok[u] = i < n;
+			uint32_t row = 0; int c = 0;
+			if(ok[u]) {
+				if(synth) { uint64_t h = splitmix64(seed + i); row = (uint32_t)(h % g.gbwtLen); c = (int)((h >> 40) & 3); }
+				else { row = rows[i]; c = cs[i]; }
+			}
+			sn[u] = row / H2G_GSIDE_SYMS; off[u] = row - sn[u] * H2G_GSIDE_SYMS; cc[u] = c;
+			v[u] = reinterpret_cast<const uint4*>(g.sides + (size_t)sn[u] * 128)[sub];
+		}
+#pragma unroll
+		for(int u = 0; u < UNROLL; u++) {
+			const uint64_t w0 = v[u].x | ((uint64_t)v[u].y << 32), w1 = v[u].z | ((uint64_t)v[u].w << 32);
+			const int c = cc[u];
+			uint32_t cnt = 0;
+			if(sub < 3) cnt = count_word(w0, c, (int)off[u] - 64 * (int)sub) + count_word(w1, c, (int)off[u] - 64 * (int)sub - 32);
+			else if(sub == 3) cnt = count_word(w0 & 0xffffffffull, c, (int)off[u] - 192 > 16 ? 16 : (int)off[u] - 192);
+			else if(sub == 7) {
+				const uint64_t ow = (c & 2) ? w1 : w0;
+				cnt = (c & 1) ? (uint32_t)(ow >> 32) : (uint32_t)ow;
+			}
+			cnt += __shfl_xor(cnt, 1); cnt += __shfl_xor(cnt, 2); cnt += __shfl_xor(cnt, 4);
+			if(sub == 0 && ok[u]) {
+				if(c == 0 && g.nZ) {
+					const uint32_t zs = g.zoff / H2G_GSIDE_SYMS, zc = g.zoff - zs * H2G_GSIDE_SYMS;
+					if(zs == sn[u] && zc < off[u]) cnt--;
+				}
+				const uint32_t fc = c == 0 ? g.fchr[0] : c == 1 ? g.fchr[1] : c == 2 ? g.fchr[2] : g.fchr[3];
+				out[base + (size_t)u * 8 + grp] = cnt + fc;
+			}
+		}
+	}
+}
+
 __global__ void k_checksum(const uint32_t* v, size_t n, unsigned long long* out) {
 	unsigned long long acc = 0;
 	size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -458,11 +534,17 @@ static int launch_rank(h2g_stream* s, const uint32_t* d_rows, const uint8_t* d_c
                        uint64_t seed, int synth, int variant, int repeats, float* ms)
 {
 	const DGfm& g = s->ix->dg;
-	if(!g.linear || g.lineRate != 6) { snprintf(g_err, sizeof g_err, "rank kernels: linear 64 B sides only"); return H2G_ERR_UNSUPPORTED; }
+	const bool graph = !g.linear && g.lineRate == 7;
+	if(!graph && (!g.linear || g.lineRate != 6)) { snprintf(g_err, sizeof g_err, "rank kernels: 64 B linear or 128 B graph sides only"); return H2G_ERR_UNSUPPORTED; }
+	if(graph && g.nZ > 1 && variant == 1) variant = 0;   // the cooperative kernel handles a single '$' row
 	if(repeats < 1) repeats = 1;
 	HIPCHK(hipEventRecord(s->ev[0], s->st));
 	for(int r = 0; r < repeats; r++) {
-		if(variant == 0) {
+		if(graph) {
+			if(variant == 0) hipLaunchKernelGGL(k_rank_g0, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
+			else if(variant == 1) hipLaunchKernelGGL(k_rank_g1<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
+			else return H2G_ERR_ARG;
+		} else if(variant == 0) {
 			hipLaunchKernelGGL(k_rank_v0, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
 		} else if(variant == 1) {
 			hipLaunchKernelGGL(k_rank_v1<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
@@ -559,8 +641,44 @@ __global__ __launch_bounds__(256) void k_extend(DRef ref, DReads rd, DScoring sc
 	}
 }
 
+__global__ __launch_bounds__(256) void k_graph_lf(DGfm g, const h2g_glf_query* q, size_t n, uint32_t k, h2g_glf_result* res, h2g_iedges* ie)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		GRange r;
+		IEdges e;
+		e.n = 0;
+		bool ok;
+		if(q[i].single) ok = map_glf1(g, q[i].top, q[i].c, &r);
+		else ok = map_glf(g, q[i].top, q[i].bot, q[i].c, k, &r, &e);
+		h2g_glf_result o;
+		o.ok = ok; o.top = r.top; o.bot = r.bot; o.node_top = r.node_top; o.node_bot = r.node_bot;
+		res[i] = o;
+		if(ie) {
+			ie[i].n = e.n;
+			for(uint32_t j = 0; j < e.n && j < H2G_IEDGE_CAP; j++) { ie[i].e[j][0] = e.e[j][0]; ie[i].e[j][1] = e.e[j][1]; }
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_fm_search_graph(DGfm g, DReads rd, const h2g_fm_query* q, size_t n, uint32_t khits,
+                                                         uint32_t kseeds, h2g_fm_hit* out, h2g_iedges* ie)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		SeqView sv = seq_view(rd, q[i].read, q[i].fw != 0);
+		partial_search_graph_item(g, sv, q[i].offset, q[i].pseudogeneStop != 0, q[i].anchorStop != 0, khits, kseeds, &out[i],
+		                          ie ? &ie[i] : nullptr);
+	}
+}
+
 static int need_reads(h2g_stream* s) {
 	if(s->n_reads == 0) { snprintf(g_err, sizeof g_err, "no read batch set (h2g_set_reads)"); return H2G_ERR_ARG; }
+	return H2G_OK;
+}
+static int need_graph(h2g_stream* s) {
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	if(s->ix->dg.linear || s->ix->dg.lineRate != 7) { snprintf(g_err, sizeof g_err, "not a graph (GFM, 128 B side) index"); return H2G_ERR_ARG; }
 	return H2G_OK;
 }
 static int need_linear(h2g_stream* s) {
@@ -569,9 +687,57 @@ static int need_linear(h2g_stream* s) {
 	return H2G_OK;
 }
 
+extern "C" h2g_status h2g_graph_lf(h2g_stream* s, const h2g_glf_query* q, size_t n, uint32_t k, h2g_glf_result* res, h2g_iedges* iedges) {
+	if(!s || !q || !res || n == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_graph(s))) return rc;
+	const uint32_t glen = s->ix->dg.gbwtLen;
+	for(size_t i = 0; i < n; i++) {
+		if(q[i].c > 3 || q[i].top >= glen) return H2G_ERR_ARG;
+		if(!q[i].single && (q[i].bot <= q[i].top + 1 || q[i].bot > glen)) return H2G_ERR_ARG;   // bloc.valid(): bot - top > 1
+	}
+	HIPCHK(hipSetDevice(s->ix->device));
+	void *dq, *dres, *die = nullptr;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * sizeof *res, &dres))) return rc;
+	if(iedges && (rc = tmp_buf(s, 2, n * sizeof *iedges, &die))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	hipLaunchKernelGGL(k_graph_lf, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, (const h2g_glf_query*)dq, n, k, (h2g_glf_result*)dres, (h2g_iedges*)die);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
+	if(iedges) HIPCHK(hipMemcpyAsync(iedges, die, n * sizeof *iedges, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_fm_search_graph(h2g_stream* s, const h2g_fm_query* q, size_t n, uint32_t khits, uint32_t kseeds,
+                                          h2g_fm_hit* out, h2g_iedges* iedges)
+{
+	if(!s || !q || !out || n == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s)) || (rc = need_graph(s))) return rc;
+	for(size_t i = 0; i < n; i++) {
+		if(q[i].read >= s->n_reads) return H2G_ERR_ARG;
+		if(q[i].mode != H2G_FM_PARTIAL) { snprintf(g_err, sizeof g_err, "fm_search: only H2G_FM_PARTIAL built"); return H2G_ERR_UNSUPPORTED; }
+	}
+	HIPCHK(hipSetDevice(s->ix->device));
+	void *dq, *dout, *die = nullptr;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * sizeof *out, &dout))) return rc;
+	if(iedges && (rc = tmp_buf(s, 2, n * sizeof *iedges, &die))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	hipLaunchKernelGGL(k_fm_search_graph, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), (const h2g_fm_query*)dq, n,
+	                   khits, kseeds, (h2g_fm_hit*)dout, (h2g_iedges*)die);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
+	if(iedges) HIPCHK(hipMemcpyAsync(iedges, die, n * sizeof *iedges, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
 extern "C" h2g_status h2g_fm_search(h2g_stream* s, const h2g_fm_query* q, size_t n, uint32_t khits, h2g_fm_hit* out) {
 	if(!s || !q || !out || n == 0) return H2G_ERR_ARG;
 	int rc;
+	if(s->ix && !s->ix->synthetic && !s->ix->dg.linear && s->ix->dg.lineRate == 7)
+		return h2g_fm_search_graph(s, q, n, khits, khits * 2 > 5 ? khits * 2 : 5, out, nullptr);
 	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
 	for(size_t i = 0; i < n; i++) {
 		if(q[i].read >= s->n_reads) return H2G_ERR_ARG;

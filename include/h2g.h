@@ -82,6 +82,7 @@ H2G_EXPORT h2g_status h2g_set_reads(h2g_stream*, const uint8_t* codes, const uin
 
 /* GFM::mapLF(SideLocus(row), c) -> countBt2Side (gfm.h:3712, :2958): the Occ-rank micro-kernel.
  * variant: 0 = one lane per side, 1 = 4 lanes per side (16 B each + DPP reduce), 2 = 8 lanes per side.
+ * On a graph index (128 B sides): 0 = one lane per side (8 x dwordx4), 1 = 8 lanes per side.
  * rows/cs/out are HOST arrays unless device_ptrs != 0.  *kernel_ms = HIP-event time of the kernel. */
 H2G_EXPORT h2g_status h2g_rank_bench(h2g_stream*, const uint32_t* rows, const uint8_t* cs, size_t n, uint32_t* out,
                                      int variant, int device_ptrs, int repeats, float* kernel_ms);
@@ -110,6 +111,27 @@ typedef struct {
 } h2g_fm_hit;
 
 H2G_EXPORT h2g_status h2g_fm_search(h2g_stream*, const h2g_fm_query* q, size_t n, uint32_t khits, h2g_fm_hit* out);
+
+/* ---- graph (GFM) index primitives: 128 B sides with F/M bit vectors (gfm.h:160-176) ------------------- */
+/* BWTHit::_node_iedge_count (hi_aligner.h:199): nodes of a range with more than one incoming edge */
+#define H2G_IEDGE_CAP 24
+typedef struct {
+	uint32_t n;                        /* true count; only the first H2G_IEDGE_CAP entries are stored */
+	uint32_t e[H2G_IEDGE_CAP][2];      /* {node index relative to node_top, extra in-edges} */
+} h2g_iedges;
+/* single == 0: GFM::mapGLF(tloc(top), bloc(bot), c, &node_range, &node_iedges, k)   (gfm.h:3759-3837)
+ * single != 0: GFM::mapGLF1(top, loc(top), c, &node_range)                          (gfm.h:3957-4021) */
+typedef struct { uint32_t top, bot; uint8_t c, single, pad[2]; } h2g_glf_query;
+typedef struct { uint32_t ok, top, bot, node_top, node_bot; } h2g_glf_result;   /* ok == 0: empty (0,0) */
+H2G_EXPORT h2g_status h2g_graph_lf(h2g_stream*, const h2g_glf_query* q, size_t n, uint32_t k, h2g_glf_result* res,
+                                   h2g_iedges* iedges /* [n] or NULL */);
+/* partialSearch on a graph index (h2g_fm_search forwards here with kseeds = max(5, 2 khits), hisat2.cpp:3177);
+ * iedges[n] (or NULL) receives the in-edge list the BWTHit is initialised with (hi_aligner.h:6570-6578) */
+H2G_EXPORT h2g_status h2g_fm_search_graph(h2g_stream*, const h2g_fm_query* q, size_t n, uint32_t khits, uint32_t kseeds,
+                                          h2g_fm_hit* out, h2g_iedges* iedges);
+/* Roofline helper, graph flavour of h2g_index_synth_sides: random 128 B graph sides with consistent Occ
+ * checkpoints (F/M bits random, headers zero); only rank queries (h2g_rank_bench*) are valid on it. */
+H2G_EXPORT h2g_status h2g_index_synth_graph_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out);
 
 /* HI_Aligner::getGenomeCoords (hi_aligner.h:5774-5855): GroupWalk2S::advanceElement + GFM::joinedToTextOff */
 typedef struct { uint32_t top, bot, maxelt, len; uint32_t rejectStraddle; } h2g_sa_query;

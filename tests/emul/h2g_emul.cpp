@@ -8,6 +8,7 @@
 #include "../../hisat2_amd/csrc/h2g_core.h"
 #include "../../hisat2_amd/csrc/h2g_host_index.h"
 #include "../../hisat2_amd/csrc/h2g_align.h"
+#include "../../hisat2_amd/csrc/h2g_graph.h"
 #include "../../hisat2_amd/csrc/h2g_local_pack.h"
 
 using namespace h2g;
@@ -39,7 +40,7 @@ int h2gemu_load(const char* base, Emu** out) {
 	const HostGfm& g = e->host.g;
 	DGfm& d = e->dg;
 	d.sides = g.sides.data(); d.ftab = g.ftab.data(); d.eftab = g.eftab.data(); d.offs = g.offs.data();
-	d.rstarts = g.rstarts.data(); d.plen = g.plen.data();
+	d.rstarts = g.rstarts.data(); d.plen = g.plen.data(); d.zoffs = g.zOffs.data();
 	for(int i = 0; i < 5; i++) d.fchr[i] = g.fchr[i];
 	d.len = g.p.len; d.gbwtLen = g.p.gbwtLen; d.ftabLim = g.p.linear ? g.p.len : g.p.gbwtLen;
 	d.sideGbwtLen = g.p.sideGbwtLen; d.sideGbwtSz = g.p.sideGbwtSz; d.lineRate = g.p.lineRate; d.offRate = g.p.offRate;
@@ -50,7 +51,7 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dr.buf = r.buf.data(); e->dr.rec_start = r.rec_start.data(); e->dr.rec_len = r.rec_len.data();
 	e->dr.rec_bufoff = r.rec_bufoff.data(); e->dr.refRecOffs = r.refRecOffs.data(); e->dr.refLens = r.refLens.data();
 	e->dr.nrefs = r.nrefs;
-	pack_local(e->host, e->lp);
+	if(g.p.linear) pack_local(e->host, e->lp);
 	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data());
 	*out = e;
 	return 0;
@@ -64,7 +65,28 @@ void h2gemu_set_reads(Emu* e, const uint8_t* codes, const uint32_t* offs, const 
 }
 
 void h2gemu_rank(Emu* e, const uint32_t* rows, const uint8_t* cs, size_t n, uint32_t* out) {
-	for(size_t i = 0; i < n; i++) out[i] = rank64(e->dg, rows[i], cs[i]);
+	const bool graph = !e->dg.linear;
+	for(size_t i = 0; i < n; i++) out[i] = graph ? rank128(e->dg, rows[i], cs[i]) : rank64(e->dg, rows[i], cs[i]);
+}
+
+void h2gemu_graph_lf(Emu* e, const h2g_glf_query* q, size_t n, uint32_t k, h2g_glf_result* res, h2g_iedges* ie) {
+	for(size_t i = 0; i < n; i++) {
+		GRange r;
+		IEdges x;
+		x.n = 0;
+		bool ok = q[i].single ? map_glf1(e->dg, q[i].top, q[i].c, &r) : map_glf(e->dg, q[i].top, q[i].bot, q[i].c, k, &r, &x);
+		res[i].ok = ok; res[i].top = r.top; res[i].bot = r.bot; res[i].node_top = r.node_top; res[i].node_bot = r.node_bot;
+		if(ie) ie[i] = x;
+	}
+}
+
+void h2gemu_fm_search_graph(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, uint32_t kseeds, h2g_fm_hit* out, h2g_iedges* ie) {
+	DReads rd = e->reads();
+	for(size_t i = 0; i < n; i++) {
+		SeqView sv = seq_view(rd, q[i].read, q[i].fw != 0);
+		partial_search_graph_item(e->dg, sv, q[i].offset, q[i].pseudogeneStop != 0, q[i].anchorStop != 0, khits, kseeds, &out[i],
+		                          ie ? &ie[i] : nullptr);
+	}
 }
 
 void h2gemu_fm_search(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, h2g_fm_hit* out) {

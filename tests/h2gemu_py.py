@@ -20,6 +20,8 @@ class Emu:
         self.L.h2gemu_rank.argtypes = [vp, vp, vp, C.c_size_t, vp]
         self.L.h2gemu_fm_search.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
         self.L.h2gemu_sa_resolve.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
+        self.L.h2gemu_graph_lf.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
+        self.L.h2gemu_fm_search_graph.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp]
         self.L.h2gemu_extend.argtypes = [vp, vp, vp, C.c_size_t, vp]
         self.L.h2gemu_seed_extend.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
         self.h = vp()
@@ -47,6 +49,22 @@ class Emu:
         out = (api.FmHit * n)()
         self.L.h2gemu_fm_search(self.h, q, n, khits, out)
         return out
+
+    def graph_lf(self, queries, k=10):
+        n = len(queries)
+        q = (api.GlfQuery * n)(*queries)
+        res = (api.GlfResult * n)()
+        ie = (api.IEdges * n)()
+        self.L.h2gemu_graph_lf(self.h, q, n, k, res, ie)
+        return res, ie
+
+    def fm_search_graph(self, queries, khits=10, kseeds=20):
+        n = len(queries)
+        q = (api.FmQuery * n)(*queries)
+        out = (api.FmHit * n)()
+        ie = (api.IEdges * n)()
+        self.L.h2gemu_fm_search_graph(self.h, q, n, khits, kseeds, out, ie)
+        return out, ie
 
     def sa_resolve(self, queries, cap=16):
         n = len(queries)

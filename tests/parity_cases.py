@@ -136,3 +136,71 @@ def assert_seed_equal(got, want):
         assert np.array_equal(got["hit"][f], want["hit"][f]), f
     for f in ("tidx", "toff", "joinedOff", "rdoff", "len", "score"):
         assert np.array_equal(got["ext"][f], want["ext"][f]), f
+
+
+# ---------------------------------------------------------------- graph index (g1s)
+def load_snp_reads(golden_dir):
+    _, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_snp.fa.gz"))
+    L = len(seqs[0])
+    arr = np.stack(seqs)
+    offs = (np.arange(len(seqs) + 1, dtype=np.uint64) * L).astype(np.uint32)
+    return arr, offs
+
+
+def check_graph_rank(backend_rank, golden_dir):
+    rows, cs, want = [], [], []
+    for l in H.glines(golden_dir, "probe_g1s_rank.txt.gz"):
+        row, c, r, _ = map(int, l.split())
+        rows.append(row); cs.append(c); want.append(r)
+    got = backend_rank(np.array(rows, dtype=np.uint32), np.array(cs, dtype=np.uint8))
+    assert np.array_equal(got, np.array(want, dtype=np.uint32))
+    return len(rows)
+
+
+def check_graph_lf(be, golden_dir):
+    """mapGLF (ranges, k = 10 as in the probe) and mapGLF1 (single rows) against the reference GFM"""
+    qs, want = [], []
+    for l in H.glines(golden_dir, "probe_g1s_glf.txt.gz"):
+        f = l.split()
+        qs.append(api.GlfQuery(int(f[0]), int(f[1]), int(f[2]), 0))
+        want.append((tuple(map(int, f[3:7])), [tuple(map(int, x.split(":"))) for x in f[8:]]))
+    res, ie = be.graph_lf(qs, k=10)
+    nie = 0
+    for r, e, (w, wie), q in zip(res, ie, want, qs):
+        if w[0] == 0 and w[1] == 0:
+            assert not r.ok and r.top == 0 and r.bot == 0, (q.top, q.bot, q.c)
+            continue
+        assert r.ok and (r.top, r.bot, r.node_top, r.node_bot) == w, (q.top, q.bot, q.c)
+        assert e.n == len(wie) and e.pairs() == wie, (q.top, q.bot, q.c)
+        nie += bool(wie)
+    assert nie >= 20
+    qs, want = [], []
+    for l in H.glines(golden_dir, "probe_g1s_glf1.txt.gz"):
+        row, c, t, b, nt, nb = map(int, l.split())
+        qs.append(api.GlfQuery(row, row + 1, c, 1))
+        want.append((t, b, nt, nb))
+    res, _ = be.graph_lf(qs, k=10)
+    wide = 0
+    for r, w, q in zip(res, want, qs):
+        if w[0] == 0 and w[1] == 0:
+            assert not r.ok, (q.top, q.c)
+        else:
+            assert r.ok and (r.top, r.bot, r.node_top, r.node_bot) == w, (q.top, q.c)
+            wide += (w[1] - w[0]) > 1
+    assert wide >= 5
+    return len(qs)
+
+
+def check_graph_fm_search(be, golden_dir, fn="probe_g1s_psearch.txt.gz"):
+    qs, want = [], []
+    for l in H.glines(golden_dir, fn):
+        f = l.split()
+        v = list(map(int, f[:15]))
+        qs.append(api.FmQuery(v[0], 0, v[1], 0, 0, 1))
+        want.append((v[2:], [tuple(map(int, x.split(":"))) for x in f[16:]]))
+    out, ie = be.fm_search_graph(qs, khits=10, kseeds=20)
+    for o, e, (w, wie), q in zip(out, ie, want, qs):
+        got = [getattr(o, f) for f in api.FM_HIT_FIELDS[:13]]
+        assert got == w, (q.read, q.fw, got, w)
+        assert e.pairs() == wie
+    return len(qs)

@@ -46,3 +46,52 @@ def test_seed_stage_matches_oracle(oracle_lib, g1_index, golden_dir):
         want = PC.oracle_seed_extend(oracle_lib, oix, reads, pseudo)
         PC.assert_seed_equal(got, want)
     assert (got["ncoords"] > 0).sum() > 300
+
+
+# ---------------------------------------------------------------- graph index primitives (h2g_graph.h)
+@pytest.fixture(scope="module")
+def gemu(g1s_index, golden_dir):
+    e = Emu(g1s_index)
+    reads, offs = PC.load_snp_reads(golden_dir)
+    e.set_reads(reads.reshape(-1), offs)
+    return e
+
+
+def test_graph_rank(gemu, golden_dir):
+    assert PC.check_graph_rank(gemu.rank, golden_dir) == 3000
+
+
+def test_graph_lf(gemu, golden_dir):
+    assert PC.check_graph_lf(gemu, golden_dir) == 6000
+
+
+def test_graph_fm_search(gemu, golden_dir):
+    assert PC.check_graph_fm_search(gemu, golden_dir) == 600
+    assert PC.check_graph_fm_search(gemu, golden_dir, "probe_g1s_psearch_spliced.txt.gz") == 600
+
+
+def test_graph_lf_matches_oracle_on_random_ranges(gemu, oracle_lib, g1s_index):
+    """fresh seeded ranges, incl. ranges that straddle sides and tiny ranges around multi-in-edge nodes"""
+    import ctypes as C
+    import numpy as np
+    from hisat2_amd import api
+    oix = H.load_index(oracle_lib, g1s_index)
+    g = C.byref(oix.contents.g)
+    glen = oix.contents.g.p.gbwtLen
+    rng = np.random.default_rng(99)
+    qs = []
+    for _ in range(20000):
+        top = int(rng.integers(0, glen - 2))
+        spread = int(rng.integers(2, 7)) if rng.random() < 0.5 else int(rng.integers(2, 600))
+        qs.append(api.GlfQuery(top, min(glen, top + spread), int(rng.integers(0, 4)), 0))
+    qs = [q for q in qs if q.bot > q.top + 1]
+    res, ie = gemu.graph_lf(qs, k=20)
+    u32 = C.c_uint32
+    for q, r, e in zip(qs, res, ie):
+        a, b, na, nb, n = u32(), u32(), u32(), u32(), u32()
+        buf = (u32 * 128)()
+        ok = oracle_lib.h2o_map_glf(g, q.top, q.bot, q.c, 20, a, b, na, nb, buf, 64, n)
+        assert bool(ok) == bool(r.ok)
+        if ok:
+            assert (r.top, r.bot, r.node_top, r.node_bot) == (a.value, b.value, na.value, nb.value)
+            assert e.n == n.value and e.pairs() == [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n.value, 24))]

@@ -168,3 +168,110 @@ def test_full_size_properties(tmp_path):
     assert res.tobytes() == st.seed_extend_fetch().tobytes()
     st.close()
     ix.close()
+
+
+# ---------------------------------------------------------------- graph (GFM) index: 128 B sides, F/M bit vectors
+@pytest.fixture(scope="module")
+def ggpu(g1s_index, golden_dir):
+    ix = api.Index(g1s_index, device=0)
+    reads, offs = PC.load_snp_reads(golden_dir)
+    st = api.Stream(ix, max_reads=1000, max_bases=1000 * 101)
+    st.set_reads(reads.reshape(-1), offs)
+    yield st
+    st.close()
+    ix.close()
+
+
+def test_graph_index_info(ggpu, golden_dir):
+    kv = H.glines(golden_dir, "probe_g1s_params.txt.gz")[0].split()
+    d = dict(zip(kv[0::2], map(int, kv[1::2])))
+    info = ggpu.ix.info
+    assert info.linear == 0 and info.sideSz == 128
+    for k in ("len", "gbwtLen", "numNodes", "lineRate", "sideSz", "sideGbwtSz", "sideGbwtLen", "numSides", "offsLen"):
+        assert getattr(info, k) == d[k], k
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_graph_rank_golden(ggpu, golden_dir, variant):
+    assert PC.check_graph_rank(lambda r, c: ggpu.rank(r, c, variant=variant)[0], golden_dir) == 3000
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_graph_rank_vs_oracle_random(ggpu, oracle_lib, g1s_index, variant):
+    oix = H.load_index(oracle_lib, g1s_index)
+    g = C.byref(oix.contents.g)
+    rng = np.random.default_rng(15 + variant)
+    n = 30001
+    rows = rng.integers(0, ggpu.ix.info.gbwtLen, size=n, dtype=np.uint32)
+    rows[:5] = [0, 1, ggpu.ix.info.gbwtLen - 1, 207, 208]
+    cs = rng.integers(0, 4, size=n, dtype=np.uint8)
+    got, _ = ggpu.rank(rows, cs, variant=variant)
+    want = np.array([oracle_lib.h2o_rank(g, int(r), int(c)) for r, c in zip(rows, cs)], dtype=np.uint32)
+    assert np.array_equal(got, want)
+
+
+def test_graph_lf_golden(ggpu, golden_dir):
+    assert PC.check_graph_lf(ggpu, golden_dir) == 6000
+
+
+def test_graph_fm_search_golden(ggpu, golden_dir):
+    assert PC.check_graph_fm_search(ggpu, golden_dir) == 600
+    # h2g_fm_search on a graph index forwards to the graph search with kseeds = max(5, 2 khits)
+    qs = [api.FmQuery(r, 0, fw, 0, 0, 1) for r in range(50) for fw in (1, 0)]
+    a = ggpu.fm_search(qs, khits=10)
+    b, _ = ggpu.fm_search_graph(qs, khits=10, kseeds=20)
+    for x, y in zip(a, b):
+        assert [getattr(x, f) for f in api.FM_HIT_FIELDS[:13]] == [getattr(y, f) for f in api.FM_HIT_FIELDS[:13]]
+
+
+def test_graph_lf_vs_oracle_random(ggpu, oracle_lib, g1s_index):
+    oix = H.load_index(oracle_lib, g1s_index)
+    g = C.byref(oix.contents.g)
+    glen = oix.contents.g.p.gbwtLen
+    rng = np.random.default_rng(199)
+    qs = []
+    for _ in range(30000):
+        top = int(rng.integers(0, glen - 2))
+        spread = int(rng.integers(2, 7)) if rng.random() < 0.5 else int(rng.integers(2, 600))
+        if min(glen, top + spread) > top + 1:
+            qs.append(api.GlfQuery(top, min(glen, top + spread), int(rng.integers(0, 4)), 0))
+    res, ie = ggpu.graph_lf(qs, k=20)
+    u32 = C.c_uint32
+    nie = 0
+    for q, r, e in zip(qs, res, ie):
+        a, b, na, nb, n = u32(), u32(), u32(), u32(), u32()
+        buf = (u32 * 128)()
+        ok = oracle_lib.h2o_map_glf(g, q.top, q.bot, q.c, 20, a, b, na, nb, buf, 64, n)
+        assert bool(ok) == bool(r.ok)
+        if ok:
+            assert (r.top, r.bot, r.node_top, r.node_bot) == (a.value, b.value, na.value, nb.value)
+            assert e.n == n.value and e.pairs() == [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n.value, 24))]
+            nie += n.value > 0
+    assert nie > 10
+
+
+def test_graph_rank_variants_agree_on_large_synthetic_sides():
+    """1 GB of synthetic 128 B graph sides: both kernels give the same checksum; sum_c rank(row, c) == row + const"""
+    ix = api.Index(synth_sides=8_000_000, seed=11, graph=True)
+    assert ix.info.linear == 0 and ix.info.sideSz == 128
+    st = api.Stream(ix)
+    n = 1 << 23
+    cks = [st.rank_synth(n, 20260925, variant=v)[1] for v in (0, 1)]
+    assert cks[0] == cks[1] and cks[0] != 0
+    rng = np.random.default_rng(2)
+    rows = rng.integers(0, ix.info.gbwtLen, size=4096, dtype=np.uint32)
+    tot = np.zeros(len(rows), dtype=np.uint64)
+    for c in range(4):
+        r, _ = st.rank(rows, np.full(len(rows), c, dtype=np.uint8), variant=1)
+        tot += r
+    base = int(tot[0]) - int(rows[0])
+    assert np.array_equal(tot, rows.astype(np.uint64) + np.uint64(base))
+    st.close()
+    ix.close()
+
+
+def test_graph_index_alignment_is_refused_not_faked(ggpu):
+    """the graph index has no alignment path yet: the library must say so instead of running the linear code"""
+    with pytest.raises(api.H2GError) as ei:
+        ggpu.align_run()
+    assert "status -5" in str(ei.value)
