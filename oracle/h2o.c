@@ -880,3 +880,247 @@ uint64_t h2o_seed_extend_batch(const h2o_index* ix, const uint8_t* seqs, const u
 	if(counters) { counters[0] = nrank; counters[1] = nsteps; counters[2] = next; }
 	return sum;
 }
+
+/* ------------------------------------------------------------------ Smith-Waterman (a23-a25) */
+/* The 8-bit end-to-end DP of SwAligner as HISAT2 calls it from hybridSearch (spliced_aligner.h:209-262):
+ *   frameSeedExtensionRect dp_framer.cpp:81-130; initRef aligner_sw.cpp:137-253;
+ *   alignNucleotidesEnd2EndSseU8 aligner_swsse_ee_u8.cpp:791-1172 (Farrar striped fill + lazy-F fix-up; the
+ *   H/E/F bytes it leaves in SSEMatrix equal the plain saturating recurrences below);
+ *   gatherCellsNucleotidesEnd2EndSseU8 :1202-1234; SwAligner::nextAlignment aligner_sw.cpp:709-870;
+ *   backtraceNucleotidesEnd2EndSseU8 :1309-1900 (tie-breaks are the deterministic `#if 1` branches). */
+static inline uint8_t subs8(uint8_t a, uint8_t b) { return a > b ? (uint8_t)(a - b) : 0; }
+static inline uint8_t max8(uint8_t a, uint8_t b) { return a > b ? a : b; }
+static uint32_t lcg_next(uint32_t* last) { /* RandomSource::nextU32 random_source.h:52-61 */
+	*last = 1664525u * *last + 1013904223u;
+	uint32_t ret = *last >> 16;
+	*last = 1664525u * *last + 1013904223u;
+	return ret ^ *last;
+}
+static int mmpen_q(const h2o_scoring* sc, int q) { /* Scoring::initPens COST_MODEL_QUAL scoring.h:117-124 */
+	if(q < 0) q = 0;
+	int ii = q < 40 ? q : 40;
+	float frac = (float)ii / 40.0f;
+	return sc->mmpMin + (int)(frac * (float)(sc->mmpMax - sc->mmpMin));
+}
+static const char MASK2DNA[] = "?ACMGRSVTWYHKDBNN";   /* alphabet.cpp:71-89 */
+
+int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq, const char* qual, uint32_t rdlen,
+                 uint32_t tidx, uint32_t refoff, int64_t minsc, int nceil, int gapbar, uint32_t* rnd, h2o_sw_result* o)
+{
+	memset(o, 0, sizeof *o);
+	o->best = -99999;
+	/* frame: maxgap = min(max(10, 10), 10); maxns = 0 => trim to the reference */
+	const int64_t maxgap = 10, reflen = ix->r.refLens[tidx];
+	int64_t refl = (int64_t)refoff - 2 * maxgap, refr = (int64_t)refoff + (rdlen - 1) + 2 * maxgap;
+	int64_t triml = 0, trimr = 0;
+	if(refr >= reflen) trimr = refr - (reflen - 1);
+	if(refl < 0) triml = -refl;
+	o->refl = refl + triml; o->refr = refr - trimr; o->refl_pretrim = refl; o->refr_pretrim = refr;
+	o->corel = maxgap; o->corer = maxgap + 2 * maxgap;
+	const int64_t rfi = o->refl;
+	const uint32_t ncol = (uint32_t)(o->refr - o->refl + 1), nrow = rdlen;
+	uint8_t* rf = (uint8_t*)malloc(ncol + 1);
+	h2o_get_stretch(&ix->r, tidx, rfi, ncol, rf);           /* 0..3, 4 = N / outside */
+	uint8_t* H = (uint8_t*)calloc((size_t)nrow * ncol, 1);
+	uint8_t* E = (uint8_t*)calloc((size_t)nrow * ncol, 1);
+	uint8_t* F = (uint8_t*)calloc((size_t)nrow * ncol, 1);
+	uint16_t* M = (uint16_t*)calloc((size_t)nrow * ncol, 2);
+	const uint8_t rdgapo = (uint8_t)(sc->rdGapConst + sc->rdGapLinear), rdgape = (uint8_t)sc->rdGapLinear;
+	const uint8_t rfgapo = (uint8_t)(sc->rfGapConst + sc->rfGapLinear), rfgape = (uint8_t)sc->rfGapLinear;
+#define AT(m, i, j) m[(size_t)(i) * ncol + (j)]
+	uint8_t lrmax = 0;
+	for(uint32_t j = 0; j < ncol; j++) {
+		const int refc = rf[j];
+		for(uint32_t i = 0; i < nrow; i++) {
+			const uint8_t gb = (i < (uint32_t)gapbar || (nrow - i - 1) < (uint32_t)gapbar) ? 0xff : 0;
+			const int readc = seq[i], q = (qual ? qual[i] : 'I') - 33;
+			uint8_t pen;                                   /* query profile :76-147 == -Scoring::score scoring.h:259 */
+			if(readc > 3 || refc > 3) pen = (uint8_t)sc->nPen;
+			else pen = readc == refc ? 0 : (uint8_t)mmpen_q(sc, q);
+			const uint8_t e = j == 0 ? 0 : max8(subs8(AT(E, i, j - 1), rdgape), subs8(subs8(AT(H, i, j - 1), rdgapo), gb));
+			const uint8_t f = i == 0 ? 0 : subs8(max8(subs8(AT(F, i - 1, j), rfgape), subs8(AT(H, i - 1, j), rfgapo)), gb);
+			const uint8_t diag = i == 0 ? 0xff : (j == 0 ? 0 : AT(H, i - 1, j - 1));
+			AT(E, i, j) = e;
+			AT(F, i, j) = f;
+			AT(H, i, j) = max8(max8(subs8(diag, pen), e), f);
+		}
+		if(AT(H, nrow - 1, j) > lrmax) lrmax = AT(H, nrow - 1, j);
+	}
+	int64_t best = (int64_t)lrmax - 0xff;
+	o->best = best;
+	int found = !(best < minsc) && lrmax != 0;
+	o->found_align = 0;
+	if(found) {
+		/* gather :1202-1234 + sort (DpBtCandidate::operator< aligner_sw_nuc.h:149: score desc, row desc, col desc) */
+		uint32_t ncand = 0;
+		uint32_t* cand = (uint32_t*)malloc(4 * ncol);
+		for(uint32_t j = 0; j < ncol; j++) if((int64_t)AT(H, nrow - 1, j) - 0xff >= minsc) cand[ncand++] = j;
+		for(uint32_t a = 1; a < ncand; a++) {            /* insertion sort: score desc, then col desc */
+			uint32_t c = cand[a]; int b = (int)a - 1;
+			while(b >= 0 && (AT(H, nrow - 1, cand[b]) < AT(H, nrow - 1, c) ||
+			                 (AT(H, nrow - 1, cand[b]) == AT(H, nrow - 1, c) && cand[b] < c))) { cand[b + 1] = cand[b]; b--; }
+			cand[b + 1] = c;
+		}
+		o->found_align = ncand > 0;
+		/* nextAlignment aligner_sw.cpp:709-870 */
+		typedef struct { uint32_t nedsz, celsz, row, col, gaps, readGaps, refGaps; int64_t score; int ns, ct; } frame_t;
+		frame_t* stack = (frame_t*)malloc(sizeof(frame_t) * 4096);
+		uint32_t* cells = (uint32_t*)malloc(8 * 4096);
+		for(uint32_t ci = 0; ci < ncand && !o->found; ci++) {
+			uint32_t row = nrow - 1, col = cand[ci];
+			const int64_t escore = (int64_t)AT(H, row, col) - 0xff;
+			if(escore < minsc) continue;
+			if(AT(M, row, col) & 1) continue;                /* BT_CAND_FATE_FILT_START */
+			uint32_t reseed = lcg_next(rnd) + 1;
+			*rnd = reseed;
+			/* ---- backtrace */
+			uint32_t nstack = 0, ncells = 0, ned = 0, gaps = 0, readGaps = 0, refGaps = 0;
+			int64_t score = 0; int ns = 0;
+			const uint32_t origCol = col;
+			int ct = 0;                                      /* 0 = H, 1 = E, 2 = F */
+			int ok = 0, fail = 0;
+			while(1) {
+				const int readc = seq[row];
+				const int refm = 1 << rf[col];
+				int empty = 0, reportedThru, canMoveThru = 1, branch = 0, cur = -1;
+				uint16_t* mk = &AT(M, row, col);
+				reportedThru = (*mk & 1) != 0;
+				if(reportedThru) canMoveThru = 0;
+				else if(row > 0) {
+					const int gapsAllowed = !(row < (uint32_t)gapbar || (nrow - row - 1) < (uint32_t)gapbar);
+					if(ct == 1) {                            /* E: came from the left */
+						const int64_t sc_cur = (int64_t)AT(E, row, col) - 0xff;
+						int mask = 0, origMask;
+						const int64_t sc_h_left = (int64_t)AT(H, row, col - 1) - 0xff, sc_e_left = (int64_t)AT(E, row, col - 1) - 0xff;
+						if(sc_h_left - rdgapo == sc_cur) mask |= 1;
+						if(sc_e_left - rdgape == sc_cur) mask |= 2;
+						origMask = mask;
+						if(*mk & (1 << 7)) mask = (*mk >> 8) & 3;
+#define EMASK(v) (*mk = (uint16_t)((*mk & ~(7 << 7)) | (1 << 7) | ((v) << 8)))
+#define FMASK(v) (*mk = (uint16_t)((*mk & ~(7 << 10)) | (1 << 10) | ((v) << 11)))
+#define HMASK(v) (*mk = (uint16_t)((*mk & ~(31 << 1)) | (1 << 1) | ((v) << 2)))
+						if(mask == 3) { cur = 3 /* READ_OPEN */; EMASK(2); branch = 1; }
+						else if(mask == 2) { cur = 4 /* RDGAP_EXTEND */; EMASK(0); }
+						else if(mask == 1) { cur = 3; EMASK(0); }
+						else { empty = 1; canMoveThru = (origMask == 0); }
+					} else if(ct == 2) {                     /* F: came from above */
+						const int64_t sc_h_up = (int64_t)AT(H, row - 1, col) - 0xff, sc_f_up = (int64_t)AT(F, row - 1, col) - 0xff;
+						const int64_t sc_cur = (int64_t)AT(F, row, col) - 0xff;
+						int mask = 0, origMask;
+						if(sc_h_up - rfgapo == sc_cur) mask |= 1;
+						if(sc_f_up - rfgape == sc_cur) mask |= 2;
+						origMask = mask;
+						if(*mk & (1 << 10)) mask = (*mk >> 11) & 3;
+						if(mask == 3) { cur = 1 /* REF_OPEN */; FMASK(2); branch = 1; }
+						else if(mask == 2) { cur = 2 /* RFGAP_EXTEND */; FMASK(0); }
+						else if(mask == 1) { cur = 1; FMASK(0); }
+						else { empty = 1; canMoveThru = (origMask == 0); }
+					} else {
+						const int64_t sc_cur = (int64_t)AT(H, row, col) - 0xff;
+						const int64_t sc_f_up = (int64_t)AT(F, row - 1, col) - 0xff, sc_h_up = (int64_t)AT(H, row - 1, col) - 0xff;
+						const int hasl = col > 0;
+						const int64_t sc_h_left = hasl ? (int64_t)AT(H, row, col - 1) - 0xff : 0;
+						const int64_t sc_e_left = hasl ? (int64_t)AT(E, row, col - 1) - 0xff : 0;
+						const int64_t sc_h_upleft = hasl ? (int64_t)AT(H, row - 1, col - 1) - 0xff : 0;
+						const int q = (qual ? qual[row] : 'I') - 33;
+						int64_t sc_diag;                         /* Scoring::score(readc, refm, q) */
+						if(readc > 3 || refm > 15) sc_diag = -sc->nPen;
+						else sc_diag = (refm & (1 << readc)) ? 0 : -mmpen_q(sc, q);
+						int mask = 0, origMask;
+						if(gapsAllowed) {
+							if(sc_cur == sc_h_up - rfgapo) mask |= 1;
+							if(hasl && sc_cur == sc_h_left - rdgapo) mask |= 2;
+							if(sc_cur == sc_f_up - rfgape) mask |= 4;
+							if(hasl && sc_cur == sc_e_left - rdgape) mask |= 8;
+						}
+						if(hasl && sc_cur == sc_h_upleft + sc_diag) mask |= 16;
+						origMask = mask;
+						if(*mk & (1 << 1)) mask = (*mk >> 2) & 31;
+						const int opts = __builtin_popcount((unsigned)mask);
+						int select = -1;
+						if(opts == 1) { select = __builtin_ctz((unsigned)mask); HMASK(0); }
+						else if(opts > 1) {
+							if(mask & 16) select = 4; else if(mask & 1) select = 0; else if(mask & 4) select = 2;
+							else if(mask & 2) select = 1; else select = 3;
+							mask &= ~(1 << select);
+							HMASK(mask);
+							branch = 1;
+						}
+						if(select == 4) cur = 0; else if(select == 0) cur = 1; else if(select == 1) cur = 3;
+						else if(select == 2) cur = 2; else if(select == 3) cur = 4;
+						else { empty = 1; canMoveThru = (origMask == 0); }
+					}
+				}
+				*mk |= 1;                                    /* setReportedThrough */
+				if(!canMoveThru) {
+					if(nstack > 0) {
+						frame_t* fr = &stack[--nstack];
+						ncells = fr->celsz; ned = fr->nedsz; row = fr->row; col = fr->col; gaps = fr->gaps;
+						readGaps = fr->readGaps; refGaps = fr->refGaps; score = fr->score; ns = fr->ns; ct = fr->ct;
+						continue;
+					}
+					fail = 1; break;
+				}
+				if(empty || row == 0) { cells[2 * ncells] = row; cells[2 * ncells + 1] = col; ncells++; ok = 1; break; }
+				if(branch) {
+					frame_t* fr = &stack[nstack++];
+					fr->nedsz = ned; fr->celsz = ncells; fr->row = row; fr->col = col; fr->gaps = gaps; fr->readGaps = readGaps;
+					fr->refGaps = refGaps; fr->score = score; fr->ns = ns; fr->ct = ct;
+				}
+				cells[2 * ncells] = row; cells[2 * ncells + 1] = col; ncells++;
+				h2o_edit* e = &o->edits[ned < H2O_MAX_EDITS ? ned : H2O_MAX_EDITS - 1];
+				switch(cur) {
+				case 0: {                                    /* SW_BT_OALL_DIAG */
+					const int m = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
+					ct = 0;
+					if(m != 1) {
+						e->pos = row; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_MM; ned++;
+						const int q = (qual ? qual[row] : 'I') - 33;
+						score -= (readc > 3 || refm > 15) ? sc->nPen : mmpen_q(sc, q);
+					}
+					if(m == -1) ns++;
+					row--; col--;
+					break; }
+				case 1: case 2:                              /* REF_OPEN / RFGAP_EXTEND: move up */
+					e->pos = row; e->chr = '-'; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_REF_GAP; ned++;
+					row--; ct = cur == 1 ? 0 : 2; score -= cur == 1 ? rfgapo : rfgape; gaps++; refGaps++;
+					break;
+				default:                                     /* READ_OPEN / RDGAP_EXTEND: move left */
+					e->pos = row + 1; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = '-'; e->type = H2O_EDIT_READ_GAP; ned++;
+					col--; ct = cur == 3 ? 0 : 1; score -= cur == 3 ? rdgapo : rdgape; gaps++; readGaps++;
+					break;
+				}
+			}
+			if(ok) {                                         /* :1770-1850 */
+				int overlapped = 0;
+				for(uint32_t k = 0; k < ncells && !overlapped; k++) {
+					int64_t diagi = (int64_t)cells[2 * k + 1] - (int64_t)cells[2 * k] + triml;
+					if(diagi >= 0 && diagi >= o->corel && diagi <= o->corer) overlapped = 1;
+				}
+				if(!overlapped) ok = 0;
+			}
+			if(ok) {
+				const int readc = seq[row], refm = 1 << rf[col];
+				const int m = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
+				if(m != 1) {
+					h2o_edit* e = &o->edits[ned < H2O_MAX_EDITS ? ned : H2O_MAX_EDITS - 1];
+					e->pos = row; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_MM; ned++;
+					const int q = (qual ? qual[row] : 'I') - 33;
+					score -= (readc > 3 || refm > 15) ? sc->nPen : mmpen_q(sc, q);
+				}
+				if(m == -1) ns++;
+				if(ns > nceil) ok = 0;
+			}
+			if(ok) {
+				if(ned > H2O_MAX_EDITS) { o->overflow = 1; ned = H2O_MAX_EDITS; }
+				for(uint32_t a = 0; a < ned / 2; a++) { h2o_edit t = o->edits[a]; o->edits[a] = o->edits[ned - 1 - a]; o->edits[ned - 1 - a] = t; }
+				o->found = 1; o->score = score; o->nedits = ned; o->off = (int64_t)col + rfi; o->gaps = gaps;
+				(void)origCol; (void)fail; (void)refGaps; (void)readGaps;
+			}
+			*rnd = reseed + 1;
+		}
+		free(stack); free(cells); free(cand);
+	}
+	free(rf); free(H); free(E); free(F); free(M);
+	return o->found;
+}

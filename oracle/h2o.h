@@ -135,6 +135,20 @@ int  h2o_extend(const h2o_index*, const h2o_scoring*, const uint8_t* seq, const 
                 h2o_ghit* hit, uint32_t* leftext, uint32_t* rightext, uint32_t mm);
 int64_t h2o_calculate_score(const h2o_scoring*, const char* qual, h2o_ghit* hit);
 
+/* SwAligner as called from hybridSearch (spliced_aligner.h:209-262): frame + 8-bit end-to-end fill + gather + the first
+ * nextAlignment.  seq/qual in the aligned orientation; refoff = hit.refoff - hit.rdoff (or 0); *rnd = RandomSource::last */
+typedef struct {
+	int64_t  refl, refr, refl_pretrim, refr_pretrim, corel, corer;   /* DPRect dp_framer.h */
+	int32_t  found_align;         /* SwAligner::align() */
+	int64_t  best;                /* bestCell (lrmax - 0xff) */
+	int32_t  found;               /* nextAlignment() */
+	int64_t  score, off;          /* AlnRes score, refcoord().off() */
+	uint32_t nedits, gaps, overflow;
+	h2o_edit edits[H2O_MAX_EDITS];
+} h2o_sw_result;
+int h2o_sw_align(const h2o_index*, const h2o_scoring*, const uint8_t* seq, const char* qual, uint32_t rdlen,
+                 uint32_t tidx, uint32_t refoff, int64_t minsc, int nceil, int gapbar, uint32_t* rnd, h2o_sw_result* out);
+
 /* whole-batch CPU baseline of the stage timed by bench.py: both strands' partialSearch +
  * coordinate resolution + 0-mismatch extension, returns a checksum */
 uint64_t h2o_seed_extend_batch(const h2o_index*, const uint8_t* seqs, const uint32_t* offs, uint32_t nreads,

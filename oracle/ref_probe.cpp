@@ -251,7 +251,7 @@ int main(int argc, char** argv) {
 		}
 		return 0;
 	}
-	if(cmd == "psearch" || cmd == "coords" || cmd == "extend") {
+	if(cmd == "psearch" || cmd == "coords" || cmd == "extend" || cmd == "sw") {
 		// <cmd> <base> <reads.fa> <nospliced:0|1>
 		vector<Read*> rds;
 		loadReads(argv[3], rds);
@@ -316,6 +316,53 @@ int main(int argc, char** argv) {
 						printf(" %lld:%lld:%llu", (long long)(int32_t)coords[k].ref(), (long long)coords[k].off(),
 						       (unsigned long long)coords[k].joinedOff());
 					putchar('\n');
+					continue;
+				}
+				if(cmd == "sw") {
+					// the SwAligner call site of hybridSearch (spliced_aligner.h:209-262): frame the DP rectangle around the
+					// seed hit, fill (8-bit end-to-end SSE), gather, one nextAlignment.  Output: the rectangle, whether an
+					// alignment was found, its score, reference offset, edits (read coordinates of the aligned strand,
+					// i.e. before invertEdits) and the next PRNG draw (nextAlignment reseeds rnd).
+					for(size_t k = 0; k < coords.size(); k++) {
+						if(coords[k].ref() == (TRefId)std::numeric_limits<index_t>::max()) continue;
+						swa.initRead(rd.patFw, rd.patRc, rd.qual, rd.qualRev, 0, rd.length(), *sc);
+						DynProgFramer dpframe(false);
+						size_t tlen = p.ref->approxLen(coords[k].ref());
+						size_t readGaps = 10, refGaps = 10, nceil = 0, maxhalf = 10;
+						index_t hit_refoff = (index_t)coords[k].off();
+						index_t refoff = hit_refoff > rdoff ? hit_refoff - rdoff : 0;
+						DPRect rect;
+						dpframe.frameSeedExtensionRect(refoff, rd.length(), tlen, readGaps, refGaps, nceil, maxhalf, rect);
+						size_t cminlen = 2000, cpow2 = 4, nwindow = 10, nsInLeftShift = 0;
+						swa.initRef(fw, coords[k].ref(), rect, *p.ref, tlen, *sc, minsc, true, cminlen, cpow2, false, true,
+						            nwindow, nsInLeftShift);
+						rnd.init((uint32_t)(rd.rdid * 7 + k + 1));
+						TAlScore bestCell = std::numeric_limits<TAlScore>::min();
+						bool found = swa.align(rnd, bestCell);
+						printf("%llu %d %u %u %u %lld | %lld %lld %lld %lld %lld %lld | %d %lld",
+						       (unsigned long long)rd.rdid, (int)fw, (unsigned)k, (unsigned)coords[k].ref(), refoff, (long long)minsc,
+						       (long long)rect.refl, (long long)rect.refr, (long long)rect.refl_pretrim, (long long)rect.refr_pretrim,
+						       (long long)rect.corel, (long long)rect.corer, (int)found,
+						       bestCell == std::numeric_limits<TAlScore>::min() ? -99999LL : (long long)bestCell);
+						bool found2 = false;
+						SwResult res;
+						LinkedEList<EList<Edit> > rawEdits;
+						if(found) {
+							res.reset();
+							res.alres.init_raw_edits(&rawEdits);
+							found2 = swa.nextAlignment(res, minsc, rnd);
+						}
+						printf(" %d", (int)found2);
+						if(found2) {
+							const Coord& co = res.alres.refcoord();
+							printf(" %lld %lld %u", (long long)res.alres.score().score(), (long long)co.off(), (unsigned)res.alres.ned().size());
+							for(size_t e = 0; e < res.alres.ned().size(); e++) {
+								const Edit& ed = res.alres.ned()[e];
+								printf(" %u:%c>%c:%d", ed.pos, (char)ed.chr, (char)ed.qchr, (int)ed.type);
+							}
+						}
+						printf(" r%u\n", rnd.nextU32());
+					}
 					continue;
 				}
 				// extend: for each coordinate, a GenomeHit extended with mm = 0, 1, 2, 3

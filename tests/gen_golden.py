@@ -10,7 +10,7 @@ for a small seeded genome ("g1"):
   ref_se_nospliced.sam.gz         hisat2-align-s -f -p 1 --no-spliced-alignment (minus @PG)
   ref_se_spliced.sam.gz           hisat2-align-s -f -p 1 (default), minus @PG
   reads_pe_{1,2}.fa.gz, ref_pe_nospliced.sam.gz   300 pairs and their -1/-2 --no-spliced-alignment SAM
-`gen_golden.py graph` adds the GRAPH index fixtures without touching the above:
+`gen_golden.py sw` adds reads_sw.fa.gz + probe_sw.txt.gz (SwAligner call-site vectors); `gen_golden.py graph` adds the GRAPH index fixtures without touching the above:
   g1s.snp.gz, g1s.{1..8}.ht2.gz   ~500 seeded variants of g1 and the hisat2-build-s --snp graph index
   reads_snp.fa.gz                 300 reads drawn from the alternate haplotype (all variants applied)
   probe_g1s_{params,rank,glf,glf1,psearch,psearch_spliced}.txt.gz   reference GFM graph-LF outputs
@@ -119,8 +119,28 @@ def main_graph():
     print("golden bytes:", tot)
 
 
+def main_sw():
+    """reads_sw.fa.gz (indel-rich reads of g1) + probe_sw.txt.gz: the reference SwAligner run exactly as hybridSearch
+    calls it (frame, 8-bit end-to-end fill, gather, first nextAlignment) around every seed-hit coordinate"""
+    tmp = tempfile.mkdtemp(prefix="h2goldsw")
+    base = os.path.join(tmp, "g1")
+    for k in range(1, 9):
+        open(f"{base}.{k}.ht2", "wb").write(gzip.open(os.path.join(GOLD, f"g1.{k}.ht2.gz")).read())
+    contigs = synth.make_genome([60000, 45000, 30000], SEED, n_gaps=1, gap_len=500, repeats=2, repeat_len=400)
+    reads, _ = synth.make_reads(contigs, 400, 101, SEED + 21, sub_rate=0.02, indel_rate=0.01, n_rate=0.001)
+    rfa = os.path.join(tmp, "reads_sw.fa")
+    synth.write_reads_fasta(rfa, reads)
+    gz_write(os.path.join(GOLD, "reads_sw.fa.gz"), open(rfa, "rb").read())
+    out = run([os.path.join(REF, "ref_probe"), "sw", base, rfa, "1"]).stdout
+    gz_write(os.path.join(GOLD, "probe_sw.txt.gz"), out)
+    print("sw", len(out.splitlines()), "lines")
+    shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "graph":
         main_graph()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sw":
+        main_sw()
     else:
         main()

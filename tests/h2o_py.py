@@ -61,6 +61,21 @@ class Index(C.Structure):
                 ("local_first", C.POINTER(C.c_uint32)), ("minK", C.c_uint32), ("names", C.POINTER(C.c_char_p))]
 
 
+class SwResult(C.Structure):       # h2o_sw_result
+    _fields_ = [("refl", C.c_int64), ("refr", C.c_int64), ("refl_pretrim", C.c_int64), ("refr_pretrim", C.c_int64),
+                ("corel", C.c_int64), ("corer", C.c_int64), ("found_align", C.c_int32), ("best", C.c_int64),
+                ("found", C.c_int32), ("score", C.c_int64), ("off", C.c_int64), ("nedits", C.c_uint32),
+                ("gaps", C.c_uint32), ("overflow", C.c_uint32), ("edits", Edit * 64)]
+
+
+def lcg_next(last):
+    """RandomSource::nextU32 (random_source.h:52-61) -> (value, new state)"""
+    last = (1664525 * last + 1013904223) & 0xFFFFFFFF
+    r = last >> 16
+    last = (1664525 * last + 1013904223) & 0xFFFFFFFF
+    return r ^ last, last
+
+
 def load():
     lib = C.CDLL(os.path.join(ROOT, "oracle", "libh2o.so"))
     P = C.POINTER
@@ -101,6 +116,9 @@ def load():
                                P(C.c_uint32), C.c_uint32]
     lib.h2o_extend.restype = C.c_int
     lib.h2o_scoring_default.argtypes = [P(Scoring)]
+    lib.h2o_sw_align.argtypes = [P(Index), P(Scoring), C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.c_int64, C.c_int, C.c_int, P(C.c_uint32), P(SwResult)]
+    lib.h2o_sw_align.restype = C.c_int
     lib.h2o_seed_extend_batch.argtypes = [P(Index), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
                                           P(C.c_uint64)]
     lib.h2o_seed_extend_batch.restype = C.c_uint64

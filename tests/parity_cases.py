@@ -204,3 +204,30 @@ def check_graph_fm_search(be, golden_dir, fn="probe_g1s_psearch.txt.gz"):
         assert got == w, (q.read, q.fw, got, w)
         assert e.pairs() == wie
     return len(qs)
+
+
+# ---------------------------------------------------------------- Smith-Waterman (a23-a25)
+def parse_sw_probe(golden_dir):
+    """-> list of dicts: the reference SwAligner outcome for every (read, strand, seed coordinate) of probe_sw.txt.gz"""
+    out = []
+    for l in H.glines(golden_dir, "probe_sw.txt.gz"):
+        f = l.split()
+        d = dict(zip(("rid", "fw", "k", "tidx", "refoff", "minsc"), map(int, f[:6])))
+        d["rect"] = list(map(int, f[7:13]))
+        d["found_align"], d["best"], d["found"] = int(f[14]), int(f[15]), int(f[16])
+        rest = f[17:]
+        d["rnd_next"] = int(rest[-1][1:])
+        if d["found"]:
+            d["score"], d["off"], ne = int(rest[0]), int(rest[1]), int(rest[2])
+            d["edits"] = rest[3:3 + ne]
+        out.append(d)
+    return out
+
+
+def sw_edit_strings(edits, nedits, fw, rdlen):
+    """the reference prints AlnRes::ned() after setShape, i.e. w.r.t. the 5' end: invert ours for the rc strand"""
+    def s(e, pos):
+        return f"{pos}:{chr(e.chr)}>{chr(e.qchr)}:{e.type}"
+    if fw:
+        return [s(edits[i], edits[i].pos) for i in range(nedits)]
+    return [s(edits[i], (rdlen - edits[i].pos) if edits[i].type == 1 else (rdlen - edits[i].pos - 1)) for i in reversed(range(nedits))]

@@ -229,3 +229,30 @@ def test_graph_partial_search(oracle_lib, g1s_index, golden_dir):
 def test_graph_partial_search_spliced_mode(oracle_lib, g1s_index, golden_dir):
     # pseudogeneStop is only ever armed on linear indexes (hi_aligner.h:4669), so spliced mode == no-spliced here
     _psearch_graph(oracle_lib, golden_dir, g1s_index, "probe_g1s_psearch_spliced.txt.gz", 0)
+
+
+# ---------------------------------------------------------------- Smith-Waterman (a23-a25)
+def test_sw_align_matches_reference_swaligner(oracle_lib, g1_index, golden_dir):
+    """frame + u8 end-to-end fill + gather + first nextAlignment (incl. its PRNG reseeding) == SwAligner"""
+    import parity_cases as PC
+    ix = H.load_index(oracle_lib, g1_index)
+    sc = H.Scoring()
+    oracle_lib.h2o_scoring_default(C.byref(sc))
+    _, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_sw.fa.gz"))
+    cases = PC.parse_sw_probe(golden_dir)
+    nfound = ngap = 0
+    for d in cases:
+        seq = np.ascontiguousarray(seqs[d["rid"]] if d["fw"] else H.revcomp(seqs[d["rid"]]))
+        rnd = C.c_uint32((d["rid"] * 7 + d["k"] + 1) & 0xFFFFFFFF)
+        o = H.SwResult()
+        oracle_lib.h2o_sw_align(ix, C.byref(sc), seq.ctypes.data, None, len(seq), d["tidx"], d["refoff"], d["minsc"], 15, 4,
+                                C.byref(rnd), C.byref(o))
+        assert [o.refl, o.refr, o.refl_pretrim, o.refr_pretrim, o.corel, o.corer] == d["rect"], d
+        assert (o.found_align, o.best, o.found) == (d["found_align"], d["best"], d["found"]), d
+        assert H.lcg_next(rnd.value)[0] == d["rnd_next"], d
+        if d["found"]:
+            assert (o.score, o.off) == (d["score"], d["off"]), d
+            assert PC.sw_edit_strings(o.edits, o.nedits, d["fw"], len(seq)) == d["edits"], d
+            nfound += 1
+            ngap += any(e.split(":")[2] in ("1", "2") for e in d["edits"])
+    assert len(cases) > 250 and nfound > 100 and ngap > 50
