@@ -81,6 +81,16 @@ class GHit(C.Structure):
                 ("edits", Edit * MAX_EDITS)]
 
 
+class SwQuery(C.Structure):          # h2g_sw_query
+    _fields_ = [("read", u32), ("fw", u32), ("tidx", u32), ("refoff", u32), ("minsc", C.c_int32), ("rnd", u32)]
+
+
+class SwResult(C.Structure):         # h2g_sw_result
+    _fields_ = [("found_align", C.c_int32), ("found", C.c_int32), ("best", C.c_int32), ("score", C.c_int32),
+                ("off", C.c_int64), ("nedits", u32), ("gaps", u32), ("overflow", u32), ("rnd", u32),
+                ("refl", C.c_int64), ("refr", C.c_int64), ("edits", Edit * 48)]
+
+
 class ExtArgs(C.Structure):
     _fields_ = [("mm", u32), ("max_leftext", u32), ("max_rightext", u32)]
 
@@ -151,7 +161,7 @@ EXPORTS = [
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_align_params_init", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
     "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch",
-    "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides",
+    "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align",
 ]
 
 
@@ -188,6 +198,7 @@ def lib():
     L.h2g_rank_bench_synth.argtypes = [vp, C.c_size_t, u64, C.c_int, C.c_int, P(C.c_float), P(u64)]
     L.h2g_fm_search.argtypes = [vp, vp, C.c_size_t, u32, vp]
     L.h2g_sa_resolve.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
+    L.h2g_sw_align.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, P(C.c_float)]
     L.h2g_graph_lf.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
     L.h2g_fm_search_graph.argtypes = [vp, vp, C.c_size_t, u32, u32, vp, vp]
     L.h2g_index_synth_graph_sides.argtypes = [u64, u64, C.c_int, P(vp)]
@@ -278,6 +289,15 @@ class Stream:
         out = (FmHit * n)()
         _chk(lib().h2g_fm_search(self.h, q, n, khits, out), "h2g_fm_search")
         return out
+
+    def sw_align(self, queries, repeats=1):
+        """SwAligner call site of hybridSearch (frame + u8 end-to-end DP + gather + first backtrace) -> (results, kernel ms)"""
+        n = len(queries)
+        q = (SwQuery * n)(*queries)
+        out = (SwResult * n)()
+        ms = C.c_float(0)
+        _chk(lib().h2g_sw_align(self.h, q, n, out, repeats, C.byref(ms)), "h2g_sw_align")
+        return out, ms.value
 
     def graph_lf(self, queries, k=10):
         """GFM::mapGLF / mapGLF1 on a graph index -> (results, in-edge lists)"""

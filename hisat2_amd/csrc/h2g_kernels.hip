@@ -12,6 +12,7 @@
 #include "h2g_host_index.h"
 #include "h2g_align.h"
 #include "h2g_graph.h"
+#include "h2g_sw.h"
 #include "h2g_local_pack.h"
 
 using namespace h2g;
@@ -43,6 +44,7 @@ struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
 	size_t max_reads = 0, max_bases = 0, n_reads = 0;
+	uint32_t max_read_len = 0;
 	uint8_t* d_codes = nullptr;
 	uint32_t* d_offs = nullptr;
 	char* d_quals = nullptr;
@@ -317,6 +319,9 @@ extern "C" h2g_status h2g_set_reads(h2g_stream* s, const uint8_t* codes, const u
 	if(!s || !codes || !offs || n > s->max_reads) return H2G_ERR_ARG;
 	size_t nb = offs[n];
 	if(nb > s->max_bases) return H2G_ERR_ARG;
+	uint32_t mx = 0;
+	for(size_t i = 0; i < n; i++) { const uint32_t l = offs[i + 1] - offs[i]; if(l > mx) mx = l; }
+	s->max_read_len = mx;
 	HIPCHK(hipMemcpyAsync(s->d_codes, codes, nb, hipMemcpyHostToDevice, s->st));
 	HIPCHK(hipMemcpyAsync(s->d_offs, offs, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
 	s->has_quals = quals != nullptr;
@@ -672,6 +677,53 @@ __global__ __launch_bounds__(256) void k_fm_search_graph(DGfm g, DReads rd, cons
 	}
 }
 
+// ------------------------------------------------------------------------------------------ Smith-Waterman
+static_assert(sizeof(h2g_sw_result) == sizeof(SwOut), "h2g_sw_result must mirror SwOut");
+// One wavefront per problem: H/E/F (u8) and the backtrace masks (u16) of the whole rdlen x (rdlen + 40) rectangle live
+// in LDS; 64 lanes fill one anti-diagonal per step (lane stride in LDS = ncol - 1 bytes, odd dword stride => no bank
+// conflicts), lane 0 then gathers + backtraces.  Problems are fetched through a grid-stride loop.
+__global__ __launch_bounds__(64) void k_sw(DRef ref, DReads rd, SwParams P, const h2g_sw_query* q, size_t n, h2g_sw_result* out)
+{
+	extern __shared__ uint8_t smem[];
+	__shared__ SwFrame stack[H2G_SW_STACK];
+	__shared__ uint16_t cells[2 * H2G_SW_CELLS];
+	const uint32_t lane = threadIdx.x;
+	for(size_t p = blockIdx.x; p < n; p += gridDim.x) {
+		const h2g_sw_query qq = q[p];
+		SeqView sv = seq_view(rd, qq.read, qq.fw != 0);
+		const uint32_t nrow = sv.len;
+		const uint32_t reflen = ref.refLens[qq.tidx];
+		const SwRect rect = sw_frame(qq.refoff, nrow, reflen);
+		const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
+		const size_t cellsz = ((size_t)nrow * ncol + 15) & ~(size_t)15;
+		SwMats m;
+		m.nrow = nrow; m.ncol = ncol;
+		m.H = smem; m.E = smem + cellsz; m.F = smem + 2 * cellsz;
+		m.M = reinterpret_cast<uint16_t*>(smem + 3 * cellsz);
+		m.rf = smem + 5 * cellsz;
+		{   // reference window: BitPairReference::getStretch semantics (N / outside the sequence = 4)
+			RefCursor rc;
+			rc.init(&ref, qq.tidx);
+			for(uint32_t j = lane; j < ncol; j += 64) m.rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
+		}
+		__syncthreads();
+		sw_fill(m, P, sv, lane, 64);
+		if(lane == 0) {
+			SwOut o;
+			uint32_t rnd = qq.rnd;
+			const int nceil = (int)((double)P.nceil_pct * 0.01 * (double)nrow);
+			o.refl = rect.refl; o.refr = rect.refr;
+			sw_gather_backtrace(m, P, sv, rect, qq.minsc, nceil, &rnd, stack, cells, &o);
+			o.rnd = rnd;
+			SwOut* dst = reinterpret_cast<SwOut*>(&out[p]);
+			dst->found_align = o.found_align; dst->found = o.found; dst->best = o.best; dst->score = o.score; dst->off = o.off;
+			dst->nedits = o.nedits; dst->gaps = o.gaps; dst->overflow = o.overflow; dst->rnd = o.rnd; dst->refl = o.refl; dst->refr = o.refr;
+			for(uint32_t e = 0; e < o.nedits; e++) dst->edits[e] = o.edits[e];
+		}
+		__syncthreads();
+	}
+}
+
 static int need_reads(h2g_stream* s) {
 	if(s->n_reads == 0) { snprintf(g_err, sizeof g_err, "no read batch set (h2g_set_reads)"); return H2G_ERR_ARG; }
 	return H2G_OK;
@@ -751,6 +803,39 @@ extern "C" h2g_status h2g_fm_search(h2g_stream* s, const h2g_fm_query* q, size_t
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_sw_align(h2g_stream* s, const h2g_sw_query* q, size_t n, h2g_sw_result* out, int repeats, float* kernel_ms) {
+	if(!s || !q || !out || n == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s))) return rc;
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	for(size_t i = 0; i < n; i++) if(q[i].read >= s->n_reads || q[i].tidx >= s->ix->dr.nrefs) return H2G_ERR_ARG;
+	const uint32_t maxlen = s->max_read_len;   // longest read of the resident batch: sizes the LDS rectangle
+	if(maxlen == 0 || maxlen > H2G_SW_MAX_ROWS) { snprintf(g_err, sizeof g_err, "h2g_sw_align: read length %u outside 1..%d", maxlen, H2G_SW_MAX_ROWS); return H2G_ERR_ARG; }
+	HIPCHK(hipSetDevice(s->ix->device));
+	const size_t ncolmax = maxlen + 4 * H2G_SW_MAXGAP;
+	const size_t cellsz = ((size_t)maxlen * ncolmax + 15) & ~(size_t)15;
+	const size_t lds = 5 * cellsz + ((ncolmax + 15) & ~(size_t)15);
+	if(lds > 150 * 1024) { snprintf(g_err, sizeof g_err, "h2g_sw_align: %zu B of LDS needed", lds); return H2G_ERR_ARG; }
+	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	void *dq, *dout;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * sizeof *out, &dout))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	SwParams P;
+	const unsigned grid = (unsigned)(n < 256 * 8 ? n : 256 * 8);
+	if(repeats < 1) repeats = 1;
+	HIPCHK(hipEventRecord(s->ev[0], s->st));
+	for(int r = 0; r < repeats; r++)
+		hipLaunchKernelGGL(k_sw, dim3(grid), dim3(64), lds, s->st, s->ix->dr, dreads(s), P, (const h2g_sw_query*)dq, n, (h2g_sw_result*)dout);
+	HIPCHK(hipEventRecord(s->ev[1], s->st));
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	float t = 0;
+	HIPCHK(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+	if(kernel_ms) *kernel_ms = t / repeats;
 	return H2G_OK;
 }
 

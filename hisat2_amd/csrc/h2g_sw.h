@@ -1,0 +1,311 @@
+// h2g_sw.h — the 8-bit end-to-end Smith-Waterman of SwAligner as HISAT2 uses it.
+//
+// Reference: frameSeedExtensionRect dp_framer.cpp:81-130; SwAligner::initRef aligner_sw.cpp:137-253;
+// alignNucleotidesEnd2EndSseU8 aligner_swsse_ee_u8.cpp:791-1172; gatherCellsNucleotidesEnd2EndSseU8 :1202-1234;
+// SwAligner::align / nextAlignment aligner_sw.cpp:477-870; backtraceNucleotidesEnd2EndSseU8 :1309-1900.
+//
+// The reference fills H/E/F with Farrar's striped SSE loop plus a lazy-F fix-up that runs until F stops
+// improving against the *stored* F, so the bytes it leaves in SSEMatrix are exactly the saturating-u8
+// recurrences
+//     E[i][j] = max(E[i][j-1] (-) rdGapExt,  (H[i][j-1] (-) rdGapOpen) (-) gbar[i])          E[i][0] = 0
+//     F[i][j] = max(F[i-1][j] (-) rfGapExt,   H[i-1][j] (-) rfGapOpen) (-) gbar[i]           F[0][j] = 0
+//     H[i][j] = max(H[i-1][j-1] (-) pen(i,j), E[i][j], F[i][j])    H[-1][*] = 0xff, H[i>=0][-1] = 0
+// ((-) = unsigned saturating subtract; gbar[i] = 0xff inside the gap barrier, else 0), independent of the fill
+// order.  That is what lets the GPU fill by anti-diagonals — 64 lanes, one cell each, matrices in LDS — and
+// still hand the reference's backtrace byte-identical matrices.  The backtrace itself (deterministic `#if 1`
+// tie-breaks, branch stack, reported-through masks) is sequential and runs on lane 0.
+//
+// All functions are `__host__ __device__`; tests/emul instantiates them on the host with one "lane".
+#pragma once
+#include "h2g_core.h"
+
+namespace h2g {
+
+#define H2G_SW_MAX_ROWS 160                 // read length cap of the SW path (LDS budget; longer reads: H2G_ERR_ARG)
+#define H2G_SW_MAXGAP 10                    // readGaps = refGaps = maxhalf = 10 (spliced_aligner.h:222)
+#define H2G_SW_MAX_COLS (H2G_SW_MAX_ROWS + 4 * H2G_SW_MAXGAP)
+#define H2G_SW_STACK 96                     // branch frames (the reference's list is unbounded; overflow is flagged)
+#define H2G_SW_CELLS (H2G_SW_MAX_ROWS + 2 * H2G_SW_MAXGAP + 8)
+
+struct SwParams {   // Scoring (scoring.h) + the constants of the call site
+	DScoring sc;
+	int32_t gapbar = 4;          // gGapBarrier hisat2.cpp:419
+	uint32_t nceil_pct = 15;     // nCeil = L,0,0.15 (SeedAlignmentPolicy::parseString), evaluated per read length
+};
+
+struct SwFrame { uint16_t nedsz, celsz, row, col, gaps; int16_t ns; int32_t score; uint8_t ct; };
+
+// Per-problem working set.  On the device H/E/F/M live in LDS (one workgroup per problem); the emulator mallocs them.
+struct SwMats {
+	uint8_t*  H; uint8_t* E; uint8_t* F;   // [nrow * ncol]
+	uint16_t* M;                           // SSEMatrix::masks_: bit 0 reportedThru, H mask 1/2-6, E 7/8-9, F 10/11-12
+	uint8_t*  rf;                          // reference chars 0..4 for the ncol columns
+	uint32_t  nrow, ncol;
+};
+
+H2G_HD uint8_t subs8(uint32_t a, uint32_t b) { return (uint8_t)(a > b ? a - b : 0u); }
+H2G_HD uint8_t max8(uint32_t a, uint32_t b) { return (uint8_t)(a > b ? a : b); }
+
+// DPRect of frameSeedExtensionRect with maxns = 0, trimToRef = false (dp_framer.cpp:81-130)
+struct SwRect { int64_t refl, refr, refl_pretrim, refr_pretrim, triml, trimr, corel, corer; };
+H2G_HD SwRect sw_frame(uint32_t refoff, uint32_t rdlen, uint32_t reflen) {
+	SwRect r;
+	const int64_t maxgap = H2G_SW_MAXGAP;
+	int64_t refl = (int64_t)refoff - 2 * maxgap, refr = (int64_t)refoff + ((int64_t)rdlen - 1) + 2 * maxgap;
+	r.triml = r.trimr = 0;
+	if(refr >= (int64_t)reflen) r.trimr = refr - ((int64_t)reflen - 1);
+	if(refl < 0) r.triml = -refl;
+	r.refl_pretrim = refl; r.refr_pretrim = refr;
+	r.refl = refl + r.triml; r.refr = refr - r.trimr;
+	r.corel = maxgap; r.corer = maxgap + 2 * maxgap;
+	return r;
+}
+
+// -Scoring::score(readc, 1 << refc, q) (scoring.h:259-269) — the query-profile entry (:76-147)
+H2G_HD uint32_t sw_pen(const DScoring& sc, int readc, int refc, int q) {
+	if(readc > 3 || refc > 3) return (uint32_t)sc.nPen;
+	return readc == refc ? 0u : (uint32_t)mm_penalty(sc, q);
+}
+
+// One DP cell.  Reads only cells of the two previous anti-diagonals.
+H2G_HD void sw_cell(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t i, uint32_t j) {
+	const uint32_t ncol = m.ncol, nrow = m.nrow;
+	const uint32_t gb = (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar) ? 0xffu : 0u;
+	const uint32_t rdgapo = (uint32_t)(P.sc.rdGapConst + P.sc.rdGapLinear), rdgape = (uint32_t)P.sc.rdGapLinear;
+	const uint32_t rfgapo = (uint32_t)(P.sc.rfGapConst + P.sc.rfGapLinear), rfgape = (uint32_t)P.sc.rfGapLinear;
+	const size_t at = (size_t)i * ncol + j;
+	uint32_t e = 0, f = 0, diag;
+	if(j > 0) e = max8(subs8(m.E[at - 1], rdgape), subs8(subs8(m.H[at - 1], rdgapo), gb));
+	if(i > 0) f = subs8(max8(subs8(m.F[at - ncol], rfgape), subs8(m.H[at - ncol], rfgapo)), gb);
+	diag = i == 0 ? 0xffu : (j == 0 ? 0u : m.H[at - ncol - 1]);
+	const uint32_t pen = sw_pen(P.sc, seq.at(i), m.rf[j], seq.qual(i) - 33);
+	m.E[at] = (uint8_t)e;
+	m.F[at] = (uint8_t)f;
+	m.H[at] = max8(max8(subs8(diag, pen), e), f);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define H2G_SW_SYNC() __syncthreads()
+#else
+#define H2G_SW_SYNC() ((void)0)
+#endif
+
+// Anti-diagonal fill by `nlanes` cooperating lanes (64 on the device, 1 in the emulator); also zeroes the masks.
+H2G_HD void sw_fill(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t lane, uint32_t nlanes) {
+	const uint32_t nrow = m.nrow, ncol = m.ncol;
+	for(uint32_t k = lane; k < nrow * ncol; k += nlanes) m.M[k] = 0;
+	for(uint32_t d = 0; d < nrow + ncol - 1; d++) {
+		const uint32_t ilo = d >= ncol ? d - ncol + 1 : 0, ihi = d < nrow ? d : nrow - 1;
+		for(uint32_t i = ilo + lane; i <= ihi; i += nlanes) sw_cell(m, P, seq, i, d - i);
+		H2G_SW_SYNC();
+	}
+}
+
+struct SwOut {   // mirrors h2g_sw_result
+	int32_t  found_align, found;
+	int32_t  best, score;
+	int64_t  off;                // refcoord().off()
+	uint32_t nedits, gaps, overflow, rnd;
+	int64_t  refl, refr;
+	h2g_edit edits[H2G_MAX_EDITS];
+};
+
+H2G_HD uint32_t sw_lcg_next(uint32_t* last) {   // RandomSource::nextU32 random_source.h:52-61
+	*last = 1664525u * *last + 1013904223u;
+	const uint32_t ret = *last >> 16;
+	*last = 1664525u * *last + 1013904223u;
+	return ret ^ *last;
+}
+
+H2G_HD char sw_mask2dna(int refm) {   // alphabet.cpp:71-89 for the masks that occur here (1, 2, 4, 8, 16)
+	return refm == 1 ? 'A' : refm == 2 ? 'C' : refm == 4 ? 'G' : refm == 8 ? 'T' : 'N';
+}
+
+// gather (:1202-1234) + candidate order (aligner_sw_nuc.h:149) + nextAlignment loop (aligner_sw.cpp:709-870) +
+// backtrace (:1309-1900).  Sequential; call from one lane after sw_fill.  `rnd` = RandomSource::last.
+H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqView& seq, const SwRect& rect, int64_t minsc,
+                                int nceil, uint32_t* rnd, SwFrame* stack, uint16_t* cells /* [2 * H2G_SW_CELLS] */, SwOut* o)
+{
+	const uint32_t nrow = m.nrow, ncol = m.ncol;
+	const int64_t rdgapo = P.sc.rdGapConst + P.sc.rdGapLinear, rdgape = P.sc.rdGapLinear;
+	const int64_t rfgapo = P.sc.rfGapConst + P.sc.rfGapLinear, rfgape = P.sc.rfGapLinear;
+#define SW_AT(mat, i, j) mat[(size_t)(i) * ncol + (j)]
+	uint32_t lrmax = 0;
+	for(uint32_t j = 0; j < ncol; j++) { const uint32_t v = SW_AT(m.H, nrow - 1, j); if(v > lrmax) lrmax = v; }
+	o->best = (int32_t)lrmax - 0xff;
+	o->found_align = 0; o->found = 0; o->score = 0; o->off = 0; o->nedits = 0; o->gaps = 0; o->overflow = 0;
+	if((int64_t)o->best < minsc || lrmax == 0) return;         // flag -1 / -2 (:1140-1165)
+	// Candidates = last-row cells with score >= minsc, visited best score first, then rightmost column first.
+	// Instead of sorting a list, repeatedly take the next (score, col) in that order: O(ncol) per candidate.
+	uint32_t prev_v = 256, prev_col = 0;
+	bool any = false;
+	while(true) {
+		// next candidate strictly after (prev_v, prev_col) in (score desc, col desc) order
+		uint32_t best_v = 0, best_col = 0;
+		bool have = false;
+		for(uint32_t j = 0; j < ncol; j++) {
+			const uint32_t v = SW_AT(m.H, nrow - 1, j);
+			if((int64_t)v - 0xff < minsc) continue;
+			any = true;
+			const bool after = v < prev_v || (v == prev_v && j < prev_col);
+			if(!after) continue;
+			if(!have || v > best_v || (v == best_v && j > best_col)) { have = true; best_v = v; best_col = j; }
+		}
+		o->found_align = any;
+		if(!have) break;
+		prev_v = best_v; prev_col = best_col;
+		uint32_t row = nrow - 1, col = best_col;
+		if(SW_AT(m.M, row, col) & 1) continue;                 // BT_CAND_FATE_FILT_START
+		const uint32_t reseed = sw_lcg_next(rnd) + 1;          // aligner_sw.cpp:766-767
+		// ---- backtrace
+		uint32_t nstack = 0, ncells = 0, ned = 0, gaps = 0;
+		int64_t score = 0; int ns = 0;
+		int ct = 0;                                            // SSEMatrix::H / E / F = 0 / 1 / 2
+		bool ok = false;
+		while(true) {
+			const int readc = seq.at(row);
+			const int refm = 1 << m.rf[col];
+			bool empty = false, canMoveThru = true, branch = false;
+			int cur = -1;
+			uint16_t mk = SW_AT(m.M, row, col);
+			if(mk & 1) canMoveThru = false;
+			else if(row > 0) {
+				const bool gapsAllowed = !(row < (uint32_t)P.gapbar || (nrow - row - 1) < (uint32_t)P.gapbar);
+				if(ct == 1) {                                  // E: gap open from H-left or extension from E-left
+					const int64_t sc_cur = (int64_t)SW_AT(m.E, row, col) - 0xff;
+					int mask = 0;
+					if((int64_t)SW_AT(m.H, row, col - 1) - 0xff - rdgapo == sc_cur) mask |= 1;
+					if((int64_t)SW_AT(m.E, row, col - 1) - 0xff - rdgape == sc_cur) mask |= 2;
+					const int origMask = mask;
+					if(mk & (1 << 7)) mask = (mk >> 8) & 3;
+					int nm = -1;
+					if(mask == 3) { cur = 3; nm = 2; branch = true; }
+					else if(mask == 2) { cur = 4; nm = 0; }
+					else if(mask == 1) { cur = 3; nm = 0; }
+					else { empty = true; canMoveThru = (origMask == 0); }
+					if(nm >= 0) mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7) | (nm << 8));
+				} else if(ct == 2) {                           // F: gap open from H-up or extension from F-up
+					const int64_t sc_cur = (int64_t)SW_AT(m.F, row, col) - 0xff;
+					int mask = 0;
+					if((int64_t)SW_AT(m.H, row - 1, col) - 0xff - rfgapo == sc_cur) mask |= 1;
+					if((int64_t)SW_AT(m.F, row - 1, col) - 0xff - rfgape == sc_cur) mask |= 2;
+					const int origMask = mask;
+					if(mk & (1 << 10)) mask = (mk >> 11) & 3;
+					int nm = -1;
+					if(mask == 3) { cur = 1; nm = 2; branch = true; }
+					else if(mask == 2) { cur = 2; nm = 0; }
+					else if(mask == 1) { cur = 1; nm = 0; }
+					else { empty = true; canMoveThru = (origMask == 0); }
+					if(nm >= 0) mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10) | (nm << 11));
+				} else {
+					const int64_t sc_cur = (int64_t)SW_AT(m.H, row, col) - 0xff;
+					const bool hasl = col > 0;
+					int64_t sc_diag;                           // Scoring::score scoring.h:259
+					if(readc > 3 || refm > 15) sc_diag = -P.sc.nPen;
+					else sc_diag = (refm & (1 << readc)) ? 0 : -mm_penalty(P.sc, seq.qual(row) - 33);
+					int mask = 0;
+					if(gapsAllowed) {
+						if(sc_cur == (int64_t)SW_AT(m.H, row - 1, col) - 0xff - rfgapo) mask |= 1;
+						if(hasl && sc_cur == (int64_t)SW_AT(m.H, row, col - 1) - 0xff - rdgapo) mask |= 2;
+						if(sc_cur == (int64_t)SW_AT(m.F, row - 1, col) - 0xff - rfgape) mask |= 4;
+						if(hasl && sc_cur == (int64_t)SW_AT(m.E, row, col - 1) - 0xff - rdgape) mask |= 8;
+					}
+					if(hasl && sc_cur == (int64_t)SW_AT(m.H, row - 1, col - 1) - 0xff + sc_diag) mask |= 16;
+					const int origMask = mask;
+					if(mk & (1 << 1)) mask = (mk >> 2) & 31;
+					const int opts = __builtin_popcount((unsigned)mask);
+					int select = -1, nm = -1;
+					if(opts == 1) { select = __builtin_ctz((unsigned)mask); nm = 0; }
+					else if(opts > 1) {                        // the `#if 1` order: diag, H up, F up, H left, E left
+						if(mask & 16) select = 4; else if(mask & 1) select = 0; else if(mask & 4) select = 2;
+						else if(mask & 2) select = 1; else select = 3;
+						nm = mask & ~(1 << select);
+						branch = true;
+					}
+					if(nm >= 0) mk = (uint16_t)((mk & ~(31 << 1)) | (1 << 1) | (nm << 2));   // hMaskSet clears 5 bits at offset 1
+					if(select == 4) cur = 0; else if(select == 0) cur = 1; else if(select == 1) cur = 3;
+					else if(select == 2) cur = 2; else if(select == 3) cur = 4;
+					else { empty = true; canMoveThru = (origMask == 0); }
+				}
+			}
+			SW_AT(m.M, row, col) = (uint16_t)(mk | 1);             // setReportedThrough
+			if(!canMoveThru) {
+				if(nstack == 0) break;                         // give up on this candidate
+				const SwFrame& fr = stack[--nstack];
+				ncells = fr.celsz; ned = fr.nedsz; row = fr.row; col = fr.col; gaps = fr.gaps; ns = fr.ns; score = fr.score; ct = fr.ct;
+				continue;
+			}
+			if(empty || row == 0) {
+				if(ncells < H2G_SW_CELLS) { cells[2 * ncells] = (uint16_t)row; cells[2 * ncells + 1] = (uint16_t)col; }
+				ncells++;
+				ok = true;
+				break;
+			}
+			if(branch) {
+				if(nstack < H2G_SW_STACK) {
+					SwFrame& fr = stack[nstack];
+					fr.nedsz = (uint16_t)ned; fr.celsz = (uint16_t)ncells; fr.row = (uint16_t)row; fr.col = (uint16_t)col; fr.gaps = (uint16_t)gaps;
+					fr.ns = (int16_t)ns; fr.score = (int32_t)score; fr.ct = (uint8_t)ct;
+					nstack++;
+				} else o->overflow = 1;
+			}
+			if(ncells < H2G_SW_CELLS) { cells[2 * ncells] = (uint16_t)row; cells[2 * ncells + 1] = (uint16_t)col; }
+			else o->overflow = 1;
+			ncells++;
+			h2g_edit ed;
+			ed.pad = 0;
+			bool has_edit = true;
+			if(cur == 0) {                                     // SW_BT_OALL_DIAG
+				const int mt = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
+				ct = 0;
+				if(mt != 1) {
+					ed.pos = row; ed.chr = (uint8_t)sw_mask2dna(refm); ed.qchr = (uint8_t)"ACGTN"[readc]; ed.type = H2G_EDIT_MM;
+					score -= (readc > 3 || refm > 15) ? P.sc.nPen : mm_penalty(P.sc, seq.qual(row) - 33);
+				} else has_edit = false;
+				if(mt == -1) ns++;
+				row--; col--;
+			} else if(cur == 1 || cur == 2) {                  // REF_OPEN / RFGAP_EXTEND: up
+				ed.pos = row; ed.chr = '-'; ed.qchr = (uint8_t)"ACGTN"[readc]; ed.type = H2G_EDIT_REF_GAP;
+				row--; ct = cur == 1 ? 0 : 2; score -= cur == 1 ? rfgapo : rfgape; gaps++;
+			} else {                                           // READ_OPEN / RDGAP_EXTEND: left
+				ed.pos = row + 1; ed.chr = (uint8_t)sw_mask2dna(refm); ed.qchr = '-'; ed.type = H2G_EDIT_READ_GAP;
+				col--; ct = cur == 3 ? 0 : 1; score -= cur == 3 ? rdgapo : rdgape; gaps++;
+			}
+			if(has_edit) {
+				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed; else o->overflow = 1;
+				ned++;
+			}
+		}
+		if(ok) {                                               // must overlap a core diagonal (:1776-1804)
+			bool overlapped = false;
+			for(uint32_t k = 0; k < ncells && k < H2G_SW_CELLS && !overlapped; k++) {
+				const int64_t diagi = (int64_t)cells[2 * k + 1] - (int64_t)cells[2 * k] + rect.triml;
+				if(diagi >= 0 && diagi >= rect.corel && diagi <= rect.corer) overlapped = true;
+			}
+			if(!overlapped) ok = false;
+		}
+		if(ok) {                                               // the first aligned column (:1805-1830)
+			const int readc = seq.at(row), refm = 1 << m.rf[col];
+			const int mt = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
+			if(mt != 1) {
+				h2g_edit ed;
+				ed.pad = 0; ed.pos = row; ed.chr = (uint8_t)sw_mask2dna(refm); ed.qchr = (uint8_t)"ACGTN"[readc]; ed.type = H2G_EDIT_MM;
+				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed; else o->overflow = 1;
+				ned++;
+				score -= (readc > 3 || refm > 15) ? P.sc.nPen : mm_penalty(P.sc, seq.qual(row) - 33);
+			}
+			if(mt == -1) ns++;
+			if(ns > nceil) ok = false;
+		}
+		*rnd = reseed + 1;                                     // aligner_sw.cpp:840
+		if(ok) {
+			const uint32_t n = ned < H2G_MAX_EDITS ? ned : H2G_MAX_EDITS;
+			for(uint32_t a = 0; a < n / 2; a++) { h2g_edit t = o->edits[a]; o->edits[a] = o->edits[n - 1 - a]; o->edits[n - 1 - a] = t; }   // res.reverse()
+			o->found = 1; o->score = (int32_t)score; o->nedits = n; o->off = (int64_t)col + rect.refl; o->gaps = gaps;
+			break;
+		}
+	}
+#undef SW_AT
+}
+
+}  // namespace h2g

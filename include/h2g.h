@@ -157,6 +157,35 @@ typedef struct { uint32_t extended, leftext, rightext; } h2g_ext_result;
 H2G_EXPORT h2g_status h2g_extend(h2g_stream*, h2g_ghit* hits /* in/out */, const h2g_ext_args* args, size_t n,
                                  h2g_ext_result* res);
 
+/* ---- Smith-Waterman extension (opt-in in the reference: --bowtie2-dp / --sensitive) ---------------------------- */
+/* One problem = the SwAligner call site of hybridSearch (spliced_aligner.h:209-262) for one seed hit of one read:
+ * DynProgFramer::frameSeedExtensionRect (dp_framer.cpp:81) around refoff = hit.refoff - hit.rdoff, SwAligner::initRef
+ * (aligner_sw.cpp:137), the 8-bit end-to-end fill alignNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:791),
+ * gatherCells (:1202), and the first SwAligner::nextAlignment (aligner_sw.cpp:709) with its backtrace (:1309) and PRNG
+ * reseeding.  Edits are in the coordinates of the aligned strand (fw: patFw, !fw: patRc), ascending. */
+typedef struct {
+	uint32_t read;             /* index into the batch set by h2g_set_reads */
+	uint32_t fw;               /* 1: align patFw, 0: patRc */
+	uint32_t tidx, refoff;     /* reference id; ref offset implied by the seed hit assuming no gaps */
+	int32_t  minsc;            /* _minsc[rdi] (scoreMin.f(len), hisat2.cpp:3470) */
+	uint32_t rnd;              /* RandomSource::last on entry */
+} h2g_sw_query;
+typedef struct {
+	int32_t  found_align;      /* SwAligner::align(): at least one candidate cell */
+	int32_t  found;            /* SwAligner::nextAlignment() */
+	int32_t  best;             /* bestCell: best last-row score (lrmax - 0xff) */
+	int32_t  score;            /* AlnRes::score().score() */
+	int64_t  off;              /* AlnRes::refcoord().off() */
+	uint32_t nedits, gaps;
+	uint32_t overflow;         /* edit / branch-stack capacity exceeded: caller must take its own path */
+	uint32_t rnd;              /* RandomSource::last on exit */
+	int64_t  refl, refr;       /* DPRect::refl / refr (inclusive) */
+	h2g_edit edits[H2G_MAX_EDITS];
+} h2g_sw_result;
+/* *kernel_ms (nullable) = HIP-event time of the SW kernel; repeats > 1 re-runs it for timing */
+H2G_EXPORT h2g_status h2g_sw_align(h2g_stream*, const h2g_sw_query* q, size_t n, h2g_sw_result* out, int repeats,
+                                   float* kernel_ms);
+
 /* ---- fused seed-and-extend stage over the resident read batch ------------------------------------------ */
 /* For every read and both strands: partialSearch from offset 0 (nextBWT hi_aligner.h:4644-4760) ->
  * getAnchorHits coordinate resolution (:5007, ranges up to H2G_SEED_CAP rows) -> 0-mismatch extend

@@ -9,6 +9,7 @@
 #include "../../hisat2_amd/csrc/h2g_host_index.h"
 #include "../../hisat2_amd/csrc/h2g_align.h"
 #include "../../hisat2_amd/csrc/h2g_graph.h"
+#include "../../hisat2_amd/csrc/h2g_sw.h"
 #include "../../hisat2_amd/csrc/h2g_local_pack.h"
 
 using namespace h2g;
@@ -94,6 +95,32 @@ void h2gemu_fm_search(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, h
 	for(size_t i = 0; i < n; i++) {
 		SeqView sv = seq_view(rd, q[i].read, q[i].fw != 0);
 		partial_search_item(e->dg, sv, q[i].offset, q[i].pseudogeneStop != 0, q[i].anchorStop != 0, khits, &out[i]);
+	}
+}
+
+void h2gemu_sw_align(Emu* e, const h2g_sw_query* q, size_t n, h2g_sw_result* out) {
+	DReads rd = e->reads();
+	SwParams P;
+	std::vector<SwFrame> stack(H2G_SW_STACK);
+	std::vector<uint16_t> cells(2 * H2G_SW_CELLS);
+	for(size_t p = 0; p < n; p++) {
+		SeqView sv = seq_view(rd, q[p].read, q[p].fw != 0);
+		const uint32_t nrow = sv.len;
+		const SwRect rect = sw_frame(q[p].refoff, nrow, e->dr.refLens[q[p].tidx]);
+		const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
+		std::vector<uint8_t> H((size_t)nrow * ncol), E(H.size()), F(H.size()), rf(ncol);
+		std::vector<uint16_t> M(H.size());
+		SwMats m;
+		m.nrow = nrow; m.ncol = ncol; m.H = H.data(); m.E = E.data(); m.F = F.data(); m.M = M.data(); m.rf = rf.data();
+		RefCursor rc;
+		rc.init(&e->dr, q[p].tidx);
+		for(uint32_t j = 0; j < ncol; j++) rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
+		sw_fill(m, P, sv, 0, 1);
+		SwOut* o = reinterpret_cast<SwOut*>(&out[p]);
+		uint32_t rnd = q[p].rnd;
+		o->refl = rect.refl; o->refr = rect.refr;
+		sw_gather_backtrace(m, P, sv, rect, q[p].minsc, (int)((double)P.nceil_pct * 0.01 * (double)nrow), &rnd, stack.data(), cells.data(), o);
+		o->rnd = rnd;
 	}
 }
 

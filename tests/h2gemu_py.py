@@ -20,6 +20,7 @@ class Emu:
         self.L.h2gemu_rank.argtypes = [vp, vp, vp, C.c_size_t, vp]
         self.L.h2gemu_fm_search.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
         self.L.h2gemu_sa_resolve.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
+        self.L.h2gemu_sw_align.argtypes = [vp, vp, C.c_size_t, vp]
         self.L.h2gemu_graph_lf.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_fm_search_graph.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp]
         self.L.h2gemu_extend.argtypes = [vp, vp, vp, C.c_size_t, vp]
@@ -49,6 +50,13 @@ class Emu:
         out = (api.FmHit * n)()
         self.L.h2gemu_fm_search(self.h, q, n, khits, out)
         return out
+
+    def sw_align(self, queries, repeats=1):
+        n = len(queries)
+        q = (api.SwQuery * n)(*queries)
+        out = (api.SwResult * n)()
+        self.L.h2gemu_sw_align(self.h, q, n, out)
+        return out, 0.0
 
     def graph_lf(self, queries, k=10):
         n = len(queries)

@@ -231,3 +231,30 @@ def sw_edit_strings(edits, nedits, fw, rdlen):
     if fw:
         return [s(edits[i], edits[i].pos) for i in range(nedits)]
     return [s(edits[i], (rdlen - edits[i].pos) if edits[i].type == 1 else (rdlen - edits[i].pos - 1)) for i in reversed(range(nedits))]
+
+
+def load_sw_reads(golden_dir):
+    _, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_sw.fa.gz"))
+    L = len(seqs[0])
+    arr = np.stack(seqs)
+    offs = (np.arange(len(seqs) + 1, dtype=np.uint64) * L).astype(np.uint32)
+    return arr, offs
+
+
+def check_sw(be, golden_dir, rdlen=101):
+    """backend.sw_align against the reference SwAligner vectors"""
+    cases = parse_sw_probe(golden_dir)
+    qs = [api.SwQuery(d["rid"], d["fw"], d["tidx"], d["refoff"], d["minsc"], (d["rid"] * 7 + d["k"] + 1) & 0xFFFFFFFF) for d in cases]
+    out, _ = be.sw_align(qs)
+    nfound = 0
+    for d, o in zip(cases, out):
+        assert not o.overflow
+        assert [o.refl, o.refr] == d["rect"][:2], d
+        assert (o.found_align, o.best, o.found) == (d["found_align"], d["best"], d["found"]), d
+        assert H.lcg_next(o.rnd)[0] == d["rnd_next"], d
+        if d["found"]:
+            assert (o.score, o.off) == (d["score"], d["off"]), d
+            assert sw_edit_strings(o.edits, o.nedits, d["fw"], rdlen) == d["edits"], d
+            nfound += 1
+    assert nfound > 100
+    return len(cases)

@@ -95,3 +95,11 @@ def test_graph_lf_matches_oracle_on_random_ranges(gemu, oracle_lib, g1s_index):
         if ok:
             assert (r.top, r.bot, r.node_top, r.node_bot) == (a.value, b.value, na.value, nb.value)
             assert e.n == n.value and e.pairs() == [(buf[2 * i], buf[2 * i + 1]) for i in range(min(n.value, 24))]
+
+
+# ---------------------------------------------------------------- Smith-Waterman (h2g_sw.h)
+def test_sw_align(g1_index, golden_dir):
+    e = Emu(g1_index)
+    reads, offs = PC.load_sw_reads(golden_dir)
+    e.set_reads(reads.reshape(-1), offs)
+    assert PC.check_sw(e, golden_dir) > 250
