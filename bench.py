@@ -159,7 +159,7 @@ def main():
         base, contigs = build_index(cache, a.genome_len)
 
     # reads are sharded by id range: rank r owns ids [r*n, (r+1)*n) — per-GPU work is fixed (weak scaling)
-    reads, _ = synth.make_reads(contigs, a.reads, 101, SEED + 1000 * (rank + 1), sub_rate=0.005)
+    reads, truth = synth.make_reads(contigs, a.reads, 101, SEED + 1000 * (rank + 1), sub_rate=0.005)
     codes, offs = synth.flatten_reads(reads)
     ix = api.Index(base, device=local)
     st = api.Stream(ix, max_reads=a.reads, max_bases=codes.size)
@@ -238,6 +238,17 @@ def main():
             micro_g[name] = {"ms": ms, "GB/s": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "checksum": int(ck)}
         gst.close()
         gix.close()
+        # Smith-Waterman kernel (a23-a25, opt-in path of the reference): one wavefront per DP problem, 101 x 141 cells x {H,E,F}
+        # in LDS; problems = the first 65536 bench reads framed around their true position, as hybridSearch frames a seed hit
+        nsw = min(65536, a.reads)
+        swq = [api.SwQuery(i, int(truth[i][2]), int(truth[i][0]), int(truth[i][1]), -20, i + 1) for i in range(nsw)]
+        st.sw_align(swq[:1024])
+        swres, sw_ms = st.sw_align(swq, repeats=3)
+        sw_found = sum(1 for r in swres if r.found)
+        sw_cells = sum(101 * int(r.refr - r.refl + 1) for r in swres)
+        sw_micro = {"problems": nsw, "kernel_ms": sw_ms, "problems_per_s": nsw / (sw_ms * 1e-3), "GCUPS": sw_cells / (sw_ms * 1e-3) / 1e9,
+                    "found": sw_found, "cells_per_problem": sw_cells / nsw,
+                    "note": "integer u8 DP, LDS-resident (71 KB/problem => 2 wavefronts per CU); bound by LDS issue + the sequential backtrace, not HBM"}
         nver = 2000
         verify_sample(base, reads, got, nver)          # seed stage vs oracle/h2o.c
         cpu_ref, ref_sam = (None, None)
@@ -303,6 +314,7 @@ def main():
             "roofline": roofline,
             "rank_microbench": {"sides": 15_300_000, "bytes": 15_300_000 * 64, "queries": a.rank_queries, **micro},
             "rank_microbench_graph": {"sides": 7_650_000, "bytes": 7_650_000 * 128, "queries": a.rank_queries, **micro_g},
+            "sw_microbench": sw_micro,
             "seed_stage": seed_stage,
             "paired_end": pe,
             "counters": {"reads_aligned": int(asum[0]), "reads_multi": int(asum[1]), "reads_overflow": int(asum[2]),

@@ -131,7 +131,7 @@ class ReadResult(C.Structure):
 
 
 class AlignParams(C.Structure):
-    _fields_ = [("khits", u32), ("kseeds", u32), ("no_spliced_alignment", u32), ("secondary", u32)]
+    _fields_ = [("khits", u32), ("kseeds", u32), ("no_spliced_alignment", u32), ("secondary", u32), ("bowtie2_dp", u32)]
 
 
 PAIR_RES_CAP = 16

@@ -12,6 +12,7 @@
 //   selectByScore aln_sink.h:2680   RandomSource random_source.h:33
 #pragma once
 #include "h2g_core.h"
+#include "h2g_sw.h"
 #if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
 #include <stdio.h>
 #define AL_TRACE(...) fprintf(stderr, __VA_ARGS__)
@@ -493,6 +494,7 @@ struct AlnParams {
 	uint32_t minIntronLen, maxIntronLen, minAnchorLen, minAnchorLen_noncan, minK_local;
 	uint32_t pseudogeneStop, anchorStop;
 	uint32_t maxFragLen;     // PairedEndPolicy::maxFragLen = -X (hisat2.cpp:345)
+	uint32_t bowtie2_dp;     // ReportingParams::bowtie2_dp: 0 off, 1 conditional, 2 unconditional (hisat2.cpp:529, 1770)
 	DScoring sc;
 };
 
@@ -716,6 +718,7 @@ struct AlnCtx {
 	const DRef* ref;
 	const DLocalSet* ls;
 	const AlnParams* P;
+	uint8_t* sw = nullptr;   // this lane's Smith-Waterman scratch (sw_scratch_bytes), only when P->bowtie2_dp != 0
 };
 
 H2G_HD uint32_t local_index_of(const DLocalSet& ls, uint32_t tidx, uint32_t toff) {   // HGFM::getLocalGFM hgfm.h:1713
@@ -1235,7 +1238,8 @@ H2G_HD void al_pair_reads(const AlnParams& P, AlignWS* ws, uint32_t rdlen1, uint
 }
 
 // hybridSearch spliced_aligner.h:112-322 (bowtie2_dp = 0) over ws->ghits
-H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw) {
+H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw, Rng* rnd) {
+	const AlnParams& P = *C.P;
 	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
 		uint32_t le = H2G_MAX, re = H2G_MAX;
 		extend_item(*C.ref, C.P->sc, sv, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
@@ -1251,7 +1255,34 @@ H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, Ma
 			const h2g_ghit& b = ws->ghits[hk];
 			if(b.read > a.read || (b.read == a.read && b.len > a.len)) hj = hk;
 		}
-		al_hybrid_search_recur(C, sv, ws, mw, &ws->ghits[hj], ws->ghits[hj].rdoff, ws->ghits[hj].len, mw->minsc, false);
+		h2g_ghit* gh = &ws->ghits[hj];
+		const int64_t maxsc = al_hybrid_search_recur(C, sv, ws, mw, gh, gh->rdoff, gh->len, mw->minsc, false);
+		// spliced_aligner.h:209-317: the opt-in SwAligner pass (--bowtie2-dp 1: only when nothing reached minsc; 2: always)
+		if(P.bowtie2_dp == 2 || (P.bowtie2_dp == 1 && maxsc < mw->minsc)) {
+			bool found = gh->len >= sv.len;
+			if(!found) {
+				if(C.sw == nullptr) ws->overflow |= 256;          // caller did not provide SW scratch
+				else {
+					SwParams SP;
+					SP.sc = P.sc;
+					const uint32_t refoff = gh->toff > gh->rdoff ? gh->toff - gh->rdoff : 0;
+					SwOut* o = nullptr;
+					sw_align_single(*C.ref, SP, sv, gh->tidx, refoff, mw->minsc, &rnd->last, C.sw, &o);
+					if(o->overflow) ws->overflow |= 256;
+					if(o->found) {
+						// res.alres edits: setShape turned them to 5'-end coordinates, `if(!fw) invertEdits()` turns them back
+						// to the aligned strand's => exactly the backtrace's own coordinates.  genomeHit.init(fw, 0, rdlen, ...)
+						const uint32_t joinedOff = (uint32_t)((int64_t)gh->joinedOff + o->off - (int64_t)gh->toff);
+						hit_init(gh, sv.fw, 0, sv.len, gh->tidx, (uint32_t)o->off, joinedOff);
+						gh->score = o->score;
+						gh->nedits = o->nedits;
+						for(uint32_t e = 0; e < o->nedits; e++) gh->edits[e] = o->edits[e];
+						found = true;                                  // replace_edits_with_alts: no ALTs on a linear index
+					}
+				}
+			}
+			if(found) al_hybrid_search_recur(C, sv, ws, mw, gh, gh->rdoff, gh->len, mw->minsc, false);
+		}
 		ws->ghit_done[hj] = 1;
 	}
 }
@@ -1272,7 +1303,7 @@ H2G_HD bool al_align(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw
 	if(numHits == 0) return false;
 	uint64_t add = (uint64_t)((-mw->minsc) / P.sc.mmpMax) * numHits * (P.secondary ? 2 : 1);
 	ws->max_localindexatts = ws->localindexatts + (add > 10 ? add : 10);
-	al_hybrid_search(C, sv, ws, mw);
+	al_hybrid_search(C, sv, ws, mw, rnd);
 	return true;
 }
 

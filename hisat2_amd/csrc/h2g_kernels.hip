@@ -56,6 +56,8 @@ struct h2g_stream {
 	bool has_names = false;
 	AlignWS* d_ws = nullptr;
 	size_t ws_threads = 0;
+	uint8_t* d_sw = nullptr;      // per-lane Smith-Waterman scratch of the go() kernels (only with bowtie2_dp != 0)
+	size_t sw_stride = 0, sw_lanes = 0;
 	ReadOut* d_rout = nullptr;
 	h2g_alnres* d_aln = nullptr;
 	uint8_t* d_codes2 = nullptr;
@@ -288,7 +290,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws);
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws); (void)hipFree(s->d_sw);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(64) void k_sw(DRef ref, DReads rd, SwParams P, cons
 			for(uint32_t j = lane; j < ncol; j += 64) m.rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
 		}
 		__syncthreads();
-		sw_fill(m, P, sv, lane, 64);
+		sw_fill<true>(m, P, sv, lane, 64);
 		if(lane == 0) {
 			SwOut o;
 			uint32_t rnd = qq.rnd;
@@ -1029,12 +1031,14 @@ __global__ __launch_bounds__(256) void k_class_scatter(const uint8_t* keys, uint
 template <int WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref, DLocalSet ls, DReads rd, AlnParams P, const char* names,
                                                const uint32_t* name_offs, AlignWS* pool, ReadOut* outs, h2g_alnres* aln,
-                                               unsigned long long* counters, const uint32_t* perm, unsigned long long* work)
+                                               unsigned long long* counters, const uint32_t* perm, unsigned long long* work,
+                                               uint8_t* sw_base, size_t sw_stride)
 {
 	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	AlignWS* ws = pool + tid;
 	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
+	C.sw = sw_base ? sw_base + tid * sw_stride : nullptr;
 	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0, nside = 0;
 	// per-lane packed copy of the current read in LDS: the byte-per-base global reads of the search / extension
 	// loops become conflict-free ds_read_b32 (word k of lane t at [k][t])
@@ -1093,6 +1097,7 @@ extern "C" void h2g_align_params_init(h2g_align_params* p, const h2g_index* ix) 
 	p->kseeds = p->khits * 2 > 5 ? p->khits * 2 : 5;  // --max-seeds default hisat2.cpp:3174-3176
 	p->no_spliced_alignment = 1;
 	p->secondary = 0;
+	p->bowtie2_dp = 0;                                // hisat2.cpp:529
 }
 
 extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const uint32_t* offs, size_t n) {
@@ -1110,6 +1115,22 @@ extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const
 	HIPCHK(hipMemcpyAsync(s->d_name_offs, offs, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
 	HIPCHK(hipStreamSynchronize(s->st));
 	s->has_names = true;
+	return H2G_OK;
+}
+
+// per-lane Smith-Waterman scratch of the go() kernels (bowtie2_dp != 0): sw_scratch_bytes(longest read) per lane
+static int sw_scratch_for(h2g_stream* s, uint32_t bowtie2_dp, size_t nthreads, uint8_t** base) {
+	*base = nullptr;
+	if(bowtie2_dp == 0) return H2G_OK;
+	if(bowtie2_dp > 2) return H2G_ERR_ARG;
+	if(s->max_read_len == 0 || s->max_read_len > H2G_SW_MAX_ROWS) { snprintf(g_err, sizeof g_err, "bowtie2_dp: read length %u outside 1..%d", s->max_read_len, H2G_SW_MAX_ROWS); return H2G_ERR_ARG; }
+	const size_t stride = (sw_scratch_bytes(s->max_read_len) + 255) & ~(size_t)255;
+	if(s->sw_stride < stride || s->sw_lanes < nthreads) {
+		(void)hipFree(s->d_sw); s->d_sw = nullptr; s->sw_stride = 0; s->sw_lanes = 0;
+		HIPCHK(hipMalloc((void**)&s->d_sw, stride * nthreads));
+		s->sw_stride = stride; s->sw_lanes = nthreads;
+	}
+	*base = s->d_sw;
 	return H2G_OK;
 }
 
@@ -1141,6 +1162,9 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	P.khits = p->khits; P.kseeds = p->kseeds; P.no_spliced = 1; P.secondary = p->secondary;
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
 	P.pseudogeneStop = 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	P.bowtie2_dp = p->bowtie2_dp;
+	uint8_t* sw_base = nullptr;
+	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
 	(void)hipGetLastError();
 	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
@@ -1168,13 +1192,13 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
 	if(occ_mode >= 4)
 		hipLaunchKernelGGL(k_align<4>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr);
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride);
 	else if(occ_mode == 3)
 		hipLaunchKernelGGL(k_align<3>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr);
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride);
 	else
 		hipLaunchKernelGGL(k_align<2>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr);
+		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride);
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;
@@ -1202,12 +1226,13 @@ static_assert(H2G_PAIR_CAP == AL_MAX_PAIRS, "pair capacity");
 __global__ __launch_bounds__(256, 3) void k_align_pairs(DGfm g, DRef ref, DLocalSet ls, DReads rd1, DReads rd2, AlnParams P,
                                                         const char* names1, const uint32_t* noffs1, const char* names2,
                                                         const uint32_t* noffs2, AlignWS* pool, PairOut* outs, h2g_alnres* aln1,
-                                                        h2g_alnres* aln2, unsigned long long* counters)
+                                                        h2g_alnres* aln2, unsigned long long* counters, uint8_t* sw_base, size_t sw_stride)
 {
 	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	AlignWS* ws = pool + tid;
 	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
+	C.sw = sw_base ? sw_base + tid * sw_stride : nullptr;
 	unsigned long long nrank = 0, nsteps = 0, npair = 0, novf = 0, nside = 0;
 	__shared__ uint32_t s_pk[2 * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256];
 	DReads rl[2] = {rd1, rd2};
@@ -1262,6 +1287,7 @@ extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const 
 {
 	if(!s || !codes2 || !offs2 || !nb2 || !noffs2 || n != s->n_reads || n == 0) return H2G_ERR_ARG;
 	if(offs2[n] > s->max_bases) return H2G_ERR_ARG;
+	for(size_t i = 0; i < n; i++) { const uint32_t l = offs2[i + 1] - offs2[i]; if(l > s->max_read_len) s->max_read_len = l; }
 	HIPCHK(hipSetDevice(s->ix->device));
 	if(!s->d_codes2) {
 		HIPCHK(hipMalloc((void**)&s->d_codes2, s->max_bases + 64));
@@ -1309,6 +1335,9 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	P.khits = p->khits; P.kseeds = p->kseeds; P.no_spliced = 1; P.secondary = p->secondary;
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
 	P.pseudogeneStop = 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	P.bowtie2_dp = p->bowtie2_dp;
+	uint8_t* sw_base = nullptr;
+	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
 	DReads r1 = dreads(s), r2 = r1;
 	r2.codes = s->d_codes2; r2.offs = s->d_offs2; r2.quals = s->has_quals2 ? s->d_quals2 : nullptr;
 	(void)hipGetLastError();
@@ -1316,7 +1345,7 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
 	hipLaunchKernelGGL(k_align_pairs, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
-	                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters);
+	                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride);
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;

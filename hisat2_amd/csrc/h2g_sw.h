@@ -91,13 +91,15 @@ H2G_HD void sw_cell(const SwMats& m, const SwParams& P, const SeqView& seq, uint
 #endif
 
 // Anti-diagonal fill by `nlanes` cooperating lanes (64 on the device, 1 in the emulator); also zeroes the masks.
+// COOP = false: a single lane fills alone (no barrier) — the in-go() use from the lane-per-read kernels.
+template <bool COOP>
 H2G_HD void sw_fill(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t lane, uint32_t nlanes) {
 	const uint32_t nrow = m.nrow, ncol = m.ncol;
 	for(uint32_t k = lane; k < nrow * ncol; k += nlanes) m.M[k] = 0;
 	for(uint32_t d = 0; d < nrow + ncol - 1; d++) {
 		const uint32_t ilo = d >= ncol ? d - ncol + 1 : 0, ihi = d < nrow ? d : nrow - 1;
 		for(uint32_t i = ilo + lane; i <= ihi; i += nlanes) sw_cell(m, P, seq, i, d - i);
-		H2G_SW_SYNC();
+		if(COOP) H2G_SW_SYNC();
 	}
 }
 
@@ -306,6 +308,43 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 		}
 	}
 #undef SW_AT
+}
+
+// bytes of per-problem working memory behind a SwMats + stack + cell list + SwOut for reads up to `maxlen`
+H2G_HD size_t sw_cell_bytes(uint32_t nrow, uint32_t ncol) { return ((size_t)nrow * ncol + 15) & ~(size_t)15; }
+H2G_HD size_t sw_scratch_bytes(uint32_t maxlen) {
+	const uint32_t ncol = maxlen + 4 * H2G_SW_MAXGAP;
+	return 5 * sw_cell_bytes(maxlen, ncol) + ((ncol + 15) & ~15u) + sizeof(SwFrame) * H2G_SW_STACK + 4 * H2G_SW_CELLS + 16 + sizeof(SwOut);
+}
+
+// The whole call site (spliced_aligner.h:209-262 without genomeHit bookkeeping) run by ONE lane over scratch memory.
+H2G_HD void sw_align_single(const DRef& ref, const SwParams& P, const SeqView& sv, uint32_t tidx, uint32_t refoff, int64_t minsc,
+                            uint32_t* rnd, uint8_t* scratch, SwOut** out)
+{
+	const uint32_t nrow = sv.len;
+	const SwRect rect = sw_frame(refoff, nrow, ref.refLens[tidx]);
+	const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
+	const size_t cs = sw_cell_bytes(nrow, ncol);
+	SwMats m;
+	m.nrow = nrow; m.ncol = ncol;
+	m.H = scratch; m.E = scratch + cs; m.F = scratch + 2 * cs;
+	m.M = reinterpret_cast<uint16_t*>(scratch + 3 * cs);
+	m.rf = scratch + 5 * cs;
+	uint8_t* p = scratch + 5 * cs + ((ncol + 15) & ~15u);
+	SwFrame* stack = reinterpret_cast<SwFrame*>(p);
+	p += sizeof(SwFrame) * H2G_SW_STACK;
+	uint16_t* cells = reinterpret_cast<uint16_t*>(p);
+	p += 4 * H2G_SW_CELLS;
+	p = reinterpret_cast<uint8_t*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
+	SwOut* o = reinterpret_cast<SwOut*>(p);
+	RefCursor rc;
+	rc.init(&ref, tidx);
+	for(uint32_t j = 0; j < ncol; j++) m.rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
+	sw_fill<false>(m, P, sv, 0, 1);
+	o->refl = rect.refl; o->refr = rect.refr;
+	sw_gather_backtrace(m, P, sv, rect, minsc, (int)((double)P.nceil_pct * 0.01 * (double)nrow), rnd, stack, cells, o);
+	o->rnd = *rnd;
+	*out = o;
 }
 
 }  // namespace h2g

@@ -210,7 +210,7 @@ H2G_EXPORT h2g_status h2g_seed_extend_fetch(h2g_stream*, h2g_seed_result* out, s
 /* Semantics == one iteration of the worker loop body (hisat2.cpp:3380-3640) for an unpaired read that passed the
  * filters: rnd.init(genRandSeed(read)) (pat.h:55), splicedAligner.go(...) (hi_aligner.h:4048), and the selection
  * half of AlnSinkWrap::finishRead (aln_sink.h:1939 -> selectByScore :2680).  Built so far: linear (HFM) indexes,
- * unpaired reads, --no-spliced-alignment, default scoring, bowtie2_dp = 0. */
+ * unpaired reads, --no-spliced-alignment, default scoring, --bowtie2-dp 0/1/2. */
 #define H2G_ALN_CAP 8              /* alignments returned per read (>= -k) */
 typedef struct {                   /* == the arguments reportHit (hi_aligner.h:6064-6166) passes to AlnRes::init */
 	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, pad;
@@ -228,6 +228,9 @@ typedef struct {
 	uint32_t khits, kseeds;        /* -k, --max-seeds */
 	uint32_t no_spliced_alignment; /* must be 1 for now */
 	uint32_t secondary;
+	uint32_t bowtie2_dp;           /* --bowtie2-dp: 0 off (default), 1 SwAligner when no alignment reached minsc, 2 always
+	                                * (spliced_aligner.h:209).  Inside go() the DP is run by the read's own lane over
+	                                * ~75 KB of HBM scratch per lane; the batched LDS kernel is h2g_sw_align. */
 } h2g_align_params;
 H2G_EXPORT void       h2g_align_params_init(h2g_align_params*, const h2g_index*);
 /* read names (needed by genRandSeed): name i = bytes[offs[i] .. offs[i+1]) */

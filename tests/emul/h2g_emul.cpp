@@ -24,6 +24,8 @@ struct Emu {
 	bool has_quals = false;
 	LocalPack lp;
 	DLocalSet dls;
+	uint32_t bowtie2_dp = 0;
+	std::vector<uint8_t> sw;
 	DReads reads() const {
 		DReads r;
 		r.codes = codes.data(); r.offs = offs.data(); r.quals = has_quals ? quals.data() : nullptr;
@@ -57,6 +59,8 @@ int h2gemu_load(const char* base, Emu** out) {
 	*out = e;
 	return 0;
 }
+
+void h2gemu_set_bowtie2_dp(Emu* e, uint32_t v) { e->bowtie2_dp = v; }
 
 void h2gemu_set_reads(Emu* e, const uint8_t* codes, const uint32_t* offs, const char* quals, size_t n) {
 	e->codes.assign(codes, codes + offs[n]);
@@ -115,7 +119,7 @@ void h2gemu_sw_align(Emu* e, const h2g_sw_query* q, size_t n, h2g_sw_result* out
 		RefCursor rc;
 		rc.init(&e->dr, q[p].tidx);
 		for(uint32_t j = 0; j < ncol; j++) rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
-		sw_fill(m, P, sv, 0, 1);
+		sw_fill<false>(m, P, sv, 0, 1);
 		SwOut* o = reinterpret_cast<SwOut*>(&out[p]);
 		uint32_t rnd = q[p].rnd;
 		o->refl = rect.refl; o->refr = rect.refr;
@@ -159,7 +163,10 @@ void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t
 	P.khits = 5; P.kseeds = 10; P.no_spliced = no_spliced; P.secondary = 0;
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
 	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	P.bowtie2_dp = e->bowtie2_dp;
 	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
+	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
+	C.sw = e->sw.data();
 	AlignWS* ws = new AlignWS();
 	for(uint32_t i = 0; i < rd.n; i++) {
 		al_read(C, rd, i, names + name_offs[i], name_offs[i + 1] - name_offs[i], ws, &outs[i]);
@@ -179,7 +186,10 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	P.khits = 5; P.kseeds = 10; P.no_spliced = no_spliced; P.secondary = 0;
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
 	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	P.bowtie2_dp = e->bowtie2_dp;
 	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
+	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
+	C.sw = e->sw.data();
 	AlignWS* ws = new AlignWS();
 	for(uint32_t i = 0; i < rd1.n; i++) {
 		al_pair(C, rd1, rd2, i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &outs[i]);

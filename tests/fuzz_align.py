@@ -17,7 +17,7 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=(), backend=None):
+def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=(), backend=None, bowtie2_dp=0):
     tmp = tempfile.mkdtemp(prefix="h2fuzz")
     contigs = synth.make_genome(list(lens), seed, n_gaps=gaps, gap_len=300, repeats=repeats, repeat_len=500)
     fa = os.path.join(tmp, "g.fa")
@@ -33,7 +33,7 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
     refnames, want = SU.parse_sam(sam)
     qnames = [str(i) for i in range(nreads)]
     if backend is None:
-        outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames)
+        outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames, bowtie2_dp=bowtie2_dp)
         got = SU.render(outs, recs, refnames, [rdlen] * nreads, qnames)
     else:   # backend(base, reads, qnames) -> (outs with .overflow/.depth, rendered dict)
         outs, got = backend(base, reads, qnames, refnames)
@@ -56,4 +56,5 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    run_case(int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]), float(a[5]))
+    dp = int(a[6]) if len(a) > 6 else 0
+    run_case(int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]), float(a[5]), extra=(("--bowtie2-dp", str(dp)) if dp else ()), bowtie2_dp=dp)

@@ -20,8 +20,13 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
+DP = int(os.environ.get("H2G_FUZZ_DP", "0"))   # --bowtie2-dp for both sides
+
+
 def emu_pairs(base, m1, m2, q1, q2):
     e = Emu(base)
+    e.L.h2gemu_set_bowtie2_dp.argtypes = [C.c_void_p, C.c_uint32]
+    e.L.h2gemu_set_bowtie2_dp(e.h, DP)
     n, L = m1.shape
     c1, o1 = synth.flatten_reads(m1)
     c2, o2 = synth.flatten_reads(m2)
@@ -66,7 +71,7 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)
     sam = os.path.join(tmp, "ref.sam")
-    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam],
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam] + (["--bowtie2-dp", str(DP)] if DP else []),
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refnames, want = parse_pe_sam(sam)
     q = [str(i) for i in range(npairs)]

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def gpu_align(base, reads, qnames):
+def gpu_align(base, reads, qnames, bowtie2_dp=0):
     """reads: (n, L) uint8 array or list of arrays"""
     lst = [np.asarray(r, dtype=np.uint8) for r in reads]
     codes = np.concatenate(lst)
@@ -22,7 +22,9 @@ def gpu_align(base, reads, qnames):
     st = api.Stream(ix, max_reads=len(lst), max_bases=codes.size)
     st.set_reads(codes, offs)
     st.set_read_names(qnames)
-    st.align_run()
+    p = st.align_params()
+    p.bowtie2_dp = bowtie2_dp
+    st.align_run(p)
     res, aln = st.align_fetch()
     c = st.counters()
     st.close()
@@ -47,8 +49,8 @@ class _Out:
         self.overflow, self.depth = int(r["overflow"]), int(r["depth"])
 
 
-def _backend(base, reads, qnames, refnames):
-    res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames)
+def _backend(base, reads, qnames, refnames, bowtie2_dp=0):
+    res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames, bowtie2_dp=bowtie2_dp)
     got = SU.render_selected(res, aln, refnames, [reads.shape[1]] * len(reads), qnames)
     return [_Out(r) for r in res], got
 
@@ -63,6 +65,17 @@ def _backend(base, reads, qnames, refnames):
 def test_live_reference(case):
     import fuzz_align as F
     bad, _ = F.run_case(verbose=3, backend=_backend, **case)
+    assert bad == 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("dp", [1, 2])
+def test_live_reference_bowtie2_dp(dp):
+    """--bowtie2-dp 1 / 2: the SwAligner pass of hybridSearch runs inside the go() kernel (lane-sequential DP over HBM scratch)"""
+    import functools
+    import fuzz_align as F
+    bad, _ = F.run_case(verbose=3, backend=functools.partial(_backend, bowtie2_dp=dp), seed=210 + dp, nreads=6000, rdlen=101, sub=0.02,
+                        indel=0.006, nrate=0.001, extra=("--bowtie2-dp", str(dp)))
     assert bad == 0
 
 
