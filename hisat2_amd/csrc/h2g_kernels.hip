@@ -58,6 +58,10 @@ struct h2g_stream {
 	size_t ws_threads = 0;
 	uint8_t* d_sw = nullptr;      // per-lane Smith-Waterman scratch of the go() kernels (only with bowtie2_dp != 0)
 	size_t sw_stride = 0, sw_lanes = 0;
+	uint8_t* d_sw_ws = nullptr;   // h2g_sw_align: H/E/F workspace of one batch of problems
+	size_t sw_ws_bytes = 0;
+	SwLaneState* d_sw_states = nullptr;
+	size_t sw_states = 0;
 	ReadOut* d_rout = nullptr;
 	h2g_alnres* d_aln = nullptr;
 	uint8_t* d_codes2 = nullptr;
@@ -290,7 +294,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws); (void)hipFree(s->d_sw);
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws); (void)hipFree(s->d_sw); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -681,48 +685,58 @@ __global__ __launch_bounds__(256) void k_fm_search_graph(DGfm g, DReads rd, cons
 
 // ------------------------------------------------------------------------------------------ Smith-Waterman
 static_assert(sizeof(h2g_sw_result) == sizeof(SwOut), "h2g_sw_result must mirror SwOut");
-// One wavefront per problem: H/E/F (u8) and the backtrace masks (u16) of the whole rdlen x (rdlen + 40) rectangle live
-// in LDS; 64 lanes fill one anti-diagonal per step (lane stride in LDS = ncol - 1 bytes, odd dword stride => no bank
-// conflicts), lane 0 then gathers + backtraces.  Problems are fetched through a grid-stride loop.
-__global__ __launch_bounds__(64) void k_sw(DRef ref, DReads rd, SwParams P, const h2g_sw_query* q, size_t n, h2g_sw_result* out)
+// Two kernels.  k_sw_fill: one wavefront per problem, register-resident systolic fill (sw_fill_wave), H/E/F streamed to an
+// HBM workspace in anti-diagonal-major order (64 contiguous bytes per step and matrix).  k_sw_backtrace: one LANE per
+// problem walks the reference's sequential gather/backtrace over that workspace, so 64 backtraces share a wavefront
+// instead of 63 lanes idling behind one.
+struct SwWs { uint8_t* base; size_t stride, mat_bytes; };   // per problem: H | E | F (mat_bytes each) | rf
+__global__ __launch_bounds__(64) void k_sw_fill(DRef ref, DReads rd, SwParams P, const h2g_sw_query* q, size_t n, SwWs ws)
 {
-	extern __shared__ uint8_t smem[];
-	__shared__ SwFrame stack[H2G_SW_STACK];
-	__shared__ uint16_t cells[2 * H2G_SW_CELLS];
+	__shared__ uint8_t s_rf[H2G_SW_MAX_COLS + 8];
 	const uint32_t lane = threadIdx.x;
 	for(size_t p = blockIdx.x; p < n; p += gridDim.x) {
 		const h2g_sw_query qq = q[p];
 		SeqView sv = seq_view(rd, qq.read, qq.fw != 0);
 		const uint32_t nrow = sv.len;
-		const uint32_t reflen = ref.refLens[qq.tidx];
-		const SwRect rect = sw_frame(qq.refoff, nrow, reflen);
+		const SwRect rect = sw_frame(qq.refoff, nrow, ref.refLens[qq.tidx]);
 		const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
-		const size_t cellsz = ((size_t)nrow * ncol + 15) & ~(size_t)15;
+		uint8_t* w = ws.base + p * ws.stride;
 		SwMats m;
-		m.nrow = nrow; m.ncol = ncol;
-		m.H = smem; m.E = smem + cellsz; m.F = smem + 2 * cellsz;
-		m.M = reinterpret_cast<uint16_t*>(smem + 3 * cellsz);
-		m.rf = smem + 5 * cellsz;
+		m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1;
+		m.H = w; m.E = w + ws.mat_bytes; m.F = w + 2 * ws.mat_bytes; m.rf = s_rf;
 		{   // reference window: BitPairReference::getStretch semantics (N / outside the sequence = 4)
 			RefCursor rc;
 			rc.init(&ref, qq.tidx);
-			for(uint32_t j = lane; j < ncol; j += 64) m.rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
+			uint8_t* grf = w + 3 * ws.mat_bytes;
+			for(uint32_t j = lane; j < ncol; j += 64) { const uint8_t c = (uint8_t)rc.get(rect.refl + (int64_t)j); s_rf[j] = c; grf[j] = c; }
 		}
 		__syncthreads();
-		sw_fill<true>(m, P, sv, lane, 64);
-		if(lane == 0) {
-			SwOut o;
-			uint32_t rnd = qq.rnd;
-			const int nceil = (int)((double)P.nceil_pct * 0.01 * (double)nrow);
-			o.refl = rect.refl; o.refr = rect.refr;
-			sw_gather_backtrace(m, P, sv, rect, qq.minsc, nceil, &rnd, stack, cells, &o);
-			o.rnd = rnd;
-			SwOut* dst = reinterpret_cast<SwOut*>(&out[p]);
-			dst->found_align = o.found_align; dst->found = o.found; dst->best = o.best; dst->score = o.score; dst->off = o.off;
-			dst->nedits = o.nedits; dst->gaps = o.gaps; dst->overflow = o.overflow; dst->rnd = o.rnd; dst->refl = o.refl; dst->refr = o.refr;
-			for(uint32_t e = 0; e < o.nedits; e++) dst->edits[e] = o.edits[e];
-		}
+		sw_fill_wave(m, P, sv, lane);
 		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(256) void k_sw_backtrace(DRef ref, DReads rd, SwParams P, const h2g_sw_query* q, size_t n, SwWs ws,
+                                                      SwLaneState* states, h2g_sw_result* out)
+{
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	SwLaneState* ls = states + tid;
+	for(size_t p = tid; p < n; p += stride) {
+		const h2g_sw_query qq = q[p];
+		SeqView sv = seq_view(rd, qq.read, qq.fw != 0);
+		const uint32_t nrow = sv.len;
+		const SwRect rect = sw_frame(qq.refoff, nrow, ref.refLens[qq.tidx]);
+		const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
+		uint8_t* w = ws.base + p * ws.stride;
+		SwMats m;
+		m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1;
+		m.H = w; m.E = w + ws.mat_bytes; m.F = w + 2 * ws.mat_bytes; m.rf = w + 3 * ws.mat_bytes;
+		uint32_t rnd = qq.rnd;
+		const SwOut* o = sw_finish(m, P, sv, rect, qq.minsc, &rnd, ls);
+		SwOut* dst = reinterpret_cast<SwOut*>(&out[p]);
+		dst->found_align = o->found_align; dst->found = o->found; dst->best = o->best; dst->score = o->score; dst->off = o->off;
+		dst->nedits = o->nedits; dst->gaps = o->gaps; dst->overflow = o->overflow; dst->rnd = o->rnd; dst->refl = o->refl; dst->refr = o->refr;
+		for(uint32_t e = 0; e < o->nedits; e++) dst->edits[e] = o->edits[e];
 	}
 }
 
@@ -814,23 +828,41 @@ extern "C" h2g_status h2g_sw_align(h2g_stream* s, const h2g_sw_query* q, size_t 
 	if((rc = need_reads(s))) return rc;
 	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
 	for(size_t i = 0; i < n; i++) if(q[i].read >= s->n_reads || q[i].tidx >= s->ix->dr.nrefs) return H2G_ERR_ARG;
-	const uint32_t maxlen = s->max_read_len;   // longest read of the resident batch: sizes the LDS rectangle
+	const uint32_t maxlen = s->max_read_len;   // longest read of the resident batch: sizes the per-problem workspace
 	if(maxlen == 0 || maxlen > H2G_SW_MAX_ROWS) { snprintf(g_err, sizeof g_err, "h2g_sw_align: read length %u outside 1..%d", maxlen, H2G_SW_MAX_ROWS); return H2G_ERR_ARG; }
 	HIPCHK(hipSetDevice(s->ix->device));
-	const size_t ncolmax = maxlen + 4 * H2G_SW_MAXGAP;
-	const size_t cellsz = ((size_t)maxlen * ncolmax + 15) & ~(size_t)15;
-	const size_t lds = 5 * cellsz + ((ncolmax + 15) & ~(size_t)15);
-	if(lds > 150 * 1024) { snprintf(g_err, sizeof g_err, "h2g_sw_align: %zu B of LDS needed", lds); return H2G_ERR_ARG; }
-	HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	const size_t ncolmax = maxlen + 4 * H2G_SW_MAXGAP, ndmax = maxlen + ncolmax - 1;
+	SwWs ws;
+	ws.mat_bytes = (size_t)((maxlen + 63) / 64) * ndmax * 64;
+	ws.stride = 3 * ws.mat_bytes + ((ncolmax + 255) & ~(size_t)255);
+	const size_t batch = n < 32768 ? n : 32768;                   // 32 k problems x ~93 KB = 3 GB of HBM workspace
+	const size_t bt_threads = ((batch + 255) / 256) * 256;
+	if(s->sw_ws_bytes < batch * ws.stride) {
+		(void)hipFree(s->d_sw_ws); s->d_sw_ws = nullptr; s->sw_ws_bytes = 0;
+		HIPCHK(hipMalloc((void**)&s->d_sw_ws, batch * ws.stride));
+		s->sw_ws_bytes = batch * ws.stride;
+	}
+	if(s->sw_states < bt_threads) {
+		(void)hipFree(s->d_sw_states); s->d_sw_states = nullptr; s->sw_states = 0;
+		HIPCHK(hipMalloc((void**)&s->d_sw_states, bt_threads * sizeof(SwLaneState)));
+		HIPCHK(hipMemset(s->d_sw_states, 0, bt_threads * sizeof(SwLaneState)));   // mask-table generations start at 0
+		s->sw_states = bt_threads;
+	}
+	ws.base = s->d_sw_ws;
 	void *dq, *dout;
 	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * sizeof *out, &dout))) return rc;
 	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
 	SwParams P;
-	const unsigned grid = (unsigned)(n < 256 * 8 ? n : 256 * 8);
 	if(repeats < 1) repeats = 1;
 	HIPCHK(hipEventRecord(s->ev[0], s->st));
-	for(int r = 0; r < repeats; r++)
-		hipLaunchKernelGGL(k_sw, dim3(grid), dim3(64), lds, s->st, s->ix->dr, dreads(s), P, (const h2g_sw_query*)dq, n, (h2g_sw_result*)dout);
+	for(int r = 0; r < repeats; r++) {
+		for(size_t first = 0; first < n; first += batch) {
+			const size_t nb = n - first < batch ? n - first : batch;
+			hipLaunchKernelGGL(k_sw_fill, dim3((unsigned)nb), dim3(64), 0, s->st, s->ix->dr, dreads(s), P, (const h2g_sw_query*)dq + first, nb, ws);
+			hipLaunchKernelGGL(k_sw_backtrace, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s->st, s->ix->dr, dreads(s), P,
+			                   (const h2g_sw_query*)dq + first, nb, ws, s->d_sw_states, (h2g_sw_result*)dout + first);
+		}
+	}
 	HIPCHK(hipEventRecord(s->ev[1], s->st));
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
@@ -1128,6 +1160,7 @@ static int sw_scratch_for(h2g_stream* s, uint32_t bowtie2_dp, size_t nthreads, u
 	if(s->sw_stride < stride || s->sw_lanes < nthreads) {
 		(void)hipFree(s->d_sw); s->d_sw = nullptr; s->sw_stride = 0; s->sw_lanes = 0;
 		HIPCHK(hipMalloc((void**)&s->d_sw, stride * nthreads));
+		HIPCHK(hipMemset(s->d_sw, 0, stride * nthreads));   // SwLaneState: mask-table generations start at 0
 		s->sw_stride = stride; s->sw_lanes = nthreads;
 	}
 	*base = s->d_sw;

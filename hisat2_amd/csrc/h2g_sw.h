@@ -35,12 +35,48 @@ struct SwParams {   // Scoring (scoring.h) + the constants of the call site
 
 struct SwFrame { uint16_t nedsz, celsz, row, col, gaps; int16_t ns; int32_t score; uint8_t ct; };
 
-// Per-problem working set.  On the device H/E/F/M live in LDS (one workgroup per problem); the emulator mallocs them.
+// SSEMatrix::masks_ (reportedThru bit 0, H mask 1/2-6, E mask 7/8-9, F mask 10/11-12) is only ever touched along the
+// backtraced paths (a few hundred cells of 14 k), so it is kept as a small open-addressing table instead of a matrix.
+// Entry = generation << 32 | (row << 8 | col) << 16 | mask; a new problem bumps the generation instead of clearing.
+#define H2G_SW_MASK_SLOTS 1024
+struct SwMaskTab {
+	uint64_t* e;      // [H2G_SW_MASK_SLOTS], zero-initialised once
+	uint32_t  gen;    // > 0
+	uint32_t  full;   // set when an insert found no slot (reported as overflow)
+	H2G_HD uint32_t slot(uint32_t key) const { return (key * 40503u >> 4) & (H2G_SW_MASK_SLOTS - 1); }
+	H2G_HD uint32_t get(uint32_t row, uint32_t col) const {
+		const uint32_t key = (row << 8) | col;
+		uint32_t h = slot(key);
+		for(uint32_t n = 0; n < H2G_SW_MASK_SLOTS; n++, h = (h + 1) & (H2G_SW_MASK_SLOTS - 1)) {
+			const uint64_t v = e[h];
+			if((uint32_t)(v >> 32) != gen) return 0;
+			if(((uint32_t)v >> 16) == key) return (uint32_t)v & 0xffffu;
+		}
+		return 0;
+	}
+	H2G_HD void set(uint32_t row, uint32_t col, uint32_t mask) {
+		const uint32_t key = (row << 8) | col;
+		uint32_t h = slot(key);
+		for(uint32_t n = 0; n < H2G_SW_MASK_SLOTS; n++, h = (h + 1) & (H2G_SW_MASK_SLOTS - 1)) {
+			const uint64_t v = e[h];
+			if((uint32_t)(v >> 32) != gen || ((uint32_t)v >> 16) == key) { e[h] = ((uint64_t)gen << 32) | (key << 16) | (mask & 0xffffu); return; }
+		}
+		full = 1;
+	}
+};
+
+// Per-problem working set.  Two layouts of H/E/F:
+//   layout 0: row-major [i * ncol + j]                      (single-lane fill: emulator, in-go() use)
+//   layout 1: anti-diagonal-major [((i >> 6) * nd + i + j) << 6 | (i & 63)], nd = nrow + ncol - 1
+//             — what the wavefront fill writes: the 64 cells of one step are 64 contiguous bytes
 struct SwMats {
-	uint8_t*  H; uint8_t* E; uint8_t* F;   // [nrow * ncol]
-	uint16_t* M;                           // SSEMatrix::masks_: bit 0 reportedThru, H mask 1/2-6, E 7/8-9, F 10/11-12
+	uint8_t*  H; uint8_t* E; uint8_t* F;
 	uint8_t*  rf;                          // reference chars 0..4 for the ncol columns
-	uint32_t  nrow, ncol;
+	uint32_t  nrow, ncol, nd, layout;
+	H2G_HD size_t at(uint32_t i, uint32_t j) const {
+		return layout ? ((((size_t)(i >> 6) * nd + i + j) << 6) | (i & 63u)) : ((size_t)i * ncol + j);
+	}
+	H2G_HD size_t bytes() const { return layout ? ((size_t)((nrow + 63) >> 6) * nd) << 6 : (size_t)nrow * ncol; }
 };
 
 H2G_HD uint8_t subs8(uint32_t a, uint32_t b) { return (uint8_t)(a > b ? a - b : 0u); }
@@ -69,16 +105,16 @@ H2G_HD uint32_t sw_pen(const DScoring& sc, int readc, int refc, int q) {
 
 // One DP cell.  Reads only cells of the two previous anti-diagonals.
 H2G_HD void sw_cell(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t i, uint32_t j) {
-	const uint32_t ncol = m.ncol, nrow = m.nrow;
+	const uint32_t nrow = m.nrow;
 	const uint32_t gb = (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar) ? 0xffu : 0u;
 	const uint32_t rdgapo = (uint32_t)(P.sc.rdGapConst + P.sc.rdGapLinear), rdgape = (uint32_t)P.sc.rdGapLinear;
 	const uint32_t rfgapo = (uint32_t)(P.sc.rfGapConst + P.sc.rfGapLinear), rfgape = (uint32_t)P.sc.rfGapLinear;
-	const size_t at = (size_t)i * ncol + j;
 	uint32_t e = 0, f = 0, diag;
-	if(j > 0) e = max8(subs8(m.E[at - 1], rdgape), subs8(subs8(m.H[at - 1], rdgapo), gb));
-	if(i > 0) f = subs8(max8(subs8(m.F[at - ncol], rfgape), subs8(m.H[at - ncol], rfgapo)), gb);
-	diag = i == 0 ? 0xffu : (j == 0 ? 0u : m.H[at - ncol - 1]);
+	if(j > 0) { const size_t l = m.at(i, j - 1); e = max8(subs8(m.E[l], rdgape), subs8(subs8(m.H[l], rdgapo), gb)); }
+	if(i > 0) { const size_t u = m.at(i - 1, j); f = subs8(max8(subs8(m.F[u], rfgape), subs8(m.H[u], rfgapo)), gb); }
+	diag = i == 0 ? 0xffu : (j == 0 ? 0u : m.H[m.at(i - 1, j - 1)]);
 	const uint32_t pen = sw_pen(P.sc, seq.at(i), m.rf[j], seq.qual(i) - 33);
+	const size_t at = m.at(i, j);
 	m.E[at] = (uint8_t)e;
 	m.F[at] = (uint8_t)f;
 	m.H[at] = max8(max8(subs8(diag, pen), e), f);
@@ -90,18 +126,72 @@ H2G_HD void sw_cell(const SwMats& m, const SwParams& P, const SeqView& seq, uint
 #define H2G_SW_SYNC() ((void)0)
 #endif
 
-// Anti-diagonal fill by `nlanes` cooperating lanes (64 on the device, 1 in the emulator); also zeroes the masks.
-// COOP = false: a single lane fills alone (no barrier) — the in-go() use from the lane-per-read kernels.
+// Anti-diagonal fill by `nlanes` cooperating lanes through memory (1 lane: emulator and in-go() use).
+// COOP = true adds a barrier per anti-diagonal (lanes of one workgroup sharing the matrices).
 template <bool COOP>
 H2G_HD void sw_fill(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t lane, uint32_t nlanes) {
 	const uint32_t nrow = m.nrow, ncol = m.ncol;
-	for(uint32_t k = lane; k < nrow * ncol; k += nlanes) m.M[k] = 0;
 	for(uint32_t d = 0; d < nrow + ncol - 1; d++) {
 		const uint32_t ilo = d >= ncol ? d - ncol + 1 : 0, ihi = d < nrow ? d : nrow - 1;
 		for(uint32_t i = ilo + lane; i <= ihi; i += nlanes) sw_cell(m, P, seq, i, d - i);
 		if(COOP) H2G_SW_SYNC();
 	}
 }
+
+#if defined(__HIPCC__)
+// Wavefront fill (layout 1): lane l owns rows l, 64 + l, 128 + l.  At step d it computes cell (i, d - i) of each of its
+// rows from its own previous cell (H/E to the left) and the previous cells of the lane above (H/F up, H diagonal), which
+// arrive by one 32-bit __shfl_up per chunk — the packed word also conveys the reference character down the diagonal.
+// No LDS, no barriers; the three result bytes of a step are 64 contiguous bytes per matrix (coalesced stores).
+//   packed word: h_cur | h_old << 8 | f_cur << 16 | refc << 24
+__device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t lane) {
+	const uint32_t nrow = m.nrow, ncol = m.ncol, nd = m.nd;
+	const uint32_t nch = (nrow + 63) >> 6;
+	const uint32_t rdgapo = (uint32_t)(P.sc.rdGapConst + P.sc.rdGapLinear), rdgape = (uint32_t)P.sc.rdGapLinear;
+	const uint32_t rfgapo = (uint32_t)(P.sc.rfGapConst + P.sc.rfGapLinear), rfgape = (uint32_t)P.sc.rfGapLinear;
+	uint32_t pk[3] = {0, 0, 0}, e_cur[3] = {0, 0, 0};
+	int readc[3]; uint32_t mmpen[3], gb[3];
+#pragma unroll
+	for(int c = 0; c < 3; c++) {
+		const uint32_t i = (uint32_t)c * 64 + lane;
+		const bool in = i < nrow;
+		readc[c] = in ? seq.at(i) : 4;
+		mmpen[c] = in ? (uint32_t)mm_penalty(P.sc, seq.qual(i) - 33) : 0u;
+		gb[c] = (in && (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar)) ? 0xffu : 0u;
+	}
+	for(uint32_t d = 0; d < nd; d++) {
+		uint32_t up[3];
+		const uint32_t fresh = d < ncol ? (uint32_t)m.rf[d] : 4u;     // row 0 meets column d at step d
+#pragma unroll
+		for(int c = 0; c < 3; c++) {
+			if((uint32_t)c >= nch) break;
+			uint32_t u = __shfl_up(pk[c], 1);
+			if(c > 0) { const uint32_t w = __shfl(pk[c - 1], 63); if(lane == 0) u = w; }
+			else if(lane == 0) u = fresh << 24;
+			up[c] = u;
+		}
+#pragma unroll
+		for(int c = 0; c < 3; c++) {
+			if((uint32_t)c >= nch) break;
+			const uint32_t i = (uint32_t)c * 64 + lane;
+			const int32_t j = (int32_t)d - (int32_t)i;
+			if(i < nrow && j >= 0 && j < (int32_t)ncol) {
+				const uint32_t h_left = pk[c] & 0xffu, e_left = e_cur[c];
+				const uint32_t up_h = up[c] & 0xffu, up_hold = (up[c] >> 8) & 0xffu, up_f = (up[c] >> 16) & 0xffu, refc = up[c] >> 24;
+				const uint32_t e = j == 0 ? 0u : max8(subs8(e_left, rdgape), subs8(subs8(h_left, rdgapo), gb[c]));
+				const uint32_t f = i == 0 ? 0u : subs8(max8(subs8(up_f, rfgape), subs8(up_h, rfgapo)), gb[c]);
+				const uint32_t diag = i == 0 ? 0xffu : (j == 0 ? 0u : up_hold);
+				const uint32_t pen = (readc[c] > 3 || refc > 3) ? (uint32_t)P.sc.nPen : ((uint32_t)readc[c] == refc ? 0u : mmpen[c]);
+				const uint32_t h = max8(max8(subs8(diag, pen), e), f);
+				const size_t at = ((((size_t)c * nd + d) << 6) | lane);
+				m.H[at] = (uint8_t)h; m.E[at] = (uint8_t)e; m.F[at] = (uint8_t)f;
+				pk[c] = h | (h_left << 8) | (f << 16) | (refc << 24);
+				e_cur[c] = e;
+			}
+		}
+	}
+}
+#endif
 
 struct SwOut {   // mirrors h2g_sw_result
 	int32_t  found_align, found;
@@ -126,14 +216,13 @@ H2G_HD char sw_mask2dna(int refm) {   // alphabet.cpp:71-89 for the masks that o
 // gather (:1202-1234) + candidate order (aligner_sw_nuc.h:149) + nextAlignment loop (aligner_sw.cpp:709-870) +
 // backtrace (:1309-1900).  Sequential; call from one lane after sw_fill.  `rnd` = RandomSource::last.
 H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqView& seq, const SwRect& rect, int64_t minsc,
-                                int nceil, uint32_t* rnd, SwFrame* stack, uint16_t* cells /* [2 * H2G_SW_CELLS] */, SwOut* o)
+                                int nceil, uint32_t* rnd, SwMaskTab& mt, SwFrame* stack, uint16_t* cells /* [2 * H2G_SW_CELLS] */, SwOut* o)
 {
 	const uint32_t nrow = m.nrow, ncol = m.ncol;
 	const int64_t rdgapo = P.sc.rdGapConst + P.sc.rdGapLinear, rdgape = P.sc.rdGapLinear;
 	const int64_t rfgapo = P.sc.rfGapConst + P.sc.rfGapLinear, rfgape = P.sc.rfGapLinear;
-#define SW_AT(mat, i, j) mat[(size_t)(i) * ncol + (j)]
 	uint32_t lrmax = 0;
-	for(uint32_t j = 0; j < ncol; j++) { const uint32_t v = SW_AT(m.H, nrow - 1, j); if(v > lrmax) lrmax = v; }
+	for(uint32_t j = 0; j < ncol; j++) { const uint32_t v = m.H[m.at(nrow - 1, j)]; if(v > lrmax) lrmax = v; }
 	o->best = (int32_t)lrmax - 0xff;
 	o->found_align = 0; o->found = 0; o->score = 0; o->off = 0; o->nedits = 0; o->gaps = 0; o->overflow = 0;
 	if((int64_t)o->best < minsc || lrmax == 0) return;         // flag -1 / -2 (:1140-1165)
@@ -146,7 +235,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 		uint32_t best_v = 0, best_col = 0;
 		bool have = false;
 		for(uint32_t j = 0; j < ncol; j++) {
-			const uint32_t v = SW_AT(m.H, nrow - 1, j);
+			const uint32_t v = m.H[m.at(nrow - 1, j)];
 			if((int64_t)v - 0xff < minsc) continue;
 			any = true;
 			const bool after = v < prev_v || (v == prev_v && j < prev_col);
@@ -157,7 +246,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 		if(!have) break;
 		prev_v = best_v; prev_col = best_col;
 		uint32_t row = nrow - 1, col = best_col;
-		if(SW_AT(m.M, row, col) & 1) continue;                 // BT_CAND_FATE_FILT_START
+		if(mt.get(row, col) & 1) continue;                 // BT_CAND_FATE_FILT_START
 		const uint32_t reseed = sw_lcg_next(rnd) + 1;          // aligner_sw.cpp:766-767
 		// ---- backtrace
 		uint32_t nstack = 0, ncells = 0, ned = 0, gaps = 0;
@@ -169,15 +258,15 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 			const int refm = 1 << m.rf[col];
 			bool empty = false, canMoveThru = true, branch = false;
 			int cur = -1;
-			uint16_t mk = SW_AT(m.M, row, col);
+			uint16_t mk = (uint16_t)mt.get(row, col);
 			if(mk & 1) canMoveThru = false;
 			else if(row > 0) {
 				const bool gapsAllowed = !(row < (uint32_t)P.gapbar || (nrow - row - 1) < (uint32_t)P.gapbar);
 				if(ct == 1) {                                  // E: gap open from H-left or extension from E-left
-					const int64_t sc_cur = (int64_t)SW_AT(m.E, row, col) - 0xff;
+					const int64_t sc_cur = (int64_t)m.E[m.at(row, col)] - 0xff;
 					int mask = 0;
-					if((int64_t)SW_AT(m.H, row, col - 1) - 0xff - rdgapo == sc_cur) mask |= 1;
-					if((int64_t)SW_AT(m.E, row, col - 1) - 0xff - rdgape == sc_cur) mask |= 2;
+					if((int64_t)m.H[m.at(row, col - 1)] - 0xff - rdgapo == sc_cur) mask |= 1;
+					if((int64_t)m.E[m.at(row, col - 1)] - 0xff - rdgape == sc_cur) mask |= 2;
 					const int origMask = mask;
 					if(mk & (1 << 7)) mask = (mk >> 8) & 3;
 					int nm = -1;
@@ -187,10 +276,10 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 					else { empty = true; canMoveThru = (origMask == 0); }
 					if(nm >= 0) mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7) | (nm << 8));
 				} else if(ct == 2) {                           // F: gap open from H-up or extension from F-up
-					const int64_t sc_cur = (int64_t)SW_AT(m.F, row, col) - 0xff;
+					const int64_t sc_cur = (int64_t)m.F[m.at(row, col)] - 0xff;
 					int mask = 0;
-					if((int64_t)SW_AT(m.H, row - 1, col) - 0xff - rfgapo == sc_cur) mask |= 1;
-					if((int64_t)SW_AT(m.F, row - 1, col) - 0xff - rfgape == sc_cur) mask |= 2;
+					if((int64_t)m.H[m.at(row - 1, col)] - 0xff - rfgapo == sc_cur) mask |= 1;
+					if((int64_t)m.F[m.at(row - 1, col)] - 0xff - rfgape == sc_cur) mask |= 2;
 					const int origMask = mask;
 					if(mk & (1 << 10)) mask = (mk >> 11) & 3;
 					int nm = -1;
@@ -200,19 +289,19 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 					else { empty = true; canMoveThru = (origMask == 0); }
 					if(nm >= 0) mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10) | (nm << 11));
 				} else {
-					const int64_t sc_cur = (int64_t)SW_AT(m.H, row, col) - 0xff;
+					const int64_t sc_cur = (int64_t)m.H[m.at(row, col)] - 0xff;
 					const bool hasl = col > 0;
 					int64_t sc_diag;                           // Scoring::score scoring.h:259
 					if(readc > 3 || refm > 15) sc_diag = -P.sc.nPen;
 					else sc_diag = (refm & (1 << readc)) ? 0 : -mm_penalty(P.sc, seq.qual(row) - 33);
 					int mask = 0;
 					if(gapsAllowed) {
-						if(sc_cur == (int64_t)SW_AT(m.H, row - 1, col) - 0xff - rfgapo) mask |= 1;
-						if(hasl && sc_cur == (int64_t)SW_AT(m.H, row, col - 1) - 0xff - rdgapo) mask |= 2;
-						if(sc_cur == (int64_t)SW_AT(m.F, row - 1, col) - 0xff - rfgape) mask |= 4;
-						if(hasl && sc_cur == (int64_t)SW_AT(m.E, row, col - 1) - 0xff - rdgape) mask |= 8;
+						if(sc_cur == (int64_t)m.H[m.at(row - 1, col)] - 0xff - rfgapo) mask |= 1;
+						if(hasl && sc_cur == (int64_t)m.H[m.at(row, col - 1)] - 0xff - rdgapo) mask |= 2;
+						if(sc_cur == (int64_t)m.F[m.at(row - 1, col)] - 0xff - rfgape) mask |= 4;
+						if(hasl && sc_cur == (int64_t)m.E[m.at(row, col - 1)] - 0xff - rdgape) mask |= 8;
 					}
-					if(hasl && sc_cur == (int64_t)SW_AT(m.H, row - 1, col - 1) - 0xff + sc_diag) mask |= 16;
+					if(hasl && sc_cur == (int64_t)m.H[m.at(row - 1, col - 1)] - 0xff + sc_diag) mask |= 16;
 					const int origMask = mask;
 					if(mk & (1 << 1)) mask = (mk >> 2) & 31;
 					const int opts = __builtin_popcount((unsigned)mask);
@@ -230,7 +319,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 					else { empty = true; canMoveThru = (origMask == 0); }
 				}
 			}
-			SW_AT(m.M, row, col) = (uint16_t)(mk | 1);             // setReportedThrough
+			mt.set(row, col, (uint32_t)mk | 1u);                     // setReportedThrough
 			if(!canMoveThru) {
 				if(nstack == 0) break;                         // give up on this candidate
 				const SwFrame& fr = stack[--nstack];
@@ -307,14 +396,33 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 			break;
 		}
 	}
-#undef SW_AT
+	if(mt.full) o->overflow = 1;
 }
 
-// bytes of per-problem working memory behind a SwMats + stack + cell list + SwOut for reads up to `maxlen`
+// Per-lane backtrace state that persists across problems: the mask table (+ its generation), branch stack, cell list, result
+struct SwLaneState {
+	uint32_t gen, pad[3];
+	uint64_t mask[H2G_SW_MASK_SLOTS];
+	SwFrame  stack[H2G_SW_STACK];
+	uint16_t cells[2 * H2G_SW_CELLS];
+	SwOut    out;
+};
 H2G_HD size_t sw_cell_bytes(uint32_t nrow, uint32_t ncol) { return ((size_t)nrow * ncol + 15) & ~(size_t)15; }
+// in-go() scratch of one lane for reads up to `maxlen`: SwLaneState + row-major H/E/F + the reference window
 H2G_HD size_t sw_scratch_bytes(uint32_t maxlen) {
 	const uint32_t ncol = maxlen + 4 * H2G_SW_MAXGAP;
-	return 5 * sw_cell_bytes(maxlen, ncol) + ((ncol + 15) & ~15u) + sizeof(SwFrame) * H2G_SW_STACK + 4 * H2G_SW_CELLS + 16 + sizeof(SwOut);
+	return ((sizeof(SwLaneState) + 15) & ~(size_t)15) + 3 * sw_cell_bytes(maxlen, ncol) + ((ncol + 15) & ~15u);
+}
+
+// gather + backtrace of one filled problem on the calling lane, using its persistent SwLaneState (zero-initialised once)
+H2G_HD SwOut* sw_finish(const SwMats& m, const SwParams& P, const SeqView& sv, const SwRect& rect, int64_t minsc, uint32_t* rnd, SwLaneState* ls) {
+	SwMaskTab mt;
+	mt.e = ls->mask; mt.gen = ++ls->gen; mt.full = 0;
+	SwOut* o = &ls->out;
+	o->refl = rect.refl; o->refr = rect.refr;
+	sw_gather_backtrace(m, P, sv, rect, minsc, (int)((double)P.nceil_pct * 0.01 * (double)m.nrow), rnd, mt, ls->stack, ls->cells, o);
+	o->rnd = *rnd;
+	return o;
 }
 
 // The whole call site (spliced_aligner.h:209-262 without genomeHit bookkeeping) run by ONE lane over scratch memory.
@@ -325,26 +433,16 @@ H2G_HD void sw_align_single(const DRef& ref, const SwParams& P, const SeqView& s
 	const SwRect rect = sw_frame(refoff, nrow, ref.refLens[tidx]);
 	const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
 	const size_t cs = sw_cell_bytes(nrow, ncol);
+	SwLaneState* ls = reinterpret_cast<SwLaneState*>(scratch);
+	uint8_t* p = scratch + ((sizeof(SwLaneState) + 15) & ~(size_t)15);
 	SwMats m;
-	m.nrow = nrow; m.ncol = ncol;
-	m.H = scratch; m.E = scratch + cs; m.F = scratch + 2 * cs;
-	m.M = reinterpret_cast<uint16_t*>(scratch + 3 * cs);
-	m.rf = scratch + 5 * cs;
-	uint8_t* p = scratch + 5 * cs + ((ncol + 15) & ~15u);
-	SwFrame* stack = reinterpret_cast<SwFrame*>(p);
-	p += sizeof(SwFrame) * H2G_SW_STACK;
-	uint16_t* cells = reinterpret_cast<uint16_t*>(p);
-	p += 4 * H2G_SW_CELLS;
-	p = reinterpret_cast<uint8_t*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
-	SwOut* o = reinterpret_cast<SwOut*>(p);
+	m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 0;
+	m.H = p; m.E = p + cs; m.F = p + 2 * cs; m.rf = p + 3 * cs;
 	RefCursor rc;
 	rc.init(&ref, tidx);
 	for(uint32_t j = 0; j < ncol; j++) m.rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
 	sw_fill<false>(m, P, sv, 0, 1);
-	o->refl = rect.refl; o->refr = rect.refr;
-	sw_gather_backtrace(m, P, sv, rect, minsc, (int)((double)P.nceil_pct * 0.01 * (double)nrow), rnd, stack, cells, o);
-	o->rnd = *rnd;
-	*out = o;
+	*out = sw_finish(m, P, sv, rect, minsc, rnd, ls);
 }
 
 }  // namespace h2g

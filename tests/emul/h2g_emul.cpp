@@ -103,29 +103,35 @@ void h2gemu_fm_search(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, h
 }
 
 void h2gemu_sw_align(Emu* e, const h2g_sw_query* q, size_t n, h2g_sw_result* out) {
+	// both matrix layouts through the same gather/backtrace: odd problems use the anti-diagonal-major layout of the
+	// wavefront kernel (filled here cell by cell), even ones the row-major layout of the in-go() path
 	DReads rd = e->reads();
 	SwParams P;
-	std::vector<SwFrame> stack(H2G_SW_STACK);
-	std::vector<uint16_t> cells(2 * H2G_SW_CELLS);
+	std::vector<uint8_t> scratch(sw_scratch_bytes(H2G_SW_MAX_ROWS));
+	SwLaneState* ls = new SwLaneState();
+	memset(ls, 0, sizeof *ls);
 	for(size_t p = 0; p < n; p++) {
 		SeqView sv = seq_view(rd, q[p].read, q[p].fw != 0);
-		const uint32_t nrow = sv.len;
-		const SwRect rect = sw_frame(q[p].refoff, nrow, e->dr.refLens[q[p].tidx]);
-		const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
-		std::vector<uint8_t> H((size_t)nrow * ncol), E(H.size()), F(H.size()), rf(ncol);
-		std::vector<uint16_t> M(H.size());
-		SwMats m;
-		m.nrow = nrow; m.ncol = ncol; m.H = H.data(); m.E = E.data(); m.F = F.data(); m.M = M.data(); m.rf = rf.data();
-		RefCursor rc;
-		rc.init(&e->dr, q[p].tidx);
-		for(uint32_t j = 0; j < ncol; j++) rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
-		sw_fill<false>(m, P, sv, 0, 1);
-		SwOut* o = reinterpret_cast<SwOut*>(&out[p]);
 		uint32_t rnd = q[p].rnd;
-		o->refl = rect.refl; o->refr = rect.refr;
-		sw_gather_backtrace(m, P, sv, rect, q[p].minsc, (int)((double)P.nceil_pct * 0.01 * (double)nrow), &rnd, stack.data(), cells.data(), o);
-		o->rnd = rnd;
+		SwOut* o = nullptr;
+		if((p & 1) == 0) sw_align_single(e->dr, P, sv, q[p].tidx, q[p].refoff, q[p].minsc, &rnd, scratch.data(), &o);
+		else {
+			const uint32_t nrow = sv.len;
+			const SwRect rect = sw_frame(q[p].refoff, nrow, e->dr.refLens[q[p].tidx]);
+			const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
+			SwMats m;
+			m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1;
+			std::vector<uint8_t> H(m.bytes()), E(H.size()), F(H.size()), rf(ncol);
+			m.H = H.data(); m.E = E.data(); m.F = F.data(); m.rf = rf.data();
+			RefCursor rc;
+			rc.init(&e->dr, q[p].tidx);
+			for(uint32_t j = 0; j < ncol; j++) rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
+			sw_fill<false>(m, P, sv, 0, 1);
+			o = sw_finish(m, P, sv, rect, q[p].minsc, &rnd, ls);
+		}
+		memcpy(&out[p], o, sizeof(SwOut));
 	}
+	delete ls;
 }
 
 void h2gemu_sa_resolve(Emu* e, const h2g_sa_query* q, size_t n, uint32_t cap, h2g_coord* coords, h2g_sa_result* res) {

@@ -298,7 +298,8 @@ def test_sw_align_vs_oracle_random(oracle_lib, g1_index, golden_dir):
         r, t = synth.make_reads(contigs, 400, L, 1000 + L, sub_rate=0.02, indel_rate=0.01, n_rate=0.002)
         reads += [x for x in r]
         truth += [tuple(int(v) for v in x) for x in t]
-    codes, offs = synth.flatten_reads(reads)
+    codes = np.concatenate(reads).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint32)
     ix = api.Index(g1_index, device=0)
     st = api.Stream(ix, max_reads=len(reads), max_bases=codes.size)
     st.set_reads(codes, offs)
