@@ -238,8 +238,7 @@ def main():
             micro_g[name] = {"ms": ms, "GB/s": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "checksum": int(ck)}
         gst.close()
         gix.close()
-        # Smith-Waterman kernel (a23-a25, opt-in path of the reference): one wavefront per DP problem, 101 x 141 cells x {H,E,F}
-        # in LDS; problems = the first 65536 bench reads framed around their true position, as hybridSearch frames a seed hit
+        # Smith-Waterman kernels (a23-a25, opt-in path of the reference): 101 x 141 cells x {H,E,F} per problem; problems = the first 65536 bench reads framed around their true position, as hybridSearch frames a seed hit
         nsw = min(65536, a.reads)
         swq = [api.SwQuery(i, int(truth[i][2]), int(truth[i][0]), int(truth[i][1]), -20, i + 1) for i in range(nsw)]
         st.sw_align(swq[:1024])
@@ -248,7 +247,7 @@ def main():
         sw_cells = sum(101 * int(r.refr - r.refl + 1) for r in swres)
         sw_micro = {"problems": nsw, "kernel_ms": sw_ms, "problems_per_s": nsw / (sw_ms * 1e-3), "GCUPS": sw_cells / (sw_ms * 1e-3) / 1e9,
                     "found": sw_found, "cells_per_problem": sw_cells / nsw,
-                    "note": "integer u8 DP, LDS-resident (71 KB/problem => 2 wavefronts per CU); bound by LDS issue + the sequential backtrace, not HBM"}
+                    "note": "k_sw_fill: register-systolic wavefront per problem (one __shfl_up per anti-diagonal step), H/E/F streamed to HBM anti-diagonal-major (92.5 KB/problem, coalesced 64 B stores); k_sw_backtrace: one lane per problem"}
         nver = 2000
         verify_sample(base, reads, got, nver)          # seed stage vs oracle/h2o.c
         cpu_ref, ref_sam = (None, None)

@@ -13,7 +13,7 @@ from hisat2_amd import api, synth  # noqa: E402
 nreads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 26
 base, contigs = bench.build_index(os.path.join(ROOT, ".bench_cache"), 4_900_000)
-reads, _ = synth.make_reads(contigs, nreads, 101, bench.SEED + 1000, sub_rate=0.005)
+reads, truth = synth.make_reads(contigs, nreads, 101, bench.SEED + 1000, sub_rate=0.005)
 codes, offs = synth.flatten_reads(reads)
 ix = api.Index(base)
 st = api.Stream(ix, max_reads=nreads, max_bases=codes.size)
@@ -34,3 +34,27 @@ rst = api.Stream(rix)
 for v in (0, 1, 2):
     ms, ck = rst.rank_synth(nq, bench.SEED, variant=v, repeats=1)
     print("rank variant %d: %.3f ms  %.1f GB/s" % (v, ms, nq * 64 / ms / 1e6))
+rst.close(); rix.close()
+gix = api.Index(synth_sides=7_650_000, seed=bench.SEED, graph=True)
+gst = api.Stream(gix)
+for v in (0, 1):
+    ms, ck = gst.rank_synth(nq, bench.SEED, variant=v, repeats=1)
+    print("graph rank variant %d: %.3f ms  %.1f GB/s" % (v, ms, nq * 128 / ms / 1e6))
+gst.close(); gix.close()
+# Smith-Waterman: 65536 problems framed around the true positions
+nsw = min(65536, nreads)
+swq = [api.SwQuery(i, int(truth[i][2]), int(truth[i][0]), int(truth[i][1]), -20, i + 1) for i in range(nsw)]
+res, ms = st.sw_align(swq, repeats=2)
+print("sw: %d problems %.3f ms (fill + backtrace kernels), found %d" % (nsw, ms, sum(1 for r in res if r.found)))
+# paired-end go()
+npairs = nreads // 2
+m1, m2 = synth.make_pairs(contigs, npairs, 101, bench.SEED + 77, sub_rate=0.005)
+c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
+qn = [str(i) for i in range(npairs)]
+pst = api.Stream(ix, max_reads=npairs, max_bases=c1.size)
+pst.set_reads(c1, o1); pst.set_read_names(qn); pst.set_mates(c2, o2, qn)
+for _ in range(2):
+    pst.align_pairs_run()
+pst.sync()
+pc = pst.counters()
+print("pairs: %.3f ms for %d pairs, concordant %d" % (pc.ms_align, npairs, pc.n_aligned))
