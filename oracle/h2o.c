@@ -1124,3 +1124,306 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 	free(rf); free(H); free(E); free(F); free(M);
 	return o->found;
 }
+
+/* ------------------------------------------------------------------ graph SA walk (a14 on a graph index) */
+/* getGenomeCoords hi_aligner.h:5774-5855 on a GRAPH index: GroupWalk2S::init/advanceElement (group_walk.h:1430-1545)
+ * driving GWState::init (:464-885) and GWState::advance (:1035-1336).  Elements are NODES of [node_top, node_bot); a
+ * range is walked left as a group, split by preceding character (mapLFRange masks, gfm.h:3636) and at '$' rows, and
+ * merged when several rows lead into one node — the merged-away duplicates are "resolved" with their own element index
+ * as the offset (group_walk.h:1171, 1246), which is reproduced here because it reaches the alignment through
+ * joinedToTextOff.  tryOffset (gfm.h:2719) samples by NODE: (node & offMask) == node -> offs[node >> offRate]. */
+#define GW_MAXELT 64
+#define GW_MAXST 96
+#define GW_MAXIE 64
+typedef struct { uint32_t first, second; } gw_pair;
+typedef struct {
+	uint32_t top, bot, node_top, node_bot, step, mapi, nmap, nie;
+	uint32_t map[GW_MAXELT];
+	gw_pair ie[GW_MAXIE];
+} gw_state;
+typedef struct {
+	const h2o_gfm* g;
+	uint32_t topf, botf, sa_node_top, nelt;
+	uint32_t offs[GW_MAXELT];
+	gw_pair fmap[GW_MAXELT];
+	gw_state st[GW_MAXST];
+	uint32_t nst;
+	uint32_t nsteps;
+	int overflow;
+} gw_ctx;
+
+static uint32_t gw_try_offset(const h2o_gfm* g, uint32_t row, uint32_t node) {
+	for(uint32_t i = 0; i < g->nZ; i++) if(row == g->zOffs[i]) return 0;
+	if((node & g->p.offMask) == node) return g->offs[node >> g->p.offRate];
+	return H2O_MAX;
+}
+/* mapGLF1(row, l, &node_range) without a required character (gfm.h:4029-4095) */
+static void gw_map_glf1_nochar(const h2o_gfm* g, uint32_t row, uint32_t* otop, uint32_t* obot, uint32_t* ontop, uint32_t* onbot) {
+	for(uint32_t i = 0; i < g->nZ; i++) if(row == g->zOffs[i]) { *otop = *obot = H2O_MAX; *ontop = *onbot = 0; return; }
+	const int c = h2o_rowL(g, row);
+	uint32_t t = h2o_rank(g, row, c);
+	if(g->p.linear) { *otop = *ontop = t; *obot = *onbot = t + 1; return; }
+	uint32_t node_top = h2o_rank_M(g, t + 1) - 1, F_loc, M_occ;
+	uint32_t ft = node_to_Frow(g, t + 1, node_top, &F_loc, &M_occ);
+	uint32_t node_bot = node_top + 1;
+	uint32_t fb = (node_bot + 1 > M_occ) ? h2o_select_F(g, F_loc, node_bot + 1 - M_occ) : F_loc;
+	*otop = ft; *obot = fb; *ontop = node_top; *onbot = node_bot;
+}
+static void gw_init(gw_ctx* x, uint32_t range);
+static gw_state* gw_new_state(gw_ctx* x) {
+	if(x->nst >= GW_MAXST) { x->overflow = 1; return &x->st[GW_MAXST - 1]; }
+	gw_state* s = &x->st[x->nst++];
+	memset(s, 0, sizeof *s);
+	return s;
+}
+/* GWState::init (group_walk.h:506-885); top/bot/node range/iedges/step/map already set */
+static void gw_init(gw_ctx* x, uint32_t range) {
+	const h2o_gfm* g = x->g;
+	gw_state* s = &x->st[range];
+	uint32_t trimBegin = 0, trimEnd = 0;
+	int empty = 1;
+	uint32_t num_iedges = 0, e = 0;
+	for(uint32_t i = s->mapi; i < s->nmap; i++) {
+		int resolved = x->offs[s->map[i]] != H2O_MAX;
+		if(!resolved) {
+			while(e < s->nie) {
+				if(i <= s->ie[e].first) break;
+				num_iedges += s->ie[e].second;
+				e++;
+			}
+			uint32_t bwrow = s->top + i + num_iedges, node = s->node_top + i;
+			uint32_t toff = gw_try_offset(g, bwrow, node);
+			if(toff != H2O_MAX) {
+				toff += s->step;
+				x->offs[s->map[i + s->mapi]] = toff;        /* setOff(i, ...) indexes map_[i + mapi_] (:1013) */
+			}
+		}
+		if(x->offs[s->map[i]] != H2O_MAX) {
+			if(empty) trimBegin++; else trimEnd++;
+		} else {
+			trimEnd = 0;
+			empty = 0;
+			x->fmap[s->map[i]].first = range;
+			x->fmap[s->map[i]].second = i;
+		}
+	}
+	s->mapi += trimBegin;
+	if(trimBegin > 0) {
+		s->top += trimBegin;
+		uint32_t k = 0;
+		for(; k < s->nie; k++) {
+			if(s->ie[k].first >= trimBegin) break;
+			s->top += s->ie[k].second;
+		}
+		if(k > 0) { memmove(s->ie, s->ie + k, sizeof(gw_pair) * (s->nie - k)); s->nie -= k; }
+		for(k = 0; k < s->nie; k++) s->ie[k].first -= trimBegin;
+	}
+	s->node_top += trimBegin;
+	if(trimEnd > 0) {
+		s->nmap -= trimEnd;
+		s->bot -= trimEnd;
+		uint32_t node_range = s->node_bot - s->node_top;
+		while(s->nie > 0) {
+			if(s->ie[s->nie - 1].first < (node_range - trimEnd)) break;
+			s->bot -= s->ie[s->nie - 1].second;
+			s->nie--;
+		}
+	}
+	s->node_bot -= trimEnd;
+	if(empty) return;
+	/* '$' rows strictly inside (top, bot): split (:741-868) */
+	uint32_t zin[8], nz = 0;
+	for(uint32_t i = 0; i < g->nZ; i++) if(g->zOffs[i] > s->top && g->zOffs[i] < s->bot && nz < 8) zin[nz++] = g->zOffs[i];
+	if(nz > 0) {
+		uint32_t g2n[GW_MAXELT * 4], ng = 0;
+		uint32_t n = 0, ee = 0;
+		for(uint32_t r = 0; r < s->bot - s->top; r++) {
+			if(ng < GW_MAXELT * 4) g2n[ng++] = n; else x->overflow = 1;
+			if(ee < s->nie) {
+				if(n == s->ie[ee].first) {
+					for(uint32_t a = 0; a < s->ie[ee].second; a++) { if(ng < GW_MAXELT * 4) g2n[ng++] = n; else x->overflow = 1; r++; }
+					ee++;
+				}
+			}
+			n++;
+		}
+		for(uint32_t i = 0; i < nz; i++) {
+			s = &x->st[range];
+			uint32_t new_top = zin[i] + 1;
+			if(i + 1 < nz && new_top == zin[i + 1]) continue;
+			if(new_top - s->top == ng) break;
+			uint32_t new_node_top = g2n[new_top - s->top] + s->node_top;
+			uint32_t new_bot = (i + 1 < nz) ? zin[i + 1] : s->bot;
+			uint32_t new_node_bot = s->node_bot;
+			if(new_bot - s->top < ng) {
+				new_node_bot = s->node_top + g2n[new_bot - s->top];
+				if(new_bot - s->top > 0 && g2n[new_bot - s->top] == g2n[new_bot - s->top - 1]) new_node_bot++;
+			}
+			if(new_top >= new_bot) continue;
+			gw_pair tie[GW_MAXIE]; uint32_t ntie = 0;
+			for(uint32_t j = new_top - s->top; j + 1 < new_bot - s->top;) {
+				uint32_t nn = g2n[j], j2 = j + 1;
+				while(j2 < new_bot - s->top) { if(nn != g2n[j2]) break; j2++; }
+				if(j + 1 < j2 && ntie < GW_MAXIE) { tie[ntie].first = nn - (new_node_top - s->node_top); tie[ntie].second = j2 - j - 1; ntie++; }
+				j = j2;
+			}
+			gw_state* ns = gw_new_state(x);
+			s = &x->st[range];
+			ns->nmap = new_node_bot - new_node_top; ns->mapi = 0;
+			for(uint32_t j = new_node_top; j < new_node_bot; j++) ns->map[j - new_node_top] = s->map[j - s->node_top + s->mapi];
+			ns->top = new_top; ns->bot = new_bot; ns->node_top = new_node_top; ns->node_bot = new_node_bot;
+			ns->nie = ntie; memcpy(ns->ie, tie, sizeof(gw_pair) * ntie);
+			ns->step = s->step;
+			gw_init(x, x->nst - 1);
+		}
+		s = &x->st[range];
+		s->bot = zin[0];
+		s->node_bot = g2n[s->bot - s->top - 1] + s->node_top + 1;
+		s->nmap = s->node_bot - s->node_top + s->mapi;
+		uint32_t width = s->node_bot - s->node_top;
+		for(uint32_t k = 0; k < s->nie; k++) {
+			if(s->ie[k].first >= s->node_bot - s->node_top) { s->nie = k; break; }
+			width += s->ie[k].second;
+		}
+		if(width != s->bot - s->top) {
+			s->ie[s->nie - 1].second -= 1;
+			if(s->ie[s->nie - 1].second == 0) s->nie--;
+		}
+	}
+}
+/* narrow a freshly mapped (node-merged) element list: group_walk.h:1143-1185 / :1218-1262 */
+static void gw_merge_dups(gw_ctx* x, uint32_t curtop, const uint8_t* mask, uint32_t nmask, int c, uint32_t* map, uint32_t* nmap) {
+	const h2o_gfm* g = x->g;
+	uint32_t j1 = 0, j2 = 0;
+	for(uint32_t k = 0; k < nmask; k++) if(mask[k]) { j1 = k; break; }
+	for(uint32_t j = 0; j + 1 < *nmap; j++) {
+		for(uint32_t k = j1 + 1; k < nmask; k++) if(mask[k]) { j2 = k; break; }
+		uint32_t t, b, nt, nb, nie = 0;
+		h2o_map_glf(g, curtop + j1, curtop + j2 + 1, c, 5, &t, &b, &nt, &nb, NULL, 0, &nie);
+		if(nb - nt == 1) { x->offs[map[j]] = map[j]; map[j] = H2O_MAX; }
+		j1 = j2; j2 = 0;
+	}
+	uint32_t w = 0;
+	for(uint32_t j = 0; j < *nmap; j++) if(map[j] != H2O_MAX) map[w++] = map[j];
+	*nmap = w;
+}
+/* GWState::advance (group_walk.h:1035-1336) */
+static void gw_advance(gw_ctx* x, uint32_t range) {
+	const h2o_gfm* g = x->g;
+	gw_state* s = &x->st[range];
+	x->nsteps++;
+	if(s->bot - s->top > 1) {
+		int first = 1;
+		uint32_t newtop = 0, newbot = 0, new_node_top = 0, new_node_bot = 0;
+		uint32_t gmap[GW_MAXELT], ngmap = 0;
+		gw_pair backup[GW_MAXIE]; uint32_t nbackup = 0;
+		uint32_t curtop = s->top, curbot = s->bot, cur_node_top = s->node_top, cur_node_bot = s->node_bot;
+		for(uint32_t e = 0; e < s->nie + 1; e++) {
+			s = &x->st[range];
+			if(e >= s->nie) {
+				if(e > 0) {
+					curtop = curbot + s->ie[e - 1].second;
+					curbot = s->bot;
+					if(curtop >= curbot) break;
+					cur_node_top = cur_node_bot;
+					cur_node_bot = s->node_bot;
+				}
+			} else {
+				if(e > 0) {
+					curtop = curbot + s->ie[e - 1].second;
+					curbot = curtop + (s->ie[e].first - s->ie[e - 1].first);
+					cur_node_top = cur_node_bot;
+				} else curbot = curtop + s->ie[e].first + 1;
+				cur_node_bot = s->node_top + s->ie[e].first + 1;
+			}
+			uint32_t n = curbot - curtop, in[4] = {0, 0, 0, 0};
+			uint8_t mask[4][GW_MAXELT * 2];
+			if(n > GW_MAXELT * 2) { x->overflow = 1; n = GW_MAXELT * 2; }
+			memset(mask, 0, sizeof mask);
+			for(uint32_t k = 0; k < n; k++) { int c = h2o_rowL(g, curtop + k); mask[c][k] = 1; in[c]++; }   /* mapLFRange */
+			for(int c = 0; c < 4; c++) {
+				if(in[c] == 0) continue;
+				s = &x->st[range];
+				uint32_t t, b, nt, nb;
+				gw_pair tie[GW_MAXIE]; uint32_t ntie = 0, tmpie[2 * GW_MAXIE];
+				h2o_map_glf(g, curtop, curbot, c, cur_node_bot - cur_node_top, &t, &b, &nt, &nb, tmpie, GW_MAXIE, &ntie);
+				if(ntie > GW_MAXIE) { ntie = GW_MAXIE; x->overflow = 1; }
+				for(uint32_t k = 0; k < ntie; k++) { tie[k].first = tmpie[2 * k]; tie[k].second = tmpie[2 * k + 1]; }
+				if(first) {
+					first = 0;
+					newtop = t; newbot = b; new_node_top = nt; new_node_bot = nb;
+					nbackup = ntie; memcpy(backup, tie, sizeof(gw_pair) * ntie);
+					for(uint32_t j = 0; j < n; j++) if(mask[c][j]) gmap[ngmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)];
+					if(new_node_bot - new_node_top < ngmap) gw_merge_dups(x, curtop, mask[c], n, c, gmap, &ngmap);
+				} else {
+					gw_state* ns = gw_new_state(x);
+					s = &x->st[range];
+					ns->mapi = 0; ns->nmap = 0;
+					for(uint32_t j = 0; j < n; j++) if(mask[c][j]) ns->map[ns->nmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)];
+					if(nb - nt < ns->nmap) gw_merge_dups(x, curtop, mask[c], n, c, ns->map, &ns->nmap);
+					ns->top = t; ns->bot = b; ns->node_top = nt; ns->node_bot = nb;
+					ns->nie = ntie; memcpy(ns->ie, tie, sizeof(gw_pair) * ntie);
+					ns->step = s->step + 1;
+					gw_init(x, x->nst - 1);
+				}
+			}
+		}
+		s = &x->st[range];
+		s->mapi = 0;
+		s->top = newtop; s->bot = newbot; s->node_top = new_node_top; s->node_bot = new_node_bot;
+		s->nie = nbackup; memcpy(s->ie, backup, sizeof(gw_pair) * nbackup);
+		if(ngmap > 0) { memcpy(s->map, gmap, 4 * ngmap); s->nmap = ngmap; }
+	} else {
+		uint32_t t, b, nt, nb;
+		gw_map_glf1_nochar(g, s->top, &t, &b, &nt, &nb);
+		s->top = t; s->bot = t + 1; s->node_top = nt; s->node_bot = nb;
+		if(s->mapi > 0) { s->map[0] = s->map[s->mapi]; s->mapi = 0; }
+		s->nmap = 1;
+		(void)b;
+	}
+	s->step++;
+	gw_init(x, range);
+}
+
+int h2o_genome_coords_graph(const h2o_index* ix, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot,
+                            const uint32_t* iedges, uint32_t niedges, uint32_t maxelt, uint32_t rdlen, int rejectStraddle,
+                            h2o_coord* coords, uint32_t* ncoords, int* straddled, uint32_t* nsteps)
+{
+	static gw_ctx ctx;                                      /* ~60 KB; the oracle is single-threaded test code */
+	gw_ctx* x = &ctx;
+	const h2o_gfm* g = &ix->g;
+	*straddled = 0;
+	uint32_t nelt = node_bot - node_top;
+	if(nelt > maxelt) nelt = maxelt;
+	if(nelt > GW_MAXELT) return -1;
+	x->g = g; x->topf = top; x->botf = bot; x->sa_node_top = node_top; x->nelt = nelt; x->nst = 0; x->nsteps = 0; x->overflow = 0;
+	for(uint32_t i = 0; i < nelt; i++) { x->offs[i] = H2O_MAX; x->fmap[i].first = x->fmap[i].second = H2O_MAX; }
+	gw_state* s = gw_new_state(x);                          /* GroupWalk2S::init :1430-1470 */
+	s->nmap = nelt; s->mapi = 0;
+	for(uint32_t i = 0; i < nelt; i++) s->map[i] = i;
+	s->top = top; s->bot = bot; s->node_top = node_top; s->node_bot = node_top + nelt;
+	s->nie = niedges < GW_MAXIE ? niedges : GW_MAXIE;
+	for(uint32_t k = 0; k < s->nie; k++) { s->ie[k].first = iedges[2 * k]; s->ie[k].second = iedges[2 * k + 1]; }
+	s->step = 0;
+	gw_init(x, 0);
+	uint32_t n = *ncoords;
+	for(uint32_t elt = 0; elt < nelt; elt++) {
+		uint32_t guard = 0;
+		while(x->offs[elt] == H2O_MAX) {                     /* advanceElement :1491-1545 */
+			gw_advance(x, x->fmap[elt].first);
+			if(++guard > 100000 || x->overflow) return -1;
+		}
+		uint32_t tidx = 0, toff = 0, tlen = 0;
+		int st2 = 0;
+		h2o_joined_to_text(g, rdlen, x->offs[elt], &tidx, &toff, &tlen, rejectStraddle, &st2);
+		*straddled |= st2;
+		if(tidx == H2O_MAX) { *ncoords = n; if(nsteps) *nsteps += x->nsteps; return 0; }
+		coords[n].tidx = st2 ? H2O_MAX : tidx;
+		coords[n].toff = toff;
+		coords[n].joinedOff = x->offs[elt];
+		n++;
+	}
+	*ncoords = n;
+	if(nsteps) *nsteps += x->nsteps;
+	return 1;
+}

@@ -129,6 +129,10 @@ int h2o_map_glf1(const h2o_gfm*, uint32_t row, int c, uint32_t* otop, uint32_t* 
 /* getGenomeCoords hi_aligner.h:5774 (linear index): coords for rows [top, top+nelt) */
 int  h2o_genome_coords(const h2o_index*, uint32_t top, uint32_t bot, uint32_t maxelt, uint32_t rdlen,
                        int rejectStraddle, h2o_coord* coords, uint32_t* ncoords, int* straddled, uint32_t* nsteps);
+/* getGenomeCoords on a GRAPH index: the group walk over NODES (group_walk.h:464-1545); iedges = BWTHit::_node_iedge_count */
+int  h2o_genome_coords_graph(const h2o_index*, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot,
+                             const uint32_t* iedges, uint32_t niedges, uint32_t maxelt, uint32_t rdlen, int rejectStraddle,
+                             h2o_coord* coords, uint32_t* ncoords, int* straddled, uint32_t* nsteps);
 /* GenomeHit::extend hi_aligner.h:2031 (+alignWithALTs :683, _recur :2763 without ALTs,
  * calculateScore :3711).  seq/qual in the hit's orientation. */
 int  h2o_extend(const h2o_index*, const h2o_scoring*, const uint8_t* seq, const char* qual, uint32_t rdlen,

@@ -315,6 +315,10 @@ int main(int argc, char** argv) {
 					for(size_t k = 0; k < coords.size(); k++)
 						printf(" %lld:%lld:%llu", (long long)(int32_t)coords[k].ref(), (long long)coords[k].off(),
 						       (unsigned long long)coords[k].joinedOff());
+					if(!linear) {   // graph index: the node range and in-edge list getGenomeCoords was called with
+						printf(" | %u %u %u", ph._node_top, ph._node_bot, (unsigned)ph._node_iedge_count.size());
+						for(size_t e = 0; e < ph._node_iedge_count.size(); e++) printf(" %u:%u", ph._node_iedge_count[e].first, ph._node_iedge_count[e].second);
+					}
 					putchar('\n');
 					continue;
 				}

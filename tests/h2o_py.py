@@ -109,6 +109,9 @@ def load():
     lib.h2o_map_glf.restype = C.c_int
     lib.h2o_map_glf1.argtypes = [P(Gfm), u32, C.c_int] + [P(u32)] * 4
     lib.h2o_map_glf1.restype = C.c_int
+    lib.h2o_genome_coords_graph.argtypes = [P(Index), u32, u32, u32, u32, P(u32), u32, u32, u32, C.c_int, P(Coord), P(u32),
+                                            P(C.c_int), P(u32)]
+    lib.h2o_genome_coords_graph.restype = C.c_int
     lib.h2o_genome_coords.argtypes = [P(Index), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, P(Coord),
                                       P(C.c_uint32), P(C.c_int), P(C.c_uint32)]
     lib.h2o_genome_coords.restype = C.c_int

@@ -258,3 +258,18 @@ def check_sw(be, golden_dir, rdlen=101):
             nfound += 1
     assert nfound > 100
     return len(cases)
+
+
+def parse_graph_coords(golden_dir, fn):
+    """-> [(top, bot, node_top, node_bot, iedges, hitlen, straddled, [(tidx, toff, joinedOff)])]"""
+    out = []
+    for l in H.glines(golden_dir, fn):
+        lhs, rhs = l.split(" | ")
+        f, r = lhs.split(), rhs.split()
+        top, bot, rdoff, hlen, strad, nco = map(int, f[2:8])
+        want = [tuple(int(x) & 0xFFFFFFFF for x in c.split(":")) for c in f[8:8 + nco]]
+        nt, nb, nie = map(int, r[:3])
+        ie = [tuple(map(int, x.split(":"))) for x in r[3:]]
+        assert len(ie) == nie
+        out.append((top, bot, nt, nb, ie, hlen, strad, want))
+    return out

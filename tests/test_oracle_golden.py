@@ -4,6 +4,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 
 import h2o_py as H
 
@@ -256,3 +257,24 @@ def test_sw_align_matches_reference_swaligner(oracle_lib, g1_index, golden_dir):
             nfound += 1
             ngap += any(e.split(":")[2] in ("1", "2") for e in d["edits"])
     assert len(cases) > 250 and nfound > 100 and ngap > 50
+
+
+@pytest.mark.parametrize("fn", ["probe_g1s_coords.txt.gz", "probe_g1s_coords_short.txt.gz"])
+def test_graph_genome_coords(oracle_lib, g1s_index, golden_dir, fn):
+    """the node-based group walk (GWState on a graph index) incl. ref/alt duplicate nodes and in-edge lists"""
+    import parity_cases as PC
+    ix = H.load_index(oracle_lib, g1s_index)
+    u32 = C.c_uint32
+    nmulti = 0
+    for top, bot, nt, nb, ie, hlen, strad, want in PC.parse_graph_coords(golden_dir, fn):
+        buf = (u32 * (2 * max(1, len(ie))))()
+        for k, (a, b) in enumerate(ie):
+            buf[2 * k], buf[2 * k + 1] = a, b
+        co = (H.Coord * 64)()
+        nc, st, steps = u32(0), C.c_int(0), u32(0)
+        rc = oracle_lib.h2o_genome_coords_graph(ix, top, bot, nt, nb, buf, len(ie), bot - top, hlen, 0, co, C.byref(nc), C.byref(st),
+                                                C.byref(steps))
+        assert rc == 1 and st.value == strad
+        assert [(co[k].tidx, co[k].toff, co[k].joinedOff) for k in range(nc.value)] == want, (top, bot)
+        nmulti += len(want) > 1
+    assert nmulti >= (100 if "short" in fn else 4)
