@@ -325,4 +325,306 @@ H2G_HD void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32_
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------ graph SA walk (a14)
+// getGenomeCoords (hi_aligner.h:5774-5855) on a graph index = GroupWalk2S::init/advanceElement (group_walk.h:1430-1545)
+// driving GWState::init (:464-885) and GWState::advance (:1035-1336).  Elements are the NODES of [node_top, node_bot);
+// a range is walked left as a group, split by preceding character (mapLFRange masks, gfm.h:3636) and at '$' rows, and
+// merged when several rows lead into one node — merged-away duplicates get their own element index as the "offset"
+// (group_walk.h:1171, :1246), reproduced because that value reaches joinedToTextOff.  tryOffset (gfm.h:2719) samples by
+// node: (node & offMask) == node -> offs[node >> offRate].  Fixed capacities; exceeding one sets GwCtx::overflow.
+#define H2G_GW_MAXELT 24          // >= kseeds (20 on graph indexes)
+#define H2G_GW_MAXST 40
+#define H2G_GW_MAXROWS 64         // rows of one sub-range handed to mapLFRange
+struct GwPair { uint32_t first, second; };
+struct GwState {
+	uint32_t top, bot, node_top, node_bot, step, mapi, nmap, nie;
+	uint32_t map[H2G_GW_MAXELT];
+	GwPair   ie[H2G_GW_MAXELT];
+};
+struct GwCtx {
+	uint32_t nelt, nst, nsteps, overflow;
+	uint32_t offs[H2G_GW_MAXELT];
+	uint32_t fmap[H2G_GW_MAXELT];       // GWHit::fmap[elt].first (the range currently holding the element)
+	GwState  st[H2G_GW_MAXST];
+};
+
+H2G_HD int rowL128(const DGfm& g, uint32_t row) {
+	const uint32_t s0 = row / H2G_GSIDE_SYMS, c0 = row - s0 * H2G_GSIDE_SYMS;
+	const uint32_t w = reinterpret_cast<const uint32_t*>(g.sides + (size_t)s0 * 128)[c0 >> 4];
+	return (int)((w >> ((c0 & 15) * 2)) & 3);
+}
+H2G_HD uint32_t gw_try_offset(const DGfm& g, uint32_t row, uint32_t node) {
+	if(is_zoff(g, row)) return 0;
+	if((node & g.offMask) == node) return g.offs[node >> g.offRate];
+	return H2G_MAX;
+}
+// mapGLF1(row, l, &node_range) — no required character (gfm.h:4029-4095)
+H2G_HD void map_glf1_nochar(const DGfm& g, uint32_t row, GRange* r) {
+	if(is_zoff(g, row)) { r->top = r->bot = H2G_MAX; r->node_top = r->node_bot = 0; return; }
+	const uint32_t s0 = row / H2G_GSIDE_SYMS, c0 = row - s0 * H2G_GSIDE_SYMS;
+	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
+	const int c = rowL_in_side128(sd, c0);
+	const uint32_t t = rank_in_side128(g, sd, s0, c0, c);
+	const uint32_t node_top = rank_M(g, t + 1) - 1;
+	uint32_t F_loc, M_occ;
+	const uint32_t ft = node_to_Frow(g, t + 1, node_top, &F_loc, &M_occ);
+	const uint32_t node_bot = node_top + 1;
+	const uint32_t fb = (node_bot + 1 > M_occ) ? select_F(g, F_loc, node_bot + 1 - M_occ) : F_loc;
+	r->top = ft; r->bot = fb; r->node_top = node_top; r->node_bot = node_bot;
+}
+H2G_HD GwState* gw_new_state(GwCtx* x) {
+	if(x->nst >= H2G_GW_MAXST) { x->overflow = 1; return &x->st[H2G_GW_MAXST - 1]; }
+	GwState* s = &x->st[x->nst++];
+	s->top = s->bot = s->node_top = s->node_bot = s->step = s->mapi = s->nmap = s->nie = 0;
+	return s;
+}
+// GWState::init (group_walk.h:506-885).  The '$'-split creates new states and initialises them; those never split again
+// at the same step deeper than the number of '$' rows, so the recursion of the reference is a bounded loop here.
+H2G_HD void gw_init(const DGfm& g, GwCtx* x, uint32_t range0) {
+	uint32_t pending[H2G_GW_MAXST];
+	uint32_t npend = 0;
+	pending[npend++] = range0;
+	while(npend > 0) {
+		const uint32_t range = pending[--npend];
+		GwState* s = &x->st[range];
+		uint32_t trimBegin = 0, trimEnd = 0, num_iedges = 0, e = 0;
+		bool empty = true;
+		for(uint32_t i = s->mapi; i < s->nmap; i++) {
+			if(x->offs[s->map[i]] == H2G_MAX) {
+				while(e < s->nie) {
+					if(i <= s->ie[e].first) break;
+					num_iedges += s->ie[e].second;
+					e++;
+				}
+				uint32_t toff = gw_try_offset(g, s->top + i + num_iedges, s->node_top + i);
+				if(toff != H2G_MAX) {
+					const uint32_t k = i + s->mapi;            // setOff indexes map_[i + mapi_] (:1013); mapi_ is 0 here
+					if(k < s->nmap) x->offs[s->map[k]] = toff + s->step;
+				}
+			}
+			if(x->offs[s->map[i]] != H2G_MAX) { if(empty) trimBegin++; else trimEnd++; }
+			else { trimEnd = 0; empty = false; x->fmap[s->map[i]] = range; }
+		}
+		s->mapi += trimBegin;
+		if(trimBegin > 0) {
+			s->top += trimBegin;
+			uint32_t k = 0;
+			for(; k < s->nie; k++) {
+				if(s->ie[k].first >= trimBegin) break;
+				s->top += s->ie[k].second;
+			}
+			if(k > 0) { for(uint32_t q = k; q < s->nie; q++) s->ie[q - k] = s->ie[q]; s->nie -= k; }
+			for(k = 0; k < s->nie; k++) s->ie[k].first -= trimBegin;
+		}
+		s->node_top += trimBegin;
+		if(trimEnd > 0) {
+			s->nmap -= trimEnd;
+			s->bot -= trimEnd;
+			const uint32_t node_range = s->node_bot - s->node_top;
+			while(s->nie > 0) {
+				if(s->ie[s->nie - 1].first < (node_range - trimEnd)) break;
+				s->bot -= s->ie[s->nie - 1].second;
+				s->nie--;
+			}
+		}
+		s->node_bot -= trimEnd;
+		if(empty) continue;
+		// '$' rows strictly inside (top, bot): split (:741-868)
+		uint32_t zin[4], nz = 0;
+		for(uint32_t i = 0; i < g.nZ; i++) {
+			const uint32_t z = i == 0 ? g.zoff : g.zoffs[i];
+			if(z > s->top && z < s->bot) { if(nz < 4) zin[nz++] = z; else x->overflow = 1; }
+		}
+		if(nz == 0) continue;
+		uint32_t g2n[H2G_GW_MAXROWS], ng = 0, n = 0, ee = 0;
+		for(uint32_t r = 0; r < s->bot - s->top; r++) {
+			if(ng < H2G_GW_MAXROWS) g2n[ng++] = n; else x->overflow = 1;
+			if(ee < s->nie && n == s->ie[ee].first) {
+				for(uint32_t a = 0; a < s->ie[ee].second; a++) { if(ng < H2G_GW_MAXROWS) g2n[ng++] = n; else x->overflow = 1; r++; }
+				ee++;
+			}
+			n++;
+		}
+		if(x->overflow) continue;
+		for(uint32_t i = 0; i < nz; i++) {
+			const uint32_t new_top = zin[i] + 1;
+			if(i + 1 < nz && new_top == zin[i + 1]) continue;
+			if(new_top - s->top == ng) break;
+			const uint32_t new_node_top = g2n[new_top - s->top] + s->node_top;
+			const uint32_t new_bot = (i + 1 < nz) ? zin[i + 1] : s->bot;
+			uint32_t new_node_bot = s->node_bot;
+			if(new_bot - s->top < ng) {
+				new_node_bot = s->node_top + g2n[new_bot - s->top];
+				if(new_bot - s->top > 0 && g2n[new_bot - s->top] == g2n[new_bot - s->top - 1]) new_node_bot++;
+			}
+			if(new_top >= new_bot) continue;
+			GwState* ns = gw_new_state(x);
+			if(x->overflow) break;
+			for(uint32_t j = new_top - s->top; j + 1 < new_bot - s->top;) {
+				const uint32_t nn = g2n[j];
+				uint32_t j2 = j + 1;
+				while(j2 < new_bot - s->top) { if(nn != g2n[j2]) break; j2++; }
+				if(j + 1 < j2) {
+					if(ns->nie < H2G_GW_MAXELT) { ns->ie[ns->nie].first = nn - (new_node_top - s->node_top); ns->ie[ns->nie].second = j2 - j - 1; ns->nie++; }
+					else x->overflow = 1;
+				}
+				j = j2;
+			}
+			ns->nmap = new_node_bot - new_node_top; ns->mapi = 0;
+			if(ns->nmap > H2G_GW_MAXELT) { x->overflow = 1; ns->nmap = H2G_GW_MAXELT; }
+			for(uint32_t j = 0; j < ns->nmap; j++) ns->map[j] = s->map[new_node_top + j - s->node_top + s->mapi];
+			ns->top = new_top; ns->bot = new_bot; ns->node_top = new_node_top; ns->node_bot = new_node_bot; ns->step = s->step;
+			// the reference initialises the new state right here (depth-first); deferring it is equivalent because the
+			// new states only touch their own elements' offs/fmap entries, which this state no longer owns
+			if(npend < H2G_GW_MAXST) pending[npend++] = x->nst - 1; else x->overflow = 1;
+		}
+		s->bot = zin[0];
+		s->node_bot = g2n[s->bot - s->top - 1] + s->node_top + 1;
+		s->nmap = s->node_bot - s->node_top + s->mapi;
+		uint32_t width = s->node_bot - s->node_top;
+		for(uint32_t k = 0; k < s->nie; k++) {
+			if(s->ie[k].first >= s->node_bot - s->node_top) { s->nie = k; break; }
+			width += s->ie[k].second;
+		}
+		if(width != s->bot - s->top && s->nie > 0) {
+			s->ie[s->nie - 1].second -= 1;
+			if(s->ie[s->nie - 1].second == 0) s->nie--;
+		}
+	}
+}
+// narrowing of a freshly mapped element list whose rows merged into fewer nodes (:1143-1185, :1218-1262)
+H2G_HD void gw_merge_dups(const DGfm& g, GwCtx* x, uint32_t curtop, uint64_t mask, uint32_t nmask, int c, uint32_t* map, uint32_t* nmap) {
+	uint32_t j1 = 0, j2 = 0;
+	for(uint32_t k = 0; k < nmask; k++) if((mask >> k) & 1) { j1 = k; break; }
+	for(uint32_t j = 0; j + 1 < *nmap; j++) {
+		for(uint32_t k = j1 + 1; k < nmask; k++) if((mask >> k) & 1) { j2 = k; break; }
+		GRange r;
+		map_glf(g, curtop + j1, curtop + j2 + 1, c, 5, &r, nullptr);
+		if(r.node_bot - r.node_top == 1) { x->offs[map[j]] = map[j]; map[j] = H2G_MAX; }
+		j1 = j2; j2 = 0;
+	}
+	uint32_t w = 0;
+	for(uint32_t j = 0; j < *nmap; j++) if(map[j] != H2G_MAX) map[w++] = map[j];
+	*nmap = w;
+}
+// GWState::advance (group_walk.h:1035-1336)
+H2G_HD void gw_advance(const DGfm& g, GwCtx* x, uint32_t range) {
+	GwState* s = &x->st[range];
+	x->nsteps++;
+	if(s->bot - s->top > 1) {
+		bool first = true;
+		uint32_t newtop = 0, newbot = 0, new_node_top = 0, new_node_bot = 0;
+		uint32_t gmap[H2G_GW_MAXELT], ngmap = 0;
+		IEdges backup;
+		backup.n = 0;
+		uint32_t curtop = s->top, curbot = s->bot, cur_node_top = s->node_top, cur_node_bot = s->node_bot;
+		const uint32_t nie0 = s->nie;
+		for(uint32_t e = 0; e < nie0 + 1; e++) {
+			if(e >= s->nie) {
+				if(e > 0) {
+					curtop = curbot + s->ie[e - 1].second;
+					curbot = s->bot;
+					if(curtop >= curbot) break;
+					cur_node_top = cur_node_bot;
+					cur_node_bot = s->node_bot;
+				}
+			} else {
+				if(e > 0) {
+					curtop = curbot + s->ie[e - 1].second;
+					curbot = curtop + (s->ie[e].first - s->ie[e - 1].first);
+					cur_node_top = cur_node_bot;
+				} else curbot = curtop + s->ie[e].first + 1;
+				cur_node_bot = s->node_top + s->ie[e].first + 1;
+			}
+			uint32_t n = curbot - curtop;
+			if(n > H2G_GW_MAXROWS) { x->overflow = 1; return; }
+			uint64_t mask[4] = {0, 0, 0, 0};
+			for(uint32_t k = 0; k < n; k++) mask[rowL128(g, curtop + k)] |= 1ull << k;          // mapLFRange masks
+			for(int c = 0; c < 4; c++) {
+				if(mask[c] == 0) continue;
+				GRange r;
+				IEdges tie;
+				map_glf(g, curtop, curbot, c, cur_node_bot - cur_node_top, &r, &tie);
+				if(tie.n > H2G_GW_MAXELT) { x->overflow = 1; return; }
+				if(first) {
+					first = false;
+					newtop = r.top; newbot = r.bot; new_node_top = r.node_top; new_node_bot = r.node_bot;
+					backup.n = tie.n;
+					for(uint32_t k = 0; k < tie.n; k++) { backup.e[k][0] = tie.e[k][0]; backup.e[k][1] = tie.e[k][1]; }
+					for(uint32_t j = 0; j < n; j++) if((mask[c] >> j) & 1) {
+						if(ngmap < H2G_GW_MAXELT) gmap[ngmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)]; else x->overflow = 1;
+					}
+					if(new_node_bot - new_node_top < ngmap) gw_merge_dups(g, x, curtop, mask[c], n, c, gmap, &ngmap);
+				} else {
+					GwState* ns = gw_new_state(x);
+					if(x->overflow) return;
+					s = &x->st[range];
+					for(uint32_t j = 0; j < n; j++) if((mask[c] >> j) & 1) {
+						if(ns->nmap < H2G_GW_MAXELT) ns->map[ns->nmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)]; else x->overflow = 1;
+					}
+					if(r.node_bot - r.node_top < ns->nmap) gw_merge_dups(g, x, curtop, mask[c], n, c, ns->map, &ns->nmap);
+					ns->top = r.top; ns->bot = r.bot; ns->node_top = r.node_top; ns->node_bot = r.node_bot;
+					ns->nie = tie.n;
+					for(uint32_t k = 0; k < tie.n; k++) { ns->ie[k].first = tie.e[k][0]; ns->ie[k].second = tie.e[k][1]; }
+					ns->step = s->step + 1;
+					gw_init(g, x, x->nst - 1);
+					if(x->overflow) return;
+				}
+			}
+		}
+		s->mapi = 0;
+		s->top = newtop; s->bot = newbot; s->node_top = new_node_top; s->node_bot = new_node_bot;
+		s->nie = backup.n;
+		for(uint32_t k = 0; k < backup.n; k++) { s->ie[k].first = backup.e[k][0]; s->ie[k].second = backup.e[k][1]; }
+		if(ngmap > 0) { for(uint32_t k = 0; k < ngmap; k++) s->map[k] = gmap[k]; s->nmap = ngmap; }
+	} else {
+		GRange r;
+		map_glf1_nochar(g, s->top, &r);
+		s->top = r.top; s->bot = r.top + 1; s->node_top = r.node_top; s->node_bot = r.node_bot;
+		if(s->mapi > 0) { s->map[0] = s->map[s->mapi]; s->mapi = 0; }
+		s->nmap = 1;
+	}
+	s->step++;
+	gw_init(g, x, range);
+}
+
+// one getGenomeCoords call; x = caller-provided scratch.  res->ok = 0 also on capacity overflow (res->nsteps = H2G_MAX then)
+H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot,
+                                     const IEdges* ie, uint32_t maxelt, uint32_t rdlen, bool rejectStraddle, h2g_coord* coords,
+                                     uint32_t cap, h2g_sa_result* res)
+{
+	res->ok = 0; res->ncoords = 0; res->straddled = 0; res->nsteps = 0;
+	uint32_t nelt = node_bot - node_top;
+	if(nelt > maxelt) nelt = maxelt;
+	if(nelt > H2G_GW_MAXELT || nelt > cap || (ie && ie->n > H2G_GW_MAXELT)) { res->nsteps = H2G_MAX; return; }
+	x->nelt = nelt; x->nst = 0; x->nsteps = 0; x->overflow = 0;
+	for(uint32_t i = 0; i < nelt; i++) { x->offs[i] = H2G_MAX; x->fmap[i] = H2G_MAX; }
+	GwState* s = gw_new_state(x);                             // GroupWalk2S::init :1430-1470
+	s->nmap = nelt;
+	for(uint32_t i = 0; i < nelt; i++) s->map[i] = i;
+	s->top = top; s->bot = bot; s->node_top = node_top; s->node_bot = node_top + nelt;
+	s->nie = ie ? ie->n : 0;
+	for(uint32_t k = 0; k < s->nie; k++) { s->ie[k].first = ie->e[k][0]; s->ie[k].second = ie->e[k][1]; }
+	gw_init(g, x, 0);
+	for(uint32_t elt = 0; elt < nelt; elt++) {
+		uint32_t guard = 0;
+		while(x->offs[elt] == H2G_MAX) {                      // advanceElement :1491-1545
+			if(x->overflow || x->fmap[elt] == H2G_MAX || ++guard > 200000u) { res->nsteps = H2G_MAX; return; }
+			gw_advance(g, x, x->fmap[elt]);
+		}
+		uint32_t tidx = 0, toff = 0;
+		bool st2 = false;
+		joined_to_text(g, rdlen, x->offs[elt], &tidx, &toff, rejectStraddle, &st2);
+		res->straddled |= st2 ? 1u : 0u;
+		if(tidx == H2G_MAX) { res->nsteps = x->nsteps; return; }
+		coords[res->ncoords].tidx = st2 ? H2G_MAX : tidx;
+		coords[res->ncoords].toff = toff;
+		coords[res->ncoords].joinedOff = x->offs[elt];
+		res->ncoords++;
+	}
+	res->nsteps = x->nsteps;
+	res->ok = x->overflow ? 0 : 1;
+}
+
 }  // namespace h2g

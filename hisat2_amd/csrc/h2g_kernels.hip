@@ -672,6 +672,16 @@ __global__ __launch_bounds__(256) void k_graph_lf(DGfm g, const h2g_glf_query* q
 	}
 }
 
+__global__ __launch_bounds__(256) void k_sa_resolve_graph(DGfm g, const h2g_gsa_query* q, const h2g_iedges* ie, size_t n, uint32_t cap,
+                                                          h2g_coord* coords, h2g_sa_result* res, GwCtx* scratch)
+{
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	GwCtx* x = scratch + tid;
+	for(size_t i = tid; i < n; i += stride)
+		genome_coords_graph_item(g, x, q[i].top, q[i].bot, q[i].node_top, q[i].node_bot, ie ? &ie[i] : nullptr, q[i].maxelt, q[i].len,
+		                         q[i].rejectStraddle != 0, coords + i * cap, cap, &res[i]);
+}
+
 __global__ __launch_bounds__(256) void k_fm_search_graph(DGfm g, DReads rd, const h2g_fm_query* q, size_t n, uint32_t khits,
                                                          uint32_t kseeds, h2g_fm_hit* out, h2g_iedges* ie)
 {
@@ -773,6 +783,35 @@ extern "C" h2g_status h2g_graph_lf(h2g_stream* s, const h2g_glf_query* q, size_t
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
 	if(iedges) HIPCHK(hipMemcpyAsync(iedges, die, n * sizeof *iedges, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_sa_resolve_graph(h2g_stream* s, const h2g_gsa_query* q, const h2g_iedges* iedges, size_t n, uint32_t cap,
+                                           h2g_coord* coords, h2g_sa_result* res)
+{
+	if(!s || !q || !coords || !res || n == 0 || cap == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_graph(s))) return rc;
+	const uint32_t glen = s->ix->dg.gbwtLen;
+	for(size_t i = 0; i < n; i++)
+		if(q[i].top >= q[i].bot || q[i].bot > glen || q[i].node_top >= q[i].node_bot || q[i].node_bot - q[i].node_top > q[i].bot - q[i].top) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	const unsigned grid = grid_for(n, 256) > 128 ? 128 : grid_for(n, 256);   // 32 k lanes x sizeof(GwCtx) of scratch
+	void *dq, *dco, *dres, *die = nullptr, *dscr;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * cap * sizeof *coords, &dco)) ||
+	   (rc = tmp_buf(s, 2, n * sizeof *res + (iedges ? n * sizeof *iedges : 0), &dres)) ||
+	   (rc = tmp_buf(s, 3, (size_t)grid * 256 * sizeof(GwCtx), &dscr))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	if(iedges) {
+		die = (char*)dres + n * sizeof *res;
+		HIPCHK(hipMemcpyAsync(die, iedges, n * sizeof *iedges, hipMemcpyHostToDevice, s->st));
+	}
+	hipLaunchKernelGGL(k_sa_resolve_graph, dim3(grid), dim3(256), 0, s->st, s->ix->dg, (const h2g_gsa_query*)dq, (const h2g_iedges*)die, n, cap,
+	                   (h2g_coord*)dco, (h2g_sa_result*)dres, (GwCtx*)dscr);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(coords, dco, n * cap * sizeof *coords, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipStreamSynchronize(s->st));
 	return H2G_OK;
 }

@@ -139,6 +139,12 @@ typedef struct { uint32_t tidx, toff, joinedOff; } h2g_coord;          /* tidx =
 typedef struct { uint32_t ok, ncoords, straddled, nsteps; } h2g_sa_result;
 H2G_EXPORT h2g_status h2g_sa_resolve(h2g_stream*, const h2g_sa_query* q, size_t n, uint32_t cap_per_query,
                                      h2g_coord* coords /* [n*cap] */, h2g_sa_result* res /* [n] */);
+/* getGenomeCoords on a graph index: the node-based group walk (GroupWalk2S / GWState, group_walk.h:464-1545).  Query i
+ * walks the nodes [node_top, node_bot) of rows [top, bot) with in-edge list iedges[i] (as h2g_fm_search_graph returns
+ * them; NULL = none).  Results as h2g_sa_resolve; res[i].nsteps == H2G_MAX flags a capacity overflow (ok = 0). */
+typedef struct { uint32_t top, bot, node_top, node_bot, maxelt, len, rejectStraddle; } h2g_gsa_query;
+H2G_EXPORT h2g_status h2g_sa_resolve_graph(h2g_stream*, const h2g_gsa_query* q, const h2g_iedges* iedges, size_t n,
+                                           uint32_t cap_per_query, h2g_coord* coords /* [n*cap] */, h2g_sa_result* res /* [n] */);
 
 /* GenomeHit::extend (hi_aligner.h:2031-2232) incl. alignWithALTs (:683) and calculateScore (:3711) */
 #define H2G_MAX_EDITS 48

@@ -85,6 +85,14 @@ void h2gemu_graph_lf(Emu* e, const h2g_glf_query* q, size_t n, uint32_t k, h2g_g
 	}
 }
 
+void h2gemu_sa_resolve_graph(Emu* e, const h2g_gsa_query* q, const h2g_iedges* ie, size_t n, uint32_t cap, h2g_coord* coords, h2g_sa_result* res) {
+	GwCtx* x = new GwCtx();
+	for(size_t i = 0; i < n; i++)
+		genome_coords_graph_item(e->dg, x, q[i].top, q[i].bot, q[i].node_top, q[i].node_bot, ie ? &ie[i] : nullptr, q[i].maxelt, q[i].len,
+		                         q[i].rejectStraddle != 0, coords + i * cap, cap, &res[i]);
+	delete x;
+}
+
 void h2gemu_fm_search_graph(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, uint32_t kseeds, h2g_fm_hit* out, h2g_iedges* ie) {
 	DReads rd = e->reads();
 	for(size_t i = 0; i < n; i++) {

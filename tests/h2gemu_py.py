@@ -21,6 +21,7 @@ class Emu:
         self.L.h2gemu_fm_search.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
         self.L.h2gemu_sa_resolve.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_sw_align.argtypes = [vp, vp, C.c_size_t, vp]
+        self.L.h2gemu_sa_resolve_graph.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_graph_lf.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_fm_search_graph.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp]
         self.L.h2gemu_extend.argtypes = [vp, vp, vp, C.c_size_t, vp]
@@ -57,6 +58,15 @@ class Emu:
         out = (api.SwResult * n)()
         self.L.h2gemu_sw_align(self.h, q, n, out)
         return out, 0.0
+
+    def sa_resolve_graph(self, queries, iedges, cap=24):
+        n = len(queries)
+        q = (api.GsaQuery * n)(*queries)
+        ie = (api.IEdges * n)(*iedges)
+        co = (api.Coord * (n * cap))()
+        res = (api.SaResult * n)()
+        self.L.h2gemu_sa_resolve_graph(self.h, q, ie, n, cap, co, res)
+        return co, res
 
     def graph_lf(self, queries, k=10):
         n = len(queries)

@@ -273,3 +273,23 @@ def parse_graph_coords(golden_dir, fn):
         assert len(ie) == nie
         out.append((top, bot, nt, nb, ie, hlen, strad, want))
     return out
+
+
+def check_graph_coords(be, golden_dir, fn):
+    cases = parse_graph_coords(golden_dir, fn)
+    qs, ies = [], []
+    for top, bot, nt, nb, ie, hlen, strad, want in cases:
+        qs.append(api.GsaQuery(top, bot, nt, nb, bot - top, hlen, 0))
+        x = api.IEdges()
+        x.n = len(ie)
+        for k, (a, b) in enumerate(ie):
+            x.e[k][0], x.e[k][1] = a, b
+        ies.append(x)
+    cap = 24
+    co, res = be.sa_resolve_graph(qs, ies, cap=cap)
+    nmulti = 0
+    for i, (top, bot, nt, nb, ie, hlen, strad, want) in enumerate(cases):
+        assert res[i].ok == 1 and res[i].ncoords == len(want) and res[i].straddled == strad, (top, bot, res[i].ok, res[i].nsteps)
+        assert [(co[i * cap + k].tidx, co[i * cap + k].toff, co[i * cap + k].joinedOff) for k in range(len(want))] == want, (top, bot)
+        nmulti += len(want) > 1
+    return len(cases), nmulti

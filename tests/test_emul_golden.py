@@ -70,6 +70,13 @@ def test_graph_fm_search(gemu, golden_dir):
     assert PC.check_graph_fm_search(gemu, golden_dir, "probe_g1s_psearch_spliced.txt.gz") == 600
 
 
+def test_graph_genome_coords(gemu, golden_dir):
+    n, multi = PC.check_graph_coords(gemu, golden_dir, "probe_g1s_coords.txt.gz")
+    assert n > 250 and multi >= 4
+    n, multi = PC.check_graph_coords(gemu, golden_dir, "probe_g1s_coords_short.txt.gz")
+    assert n > 3000 and multi >= 100
+
+
 def test_graph_lf_matches_oracle_on_random_ranges(gemu, oracle_lib, g1s_index):
     """fresh seeded ranges, incl. ranges that straddle sides and tiny ranges around multi-in-edge nodes"""
     import ctypes as C

@@ -224,6 +224,13 @@ def test_graph_fm_search_golden(ggpu, golden_dir):
         assert [getattr(x, f) for f in api.FM_HIT_FIELDS[:13]] == [getattr(y, f) for f in api.FM_HIT_FIELDS[:13]]
 
 
+def test_graph_genome_coords_golden(ggpu, golden_dir):
+    n, multi = PC.check_graph_coords(ggpu, golden_dir, "probe_g1s_coords.txt.gz")
+    assert n > 250 and multi >= 4
+    n, multi = PC.check_graph_coords(ggpu, golden_dir, "probe_g1s_coords_short.txt.gz")
+    assert n > 3000 and multi >= 100
+
+
 def test_graph_lf_vs_oracle_random(ggpu, oracle_lib, g1s_index):
     oix = H.load_index(oracle_lib, g1s_index)
     g = C.byref(oix.contents.g)
