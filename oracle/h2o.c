@@ -164,6 +164,51 @@ int h2o_index_load(const char* base, h2o_index** out) {
 		while(ntext <= ix->g.nPat) ix->local_first[ntext++] = ix->nlocal;
 		free(b5.d); free(b6.d);
 	}
+	/* .7.ht2: ALTs  gfm.h:728-905 (haplotypes/repeats behind them are not needed: use_haplotype defaults to false) */
+	{
+		rbuf b7;
+		if(slurp(base, "7.ht2", &b7) == 0 && b7.n >= 8) {
+			rd_u32(&b7);
+			uint32_t n = rd_u32(&b7);
+			h2o_alt* a = (h2o_alt*)calloc(2 * (size_t)n + 1, sizeof *a);
+			uint32_t* ord = (uint32_t*)calloc(2 * (size_t)n + 1, 4);
+			uint32_t m = 0;
+			for(uint32_t i = 0; i < n && b7.pos + 20 <= b7.n; i++) {
+				a[m].pos = rd_u32(&b7); a[m].type = rd_u32(&b7); a[m].len = rd_u32(&b7);
+				memcpy(&a[m].seq, b7.d + b7.pos, 8); b7.pos += 8;
+				m++;
+			}
+			uint32_t n0 = m;
+			for(uint32_t i = 0; i < n0; i++) {
+				if(a[i].type == H2O_ALT_SNP_DEL) {              /* :879-885 */
+					a[m] = a[i]; a[m].pos = a[i].pos + a[i].len - 1; a[m].seq = (a[i].seq & ~0xffull) | 1; m++;
+				} else if(a[i].type == H2O_ALT_SPLICESITE) {      /* :874-878 */
+					a[m] = a[i]; a[m].pos = a[i].len; a[m].len = a[i].pos; m++;
+				}
+			}
+			for(uint32_t i = 0; i < m; i++) ord[i] = i;
+			/* buf.sort() of (ALT, original index) pairs :887-903; insertion sort keeps it simple (ALT::operator< alt.h:88) */
+			for(uint32_t i = 1; i < m; i++) {
+				h2o_alt x = a[i]; uint32_t xo = ord[i]; int j = (int)i - 1;
+				while(j >= 0) {
+					const h2o_alt* y = &a[j];
+					int lt;                                         /* x < y ? */
+					if(x.pos != y->pos) lt = x.pos < y->pos;
+					else if(x.type != y->type) {
+						if(x.type == H2O_ALT_SNP_INS) lt = 1; else if(y->type == H2O_ALT_SNP_INS) lt = 0; else lt = x.type < y->type;
+					} else if(x.len != y->len) lt = x.len < y->len;
+					else if(x.seq != y->seq) lt = x.seq < y->seq;
+					else lt = xo < ord[j];
+					if(!lt) break;
+					a[j + 1] = a[j]; ord[j + 1] = ord[j]; j--;
+				}
+				a[j + 1] = x; ord[j + 1] = xo;
+			}
+			free(ord);
+			ix->alts = a; ix->nalts = m;
+			free(b7.d);
+		}
+	}
 	/* _minK  hi_aligner.h:3979-3984 */
 	{ uint32_t gl = ix->g.p.len; ix->minK = 0; while(gl > 0) { gl >>= 2; ix->minK++; } }
 	free(b1.d); free(b2.d); free(b3.d);
@@ -644,6 +689,7 @@ int64_t h2o_calculate_score(const h2o_scoring* sc, const char* qual, h2o_ghit* h
 	uint32_t mm = 0;
 	for(uint32_t i = 0; i < h->nedits; i++) {
 		const h2o_edit* e = &h->edits[i];
+		if(e->snp != H2O_MAX) continue;                      /* known-variant edits cost nothing (:3737, :3846, :3858) */
 		if(e->type == H2O_EDIT_MM) {
 			int q = qual[h->rdoff + e->pos] - 33;
 			/* Scoring::score(rdc, refm, q) scoring.h:259-269 */
@@ -712,7 +758,7 @@ static uint32_t align_no_alts(const h2o_index* ix, uint32_t joinedOff, const uin
 				if(rf_bp != rd_bp || rd_bp == 4) {
 					if(tmp_mm >= mm) break;
 					tmp_mm++;
-					h2o_edit e = { (uint32_t)mm_min_rd_i, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0 };
+					h2o_edit e = { (uint32_t)mm_min_rd_i, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0, H2O_MAX };
 					edits_insert_front(tmp, &ntmp, e);
 				}
 				if(rf_bp == 4) mm_tmp_numNs++;
@@ -730,7 +776,7 @@ static uint32_t align_no_alts(const h2o_index* ix, uint32_t joinedOff, const uin
 					if(tmp_mm >= mm) break;
 					tmp_mm++;
 					if(ntmp < H2O_MAX_EDITS) {
-						h2o_edit e = { mm_max_rd_i + rdoff_add, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0 };
+						h2o_edit e = { mm_max_rd_i + rdoff_add, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0, H2O_MAX };
 						tmp[ntmp++] = e;
 					}
 				}
@@ -742,6 +788,313 @@ static uint32_t align_no_alts(const h2o_index* ix, uint32_t joinedOff, const uin
 		}
 	} while(0);
 	uint32_t extlen = left ? rdoff - best_rdoff : best_rdoff - rdoff;   /* :741-750 */
+	uint32_t ne = *nedits_io;
+	if(extlen > 0 && ne > 0) {                                            /* :751-779 */
+		const h2o_edit* f = &edits[0];
+		if(f->pos + extlen == base_rdoff + 1) {
+			if(f->type == H2O_EDIT_READ_GAP || f->type == H2O_EDIT_REF_GAP) extlen = 0;
+			if(f->type == H2O_EDIT_MM && f->chr == 'N') extlen = 0;
+		}
+		const h2o_edit* b = &edits[ne - 1];
+		if(extlen > 0 && b->pos == rdoff - base_rdoff + extlen - 1) {
+			if(b->type == H2O_EDIT_READ_GAP || b->type == H2O_EDIT_REF_GAP) extlen = 0;
+		}
+		if(extlen == 0 && ne > nedits) {
+			if(left) memmove(edits, edits + (ne - nedits), nedits * sizeof *edits);
+			*nedits_io = nedits;
+		}
+	}
+	return extlen;
+}
+
+/* ---- ALT-aware extension: alignWithALTs (hi_aligner.h:683-783) + alignWithALTs_recur (:2763-3550) for SNP ALTs
+ * (single / insertion / deletion).  Splice-site and exon ALTs are skipped (not present in a --snp-only index);
+ * haplotypes are not used (use_haplotype defaults to false, hisat2.cpp:522). */
+typedef struct {
+	const h2o_index* ix;
+	const uint8_t* rdseq;
+	uint32_t tidx, mm, maxAltsTried, numALTsTried;
+	int left;
+	int best_rdoff;
+	h2o_edit tmp[H2O_MAX_EDITS]; uint32_t ntmp;       /* tmp_edits */
+	h2o_edit* best; uint32_t* nbest;                   /* edits */
+	uint32_t* numNs;
+	int overflow;
+} awa_ctx;
+static void awa_push_front(awa_ctx* x, h2o_edit e) { if(x->ntmp >= H2O_MAX_EDITS) { x->overflow = 1; return; } memmove(x->tmp + 1, x->tmp, x->ntmp * sizeof e); x->tmp[0] = e; x->ntmp++; }
+static void awa_push_back(awa_ctx* x, h2o_edit e) { if(x->ntmp >= H2O_MAX_EDITS) { x->overflow = 1; return; } x->tmp[x->ntmp++] = e; }
+static void awa_erase_front(awa_ctx* x, uint32_t n) { memmove(x->tmp, x->tmp + n, (x->ntmp - n) * sizeof x->tmp[0]); x->ntmp -= n; }
+static void awa_commit(awa_ctx* x) { memcpy(x->best, x->tmp, x->ntmp * sizeof x->tmp[0]); *x->nbest = x->ntmp; }
+static uint32_t alt_lobound(const h2o_index* ix, uint32_t pos) {   /* EList::bsearchLoBound with a type-NONE key */
+	uint32_t lo = 0, hi = ix->nalts;
+	while(lo < hi) { uint32_t m = (lo + hi) >> 1; if(ix->alts[m].pos < pos) lo = m + 1; else hi = m; }
+	return lo;
+}
+static const uint8_t* awa_fetch(const h2o_index* ix, uint32_t tidx, int rfoff, uint32_t rflen, uint8_t* buf /* >= rflen + 64 */) {
+	memset(buf, 4, rflen + 64);
+	int s = rfoff > 0 ? rfoff : 0;
+	int cnt = rfoff > 0 ? (int)rflen : (int)rflen + rfoff;
+	if(cnt > 0) h2o_get_stretch(&ix->r, tidx, s, (uint32_t)cnt, buf + 32);
+	return buf + 32 + (rfoff < 0 ? rfoff : 0);
+}
+#define AWA_BUF 1400
+static uint32_t awa_recur(awa_ctx* x, uint32_t joinedOff, uint32_t rdoff_add, uint32_t rdoff, uint32_t rdlen,
+                          const uint8_t* rfseq, int rfoff, uint32_t rflen, uint32_t tmp_numNs, uint32_t dep, uint32_t prev_alt_type)
+{
+	const h2o_index* ix = x->ix;
+	const h2o_alt* alts = ix->alts;
+	const uint8_t* rdseq = x->rdseq;
+	(void)prev_alt_type;
+	if(x->numALTsTried > x->maxAltsTried + dep) return 0;
+	if(rfoff < -16) return 0;
+	uint32_t contig_len = ix->r.refLens[x->tidx];
+	if(rfoff >= (int64_t)contig_len) return 0;
+	if(rfoff >= 0 && (uint64_t)rfoff + rflen > contig_len) rflen = contig_len - rfoff;
+	else if(rfoff < 0 && rflen > contig_len) rflen = contig_len;
+	if(rflen == 0) return 0;
+	uint8_t buf[AWA_BUF], buf2[AWA_BUF];
+	if(rflen + 64 > AWA_BUF) { x->overflow = 1; return 0; }
+	if(rfseq == NULL) rfseq = awa_fetch(ix, x->tidx, rfoff, rflen, buf);
+	if(x->left) {
+		uint32_t tmp_mm = 0, mm_tmp_numNs = 0;
+		int min_rd_i = (int)rdoff, mm_min_rd_i = (int)rdoff;
+		for(int rf_i = (int)rflen - 1; rf_i >= 0 && mm_min_rd_i >= 0; rf_i--, mm_min_rd_i--) {
+			int rf_bp = rfseq[rf_i], rd_bp = rdseq[mm_min_rd_i];
+			if(rf_bp != rd_bp || rd_bp == 4) {
+				if(tmp_mm == 0) min_rd_i = mm_min_rd_i;
+				if(tmp_mm >= x->mm) break;
+				tmp_mm++;
+				h2o_edit e = { (uint32_t)mm_min_rd_i, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0, H2O_MAX };
+				awa_push_front(x, e);
+			}
+			if(rf_bp == 4) { if(tmp_mm == 0) tmp_numNs++; mm_tmp_numNs++; }
+		}
+		if(tmp_mm == 0) min_rd_i = mm_min_rd_i;
+		if(mm_min_rd_i < x->best_rdoff) { x->best_rdoff = mm_min_rd_i; awa_commit(x); if(x->numNs) *x->numNs = mm_tmp_numNs; }
+		if(mm_min_rd_i < 0) return rdlen;
+		if(tmp_mm > 0) { awa_erase_front(x, tmp_mm); tmp_mm = 0; }
+		int a_first = 0, a_second = 0;
+		if(ix->nalts > 0) {
+			uint32_t rd_diff = rdoff - (uint32_t)mm_min_rd_i;
+			rd_diff = rd_diff > 16 ? rd_diff - 16 : 0;
+			uint32_t cpos = rd_diff >= joinedOff ? joinedOff : joinedOff - rd_diff;
+			a_first = a_second = (int)alt_lobound(ix, cpos);
+			if(a_first >= (int)ix->nalts) a_first = a_second = a_second - 1;
+			for(; a_first >= 0; a_first--) {
+				const h2o_alt* alt = &alts[a_first];
+				if(alt->type == H2O_ALT_SNP_SGL || alt->type == H2O_ALT_SNP_DEL || alt->type == H2O_ALT_SNP_INS) {
+					if(alt->type == H2O_ALT_SNP_DEL && !(alt->seq & 0xff)) continue;
+					if((uint64_t)alt->pos + rdlen < joinedOff) break;
+				} else if(alt->type == H2O_ALT_SPLICESITE) {
+					if(alt->pos < alt->len) continue;
+					if((uint64_t)alt->pos + rdlen - 1 < joinedOff) break;
+				} else continue;
+			}
+		}
+		const uint32_t orig_nedits = x->ntmp;
+		for(; a_second > a_first; a_second--) {
+			h2o_alt alt = alts[a_second];
+			if(alt.pos >= joinedOff) continue;
+			if(alt.type == H2O_ALT_SPLICESITE || alt.type == H2O_ALT_EXON) continue;   /* not built: splice-site ALTs */
+			if(alt.type == H2O_ALT_SNP_DEL) {
+				if(!(alt.seq & 0xff)) continue;
+				alt.pos = alt.pos - alt.len + 1;
+			}
+			int alt_compatible = 0;
+			int rf_i = (int)rflen - 1, rd_i = (int)rdoff, diff = 0;
+			if(alt.type == H2O_ALT_SNP_SGL) diff = (int)(joinedOff - alt.pos - 1);
+			else if(alt.type == H2O_ALT_SNP_DEL) {
+				if(alt.pos + alt.len >= joinedOff) continue;
+				diff = (int)(joinedOff - (alt.pos + alt.len));
+			} else if(alt.type == H2O_ALT_SNP_INS) diff = (int)(joinedOff - alt.pos);
+			else continue;
+			if(rf_i < diff || rd_i < diff) continue;
+			rf_i -= diff; rd_i -= diff;
+			int rd_bp = rdseq[rd_i];
+			if(rd_i < min_rd_i) {
+				if(alt.type == H2O_ALT_SNP_INS) { if(rd_i + 1 >= min_rd_i) continue; }
+				break;
+			}
+			if(alt.type == H2O_ALT_SNP_SGL) {
+				if(rd_bp == (int)alt.seq) {
+					int rf_bp = rfseq[rf_i];
+					h2o_edit e = { (uint32_t)rd_i, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0, (uint32_t)a_second };
+					awa_push_front(x, e);
+					rd_i--; rf_i--;
+					alt_compatible = 1;
+				}
+			} else if(alt.type == H2O_ALT_SNP_DEL) {
+				if(rfoff + rf_i > (int)alt.len) {
+					if(rf_i > (int)alt.len) {
+						for(uint32_t i = 0; i < alt.len; i++) {
+							int rf_bp = rfseq[rf_i - (int)i];
+							h2o_edit e = { (uint32_t)(rd_i + 1), (uint8_t)"ACGTN"[rf_bp], '-', H2O_EDIT_READ_GAP, 0, (uint32_t)a_second };
+							awa_push_front(x, e);
+						}
+					} else {                                       /* long deletions: refetch further left */
+						int new_rfoff = rfoff - (int)alt.len;
+						uint32_t new_rflen = (uint32_t)(rf_i + (int)alt.len + 10);
+						if(new_rflen + 64 > AWA_BUF) { x->overflow = 1; return 0; }
+						const uint8_t* new_rfseq = awa_fetch(ix, x->tidx, new_rfoff, new_rflen, buf2);
+						for(int i = 0; i < (int)alt.len; i++) {
+							int rf_bp = new_rfseq[rf_i - i + (int)alt.len];
+							h2o_edit e = { (uint32_t)(rd_i + 1), (uint8_t)"ACGTN"[rf_bp], '-', H2O_EDIT_READ_GAP, 0, (uint32_t)a_second };
+							awa_push_front(x, e);
+						}
+					}
+					rf_i -= (int)alt.len;
+					alt_compatible = 1;
+				}
+			} else {                                               /* insertion */
+				if(rd_i > (int)alt.len) {
+					int same_seq = 1;
+					for(uint32_t i = 0; i < alt.len; i++) {
+						rd_bp = rdseq[rd_i - (int)i];
+						int snp_bp = (int)((alt.seq >> (i << 1)) & 3);
+						if(rd_bp != snp_bp) { same_seq = 0; break; }
+						h2o_edit e = { (uint32_t)(rd_i - (int)i), '-', (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_REF_GAP, 0, (uint32_t)a_second };
+						awa_push_front(x, e);
+					}
+					if(same_seq) { rd_i -= (int)alt.len; alt_compatible = 1; }
+				}
+			}
+			if(alt_compatible) {
+				x->numALTsTried++;
+				if(rd_i < 0) { x->best_rdoff = rd_i; awa_commit(x); return rdlen; }
+				uint32_t next_joinedOff = alt.pos;
+				int next_rfoff = rfoff, next_rdoff = rd_i, next_rflen = rf_i + 1, next_rdlen = rd_i + 1;
+				const uint8_t* next_rfseq = rfseq;
+				if(next_rflen < next_rdlen) {
+					int add_len = next_rdlen + 10 - next_rflen;
+					if(next_rfoff < add_len) add_len = next_rfoff;
+					next_rfoff -= add_len; next_rflen += add_len; next_rfseq = NULL;
+				}
+				uint32_t alignedLen = awa_recur(x, next_joinedOff, rdoff_add, (uint32_t)next_rdoff, (uint32_t)next_rdlen, next_rfseq, next_rfoff,
+				                                (uint32_t)next_rflen, tmp_numNs, dep + 1, alt.type);
+				if(alignedLen == (uint32_t)next_rdlen) return rdlen;
+			}
+			if(orig_nedits < x->ntmp) awa_erase_front(x, x->ntmp - orig_nedits);
+		}
+		return 0;
+	} else {
+		uint32_t tmp_mm = 0, max_rd_i = 0, mm_max_rd_i = 0, mm_tmp_numNs = 0;
+		for(uint32_t rf_i = 0; rf_i < rflen && mm_max_rd_i < rdlen; rf_i++, mm_max_rd_i++) {
+			int rf_bp = rfseq[rf_i], rd_bp = rdseq[rdoff + mm_max_rd_i];
+			if(rf_bp != rd_bp || rd_bp == 4) {
+				if(tmp_mm == 0) max_rd_i = mm_max_rd_i;
+				if(tmp_mm >= x->mm) break;
+				tmp_mm++;
+				h2o_edit e = { mm_max_rd_i + rdoff_add, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0, H2O_MAX };
+				awa_push_back(x, e);
+			}
+			if(rf_bp == 4) { if(tmp_mm == 0) tmp_numNs++; mm_tmp_numNs++; }
+		}
+		if(tmp_mm == 0) max_rd_i = mm_max_rd_i;
+		if((int)(mm_max_rd_i + rdoff) > x->best_rdoff) { x->best_rdoff = (int)(mm_max_rd_i + rdoff); awa_commit(x); if(x->numNs) *x->numNs = mm_tmp_numNs; }
+		if(mm_max_rd_i == rflen) return mm_max_rd_i;
+		if(ix->nalts == 0) return 0;                               /* bsearchLoBound on an empty list: first >= size */
+		uint32_t a_first, a_second;
+		{
+			uint32_t rd_diff = max_rd_i > 16 ? max_rd_i - 16 : 0;
+			a_first = a_second = alt_lobound(ix, joinedOff + rd_diff);
+			if(a_first >= ix->nalts) return 0;
+			for(; a_second < ix->nalts; a_second++) {
+				const h2o_alt* alt = &alts[a_second];
+				if(alt->type == H2O_ALT_SPLICESITE) { if(alt->pos > alt->len) continue; }
+				if(alt->type == H2O_ALT_SNP_DEL) { if(alt->seq & 0xff) continue; }
+				if(alt->pos > joinedOff + max_rd_i) break;
+			}
+		}
+		if(mm_max_rd_i == rdlen) return mm_max_rd_i;               /* no splice-site ALTs to look further for */
+		if(tmp_mm > 0) { x->ntmp -= tmp_mm; tmp_mm = 0; }
+		const uint32_t orig_nedits = x->ntmp;
+		for(; a_first < a_second; a_first++) {
+			const h2o_alt* alt = &alts[a_first];
+			if(alt->type == H2O_ALT_SPLICESITE || alt->type == H2O_ALT_EXON) continue;
+			if(alt->type == H2O_ALT_SNP_DEL) { if(alt->seq & 0xff) continue; }
+			int alt_compatible = 0;
+			uint32_t rf_i, rd_i;
+			rf_i = rd_i = alt->pos - joinedOff;
+			if(rd_i >= rdlen) continue;
+			int rf_bp = rfseq[rf_i], rd_bp = rdseq[rdoff + rd_i];
+			if(alt->type == H2O_ALT_SNP_SGL) {
+				if(rd_bp == (int)alt->seq) {
+					h2o_edit e = { rd_i + rdoff_add, (uint8_t)"ACGTN"[rf_bp], (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_MM, 0, a_first };
+					awa_push_back(x, e);
+					rd_i++; rf_i++;
+					alt_compatible = 1;
+				}
+			} else if(alt->type == H2O_ALT_SNP_DEL) {
+				int try_del = rd_i > 0;
+				if(rd_i == 0 && dep > 0) { if(x->ntmp > 0 && x->tmp[x->ntmp - 1].type != H2O_EDIT_READ_GAP) try_del = 1; }
+				if(try_del) {
+					if(rf_i + alt->len <= rflen) {
+						for(uint32_t i = 0; i < alt->len; i++) {
+							rf_bp = rfseq[rf_i + i];
+							h2o_edit e = { rd_i + rdoff_add, (uint8_t)"ACGTN"[rf_bp], '-', H2O_EDIT_READ_GAP, 0, a_first };
+							awa_push_back(x, e);
+						}
+					} else {                                       /* long deletions */
+						uint32_t new_rflen = rf_i + alt->len + 10;
+						if(new_rflen + 64 > AWA_BUF) { x->overflow = 1; return 0; }
+						const uint8_t* new_rfseq = awa_fetch(ix, x->tidx, rfoff, new_rflen, buf2);
+						for(uint32_t i = 0; i < alt->len; i++) {
+							rf_bp = new_rfseq[rf_i + i];
+							h2o_edit e = { rd_i + rdoff_add, (uint8_t)"ACGTN"[rf_bp], '-', H2O_EDIT_READ_GAP, 0, a_first };
+							awa_push_back(x, e);
+						}
+					}
+					rf_i += alt->len;
+					alt_compatible = 1;
+				}
+			} else if(alt->type == H2O_ALT_SNP_INS) {
+				if(rd_i + alt->len <= rdlen && rf_i > 0) {
+					int same_seq = 1;
+					for(uint32_t i = 0; i < alt->len; i++) {
+						rd_bp = rdseq[rdoff + rd_i + i];
+						int snp_bp = (int)((alt->seq >> ((alt->len - i - 1) << 1)) & 3);
+						if(rd_bp != snp_bp) { same_seq = 0; break; }
+						h2o_edit e = { rd_i + i + rdoff_add, '-', (uint8_t)"ACGTN"[rd_bp], H2O_EDIT_REF_GAP, 0, a_first };
+						awa_push_back(x, e);
+					}
+					if(same_seq) { rd_i += alt->len; alt_compatible = 1; }
+				}
+			}
+			if(alt_compatible) {
+				x->numALTsTried++;
+				if(rd_i == rdlen) { x->best_rdoff = (int)(rdoff + rd_i); awa_commit(x); return rd_i; }
+				uint32_t next_joinedOff = 0;
+				int next_rfoff = rfoff + (int)rf_i;
+				uint32_t next_rdoff = rdoff + rd_i;
+				const uint8_t* next_rfseq = rfseq + rf_i;
+				uint32_t next_rflen = rflen - rf_i, next_rdlen = rdlen - rd_i;
+				if(alt->type == H2O_ALT_SNP_SGL) next_joinedOff = alt->pos + 1;
+				else if(alt->type == H2O_ALT_SNP_DEL) { next_joinedOff = alt->pos + alt->len; if(rflen <= rf_i) next_rflen = 0; }
+				else next_joinedOff = alt->pos;
+				if(next_rflen < next_rdlen) { next_rflen = next_rdlen + 10; next_rfseq = NULL; }
+				uint32_t alignedLen = awa_recur(x, next_joinedOff, rdoff_add + rd_i, next_rdoff, next_rdlen, next_rfseq, next_rfoff, next_rflen,
+				                                tmp_numNs, dep + 1, alt->type);
+				if(alignedLen > 0) { if(rd_i + alignedLen == rdlen) return rd_i + alignedLen; }
+			}
+			if(orig_nedits < x->ntmp) x->ntmp = orig_nedits;
+		}
+		return 0;
+	}
+}
+/* alignWithALTs hi_aligner.h:683-783 */
+static uint32_t align_with_alts(const h2o_index* ix, uint32_t joinedOff, const uint8_t* rdseq, uint32_t base_rdoff,
+                                uint32_t rdoff, uint32_t rdlen, uint32_t tidx, int rfoff, uint32_t rflen, int left,
+                                h2o_edit* edits, uint32_t* nedits_io, uint32_t mm, uint32_t* numNs)
+{
+	awa_ctx x;
+	x.ix = ix; x.rdseq = rdseq; x.tidx = tidx; x.mm = mm; x.maxAltsTried = 16; x.numALTsTried = 0; x.left = left;
+	x.best_rdoff = (int)rdoff; x.best = edits; x.nbest = nedits_io; x.numNs = numNs; x.overflow = 0;
+	if(numNs) *numNs = 0;
+	const uint32_t nedits = *nedits_io;
+	x.ntmp = nedits;
+	memcpy(x.tmp, edits, nedits * sizeof x.tmp[0]);
+	awa_recur(&x, joinedOff, rdoff - base_rdoff, rdoff, rdlen, NULL, rfoff, rflen, 0, 0, 0);
+	uint32_t extlen = left ? rdoff - (uint32_t)x.best_rdoff : (uint32_t)x.best_rdoff - rdoff;
 	uint32_t ne = *nedits_io;
 	if(extlen > 0 && ne > 0) {                                            /* :751-779 */
 		const h2o_edit* f = &edits[0];
@@ -773,7 +1126,7 @@ int h2o_extend(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq, c
 		rl -= (int)(reflen - h->rdoff);
 		if(rl < 0) { reflen += rl; rl = 0; }
 		uint32_t numNs = 0, num_prev = h->nedits;
-		uint32_t best_ext = align_no_alts(ix, h->joinedOff, seq, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx,
+		uint32_t best_ext = (ix->nalts ? align_with_alts : align_no_alts)(ix, h->joinedOff, seq, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx,
 		                                  rl, reflen, 1, h->edits, &h->nedits, mm, &numNs);
 		if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return 0; }
 		if(best_ext > 0) {
@@ -825,7 +1178,7 @@ int h2o_extend(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq, c
 				else if(e->type == H2O_EDIT_READ_GAP) ref_ext++;
 				else if(e->type == H2O_EDIT_MM && e->chr == 'N') ref_ext--;
 			}
-			uint32_t best_ext = align_no_alts(ix, h->joinedOff + ref_ext, seq, h->rdoff, h->rdoff + h->len,
+			uint32_t best_ext = (ix->nalts ? align_with_alts : align_no_alts)(ix, h->joinedOff + ref_ext, seq, h->rdoff, h->rdoff + h->len,
 			                                  rdlen - (h->rdoff + h->len), h->tidx, (int)rl, reflen, 0,
 			                                  h->edits, &h->nedits, mm, NULL);
 			if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return 0; }
@@ -1074,7 +1427,7 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 					const int m = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
 					ct = 0;
 					if(m != 1) {
-						e->pos = row; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_MM; ned++;
+						e->pos = row; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_MM; e->pad = 0; e->snp = H2O_MAX; ned++;
 						const int q = (qual ? qual[row] : 'I') - 33;
 						score -= (readc > 3 || refm > 15) ? sc->nPen : mmpen_q(sc, q);
 					}
@@ -1082,11 +1435,11 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 					row--; col--;
 					break; }
 				case 1: case 2:                              /* REF_OPEN / RFGAP_EXTEND: move up */
-					e->pos = row; e->chr = '-'; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_REF_GAP; ned++;
+					e->pos = row; e->chr = '-'; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_REF_GAP; e->pad = 0; e->snp = H2O_MAX; ned++;
 					row--; ct = cur == 1 ? 0 : 2; score -= cur == 1 ? rfgapo : rfgape; gaps++; refGaps++;
 					break;
 				default:                                     /* READ_OPEN / RDGAP_EXTEND: move left */
-					e->pos = row + 1; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = '-'; e->type = H2O_EDIT_READ_GAP; ned++;
+					e->pos = row + 1; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = '-'; e->type = H2O_EDIT_READ_GAP; e->pad = 0; e->snp = H2O_MAX; ned++;
 					col--; ct = cur == 3 ? 0 : 1; score -= cur == 3 ? rdgapo : rdgape; gaps++; readGaps++;
 					break;
 				}
@@ -1104,7 +1457,7 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 				const int m = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
 				if(m != 1) {
 					h2o_edit* e = &o->edits[ned < H2O_MAX_EDITS ? ned : H2O_MAX_EDITS - 1];
-					e->pos = row; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_MM; ned++;
+					e->pos = row; e->chr = (uint8_t)MASK2DNA[refm]; e->qchr = (uint8_t)"ACGTN"[readc]; e->type = H2O_EDIT_MM; e->pad = 0; e->snp = H2O_MAX; ned++;
 					const int q = (qual ? qual[row] : 'I') - 33;
 					score -= (readc > 3 || refm > 15) ? sc->nPen : mmpen_q(sc, q);
 				}

@@ -55,6 +55,11 @@ typedef struct {
 	uint64_t  bufSz;
 } h2o_ref;
 
+/* ALT (alt.h:41-120) as GFM::GFM loads them (gfm.h:728-905): a reversed copy of every deletion is appended
+ * (pos = last deleted base, reversed = 1) and the list is sorted by ALT::operator< (alt.h:88-102) */
+enum { H2O_ALT_SNP_SGL = 1, H2O_ALT_SNP_INS = 2, H2O_ALT_SNP_DEL = 3, H2O_ALT_SNP_ALT = 4, H2O_ALT_SPLICESITE = 5, H2O_ALT_EXON = 6 };
+typedef struct { uint32_t pos, type, len; uint64_t seq; } h2o_alt;   /* seq & 0xff = `reversed` for deletions */
+
 typedef struct {
 	h2o_gfm   g;                  /* global index (.1/.2) */
 	h2o_ref   r;                  /* reference (.3/.4) */
@@ -63,6 +68,8 @@ typedef struct {
 	uint32_t *local_first;        /* [nPat+1] first local index of each text */
 	uint32_t  minK;               /* hi_aligner.h:3979-3984 */
 	char    **names;
+	uint32_t  nalts;              /* ALTDB (.7.ht2), graph indexes only */
+	h2o_alt  *alts;
 } h2o_index;
 
 /* Scoring subset (scoring.h:100-546, defaults hisat2.cpp:425-441) */
@@ -73,7 +80,8 @@ typedef struct {
 
 /* Edit (edit.h) — only what the linear path uses */
 enum { H2O_EDIT_READ_GAP = 1, H2O_EDIT_REF_GAP = 2, H2O_EDIT_MM = 3 }; /* edit.h:37-39 */
-typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; } h2o_edit;
+typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; uint32_t snp; /* Edit::snpID, H2O_MAX = none */ } h2o_edit;
+
 
 enum { H2O_CANDIDATE_HIT = 1, H2O_PSEUDOGENE_HIT = 2, H2O_ANCHOR_HIT = 3 }; /* hi_aligner.h:98 */
 

@@ -387,7 +387,9 @@ int main(int argc, char** argv) {
 						       leftext, rightext, (long long)gh_.score(), (unsigned)gh_.edits().size());
 						for(size_t e = 0; e < gh_.edits().size(); e++) {
 							const Edit& ed = gh_.edits()[e];
-							printf(" %u:%c>%c", ed.pos, (char)ed.chr, (char)ed.qchr);
+							if(linear) printf(" %u:%c>%c", ed.pos, (char)ed.chr, (char)ed.qchr);
+							else printf(" %u:%c>%c:%d:%lld", ed.pos, (char)ed.chr, (char)ed.qchr, (int)ed.type,
+							            ed.snpID == (uint32_t)INDEX_MAX ? -1LL : (long long)ed.snpID);   // graph: + type and snpID
 						}
 						putchar('\n');
 					}

@@ -20,7 +20,8 @@ class Coord(C.Structure):
 
 
 class Edit(C.Structure):
-    _fields_ = [("pos", C.c_uint32), ("chr", C.c_uint8), ("qchr", C.c_uint8), ("type", C.c_uint8), ("pad", C.c_uint8)]
+    _fields_ = [("pos", C.c_uint32), ("chr", C.c_uint8), ("qchr", C.c_uint8), ("type", C.c_uint8), ("pad", C.c_uint8),
+                ("snp", C.c_uint32)]
 
 
 class GHit(C.Structure):
@@ -58,7 +59,8 @@ class Ref(C.Structure):
 
 class Index(C.Structure):
     _fields_ = [("g", Gfm), ("r", Ref), ("nlocal", C.c_uint32), ("local", C.POINTER(Gfm)),
-                ("local_first", C.POINTER(C.c_uint32)), ("minK", C.c_uint32), ("names", C.POINTER(C.c_char_p))]
+                ("local_first", C.POINTER(C.c_uint32)), ("minK", C.c_uint32), ("names", C.POINTER(C.c_char_p)),
+                ("nalts", C.c_uint32), ("alts", C.c_void_p)]
 
 
 class SwResult(C.Structure):       # h2o_sw_result

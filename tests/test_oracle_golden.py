@@ -278,3 +278,32 @@ def test_graph_genome_coords(oracle_lib, g1s_index, golden_dir, fn):
         assert [(co[k].tidx, co[k].toff, co[k].joinedOff) for k in range(nc.value)] == want, (top, bot)
         nmulti += len(want) > 1
     assert nmulti >= (100 if "short" in fn else 4)
+
+
+def test_graph_extend_with_alts(oracle_lib, g1s_index, golden_dir):
+    """GenomeHit::extend on a graph index: alignWithALTs_recur through known SNPs / insertions / deletions (edits carry snpID
+    and cost nothing), mm = 0..3"""
+    ix = H.load_index(oracle_lib, g1s_index)
+    assert ix.contents.nalts > 500     # 508 ALTs + one reversed copy per deletion (gfm.h:879-885)
+    _, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_snp.fa.gz"))
+    sc = H.Scoring()
+    oracle_lib.h2o_scoring_default(C.byref(sc))
+    n = nsnp = ngap = 0
+    for l in H.glines(golden_dir, "probe_g1s_extend.txt.gz"):
+        lhs, rhs = l.split(" -> ")
+        rid, fw, rdoff, hlen, tidx, toff, joff, mm = map(int, lhs.split())
+        r = rhs.split()
+        seq = np.ascontiguousarray(seqs[rid] if fw else H.revcomp(seqs[rid]))
+        h = H.GHit()
+        h.fw, h.rdoff, h.len, h.tidx, h.toff, h.joinedOff = fw, rdoff, hlen, tidx, toff, joff
+        le, re = C.c_uint32(H.MAX), C.c_uint32(H.MAX)
+        ext = oracle_lib.h2o_extend(ix, C.byref(sc), seq.ctypes.data, b"I" * len(seq), len(seq), C.byref(h), C.byref(le), C.byref(re), mm)
+        got = [ext, h.rdoff, h.len, h.toff, h.joinedOff, le.value, re.value, h.score, h.nedits]
+        assert got == list(map(int, r[:9])), (l, got)
+        eds = [f"{h.edits[k].pos}:{chr(h.edits[k].chr)}>{chr(h.edits[k].qchr)}:{h.edits[k].type}:{-1 if h.edits[k].snp == H.MAX else h.edits[k].snp}"
+               for k in range(h.nedits)]
+        assert eds == r[9:], (l, eds)
+        n += 1
+        nsnp += any(not e.endswith(":-1") for e in eds)
+        ngap += any(e.split(":")[2] in ("1", "2") for e in eds)
+    assert n > 1000 and nsnp > 80 and ngap > 10
