@@ -76,7 +76,7 @@ class SaResult(C.Structure):
 
 
 class Edit(C.Structure):
-    _fields_ = [("pos", u32), ("chr", u8), ("qchr", u8), ("type", u8), ("pad", u8)]
+    _fields_ = [("pos", u32), ("chr", u8), ("qchr", u8), ("type", u8), ("pad", u8), ("snp", u32)]
 
 
 class GHit(C.Structure):

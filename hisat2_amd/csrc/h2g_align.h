@@ -340,7 +340,7 @@ H2G_HD void hit_left_align(h2g_ghit* h, const SeqView& seq) {
 H2G_HD void hit_push_edit(h2g_ghit* h, uint32_t pos, uint8_t chr, uint8_t qchr, uint8_t type) {
 	if(h->nedits >= H2G_MAX_EDITS) { h->overflow = 1; return; }
 	h2g_edit& e = h->edits[h->nedits++];
-	e.pos = pos; e.chr = chr; e.qchr = qchr; e.type = type; e.pad = 0;
+	e.pos = pos; e.chr = chr; e.qchr = qchr; e.type = type; e.pad = 0; e.snp = H2G_MAX;
 }
 
 // combineWith hi_aligner.h:1420-2025 for linear indexes without spliced alignment: plain concatenation

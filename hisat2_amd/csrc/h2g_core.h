@@ -409,6 +409,7 @@ H2G_HD int64_t calculate_score(const DScoring& sc, const SeqView& seq, h2g_ghit*
 	uint32_t mm = 0;
 	for(uint32_t i = 0; i < h->nedits; i++) {
 		const h2g_edit e = h->edits[i];
+		if(e.snp != H2G_MAX) continue;                     // edits through known variants cost nothing (:3737, :3846, :3858)
 		if(e.type == H2G_EDIT_MM) {
 			int q = seq.qual(h->rdoff + e.pos) - 33;
 			if(e.qchr == 'N') score -= sc.nPen;            // Scoring::score scoring.h:259-269: rdc > 3
@@ -467,7 +468,7 @@ H2G_HD uint32_t align_no_alts(const DRef& ref, const SeqView& seq, uint32_t base
 					if(tmp_mm >= mm) break;
 					if(tmp_mm < H2G_NEW_EDITS) {
 						ne[tmp_mm].pos = (uint32_t)i; ne[tmp_mm].chr = base_char(rf_bp); ne[tmp_mm].qchr = base_char(rd_bp);
-						ne[tmp_mm].type = H2G_EDIT_MM; ne[tmp_mm].pad = 0;
+						ne[tmp_mm].type = H2G_EDIT_MM; ne[tmp_mm].pad = 0; ne[tmp_mm].snp = H2G_MAX;
 					} else h->overflow = 1;
 					tmp_mm++;
 				}
@@ -483,7 +484,7 @@ H2G_HD uint32_t align_no_alts(const DRef& ref, const SeqView& seq, uint32_t base
 					if(tmp_mm >= mm) break;
 					if(tmp_mm < H2G_NEW_EDITS) {
 						ne[tmp_mm].pos = i + rdoff_add; ne[tmp_mm].chr = base_char(rf_bp); ne[tmp_mm].qchr = base_char(rd_bp);
-						ne[tmp_mm].type = H2G_EDIT_MM; ne[tmp_mm].pad = 0;
+						ne[tmp_mm].type = H2G_EDIT_MM; ne[tmp_mm].pad = 0; ne[tmp_mm].snp = H2G_MAX;
 					} else h->overflow = 1;
 					tmp_mm++;
 				}

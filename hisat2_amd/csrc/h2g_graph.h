@@ -627,4 +627,392 @@ H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint
 	res->ok = x->overflow ? 0 : 1;
 }
 
+
+// ------------------------------------------------------------------------------------------ ALT-aware extension (a18, a28)
+// ALT (alt.h:41-120) as GFM::GFM loads the list (gfm.h:728-905): one reversed copy per deletion appended
+// (pos = last deleted base, reversed = 1 in the low byte of seq), sorted by ALT::operator< (alt.h:88-102).
+enum { H2G_ALT_SNP_SGL = 1, H2G_ALT_SNP_INS = 2, H2G_ALT_SNP_DEL = 3, H2G_ALT_SNP_ALT = 4, H2G_ALT_SPLICESITE = 5, H2G_ALT_EXON = 6 };
+struct DAlt { uint32_t pos, type, len, pad; uint64_t seq; };
+struct DAlts { const DAlt* a; uint32_t n; uint32_t maxAltsTried; };   // GraphPolicy::maxAltsTried = 16 (hisat2.cpp:521)
+
+H2G_HD uint32_t alt_lobound(const DAlts& A, uint32_t pos) {   // EList::bsearchLoBound with a type-NONE key: first pos >= key
+	uint32_t lo = 0, hi = A.n;
+	while(lo < hi) { const uint32_t m = (lo + hi) >> 1; if(A.a[m].pos < pos) lo = m + 1; else hi = m; }
+	return lo;
+}
+
+// alignWithALTs_recur (hi_aligner.h:2763-3550) for SNP ALTs (single / insertion / deletion), recursion turned into an
+// explicit stack.  Splice-site / exon ALTs are skipped (a --snp-only index has none) and haplotypes are unused
+// (use_haplotype = false, hisat2.cpp:522).  The reference window needs no buffers: rfseq[i] is always the base of text
+// `tidx` at rfoff + i (4 outside the text), which RefCursor serves directly.
+#define H2G_AWA_DEPTH 12
+struct AwaFrame {
+	uint32_t joinedOff, rdoff_add, rdoff, rdlen, rflen, tmp_numNs, orig_nedits, next_rdlen, rd_i, max_rd_i, dep;
+	int32_t  rfoff, a_first, a_second, min_rd_i;
+	uint32_t state;   // 0 entry, 1 loop, 2 after call
+};
+struct AwaWS {
+	h2g_edit tmp[H2G_MAX_EDITS];
+	uint32_t ntmp;
+	AwaFrame fr[H2G_AWA_DEPTH];
+};
+
+H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t joinedOff0, uint32_t base_rdoff,
+                                uint32_t rdoff0, uint32_t rdlen0, uint32_t tidx, int rfoff0, uint32_t rflen0, bool left,
+                                h2g_ghit* h, uint32_t mm, uint32_t* numNs, AwaWS* W)
+{
+	if(numNs) *numNs = 0;
+	const uint32_t nedits0 = h->nedits;
+	W->ntmp = nedits0;
+	for(uint32_t k = 0; k < nedits0; k++) W->tmp[k] = h->edits[k];
+	int best_rdoff = (int)rdoff0;
+	uint32_t numALTsTried = 0;
+	const uint32_t contig_len = ref.refLens[tidx];
+	RefCursor rc;
+	rc.init(&ref, tidx);
+#define AWA_RF(F, I) ((int64_t)(F).rfoff + (int64_t)(I) < 0 ? 4 : rc.get((int64_t)(F).rfoff + (int64_t)(I)))
+#define AWA_PUSH_FRONT(E) do { if(W->ntmp >= H2G_MAX_EDITS) h->overflow = 1; else { for(int q_ = (int)W->ntmp - 1; q_ >= 0; q_--) W->tmp[q_ + 1] = W->tmp[q_]; W->tmp[0] = (E); W->ntmp++; } } while(0)
+#define AWA_PUSH_BACK(E) do { if(W->ntmp >= H2G_MAX_EDITS) h->overflow = 1; else W->tmp[W->ntmp++] = (E); } while(0)
+#define AWA_ERASE_FRONT(N) do { const uint32_t n_ = (N); for(uint32_t q_ = n_; q_ < W->ntmp; q_++) W->tmp[q_ - n_] = W->tmp[q_]; W->ntmp -= n_; } while(0)
+#define AWA_COMMIT() do { for(uint32_t q_ = 0; q_ < W->ntmp; q_++) h->edits[q_] = W->tmp[q_]; h->nedits = W->ntmp; } while(0)
+#define AWA_RETURN(V) do { ret = (V); sp--; goto next_frame; } while(0)
+	int sp = 0;
+	uint32_t ret = 0;
+	{
+		AwaFrame& f = W->fr[0];
+		f.joinedOff = joinedOff0; f.rdoff_add = rdoff0 - base_rdoff; f.rdoff = rdoff0; f.rdlen = rdlen0; f.rfoff = rfoff0; f.rflen = rflen0;
+		f.tmp_numNs = 0; f.dep = 0; f.state = 0;
+	}
+	while(sp >= 0) {
+		{
+		AwaFrame& f = W->fr[sp];
+		if(f.state == 0) {
+			if(numALTsTried > A.maxAltsTried + f.dep) AWA_RETURN(0);
+			if(f.rfoff < -16) AWA_RETURN(0);
+			if((int64_t)f.rfoff >= (int64_t)contig_len) AWA_RETURN(0);
+			if(f.rfoff >= 0 && (uint64_t)f.rfoff + f.rflen > contig_len) f.rflen = contig_len - (uint32_t)f.rfoff;
+			else if(f.rfoff < 0 && f.rflen > contig_len) f.rflen = contig_len;
+			if(f.rflen == 0) AWA_RETURN(0);
+			if(left) {
+				uint32_t tmp_mm = 0, mm_tmp_numNs = 0;
+				int min_rd_i = (int)f.rdoff, mm_min_rd_i = (int)f.rdoff;
+				for(int rf_i = (int)f.rflen - 1; rf_i >= 0 && mm_min_rd_i >= 0; rf_i--, mm_min_rd_i--) {
+					const int rf_bp = AWA_RF(f, rf_i), rd_bp = seq.at((uint32_t)mm_min_rd_i);
+					if(rf_bp != rd_bp || rd_bp == 4) {
+						if(tmp_mm == 0) min_rd_i = mm_min_rd_i;
+						if(tmp_mm >= mm) break;
+						tmp_mm++;
+						h2g_edit e; e.pos = (uint32_t)mm_min_rd_i; e.chr = base_char(rf_bp); e.qchr = base_char(rd_bp); e.type = H2G_EDIT_MM; e.pad = 0; e.snp = H2G_MAX;
+						AWA_PUSH_FRONT(e);
+					}
+					if(rf_bp == 4) { if(tmp_mm == 0) f.tmp_numNs++; mm_tmp_numNs++; }
+				}
+				if(tmp_mm == 0) min_rd_i = mm_min_rd_i;
+				if(mm_min_rd_i < best_rdoff) { best_rdoff = mm_min_rd_i; AWA_COMMIT(); if(numNs) *numNs = mm_tmp_numNs; }
+				if(mm_min_rd_i < 0) AWA_RETURN(f.rdlen);
+				if(tmp_mm > 0) AWA_ERASE_FRONT(tmp_mm);
+				f.min_rd_i = min_rd_i;
+				f.a_first = 0; f.a_second = 0;
+				if(A.n > 0) {
+					uint32_t rd_diff = f.rdoff - (uint32_t)mm_min_rd_i;
+					rd_diff = rd_diff > 16 ? rd_diff - 16 : 0;
+					const uint32_t cpos = rd_diff >= f.joinedOff ? f.joinedOff : f.joinedOff - rd_diff;
+					f.a_first = f.a_second = (int)alt_lobound(A, cpos);
+					if(f.a_first >= (int)A.n) f.a_first = f.a_second = f.a_second - 1;
+					for(; f.a_first >= 0; f.a_first--) {
+						const DAlt alt = A.a[f.a_first];
+						if(alt.type == H2G_ALT_SNP_SGL || alt.type == H2G_ALT_SNP_DEL || alt.type == H2G_ALT_SNP_INS) {
+							if(alt.type == H2G_ALT_SNP_DEL && !(alt.seq & 0xff)) continue;
+							if((uint64_t)alt.pos + f.rdlen < f.joinedOff) break;
+						} else if(alt.type == H2G_ALT_SPLICESITE) {
+							if(alt.pos < alt.len) continue;
+							if((uint64_t)alt.pos + f.rdlen - 1 < f.joinedOff) break;
+						} else continue;
+					}
+				}
+				f.orig_nedits = W->ntmp;
+				f.state = 1;
+			} else {
+				uint32_t tmp_mm = 0, max_rd_i = 0, mm_max_rd_i = 0, mm_tmp_numNs = 0;
+				for(uint32_t rf_i = 0; rf_i < f.rflen && mm_max_rd_i < f.rdlen; rf_i++, mm_max_rd_i++) {
+					const int rf_bp = AWA_RF(f, rf_i), rd_bp = seq.at(f.rdoff + mm_max_rd_i);
+					if(rf_bp != rd_bp || rd_bp == 4) {
+						if(tmp_mm == 0) max_rd_i = mm_max_rd_i;
+						if(tmp_mm >= mm) break;
+						tmp_mm++;
+						h2g_edit e; e.pos = mm_max_rd_i + f.rdoff_add; e.chr = base_char(rf_bp); e.qchr = base_char(rd_bp); e.type = H2G_EDIT_MM; e.pad = 0; e.snp = H2G_MAX;
+						AWA_PUSH_BACK(e);
+					}
+					if(rf_bp == 4) { if(tmp_mm == 0) f.tmp_numNs++; mm_tmp_numNs++; }
+				}
+				if(tmp_mm == 0) max_rd_i = mm_max_rd_i;
+				if((int)(mm_max_rd_i + f.rdoff) > best_rdoff) { best_rdoff = (int)(mm_max_rd_i + f.rdoff); AWA_COMMIT(); if(numNs) *numNs = mm_tmp_numNs; }
+				if(mm_max_rd_i == f.rflen) AWA_RETURN(mm_max_rd_i);
+				if(A.n == 0) AWA_RETURN(0);
+				const uint32_t rd_diff = max_rd_i > 16 ? max_rd_i - 16 : 0;
+				uint32_t a1 = alt_lobound(A, f.joinedOff + rd_diff), a2 = a1;
+				if(a1 >= A.n) AWA_RETURN(0);
+				for(; a2 < A.n; a2++) {
+					const DAlt alt = A.a[a2];
+					if(alt.type == H2G_ALT_SPLICESITE) { if(alt.pos > alt.len) continue; }
+					if(alt.type == H2G_ALT_SNP_DEL) { if(alt.seq & 0xff) continue; }
+					if(alt.pos > f.joinedOff + max_rd_i) break;
+				}
+				if(mm_max_rd_i == f.rdlen) AWA_RETURN(mm_max_rd_i);     // no splice-site ALTs to search further for
+				if(tmp_mm > 0) W->ntmp -= tmp_mm;
+				f.max_rd_i = max_rd_i;
+				f.a_first = (int)a1; f.a_second = (int)a2;
+				f.orig_nedits = W->ntmp;
+				f.state = 1;
+			}
+		} else if(f.state == 2) {                                // back from the recursive call
+			if(left) {
+				if(ret == f.next_rdlen) AWA_RETURN(f.rdlen);
+				if(f.orig_nedits < W->ntmp) AWA_ERASE_FRONT(W->ntmp - f.orig_nedits);
+				f.a_second--;
+			} else {
+				if(ret > 0 && f.rd_i + ret == f.rdlen) AWA_RETURN(f.rd_i + ret);
+				if(f.orig_nedits < W->ntmp) W->ntmp = f.orig_nedits;
+				f.a_first++;
+			}
+			f.state = 1;
+		}
+		// state 1: the loop over candidate ALTs
+		if(left) {
+			for(; f.a_second > f.a_first; f.a_second--) {
+				DAlt alt = A.a[f.a_second];
+				if(alt.pos >= f.joinedOff) continue;
+				if(alt.type == H2G_ALT_SPLICESITE || alt.type == H2G_ALT_EXON) continue;
+				if(alt.type == H2G_ALT_SNP_DEL) {
+					if(!(alt.seq & 0xff)) continue;
+					alt.pos = alt.pos - alt.len + 1;
+				}
+				bool alt_compatible = false;
+				int rf_i = (int)f.rflen - 1, rd_i = (int)f.rdoff, diff = 0;
+				if(alt.type == H2G_ALT_SNP_SGL) diff = (int)(f.joinedOff - alt.pos - 1);
+				else if(alt.type == H2G_ALT_SNP_DEL) {
+					if(alt.pos + alt.len >= f.joinedOff) continue;
+					diff = (int)(f.joinedOff - (alt.pos + alt.len));
+				} else if(alt.type == H2G_ALT_SNP_INS) diff = (int)(f.joinedOff - alt.pos);
+				else continue;
+				if(rf_i < diff || rd_i < diff) continue;
+				rf_i -= diff; rd_i -= diff;
+				int rd_bp = seq.at((uint32_t)rd_i);
+				if(rd_i < f.min_rd_i) {
+					if(alt.type == H2G_ALT_SNP_INS) { if(rd_i + 1 >= f.min_rd_i) continue; }
+					break;
+				}
+				if(alt.type == H2G_ALT_SNP_SGL) {
+					if(rd_bp == (int)alt.seq) {
+						const int rf_bp = AWA_RF(f, rf_i);
+						h2g_edit e; e.pos = (uint32_t)rd_i; e.chr = base_char(rf_bp); e.qchr = base_char(rd_bp); e.type = H2G_EDIT_MM; e.pad = 0; e.snp = (uint32_t)f.a_second;
+						AWA_PUSH_FRONT(e);
+						rd_i--; rf_i--;
+						alt_compatible = true;
+					}
+				} else if(alt.type == H2G_ALT_SNP_DEL) {
+					if(f.rfoff + rf_i > (int)alt.len) {
+						// the "long deletion" refetch of the reference (:2986-3008) reads the same text positions: rfoff + rf_i - i
+						for(uint32_t i = 0; i < alt.len; i++) {
+							const int rf_bp = AWA_RF(f, rf_i - (int)i);
+							h2g_edit e; e.pos = (uint32_t)(rd_i + 1); e.chr = base_char(rf_bp); e.qchr = '-'; e.type = H2G_EDIT_READ_GAP; e.pad = 0; e.snp = (uint32_t)f.a_second;
+							AWA_PUSH_FRONT(e);
+						}
+						rf_i -= (int)alt.len;
+						alt_compatible = true;
+					}
+				} else {
+					if(rd_i > (int)alt.len) {
+						bool same_seq = true;
+						for(uint32_t i = 0; i < alt.len; i++) {
+							rd_bp = seq.at((uint32_t)(rd_i - (int)i));
+							const int snp_bp = (int)((alt.seq >> (i << 1)) & 3);
+							if(rd_bp != snp_bp) { same_seq = false; break; }
+							h2g_edit e; e.pos = (uint32_t)(rd_i - (int)i); e.chr = '-'; e.qchr = base_char(rd_bp); e.type = H2G_EDIT_REF_GAP; e.pad = 0; e.snp = (uint32_t)f.a_second;
+							AWA_PUSH_FRONT(e);
+						}
+						if(same_seq) { rd_i -= (int)alt.len; alt_compatible = true; }
+					}
+				}
+				if(alt_compatible) {
+					numALTsTried++;
+					if(rd_i < 0) { best_rdoff = rd_i; AWA_COMMIT(); AWA_RETURN(f.rdlen); }
+					int next_rfoff = f.rfoff, next_rflen = rf_i + 1, next_rdlen = rd_i + 1;
+					if(next_rflen < next_rdlen) {
+						int add_len = next_rdlen + 10 - next_rflen;
+						if(next_rfoff < add_len) add_len = next_rfoff;
+						next_rfoff -= add_len; next_rflen += add_len;
+					}
+					if(sp + 1 >= H2G_AWA_DEPTH) { h->overflow = 1; }
+					else {
+						AwaFrame& nf = W->fr[sp + 1];
+						nf.joinedOff = alt.pos; nf.rdoff_add = f.rdoff_add; nf.rdoff = (uint32_t)rd_i; nf.rdlen = (uint32_t)next_rdlen;
+						nf.rfoff = next_rfoff; nf.rflen = (uint32_t)next_rflen; nf.tmp_numNs = f.tmp_numNs; nf.dep = f.dep + 1; nf.state = 0;
+						f.next_rdlen = (uint32_t)next_rdlen;
+						f.state = 2;
+						sp++;
+						goto next_frame;
+					}
+				}
+				if(f.orig_nedits < W->ntmp) AWA_ERASE_FRONT(W->ntmp - f.orig_nedits);
+			}
+			AWA_RETURN(0);
+		} else {
+			for(; f.a_first < f.a_second; f.a_first++) {
+				const DAlt alt = A.a[f.a_first];
+				if(alt.type == H2G_ALT_SPLICESITE || alt.type == H2G_ALT_EXON) continue;
+				if(alt.type == H2G_ALT_SNP_DEL) { if(alt.seq & 0xff) continue; }
+				bool alt_compatible = false;
+				uint32_t rf_i, rd_i;
+				rf_i = rd_i = alt.pos - f.joinedOff;
+				if(rd_i >= f.rdlen) continue;
+				int rf_bp = AWA_RF(f, rf_i), rd_bp = seq.at(f.rdoff + rd_i);
+				if(alt.type == H2G_ALT_SNP_SGL) {
+					if(rd_bp == (int)alt.seq) {
+						h2g_edit e; e.pos = rd_i + f.rdoff_add; e.chr = base_char(rf_bp); e.qchr = base_char(rd_bp); e.type = H2G_EDIT_MM; e.pad = 0; e.snp = (uint32_t)f.a_first;
+						AWA_PUSH_BACK(e);
+						rd_i++; rf_i++;
+						alt_compatible = true;
+					}
+				} else if(alt.type == H2G_ALT_SNP_DEL) {
+					bool try_del = rd_i > 0;
+					if(rd_i == 0 && f.dep > 0) { if(W->ntmp > 0 && W->tmp[W->ntmp - 1].type != H2G_EDIT_READ_GAP) try_del = true; }
+					if(try_del) {
+						// (:3352-3392: the long-deletion refetch reads the same text positions rfoff + rf_i + i)
+						for(uint32_t i = 0; i < alt.len; i++) {
+							rf_bp = AWA_RF(f, rf_i + i);
+							h2g_edit e; e.pos = rd_i + f.rdoff_add; e.chr = base_char(rf_bp); e.qchr = '-'; e.type = H2G_EDIT_READ_GAP; e.pad = 0; e.snp = (uint32_t)f.a_first;
+							AWA_PUSH_BACK(e);
+						}
+						rf_i += alt.len;
+						alt_compatible = true;
+					}
+				} else if(alt.type == H2G_ALT_SNP_INS) {
+					if(rd_i + alt.len <= f.rdlen && rf_i > 0) {
+						bool same_seq = true;
+						for(uint32_t i = 0; i < alt.len; i++) {
+							rd_bp = seq.at(f.rdoff + rd_i + i);
+							const int snp_bp = (int)((alt.seq >> ((alt.len - i - 1) << 1)) & 3);
+							if(rd_bp != snp_bp) { same_seq = false; break; }
+							h2g_edit e; e.pos = rd_i + i + f.rdoff_add; e.chr = '-'; e.qchr = base_char(rd_bp); e.type = H2G_EDIT_REF_GAP; e.pad = 0; e.snp = (uint32_t)f.a_first;
+							AWA_PUSH_BACK(e);
+						}
+						if(same_seq) { rd_i += alt.len; alt_compatible = true; }
+					}
+				}
+				if(alt_compatible) {
+					numALTsTried++;
+					if(rd_i == f.rdlen) { best_rdoff = (int)(f.rdoff + rd_i); AWA_COMMIT(); AWA_RETURN(rd_i); }
+					uint32_t next_joinedOff;
+					uint32_t next_rflen = f.rflen - rf_i;
+					const uint32_t next_rdlen = f.rdlen - rd_i;
+					if(alt.type == H2G_ALT_SNP_SGL) next_joinedOff = alt.pos + 1;
+					else if(alt.type == H2G_ALT_SNP_DEL) { next_joinedOff = alt.pos + alt.len; if(f.rflen <= rf_i) next_rflen = 0; }
+					else next_joinedOff = alt.pos;
+					if(next_rflen < next_rdlen) next_rflen = next_rdlen + 10;
+					if(sp + 1 >= H2G_AWA_DEPTH) { h->overflow = 1; }
+					else {
+						AwaFrame& nf = W->fr[sp + 1];
+						nf.joinedOff = next_joinedOff; nf.rdoff_add = f.rdoff_add + rd_i; nf.rdoff = f.rdoff + rd_i; nf.rdlen = next_rdlen;
+						nf.rfoff = f.rfoff + (int)rf_i; nf.rflen = next_rflen; nf.tmp_numNs = f.tmp_numNs; nf.dep = f.dep + 1; nf.state = 0;
+						f.rd_i = rd_i;
+						f.state = 2;
+						sp++;
+						goto next_frame;
+					}
+				}
+				if(f.orig_nedits < W->ntmp) W->ntmp = f.orig_nedits;
+			}
+			AWA_RETURN(0);
+		}
+		}
+	next_frame:;
+	}
+#undef AWA_RF
+#undef AWA_PUSH_FRONT
+#undef AWA_PUSH_BACK
+#undef AWA_ERASE_FRONT
+#undef AWA_COMMIT
+#undef AWA_RETURN
+	// alignWithALTs :741-783
+	uint32_t extlen = left ? rdoff0 - (uint32_t)best_rdoff : (uint32_t)best_rdoff - rdoff0;
+	const uint32_t ne = h->nedits;
+	if(extlen > 0 && ne > 0) {
+		const h2g_edit f = h->edits[0];
+		if(f.pos + extlen == base_rdoff + 1) {
+			if(is_gap(f.type)) extlen = 0;
+			if(f.type == H2G_EDIT_MM && f.chr == 'N') extlen = 0;
+		}
+		const h2g_edit b = h->edits[ne - 1];
+		if(extlen > 0 && b.pos == rdoff0 - base_rdoff + extlen - 1) {
+			if(is_gap(b.type)) extlen = 0;
+		}
+		if(extlen == 0 && ne > nedits0) {
+			if(left) for(uint32_t k = 0; k < nedits0; k++) h->edits[k] = h->edits[k + (ne - nedits0)];
+			h->nedits = nedits0;
+		}
+	}
+	return extlen;
+}
+
+// GenomeHit::extend hi_aligner.h:2031-2232 on a graph index (same bookkeeping as extend_item, ALT-aware alignment)
+H2G_HD bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& sc, const SeqView& seq, h2g_ghit* h, uint32_t mm,
+                             uint32_t max_leftext, uint32_t max_rightext, uint32_t* leftext, uint32_t* rightext, AwaWS* W)
+{
+	const uint32_t rdlen = seq.len;
+	*leftext = 0; *rightext = 0;
+	if(max_leftext > 0 && h->rdoff > 0) {
+		if(h->toff <= 0) return false;
+		int rl = (int)h->toff - (int)h->rdoff;
+		uint32_t reflen = h->rdoff + 10;
+		rl -= (int)(reflen - h->rdoff);
+		if(rl < 0) { reflen += rl; rl = 0; }
+		uint32_t numNs = 0;
+		const uint32_t n_prev = h->nedits;
+		const uint32_t best_ext = align_with_alts(ref, A, seq, h->joinedOff, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx, rl, reflen, true, h, mm, &numNs, W);
+		if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return false; }
+		if(best_ext > 0) {
+			*leftext = best_ext;
+			const uint32_t added = h->nedits - n_prev;
+			int ref_ext = (int)best_ext;
+			for(uint32_t i = 0; i < added; i++) {
+				if(h->edits[i].type == H2G_EDIT_REF_GAP) ref_ext--;
+				else if(h->edits[i].type == H2G_EDIT_READ_GAP) ref_ext++;
+			}
+			h->rdoff -= best_ext;
+			h->toff -= (uint32_t)ref_ext;
+			h->len += best_ext;
+			h->joinedOff -= (uint32_t)(ref_ext - (int)numNs);
+			for(uint32_t i = 0; i < h->nedits; i++) {
+				if(i < added) h->edits[i].pos -= h->rdoff;
+				else h->edits[i].pos += best_ext;
+			}
+		}
+	}
+	if(max_rightext > 0 && h->rdoff + h->len < rdlen) {
+		uint32_t r_rdoff, r_len, r_toff;
+		hit_get_right(h, &r_rdoff, &r_len, &r_toff);
+		const uint32_t rl = r_toff + r_len;
+		const uint32_t rr = rdlen - (r_rdoff + r_len);
+		const uint32_t tlen = ref.refLens[h->tidx];
+		if(rl < tlen) {
+			uint32_t reflen = rr + 10;
+			if(rl + reflen > tlen) reflen = tlen - rl;
+			int ref_ext = (int)h->len;
+			for(uint32_t ei = 0; ei < h->nedits; ei++) {
+				const h2g_edit e = h->edits[ei];
+				if(e.type == H2G_EDIT_REF_GAP) ref_ext--;
+				else if(e.type == H2G_EDIT_READ_GAP) ref_ext++;
+				else if(e.type == H2G_EDIT_MM && e.chr == 'N') ref_ext--;
+			}
+			const uint32_t best_ext = align_with_alts(ref, A, seq, h->joinedOff + (uint32_t)ref_ext, h->rdoff, h->rdoff + h->len,
+			                                          rdlen - (h->rdoff + h->len), h->tidx, (int)rl, reflen, false, h, mm, nullptr, W);
+			if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return false; }
+			if(best_ext > 0) { *rightext = best_ext; h->len += best_ext; }
+		}
+	}
+	calculate_score(sc, seq, h);
+	return *leftext > 0 || *rightext > 0;
+}
+
 }  // namespace h2g

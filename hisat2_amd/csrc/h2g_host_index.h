@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace h2g {
@@ -62,7 +63,11 @@ struct HostRef {  // BitPairReference
 	uint32_t nrefs = 0;
 };
 
+// ALT (alt.h:41-120); same layout as the device DAlt (h2g_graph.h)
+struct HostAlt { uint32_t pos, type, len, pad; uint64_t seq; };
+
 struct HostIndex {
+	std::vector<HostAlt> alts;          // ALTDB::alts() as GFM::GFM leaves it (gfm.h:728-905)
 	HostGfm g;
 	HostRef r;
 	std::vector<HostGfm> local;
@@ -189,6 +194,38 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 				if(b6.bad) return -2;
 			}
 			while(ix.local_first.size() <= ix.g.nPat) ix.local_first.push_back(nlocal);
+		}
+	}
+	// .7.ht2: ALTs (gfm.h:728-905).  Every deletion gets a reversed copy (pos = last deleted base, low byte of seq = 1),
+	// every splice site a mirrored copy, then the list is sorted by (ALT::operator< alt.h:88-102, original index).
+	{
+		Reader b7;
+		ix.alts.clear();
+		if(b7.open(base + ".7.ht2") && b7.d.size() >= 8) {
+			b7.u32();
+			const uint32_t n = b7.u32();
+			std::vector<std::pair<HostAlt, uint32_t> > v;
+			for(uint32_t i = 0; i < n && b7.has(20); i++) {
+				HostAlt a;
+				a.pos = b7.u32(); a.type = b7.u32(); a.len = b7.u32(); a.pad = 0;
+				memcpy(&a.seq, &b7.d[b7.pos], 8); b7.pos += 8;
+				v.push_back(std::make_pair(a, (uint32_t)v.size()));
+			}
+			const size_t n0 = v.size();
+			for(size_t i = 0; i < n0; i++) {
+				HostAlt a = v[i].first;
+				if(a.type == 3) { a.pos = a.pos + a.len - 1; a.seq = (a.seq & ~0xffull) | 1; v.push_back(std::make_pair(a, (uint32_t)v.size())); }
+				else if(a.type == 5) { std::swap(a.pos, a.len); v.push_back(std::make_pair(a, (uint32_t)v.size())); }
+			}
+			std::sort(v.begin(), v.end(), [](const std::pair<HostAlt, uint32_t>& x, const std::pair<HostAlt, uint32_t>& y) {
+				const HostAlt &a = x.first, &b = y.first;
+				if(a.pos != b.pos) return a.pos < b.pos;
+				if(a.type != b.type) { if(a.type == 2) return true; if(b.type == 2) return false; return a.type < b.type; }
+				if(a.len != b.len) return a.len < b.len;
+				if(a.seq != b.seq) return a.seq < b.seq;
+				return x.second < y.second;
+			});
+			for(auto& e : v) ix.alts.push_back(e.first);
 		}
 	}
 	uint32_t gl = ix.g.p.len;

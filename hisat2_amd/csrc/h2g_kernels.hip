@@ -35,6 +35,7 @@ struct h2g_index {
 	DGfm dg;
 	DRef dr;
 	DLocalSet dls;
+	DAlts dalts;
 	bool has_local = false;
 	std::vector<void*> allocs;
 	uint64_t device_bytes = 0;
@@ -131,6 +132,14 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	if((s = upload(ix, r.buf, &ix->dr.buf)) || (s = upload(ix, r.rec_start, &ix->dr.rec_start)) ||
 	   (s = upload(ix, r.rec_len, &ix->dr.rec_len)) || (s = upload(ix, r.rec_bufoff, &ix->dr.rec_bufoff)) ||
 	   (s = upload(ix, r.refRecOffs, &ix->dr.refRecOffs)) || (s = upload(ix, r.refLens, &ix->dr.refLens))) { h2g_index_free(ix); return s; }
+	static_assert(sizeof(HostAlt) == sizeof(DAlt), "HostAlt mirrors DAlt");
+	ix->dalts.a = nullptr; ix->dalts.n = 0; ix->dalts.maxAltsTried = 16;      // --max-altstried default hisat2.cpp:521
+	if(!g.p.linear && !ix->host.alts.empty()) {
+		const HostAlt* da = nullptr;
+		if((s = upload(ix, ix->host.alts, &da))) { h2g_index_free(ix); return s; }
+		ix->dalts.a = reinterpret_cast<const DAlt*>(da);
+		ix->dalts.n = (uint32_t)ix->host.alts.size();
+	}
 	memset(&ix->dls, 0, sizeof ix->dls);
 	if(o.load_local && !ix->host.local.empty() && g.p.linear) {
 		LocalPack lp;
@@ -652,6 +661,21 @@ __global__ __launch_bounds__(256) void k_extend(DRef ref, DReads rd, DScoring sc
 	}
 }
 
+// graph index: GenomeHit::extend through the ALT database (known SNPs / insertions / deletions)
+__global__ __launch_bounds__(256) void k_extend_alts(DRef ref, DAlts alts, DReads rd, DScoring sc, h2g_ghit* hits, const h2g_ext_args* args,
+                                                     size_t n, h2g_ext_result* res, AwaWS* scratch)
+{
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	AwaWS* W = scratch + tid;
+	for(size_t i = tid; i < n; i += stride) {
+		h2g_ghit* h = &hits[i];
+		SeqView sv = seq_view(rd, h->read, h->fw != 0);
+		uint32_t le = 0, re = 0;
+		bool ext = extend_item_alts(ref, alts, sc, sv, h, args[i].mm, args[i].max_leftext, args[i].max_rightext, &le, &re, W);
+		res[i].extended = ext; res[i].leftext = le; res[i].rightext = re;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_graph_lf(DGfm g, const h2g_glf_query* q, size_t n, uint32_t k, h2g_glf_result* res, h2g_iedges* ie)
 {
 	size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -937,7 +961,9 @@ extern "C" h2g_status h2g_sa_resolve(h2g_stream* s, const h2g_sa_query* q, size_
 extern "C" h2g_status h2g_extend(h2g_stream* s, h2g_ghit* hits, const h2g_ext_args* args, size_t n, h2g_ext_result* res) {
 	if(!s || !hits || !args || !res || n == 0) return H2G_ERR_ARG;
 	int rc;
-	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	if((rc = need_reads(s))) return rc;
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	const bool graph = !s->ix->dg.linear;
 	for(size_t i = 0; i < n; i++) {
 		if(hits[i].read >= s->n_reads || hits[i].tidx >= s->ix->dr.nrefs || hits[i].nedits > H2G_MAX_EDITS) return H2G_ERR_ARG;
 	}
@@ -948,6 +974,13 @@ extern "C" h2g_status h2g_extend(h2g_stream* s, h2g_ghit* hits, const h2g_ext_ar
 	HIPCHK(hipMemcpyAsync(dh, hits, n * sizeof *hits, hipMemcpyHostToDevice, s->st));
 	HIPCHK(hipMemcpyAsync(da, args, n * sizeof *args, hipMemcpyHostToDevice, s->st));
 	DScoring sc;
+	if(graph) {
+		const unsigned grid = grid_for(n, 256) > 256 ? 256 : grid_for(n, 256);
+		void* dscr;
+		if((rc = tmp_buf(s, 3, (size_t)grid * 256 * sizeof(AwaWS), &dscr))) return rc;
+		hipLaunchKernelGGL(k_extend_alts, dim3(grid), dim3(256), 0, s->st, s->ix->dr, s->ix->dalts, dreads(s), sc, (h2g_ghit*)dh,
+		                   (const h2g_ext_args*)da, n, (h2g_ext_result*)dres, (AwaWS*)dscr);
+	} else
 	hipLaunchKernelGGL(k_extend, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dr, dreads(s), sc, (h2g_ghit*)dh, (const h2g_ext_args*)da, n, (h2g_ext_result*)dres);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(hits, dh, n * sizeof *hits, hipMemcpyDeviceToHost, s->st));

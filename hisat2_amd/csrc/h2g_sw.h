@@ -344,7 +344,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 			else o->overflow = 1;
 			ncells++;
 			h2g_edit ed;
-			ed.pad = 0;
+			ed.pad = 0; ed.snp = H2G_MAX;
 			bool has_edit = true;
 			if(cur == 0) {                                     // SW_BT_OALL_DIAG
 				const int mt = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
@@ -380,7 +380,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 			const int mt = (refm >= 16 || readc > 3) ? -1 : ((refm >> readc) & 1);
 			if(mt != 1) {
 				h2g_edit ed;
-				ed.pad = 0; ed.pos = row; ed.chr = (uint8_t)sw_mask2dna(refm); ed.qchr = (uint8_t)"ACGTN"[readc]; ed.type = H2G_EDIT_MM;
+				ed.pad = 0; ed.snp = H2G_MAX; ed.pos = row; ed.chr = (uint8_t)sw_mask2dna(refm); ed.qchr = (uint8_t)"ACGTN"[readc]; ed.type = H2G_EDIT_MM;
 				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed; else o->overflow = 1;
 				ned++;
 				score -= (readc > 3 || refm > 15) ? P.sc.nPen : mm_penalty(P.sc, seq.qual(row) - 33);

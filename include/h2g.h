@@ -149,7 +149,7 @@ H2G_EXPORT h2g_status h2g_sa_resolve_graph(h2g_stream*, const h2g_gsa_query* q, 
 /* GenomeHit::extend (hi_aligner.h:2031-2232) incl. alignWithALTs (:683) and calculateScore (:3711) */
 #define H2G_MAX_EDITS 48
 enum { H2G_EDIT_READ_GAP = 1, H2G_EDIT_REF_GAP = 2, H2G_EDIT_MM = 3 };  /* edit.h:37-39 */
-typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; } h2g_edit;   /* Edit, edit.h */
+typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; uint32_t snp; /* Edit::snpID: index into the ALT list, H2G_MAX = none */ } h2g_edit;   /* Edit, edit.h */
 typedef struct {
 	uint32_t read;
 	uint32_t fw, rdoff, len, trim5, trim3, tidx, toff, joinedOff;

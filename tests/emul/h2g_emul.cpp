@@ -24,6 +24,7 @@ struct Emu {
 	bool has_quals = false;
 	LocalPack lp;
 	DLocalSet dls;
+	DAlts dalts;
 	uint32_t bowtie2_dp = 0;
 	std::vector<uint8_t> sw;
 	DReads reads() const {
@@ -54,6 +55,8 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dr.buf = r.buf.data(); e->dr.rec_start = r.rec_start.data(); e->dr.rec_len = r.rec_len.data();
 	e->dr.rec_bufoff = r.rec_bufoff.data(); e->dr.refRecOffs = r.refRecOffs.data(); e->dr.refLens = r.refLens.data();
 	e->dr.nrefs = r.nrefs;
+	e->dalts.a = reinterpret_cast<const DAlt*>(e->host.alts.data()); e->dalts.n = g.p.linear ? 0 : (uint32_t)e->host.alts.size();
+	e->dalts.maxAltsTried = 16;
 	if(g.p.linear) pack_local(e->host, e->lp);
 	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data());
 	*out = e;
@@ -153,7 +156,12 @@ void h2gemu_extend(Emu* e, h2g_ghit* hits, const h2g_ext_args* args, size_t n, h
 	for(size_t i = 0; i < n; i++) {
 		SeqView sv = seq_view(rd, hits[i].read, hits[i].fw != 0);
 		uint32_t le = 0, re = 0;
-		bool ext = extend_item(e->dr, sc, sv, &hits[i], args[i].mm, args[i].max_leftext, args[i].max_rightext, &le, &re);
+		bool ext;
+		if(e->dg.linear) ext = extend_item(e->dr, sc, sv, &hits[i], args[i].mm, args[i].max_leftext, args[i].max_rightext, &le, &re);
+		else {
+			static AwaWS W;
+			ext = extend_item_alts(e->dr, e->dalts, sc, sv, &hits[i], args[i].mm, args[i].max_leftext, args[i].max_rightext, &le, &re, &W);
+		}
 		res[i].extended = ext; res[i].leftext = le; res[i].rightext = re;
 	}
 }

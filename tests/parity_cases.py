@@ -293,3 +293,27 @@ def check_graph_coords(be, golden_dir, fn):
         assert [(co[i * cap + k].tidx, co[i * cap + k].toff, co[i * cap + k].joinedOff) for k in range(len(want))] == want, (top, bot)
         nmulti += len(want) > 1
     return len(cases), nmulti
+
+
+def check_graph_extend(be, golden_dir):
+    """GenomeHit::extend on the graph index: ALT-aware (edit strings carry type and snpID)"""
+    hits, args, want = [], [], []
+    for l in H.glines(golden_dir, "probe_g1s_extend.txt.gz"):
+        lhs, rhs = l.split(" -> ")
+        rid, fw, rdoff, hlen, tidx, toff, joff, mm = map(int, lhs.split())
+        h = api.GHit()
+        h.read, h.fw, h.rdoff, h.len, h.tidx, h.toff, h.joinedOff = rid, fw, rdoff, hlen, tidx, toff, joff
+        hits.append(h)
+        args.append(api.ExtArgs(mm, api.MAX, api.MAX))
+        want.append(rhs.split())
+    out, res = be.extend(hits, args)
+    nsnp = 0
+    for h, r, w in zip(out, res, want):
+        got = [r.extended, h.rdoff, h.len, h.toff, h.joinedOff, r.leftext, r.rightext, h.score, h.nedits]
+        assert got == list(map(int, w[:9])), (got, w)
+        eds = [f"{h.edits[k].pos}:{chr(h.edits[k].chr)}>{chr(h.edits[k].qchr)}:{h.edits[k].type}:{-1 if h.edits[k].snp == api.MAX else h.edits[k].snp}"
+               for k in range(h.nedits)]
+        assert eds == w[9:] and h.overflow == 0, (eds, w)
+        nsnp += any(not e.endswith(":-1") for e in eds)
+    assert nsnp > 80
+    return len(hits)

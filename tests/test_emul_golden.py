@@ -77,6 +77,10 @@ def test_graph_genome_coords(gemu, golden_dir):
     assert n > 3000 and multi >= 100
 
 
+def test_graph_extend_with_alts(gemu, golden_dir):
+    assert PC.check_graph_extend(gemu, golden_dir) > 1000
+
+
 def test_graph_lf_matches_oracle_on_random_ranges(gemu, oracle_lib, g1s_index):
     """fresh seeded ranges, incl. ranges that straddle sides and tiny ranges around multi-in-edge nodes"""
     import ctypes as C

@@ -231,6 +231,10 @@ def test_graph_genome_coords_golden(ggpu, golden_dir):
     assert n > 3000 and multi >= 100
 
 
+def test_graph_extend_with_alts_golden(ggpu, golden_dir):
+    assert PC.check_graph_extend(ggpu, golden_dir) > 1000
+
+
 def test_graph_lf_vs_oracle_random(ggpu, oracle_lib, g1s_index):
     oix = H.load_index(oracle_lib, g1s_index)
     g = C.byref(oix.contents.g)
