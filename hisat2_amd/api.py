@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libh2g.so")
 MAX = 0xFFFFFFFF
-MAX_EDITS = 48
+MAX_EDITS = 32
 SEED_CAP = 5
 
 u32, u8, i32, u64, i64 = C.c_uint32, C.c_uint8, C.c_int32, C.c_uint64, C.c_int64
@@ -92,7 +92,7 @@ class SwQuery(C.Structure):          # h2g_sw_query
 class SwResult(C.Structure):         # h2g_sw_result
     _fields_ = [("found_align", C.c_int32), ("found", C.c_int32), ("best", C.c_int32), ("score", C.c_int32),
                 ("off", C.c_int64), ("nedits", u32), ("gaps", u32), ("overflow", u32), ("rnd", u32),
-                ("refl", C.c_int64), ("refr", C.c_int64), ("edits", Edit * 48)]
+                ("refl", C.c_int64), ("refr", C.c_int64), ("edits", Edit * MAX_EDITS)]
 
 
 class ExtArgs(C.Structure):

@@ -147,7 +147,7 @@ H2G_EXPORT h2g_status h2g_sa_resolve_graph(h2g_stream*, const h2g_gsa_query* q, 
                                            uint32_t cap_per_query, h2g_coord* coords /* [n*cap] */, h2g_sa_result* res /* [n] */);
 
 /* GenomeHit::extend (hi_aligner.h:2031-2232) incl. alignWithALTs (:683) and calculateScore (:3711) */
-#define H2G_MAX_EDITS 48
+#define H2G_MAX_EDITS 32
 enum { H2G_EDIT_READ_GAP = 1, H2G_EDIT_REF_GAP = 2, H2G_EDIT_MM = 3 };  /* edit.h:37-39 */
 typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; uint32_t snp; /* Edit::snpID: index into the ALT list, H2G_MAX = none */ } h2g_edit;   /* Edit, edit.h */
 typedef struct {

@@ -820,7 +820,14 @@ typedef struct {
 	h2o_edit* best; uint32_t* nbest;                   /* edits */
 	uint32_t* numNs;
 	int overflow;
+	/* candidate_edits (ELList<Edit,128,4>*): alternative edit lists reaching the same best offset; NULL when cand == NULL */
+	h2o_edit (*cand)[H2O_MAX_EDITS]; uint32_t* cand_n; uint32_t ncand, cand_cap;
 } awa_ctx;
+static void awa_cand_push(awa_ctx* x) {
+	if(!x->cand) return;
+	if(x->ncand >= x->cand_cap) { x->overflow = 1; return; }
+	memcpy(x->cand[x->ncand], x->tmp, x->ntmp * sizeof x->tmp[0]); x->cand_n[x->ncand] = x->ntmp; x->ncand++;
+}
 static void awa_push_front(awa_ctx* x, h2o_edit e) { if(x->ntmp >= H2O_MAX_EDITS) { x->overflow = 1; return; } memmove(x->tmp + 1, x->tmp, x->ntmp * sizeof e); x->tmp[0] = e; x->ntmp++; }
 static void awa_push_back(awa_ctx* x, h2o_edit e) { if(x->ntmp >= H2O_MAX_EDITS) { x->overflow = 1; return; } x->tmp[x->ntmp++] = e; }
 static void awa_erase_front(awa_ctx* x, uint32_t n) { memmove(x->tmp, x->tmp + n, (x->ntmp - n) * sizeof x->tmp[0]); x->ntmp -= n; }
@@ -990,7 +997,8 @@ static uint32_t awa_recur(awa_ctx* x, uint32_t joinedOff, uint32_t rdoff_add, ui
 			if(rf_bp == 4) { if(tmp_mm == 0) tmp_numNs++; mm_tmp_numNs++; }
 		}
 		if(tmp_mm == 0) max_rd_i = mm_max_rd_i;
-		if((int)(mm_max_rd_i + rdoff) > x->best_rdoff) { x->best_rdoff = (int)(mm_max_rd_i + rdoff); awa_commit(x); if(x->numNs) *x->numNs = mm_tmp_numNs; }
+		if((int)(mm_max_rd_i + rdoff) > x->best_rdoff) { x->best_rdoff = (int)(mm_max_rd_i + rdoff); awa_commit(x); if(x->numNs) *x->numNs = mm_tmp_numNs; x->ncand = 0; }
+		else if((int)(mm_max_rd_i + rdoff) == x->best_rdoff) awa_cand_push(x);
 		if(mm_max_rd_i == rflen) return mm_max_rd_i;
 		if(ix->nalts == 0) return 0;                               /* bsearchLoBound on an empty list: first >= size */
 		uint32_t a_first, a_second;
@@ -1062,7 +1070,11 @@ static uint32_t awa_recur(awa_ctx* x, uint32_t joinedOff, uint32_t rdoff_add, ui
 			}
 			if(alt_compatible) {
 				x->numALTsTried++;
-				if(rd_i == rdlen) { x->best_rdoff = (int)(rdoff + rd_i); awa_commit(x); return rd_i; }
+				if(rd_i == rdlen) {
+					if(x->best_rdoff < (int)(rdoff + rd_i)) x->ncand = 0;
+					awa_cand_push(x);
+					x->best_rdoff = (int)(rdoff + rd_i); awa_commit(x); return rd_i;
+				}
 				uint32_t next_joinedOff = 0;
 				int next_rfoff = rfoff + (int)rf_i;
 				uint32_t next_rdoff = rdoff + rd_i;
@@ -1082,11 +1094,23 @@ static uint32_t awa_recur(awa_ctx* x, uint32_t joinedOff, uint32_t rdoff_add, ui
 	}
 }
 /* alignWithALTs hi_aligner.h:683-783 */
+static uint32_t align_with_alts_c(const h2o_index* ix, uint32_t joinedOff, const uint8_t* rdseq, uint32_t base_rdoff,
+                                  uint32_t rdoff, uint32_t rdlen, uint32_t tidx, int rfoff, uint32_t rflen, int left,
+                                  h2o_edit* edits, uint32_t* nedits_io, uint32_t mm, uint32_t* numNs,
+                                  h2o_edit (*cand)[H2O_MAX_EDITS], uint32_t* cand_n, uint32_t cand_cap, uint32_t* ncand);
 static uint32_t align_with_alts(const h2o_index* ix, uint32_t joinedOff, const uint8_t* rdseq, uint32_t base_rdoff,
                                 uint32_t rdoff, uint32_t rdlen, uint32_t tidx, int rfoff, uint32_t rflen, int left,
                                 h2o_edit* edits, uint32_t* nedits_io, uint32_t mm, uint32_t* numNs)
 {
+	return align_with_alts_c(ix, joinedOff, rdseq, base_rdoff, rdoff, rdlen, tidx, rfoff, rflen, left, edits, nedits_io, mm, numNs, NULL, NULL, 0, NULL);
+}
+static uint32_t align_with_alts_c(const h2o_index* ix, uint32_t joinedOff, const uint8_t* rdseq, uint32_t base_rdoff,
+                                  uint32_t rdoff, uint32_t rdlen, uint32_t tidx, int rfoff, uint32_t rflen, int left,
+                                  h2o_edit* edits, uint32_t* nedits_io, uint32_t mm, uint32_t* numNs,
+                                  h2o_edit (*cand)[H2O_MAX_EDITS], uint32_t* cand_n, uint32_t cand_cap, uint32_t* ncand)
+{
 	awa_ctx x;
+	x.cand = cand; x.cand_n = cand_n; x.cand_cap = cand_cap; x.ncand = 0;
 	x.ix = ix; x.rdseq = rdseq; x.tidx = tidx; x.mm = mm; x.maxAltsTried = 16; x.numALTsTried = 0; x.left = left;
 	x.best_rdoff = (int)rdoff; x.best = edits; x.nbest = nedits_io; x.numNs = numNs; x.overflow = 0;
 	if(numNs) *numNs = 0;
@@ -1094,6 +1118,7 @@ static uint32_t align_with_alts(const h2o_index* ix, uint32_t joinedOff, const u
 	x.ntmp = nedits;
 	memcpy(x.tmp, edits, nedits * sizeof x.tmp[0]);
 	awa_recur(&x, joinedOff, rdoff - base_rdoff, rdoff, rdlen, NULL, rfoff, rflen, 0, 0, 0);
+	if(ncand) *ncand = x.ncand;
 	uint32_t extlen = left ? rdoff - (uint32_t)x.best_rdoff : (uint32_t)x.best_rdoff - rdoff;
 	uint32_t ne = *nedits_io;
 	if(extlen > 0 && ne > 0) {                                            /* :751-779 */
@@ -1112,6 +1137,112 @@ static uint32_t align_with_alts(const h2o_index* ix, uint32_t joinedOff, const u
 		}
 	}
 	return extlen;
+}
+
+/* findOffDiffs hi_aligner.h:2545-2640: offset differences that indel ALTs near [start, end) can introduce */
+typedef struct { uint32_t first; int second; } offdiff_t;
+static int offdiff_lt(offdiff_t a, offdiff_t b) { return a.first != b.first ? a.first < b.first : a.second < b.second; }
+static uint32_t find_off_diffs(const h2o_index* ix, uint32_t start, uint32_t end, offdiff_t* od, uint32_t cap, uint32_t* nod) {
+	uint32_t n = 0;
+	od[n].first = 0; od[n].second = 0; n++;
+	*nod = n;
+	if(ix->g.p.linear) return n;
+	const h2o_alt* alts = ix->alts;
+	uint32_t a1 = alt_lobound(ix, start), a2 = a1;
+	for(; a2 < ix->nalts; a2++) {
+		const h2o_alt* alt = &alts[a2];
+		if(alt->type == H2O_ALT_SPLICESITE && alt->pos > alt->len) continue;
+		if(alt->type == H2O_ALT_SNP_DEL && (alt->seq & 0xff)) continue;
+		if(alt->pos >= end) break;
+	}
+	if(a1 >= a2) return n;
+#define IS_GAPALT(a) (((a)->type == H2O_ALT_SNP_DEL && !((a)->seq & 0xff)) || (a)->type == H2O_ALT_SNP_INS)
+	for(uint32_t s2 = a2; s2 > a1; s2--) {
+		const h2o_alt* alt = &alts[s2 - 1];
+		if(!IS_GAPALT(alt)) continue;
+		int off = alt->type == H2O_ALT_SNP_DEL ? (int)alt->len : -(int)alt->len;
+		if(n < cap) { od[n].first = (uint32_t)(off < 0 ? -off : off); od[n].second = off > 0 ? 1 : -1; n++; }
+	}
+	if(n > 1) {                                            /* sort + unique */
+		for(uint32_t i = 1; i < n; i++) { offdiff_t x = od[i]; int j = (int)i - 1; while(j >= 0 && offdiff_lt(x, od[j])) { od[j + 1] = od[j]; j--; } od[j + 1] = x; }
+		uint32_t w = 1;
+		for(uint32_t i = 1; i < n; i++) if(od[i].first != od[w - 1].first || od[i].second != od[w - 1].second) od[w++] = od[i];
+		n = w;
+	}
+	const uint32_t single = n;
+	for(uint32_t s2 = a2; s2 > a1; s2--) {
+		const h2o_alt* alt = &alts[s2 - 1];
+		if(!IS_GAPALT(alt)) continue;
+		int off = alt->type == H2O_ALT_SNP_DEL ? (int)alt->len : -(int)alt->len;
+		for(uint32_t s3 = s2 - 1; s3 > a1; s3--) {
+			const h2o_alt* alt2 = &alts[s3 - 1];
+			if(!IS_GAPALT(alt2)) continue;
+			if(alt2->type == H2O_ALT_SNP_DEL) { if(alt2->pos + alt2->len >= alt->pos) continue; off += (int)alt2->len; }
+			else { if(alt2->pos >= alt->pos) continue; off -= (int)alt2->len; }
+			int found = 0;
+			for(uint32_t i = 0; i < n; i++) if(off == (int)od[i].first * od[i].second) { found = 1; break; }
+			if(!found && n < cap) { od[n].first = (uint32_t)(off < 0 ? -off : off); od[n].second = off > 0 ? 1 : -1; n++; }
+		}
+	}
+#undef IS_GAPALT
+	*nod = n;
+	return single;
+}
+static int ghit_equal(const h2o_ghit* a, const h2o_ghit* b) { /* GenomeHit::operator== hi_aligner.h:1156-1183 */
+	if(a->fw != b->fw || a->rdoff != b->rdoff || a->len != b->len || a->tidx != b->tidx || a->toff != b->toff || a->trim5 != b->trim5 ||
+	   a->trim3 != b->trim3 || a->nedits != b->nedits) return 0;
+	for(uint32_t i = 0; i < a->nedits; i++) {
+		const h2o_edit *e = &a->edits[i], *o = &b->edits[i];
+		if(e->type == H2O_EDIT_READ_GAP) { if(o->type != H2O_EDIT_READ_GAP) return 0; }
+		else if(e->type == H2O_EDIT_REF_GAP) { if(o->type != H2O_EDIT_REF_GAP) return 0; }
+		else if(e->type != o->type || e->pos != o->pos || e->chr != o->chr || e->qchr != o->qchr) return 0;
+	}
+	return 1;
+}
+/* static GenomeHit::adjustWithALT hi_aligner.h:2239-2390 (no splice-site ALTs: findSSOffs yields the single (0,0)).
+ * Appends to hits[*nhits..cap); returns whether any hit was added. */
+int h2o_adjust_with_alt(const h2o_index* ix, const uint8_t* seq, int fw, uint32_t rdoff, uint32_t len, uint32_t tidx, uint32_t toff,
+                        uint32_t joinedOff, h2o_ghit* hits, uint32_t* nhits, uint32_t cap)
+{
+	const uint32_t n0 = *nhits;
+	if(*nhits >= cap) return 0;
+	h2o_ghit* gh = &hits[*nhits];
+	memset(gh, 0, sizeof *gh);
+	gh->fw = (uint32_t)fw; gh->rdoff = rdoff; gh->len = len; gh->tidx = tidx; gh->toff = toff; gh->joinedOff = joinedOff;
+	if(ix->g.p.linear) { (*nhits)++; return 1; }
+	(*nhits)++;
+	const uint32_t width = 1u << (ix->g.p.offRate + 2);
+	offdiff_t od[64]; uint32_t nod = 0;
+	const uint32_t single = find_off_diffs(ix, gh->joinedOff >= width ? gh->joinedOff - width : 0, gh->joinedOff + width, od, 64, &nod);
+	const uint32_t max_od = 4;                              /* max(4, maxAltsTried / 4) */
+	if(nod - single > max_od) nod = single + max_od;
+	const uint32_t orig_joinedOff = gh->joinedOff, orig_toff = gh->toff;
+	int found2 = 0;
+	static h2o_edit cand[8][H2O_MAX_EDITS]; uint32_t cand_n[8], ncand = 0;
+	for(uint32_t o = 0; o < nod && !found2; o++) {
+		if(od[o].second >= 0) { gh->joinedOff = orig_joinedOff + od[o].first; gh->toff = orig_toff + od[o].first; }
+		else { if(orig_toff < od[o].first) continue; gh->joinedOff = orig_joinedOff - od[o].first; gh->toff = orig_toff - od[o].first; }
+		gh->nedits = 0;
+		ncand = 0;
+		uint32_t alignedLen = align_with_alts_c(ix, gh->joinedOff, seq, gh->rdoff, gh->rdoff, gh->len, gh->tidx, (int)gh->toff, gh->len + 10, 0,
+		                                        gh->edits, &gh->nedits, 0, NULL, cand, cand_n, 8, &ncand);
+		if(alignedLen == gh->len) {
+			found2 = 1;
+			for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], gh)) found2 = 0;
+			if(found2) {
+				for(uint32_t e = 0; e < ncand; e++) {
+					if(*nhits >= cap) break;
+					h2o_ghit* c = &hits[*nhits];
+					*c = hits[*nhits - 1];
+					memcpy(c->edits, cand[e], cand_n[e] * sizeof(h2o_edit)); c->nedits = cand_n[e];
+					(*nhits)++;
+					for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], c)) { (*nhits)--; break; }
+				}
+			}
+		} else gh->nedits = 0;
+	}
+	if(!found2) (*nhits)--;                                 /* genomeHits.pop_back() */
+	return *nhits > n0;
 }
 
 int h2o_extend(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq, const char* qual, uint32_t rdlen,

@@ -145,6 +145,10 @@ int  h2o_genome_coords_graph(const h2o_index*, uint32_t top, uint32_t bot, uint3
  * calculateScore :3711).  seq/qual in the hit's orientation. */
 int  h2o_extend(const h2o_index*, const h2o_scoring*, const uint8_t* seq, const char* qual, uint32_t rdlen,
                 h2o_ghit* hit, uint32_t* leftext, uint32_t* rightext, uint32_t mm);
+/* static GenomeHit::adjustWithALT hi_aligner.h:2239 (as getAnchorHits calls it, :5175): appends the hits an anchor coordinate
+ * yields once indel ALTs are accounted for (findOffDiffs :2545) and known variants are written as edits */
+int  h2o_adjust_with_alt(const h2o_index*, const uint8_t* seq, int fw, uint32_t rdoff, uint32_t len, uint32_t tidx, uint32_t toff,
+                         uint32_t joinedOff, h2o_ghit* hits, uint32_t* nhits, uint32_t cap);
 int64_t h2o_calculate_score(const h2o_scoring*, const char* qual, h2o_ghit* hit);
 
 /* SwAligner as called from hybridSearch (spliced_aligner.h:209-262): frame + 8-bit end-to-end fill + gather + the first

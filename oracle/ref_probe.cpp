@@ -251,7 +251,7 @@ int main(int argc, char** argv) {
 		}
 		return 0;
 	}
-	if(cmd == "psearch" || cmd == "coords" || cmd == "extend" || cmd == "sw") {
+	if(cmd == "psearch" || cmd == "coords" || cmd == "extend" || cmd == "sw" || cmd == "adjust") {
 		// <cmd> <base> <reads.fa> <nospliced:0|1>
 		vector<Read*> rds;
 		loadReads(argv[3], rds);
@@ -320,6 +320,27 @@ int main(int argc, char** argv) {
 						for(size_t e = 0; e < ph._node_iedge_count.size(); e++) printf(" %u:%u", ph._node_iedge_count[e].first, ph._node_iedge_count[e].second);
 					}
 					putchar('\n');
+					continue;
+				}
+				if(cmd == "adjust") {
+					// GenomeHit::adjustWithALT (static, hi_aligner.h:2239-2390) as getAnchorHits calls it (:5175): one anchor
+					// coordinate -> the GenomeHits it yields once offsets are corrected for indel ALTs and edits rewritten
+					for(size_t k = 0; k < coords.size(); k++) {
+						if(coords[k].ref() == (TRefId)std::numeric_limits<index_t>::max()) continue;
+						EList<GenomeHit<index_t> > ghs;
+						bool found = GenomeHit<index_t>::adjustWithALT(rdoff, ph._len, coords[k], sharedVars, ghs, rd, gfm, *p.altdb, *p.ref, gpol);
+						printf("%llu %d %u %u %u %u %u -> %d %u", (unsigned long long)rd.rdid, (int)fw, rdoff, ph._len, (unsigned)coords[k].ref(),
+						       (unsigned)coords[k].off(), (unsigned)coords[k].joinedOff(), (int)found, (unsigned)ghs.size());
+						for(size_t g = 0; g < ghs.size(); g++) {
+							printf(" | %u %u %u %u %u", ghs[g].rdoff(), ghs[g].len(), ghs[g].refoff(), ghs[g]._joinedOff, (unsigned)ghs[g].edits().size());
+							for(size_t e = 0; e < ghs[g].edits().size(); e++) {
+								const Edit& ed = ghs[g].edits()[e];
+								printf(" %u:%c>%c:%d:%lld", ed.pos, (char)ed.chr, (char)ed.qchr, (int)ed.type,
+								       ed.snpID == (uint32_t)INDEX_MAX ? -1LL : (long long)ed.snpID);
+							}
+						}
+						putchar('\n');
+					}
 					continue;
 				}
 				if(cmd == "sw") {

@@ -114,6 +114,8 @@ def load():
     lib.h2o_genome_coords_graph.argtypes = [P(Index), u32, u32, u32, u32, P(u32), u32, u32, u32, C.c_int, P(Coord), P(u32),
                                             P(C.c_int), P(u32)]
     lib.h2o_genome_coords_graph.restype = C.c_int
+    lib.h2o_adjust_with_alt.argtypes = [P(Index), C.c_void_p, C.c_int, u32, u32, u32, u32, u32, P(GHit), P(u32), u32]
+    lib.h2o_adjust_with_alt.restype = C.c_int
     lib.h2o_genome_coords.argtypes = [P(Index), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, P(Coord),
                                       P(C.c_uint32), P(C.c_int), P(C.c_uint32)]
     lib.h2o_genome_coords.restype = C.c_int

@@ -317,3 +317,23 @@ def check_graph_extend(be, golden_dir):
         nsnp += any(not e.endswith(":-1") for e in eds)
     assert nsnp > 80
     return len(hits)
+
+
+def parse_adjust(golden_dir, fn):
+    """-> [(rid, fw, rdoff, len, tidx, toff, joff, found, [([rdoff, len, toff, joff, nedits], [edit strings])])]"""
+    out = []
+    for l in H.glines(golden_dir, fn):
+        lhs, rhs = l.split(" -> ")
+        parts = rhs.split(" | ")
+        found, nh = map(int, parts[0].split())
+        want = []
+        for p in parts[1:]:
+            f = p.split()
+            want.append((list(map(int, f[:5])), f[5:]))
+        assert len(want) == nh
+        out.append(tuple(map(int, lhs.split())) + (found, want))
+    return out
+
+
+def edit_strings_snp(edits, n, MAXV=0xFFFFFFFF):
+    return [f"{edits[e].pos}:{chr(edits[e].chr)}>{chr(edits[e].qchr)}:{edits[e].type}:{-1 if edits[e].snp == MAXV else edits[e].snp}" for e in range(n)]

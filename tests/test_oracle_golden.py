@@ -307,3 +307,24 @@ def test_graph_extend_with_alts(oracle_lib, g1s_index, golden_dir):
         nsnp += any(not e.endswith(":-1") for e in eds)
         ngap += any(e.split(":")[2] in ("1", "2") for e in eds)
     assert n > 1000 and nsnp > 80 and ngap > 10
+
+
+@pytest.mark.parametrize("fn,reads", [("probe_g1s_adjust.txt.gz", "reads_snp.fa.gz"), ("probe_g1s_adjust_short.txt.gz", "reads_snp_short.fa.gz")])
+def test_graph_adjust_with_alt(oracle_lib, g1s_index, golden_dir, fn, reads):
+    """static GenomeHit::adjustWithALT: anchor coordinates corrected for indel ALTs (findOffDiffs), known variants written as edits"""
+    import parity_cases as PC
+    ix = H.load_index(oracle_lib, g1s_index)
+    _, seqs = H.read_fasta_reads(os.path.join(golden_dir, reads))
+    u32 = C.c_uint32
+    nshift = nsnp = 0
+    for rid, fw, rdoff, ln, tidx, toff, joff, found, want in PC.parse_adjust(golden_dir, fn):
+        seq = np.ascontiguousarray(seqs[rid] if fw else H.revcomp(seqs[rid]))
+        hits = (H.GHit * 8)()
+        nh = u32(0)
+        r = oracle_lib.h2o_adjust_with_alt(ix, seq.ctypes.data, fw, rdoff, ln, tidx, toff, joff, hits, C.byref(nh), 8)
+        got = [([hits[k].rdoff, hits[k].len, hits[k].toff, hits[k].joinedOff, hits[k].nedits], PC.edit_strings_snp(hits[k].edits, hits[k].nedits))
+               for k in range(nh.value)]
+        assert r == found and got == want, (rid, fw, got, want)
+        nshift += any(w[0][2] != toff for w in want)
+        nsnp += any(w[0][4] > 0 for w in want)
+    assert nsnp > 10 and (nshift > 3 or "short" not in fn)
