@@ -59,6 +59,10 @@ class GlfResult(C.Structure):        # h2g_glf_result
     _fields_ = [("ok", u32), ("top", u32), ("bot", u32), ("node_top", u32), ("node_bot", u32)]
 
 
+class AdjustQuery(C.Structure):      # h2g_adjust_query
+    _fields_ = [(n, u32) for n in ("read", "fw", "rdoff", "len", "tidx", "toff", "joinedOff")]
+
+
 class GsaQuery(C.Structure):         # h2g_gsa_query
     _fields_ = [(n, u32) for n in ("top", "bot", "node_top", "node_bot", "maxelt", "len", "rejectStraddle")]
 
@@ -165,7 +169,7 @@ EXPORTS = [
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_align_params_init", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
     "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch",
-    "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph",
+    "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph", "h2g_adjust_with_alt",
 ]
 
 
@@ -203,6 +207,7 @@ def lib():
     L.h2g_fm_search.argtypes = [vp, vp, C.c_size_t, u32, vp]
     L.h2g_sa_resolve.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
     L.h2g_sw_align.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, P(C.c_float)]
+    L.h2g_adjust_with_alt.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
     L.h2g_sa_resolve_graph.argtypes = [vp, vp, vp, C.c_size_t, u32, vp, vp]
     L.h2g_graph_lf.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
     L.h2g_fm_search_graph.argtypes = [vp, vp, C.c_size_t, u32, u32, vp, vp]
@@ -303,6 +308,14 @@ class Stream:
         ms = C.c_float(0)
         _chk(lib().h2g_sw_align(self.h, q, n, out, repeats, C.byref(ms)), "h2g_sw_align")
         return out, ms.value
+
+    def adjust_with_alt(self, queries, cap=8):
+        n = len(queries)
+        q = (AdjustQuery * n)(*queries)
+        hits = (GHit * (n * cap))()
+        nh = (u32 * n)()
+        _chk(lib().h2g_adjust_with_alt(self.h, q, n, cap, hits, nh), "h2g_adjust_with_alt")
+        return hits, nh
 
     def sa_resolve_graph(self, queries, iedges, cap=24):
         n = len(queries)

@@ -651,17 +651,23 @@ struct AwaFrame {
 	int32_t  rfoff, a_first, a_second, min_rd_i;
 	uint32_t state;   // 0 entry, 1 loop, 2 after call
 };
+#define H2G_AWA_CAND 4
 struct AwaWS {
 	h2g_edit tmp[H2G_MAX_EDITS];
 	uint32_t ntmp;
 	AwaFrame fr[H2G_AWA_DEPTH];
+	// candidate_edits (ELList<Edit,128,4>): other edit lists reaching the same best offset (adjustWithALT only)
+	h2g_edit cand[H2G_AWA_CAND][H2G_MAX_EDITS];
+	uint32_t cand_n[H2G_AWA_CAND], ncand;
+	h2g_ghit scratch;     // adjust_with_alt builds its candidate hit here
 };
 
 H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t joinedOff0, uint32_t base_rdoff,
                                 uint32_t rdoff0, uint32_t rdlen0, uint32_t tidx, int rfoff0, uint32_t rflen0, bool left,
-                                h2g_ghit* h, uint32_t mm, uint32_t* numNs, AwaWS* W)
+                                h2g_ghit* h, uint32_t mm, uint32_t* numNs, AwaWS* W, bool want_cand = false)
 {
 	if(numNs) *numNs = 0;
+	W->ncand = 0;
 	const uint32_t nedits0 = h->nedits;
 	W->ntmp = nedits0;
 	for(uint32_t k = 0; k < nedits0; k++) W->tmp[k] = h->edits[k];
@@ -676,6 +682,7 @@ H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& 
 #define AWA_ERASE_FRONT(N) do { const uint32_t n_ = (N); for(uint32_t q_ = n_; q_ < W->ntmp; q_++) W->tmp[q_ - n_] = W->tmp[q_]; W->ntmp -= n_; } while(0)
 #define AWA_COMMIT() do { for(uint32_t q_ = 0; q_ < W->ntmp; q_++) h->edits[q_] = W->tmp[q_]; h->nedits = W->ntmp; } while(0)
 #define AWA_RETURN(V) do { ret = (V); sp--; goto next_frame; } while(0)
+#define AWA_CAND_PUSH() do { if(want_cand) { if(W->ncand >= H2G_AWA_CAND) h->overflow = 1; else { for(uint32_t q_ = 0; q_ < W->ntmp; q_++) W->cand[W->ncand][q_] = W->tmp[q_]; W->cand_n[W->ncand] = W->ntmp; W->ncand++; } } } while(0)
 	int sp = 0;
 	uint32_t ret = 0;
 	{
@@ -746,7 +753,8 @@ H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& 
 					if(rf_bp == 4) { if(tmp_mm == 0) f.tmp_numNs++; mm_tmp_numNs++; }
 				}
 				if(tmp_mm == 0) max_rd_i = mm_max_rd_i;
-				if((int)(mm_max_rd_i + f.rdoff) > best_rdoff) { best_rdoff = (int)(mm_max_rd_i + f.rdoff); AWA_COMMIT(); if(numNs) *numNs = mm_tmp_numNs; }
+				if((int)(mm_max_rd_i + f.rdoff) > best_rdoff) { best_rdoff = (int)(mm_max_rd_i + f.rdoff); AWA_COMMIT(); if(numNs) *numNs = mm_tmp_numNs; W->ncand = 0; }
+				else if((int)(mm_max_rd_i + f.rdoff) == best_rdoff) AWA_CAND_PUSH();
 				if(mm_max_rd_i == f.rflen) AWA_RETURN(mm_max_rd_i);
 				if(A.n == 0) AWA_RETURN(0);
 				const uint32_t rd_diff = max_rd_i > 16 ? max_rd_i - 16 : 0;
@@ -902,7 +910,11 @@ H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& 
 				}
 				if(alt_compatible) {
 					numALTsTried++;
-					if(rd_i == f.rdlen) { best_rdoff = (int)(f.rdoff + rd_i); AWA_COMMIT(); AWA_RETURN(rd_i); }
+					if(rd_i == f.rdlen) {
+						if(best_rdoff < (int)(f.rdoff + rd_i)) W->ncand = 0;
+						AWA_CAND_PUSH();
+						best_rdoff = (int)(f.rdoff + rd_i); AWA_COMMIT(); AWA_RETURN(rd_i);
+					}
 					uint32_t next_joinedOff;
 					uint32_t next_rflen = f.rflen - rf_i;
 					const uint32_t next_rdlen = f.rdlen - rd_i;
@@ -934,6 +946,7 @@ H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& 
 #undef AWA_ERASE_FRONT
 #undef AWA_COMMIT
 #undef AWA_RETURN
+#undef AWA_CAND_PUSH
 	// alignWithALTs :741-783
 	uint32_t extlen = left ? rdoff0 - (uint32_t)best_rdoff : (uint32_t)best_rdoff - rdoff0;
 	const uint32_t ne = h->nedits;
@@ -1013,6 +1026,122 @@ H2G_HD bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& sc
 	}
 	calculate_score(sc, seq, h);
 	return *leftext > 0 || *rightext > 0;
+}
+
+// findOffDiffs (hi_aligner.h:2545-2640): offset differences that indel ALTs inside [start, end) can introduce.
+// od[k] = {|off|, sign}; returns the number of single-ALT entries (the combinations follow them).
+struct OffDiff { uint32_t first; int32_t second; };
+#define H2G_OFFDIFF_CAP 32
+H2G_HD bool alt_is_gap_fw(const DAlt& a) { return (a.type == H2G_ALT_SNP_DEL && !(a.seq & 0xff)) || a.type == H2G_ALT_SNP_INS; }
+H2G_HD uint32_t find_off_diffs(const DAlts& A, uint32_t start, uint32_t end, OffDiff* od, uint32_t* nod, uint32_t* overflow) {
+	uint32_t n = 0;
+	od[n].first = 0; od[n].second = 0; n++;
+	*nod = n;
+	uint32_t a1 = alt_lobound(A, start), a2 = a1;
+	for(; a2 < A.n; a2++) {
+		const DAlt alt = A.a[a2];
+		if(alt.type == H2G_ALT_SPLICESITE && alt.pos > alt.len) continue;
+		if(alt.type == H2G_ALT_SNP_DEL && (alt.seq & 0xff)) continue;
+		if(alt.pos >= end) break;
+	}
+	if(a1 >= a2) return n;
+	for(uint32_t s2 = a2; s2 > a1; s2--) {
+		const DAlt alt = A.a[s2 - 1];
+		if(!alt_is_gap_fw(alt)) continue;
+		const int off = alt.type == H2G_ALT_SNP_DEL ? (int)alt.len : -(int)alt.len;
+		if(n < H2G_OFFDIFF_CAP) { od[n].first = (uint32_t)(off < 0 ? -off : off); od[n].second = off > 0 ? 1 : -1; n++; } else *overflow = 1;
+	}
+	if(n > 1) {   // sort + unique
+		for(uint32_t i = 1; i < n; i++) {
+			const OffDiff x = od[i];
+			int j = (int)i - 1;
+			while(j >= 0 && (x.first != od[j].first ? x.first < od[j].first : x.second < od[j].second)) { od[j + 1] = od[j]; j--; }
+			od[j + 1] = x;
+		}
+		uint32_t w = 1;
+		for(uint32_t i = 1; i < n; i++) if(od[i].first != od[w - 1].first || od[i].second != od[w - 1].second) od[w++] = od[i];
+		n = w;
+	}
+	const uint32_t single = n;
+	for(uint32_t s2 = a2; s2 > a1; s2--) {
+		const DAlt alt = A.a[s2 - 1];
+		if(!alt_is_gap_fw(alt)) continue;
+		int off = alt.type == H2G_ALT_SNP_DEL ? (int)alt.len : -(int)alt.len;
+		for(uint32_t s3 = s2 - 1; s3 > a1; s3--) {
+			const DAlt alt2 = A.a[s3 - 1];
+			if(!alt_is_gap_fw(alt2)) continue;
+			if(alt2.type == H2G_ALT_SNP_DEL) { if(alt2.pos + alt2.len >= alt.pos) continue; off += (int)alt2.len; }
+			else { if(alt2.pos >= alt.pos) continue; off -= (int)alt2.len; }
+			bool found = false;
+			for(uint32_t i = 0; i < n; i++) if(off == (int)od[i].first * od[i].second) { found = true; break; }
+			if(!found) { if(n < H2G_OFFDIFF_CAP) { od[n].first = (uint32_t)(off < 0 ? -off : off); od[n].second = off > 0 ? 1 : -1; n++; } else *overflow = 1; }
+		}
+	}
+	*nod = n;
+	return single;
+}
+
+// GenomeHit::operator== (hi_aligner.h:1156-1183)
+H2G_HD bool ghit_equal(const h2g_ghit* a, const h2g_ghit* b) {
+	if(a->fw != b->fw || a->rdoff != b->rdoff || a->len != b->len || a->tidx != b->tidx || a->toff != b->toff || a->trim5 != b->trim5 ||
+	   a->trim3 != b->trim3 || a->nedits != b->nedits) return false;
+	for(uint32_t i = 0; i < a->nedits; i++) {
+		const h2g_edit e = a->edits[i], o = b->edits[i];
+		if(e.type == H2G_EDIT_READ_GAP) { if(o.type != H2G_EDIT_READ_GAP) return false; }
+		else if(e.type == H2G_EDIT_REF_GAP) { if(o.type != H2G_EDIT_REF_GAP) return false; }
+		else if(e.type != o.type || e.pos != o.pos || e.chr != o.chr || e.qchr != o.qchr) return false;
+	}
+	return true;
+}
+
+// static GenomeHit::adjustWithALT (hi_aligner.h:2239-2390) as getAnchorHits calls it (:5175); no splice-site ALTs, so
+// findSSOffs yields the single (0, 0).  Appends to hits[*nhits .. cap); returns whether any hit was added.
+H2G_HD bool adjust_with_alt(const DGfm& g, const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t rdoff, uint32_t len,
+                            uint32_t tidx, uint32_t toff, uint32_t joinedOff, h2g_ghit* hits, uint32_t* nhits, uint32_t cap,
+                            AwaWS* W, uint32_t* overflow)
+{
+	const uint32_t n0 = *nhits;
+	if(*nhits >= cap) { *overflow = 1; return false; }
+	h2g_ghit* gh = &hits[*nhits];
+	gh->read = 1;   // _hitcount
+	gh->fw = seq.fw; gh->rdoff = rdoff; gh->len = len; gh->trim5 = 0; gh->trim3 = 0; gh->tidx = tidx; gh->toff = toff; gh->joinedOff = joinedOff;
+	gh->score = 0; gh->nedits = 0; gh->overflow = 0;
+	(*nhits)++;
+	if(g.linear) return true;
+	const uint32_t width = 1u << (g.offRate + 2);
+	OffDiff od[H2G_OFFDIFF_CAP];
+	uint32_t nod = 0;
+	const uint32_t single = find_off_diffs(A, joinedOff >= width ? joinedOff - width : 0, joinedOff + width, od, &nod, overflow);
+	const uint32_t max_od = (A.maxAltsTried / 4) > 4 ? (A.maxAltsTried / 4) : 4;
+	if(nod - single > max_od) nod = single + max_od;
+	bool found2 = false;
+	for(uint32_t o = 0; o < nod && !found2; o++) {
+		if(od[o].second >= 0) { gh->joinedOff = joinedOff + od[o].first; gh->toff = toff + od[o].first; }
+		else { if(toff < od[o].first) continue; gh->joinedOff = joinedOff - od[o].first; gh->toff = toff - od[o].first; }
+		gh->nedits = 0;
+		const uint32_t alignedLen = align_with_alts(ref, A, seq, gh->joinedOff, gh->rdoff, gh->rdoff, gh->len, gh->tidx, (int)gh->toff, gh->len + 10,
+		                                            false, gh, 0, nullptr, W, true);
+		if(gh->overflow) *overflow = 1;
+		if(alignedLen == gh->len) {
+			found2 = true;
+			for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], gh)) found2 = false;
+			if(found2) {
+				for(uint32_t e = 0; e < W->ncand; e++) {
+					if(*nhits >= cap) { *overflow = 1; break; }
+					h2g_ghit* c = &hits[*nhits];
+					const h2g_ghit* prev = &hits[*nhits - 1];
+					c->read = prev->read; c->fw = prev->fw; c->rdoff = prev->rdoff; c->len = prev->len; c->trim5 = prev->trim5; c->trim3 = prev->trim3;
+					c->tidx = prev->tidx; c->toff = prev->toff; c->joinedOff = prev->joinedOff; c->score = prev->score; c->overflow = 0;
+					c->nedits = W->cand_n[e];
+					for(uint32_t q = 0; q < c->nedits; q++) c->edits[q] = W->cand[e][q];
+					(*nhits)++;
+					for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], c)) { (*nhits)--; break; }
+				}
+			}
+		} else gh->nedits = 0;
+	}
+	if(!found2) (*nhits)--;
+	return *nhits > n0;
 }
 
 }  // namespace h2g

@@ -676,6 +676,20 @@ __global__ __launch_bounds__(256) void k_extend_alts(DRef ref, DAlts alts, DRead
 	}
 }
 
+__global__ __launch_bounds__(256) void k_adjust_alt(DGfm g, DRef ref, DAlts alts, DReads rd, const h2g_adjust_query* q, size_t n, uint32_t cap,
+                                                    h2g_ghit* hits, uint32_t* nhits, AwaWS* scratch)
+{
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	AwaWS* W = scratch + tid;
+	for(size_t i = tid; i < n; i += stride) {
+		SeqView sv = seq_view(rd, q[i].read, q[i].fw != 0);
+		uint32_t nh = 0, ovf = 0;
+		adjust_with_alt(g, ref, alts, sv, q[i].rdoff, q[i].len, q[i].tidx, q[i].toff, q[i].joinedOff, hits + i * cap, &nh, cap, W, &ovf);
+		nhits[i] = ovf ? H2G_MAX : nh;
+		for(uint32_t k = 0; k < nh; k++) hits[i * cap + k].read = q[i].read;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_graph_lf(DGfm g, const h2g_glf_query* q, size_t n, uint32_t k, h2g_glf_result* res, h2g_iedges* ie)
 {
 	size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -807,6 +821,26 @@ extern "C" h2g_status h2g_graph_lf(h2g_stream* s, const h2g_glf_query* q, size_t
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
 	if(iedges) HIPCHK(hipMemcpyAsync(iedges, die, n * sizeof *iedges, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_adjust_with_alt(h2g_stream* s, const h2g_adjust_query* q, size_t n, uint32_t cap, h2g_ghit* hits, uint32_t* nhits) {
+	if(!s || !q || !hits || !nhits || n == 0 || cap == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s)) || (rc = need_graph(s))) return rc;
+	for(size_t i = 0; i < n; i++) if(q[i].read >= s->n_reads || q[i].tidx >= s->ix->dr.nrefs) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	const unsigned grid = grid_for(n, 256) > 128 ? 128 : grid_for(n, 256);
+	void *dq, *dh, *dn, *dscr;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * cap * sizeof *hits, &dh)) || (rc = tmp_buf(s, 2, n * 4, &dn)) ||
+	   (rc = tmp_buf(s, 3, (size_t)grid * 256 * sizeof(AwaWS), &dscr))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	hipLaunchKernelGGL(k_adjust_alt, dim3(grid), dim3(256), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dalts, dreads(s), (const h2g_adjust_query*)dq, n, cap,
+	                   (h2g_ghit*)dh, (uint32_t*)dn, (AwaWS*)dscr);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(hits, dh, n * cap * sizeof *hits, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipMemcpyAsync(nhits, dn, n * 4, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipStreamSynchronize(s->st));
 	return H2G_OK;
 }

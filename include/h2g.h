@@ -163,6 +163,13 @@ typedef struct { uint32_t extended, leftext, rightext; } h2g_ext_result;
 H2G_EXPORT h2g_status h2g_extend(h2g_stream*, h2g_ghit* hits /* in/out */, const h2g_ext_args* args, size_t n,
                                  h2g_ext_result* res);
 
+/* static GenomeHit::adjustWithALT (hi_aligner.h:2239-2390) as getAnchorHits calls it on a graph index (:5175): an anchor
+ * (read, strand, rdoff, len) placed at (tidx, toff, joinedOff) by the SA walk -> the GenomeHits it yields once offsets are
+ * corrected for indel ALTs (findOffDiffs :2545) and known variants are written as edits.  hits[i * cap ...], nhits[i]. */
+typedef struct { uint32_t read, fw, rdoff, len, tidx, toff, joinedOff; } h2g_adjust_query;
+H2G_EXPORT h2g_status h2g_adjust_with_alt(h2g_stream*, const h2g_adjust_query* q, size_t n, uint32_t cap, h2g_ghit* hits /* [n*cap] */,
+                                          uint32_t* nhits /* [n] */);
+
 /* ---- Smith-Waterman extension (opt-in in the reference: --bowtie2-dp / --sensitive) ---------------------------- */
 /* One problem = the SwAligner call site of hybridSearch (spliced_aligner.h:209-262) for one seed hit of one read:
  * DynProgFramer::frameSeedExtensionRect (dp_framer.cpp:81) around refoff = hit.refoff - hit.rdoff, SwAligner::initRef

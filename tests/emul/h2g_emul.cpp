@@ -96,6 +96,18 @@ void h2gemu_sa_resolve_graph(Emu* e, const h2g_gsa_query* q, const h2g_iedges* i
 	delete x;
 }
 
+void h2gemu_adjust_with_alt(Emu* e, const h2g_adjust_query* q, size_t n, uint32_t cap, h2g_ghit* hits, uint32_t* nhits) {
+	DReads rd = e->reads();
+	AwaWS* W = new AwaWS();
+	for(size_t i = 0; i < n; i++) {
+		SeqView sv = seq_view(rd, q[i].read, q[i].fw != 0);
+		uint32_t nh = 0, ovf = 0;
+		adjust_with_alt(e->dg, e->dr, e->dalts, sv, q[i].rdoff, q[i].len, q[i].tidx, q[i].toff, q[i].joinedOff, hits + i * cap, &nh, cap, W, &ovf);
+		nhits[i] = ovf ? H2G_MAX : nh;
+	}
+	delete W;
+}
+
 void h2gemu_fm_search_graph(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, uint32_t kseeds, h2g_fm_hit* out, h2g_iedges* ie) {
 	DReads rd = e->reads();
 	for(size_t i = 0; i < n; i++) {

@@ -21,6 +21,7 @@ class Emu:
         self.L.h2gemu_fm_search.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp]
         self.L.h2gemu_sa_resolve.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_sw_align.argtypes = [vp, vp, C.c_size_t, vp]
+        self.L.h2gemu_adjust_with_alt.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_sa_resolve_graph.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_graph_lf.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp]
         self.L.h2gemu_fm_search_graph.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp]
@@ -58,6 +59,14 @@ class Emu:
         out = (api.SwResult * n)()
         self.L.h2gemu_sw_align(self.h, q, n, out)
         return out, 0.0
+
+    def adjust_with_alt(self, queries, cap=8):
+        n = len(queries)
+        q = (api.AdjustQuery * n)(*queries)
+        hits = (api.GHit * (n * cap))()
+        nh = (C.c_uint32 * n)()
+        self.L.h2gemu_adjust_with_alt(self.h, q, n, cap, hits, nh)
+        return hits, nh
 
     def sa_resolve_graph(self, queries, iedges, cap=24):
         n = len(queries)

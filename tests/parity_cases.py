@@ -337,3 +337,17 @@ def parse_adjust(golden_dir, fn):
 
 def edit_strings_snp(edits, n, MAXV=0xFFFFFFFF):
     return [f"{edits[e].pos}:{chr(edits[e].chr)}>{chr(edits[e].qchr)}:{edits[e].type}:{-1 if edits[e].snp == MAXV else edits[e].snp}" for e in range(n)]
+
+
+def check_graph_adjust(be, golden_dir, fn):
+    cases = parse_adjust(golden_dir, fn)
+    qs = [api.AdjustQuery(c[0], c[1], c[2], c[3], c[4], c[5], c[6]) for c in cases]
+    cap = 8
+    hits, nh = be.adjust_with_alt(qs, cap=cap)
+    for i, c in enumerate(cases):
+        found, want = c[7], c[8]
+        assert nh[i] == len(want) and (nh[i] > 0) == bool(found), (c[:7], nh[i])
+        got = [([hits[i * cap + k].rdoff, hits[i * cap + k].len, hits[i * cap + k].toff, hits[i * cap + k].joinedOff, hits[i * cap + k].nedits],
+                edit_strings_snp(hits[i * cap + k].edits, hits[i * cap + k].nedits)) for k in range(nh[i])]
+        assert got == want, (c[:7], got, want)
+    return len(cases)

@@ -81,6 +81,20 @@ def test_graph_extend_with_alts(gemu, golden_dir):
     assert PC.check_graph_extend(gemu, golden_dir) > 1000
 
 
+def test_graph_adjust_with_alt(golden_dir, g1s_index):
+    for fn, reads in (("probe_g1s_adjust.txt.gz", PC.load_snp_reads), ("probe_g1s_adjust_short.txt.gz", None)):
+        e = Emu(g1s_index)
+        if reads is None:
+            _, seqs = H.read_fasta_reads(__import__("os").path.join(golden_dir, "reads_snp_short.fa.gz"))
+            import numpy as np
+            arr = np.stack(seqs)
+            offs = (np.arange(len(seqs) + 1, dtype=np.uint64) * arr.shape[1]).astype(np.uint32)
+        else:
+            arr, offs = reads(golden_dir)
+        e.set_reads(arr.reshape(-1), offs)
+        assert PC.check_graph_adjust(e, golden_dir, fn) > 250
+
+
 def test_graph_lf_matches_oracle_on_random_ranges(gemu, oracle_lib, g1s_index):
     """fresh seeded ranges, incl. ranges that straddle sides and tiny ranges around multi-in-edge nodes"""
     import ctypes as C

@@ -235,6 +235,10 @@ def test_graph_extend_with_alts_golden(ggpu, golden_dir):
     assert PC.check_graph_extend(ggpu, golden_dir) > 1000
 
 
+def test_graph_adjust_with_alt_golden(ggpu, golden_dir):
+    assert PC.check_graph_adjust(ggpu, golden_dir, "probe_g1s_adjust.txt.gz") > 250
+
+
 def test_graph_lf_vs_oracle_random(ggpu, oracle_lib, g1s_index):
     oix = H.load_index(oracle_lib, g1s_index)
     g = C.byref(oix.contents.g)
