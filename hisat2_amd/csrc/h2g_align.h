@@ -13,6 +13,7 @@
 #pragma once
 #include "h2g_core.h"
 #include "h2g_sw.h"
+#include "h2g_graph.h"
 #if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
 #include <stdio.h>
 #define AL_TRACE(...) fprintf(stderr, __VA_ARGS__)
@@ -37,6 +38,7 @@ struct DLocalDesc {
 	uint32_t len, gbwtLen, eftabLen, nFrag, nZ, zoff;
 	uint32_t tidx, localOffset, joinedOffset;
 	uint32_t fchr[5];
+	uint32_t ftabLim;        // ftab entries above this point into eftab: len (linear) or gbwtLen (graph), gfm.h:2618
 };
 struct DLocalSet {
 	const DLocalDesc* desc;
@@ -46,6 +48,25 @@ struct DLocalSet {
 	uint32_t n, ftabChars, offRate;
 };
 #define H2G_LOCAL_INTERVAL 56320u   // local_index_interval hier_idx_common.h:24-31
+
+// Policy of a GRAPH local index for the templates of h2g_graph.h: 128 B sides of u16 words — 232 symbols in 58 B,
+// F bits at 58, M bits at 87, u16 {F_loc, M_occ, occ[4]} at 116 (GFMParams::init gfm.h:156-179 with index_t = uint16_t)
+struct LGfm {
+	const uint8_t*  sides;
+	const uint16_t* offs;
+	const uint32_t* zoffs;
+	uint32_t nZ, zoff, gbwtLen, offMask, offRate;
+	uint32_t fchr[5];
+	static constexpr uint32_t SYMS = 232, NCW = 8, F_OFF = 58, M_OFF = 87, HDR = 116, WSZ = 2;
+	H2G_HD uint32_t offs_at(uint32_t i) const { const uint32_t v = offs[i]; return v == 0xffffu ? H2G_MAX : v; }
+};
+H2G_HD LGfm lgfm_of(const DLocalSet& ls, const DLocalDesc& d) {
+	LGfm x;
+	x.sides = ls.sides + d.sides_off; x.offs = ls.words + d.offs_off; x.zoffs = nullptr;
+	x.nZ = d.nZ ? 1 : 0; x.zoff = d.zoff; x.gbwtLen = d.gbwtLen; x.offRate = ls.offRate; x.offMask = (0xffffu << ls.offRate) & 0xffffu;
+	for(int i = 0; i < 5; i++) x.fchr[i] = d.fchr[i];
+	return x;
+}
 
 // Uniform view of "an FM index" for the search loops: global (u32, 192 symbols/side) or local (u16, 224/side)
 struct GIdx {
@@ -68,12 +89,12 @@ struct LIdx {
 	H2G_HD uint32_t side_of(uint32_t row) const { return row / 224u; }
 	H2G_HD uint32_t fh(uint32_t i) const {   // ftabHi gfm.h:2618 with 16-bit words
 		uint32_t v = ls->words[d->ftab_off + i];
-		if(v <= d->len) return v;
+		if(v <= d->ftabLim) return v;
 		return ls->words[d->eftab_off + ((v ^ 0xffffu) * 2 + 1)];
 	}
 	H2G_HD uint32_t fl(uint32_t i) const {
 		uint32_t v = ls->words[d->ftab_off + i];
-		if(v <= d->len) return v;
+		if(v <= d->ftabLim) return v;
 		return ls->words[d->eftab_off + ((v ^ 0xffffu) * 2)];
 	}
 	H2G_HD void lohi(uint32_t fi, uint32_t* top, uint32_t* bot) const { *top = fh(fi); *bot = fl(fi + 1); }

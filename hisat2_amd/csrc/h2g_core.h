@@ -31,6 +31,10 @@ struct DGfm {   // one 32-bit GFM resident in HBM (sides exactly as on disk: 64 
 	uint32_t fchr[5];
 	uint32_t len, gbwtLen, ftabLim, sideGbwtLen, sideGbwtSz, lineRate, offRate, offMask, ftabChars;
 	uint32_t nFrag, nPat, nZ, zoff, minK, linear;
+	// geometry of a GRAPH side of the global index (policy interface of h2g_graph.h): 208 symbols in 52 B, F bits at 52,
+	// M bits at 78, u32 {F_loc, M_occ, occ[4]} at 104
+	static constexpr uint32_t SYMS = 208, NCW = 7, F_OFF = 52, M_OFF = 78, HDR = 104, WSZ = 4;
+	H2G_HD uint32_t offs_at(uint32_t i) const { return offs[i]; }
 };
 
 struct DRef {   // BitPairReference: records sorted by (text, offset); buf 2 bit/base

@@ -16,6 +16,11 @@ namespace h2g {
 
 #define H2G_GSIDE_SYMS 208u
 
+// Index policy ("X" below): what the graph functions need from an index.  DGfm is the policy of the global index
+// (u32 words, 208 symbols per side); LGfm (further down) that of a local index (u16 words, 232 symbols per side).
+//   X::SYMS  symbols per side          X::NCW  u64 words holding them        X::F_OFF / M_OFF  byte offsets of the bit vectors
+//   X::HDR   byte offset of {F_loc, M_occ, occ[4]}      X::WSZ  word size of those six fields
+//   members: sides, nZ, zoff, zoffs, fchr[5], gbwtLen, offMask, offRate and offs_at(i)
 struct Side128 { uint64_t w[16]; };
 
 H2G_HD Side128 load_side128(const uint8_t* p) {
@@ -34,27 +39,41 @@ H2G_HD Side128 load_side128(const uint8_t* p) {
 	return s;
 }
 
-H2G_HD bool is_zoff(const DGfm& g, uint32_t row) {   // GFM::_zOffs (gfm.h:2783); a handful of entries at most
+template <class X>
+H2G_HD bool is_zoff(const X& g, uint32_t row) {   // GFM::_zOffs (gfm.h:2783); a handful of entries at most
 	if(g.nZ == 0) return false;
 	if(row == g.zoff) return true;
 	for(uint32_t i = 1; i < g.nZ; i++) if(g.zoffs[i] == row) return true;
 	return false;
 }
 
-// countBt2Side (gfm.h:2958-3001) on a loaded graph side; charOff = row % 208
-H2G_HD uint32_t rank_in_side128(const DGfm& g, const Side128& s, uint32_t sideNum, uint32_t charOff, int c) {
+// header word k of a side held in registers: 0 F_loc, 1 M_occ, 2..5 occ[A,C,G,T]
+template <class X>
+H2G_HD uint32_t side_hdr(const Side128& s, int k) {
+	const uint32_t byte = X::HDR + X::WSZ * (uint32_t)k;
+	const uint64_t w = s.w[byte >> 3];
+	return X::WSZ == 4 ? (uint32_t)(w >> ((byte & 7) * 8)) : (uint32_t)((w >> ((byte & 7) * 8)) & 0xffffu);
+}
+template <class X>
+H2G_HD uint32_t side_hdr_mem(const uint8_t* side, int k) {   // same, straight from memory
+	if(X::WSZ == 4) return reinterpret_cast<const uint32_t*>(side + X::HDR)[k];
+	return reinterpret_cast<const uint16_t*>(side + X::HDR)[k];
+}
+
+// countBt2Side (gfm.h:2958-3001) on a loaded graph side; charOff = row % SYMS
+template <class X>
+H2G_HD uint32_t rank_in_side128(const X& g, const Side128& s, uint32_t sideNum, uint32_t charOff, int c) {
 	uint32_t cnt = 0;
 #pragma unroll
-	for(int k = 0; k < 7; k++) cnt += count_word(s.w[k], c, (int)charOff - 32 * k);   // word 6: symbols 192..207 only
+	for(int k = 0; k < (int)X::NCW; k++) cnt += count_word(s.w[k], c, (int)charOff - 32 * k);   // count_word masks beyond charOff
 	if(c == 0 && g.nZ) {                                  // '$' rows are stored as 'A' (gfm.h:2967-2979)
 		for(uint32_t i = 0; i < g.nZ; i++) {
 			const uint32_t z = i == 0 ? g.zoff : g.zoffs[i];
-			const uint32_t zs = z / H2G_GSIDE_SYMS, zc = z - zs * H2G_GSIDE_SYMS;
+			const uint32_t zs = z / X::SYMS, zc = z - zs * X::SYMS;
 			if(zs == sideNum && zc < charOff) cnt--;
 		}
 	}
-	const uint64_t ow = (c & 2) ? s.w[15] : s.w[14];
-	const uint32_t occ = (c & 1) ? (uint32_t)(ow >> 32) : (uint32_t)ow;
+	const uint32_t occ = side_hdr<X>(s, 2 + c);
 	const uint32_t fc = c == 0 ? g.fchr[0] : c == 1 ? g.fchr[1] : c == 2 ? g.fchr[2] : g.fchr[3];
 	return occ + cnt + fc;
 }
@@ -63,52 +82,48 @@ H2G_HD int rowL_in_side128(const Side128& s, uint32_t charOff) {   // rowL gfm.h
 	const uint32_t k = charOff >> 5;
 	uint64_t w = s.w[0];
 #pragma unroll
-	for(int j = 1; j < 7; j++) w = (k == (uint32_t)j) ? s.w[j] : w;
+	for(int j = 1; j < 8; j++) w = (k == (uint32_t)j) ? s.w[j] : w;
 	return (int)((w >> ((charOff & 31) * 2)) & 3);
 }
 
-H2G_HD uint32_t rank128(const DGfm& g, uint32_t row, int c) {      // SideLocus::initFromRow + mapLF gfm.h:3712
-	const uint32_t sideNum = row / H2G_GSIDE_SYMS, charOff = row - sideNum * H2G_GSIDE_SYMS;
+template <class X>
+H2G_HD uint32_t rank128(const X& g, uint32_t row, int c) {      // SideLocus::initFromRow + mapLF gfm.h:3712
+	const uint32_t sideNum = row / X::SYMS, charOff = row - sideNum * X::SYMS;
 	Side128 s = load_side128(g.sides + (size_t)sideNum * 128);
 	return rank_in_side128(g, s, sideNum, charOff, c);
 }
 
 // ---- bit vectors ------------------------------------------------------------------------------------------
-// Both bit vectors are read with aligned dword loads: F starts at byte 52 (dword 13), M at byte 78 (the
-// upper half of dword 19).  208 bits = 3 full u64 + 16 bits.
-struct Bits208 { uint64_t w[4]; };
-
-H2G_HD Bits208 load_F(const uint8_t* side) {
-	const uint32_t* q = reinterpret_cast<const uint32_t*>(side + 52);
-	Bits208 b;
-	b.w[0] = q[0] | ((uint64_t)q[1] << 32);
-	b.w[1] = q[2] | ((uint64_t)q[3] << 32);
-	b.w[2] = q[4] | ((uint64_t)q[5] << 32);
-	b.w[3] = q[6] & 0xffffu;
-	return b;
+// F and M start at arbitrary byte offsets of the side (52 / 78 global, 58 / 87 local); they are read with aligned
+// dword loads and funnel shifts.  SYMS bits = 3 full u64 + 16 (global) or 40 (local) bits.
+struct Bits256 { uint64_t w[4]; };
+H2G_HD uint64_t ld64_at(const uint8_t* side, uint32_t byte) {   // 8 bytes at any offset inside the 128 B side
+	const uint32_t* q = reinterpret_cast<const uint32_t*>(side + (byte & ~3u));
+	const uint32_t sh = (byte & 3u) * 8;
+	const uint64_t lo = q[0] | ((uint64_t)q[1] << 32);
+	if(sh == 0) return lo;
+	return (lo >> sh) | ((uint64_t)q[2] << (64 - sh));
 }
-H2G_HD Bits208 load_M(const uint8_t* side, uint32_t* F_loc, uint32_t* M_occ) {
-	const uint32_t* q = reinterpret_cast<const uint32_t*>(side + 76);   // dwords 19..27
-	uint32_t a[7];
-#pragma unroll
-	for(int k = 0; k < 7; k++) a[k] = q[k];
-	Bits208 b;
-	b.w[0] = (a[0] >> 16) | ((uint64_t)a[1] << 16) | ((uint64_t)a[2] << 48);
-	b.w[1] = (a[2] >> 16) | ((uint64_t)a[3] << 16) | ((uint64_t)a[4] << 48);
-	b.w[2] = (a[4] >> 16) | ((uint64_t)a[5] << 16) | ((uint64_t)a[6] << 48);
-	b.w[3] = a[6] >> 16;
-	*F_loc = q[7];
-	*M_occ = q[8];
+template <class X>
+H2G_HD Bits256 load_bits(const uint8_t* side, uint32_t off) {
+	Bits256 b;
+	b.w[0] = ld64_at(side, off); b.w[1] = ld64_at(side, off + 8); b.w[2] = ld64_at(side, off + 16);
+	// the last word may start within 8 bytes of the end of the side: read what is there, keep SYMS - 192 bits
+	const uint32_t last = off + 24;
+	uint64_t v = 0;
+	for(uint32_t k = 0; k < (X::SYMS - 192 + 7) / 8; k++) v |= (uint64_t)side[last + k] << (8 * k);
+	b.w[3] = v & ((1ull << (X::SYMS - 192)) - 1ull);
 	return b;
 }
 H2G_HD uint64_t low_mask(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull)); }
 
 // rank_M (gfm.h:4100) = countMSide (:3146): ones of M strictly before `row`, plus the side's M_occ
-H2G_HD uint32_t rank_M(const DGfm& g, uint32_t row) {
-	const uint32_t sideNum = row / H2G_GSIDE_SYMS, off = row - sideNum * H2G_GSIDE_SYMS;
-	uint32_t F_loc, M_occ;
-	Bits208 m = load_M(g.sides + (size_t)sideNum * 128, &F_loc, &M_occ);
-	uint32_t cnt = M_occ;
+template <class X>
+H2G_HD uint32_t rank_M(const X& g, uint32_t row) {
+	const uint32_t sideNum = row / X::SYMS, off = row - sideNum * X::SYMS;
+	const uint8_t* side = g.sides + (size_t)sideNum * 128;
+	Bits256 m = load_bits<X>(side, X::M_OFF);
+	uint32_t cnt = side_hdr_mem<X>(side, 1);
 #pragma unroll
 	for(int k = 0; k < 4; k++) cnt += (uint32_t)__builtin_popcountll(m.w[k] & low_mask((int)off - 64 * k));
 	return cnt;
@@ -120,16 +135,17 @@ H2G_HD uint32_t select_in_word(uint64_t w, uint32_t count) {   // position of th
 }
 
 // select_F (gfm.h:4113-4167): row of the count-th F one at or after `row` (count >= 1), crossing sides as needed
-H2G_HD uint32_t select_F(const DGfm& g, uint32_t row, uint32_t count) {
-	uint32_t sideNum = row / H2G_GSIDE_SYMS, off = row - sideNum * H2G_GSIDE_SYMS;
-	const uint32_t lastSide = (g.gbwtLen - 1) / H2G_GSIDE_SYMS;
+template <class X>
+H2G_HD uint32_t select_F(const X& g, uint32_t row, uint32_t count) {
+	uint32_t sideNum = row / X::SYMS, off = row - sideNum * X::SYMS;
+	const uint32_t lastSide = (g.gbwtLen - 1) / X::SYMS;
 	while(true) {
-		Bits208 f = load_F(g.sides + (size_t)sideNum * 128);
+		Bits256 f = load_bits<X>(g.sides + (size_t)sideNum * 128, X::F_OFF);
 #pragma unroll
 		for(int k = 0; k < 4; k++) {
 			const uint64_t w = f.w[k] & ~low_mask((int)off - 64 * k);
 			const uint32_t pc = (uint32_t)__builtin_popcountll(w);
-			if(count <= pc) return sideNum * H2G_GSIDE_SYMS + 64u * k + select_in_word(w, count);
+			if(count <= pc) return sideNum * X::SYMS + 64u * k + select_in_word(w, count);
 			count -= pc;
 		}
 		if(sideNum >= lastSide) return g.gbwtLen;   // not reachable on a well-formed index (the reference would run off the array)
@@ -140,13 +156,14 @@ H2G_HD uint32_t select_F(const DGfm& g, uint32_t row, uint32_t count) {
 
 // F-row of node `node`: backward scan over the (F_loc, M_occ) side headers starting at the side of `locRow`
 // (mapGLF gfm.h:3788-3810, mapGLF1 :3978-3998).  Returns the scan's F_loc (already +1 when M_occ > 0) and M_occ.
-H2G_HD uint32_t node_to_Frow(const DGfm& g, uint32_t locRow, uint32_t node, uint32_t* F_loc_out, uint32_t* M_occ_out) {
-	uint32_t sideNum = locRow / H2G_GSIDE_SYMS;
+template <class X>
+H2G_HD uint32_t node_to_Frow(const X& g, uint32_t locRow, uint32_t node, uint32_t* F_loc_out, uint32_t* M_occ_out) {
+	uint32_t sideNum = locRow / X::SYMS;
 	uint32_t F_loc, M_occ;
 	while(true) {
-		const uint32_t* q = reinterpret_cast<const uint32_t*>(g.sides + (size_t)sideNum * 128 + 104);
-		F_loc = q[0];
-		M_occ = q[1];
+		const uint8_t* sd = g.sides + (size_t)sideNum * 128;
+		F_loc = side_hdr_mem<X>(sd, 0);
+		M_occ = side_hdr_mem<X>(sd, 1);
 		if(M_occ <= node || sideNum == 0) break;
 		sideNum--;
 	}
@@ -161,15 +178,16 @@ H2G_HD uint32_t node_to_Frow(const DGfm& g, uint32_t locRow, uint32_t node, uint
 typedef h2g_iedges IEdges;            // n = true count; entries beyond H2G_IEDGE_CAP are dropped (caller checks n)
 
 // getInEdgeCount (gfm.h:4172-4213)
-H2G_HD void in_edge_count(const DGfm& g, uint32_t top, uint32_t bot, IEdges* ie) {
+template <class X>
+H2G_HD void in_edge_count(const X& g, uint32_t top, uint32_t bot, IEdges* ie) {
 	ie->n = 0;
 	uint32_t curr_node = 0, num0s = 0;
 	uint32_t sideNum = H2G_MAX;
-	Bits208 f;
+	Bits256 f;
 	f.w[0] = f.w[1] = f.w[2] = f.w[3] = 0;
 	for(uint32_t row = top + 1; row < bot; row++) {
-		const uint32_t sn = row / H2G_GSIDE_SYMS, off = row - sn * H2G_GSIDE_SYMS;
-		if(sn != sideNum) { sideNum = sn; f = load_F(g.sides + (size_t)sn * 128); }
+		const uint32_t sn = row / X::SYMS, off = row - sn * X::SYMS;
+		if(sn != sideNum) { sideNum = sn; f = load_bits<X>(g.sides + (size_t)sn * 128, X::F_OFF); }
 		const uint32_t k = off >> 6;
 		const uint64_t w = k == 0 ? f.w[0] : (k == 1 ? f.w[1] : (k == 2 ? f.w[2] : f.w[3]));
 		if((w >> (off & 63)) & 1) { curr_node++; num0s = 0; }
@@ -185,12 +203,13 @@ struct GRange { uint32_t top, bot, node_top, node_bot; };
 
 // mapGLF (gfm.h:3759-3837): LF of a row range + translation of the outgoing-edge rows back to incoming rows
 // through M-rank / F-select.  false = empty range.  `ie` may be null.
-H2G_HD bool map_glf(const DGfm& g, uint32_t top, uint32_t bot, int c, uint32_t k, GRange* r, IEdges* ie) {
-	const uint32_t s0 = top / H2G_GSIDE_SYMS, c0 = top - s0 * H2G_GSIDE_SYMS;
+template <class X>
+H2G_HD bool map_glf(const X& g, uint32_t top, uint32_t bot, int c, uint32_t k, GRange* r, IEdges* ie) {
+	const uint32_t s0 = top / X::SYMS, c0 = top - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
 	uint32_t t = rank_in_side128(g, sd, s0, c0, c), b;
 	const uint32_t spread = bot - top;
-	if(c0 + spread < H2G_GSIDE_SYMS) b = rank_in_side128(g, sd, s0, c0 + spread, c);   // initFromTopBot gfm.h:347
+	if(c0 + spread < X::SYMS) b = rank_in_side128(g, sd, s0, c0 + spread, c);   // initFromTopBot gfm.h:347
 	else b = rank128(g, bot, c);
 	if(ie) ie->n = 0;
 	r->top = r->bot = r->node_top = r->node_bot = 0;
@@ -200,9 +219,9 @@ H2G_HD bool map_glf(const DGfm& g, uint32_t top, uint32_t bot, int c, uint32_t k
 	const uint32_t ft = node_to_Frow(g, t + 1, node_top, &F_loc, &M_occ);
 	const uint32_t node_bot = rank_M(g, b);
 	// :3812-3827 — the bottom takes the header of bot's own side, no backward scan
-	const uint32_t* q = reinterpret_cast<const uint32_t*>(g.sides + (size_t)(b / H2G_GSIDE_SYMS) * 128 + 104);
-	uint32_t bF = q[0];
-	const uint32_t bM = q[1];
+	const uint8_t* bsd = g.sides + (size_t)(b / X::SYMS) * 128;
+	uint32_t bF = side_hdr_mem<X>(bsd, 0);
+	const uint32_t bM = side_hdr_mem<X>(bsd, 1);
 	if(bM > 0) bF++;
 	const uint32_t fb = (node_bot + 1 > bM) ? select_F(g, bF, node_bot + 1 - bM) : bF;
 	r->top = ft; r->bot = fb; r->node_top = node_top; r->node_bot = node_bot;
@@ -211,9 +230,10 @@ H2G_HD bool map_glf(const DGfm& g, uint32_t top, uint32_t bot, int c, uint32_t k
 }
 
 // mapGLF1 (gfm.h:3957-4021) with mapLF1 (:3892): one row; false = cannot proceed on c
-H2G_HD bool map_glf1(const DGfm& g, uint32_t row, int c, GRange* r) {
+template <class X>
+H2G_HD bool map_glf1(const X& g, uint32_t row, int c, GRange* r) {
 	r->top = r->bot = r->node_top = r->node_bot = 0;
-	const uint32_t s0 = row / H2G_GSIDE_SYMS, c0 = row - s0 * H2G_GSIDE_SYMS;
+	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
 	if(rowL_in_side128(sd, c0) != c || is_zoff(g, row)) return false;
 	const uint32_t t = rank_in_side128(g, sd, s0, c0, c);
@@ -349,20 +369,23 @@ struct GwCtx {
 	GwState  st[H2G_GW_MAXST];
 };
 
-H2G_HD int rowL128(const DGfm& g, uint32_t row) {
-	const uint32_t s0 = row / H2G_GSIDE_SYMS, c0 = row - s0 * H2G_GSIDE_SYMS;
+template <class X>
+H2G_HD int rowL128(const X& g, uint32_t row) {
+	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
 	const uint32_t w = reinterpret_cast<const uint32_t*>(g.sides + (size_t)s0 * 128)[c0 >> 4];
 	return (int)((w >> ((c0 & 15) * 2)) & 3);
 }
-H2G_HD uint32_t gw_try_offset(const DGfm& g, uint32_t row, uint32_t node) {
+template <class X>
+H2G_HD uint32_t gw_try_offset(const X& g, uint32_t row, uint32_t node) {
 	if(is_zoff(g, row)) return 0;
-	if((node & g.offMask) == node) return g.offs[node >> g.offRate];
+	if((node & g.offMask) == node) return g.offs_at(node >> g.offRate);
 	return H2G_MAX;
 }
 // mapGLF1(row, l, &node_range) — no required character (gfm.h:4029-4095)
-H2G_HD void map_glf1_nochar(const DGfm& g, uint32_t row, GRange* r) {
+template <class X>
+H2G_HD void map_glf1_nochar(const X& g, uint32_t row, GRange* r) {
 	if(is_zoff(g, row)) { r->top = r->bot = H2G_MAX; r->node_top = r->node_bot = 0; return; }
-	const uint32_t s0 = row / H2G_GSIDE_SYMS, c0 = row - s0 * H2G_GSIDE_SYMS;
+	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
 	const int c = rowL_in_side128(sd, c0);
 	const uint32_t t = rank_in_side128(g, sd, s0, c0, c);
@@ -381,7 +404,8 @@ H2G_HD GwState* gw_new_state(GwCtx* x) {
 }
 // GWState::init (group_walk.h:506-885).  The '$'-split creates new states and initialises them; those never split again
 // at the same step deeper than the number of '$' rows, so the recursion of the reference is a bounded loop here.
-H2G_HD void gw_init(const DGfm& g, GwCtx* x, uint32_t range0) {
+template <class X>
+H2G_HD void gw_init(const X& g, GwCtx* x, uint32_t range0) {
 	uint32_t pending[H2G_GW_MAXST];
 	uint32_t npend = 0;
 	pending[npend++] = range0;
@@ -494,7 +518,8 @@ H2G_HD void gw_init(const DGfm& g, GwCtx* x, uint32_t range0) {
 	}
 }
 // narrowing of a freshly mapped element list whose rows merged into fewer nodes (:1143-1185, :1218-1262)
-H2G_HD void gw_merge_dups(const DGfm& g, GwCtx* x, uint32_t curtop, uint64_t mask, uint32_t nmask, int c, uint32_t* map, uint32_t* nmap) {
+template <class X>
+H2G_HD void gw_merge_dups(const X& g, GwCtx* x, uint32_t curtop, uint64_t mask, uint32_t nmask, int c, uint32_t* map, uint32_t* nmap) {
 	uint32_t j1 = 0, j2 = 0;
 	for(uint32_t k = 0; k < nmask; k++) if((mask >> k) & 1) { j1 = k; break; }
 	for(uint32_t j = 0; j + 1 < *nmap; j++) {
@@ -509,7 +534,8 @@ H2G_HD void gw_merge_dups(const DGfm& g, GwCtx* x, uint32_t curtop, uint64_t mas
 	*nmap = w;
 }
 // GWState::advance (group_walk.h:1035-1336)
-H2G_HD void gw_advance(const DGfm& g, GwCtx* x, uint32_t range) {
+template <class X>
+H2G_HD void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 	GwState* s = &x->st[range];
 	x->nsteps++;
 	if(s->bot - s->top > 1) {

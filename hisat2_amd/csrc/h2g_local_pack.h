@@ -32,9 +32,10 @@ inline void pack_local(const HostIndex& ix, LocalPack& lp) {
 		d.nZ = (uint32_t)l.zOffs.size(); d.zoff = l.zOffs.empty() ? H2G_MAX : l.zOffs[0];
 		d.tidx = l.tidx; d.localOffset = l.localOffset; d.joinedOffset = l.joinedOffset;
 		for(int i = 0; i < 5; i++) d.fchr[i] = l.fchr[i];
+		d.ftabLim = l.p.linear ? l.p.len : l.p.gbwtLen;
 		if(l.p.len > 0) {
 			lp.ftabChars = (uint32_t)l.p.ftabChars; lp.offRate = (uint32_t)l.p.offRate;
-			while(lp.sides.size() % 64) lp.sides.push_back(0);
+			while(lp.sides.size() % 128) lp.sides.push_back(0);
 			d.sides_off = lp.sides.size();
 			lp.sides.insert(lp.sides.end(), l.sides.begin(), l.sides.end());
 			auto put = [&](const std::vector<uint32_t>& v) { uint32_t off = (uint32_t)lp.words.size(); for(uint32_t x : v) lp.words.push_back((uint16_t)x); return off; };

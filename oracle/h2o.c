@@ -306,10 +306,10 @@ static uint32_t countUpTo_bits(const uint8_t* bits, int by, int bp) { /* gfm.h:3
 	}
 	return cCnt;
 }
-static uint32_t side_u32(const h2o_gfm* g, uint32_t sideNum, uint32_t k) { /* k: 0 F_loc, 1 M_occ */
-	uint32_t v;
-	memcpy(&v, g->gfm + (size_t)sideNum * g->p.sideSz + g->p.sideGbwtSz + 4 * k, 4);
-	return v;
+static uint32_t side_u32(const h2o_gfm* g, uint32_t sideNum, uint32_t k) { /* k: 0 F_loc, 1 M_occ (index_t / local_index_t words) */
+	const uint8_t* p = g->gfm + (size_t)sideNum * g->p.sideSz + g->p.sideGbwtSz + (size_t)g->p.wsz * k;
+	if(g->p.wsz == 4) { uint32_t v; memcpy(&v, p, 4); return v; }
+	uint16_t v; memcpy(&v, p, 2); return v;
 }
 uint32_t h2o_rank_M(const h2o_gfm* g, uint32_t row) { /* initFromRow_bit gfm.h:428; rank_M :4100; countMSide :3146 */
 	const h2o_params* p = &g->p;

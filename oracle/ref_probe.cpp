@@ -217,6 +217,45 @@ int main(int argc, char** argv) {
 		}
 		return 0;
 	}
+	if(cmd == "lglf") {
+		// lglf <base> <n> <seed>: mapGLF / mapGLF1 on random LOCAL graph indexes (LocalGFM<local_index_t>, 128 B sides of u16 words)
+		uint64_t n = strtoull(argv[3], NULL, 10), s = strtoull(argv[4], NULL, 10);
+		EList<pair<local_index_t, local_index_t> > iedges;
+		for(uint64_t i = 0; i < n; i++) {
+			uint64_t h = splitmix64(s);
+			index_t tidx = (index_t)((h >> 48) % gfm.nPat());
+			index_t tlen = gfm.plen()[tidx];
+			index_t toff = (index_t)((h >> 8) % tlen);
+			const LocalGFM<local_index_t, index_t>* l = p.gfm->getLocalGFM(tidx, toff);
+			if(l == NULL || l->gh()._len == 0) continue;
+			const GFMParams<local_index_t>& lh = l->gh();
+			local_index_t top = (local_index_t)(h % (lh._gbwtLen - 1));
+			int c = (int)((h >> 40) & 3);
+			if((h >> 63) & 1) {
+				SideLocus<local_index_t> loc;
+				loc.initFromRow(top, lh, l->gfm());
+				if(((h >> 50) & 7) != 0) c = l->rowL(loc);
+				pair<local_index_t, local_index_t> nr(0, 0);
+				pair<local_index_t, local_index_t> r = l->mapGLF1(top, loc, c, &nr);
+				printf("1 %u %u %u 0 %d %u %u %u %u 0\n", tidx, toff, (unsigned)top, c, (unsigned)r.first, (unsigned)r.second, (unsigned)nr.first, (unsigned)nr.second);
+				continue;
+			}
+			uint32_t spread = (uint32_t)((h >> 44) % 300) + 2;
+			if(((h >> 60) & 3) == 0) spread = (uint32_t)((h >> 44) % 6) + 2;
+			uint32_t bot = (uint32_t)top + spread;
+			if(bot > lh._gbwtLen) bot = lh._gbwtLen;
+			if(bot <= (uint32_t)top + 1) continue;
+			SideLocus<local_index_t> tl, bl;
+			SideLocus<local_index_t>::initFromTopBot(top, (local_index_t)bot, lh, l->gfm(), tl, bl);
+			pair<local_index_t, local_index_t> nr(0, 0);
+			iedges.clear();
+			pair<local_index_t, local_index_t> r = l->mapGLF(tl, bl, c, &nr, &iedges, 10);
+			printf("0 %u %u %u %u %d %u %u %u %u %u", tidx, toff, (unsigned)top, bot, c, (unsigned)r.first, (unsigned)r.second, (unsigned)nr.first, (unsigned)nr.second, (unsigned)iedges.size());
+			for(size_t e = 0; e < iedges.size(); e++) printf(" %u:%u", (unsigned)iedges[e].first, (unsigned)iedges[e].second);
+			putchar('\n');
+		}
+		return 0;
+	}
 	if(cmd == "glf" || cmd == "glf1") {
 		// glf  <base> <n> <seed>: random ranges [top, top+spread) and c -> mapGLF (graph LF on a range, gfm.h:3759)
 		// glf1 <base> <n> <seed>: random row and c -> mapGLF1 (gfm.h:3957)

@@ -57,7 +57,7 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dr.nrefs = r.nrefs;
 	e->dalts.a = reinterpret_cast<const DAlt*>(e->host.alts.data()); e->dalts.n = g.p.linear ? 0 : (uint32_t)e->host.alts.size();
 	e->dalts.maxAltsTried = 16;
-	if(g.p.linear) pack_local(e->host, e->lp);
+	pack_local(e->host, e->lp);
 	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data());
 	*out = e;
 	return 0;
@@ -106,6 +106,21 @@ void h2gemu_adjust_with_alt(Emu* e, const h2g_adjust_query* q, size_t n, uint32_
 		nhits[i] = ovf ? H2G_MAX : nh;
 	}
 	delete W;
+}
+
+// mapGLF / mapGLF1 on the LOCAL graph index covering (tidx, toff): q = {single, tidx, toff, top, bot, c}
+void h2gemu_local_graph_lf(Emu* e, const uint32_t* q, size_t n, uint32_t k, h2g_glf_result* res, h2g_iedges* ie) {
+	for(size_t i = 0; i < n; i++) {
+		const uint32_t* a = q + 6 * i;
+		const uint32_t lidx = local_index_of(e->dls, a[1], a[2]);
+		LGfm x = lgfm_of(e->dls, e->dls.desc[lidx]);
+		GRange r;
+		IEdges t;
+		t.n = 0;
+		bool ok = a[0] ? map_glf1(x, a[3], (int)a[5], &r) : map_glf(x, a[3], a[4], (int)a[5], k, &r, &t);
+		res[i].ok = ok; res[i].top = r.top; res[i].bot = r.bot; res[i].node_top = r.node_top; res[i].node_bot = r.node_bot;
+		ie[i] = t;
+	}
 }
 
 void h2gemu_fm_search_graph(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, uint32_t kseeds, h2g_fm_hit* out, h2g_iedges* ie) {

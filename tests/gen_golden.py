@@ -13,7 +13,7 @@ for a small seeded genome ("g1"):
 `gen_golden.py sw` adds reads_sw.fa.gz + probe_sw.txt.gz (SwAligner call-site vectors); `gen_golden.py graph` adds the GRAPH index fixtures without touching the above:
   g1s.snp.gz, g1s.{1..8}.ht2.gz   ~500 seeded variants of g1 and the hisat2-build-s --snp graph index
   reads_snp.fa.gz                 300 reads drawn from the alternate haplotype (all variants applied)
-  probe_g1s_{params,rank,glf,glf1,psearch,psearch_spliced,coords,coords_short,extend,adjust,adjust_short}.txt.gz   reference GFM graph-LF / group-walk outputs
+  probe_g1s_{params,rank,glf,glf1,psearch,psearch_spliced,coords,coords_short,extend,adjust,adjust_short,lglf}.txt.gz   reference GFM graph-LF / group-walk outputs
 Everything is deterministic (seeds below); the fixtures are committed.
 """
 import gzip
@@ -113,7 +113,7 @@ def main_graph():
     gz_write(os.path.join(GOLD, "reads_snp_short.fa.gz"), open(sfa, "rb").read())
     probe = os.path.join(REF, "ref_probe")
     for name, cmd, args in [("coords", "coords", [rfa, "1"]), ("coords_short", "coords", [sfa, "1"]), ("extend", "extend", [rfa, "1"]),
-                            ("adjust", "adjust", [rfa, "1"]), ("adjust_short", "adjust", [sfa, "1"]),
+                            ("lglf", "lglf", ["6000", "24"]), ("adjust", "adjust", [rfa, "1"]), ("adjust_short", "adjust", [sfa, "1"]),
                             ("params", "params", []), ("rank", "rank", ["3000", "21"]), ("glf", "glf", ["12000", "22"]),
                             ("glf1", "glf1", ["6000", "23"]), ("psearch", "psearch", [rfa, "1"]),
                             ("psearch_spliced", "psearch", [rfa, "0"])]:

@@ -68,6 +68,16 @@ class Emu:
         self.L.h2gemu_adjust_with_alt(self.h, q, n, cap, hits, nh)
         return hits, nh
 
+    def local_graph_lf(self, q6, k=10):
+        """q6: (n, 6) uint32 rows {single, tidx, toff, top, bot, c} -> mapGLF / mapGLF1 on the covering local graph index"""
+        q6 = np.ascontiguousarray(q6, dtype=np.uint32)
+        n = len(q6)
+        res = (api.GlfResult * n)()
+        ie = (api.IEdges * n)()
+        self.L.h2gemu_local_graph_lf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
+        self.L.h2gemu_local_graph_lf(self.h, q6.ctypes.data, n, k, res, ie)
+        return res, ie
+
     def sa_resolve_graph(self, queries, iedges, cap=24):
         n = len(queries)
         q = (api.GsaQuery * n)(*queries)

@@ -95,6 +95,19 @@ def test_graph_adjust_with_alt(golden_dir, g1s_index):
         assert PC.check_graph_adjust(e, golden_dir, fn) > 250
 
 
+def test_local_graph_lf(gemu, golden_dir):
+    import numpy as np
+    rows = [l.split() for l in H.glines(golden_dir, "probe_g1s_lglf.txt.gz")]
+    q = np.array([[int(v) for v in f[:6]] for f in rows], dtype=np.uint32)
+    res, ie = gemu.local_graph_lf(q, k=10)
+    for f, r, e in zip(rows, res, ie):
+        exp = tuple(map(int, f[6:10]))
+        if exp[:2] == (0, 0):
+            assert not r.ok
+        else:
+            assert r.ok and (r.top, r.bot, r.node_top, r.node_bot) == exp and e.pairs() == [tuple(map(int, x.split(":"))) for x in f[11:]], f
+
+
 def test_graph_lf_matches_oracle_on_random_ranges(gemu, oracle_lib, g1s_index):
     """fresh seeded ranges, incl. ranges that straddle sides and tiny ranges around multi-in-edge nodes"""
     import ctypes as C

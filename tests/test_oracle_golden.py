@@ -328,3 +328,31 @@ def test_graph_adjust_with_alt(oracle_lib, g1s_index, golden_dir, fn, reads):
         nshift += any(w[0][2] != toff for w in want)
         nsnp += any(w[0][4] > 0 for w in want)
     assert nsnp > 10 and (nshift > 3 or "short" not in fn)
+
+
+def test_local_graph_lf(oracle_lib, g1s_index, golden_dir):
+    """mapGLF / mapGLF1 on the LOCAL graph indexes (u16 words, 232 symbols per 128 B side)"""
+    ix = H.load_index(oracle_lib, g1s_index)
+    x = ix.contents
+    u32 = C.c_uint32
+    n = nie = 0
+    for l in H.glines(golden_dir, "probe_g1s_lglf.txt.gz"):
+        f = l.split()
+        single, tidx, toff, top, bot, c = map(int, f[:6])
+        exp = tuple(map(int, f[6:10]))
+        ie = [tuple(map(int, e.split(":"))) for e in f[11:]]
+        g = C.byref(x.local[x.local_first[tidx] + toff // 56320])
+        a, b, na, nb, nn = u32(), u32(), u32(), u32(), u32()
+        buf = (u32 * 128)()
+        if single:
+            r = oracle_lib.h2o_map_glf1(g, top, c, a, b, na, nb)
+            assert (not r and exp[:2] == (0, 0)) or (r and (a.value, b.value, na.value, nb.value) == exp), l
+        else:
+            oracle_lib.h2o_map_glf(g, top, bot, c, 10, a, b, na, nb, buf, 64, nn)
+            if exp[:2] == (0, 0):
+                assert (a.value, b.value) == (0, 0), l
+            else:
+                assert (a.value, b.value, na.value, nb.value) == exp and [(buf[2 * i], buf[2 * i + 1]) for i in range(nn.value)] == ie, l
+                nie += bool(ie)
+        n += 1
+    assert n == 6000 and nie >= 3
