@@ -23,7 +23,7 @@
 
 namespace h2g {
 
-#define AL_MAX_GHITS    10    // max(khits, kseeds) for linear indexes (hisat2.cpp:3174-3176, 3903-3906)
+#define AL_MAX_GHITS    20    // max(khits, kseeds): 10 on linear, 20 on graph indexes (hisat2.cpp:3174-3176, 3903-3906)
 #define AL_MAX_SEARCHED 64
 #define AL_MAX_RESULTS  32
 #define AL_MAX_DEPTH    40
@@ -186,40 +186,46 @@ H2G_HD uint32_t sa_walk_idx(const IDX& ix, uint32_t row, uint32_t offMask, uint3
 	return jumps;
 }
 
-// getGenomeCoords_local hi_aligner.h:5861-5941 (LocalGFM joinedToTextOff with 16-bit rstarts; forward index)
+// LocalGFM::joinedToTextOff (gfm.h:5527, 16-bit rstarts, rejectStraddle = true) + the local -> global shift of
+// getGenomeCoords_local (hi_aligner.h:5925-5934).  false = skip this element.
+H2G_HD bool local_joff_to_coord(const DLocalSet& ls, const DLocalDesc* d, uint32_t joff, uint32_t rdoff, uint32_t rdlen, h2g_coord* out) {
+	const uint16_t* rs = ls.words + d->rstarts_off;
+	uint32_t lo = 0, hi = d->nFrag, elt = H2G_MAX, toff = 0;
+	bool ok = false;
+	while(true) {
+		uint32_t oldelt = elt;
+		elt = lo + ((hi - lo) >> 1);
+		if(oldelt == elt) break;
+		uint32_t lower = rs[elt * 3], upper = (elt == d->nFrag - 1) ? d->len : rs[(elt + 1) * 3];
+		if(lower <= joff) {
+			if(upper > joff) {
+				if(joff + rdlen > upper) break;          // straddles: rejected => result false
+				toff = (joff - lower) + rs[elt * 3 + 2];
+				ok = true;
+				break;
+			}
+			lo = elt;
+		} else hi = elt;
+	}
+	if(!ok) return false;                                    // `if(!result) continue;`
+	const uint32_t global_toff = toff + d->localOffset;
+	if(global_toff < rdoff) return false;
+	out->tidx = d->tidx; out->toff = global_toff; out->joinedOff = joff + d->joinedOffset;
+	return true;
+}
+
+// getGenomeCoords_local hi_aligner.h:5861-5941 on a linear local index
 H2G_HD bool genome_coords_local(const LIdx& ix, uint32_t top, uint32_t bot, uint32_t rdoff, uint32_t rdlen, h2g_coord* coords,
                                 uint32_t cap, uint32_t* ncoords, uint32_t* nsteps)
 {
 	const DLocalDesc* d = ix.d;
-	const uint16_t* rs = ix.ls->words + d->rstarts_off;
 	const uint32_t offMask = (0xffffu << ix.ls->offRate) & 0xffffu;
 	uint32_t n = 0;
 	for(uint32_t e = 0; e < bot - top; e++) {
 		uint32_t joff = sa_walk_idx(ix, top + e, offMask, ix.ls->offRate, ix.ls->words + d->offs_off, true, nsteps);
-		// joinedToTextOff (gfm.h:5527) with rejectStraddle = true
-		uint32_t lo = 0, hi = d->nFrag, elt = H2G_MAX, tidx = H2G_MAX, toff = 0;
-		bool ok = false;
-		while(true) {
-			uint32_t oldelt = elt;
-			elt = lo + ((hi - lo) >> 1);
-			if(oldelt == elt) break;
-			uint32_t lower = rs[elt * 3], upper = (elt == d->nFrag - 1) ? d->len : rs[(elt + 1) * 3];
-			if(lower <= joff) {
-				if(upper > joff) {
-					if(joff + rdlen > upper) break;          // straddles: rejected => result false
-					tidx = rs[elt * 3 + 1];
-					toff = (joff - lower) + rs[elt * 3 + 2];
-					ok = true;
-					break;
-				}
-				lo = elt;
-			} else hi = elt;
-		}
-		if(!ok) continue;                                    // `if(!result) continue;`
-		(void)tidx;
-		uint32_t global_toff = toff + d->localOffset;
-		if(global_toff < rdoff) continue;
-		if(n < cap) { coords[n].tidx = d->tidx; coords[n].toff = global_toff; coords[n].joinedOff = joff + d->joinedOffset; n++; }
+		h2g_coord c;
+		if(!local_joff_to_coord(*ix.ls, d, joff, rdoff, rdlen, &c)) continue;
+		if(n < cap) coords[n++] = c;
 	}
 	*ncoords = n;
 	return true;
@@ -279,7 +285,7 @@ H2G_HD void hit_get_left(const h2g_ghit* h, const DScoring* sc, const SeqView* s
 	if(score) *score = 0;
 	for(uint32_t i = 0; i < h->nedits; i++) {
 		const h2g_edit e = h->edits[i];
-		if(is_gap(e.type)) { *len = e.pos; break; }
+		if(is_stop_edit(e)) { *len = e.pos; break; }
 		if(score && e.type == H2G_EDIT_MM)
 			*score += score_cell(*sc, base_code(e.qchr), base_code(e.chr), seq->qual(h->rdoff + e.pos) - 33);
 	}
@@ -293,7 +299,7 @@ H2G_HD void hit_get_right_sc(const h2g_ghit* h, const DScoring* sc, const SeqVie
 	*score = 0;
 	for(int i = (int)h->nedits - 1; i >= 0; i--) {
 		const h2g_edit e = h->edits[i];
-		if(is_gap(e.type)) break;
+		if(is_stop_edit(e)) break;
 		if(e.type == H2G_EDIT_MM)
 			*score += score_cell(*sc, base_code(e.qchr), base_code(e.chr), seq->qual(h->rdoff + e.pos) - 33);
 	}
@@ -330,6 +336,7 @@ H2G_HD void hit_left_align(h2g_ghit* h, const SeqView& seq) {
 	for(uint32_t ei = 0; ei < h->nedits; ei++) {
 		h2g_edit& edit = h->edits[ei];
 		if(!is_gap(edit.type)) continue;
+		if(edit.snp != H2G_MAX) continue;                        // known indels stay where the ALT puts them (:3562)
 		uint32_t ei2 = ei + 1;
 		for(; ei2 < h->nedits; ei2++) {
 			const h2g_edit& e2 = h->edits[ei2];
@@ -367,7 +374,7 @@ H2G_HD void hit_push_edit(h2g_ghit* h, uint32_t pos, uint8_t chr, uint8_t qchr, 
 // combineWith hi_aligner.h:1420-2025 for linear indexes without spliced alignment: plain concatenation
 // (:1506-1525) or one insertion / deletion placed by the prefix/suffix score scan (:1741-1794).
 H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq, h2g_ghit* a, const h2g_ghit* b, int64_t minsc,
-                        uint32_t minIntronLen, bool no_spliced, int64_t* tmp1, int64_t* tmp2)
+                        uint32_t minIntronLen, bool no_spliced, int64_t* tmp1, int64_t* tmp2, const DAlts* alts = nullptr)
 {
 	if(a == b) return false;
 	uint32_t this_rdoff, this_len, this_toff, other_rdoff, other_len, other_toff;
@@ -447,7 +454,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 	{
 		bool clear = true;
 		for(int i = (int)a->nedits - 1; i >= 0; i--) {
-			if(is_gap(a->edits[i].type)) { a->nedits = (uint32_t)i + 1; clear = false; break; }
+			if(is_stop_edit(a->edits[i])) { a->nedits = (uint32_t)i + 1; clear = false; break; }
 		}
 		if(clear) a->nedits = 0;
 	}
@@ -458,7 +465,18 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 			int rdc = seq.at(this_rdoff + i);
 			int64_t p2 = base2 + i;
 			int rfc = (i <= maxscorei) ? rc1.get((int64_t)this_toff + i) : (p2 < 0 ? 4 : rc2.get(p2));
-			if(rdc != rfc) hit_push_edit(a, i + addoff, base_char(rfc), base_char(rdc), H2G_EDIT_MM);
+			if(rdc != rfc) {
+				hit_push_edit(a, i + addoff, base_char(rfc), base_char(rdc), H2G_EDIT_MM);
+				if(alts && alts->n && !a->overflow) {                  // known SNP at this position? (:1913-1931)
+					const uint32_t cpos = a->joinedOff + i + (this_toff - a->toff) - ins_len;
+					for(uint32_t ai = alt_lobound(*alts, cpos); ai < alts->n; ai++) {
+						const DAlt alt = alts->a[ai];
+						if(alt.pos > cpos) break;
+						if(alt.type != H2G_ALT_SNP_SGL) continue;
+						if(alt.seq == (uint64_t)rdc) { a->edits[a->nedits - 1].snp = ai; break; }
+					}
+				}
+			}
 			if(i == maxscorei) {
 				const uint32_t left = this_toff + i + 1;
 				if(other_toff + other_len < len - i - 1) return false;
@@ -480,13 +498,15 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 				}
 			}
 		}
-		(void)ins_len;
 	}
 	{
 		uint32_t fsi = b->nedits;
-		for(uint32_t i = 0; i < b->nedits; i++) if(is_gap(b->edits[i].type)) { fsi = i; break; }
+		for(uint32_t i = 0; i < b->nedits; i++) if(is_stop_edit(b->edits[i])) { fsi = i; break; }
 		const uint32_t addoff = b->rdoff - a->rdoff;
-		for(uint32_t i = fsi; i < b->nedits; i++) hit_push_edit(a, b->edits[i].pos + addoff, b->edits[i].chr, b->edits[i].qchr, b->edits[i].type);
+		for(uint32_t i = fsi; i < b->nedits; i++) {
+			hit_push_edit(a, b->edits[i].pos + addoff, b->edits[i].chr, b->edits[i].qchr, b->edits[i].type);
+			if(!a->overflow) a->edits[a->nedits - 1].snp = b->edits[i].snp;
+		}
 	}
 	if(ins || del) hit_left_align(a, seq);
 	a->len = b->rdoff + b->len - a->rdoff;
@@ -635,8 +655,53 @@ H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdl
 // ---------------------------------------------------------------------------------------- getAnchorHits (a16)
 H2G_HD bool ph_empty(const PartialHit& p) { return p.bot <= p.top; }
 
+struct AlnCtx {
+	const DGfm* g;
+	const DRef* ref;
+	const DLocalSet* ls;
+	const AlnParams* P;
+	uint8_t* sw = nullptr;   // this lane's Smith-Waterman scratch (sw_scratch_bytes), only when P->bowtie2_dp != 0
+	const DAlts* alts = nullptr;      // graph index: the ALT database
+	struct GraphWS* gws = nullptr;    // graph index: this lane's graph scratch
+};
+
+// Per-lane scratch of the graph paths (allocated only for graph indexes, so the linear workspace keeps its size):
+// group-walk state, ALT-extension state, and the node range + in-edge list of every partial hit (BWTHit::_node_top,
+// _node_bot, _node_iedge_count hi_aligner.h:196-199), indexed [mate slot][strand][partial hit].
+struct GraphPNode { uint32_t node_top, node_bot; IEdges ie; };
+struct GraphWS {
+	GwCtx      gw;
+	AwaWS      awa;
+	IEdges     ie;                 // in-edge list of the last search (waits for the coordinate call)
+	uint32_t   node_top, node_bot; // its node range
+	GraphPNode pnode[2][2][AL_MAX_PARTIAL];
+};
+
+// localGFMSearch / getGenomeCoords_local / globalGFMSearch / getGenomeCoords on whichever index this is.  On a graph
+// index the node range and in-edge list of the last search wait in the lane's GraphWS for the coordinate call.
+H2G_HD uint32_t al_local_search(const AlnCtx& C, AlignWS* ws, uint32_t lidx, const SeqView& seq, uint32_t extoff, uint32_t* extlen,
+                                uint32_t* top, uint32_t* bot, bool* uniqueStop, uint32_t maxHitLen);
+H2G_HD void al_local_coords(const AlnCtx& C, AlignWS* ws, uint32_t lidx, uint32_t top, uint32_t bot, uint32_t rdoff, uint32_t rdlen,
+                            h2g_coord* coords, uint32_t cap, uint32_t* ncoords);
+H2G_HD uint32_t al_global_search(const AlnCtx& C, AlignWS* ws, const SeqView& seq, uint32_t extoff, uint32_t* extlen, uint32_t* top,
+                                 uint32_t* bot, bool* uniqueStop);
+H2G_HD uint32_t al_global_coords(const AlnCtx& C, AlignWS* ws, uint32_t top, uint32_t bot, uint32_t extlen, h2g_coord* coords, uint32_t cap);
+
+// tempHit.adjustWithALT(...) of hybridSearch_recur (spliced_aligner.h:946, 1139, 1635, 1826): always true on a linear index
+H2G_HD bool al_adjust_member(const AlnCtx& C, const SeqView& seq, h2g_ghit* t, AlignWS* ws);
+
+// GenomeHit::extend on whichever index this is
+H2G_HD bool al_extend(const AlnCtx& C, const SeqView& seq, h2g_ghit* h, uint32_t mm, uint32_t ml, uint32_t mr, uint32_t* le, uint32_t* re) {
+	if(C.g->linear) return extend_item(*C.ref, C.P->sc, seq, h, mm, ml, mr, le, re);
+	return extend_item_alts(*C.ref, *C.alts, C.P->sc, seq, h, mm, ml, mr, le, re, &C.gws->awa);
+}
+
 // hi_aligner.h:5007-5193 for one (read, strand)
-H2G_HD uint32_t al_get_anchor_hits(const DGfm& g, const AlnParams& P, const SeqView& seq, AlignWS* ws, MateWS* mw, int fwi, Rng* rnd) {
+H2G_HD uint32_t al_get_anchor_hits(const AlnCtx& C, const SeqView& seq, AlignWS* ws, MateWS* mw, int fwi, Rng* rnd) {
+	const DGfm& g = *C.g;
+	const AlnParams& P = *C.P;
+	const bool graph = !g.linear;
+	const int slot = (int)(mw - ws->m);
 	RBHit& hit = mw->rb[fwi];
 	const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
 	const uint32_t minK = g.minK;
@@ -662,15 +727,45 @@ H2G_HD uint32_t al_get_anchor_hits(const DGfm& g, const AlnParams& P, const SeqV
 		PartialHit& ph = hit.partial[hj];
 		const uint32_t remained = maxsz - ws->nghits;
 		if(remained == 0) break;
-		uint32_t expected = ph.bot - ph.top;
+		const GraphPNode* pn = graph ? &C.gws->pnode[slot][fwi][hj] : nullptr;
+		uint32_t expected = graph ? pn->node_bot - pn->node_top : ph.bot - ph.top;
 		h2g_coord* co = ph.coords;
 		uint32_t nco = 0;
 		const uint32_t rdoff = hit.len - ph.bwoff - ph.len;
 		if(expected <= remained) {
 			h2g_sa_result res;
-			genome_coords_item(g, ph.top, ph.bot, ph.bot - ph.top, ph.len, false, co, AL_MAX_GHITS, &res);
+			if(graph) genome_coords_graph_item(g, &C.gws->gw, ph.top, ph.bot, pn->node_top, pn->node_bot, &pn->ie, ph.bot - ph.top, ph.len, false, co, AL_MAX_GHITS, &res);
+			else genome_coords_item(g, ph.top, ph.bot, ph.bot - ph.top, ph.len, false, co, AL_MAX_GHITS, &res);
+			if(res.nsteps == H2G_MAX) { ws->overflow |= 512; res.nsteps = 0; }
 			nco = res.ncoords;
 			ws->nsteps += res.nsteps;
+		} else if(graph) {   // random sub-sample of `remained` NODES, each with its own rows / extra in-edges (:5096-5136)
+			uint32_t edgeIdx = 0, top = ph.top, added = 0;
+			for(uint32_t node = pn->node_top; node < pn->node_bot; node++, expected--) {
+				uint32_t bot = top + 1;
+				IEdges& t = C.gws->ie;
+				t.n = 0;
+				if(edgeIdx < pn->ie.n && edgeIdx < H2G_IEDGE_CAP) {
+					if(node - pn->node_top == pn->ie.e[edgeIdx][0]) {
+						bot += pn->ie.e[edgeIdx][1];
+						t.n = 1; t.e[0][0] = 0; t.e[0][1] = pn->ie.e[edgeIdx][1];
+						edgeIdx++;
+					}
+				}
+				uint32_t rndi = rnd->nextU32() % expected;
+				if(rndi < remained - added) {
+					h2g_sa_result res;
+					if(nco < AL_MAX_GHITS) {
+						genome_coords_graph_item(g, &C.gws->gw, top, bot, node, node + 1, &t, ph.bot - ph.top, ph.len, false, co + nco, AL_MAX_GHITS - nco, &res);
+						if(res.nsteps == H2G_MAX) { ws->overflow |= 512; res.nsteps = 0; }
+						nco += res.ncoords;
+						ws->nsteps += res.nsteps;
+					} else ws->overflow |= 64;
+					added++;
+					if(added >= remained) break;
+				}
+				top = bot;
+			}
 		} else {   // random sub-sample of `remained` rows (:5096-5136)
 			uint32_t top = ph.top, added = 0;
 			for(uint32_t node = ph.top; node < ph.bot; node++, expected--) {
@@ -689,6 +784,7 @@ H2G_HD uint32_t al_get_anchor_hits(const DGfm& g, const AlnParams& P, const SeqV
 				top = bot;
 			}
 		}
+		AL_TRACE("   anchor hj %u nco %u expected %u remained %u\n", hj, nco, expected, remained);
 		ph.ncoords = nco;
 		if(nco == 0) continue;                       // !hasGenomeCoords()
 		const uint32_t genomeHit_size = ws->nghits;
@@ -715,7 +811,12 @@ H2G_HD uint32_t al_get_anchor_hits(const DGfm& g, const AlnParams& P, const SeqV
 				if(d <= diff) { overlapped = true; gh.read++; break; }   // _hitcount++
 			}
 			if(!overlapped) {
-				if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], seq.fw, rdoff, len, co[k].tidx, co[k].toff, co[k].joinedOff);
+				if(graph) {                                        // adjustWithALT may add several (or no) hits (:5175)
+					uint32_t ovf = 0;
+					adjust_with_alt(g, *C.ref, *C.alts, seq, rdoff, len, co[k].tidx, co[k].toff, co[k].joinedOff, ws->ghits, &ws->nghits, AL_MAX_GHITS,
+					                &C.gws->awa, &ovf);
+					if(ovf) ws->overflow |= 64;
+				} else if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], seq.fw, rdoff, len, co[k].tidx, co[k].toff, co[k].joinedOff);
 				else ws->overflow |= 64;
 			}
 			if(ph.hit_type == H2G_CANDIDATE_HIT && ws->nghits >= maxsz) break;
@@ -725,6 +826,73 @@ H2G_HD uint32_t al_get_anchor_hits(const DGfm& g, const AlnParams& P, const SeqV
 	return ws->nghits;
 }
 
+H2G_HD bool al_adjust_member(const AlnCtx& C, const SeqView& seq, h2g_ghit* t, AlignWS* ws) {
+	if(C.g->linear) return true;
+	uint32_t ovf = 0;
+	const bool ok = adjust_with_alt_member(*C.g, *C.ref, *C.alts, seq, t, &C.gws->awa, &ovf);
+	if(ovf) ws->overflow |= 1;
+	return ok;
+}
+H2G_HD uint32_t al_local_search(const AlnCtx& C, AlignWS* ws, uint32_t lidx, const SeqView& seq, uint32_t extoff, uint32_t* extlen,
+                                uint32_t* top, uint32_t* bot, bool* uniqueStop, uint32_t maxHitLen)
+{
+	const AlnParams& P = *C.P;
+	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
+	if(C.g->linear) return gfm_search(lx, seq, extoff, extlen, top, bot, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true, &ws->nrank);
+	const LGfm x = lgfm_of(*C.ls, *lx.d);
+	GRange r;
+	r.top = *top; r.bot = *bot; r.node_top = r.node_bot = 0;
+	const uint32_t nelt = gfm_search_graph(x, lx, seq, extoff, extlen, &r, &C.gws->ie, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true,
+	                                       P.kseeds, &ws->nrank);
+	*top = r.top; *bot = r.bot;
+	C.gws->node_top = r.node_top; C.gws->node_bot = r.node_bot;
+	return nelt;
+}
+H2G_HD void al_local_coords(const AlnCtx& C, AlignWS* ws, uint32_t lidx, uint32_t top, uint32_t bot, uint32_t rdoff, uint32_t rdlen,
+                            h2g_coord* coords, uint32_t cap, uint32_t* ncoords)
+{
+	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
+	if(C.g->linear) { genome_coords_local(lx, top, bot, rdoff, rdlen, coords, cap, ncoords, &ws->nsteps); return; }
+	const LGfm x = lgfm_of(*C.ls, *lx.d);
+	const uint32_t node_top = C.gws->node_top, node_bot = C.gws->node_bot;
+	uint32_t nelt = 0, n = 0;
+	*ncoords = 0;
+	if(!gw_resolve(x, &C.gws->gw, top, bot, node_top, node_bot, &C.gws->ie, bot - top, &nelt)) { ws->overflow |= 512; return; }
+	ws->nsteps += C.gws->gw.nsteps;
+	for(uint32_t e = 0; e < nelt; e++) {
+		h2g_coord c;
+		if(!local_joff_to_coord(*C.ls, lx.d, C.gws->gw.offs[e] & 0xffffu, rdoff, rdlen, &c)) continue;
+		if(n < cap) coords[n++] = c; else ws->overflow |= 512;
+	}
+	*ncoords = n;
+}
+H2G_HD uint32_t al_global_search(const AlnCtx& C, AlignWS* ws, const SeqView& seq, uint32_t extoff, uint32_t* extlen, uint32_t* top,
+                                 uint32_t* bot, bool* uniqueStop)
+{
+	const AlnParams& P = *C.P;
+	GIdx gx; gx.g = C.g;
+	if(C.g->linear) return gfm_search(gx, seq, extoff, extlen, top, bot, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false, &ws->nrank);
+	GRange r;
+	r.top = *top; r.bot = *bot; r.node_top = r.node_bot = 0;
+	const uint32_t nelt = gfm_search_graph(*C.g, gx, seq, extoff, extlen, &r, &C.gws->ie, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false,
+	                                       P.kseeds, &ws->nrank);
+	if(nelt > 0) { *top = r.top; *bot = r.bot; }
+	C.gws->node_top = r.node_top; C.gws->node_bot = r.node_bot;
+	return nelt;
+}
+H2G_HD uint32_t al_global_coords(const AlnCtx& C, AlignWS* ws, uint32_t top, uint32_t bot, uint32_t extlen, h2g_coord* coords, uint32_t cap) {
+	h2g_sa_result res;
+	if(C.g->linear) genome_coords_item(*C.g, top, bot, bot - top, extlen, true, coords, cap, &res);
+	else {
+		genome_coords_graph_item(*C.g, &C.gws->gw, top, bot, C.gws->node_top, C.gws->node_bot, &C.gws->ie, bot - top, extlen, true,
+		                         coords, cap, &res);
+		if(res.nsteps == H2G_MAX) { ws->overflow |= 512; res.nsteps = 0; }
+	}
+	ws->nsteps += res.nsteps;
+	return res.ncoords;
+}
+
+
 // ---------------------------------------------------------------------------------------- hybridSearch_recur (a21)
 enum {
 	ST_ENTRY = 0,
@@ -732,14 +900,6 @@ enum {
 	ST_L_EXT, ST_L_R5,
 	ST_R_WHILE, ST_R_FOR_RI, ST_R_R1, ST_R_AFTER_FOR, ST_R_FOR_TI, ST_R_R2, ST_R_AFTER_WHILE, ST_R_FOR_G, ST_R_R3, ST_R_TRIM, ST_R_R4,
 	ST_R_EXT, ST_R_R5
-};
-
-struct AlnCtx {
-	const DGfm* g;
-	const DRef* ref;
-	const DLocalSet* ls;
-	const AlnParams* P;
-	uint8_t* sw = nullptr;   // this lane's Smith-Waterman scratch (sw_scratch_bytes), only when P->bowtie2_dp != 0
 };
 
 H2G_HD uint32_t local_index_of(const DLocalSet& ls, uint32_t tidx, uint32_t toff) {   // HGFM::getLocalGFM hgfm.h:1713
@@ -821,7 +981,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				if(hitoff == hit.rdoff && hitoff <= minK) {
 					hit_copy(&ws->tmp, &hit);
 					uint32_t le, re;
-					extend_item(*C.ref, sc, seq, &ws->tmp, 1, H2G_MAX, 0, &le, &re);
+					al_extend(C, seq, &ws->tmp, 1, H2G_MAX, 0, &le, &re);
 					if(ws->tmp.rdoff == 0) f.use_localindex = 0;
 				}
 				f.lidx = local_index_of(*C.ls, hit.tidx, hit.toff);
@@ -834,7 +994,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				if(hit.len == hitlen && hitoff + hitlen + minK > rdlen) {
 					hit_copy(&ws->tmp, &hit);
 					uint32_t le, re;
-					extend_item(*C.ref, sc, seq, &ws->tmp, 1, 0, H2G_MAX, &le, &re);
+					al_extend(C, seq, &ws->tmp, 1, 0, H2G_MAX, &le, &re);
 					if(ws->tmp.rdoff + ws->tmp.len == rdlen) f.use_localindex = 0;
 				}
 				f.lidx = local_index_of(*C.ls, hit.tidx, hit.toff);
@@ -867,14 +1027,14 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				extlen = 0; uniqueStop = true;
 				ws->localindexatts++;
 				nelt = C.ls->desc[f.lidx].len == 0 ? 0 :
-				       gfm_search(lx, seq, extoff, &extlen, &top, &bot, &uniqueStop, minK_local, 0xffffu, P.kseeds, true, &ws->nrank);
+				       al_local_search(C, ws, f.lidx, seq, extoff, &extlen, &top, &bot, &uniqueStop, 0xffffu);
 				if(extoff + 1 - extlen >= hitoff) { no_extension = true; break; }
 				if(nelt <= max_nelt) break;
 			}
 			f.ncoords = 0; f.ri = -1;
 			f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
 			if(nelt > 0 && nelt <= max_nelt && extlen >= P.minAnchorLen && !no_extension) {
-				genome_coords_local(lx, top, bot, extoff + 1 - extlen, extlen, f.coords, AL_MAX_COORDS, &f.ncoords, &ws->nsteps);
+				al_local_coords(C, ws, f.lidx, top, bot, extoff + 1 - extlen, extlen, f.coords, AL_MAX_COORDS, &f.ncoords);
 				sort_coords(f.coords, f.ncoords);
 				f.ri = (int)f.ncoords - 1;
 			}
@@ -886,13 +1046,14 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			const h2g_coord co = f.coords[f.ri];
 			h2g_ghit* t = &ws->tmp;
 			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+			if(!al_adjust_member(C, seq, t, ws)) { f.ri--; goto next_iter; }
 			if(!hit_compatible(t, &hit, P.maxIntronLen, no_spliced)) {
 				if(f.count == 1) { f.ri--; goto next_iter; }
 				f.state = ST_L_AFTER_FOR; goto next_iter;
 			}
-			if(f.uniqueStop) { uint32_t le, re; extend_item(*C.ref, sc, seq, t, 0, H2G_MAX, 0, &le, &re); }
+			if(f.uniqueStop) { uint32_t le, re; al_extend(C, seq, t, 0, H2G_MAX, 0, &le, &re); }
 			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2);
+			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
 			if(t->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			f.ri--;
@@ -930,13 +1091,10 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				const uint32_t extoff = hitoff - 1;
 				bool uniqueStop = true;
 				GIdx gx; gx.g = C.g;
-				uint32_t nelt = gfm_search(gx, seq, extoff, &extlen, &top, &bot, &uniqueStop, minK, H2G_MAX, P.kseeds, false, &ws->nrank);
+				uint32_t nelt = al_global_search(C, ws, seq, extoff, &extlen, &top, &bot, &uniqueStop);
 				f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
 				if(nelt > 0 && nelt <= 5 && extlen >= minK) {
-					h2g_sa_result res;
-					genome_coords_item(*C.g, top, bot, bot - top, extlen, true, f.coords, AL_MAX_COORDS, &res);
-					ws->nsteps += res.nsteps;
-					f.ncoords = res.ok ? res.ncoords : res.ncoords;
+					f.ncoords = al_global_coords(C, ws, top, bot, extlen, f.coords, AL_MAX_COORDS);
 					if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
 					f.ri = (int)f.ncoords - 1;
 				}
@@ -950,10 +1108,11 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			f.ri--;
 			h2g_ghit* t = &ws->tmp;
 			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+			if(!al_adjust_member(C, seq, t, ws)) goto next_iter;
 			if(!hit_compatible(t, &hit, P.maxIntronLen, no_spliced)) goto next_iter;
-			if(f.uniqueStop) { uint32_t le, re; extend_item(*C.ref, sc, seq, t, 0, H2G_MAX, 0, &le, &re); }
+			if(f.uniqueStop) { uint32_t le, re; al_extend(C, seq, t, 0, H2G_MAX, 0, &le, &re); }
 			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2);
+			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
 			if(t->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			if(combined && t->score >= m) AL_CALL(t, t->rdoff, t->len + t->trim3, ST_L_R3);
@@ -983,7 +1142,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			uint32_t nmm = 1;
 			if(hitoff <= minK_local) nmm = t->rdoff < mm ? t->rdoff : mm;
 			uint32_t le = 0, re = 0;
-			extend_item(*C.ref, sc, seq, t, nmm, H2G_MAX, 0, &le, &re);
+			al_extend(C, seq, t, nmm, H2G_MAX, 0, &le, &re);
 			if(t->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			const uint32_t need = minK_local < hit.rdoff ? minK_local : hit.rdoff;
@@ -1022,7 +1181,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				extlen = 0; uniqueStop = false;
 				ws->localindexatts++;
 				nelt = C.ls->desc[f.lidx].len == 0 ? 0 :
-				       gfm_search(lx, seq, extoff, &extlen, &top, &bot, &uniqueStop, minK_local, maxHitLen, P.kseeds, true, &ws->nrank);
+				       al_local_search(C, ws, f.lidx, seq, extoff, &extlen, &top, &bot, &uniqueStop, maxHitLen);
 				if(extoff < hitoff + hitlen) { no_extension = true; break; }
 				if(nelt <= max_nelt) break;
 				if(extoff + 1 < rdlen) extoff++;
@@ -1031,7 +1190,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			f.ncoords = 0; f.ri = 0;
 			f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
 			if(nelt > 0 && nelt <= max_nelt && extlen >= P.minAnchorLen && !no_extension) {
-				genome_coords_local(lx, top, bot, extoff + 1 - extlen, extlen, f.coords, AL_MAX_COORDS, &f.ncoords, &ws->nsteps);
+				al_local_coords(C, ws, f.lidx, top, bot, extoff + 1 - extlen, extlen, f.coords, AL_MAX_COORDS, &f.ncoords);
 				if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
 			}
 			f.state = ST_R_FOR_RI;
@@ -1042,15 +1201,16 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			const h2g_coord co = f.coords[f.ri];
 			h2g_ghit* t = &ws->tmp;
 			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+			if(!al_adjust_member(C, seq, t, ws)) { f.ri++; goto next_iter; }
 			if(!hit_compatible(&hit, t, P.maxIntronLen, no_spliced)) {
 				if(f.count == 1) { f.ri++; goto next_iter; }
 				f.state = ST_R_AFTER_FOR; goto next_iter;
 			}
-			{ uint32_t le, re; extend_item(*C.ref, sc, seq, t, 0, 0, H2G_MAX, &le, &re); }
+			{ uint32_t le, re; al_extend(C, seq, t, 0, 0, H2G_MAX, &le, &re); }
 			h2g_ghit* cmb = &ws->tmp2;
 			hit_copy(cmb, &hit);
 			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, cmb, t, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2);
+			bool combined = hit_combine(*C.ref, sc, seq, cmb, t, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
 			if(cmb->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			f.ri++;
@@ -1088,13 +1248,10 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				const uint32_t extoff = hitoff + hitlen + minK + 1;
 				bool uniqueStop = true;
 				GIdx gx; gx.g = C.g;
-				uint32_t nelt = gfm_search(gx, seq, extoff, &extlen, &top, &bot, &uniqueStop, minK, H2G_MAX, P.kseeds, false, &ws->nrank);
+				uint32_t nelt = al_global_search(C, ws, seq, extoff, &extlen, &top, &bot, &uniqueStop);
 				f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
 				if(nelt > 0 && nelt <= 5 && extlen >= minK) {
-					h2g_sa_result res;
-					genome_coords_item(*C.g, top, bot, bot - top, extlen, true, f.coords, AL_MAX_COORDS, &res);
-					ws->nsteps += res.nsteps;
-					f.ncoords = res.ncoords;
+					f.ncoords = al_global_coords(C, ws, top, bot, extlen, f.coords, AL_MAX_COORDS);
 					sort_coords(f.coords, f.ncoords);
 				}
 			}
@@ -1107,12 +1264,13 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			f.ri++;
 			h2g_ghit* t = &ws->tmp;
 			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+			if(!al_adjust_member(C, seq, t, ws)) goto next_iter;
 			if(!hit_compatible(&hit, t, P.maxIntronLen, no_spliced)) goto next_iter;
-			{ uint32_t le, re; extend_item(*C.ref, sc, seq, t, 0, 0, H2G_MAX, &le, &re); }
+			{ uint32_t le, re; al_extend(C, seq, t, 0, 0, H2G_MAX, &le, &re); }
 			h2g_ghit* cmb = &ws->tmp2;
 			hit_copy(cmb, &hit);
 			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, cmb, t, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2);
+			bool combined = hit_combine(*C.ref, sc, seq, cmb, t, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
 			if(cmb->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			if(combined && cmb->score >= m) AL_CALL(cmb, cmb->rdoff - cmb->trim5, cmb->len + cmb->trim5, ST_R_R3);
@@ -1146,7 +1304,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				nmm = rest < mm ? rest : mm;
 			}
 			uint32_t le = 0, re = 0;
-			extend_item(*C.ref, sc, seq, t, nmm, 0, H2G_MAX, &le, &re);
+			al_extend(C, seq, t, nmm, 0, H2G_MAX, &le, &re);
 			if(t->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			const uint32_t rest0 = rdlen - hit.len - hit.rdoff;
@@ -1263,7 +1421,7 @@ H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, Ma
 	const AlnParams& P = *C.P;
 	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
 		uint32_t le = H2G_MAX, re = H2G_MAX;
-		extend_item(*C.ref, C.P->sc, sv, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
+		al_extend(C, sv, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
 		ws->ghit_done[hi] = 0;
 	}
 	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
@@ -1320,7 +1478,7 @@ H2G_HD bool al_align(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw
 	const uint32_t maxmm = (uint32_t)((-bestScore + P.sc.mmpMax - 1) / P.sc.mmpMax);
 	const uint32_t nact = hit.numPartialSearch - hit.numUniqueSearch;
 	if(!P.secondary && nact > maxmm + 0 + 1) return true;
-	uint32_t numHits = al_get_anchor_hits(*C.g, P, sv, ws, mw, fwi, rnd);
+	uint32_t numHits = al_get_anchor_hits(C, sv, ws, mw, fwi, rnd);
 	if(numHits == 0) return false;
 	uint64_t add = (uint64_t)((-mw->minsc) / P.sc.mmpMax) * numHits * (P.secondary ? 2 : 1);
 	ws->max_localindexatts = ws->localindexatts + (add > 10 ? add : 10);
@@ -1350,17 +1508,22 @@ H2G_HD void al_align_mate(const AlnCtx& C, const SeqView& ord, AlignWS* ws, Mate
 			uint32_t hitlen = 0, top = H2G_MAX, bot = H2G_MAX;
 			bool uniqueStop = false;
 			uint32_t nelt = C.ls->desc[lidx].len == 0 ? 0 :
-			                gfm_search(lx, ord, hitoff, &hitlen, &top, &bot, &uniqueStop, minK_local, 0xffffu, P.kseeds, true, &ws->nrank);
+			                al_local_search(C, ws, lidx, ord, hitoff, &hitlen, &top, &bot, &uniqueStop, 0xffffu);
 			if(nelt > 0 && nelt <= P.kseeds && hitlen > max_hitlen) {
-				h2g_coord co[AL_MAX_COORDS];
+				h2g_coord co[AL_MAX_GHITS];
 				uint32_t nco = 0;
-				genome_coords_local(lx, top, bot, hitoff - hitlen + 1, hitlen, co, AL_MAX_COORDS, &nco, &ws->nsteps);
+				al_local_coords(C, ws, lidx, top, bot, hitoff - hitlen + 1, hitlen, co, AL_MAX_GHITS, &nco);
 				ws->nghits = 0;
 				for(uint32_t ri = 0; ri < nco; ri++) {
 					if(P.no_spliced) {
 						if((uint64_t)co[ri].toff + (uint64_t)P.maxFragLen * 2 < toff || (uint64_t)toff + (uint64_t)P.maxFragLen * 2 < co[ri].toff) continue;
 					}
-					if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], ord.fw, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff);
+					if(!C.g->linear) {                            // adjustWithALT (:5692)
+						uint32_t ovf = 0;
+						adjust_with_alt(*C.g, *C.ref, *C.alts, ord, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff, ws->ghits,
+						                &ws->nghits, AL_MAX_GHITS, &C.gws->awa, &ovf);
+						if(ovf) ws->overflow |= 64;
+					} else if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], ord.fw, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff);
 					else ws->overflow |= 64;
 				}
 				max_hitlen = hitlen;
@@ -1372,7 +1535,7 @@ H2G_HD void al_align_mate(const AlnCtx& C, const SeqView& ord, AlignWS* ws, Mate
 	// (genomeHits never exceeds kseeds here: nelt <= kseeds)
 	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
 		uint32_t le = H2G_MAX, re = H2G_MAX;
-		extend_item(*C.ref, P.sc, ord, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
+		al_extend(C, ord, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
 		hit_copy(&ws->tmp2, &ws->ghits[hi]);
 		al_hybrid_search_recur(C, ord, ws, omw, &ws->tmp2, ws->tmp2.rdoff, ws->tmp2.len, omw->minsc, true);
 	}
@@ -1446,7 +1609,15 @@ H2G_HD void al_go(const AlnCtx& C, const DReads* const rds[2], uint32_t read, Al
 			if(cont) continue;
 			SeqView sv = seq_view(*rds[rdi], read, fwi == 0);
 			h2g_fm_hit fh;
-			partial_search_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &fh);
+			if(C.g->linear) partial_search_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &fh);
+			else {
+				partial_search_graph_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &fh, &C.gws->ie);
+				if(hit.npartial < AL_MAX_PARTIAL) {
+					GraphPNode& pn = C.gws->pnode[(int)(&mw - ws->m)][fwi][hit.npartial];
+					pn.node_top = fh.node_top; pn.node_bot = fh.node_bot; pn.ie = C.gws->ie;
+					if(pn.ie.n > H2G_IEDGE_CAP) ws->overflow |= 512;
+				}
+			}
 			AL_TRACE("  psearch rdi %d fwi %d cur %u -> top %u bot %u len %u type %u cur %u done %u anchor %u\n", rdi, fwi, hit.cur, fh.top, fh.bot, fh.len, fh.hit_type, fh.cur, fh.done, fh.anchorStop);
 			ws->nrank += fh.nrank; ws->nside += fh.nside;
 			hit.numPartialSearch += 1; hit.numUniqueSearch += fh.numUniqueSearch; hit.cur = fh.cur;

@@ -439,6 +439,8 @@ H2G_HD int64_t calculate_score(const DScoring& sc, const SeqView& seq, h2g_ghit*
 #define H2G_NEW_EDITS 24
 H2G_HD uint8_t base_char(int c) { return (uint8_t)("ACGTN"[c]); }
 H2G_HD bool is_gap(uint8_t t) { return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
+// the edits getLeft / getRight / combineWith stop at: gaps and mismatches through a known SNP (hi_aligner.h:937-940, :981-984)
+H2G_HD bool is_stop_edit(const h2g_edit& e) { return is_gap(e.type) || (e.type == H2G_EDIT_MM && e.snp != H2G_MAX); }
 
 // alignWithALTs (hi_aligner.h:683-783) over alignWithALTs_recur without ALTs (:2763-2853 left,
 // :3168-3216 right).  Edits are committed in place instead of through a scratch copy.
@@ -531,10 +533,10 @@ H2G_HD void hit_get_right(const h2g_ghit* h, uint32_t* rdoff, uint32_t* len, uin
 	*rdoff = h->rdoff; *len = h->len; *toff = h->toff;
 	for(int i = (int)h->nedits - 1; i >= 0; i--) {
 		const h2g_edit e = h->edits[i];
-		if(is_gap(e.type)) {
+		if(is_stop_edit(e)) {
 			*rdoff = h->rdoff + e.pos;
 			*len = h->len - e.pos;
-			if(e.type == H2G_EDIT_REF_GAP) { (*rdoff)++; (*len)--; }
+			if(e.type == H2G_EDIT_REF_GAP || e.type == H2G_EDIT_MM) { (*rdoff)++; (*len)--; }
 			uint32_t roff = h->toff + h->len;
 			for(uint32_t k = 0; k < h->nedits; k++) {
 				if(h->edits[k].type == H2G_EDIT_READ_GAP) roff++;

@@ -615,15 +615,16 @@ H2G_HD void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 	gw_init(g, x, range);
 }
 
-// one getGenomeCoords call; x = caller-provided scratch.  res->ok = 0 also on capacity overflow (res->nsteps = H2G_MAX then)
-H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot,
-                                     const IEdges* ie, uint32_t maxelt, uint32_t rdlen, bool rejectStraddle, h2g_coord* coords,
-                                     uint32_t cap, h2g_sa_result* res)
+// GroupWalk2S::init + advanceElement for every element (group_walk.h:1430-1545): fills x->offs[0 .. *nelt) with the joined
+// offsets (index-local for a local index).  false on capacity overflow.
+template <class X>
+H2G_HD bool gw_resolve(const X& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot, const IEdges* ie,
+                       uint32_t maxelt, uint32_t* nelt_out)
 {
-	res->ok = 0; res->ncoords = 0; res->straddled = 0; res->nsteps = 0;
 	uint32_t nelt = node_bot - node_top;
 	if(nelt > maxelt) nelt = maxelt;
-	if(nelt > H2G_GW_MAXELT || nelt > cap || (ie && ie->n > H2G_GW_MAXELT)) { res->nsteps = H2G_MAX; return; }
+	*nelt_out = nelt;
+	if(nelt > H2G_GW_MAXELT || (ie && ie->n > H2G_GW_MAXELT)) return false;
 	x->nelt = nelt; x->nst = 0; x->nsteps = 0; x->overflow = 0;
 	for(uint32_t i = 0; i < nelt; i++) { x->offs[i] = H2G_MAX; x->fmap[i] = H2G_MAX; }
 	GwState* s = gw_new_state(x);                             // GroupWalk2S::init :1430-1470
@@ -636,9 +637,23 @@ H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint
 	for(uint32_t elt = 0; elt < nelt; elt++) {
 		uint32_t guard = 0;
 		while(x->offs[elt] == H2G_MAX) {                      // advanceElement :1491-1545
-			if(x->overflow || x->fmap[elt] == H2G_MAX || ++guard > 200000u) { res->nsteps = H2G_MAX; return; }
+			if(x->overflow || x->fmap[elt] == H2G_MAX || ++guard > 200000u) return false;
 			gw_advance(g, x, x->fmap[elt]);
 		}
+	}
+	return !x->overflow;
+}
+
+// one getGenomeCoords call (hi_aligner.h:5774-5855); x = caller-provided scratch.  res->ok = 0 also on capacity overflow
+// (res->nsteps = H2G_MAX then)
+H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot,
+                                     const IEdges* ie, uint32_t maxelt, uint32_t rdlen, bool rejectStraddle, h2g_coord* coords,
+                                     uint32_t cap, h2g_sa_result* res)
+{
+	res->ok = 0; res->ncoords = 0; res->straddled = 0; res->nsteps = 0;
+	uint32_t nelt = 0;
+	if(!gw_resolve(g, x, top, bot, node_top, node_bot, ie, maxelt, &nelt) || nelt > cap) { res->nsteps = H2G_MAX; return; }
+	for(uint32_t elt = 0; elt < nelt; elt++) {
 		uint32_t tidx = 0, toff = 0;
 		bool st2 = false;
 		joined_to_text(g, rdlen, x->offs[elt], &tidx, &toff, rejectStraddle, &st2);
@@ -650,9 +665,64 @@ H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint
 		res->ncoords++;
 	}
 	res->nsteps = x->nsteps;
-	res->ok = x->overflow ? 0 : 1;
+	res->ok = 1;
 }
 
+// globalGFMSearch (hi_aligner.h:6606-6744) / localGFMSearch (:6751-6892) on a graph index.  X = side policy (DGfm / LGfm),
+// FT = ftab access (ftabChars(), lohi()).  Returns nelt (nodes); r / ie as the reference leaves top/bot/node range/iedges.
+template <class X, class FT>
+H2G_HD uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, uint32_t rdoff, uint32_t* hitlen, GRange* out,
+                                 IEdges* ie_out, bool* uniqueStop, uint32_t minUniqueLen, uint32_t maxHitLen, uint32_t maxHits,
+                                 bool local, uint32_t kseeds, uint32_t* nrank)
+{
+	const bool uniqueStop_ = *uniqueStop;
+	*uniqueStop = false;
+	const uint32_t ftabLen = ft.ftabChars(), len = seq.len;
+	const uint32_t offset = len - rdoff - 1;
+	uint32_t dep = offset;
+	ie_out->n = 0;
+	if(local) { out->top = out->bot = out->node_top = out->node_bot = 0; }
+	const uint32_t left = len - dep;
+	if(left < ftabLen + 1) { *hitlen = left; return 0; }
+	uint32_t fi = 0;
+	for(uint32_t i = 0; i < ftabLen; i++) {
+		const int c = seq.at(len - dep - 1 - i);
+		if(c > 3) { *hitlen = i + 1; return 0; }
+		fi |= (uint32_t)c << (2 * i);
+	}
+	uint32_t top, bot;
+	ft.lohi(fi, &top, &bot);
+	dep += ftabLen;
+	if(top >= bot) { *hitlen = ftabLen; return 0; }
+	uint32_t ntop = 0, nbot = 0;
+	IEdges tmp;
+	while(dep < len) {
+		const int c = seq.at(len - dep - 1);
+		GRange r;
+		r.top = r.bot = r.node_top = r.node_bot = 0;
+		tmp.n = 0;
+		if(c <= 3) {
+			if(bot - top > 1) { nrank[0] += 2; map_glf(g, top, bot, c, kseeds, &r, &tmp); }
+			else {
+				nrank[0] += 1;
+				if(map_glf1(g, top, c, &r) && r.top + 1 < r.bot) { tmp.n = 1; tmp.e[0][0] = 0; tmp.e[0][1] = r.bot - r.top - 1; }
+			}
+		}
+		if(r.top >= r.bot) break;
+		top = r.top; bot = r.bot; ntop = r.node_top; nbot = r.node_bot;
+		ie_out->n = tmp.n;
+		for(uint32_t e = 0; e < tmp.n && e < H2G_IEDGE_CAP; e++) { ie_out->e[e][0] = tmp.e[e][0]; ie_out->e[e][1] = tmp.e[e][1]; }
+		dep++;
+		if(uniqueStop_ && bot - top == 1 && dep - offset >= minUniqueLen) { *uniqueStop = true; break; }
+		if(local && dep - offset >= maxHitLen) break;
+	}
+	if(ntop < nbot && nbot - ntop <= maxHits) {
+		out->top = top; out->bot = bot; out->node_top = ntop; out->node_bot = nbot;
+		*hitlen = dep - offset;
+		return nbot - ntop;
+	}
+	return 0;
+}
 
 // ------------------------------------------------------------------------------------------ ALT-aware extension (a18, a28)
 // ALT (alt.h:41-120) as GFM::GFM loads the list (gfm.h:728-905): one reversed copy per deletion appended
@@ -1168,6 +1238,29 @@ H2G_HD bool adjust_with_alt(const DGfm& g, const DRef& ref, const DAlts& A, cons
 	}
 	if(!found2) (*nhits)--;
 	return *nhits > n0;
+}
+
+// member GenomeHit::adjustWithALT (hi_aligner.h:2395-2476): re-seat an already initialised hit; false = no offset works
+H2G_HD bool adjust_with_alt_member(const DGfm& g, const DRef& ref, const DAlts& A, const SeqView& seq, h2g_ghit* gh, AwaWS* W, uint32_t* overflow) {
+	if(g.linear) return true;
+	const uint32_t width = 1u << (g.offRate + 2);
+	OffDiff od[H2G_OFFDIFF_CAP];
+	uint32_t nod = 0;
+	const uint32_t single = find_off_diffs(A, gh->joinedOff >= width ? gh->joinedOff - width : 0, gh->joinedOff + width, od, &nod, overflow);
+	const uint32_t max_od = (A.maxAltsTried / 4) > 4 ? (A.maxAltsTried / 4) : 4;
+	if(nod - single > max_od) nod = single + max_od;
+	const uint32_t orig_joinedOff = gh->joinedOff, orig_toff = gh->toff;
+	bool found = false;
+	for(uint32_t o = 0; o < nod && !found; o++) {
+		if(od[o].second >= 0) { gh->joinedOff = orig_joinedOff + od[o].first; gh->toff = orig_toff + od[o].first; }
+		else { if(orig_toff < od[o].first) continue; gh->joinedOff = orig_joinedOff - od[o].first; gh->toff = orig_toff - od[o].first; }
+		const uint32_t alignedLen = align_with_alts(ref, A, seq, gh->joinedOff, gh->rdoff, gh->rdoff, gh->len, gh->tidx, (int)gh->toff, gh->len + 10,
+		                                            false, gh, 0, nullptr, W, true);
+		if(gh->overflow) *overflow = 1;
+		if(alignedLen == gh->len) found = true;
+		else gh->nedits = 0;
+	}
+	return found;
 }
 
 }  // namespace h2g

@@ -209,13 +209,15 @@ void h2gemu_seed_extend(Emu* e, uint32_t pseudogeneStop, uint32_t khits, h2g_see
 void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, AlnRec* recs) {
 	DReads rd = e->reads();
 	AlnParams P;
-	P.khits = 5; P.kseeds = 10; P.no_spliced = no_spliced; P.secondary = 0;
+	P.khits = e->dg.linear ? 5 : 10; P.kseeds = P.khits * 2; P.no_spliced = no_spliced; P.secondary = 0;   // hisat2.cpp:3903-3906, 3174
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
 	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
 	P.bowtie2_dp = e->bowtie2_dp;
 	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C.sw = e->sw.data();
+	static GraphWS gws_;
+	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_;
 	AlignWS* ws = new AlignWS();
 	for(uint32_t i = 0; i < rd.n; i++) {
 		al_read(C, rd, i, names + name_offs[i], name_offs[i + 1] - name_offs[i], ws, &outs[i]);
@@ -232,13 +234,15 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	DReads rd2 = rd1;
 	rd2.codes = codes2; rd2.offs = offs2; rd2.quals = nullptr;
 	AlnParams P;
-	P.khits = 5; P.kseeds = 10; P.no_spliced = no_spliced; P.secondary = 0;
+	P.khits = e->dg.linear ? 5 : 10; P.kseeds = P.khits * 2; P.no_spliced = no_spliced; P.secondary = 0;   // hisat2.cpp:3903-3906, 3174
 	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
 	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
 	P.bowtie2_dp = e->bowtie2_dp;
 	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C.sw = e->sw.data();
+	static GraphWS gws_;
+	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_;
 	AlignWS* ws = new AlignWS();
 	for(uint32_t i = 0; i < rd1.n; i++) {
 		al_pair(C, rd1, rd2, i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &outs[i]);

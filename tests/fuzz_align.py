@@ -17,14 +17,22 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=(), backend=None, bowtie2_dp=0):
+def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=(), backend=None, bowtie2_dp=0, snps=0):
     tmp = tempfile.mkdtemp(prefix="h2fuzz")
     contigs = synth.make_genome(list(lens), seed, n_gaps=gaps, gap_len=300, repeats=repeats, repeat_len=500)
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
-    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    reads, _ = synth.make_reads(contigs, nreads, rdlen, seed + 1, sub_rate=sub, indel_rate=indel, n_rate=nrate)
+    src = contigs
+    if snps:   # graph index: seeded variants every ~`snps` bp, reads drawn from the alternate haplotype
+        var = synth.make_snps(contigs, seed + 5, every=snps)
+        synth.write_snps(os.path.join(tmp, "g.snp"), var)
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        src = synth.apply_snps(contigs, var)
+    else:
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads, _ = synth.make_reads(src, nreads, rdlen, seed + 1, sub_rate=sub, indel_rate=indel, n_rate=nrate)
     rfa = os.path.join(tmp, "r.fa")
     synth.write_reads_fasta(rfa, reads)
     sam = os.path.join(tmp, "ref.sam")
@@ -57,4 +65,6 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
 if __name__ == "__main__":
     a = sys.argv[1:]
     dp = int(a[6]) if len(a) > 6 else 0
-    run_case(int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]), float(a[5]), extra=(("--bowtie2-dp", str(dp)) if dp else ()), bowtie2_dp=dp)
+    snps = int(a[7]) if len(a) > 7 else 0
+    run_case(int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]), float(a[5]), extra=(("--bowtie2-dp", str(dp)) if dp else ()), bowtie2_dp=dp,
+             snps=snps)
