@@ -126,7 +126,7 @@ class Counters(C.Structure):
                 ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_align_kernel", C.c_float)]
 
 
-ALN_CAP = 8
+ALN_CAP = 10
 
 
 class AlnRes(C.Structure):

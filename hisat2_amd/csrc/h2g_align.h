@@ -663,6 +663,7 @@ struct AlnCtx {
 	uint8_t* sw = nullptr;   // this lane's Smith-Waterman scratch (sw_scratch_bytes), only when P->bowtie2_dp != 0
 	const DAlts* alts = nullptr;      // graph index: the ALT database
 	struct GraphWS* gws = nullptr;    // graph index: this lane's graph scratch
+	bool graph = false;               // set from a kernel template constant so that the linear kernels carry no graph code
 };
 
 // Per-lane scratch of the graph paths (allocated only for graph indexes, so the linear workspace keeps its size):
@@ -692,7 +693,7 @@ H2G_HD bool al_adjust_member(const AlnCtx& C, const SeqView& seq, h2g_ghit* t, A
 
 // GenomeHit::extend on whichever index this is
 H2G_HD bool al_extend(const AlnCtx& C, const SeqView& seq, h2g_ghit* h, uint32_t mm, uint32_t ml, uint32_t mr, uint32_t* le, uint32_t* re) {
-	if(C.g->linear) return extend_item(*C.ref, C.P->sc, seq, h, mm, ml, mr, le, re);
+	if(!C.graph) return extend_item(*C.ref, C.P->sc, seq, h, mm, ml, mr, le, re);
 	return extend_item_alts(*C.ref, *C.alts, C.P->sc, seq, h, mm, ml, mr, le, re, &C.gws->awa);
 }
 
@@ -700,7 +701,7 @@ H2G_HD bool al_extend(const AlnCtx& C, const SeqView& seq, h2g_ghit* h, uint32_t
 H2G_HD uint32_t al_get_anchor_hits(const AlnCtx& C, const SeqView& seq, AlignWS* ws, MateWS* mw, int fwi, Rng* rnd) {
 	const DGfm& g = *C.g;
 	const AlnParams& P = *C.P;
-	const bool graph = !g.linear;
+	const bool graph = C.graph;
 	const int slot = (int)(mw - ws->m);
 	RBHit& hit = mw->rb[fwi];
 	const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
@@ -827,7 +828,7 @@ H2G_HD uint32_t al_get_anchor_hits(const AlnCtx& C, const SeqView& seq, AlignWS*
 }
 
 H2G_HD bool al_adjust_member(const AlnCtx& C, const SeqView& seq, h2g_ghit* t, AlignWS* ws) {
-	if(C.g->linear) return true;
+	if(!C.graph) return true;
 	uint32_t ovf = 0;
 	const bool ok = adjust_with_alt_member(*C.g, *C.ref, *C.alts, seq, t, &C.gws->awa, &ovf);
 	if(ovf) ws->overflow |= 1;
@@ -838,7 +839,7 @@ H2G_HD uint32_t al_local_search(const AlnCtx& C, AlignWS* ws, uint32_t lidx, con
 {
 	const AlnParams& P = *C.P;
 	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
-	if(C.g->linear) return gfm_search(lx, seq, extoff, extlen, top, bot, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true, &ws->nrank);
+	if(!C.graph) return gfm_search(lx, seq, extoff, extlen, top, bot, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true, &ws->nrank);
 	const LGfm x = lgfm_of(*C.ls, *lx.d);
 	GRange r;
 	r.top = *top; r.bot = *bot; r.node_top = r.node_bot = 0;
@@ -852,7 +853,7 @@ H2G_HD void al_local_coords(const AlnCtx& C, AlignWS* ws, uint32_t lidx, uint32_
                             h2g_coord* coords, uint32_t cap, uint32_t* ncoords)
 {
 	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
-	if(C.g->linear) { genome_coords_local(lx, top, bot, rdoff, rdlen, coords, cap, ncoords, &ws->nsteps); return; }
+	if(!C.graph) { genome_coords_local(lx, top, bot, rdoff, rdlen, coords, cap, ncoords, &ws->nsteps); return; }
 	const LGfm x = lgfm_of(*C.ls, *lx.d);
 	const uint32_t node_top = C.gws->node_top, node_bot = C.gws->node_bot;
 	uint32_t nelt = 0, n = 0;
@@ -871,7 +872,7 @@ H2G_HD uint32_t al_global_search(const AlnCtx& C, AlignWS* ws, const SeqView& se
 {
 	const AlnParams& P = *C.P;
 	GIdx gx; gx.g = C.g;
-	if(C.g->linear) return gfm_search(gx, seq, extoff, extlen, top, bot, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false, &ws->nrank);
+	if(!C.graph) return gfm_search(gx, seq, extoff, extlen, top, bot, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false, &ws->nrank);
 	GRange r;
 	r.top = *top; r.bot = *bot; r.node_top = r.node_bot = 0;
 	const uint32_t nelt = gfm_search_graph(*C.g, gx, seq, extoff, extlen, &r, &C.gws->ie, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false,
@@ -882,7 +883,7 @@ H2G_HD uint32_t al_global_search(const AlnCtx& C, AlignWS* ws, const SeqView& se
 }
 H2G_HD uint32_t al_global_coords(const AlnCtx& C, AlignWS* ws, uint32_t top, uint32_t bot, uint32_t extlen, h2g_coord* coords, uint32_t cap) {
 	h2g_sa_result res;
-	if(C.g->linear) genome_coords_item(*C.g, top, bot, bot - top, extlen, true, coords, cap, &res);
+	if(!C.graph) genome_coords_item(*C.g, top, bot, bot - top, extlen, true, coords, cap, &res);
 	else {
 		genome_coords_graph_item(*C.g, &C.gws->gw, top, bot, C.gws->node_top, C.gws->node_bot, &C.gws->ie, bot - top, extlen, true,
 		                         coords, cap, &res);
@@ -1518,7 +1519,7 @@ H2G_HD void al_align_mate(const AlnCtx& C, const SeqView& ord, AlignWS* ws, Mate
 					if(P.no_spliced) {
 						if((uint64_t)co[ri].toff + (uint64_t)P.maxFragLen * 2 < toff || (uint64_t)toff + (uint64_t)P.maxFragLen * 2 < co[ri].toff) continue;
 					}
-					if(!C.g->linear) {                            // adjustWithALT (:5692)
+					if(C.graph) {                            // adjustWithALT (:5692)
 						uint32_t ovf = 0;
 						adjust_with_alt(*C.g, *C.ref, *C.alts, ord, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff, ws->ghits,
 						                &ws->nghits, AL_MAX_GHITS, &C.gws->awa, &ovf);
@@ -1609,7 +1610,7 @@ H2G_HD void al_go(const AlnCtx& C, const DReads* const rds[2], uint32_t read, Al
 			if(cont) continue;
 			SeqView sv = seq_view(*rds[rdi], read, fwi == 0);
 			h2g_fm_hit fh;
-			if(C.g->linear) partial_search_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &fh);
+			if(!C.graph) partial_search_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &fh);
 			else {
 				partial_search_graph_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &fh, &C.gws->ie);
 				if(hit.npartial < AL_MAX_PARTIAL) {

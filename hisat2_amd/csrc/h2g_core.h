@@ -13,8 +13,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define H2G_HD __host__ __device__ __forceinline__
+// out-of-line device functions: the graph paths are large and called from many places of the go() state machine; forcing
+// them inline makes the kernels explode (compile time, registers) and would tax the linear path that never runs them
+#define H2G_HDN __host__ __device__ __noinline__ inline
 #else
 #define H2G_HD inline
+#define H2G_HDN inline
 #endif
 
 namespace h2g {

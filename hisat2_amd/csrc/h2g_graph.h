@@ -136,7 +136,7 @@ H2G_HD uint32_t select_in_word(uint64_t w, uint32_t count) {   // position of th
 
 // select_F (gfm.h:4113-4167): row of the count-th F one at or after `row` (count >= 1), crossing sides as needed
 template <class X>
-H2G_HD uint32_t select_F(const X& g, uint32_t row, uint32_t count) {
+H2G_HDN uint32_t select_F(const X& g, uint32_t row, uint32_t count) {
 	uint32_t sideNum = row / X::SYMS, off = row - sideNum * X::SYMS;
 	const uint32_t lastSide = (g.gbwtLen - 1) / X::SYMS;
 	while(true) {
@@ -157,7 +157,7 @@ H2G_HD uint32_t select_F(const X& g, uint32_t row, uint32_t count) {
 // F-row of node `node`: backward scan over the (F_loc, M_occ) side headers starting at the side of `locRow`
 // (mapGLF gfm.h:3788-3810, mapGLF1 :3978-3998).  Returns the scan's F_loc (already +1 when M_occ > 0) and M_occ.
 template <class X>
-H2G_HD uint32_t node_to_Frow(const X& g, uint32_t locRow, uint32_t node, uint32_t* F_loc_out, uint32_t* M_occ_out) {
+H2G_HDN uint32_t node_to_Frow(const X& g, uint32_t locRow, uint32_t node, uint32_t* F_loc_out, uint32_t* M_occ_out) {
 	uint32_t sideNum = locRow / X::SYMS;
 	uint32_t F_loc, M_occ;
 	while(true) {
@@ -179,7 +179,7 @@ typedef h2g_iedges IEdges;            // n = true count; entries beyond H2G_IEDG
 
 // getInEdgeCount (gfm.h:4172-4213)
 template <class X>
-H2G_HD void in_edge_count(const X& g, uint32_t top, uint32_t bot, IEdges* ie) {
+H2G_HDN void in_edge_count(const X& g, uint32_t top, uint32_t bot, IEdges* ie) {
 	ie->n = 0;
 	uint32_t curr_node = 0, num0s = 0;
 	uint32_t sideNum = H2G_MAX;
@@ -204,7 +204,7 @@ struct GRange { uint32_t top, bot, node_top, node_bot; };
 // mapGLF (gfm.h:3759-3837): LF of a row range + translation of the outgoing-edge rows back to incoming rows
 // through M-rank / F-select.  false = empty range.  `ie` may be null.
 template <class X>
-H2G_HD bool map_glf(const X& g, uint32_t top, uint32_t bot, int c, uint32_t k, GRange* r, IEdges* ie) {
+H2G_HDN bool map_glf(const X& g, uint32_t top, uint32_t bot, int c, uint32_t k, GRange* r, IEdges* ie) {
 	const uint32_t s0 = top / X::SYMS, c0 = top - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
 	uint32_t t = rank_in_side128(g, sd, s0, c0, c), b;
@@ -231,7 +231,7 @@ H2G_HD bool map_glf(const X& g, uint32_t top, uint32_t bot, int c, uint32_t k, G
 
 // mapGLF1 (gfm.h:3957-4021) with mapLF1 (:3892): one row; false = cannot proceed on c
 template <class X>
-H2G_HD bool map_glf1(const X& g, uint32_t row, int c, GRange* r) {
+H2G_HDN bool map_glf1(const X& g, uint32_t row, int c, GRange* r) {
 	r->top = r->bot = r->node_top = r->node_bot = 0;
 	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
@@ -249,7 +249,7 @@ H2G_HD bool map_glf1(const X& g, uint32_t row, int c, GRange* r) {
 // ------------------------------------------------------------------------------------------ partialSearch (a11)
 // hi_aligner.h:6361-6600 on a graph index: mapGLF / mapGLF1 per base, node ranges drive the stop rules,
 // the in-edge list of the last step rides along (:6522-6527) and gates reporting (:6551-6553).
-H2G_HD void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32_t cur_in, bool pseudogeneStopIn,
+H2G_HDN void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32_t cur_in, bool pseudogeneStopIn,
                                       bool anchorStopIn, uint32_t khits, uint32_t kseeds, h2g_fm_hit* o, IEdges* ie_out)
 {
 	// (the aligner never arms pseudogeneStop on a graph index, hi_aligner.h:4669; the function itself honours it)
@@ -383,7 +383,7 @@ H2G_HD uint32_t gw_try_offset(const X& g, uint32_t row, uint32_t node) {
 }
 // mapGLF1(row, l, &node_range) — no required character (gfm.h:4029-4095)
 template <class X>
-H2G_HD void map_glf1_nochar(const X& g, uint32_t row, GRange* r) {
+H2G_HDN void map_glf1_nochar(const X& g, uint32_t row, GRange* r) {
 	if(is_zoff(g, row)) { r->top = r->bot = H2G_MAX; r->node_top = r->node_bot = 0; return; }
 	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
@@ -405,7 +405,7 @@ H2G_HD GwState* gw_new_state(GwCtx* x) {
 // GWState::init (group_walk.h:506-885).  The '$'-split creates new states and initialises them; those never split again
 // at the same step deeper than the number of '$' rows, so the recursion of the reference is a bounded loop here.
 template <class X>
-H2G_HD void gw_init(const X& g, GwCtx* x, uint32_t range0) {
+H2G_HDN void gw_init(const X& g, GwCtx* x, uint32_t range0) {
 	uint32_t pending[H2G_GW_MAXST];
 	uint32_t npend = 0;
 	pending[npend++] = range0;
@@ -519,7 +519,7 @@ H2G_HD void gw_init(const X& g, GwCtx* x, uint32_t range0) {
 }
 // narrowing of a freshly mapped element list whose rows merged into fewer nodes (:1143-1185, :1218-1262)
 template <class X>
-H2G_HD void gw_merge_dups(const X& g, GwCtx* x, uint32_t curtop, uint64_t mask, uint32_t nmask, int c, uint32_t* map, uint32_t* nmap) {
+H2G_HDN void gw_merge_dups(const X& g, GwCtx* x, uint32_t curtop, uint64_t mask, uint32_t nmask, int c, uint32_t* map, uint32_t* nmap) {
 	uint32_t j1 = 0, j2 = 0;
 	for(uint32_t k = 0; k < nmask; k++) if((mask >> k) & 1) { j1 = k; break; }
 	for(uint32_t j = 0; j + 1 < *nmap; j++) {
@@ -535,7 +535,7 @@ H2G_HD void gw_merge_dups(const X& g, GwCtx* x, uint32_t curtop, uint64_t mask, 
 }
 // GWState::advance (group_walk.h:1035-1336)
 template <class X>
-H2G_HD void gw_advance(const X& g, GwCtx* x, uint32_t range) {
+H2G_HDN void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 	GwState* s = &x->st[range];
 	x->nsteps++;
 	if(s->bot - s->top > 1) {
@@ -618,7 +618,7 @@ H2G_HD void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 // GroupWalk2S::init + advanceElement for every element (group_walk.h:1430-1545): fills x->offs[0 .. *nelt) with the joined
 // offsets (index-local for a local index).  false on capacity overflow.
 template <class X>
-H2G_HD bool gw_resolve(const X& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot, const IEdges* ie,
+H2G_HDN bool gw_resolve(const X& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot, const IEdges* ie,
                        uint32_t maxelt, uint32_t* nelt_out)
 {
 	uint32_t nelt = node_bot - node_top;
@@ -646,7 +646,7 @@ H2G_HD bool gw_resolve(const X& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_
 
 // one getGenomeCoords call (hi_aligner.h:5774-5855); x = caller-provided scratch.  res->ok = 0 also on capacity overflow
 // (res->nsteps = H2G_MAX then)
-H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot,
+H2G_HDN void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint32_t bot, uint32_t node_top, uint32_t node_bot,
                                      const IEdges* ie, uint32_t maxelt, uint32_t rdlen, bool rejectStraddle, h2g_coord* coords,
                                      uint32_t cap, h2g_sa_result* res)
 {
@@ -671,7 +671,7 @@ H2G_HD void genome_coords_graph_item(const DGfm& g, GwCtx* x, uint32_t top, uint
 // globalGFMSearch (hi_aligner.h:6606-6744) / localGFMSearch (:6751-6892) on a graph index.  X = side policy (DGfm / LGfm),
 // FT = ftab access (ftabChars(), lohi()).  Returns nelt (nodes); r / ie as the reference leaves top/bot/node range/iedges.
 template <class X, class FT>
-H2G_HD uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, uint32_t rdoff, uint32_t* hitlen, GRange* out,
+H2G_HDN uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, uint32_t rdoff, uint32_t* hitlen, GRange* out,
                                  IEdges* ie_out, bool* uniqueStop, uint32_t minUniqueLen, uint32_t maxHitLen, uint32_t maxHits,
                                  bool local, uint32_t kseeds, uint32_t* nrank)
 {
@@ -758,7 +758,7 @@ struct AwaWS {
 	h2g_ghit scratch;     // adjust_with_alt builds its candidate hit here
 };
 
-H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t joinedOff0, uint32_t base_rdoff,
+H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t joinedOff0, uint32_t base_rdoff,
                                 uint32_t rdoff0, uint32_t rdlen0, uint32_t tidx, int rfoff0, uint32_t rflen0, bool left,
                                 h2g_ghit* h, uint32_t mm, uint32_t* numNs, AwaWS* W, bool want_cand = false)
 {
@@ -1065,7 +1065,7 @@ H2G_HD uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& 
 }
 
 // GenomeHit::extend hi_aligner.h:2031-2232 on a graph index (same bookkeeping as extend_item, ALT-aware alignment)
-H2G_HD bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& sc, const SeqView& seq, h2g_ghit* h, uint32_t mm,
+H2G_HDN bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& sc, const SeqView& seq, h2g_ghit* h, uint32_t mm,
                              uint32_t max_leftext, uint32_t max_rightext, uint32_t* leftext, uint32_t* rightext, AwaWS* W)
 {
 	const uint32_t rdlen = seq.len;
@@ -1129,7 +1129,7 @@ H2G_HD bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& sc
 struct OffDiff { uint32_t first; int32_t second; };
 #define H2G_OFFDIFF_CAP 32
 H2G_HD bool alt_is_gap_fw(const DAlt& a) { return (a.type == H2G_ALT_SNP_DEL && !(a.seq & 0xff)) || a.type == H2G_ALT_SNP_INS; }
-H2G_HD uint32_t find_off_diffs(const DAlts& A, uint32_t start, uint32_t end, OffDiff* od, uint32_t* nod, uint32_t* overflow) {
+H2G_HDN uint32_t find_off_diffs(const DAlts& A, uint32_t start, uint32_t end, OffDiff* od, uint32_t* nod, uint32_t* overflow) {
 	uint32_t n = 0;
 	od[n].first = 0; od[n].second = 0; n++;
 	*nod = n;
@@ -1192,7 +1192,7 @@ H2G_HD bool ghit_equal(const h2g_ghit* a, const h2g_ghit* b) {
 
 // static GenomeHit::adjustWithALT (hi_aligner.h:2239-2390) as getAnchorHits calls it (:5175); no splice-site ALTs, so
 // findSSOffs yields the single (0, 0).  Appends to hits[*nhits .. cap); returns whether any hit was added.
-H2G_HD bool adjust_with_alt(const DGfm& g, const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t rdoff, uint32_t len,
+H2G_HDN bool adjust_with_alt(const DGfm& g, const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t rdoff, uint32_t len,
                             uint32_t tidx, uint32_t toff, uint32_t joinedOff, h2g_ghit* hits, uint32_t* nhits, uint32_t cap,
                             AwaWS* W, uint32_t* overflow)
 {
@@ -1241,7 +1241,7 @@ H2G_HD bool adjust_with_alt(const DGfm& g, const DRef& ref, const DAlts& A, cons
 }
 
 // member GenomeHit::adjustWithALT (hi_aligner.h:2395-2476): re-seat an already initialised hit; false = no offset works
-H2G_HD bool adjust_with_alt_member(const DGfm& g, const DRef& ref, const DAlts& A, const SeqView& seq, h2g_ghit* gh, AwaWS* W, uint32_t* overflow) {
+H2G_HDN bool adjust_with_alt_member(const DGfm& g, const DRef& ref, const DAlts& A, const SeqView& seq, h2g_ghit* gh, AwaWS* W, uint32_t* overflow) {
 	if(g.linear) return true;
 	const uint32_t width = 1u << (g.offRate + 2);
 	OffDiff od[H2G_OFFDIFF_CAP];

@@ -1,0 +1,4 @@
+// Explicit instantiation of the paired-end go() kernel for LINEAR indexes (see h2g_go_kernels.h).
+#include "h2g_go_kernels.h"
+template __global__ void k_align_pairs<false>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
+        const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);

@@ -14,6 +14,8 @@
 #include "h2g_graph.h"
 #include "h2g_sw.h"
 #include "h2g_local_pack.h"
+#define H2G_GO_DECLARE_ONLY
+#include "h2g_go_kernels.h"
 
 using namespace h2g;
 
@@ -59,6 +61,8 @@ struct h2g_stream {
 	size_t ws_threads = 0;
 	uint8_t* d_sw = nullptr;      // per-lane Smith-Waterman scratch of the go() kernels (only with bowtie2_dp != 0)
 	size_t sw_stride = 0, sw_lanes = 0;
+	GraphWS* d_gws = nullptr;     // per-lane graph scratch of the go() kernels (graph indexes only)
+	size_t gws_lanes = 0;
 	uint8_t* d_sw_ws = nullptr;   // h2g_sw_align: H/E/F workspace of one batch of problems
 	size_t sw_ws_bytes = 0;
 	SwLaneState* d_sw_states = nullptr;
@@ -141,7 +145,7 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		ix->dalts.n = (uint32_t)ix->host.alts.size();
 	}
 	memset(&ix->dls, 0, sizeof ix->dls);
-	if(o.load_local && !ix->host.local.empty() && g.p.linear) {
+	if(o.load_local && !ix->host.local.empty()) {
 		LocalPack lp;
 		pack_local(ix->host, lp);
 		const DLocalDesc* dd; const uint8_t* ds; const uint16_t* dw; const uint32_t* df;
@@ -303,7 +307,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws); (void)hipFree(s->d_sw); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws); (void)hipFree(s->d_sw); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->d_gws);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -1024,10 +1028,6 @@ extern "C" h2g_status h2g_extend(h2g_stream* s, h2g_ghit* hits, const h2g_ext_ar
 }
 
 // ------------------------------------------------------------------------------------------ fused seed stage
-__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
-	for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-	if((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
-}
 
 // K1: every (read, strand) runs partialSearch from offset 0 (one lane per item)
 __global__ __launch_bounds__(256) void k_seed_search(DGfm g, DReads rd, h2g_seed_params p, h2g_seed_result* out,
@@ -1166,69 +1166,6 @@ __global__ __launch_bounds__(256) void k_class_scatter(const uint8_t* keys, uint
 
 // `perm` (optional) lists read ids bucketed by the outcome class of the seed stage, so that the 64 lanes of a
 // wave walk similar control flow (k_classify below); results are written by read id, so order is irrelevant.
-template <int WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref, DLocalSet ls, DReads rd, AlnParams P, const char* names,
-                                               const uint32_t* name_offs, AlignWS* pool, ReadOut* outs, h2g_alnres* aln,
-                                               unsigned long long* counters, const uint32_t* perm, unsigned long long* work,
-                                               uint8_t* sw_base, size_t sw_stride)
-{
-	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	AlignWS* ws = pool + tid;
-	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
-	C.sw = sw_base ? sw_base + tid * sw_stride : nullptr;
-	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0, nside = 0;
-	// per-lane packed copy of the current read in LDS: the byte-per-base global reads of the search / extension
-	// loops become conflict-free ds_read_b32 (word k of lane t at [k][t])
-	__shared__ uint32_t s_pk[(H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256];
-	DReads rdl = rd;
-	rdl.pk = s_pk + threadIdx.x;
-	rdl.pk_stride = 256;
-	// scheduling knob (work != nullptr): a lane that finishes a read takes the next one of the work list instead of
-	// waiting for its wave's round (measured: no gain, the kernel is issue-bound under divergence)
-	for(size_t jj = tid;; jj += stride) {
-		size_t j = jj;
-		if(work) j = (size_t)atomicAdd(work, 1ull);
-		if(j >= rd.n) break;
-		const size_t i = perm ? perm[j] : j;
-		ReadOut o;
-		const uint32_t a = name_offs[i], b = name_offs[i + 1];
-		{
-			const uint32_t ro = rd.offs[i], rl = rd.offs[i + 1] - ro;
-			rdl.pk_read = 0xffffffffu;
-			if(rl <= H2G_PK_MAXLEN) {
-				for(uint32_t w = 0; w < (rl + 15) / 16; w++) {
-					uint32_t bits = 0, mask = 0;
-					for(uint32_t k = 0; k < 16 && w * 16 + k < rl; k++) {
-						const uint32_t c = rd.codes[ro + w * 16 + k];
-						bits |= (c & 3u) << (2 * k);
-						mask |= (c > 3u ? 1u : 0u) << k;
-					}
-					s_pk[w * 256 + threadIdx.x] = bits;
-					uint32_t& mw = s_pk[(H2G_PK_WORDS + (w >> 1)) * 256 + threadIdx.x];
-					mw = (w & 1) ? (mw | (mask << 16)) : mask;
-				}
-				rdl.pk_read = (uint32_t)i;
-			}
-		}
-		al_read(C, rdl, (uint32_t)i, names + a, b - a, ws, &o);
-		outs[i] = o;
-		for(uint32_t k = 0; k < o.nselect && k < H2G_ALN_CAP; k++) {
-			const AlnRec& r = ws->m[0].res[o.select[k]];
-			h2g_alnres& d = aln[i * H2G_ALN_CAP + k];
-			d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
-			d.nedits = r.nedits; d.pad = 0; d.score = r.score;
-			for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
-		}
-		nrank += o.nrank; nsteps += o.nsteps; naln += o.nselect > 0; novf += o.overflow != 0; nside += o.nside;
-	}
-	wave_add(counters + 0, nrank);
-	wave_add(counters + 1, nside);
-	wave_add(counters + 2, nsteps);
-	wave_add(counters + 4, naln);
-	wave_add(counters + 5, novf);
-}
-
 extern "C" void h2g_align_params_init(h2g_align_params* p, const h2g_index* ix) {
 	const bool linear = !ix || ix->dg.linear;
 	p->khits = linear ? 5 : 10;                       // hisat2.cpp:3903-3906
@@ -1273,10 +1210,32 @@ static int sw_scratch_for(h2g_stream* s, uint32_t bowtie2_dp, size_t nthreads, u
 	return H2G_OK;
 }
 
+// go() on a graph index: the index must be a SNP graph (ALT database present) and every lane needs a GraphWS
+static int need_alignable(h2g_stream* s) {
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	const DGfm& g = s->ix->dg;
+	if(g.linear && g.lineRate == 6) return H2G_OK;
+	if(!g.linear && g.lineRate == 7) return H2G_OK;
+	snprintf(g_err, sizeof g_err, "unsupported side geometry (lineRate %u)", g.lineRate);
+	return H2G_ERR_UNSUPPORTED;
+}
+static int graph_scratch_for(h2g_stream* s, size_t nthreads, GraphArgs* ga) {
+	ga->alts = s->ix->dalts;
+	ga->base = nullptr;
+	if(s->ix->dg.linear) return H2G_OK;
+	if(s->gws_lanes < nthreads) {
+		(void)hipFree(s->d_gws); s->d_gws = nullptr; s->gws_lanes = 0;
+		HIPCHK(hipMalloc((void**)&s->d_gws, nthreads * sizeof(GraphWS)));
+		s->gws_lanes = nthreads;
+	}
+	ga->base = s->d_gws;
+	return H2G_OK;
+}
+
 extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	if(!s || !p) return H2G_ERR_ARG;
 	int rc;
-	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	if((rc = need_reads(s)) || (rc = need_alignable(s))) return rc;
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names) { snprintf(g_err, sizeof g_err, "align: read names not set (h2g_set_read_names)"); return H2G_ERR_ARG; }
 	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
@@ -1285,7 +1244,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	// 2 waves per SIMD on every CU: enough lanes to cover HBM latency, bounded workspace (sizeof(AlignWS) each)
 	const unsigned block = 256;
 	size_t want = (s->n_reads + block - 1) / block;
-	const size_t maxblocks = 256 * (size_t)(getenv("H2G_ALIGN_OCC") ? (atoi(getenv("H2G_ALIGN_OCC")) >= 4 ? 4 : atoi(getenv("H2G_ALIGN_OCC")) == 3 ? 3 : 2) : 4);
+	const size_t maxblocks = 256 * (size_t)(!s->ix->dg.linear ? 2 : getenv("H2G_ALIGN_OCC") ? (atoi(getenv("H2G_ALIGN_OCC")) >= 3 ? 4 : 2) : 4)   /* resident blocks per CU */;
 	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	const size_t nthreads = (size_t)grid * block;
 	if(s->ws_threads < nthreads) {
@@ -1304,6 +1263,8 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	P.bowtie2_dp = p->bowtie2_dp;
 	uint8_t* sw_base = nullptr;
 	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
+	GraphArgs ga;
+	if((rc = graph_scratch_for(s, nthreads, &ga))) return rc;
 	(void)hipGetLastError();
 	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
@@ -1311,7 +1272,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	static const int sort_mode = getenv("H2G_ALIGN_SORT") ? atoi(getenv("H2G_ALIGN_SORT")) : 0;
 	static const int dyn_mode = getenv("H2G_ALIGN_DYN") ? atoi(getenv("H2G_ALIGN_DYN")) : 0;
 	static const int occ_mode = getenv("H2G_ALIGN_OCC") ? atoi(getenv("H2G_ALIGN_OCC")) : 4;
-	if(sort_mode) {
+	if(sort_mode && s->ix->dg.linear) {
 		// seed stage (partialSearch both strands from offset 0 -> coordinates -> 0-mm extension) + Hamming distance
 		// of the whole read as a cost classifier; bucket read ids by class, heaviest first
 		h2g_seed_params sp;
@@ -1329,15 +1290,11 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 		perm = (const uint32_t*)dperm;
 	}
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
-	if(occ_mode >= 4)
-		hipLaunchKernelGGL(k_align<4>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride);
-	else if(occ_mode == 3)
-		hipLaunchKernelGGL(k_align<3>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride);
-	else
-		hipLaunchKernelGGL(k_align<2>, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, s->d_names,
-		                   s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride);
+#define H2G_LAUNCH_ALIGN(W, G) hipLaunchKernelGGL((k_align<W, G>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, \
+		s->d_names, s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride, ga)
+	if(!s->ix->dg.linear) H2G_LAUNCH_ALIGN(2, true);        // graph: the out-of-line graph functions need ~230 VGPRs
+	else H2G_LAUNCH_ALIGN(4, false);
+#undef H2G_LAUNCH_ALIGN
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;
@@ -1360,66 +1317,6 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 // ------------------------------------------------------------------------------------------ paired go()
 static_assert(sizeof(h2g_pair_result) == sizeof(PairOut), "h2g_pair_result must mirror PairOut");
 static_assert(H2G_PAIR_CAP == AL_MAX_PAIRS, "pair capacity");
-
-// lane = one read pair; both mates are packed into LDS (mate 2 behind mate 1)
-__global__ __launch_bounds__(256, 3) void k_align_pairs(DGfm g, DRef ref, DLocalSet ls, DReads rd1, DReads rd2, AlnParams P,
-                                                        const char* names1, const uint32_t* noffs1, const char* names2,
-                                                        const uint32_t* noffs2, AlignWS* pool, PairOut* outs, h2g_alnres* aln1,
-                                                        h2g_alnres* aln2, unsigned long long* counters, uint8_t* sw_base, size_t sw_stride)
-{
-	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	AlignWS* ws = pool + tid;
-	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
-	C.sw = sw_base ? sw_base + tid * sw_stride : nullptr;
-	unsigned long long nrank = 0, nsteps = 0, npair = 0, novf = 0, nside = 0;
-	__shared__ uint32_t s_pk[2 * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256];
-	DReads rl[2] = {rd1, rd2};
-	for(int m = 0; m < 2; m++) { rl[m].pk = s_pk + m * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256 + threadIdx.x; rl[m].pk_stride = 256; }
-	for(size_t i = tid; i < rd1.n; i += stride) {
-		for(int m = 0; m < 2; m++) {
-			const DReads& rd = m == 0 ? rd1 : rd2;
-			uint32_t* pk = s_pk + m * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256;
-			const uint32_t ro = rd.offs[i], rlen = rd.offs[i + 1] - ro;
-			rl[m].pk_read = 0xffffffffu;
-			if(rlen <= H2G_PK_MAXLEN) {
-				for(uint32_t w = 0; w < (rlen + 15) / 16; w++) {
-					uint32_t bits = 0, mask = 0;
-					for(uint32_t k = 0; k < 16 && w * 16 + k < rlen; k++) {
-						const uint32_t c = rd.codes[ro + w * 16 + k];
-						bits |= (c & 3u) << (2 * k);
-						mask |= (c > 3u ? 1u : 0u) << k;
-					}
-					pk[w * 256 + threadIdx.x] = bits;
-					uint32_t& mw = pk[(H2G_PK_WORDS + (w >> 1)) * 256 + threadIdx.x];
-					mw = (w & 1) ? (mw | (mask << 16)) : mask;
-				}
-				rl[m].pk_read = (uint32_t)i;
-			}
-		}
-		PairOut o;
-		al_pair(C, rl[0], rl[1], (uint32_t)i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &o);
-		outs[i] = o;
-		for(int m = 0; m < 2; m++) {
-			h2g_alnres* dst = (m == 0 ? aln1 : aln2) + i * H2G_PAIR_RES_CAP;
-			const uint32_t n = o.nres[m] < H2G_PAIR_RES_CAP ? o.nres[m] : H2G_PAIR_RES_CAP;
-			for(uint32_t k = 0; k < n; k++) {
-				const AlnRec& r = ws->m[m].res[k];
-				h2g_alnres& d = dst[k];
-				d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
-				d.nedits = r.nedits; d.pad = 0; d.score = r.score;
-				for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
-			}
-		}
-		nrank += o.nrank; nsteps += o.nsteps; npair += o.npairs > 0; nside += o.nside;
-		novf += (o.overflow != 0 || o.nres[0] > H2G_PAIR_RES_CAP || o.nres[1] > H2G_PAIR_RES_CAP);
-	}
-	wave_add(counters + 0, nrank);
-	wave_add(counters + 1, nside);
-	wave_add(counters + 2, nsteps);
-	wave_add(counters + 4, npair);
-	wave_add(counters + 5, novf);
-}
 
 extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const uint32_t* offs2, const char* quals2,
                                     const char* nb2, const uint32_t* noffs2, size_t n)
@@ -1450,7 +1347,7 @@ extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const 
 extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params* p) {
 	if(!s || !p) return H2G_ERR_ARG;
 	int rc;
-	if((rc = need_reads(s)) || (rc = need_linear(s))) return rc;
+	if((rc = need_reads(s)) || (rc = need_alignable(s))) return rc;
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names || !s->has_mates) { snprintf(g_err, sizeof g_err, "align_pairs: names (h2g_set_read_names) and mates (h2g_set_mates) required"); return H2G_ERR_ARG; }
 	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
@@ -1458,7 +1355,7 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	HIPCHK(hipSetDevice(s->ix->device));
 	const unsigned block = 256;
 	size_t want = (s->n_reads + block - 1) / block;
-	const size_t maxblocks = 256 * 3;
+	const size_t maxblocks = 256 * (size_t)(s->ix->dg.linear ? 3 : 2);
 	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	const size_t nthreads = (size_t)grid * block;
 	if(s->ws_threads < nthreads) {
@@ -1477,14 +1374,20 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	P.bowtie2_dp = p->bowtie2_dp;
 	uint8_t* sw_base = nullptr;
 	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
+	GraphArgs ga;
+	if((rc = graph_scratch_for(s, nthreads, &ga))) return rc;
 	DReads r1 = dreads(s), r2 = r1;
 	r2.codes = s->d_codes2; r2.offs = s->d_offs2; r2.quals = s->has_quals2 ? s->d_quals2 : nullptr;
 	(void)hipGetLastError();
 	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
-	hipLaunchKernelGGL(k_align_pairs, dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
-	                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride);
+	if(s->ix->dg.linear)
+		hipLaunchKernelGGL((k_align_pairs<false>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
+		                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride, ga);
+	else
+		hipLaunchKernelGGL((k_align_pairs<true>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
+		                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride, ga);
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;

@@ -222,9 +222,9 @@ H2G_EXPORT h2g_status h2g_seed_extend_fetch(h2g_stream*, h2g_seed_result* out, s
 /* ---- the coarse entry: HI_Aligner::go for every read of the resident batch ---------------------------------- */
 /* Semantics == one iteration of the worker loop body (hisat2.cpp:3380-3640) for an unpaired read that passed the
  * filters: rnd.init(genRandSeed(read)) (pat.h:55), splicedAligner.go(...) (hi_aligner.h:4048), and the selection
- * half of AlnSinkWrap::finishRead (aln_sink.h:1939 -> selectByScore :2680).  Built so far: linear (HFM) indexes,
- * unpaired reads, --no-spliced-alignment, default scoring, --bowtie2-dp 0/1/2. */
-#define H2G_ALN_CAP 8              /* alignments returned per read (>= -k) */
+ * half of AlnSinkWrap::finishRead (aln_sink.h:1939 -> selectByScore :2680).  Built so far: linear (HFM) and SNP-graph
+ * (GFM + ALT database) indexes, --no-spliced-alignment, default scoring, --bowtie2-dp 0/1/2. */
+#define H2G_ALN_CAP 10             /* alignments returned per read (>= -k: 5 on linear, 10 on graph indexes) */
 typedef struct {                   /* == the arguments reportHit (hi_aligner.h:6064-6166) passes to AlnRes::init */
 	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, pad;
 	int64_t  score;                /* AS:i */

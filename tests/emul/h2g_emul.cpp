@@ -217,7 +217,7 @@ void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C.sw = e->sw.data();
 	static GraphWS gws_;
-	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_;
+	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_; C.graph = !e->dg.linear;
 	AlignWS* ws = new AlignWS();
 	for(uint32_t i = 0; i < rd.n; i++) {
 		al_read(C, rd, i, names + name_offs[i], name_offs[i + 1] - name_offs[i], ws, &outs[i]);
@@ -242,7 +242,7 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C.sw = e->sw.data();
 	static GraphWS gws_;
-	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_;
+	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_; C.graph = !e->dg.linear;
 	AlignWS* ws = new AlignWS();
 	for(uint32_t i = 0; i < rd1.n; i++) {
 		al_pair(C, rd1, rd2, i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &outs[i]);

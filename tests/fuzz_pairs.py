@@ -21,6 +21,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 
 
 DP = int(os.environ.get("H2G_FUZZ_DP", "0"))   # --bowtie2-dp for both sides
+SNPS = int(os.environ.get("H2G_FUZZ_SNPS", "0"))   # > 0: graph index with a seeded variant every ~SNPS bp, pairs from the alt haplotype
 
 
 def emu_pairs(base, m1, m2, q1, q2):
@@ -65,8 +66,16 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
-    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    m1, m2 = synth.make_pairs(contigs, npairs, rdlen, seed + 1, frag_mean=frag_mean, frag_sd=frag_sd, sub_rate=sub)
+    src = contigs
+    if SNPS:
+        var = synth.make_snps(contigs, seed + 5, every=SNPS)
+        synth.write_snps(os.path.join(tmp, "g.snp"), var)
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        src = synth.apply_snps(contigs, var)
+    else:
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    m1, m2 = synth.make_pairs(src, npairs, rdlen, seed + 1, frag_mean=frag_mean, frag_sd=frag_sd, sub_rate=sub)
     f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)

@@ -31,6 +31,9 @@ def test_golden_sam(g1_index, golden_dir):
     # the opt-in SwAligner pass inside hybridSearch (spliced_aligner.h:209): unconditional and conditional
     dict(seed=104, nreads=1500, rdlen=101, sub=0.02, indel=0.006, nrate=0.001, extra=("--bowtie2-dp", "2"), bowtie2_dp=2),
     dict(seed=105, nreads=1500, rdlen=75, sub=0.02, indel=0.01, nrate=0.0, extra=("--bowtie2-dp", "1"), bowtie2_dp=1),
+    # SNP-graph index (hisat2-build --snp), reads drawn from the alternate haplotype
+    dict(seed=106, nreads=1500, rdlen=101, sub=0.01, indel=0.001, nrate=0.001, snps=250),
+    dict(seed=107, nreads=1000, rdlen=101, sub=0.02, indel=0.002, nrate=0.0, snps=100),
 ])
 def test_live_reference(case):
     """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""

@@ -79,6 +79,18 @@ def test_live_reference_bowtie2_dp(dp):
     assert bad == 0
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("case", [
+    dict(seed=221, nreads=8000, rdlen=101, sub=0.01, indel=0.001, nrate=0.001, snps=250),
+    dict(seed=222, nreads=5000, rdlen=101, sub=0.02, indel=0.002, nrate=0.0, snps=100),
+])
+def test_live_reference_graph_index(case):
+    """go() on a SNP-graph index (hisat2-build --snp): graph LF, node walk, ALT-aware extension; reads from the alt haplotype"""
+    import fuzz_align as F
+    bad, _ = F.run_case(verbose=3, backend=_backend, **case)
+    assert bad == 0
+
+
 def test_align_requires_names_and_nospliced(g1_index, golden_dir):
     names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
     codes = np.concatenate(seqs)
