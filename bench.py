@@ -248,6 +248,54 @@ def main():
         sw_micro = {"problems": nsw, "kernel_ms": sw_ms, "problems_per_s": nsw / (sw_ms * 1e-3), "GCUPS": sw_cells / (sw_ms * 1e-3) / 1e9,
                     "found": sw_found, "cells_per_problem": sw_cells / nsw,
                     "note": "k_sw_fill: register-systolic wavefront per problem (one __shfl_up per anti-diagonal step), H/E/F streamed to HBM anti-diagonal-major (92.5 KB/problem, coalesced 64 B stores); k_sw_backtrace: one lane per problem"}
+        # go() on a SNP-GRAPH index (BASELINE configs[3] shape at config-2 size): the same genome with a seeded variant every
+        # ~250 bp (hisat2-build-s --snp), reads drawn from the alternate haplotype; 2000 reads checked against the reference
+        graph_leg = None
+        builder = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
+        if os.path.exists(builder):
+            import tempfile, shutil
+            gtmp = os.path.join(cache, f"rnd{a.genome_len}_s{SEED}_snp")
+            gbase = os.path.join(gtmp, "g")
+            var = synth.make_snps(contigs, SEED + 5, every=250, names=["ecoli_substitute"])
+            if not os.path.exists(gbase + ".8.ht2"):
+                os.makedirs(gtmp, exist_ok=True)
+                synth.write_fasta(gbase + ".fa", contigs, names=["ecoli_substitute"])
+                synth.write_snps(gbase + ".snp", var)
+                subprocess.run([builder, "-q", "-p", str(min(os.cpu_count() or 1, 64)), "--snp", gbase + ".snp", gbase + ".fa", gbase], check=True,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            alt = synth.apply_snps(contigs, var, names=["ecoli_substitute"])
+            greads, _ = synth.make_reads(alt, a.reads, 101, SEED + 4242, sub_rate=0.005)
+            gcodes, goffs = synth.flatten_reads(greads)
+            gix = api.Index(gbase, device=local)
+            gst = api.Stream(gix, max_reads=a.reads, max_bases=gcodes.size)
+            gst.set_reads(gcodes, goffs); gst.set_read_names([str(i) for i in range(a.reads)])
+            gst.align_run(); gst.sync()
+            t0g = time.perf_counter()
+            for _ in range(3):
+                gst.align_run()
+            gst.sync()
+            gdt = (time.perf_counter() - t0g) / 3
+            gc_ = gst.counters()
+            graph_leg = {"reads": a.reads, "variants": len(var), "ms_per_step": gdt * 1e3, "reads_per_s": a.reads / gdt, "kernel_ms": float(gc_.ms_align),
+                         "aligned": int(gc_.n_aligned), "overflow": int(gc_.n_overflow), "numSides": int(gix.info.numSides), "sideSz": int(gix.info.sideSz)}
+            exe = os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")
+            if os.path.exists(exe) and not a.no_cpu_baseline:
+                import sam_util as SU
+                nvg = 2000
+                tmpg = tempfile.mkdtemp(prefix="h2benchg")
+                synth.write_reads_fasta(os.path.join(tmpg, "r.fa"), greads[:nvg])
+                subprocess.run([exe, "-f", "-p", "1", "--no-spliced-alignment", "-x", gbase, "-U", os.path.join(tmpg, "r.fa"), "-S", os.path.join(tmpg, "r.sam")],
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                rn, wantg = SU.parse_sam(os.path.join(tmpg, "r.sam"))
+                gres, galn = gst.align_fetch(0, nvg)
+                qg = [str(i) for i in range(nvg)]
+                gotg = SU.render_selected(gres, galn, rn, [101] * nvg, qg)
+                nbadg = sum(1 for q in qg if gotg[q] != wantg[q])
+                shutil.rmtree(tmpg, ignore_errors=True)
+                graph_leg.update({"sam_checked_reads": nvg, "sam_mismatching_reads": nbadg})
+                if nbadg:
+                    raise SystemExit(f"bench.py: {nbadg} of {nvg} graph-index reads differ from the reference SAM")
+            gst.close(); gix.close()
         nver = 2000
         verify_sample(base, reads, got, nver)          # seed stage vs oracle/h2o.c
         cpu_ref, ref_sam = (None, None)
@@ -314,6 +362,7 @@ def main():
             "rank_microbench": {"sides": 15_300_000, "bytes": 15_300_000 * 64, "queries": a.rank_queries, **micro},
             "rank_microbench_graph": {"sides": 7_650_000, "bytes": 7_650_000 * 128, "queries": a.rank_queries, **micro_g},
             "sw_microbench": sw_micro,
+            "graph_index": graph_leg,
             "seed_stage": seed_stage,
             "paired_end": pe,
             "counters": {"reads_aligned": int(asum[0]), "reads_multi": int(asum[1]), "reads_overflow": int(asum[2]),

@@ -64,3 +64,11 @@ def test_golden_pairs_sam(g1_index, golden_dir):
         assert got == want[q[i]], i
         kinds.add(got[0][0] & 0xF)
     assert len(kinds) >= 2   # concordant and at least one other outcome class are exercised
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+def test_live_reference_pairs_graph_index(monkeypatch):
+    import fuzz_pairs as F
+    monkeypatch.setattr(F, "SNPS", 200)
+    bad, _ = F.run_case(verbose=3, seed=108, npairs=800, rdlen=101, sub=0.01)
+    assert bad == 0

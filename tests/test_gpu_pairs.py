@@ -39,6 +39,14 @@ def test_live_reference_pairs(case):
     assert bad == 0
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+def test_live_reference_pairs_graph_index(monkeypatch):
+    """paired go() on a SNP-graph index, pairs drawn from the alternate haplotype"""
+    monkeypatch.setattr(F, "SNPS", 200)
+    bad, _ = F.run_case(verbose=3, backend=_backend, stride=api.PAIR_RES_CAP, seed=311, npairs=6000, rdlen=101, sub=0.01)
+    assert bad == 0
+
+
 def test_golden_pairs_sam(g1_index, golden_dir):
     import gzip
     import tempfile
