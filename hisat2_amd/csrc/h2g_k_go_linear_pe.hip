@@ -2,3 +2,5 @@
 #include "h2g_go_kernels.h"
 template __global__ void k_align_pairs<false>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
         const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);
+// per-lane workspace size of THIS translation unit's layout (AL_MAX_GHITS differs between the linear and graph units)
+extern "C" size_t h2g_ws_bytes_linear_pe() { return sizeof(AlignWS); }

@@ -16,6 +16,13 @@
 #include "h2g_local_pack.h"
 #define H2G_GO_DECLARE_ONLY
 #include "h2g_go_kernels.h"
+// AlignWS is opaque on this side: each go() unit reports the size of its own layout
+extern "C" size_t h2g_ws_bytes_linear_se(); extern "C" size_t h2g_ws_bytes_linear_pe();
+extern "C" size_t h2g_ws_bytes_graph_se();  extern "C" size_t h2g_ws_bytes_graph_pe();
+static size_t ws_bytes_per_lane(bool linear) {
+	const size_t a = linear ? h2g_ws_bytes_linear_se() : h2g_ws_bytes_graph_se(), b = linear ? h2g_ws_bytes_linear_pe() : h2g_ws_bytes_graph_pe();
+	return a > b ? a : b;
+}
 
 using namespace h2g;
 
@@ -1239,7 +1246,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names) { snprintf(g_err, sizeof g_err, "align: read names not set (h2g_set_read_names)"); return H2G_ERR_ARG; }
 	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
-	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > AL_MAX_GHITS || p->kseeds < p->khits) return H2G_ERR_ARG;
+	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > (s->ix->dg.linear ? 10u : 20u) || p->kseeds < p->khits) return H2G_ERR_ARG;
 	HIPCHK(hipSetDevice(s->ix->device));
 	// 2 waves per SIMD on every CU: enough lanes to cover HBM latency, bounded workspace (sizeof(AlignWS) each)
 	const unsigned block = 256;
@@ -1249,7 +1256,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	const size_t nthreads = (size_t)grid * block;
 	if(s->ws_threads < nthreads) {
 		(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_threads = 0;
-		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * sizeof(AlignWS)));
+		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0)));
 		s->ws_threads = nthreads;
 	}
 	if(!s->d_rout) {
@@ -1351,7 +1358,7 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names || !s->has_mates) { snprintf(g_err, sizeof g_err, "align_pairs: names (h2g_set_read_names) and mates (h2g_set_mates) required"); return H2G_ERR_ARG; }
 	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
-	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > AL_MAX_GHITS || p->kseeds < p->khits) return H2G_ERR_ARG;
+	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > (s->ix->dg.linear ? 10u : 20u) || p->kseeds < p->khits) return H2G_ERR_ARG;
 	HIPCHK(hipSetDevice(s->ix->device));
 	const unsigned block = 256;
 	size_t want = (s->n_reads + block - 1) / block;
@@ -1360,7 +1367,7 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	const size_t nthreads = (size_t)grid * block;
 	if(s->ws_threads < nthreads) {
 		(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_threads = 0;
-		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * sizeof(AlignWS)));
+		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0)));
 		s->ws_threads = nthreads;
 	}
 	if(!s->d_pout) {
