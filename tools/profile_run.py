@@ -58,3 +58,19 @@ for _ in range(2):
 pst.sync()
 pc = pst.counters()
 print("pairs: %.3f ms for %d pairs, concordant %d" % (pc.ms_align, npairs, pc.n_aligned))
+pst.close()
+# go() on the SNP-graph index of the bench genome (built/cached by bench.py)
+gbase = os.path.join(ROOT, ".bench_cache", "rnd4900000_s%d_snp" % bench.SEED, "g")
+if os.path.exists(gbase + ".8.ht2"):
+    var = synth.make_snps(contigs, bench.SEED + 5, every=250, names=["ecoli_substitute"])
+    alt = synth.apply_snps(contigs, var, names=["ecoli_substitute"])
+    greads, _ = synth.make_reads(alt, nreads, 101, bench.SEED + 4242, sub_rate=0.005)
+    gc, go = synth.flatten_reads(greads)
+    gix2 = api.Index(gbase)
+    gst2 = api.Stream(gix2, max_reads=nreads, max_bases=gc.size)
+    gst2.set_reads(gc, go); gst2.set_read_names([str(i) for i in range(nreads)])
+    for _ in range(2):
+        gst2.align_run()
+    gst2.sync()
+    c3 = gst2.counters()
+    print("graph go(): %.3f ms for %d reads, aligned %d, n_rank %d" % (c3.ms_align, nreads, c3.n_aligned, c3.n_rank))
