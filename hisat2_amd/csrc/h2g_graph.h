@@ -47,12 +47,14 @@ H2G_HD bool is_zoff(const X& g, uint32_t row) {   // GFM::_zOffs (gfm.h:2783); a
 	return false;
 }
 
-// header word k of a side held in registers: 0 F_loc, 1 M_occ, 2..5 occ[A,C,G,T]
+// occ[c] of a side held in registers — selects, no dynamic indexing of the register array (that would go to scratch)
 template <class X>
-H2G_HD uint32_t side_hdr(const Side128& s, int k) {
-	const uint32_t byte = X::HDR + X::WSZ * (uint32_t)k;
-	const uint64_t w = s.w[byte >> 3];
-	return X::WSZ == 4 ? (uint32_t)(w >> ((byte & 7) * 8)) : (uint32_t)((w >> ((byte & 7) * 8)) & 0xffffu);
+H2G_HD uint32_t side_occ(const Side128& s, int c) {
+	if(X::WSZ == 4) {                                   // u32 occ[4] at byte 112: words 14, 15
+		const uint64_t ow = (c & 2) ? s.w[15] : s.w[14];
+		return (c & 1) ? (uint32_t)(ow >> 32) : (uint32_t)ow;
+	}
+	return (uint32_t)((s.w[15] >> (16 * c)) & 0xffffu);   // u16 occ[4] at byte 120: word 15
 }
 template <class X>
 H2G_HD uint32_t side_hdr_mem(const uint8_t* side, int k) {   // same, straight from memory
@@ -73,7 +75,7 @@ H2G_HD uint32_t rank_in_side128(const X& g, const Side128& s, uint32_t sideNum, 
 			if(zs == sideNum && zc < charOff) cnt--;
 		}
 	}
-	const uint32_t occ = side_hdr<X>(s, 2 + c);
+	const uint32_t occ = side_occ<X>(s, c);
 	const uint32_t fc = c == 0 ? g.fchr[0] : c == 1 ? g.fchr[1] : c == 2 ? g.fchr[2] : g.fchr[3];
 	return occ + cnt + fc;
 }
