@@ -289,7 +289,7 @@ def main():
                 rn, wantg = SU.parse_sam(os.path.join(tmpg, "r.sam"))
                 gres, galn = gst.align_fetch(0, nvg)
                 qg = [str(i) for i in range(nvg)]
-                gotg = SU.render_selected(gres, galn, rn, [101] * nvg, qg)
+                gotg = SU.render_selected(gres, galn, rn, [greads[i] for i in range(nvg)], qg)
                 nbadg = sum(1 for q in qg if gotg[q] != wantg[q])
                 shutil.rmtree(tmpg, ignore_errors=True)
                 graph_leg.update({"sam_checked_reads": nvg, "sam_mismatching_reads": nbadg})
@@ -305,7 +305,7 @@ def main():
         if ref_sam is not None:
             import sam_util as SU
             qn = [str(i) for i in range(len(ares))]
-            gotsam = SU.render_selected(ares, aaln, ref_sam[0], [101] * len(ares), qn)
+            gotsam = SU.render_selected(ares, aaln, ref_sam[0], [reads[i] for i in range(len(ares))], qn)
             nbad = sum(1 for q in qn if gotsam[q] != ref_sam[1][q])
             parity.update({"sam_checked_reads": len(ares), "sam_mismatching_reads": nbad,
                            "against": "oracle/_ref/hisat2-align-s (FLAG, RNAME, POS, CIGAR, AS:i per line)"})
@@ -342,7 +342,7 @@ def main():
                                 os.path.join(tmp, "2.fa"), "-S", os.path.join(tmp, "pe.sam")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 rn, want = FP.parse_pe_sam(os.path.join(tmp, "pe.sam"))
                 pres, pa1, pa2 = pst.align_pairs_fetch(0, nv)
-                nbad = sum(1 for i in range(nv) if PS.finish_pair(pres[i], pa1, pa2, i * api.PAIR_RES_CAP, rn, (101, 101)) != want[str(i)])
+                nbad = sum(1 for i in range(nv) if PS.finish_pair(pres[i], pa1, pa2, i * api.PAIR_RES_CAP, rn, (m1[i], m2[i])) != want[str(i)])
                 shutil.rmtree(tmp, ignore_errors=True)
                 pe.update({"sam_checked_pairs": nv, "sam_mismatching_pairs": nbad})
                 if nbad:

@@ -41,12 +41,14 @@ struct DLocalDesc {
 	uint32_t tidx, localOffset, joinedOffset;
 	uint32_t fchr[5];
 	uint32_t ftabLim;        // ftab entries above this point into eftab: len (linear) or gbwtLen (graph), gfm.h:2618
+	uint32_t zoffs_off;      // index into DLocalSet::zoffs of this index's nZ '$' rows (a graph local index can have several)
 };
 struct DLocalSet {
 	const DLocalDesc* desc;
 	const uint8_t*    sides;
 	const uint16_t*   words;
 	const uint32_t*   first;   // [nPat+1] first local index of each text (HGFM::_localGFMs[tidx])
+	const uint32_t*   zoffs;   // all '$' rows, DLocalDesc::zoffs_off
 	uint32_t n, ftabChars, offRate;
 };
 #define H2G_LOCAL_INTERVAL 56320u   // local_index_interval hier_idx_common.h:24-31
@@ -64,8 +66,8 @@ struct LGfm {
 };
 H2G_HD LGfm lgfm_of(const DLocalSet& ls, const DLocalDesc& d) {
 	LGfm x;
-	x.sides = ls.sides + d.sides_off; x.offs = ls.words + d.offs_off; x.zoffs = nullptr;
-	x.nZ = d.nZ ? 1 : 0; x.zoff = d.zoff; x.gbwtLen = d.gbwtLen; x.offRate = ls.offRate; x.offMask = (0xffffu << ls.offRate) & 0xffffu;
+	x.sides = ls.sides + d.sides_off; x.offs = ls.words + d.offs_off; x.zoffs = ls.zoffs + d.zoffs_off;
+	x.nZ = d.nZ; x.zoff = d.zoff; x.gbwtLen = d.gbwtLen; x.offRate = ls.offRate; x.offMask = (0xffffu << ls.offRate) & 0xffffu;
 	for(int i = 0; i < 5; i++) x.fchr[i] = d.fchr[i];
 	return x;
 }
@@ -199,6 +201,7 @@ H2G_HD bool local_joff_to_coord(const DLocalSet& ls, const DLocalDesc* d, uint32
 		elt = lo + ((hi - lo) >> 1);
 		if(oldelt == elt) break;
 		uint32_t lower = rs[elt * 3], upper = (elt == d->nFrag - 1) ? d->len : rs[(elt + 1) * 3];
+		AL_TRACE("       frag %u/%u lower %u upper %u joff %u rdlen %u fragoff %u\n", elt, d->nFrag, lower, upper, joff, rdlen, rs[elt * 3 + 2]);
 		if(lower <= joff) {
 			if(upper > joff) {
 				if(joff + rdlen > upper) break;          // straddles: rejected => result false
@@ -397,7 +400,10 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 	if(spliced) return false;   // spliced alignment is not built (no_spliced_alignment mode only)
 	if(!ins && !del && this_rdoff + this_len == other_rdoff) {
 		const uint32_t addoff = b->rdoff - a->rdoff;
-		for(uint32_t i = 0; i < b->nedits; i++) hit_push_edit(a, b->edits[i].pos + addoff, b->edits[i].chr, b->edits[i].qchr, b->edits[i].type);
+		for(uint32_t i = 0; i < b->nedits; i++) {
+			hit_push_edit(a, b->edits[i].pos + addoff, b->edits[i].chr, b->edits[i].qchr, b->edits[i].type);
+			if(!a->overflow) a->edits[a->nedits - 1].snp = b->edits[i].snp;
+		}
 		a->len += b->len;
 		calculate_score(sc, seq, a);
 		return true;
@@ -862,8 +868,10 @@ H2G_HD void al_local_coords(const AlnCtx& C, AlignWS* ws, uint32_t lidx, uint32_
 	*ncoords = 0;
 	if(!gw_resolve(x, &C.gws->gw, top, bot, node_top, node_bot, &C.gws->ie, bot - top, &nelt)) { ws->overflow |= 512; return; }
 	ws->nsteps += C.gws->gw.nsteps;
+	AL_TRACE("     lcoords top %u bot %u node %u %u -> nelt %u\n", top, bot, node_top, node_bot, nelt);
 	for(uint32_t e = 0; e < nelt; e++) {
 		h2g_coord c;
+		AL_TRACE("      off %u\n", C.gws->gw.offs[e]);
 		if(!local_joff_to_coord(*C.ls, lx.d, C.gws->gw.offs[e] & 0xffffu, rdoff, rdlen, &c)) continue;
 		if(n < cap) coords[n++] = c; else ws->overflow |= 512;
 	}
@@ -1036,6 +1044,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			}
 			f.ncoords = 0; f.ri = -1;
 			f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
+			AL_TRACE("    L local lidx %u extoff %u extlen %u nelt %u top %u bot %u unique %d noext %d\n", f.lidx, extoff, extlen, nelt, top, bot, (int)uniqueStop, (int)no_extension);
 			if(nelt > 0 && nelt <= max_nelt && extlen >= P.minAnchorLen && !no_extension) {
 				al_local_coords(C, ws, f.lidx, top, bot, extoff + 1 - extlen, extlen, f.coords, AL_MAX_COORDS, &f.ncoords);
 				sort_coords(f.coords, f.ncoords);
@@ -1054,9 +1063,12 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				if(f.count == 1) { f.ri--; goto next_iter; }
 				f.state = ST_L_AFTER_FOR; goto next_iter;
 			}
+			AL_TRACE("    L coord tidx %u toff %u -> adjusted rdoff %u len %u toff %u nedits %u\n", co.tidx, co.toff, t->rdoff, t->len, t->toff, t->nedits);
 			if(f.uniqueStop) { uint32_t le, re; al_extend(C, seq, t, 0, H2G_MAX, 0, &le, &re); }
+			AL_TRACE("    L extended rdoff %u len %u toff %u nedits %u\n", t->rdoff, t->len, t->toff, t->nedits);
 			int64_t m = minsc;
 			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
+			AL_TRACE("    L combined %d rdoff %u len %u score %lld nedits %u\n", (int)combined, t->rdoff, t->len, (long long)t->score, t->nedits);
 			if(t->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			f.ri--;
@@ -1096,6 +1108,7 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 				GIdx gx; gx.g = C.g;
 				uint32_t nelt = al_global_search(C, ws, seq, extoff, &extlen, &top, &bot, &uniqueStop);
 				f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
+				AL_TRACE("    L global extoff %u extlen %u nelt %u top %u bot %u unique %d\n", extoff, extlen, nelt, top, bot, (int)uniqueStop);
 				if(nelt > 0 && nelt <= 5 && extlen >= minK) {
 					f.ncoords = al_global_coords(C, ws, top, bot, extlen, f.coords, AL_MAX_COORDS);
 					if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
@@ -1111,11 +1124,17 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			f.ri--;
 			h2g_ghit* t = &ws->tmp;
 			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+			AL_TRACE("    LG coord tidx %u toff %u joff %u rdoff %u len %u\n", co.tidx, co.toff, co.joinedOff, t->rdoff, t->len);
 			if(!al_adjust_member(C, seq, t, ws)) goto next_iter;
+			AL_TRACE("    LG adjusted rdoff %u len %u toff %u joff %u nedits %u\n", t->rdoff, t->len, t->toff, t->joinedOff, t->nedits);
 			if(!hit_compatible(t, &hit, P.maxIntronLen, no_spliced)) goto next_iter;
 			if(f.uniqueStop) { uint32_t le, re; al_extend(C, seq, t, 0, H2G_MAX, 0, &le, &re); }
+			AL_TRACE("    LG extended rdoff %u len %u toff %u joff %u nedits %u\n", t->rdoff, t->len, t->toff, t->joinedOff, t->nedits);
+			for(uint32_t q = 0; q < t->nedits; q++) AL_TRACE("       edit %u %c>%c type %u snp %u\n", t->edits[q].pos, t->edits[q].chr, t->edits[q].qchr, t->edits[q].type, t->edits[q].snp);
 			int64_t m = minsc;
 			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
+			AL_TRACE("    LG combined %d rdoff %u len %u score %lld nedits %u\n", (int)combined, t->rdoff, t->len, (long long)t->score, t->nedits);
+			for(uint32_t q = 0; q < t->nedits; q++) AL_TRACE("       edit %u %c>%c type %u snp %u\n", t->edits[q].pos, t->edits[q].chr, t->edits[q].qchr, t->edits[q].type, t->edits[q].snp);
 			if(t->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			if(combined && t->score >= m) AL_CALL(t, t->rdoff, t->len + t->trim3, ST_L_R3);
@@ -1145,7 +1164,9 @@ H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, Align
 			uint32_t nmm = 1;
 			if(hitoff <= minK_local) nmm = t->rdoff < mm ? t->rdoff : mm;
 			uint32_t le = 0, re = 0;
+			AL_TRACE("    L ext from rdoff %u len %u toff %u joff %u nmm %u\n", t->rdoff, t->len, t->toff, t->joinedOff, nmm);
 			al_extend(C, seq, t, nmm, H2G_MAX, 0, &le, &re);
+			AL_TRACE("    L ext -> rdoff %u len %u toff %u joff %u score %lld nedits %u le %u\n", t->rdoff, t->len, t->toff, t->joinedOff, (long long)t->score, t->nedits, le);
 			if(t->overflow) ws->overflow |= 1;
 			AL_MINSC_LIVE(m);
 			const uint32_t need = minK_local < hit.rdoff ? minK_local : hit.rdoff;
@@ -1459,7 +1480,11 @@ H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, Ma
 						gh->score = o->score;
 						gh->nedits = o->nedits;
 						for(uint32_t e = 0; e < o->nedits; e++) gh->edits[e] = o->edits[e];
-						found = true;                                  // replace_edits_with_alts: no ALTs on a linear index
+						if(C.graph && C.alts->n > 0 && gh->nedits > 0) {  // replace_edits_with_alts spliced_aligner.h:282 (re-scores)
+							replace_edits_with_alts(*C.alts, gh);
+							calculate_score(P.sc, sv, gh);
+						}
+						found = true;
 					}
 				}
 			}

@@ -424,6 +424,9 @@ H2G_HDN void gw_init(const X& g, GwCtx* x, uint32_t range0) {
 					e++;
 				}
 				uint32_t toff = gw_try_offset(g, s->top + i + num_iedges, s->node_top + i);
+#if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+				fprintf(stderr, "        gw range %u step %u row %u node %u -> toff %u (top %u bot %u ntop %u nbot %u nie %u)\n", range, s->step, s->top + i + num_iedges, s->node_top + i, toff, s->top, s->bot, s->node_top, s->node_bot, s->nie);
+#endif
 				if(toff != H2G_MAX) {
 					const uint32_t k = i + s->mapi;            // setOff indexes map_[i + mapi_] (:1013); mapi_ is 0 here
 					if(k < s->nmap) x->offs[s->map[k]] = toff + s->step;
@@ -737,6 +740,47 @@ H2G_HD uint32_t alt_lobound(const DAlts& A, uint32_t pos) {   // EList::bsearchL
 	uint32_t lo = 0, hi = A.n;
 	while(lo < hi) { const uint32_t m = (lo + hi) >> 1; if(A.a[m].pos < pos) lo = m + 1; else hi = m; }
 	return lo;
+}
+
+H2G_HD int char_base(uint8_t ch) { return ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 4 : 0; }   // asc2dna (alphabet.cpp:298)
+// GenomeHit::replace_edits_with_alts (hi_aligner.h:1229-1319): after the SwAligner pass on a graph index, edits that coincide
+// with a known SNP get its id (and then cost nothing in calculateScore).  A run of gap edits is delimited by edit TYPE only,
+// as in the reference; the caller re-scores the hit.
+H2G_HDN void replace_edits_with_alts(const DAlts& A, h2g_ghit* h) {
+	if(A.n == 0 || h->nedits == 0) return;
+	int64_t offset = 0;
+	uint32_t i = 0;
+	while(i < h->nedits) {
+		uint32_t next_i = i + 1;
+		h2g_edit& ed = h->edits[i];
+		const bool gap = ed.type == H2G_EDIT_READ_GAP || ed.type == H2G_EDIT_REF_GAP;
+		if(gap) { for(; next_i < h->nedits; next_i++) if(h->edits[next_i].type != ed.type) break; }
+		const uint32_t glen = next_i - i;
+		if(ed.snp == H2G_MAX) {
+			const uint32_t cpos = (uint32_t)((int64_t)h->joinedOff + ed.pos + offset);
+			for(uint32_t ai = alt_lobound(A, cpos); ai < A.n; ai++) {
+				const DAlt& alt = A.a[ai];
+				if(alt.pos > cpos) break;
+				if(ed.type == H2G_EDIT_MM) {
+					if(alt.type != H2G_ALT_SNP_SGL) continue;
+					if(alt.seq < 4 && base_char((int)alt.seq) == ed.qchr) { ed.snp = ai; break; }
+				} else if(ed.type == H2G_EDIT_READ_GAP) {
+					if(alt.type != H2G_ALT_SNP_DEL) continue;
+					if(alt.len == glen) { for(uint32_t k = i; k < next_i; k++) h->edits[k].snp = ai; break; }
+				} else {
+					if(alt.type != H2G_ALT_SNP_INS) continue;
+					if(alt.len == glen) {
+						uint64_t seq = 0;
+						for(uint32_t k = i; k < next_i; k++) seq = (seq << 2) | (uint64_t)char_base(h->edits[k].qchr);
+						if(alt.seq == seq) { for(uint32_t k = i; k < next_i; k++) h->edits[k].snp = ai; break; }
+					}
+				}
+			}
+		}
+		if(ed.type == H2G_EDIT_READ_GAP) offset += glen;
+		else if(ed.type == H2G_EDIT_REF_GAP) offset -= glen;
+		i = next_i;
+	}
 }
 
 // alignWithALTs_recur (hi_aligner.h:2763-3550) for SNP ALTs (single / insertion / deletion), recursion turned into an

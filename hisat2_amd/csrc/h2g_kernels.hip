@@ -155,10 +155,10 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	if(o.load_local && !ix->host.local.empty()) {
 		LocalPack lp;
 		pack_local(ix->host, lp);
-		const DLocalDesc* dd; const uint8_t* ds; const uint16_t* dw; const uint32_t* df;
+		const DLocalDesc* dd; const uint8_t* ds; const uint16_t* dw; const uint32_t* df; const uint32_t* dz;
 		if((s = upload(ix, lp.desc, &dd)) || (s = upload(ix, lp.sides, &ds, 256)) || (s = upload(ix, lp.words, &dw)) ||
-		   (s = upload(ix, lp.first, &df))) { h2g_index_free(ix); return s; }
-		ix->dls = lp.view(dd, ds, dw, df);
+		   (s = upload(ix, lp.first, &df)) || (s = upload(ix, lp.zoffs, &dz))) { h2g_index_free(ix); return s; }
+		ix->dls = lp.view(dd, ds, dw, df, dz);
 		ix->has_local = true;
 	}
 	*out = ix;

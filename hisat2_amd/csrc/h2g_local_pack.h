@@ -12,17 +12,17 @@ struct LocalPack {
 	std::vector<DLocalDesc> desc;
 	std::vector<uint8_t> sides;
 	std::vector<uint16_t> words;
-	std::vector<uint32_t> first;
+	std::vector<uint32_t> first, zoffs;
 	uint32_t ftabChars = 6, offRate = 3;
-	DLocalSet view(const DLocalDesc* d, const uint8_t* s, const uint16_t* w, const uint32_t* f) const {
+	DLocalSet view(const DLocalDesc* d, const uint8_t* s, const uint16_t* w, const uint32_t* f, const uint32_t* z) const {
 		DLocalSet v;
-		v.desc = d; v.sides = s; v.words = w; v.first = f; v.n = (uint32_t)desc.size(); v.ftabChars = ftabChars; v.offRate = offRate;
+		v.desc = d; v.sides = s; v.words = w; v.first = f; v.zoffs = z; v.n = (uint32_t)desc.size(); v.ftabChars = ftabChars; v.offRate = offRate;
 		return v;
 	}
 };
 
 inline void pack_local(const HostIndex& ix, LocalPack& lp) {
-	lp.desc.clear(); lp.sides.clear(); lp.words.clear();
+	lp.desc.clear(); lp.sides.clear(); lp.words.clear(); lp.zoffs.clear();
 	lp.first = ix.local_first;
 	if(lp.first.empty()) lp.first.assign(ix.g.nPat + 1, 0);
 	for(const HostGfm& l : ix.local) {
@@ -30,6 +30,8 @@ inline void pack_local(const HostIndex& ix, LocalPack& lp) {
 		memset(&d, 0, sizeof d);
 		d.len = l.p.len; d.gbwtLen = l.p.gbwtLen; d.eftabLen = l.p.eftabLen; d.nFrag = l.nFrag;
 		d.nZ = (uint32_t)l.zOffs.size(); d.zoff = l.zOffs.empty() ? H2G_MAX : l.zOffs[0];
+		d.zoffs_off = (uint32_t)lp.zoffs.size();
+		lp.zoffs.insert(lp.zoffs.end(), l.zOffs.begin(), l.zOffs.end());
 		d.tidx = l.tidx; d.localOffset = l.localOffset; d.joinedOffset = l.joinedOffset;
 		for(int i = 0; i < 5; i++) d.fchr[i] = l.fchr[i];
 		d.ftabLim = l.p.linear ? l.p.len : l.p.gbwtLen;
@@ -45,6 +47,7 @@ inline void pack_local(const HostIndex& ix, LocalPack& lp) {
 	}
 	lp.sides.resize(lp.sides.size() + 256, 0);
 	lp.words.resize(lp.words.size() + 64, 0);
+	lp.zoffs.resize(lp.zoffs.size() + 4, H2G_MAX);
 }
 
 }  // namespace h2g

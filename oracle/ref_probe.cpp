@@ -290,7 +290,7 @@ int main(int argc, char** argv) {
 		}
 		return 0;
 	}
-	if(cmd == "psearch" || cmd == "coords" || cmd == "extend" || cmd == "sw" || cmd == "adjust") {
+	if(cmd == "psearch" || cmd == "lsearch" || cmd == "coords" || cmd == "extend" || cmd == "sw" || cmd == "adjust") {
 		// <cmd> <base> <reads.fa> <nospliced:0|1>
 		vector<Read*> rds;
 		loadReads(argv[3], rds);
@@ -337,6 +337,31 @@ int main(int argc, char** argv) {
 					if(!linear) {   // graph index: in-edge list of the hit
 						printf(" %u", (unsigned)ph._node_iedge_count.size());
 						for(size_t e = 0; e < ph._node_iedge_count.size(); e++) printf(" %u:%u", ph._node_iedge_count[e].first, ph._node_iedge_count[e].second);
+					}
+					putchar('\n');
+					continue;
+				}
+				if(cmd == "lsearch") {
+					// lsearch <base> <reads.fa> <nospliced> <tidx> <toff> <extoff> <fw>: localGFMSearch (hi_aligner.h:6751) leftwards from
+					// read offset extoff on the local index covering (tidx, toff), then getGenomeCoords_local (:5861)
+					if(fwi != 0) continue;
+					index_t tidx = (index_t)atoi(argv[5]), toff = (index_t)atoi(argv[6]), extoff = (index_t)atoi(argv[7]);
+					bool lfw = atoi(argv[8]) != 0;
+					const LocalGFM<local_index_t, index_t>* l = p.gfm->getLocalGFM(tidx, toff);
+					index_t extlen = 0;
+					local_index_t top = (local_index_t)INDEX_MAX, bot = (local_index_t)INDEX_MAX, ntop = top, nbot = bot;
+					EList<pair<local_index_t, local_index_t> > lie;
+					bool uniqueStop = true;
+					index_t nelt = al.localGFMSearch(*l, rd, *sc, rp, lfw, extoff, extlen, top, bot, ntop, nbot, lie, rnd, uniqueStop, 8);
+					printf("%llu nelt %u extlen %u top %u bot %u node %u %u unique %d nie %u", (unsigned long long)rd.rdid, nelt, extlen, (unsigned)top, (unsigned)bot,
+					       (unsigned)ntop, (unsigned)nbot, (int)uniqueStop, (unsigned)lie.size());
+					for(size_t e = 0; e < lie.size(); e++) printf(" %u:%u", (unsigned)lie[e].first, (unsigned)lie[e].second);
+					if(nelt > 0 && nelt <= 5) {
+						EList<Coord> lco;
+						bool st = false;
+						al.getGenomeCoords_local(*l, *p.altdb, *p.ref, rnd, top, bot, ntop, nbot, lie, lfw, extoff + 1 - extlen, extlen, lco, wlm, prm, him, true, st);
+						printf(" | %u", (unsigned)lco.size());
+						for(size_t k = 0; k < lco.size(); k++) printf(" %lld:%lld:%llu", (long long)(int32_t)lco[k].ref(), (long long)lco[k].off(), (unsigned long long)lco[k].joinedOff());
 					}
 					putchar('\n');
 					continue;

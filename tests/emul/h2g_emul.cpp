@@ -58,7 +58,7 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dalts.a = reinterpret_cast<const DAlt*>(e->host.alts.data()); e->dalts.n = g.p.linear ? 0 : (uint32_t)e->host.alts.size();
 	e->dalts.maxAltsTried = 16;
 	pack_local(e->host, e->lp);
-	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data());
+	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data(), e->lp.zoffs.data());
 	*out = e;
 	return 0;
 }

@@ -42,7 +42,7 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
     qnames = [str(i) for i in range(nreads)]
     if backend is None:
         outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames, bowtie2_dp=bowtie2_dp)
-        got = SU.render(outs, recs, refnames, [rdlen] * nreads, qnames)
+        got = SU.render(outs, recs, refnames, [reads[i] for i in range(nreads)], qnames)
     else:   # backend(base, reads, qnames) -> (outs with .overflow/.depth, rendered dict)
         outs, got = backend(base, reads, qnames, refnames)
     bad = ovf = setbad = 0

@@ -88,7 +88,7 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     bad = ovf = setbad = 0
     ncon = 0
     for i in range(npairs):
-        got = PS.finish_pair(outs[i], r1, r2, i * (stride if backend else SU.AL_MAX_RESULTS), refnames, (rdlen, rdlen))
+        got = PS.finish_pair(outs[i], r1, r2, i * (stride if backend else SU.AL_MAX_RESULTS), refnames, (m1[i], m2[i]))
         w = want[q[i]]
         ncon += 1 if (w[0][0] & 2) else 0
         ovf += 1 if outs[i].overflow else 0

@@ -40,11 +40,67 @@ def parse_sam(path):
     return names, recs
 
 
-def cigar_of(rec: AlnRec, rdlen):
-    """CIGAR in reference-forward orientation from the stored edit list (5'-relative, inverted when !fw)."""
-    eds = [(rec.edits[k].pos, rec.edits[k].type) for k in range(rec.nedits)]
+def cigar_of(rec: AlnRec, rd):
+    """CIGAR in reference-forward orientation from the stored edit list (5'-relative, inverted when !fw).  `rd` = the read
+    as base codes (forward strand): the SAM printer's own gap left-alignment is then reproduced (StackedAln::leftAlign,
+    aligner_result.cpp:746, called from aln_sink.h:3048) — it slides a non-SNP gap left over matching bases until it meets
+    another gap, which the aligner's GenomeHit::leftAlign does not do next to an ALT gap.  An int (read length) skips it."""
+    eds = [(rec.edits[k].pos, rec.edits[k].type, chr(rec.edits[k].chr), rec.edits[k].snp != api.MAX) for k in range(rec.nedits)]
     if not rec.fw:   # stored 5'->3' along the original read, relative to the first aligned base: mirror within len
-        eds = [((rec.len - p) if t == 1 else (rec.len - p - 1), t) for p, t in reversed(eds)]
+        eds = [((rec.len - p) if t == 1 else (rec.len - p - 1), t, c, sn) for p, t, c, sn in reversed(eds)]
+    rel, snp, refc = [], [], []     # StackedAln::init (aligner_result.cpp:660-728)
+    seq = None
+    if not isinstance(rd, (int, np.integer)):
+        seq = np.asarray(rd)
+        if not rec.fw:
+            seq = np.where(seq[::-1] < 4, 3 - seq[::-1], 4)
+    ei = 0
+    for i in range(rec.len):
+        consumed = False
+        while ei < len(eds) and eds[ei][0] == i and not consumed:
+            p, t, c, sn = eds[ei]
+            if t == 1:
+                rel.append("D"); snp.append(sn); refc.append(c)
+            elif t == 2:
+                rel.append("I"); snp.append(sn); refc.append("-"); consumed = True
+            else:
+                rel.append("X"); snp.append(sn); refc.append(c); consumed = True
+            ei += 1
+        if not consumed:
+            rel.append("="); snp.append(False)
+            refc.append("ACGTN"[int(seq[rec.trim5 + i])] if seq is not None else "?")
+    if seq is not None:
+        readc = []
+        k = 0
+        for r in rel:
+            if r == "D":
+                readc.append("-")
+            else:
+                readc.append("ACGTN"[int(seq[rec.trim5 + k])]); k += 1
+        ln = len(rel)
+        i = 0
+        while i < ln:                # StackedAln::leftAlign(false)
+            r = rel[i]
+            if r in "ID":
+                if snp[i]:
+                    i += 1
+                    continue
+                glen = 1
+                for j in range(i + 1, ln):
+                    if rel[j] != r:
+                        break
+                    glen += 1
+                gp, ngp = (refc, readc) if r == "I" else (readc, refc)
+                l = i - 1
+                rr = l + glen
+                while l > 0 and ngp[l] == ngp[rr]:
+                    if rel[l] in "IDXN":
+                        break
+                    gp[l], gp[rr] = gp[rr], gp[l]
+                    rel[l], rel[rr] = rel[rr], rel[l]
+                    l -= 1; rr -= 1
+                i += glen - 1
+            i += 1
     ops = []
 
     def add(op, n=1):
@@ -55,17 +111,8 @@ def cigar_of(rec: AlnRec, rdlen):
         else:
             ops.append([op, n])
     add("S", rec.trim5)
-    ei = 0
-    for i in range(rec.len):
-        isins = False
-        while ei < len(eds) and eds[ei][0] == i:
-            t = eds[ei][1]
-            if t == 1:
-                add("D")
-            elif t == 2:
-                isins = True
-            ei += 1
-        add("I" if isins else "M")
+    for r in rel:
+        add("M" if r in "=X" else r)
     add("S", rec.trim3)
     return "".join(f"{n}{op}" for op, n in ops)
 

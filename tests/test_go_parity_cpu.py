@@ -16,7 +16,7 @@ def test_golden_sam(g1_index, golden_dir):
     names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
     outs, recs = emu_align(g1_index, seqs, names)
     refnames, want = SU.parse_sam(os.path.join(golden_dir, "ref_se_nospliced.sam.gz"))
-    got = SU.render(outs, recs, refnames, [len(s) for s in seqs], names)
+    got = SU.render(outs, recs, refnames, seqs, names)
     assert sum(1 for q in names if want[q][0][0] != 4) > 300
     for i, q in enumerate(names):
         assert outs[i].overflow == 0
@@ -34,6 +34,13 @@ def test_golden_sam(g1_index, golden_dir):
     # SNP-graph index (hisat2-build --snp), reads drawn from the alternate haplotype
     dict(seed=106, nreads=1500, rdlen=101, sub=0.01, indel=0.001, nrate=0.001, snps=250),
     dict(seed=107, nreads=1000, rdlen=101, sub=0.02, indel=0.002, nrate=0.0, snps=100),
+    # dense variants: local graph indexes with several '$' rows, SNP ids kept across combineWith, the SAM printer's
+    # own gap left-alignment next to ALT gaps (seed 903 is the case that exposed all three)
+    dict(seed=903, nreads=8000, rdlen=101, sub=0.02, indel=0.003, nrate=0.0, snps=80),
+    dict(seed=923, nreads=5000, rdlen=76, sub=0.03, indel=0.005, nrate=0.0, snps=30),
+    dict(seed=924, nreads=3000, rdlen=250, sub=0.01, indel=0.002, nrate=0.001, snps=100),
+    # SwAligner pass on a graph index: replace_edits_with_alts (spliced_aligner.h:282)
+    dict(seed=925, nreads=4000, rdlen=101, sub=0.02, indel=0.006, nrate=0.001, snps=50, extra=("--bowtie2-dp", "2"), bowtie2_dp=2),
 ])
 def test_live_reference(case):
     """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""
@@ -59,7 +66,7 @@ def test_golden_pairs_sam(g1_index, golden_dir):
     outs, r1, r2 = F.emu_pairs(g1_index, np.stack(s1), np.stack(s2), q, q)
     kinds = set()
     for i in range(len(s1)):
-        got = PS.finish_pair(outs[i], r1, r2, i * SU.AL_MAX_RESULTS, refnames, (101, 101))
+        got = PS.finish_pair(outs[i], r1, r2, i * SU.AL_MAX_RESULTS, refnames, (s1[i], s2[i]))
         assert outs[i].overflow == 0
         assert got == want[q[i]], i
         kinds.add(got[0][0] & 0xF)

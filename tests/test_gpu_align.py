@@ -36,7 +36,7 @@ def test_golden_sam(g1_index, golden_dir):
     names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
     res, aln, c = gpu_align(g1_index, seqs, names)
     refnames, want = SU.parse_sam(os.path.join(golden_dir, "ref_se_nospliced.sam.gz"))
-    got = SU.render_selected(res, aln, refnames, [len(s) for s in seqs], names)
+    got = SU.render_selected(res, aln, refnames, seqs, names)
     assert (res["overflow"] == 0).all()
     for q in names:
         assert got[q] == want[q], q
@@ -51,7 +51,7 @@ class _Out:
 
 def _backend(base, reads, qnames, refnames, bowtie2_dp=0):
     res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames, bowtie2_dp=bowtie2_dp)
-    got = SU.render_selected(res, aln, refnames, [reads.shape[1]] * len(reads), qnames)
+    got = SU.render_selected(res, aln, refnames, [reads[i] for i in range(len(reads))], qnames)
     return [_Out(r) for r in res], got
 
 
@@ -83,11 +83,24 @@ def test_live_reference_bowtie2_dp(dp):
 @pytest.mark.parametrize("case", [
     dict(seed=221, nreads=8000, rdlen=101, sub=0.01, indel=0.001, nrate=0.001, snps=250),
     dict(seed=222, nreads=5000, rdlen=101, sub=0.02, indel=0.002, nrate=0.0, snps=100),
+    dict(seed=903, nreads=30000, rdlen=101, sub=0.02, indel=0.003, nrate=0.0, snps=80),
+    dict(seed=904, nreads=20000, rdlen=150, sub=0.01, indel=0.002, nrate=0.001, snps=150, lens=(400000, 150000), repeats=40),
+    dict(seed=923, nreads=20000, rdlen=76, sub=0.03, indel=0.005, nrate=0.0, snps=30),
 ])
 def test_live_reference_graph_index(case):
     """go() on a SNP-graph index (hisat2-build --snp): graph LF, node walk, ALT-aware extension; reads from the alt haplotype"""
     import fuzz_align as F
     bad, _ = F.run_case(verbose=3, backend=_backend, **case)
+    assert bad == 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+def test_live_reference_graph_index_bowtie2_dp():
+    """SwAligner pass on a graph index: SW edits that coincide with known variants get their ids (replace_edits_with_alts)"""
+    import functools
+    import fuzz_align as F
+    bad, _ = F.run_case(verbose=3, backend=functools.partial(_backend, bowtie2_dp=2), seed=925, nreads=10000, rdlen=101, sub=0.02,
+                        indel=0.006, nrate=0.001, snps=50, extra=("--bowtie2-dp", "2"))
     assert bad == 0
 
 

@@ -47,6 +47,14 @@ def test_live_reference_pairs_graph_index(monkeypatch):
     assert bad == 0
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+def test_live_reference_pairs_dense_graph_index(monkeypatch):
+    """variants every ~100 bp, 125 bp mates, wide fragments (the case that exposed the multi-'$' local index bug)"""
+    monkeypatch.setattr(F, "SNPS", 100)
+    bad, _ = F.run_case(verbose=3, backend=_backend, stride=api.PAIR_RES_CAP, seed=913, npairs=20000, rdlen=125, sub=0.02, frag_mean=350, frag_sd=120)
+    assert bad == 0
+
+
 def test_golden_pairs_sam(g1_index, golden_dir):
     import gzip
     import tempfile
@@ -65,4 +73,4 @@ def test_golden_pairs_sam(g1_index, golden_dir):
     res, a1, a2 = _backend(g1_index, np.stack(s1), np.stack(s2), q, q)
     for i in range(len(s1)):
         assert res[i].overflow == 0
-        assert PS.finish_pair(res[i], a1, a2, i * api.PAIR_RES_CAP, refnames, (101, 101)) == want[q[i]], i
+        assert PS.finish_pair(res[i], a1, a2, i * api.PAIR_RES_CAP, refnames, (s1[i], s2[i])) == want[q[i]], i

@@ -94,7 +94,7 @@ subprocess.run([exe, "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-U"
 out["t_ref_se_sample_s"] = time.time() - t0
 refnames, want = SU.parse_sam(os.path.join(tmp, "se.sam"))
 res, aln = st.align_fetch(0, nv)
-got = SU.render_selected(res, aln, refnames, [101] * nv, qn[:nv])
+got = SU.render_selected(res, aln, refnames, [reads[i] for i in range(nv)], qn[:nv])
 nbad = sum(1 for q in qn[:nv] if got[q] != want[q])
 out["se"]["sam_checked_reads"] = nv; out["se"]["sam_mismatching_reads"] = nbad
 log("SE parity: %d of %d differ" % (nbad, nv))
@@ -144,7 +144,7 @@ subprocess.run([exe, "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1"
                 "-S", os.path.join(tmp, "pe.sam")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 rn, wantp = FP.parse_pe_sam(os.path.join(tmp, "pe.sam"))
 pres, pa1, pa2 = pst.align_pairs_fetch(0, nvp)
-nbad = sum(1 for i in range(nvp) if PS.finish_pair(pres[i], pa1, pa2, i * api.PAIR_RES_CAP, rn, (101, 101)) != wantp[str(i)])
+nbad = sum(1 for i in range(nvp) if PS.finish_pair(pres[i], pa1, pa2, i * api.PAIR_RES_CAP, rn, (m1[i], m2[i])) != wantp[str(i)])
 out["pe"]["sam_checked_pairs"] = nvp; out["pe"]["sam_mismatching_pairs"] = nbad
 log("PE parity: %d of %d differ" % (nbad, nvp))
 save()
