@@ -135,7 +135,8 @@ class AlnRes(C.Structure):
 
 
 class ReadResult(C.Structure):
-    _fields_ = [("nres", u32), ("nselect", u32), ("overflow", u32), ("nrank", u32), ("nsteps", u32), ("depth", u32)]
+    _fields_ = [("nres", u32), ("nselect", u32), ("overflow", u32), ("nrank", u32), ("nsteps", u32), ("depth", u32),
+                ("best", C.c_int32), ("secbest", C.c_int32), ("best_trim", u32), ("secbest_trim", u32)]
 
 
 class AlignParams(C.Structure):
@@ -151,7 +152,8 @@ class PairResult(C.Structure):
                 ("nside", u32), ("rnd_state", u32), ("pad", u32), ("pair_i", u8 * PAIR_CAP), ("pair_j", u8 * PAIR_CAP)]
 
 
-READ_RESULT_DTYPE = np.dtype([(n, np.uint32) for n in ("nres", "nselect", "overflow", "nrank", "nsteps", "depth")])
+READ_RESULT_DTYPE = np.dtype([(n, np.uint32) for n in ("nres", "nselect", "overflow", "nrank", "nsteps", "depth")] +
+                             [("best", np.int32), ("secbest", np.int32), ("best_trim", np.uint32), ("secbest_trim", np.uint32)])
 
 
 # numpy views of the result structs (same memory layout)

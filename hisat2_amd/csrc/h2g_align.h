@@ -1736,6 +1736,10 @@ H2G_HD uint32_t al_select(const MateWS* ws, const AlnParams& P, Rng* rnd, uint8_
 // the filters: seed the PRNG, go(), select.
 struct ReadOut {
 	uint32_t nres, nselect, overflow, nrank, nsteps, depth, nside;
+	// AlnSetSumm::init (aligner_result.cpp:1209-1234) over ALL reported alignments, not only the selected ones: best and
+	// second-best AlnScore (score, then fewer soft-trimmed bases) — the inputs of MAPQ and ZS:i.  INT32_MIN = invalid.
+	int32_t  best, secbest;
+	uint32_t best_trim, secbest_trim;
 	uint8_t  select[AL_MAX_RESULTS];
 };
 
@@ -1760,6 +1764,16 @@ H2G_HD void al_read(const AlnCtx& C, const DReads& rd, uint32_t read, const char
 	al_go(C, rds, read, ws, &rnd);
 	out->nres = ws->m[0].nres; out->overflow = ws->overflow; out->nrank = ws->nrank; out->nsteps = ws->nsteps; out->depth = ws->nframes_max; out->nside = ws->nside;
 	out->nselect = al_select(&ws->m[0], *C.P, &rnd, out->select);
+	int64_t b = INT64_MIN, sb = INT64_MIN;
+	uint32_t bt = 0, sbt = 0;
+	for(uint32_t i = 0; i < ws->m[0].nres; i++) {
+		const AlnRec& r = ws->m[0].res[i];
+		const uint32_t t = r.trim5 + r.trim3;
+		if(b == INT64_MIN || r.score > b || (r.score == b && t < bt)) { sb = b; sbt = bt; b = r.score; bt = t; }
+		else if(sb == INT64_MIN || r.score > sb || (r.score == sb && t < sbt)) { sb = r.score; sbt = t; }
+	}
+	out->best = b == INT64_MIN ? INT32_MIN : (int32_t)b; out->secbest = sb == INT64_MIN ? INT32_MIN : (int32_t)sb;
+	out->best_trim = bt; out->secbest_trim = sbt;
 }
 
 // Paired read: rnd.init(seedA ^ seedB) (hisat2.cpp:3464-3466), go() with both mates.  The concordant /

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <ctype.h>
 #include <string>
 #include <algorithm>
 #include <vector>
@@ -73,6 +74,7 @@ struct HostIndex {
 	std::vector<HostGfm> local;
 	std::vector<uint32_t> local_first;  // [nPat+1]
 	std::vector<std::string> names;
+	std::vector<std::string> alt_names;  // ALTDB::altnames() (.8.ht2), permuted like `alts`
 	uint32_t minK = 0;
 };
 
@@ -212,10 +214,26 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 				v.push_back(std::make_pair(a, (uint32_t)v.size()));
 			}
 			const size_t n0 = v.size();
+			// .8.ht2: i32 endian, index_t count, then whitespace-separated names (gfm.h:736-758); appended copies inherit
+			// the name of the deletion they mirror ("ssr" for splice sites, gfm.h:879-885)
+			std::vector<std::string> nm(n0);
+			{
+				Reader b8;
+				if(b8.open(base + ".8.ht2") && b8.d.size() >= 8) {
+					size_t p = 8, k = 0;
+					while(k < n0 && p < b8.d.size()) {
+						while(p < b8.d.size() && isspace((unsigned char)b8.d[p])) p++;
+						std::string s;
+						while(p < b8.d.size() && !isspace((unsigned char)b8.d[p])) s.push_back((char)b8.d[p++]);
+						if(s.empty()) break;
+						nm[k++] = s;
+					}
+				}
+			}
 			for(size_t i = 0; i < n0; i++) {
 				HostAlt a = v[i].first;
-				if(a.type == 3) { a.pos = a.pos + a.len - 1; a.seq = (a.seq & ~0xffull) | 1; v.push_back(std::make_pair(a, (uint32_t)v.size())); }
-				else if(a.type == 5) { std::swap(a.pos, a.len); v.push_back(std::make_pair(a, (uint32_t)v.size())); }
+				if(a.type == 3) { a.pos = a.pos + a.len - 1; a.seq = (a.seq & ~0xffull) | 1; v.push_back(std::make_pair(a, (uint32_t)v.size())); nm.push_back(nm[i]); }
+				else if(a.type == 5) { std::swap(a.pos, a.len); v.push_back(std::make_pair(a, (uint32_t)v.size())); nm.push_back("ssr"); }
 			}
 			std::sort(v.begin(), v.end(), [](const std::pair<HostAlt, uint32_t>& x, const std::pair<HostAlt, uint32_t>& y) {
 				const HostAlt &a = x.first, &b = y.first;
@@ -225,7 +243,8 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 				if(a.seq != b.seq) return a.seq < b.seq;
 				return x.second < y.second;
 			});
-			for(auto& e : v) ix.alts.push_back(e.first);
+			ix.alt_names.clear();
+			for(auto& e : v) { ix.alts.push_back(e.first); ix.alt_names.push_back(nm[e.second]); }
 		}
 	}
 	uint32_t gl = ix.g.p.len;

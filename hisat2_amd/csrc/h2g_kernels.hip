@@ -1106,7 +1106,7 @@ extern "C" h2g_status h2g_seed_extend_fetch(h2g_stream* s, h2g_seed_result* out,
 
 // ------------------------------------------------------------------------------------------ go() for the batch
 static_assert(sizeof(h2g_alnres) == sizeof(AlnRec), "h2g_alnres must mirror AlnRec");
-static_assert(sizeof(h2g_read_result) == 24, "h2g_read_result layout");
+static_assert(sizeof(h2g_read_result) == 40, "h2g_read_result layout");
 
 // One lane = one read at a time (grid-stride); each lane owns one AlignWS in HBM (explicit recursion stack,
 // sink, searched list).  Selected alignments are written in print order.
@@ -1317,6 +1317,7 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 	for(size_t i = 0; i < n; i++) {
 		res[i].nres = tmp[i].nres; res[i].nselect = tmp[i].nselect; res[i].overflow = tmp[i].overflow;
 		res[i].nrank = tmp[i].nrank; res[i].nsteps = tmp[i].nsteps; res[i].depth = tmp[i].depth;
+		res[i].best = tmp[i].best; res[i].secbest = tmp[i].secbest; res[i].best_trim = tmp[i].best_trim; res[i].secbest_trim = tmp[i].secbest_trim;
 	}
 	return H2G_OK;
 }

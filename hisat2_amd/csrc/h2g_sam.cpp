@@ -1,0 +1,546 @@
+// h2g_sam.cpp — host-side SAM emission for device-produced alignments (include/h2g_sam.h).
+// Plain C++ (no HIP): compiled by the host compiler and linked into libh2g.so.  Each function cites the reference code
+// whose output it reproduces byte for byte (hisat2 2.2.3, default print options hisat2.cpp:371-409, --mapq-v 2).
+#include <stdint.h>
+#include <string.h>
+#include <ctype.h>
+#include <limits.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/h2g_sam.h"
+#include "h2g_host_index.h"
+
+using namespace h2g;
+
+struct h2g_sam {
+	std::vector<std::string> refnames;
+	std::vector<uint32_t>    reflens;
+	std::vector<HostAlt>     alts;
+	std::vector<std::string> altnames;
+};
+
+namespace {
+
+enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };                      // edit.h:41-46
+enum { ALT_SGL = 1, ALT_INS = 2, ALT_DEL = 3 };                                 // alt.h:31-39
+enum { PAIR_CONCORD_M1 = 1, PAIR_CONCORD_M2, PAIR_DISCORD_M1, PAIR_DISCORD_M2, PAIR_UNP_M1, PAIR_UNP_M2, PAIR_UNPAIRED };   // aligner_result.h:404-412
+
+struct Score {        // AlnScore (aligner_result.h:44-330): score, then hisat2_score (fewer trimmed bases wins)
+	bool valid = false;
+	int64_t score = 0, h2 = 0;
+	bool gt(const Score& o) const { if(!o.valid) return valid; if(!valid) return false; return score > o.score || (score == o.score && h2 > o.h2); }
+	bool eq(const Score& o) const { return valid && o.valid && score == o.score && h2 == o.h2; }
+};
+// AlnScore::calculate_hisat2_score aligner_result.h:322-350 without repeat / transcript / splice terms
+int64_t hisat2_score(int64_t sc, uint32_t trim) {
+	if(sc > INT32_MAX) sc = INT32_MAX; else if(sc < INT32_MIN) sc = INT32_MIN;
+	const int64_t t = trim > 0xFFFF ? 0 : 0xFFFF - (int64_t)trim;
+	return (int64_t)(((uint64_t)sc << 32) | (255ull << 16) | (uint64_t)t);
+}
+Score score_of(const h2g_alnres& r) { Score s; s.valid = true; s.score = r.score; s.h2 = hisat2_score(r.score, r.trim5 + r.trim3); return s; }
+Score add(const Score& a, const Score& b) { Score s; s.valid = a.valid; s.score = a.score + b.score; s.h2 = a.h2 + b.h2; return s; }
+
+struct Flags {        // AlnFlags (aligner_result.h:414-640); the filters are "passed" bits
+	int  pairing = PAIR_UNPAIRED;
+	bool primary = true, oppAligned = false, oppFw = true, nfilt = true, lenfilt = true;
+	bool partOfPair() const { return pairing < PAIR_UNPAIRED; }
+	bool concordant() const { return pairing == PAIR_CONCORD_M1 || pairing == PAIR_CONCORD_M2; }
+	bool discordant() const { return pairing == PAIR_DISCORD_M1 || pairing == PAIR_DISCORD_M2; }
+	bool unpairedMate() const { return pairing == PAIR_UNP_M1 || pairing == PAIR_UNP_M2; }
+	bool readMate1() const { return pairing == PAIR_CONCORD_M1 || pairing == PAIR_DISCORD_M1 || pairing == PAIR_UNP_M1; }
+};
+struct Summ {         // AlnSetSumm (aligner_result.cpp:1167-1260)
+	bool paired = false;
+	Score best[2], secbest[2], bestPaired, secbestPaired;
+	uint64_t numAlns[2] = {0, 0}, numAlnsPaired = 0;
+	int64_t orefid = -1, orefoff = -1;
+};
+struct Rd { const char* name; uint32_t namelen; const uint8_t* codes; uint32_t len; const char* qual; };
+
+void put(std::string& o, int64_t v) { char b[32]; snprintf(b, sizeof b, "%lld", (long long)v); o += b; }
+
+// Scoring::nFilter / length filter as the worker applies them (hisat2.cpp:3404-3440): which YF:Z flag an unaligned read gets
+void read_filters(const Rd& r, bool* lenfilt, bool* nfilt) {
+	*lenfilt = r.len >= 2;                     // rdlens <= multiseedMms(0) || < 2  => filtered
+	uint32_t ns = 0;
+	for(uint32_t i = 0; i < r.len; i++) ns += r.codes[i] > 3;
+	*nfilt = ns <= (uint32_t)(0.0 + (double)0.15f * (double)r.len);
+}
+
+// BowtieMapq2::mapq unique.h:187-403 (end-to-end branch; canMax = false, exhausted = false)
+int mapq_v2(const Summ& s, bool mate1, uint32_t rdlen, uint32_t ordlen) {
+	const int m = mate1 ? 0 : 1;
+	const Score& bst = s.paired ? s.bestPaired : s.best[m];
+	const Score& sec = s.paired ? s.secbestPaired : s.secbest[m];
+	const bool hasSecbest = sec.valid;
+	const bool equalSecbest = hasSecbest && bst.eq(sec);
+	if(!hasSecbest || !equalSecbest) return 60;
+	auto scmin = [](uint32_t len) { int64_t v = (int64_t)(0.0 + (double)(-0.2f) * (double)(float)len); return v; };
+	int64_t scPer = 0;                                    // monotone scoring: perfect score 0
+	int64_t scMin = scmin(rdlen);
+	if(s.paired) scMin += scmin(ordlen);
+	const int64_t diff = scPer - scMin;
+	const int64_t best = bst.score, bestOver = best - scMin;
+	const int64_t secb = sec.score;
+	int64_t bestdiff = llabs(llabs(best) - llabs(secb));
+	const double d = (double)diff;
+	int ret;
+	if(bestdiff >= d * (double)0.9f)      ret = bestOver == diff ? 39 : 33;
+	else if(bestdiff >= d * (double)0.8f) ret = bestOver == diff ? 38 : 27;
+	else if(bestdiff >= d * (double)0.7f) ret = bestOver == diff ? 37 : 26;
+	else if(bestdiff >= d * (double)0.6f) ret = bestOver == diff ? 36 : 22;
+	else if(bestdiff >= d * (double)0.5f) ret = bestOver == diff ? 35 : bestOver >= d * (double)0.84f ? 25 : bestOver >= d * (double)0.68f ? 16 : 5;
+	else if(bestdiff >= d * (double)0.4f) ret = bestOver == diff ? 34 : bestOver >= d * (double)0.84f ? 21 : bestOver >= d * (double)0.68f ? 14 : 4;
+	else if(bestdiff >= d * (double)0.3f) ret = bestOver == diff ? 32 : bestOver >= d * (double)0.88f ? 18 : bestOver >= d * (double)0.67f ? 15 : 3;
+	else if(bestdiff >= d * (double)0.2f) ret = bestOver == diff ? 31 : bestOver >= d * (double)0.88f ? 17 : bestOver >= d * (double)0.67f ? 11 : 0;
+	else if(bestdiff >= d * (double)0.1f) ret = bestOver == diff ? 30 : bestOver >= d * (double)0.88f ? 12 : bestOver >= d * (double)0.67f ? 7 : 0;
+	else if(bestdiff > 0)                 ret = bestOver >= d * (double)0.67f ? 6 : 2;
+	else                                  ret = bestOver >= d * (double)0.67f ? 1 : 0;
+	return ret;
+}
+
+struct Ed { uint32_t pos; char chr, qchr; uint8_t type; uint32_t snp; };
+// Edit::invertPoss(edits, sz, false) edit.cpp:69-96
+void invert(std::vector<Ed>& e, uint32_t sz) {
+	std::reverse(e.begin(), e.end());
+	for(auto& x : e) x.pos = x.type == EDIT_READ_GAP ? sz - x.pos : sz - x.pos - 1;
+}
+struct Stacked { std::string ref, rel, read; std::vector<uint8_t> snp; uint32_t trimLS = 0, trimRS = 0; };
+// AlnRes::initStacked aligner_result.h:1856 + StackedAln::init aligner_result.cpp:660-728 + leftAlign(false) :746-791
+void stack_alignment(const h2g_alnres& r, const std::string& seq /* aligned strand, ASCII */, Stacked& st) {
+	std::vector<Ed> ed(r.nedits);
+	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = r.edits[i].pos; ed[i].chr = (char)r.edits[i].chr; ed[i].qchr = (char)r.edits[i].qchr; ed[i].type = r.edits[i].type; ed[i].snp = r.edits[i].snp; }
+	// h2g_alnres trims are those of the GenomeHit (left / right of the aligned strand) == trimLS / trimRS after the swap
+	st.trimLS = r.trim5; st.trimRS = r.trim3;
+	const uint32_t len_trimmed = (uint32_t)seq.size() - st.trimLS - st.trimRS;
+	if(!r.fw) invert(ed, len_trimmed);
+	st.ref.clear(); st.rel.clear(); st.read.clear(); st.snp.clear();
+	size_t rdoff = st.trimLS;
+	auto match_to = [&](size_t pos) { while(rdoff < pos) { const char c = seq[rdoff++]; st.ref.push_back(c); st.rel.push_back('='); st.snp.push_back(0); st.read.push_back(c); } };
+	for(const Ed& e : ed) {
+		match_to(e.pos + st.trimLS);
+		const uint8_t sn = e.snp != 0xffffffffu;
+		if(e.type == EDIT_MM)            { const char c = seq[rdoff++]; st.ref.push_back(e.chr); st.rel.push_back('X'); st.snp.push_back(sn); st.read.push_back(c); }
+		else if(e.type == EDIT_REF_GAP)  { const char c = seq[rdoff++]; st.ref.push_back('-');   st.rel.push_back('I'); st.snp.push_back(sn); st.read.push_back(c); }
+		else if(e.type == EDIT_READ_GAP) {                               st.ref.push_back(e.chr); st.rel.push_back('D'); st.snp.push_back(sn); st.read.push_back('-'); }
+	}
+	match_to(seq.size() - st.trimRS);
+	const size_t ln = st.ref.size();
+	for(size_t i = 0; i < ln; i++) {
+		const char rel = st.rel[i];
+		if(rel != '=' && rel != 'X' && rel != 'N') {
+			if(st.snp[i]) continue;
+			size_t glen = 1;
+			for(size_t j = i + 1; j < ln; j++) { if(rel != st.rel[j]) break; glen++; }
+			size_t l = i - 1, rr = l + glen;
+			std::string& gp = rel == 'I' ? st.ref : st.read;
+			const std::string& ngp = rel == 'I' ? st.read : st.ref;
+			while(l > 0 && l < ln && ngp[l] == ngp[rr]) {
+				if(st.rel[l] == 'I' || st.rel[l] == 'D') break;
+				if(st.rel[l] == 'X' || st.rel[l] == 'N') break;
+				std::swap(gp[l], gp[rr]);
+				std::swap(st.rel[l], st.rel[rr]);
+				l--; rr--;
+			}
+			i += glen - 1;
+		}
+	}
+}
+// StackedAln::buildCigar(false) + writeCigar aligner_result.cpp:796-843, 898
+void write_cigar(const Stacked& st, std::string& o) {
+	if(st.trimLS > 0) { put(o, st.trimLS); o.push_back('S'); }
+	const size_t ln = st.rel.size();
+	for(size_t i = 0; i < ln; i++) {
+		char op = st.rel[i];
+		if(op == 'X' || op == '=') op = 'M';
+		size_t run = 1;
+		for(; i + run < ln; run++) { char op2 = st.rel[i + run]; if(op2 == 'X' || op2 == '=') op2 = 'M'; if(op2 != op) break; }
+		i += run - 1;
+		put(o, (int64_t)run); o.push_back(op);
+	}
+	if(st.trimRS > 0) { put(o, st.trimRS); o.push_back('S'); }
+}
+// StackedAln::buildMdz + writeMdz aligner_result.cpp:848-893, 935-1000
+void write_mdz(const Stacked& st, std::string& o) {
+	bool mm_last = false, rdgap_last = false, first_print = true;
+	const size_t ln = st.rel.size();
+	for(size_t i = 0; i < ln; i++) {
+		const char op = st.rel[i];
+		if(op == '=') {
+			size_t run = 1, nins = 0;
+			for(; i + run < ln; run++) { if(st.rel[i + run] == '=') {} else if(st.rel[i + run] == 'I') nins++; else break; }
+			i += run - 1;
+			if(run - nins > 0) { put(o, (int64_t)(run - nins)); first_print = false; mm_last = false; rdgap_last = false; }
+		} else if(op == 'X') {
+			if(rdgap_last || mm_last || first_print) o.push_back('0');
+			o.push_back(st.ref[i]);
+			first_print = false; mm_last = true; rdgap_last = false;
+		} else if(op == 'D') {
+			if(mm_last || first_print) o.push_back('0');
+			if(!rdgap_last) o.push_back('^');
+			o.push_back(st.ref[i]);
+			first_print = false; mm_last = false; rdgap_last = true;
+		}
+	}
+	if(mm_last || rdgap_last) o.push_back('0');
+}
+
+void seq_ascii(const Rd& r, bool fw, std::string& s, std::string& q) {
+	s.resize(r.len); q.resize(r.len);
+	for(uint32_t i = 0; i < r.len; i++) {
+		const uint32_t k = fw ? i : r.len - 1 - i;
+		const uint8_t c = r.codes[k];
+		s[i] = "ACGTN"[fw ? (c > 4 ? 4 : c) : (c > 3 ? 4 : 3 - c)];
+		q[i] = r.qual ? r.qual[k] : 'I';
+	}
+}
+// SamConfig::printReadName sam.h:233-256 (truncQname_ = true)
+void put_read_name(std::string& o, const Rd& r, bool omitSlashMate) {
+	size_t n = r.namelen;
+	if(omitSlashMate && n >= 2 && r.name[n - 2] == '/' && (r.name[n - 1] == '1' || r.name[n - 1] == '2' || r.name[n - 1] == '3')) n -= 2;
+	if(n > 255) n = 255;
+	for(size_t i = 0; i < n; i++) { if(isspace((unsigned char)r.name[i])) return; o.push_back(r.name[i]); }
+}
+// SamConfig::printRefName: the name up to the first whitespace
+void put_ref_name(std::string& o, const std::string& name) { for(char c : name) { if(isspace((unsigned char)c)) break; o.push_back(c); } }
+
+// reference extent of an alignment (AlnRes::calcRefExtent aligner_result.h:1880)
+int64_t ref_extent(const h2g_alnres& r) {
+	int64_t e = r.len;
+	for(uint32_t i = 0; i < r.nedits; i++) { if(r.edits[i].type == EDIT_REF_GAP) e--; else if(r.edits[i].type == EDIT_READ_GAP) e++; }
+	return e;
+}
+// AlnRes::setFragmentLength aligner_result.h:1631-1697 without splice sites; trims extend both ends (getExtendedCoords :1156)
+int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1) {
+	const int64_t st = (int64_t)me.toff - me.trim5, en = (int64_t)me.toff + ref_extent(me) - 1 + me.trim3;
+	const int64_t ost = (int64_t)o.toff - o.trim5, oen = (int64_t)o.toff + ref_extent(o) - 1 + o.trim3;
+	bool imUpstream;
+	if(st < ost) imUpstream = true;
+	else if(st == ost) {
+		if(me.fw && o.fw && meMate1) imUpstream = true;
+		else if(me.fw && !o.fw) imUpstream = true;
+		else imUpstream = false;
+	} else imUpstream = false;
+	const int64_t up = std::min(st, ost), dn = std::max(en, oen);
+	int64_t fl = 1 + dn - up;
+	return imUpstream ? fl : -fl;
+}
+
+// AlnSinkSam::appendMate aln_sink.h:3024-3260 + printAlignedOptFlags / printEmptyOptFlags sam.h:525-1100
+void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, const h2g_alnres* rs, const h2g_alnres* rso,
+                 const Summ& summ, const Flags& fl, uint64_t nh)
+{
+	Stacked st;
+	std::string seq, qual;
+	seq_ascii(rd, rs == nullptr || rs->fw, seq, qual);
+	if(rs) stack_alignment(*rs, seq, st);
+	put_read_name(o, rd, fl.partOfPair());
+	o.push_back('\t');
+	int f = 0;
+	if(fl.partOfPair()) {
+		f |= 1;
+		if(fl.concordant()) f |= 2;
+		if(!fl.oppAligned) f |= 8;
+		f |= fl.readMate1() ? 0x40 : 0x80;
+		if(fl.oppAligned && rso != nullptr && !rso->fw) f |= 0x20;
+	}
+	if(!fl.primary) f |= 0x100;
+	if(rs && !rs->fw) f |= 0x10;
+	if(!rs) f |= 4;
+	put(o, f); o.push_back('\t');
+	if(rs) put_ref_name(o, S.refnames[rs->tidx]);
+	else if(summ.orefid != -1) put_ref_name(o, S.refnames[(size_t)summ.orefid]);
+	else o.push_back('*');
+	o.push_back('\t');
+	if(rs) put(o, (int64_t)rs->toff + 1);
+	else if(summ.orefid != -1) put(o, summ.orefoff + 1);
+	else o.push_back('0');
+	o.push_back('\t');
+	if(rs) put(o, mapq_v2(summ, fl.pairing == PAIR_UNPAIRED || fl.readMate1(), rd.len, rdo ? rdo->len : 0));
+	else o.push_back('0');
+	o.push_back('\t');
+	if(rs) write_cigar(st, o); else o.push_back('*');
+	o.push_back('\t');
+	if(rs && fl.partOfPair()) {                                         // RNEXT
+		if(rso && rs->tidx != rso->tidx) put_ref_name(o, S.refnames[rso->tidx]); else o.push_back('=');
+	} else if(summ.orefid != -1) o.push_back('=');
+	else o.push_back('*');
+	o.push_back('\t');
+	if(rs && fl.partOfPair()) put(o, (int64_t)(rso ? rso->toff : rs->toff) + 1);   // PNEXT
+	else if(summ.orefid != -1) put(o, summ.orefoff + 1);
+	else o.push_back('0');
+	o.push_back('\t');
+	// ISIZE: setMateParams computes it when the opposite mate is known and on the same reference (or concordant)
+	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1()));
+	else o.push_back('0');
+	o.push_back('\t');
+	o += seq; o.push_back('\t');
+	o += qual; o.push_back('\t');
+	if(!rs) {                                                            // printEmptyOptFlags sam.h:1033-1100
+		o += "YT:Z:";
+		o += fl.concordant() ? "CP" : fl.discordant() ? "DP" : fl.unpairedMate() ? "UP" : "UU";
+		if(!fl.lenfilt) o += "\tYF:Z:LN"; else if(!fl.nfilt) o += "\tYF:Z:NS";
+		o.push_back('\n');
+		return;
+	}
+	o += "AS:i:"; put(o, rs->score);
+	{
+		const Score& sco = summ.secbest[(fl.pairing == PAIR_UNPAIRED || fl.readMate1()) ? 0 : 1];      // summ.secbestMate(rd.mate < 2)
+		if(sco.valid) { o += "\tZS:i:"; put(o, sco.score); }
+	}
+	o += "\tXN:i:0";                                                       // refNs is never set (hi_aligner.h:6170)
+	const size_t nalts = S.alts.size();
+	size_t num_mm = 0, num_go = 0, num_gx = 0, NM = 0;
+	for(uint32_t i = 0; i < rs->nedits; i++) {                            // on the edits as stored (5'-relative)
+		const h2g_edit* e = rs->edits;
+		if(e[i].type == EDIT_MM) { if(e[i].snp >= nalts) num_mm++; }
+		else if(e[i].type == EDIT_READ_GAP) {
+			if(e[i].snp >= nalts) { num_go++; num_gx++; }
+			while(i + 1 < rs->nedits && e[i + 1].pos == e[i].pos && e[i + 1].type == EDIT_READ_GAP) { i++; if(e[i].snp >= nalts) num_gx++; }
+		} else if(e[i].type == EDIT_REF_GAP) {
+			if(e[i].snp >= nalts) { num_go++; num_gx++; }
+			while(i + 1 < rs->nedits && e[i + 1].pos == e[i].pos + 1 && e[i + 1].type == EDIT_REF_GAP) { i++; if(e[i].snp >= nalts) num_gx++; }
+		}
+	}
+	for(uint32_t i = 0; i < rs->nedits; i++) if(rs->edits[i].snp >= nalts) NM++;
+	o += "\tXM:i:"; put(o, (int64_t)num_mm);
+	o += "\tXO:i:"; put(o, (int64_t)num_go);
+	o += "\tXG:i:"; put(o, (int64_t)num_gx);
+	o += "\tNM:i:"; put(o, (int64_t)NM);
+	o += "\tMD:Z:"; write_mdz(st, o);
+	if(summ.paired && rso) { o += "\tYS:i:"; put(o, rso->score); }
+	o += "\tYT:Z:";
+	o += fl.concordant() ? "CP" : fl.discordant() ? "DP" : fl.unpairedMate() ? "UP" : "UU";
+	if(!fl.lenfilt) o += "\tYF:Z:LN"; else if(!fl.nfilt) o += "\tYF:Z:NS";
+	o += "\tNH:i:"; put(o, (int64_t)nh);
+	// Zs:Z (sam.h:985-1030): the known variants the alignment goes through, positions relative to the previous one
+	{
+		std::vector<Ed> ed(rs->nedits);
+		for(uint32_t i = 0; i < rs->nedits; i++) { ed[i].pos = rs->edits[i].pos; ed[i].type = rs->edits[i].type; ed[i].snp = rs->edits[i].snp; ed[i].chr = ed[i].qchr = 0; }
+		const uint32_t len_trimmed = rd.len - rs->trim5 - rs->trim3;
+		if(!rs->fw) invert(ed, len_trimmed);
+		bool snp_first = true;
+		uint32_t prev = 0xffffffffu;
+		for(size_t i = 0; i < ed.size(); i++) {
+			if(ed[i].snp >= nalts) continue;
+			const uint32_t si = ed[i].snp;
+			const HostAlt& snp = S.alts[si];
+			if(si == prev) continue;
+			o += snp_first ? "\tZs:Z:" : ",";
+			uint64_t pos = ed[i].pos;
+			size_t j = i;
+			while(j > 0) {
+				if(ed[j - 1].snp < nalts) {
+					const HostAlt& s2 = S.alts[ed[j - 1].snp];
+					if(s2.type == ALT_SGL) pos -= (ed[j - 1].pos + 1);
+					else if(s2.type == ALT_DEL) pos -= ed[j - 1].pos;
+					else if(s2.type == ALT_INS) pos -= (ed[j - 1].pos + snp.len);
+					break;
+				}
+				j--;
+			}
+			put(o, (int64_t)pos);
+			o += snp.type == ALT_SGL ? "|S|" : snp.type == ALT_DEL ? "|D|" : "|I|";
+			o += S.altnames[si];
+			snp_first = false;
+			prev = si;
+		}
+	}
+	o.push_back('\n');
+}
+
+// selectByScore aln_sink.h:2680-2760 on a list of AlnScore keys; RandomSource random_source.h:33
+struct Rng { uint32_t last; uint32_t next() { last = 1664525u * last + 1013904223u; uint32_t r = last >> 16; last = 1664525u * last + 1013904223u; return r ^ last; } };
+void select_by_score(const std::vector<Score>& keys, size_t num, Rng& rnd, std::vector<size_t>& sel) {
+	sel.clear();
+	const size_t sz = keys.size();
+	if(sz < 1) return;
+	if(num > sz) num = sz;
+	std::vector<std::pair<Score, size_t> > buf(sz);
+	for(size_t i = 0; i < sz; i++) buf[i] = std::make_pair(keys[i], i);
+	// EList::sort of pair<AlnScore, size_t> descending: (score, h2) then index
+	std::sort(buf.begin(), buf.end(), [](const std::pair<Score, size_t>& a, const std::pair<Score, size_t>& b) {
+		if(a.first.score != b.first.score) return a.first.score > b.first.score;
+		if(a.first.h2 != b.first.h2) return a.first.h2 > b.first.h2;
+		return a.second > b.second;
+	});
+	auto shuffle = [&](size_t begin, size_t cnt) {
+		size_t left = cnt;
+		for(size_t q = begin; q + 1 < begin + cnt; q++) { const uint32_t r = rnd.next() % (uint32_t)left; if(r > 0) std::swap(buf[q], buf[q + r]); left--; }
+	};
+	size_t streak = 0;
+	for(size_t i = 1; i < sz; i++) {
+		if(buf[i].first.eq(buf[i - 1].first)) { if(streak == 0) streak = 1; streak++; }
+		else { if(streak > 1) shuffle(i - streak, streak); streak = 0; }
+	}
+	if(streak > 1) shuffle(sz - streak, streak);
+	for(size_t i = 0; i < num; i++) sel.push_back(buf[i].second);
+	for(size_t i = 0; i + 1 < sel.size(); i++) if(!buf[i].first.eq(buf[i + 1].first)) { sel.resize(i + 1); break; }   // !secondary
+}
+
+void summ_unpaired(Summ& s, int m, const h2g_alnres* lst, size_t n) {   // the rs1u_/rs2u_ loop of AlnSetSumm::init
+	for(size_t i = 0; i < n; i++) {
+		const Score sc = score_of(lst[i]);
+		if(sc.gt(s.best[m])) { s.secbest[m] = s.best[m]; s.best[m] = sc; }
+		else if(sc.gt(s.secbest[m])) s.secbest[m] = sc;
+	}
+	s.numAlns[m] = n;
+}
+
+}  // namespace
+
+extern "C" h2g_status h2g_sam_open(const char* base, h2g_sam** out) {
+	if(!base || !out) return H2G_ERR_ARG;
+	HostIndex ix;
+	const int rc = load_host_index(base, false, ix);
+	if(rc != 0) return (h2g_status)rc;
+	h2g_sam* s = new h2g_sam();
+	s->refnames = ix.names;
+	s->reflens.assign(ix.g.plen.begin(), ix.g.plen.end());
+	s->alts = ix.alts;
+	s->altnames = ix.alt_names;
+	*out = s;
+	return H2G_OK;
+}
+extern "C" void h2g_sam_close(h2g_sam* s) { delete s; }
+
+extern "C" size_t h2g_sam_header(const h2g_sam* S, const char* cmdline, char* out, size_t cap) {
+	if(!S) return 0;
+	std::string o = "@HD\tVN:1.0\tSO:unsorted\n";
+	for(size_t i = 0; i < S->refnames.size(); i++) {
+		o += "@SQ\tSN:"; put_ref_name(o, S->refnames[i]); o += "\tLN:"; put(o, i < S->reflens.size() ? S->reflens[i] : 0); o.push_back('\n');
+	}
+	o += "@PG\tID:hisat2\tPN:hisat2\tVN:2.2.3\tCL:\""; o += cmdline ? cmdline : ""; o += "\"\n";
+	if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
+	return o.size();
+}
+
+extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                              const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
+                                              const h2g_alnres* aln, char* out, size_t cap, size_t* used)
+{
+	if(!S || !codes || !offs || !nb || !noffs || !res || !aln || !used) return H2G_ERR_ARG;
+	std::string o;
+	size_t total = 0;
+	for(size_t i = 0; i < n; i++) {
+		o.clear();
+		Rd rd = {nb + noffs[i], noffs[i + 1] - noffs[i], codes + offs[i], offs[i + 1] - offs[i], quals ? quals + offs[i] : nullptr};
+		Flags fl;
+		read_filters(rd, &fl.lenfilt, &fl.nfilt);
+		Summ summ;
+		const h2g_read_result& r = res[i];
+		if(r.best != INT32_MIN) { summ.best[0].valid = true; summ.best[0].score = r.best; summ.best[0].h2 = hisat2_score(r.best, r.best_trim); }
+		if(r.secbest != INT32_MIN) { summ.secbest[0].valid = true; summ.secbest[0].score = r.secbest; summ.secbest[0].h2 = hisat2_score(r.secbest, r.secbest_trim); }
+		const uint32_t nsel = r.nselect < H2G_ALN_CAP ? r.nselect : H2G_ALN_CAP;
+		if(nsel == 0) append_mate(*S, o, rd, nullptr, nullptr, nullptr, summ, fl, 0);
+		for(uint32_t k = 0; k < nsel; k++) {
+			fl.primary = k == 0;
+			append_mate(*S, o, rd, nullptr, &aln[i * H2G_ALN_CAP + k], nullptr, summ, fl, nsel);
+		}
+		if(total + o.size() <= cap && out) memcpy(out + total, o.data(), o.size());
+		total += o.size();
+	}
+	*used = total;
+	return total <= cap ? H2G_OK : H2G_ERR_ARG;
+}
+
+extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                            const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
+                                            const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
+                                            const h2g_pair_result* res, const h2g_alnres* aln1, const h2g_alnres* aln2,
+                                            uint32_t khits, char* out, size_t cap, size_t* used)
+{
+	if(!S || !codes1 || !offs1 || !nb1 || !noffs1 || !codes2 || !offs2 || !nb2 || !noffs2 || !res || !aln1 || !aln2 || !used) return H2G_ERR_ARG;
+	std::string o;
+	size_t total = 0;
+	std::vector<size_t> sel, sel1, sel2;
+	std::vector<Score> keys;
+	for(size_t i = 0; i < n; i++) {
+		o.clear();
+		const h2g_pair_result& pr = res[i];
+		Rd rd[2] = {{nb1 + noffs1[i], noffs1[i + 1] - noffs1[i], codes1 + offs1[i], offs1[i + 1] - offs1[i], quals1 ? quals1 + offs1[i] : nullptr},
+		            {nb2 + noffs2[i], noffs2[i + 1] - noffs2[i], codes2 + offs2[i], offs2[i + 1] - offs2[i], quals2 ? quals2 + offs2[i] : nullptr}};
+		const h2g_alnres* r1 = aln1 + i * H2G_PAIR_RES_CAP;
+		const h2g_alnres* r2 = aln2 + i * H2G_PAIR_RES_CAP;
+		const size_t n1 = std::min<size_t>(pr.nres[0], H2G_PAIR_RES_CAP), n2 = std::min<size_t>(pr.nres[1], H2G_PAIR_RES_CAP);
+		Flags f1, f2;
+		read_filters(rd[0], &f1.lenfilt, &f1.nfilt);
+		read_filters(rd[1], &f2.lenfilt, &f2.nfilt);
+		Rng rnd = {pr.rnd_state};
+		// ReportingState::foundConcordant aln_sink.cpp:74-112: concordant pairs are kept while they tie the best pair score?
+		// No — every concordant pair reported is kept (rs1_/rs2_); nconcord = their count
+		const size_t np = std::min<size_t>(pr.npairs, H2G_PAIR_CAP);
+		if(np > 0) {
+			Summ summ;
+			summ.paired = true;
+			summ_unpaired(summ, 0, r1, n1); summ_unpaired(summ, 1, r2, n2);
+			keys.clear();
+			for(size_t k = 0; k < np; k++) {
+				const Score sc = add(score_of(r1[pr.pair_i[k]]), score_of(r2[pr.pair_j[k]]));
+				keys.push_back(sc);
+				if(sc.gt(summ.bestPaired)) { summ.secbestPaired = summ.bestPaired; summ.bestPaired = sc; }
+				else if(sc.gt(summ.secbestPaired)) summ.secbestPaired = sc;
+			}
+			select_by_score(keys, std::min<size_t>(khits, np), rnd, sel);
+			for(size_t q = 0; q < sel.size(); q++) {
+				const h2g_alnres* a = &r1[pr.pair_i[sel[q]]];
+				const h2g_alnres* b = &r2[pr.pair_j[sel[q]]];
+				f1.pairing = PAIR_CONCORD_M1; f2.pairing = PAIR_CONCORD_M2;
+				f1.primary = f2.primary = q == 0;
+				f1.oppAligned = f2.oppAligned = true;
+				append_mate(*S, o, rd[0], &rd[1], a, b, summ, f1, sel.size());
+				append_mate(*S, o, rd[1], &rd[0], b, a, summ, f2, sel.size());
+			}
+		} else if(n1 == 1 && n2 == 1) {
+			// discordant: one unpaired alignment per mate (ReportingState::finish -> convertUnpairedToDiscordant)
+			Summ summ;
+			summ.paired = true;
+			summ_unpaired(summ, 0, r1, n1); summ_unpaired(summ, 1, r2, n2);
+			keys.assign(1, add(score_of(r1[0]), score_of(r2[0])));
+			summ.bestPaired = keys[0];
+			select_by_score(keys, 1, rnd, sel);
+			f1.pairing = PAIR_DISCORD_M1; f2.pairing = PAIR_DISCORD_M2;
+			f1.oppAligned = f2.oppAligned = true;
+			append_mate(*S, o, rd[0], &rd[1], &r1[0], &r2[0], summ, f1, 1);
+			append_mate(*S, o, rd[1], &rd[0], &r2[0], &r1[0], summ, f2, 1);
+		} else {
+			Summ s1, s2;
+			sel1.clear(); sel2.clear();
+			if(n1) { keys.clear(); for(size_t k = 0; k < n1; k++) keys.push_back(score_of(r1[k])); select_by_score(keys, std::min<size_t>(khits, n1), rnd, sel1); }
+			if(n2) { keys.clear(); for(size_t k = 0; k < n2; k++) keys.push_back(score_of(r2[k])); select_by_score(keys, std::min<size_t>(khits, n2), rnd, sel2); }
+			summ_unpaired(s1, 0, r1, n1); summ_unpaired(s1, 1, r2, n2);
+			s2 = s1;
+			const h2g_alnres* p1 = sel1.empty() ? nullptr : &r1[sel1[0]];
+			const h2g_alnres* p2 = sel2.empty() ? nullptr : &r2[sel2[0]];
+			f1.pairing = PAIR_UNP_M1; f2.pairing = PAIR_UNP_M2;
+			f1.oppAligned = p2 != nullptr; f2.oppAligned = p1 != nullptr;
+			auto unal = [&](int m, const h2g_alnres* opp) {          // g_.reportUnaligned for the mate that did not align
+				Summ se = m == 0 ? s1 : s2;
+				if(opp) { se.orefid = opp->tidx; se.orefoff = opp->toff; }
+				Flags& f = m == 0 ? f1 : f2;
+				f.primary = true;
+				append_mate(*S, o, rd[m], nullptr, nullptr, nullptr, se, f, 0);
+			};
+			// print order of finishRead's unpaired branch (aln_sink.h:2380-2560; reportHits interleaves the two primaries)
+			if(p1 && p2) {
+				f1.primary = f2.primary = true;
+				append_mate(*S, o, rd[0], &rd[1], p1, p2, s1, f1, sel1.size());
+				append_mate(*S, o, rd[1], &rd[0], p2, p1, s2, f2, sel2.size());
+				f1.primary = f2.primary = false;
+				for(size_t q = 1; q < sel1.size(); q++) append_mate(*S, o, rd[0], &rd[1], &r1[sel1[q]], p2, s1, f1, sel1.size());
+				for(size_t q = 1; q < sel2.size(); q++) append_mate(*S, o, rd[1], &rd[0], &r2[sel2[q]], p1, s2, f2, sel2.size());
+			} else if(p1) {
+				for(size_t q = 0; q < sel1.size(); q++) { f1.primary = q == 0; append_mate(*S, o, rd[0], nullptr, &r1[sel1[q]], nullptr, s1, f1, sel1.size()); }
+				unal(1, p1);
+			} else if(p2) {
+				for(size_t q = 0; q < sel2.size(); q++) { f2.primary = q == 0; append_mate(*S, o, rd[1], nullptr, &r2[sel2[q]], nullptr, s2, f2, sel2.size()); }
+				unal(0, p2);
+			} else { unal(0, nullptr); unal(1, nullptr); }
+		}
+		if(total + o.size() <= cap && out) memcpy(out + total, o.data(), o.size());
+		total += o.size();
+	}
+	*used = total;
+	return total <= cap ? H2G_OK : H2G_ERR_ARG;
+}

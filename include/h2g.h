@@ -236,6 +236,8 @@ typedef struct {
 	uint32_t nselect;              /* alignments to print, best first; [0] is the primary */
 	uint32_t overflow;             /* !=0: a fixed-capacity list overflowed -> caller runs this read through its own go() */
 	uint32_t nrank, nsteps, depth; /* work counters: rank calls, SA-walk steps, deepest recursion frame */
+	int32_t  best, secbest;        /* AlnSetSumm over all nres alignments (aligner_result.cpp:1209): best / second-best AS:i, */
+	uint32_t best_trim, secbest_trim; /* and their soft-trimmed base counts (the AlnScore tie-break); INT32_MIN = none.  MAPQ, ZS:i */
 } h2g_read_result;
 typedef struct {
 	uint32_t khits, kseeds;        /* -k, --max-seeds */

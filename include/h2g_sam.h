@@ -1,0 +1,52 @@
+/* h2g_sam.h — SAM emission for the alignments the device path produces.
+ *
+ * The go() kernels return what HI_Aligner::reportHit hands to the sink (h2g_alnres == the arguments of AlnRes::init,
+ * hi_aligner.h:6143-6167).  These entry points are the host half that the reference runs afterwards for every read:
+ *   AlnSinkWrap::finishRead          aln_sink.h:1939   (which lists are printed, primary / secondary, NH:i)
+ *   AlnSetSumm::init                 aligner_result.cpp:1167   (best / second-best scores)
+ *   BowtieMapq2::mapq                unique.h:187      (MAPQ, `--mapq-v 2`, the default hisat2.cpp:480)
+ *   AlnSinkSam::appendMate           aln_sink.h:3024   (the eleven mandatory fields)
+ *   StackedAln::init/leftAlign/buildCigar/buildMdz   aligner_result.cpp:660-1000 (CIGAR, MD:Z)
+ *   SamConfig::printAlignedOptFlags / printEmptyOptFlags   sam.h:525 / :1033 (AS ZS XN XM XO XG NM MD YS YT YF NH Zs)
+ *   AlnRes::setMateParams / setFragmentLength        aligner_result.h:1594-1697 (TLEN)
+ * with the reference's default print options (hisat2.cpp:371-409).  Pure host code: no device, no index traffic; it
+ * needs only the reference names (.1.ht2) and, for Zs:Z, the ALT names (.7/.8.ht2).  Every line it writes is byte-identical
+ * to the line `hisat2 --no-spliced-alignment` prints for the same read (tests/test_sam_lines.py).
+ */
+#ifndef H2G_SAM_H_
+#define H2G_SAM_H_
+#include "h2g.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct h2g_sam h2g_sam;
+
+/* reference names + lengths, ALT types/lengths/names of the index `base` (no device needed) */
+H2G_EXPORT h2g_status h2g_sam_open(const char* index_base, h2g_sam** out);
+H2G_EXPORT void       h2g_sam_close(h2g_sam*);
+
+/* "@HD / @SQ / @PG" header as the reference prints it (sam.h printHeader: VN:1.0 SO:unsorted, one @SQ per reference,
+ * @PG ID:hisat2 PN:hisat2 VN:<version> CL:"<cmdline>").  Returns bytes needed; writes at most cap. */
+H2G_EXPORT size_t     h2g_sam_header(const h2g_sam*, const char* cmdline, char* out, size_t cap);
+
+/* Unpaired reads: one h2g_read_result + H2G_ALN_CAP h2g_alnres slots per read, exactly as h2g_align_fetch returns them.
+ * codes = base codes 0..4 of the forward strand, offs[n+1]; quals = ASCII qualities with the same offsets or NULL (FASTA:
+ * 'I').  *used = bytes needed for the whole batch; H2G_ERR_ARG (nothing truncated mid-line is ever left) if > cap. */
+H2G_EXPORT h2g_status h2g_sam_format_unpaired(const h2g_sam*, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                              const char* name_bytes, const uint32_t* name_offs, size_t n_reads,
+                                              const h2g_read_result* res, const h2g_alnres* aln /* [n*H2G_ALN_CAP] */,
+                                              char* out, size_t cap, size_t* used);
+
+/* Read pairs: the report events of h2g_align_pairs_fetch (per-mate lists + concordant pair list + PRNG state).  Runs the
+ * sink's decision (concordant / discordant / unpaired, -k selection continuing the per-pair PRNG) and prints both mates. */
+H2G_EXPORT h2g_status h2g_sam_format_paired(const h2g_sam*, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                            const char* name_bytes1, const uint32_t* name_offs1, const uint8_t* codes2,
+                                            const uint32_t* offs2, const char* quals2, const char* name_bytes2,
+                                            const uint32_t* name_offs2, size_t n_pairs, const h2g_pair_result* res,
+                                            const h2g_alnres* aln1 /* [n*H2G_PAIR_RES_CAP] */, const h2g_alnres* aln2,
+                                            uint32_t khits, char* out, size_t cap, size_t* used);
+#ifdef __cplusplus
+}
+#endif
+#endif

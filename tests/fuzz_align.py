@@ -17,7 +17,7 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=(), backend=None, bowtie2_dp=0, snps=0):
+def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000), repeats=6, gaps=2, verbose=8, extra=(), backend=None, bowtie2_dp=0, snps=0, fastq=False):
     tmp = tempfile.mkdtemp(prefix="h2fuzz")
     contigs = synth.make_genome(list(lens), seed, n_gaps=gaps, gap_len=300, repeats=repeats, repeat_len=500)
     fa = os.path.join(tmp, "g.fa")
@@ -35,16 +35,26 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
     reads, _ = synth.make_reads(src, nreads, rdlen, seed + 1, sub_rate=sub, indel_rate=indel, n_rate=nrate)
     rfa = os.path.join(tmp, "r.fa")
     synth.write_reads_fasta(rfa, reads)
+    quals = None
+    if fastq:   # FASTQ input with seeded random qualities: the mismatch / N penalties become quality-dependent (scoring.h:206-260)
+        import numpy as np
+        rng = np.random.default_rng(seed + 9)
+        quals = (33 + rng.choice(np.array([2, 8, 15, 20, 25, 30, 37, 40], dtype=np.uint8), size=reads.shape)).astype(np.uint8)
+        rfa = os.path.join(tmp, "r.fq")
+        with open(rfa, "wb") as f:
+            txt = synth._ALPHA[reads]
+            for i in range(nreads):
+                f.write(b"@%d\n" % i + txt[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
     sam = os.path.join(tmp, "ref.sam")
-    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-U", rfa, "-S", sam] + list(extra),
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-q" if fastq else "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-U", rfa, "-S", sam] + list(extra),
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refnames, want = SU.parse_sam(sam)
     qnames = [str(i) for i in range(nreads)]
     if backend is None:
-        outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames, bowtie2_dp=bowtie2_dp)
+        outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames, bowtie2_dp=bowtie2_dp, quals=None if quals is None else quals.reshape(-1))
         got = SU.render(outs, recs, refnames, [reads[i] for i in range(nreads)], qnames)
     else:   # backend(base, reads, qnames) -> (outs with .overflow/.depth, rendered dict)
-        outs, got = backend(base, reads, qnames, refnames)
+        outs, got = backend(base, reads, qnames, refnames) if quals is None else backend(base, reads, qnames, refnames, quals=quals.reshape(-1))
     bad = ovf = setbad = 0
     maxdep = 0
     for i, q in enumerate(qnames):

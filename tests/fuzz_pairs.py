@@ -60,7 +60,7 @@ def parse_pe_sam(path):
 
 
 def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, gaps=2, frag_mean=300, frag_sd=30, verbose=6,
-             backend=None, stride=16):
+             backend=None, stride=16, mutate=None):
     tmp = tempfile.mkdtemp(prefix="h2pe")
     contigs = synth.make_genome(list(lens), seed, n_gaps=gaps, gap_len=300, repeats=repeats, repeat_len=500)
     fa = os.path.join(tmp, "g.fa")
@@ -76,6 +76,8 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     else:
         subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     m1, m2 = synth.make_pairs(src, npairs, rdlen, seed + 1, frag_mean=frag_mean, frag_sd=frag_sd, sub_rate=sub)
+    if mutate is not None:   # e.g. flip the orientation of some mates to obtain discordant pairs
+        m1, m2 = mutate(m1, m2)
     f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)

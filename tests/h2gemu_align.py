@@ -7,13 +7,13 @@ import sam_util as SU
 from h2gemu_py import Emu
 
 
-def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0):
+def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0, quals=None):
     e = Emu(base)
     e.L.h2gemu_set_bowtie2_dp.argtypes = [C.c_void_p, C.c_uint32]
     e.L.h2gemu_set_bowtie2_dp(e.h, bowtie2_dp)
     codes = np.concatenate(reads_list).astype(np.uint8)
     offs = np.concatenate([[0], np.cumsum([len(r) for r in reads_list])]).astype(np.uint32)
-    e.set_reads(codes, offs)
+    e.set_reads(codes, offs, quals)   # quals: flat phred+33 bytes, same offsets (FASTQ input); None = FASTA ('I')
     nb = "".join(qnames).encode()
     noffs = np.concatenate([[0], np.cumsum([len(q) for q in qnames])]).astype(np.uint32)
     n = len(reads_list)

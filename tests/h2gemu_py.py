@@ -35,9 +35,12 @@ class Emu:
     def set_reads(self, codes, offs, quals=None):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint32)
-        self._keep = (codes, offs)
+        if quals is not None:
+            quals = np.ascontiguousarray(np.frombuffer(quals, dtype=np.uint8) if isinstance(quals, (bytes, bytearray)) else quals, dtype=np.uint8)
+            assert quals.size == codes.size
+        self._keep = (codes, offs, quals)
         self.n_reads = len(offs) - 1
-        self.L.h2gemu_set_reads(self.h, codes.ctypes.data, offs.ctypes.data, None, self.n_reads)
+        self.L.h2gemu_set_reads(self.h, codes.ctypes.data, offs.ctypes.data, quals.ctypes.data if quals is not None else None, self.n_reads)
 
     def rank(self, rows, cs):
         rows = np.ascontiguousarray(rows, dtype=np.uint32)

@@ -1,0 +1,96 @@
+"""Full-line SAM comparison helpers: run the C++ SAM emitter (include/h2g_sam.h) over alignment records and diff every
+non-header line against the reference's SAM text."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from hisat2_amd import api
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def load_sam_lib(path=None):
+    L = C.CDLL(path or os.environ.get("H2G_SAM_LIB") or os.path.join(ROOT, "hisat2_amd", "libh2g.so"))
+    L.h2g_sam_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.h2g_sam_close.argtypes = [C.c_void_p]
+    L.h2g_sam_format_unpaired.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.h2g_sam_format_paired.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                                                             C.POINTER(C.c_size_t)]
+    L.h2g_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.h2g_sam_header.restype = C.c_size_t
+    return L
+
+
+def flat(reads):
+    codes = np.concatenate([np.asarray(r, dtype=np.uint8) for r in reads])
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint32)
+    return codes, offs
+
+
+def flat_names(names):
+    nb = "".join(names).encode()
+    noffs = np.concatenate([[0], np.cumsum([len(q) for q in names])]).astype(np.uint32)
+    return nb, noffs
+
+
+def format_unpaired(L, base, reads, names, res, aln, quals=None):
+    """res: array of api.ReadResult (or same-layout numpy), aln: api.AlnRes * (n*ALN_CAP) -> list of SAM lines"""
+    h = C.c_void_p()
+    assert L.h2g_sam_open(base.encode(), C.byref(h)) == 0
+    codes, offs = flat(reads)
+    nb, noffs = flat_names(names)
+    n = len(reads)
+    cap = 600 * n * 3 + 4096 + 6 * int(offs[-1])
+    buf = C.create_string_buffer(cap)
+    used = C.c_size_t(0)
+    rp = res.ctypes.data if isinstance(res, np.ndarray) else C.addressof(res)
+    ap = aln.ctypes.data if isinstance(aln, np.ndarray) else C.addressof(aln)
+    qp = None
+    if quals is not None:
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        qp = quals.ctypes.data
+    rc = L.h2g_sam_format_unpaired(h, codes.ctypes.data, offs.ctypes.data, qp, nb, noffs.ctypes.data, n, rp, ap, buf, cap, C.byref(used))
+    L.h2g_sam_close(h)
+    assert rc == 0, (rc, used.value, cap)
+    return buf.raw[:used.value].decode().splitlines()
+
+
+def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits):
+    h = C.c_void_p()
+    assert L.h2g_sam_open(base.encode(), C.byref(h)) == 0
+    c1, o1 = flat(m1)
+    c2, o2 = flat(m2)
+    nb1, no1 = flat_names(n1)
+    nb2, no2 = flat_names(n2)
+    n = len(m1)
+    cap = 700 * n * 6 + 4096 + 12 * int(o1[-1] + o2[-1])
+    buf = C.create_string_buffer(cap)
+    used = C.c_size_t(0)
+    ptr = lambda x: x.ctypes.data if isinstance(x, np.ndarray) else C.addressof(x)
+    rc = L.h2g_sam_format_paired(h, c1.ctypes.data, o1.ctypes.data, None, nb1, no1.ctypes.data, c2.ctypes.data, o2.ctypes.data, None, nb2,
+                                 no2.ctypes.data, n, ptr(res), ptr(a1), ptr(a2), khits, buf, cap, C.byref(used))
+    L.h2g_sam_close(h)
+    assert rc == 0, (rc, used.value, cap)
+    return buf.raw[:used.value].decode().splitlines()
+
+
+def body_lines(path):
+    return [l.rstrip("\n") for l in open(path) if not l.startswith("@")]
+
+
+def emu_to_abi(outs, recs, cap=api.ALN_CAP):
+    """emulator output (ReadOut + 32 AlnRec per read) -> (ReadResult array, AlnRes array) as h2g_align_fetch lays them out"""
+    import sam_util as SU
+    n = len(outs)
+    res = (api.ReadResult * n)()
+    aln = (api.AlnRes * (n * cap))()
+    for i in range(n):
+        o = outs[i]
+        r = res[i]
+        r.nres, r.nselect, r.overflow, r.nrank, r.nsteps, r.depth = o.nres, o.nselect, o.overflow, o.nrank, o.nsteps, o.depth
+        r.best, r.secbest, r.best_trim, r.secbest_trim = o.best, o.secbest, o.best_trim, o.secbest_trim
+        for k in range(min(o.nselect, cap)):
+            C.memmove(C.byref(aln[i * cap + k]), C.byref(recs[i * SU.AL_MAX_RESULTS + o.select[k]]), C.sizeof(api.AlnRes))
+    return res, aln

@@ -13,9 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "h2g.h")
 
 
-def _declared():
-    txt = open(HDR).read()
+def _declared(hdr=HDR):
+    txt = open(hdr).read()
     return re.findall(r"H2G_EXPORT\s+[\w\s\*]+?\b(h2g_\w+)\s*\(", txt)
+
+
+def test_library_exports_the_sam_emitter():
+    """include/h2g_sam.h (host-side SAM emission) lives in the same library"""
+    names = _declared(os.path.join(ROOT, "include", "h2g_sam.h"))
+    assert sorted(names) == ["h2g_sam_close", "h2g_sam_format_paired", "h2g_sam_format_unpaired", "h2g_sam_header", "h2g_sam_open"]
+    L = api.lib()
+    for n in names:
+        assert hasattr(L, n), n
 
 
 def test_library_exports_every_declared_symbol():

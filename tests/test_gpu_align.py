@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def gpu_align(base, reads, qnames, bowtie2_dp=0):
+def gpu_align(base, reads, qnames, bowtie2_dp=0, quals=None):
     """reads: (n, L) uint8 array or list of arrays"""
     lst = [np.asarray(r, dtype=np.uint8) for r in reads]
     codes = np.concatenate(lst)
     offs = np.concatenate([[0], np.cumsum([len(r) for r in lst])]).astype(np.uint32)
     ix = api.Index(base, device=0)
     st = api.Stream(ix, max_reads=len(lst), max_bases=codes.size)
-    st.set_reads(codes, offs)
+    st.set_reads(codes, offs, quals)
     st.set_read_names(qnames)
     p = st.align_params()
     p.bowtie2_dp = bowtie2_dp
@@ -49,8 +49,8 @@ class _Out:
         self.overflow, self.depth = int(r["overflow"]), int(r["depth"])
 
 
-def _backend(base, reads, qnames, refnames, bowtie2_dp=0):
-    res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames, bowtie2_dp=bowtie2_dp)
+def _backend(base, reads, qnames, refnames, bowtie2_dp=0, quals=None):
+    res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames, bowtie2_dp=bowtie2_dp, quals=quals)
     got = SU.render_selected(res, aln, refnames, [reads[i] for i in range(len(reads))], qnames)
     return [_Out(r) for r in res], got
 

@@ -1,0 +1,79 @@
+"""GPU: the whole drop-in path — reads in, SAM text out — against the reference binary: h2g_align_run / h2g_align_pairs_run on
+the device, include/h2g_sam.h on the host, and the `hisat2-align-amd` command line (FASTA and FASTQ, unpaired and paired,
+linear and SNP-graph index).  Every non-header SAM line must be byte-identical to `hisat2-align-s --no-spliced-alignment`."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import sam_lines as SL
+from test_sam_lines import diff_lines, read_fa
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+
+
+@needs_ref
+@pytest.mark.parametrize("case", [
+    dict(seed=401, nreads=20000, rdlen=101, sub=0.02, indel=0.003, nrate=0.004),
+    dict(seed=402, nreads=8000, rdlen=101, sub=0.004, indel=0.0, nrate=0.0, lens=(120000,), repeats=300, gaps=0),
+    dict(seed=403, nreads=20000, rdlen=101, sub=0.02, indel=0.003, nrate=0.0, snps=80),
+    dict(seed=404, nreads=10000, rdlen=101, sub=0.02, indel=0.003, nrate=0.003, fastq=True),
+])
+def test_unpaired_sam_text(case):
+    """device alignments -> h2g_sam_format_unpaired == the reference's lines; then the same through the command line"""
+    import fuzz_align as F
+    from test_gpu_align import _backend, gpu_align
+    bad, tmp = F.run_case(verbose=2, backend=_backend, **case)
+    assert bad == 0
+    names, reads = read_fa(os.path.join(tmp, "r.fa"))
+    quals = None
+    if case.get("fastq"):
+        lines = open(os.path.join(tmp, "r.fq"), "rb").read().split(b"\n")
+        quals = np.frombuffer(b"".join(lines[3::4]), dtype=np.uint8)
+    res, aln, _ = gpu_align(os.path.join(tmp, "g"), reads, names, quals=quals)
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, quals=quals)
+    assert diff_lines(got, want) == 0
+    out = os.path.join(tmp, "amd.sam")
+    rd = os.path.join(tmp, "r.fq" if case.get("fastq") else "r.fa")
+    subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-q" if case.get("fastq") else "-f", "-U", rd, "--no-spliced-alignment", "-S", out,
+                    "--batch", "7000"], check=True)
+    assert diff_lines(SL.body_lines(out), want) == 0
+    hdr = [l for l in open(out) if l.startswith("@")]
+    ref_hdr = [l for l in open(os.path.join(tmp, "ref.sam")) if l.startswith("@")]
+    assert hdr[:-1] == ref_hdr[:-1] and hdr[-1].startswith("@PG\tID:hisat2\tPN:hisat2\tVN:")      # @HD, @SQ identical; @PG differs by CL
+
+
+@needs_ref
+@pytest.mark.parametrize("snps,case", [
+    (0, dict(seed=411, npairs=15000, rdlen=101, sub=0.02)),
+    (0, dict(seed=412, npairs=6000, rdlen=101, sub=0.01, mutate="flip")),
+    (60, dict(seed=413, npairs=10000, rdlen=101, sub=0.02)),
+])
+def test_paired_command_line(monkeypatch, snps, case):
+    import fuzz_pairs as F
+    from test_gpu_pairs import _backend
+    from hisat2_amd import api
+    monkeypatch.setattr(F, "SNPS", snps)
+    case = dict(case)
+    if case.get("mutate") == "flip":
+        def flip(m1, m2):
+            m2 = m2.copy()
+            m2[::4] = np.where(m2[::4, ::-1] < 4, 3 - m2[::4, ::-1], 4)
+            return m1, m2
+        case["mutate"] = flip
+    bad, tmp = F.run_case(verbose=2, backend=_backend, stride=api.PAIR_RES_CAP, **case)
+    assert bad == 0
+    out = os.path.join(tmp, "amd.sam")
+    subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-f", "-1", os.path.join(tmp, "r1.fa"), "-2", os.path.join(tmp, "r2.fa"),
+                    "--no-spliced-alignment", "-S", out, "--batch", "4000"], check=True)
+    assert diff_lines(SL.body_lines(out), SL.body_lines(os.path.join(tmp, "ref.sam"))) == 0
+
+
+def test_command_line_refuses_what_is_not_built(tmp_path):
+    r = subprocess.run([CLI, "-x", "nonexistent", "-U", "x.fq"], capture_output=True, text=True)
+    assert r.returncode != 0 and "spliced alignment is not built" in r.stderr

@@ -1,0 +1,101 @@
+"""SURVEY §8(f) N1 — the C++ SAM emitter (include/h2g_sam.h, hisat2_amd/csrc/h2g_sam.cpp) against the reference's own SAM
+text: every non-header line byte for byte (QNAME … QUAL, AS ZS XN XM XO XG NM MD YS YT YF NH Zs, MAPQ, TLEN).  The
+alignment records come from the host instantiation of the go() state machine here and from the GPU in test_gpu_sam.py."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import sam_lines as SL
+import sam_util as SU
+from hisat2_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+
+
+def read_fa(path, n=None):
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
+    names, reads = [], []
+    for ln in open(path):
+        if ln[0] == ">":
+            names.append(ln[1:].strip())
+        else:
+            reads.append(np.array([code[c] for c in ln.strip()], dtype=np.uint8))
+    return names[:n], reads[:n]
+
+
+def diff_lines(got, want, show=4):
+    bad = 0
+    for i, (a, b) in enumerate(zip(got, want)):
+        if a != b:
+            bad += 1
+            if bad <= show:
+                print("line", i, "\n  got ", a, "\n  want", b)
+    return bad + abs(len(got) - len(want))
+
+
+@needs_ref
+@pytest.mark.parametrize("case", [
+    dict(seed=301, nreads=4000, rdlen=101, sub=0.02, indel=0.003, nrate=0.004),                                   # Ns, YF:Z:NS, soft clips
+    dict(seed=302, nreads=3000, rdlen=101, sub=0.004, indel=0.0, nrate=0.0, lens=(120000,), repeats=300, gaps=0),  # multi-mappers: MAPQ 0/1, ZS, NH, 256
+    dict(seed=303, nreads=4000, rdlen=101, sub=0.02, indel=0.003, nrate=0.0, snps=80),                             # graph index: Zs:Z, XM/NM without variants
+    dict(seed=304, nreads=2000, rdlen=150, sub=0.01, indel=0.004, nrate=0.001, snps=40),
+    dict(seed=305, nreads=4000, rdlen=101, sub=0.02, indel=0.003, nrate=0.003, fastq=True),                        # FASTQ: quality-dependent penalties, QUAL column
+])
+def test_unpaired_lines_identical(case):
+    import fuzz_align as F
+    from h2gemu_align import emu_align
+    assert C.sizeof(SU.AlnRec) == C.sizeof(api.AlnRes)
+    bad, tmp = F.run_case(verbose=2, **case)
+    assert bad == 0
+    names, reads = read_fa(os.path.join(tmp, "r.fa"))
+    quals = None
+    if case.get("fastq"):
+        lines = open(os.path.join(tmp, "r.fq"), "rb").read().split(b"\n")
+        quals = np.frombuffer(b"".join(lines[3::4]), dtype=np.uint8)
+    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, quals=quals)
+    res, aln = SL.emu_to_abi(outs, recs)
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, quals=quals)
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert len(want) >= case["nreads"]
+    assert diff_lines(got, want) == 0
+
+
+@needs_ref
+@pytest.mark.parametrize("snps,case", [
+    (0, dict(seed=311, npairs=2500, rdlen=101, sub=0.02)),
+    (0, dict(seed=312, npairs=1500, rdlen=101, sub=0.06, frag_mean=250, frag_sd=80)),     # many lone mates / discordant / unaligned
+    (60, dict(seed=313, npairs=2000, rdlen=101, sub=0.02)),
+    (0, dict(seed=314, npairs=1500, rdlen=101, sub=0.01, mutate="flip")),                 # every 4th mate 2 reverse-complemented: YT:Z:DP
+])
+def test_paired_lines_identical(monkeypatch, snps, case):
+    import fuzz_pairs as F
+    monkeypatch.setattr(F, "SNPS", snps)
+    case = dict(case)
+    if case.get("mutate") == "flip":
+        def flip(m1, m2):
+            m2 = m2.copy()
+            m2[::4] = np.where(m2[::4, ::-1] < 4, 3 - m2[::4, ::-1], 4)
+            return m1, m2
+        case["mutate"] = flip
+    bad, tmp = F.run_case(verbose=2, **case)
+    assert bad == 0
+    n1, m1 = read_fa(os.path.join(tmp, "r1.fa"))
+    n2, m2 = read_fa(os.path.join(tmp, "r2.fa"))
+    outs, r1, r2 = F.emu_pairs(os.path.join(tmp, "g"), np.stack(m1), np.stack(m2), n1, n2)
+    n = len(m1)
+    res = (api.PairResult * n)()
+    a1 = (api.AlnRes * (n * api.PAIR_RES_CAP))()
+    a2 = (api.AlnRes * (n * api.PAIR_RES_CAP))()
+    assert C.sizeof(api.PairResult) == C.sizeof(outs[0])
+    C.memmove(res, outs, C.sizeof(res))
+    for i in range(n):
+        for m, (src, dst) in enumerate(((r1, a1), (r2, a2))):
+            for k in range(min(outs[i].nres[m], api.PAIR_RES_CAP)):
+                C.memmove(C.byref(dst[i * api.PAIR_RES_CAP + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
+    khits = 10 if snps else 5
+    got = SL.format_paired(SL.load_sam_lib(), os.path.join(tmp, "g"), m1, m2, n1, n2, res, a1, a2, khits)
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert diff_lines(got, want) == 0
