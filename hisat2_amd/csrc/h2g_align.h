@@ -585,6 +585,10 @@ struct MateWS {              // per-mate state of HI_Aligner + the per-mate half
 	uint32_t   nres;
 	int64_t    bestUnp, best2Unp;                // bestUnp1_/bestUnp2_, best2Unp*_
 	int64_t    minsc;
+	// initRead(rds[1], ..., rightendonly) (hi_aligner.h:3993, hisat2.cpp:3524): the lone mate 2 is searched as rdi 0 but
+	// REPORTED into the sink's mate-2 list (:6192), so everything the aligner reads back by rdi — sink.bestUnp1() in
+	// nextBWT / align / hybridSearch, redundant() :6311 — sees the empty mate-1 list
+	uint32_t   sink_hidden;
 };
 
 struct AlignWS {
@@ -614,6 +618,7 @@ H2G_HD h2g_edit inverted_edit(const h2g_ghit* h, uint32_t k, uint32_t sz, uint32
 
 // redundant hi_aligner.h:6311-6351
 H2G_HD bool al_redundant(const MateWS* ws, const h2g_ghit* hit, uint32_t rdlen) {
+	if(ws->sink_hidden) return false;
 	for(uint32_t i = 0; i < ws->nres; i++) {
 		const AlnRec& r = ws->res[i];
 		if(r.tidx != hit->tidx || r.toff != hit->toff || r.fw != hit->fw) continue;
@@ -655,8 +660,10 @@ H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdl
 		else r.edits[k] = inverted_edit(hit, k, rdlen, hit->trim5);
 		r.edits[k].pos -= trim5p;
 	}
-	if(hit->score > ws->bestUnp) { ws->best2Unp = ws->bestUnp; ws->bestUnp = hit->score; }
-	else if(hit->score > ws->best2Unp) ws->best2Unp = hit->score;
+	if(!ws->sink_hidden) {
+		if(hit->score > ws->bestUnp) { ws->best2Unp = ws->bestUnp; ws->bestUnp = hit->score; }
+		else if(hit->score > ws->best2Unp) ws->best2Unp = hit->score;
+	}
 	return true;
 }
 
@@ -1585,6 +1592,7 @@ H2G_HD void al_go(const AlnCtx& C, const DReads* const rds[2], uint32_t read, Al
 	for(int r = 0; r < 2; r++) {
 		MateWS& mw = ws->m[r ^ slot0];
 		mw.nsearched = 0; mw.nres = 0; mw.bestUnp = INT64_MIN; mw.best2Unp = INT64_MIN; mw.minsc = INT64_MAX;
+		mw.sink_hidden = (slot0 != 0 && nm == 1) ? 1u : 0u;
 		if(r < nm) {
 			SeqView v = seq_view(*rds[r], read, true);
 			rdlens[r] = v.len;

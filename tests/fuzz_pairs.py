@@ -59,6 +59,23 @@ def parse_pe_sam(path):
     return names, recs
 
 
+def _flip(m1, m2):      # every 4th mate 2 reverse-complemented: same-strand pairs => discordant (YT:Z:DP)
+    m2 = m2.copy()
+    m2[::4] = np.where(m2[::4, ::-1] < 4, 3 - m2[::4, ::-1], 4)
+    return m1, m2
+
+
+def _nmask(m1, m2):     # N-filtered mates: the other mate goes through initRead (mate 2: rightendonly, hi_aligner.h:3993); N tails
+    m1 = m1.copy(); m2 = m2.copy()
+    m1[::3] = 4
+    m2[1::7] = 4
+    m1[5::11, 50:] = 4
+    return m1, m2
+
+
+MUTATORS = {"flip": _flip, "nmask": _nmask}
+
+
 def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, gaps=2, frag_mean=300, frag_sd=30, verbose=6,
              backend=None, stride=16, mutate=None):
     tmp = tempfile.mkdtemp(prefix="h2pe")
@@ -76,8 +93,8 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     else:
         subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     m1, m2 = synth.make_pairs(src, npairs, rdlen, seed + 1, frag_mean=frag_mean, frag_sd=frag_sd, sub_rate=sub)
-    if mutate is not None:   # e.g. flip the orientation of some mates to obtain discordant pairs
-        m1, m2 = mutate(m1, m2)
+    if mutate is not None:   # a name in MUTATORS or a callable (m1, m2) -> (m1, m2)
+        m1, m2 = (MUTATORS[mutate] if isinstance(mutate, str) else mutate)(m1, m2)
     f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)

@@ -49,6 +49,16 @@ def test_live_reference(case):
     assert bad == 0
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+def test_live_reference_pairs_with_filtered_mates():
+    """one mate N-filtered: the other is aligned alone; a lone mate 2 (`rightendonly`) reports into the sink's mate-2 list
+    while the aligner keeps reading the empty mate-1 list back (no redundancy check, no best-score pruning)"""
+    import fuzz_pairs as F
+    for kw in (dict(seed=421, npairs=6000, rdlen=101, sub=0.03, repeats=60), dict(seed=411, npairs=15000, rdlen=101, sub=0.02)):
+        bad, _ = F.run_case(verbose=3, mutate="nmask" if kw["seed"] == 421 else None, **kw)
+        assert bad == 0
+
+
 def test_golden_pairs_sam(g1_index, golden_dir):
     """Paired go() (pairReads, alignMate, lone mates, N filter) + the host-side finishRead mirror vs the
     reference's -1/-2 SAM: every line, in order."""

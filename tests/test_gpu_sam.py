@@ -53,19 +53,13 @@ def test_unpaired_sam_text(case):
     (0, dict(seed=411, npairs=15000, rdlen=101, sub=0.02)),
     (0, dict(seed=412, npairs=6000, rdlen=101, sub=0.01, mutate="flip")),
     (60, dict(seed=413, npairs=10000, rdlen=101, sub=0.02)),
+    (0, dict(seed=414, npairs=12000, rdlen=101, sub=0.03, repeats=60, mutate="nmask")),
 ])
 def test_paired_command_line(monkeypatch, snps, case):
     import fuzz_pairs as F
     from test_gpu_pairs import _backend
     from hisat2_amd import api
     monkeypatch.setattr(F, "SNPS", snps)
-    case = dict(case)
-    if case.get("mutate") == "flip":
-        def flip(m1, m2):
-            m2 = m2.copy()
-            m2[::4] = np.where(m2[::4, ::-1] < 4, 3 - m2[::4, ::-1], 4)
-            return m1, m2
-        case["mutate"] = flip
     bad, tmp = F.run_case(verbose=2, backend=_backend, stride=api.PAIR_RES_CAP, **case)
     assert bad == 0
     out = os.path.join(tmp, "amd.sam")

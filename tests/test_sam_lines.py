@@ -69,17 +69,11 @@ def test_unpaired_lines_identical(case):
     (0, dict(seed=312, npairs=1500, rdlen=101, sub=0.06, frag_mean=250, frag_sd=80)),     # many lone mates / discordant / unaligned
     (60, dict(seed=313, npairs=2000, rdlen=101, sub=0.02)),
     (0, dict(seed=314, npairs=1500, rdlen=101, sub=0.01, mutate="flip")),                 # every 4th mate 2 reverse-complemented: YT:Z:DP
+    (0, dict(seed=315, npairs=3000, rdlen=101, sub=0.03, repeats=60, mutate="nmask")),    # N-filtered mates: YF:Z:NS + lone-mate paths
 ])
 def test_paired_lines_identical(monkeypatch, snps, case):
     import fuzz_pairs as F
     monkeypatch.setattr(F, "SNPS", snps)
-    case = dict(case)
-    if case.get("mutate") == "flip":
-        def flip(m1, m2):
-            m2 = m2.copy()
-            m2[::4] = np.where(m2[::4, ::-1] < 4, 3 - m2[::4, ::-1], 4)
-            return m1, m2
-        case["mutate"] = flip
     bad, tmp = F.run_case(verbose=2, **case)
     assert bad == 0
     n1, m1 = read_fa(os.path.join(tmp, "r1.fa"))
