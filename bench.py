@@ -104,9 +104,32 @@ def cpu_reference(base, reads, sample, nver):
     subprocess.run([exe, "-f", "--no-spliced-alignment", "-p", "1", "-x", base, "-U", fa, "-u", str(nver), "-S", sam],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refnames, want = SU.parse_sam(sam)
+    # the whole drop-in path on the same sample: reads file -> hisat2-align-amd (parse, GPU go(), C++ sink + SAM text) -> SAM
+    # file, diffed line by line against the reference's own SAM of the sample
+    cli = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+    cli_leg = None
+    if os.path.exists(cli):
+        full = os.path.join(tmp, "full.sam")
+        subprocess.run([exe, "-f", "--no-spliced-alignment", "-p", str(cores), "--reorder", "-x", base, "-U", fa, "-S", full], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        mine = os.path.join(tmp, "amd.sam")
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "-f", "--no-spliced-alignment", "-x", base, "-U", fa, "-S", mine], capture_output=True, text=True)
+        t_cli = time.perf_counter() - t0
+        if r.returncode == 0:
+            a = [l for l in open(mine) if not l.startswith("@")]
+            b = [l for l in open(full) if not l.startswith("@")]
+            ndiff = sum(1 for x, y in zip(a, b) if x != y) + abs(len(a) - len(b))
+            cli_leg = {"reads": sample, "wall_s": t_cli, "reads_per_s_wall": sample / t_cli, "timing": r.stderr.strip().splitlines()[-1],
+                       "sam_lines": len(b), "sam_lines_differing": ndiff,
+                       "note": "wall time of the process incl. index load + upload, FASTA parsing, SAM formatting and file write"}
+            if ndiff:
+                raise SystemExit(f"bench.py: hisat2-align-amd SAM differs from the reference on {ndiff} lines")
+        else:
+            cli_leg = {"error": r.stderr[-400:]}
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
-    return ({"value": sample / dt, "unit": "reads/s", "cores": cores, "kind": "reference", "host_cpus": ncpu, "threads_scan_reads_per_s": scan,
+    return ({"value": sample / dt, "cli_end_to_end": cli_leg, "unit": "reads/s", "cores": cores, "kind": "reference", "host_cpus": ncpu, "threads_scan_reads_per_s": scan,
              "sample": f"first {sample} reads of the bench batch, oracle/_ref/hisat2-align-s -p {cores} --no-spliced-alignment -S /dev/null, {dt:.2f} s (index load {t_load:.2f} s subtracted); best of the thread counts scanned"},
             (refnames, want))
 
@@ -371,6 +394,9 @@ def main():
             "parity": parity,
         }
         if cpu_ref is not None:
+            cli_leg = cpu_ref.pop("cli_end_to_end", None)
+            if cli_leg is not None:
+                out["cli_end_to_end"] = cli_leg
             out["cpu_baseline"] = cpu_ref
             out["cpu_baseline_port"] = cpu_baseline(base, reads, min(200000, a.reads))
         elif not a.no_cpu_baseline:
