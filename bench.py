@@ -114,7 +114,7 @@ def cpu_reference(base, reads, sample, nver):
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         mine = os.path.join(tmp, "amd.sam")
         t0 = time.perf_counter()
-        r = subprocess.run([cli, "-f", "--no-spliced-alignment", "-x", base, "-U", fa, "-S", mine], capture_output=True, text=True)
+        r = subprocess.run([cli, "-f", "--no-spliced-alignment", "-p", "16", "-x", base, "-U", fa, "-S", mine], capture_output=True, text=True)
         t_cli = time.perf_counter() - t0
         if r.returncode == 0:
             a = [l for l in open(mine) if not l.startswith("@")]
@@ -122,7 +122,7 @@ def cpu_reference(base, reads, sample, nver):
             ndiff = sum(1 for x, y in zip(a, b) if x != y) + abs(len(a) - len(b))
             cli_leg = {"reads": sample, "wall_s": t_cli, "reads_per_s_wall": sample / t_cli, "timing": r.stderr.strip().splitlines()[-1],
                        "sam_lines": len(b), "sam_lines_differing": ndiff,
-                       "note": "wall time of the process incl. index load + upload, FASTA parsing, SAM formatting and file write"}
+                       "host_threads": 16, "note": "wall time of the process incl. index load + upload, FASTA parsing, SAM formatting and file write"}
             if ndiff:
                 raise SystemExit(f"bench.py: hisat2-align-amd SAM differs from the reference on {ndiff} lines")
         else:

@@ -11,6 +11,11 @@
 #include <vector>
 #include <thread>
 #include <chrono>
+#include <algorithm>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include "../../include/h2g.h"
 #include "../../include/h2g_sam.h"
 
@@ -33,68 +38,129 @@ inline bool is_read_char(int c) {
 }
 inline uint8_t base_code(int c) { switch(c | 0x20) { case 'c': return 1; case 'g': return 2; case 't': return 3; case 'n': return 4; } return 0; }
 
-class Reader {          // sequential reader over a list of FASTA / FASTQ files (pat.cpp FastaPatternSource / FastqPatternSource)
+// Sequential stream of reads over a list of FASTA / FASTQ files (pat.cpp FastaPatternSource / FastqPatternSource), parsed
+// in parallel: a file is mapped, the record starts are found by all threads (FASTA: lines beginning with '>'; FASTQ: every
+// fourth line), and each fill() hands contiguous record ranges to the threads and concatenates their output in file order.
+class Reader {
 public:
-	Reader(const std::vector<std::string>& files, bool fasta) : files_(files), fasta_(fasta) {}
-	~Reader() { if(f_) fclose(f_); }
-	// appends up to `max` reads to b; returns the number appended (0 at end of input)
+	Reader(const std::vector<std::string>& files, bool fasta, int threads) : files_(files), fasta_(fasta), T_(threads < 1 ? 1 : threads) {}
+	~Reader() { unmap(); }
 	size_t fill(Batch& b, size_t max) {
 		size_t got = 0;
-		std::string name, seq, qual, line;
 		while(got < max) {
-			if(!next_record(name, seq, qual)) break;
-			if(name.empty()) name = std::to_string(count_);
-			count_++;
-			b.names += name; b.noffs.push_back((uint32_t)b.names.size());
-			for(char c : seq) b.codes.push_back(base_code(c));
-			b.offs.push_back((uint32_t)b.codes.size());
-			if(!fasta_) { b.have_quals = true; b.quals += qual; }
-			got++;
+			if(cur_ >= nrec()) { if(!next_file()) break; continue; }
+			const size_t take = std::min(max - got, nrec() - cur_);
+			const size_t T = std::min<size_t>((size_t)T_, take / 4096 + 1);
+			std::vector<Batch> part(T);
+			auto work = [&](size_t t) {
+				Batch& pb = part[t];
+				pb.clear();
+				const size_t rb = cur_ + take * t / T, re = cur_ + take * (t + 1) / T;
+				for(size_t r = rb; r < re; r++) parse_record(r, pb);
+			};
+			std::vector<std::thread> th;
+			for(size_t t = 1; t < T; t++) th.emplace_back(work, t);
+			work(0);
+			for(auto& x : th) x.join();
+			for(size_t t = 0; t < T; t++) {
+				const Batch& pb = part[t];
+				const uint32_t cb = (uint32_t)b.codes.size(), nb = (uint32_t)b.names.size();
+				b.codes.insert(b.codes.end(), pb.codes.begin(), pb.codes.end());
+				b.names += pb.names;
+				if(!fasta_) { b.have_quals = true; b.quals += pb.quals; }
+				for(size_t k = 1; k < pb.offs.size(); k++) { b.offs.push_back(cb + pb.offs[k]); b.noffs.push_back(nb + pb.noffs[k]); }
+			}
+			cur_ += take; got += take; count_ += take;
 		}
 		return got;
 	}
 private:
-	bool getline_(std::string& s) {
-		s.clear();
-		for(;;) {
-			if(!f_) { if(fi_ >= files_.size()) return false; f_ = fopen(files_[fi_].c_str(), "rb"); if(!f_) { fprintf(stderr, "Error: could not open %s\n", files_[fi_].c_str()); exit(1); } fi_++; }
-			int c;
-			bool any = false;
-			while((c = getc_unlocked(f_)) != EOF) { any = true; if(c == '\n') break; if(c != '\r') s.push_back((char)c); }
-			if(c == EOF && !any) { fclose(f_); f_ = nullptr; continue; }
-			return true;
-		}
-	}
-	bool next_record(std::string& name, std::string& seq, std::string& qual) {
-		std::string line;
-		name.clear(); seq.clear(); qual.clear();
+	size_t nrec() const { return starts_.empty() ? 0 : starts_.size() - 1; }
+	void unmap() { if(p_) { munmap((void*)p_, n_); p_ = nullptr; n_ = 0; } starts_.clear(); cur_ = 0; }
+	bool next_file() {
+		unmap();
+		if(fi_ >= files_.size()) return false;
+		const std::string& fn = files_[fi_++];
+		const int fd = open(fn.c_str(), O_RDONLY);
+		if(fd < 0) { fprintf(stderr, "Error: could not open %s\n", fn.c_str()); exit(1); }
+		struct stat sb;
+		fstat(fd, &sb);
+		n_ = (size_t)sb.st_size;
+		if(n_ == 0) { close(fd); return true; }
+		p_ = (const char*)mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd, 0);
+		close(fd);
+		if(p_ == MAP_FAILED) { fprintf(stderr, "Error: could not map %s\n", fn.c_str()); exit(1); }
+		const size_t T = std::min<size_t>((size_t)T_, n_ / (1 << 20) + 1);
+		std::vector<std::vector<size_t> > loc(T);
+		std::vector<size_t> nl(T + 1, 0);
+		std::vector<std::thread> th;
 		if(fasta_) {
-			if(pending_.empty()) { do { if(!getline_(line)) return false; } while(line.empty() || line[0] == '#' || line[0] == ';'); }
-			else { line = pending_; pending_.clear(); }
-			if(line[0] != '>') { fprintf(stderr, "Error: reads file does not look like a FASTA file\n"); exit(1); }
-			name = line.substr(1);
-			while(getline_(line)) {
-				if(!line.empty() && line[0] == '>') { pending_ = line; break; }
-				for(char c : line) if(is_read_char((unsigned char)c)) seq.push_back(c);
-			}
-			return true;
+			auto scan = [&](size_t t) {
+				const size_t b = n_ * t / T, e = n_ * (t + 1) / T;
+				for(size_t i = b; i < e; i++) if(p_[i] == '>' && (i == 0 || p_[i - 1] == '\n')) loc[t].push_back(i);
+			};
+			for(size_t t = 1; t < T; t++) th.emplace_back(scan, t);
+			scan(0);
+			for(auto& x : th) x.join();
+			if(p_[0] != '>' && p_[0] != '#' && p_[0] != ';' && p_[0] != '\n' && p_[0] != '\r') { fprintf(stderr, "Error: reads file does not look like a FASTA file\n"); exit(1); }
+		} else {
+			auto cnt = [&](size_t t) { const size_t b = n_ * t / T, e = n_ * (t + 1) / T; size_t c = 0; for(size_t i = b; i < e; i++) c += p_[i] == '\n'; nl[t + 1] = c; };
+			for(size_t t = 1; t < T; t++) th.emplace_back(cnt, t);
+			cnt(0);
+			for(auto& x : th) x.join();
+			th.clear();
+			for(size_t t = 0; t < T; t++) nl[t + 1] += nl[t];
+			auto scan = [&](size_t t) {
+				const size_t b = n_ * t / T, e = n_ * (t + 1) / T;
+				size_t line = nl[t];                       // index of the line that starts after the next newline is line+1
+				if(b == 0 && (line & 3) == 0) loc[t].push_back(0);
+				for(size_t i = b; i < e; i++) if(p_[i] == '\n') { line++; if((line & 3) == 0 && i + 1 < n_) loc[t].push_back(i + 1); }
+			};
+			for(size_t t = 1; t < T; t++) th.emplace_back(scan, t);
+			scan(0);
+			for(auto& x : th) x.join();
+			if(p_[0] != '@') { fprintf(stderr, "Error: reads file does not look like a FASTQ file\n"); exit(1); }
 		}
-		do { if(!getline_(line)) return false; } while(line.empty());
-		if(line[0] != '@') { fprintf(stderr, "Error: reads file does not look like a FASTQ file\n"); exit(1); }
-		name = line.substr(1);
-		if(!getline_(line)) return false;
-		for(char c : line) { if(c == '.') c = 'N'; if(is_read_char((unsigned char)c)) seq.push_back(c); }
-		if(!getline_(line)) return false;      // '+' line
-		if(!getline_(qual)) return false;
-		if(qual.size() < seq.size()) { fprintf(stderr, "Error: Read %s has more read characters than quality values.\n", name.c_str()); exit(1); }
-		qual.resize(seq.size());
+		for(auto& v : loc) starts_.insert(starts_.end(), v.begin(), v.end());
+		if(!fasta_) while(!starts_.empty() && (starts_.back() >= n_ || p_[starts_.back()] != '@')) starts_.pop_back();   // trailing blank lines
+		starts_.push_back(n_);
 		return true;
+	}
+	void parse_record(size_t r, Batch& b) const {
+		const char* q = p_ + starts_[r];
+		const char* end = p_ + starts_[r + 1];
+		q++;                                                         // '>' or '@'
+		const char* nm = q;
+		while(q < end && *q != '\n') q++;
+		size_t nlen = (size_t)(q - nm);
+		if(nlen && nm[nlen - 1] == '\r') nlen--;
+		if(nlen == 0) b.names += std::to_string(count_ + (r - cur_)); else b.names.append(nm, nlen);
+		b.noffs.push_back((uint32_t)b.names.size());
+		if(q < end) q++;
+		if(fasta_) {
+			for(; q < end; q++) if(is_read_char((unsigned char)*q)) b.codes.push_back(base_code(*q));
+			b.offs.push_back((uint32_t)b.codes.size());
+			return;
+		}
+		const size_t c0 = b.codes.size();
+		for(; q < end && *q != '\n'; q++) { char c = *q; if(c == '.') c = 'N'; if(is_read_char((unsigned char)c)) b.codes.push_back(base_code(c)); }
+		b.offs.push_back((uint32_t)b.codes.size());
+		const size_t L = b.codes.size() - c0;
+		if(q < end) q++;
+		while(q < end && *q != '\n') q++;                            // '+' line
+		if(q < end) q++;
+		const char* ql = q;
+		while(q < end && *q != '\n' && *q != '\r') q++;
+		if((size_t)(q - ql) < L) { fprintf(stderr, "Error: Read %.*s has more read characters than quality values.\n", (int)nlen, nm); exit(1); }
+		b.quals.append(ql, L);
 	}
 	std::vector<std::string> files_;
 	bool fasta_;
+	int T_;
 	size_t fi_ = 0;
-	FILE* f_ = nullptr;
-	std::string pending_;
+	const char* p_ = nullptr;
+	size_t n_ = 0, cur_ = 0;
+	std::vector<size_t> starts_;
 	uint64_t count_ = 0;
 };
 
@@ -113,10 +179,10 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 int main(int argc, char** argv) {
 	std::string base, outfn;
 	std::vector<std::string> u, m1, m2;
-	bool fasta = false, nospliced = false, nohead = false;
+	bool fasta = false, nospliced = false, nohead = false, parse_only = false;
 	uint32_t dp = 0;
 	size_t batch = 1u << 20;
-	int device = 0;
+	int device = 0, threads = 1;
 	std::string cmdline;
 	for(int i = 0; i < argc; i++) { if(i) cmdline.push_back(' '); cmdline += argv[i]; }
 	for(int i = 1; i < argc; i++) {
@@ -129,17 +195,34 @@ int main(int argc, char** argv) {
 		else if(a == "-S") outfn = need("-S");
 		else if(a == "-f") fasta = true;
 		else if(a == "-q") fasta = false;
-		else if(a == "-p" || a == "--threads") need("-p");                       // host threads: the device does the work
+		else if(a == "-p" || a == "--threads") threads = atoi(need("-p"));        // host threads for parsing and SAM formatting
 		else if(a == "--no-spliced-alignment") nospliced = true;
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
 		else if(a == "--no-hd" || a == "--no-head") nohead = true;
 		else if(a == "--batch") batch = (size_t)atoll(need("--batch"));
 		else if(a == "--device") device = atoi(need("--device"));
+		else if(a == "--parse-only") parse_only = true;                           // test hook: ingest the reads, print counts + checksums
 		else { fprintf(stderr, "hisat2-align-amd: option %s is not built (see DESIGN.md, scope)\n", a.c_str()); return 1; }
 	}
 	if(base.empty() || (u.empty() && (m1.empty() || m2.empty()))) {
 		fprintf(stderr, "usage: hisat2-align-amd -x <ht2-base> {-U <r.fq> | -1 <m1.fq> -2 <m2.fq>} [-f|-q] --no-spliced-alignment [--bowtie2-dp 0|1|2] [-S out.sam]\n");
 		return 1;
+	}
+	if(parse_only) {
+		Reader r(u.empty() ? m1 : u, fasta, threads);
+		Batch b;
+		uint64_t n = 0, bases = 0, h = 1469598103934665603ull;
+		auto mix = [&](const void* p, size_t len) { const uint8_t* c = (const uint8_t*)p; for(size_t i = 0; i < len; i++) { h ^= c[i]; h *= 1099511628211ull; } };
+		for(;;) {
+			b.clear();
+			const size_t got = r.fill(b, batch);
+			if(!got) break;
+			n += got; bases += b.codes.size();
+			mix(b.codes.data(), b.codes.size()); mix(b.names.data(), b.names.size()); mix(b.quals.data(), b.quals.size());
+			for(size_t i = 1; i <= got; i++) { const uint32_t l = b.offs[i] - b.offs[i - 1], nl = b.noffs[i] - b.noffs[i - 1]; mix(&l, 4); mix(&nl, 4); }
+		}
+		printf("%llu %llu %016llx\n", (unsigned long long)n, (unsigned long long)bases, (unsigned long long)h);
+		return 0;
 	}
 	if(!nospliced) { fprintf(stderr, "hisat2-align-amd: spliced alignment is not built yet; pass --no-spliced-alignment\n"); return 1; }
 	const bool paired = u.empty();
@@ -161,7 +244,8 @@ int main(int argc, char** argv) {
 		fwrite(buf.data(), 1, need, out);
 	}
 	const double t1 = now();
-	Reader ra(paired ? m1 : u, fasta), rb(m2, fasta);
+	h2g_sam_set_threads(sam, threads);
+	Reader ra(paired ? m1 : u, fasta, threads), rb(m2, fasta, threads);
 	h2g_stream* st = nullptr;
 	Batch A[2], B[2];                                 // double buffer: batch k+1 is parsed while batch k is on the GPU
 	uint64_t nreads = 0, naligned = 0, novf = 0;

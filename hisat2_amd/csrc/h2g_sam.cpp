@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <thread>
 #include "../../include/h2g_sam.h"
 #include "h2g_host_index.h"
 
@@ -18,6 +19,7 @@ struct h2g_sam {
 	std::vector<uint32_t>    reflens;
 	std::vector<HostAlt>     alts;
 	std::vector<std::string> altnames;
+	int threads = 1;
 };
 
 namespace {
@@ -416,15 +418,44 @@ extern "C" size_t h2g_sam_header(const h2g_sam* S, const char* cmdline, char* ou
 	return o.size();
 }
 
+namespace {
+// formats reads [0, n) with `one(i, text)` on S->threads host threads (contiguous ranges, concatenated in read order)
+template <class F>
+h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_t* used) {
+	size_t T = S->threads < 1 ? 1 : (size_t)S->threads;
+	if(T > n / 2048 + 1) T = n / 2048 + 1;
+	std::vector<std::string> parts(T);
+	auto work = [&](size_t t) {
+		const size_t b = n * t / T, e = n * (t + 1) / T;
+		std::string& o = parts[t];
+		o.reserve((e - b) * 420);
+		for(size_t i = b; i < e; i++) one(i, o);
+	};
+	if(T == 1) work(0);
+	else {
+		std::vector<std::thread> th;
+		for(size_t t = 1; t < T; t++) th.emplace_back(work, t);
+		work(0);
+		for(auto& x : th) x.join();
+	}
+	size_t total = 0;
+	for(auto& p : parts) total += p.size();
+	*used = total;
+	if(total > cap || !out) return total <= cap && total == 0 ? H2G_OK : H2G_ERR_ARG;
+	size_t off = 0;
+	for(auto& p : parts) { memcpy(out + off, p.data(), p.size()); off += p.size(); }
+	return H2G_OK;
+}
+}  // namespace
+
+extern "C" void h2g_sam_set_threads(h2g_sam* S, int threads) { if(S) S->threads = threads < 1 ? 1 : threads; }
+
 extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
                                               const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
                                               const h2g_alnres* aln, char* out, size_t cap, size_t* used)
 {
 	if(!S || !codes || !offs || !nb || !noffs || !res || !aln || !used) return H2G_ERR_ARG;
-	std::string o;
-	size_t total = 0;
-	for(size_t i = 0; i < n; i++) {
-		o.clear();
+	auto one = [&](size_t i, std::string& o) {
 		Rd rd = {nb + noffs[i], noffs[i + 1] - noffs[i], codes + offs[i], offs[i + 1] - offs[i], quals ? quals + offs[i] : nullptr};
 		Flags fl;
 		read_filters(rd, &fl.lenfilt, &fl.nfilt);
@@ -438,11 +469,8 @@ extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* c
 			fl.primary = k == 0;
 			append_mate(*S, o, rd, nullptr, &aln[i * H2G_ALN_CAP + k], nullptr, summ, fl, nsel);
 		}
-		if(total + o.size() <= cap && out) memcpy(out + total, o.data(), o.size());
-		total += o.size();
-	}
-	*used = total;
-	return total <= cap ? H2G_OK : H2G_ERR_ARG;
+	};
+	return drive(S, n, one, out, cap, used);
 }
 
 extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
@@ -452,12 +480,9 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
                                             uint32_t khits, char* out, size_t cap, size_t* used)
 {
 	if(!S || !codes1 || !offs1 || !nb1 || !noffs1 || !codes2 || !offs2 || !nb2 || !noffs2 || !res || !aln1 || !aln2 || !used) return H2G_ERR_ARG;
-	std::string o;
-	size_t total = 0;
-	std::vector<size_t> sel, sel1, sel2;
-	std::vector<Score> keys;
-	for(size_t i = 0; i < n; i++) {
-		o.clear();
+	auto one = [&](size_t i, std::string& o) {
+		std::vector<size_t> sel, sel1, sel2;
+		std::vector<Score> keys;
 		const h2g_pair_result& pr = res[i];
 		Rd rd[2] = {{nb1 + noffs1[i], noffs1[i + 1] - noffs1[i], codes1 + offs1[i], offs1[i + 1] - offs1[i], quals1 ? quals1 + offs1[i] : nullptr},
 		            {nb2 + noffs2[i], noffs2[i + 1] - noffs2[i], codes2 + offs2[i], offs2[i + 1] - offs2[i], quals2 ? quals2 + offs2[i] : nullptr}};
@@ -538,9 +563,6 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 				unal(0, p2);
 			} else { unal(0, nullptr); unal(1, nullptr); }
 		}
-		if(total + o.size() <= cap && out) memcpy(out + total, o.data(), o.size());
-		total += o.size();
-	}
-	*used = total;
-	return total <= cap ? H2G_OK : H2G_ERR_ARG;
+	};
+	return drive(S, n, one, out, cap, used);
 }

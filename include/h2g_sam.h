@@ -25,6 +25,8 @@ typedef struct h2g_sam h2g_sam;
 /* reference names + lengths, ALT types/lengths/names of the index `base` (no device needed) */
 H2G_EXPORT h2g_status h2g_sam_open(const char* index_base, h2g_sam** out);
 H2G_EXPORT void       h2g_sam_close(h2g_sam*);
+/* host threads used by the format calls (contiguous read ranges, output concatenated in read order); default 1 */
+H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
 
 /* "@HD / @SQ / @PG" header as the reference prints it (sam.h printHeader: VN:1.0 SO:unsorted, one @SQ per reference,
  * @PG ID:hisat2 PN:hisat2 VN:<version> CL:"<cmdline>").  Returns bytes needed; writes at most cap. */

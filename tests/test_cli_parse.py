@@ -1,0 +1,64 @@
+"""N2: the command line's parallel FASTA / FASTQ reader (hisat2_amd/csrc/h2g_cli.cpp) — same reads, names and qualities for
+every thread count and batch size, CRLF and multi-line FASTA included (parse rules of pat.cpp:725-1010).  No GPU needed."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+pytestmark = pytest.mark.skipif(not os.path.exists(CLI), reason="hisat2-align-amd not built")
+
+
+def fnv(chunks):
+    h = 1469598103934665603
+    for c in chunks:
+        for b in c:
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def expected(names, seqs, quals, batch):
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
+    n = len(names)
+    h = 1469598103934665603
+    tot = 0
+    for b0 in range(0, n, batch):
+        sl = slice(b0, min(n, b0 + batch))
+        codes = bytes(code.get(c.upper(), 0) for s in seqs[sl] for c in s)
+        nm = "".join(names[sl]).encode()
+        q = "".join(quals[sl]).encode() if quals else b""
+        lens = b"".join(np.uint32(len(s)).tobytes() + np.uint32(len(m)).tobytes() for s, m in zip(seqs[sl], names[sl]))
+        for c in (codes, nm, q, lens):
+            for b in c:
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        tot += len(codes)
+    return n, tot, h
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "fasta_multiline_crlf", "fastq"])
+def test_reader_is_thread_and_batch_invariant(tmp_path, fmt):
+    rng = np.random.default_rng(5)
+    n = 3000
+    names = [("r%d extra words" % i) if i % 3 else "" for i in range(n)]          # empty name -> read id (pat.cpp:842)
+    seqs = ["".join(rng.choice(list("ACGTNacgtRY"), size=int(rng.integers(30, 160)))) for _ in range(n)]
+    quals = ["".join(chr(int(q)) for q in rng.integers(35, 74, size=len(s))) for s in seqs] if fmt == "fastq" else None
+    path = tmp_path / ("r.fq" if fmt == "fastq" else "r.fa")
+    with open(path, "w", newline="") as f:
+        for i in range(n):
+            if fmt == "fastq":
+                f.write("@%s\n%s\n+\n%s\n" % (names[i], seqs[i], quals[i]))
+            elif fmt == "fasta":
+                f.write(">%s\n%s\n" % (names[i], seqs[i]))
+            else:
+                s = seqs[i]
+                f.write(">%s\r\n%s\r\n%s\r\n" % (names[i], s[:40], s[40:]))
+    names = [nm if nm else str(i) for i, nm in enumerate(names)]
+    seqs2 = ["".join(c if c.upper() in "ACGTN" else "A" for c in s) for s in seqs]     # asc2dna: IUPAC codes read as 0
+    want = None
+    for threads, batch in ((1, 1 << 20), (4, 1 << 20), (7, 700), (3, 1)):
+        out = subprocess.run([CLI, "--parse-only", "-f" if fmt != "fastq" else "-q", "-U", str(path), "-p", str(threads), "--batch", str(batch),
+                              "-x", "unused"], check=True, capture_output=True, text=True).stdout.split()
+        got = (int(out[0]), int(out[1]), int(out[2], 16))
+        assert got == expected(names, seqs2, quals, batch), (threads, batch)

@@ -41,7 +41,7 @@ def test_unpaired_sam_text(case):
     out = os.path.join(tmp, "amd.sam")
     rd = os.path.join(tmp, "r.fq" if case.get("fastq") else "r.fa")
     subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-q" if case.get("fastq") else "-f", "-U", rd, "--no-spliced-alignment", "-S", out,
-                    "--batch", "7000"], check=True)
+                    "--batch", "7000", "-p", "5"], check=True)
     assert diff_lines(SL.body_lines(out), want) == 0
     hdr = [l for l in open(out) if l.startswith("@")]
     ref_hdr = [l for l in open(os.path.join(tmp, "ref.sam")) if l.startswith("@")]
@@ -64,7 +64,7 @@ def test_paired_command_line(monkeypatch, snps, case):
     assert bad == 0
     out = os.path.join(tmp, "amd.sam")
     subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-f", "-1", os.path.join(tmp, "r1.fa"), "-2", os.path.join(tmp, "r2.fa"),
-                    "--no-spliced-alignment", "-S", out, "--batch", "4000"], check=True)
+                    "--no-spliced-alignment", "-S", out, "--batch", "4000", "-p", "3"], check=True)
     assert diff_lines(SL.body_lines(out), SL.body_lines(os.path.join(tmp, "ref.sam"))) == 0
 
 

@@ -5,6 +5,10 @@ import sys
 
 
 def main(path):
+    import glob, os
+    if os.path.isdir(path):   # rocprofv3 -d <dir>: <dir>/<host>/<pid>_results.db
+        dbs = sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True), key=os.path.getsize)
+        path = dbs[-1]
     db = sqlite3.connect(path)
     cur = db.cursor()
     rows = cur.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) from kernels group by name order by 6 desc").fetchall()
