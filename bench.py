@@ -237,6 +237,22 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_align", "kernel_ms": ms_align,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "lane-per-read state machine, latency/divergence-bound at this index size (1.2 MB of sides is L2-resident); the HBM-scale Occ-rank number is rank_microbench"}
+        # HBM traffic of the same kernel on the same workload from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+        # need separate passes; they cannot be collected inside this process).  FETCH_SIZE is in KB and counts 128 B requests
+        # at 64 B on gfx950 => x2 (MI355X guide, HBM section); WRITE_SIZE is taken as reported (uncalibrated).
+        try:
+            def _pmc(fn, ctr):
+                for ln in open(os.path.join(ROOT, "profiles", fn)):
+                    if "k_align<4, false>" in ln and ctr in ln:
+                        return float(ln.split()[-1])
+                return None
+            fk, wk = _pmc("r01_k_pmc_fetch.txt", "FETCH_SIZE"), _pmc("r01_k_pmc_write.txt", "WRITE_SIZE")
+            if fk is not None and wk is not None and a.reads == 1_000_000:
+                roofline["traffic"] = int(fk * 1024 * 2 + wk * 1024)
+                roofline["traffic_source"] = ("profiles/r01_k_pmc_fetch.txt + r01_k_pmc_write.txt (rocprofv3 --pmc, same workload, per launch): "
+                                              "2 x FETCH_SIZE + WRITE_SIZE; ~8x the algorithmic bytes = per-lane workspace traffic, DESIGN.md §3")
+        except OSError:
+            pass
         seed_stage = {"ms_search": float(cnt.ms_search), "ms_resolve_extend": float(cnt.ms_resolve_extend),
                       "reads_per_s": a.reads / ((float(cnt.ms_search) + float(cnt.ms_resolve_extend)) * 1e-3)}
         # Occ-rank micro-kernel at GRCh38 scale: 15.3 M synthetic 64 B sides (0.98 GB), uniform rows

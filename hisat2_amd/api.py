@@ -140,7 +140,47 @@ class ReadResult(C.Structure):
 
 
 class AlignParams(C.Structure):
-    _fields_ = [("khits", u32), ("kseeds", u32), ("no_spliced_alignment", u32), ("secondary", u32), ("bowtie2_dp", u32)]
+    _fields_ = [("khits", u32), ("kseeds", u32), ("no_spliced_alignment", u32), ("secondary", u32), ("bowtie2_dp", u32),
+                ("mm_max", C.c_int32), ("mm_min", C.c_int32), ("n_pen", C.c_int32), ("rdg_const", C.c_int32), ("rdg_linear", C.c_int32),
+                ("rfg_const", C.c_int32), ("rfg_linear", C.c_int32), ("sc_max", C.c_int32), ("sc_min", C.c_int32), ("score_min_type", u32),
+                ("score_min_const", C.c_double), ("score_min_coeff", C.c_double)]
+
+    def apply_options(self, opts):
+        """apply a list of reference command-line options (['-k', '3', '--mp', '4,2', ...]) to this block; returns leftovers"""
+        rest, i = [], 0
+        while i < len(opts):
+            o = opts[i]
+            v = opts[i + 1] if i + 1 < len(opts) else None
+            if o == "-k":
+                self.khits = int(v); self.kseeds = max(5, 2 * self.khits); i += 2
+            elif o == "--max-seeds":
+                self.kseeds = int(v); i += 2
+            elif o == "--secondary":
+                self.secondary = 1; i += 1
+            elif o == "--bowtie2-dp":
+                self.bowtie2_dp = int(v); i += 2
+            elif o == "--mp":
+                a = v.split(","); self.mm_max = int(a[0]); self.mm_min = int(a[1]) if len(a) > 1 else self.mm_min; i += 2
+            elif o == "--sp":
+                a = v.split(",")   # the reference reads BOTH max and min from the first number (aligner_seed_policy.cpp:438-441)
+                self.sc_max = self.sc_min = int(a[0]); i += 2
+            elif o == "--no-softclip":
+                self.sc_max = self.sc_min = 2 ** 31 - 1; i += 1
+            elif o == "--np":
+                self.n_pen = int(v); i += 2
+            elif o == "--rdg":
+                a = v.split(","); self.rdg_const = int(a[0]); self.rdg_linear = int(a[1]) if len(a) > 1 else self.rdg_linear; i += 2
+            elif o == "--rfg":
+                a = v.split(","); self.rfg_const = int(a[0]); self.rfg_linear = int(a[1]) if len(a) > 1 else self.rfg_linear; i += 2
+            elif o == "--score-min":
+                a = v.split(",")
+                self.score_min_type = {"C": 1, "L": 2, "S": 3, "G": 4}[a[0]]
+                self.score_min_const = float(a[1]) if len(a) > 1 else 0.0
+                self.score_min_coeff = float(a[2]) if len(a) > 2 else 0.0
+                i += 2
+            else:
+                rest.append(o); i += 1
+        return rest
 
 
 PAIR_RES_CAP = 16

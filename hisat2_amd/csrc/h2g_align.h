@@ -11,6 +11,7 @@
 //   reportHit :6064  redundant :6311  isSearched/addSearched :6898  AlnSinkWrap::report aln_sink.h:2565
 //   selectByScore aln_sink.h:2680   RandomSource random_source.h:33
 #pragma once
+#include <math.h>
 #include "h2g_core.h"
 #include "h2g_sw.h"
 #include "h2g_graph.h"
@@ -544,8 +545,38 @@ struct AlnParams {
 	uint32_t pseudogeneStop, anchorStop;
 	uint32_t maxFragLen;     // PairedEndPolicy::maxFragLen = -X (hisat2.cpp:345)
 	uint32_t bowtie2_dp;     // ReportingParams::bowtie2_dp: 0 off, 1 conditional, 2 unconditional (hisat2.cpp:529, 1770)
+	uint32_t scoreMinType = 2;                                     // SimpleFunc scoreMin: 1 C, 2 L, 3 S, 4 G (simple_func.h:30-33)
+	double   scoreMinConst = 0.0, scoreMinCoeff = (double)(-0.2f); // --score-min, default L,0,-0.2 (hisat2.cpp:440)
 	DScoring sc;
 };
+// scoreMin.f<TAlScore>(len) (simple_func.h:88-110, hisat2.cpp:3380-3397: clamped to <= 0 in end-to-end mode)
+H2G_HD int64_t min_score_for(const AlnParams& P, uint32_t len) {
+	double X = 0.0;
+	if(P.scoreMinType == 2) X = (double)len;
+	else if(P.scoreMinType == 3) X = sqrt((double)len);
+	else if(P.scoreMinType == 4) X = log((double)len);
+	int64_t minsc = (int64_t)(P.scoreMinConst + P.scoreMinCoeff * X);
+	return minsc > 0 ? 0 : minsc;
+}
+// the C-ABI parameter block -> AlnParams (everything that is not an option is the reference's constant)
+inline AlnParams aln_params_from(const h2g_align_params& p, bool no_spliced, bool linear) {
+	AlnParams P;
+	P.khits = p.khits; P.kseeds = p.kseeds; P.no_spliced = no_spliced ? 1 : 0; P.secondary = p.secondary;
+	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
+	P.pseudogeneStop = (linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	P.bowtie2_dp = p.bowtie2_dp;
+	P.scoreMinType = p.score_min_type; P.scoreMinConst = p.score_min_const; P.scoreMinCoeff = p.score_min_coeff;
+	P.sc.mmpMax = p.mm_max; P.sc.mmpMin = p.mm_min; P.sc.nPen = p.n_pen; P.sc.rdGapConst = p.rdg_const; P.sc.rdGapLinear = p.rdg_linear;
+	P.sc.rfGapConst = p.rfg_const; P.sc.rfGapLinear = p.rfg_linear; P.sc.scMax = p.sc_max; P.sc.scMin = p.sc_min;
+	return P;
+}
+inline void align_params_defaults(h2g_align_params* p, bool linear) {
+	p->khits = linear ? 5 : 10;                       // hisat2.cpp:3903-3906
+	p->kseeds = p->khits * 2 > 5 ? p->khits * 2 : 5;  // --max-seeds default hisat2.cpp:3174-3176
+	p->no_spliced_alignment = 1; p->secondary = 0; p->bowtie2_dp = 0;
+	p->mm_max = 6; p->mm_min = 2; p->n_pen = 1; p->rdg_const = 5; p->rdg_linear = 3; p->rfg_const = 5; p->rfg_linear = 3; p->sc_max = 2; p->sc_min = 1;
+	p->score_min_type = 2; p->score_min_const = 0.0; p->score_min_coeff = (double)(-0.2f);
+}
 
 // One reported alignment = the arguments reportHit (hi_aligner.h:6064-6166) hands to AlnRes::init
 struct AlnRec {
@@ -1597,9 +1628,7 @@ H2G_HD void al_go(const AlnCtx& C, const DReads* const rds[2], uint32_t read, Al
 			SeqView v = seq_view(*rds[r], read, true);
 			rdlens[r] = v.len;
 			// scoreMin.f<TAlScore>(len), SIMPLE_FUNC_LINEAR 0, -0.2 (hisat2.cpp:440, simple_func.h:88)
-			int64_t minsc = (int64_t)(0.0 + (double)(-0.2f) * (double)v.len);
-			if(minsc > 0) minsc = 0;
-			mw.minsc = minsc;
+			mw.minsc = min_score_for(P, v.len);
 			for(int k = 0; k < 2; k++) {
 				RBHit& h = mw.rb[k];
 				h.len = v.len; h.cur = 0; h.done = 0; h.numPartialSearch = 0; h.numUniqueSearch = 0; h.npartial = 0;

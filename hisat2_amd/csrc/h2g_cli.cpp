@@ -184,6 +184,7 @@ int main(int argc, char** argv) {
 	size_t batch = 1u << 20;
 	int device = 0, threads = 1;
 	std::string cmdline;
+	std::vector<std::string> opts;                      // scoring / reporting options, applied once the index type is known
 	for(int i = 0; i < argc; i++) { if(i) cmdline.push_back(' '); cmdline += argv[i]; }
 	for(int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
@@ -198,6 +199,10 @@ int main(int argc, char** argv) {
 		else if(a == "-p" || a == "--threads") threads = atoi(need("-p"));        // host threads for parsing and SAM formatting
 		else if(a == "--no-spliced-alignment") nospliced = true;
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
+		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min") {
+			opts.push_back(a); opts.push_back(need(a.c_str()));
+		}
+		else if(a == "--secondary" || a == "--no-softclip") opts.push_back(a);
 		else if(a == "--no-hd" || a == "--no-head") nohead = true;
 		else if(a == "--batch") batch = (size_t)atoll(need("--batch"));
 		else if(a == "--device") device = atoi(need("--device"));
@@ -234,6 +239,29 @@ int main(int argc, char** argv) {
 	if(h2g_sam_open(base.c_str(), &sam) != H2G_OK) die("cannot read reference names");
 	h2g_align_params P; h2g_align_params_init(&P, ix);
 	P.bowtie2_dp = dp;
+	for(size_t i = 0; i < opts.size(); i++) {             // same parse rules as hisat2.cpp:1500-1620 / aligner_seed_policy.cpp
+		const std::string& o = opts[i];
+		auto two = [&](int32_t* x, int32_t* y) { const std::string& v = opts[++i]; *x = atoi(v.c_str()); const size_t c = v.find(','); if(c != std::string::npos) *y = atoi(v.c_str() + c + 1); };
+		if(o == "-k") { P.khits = (uint32_t)atoi(opts[++i].c_str()); P.kseeds = P.khits * 2 > 5 ? P.khits * 2 : 5; }
+		else if(o == "--max-seeds") P.kseeds = (uint32_t)atoi(opts[++i].c_str());
+		else if(o == "--secondary") P.secondary = 1;
+		else if(o == "--mp") two(&P.mm_max, &P.mm_min);
+		else if(o == "--sp") { int32_t unused = 0; two(&P.sc_max, &unused); P.sc_min = P.sc_max; }   // both read from the first number (aligner_seed_policy.cpp:438)
+		else if(o == "--no-softclip") P.sc_max = P.sc_min = INT32_MAX;
+		else if(o == "--np") P.n_pen = atoi(opts[++i].c_str());
+		else if(o == "--rdg") two(&P.rdg_const, &P.rdg_linear);
+		else if(o == "--rfg") two(&P.rfg_const, &P.rfg_linear);
+		else if(o == "--score-min") {
+			const std::string& v = opts[++i];
+			P.score_min_type = v[0] == 'C' ? 1 : v[0] == 'L' ? 2 : v[0] == 'S' ? 3 : v[0] == 'G' ? 4 : 0;
+			if(!P.score_min_type) { fprintf(stderr, "Error: bad function type in --score-min %s\n", v.c_str()); return 1; }
+			P.score_min_const = P.score_min_coeff = 0.0;
+			const size_t c1 = v.find(',');
+			if(c1 != std::string::npos) { P.score_min_const = atof(v.c_str() + c1 + 1); const size_t c2 = v.find(',', c1 + 1); if(c2 != std::string::npos) P.score_min_coeff = atof(v.c_str() + c2 + 1); }
+		}
+	}
+	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
+	h2g_sam_set_secondary(sam, (int)P.secondary);
 	FILE* out = outfn.empty() ? stdout : fopen(outfn.c_str(), "wb");
 	if(!out) { fprintf(stderr, "cannot open %s\n", outfn.c_str()); return 1; }
 	std::vector<char> buf(1 << 20);

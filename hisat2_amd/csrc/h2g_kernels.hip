@@ -1173,14 +1173,7 @@ __global__ __launch_bounds__(256) void k_class_scatter(const uint8_t* keys, uint
 
 // `perm` (optional) lists read ids bucketed by the outcome class of the seed stage, so that the 64 lanes of a
 // wave walk similar control flow (k_classify below); results are written by read id, so order is irrelevant.
-extern "C" void h2g_align_params_init(h2g_align_params* p, const h2g_index* ix) {
-	const bool linear = !ix || ix->dg.linear;
-	p->khits = linear ? 5 : 10;                       // hisat2.cpp:3903-3906
-	p->kseeds = p->khits * 2 > 5 ? p->khits * 2 : 5;  // --max-seeds default hisat2.cpp:3174-3176
-	p->no_spliced_alignment = 1;
-	p->secondary = 0;
-	p->bowtie2_dp = 0;                                // hisat2.cpp:529
-}
+extern "C" void h2g_align_params_init(h2g_align_params* p, const h2g_index* ix) { align_params_defaults(p, !ix || ix->dg.linear); }
 
 extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const uint32_t* offs, size_t n) {
 	if(!s || !bytes || !offs || n != s->n_reads || n == 0) return H2G_ERR_ARG;
@@ -1263,11 +1256,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 		HIPCHK(hipMalloc((void**)&s->d_rout, s->max_reads * sizeof(ReadOut)));
 		HIPCHK(hipMalloc((void**)&s->d_aln, s->max_reads * (size_t)H2G_ALN_CAP * sizeof(h2g_alnres)));
 	}
-	AlnParams P;
-	P.khits = p->khits; P.kseeds = p->kseeds; P.no_spliced = 1; P.secondary = p->secondary;
-	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
-	P.pseudogeneStop = 0; P.anchorStop = 1; P.maxFragLen = 1000;
-	P.bowtie2_dp = p->bowtie2_dp;
+	const AlnParams P = aln_params_from(*p, true, s->ix->dg.linear);
 	uint8_t* sw_base = nullptr;
 	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
 	GraphArgs ga;
@@ -1375,11 +1364,7 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 		HIPCHK(hipMalloc((void**)&s->d_pout, s->max_reads * sizeof(PairOut)));
 		for(int m = 0; m < 2; m++) HIPCHK(hipMalloc((void**)&s->d_paln[m], s->max_reads * (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres)));
 	}
-	AlnParams P;
-	P.khits = p->khits; P.kseeds = p->kseeds; P.no_spliced = 1; P.secondary = p->secondary;
-	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
-	P.pseudogeneStop = 0; P.anchorStop = 1; P.maxFragLen = 1000;
-	P.bowtie2_dp = p->bowtie2_dp;
+	const AlnParams P = aln_params_from(*p, true, s->ix->dg.linear);
 	uint8_t* sw_base = nullptr;
 	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
 	GraphArgs ga;

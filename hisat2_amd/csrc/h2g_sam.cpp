@@ -5,6 +5,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <limits.h>
+#include <math.h>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -20,6 +21,9 @@ struct h2g_sam {
 	std::vector<HostAlt>     alts;
 	std::vector<std::string> altnames;
 	int threads = 1;
+	bool secondary = false;                               // --secondary: selectByScore keeps lower-scoring alignments too
+	uint32_t smType = 2;                                  // --score-min (MAPQ's scMin), default L,0,-0.2
+	double smConst = 0.0, smCoeff = (double)(-0.2f);
 };
 
 namespace {
@@ -71,14 +75,18 @@ void read_filters(const Rd& r, bool* lenfilt, bool* nfilt) {
 }
 
 // BowtieMapq2::mapq unique.h:187-403 (end-to-end branch; canMax = false, exhausted = false)
-int mapq_v2(const Summ& s, bool mate1, uint32_t rdlen, uint32_t ordlen) {
+int mapq_v2(const h2g_sam& S, const Summ& s, bool mate1, uint32_t rdlen, uint32_t ordlen) {
 	const int m = mate1 ? 0 : 1;
 	const Score& bst = s.paired ? s.bestPaired : s.best[m];
 	const Score& sec = s.paired ? s.secbestPaired : s.secbest[m];
 	const bool hasSecbest = sec.valid;
 	const bool equalSecbest = hasSecbest && bst.eq(sec);
 	if(!hasSecbest || !equalSecbest) return 60;
-	auto scmin = [](uint32_t len) { int64_t v = (int64_t)(0.0 + (double)(-0.2f) * (double)(float)len); return v; };
+	auto scmin = [&](uint32_t len) {                     // scoreMin_.f<TAlScore>((float)rdlen) simple_func.h:88
+		const double x = (double)(float)len;
+		const double X = S.smType == 2 ? x : S.smType == 3 ? sqrt(x) : S.smType == 4 ? log(x) : 0.0;
+		return (int64_t)(S.smConst + S.smCoeff * X);
+	};
 	int64_t scPer = 0;                                    // monotone scoring: perfect score 0
 	int64_t scMin = scmin(rdlen);
 	if(s.paired) scMin += scmin(ordlen);
@@ -259,7 +267,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	else if(summ.orefid != -1) put(o, summ.orefoff + 1);
 	else o.push_back('0');
 	o.push_back('\t');
-	if(rs) put(o, mapq_v2(summ, fl.pairing == PAIR_UNPAIRED || fl.readMate1(), rd.len, rdo ? rdo->len : 0));
+	if(rs) put(o, mapq_v2(S, summ, fl.pairing == PAIR_UNPAIRED || fl.readMate1(), rd.len, rdo ? rdo->len : 0));
 	else o.push_back('0');
 	o.push_back('\t');
 	if(rs) write_cigar(st, o); else o.push_back('*');
@@ -354,7 +362,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 
 // selectByScore aln_sink.h:2680-2760 on a list of AlnScore keys; RandomSource random_source.h:33
 struct Rng { uint32_t last; uint32_t next() { last = 1664525u * last + 1013904223u; uint32_t r = last >> 16; last = 1664525u * last + 1013904223u; return r ^ last; } };
-void select_by_score(const std::vector<Score>& keys, size_t num, Rng& rnd, std::vector<size_t>& sel) {
+void select_by_score(const std::vector<Score>& keys, size_t num, Rng& rnd, std::vector<size_t>& sel, bool secondary) {
 	sel.clear();
 	const size_t sz = keys.size();
 	if(sz < 1) return;
@@ -378,7 +386,7 @@ void select_by_score(const std::vector<Score>& keys, size_t num, Rng& rnd, std::
 	}
 	if(streak > 1) shuffle(sz - streak, streak);
 	for(size_t i = 0; i < num; i++) sel.push_back(buf[i].second);
-	for(size_t i = 0; i + 1 < sel.size(); i++) if(!buf[i].first.eq(buf[i + 1].first)) { sel.resize(i + 1); break; }   // !secondary
+	if(!secondary) for(size_t i = 0; i + 1 < sel.size(); i++) if(!buf[i].first.eq(buf[i + 1].first)) { sel.resize(i + 1); break; }
 }
 
 void summ_unpaired(Summ& s, int m, const h2g_alnres* lst, size_t n) {   // the rs1u_/rs2u_ loop of AlnSetSumm::init
@@ -449,6 +457,8 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 }  // namespace
 
 extern "C" void h2g_sam_set_threads(h2g_sam* S, int threads) { if(S) S->threads = threads < 1 ? 1 : threads; }
+extern "C" void h2g_sam_set_secondary(h2g_sam* S, int on) { if(S) S->secondary = on != 0; }
+extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, double coeff) { if(S) { S->smType = type; S->smConst = c; S->smCoeff = coeff; } }
 
 extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
                                               const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
@@ -501,13 +511,19 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 			summ.paired = true;
 			summ_unpaired(summ, 0, r1, n1); summ_unpaired(summ, 1, r2, n2);
 			keys.clear();
+			// ReportingState::foundConcordant (aln_sink.cpp:74-112): the count of concordant pairs to report restarts whenever a
+			// pair with a strictly better score sum arrives
+			size_t nconc = 0;
+			int64_t bestsum = INT64_MIN;
 			for(size_t k = 0; k < np; k++) {
 				const Score sc = add(score_of(r1[pr.pair_i[k]]), score_of(r2[pr.pair_j[k]]));
+				if(k == 0 || sc.score > bestsum) { bestsum = sc.score; nconc = 0; }
+				nconc++;
 				keys.push_back(sc);
 				if(sc.gt(summ.bestPaired)) { summ.secbestPaired = summ.bestPaired; summ.bestPaired = sc; }
 				else if(sc.gt(summ.secbestPaired)) summ.secbestPaired = sc;
 			}
-			select_by_score(keys, std::min<size_t>(khits, np), rnd, sel);
+			select_by_score(keys, std::min<size_t>(khits, nconc), rnd, sel, S->secondary);
 			for(size_t q = 0; q < sel.size(); q++) {
 				const h2g_alnres* a = &r1[pr.pair_i[sel[q]]];
 				const h2g_alnres* b = &r2[pr.pair_j[sel[q]]];
@@ -524,7 +540,7 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 			summ_unpaired(summ, 0, r1, n1); summ_unpaired(summ, 1, r2, n2);
 			keys.assign(1, add(score_of(r1[0]), score_of(r2[0])));
 			summ.bestPaired = keys[0];
-			select_by_score(keys, 1, rnd, sel);
+			select_by_score(keys, 1, rnd, sel, S->secondary);
 			f1.pairing = PAIR_DISCORD_M1; f2.pairing = PAIR_DISCORD_M2;
 			f1.oppAligned = f2.oppAligned = true;
 			append_mate(*S, o, rd[0], &rd[1], &r1[0], &r2[0], summ, f1, 1);
@@ -532,8 +548,8 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 		} else {
 			Summ s1, s2;
 			sel1.clear(); sel2.clear();
-			if(n1) { keys.clear(); for(size_t k = 0; k < n1; k++) keys.push_back(score_of(r1[k])); select_by_score(keys, std::min<size_t>(khits, n1), rnd, sel1); }
-			if(n2) { keys.clear(); for(size_t k = 0; k < n2; k++) keys.push_back(score_of(r2[k])); select_by_score(keys, std::min<size_t>(khits, n2), rnd, sel2); }
+			if(n1) { keys.clear(); for(size_t k = 0; k < n1; k++) keys.push_back(score_of(r1[k])); select_by_score(keys, std::min<size_t>(khits, n1), rnd, sel1, S->secondary); }
+			if(n2) { keys.clear(); for(size_t k = 0; k < n2; k++) keys.push_back(score_of(r2[k])); select_by_score(keys, std::min<size_t>(khits, n2), rnd, sel2, S->secondary); }
 			summ_unpaired(s1, 0, r1, n1); summ_unpaired(s1, 1, r2, n2);
 			s2 = s1;
 			const h2g_alnres* p1 = sel1.empty() ? nullptr : &r1[sel1[0]];

@@ -246,6 +246,14 @@ typedef struct {
 	uint32_t bowtie2_dp;           /* --bowtie2-dp: 0 off (default), 1 SwAligner when no alignment reached minsc, 2 always
 	                                * (spliced_aligner.h:209).  Inside go() the DP is run by the read's own lane over
 	                                * ~75 KB of HBM scratch per lane; the batched LDS kernel is h2g_sw_align. */
+	/* scoring scheme (Scoring scoring.h:29-87; option -> SeedAlignmentPolicy::parseString aligner_seed_policy.cpp:294-620) */
+	int32_t  mm_max, mm_min;       /* --mp MX,MN      6,2  (quality-aware mismatch penalty, COST_MODEL_QUAL) */
+	int32_t  n_pen;                /* --np            1 */
+	int32_t  rdg_const, rdg_linear;/* --rdg           5,3 */
+	int32_t  rfg_const, rfg_linear;/* --rfg           5,3 */
+	int32_t  sc_max, sc_min;       /* --sp MX,MN      2,1  (soft-clip penalty); --no-softclip = INT32_MAX,INT32_MAX */
+	uint32_t score_min_type;       /* --score-min <type>,<const>,<coeff>: 1 = C, 2 = L, 3 = S (sqrt), 4 = G (log)   (simple_func.h:30-33) */
+	double   score_min_const, score_min_coeff;   /* default L,0,-0.2 (hisat2.cpp:440) */
 } h2g_align_params;
 H2G_EXPORT void       h2g_align_params_init(h2g_align_params*, const h2g_index*);
 /* read names (needed by genRandSeed): name i = bytes[offs[i] .. offs[i+1]) */

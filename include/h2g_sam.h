@@ -27,6 +27,10 @@ H2G_EXPORT h2g_status h2g_sam_open(const char* index_base, h2g_sam** out);
 H2G_EXPORT void       h2g_sam_close(h2g_sam*);
 /* host threads used by the format calls (contiguous read ranges, output concatenated in read order); default 1 */
 H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
+/* --secondary: the sink's -k selection for pairs keeps lower-scoring alignments (aln_sink.h:2733-2745) */
+H2G_EXPORT void       h2g_sam_set_secondary(h2g_sam*, int on);
+/* --score-min as given to the aligner (h2g_align_params.score_min_*): MAPQ is relative to it (unique.h:214-222) */
+H2G_EXPORT void       h2g_sam_set_score_min(h2g_sam*, uint32_t type, double constant, double coeff);
 
 /* "@HD / @SQ / @PG" header as the reference prints it (sam.h printHeader: VN:1.0 SO:unsorted, one @SQ per reference,
  * @PG ID:hisat2 PN:hisat2 VN:<version> CL:"<cmdline>").  Returns bytes needed; writes at most cap. */

@@ -26,6 +26,8 @@ struct Emu {
 	DLocalSet dls;
 	DAlts dalts;
 	uint32_t bowtie2_dp = 0;
+	bool has_params = false;
+	h2g_align_params params;
 	std::vector<uint8_t> sw;
 	DReads reads() const {
 		DReads r;
@@ -64,6 +66,9 @@ int h2gemu_load(const char* base, Emu** out) {
 }
 
 void h2gemu_set_bowtie2_dp(Emu* e, uint32_t v) { e->bowtie2_dp = v; }
+// full option block (same struct as the C ABI); defaults: h2gemu_default_params
+void h2gemu_default_params(Emu* e, h2g_align_params* p) { align_params_defaults(p, e->dg.linear); }
+void h2gemu_set_params(Emu* e, const h2g_align_params* p) { e->params = *p; e->has_params = true; }
 
 void h2gemu_set_reads(Emu* e, const uint8_t* codes, const uint32_t* offs, const char* quals, size_t n) {
 	e->codes.assign(codes, codes + offs[n]);
@@ -208,11 +213,9 @@ void h2gemu_seed_extend(Emu* e, uint32_t pseudogeneStop, uint32_t khits, h2g_see
 // HI_Aligner::go + selection for every read of the batch (names: '\0'-free bytes + offsets)
 void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, AlnRec* recs) {
 	DReads rd = e->reads();
-	AlnParams P;
-	P.khits = e->dg.linear ? 5 : 10; P.kseeds = P.khits * 2; P.no_spliced = no_spliced; P.secondary = 0;   // hisat2.cpp:3903-3906, 3174
-	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
-	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
-	P.bowtie2_dp = e->bowtie2_dp;
+	h2g_align_params hp;
+	if(e->has_params) hp = e->params; else { align_params_defaults(&hp, e->dg.linear); hp.bowtie2_dp = e->bowtie2_dp; }
+	AlnParams P = aln_params_from(hp, no_spliced != 0, e->dg.linear);
 	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C.sw = e->sw.data();
@@ -233,11 +236,9 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	DReads rd1 = e->reads();
 	DReads rd2 = rd1;
 	rd2.codes = codes2; rd2.offs = offs2; rd2.quals = nullptr;
-	AlnParams P;
-	P.khits = e->dg.linear ? 5 : 10; P.kseeds = P.khits * 2; P.no_spliced = no_spliced; P.secondary = 0;   // hisat2.cpp:3903-3906, 3174
-	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;
-	P.pseudogeneStop = (e->dg.linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
-	P.bowtie2_dp = e->bowtie2_dp;
+	h2g_align_params hp;
+	if(e->has_params) hp = e->params; else { align_params_defaults(&hp, e->dg.linear); hp.bowtie2_dp = e->bowtie2_dp; }
+	AlnParams P = aln_params_from(hp, no_spliced != 0, e->dg.linear);
 	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C.sw = e->sw.data();

@@ -51,10 +51,17 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
     refnames, want = SU.parse_sam(sam)
     qnames = [str(i) for i in range(nreads)]
     if backend is None:
-        outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames, bowtie2_dp=bowtie2_dp, quals=None if quals is None else quals.reshape(-1))
+        outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames, bowtie2_dp=bowtie2_dp, quals=None if quals is None else quals.reshape(-1),
+                               options=[x for x in extra if not (x == "--bowtie2-dp" or x == str(bowtie2_dp) and "--bowtie2-dp" in extra)])
         got = SU.render(outs, recs, refnames, [reads[i] for i in range(nreads)], qnames)
     else:   # backend(base, reads, qnames) -> (outs with .overflow/.depth, rendered dict)
-        outs, got = backend(base, reads, qnames, refnames) if quals is None else backend(base, reads, qnames, refnames, quals=quals.reshape(-1))
+        kw = {}
+        if quals is not None:
+            kw["quals"] = quals.reshape(-1)
+        opts = [x for x in extra if not (x == "--bowtie2-dp" or x == str(bowtie2_dp) and "--bowtie2-dp" in extra)]
+        if opts:
+            kw["options"] = opts
+        outs, got = backend(base, reads, qnames, refnames, **kw)
     bad = ovf = setbad = 0
     maxdep = 0
     for i, q in enumerate(qnames):

@@ -21,6 +21,7 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 
 
 DP = int(os.environ.get("H2G_FUZZ_DP", "0"))   # --bowtie2-dp for both sides
+OPTS = ()   # extra reference command-line options (scoring / reporting), applied to both sides
 SNPS = int(os.environ.get("H2G_FUZZ_SNPS", "0"))   # > 0: graph index with a seeded variant every ~SNPS bp, pairs from the alt haplotype
 
 
@@ -28,6 +29,9 @@ def emu_pairs(base, m1, m2, q1, q2):
     e = Emu(base)
     e.L.h2gemu_set_bowtie2_dp.argtypes = [C.c_void_p, C.c_uint32]
     e.L.h2gemu_set_bowtie2_dp(e.h, DP)
+    if OPTS:
+        from h2gemu_align import set_options
+        set_options(e, DP, OPTS)
     n, L = m1.shape
     c1, o1 = synth.flatten_reads(m1)
     c2, o2 = synth.flatten_reads(m2)
@@ -99,15 +103,17 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)
     sam = os.path.join(tmp, "ref.sam")
-    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam] + (["--bowtie2-dp", str(DP)] if DP else []),
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam] + (["--bowtie2-dp", str(DP)] if DP else []) + list(OPTS),
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refnames, want = parse_pe_sam(sam)
+    khits = int(OPTS[OPTS.index("-k") + 1]) if "-k" in OPTS else (10 if SNPS else 5)
+    secondary = "--secondary" in OPTS
     q = [str(i) for i in range(npairs)]
     outs, r1, r2 = (backend or emu_pairs)(base, m1, m2, q, q)
     bad = ovf = setbad = 0
     ncon = 0
     for i in range(npairs):
-        got = PS.finish_pair(outs[i], r1, r2, i * (stride if backend else SU.AL_MAX_RESULTS), refnames, (m1[i], m2[i]))
+        got = PS.finish_pair(outs[i], r1, r2, i * (stride if backend else SU.AL_MAX_RESULTS), refnames, (m1[i], m2[i]), khits=khits, secondary=secondary)
         w = want[q[i]]
         ncon += 1 if (w[0][0] & 2) else 0
         ovf += 1 if outs[i].overflow else 0

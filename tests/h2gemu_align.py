@@ -7,8 +7,24 @@ import sam_util as SU
 from h2gemu_py import Emu
 
 
-def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0, quals=None):
+def set_options(e, bowtie2_dp, options):
+    """reference command-line options -> the emulator's h2g_align_params block"""
+    from hisat2_amd import api
+    p = api.AlignParams()
+    e.L.h2gemu_default_params.argtypes = [C.c_void_p, C.c_void_p]
+    e.L.h2gemu_set_params.argtypes = [C.c_void_p, C.c_void_p]
+    e.L.h2gemu_default_params(e.h, C.byref(p))
+    p.bowtie2_dp = bowtie2_dp
+    rest = p.apply_options(list(options))
+    assert not rest, rest
+    e.L.h2gemu_set_params(e.h, C.byref(p))
+    return p
+
+
+def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0, quals=None, options=()):
     e = Emu(base)
+    if options:
+        set_options(e, bowtie2_dp, options)
     e.L.h2gemu_set_bowtie2_dp.argtypes = [C.c_void_p, C.c_uint32]
     e.L.h2gemu_set_bowtie2_dp(e.h, bowtie2_dp)
     codes = np.concatenate(reads_list).astype(np.uint8)

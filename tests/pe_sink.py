@@ -72,7 +72,7 @@ def select_by_score(keys, num, rnd, secondary=False):
     return sel
 
 
-def finish_pair(out, recs1, recs2, base, names, rdlens, khits=5):
+def finish_pair(out, recs1, recs2, base, names, rdlens, khits=5, secondary=False):
     """-> list of (flag, rname, pos, cigar, AS) in the order the reference prints the lines of this pair."""
     r1 = [recs1[base + k] for k in range(out.nres[0])]
     r2 = [recs2[base + k] for k in range(out.nres[1])]
@@ -102,7 +102,7 @@ def finish_pair(out, recs1, recs2, base, names, rdlens, khits=5):
         return (fl, names[rec.tidx], rec.toff + 1, SU.cigar_of(rec, rdlen), int(rec.score))
     if nconc > 0:
         keys = [hisat2_score(r1[i]) + hisat2_score(r2[j]) for i, j in pairs]
-        sel = select_by_score(keys, min(khits, nconc), rnd)
+        sel = select_by_score(keys, min(khits, nconc), rnd, secondary)
         for n, k in enumerate(sel):
             i, j = pairs[k]
             lines.append(line(r1[i], 0, rdlens[0], r2[j], True, n == 0, True))
@@ -110,12 +110,12 @@ def finish_pair(out, recs1, recs2, base, names, rdlens, khits=5):
         return lines
     n1, n2 = len(r1), len(r2)
     if n1 == 1 and n2 == 1:   # finish(): convertUnpairedToDiscordant; prepareDiscordants aln_sink.h:2660
-        select_by_score([hisat2_score(r1[0]) + hisat2_score(r2[0])], 1, rnd)
+        select_by_score([hisat2_score(r1[0]) + hisat2_score(r2[0])], 1, rnd, secondary)
         lines.append(line(r1[0], 0, rdlens[0], r2[0], False, True, True))
         lines.append(line(r2[0], 1, rdlens[1], r1[0], False, True, True))
         return lines
-    sel1 = select_by_score([hisat2_score(x) for x in r1], min(khits, n1), rnd) if n1 else []
-    sel2 = select_by_score([hisat2_score(x) for x in r2], min(khits, n2), rnd) if n2 else []
+    sel1 = select_by_score([hisat2_score(x) for x in r1], min(khits, n1), rnd, secondary) if n1 else []
+    sel2 = select_by_score([hisat2_score(x) for x in r2], min(khits, n2), rnd, secondary) if n2 else []
     p1 = r1[sel1[0]] if sel1 else None
     p2 = r2[sel2[0]] if sel2 else None
     if p1 is not None and p2 is not None:

@@ -20,6 +20,7 @@ def load_sam_lib(path=None):
                                                                              C.POINTER(C.c_size_t)]
     L.h2g_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     L.h2g_sam_header.restype = C.c_size_t
+    L.h2g_sam_set_score_min.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
     return L
 
 
@@ -35,10 +36,21 @@ def flat_names(names):
     return nb, noffs
 
 
-def format_unpaired(L, base, reads, names, res, aln, quals=None):
+def _score_min(L, h, options):
+    if options and "--score-min" in options:
+        p = api.AlignParams()
+        p.apply_options(list(options))
+        L.h2g_sam_set_score_min(h, p.score_min_type, p.score_min_const, p.score_min_coeff)
+    if options and "--secondary" in options:
+        L.h2g_sam_set_secondary.argtypes = [C.c_void_p, C.c_int]
+        L.h2g_sam_set_secondary(h, 1)
+
+
+def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):
     """res: array of api.ReadResult (or same-layout numpy), aln: api.AlnRes * (n*ALN_CAP) -> list of SAM lines"""
     h = C.c_void_p()
     assert L.h2g_sam_open(base.encode(), C.byref(h)) == 0
+    _score_min(L, h, options)
     codes, offs = flat(reads)
     nb, noffs = flat_names(names)
     n = len(reads)
@@ -57,9 +69,10 @@ def format_unpaired(L, base, reads, names, res, aln, quals=None):
     return buf.raw[:used.value].decode().splitlines()
 
 
-def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits):
+def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=()):
     h = C.c_void_p()
     assert L.h2g_sam_open(base.encode(), C.byref(h)) == 0
+    _score_min(L, h, options)
     c1, o1 = flat(m1)
     c2, o2 = flat(m2)
     nb1, no1 = flat_names(n1)

@@ -41,6 +41,12 @@ def test_golden_sam(g1_index, golden_dir):
     dict(seed=924, nreads=3000, rdlen=250, sub=0.01, indel=0.002, nrate=0.001, snps=100),
     # SwAligner pass on a graph index: replace_edits_with_alts (spliced_aligner.h:282)
     dict(seed=925, nreads=4000, rdlen=101, sub=0.02, indel=0.006, nrate=0.001, snps=50, extra=("--bowtie2-dp", "2"), bowtie2_dp=2),
+    # the option surface of h2g_align_params: -k / --secondary / --mp / --np / --rdg / --rfg / --sp / --no-softclip / --score-min,
+    # with FASTQ qualities so that the quality-aware penalties differ per base
+    dict(seed=961, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, fastq=True, extra=("-k", "3", "--mp", "4,2", "--np", "3")),
+    dict(seed=962, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, fastq=True, extra=("--rdg", "4,2", "--rfg", "7,2", "--score-min", "L,0,-0.4")),
+    dict(seed=963, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, fastq=True, extra=("--secondary", "--sp", "3,1", "--score-min", "C,-18")),
+    dict(seed=964, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, snps=60, extra=("--no-softclip", "-k", "4", "--mp", "5,1")),
 ])
 def test_live_reference(case):
     """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def gpu_align(base, reads, qnames, bowtie2_dp=0, quals=None):
+def gpu_align(base, reads, qnames, bowtie2_dp=0, quals=None, options=()):
     """reads: (n, L) uint8 array or list of arrays"""
     lst = [np.asarray(r, dtype=np.uint8) for r in reads]
     codes = np.concatenate(lst)
@@ -24,6 +24,8 @@ def gpu_align(base, reads, qnames, bowtie2_dp=0, quals=None):
     st.set_read_names(qnames)
     p = st.align_params()
     p.bowtie2_dp = bowtie2_dp
+    rest = p.apply_options(list(options))
+    assert not rest, rest
     st.align_run(p)
     res, aln = st.align_fetch()
     c = st.counters()
@@ -49,8 +51,8 @@ class _Out:
         self.overflow, self.depth = int(r["overflow"]), int(r["depth"])
 
 
-def _backend(base, reads, qnames, refnames, bowtie2_dp=0, quals=None):
-    res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames, bowtie2_dp=bowtie2_dp, quals=quals)
+def _backend(base, reads, qnames, refnames, bowtie2_dp=0, quals=None, options=()):
+    res, aln, _ = gpu_align(base, [reads[i] for i in range(len(reads))], qnames, bowtie2_dp=bowtie2_dp, quals=quals, options=options)
     got = SU.render_selected(res, aln, refnames, [reads[i] for i in range(len(reads))], qnames)
     return [_Out(r) for r in res], got
 

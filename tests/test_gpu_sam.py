@@ -22,6 +22,8 @@ needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "
     dict(seed=402, nreads=8000, rdlen=101, sub=0.004, indel=0.0, nrate=0.0, lens=(120000,), repeats=300, gaps=0),
     dict(seed=403, nreads=20000, rdlen=101, sub=0.02, indel=0.003, nrate=0.0, snps=80),
     dict(seed=404, nreads=10000, rdlen=101, sub=0.02, indel=0.003, nrate=0.003, fastq=True),
+    dict(seed=405, nreads=10000, rdlen=101, sub=0.03, indel=0.004, nrate=0.001, fastq=True, extra=("--score-min", "L,0,-0.4", "--mp", "4,2", "-k", "3", "--rdg", "4,2")),
+    dict(seed=406, nreads=8000, rdlen=101, sub=0.02, indel=0.003, nrate=0.001, snps=70, extra=("--secondary", "--no-softclip", "--np", "2")),
 ])
 def test_unpaired_sam_text(case):
     """device alignments -> h2g_sam_format_unpaired == the reference's lines; then the same through the command line"""
@@ -34,14 +36,15 @@ def test_unpaired_sam_text(case):
     if case.get("fastq"):
         lines = open(os.path.join(tmp, "r.fq"), "rb").read().split(b"\n")
         quals = np.frombuffer(b"".join(lines[3::4]), dtype=np.uint8)
-    res, aln, _ = gpu_align(os.path.join(tmp, "g"), reads, names, quals=quals)
+    opts = list(case.get("extra", ()))
+    res, aln, _ = gpu_align(os.path.join(tmp, "g"), reads, names, quals=quals, options=opts)
     want = SL.body_lines(os.path.join(tmp, "ref.sam"))
-    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, quals=quals)
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, quals=quals, options=opts)
     assert diff_lines(got, want) == 0
     out = os.path.join(tmp, "amd.sam")
     rd = os.path.join(tmp, "r.fq" if case.get("fastq") else "r.fa")
     subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-q" if case.get("fastq") else "-f", "-U", rd, "--no-spliced-alignment", "-S", out,
-                    "--batch", "7000", "-p", "5"], check=True)
+                    "--batch", "7000", "-p", "5"] + opts, check=True)
     assert diff_lines(SL.body_lines(out), want) == 0
     hdr = [l for l in open(out) if l.startswith("@")]
     ref_hdr = [l for l in open(os.path.join(tmp, "ref.sam")) if l.startswith("@")]

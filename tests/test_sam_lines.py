@@ -43,6 +43,9 @@ def diff_lines(got, want, show=4):
     dict(seed=303, nreads=4000, rdlen=101, sub=0.02, indel=0.003, nrate=0.0, snps=80),                             # graph index: Zs:Z, XM/NM without variants
     dict(seed=304, nreads=2000, rdlen=150, sub=0.01, indel=0.004, nrate=0.001, snps=40),
     dict(seed=305, nreads=4000, rdlen=101, sub=0.02, indel=0.003, nrate=0.003, fastq=True),                        # FASTQ: quality-dependent penalties, QUAL column
+    # scoring / reporting options: MAPQ is relative to --score-min, NH / secondary lines follow -k and --secondary
+    dict(seed=306, nreads=3000, rdlen=101, sub=0.03, indel=0.004, nrate=0.001, fastq=True, extra=("--score-min", "L,0,-0.4", "--mp", "4,2", "-k", "3")),
+    dict(seed=307, nreads=3000, rdlen=101, sub=0.004, indel=0.0, nrate=0.0, lens=(120000,), repeats=300, gaps=0, extra=("--secondary", "--rdg", "4,2", "--no-softclip")),
 ])
 def test_unpaired_lines_identical(case):
     import fuzz_align as F
@@ -55,9 +58,10 @@ def test_unpaired_lines_identical(case):
     if case.get("fastq"):
         lines = open(os.path.join(tmp, "r.fq"), "rb").read().split(b"\n")
         quals = np.frombuffer(b"".join(lines[3::4]), dtype=np.uint8)
-    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, quals=quals)
+    opts = case.get("extra", ())
+    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, quals=quals, options=opts)
     res, aln = SL.emu_to_abi(outs, recs)
-    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, quals=quals)
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, quals=quals, options=opts)
     want = SL.body_lines(os.path.join(tmp, "ref.sam"))
     assert len(want) >= case["nreads"]
     assert diff_lines(got, want) == 0
@@ -70,10 +74,15 @@ def test_unpaired_lines_identical(case):
     (60, dict(seed=313, npairs=2000, rdlen=101, sub=0.02)),
     (0, dict(seed=314, npairs=1500, rdlen=101, sub=0.01, mutate="flip")),                 # every 4th mate 2 reverse-complemented: YT:Z:DP
     (0, dict(seed=315, npairs=3000, rdlen=101, sub=0.03, repeats=60, mutate="nmask")),    # N-filtered mates: YF:Z:NS + lone-mate paths
+    (0, dict(seed=316, npairs=2500, rdlen=101, sub=0.025, opts=("-k", "2", "--mp", "5,3", "--score-min", "L,0,-0.35"))),
+    (0, dict(seed=317, npairs=2500, rdlen=101, sub=0.025, repeats=80, mutate="nmask", opts=("--secondary",))),
 ])
 def test_paired_lines_identical(monkeypatch, snps, case):
     import fuzz_pairs as F
     monkeypatch.setattr(F, "SNPS", snps)
+    case = dict(case)
+    opts = case.pop("opts", ())
+    monkeypatch.setattr(F, "OPTS", opts)
     bad, tmp = F.run_case(verbose=2, **case)
     assert bad == 0
     n1, m1 = read_fa(os.path.join(tmp, "r1.fa"))
@@ -89,7 +98,7 @@ def test_paired_lines_identical(monkeypatch, snps, case):
         for m, (src, dst) in enumerate(((r1, a1), (r2, a2))):
             for k in range(min(outs[i].nres[m], api.PAIR_RES_CAP)):
                 C.memmove(C.byref(dst[i * api.PAIR_RES_CAP + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
-    khits = 10 if snps else 5
-    got = SL.format_paired(SL.load_sam_lib(), os.path.join(tmp, "g"), m1, m2, n1, n2, res, a1, a2, khits)
+    khits = int(opts[opts.index("-k") + 1]) if "-k" in opts else (10 if snps else 5)
+    got = SL.format_paired(SL.load_sam_lib(), os.path.join(tmp, "g"), m1, m2, n1, n2, res, a1, a2, khits, options=opts)
     want = SL.body_lines(os.path.join(tmp, "ref.sam"))
     assert diff_lines(got, want) == 0
