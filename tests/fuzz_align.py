@@ -52,13 +52,13 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
     qnames = [str(i) for i in range(nreads)]
     if backend is None:
         outs, recs = emu_align(base, [reads[i] for i in range(nreads)], qnames, bowtie2_dp=bowtie2_dp, quals=None if quals is None else quals.reshape(-1),
-                               options=[x for x in extra if not (x == "--bowtie2-dp" or x == str(bowtie2_dp) and "--bowtie2-dp" in extra)])
+                               options=list(extra))
         got = SU.render(outs, recs, refnames, [reads[i] for i in range(nreads)], qnames)
     else:   # backend(base, reads, qnames) -> (outs with .overflow/.depth, rendered dict)
         kw = {}
         if quals is not None:
             kw["quals"] = quals.reshape(-1)
-        opts = [x for x in extra if not (x == "--bowtie2-dp" or x == str(bowtie2_dp) and "--bowtie2-dp" in extra)]
+        opts = list(extra)
         if opts:
             kw["options"] = opts
         outs, got = backend(base, reads, qnames, refnames, **kw)
