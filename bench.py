@@ -114,7 +114,8 @@ def cpu_reference(base, reads, sample, nver):
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         mine = os.path.join(tmp, "amd.sam")
         t0 = time.perf_counter()
-        r = subprocess.run([cli, "-f", "--no-spliced-alignment", "-p", "16", "-x", base, "-U", fa, "-S", mine], capture_output=True, text=True)
+        r = subprocess.run([cli, "-f", "--no-spliced-alignment", "-p", "16", "-x", base, "-U", fa, "-S", mine], capture_output=True, text=True,
+                           env=dict(os.environ, H2G_CLI_TIMING="1"))
         t_cli = time.perf_counter() - t0
         if r.returncode == 0:
             a = [l for l in open(mine) if not l.startswith("@")]

@@ -157,6 +157,13 @@ class AlignParams(C.Structure):
                 self.kseeds = int(v); i += 2
             elif o == "--secondary":
                 self.secondary = 1; i += 1
+            elif o == "--sensitive":   # hisat2.cpp:1892-1901: SwAligner when nothing reached minsc, -k >= 10, --score-min L,0,-0.5
+                if self.bowtie2_dp == 0:
+                    self.bowtie2_dp = 1
+                if self.khits < 10:
+                    self.khits = 10; self.kseeds = 20
+                self.score_min_type, self.score_min_const, self.score_min_coeff = 2, 0.0, -0.5
+                i += 1
             elif o == "--bowtie2-dp":
                 self.bowtie2_dp = int(v); i += 2
             elif o == "--mp":

@@ -16,6 +16,7 @@
 #include <unistd.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <zlib.h>
 #include "../../include/h2g.h"
 #include "../../include/h2g_sam.h"
 
@@ -76,20 +77,33 @@ public:
 	}
 private:
 	size_t nrec() const { return starts_.empty() ? 0 : starts_.size() - 1; }
-	void unmap() { if(p_) { munmap((void*)p_, n_); p_ = nullptr; n_ = 0; } starts_.clear(); cur_ = 0; }
+	void unmap() { if(p_ && !inflated_.empty()) { inflated_.clear(); inflated_.shrink_to_fit(); } else if(p_) munmap((void*)p_, n_); p_ = nullptr; n_ = 0; starts_.clear(); cur_ = 0; }
 	bool next_file() {
 		unmap();
 		if(fi_ >= files_.size()) return false;
 		const std::string& fn = files_[fi_++];
-		const int fd = open(fn.c_str(), O_RDONLY);
-		if(fd < 0) { fprintf(stderr, "Error: could not open %s\n", fn.c_str()); exit(1); }
-		struct stat sb;
-		fstat(fd, &sb);
-		n_ = (size_t)sb.st_size;
-		if(n_ == 0) { close(fd); return true; }
-		p_ = (const char*)mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd, 0);
-		close(fd);
-		if(p_ == MAP_FAILED) { fprintf(stderr, "Error: could not map %s\n", fn.c_str()); exit(1); }
+		if(fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0) {     // gzipped input (the reference reads it through zlib too)
+			gzFile g = gzopen(fn.c_str(), "rb");
+			if(!g) { fprintf(stderr, "Error: could not open %s\n", fn.c_str()); exit(1); }
+			gzbuffer(g, 1 << 20);
+			inflated_.clear();
+			std::vector<char> chunk(8 << 20);
+			int got;
+			while((got = gzread(g, chunk.data(), (unsigned)chunk.size())) > 0) inflated_.insert(inflated_.end(), chunk.begin(), chunk.begin() + got);
+			gzclose(g);
+			if(inflated_.empty()) return true;
+			p_ = inflated_.data(); n_ = inflated_.size();
+		} else {
+			const int fd = open(fn.c_str(), O_RDONLY);
+			if(fd < 0) { fprintf(stderr, "Error: could not open %s\n", fn.c_str()); exit(1); }
+			struct stat sb;
+			fstat(fd, &sb);
+			n_ = (size_t)sb.st_size;
+			if(n_ == 0) { close(fd); return true; }
+			p_ = (const char*)mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd, 0);
+			close(fd);
+			if(p_ == MAP_FAILED) { fprintf(stderr, "Error: could not map %s\n", fn.c_str()); exit(1); }
+		}
 		const size_t T = std::min<size_t>((size_t)T_, n_ / (1 << 20) + 1);
 		std::vector<std::vector<size_t> > loc(T);
 		std::vector<size_t> nl(T + 1, 0);
@@ -161,6 +175,7 @@ private:
 	const char* p_ = nullptr;
 	size_t n_ = 0, cur_ = 0;
 	std::vector<size_t> starts_;
+	std::vector<char> inflated_;
 	uint64_t count_ = 0;
 };
 
@@ -202,7 +217,7 @@ int main(int argc, char** argv) {
 		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min") {
 			opts.push_back(a); opts.push_back(need(a.c_str()));
 		}
-		else if(a == "--secondary" || a == "--no-softclip") opts.push_back(a);
+		else if(a == "--secondary" || a == "--no-softclip" || a == "--sensitive") opts.push_back(a);
 		else if(a == "--no-hd" || a == "--no-head") nohead = true;
 		else if(a == "--batch") batch = (size_t)atoll(need("--batch"));
 		else if(a == "--device") device = atoi(need("--device"));
@@ -245,6 +260,11 @@ int main(int argc, char** argv) {
 		if(o == "-k") { P.khits = (uint32_t)atoi(opts[++i].c_str()); P.kseeds = P.khits * 2 > 5 ? P.khits * 2 : 5; }
 		else if(o == "--max-seeds") P.kseeds = (uint32_t)atoi(opts[++i].c_str());
 		else if(o == "--secondary") P.secondary = 1;
+		else if(o == "--sensitive") {                       // hisat2.cpp:1892-1901
+			if(P.bowtie2_dp == 0) P.bowtie2_dp = 1;
+			if(P.khits < 10) { P.khits = 10; P.kseeds = 20; }
+			P.score_min_type = 2; P.score_min_const = 0.0; P.score_min_coeff = -0.5;
+		}
 		else if(o == "--mp") two(&P.mm_max, &P.mm_min);
 		else if(o == "--sp") { int32_t unused = 0; two(&P.sc_max, &unused); P.sc_min = P.sc_max; }   // both read from the first number (aligner_seed_policy.cpp:438)
 		else if(o == "--no-softclip") P.sc_max = P.sc_min = INT32_MAX;
@@ -354,11 +374,16 @@ int main(int argc, char** argv) {
 	}
 	if(out != stdout) fclose(out);
 	const double t2 = now();
-	fprintf(stderr, "%llu %s; %llu %s (%.2f%%)\n", (unsigned long long)nreads, paired ? "pairs" : "reads", (unsigned long long)naligned,
-	        paired ? "aligned concordantly at least once" : "aligned", nreads ? 100.0 * naligned / nreads : 0.0);
+	{   // the reference's alignment summary (aln_sink.h:1637), same text
+		const size_t need = h2g_sam_summary(sam, nullptr, 0);
+		std::vector<char> sb(need + 1);
+		h2g_sam_summary(sam, sb.data(), need);
+		fwrite(sb.data(), 1, need, stderr);
+	}
+	(void)naligned; (void)nreads;
 	if(novf) fprintf(stderr, "Warning: %llu %s exceeded a fixed device capacity (h2g overflow bit); rerun them with the reference aligner\n",
 	                 (unsigned long long)novf, paired ? "pairs" : "reads");
-	fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (includes overlapped parsing %.2f s), SAM formatting %.2f s, total %.2f s\n", t1 - t0, t_gpu,
+	if(getenv("H2G_CLI_TIMING")) fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (includes overlapped parsing %.2f s), SAM formatting %.2f s, total %.2f s\n", t1 - t0, t_gpu,
 	        t_parse, t_fmt, t2 - t0);
 	if(st) h2g_stream_free(st);
 	h2g_sam_close(sam);

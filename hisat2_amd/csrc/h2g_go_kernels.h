@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref,
 }
 
 // lane = one read pair; both mates are packed into LDS (mate 2 behind mate 1)
-template <bool GRAPH>
+template <bool GRAPH, int WIDE = 0>   // WIDE only tags the linear build with AL_MAX_GHITS = 20 (-k up to 10, --sensitive)
 __global__ __launch_bounds__(256, GRAPH ? 2 : 3) void k_align_pairs(DGfm g, DRef ref, DLocalSet ls, DReads rd1, DReads rd2, AlnParams P,
                                                         const char* names1, const uint32_t* noffs1, const char* names2,
                                                         const uint32_t* noffs2, AlignWS* pool, PairOut* outs, h2g_alnres* aln1,
@@ -148,6 +148,10 @@ extern template __global__ void k_align<2, true>(DGfm, DRef, DLocalSet, DReads, 
                                                  unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
 extern template __global__ void k_align_pairs<false>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
                                                      const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);
+extern template __global__ void k_align<3, false>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
+                                                  unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
+extern template __global__ void k_align_pairs<false, 1>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
+                                                        const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);
 extern template __global__ void k_align_pairs<true>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
                                                     const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);
 #endif

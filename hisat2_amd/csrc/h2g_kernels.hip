@@ -19,8 +19,10 @@
 // AlignWS is opaque on this side: each go() unit reports the size of its own layout
 extern "C" size_t h2g_ws_bytes_linear_se(); extern "C" size_t h2g_ws_bytes_linear_pe();
 extern "C" size_t h2g_ws_bytes_graph_se();  extern "C" size_t h2g_ws_bytes_graph_pe();
+extern "C" size_t h2g_ws_bytes_linear_wide_se(); extern "C" size_t h2g_ws_bytes_linear_wide_pe();
 static size_t ws_bytes_per_lane(bool linear) {
-	const size_t a = linear ? h2g_ws_bytes_linear_se() : h2g_ws_bytes_graph_se(), b = linear ? h2g_ws_bytes_linear_pe() : h2g_ws_bytes_graph_pe();
+	size_t a = linear ? h2g_ws_bytes_linear_se() : h2g_ws_bytes_graph_se(), b = linear ? h2g_ws_bytes_linear_pe() : h2g_ws_bytes_graph_pe();
+	if(linear) { a = std::max(a, h2g_ws_bytes_linear_wide_se()); b = std::max(b, h2g_ws_bytes_linear_wide_pe()); }   // either linear build may run
 	return a > b ? a : b;
 }
 
@@ -1239,7 +1241,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names) { snprintf(g_err, sizeof g_err, "align: read names not set (h2g_set_read_names)"); return H2G_ERR_ARG; }
 	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
-	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > (s->ix->dg.linear ? 10u : 20u) || p->kseeds < p->khits) return H2G_ERR_ARG;
+	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > 20u || p->kseeds < p->khits) return H2G_ERR_ARG;
 	HIPCHK(hipSetDevice(s->ix->device));
 	// 2 waves per SIMD on every CU: enough lanes to cover HBM latency, bounded workspace (sizeof(AlignWS) each)
 	const unsigned block = 256;
@@ -1289,6 +1291,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 #define H2G_LAUNCH_ALIGN(W, G) hipLaunchKernelGGL((k_align<W, G>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, \
 		s->d_names, s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride, ga)
 	if(!s->ix->dg.linear) H2G_LAUNCH_ALIGN(2, true);        // graph: the out-of-line graph functions need ~230 VGPRs
+	else if(p->kseeds > 10) H2G_LAUNCH_ALIGN(3, false);     // linear, wide genome-hit list (-k > 5, --sensitive)
 	else H2G_LAUNCH_ALIGN(4, false);
 #undef H2G_LAUNCH_ALIGN
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
@@ -1348,7 +1351,7 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names || !s->has_mates) { snprintf(g_err, sizeof g_err, "align_pairs: names (h2g_set_read_names) and mates (h2g_set_mates) required"); return H2G_ERR_ARG; }
 	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
-	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > (s->ix->dg.linear ? 10u : 20u) || p->kseeds < p->khits) return H2G_ERR_ARG;
+	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > 20u || p->kseeds < p->khits) return H2G_ERR_ARG;
 	HIPCHK(hipSetDevice(s->ix->device));
 	const unsigned block = 256;
 	size_t want = (s->n_reads + block - 1) / block;
@@ -1375,7 +1378,10 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
-	if(s->ix->dg.linear)
+	if(s->ix->dg.linear && p->kseeds > 10)
+		hipLaunchKernelGGL((k_align_pairs<false, 1>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
+		                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride, ga);
+	else if(s->ix->dg.linear)
 		hipLaunchKernelGGL((k_align_pairs<false>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
 		                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride, ga);
 	else

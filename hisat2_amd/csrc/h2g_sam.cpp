@@ -15,7 +15,17 @@
 
 using namespace h2g;
 
+struct Met {            // ReportingMetrics (aln_sink.h:51-160), the counters printAlSumm reads
+	uint64_t nread = 0, npaired = 0, nunpaired = 0, nconcord_0 = 0, nconcord_uni1 = 0, nconcord_uni2 = 0, ndiscord = 0;
+	uint64_t nunp_0_0 = 0, nunp_0_uni1 = 0, nunp_0_uni2 = 0, nunp_0 = 0, nunp_uni1 = 0, nunp_uni2 = 0;
+	void add(const Met& o) {
+		nread += o.nread; npaired += o.npaired; nunpaired += o.nunpaired; nconcord_0 += o.nconcord_0; nconcord_uni1 += o.nconcord_uni1;
+		nconcord_uni2 += o.nconcord_uni2; ndiscord += o.ndiscord; nunp_0_0 += o.nunp_0_0; nunp_0_uni1 += o.nunp_0_uni1; nunp_0_uni2 += o.nunp_0_uni2;
+		nunp_0 += o.nunp_0; nunp_uni1 += o.nunp_uni1; nunp_uni2 += o.nunp_uni2;
+	}
+};
 struct h2g_sam {
+	mutable Met met;                                      // summed over every format call (single caller thread)
 	std::vector<std::string> refnames;
 	std::vector<uint32_t>    reflens;
 	std::vector<HostAlt>     alts;
@@ -433,11 +443,12 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 	size_t T = S->threads < 1 ? 1 : (size_t)S->threads;
 	if(T > n / 2048 + 1) T = n / 2048 + 1;
 	std::vector<std::string> parts(T);
+	std::vector<Met> mets(T);
 	auto work = [&](size_t t) {
 		const size_t b = n * t / T, e = n * (t + 1) / T;
 		std::string& o = parts[t];
 		o.reserve((e - b) * 420);
-		for(size_t i = b; i < e; i++) one(i, o);
+		for(size_t i = b; i < e; i++) one(i, o, mets[t]);
 	};
 	if(T == 1) work(0);
 	else {
@@ -450,6 +461,7 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 	for(auto& p : parts) total += p.size();
 	*used = total;
 	if(total > cap || !out) return total <= cap && total == 0 ? H2G_OK : H2G_ERR_ARG;
+	for(auto& m : mets) S->met.add(m);                    // only a call that delivered its text counts
 	size_t off = 0;
 	for(auto& p : parts) { memcpy(out + off, p.data(), p.size()); off += p.size(); }
 	return H2G_OK;
@@ -457,6 +469,41 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 }  // namespace
 
 extern "C" void h2g_sam_set_threads(h2g_sam* S, int threads) { if(S) S->threads = threads < 1 ? 1 : threads; }
+// AlnSink::printAlSumm aln_sink.h:1637-1815 (old-style summary, -k mode: no repeat threshold, discordant + mixed reporting on)
+extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
+	if(!S) return 0;
+	const Met& m = S->met;
+	std::string o;
+	char b[64];
+	auto pct = [&](uint64_t num, uint64_t den) { snprintf(b, sizeof b, "%.2f%%", den ? 100.0 * (double)num / (double)den : 0.0); o += b; };
+	auto line = [&](const char* ind, uint64_t v, uint64_t den, const char* txt) { o += ind; o += std::to_string(v); o += " ("; pct(v, den); o += ") "; o += txt; o += "\n"; };
+	const uint64_t tot_al_cand = m.nunpaired + m.npaired * 2;
+	const uint64_t tot_al = (m.nconcord_uni1 + m.nconcord_uni2) * 2 + m.ndiscord * 2 + m.nunp_0_uni1 + m.nunp_0_uni2 + m.nunp_uni1 + m.nunp_uni2;
+	o += std::to_string(m.nread); o += m.nread ? " reads; of these:\n" : " reads\n";
+	if(m.npaired > 0) {
+		line("  ", m.npaired, m.nread, "were paired; of these:");
+		line("    ", m.nconcord_0, m.npaired, "aligned concordantly 0 times");
+		line("    ", m.nconcord_uni1, m.npaired, "aligned concordantly exactly 1 time");
+		line("    ", m.nconcord_uni2, m.npaired, "aligned concordantly >1 times");
+		o += "    ----\n    "; o += std::to_string(m.nconcord_0); o += " pairs aligned concordantly 0 times; of these:\n";
+		line("      ", m.ndiscord, m.nconcord_0, "aligned discordantly 1 time");
+		const uint64_t n0 = m.nconcord_0 - m.ndiscord;
+		o += "    ----\n    "; o += std::to_string(n0); o += " pairs aligned 0 times concordantly or discordantly; of these:\n";
+		o += "      "; o += std::to_string(n0 * 2); o += " mates make up the pairs; of these:\n";
+		line("        ", m.nunp_0_0, n0 * 2, "aligned 0 times");
+		line("        ", m.nunp_0_uni1, n0 * 2, "aligned exactly 1 time");
+		line("        ", m.nunp_0_uni2, n0 * 2, "aligned >1 times");
+	}
+	if(m.nunpaired > 0) {
+		line("  ", m.nunpaired, m.nread, "were unpaired; of these:");
+		line("    ", m.nunp_0, m.nunpaired, "aligned 0 times");
+		line("    ", m.nunp_uni1, m.nunpaired, "aligned exactly 1 time");
+		line("    ", m.nunp_uni2, m.nunpaired, "aligned >1 times");
+	}
+	pct(tot_al, tot_al_cand); o += " overall alignment rate\n";
+	if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
+	return o.size();
+}
 extern "C" void h2g_sam_set_secondary(h2g_sam* S, int on) { if(S) S->secondary = on != 0; }
 extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, double coeff) { if(S) { S->smType = type; S->smConst = c; S->smCoeff = coeff; } }
 
@@ -465,7 +512,7 @@ extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* c
                                               const h2g_alnres* aln, char* out, size_t cap, size_t* used)
 {
 	if(!S || !codes || !offs || !nb || !noffs || !res || !aln || !used) return H2G_ERR_ARG;
-	auto one = [&](size_t i, std::string& o) {
+	auto one = [&](size_t i, std::string& o, Met& met) {
 		Rd rd = {nb + noffs[i], noffs[i + 1] - noffs[i], codes + offs[i], offs[i + 1] - offs[i], quals ? quals + offs[i] : nullptr};
 		Flags fl;
 		read_filters(rd, &fl.lenfilt, &fl.nfilt);
@@ -474,6 +521,8 @@ extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* c
 		if(r.best != INT32_MIN) { summ.best[0].valid = true; summ.best[0].score = r.best; summ.best[0].h2 = hisat2_score(r.best, r.best_trim); }
 		if(r.secbest != INT32_MIN) { summ.secbest[0].valid = true; summ.secbest[0].score = r.secbest; summ.secbest[0].h2 = hisat2_score(r.secbest, r.secbest_trim); }
 		const uint32_t nsel = r.nselect < H2G_ALN_CAP ? r.nselect : H2G_ALN_CAP;
+		met.nread++; met.nunpaired++;
+		if(nsel == 0) met.nunp_0++; else if(nsel == 1) met.nunp_uni1++; else met.nunp_uni2++;
 		if(nsel == 0) append_mate(*S, o, rd, nullptr, nullptr, nullptr, summ, fl, 0);
 		for(uint32_t k = 0; k < nsel; k++) {
 			fl.primary = k == 0;
@@ -490,8 +539,9 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
                                             uint32_t khits, char* out, size_t cap, size_t* used)
 {
 	if(!S || !codes1 || !offs1 || !nb1 || !noffs1 || !codes2 || !offs2 || !nb2 || !noffs2 || !res || !aln1 || !aln2 || !used) return H2G_ERR_ARG;
-	auto one = [&](size_t i, std::string& o) {
+	auto one = [&](size_t i, std::string& o, Met& met) {
 		std::vector<size_t> sel, sel1, sel2;
+		met.nread++; met.npaired++;
 		std::vector<Score> keys;
 		const h2g_pair_result& pr = res[i];
 		Rd rd[2] = {{nb1 + noffs1[i], noffs1[i + 1] - noffs1[i], codes1 + offs1[i], offs1[i + 1] - offs1[i], quals1 ? quals1 + offs1[i] : nullptr},
@@ -524,6 +574,7 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 				else if(sc.gt(summ.secbestPaired)) summ.secbestPaired = sc;
 			}
 			select_by_score(keys, std::min<size_t>(khits, nconc), rnd, sel, S->secondary);
+			if(sel.size() == 1) met.nconcord_uni1++; else met.nconcord_uni2++;
 			for(size_t q = 0; q < sel.size(); q++) {
 				const h2g_alnres* a = &r1[pr.pair_i[sel[q]]];
 				const h2g_alnres* b = &r2[pr.pair_j[sel[q]]];
@@ -541,6 +592,7 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 			keys.assign(1, add(score_of(r1[0]), score_of(r2[0])));
 			summ.bestPaired = keys[0];
 			select_by_score(keys, 1, rnd, sel, S->secondary);
+			met.nconcord_0++; met.ndiscord++;
 			f1.pairing = PAIR_DISCORD_M1; f2.pairing = PAIR_DISCORD_M2;
 			f1.oppAligned = f2.oppAligned = true;
 			append_mate(*S, o, rd[0], &rd[1], &r1[0], &r2[0], summ, f1, 1);
@@ -552,6 +604,9 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 			if(n2) { keys.clear(); for(size_t k = 0; k < n2; k++) keys.push_back(score_of(r2[k])); select_by_score(keys, std::min<size_t>(khits, n2), rnd, sel2, S->secondary); }
 			summ_unpaired(s1, 0, r1, n1); summ_unpaired(s1, 1, r2, n2);
 			s2 = s1;
+			met.nconcord_0++;
+			if(sel1.empty()) met.nunp_0_0++; else if(sel1.size() == 1) met.nunp_0_uni1++; else met.nunp_0_uni2++;
+			if(sel2.empty()) met.nunp_0_0++; else if(sel2.size() == 1) met.nunp_0_uni1++; else met.nunp_0_uni2++;
 			const h2g_alnres* p1 = sel1.empty() ? nullptr : &r1[sel1[0]];
 			const h2g_alnres* p2 = sel2.empty() ? nullptr : &r2[sel2[0]];
 			f1.pairing = PAIR_UNP_M1; f2.pairing = PAIR_UNP_M2;

@@ -27,6 +27,9 @@ H2G_EXPORT h2g_status h2g_sam_open(const char* index_base, h2g_sam** out);
 H2G_EXPORT void       h2g_sam_close(h2g_sam*);
 /* host threads used by the format calls (contiguous read ranges, output concatenated in read order); default 1 */
 H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
+/* the alignment summary the reference prints on stderr at the end of a run (AlnSink::printAlSumm aln_sink.h:1637), over all
+ * reads formatted so far by this handle.  Returns bytes needed; writes at most cap. */
+H2G_EXPORT size_t     h2g_sam_summary(const h2g_sam*, char* out, size_t cap);
 /* --secondary: the sink's -k selection for pairs keeps lower-scoring alignments (aln_sink.h:2733-2745) */
 H2G_EXPORT void       h2g_sam_set_secondary(h2g_sam*, int on);
 /* --score-min as given to the aligner (h2g_align_params.score_min_*): MAPQ is relative to it (unique.h:214-222) */

@@ -47,7 +47,7 @@ def run_case(seed, nreads, rdlen, sub, indel, nrate, lens=(300000, 120000, 60000
                 f.write(b"@%d\n" % i + txt[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
     sam = os.path.join(tmp, "ref.sam")
     subprocess.run([os.path.join(REF, "hisat2-align-s"), "-q" if fastq else "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-U", rfa, "-S", sam] + list(extra),
-                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                   check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
     refnames, want = SU.parse_sam(sam)
     qnames = [str(i) for i in range(nreads)]
     if backend is None:

@@ -104,7 +104,7 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     synth.write_reads_fasta(f2, m2)
     sam = os.path.join(tmp, "ref.sam")
     subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam] + (["--bowtie2-dp", str(DP)] if DP else []) + list(OPTS),
-                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                   check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
     refnames, want = parse_pe_sam(sam)
     khits = int(OPTS[OPTS.index("-k") + 1]) if "-k" in OPTS else (10 if SNPS else 5)
     secondary = "--secondary" in OPTS

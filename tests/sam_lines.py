@@ -11,6 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+LAST_SUMMARY = None   # alignment summary text of the last format_* call (h2g_sam_summary)
+
+
 def load_sam_lib(path=None):
     L = C.CDLL(path or os.environ.get("H2G_SAM_LIB") or os.path.join(ROOT, "hisat2_amd", "libh2g.so"))
     L.h2g_sam_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
@@ -20,6 +23,8 @@ def load_sam_lib(path=None):
                                                                              C.POINTER(C.c_size_t)]
     L.h2g_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     L.h2g_sam_header.restype = C.c_size_t
+    L.h2g_sam_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.h2g_sam_summary.restype = C.c_size_t
     L.h2g_sam_set_score_min.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
     return L
 
@@ -64,6 +69,10 @@ def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):
         quals = np.ascontiguousarray(quals, dtype=np.uint8)
         qp = quals.ctypes.data
     rc = L.h2g_sam_format_unpaired(h, codes.ctypes.data, offs.ctypes.data, qp, nb, noffs.ctypes.data, n, rp, ap, buf, cap, C.byref(used))
+    global LAST_SUMMARY
+    sb = C.create_string_buffer(4096)
+    nsum = L.h2g_sam_summary(h, sb, 4096)
+    LAST_SUMMARY = sb.raw[:nsum].decode()
     L.h2g_sam_close(h)
     assert rc == 0, (rc, used.value, cap)
     return buf.raw[:used.value].decode().splitlines()
@@ -84,6 +93,10 @@ def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=()):
     ptr = lambda x: x.ctypes.data if isinstance(x, np.ndarray) else C.addressof(x)
     rc = L.h2g_sam_format_paired(h, c1.ctypes.data, o1.ctypes.data, None, nb1, no1.ctypes.data, c2.ctypes.data, o2.ctypes.data, None, nb2,
                                  no2.ctypes.data, n, ptr(res), ptr(a1), ptr(a2), khits, buf, cap, C.byref(used))
+    global LAST_SUMMARY
+    sb = C.create_string_buffer(4096)
+    nsum = L.h2g_sam_summary(h, sb, 4096)
+    LAST_SUMMARY = sb.raw[:nsum].decode()
     L.h2g_sam_close(h)
     assert rc == 0, (rc, used.value, cap)
     return buf.raw[:used.value].decode().splitlines()

@@ -62,3 +62,9 @@ def test_reader_is_thread_and_batch_invariant(tmp_path, fmt):
                               "-x", "unused"], check=True, capture_output=True, text=True).stdout.split()
         got = (int(out[0]), int(out[1]), int(out[2], 16))
         assert got == expected(names, seqs2, quals, batch), (threads, batch)
+    import gzip, shutil
+    with open(path, "rb") as fi, gzip.open(str(path) + ".gz", "wb") as fo:       # gzipped input gives the same reads
+        shutil.copyfileobj(fi, fo)
+    out = subprocess.run([CLI, "--parse-only", "-f" if fmt != "fastq" else "-q", "-U", str(path) + ".gz", "-p", "4", "-x", "unused"], check=True,
+                         capture_output=True, text=True).stdout.split()
+    assert (int(out[0]), int(out[1]), int(out[2], 16)) == expected(names, seqs2, quals, 1 << 20)

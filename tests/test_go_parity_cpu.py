@@ -47,6 +47,7 @@ def test_golden_sam(g1_index, golden_dir):
     dict(seed=962, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, fastq=True, extra=("--rdg", "4,2", "--rfg", "7,2", "--score-min", "L,0,-0.4")),
     dict(seed=963, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, fastq=True, extra=("--secondary", "--sp", "3,1", "--score-min", "C,-18")),
     dict(seed=964, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, snps=60, extra=("--no-softclip", "-k", "4", "--mp", "5,1")),
+    dict(seed=965, nreads=5000, rdlen=101, sub=0.03, indel=0.005, nrate=0.002, fastq=True, extra=("--sensitive",)),
 ])
 def test_live_reference(case):
     """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""

@@ -106,6 +106,21 @@ def test_live_reference_graph_index_bowtie2_dp():
     assert bad == 0
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("case", [
+    dict(extra=("--sensitive",)),                                                       # wide linear kernel k_align<3, false> + SwAligner + L,0,-0.5
+    dict(extra=("-k", "10")),
+    dict(extra=("-k", "3", "--mp", "4,2", "--np", "3", "--rdg", "4,2", "--rfg", "7,2")),
+    dict(extra=("--sensitive",), snps=60),
+])
+def test_live_reference_options(case):
+    import fuzz_align as F
+    kw = dict(seed=231, nreads=10000, rdlen=101, sub=0.03, indel=0.005, nrate=0.002, fastq=True)
+    kw.update(case)
+    bad, _ = F.run_case(verbose=3, backend=_backend, **kw)
+    assert bad == 0
+
+
 def test_align_requires_names_and_nospliced(g1_index, golden_dir):
     names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
     codes = np.concatenate(seqs)

@@ -20,7 +20,10 @@ def _backend(base, m1, m2, q1, q2):
     st.set_reads(c1, o1)
     st.set_read_names(q1)
     st.set_mates(c2, o2, q2)
-    st.align_pairs_run()
+    p = st.align_params()
+    rest = p.apply_options(list(F.OPTS))          # scoring / reporting options of the case (fuzz_pairs.OPTS)
+    assert not rest, rest
+    st.align_pairs_run(p)
     res, a1, a2 = st.align_pairs_fetch()
     st.close()
     ix.close()
@@ -52,6 +55,15 @@ def test_live_reference_pairs_dense_graph_index(monkeypatch):
     """variants every ~100 bp, 125 bp mates, wide fragments (the case that exposed the multi-'$' local index bug)"""
     monkeypatch.setattr(F, "SNPS", 100)
     bad, _ = F.run_case(verbose=3, backend=_backend, stride=api.PAIR_RES_CAP, seed=913, npairs=20000, rdlen=125, sub=0.02, frag_mean=350, frag_sd=120)
+    assert bad == 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("opts", [("--sensitive",), ("-k", "9"), ("-k", "2", "--mp", "5,3", "--score-min", "L,0,-0.35")])
+def test_live_reference_pairs_options(monkeypatch, opts):
+    """option surface on pairs; -k > 5 / --sensitive run the wide linear kernel (k_align_pairs<false, 1>)"""
+    monkeypatch.setattr(F, "OPTS", opts)
+    bad, _ = F.run_case(verbose=3, backend=_backend, stride=api.PAIR_RES_CAP, seed=331, npairs=8000, rdlen=101, sub=0.03)
     assert bad == 0
 
 

@@ -44,8 +44,9 @@ def test_unpaired_sam_text(case):
     out = os.path.join(tmp, "amd.sam")
     rd = os.path.join(tmp, "r.fq" if case.get("fastq") else "r.fa")
     subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-q" if case.get("fastq") else "-f", "-U", rd, "--no-spliced-alignment", "-S", out,
-                    "--batch", "7000", "-p", "5"] + opts, check=True)
+                    "--batch", "7000", "-p", "5"] + opts, check=True, stderr=open(os.path.join(tmp, "amd.err"), "w"))
     assert diff_lines(SL.body_lines(out), want) == 0
+    assert open(os.path.join(tmp, "amd.err")).read() == open(os.path.join(tmp, "ref.err")).read()          # alignment summary
     hdr = [l for l in open(out) if l.startswith("@")]
     ref_hdr = [l for l in open(os.path.join(tmp, "ref.sam")) if l.startswith("@")]
     assert hdr[:-1] == ref_hdr[:-1] and hdr[-1].startswith("@PG\tID:hisat2\tPN:hisat2\tVN:")      # @HD, @SQ identical; @PG differs by CL
@@ -67,8 +68,9 @@ def test_paired_command_line(monkeypatch, snps, case):
     assert bad == 0
     out = os.path.join(tmp, "amd.sam")
     subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-f", "-1", os.path.join(tmp, "r1.fa"), "-2", os.path.join(tmp, "r2.fa"),
-                    "--no-spliced-alignment", "-S", out, "--batch", "4000", "-p", "3"], check=True)
+                    "--no-spliced-alignment", "-S", out, "--batch", "4000", "-p", "3"], check=True, stderr=open(os.path.join(tmp, "amd.err"), "w"))
     assert diff_lines(SL.body_lines(out), SL.body_lines(os.path.join(tmp, "ref.sam"))) == 0
+    assert open(os.path.join(tmp, "amd.err")).read() == open(os.path.join(tmp, "ref.err")).read()
 
 
 def test_command_line_refuses_what_is_not_built(tmp_path):

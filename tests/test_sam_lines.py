@@ -65,6 +65,7 @@ def test_unpaired_lines_identical(case):
     want = SL.body_lines(os.path.join(tmp, "ref.sam"))
     assert len(want) >= case["nreads"]
     assert diff_lines(got, want) == 0
+    assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()      # the alignment summary on stderr
 
 
 @needs_ref
@@ -102,3 +103,4 @@ def test_paired_lines_identical(monkeypatch, snps, case):
     got = SL.format_paired(SL.load_sam_lib(), os.path.join(tmp, "g"), m1, m2, n1, n2, res, a1, a2, khits, options=opts)
     want = SL.body_lines(os.path.join(tmp, "ref.sam"))
     assert diff_lines(got, want) == 0
+    assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
