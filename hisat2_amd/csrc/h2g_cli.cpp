@@ -44,7 +44,8 @@ inline uint8_t base_code(int c) { switch(c | 0x20) { case 'c': return 1; case 'g
 // fourth line), and each fill() hands contiguous record ranges to the threads and concatenates their output in file order.
 class Reader {
 public:
-	Reader(const std::vector<std::string>& files, bool fasta, int threads) : files_(files), fasta_(fasta), T_(threads < 1 ? 1 : threads) {}
+	Reader(const std::vector<std::string>& files, bool fasta, int threads, uint32_t trim5 = 0, uint32_t trim3 = 0)
+		: files_(files), fasta_(fasta), T_(threads < 1 ? 1 : threads), trim5_(trim5), trim3_(trim3) {}
 	~Reader() { unmap(); }
 	size_t fill(Batch& b, size_t max) {
 		size_t got = 0;
@@ -151,13 +152,25 @@ private:
 		if(nlen == 0) b.names += std::to_string(count_ + (r - cur_)); else b.names.append(nm, nlen);
 		b.noffs.push_back((uint32_t)b.names.size());
 		if(q < end) q++;
+		const size_t c0 = b.codes.size();
+		// -5 / -3 (gTrim5 / gTrim3, pat.cpp:820-832, 930-1010): bases dropped from the 5' / 3' end before alignment
+		auto trim = [&]() {
+			size_t L = b.codes.size() - c0;
+			const size_t t5 = std::min<size_t>(trim5_, L);
+			if(t5) { b.codes.erase(b.codes.begin() + c0, b.codes.begin() + c0 + t5); L -= t5; }
+			const size_t t3 = std::min<size_t>(trim3_, L);
+			if(t3) b.codes.resize(b.codes.size() - t3);
+			return t5;
+		};
 		if(fasta_) {
 			for(; q < end; q++) if(is_read_char((unsigned char)*q)) b.codes.push_back(base_code(*q));
+			trim();
 			b.offs.push_back((uint32_t)b.codes.size());
 			return;
 		}
-		const size_t c0 = b.codes.size();
 		for(; q < end && *q != '\n'; q++) { char c = *q; if(c == '.') c = 'N'; if(is_read_char((unsigned char)c)) b.codes.push_back(base_code(c)); }
+		const size_t Lraw = b.codes.size() - c0;
+		const size_t t5 = trim();
 		b.offs.push_back((uint32_t)b.codes.size());
 		const size_t L = b.codes.size() - c0;
 		if(q < end) q++;
@@ -165,12 +178,13 @@ private:
 		if(q < end) q++;
 		const char* ql = q;
 		while(q < end && *q != '\n' && *q != '\r') q++;
-		if((size_t)(q - ql) < L) { fprintf(stderr, "Error: Read %.*s has more read characters than quality values.\n", (int)nlen, nm); exit(1); }
-		b.quals.append(ql, L);
+		if((size_t)(q - ql) < Lraw) { fprintf(stderr, "Error: Read %.*s has more read characters than quality values.\n", (int)nlen, nm); exit(1); }
+		b.quals.append(ql + t5, L);
 	}
 	std::vector<std::string> files_;
 	bool fasta_;
 	int T_;
+	uint32_t trim5_ = 0, trim3_ = 0;
 	size_t fi_ = 0;
 	const char* p_ = nullptr;
 	size_t n_ = 0, cur_ = 0;
@@ -194,7 +208,9 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 int main(int argc, char** argv) {
 	std::string base, outfn;
 	std::vector<std::string> u, m1, m2;
-	bool fasta = false, nospliced = false, nohead = false, parse_only = false;
+	bool fasta = false, nospliced = false, nohead = false, parse_only = false, no_unal = false;
+	uint64_t skip = 0, upto = ~0ull;
+	uint32_t trim5 = 0, trim3 = 0;
 	uint32_t dp = 0;
 	size_t batch = 1u << 20;
 	int device = 0, threads = 1;
@@ -221,6 +237,12 @@ int main(int argc, char** argv) {
 		else if(a == "--no-hd" || a == "--no-head") nohead = true;
 		else if(a == "--batch") batch = (size_t)atoll(need("--batch"));
 		else if(a == "--device") device = atoi(need("--device"));
+		else if(a == "-s" || a == "--skip") skip = (uint64_t)atoll(need("-s"));     // skip the first <int> reads / pairs (hisat2.cpp:3319)
+		else if(a == "-u" || a == "--upto" || a == "--qupto") upto = (uint64_t)atoll(need("-u"));
+		else if(a == "-5" || a == "--trim5") trim5 = (uint32_t)atoi(need("-5"));
+		else if(a == "-3" || a == "--trim3") trim3 = (uint32_t)atoi(need("-3"));
+		else if(a == "--no-unal") no_unal = true;
+		else if(a == "--reorder" || a == "-t" || a == "--time" || a == "--quiet") {}    // output is always in read order
 		else if(a == "--parse-only") parse_only = true;                           // test hook: ingest the reads, print counts + checksums
 		else { fprintf(stderr, "hisat2-align-amd: option %s is not built (see DESIGN.md, scope)\n", a.c_str()); return 1; }
 	}
@@ -293,7 +315,13 @@ int main(int argc, char** argv) {
 	}
 	const double t1 = now();
 	h2g_sam_set_threads(sam, threads);
-	Reader ra(paired ? m1 : u, fasta, threads), rb(m2, fasta, threads);
+	h2g_sam_set_no_unal(sam, no_unal ? 1 : 0);
+	Reader ra(paired ? m1 : u, fasta, threads, trim5, trim3), rb(m2, fasta, threads, trim5, trim3);
+	if(skip) {   // -s: the skipped reads are parsed (their ids count) but not aligned
+		Batch junk;
+		for(uint64_t left = skip; left > 0;) { junk.clear(); const size_t g = ra.fill(junk, (size_t)std::min<uint64_t>(left, batch)); if(paired) { junk.clear(); rb.fill(junk, g); } if(!g) break; left -= g; }
+	}
+	uint64_t budget = upto;                               // -u counts the reads after the skipped ones (qUpto += skipReads, hisat2.cpp:1959-1963)
 	h2g_stream* st = nullptr;
 	Batch A[2], B[2];                                 // double buffer: batch k+1 is parsed while batch k is on the GPU
 	uint64_t nreads = 0, naligned = 0, novf = 0;
@@ -302,7 +330,9 @@ int main(int argc, char** argv) {
 	int cur = 0;
 	A[0].clear(); B[0].clear();
 	double tp = now();
-	size_t n = ra.fill(A[0], batch);
+	auto want = [&]() { const size_t w = (size_t)std::min<uint64_t>(batch, budget); return w; };
+	size_t n = ra.fill(A[0], want());
+	budget -= std::min<uint64_t>(budget, n);
 	if(paired && rb.fill(B[0], n) != n) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
 	t_parse += now() - tp;
 	std::vector<h2g_read_result> res;
@@ -328,7 +358,8 @@ int main(int argc, char** argv) {
 		const int nxt = cur ^ 1;
 		A[nxt].clear(); B[nxt].clear();
 		tp = now();
-		const size_t n2 = ra.fill(A[nxt], batch);
+		const size_t n2 = budget ? ra.fill(A[nxt], want()) : 0;
+		budget -= std::min<uint64_t>(budget, n2);
 		if(paired && rb.fill(B[nxt], n2) != n2) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
 		t_parse += now() - tp;
 		size_t used = 0;

@@ -31,6 +31,7 @@ struct h2g_sam {
 	std::vector<HostAlt>     alts;
 	std::vector<std::string> altnames;
 	int threads = 1;
+	bool no_unal = false;                                 // --no-unal: SamConfig::omitUnalignedReads
 	bool secondary = false;                               // --secondary: selectByScore keeps lower-scoring alignments too
 	uint32_t smType = 2;                                  // --score-min (MAPQ's scMin), default L,0,-0.2
 	double smConst = 0.0, smCoeff = (double)(-0.2f);
@@ -251,6 +252,7 @@ int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1)
 void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, const h2g_alnres* rs, const h2g_alnres* rso,
                  const Summ& summ, const Flags& fl, uint64_t nh)
 {
+	if(rs == nullptr && S.no_unal) return;                 // aln_sink.h:3040
 	Stacked st;
 	std::string seq, qual;
 	seq_ascii(rd, rs == nullptr || rs->fw, seq, qual);
@@ -504,6 +506,7 @@ extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
 	if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
 	return o.size();
 }
+extern "C" void h2g_sam_set_no_unal(h2g_sam* S, int on) { if(S) S->no_unal = on != 0; }
 extern "C" void h2g_sam_set_secondary(h2g_sam* S, int on) { if(S) S->secondary = on != 0; }
 extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, double coeff) { if(S) { S->smType = type; S->smConst = c; S->smCoeff = coeff; } }
 

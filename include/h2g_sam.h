@@ -30,6 +30,8 @@ H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
 /* the alignment summary the reference prints on stderr at the end of a run (AlnSink::printAlSumm aln_sink.h:1637), over all
  * reads formatted so far by this handle.  Returns bytes needed; writes at most cap. */
 H2G_EXPORT size_t     h2g_sam_summary(const h2g_sam*, char* out, size_t cap);
+/* --no-unal: lines of reads / mates that failed to align are not printed (aln_sink.h:3040) */
+H2G_EXPORT void       h2g_sam_set_no_unal(h2g_sam*, int on);
 /* --secondary: the sink's -k selection for pairs keeps lower-scoring alignments (aln_sink.h:2733-2745) */
 H2G_EXPORT void       h2g_sam_set_secondary(h2g_sam*, int on);
 /* --score-min as given to the aligner (h2g_align_params.score_min_*): MAPQ is relative to it (unique.h:214-222) */

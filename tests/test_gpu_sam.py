@@ -73,6 +73,29 @@ def test_paired_command_line(monkeypatch, snps, case):
     assert open(os.path.join(tmp, "amd.err")).read() == open(os.path.join(tmp, "ref.err")).read()
 
 
+@needs_ref
+def test_command_line_skip_upto_trim_no_unal():
+    """-s / -u / -5 / -3 / --no-unal and gzipped input behave as in the reference"""
+    import gzip
+    import shutil
+    import fuzz_align as F
+    from test_gpu_align import _backend
+    bad, tmp = F.run_case(verbose=2, backend=_backend, seed=421, nreads=6000, rdlen=101, sub=0.02, indel=0.003, nrate=0.004, fastq=True)
+    assert bad == 0
+    with open(os.path.join(tmp, "r.fq"), "rb") as fi, gzip.open(os.path.join(tmp, "r.fq.gz"), "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    opts = ["-s", "500", "-u", "3000", "-5", "4", "-3", "7", "--no-unal"]
+    ref = os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")
+    subprocess.run([ref, "-q", "-p", "1", "--no-spliced-alignment", "-x", os.path.join(tmp, "g"), "-U", os.path.join(tmp, "r.fq"), "-S",
+                    os.path.join(tmp, "ref2.sam")] + opts, check=True, stderr=open(os.path.join(tmp, "ref2.err"), "w"))
+    subprocess.run([CLI, "-q", "-p", "4", "--no-spliced-alignment", "-x", os.path.join(tmp, "g"), "-U", os.path.join(tmp, "r.fq.gz"), "-S",
+                    os.path.join(tmp, "amd2.sam"), "--batch", "1000"] + opts, check=True, stderr=open(os.path.join(tmp, "amd2.err"), "w"))
+    want = SL.body_lines(os.path.join(tmp, "ref2.sam"))
+    assert 1000 < len(want) < 3000
+    assert diff_lines(SL.body_lines(os.path.join(tmp, "amd2.sam")), want) == 0
+    assert open(os.path.join(tmp, "amd2.err")).read() == open(os.path.join(tmp, "ref2.err")).read()
+
+
 def test_command_line_refuses_what_is_not_built(tmp_path):
     r = subprocess.run([CLI, "-x", "nonexistent", "-U", "x.fq"], capture_output=True, text=True)
     assert r.returncode != 0 and "spliced alignment is not built" in r.stderr
