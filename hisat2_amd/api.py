@@ -217,7 +217,7 @@ EXPORTS = [
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_align_params_init", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
-    "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch",
+    "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense",
     "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph", "h2g_adjust_with_alt",
 ]
 
@@ -458,6 +458,37 @@ class Stream:
         noffs = np.concatenate([[0], np.cumsum([len(q) for q in qnames2])]).astype(np.uint32)
         q = None if quals2 is None else np.ascontiguousarray(quals2, dtype=np.uint8).ctypes.data
         _chk(lib().h2g_set_mates(self.h, codes2.ctypes.data, offs2.ctypes.data, q, nb, noffs.ctypes.data, len(offs2) - 1), "h2g_set_mates")
+
+    def align_fetch_dense(self, first=0, n=None):
+        """-> (res, aln, offs): only the printed alignments, read i's records are aln[offs[i]:offs[i+1]]"""
+        n = self.n_reads - first if n is None else n
+        res = np.zeros(n, dtype=READ_RESULT_DTYPE)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        cap = n * 2 + 16
+        while True:
+            aln = (AlnRes * cap)()
+            rc = lib().h2g_align_fetch_dense(self.h, res.ctypes.data, aln, cap, offs.ctypes.data, first, n)
+            if rc == 0:
+                return res, aln, offs
+            if int(offs[n]) <= cap:
+                _chk(rc, "h2g_align_fetch_dense")
+            cap = int(offs[n])
+
+    def align_pairs_fetch_dense(self, first=0, n=None):
+        n = self.n_reads - first if n is None else n
+        res = (PairResult * n)()
+        o1 = np.zeros(n + 1, dtype=np.uint64)
+        o2 = np.zeros(n + 1, dtype=np.uint64)
+        c1 = c2 = n * 2 + 16
+        while True:
+            a1 = (AlnRes * c1)()
+            a2 = (AlnRes * c2)()
+            rc = lib().h2g_align_pairs_fetch_dense(self.h, res, a1, c1, o1.ctypes.data, a2, c2, o2.ctypes.data, first, n)
+            if rc == 0:
+                return res, a1, o1, a2, o2
+            if int(o1[n]) <= c1 and int(o2[n]) <= c2:
+                _chk(rc, "h2g_align_pairs_fetch_dense")
+            c1, c2 = max(c1, int(o1[n])), max(c2, int(o2[n]))
 
     def align_pairs_run(self, params=None):
         params = params or self.align_params()

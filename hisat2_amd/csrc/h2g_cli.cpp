@@ -338,6 +338,7 @@ int main(int argc, char** argv) {
 	std::vector<h2g_read_result> res;
 	std::vector<h2g_pair_result> pres;
 	std::vector<h2g_alnres> aln, aln2;
+	std::vector<uint64_t> ao1, ao2;
 	while(n > 0) {
 		Batch& a = A[cur]; Batch& b = B[cur];
 		size_t bases = a.codes.size();
@@ -364,35 +365,46 @@ int main(int argc, char** argv) {
 		t_parse += now() - tp;
 		size_t used = 0;
 		if(paired) {
-			pres.resize(n); aln.resize(n * H2G_PAIR_RES_CAP); aln2.resize(n * H2G_PAIR_RES_CAP);
-			if(h2g_align_pairs_fetch(st, pres.data(), aln.data(), aln2.data(), 0, n) != H2G_OK) die("h2g_align_pairs_fetch");
+			pres.resize(n); ao1.resize(n + 1); ao2.resize(n + 1);
+			if(aln.size() < 2 * n + 64) aln.resize(2 * n + 64);
+			if(aln2.size() < 2 * n + 64) aln2.resize(2 * n + 64);
+			// dense fetch: only the records that exist cross PCIe (the slot layout would move 2 x 16 x 424 B per pair)
+			if(h2g_align_pairs_fetch_dense(st, pres.data(), aln.data(), aln.size(), ao1.data(), aln2.data(), aln2.size(), ao2.data(), 0, n) != H2G_OK) {
+				if(aln.size() < ao1[n]) aln.resize(ao1[n]);
+				if(aln2.size() < ao2[n]) aln2.resize(ao2[n]);
+				if(h2g_align_pairs_fetch_dense(st, pres.data(), aln.data(), aln.size(), ao1.data(), aln2.data(), aln2.size(), ao2.data(), 0, n) != H2G_OK) die("h2g_align_pairs_fetch_dense");
+			}
 			t_gpu += now() - tg;
 			const double tf = now();
 			buf.resize(n * 1400 + 6 * (a.codes.size() + b.codes.size()) + 4096);
-			h2g_status rc = h2g_sam_format_paired(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
+			h2g_status rc = h2g_sam_format_paired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
 			                                      b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n,
-			                                      pres.data(), aln.data(), aln2.data(), P.khits, buf.data(), buf.size(), &used);
+			                                      pres.data(), aln.data(), ao1.data(), aln2.data(), ao2.data(), P.khits, buf.data(), buf.size(), &used);
 			if(rc != H2G_OK) {
 				buf.resize(used + 16);
-				rc = h2g_sam_format_paired(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
+				rc = h2g_sam_format_paired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
 				                           b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n,
-				                           pres.data(), aln.data(), aln2.data(), P.khits, buf.data(), buf.size(), &used);
+				                           pres.data(), aln.data(), ao1.data(), aln2.data(), ao2.data(), P.khits, buf.data(), buf.size(), &used);
 				if(rc != H2G_OK) die("h2g_sam_format_paired");
 			}
 			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; novf += pres[i].overflow != 0; }
 			t_fmt += now() - tf;
 		} else {
-			res.resize(n); aln.resize(n * H2G_ALN_CAP);
-			if(h2g_align_fetch(st, res.data(), aln.data(), 0, n) != H2G_OK) die("h2g_align_fetch");
+			res.resize(n); ao1.resize(n + 1);
+			if(aln.size() < n + n / 4 + 64) aln.resize(n + n / 4 + 64);
+			if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) {
+				if(aln.size() < ao1[n]) aln.resize(ao1[n]);
+				if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) die("h2g_align_fetch_dense");
+			}
 			t_gpu += now() - tg;
 			const double tf = now();
 			buf.resize(n * 700 + 3 * a.codes.size() + 4096);
-			h2g_status rc = h2g_sam_format_unpaired(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
-			                                        res.data(), aln.data(), buf.data(), buf.size(), &used);
+			h2g_status rc = h2g_sam_format_unpaired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
+			                                        res.data(), aln.data(), ao1.data(), buf.data(), buf.size(), &used);
 			if(rc != H2G_OK) {
 				buf.resize(used + 16);
-				rc = h2g_sam_format_unpaired(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
-				                             res.data(), aln.data(), buf.data(), buf.size(), &used);
+				rc = h2g_sam_format_unpaired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
+				                             res.data(), aln.data(), ao1.data(), buf.data(), buf.size(), &used);
 				if(rc != H2G_OK) die("h2g_sam_format_unpaired");
 			}
 			for(size_t i = 0; i < n; i++) { naligned += res[i].nselect > 0; novf += res[i].overflow != 0; }

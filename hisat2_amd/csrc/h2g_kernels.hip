@@ -20,9 +20,10 @@
 extern "C" size_t h2g_ws_bytes_linear_se(); extern "C" size_t h2g_ws_bytes_linear_pe();
 extern "C" size_t h2g_ws_bytes_graph_se();  extern "C" size_t h2g_ws_bytes_graph_pe();
 extern "C" size_t h2g_ws_bytes_linear_wide_se(); extern "C" size_t h2g_ws_bytes_linear_wide_pe();
-static size_t ws_bytes_per_lane(bool linear) {
+// per-lane workspace of the go() build that is about to run (linear narrow / linear wide / graph; the larger of SE and PE)
+static size_t ws_bytes_per_lane(bool linear, bool wide) {
 	size_t a = linear ? h2g_ws_bytes_linear_se() : h2g_ws_bytes_graph_se(), b = linear ? h2g_ws_bytes_linear_pe() : h2g_ws_bytes_graph_pe();
-	if(linear) { a = std::max(a, h2g_ws_bytes_linear_wide_se()); b = std::max(b, h2g_ws_bytes_linear_wide_pe()); }   // either linear build may run
+	if(linear && wide) { a = h2g_ws_bytes_linear_wide_se(); b = h2g_ws_bytes_linear_wide_pe(); }
 	return a > b ? a : b;
 }
 
@@ -67,7 +68,7 @@ struct h2g_stream {
 	size_t names_cap = 0;
 	bool has_names = false;
 	AlignWS* d_ws = nullptr;
-	size_t ws_threads = 0;
+	size_t ws_bytes = 0;          // bytes allocated behind d_ws (lanes x per-lane size of the build last run)
 	uint8_t* d_sw = nullptr;      // per-lane Smith-Waterman scratch of the go() kernels (only with bowtie2_dp != 0)
 	size_t sw_stride = 0, sw_lanes = 0;
 	GraphWS* d_gws = nullptr;     // per-lane graph scratch of the go() kernels (graph indexes only)
@@ -1249,10 +1250,13 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	const size_t maxblocks = 256 * (size_t)(!s->ix->dg.linear ? 2 : getenv("H2G_ALIGN_OCC") ? (atoi(getenv("H2G_ALIGN_OCC")) >= 3 ? 4 : 2) : 4)   /* resident blocks per CU */;
 	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	const size_t nthreads = (size_t)grid * block;
-	if(s->ws_threads < nthreads) {
-		(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_threads = 0;
-		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0)));
-		s->ws_threads = nthreads;
+	{
+		const size_t need = nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0, p->kseeds > 10);
+		if(s->ws_bytes < need) {
+			(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_bytes = 0;
+			HIPCHK(hipMalloc((void**)&s->d_ws, need));
+			s->ws_bytes = need;
+		}
 	}
 	if(!s->d_rout) {
 		HIPCHK(hipMalloc((void**)&s->d_rout, s->max_reads * sizeof(ReadOut)));
@@ -1358,10 +1362,13 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	const size_t maxblocks = 256 * (size_t)(s->ix->dg.linear ? 3 : 2);
 	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	const size_t nthreads = (size_t)grid * block;
-	if(s->ws_threads < nthreads) {
-		(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_threads = 0;
-		HIPCHK(hipMalloc((void**)&s->d_ws, nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0)));
-		s->ws_threads = nthreads;
+	{
+		const size_t need = nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0, p->kseeds > 10);
+		if(s->ws_bytes < need) {
+			(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_bytes = 0;
+			HIPCHK(hipMalloc((void**)&s->d_ws, need));
+			s->ws_bytes = need;
+		}
 	}
 	if(!s->d_pout) {
 		HIPCHK(hipMalloc((void**)&s->d_pout, s->max_reads * sizeof(PairOut)));
@@ -1400,6 +1407,68 @@ extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res,
 	if(aln2) HIPCHK(hipMemcpyAsync(aln2, s->d_paln[1] + first * H2G_PAIR_RES_CAP, n * H2G_PAIR_RES_CAP * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipStreamSynchronize(s->st));
 	return H2G_OK;
+}
+
+// ------------------------------------------------------------------------------------------ dense result fetch
+// The slot layout of h2g_align_fetch moves H2G_ALN_CAP x 424 B per read over PCIe whatever was found; these variants gather
+// only the records that exist into one dense array on the device (one lane per read) and copy that.
+__global__ __launch_bounds__(256) void k_gather_aln(const h2g_alnres* src, uint32_t slots, const uint32_t* cnt, uint32_t cnt_stride,
+                                                    const unsigned long long* offs, size_t n, h2g_alnres* dst)
+{
+	const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	uint32_t c = cnt[i * cnt_stride];
+	if(c > slots) c = slots;
+	const h2g_alnres* a = src + i * slots;
+	h2g_alnres* d = dst + offs[i];
+	for(uint32_t k = 0; k < c; k++) {
+		d[k].fw = a[k].fw; d[k].tidx = a[k].tidx; d[k].toff = a[k].toff; d[k].len = a[k].len; d[k].trim5 = a[k].trim5; d[k].trim3 = a[k].trim3;
+		d[k].nedits = a[k].nedits; d[k].pad = 0; d[k].score = a[k].score;
+		for(uint32_t e = 0; e < a[k].nedits && e < H2G_MAX_EDITS; e++) d[k].edits[e] = a[k].edits[e];
+	}
+}
+// gathers [first, first+n) of a slot array into `out` (host); counts = the per-read record counts already on the host
+static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, const uint32_t* d_cnt, uint32_t cnt_stride, const uint32_t* h_cnt,
+                        uint32_t h_stride, size_t n, h2g_alnres* out, size_t cap, uint64_t* offs, int tmp_slot)
+{
+	uint64_t tot = 0;
+	for(size_t i = 0; i < n; i++) { offs[i] = tot; const uint32_t c = h_cnt[i * h_stride]; tot += c < slots ? c : slots; }
+	offs[n] = tot;
+	if(tot > cap) return H2G_ERR_ARG;
+	if(tot == 0) return H2G_OK;
+	void *d_offs = nullptr, *d_dense = nullptr;
+	int rc;
+	if((rc = tmp_buf(s, tmp_slot, (n + 1) * 8, &d_offs)) || (rc = tmp_buf(s, tmp_slot + 1, tot * sizeof(h2g_alnres), &d_dense))) return rc;
+	HIPCHK(hipMemcpyAsync(d_offs, offs, (n + 1) * 8, hipMemcpyHostToDevice, s->st));
+	hipLaunchKernelGGL(k_gather_aln, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->st, d_src, slots, d_cnt, cnt_stride,
+	                   (const unsigned long long*)d_offs, n, (h2g_alnres*)d_dense);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, d_dense, tot * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t aln_cap, uint64_t* aln_offs, size_t first, size_t n) {
+	if(!s || !res || !aln || !aln_offs || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
+	const h2g_status rc = h2g_align_fetch(s, res, nullptr, first, n);
+	if(rc != H2G_OK) return rc;
+	static_assert(offsetof(ReadOut, nselect) == 4, "ReadOut layout");
+	return gather_dense(s, s->d_aln + first * H2G_ALN_CAP, H2G_ALN_CAP, reinterpret_cast<const uint32_t*>(s->d_rout + first) + 1, sizeof(ReadOut) / 4,
+	                    &res[0].nselect, sizeof(h2g_read_result) / 4, n, aln, aln_cap, aln_offs, 0);
+}
+
+extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, size_t cap1, uint64_t* offs1,
+                                                  h2g_alnres* aln2, size_t cap2, uint64_t* offs2, size_t first, size_t n)
+{
+	if(!s || !res || !aln1 || !aln2 || !offs1 || !offs2 || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
+	const h2g_status rc = h2g_align_pairs_fetch(s, res, nullptr, nullptr, first, n);
+	if(rc != H2G_OK) return rc;
+	static_assert(offsetof(PairOut, nres) == 0, "PairOut layout");
+	int r;
+	if((r = gather_dense(s, s->d_paln[0] + first * H2G_PAIR_RES_CAP, H2G_PAIR_RES_CAP, reinterpret_cast<const uint32_t*>(s->d_pout + first), sizeof(PairOut) / 4,
+	                     &res[0].nres[0], sizeof(h2g_pair_result) / 4, n, aln1, cap1, offs1, 0))) return r;
+	return gather_dense(s, s->d_paln[1] + first * H2G_PAIR_RES_CAP, H2G_PAIR_RES_CAP, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
+	                    &res[0].nres[1], sizeof(h2g_pair_result) / 4, n, aln2, cap2, offs2, 2);
 }
 
 extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {

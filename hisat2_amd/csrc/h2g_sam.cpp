@@ -510,9 +510,9 @@ extern "C" void h2g_sam_set_no_unal(h2g_sam* S, int on) { if(S) S->no_unal = on 
 extern "C" void h2g_sam_set_secondary(h2g_sam* S, int on) { if(S) S->secondary = on != 0; }
 extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, double coeff) { if(S) { S->smType = type; S->smConst = c; S->smCoeff = coeff; } }
 
-extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
-                                              const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
-                                              const h2g_alnres* aln, char* out, size_t cap, size_t* used)
+static h2g_status format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                  const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
+                                  const h2g_alnres* aln, const uint64_t* aln_offs, char* out, size_t cap, size_t* used)
 {
 	if(!S || !codes || !offs || !nb || !noffs || !res || !aln || !used) return H2G_ERR_ARG;
 	auto one = [&](size_t i, std::string& o, Met& met) {
@@ -529,17 +529,26 @@ extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* c
 		if(nsel == 0) append_mate(*S, o, rd, nullptr, nullptr, nullptr, summ, fl, 0);
 		for(uint32_t k = 0; k < nsel; k++) {
 			fl.primary = k == 0;
-			append_mate(*S, o, rd, nullptr, &aln[i * H2G_ALN_CAP + k], nullptr, summ, fl, nsel);
+			append_mate(*S, o, rd, nullptr, (aln_offs ? aln + aln_offs[i] : aln + i * H2G_ALN_CAP) + k, nullptr, summ, fl, nsel);
 		}
 	};
 	return drive(S, n, one, out, cap, used);
 }
 
-extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
-                                            const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
-                                            const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
-                                            const h2g_pair_result* res, const h2g_alnres* aln1, const h2g_alnres* aln2,
-                                            uint32_t khits, char* out, size_t cap, size_t* used)
+extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                              const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
+                                              const h2g_alnres* aln, char* out, size_t cap, size_t* used)
+{ return format_unpaired(S, codes, offs, quals, nb, noffs, n, res, aln, nullptr, out, cap, used); }
+extern "C" h2g_status h2g_sam_format_unpaired_dense(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                                    const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
+                                                    const h2g_alnres* aln, const uint64_t* aln_offs, char* out, size_t cap, size_t* used)
+{ return aln_offs ? format_unpaired(S, codes, offs, quals, nb, noffs, n, res, aln, aln_offs, out, cap, used) : H2G_ERR_ARG; }
+
+static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
+                                const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
+                                const h2g_pair_result* res, const h2g_alnres* aln1, const uint64_t* ao1, const h2g_alnres* aln2, const uint64_t* ao2,
+                                uint32_t khits, char* out, size_t cap, size_t* used)
 {
 	if(!S || !codes1 || !offs1 || !nb1 || !noffs1 || !codes2 || !offs2 || !nb2 || !noffs2 || !res || !aln1 || !aln2 || !used) return H2G_ERR_ARG;
 	auto one = [&](size_t i, std::string& o, Met& met) {
@@ -549,8 +558,8 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 		const h2g_pair_result& pr = res[i];
 		Rd rd[2] = {{nb1 + noffs1[i], noffs1[i + 1] - noffs1[i], codes1 + offs1[i], offs1[i + 1] - offs1[i], quals1 ? quals1 + offs1[i] : nullptr},
 		            {nb2 + noffs2[i], noffs2[i + 1] - noffs2[i], codes2 + offs2[i], offs2[i + 1] - offs2[i], quals2 ? quals2 + offs2[i] : nullptr}};
-		const h2g_alnres* r1 = aln1 + i * H2G_PAIR_RES_CAP;
-		const h2g_alnres* r2 = aln2 + i * H2G_PAIR_RES_CAP;
+		const h2g_alnres* r1 = ao1 ? aln1 + ao1[i] : aln1 + i * H2G_PAIR_RES_CAP;
+		const h2g_alnres* r2 = ao2 ? aln2 + ao2[i] : aln2 + i * H2G_PAIR_RES_CAP;
 		const size_t n1 = std::min<size_t>(pr.nres[0], H2G_PAIR_RES_CAP), n2 = std::min<size_t>(pr.nres[1], H2G_PAIR_RES_CAP);
 		Flags f1, f2;
 		read_filters(rd[0], &f1.lenfilt, &f1.nfilt);
@@ -639,4 +648,20 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
 		}
 	};
 	return drive(S, n, one, out, cap, used);
+}
+
+extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                            const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
+                                            const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
+                                            const h2g_pair_result* res, const h2g_alnres* aln1, const h2g_alnres* aln2,
+                                            uint32_t khits, char* out, size_t cap, size_t* used)
+{ return format_paired(S, codes1, offs1, quals1, nb1, noffs1, codes2, offs2, quals2, nb2, noffs2, n, res, aln1, nullptr, aln2, nullptr, khits, out, cap, used); }
+extern "C" h2g_status h2g_sam_format_paired_dense(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                                  const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
+                                                  const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
+                                                  const h2g_pair_result* res, const h2g_alnres* aln1, const uint64_t* aln_offs1,
+                                                  const h2g_alnres* aln2, const uint64_t* aln_offs2, uint32_t khits, char* out, size_t cap, size_t* used)
+{
+	if(!aln_offs1 || !aln_offs2) return H2G_ERR_ARG;
+	return format_paired(S, codes1, offs1, quals1, nb1, noffs1, codes2, offs2, quals2, nb2, noffs2, n, res, aln1, aln_offs1, aln2, aln_offs2, khits, out, cap, used);
 }

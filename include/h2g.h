@@ -262,6 +262,12 @@ H2G_EXPORT h2g_status h2g_align_run(h2g_stream*, const h2g_align_params*);      
 H2G_EXPORT h2g_status h2g_align_fetch(h2g_stream*, h2g_read_result* res /* [n] */, h2g_alnres* aln /* [n*H2G_ALN_CAP] or NULL */,
                                       size_t first_read, size_t n_reads);
 
+/* Dense variant for callers that move the results over PCIe: only the nselect printed alignments of every read, back to back
+ * (gathered on the device); read i's records are aln[aln_offs[i] .. aln_offs[i+1]).  H2G_ERR_ARG if aln_cap is too small
+ * (aln_offs[n] then holds the count needed). */
+H2G_EXPORT h2g_status h2g_align_fetch_dense(h2g_stream*, h2g_read_result* res /* [n] */, h2g_alnres* aln, size_t aln_cap,
+                                            uint64_t* aln_offs /* [n+1] */, size_t first_read, size_t n_reads);
+
 /* ---- paired-end: HI_Aligner::go with both mates (initReads hi_aligner.h:4019; pairReads :5948; alignMate :5579) -- */
 /* Mate 2 of every read of the batch (same count as h2g_set_reads); names2 feed genRandSeed of mate 2. */
 H2G_EXPORT h2g_status h2g_set_mates(h2g_stream*, const uint8_t* codes2, const uint32_t* offs2, const char* quals2,
@@ -281,6 +287,10 @@ typedef struct {
 H2G_EXPORT h2g_status h2g_align_pairs_run(h2g_stream*, const h2g_align_params*);
 H2G_EXPORT h2g_status h2g_align_pairs_fetch(h2g_stream*, h2g_pair_result* res /* [n] */, h2g_alnres* aln1 /* [n*H2G_PAIR_RES_CAP] */,
                                             h2g_alnres* aln2 /* [n*H2G_PAIR_RES_CAP] */, size_t first_read, size_t n_reads);
+
+/* Dense variant: the nres[m] report events of each mate back to back (see h2g_align_fetch_dense) */
+H2G_EXPORT h2g_status h2g_align_pairs_fetch_dense(h2g_stream*, h2g_pair_result* res /* [n] */, h2g_alnres* aln1, size_t cap1, uint64_t* aln_offs1 /* [n+1] */,
+                                                  h2g_alnres* aln2, size_t cap2, uint64_t* aln_offs2 /* [n+1] */, size_t first_read, size_t n_reads);
 
 /* ---- counters (roofline numerators) ------------------------------------------------- */
 typedef struct {

@@ -49,6 +49,12 @@ H2G_EXPORT h2g_status h2g_sam_format_unpaired(const h2g_sam*, const uint8_t* cod
                                               const h2g_read_result* res, const h2g_alnres* aln /* [n*H2G_ALN_CAP] */,
                                               char* out, size_t cap, size_t* used);
 
+/* Same, over the dense layout of h2g_align_fetch_dense: read i's records start at aln[aln_offs[i]] */
+H2G_EXPORT h2g_status h2g_sam_format_unpaired_dense(const h2g_sam*, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                                    const char* name_bytes, const uint32_t* name_offs, size_t n_reads,
+                                                    const h2g_read_result* res, const h2g_alnres* aln, const uint64_t* aln_offs /* [n+1] */,
+                                                    char* out, size_t cap, size_t* used);
+
 /* Read pairs: the report events of h2g_align_pairs_fetch (per-mate lists + concordant pair list + PRNG state).  Runs the
  * sink's decision (concordant / discordant / unpaired, -k selection continuing the per-pair PRNG) and prints both mates. */
 H2G_EXPORT h2g_status h2g_sam_format_paired(const h2g_sam*, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
@@ -57,6 +63,13 @@ H2G_EXPORT h2g_status h2g_sam_format_paired(const h2g_sam*, const uint8_t* codes
                                             const uint32_t* name_offs2, size_t n_pairs, const h2g_pair_result* res,
                                             const h2g_alnres* aln1 /* [n*H2G_PAIR_RES_CAP] */, const h2g_alnres* aln2,
                                             uint32_t khits, char* out, size_t cap, size_t* used);
+/* Same, over the dense layout of h2g_align_pairs_fetch_dense */
+H2G_EXPORT h2g_status h2g_sam_format_paired_dense(const h2g_sam*, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                                  const char* name_bytes1, const uint32_t* name_offs1, const uint8_t* codes2,
+                                                  const uint32_t* offs2, const char* quals2, const char* name_bytes2,
+                                                  const uint32_t* name_offs2, size_t n_pairs, const h2g_pair_result* res,
+                                                  const h2g_alnres* aln1, const uint64_t* aln_offs1, const h2g_alnres* aln2,
+                                                  const uint64_t* aln_offs2, uint32_t khits, char* out, size_t cap, size_t* used);
 #ifdef __cplusplus
 }
 #endif

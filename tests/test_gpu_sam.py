@@ -99,3 +99,52 @@ def test_command_line_skip_upto_trim_no_unal():
 def test_command_line_refuses_what_is_not_built(tmp_path):
     r = subprocess.run([CLI, "-x", "nonexistent", "-U", "x.fq"], capture_output=True, text=True)
     assert r.returncode != 0 and "spliced alignment is not built" in r.stderr
+
+
+def test_dense_fetch_equals_slot_fetch(g1_index, golden_dir):
+    """h2g_align_fetch_dense / h2g_align_pairs_fetch_dense return the same records as the slot layout, back to back"""
+    import ctypes as C
+    import h2o_py as H
+    from hisat2_amd import api
+    names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
+    codes = np.concatenate(seqs)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in seqs])]).astype(np.uint32)
+    ix = api.Index(g1_index)
+    st = api.Stream(ix, max_reads=len(seqs), max_bases=codes.size)
+    st.set_reads(codes, offs)
+    st.set_read_names(names)
+    st.align_run()
+    res, aln = st.align_fetch()
+    dres, daln, doffs = st.align_fetch_dense()
+    assert res.tobytes() == dres.tobytes()
+    tot = 0
+    for i in range(len(seqs)):
+        assert int(doffs[i]) == tot
+        for k in range(int(res[i]["nselect"])):
+            a, b = aln[i * api.ALN_CAP + k], daln[tot + k]
+            assert (a.fw, a.tidx, a.toff, a.len, a.trim5, a.trim3, a.nedits, a.score) == (b.fw, b.tidx, b.toff, b.len, b.trim5, b.trim3, b.nedits, b.score)
+            assert bytes(a.edits)[:12 * a.nedits] == bytes(b.edits)[:12 * a.nedits]
+        tot += int(res[i]["nselect"])
+    assert int(doffs[len(seqs)]) == tot and tot > 300
+    st.close()
+    _, s1 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_1.fa.gz"))
+    _, s2 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_2.fa.gz"))
+    c1, o1 = np.concatenate(s1), np.concatenate([[0], np.cumsum([len(r) for r in s1])]).astype(np.uint32)
+    c2, o2 = np.concatenate(s2), np.concatenate([[0], np.cumsum([len(r) for r in s2])]).astype(np.uint32)
+    q = [str(i) for i in range(len(s1))]
+    st = api.Stream(ix, max_reads=len(s1), max_bases=max(c1.size, c2.size))
+    st.set_reads(c1, o1)
+    st.set_read_names(q)
+    st.set_mates(c2, o2, q)
+    st.align_pairs_run()
+    pres, a1, a2 = st.align_pairs_fetch()
+    dpres, d1, do1, d2, do2 = st.align_pairs_fetch_dense()
+    assert bytes(pres) == bytes(dpres)
+    for m, (slot, dense, doff) in enumerate(((a1, d1, do1), (a2, d2, do2))):
+        for i in range(len(s1)):
+            for k in range(min(pres[i].nres[m], api.PAIR_RES_CAP)):
+                a, b = slot[i * api.PAIR_RES_CAP + k], dense[int(doff[i]) + k]
+                assert (a.fw, a.tidx, a.toff, a.len, a.nedits, a.score) == (b.fw, b.tidx, b.toff, b.len, b.nedits, b.score)
+                assert bytes(a.edits)[:12 * a.nedits] == bytes(b.edits)[:12 * a.nedits]
+    st.close()
+    ix.close()
