@@ -275,6 +275,8 @@ def lib():
     L.h2g_set_mates.argtypes = [vp, vp, vp, vp, C.c_char_p, vp, C.c_size_t]
     L.h2g_align_pairs_run.argtypes = [vp, P(AlignParams)]
     L.h2g_align_pairs_fetch.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t]
+    L.h2g_align_fetch_dense.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t]
+    L.h2g_align_pairs_fetch_dense.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t]
     _lib = L
     return L
 

@@ -306,7 +306,9 @@ int main(int argc, char** argv) {
 	h2g_sam_set_secondary(sam, (int)P.secondary);
 	FILE* out = outfn.empty() ? stdout : fopen(outfn.c_str(), "wb");
 	if(!out) { fprintf(stderr, "cannot open %s\n", outfn.c_str()); return 1; }
-	std::vector<char> buf(1 << 20);
+	// output text buffer: raw storage, grown without value-initialising hundreds of MB per batch
+	struct RawBuf { char* p = nullptr; size_t n = 0; void resize(size_t m) { if(m > n) { free(p); p = (char*)malloc(m); n = m; if(!p) { fprintf(stderr, "out of memory\n"); exit(1); } } } char* data() { return p; } size_t size() const { return n; } ~RawBuf() { free(p); } } buf;
+	buf.resize(1 << 20);
 	if(!nohead) {
 		const size_t need = h2g_sam_header(sam, cmdline.c_str(), nullptr, 0);
 		buf.resize(need + 1);
@@ -325,7 +327,7 @@ int main(int argc, char** argv) {
 	h2g_stream* st = nullptr;
 	Batch A[2], B[2];                                 // double buffer: batch k+1 is parsed while batch k is on the GPU
 	uint64_t nreads = 0, naligned = 0, novf = 0;
-	double t_gpu = 0, t_fmt = 0, t_parse = 0;
+	double t_gpu = 0, t_fmt = 0, t_parse = 0, t_up = 0, t_fetch = 0, t_stream = 0;
 	size_t stream_reads = 0, stream_bases = 0;
 	int cur = 0;
 	A[0].clear(); B[0].clear();
@@ -346,15 +348,19 @@ int main(int argc, char** argv) {
 		if(!st || n > stream_reads || bases > stream_bases) {
 			if(st) h2g_stream_free(st);
 			stream_reads = n > batch ? n : batch; stream_bases = bases + bases / 4 + 1024;
+			const double ts = now();
 			if(h2g_stream_create(ix, stream_reads, stream_bases, &st) != H2G_OK) die("cannot create the device stream");
+			t_stream += now() - ts;
 		}
 		const double tg = now();
+		double tq0 = now();
 		if(h2g_set_reads(st, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, n) != H2G_OK) die("h2g_set_reads");
 		if(h2g_set_read_names(st, a.names.data(), a.noffs.data(), n) != H2G_OK) die("h2g_set_read_names");
 		if(paired) {
 			if(h2g_set_mates(st, b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n) != H2G_OK) die("h2g_set_mates");
 			if(h2g_align_pairs_run(st, &P) != H2G_OK) die("h2g_align_pairs_run");
 		} else if(h2g_align_run(st, &P) != H2G_OK) die("h2g_align_run");
+		t_up += now() - tq0;
 		// ingest the next batch on this thread while the kernel runs (the run calls are asynchronous)
 		const int nxt = cur ^ 1;
 		A[nxt].clear(); B[nxt].clear();
@@ -365,6 +371,7 @@ int main(int argc, char** argv) {
 		t_parse += now() - tp;
 		size_t used = 0;
 		if(paired) {
+			tq0 = now();
 			pres.resize(n); ao1.resize(n + 1); ao2.resize(n + 1);
 			if(aln.size() < 2 * n + 64) aln.resize(2 * n + 64);
 			if(aln2.size() < 2 * n + 64) aln2.resize(2 * n + 64);
@@ -374,6 +381,7 @@ int main(int argc, char** argv) {
 				if(aln2.size() < ao2[n]) aln2.resize(ao2[n]);
 				if(h2g_align_pairs_fetch_dense(st, pres.data(), aln.data(), aln.size(), ao1.data(), aln2.data(), aln2.size(), ao2.data(), 0, n) != H2G_OK) die("h2g_align_pairs_fetch_dense");
 			}
+			t_fetch += now() - tq0;
 			t_gpu += now() - tg;
 			const double tf = now();
 			buf.resize(n * 1400 + 6 * (a.codes.size() + b.codes.size()) + 4096);
@@ -390,12 +398,14 @@ int main(int argc, char** argv) {
 			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; novf += pres[i].overflow != 0; }
 			t_fmt += now() - tf;
 		} else {
+			tq0 = now();
 			res.resize(n); ao1.resize(n + 1);
 			if(aln.size() < n + n / 4 + 64) aln.resize(n + n / 4 + 64);
 			if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) {
 				if(aln.size() < ao1[n]) aln.resize(ao1[n]);
 				if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) die("h2g_align_fetch_dense");
 			}
+			t_fetch += now() - tq0;
 			t_gpu += now() - tg;
 			const double tf = now();
 			buf.resize(n * 700 + 3 * a.codes.size() + 4096);
@@ -426,8 +436,8 @@ int main(int argc, char** argv) {
 	(void)naligned; (void)nreads;
 	if(novf) fprintf(stderr, "Warning: %llu %s exceeded a fixed device capacity (h2g overflow bit); rerun them with the reference aligner\n",
 	                 (unsigned long long)novf, paired ? "pairs" : "reads");
-	if(getenv("H2G_CLI_TIMING")) fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (includes overlapped parsing %.2f s), SAM formatting %.2f s, total %.2f s\n", t1 - t0, t_gpu,
-	        t_parse, t_fmt, t2 - t0);
+	if(getenv("H2G_CLI_TIMING")) fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (includes overlapped parsing %.2f s), SAM formatting %.2f s, total %.2f s [stream create %.2f, upload+launch %.2f, wait+fetch %.2f]\n", t1 - t0, t_gpu,
+	        t_parse, t_fmt, t2 - t0, t_stream, t_up, t_fetch);
 	if(st) h2g_stream_free(st);
 	h2g_sam_close(sam);
 	h2g_index_free(ix);
