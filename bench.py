@@ -244,7 +244,7 @@ def main():
         try:
             def _pmc(fn, ctr):
                 for ln in open(os.path.join(ROOT, "profiles", fn)):
-                    if "k_align<4, false>" in ln and ctr in ln:
+                    if "k_align<" in ln and ", false>" in ln and "k_align<3," not in ln and ctr in ln:
                         return float(ln.split()[-1])
                 return None
             fk, wk = _pmc("r01_k_pmc_fetch.txt", "FETCH_SIZE"), _pmc("r01_k_pmc_write.txt", "WRITE_SIZE")

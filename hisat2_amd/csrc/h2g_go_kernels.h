@@ -8,6 +8,20 @@
 
 using namespace h2g;
 
+// waves per SIMD each go() kernel is compiled for (register budget = 512 / waves; measured on the bench workload)
+#ifndef H2G_GRAPH_WAVES
+#define H2G_GRAPH_WAVES 5
+#endif
+#ifndef H2G_LINEAR_WAVES
+#define H2G_LINEAR_WAVES 5
+#endif
+#ifndef H2G_LINEAR_PE_WAVES
+#define H2G_LINEAR_PE_WAVES 3
+#endif
+#ifndef H2G_GRAPH_PE_WAVES
+#define H2G_GRAPH_PE_WAVES 2
+#endif
+
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
 	for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
 	if((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref,
 
 // lane = one read pair; both mates are packed into LDS (mate 2 behind mate 1)
 template <bool GRAPH, int WIDE = 0>   // WIDE only tags the linear build with AL_MAX_GHITS = 20 (-k up to 10, --sensitive)
-__global__ __launch_bounds__(256, GRAPH ? 2 : 3) void k_align_pairs(DGfm g, DRef ref, DLocalSet ls, DReads rd1, DReads rd2, AlnParams P,
+__global__ __launch_bounds__(256, GRAPH ? H2G_GRAPH_PE_WAVES : H2G_LINEAR_PE_WAVES) void k_align_pairs(DGfm g, DRef ref, DLocalSet ls, DReads rd1, DReads rd2, AlnParams P,
                                                         const char* names1, const uint32_t* noffs1, const char* names2,
                                                         const uint32_t* noffs2, AlignWS* pool, PairOut* outs, h2g_alnres* aln1,
                                                         h2g_alnres* aln2, unsigned long long* counters, uint8_t* sw_base, size_t sw_stride, GraphArgs ga)
@@ -142,9 +156,9 @@ __global__ __launch_bounds__(256, GRAPH ? 2 : 3) void k_align_pairs(DGfm g, DRef
 }
 
 #if defined(H2G_GO_DECLARE_ONLY)
-extern template __global__ void k_align<4, false>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
+extern template __global__ void k_align<H2G_LINEAR_WAVES, false>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
                                                   unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-extern template __global__ void k_align<2, true>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
+extern template __global__ void k_align<H2G_GRAPH_WAVES, true>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
                                                  unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
 extern template __global__ void k_align_pairs<false>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
                                                      const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);

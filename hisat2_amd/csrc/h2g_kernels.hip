@@ -1247,7 +1247,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	// 2 waves per SIMD on every CU: enough lanes to cover HBM latency, bounded workspace (sizeof(AlignWS) each)
 	const unsigned block = 256;
 	size_t want = (s->n_reads + block - 1) / block;
-	const size_t maxblocks = 256 * (size_t)(!s->ix->dg.linear ? 2 : getenv("H2G_ALIGN_OCC") ? (atoi(getenv("H2G_ALIGN_OCC")) >= 3 ? 4 : 2) : 4)   /* resident blocks per CU */;
+	const size_t maxblocks = 256 * (size_t)(!s->ix->dg.linear ? H2G_GRAPH_WAVES : p->kseeds > 10 ? 3 : H2G_LINEAR_WAVES)   /* resident blocks per CU */;
 	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	const size_t nthreads = (size_t)grid * block;
 	{
@@ -1294,9 +1294,9 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
 #define H2G_LAUNCH_ALIGN(W, G) hipLaunchKernelGGL((k_align<W, G>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, \
 		s->d_names, s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride, ga)
-	if(!s->ix->dg.linear) H2G_LAUNCH_ALIGN(2, true);        // graph: the out-of-line graph functions need ~230 VGPRs
+	if(!s->ix->dg.linear) H2G_LAUNCH_ALIGN(H2G_GRAPH_WAVES, true);        // graph: the out-of-line graph functions need ~230 VGPRs
 	else if(p->kseeds > 10) H2G_LAUNCH_ALIGN(3, false);     // linear, wide genome-hit list (-k > 5, --sensitive)
-	else H2G_LAUNCH_ALIGN(4, false);
+	else H2G_LAUNCH_ALIGN(H2G_LINEAR_WAVES, false);
 #undef H2G_LAUNCH_ALIGN
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	HIPCHK(hipGetLastError());
@@ -1359,7 +1359,7 @@ extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params*
 	HIPCHK(hipSetDevice(s->ix->device));
 	const unsigned block = 256;
 	size_t want = (s->n_reads + block - 1) / block;
-	const size_t maxblocks = 256 * (size_t)(s->ix->dg.linear ? 3 : 2);
+	const size_t maxblocks = 256 * (size_t)(s->ix->dg.linear ? H2G_LINEAR_PE_WAVES : H2G_GRAPH_PE_WAVES);
 	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	const size_t nthreads = (size_t)grid * block;
 	{
