@@ -247,10 +247,10 @@ def main():
                     if "k_align<" in ln and ", false>" in ln and "k_align<3," not in ln and ctr in ln:
                         return float(ln.split()[-1])
                 return None
-            fk, wk = _pmc("r01_k_pmc_fetch.txt", "FETCH_SIZE"), _pmc("r01_k_pmc_write.txt", "WRITE_SIZE")
+            fk, wk = _pmc("r01_m_pmc_fetch.txt", "FETCH_SIZE"), _pmc("r01_m_pmc_write.txt", "WRITE_SIZE")
             if fk is not None and wk is not None and a.reads == 1_000_000:
                 roofline["traffic"] = int(fk * 1024 * 2 + wk * 1024)
-                roofline["traffic_source"] = ("profiles/r01_k_pmc_fetch.txt + r01_k_pmc_write.txt (rocprofv3 --pmc, same workload, per launch): "
+                roofline["traffic_source"] = ("profiles/r01_m_pmc_fetch.txt + r01_m_pmc_write.txt (rocprofv3 --pmc, same workload, per launch): "
                                               "2 x FETCH_SIZE + WRITE_SIZE; ~8x the algorithmic bytes = per-lane workspace traffic, DESIGN.md §3")
         except OSError:
             pass
