@@ -10,6 +10,7 @@
 // so a side is exactly one 128 B L2 line of MI355X (MI355X_MICROARCH.md: 128 B lines) — the reason the
 // graph rank reaches a higher fraction of HBM peak than the 64 B linear side.
 #pragma once
+#include <vector>
 #include "h2g_core.h"
 
 namespace h2g {
@@ -734,12 +735,34 @@ H2G_HDN uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, 
 // (pos = last deleted base, reversed = 1 in the low byte of seq), sorted by ALT::operator< (alt.h:88-102).
 enum { H2G_ALT_SNP_SGL = 1, H2G_ALT_SNP_INS = 2, H2G_ALT_SNP_DEL = 3, H2G_ALT_SNP_ALT = 4, H2G_ALT_SPLICESITE = 5, H2G_ALT_EXON = 6 };
 struct DAlt { uint32_t pos, type, len, pad; uint64_t seq; };
-struct DAlts { const DAlt* a; uint32_t n; uint32_t maxAltsTried; };   // GraphPolicy::maxAltsTried = 16 (hisat2.cpp:521)
+struct DAlts {
+	const DAlt* a; uint32_t n; uint32_t maxAltsTried;      // GraphPolicy::maxAltsTried = 16 (hisat2.cpp:521)
+	// optional position index: bucket[b] = first ALT with pos >= b << H2G_ALT_BUCKET_SHIFT, so that the lower bound is one load
+	// plus a scan of the few ALTs of the bucket instead of ~log2(n) dependent loads (15 at E. coli scale, 24 at GRCh38+SNP scale)
+	const uint32_t* bucket = nullptr; uint32_t nbucket = 0;
+};
+#define H2G_ALT_BUCKET_SHIFT 7
 
 H2G_HD uint32_t alt_lobound(const DAlts& A, uint32_t pos) {   // EList::bsearchLoBound with a type-NONE key: first pos >= key
+	if(A.bucket) {
+		const uint32_t b = pos >> H2G_ALT_BUCKET_SHIFT;
+		if(b >= A.nbucket) return A.n;
+		uint32_t i = A.bucket[b];
+		while(i < A.n && A.a[i].pos < pos) i++;
+		return i;
+	}
 	uint32_t lo = 0, hi = A.n;
 	while(lo < hi) { const uint32_t m = (lo + hi) >> 1; if(A.a[m].pos < pos) lo = m + 1; else hi = m; }
 	return lo;
+}
+// host: the bucket table for a sorted ALT list (one extra entry so that every pos below the last bucket end resolves)
+inline void alt_buckets(const DAlt* a, uint32_t n, std::vector<uint32_t>& out) {
+	out.clear();
+	if(n == 0) return;
+	const uint32_t nb = (a[n - 1].pos >> H2G_ALT_BUCKET_SHIFT) + 2;
+	out.assign(nb, n);
+	uint32_t i = 0;
+	for(uint32_t b = 0; b < nb; b++) { while(i < n && (a[i].pos >> H2G_ALT_BUCKET_SHIFT) < b) i++; out[b] = i; }
 }
 
 H2G_HD int char_base(uint8_t ch) { return ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 4 : 0; }   // asc2dna (alphabet.cpp:298)

@@ -153,6 +153,10 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		if((s = upload(ix, ix->host.alts, &da))) { h2g_index_free(ix); return s; }
 		ix->dalts.a = reinterpret_cast<const DAlt*>(da);
 		ix->dalts.n = (uint32_t)ix->host.alts.size();
+		std::vector<uint32_t> bk;
+		alt_buckets(reinterpret_cast<const DAlt*>(ix->host.alts.data()), ix->dalts.n, bk);
+		const uint32_t* dbk = nullptr;
+		if(!bk.empty()) { if((s = upload(ix, bk, &dbk))) { h2g_index_free(ix); return s; } ix->dalts.bucket = dbk; ix->dalts.nbucket = (uint32_t)bk.size(); }
 	}
 	memset(&ix->dls, 0, sizeof ix->dls);
 	if(o.load_local && !ix->host.local.empty()) {
@@ -1273,7 +1277,6 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
 	const uint32_t* perm = nullptr;
 	static const int sort_mode = getenv("H2G_ALIGN_SORT") ? atoi(getenv("H2G_ALIGN_SORT")) : 0;
 	static const int dyn_mode = getenv("H2G_ALIGN_DYN") ? atoi(getenv("H2G_ALIGN_DYN")) : 0;
-	static const int occ_mode = getenv("H2G_ALIGN_OCC") ? atoi(getenv("H2G_ALIGN_OCC")) : 4;
 	if(sort_mode && s->ix->dg.linear) {
 		// seed stage (partialSearch both strands from offset 0 -> coordinates -> 0-mm extension) + Hamming distance
 		// of the whole read as a cost classifier; bucket read ids by class, heaviest first

@@ -25,6 +25,7 @@ struct Emu {
 	LocalPack lp;
 	DLocalSet dls;
 	DAlts dalts;
+	std::vector<uint32_t> alt_bk;
 	uint32_t bowtie2_dp = 0;
 	bool has_params = false;
 	h2g_align_params params;
@@ -59,6 +60,8 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dr.nrefs = r.nrefs;
 	e->dalts.a = reinterpret_cast<const DAlt*>(e->host.alts.data()); e->dalts.n = g.p.linear ? 0 : (uint32_t)e->host.alts.size();
 	e->dalts.maxAltsTried = 16;
+	alt_buckets(e->dalts.a, e->dalts.n, e->alt_bk);
+	if(!e->alt_bk.empty()) { e->dalts.bucket = e->alt_bk.data(); e->dalts.nbucket = (uint32_t)e->alt_bk.size(); }
 	pack_local(e->host, e->lp);
 	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data(), e->lp.zoffs.data());
 	*out = e;
