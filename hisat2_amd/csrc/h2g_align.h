@@ -429,7 +429,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 	uint32_t maxscorei = H2G_MAX;
 	int64_t maxscore = INT64_MIN;
 	if(ins || del) {
-		if(len > 1024) return false;
+		if(len > 512) { a->overflow = 1; return false; }   // sc1 / sc2 capacity (reads up to 512 bp scan exactly; longer ones are flagged)
 		const int inslen = ins ? (int)(rddif - refdif) : 0, dellen = del ? (int)(refdif - rddif) : 0;
 		int64_t gap_penalty;
 		if(ins) gap_penalty = -((int64_t)(sc.rfGapConst + sc.rfGapLinear) + (int64_t)sc.rfGapLinear * (inslen - 1));
@@ -635,7 +635,7 @@ struct AlignWS {
 	uint32_t   overflow;
 	uint32_t   nrank, nside, nsteps, nframes_max;   // nrank, nside adjacent: gfm_search updates both through &nrank
 	h2g_ghit   tmp, tmp2;                        // scratch hits
-	int64_t    sc1[256], sc2[256];               // combineWith temp_scores
+	int64_t    sc1[512], sc2[512];               // combineWith temp_scores
 	Frame      stack[AL_MAX_DEPTH];
 };
 

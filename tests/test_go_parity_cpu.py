@@ -48,6 +48,9 @@ def test_golden_sam(g1_index, golden_dir):
     dict(seed=963, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, fastq=True, extra=("--secondary", "--sp", "3,1", "--score-min", "C,-18")),
     dict(seed=964, nreads=5000, rdlen=101, sub=0.025, indel=0.004, nrate=0.002, snps=60, extra=("--no-softclip", "-k", "4", "--mp", "5,1")),
     dict(seed=965, nreads=5000, rdlen=101, sub=0.03, indel=0.005, nrate=0.002, fastq=True, extra=("--sensitive",)),
+    # reads longer than 256 bp: the combineWith score scan holds up to 512 positions (longer reads set the overflow bit)
+    dict(seed=995, nreads=2500, rdlen=300, sub=0.01, indel=0.003, nrate=0.001),
+    dict(seed=996, nreads=2500, rdlen=300, sub=0.01, indel=0.003, nrate=0.001, snps=100),
 ])
 def test_live_reference(case):
     """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""

@@ -63,6 +63,7 @@ def _backend(base, reads, qnames, refnames, bowtie2_dp=0, quals=None, options=()
     dict(seed=202, nreads=10000, rdlen=150, sub=0.01, indel=0.001, nrate=0.001),
     dict(seed=203, nreads=10000, rdlen=101, sub=0.003, indel=0.0, nrate=0.0, lens=(120000,), repeats=300, gaps=0),
     dict(seed=204, nreads=5000, rdlen=36, sub=0.01, indel=0.0, nrate=0.0),
+    dict(seed=205, nreads=6000, rdlen=300, sub=0.01, indel=0.003, nrate=0.001),
 ])
 def test_live_reference(case):
     import fuzz_align as F
