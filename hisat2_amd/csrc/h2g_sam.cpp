@@ -75,7 +75,14 @@ struct Summ {         // AlnSetSumm (aligner_result.cpp:1167-1260)
 };
 struct Rd { const char* name; uint32_t namelen; const uint8_t* codes; uint32_t len; const char* qual; };
 
-void put(std::string& o, int64_t v) { char b[32]; snprintf(b, sizeof b, "%lld", (long long)v); o += b; }
+void put(std::string& o, int64_t v) {     // itoa10
+	char b[24];
+	int k = 24;
+	uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v;
+	do { b[--k] = (char)('0' + u % 10); u /= 10; } while(u);
+	if(v < 0) b[--k] = '-';
+	o.append(b + k, 24 - k);
+}
 
 // Scoring::nFilter / length filter as the worker applies them (hisat2.cpp:3404-3440): which YF:Z flag an unaligned read gets
 void read_filters(const Rd& r, bool* lenfilt, bool* nfilt) {
@@ -130,7 +137,8 @@ void invert(std::vector<Ed>& e, uint32_t sz) {
 struct Stacked { std::string ref, rel, read; std::vector<uint8_t> snp; uint32_t trimLS = 0, trimRS = 0; };
 // AlnRes::initStacked aligner_result.h:1856 + StackedAln::init aligner_result.cpp:660-728 + leftAlign(false) :746-791
 void stack_alignment(const h2g_alnres& r, const std::string& seq /* aligned strand, ASCII */, Stacked& st) {
-	std::vector<Ed> ed(r.nedits);
+	static thread_local std::vector<Ed> ed;
+	ed.resize(r.nedits);
 	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = r.edits[i].pos; ed[i].chr = (char)r.edits[i].chr; ed[i].qchr = (char)r.edits[i].qchr; ed[i].type = r.edits[i].type; ed[i].snp = r.edits[i].snp; }
 	// h2g_alnres trims are those of the GenomeHit (left / right of the aligned strand) == trimLS / trimRS after the swap
 	st.trimLS = r.trim5; st.trimRS = r.trim3;
@@ -253,8 +261,8 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
                  const Summ& summ, const Flags& fl, uint64_t nh)
 {
 	if(rs == nullptr && S.no_unal) return;                 // aln_sink.h:3040
-	Stacked st;
-	std::string seq, qual;
+	static thread_local Stacked st;                       // scratch reused across lines (no per-line allocations)
+	static thread_local std::string seq, qual;
 	seq_ascii(rd, rs == nullptr || rs->fw, seq, qual);
 	if(rs) stack_alignment(*rs, seq, st);
 	put_read_name(o, rd, fl.partOfPair());
@@ -338,7 +346,8 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	o += "\tNH:i:"; put(o, (int64_t)nh);
 	// Zs:Z (sam.h:985-1030): the known variants the alignment goes through, positions relative to the previous one
 	{
-		std::vector<Ed> ed(rs->nedits);
+		static thread_local std::vector<Ed> ed;
+		ed.resize(rs->nedits);
 		for(uint32_t i = 0; i < rs->nedits; i++) { ed[i].pos = rs->edits[i].pos; ed[i].type = rs->edits[i].type; ed[i].snp = rs->edits[i].snp; ed[i].chr = ed[i].qchr = 0; }
 		const uint32_t len_trimmed = rd.len - rs->trim5 - rs->trim3;
 		if(!rs->fw) invert(ed, len_trimmed);
