@@ -318,6 +318,24 @@ def main():
             gc_ = gst.counters()
             graph_leg = {"reads": a.reads, "variants": len(var), "ms_per_step": gdt * 1e3, "reads_per_s": a.reads / gdt, "kernel_ms": float(gc_.ms_align),
                          "aligned": int(gc_.n_aligned), "overflow": int(gc_.n_overflow), "numSides": int(gix.info.numSides), "sideSz": int(gix.info.sideSz)}
+            # paired-end on the graph index (the shape of BASELINE configs[3]): half as many pairs
+            gnp = a.reads // 2
+            gm1, gm2 = synth.make_pairs(alt, gnp, 101, SEED + 4343, frag_mean=300, frag_sd=30, sub_rate=0.005)
+            gq = [str(i) for i in range(gnp)]
+            gc1, go1 = synth.flatten_reads(gm1)
+            gc2, go2 = synth.flatten_reads(gm2)
+            gpst = api.Stream(gix, max_reads=gnp, max_bases=gc1.size)
+            gpst.set_reads(gc1, go1); gpst.set_read_names(gq); gpst.set_mates(gc2, go2, gq)
+            gpst.align_pairs_run(); gpst.sync()
+            t0g = time.perf_counter()
+            for _ in range(3):
+                gpst.align_pairs_run()
+            gpst.sync()
+            gpdt = (time.perf_counter() - t0g) / 3
+            gpc = gpst.counters()
+            graph_leg["paired_end"] = {"pairs": gnp, "ms_per_step": gpdt * 1e3, "reads_per_s": 2 * gnp / gpdt, "kernel_ms": float(gpc.ms_align),
+                                       "pairs_with_concordant": int(gpc.n_aligned), "pairs_overflow": int(gpc.n_overflow)}
+            gpst.close()
             exe = os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")
             if os.path.exists(exe) and not a.no_cpu_baseline:
                 import sam_util as SU

@@ -19,7 +19,7 @@ using namespace h2g;
 #define H2G_LINEAR_PE_WAVES 3
 #endif
 #ifndef H2G_GRAPH_PE_WAVES
-#define H2G_GRAPH_PE_WAVES 2
+#define H2G_GRAPH_PE_WAVES 3
 #endif
 
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
