@@ -148,3 +148,47 @@ def test_dense_fetch_equals_slot_fetch(g1_index, golden_dir):
                 assert bytes(a.edits)[:12 * a.nedits] == bytes(b.edits)[:12 * a.nedits]
     st.close()
     ix.close()
+
+
+@needs_ref
+def test_command_line_ragged_and_odd_reads():
+    """ragged lengths (1 .. 260 bp), lower case, IUPAC codes, names with blanks / over 255 characters, all-N and very short reads"""
+    import fuzz_align as F
+    from test_gpu_align import _backend
+    from hisat2_amd import synth
+    bad, tmp = F.run_case(verbose=2, backend=_backend, seed=431, nreads=500, rdlen=101, sub=0.01, indel=0.001, nrate=0.001)
+    assert bad == 0
+    rng = np.random.default_rng(17)
+    names, seqs = read_fa(os.path.join(tmp, "r.fa"))
+    contig = "".join(l.strip() for l in open(os.path.join(tmp, "g.fa")) if l[0] != ">")
+    fq = os.path.join(tmp, "odd.fq")
+    with open(fq, "w") as f:
+        for i in range(3000):
+            L = int(rng.choice([1, 2, 5, 12, 19, 20, 21, 33, 50, 75, 101, 150, 200, 260]))
+            p = int(rng.integers(0, len(contig) - 300))
+            s = list(contig[p:p + L].replace("N", "A"))
+            for k in range(len(s)):
+                if rng.random() < 0.02:
+                    s[k] = "ACGT"[int(rng.integers(0, 4))]
+                if rng.random() < 0.01:
+                    s[k] = "RYKMN"[int(rng.integers(0, 5))]
+            s = "".join(s)
+            if i % 7 == 0:
+                s = s.lower()
+            if i % 97 == 0:
+                s = "N" * len(s)
+            if rng.random() < 0.5:
+                s = s[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+            name = ("read %d with blanks\tand a tab" % i) if i % 5 == 0 else ("r%d" % i) if i % 11 else "x" * 300 + str(i)
+            q = "".join(chr(int(c)) for c in rng.integers(35, 74, size=len(s)))
+            f.write("@%s\n%s\n+\n%s\n" % (name, s, q))
+    ref = os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")
+    subprocess.run([ref, "-q", "-p", "1", "--no-spliced-alignment", "-x", os.path.join(tmp, "g"), "-U", fq, "-S", os.path.join(tmp, "ref3.sam")], check=True,
+                   stderr=open(os.path.join(tmp, "ref3.err"), "w"))
+    subprocess.run([CLI, "-q", "-p", "3", "--no-spliced-alignment", "-x", os.path.join(tmp, "g"), "-U", fq, "-S", os.path.join(tmp, "amd3.sam"), "--batch", "700"],
+                   check=True, stderr=open(os.path.join(tmp, "amd3.err"), "w"))
+    want = SL.body_lines(os.path.join(tmp, "ref3.sam"))
+    assert len(want) >= 3000
+    assert diff_lines(SL.body_lines(os.path.join(tmp, "amd3.sam")), want) == 0
+    ref_err = [l for l in open(os.path.join(tmp, "ref3.err")) if not l.startswith("Warning")]
+    assert open(os.path.join(tmp, "amd3.err")).read() == "".join(ref_err)
