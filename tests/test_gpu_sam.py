@@ -192,3 +192,30 @@ def test_command_line_ragged_and_odd_reads():
     assert diff_lines(SL.body_lines(os.path.join(tmp, "amd3.sam")), want) == 0
     ref_err = [l for l in open(os.path.join(tmp, "ref3.err")) if not l.startswith("Warning")]
     assert open(os.path.join(tmp, "amd3.err")).read() == "".join(ref_err)
+
+
+@needs_ref
+@pytest.mark.parametrize("snps", [0, 70])
+def test_command_line_paired_fastq_unequal_mates(monkeypatch, snps):
+    """pairs from FASTQ files (quality-dependent penalties on both mates), mate 2 shorter than mate 1"""
+    import fuzz_pairs as F
+    from test_gpu_pairs import _backend
+    from hisat2_amd import api
+    monkeypatch.setattr(F, "SNPS", snps)
+    bad, tmp = F.run_case(verbose=2, backend=_backend, stride=api.PAIR_RES_CAP, seed=441 + snps, npairs=6000, rdlen=101, sub=0.025, mutate="nmask")
+    assert bad == 0
+    rng = np.random.default_rng(23)
+    for m, cut in (("1", 101), ("2", 76)):
+        names, seqs = read_fa(os.path.join(tmp, "r%s.fa" % m))
+        with open(os.path.join(tmp, "q%s.fq" % m), "w") as f:
+            for nm, s in zip(names, seqs):
+                s = s[:cut]
+                q = rng.choice(np.array([2, 8, 15, 20, 25, 30, 37, 40]) + 33, size=len(s))
+                f.write("@%s/%s\n%s\n+\n%s\n" % (nm, m, "".join("ACGTN"[c] for c in s), "".join(chr(int(c)) for c in q)))
+    ref = os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")
+    args = ["-q", "--no-spliced-alignment", "-x", os.path.join(tmp, "g"), "-1", os.path.join(tmp, "q1.fq"), "-2", os.path.join(tmp, "q2.fq")]
+    subprocess.run([ref, "-p", "1"] + args + ["-S", os.path.join(tmp, "ref4.sam")], check=True, stderr=open(os.path.join(tmp, "ref4.err"), "w"))
+    subprocess.run([CLI, "-p", "4", "--batch", "2500"] + args + ["-S", os.path.join(tmp, "amd4.sam")], check=True, stderr=open(os.path.join(tmp, "amd4.err"), "w"))
+    want = SL.body_lines(os.path.join(tmp, "ref4.sam"))
+    assert diff_lines(SL.body_lines(os.path.join(tmp, "amd4.sam")), want) == 0
+    assert open(os.path.join(tmp, "amd4.err")).read() == "".join(l for l in open(os.path.join(tmp, "ref4.err")) if not l.startswith("Warning"))
