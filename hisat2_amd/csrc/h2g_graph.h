@@ -40,6 +40,14 @@ H2G_HD Side128 load_side128(const uint8_t* p) {
 	return s;
 }
 
+// graph LF leaf functions: out of line by default (bounded code size / compile time); the single-end graph unit inlines them
+// into its search loops (H2G_INLINE_GLF: -5 % there, +5 % in the paired unit whose register budget is tighter)
+#ifdef H2G_INLINE_GLF
+#define H2G_GLF H2G_HD
+#else
+#define H2G_GLF H2G_HDN
+#endif
+
 template <class X>
 H2G_HD bool is_zoff(const X& g, uint32_t row) {   // GFM::_zOffs (gfm.h:2783); a handful of entries at most
 	if(g.nZ == 0) return false;
@@ -139,7 +147,7 @@ H2G_HD uint32_t select_in_word(uint64_t w, uint32_t count) {   // position of th
 
 // select_F (gfm.h:4113-4167): row of the count-th F one at or after `row` (count >= 1), crossing sides as needed
 template <class X>
-H2G_HDN uint32_t select_F(const X& g, uint32_t row, uint32_t count) {
+H2G_GLF uint32_t select_F(const X& g, uint32_t row, uint32_t count) {
 	uint32_t sideNum = row / X::SYMS, off = row - sideNum * X::SYMS;
 	const uint32_t lastSide = (g.gbwtLen - 1) / X::SYMS;
 	while(true) {
@@ -160,7 +168,7 @@ H2G_HDN uint32_t select_F(const X& g, uint32_t row, uint32_t count) {
 // F-row of node `node`: backward scan over the (F_loc, M_occ) side headers starting at the side of `locRow`
 // (mapGLF gfm.h:3788-3810, mapGLF1 :3978-3998).  Returns the scan's F_loc (already +1 when M_occ > 0) and M_occ.
 template <class X>
-H2G_HDN uint32_t node_to_Frow(const X& g, uint32_t locRow, uint32_t node, uint32_t* F_loc_out, uint32_t* M_occ_out) {
+H2G_GLF uint32_t node_to_Frow(const X& g, uint32_t locRow, uint32_t node, uint32_t* F_loc_out, uint32_t* M_occ_out) {
 	uint32_t sideNum = locRow / X::SYMS;
 	uint32_t F_loc, M_occ;
 	while(true) {
@@ -182,7 +190,7 @@ typedef h2g_iedges IEdges;            // n = true count; entries beyond H2G_IEDG
 
 // getInEdgeCount (gfm.h:4172-4213)
 template <class X>
-H2G_HDN void in_edge_count(const X& g, uint32_t top, uint32_t bot, IEdges* ie) {
+H2G_GLF void in_edge_count(const X& g, uint32_t top, uint32_t bot, IEdges* ie) {
 	ie->n = 0;
 	uint32_t curr_node = 0, num0s = 0;
 	uint32_t sideNum = H2G_MAX;
@@ -207,7 +215,7 @@ struct GRange { uint32_t top, bot, node_top, node_bot; };
 // mapGLF (gfm.h:3759-3837): LF of a row range + translation of the outgoing-edge rows back to incoming rows
 // through M-rank / F-select.  false = empty range.  `ie` may be null.
 template <class X>
-H2G_HDN bool map_glf(const X& g, uint32_t top, uint32_t bot, int c, uint32_t k, GRange* r, IEdges* ie) {
+H2G_GLF bool map_glf(const X& g, uint32_t top, uint32_t bot, int c, uint32_t k, GRange* r, IEdges* ie) {
 	const uint32_t s0 = top / X::SYMS, c0 = top - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
 	uint32_t t = rank_in_side128(g, sd, s0, c0, c), b;
@@ -234,7 +242,7 @@ H2G_HDN bool map_glf(const X& g, uint32_t top, uint32_t bot, int c, uint32_t k, 
 
 // mapGLF1 (gfm.h:3957-4021) with mapLF1 (:3892): one row; false = cannot proceed on c
 template <class X>
-H2G_HDN bool map_glf1(const X& g, uint32_t row, int c, GRange* r) {
+H2G_GLF bool map_glf1(const X& g, uint32_t row, int c, GRange* r) {
 	r->top = r->bot = r->node_top = r->node_bot = 0;
 	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
 	Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
