@@ -1155,7 +1155,12 @@ H2G_HDN bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& s
 		if(rl < 0) { reflen += rl; rl = 0; }
 		uint32_t numNs = 0;
 		const uint32_t n_prev = h->nedits;
-		const uint32_t best_ext = align_with_alts(ref, A, seq, h->joinedOff, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx, rl, reflen, true, h, mm, &numNs, W);
+		// no ALT within reach of this extension (the read cannot get further than rdoff reference bases to the left without one):
+		// alignWithALTs_recur then degenerates to its mismatch scan — the linear-index code path, without the frame stack
+		const uint32_t wlo = h->joinedOff > h->rdoff + 16 ? h->joinedOff - h->rdoff - 16 : 0;
+		const bool no_alt = alt_lobound(A, wlo) == alt_lobound(A, h->joinedOff + 2);
+		const uint32_t best_ext = no_alt ? align_no_alts(ref, seq, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx, rl, reflen, true, h, mm, &numNs)
+		                                 : align_with_alts(ref, A, seq, h->joinedOff, h->rdoff - 1, h->rdoff - 1, h->rdoff, h->tidx, rl, reflen, true, h, mm, &numNs, W);
 		if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return false; }
 		if(best_ext > 0) {
 			*leftext = best_ext;
@@ -1191,8 +1196,11 @@ H2G_HDN bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& s
 				else if(e.type == H2G_EDIT_READ_GAP) ref_ext++;
 				else if(e.type == H2G_EDIT_MM && e.chr == 'N') ref_ext--;
 			}
-			const uint32_t best_ext = align_with_alts(ref, A, seq, h->joinedOff + (uint32_t)ref_ext, h->rdoff, h->rdoff + h->len,
-			                                          rdlen - (h->rdoff + h->len), h->tidx, (int)rl, reflen, false, h, mm, nullptr, W);
+			const uint32_t jr = h->joinedOff + (uint32_t)ref_ext;
+			const bool no_alt = alt_lobound(A, jr > 2 ? jr - 2 : 0) == alt_lobound(A, jr + rr + 16);
+			const uint32_t best_ext = no_alt ? align_no_alts(ref, seq, h->rdoff, h->rdoff + h->len, rdlen - (h->rdoff + h->len), h->tidx, (int)rl, reflen, false, h, mm, nullptr)
+			                                 : align_with_alts(ref, A, seq, jr, h->rdoff, h->rdoff + h->len,
+			                                                   rdlen - (h->rdoff + h->len), h->tidx, (int)rl, reflen, false, h, mm, nullptr, W);
 			if(h->len == 0 && mm == 0 && h->nedits > 0) { h->nedits = 0; return false; }
 			if(best_ext > 0) { *rightext = best_ext; h->len += best_ext; }
 		}
