@@ -1502,7 +1502,7 @@ H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, Ma
 		if(P.bowtie2_dp == 2 || (P.bowtie2_dp == 1 && maxsc < mw->minsc)) {
 			bool found = gh->len >= sv.len;
 			if(!found) {
-				if(C.sw == nullptr) ws->overflow |= 256;          // caller did not provide SW scratch
+				if(C.sw == nullptr || sv.len > H2G_SW_MAX_ROWS) ws->overflow |= 256;   // no SW scratch / read longer than the DP path holds
 				else {
 					SwParams SP;
 					SP.sc = P.sc;
