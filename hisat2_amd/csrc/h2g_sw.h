@@ -21,7 +21,8 @@
 
 namespace h2g {
 
-#define H2G_SW_MAX_ROWS 160                 // read length cap of the SW path (LDS budget; longer reads: H2G_ERR_ARG)
+#define H2G_SW_MAX_ROWS 256                 // read length cap of the SW path (longer reads: H2G_ERR_ARG)
+#define H2G_SW_NCH ((H2G_SW_MAX_ROWS + 63) / 64)   // row chunks of 64 per lane in the wave-systolic fill
 #define H2G_SW_MAXGAP 10                    // readGaps = refGaps = maxhalf = 10 (spliced_aligner.h:222)
 #define H2G_SW_MAX_COLS (H2G_SW_MAX_ROWS + 4 * H2G_SW_MAXGAP)
 #define H2G_SW_STACK 96                     // branch frames (the reference's list is unbounded; overflow is flagged)
@@ -44,22 +45,23 @@ struct SwMaskTab {
 	uint32_t  gen;    // > 0
 	uint32_t  full;   // set when an insert found no slot (reported as overflow)
 	H2G_HD uint32_t slot(uint32_t key) const { return (key * 40503u >> 4) & (H2G_SW_MASK_SLOTS - 1); }
+	// entry = generation (30 bits) | key (18 bits: row << 10 | col; col < 1024 covers 256 rows + 4 * maxgap columns) | mask (16 bits)
 	H2G_HD uint32_t get(uint32_t row, uint32_t col) const {
-		const uint32_t key = (row << 8) | col;
+		const uint32_t key = (row << 10) | col;
 		uint32_t h = slot(key);
 		for(uint32_t n = 0; n < H2G_SW_MASK_SLOTS; n++, h = (h + 1) & (H2G_SW_MASK_SLOTS - 1)) {
 			const uint64_t v = e[h];
-			if((uint32_t)(v >> 32) != gen) return 0;
-			if(((uint32_t)v >> 16) == key) return (uint32_t)v & 0xffffu;
+			if((uint32_t)(v >> 34) != gen) return 0;
+			if(((uint32_t)(v >> 16) & 0x3ffffu) == key) return (uint32_t)v & 0xffffu;
 		}
 		return 0;
 	}
 	H2G_HD void set(uint32_t row, uint32_t col, uint32_t mask) {
-		const uint32_t key = (row << 8) | col;
+		const uint32_t key = (row << 10) | col;
 		uint32_t h = slot(key);
 		for(uint32_t n = 0; n < H2G_SW_MASK_SLOTS; n++, h = (h + 1) & (H2G_SW_MASK_SLOTS - 1)) {
 			const uint64_t v = e[h];
-			if((uint32_t)(v >> 32) != gen || ((uint32_t)v >> 16) == key) { e[h] = ((uint64_t)gen << 32) | (key << 16) | (mask & 0xffffu); return; }
+			if((uint32_t)(v >> 34) != gen || ((uint32_t)(v >> 16) & 0x3ffffu) == key) { e[h] = ((uint64_t)gen << 34) | ((uint64_t)key << 16) | (mask & 0xffffu); return; }
 		}
 		full = 1;
 	}
@@ -149,10 +151,11 @@ __device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const Se
 	const uint32_t nch = (nrow + 63) >> 6;
 	const uint32_t rdgapo = (uint32_t)(P.sc.rdGapConst + P.sc.rdGapLinear), rdgape = (uint32_t)P.sc.rdGapLinear;
 	const uint32_t rfgapo = (uint32_t)(P.sc.rfGapConst + P.sc.rfGapLinear), rfgape = (uint32_t)P.sc.rfGapLinear;
-	uint32_t pk[3] = {0, 0, 0}, e_cur[3] = {0, 0, 0};
-	int readc[3]; uint32_t mmpen[3], gb[3];
+	uint32_t pk[H2G_SW_NCH], e_cur[H2G_SW_NCH];
+	int readc[H2G_SW_NCH]; uint32_t mmpen[H2G_SW_NCH], gb[H2G_SW_NCH];
 #pragma unroll
-	for(int c = 0; c < 3; c++) {
+	for(int c = 0; c < H2G_SW_NCH; c++) {
+		pk[c] = 0; e_cur[c] = 0;
 		const uint32_t i = (uint32_t)c * 64 + lane;
 		const bool in = i < nrow;
 		readc[c] = in ? seq.at(i) : 4;
@@ -160,10 +163,10 @@ __device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const Se
 		gb[c] = (in && (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar)) ? 0xffu : 0u;
 	}
 	for(uint32_t d = 0; d < nd; d++) {
-		uint32_t up[3];
+		uint32_t up[H2G_SW_NCH];
 		const uint32_t fresh = d < ncol ? (uint32_t)m.rf[d] : 4u;     // row 0 meets column d at step d
 #pragma unroll
-		for(int c = 0; c < 3; c++) {
+		for(int c = 0; c < H2G_SW_NCH; c++) {
 			if((uint32_t)c >= nch) break;
 			uint32_t u = __shfl_up(pk[c], 1);
 			if(c > 0) { const uint32_t w = __shfl(pk[c - 1], 63); if(lane == 0) u = w; }
@@ -171,7 +174,7 @@ __device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const Se
 			up[c] = u;
 		}
 #pragma unroll
-		for(int c = 0; c < 3; c++) {
+		for(int c = 0; c < H2G_SW_NCH; c++) {
 			if((uint32_t)c >= nch) break;
 			const uint32_t i = (uint32_t)c * 64 + lane;
 			const int32_t j = (int32_t)d - (int32_t)i;
@@ -417,7 +420,8 @@ H2G_HD size_t sw_scratch_bytes(uint32_t maxlen) {
 // gather + backtrace of one filled problem on the calling lane, using its persistent SwLaneState (zero-initialised once)
 H2G_HD SwOut* sw_finish(const SwMats& m, const SwParams& P, const SeqView& sv, const SwRect& rect, int64_t minsc, uint32_t* rnd, SwLaneState* ls) {
 	SwMaskTab mt;
-	mt.e = ls->mask; mt.gen = ++ls->gen; mt.full = 0;
+	if(++ls->gen >= (1u << 30)) { for(uint32_t k = 0; k < H2G_SW_MASK_SLOTS; k++) ls->mask[k] = 0; ls->gen = 1; }   // generation field is 30 bits
+	mt.e = ls->mask; mt.gen = ls->gen; mt.full = 0;
 	SwOut* o = &ls->out;
 	o->refl = rect.refl; o->refr = rect.refr;
 	sw_gather_backtrace(m, P, sv, rect, minsc, (int)((double)P.nceil_pct * 0.01 * (double)m.nrow), rnd, mt, ls->stack, ls->cells, o);

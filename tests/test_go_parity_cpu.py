@@ -51,6 +51,9 @@ def test_golden_sam(g1_index, golden_dir):
     # reads longer than 256 bp: the combineWith score scan holds up to 512 positions (longer reads set the overflow bit)
     dict(seed=995, nreads=2500, rdlen=300, sub=0.01, indel=0.003, nrate=0.001),
     dict(seed=996, nreads=2500, rdlen=300, sub=0.01, indel=0.003, nrate=0.001, snps=100),
+    # SwAligner pass on reads up to 256 bp (4 row chunks; mask-table keys hold 10-bit columns)
+    dict(seed=771, nreads=3000, rdlen=250, sub=0.02, indel=0.006, nrate=0.002, extra=("--bowtie2-dp", "1"), bowtie2_dp=1),
+    dict(seed=773, nreads=3000, rdlen=230, sub=0.03, indel=0.008, nrate=0.002, extra=("--sensitive",)),
 ])
 def test_live_reference(case):
     """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""

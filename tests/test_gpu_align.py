@@ -113,6 +113,8 @@ def test_live_reference_graph_index_bowtie2_dp():
     dict(extra=("-k", "10")),
     dict(extra=("-k", "3", "--mp", "4,2", "--np", "3", "--rdg", "4,2", "--rfg", "7,2")),
     dict(extra=("--sensitive",), snps=60),
+    dict(extra=("--sensitive",), rdlen=230, nreads=6000),
+    dict(extra=("--bowtie2-dp", "2"), rdlen=250, nreads=5000, fastq=False),
 ])
 def test_live_reference_options(case):
     import fuzz_align as F
