@@ -27,9 +27,9 @@ namespace h2g {
 #ifndef AL_MAX_GHITS           // the linear go() kernels are compiled with -DAL_MAX_GHITS=10 (smaller per-lane workspace)
 #define AL_MAX_GHITS    20    // max(khits, kseeds): 10 on linear, 20 on graph indexes (hisat2.cpp:3174-3176, 3903-3906)
 #endif
-#define AL_MAX_SEARCHED 48
+#define AL_MAX_SEARCHED 64
 #define AL_MAX_RESULTS  32
-#define AL_MAX_DEPTH    28
+#define AL_MAX_DEPTH    32
 #define AL_MAX_LOCALHITS 4
 #define AL_MAX_COORDS   12
 
