@@ -123,7 +123,8 @@ class SeedParams(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("n_rank", u64), ("n_side", u64), ("n_sa_steps", u64), ("n_ext", u64), ("n_ref_bytes", u64),
                 ("n_queries", u64), ("n_aligned", u64), ("n_overflow", u64), ("ms_search", C.c_float),
-                ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_align_kernel", C.c_float)]
+                ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_align_kernel", C.c_float),
+                ("n_second_pass", u64)]
 
 
 ALN_CAP = 10
@@ -145,25 +146,28 @@ class AlignParams(C.Structure):
                 ("rfg_const", C.c_int32), ("rfg_linear", C.c_int32), ("sc_max", C.c_int32), ("sc_min", C.c_int32), ("score_min_type", u32),
                 ("score_min_const", C.c_double), ("score_min_coeff", C.c_double)]
 
-    def apply_options(self, opts):
-        """apply a list of reference command-line options (['-k', '3', '--mp', '4,2', ...]) to this block; returns leftovers"""
+    def apply_options(self, opts, linear=None):
+        """apply a list of reference command-line options (['-k', '3', '--mp', '4,2', ...]) to this block; returns leftovers.
+        Presets are resolved AFTER all options were read, as hisat2.cpp:1882-1909 / 3174-3176 / 3903-3906 does (the same
+        rules as h2g_align_params_presets): --sensitive alone keeps -k 5 on a linear index, and a preset's --score-min wins.
+        `linear` defaults to what the block's default -k says about the index (5 = linear, 10 = graph)."""
+        if linear is None:
+            linear = self.khits == 5
         rest, i = [], 0
+        saw_k, k_arg, max_seeds, sensitive, very = False, 0, 0, False, False
         while i < len(opts):
             o = opts[i]
             v = opts[i + 1] if i + 1 < len(opts) else None
             if o == "-k":
-                self.khits = int(v); self.kseeds = max(5, 2 * self.khits); i += 2
+                k_arg = int(v); saw_k = True; i += 2
             elif o == "--max-seeds":
-                self.kseeds = int(v); i += 2
+                max_seeds = int(v); i += 2
             elif o == "--secondary":
                 self.secondary = 1; i += 1
-            elif o == "--sensitive":   # hisat2.cpp:1892-1901: SwAligner when nothing reached minsc, -k >= 10, --score-min L,0,-0.5
-                if self.bowtie2_dp == 0:
-                    self.bowtie2_dp = 1
-                if self.khits < 10:
-                    self.khits = 10; self.kseeds = 20
-                self.score_min_type, self.score_min_const, self.score_min_coeff = 2, 0.0, -0.5
-                i += 1
+            elif o == "--sensitive":
+                sensitive = True; i += 1
+            elif o == "--very-sensitive":
+                very = True; i += 1
             elif o == "--bowtie2-dp":
                 self.bowtie2_dp = int(v); i += 2
             elif o == "--mp":
@@ -187,7 +191,28 @@ class AlignParams(C.Structure):
                 i += 2
             else:
                 rest.append(o); i += 1
+        self.presets(linear, saw_k, k_arg, max_seeds, sensitive, very)
         return rest
+
+    def presets(self, linear, saw_k, k_arg, max_seeds, sensitive, very_sensitive):
+        """Python mirror of h2g_align_params_presets (tests/test_abi.py checks the two against each other)"""
+        import numpy as np
+        khits = k_arg if saw_k else 10
+        if sensitive:
+            if self.bowtie2_dp == 0:
+                self.bowtie2_dp = 1
+            if khits < 10:
+                khits, saw_k = 10, True
+            self.score_min_type, self.score_min_const, self.score_min_coeff = 2, 0.0, float(np.float32(-0.5))
+        elif very_sensitive:
+            self.bowtie2_dp = 2
+            if khits < 30:
+                khits, saw_k = 30, True
+            self.score_min_type, self.score_min_const, self.score_min_coeff = 2, 0.0, float(np.float32(-1.0))
+        if not saw_k:
+            khits = 5 if linear else 10
+        self.khits = khits
+        self.kseeds = max_seeds if max_seeds else max(5, 2 * khits)
 
 
 PAIR_RES_CAP = 16
@@ -216,7 +241,7 @@ EXPORTS = [
     "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_set_reads",
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
-    "h2g_align_params_init", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
+    "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
     "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense",
     "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph", "h2g_adjust_with_alt",
 ]
@@ -269,6 +294,8 @@ def lib():
     L.h2g_get_counters.argtypes = [vp, P(Counters)]
     L.h2g_align_params_init.argtypes = [P(AlignParams), vp]
     L.h2g_align_params_init.restype = None
+    L.h2g_align_params_presets.argtypes = [P(AlignParams), vp, C.c_int, u32, u32, C.c_int, C.c_int]
+    L.h2g_align_params_presets.restype = None
     L.h2g_set_read_names.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.h2g_align_run.argtypes = [vp, P(AlignParams)]
     L.h2g_align_fetch.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]

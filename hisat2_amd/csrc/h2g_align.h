@@ -27,11 +27,15 @@ namespace h2g {
 #ifndef AL_MAX_GHITS           // the linear go() kernels are compiled with -DAL_MAX_GHITS=10 (smaller per-lane workspace)
 #define AL_MAX_GHITS    20    // max(khits, kseeds): 10 on linear, 20 on graph indexes (hisat2.cpp:3174-3176, 3903-3906)
 #endif
+#ifndef AL_MAX_SEARCHED        // the *_big units raise these (second pass over overflowed reads, option sets beyond the defaults)
 #define AL_MAX_SEARCHED 64
 #define AL_MAX_RESULTS  32
 #define AL_MAX_DEPTH    32
 #define AL_MAX_LOCALHITS 4
 #define AL_MAX_COORDS   12
+#define AL_MAX_PARTIAL  24
+#endif
+#define H2G_SELECT_CAP 32      // alignments selected per read: >= the largest -k (30: --very-sensitive); fixed in every unit
 
 // ---------------------------------------------------------------------------------------- local indexes (a13)
 // LocalGFM (hgfm.h:35): 16-bit words.  Linear local side = 64 B = 56 B payload (224 symbols) + u16 occ[4].
@@ -585,7 +589,7 @@ struct AlnRec {
 	h2g_edit edits[H2G_MAX_EDITS];   // as stored in the AlnRes: 5'-to-3' positions of the ORIGINAL read relative to the first aligned base
 };
 
-struct Frame {
+struct Frame {                 // one activation of hybridSearch_recur (spliced_aligner.h:331); `state` = the machine pc to resume at
 	h2g_ghit hit;
 	uint32_t hitoff, hitlen;
 	int64_t  maxsc, prev_score;
@@ -593,11 +597,11 @@ struct Frame {
 	uint32_t count, lidx, extoff, extlen, ncoords, nlocal, ti;
 	int32_t  ri;
 	uint8_t  success, first, use_localindex, uniqueStop;
+	uint32_t top, bot, nelt, noext, maxHitLen;   // locals of the local / global search loops that live across machine ops
 	h2g_coord coords[AL_MAX_COORDS];
 	h2g_ghit  local_hits[AL_MAX_LOCALHITS];
 };
 
-#define AL_MAX_PARTIAL 24
 struct PartialHit {          // BWTHit hi_aligner.h:108 (linear: node range == row range, no in-edge list)
 	uint32_t top, bot, bwoff, len, hit_type, ncoords;
 	h2g_coord coords[AL_MAX_GHITS];
@@ -622,6 +626,29 @@ struct MateWS {              // per-mate state of HI_Aligner + the per-mate half
 	uint32_t   sink_hidden;
 };
 
+// Locals of go() / nextBWT / align / getAnchorHits / hybridSearch / alignMate that live across machine ops (h2g_machine.h)
+struct GoVars {
+	uint32_t paired, nm, slot0, read;
+	uint32_t rd_sel[2];              // which read set (0 = mate-1 file, 1 = mate-2 file) go()'s rds[r] is
+	uint32_t rdlens[2];
+	uint8_t  found[2][2];
+	int32_t  sel_r, sel_f;           // nextBWT's selection = the (read, strand) align() works on
+	int32_t  nb_rdi, nb_fwi;
+	uint32_t sv_rdi, sv_fw, mw_slot; // the SeqView / MateWS the current phase works on
+	uint32_t rnd;                    // RandomSource::last
+	// getAnchorHits
+	uint32_t gh_hi, gh_hj, gh_remained, gh_expected, gh_nco, gh_node, gh_node_end, gh_top, gh_bot, gh_added, gh_edgeIdx, gh_gsize, gh_k, gh_rdoff;
+	// hybridSearch
+	uint32_t hs_hi, hs_hj, hs_found;
+	// mate phase / alignMate
+	uint32_t mp_i, mp_j, mp_rs[2], mate_found;
+	uint32_t am_lidx, am_first, am_count, am_maxhitlen, am_hitoff, am_hitlen, am_hi, am_fw, am_tidx, am_toff, am_ri, am_nco;
+	// hybridSearch_recur driver
+	int32_t  sp;
+	uint32_t rc_ret_pc, rc_alignMate, pr_ret_pc;
+	int64_t  ret, rc_minsc, rc_cushion;
+};
+
 struct AlignWS {
 	MateWS     m[2];
 	h2g_ghit   ghits[AL_MAX_GHITS];              // _genomeHits (hitcount lives in .read)
@@ -636,6 +663,9 @@ struct AlignWS {
 	uint32_t   nrank, nside, nsteps, nframes_max;   // nrank, nside adjacent: gfm_search updates both through &nrank
 	h2g_ghit   tmp, tmp2;                        // scratch hits
 	int64_t    sc1[512], sc2[512];               // combineWith temp_scores
+	GoVars     gv;
+	h2g_fm_hit fh;                               // result of the last partial search
+	h2g_coord  am_co[AL_MAX_GHITS];              // alignMate's coordinate list
 	Frame      stack[AL_MAX_DEPTH];
 };
 
@@ -942,15 +972,6 @@ H2G_HD uint32_t al_global_coords(const AlnCtx& C, AlignWS* ws, uint32_t top, uin
 }
 
 
-// ---------------------------------------------------------------------------------------- hybridSearch_recur (a21)
-enum {
-	ST_ENTRY = 0,
-	ST_L_WHILE, ST_L_FOR_RI, ST_L_R1, ST_L_AFTER_FOR, ST_L_FOR_TI, ST_L_R2, ST_L_AFTER_WHILE, ST_L_FOR_G, ST_L_R3, ST_L_TRIM, ST_L_R4,
-	ST_L_EXT, ST_L_R5,
-	ST_R_WHILE, ST_R_FOR_RI, ST_R_R1, ST_R_AFTER_FOR, ST_R_FOR_TI, ST_R_R2, ST_R_AFTER_WHILE, ST_R_FOR_G, ST_R_R3, ST_R_TRIM, ST_R_R4,
-	ST_R_EXT, ST_R_R5
-};
-
 H2G_HD uint32_t local_index_of(const DLocalSet& ls, uint32_t tidx, uint32_t toff) {   // HGFM::getLocalGFM hgfm.h:1713
 	uint32_t a = ls.first[tidx], b = ls.first[tidx + 1];
 	uint32_t k = toff / H2G_LOCAL_INTERVAL;
@@ -974,421 +995,6 @@ H2G_HD void sort_coords(h2g_coord* c, uint32_t n) {   // Coord::operator< ref_co
 		while(j >= 0 && (c[j].tidx > x.tidx || (c[j].tidx == x.tidx && c[j].toff > x.toff))) { c[j + 1] = c[j]; j--; }
 		c[j + 1] = x;
 	}
-}
-
-// Runs hybridSearch_recur(hit, hitoff, hitlen) to completion; returns maxsc.
-H2G_HD int64_t al_hybrid_search_recur(const AlnCtx& C, const SeqView& seq, AlignWS* ws, MateWS* mw, const h2g_ghit* root,
-                                      uint32_t hitoff0, uint32_t hitlen0, int64_t minsc, bool alignMate)
-{
-	const AlnParams& P = *C.P;
-	const DScoring& sc = P.sc;
-	const uint32_t rdlen = seq.len, minK = C.g->minK, minK_local = P.minK_local;
-	const bool no_spliced = P.no_spliced != 0;
-	// spliced_aligner.h:363-366: cushion = alignMate ? rdlen * 0.03 * sc.mm(255) : 0 (no_spliced_alignment only)
-	const int64_t cushion = (no_spliced && alignMate) ? (int64_t)((double)rdlen * 0.03 * (double)sc.mmpMax) : 0;
-	int sp = 0;
-	int64_t ret = INT64_MIN;
-	{
-		Frame& f = ws->stack[0];
-		hit_copy(&f.hit, root);
-		f.hitoff = hitoff0; f.hitlen = hitlen0; f.state = ST_ENTRY;
-	}
-#define AL_CALL(HITPTR, HOFF, HLEN, RESUME) do { \
-		f.state = (RESUME); \
-		if(sp + 1 >= AL_MAX_DEPTH) { ws->overflow |= 8; ret = INT64_MIN; } \
-		else { Frame& nf = ws->stack[sp + 1]; hit_copy(&nf.hit, (HITPTR)); nf.hitoff = (HOFF); nf.hitlen = (HLEN); nf.state = ST_ENTRY; sp++; \
-		       if((uint32_t)sp + 1 > ws->nframes_max) ws->nframes_max = sp + 1; } \
-		goto next_iter; } while(0)
-#define AL_RET(V) do { ret = (V); sp--; goto next_iter; } while(0)
-#define AL_MINSC_LIVE(M) do { if(!P.secondary) { int64_t b_ = mw->bestUnp - cushion; if(b_ > (M)) (M) = b_; } } while(0)
-
-	while(sp >= 0) {
-		{
-		Frame& f = ws->stack[sp];
-		const h2g_ghit& hit = f.hit;
-		const uint32_t hitoff = f.hitoff, hitlen = f.hitlen;
-		const uint32_t dep = (uint32_t)sp;
-		switch(f.state) {
-		case ST_ENTRY: {
-			AL_TRACE("   recur dep %u fw %u hitoff %u hitlen %u (rdoff %u len %u) toff %u score %lld nedits %u mate %d\n", dep, hit.fw, hitoff, hitlen, hit.rdoff, hit.len, hit.toff, (long long)hit.score, hit.nedits, (int)alignMate);
-			f.maxsc = INT64_MIN;
-			if(hit.score + cushion < minsc) AL_RET(f.maxsc);
-			if(dep >= 128) AL_RET(f.maxsc);
-			if(hitoff == hit.rdoff - hit.trim5 && hitlen == hit.len + hit.trim5 + hit.trim3) {
-				if(al_is_searched(mw, &hit)) AL_RET(f.maxsc);
-				al_add_searched(ws, mw, &hit);
-			}
-			if(hitoff == 0 && hitlen == rdlen) {
-				if(!al_redundant(mw, &hit, rdlen)) {
-					al_report(ws, mw, &hit, rdlen, minsc);
-					if(hit.score > f.maxsc) f.maxsc = hit.score;
-				}
-				AL_RET(f.maxsc);
-			} else if(hitoff > 0 && (hitoff + hitlen == rdlen || hitoff + hitoff < rdlen - hitlen)) {
-				// ---------------- extend to the left (spliced_aligner.h:813-1360) ----------------
-				f.use_localindex = 1;
-				if(hitoff == hit.rdoff && hitoff <= minK) {
-					hit_copy(&ws->tmp, &hit);
-					uint32_t le, re;
-					al_extend(C, seq, &ws->tmp, 1, H2G_MAX, 0, &le, &re);
-					if(ws->tmp.rdoff == 0) f.use_localindex = 0;
-				}
-				f.lidx = local_index_of(*C.ls, hit.tidx, hit.toff);
-				f.success = 0; f.first = 1; f.count = 0; f.prev_score = hit.score; f.nlocal = 0;
-				f.state = ST_L_WHILE;
-				goto next_iter;
-			} else {
-				// ---------------- extend to the right (spliced_aligner.h:1496-2050) ----------------
-				f.use_localindex = 1;
-				if(hit.len == hitlen && hitoff + hitlen + minK > rdlen) {
-					hit_copy(&ws->tmp, &hit);
-					uint32_t le, re;
-					al_extend(C, seq, &ws->tmp, 1, 0, H2G_MAX, &le, &re);
-					if(ws->tmp.rdoff + ws->tmp.len == rdlen) f.use_localindex = 0;
-				}
-				f.lidx = local_index_of(*C.ls, hit.tidx, hit.toff);
-				f.success = 0; f.first = 1; f.count = 0; f.prev_score = hit.score; f.nlocal = 0;
-				f.state = ST_R_WHILE;
-				goto next_iter;
-			}
-		}
-		// =============================== LEFT ===============================
-		case ST_L_WHILE: {
-			if(f.success) { f.state = ST_L_AFTER_WHILE; goto next_iter; }
-			if(!(f.count++ < 2)) { f.state = ST_L_AFTER_WHILE; goto next_iter; }
-			if(!f.use_localindex) { f.state = ST_L_AFTER_WHILE; goto next_iter; }
-			if(ws->localindexatts >= ws->max_localindexatts) { f.state = ST_L_AFTER_WHILE; goto next_iter; }
-			if(f.first) f.first = 0;
-			else {
-				f.lidx = f.lidx == H2G_MAX ? H2G_MAX : local_index_prev(*C.ls, f.lidx);
-				if(f.lidx == H2G_MAX || C.ls->desc[f.lidx].len == 0) { f.state = ST_L_AFTER_WHILE; goto next_iter; }
-			}
-			if(f.lidx == H2G_MAX) { f.state = ST_L_AFTER_WHILE; goto next_iter; }
-			uint32_t extlen = 0, top = H2G_MAX, bot = H2G_MAX;
-			uint32_t extoff = hitoff - 1;
-			if(extoff > 0) extoff -= 1;
-			if(extoff < P.minAnchorLen) extoff = P.minAnchorLen;
-			uint32_t nelt = H2G_MAX;
-			const uint32_t max_nelt = 5;
-			bool no_extension = false, uniqueStop = false;
-			LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[f.lidx];
-			for(; extoff < rdlen; extoff++) {
-				extlen = 0; uniqueStop = true;
-				ws->localindexatts++;
-				nelt = C.ls->desc[f.lidx].len == 0 ? 0 :
-				       al_local_search(C, ws, f.lidx, seq, extoff, &extlen, &top, &bot, &uniqueStop, 0xffffu);
-				if(extoff + 1 - extlen >= hitoff) { no_extension = true; break; }
-				if(nelt <= max_nelt) break;
-			}
-			f.ncoords = 0; f.ri = -1;
-			f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
-			AL_TRACE("    L local lidx %u extoff %u extlen %u nelt %u top %u bot %u unique %d noext %d\n", f.lidx, extoff, extlen, nelt, top, bot, (int)uniqueStop, (int)no_extension);
-			if(nelt > 0 && nelt <= max_nelt && extlen >= P.minAnchorLen && !no_extension) {
-				al_local_coords(C, ws, f.lidx, top, bot, extoff + 1 - extlen, extlen, f.coords, AL_MAX_COORDS, &f.ncoords);
-				sort_coords(f.coords, f.ncoords);
-				f.ri = (int)f.ncoords - 1;
-			}
-			f.state = ST_L_FOR_RI;
-			goto next_iter;
-		}
-		case ST_L_FOR_RI: {
-			if(f.ri < 0) { f.state = ST_L_AFTER_FOR; goto next_iter; }
-			const h2g_coord co = f.coords[f.ri];
-			h2g_ghit* t = &ws->tmp;
-			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
-			if(!al_adjust_member(C, seq, t, ws)) { f.ri--; goto next_iter; }
-			if(!hit_compatible(t, &hit, P.maxIntronLen, no_spliced)) {
-				if(f.count == 1) { f.ri--; goto next_iter; }
-				f.state = ST_L_AFTER_FOR; goto next_iter;
-			}
-			AL_TRACE("    L coord tidx %u toff %u -> adjusted rdoff %u len %u toff %u nedits %u\n", co.tidx, co.toff, t->rdoff, t->len, t->toff, t->nedits);
-			if(f.uniqueStop) { uint32_t le, re; al_extend(C, seq, t, 0, H2G_MAX, 0, &le, &re); }
-			AL_TRACE("    L extended rdoff %u len %u toff %u nedits %u\n", t->rdoff, t->len, t->toff, t->nedits);
-			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
-			AL_TRACE("    L combined %d rdoff %u len %u score %lld nedits %u\n", (int)combined, t->rdoff, t->len, (long long)t->score, t->nedits);
-			if(t->overflow) ws->overflow |= 1;
-			AL_MINSC_LIVE(m);
-			f.ri--;
-			if(combined && t->score >= m) {
-				if(t->score >= f.prev_score - sc.mmpMax) AL_CALL(t, t->rdoff, t->len + t->trim3, ST_L_R1);
-				else if(f.nlocal < AL_MAX_LOCALHITS) hit_copy(&f.local_hits[f.nlocal++], t);
-				else ws->overflow |= 16;
-			}
-			goto next_iter;
-		}
-		case ST_L_R1: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_L_FOR_RI; goto next_iter; }
-		case ST_L_AFTER_FOR: {
-			if(f.maxsc >= f.prev_score - sc.mmpMax) f.success = 1;
-			f.ti = 0;
-			if(!f.success && (ws->localindexatts >= ws->max_localindexatts || f.count == 2 ||
-			                  (f.lidx == H2G_MAX || local_index_prev(*C.ls, f.lidx) == H2G_MAX)))
-				f.state = ST_L_FOR_TI;
-			else f.state = ST_L_WHILE;
-			goto next_iter;
-		}
-		case ST_L_FOR_TI: {
-			if(f.ti >= f.nlocal) { f.state = ST_L_WHILE; goto next_iter; }
-			h2g_ghit* t = &f.local_hits[f.ti++];
-			int64_t m = minsc;
-			AL_MINSC_LIVE(m);
-			if(t->score >= m) AL_CALL(t, t->rdoff, t->len + t->trim3, ST_L_R2);
-			goto next_iter;
-		}
-		case ST_L_R2: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_L_FOR_TI; goto next_iter; }
-		case ST_L_AFTER_WHILE: {
-			if(f.success) AL_RET(f.maxsc);
-			f.ncoords = 0; f.ri = -1;
-			if(hitoff > minK && ws->localindexatts < ws->max_localindexatts) {   // global search for long introns (:1085)
-				uint32_t extlen = 0, top = H2G_MAX, bot = H2G_MAX;
-				const uint32_t extoff = hitoff - 1;
-				bool uniqueStop = true;
-				GIdx gx; gx.g = C.g;
-				uint32_t nelt = al_global_search(C, ws, seq, extoff, &extlen, &top, &bot, &uniqueStop);
-				f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
-				AL_TRACE("    L global extoff %u extlen %u nelt %u top %u bot %u unique %d\n", extoff, extlen, nelt, top, bot, (int)uniqueStop);
-				if(nelt > 0 && nelt <= 5 && extlen >= minK) {
-					f.ncoords = al_global_coords(C, ws, top, bot, extlen, f.coords, AL_MAX_COORDS);
-					if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
-					f.ri = (int)f.ncoords - 1;
-				}
-			}
-			f.state = ST_L_FOR_G;
-			goto next_iter;
-		}
-		case ST_L_FOR_G: {
-			if(f.ri < 0) { f.state = ST_L_TRIM; goto next_iter; }
-			const h2g_coord co = f.coords[f.ri];
-			f.ri--;
-			h2g_ghit* t = &ws->tmp;
-			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
-			AL_TRACE("    LG coord tidx %u toff %u joff %u rdoff %u len %u\n", co.tidx, co.toff, co.joinedOff, t->rdoff, t->len);
-			if(!al_adjust_member(C, seq, t, ws)) goto next_iter;
-			AL_TRACE("    LG adjusted rdoff %u len %u toff %u joff %u nedits %u\n", t->rdoff, t->len, t->toff, t->joinedOff, t->nedits);
-			if(!hit_compatible(t, &hit, P.maxIntronLen, no_spliced)) goto next_iter;
-			if(f.uniqueStop) { uint32_t le, re; al_extend(C, seq, t, 0, H2G_MAX, 0, &le, &re); }
-			AL_TRACE("    LG extended rdoff %u len %u toff %u joff %u nedits %u\n", t->rdoff, t->len, t->toff, t->joinedOff, t->nedits);
-			for(uint32_t q = 0; q < t->nedits; q++) AL_TRACE("       edit %u %c>%c type %u snp %u\n", t->edits[q].pos, t->edits[q].chr, t->edits[q].qchr, t->edits[q].type, t->edits[q].snp);
-			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, t, &hit, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
-			AL_TRACE("    LG combined %d rdoff %u len %u score %lld nedits %u\n", (int)combined, t->rdoff, t->len, (long long)t->score, t->nedits);
-			for(uint32_t q = 0; q < t->nedits; q++) AL_TRACE("       edit %u %c>%c type %u snp %u\n", t->edits[q].pos, t->edits[q].chr, t->edits[q].qchr, t->edits[q].type, t->edits[q].snp);
-			if(t->overflow) ws->overflow |= 1;
-			AL_MINSC_LIVE(m);
-			if(combined && t->score >= m) AL_CALL(t, t->rdoff, t->len + t->trim3, ST_L_R3);
-			goto next_iter;
-		}
-		case ST_L_R3: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_L_FOR_G; goto next_iter; }
-		case ST_L_TRIM: {
-			const int64_t floor_ = f.maxsc > minsc ? f.maxsc : minsc;
-			const int64_t tm = (hit.score - floor_) / sc_penalty(sc, 0);
-			const uint32_t trimMax = (uint32_t)tm;
-			f.state = ST_L_EXT;
-			if(hit.rdoff < trimMax) {
-				h2g_ghit* t = &ws->tmp;
-				hit_copy(t, &hit);
-				t->trim5 = hit.rdoff;                         // GenomeHit::trim5 hi_aligner.h:831
-				calculate_score(sc, seq, t);
-				if(t->score > f.maxsc && t->score >= minsc) AL_CALL(t, 0, t->len + t->trim5 + t->trim3, ST_L_R4);
-			}
-			goto next_iter;
-		}
-		case ST_L_R4: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_L_EXT; goto next_iter; }
-		case ST_L_EXT: {
-			h2g_ghit* t = &ws->tmp;
-			hit_copy(t, &hit);
-			int64_t m = minsc;
-			const uint32_t mm = (uint32_t)((t->score - m) / sc.mmpMax);
-			uint32_t nmm = 1;
-			if(hitoff <= minK_local) nmm = t->rdoff < mm ? t->rdoff : mm;
-			uint32_t le = 0, re = 0;
-			AL_TRACE("    L ext from rdoff %u len %u toff %u joff %u nmm %u\n", t->rdoff, t->len, t->toff, t->joinedOff, nmm);
-			al_extend(C, seq, t, nmm, H2G_MAX, 0, &le, &re);
-			AL_TRACE("    L ext -> rdoff %u len %u toff %u joff %u score %lld nedits %u le %u\n", t->rdoff, t->len, t->toff, t->joinedOff, (long long)t->score, t->nedits, le);
-			if(t->overflow) ws->overflow |= 1;
-			AL_MINSC_LIVE(m);
-			const uint32_t need = minK_local < hit.rdoff ? minK_local : hit.rdoff;
-			if(t->score >= m && le >= need) AL_CALL(t, t->rdoff, t->len + t->trim3, ST_L_R5);
-			else if(hitoff > minK_local) {
-				const uint32_t jumplen = hitoff > minK ? minK : minK_local;
-				const int64_t expected = hit.score - (int64_t)((hit.rdoff - hitoff) / jumplen) * sc.mmpMax - sc.mmpMax;
-				if(expected >= m) AL_CALL(&hit, hitoff - jumplen, hitlen + jumplen, ST_L_R5);
-			}
-			AL_RET(f.maxsc);
-		}
-		case ST_L_R5: { if(ret > f.maxsc) f.maxsc = ret; AL_RET(f.maxsc); }
-		// =============================== RIGHT ===============================
-		case ST_R_WHILE: {
-			if(f.success) { f.state = ST_R_AFTER_WHILE; goto next_iter; }
-			if(!(f.count++ < 2)) { f.state = ST_R_AFTER_WHILE; goto next_iter; }
-			if(!f.use_localindex) { f.state = ST_R_AFTER_WHILE; goto next_iter; }
-			if(ws->localindexatts >= ws->max_localindexatts) { f.state = ST_R_AFTER_WHILE; goto next_iter; }
-			if(f.first) f.first = 0;
-			else {
-				f.lidx = f.lidx == H2G_MAX ? H2G_MAX : local_index_next(*C.ls, f.lidx);
-				if(f.lidx == H2G_MAX || C.ls->desc[f.lidx].len == 0) { f.state = ST_R_AFTER_WHILE; goto next_iter; }
-			}
-			if(f.lidx == H2G_MAX) { f.state = ST_R_AFTER_WHILE; goto next_iter; }
-			uint32_t extlen = 0, top = H2G_MAX, bot = H2G_MAX;
-			uint32_t extoff = hitoff + hitlen + minK_local;
-			if(extoff + 1 < rdlen) extoff += 1;
-			if(extoff >= rdlen) extoff = rdlen - 1;
-			uint32_t nelt = H2G_MAX;
-			const uint32_t max_nelt = 5;
-			bool no_extension = false, uniqueStop = false;
-			uint32_t maxHitLen = extoff - hitoff - hitlen;
-			if(maxHitLen < minK_local) maxHitLen = minK_local;
-			LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[f.lidx];
-			for(; maxHitLen < extoff + 1 && extoff < rdlen;) {
-				extlen = 0; uniqueStop = false;
-				ws->localindexatts++;
-				nelt = C.ls->desc[f.lidx].len == 0 ? 0 :
-				       al_local_search(C, ws, f.lidx, seq, extoff, &extlen, &top, &bot, &uniqueStop, maxHitLen);
-				if(extoff < hitoff + hitlen) { no_extension = true; break; }
-				if(nelt <= max_nelt) break;
-				if(extoff + 1 < rdlen) extoff++;
-				else { if(extlen < maxHitLen) break; else maxHitLen++; }
-			}
-			f.ncoords = 0; f.ri = 0;
-			f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
-			if(nelt > 0 && nelt <= max_nelt && extlen >= P.minAnchorLen && !no_extension) {
-				al_local_coords(C, ws, f.lidx, top, bot, extoff + 1 - extlen, extlen, f.coords, AL_MAX_COORDS, &f.ncoords);
-				if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
-			}
-			f.state = ST_R_FOR_RI;
-			goto next_iter;
-		}
-		case ST_R_FOR_RI: {
-			if(f.ri >= (int)f.ncoords) { f.state = ST_R_AFTER_FOR; goto next_iter; }
-			const h2g_coord co = f.coords[f.ri];
-			h2g_ghit* t = &ws->tmp;
-			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
-			if(!al_adjust_member(C, seq, t, ws)) { f.ri++; goto next_iter; }
-			if(!hit_compatible(&hit, t, P.maxIntronLen, no_spliced)) {
-				if(f.count == 1) { f.ri++; goto next_iter; }
-				f.state = ST_R_AFTER_FOR; goto next_iter;
-			}
-			{ uint32_t le, re; al_extend(C, seq, t, 0, 0, H2G_MAX, &le, &re); }
-			h2g_ghit* cmb = &ws->tmp2;
-			hit_copy(cmb, &hit);
-			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, cmb, t, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
-			if(cmb->overflow) ws->overflow |= 1;
-			AL_MINSC_LIVE(m);
-			f.ri++;
-			if(combined && cmb->score >= m) {
-				if(cmb->score >= f.prev_score - sc.mmpMax) AL_CALL(cmb, cmb->rdoff - cmb->trim5, cmb->len + cmb->trim5, ST_R_R1);
-				else if(f.nlocal < AL_MAX_LOCALHITS) hit_copy(&f.local_hits[f.nlocal++], cmb);
-				else ws->overflow |= 16;
-			}
-			goto next_iter;
-		}
-		case ST_R_R1: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_R_FOR_RI; goto next_iter; }
-		case ST_R_AFTER_FOR: {
-			if(f.maxsc >= f.prev_score - sc.mmpMax) f.success = 1;
-			f.ti = 0;
-			if(!f.success && (ws->localindexatts >= ws->max_localindexatts || f.count == 2 ||
-			                  (f.lidx == H2G_MAX || local_index_next(*C.ls, f.lidx) == H2G_MAX)))
-				f.state = ST_R_FOR_TI;
-			else f.state = ST_R_WHILE;
-			goto next_iter;
-		}
-		case ST_R_FOR_TI: {
-			if(f.ti >= f.nlocal) { f.state = ST_R_WHILE; goto next_iter; }
-			h2g_ghit* t = &f.local_hits[f.ti++];
-			int64_t m = minsc;
-			AL_MINSC_LIVE(m);
-			if(t->score >= m) AL_CALL(t, t->rdoff - t->trim5, t->len + t->trim5, ST_R_R2);
-			goto next_iter;
-		}
-		case ST_R_R2: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_R_FOR_TI; goto next_iter; }
-		case ST_R_AFTER_WHILE: {
-			if(f.success) AL_RET(f.maxsc);
-			f.ncoords = 0; f.ri = 0;
-			if(hitoff + hitlen + minK + 1 < rdlen && ws->localindexatts < ws->max_localindexatts) {
-				uint32_t extlen = 0, top = H2G_MAX, bot = H2G_MAX;
-				const uint32_t extoff = hitoff + hitlen + minK + 1;
-				bool uniqueStop = true;
-				GIdx gx; gx.g = C.g;
-				uint32_t nelt = al_global_search(C, ws, seq, extoff, &extlen, &top, &bot, &uniqueStop);
-				f.extoff = extoff; f.extlen = extlen; f.uniqueStop = uniqueStop;
-				if(nelt > 0 && nelt <= 5 && extlen >= minK) {
-					f.ncoords = al_global_coords(C, ws, top, bot, extlen, f.coords, AL_MAX_COORDS);
-					sort_coords(f.coords, f.ncoords);
-				}
-			}
-			f.state = ST_R_FOR_G;
-			goto next_iter;
-		}
-		case ST_R_FOR_G: {
-			if(f.ri >= (int)f.ncoords) { f.state = ST_R_TRIM; goto next_iter; }
-			const h2g_coord co = f.coords[f.ri];
-			f.ri++;
-			h2g_ghit* t = &ws->tmp;
-			hit_init(t, hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
-			if(!al_adjust_member(C, seq, t, ws)) goto next_iter;
-			if(!hit_compatible(&hit, t, P.maxIntronLen, no_spliced)) goto next_iter;
-			{ uint32_t le, re; al_extend(C, seq, t, 0, 0, H2G_MAX, &le, &re); }
-			h2g_ghit* cmb = &ws->tmp2;
-			hit_copy(cmb, &hit);
-			int64_t m = minsc;
-			bool combined = hit_combine(*C.ref, sc, seq, cmb, t, m, P.minIntronLen, no_spliced, ws->sc1, ws->sc2, C.alts);
-			if(cmb->overflow) ws->overflow |= 1;
-			AL_MINSC_LIVE(m);
-			if(combined && cmb->score >= m) AL_CALL(cmb, cmb->rdoff - cmb->trim5, cmb->len + cmb->trim5, ST_R_R3);
-			goto next_iter;
-		}
-		case ST_R_R3: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_R_FOR_G; goto next_iter; }
-		case ST_R_TRIM: {
-			const uint32_t trimLen = rdlen - hitoff - hit.len - hit.trim5;
-			const int64_t floor_ = f.maxsc > minsc ? f.maxsc : minsc;
-			const uint32_t trimMax = (uint32_t)((hit.score - floor_) / sc_penalty(sc, 0));
-			f.state = ST_R_EXT;
-			if(trimLen < trimMax) {
-				h2g_ghit* t = &ws->tmp;
-				hit_copy(t, &hit);
-				t->trim3 = trimLen;                           // GenomeHit::trim3 hi_aligner.h:855
-				calculate_score(sc, seq, t);
-				if(t->score > f.maxsc && t->score >= minsc)
-					AL_CALL(t, t->rdoff - t->trim5, t->len + t->trim5 + t->trim3, ST_R_R4);
-			}
-			goto next_iter;
-		}
-		case ST_R_R4: { if(ret > f.maxsc) f.maxsc = ret; f.state = ST_R_EXT; goto next_iter; }
-		case ST_R_EXT: {
-			h2g_ghit* t = &ws->tmp;
-			hit_copy(t, &hit);
-			int64_t m = minsc;
-			const uint32_t mm = (uint32_t)((t->score - m) / sc.mmpMax);
-			uint32_t nmm = 1;
-			if(rdlen - hitoff - hitlen <= minK_local) {
-				const uint32_t rest = rdlen - t->rdoff - t->len;
-				nmm = rest < mm ? rest : mm;
-			}
-			uint32_t le = 0, re = 0;
-			al_extend(C, seq, t, nmm, 0, H2G_MAX, &le, &re);
-			if(t->overflow) ws->overflow |= 1;
-			AL_MINSC_LIVE(m);
-			const uint32_t rest0 = rdlen - hit.len - hit.rdoff;
-			const uint32_t need = minK_local < rest0 ? minK_local : rest0;
-			if(t->score >= m && re >= need) AL_CALL(t, t->rdoff - t->trim5, t->len + t->trim5, ST_R_R5);
-			else if(hitoff + hitlen + minK_local < rdlen) {
-				const uint32_t jumplen = hitoff + hitlen + minK < rdlen ? minK : minK_local;
-				const int64_t expected = hit.score - (int64_t)((hitlen - hit.len) / jumplen) * sc.mmpMax - sc.mmpMax;
-				if(expected >= m) AL_CALL(&hit, hitoff, hitlen + jumplen, ST_R_R5);
-			}
-			AL_RET(f.maxsc);
-		}
-		case ST_R_R5: { if(ret > f.maxsc) f.maxsc = ret; AL_RET(f.maxsc); }
-		default: AL_RET(INT64_MIN);
-		}
-		}
-	next_iter:;
-	}
-#undef AL_CALL
-#undef AL_RET
-#undef AL_MINSC_LIVE
-	return ret;
 }
 
 // ---------------------------------------------------------------------------------------- go()
@@ -1477,248 +1083,6 @@ H2G_HD void al_pair_reads(const AlnParams& P, AlignWS* ws, uint32_t rdlen1, uint
 		}
 	}
 }
-
-// hybridSearch spliced_aligner.h:112-322 (bowtie2_dp = 0) over ws->ghits
-H2G_HD void al_hybrid_search(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw, Rng* rnd) {
-	const AlnParams& P = *C.P;
-	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
-		uint32_t le = H2G_MAX, re = H2G_MAX;
-		al_extend(C, sv, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
-		ws->ghit_done[hi] = 0;
-	}
-	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
-		uint32_t hj = 0;
-		for(; hj < ws->nghits; hj++) if(!ws->ghit_done[hj]) break;
-		if(hj >= ws->nghits) break;
-		for(uint32_t hk = hj + 1; hk < ws->nghits; hk++) {
-			if(ws->ghit_done[hk]) continue;
-			const h2g_ghit& a = ws->ghits[hj];
-			const h2g_ghit& b = ws->ghits[hk];
-			if(b.read > a.read || (b.read == a.read && b.len > a.len)) hj = hk;
-		}
-		h2g_ghit* gh = &ws->ghits[hj];
-		const int64_t maxsc = al_hybrid_search_recur(C, sv, ws, mw, gh, gh->rdoff, gh->len, mw->minsc, false);
-		// spliced_aligner.h:209-317: the opt-in SwAligner pass (--bowtie2-dp 1: only when nothing reached minsc; 2: always)
-		if(P.bowtie2_dp == 2 || (P.bowtie2_dp == 1 && maxsc < mw->minsc)) {
-			bool found = gh->len >= sv.len;
-			if(!found) {
-				if(C.sw == nullptr || sv.len > H2G_SW_MAX_ROWS) ws->overflow |= 256;   // no SW scratch / read longer than the DP path holds
-				else {
-					SwParams SP;
-					SP.sc = P.sc;
-					const uint32_t refoff = gh->toff > gh->rdoff ? gh->toff - gh->rdoff : 0;
-					SwOut* o = nullptr;
-					sw_align_single(*C.ref, SP, sv, gh->tidx, refoff, mw->minsc, &rnd->last, C.sw, &o);
-					if(o->overflow) ws->overflow |= 256;
-					if(o->found) {
-						// res.alres edits: setShape turned them to 5'-end coordinates, `if(!fw) invertEdits()` turns them back
-						// to the aligned strand's => exactly the backtrace's own coordinates.  genomeHit.init(fw, 0, rdlen, ...)
-						const uint32_t joinedOff = (uint32_t)((int64_t)gh->joinedOff + o->off - (int64_t)gh->toff);
-						hit_init(gh, sv.fw, 0, sv.len, gh->tidx, (uint32_t)o->off, joinedOff);
-						gh->score = o->score;
-						gh->nedits = o->nedits;
-						for(uint32_t e = 0; e < o->nedits; e++) gh->edits[e] = o->edits[e];
-						if(C.graph && C.alts->n > 0 && gh->nedits > 0) {  // replace_edits_with_alts spliced_aligner.h:282 (re-scores)
-							replace_edits_with_alts(*C.alts, gh);
-							calculate_score(P.sc, sv, gh);
-						}
-						found = true;
-					}
-				}
-			}
-			if(found) al_hybrid_search_recur(C, sv, ws, mw, gh, gh->rdoff, gh->len, mw->minsc, false);
-		}
-		ws->ghit_done[hj] = 1;
-	}
-}
-
-// align hi_aligner.h:5484-5573
-H2G_HD bool al_align(const AlnCtx& C, const SeqView& sv, AlignWS* ws, MateWS* mw, int fwi, Rng* rnd) {
-	const AlnParams& P = *C.P;
-	RBHit& hit = mw->rb[fwi];
-	bool any = false;
-	for(uint32_t i = 0; i < hit.npartial; i++) if(!ph_empty(hit.partial[i])) { any = true; break; }
-	if(!any) return false;                                    // minWidth() == max
-	int64_t bestScore = mw->bestUnp;
-	if(bestScore < mw->minsc) bestScore = mw->minsc;
-	const uint32_t maxmm = (uint32_t)((-bestScore + P.sc.mmpMax - 1) / P.sc.mmpMax);
-	const uint32_t nact = hit.numPartialSearch - hit.numUniqueSearch;
-	if(!P.secondary && nact > maxmm + 0 + 1) return true;
-	uint32_t numHits = al_get_anchor_hits(C, sv, ws, mw, fwi, rnd);
-	if(numHits == 0) return false;
-	uint64_t add = (uint64_t)((-mw->minsc) / P.sc.mmpMax) * numHits * (P.secondary ? 2 : 1);
-	ws->max_localindexatts = ws->localindexatts + (add > 10 ? add : 10);
-	al_hybrid_search(C, sv, ws, mw, rnd);
-	return true;
-}
-
-// alignMate hi_aligner.h:5579-5770: anchor the OTHER mate (ordi) near (tidx, toff) through the local index
-H2G_HD void al_align_mate(const AlnCtx& C, const SeqView& ord, AlignWS* ws, MateWS* omw, bool fw, uint32_t tidx, uint32_t toff, Rng* rnd) {
-	const AlnParams& P = *C.P;
-	const uint32_t rdlen = ord.len, minK_local = P.minK_local;
-	ws->nghits = 0;
-	uint32_t lidx = local_index_of(*C.ls, tidx, toff);
-	bool first = true;
-	uint32_t count = 0, max_hitlen = 0;
-	while(count++ < 2) {
-		if(first) first = false;
-		else {
-			if(ws->nghits > 0) break;
-			if(lidx != H2G_MAX) lidx = fw ? local_index_next(*C.ls, lidx) : local_index_prev(*C.ls, lidx);
-			if(lidx == H2G_MAX || C.ls->desc[lidx].len == 0) break;
-		}
-		if(lidx == H2G_MAX) break;
-		LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
-		uint32_t hitoff = rdlen - 1;
-		while(hitoff >= minK_local - 1) {
-			uint32_t hitlen = 0, top = H2G_MAX, bot = H2G_MAX;
-			bool uniqueStop = false;
-			uint32_t nelt = C.ls->desc[lidx].len == 0 ? 0 :
-			                al_local_search(C, ws, lidx, ord, hitoff, &hitlen, &top, &bot, &uniqueStop, 0xffffu);
-			if(nelt > 0 && nelt <= P.kseeds && hitlen > max_hitlen) {
-				h2g_coord co[AL_MAX_GHITS];
-				uint32_t nco = 0;
-				al_local_coords(C, ws, lidx, top, bot, hitoff - hitlen + 1, hitlen, co, AL_MAX_GHITS, &nco);
-				ws->nghits = 0;
-				for(uint32_t ri = 0; ri < nco; ri++) {
-					if(P.no_spliced) {
-						if((uint64_t)co[ri].toff + (uint64_t)P.maxFragLen * 2 < toff || (uint64_t)toff + (uint64_t)P.maxFragLen * 2 < co[ri].toff) continue;
-					}
-					if(C.graph) {                            // adjustWithALT (:5692)
-						uint32_t ovf = 0;
-						adjust_with_alt(*C.g, *C.ref, *C.alts, ord, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff, ws->ghits,
-						                &ws->nghits, AL_MAX_GHITS, &C.gws->awa, &ovf);
-						if(ovf) ws->overflow |= 64;
-					} else if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], ord.fw, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff);
-					else ws->overflow |= 64;
-				}
-				max_hitlen = hitlen;
-			}
-			if(hitlen > 0) hitoff -= (hitlen - 1);
-			if(hitoff > 0) hitoff -= 1;
-		}
-	}
-	// (genomeHits never exceeds kseeds here: nelt <= kseeds)
-	for(uint32_t hi = 0; hi < ws->nghits; hi++) {
-		uint32_t le = H2G_MAX, re = H2G_MAX;
-		al_extend(C, ord, &ws->ghits[hi], 0, H2G_MAX, H2G_MAX, &le, &re);
-		hit_copy(&ws->tmp2, &ws->ghits[hi]);
-		al_hybrid_search_recur(C, ord, ws, omw, &ws->tmp2, ws->tmp2.rdoff, ws->tmp2.len, omw->minsc, true);
-	}
-	(void)rnd;
-}
-
-// hi_aligner.h:4048 (go) / :4644 (nextBWT) / :4868 (pickNextReadToSearch); rds[1] == nullptr for an unpaired read
-H2G_HD void al_go(const AlnCtx& C, const DReads* const rds[2], uint32_t read, AlignWS* ws, Rng* rndp, int slot0 = 0)
-{
-	const AlnParams& P = *C.P;
-	const bool paired = rds[1] != nullptr;
-	const int nm = paired ? 2 : 1;
-	const uint32_t minK = C.g->minK;
-	Rng& rnd = *rndp;
-	ws->nghits = 0; ws->overflow = 0; ws->nrank = 0; ws->nside = 0; ws->nsteps = 0; ws->nframes_max = 0;
-	ws->npairs = 0; ws->insp_i = 0; ws->insp_j = 0; ws->bestPair = INT64_MIN; ws->best2Pair = INT64_MIN;
-	ws->localindexatts = 0; ws->max_localindexatts = 0;
-	uint32_t rdlens[2] = {0, 0};
-	for(int r = 0; r < 2; r++) {
-		MateWS& mw = ws->m[r ^ slot0];
-		mw.nsearched = 0; mw.nres = 0; mw.bestUnp = INT64_MIN; mw.best2Unp = INT64_MIN; mw.minsc = INT64_MAX;
-		mw.sink_hidden = (slot0 != 0 && nm == 1) ? 1u : 0u;
-		if(r < nm) {
-			SeqView v = seq_view(*rds[r], read, true);
-			rdlens[r] = v.len;
-			// scoreMin.f<TAlScore>(len), SIMPLE_FUNC_LINEAR 0, -0.2 (hisat2.cpp:440, simple_func.h:88)
-			mw.minsc = min_score_for(P, v.len);
-			for(int k = 0; k < 2; k++) {
-				RBHit& h = mw.rb[k];
-				h.len = v.len; h.cur = 0; h.done = 0; h.numPartialSearch = 0; h.numUniqueSearch = 0; h.npartial = 0;
-			}
-		}
-	}
-	bool found[2][2] = {{true, true}, {paired, paired}};
-	while(true) {
-		// ---------------- nextBWT ----------------
-		int sel_r = -1, sel_f = -1;
-		while(true) {
-			int rdi = -1, fwi = -1;
-			int64_t maxScore = INT64_MIN;
-			for(int r = 0; r < nm; r++) for(int k = 0; k < 2; k++) {
-				const RBHit& h = ws->m[r ^ slot0].rb[k];
-				if(h.done) continue;
-				int64_t cs = rb_search_score(h, minK);
-				if(h.cur == 0) cs = INT64_MAX;
-				if(cs > maxScore) { maxScore = cs; rdi = r; fwi = k; }
-			}
-			if(rdi < 0) break;
-			MateWS& mw = ws->m[rdi ^ slot0];
-			MateWS& ow = ws->m[(1 - rdi) ^ slot0];
-			RBHit& hit = mw.rb[fwi];
-			RBHit& rchit = mw.rb[1 - fwi];
-			bool ret_false = false, cont = false;
-			if(!P.secondary) {
-				const uint32_t numSearched = hit.numPartialSearch - hit.numUniqueSearch;
-				const int64_t bestScore = mw.bestUnp;
-				if(bestScore >= mw.minsc) {
-					const uint32_t maxmm = (uint32_t)((-bestScore + P.sc.mmpMax - 1) / P.sc.mmpMax);
-					if(numSearched > maxmm + 0 + 1) {
-						hit.done = 1;
-						if(paired) { if(ow.bestUnp >= ow.minsc && ws->npairs > 0) ret_false = true; else cont = true; }
-						else ret_false = true;
-					}
-				}
-				if(!ret_false && !cont && rchit.done && bestScore < mw.minsc) {
-					if(numSearched > (rchit.numPartialSearch - rchit.numUniqueSearch) + (P.anchorStop ? 1u : 0u)) { hit.done = 1; ret_false = true; }
-				}
-			}
-			if(ret_false) break;
-			if(cont) continue;
-			SeqView sv = seq_view(*rds[rdi], read, fwi == 0);
-			h2g_fm_hit fh;
-			if(!C.graph) partial_search_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &fh);
-			else {
-				partial_search_graph_item(*C.g, sv, hit.cur, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &fh, &C.gws->ie);
-				if(hit.npartial < AL_MAX_PARTIAL) {
-					GraphPNode& pn = C.gws->pnode[(int)(&mw - ws->m)][fwi][hit.npartial];
-					pn.node_top = fh.node_top; pn.node_bot = fh.node_bot; pn.ie = C.gws->ie;
-					if(pn.ie.n > H2G_IEDGE_CAP) ws->overflow |= 512;
-				}
-			}
-			AL_TRACE("  psearch rdi %d fwi %d cur %u -> top %u bot %u len %u type %u cur %u done %u anchor %u\n", rdi, fwi, hit.cur, fh.top, fh.bot, fh.len, fh.hit_type, fh.cur, fh.done, fh.anchorStop);
-			ws->nrank += fh.nrank; ws->nside += fh.nside;
-			hit.numPartialSearch += 1; hit.numUniqueSearch += fh.numUniqueSearch; hit.cur = fh.cur;
-			if(hit.npartial < AL_MAX_PARTIAL) {
-				PartialHit& p = hit.partial[hit.npartial++];
-				p.top = fh.top; p.bot = fh.bot; p.bwoff = fh.bwoff; p.len = fh.len; p.hit_type = fh.hit_type; p.ncoords = 0;
-			} else { ws->overflow |= 32; hit.done = 1; break; }
-			if(fh.done) { hit.done = 1; sel_r = rdi; sel_f = fwi; break; }
-			if(!fh.pseudogeneStop) { if(hit.cur + 1 < hit.len) hit.cur++; }
-			if(fh.anchorStop) { hit.done = 1; sel_r = rdi; sel_f = fwi; break; }
-		}
-		if(sel_r < 0) break;
-		SeqView sv = seq_view(*rds[sel_r], read, sel_f == 0);
-		found[sel_r][sel_f] = al_align(C, sv, ws, &ws->m[sel_r ^ slot0], sel_f, &rnd);
-		AL_TRACE(" align rdi %d fwi %d -> found %d nghits %u\n", sel_r, sel_f, (int)found[sel_r][sel_f], ws->nghits);
-		if(!found[0][0] && !found[0][1] && !found[1][0] && !found[1][1]) break;
-		if(paired) al_pair_reads(P, ws, rdlens[0], rdlens[1]);
-	}
-	// no concordant pair: use each mate's alignments as anchors for the other mate (hi_aligner.h:4092-4148)
-	if(paired && ws->npairs == 0 && (ws->m[0].bestUnp >= ws->m[0].minsc || ws->m[1].bestUnp >= ws->m[1].minsc)) {
-		bool mate_found = false;
-		const uint32_t rs_size[2] = {ws->m[0].nres, ws->m[1].nres};
-		for(int i = 0; i < 2; i++) {
-			for(uint32_t j = 0; j < rs_size[i]; j++) {
-				const bool fw = ws->m[i].res[j].fw != 0;
-				const uint32_t tidx = ws->m[i].res[j].tidx, toff = ws->m[i].res[j].toff;
-				SeqView ord = seq_view(*rds[1 - i], read, !fw);   // ofw = (fw == gMate2fw ? gMate1fw : gMate2fw) = !fw
-				AL_TRACE(" alignMate anchor mate %d res %u fw %d toff %u\n", i, j, (int)fw, toff);
-				al_align_mate(C, ord, ws, &ws->m[1 - i], fw, tidx, toff, &rnd);
-				mate_found = true;
-			}
-		}
-		if(mate_found) al_pair_reads(P, ws, rdlens[0], rdlens[1]);
-	}
-}
-
 // ---------------------------------------------------------------------------------------- finishRead selection (N1)
 // AlnSinkWrap::finishRead (aln_sink.h:1939) unpaired branch -> selectByScore (aln_sink.h:2680-2760), -k mode
 // (mhits unset): `select` lists the alignments to print, best first; select[0] is the primary.
@@ -1762,7 +1126,7 @@ H2G_HD uint32_t al_select(const MateWS* ws, const AlnParams& P, Rng* rnd, uint8_
 		}
 	}
 	uint32_t nsel = 0;
-	for(uint32_t i = 0; i < sz; i++) { if(i >= num) break; select[nsel++] = (uint8_t)idx[i]; }
+	for(uint32_t i = 0; i < sz; i++) { if(i >= num || nsel >= H2G_SELECT_CAP) break; select[nsel++] = (uint8_t)idx[i]; }
 	if(!P.secondary) {
 		for(uint32_t i = 0; i + 1 < nsel; i++) if(key[i] != key[i + 1]) { nsel = i + 1; break; }
 	}
@@ -1777,7 +1141,7 @@ struct ReadOut {
 	// second-best AlnScore (score, then fewer soft-trimmed bases) — the inputs of MAPQ and ZS:i.  INT32_MIN = invalid.
 	int32_t  best, secbest;
 	uint32_t best_trim, secbest_trim;
-	uint8_t  select[AL_MAX_RESULTS];
+	uint8_t  select[H2G_SELECT_CAP];   // fixed: the same layout in every translation unit whatever its AL_MAX_RESULTS
 };
 
 // Scoring::nFilter scoring.cpp:104 with the effective default nCeil = L,0,0.15 (SeedAlignmentPolicy::parseString
@@ -1789,30 +1153,6 @@ H2G_HD bool read_passes_filters(const SeqView& v) {
 	for(uint32_t i = 0; i < v.len; i++) if(v.fwc[i] == 4) { if(++ns > maxns) return false; }
 	return true;
 }
-
-H2G_HD void al_read(const AlnCtx& C, const DReads& rd, uint32_t read, const char* name, uint32_t namelen, AlignWS* ws, ReadOut* out) {
-	SeqView fwv = seq_view(rd, read, true);
-	Rng rnd;
-	rnd.init(gen_rand_seed(fwv, name, namelen, 0));                // rnd.init(ps->bufa().seed) hisat2.cpp:3468
-	const DReads* rds[2] = {&rd, nullptr};
-	if(!read_passes_filters(fwv)) {                                // filt[0] false: go() is skipped (hisat2.cpp:3518)
-		ws->m[0].nres = 0; ws->overflow = 0; ws->nrank = 0; ws->nsteps = 0; ws->nframes_max = 0; ws->nside = 0;
-	} else
-	al_go(C, rds, read, ws, &rnd);
-	out->nres = ws->m[0].nres; out->overflow = ws->overflow; out->nrank = ws->nrank; out->nsteps = ws->nsteps; out->depth = ws->nframes_max; out->nside = ws->nside;
-	out->nselect = al_select(&ws->m[0], *C.P, &rnd, out->select);
-	int64_t b = INT64_MIN, sb = INT64_MIN;
-	uint32_t bt = 0, sbt = 0;
-	for(uint32_t i = 0; i < ws->m[0].nres; i++) {
-		const AlnRec& r = ws->m[0].res[i];
-		const uint32_t t = r.trim5 + r.trim3;
-		if(b == INT64_MIN || r.score > b || (r.score == b && t < bt)) { sb = b; sbt = bt; b = r.score; bt = t; }
-		else if(sb == INT64_MIN || r.score > sb || (r.score == sb && t < sbt)) { sb = r.score; sbt = t; }
-	}
-	out->best = b == INT64_MIN ? INT32_MIN : (int32_t)b; out->secbest = sb == INT64_MIN ? INT32_MIN : (int32_t)sb;
-	out->best_trim = bt; out->secbest_trim = sbt;
-}
-
 // Paired read: rnd.init(seedA ^ seedB) (hisat2.cpp:3464-3466), go() with both mates.  The concordant /
 // discordant / unpaired classification and selection of finishRead stay on the host: the
 // caller replays the returned report events into its sink and continues the PRNG from `rnd_state`.
@@ -1821,20 +1161,6 @@ struct PairOut {
 	uint8_t  pair_i[AL_MAX_PAIRS], pair_j[AL_MAX_PAIRS];
 };
 
-H2G_HD void al_pair(const AlnCtx& C, const DReads& rd1, const DReads& rd2, uint32_t read, const char* name1, uint32_t namelen1,
-                    const char* name2, uint32_t namelen2, AlignWS* ws, PairOut* out) {
-	SeqView v1 = seq_view(rd1, read, true), v2 = seq_view(rd2, read, true);
-	Rng rnd;
-	const bool f1 = read_passes_filters(v1), f2 = read_passes_filters(v2);
-	const uint32_t s1 = gen_rand_seed(v1, name1, namelen1, 0), s2 = gen_rand_seed(v2, name2, namelen2, 0);
-	rnd.init((f1 && f2) ? (s1 ^ s2) : s1);                       // hisat2.cpp:3463-3468
-	ws->m[0].nres = 0; ws->m[1].nres = 0; ws->npairs = 0; ws->overflow = 0; ws->nrank = 0; ws->nsteps = 0; ws->nframes_max = 0; ws->nside = 0;
-	if(f1 && f2) { const DReads* rds[2] = {&rd1, &rd2}; al_go(C, rds, read, ws, &rnd); }
-	else if(f1)  { const DReads* rds[2] = {&rd1, nullptr}; al_go(C, rds, read, ws, &rnd, 0); }     // initRead(rds[0]) hisat2.cpp:3522
-	else if(f2)  { const DReads* rds[2] = {&rd2, nullptr}; al_go(C, rds, read, ws, &rnd, 1); }     // initRead(rds[1], rightendonly) :3524
-	out->nres[0] = ws->m[0].nres; out->nres[1] = ws->m[1].nres; out->npairs = ws->npairs; out->overflow = ws->overflow;
-	out->nrank = ws->nrank; out->nsteps = ws->nsteps; out->depth = ws->nframes_max; out->nside = ws->nside; out->rnd_state = rnd.last; out->pad = 0;
-	for(uint32_t k = 0; k < ws->npairs; k++) { out->pair_i[k] = ws->pair_i[k]; out->pair_j[k] = ws->pair_j[k]; }
-}
-
 }  // namespace h2g
+
+#include "h2g_machine.h"

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include <string>
 #include <vector>
 #include <thread>
@@ -168,7 +169,11 @@ private:
 			b.offs.push_back((uint32_t)b.codes.size());
 			return;
 		}
-		for(; q < end && *q != '\n'; q++) { char c = *q; if(c == '.') c = 'N'; if(is_read_char((unsigned char)c)) b.codes.push_back(base_code(c)); }
+		// FastqPatternSource::read (pat.cpp:932-945): '.' is N, every isalpha() character is a base through asc2dna
+		// (alphabet.cpp:298: A C G T N, every other letter reads as A); anything else is skipped
+		if(*(nm - 1) != '@') { fprintf(stderr, "Error: reads file does not look like a FASTQ file (record %llu does not start with '@'; wrapped records are not supported)\n", (unsigned long long)(count_ + (r - cur_))); exit(1); }
+		for(; q < end && *q != '\n'; q++) { int c = (unsigned char)*q; if(c == '.') c = 'N'; if(isalpha(c)) b.codes.push_back(base_code(c)); }
+		if(q + 1 < end && q[1] != '+') { fprintf(stderr, "Error: FASTQ record %.*s: the line after the sequence does not start with '+' (sequences wrapped over several lines are not supported)\n", (int)nlen, nm); exit(1); }
 		const size_t Lraw = b.codes.size() - c0;
 		const size_t t5 = trim();
 		b.offs.push_back((uint32_t)b.codes.size());
@@ -216,6 +221,8 @@ int main(int argc, char** argv) {
 	int device = 0, threads = 1;
 	std::string cmdline;
 	std::vector<std::string> opts;                      // scoring / reporting options, applied once the index type is known
+	bool sensitive = false, very_sensitive = false, saw_k = false;
+	uint32_t k_arg = 0, max_seeds_arg = 0;
 	for(int i = 0; i < argc; i++) { if(i) cmdline.push_back(' '); cmdline += argv[i]; }
 	for(int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
@@ -233,7 +240,9 @@ int main(int argc, char** argv) {
 		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min") {
 			opts.push_back(a); opts.push_back(need(a.c_str()));
 		}
-		else if(a == "--secondary" || a == "--no-softclip" || a == "--sensitive") opts.push_back(a);
+		else if(a == "--secondary" || a == "--no-softclip") opts.push_back(a);
+		else if(a == "--sensitive") sensitive = true;
+		else if(a == "--very-sensitive") very_sensitive = true;
 		else if(a == "--no-hd" || a == "--no-head") nohead = true;
 		else if(a == "--batch") batch = (size_t)atoll(need("--batch"));
 		else if(a == "--device") device = atoi(need("--device"));
@@ -279,14 +288,13 @@ int main(int argc, char** argv) {
 	for(size_t i = 0; i < opts.size(); i++) {             // same parse rules as hisat2.cpp:1500-1620 / aligner_seed_policy.cpp
 		const std::string& o = opts[i];
 		auto two = [&](int32_t* x, int32_t* y) { const std::string& v = opts[++i]; *x = atoi(v.c_str()); const size_t c = v.find(','); if(c != std::string::npos) *y = atoi(v.c_str() + c + 1); };
-		if(o == "-k") { P.khits = (uint32_t)atoi(opts[++i].c_str()); P.kseeds = P.khits * 2 > 5 ? P.khits * 2 : 5; }
-		else if(o == "--max-seeds") P.kseeds = (uint32_t)atoi(opts[++i].c_str());
-		else if(o == "--secondary") P.secondary = 1;
-		else if(o == "--sensitive") {                       // hisat2.cpp:1892-1901
-			if(P.bowtie2_dp == 0) P.bowtie2_dp = 1;
-			if(P.khits < 10) { P.khits = 10; P.kseeds = 20; }
-			P.score_min_type = 2; P.score_min_const = 0.0; P.score_min_coeff = -0.5;
+		if(o == "-k") {
+			const int k = atoi(opts[++i].c_str());
+			if(k < 1) { fprintf(stderr, "-k arg must be at least 1\n"); return 1; }
+			k_arg = (uint32_t)k; saw_k = true;
 		}
+		else if(o == "--max-seeds") max_seeds_arg = (uint32_t)atoi(opts[++i].c_str());
+		else if(o == "--secondary") P.secondary = 1;
 		else if(o == "--mp") two(&P.mm_max, &P.mm_min);
 		else if(o == "--sp") { int32_t unused = 0; two(&P.sc_max, &unused); P.sc_min = P.sc_max; }   // both read from the first number (aligner_seed_policy.cpp:438)
 		else if(o == "--no-softclip") P.sc_max = P.sc_min = INT32_MAX;
@@ -301,6 +309,12 @@ int main(int argc, char** argv) {
 			const size_t c1 = v.find(',');
 			if(c1 != std::string::npos) { P.score_min_const = atof(v.c_str() + c1 + 1); const size_t c2 = v.find(',', c1 + 1); if(c2 != std::string::npos) P.score_min_coeff = atof(v.c_str() + c2 + 1); }
 		}
+	}
+	// presets and the -k / --max-seeds defaults are resolved after every option was read, whatever their order (hisat2.cpp:1882-1909, 3903)
+	h2g_align_params_presets(&P, ix, saw_k ? 1 : 0, k_arg, max_seeds_arg, sensitive ? 1 : 0, very_sensitive ? 1 : 0);
+	if(P.khits > 30 || P.kseeds > 64 || P.kseeds < P.khits) {
+		fprintf(stderr, "hisat2-align-amd: -k %u / --max-seeds %u is outside the built range (-k <= 30, -k <= --max-seeds <= 64)\n", P.khits, P.kseeds);
+		return 1;
 	}
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);
@@ -341,6 +355,7 @@ int main(int argc, char** argv) {
 	std::vector<h2g_pair_result> pres;
 	std::vector<h2g_alnres> aln, aln2;
 	std::vector<uint64_t> ao1, ao2;
+	std::string ovf_names;
 	while(n > 0) {
 		Batch& a = A[cur]; Batch& b = B[cur];
 		size_t bases = a.codes.size();
@@ -372,7 +387,7 @@ int main(int argc, char** argv) {
 		size_t used = 0;
 		if(paired) {
 			tq0 = now();
-			pres.resize(n); ao1.resize(n + 1); ao2.resize(n + 1);
+			pres.resize(n); ao1.assign(n + 1, 0); ao2.assign(n + 1, 0);
 			if(aln.size() < 2 * n + 64) aln.resize(2 * n + 64);
 			if(aln2.size() < 2 * n + 64) aln2.resize(2 * n + 64);
 			// dense fetch: only the records that exist cross PCIe (the slot layout would move 2 x 16 x 424 B per pair)
@@ -395,7 +410,7 @@ int main(int argc, char** argv) {
 				                           pres.data(), aln.data(), ao1.data(), aln2.data(), ao2.data(), P.khits, buf.data(), buf.size(), &used);
 				if(rc != H2G_OK) die("h2g_sam_format_paired");
 			}
-			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; novf += pres[i].overflow != 0; }
+			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; if(pres[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names.push_back('\n'); } } }
 			t_fmt += now() - tf;
 		} else {
 			tq0 = now();
@@ -417,7 +432,7 @@ int main(int argc, char** argv) {
 				                             res.data(), aln.data(), ao1.data(), buf.data(), buf.size(), &used);
 				if(rc != H2G_OK) die("h2g_sam_format_unpaired");
 			}
-			for(size_t i = 0; i < n; i++) { naligned += res[i].nselect > 0; novf += res[i].overflow != 0; }
+			for(size_t i = 0; i < n; i++) { naligned += res[i].nselect > 0; if(res[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names.push_back('\n'); } } }
 			t_fmt += now() - tf;
 		}
 		fwrite(buf.data(), 1, used, out);
@@ -434,12 +449,14 @@ int main(int argc, char** argv) {
 		fwrite(sb.data(), 1, need, stderr);
 	}
 	(void)naligned; (void)nreads;
-	if(novf) fprintf(stderr, "Warning: %llu %s exceeded a fixed device capacity (h2g overflow bit); rerun them with the reference aligner\n",
-	                 (unsigned long long)novf, paired ? "pairs" : "reads");
+	// Reads whose lists overflow the default device workspace are re-run on the device with the large one (h2g_align_run's
+	// second pass).  What is still flagged after that is NOT known to equal the reference's output: name it and fail.
+	if(novf) fprintf(stderr, "Error: %llu %s exceeded even the large device workspace (h2g overflow bit); their SAM records are not verified "
+	                 "against hisat2 -- rerun these with the reference aligner:\n%s", (unsigned long long)novf, paired ? "pairs" : "reads", ovf_names.c_str());
 	if(getenv("H2G_CLI_TIMING")) fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (includes overlapped parsing %.2f s), SAM formatting %.2f s, total %.2f s [stream create %.2f, upload+launch %.2f, wait+fetch %.2f]\n", t1 - t0, t_gpu,
 	        t_parse, t_fmt, t2 - t0, t_stream, t_up, t_fetch);
 	if(st) h2g_stream_free(st);
 	h2g_sam_close(sam);
 	h2g_index_free(ix);
-	return 0;
+	return novf ? 3 : 0;
 }

@@ -1,0 +1,35 @@
+// h2g_go_args.h — the one kernel-argument block of every go() kernel build, and the extern "C" face of the translation
+// units that instantiate them.  Nothing in here depends on a unit's AL_MAX_* capacities: the per-lane workspaces are passed
+// as byte pools with strides, the results as fixed-layout records.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "h2g_align.h"
+
+__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
+	for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	if((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+struct GoArgs {
+	h2g::DGfm g; h2g::DRef ref; h2g::DLocalSet ls; h2g::DAlts alts;
+	h2g::DReads rd1, rd2;                 // rd2 only when paired
+	h2g::AlnParams P;
+	const char* names1; const uint32_t* noffs1;
+	const char* names2; const uint32_t* noffs2;
+	uint8_t* pool; size_t ws_stride;      // AlignWS per lane
+	uint8_t* gws_base; size_t gws_stride; // GraphWS per lane (graph indexes)
+	uint8_t* sw_base; size_t sw_stride;   // Smith-Waterman scratch per lane (bowtie2_dp != 0)
+	h2g::MachOut O;
+	unsigned long long* counters;
+	uint32_t* work;                       // next unclaimed position of the read list (device counter, zeroed before the launch)
+	const uint32_t* list;                 // nullptr = every read of the batch; else the read ids to process ...
+	const uint32_t* nlist;                // ... and how many (device memory: the second pass is launched without a host sync)
+	uint32_t paired;
+	uint32_t defer_overflow;              // 1: a second pass follows; overflowed reads are not counted as aligned here
+};
+#define H2G_PK_LANE_WORDS_HOST (H2G_PK_WORDS + H2G_PK_WORDS / 2)
+
+#define H2G_GO_DECLARE(NAME) \
+	extern "C" size_t h2g_go_ws_bytes_##NAME(); extern "C" size_t h2g_go_gws_bytes_##NAME(); extern "C" int h2g_go_waves_##NAME(); \
+	extern "C" void h2g_go_caps_##NAME(uint32_t*); extern "C" int h2g_go_launch_##NAME(const GoArgs*, unsigned, hipStream_t);
+H2G_GO_DECLARE(linear) H2G_GO_DECLARE(graph) H2G_GO_DECLARE(linear_big) H2G_GO_DECLARE(graph_big)

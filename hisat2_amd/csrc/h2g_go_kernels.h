@@ -1,171 +1,133 @@
-// h2g_go_kernels.h — the go() kernels (HI_Aligner::go per read / per pair).  They are instantiated in their own translation
-// units (h2g_k_go_linear.hip, h2g_k_go_graph.hip) so that the three .hip files compile in parallel and the linear kernels
-// never see the graph code; h2g_kernels.hip only declares them (H2G_GO_DECLARE_ONLY) and launches them.
+// h2g_go_kernels.h — the go() kernel (HI_Aligner::go per read / per pair) around the micro-op machine of h2g_machine.h.
+//
+// One lane = one read (pair) in flight; a lane that finishes takes the next read of the batch at once (wave-aggregated
+// atomic), so the 64 lanes of a wavefront are always populated.  Each trip of the kernel's loop every lane first runs its
+// own control flow up to its next primitive request (mach_step), then the wavefront votes and executes ONE primitive —
+// the one with the most (oldest) requesters — at ONE code site for all of them (mach_exec with a wave-uniform op).  Lanes
+// whose request lost the vote simply wait; because lanes never idle for lack of reads, waiting costs latency, not throughput.
+//
+// This header is compiled once per translation unit with that unit's capacities (-DAL_MAX_*): h2g_k_go_linear.hip,
+// h2g_k_go_graph.hip and their *_big.hip siblings (large workspaces: the second pass over reads whose lists overflowed, and
+// option sets beyond the default capacities).  h2g_kernels.hip sees only GoArgs and the extern "C" launchers of H2G_GO_UNIT.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "h2g_core.h"
 #include "h2g_align.h"
+#include "h2g_go_args.h"
 
 using namespace h2g;
 
-// waves per SIMD each go() kernel is compiled for (register budget = 512 / waves; measured on the bench workload)
-#ifndef H2G_GRAPH_WAVES
-#define H2G_GRAPH_WAVES 5
-#endif
-#ifndef H2G_LINEAR_WAVES
-#define H2G_LINEAR_WAVES 5
-#endif
-#ifndef H2G_LINEAR_PE_WAVES
-#define H2G_LINEAR_PE_WAVES 3
-#endif
-#ifndef H2G_GRAPH_PE_WAVES
-#define H2G_GRAPH_PE_WAVES 3
-#endif
-
-__device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
-	for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-	if((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+// packs read i of `rd` into this lane's LDS slot: H2G_PK_WORDS 2-bit words then H2G_PK_WORDS/2 N-mask words, word k of lane
+// t at pk[k * 256 + t] (lane-interleaved => conflict-free ds_read_b32)
+__device__ __forceinline__ void pack_read(const DReads& rd, uint32_t i, uint32_t* pk, DReads* view) {
+	const uint32_t ro = rd.offs[i], rl = rd.offs[i + 1] - ro;
+	view->pk_read = 0xffffffffu;
+	if(rl > H2G_PK_MAXLEN) return;
+	for(uint32_t w = 0; w < (rl + 15) / 16; w++) {
+		uint32_t bits = 0, mask = 0;
+		for(uint32_t k = 0; k < 16 && w * 16 + k < rl; k++) {
+			const uint32_t c = rd.codes[ro + w * 16 + k];
+			bits |= (c & 3u) << (2 * k);
+			mask |= (c > 3u ? 1u : 0u) << k;
+		}
+		pk[w * 256 + threadIdx.x] = bits;
+		uint32_t& mw = pk[(H2G_PK_WORDS + (w >> 1)) * 256 + threadIdx.x];
+		mw = (w & 1) ? (mw | (mask << 16)) : mask;
+	}
+	view->pk_read = i;
 }
 
-struct GraphArgs { DAlts alts; GraphWS* base; };   // graph index: ALT database + per-lane graph scratch (base == nullptr on linear)
+#define H2G_PK_LANE_WORDS (H2G_PK_WORDS + H2G_PK_WORDS / 2)
 
-template <int WAVES_PER_SIMD, bool GRAPH>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_align(DGfm g, DRef ref, DLocalSet ls, DReads rd, AlnParams P, const char* names,
-                                               const uint32_t* name_offs, AlignWS* pool, ReadOut* outs, h2g_alnres* aln,
-                                               unsigned long long* counters, const uint32_t* perm, unsigned long long* work,
-                                               uint8_t* sw_base, size_t sw_stride, GraphArgs ga)
+template <bool GRAPH, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_go(GoArgs A)
 {
+	extern __shared__ uint32_t s_pk[];   // [mates][H2G_PK_LANE_WORDS][256]
 	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	AlignWS* ws = pool + tid;
-	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
-	C.sw = sw_base ? sw_base + tid * sw_stride : nullptr;
-	C.alts = &ga.alts; C.gws = ga.base ? ga.base + tid : nullptr; C.graph = GRAPH;
+	const int lane = (int)(threadIdx.x & 63);
+	const bool paired = A.paired != 0;
+	AlnCtx C; C.g = &A.g; C.ref = &A.ref; C.ls = &A.ls; C.P = &A.P;
+	C.sw = A.sw_base ? A.sw_base + tid * A.sw_stride : nullptr;
+	C.alts = &A.alts; C.gws = A.gws_base ? (GraphWS*)(A.gws_base + tid * A.gws_stride) : nullptr; C.graph = GRAPH;
+	Mach M;
+	M.ws = (AlignWS*)(A.pool + tid * A.ws_stride);
+	M.L.pc = PC_IDLE; M.L.op = OP_NONE;
+	M.rd[0] = A.rd1; M.rd[1] = paired ? A.rd2 : A.rd1;
+	M.rd[0].pk = s_pk + threadIdx.x; M.rd[0].pk_stride = 256;
+	M.rd[1].pk = s_pk + H2G_PK_LANE_WORDS * 256 + threadIdx.x; M.rd[1].pk_stride = 256;
+	M.name[0] = M.name[1] = nullptr; M.namelen[0] = M.namelen[1] = 0; M.read = 0;
+	const uint32_t total = A.list ? *A.nlist : A.rd1.n;
 	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0, nside = 0;
-	// per-lane packed copy of the current read in LDS: the byte-per-base global reads of the search / extension
-	// loops become conflict-free ds_read_b32 (word k of lane t at [k][t])
-	__shared__ uint32_t s_pk[(H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256];
-	DReads rdl = rd;
-	rdl.pk = s_pk + threadIdx.x;
-	rdl.pk_stride = 256;
-	// scheduling knob (work != nullptr): a lane that finishes a read takes the next one of the work list instead of
-	// waiting for its wave's round (measured: no gain, the kernel is issue-bound under divergence)
-	for(size_t jj = tid;; jj += stride) {
-		size_t j = jj;
-		if(work) j = (size_t)atomicAdd(work, 1ull);
-		if(j >= rd.n) break;
-		const size_t i = perm ? perm[j] : j;
-		ReadOut o;
-		const uint32_t a = name_offs[i], b = name_offs[i + 1];
-		{
-			const uint32_t ro = rd.offs[i], rl = rd.offs[i + 1] - ro;
-			rdl.pk_read = 0xffffffffu;
-			if(rl <= H2G_PK_MAXLEN) {
-				for(uint32_t w = 0; w < (rl + 15) / 16; w++) {
-					uint32_t bits = 0, mask = 0;
-					for(uint32_t k = 0; k < 16 && w * 16 + k < rl; k++) {
-						const uint32_t c = rd.codes[ro + w * 16 + k];
-						bits |= (c & 3u) << (2 * k);
-						mask |= (c > 3u ? 1u : 0u) << k;
+	bool more = true;
+	uint32_t age[OP_COUNT];
+#pragma unroll
+	for(int k = 0; k < (int)OP_COUNT; k++) age[k] = 0;
+	for(;;) {
+		if(M.L.pc == PC_FINISHED) {                      // the read this lane carried is done: account, free the lane
+			nrank += M.ws->nrank; nsteps += M.ws->nsteps; nside += M.ws->nside;
+			naln += (M.L.a0 != 0) && !(A.defer_overflow && M.L.a1 != 0); novf += M.L.a1 != 0;
+			M.L.pc = PC_IDLE;
+		}
+		if(more) {                                       // idle lanes take the next reads of the batch
+			const bool idle = M.L.pc == PC_IDLE;
+			const unsigned long long need = __ballot(idle);
+			if(need) {
+				const int leader = __ffsll((long long)need) - 1;
+				const uint32_t cnt = (uint32_t)__popcll(need);
+				uint32_t base = 0;
+				if(lane == leader) base = atomicAdd(A.work, cnt);
+				base = (uint32_t)__shfl((int)base, leader);
+				if(idle) {
+					const uint32_t j = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+					if(j < total) {
+						const uint32_t i = A.list ? A.list[j] : j;
+						pack_read(A.rd1, i, s_pk, &M.rd[0]);
+						M.name[0] = A.names1 + A.noffs1[i]; M.namelen[0] = A.noffs1[i + 1] - A.noffs1[i];
+						if(paired) {
+							pack_read(A.rd2, i, s_pk + H2G_PK_LANE_WORDS * 256, &M.rd[1]);
+							M.name[1] = A.names2 + A.noffs2[i]; M.namelen[1] = A.noffs2[i + 1] - A.noffs2[i];
+						}
+						mach_begin(M, i, paired);
 					}
-					s_pk[w * 256 + threadIdx.x] = bits;
-					uint32_t& mw = s_pk[(H2G_PK_WORDS + (w >> 1)) * 256 + threadIdx.x];
-					mw = (w & 1) ? (mw | (mask << 16)) : mask;
 				}
-				rdl.pk_read = (uint32_t)i;
+				if(base + cnt >= total) more = false;
 			}
 		}
-		al_read(C, rdl, (uint32_t)i, names + a, b - a, ws, &o);
-		outs[i] = o;
-		for(uint32_t k = 0; k < o.nselect && k < H2G_ALN_CAP; k++) {
-			const AlnRec& r = ws->m[0].res[o.select[k]];
-			h2g_alnres& d = aln[i * H2G_ALN_CAP + k];
-			d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
-			d.nedits = r.nedits; d.pad = 0; d.score = r.score;
-			for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
+		if(M.L.pc != PC_IDLE && M.L.op == OP_NONE) mach_step(C, M);   // control flow up to the next primitive request
+		// vote: the primitive with the most requesters, aged so that a rare request cannot starve behind common ones
+		uint32_t best = 0, bestScore = 0;
+#pragma unroll
+		for(int k = 1; k < (int)OP_COUNT; k++) {
+			const uint32_t c = (uint32_t)__popcll(__ballot(M.L.op == (uint32_t)k));
+			if(c) {
+				const uint32_t sc = c + age[k];
+				if(sc > bestScore) { bestScore = sc; best = (uint32_t)k; }
+				age[k] += 2;
+			} else age[k] = 0;
 		}
-		nrank += o.nrank; nsteps += o.nsteps; naln += o.nselect > 0; novf += o.overflow != 0; nside += o.nside;
+		if(best == 0) {
+			if(!more && __ballot(M.L.pc != PC_IDLE) == 0ull) break;
+			continue;
+		}
+#pragma unroll
+		for(int k = 1; k < (int)OP_COUNT; k++) if((uint32_t)k == best) age[k] = 0;
+		best = (uint32_t)__builtin_amdgcn_readfirstlane((int)best);
+		if(M.L.op == best) mach_exec(C, M, best, A.O, paired);
 	}
-	wave_add(counters + 0, nrank);
-	wave_add(counters + 1, nside);
-	wave_add(counters + 2, nsteps);
-	wave_add(counters + 4, naln);
-	wave_add(counters + 5, novf);
+	wave_add(A.counters + 0, nrank);
+	wave_add(A.counters + 1, nside);
+	wave_add(A.counters + 2, nsteps);
+	wave_add(A.counters + 4, naln);
+	wave_add(A.counters + 5, novf);
 }
 
-// lane = one read pair; both mates are packed into LDS (mate 2 behind mate 1)
-template <bool GRAPH, int WIDE = 0>   // WIDE only tags the linear build with AL_MAX_GHITS = 20 (-k up to 10, --sensitive)
-__global__ __launch_bounds__(256, GRAPH ? H2G_GRAPH_PE_WAVES : H2G_LINEAR_PE_WAVES) void k_align_pairs(DGfm g, DRef ref, DLocalSet ls, DReads rd1, DReads rd2, AlnParams P,
-                                                        const char* names1, const uint32_t* noffs1, const char* names2,
-                                                        const uint32_t* noffs2, AlignWS* pool, PairOut* outs, h2g_alnres* aln1,
-                                                        h2g_alnres* aln2, unsigned long long* counters, uint8_t* sw_base, size_t sw_stride, GraphArgs ga)
-{
-	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	AlignWS* ws = pool + tid;
-	AlnCtx C; C.g = &g; C.ref = &ref; C.ls = &ls; C.P = &P;
-	C.sw = sw_base ? sw_base + tid * sw_stride : nullptr;
-	C.alts = &ga.alts; C.gws = ga.base ? ga.base + tid : nullptr; C.graph = GRAPH;
-	unsigned long long nrank = 0, nsteps = 0, npair = 0, novf = 0, nside = 0;
-	__shared__ uint32_t s_pk[2 * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256];
-	DReads rl[2] = {rd1, rd2};
-	for(int m = 0; m < 2; m++) { rl[m].pk = s_pk + m * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256 + threadIdx.x; rl[m].pk_stride = 256; }
-	for(size_t i = tid; i < rd1.n; i += stride) {
-		for(int m = 0; m < 2; m++) {
-			const DReads& rd = m == 0 ? rd1 : rd2;
-			uint32_t* pk = s_pk + m * (H2G_PK_WORDS + H2G_PK_WORDS / 2) * 256;
-			const uint32_t ro = rd.offs[i], rlen = rd.offs[i + 1] - ro;
-			rl[m].pk_read = 0xffffffffu;
-			if(rlen <= H2G_PK_MAXLEN) {
-				for(uint32_t w = 0; w < (rlen + 15) / 16; w++) {
-					uint32_t bits = 0, mask = 0;
-					for(uint32_t k = 0; k < 16 && w * 16 + k < rlen; k++) {
-						const uint32_t c = rd.codes[ro + w * 16 + k];
-						bits |= (c & 3u) << (2 * k);
-						mask |= (c > 3u ? 1u : 0u) << k;
-					}
-					pk[w * 256 + threadIdx.x] = bits;
-					uint32_t& mw = pk[(H2G_PK_WORDS + (w >> 1)) * 256 + threadIdx.x];
-					mw = (w & 1) ? (mw | (mask << 16)) : mask;
-				}
-				rl[m].pk_read = (uint32_t)i;
-			}
-		}
-		PairOut o;
-		al_pair(C, rl[0], rl[1], (uint32_t)i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &o);
-		outs[i] = o;
-		for(int m = 0; m < 2; m++) {
-			h2g_alnres* dst = (m == 0 ? aln1 : aln2) + i * H2G_PAIR_RES_CAP;
-			const uint32_t n = o.nres[m] < H2G_PAIR_RES_CAP ? o.nres[m] : H2G_PAIR_RES_CAP;
-			for(uint32_t k = 0; k < n; k++) {
-				const AlnRec& r = ws->m[m].res[k];
-				h2g_alnres& d = dst[k];
-				d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
-				d.nedits = r.nedits; d.pad = 0; d.score = r.score;
-				for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
-			}
-		}
-		nrank += o.nrank; nsteps += o.nsteps; npair += o.npairs > 0; nside += o.nside;
-		novf += (o.overflow != 0 || o.nres[0] > H2G_PAIR_RES_CAP || o.nres[1] > H2G_PAIR_RES_CAP);
-	}
-	wave_add(counters + 0, nrank);
-	wave_add(counters + 1, nside);
-	wave_add(counters + 2, nsteps);
-	wave_add(counters + 4, npair);
-	wave_add(counters + 5, novf);
-}
-
-#if defined(H2G_GO_DECLARE_ONLY)
-extern template __global__ void k_align<H2G_LINEAR_WAVES, false>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
-                                                  unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-extern template __global__ void k_align<H2G_GRAPH_WAVES, true>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
-                                                 unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-extern template __global__ void k_align_pairs<false>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
-                                                     const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-extern template __global__ void k_align<3, false>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
-                                                  unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-extern template __global__ void k_align_pairs<false, 1>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
-                                                        const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-extern template __global__ void k_align_pairs<true>(DGfm, DRef, DLocalSet, DReads, DReads, AlnParams, const char*, const uint32_t*, const char*,
-                                                    const uint32_t*, AlignWS*, PairOut*, h2g_alnres*, h2g_alnres*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-#endif
+// the extern "C" face of one translation unit (declared in h2g_go_args.h)
+#define H2G_GO_UNIT(NAME, GRAPH, WAVES) \
+	extern "C" size_t h2g_go_ws_bytes_##NAME() { return (sizeof(AlignWS) + 255) & ~(size_t)255; } \
+	extern "C" size_t h2g_go_gws_bytes_##NAME() { return (GRAPH) ? ((sizeof(GraphWS) + 255) & ~(size_t)255) : 0; } \
+	extern "C" int h2g_go_waves_##NAME() { return (WAVES); } \
+	extern "C" void h2g_go_caps_##NAME(uint32_t* c) { c[0] = AL_MAX_GHITS; c[1] = AL_MAX_RESULTS; c[2] = AL_MAX_SEARCHED; c[3] = AL_MAX_DEPTH; c[4] = AL_MAX_PARTIAL; } \
+	extern "C" int h2g_go_launch_##NAME(const GoArgs* a, unsigned grid, hipStream_t st) { \
+		const unsigned lds = (a->paired ? 2u : 1u) * H2G_PK_LANE_WORDS * 256u * 4u; \
+		hipLaunchKernelGGL((k_go<GRAPH, WAVES>), dim3(grid), dim3(256), lds, st, *a); \
+		return (int)hipGetLastError(); }

@@ -1,6 +1,7 @@
-// Explicit instantiation of the single-end go() kernel for LINEAR indexes (see h2g_go_kernels.h).
+// go() kernel for LINEAR indexes with the default capacities (see h2g_go_kernels.h): -k <= 5 / --max-seeds <= 10.
+#define AL_MAX_GHITS 10   // max(khits, kseeds) of the default option set on a linear index (hisat2.cpp:3174-3176, 3903-3906)
 #include "h2g_go_kernels.h"
-template __global__ void k_align<H2G_LINEAR_WAVES, false>(DGfm, DRef, DLocalSet, DReads, AlnParams, const char*, const uint32_t*, AlignWS*, ReadOut*, h2g_alnres*,
-        unsigned long long*, const uint32_t*, unsigned long long*, uint8_t*, size_t, GraphArgs);
-// per-lane workspace size of THIS translation unit's layout (AL_MAX_GHITS differs between the linear and graph units)
-extern "C" size_t h2g_ws_bytes_linear_se() { return sizeof(AlignWS); }
+#ifndef H2G_LINEAR_WAVES
+#define H2G_LINEAR_WAVES 4
+#endif
+H2G_GO_UNIT(linear, false, H2G_LINEAR_WAVES)

@@ -14,18 +14,7 @@
 #include "h2g_graph.h"
 #include "h2g_sw.h"
 #include "h2g_local_pack.h"
-#define H2G_GO_DECLARE_ONLY
-#include "h2g_go_kernels.h"
-// AlignWS is opaque on this side: each go() unit reports the size of its own layout
-extern "C" size_t h2g_ws_bytes_linear_se(); extern "C" size_t h2g_ws_bytes_linear_pe();
-extern "C" size_t h2g_ws_bytes_graph_se();  extern "C" size_t h2g_ws_bytes_graph_pe();
-extern "C" size_t h2g_ws_bytes_linear_wide_se(); extern "C" size_t h2g_ws_bytes_linear_wide_pe();
-// per-lane workspace of the go() build that is about to run (linear narrow / linear wide / graph; the larger of SE and PE)
-static size_t ws_bytes_per_lane(bool linear, bool wide) {
-	size_t a = linear ? h2g_ws_bytes_linear_se() : h2g_ws_bytes_graph_se(), b = linear ? h2g_ws_bytes_linear_pe() : h2g_ws_bytes_graph_pe();
-	if(linear && wide) { a = h2g_ws_bytes_linear_wide_se(); b = h2g_ws_bytes_linear_wide_pe(); }
-	return a > b ? a : b;
-}
+#include "h2g_go_args.h"   // GoArgs + the extern "C" face of the go() units (their AlignWS layouts are opaque on this side)
 
 using namespace h2g;
 
@@ -67,12 +56,15 @@ struct h2g_stream {
 	uint32_t* d_name_offs = nullptr;
 	size_t names_cap = 0;
 	bool has_names = false;
-	AlignWS* d_ws = nullptr;
-	size_t ws_bytes = 0;          // bytes allocated behind d_ws (lanes x per-lane size of the build last run)
-	uint8_t* d_sw = nullptr;      // per-lane Smith-Waterman scratch of the go() kernels (only with bowtie2_dp != 0)
-	size_t sw_stride = 0, sw_lanes = 0;
-	GraphWS* d_gws = nullptr;     // per-lane graph scratch of the go() kernels (graph indexes only)
-	size_t gws_lanes = 0;
+	// per-lane scratch of the go() kernels: [0] the main pass, [1] the second pass over overflowed reads (large workspace)
+	struct GoPool {
+		uint8_t* ws = nullptr;  size_t ws_bytes = 0;      // AlignWS x lanes of the unit last run
+		uint8_t* gws = nullptr; size_t gws_bytes = 0;     // GraphWS x lanes (graph indexes only)
+		uint8_t* sw = nullptr;  size_t sw_stride = 0, sw_lanes = 0;   // Smith-Waterman scratch (only with bowtie2_dp != 0)
+	} pool[2];
+	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
+	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
+	size_t aln_alloc = 0;             // records allocated behind d_aln
 	uint8_t* d_sw_ws = nullptr;   // h2g_sw_align: H/E/F workspace of one batch of problems
 	size_t sw_ws_bytes = 0;
 	SwLaneState* d_sw_states = nullptr;
@@ -90,7 +82,7 @@ struct h2g_stream {
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t tmp_sz[4] = {0, 0, 0, 0};
-	hipEvent_t ev[8];
+	hipEvent_t ev[10];
 	bool ran_seed = false, ran_align = false;
 	h2g_counters last;
 };
@@ -303,7 +295,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	h2g_stream* s = new h2g_stream();
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-	for(int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&s->ev[i]));
+	for(int i = 0; i < 10; i++) HIPCHK(hipEventCreate(&s->ev[i]));
 	HIPCHK(hipMalloc((void**)&s->d_counters, 16 * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(s->d_counters, 0, 16 * sizeof(unsigned long long)));
 	if(max_reads) {
@@ -321,11 +313,12 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); (void)hipFree(s->d_ws); (void)hipFree(s->d_sw); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->d_gws);
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); }
+	(void)hipFree(s->d_ovf_list); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
-	for(int i = 0; i < 8; i++) (void)hipEventDestroy(s->ev[i]);
+	for(int i = 0; i < 10; i++) (void)hipEventDestroy(s->ev[i]);
 	(void)hipStreamDestroy(s->st);
 	delete s;
 }
@@ -1114,73 +1107,35 @@ extern "C" h2g_status h2g_seed_extend_fetch(h2g_stream* s, h2g_seed_result* out,
 // ------------------------------------------------------------------------------------------ go() for the batch
 static_assert(sizeof(h2g_alnres) == sizeof(AlnRec), "h2g_alnres must mirror AlnRec");
 static_assert(sizeof(h2g_read_result) == 40, "h2g_read_result layout");
+static_assert(sizeof(h2g_pair_result) == sizeof(PairOut), "h2g_pair_result must mirror PairOut");
+static_assert(H2G_PAIR_CAP == AL_MAX_PAIRS, "pair capacity");
 
-// One lane = one read at a time (grid-stride); each lane owns one AlignWS in HBM (explicit recursion stack,
-// sink, searched list).  Selected alignments are written in print order.
-#define H2G_NCLASS 8
-// Expected-cost class of one read for scheduling k_align (results do not depend on it): Hamming distance between
-// the whole read and the reference at the position implied by its first anchor coordinate, on the better strand.
-// 0 = >= 4 mismatches / indel-like (heaviest), 1 = 3, 2 = 2, 3 = several anchor coordinates, 4 = no anchor on either
-// strand, 5 = 1 mismatch, 6 = perfect.  Buckets are processed in this order (longest-processing-time first).
-__device__ __forceinline__ uint32_t read_hamming(const DRef& ref, const SeqView& sv, const h2g_seed_result& r) {
-	if(r.ncoords == 0 || r.ext[0].tidx == H2G_MAX) return 0xffffu;
-	const int64_t start = (int64_t)r.ext[0].toff - (int64_t)r.ext[0].rdoff;
-	RefCursor rc;
-	rc.init(&ref, r.ext[0].tidx);
-	uint32_t mm = 0;
-	for(uint32_t i = 0; i < sv.len; i++) {
-		const int64_t p = start + i;
-		const int rf = p < 0 ? 4 : rc.get(p);
-		if(rf != sv.at(i)) { if(++mm >= 8) break; }
-	}
-	return mm;
-}
-__global__ __launch_bounds__(256) void k_classify(DRef ref, DReads rd, const h2g_seed_result* seed, uint8_t* keys, uint32_t* blockhist) {
-	__shared__ uint32_t hist[H2G_NCLASS];
-	if(threadIdx.x < H2G_NCLASS) hist[threadIdx.x] = 0;
-	__syncthreads();
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i < rd.n) {
-		const h2g_seed_result* r = seed + 2 * (size_t)i;
-		uint32_t best = 0xffffu, multi = 0;
-		for(int k = 0; k < 2; k++) {
-			if(r[k].ncoords > 1) multi = 1;
-			uint32_t h = read_hamming(ref, seq_view(rd, i, k == 0), r[k]);
-			if(h < best) best = h;
-		}
-		uint32_t key = best == 0xffffu ? 4u : multi ? 3u : best == 0 ? 6u : best == 1 ? 5u : best == 2 ? 2u : best == 3 ? 1u : 0u;
-		keys[i] = (uint8_t)key;
-		atomicAdd(&hist[key], 1u);
-	}
-	__syncthreads();
-	if(threadIdx.x < H2G_NCLASS) blockhist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];   // class-major
-}
-// exclusive scan of the class-major (class, block) histogram: one wave, chunked
-__global__ void k_class_scan(uint32_t* blockhist, uint32_t total) {
-	__shared__ uint32_t carry;
-	if(threadIdx.x == 0) carry = 0;
-	__syncthreads();
-	for(uint32_t base = 0; base < total; base += 64) {
-		const uint32_t i = base + threadIdx.x;
-		uint32_t v = i < total ? blockhist[i] : 0, x = v;
-		for(int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if((int)threadIdx.x >= o) x += y; }
-		if(i < total) blockhist[i] = carry + x - v;
-		__syncthreads();
-		if(threadIdx.x == 63) carry += x;
-		__syncthreads();
-	}
-}
-__global__ __launch_bounds__(256) void k_class_scatter(const uint8_t* keys, uint32_t n, const uint32_t* blockoff, uint32_t* perm) {
-	__shared__ uint32_t cur[H2G_NCLASS];
-	if(threadIdx.x < H2G_NCLASS) cur[threadIdx.x] = blockoff[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
-	__syncthreads();
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i < n) perm[atomicAdd(&cur[keys[i]], 1u)] = i;
-}
-
-// `perm` (optional) lists read ids bucketed by the outcome class of the seed stage, so that the 64 lanes of a
-// wave walk similar control flow (k_classify below); results are written by read id, so order is irrelevant.
 extern "C" void h2g_align_params_init(h2g_align_params* p, const h2g_index* ix) { align_params_defaults(p, !ix || ix->dg.linear); }
+
+// hisat2.cpp applies its presets AFTER every option was read, and the index type decides the default -k:
+//   khits starts at 10 (:336); -k sets it and saw_k (:1316-1322); --sensitive: bowtie2_dp 0 -> 1, khits < 10 -> 10 (+ saw_k),
+//   --score-min L,0,-0.5 (:1892-1901); --very-sensitive: bowtie2_dp 2, khits < 30 -> 30 (+ saw_k), L,0,-1 (:1902-1909);
+//   without saw_k khits = 5 on a linear index, 10 on a graph (:3903-3906); --max-seeds 0 -> max(5, 2 khits) (:3174-3176).
+// So `--sensitive` alone keeps -k 5 on a linear index, and a preset's --score-min wins over an explicit one.
+extern "C" void h2g_align_params_presets(h2g_align_params* p, const h2g_index* ix, int saw_k, uint32_t k_arg, uint32_t max_seeds_arg,
+                                         int sensitive, int very_sensitive)
+{
+	if(!p) return;
+	uint32_t khits = saw_k ? k_arg : 10u;
+	bool sawk = saw_k != 0;
+	if(sensitive) {
+		if(p->bowtie2_dp == 0) p->bowtie2_dp = 1;
+		if(khits < 10) { khits = 10; sawk = true; }
+		p->score_min_type = 2; p->score_min_const = 0.0; p->score_min_coeff = (double)(-0.5f);
+	} else if(very_sensitive) {
+		p->bowtie2_dp = 2;
+		if(khits < 30) { khits = 30; sawk = true; }
+		p->score_min_type = 2; p->score_min_const = 0.0; p->score_min_coeff = (double)(-1.0f);
+	}
+	if(!sawk) khits = (!ix || ix->dg.linear) ? 5u : 10u;
+	p->khits = khits;
+	p->kseeds = max_seeds_arg ? max_seeds_arg : (khits * 2 > 5 ? khits * 2 : 5);
+}
 
 extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const uint32_t* offs, size_t n) {
 	if(!s || !bytes || !offs || n != s->n_reads || n == 0) return H2G_ERR_ARG;
@@ -1199,131 +1154,6 @@ extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const
 	s->has_names = true;
 	return H2G_OK;
 }
-
-// per-lane Smith-Waterman scratch of the go() kernels (bowtie2_dp != 0): sw_scratch_bytes(longest read) per lane
-static int sw_scratch_for(h2g_stream* s, uint32_t bowtie2_dp, size_t nthreads, uint8_t** base) {
-	*base = nullptr;
-	if(bowtie2_dp == 0) return H2G_OK;
-	if(bowtie2_dp > 2) return H2G_ERR_ARG;
-	if(s->max_read_len == 0 || s->max_read_len > H2G_SW_MAX_ROWS) { snprintf(g_err, sizeof g_err, "bowtie2_dp: read length %u outside 1..%d", s->max_read_len, H2G_SW_MAX_ROWS); return H2G_ERR_ARG; }
-	const size_t stride = (sw_scratch_bytes(s->max_read_len) + 255) & ~(size_t)255;
-	if(s->sw_stride < stride || s->sw_lanes < nthreads) {
-		(void)hipFree(s->d_sw); s->d_sw = nullptr; s->sw_stride = 0; s->sw_lanes = 0;
-		HIPCHK(hipMalloc((void**)&s->d_sw, stride * nthreads));
-		HIPCHK(hipMemset(s->d_sw, 0, stride * nthreads));   // SwLaneState: mask-table generations start at 0
-		s->sw_stride = stride; s->sw_lanes = nthreads;
-	}
-	*base = s->d_sw;
-	return H2G_OK;
-}
-
-// go() on a graph index: the index must be a SNP graph (ALT database present) and every lane needs a GraphWS
-static int need_alignable(h2g_stream* s) {
-	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
-	const DGfm& g = s->ix->dg;
-	if(g.linear && g.lineRate == 6) return H2G_OK;
-	if(!g.linear && g.lineRate == 7) return H2G_OK;
-	snprintf(g_err, sizeof g_err, "unsupported side geometry (lineRate %u)", g.lineRate);
-	return H2G_ERR_UNSUPPORTED;
-}
-static int graph_scratch_for(h2g_stream* s, size_t nthreads, GraphArgs* ga) {
-	ga->alts = s->ix->dalts;
-	ga->base = nullptr;
-	if(s->ix->dg.linear) return H2G_OK;
-	if(s->gws_lanes < nthreads) {
-		(void)hipFree(s->d_gws); s->d_gws = nullptr; s->gws_lanes = 0;
-		HIPCHK(hipMalloc((void**)&s->d_gws, nthreads * sizeof(GraphWS)));
-		s->gws_lanes = nthreads;
-	}
-	ga->base = s->d_gws;
-	return H2G_OK;
-}
-
-extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) {
-	if(!s || !p) return H2G_ERR_ARG;
-	int rc;
-	if((rc = need_reads(s)) || (rc = need_alignable(s))) return rc;
-	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
-	if(!s->has_names) { snprintf(g_err, sizeof g_err, "align: read names not set (h2g_set_read_names)"); return H2G_ERR_ARG; }
-	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
-	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > 20u || p->kseeds < p->khits) return H2G_ERR_ARG;
-	HIPCHK(hipSetDevice(s->ix->device));
-	// 2 waves per SIMD on every CU: enough lanes to cover HBM latency, bounded workspace (sizeof(AlignWS) each)
-	const unsigned block = 256;
-	size_t want = (s->n_reads + block - 1) / block;
-	const size_t maxblocks = 256 * (size_t)(!s->ix->dg.linear ? H2G_GRAPH_WAVES : p->kseeds > 10 ? 3 : H2G_LINEAR_WAVES)   /* resident blocks per CU */;
-	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
-	const size_t nthreads = (size_t)grid * block;
-	{
-		const size_t need = nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0, p->kseeds > 10);
-		if(s->ws_bytes < need) {
-			(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_bytes = 0;
-			HIPCHK(hipMalloc((void**)&s->d_ws, need));
-			s->ws_bytes = need;
-		}
-	}
-	if(!s->d_rout) {
-		HIPCHK(hipMalloc((void**)&s->d_rout, s->max_reads * sizeof(ReadOut)));
-		HIPCHK(hipMalloc((void**)&s->d_aln, s->max_reads * (size_t)H2G_ALN_CAP * sizeof(h2g_alnres)));
-	}
-	const AlnParams P = aln_params_from(*p, true, s->ix->dg.linear);
-	uint8_t* sw_base = nullptr;
-	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
-	GraphArgs ga;
-	if((rc = graph_scratch_for(s, nthreads, &ga))) return rc;
-	(void)hipGetLastError();
-	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
-	HIPCHK(hipEventRecord(s->ev[5], s->st));
-	const uint32_t* perm = nullptr;
-	static const int sort_mode = getenv("H2G_ALIGN_SORT") ? atoi(getenv("H2G_ALIGN_SORT")) : 0;
-	static const int dyn_mode = getenv("H2G_ALIGN_DYN") ? atoi(getenv("H2G_ALIGN_DYN")) : 0;
-	if(sort_mode && s->ix->dg.linear) {
-		// seed stage (partialSearch both strands from offset 0 -> coordinates -> 0-mm extension) + Hamming distance
-		// of the whole read as a cost classifier; bucket read ids by class, heaviest first
-		h2g_seed_params sp;
-		sp.pseudogeneStop = 0; sp.anchorStop = 1; sp.khits = p->khits; sp.search_variant = 0;
-		const size_t n2 = s->n_reads * 2;
-		const unsigned cg = (unsigned)((s->n_reads + 255) / 256);
-		void *dkeys, *dhist, *dperm;
-		if((rc = tmp_buf(s, 0, s->n_reads, &dkeys)) || (rc = tmp_buf(s, 1, (size_t)H2G_NCLASS * cg * 4, &dhist)) || (rc = tmp_buf(s, 2, s->n_reads * 4, &dperm))) return rc;
-		DScoring sc;
-		hipLaunchKernelGGL(k_seed_search, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), sp, s->d_seed, s->d_counters + 8);
-		hipLaunchKernelGGL(k_seed_resolve_extend, dim3(grid_for(n2, 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dr, dreads(s), sc, s->d_seed, s->d_counters + 8);
-		hipLaunchKernelGGL(k_classify, dim3(cg), dim3(256), 0, s->st, s->ix->dr, dreads(s), (const h2g_seed_result*)s->d_seed, (uint8_t*)dkeys, (uint32_t*)dhist);
-		hipLaunchKernelGGL(k_class_scan, dim3(1), dim3(64), 0, s->st, (uint32_t*)dhist, (uint32_t)(H2G_NCLASS * cg));
-		hipLaunchKernelGGL(k_class_scatter, dim3(cg), dim3(256), 0, s->st, (const uint8_t*)dkeys, (uint32_t)s->n_reads, (const uint32_t*)dhist, (uint32_t*)dperm);
-		perm = (const uint32_t*)dperm;
-	}
-	HIPCHK(hipEventRecord(s->ev[7], s->st));
-#define H2G_LAUNCH_ALIGN(W, G) hipLaunchKernelGGL((k_align<W, G>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, dreads(s), P, \
-		s->d_names, s->d_name_offs, s->d_ws, s->d_rout, s->d_aln, s->d_counters, perm, dyn_mode ? s->d_counters + 7 : nullptr, sw_base, s->sw_stride, ga)
-	if(!s->ix->dg.linear) H2G_LAUNCH_ALIGN(H2G_GRAPH_WAVES, true);        // graph: the out-of-line graph functions need ~230 VGPRs
-	else if(p->kseeds > 10) H2G_LAUNCH_ALIGN(3, false);     // linear, wide genome-hit list (-k > 5, --sensitive)
-	else H2G_LAUNCH_ALIGN(H2G_LINEAR_WAVES, false);
-#undef H2G_LAUNCH_ALIGN
-	HIPCHK(hipEventRecord(s->ev[6], s->st));
-	HIPCHK(hipGetLastError());
-	s->ran_align = true;
-	return H2G_OK;
-}
-
-extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t first, size_t n) {
-	if(!s || !res || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
-	std::vector<ReadOut> tmp(n);
-	HIPCHK(hipMemcpyAsync(tmp.data(), s->d_rout + first, n * sizeof(ReadOut), hipMemcpyDeviceToHost, s->st));
-	if(aln) HIPCHK(hipMemcpyAsync(aln, s->d_aln + first * H2G_ALN_CAP, n * H2G_ALN_CAP * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
-	for(size_t i = 0; i < n; i++) {
-		res[i].nres = tmp[i].nres; res[i].nselect = tmp[i].nselect; res[i].overflow = tmp[i].overflow;
-		res[i].nrank = tmp[i].nrank; res[i].nsteps = tmp[i].nsteps; res[i].depth = tmp[i].depth;
-		res[i].best = tmp[i].best; res[i].secbest = tmp[i].secbest; res[i].best_trim = tmp[i].best_trim; res[i].secbest_trim = tmp[i].secbest_trim;
-	}
-	return H2G_OK;
-}
-
-// ------------------------------------------------------------------------------------------ paired go()
-static_assert(sizeof(h2g_pair_result) == sizeof(PairOut), "h2g_pair_result must mirror PairOut");
-static_assert(H2G_PAIR_CAP == AL_MAX_PAIRS, "pair capacity");
 
 extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const uint32_t* offs2, const char* quals2,
                                     const char* nb2, const uint32_t* noffs2, size_t n)
@@ -1351,58 +1181,194 @@ extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const 
 	return H2G_OK;
 }
 
-extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params* p) {
+// go() on a graph index: the index must be a SNP graph (ALT database present)
+static int need_alignable(h2g_stream* s) {
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	const DGfm& g = s->ix->dg;
+	if(g.linear && g.lineRate == 6) return H2G_OK;
+	if(!g.linear && g.lineRate == 7) return H2G_OK;
+	snprintf(g_err, sizeof g_err, "unsupported side geometry (lineRate %u)", g.lineRate);
+	return H2G_ERR_UNSUPPORTED;
+}
+
+// the go() units: [linear?][big?]
+struct GoUnit {
+	size_t (*ws_bytes)(); size_t (*gws_bytes)(); int (*waves)(); void (*caps)(uint32_t*); int (*launch)(const GoArgs*, unsigned, hipStream_t);
+};
+static const GoUnit& go_unit(bool linear, bool big) {
+	static const GoUnit u[2][2] = {
+		{{h2g_go_ws_bytes_graph, h2g_go_gws_bytes_graph, h2g_go_waves_graph, h2g_go_caps_graph, h2g_go_launch_graph},
+		 {h2g_go_ws_bytes_graph_big, h2g_go_gws_bytes_graph_big, h2g_go_waves_graph_big, h2g_go_caps_graph_big, h2g_go_launch_graph_big}},
+		{{h2g_go_ws_bytes_linear, h2g_go_gws_bytes_linear, h2g_go_waves_linear, h2g_go_caps_linear, h2g_go_launch_linear},
+		 {h2g_go_ws_bytes_linear_big, h2g_go_gws_bytes_linear_big, h2g_go_waves_linear_big, h2g_go_caps_linear_big, h2g_go_launch_linear_big}}};
+	return u[linear ? 1 : 0][big ? 1 : 0];
+}
+
+// sizes the per-lane scratch of one pass and fills the pool fields of `a`
+static int go_pool_for(h2g_stream* s, int which, const GoUnit& u, size_t lanes, uint32_t bowtie2_dp, GoArgs* a) {
+	h2g_stream::GoPool& pl = s->pool[which];
+	const size_t wsb = u.ws_bytes(), gwb = u.gws_bytes();
+	if(pl.ws_bytes < lanes * wsb) {
+		(void)hipFree(pl.ws); pl.ws = nullptr; pl.ws_bytes = 0;
+		HIPCHK(hipMalloc((void**)&pl.ws, lanes * wsb));
+		pl.ws_bytes = lanes * wsb;
+	}
+	a->pool = pl.ws; a->ws_stride = wsb;
+	a->gws_base = nullptr; a->gws_stride = gwb;
+	if(gwb) {
+		if(pl.gws_bytes < lanes * gwb) {
+			(void)hipFree(pl.gws); pl.gws = nullptr; pl.gws_bytes = 0;
+			HIPCHK(hipMalloc((void**)&pl.gws, lanes * gwb));
+			pl.gws_bytes = lanes * gwb;
+		}
+		a->gws_base = pl.gws;
+	}
+	a->sw_base = nullptr; a->sw_stride = 0;
+	if(bowtie2_dp) {
+		const size_t stride = (sw_scratch_bytes(s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len) + 255) & ~(size_t)255;
+		if(pl.sw_stride < stride || pl.sw_lanes < lanes) {
+			(void)hipFree(pl.sw); pl.sw = nullptr; pl.sw_stride = 0; pl.sw_lanes = 0;
+			HIPCHK(hipMalloc((void**)&pl.sw, stride * lanes));
+			HIPCHK(hipMemset(pl.sw, 0, stride * lanes));   // SwLaneState: mask-table generations start at 0
+			pl.sw_stride = stride; pl.sw_lanes = lanes;
+		}
+		a->sw_base = pl.sw; a->sw_stride = pl.sw_stride;
+	}
+	return H2G_OK;
+}
+
+// read ids whose main-pass workspace overflowed -> list (the count lands behind the list's n slots)
+__global__ __launch_bounds__(256) void k_collect_overflow(const ReadOut* rout, const PairOut* pout, uint32_t n, uint32_t* list, uint32_t* count) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const uint32_t ovf = rout ? rout[i].overflow : pout[i].overflow;
+	if(ovf) list[atomicAdd(count, 1u)] = i;
+}
+
+// HI_Aligner::go for every read (pair) of the resident batch.  Two passes, both asynchronous on the stream: the main pass
+// with the default workspace, then the reads it flagged (a list overflowed) once more through the large-workspace unit,
+// whose results replace theirs.  Reads still flagged after that keep `overflow` set (n_overflow counts them).
+static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) {
 	if(!s || !p) return H2G_ERR_ARG;
 	int rc;
 	if((rc = need_reads(s)) || (rc = need_alignable(s))) return rc;
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
-	if(!s->has_names || !s->has_mates) { snprintf(g_err, sizeof g_err, "align_pairs: names (h2g_set_read_names) and mates (h2g_set_mates) required"); return H2G_ERR_ARG; }
+	if(!s->has_names || (paired && !s->has_mates)) { snprintf(g_err, sizeof g_err, "align: read names (h2g_set_read_names)%s not set", paired ? " / mates (h2g_set_mates)" : ""); return H2G_ERR_ARG; }
 	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
-	if(p->khits == 0 || p->khits > H2G_ALN_CAP || p->kseeds > 20u || p->kseeds < p->khits) return H2G_ERR_ARG;
+	const bool linear = s->ix->dg.linear != 0;
+	const uint32_t maxsz = p->khits > p->kseeds ? p->khits : p->kseeds;
+	uint32_t caps[5], bcaps[5];
+	go_unit(linear, false).caps(caps); go_unit(linear, true).caps(bcaps);
+	if(p->khits == 0 || p->khits > H2G_SELECT_CAP || p->kseeds < p->khits || maxsz > bcaps[0]) {
+		snprintf(g_err, sizeof g_err, "align: -k %u / --max-seeds %u outside the built range (-k 1..%u, --max-seeds <= %u)", p->khits, p->kseeds, (unsigned)H2G_SELECT_CAP, bcaps[0]);
+		return H2G_ERR_ARG;
+	}
+	if(p->bowtie2_dp > 2) return H2G_ERR_ARG;
+	if(p->bowtie2_dp) {
+		if(s->max_read_len == 0) return H2G_ERR_ARG;
+		// a read longer than H2G_SW_MAX_ROWS is flagged by the kernel (overflow bit 256) instead of run through the DP
+		// SwAligner::align switches to 16-bit scores when minsc < -254 (aligner_sw.cpp:494-504); only the 8-bit fill is built
+		const AlnParams Pq = aln_params_from(*p, true, linear);
+		const uint32_t swlen = s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len;
+		if(min_score_for(Pq, swlen) < -254) { snprintf(g_err, sizeof g_err, "bowtie2_dp: --score-min gives %lld for %u-base reads; below -254 the reference runs its 16-bit DP, which is not built", (long long)min_score_for(Pq, s->max_read_len), s->max_read_len); return H2G_ERR_UNSUPPORTED; }
+	}
 	HIPCHK(hipSetDevice(s->ix->device));
+	const bool big_main = maxsz > caps[0];
+	const GoUnit& U = go_unit(linear, big_main);
 	const unsigned block = 256;
+	// resident blocks per CU = waves per SIMD of the unit, bounded by the LDS the packed reads take (24 KB per mate per block)
+	size_t per_cu = (size_t)U.waves();
+	const size_t lds_blocks = (160u * 1024u) / ((paired ? 2u : 1u) * H2G_PK_LANE_WORDS_HOST * 256u * 4u);
+	if(per_cu > lds_blocks) per_cu = lds_blocks;
+	static const int grid_env = getenv("H2G_GO_BLOCKS_PER_CU") ? atoi(getenv("H2G_GO_BLOCKS_PER_CU")) : 0;
+	if(grid_env > 0) per_cu = (size_t)grid_env;
 	size_t want = (s->n_reads + block - 1) / block;
-	const size_t maxblocks = 256 * (size_t)(s->ix->dg.linear ? H2G_LINEAR_PE_WAVES : H2G_GRAPH_PE_WAVES);
-	unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
-	const size_t nthreads = (size_t)grid * block;
-	{
-		const size_t need = nthreads * ws_bytes_per_lane(s->ix->dg.linear != 0, p->kseeds > 10);
-		if(s->ws_bytes < need) {
-			(void)hipFree(s->d_ws); s->d_ws = nullptr; s->ws_bytes = 0;
-			HIPCHK(hipMalloc((void**)&s->d_ws, need));
-			s->ws_bytes = need;
+	size_t maxblocks = 256 * per_cu;
+	if(big_main && maxblocks > 128) maxblocks = 128;      // ~1.3 MB of workspace per lane
+	const unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
+	GoArgs A;
+	memset(&A, 0, sizeof A);
+	A.g = s->ix->dg; A.ref = s->ix->dr; A.ls = s->ix->dls; A.alts = s->ix->dalts;
+	A.rd1 = dreads(s); A.rd2 = A.rd1;
+	if(paired) { A.rd2.codes = s->d_codes2; A.rd2.offs = s->d_offs2; A.rd2.quals = s->has_quals2 ? s->d_quals2 : nullptr; }
+	A.P = aln_params_from(*p, true, linear);
+	A.names1 = s->d_names; A.noffs1 = s->d_name_offs; A.names2 = s->d_names2; A.noffs2 = s->d_name_offs2;
+	A.paired = paired ? 1u : 0u;
+	if((rc = go_pool_for(s, 0, U, (size_t)grid * block, p->bowtie2_dp, &A))) return rc;
+	memset(&A.O, 0, sizeof A.O);
+	if(!paired) {
+		if(!s->d_rout) HIPCHK(hipMalloc((void**)&s->d_rout, s->max_reads * sizeof(ReadOut)));
+		const uint32_t slots = p->khits;
+		if(s->aln_alloc < s->max_reads * (size_t)slots) {
+			(void)hipFree(s->d_aln); s->d_aln = nullptr; s->aln_alloc = 0;
+			HIPCHK(hipMalloc((void**)&s->d_aln, s->max_reads * (size_t)slots * sizeof(h2g_alnres)));
+			s->aln_alloc = s->max_reads * (size_t)slots;
 		}
+		s->aln_slots = slots;
+		A.O.rout = s->d_rout; A.O.aln = s->d_aln; A.O.aln_slots = slots;
+	} else {
+		if(!s->d_pout) {
+			HIPCHK(hipMalloc((void**)&s->d_pout, s->max_reads * sizeof(PairOut)));
+			for(int m = 0; m < 2; m++) HIPCHK(hipMalloc((void**)&s->d_paln[m], s->max_reads * (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres)));
+		}
+		A.O.pout = s->d_pout; A.O.paln[0] = s->d_paln[0]; A.O.paln[1] = s->d_paln[1];
 	}
-	if(!s->d_pout) {
-		HIPCHK(hipMalloc((void**)&s->d_pout, s->max_reads * sizeof(PairOut)));
-		for(int m = 0; m < 2; m++) HIPCHK(hipMalloc((void**)&s->d_paln[m], s->max_reads * (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres)));
-	}
-	const AlnParams P = aln_params_from(*p, true, s->ix->dg.linear);
-	uint8_t* sw_base = nullptr;
-	if((rc = sw_scratch_for(s, p->bowtie2_dp, nthreads, &sw_base))) return rc;
-	GraphArgs ga;
-	if((rc = graph_scratch_for(s, nthreads, &ga))) return rc;
-	DReads r1 = dreads(s), r2 = r1;
-	r2.codes = s->d_codes2; r2.offs = s->d_offs2; r2.quals = s->has_quals2 ? s->d_quals2 : nullptr;
+	if(!s->d_ovf_list) HIPCHK(hipMalloc((void**)&s->d_ovf_list, (s->max_reads + 4) * 4));
 	(void)hipGetLastError();
-	HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->st));
+	HIPCHK(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), s->st));
+	HIPCHK(hipMemsetAsync(s->d_ovf_list + s->max_reads, 0, 16, s->st));
+	A.counters = s->d_counters;
+	A.work = reinterpret_cast<uint32_t*>(s->d_counters + 14);
+	A.list = nullptr; A.nlist = nullptr;
+	static const int no_second = getenv("H2G_GO_NO_SECOND_PASS") ? atoi(getenv("H2G_GO_NO_SECOND_PASS")) : 0;
+	const bool second = !big_main && !no_second;
+	A.defer_overflow = second ? 1u : 0u;
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
-	if(s->ix->dg.linear && p->kseeds > 10)
-		hipLaunchKernelGGL((k_align_pairs<false, 1>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
-		                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride, ga);
-	else if(s->ix->dg.linear)
-		hipLaunchKernelGGL((k_align_pairs<false>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
-		                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride, ga);
-	else
-		hipLaunchKernelGGL((k_align_pairs<true>), dim3(grid), dim3(block), 0, s->st, s->ix->dg, s->ix->dr, s->ix->dls, r1, r2, P, s->d_names,
-		                   s->d_name_offs, s->d_names2, s->d_name_offs2, s->d_ws, s->d_pout, s->d_paln[0], s->d_paln[1], s->d_counters, sw_base, s->sw_stride, ga);
+	if(U.launch(&A, grid, s->st) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
+	if(second) {
+		const GoUnit& B = go_unit(linear, true);
+		uint32_t* cnt = s->d_ovf_list + s->max_reads;
+		hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st,
+		                   paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, s->d_ovf_list, cnt);
+		const unsigned bgrid = 16;
+		GoArgs A2 = A;
+		if((rc = go_pool_for(s, 1, B, (size_t)bgrid * block, p->bowtie2_dp, &A2))) return rc;
+		A2.counters = s->d_counters + 8;
+		A2.work = reinterpret_cast<uint32_t*>(s->d_counters + 15);
+		A2.list = s->d_ovf_list; A2.nlist = cnt;
+		A2.defer_overflow = 0;
+		if(B.launch(&A2, bgrid, s->st) != 0) return set_err("go() second pass launch", hipGetLastError());
+	}
+	HIPCHK(hipEventRecord(s->ev[8], s->st));
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;
 	return H2G_OK;
 }
 
+extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) { return go_run(s, p, false); }
+extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params* p) { return go_run(s, p, true); }
+
+extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t first, size_t n) {
+	if(!s || !res || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
+	std::vector<ReadOut> tmp(n);
+	HIPCHK(hipMemcpyAsync(tmp.data(), s->d_rout + first, n * sizeof(ReadOut), hipMemcpyDeviceToHost, s->st));
+	if(aln && n) {   // device rows hold aln_slots (= -k of the run) records, the caller's rows H2G_ALN_CAP: copy what fits in both
+		const uint32_t w = s->aln_slots < H2G_ALN_CAP ? s->aln_slots : H2G_ALN_CAP;
+		HIPCHK(hipMemcpy2DAsync(aln, (size_t)H2G_ALN_CAP * sizeof(h2g_alnres), s->d_aln + first * s->aln_slots, (size_t)s->aln_slots * sizeof(h2g_alnres),
+		                        (size_t)w * sizeof(h2g_alnres), n, hipMemcpyDeviceToHost, s->st));
+	}
+	HIPCHK(hipStreamSynchronize(s->st));
+	for(size_t i = 0; i < n; i++) {
+		res[i].nres = tmp[i].nres; res[i].nselect = tmp[i].nselect; res[i].overflow = tmp[i].overflow;
+		res[i].nrank = tmp[i].nrank; res[i].nsteps = tmp[i].nsteps; res[i].depth = tmp[i].depth;
+		res[i].best = tmp[i].best; res[i].secbest = tmp[i].secbest; res[i].best_trim = tmp[i].best_trim; res[i].secbest_trim = tmp[i].secbest_trim;
+	}
+	return H2G_OK;
+}
+
+// ------------------------------------------------------------------------------------------ paired go(): fetch
 extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) {
 	if(!s || !res || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
@@ -1430,14 +1396,18 @@ __global__ __launch_bounds__(256) void k_gather_aln(const h2g_alnres* src, uint3
 		for(uint32_t e = 0; e < a[k].nedits && e < H2G_MAX_EDITS; e++) d[k].edits[e] = a[k].edits[e];
 	}
 }
-// gathers [first, first+n) of a slot array into `out` (host); counts = the per-read record counts already on the host
-static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, const uint32_t* d_cnt, uint32_t cnt_stride, const uint32_t* h_cnt,
-                        uint32_t h_stride, size_t n, h2g_alnres* out, size_t cap, uint64_t* offs, int tmp_slot)
-{
+// dense offsets of [first, first+n) of a slot array from the per-read record counts already on the host
+static uint64_t dense_offsets(const uint32_t* h_cnt, uint32_t h_stride, uint32_t slots, size_t n, uint64_t* offs) {
 	uint64_t tot = 0;
 	for(size_t i = 0; i < n; i++) { offs[i] = tot; const uint32_t c = h_cnt[i * h_stride]; tot += c < slots ? c : slots; }
 	offs[n] = tot;
-	if(tot > cap) return H2G_ERR_ARG;
+	return tot;
+}
+// gathers the records into `out` (host) at the offsets computed by dense_offsets
+static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, const uint32_t* d_cnt, uint32_t cnt_stride, size_t n, h2g_alnres* out,
+                        const uint64_t* offs, int tmp_slot)
+{
+	const uint64_t tot = offs[n];
 	if(tot == 0) return H2G_OK;
 	void *d_offs = nullptr, *d_dense = nullptr;
 	int rc;
@@ -1456,8 +1426,9 @@ extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res,
 	const h2g_status rc = h2g_align_fetch(s, res, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
 	static_assert(offsetof(ReadOut, nselect) == 4, "ReadOut layout");
-	return gather_dense(s, s->d_aln + first * H2G_ALN_CAP, H2G_ALN_CAP, reinterpret_cast<const uint32_t*>(s->d_rout + first) + 1, sizeof(ReadOut) / 4,
-	                    &res[0].nselect, sizeof(h2g_read_result) / 4, n, aln, aln_cap, aln_offs, 0);
+	if(dense_offsets(&res[0].nselect, sizeof(h2g_read_result) / 4, s->aln_slots, n, aln_offs) > aln_cap) return H2G_ERR_ARG;
+	return gather_dense(s, s->d_aln + first * s->aln_slots, s->aln_slots, reinterpret_cast<const uint32_t*>(s->d_rout + first) + 1, sizeof(ReadOut) / 4,
+	                    n, aln, aln_offs, 0);
 }
 
 extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, size_t cap1, uint64_t* offs1,
@@ -1467,28 +1438,37 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 	const h2g_status rc = h2g_align_pairs_fetch(s, res, nullptr, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
 	static_assert(offsetof(PairOut, nres) == 0, "PairOut layout");
+	// both totals are known before either capacity is judged, so a caller that has to grow its buffers learns both needs at once
+	const uint64_t t1 = dense_offsets(&res[0].nres[0], sizeof(h2g_pair_result) / 4, H2G_PAIR_RES_CAP, n, offs1);
+	const uint64_t t2 = dense_offsets(&res[0].nres[1], sizeof(h2g_pair_result) / 4, H2G_PAIR_RES_CAP, n, offs2);
+	if(t1 > cap1 || t2 > cap2) return H2G_ERR_ARG;
 	int r;
 	if((r = gather_dense(s, s->d_paln[0] + first * H2G_PAIR_RES_CAP, H2G_PAIR_RES_CAP, reinterpret_cast<const uint32_t*>(s->d_pout + first), sizeof(PairOut) / 4,
-	                     &res[0].nres[0], sizeof(h2g_pair_result) / 4, n, aln1, cap1, offs1, 0))) return r;
+	                     n, aln1, offs1, 0))) return r;
 	return gather_dense(s, s->d_paln[1] + first * H2G_PAIR_RES_CAP, H2G_PAIR_RES_CAP, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
-	                    &res[0].nres[1], sizeof(h2g_pair_result) / 4, n, aln2, cap2, offs2, 2);
+	                    n, aln2, offs2, 2);
 }
 
 extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	if(!s || !c) return H2G_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(s->st));
-	unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long v[16];
 	HIPCHK(hipMemcpy(v, s->d_counters, sizeof v, hipMemcpyDeviceToHost));
-	s->last.n_rank = v[0]; s->last.n_side = v[1]; s->last.n_sa_steps = v[2]; s->last.n_ext = v[3];
-	s->last.n_aligned = v[4]; s->last.n_overflow = v[5];
+	// [0..7] the main pass, [8..15] the second pass over its overflowed reads (go_run)
+	s->last.n_rank = v[0] + v[8]; s->last.n_side = v[1] + v[9]; s->last.n_sa_steps = v[2] + v[10]; s->last.n_ext = v[3];
+	s->last.n_aligned = v[4] + v[12];
+	uint32_t nsecond = 0;
+	if(s->d_ovf_list && s->ran_align) HIPCHK(hipMemcpy(&nsecond, s->d_ovf_list + s->max_reads, 4, hipMemcpyDeviceToHost));
+	s->last.n_second_pass = nsecond;
+	s->last.n_overflow = nsecond ? v[13] : v[5];   // reads still flagged after the last pass that saw them
 	s->last.n_queries = s->n_reads * 2;
 	float t = 0;
 	if(s->ran_seed) {
 		if(hipEventElapsedTime(&t, s->ev[2], s->ev[3]) == hipSuccess) s->last.ms_search = t;
 		if(hipEventElapsedTime(&t, s->ev[3], s->ev[4]) == hipSuccess) s->last.ms_resolve_extend = t;
 	}
-	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[6]) == hipSuccess) s->last.ms_align = t;
 	if(s->ran_align && hipEventElapsedTime(&t, s->ev[7], s->ev[6]) == hipSuccess) s->last.ms_align_kernel = t;
+	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[8]) == hipSuccess) s->last.ms_align = t;   // both passes
 	(void)hipGetLastError();
 	*c = s->last;
 	return H2G_OK;

@@ -1,0 +1,1240 @@
+// h2g_machine.h — HI_Aligner::go as a flat per-lane micro-op machine.
+//
+// Every read (or pair) is one lane-resident continuation: `mach_step` runs the control flow of go() / nextBWT / align /
+// getAnchorHits / hybridSearch / hybridSearch_recur / alignMate (hi_aligner.h:4048-5770, spliced_aligner.h:112-2052) until
+// it needs one of a dozen heavy primitives (an FM search, an SA walk, an extension, a combineWith, ...), posts that as an
+// op request and yields.  The kernel (h2g_go_kernels.h) then lets the whole wavefront vote, and executes ONE primitive at
+// ONE code site for every lane that asked for it — instead of 64 unrelated recursive state machines diverging through
+// 27 inlined copies of the same primitives.  Recursion frames, loop variables that live across an op and every list are
+// in the lane's AlignWS (HBM); pc / op / op arguments are registers.  `__host__ __device__` like the rest: tests/emul
+// runs the identical source one lane at a time.
+#pragma once
+
+namespace h2g {
+
+enum : uint32_t {
+	OP_NONE = 0,
+	OP_PSEARCH,    // partialSearch hi_aligner.h:6361                a0 = cur                                -> ws->fh (+ graph in-edges)
+	OP_GCOORDS,    // getGenomeCoords :5774                          a0 top a1 bot a2 maxelt a3 len a4 reject a5 cap a6/a7 node range p0 dst p1 in-edges -> a0 n a1 steps
+	OP_EXTEND,     // GenomeHit::extend :2031                        p0 hit a0 mm a1 maxleft a2 maxright     -> a0 leftext a1 rightext
+	OP_LSEARCH,    // localGFMSearch :6751                           a0 lidx a1 extoff a2 maxHitLen a3 uniqueStop a4 top a5 bot -> a0 nelt a1 extlen a2 top a3 bot a4 uniqueStop
+	OP_LCOORDS,    // getGenomeCoords_local :5861                    a0 lidx a1 top a2 bot a3 rdoff a4 rdlen a5 cap p0 dst -> a0 n
+	OP_GSEARCH,    // globalGFMSearch :6606                          a1 extoff a3 uniqueStop a4 top a5 bot   -> as OP_LSEARCH
+	OP_COMBINE,    // GenomeHit::combineWith :1420                   p0 this p1 other                        -> a0 combined
+	OP_ADJUST,     // static adjustWithALT :2239 (graph)             a0 rdoff a1 len a2 tidx a3 toff a4 joinedOff -> appends to ws->ghits, a0 overflow
+	OP_ADJMEMBER,  // member adjustWithALT :2395 (graph)             p0 hit                                  -> a0 ok
+	OP_SW,         // SwAligner pass of hybridSearch spliced_aligner.h:209-317   p0 genome hit               -> a0 found
+	OP_FINISH,     // selectByScore + result records
+	OP_COUNT
+};
+
+enum : uint32_t {
+	PC_IDLE = 0,
+	PC_GO_INIT, PC_NB_PICK, PC_NB_AFTER_PS, PC_ALIGN, PC_AFTER_ALIGN, PC_GO_AFTER_LOOP, PC_PAIR_READS, PC_FINISH, PC_FINISHED,
+	PC_GAH_BEGIN, PC_GAH_LOOP, PC_GAH_FULL_AFTER, PC_GAH_SUB_LOOP, PC_GAH_SUB_AFTER, PC_GAH_HAVE, PC_GAH_K_LOOP, PC_GAH_K_AFTER, PC_GAH_END,
+	PC_HS_BEGIN, PC_HS_EXT_LOOP, PC_HS_EXT_AFTER, PC_HS_LOOP, PC_HS_AFTER_REC1, PC_HS_AFTER_SW, PC_HS_ONE_DONE,
+	PC_MP_LOOP, PC_MP_AFTER_PAIR, PC_AM_WHILE, PC_AM_INNER, PC_AM_AFTER_LS, PC_AM_AFTER_LC, PC_AM_RI_LOOP, PC_AM_RI_AFTER, PC_AM_ADV, PC_AM_EXT_LOOP,
+	PC_AM_EXT_AFTER, PC_AM_REC_AFTER,
+	// hybridSearch_recur (one Frame per activation)
+	PC_RC_ENTRY, PC_RC_ENTRY_L2, PC_RC_ENTRY_L3, PC_RC_ENTRY_R2, PC_RC_ENTRY_R3,
+	PC_L_WHILE, PC_L_LS_LOOP, PC_L_LS_AFTER, PC_L_LS_DONE, PC_L_LC_AFTER, PC_L_FOR_RI, PC_L_RI_A, PC_L_RI_B, PC_L_RI_C, PC_L_R1, PC_L_AFTER_FOR,
+	PC_L_FOR_TI, PC_L_R2, PC_L_AFTER_WHILE, PC_L_GS_AFTER, PC_L_GC_AFTER, PC_L_FOR_G, PC_L_G_A, PC_L_G_B, PC_L_G_C, PC_L_R3, PC_L_TRIM, PC_L_R4,
+	PC_L_EXT, PC_L_EXT_A, PC_L_R5,
+	PC_R_WHILE, PC_R_LS_LOOP, PC_R_LS_AFTER, PC_R_LS_DONE, PC_R_LC_AFTER, PC_R_FOR_RI, PC_R_RI_A, PC_R_RI_B, PC_R_RI_C, PC_R_R1, PC_R_AFTER_FOR,
+	PC_R_FOR_TI, PC_R_R2, PC_R_AFTER_WHILE, PC_R_GS_AFTER, PC_R_GC_AFTER, PC_R_FOR_G, PC_R_G_A, PC_R_G_B, PC_R_G_C, PC_R_R3, PC_R_TRIM, PC_R_R4,
+	PC_R_EXT, PC_R_EXT_A, PC_R_R5
+};
+
+struct Lane {                 // the registers of one lane's machine
+	uint32_t pc, op;
+	uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
+	void *p0, *p1;
+};
+
+struct Mach {                 // per-lane context (kernel locals; nothing of this lives in HBM)
+	Lane      L;
+	AlignWS*  ws;
+	DReads    rd[2];           // mate-1 / mate-2 read sets (with this lane's LDS pack of the current read)
+	const char* name[2];
+	uint32_t  namelen[2];
+	uint32_t  read;
+};
+
+H2G_HD SeqView mach_sv(const Mach& M) {
+	const GoVars& gv = M.ws->gv;
+	return seq_view(M.rd[gv.rd_sel[gv.sv_rdi]], M.read, gv.sv_fw != 0);
+}
+
+// The prelude of the worker loop body for one read / pair (hisat2.cpp:3380-3530): filters, PRNG seed, which mates go() sees.
+H2G_HD void mach_begin(Mach& M, uint32_t read, bool paired_input) {
+	AlignWS* ws = M.ws;
+	GoVars& gv = ws->gv;
+	M.read = read;
+	M.L.op = OP_NONE;
+	gv.read = read;
+	ws->m[0].nres = 0; ws->m[1].nres = 0; ws->npairs = 0; ws->overflow = 0; ws->nrank = 0; ws->nsteps = 0; ws->nframes_max = 0; ws->nside = 0;
+	SeqView v1 = seq_view(M.rd[0], read, true);
+	Rng rnd;
+	if(!paired_input) {
+		rnd.init(gen_rand_seed(v1, M.name[0], M.namelen[0], 0));       // rnd.init(ps->bufa().seed) hisat2.cpp:3468
+		gv.rnd = rnd.last;
+		gv.paired = 0; gv.nm = 1; gv.slot0 = 0; gv.rd_sel[0] = 0; gv.rd_sel[1] = 0;
+		M.L.pc = read_passes_filters(v1) ? PC_GO_INIT : PC_FINISH;      // filt[0] false: go() is skipped (hisat2.cpp:3518)
+		return;
+	}
+	SeqView v2 = seq_view(M.rd[1], read, true);
+	const bool f1 = read_passes_filters(v1), f2 = read_passes_filters(v2);
+	const uint32_t s1 = gen_rand_seed(v1, M.name[0], M.namelen[0], 0), s2 = gen_rand_seed(v2, M.name[1], M.namelen[1], 0);
+	rnd.init((f1 && f2) ? (s1 ^ s2) : s1);                              // hisat2.cpp:3463-3468
+	gv.rnd = rnd.last;
+	gv.slot0 = 0; gv.rd_sel[0] = 0; gv.rd_sel[1] = 1;
+	if(f1 && f2) { gv.paired = 1; gv.nm = 2; M.L.pc = PC_GO_INIT; }
+	else if(f1)  { gv.paired = 0; gv.nm = 1; M.L.pc = PC_GO_INIT; }                                   // initRead(rds[0]) hisat2.cpp:3522
+	else if(f2)  { gv.paired = 0; gv.nm = 1; gv.slot0 = 1; gv.rd_sel[0] = 1; M.L.pc = PC_GO_INIT; }   // initRead(rds[1], rightendonly) :3524
+	else M.L.pc = PC_FINISH;
+}
+
+#define M_GOTO(NEXT) do { L.pc = (NEXT); goto again; } while(0)
+#define M_OP(OPC, NEXT) do { L.op = (OPC); L.pc = (NEXT); return; } while(0)
+#define FR (ws->stack[gv.sp])
+#define RC_CALL(HITPTR, HOFF, HLEN, RESUME) do { \
+		FR.state = (RESUME); \
+		if(gv.sp + 1 >= AL_MAX_DEPTH) { ws->overflow |= 8; gv.ret = INT64_MIN; M_GOTO(RESUME); } \
+		else { Frame& nf_ = ws->stack[gv.sp + 1]; hit_copy(&nf_.hit, (HITPTR)); nf_.hitoff = (HOFF); nf_.hitlen = (HLEN); gv.sp++; \
+		       if((uint32_t)gv.sp + 1 > ws->nframes_max) ws->nframes_max = (uint32_t)gv.sp + 1; M_GOTO(PC_RC_ENTRY); } } while(0)
+#define RC_RET(V) do { gv.ret = (V); gv.sp--; if(gv.sp >= 0) M_GOTO(ws->stack[gv.sp].state); else M_GOTO(gv.rc_ret_pc); } while(0)
+// hybridSearch_recur(root, hitoff, hitlen) on the current SeqView / MateWS; control resumes at RETPC with the result in gv.ret
+#define RC_START(ROOT, HOFF, HLEN, MINSC, MATE, RETPC) do { \
+		Frame& f0_ = ws->stack[0]; hit_copy(&f0_.hit, (ROOT)); f0_.hitoff = (HOFF); f0_.hitlen = (HLEN); \
+		gv.sp = 0; gv.rc_minsc = (MINSC); gv.rc_alignMate = (MATE) ? 1u : 0u; gv.rc_ret_pc = (RETPC); gv.ret = INT64_MIN; \
+		/* spliced_aligner.h:363-366: cushion = alignMate ? rdlen * 0.03 * sc.mm(255) : 0 (no_spliced_alignment only) */ \
+		gv.rc_cushion = (no_spliced && (MATE)) ? (int64_t)((double)mach_sv(M).len * 0.03 * (double)sc.mmpMax) : 0; \
+		M_GOTO(PC_RC_ENTRY); } while(0)
+#define MINSC_LIVE(MV) do { if(!P.secondary) { int64_t b_ = mw->bestUnp - gv.rc_cushion; if(b_ > (MV)) (MV) = b_; } } while(0)
+
+// Runs the control flow of this lane until it needs a primitive (L.op != OP_NONE) or the read is finished (PC_FINISHED).
+H2G_HD void mach_step(const AlnCtx& C, Mach& M)
+{
+	Lane& L = M.L;
+	AlignWS* ws = M.ws;
+	GoVars& gv = ws->gv;
+	const AlnParams& P = *C.P;
+	const DScoring& sc = P.sc;
+	const uint32_t minK = C.g->minK, minK_local = P.minK_local;
+	const bool no_spliced = P.no_spliced != 0;
+again:
+	switch(L.pc) {
+	// ======================================================================== go() hi_aligner.h:4048 / nextBWT :4644
+	case PC_GO_INIT: {
+		ws->nghits = 0; ws->overflow = 0; ws->nrank = 0; ws->nside = 0; ws->nsteps = 0; ws->nframes_max = 0;
+		ws->npairs = 0; ws->insp_i = 0; ws->insp_j = 0; ws->bestPair = INT64_MIN; ws->best2Pair = INT64_MIN;
+		ws->localindexatts = 0; ws->max_localindexatts = 0;
+		gv.rdlens[0] = gv.rdlens[1] = 0;
+		for(uint32_t r = 0; r < 2; r++) {
+			MateWS& mw = ws->m[r ^ gv.slot0];
+			mw.nsearched = 0; mw.nres = 0; mw.bestUnp = INT64_MIN; mw.best2Unp = INT64_MIN; mw.minsc = INT64_MAX;
+			mw.sink_hidden = (gv.slot0 != 0 && gv.nm == 1) ? 1u : 0u;
+			if(r < gv.nm) {
+				SeqView v = seq_view(M.rd[gv.rd_sel[r]], M.read, true);
+				gv.rdlens[r] = v.len;
+				mw.minsc = min_score_for(P, v.len);   // scoreMin.f<TAlScore>(len) (hisat2.cpp:440, simple_func.h:88)
+				for(int k = 0; k < 2; k++) {
+					RBHit& h = mw.rb[k];
+					h.len = v.len; h.cur = 0; h.done = 0; h.numPartialSearch = 0; h.numUniqueSearch = 0; h.npartial = 0;
+				}
+			}
+		}
+		gv.found[0][0] = gv.found[0][1] = 1; gv.found[1][0] = gv.found[1][1] = (uint8_t)gv.paired;
+		M_GOTO(PC_NB_PICK);
+	}
+	case PC_NB_PICK: {                                   // one iteration of nextBWT's loop (:4644-4760)
+		int rdi = -1, fwi = -1;
+		int64_t maxScore = INT64_MIN;
+		for(uint32_t r = 0; r < gv.nm; r++) for(int k = 0; k < 2; k++) {
+			const RBHit& h = ws->m[r ^ gv.slot0].rb[k];
+			if(h.done) continue;
+			int64_t cs = rb_search_score(h, minK);
+			if(h.cur == 0) cs = INT64_MAX;
+			if(cs > maxScore) { maxScore = cs; rdi = (int)r; fwi = k; }
+		}
+		if(rdi < 0) M_GOTO(PC_GO_AFTER_LOOP);
+		MateWS& mw = ws->m[(uint32_t)rdi ^ gv.slot0];
+		MateWS& ow = ws->m[(uint32_t)(1 - rdi) ^ gv.slot0];
+		RBHit& hit = mw.rb[fwi];
+		RBHit& rchit = mw.rb[1 - fwi];
+		if(!P.secondary) {
+			const uint32_t numSearched = hit.numPartialSearch - hit.numUniqueSearch;
+			const int64_t bestScore = mw.bestUnp;
+			if(bestScore >= mw.minsc) {
+				const uint32_t maxmm = (uint32_t)((-bestScore + sc.mmpMax - 1) / sc.mmpMax);
+				if(numSearched > maxmm + 0 + 1) {
+					hit.done = 1;
+					if(gv.paired) { if(ow.bestUnp >= ow.minsc && ws->npairs > 0) M_GOTO(PC_GO_AFTER_LOOP); else M_GOTO(PC_NB_PICK); }
+					else M_GOTO(PC_GO_AFTER_LOOP);
+				}
+			}
+			if(rchit.done && bestScore < mw.minsc) {
+				if(numSearched > (rchit.numPartialSearch - rchit.numUniqueSearch) + (P.anchorStop ? 1u : 0u)) { hit.done = 1; M_GOTO(PC_GO_AFTER_LOOP); }
+			}
+		}
+		gv.nb_rdi = rdi; gv.nb_fwi = fwi;
+		gv.sv_rdi = (uint32_t)rdi; gv.sv_fw = fwi == 0; gv.mw_slot = (uint32_t)rdi ^ gv.slot0;
+		L.a0 = hit.cur;
+		M_OP(OP_PSEARCH, PC_NB_AFTER_PS);
+	}
+	case PC_NB_AFTER_PS: {
+		const int rdi = gv.nb_rdi, fwi = gv.nb_fwi;
+		MateWS& mw = ws->m[gv.mw_slot];
+		RBHit& hit = mw.rb[fwi];
+		const h2g_fm_hit& fh = ws->fh;
+		if(C.graph && hit.npartial < AL_MAX_PARTIAL) {
+			GraphPNode& pn = C.gws->pnode[gv.mw_slot][fwi][hit.npartial];
+			pn.node_top = fh.node_top; pn.node_bot = fh.node_bot; pn.ie = C.gws->ie;
+			if(pn.ie.n > H2G_IEDGE_CAP) ws->overflow |= 512;
+		}
+		AL_TRACE("  psearch rdi %d fwi %d cur %u -> top %u bot %u len %u type %u cur %u done %u anchor %u\n", rdi, fwi, hit.cur, fh.top, fh.bot, fh.len, fh.hit_type, fh.cur, fh.done, fh.anchorStop);
+		ws->nrank += fh.nrank; ws->nside += fh.nside;
+		hit.numPartialSearch += 1; hit.numUniqueSearch += fh.numUniqueSearch; hit.cur = fh.cur;
+		if(hit.npartial < AL_MAX_PARTIAL) {
+			PartialHit& p = hit.partial[hit.npartial++];
+			p.top = fh.top; p.bot = fh.bot; p.bwoff = fh.bwoff; p.len = fh.len; p.hit_type = fh.hit_type; p.ncoords = 0;
+		} else { ws->overflow |= 32; hit.done = 1; M_GOTO(PC_GO_AFTER_LOOP); }
+		if(fh.done) { hit.done = 1; gv.sel_r = rdi; gv.sel_f = fwi; M_GOTO(PC_ALIGN); }
+		if(!fh.pseudogeneStop) { if(hit.cur + 1 < hit.len) hit.cur++; }
+		if(fh.anchorStop) { hit.done = 1; gv.sel_r = rdi; gv.sel_f = fwi; M_GOTO(PC_ALIGN); }
+		M_GOTO(PC_NB_PICK);
+	}
+	// ======================================================================== align() :5484-5573
+	case PC_ALIGN: {
+		gv.sv_rdi = (uint32_t)gv.sel_r; gv.sv_fw = gv.sel_f == 0; gv.mw_slot = (uint32_t)gv.sel_r ^ gv.slot0;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		RBHit& hit = mw->rb[gv.sel_f];
+		bool any = false;
+		for(uint32_t i = 0; i < hit.npartial; i++) if(!ph_empty(hit.partial[i])) { any = true; break; }
+		if(!any) { gv.hs_found = 0; M_GOTO(PC_AFTER_ALIGN); }        // minWidth() == max
+		int64_t bestScore = mw->bestUnp;
+		if(bestScore < mw->minsc) bestScore = mw->minsc;
+		const uint32_t maxmm = (uint32_t)((-bestScore + sc.mmpMax - 1) / sc.mmpMax);
+		const uint32_t nact = hit.numPartialSearch - hit.numUniqueSearch;
+		if(!P.secondary && nact > maxmm + 0 + 1) { gv.hs_found = 1; M_GOTO(PC_AFTER_ALIGN); }
+		M_GOTO(PC_GAH_BEGIN);
+	}
+	case PC_AFTER_ALIGN: {
+		gv.found[gv.sel_r][gv.sel_f] = (uint8_t)gv.hs_found;
+		AL_TRACE(" align rdi %d fwi %d -> found %d nghits %u\n", gv.sel_r, gv.sel_f, (int)gv.hs_found, ws->nghits);
+		if(!gv.found[0][0] && !gv.found[0][1] && !gv.found[1][0] && !gv.found[1][1]) M_GOTO(PC_GO_AFTER_LOOP);
+		if(gv.paired) { gv.pr_ret_pc = PC_NB_PICK; M_GOTO(PC_PAIR_READS); }
+		M_GOTO(PC_NB_PICK);
+	}
+	case PC_PAIR_READS: {
+		al_pair_reads(P, ws, gv.rdlens[0], gv.rdlens[1]);
+		M_GOTO(gv.pr_ret_pc);
+	}
+	// no concordant pair: use each mate's alignments as anchors for the other mate (hi_aligner.h:4092-4148)
+	case PC_GO_AFTER_LOOP: {
+		if(gv.paired && ws->npairs == 0 && (ws->m[0].bestUnp >= ws->m[0].minsc || ws->m[1].bestUnp >= ws->m[1].minsc)) {
+			gv.mate_found = 0; gv.mp_rs[0] = ws->m[0].nres; gv.mp_rs[1] = ws->m[1].nres; gv.mp_i = 0; gv.mp_j = 0;
+			M_GOTO(PC_MP_LOOP);
+		}
+		M_GOTO(PC_FINISH);
+	}
+	case PC_MP_LOOP: {
+		if(gv.mp_i >= 2) {
+			if(gv.mate_found) { gv.pr_ret_pc = PC_FINISH; M_GOTO(PC_PAIR_READS); }
+			M_GOTO(PC_FINISH);
+		}
+		if(gv.mp_j >= gv.mp_rs[gv.mp_i]) { gv.mp_i++; gv.mp_j = 0; M_GOTO(PC_MP_LOOP); }
+		const AlnRec& r = ws->m[gv.mp_i].res[gv.mp_j];
+		const bool fw = r.fw != 0;
+		AL_TRACE(" alignMate anchor mate %u res %u fw %d toff %u\n", gv.mp_i, gv.mp_j, (int)fw, r.toff);
+		// alignMate hi_aligner.h:5579-5770: anchor the OTHER mate near (tidx, toff) through the local index
+		gv.am_fw = fw; gv.am_tidx = r.tidx; gv.am_toff = r.toff;
+		gv.sv_rdi = 1 - gv.mp_i; gv.sv_fw = !fw;                     // ofw = (fw == gMate2fw ? gMate1fw : gMate2fw) = !fw
+		gv.mw_slot = 1 - gv.mp_i;
+		ws->nghits = 0;
+		gv.am_lidx = local_index_of(*C.ls, r.tidx, r.toff);
+		gv.am_first = 1; gv.am_count = 0; gv.am_maxhitlen = 0;
+		M_GOTO(PC_AM_WHILE);
+	}
+	case PC_AM_WHILE: {
+		if(!(gv.am_count++ < 2)) { gv.am_hi = 0; M_GOTO(PC_AM_EXT_LOOP); }
+		if(gv.am_first) gv.am_first = 0;
+		else {
+			if(ws->nghits > 0) { gv.am_hi = 0; M_GOTO(PC_AM_EXT_LOOP); }
+			if(gv.am_lidx != H2G_MAX) gv.am_lidx = gv.am_fw ? local_index_next(*C.ls, gv.am_lidx) : local_index_prev(*C.ls, gv.am_lidx);
+			if(gv.am_lidx == H2G_MAX || C.ls->desc[gv.am_lidx].len == 0) { gv.am_hi = 0; M_GOTO(PC_AM_EXT_LOOP); }
+		}
+		if(gv.am_lidx == H2G_MAX) { gv.am_hi = 0; M_GOTO(PC_AM_EXT_LOOP); }
+		gv.am_hitoff = mach_sv(M).len - 1;
+		M_GOTO(PC_AM_INNER);
+	}
+	case PC_AM_INNER: {
+		if(!(gv.am_hitoff >= minK_local - 1)) M_GOTO(PC_AM_WHILE);
+		if(C.ls->desc[gv.am_lidx].len == 0) { L.a0 = 0; L.a1 = 0; L.a2 = H2G_MAX; L.a3 = H2G_MAX; L.a4 = 0; M_GOTO(PC_AM_AFTER_LS); }
+		L.a0 = gv.am_lidx; L.a1 = gv.am_hitoff; L.a2 = 0xffffu; L.a3 = 0; L.a4 = H2G_MAX; L.a5 = H2G_MAX;
+		M_OP(OP_LSEARCH, PC_AM_AFTER_LS);
+	}
+	case PC_AM_AFTER_LS: {
+		const uint32_t nelt = L.a0, hitlen = L.a1, top = L.a2, bot = L.a3;
+		gv.am_hitlen = hitlen;
+		if(nelt > 0 && nelt <= P.kseeds && hitlen > gv.am_maxhitlen) {
+			L.a0 = gv.am_lidx; L.a1 = top; L.a2 = bot; L.a3 = gv.am_hitoff - hitlen + 1; L.a4 = hitlen; L.a5 = AL_MAX_GHITS; L.p0 = ws->am_co;
+			M_OP(OP_LCOORDS, PC_AM_AFTER_LC);
+		}
+		M_GOTO(PC_AM_ADV);
+	}
+	case PC_AM_AFTER_LC: {
+		gv.am_nco = L.a0;
+		ws->nghits = 0;
+		gv.am_ri = 0;
+		M_GOTO(PC_AM_RI_LOOP);
+	}
+	case PC_AM_RI_LOOP: {
+		const uint32_t hitoff = gv.am_hitoff, hitlen = gv.am_hitlen, toff = gv.am_toff;
+		const h2g_coord* co = ws->am_co;
+		for(; gv.am_ri < gv.am_nco; gv.am_ri++) {
+			const uint32_t ri = gv.am_ri;
+			if(no_spliced) {
+				if((uint64_t)co[ri].toff + (uint64_t)P.maxFragLen * 2 < toff || (uint64_t)toff + (uint64_t)P.maxFragLen * 2 < co[ri].toff) continue;
+			}
+			if(C.graph) {                                            // adjustWithALT (:5692)
+				L.a0 = hitoff - hitlen + 1; L.a1 = hitlen; L.a2 = co[ri].tidx; L.a3 = co[ri].toff; L.a4 = co[ri].joinedOff;
+				M_OP(OP_ADJUST, PC_AM_RI_AFTER);
+			} else if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], gv.sv_fw != 0, hitoff - hitlen + 1, hitlen, co[ri].tidx, co[ri].toff, co[ri].joinedOff);
+			else ws->overflow |= 64;
+		}
+		gv.am_maxhitlen = hitlen;
+		M_GOTO(PC_AM_ADV);
+	}
+	case PC_AM_RI_AFTER: {
+		if(L.a0) ws->overflow |= 64;
+		gv.am_ri++;
+		M_GOTO(PC_AM_RI_LOOP);
+	}
+	case PC_AM_ADV: {
+		if(gv.am_hitlen > 0) gv.am_hitoff -= (gv.am_hitlen - 1);
+		if(gv.am_hitoff > 0) gv.am_hitoff -= 1;
+		M_GOTO(PC_AM_INNER);
+	}
+	case PC_AM_EXT_LOOP: {                                 // (genomeHits never exceeds kseeds here: nelt <= kseeds)
+		if(gv.am_hi >= ws->nghits) { gv.mate_found = 1; gv.mp_j++; M_GOTO(PC_MP_LOOP); }
+		L.p0 = &ws->ghits[gv.am_hi]; L.a0 = 0; L.a1 = H2G_MAX; L.a2 = H2G_MAX;
+		M_OP(OP_EXTEND, PC_AM_EXT_AFTER);
+	}
+	case PC_AM_EXT_AFTER: {
+		hit_copy(&ws->tmp2, &ws->ghits[gv.am_hi]);
+		RC_START(&ws->tmp2, ws->tmp2.rdoff, ws->tmp2.len, ws->m[gv.mw_slot].minsc, true, PC_AM_REC_AFTER);
+	}
+	case PC_AM_REC_AFTER: { gv.am_hi++; M_GOTO(PC_AM_EXT_LOOP); }
+	// ======================================================================== getAnchorHits :5007-5193
+	case PC_GAH_BEGIN: { ws->nghits = 0; gv.gh_hi = 0; M_GOTO(PC_GAH_LOOP); }
+	case PC_GAH_LOOP: {
+		MateWS* mw = &ws->m[gv.mw_slot];
+		const int fwi = gv.sel_f;
+		RBHit& hit = mw->rb[fwi];
+		const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
+		const uint32_t offsetSize = hit.npartial;
+		if(gv.gh_hi >= offsetSize) M_GOTO(PC_GAH_END);
+		uint32_t hj = 0;
+		for(; hj < offsetSize; hj++) {
+			const PartialHit& pj = hit.partial[hj];
+			if(ph_empty(pj) || pj.ncoords > 0 || pj.len <= minK + 2) continue;
+			else break;
+		}
+		if(hj >= offsetSize) M_GOTO(PC_GAH_END);
+		for(uint32_t hk = hj + 1; hk < offsetSize; hk++) {
+			const PartialHit& pj = hit.partial[hj];
+			const PartialHit& pk = hit.partial[hk];
+			if(ph_empty(pk) || pk.ncoords > 0 || pk.len <= minK + 2) continue;
+			if(pj.hit_type == pk.hit_type) {
+				const uint32_t sj = pj.bot - pj.top, sk = pk.bot - pk.top;
+				if(sj > sk || (sj == sk && pj.len < pk.len)) hj = hk;
+			} else if(pk.hit_type > pj.hit_type) hj = hk;
+		}
+		PartialHit& ph = hit.partial[hj];
+		const uint32_t remained = maxsz - ws->nghits;
+		if(remained == 0) M_GOTO(PC_GAH_END);
+		const GraphPNode* pn = C.graph ? &C.gws->pnode[gv.mw_slot][fwi][hj] : nullptr;
+		const uint32_t expected = C.graph ? pn->node_bot - pn->node_top : ph.bot - ph.top;
+		gv.gh_hj = hj; gv.gh_nco = 0; gv.gh_remained = remained;
+		gv.gh_rdoff = hit.len - ph.bwoff - ph.len;
+		if(expected <= remained) {
+			L.a0 = ph.top; L.a1 = ph.bot; L.a2 = ph.bot - ph.top; L.a3 = ph.len; L.a4 = 0; L.a5 = AL_MAX_GHITS; L.p0 = ph.coords;
+			if(C.graph) { L.a6 = pn->node_top; L.a7 = pn->node_bot; L.p1 = (void*)&pn->ie; }
+			M_OP(OP_GCOORDS, PC_GAH_FULL_AFTER);
+		}
+		// random sub-sample of `remained` rows (linear) / NODES, each with its own rows and extra in-edges (graph) (:5096-5136)
+		gv.gh_expected = expected; gv.gh_top = ph.top; gv.gh_added = 0; gv.gh_edgeIdx = 0;
+		gv.gh_node = C.graph ? pn->node_top : ph.top; gv.gh_node_end = C.graph ? pn->node_bot : ph.bot;
+		M_GOTO(PC_GAH_SUB_LOOP);
+	}
+	case PC_GAH_FULL_AFTER: {
+		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		gv.gh_nco = L.a0;
+		ws->nsteps += L.a1;
+		M_GOTO(PC_GAH_HAVE);
+	}
+	case PC_GAH_SUB_LOOP: {
+		MateWS* mw = &ws->m[gv.mw_slot];
+		PartialHit& ph = mw->rb[gv.sel_f].partial[gv.gh_hj];
+		const GraphPNode* pn = C.graph ? &C.gws->pnode[gv.mw_slot][gv.sel_f][gv.gh_hj] : nullptr;
+		Rng rnd; rnd.last = gv.rnd;
+		for(; gv.gh_node < gv.gh_node_end; gv.gh_node++, gv.gh_expected--) {
+			uint32_t bot = gv.gh_top + 1;
+			if(C.graph) {
+				IEdges& t = C.gws->ie;
+				t.n = 0;
+				if(gv.gh_edgeIdx < pn->ie.n && gv.gh_edgeIdx < H2G_IEDGE_CAP) {
+					if(gv.gh_node - pn->node_top == pn->ie.e[gv.gh_edgeIdx][0]) {
+						bot += pn->ie.e[gv.gh_edgeIdx][1];
+						t.n = 1; t.e[0][0] = 0; t.e[0][1] = pn->ie.e[gv.gh_edgeIdx][1];
+						gv.gh_edgeIdx++;
+					}
+				}
+			}
+			const uint32_t rndi = rnd.nextU32() % gv.gh_expected;
+			if(rndi < gv.gh_remained - gv.gh_added) {
+				if(gv.gh_nco < AL_MAX_GHITS) {
+					gv.rnd = rnd.last; gv.gh_bot = bot;
+					L.a0 = gv.gh_top; L.a1 = bot; L.a2 = ph.bot - ph.top; L.a3 = ph.len; L.a4 = 0; L.a5 = AL_MAX_GHITS - gv.gh_nco; L.p0 = ph.coords + gv.gh_nco;
+					if(C.graph) { L.a6 = gv.gh_node; L.a7 = gv.gh_node + 1; L.p1 = (void*)&C.gws->ie; }
+					M_OP(OP_GCOORDS, PC_GAH_SUB_AFTER);
+				} else ws->overflow |= 64;
+				gv.gh_added++;
+				if(gv.gh_added >= gv.gh_remained) break;
+			}
+			gv.gh_top = bot;
+		}
+		gv.rnd = rnd.last;
+		M_GOTO(PC_GAH_HAVE);
+	}
+	case PC_GAH_SUB_AFTER: {
+		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		gv.gh_nco += L.a0;
+		ws->nsteps += L.a1;
+		gv.gh_added++;
+		if(gv.gh_added >= gv.gh_remained) M_GOTO(PC_GAH_HAVE);
+		gv.gh_top = gv.gh_bot;
+		gv.gh_node++; gv.gh_expected--;
+		M_GOTO(PC_GAH_SUB_LOOP);
+	}
+	case PC_GAH_HAVE: {
+		MateWS* mw = &ws->m[gv.mw_slot];
+		PartialHit& ph = mw->rb[gv.sel_f].partial[gv.gh_hj];
+		const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
+		const uint32_t nco = gv.gh_nco;
+		h2g_coord* co = ph.coords;
+		AL_TRACE("   anchor hj %u nco %u expected %u remained %u\n", gv.gh_hj, nco, gv.gh_expected, gv.gh_remained);
+		ph.ncoords = nco;
+		if(nco == 0) { gv.gh_hi++; M_GOTO(PC_GAH_LOOP); }          // !hasGenomeCoords()
+		gv.gh_gsize = ws->nghits;
+		if(gv.gh_gsize + nco > maxsz) {                              // coords.shufflePortion(0, size, rnd) ds.h:836
+			Rng rnd; rnd.last = gv.rnd;
+			uint32_t left = nco;
+			for(uint32_t i = 0; i + 1 < nco; i++) {
+				uint32_t r = rnd.nextU32() % left;
+				if(r > 0) { h2g_coord t = co[i]; co[i] = co[i + r]; co[i + r] = t; }
+				left--;
+			}
+			gv.rnd = rnd.last;
+		}
+		gv.gh_k = 0;
+		M_GOTO(PC_GAH_K_LOOP);
+	}
+	case PC_GAH_K_LOOP: {
+		MateWS* mw = &ws->m[gv.mw_slot];
+		RBHit& hit = mw->rb[gv.sel_f];
+		PartialHit& ph = hit.partial[gv.gh_hj];
+		const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
+		const h2g_coord* co = ph.coords;
+		const uint32_t rdoff = gv.gh_rdoff;
+		const bool svfw = gv.sv_fw != 0;
+		for(; gv.gh_k < gv.gh_nco; gv.gh_k++) {
+			const uint32_t k = gv.gh_k;
+			if(co[k].tidx == H2G_MAX) continue;
+			const uint32_t len = ph.len;
+			bool overlapped = false;
+			for(uint32_t l = 0; l < gv.gh_gsize; l++) {
+				h2g_ghit& gh = ws->ghits[l];
+				if(gh.tidx != co[k].tidx || (gh.fw != 0) != svfw) continue;
+				const uint32_t hitoff = gh.toff + hit.len - gh.rdoff;
+				const uint32_t hitoff2 = co[k].toff + hit.len - rdoff;
+				const int64_t diff = no_spliced ? 0 : (int64_t)P.maxIntronLen;
+				int64_t d = (int64_t)hitoff - (int64_t)hitoff2;
+				if(d < 0) d = -d;
+				if(d <= diff) { overlapped = true; gh.read++; break; }   // _hitcount++
+			}
+			if(!overlapped) {
+				if(C.graph) {                                        // adjustWithALT may add several (or no) hits (:5175)
+					L.a0 = rdoff; L.a1 = len; L.a2 = co[k].tidx; L.a3 = co[k].toff; L.a4 = co[k].joinedOff;
+					M_OP(OP_ADJUST, PC_GAH_K_AFTER);
+				} else if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], svfw, rdoff, len, co[k].tidx, co[k].toff, co[k].joinedOff);
+				else ws->overflow |= 64;
+			}
+			if(ph.hit_type == H2G_CANDIDATE_HIT && ws->nghits >= maxsz) break;
+		}
+		if(ph.hit_type == H2G_CANDIDATE_HIT && ws->nghits >= maxsz) M_GOTO(PC_GAH_END);
+		gv.gh_hi++;
+		M_GOTO(PC_GAH_LOOP);
+	}
+	case PC_GAH_K_AFTER: {
+		const PartialHit& ph = ws->m[gv.mw_slot].rb[gv.sel_f].partial[gv.gh_hj];
+		const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
+		if(L.a0) ws->overflow |= 64;
+		if(ph.hit_type == H2G_CANDIDATE_HIT && ws->nghits >= maxsz) M_GOTO(PC_GAH_END);
+		gv.gh_k++;
+		M_GOTO(PC_GAH_K_LOOP);
+	}
+	case PC_GAH_END: {
+		MateWS* mw = &ws->m[gv.mw_slot];
+		const uint32_t numHits = ws->nghits;
+		if(numHits == 0) { gv.hs_found = 0; M_GOTO(PC_AFTER_ALIGN); }
+		const uint64_t add = (uint64_t)((-mw->minsc) / sc.mmpMax) * numHits * (P.secondary ? 2 : 1);
+		ws->max_localindexatts = ws->localindexatts + (add > 10 ? add : 10);
+		M_GOTO(PC_HS_BEGIN);
+	}
+	// ======================================================================== hybridSearch spliced_aligner.h:112-322
+	case PC_HS_BEGIN: { gv.hs_hi = 0; M_GOTO(PC_HS_EXT_LOOP); }
+	case PC_HS_EXT_LOOP: {
+		if(gv.hs_hi >= ws->nghits) { gv.hs_hi = 0; M_GOTO(PC_HS_LOOP); }
+		L.p0 = &ws->ghits[gv.hs_hi]; L.a0 = 0; L.a1 = H2G_MAX; L.a2 = H2G_MAX;
+		M_OP(OP_EXTEND, PC_HS_EXT_AFTER);
+	}
+	case PC_HS_EXT_AFTER: { ws->ghit_done[gv.hs_hi] = 0; gv.hs_hi++; M_GOTO(PC_HS_EXT_LOOP); }
+	case PC_HS_LOOP: {
+		if(gv.hs_hi >= ws->nghits) { gv.hs_found = 1; M_GOTO(PC_AFTER_ALIGN); }
+		uint32_t hj = 0;
+		for(; hj < ws->nghits; hj++) if(!ws->ghit_done[hj]) break;
+		if(hj >= ws->nghits) { gv.hs_found = 1; M_GOTO(PC_AFTER_ALIGN); }
+		for(uint32_t hk = hj + 1; hk < ws->nghits; hk++) {
+			if(ws->ghit_done[hk]) continue;
+			const h2g_ghit& a = ws->ghits[hj];
+			const h2g_ghit& b = ws->ghits[hk];
+			if(b.read > a.read || (b.read == a.read && b.len > a.len)) hj = hk;
+		}
+		gv.hs_hj = hj;
+		h2g_ghit* gh = &ws->ghits[hj];
+		RC_START(gh, gh->rdoff, gh->len, ws->m[gv.mw_slot].minsc, false, PC_HS_AFTER_REC1);
+	}
+	case PC_HS_AFTER_REC1: {
+		// spliced_aligner.h:209-317: the opt-in SwAligner pass (--bowtie2-dp 1: only when nothing reached minsc; 2: always)
+		MateWS* mw = &ws->m[gv.mw_slot];
+		const int64_t maxsc = gv.ret;
+		if(P.bowtie2_dp == 2 || (P.bowtie2_dp == 1 && maxsc < mw->minsc)) {
+			h2g_ghit* gh = &ws->ghits[gv.hs_hj];
+			const uint32_t svlen = mach_sv(M).len;
+			if(gh->len >= svlen) RC_START(gh, gh->rdoff, gh->len, mw->minsc, false, PC_HS_ONE_DONE);
+			if(C.sw == nullptr || svlen > H2G_SW_MAX_ROWS) { ws->overflow |= 256; M_GOTO(PC_HS_ONE_DONE); }   // no SW scratch / read longer than the DP path holds
+			L.p0 = gh;
+			M_OP(OP_SW, PC_HS_AFTER_SW);
+		}
+		M_GOTO(PC_HS_ONE_DONE);
+	}
+	case PC_HS_AFTER_SW: {
+		if(L.a0) { h2g_ghit* gh = &ws->ghits[gv.hs_hj]; RC_START(gh, gh->rdoff, gh->len, ws->m[gv.mw_slot].minsc, false, PC_HS_ONE_DONE); }
+		M_GOTO(PC_HS_ONE_DONE);
+	}
+	case PC_HS_ONE_DONE: { ws->ghit_done[gv.hs_hj] = 1; gv.hs_hi++; M_GOTO(PC_HS_LOOP); }
+	// ======================================================================== hybridSearch_recur spliced_aligner.h:331-2052
+	case PC_RC_ENTRY: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		const h2g_ghit& hit = f.hit;
+		const uint32_t hitoff = f.hitoff, hitlen = f.hitlen, dep = (uint32_t)gv.sp, rdlen = mach_sv(M).len;
+		const int64_t minsc = gv.rc_minsc;
+		AL_TRACE("   recur dep %u fw %u hitoff %u hitlen %u (rdoff %u len %u) toff %u score %lld nedits %u mate %d\n", dep, hit.fw, hitoff, hitlen, hit.rdoff, hit.len, hit.toff, (long long)hit.score, hit.nedits, (int)gv.rc_alignMate);
+		f.maxsc = INT64_MIN;
+		if(hit.score + gv.rc_cushion < minsc) RC_RET(f.maxsc);
+		if(dep >= 128) RC_RET(f.maxsc);
+		if(hitoff == hit.rdoff - hit.trim5 && hitlen == hit.len + hit.trim5 + hit.trim3) {
+			if(al_is_searched(mw, &hit)) RC_RET(f.maxsc);
+			al_add_searched(ws, mw, &hit);
+		}
+		if(hitoff == 0 && hitlen == rdlen) {
+			if(!al_redundant(mw, &hit, rdlen)) {
+				al_report(ws, mw, &hit, rdlen, minsc);
+				if(hit.score > f.maxsc) f.maxsc = hit.score;
+			}
+			RC_RET(f.maxsc);
+		} else if(hitoff > 0 && (hitoff + hitlen == rdlen || hitoff + hitoff < rdlen - hitlen)) {
+			// ---------------- extend to the left (spliced_aligner.h:813-1360) ----------------
+			f.use_localindex = 1;
+			if(hitoff == hit.rdoff && hitoff <= minK) {
+				hit_copy(&ws->tmp, &hit);
+				L.p0 = &ws->tmp; L.a0 = 1; L.a1 = H2G_MAX; L.a2 = 0;
+				M_OP(OP_EXTEND, PC_RC_ENTRY_L2);
+			}
+			M_GOTO(PC_RC_ENTRY_L3);
+		} else {
+			// ---------------- extend to the right (spliced_aligner.h:1496-2050) ----------------
+			f.use_localindex = 1;
+			if(hit.len == hitlen && hitoff + hitlen + minK > rdlen) {
+				hit_copy(&ws->tmp, &hit);
+				L.p0 = &ws->tmp; L.a0 = 1; L.a1 = 0; L.a2 = H2G_MAX;
+				M_OP(OP_EXTEND, PC_RC_ENTRY_R2);
+			}
+			M_GOTO(PC_RC_ENTRY_R3);
+		}
+	}
+	case PC_RC_ENTRY_L2: { if(ws->tmp.rdoff == 0) FR.use_localindex = 0; M_GOTO(PC_RC_ENTRY_L3); }
+	case PC_RC_ENTRY_L3: {
+		Frame& f = FR;
+		f.lidx = local_index_of(*C.ls, f.hit.tidx, f.hit.toff);
+		f.success = 0; f.first = 1; f.count = 0; f.prev_score = f.hit.score; f.nlocal = 0;
+		M_GOTO(PC_L_WHILE);
+	}
+	case PC_RC_ENTRY_R2: { if(ws->tmp.rdoff + ws->tmp.len == mach_sv(M).len) FR.use_localindex = 0; M_GOTO(PC_RC_ENTRY_R3); }
+	case PC_RC_ENTRY_R3: {
+		Frame& f = FR;
+		f.lidx = local_index_of(*C.ls, f.hit.tidx, f.hit.toff);
+		f.success = 0; f.first = 1; f.count = 0; f.prev_score = f.hit.score; f.nlocal = 0;
+		M_GOTO(PC_R_WHILE);
+	}
+	// =============================== LEFT ===============================
+	case PC_L_WHILE: {
+		Frame& f = FR;
+		if(f.success) M_GOTO(PC_L_AFTER_WHILE);
+		if(!(f.count++ < 2)) M_GOTO(PC_L_AFTER_WHILE);
+		if(!f.use_localindex) M_GOTO(PC_L_AFTER_WHILE);
+		if(ws->localindexatts >= ws->max_localindexatts) M_GOTO(PC_L_AFTER_WHILE);
+		if(f.first) f.first = 0;
+		else {
+			f.lidx = f.lidx == H2G_MAX ? H2G_MAX : local_index_prev(*C.ls, f.lidx);
+			if(f.lidx == H2G_MAX || C.ls->desc[f.lidx].len == 0) M_GOTO(PC_L_AFTER_WHILE);
+		}
+		if(f.lidx == H2G_MAX) M_GOTO(PC_L_AFTER_WHILE);
+		uint32_t extoff = f.hitoff - 1;
+		if(extoff > 0) extoff -= 1;
+		if(extoff < P.minAnchorLen) extoff = P.minAnchorLen;
+		f.extoff = extoff; f.extlen = 0; f.top = H2G_MAX; f.bot = H2G_MAX; f.nelt = H2G_MAX; f.noext = 0; f.uniqueStop = 0;
+		M_GOTO(PC_L_LS_LOOP);
+	}
+	case PC_L_LS_LOOP: {
+		Frame& f = FR;
+		if(!(f.extoff < mach_sv(M).len)) M_GOTO(PC_L_LS_DONE);
+		f.extlen = 0; f.uniqueStop = 1;
+		ws->localindexatts++;
+		if(C.ls->desc[f.lidx].len == 0) { L.a0 = 0; L.a1 = 0; L.a2 = f.top; L.a3 = f.bot; L.a4 = 1; M_GOTO(PC_L_LS_AFTER); }
+		L.a0 = f.lidx; L.a1 = f.extoff; L.a2 = 0xffffu; L.a3 = 1; L.a4 = f.top; L.a5 = f.bot;
+		M_OP(OP_LSEARCH, PC_L_LS_AFTER);
+	}
+	case PC_L_LS_AFTER: {
+		Frame& f = FR;
+		f.nelt = L.a0; f.extlen = L.a1; f.top = L.a2; f.bot = L.a3; f.uniqueStop = (uint8_t)L.a4;
+		if(f.extoff + 1 - f.extlen >= f.hitoff) { f.noext = 1; M_GOTO(PC_L_LS_DONE); }
+		if(f.nelt <= 5) M_GOTO(PC_L_LS_DONE);
+		f.extoff++;
+		M_GOTO(PC_L_LS_LOOP);
+	}
+	case PC_L_LS_DONE: {
+		Frame& f = FR;
+		f.ncoords = 0; f.ri = -1;
+		AL_TRACE("    L local lidx %u extoff %u extlen %u nelt %u top %u bot %u unique %d noext %d\n", f.lidx, f.extoff, f.extlen, f.nelt, f.top, f.bot, (int)f.uniqueStop, (int)f.noext);
+		if(f.nelt > 0 && f.nelt <= 5 && f.extlen >= P.minAnchorLen && !f.noext) {
+			L.a0 = f.lidx; L.a1 = f.top; L.a2 = f.bot; L.a3 = f.extoff + 1 - f.extlen; L.a4 = f.extlen; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
+			M_OP(OP_LCOORDS, PC_L_LC_AFTER);
+		}
+		M_GOTO(PC_L_FOR_RI);
+	}
+	case PC_L_LC_AFTER: {
+		Frame& f = FR;
+		f.ncoords = L.a0;
+		sort_coords(f.coords, f.ncoords);
+		f.ri = (int)f.ncoords - 1;
+		M_GOTO(PC_L_FOR_RI);
+	}
+	case PC_L_FOR_RI: {
+		Frame& f = FR;
+		if(f.ri < 0) M_GOTO(PC_L_AFTER_FOR);
+		const h2g_coord co = f.coords[f.ri];
+		h2g_ghit* t = &ws->tmp;
+		hit_init(t, f.hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+		if(C.graph) { L.p0 = t; M_OP(OP_ADJMEMBER, PC_L_RI_A); }
+		L.a0 = 1;
+		M_GOTO(PC_L_RI_A);
+	}
+	case PC_L_RI_A: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		if(!L.a0) { f.ri--; M_GOTO(PC_L_FOR_RI); }
+		if(!hit_compatible(t, &f.hit, P.maxIntronLen, no_spliced)) {
+			if(f.count == 1) { f.ri--; M_GOTO(PC_L_FOR_RI); }
+			M_GOTO(PC_L_AFTER_FOR);
+		}
+		if(f.uniqueStop) { L.p0 = t; L.a0 = 0; L.a1 = H2G_MAX; L.a2 = 0; M_OP(OP_EXTEND, PC_L_RI_B); }
+		M_GOTO(PC_L_RI_B);
+	}
+	case PC_L_RI_B: { L.p0 = &ws->tmp; L.p1 = &FR.hit; M_OP(OP_COMBINE, PC_L_RI_C); }
+	case PC_L_RI_C: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* t = &ws->tmp;
+		const bool combined = L.a0 != 0;
+		AL_TRACE("    L combined %d rdoff %u len %u score %lld nedits %u\n", (int)combined, t->rdoff, t->len, (long long)t->score, t->nedits);
+		int64_t m = gv.rc_minsc;
+		if(t->overflow) ws->overflow |= 1;
+		MINSC_LIVE(m);
+		f.ri--;
+		if(combined && t->score >= m) {
+			if(t->score >= f.prev_score - sc.mmpMax) RC_CALL(t, t->rdoff, t->len + t->trim3, PC_L_R1);
+			else if(f.nlocal < AL_MAX_LOCALHITS) hit_copy(&f.local_hits[f.nlocal++], t);
+			else ws->overflow |= 16;
+		}
+		M_GOTO(PC_L_FOR_RI);
+	}
+	case PC_L_R1: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_L_FOR_RI); }
+	case PC_L_AFTER_FOR: {
+		Frame& f = FR;
+		if(f.maxsc >= f.prev_score - sc.mmpMax) f.success = 1;
+		f.ti = 0;
+		if(!f.success && (ws->localindexatts >= ws->max_localindexatts || f.count == 2 ||
+		                  (f.lidx == H2G_MAX || local_index_prev(*C.ls, f.lidx) == H2G_MAX)))
+			M_GOTO(PC_L_FOR_TI);
+		M_GOTO(PC_L_WHILE);
+	}
+	case PC_L_FOR_TI: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		if(f.ti >= f.nlocal) M_GOTO(PC_L_WHILE);
+		h2g_ghit* t = &f.local_hits[f.ti++];
+		int64_t m = gv.rc_minsc;
+		MINSC_LIVE(m);
+		if(t->score >= m) RC_CALL(t, t->rdoff, t->len + t->trim3, PC_L_R2);
+		M_GOTO(PC_L_FOR_TI);
+	}
+	case PC_L_R2: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_L_FOR_TI); }
+	case PC_L_AFTER_WHILE: {
+		Frame& f = FR;
+		if(f.success) RC_RET(f.maxsc);
+		f.ncoords = 0; f.ri = -1;
+		if(f.hitoff > minK && ws->localindexatts < ws->max_localindexatts) {   // global search for long introns (:1085)
+			f.extoff = f.hitoff - 1; f.extlen = 0;
+			L.a1 = f.extoff; L.a3 = 1; L.a4 = H2G_MAX; L.a5 = H2G_MAX;
+			M_OP(OP_GSEARCH, PC_L_GS_AFTER);
+		}
+		M_GOTO(PC_L_FOR_G);
+	}
+	case PC_L_GS_AFTER: {
+		Frame& f = FR;
+		const uint32_t nelt = L.a0, top = L.a2, bot = L.a3;
+		f.extlen = L.a1; f.uniqueStop = (uint8_t)L.a4;
+		AL_TRACE("    L global extoff %u extlen %u nelt %u top %u bot %u unique %d\n", f.extoff, f.extlen, nelt, top, bot, (int)f.uniqueStop);
+		if(nelt > 0 && nelt <= 5 && f.extlen >= minK) {
+			L.a0 = top; L.a1 = bot; L.a2 = bot - top; L.a3 = f.extlen; L.a4 = 1; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
+			if(C.graph) { L.a6 = C.gws->node_top; L.a7 = C.gws->node_bot; L.p1 = (void*)&C.gws->ie; }
+			M_OP(OP_GCOORDS, PC_L_GC_AFTER);
+		}
+		M_GOTO(PC_L_FOR_G);
+	}
+	case PC_L_GC_AFTER: {
+		Frame& f = FR;
+		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		ws->nsteps += L.a1;
+		f.ncoords = L.a0;
+		if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
+		f.ri = (int)f.ncoords - 1;
+		M_GOTO(PC_L_FOR_G);
+	}
+	case PC_L_FOR_G: {
+		Frame& f = FR;
+		if(f.ri < 0) M_GOTO(PC_L_TRIM);
+		const h2g_coord co = f.coords[f.ri];
+		f.ri--;
+		h2g_ghit* t = &ws->tmp;
+		hit_init(t, f.hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+		if(C.graph) { L.p0 = t; M_OP(OP_ADJMEMBER, PC_L_G_A); }
+		L.a0 = 1;
+		M_GOTO(PC_L_G_A);
+	}
+	case PC_L_G_A: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		if(!L.a0) M_GOTO(PC_L_FOR_G);
+		if(!hit_compatible(t, &f.hit, P.maxIntronLen, no_spliced)) M_GOTO(PC_L_FOR_G);
+		if(f.uniqueStop) { L.p0 = t; L.a0 = 0; L.a1 = H2G_MAX; L.a2 = 0; M_OP(OP_EXTEND, PC_L_G_B); }
+		M_GOTO(PC_L_G_B);
+	}
+	case PC_L_G_B: { L.p0 = &ws->tmp; L.p1 = &FR.hit; M_OP(OP_COMBINE, PC_L_G_C); }
+	case PC_L_G_C: {
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* t = &ws->tmp;
+		const bool combined = L.a0 != 0;
+		int64_t m = gv.rc_minsc;
+		if(t->overflow) ws->overflow |= 1;
+		MINSC_LIVE(m);
+		if(combined && t->score >= m) RC_CALL(t, t->rdoff, t->len + t->trim3, PC_L_R3);
+		M_GOTO(PC_L_FOR_G);
+	}
+	case PC_L_R3: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_L_FOR_G); }
+	case PC_L_TRIM: {
+		Frame& f = FR;
+		const h2g_ghit& hit = f.hit;
+		const int64_t minsc = gv.rc_minsc;
+		const int64_t floor_ = f.maxsc > minsc ? f.maxsc : minsc;
+		const int64_t tm = (hit.score - floor_) / sc_penalty(sc, 0);
+		const uint32_t trimMax = (uint32_t)tm;
+		if(hit.rdoff < trimMax) {
+			h2g_ghit* t = &ws->tmp;
+			hit_copy(t, &hit);
+			t->trim5 = hit.rdoff;                         // GenomeHit::trim5 hi_aligner.h:831
+			calculate_score(sc, mach_sv(M), t);
+			if(t->score > f.maxsc && t->score >= minsc) RC_CALL(t, 0, t->len + t->trim5 + t->trim3, PC_L_R4);
+		}
+		M_GOTO(PC_L_EXT);
+	}
+	case PC_L_R4: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_L_EXT); }
+	case PC_L_EXT: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		hit_copy(t, &f.hit);
+		const uint32_t mm = (uint32_t)((t->score - gv.rc_minsc) / sc.mmpMax);
+		uint32_t nmm = 1;
+		if(f.hitoff <= minK_local) nmm = t->rdoff < mm ? t->rdoff : mm;
+		AL_TRACE("    L ext from rdoff %u len %u toff %u joff %u nmm %u\n", t->rdoff, t->len, t->toff, t->joinedOff, nmm);
+		L.p0 = t; L.a0 = nmm; L.a1 = H2G_MAX; L.a2 = 0;
+		M_OP(OP_EXTEND, PC_L_EXT_A);
+	}
+	case PC_L_EXT_A: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		const h2g_ghit& hit = f.hit;
+		h2g_ghit* t = &ws->tmp;
+		const uint32_t le = L.a0, hitoff = f.hitoff, hitlen = f.hitlen;
+		int64_t m = gv.rc_minsc;
+		AL_TRACE("    L ext -> rdoff %u len %u toff %u joff %u score %lld nedits %u le %u\n", t->rdoff, t->len, t->toff, t->joinedOff, (long long)t->score, t->nedits, le);
+		if(t->overflow) ws->overflow |= 1;
+		MINSC_LIVE(m);
+		const uint32_t need = minK_local < hit.rdoff ? minK_local : hit.rdoff;
+		if(t->score >= m && le >= need) RC_CALL(t, t->rdoff, t->len + t->trim3, PC_L_R5);
+		else if(hitoff > minK_local) {
+			const uint32_t jumplen = hitoff > minK ? minK : minK_local;
+			const int64_t expected = hit.score - (int64_t)((hit.rdoff - hitoff) / jumplen) * sc.mmpMax - sc.mmpMax;
+			if(expected >= m) RC_CALL(&hit, hitoff - jumplen, hitlen + jumplen, PC_L_R5);
+		}
+		RC_RET(f.maxsc);
+	}
+	case PC_L_R5: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; RC_RET(f.maxsc); }
+	// =============================== RIGHT ===============================
+	case PC_R_WHILE: {
+		Frame& f = FR;
+		const uint32_t rdlen = mach_sv(M).len;
+		if(f.success) M_GOTO(PC_R_AFTER_WHILE);
+		if(!(f.count++ < 2)) M_GOTO(PC_R_AFTER_WHILE);
+		if(!f.use_localindex) M_GOTO(PC_R_AFTER_WHILE);
+		if(ws->localindexatts >= ws->max_localindexatts) M_GOTO(PC_R_AFTER_WHILE);
+		if(f.first) f.first = 0;
+		else {
+			f.lidx = f.lidx == H2G_MAX ? H2G_MAX : local_index_next(*C.ls, f.lidx);
+			if(f.lidx == H2G_MAX || C.ls->desc[f.lidx].len == 0) M_GOTO(PC_R_AFTER_WHILE);
+		}
+		if(f.lidx == H2G_MAX) M_GOTO(PC_R_AFTER_WHILE);
+		uint32_t extoff = f.hitoff + f.hitlen + minK_local;
+		if(extoff + 1 < rdlen) extoff += 1;
+		if(extoff >= rdlen) extoff = rdlen - 1;
+		uint32_t maxHitLen = extoff - f.hitoff - f.hitlen;
+		if(maxHitLen < minK_local) maxHitLen = minK_local;
+		f.extoff = extoff; f.extlen = 0; f.top = H2G_MAX; f.bot = H2G_MAX; f.nelt = H2G_MAX; f.noext = 0; f.uniqueStop = 0; f.maxHitLen = maxHitLen;
+		M_GOTO(PC_R_LS_LOOP);
+	}
+	case PC_R_LS_LOOP: {
+		Frame& f = FR;
+		if(!(f.maxHitLen < f.extoff + 1 && f.extoff < mach_sv(M).len)) M_GOTO(PC_R_LS_DONE);
+		f.extlen = 0; f.uniqueStop = 0;
+		ws->localindexatts++;
+		if(C.ls->desc[f.lidx].len == 0) { L.a0 = 0; L.a1 = 0; L.a2 = f.top; L.a3 = f.bot; L.a4 = 0; M_GOTO(PC_R_LS_AFTER); }
+		L.a0 = f.lidx; L.a1 = f.extoff; L.a2 = f.maxHitLen; L.a3 = 0; L.a4 = f.top; L.a5 = f.bot;
+		M_OP(OP_LSEARCH, PC_R_LS_AFTER);
+	}
+	case PC_R_LS_AFTER: {
+		Frame& f = FR;
+		const uint32_t rdlen = mach_sv(M).len;
+		f.nelt = L.a0; f.extlen = L.a1; f.top = L.a2; f.bot = L.a3; f.uniqueStop = (uint8_t)L.a4;
+		if(f.extoff < f.hitoff + f.hitlen) { f.noext = 1; M_GOTO(PC_R_LS_DONE); }
+		if(f.nelt <= 5) M_GOTO(PC_R_LS_DONE);
+		if(f.extoff + 1 < rdlen) f.extoff++;
+		else { if(f.extlen < f.maxHitLen) M_GOTO(PC_R_LS_DONE); else f.maxHitLen++; }
+		M_GOTO(PC_R_LS_LOOP);
+	}
+	case PC_R_LS_DONE: {
+		Frame& f = FR;
+		f.ncoords = 0; f.ri = 0;
+		if(f.nelt > 0 && f.nelt <= 5 && f.extlen >= P.minAnchorLen && !f.noext) {
+			L.a0 = f.lidx; L.a1 = f.top; L.a2 = f.bot; L.a3 = f.extoff + 1 - f.extlen; L.a4 = f.extlen; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
+			M_OP(OP_LCOORDS, PC_R_LC_AFTER);
+		}
+		M_GOTO(PC_R_FOR_RI);
+	}
+	case PC_R_LC_AFTER: {
+		Frame& f = FR;
+		f.ncoords = L.a0;
+		if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
+		M_GOTO(PC_R_FOR_RI);
+	}
+	case PC_R_FOR_RI: {
+		Frame& f = FR;
+		if(f.ri >= (int)f.ncoords) M_GOTO(PC_R_AFTER_FOR);
+		const h2g_coord co = f.coords[f.ri];
+		h2g_ghit* t = &ws->tmp;
+		hit_init(t, f.hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+		if(C.graph) { L.p0 = t; M_OP(OP_ADJMEMBER, PC_R_RI_A); }
+		L.a0 = 1;
+		M_GOTO(PC_R_RI_A);
+	}
+	case PC_R_RI_A: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		if(!L.a0) { f.ri++; M_GOTO(PC_R_FOR_RI); }
+		if(!hit_compatible(&f.hit, t, P.maxIntronLen, no_spliced)) {
+			if(f.count == 1) { f.ri++; M_GOTO(PC_R_FOR_RI); }
+			M_GOTO(PC_R_AFTER_FOR);
+		}
+		L.p0 = t; L.a0 = 0; L.a1 = 0; L.a2 = H2G_MAX;
+		M_OP(OP_EXTEND, PC_R_RI_B);
+	}
+	case PC_R_RI_B: {
+		hit_copy(&ws->tmp2, &FR.hit);
+		L.p0 = &ws->tmp2; L.p1 = &ws->tmp;
+		M_OP(OP_COMBINE, PC_R_RI_C);
+	}
+	case PC_R_RI_C: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* cmb = &ws->tmp2;
+		const bool combined = L.a0 != 0;
+		int64_t m = gv.rc_minsc;
+		if(cmb->overflow) ws->overflow |= 1;
+		MINSC_LIVE(m);
+		f.ri++;
+		if(combined && cmb->score >= m) {
+			if(cmb->score >= f.prev_score - sc.mmpMax) RC_CALL(cmb, cmb->rdoff - cmb->trim5, cmb->len + cmb->trim5, PC_R_R1);
+			else if(f.nlocal < AL_MAX_LOCALHITS) hit_copy(&f.local_hits[f.nlocal++], cmb);
+			else ws->overflow |= 16;
+		}
+		M_GOTO(PC_R_FOR_RI);
+	}
+	case PC_R_R1: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_R_FOR_RI); }
+	case PC_R_AFTER_FOR: {
+		Frame& f = FR;
+		if(f.maxsc >= f.prev_score - sc.mmpMax) f.success = 1;
+		f.ti = 0;
+		if(!f.success && (ws->localindexatts >= ws->max_localindexatts || f.count == 2 ||
+		                  (f.lidx == H2G_MAX || local_index_next(*C.ls, f.lidx) == H2G_MAX)))
+			M_GOTO(PC_R_FOR_TI);
+		M_GOTO(PC_R_WHILE);
+	}
+	case PC_R_FOR_TI: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		if(f.ti >= f.nlocal) M_GOTO(PC_R_WHILE);
+		h2g_ghit* t = &f.local_hits[f.ti++];
+		int64_t m = gv.rc_minsc;
+		MINSC_LIVE(m);
+		if(t->score >= m) RC_CALL(t, t->rdoff - t->trim5, t->len + t->trim5, PC_R_R2);
+		M_GOTO(PC_R_FOR_TI);
+	}
+	case PC_R_R2: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_R_FOR_TI); }
+	case PC_R_AFTER_WHILE: {
+		Frame& f = FR;
+		if(f.success) RC_RET(f.maxsc);
+		f.ncoords = 0; f.ri = 0;
+		if(f.hitoff + f.hitlen + minK + 1 < mach_sv(M).len && ws->localindexatts < ws->max_localindexatts) {
+			f.extoff = f.hitoff + f.hitlen + minK + 1; f.extlen = 0;
+			L.a1 = f.extoff; L.a3 = 1; L.a4 = H2G_MAX; L.a5 = H2G_MAX;
+			M_OP(OP_GSEARCH, PC_R_GS_AFTER);
+		}
+		M_GOTO(PC_R_FOR_G);
+	}
+	case PC_R_GS_AFTER: {
+		Frame& f = FR;
+		const uint32_t nelt = L.a0, top = L.a2, bot = L.a3;
+		f.extlen = L.a1; f.uniqueStop = (uint8_t)L.a4;
+		if(nelt > 0 && nelt <= 5 && f.extlen >= minK) {
+			L.a0 = top; L.a1 = bot; L.a2 = bot - top; L.a3 = f.extlen; L.a4 = 1; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
+			if(C.graph) { L.a6 = C.gws->node_top; L.a7 = C.gws->node_bot; L.p1 = (void*)&C.gws->ie; }
+			M_OP(OP_GCOORDS, PC_R_GC_AFTER);
+		}
+		M_GOTO(PC_R_FOR_G);
+	}
+	case PC_R_GC_AFTER: {
+		Frame& f = FR;
+		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		ws->nsteps += L.a1;
+		f.ncoords = L.a0;
+		sort_coords(f.coords, f.ncoords);
+		M_GOTO(PC_R_FOR_G);
+	}
+	case PC_R_FOR_G: {
+		Frame& f = FR;
+		if(f.ri >= (int)f.ncoords) M_GOTO(PC_R_TRIM);
+		const h2g_coord co = f.coords[f.ri];
+		f.ri++;
+		h2g_ghit* t = &ws->tmp;
+		hit_init(t, f.hit.fw, f.extoff + 1 - f.extlen, f.extlen, co.tidx, co.toff, co.joinedOff);
+		if(C.graph) { L.p0 = t; M_OP(OP_ADJMEMBER, PC_R_G_A); }
+		L.a0 = 1;
+		M_GOTO(PC_R_G_A);
+	}
+	case PC_R_G_A: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		if(!L.a0) M_GOTO(PC_R_FOR_G);
+		if(!hit_compatible(&f.hit, t, P.maxIntronLen, no_spliced)) M_GOTO(PC_R_FOR_G);
+		L.p0 = t; L.a0 = 0; L.a1 = 0; L.a2 = H2G_MAX;
+		M_OP(OP_EXTEND, PC_R_G_B);
+	}
+	case PC_R_G_B: {
+		hit_copy(&ws->tmp2, &FR.hit);
+		L.p0 = &ws->tmp2; L.p1 = &ws->tmp;
+		M_OP(OP_COMBINE, PC_R_G_C);
+	}
+	case PC_R_G_C: {
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* cmb = &ws->tmp2;
+		const bool combined = L.a0 != 0;
+		int64_t m = gv.rc_minsc;
+		if(cmb->overflow) ws->overflow |= 1;
+		MINSC_LIVE(m);
+		if(combined && cmb->score >= m) RC_CALL(cmb, cmb->rdoff - cmb->trim5, cmb->len + cmb->trim5, PC_R_R3);
+		M_GOTO(PC_R_FOR_G);
+	}
+	case PC_R_R3: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_R_FOR_G); }
+	case PC_R_TRIM: {
+		Frame& f = FR;
+		const h2g_ghit& hit = f.hit;
+		const int64_t minsc = gv.rc_minsc;
+		const uint32_t trimLen = mach_sv(M).len - f.hitoff - hit.len - hit.trim5;
+		const int64_t floor_ = f.maxsc > minsc ? f.maxsc : minsc;
+		const uint32_t trimMax = (uint32_t)((hit.score - floor_) / sc_penalty(sc, 0));
+		if(trimLen < trimMax) {
+			h2g_ghit* t = &ws->tmp;
+			hit_copy(t, &hit);
+			t->trim3 = trimLen;                           // GenomeHit::trim3 hi_aligner.h:855
+			calculate_score(sc, mach_sv(M), t);
+			if(t->score > f.maxsc && t->score >= minsc) RC_CALL(t, t->rdoff - t->trim5, t->len + t->trim5 + t->trim3, PC_R_R4);
+		}
+		M_GOTO(PC_R_EXT);
+	}
+	case PC_R_R4: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_R_EXT); }
+	case PC_R_EXT: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		hit_copy(t, &f.hit);
+		const uint32_t rdlen = mach_sv(M).len;
+		const uint32_t mm = (uint32_t)((t->score - gv.rc_minsc) / sc.mmpMax);
+		uint32_t nmm = 1;
+		if(rdlen - f.hitoff - f.hitlen <= minK_local) {
+			const uint32_t rest = rdlen - t->rdoff - t->len;
+			nmm = rest < mm ? rest : mm;
+		}
+		L.p0 = t; L.a0 = nmm; L.a1 = 0; L.a2 = H2G_MAX;
+		M_OP(OP_EXTEND, PC_R_EXT_A);
+	}
+	case PC_R_EXT_A: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		const h2g_ghit& hit = f.hit;
+		h2g_ghit* t = &ws->tmp;
+		const uint32_t re = L.a1, hitoff = f.hitoff, hitlen = f.hitlen, rdlen = mach_sv(M).len;
+		int64_t m = gv.rc_minsc;
+		if(t->overflow) ws->overflow |= 1;
+		MINSC_LIVE(m);
+		const uint32_t rest0 = rdlen - hit.len - hit.rdoff;
+		const uint32_t need = minK_local < rest0 ? minK_local : rest0;
+		if(t->score >= m && re >= need) RC_CALL(t, t->rdoff - t->trim5, t->len + t->trim5, PC_R_R5);
+		else if(hitoff + hitlen + minK_local < rdlen) {
+			const uint32_t jumplen = hitoff + hitlen + minK < rdlen ? minK : minK_local;
+			const int64_t expected = hit.score - (int64_t)((hitlen - hit.len) / jumplen) * sc.mmpMax - sc.mmpMax;
+			if(expected >= m) RC_CALL(&hit, hitoff, hitlen + jumplen, PC_R_R5);
+		}
+		RC_RET(f.maxsc);
+	}
+	case PC_R_R5: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; RC_RET(f.maxsc); }
+	// ========================================================================
+	case PC_FINISH: M_OP(OP_FINISH, PC_FINISHED);
+	case PC_FINISHED:
+	default: return;
+	}
+}
+#undef M_GOTO
+#undef M_OP
+#undef FR
+#undef RC_CALL
+#undef RC_RET
+#undef RC_START
+#undef MINSC_LIVE
+
+// ---------------------------------------------------------------------------------------- the primitives
+// Each executes for the lanes that requested it; the kernel calls mach_exec with a wave-uniform `op`, so every body below
+// is one code site shared by all requesters whatever control state they came from.
+H2G_HD void mach_op_psearch(const AlnCtx& C, Mach& M) {
+	const AlnParams& P = *C.P;
+	const SeqView sv = mach_sv(M);
+	if(!C.graph) partial_search_item(*C.g, sv, M.L.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &M.ws->fh);
+	else partial_search_graph_item(*C.g, sv, M.L.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &M.ws->fh, &C.gws->ie);
+}
+H2G_HD void mach_op_gcoords(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	h2g_sa_result res;
+	if(!C.graph) genome_coords_item(*C.g, L.a0, L.a1, L.a2, L.a3, L.a4 != 0, (h2g_coord*)L.p0, L.a5, &res);
+	else genome_coords_graph_item(*C.g, &C.gws->gw, L.a0, L.a1, L.a6, L.a7, (const IEdges*)L.p1, L.a2, L.a3, L.a4 != 0, (h2g_coord*)L.p0, L.a5, &res);
+	L.a0 = res.ncoords; L.a1 = res.nsteps;
+}
+H2G_HD void mach_op_extend(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	uint32_t le = H2G_MAX, re = H2G_MAX;
+	al_extend(C, mach_sv(M), (h2g_ghit*)L.p0, L.a0, L.a1, L.a2, &le, &re);
+	L.a0 = le; L.a1 = re;
+}
+H2G_HD void mach_op_lsearch(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	uint32_t extlen = 0, top = L.a4, bot = L.a5;
+	bool uniqueStop = L.a3 != 0;
+	const uint32_t nelt = al_local_search(C, M.ws, L.a0, mach_sv(M), L.a1, &extlen, &top, &bot, &uniqueStop, L.a2);
+	L.a0 = nelt; L.a1 = extlen; L.a2 = top; L.a3 = bot; L.a4 = uniqueStop ? 1u : 0u;
+}
+H2G_HD void mach_op_lcoords(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	uint32_t n = 0;
+	al_local_coords(C, M.ws, L.a0, L.a1, L.a2, L.a3, L.a4, (h2g_coord*)L.p0, L.a5, &n);
+	L.a0 = n;
+}
+H2G_HD void mach_op_gsearch(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	uint32_t extlen = 0, top = L.a4, bot = L.a5;
+	bool uniqueStop = L.a3 != 0;
+	const uint32_t nelt = al_global_search(C, M.ws, mach_sv(M), L.a1, &extlen, &top, &bot, &uniqueStop);
+	L.a0 = nelt; L.a1 = extlen; L.a2 = top; L.a3 = bot; L.a4 = uniqueStop ? 1u : 0u;
+}
+H2G_HD void mach_op_combine(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	const AlnParams& P = *C.P;
+	AlignWS* ws = M.ws;
+	L.a0 = hit_combine(*C.ref, P.sc, mach_sv(M), (h2g_ghit*)L.p0, (const h2g_ghit*)L.p1, ws->gv.rc_minsc, P.minIntronLen, P.no_spliced != 0,
+	                   ws->sc1, ws->sc2, C.alts) ? 1u : 0u;
+}
+H2G_HD void mach_op_adjust(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	AlignWS* ws = M.ws;
+	uint32_t ovf = 0;
+	if(C.graph)
+		adjust_with_alt(*C.g, *C.ref, *C.alts, mach_sv(M), L.a0, L.a1, L.a2, L.a3, L.a4, ws->ghits, &ws->nghits, AL_MAX_GHITS, &C.gws->awa, &ovf);
+	L.a0 = ovf;
+}
+H2G_HD void mach_op_adjmember(const AlnCtx& C, Mach& M) {
+	M.L.a0 = al_adjust_member(C, mach_sv(M), (h2g_ghit*)M.L.p0, M.ws) ? 1u : 0u;
+}
+H2G_HD void mach_op_sw(const AlnCtx& C, Mach& M) {
+	Lane& L = M.L;
+	const AlnParams& P = *C.P;
+	AlignWS* ws = M.ws;
+	GoVars& gv = ws->gv;
+	h2g_ghit* gh = (h2g_ghit*)L.p0;
+	const SeqView sv = mach_sv(M);
+	SwParams SP;
+	SP.sc = P.sc;
+	const uint32_t refoff = gh->toff > gh->rdoff ? gh->toff - gh->rdoff : 0;
+	SwOut* o = nullptr;
+	sw_align_single(*C.ref, SP, sv, gh->tidx, refoff, ws->m[gv.mw_slot].minsc, &gv.rnd, C.sw, &o);
+	if(o->overflow) ws->overflow |= 256;
+	L.a0 = 0;
+	if(o->found) {
+		// res.alres edits: setShape turned them to 5'-end coordinates, `if(!fw) invertEdits()` turns them back to the aligned
+		// strand's => exactly the backtrace's own coordinates.  genomeHit.init(fw, 0, rdlen, ...)
+		const uint32_t joinedOff = (uint32_t)((int64_t)gh->joinedOff + o->off - (int64_t)gh->toff);
+		hit_init(gh, sv.fw, 0, sv.len, gh->tidx, (uint32_t)o->off, joinedOff);
+		gh->score = o->score;
+		gh->nedits = o->nedits;
+		for(uint32_t e = 0; e < o->nedits; e++) gh->edits[e] = o->edits[e];
+		if(C.graph && C.alts->n > 0 && gh->nedits > 0) {  // replace_edits_with_alts spliced_aligner.h:282 (re-scores)
+			replace_edits_with_alts(*C.alts, gh);
+			calculate_score(P.sc, sv, gh);
+		}
+		L.a0 = 1;
+	}
+}
+
+// What a finished read leaves behind (the selection half of AlnSinkWrap::finishRead for unpaired reads; the report events of
+// both mates + the PRNG state for pairs, whose finishRead runs in h2g_sam_format_paired)
+struct MachOut {
+	ReadOut*    rout;      // unpaired: [n]
+	h2g_alnres* aln;       // unpaired: [n * aln_slots]
+	uint32_t    aln_slots; // records kept per read (>= -k)
+	PairOut*    pout;      // paired: [n]
+	h2g_alnres* paln[2];   // paired: [n * H2G_PAIR_RES_CAP] each
+};
+
+H2G_HD void mach_copy_rec(h2g_alnres& d, const AlnRec& r) {
+	d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
+	d.nedits = r.nedits; d.pad = 0; d.score = r.score;
+	for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
+}
+
+H2G_HD void mach_op_finish(const AlnCtx& C, Mach& M, const MachOut& O, bool paired_input) {
+	AlignWS* ws = M.ws;
+	GoVars& gv = ws->gv;
+	const uint32_t i = M.read;
+	if(!paired_input) {
+		ReadOut o;
+		Rng rnd; rnd.last = gv.rnd;
+		o.nres = ws->m[0].nres; o.overflow = ws->overflow; o.nrank = ws->nrank; o.nsteps = ws->nsteps; o.depth = ws->nframes_max; o.nside = ws->nside;
+		o.nselect = al_select(&ws->m[0], *C.P, &rnd, o.select);
+		int64_t b = INT64_MIN, sb = INT64_MIN;
+		uint32_t bt = 0, sbt = 0;
+		for(uint32_t k = 0; k < ws->m[0].nres; k++) {
+			const AlnRec& r = ws->m[0].res[k];
+			const uint32_t t = r.trim5 + r.trim3;
+			if(b == INT64_MIN || r.score > b || (r.score == b && t < bt)) { sb = b; sbt = bt; b = r.score; bt = t; }
+			else if(sb == INT64_MIN || r.score > sb || (r.score == sb && t < sbt)) { sb = r.score; sbt = t; }
+		}
+		o.best = b == INT64_MIN ? INT32_MIN : (int32_t)b; o.secbest = sb == INT64_MIN ? INT32_MIN : (int32_t)sb;
+		o.best_trim = bt; o.secbest_trim = sbt;
+		if(O.rout) O.rout[i] = o;
+		if(O.aln) for(uint32_t k = 0; k < o.nselect && k < O.aln_slots; k++) mach_copy_rec(O.aln[(size_t)i * O.aln_slots + k], ws->m[0].res[o.select[k]]);
+		M.L.a0 = o.nselect > 0; M.L.a1 = o.overflow != 0;
+	} else {
+		PairOut o;
+		o.nres[0] = ws->m[0].nres; o.nres[1] = ws->m[1].nres; o.npairs = ws->npairs; o.overflow = ws->overflow;
+		// the records beyond H2G_PAIR_RES_CAP are not returned: the pair is flagged so that no caller indexes past them
+		if(o.nres[0] > H2G_PAIR_RES_CAP || o.nres[1] > H2G_PAIR_RES_CAP) o.overflow |= 4;
+		o.nrank = ws->nrank; o.nsteps = ws->nsteps; o.depth = ws->nframes_max; o.nside = ws->nside; o.rnd_state = gv.rnd; o.pad = 0;
+		for(uint32_t k = 0; k < AL_MAX_PAIRS; k++) { o.pair_i[k] = k < ws->npairs ? ws->pair_i[k] : 0; o.pair_j[k] = k < ws->npairs ? ws->pair_j[k] : 0; }
+		if(O.pout) O.pout[i] = o;
+		for(int m = 0; m < 2; m++) {
+			if(!O.paln[m]) continue;
+			const uint32_t n = o.nres[m] < H2G_PAIR_RES_CAP ? o.nres[m] : H2G_PAIR_RES_CAP;
+			for(uint32_t k = 0; k < n; k++) mach_copy_rec(O.paln[m][(size_t)i * H2G_PAIR_RES_CAP + k], ws->m[m].res[k]);
+		}
+		M.L.a0 = o.npairs > 0; M.L.a1 = o.overflow != 0;
+	}
+}
+
+// one op for this lane; `op` is wave-uniform in the kernel
+H2G_HD void mach_exec(const AlnCtx& C, Mach& M, uint32_t op, const MachOut& O, bool paired_input) {
+	switch(op) {
+	case OP_PSEARCH:   mach_op_psearch(C, M); break;
+	case OP_GCOORDS:   mach_op_gcoords(C, M); break;
+	case OP_EXTEND:    mach_op_extend(C, M); break;
+	case OP_LSEARCH:   mach_op_lsearch(C, M); break;
+	case OP_LCOORDS:   mach_op_lcoords(C, M); break;
+	case OP_GSEARCH:   mach_op_gsearch(C, M); break;
+	case OP_COMBINE:   mach_op_combine(C, M); break;
+	case OP_ADJUST:    mach_op_adjust(C, M); break;
+	case OP_ADJMEMBER: mach_op_adjmember(C, M); break;
+	case OP_SW:        mach_op_sw(C, M); break;
+	case OP_FINISH:    mach_op_finish(C, M, O, paired_input); break;
+	default: break;
+	}
+	M.L.op = OP_NONE;
+}
+
+// One read / pair to completion on ONE lane (tests/emul; the kernels interleave 64 of these per wavefront)
+H2G_HD void mach_run_single(const AlnCtx& C, Mach& M, uint32_t read, bool paired_input, const MachOut& O) {
+	mach_begin(M, read, paired_input);
+	while(M.L.pc != PC_FINISHED) {
+		mach_step(C, M);
+		if(M.L.op != OP_NONE) mach_exec(C, M, M.L.op, O, paired_input);
+	}
+	M.L.pc = PC_IDLE;
+}
+
+}  // namespace h2g

@@ -576,7 +576,12 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 		Rng rnd = {pr.rnd_state};
 		// ReportingState::foundConcordant aln_sink.cpp:74-112: concordant pairs are kept while they tie the best pair score?
 		// No — every concordant pair reported is kept (rs1_/rs2_); nconcord = their count
-		const size_t np = std::min<size_t>(pr.npairs, H2G_PAIR_CAP);
+		// pairs naming a record beyond the H2G_PAIR_RES_CAP returned per mate (such a pair carries an overflow flag) are dropped
+		// rather than indexed past the end of the fetched records
+		uint8_t pi[H2G_PAIR_CAP], pj[H2G_PAIR_CAP];
+		size_t np = 0;
+		for(size_t k = 0; k < std::min<size_t>(pr.npairs, H2G_PAIR_CAP); k++)
+			if(pr.pair_i[k] < n1 && pr.pair_j[k] < n2) { pi[np] = pr.pair_i[k]; pj[np] = pr.pair_j[k]; np++; }
 		if(np > 0) {
 			Summ summ;
 			summ.paired = true;
@@ -587,7 +592,7 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 			size_t nconc = 0;
 			int64_t bestsum = INT64_MIN;
 			for(size_t k = 0; k < np; k++) {
-				const Score sc = add(score_of(r1[pr.pair_i[k]]), score_of(r2[pr.pair_j[k]]));
+				const Score sc = add(score_of(r1[pi[k]]), score_of(r2[pj[k]]));
 				if(k == 0 || sc.score > bestsum) { bestsum = sc.score; nconc = 0; }
 				nconc++;
 				keys.push_back(sc);
@@ -597,8 +602,8 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 			select_by_score(keys, std::min<size_t>(khits, nconc), rnd, sel, S->secondary);
 			if(sel.size() == 1) met.nconcord_uni1++; else met.nconcord_uni2++;
 			for(size_t q = 0; q < sel.size(); q++) {
-				const h2g_alnres* a = &r1[pr.pair_i[sel[q]]];
-				const h2g_alnres* b = &r2[pr.pair_j[sel[q]]];
+				const h2g_alnres* a = &r1[pi[sel[q]]];
+				const h2g_alnres* b = &r2[pj[sel[q]]];
 				f1.pairing = PAIR_CONCORD_M1; f2.pairing = PAIR_CONCORD_M2;
 				f1.primary = f2.primary = q == 0;
 				f1.oppAligned = f2.oppAligned = true;

@@ -256,6 +256,12 @@ typedef struct {
 	double   score_min_const, score_min_coeff;   /* default L,0,-0.2 (hisat2.cpp:440) */
 } h2g_align_params;
 H2G_EXPORT void       h2g_align_params_init(h2g_align_params*, const h2g_index*);
+/* The reference applies its presets after ALL options were read (hisat2.cpp:1882-1909) and lets the index type decide the
+ * default -k (:3903-3906): khits = saw_k ? k_arg : 10; --sensitive: bowtie2_dp 0 -> 1, khits < 10 -> 10 (counts as saw_k),
+ * --score-min L,0,-0.5; --very-sensitive: bowtie2_dp 2, khits < 30 -> 30, L,0,-1; without saw_k khits = 5 (linear) / 10 (graph);
+ * max_seeds_arg 0 -> max(5, 2 khits) (:3174).  Call it last, after every other field of *p was set from the options. */
+H2G_EXPORT void       h2g_align_params_presets(h2g_align_params* p, const h2g_index* ix, int saw_k, uint32_t k_arg, uint32_t max_seeds_arg,
+                                               int sensitive, int very_sensitive);
 /* read names (needed by genRandSeed): name i = bytes[offs[i] .. offs[i+1]) */
 H2G_EXPORT h2g_status h2g_set_read_names(h2g_stream*, const char* bytes, const uint32_t* offs, size_t n_reads);
 H2G_EXPORT h2g_status h2g_align_run(h2g_stream*, const h2g_align_params*);           /* async on the stream */
@@ -296,7 +302,9 @@ H2G_EXPORT h2g_status h2g_align_pairs_fetch_dense(h2g_stream*, h2g_pair_result* 
 typedef struct {
 	uint64_t n_rank, n_side, n_sa_steps, n_ext, n_ref_bytes, n_queries, n_aligned, n_overflow;
 	float    ms_search, ms_resolve_extend, ms_rank, ms_align;   /* HIP-event durations of the last launches */
-	float    ms_align_kernel;                                   /* k_align alone (ms_align includes the classifier stage) */
+	float    ms_align_kernel;                                   /* the main go() pass alone (ms_align includes the second pass) */
+	uint64_t n_second_pass;                                     /* reads whose default workspace overflowed and that were re-run with the
+	                                                             * large one; n_overflow = reads still flagged after that */
 } h2g_counters;
 H2G_EXPORT h2g_status h2g_get_counters(h2g_stream*, h2g_counters*);
 

@@ -213,20 +213,29 @@ void h2gemu_seed_extend(Emu* e, uint32_t pseudogeneStop, uint32_t khits, h2g_see
 }
 
 
-// HI_Aligner::go + selection for every read of the batch (names: '\0'-free bytes + offsets)
-void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, AlnRec* recs) {
-	DReads rd = e->reads();
+// HI_Aligner::go + selection for every read of the batch (names: '\0'-free bytes + offsets), one lane of the machine at a time
+static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	h2g_align_params hp;
 	if(e->has_params) hp = e->params; else { align_params_defaults(&hp, e->dg.linear); hp.bowtie2_dp = e->bowtie2_dp; }
-	AlnParams P = aln_params_from(hp, no_spliced != 0, e->dg.linear);
-	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
+	*P = aln_params_from(hp, no_spliced != 0, e->dg.linear);
+	C->g = &e->dg; C->ref = &e->dr; C->ls = &e->dls; C->P = P;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
-	C.sw = e->sw.data();
+	C->sw = e->sw.data();
 	static GraphWS gws_;
-	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_; C.graph = !e->dg.linear;
+	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->graph = !e->dg.linear;
+}
+
+void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, AlnRec* recs) {
+	AlnParams P; AlnCtx C;
+	emu_ctx(e, no_spliced, &P, &C);
 	AlignWS* ws = new AlignWS();
-	for(uint32_t i = 0; i < rd.n; i++) {
-		al_read(C, rd, i, names + name_offs[i], name_offs[i + 1] - name_offs[i], ws, &outs[i]);
+	Mach M;
+	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
+	MachOut O; O.rout = outs; O.aln = nullptr; O.pout = nullptr; O.paln[0] = O.paln[1] = nullptr;
+	for(uint32_t i = 0; i < M.rd[0].n; i++) {
+		M.name[0] = names + name_offs[i]; M.namelen[0] = name_offs[i + 1] - name_offs[i];
+		M.name[1] = nullptr; M.namelen[1] = 0;
+		mach_run_single(C, M, i, false, O);
 		for(uint32_t k = 0; k < ws->m[0].nres; k++) recs[(size_t)i * AL_MAX_RESULTS + k] = ws->m[0].res[k];
 	}
 	delete ws;
@@ -236,20 +245,17 @@ void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t
 // paired go(): mate 2 passed separately; names1/names2 as in the FASTA files
 void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, const uint32_t* offs2, const char* names1,
                         const uint32_t* noffs1, const char* names2, const uint32_t* noffs2, PairOut* outs, AlnRec* recs1, AlnRec* recs2) {
-	DReads rd1 = e->reads();
-	DReads rd2 = rd1;
-	rd2.codes = codes2; rd2.offs = offs2; rd2.quals = nullptr;
-	h2g_align_params hp;
-	if(e->has_params) hp = e->params; else { align_params_defaults(&hp, e->dg.linear); hp.bowtie2_dp = e->bowtie2_dp; }
-	AlnParams P = aln_params_from(hp, no_spliced != 0, e->dg.linear);
-	AlnCtx C; C.g = &e->dg; C.ref = &e->dr; C.ls = &e->dls; C.P = &P;
-	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
-	C.sw = e->sw.data();
-	static GraphWS gws_;
-	C.alts = &e->dalts; C.gws = e->dg.linear ? nullptr : &gws_; C.graph = !e->dg.linear;
+	AlnParams P; AlnCtx C;
+	emu_ctx(e, no_spliced, &P, &C);
 	AlignWS* ws = new AlignWS();
-	for(uint32_t i = 0; i < rd1.n; i++) {
-		al_pair(C, rd1, rd2, i, names1 + noffs1[i], noffs1[i + 1] - noffs1[i], names2 + noffs2[i], noffs2[i + 1] - noffs2[i], ws, &outs[i]);
+	Mach M;
+	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
+	M.rd[1].codes = codes2; M.rd[1].offs = offs2; M.rd[1].quals = nullptr;
+	MachOut O; O.rout = nullptr; O.aln = nullptr; O.pout = outs; O.paln[0] = O.paln[1] = nullptr;
+	for(uint32_t i = 0; i < M.rd[0].n; i++) {
+		M.name[0] = names1 + noffs1[i]; M.namelen[0] = noffs1[i + 1] - noffs1[i];
+		M.name[1] = names2 + noffs2[i]; M.namelen[1] = noffs2[i + 1] - noffs2[i];
+		mach_run_single(C, M, i, true, O);
 		for(uint32_t k = 0; k < ws->m[0].nres; k++) recs1[(size_t)i * AL_MAX_RESULTS + k] = ws->m[0].res[k];
 		for(uint32_t k = 0; k < ws->m[1].nres; k++) recs2[(size_t)i * AL_MAX_RESULTS + k] = ws->m[1].res[k];
 	}
