@@ -28,12 +28,12 @@ namespace h2g {
 #define AL_MAX_GHITS    20    // max(khits, kseeds): 10 on linear, 20 on graph indexes (hisat2.cpp:3174-3176, 3903-3906)
 #endif
 #ifndef AL_MAX_SEARCHED        // the *_big units raise these (second pass over overflowed reads, option sets beyond the defaults)
-#define AL_MAX_SEARCHED 64
-#define AL_MAX_RESULTS  32
-#define AL_MAX_DEPTH    32
+#define AL_MAX_SEARCHED 32     // the default workspace is sized for the common read: ~100 KB per read in flight; whatever
+#define AL_MAX_RESULTS  16     // overflows it is re-run with the *_big capacities (h2g_go_big.h) by the second pass
+#define AL_MAX_DEPTH    20
 #define AL_MAX_LOCALHITS 4
 #define AL_MAX_COORDS   12
-#define AL_MAX_PARTIAL  24
+#define AL_MAX_PARTIAL  16
 #endif
 #define H2G_SELECT_CAP 32      // alignments selected per read: >= the largest -k (30: --very-sensitive); fixed in every unit
 
@@ -738,7 +738,8 @@ struct AlnCtx {
 	const AlnParams* P;
 	uint8_t* sw = nullptr;   // this lane's Smith-Waterman scratch (sw_scratch_bytes), only when P->bowtie2_dp != 0
 	const DAlts* alts = nullptr;      // graph index: the ALT database
-	struct GraphWS* gws = nullptr;    // graph index: this lane's graph scratch
+	struct GraphWS* gws = nullptr;    // graph index: this lane's scratch for one primitive (group walk, ALT extension)
+	struct GraphSlot* gsl = nullptr;  // graph index: the graph state of the read being worked on
 	bool graph = false;               // set from a kernel template constant so that the linear kernels carry no graph code
 };
 
@@ -746,9 +747,11 @@ struct AlnCtx {
 // group-walk state, ALT-extension state, and the node range + in-edge list of every partial hit (BWTHit::_node_top,
 // _node_bot, _node_iedge_count hi_aligner.h:196-199), indexed [mate slot][strand][partial hit].
 struct GraphPNode { uint32_t node_top, node_bot; IEdges ie; };
-struct GraphWS {
+struct GraphWS {               // scratch of ONE primitive execution: per lane of the kernel, not per read
 	GwCtx      gw;
 	AwaWS      awa;
+};
+struct GraphSlot {             // graph state that lives as long as the read: per read in flight
 	IEdges     ie;                 // in-edge list of the last search (waits for the coordinate call)
 	uint32_t   node_top, node_bot; // its node range
 	GraphPNode pnode[2][2][AL_MAX_PARTIAL];
@@ -773,136 +776,6 @@ H2G_HD bool al_extend(const AlnCtx& C, const SeqView& seq, h2g_ghit* h, uint32_t
 	return extend_item_alts(*C.ref, *C.alts, C.P->sc, seq, h, mm, ml, mr, le, re, &C.gws->awa);
 }
 
-// hi_aligner.h:5007-5193 for one (read, strand)
-H2G_HD uint32_t al_get_anchor_hits(const AlnCtx& C, const SeqView& seq, AlignWS* ws, MateWS* mw, int fwi, Rng* rnd) {
-	const DGfm& g = *C.g;
-	const AlnParams& P = *C.P;
-	const bool graph = C.graph;
-	const int slot = (int)(mw - ws->m);
-	RBHit& hit = mw->rb[fwi];
-	const uint32_t maxsz = P.khits > P.kseeds ? P.khits : P.kseeds;
-	const uint32_t minK = g.minK;
-	ws->nghits = 0;
-	const uint32_t offsetSize = hit.npartial;
-	for(uint32_t hi = 0; hi < offsetSize; hi++) {
-		uint32_t hj = 0;
-		for(; hj < offsetSize; hj++) {
-			const PartialHit& pj = hit.partial[hj];
-			if(ph_empty(pj) || pj.ncoords > 0 || pj.len <= minK + 2) continue;
-			else break;
-		}
-		if(hj >= offsetSize) break;
-		for(uint32_t hk = hj + 1; hk < offsetSize; hk++) {
-			const PartialHit& pj = hit.partial[hj];
-			const PartialHit& pk = hit.partial[hk];
-			if(ph_empty(pk) || pk.ncoords > 0 || pk.len <= minK + 2) continue;
-			if(pj.hit_type == pk.hit_type) {
-				const uint32_t sj = pj.bot - pj.top, sk = pk.bot - pk.top;
-				if(sj > sk || (sj == sk && pj.len < pk.len)) hj = hk;
-			} else if(pk.hit_type > pj.hit_type) hj = hk;
-		}
-		PartialHit& ph = hit.partial[hj];
-		const uint32_t remained = maxsz - ws->nghits;
-		if(remained == 0) break;
-		const GraphPNode* pn = graph ? &C.gws->pnode[slot][fwi][hj] : nullptr;
-		uint32_t expected = graph ? pn->node_bot - pn->node_top : ph.bot - ph.top;
-		h2g_coord* co = ph.coords;
-		uint32_t nco = 0;
-		const uint32_t rdoff = hit.len - ph.bwoff - ph.len;
-		if(expected <= remained) {
-			h2g_sa_result res;
-			if(graph) genome_coords_graph_item(g, &C.gws->gw, ph.top, ph.bot, pn->node_top, pn->node_bot, &pn->ie, ph.bot - ph.top, ph.len, false, co, AL_MAX_GHITS, &res);
-			else genome_coords_item(g, ph.top, ph.bot, ph.bot - ph.top, ph.len, false, co, AL_MAX_GHITS, &res);
-			if(res.nsteps == H2G_MAX) { ws->overflow |= 512; res.nsteps = 0; }
-			nco = res.ncoords;
-			ws->nsteps += res.nsteps;
-		} else if(graph) {   // random sub-sample of `remained` NODES, each with its own rows / extra in-edges (:5096-5136)
-			uint32_t edgeIdx = 0, top = ph.top, added = 0;
-			for(uint32_t node = pn->node_top; node < pn->node_bot; node++, expected--) {
-				uint32_t bot = top + 1;
-				IEdges& t = C.gws->ie;
-				t.n = 0;
-				if(edgeIdx < pn->ie.n && edgeIdx < H2G_IEDGE_CAP) {
-					if(node - pn->node_top == pn->ie.e[edgeIdx][0]) {
-						bot += pn->ie.e[edgeIdx][1];
-						t.n = 1; t.e[0][0] = 0; t.e[0][1] = pn->ie.e[edgeIdx][1];
-						edgeIdx++;
-					}
-				}
-				uint32_t rndi = rnd->nextU32() % expected;
-				if(rndi < remained - added) {
-					h2g_sa_result res;
-					if(nco < AL_MAX_GHITS) {
-						genome_coords_graph_item(g, &C.gws->gw, top, bot, node, node + 1, &t, ph.bot - ph.top, ph.len, false, co + nco, AL_MAX_GHITS - nco, &res);
-						if(res.nsteps == H2G_MAX) { ws->overflow |= 512; res.nsteps = 0; }
-						nco += res.ncoords;
-						ws->nsteps += res.nsteps;
-					} else ws->overflow |= 64;
-					added++;
-					if(added >= remained) break;
-				}
-				top = bot;
-			}
-		} else {   // random sub-sample of `remained` rows (:5096-5136)
-			uint32_t top = ph.top, added = 0;
-			for(uint32_t node = ph.top; node < ph.bot; node++, expected--) {
-				uint32_t bot = top + 1;
-				uint32_t rndi = rnd->nextU32() % expected;
-				if(rndi < remained - added) {
-					h2g_sa_result res;
-					if(nco < AL_MAX_GHITS) {
-						genome_coords_item(g, top, bot, ph.bot - ph.top, ph.len, false, co + nco, AL_MAX_GHITS - nco, &res);
-						nco += res.ncoords;
-						ws->nsteps += res.nsteps;
-					} else ws->overflow |= 64;
-					added++;
-					if(added >= remained) break;
-				}
-				top = bot;
-			}
-		}
-		AL_TRACE("   anchor hj %u nco %u expected %u remained %u\n", hj, nco, expected, remained);
-		ph.ncoords = nco;
-		if(nco == 0) continue;                       // !hasGenomeCoords()
-		const uint32_t genomeHit_size = ws->nghits;
-		if(genomeHit_size + nco > maxsz) {           // coords.shufflePortion(0, size, rnd) ds.h:836
-			uint32_t left = nco;
-			for(uint32_t i = 0; i + 1 < nco; i++) {
-				uint32_t r = rnd->nextU32() % left;
-				if(r > 0) { h2g_coord t = co[i]; co[i] = co[i + r]; co[i + r] = t; }
-				left--;
-			}
-		}
-		for(uint32_t k = 0; k < nco; k++) {
-			if(co[k].tidx == H2G_MAX) continue;
-			const uint32_t len = ph.len;
-			bool overlapped = false;
-			for(uint32_t l = 0; l < genomeHit_size; l++) {
-				h2g_ghit& gh = ws->ghits[l];
-				if(gh.tidx != co[k].tidx || (gh.fw != 0) != seq.fw) continue;
-				const uint32_t hitoff = gh.toff + hit.len - gh.rdoff;
-				const uint32_t hitoff2 = co[k].toff + hit.len - rdoff;
-				const int64_t diff = P.no_spliced ? 0 : (int64_t)P.maxIntronLen;
-				int64_t d = (int64_t)hitoff - (int64_t)hitoff2;
-				if(d < 0) d = -d;
-				if(d <= diff) { overlapped = true; gh.read++; break; }   // _hitcount++
-			}
-			if(!overlapped) {
-				if(graph) {                                        // adjustWithALT may add several (or no) hits (:5175)
-					uint32_t ovf = 0;
-					adjust_with_alt(g, *C.ref, *C.alts, seq, rdoff, len, co[k].tidx, co[k].toff, co[k].joinedOff, ws->ghits, &ws->nghits, AL_MAX_GHITS,
-					                &C.gws->awa, &ovf);
-					if(ovf) ws->overflow |= 64;
-				} else if(ws->nghits < AL_MAX_GHITS) hit_init(&ws->ghits[ws->nghits++], seq.fw, rdoff, len, co[k].tidx, co[k].toff, co[k].joinedOff);
-				else ws->overflow |= 64;
-			}
-			if(ph.hit_type == H2G_CANDIDATE_HIT && ws->nghits >= maxsz) break;
-		}
-		if(ph.hit_type == H2G_CANDIDATE_HIT && ws->nghits >= maxsz) break;
-	}
-	return ws->nghits;
-}
-
 H2G_HD bool al_adjust_member(const AlnCtx& C, const SeqView& seq, h2g_ghit* t, AlignWS* ws) {
 	if(!C.graph) return true;
 	uint32_t ovf = 0;
@@ -919,10 +792,10 @@ H2G_HD uint32_t al_local_search(const AlnCtx& C, AlignWS* ws, uint32_t lidx, con
 	const LGfm x = lgfm_of(*C.ls, *lx.d);
 	GRange r;
 	r.top = *top; r.bot = *bot; r.node_top = r.node_bot = 0;
-	const uint32_t nelt = gfm_search_graph(x, lx, seq, extoff, extlen, &r, &C.gws->ie, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true,
+	const uint32_t nelt = gfm_search_graph(x, lx, seq, extoff, extlen, &r, &C.gsl->ie, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true,
 	                                       P.kseeds, &ws->nrank);
 	*top = r.top; *bot = r.bot;
-	C.gws->node_top = r.node_top; C.gws->node_bot = r.node_bot;
+	C.gsl->node_top = r.node_top; C.gsl->node_bot = r.node_bot;
 	return nelt;
 }
 H2G_HD void al_local_coords(const AlnCtx& C, AlignWS* ws, uint32_t lidx, uint32_t top, uint32_t bot, uint32_t rdoff, uint32_t rdlen,
@@ -931,10 +804,10 @@ H2G_HD void al_local_coords(const AlnCtx& C, AlignWS* ws, uint32_t lidx, uint32_
 	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
 	if(!C.graph) { genome_coords_local(lx, top, bot, rdoff, rdlen, coords, cap, ncoords, &ws->nsteps); return; }
 	const LGfm x = lgfm_of(*C.ls, *lx.d);
-	const uint32_t node_top = C.gws->node_top, node_bot = C.gws->node_bot;
+	const uint32_t node_top = C.gsl->node_top, node_bot = C.gsl->node_bot;
 	uint32_t nelt = 0, n = 0;
 	*ncoords = 0;
-	if(!gw_resolve(x, &C.gws->gw, top, bot, node_top, node_bot, &C.gws->ie, bot - top, &nelt)) { ws->overflow |= 512; return; }
+	if(!gw_resolve(x, &C.gws->gw, top, bot, node_top, node_bot, &C.gsl->ie, bot - top, &nelt)) { ws->overflow |= 512; return; }
 	ws->nsteps += C.gws->gw.nsteps;
 	AL_TRACE("     lcoords top %u bot %u node %u %u -> nelt %u\n", top, bot, node_top, node_bot, nelt);
 	for(uint32_t e = 0; e < nelt; e++) {
@@ -953,17 +826,17 @@ H2G_HD uint32_t al_global_search(const AlnCtx& C, AlignWS* ws, const SeqView& se
 	if(!C.graph) return gfm_search(gx, seq, extoff, extlen, top, bot, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false, &ws->nrank);
 	GRange r;
 	r.top = *top; r.bot = *bot; r.node_top = r.node_bot = 0;
-	const uint32_t nelt = gfm_search_graph(*C.g, gx, seq, extoff, extlen, &r, &C.gws->ie, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false,
+	const uint32_t nelt = gfm_search_graph(*C.g, gx, seq, extoff, extlen, &r, &C.gsl->ie, uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false,
 	                                       P.kseeds, &ws->nrank);
 	if(nelt > 0) { *top = r.top; *bot = r.bot; }
-	C.gws->node_top = r.node_top; C.gws->node_bot = r.node_bot;
+	C.gsl->node_top = r.node_top; C.gsl->node_bot = r.node_bot;
 	return nelt;
 }
 H2G_HD uint32_t al_global_coords(const AlnCtx& C, AlignWS* ws, uint32_t top, uint32_t bot, uint32_t extlen, h2g_coord* coords, uint32_t cap) {
 	h2g_sa_result res;
 	if(!C.graph) genome_coords_item(*C.g, top, bot, bot - top, extlen, true, coords, cap, &res);
 	else {
-		genome_coords_graph_item(*C.g, &C.gws->gw, top, bot, C.gws->node_top, C.gws->node_bot, &C.gws->ie, bot - top, extlen, true,
+		genome_coords_graph_item(*C.g, &C.gws->gw, top, bot, C.gsl->node_top, C.gsl->node_bot, &C.gsl->ie, bot - top, extlen, true,
 		                         coords, cap, &res);
 		if(res.nsteps == H2G_MAX) { ws->overflow |= 512; res.nsteps = 0; }
 	}

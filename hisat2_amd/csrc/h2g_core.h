@@ -61,7 +61,7 @@ struct DReads {
 	const uint32_t* pk = nullptr;
 	uint32_t pk_stride = 0, pk_read = 0xffffffffu;
 };
-#define H2G_PK_WORDS 16          // 256 bases
+#define H2G_PK_WORDS 8           // 128 bases (longer reads are read from HBM base by base)
 #define H2G_PK_MAXLEN (H2G_PK_WORDS * 16)
 
 struct DScoring {  // Scoring defaults scoring.h:29-87 / hisat2.cpp:425-441

@@ -16,8 +16,9 @@ struct GoArgs {
 	h2g::AlnParams P;
 	const char* names1; const uint32_t* noffs1;
 	const char* names2; const uint32_t* noffs2;
-	uint8_t* pool; size_t ws_stride;      // AlignWS per lane
-	uint8_t* gws_base; size_t gws_stride; // GraphWS per lane (graph indexes)
+	uint8_t* pool; size_t ws_stride;      // per read in flight (slot): AlignWS, then GoSlot at slot_off, then GraphSlot at gsl_off
+	size_t slot_off, gsl_off;
+	uint8_t* gws_base; size_t gws_stride; // GraphWS per lane (graph indexes): scratch of one primitive
 	uint8_t* sw_base; size_t sw_stride;   // Smith-Waterman scratch per lane (bowtie2_dp != 0)
 	h2g::MachOut O;
 	unsigned long long* counters;
@@ -25,11 +26,13 @@ struct GoArgs {
 	const uint32_t* list;                 // nullptr = every read of the batch; else the read ids to process ...
 	const uint32_t* nlist;                // ... and how many (device memory: the second pass is launched without a host sync)
 	uint32_t paired;
+	uint32_t dbg_read; uint32_t* dbg_buf; // development hook: trace of one read id (H2G_GO_DBG_READ): [0] = words used, then 8 words per primitive request
 	uint32_t defer_overflow;              // 1: a second pass follows; overflowed reads are not counted as aligned here
 };
 #define H2G_PK_LANE_WORDS_HOST (H2G_PK_WORDS + H2G_PK_WORDS / 2)
 
 #define H2G_GO_DECLARE(NAME) \
 	extern "C" size_t h2g_go_ws_bytes_##NAME(); extern "C" size_t h2g_go_gws_bytes_##NAME(); extern "C" int h2g_go_waves_##NAME(); \
+	extern "C" size_t h2g_go_slot_off_##NAME(); extern "C" size_t h2g_go_gsl_off_##NAME(); extern "C" void h2g_go_geometry_##NAME(uint32_t*); \
 	extern "C" void h2g_go_caps_##NAME(uint32_t*); extern "C" int h2g_go_launch_##NAME(const GoArgs*, unsigned, hipStream_t);
 H2G_GO_DECLARE(linear) H2G_GO_DECLARE(graph) H2G_GO_DECLARE(linear_big) H2G_GO_DECLARE(graph_big)

@@ -62,6 +62,7 @@ struct h2g_stream {
 		uint8_t* gws = nullptr; size_t gws_bytes = 0;     // GraphWS x lanes (graph indexes only)
 		uint8_t* sw = nullptr;  size_t sw_stride = 0, sw_lanes = 0;   // Smith-Waterman scratch (only with bowtie2_dp != 0)
 	} pool[2];
+	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
 	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	size_t aln_alloc = 0;             // records allocated behind d_aln
@@ -296,8 +297,8 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
 	for(int i = 0; i < 10; i++) HIPCHK(hipEventCreate(&s->ev[i]));
-	HIPCHK(hipMalloc((void**)&s->d_counters, 16 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(s->d_counters, 0, 16 * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&s->d_counters, 128 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->d_counters, 0, 128 * sizeof(unsigned long long)));
 	if(max_reads) {
 		HIPCHK(hipMalloc((void**)&s->d_codes, max_bases + 64));
 		HIPCHK(hipMalloc((void**)&s->d_quals, max_bases + 64));
@@ -1194,26 +1195,27 @@ static int need_alignable(h2g_stream* s) {
 // the go() units: [linear?][big?]
 struct GoUnit {
 	size_t (*ws_bytes)(); size_t (*gws_bytes)(); int (*waves)(); void (*caps)(uint32_t*); int (*launch)(const GoArgs*, unsigned, hipStream_t);
+	size_t (*slot_off)(); size_t (*gsl_off)(); void (*geometry)(uint32_t*);
 };
 static const GoUnit& go_unit(bool linear, bool big) {
 	static const GoUnit u[2][2] = {
-		{{h2g_go_ws_bytes_graph, h2g_go_gws_bytes_graph, h2g_go_waves_graph, h2g_go_caps_graph, h2g_go_launch_graph},
-		 {h2g_go_ws_bytes_graph_big, h2g_go_gws_bytes_graph_big, h2g_go_waves_graph_big, h2g_go_caps_graph_big, h2g_go_launch_graph_big}},
-		{{h2g_go_ws_bytes_linear, h2g_go_gws_bytes_linear, h2g_go_waves_linear, h2g_go_caps_linear, h2g_go_launch_linear},
-		 {h2g_go_ws_bytes_linear_big, h2g_go_gws_bytes_linear_big, h2g_go_waves_linear_big, h2g_go_caps_linear_big, h2g_go_launch_linear_big}}};
+		{{h2g_go_ws_bytes_graph, h2g_go_gws_bytes_graph, h2g_go_waves_graph, h2g_go_caps_graph, h2g_go_launch_graph, h2g_go_slot_off_graph, h2g_go_gsl_off_graph, h2g_go_geometry_graph},
+		 {h2g_go_ws_bytes_graph_big, h2g_go_gws_bytes_graph_big, h2g_go_waves_graph_big, h2g_go_caps_graph_big, h2g_go_launch_graph_big, h2g_go_slot_off_graph_big, h2g_go_gsl_off_graph_big, h2g_go_geometry_graph_big}},
+		{{h2g_go_ws_bytes_linear, h2g_go_gws_bytes_linear, h2g_go_waves_linear, h2g_go_caps_linear, h2g_go_launch_linear, h2g_go_slot_off_linear, h2g_go_gsl_off_linear, h2g_go_geometry_linear},
+		 {h2g_go_ws_bytes_linear_big, h2g_go_gws_bytes_linear_big, h2g_go_waves_linear_big, h2g_go_caps_linear_big, h2g_go_launch_linear_big, h2g_go_slot_off_linear_big, h2g_go_gsl_off_linear_big, h2g_go_geometry_linear_big}}};
 	return u[linear ? 1 : 0][big ? 1 : 0];
 }
 
 // sizes the per-lane scratch of one pass and fills the pool fields of `a`
-static int go_pool_for(h2g_stream* s, int which, const GoUnit& u, size_t lanes, uint32_t bowtie2_dp, GoArgs* a) {
+static int go_pool_for(h2g_stream* s, int which, const GoUnit& u, size_t slots, size_t lanes, uint32_t bowtie2_dp, GoArgs* a) {
 	h2g_stream::GoPool& pl = s->pool[which];
 	const size_t wsb = u.ws_bytes(), gwb = u.gws_bytes();
-	if(pl.ws_bytes < lanes * wsb) {
+	if(pl.ws_bytes < slots * wsb) {
 		(void)hipFree(pl.ws); pl.ws = nullptr; pl.ws_bytes = 0;
-		HIPCHK(hipMalloc((void**)&pl.ws, lanes * wsb));
-		pl.ws_bytes = lanes * wsb;
+		HIPCHK(hipMalloc((void**)&pl.ws, slots * wsb));
+		pl.ws_bytes = slots * wsb;
 	}
-	a->pool = pl.ws; a->ws_stride = wsb;
+	a->pool = pl.ws; a->ws_stride = wsb; a->slot_off = u.slot_off(); a->gsl_off = u.gsl_off();
 	a->gws_base = nullptr; a->gws_stride = gwb;
 	if(gwb) {
 		if(pl.gws_bytes < lanes * gwb) {
@@ -1275,16 +1277,20 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	HIPCHK(hipSetDevice(s->ix->device));
 	const bool big_main = maxsz > caps[0];
 	const GoUnit& U = go_unit(linear, big_main);
-	const unsigned block = 256;
-	// resident blocks per CU = waves per SIMD of the unit, bounded by the LDS the packed reads take (24 KB per mate per block)
-	size_t per_cu = (size_t)U.waves();
-	const size_t lds_blocks = (160u * 1024u) / ((paired ? 2u : 1u) * H2G_PK_LANE_WORDS_HOST * 256u * 4u);
+	// geometry of the unit: workgroups of geo[0] threads own geo[1] reads in flight; resident workgroups per CU = what the
+	// unit's waves per SIMD and the LDS (rings + one packed-read region per mate) allow
+	uint32_t geo[4];
+	U.geometry(geo);
+	const unsigned block = geo[0];
+	size_t per_cu = (size_t)U.waves() * 256 / block;
+	const size_t lds_blocks = (160u * 1024u) / (geo[2] + (paired ? 2u : 1u) * geo[3]);
 	if(per_cu > lds_blocks) per_cu = lds_blocks;
+	if(per_cu < 1) per_cu = 1;
 	static const int grid_env = getenv("H2G_GO_BLOCKS_PER_CU") ? atoi(getenv("H2G_GO_BLOCKS_PER_CU")) : 0;
 	if(grid_env > 0) per_cu = (size_t)grid_env;
-	size_t want = (s->n_reads + block - 1) / block;
+	size_t want = (s->n_reads + geo[1] - 1) / geo[1];
 	size_t maxblocks = 256 * per_cu;
-	if(big_main && maxblocks > 128) maxblocks = 128;      // ~1.3 MB of workspace per lane
+	if(big_main && maxblocks > 32) maxblocks = 32;        // ~1.3 MB of workspace per read in flight
 	const unsigned grid = (unsigned)(want < 1 ? 1 : (want > maxblocks ? maxblocks : want));
 	GoArgs A;
 	memset(&A, 0, sizeof A);
@@ -1294,7 +1300,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	A.P = aln_params_from(*p, true, linear);
 	A.names1 = s->d_names; A.noffs1 = s->d_name_offs; A.names2 = s->d_names2; A.noffs2 = s->d_name_offs2;
 	A.paired = paired ? 1u : 0u;
-	if((rc = go_pool_for(s, 0, U, (size_t)grid * block, p->bowtie2_dp, &A))) return rc;
+	if((rc = go_pool_for(s, 0, U, (size_t)grid * geo[1], (size_t)grid * block, p->bowtie2_dp, &A))) return rc;
 	memset(&A.O, 0, sizeof A.O);
 	if(!paired) {
 		if(!s->d_rout) HIPCHK(hipMalloc((void**)&s->d_rout, s->max_reads * sizeof(ReadOut)));
@@ -1315,12 +1321,19 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	}
 	if(!s->d_ovf_list) HIPCHK(hipMalloc((void**)&s->d_ovf_list, (s->max_reads + 4) * 4));
 	(void)hipGetLastError();
-	HIPCHK(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), s->st));
+	HIPCHK(hipMemsetAsync(s->d_counters, 0, 128 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipMemsetAsync(s->d_ovf_list + s->max_reads, 0, 16, s->st));
 	A.counters = s->d_counters;
 	A.work = reinterpret_cast<uint32_t*>(s->d_counters + 14);
 	A.list = nullptr; A.nlist = nullptr;
-	static const int no_second = getenv("H2G_GO_NO_SECOND_PASS") ? atoi(getenv("H2G_GO_NO_SECOND_PASS")) : 0;
+	if(getenv("H2G_GO_DBG_READ")) {
+		static uint32_t* dbg = nullptr;
+		if(!dbg) HIPCHK(hipMalloc((void**)&dbg, (1u << 20) * 4));
+		HIPCHK(hipMemsetAsync(dbg, 0, (1u << 20) * 4, s->st));
+		A.dbg_buf = dbg; A.dbg_read = (uint32_t)atoi(getenv("H2G_GO_DBG_READ"));
+		s->dbg_buf = dbg;
+	}
+	const int no_second = getenv("H2G_GO_NO_SECOND_PASS") ? atoi(getenv("H2G_GO_NO_SECOND_PASS")) : 0;   // measurement / debugging knob
 	const bool second = !big_main && !no_second;
 	A.defer_overflow = second ? 1u : 0u;
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
@@ -1332,10 +1345,12 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		uint32_t* cnt = s->d_ovf_list + s->max_reads;
 		hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st,
 		                   paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, s->d_ovf_list, cnt);
-		const unsigned bgrid = 16;
+		const unsigned bgrid = 4;
+		uint32_t bgeo[4];
+		B.geometry(bgeo);
 		GoArgs A2 = A;
-		if((rc = go_pool_for(s, 1, B, (size_t)bgrid * block, p->bowtie2_dp, &A2))) return rc;
-		A2.counters = s->d_counters + 8;
+		if((rc = go_pool_for(s, 1, B, (size_t)bgrid * bgeo[1], (size_t)bgrid * bgeo[0], p->bowtie2_dp, &A2))) return rc;
+		A2.counters = s->d_counters + 64;
 		A2.work = reinterpret_cast<uint32_t*>(s->d_counters + 15);
 		A2.list = s->d_ovf_list; A2.nlist = cnt;
 		A2.defer_overflow = 0;
@@ -1449,12 +1464,29 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 	                    n, aln2, offs2, 2);
 }
 
+// development hook (env H2G_GO_DBG_READ=<read id>): the primitive requests of that read in the last go() launch, 8 words each
+extern "C" __attribute__((visibility("default"))) int h2g_go_debug_trace(h2g_stream* s, uint32_t* out, uint32_t cap_words) {
+	if(!s || !out || !s->dbg_buf) return H2G_ERR_ARG;
+	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(hipMemcpy(out, s->dbg_buf, (size_t)cap_words * 4, hipMemcpyDeviceToHost));
+	return H2G_OK;
+}
+
+// development hook (builds with -DH2G_GO_PROF): the wave-level time split of the last go() launch, 48 slots (h2g_go_kernels.h)
+extern "C" __attribute__((visibility("default"))) int h2g_go_prof(h2g_stream* s, unsigned long long* out48) {
+	if(!s || !out48) return H2G_ERR_ARG;
+	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(hipMemcpy(out48, s->d_counters + 16, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return H2G_OK;
+}
+
 extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	if(!s || !c) return H2G_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(s->st));
 	unsigned long long v[16];
-	HIPCHK(hipMemcpy(v, s->d_counters, sizeof v, hipMemcpyDeviceToHost));
-	// [0..7] the main pass, [8..15] the second pass over its overflowed reads (go_run)
+	HIPCHK(hipMemcpy(v, s->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(v + 8, s->d_counters + 64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	// [0..7] the main pass, [8..15] <- slots 64..71: the second pass over its overflowed reads (go_run)
 	s->last.n_rank = v[0] + v[8]; s->last.n_side = v[1] + v[9]; s->last.n_sa_steps = v[2] + v[10]; s->last.n_ext = v[3];
 	s->last.n_aligned = v[4] + v[12];
 	uint32_t nsecond = 0;

@@ -101,7 +101,8 @@ H2G_HD void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 		FR.state = (RESUME); \
 		if(gv.sp + 1 >= AL_MAX_DEPTH) { ws->overflow |= 8; gv.ret = INT64_MIN; M_GOTO(RESUME); } \
 		else { Frame& nf_ = ws->stack[gv.sp + 1]; hit_copy(&nf_.hit, (HITPTR)); nf_.hitoff = (HOFF); nf_.hitlen = (HLEN); gv.sp++; \
-		       if((uint32_t)gv.sp + 1 > ws->nframes_max) ws->nframes_max = (uint32_t)gv.sp + 1; M_GOTO(PC_RC_ENTRY); } } while(0)
+		       if((uint32_t)gv.sp + 1 > ws->nframes_max) { ws->nframes_max = (uint32_t)gv.sp + 1; } \
+		       M_GOTO(PC_RC_ENTRY); } } while(0)
 #define RC_RET(V) do { gv.ret = (V); gv.sp--; if(gv.sp >= 0) M_GOTO(ws->stack[gv.sp].state); else M_GOTO(gv.rc_ret_pc); } while(0)
 // hybridSearch_recur(root, hitoff, hitlen) on the current SeqView / MateWS; control resumes at RETPC with the result in gv.ret
 #define RC_START(ROOT, HOFF, HLEN, MINSC, MATE, RETPC) do { \
@@ -188,8 +189,8 @@ again:
 		RBHit& hit = mw.rb[fwi];
 		const h2g_fm_hit& fh = ws->fh;
 		if(C.graph && hit.npartial < AL_MAX_PARTIAL) {
-			GraphPNode& pn = C.gws->pnode[gv.mw_slot][fwi][hit.npartial];
-			pn.node_top = fh.node_top; pn.node_bot = fh.node_bot; pn.ie = C.gws->ie;
+			GraphPNode& pn = C.gsl->pnode[gv.mw_slot][fwi][hit.npartial];
+			pn.node_top = fh.node_top; pn.node_bot = fh.node_bot; pn.ie = C.gsl->ie;
 			if(pn.ie.n > H2G_IEDGE_CAP) ws->overflow |= 512;
 		}
 		AL_TRACE("  psearch rdi %d fwi %d cur %u -> top %u bot %u len %u type %u cur %u done %u anchor %u\n", rdi, fwi, hit.cur, fh.top, fh.bot, fh.len, fh.hit_type, fh.cur, fh.done, fh.anchorStop);
@@ -343,18 +344,17 @@ again:
 		}
 		if(hj >= offsetSize) M_GOTO(PC_GAH_END);
 		for(uint32_t hk = hj + 1; hk < offsetSize; hk++) {
-			const PartialHit& pj = hit.partial[hj];
 			const PartialHit& pk = hit.partial[hk];
 			if(ph_empty(pk) || pk.ncoords > 0 || pk.len <= minK + 2) continue;
-			if(pj.hit_type == pk.hit_type) {
-				const uint32_t sj = pj.bot - pj.top, sk = pk.bot - pk.top;
-				if(sj > sk || (sj == sk && pj.len < pk.len)) hj = hk;
-			} else if(pk.hit_type > pj.hit_type) hj = hk;
+			const uint32_t tj = hit.partial[hj].hit_type, tk = pk.hit_type, lj = hit.partial[hj].len, lk = pk.len;
+			const uint32_t sj = hit.partial[hj].bot - hit.partial[hj].top, sk = pk.bot - pk.top;
+			const bool better = tj == tk ? (sj > sk || (sj == sk && lj < lk)) : (tk > tj);
+			if(better) hj = hk;
 		}
 		PartialHit& ph = hit.partial[hj];
 		const uint32_t remained = maxsz - ws->nghits;
 		if(remained == 0) M_GOTO(PC_GAH_END);
-		const GraphPNode* pn = C.graph ? &C.gws->pnode[gv.mw_slot][fwi][hj] : nullptr;
+		const GraphPNode* pn = C.graph ? &C.gsl->pnode[gv.mw_slot][fwi][hj] : nullptr;
 		const uint32_t expected = C.graph ? pn->node_bot - pn->node_top : ph.bot - ph.top;
 		gv.gh_hj = hj; gv.gh_nco = 0; gv.gh_remained = remained;
 		gv.gh_rdoff = hit.len - ph.bwoff - ph.len;
@@ -377,12 +377,12 @@ again:
 	case PC_GAH_SUB_LOOP: {
 		MateWS* mw = &ws->m[gv.mw_slot];
 		PartialHit& ph = mw->rb[gv.sel_f].partial[gv.gh_hj];
-		const GraphPNode* pn = C.graph ? &C.gws->pnode[gv.mw_slot][gv.sel_f][gv.gh_hj] : nullptr;
+		const GraphPNode* pn = C.graph ? &C.gsl->pnode[gv.mw_slot][gv.sel_f][gv.gh_hj] : nullptr;
 		Rng rnd; rnd.last = gv.rnd;
 		for(; gv.gh_node < gv.gh_node_end; gv.gh_node++, gv.gh_expected--) {
 			uint32_t bot = gv.gh_top + 1;
 			if(C.graph) {
-				IEdges& t = C.gws->ie;
+				IEdges& t = C.gsl->ie;
 				t.n = 0;
 				if(gv.gh_edgeIdx < pn->ie.n && gv.gh_edgeIdx < H2G_IEDGE_CAP) {
 					if(gv.gh_node - pn->node_top == pn->ie.e[gv.gh_edgeIdx][0]) {
@@ -397,7 +397,7 @@ again:
 				if(gv.gh_nco < AL_MAX_GHITS) {
 					gv.rnd = rnd.last; gv.gh_bot = bot;
 					L.a0 = gv.gh_top; L.a1 = bot; L.a2 = ph.bot - ph.top; L.a3 = ph.len; L.a4 = 0; L.a5 = AL_MAX_GHITS - gv.gh_nco; L.p0 = ph.coords + gv.gh_nco;
-					if(C.graph) { L.a6 = gv.gh_node; L.a7 = gv.gh_node + 1; L.p1 = (void*)&C.gws->ie; }
+					if(C.graph) { L.a6 = gv.gh_node; L.a7 = gv.gh_node + 1; L.p1 = (void*)&C.gsl->ie; }
 					M_OP(OP_GCOORDS, PC_GAH_SUB_AFTER);
 				} else ws->overflow |= 64;
 				gv.gh_added++;
@@ -508,9 +508,11 @@ again:
 		if(hj >= ws->nghits) { gv.hs_found = 1; M_GOTO(PC_AFTER_ALIGN); }
 		for(uint32_t hk = hj + 1; hk < ws->nghits; hk++) {
 			if(ws->ghit_done[hk]) continue;
-			const h2g_ghit& a = ws->ghits[hj];
-			const h2g_ghit& b = ws->ghits[hk];
-			if(b.read > a.read || (b.read == a.read && b.len > a.len)) hj = hk;
+			// (values into locals, then one bool: the reference-to-element form of this test was miscompiled by hipcc 7.2 -O3 for
+			// gfx950 inside this divergent loop — the update of hj was dropped; tests/test_gpu_align.py::test_live_reference[case2])
+			const uint32_t ar = ws->ghits[hj].read, al = ws->ghits[hj].len, br = ws->ghits[hk].read, bl = ws->ghits[hk].len;
+			const bool better = br > ar || (br == ar && bl > al);
+			if(better) hj = hk;
 		}
 		gv.hs_hj = hj;
 		h2g_ghit* gh = &ws->ghits[hj];
@@ -721,7 +723,7 @@ again:
 		AL_TRACE("    L global extoff %u extlen %u nelt %u top %u bot %u unique %d\n", f.extoff, f.extlen, nelt, top, bot, (int)f.uniqueStop);
 		if(nelt > 0 && nelt <= 5 && f.extlen >= minK) {
 			L.a0 = top; L.a1 = bot; L.a2 = bot - top; L.a3 = f.extlen; L.a4 = 1; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
-			if(C.graph) { L.a6 = C.gws->node_top; L.a7 = C.gws->node_bot; L.p1 = (void*)&C.gws->ie; }
+			if(C.graph) { L.a6 = C.gsl->node_top; L.a7 = C.gsl->node_bot; L.p1 = (void*)&C.gsl->ie; }
 			M_OP(OP_GCOORDS, PC_L_GC_AFTER);
 		}
 		M_GOTO(PC_L_FOR_G);
@@ -950,7 +952,7 @@ again:
 		f.extlen = L.a1; f.uniqueStop = (uint8_t)L.a4;
 		if(nelt > 0 && nelt <= 5 && f.extlen >= minK) {
 			L.a0 = top; L.a1 = bot; L.a2 = bot - top; L.a3 = f.extlen; L.a4 = 1; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
-			if(C.graph) { L.a6 = C.gws->node_top; L.a7 = C.gws->node_bot; L.p1 = (void*)&C.gws->ie; }
+			if(C.graph) { L.a6 = C.gsl->node_top; L.a7 = C.gsl->node_bot; L.p1 = (void*)&C.gsl->ie; }
 			M_OP(OP_GCOORDS, PC_R_GC_AFTER);
 		}
 		M_GOTO(PC_R_FOR_G);
@@ -1070,7 +1072,7 @@ H2G_HD void mach_op_psearch(const AlnCtx& C, Mach& M) {
 	const AlnParams& P = *C.P;
 	const SeqView sv = mach_sv(M);
 	if(!C.graph) partial_search_item(*C.g, sv, M.L.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &M.ws->fh);
-	else partial_search_graph_item(*C.g, sv, M.L.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &M.ws->fh, &C.gws->ie);
+	else partial_search_graph_item(*C.g, sv, M.L.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &M.ws->fh, &C.gsl->ie);
 }
 H2G_HD void mach_op_gcoords(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
@@ -1230,9 +1232,18 @@ H2G_HD void mach_exec(const AlnCtx& C, Mach& M, uint32_t op, const MachOut& O, b
 // One read / pair to completion on ONE lane (tests/emul; the kernels interleave 64 of these per wavefront)
 H2G_HD void mach_run_single(const AlnCtx& C, Mach& M, uint32_t read, bool paired_input, const MachOut& O) {
 	mach_begin(M, read, paired_input);
-	while(M.L.pc != PC_FINISHED) {
+	while(M.L.pc != PC_FINISHED || M.L.op != OP_NONE) {
 		mach_step(C, M);
+#if defined(H2G_MACH_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+		extern unsigned long long g_mach_stats[64];
+		g_mach_stats[M.L.op]++;
+#endif
+#if defined(H2G_MACH_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+		if((int)read == H2G_MACH_TRACE) fprintf(stderr, "T %u %u %u %u %u %u %u %u\n", M.L.pc, M.L.op, M.L.a0, M.L.a1, M.L.a2, M.L.a3, M.L.a4, M.L.a5);
+#endif
+		const uint32_t op_ = M.L.op;
 		if(M.L.op != OP_NONE) mach_exec(C, M, M.L.op, O, paired_input);
+		(void)op_;
 	}
 	M.L.pc = PC_IDLE;
 }

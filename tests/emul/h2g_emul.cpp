@@ -5,6 +5,10 @@
 // `-m "not gpu"` runs.  This library lives under tests/, is never shipped with or loaded by hisat2_amd, and
 // is not a fallback: libh2g.so has no host execution path.
 #include <vector>
+#include <stdlib.h>
+#include <string.h>
+// the host instantiation runs with the large-workspace capacities (one workspace, no second pass on the host)
+#include "../../hisat2_amd/csrc/h2g_go_big.h"
 #include "../../hisat2_amd/csrc/h2g_core.h"
 #include "../../hisat2_amd/csrc/h2g_host_index.h"
 #include "../../hisat2_amd/csrc/h2g_align.h"
@@ -213,6 +217,7 @@ void h2gemu_seed_extend(Emu* e, uint32_t pseudogeneStop, uint32_t khits, h2g_see
 }
 
 
+#define EMU_REC_STRIDE 32   // records per read in the output arrays (tests/sam_util.py AL_MAX_RESULTS), whatever the workspace holds
 // HI_Aligner::go + selection for every read of the batch (names: '\0'-free bytes + offsets), one lane of the machine at a time
 static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	h2g_align_params hp;
@@ -222,7 +227,8 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C->sw = e->sw.data();
 	static GraphWS gws_;
-	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->graph = !e->dg.linear;
+	static GraphSlot gsl_;
+	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->gsl = e->dg.linear ? nullptr : &gsl_; C->graph = !e->dg.linear;
 }
 
 void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, AlnRec* recs) {
@@ -235,8 +241,9 @@ void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t
 	for(uint32_t i = 0; i < M.rd[0].n; i++) {
 		M.name[0] = names + name_offs[i]; M.namelen[0] = name_offs[i + 1] - name_offs[i];
 		M.name[1] = nullptr; M.namelen[1] = 0;
+		if(getenv("H2GEMU_POISON")) memset((void*)ws, atoi(getenv("H2GEMU_POISON")), sizeof *ws);   // stale-state hunting: nothing may be read before it is written
 		mach_run_single(C, M, i, false, O);
-		for(uint32_t k = 0; k < ws->m[0].nres; k++) recs[(size_t)i * AL_MAX_RESULTS + k] = ws->m[0].res[k];
+		for(uint32_t k = 0; k < ws->m[0].nres; k++) if(k < EMU_REC_STRIDE) recs[(size_t)i * EMU_REC_STRIDE + k] = ws->m[0].res[k];
 	}
 	delete ws;
 }
@@ -255,9 +262,10 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	for(uint32_t i = 0; i < M.rd[0].n; i++) {
 		M.name[0] = names1 + noffs1[i]; M.namelen[0] = noffs1[i + 1] - noffs1[i];
 		M.name[1] = names2 + noffs2[i]; M.namelen[1] = noffs2[i + 1] - noffs2[i];
+		if(getenv("H2GEMU_POISON")) memset((void*)ws, atoi(getenv("H2GEMU_POISON")), sizeof *ws);
 		mach_run_single(C, M, i, true, O);
-		for(uint32_t k = 0; k < ws->m[0].nres; k++) recs1[(size_t)i * AL_MAX_RESULTS + k] = ws->m[0].res[k];
-		for(uint32_t k = 0; k < ws->m[1].nres; k++) recs2[(size_t)i * AL_MAX_RESULTS + k] = ws->m[1].res[k];
+		for(uint32_t k = 0; k < ws->m[0].nres; k++) if(k < EMU_REC_STRIDE) recs1[(size_t)i * EMU_REC_STRIDE + k] = ws->m[0].res[k];
+		for(uint32_t k = 0; k < ws->m[1].nres; k++) if(k < EMU_REC_STRIDE) recs2[(size_t)i * EMU_REC_STRIDE + k] = ws->m[1].res[k];
 	}
 	delete ws;
 }
