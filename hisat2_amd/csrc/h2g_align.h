@@ -606,18 +606,22 @@ struct PartialHit {          // BWTHit hi_aligner.h:108 (linear: node range == r
 	uint32_t top, bot, bwoff, len, hit_type, ncoords;
 	h2g_coord coords[AL_MAX_GHITS];
 };
-struct RBHit {               // ReadBWTHit hi_aligner.h:216
+struct RBHit {               // ReadBWTHit hi_aligner.h:216 (the BWTHit list itself lives in MateArr: this header stays in the hot part)
 	uint32_t len, cur, done, numPartialSearch, numUniqueSearch, npartial;
-	PartialHit partial[AL_MAX_PARTIAL];
+	PartialHit* partial;     // -> MateArr::partial[strand]
 };
 
 #define AL_MAX_PAIRS 32
-struct MateWS {              // per-mate state of HI_Aligner + the per-mate half of AlnSinkWrap
-	RBHit      rb[2];                            // _hits[rdi][fwi]
+struct MateArr {             // the big lists of one mate (cold part of the workspace)
+	PartialHit partial[2][AL_MAX_PARTIAL];       // _hits[rdi][fwi]
 	h2g_ghit   searched[AL_MAX_SEARCHED];        // _hits_searched[rdi]
-	uint32_t   nsearched;
 	AlnRec     res[AL_MAX_RESULTS];              // AlnSinkWrap rs1u_ / rs2u_
-	uint32_t   nres;
+};
+struct MateWS {              // per-mate state of HI_Aligner + the per-mate half of AlnSinkWrap: scalars + pointers into MateArr
+	RBHit      rb[2];
+	h2g_ghit*  searched;
+	AlnRec*    res;
+	uint32_t   nsearched, nres;
 	int64_t    bestUnp, best2Unp;                // bestUnp1_/bestUnp2_, best2Unp*_
 	int64_t    minsc;
 	// initRead(rds[1], ..., rightendonly) (hi_aligner.h:3993, hisat2.cpp:3524): the lone mate 2 is searched as rdi 0 but
@@ -649,24 +653,27 @@ struct GoVars {
 	int64_t  ret, rc_minsc, rc_cushion;
 };
 
+// Per-read workspace.  Every primitive of a read touches a handful of its scalars: those come first, packed into a few cache
+// lines (a scattered 4-byte access costs a whole HBM line), the big lists behind them.
 struct AlignWS {
+	GoVars     gv;
+	h2g_fm_hit fh;                               // result of the last partial search
 	MateWS     m[2];
-	h2g_ghit   ghits[AL_MAX_GHITS];              // _genomeHits (hitcount lives in .read)
 	uint32_t   nghits;
 	uint8_t    ghit_done[AL_MAX_GHITS];
 	// concordant pairs (AlnSinkWrap rs1_/rs2_ as indexes into m[0].res / m[1].res)
-	uint8_t    pair_i[AL_MAX_PAIRS], pair_j[AL_MAX_PAIRS];
 	uint32_t   npairs, insp_i, insp_j;           // _concordantIdxInspected
 	int64_t    bestPair, best2Pair;
 	uint64_t   localindexatts, max_localindexatts;
 	uint32_t   overflow;
 	uint32_t   nrank, nside, nsteps, nframes_max;   // nrank, nside adjacent: gfm_search updates both through &nrank
+	uint8_t    pair_i[AL_MAX_PAIRS], pair_j[AL_MAX_PAIRS];
+	// ---- lists
 	h2g_ghit   tmp, tmp2;                        // scratch hits
-	int64_t    sc1[512], sc2[512];               // combineWith temp_scores
-	GoVars     gv;
-	h2g_fm_hit fh;                               // result of the last partial search
+	h2g_ghit   ghits[AL_MAX_GHITS];              // _genomeHits (hitcount lives in .read)
 	h2g_coord  am_co[AL_MAX_GHITS];              // alignMate's coordinate list
 	Frame      stack[AL_MAX_DEPTH];
+	MateArr    marr[2];
 };
 
 // Edit::invertPoss edit.cpp:70-111 applied to the k-th element of the inverted list
@@ -731,12 +738,14 @@ H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdl
 // ---------------------------------------------------------------------------------------- getAnchorHits (a16)
 H2G_HD bool ph_empty(const PartialHit& p) { return p.bot <= p.top; }
 
+#define H2G_COMBINE_MAXLEN 512   // reads up to 512 bp scan exactly in combineWith; longer ones are flagged
 struct AlnCtx {
 	const DGfm* g;
 	const DRef* ref;
 	const DLocalSet* ls;
 	const AlnParams* P;
 	uint8_t* sw = nullptr;   // this lane's Smith-Waterman scratch (sw_scratch_bytes), only when P->bowtie2_dp != 0
+	int64_t* sc = nullptr;   // this lane's combineWith temp_scores: 2 x H2G_COMBINE_MAXLEN (scratch of one primitive)
 	const DAlts* alts = nullptr;      // graph index: the ALT database
 	struct GraphWS* gws = nullptr;    // graph index: this lane's scratch for one primitive (group walk, ALT extension)
 	struct GraphSlot* gsl = nullptr;  // graph index: the graph state of the read being worked on

@@ -20,6 +20,7 @@ struct GoArgs {
 	size_t slot_off, gsl_off;
 	uint8_t* gws_base; size_t gws_stride; // GraphWS per lane (graph indexes): scratch of one primitive
 	uint8_t* sw_base; size_t sw_stride;   // Smith-Waterman scratch per lane (bowtie2_dp != 0)
+	uint8_t* sc_base;                     // combineWith temp_scores per lane: 2 x H2G_COMBINE_MAXLEN int64
 	h2g::MachOut O;
 	unsigned long long* counters;
 	uint32_t* work;                       // next unclaimed position of the read list (device counter, zeroed before the launch)

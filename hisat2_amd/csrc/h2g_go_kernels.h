@@ -34,6 +34,7 @@ using namespace h2g;
 struct GoSlot {
 	Lane     L;
 	uint32_t read;
+	uint32_t ro[2], rl[2];           // offset / length of the read in each read set
 	uint32_t pk_ok[2];
 	uint32_t pk[2][H2G_PK_LANE_WORDS];
 };
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	__syncthreads();
 	AlnCtx C; C.g = &A.g; C.ref = &A.ref; C.ls = &A.ls; C.P = &A.P;
 	C.sw = A.sw_base ? A.sw_base + tid * A.sw_stride : nullptr;
+	C.sc = (int64_t*)(A.sc_base + tid * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t)));
 	C.alts = &A.alts; C.gws = A.gws_base ? (GraphWS*)(A.gws_base + tid * A.gws_stride) : nullptr; C.graph = GRAPH;
 	const size_t slot0 = (size_t)blockIdx.x * H2G_GO_SLOTS;
 	Mach M;
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	M.rd[1].pk = my_pk1; M.rd[1].pk_stride = H2G_GO_THREADS;
 	M.name[0] = M.name[1] = nullptr; M.namelen[0] = M.namelen[1] = 0; M.read = 0;
 	M.ws = nullptr;
+	M.out = &A.O; M.paired_input = paired;
 	const uint32_t total = A.list ? *A.nlist : A.rd1.n;
 	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0, nside = 0;
 	bool more = true;                                         // reads left in the batch (wave-local view)
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 					M.name[1] = A.names2 + A.noffs2[i]; M.namelen[1] = A.noffs2[i + 1] - A.noffs2[i];
 				}
 				mach_begin(M, i, paired);
+				gs->ro[0] = M.ro[0]; gs->ro[1] = M.ro[1]; gs->rl[0] = M.rl[0]; gs->rl[1] = M.rl[1];
 			}
 			PROF(0);
 		} else {
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 				C.gsl = GRAPH ? (GraphSlot*)((uint8_t*)M.ws + A.gsl_off) : nullptr;
 				M.L = gs->L;
 				M.read = gs->read;
+				M.ro[0] = gs->ro[0]; M.ro[1] = gs->ro[1]; M.rl[0] = gs->rl[0]; M.rl[1] = gs->rl[1];
 				for(uint32_t w = 0; w < H2G_PK_LANE_WORDS; w++) my_pk0[w * H2G_GO_THREADS] = gs->pk[0][w];
 				M.rd[0].pk_read = gs->pk_ok[0] ? M.read : 0xffffffffu;
 				if(paired) {
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 			prof[20 + op] += n; prof[32 + op]++; prof[47]++;
 #endif
 			PROF(0);
-			if(have) mach_exec(C, M, op, A.O, paired);          // ONE primitive, one code site, every lane that carries a slot
+			if(have) mach_exec(C, M, op);          // ONE primitive, one code site, every lane that carries a slot
 			PROF(3 + op);
 		}
 		// ---- control flow of each read up to its next primitive request; then hand the slots on

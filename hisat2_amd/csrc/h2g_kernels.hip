@@ -61,6 +61,7 @@ struct h2g_stream {
 		uint8_t* ws = nullptr;  size_t ws_bytes = 0;      // AlignWS x lanes of the unit last run
 		uint8_t* gws = nullptr; size_t gws_bytes = 0;     // GraphWS x lanes (graph indexes only)
 		uint8_t* sw = nullptr;  size_t sw_stride = 0, sw_lanes = 0;   // Smith-Waterman scratch (only with bowtie2_dp != 0)
+		uint8_t* sc = nullptr;  size_t sc_lanes = 0;                  // combineWith temp_scores per lane
 	} pool[2];
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
 	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
@@ -314,7 +315,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); }
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
 	(void)hipFree(s->d_ovf_list); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
@@ -1225,6 +1226,12 @@ static int go_pool_for(h2g_stream* s, int which, const GoUnit& u, size_t slots, 
 		}
 		a->gws_base = pl.gws;
 	}
+	if(pl.sc_lanes < lanes) {
+		(void)hipFree(pl.sc); pl.sc = nullptr; pl.sc_lanes = 0;
+		HIPCHK(hipMalloc((void**)&pl.sc, lanes * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t))));
+		pl.sc_lanes = lanes;
+	}
+	a->sc_base = pl.sc;
 	a->sw_base = nullptr; a->sw_stride = 0;
 	if(bowtie2_dp) {
 		const size_t stride = (sw_scratch_bytes(s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len) + 255) & ~(size_t)255;

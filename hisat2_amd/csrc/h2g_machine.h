@@ -45,6 +45,16 @@ enum : uint32_t {
 	PC_R_EXT, PC_R_EXT_A, PC_R_R5
 };
 
+// What a finished read leaves behind (the selection half of AlnSinkWrap::finishRead for unpaired reads; the report events of
+// both mates + the PRNG state for pairs, whose finishRead runs in h2g_sam_format_paired)
+struct MachOut {
+	ReadOut*    rout;      // unpaired: [n]
+	h2g_alnres* aln;       // unpaired: [n * aln_slots]
+	uint32_t    aln_slots; // records kept per read (>= -k)
+	PairOut*    pout;      // paired: [n]
+	h2g_alnres* paln[2];   // paired: [n * H2G_PAIR_RES_CAP] each
+};
+
 struct Lane {                 // the registers of one lane's machine
 	uint32_t pc, op;
 	uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
@@ -58,11 +68,28 @@ struct Mach {                 // per-lane context (kernel locals; nothing of thi
 	const char* name[2];
 	uint32_t  namelen[2];
 	uint32_t  read;
+	uint32_t  ro[2], rl[2];    // offset / length of the current read in each read set (cached: seq_view would load them every time)
+	const MachOut* out;        // where a finished read leaves its result
+	bool      paired_input;
 };
 
+H2G_HD SeqView mach_view(const Mach& M, uint32_t set, bool fw) {   // seq_view() from the cached offset / length
+	const DReads& r = M.rd[set];
+	SeqView s;
+	s.fwc = r.codes + M.ro[set];
+	s.q = r.quals ? r.quals + M.ro[set] : nullptr;
+	s.len = M.rl[set];
+	s.fw = fw;
+	if(r.pk && r.pk_read == M.read) { s.pk = r.pk; s.pk_stride = r.pk_stride; }
+	return s;
+}
 H2G_HD SeqView mach_sv(const Mach& M) {
 	const GoVars& gv = M.ws->gv;
-	return seq_view(M.rd[gv.rd_sel[gv.sv_rdi]], M.read, gv.sv_fw != 0);
+	return mach_view(M, gv.rd_sel[gv.sv_rdi], gv.sv_fw != 0);
+}
+H2G_HD void mach_cache_read(Mach& M, uint32_t read, bool paired_input) {
+	for(int k = 0; k < (paired_input ? 2 : 1); k++) { M.ro[k] = M.rd[k].offs[read]; M.rl[k] = M.rd[k].offs[read + 1] - M.ro[k]; }
+	if(!paired_input) { M.ro[1] = M.ro[0]; M.rl[1] = M.rl[0]; }
 }
 
 // The prelude of the worker loop body for one read / pair (hisat2.cpp:3380-3530): filters, PRNG seed, which mates go() sees.
@@ -73,7 +100,8 @@ H2G_HD void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 	M.L.op = OP_NONE;
 	gv.read = read;
 	ws->m[0].nres = 0; ws->m[1].nres = 0; ws->npairs = 0; ws->overflow = 0; ws->nrank = 0; ws->nsteps = 0; ws->nframes_max = 0; ws->nside = 0;
-	SeqView v1 = seq_view(M.rd[0], read, true);
+	mach_cache_read(M, read, paired_input);
+	SeqView v1 = mach_view(M, 0, true);
 	Rng rnd;
 	if(!paired_input) {
 		rnd.init(gen_rand_seed(v1, M.name[0], M.namelen[0], 0));       // rnd.init(ps->bufa().seed) hisat2.cpp:3468
@@ -82,7 +110,7 @@ H2G_HD void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 		M.L.pc = read_passes_filters(v1) ? PC_GO_INIT : PC_FINISH;      // filt[0] false: go() is skipped (hisat2.cpp:3518)
 		return;
 	}
-	SeqView v2 = seq_view(M.rd[1], read, true);
+	SeqView v2 = mach_view(M, 1, true);
 	const bool f1 = read_passes_filters(v1), f2 = read_passes_filters(v2);
 	const uint32_t s1 = gen_rand_seed(v1, M.name[0], M.namelen[0], 0), s2 = gen_rand_seed(v2, M.name[1], M.namelen[1], 0);
 	rnd.init((f1 && f2) ? (s1 ^ s2) : s1);                              // hisat2.cpp:3463-3468
@@ -113,6 +141,8 @@ H2G_HD void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 		M_GOTO(PC_RC_ENTRY); } while(0)
 #define MINSC_LIVE(MV) do { if(!P.secondary) { int64_t b_ = mw->bestUnp - gv.rc_cushion; if(b_ > (MV)) (MV) = b_; } } while(0)
 
+H2G_HD void mach_finish(const AlnCtx& C, Mach& M);
+
 // Runs the control flow of this lane until it needs a primitive (L.op != OP_NONE) or the read is finished (PC_FINISHED).
 H2G_HD void mach_step(const AlnCtx& C, Mach& M)
 {
@@ -132,11 +162,16 @@ again:
 		ws->localindexatts = 0; ws->max_localindexatts = 0;
 		gv.rdlens[0] = gv.rdlens[1] = 0;
 		for(uint32_t r = 0; r < 2; r++) {
+			MateWS& pm = ws->m[r];
+			pm.searched = ws->marr[r].searched; pm.res = ws->marr[r].res;
+			pm.rb[0].partial = ws->marr[r].partial[0]; pm.rb[1].partial = ws->marr[r].partial[1];
+		}
+		for(uint32_t r = 0; r < 2; r++) {
 			MateWS& mw = ws->m[r ^ gv.slot0];
 			mw.nsearched = 0; mw.nres = 0; mw.bestUnp = INT64_MIN; mw.best2Unp = INT64_MIN; mw.minsc = INT64_MAX;
 			mw.sink_hidden = (gv.slot0 != 0 && gv.nm == 1) ? 1u : 0u;
 			if(r < gv.nm) {
-				SeqView v = seq_view(M.rd[gv.rd_sel[r]], M.read, true);
+				SeqView v = mach_view(M, gv.rd_sel[r], true);
 				gv.rdlens[r] = v.len;
 				mw.minsc = min_score_for(P, v.len);   // scoreMin.f<TAlScore>(len) (hisat2.cpp:440, simple_func.h:88)
 				for(int k = 0; k < 2; k++) {
@@ -1052,7 +1087,11 @@ again:
 	}
 	case PC_R_R5: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; RC_RET(f.maxsc); }
 	// ========================================================================
-	case PC_FINISH: M_OP(OP_FINISH, PC_FINISHED);
+	case PC_FINISH: {                                    // selectByScore + the result records, inline (no primitive worth a trip)
+		mach_finish(C, M);
+		L.pc = PC_FINISHED; L.op = OP_NONE;
+		return;
+	}
 	case PC_FINISHED:
 	default: return;
 	}
@@ -1112,7 +1151,7 @@ H2G_HD void mach_op_combine(const AlnCtx& C, Mach& M) {
 	const AlnParams& P = *C.P;
 	AlignWS* ws = M.ws;
 	L.a0 = hit_combine(*C.ref, P.sc, mach_sv(M), (h2g_ghit*)L.p0, (const h2g_ghit*)L.p1, ws->gv.rc_minsc, P.minIntronLen, P.no_spliced != 0,
-	                   ws->sc1, ws->sc2, C.alts) ? 1u : 0u;
+	                   C.sc, C.sc + H2G_COMBINE_MAXLEN, C.alts) ? 1u : 0u;
 }
 H2G_HD void mach_op_adjust(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
@@ -1155,23 +1194,15 @@ H2G_HD void mach_op_sw(const AlnCtx& C, Mach& M) {
 	}
 }
 
-// What a finished read leaves behind (the selection half of AlnSinkWrap::finishRead for unpaired reads; the report events of
-// both mates + the PRNG state for pairs, whose finishRead runs in h2g_sam_format_paired)
-struct MachOut {
-	ReadOut*    rout;      // unpaired: [n]
-	h2g_alnres* aln;       // unpaired: [n * aln_slots]
-	uint32_t    aln_slots; // records kept per read (>= -k)
-	PairOut*    pout;      // paired: [n]
-	h2g_alnres* paln[2];   // paired: [n * H2G_PAIR_RES_CAP] each
-};
-
 H2G_HD void mach_copy_rec(h2g_alnres& d, const AlnRec& r) {
 	d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
 	d.nedits = r.nedits; d.pad = 0; d.score = r.score;
 	for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
 }
 
-H2G_HD void mach_op_finish(const AlnCtx& C, Mach& M, const MachOut& O, bool paired_input) {
+H2G_HD void mach_finish(const AlnCtx& C, Mach& M) {
+	const MachOut& O = *M.out;
+	const bool paired_input = M.paired_input;
 	AlignWS* ws = M.ws;
 	GoVars& gv = ws->gv;
 	const uint32_t i = M.read;
@@ -1211,7 +1242,7 @@ H2G_HD void mach_op_finish(const AlnCtx& C, Mach& M, const MachOut& O, bool pair
 }
 
 // one op for this lane; `op` is wave-uniform in the kernel
-H2G_HD void mach_exec(const AlnCtx& C, Mach& M, uint32_t op, const MachOut& O, bool paired_input) {
+H2G_HD void mach_exec(const AlnCtx& C, Mach& M, uint32_t op) {
 	switch(op) {
 	case OP_PSEARCH:   mach_op_psearch(C, M); break;
 	case OP_GCOORDS:   mach_op_gcoords(C, M); break;
@@ -1223,7 +1254,6 @@ H2G_HD void mach_exec(const AlnCtx& C, Mach& M, uint32_t op, const MachOut& O, b
 	case OP_ADJUST:    mach_op_adjust(C, M); break;
 	case OP_ADJMEMBER: mach_op_adjmember(C, M); break;
 	case OP_SW:        mach_op_sw(C, M); break;
-	case OP_FINISH:    mach_op_finish(C, M, O, paired_input); break;
 	default: break;
 	}
 	M.L.op = OP_NONE;
@@ -1231,6 +1261,7 @@ H2G_HD void mach_exec(const AlnCtx& C, Mach& M, uint32_t op, const MachOut& O, b
 
 // One read / pair to completion on ONE lane (tests/emul; the kernels interleave 64 of these per wavefront)
 H2G_HD void mach_run_single(const AlnCtx& C, Mach& M, uint32_t read, bool paired_input, const MachOut& O) {
+	M.out = &O; M.paired_input = paired_input;
 	mach_begin(M, read, paired_input);
 	while(M.L.pc != PC_FINISHED || M.L.op != OP_NONE) {
 		mach_step(C, M);
@@ -1242,7 +1273,7 @@ H2G_HD void mach_run_single(const AlnCtx& C, Mach& M, uint32_t read, bool paired
 		if((int)read == H2G_MACH_TRACE) fprintf(stderr, "T %u %u %u %u %u %u %u %u\n", M.L.pc, M.L.op, M.L.a0, M.L.a1, M.L.a2, M.L.a3, M.L.a4, M.L.a5);
 #endif
 		const uint32_t op_ = M.L.op;
-		if(M.L.op != OP_NONE) mach_exec(C, M, M.L.op, O, paired_input);
+		if(M.L.op != OP_NONE) mach_exec(C, M, M.L.op);
 		(void)op_;
 	}
 	M.L.pc = PC_IDLE;

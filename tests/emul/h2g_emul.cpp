@@ -228,6 +228,8 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	C->sw = e->sw.data();
 	static GraphWS gws_;
 	static GraphSlot gsl_;
+	static int64_t sc_[2 * H2G_COMBINE_MAXLEN];
+	C->sc = sc_;
 	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->gsl = e->dg.linear ? nullptr : &gsl_; C->graph = !e->dg.linear;
 }
 

@@ -43,7 +43,7 @@ if hasattr(L, "h2g_go_prof"):
     if L.h2g_go_prof(st.h, v) == 0 and v[47]:
         names = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS GSEARCH COMBINE ADJUST ADJMEMBER SW FINISH".split()
         tot = sum(v[k] for k in range(0, 16))
-        print("iterations %d  total wave-ticks %d" % (v[47], tot))
+        print("trips %d  avg slots per trip %.1f  total wave-ticks %d" % (v[47], v[46] / max(1, v[47]), tot))
         for k, nm in ((0, "refill"), (1, "control"), (2, "vote")):
             print("  %-10s %5.1f %%" % (nm, 100.0 * v[k] / tot))
         for op in range(1, 12):
