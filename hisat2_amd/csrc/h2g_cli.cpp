@@ -211,7 +211,7 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 }  // namespace
 
 int main(int argc, char** argv) {
-	std::string base, outfn;
+	std::string base, outfn, stats_fn;
 	std::vector<std::string> u, m1, m2;
 	bool fasta = false, nospliced = false, nohead = false, parse_only = false, no_unal = false;
 	uint64_t skip = 0, upto = ~0ull;
@@ -252,6 +252,7 @@ int main(int argc, char** argv) {
 		else if(a == "-3" || a == "--trim3") trim3 = (uint32_t)atoi(need("-3"));
 		else if(a == "--no-unal") no_unal = true;
 		else if(a == "--reorder" || a == "-t" || a == "--time" || a == "--quiet") {}    // output is always in read order
+		else if(a == "--h2g-stats") stats_fn = need("--h2g-stats");               // writes {reads, second_pass, overflow} as JSON (tests, bench)
 		else if(a == "--parse-only") parse_only = true;                           // test hook: ingest the reads, print counts + checksums
 		else { fprintf(stderr, "hisat2-align-amd: option %s is not built (see DESIGN.md, scope)\n", a.c_str()); return 1; }
 	}
@@ -340,7 +341,7 @@ int main(int argc, char** argv) {
 	uint64_t budget = upto;                               // -u counts the reads after the skipped ones (qUpto += skipReads, hisat2.cpp:1959-1963)
 	h2g_stream* st = nullptr;
 	Batch A[2], B[2];                                 // double buffer: batch k+1 is parsed while batch k is on the GPU
-	uint64_t nreads = 0, naligned = 0, novf = 0;
+	uint64_t nreads = 0, naligned = 0, novf = 0, nsecond = 0;
 	double t_gpu = 0, t_fmt = 0, t_parse = 0, t_up = 0, t_fetch = 0, t_stream = 0;
 	size_t stream_reads = 0, stream_bases = 0;
 	int cur = 0;
@@ -410,7 +411,7 @@ int main(int argc, char** argv) {
 				                           pres.data(), aln.data(), ao1.data(), aln2.data(), ao2.data(), P.khits, buf.data(), buf.size(), &used);
 				if(rc != H2G_OK) die("h2g_sam_format_paired");
 			}
-			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; if(pres[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names.push_back('\n'); } } }
+			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; if(pres[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names += " (bits " + std::to_string(pres[i].overflow) + ")\n"; } } }
 			t_fmt += now() - tf;
 		} else {
 			tq0 = now();
@@ -432,10 +433,11 @@ int main(int argc, char** argv) {
 				                             res.data(), aln.data(), ao1.data(), buf.data(), buf.size(), &used);
 				if(rc != H2G_OK) die("h2g_sam_format_unpaired");
 			}
-			for(size_t i = 0; i < n; i++) { naligned += res[i].nselect > 0; if(res[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names.push_back('\n'); } } }
+			for(size_t i = 0; i < n; i++) { naligned += res[i].nselect > 0; if(res[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names += " (bits " + std::to_string(res[i].overflow) + ")\n"; } } }
 			t_fmt += now() - tf;
 		}
 		fwrite(buf.data(), 1, used, out);
+		{ h2g_counters hc; if(h2g_get_counters(st, &hc) == H2G_OK) nsecond += hc.n_second_pass; }
 		nreads += n;
 		n = n2;
 		cur = nxt;
@@ -455,6 +457,10 @@ int main(int argc, char** argv) {
 	                 "against hisat2 -- rerun these with the reference aligner:\n%s", (unsigned long long)novf, paired ? "pairs" : "reads", ovf_names.c_str());
 	if(getenv("H2G_CLI_TIMING")) fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (includes overlapped parsing %.2f s), SAM formatting %.2f s, total %.2f s [stream create %.2f, upload+launch %.2f, wait+fetch %.2f]\n", t1 - t0, t_gpu,
 	        t_parse, t_fmt, t2 - t0, t_stream, t_up, t_fetch);
+	if(!stats_fn.empty()) {
+		FILE* sf = fopen(stats_fn.c_str(), "w");
+		if(sf) { fprintf(sf, "{\"reads\": %llu, \"second_pass\": %llu, \"overflow\": %llu}\n", (unsigned long long)nreads, (unsigned long long)nsecond, (unsigned long long)novf); fclose(sf); }
+	}
 	if(st) h2g_stream_free(st);
 	h2g_sam_close(sam);
 	h2g_index_free(ix);

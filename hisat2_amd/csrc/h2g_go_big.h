@@ -9,3 +9,10 @@
 #define AL_MAX_LOCALHITS 8
 #define AL_MAX_COORDS    24
 #define AL_MAX_PARTIAL   64
+// graph walk / ALT extension scratch (h2g_graph.h)
+#define H2G_GW_MAXELT    96
+#define H2G_GW_MAXST     160
+#define H2G_GW_MAXROWS   64      // fixed: the row masks of the group walk are 64-bit words
+#define H2G_AWA_DEPTH    24
+#define H2G_AWA_CAND     8
+#define H2G_OFFDIFF_CAP  64

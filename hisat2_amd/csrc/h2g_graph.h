@@ -364,9 +364,11 @@ H2G_HDN void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32
 // merged when several rows lead into one node — merged-away duplicates get their own element index as the "offset"
 // (group_walk.h:1171, :1246), reproduced because that value reaches joinedToTextOff.  tryOffset (gfm.h:2719) samples by
 // node: (node & offMask) == node -> offs[node >> offRate].  Fixed capacities; exceeding one sets GwCtx::overflow.
+#ifndef H2G_GW_MAXELT             // the *_big units raise these (h2g_go_big.h)
 #define H2G_GW_MAXELT 24          // >= kseeds (20 on graph indexes)
 #define H2G_GW_MAXST 40
 #define H2G_GW_MAXROWS 64         // rows of one sub-range handed to mapLFRange
+#endif
 struct GwPair { uint32_t first, second; };
 struct GwState {
 	uint32_t top, bot, node_top, node_bot, step, mapi, nmap, nie;
@@ -818,13 +820,17 @@ H2G_HDN void replace_edits_with_alts(const DAlts& A, h2g_ghit* h) {
 // explicit stack.  Splice-site / exon ALTs are skipped (a --snp-only index has none) and haplotypes are unused
 // (use_haplotype = false, hisat2.cpp:522).  The reference window needs no buffers: rfseq[i] is always the base of text
 // `tidx` at rfoff + i (4 outside the text), which RefCursor serves directly.
+#ifndef H2G_AWA_DEPTH
 #define H2G_AWA_DEPTH 12
+#endif
 struct AwaFrame {
 	uint32_t joinedOff, rdoff_add, rdoff, rdlen, rflen, tmp_numNs, orig_nedits, next_rdlen, rd_i, max_rd_i, dep;
 	int32_t  rfoff, a_first, a_second, min_rd_i;
 	uint32_t state;   // 0 entry, 1 loop, 2 after call
 };
+#ifndef H2G_AWA_CAND
 #define H2G_AWA_CAND 4
+#endif
 struct AwaWS {
 	h2g_edit tmp[H2G_MAX_EDITS];
 	uint32_t ntmp;
@@ -1212,7 +1218,9 @@ H2G_HDN bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& s
 // findOffDiffs (hi_aligner.h:2545-2640): offset differences that indel ALTs inside [start, end) can introduce.
 // od[k] = {|off|, sign}; returns the number of single-ALT entries (the combinations follow them).
 struct OffDiff { uint32_t first; int32_t second; };
+#ifndef H2G_OFFDIFF_CAP
 #define H2G_OFFDIFF_CAP 32
+#endif
 H2G_HD bool alt_is_gap_fw(const DAlt& a) { return (a.type == H2G_ALT_SNP_DEL && !(a.seq & 0xff)) || a.type == H2G_ALT_SNP_INS; }
 H2G_HDN uint32_t find_off_diffs(const DAlts& A, uint32_t start, uint32_t end, OffDiff* od, uint32_t* nod, uint32_t* overflow) {
 	uint32_t n = 0;

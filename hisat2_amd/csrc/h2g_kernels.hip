@@ -66,6 +66,8 @@ struct h2g_stream {
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
 	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
+	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
+	size_t paln_alloc = 0;
 	size_t aln_alloc = 0;             // records allocated behind d_aln
 	uint8_t* d_sw_ws = nullptr;   // h2g_sw_align: H/E/F workspace of one batch of problems
 	size_t sw_ws_bytes = 0;
@@ -1320,11 +1322,18 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		s->aln_slots = slots;
 		A.O.rout = s->d_rout; A.O.aln = s->d_aln; A.O.aln_slots = slots;
 	} else {
-		if(!s->d_pout) {
-			HIPCHK(hipMalloc((void**)&s->d_pout, s->max_reads * sizeof(PairOut)));
-			for(int m = 0; m < 2; m++) HIPCHK(hipMalloc((void**)&s->d_paln[m], s->max_reads * (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres)));
+		if(!s->d_pout) HIPCHK(hipMalloc((void**)&s->d_pout, s->max_reads * sizeof(PairOut)));
+		// a mate can report more alignments than -k before the pair is settled: 2 k + 4 slots, at least H2G_PAIR_RES_CAP
+		uint32_t pslots = p->khits * 2 + 4;
+		if(pslots < H2G_PAIR_RES_CAP) pslots = H2G_PAIR_RES_CAP;
+		if(s->paln_alloc < s->max_reads * (size_t)pslots) {
+			for(int m = 0; m < 2; m++) { (void)hipFree(s->d_paln[m]); s->d_paln[m] = nullptr; }
+			s->paln_alloc = 0;
+			for(int m = 0; m < 2; m++) HIPCHK(hipMalloc((void**)&s->d_paln[m], s->max_reads * (size_t)pslots * sizeof(h2g_alnres)));
+			s->paln_alloc = s->max_reads * (size_t)pslots;
 		}
-		A.O.pout = s->d_pout; A.O.paln[0] = s->d_paln[0]; A.O.paln[1] = s->d_paln[1];
+		s->pair_slots = pslots;
+		A.O.pout = s->d_pout; A.O.paln[0] = s->d_paln[0]; A.O.paln[1] = s->d_paln[1]; A.O.pair_slots = pslots;
 	}
 	if(!s->d_ovf_list) HIPCHK(hipMalloc((void**)&s->d_ovf_list, (s->max_reads + 4) * 4));
 	(void)hipGetLastError();
@@ -1394,8 +1403,12 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) {
 	if(!s || !res || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
-	if(aln1) HIPCHK(hipMemcpyAsync(aln1, s->d_paln[0] + first * H2G_PAIR_RES_CAP, n * H2G_PAIR_RES_CAP * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
-	if(aln2) HIPCHK(hipMemcpyAsync(aln2, s->d_paln[1] + first * H2G_PAIR_RES_CAP, n * H2G_PAIR_RES_CAP * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
+	// device rows hold pair_slots records, the caller's rows H2G_PAIR_RES_CAP (the dense variant returns all of them)
+	for(int m = 0; m < 2 && n; m++) {
+		h2g_alnres* dst = m == 0 ? aln1 : aln2;
+		if(dst) HIPCHK(hipMemcpy2DAsync(dst, (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres), s->d_paln[m] + first * s->pair_slots, (size_t)s->pair_slots * sizeof(h2g_alnres),
+		                                (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres), n, hipMemcpyDeviceToHost, s->st));
+	}
 	HIPCHK(hipStreamSynchronize(s->st));
 	return H2G_OK;
 }
@@ -1461,13 +1474,13 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 	if(rc != H2G_OK) return rc;
 	static_assert(offsetof(PairOut, nres) == 0, "PairOut layout");
 	// both totals are known before either capacity is judged, so a caller that has to grow its buffers learns both needs at once
-	const uint64_t t1 = dense_offsets(&res[0].nres[0], sizeof(h2g_pair_result) / 4, H2G_PAIR_RES_CAP, n, offs1);
-	const uint64_t t2 = dense_offsets(&res[0].nres[1], sizeof(h2g_pair_result) / 4, H2G_PAIR_RES_CAP, n, offs2);
+	const uint64_t t1 = dense_offsets(&res[0].nres[0], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs1);
+	const uint64_t t2 = dense_offsets(&res[0].nres[1], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs2);
 	if(t1 > cap1 || t2 > cap2) return H2G_ERR_ARG;
 	int r;
-	if((r = gather_dense(s, s->d_paln[0] + first * H2G_PAIR_RES_CAP, H2G_PAIR_RES_CAP, reinterpret_cast<const uint32_t*>(s->d_pout + first), sizeof(PairOut) / 4,
+	if((r = gather_dense(s, s->d_paln[0] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first), sizeof(PairOut) / 4,
 	                     n, aln1, offs1, 0))) return r;
-	return gather_dense(s, s->d_paln[1] + first * H2G_PAIR_RES_CAP, H2G_PAIR_RES_CAP, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
+	return gather_dense(s, s->d_paln[1] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
 	                    n, aln2, offs2, 2);
 }
 

@@ -52,7 +52,8 @@ struct MachOut {
 	h2g_alnres* aln;       // unpaired: [n * aln_slots]
 	uint32_t    aln_slots; // records kept per read (>= -k)
 	PairOut*    pout;      // paired: [n]
-	h2g_alnres* paln[2];   // paired: [n * H2G_PAIR_RES_CAP] each
+	h2g_alnres* paln[2];   // paired: [n * pair_slots] each
+	uint32_t    pair_slots;
 };
 
 struct Lane {                 // the registers of one lane's machine
@@ -1227,15 +1228,15 @@ H2G_HD void mach_finish(const AlnCtx& C, Mach& M) {
 	} else {
 		PairOut o;
 		o.nres[0] = ws->m[0].nres; o.nres[1] = ws->m[1].nres; o.npairs = ws->npairs; o.overflow = ws->overflow;
-		// the records beyond H2G_PAIR_RES_CAP are not returned: the pair is flagged so that no caller indexes past them
-		if(o.nres[0] > H2G_PAIR_RES_CAP || o.nres[1] > H2G_PAIR_RES_CAP) o.overflow |= 4;
+		// the records beyond pair_slots are not returned: the pair is flagged so that no caller indexes past them
+		if(o.nres[0] > O.pair_slots || o.nres[1] > O.pair_slots) o.overflow |= 4;
 		o.nrank = ws->nrank; o.nsteps = ws->nsteps; o.depth = ws->nframes_max; o.nside = ws->nside; o.rnd_state = gv.rnd; o.pad = 0;
 		for(uint32_t k = 0; k < AL_MAX_PAIRS; k++) { o.pair_i[k] = k < ws->npairs ? ws->pair_i[k] : 0; o.pair_j[k] = k < ws->npairs ? ws->pair_j[k] : 0; }
 		if(O.pout) O.pout[i] = o;
 		for(int m = 0; m < 2; m++) {
 			if(!O.paln[m]) continue;
-			const uint32_t n = o.nres[m] < H2G_PAIR_RES_CAP ? o.nres[m] : H2G_PAIR_RES_CAP;
-			for(uint32_t k = 0; k < n; k++) mach_copy_rec(O.paln[m][(size_t)i * H2G_PAIR_RES_CAP + k], ws->m[m].res[k]);
+			const uint32_t n = o.nres[m] < O.pair_slots ? o.nres[m] : O.pair_slots;
+			for(uint32_t k = 0; k < n; k++) mach_copy_rec(O.paln[m][(size_t)i * O.pair_slots + k], ws->m[m].res[k]);
 		}
 		M.L.a0 = o.npairs > 0; M.L.a1 = o.overflow != 0;
 	}

@@ -569,7 +569,9 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 		            {nb2 + noffs2[i], noffs2[i + 1] - noffs2[i], codes2 + offs2[i], offs2[i + 1] - offs2[i], quals2 ? quals2 + offs2[i] : nullptr}};
 		const h2g_alnres* r1 = ao1 ? aln1 + ao1[i] : aln1 + i * H2G_PAIR_RES_CAP;
 		const h2g_alnres* r2 = ao2 ? aln2 + ao2[i] : aln2 + i * H2G_PAIR_RES_CAP;
-		const size_t n1 = std::min<size_t>(pr.nres[0], H2G_PAIR_RES_CAP), n2 = std::min<size_t>(pr.nres[1], H2G_PAIR_RES_CAP);
+		// records available: the dense layout carries every record the device kept, the slot layout H2G_PAIR_RES_CAP per mate
+		const size_t n1 = ao1 ? (size_t)(ao1[i + 1] - ao1[i]) : std::min<size_t>(pr.nres[0], H2G_PAIR_RES_CAP);
+		const size_t n2 = ao2 ? (size_t)(ao2[i + 1] - ao2[i]) : std::min<size_t>(pr.nres[1], H2G_PAIR_RES_CAP);
 		Flags f1, f2;
 		read_filters(rd[0], &f1.lenfilt, &f1.nfilt);
 		read_filters(rd[1], &f2.lenfilt, &f2.nfilt);

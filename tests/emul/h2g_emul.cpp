@@ -239,7 +239,7 @@ void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t
 	AlignWS* ws = new AlignWS();
 	Mach M;
 	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
-	MachOut O; O.rout = outs; O.aln = nullptr; O.pout = nullptr; O.paln[0] = O.paln[1] = nullptr;
+	MachOut O; O.rout = outs; O.aln = nullptr; O.aln_slots = 0; O.pout = nullptr; O.paln[0] = O.paln[1] = nullptr; O.pair_slots = 0;
 	for(uint32_t i = 0; i < M.rd[0].n; i++) {
 		M.name[0] = names + name_offs[i]; M.namelen[0] = name_offs[i + 1] - name_offs[i];
 		M.name[1] = nullptr; M.namelen[1] = 0;
@@ -260,7 +260,7 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	Mach M;
 	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
 	M.rd[1].codes = codes2; M.rd[1].offs = offs2; M.rd[1].quals = nullptr;
-	MachOut O; O.rout = nullptr; O.aln = nullptr; O.pout = outs; O.paln[0] = O.paln[1] = nullptr;
+	MachOut O; O.rout = nullptr; O.aln = nullptr; O.pout = outs; O.paln[0] = O.paln[1] = nullptr; O.pair_slots = EMU_REC_STRIDE;
 	for(uint32_t i = 0; i < M.rd[0].n; i++) {
 		M.name[0] = names1 + noffs1[i]; M.namelen[0] = noffs1[i + 1] - noffs1[i];
 		M.name[1] = names2 + noffs2[i]; M.namelen[1] = noffs2[i + 1] - noffs2[i];
