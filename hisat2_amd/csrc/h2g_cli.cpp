@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
 	uint32_t trim5 = 0, trim3 = 0;
 	uint32_t dp = 0;
 	size_t batch = 1u << 20;
-	int device = 0, threads = 1;
+	int device = 0, threads = 1, gpus = 1;
 	std::string cmdline;
 	std::vector<std::string> opts;                      // scoring / reporting options, applied once the index type is known
 	bool sensitive = false, very_sensitive = false, saw_k = false;
@@ -246,6 +246,7 @@ int main(int argc, char** argv) {
 		else if(a == "--no-hd" || a == "--no-head") nohead = true;
 		else if(a == "--batch") batch = (size_t)atoll(need("--batch"));
 		else if(a == "--device") device = atoi(need("--device"));
+		else if(a == "--gpus") gpus = atoi(need("--gpus"));                        // batches round-robin over <int> devices, output in read order
 		else if(a == "-s" || a == "--skip") skip = (uint64_t)atoll(need("-s"));     // skip the first <int> reads / pairs (hisat2.cpp:3319)
 		else if(a == "-u" || a == "--upto" || a == "--qupto") upto = (uint64_t)atoll(need("-u"));
 		else if(a == "-5" || a == "--trim5") trim5 = (uint32_t)atoi(need("-5"));
@@ -280,8 +281,22 @@ int main(int argc, char** argv) {
 	const bool paired = u.empty();
 	const double t0 = now();
 	h2g_load_opts lo; h2g_load_opts_init(&lo); lo.device = device; lo.load_local = 1;
-	h2g_index* ix = nullptr;
-	if(h2g_index_load(base.c_str(), &lo, &ix) != H2G_OK) die("cannot load the index onto the GPU");
+	// --gpus N: one index replica and one stream per device; batch k runs on device k mod N while the others are in flight, and
+	// the batches are completed (fetched, formatted, written) strictly in order, so the output is the single-GPU output.
+	// H2G_GPUS_SHARE_DEVICE=1 (test hook) lets the N streams share the devices that exist.
+	if(gpus < 1) gpus = 1;
+	int ndev = h2g_device_count();
+	if(ndev < 1) die("no GPU");
+	if(gpus > ndev && !getenv("H2G_GPUS_SHARE_DEVICE")) { fprintf(stderr, "hisat2-align-amd: --gpus %d but %d device(s) visible\n", gpus, ndev); return 1; }
+	std::vector<h2g_index*> ixs((size_t)gpus, nullptr);
+	for(int g = 0; g < gpus; g++) {
+		const int dev = (device + g) % ndev;
+		for(int q = 0; q < g; q++) if((device + q) % ndev == dev) ixs[g] = ixs[q];      // shared device: share the replica
+		if(ixs[g]) continue;
+		lo.device = dev;
+		if(h2g_index_load(base.c_str(), &lo, &ixs[g]) != H2G_OK) die("cannot load the index onto the GPU");
+	}
+	h2g_index* ix = ixs[0];
 	h2g_sam* sam = nullptr;
 	if(h2g_sam_open(base.c_str(), &sam) != H2G_OK) die("cannot read reference names");
 	h2g_align_params P; h2g_align_params_init(&P, ix);
@@ -339,66 +354,38 @@ int main(int argc, char** argv) {
 		for(uint64_t left = skip; left > 0;) { junk.clear(); const size_t g = ra.fill(junk, (size_t)std::min<uint64_t>(left, batch)); if(paired) { junk.clear(); rb.fill(junk, g); } if(!g) break; left -= g; }
 	}
 	uint64_t budget = upto;                               // -u counts the reads after the skipped ones (qUpto += skipReads, hisat2.cpp:1959-1963)
-	h2g_stream* st = nullptr;
-	Batch A[2], B[2];                                 // double buffer: batch k+1 is parsed while batch k is on the GPU
+	const int G = gpus, H = gpus + 1;                    // G streams (one per device) in flight, H host batch buffers: batch k is
+	std::vector<Batch> A((size_t)H), B((size_t)H);     // parsed into buffer k mod H while up to G earlier ones are on the GPUs
+	struct Str { h2g_stream* st = nullptr; size_t reads = 0, bases = 0; long batch = -1; size_t n = 0; };
+	std::vector<Str> S((size_t)G);
 	uint64_t nreads = 0, naligned = 0, novf = 0, nsecond = 0;
 	double t_gpu = 0, t_fmt = 0, t_parse = 0, t_up = 0, t_fetch = 0, t_stream = 0;
-	size_t stream_reads = 0, stream_bases = 0;
-	int cur = 0;
-	A[0].clear(); B[0].clear();
-	double tp = now();
-	auto want = [&]() { const size_t w = (size_t)std::min<uint64_t>(batch, budget); return w; };
-	size_t n = ra.fill(A[0], want());
-	budget -= std::min<uint64_t>(budget, n);
-	if(paired && rb.fill(B[0], n) != n) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
-	t_parse += now() - tp;
 	std::vector<h2g_read_result> res;
 	std::vector<h2g_pair_result> pres;
 	std::vector<h2g_alnres> aln, aln2;
 	std::vector<uint64_t> ao1, ao2;
 	std::string ovf_names;
-	while(n > 0) {
-		Batch& a = A[cur]; Batch& b = B[cur];
-		size_t bases = a.codes.size();
-		if(paired && b.codes.size() > bases) bases = b.codes.size();
-		if(!st || n > stream_reads || bases > stream_bases) {
-			if(st) h2g_stream_free(st);
-			stream_reads = n > batch ? n : batch; stream_bases = bases + bases / 4 + 1024;
-			const double ts = now();
-			if(h2g_stream_create(ix, stream_reads, stream_bases, &st) != H2G_OK) die("cannot create the device stream");
-			t_stream += now() - ts;
-		}
-		const double tg = now();
-		double tq0 = now();
-		if(h2g_set_reads(st, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, n) != H2G_OK) die("h2g_set_reads");
-		if(h2g_set_read_names(st, a.names.data(), a.noffs.data(), n) != H2G_OK) die("h2g_set_read_names");
-		if(paired) {
-			if(h2g_set_mates(st, b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n) != H2G_OK) die("h2g_set_mates");
-			if(h2g_align_pairs_run(st, &P) != H2G_OK) die("h2g_align_pairs_run");
-		} else if(h2g_align_run(st, &P) != H2G_OK) die("h2g_align_run");
-		t_up += now() - tq0;
-		// ingest the next batch on this thread while the kernel runs (the run calls are asynchronous)
-		const int nxt = cur ^ 1;
-		A[nxt].clear(); B[nxt].clear();
-		tp = now();
-		const size_t n2 = budget ? ra.fill(A[nxt], want()) : 0;
-		budget -= std::min<uint64_t>(budget, n2);
-		if(paired && rb.fill(B[nxt], n2) != n2) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
-		t_parse += now() - tp;
+	auto want = [&]() { const size_t w = (size_t)std::min<uint64_t>(batch, budget); return w; };
+	// fetch + format + write the batch that stream `g` carries
+	auto complete = [&](int g) {
+		Str& sg = S[(size_t)g];
+		if(sg.batch < 0) return;
+		Batch& a = A[(size_t)(sg.batch % H)]; Batch& b = B[(size_t)(sg.batch % H)];
+		h2g_stream* st = sg.st;
+		const size_t n = sg.n;
 		size_t used = 0;
+		const double tq0 = now();
 		if(paired) {
-			tq0 = now();
 			pres.resize(n); ao1.assign(n + 1, 0); ao2.assign(n + 1, 0);
 			if(aln.size() < 2 * n + 64) aln.resize(2 * n + 64);
 			if(aln2.size() < 2 * n + 64) aln2.resize(2 * n + 64);
-			// dense fetch: only the records that exist cross PCIe (the slot layout would move 2 x 16 x 424 B per pair)
+			// dense fetch: only the records that exist cross PCIe
 			if(h2g_align_pairs_fetch_dense(st, pres.data(), aln.data(), aln.size(), ao1.data(), aln2.data(), aln2.size(), ao2.data(), 0, n) != H2G_OK) {
 				if(aln.size() < ao1[n]) aln.resize(ao1[n]);
 				if(aln2.size() < ao2[n]) aln2.resize(ao2[n]);
 				if(h2g_align_pairs_fetch_dense(st, pres.data(), aln.data(), aln.size(), ao1.data(), aln2.data(), aln2.size(), ao2.data(), 0, n) != H2G_OK) die("h2g_align_pairs_fetch_dense");
 			}
 			t_fetch += now() - tq0;
-			t_gpu += now() - tg;
 			const double tf = now();
 			buf.resize(n * 1400 + 6 * (a.codes.size() + b.codes.size()) + 4096);
 			h2g_status rc = h2g_sam_format_paired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
@@ -414,15 +401,13 @@ int main(int argc, char** argv) {
 			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; if(pres[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names += " (bits " + std::to_string(pres[i].overflow) + ")\n"; } } }
 			t_fmt += now() - tf;
 		} else {
-			tq0 = now();
-			res.resize(n); ao1.resize(n + 1);
+			res.resize(n); ao1.assign(n + 1, 0);
 			if(aln.size() < n + n / 4 + 64) aln.resize(n + n / 4 + 64);
 			if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) {
 				if(aln.size() < ao1[n]) aln.resize(ao1[n]);
 				if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) die("h2g_align_fetch_dense");
 			}
 			t_fetch += now() - tq0;
-			t_gpu += now() - tg;
 			const double tf = now();
 			buf.resize(n * 700 + 3 * a.codes.size() + 4096);
 			h2g_status rc = h2g_sam_format_unpaired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
@@ -439,8 +424,51 @@ int main(int argc, char** argv) {
 		fwrite(buf.data(), 1, used, out);
 		{ h2g_counters hc; if(h2g_get_counters(st, &hc) == H2G_OK) nsecond += hc.n_second_pass; }
 		nreads += n;
-		n = n2;
-		cur = nxt;
+		sg.batch = -1;
+	};
+	for(long k = 0;; k++) {
+		Batch& a = A[(size_t)(k % H)]; Batch& b = B[(size_t)(k % H)];
+		a.clear(); b.clear();
+		double tp = now();
+		const size_t n = budget ? ra.fill(a, want()) : 0;
+		budget -= std::min<uint64_t>(budget, n);
+		if(paired && rb.fill(b, n) != n) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
+		t_parse += now() - tp;
+		if(n == 0) break;
+		const int g = (int)(k % G);
+		const double tg = now();
+		complete(g);                                   // the batch this stream still carries (k - G): the oldest one in flight
+		Str& sg = S[(size_t)g];
+		size_t bases = a.codes.size();
+		if(paired && b.codes.size() > bases) bases = b.codes.size();
+		if(!sg.st || n > sg.reads || bases > sg.bases) {
+			if(sg.st) h2g_stream_free(sg.st);
+			sg.reads = n > batch ? n : batch; sg.bases = bases + bases / 4 + 1024;
+			const double ts = now();
+			if(h2g_stream_create(ixs[(size_t)g], sg.reads, sg.bases, &sg.st) != H2G_OK) die("cannot create the device stream");
+			t_stream += now() - ts;
+		}
+		const double tq0 = now();
+		if(h2g_set_reads(sg.st, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, n) != H2G_OK) die("h2g_set_reads");
+		if(h2g_set_read_names(sg.st, a.names.data(), a.noffs.data(), n) != H2G_OK) die("h2g_set_read_names");
+		if(paired) {
+			if(h2g_set_mates(sg.st, b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n) != H2G_OK) die("h2g_set_mates");
+			if(h2g_align_pairs_run(sg.st, &P) != H2G_OK) die("h2g_align_pairs_run");
+		} else if(h2g_align_run(sg.st, &P) != H2G_OK) die("h2g_align_run");
+		t_up += now() - tq0;
+		sg.batch = k; sg.n = n;
+		t_gpu += now() - tg;
+	}
+	{   // drain, oldest first
+		long oldest = -1;
+		for(;;) {
+			int gi = -1;
+			for(int g = 0; g < G; g++) if(S[(size_t)g].batch >= 0 && (gi < 0 || S[(size_t)g].batch < oldest)) { gi = g; oldest = S[(size_t)g].batch; }
+			if(gi < 0) break;
+			const double tg = now();
+			complete(gi);
+			t_gpu += now() - tg;
+		}
 	}
 	if(out != stdout) fclose(out);
 	const double t2 = now();
@@ -461,8 +489,8 @@ int main(int argc, char** argv) {
 		FILE* sf = fopen(stats_fn.c_str(), "w");
 		if(sf) { fprintf(sf, "{\"reads\": %llu, \"second_pass\": %llu, \"overflow\": %llu}\n", (unsigned long long)nreads, (unsigned long long)nsecond, (unsigned long long)novf); fclose(sf); }
 	}
-	if(st) h2g_stream_free(st);
+	for(auto& sg : S) if(sg.st) h2g_stream_free(sg.st);
 	h2g_sam_close(sam);
-	h2g_index_free(ix);
+	for(int g = 0; g < gpus; g++) { bool dup = false; for(int q = 0; q < g; q++) dup |= ixs[(size_t)q] == ixs[(size_t)g]; if(!dup) h2g_index_free(ixs[(size_t)g]); }
 	return novf ? 3 : 0;
 }

@@ -1114,6 +1114,8 @@ static_assert(sizeof(h2g_read_result) == 40, "h2g_read_result layout");
 static_assert(sizeof(h2g_pair_result) == sizeof(PairOut), "h2g_pair_result must mirror PairOut");
 static_assert(H2G_PAIR_CAP == AL_MAX_PAIRS, "pair capacity");
 
+extern "C" int h2g_device_count(void) { int n = 0; if(hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+
 extern "C" void h2g_align_params_init(h2g_align_params* p, const h2g_index* ix) { align_params_defaults(p, !ix || ix->dg.linear); }
 
 // hisat2.cpp applies its presets AFTER every option was read, and the index type decides the default -k:

@@ -255,6 +255,8 @@ typedef struct {
 	uint32_t score_min_type;       /* --score-min <type>,<const>,<coeff>: 1 = C, 2 = L, 3 = S (sqrt), 4 = G (log)   (simple_func.h:30-33) */
 	double   score_min_const, score_min_coeff;   /* default L,0,-0.2 (hisat2.cpp:440) */
 } h2g_align_params;
+/* number of visible HIP devices (0 without a GPU: the library has no CPU path) */
+H2G_EXPORT int        h2g_device_count(void);
 H2G_EXPORT void       h2g_align_params_init(h2g_align_params*, const h2g_index*);
 /* The reference applies its presets after ALL options were read (hisat2.cpp:1882-1909) and lets the index type decide the
  * default -k (:3903-3906): khits = saw_k ? k_arg : 10; --sensitive: bowtie2_dp 0 -> 1, khits < 10 -> 10 (counts as saw_k),

@@ -219,3 +219,29 @@ def test_command_line_paired_fastq_unequal_mates(monkeypatch, snps):
     want = SL.body_lines(os.path.join(tmp, "ref4.sam"))
     assert diff_lines(SL.body_lines(os.path.join(tmp, "amd4.sam")), want) == 0
     assert open(os.path.join(tmp, "amd4.err")).read() == "".join(l for l in open(os.path.join(tmp, "ref4.err")) if not l.startswith("Warning"))
+
+
+@needs_ref
+@pytest.mark.parametrize("paired", [False, True])
+def test_command_line_gpus_front_end(paired):
+    """--gpus N: batches round-robin over N streams (here sharing the one device: H2G_GPUS_SHARE_DEVICE), completed in order —
+    the SAM file and the summary are those of the single-stream run, i.e. the reference's"""
+    if paired:
+        import fuzz_pairs as F
+        from test_gpu_pairs import _backend
+        from hisat2_amd import api
+        bad, tmp = F.run_case(verbose=2, backend=_backend, stride=api.PAIR_RES_CAP, seed=431, npairs=9000, rdlen=101, sub=0.02)
+        rd = ["-1", os.path.join(tmp, "r1.fa"), "-2", os.path.join(tmp, "r2.fa")]
+    else:
+        import fuzz_align as F
+        from test_gpu_align import _backend
+        bad, tmp = F.run_case(verbose=2, backend=_backend, seed=432, nreads=15000, rdlen=101, sub=0.02, indel=0.003, nrate=0.002)
+        rd = ["-U", os.path.join(tmp, "r.fa")]
+    assert bad == 0
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    for gpus in (2, 3):
+        out = os.path.join(tmp, f"amd{gpus}.sam")
+        subprocess.run([CLI, "-x", os.path.join(tmp, "g"), "-f"] + rd + ["--no-spliced-alignment", "-S", out, "--batch", "1700", "-p", "3", "--gpus", str(gpus)],
+                       check=True, stderr=open(os.path.join(tmp, "amd.err"), "w"), env=dict(os.environ, H2G_GPUS_SHARE_DEVICE="1"))
+        assert diff_lines(SL.body_lines(out), want) == 0
+        assert open(os.path.join(tmp, "amd.err")).read() == open(os.path.join(tmp, "ref.err")).read()

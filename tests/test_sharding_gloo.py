@@ -57,3 +57,48 @@ def test_two_rank_sharding_matches_single(g1_index, golden_dir):
         assert p.exitcode == 0
     assert got == want.tolist()
     assert got[0] == len(reads) and got[1] > 300
+
+
+def _go_worker(rank, world, port, base, golden, q):
+    """one shard of the batch through the whole go() machine (host instantiation), rendered as SAM fields"""
+    import torch.distributed as dist
+    import h2o_py as H
+    import sam_util as SU
+    from h2gemu_align import emu_align
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    names, seqs = H.read_fasta_reads(os.path.join(golden, "reads_se.fa.gz"))
+    lo, hi = shard.shard_range(len(seqs), rank, world)
+    outs, recs = emu_align(base, seqs[lo:hi], names[lo:hi])      # the names travel with the reads: they seed the per-read PRNG
+    refnames, _ = SU.parse_sam(os.path.join(golden, "ref_se_nospliced.sam.gz"))
+    got = SU.render(outs, recs, refnames, seqs[lo:hi], names[lo:hi])
+    naln = np.array([sum(1 for o in outs if o.nselect > 0), hi - lo], dtype=np.int64)
+    tot = shard.all_reduce_sum(naln, dist)
+    q.put((rank, [(nm, got[nm]) for nm in names[lo:hi]], tot.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_go_concatenation_equals_unsharded(g1_index, golden_dir):
+    """N>1 of the product path: each rank runs HI_Aligner::go on its id range; the shards' records concatenated in rank order are
+    the reference's SAM of the whole file, and the one collective (alignment-count all-reduce) gives the whole-file count"""
+    import h2o_py as H
+    import sam_util as SU
+    names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
+    _, want = SU.parse_sam(os.path.join(golden_dir, "ref_se_nospliced.sam.gz"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_go_worker, args=(r, 2, port, g1_index, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = sorted([q.get(timeout=300) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cat = [x for _, part, _ in parts for x in part]
+    assert [nm for nm, _ in cat] == names                       # ordered concatenation = --reorder output
+    for nm, rec in cat:
+        assert rec == want[nm], nm
+    assert parts[0][2] == parts[1][2] == [sum(1 for nm in names if want[nm][0][0] != 4), len(names)]
