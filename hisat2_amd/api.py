@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libh2g.so")
+LIB_PATH = os.environ.get("H2G_LIBPATH") or os.path.join(_HERE, "libh2g.so")   # H2G_LIBPATH: development builds (tools/)
 MAX = 0xFFFFFFFF
 MAX_EDITS = 32
 SEED_CAP = 5
@@ -87,6 +87,19 @@ class GHit(C.Structure):
     _fields_ = [("read", u32), ("fw", u32), ("rdoff", u32), ("len", u32), ("trim5", u32), ("trim3", u32),
                 ("tidx", u32), ("toff", u32), ("joinedOff", u32), ("score", i64), ("nedits", u32), ("overflow", u32),
                 ("edits", Edit * MAX_EDITS)]
+
+
+class ExtSearchQuery(C.Structure):   # h2g_ext_search_query
+    _fields_ = [("read", u32), ("rdoff", u32), ("lidx", u32), ("maxHitLen", u32), ("fw", u8), ("uniqueStop", u8), ("pad", u8 * 2)]
+
+
+class ExtSearchHit(C.Structure):     # h2g_ext_search_hit
+    _fields_ = [("nelt", u32), ("hitlen", u32), ("top", u32), ("bot", u32), ("uniqueStop", u32), ("nrank", u32), ("nside", u32), ("staged", u32)]
+
+
+class ExtSearchStats(C.Structure):   # h2g_ext_search_stats
+    _fields_ = [("n_local", u64), ("n_staged", u64), ("n_buckets", u64), ("n_buckets_staged", u64), ("lds_bytes_staged", u64),
+                ("ms_staged", C.c_float), ("ms_hbm", C.c_float)]
 
 
 class SwQuery(C.Structure):          # h2g_sw_query
@@ -241,7 +254,7 @@ EXPORTS = [
     "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_set_reads",
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
-    "h2g_device_count", "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
+    "h2g_device_count", "h2g_ext_search", "h2g_local_index_of", "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
     "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense",
     "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph", "h2g_adjust_with_alt",
 ]
@@ -296,6 +309,9 @@ def lib():
     L.h2g_align_params_init.restype = None
     L.h2g_align_params_presets.argtypes = [P(AlignParams), vp, C.c_int, u32, u32, C.c_int, C.c_int]
     L.h2g_align_params_presets.restype = None
+    L.h2g_ext_search.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
+    L.h2g_local_index_of.argtypes = [vp, u32, u32]
+    L.h2g_local_index_of.restype = u32
     L.h2g_set_read_names.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.h2g_align_run.argtypes = [vp, P(AlignParams)]
     L.h2g_align_fetch.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
@@ -377,6 +393,15 @@ class Stream:
         out = (FmHit * n)()
         _chk(lib().h2g_fm_search(self.h, q, n, khits, out), "h2g_fm_search")
         return out
+
+    def ext_search(self, queries, stage_min=8):
+        """h2g_ext_search: (hits, stats)"""
+        n = len(queries)
+        q = (ExtSearchQuery * n)(*queries) if not isinstance(queries, C.Array) else queries
+        out = (ExtSearchHit * n)()
+        st = ExtSearchStats()
+        _chk(lib().h2g_ext_search(self.h, q, n, stage_min, out, C.byref(st)), "h2g_ext_search")
+        return out, st
 
     def sw_align(self, queries, repeats=1):
         """SwAligner call site of hybridSearch (frame + u8 end-to-end DP + gather + first backtrace) -> (results, kernel ms)"""

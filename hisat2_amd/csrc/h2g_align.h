@@ -47,6 +47,7 @@ struct DLocalDesc {
 	uint32_t fchr[5];
 	uint32_t ftabLim;        // ftab entries above this point into eftab: len (linear) or gbwtLen (graph), gfm.h:2618
 	uint32_t zoffs_off;      // index into DLocalSet::zoffs of this index's nZ '$' rows (a graph local index can have several)
+	uint32_t sides_bytes;    // size of its side array (what a workgroup stages in LDS, h2g_ext_search)
 };
 struct DLocalSet {
 	const DLocalDesc* desc;
@@ -93,23 +94,27 @@ struct GIdx {
 struct LIdx {
 	const DLocalSet* ls;
 	const DLocalDesc* d;
+	const uint8_t*  sbase = nullptr;   // the index's sides / ftab staged in LDS (h2g_ext_search); nullptr: read them from HBM
+	const uint16_t* fbase = nullptr;
+	H2G_HD const uint8_t* side_ptr(uint32_t sideNum) const { return (sbase ? sbase : ls->sides + d->sides_off) + (size_t)sideNum * 64; }
+	H2G_HD uint32_t ftab_at(uint32_t i) const { return fbase ? fbase[i] : ls->words[d->ftab_off + i]; }
 	H2G_HD uint32_t ftabChars() const { return ls->ftabChars; }
 	H2G_HD bool is_zoff(uint32_t row) const { return d->nZ && row == d->zoff; }
 	H2G_HD uint32_t side_of(uint32_t row) const { return row / 224u; }
 	H2G_HD uint32_t fh(uint32_t i) const {   // ftabHi gfm.h:2618 with 16-bit words
-		uint32_t v = ls->words[d->ftab_off + i];
+		uint32_t v = ftab_at(i);
 		if(v <= d->ftabLim) return v;
 		return ls->words[d->eftab_off + ((v ^ 0xffffu) * 2 + 1)];
 	}
 	H2G_HD uint32_t fl(uint32_t i) const {
-		uint32_t v = ls->words[d->ftab_off + i];
+		uint32_t v = ftab_at(i);
 		if(v <= d->ftabLim) return v;
 		return ls->words[d->eftab_off + ((v ^ 0xffffu) * 2)];
 	}
 	H2G_HD void lohi(uint32_t fi, uint32_t* top, uint32_t* bot) const { *top = fh(fi); *bot = fl(fi + 1); }
 	H2G_HD uint32_t rank(uint32_t row, int c) const {   // countBt2Side gfm.h:2958 for index_t = uint16_t
 		uint32_t sideNum = row / 224u, charOff = row - sideNum * 224u;
-		Side64 s = load_side64(ls->sides + d->sides_off + (size_t)sideNum * 64);
+		Side64 s = load_side64(side_ptr(sideNum));
 		uint32_t cnt = 0;
 #pragma unroll
 		for(int k = 0; k < 7; k++) cnt += count_word(s.w[k], c, (int)charOff - 32 * k);
@@ -122,7 +127,7 @@ struct LIdx {
 	}
 	H2G_HD int rowL(uint32_t row) const {
 		uint32_t sideNum = row / 224u, charOff = row - sideNum * 224u;
-		const uint8_t* p = ls->sides + d->sides_off + (size_t)sideNum * 64;
+		const uint8_t* p = side_ptr(sideNum);
 		return (p[charOff >> 2] >> ((charOff & 3) * 2)) & 3;
 	}
 };

@@ -137,8 +137,10 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 #ifdef H2G_GO_PROF
 	// wave-level time split (shader clock ticks): [0] choose + pop + load [1] control + push [2] (unused) [3+op] each primitive;
 	// [20+op] slots executed; [32+op] executions; [47] trips
-	unsigned long long prof[48];
+	unsigned long long prof[48], prof_ctl[16];
+	uint32_t trip_op = 0;
 	for(int k = 0; k < 48; k++) prof[k] = 0;
+	for(int k = 0; k < 16; k++) prof_ctl[k] = 0;
 	unsigned long long tp0 = __builtin_readcyclecounter(), tp1;
 #define PROF(SLOT) do { tp1 = __builtin_readcyclecounter(); prof[SLOT] += tp1 - tp0; tp0 = tp1; } while(0)
 #else
@@ -163,6 +165,9 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 			// ---- new reads into free slots
 			const uint32_t n = ring_pop(Q, 0, lane, &slot);
 			if(n == 0) continue;
+#ifdef H2G_GO_PROF
+			trip_op = 0;
+#endif
 			uint32_t base = 0;
 			if(lane == 0) base = atomicAdd(A.work, n);
 			base = (uint32_t)__shfl((int)base, 0);
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 				}
 			}
 #ifdef H2G_GO_PROF
-			prof[20 + op] += n; prof[32 + op]++; prof[47]++;
+			prof[20 + op] += n; prof[32 + op]++; prof[47]++; trip_op = op;
 #endif
 			PROF(0);
 			if(have) mach_exec(C, M, op);          // ONE primitive, one code site, every lane that carries a slot
@@ -243,10 +248,13 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		ring_push(Q, have, nextq, slot, lane);
-		PROF(1);
+#ifdef H2G_GO_PROF
+		tp1 = __builtin_readcyclecounter(); prof[1] += tp1 - tp0; prof_ctl[trip_op] += tp1 - tp0; tp0 = tp1;
+#endif
 	}
 #ifdef H2G_GO_PROF
 	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A.counters + 16 + k, prof[k]);
+	if(lane == 0) for(int k = 0; k < 16; k++) if(prof_ctl[k]) atomicAdd(A.counters + 80 + k, prof_ctl[k]);
 #endif
 	wave_add(A.counters + 0, nrank);
 	wave_add(A.counters + 1, nside);

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "h2g_core.h"
 #include "h2g_host_index.h"
 #include "h2g_align.h"
@@ -38,6 +39,7 @@ struct h2g_index {
 	DLocalSet dls;
 	DAlts dalts;
 	bool has_local = false;
+	std::vector<DLocalDesc> h_ldesc;   // host copy of the local-index descriptors (bucketing of h2g_ext_search)
 	std::vector<void*> allocs;
 	uint64_t device_bytes = 0;
 };
@@ -162,6 +164,7 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		if((s = upload(ix, lp.desc, &dd)) || (s = upload(ix, lp.sides, &ds, 256)) || (s = upload(ix, lp.words, &dw)) ||
 		   (s = upload(ix, lp.first, &df)) || (s = upload(ix, lp.zoffs, &dz))) { h2g_index_free(ix); return s; }
 		ix->dls = lp.view(dd, ds, dw, df, dz);
+		ix->h_ldesc = lp.desc;
 		ix->has_local = true;
 	}
 	*out = ix;
@@ -934,6 +937,154 @@ extern "C" h2g_status h2g_fm_search(h2g_stream* s, const h2g_fm_query* q, size_t
 	return H2G_OK;
 }
 
+// ------------------------------------------------------------------------------------------ globalGFMSearch / localGFMSearch
+// one query on whichever index this is (the item function of both kernels below; sbase/fbase != nullptr: the local index is in LDS)
+template <bool GRAPH>
+__device__ __forceinline__ void ext_search_item(const DGfm& g, const DLocalSet& ls, const DReads& rd, const h2g_ext_search_query& qq, uint32_t minK,
+                                                uint32_t minK_local, uint32_t kseeds, const uint8_t* sbase, const uint16_t* fbase, h2g_ext_search_hit* o)
+{
+	const SeqView sv = seq_view(rd, qq.read, qq.fw != 0);
+	uint32_t hitlen = 0, top = H2G_MAX, bot = H2G_MAX, nr[2] = {0, 0}, nelt = 0;
+	bool us = qq.uniqueStop != 0;
+	if(qq.lidx == H2G_MAX) {
+		GIdx gx; gx.g = &g;
+		if(!GRAPH) nelt = gfm_search(gx, sv, qq.rdoff, &hitlen, &top, &bot, &us, minK, H2G_MAX, kseeds, false, nr);
+		else { GRange r; r.top = top; r.bot = bot; r.node_top = r.node_bot = 0; IEdges ie; nelt = gfm_search_graph(g, gx, sv, qq.rdoff, &hitlen, &r, &ie, &us, minK, H2G_MAX, kseeds, false, kseeds, nr); if(nelt > 0) { top = r.top; bot = r.bot; } }
+	} else {
+		LIdx lx; lx.ls = &ls; lx.d = &ls.desc[qq.lidx]; lx.sbase = sbase; lx.fbase = fbase;
+		if(lx.d->len == 0) nelt = 0;
+		else if(!GRAPH) nelt = gfm_search(lx, sv, qq.rdoff, &hitlen, &top, &bot, &us, minK_local, qq.maxHitLen, kseeds, true, nr);
+		else { const LGfm x = lgfm_of(ls, *lx.d); GRange r; r.top = top; r.bot = bot; r.node_top = r.node_bot = 0; IEdges ie;
+		       nelt = gfm_search_graph(x, lx, sv, qq.rdoff, &hitlen, &r, &ie, &us, minK_local, qq.maxHitLen, kseeds, true, kseeds, nr); top = r.top; bot = r.bot; }
+	}
+	o->nelt = nelt; o->hitlen = hitlen; o->top = top; o->bot = bot; o->uniqueStop = us ? 1u : 0u; o->nrank = nr[0]; o->nside = nr[1]; o->staged = sbase ? 1u : 0u;
+}
+
+// lane per query, sides from HBM: global queries, local queries of thin buckets, graph-index locals
+template <bool GRAPH>
+__global__ __launch_bounds__(256) void k_ext_search_hbm(DGfm g, DLocalSet ls, DReads rd, const h2g_ext_search_query* q, const uint32_t* order, size_t n,
+                                                        uint32_t minK, uint32_t minK_local, uint32_t kseeds, h2g_ext_search_hit* out)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		const uint32_t k = order[i];
+		ext_search_item<GRAPH>(g, ls, rd, q[k], minK, minK_local, kseeds, nullptr, nullptr, &out[k]);
+	}
+}
+
+// one workgroup per bucket of same-local-index queries: the index's sides and ftab are copied into LDS once (coalesced 16 B
+// loads), then every Occ-rank of the bucket's queries is an LDS read.  Linear local indexes (64 B sides of 16-bit words).
+__global__ __launch_bounds__(256) void k_ext_search_lds(DGfm g, DLocalSet ls, DReads rd, const h2g_ext_search_query* q, const uint32_t* order,
+                                                        const uint2* buckets /* {first, count} into order */, uint32_t nbuckets, uint32_t minK, uint32_t minK_local,
+                                                        uint32_t kseeds, h2g_ext_search_hit* out)
+{
+	extern __shared__ uint4 s_stage[];
+	for(uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+		const uint2 bk = buckets[b];
+		const uint32_t lidx = q[order[bk.x]].lidx;
+		const DLocalDesc& d = ls.desc[lidx];
+		const uint32_t nside16 = (d.sides_bytes + 15) / 16, nftab = (1u << (2 * ls.ftabChars)) + 1;
+		const uint4* src = reinterpret_cast<const uint4*>(ls.sides + d.sides_off);
+		for(uint32_t i = threadIdx.x; i < nside16; i += blockDim.x) s_stage[i] = src[i];
+		uint16_t* s_ftab = reinterpret_cast<uint16_t*>(s_stage + nside16);
+		for(uint32_t i = threadIdx.x; i < nftab; i += blockDim.x) s_ftab[i] = ls.words[d.ftab_off + i];
+		__syncthreads();
+		for(uint32_t i = threadIdx.x; i < bk.y; i += blockDim.x) {
+			const uint32_t k = order[bk.x + i];
+			ext_search_item<false>(g, ls, rd, q[k], minK, minK_local, kseeds, reinterpret_cast<const uint8_t*>(s_stage), s_ftab, &out[k]);
+		}
+		__syncthreads();
+	}
+}
+
+extern "C" uint32_t h2g_local_index_of(const h2g_index* ix, uint32_t tidx, uint32_t toff) {
+	if(!ix || !ix->has_local || tidx >= ix->host.local_first.size() - 1) return H2G_MAX;
+	const uint32_t a = ix->host.local_first[tidx], b = ix->host.local_first[tidx + 1], k = toff / H2G_LOCAL_INTERVAL;
+	return a + k >= b ? H2G_MAX : a + k;
+}
+
+extern "C" h2g_status h2g_ext_search(h2g_stream* s, const h2g_ext_search_query* q, size_t n, uint32_t stage_min, h2g_ext_search_hit* out,
+                                     h2g_ext_search_stats* stats)
+{
+	if(!s || !q || !out || n == 0 || n > 0xffffffffull) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s))) return rc;
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	const bool graph = !s->ix->dg.linear;
+	const uint32_t nlocal = s->ix->dls.n;
+	for(size_t i = 0; i < n; i++) {
+		if(q[i].read >= s->n_reads) return H2G_ERR_ARG;
+		if(q[i].lidx != H2G_MAX && (!s->ix->has_local || q[i].lidx >= nlocal)) return H2G_ERR_ARG;
+	}
+	HIPCHK(hipSetDevice(s->ix->device));
+	// bucket the local queries by index (host: the queries come from the host anyway); thin buckets and global queries go to the HBM kernel
+	std::vector<uint32_t> ord(n);
+	for(size_t i = 0; i < n; i++) ord[i] = (uint32_t)i;
+	std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return q[a].lidx < q[b].lidx; });
+	std::vector<uint32_t> o_lds, o_hbm;
+	std::vector<uint2> buckets;
+	h2g_ext_search_stats st;
+	memset(&st, 0, sizeof st);
+	uint32_t max_stage = 0;
+	for(size_t i = 0; i < n;) {
+		size_t j = i;
+		while(j < n && q[ord[j]].lidx == q[ord[i]].lidx) j++;
+		const uint32_t lidx = q[ord[i]].lidx;
+		const bool local = lidx != H2G_MAX;
+		if(local) { st.n_local += j - i; st.n_buckets++; }
+		const DLocalDesc* d = local ? &s->ix->h_ldesc[lidx] : nullptr;
+		if(local && !graph && stage_min > 0 && j - i >= stage_min && d->len > 0) {
+			// a fat bucket is cut into workgroup-sized pieces (each stages its own copy: 25-40 KB against >= 1 MB of side reads saved)
+			const uint32_t bytes = (d->sides_bytes + 15) / 16 * 16 + ((1u << (2 * s->ix->dls.ftabChars)) + 1) * 2 + 16;
+			for(size_t c = i; c < j; c += 1024) {
+				const size_t ce = c + 1024 < j ? c + 1024 : j;
+				buckets.push_back(make_uint2((uint32_t)o_lds.size(), (uint32_t)(ce - c)));
+				for(size_t k = c; k < ce; k++) o_lds.push_back(ord[k]);
+				st.n_buckets_staged++;
+				st.lds_bytes_staged += bytes;
+			}
+			st.n_staged += j - i;
+			if(bytes > max_stage) max_stage = bytes;
+		} else for(size_t k = i; k < j; k++) o_hbm.push_back(ord[k]);
+		i = j;
+	}
+	void *dq, *dout, *dord, *dbk;
+	if((rc = tmp_buf(s, 0, n * sizeof *q, &dq)) || (rc = tmp_buf(s, 1, n * sizeof *out, &dout)) || (rc = tmp_buf(s, 2, n * 4 + 64, &dord)) ||
+	   (rc = tmp_buf(s, 3, buckets.size() * sizeof(uint2) + 64, &dbk))) return rc;
+	HIPCHK(hipMemcpyAsync(dq, q, n * sizeof *q, hipMemcpyHostToDevice, s->st));
+	uint32_t* d_olds = (uint32_t*)dord;
+	uint32_t* d_ohbm = d_olds + o_lds.size();
+	if(!o_lds.empty()) HIPCHK(hipMemcpyAsync(d_olds, o_lds.data(), o_lds.size() * 4, hipMemcpyHostToDevice, s->st));
+	if(!o_hbm.empty()) HIPCHK(hipMemcpyAsync(d_ohbm, o_hbm.data(), o_hbm.size() * 4, hipMemcpyHostToDevice, s->st));
+	if(!buckets.empty()) HIPCHK(hipMemcpyAsync(dbk, buckets.data(), buckets.size() * sizeof(uint2), hipMemcpyHostToDevice, s->st));
+	h2g_align_params ap;
+	align_params_defaults(&ap, !graph);
+	const AlnParams P = aln_params_from(ap, true, !graph);
+	const uint32_t minK = s->ix->dg.minK, minKl = P.minK_local, kseeds = P.kseeds;
+	HIPCHK(hipEventRecord(s->ev[0], s->st));
+	if(!buckets.empty()) {
+		const unsigned grid = (unsigned)(buckets.size() < 256 * 8 ? buckets.size() : 256 * 8);
+		hipLaunchKernelGGL(k_ext_search_lds, dim3(grid), dim3(256), max_stage, s->st, s->ix->dg, s->ix->dls, dreads(s), (const h2g_ext_search_query*)dq, d_olds,
+		                   (const uint2*)dbk, (uint32_t)buckets.size(), minK, minKl, kseeds, (h2g_ext_search_hit*)dout);
+	}
+	HIPCHK(hipEventRecord(s->ev[1], s->st));
+	if(!o_hbm.empty()) {
+		if(graph) hipLaunchKernelGGL((k_ext_search_hbm<true>), dim3(grid_for(o_hbm.size(), 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dls, dreads(s),
+		                             (const h2g_ext_search_query*)dq, d_ohbm, o_hbm.size(), minK, minKl, kseeds, (h2g_ext_search_hit*)dout);
+		else hipLaunchKernelGGL((k_ext_search_hbm<false>), dim3(grid_for(o_hbm.size(), 256)), dim3(256), 0, s->st, s->ix->dg, s->ix->dls, dreads(s),
+		                        (const h2g_ext_search_query*)dq, d_ohbm, o_hbm.size(), minK, minKl, kseeds, (h2g_ext_search_hit*)dout);
+	}
+	HIPCHK(hipEventRecord(s->ev[9], s->st));
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	float t = 0;
+	if(hipEventElapsedTime(&t, s->ev[0], s->ev[1]) == hipSuccess) st.ms_staged = t;
+	if(hipEventElapsedTime(&t, s->ev[1], s->ev[9]) == hipSuccess) st.ms_hbm = t;
+	if(stats) *stats = st;
+	return H2G_OK;
+}
+
 extern "C" h2g_status h2g_sw_align(h2g_stream* s, const h2g_sw_query* q, size_t n, h2g_sw_result* out, int repeats, float* kernel_ms) {
 	if(!s || !q || !out || n == 0) return H2G_ERR_ARG;
 	int rc;
@@ -1498,7 +1649,7 @@ extern "C" __attribute__((visibility("default"))) int h2g_go_debug_trace(h2g_str
 extern "C" __attribute__((visibility("default"))) int h2g_go_prof(h2g_stream* s, unsigned long long* out48) {
 	if(!s || !out48) return H2G_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(s->st));
-	HIPCHK(hipMemcpy(out48, s->d_counters + 16, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out48, s->d_counters + 16, 80 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // [0..47] split, [64..79] control by source ring
 	return H2G_OK;
 }
 

@@ -39,6 +39,7 @@ inline void pack_local(const HostIndex& ix, LocalPack& lp) {
 			lp.ftabChars = (uint32_t)l.p.ftabChars; lp.offRate = (uint32_t)l.p.offRate;
 			while(lp.sides.size() % 128) lp.sides.push_back(0);
 			d.sides_off = lp.sides.size();
+			d.sides_bytes = (uint32_t)l.sides.size();
 			lp.sides.insert(lp.sides.end(), l.sides.begin(), l.sides.end());
 			auto put = [&](const std::vector<uint32_t>& v) { uint32_t off = (uint32_t)lp.words.size(); for(uint32_t x : v) lp.words.push_back((uint16_t)x); return off; };
 			d.ftab_off = put(l.ftab); d.eftab_off = put(l.eftab); d.offs_off = put(l.offs); d.rstarts_off = put(l.rstarts);

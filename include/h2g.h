@@ -112,6 +112,19 @@ typedef struct {
 
 H2G_EXPORT h2g_status h2g_fm_search(h2g_stream*, const h2g_fm_query* q, size_t n, uint32_t khits, h2g_fm_hit* out);
 
+/* ---- the searches of hybridSearch_recur: globalGFMSearch (hi_aligner.h:6606) and localGFMSearch (:6751) -----------------
+ * Backward search of the read bases [.., rdoff] of the searched strand (rdoff counted from its 5' end, inclusive) in the global
+ * index (lidx == H2G_MAX) or in local index `lidx` (HGFM::getLocalGFM hgfm.h:1713: lidx = h2g_local_index_of(tidx, toff)).
+ * Local queries are bucketed by lidx; a bucket with at least `stage_min` queries is served by one workgroup that first copies
+ * the local index's sides (16-33 KB) and ftab (8 KB) into LDS — every rank of those queries is an LDS read; the other queries
+ * (and graph-index locals) read their sides from HBM.  stage_min == 0 never stages.  Linear and graph indexes. */
+typedef struct { uint32_t read, rdoff, lidx, maxHitLen; uint8_t fw, uniqueStop, pad[2]; } h2g_ext_search_query;
+typedef struct { uint32_t nelt, hitlen, top, bot, uniqueStop, nrank, nside, staged; } h2g_ext_search_hit;
+typedef struct { uint64_t n_local, n_staged, n_buckets, n_buckets_staged, lds_bytes_staged; float ms_staged, ms_hbm; } h2g_ext_search_stats;
+H2G_EXPORT h2g_status h2g_ext_search(h2g_stream*, const h2g_ext_search_query* q, size_t n, uint32_t stage_min, h2g_ext_search_hit* out,
+                                     h2g_ext_search_stats* stats /* nullable */);
+H2G_EXPORT uint32_t   h2g_local_index_of(const h2g_index*, uint32_t tidx, uint32_t toff);   /* H2G_MAX: none */
+
 /* ---- graph (GFM) index primitives: 128 B sides with F/M bit vectors (gfm.h:160-176) ------------------- */
 /* BWTHit::_node_iedge_count (hi_aligner.h:199): nodes of a range with more than one incoming edge */
 #define H2G_IEDGE_CAP 24

@@ -152,6 +152,22 @@ void h2gemu_fm_search(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, h
 	}
 }
 
+// globalGFMSearch / localGFMSearch as h2g_ext_search runs them (linear index)
+void h2gemu_ext_search(Emu* e, const h2g_ext_search_query* q, size_t n, h2g_ext_search_hit* out) {
+	DReads rd = e->reads();
+	h2g_align_params hp;
+	align_params_defaults(&hp, e->dg.linear);
+	const AlnParams P = aln_params_from(hp, true, e->dg.linear);
+	for(size_t i = 0; i < n; i++) {
+		const SeqView sv = seq_view(rd, q[i].read, q[i].fw != 0);
+		uint32_t hitlen = 0, top = H2G_MAX, bot = H2G_MAX, nr[2] = {0, 0}, nelt = 0;
+		bool us = q[i].uniqueStop != 0;
+		if(q[i].lidx == H2G_MAX) { GIdx gx; gx.g = &e->dg; nelt = gfm_search(gx, sv, q[i].rdoff, &hitlen, &top, &bot, &us, e->dg.minK, H2G_MAX, P.kseeds, false, nr); }
+		else { LIdx lx; lx.ls = &e->dls; lx.d = &e->dls.desc[q[i].lidx]; nelt = lx.d->len == 0 ? 0 : gfm_search(lx, sv, q[i].rdoff, &hitlen, &top, &bot, &us, P.minK_local, q[i].maxHitLen, P.kseeds, true, nr); }
+		out[i].nelt = nelt; out[i].hitlen = hitlen; out[i].top = top; out[i].bot = bot; out[i].uniqueStop = us; out[i].nrank = nr[0]; out[i].nside = nr[1]; out[i].staged = 0;
+	}
+}
+
 void h2gemu_sw_align(Emu* e, const h2g_sw_query* q, size_t n, h2g_sw_result* out) {
 	// both matrix layouts through the same gather/backtrace: odd problems use the anti-diagonal-major layout of the
 	// wavefront kernel (filled here cell by cell), even ones the row-major layout of the in-go() path

@@ -38,7 +38,7 @@ print("align %.3f ms (main kernel %.3f ms) aligned %d overflow %d second-pass %d
     c.ms_align, c.ms_align_kernel, c.n_aligned, c.n_overflow, c.n_second_pass, c.n_rank / nreads, c.n_sa_steps / nreads))
 L = api.lib()
 if hasattr(L, "h2g_go_prof"):
-    v = (C.c_ulonglong * 48)()
+    v = (C.c_ulonglong * 80)()
     L.h2g_go_prof.argtypes = [C.c_void_p, C.c_void_p]
     if L.h2g_go_prof(st.h, v) == 0 and v[47]:
         names = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS GSEARCH COMBINE ADJUST ADJMEMBER SW FINISH".split()
@@ -49,4 +49,5 @@ if hasattr(L, "h2g_go_prof"):
         for op in range(1, 12):
             if v[3 + op]:
                 print("  %-10s %5.1f %%   executions: avg %.1f of 64 lanes" % (names[op], 100.0 * v[3 + op] / tot, v[20 + op] / max(1, v[32 + op])))
+        print("  control time by the ring the trip popped (0 = new reads):", {names[op] if op else "FETCH": "%.1f %%" % (100.0 * v[64 + op] / tot) for op in range(0, 12) if v[64 + op]})
         print("  executions:", {names[op]: int(v[32 + op]) for op in range(1, 12) if v[32 + op]})
