@@ -157,7 +157,11 @@ class AlignParams(C.Structure):
     _fields_ = [("khits", u32), ("kseeds", u32), ("no_spliced_alignment", u32), ("secondary", u32), ("bowtie2_dp", u32),
                 ("mm_max", C.c_int32), ("mm_min", C.c_int32), ("n_pen", C.c_int32), ("rdg_const", C.c_int32), ("rdg_linear", C.c_int32),
                 ("rfg_const", C.c_int32), ("rfg_linear", C.c_int32), ("sc_max", C.c_int32), ("sc_min", C.c_int32), ("score_min_type", u32),
-                ("score_min_const", C.c_double), ("score_min_coeff", C.c_double)]
+                ("score_min_const", C.c_double), ("score_min_coeff", C.c_double), ("no_temp_splicesite", u32),
+                ("min_intronlen", u32), ("max_intronlen", u32), ("pen_cansplice", C.c_int32), ("pen_noncansplice", C.c_int32),
+                ("pen_canintronlen_type", u32), ("pen_noncanintronlen_type", u32), ("pad_", u32),
+                ("pen_canintronlen_const", C.c_double), ("pen_canintronlen_coeff", C.c_double),
+                ("pen_noncanintronlen_const", C.c_double), ("pen_noncanintronlen_coeff", C.c_double)]
 
     def apply_options(self, opts, linear=None):
         """apply a list of reference command-line options (['-k', '3', '--mp', '4,2', ...]) to this block; returns leftovers.
@@ -177,6 +181,12 @@ class AlignParams(C.Structure):
                 max_seeds = int(v); i += 2
             elif o == "--secondary":
                 self.secondary = 1; i += 1
+            elif o == "--no-temp-splicesite":
+                self.no_temp_splicesite = 1; i += 1
+            elif o == "--no-spliced-alignment":
+                self.no_spliced_alignment = 1; i += 1
+            elif o == "--spliced":          # test shorthand: the reference's default mode
+                self.no_spliced_alignment = 0; i += 1
             elif o == "--sensitive":
                 sensitive = True; i += 1
             elif o == "--very-sensitive":
@@ -196,6 +206,23 @@ class AlignParams(C.Structure):
                 a = v.split(","); self.rdg_const = int(a[0]); self.rdg_linear = int(a[1]) if len(a) > 1 else self.rdg_linear; i += 2
             elif o == "--rfg":
                 a = v.split(","); self.rfg_const = int(a[0]); self.rfg_linear = int(a[1]) if len(a) > 1 else self.rfg_linear; i += 2
+            elif o == "--min-intronlen":
+                self.min_intronlen = int(v); i += 2
+            elif o == "--max-intronlen":
+                self.max_intronlen = int(v); i += 2
+            elif o == "--pen-cansplice":
+                self.pen_cansplice = int(v); i += 2
+            elif o == "--pen-noncansplice":
+                self.pen_noncansplice = int(v); i += 2
+            elif o in ("--pen-canintronlen", "--pen-intronlen", "--pen-noncanintronlen"):
+                a = v.split(",")            # PARSE_FUNC aligner_seed_policy.cpp:47: only the fields given are changed
+                w = "pen_noncanintronlen" if o == "--pen-noncanintronlen" else "pen_canintronlen"
+                setattr(self, w + "_type", {"C": 1, "L": 2, "S": 3, "G": 4}[a[0]])
+                if len(a) > 1:
+                    setattr(self, w + "_const", float(a[1]))
+                if len(a) > 2:
+                    setattr(self, w + "_coeff", float(a[2]))
+                i += 2
             elif o == "--score-min":
                 a = v.split(",")
                 self.score_min_type = {"C": 1, "L": 2, "S": 3, "G": 4}[a[0]]

@@ -275,12 +275,12 @@ H2G_HD uint32_t gen_rand_seed(const SeqView& fwseq, const char* name, uint32_t n
 H2G_HD void hit_init(h2g_ghit* h, bool fw, uint32_t rdoff, uint32_t len, uint32_t tidx, uint32_t toff, uint32_t joff) {
 	h->read = 1;   // _hitcount
 	h->fw = fw; h->rdoff = rdoff; h->len = len; h->trim5 = 0; h->trim3 = 0; h->tidx = tidx; h->toff = toff; h->joinedOff = joff;
-	h->score = 0; h->nedits = 0; h->overflow = 0;
+	h->score = 0; h->nedits = 0; h->overflow = 0; h->splicescore = 0;
 }
 H2G_HD void hit_copy(h2g_ghit* d, const h2g_ghit* s) {
 	d->read = s->read; d->fw = s->fw; d->rdoff = s->rdoff; d->len = s->len; d->trim5 = s->trim5; d->trim3 = s->trim3;
 	d->tidx = s->tidx; d->toff = s->toff; d->joinedOff = s->joinedOff; d->score = s->score; d->nedits = s->nedits;
-	d->overflow = s->overflow;
+	d->overflow = s->overflow; d->splicescore = s->splicescore;
 	for(uint32_t i = 0; i < s->nedits; i++) d->edits[i] = s->edits[i];
 }
 H2G_HD int base_code(uint8_t ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
@@ -388,6 +388,7 @@ H2G_HD void hit_push_edit(h2g_ghit* h, uint32_t pos, uint8_t chr, uint8_t qchr, 
 
 // combineWith hi_aligner.h:1420-2025 for linear indexes without spliced alignment: plain concatenation
 // (:1506-1525) or one insertion / deletion placed by the prefix/suffix score scan (:1741-1794).
+#define H2G_COMBINE_SCRATCH 512
 H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq, h2g_ghit* a, const h2g_ghit* b, int64_t minsc,
                         uint32_t minIntronLen, bool no_spliced, int64_t* tmp1, int64_t* tmp2, const DAlts* alts = nullptr)
 {
@@ -407,12 +408,12 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 			if(!no_spliced && refdif - rddif >= minIntronLen) spliced = true; else del = true;
 		} else ins = true;
 	}
-	if(spliced) return false;   // spliced alignment is not built (no_spliced_alignment mode only)
-	if(!ins && !del && this_rdoff + this_len == other_rdoff) {
+	if(spliced && (sc.donor_sum == nullptr || refdif - rddif > H2G_SPL_MAXLEN)) return false;   // probscore tables are uploaded with spliced alignment on
+	if(!spliced && !ins && !del && this_rdoff + this_len == other_rdoff) {
 		const uint32_t addoff = b->rdoff - a->rdoff;
 		for(uint32_t i = 0; i < b->nedits; i++) {
 			hit_push_edit(a, b->edits[i].pos + addoff, b->edits[i].chr, b->edits[i].qchr, b->edits[i].type);
-			if(!a->overflow) a->edits[a->nedits - 1].snp = b->edits[i].snp;
+			if(!a->overflow) { a->edits[a->nedits - 1].snp = b->edits[i].snp; a->edits[a->nedits - 1].pad = b->edits[i].pad; }   // whole Edit (ALT id, splice fields)
 		}
 		a->len += b->len;
 		calculate_score(sc, seq, a);
@@ -421,12 +422,14 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 	const uint32_t rdlen = seq.len;
 	int64_t remainsc = minsc - (a->score - this_score) - (b->score - other_score);
 	if(remainsc > 0) remainsc = 0;
-	const int read_gaps = max_gaps(remainsc, sc.rdGapConst + sc.rdGapLinear, sc.rdGapLinear);
-	const int ref_gaps = max_gaps(remainsc, sc.rfGapConst + sc.rfGapLinear, sc.rfGapLinear);
+	// sc.maxReadGaps(remainsc + sc.canSpl(), rdlen) (:1539-1540; canSpl() = --pen-cansplice, 0 by default); 0 when an intron is placed
+	const int read_gaps = spliced ? 0 : max_gaps(remainsc + sc.cp, sc.rdGapConst + sc.rdGapLinear, sc.rdGapLinear);
+	const int ref_gaps = spliced ? 0 : max_gaps(remainsc + sc.cp, sc.rfGapConst + sc.rfGapLinear, sc.rfGapLinear);
 	(void)rdlen;
 	if(ins) { if(refdif + ref_gaps < rddif) return false; }
 	else if(del) { if(rddif + read_gaps < refdif) return false; }
 	int this_ref_ext = read_gaps;
+	if(spliced) this_ref_ext += H2G_SPL_INTRONIC;
 	if(this_toff + len > reflen) return false;
 	if(this_toff + len + this_ref_ext > reflen) this_ref_ext = (int)(reflen - (this_toff + len));
 	// refbuf[i]  = ref[this_toff + i]                              (i < len + this_ref_ext)
@@ -437,8 +440,88 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 	const int64_t base2 = (int64_t)other_toff + other_len - len;
 	uint32_t maxscorei = H2G_MAX;
 	int64_t maxscore = INT64_MIN;
+	uint32_t maxspldir = H2G_SPL_UNKNOWN;
+	float maxsplscore = 0.0f, spl_probstore = 0.0f;
+	if(spliced) {
+		// ---- discover the splice site (:1588-1739): prefix / suffix mismatch scores, donor / acceptor dinucleotides, PWM tie-break
+		if(len > H2G_COMBINE_SCRATCH) { a->overflow = 1; return false; }
+		int64_t other_ref_ext = (int64_t)read_gaps + H2G_SPL_INTRONIC;
+		{ const int64_t lim = (int64_t)other_toff + other_len - len; if(lim < other_ref_ext) other_ref_ext = lim; }
+		int i;
+		for(i = 0; i < (int)len; i++) {
+			int rdc = seq.at(this_rdoff + i), rfc = rc1.get((int64_t)this_toff + i);
+			tmp1[i] = i > 0 ? tmp1[i - 1] : 0;
+			if(rdc != rfc) tmp1[i] += score_cell(sc, rdc, rfc, seq.qual(this_rdoff + i) - 33);
+			if(tmp1[i] < remainsc) break;
+		}
+		const int i_limit = i < (int)len ? i : (int)len;
+		int i2;
+		for(i2 = (int)len - 1; i2 >= 0; i2--) {
+			int64_t p = base2 + i2;
+			int rdc = seq.at(this_rdoff + i2), rfc = p < 0 ? 4 : rc2.get(p);
+			tmp2[i2] = (uint32_t)(i2 + 1) < len ? tmp2[i2 + 1] : 0;
+			if(rdc != rfc) tmp2[i2] += score_cell(sc, rdc, rfc, seq.qual(this_rdoff + i2) - 33);
+			if(tmp2[i2] < remainsc) break;
+		}
+		const int i2_limit = i2 > 0 ? i2 : 0;
+		const int GT = 0x23, AG = 0x02, GTrc = 0x01, AGrc = 0x13, GC = 0x21, GCrc = 0x21, AT = 0x03, AC = 0x01, ATrc = 0x03, ACrc = 0x20;
+		auto rf1 = [&](int j) -> int { return rc1.get((int64_t)this_toff + j); };                     // refbuf[j]
+		auto rf2 = [&](int j) -> int { const int64_t p = base2 + j; return p < 0 ? 4 : rc2.get(p); }; // refbuf2[j], j >= -other_ref_ext
+		for(i = i2_limit, i2 = i2_limit + 1; i < i_limit && i2 < (int)len; i++, i2++) {
+			int64_t tempscore = tmp1[i] + tmp2[i2];
+			int donor = 0xff, acceptor = 0xff;
+			if((uint32_t)(i + 2) < len + (uint32_t)this_ref_ext) donor = ((rf1(i + 1) << 4) | rf1(i + 2)) & 0xff;
+			if((int64_t)i2 - 2 >= -other_ref_ext) acceptor = ((rf2(i2 - 2) << 4) | rf2(i2 - 1)) & 0xff;
+			bool canonical = false, semi = false;
+			uint32_t spldir = H2G_SPL_UNKNOWN;
+			if(donor == GT && acceptor == AG) { spldir = H2G_SPL_FW; canonical = true; }
+			else if(donor == AGrc && acceptor == GTrc) { spldir = H2G_SPL_RC; canonical = true; }
+			else if((donor == GC && acceptor == AG) || (donor == AT && acceptor == AC)) { spldir = H2G_SPL_SEMI_FW; semi = true; }
+			else if((donor == AGrc && acceptor == GCrc) || (donor == ACrc && acceptor == ATrc)) { spldir = H2G_SPL_SEMI_RC; semi = true; }
+			tempscore -= (canonical ? sc.cp : sc.ncp);
+			int64_t dseq = 0, aseq = 0;
+			float splscore = 0.0f;
+			if(canonical) {
+				const int LT = (int)len + this_ref_ext, ORE = (int)other_ref_ext;
+				if(spldir == H2G_SPL_FW) {
+					if(i + 1 >= H2G_SPL_DONOR_EXONIC && LT > i + H2G_SPL_DONOR_INTRONIC && i2 + ORE >= H2G_SPL_ACC_INTRONIC && (int)len > i2 + H2G_SPL_ACC_EXONIC - 1) {
+						for(int j = i + 1 - H2G_SPL_DONOR_EXONIC; j <= i + H2G_SPL_DONOR_INTRONIC; j++) { int b = rf1(j); if(b > 3) b = 0; dseq = dseq << 2 | b; }
+						for(int j = i2 - H2G_SPL_ACC_INTRONIC; j <= i2 + H2G_SPL_ACC_EXONIC - 1; j++) { int b = rf2(j); if(b > 3) b = 0; aseq = aseq << 2 | b; }
+					}
+				} else {
+					if(i + 1 >= H2G_SPL_ACC_EXONIC && LT > i + H2G_SPL_ACC_INTRONIC && i2 + ORE >= H2G_SPL_DONOR_INTRONIC && (int)len > i2 + H2G_SPL_DONOR_EXONIC - 1) {
+						for(int j = i + H2G_SPL_ACC_INTRONIC; j >= i + 1 - H2G_SPL_ACC_EXONIC; j--) { int b = rf1(j); if(b > 3) b = 0; aseq = aseq << 2 | (b ^ 3); }
+						for(int j = i2 + H2G_SPL_DONOR_EXONIC - 1; j >= i2 - H2G_SPL_DONOR_INTRONIC; j--) { int b = rf2(j); if(b > 3) b = 0; dseq = dseq << 2 | (b ^ 3); }
+					}
+				}
+				splscore = spl_probscore(sc, dseq, aseq);
+			}
+			if((maxspldir == H2G_SPL_UNKNOWN && spldir == H2G_SPL_UNKNOWN && maxscore < tempscore) ||
+			   (maxspldir == H2G_SPL_UNKNOWN && spldir == H2G_SPL_UNKNOWN && maxscore == tempscore && semi) ||
+			   (maxspldir != H2G_SPL_UNKNOWN && spldir != H2G_SPL_UNKNOWN && (maxscore < tempscore || (maxscore == tempscore && maxsplscore < splscore))) ||
+			   (maxspldir == H2G_SPL_UNKNOWN && spldir != H2G_SPL_UNKNOWN)) {
+				maxscore = tempscore; maxscorei = (uint32_t)i; maxspldir = spldir; maxsplscore = splscore;
+				spl_probstore = splscore;   // = probscore(donor_seq, acceptor_seq) of the Edit; only read back for canonical sites (:3774)
+			}
+		}
+		if(maxscore == INT64_MIN) return false;
+		{   // anchor-length / intron-length veto for a novel site (:1797-1813)
+			const uint32_t shorter = maxscorei + 1 < len - maxscorei - 1 ? maxscorei + 1 : len - maxscorei - 1;
+			const bool noncan = maxspldir == H2G_SPL_SEMI_FW || maxspldir == H2G_SPL_SEMI_RC || maxspldir == H2G_SPL_UNKNOWN;
+			if(shorter < (noncan ? sc.minAnchorLen_noncan : sc.minAnchorLen)) {
+				uint32_t expected = sc.maxIntronLen;
+				if(noncan) { if(shorter < 16) expected = 1u << (shorter << 1); }
+				else if(shorter < 14) expected = 1u << ((shorter << 1) + 4);
+				if(expected > sc.maxIntronLen) expected = sc.maxIntronLen;
+				float prob = (float)(other_toff - this_toff) / (float)expected;
+				if(prob > 1.0f) prob = 1.0f;
+				if(prob > 0.01f) return false;
+			}
+		}
+		if(maxscore < remainsc) return false;
+	}
 	if(ins || del) {
-		if(len > 512) { a->overflow = 1; return false; }   // sc1 / sc2 capacity (reads up to 512 bp scan exactly; longer ones are flagged)
+		if(len > H2G_COMBINE_SCRATCH) { a->overflow = 1; return false; }   // temp_scores capacity (reads up to 512 bp scan exactly; longer ones are flagged)
 		const int inslen = ins ? (int)(rddif - refdif) : 0, dellen = del ? (int)(refdif - rddif) : 0;
 		int64_t gap_penalty;
 		if(ins) gap_penalty = -((int64_t)(sc.rfGapConst + sc.rfGapLinear) + (int64_t)sc.rfGapLinear * (inslen - 1));
@@ -476,7 +559,21 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 		}
 		if(clear) a->nedits = 0;
 	}
-	{
+	if(spliced) {   // :1832-1878 (splice_gap_off is never set in 2.2.3: no indel next to the site)
+		const uint32_t addoff = this_rdoff - a->rdoff;
+		for(uint32_t i = 0; i < len; i++) {
+			const int rdc = seq.at(this_rdoff + i);
+			const int64_t p2 = base2 + i;
+			const int rfc = (i <= maxscorei) ? rc1.get((int64_t)this_toff + i) : (p2 < 0 ? 4 : rc2.get(p2));
+			if(rdc != rfc) hit_push_edit(a, i + addoff, base_char(rfc), base_char(rdc), H2G_EDIT_MM);
+			if(i == maxscorei) {
+				const uint32_t left = this_toff + i + 1, right = other_toff + other_len - (len - i - 1);
+				const uint32_t skipLen = right - left;
+				if(a->nedits >= H2G_MAX_EDITS) a->overflow = 1;
+				else a->edits[a->nedits++] = make_spl_edit(i + 1 + addoff, skipLen, maxspldir, false, spl_probstore);
+			}
+		}
+	} else {
 		uint32_t ins_len = 0;
 		const uint32_t addoff = this_rdoff - a->rdoff;
 		for(uint32_t i = 0; i < len; i++) {
@@ -523,7 +620,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 		const uint32_t addoff = b->rdoff - a->rdoff;
 		for(uint32_t i = fsi; i < b->nedits; i++) {
 			hit_push_edit(a, b->edits[i].pos + addoff, b->edits[i].chr, b->edits[i].qchr, b->edits[i].type);
-			if(!a->overflow) a->edits[a->nedits - 1].snp = b->edits[i].snp;
+			if(!a->overflow) { a->edits[a->nedits - 1].snp = b->edits[i].snp; a->edits[a->nedits - 1].pad = b->edits[i].pad; }   // whole Edit (ALT id, splice fields)
 		}
 	}
 	if(ins || del) hit_left_align(a, seq);
@@ -542,6 +639,7 @@ H2G_HD bool hit_equal(const h2g_ghit* a, const h2g_ghit* b) {
 		const h2g_edit e = a->edits[i], o = b->edits[i];
 		if(e.type == H2G_EDIT_READ_GAP) { if(o.type != H2G_EDIT_READ_GAP) return false; }
 		else if(e.type == H2G_EDIT_REF_GAP) { if(o.type != H2G_EDIT_REF_GAP) return false; }
+		else if(e.type == H2G_EDIT_SPL) { if(!(o.type == H2G_EDIT_SPL && e.pos == o.pos && spl_len(e) == spl_len(o) && spl_dir(e) == spl_dir(o))) return false; }   // Edit::operator== edit.h:194
 		else if(!(e.type == o.type && e.pos == o.pos && e.chr == o.chr && e.qchr == o.qchr)) return false;
 	}
 	return true;
@@ -571,12 +669,16 @@ H2G_HD int64_t min_score_for(const AlnParams& P, uint32_t len) {
 inline AlnParams aln_params_from(const h2g_align_params& p, bool no_spliced, bool linear) {
 	AlnParams P;
 	P.khits = p.khits; P.kseeds = p.kseeds; P.no_spliced = no_spliced ? 1 : 0; P.secondary = p.secondary;
-	P.minIntronLen = 20; P.maxIntronLen = 500000; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
+	P.minIntronLen = p.min_intronlen; P.maxIntronLen = p.max_intronlen; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
 	P.pseudogeneStop = (linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
 	P.bowtie2_dp = p.bowtie2_dp;
 	P.scoreMinType = p.score_min_type; P.scoreMinConst = p.score_min_const; P.scoreMinCoeff = p.score_min_coeff;
 	P.sc.mmpMax = p.mm_max; P.sc.mmpMin = p.mm_min; P.sc.nPen = p.n_pen; P.sc.rdGapConst = p.rdg_const; P.sc.rdGapLinear = p.rdg_linear;
 	P.sc.rfGapConst = p.rfg_const; P.sc.rfGapLinear = p.rfg_linear; P.sc.scMax = p.sc_max; P.sc.scMin = p.sc_min;
+	P.sc.minAnchorLen = P.minAnchorLen; P.sc.minAnchorLen_noncan = P.minAnchorLen_noncan; P.sc.maxIntronLen = P.maxIntronLen;
+	P.sc.cp = p.pen_cansplice; P.sc.ncp = p.pen_noncansplice;
+	P.sc.icpT = p.pen_canintronlen_type; P.sc.icpC = p.pen_canintronlen_const; P.sc.icpL = p.pen_canintronlen_coeff;
+	P.sc.incpT = p.pen_noncanintronlen_type; P.sc.incpC = p.pen_noncanintronlen_const; P.sc.incpL = p.pen_noncanintronlen_coeff;
 	return P;
 }
 inline void align_params_defaults(h2g_align_params* p, bool linear) {
@@ -585,11 +687,15 @@ inline void align_params_defaults(h2g_align_params* p, bool linear) {
 	p->no_spliced_alignment = 1; p->secondary = 0; p->bowtie2_dp = 0;
 	p->mm_max = 6; p->mm_min = 2; p->n_pen = 1; p->rdg_const = 5; p->rdg_linear = 3; p->rfg_const = 5; p->rfg_linear = 3; p->sc_max = 2; p->sc_min = 1;
 	p->score_min_type = 2; p->score_min_const = 0.0; p->score_min_coeff = (double)(-0.2f);
+	p->no_temp_splicesite = 0; p->pad_ = 0;
+	p->min_intronlen = 20; p->max_intronlen = 500000; p->pen_cansplice = 0; p->pen_noncansplice = 12;   // hisat2.cpp:493-499
+	p->pen_canintronlen_type = 4; p->pen_canintronlen_const = -8.0; p->pen_canintronlen_coeff = 1.0;
+	p->pen_noncanintronlen_type = 4; p->pen_noncanintronlen_const = -8.0; p->pen_noncanintronlen_coeff = 1.0;
 }
 
 // One reported alignment = the arguments reportHit (hi_aligner.h:6064-6166) hands to AlnRes::init
 struct AlnRec {
-	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, pad;
+	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, splicescore;
 	int64_t  score;
 	h2g_edit edits[H2G_MAX_EDITS];   // as stored in the AlnRes: 5'-to-3' positions of the ORIGINAL read relative to the first aligned base
 };
@@ -685,7 +791,7 @@ struct AlignWS {
 H2G_HD h2g_edit inverted_edit(const h2g_ghit* h, uint32_t k, uint32_t sz, uint32_t add) {
 	h2g_edit e = h->edits[h->nedits - 1 - k];
 	uint32_t pos = e.pos + add;
-	e.pos = (e.type == H2G_EDIT_READ_GAP) ? sz - pos : sz - pos - 1;
+	e.pos = (e.type == H2G_EDIT_READ_GAP || e.type == H2G_EDIT_SPL) ? sz - pos : sz - pos - 1;
 	return e;
 }
 
@@ -701,6 +807,7 @@ H2G_HD bool al_redundant(const MateWS* ws, const h2g_ghit* hit, uint32_t rdlen) 
 			h2g_edit e = hit->fw ? hit->edits[k] : inverted_edit(hit, k, rdlen, 0);
 			const h2g_edit o = r.edits[k];
 			if(!(e.type == o.type && e.pos == o.pos && e.chr == o.chr && e.qchr == o.qchr)) break;
+			if(e.type == H2G_EDIT_SPL && ((e.pad ^ o.pad) & 0x7f)) break;
 		}
 		if(k >= r.nedits) return true;
 	}
@@ -722,9 +829,10 @@ H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdl
 	if(hit->score < minsc) return false;
 	if(ws->nres >= AL_MAX_RESULTS) { aw->overflow |= 4; return false; }
 	AL_TRACE("  REPORT fw %u tidx %u toff %u len %u trim %u/%u score %lld nedits %u\n", hit->fw, hit->tidx, hit->toff, hit->len, hit->trim5, hit->trim3, (long long)hit->score, hit->nedits);
+	for(uint32_t q_ = 0; q_ < hit->nedits; q_++) AL_TRACE("      edit pos %u type %u chr %u qchr %u pad %u snp %x\n", hit->edits[q_].pos, hit->edits[q_].type, hit->edits[q_].chr, hit->edits[q_].qchr, hit->edits[q_].pad, hit->edits[q_].snp);
 	AlnRec& r = ws->res[ws->nres++];
 	r.fw = hit->fw; r.tidx = hit->tidx; r.toff = hit->toff; r.len = hit->len; r.trim5 = hit->trim5; r.trim3 = hit->trim3;
-	r.nedits = hit->nedits; r.pad = 0; r.score = hit->score;
+	r.nedits = hit->nedits; r.splicescore = hit->splicescore; r.score = hit->score;
 	// reportHit shifts by trim5 and inverts for !fw (hi_aligner.h:6093-6101); AlnRes::setShape then shifts the
 	// stored copy by the 5' trim in read orientation (aligner_result.cpp:110-118)
 	const uint32_t trim5p = hit->fw ? hit->trim5 : hit->trim3;
@@ -899,7 +1007,8 @@ H2G_HD int64_t rb_search_score(const RBHit& h, uint32_t minK) {
 H2G_HD uint32_t rec_ref_extent(const AlnRec& r) {
 	uint32_t ext = r.len;
 	for(uint32_t k = 0; k < r.nedits; k++) {
-		if(r.edits[k].type == H2G_EDIT_READ_GAP) ext++;
+		if(r.edits[k].type == H2G_EDIT_SPL) ext += spl_len(r.edits[k]);
+		else if(r.edits[k].type == H2G_EDIT_READ_GAP) ext++;
 		else if(r.edits[k].type == H2G_EDIT_REF_GAP) ext--;
 	}
 	return ext;
@@ -978,7 +1087,12 @@ H2G_HD int64_t hisat2_score(const AlnRec& r) {   // AlnScore::calculate_hisat2_s
 	if(score > INT32_MAX) score = INT32_MAX; else if(score < INT32_MIN) score = INT32_MIN;
 	int64_t trim = (int64_t)r.trim5 + r.trim3;
 	trim = trim > 0xffff ? 0 : 0xffff - trim;
-	return (int64_t)((uint64_t)score << 32) | (0ll << 28) | (0ll << 24) | (255ll << 16) | trim;
+	// transcript score: 2 known transcripts (never here), 1 near splice sites = the alignment is spliced (reportHit hi_aligner.h:6100-6143)
+	int64_t tscore = 0;
+	for(uint32_t k = 0; k < r.nedits; k++) if(r.edits[k].type == H2G_EDIT_SPL) { tscore = 1; break; }
+	int64_t spl = (int64_t)r.splicescore / 100;
+	spl = spl > 255 ? 0 : 255 - spl;
+	return (int64_t)((uint64_t)score << 32) | (0ll << 28) | (tscore << 24) | (spl << 16) | trim;
 }
 
 H2G_HD uint32_t al_select(const MateWS* ws, const AlnParams& P, Rng* rnd, uint8_t* select) {

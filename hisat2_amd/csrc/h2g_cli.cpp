@@ -213,7 +213,7 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 int main(int argc, char** argv) {
 	std::string base, outfn, stats_fn;
 	std::vector<std::string> u, m1, m2;
-	bool fasta = false, nospliced = false, nohead = false, parse_only = false, no_unal = false;
+	bool fasta = false, nospliced = false, notempss = false, nohead = false, parse_only = false, no_unal = false;
 	uint64_t skip = 0, upto = ~0ull;
 	uint32_t trim5 = 0, trim3 = 0;
 	uint32_t dp = 0;
@@ -236,8 +236,11 @@ int main(int argc, char** argv) {
 		else if(a == "-q") fasta = false;
 		else if(a == "-p" || a == "--threads") threads = atoi(need("-p"));        // host threads for parsing and SAM formatting
 		else if(a == "--no-spliced-alignment") nospliced = true;
+		else if(a == "--no-temp-splicesite") notempss = true;
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
-		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min") {
+		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min" ||
+		        a == "--min-intronlen" || a == "--max-intronlen" || a == "--pen-cansplice" || a == "--pen-noncansplice" ||
+		        a == "--pen-canintronlen" || a == "--pen-intronlen" || a == "--pen-noncanintronlen") {
 			opts.push_back(a); opts.push_back(need(a.c_str()));
 		}
 		else if(a == "--secondary" || a == "--no-softclip") opts.push_back(a);
@@ -277,7 +280,11 @@ int main(int argc, char** argv) {
 		printf("%llu %llu %016llx\n", (unsigned long long)n, (unsigned long long)bases, (unsigned long long)h);
 		return 0;
 	}
-	if(!nospliced) { fprintf(stderr, "hisat2-align-amd: spliced alignment is not built yet; pass --no-spliced-alignment\n"); return 1; }
+	if(!nospliced && !notempss) {
+		fprintf(stderr, "hisat2-align-amd: spliced alignment is built for --no-temp-splicesite (novel splice sites are not shared between reads); "
+		        "pass it, or --no-spliced-alignment\n");
+		return 1;
+	}
 	const bool paired = u.empty();
 	const double t0 = now();
 	h2g_load_opts lo; h2g_load_opts_init(&lo); lo.device = device; lo.load_local = 1;
@@ -301,6 +308,7 @@ int main(int argc, char** argv) {
 	if(h2g_sam_open(base.c_str(), &sam) != H2G_OK) die("cannot read reference names");
 	h2g_align_params P; h2g_align_params_init(&P, ix);
 	P.bowtie2_dp = dp;
+	P.no_spliced_alignment = nospliced ? 1 : 0; P.no_temp_splicesite = notempss ? 1 : 0;
 	for(size_t i = 0; i < opts.size(); i++) {             // same parse rules as hisat2.cpp:1500-1620 / aligner_seed_policy.cpp
 		const std::string& o = opts[i];
 		auto two = [&](int32_t* x, int32_t* y) { const std::string& v = opts[++i]; *x = atoi(v.c_str()); const size_t c = v.find(','); if(c != std::string::npos) *y = atoi(v.c_str() + c + 1); };
@@ -325,9 +333,37 @@ int main(int argc, char** argv) {
 			const size_t c1 = v.find(',');
 			if(c1 != std::string::npos) { P.score_min_const = atof(v.c_str() + c1 + 1); const size_t c2 = v.find(',', c1 + 1); if(c2 != std::string::npos) P.score_min_coeff = atof(v.c_str() + c2 + 1); }
 		}
+		// splice scoring hisat2.cpp:1631-1688
+		else if(o == "--min-intronlen" || o == "--max-intronlen") {
+			const int v = atoi(opts[++i].c_str());
+			if(v < 20) { fprintf(stderr, "%s arg must be at least 20\n", o.c_str()); return 1; }
+			(o == "--min-intronlen" ? P.min_intronlen : P.max_intronlen) = (uint32_t)v;
+		}
+		else if(o == "--pen-cansplice" || o == "--pen-noncansplice") {
+			const int v = atoi(opts[++i].c_str());
+			if(v < 0) { fprintf(stderr, "%s arg must be at least 0\n", o.c_str()); return 1; }
+			(o == "--pen-cansplice" ? P.pen_cansplice : P.pen_noncansplice) = v;
+		}
+		else if(o == "--pen-canintronlen" || o == "--pen-intronlen" || o == "--pen-noncanintronlen") {   // PARSE_FUNC: only the given fields change
+			const bool nc = o == "--pen-noncanintronlen";
+			const std::string& v = opts[++i];
+			const uint32_t t = v[0] == 'C' ? 1 : v[0] == 'L' ? 2 : v[0] == 'S' ? 3 : v[0] == 'G' ? 4 : 0;
+			if(!t) { fprintf(stderr, "Error: bad function type in %s %s\n", o.c_str(), v.c_str()); return 1; }
+			(nc ? P.pen_noncanintronlen_type : P.pen_canintronlen_type) = t;
+			const size_t c1 = v.find(',');
+			if(c1 != std::string::npos) {
+				(nc ? P.pen_noncanintronlen_const : P.pen_canintronlen_const) = atof(v.c_str() + c1 + 1);
+				const size_t c2 = v.find(',', c1 + 1);
+				if(c2 != std::string::npos) (nc ? P.pen_noncanintronlen_coeff : P.pen_canintronlen_coeff) = atof(v.c_str() + c2 + 1);
+			}
+		}
 	}
 	// presets and the -k / --max-seeds defaults are resolved after every option was read, whatever their order (hisat2.cpp:1882-1909, 3903)
 	h2g_align_params_presets(&P, ix, saw_k ? 1 : 0, k_arg, max_seeds_arg, sensitive ? 1 : 0, very_sensitive ? 1 : 0);
+	if(P.min_intronlen > P.max_intronlen) {   // hisat2.cpp:4278
+		fprintf(stderr, "--min-intronlen(%u) should not be greater than --max-intronlen(%u)\n", P.min_intronlen, P.max_intronlen);
+		return 1;
+	}
 	if(P.khits > 30 || P.kseeds > 64 || P.kseeds < P.khits) {
 		fprintf(stderr, "hisat2-align-amd: -k %u / --max-seeds %u is outside the built range (-k <= 30, -k <= --max-seeds <= 64)\n", P.khits, P.kseeds);
 		return 1;

@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <math.h>
 #include "../../include/h2g.h"
 
 #if defined(__HIPCC__)
@@ -67,7 +68,70 @@ struct DReads {
 struct DScoring {  // Scoring defaults scoring.h:29-87 / hisat2.cpp:425-441
 	int mmpMax = 6, mmpMin = 2, nPen = 1, rdGapConst = 5, rdGapLinear = 3, rfGapConst = 5, rfGapLinear = 3;
 	int scMax = 2, scMin = 1, matchBonus = 0;
+	// spliced alignment (hisat2.cpp:493-497): --pen-cansplice 0, --pen-noncansplice 12, conflicting splice directions 1000000,
+	// --pen-canintronlen / --pen-noncanintronlen G,-8,1 (SimpleFunc LOG: C + L ln(x)); anchor / intron limits of tp.h
+	int cp = 0, ncp = 12, csp = 1000000;
+	double icpC = -8.0, icpL = 1.0, incpC = -8.0, incpL = 1.0;
+	uint32_t icpT = 4, incpT = 4;                  // SimpleFunc type of the intron-length penalties (4 = log)
+	uint32_t minAnchorLen = 7, minAnchorLen_noncan = 14, maxIntronLen = 500000;
+	// SpliceSiteDB::probscore tables (splice_site.cpp:45-105), resident in HBM; nullptr when spliced alignment is off
+	const float* donor_sum = nullptr; const float* acc_sum1 = nullptr; const float* acc_sum2 = nullptr;
 };
+
+// ---- splice edits (EDIT_TYPE_SPL): see include/h2g.h for the packing
+enum { H2G_SPL_UNKNOWN = 1, H2G_SPL_FW, H2G_SPL_RC, H2G_SPL_SEMI_FW, H2G_SPL_SEMI_RC };   // splice_site.h:37-43
+#define H2G_SPL_DONOR_EXONIC 3
+#define H2G_SPL_DONOR_INTRONIC 6
+#define H2G_SPL_ACC_INTRONIC 14
+#define H2G_SPL_ACC_EXONIC 1
+#define H2G_SPL_INTRONIC 14          // max(donor_intronic_len, acceptor_intronic_len) splice_site.h:76
+#define H2G_SPL_MAXLEN 0xfffffu
+H2G_HD uint32_t spl_len(const h2g_edit& e) { return (uint32_t)e.chr | ((uint32_t)e.qchr << 8) | (((uint32_t)e.pad & 15u) << 16); }
+H2G_HD uint32_t spl_dir(const h2g_edit& e) { return ((uint32_t)e.pad >> 4) & 7u; }
+H2G_HD bool spl_known(const h2g_edit& e) { return (e.pad >> 7) != 0; }
+H2G_HD float spl_prob(const h2g_edit& e) { float f; memcpy(&f, &e.snp, 4); return f; }
+H2G_HD h2g_edit make_spl_edit(uint32_t pos, uint32_t len, uint32_t dir, bool known, float prob) {
+	h2g_edit e;
+	e.pos = pos; e.type = H2G_EDIT_SPL;
+	e.chr = (uint8_t)(len & 0xff); e.qchr = (uint8_t)((len >> 8) & 0xff); e.pad = (uint8_t)(((len >> 16) & 15u) | ((dir & 7u) << 4) | (known ? 0x80u : 0u));
+	memcpy(&e.snp, &prob, 4);
+	return e;
+}
+// SpliceSiteDB::probscore splice_site.cpp:836-846 (old probability model: NEW_PROB_MODEL is not defined)
+H2G_HD float spl_probscore(const DScoring& sc, int64_t donor_seq, int64_t acceptor_seq) {
+	float p = sc.donor_sum[donor_seq];
+	p *= sc.acc_sum1[(int)(acceptor_seq >> 16)];            // acceptor_len2 = 8 bases
+	p *= sc.acc_sum2[(int)(acceptor_seq % (1 << 16))];
+	return (float)(1.0 / (1.0 + (double)p));
+}
+// MaxIntronLen / MaxIntronLen_noncan hi_aligner.h:48-79
+H2G_HD uint32_t max_intron_len(uint32_t anchor, uint32_t minAnchorLen) {
+	if(anchor < minAnchorLen) return 0;
+	if(anchor < 2) anchor = 2;
+	uint32_t shift = (anchor << 1) - 4;
+	shift = shift < 13 ? 13 : shift; shift = shift > 30 ? 30 : shift;
+	return 1u << shift;
+}
+H2G_HD uint32_t max_intron_len_noncan(uint32_t anchor, uint32_t minAnchorLen_noncan) {
+	if(anchor < minAnchorLen_noncan) return 0;
+	if(anchor < 5) anchor = 5;
+	uint32_t shift = (anchor << 1) - 10;
+	shift = shift > 30 ? 30 : shift;
+	return 1u << shift;
+}
+// Scoring::canSpl / noncanSpl scoring.h:473-487 with the default minanchor (100): intron-length term SimpleFunc::f<int>
+H2G_HD int64_t spl_penalty(const DScoring& sc, bool canonical, int intronlen) {
+	const double C = canonical ? sc.icpC : sc.incpC, L = canonical ? sc.icpL : sc.incpL;
+	const uint32_t T = canonical ? sc.icpT : sc.incpT;
+	int pen = 0;
+	if(intronlen > 0) {
+		const double x = (double)intronlen;
+		const double X = T == 1 ? 0.0 : T == 2 ? x : T == 3 ? sqrt(x) : log(x);   // SimpleFunc::f simple_func.h:88-110
+		pen = (int)(C + L * X);
+	}
+	if(pen < 0) pen = 0;
+	return (int64_t)pen + (canonical ? sc.cp : sc.ncp);
+}
 
 // Read in search orientation: fw -> patFw, !fw -> patRc (Read::constructRevComps read.h:138)
 struct SeqView {
@@ -411,31 +475,79 @@ H2G_HD int sc_penalty(const DScoring& sc, int q) {   // Scoring::sc scoring.h:31
 	return (int)(((float)q / 40.0f) * (float)(sc.scMax - sc.scMin) + (float)sc.scMin);
 }
 
-// GenomeHit::calculateScore hi_aligner.h:3711-3891 (mismatch / gap / soft-clip terms; no splice edits)
+// GenomeHit::calculateScore hi_aligner.h:3711-3891
 H2G_HD int64_t calculate_score(const DScoring& sc, const SeqView& seq, h2g_ghit* h) {
 	int64_t score = 0;
-	uint32_t mm = 0;
+	double splicescore = 0;
+	uint32_t mm = 0, numsplices = 0;
+	const uint32_t rdlen = seq.len;
+	bool conflict = false;
+	uint32_t whichsense = H2G_SPL_UNKNOWN;
 	for(uint32_t i = 0; i < h->nedits; i++) {
 		const h2g_edit e = h->edits[i];
-		if(e.snp != H2G_MAX) continue;                     // edits through known variants cost nothing (:3737, :3846, :3858)
+		if(e.type == H2G_EDIT_SPL) {
+			const uint32_t splLen = spl_len(e), splDir = spl_dir(e);
+			const bool can = splDir == H2G_SPL_FW || splDir == H2G_SPL_RC;
+			if(!spl_known(e)) {
+				int left_anchor = (int)(h->rdoff + e.pos), right_anchor = (int)rdlen - left_anchor;
+				uint32_t mm2 = 0;
+				for(uint32_t j = i + 1; j < h->nedits; j++) { const uint8_t t = h->edits[j].type; if(t == H2G_EDIT_MM || t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP) mm2++; }
+				left_anchor -= (int)(mm * 2); right_anchor -= (int)(mm2 * 2);
+				int shorter = left_anchor < right_anchor ? left_anchor : right_anchor;
+				if(shorter <= 0) shorter = 1;
+				const uint32_t thresh = can ? max_intron_len((uint32_t)shorter, sc.minAnchorLen) : max_intron_len_noncan((uint32_t)shorter, sc.minAnchorLen_noncan);
+				if(thresh < sc.maxIntronLen) {
+					if(splLen > thresh) score += INT32_MIN;
+					if(can) {
+						const float probscore = spl_prob(e);
+						float pt = 0.8f;
+						if(splLen >> 16) pt = 0.99f; else if(splLen >> 15) pt = 0.97f; else if(splLen >> 14) pt = 0.94f; else if(splLen >> 13) pt = 0.91f; else if(splLen >> 12) pt = 0.88f;
+						if(probscore < pt) score += INT32_MIN;
+					}
+					if(shorter == left_anchor) {
+						if(h->trim5 > 0) score += INT32_MIN;
+						for(int j = (int)i - 1; j >= 0; j--) { const uint8_t t = h->edits[j].type; if(t == H2G_EDIT_MM || t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP) score += INT32_MIN; }
+					} else {
+						if(h->trim3 > 0) score += INT32_MIN;
+						for(uint32_t j = i + 1; j < h->nedits; j++) { const uint8_t t = h->edits[j].type; if(t == H2G_EDIT_MM || t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP) score += INT32_MIN; }
+					}
+				}
+				score -= spl_penalty(sc, can, (int)splLen);
+				if(shorter <= 15) { numsplices++; splicescore += (double)splLen; }
+			}
+			if(!conflict) {
+				if(whichsense == H2G_SPL_UNKNOWN) whichsense = splDir;
+				else if(splDir != H2G_SPL_UNKNOWN) {
+					if((splDir == H2G_SPL_FW || splDir == H2G_SPL_SEMI_FW) && whichsense != H2G_SPL_FW && whichsense != H2G_SPL_SEMI_FW) conflict = true;
+					if((splDir == H2G_SPL_RC || splDir == H2G_SPL_SEMI_RC) && whichsense != H2G_SPL_RC && whichsense != H2G_SPL_SEMI_RC) conflict = true;
+				}
+			}
+			continue;
+		}
 		if(e.type == H2G_EDIT_MM) {
+			if(e.snp != H2G_MAX) continue;                 // edits through known variants cost nothing (:3737, :3846, :3858)
 			int q = seq.qual(h->rdoff + e.pos) - 33;
 			if(e.qchr == 'N') score -= sc.nPen;            // Scoring::score scoring.h:259-269: rdc > 3
 			else if(e.chr == 'N') score += sc.matchBonus;  // ref mask 15 contains every base
 			else score -= mm_penalty(sc, q);
 			mm++;
 		} else if(e.type == H2G_EDIT_READ_GAP) {
+			if(e.snp != H2G_MAX) continue;
 			bool open = !(i > 0 && h->edits[i - 1].type == H2G_EDIT_READ_GAP && h->edits[i - 1].pos == e.pos);
 			score -= open ? (sc.rdGapConst + sc.rdGapLinear) : sc.rdGapLinear;
 		} else if(e.type == H2G_EDIT_REF_GAP) {
+			if(e.snp != H2G_MAX) continue;
 			bool open = !(i > 0 && h->edits[i - 1].type == H2G_EDIT_REF_GAP && h->edits[i - 1].pos + 1 == e.pos);
 			score -= open ? (sc.rfGapConst + sc.rfGapLinear) : sc.rfGapLinear;
 		}
 	}
 	for(uint32_t i = 0; i < h->trim5; i++) score -= sc_penalty(sc, seq.qual(i));   // :3868-3874 (qual[i] both times)
 	for(uint32_t i = 0; i < h->trim3; i++) score -= sc_penalty(sc, seq.qual(i));
+	if(conflict) score -= sc.csp;
+	if(numsplices > 1) splicescore /= (double)numsplices;
 	score += (int64_t)(h->len - mm) * sc.matchBonus;
 	h->score = score;
+	h->splicescore = (uint32_t)(int64_t)splicescore;       // AlnScore keeps it as a TAlScore (truncated)
 	return score;
 }
 
@@ -444,7 +556,7 @@ H2G_HD int64_t calculate_score(const DScoring& sc, const SeqView& seq, h2g_ghit*
 H2G_HD uint8_t base_char(int c) { return (uint8_t)("ACGTN"[c]); }
 H2G_HD bool is_gap(uint8_t t) { return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
 // the edits getLeft / getRight / combineWith stop at: gaps and mismatches through a known SNP (hi_aligner.h:937-940, :981-984)
-H2G_HD bool is_stop_edit(const h2g_edit& e) { return is_gap(e.type) || (e.type == H2G_EDIT_MM && e.snp != H2G_MAX); }
+H2G_HD bool is_stop_edit(const h2g_edit& e) { return e.type == H2G_EDIT_SPL || is_gap(e.type) || (e.type == H2G_EDIT_MM && e.snp != H2G_MAX); }
 
 // alignWithALTs (hi_aligner.h:683-783) over alignWithALTs_recur without ALTs (:2763-2853 left,
 // :3168-3216 right).  Edits are committed in place instead of through a scratch copy.
@@ -511,11 +623,11 @@ H2G_HD uint32_t align_no_alts(const DRef& ref, const SeqView& seq, uint32_t base
 		if(left) { f = tmp_mm ? ne[tmp_mm - 1] : h->edits[0]; b = n_old ? h->edits[n_old - 1] : ne[0]; }
 		else     { f = n_old ? h->edits[0] : ne[0];            b = tmp_mm ? ne[tmp_mm - 1] : h->edits[n_old - 1]; }
 		if(f.pos + extlen == base_rdoff + 1) {
-			if(is_gap(f.type)) extlen = 0;
+			if(is_gap(f.type) || f.type == H2G_EDIT_SPL) extlen = 0;
 			if(f.type == H2G_EDIT_MM && f.chr == 'N') extlen = 0;
 		}
 		if(extlen > 0 && b.pos == rdoff - base_rdoff + extlen - 1) {
-			if(is_gap(b.type)) extlen = 0;
+			if(is_gap(b.type)) extlen = 0;   // the back test covers gaps only (:769-773)
 		}
 	}
 	if(extlen > 0 && tmp_mm > 0) {   // commit the new edits
@@ -545,6 +657,7 @@ H2G_HD void hit_get_right(const h2g_ghit* h, uint32_t* rdoff, uint32_t* len, uin
 			for(uint32_t k = 0; k < h->nedits; k++) {
 				if(h->edits[k].type == H2G_EDIT_READ_GAP) roff++;
 				else if(h->edits[k].type == H2G_EDIT_REF_GAP) roff--;
+				else if(h->edits[k].type == H2G_EDIT_SPL) roff += spl_len(h->edits[k]);
 			}
 			*toff = roff - *len;
 			return;
@@ -576,6 +689,7 @@ H2G_HD bool extend_item(const DRef& ref, const DScoring& sc, const SeqView& seq,
 			for(uint32_t i = 0; i < added; i++) {
 				if(h->edits[i].type == H2G_EDIT_REF_GAP) ref_ext--;
 				else if(h->edits[i].type == H2G_EDIT_READ_GAP) ref_ext++;
+				else if(h->edits[i].type == H2G_EDIT_SPL) ref_ext += (int)spl_len(h->edits[i]);
 			}
 			h->rdoff -= best_ext;
 			h->toff -= (uint32_t)ref_ext;

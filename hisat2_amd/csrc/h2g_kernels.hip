@@ -15,6 +15,7 @@
 #include "h2g_graph.h"
 #include "h2g_sw.h"
 #include "h2g_local_pack.h"
+#include "h2g_splice_host.h"
 #include "h2g_go_args.h"   // GoArgs + the extern "C" face of the go() units (their AlignWS layouts are opaque on this side)
 
 using namespace h2g;
@@ -39,6 +40,7 @@ struct h2g_index {
 	DLocalSet dls;
 	DAlts dalts;
 	bool has_local = false;
+	const float* d_spl[3] = {nullptr, nullptr, nullptr};   // SpliceSiteDB::probscore tables (donor, acceptor halves), uploaded with the index
 	std::vector<DLocalDesc> h_ldesc;   // host copy of the local-index descriptors (bucketing of h2g_ext_search)
 	std::vector<void*> allocs;
 	uint64_t device_bytes = 0;
@@ -166,6 +168,11 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		ix->dls = lp.view(dd, ds, dw, df, dz);
 		ix->h_ldesc = lp.desc;
 		ix->has_local = true;
+	}
+	{   // splice-site probability tables (spliced alignment): 1.4 MB, index-independent
+		std::vector<float> d, a1, a2;
+		splice_tables(d, a1, a2);
+		if((s = upload(ix, d, &ix->d_spl[0])) || (s = upload(ix, a1, &ix->d_spl[1])) || (s = upload(ix, a2, &ix->d_spl[2]))) { h2g_index_free(ix); return s; }
 	}
 	*out = ix;
 	return H2G_OK;
@@ -1418,8 +1425,18 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if((rc = need_reads(s)) || (rc = need_alignable(s))) return rc;
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names || (paired && !s->has_mates)) { snprintf(g_err, sizeof g_err, "align: read names (h2g_set_read_names)%s not set", paired ? " / mates (h2g_set_mates)" : ""); return H2G_ERR_ARG; }
-	if(!p->no_spliced_alignment) { snprintf(g_err, sizeof g_err, "align: spliced alignment not built yet"); return H2G_ERR_UNSUPPORTED; }
 	const bool linear = s->ix->dg.linear != 0;
+	if(!p->no_spliced_alignment) {
+		// spliced alignment: combineWith places introns (hi_aligner.h:1588-1739) and every read is independent when novel splice
+		// sites are not shared (--no-temp-splicesite); the shared SpliceSiteDB of the default mode and graph indexes are not built
+		if(!p->no_temp_splicesite) { snprintf(g_err, sizeof g_err, "align: spliced alignment is built for --no-temp-splicesite (no SpliceSiteDB shared between reads)"); return H2G_ERR_UNSUPPORTED; }
+		if(!linear) { snprintf(g_err, sizeof g_err, "align: spliced alignment is built for linear indexes"); return H2G_ERR_UNSUPPORTED; }
+		if(p->pen_canintronlen_type < 1 || p->pen_canintronlen_type > 4 || p->pen_noncanintronlen_type < 1 || p->pen_noncanintronlen_type > 4 ||
+		   p->min_intronlen < 20 || p->max_intronlen < p->min_intronlen || p->pen_cansplice < 0 || p->pen_noncansplice < 0) {
+			snprintf(g_err, sizeof g_err, "align: splice scoring outside its range (intron-length function type 1..4, 20 <= min_intronlen <= max_intronlen, penalties >= 0)");
+			return H2G_ERR_ARG;
+		}
+	}
 	const uint32_t maxsz = p->khits > p->kseeds ? p->khits : p->kseeds;
 	uint32_t caps[5], bcaps[5];
 	go_unit(linear, false).caps(caps); go_unit(linear, true).caps(bcaps);
@@ -1432,7 +1449,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if(s->max_read_len == 0) return H2G_ERR_ARG;
 		// a read longer than H2G_SW_MAX_ROWS is flagged by the kernel (overflow bit 256) instead of run through the DP
 		// SwAligner::align switches to 16-bit scores when minsc < -254 (aligner_sw.cpp:494-504); only the 8-bit fill is built
-		const AlnParams Pq = aln_params_from(*p, true, linear);
+		const AlnParams Pq = aln_params_from(*p, p->no_spliced_alignment != 0, linear);
 		const uint32_t swlen = s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len;
 		if(min_score_for(Pq, swlen) < -254) { snprintf(g_err, sizeof g_err, "bowtie2_dp: --score-min gives %lld for %u-base reads; below -254 the reference runs its 16-bit DP, which is not built", (long long)min_score_for(Pq, s->max_read_len), s->max_read_len); return H2G_ERR_UNSUPPORTED; }
 	}
@@ -1459,7 +1476,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	A.g = s->ix->dg; A.ref = s->ix->dr; A.ls = s->ix->dls; A.alts = s->ix->dalts;
 	A.rd1 = dreads(s); A.rd2 = A.rd1;
 	if(paired) { A.rd2.codes = s->d_codes2; A.rd2.offs = s->d_offs2; A.rd2.quals = s->has_quals2 ? s->d_quals2 : nullptr; }
-	A.P = aln_params_from(*p, true, linear);
+	A.P = aln_params_from(*p, p->no_spliced_alignment != 0, linear);
+	if(!p->no_spliced_alignment) { A.P.sc.donor_sum = s->ix->d_spl[0]; A.P.sc.acc_sum1 = s->ix->d_spl[1]; A.P.sc.acc_sum2 = s->ix->d_spl[2]; }
 	A.names1 = s->d_names; A.noffs1 = s->d_name_offs; A.names2 = s->d_names2; A.noffs2 = s->d_name_offs2;
 	A.paired = paired ? 1u : 0u;
 	if((rc = go_pool_for(s, 0, U, (size_t)grid * geo[1], (size_t)grid * block, p->bowtie2_dp, &A))) return rc;
@@ -1580,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_gather_aln(const h2g_alnres* src, uint3
 	h2g_alnres* d = dst + offs[i];
 	for(uint32_t k = 0; k < c; k++) {
 		d[k].fw = a[k].fw; d[k].tidx = a[k].tidx; d[k].toff = a[k].toff; d[k].len = a[k].len; d[k].trim5 = a[k].trim5; d[k].trim3 = a[k].trim3;
-		d[k].nedits = a[k].nedits; d[k].pad = 0; d[k].score = a[k].score;
+		d[k].nedits = a[k].nedits; d[k].splicescore = a[k].splicescore; d[k].score = a[k].score;
 		for(uint32_t e = 0; e < a[k].nedits && e < H2G_MAX_EDITS; e++) d[k].edits[e] = a[k].edits[e];
 	}
 }

@@ -667,7 +667,7 @@ again:
 	case PC_L_LS_DONE: {
 		Frame& f = FR;
 		f.ncoords = 0; f.ri = -1;
-		AL_TRACE("    L local lidx %u extoff %u extlen %u nelt %u top %u bot %u unique %d noext %d\n", f.lidx, f.extoff, f.extlen, f.nelt, f.top, f.bot, (int)f.uniqueStop, (int)f.noext);
+		AL_TRACE("    L local lidx %u extoff %u extlen %u nelt %u top %u bot %u unique %d noext %d atts %llu/%llu\n", f.lidx, f.extoff, f.extlen, f.nelt, f.top, f.bot, (int)f.uniqueStop, (int)f.noext, (unsigned long long)ws->localindexatts, (unsigned long long)ws->max_localindexatts);
 		if(f.nelt > 0 && f.nelt <= 5 && f.extlen >= P.minAnchorLen && !f.noext) {
 			L.a0 = f.lidx; L.a1 = f.top; L.a2 = f.bot; L.a3 = f.extoff + 1 - f.extlen; L.a4 = f.extlen; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
 			M_OP(OP_LCOORDS, PC_L_LC_AFTER);
@@ -896,6 +896,7 @@ again:
 	case PC_R_LS_DONE: {
 		Frame& f = FR;
 		f.ncoords = 0; f.ri = 0;
+		AL_TRACE("    R local lidx %u extoff %u extlen %u nelt %u top %u bot %u unique %d noext %d atts %llu/%llu\n", f.lidx, f.extoff, f.extlen, f.nelt, f.top, f.bot, (int)f.uniqueStop, (int)f.noext, (unsigned long long)ws->localindexatts, (unsigned long long)ws->max_localindexatts);
 		if(f.nelt > 0 && f.nelt <= 5 && f.extlen >= P.minAnchorLen && !f.noext) {
 			L.a0 = f.lidx; L.a1 = f.top; L.a2 = f.bot; L.a3 = f.extoff + 1 - f.extlen; L.a4 = f.extlen; L.a5 = AL_MAX_COORDS; L.p0 = f.coords;
 			M_OP(OP_LCOORDS, PC_R_LC_AFTER);
@@ -1197,7 +1198,7 @@ H2G_HD void mach_op_sw(const AlnCtx& C, Mach& M) {
 
 H2G_HD void mach_copy_rec(h2g_alnres& d, const AlnRec& r) {
 	d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
-	d.nedits = r.nedits; d.pad = 0; d.score = r.score;
+	d.nedits = r.nedits; d.splicescore = r.splicescore; d.score = r.score;
 	for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
 }
 

@@ -39,7 +39,10 @@ struct h2g_sam {
 
 namespace {
 
-enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3 };                      // edit.h:41-46
+enum { EDIT_READ_GAP = 1, EDIT_REF_GAP = 2, EDIT_MM = 3, EDIT_SPL = 5 };        // edit.h:36-42
+// splice edits keep splLen / splDir in chr, qchr, pad (include/h2g.h)
+inline uint32_t spl_len(const h2g_edit& e) { return (uint32_t)e.chr | ((uint32_t)e.qchr << 8) | (((uint32_t)e.pad & 15u) << 16); }
+inline uint32_t spl_dir(const h2g_edit& e) { return ((uint32_t)e.pad >> 4) & 7u; }
 enum { ALT_SGL = 1, ALT_INS = 2, ALT_DEL = 3 };                                 // alt.h:31-39
 enum { PAIR_CONCORD_M1 = 1, PAIR_CONCORD_M2, PAIR_DISCORD_M1, PAIR_DISCORD_M2, PAIR_UNP_M1, PAIR_UNP_M2, PAIR_UNPAIRED };   // aligner_result.h:404-412
 
@@ -49,13 +52,22 @@ struct Score {        // AlnScore (aligner_result.h:44-330): score, then hisat2_
 	bool gt(const Score& o) const { if(!o.valid) return valid; if(!valid) return false; return score > o.score || (score == o.score && h2 > o.h2); }
 	bool eq(const Score& o) const { return valid && o.valid && score == o.score && h2 == o.h2; }
 };
-// AlnScore::calculate_hisat2_score aligner_result.h:322-350 without repeat / transcript / splice terms
-int64_t hisat2_score(int64_t sc, uint32_t trim) {
+// AlnScore::calculate_hisat2_score aligner_result.h:322-350: score, repeat (never), transcript (1 = spliced: near splice sites,
+// reportHit hi_aligner.h:6100-6143), splice score (mean intron length of the short-anchored splices / 100), trimmed bases
+int64_t hisat2_score(int64_t sc, uint32_t trim, bool spliced = false, uint32_t splicescore = 0) {
 	if(sc > INT32_MAX) sc = INT32_MAX; else if(sc < INT32_MIN) sc = INT32_MIN;
 	const int64_t t = trim > 0xFFFF ? 0 : 0xFFFF - (int64_t)trim;
-	return (int64_t)(((uint64_t)sc << 32) | (255ull << 16) | (uint64_t)t);
+	int64_t spl = (int64_t)splicescore / 100;
+	spl = spl > 255 ? 0 : 255 - spl;
+	return (int64_t)(((uint64_t)sc << 32) | ((uint64_t)(spliced ? 1 : 0) << 24) | ((uint64_t)spl << 16) | (uint64_t)t);
 }
-Score score_of(const h2g_alnres& r) { Score s; s.valid = true; s.score = r.score; s.h2 = hisat2_score(r.score, r.trim5 + r.trim3); return s; }
+Score score_of(const h2g_alnres& r) {
+	Score s; s.valid = true; s.score = r.score;
+	bool spliced = false;
+	for(uint32_t i = 0; i < r.nedits; i++) if(r.edits[i].type == EDIT_SPL) { spliced = true; break; }
+	s.h2 = hisat2_score(r.score, r.trim5 + r.trim3, spliced, r.splicescore);
+	return s;
+}
 Score add(const Score& a, const Score& b) { Score s; s.valid = a.valid; s.score = a.score + b.score; s.h2 = a.h2 + b.h2; return s; }
 
 struct Flags {        // AlnFlags (aligner_result.h:414-640); the filters are "passed" bits
@@ -128,29 +140,30 @@ int mapq_v2(const h2g_sam& S, const Summ& s, bool mate1, uint32_t rdlen, uint32_
 	return ret;
 }
 
-struct Ed { uint32_t pos; char chr, qchr; uint8_t type; uint32_t snp; };
+struct Ed { uint32_t pos; char chr, qchr; uint8_t type; uint32_t snp; uint32_t skip; };
 // Edit::invertPoss(edits, sz, false) edit.cpp:69-96
 void invert(std::vector<Ed>& e, uint32_t sz) {
 	std::reverse(e.begin(), e.end());
-	for(auto& x : e) x.pos = x.type == EDIT_READ_GAP ? sz - x.pos : sz - x.pos - 1;
+	for(auto& x : e) x.pos = (x.type == EDIT_READ_GAP || x.type == EDIT_SPL) ? sz - x.pos : sz - x.pos - 1;
 }
-struct Stacked { std::string ref, rel, read; std::vector<uint8_t> snp; uint32_t trimLS = 0, trimRS = 0; };
+struct Stacked { std::string ref, rel, read; std::vector<uint8_t> snp; std::vector<uint32_t> skip; uint32_t trimLS = 0, trimRS = 0; };
 // AlnRes::initStacked aligner_result.h:1856 + StackedAln::init aligner_result.cpp:660-728 + leftAlign(false) :746-791
 void stack_alignment(const h2g_alnres& r, const std::string& seq /* aligned strand, ASCII */, Stacked& st) {
 	static thread_local std::vector<Ed> ed;
 	ed.resize(r.nedits);
-	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = r.edits[i].pos; ed[i].chr = (char)r.edits[i].chr; ed[i].qchr = (char)r.edits[i].qchr; ed[i].type = r.edits[i].type; ed[i].snp = r.edits[i].snp; }
+	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = r.edits[i].pos; ed[i].chr = (char)r.edits[i].chr; ed[i].qchr = (char)r.edits[i].qchr; ed[i].type = r.edits[i].type; ed[i].snp = r.edits[i].snp; ed[i].skip = r.edits[i].type == EDIT_SPL ? spl_len(r.edits[i]) : 0; }
 	// h2g_alnres trims are those of the GenomeHit (left / right of the aligned strand) == trimLS / trimRS after the swap
 	st.trimLS = r.trim5; st.trimRS = r.trim3;
 	const uint32_t len_trimmed = (uint32_t)seq.size() - st.trimLS - st.trimRS;
 	if(!r.fw) invert(ed, len_trimmed);
-	st.ref.clear(); st.rel.clear(); st.read.clear(); st.snp.clear();
+	st.ref.clear(); st.rel.clear(); st.read.clear(); st.snp.clear(); st.skip.clear();
 	size_t rdoff = st.trimLS;
 	auto match_to = [&](size_t pos) { while(rdoff < pos) { const char c = seq[rdoff++]; st.ref.push_back(c); st.rel.push_back('='); st.snp.push_back(0); st.read.push_back(c); } };
 	for(const Ed& e : ed) {
 		match_to(e.pos + st.trimLS);
 		const uint8_t sn = e.snp != 0xffffffffu;
-		if(e.type == EDIT_MM)            { const char c = seq[rdoff++]; st.ref.push_back(e.chr); st.rel.push_back('X'); st.snp.push_back(sn); st.read.push_back(c); }
+		if(e.type == EDIT_SPL)           { st.ref.push_back('N'); st.rel.push_back('N'); st.snp.push_back(0); st.read.push_back('N'); st.skip.push_back(e.skip); }
+		else if(e.type == EDIT_MM)            { const char c = seq[rdoff++]; st.ref.push_back(e.chr); st.rel.push_back('X'); st.snp.push_back(sn); st.read.push_back(c); }
 		else if(e.type == EDIT_REF_GAP)  { const char c = seq[rdoff++]; st.ref.push_back('-');   st.rel.push_back('I'); st.snp.push_back(sn); st.read.push_back(c); }
 		else if(e.type == EDIT_READ_GAP) {                               st.ref.push_back(e.chr); st.rel.push_back('D'); st.snp.push_back(sn); st.read.push_back('-'); }
 	}
@@ -180,12 +193,15 @@ void stack_alignment(const h2g_alnres& r, const std::string& seq /* aligned stra
 void write_cigar(const Stacked& st, std::string& o) {
 	if(st.trimLS > 0) { put(o, st.trimLS); o.push_back('S'); }
 	const size_t ln = st.rel.size();
+	size_t nskip = 0;
 	for(size_t i = 0; i < ln; i++) {
 		char op = st.rel[i];
 		if(op == 'X' || op == '=') op = 'M';
 		size_t run = 1;
-		for(; i + run < ln; run++) { char op2 = st.rel[i + run]; if(op2 == 'X' || op2 == '=') op2 = 'M'; if(op2 != op) break; }
-		i += run - 1;
+		if(op != 'N') {
+			for(; i + run < ln; run++) { char op2 = st.rel[i + run]; if(op2 == 'X' || op2 == '=') op2 = 'M'; if(op2 != op) break; }
+			i += run - 1;
+		} else run = st.skip[nskip++];
 		put(o, (int64_t)run); o.push_back(op);
 	}
 	if(st.trimRS > 0) { put(o, st.trimRS); o.push_back('S'); }
@@ -198,7 +214,7 @@ void write_mdz(const Stacked& st, std::string& o) {
 		const char op = st.rel[i];
 		if(op == '=') {
 			size_t run = 1, nins = 0;
-			for(; i + run < ln; run++) { if(st.rel[i + run] == '=') {} else if(st.rel[i + run] == 'I') nins++; else break; }
+			for(; i + run < ln; run++) { if(st.rel[i + run] == '=') {} else if(st.rel[i + run] == 'I' || st.rel[i + run] == 'N') nins++; else break; }
 			i += run - 1;
 			if(run - nins > 0) { put(o, (int64_t)(run - nins)); first_print = false; mm_last = false; rdgap_last = false; }
 		} else if(op == 'X') {
@@ -234,16 +250,23 @@ void put_read_name(std::string& o, const Rd& r, bool omitSlashMate) {
 // SamConfig::printRefName: the name up to the first whitespace
 void put_ref_name(std::string& o, const std::string& name) { for(char c : name) { if(isspace((unsigned char)c)) break; o.push_back(c); } }
 
-// reference extent of an alignment (AlnRes::calcRefExtent aligner_result.h:1880)
-int64_t ref_extent(const h2g_alnres& r) {
-	int64_t e = r.len;
-	for(uint32_t i = 0; i < r.nedits; i++) { if(r.edits[i].type == EDIT_REF_GAP) e--; else if(r.edits[i].type == EDIT_READ_GAP) e++; }
-	return e;
-}
-// AlnRes::setFragmentLength aligner_result.h:1631-1697 without splice sites; trims extend both ends (getExtendedCoords :1156)
+// AlnRes::setFragmentLength aligner_result.h:1631-1697 with an empty splice-site database; trims extend both ends
+// (getExtendedCoords :1156).  rfextent_ does not count introns (calcRefExtent :1880) while refcoord_right() does (:1256), so
+// each alignment has two (start, end) pairs — (st, en) anchored at its left end, (st2, en2) at its right end — and the
+// upstream mate enters with the right-anchored pair: introns inside the mates do not count towards TLEN.
 int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1) {
-	const int64_t st = (int64_t)me.toff - me.trim5, en = (int64_t)me.toff + ref_extent(me) - 1 + me.trim3;
-	const int64_t ost = (int64_t)o.toff - o.trim5, oen = (int64_t)o.toff + ref_extent(o) - 1 + o.trim3;
+	auto coords = [](const h2g_alnres& r, int64_t& st, int64_t& en, int64_t& st2, int64_t& en2) {
+		int64_t ext = r.len, spl = 0;
+		for(uint32_t i = 0; i < r.nedits; i++) {
+			if(r.edits[i].type == EDIT_REF_GAP) ext--; else if(r.edits[i].type == EDIT_READ_GAP) ext++;
+			else if(r.edits[i].type == EDIT_SPL) spl += spl_len(r.edits[i]);
+		}
+		st = (int64_t)r.toff - r.trim5; en = (int64_t)r.toff + ext - 1 + r.trim3;
+		st2 = st + spl; en2 = en + spl;
+	};
+	int64_t st, en, st2, en2, ost, oen, ost2, oen2;
+	coords(me, st, en, st2, en2);
+	coords(o, ost, oen, ost2, oen2);
 	bool imUpstream;
 	if(st < ost) imUpstream = true;
 	else if(st == ost) {
@@ -251,7 +274,8 @@ int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1)
 		else if(me.fw && !o.fw) imUpstream = true;
 		else imUpstream = false;
 	} else imUpstream = false;
-	const int64_t up = std::min(st, ost), dn = std::max(en, oen);
+	const int64_t up = imUpstream ? std::min(st2, ost) : std::min(st, ost2);
+	const int64_t dn = imUpstream ? std::max(en2, oen) : std::max(en, oen2);
 	int64_t fl = 1 + dn - up;
 	return imUpstream ? fl : -fl;
 }
@@ -324,6 +348,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	size_t num_mm = 0, num_go = 0, num_gx = 0, NM = 0;
 	for(uint32_t i = 0; i < rs->nedits; i++) {                            // on the edits as stored (5'-relative)
 		const h2g_edit* e = rs->edits;
+		if(e[i].type == EDIT_SPL) continue;
 		if(e[i].type == EDIT_MM) { if(e[i].snp >= nalts) num_mm++; }
 		else if(e[i].type == EDIT_READ_GAP) {
 			if(e[i].snp >= nalts) { num_go++; num_gx++; }
@@ -333,7 +358,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 			while(i + 1 < rs->nedits && e[i + 1].pos == e[i].pos + 1 && e[i + 1].type == EDIT_REF_GAP) { i++; if(e[i].snp >= nalts) num_gx++; }
 		}
 	}
-	for(uint32_t i = 0; i < rs->nedits; i++) if(rs->edits[i].snp >= nalts) NM++;
+	for(uint32_t i = 0; i < rs->nedits; i++) if(rs->edits[i].type != EDIT_SPL && rs->edits[i].snp >= nalts) NM++;
 	o += "\tXM:i:"; put(o, (int64_t)num_mm);
 	o += "\tXO:i:"; put(o, (int64_t)num_go);
 	o += "\tXG:i:"; put(o, (int64_t)num_gx);
@@ -343,6 +368,19 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	o += "\tYT:Z:";
 	o += fl.concordant() ? "CP" : fl.discordant() ? "DP" : fl.unpairedMate() ? "UP" : "UU";
 	if(!fl.lenfilt) o += "\tYF:Z:LN"; else if(!fl.nfilt) o += "\tYF:Z:NS";
+	{   // XS:A: sam.h:925-940 with AlnRes::spliced_whichsense_transcript aligner_result.h:1289 (unstranded library)
+		uint32_t sense = 1;
+		for(uint32_t i = 0; i < rs->nedits; i++) {
+			if(rs->edits[i].type != EDIT_SPL) continue;
+			const uint32_t d = spl_dir(rs->edits[i]);
+			if(sense == 1) sense = d;
+			else if(d != 1) {
+				if((sense == 2 || sense == 4) && d != 2 && d != 4) { sense = 1; break; }
+				if((sense == 3 || sense == 5) && d != 3 && d != 5) { sense = 1; break; }
+			}
+		}
+		if(sense != 1) { o += "\tXS:A:"; o.push_back((sense == 2 || sense == 4) ? '+' : '-'); }
+	}
 	o += "\tNH:i:"; put(o, (int64_t)nh);
 	// Zs:Z (sam.h:985-1030): the known variants the alignment goes through, positions relative to the previous one
 	{

@@ -161,11 +161,15 @@ H2G_EXPORT h2g_status h2g_sa_resolve_graph(h2g_stream*, const h2g_gsa_query* q, 
 
 /* GenomeHit::extend (hi_aligner.h:2031-2232) incl. alignWithALTs (:683) and calculateScore (:3711) */
 #define H2G_MAX_EDITS 32
-enum { H2G_EDIT_READ_GAP = 1, H2G_EDIT_REF_GAP = 2, H2G_EDIT_MM = 3 };  /* edit.h:37-39 */
+enum { H2G_EDIT_READ_GAP = 1, H2G_EDIT_REF_GAP = 2, H2G_EDIT_MM = 3, H2G_EDIT_SPL = 5 };  /* edit.h:36-42 */
+/* An H2G_EDIT_SPL edit (an intron, CIGAR N) keeps Edit::splLen / splDir / knownSpl in the three bytes chr, qchr, pad:
+ * splLen = chr | qchr << 8 | (pad & 15) << 16 (introns up to 2^20), splDir = (pad >> 4) & 7 (splice_site.h:37-43: 1 unknown, 2 +, 3 -,
+ * 4 semi +, 5 semi -), knownSpl = pad >> 7; `snp` holds the float bits of SpliceSiteDB::probscore(donor_seq, acceptor_seq). */
 typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; uint32_t snp; /* Edit::snpID: index into the ALT list, H2G_MAX = none */ } h2g_edit;   /* Edit, edit.h */
 typedef struct {
 	uint32_t read;
 	uint32_t fw, rdoff, len, trim5, trim3, tidx, toff, joinedOff;
+	uint32_t splicescore;      /* GenomeHit::_splicescore (mean intron length of the short-anchored splices), truncated */
 	int64_t  score;
 	uint32_t nedits;
 	uint32_t overflow;         /* edit list exceeded H2G_MAX_EDITS: caller must take its own path */
@@ -239,7 +243,7 @@ H2G_EXPORT h2g_status h2g_seed_extend_fetch(h2g_stream*, h2g_seed_result* out, s
  * (GFM + ALT database) indexes, --no-spliced-alignment, default scoring, --bowtie2-dp 0/1/2. */
 #define H2G_ALN_CAP 10             /* alignments returned per read (>= -k: 5 on linear, 10 on graph indexes) */
 typedef struct {                   /* == the arguments reportHit (hi_aligner.h:6064-6166) passes to AlnRes::init */
-	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, pad;
+	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, splicescore;   /* splicescore: AlnScore::splicescore_ (aligner_result.h:322) */
 	int64_t  score;                /* AS:i */
 	h2g_edit edits[H2G_MAX_EDITS]; /* as stored in the AlnRes (aligner_result.cpp:110-118): positions along the original read
 	                                * 5'->3', relative to its first aligned (non-soft-clipped) base */
@@ -254,7 +258,7 @@ typedef struct {
 } h2g_read_result;
 typedef struct {
 	uint32_t khits, kseeds;        /* -k, --max-seeds */
-	uint32_t no_spliced_alignment; /* must be 1 for now */
+	uint32_t no_spliced_alignment; /* 1: --no-spliced-alignment; 0: introns are placed by combineWith (needs no_temp_splicesite, linear index) */
 	uint32_t secondary;
 	uint32_t bowtie2_dp;           /* --bowtie2-dp: 0 off (default), 1 SwAligner when no alignment reached minsc, 2 always
 	                                * (spliced_aligner.h:209).  Inside go() the DP is run by the read's own lane over
@@ -267,6 +271,14 @@ typedef struct {
 	int32_t  sc_max, sc_min;       /* --sp MX,MN      2,1  (soft-clip penalty); --no-softclip = INT32_MAX,INT32_MAX */
 	uint32_t score_min_type;       /* --score-min <type>,<const>,<coeff>: 1 = C, 2 = L, 3 = S (sqrt), 4 = G (log)   (simple_func.h:30-33) */
 	double   score_min_const, score_min_coeff;   /* default L,0,-0.2 (hisat2.cpp:440) */
+	uint32_t no_temp_splicesite;   /* --no-temp-splicesite: novel splice sites are not shared between reads.  Spliced alignment
+	                                * (no_spliced_alignment == 0) is built for this setting on linear indexes: every read is independent */
+	/* splice scoring (Scoring::canSpl / noncanSpl scoring.h:473-487, TranscriptomePolicy tp.h; hisat2.cpp:493-499, :1631-1688) */
+	uint32_t min_intronlen, max_intronlen;           /* --min-intronlen 20, --max-intronlen 500000 */
+	int32_t  pen_cansplice, pen_noncansplice;        /* --pen-cansplice 0, --pen-noncansplice 12 */
+	uint32_t pen_canintronlen_type, pen_noncanintronlen_type;   /* --pen-canintronlen / --pen-noncanintronlen <type>,<const>,<coeff>: */
+	uint32_t pad_;                                              /* type as score_min_type; default G,-8,1 */
+	double   pen_canintronlen_const, pen_canintronlen_coeff, pen_noncanintronlen_const, pen_noncanintronlen_coeff;
 } h2g_align_params;
 /* number of visible HIP devices (0 without a GPU: the library has no CPU path) */
 H2G_EXPORT int        h2g_device_count(void);

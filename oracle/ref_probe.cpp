@@ -131,6 +131,23 @@ int main(int argc, char** argv) {
 		return 2;
 	}
 	string cmd = argv[1], base = argv[2];
+	if(cmd == "probscore") {
+		// probscore <unused> <n> <seed>: the splice-site probability tables (splice_site.cpp:45-105) as hex floats at n seeded
+		// indexes each, then SpliceSiteDB::probscore on n seeded (donor, acceptor) sequences
+		init_junction_prob();
+		uint64_t n = strtoull(argv[3], NULL, 10), s = strtoull(argv[4], NULL, 10);
+		for(uint64_t i = 0; i < n; i++) {
+			uint64_t h = splitmix64(s);
+			uint32_t a = (uint32_t)(h % (1u << (donor_len << 1))), b = (uint32_t)((h >> 20) % (1u << (acceptor_len1 << 1))), c = (uint32_t)((h >> 40) % (1u << (acceptor_len2 << 1)));
+			float fa = donor_prob_sum[a], fb = acceptor_prob_sum1[b], fc = acceptor_prob_sum2[c];
+			uint32_t ua, ub, uc; memcpy(&ua, &fa, 4); memcpy(&ub, &fb, 4); memcpy(&uc, &fc, 4);
+			int64_t dseq = (int64_t)a, aseq = ((int64_t)b << (acceptor_len2 << 1)) | c;
+			float ps = SpliceSiteDB::probscore(dseq, aseq);
+			uint32_t up; memcpy(&up, &ps, 4);
+			printf("%u %u %u %08x %08x %08x %08x\n", a, b, c, ua, ub, uc, up);
+		}
+		return 0;
+	}
 	initializeCntLut();
 	initializeCntBit();
 	Probe p(base);

@@ -26,6 +26,6 @@ for i in idx:
     s = seqs[str(i)]
     rd = np.array([code[c] for c in s], dtype=np.uint8)
     sys.stderr.write(f"==== read {i} {s}\n"); sys.stderr.flush()
-    outs, recs = emu_align(os.path.join(tmp, "g"), [rd], [str(i)], bowtie2_dp=int(os.environ.get("DP", "0")))
+    outs, recs = emu_align(os.path.join(tmp, "g"), [rd], [str(i)], bowtie2_dp=int(os.environ.get("DP", "0")), no_spliced=int(os.environ.get("NOSPLICED", "1")))
     got = SU.render(outs, recs, refnames, [rd], [str(i)])
     print(" GOT ", got[str(i)], "\n WANT", want[str(i)])

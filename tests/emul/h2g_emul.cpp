@@ -15,6 +15,7 @@
 #include "../../hisat2_amd/csrc/h2g_graph.h"
 #include "../../hisat2_amd/csrc/h2g_sw.h"
 #include "../../hisat2_amd/csrc/h2g_local_pack.h"
+#include "../../hisat2_amd/csrc/h2g_splice_host.h"
 
 using namespace h2g;
 
@@ -239,6 +240,11 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	h2g_align_params hp;
 	if(e->has_params) hp = e->params; else { align_params_defaults(&hp, e->dg.linear); hp.bowtie2_dp = e->bowtie2_dp; }
 	*P = aln_params_from(hp, no_spliced != 0, e->dg.linear);
+	if(!no_spliced) {   // spliced alignment: the splice-site probability tables of SpliceSiteDB::probscore
+		static std::vector<float> d_, a1_, a2_;
+		if(d_.empty()) splice_tables(d_, a1_, a2_);
+		P->sc.donor_sum = d_.data(); P->sc.acc_sum1 = a1_.data(); P->sc.acc_sum2 = a2_.data();
+	}
 	C->g = &e->dg; C->ref = &e->dr; C->ls = &e->dls; C->P = P;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C->sw = e->sw.data();

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Development fuzzer for spliced alignment (the reference's default mode, here with --no-temp-splicesite so that every read is
+independent): a random genome with planted GT..AG (and some non-canonical) introns, reads drawn from the spliced "transcripts",
+host instantiation of the go() machine vs the real reference binary.  usage: fuzz_spliced.py <seed> <nreads> [sub]"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import sam_util as SU  # noqa: E402
+from h2gemu_align import emu_align  # noqa: E402
+from hisat2_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=glen, dtype=np.uint8)
+    # plant introns: [a, b) with GT at a and AG at b-2 (canonical); a few GC..AG / AT..AC / random (non-canonical)
+    introns = []
+    pos = 2000
+    while len(introns) < nintrons and pos < glen - 12000:
+        L = int(rng.choice([60, 90, 150, 400, 1200, 5000, 9000]))
+        a, b = pos, pos + L
+        kind = int(rng.integers(0, 10))
+        if kind < 7:
+            g[a:a + 2] = [2, 3]; g[b - 2:b] = [0, 2]
+        elif kind == 7:
+            g[a:a + 2] = [2, 1]; g[b - 2:b] = [0, 2]
+        elif kind == 8:
+            g[a:a + 2] = [0, 3]; g[b - 2:b] = [0, 1]
+        introns.append((a, b))
+        pos = b + int(rng.integers(150, 900))
+    reads = np.zeros((nreads, rdlen), dtype=np.uint8)
+    for i in range(nreads):
+        a, b = introns[int(rng.integers(0, len(introns)))]
+        left = int(rng.integers(8, rdlen - 8)) if rng.random() < 0.8 else int(rng.integers(1, rdlen))   # bases before the intron
+        if rng.random() < 0.15:                      # unspliced read nearby
+            s = a - rdlen - int(rng.integers(0, 50))
+            r = g[s:s + rdlen].copy()
+        else:
+            r = np.concatenate([g[a - left:a], g[b:b + rdlen - left]])
+        m = rng.random(rdlen) < sub
+        r = np.where(m, (r + rng.integers(1, 4, size=rdlen)) & 3, r).astype(np.uint8)
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads[i] = r
+    return [g], reads
+
+
+def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=()):
+    tmp = tempfile.mkdtemp(prefix="h2spl")
+    contigs, reads = make_case(seed, nreads, sub=sub)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    rfa = os.path.join(tmp, "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    sam = os.path.join(tmp, "ref.sam")
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-temp-splicesite", "-x", base, "-U", rfa, "-S", sam] + list(extra),
+                   check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
+    refnames, want = SU.parse_sam(sam)
+    qnames = [str(i) for i in range(nreads)]
+    rl = [reads[i] for i in range(nreads)]
+    if backend is None:
+        outs, recs = emu_align(base, rl, qnames, no_spliced=0, options=list(extra))
+        got = SU.render(outs, recs, refnames, rl, qnames)
+    else:
+        outs, got = backend(base, reads, qnames, refnames, options=list(extra))
+    bad = 0
+    nspl = sum(1 for q in qnames if any("N" in r[3] for r in want[q]))
+    for q in qnames:
+        if got[q] != want[q]:
+            bad += 1
+            if bad <= verbose:
+                print(" read", q, "\n   GOT ", got[q], "\n   WANT", want[q])
+    print(f"seed {seed} n {nreads} sub {sub}: spliced(ref) {nspl}  mismatching {bad}  overflow {sum(1 for o in outs if o.overflow)}  tmp {tmp}")
+    return bad, tmp
+
+
+if __name__ == "__main__":
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    sub = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
+    sys.exit(1 if run_case(seed, n, sub)[0] else 0)

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Development fuzzer for paired spliced alignment (--no-temp-splicesite): fragments drawn from the spliced transcript of
+fuzz_spliced's genome, mate 2 reverse-complemented; host instantiation of the go() machine + the SAM formatter vs the lines of
+the real reference binary.  usage: fuzz_spliced_pairs.py <seed> <npairs> [sub]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import sam_lines as SL  # noqa: E402
+import sam_util as SU  # noqa: E402
+import pe_sink as PS  # noqa: E402
+from h2gemu_py import Emu  # noqa: E402
+from hisat2_amd import api, synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def make_case(seed, npairs, rdlen=101, sub=0.005, glen=400000, nintrons=300, frag_mean=280, frag_sd=40):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=glen, dtype=np.uint8)
+    introns = []
+    pos = 2000
+    while len(introns) < nintrons and pos < glen - 12000:
+        L = int(rng.choice([60, 90, 150, 400, 1200, 5000, 9000]))
+        a, b = pos, pos + L
+        kind = int(rng.integers(0, 10))
+        if kind < 8:
+            g[a:a + 2] = [2, 3]; g[b - 2:b] = [0, 2]
+        elif kind == 8:
+            g[a:a + 2] = [2, 1]; g[b - 2:b] = [0, 2]
+        introns.append((a, b))
+        pos = b + int(rng.integers(120, 700))
+    keep = np.ones(glen, dtype=bool)
+    for a, b in introns:
+        keep[a:b] = False
+    tx = g[keep]                                     # the transcript: every intron removed
+    m1 = np.zeros((npairs, rdlen), dtype=np.uint8)
+    m2 = np.zeros((npairs, rdlen), dtype=np.uint8)
+    for i in range(npairs):
+        fl = max(rdlen, int(rng.normal(frag_mean, frag_sd)))
+        s = int(rng.integers(0, len(tx) - fl))
+        f = tx[s:s + fl].copy()
+        m = rng.random(fl) < sub
+        f = np.where(m, (f + rng.integers(1, 4, size=fl)) & 3, f).astype(np.uint8)
+        if rng.random() < 0.5:
+            f = (3 - f[::-1]).astype(np.uint8)
+        m1[i] = f[:rdlen]
+        m2[i] = 3 - f[::-1][:rdlen]
+    return [g], m1, m2
+
+
+def emu_pairs(base, m1, m2, q1, q2, options=()):
+    e = Emu(base)
+    from h2gemu_align import set_options
+    set_options(e, 0, list(options))
+    n, L = m1.shape
+    c1, o1 = synth.flatten_reads(m1)
+    c2, o2 = synth.flatten_reads(m2)
+    e.set_reads(c1, o1)
+    nb1 = "".join(q1).encode(); no1 = np.concatenate([[0], np.cumsum([len(q) for q in q1])]).astype(np.uint32)
+    nb2 = "".join(q2).encode(); no2 = np.concatenate([[0], np.cumsum([len(q) for q in q2])]).astype(np.uint32)
+    outs = (PS.PairOut * n)()
+    r1 = (SU.AlnRec * (n * SU.AL_MAX_RESULTS))()
+    r2 = (SU.AlnRec * (n * SU.AL_MAX_RESULTS))()
+    vp = C.c_void_p
+    e.L.h2gemu_align_pairs.argtypes = [vp, C.c_uint32, vp, vp, C.c_char_p, vp, C.c_char_p, vp, vp, vp, vp]
+    e.L.h2gemu_align_pairs(e.h, 0, c2.ctypes.data, o2.ctypes.data, nb1, no1.ctypes.data, nb2, no2.ctypes.data, outs, r1, r2)
+    return outs, r1, r2
+
+
+def run_case(seed, npairs, sub=0.005, extra=(), show=6):
+    tmp = tempfile.mkdtemp(prefix="h2splpe")
+    contigs, m1, m2 = make_case(seed, npairs, sub=sub)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    sam = os.path.join(tmp, "ref.sam")
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-temp-splicesite", "-x", base, "-1", f1, "-2", f2, "-S", sam] + list(extra),
+                   check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
+    q = [str(i) for i in range(npairs)]
+    outs, r1, r2 = emu_pairs(base, m1, m2, q, q, options=extra)
+    n = npairs
+    res = (api.PairResult * n)()
+    a1 = (api.AlnRes * (n * api.PAIR_RES_CAP))()
+    a2 = (api.AlnRes * (n * api.PAIR_RES_CAP))()
+    C.memmove(res, outs, C.sizeof(res))
+    for i in range(n):
+        for m, (src, dst) in enumerate(((r1, a1), (r2, a2))):
+            for k in range(min(outs[i].nres[m], api.PAIR_RES_CAP)):
+                C.memmove(C.byref(dst[i * api.PAIR_RES_CAP + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
+    khits = int(extra[extra.index("-k") + 1]) if "-k" in extra else 5
+    got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra))
+    want = SL.body_lines(sam)
+    from test_sam_lines import diff_lines
+    bad = diff_lines(got, want, show=show)
+    nspl = sum(1 for l in want if "N" in l.split("\t")[5])
+    ovf = sum(1 for o in outs if o.overflow)
+    print(f"seed {seed} pairs {npairs} sub {sub}: spliced lines(ref) {nspl}  differing lines {bad}  overflow {ovf}  summary {'same' if SL.LAST_SUMMARY == open(os.path.join(tmp, 'ref.err')).read() else 'DIFFERENT'}  tmp {tmp}")
+    return bad, tmp
+
+
+if __name__ == "__main__":
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    sub = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
+    sys.exit(1 if run_case(seed, n, sub)[0] else 0)

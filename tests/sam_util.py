@@ -46,9 +46,12 @@ def cigar_of(rec: AlnRec, rd):
     as base codes (forward strand): the SAM printer's own gap left-alignment is then reproduced (StackedAln::leftAlign,
     aligner_result.cpp:746, called from aln_sink.h:3048) — it slides a non-SNP gap left over matching bases until it meets
     another gap, which the aligner's GenomeHit::leftAlign does not do next to an ALT gap.  An int (read length) skips it."""
-    eds = [(rec.edits[k].pos, rec.edits[k].type, chr(rec.edits[k].chr), rec.edits[k].snp != api.MAX) for k in range(rec.nedits)]
+    eds = [(rec.edits[k].pos, rec.edits[k].type, chr(rec.edits[k].chr), rec.edits[k].snp != api.MAX and rec.edits[k].type != 5) for k in range(rec.nedits)]
+    # splice edits (type 5, CIGAR N): splLen = chr | qchr << 8 | (pad & 15) << 16 (include/h2g.h)
+    skips = [rec.edits[k].chr | (rec.edits[k].qchr << 8) | ((rec.edits[k].pad & 15) << 16) for k in range(rec.nedits) if rec.edits[k].type == 5]
     if not rec.fw:   # stored 5'->3' along the original read, relative to the first aligned base: mirror within len
-        eds = [((rec.len - p) if t == 1 else (rec.len - p - 1), t, c, sn) for p, t, c, sn in reversed(eds)]
+        eds = [((rec.len - p) if t in (1, 5) else (rec.len - p - 1), t, c, sn) for p, t, c, sn in reversed(eds)]
+        skips = skips[::-1]
     rel, snp, refc = [], [], []     # StackedAln::init (aligner_result.cpp:660-728)
     seq = None
     if not isinstance(rd, (int, np.integer)):
@@ -60,7 +63,9 @@ def cigar_of(rec: AlnRec, rd):
         consumed = False
         while ei < len(eds) and eds[ei][0] == i and not consumed:
             p, t, c, sn = eds[ei]
-            if t == 1:
+            if t == 5:
+                rel.append("N"); snp.append(False); refc.append("N")
+            elif t == 1:
                 rel.append("D"); snp.append(sn); refc.append(c)
             elif t == 2:
                 rel.append("I"); snp.append(sn); refc.append("-"); consumed = True
@@ -76,6 +81,8 @@ def cigar_of(rec: AlnRec, rd):
         for r in rel:
             if r == "D":
                 readc.append("-")
+            elif r == "N":
+                readc.append("N")
             else:
                 readc.append("ACGTN"[int(seq[rec.trim5 + k])]); k += 1
         ln = len(rel)
@@ -112,8 +119,12 @@ def cigar_of(rec: AlnRec, rd):
         else:
             ops.append([op, n])
     add("S", rec.trim5)
+    nsk = 0
     for r in rel:
-        add("M" if r in "=X" else r)
+        if r == "N":
+            ops.append(["N", skips[nsk]]); nsk += 1
+        else:
+            add("M" if r in "=X" else r)
     add("S", rec.trim3)
     return "".join(f"{n}{op}" for op, n in ops)
 

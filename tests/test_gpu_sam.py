@@ -98,7 +98,7 @@ def test_command_line_skip_upto_trim_no_unal():
 
 def test_command_line_refuses_what_is_not_built(tmp_path):
     r = subprocess.run([CLI, "-x", "nonexistent", "-U", "x.fq"], capture_output=True, text=True)
-    assert r.returncode != 0 and "spliced alignment is not built" in r.stderr
+    assert r.returncode != 0 and "--no-temp-splicesite" in r.stderr
 
 
 def test_dense_fetch_equals_slot_fetch(g1_index, golden_dir):

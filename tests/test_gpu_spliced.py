@@ -1,0 +1,66 @@
+"""GPU: spliced alignment through the command line (`--no-temp-splicesite`: every read independent of the others, the mode the
+device path implements) — unpaired and paired, every SAM body line and the alignment summary byte-identical to the reference
+binary's on genomes with planted GT..AG / GC..AG / AT..AC introns of 60 bp to 9 kbp."""
+import os
+import subprocess
+
+import pytest
+
+import sam_lines as SL
+from hisat2_amd import synth
+from test_sam_lines import diff_lines
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+REF = os.path.join(ROOT, "oracle", "_ref")
+needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "hisat2-align-s")), reason="needs oracle/_ref")
+
+
+def _index(tmp, contigs):
+    fa = os.path.join(str(tmp), "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(str(tmp), "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return base
+
+
+def _both(tmp, base, inputs, extra):
+    ref_sam, amd_sam = os.path.join(str(tmp), "ref.sam"), os.path.join(str(tmp), "amd.sam")
+    ref_err, amd_err = os.path.join(str(tmp), "ref.err"), os.path.join(str(tmp), "amd.err")
+    common = ["-f", "--no-temp-splicesite", "-x", base] + inputs + list(extra)
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-p", "1", "-S", ref_sam] + common, check=True, stdout=subprocess.DEVNULL, stderr=open(ref_err, "w"))
+    subprocess.run([CLI, "-p", "4", "--batch", "3000", "-S", amd_sam] + common, check=True, stderr=open(amd_err, "w"))
+    want = SL.body_lines(ref_sam)
+    assert diff_lines(SL.body_lines(amd_sam), want) == 0
+    assert open(amd_err).read() == open(ref_err).read()
+    return want
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,n,sub,extra", [
+    (341, 20000, 0.005, ()),
+    (342, 12000, 0.02, ()),
+    (343, 8000, 0.01, ("-k", "3", "--pen-noncansplice", "6", "--min-intronlen", "50", "--max-intronlen", "6000")),
+])
+def test_unpaired_spliced_command_line(tmp_path, seed, n, sub, extra):
+    import fuzz_spliced as F
+    contigs, reads = F.make_case(seed, n, sub=sub)
+    base = _index(tmp_path, contigs)
+    rfa = os.path.join(str(tmp_path), "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    want = _both(tmp_path, base, ["-U", rfa], extra)
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > n // 5
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,n,sub", [(351, 10000, 0.005), (352, 6000, 0.02)])
+def test_paired_spliced_command_line(tmp_path, seed, n, sub):
+    import fuzz_spliced_pairs as F
+    contigs, m1, m2 = F.make_case(seed, n, sub=sub)
+    base = _index(tmp_path, contigs)
+    f1, f2 = os.path.join(str(tmp_path), "r1.fa"), os.path.join(str(tmp_path), "r2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    want = _both(tmp_path, base, ["-1", f1, "-2", f2], ())
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > n // 5

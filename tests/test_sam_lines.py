@@ -104,3 +104,47 @@ def test_paired_lines_identical(monkeypatch, snps, case):
     want = SL.body_lines(os.path.join(tmp, "ref.sam"))
     assert diff_lines(got, want) == 0
     assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,sub", [(321, 0.005), (322, 0.02)])
+def test_spliced_lines_identical(seed, sub):
+    """spliced alignment (the reference's default mode, --no-temp-splicesite): introns placed by combineWith, CIGAR N, XS:A,
+    MD / NM around the intron, MAPQ and NH — every line byte-identical"""
+    import fuzz_spliced as F
+    from h2gemu_align import emu_align
+    bad, tmp = F.run_case(seed, 3000, sub=sub, verbose=2)
+    assert bad == 0
+    names, reads = read_fa(os.path.join(tmp, "r.fa"))
+    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, no_spliced=0)
+    res, aln = SL.emu_to_abi(outs, recs)
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln)
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > 1500
+    assert diff_lines(got, want) == 0
+    assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,sub", [(331, 0.01)])
+def test_spliced_pairs_lines_identical(seed, sub):
+    """paired spliced alignment: mates found by alignMate across introns, concordance, and TLEN, which leaves out the introns
+    inside the mates (AlnRes::setFragmentLength over refcoord_right(), aligner_result.h:1256, :1631)"""
+    import fuzz_spliced_pairs as F
+    bad, tmp = F.run_case(seed, 1500, sub=sub, show=3)
+    assert bad == 0
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > 300
+    assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,extra", [
+    (501, ("-k", "3", "--pen-noncansplice", "6", "--min-intronlen", "50", "--max-intronlen", "6000")),
+    (502, ("--pen-cansplice", "3", "--pen-canintronlen", "S,-2,0.1", "--pen-noncanintronlen", "L,1,0.001")),
+])
+def test_spliced_scoring_options(seed, extra):
+    """splice scoring options (hisat2.cpp:1631-1688): penalties, the intron-length SimpleFuncs, the intron length window"""
+    import fuzz_spliced as F
+    bad, _ = F.run_case(seed, 2000, sub=0.01, verbose=2, extra=extra)
+    assert bad == 0
