@@ -150,7 +150,7 @@ class AlnRes(C.Structure):
 
 class ReadResult(C.Structure):
     _fields_ = [("nres", u32), ("nselect", u32), ("overflow", u32), ("nrank", u32), ("nsteps", u32), ("depth", u32),
-                ("best", C.c_int32), ("secbest", C.c_int32), ("best_trim", u32), ("secbest_trim", u32)]
+                ("best", C.c_int32), ("secbest", C.c_int32), ("best_h2", u32), ("secbest_h2", u32)]
 
 
 class AlignParams(C.Structure):
@@ -265,7 +265,7 @@ class PairResult(C.Structure):
 
 
 READ_RESULT_DTYPE = np.dtype([(n, np.uint32) for n in ("nres", "nselect", "overflow", "nrank", "nsteps", "depth")] +
-                             [("best", np.int32), ("secbest", np.int32), ("best_trim", np.uint32), ("secbest_trim", np.uint32)])
+                             [("best", np.int32), ("secbest", np.int32), ("best_h2", np.uint32), ("secbest_h2", np.uint32)])
 
 
 # numpy views of the result structs (same memory layout)

@@ -1141,7 +1141,7 @@ struct ReadOut {
 	// AlnSetSumm::init (aligner_result.cpp:1209-1234) over ALL reported alignments, not only the selected ones: best and
 	// second-best AlnScore (score, then fewer soft-trimmed bases) — the inputs of MAPQ and ZS:i.  INT32_MIN = invalid.
 	int32_t  best, secbest;
-	uint32_t best_trim, secbest_trim;
+	uint32_t best_h2, secbest_h2;
 	uint8_t  select[H2G_SELECT_CAP];   // fixed: the same layout in every translation unit whatever its AL_MAX_RESULTS
 };
 

@@ -1565,7 +1565,7 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 	for(size_t i = 0; i < n; i++) {
 		res[i].nres = tmp[i].nres; res[i].nselect = tmp[i].nselect; res[i].overflow = tmp[i].overflow;
 		res[i].nrank = tmp[i].nrank; res[i].nsteps = tmp[i].nsteps; res[i].depth = tmp[i].depth;
-		res[i].best = tmp[i].best; res[i].secbest = tmp[i].secbest; res[i].best_trim = tmp[i].best_trim; res[i].secbest_trim = tmp[i].secbest_trim;
+		res[i].best = tmp[i].best; res[i].secbest = tmp[i].secbest; res[i].best_h2 = tmp[i].best_h2; res[i].secbest_h2 = tmp[i].secbest_h2;
 	}
 	return H2G_OK;
 }

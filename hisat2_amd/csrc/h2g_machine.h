@@ -1213,16 +1213,16 @@ H2G_HD void mach_finish(const AlnCtx& C, Mach& M) {
 		Rng rnd; rnd.last = gv.rnd;
 		o.nres = ws->m[0].nres; o.overflow = ws->overflow; o.nrank = ws->nrank; o.nsteps = ws->nsteps; o.depth = ws->nframes_max; o.nside = ws->nside;
 		o.nselect = al_select(&ws->m[0], *C.P, &rnd, o.select);
-		int64_t b = INT64_MIN, sb = INT64_MIN;
-		uint32_t bt = 0, sbt = 0;
+		// AlnSetSumm::init aligner_result.cpp:1209: best / second best by AlnScore (score, then hisat2_score)
+		int64_t b = INT64_MIN, sb = INT64_MIN, bh = 0, sbh = 0;
 		for(uint32_t k = 0; k < ws->m[0].nres; k++) {
 			const AlnRec& r = ws->m[0].res[k];
-			const uint32_t t = r.trim5 + r.trim3;
-			if(b == INT64_MIN || r.score > b || (r.score == b && t < bt)) { sb = b; sbt = bt; b = r.score; bt = t; }
-			else if(sb == INT64_MIN || r.score > sb || (r.score == sb && t < sbt)) { sb = r.score; sbt = t; }
+			const int64_t h = hisat2_score(r);
+			if(b == INT64_MIN || r.score > b || (r.score == b && h > bh)) { sb = b; sbh = bh; b = r.score; bh = h; }
+			else if(sb == INT64_MIN || r.score > sb || (r.score == sb && h > sbh)) { sb = r.score; sbh = h; }
 		}
 		o.best = b == INT64_MIN ? INT32_MIN : (int32_t)b; o.secbest = sb == INT64_MIN ? INT32_MIN : (int32_t)sb;
-		o.best_trim = bt; o.secbest_trim = sbt;
+		o.best_h2 = (uint32_t)(uint64_t)bh; o.secbest_h2 = (uint32_t)(uint64_t)sbh;
 		if(O.rout) O.rout[i] = o;
 		if(O.aln) for(uint32_t k = 0; k < o.nselect && k < O.aln_slots; k++) mach_copy_rec(O.aln[(size_t)i * O.aln_slots + k], ws->m[0].res[o.select[k]]);
 		M.L.a0 = o.nselect > 0; M.L.a1 = o.overflow != 0;

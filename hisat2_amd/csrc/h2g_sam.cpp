@@ -568,8 +568,8 @@ static h2g_status format_unpaired(const h2g_sam* S, const uint8_t* codes, const 
 		read_filters(rd, &fl.lenfilt, &fl.nfilt);
 		Summ summ;
 		const h2g_read_result& r = res[i];
-		if(r.best != INT32_MIN) { summ.best[0].valid = true; summ.best[0].score = r.best; summ.best[0].h2 = hisat2_score(r.best, r.best_trim); }
-		if(r.secbest != INT32_MIN) { summ.secbest[0].valid = true; summ.secbest[0].score = r.secbest; summ.secbest[0].h2 = hisat2_score(r.secbest, r.secbest_trim); }
+		if(r.best != INT32_MIN) { summ.best[0].valid = true; summ.best[0].score = r.best; summ.best[0].h2 = (int64_t)(((uint64_t)(int64_t)r.best << 32) | r.best_h2); }
+		if(r.secbest != INT32_MIN) { summ.secbest[0].valid = true; summ.secbest[0].score = r.secbest; summ.secbest[0].h2 = (int64_t)(((uint64_t)(int64_t)r.secbest << 32) | r.secbest_h2); }
 		const uint32_t nsel = r.nselect < H2G_ALN_CAP ? r.nselect : H2G_ALN_CAP;
 		met.nread++; met.nunpaired++;
 		if(nsel == 0) met.nunp_0++; else if(nsel == 1) met.nunp_uni1++; else met.nunp_uni2++;

@@ -254,7 +254,8 @@ typedef struct {
 	uint32_t overflow;             /* !=0: a fixed-capacity list overflowed -> caller runs this read through its own go() */
 	uint32_t nrank, nsteps, depth; /* work counters: rank calls, SA-walk steps, deepest recursion frame */
 	int32_t  best, secbest;        /* AlnSetSumm over all nres alignments (aligner_result.cpp:1209): best / second-best AS:i, */
-	uint32_t best_trim, secbest_trim; /* and their soft-trimmed base counts (the AlnScore tie-break); INT32_MIN = none.  MAPQ, ZS:i */
+	uint32_t best_h2, secbest_h2;  /* and the low 32 bits of their AlnScore::hisat2_score_ (aligner_result.h:322: repeat, transcript,
+	                                * splice-score and trimmed-base fields — the AlnScore tie-break); best == INT32_MIN = none.  MAPQ, ZS:i */
 } h2g_read_result;
 typedef struct {
 	uint32_t khits, kseeds;        /* -k, --max-seeds */

@@ -116,7 +116,7 @@ def emu_to_abi(outs, recs, cap=api.ALN_CAP):
         o = outs[i]
         r = res[i]
         r.nres, r.nselect, r.overflow, r.nrank, r.nsteps, r.depth = o.nres, o.nselect, o.overflow, o.nrank, o.nsteps, o.depth
-        r.best, r.secbest, r.best_trim, r.secbest_trim = o.best, o.secbest, o.best_trim, o.secbest_trim
+        r.best, r.secbest, r.best_h2, r.secbest_h2 = o.best, o.secbest, o.best_h2, o.secbest_h2
         for k in range(min(o.nselect, cap)):
             C.memmove(C.byref(aln[i * cap + k]), C.byref(recs[i * SU.AL_MAX_RESULTS + o.select[k]]), C.sizeof(api.AlnRes))
     return res, aln

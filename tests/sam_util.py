@@ -19,7 +19,7 @@ class AlnRec(C.Structure):
 class ReadOut(C.Structure):
     _fields_ = [("nres", C.c_uint32), ("nselect", C.c_uint32), ("overflow", C.c_uint32), ("nrank", C.c_uint32),
                 ("nsteps", C.c_uint32), ("depth", C.c_uint32), ("nside", C.c_uint32), ("best", C.c_int32), ("secbest", C.c_int32),
-                ("best_trim", C.c_uint32), ("secbest_trim", C.c_uint32), ("select", C.c_uint8 * AL_MAX_RESULTS)]
+                ("best_h2", C.c_uint32), ("secbest_h2", C.c_uint32), ("select", C.c_uint8 * AL_MAX_RESULTS)]
 
 
 def parse_sam(path):

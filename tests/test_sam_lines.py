@@ -107,18 +107,20 @@ def test_paired_lines_identical(monkeypatch, snps, case):
 
 
 @needs_ref
-@pytest.mark.parametrize("seed,sub", [(321, 0.005), (322, 0.02)])
-def test_spliced_lines_identical(seed, sub):
+@pytest.mark.parametrize("seed,sub,extra", [(321, 0.005, ()), (322, 0.02, ()),
+                                            (343, 0.01, ("-k", "3", "--pen-noncansplice", "6", "--min-intronlen", "50", "--max-intronlen", "6000"))])
+def test_spliced_lines_identical(seed, sub, extra):
     """spliced alignment (the reference's default mode, --no-temp-splicesite): introns placed by combineWith, CIGAR N, XS:A,
-    MD / NM around the intron, MAPQ and NH — every line byte-identical"""
+    MD / NM around the intron, MAPQ (best vs second best by the whole hisat2_score: splice bits included) and NH — every line
+    byte-identical"""
     import fuzz_spliced as F
     from h2gemu_align import emu_align
-    bad, tmp = F.run_case(seed, 3000, sub=sub, verbose=2)
+    bad, tmp = F.run_case(seed, 3000, sub=sub, verbose=2, extra=extra)
     assert bad == 0
     names, reads = read_fa(os.path.join(tmp, "r.fa"))
-    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, no_spliced=0)
+    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, no_spliced=0, options=list(extra))
     res, aln = SL.emu_to_abi(outs, recs)
-    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln)
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, options=list(extra))
     want = SL.body_lines(os.path.join(tmp, "ref.sam"))
     assert sum(1 for l in want if "N" in l.split("\t")[5]) > 1500
     assert diff_lines(got, want) == 0
