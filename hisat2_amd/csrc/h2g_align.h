@@ -1151,6 +1151,10 @@ H2G_HD bool read_passes_filters(const SeqView& v) {
 	if(v.len < 2) return false;
 	const uint32_t maxns = (uint32_t)(0.0 + (double)0.15f * (double)v.len);
 	uint32_t ns = 0;
+	if(v.pk) {                       // packed read: the N mask words (SeqView::at)
+		for(uint32_t w = 0; w < (v.len + 31) / 32; w++) ns += (uint32_t)__builtin_popcount(v.pk[(H2G_PK_WORDS + w) * v.pk_stride]);
+		return ns <= maxns;
+	}
 	for(uint32_t i = 0; i < v.len; i++) if(v.fwc[i] == 4) { if(++ns > maxns) return false; }
 	return true;
 }

@@ -26,7 +26,7 @@ using namespace h2g;
 #ifndef H2G_GO_SLOTS
 #define H2G_GO_SLOTS 1024        // reads in flight per workgroup (power of two)
 #endif
-#define H2G_GO_NQ ((int)OP_COUNT)     // ring 0 (OP_NONE) holds the free slots
+#define H2G_GO_NQ ((int)SITE_COUNT)   // one ring per request site of the machine (h2g_machine.h H2G_MACH_SITES); ring 0 holds the free slots
 #define H2G_PK_LANE_WORDS (H2G_PK_WORDS + H2G_PK_WORDS / 2)
 #define H2G_RING_EMPTY 0xffffu
 
@@ -39,17 +39,28 @@ struct GoSlot {
 	uint32_t pk[2][H2G_PK_LANE_WORDS];
 };
 
-// packs read i of `rd`: H2G_PK_WORDS 2-bit words then H2G_PK_WORDS/2 N-mask words; false = longer than the packed form holds
+// packs read i of `rd`: H2G_PK_WORDS 2-bit words then H2G_PK_WORDS/2 N-mask words; false = longer than the packed form holds.
+// The codes are fetched four at a time (one unaligned dword per four bases; the buffer is padded past its last read).
 __device__ __forceinline__ bool pack_read(const DReads& rd, uint32_t i, uint32_t* pk) {
 	const uint32_t ro = rd.offs[i], rl = rd.offs[i + 1] - ro;
 	for(uint32_t w = 0; w < H2G_PK_LANE_WORDS; w++) pk[w] = 0;
 	if(rl > H2G_PK_MAXLEN) return false;
+	const uint8_t* src = rd.codes + ro;
 	for(uint32_t w = 0; w < (rl + 15) / 16; w++) {
 		uint32_t bits = 0, mask = 0;
-		for(uint32_t k = 0; k < 16 && w * 16 + k < rl; k++) {
-			const uint32_t c = rd.codes[ro + w * 16 + k];
-			bits |= (c & 3u) << (2 * k);
-			mask |= (c > 3u ? 1u : 0u) << k;
+#pragma unroll
+		for(uint32_t q = 0; q < 4; q++) {
+			const uint32_t at = w * 16 + q * 4;
+			if(at >= rl) break;
+			uint32_t four;
+			__builtin_memcpy(&four, src + at, 4);
+			const uint32_t left = rl - at;
+			if(left < 4) four &= (1u << (8 * left)) - 1u;             // bases of the next read: not ours
+			// each byte is a code 0..4: two low bits to the 2-bit word, bit 2 (N) to the mask
+			const uint32_t lo = four & 0x03030303u, n = (four >> 2) & 0x01010101u;
+			const uint32_t b = (lo | (lo >> 6) | (lo >> 12) | (lo >> 18)) & 0xffu;
+			const uint32_t m = (n | (n >> 7) | (n >> 14) | (n >> 21)) & 0xfu;
+			bits |= b << (8 * q); mask |= m << (4 * q);
 		}
 		pk[w] = bits;
 		pk[H2G_PK_WORDS + (w >> 1)] |= (w & 1) ? (mask << 16) : mask;
@@ -57,6 +68,7 @@ __device__ __forceinline__ bool pack_read(const DReads& rd, uint32_t i, uint32_t
 	return true;
 }
 
+static_assert(H2G_GO_NQ <= 64, "the ring census is one lane per ring");
 struct GoLds {
 	uint32_t head[H2G_GO_NQ], tail[H2G_GO_NQ];
 	uint16_t ring[H2G_GO_NQ][H2G_GO_SLOTS];
@@ -64,17 +76,19 @@ struct GoLds {
 
 // pushes this lane's slot (if `valid`) into ring q; lanes of the wave may push to different rings
 __device__ __forceinline__ void ring_push(GoLds* Q, bool valid, uint32_t q, uint32_t slot, int lane) {
-	for(uint32_t k = 0; k < (uint32_t)H2G_GO_NQ; k++) {            // one aggregated reservation per ring present in the wave
+	unsigned long long todo = __ballot(valid);
+	while(todo) {                                                  // one aggregated reservation per ring present in the wave
+		const int first = __ffsll((long long)todo) - 1;
+		const uint32_t k = (uint32_t)__shfl((int)q, first);
 		const unsigned long long m = __ballot(valid && q == k);
-		if(!m) continue;
-		const int leader = __ffsll((long long)m) - 1;
 		uint32_t base = 0;
-		if(lane == leader) base = atomicAdd(&Q->tail[k], (uint32_t)__popcll(m));
-		base = (uint32_t)__shfl((int)base, leader);
+		if(lane == first) base = atomicAdd(&Q->tail[k], (uint32_t)__popcll(m));
+		base = (uint32_t)__shfl((int)base, first);
 		if(valid && q == k) {
 			const uint32_t pos = (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (H2G_GO_SLOTS - 1);
 			__atomic_store_n(&Q->ring[k][pos], (uint16_t)slot, __ATOMIC_RELAXED);
 		}
+		todo &= ~m;
 	}
 }
 
@@ -102,7 +116,8 @@ __device__ __forceinline__ uint32_t ring_pop(GoLds* Q, uint32_t q, int lane, uin
 	return n;
 }
 
-template <bool GRAPH, int WAVES_PER_SIMD>
+// UNIT tells the builds of different translation units (capacities) apart: same template arguments would be ONE symbol
+template <bool GRAPH, int WAVES_PER_SIMD, int UNIT>
 __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 {
 	extern __shared__ uint32_t s_mem[];
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 		if(lane < H2G_GO_NQ) cnt = __atomic_load_n(&Q->tail[lane], __ATOMIC_RELAXED) - __atomic_load_n(&Q->head[lane], __ATOMIC_RELAXED);
 		const uint32_t nfree = (uint32_t)__shfl((int)cnt, 0);
 		uint32_t bestc = (lane >= 1 && lane < H2G_GO_NQ) ? cnt : 0, bestq = (uint32_t)lane;
-		for(int o = 8; o > 0; o >>= 1) {
+		for(int o = 32; o > 0; o >>= 1) {
 			const uint32_t oc = (uint32_t)__shfl_xor((int)bestc, o), oq = (uint32_t)__shfl_xor((int)bestq, o);
 			if(oc > bestc || (oc == bestc && oq < bestq)) { bestc = oc; bestq = oq; }
 		}
@@ -203,8 +218,8 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 				if(more) { uint32_t w = 0; if(lane == 0) w = __atomic_load_n(A.work, __ATOMIC_RELAXED); if((uint32_t)__shfl((int)w, 0) >= total) more = false; }
 				continue;
 			}
-			const uint32_t op = bestq;
-			const uint32_t n = ring_pop(Q, op, lane, &slot);
+			const uint32_t op = mach_site_op(bestq);      // the ring is a request site: one primitive, one resume pc
+			const uint32_t n = ring_pop(Q, bestq, lane, &slot);
 			if(n == 0) continue;
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			have = (uint32_t)lane < n;
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 				naln += (M.L.a0 != 0) && !(A.defer_overflow && M.L.a1 != 0); novf += M.L.a1 != 0;
 				nextq = 0;
 			} else {
-				nextq = M.L.op;
+				nextq = mach_site_of(M.L.pc);
 				gs->L = M.L;
 				if(A.dbg_buf && M.read == A.dbg_read) {
 					const uint32_t at = atomicAdd(A.dbg_buf, 8u);
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 
 // the extern "C" face of one translation unit (declared in h2g_go_args.h)
 #define H2G_GO_ALIGN256(X) (((X) + 255) & ~(size_t)255)
-#define H2G_GO_UNIT(NAME, GRAPH, WAVES) \
+#define H2G_GO_UNIT(NAME, GRAPH, WAVES, UNIT) \
 	extern "C" size_t h2g_go_ws_bytes_##NAME() { return H2G_GO_ALIGN256(sizeof(AlignWS)) + H2G_GO_ALIGN256(sizeof(GoSlot)) + ((GRAPH) ? H2G_GO_ALIGN256(sizeof(GraphSlot)) : 0); } \
 	extern "C" size_t h2g_go_slot_off_##NAME() { return H2G_GO_ALIGN256(sizeof(AlignWS)); } \
 	extern "C" size_t h2g_go_gsl_off_##NAME() { return H2G_GO_ALIGN256(sizeof(AlignWS)) + H2G_GO_ALIGN256(sizeof(GoSlot)); } \
@@ -276,5 +291,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	extern "C" void h2g_go_caps_##NAME(uint32_t* c) { c[0] = AL_MAX_GHITS; c[1] = AL_MAX_RESULTS; c[2] = AL_MAX_SEARCHED; c[3] = AL_MAX_DEPTH; c[4] = AL_MAX_PARTIAL; } \
 	extern "C" int h2g_go_launch_##NAME(const GoArgs* a, unsigned grid, hipStream_t st) { \
 		const unsigned lds = (unsigned)((sizeof(GoLds) + 3) / 4 * 4) + (a->paired ? 2u : 1u) * H2G_PK_LANE_WORDS * H2G_GO_THREADS * 4u; \
-		hipLaunchKernelGGL((k_go<GRAPH, WAVES>), dim3(grid), dim3(H2G_GO_THREADS), lds, st, *a); \
+		static bool lds_ok = false;   /* more than 64 KB of dynamic LDS is an opt-in */ \
+		if(!lds_ok) { if(hipFuncSetAttribute((const void*)k_go<GRAPH, WAVES, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok = true; } \
+		hipLaunchKernelGGL((k_go<GRAPH, WAVES, UNIT>), dim3(grid), dim3(H2G_GO_THREADS), lds, st, *a); \
 		return (int)hipGetLastError(); }

@@ -2,6 +2,6 @@
 #define AL_MAX_GHITS 20
 #include "h2g_go_kernels.h"
 #ifndef H2G_GRAPH_WAVES
-#define H2G_GRAPH_WAVES 4
+#define H2G_GRAPH_WAVES 2
 #endif
-H2G_GO_UNIT(graph, true, H2G_GRAPH_WAVES)
+H2G_GO_UNIT(graph, true, H2G_GRAPH_WAVES, 1)

@@ -1,4 +1,4 @@
 // go() kernel for GRAPH (SNP) indexes with the large workspace (see h2g_go_big.h).
 #include "h2g_go_big.h"
 #include "h2g_go_kernels.h"
-H2G_GO_UNIT(graph_big, true, 2)
+H2G_GO_UNIT(graph_big, true, 2, 3)

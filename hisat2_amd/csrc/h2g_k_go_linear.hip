@@ -2,6 +2,6 @@
 #define AL_MAX_GHITS 10   // max(khits, kseeds) of the default option set on a linear index (hisat2.cpp:3174-3176, 3903-3906)
 #include "h2g_go_kernels.h"
 #ifndef H2G_LINEAR_WAVES
-#define H2G_LINEAR_WAVES 4
+#define H2G_LINEAR_WAVES 2
 #endif
-H2G_GO_UNIT(linear, false, H2G_LINEAR_WAVES)
+H2G_GO_UNIT(linear, false, H2G_LINEAR_WAVES, 0)

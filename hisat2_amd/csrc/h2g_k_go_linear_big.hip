@@ -1,4 +1,4 @@
 // go() kernel for LINEAR indexes with the large workspace (see h2g_go_big.h).
 #include "h2g_go_big.h"
 #include "h2g_go_kernels.h"
-H2G_GO_UNIT(linear_big, false, 2)
+H2G_GO_UNIT(linear_big, false, 2, 2)

@@ -10,6 +10,19 @@
 // runs the identical source one lane at a time.
 #pragma once
 
+#if defined(H2G_MACH_PCTRACE) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" void mach_pctrace(unsigned pc);
+#endif
+#if defined(H2G_MEMPROF) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" { extern const void* g_mp_ws; extern const void* g_mp_mach; extern size_t g_mp_mach_sz; extern int g_mp_phase, g_mp_on; void mp_trip(); }
+#endif
+// The control function and each primitive are separate functions on the device (H2G_MACH_NOINLINE): one register allocation
+// per primitive instead of one over the whole machine.
+#ifdef H2G_MACH_NOINLINE
+#define H2G_MACH_FN H2G_HDN
+#else
+#define H2G_MACH_FN H2G_HD
+#endif
 namespace h2g {
 
 enum : uint32_t {
@@ -47,6 +60,43 @@ enum : uint32_t {
 
 // What a finished read leaves behind (the selection half of AlnSinkWrap::finishRead for unpaired reads; the report events of
 // both mates + the PRNG state for pairs, whose finishRead runs in h2g_sam_format_paired)
+// Every place the machine requests a primitive: (primitive, pc it resumes at).  The kernels queue reads in flight per SITE, not
+// per primitive: the lanes of a wave then resume at the same pc, which halves the number of distinct pc bodies a wave walks
+// through between two primitives (tools/memprof/simt.py).  tests/test_machine_sites.py checks the list against the M_OP uses.
+#define H2G_MACH_SITES(X) \
+	X(OP_PSEARCH, PC_NB_AFTER_PS) \
+	X(OP_GCOORDS, PC_GAH_FULL_AFTER) X(OP_GCOORDS, PC_GAH_SUB_AFTER) X(OP_GCOORDS, PC_L_GC_AFTER) X(OP_GCOORDS, PC_R_GC_AFTER) \
+	X(OP_EXTEND, PC_HS_EXT_AFTER) X(OP_EXTEND, PC_AM_EXT_AFTER) X(OP_EXTEND, PC_L_EXT_A) X(OP_EXTEND, PC_L_G_B) X(OP_EXTEND, PC_L_RI_B) \
+	X(OP_EXTEND, PC_RC_ENTRY_L2) X(OP_EXTEND, PC_RC_ENTRY_R2) X(OP_EXTEND, PC_R_EXT_A) X(OP_EXTEND, PC_R_G_B) X(OP_EXTEND, PC_R_RI_B) \
+	X(OP_LSEARCH, PC_AM_AFTER_LS) X(OP_LSEARCH, PC_L_LS_AFTER) X(OP_LSEARCH, PC_R_LS_AFTER) \
+	X(OP_LCOORDS, PC_AM_AFTER_LC) X(OP_LCOORDS, PC_L_LC_AFTER) X(OP_LCOORDS, PC_R_LC_AFTER) \
+	X(OP_GSEARCH, PC_L_GS_AFTER) X(OP_GSEARCH, PC_R_GS_AFTER) \
+	X(OP_COMBINE, PC_L_G_C) X(OP_COMBINE, PC_L_RI_C) X(OP_COMBINE, PC_R_G_C) X(OP_COMBINE, PC_R_RI_C) \
+	X(OP_ADJUST, PC_AM_RI_AFTER) X(OP_ADJUST, PC_GAH_K_AFTER) \
+	X(OP_ADJMEMBER, PC_L_G_A) X(OP_ADJMEMBER, PC_L_RI_A) X(OP_ADJMEMBER, PC_R_G_A) X(OP_ADJMEMBER, PC_R_RI_A) \
+	X(OP_SW, PC_HS_AFTER_SW)
+enum : uint32_t {
+#define X(OPC, PC) SITE_##PC,
+	SITE_FREE = 0, H2G_MACH_SITES(X) SITE_COUNT
+#undef X
+};
+H2G_HD uint32_t mach_site_of(uint32_t pc) {        // resume pc -> site (queue) id; 0 = not a resume pc
+	switch(pc) {
+#define X(OPC, PC) case PC: return SITE_##PC;
+	H2G_MACH_SITES(X)
+#undef X
+	default: return 0;
+	}
+}
+H2G_HD uint32_t mach_site_op(uint32_t site) {      // the primitive a site waits for
+	switch(site) {
+#define X(OPC, PC) case SITE_##PC: return OPC;
+	H2G_MACH_SITES(X)
+#undef X
+	default: return OP_NONE;
+	}
+}
+
 struct MachOut {
 	ReadOut*    rout;      // unpaired: [n]
 	h2g_alnres* aln;       // unpaired: [n * aln_slots]
@@ -94,7 +144,7 @@ H2G_HD void mach_cache_read(Mach& M, uint32_t read, bool paired_input) {
 }
 
 // The prelude of the worker loop body for one read / pair (hisat2.cpp:3380-3530): filters, PRNG seed, which mates go() sees.
-H2G_HD void mach_begin(Mach& M, uint32_t read, bool paired_input) {
+H2G_MACH_FN void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 	AlignWS* ws = M.ws;
 	GoVars& gv = ws->gv;
 	M.read = read;
@@ -142,10 +192,10 @@ H2G_HD void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 		M_GOTO(PC_RC_ENTRY); } while(0)
 #define MINSC_LIVE(MV) do { if(!P.secondary) { int64_t b_ = mw->bestUnp - gv.rc_cushion; if(b_ > (MV)) (MV) = b_; } } while(0)
 
-H2G_HD void mach_finish(const AlnCtx& C, Mach& M);
+H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M);
 
 // Runs the control flow of this lane until it needs a primitive (L.op != OP_NONE) or the read is finished (PC_FINISHED).
-H2G_HD void mach_step(const AlnCtx& C, Mach& M)
+H2G_MACH_FN void mach_step(const AlnCtx& C, Mach& M)
 {
 	Lane& L = M.L;
 	AlignWS* ws = M.ws;
@@ -155,6 +205,9 @@ H2G_HD void mach_step(const AlnCtx& C, Mach& M)
 	const uint32_t minK = C.g->minK, minK_local = P.minK_local;
 	const bool no_spliced = P.no_spliced != 0;
 again:
+#if defined(H2G_MACH_PCTRACE) && !defined(__HIP_DEVICE_COMPILE__)   // tools/memprof/simt.py: the pcs a read visits between two primitives
+	mach_pctrace(L.pc);
+#endif
 	switch(L.pc) {
 	// ======================================================================== go() hi_aligner.h:4048 / nextBWT :4644
 	case PC_GO_INIT: {
@@ -1109,53 +1162,53 @@ again:
 // ---------------------------------------------------------------------------------------- the primitives
 // Each executes for the lanes that requested it; the kernel calls mach_exec with a wave-uniform `op`, so every body below
 // is one code site shared by all requesters whatever control state they came from.
-H2G_HD void mach_op_psearch(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_psearch(const AlnCtx& C, Mach& M) {
 	const AlnParams& P = *C.P;
 	const SeqView sv = mach_sv(M);
 	if(!C.graph) partial_search_item(*C.g, sv, M.L.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &M.ws->fh);
 	else partial_search_graph_item(*C.g, sv, M.L.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &M.ws->fh, &C.gsl->ie);
 }
-H2G_HD void mach_op_gcoords(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_gcoords(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	h2g_sa_result res;
 	if(!C.graph) genome_coords_item(*C.g, L.a0, L.a1, L.a2, L.a3, L.a4 != 0, (h2g_coord*)L.p0, L.a5, &res);
 	else genome_coords_graph_item(*C.g, &C.gws->gw, L.a0, L.a1, L.a6, L.a7, (const IEdges*)L.p1, L.a2, L.a3, L.a4 != 0, (h2g_coord*)L.p0, L.a5, &res);
 	L.a0 = res.ncoords; L.a1 = res.nsteps;
 }
-H2G_HD void mach_op_extend(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_extend(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	uint32_t le = H2G_MAX, re = H2G_MAX;
 	al_extend(C, mach_sv(M), (h2g_ghit*)L.p0, L.a0, L.a1, L.a2, &le, &re);
 	L.a0 = le; L.a1 = re;
 }
-H2G_HD void mach_op_lsearch(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_lsearch(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	uint32_t extlen = 0, top = L.a4, bot = L.a5;
 	bool uniqueStop = L.a3 != 0;
 	const uint32_t nelt = al_local_search(C, M.ws, L.a0, mach_sv(M), L.a1, &extlen, &top, &bot, &uniqueStop, L.a2);
 	L.a0 = nelt; L.a1 = extlen; L.a2 = top; L.a3 = bot; L.a4 = uniqueStop ? 1u : 0u;
 }
-H2G_HD void mach_op_lcoords(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_lcoords(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	uint32_t n = 0;
 	al_local_coords(C, M.ws, L.a0, L.a1, L.a2, L.a3, L.a4, (h2g_coord*)L.p0, L.a5, &n);
 	L.a0 = n;
 }
-H2G_HD void mach_op_gsearch(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_gsearch(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	uint32_t extlen = 0, top = L.a4, bot = L.a5;
 	bool uniqueStop = L.a3 != 0;
 	const uint32_t nelt = al_global_search(C, M.ws, mach_sv(M), L.a1, &extlen, &top, &bot, &uniqueStop);
 	L.a0 = nelt; L.a1 = extlen; L.a2 = top; L.a3 = bot; L.a4 = uniqueStop ? 1u : 0u;
 }
-H2G_HD void mach_op_combine(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_combine(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	const AlnParams& P = *C.P;
 	AlignWS* ws = M.ws;
 	L.a0 = hit_combine(*C.ref, P.sc, mach_sv(M), (h2g_ghit*)L.p0, (const h2g_ghit*)L.p1, ws->gv.rc_minsc, P.minIntronLen, P.no_spliced != 0,
 	                   C.sc, C.sc + H2G_COMBINE_MAXLEN, C.alts) ? 1u : 0u;
 }
-H2G_HD void mach_op_adjust(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_adjust(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	AlignWS* ws = M.ws;
 	uint32_t ovf = 0;
@@ -1163,10 +1216,10 @@ H2G_HD void mach_op_adjust(const AlnCtx& C, Mach& M) {
 		adjust_with_alt(*C.g, *C.ref, *C.alts, mach_sv(M), L.a0, L.a1, L.a2, L.a3, L.a4, ws->ghits, &ws->nghits, AL_MAX_GHITS, &C.gws->awa, &ovf);
 	L.a0 = ovf;
 }
-H2G_HD void mach_op_adjmember(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_adjmember(const AlnCtx& C, Mach& M) {
 	M.L.a0 = al_adjust_member(C, mach_sv(M), (h2g_ghit*)M.L.p0, M.ws) ? 1u : 0u;
 }
-H2G_HD void mach_op_sw(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_op_sw(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	const AlnParams& P = *C.P;
 	AlignWS* ws = M.ws;
@@ -1202,7 +1255,7 @@ H2G_HD void mach_copy_rec(h2g_alnres& d, const AlnRec& r) {
 	for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
 }
 
-H2G_HD void mach_finish(const AlnCtx& C, Mach& M) {
+H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M) {
 	const MachOut& O = *M.out;
 	const bool paired_input = M.paired_input;
 	AlignWS* ws = M.ws;
@@ -1264,8 +1317,15 @@ H2G_HD void mach_exec(const AlnCtx& C, Mach& M, uint32_t op) {
 // One read / pair to completion on ONE lane (tests/emul; the kernels interleave 64 of these per wavefront)
 H2G_HD void mach_run_single(const AlnCtx& C, Mach& M, uint32_t read, bool paired_input, const MachOut& O) {
 	M.out = &O; M.paired_input = paired_input;
+#if defined(H2G_MEMPROF) && !defined(__HIP_DEVICE_COMPILE__)   // tools/memprof: memory-access profile by phase (development only)
+	g_mp_ws = M.ws; g_mp_mach = &M; g_mp_mach_sz = sizeof M; g_mp_phase = 0; g_mp_on = 1; mp_trip();
+#define MP_PHASE(p) { g_mp_phase = (p); mp_trip(); }
+#else
+#define MP_PHASE(p)
+#endif
 	mach_begin(M, read, paired_input);
 	while(M.L.pc != PC_FINISHED || M.L.op != OP_NONE) {
+		MP_PHASE(1)
 		mach_step(C, M);
 #if defined(H2G_MACH_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 		extern unsigned long long g_mach_stats[64];
@@ -1274,11 +1334,15 @@ H2G_HD void mach_run_single(const AlnCtx& C, Mach& M, uint32_t read, bool paired
 #if defined(H2G_MACH_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
 		if((int)read == H2G_MACH_TRACE) fprintf(stderr, "T %u %u %u %u %u %u %u %u\n", M.L.pc, M.L.op, M.L.a0, M.L.a1, M.L.a2, M.L.a3, M.L.a4, M.L.a5);
 #endif
-		const uint32_t op_ = M.L.op;
-		if(M.L.op != OP_NONE) mach_exec(C, M, M.L.op);
-		(void)op_;
+#if defined(H2G_MACH_PCTRACE) && !defined(__HIP_DEVICE_COMPILE__)
+		mach_pctrace(0x8000u | M.L.op);          // end of a control phase: the primitive requested (0 = finished)
+#endif
+		if(M.L.op != OP_NONE) { MP_PHASE(2 + (int)M.L.op) mach_exec(C, M, M.L.op); }
 	}
 	M.L.pc = PC_IDLE;
+#if defined(H2G_MEMPROF) && !defined(__HIP_DEVICE_COMPILE__)
+	g_mp_on = 0;
+#endif
 }
 
 }  // namespace h2g

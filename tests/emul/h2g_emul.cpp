@@ -8,7 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 // the host instantiation runs with the large-workspace capacities (one workspace, no second pass on the host)
+#ifndef H2G_MEMPROF   // tools/memprof profiles the default device workspace layout
 #include "../../hisat2_amd/csrc/h2g_go_big.h"
+#endif
 #include "../../hisat2_amd/csrc/h2g_core.h"
 #include "../../hisat2_amd/csrc/h2g_host_index.h"
 #include "../../hisat2_amd/csrc/h2g_align.h"
@@ -293,5 +295,14 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	}
 	delete ws;
 }
+
+
+#ifdef H2G_MEMPROF
+void mp_report(unsigned nreads, const char** opnames, int nops);
+void h2gemu_memprof_report(unsigned nreads) {
+	static const char* ops[] = {"(none)", "PSEARCH", "GCOORDS", "EXTEND", "LSEARCH", "LCOORDS", "GSEARCH", "COMBINE", "ADJUST", "ADJMEMBER", "SW", "FINISH"};
+	mp_report(nreads, ops, 12);
+}
+#endif
 
 }
