@@ -148,6 +148,30 @@ class AlnRes(C.Structure):
                 ("pad", u32), ("score", i64), ("edits", Edit * MAX_EDITS)]
 
 
+class SpliceSite(C.Structure):
+    _fields_ = [("tidx", u32), ("left", u32), ("right", u32), ("readid", u32), ("dir", u8), ("fromfile", u8), ("known", u8), ("pad_", u8)]
+
+
+def splice_site_array(sites, known=True):
+    """[(tidx, left, right, '+'|'-'), ...] -> (SpliceSite * n) as --known-splicesite-infile / --novel-splicesite-infile load them"""
+    a = (SpliceSite * max(1, len(sites)))()
+    for i, (t, l, r, d) in enumerate(sites):
+        a[i].tidx, a[i].left, a[i].right, a[i].readid = t, l, r, 0
+        a[i].dir, a[i].fromfile, a[i].known = (2 if d == "+" else 3), 1, (1 if known else 0)
+    return a
+
+
+def read_splice_site_file(path, refnames):
+    """the reference's splice-site file (SpliceSiteDB::read splice_site.cpp:727): name, left, right, strand per line"""
+    idx = {n: i for i, n in reversed(list(enumerate(refnames)))}
+    out = []
+    toks = open(path).read().split()
+    for k in range(0, len(toks) - 3, 4):
+        if toks[k] in idx:
+            out.append((idx[toks[k]], int(toks[k + 1]), int(toks[k + 2]), toks[k + 3][0]))
+    return out
+
+
 class ReadResult(C.Structure):
     _fields_ = [("nres", u32), ("nselect", u32), ("overflow", u32), ("nrank", u32), ("nsteps", u32), ("depth", u32),
                 ("best", C.c_int32), ("secbest", C.c_int32), ("best_h2", u32), ("secbest_h2", u32)]
@@ -277,7 +301,7 @@ SEED_RESULT_DTYPE = np.dtype([("hit", FM_HIT_DTYPE), ("ncoords", np.uint32), ("s
 assert SEED_RESULT_DTYPE.itemsize == C.sizeof(SeedResult)
 
 EXPORTS = [
-    "h2g_load_opts_init", "h2g_index_load", "h2g_index_get_info", "h2g_index_synth_sides", "h2g_index_free",
+    "h2g_load_opts_init", "h2g_index_load", "h2g_index_get_info", "h2g_index_synth_sides", "h2g_index_free", "h2g_index_set_splice_sites",
     "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_set_reads",
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",

@@ -389,10 +389,22 @@ H2G_HD void hit_push_edit(h2g_ghit* h, uint32_t pos, uint8_t chr, uint8_t qchr, 
 // combineWith hi_aligner.h:1420-2025 for linear indexes without spliced alignment: plain concatenation
 // (:1506-1525) or one insertion / deletion placed by the prefix/suffix score scan (:1741-1794).
 #define H2G_COMBINE_SCRATCH 512
-H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq, h2g_ghit* a, const h2g_ghit* b, int64_t minsc,
-                        uint32_t minIntronLen, bool no_spliced, int64_t* tmp1, int64_t* tmp2, const DAlts* alts = nullptr)
+// combineWith's temp_scores of one lane: element i of the lanes of a wave are adjacent (stride = lanes sharing the block), so a
+// scan in lockstep touches a handful of lines per step instead of one line per lane
+struct ScVec {
+	int64_t* p; uint32_t stride;
+	H2G_HD int64_t& operator[](uint32_t i) const { return p[(size_t)i * stride]; }
+};
+H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc_in, const SeqView& seq, h2g_ghit* a, const h2g_ghit* b, int64_t minsc,
+                        uint32_t minIntronLen, bool no_spliced, ScVec tmp1, ScVec tmp2, const DAlts* alts = nullptr,
+                        const h2g_coord* site = nullptr /* a splice site of the database: {left, right, dir} (:1439) */,
+                        uint32_t minAnchorLen = 0, uint32_t minAnchorLen_noncan = 0 /* 0: the policy's (tp.h); the database joins pass 1, 1 */)
 {
 	if(a == b) return false;
+	DScoring sc_anchor;                                  // calculateScore sees the caller's anchor minima (:1513-1522)
+	const bool anchor_override = minAnchorLen != 0;
+	if(anchor_override) { sc_anchor = sc_in; sc_anchor.minAnchorLen = minAnchorLen; sc_anchor.minAnchorLen_noncan = minAnchorLen_noncan; }
+	const DScoring& sc = anchor_override ? sc_anchor : sc_in;
 	uint32_t this_rdoff, this_len, this_toff, other_rdoff, other_len, other_toff;
 	int64_t this_score, other_score;
 	hit_get_right_sc(a, &sc, &seq, &this_rdoff, &this_len, &this_toff, &this_score);
@@ -454,7 +466,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 			if(rdc != rfc) tmp1[i] += score_cell(sc, rdc, rfc, seq.qual(this_rdoff + i) - 33);
 			if(tmp1[i] < remainsc) break;
 		}
-		const int i_limit = i < (int)len ? i : (int)len;
+		int i_limit = i < (int)len ? i : (int)len;
 		int i2;
 		for(i2 = (int)len - 1; i2 >= 0; i2--) {
 			int64_t p = base2 + i2;
@@ -463,7 +475,12 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 			if(rdc != rfc) tmp2[i2] += score_cell(sc, rdc, rfc, seq.qual(this_rdoff + i2) - 33);
 			if(tmp2[i2] < remainsc) break;
 		}
-		const int i2_limit = i2 > 0 ? i2 : 0;
+		int i2_limit = i2 > 0 ? i2 : 0;
+		if(site) {                                       // a database site fixes the junction (:1626-1634)
+			const int at = (int)(site->tidx - this_toff);
+			if(i2_limit <= at) { i2_limit = at; i_limit = i2_limit + 1; }
+			else i_limit = i2_limit;
+		}
 		const int GT = 0x23, AG = 0x02, GTrc = 0x01, AGrc = 0x13, GC = 0x21, GCrc = 0x21, AT = 0x03, AC = 0x01, ATrc = 0x03, ACrc = 0x20;
 		auto rf1 = [&](int j) -> int { return rc1.get((int64_t)this_toff + j); };                     // refbuf[j]
 		auto rf2 = [&](int j) -> int { const int64_t p = base2 + j; return p < 0 ? 4 : rc2.get(p); }; // refbuf2[j], j >= -other_ref_ext
@@ -505,7 +522,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 			}
 		}
 		if(maxscore == INT64_MIN) return false;
-		{   // anchor-length / intron-length veto for a novel site (:1797-1813)
+		if(!site) {   // anchor-length / intron-length veto for a novel site (:1797-1813)
 			const uint32_t shorter = maxscorei + 1 < len - maxscorei - 1 ? maxscorei + 1 : len - maxscorei - 1;
 			const bool noncan = maxspldir == H2G_SPL_SEMI_FW || maxspldir == H2G_SPL_SEMI_RC || maxspldir == H2G_SPL_UNKNOWN;
 			if(shorter < (noncan ? sc.minAnchorLen_noncan : sc.minAnchorLen)) {
@@ -534,7 +551,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 			if(rdc != rfc) tmp1[i] += score_cell(sc, rdc, rfc, seq.qual(this_rdoff + i) - 33);
 			if(tmp1[i] + gap_penalty < remainsc) break;
 		}
-		const int i_limit = i < (int)len ? i : (int)len;
+		int i_limit = i < (int)len ? i : (int)len;
 		int i2;
 		for(i2 = (int)len - 1; i2 >= 0; i2--) {
 			int64_t p = base2 + i2;
@@ -570,7 +587,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc, const SeqView& seq,
 				const uint32_t left = this_toff + i + 1, right = other_toff + other_len - (len - i - 1);
 				const uint32_t skipLen = right - left;
 				if(a->nedits >= H2G_MAX_EDITS) a->overflow = 1;
-				else a->edits[a->nedits++] = make_spl_edit(i + 1 + addoff, skipLen, maxspldir, false, spl_probstore);
+				else a->edits[a->nedits++] = make_spl_edit(i + 1 + addoff, skipLen, maxspldir, site != nullptr, spl_probstore);
 			}
 		}
 	} else {
@@ -761,7 +778,7 @@ struct GoVars {
 	// hybridSearch_recur driver
 	int32_t  sp;
 	uint32_t rc_ret_pc, rc_alignMate, pr_ret_pc;
-	int64_t  ret, rc_minsc, rc_cushion;
+	int64_t  ret, rc_minsc, rc_cushion, fs_tscore;
 };
 
 // Per-read workspace.  Every primitive of a read touches a handful of its scalars: those come first, packed into a few cache
@@ -858,8 +875,10 @@ struct AlnCtx {
 	const DLocalSet* ls;
 	const AlnParams* P;
 	uint8_t* sw = nullptr;   // this lane's Smith-Waterman scratch (sw_scratch_bytes), only when P->bowtie2_dp != 0
-	int64_t* sc = nullptr;   // this lane's combineWith temp_scores: 2 x H2G_COMBINE_MAXLEN (scratch of one primitive)
+	int64_t* sc = nullptr;   // this lane's combineWith temp_scores: 2 x H2G_COMBINE_MAXLEN elements, sc_stride apart (scratch of one primitive)
+	uint32_t sc_stride = 1;
 	const DAlts* alts = nullptr;      // graph index: the ALT database
+	const DSpliceDB* ssdb = nullptr;  // splice sites read from a file (h2g_index_set_splice_sites); nullptr or n == 0: ssdb.empty()
 	struct GraphWS* gws = nullptr;    // graph index: this lane's scratch for one primitive (group walk, ALT extension)
 	struct GraphSlot* gsl = nullptr;  // graph index: the graph state of the read being worked on
 	bool graph = false;               // set from a kernel template constant so that the linear kernels carry no graph code
@@ -1087,9 +1106,12 @@ H2G_HD int64_t hisat2_score(const AlnRec& r) {   // AlnScore::calculate_hisat2_s
 	if(score > INT32_MAX) score = INT32_MAX; else if(score < INT32_MIN) score = INT32_MIN;
 	int64_t trim = (int64_t)r.trim5 + r.trim3;
 	trim = trim > 0xffff ? 0 : 0xffff - trim;
-	// transcript score: 2 known transcripts (never here), 1 near splice sites = the alignment is spliced (reportHit hi_aligner.h:6100-6143)
+	// transcript score (reportHit hi_aligner.h:6100-6143 over GenomeHit::spliced() :1086): 2 = spliced through database sites only
+	// ("known transcripts"), 1 = spliced, 0 = not (the near-a-splice-site case needs --avoid-pseudogene)
 	int64_t tscore = 0;
-	for(uint32_t k = 0; k < r.nedits; k++) if(r.edits[k].type == H2G_EDIT_SPL) { tscore = 1; break; }
+	bool all_known = true;
+	for(uint32_t k = 0; k < r.nedits; k++) if(r.edits[k].type == H2G_EDIT_SPL) { tscore = 1; all_known = all_known && spl_known(r.edits[k]); }
+	if(tscore && all_known) tscore = 2;
 	int64_t spl = (int64_t)r.splicescore / 100;
 	spl = spl > 255 ? 0 : 255 - spl;
 	return (int64_t)((uint64_t)score << 32) | (0ll << 28) | (tscore << 24) | (spl << 16) | trim;

@@ -214,6 +214,7 @@ int main(int argc, char** argv) {
 	std::string base, outfn, stats_fn;
 	std::vector<std::string> u, m1, m2;
 	bool fasta = false, nospliced = false, notempss = false, nohead = false, parse_only = false, no_unal = false;
+	std::string known_ss, novel_ss;
 	uint64_t skip = 0, upto = ~0ull;
 	uint32_t trim5 = 0, trim3 = 0;
 	uint32_t dp = 0;
@@ -237,6 +238,8 @@ int main(int argc, char** argv) {
 		else if(a == "-p" || a == "--threads") threads = atoi(need("-p"));        // host threads for parsing and SAM formatting
 		else if(a == "--no-spliced-alignment") nospliced = true;
 		else if(a == "--no-temp-splicesite") notempss = true;
+		else if(a == "--known-splicesite-infile") known_ss = need("--known-splicesite-infile");
+		else if(a == "--novel-splicesite-infile") novel_ss = need("--novel-splicesite-infile");
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
 		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min" ||
 		        a == "--min-intronlen" || a == "--max-intronlen" || a == "--pen-cansplice" || a == "--pen-noncansplice" ||
@@ -367,6 +370,25 @@ int main(int argc, char** argv) {
 	if(P.khits > 30 || P.kseeds > 64 || P.kseeds < P.khits) {
 		fprintf(stderr, "hisat2-align-amd: -k %u / --max-seeds %u is outside the built range (-k <= 30, -k <= --max-seeds <= 64)\n", P.khits, P.kseeds);
 		return 1;
+	}
+	// splice sites from files (hisat2.cpp:4100-4120): one database for go() on every device and for TLEN
+	if(!nospliced && (!known_ss.empty() || !novel_ss.empty())) {
+		std::vector<h2g_splice_site> sites;
+		for(int pass = 0; pass < 2; pass++) {
+			const std::string& fn = pass == 0 ? known_ss : novel_ss;
+			if(fn.empty()) continue;
+			const size_t n = h2g_sam_read_splice_site_file(sam, fn.c_str(), pass == 0, nullptr, 0);
+			if(n == (size_t)-1) { fprintf(stderr, "Error: Could not open %s\n", fn.c_str()); return 1; }
+			const size_t at = sites.size();
+			sites.resize(at + n);
+			h2g_sam_read_splice_site_file(sam, fn.c_str(), pass == 0, sites.data() + at, n);
+		}
+		for(int g = 0; g < gpus; g++) {
+			bool first = true;
+			for(int q = 0; q < g; q++) if(ixs[q] == ixs[g]) first = false;
+			if(first && h2g_index_set_splice_sites(ixs[g], sites.data(), sites.size(), 0) != H2G_OK) die("cannot upload the splice sites");
+		}
+		h2g_sam_set_splice_sites(sam, sites.data(), sites.size(), 0);
 	}
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);

@@ -104,6 +104,45 @@ H2G_HD float spl_probscore(const DScoring& sc, int64_t donor_seq, int64_t accept
 	p *= sc.acc_sum2[(int)(acceptor_seq % (1 << 16))];
 	return (float)(1.0 / (1.0 + (double)p));
 }
+// ------------------------------------------------------------------------------------------ splice-site database
+// SpliceSiteDB (splice_site.h:470-640) as two sorted arrays: `fw` ordered by (text, left, right, dir) — the reference's _fwIndex —
+// and `bw` ordered by (text, right, left, dir) — its _bwIndex (SpliceSitePos::operator< splice_site.h:137).  Sites read from a
+// file (--known-splicesite-infile / --novel-splicesite-infile, SpliceSiteDB::read splice_site.cpp:727) are visible to every read;
+// a site found by read `readid` is visible to read r only if readid + window <= r (spliced_aligner.h:432).
+struct DSpliceSite { uint32_t left, right, readid; uint8_t dir, fromfile, known, pad; };
+struct DSpliceDB {
+	const DSpliceSite* fw = nullptr; const DSpliceSite* bw = nullptr;
+	const uint32_t* fw_first = nullptr; const uint32_t* bw_first = nullptr;   // [nPat + 1]: first entry of each text
+	uint32_t n = 0, window = 0;
+};
+H2G_HD bool ss_visible(const DSpliceDB& db, const DSpliceSite& s, uint32_t rdid) {
+	return s.fromfile || !((uint64_t)s.readid + db.window > (uint64_t)rdid);
+}
+// getLeftSpliceSites splice_site.cpp:370: sites whose RIGHT end lies in [left + 1 - range, left], in _bwIndex order;
+// getRightSpliceSites :385: sites whose LEFT end lies in [right, right + range - 1], in _fwIndex order.
+// out[k] = {left, right, dir}; returns the number found (the caller flags counts above cap).
+H2G_HD uint32_t ss_range(const DSpliceSite* a, uint32_t lo, uint32_t hi, bool by_right, uint32_t klo, uint32_t khi, const DSpliceDB& db,
+                         uint32_t rdid, h2g_coord* out, uint32_t cap) {
+	uint32_t x = lo, y = hi;
+	while(x < y) { const uint32_t m = x + ((y - x) >> 1); if((by_right ? a[m].right : a[m].left) < klo) x = m + 1; else y = m; }
+	uint32_t n = 0;
+	for(; x < hi; x++) {
+		const DSpliceSite s = a[x];
+		if((by_right ? s.right : s.left) > khi) break;
+		if(!ss_visible(db, s, rdid)) continue;                // the callers skip these (:432, :554, :699, :1380)
+		if(n < cap) { out[n].tidx = s.left; out[n].toff = s.right; out[n].joinedOff = s.dir; }
+		n++;
+	}
+	return n;
+}
+H2G_HD uint32_t ss_left_sites(const DSpliceDB& db, uint32_t tidx, uint32_t left, uint32_t range, uint32_t rdid, h2g_coord* out, uint32_t cap) {
+	if(!db.n) return 0;
+	return ss_range(db.bw, db.bw_first[tidx], db.bw_first[tidx + 1], true, left + 1 - range, left, db, rdid, out, cap);
+}
+H2G_HD uint32_t ss_right_sites(const DSpliceDB& db, uint32_t tidx, uint32_t right, uint32_t range, uint32_t rdid, h2g_coord* out, uint32_t cap) {
+	if(!db.n) return 0;
+	return ss_range(db.fw, db.fw_first[tidx], db.fw_first[tidx + 1], false, right, right + range - 1, db, rdid, out, cap);
+}
 // MaxIntronLen / MaxIntronLen_noncan hi_aligner.h:48-79
 H2G_HD uint32_t max_intron_len(uint32_t anchor, uint32_t minAnchorLen) {
 	if(anchor < minAnchorLen) return 0;
@@ -392,6 +431,35 @@ H2G_HD bool joined_to_text(const DGfm& g, uint32_t qlen, uint32_t off, uint32_t*
 			}
 			top = elt;
 		} else bot = elt;
+	}
+}
+
+// GFM::textOffToJoined gfm.h:5603-5651
+H2G_HD bool text_off_to_joined(const DGfm& g, uint32_t tid, uint32_t textoff, uint32_t* off) {
+	uint32_t top = 0, bot = g.nFrag, elt = H2G_MAX;
+	while(true) {
+		const uint32_t oldelt = elt;
+		elt = top + ((bot - top) >> 1);
+		if(oldelt == elt) return false;                              // a text without fragments (the reference asserts)
+		const uint32_t elt_tid = g.rstarts[elt * 3 + 1];
+		if(elt_tid == tid) {
+			while(true) {
+				if(tid != g.rstarts[elt * 3 + 1]) return false;
+				if(g.rstarts[elt * 3 + 2] <= textoff) break;
+				if(elt == 0) return false;
+				elt--;
+			}
+			while(true) {
+				if(elt + 1 == g.nFrag || tid + 1 == g.rstarts[(elt + 1) * 3 + 1] || textoff < g.rstarts[(elt + 1) * 3 + 2]) {
+					*off = g.rstarts[elt * 3] + (textoff - g.rstarts[elt * 3 + 2]);
+					if(elt + 1 < g.nFrag && tid == g.rstarts[(elt + 1) * 3 + 1] && *off >= g.rstarts[(elt + 1) * 3]) return false;
+					break;
+				}
+				elt++;
+			}
+			return true;
+		} else if(elt_tid < tid) top = elt;
+		else bot = elt;
 	}
 }
 

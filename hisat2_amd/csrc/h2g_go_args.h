@@ -11,7 +11,7 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long 
 }
 
 struct GoArgs {
-	h2g::DGfm g; h2g::DRef ref; h2g::DLocalSet ls; h2g::DAlts alts;
+	h2g::DGfm g; h2g::DRef ref; h2g::DLocalSet ls; h2g::DAlts alts; h2g::DSpliceDB ssdb;
 	h2g::DReads rd1, rd2;                 // rd2 only when paired
 	h2g::AlnParams P;
 	const char* names1; const uint32_t* noffs1;

@@ -16,6 +16,7 @@
 #include "h2g_sw.h"
 #include "h2g_local_pack.h"
 #include "h2g_splice_host.h"
+#include "h2g_splice_db_host.h"
 #include "h2g_go_args.h"   // GoArgs + the extern "C" face of the go() units (their AlignWS layouts are opaque on this side)
 
 using namespace h2g;
@@ -40,6 +41,8 @@ struct h2g_index {
 	DLocalSet dls;
 	DAlts dalts;
 	bool has_local = false;
+	DSpliceDB dssdb;                                       // h2g_index_set_splice_sites (device arrays; freed and replaced on every call)
+	void* d_ssdb[4] = {nullptr, nullptr, nullptr, nullptr};
 	const float* d_spl[3] = {nullptr, nullptr, nullptr};   // SpliceSiteDB::probscore tables (donor, acceptor halves), uploaded with the index
 	std::vector<DLocalDesc> h_ldesc;   // host copy of the local-index descriptors (bucketing of h2g_ext_search)
 	std::vector<void*> allocs;
@@ -190,8 +193,31 @@ extern "C" h2g_status h2g_index_get_info(const h2g_index* ix, h2g_index_info* o)
 	return H2G_OK;
 }
 
+extern "C" h2g_status h2g_index_set_splice_sites(h2g_index* ix, const h2g_splice_site* sites, size_t n, uint32_t window) {
+	if(!ix || (n && !sites)) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(ix->device));
+	HIPCHK(hipDeviceSynchronize());
+	for(void*& p : ix->d_ssdb) { if(p) (void)hipFree(p); p = nullptr; }
+	ix->dssdb = DSpliceDB();
+	if(!n) return H2G_OK;
+	HostSpliceDB h;
+	build_splice_db(sites, n, ix->host.g.nPat, h);
+	if(h.fw.empty()) return H2G_OK;
+	const void* src[4] = {h.fw.data(), h.bw.data(), h.fw_first.data(), h.bw_first.data()};
+	const size_t bytes[4] = {h.fw.size() * sizeof(DSpliceSite), h.bw.size() * sizeof(DSpliceSite), h.fw_first.size() * 4, h.bw_first.size() * 4};
+	for(int k = 0; k < 4; k++) {
+		HIPCHK(hipMalloc(&ix->d_ssdb[k], bytes[k]));
+		HIPCHK(hipMemcpy(ix->d_ssdb[k], src[k], bytes[k], hipMemcpyHostToDevice));
+	}
+	ix->dssdb.fw = (const DSpliceSite*)ix->d_ssdb[0]; ix->dssdb.bw = (const DSpliceSite*)ix->d_ssdb[1];
+	ix->dssdb.fw_first = (const uint32_t*)ix->d_ssdb[2]; ix->dssdb.bw_first = (const uint32_t*)ix->d_ssdb[3];
+	ix->dssdb.n = (uint32_t)h.fw.size(); ix->dssdb.window = window;
+	return H2G_OK;
+}
+
 extern "C" void h2g_index_free(h2g_index* ix) {
 	if(!ix) return;
+	for(void* p : ix->d_ssdb) if(p) (void)hipFree(p);
 	for(void* p : ix->allocs) (void)hipFree(p);
 	delete ix;
 }
@@ -1477,6 +1503,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	A.rd1 = dreads(s); A.rd2 = A.rd1;
 	if(paired) { A.rd2.codes = s->d_codes2; A.rd2.offs = s->d_offs2; A.rd2.quals = s->has_quals2 ? s->d_quals2 : nullptr; }
 	A.P = aln_params_from(*p, p->no_spliced_alignment != 0, linear);
+	if(!p->no_spliced_alignment) A.ssdb = s->ix->dssdb;
 	if(!p->no_spliced_alignment) { A.P.sc.donor_sum = s->ix->d_spl[0]; A.P.sc.acc_sum1 = s->ix->d_spl[1]; A.P.sc.acc_sum2 = s->ix->d_spl[2]; }
 	A.names1 = s->d_names; A.noffs1 = s->d_name_offs; A.names2 = s->d_names2; A.noffs2 = s->d_name_offs2;
 	A.paired = paired ? 1u : 0u;

@@ -55,7 +55,11 @@ enum : uint32_t {
 	PC_L_EXT, PC_L_EXT_A, PC_L_R5,
 	PC_R_WHILE, PC_R_LS_LOOP, PC_R_LS_AFTER, PC_R_LS_DONE, PC_R_LC_AFTER, PC_R_FOR_RI, PC_R_RI_A, PC_R_RI_B, PC_R_RI_C, PC_R_R1, PC_R_AFTER_FOR,
 	PC_R_FOR_TI, PC_R_R2, PC_R_AFTER_WHILE, PC_R_GS_AFTER, PC_R_GC_AFTER, PC_R_FOR_G, PC_R_G_A, PC_R_G_B, PC_R_G_C, PC_R_R3, PC_R_TRIM, PC_R_R4,
-	PC_R_EXT, PC_R_EXT_A, PC_R_R5
+	PC_R_EXT, PC_R_EXT_A, PC_R_R5,
+	// joins through the splice-site database (spliced_aligner.h:409-676 full alignments, :685-811 left, :1365-1496 right)
+	PC_FS_L_LOOP, PC_FS_L_EXT, PC_FS_L_COMB, PC_FS_R_I, PC_FS_R_LOOP, PC_FS_R_EXT, PC_FS_R_COMB, PC_FS_REPORT,
+	PC_RC_ENTRY_LX, PC_LSS_LOOP, PC_LSS_EXT, PC_LSS_COMB, PC_LSS_RET,
+	PC_RC_ENTRY_RX, PC_RSS_LOOP, PC_RSS_EXT, PC_RSS_COMB, PC_RSS_RET
 };
 
 // What a finished read leaves behind (the selection half of AlnSinkWrap::finishRead for unpaired reads; the report events of
@@ -74,7 +78,9 @@ enum : uint32_t {
 	X(OP_COMBINE, PC_L_G_C) X(OP_COMBINE, PC_L_RI_C) X(OP_COMBINE, PC_R_G_C) X(OP_COMBINE, PC_R_RI_C) \
 	X(OP_ADJUST, PC_AM_RI_AFTER) X(OP_ADJUST, PC_GAH_K_AFTER) \
 	X(OP_ADJMEMBER, PC_L_G_A) X(OP_ADJMEMBER, PC_L_RI_A) X(OP_ADJMEMBER, PC_R_G_A) X(OP_ADJMEMBER, PC_R_RI_A) \
-	X(OP_SW, PC_HS_AFTER_SW)
+	X(OP_SW, PC_HS_AFTER_SW) \
+	X(OP_EXTEND, PC_FS_L_EXT) X(OP_COMBINE, PC_FS_L_COMB) X(OP_EXTEND, PC_FS_R_EXT) X(OP_COMBINE, PC_FS_R_COMB) \
+	X(OP_EXTEND, PC_LSS_EXT) X(OP_COMBINE, PC_LSS_COMB) X(OP_EXTEND, PC_RSS_EXT) X(OP_COMBINE, PC_RSS_COMB)
 enum : uint32_t {
 #define X(OPC, PC) SITE_##PC,
 	SITE_FREE = 0, H2G_MACH_SITES(X) SITE_COUNT
@@ -641,31 +647,301 @@ again:
 			if(al_is_searched(mw, &hit)) RC_RET(f.maxsc);
 			al_add_searched(ws, mw, &hit);
 		}
+		const bool have_db = C.ssdb != nullptr && C.ssdb->n != 0;                      // !ssdb.empty()
 		if(hitoff == 0 && hitlen == rdlen) {
 			if(!al_redundant(mw, &hit, rdlen)) {
+				if(have_db) {
+					// a full alignment: look for the same read joined through database sites near its ends (:409-676);
+					// _local_genomeHits[dep] = f.local_hits, best_score = f.prev_score
+					f.prev_score = hit.score; f.nlocal = 1; hit_copy(&f.local_hits[0], &hit);
+					f.ncoords = 0; f.ri = 0;
+					uint32_t fragoff, fraglen, left;
+					hit_get_left(&hit, nullptr, nullptr, &fragoff, &fraglen, &left, nullptr);
+					if(fraglen >= minK && left >= minK && hit.trim5 == 0 && !no_spliced) {
+						f.ncoords = ss_left_sites(*C.ssdb, hit.tidx, left + minK, minK, M.read, f.coords, AL_MAX_COORDS);
+						if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
+					}
+					M_GOTO(PC_FS_L_LOOP);
+				}
 				al_report(ws, mw, &hit, rdlen, minsc);
 				if(hit.score > f.maxsc) f.maxsc = hit.score;
 			}
 			RC_RET(f.maxsc);
 		} else if(hitoff > 0 && (hitoff + hitlen == rdlen || hitoff + hitoff < rdlen - hitlen)) {
-			// ---------------- extend to the left (spliced_aligner.h:813-1360) ----------------
-			f.use_localindex = 1;
-			if(hitoff == hit.rdoff && hitoff <= minK) {
-				hit_copy(&ws->tmp, &hit);
-				L.p0 = &ws->tmp; L.a0 = 1; L.a1 = H2G_MAX; L.a2 = 0;
-				M_OP(OP_EXTEND, PC_RC_ENTRY_L2);
+			// ---------------- extend to the left: first through database sites (spliced_aligner.h:685-811) ----------------
+			f.ncoords = 0; f.ri = 0;
+			if(have_db && !no_spliced) {
+				uint32_t fragoff, fraglen, left;
+				hit_get_left(&hit, nullptr, nullptr, &fragoff, &fraglen, &left, nullptr);
+				if(fraglen >= minK_local && left >= minK_local) {
+					f.ncoords = ss_left_sites(*C.ssdb, hit.tidx, left + minK_local, minK_local + (minK_local < fragoff ? minK_local : fragoff), M.read, f.coords, AL_MAX_COORDS);
+					if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
+				}
 			}
-			M_GOTO(PC_RC_ENTRY_L3);
+			M_GOTO(PC_LSS_LOOP);
 		} else {
-			// ---------------- extend to the right (spliced_aligner.h:1496-2050) ----------------
-			f.use_localindex = 1;
-			if(hit.len == hitlen && hitoff + hitlen + minK > rdlen) {
-				hit_copy(&ws->tmp, &hit);
-				L.p0 = &ws->tmp; L.a0 = 1; L.a1 = 0; L.a2 = H2G_MAX;
-				M_OP(OP_EXTEND, PC_RC_ENTRY_R2);
+			// ---------------- extend to the right: first through database sites (:1365-1496) ----------------
+			f.ncoords = 0; f.ri = 0;
+			if(have_db && !no_spliced) {
+				uint32_t fragoff, fraglen, right;
+				hit_get_right(&hit, &fragoff, &fraglen, &right);
+				if(fraglen >= minK_local) {
+					const uint32_t unmapped = rdlen - fragoff - fraglen;
+					f.ncoords = ss_right_sites(*C.ssdb, hit.tidx, right + fraglen - minK_local, minK_local + (minK_local < unmapped ? minK_local : unmapped), M.read, f.coords, AL_MAX_COORDS);
+					if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
+				}
 			}
-			M_GOTO(PC_RC_ENTRY_R3);
+			M_GOTO(PC_RSS_LOOP);
 		}
+	}
+	// ---- full alignment, left end through a database site (:428-537)
+	case PC_FS_L_LOOP: {
+		Frame& f = FR;
+		const h2g_ghit& hit = f.hit;
+		for(; (uint32_t)f.ri < f.ncoords; f.ri++) {
+			const h2g_coord ss = f.coords[f.ri];                     // {left, right, dir}
+			uint32_t fragoff, fraglen, left;
+			hit_get_left(&hit, nullptr, nullptr, &fragoff, &fraglen, &left, nullptr);
+			if(left + fraglen - 1 < ss.toff) continue;
+			const uint32_t frag2off = ss.tidx - (ss.toff - left);
+			if(frag2off + 1 < f.hitoff) continue;
+			if(fragoff + ss.toff < left + 1) continue;
+			const uint32_t readoff = fragoff + ss.toff - left - 1;
+			uint32_t joff = 0;
+			if(!text_off_to_joined(*C.g, hit.tidx, ss.tidx, &joff)) continue;
+			hit_init(&ws->tmp, hit.fw, readoff + 1, 0, hit.tidx, ss.tidx + 1, joff + 1);
+			L.p0 = &ws->tmp; L.a0 = 0; L.a1 = readoff + 1; L.a2 = 0;
+			M_OP(OP_EXTEND, PC_FS_L_EXT);
+		}
+		f.count = f.nlocal; f.ti = 0;                                // num_local_genomeHits (:539)
+		M_GOTO(PC_FS_R_I);
+	}
+	case PC_FS_L_EXT: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		if(t->len == 0 || !hit_compatible(t, &f.hit, P.maxIntronLen, no_spliced)) { f.ri++; M_GOTO(PC_FS_L_LOOP); }
+		const h2g_coord ss = f.coords[f.ri];
+		const int64_t m = gv.rc_minsc > f.prev_score ? gv.rc_minsc : f.prev_score;
+		L.p0 = t; L.p1 = &f.hit; L.a1 = 3; L.a2 = ss.tidx; L.a3 = ss.toff; L.a4 = ss.joinedOff; L.a5 = (uint32_t)(uint64_t)m; L.a6 = (uint32_t)((uint64_t)m >> 32);
+		M_OP(OP_COMBINE, PC_FS_L_COMB);
+	}
+	case PC_FS_L_COMB: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* t = &ws->tmp;
+		const bool combined = L.a0 != 0;
+		if(t->overflow) ws->overflow |= 1;
+		int64_t m = gv.rc_minsc > f.prev_score ? gv.rc_minsc : f.prev_score;
+		if(mw->bestUnp > m) m = mw->bestUnp;                         // :515-516 (no cushion, whatever --secondary says)
+		uint32_t anchor = t->len, ned = 0;                            // getLeftAnchor hi_aligner.h:1040
+		for(uint32_t i = 0; i < t->nedits; i++) {
+			const h2g_edit e = t->edits[i];
+			if(e.type == H2G_EDIT_SPL) { anchor = e.pos; break; }
+			if(e.type == H2G_EDIT_MM || is_gap(e.type)) ned++;
+		}
+		f.ri++;
+		if(combined && t->score >= m && ned <= anchor / 4 && !al_is_searched(mw, t) && !al_redundant(mw, t, mach_sv(M).len)) {
+			if(t->score > f.prev_score) f.prev_score = t->score;
+			if(f.nlocal < AL_MAX_LOCALHITS) hit_copy(&f.local_hits[f.nlocal++], t); else ws->overflow |= 16;
+		}
+		M_GOTO(PC_FS_L_LOOP);
+	}
+	// ---- every candidate so far, right end through a database site (:540-656)
+	case PC_FS_R_I: {
+		Frame& f = FR;
+		for(; f.ti < f.count; f.ti++) {
+			const h2g_ghit& can = f.local_hits[f.ti];
+			if(can.score < f.prev_score) continue;
+			uint32_t fragoff, fraglen, right;
+			hit_get_right(&can, &fragoff, &fraglen, &right);
+			if(!(fraglen >= minK && can.trim3 == 0 && !no_spliced)) continue;
+			f.ncoords = ss_right_sites(*C.ssdb, can.tidx, right + fraglen - minK, minK, M.read, f.coords, AL_MAX_COORDS);
+			if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
+			f.ri = 0;
+			M_GOTO(PC_FS_R_LOOP);
+		}
+		f.ti = 0;
+		M_GOTO(PC_FS_REPORT);
+	}
+	case PC_FS_R_LOOP: {
+		Frame& f = FR;
+		const h2g_ghit& can = f.local_hits[f.ti];
+		const uint32_t rdlen = mach_sv(M).len;
+		for(; (uint32_t)f.ri < f.ncoords; f.ri++) {
+			const h2g_coord ss = f.coords[f.ri];
+			uint32_t fragoff, fraglen, right;
+			hit_get_right(&can, &fragoff, &fraglen, &right);
+			if(right > ss.tidx) continue;
+			const uint32_t readoff = fragoff + ss.tidx - right + 1;
+			if(readoff >= rdlen) continue;
+			uint32_t joff = 0;
+			if(!text_off_to_joined(*C.g, can.tidx, ss.toff, &joff)) continue;
+			hit_init(&ws->tmp, can.fw, readoff, 0, can.tidx, ss.toff, joff);
+			L.p0 = &ws->tmp; L.a0 = 0; L.a1 = 0; L.a2 = rdlen - readoff;
+			M_OP(OP_EXTEND, PC_FS_R_EXT);
+		}
+		f.ti++;
+		M_GOTO(PC_FS_R_I);
+	}
+	case PC_FS_R_EXT: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		const h2g_ghit& can = f.local_hits[f.ti];
+		if(t->len == 0 || !hit_compatible(&can, t, P.maxIntronLen, no_spliced)) { f.ri++; M_GOTO(PC_FS_R_LOOP); }
+		hit_copy(&ws->tmp2, &can);                                   // combinedHit = canHit
+		gv.fs_tscore = t->score;                                     // :643 raises best_score to tempHit's score, not the combined one
+		const h2g_coord ss = f.coords[f.ri];
+		const int64_t m = gv.rc_minsc > f.prev_score ? gv.rc_minsc : f.prev_score;
+		L.p0 = &ws->tmp2; L.p1 = t; L.a1 = 3; L.a2 = ss.tidx; L.a3 = ss.toff; L.a4 = ss.joinedOff; L.a5 = (uint32_t)(uint64_t)m; L.a6 = (uint32_t)((uint64_t)m >> 32);
+		M_OP(OP_COMBINE, PC_FS_R_COMB);
+	}
+	case PC_FS_R_COMB: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* t = &ws->tmp2;
+		const bool combined = L.a0 != 0;
+		if(t->overflow) ws->overflow |= 1;
+		int64_t m = gv.rc_minsc > f.prev_score ? gv.rc_minsc : f.prev_score;
+		if(mw->bestUnp > m) m = mw->bestUnp;
+		uint32_t anchor = t->len, ned = 0;                            // getRightAnchor :1062
+		for(int i = (int)t->nedits - 1; i >= 0; i--) {
+			const h2g_edit e = t->edits[i];
+			if(e.type == H2G_EDIT_SPL) { anchor = t->len - e.pos - 1; break; }
+			if(e.type == H2G_EDIT_MM || is_gap(e.type)) ned++;
+		}
+		f.ri++;
+		if(combined && t->score >= m && ned <= anchor / 4 && !al_is_searched(mw, t) && !al_redundant(mw, t, mach_sv(M).len)) {
+			if(t->score > f.prev_score) f.prev_score = gv.fs_tscore;
+			if(f.nlocal < AL_MAX_LOCALHITS) hit_copy(&f.local_hits[f.nlocal++], t); else ws->overflow |= 16;
+		}
+		M_GOTO(PC_FS_R_LOOP);
+	}
+	case PC_FS_REPORT: {                                         // :658-676
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		const uint32_t rdlen = mach_sv(M).len;
+		for(uint32_t i = 0; i < f.nlocal; i++) {
+			const h2g_ghit* can = &f.local_hits[i];
+			if(!P.secondary && can->score < f.prev_score) continue;
+			if(i > 0 && !al_is_searched(mw, can)) al_add_searched(ws, mw, can);
+			if(!al_redundant(mw, can, rdlen)) {
+				al_report(ws, mw, can, rdlen, gv.rc_minsc);
+				if(can->score > f.maxsc) f.maxsc = can->score;
+			}
+		}
+		RC_RET(f.maxsc);
+	}
+	// ---- partial alignment, left end through a database site (:697-811)
+	case PC_LSS_LOOP: {
+		Frame& f = FR;
+		const h2g_ghit& hit = f.hit;
+		for(; (uint32_t)f.ri < f.ncoords; f.ri++) {
+			const h2g_coord ss = f.coords[f.ri];
+			uint32_t fragoff, fraglen, left;
+			hit_get_left(&hit, nullptr, nullptr, &fragoff, &fraglen, &left, nullptr);
+			if(left + fraglen - 1 < ss.toff) continue;
+			if(fragoff + ss.toff < left + 1) continue;
+			const uint32_t readoff = fragoff + ss.toff - left - 1;
+			uint32_t joff = 0;
+			if(!text_off_to_joined(*C.g, hit.tidx, ss.tidx, &joff)) continue;
+			hit_init(&ws->tmp, hit.fw, readoff + 1, 0, hit.tidx, ss.tidx + 1, joff + 1);
+			L.p0 = &ws->tmp; L.a0 = 0; L.a1 = readoff + 1; L.a2 = 0;
+			M_OP(OP_EXTEND, PC_LSS_EXT);
+		}
+		M_GOTO(PC_RC_ENTRY_LX);
+	}
+	case PC_LSS_EXT: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		if(t->len == 0 || !hit_compatible(t, &f.hit, P.maxIntronLen, no_spliced)) { f.ri++; M_GOTO(PC_LSS_LOOP); }
+		const h2g_coord ss = f.coords[f.ri];
+		L.p0 = t; L.p1 = &f.hit; L.a1 = 1; L.a2 = ss.tidx; L.a3 = ss.toff; L.a4 = ss.joinedOff;
+		M_OP(OP_COMBINE, PC_LSS_COMB);
+	}
+	case PC_LSS_COMB: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* t = &ws->tmp;
+		const bool combined = L.a0 != 0;
+		if(t->overflow) ws->overflow |= 1;
+		int64_t m = gv.rc_minsc;
+		MINSC_LIVE(m);
+		f.ri++;
+		// "soft-clipping might be better" :782
+		if(combined && t->score >= m && t->score + (int64_t)sc_penalty(sc, 0) * (int64_t)f.hit.rdoff >= f.hit.score)
+			RC_CALL(t, t->rdoff, t->len + t->trim3, PC_LSS_RET);
+		M_GOTO(PC_LSS_LOOP);
+	}
+	case PC_LSS_RET: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_LSS_LOOP); }
+	case PC_RC_ENTRY_LX: {
+		Frame& f = FR;
+		const h2g_ghit& hit = f.hit;
+		// ---------------- extend to the left (spliced_aligner.h:813-1360) ----------------
+		f.use_localindex = 1;
+		if(f.hitoff == hit.rdoff && f.hitoff <= minK) {
+			hit_copy(&ws->tmp, &hit);
+			L.p0 = &ws->tmp; L.a0 = 1; L.a1 = H2G_MAX; L.a2 = 0;
+			M_OP(OP_EXTEND, PC_RC_ENTRY_L2);
+		}
+		M_GOTO(PC_RC_ENTRY_L3);
+	}
+	// ---- partial alignment, right end through a database site (:1377-1496)
+	case PC_RSS_LOOP: {
+		Frame& f = FR;
+		const h2g_ghit& hit = f.hit;
+		const uint32_t rdlen = mach_sv(M).len;
+		for(; (uint32_t)f.ri < f.ncoords; f.ri++) {
+			const h2g_coord ss = f.coords[f.ri];
+			uint32_t fragoff, fraglen, right;
+			hit_get_right(&hit, &fragoff, &fraglen, &right);
+			if(right > ss.tidx) continue;
+			const uint32_t readoff = fragoff + ss.tidx - right + 1;
+			if(readoff >= rdlen) continue;
+			uint32_t joff = 0;
+			if(!text_off_to_joined(*C.g, hit.tidx, ss.toff, &joff)) continue;
+			hit_init(&ws->tmp, hit.fw, readoff, 0, hit.tidx, ss.toff, joff);
+			L.p0 = &ws->tmp; L.a0 = 0; L.a1 = 0; L.a2 = rdlen - readoff;
+			M_OP(OP_EXTEND, PC_RSS_EXT);
+		}
+		M_GOTO(PC_RC_ENTRY_RX);
+	}
+	case PC_RSS_EXT: {
+		Frame& f = FR;
+		h2g_ghit* t = &ws->tmp;
+		if(t->len == 0 || !hit_compatible(&f.hit, t, P.maxIntronLen, no_spliced)) { f.ri++; M_GOTO(PC_RSS_LOOP); }
+		hit_copy(&ws->tmp2, &f.hit);                                  // combinedHit = hit
+		const h2g_coord ss = f.coords[f.ri];
+		L.p0 = &ws->tmp2; L.p1 = t; L.a1 = 1; L.a2 = ss.tidx; L.a3 = ss.toff; L.a4 = ss.joinedOff;
+		M_OP(OP_COMBINE, PC_RSS_COMB);
+	}
+	case PC_RSS_COMB: {
+		Frame& f = FR;
+		MateWS* mw = &ws->m[gv.mw_slot];
+		h2g_ghit* t = &ws->tmp2;
+		const bool combined = L.a0 != 0;
+		if(t->overflow) ws->overflow |= 1;
+		int64_t m = gv.rc_minsc;
+		MINSC_LIVE(m);
+		f.ri++;
+		const uint32_t rdlen = mach_sv(M).len;
+		if(combined && t->score >= m &&
+		   t->score + (int64_t)sc_penalty(sc, 0) * (int64_t)(rdlen - f.hit.rdoff - f.hit.len - f.hit.trim5) >= f.hit.score)
+			RC_CALL(t, t->rdoff - t->trim5, t->len + t->trim5, PC_RSS_RET);
+		M_GOTO(PC_RSS_LOOP);
+	}
+	case PC_RSS_RET: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_RSS_LOOP); }
+	case PC_RC_ENTRY_RX: {
+		Frame& f = FR;
+		const h2g_ghit& hit = f.hit;
+		const uint32_t rdlen = mach_sv(M).len;
+		// ---------------- extend to the right (spliced_aligner.h:1496-2050) ----------------
+		f.use_localindex = 1;
+		if(hit.len == f.hitlen && f.hitoff + f.hitlen + minK > rdlen) {
+			hit_copy(&ws->tmp, &hit);
+			L.p0 = &ws->tmp; L.a0 = 1; L.a1 = 0; L.a2 = H2G_MAX;
+			M_OP(OP_EXTEND, PC_RC_ENTRY_R2);
+		}
+		M_GOTO(PC_RC_ENTRY_R3);
 	}
 	case PC_RC_ENTRY_L2: { if(ws->tmp.rdoff == 0) FR.use_localindex = 0; M_GOTO(PC_RC_ENTRY_L3); }
 	case PC_RC_ENTRY_L3: {
@@ -755,7 +1031,7 @@ again:
 		if(f.uniqueStop) { L.p0 = t; L.a0 = 0; L.a1 = H2G_MAX; L.a2 = 0; M_OP(OP_EXTEND, PC_L_RI_B); }
 		M_GOTO(PC_L_RI_B);
 	}
-	case PC_L_RI_B: { L.p0 = &ws->tmp; L.p1 = &FR.hit; M_OP(OP_COMBINE, PC_L_RI_C); }
+	case PC_L_RI_B: { L.p0 = &ws->tmp; L.p1 = &FR.hit; L.a1 = 0; M_OP(OP_COMBINE, PC_L_RI_C); }
 	case PC_L_RI_C: {
 		Frame& f = FR;
 		MateWS* mw = &ws->m[gv.mw_slot];
@@ -845,7 +1121,7 @@ again:
 		if(f.uniqueStop) { L.p0 = t; L.a0 = 0; L.a1 = H2G_MAX; L.a2 = 0; M_OP(OP_EXTEND, PC_L_G_B); }
 		M_GOTO(PC_L_G_B);
 	}
-	case PC_L_G_B: { L.p0 = &ws->tmp; L.p1 = &FR.hit; M_OP(OP_COMBINE, PC_L_G_C); }
+	case PC_L_G_B: { L.p0 = &ws->tmp; L.p1 = &FR.hit; L.a1 = 0; M_OP(OP_COMBINE, PC_L_G_C); }
 	case PC_L_G_C: {
 		MateWS* mw = &ws->m[gv.mw_slot];
 		h2g_ghit* t = &ws->tmp;
@@ -986,6 +1262,7 @@ again:
 	case PC_R_RI_B: {
 		hit_copy(&ws->tmp2, &FR.hit);
 		L.p0 = &ws->tmp2; L.p1 = &ws->tmp;
+		L.a1 = 0;
 		M_OP(OP_COMBINE, PC_R_RI_C);
 	}
 	case PC_R_RI_C: {
@@ -1077,6 +1354,7 @@ again:
 	case PC_R_G_B: {
 		hit_copy(&ws->tmp2, &FR.hit);
 		L.p0 = &ws->tmp2; L.p1 = &ws->tmp;
+		L.a1 = 0;
 		M_OP(OP_COMBINE, PC_R_G_C);
 	}
 	case PC_R_G_C: {
@@ -1205,8 +1483,13 @@ H2G_MACH_FN void mach_op_combine(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;
 	const AlnParams& P = *C.P;
 	AlignWS* ws = M.ws;
-	L.a0 = hit_combine(*C.ref, P.sc, mach_sv(M), (h2g_ghit*)L.p0, (const h2g_ghit*)L.p1, ws->gv.rc_minsc, P.minIntronLen, P.no_spliced != 0,
-	                   C.sc, C.sc + H2G_COMBINE_MAXLEN, C.alts) ? 1u : 0u;
+	// a1 bit 0: join through the database site {a2 left, a3 right, a4 dir} with anchor minima 1, 1; bit 1: minsc in a5 / a6
+	const bool has_site = (L.a1 & 1u) != 0;
+	h2g_coord site; site.tidx = L.a2; site.toff = L.a3; site.joinedOff = L.a4;
+	const int64_t minsc = (L.a1 & 2u) ? (int64_t)(((uint64_t)L.a6 << 32) | (uint64_t)L.a5) : ws->gv.rc_minsc;
+	L.a0 = hit_combine(*C.ref, P.sc, mach_sv(M), (h2g_ghit*)L.p0, (const h2g_ghit*)L.p1, minsc, P.minIntronLen, P.no_spliced != 0,
+	                   ScVec{C.sc, C.sc_stride}, ScVec{C.sc + (size_t)H2G_COMBINE_MAXLEN * C.sc_stride, C.sc_stride}, C.alts,
+	                   has_site ? &site : nullptr, has_site ? 1u : 0u, has_site ? 1u : 0u) ? 1u : 0u;
 }
 H2G_MACH_FN void mach_op_adjust(const AlnCtx& C, Mach& M) {
 	Lane& L = M.L;

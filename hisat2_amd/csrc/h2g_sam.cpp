@@ -12,6 +12,7 @@
 #include <thread>
 #include "../../include/h2g_sam.h"
 #include "h2g_host_index.h"
+#include "h2g_splice_db_host.h"
 
 using namespace h2g;
 
@@ -35,6 +36,8 @@ struct h2g_sam {
 	bool secondary = false;                               // --secondary: selectByScore keeps lower-scoring alignments too
 	uint32_t smType = 2;                                  // --score-min (MAPQ's scMin), default L,0,-0.2
 	double smConst = 0.0, smCoeff = (double)(-0.2f);
+	h2g::HostSpliceDB ssdb;                               // h2g_sam_set_splice_sites: TLEN of concordant pairs leaves known introns out
+	uint32_t ssdb_window = 0;
 };
 
 namespace {
@@ -54,18 +57,20 @@ struct Score {        // AlnScore (aligner_result.h:44-330): score, then hisat2_
 };
 // AlnScore::calculate_hisat2_score aligner_result.h:322-350: score, repeat (never), transcript (1 = spliced: near splice sites,
 // reportHit hi_aligner.h:6100-6143), splice score (mean intron length of the short-anchored splices / 100), trimmed bases
-int64_t hisat2_score(int64_t sc, uint32_t trim, bool spliced = false, uint32_t splicescore = 0) {
+int64_t hisat2_score(int64_t sc, uint32_t trim, int transcript = 0, uint32_t splicescore = 0) {
 	if(sc > INT32_MAX) sc = INT32_MAX; else if(sc < INT32_MIN) sc = INT32_MIN;
 	const int64_t t = trim > 0xFFFF ? 0 : 0xFFFF - (int64_t)trim;
 	int64_t spl = (int64_t)splicescore / 100;
 	spl = spl > 255 ? 0 : 255 - spl;
-	return (int64_t)(((uint64_t)sc << 32) | ((uint64_t)(spliced ? 1 : 0) << 24) | ((uint64_t)spl << 16) | (uint64_t)t);
+	return (int64_t)(((uint64_t)sc << 32) | ((uint64_t)transcript << 24) | ((uint64_t)spl << 16) | (uint64_t)t);
 }
 Score score_of(const h2g_alnres& r) {
 	Score s; s.valid = true; s.score = r.score;
-	bool spliced = false;
-	for(uint32_t i = 0; i < r.nedits; i++) if(r.edits[i].type == EDIT_SPL) { spliced = true; break; }
-	s.h2 = hisat2_score(r.score, r.trim5 + r.trim3, spliced, r.splicescore);
+	int transcript = 0;                  // 2: every splice is a database site, 1: spliced (GenomeHit::spliced hi_aligner.h:1086)
+	bool all_known = true;
+	for(uint32_t i = 0; i < r.nedits; i++) if(r.edits[i].type == EDIT_SPL) { transcript = 1; all_known = all_known && (r.edits[i].pad >> 7) != 0; }
+	if(transcript && all_known) transcript = 2;
+	s.h2 = hisat2_score(r.score, r.trim5 + r.trim3, transcript, r.splicescore);
 	return s;
 }
 Score add(const Score& a, const Score& b) { Score s; s.valid = a.valid; s.score = a.score + b.score; s.h2 = a.h2 + b.h2; return s; }
@@ -254,7 +259,7 @@ void put_ref_name(std::string& o, const std::string& name) { for(char c : name) 
 // (getExtendedCoords :1156).  rfextent_ does not count introns (calcRefExtent :1880) while refcoord_right() does (:1256), so
 // each alignment has two (start, end) pairs — (st, en) anchored at its left end, (st2, en2) at its right end — and the
 // upstream mate enters with the right-anchored pair: introns inside the mates do not count towards TLEN.
-int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1) {
+int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1, const h2g_sam* S = nullptr /* concordant pairs: the splice-site database */, uint64_t rdid = 0) {
 	auto coords = [](const h2g_alnres& r, int64_t& st, int64_t& en, int64_t& st2, int64_t& en2) {
 		int64_t ext = r.len, spl = 0;
 		for(uint32_t i = 0; i < r.nedits; i++) {
@@ -276,7 +281,25 @@ int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1)
 	} else imUpstream = false;
 	const int64_t up = imUpstream ? std::min(st2, ost) : std::min(st, ost2);
 	const int64_t dn = imUpstream ? std::max(en2, oen) : std::max(en, oen2);
-	int64_t fl = 1 + dn - up;
+	int64_t intron_len = 0;
+	if(S && !S->ssdb.fw.empty() && me.tidx < S->ssdb.fw_first.size() - 1) {   // :1669-1686: the longest database intron between the mates
+		const int64_t up_right = imUpstream ? std::min(en2, oen) : std::min(en, oen2);
+		const int64_t dn_left = imUpstream ? std::max(st2, ost) : std::max(st, ost2);
+		if(up_right + 100 < dn_left) {
+			// getRightSpliceSites(ref, up_right, dn_left - up_right): sites whose left end lies in [up_right, dn_left - 1]
+			const uint32_t lo = S->ssdb.fw_first[me.tidx], hi = S->ssdb.fw_first[me.tidx + 1];
+			const auto* a = S->ssdb.fw.data();
+			uint32_t x = lo, y = hi;
+			while(x < y) { const uint32_t m = x + ((y - x) >> 1); if((int64_t)a[m].left < up_right) x = m + 1; else y = m; }
+			for(; x < hi && (int64_t)a[x].left <= dn_left - 1; x++) {
+				if(!a[x].fromfile && (uint64_t)a[x].readid + S->ssdb_window > rdid) continue;
+				if((int64_t)a[x].left <= up || (int64_t)a[x].right >= dn) continue;
+				const int64_t il = (int64_t)a[x].right - (int64_t)a[x].left - 1;
+				if(intron_len < il) intron_len = il;
+			}
+		}
+	}
+	int64_t fl = 1 + dn - up - intron_len;
 	return imUpstream ? fl : -fl;
 }
 
@@ -326,7 +349,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	else o.push_back('0');
 	o.push_back('\t');
 	// ISIZE: setMateParams computes it when the opposite mate is known and on the same reference (or concordant)
-	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1()));
+	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1(), fl.concordant() ? &S : nullptr));
 	else o.push_back('0');
 	o.push_back('\t');
 	o += seq; o.push_back('\t');
@@ -555,6 +578,40 @@ extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
 }
 extern "C" void h2g_sam_set_no_unal(h2g_sam* S, int on) { if(S) S->no_unal = on != 0; }
 extern "C" void h2g_sam_set_secondary(h2g_sam* S, int on) { if(S) S->secondary = on != 0; }
+// SpliceSiteDB::read(ifstream&, known) splice_site.cpp:727-776: whitespace-separated (name, left, right, strand) records; names the
+// index does not hold are skipped.  Returns the number of records; the first `cap` are written to out.
+extern "C" size_t h2g_sam_read_splice_site_file(const h2g_sam* S, const char* path, int known, h2g_splice_site* out, size_t cap) {
+	if(!S || !path) return 0;
+	FILE* f = fopen(path, "rb");
+	if(!f) return (size_t)-1;
+	std::string data;
+	char buf[1 << 16];
+	size_t got;
+	while((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
+	fclose(f);
+	std::vector<std::string> first(S->refnames.size());
+	for(size_t i = 0; i < S->refnames.size(); i++) { const std::string& nm = S->refnames[i]; size_t k = 0; while(k < nm.size() && !isspace((unsigned char)nm[k])) k++; first[i] = nm.substr(0, k); }
+	size_t n = 0, pos = 0;
+	auto token = [&](std::string& t) { while(pos < data.size() && isspace((unsigned char)data[pos])) pos++; const size_t a = pos; while(pos < data.size() && !isspace((unsigned char)data[pos])) pos++; t.assign(data, a, pos - a); return pos > a; };
+	std::string name, l, r, d;
+	while(token(name) && token(l) && token(r) && token(d)) {
+		uint32_t ref = 0;
+		for(; ref < first.size(); ref++) if(first[ref] == name) break;
+		if(ref >= first.size()) continue;
+		if(n < cap && out) {
+			h2g_splice_site& x = out[n];
+			x.tidx = ref; x.left = (uint32_t)strtoul(l.c_str(), nullptr, 10); x.right = (uint32_t)strtoul(r.c_str(), nullptr, 10); x.readid = 0;
+			x.dir = d[0] == '+' ? 2 : 3; x.fromfile = 1; x.known = known ? 1 : 0; x.pad_ = 0;    // SPL_FW : SPL_RC
+		}
+		n++;
+	}
+	return n;
+}
+extern "C" void h2g_sam_set_splice_sites(h2g_sam* S, const h2g_splice_site* sites, size_t n, uint32_t window) {
+	if(!S) return;
+	h2g::build_splice_db(sites, n, (uint32_t)S->refnames.size(), S->ssdb);
+	S->ssdb_window = window;
+}
 extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, double coeff) { if(S) { S->smType = type; S->smConst = c; S->smCoeff = coeff; } }
 
 static h2g_status format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,

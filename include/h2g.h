@@ -64,6 +64,15 @@ H2G_EXPORT h2g_status h2g_index_get_info(const h2g_index*, h2g_index_info* out);
  * consistent Occ checkpoints (GRCh38 scale = 15.3 M sides ~ 0.98 GB); only rank queries are valid. */
 H2G_EXPORT h2g_status h2g_index_synth_sides(uint64_t num_sides, uint64_t seed, int device, h2g_index** out);
 H2G_EXPORT void       h2g_index_free(h2g_index*);
+/* Splice sites for spliced alignment (SpliceSiteDB, splice_site.h:470): what --known-splicesite-infile / --novel-splicesite-infile
+ * hand the reference (SpliceSiteDB::read splice_site.cpp:727: text name, left = last base of the upstream exon, right = first
+ * base of the downstream exon, both 0-based, strand).  go() joins reads through them (spliced_aligner.h:409-676, 685-811,
+ * 1365-1496) and the SAM formatter leaves their introns out of TLEN (aligner_result.h:1669-1689).  Replaces the previous set;
+ * n == 0 empties the database.  readid / fromfile: a site with fromfile == 0 is one found by read `readid` and is visible only to
+ * reads readid + window and later (the reference's -p window, hisat2.cpp:3687). */
+typedef struct { uint32_t tidx, left, right, readid; uint8_t dir /* 2 = '+', 3 = '-' (SPL_FW / SPL_RC) */, fromfile, known, pad_; } h2g_splice_site;
+H2G_EXPORT h2g_status h2g_index_set_splice_sites(h2g_index*, const h2g_splice_site* sites, size_t n, uint32_t window);
+
 H2G_EXPORT const char* h2g_last_error(void);
 
 /* ---- stream / reads ---------------------------------------------------------------------------------- */

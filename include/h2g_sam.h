@@ -34,6 +34,12 @@ H2G_EXPORT size_t     h2g_sam_summary(const h2g_sam*, char* out, size_t cap);
 H2G_EXPORT void       h2g_sam_set_no_unal(h2g_sam*, int on);
 /* --secondary: the sink's -k selection for pairs keeps lower-scoring alignments (aln_sink.h:2733-2745) */
 H2G_EXPORT void       h2g_sam_set_secondary(h2g_sam*, int on);
+/* reads a --known-splicesite-infile / --novel-splicesite-infile (SpliceSiteDB::read splice_site.cpp:727): returns the number of
+ * records of texts the index holds ((size_t)-1: cannot open), the first `cap` of them in out */
+H2G_EXPORT size_t     h2g_sam_read_splice_site_file(const h2g_sam*, const char* path, int known, h2g_splice_site* out, size_t cap);
+/* the splice sites given to h2g_index_set_splice_sites: TLEN of a concordant pair leaves the longest database intron lying between
+ * its mates out (AlnRes::setFragmentLength aligner_result.h:1669-1689, --no-templatelen-adjustment is not built) */
+H2G_EXPORT void       h2g_sam_set_splice_sites(h2g_sam*, const h2g_splice_site* sites, size_t n, uint32_t window);
 /* --score-min as given to the aligner (h2g_align_params.score_min_*): MAPQ is relative to it (unique.h:214-222) */
 H2G_EXPORT void       h2g_sam_set_score_min(h2g_sam*, uint32_t type, double constant, double coeff);
 

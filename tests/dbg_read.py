@@ -26,6 +26,10 @@ for i in idx:
     s = seqs[str(i)]
     rd = np.array([code[c] for c in s], dtype=np.uint8)
     sys.stderr.write(f"==== read {i} {s}\n"); sys.stderr.flush()
-    outs, recs = emu_align(os.path.join(tmp, "g"), [rd], [str(i)], bowtie2_dp=int(os.environ.get("DP", "0")), no_spliced=int(os.environ.get("NOSPLICED", "1")))
+    sites = None
+    if os.path.exists(os.path.join(tmp, "ss.txt")):   # fuzz_spliced with known splice sites
+        from hisat2_amd import api
+        sites = api.read_splice_site_file(os.path.join(tmp, "ss.txt"), refnames)
+    outs, recs = emu_align(os.path.join(tmp, "g"), [rd], [str(i)], bowtie2_dp=int(os.environ.get("DP", "0")), no_spliced=int(os.environ.get("NOSPLICED", "1")), splice_sites=sites)
     got = SU.render(outs, recs, refnames, [rd], [str(i)])
     print(" GOT ", got[str(i)], "\n WANT", want[str(i)])

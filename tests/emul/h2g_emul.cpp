@@ -18,6 +18,7 @@
 #include "../../hisat2_amd/csrc/h2g_sw.h"
 #include "../../hisat2_amd/csrc/h2g_local_pack.h"
 #include "../../hisat2_amd/csrc/h2g_splice_host.h"
+#include "../../hisat2_amd/csrc/h2g_splice_db_host.h"
 
 using namespace h2g;
 
@@ -37,6 +38,7 @@ struct Emu {
 	bool has_params = false;
 	h2g_align_params params;
 	std::vector<uint8_t> sw;
+	HostSpliceDB hssdb; DSpliceDB dssdb;
 	DReads reads() const {
 		DReads r;
 		r.codes = codes.data(); r.offs = offs.data(); r.quals = has_quals ? quals.data() : nullptr;
@@ -248,6 +250,7 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 		P->sc.donor_sum = d_.data(); P->sc.acc_sum1 = a1_.data(); P->sc.acc_sum2 = a2_.data();
 	}
 	C->g = &e->dg; C->ref = &e->dr; C->ls = &e->dls; C->P = P;
+	C->ssdb = no_spliced ? nullptr : &e->dssdb;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C->sw = e->sw.data();
 	static GraphWS gws_;
@@ -255,6 +258,15 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	static int64_t sc_[2 * H2G_COMBINE_MAXLEN];
 	C->sc = sc_;
 	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->gsl = e->dg.linear ? nullptr : &gsl_; C->graph = !e->dg.linear;
+}
+
+void h2gemu_set_splice_sites(Emu* e, const h2g_splice_site* sites, size_t n, uint32_t window) {
+	build_splice_db(sites, n, e->host.g.nPat, e->hssdb);
+	e->dssdb = DSpliceDB();
+	if(e->hssdb.fw.empty()) return;
+	e->dssdb.fw = e->hssdb.fw.data(); e->dssdb.bw = e->hssdb.bw.data();
+	e->dssdb.fw_first = e->hssdb.fw_first.data(); e->dssdb.bw_first = e->hssdb.bw_first.data();
+	e->dssdb.n = (uint32_t)e->hssdb.fw.size(); e->dssdb.window = window;
 }
 
 void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, AlnRec* recs) {

@@ -52,12 +52,28 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400):
         if rng.random() < 0.5:
             r = (3 - r[::-1]).astype(np.uint8)
         reads[i] = r
-    return [g], reads
+    return [g], reads, introns
 
 
-def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=()):
+def known_sites(introns, seed, frac):
+    """a --known-splicesite-infile for a fraction of the planted introns plus some sites that do not exist in the reads"""
+    rng = np.random.default_rng(seed + 77)
+    sites = [(0, a - 1, b, "+") for a, b in introns if rng.random() < frac]
+    for a, b in introns[::7]:
+        sites.append((0, a - 1 - int(rng.integers(3, 40)), b + int(rng.integers(3, 40)), "-" if rng.random() < 0.5 else "+"))
+    return sites
+
+
+def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=(), known=0.0):
     tmp = tempfile.mkdtemp(prefix="h2spl")
-    contigs, reads = make_case(seed, nreads, sub=sub)
+    contigs, reads, introns = make_case(seed, nreads, sub=sub)
+    sites = None
+    if known > 0:
+        sites = known_sites(introns, seed, known)
+        with open(os.path.join(tmp, "ss.txt"), "w") as f:
+            for t, l, r, d in sites:
+                f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
+        extra = list(extra) + ["--known-splicesite-infile", os.path.join(tmp, "ss.txt")]
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
@@ -71,7 +87,8 @@ def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=()):
     qnames = [str(i) for i in range(nreads)]
     rl = [reads[i] for i in range(nreads)]
     if backend is None:
-        outs, recs = emu_align(base, rl, qnames, no_spliced=0, options=list(extra))
+        eopts = [o for o in extra if o != "--known-splicesite-infile" and not str(o).endswith("ss.txt")]
+        outs, recs = emu_align(base, rl, qnames, no_spliced=0, options=eopts, splice_sites=sites)
         got = SU.render(outs, recs, refnames, rl, qnames)
     else:
         outs, got = backend(base, reads, qnames, refnames, options=list(extra))
@@ -90,4 +107,5 @@ if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
     sub = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
-    sys.exit(1 if run_case(seed, n, sub)[0] else 0)
+    known = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    sys.exit(1 if run_case(seed, n, sub, known=known)[0] else 0)

@@ -54,13 +54,15 @@ def make_case(seed, npairs, rdlen=101, sub=0.005, glen=400000, nintrons=300, fra
             f = (3 - f[::-1]).astype(np.uint8)
         m1[i] = f[:rdlen]
         m2[i] = 3 - f[::-1][:rdlen]
-    return [g], m1, m2
+    return [g], m1, m2, introns
 
 
-def emu_pairs(base, m1, m2, q1, q2, options=()):
+def emu_pairs(base, m1, m2, q1, q2, options=(), splice_sites=None):
     e = Emu(base)
-    from h2gemu_align import set_options
+    from h2gemu_align import set_options, set_splice_sites
     set_options(e, 0, list(options))
+    if splice_sites:
+        set_splice_sites(e, splice_sites)
     n, L = m1.shape
     c1, o1 = synth.flatten_reads(m1)
     c2, o2 = synth.flatten_reads(m2)
@@ -76,9 +78,17 @@ def emu_pairs(base, m1, m2, q1, q2, options=()):
     return outs, r1, r2
 
 
-def run_case(seed, npairs, sub=0.005, extra=(), show=6):
+def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0):
     tmp = tempfile.mkdtemp(prefix="h2splpe")
-    contigs, m1, m2 = make_case(seed, npairs, sub=sub)
+    contigs, m1, m2, introns = make_case(seed, npairs, sub=sub)
+    sites, sopt = None, []
+    if known > 0:
+        import fuzz_spliced as FS
+        sites = FS.known_sites(introns, seed, known)
+        with open(os.path.join(tmp, "ss.txt"), "w") as f:
+            for t, l, r, d in sites:
+                f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
+        sopt = ["--known-splicesite-infile", os.path.join(tmp, "ss.txt")]
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
@@ -87,10 +97,10 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6):
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)
     sam = os.path.join(tmp, "ref.sam")
-    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-temp-splicesite", "-x", base, "-1", f1, "-2", f2, "-S", sam] + list(extra),
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-temp-splicesite", "-x", base, "-1", f1, "-2", f2, "-S", sam] + list(extra) + sopt,
                    check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
     q = [str(i) for i in range(npairs)]
-    outs, r1, r2 = emu_pairs(base, m1, m2, q, q, options=extra)
+    outs, r1, r2 = emu_pairs(base, m1, m2, q, q, options=extra, splice_sites=sites)
     n = npairs
     res = (api.PairResult * n)()
     a1 = (api.AlnRes * (n * api.PAIR_RES_CAP))()
@@ -101,7 +111,7 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6):
             for k in range(min(outs[i].nres[m], api.PAIR_RES_CAP)):
                 C.memmove(C.byref(dst[i * api.PAIR_RES_CAP + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
     khits = int(extra[extra.index("-k") + 1]) if "-k" in extra else 5
-    got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra))
+    got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra) + sopt)
     want = SL.body_lines(sam)
     from test_sam_lines import diff_lines
     bad = diff_lines(got, want, show=show)
@@ -115,4 +125,5 @@ if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     sub = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
-    sys.exit(1 if run_case(seed, n, sub)[0] else 0)
+    known = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+    sys.exit(1 if run_case(seed, n, sub, known=known)[0] else 0)

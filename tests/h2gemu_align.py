@@ -21,8 +21,17 @@ def set_options(e, bowtie2_dp, options):
     return p
 
 
-def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0, quals=None, options=()):
+def set_splice_sites(e, sites, known=True):
+    from hisat2_amd import api
+    a = api.splice_site_array(sites, known)
+    e.L.h2gemu_set_splice_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+    e.L.h2gemu_set_splice_sites(e.h, a, len(sites), 0)
+
+
+def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0, quals=None, options=(), splice_sites=None):
     e = Emu(base)
+    if splice_sites:
+        set_splice_sites(e, splice_sites)
     if options:
         set_options(e, bowtie2_dp, options)
     e.L.h2gemu_set_bowtie2_dp.argtypes = [C.c_void_p, C.c_uint32]

@@ -49,6 +49,15 @@ def _score_min(L, h, options):
     if options and "--secondary" in options:
         L.h2g_sam_set_secondary.argtypes = [C.c_void_p, C.c_int]
         L.h2g_sam_set_secondary(h, 1)
+    if options and "--known-splicesite-infile" in options:
+        fn = options[list(options).index("--known-splicesite-infile") + 1].encode()
+        L.h2g_sam_read_splice_site_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.h2g_sam_read_splice_site_file.restype = C.c_size_t
+        n = L.h2g_sam_read_splice_site_file(h, fn, 1, None, 0)
+        a = (api.SpliceSite * max(1, n))()
+        L.h2g_sam_read_splice_site_file(h, fn, 1, a, n)
+        L.h2g_sam_set_splice_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        L.h2g_sam_set_splice_sites(h, a, n, 0)
 
 
 def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):

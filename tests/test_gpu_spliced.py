@@ -45,7 +45,7 @@ def _both(tmp, base, inputs, extra):
 ])
 def test_unpaired_spliced_command_line(tmp_path, seed, n, sub, extra):
     import fuzz_spliced as F
-    contigs, reads = F.make_case(seed, n, sub=sub)
+    contigs, reads, _ = F.make_case(seed, n, sub=sub)
     base = _index(tmp_path, contigs)
     rfa = os.path.join(str(tmp_path), "r.fa")
     synth.write_reads_fasta(rfa, reads)
@@ -57,10 +57,43 @@ def test_unpaired_spliced_command_line(tmp_path, seed, n, sub, extra):
 @pytest.mark.parametrize("seed,n,sub", [(351, 10000, 0.005), (352, 6000, 0.02)])
 def test_paired_spliced_command_line(tmp_path, seed, n, sub):
     import fuzz_spliced_pairs as F
-    contigs, m1, m2 = F.make_case(seed, n, sub=sub)
+    contigs, m1, m2, _ = F.make_case(seed, n, sub=sub)
     base = _index(tmp_path, contigs)
     f1, f2 = os.path.join(str(tmp_path), "r1.fa"), os.path.join(str(tmp_path), "r2.fa")
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)
     want = _both(tmp_path, base, ["-1", f1, "-2", f2], ())
     assert sum(1 for l in want if "N" in l.split("\t")[5]) > n // 5
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,n,sub,known", [(361, 15000, 0.01, 0.7), (362, 8000, 0.03, 1.0)])
+def test_known_splice_sites_command_line(tmp_path, seed, n, sub, known):
+    """--known-splicesite-infile: the device database (h2g_index_set_splice_sites) through go() and the SAM formatter"""
+    import fuzz_spliced as F
+    contigs, reads, introns = F.make_case(seed, n, sub=sub)
+    base = _index(tmp_path, contigs)
+    rfa = os.path.join(str(tmp_path), "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    ss = os.path.join(str(tmp_path), "ss.txt")
+    with open(ss, "w") as f:
+        for t, l, r, d in F.known_sites(introns, seed, known):
+            f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
+    want = _both(tmp_path, base, ["-U", rfa], ("--known-splicesite-infile", ss))
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > n // 5
+
+
+@needs_ref
+def test_known_splice_sites_pairs_command_line(tmp_path):
+    import fuzz_spliced as FS
+    import fuzz_spliced_pairs as F
+    contigs, m1, m2, introns = F.make_case(371, 8000, sub=0.01)
+    base = _index(tmp_path, contigs)
+    f1, f2 = os.path.join(str(tmp_path), "r1.fa"), os.path.join(str(tmp_path), "r2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    ss = os.path.join(str(tmp_path), "ss.txt")
+    with open(ss, "w") as f:
+        for t, l, r, d in FS.known_sites(introns, 371, 0.8):
+            f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
+    _both(tmp_path, base, ["-1", f1, "-2", f2], ("--known-splicesite-infile", ss))

@@ -150,3 +150,32 @@ def test_spliced_scoring_options(seed, extra):
     import fuzz_spliced as F
     bad, _ = F.run_case(seed, 2000, sub=0.01, verbose=2, extra=extra)
     assert bad == 0
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,sub,known", [(611, 0.01, 0.6), (612, 0.005, 1.0)])
+def test_known_splice_sites_lines_identical(seed, sub, known):
+    """--known-splicesite-infile (static splice-site database): joins through database sites of full alignments
+    (spliced_aligner.h:409-676) and of partial ones (:685-811, :1365-1496), known splices cost nothing and rank above novel ones
+    (transcript bits of hisat2_score) — every line byte-identical; the database changes about a fifth of the reads"""
+    import fuzz_spliced as F
+    from h2gemu_align import emu_align
+    bad, tmp = F.run_case(seed, 2500, sub=sub, verbose=2, known=known)
+    assert bad == 0
+    names, reads = read_fa(os.path.join(tmp, "r.fa"))
+    sites = api.read_splice_site_file(os.path.join(tmp, "ss.txt"), ["chr1"])
+    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, no_spliced=0, splice_sites=sites)
+    res, aln = SL.emu_to_abi(outs, recs)
+    opts = ["--known-splicesite-infile", os.path.join(tmp, "ss.txt")]
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, options=opts)
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert diff_lines(got, want) == 0
+    assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
+
+
+@needs_ref
+def test_known_splice_sites_pairs_lines_identical():
+    """pairs with a splice-site database: TLEN leaves the longest database intron between the mates out (aligner_result.h:1669)"""
+    import fuzz_spliced_pairs as F
+    bad, tmp = F.run_case(711, 1500, sub=0.01, show=3, known=0.8)
+    assert bad == 0
