@@ -183,7 +183,7 @@ class AlignParams(C.Structure):
                 ("rfg_const", C.c_int32), ("rfg_linear", C.c_int32), ("sc_max", C.c_int32), ("sc_min", C.c_int32), ("score_min_type", u32),
                 ("score_min_const", C.c_double), ("score_min_coeff", C.c_double), ("no_temp_splicesite", u32),
                 ("min_intronlen", u32), ("max_intronlen", u32), ("pen_cansplice", C.c_int32), ("pen_noncansplice", C.c_int32),
-                ("pen_canintronlen_type", u32), ("pen_noncanintronlen_type", u32), ("pad_", u32),
+                ("pen_canintronlen_type", u32), ("pen_noncanintronlen_type", u32), ("first_read_id", u32),
                 ("pen_canintronlen_const", C.c_double), ("pen_canintronlen_coeff", C.c_double),
                 ("pen_noncanintronlen_const", C.c_double), ("pen_noncanintronlen_coeff", C.c_double)]
 

@@ -704,7 +704,7 @@ inline void align_params_defaults(h2g_align_params* p, bool linear) {
 	p->no_spliced_alignment = 1; p->secondary = 0; p->bowtie2_dp = 0;
 	p->mm_max = 6; p->mm_min = 2; p->n_pen = 1; p->rdg_const = 5; p->rdg_linear = 3; p->rfg_const = 5; p->rfg_linear = 3; p->sc_max = 2; p->sc_min = 1;
 	p->score_min_type = 2; p->score_min_const = 0.0; p->score_min_coeff = (double)(-0.2f);
-	p->no_temp_splicesite = 0; p->pad_ = 0;
+	p->no_temp_splicesite = 0; p->first_read_id = 0;
 	p->min_intronlen = 20; p->max_intronlen = 500000; p->pen_cansplice = 0; p->pen_noncansplice = 12;   // hisat2.cpp:493-499
 	p->pen_canintronlen_type = 4; p->pen_canintronlen_const = -8.0; p->pen_canintronlen_coeff = 1.0;
 	p->pen_noncanintronlen_type = 4; p->pen_noncanintronlen_const = -8.0; p->pen_noncanintronlen_coeff = 1.0;
@@ -878,6 +878,7 @@ struct AlnCtx {
 	int64_t* sc = nullptr;   // this lane's combineWith temp_scores: 2 x H2G_COMBINE_MAXLEN elements, sc_stride apart (scratch of one primitive)
 	uint32_t sc_stride = 1;
 	const DAlts* alts = nullptr;      // graph index: the ALT database
+	uint32_t rdid_base = 0;           // id of read 0 of the batch (Read::rdid): what the database's visibility window is measured against
 	const DSpliceDB* ssdb = nullptr;  // splice sites read from a file (h2g_index_set_splice_sites); nullptr or n == 0: ssdb.empty()
 	struct GraphWS* gws = nullptr;    // graph index: this lane's scratch for one primitive (group walk, ALT extension)
 	struct GraphSlot* gsl = nullptr;  // graph index: the graph state of the read being worked on

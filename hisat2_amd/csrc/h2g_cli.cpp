@@ -9,6 +9,8 @@
 #include <string.h>
 #include <ctype.h>
 #include <string>
+#include <map>
+#include <array>
 #include <vector>
 #include <thread>
 #include <chrono>
@@ -283,10 +285,18 @@ int main(int argc, char** argv) {
 		printf("%llu %llu %016llx\n", (unsigned long long)n, (unsigned long long)bases, (unsigned long long)h);
 		return 0;
 	}
-	if(!nospliced && !notempss) {
-		fprintf(stderr, "hisat2-align-amd: spliced alignment is built for --no-temp-splicesite (novel splice sites are not shared between reads); "
-		        "pass it, or --no-spliced-alignment\n");
-		return 1;
+	// Temporary splice sites (the reference's default): a read sees the junctions of reads at least W = 1000 * p ids before it
+	// (hisat2.cpp:3687; -p 1 means W = 0, every read after the other).  The batches are waves of <= W reads run one after the other.
+	const bool temp_ss = !nospliced && !notempss;
+	uint32_t ss_window = 0;
+	if(temp_ss) {
+		if(threads < 2) {
+			fprintf(stderr, "hisat2-align-amd: with temporary splice sites a read depends on the reads 1000 x <-p> before it; -p 1 would run the reads one by one. "
+			        "Pass -p >= 2 (output == hisat2 -p <int> --reorder), --no-temp-splicesite or --no-spliced-alignment\n");
+			return 1;
+		}
+		ss_window = 1000u * (uint32_t)threads;
+		if(batch > ss_window) batch = ss_window;
 	}
 	const bool paired = u.empty();
 	const double t0 = now();
@@ -372,8 +382,17 @@ int main(int argc, char** argv) {
 		return 1;
 	}
 	// splice sites from files (hisat2.cpp:4100-4120): one database for go() on every device and for TLEN
+	std::vector<h2g_splice_site> sites;                  // the splice-site database: file sites, then the temporary ones by first appearance
+	std::map<std::array<uint32_t, 4>, size_t> site_at;    // (text, left, right, dir) -> position in `sites`
+	auto publish_sites = [&]() {
+		for(int g = 0; g < gpus; g++) {
+			bool first = true;
+			for(int q = 0; q < g; q++) if(ixs[(size_t)q] == ixs[(size_t)g]) first = false;
+			if(first && h2g_index_set_splice_sites(ixs[(size_t)g], sites.data(), sites.size(), ss_window) != H2G_OK) die("cannot upload the splice sites");
+		}
+		h2g_sam_set_splice_sites(sam, sites.data(), sites.size(), ss_window);
+	};
 	if(!nospliced && (!known_ss.empty() || !novel_ss.empty())) {
-		std::vector<h2g_splice_site> sites;
 		for(int pass = 0; pass < 2; pass++) {
 			const std::string& fn = pass == 0 ? known_ss : novel_ss;
 			if(fn.empty()) continue;
@@ -383,13 +402,17 @@ int main(int argc, char** argv) {
 			sites.resize(at + n);
 			h2g_sam_read_splice_site_file(sam, fn.c_str(), pass == 0, sites.data() + at, n);
 		}
-		for(int g = 0; g < gpus; g++) {
-			bool first = true;
-			for(int q = 0; q < g; q++) if(ixs[q] == ixs[g]) first = false;
-			if(first && h2g_index_set_splice_sites(ixs[g], sites.data(), sites.size(), 0) != H2G_OK) die("cannot upload the splice sites");
+		{   // SpliceSiteDB::read keeps the first of equal sites (splice_site.cpp:750)
+			std::vector<h2g_splice_site> uniq;
+			for(const h2g_splice_site& x : sites) {
+				const std::array<uint32_t, 4> key = {x.tidx, x.left, x.right, (uint32_t)x.dir};
+				if(site_at.emplace(key, uniq.size()).second) uniq.push_back(x);
+			}
+			sites.swap(uniq);
 		}
-		h2g_sam_set_splice_sites(sam, sites.data(), sites.size(), 0);
+		publish_sites();
 	}
+	if(temp_ss) h2g_sam_collect_novel_sites(sam, 1);
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);
 	FILE* out = outfn.empty() ? stdout : fopen(outfn.c_str(), "wb");
@@ -414,7 +437,8 @@ int main(int argc, char** argv) {
 	uint64_t budget = upto;                               // -u counts the reads after the skipped ones (qUpto += skipReads, hisat2.cpp:1959-1963)
 	const int G = gpus, H = gpus + 1;                    // G streams (one per device) in flight, H host batch buffers: batch k is
 	std::vector<Batch> A((size_t)H), B((size_t)H);     // parsed into buffer k mod H while up to G earlier ones are on the GPUs
-	struct Str { h2g_stream* st = nullptr; size_t reads = 0, bases = 0; long batch = -1; size_t n = 0; };
+	struct Str { h2g_stream* st = nullptr; size_t reads = 0, bases = 0; long batch = -1; size_t n = 0; uint64_t first_id = 0; };
+	uint64_t next_id = skip;                              // Read::rdid of the next read (the skipped ones count, hisat2.cpp:3319)
 	std::vector<Str> S((size_t)G);
 	uint64_t nreads = 0, naligned = 0, novf = 0, nsecond = 0;
 	double t_gpu = 0, t_fmt = 0, t_parse = 0, t_up = 0, t_fetch = 0, t_stream = 0;
@@ -433,6 +457,7 @@ int main(int argc, char** argv) {
 		const size_t n = sg.n;
 		size_t used = 0;
 		const double tq0 = now();
+		h2g_sam_set_first_read_id(sam, sg.first_id);
 		if(paired) {
 			pres.resize(n); ao1.assign(n + 1, 0); ao2.assign(n + 1, 0);
 			if(aln.size() < 2 * n + 64) aln.resize(2 * n + 64);
@@ -480,6 +505,20 @@ int main(int argc, char** argv) {
 			t_fmt += now() - tf;
 		}
 		fwrite(buf.data(), 1, used, out);
+		if(temp_ss) {   // the junctions of the lines just written join the database (SpliceSiteDB::addSpliceSite: smallest read id per site)
+			static std::vector<h2g_splice_site> novel;
+			const size_t k = h2g_sam_take_novel_sites(sam, nullptr, 0);
+			novel.resize(k);
+			if(k) h2g_sam_take_novel_sites(sam, novel.data(), k);
+			bool changed = false;
+			for(const h2g_splice_site& x : novel) {
+				const std::array<uint32_t, 4> key = {x.tidx, x.left, x.right, (uint32_t)x.dir};
+				auto it = site_at.find(key);
+				if(it == site_at.end()) { site_at.emplace(key, sites.size()); sites.push_back(x); changed = true; }
+				else if(!sites[it->second].fromfile && x.readid < sites[it->second].readid) { sites[it->second].readid = x.readid; changed = true; }
+			}
+			if(changed) publish_sites();
+		}
 		{ h2g_counters hc; if(h2g_get_counters(st, &hc) == H2G_OK) nsecond += hc.n_second_pass; }
 		nreads += n;
 		sg.batch = -1;
@@ -495,6 +534,9 @@ int main(int argc, char** argv) {
 		if(n == 0) break;
 		const int g = (int)(k % G);
 		const double tg = now();
+		if(temp_ss) {                                  // a wave needs the sites of every earlier one: nothing stays in flight
+			for(long q = k - G; q < k; q++) if(q >= 0) complete((int)(q % G));
+		}
 		complete(g);                                   // the batch this stream still carries (k - G): the oldest one in flight
 		Str& sg = S[(size_t)g];
 		size_t bases = a.codes.size();
@@ -509,6 +551,9 @@ int main(int argc, char** argv) {
 		const double tq0 = now();
 		if(h2g_set_reads(sg.st, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, n) != H2G_OK) die("h2g_set_reads");
 		if(h2g_set_read_names(sg.st, a.names.data(), a.noffs.data(), n) != H2G_OK) die("h2g_set_read_names");
+		P.first_read_id = (uint32_t)next_id;
+		sg.first_id = next_id;
+		next_id += n;
 		if(paired) {
 			if(h2g_set_mates(sg.st, b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n) != H2G_OK) die("h2g_set_mates");
 			if(h2g_align_pairs_run(sg.st, &P) != H2G_OK) die("h2g_align_pairs_run");

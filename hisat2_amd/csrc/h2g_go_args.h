@@ -28,6 +28,7 @@ struct GoArgs {
 	const uint32_t* nlist;                // ... and how many (device memory: the second pass is launched without a host sync)
 	uint32_t paired;
 	uint32_t dbg_read; uint32_t* dbg_buf; // development hook: trace of one read id (H2G_GO_DBG_READ): [0] = words used, then 8 words per primitive request
+	uint32_t rdid_base;                   // Read::rdid of read 0 of the batch (splice-site visibility window)
 	uint32_t defer_overflow;              // 1: a second pass follows; overflowed reads are not counted as aligned here
 };
 #define H2G_PK_LANE_WORDS_HOST (H2G_PK_WORDS + H2G_PK_WORDS / 2)

@@ -1455,7 +1455,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(!p->no_spliced_alignment) {
 		// spliced alignment: combineWith places introns (hi_aligner.h:1588-1739) and every read is independent when novel splice
 		// sites are not shared (--no-temp-splicesite); the shared SpliceSiteDB of the default mode and graph indexes are not built
-		if(!p->no_temp_splicesite) { snprintf(g_err, sizeof g_err, "align: spliced alignment is built for --no-temp-splicesite (no SpliceSiteDB shared between reads)"); return H2G_ERR_UNSUPPORTED; }
+		// no_temp_splicesite == 0 (the reference's default) is the CALLER's wave protocol: batches of <= window reads, the junctions of
+		// each batch's output merged into the database (h2g_index_set_splice_sites) before the next one; first_read_id carries the ids
 		if(!linear) { snprintf(g_err, sizeof g_err, "align: spliced alignment is built for linear indexes"); return H2G_ERR_UNSUPPORTED; }
 		if(p->pen_canintronlen_type < 1 || p->pen_canintronlen_type > 4 || p->pen_noncanintronlen_type < 1 || p->pen_noncanintronlen_type > 4 ||
 		   p->min_intronlen < 20 || p->max_intronlen < p->min_intronlen || p->pen_cansplice < 0 || p->pen_noncansplice < 0) {
@@ -1503,7 +1504,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	A.rd1 = dreads(s); A.rd2 = A.rd1;
 	if(paired) { A.rd2.codes = s->d_codes2; A.rd2.offs = s->d_offs2; A.rd2.quals = s->has_quals2 ? s->d_quals2 : nullptr; }
 	A.P = aln_params_from(*p, p->no_spliced_alignment != 0, linear);
-	if(!p->no_spliced_alignment) A.ssdb = s->ix->dssdb;
+	if(!p->no_spliced_alignment) { A.ssdb = s->ix->dssdb; A.rdid_base = p->first_read_id; }
 	if(!p->no_spliced_alignment) { A.P.sc.donor_sum = s->ix->d_spl[0]; A.P.sc.acc_sum1 = s->ix->d_spl[1]; A.P.sc.acc_sum2 = s->ix->d_spl[2]; }
 	A.names1 = s->d_names; A.noffs1 = s->d_name_offs; A.names2 = s->d_names2; A.noffs2 = s->d_name_offs2;
 	A.paired = paired ? 1u : 0u;

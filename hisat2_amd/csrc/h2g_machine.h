@@ -658,7 +658,7 @@ again:
 					uint32_t fragoff, fraglen, left;
 					hit_get_left(&hit, nullptr, nullptr, &fragoff, &fraglen, &left, nullptr);
 					if(fraglen >= minK && left >= minK && hit.trim5 == 0 && !no_spliced) {
-						f.ncoords = ss_left_sites(*C.ssdb, hit.tidx, left + minK, minK, M.read, f.coords, AL_MAX_COORDS);
+						f.ncoords = ss_left_sites(*C.ssdb, hit.tidx, left + minK, minK, C.rdid_base + M.read, f.coords, AL_MAX_COORDS);
 						if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
 					}
 					M_GOTO(PC_FS_L_LOOP);
@@ -674,7 +674,7 @@ again:
 				uint32_t fragoff, fraglen, left;
 				hit_get_left(&hit, nullptr, nullptr, &fragoff, &fraglen, &left, nullptr);
 				if(fraglen >= minK_local && left >= minK_local) {
-					f.ncoords = ss_left_sites(*C.ssdb, hit.tidx, left + minK_local, minK_local + (minK_local < fragoff ? minK_local : fragoff), M.read, f.coords, AL_MAX_COORDS);
+					f.ncoords = ss_left_sites(*C.ssdb, hit.tidx, left + minK_local, minK_local + (minK_local < fragoff ? minK_local : fragoff), C.rdid_base + M.read, f.coords, AL_MAX_COORDS);
 					if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
 				}
 			}
@@ -687,7 +687,7 @@ again:
 				hit_get_right(&hit, &fragoff, &fraglen, &right);
 				if(fraglen >= minK_local) {
 					const uint32_t unmapped = rdlen - fragoff - fraglen;
-					f.ncoords = ss_right_sites(*C.ssdb, hit.tidx, right + fraglen - minK_local, minK_local + (minK_local < unmapped ? minK_local : unmapped), M.read, f.coords, AL_MAX_COORDS);
+					f.ncoords = ss_right_sites(*C.ssdb, hit.tidx, right + fraglen - minK_local, minK_local + (minK_local < unmapped ? minK_local : unmapped), C.rdid_base + M.read, f.coords, AL_MAX_COORDS);
 					if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
 				}
 			}
@@ -755,7 +755,7 @@ again:
 			uint32_t fragoff, fraglen, right;
 			hit_get_right(&can, &fragoff, &fraglen, &right);
 			if(!(fraglen >= minK && can.trim3 == 0 && !no_spliced)) continue;
-			f.ncoords = ss_right_sites(*C.ssdb, can.tidx, right + fraglen - minK, minK, M.read, f.coords, AL_MAX_COORDS);
+			f.ncoords = ss_right_sites(*C.ssdb, can.tidx, right + fraglen - minK, minK, C.rdid_base + M.read, f.coords, AL_MAX_COORDS);
 			if(f.ncoords > AL_MAX_COORDS) { ws->overflow |= 2048; f.ncoords = AL_MAX_COORDS; }
 			f.ri = 0;
 			M_GOTO(PC_FS_R_LOOP);

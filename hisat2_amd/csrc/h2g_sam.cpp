@@ -19,7 +19,9 @@ using namespace h2g;
 struct Met {            // ReportingMetrics (aln_sink.h:51-160), the counters printAlSumm reads
 	uint64_t nread = 0, npaired = 0, nunpaired = 0, nconcord_0 = 0, nconcord_uni1 = 0, nconcord_uni2 = 0, ndiscord = 0;
 	uint64_t nunp_0_0 = 0, nunp_0_uni1 = 0, nunp_0_uni2 = 0, nunp_0 = 0, nunp_uni1 = 0, nunp_uni2 = 0;
+	std::vector<h2g_splice_site> novel;                  // splice sites of the lines written (h2g_sam_collect_novel_sites), in read order
 	void add(const Met& o) {
+		novel.insert(novel.end(), o.novel.begin(), o.novel.end());
 		nread += o.nread; npaired += o.npaired; nunpaired += o.nunpaired; nconcord_0 += o.nconcord_0; nconcord_uni1 += o.nconcord_uni1;
 		nconcord_uni2 += o.nconcord_uni2; ndiscord += o.ndiscord; nunp_0_0 += o.nunp_0_0; nunp_0_uni1 += o.nunp_0_uni1; nunp_0_uni2 += o.nunp_0_uni2;
 		nunp_0 += o.nunp_0; nunp_uni1 += o.nunp_uni1; nunp_uni2 += o.nunp_uni2;
@@ -38,6 +40,8 @@ struct h2g_sam {
 	double smConst = 0.0, smCoeff = (double)(-0.2f);
 	h2g::HostSpliceDB ssdb;                               // h2g_sam_set_splice_sites: TLEN of concordant pairs leaves known introns out
 	uint32_t ssdb_window = 0;
+	bool collect_novel = false;                           // h2g_sam_collect_novel_sites
+	uint64_t first_read_id = 0;                           // Read::rdid of read 0 of the next format call
 };
 
 namespace {
@@ -303,6 +307,57 @@ int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1,
 	return imUpstream ? fl : -fl;
 }
 
+thread_local std::vector<h2g_splice_site>* tl_novel = nullptr;     // where this formatter thread collects the sites of its lines
+thread_local uint64_t tl_rdid = 0;                                 // Read::rdid of the read being formatted
+// SpliceSiteDB::addSpliceSite splice_site.cpp:190-347 (minAnchorLen 15), called for every alignment line written
+// (AlnSinkSam::append aln_sink.h:1570-1582): the junctions of an untrimmed alignment whose anchors on both sides are long enough
+// for the mismatches they carry.  The database keeps, per site, the smallest id of the reads that added it.
+void add_splice_sites(const h2g_alnres& r, uint32_t rdlen, uint64_t rdid, std::vector<h2g_splice_site>& out) {
+	if(r.trim5 + r.trim3 > 0) return;
+	static thread_local std::vector<Ed> ed;
+	ed.resize(r.nedits);
+	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = r.edits[i].pos; ed[i].chr = (char)r.edits[i].chr; ed[i].qchr = (char)r.edits[i].qchr; ed[i].type = r.edits[i].type; ed[i].snp = r.edits[i].snp; ed[i].skip = r.edits[i].type == EDIT_SPL ? spl_len(r.edits[i]) : 0; }
+	std::vector<uint32_t> dirs(r.nedits);
+	for(uint32_t i = 0; i < r.nedits; i++) dirs[i] = spl_dir(r.edits[i]);
+	if(!r.fw) { invert(ed, rdlen); std::reverse(dirs.begin(), dirs.end()); }
+	const uint32_t minAnchorLen = 15, SPL_UNKNOWN = 1;
+	auto is_mm_gap = [](const Ed& e) { return e.type == EDIT_MM || e.type == EDIT_READ_GAP || e.type == EDIT_REF_GAP; };
+	uint32_t refoff = r.toff, leftAnchor = 0, rightAnchor = 0, mm = 0;
+	size_t eidx = 0, last = 0;
+	bool inited = false;
+	h2g_splice_site ssp; memset(&ssp, 0, sizeof ssp);
+	auto consider = [&](size_t e_for_dir, size_t after) {
+		const uint32_t extra = dirs[e_for_dir] == SPL_UNKNOWN ? 6 : 0;
+		uint32_t mm2 = 0;
+		for(size_t j = after + 1; j < ed.size(); j++) if(is_mm_gap(ed[j])) mm2++;
+		if(leftAnchor >= minAnchorLen + mm * 2 + extra && rightAnchor >= minAnchorLen + mm2 * 2 + extra) out.push_back(ssp);
+	};
+	for(uint32_t i = 0; i < rdlen; i++, refoff++) {
+		while(eidx < ed.size() && ed[eidx].pos == i) {
+			if(ed[eidx].type == EDIT_READ_GAP) refoff++;
+			else if(ed[eidx].type == EDIT_REF_GAP) refoff--;
+			if(is_mm_gap(ed[eidx])) mm++;
+			if(ed[eidx].type == EDIT_SPL) {
+				if(inited) {
+					rightAnchor = ed[eidx].pos - ed[last].pos;
+					consider(eidx, eidx);
+					leftAnchor = rightAnchor; rightAnchor = 0;
+				} else leftAnchor = ed[eidx].pos;
+				ssp.tidx = r.tidx; ssp.left = refoff - 1; ssp.right = refoff + ed[eidx].skip; ssp.dir = (uint8_t)dirs[eidx];
+				ssp.readid = (uint32_t)rdid; ssp.fromfile = 0; ssp.known = 0; ssp.pad_ = 0;
+				inited = true;
+				refoff += ed[eidx].skip;
+				last = eidx;
+			}
+			eidx++;
+		}
+	}
+	if(inited) {
+		rightAnchor = rdlen - ed[last].pos;
+		consider(last, last);
+	}
+}
+
 // AlnSinkSam::appendMate aln_sink.h:3024-3260 + printAlignedOptFlags / printEmptyOptFlags sam.h:525-1100
 void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, const h2g_alnres* rs, const h2g_alnres* rso,
                  const Summ& summ, const Flags& fl, uint64_t nh)
@@ -312,6 +367,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	static thread_local std::string seq, qual;
 	seq_ascii(rd, rs == nullptr || rs->fw, seq, qual);
 	if(rs) stack_alignment(*rs, seq, st);
+	if(rs && S.collect_novel && tl_novel) add_splice_sites(*rs, rd.len, tl_rdid, *tl_novel);
 	put_read_name(o, rd, fl.partOfPair());
 	o.push_back('\t');
 	int f = 0;
@@ -349,7 +405,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	else o.push_back('0');
 	o.push_back('\t');
 	// ISIZE: setMateParams computes it when the opposite mate is known and on the same reference (or concordant)
-	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1(), fl.concordant() ? &S : nullptr));
+	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1(), fl.concordant() ? &S : nullptr, tl_rdid));
 	else o.push_back('0');
 	o.push_back('\t');
 	o += seq; o.push_back('\t');
@@ -520,7 +576,9 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 		const size_t b = n * t / T, e = n * (t + 1) / T;
 		std::string& o = parts[t];
 		o.reserve((e - b) * 420);
-		for(size_t i = b; i < e; i++) one(i, o, mets[t]);
+		tl_novel = &mets[t].novel;
+		for(size_t i = b; i < e; i++) { tl_rdid = S->first_read_id + i; one(i, o, mets[t]); }
+		tl_novel = nullptr;
 	};
 	if(T == 1) work(0);
 	else {
@@ -611,6 +669,16 @@ extern "C" void h2g_sam_set_splice_sites(h2g_sam* S, const h2g_splice_site* site
 	if(!S) return;
 	h2g::build_splice_db(sites, n, (uint32_t)S->refnames.size(), S->ssdb);
 	S->ssdb_window = window;
+}
+extern "C" void h2g_sam_collect_novel_sites(h2g_sam* S, int on) { if(S) S->collect_novel = on != 0; }
+extern "C" void h2g_sam_set_first_read_id(h2g_sam* S, uint64_t id) { if(S) S->first_read_id = id; }
+extern "C" size_t h2g_sam_take_novel_sites(h2g_sam* S, h2g_splice_site* out, size_t cap) {
+	if(!S) return 0;
+	const size_t n = S->met.novel.size();
+	if(!out || cap < n) return n;                          // nothing is consumed until the caller's buffer holds them all
+	memcpy(out, S->met.novel.data(), n * sizeof(h2g_splice_site));
+	S->met.novel.clear();
+	return n;
 }
 extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, double coeff) { if(S) { S->smType = type; S->smConst = c; S->smCoeff = coeff; } }
 

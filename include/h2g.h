@@ -287,7 +287,8 @@ typedef struct {
 	uint32_t min_intronlen, max_intronlen;           /* --min-intronlen 20, --max-intronlen 500000 */
 	int32_t  pen_cansplice, pen_noncansplice;        /* --pen-cansplice 0, --pen-noncansplice 12 */
 	uint32_t pen_canintronlen_type, pen_noncanintronlen_type;   /* --pen-canintronlen / --pen-noncanintronlen <type>,<const>,<coeff>: */
-	uint32_t pad_;                                              /* type as score_min_type; default G,-8,1 */
+	uint32_t first_read_id;                                     /* type as score_min_type; default G,-8,1.  first_read_id: Read::rdid of
+	                                                             * read 0 of the batch — the splice-site window compares read ids */
 	double   pen_canintronlen_const, pen_canintronlen_coeff, pen_noncanintronlen_const, pen_noncanintronlen_coeff;
 } h2g_align_params;
 /* number of visible HIP devices (0 without a GPU: the library has no CPU path) */

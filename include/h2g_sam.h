@@ -40,6 +40,14 @@ H2G_EXPORT size_t     h2g_sam_read_splice_site_file(const h2g_sam*, const char* 
 /* the splice sites given to h2g_index_set_splice_sites: TLEN of a concordant pair leaves the longest database intron lying between
  * its mates out (AlnRes::setFragmentLength aligner_result.h:1669-1689, --no-templatelen-adjustment is not built) */
 H2G_EXPORT void       h2g_sam_set_splice_sites(h2g_sam*, const h2g_splice_site* sites, size_t n, uint32_t window);
+/* Temporary splice sites (the reference's default mode; SpliceSiteDB::addSpliceSite splice_site.cpp:190, called for every line
+ * written, aln_sink.h:1570): with collection on, the format calls record the junctions of the alignments they print, tagged with
+ * the read's id = first_read_id + its index in the call.  h2g_sam_take_novel_sites hands them over in read order (returns the
+ * count; nothing is consumed unless cap holds them all).  The caller merges them into its database — per site the smallest
+ * read id — and passes the result to h2g_index_set_splice_sites / h2g_sam_set_splice_sites with the window of its wave scheme. */
+H2G_EXPORT void       h2g_sam_collect_novel_sites(h2g_sam*, int on);
+H2G_EXPORT void       h2g_sam_set_first_read_id(h2g_sam*, uint64_t id);
+H2G_EXPORT size_t     h2g_sam_take_novel_sites(h2g_sam*, h2g_splice_site* out, size_t cap);
 /* --score-min as given to the aligner (h2g_align_params.score_min_*): MAPQ is relative to it (unique.h:214-222) */
 H2G_EXPORT void       h2g_sam_set_score_min(h2g_sam*, uint32_t type, double constant, double coeff);
 

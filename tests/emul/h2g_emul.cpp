@@ -38,7 +38,7 @@ struct Emu {
 	bool has_params = false;
 	h2g_align_params params;
 	std::vector<uint8_t> sw;
-	HostSpliceDB hssdb; DSpliceDB dssdb;
+	HostSpliceDB hssdb; DSpliceDB dssdb; uint32_t rdid_base = 0;
 	DReads reads() const {
 		DReads r;
 		r.codes = codes.data(); r.offs = offs.data(); r.quals = has_quals ? quals.data() : nullptr;
@@ -250,7 +250,7 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 		P->sc.donor_sum = d_.data(); P->sc.acc_sum1 = a1_.data(); P->sc.acc_sum2 = a2_.data();
 	}
 	C->g = &e->dg; C->ref = &e->dr; C->ls = &e->dls; C->P = P;
-	C->ssdb = no_spliced ? nullptr : &e->dssdb;
+	C->ssdb = no_spliced ? nullptr : &e->dssdb; C->rdid_base = e->rdid_base;
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C->sw = e->sw.data();
 	static GraphWS gws_;
@@ -260,6 +260,7 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->gsl = e->dg.linear ? nullptr : &gsl_; C->graph = !e->dg.linear;
 }
 
+void h2gemu_set_rdid_base(Emu* e, uint32_t base) { e->rdid_base = base; }
 void h2gemu_set_splice_sites(Emu* e, const h2g_splice_site* sites, size_t n, uint32_t window) {
 	build_splice_db(sites, n, e->host.g.nPat, e->hssdb);
 	e->dssdb = DSpliceDB();

@@ -21,17 +21,23 @@ def set_options(e, bowtie2_dp, options):
     return p
 
 
-def set_splice_sites(e, sites, known=True):
+def set_splice_sites(e, sites, known=True, window=0, rdid_base=0):
+    """sites: [(tidx, left, right, '+'|'-'), ...] (a splice-site file) or a ready (api.SpliceSite * n) array with its length"""
     from hisat2_amd import api
-    a = api.splice_site_array(sites, known)
+    if isinstance(sites, tuple) and len(sites) == 2 and not isinstance(sites[0], tuple):
+        a, n = sites
+    else:
+        a, n = api.splice_site_array(sites, known), len(sites)
     e.L.h2gemu_set_splice_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
-    e.L.h2gemu_set_splice_sites(e.h, a, len(sites), 0)
+    e.L.h2gemu_set_splice_sites(e.h, a, n, window)
+    e.L.h2gemu_set_rdid_base.argtypes = [C.c_void_p, C.c_uint32]
+    e.L.h2gemu_set_rdid_base(e.h, rdid_base)
 
 
-def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0, quals=None, options=(), splice_sites=None):
+def emu_align(base, reads_list, qnames, no_spliced=1, bowtie2_dp=0, quals=None, options=(), splice_sites=None, window=0, rdid_base=0):
     e = Emu(base)
     if splice_sites:
-        set_splice_sites(e, splice_sites)
+        set_splice_sites(e, splice_sites, window=window, rdid_base=rdid_base)
     if options:
         set_options(e, bowtie2_dp, options)
     e.L.h2gemu_set_bowtie2_dp.argtypes = [C.c_void_p, C.c_uint32]

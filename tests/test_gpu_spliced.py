@@ -97,3 +97,43 @@ def test_known_splice_sites_pairs_command_line(tmp_path):
         for t, l, r, d in FS.known_sites(introns, 371, 0.8):
             f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
     _both(tmp_path, base, ["-1", f1, "-2", f2], ("--known-splicesite-infile", ss))
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,n,P,sub", [(381, 30000, 4, 0.01), (382, 20000, 2, 0.005)])
+def test_temporary_splice_sites_command_line(tmp_path, seed, n, P, sub):
+    """the reference's DEFAULT mode: junctions found by earlier reads help later ones (SpliceSiteDB, window 1000 x -p).  The
+    command line runs waves of <= 1000 x -p reads and merges each wave's junctions before the next: byte-identical to
+    `hisat2 -p P --reorder`, whose output the shared database changes on about a quarter of the lines"""
+    import fuzz_spliced as F
+    contigs, reads, _ = F.make_case(seed, n, sub=sub)
+    base = _index(tmp_path, contigs)
+    rfa = os.path.join(str(tmp_path), "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    t = str(tmp_path)
+    ref_sam, amd_sam, nt_sam = os.path.join(t, "ref.sam"), os.path.join(t, "amd.sam"), os.path.join(t, "ref_notemp.sam")
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", str(P), "--reorder", "-x", base, "-U", rfa, "-S", ref_sam],
+                   check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(t, "ref.err"), "w"))
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", str(P), "--reorder", "--no-temp-splicesite", "-x", base, "-U", rfa, "-S", nt_sam],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([CLI, "-f", "-p", str(P), "-x", base, "-U", rfa, "-S", amd_sam], check=True, stderr=open(os.path.join(t, "amd.err"), "w"))
+    want = SL.body_lines(ref_sam)
+    assert diff_lines(SL.body_lines(amd_sam), want) == 0
+    assert open(os.path.join(t, "amd.err")).read() == open(os.path.join(t, "ref.err")).read()
+    assert sum(1 for a, b in zip(want, SL.body_lines(nt_sam)) if a != b) > n // 20      # the database matters on this input
+
+
+@needs_ref
+def test_temporary_splice_sites_pairs_command_line(tmp_path):
+    import fuzz_spliced_pairs as F
+    contigs, m1, m2, _ = F.make_case(391, 12000, sub=0.01)
+    base = _index(tmp_path, contigs)
+    t = str(tmp_path)
+    f1, f2 = os.path.join(t, "r1.fa"), os.path.join(t, "r2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "3", "--reorder", "-x", base, "-1", f1, "-2", f2, "-S", os.path.join(t, "ref.sam")],
+                   check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(t, "ref.err"), "w"))
+    subprocess.run([CLI, "-f", "-p", "3", "-x", base, "-1", f1, "-2", f2, "-S", os.path.join(t, "amd.sam")], check=True, stderr=open(os.path.join(t, "amd.err"), "w"))
+    assert diff_lines(SL.body_lines(os.path.join(t, "amd.sam")), SL.body_lines(os.path.join(t, "ref.sam"))) == 0
+    assert open(os.path.join(t, "amd.err")).read() == open(os.path.join(t, "ref.err")).read()

@@ -179,3 +179,12 @@ def test_known_splice_sites_pairs_lines_identical():
     import fuzz_spliced_pairs as F
     bad, tmp = F.run_case(711, 1500, sub=0.01, show=3, known=0.8)
     assert bad == 0
+
+
+@needs_ref
+def test_temporary_splice_sites_wave_scheme():
+    """the reference's default mode through the host instantiation: waves of 1000 x P reads, each wave's junctions merged into the
+    database before the next (tests/temp_splice.py) == `hisat2 -p 2 --reorder`, line for line"""
+    import temp_splice as T
+    bad, _ = T.run_case(811, 5000, P=2, show=3)
+    assert bad == 0
