@@ -24,11 +24,12 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 
 def wave_run(base, reads, names, P, formatter):
     """formatter(lo, hi, outs, recs, sites_array, nsites, W) -> (lines, novel api.SpliceSite list); returns all lines"""
-    W = 1000 * P
+    W = 1000 * P if P > 1 else 0                    # -p 1: window 0, every read sees all the reads before it (hisat2.cpp:3687)
+    step = W if W else 1
     db = {}                                          # (tidx, left, right, dir) -> smallest read id, in first-seen order
     lines = []
-    for lo in range(0, len(reads), W):
-        hi = min(len(reads), lo + W)
+    for lo in range(0, len(reads), step):
+        hi = min(len(reads), lo + step)
         arr = (api.SpliceSite * max(1, len(db)))()
         for k, ((t, l, r, d), rid) in enumerate(db.items()):
             arr[k].tidx, arr[k].left, arr[k].right, arr[k].readid, arr[k].dir, arr[k].fromfile, arr[k].known = t, l, r, rid, d, 0, 0

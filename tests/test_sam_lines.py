@@ -188,3 +188,21 @@ def test_temporary_splice_sites_wave_scheme():
     import temp_splice as T
     bad, _ = T.run_case(811, 5000, P=2, show=3)
     assert bad == 0
+
+
+@needs_ref
+def test_golden_spliced_default_mode_p1(tmp_path):
+    """tests/golden/ref_se_spliced.sam.gz = `hisat2-align-s -p 1` in its default mode on the golden reads: at -p 1 the window is 0,
+    every read sees the junctions of all reads before it, i.e. waves of ONE read (what only a test can afford)"""
+    import gzip
+    import temp_splice as T
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for k in range(1, 9):
+        open(os.path.join(str(tmp_path), f"g1.{k}.ht2"), "wb").write(gzip.open(os.path.join(gold, f"g1.{k}.ht2.gz")).read())
+    rfa = os.path.join(str(tmp_path), "r.fa")
+    open(rfa, "wb").write(gzip.open(os.path.join(gold, "reads_se.fa.gz")).read())
+    names, reads = read_fa(rfa)
+    base = os.path.join(str(tmp_path), "g1")
+    got, db = T.wave_run(base, reads, names, 1, lambda lo, hi, o, r, a, k, W: T.format_wave(base, reads, names, lo, hi, o, r, a, k, W))
+    want = [l for l in gzip.open(os.path.join(gold, "ref_se_spliced.sam.gz"), "rt").read().splitlines() if not l.startswith("@")]
+    assert diff_lines(got, want) == 0
