@@ -1386,7 +1386,12 @@ struct GoUnit {
 	size_t (*ws_bytes)(); size_t (*gws_bytes)(); int (*waves)(); void (*caps)(uint32_t*); int (*launch)(const GoArgs*, unsigned, hipStream_t);
 	size_t (*slot_off)(); size_t (*gsl_off)(); void (*geometry)(uint32_t*);
 };
-static const GoUnit& go_unit(bool linear, bool big) {
+static const GoUnit& go_unit(bool linear, bool big, bool spliced = false) {
+	// spliced alignment (linear indexes): the units whose machine carries the splice-site database joins
+	static const GoUnit spl[2] = {
+		{h2g_go_ws_bytes_linear_spl, h2g_go_gws_bytes_linear_spl, h2g_go_waves_linear_spl, h2g_go_caps_linear_spl, h2g_go_launch_linear_spl, h2g_go_slot_off_linear_spl, h2g_go_gsl_off_linear_spl, h2g_go_geometry_linear_spl},
+		{h2g_go_ws_bytes_linear_spl_big, h2g_go_gws_bytes_linear_spl_big, h2g_go_waves_linear_spl_big, h2g_go_caps_linear_spl_big, h2g_go_launch_linear_spl_big, h2g_go_slot_off_linear_spl_big, h2g_go_gsl_off_linear_spl_big, h2g_go_geometry_linear_spl_big}};
+	if(spliced && linear) return spl[big ? 1 : 0];
 	static const GoUnit u[2][2] = {
 		{{h2g_go_ws_bytes_graph, h2g_go_gws_bytes_graph, h2g_go_waves_graph, h2g_go_caps_graph, h2g_go_launch_graph, h2g_go_slot_off_graph, h2g_go_gsl_off_graph, h2g_go_geometry_graph},
 		 {h2g_go_ws_bytes_graph_big, h2g_go_gws_bytes_graph_big, h2g_go_waves_graph_big, h2g_go_caps_graph_big, h2g_go_launch_graph_big, h2g_go_slot_off_graph_big, h2g_go_gsl_off_graph_big, h2g_go_geometry_graph_big}},
@@ -1452,6 +1457,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names || (paired && !s->has_mates)) { snprintf(g_err, sizeof g_err, "align: read names (h2g_set_read_names)%s not set", paired ? " / mates (h2g_set_mates)" : ""); return H2G_ERR_ARG; }
 	const bool linear = s->ix->dg.linear != 0;
+	const bool spl = !p->no_spliced_alignment;
 	if(!p->no_spliced_alignment) {
 		// spliced alignment: combineWith places introns (hi_aligner.h:1588-1739) and every read is independent when novel splice
 		// sites are not shared (--no-temp-splicesite); the shared SpliceSiteDB of the default mode and graph indexes are not built
@@ -1466,7 +1472,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	}
 	const uint32_t maxsz = p->khits > p->kseeds ? p->khits : p->kseeds;
 	uint32_t caps[5], bcaps[5];
-	go_unit(linear, false).caps(caps); go_unit(linear, true).caps(bcaps);
+	go_unit(linear, false, spl).caps(caps); go_unit(linear, true, spl).caps(bcaps);
 	if(p->khits == 0 || p->khits > H2G_SELECT_CAP || p->kseeds < p->khits || maxsz > bcaps[0]) {
 		snprintf(g_err, sizeof g_err, "align: -k %u / --max-seeds %u outside the built range (-k 1..%u, --max-seeds <= %u)", p->khits, p->kseeds, (unsigned)H2G_SELECT_CAP, bcaps[0]);
 		return H2G_ERR_ARG;
@@ -1482,7 +1488,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	}
 	HIPCHK(hipSetDevice(s->ix->device));
 	const bool big_main = maxsz > caps[0];
-	const GoUnit& U = go_unit(linear, big_main);
+	const GoUnit& U = go_unit(linear, big_main, spl);
 	// geometry of the unit: workgroups of geo[0] threads own geo[1] reads in flight; resident workgroups per CU = what the
 	// unit's waves per SIMD and the LDS (rings + one packed-read region per mate) allow
 	uint32_t geo[4];
@@ -1556,7 +1562,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(U.launch(&A, grid, s->st) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
 	if(second) {
-		const GoUnit& B = go_unit(linear, true);
+		const GoUnit& B = go_unit(linear, true, spl);
 		uint32_t* cnt = s->d_ovf_list + s->max_reads;
 		hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st,
 		                   paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, s->d_ovf_list, cnt);

@@ -67,6 +67,18 @@ enum : uint32_t {
 // Every place the machine requests a primitive: (primitive, pc it resumes at).  The kernels queue reads in flight per SITE, not
 // per primitive: the lanes of a wave then resume at the same pc, which halves the number of distinct pc bodies a wave walks
 // through between two primitives (tools/memprof/simt.py).  tests/test_machine_sites.py checks the list against the M_OP uses.
+// The joins through the splice-site database (H2G_SPLICE_DB) are compiled into the units that run spliced alignment only: the
+// other kernels keep their rings and their control switch small (the eight extra sites cost the unspliced kernels 8-10 %).
+#ifndef H2G_SPLICE_DB
+#define H2G_SPLICE_DB 1
+#endif
+#if H2G_SPLICE_DB
+#define H2G_MACH_SITES_DB(X) \
+	X(OP_EXTEND, PC_FS_L_EXT) X(OP_COMBINE, PC_FS_L_COMB) X(OP_EXTEND, PC_FS_R_EXT) X(OP_COMBINE, PC_FS_R_COMB) \
+	X(OP_EXTEND, PC_LSS_EXT) X(OP_COMBINE, PC_LSS_COMB) X(OP_EXTEND, PC_RSS_EXT) X(OP_COMBINE, PC_RSS_COMB)
+#else
+#define H2G_MACH_SITES_DB(X)
+#endif
 #define H2G_MACH_SITES(X) \
 	X(OP_PSEARCH, PC_NB_AFTER_PS) \
 	X(OP_GCOORDS, PC_GAH_FULL_AFTER) X(OP_GCOORDS, PC_GAH_SUB_AFTER) X(OP_GCOORDS, PC_L_GC_AFTER) X(OP_GCOORDS, PC_R_GC_AFTER) \
@@ -78,9 +90,7 @@ enum : uint32_t {
 	X(OP_COMBINE, PC_L_G_C) X(OP_COMBINE, PC_L_RI_C) X(OP_COMBINE, PC_R_G_C) X(OP_COMBINE, PC_R_RI_C) \
 	X(OP_ADJUST, PC_AM_RI_AFTER) X(OP_ADJUST, PC_GAH_K_AFTER) \
 	X(OP_ADJMEMBER, PC_L_G_A) X(OP_ADJMEMBER, PC_L_RI_A) X(OP_ADJMEMBER, PC_R_G_A) X(OP_ADJMEMBER, PC_R_RI_A) \
-	X(OP_SW, PC_HS_AFTER_SW) \
-	X(OP_EXTEND, PC_FS_L_EXT) X(OP_COMBINE, PC_FS_L_COMB) X(OP_EXTEND, PC_FS_R_EXT) X(OP_COMBINE, PC_FS_R_COMB) \
-	X(OP_EXTEND, PC_LSS_EXT) X(OP_COMBINE, PC_LSS_COMB) X(OP_EXTEND, PC_RSS_EXT) X(OP_COMBINE, PC_RSS_COMB)
+	X(OP_SW, PC_HS_AFTER_SW) H2G_MACH_SITES_DB(X)
 enum : uint32_t {
 #define X(OPC, PC) SITE_##PC,
 	SITE_FREE = 0, H2G_MACH_SITES(X) SITE_COUNT
@@ -647,9 +657,10 @@ again:
 			if(al_is_searched(mw, &hit)) RC_RET(f.maxsc);
 			al_add_searched(ws, mw, &hit);
 		}
-		const bool have_db = C.ssdb != nullptr && C.ssdb->n != 0;                      // !ssdb.empty()
+		const bool have_db = H2G_SPLICE_DB && C.ssdb != nullptr && C.ssdb->n != 0;     // !ssdb.empty()
 		if(hitoff == 0 && hitlen == rdlen) {
 			if(!al_redundant(mw, &hit, rdlen)) {
+#if H2G_SPLICE_DB
 				if(have_db) {
 					// a full alignment: look for the same read joined through database sites near its ends (:409-676);
 					// _local_genomeHits[dep] = f.local_hits, best_score = f.prev_score
@@ -663,12 +674,14 @@ again:
 					}
 					M_GOTO(PC_FS_L_LOOP);
 				}
+#endif
 				al_report(ws, mw, &hit, rdlen, minsc);
 				if(hit.score > f.maxsc) f.maxsc = hit.score;
 			}
 			RC_RET(f.maxsc);
 		} else if(hitoff > 0 && (hitoff + hitlen == rdlen || hitoff + hitoff < rdlen - hitlen)) {
 			// ---------------- extend to the left: first through database sites (spliced_aligner.h:685-811) ----------------
+#if H2G_SPLICE_DB
 			f.ncoords = 0; f.ri = 0;
 			if(have_db && !no_spliced) {
 				uint32_t fragoff, fraglen, left;
@@ -679,8 +692,12 @@ again:
 				}
 			}
 			M_GOTO(PC_LSS_LOOP);
+#else
+			M_GOTO(PC_RC_ENTRY_LX);
+#endif
 		} else {
 			// ---------------- extend to the right: first through database sites (:1365-1496) ----------------
+#if H2G_SPLICE_DB
 			f.ncoords = 0; f.ri = 0;
 			if(have_db && !no_spliced) {
 				uint32_t fragoff, fraglen, right;
@@ -692,8 +709,12 @@ again:
 				}
 			}
 			M_GOTO(PC_RSS_LOOP);
+#else
+			M_GOTO(PC_RC_ENTRY_RX);
+#endif
 		}
 	}
+#if H2G_SPLICE_DB
 	// ---- full alignment, left end through a database site (:428-537)
 	case PC_FS_L_LOOP: {
 		Frame& f = FR;
@@ -873,6 +894,7 @@ again:
 		M_GOTO(PC_LSS_LOOP);
 	}
 	case PC_LSS_RET: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_LSS_LOOP); }
+#endif
 	case PC_RC_ENTRY_LX: {
 		Frame& f = FR;
 		const h2g_ghit& hit = f.hit;
@@ -885,6 +907,7 @@ again:
 		}
 		M_GOTO(PC_RC_ENTRY_L3);
 	}
+#if H2G_SPLICE_DB
 	// ---- partial alignment, right end through a database site (:1377-1496)
 	case PC_RSS_LOOP: {
 		Frame& f = FR;
@@ -930,6 +953,7 @@ again:
 		M_GOTO(PC_RSS_LOOP);
 	}
 	case PC_RSS_RET: { Frame& f = FR; if(gv.ret > f.maxsc) f.maxsc = gv.ret; M_GOTO(PC_RSS_LOOP); }
+#endif
 	case PC_RC_ENTRY_RX: {
 		Frame& f = FR;
 		const h2g_ghit& hit = f.hit;

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_site_table_matches_the_request_sites():
     src = open(os.path.join(ROOT, "hisat2_amd", "csrc", "h2g_machine.h")).read()
-    table_src = src[src.index("#define H2G_MACH_SITES(X)"):src.index("enum : uint32_t {\n#define X(OPC, PC) SITE_##PC")]
+    table_src = src[src.index("#define H2G_MACH_SITES_DB(X)"):src.index("enum : uint32_t {\n#define X(OPC, PC) SITE_##PC")]   # database sites (H2G_SPLICE_DB) + the rest
     table = re.findall(r"X\((OP_[A-Z]+), (PC_[A-Z0-9_]+)\)", table_src)
     body = src[src.index("void mach_step("):]
     used = set(re.findall(r"M_OP\((OP_[A-Z]+), (PC_[A-Z0-9_]+)\)", body))
