@@ -41,6 +41,7 @@ struct h2g_index {
 	DLocalSet dls;
 	DAlts dalts;
 	bool has_local = false;
+	bool has_splice_alts = false;                         // the ALT list holds splice sites / exons (a _tran index)
 	DSpliceDB dssdb;                                       // h2g_index_set_splice_sites (device arrays; freed and replaced on every call)
 	void* d_ssdb[4] = {nullptr, nullptr, nullptr, nullptr};
 	const float* d_spl[3] = {nullptr, nullptr, nullptr};   // SpliceSiteDB::probscore tables (donor, acceptor halves), uploaded with the index
@@ -171,6 +172,7 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		ix->dls = lp.view(dd, ds, dw, df, dz);
 		ix->h_ldesc = lp.desc;
 		ix->has_local = true;
+		for(const HostAlt& a : ix->host.alts) if(a.type >= 5) ix->has_splice_alts = true;   // ALT_SPLICESITE / ALT_EXON alt.h:38-39
 	}
 	{   // splice-site probability tables (spliced alignment): 1.4 MB, index-independent
 		std::vector<float> d, a1, a2;
@@ -1387,11 +1389,10 @@ struct GoUnit {
 	size_t (*slot_off)(); size_t (*gsl_off)(); void (*geometry)(uint32_t*);
 };
 static const GoUnit& go_unit(bool linear, bool big, bool spliced = false) {
-	// spliced alignment (linear indexes): the units whose machine carries the splice-site database joins
-	static const GoUnit spl[2] = {
-		{h2g_go_ws_bytes_linear_spl, h2g_go_gws_bytes_linear_spl, h2g_go_waves_linear_spl, h2g_go_caps_linear_spl, h2g_go_launch_linear_spl, h2g_go_slot_off_linear_spl, h2g_go_gsl_off_linear_spl, h2g_go_geometry_linear_spl},
-		{h2g_go_ws_bytes_linear_spl_big, h2g_go_gws_bytes_linear_spl_big, h2g_go_waves_linear_spl_big, h2g_go_caps_linear_spl_big, h2g_go_launch_linear_spl_big, h2g_go_slot_off_linear_spl_big, h2g_go_gsl_off_linear_spl_big, h2g_go_geometry_linear_spl_big}};
-	if(spliced && linear) return spl[big ? 1 : 0];
+	// spliced alignment: the units whose machine carries the splice-site database joins
+#define H2G_UNIT_ROW(N) {h2g_go_ws_bytes_##N, h2g_go_gws_bytes_##N, h2g_go_waves_##N, h2g_go_caps_##N, h2g_go_launch_##N, h2g_go_slot_off_##N, h2g_go_gsl_off_##N, h2g_go_geometry_##N}
+	static const GoUnit spl[2][2] = {{H2G_UNIT_ROW(graph_spl), H2G_UNIT_ROW(graph_spl_big)}, {H2G_UNIT_ROW(linear_spl), H2G_UNIT_ROW(linear_spl_big)}};
+	if(spliced) return spl[linear ? 1 : 0][big ? 1 : 0];
 	static const GoUnit u[2][2] = {
 		{{h2g_go_ws_bytes_graph, h2g_go_gws_bytes_graph, h2g_go_waves_graph, h2g_go_caps_graph, h2g_go_launch_graph, h2g_go_slot_off_graph, h2g_go_gsl_off_graph, h2g_go_geometry_graph},
 		 {h2g_go_ws_bytes_graph_big, h2g_go_gws_bytes_graph_big, h2g_go_waves_graph_big, h2g_go_caps_graph_big, h2g_go_launch_graph_big, h2g_go_slot_off_graph_big, h2g_go_gsl_off_graph_big, h2g_go_geometry_graph_big}},
@@ -1463,7 +1464,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		// sites are not shared (--no-temp-splicesite); the shared SpliceSiteDB of the default mode and graph indexes are not built
 		// no_temp_splicesite == 0 (the reference's default) is the CALLER's wave protocol: batches of <= window reads, the junctions of
 		// each batch's output merged into the database (h2g_index_set_splice_sites) before the next one; first_read_id carries the ids
-		if(!linear) { snprintf(g_err, sizeof g_err, "align: spliced alignment is built for linear indexes"); return H2G_ERR_UNSUPPORTED; }
+		// graph indexes: SNP / insertion / deletion ALTs; splice-site and exon ALTs (_tran indexes) are not read by this library
+		if(s->ix->has_splice_alts) { snprintf(g_err, sizeof g_err, "align: spliced alignment on an index with splice-site / exon ALTs (_tran) is not built"); return H2G_ERR_UNSUPPORTED; }
 		if(p->pen_canintronlen_type < 1 || p->pen_canintronlen_type > 4 || p->pen_noncanintronlen_type < 1 || p->pen_noncanintronlen_type > 4 ||
 		   p->min_intronlen < 20 || p->max_intronlen < p->min_intronlen || p->pen_cansplice < 0 || p->pen_noncansplice < 0) {
 			snprintf(g_err, sizeof g_err, "align: splice scoring outside its range (intron-length function type 1..4, 20 <= min_intronlen <= max_intronlen, penalties >= 0)");

@@ -465,7 +465,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	{
 		static thread_local std::vector<Ed> ed;
 		ed.resize(rs->nedits);
-		for(uint32_t i = 0; i < rs->nedits; i++) { ed[i].pos = rs->edits[i].pos; ed[i].type = rs->edits[i].type; ed[i].snp = rs->edits[i].snp; ed[i].chr = ed[i].qchr = 0; }
+		for(uint32_t i = 0; i < rs->nedits; i++) { ed[i].pos = rs->edits[i].pos; ed[i].type = rs->edits[i].type; ed[i].snp = rs->edits[i].type == EDIT_SPL ? 0xffffffffu : rs->edits[i].snp /* a splice edit keeps its probscore there */; ed[i].chr = ed[i].qchr = 0; }
 		const uint32_t len_trimmed = rd.len - rs->trim5 - rs->trim3;
 		if(!rs->fw) invert(ed, len_trimmed);
 		bool snp_first = true;

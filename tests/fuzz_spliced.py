@@ -20,7 +20,7 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400):
+def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt_fn=None):
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, size=glen, dtype=np.uint8)
     # plant introns: [a, b) with GT at a and AG at b-2 (canonical); a few GC..AG / AT..AC / random (non-canonical)
@@ -38,6 +38,9 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400):
             g[a:a + 2] = [0, 3]; g[b - 2:b] = [0, 1]
         introns.append((a, b))
         pos = b + int(rng.integers(150, 900))
+    ref_g = g
+    if alt_fn is not None:
+        g = alt_fn(ref_g)                          # reads come from an alternate haplotype of the same length
     reads = np.zeros((nreads, rdlen), dtype=np.uint8)
     for i in range(nreads):
         a, b = introns[int(rng.integers(0, len(introns)))]
@@ -52,7 +55,7 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400):
         if rng.random() < 0.5:
             r = (3 - r[::-1]).astype(np.uint8)
         reads[i] = r
-    return [g], reads, introns
+    return [ref_g], reads, introns
 
 
 def known_sites(introns, seed, frac):
@@ -66,7 +69,13 @@ def known_sites(introns, seed, frac):
 
 def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=(), known=0.0):
     tmp = tempfile.mkdtemp(prefix="h2spl")
-    contigs, reads, introns = make_case(seed, nreads, sub=sub)
+    snps = int(os.environ.get("H2G_FUZZ_SNPS", "0"))      # > 0: SNP-graph index with a seeded variant every ~snps bp
+    var = []
+
+    def alt(g):                                           # every single-base variant applied (indels stay index-only)
+        var.extend(synth.make_snps([g], seed + 5, every=snps))
+        return synth.apply_snps([g], [v for v in var if v[1] == "single"])[0]
+    contigs, reads, introns = make_case(seed, nreads, sub=sub, alt_fn=alt if snps else None)
     sites = None
     if known > 0:
         sites = known_sites(introns, seed, known)
@@ -77,7 +86,11 @@ def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=(), known=0
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
-    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if snps:
+        synth.write_snps(os.path.join(tmp, "g.snp"), var)
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rfa = os.path.join(tmp, "r.fa")
     synth.write_reads_fasta(rfa, reads)
     sam = os.path.join(tmp, "ref.sam")

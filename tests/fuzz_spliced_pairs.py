@@ -92,7 +92,12 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0):
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
-    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    snps = int(os.environ.get("H2G_FUZZ_SNPS", "0"))      # > 0: SNP-graph index (reads stay on the reference haplotype)
+    if snps:
+        synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=snps))
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)
@@ -110,7 +115,7 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0):
         for m, (src, dst) in enumerate(((r1, a1), (r2, a2))):
             for k in range(min(outs[i].nres[m], api.PAIR_RES_CAP)):
                 C.memmove(C.byref(dst[i * api.PAIR_RES_CAP + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
-    khits = int(extra[extra.index("-k") + 1]) if "-k" in extra else 5
+    khits = int(extra[extra.index("-k") + 1]) if "-k" in extra else (10 if snps else 5)
     got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra) + sopt)
     want = SL.body_lines(sam)
     from test_sam_lines import diff_lines

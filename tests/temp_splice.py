@@ -79,7 +79,12 @@ def run_case(seed, nreads, P=2, sub=0.005, show=6):
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
-    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    snps = int(os.environ.get("H2G_FUZZ_SNPS", "0"))      # > 0: SNP-graph index (reads stay on the reference haplotype)
+    if snps:
+        synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=snps))
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rfa = os.path.join(tmp, "r.fa")
     synth.write_reads_fasta(rfa, reads)
     sam = os.path.join(tmp, "ref.sam")

@@ -124,7 +124,7 @@ def test_live_reference_options(case):
     assert bad == 0
 
 
-def test_align_requires_names_and_refuses_spliced_on_graph(g1_index, g1s_index, golden_dir):
+def test_align_requires_names_and_valid_splice_scoring(g1_index, golden_dir):
     names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_se.fa.gz"))
     codes = np.concatenate(seqs)
     offs = np.concatenate([[0], np.cumsum([len(r) for r in seqs])]).astype(np.uint32)
@@ -138,16 +138,6 @@ def test_align_requires_names_and_refuses_spliced_on_graph(g1_index, g1s_index, 
     p.no_spliced_alignment = 0
     p.pen_canintronlen_type = 9
     with pytest.raises(api.H2GError):
-        st.align_run(p)                     # splice scoring outside its range
+        st.align_run(p)                     # splice scoring outside its range: refused, not approximated
     st.close()
     ix.close()
-    gx = api.Index(g1s_index)
-    gs = api.Stream(gx, max_reads=len(seqs), max_bases=codes.size)
-    gs.set_reads(codes, offs)
-    gs.set_read_names(names)
-    p = gs.align_params()
-    p.no_spliced_alignment = 0
-    with pytest.raises(api.H2GError):
-        gs.align_run(p)                     # spliced alignment on a graph index is not built: refused, not approximated
-    gs.close()
-    gx.close()

@@ -1,0 +1,77 @@
+"""GPU: spliced alignment on SNP-graph indexes through the command line (the reference's genome_snp indexes in their default
+mode) — unpaired with a splice-site file, paired, and temporary splice sites at -p 3; every SAM line and the summary identical to
+the reference binary's.  (Sorted last on purpose: the graph + spliced units are the newest kernels.)"""
+import os
+import subprocess
+
+import pytest
+
+import sam_lines as SL
+from hisat2_amd import synth
+from test_sam_lines import diff_lines
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+REF = os.path.join(ROOT, "oracle", "_ref")
+needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "hisat2-align-s")), reason="needs oracle/_ref")
+
+
+def _graph_index(tmp, contigs, seed, every):
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=every))
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return base
+
+
+def _compare(tmp, base, inputs, ref_opts, amd_opts):
+    ref_sam, amd_sam = os.path.join(tmp, "ref.sam"), os.path.join(tmp, "amd.sam")
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-x", base, "-S", ref_sam] + inputs + ref_opts, check=True, stdout=subprocess.DEVNULL,
+                   stderr=open(os.path.join(tmp, "ref.err"), "w"))
+    subprocess.run([CLI, "-f", "-x", base, "-S", amd_sam] + inputs + amd_opts, check=True, stderr=open(os.path.join(tmp, "amd.err"), "w"))
+    want = SL.body_lines(ref_sam)
+    assert diff_lines(SL.body_lines(amd_sam), want) == 0
+    assert open(os.path.join(tmp, "amd.err")).read() == open(os.path.join(tmp, "ref.err")).read()
+    return want
+
+
+@needs_ref
+def test_unpaired_known_sites_on_snp_graph(tmp_path):
+    import fuzz_spliced as F
+    tmp = str(tmp_path)
+    contigs, reads, introns = F.make_case(1031, 12000, sub=0.01)
+    base = _graph_index(tmp, contigs, 1031, 150)
+    rfa = os.path.join(tmp, "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    ss = os.path.join(tmp, "ss.txt")
+    with open(ss, "w") as f:
+        for t, l, r, d in F.known_sites(introns, 1031, 0.6):
+            f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
+    opts = ["--no-temp-splicesite", "--known-splicesite-infile", ss]
+    want = _compare(tmp, base, ["-U", rfa], ["-p", "1"] + opts, ["-p", "4"] + opts)
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > 2000
+
+
+@needs_ref
+def test_paired_on_snp_graph(tmp_path):
+    import fuzz_spliced_pairs as F
+    tmp = str(tmp_path)
+    contigs, m1, m2, _ = F.make_case(1032, 6000, sub=0.01)
+    base = _graph_index(tmp, contigs, 1032, 200)
+    f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    _compare(tmp, base, ["-1", f1, "-2", f2], ["-p", "1", "--no-temp-splicesite"], ["-p", "4", "--no-temp-splicesite"])
+
+
+@needs_ref
+def test_temporary_splice_sites_on_snp_graph(tmp_path):
+    import fuzz_spliced as F
+    tmp = str(tmp_path)
+    contigs, reads, _ = F.make_case(1033, 15000, sub=0.01)
+    base = _graph_index(tmp, contigs, 1033, 200)
+    rfa = os.path.join(tmp, "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    _compare(tmp, base, ["-U", rfa], ["-p", "3", "--reorder"], ["-p", "3"])

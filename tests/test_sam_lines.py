@@ -206,3 +206,38 @@ def test_golden_spliced_default_mode_p1(tmp_path):
     got, db = T.wave_run(base, reads, names, 1, lambda lo, hi, o, r, a, k, W: T.format_wave(base, reads, names, lo, hi, o, r, a, k, W))
     want = [l for l in gzip.open(os.path.join(gold, "ref_se_spliced.sam.gz"), "rt").read().splitlines() if not l.startswith("@")]
     assert diff_lines(got, want) == 0
+
+
+@needs_ref
+def test_spliced_on_snp_graph_lines_identical(monkeypatch):
+    """spliced alignment on a SNP-graph index (the reference's genome_snp indexes in their default mode): reads from the alternate
+    haplotype over planted introns, a splice-site file on top — introns + known variants in one alignment (Zs:Z next to XS:A)"""
+    import fuzz_spliced as F
+    from h2gemu_align import emu_align
+    monkeypatch.setenv("H2G_FUZZ_SNPS", "150")
+    bad, tmp = F.run_case(1021, 2000, sub=0.01, verbose=2, known=0.5)
+    assert bad == 0
+    names, reads = read_fa(os.path.join(tmp, "r.fa"))
+    sites = api.read_splice_site_file(os.path.join(tmp, "ss.txt"), ["chr1"])
+    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, no_spliced=0, splice_sites=sites)
+    res, aln = SL.emu_to_abi(outs, recs)
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, options=["--known-splicesite-infile", os.path.join(tmp, "ss.txt")])
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert sum(1 for l in want if "Zs:Z" in l and "N" in l.split("\t")[5]) > 50
+    assert diff_lines(got, want) == 0
+
+
+@needs_ref
+def test_spliced_pairs_on_snp_graph_lines_identical(monkeypatch):
+    import fuzz_spliced_pairs as F
+    monkeypatch.setenv("H2G_FUZZ_SNPS", "200")
+    bad, _ = F.run_case(1022, 1200, sub=0.01, show=3, known=0.6)
+    assert bad == 0
+
+
+@needs_ref
+def test_temporary_splice_sites_on_snp_graph(monkeypatch):
+    import temp_splice as T
+    monkeypatch.setenv("H2G_FUZZ_SNPS", "200")
+    bad, _ = T.run_case(1023, 4500, P=2, show=3)
+    assert bad == 0
