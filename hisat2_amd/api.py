@@ -185,7 +185,8 @@ class AlignParams(C.Structure):
                 ("min_intronlen", u32), ("max_intronlen", u32), ("pen_cansplice", C.c_int32), ("pen_noncansplice", C.c_int32),
                 ("pen_canintronlen_type", u32), ("pen_noncanintronlen_type", u32), ("first_read_id", u32),
                 ("pen_canintronlen_const", C.c_double), ("pen_canintronlen_coeff", C.c_double),
-                ("pen_noncanintronlen_const", C.c_double), ("pen_noncanintronlen_coeff", C.c_double)]
+                ("pen_noncanintronlen_const", C.c_double), ("pen_noncanintronlen_coeff", C.c_double),
+                ("min_anchor_len", u32), ("min_anchor_len_noncan", u32), ("xs_only", u32), ("pad2_", u32)]
 
     def apply_options(self, opts, linear=None):
         """apply a list of reference command-line options (['-k', '3', '--mp', '4,2', ...]) to this block; returns leftovers.
@@ -196,6 +197,7 @@ class AlignParams(C.Structure):
             linear = self.khits == 5
         rest, i = [], 0
         saw_k, k_arg, max_seeds, sensitive, very = False, 0, 0, False, False
+        dta = False
         while i < len(opts):
             o = opts[i]
             v = opts[i + 1] if i + 1 < len(opts) else None
@@ -230,6 +232,13 @@ class AlignParams(C.Structure):
                 a = v.split(","); self.rdg_const = int(a[0]); self.rdg_linear = int(a[1]) if len(a) > 1 else self.rdg_linear; i += 2
             elif o == "--rfg":
                 a = v.split(","); self.rfg_const = int(a[0]); self.rfg_linear = int(a[1]) if len(a) > 1 else self.rfg_linear; i += 2
+            elif o in ("--dta", "--downstream-transcriptome-assembly", "--dta-cufflinks"):
+                dta = True
+                if o == "--dta-cufflinks":
+                    self.xs_only = 1
+                i += 1
+            elif o == "--rna-strandness":   # output only (XS:A): h2g_sam_set_rna_strandness
+                i += 2
             elif o == "--min-intronlen":
                 self.min_intronlen = int(v); i += 2
             elif o == "--max-intronlen":
@@ -255,6 +264,9 @@ class AlignParams(C.Structure):
                 i += 2
             else:
                 rest.append(o); i += 1
+        if dta:                              # hisat2.cpp:3920, 4078: applied after every option was read
+            self.min_anchor_len, self.min_anchor_len_noncan = 15, 20
+            self.pen_noncanintronlen_type, self.pen_noncanintronlen_const, self.pen_noncanintronlen_coeff = 4, -8.0, 2.0
         self.presets(linear, saw_k, k_arg, max_seeds, sensitive, very)
         return rest
 

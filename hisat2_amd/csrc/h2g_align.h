@@ -666,6 +666,7 @@ H2G_HD bool hit_equal(const h2g_ghit* a, const h2g_ghit* b) {
 struct AlnParams {
 	uint32_t khits, kseeds, no_spliced, secondary;
 	uint32_t minIntronLen, maxIntronLen, minAnchorLen, minAnchorLen_noncan, minK_local;
+	uint32_t xs_only = 0;                                          // --dta-cufflinks
 	uint32_t pseudogeneStop, anchorStop;
 	uint32_t maxFragLen;     // PairedEndPolicy::maxFragLen = -X (hisat2.cpp:345)
 	uint32_t bowtie2_dp;     // ReportingParams::bowtie2_dp: 0 off, 1 conditional, 2 unconditional (hisat2.cpp:529, 1770)
@@ -686,7 +687,8 @@ H2G_HD int64_t min_score_for(const AlnParams& P, uint32_t len) {
 inline AlnParams aln_params_from(const h2g_align_params& p, bool no_spliced, bool linear) {
 	AlnParams P;
 	P.khits = p.khits; P.kseeds = p.kseeds; P.no_spliced = no_spliced ? 1 : 0; P.secondary = p.secondary;
-	P.minIntronLen = p.min_intronlen; P.maxIntronLen = p.max_intronlen; P.minAnchorLen = 7; P.minAnchorLen_noncan = 14; P.minK_local = 8;   // tp.h, hi_aligner.h:3986
+	P.minIntronLen = p.min_intronlen; P.maxIntronLen = p.max_intronlen; P.minAnchorLen = p.min_anchor_len; P.minAnchorLen_noncan = p.min_anchor_len_noncan; P.minK_local = 8;
+	P.xs_only = p.xs_only;   // tp.h, hi_aligner.h:3986
 	P.pseudogeneStop = (linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
 	P.bowtie2_dp = p.bowtie2_dp;
 	P.scoreMinType = p.score_min_type; P.scoreMinConst = p.score_min_const; P.scoreMinCoeff = p.score_min_coeff;
@@ -708,6 +710,7 @@ inline void align_params_defaults(h2g_align_params* p, bool linear) {
 	p->min_intronlen = 20; p->max_intronlen = 500000; p->pen_cansplice = 0; p->pen_noncansplice = 12;   // hisat2.cpp:493-499
 	p->pen_canintronlen_type = 4; p->pen_canintronlen_const = -8.0; p->pen_canintronlen_coeff = 1.0;
 	p->pen_noncanintronlen_type = 4; p->pen_noncanintronlen_const = -8.0; p->pen_noncanintronlen_coeff = 1.0;
+	p->min_anchor_len = 7; p->min_anchor_len_noncan = 14; p->xs_only = 0; p->pad2_ = 0;
 }
 
 // One reported alignment = the arguments reportHit (hi_aligner.h:6064-6166) hands to AlnRes::init
@@ -841,7 +844,22 @@ H2G_HD void al_add_searched(AlignWS* aw, MateWS* ws, const h2g_ghit* hit) {
 }
 
 // reportHit hi_aligner.h:6064-6166 + AlnSinkWrap::report aln_sink.h:2565-2650 (unpaired mate 1)
-H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdlen, int64_t minsc) {
+H2G_HD bool al_report(AlignWS* aw, MateWS* ws, const h2g_ghit* hit, uint32_t rdlen, int64_t minsc, bool xs_only = false) {
+	if(xs_only) {   // reportHit hi_aligner.h:6101 over GenomeHit::splicing_dir :1128: a spliced alignment whose strand is unknown or mixed
+		uint32_t dir = H2G_SPL_UNKNOWN; bool spliced = false, mixed = false;
+		for(uint32_t i = 0; i < hit->nedits && !mixed; i++) {
+			if(hit->edits[i].type != H2G_EDIT_SPL) continue;
+			spliced = true;
+			const uint32_t d = spl_dir(hit->edits[i]);
+			if(dir == H2G_SPL_UNKNOWN) dir = d;
+			else if(d != H2G_SPL_UNKNOWN) {
+				const bool a_fw = dir == H2G_SPL_FW || dir == H2G_SPL_SEMI_FW, a_rc = dir == H2G_SPL_RC || dir == H2G_SPL_SEMI_RC;
+				if(a_fw && d != H2G_SPL_FW && d != H2G_SPL_SEMI_FW) mixed = true;
+				if(a_rc && d != H2G_SPL_RC && d != H2G_SPL_SEMI_RC) mixed = true;
+			}
+		}
+		if(spliced && (mixed || dir == H2G_SPL_UNKNOWN)) return false;
+	}
 	if(hit->rdoff - hit->trim5 > 0 || hit->len + hit->trim5 + hit->trim3 < rdlen) return false;
 	if(hit->score < minsc) return false;
 	if(ws->nres >= AL_MAX_RESULTS) { aw->overflow |= 4; return false; }

@@ -217,6 +217,8 @@ int main(int argc, char** argv) {
 	std::vector<std::string> u, m1, m2;
 	bool fasta = false, nospliced = false, notempss = false, nohead = false, parse_only = false, no_unal = false;
 	std::string known_ss, novel_ss;
+	bool dta = false, xs_only = false;
+	int strandness = 0;
 	uint64_t skip = 0, upto = ~0ull;
 	uint32_t trim5 = 0, trim3 = 0;
 	uint32_t dp = 0;
@@ -240,6 +242,13 @@ int main(int argc, char** argv) {
 		else if(a == "-p" || a == "--threads") threads = atoi(need("-p"));        // host threads for parsing and SAM formatting
 		else if(a == "--no-spliced-alignment") nospliced = true;
 		else if(a == "--no-temp-splicesite") notempss = true;
+		else if(a == "--dta" || a == "--downstream-transcriptome-assembly") dta = true;
+		else if(a == "--dta-cufflinks") { dta = true; xs_only = true; }
+		else if(a == "--rna-strandness") {
+			const std::string v = need("--rna-strandness");
+			strandness = v == "F" ? 1 : v == "R" ? 2 : v == "FR" ? 3 : v == "RF" ? 4 : 0;
+			if(!strandness) { fprintf(stderr, "Error: should be one of F, R, FR, or RF \n"); return 1; }
+		}
 		else if(a == "--known-splicesite-infile") known_ss = need("--known-splicesite-infile");
 		else if(a == "--novel-splicesite-infile") novel_ss = need("--novel-splicesite-infile");
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
@@ -372,6 +381,11 @@ int main(int argc, char** argv) {
 		}
 	}
 	// presets and the -k / --max-seeds defaults are resolved after every option was read, whatever their order (hisat2.cpp:1882-1909, 3903)
+	if(dta) {   // hisat2.cpp:3920, 4078-4079: after every option was read
+		P.min_anchor_len = 15; P.min_anchor_len_noncan = 20;
+		P.pen_noncanintronlen_type = 4; P.pen_noncanintronlen_const = -8.0; P.pen_noncanintronlen_coeff = 2.0;
+	}
+	P.xs_only = xs_only ? 1 : 0;
 	h2g_align_params_presets(&P, ix, saw_k ? 1 : 0, k_arg, max_seeds_arg, sensitive ? 1 : 0, very_sensitive ? 1 : 0);
 	if(P.min_intronlen > P.max_intronlen) {   // hisat2.cpp:4278
 		fprintf(stderr, "--min-intronlen(%u) should not be greater than --max-intronlen(%u)\n", P.min_intronlen, P.max_intronlen);
@@ -415,6 +429,7 @@ int main(int argc, char** argv) {
 	if(temp_ss) h2g_sam_collect_novel_sites(sam, 1);
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);
+	h2g_sam_set_rna_strandness(sam, strandness);
 	FILE* out = outfn.empty() ? stdout : fopen(outfn.c_str(), "wb");
 	if(!out) { fprintf(stderr, "cannot open %s\n", outfn.c_str()); return 1; }
 	// output text buffer: raw storage, grown without value-initialising hundreds of MB per batch

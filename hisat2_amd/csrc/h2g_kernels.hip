@@ -1467,7 +1467,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		// graph indexes: SNP / insertion / deletion ALTs; splice-site and exon ALTs (_tran indexes) are not read by this library
 		if(s->ix->has_splice_alts) { snprintf(g_err, sizeof g_err, "align: spliced alignment on an index with splice-site / exon ALTs (_tran) is not built"); return H2G_ERR_UNSUPPORTED; }
 		if(p->pen_canintronlen_type < 1 || p->pen_canintronlen_type > 4 || p->pen_noncanintronlen_type < 1 || p->pen_noncanintronlen_type > 4 ||
-		   p->min_intronlen < 20 || p->max_intronlen < p->min_intronlen || p->pen_cansplice < 0 || p->pen_noncansplice < 0) {
+		   p->min_intronlen < 20 || p->max_intronlen < p->min_intronlen || p->pen_cansplice < 0 || p->pen_noncansplice < 0 ||
+		   p->min_anchor_len < 1 || p->min_anchor_len_noncan < 1) {
 			snprintf(g_err, sizeof g_err, "align: splice scoring outside its range (intron-length function type 1..4, 20 <= min_intronlen <= max_intronlen, penalties >= 0)");
 			return H2G_ERR_ARG;
 		}

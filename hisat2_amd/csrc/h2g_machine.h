@@ -675,7 +675,7 @@ again:
 					M_GOTO(PC_FS_L_LOOP);
 				}
 #endif
-				al_report(ws, mw, &hit, rdlen, minsc);
+				al_report(ws, mw, &hit, rdlen, minsc, P.xs_only != 0);
 				if(hit.score > f.maxsc) f.maxsc = hit.score;
 			}
 			RC_RET(f.maxsc);
@@ -846,7 +846,7 @@ again:
 			if(!P.secondary && can->score < f.prev_score) continue;
 			if(i > 0 && !al_is_searched(mw, can)) al_add_searched(ws, mw, can);
 			if(!al_redundant(mw, can, rdlen)) {
-				al_report(ws, mw, can, rdlen, gv.rc_minsc);
+				al_report(ws, mw, can, rdlen, gv.rc_minsc, P.xs_only != 0);
 				if(can->score > f.maxsc) f.maxsc = can->score;
 			}
 		}

@@ -40,6 +40,7 @@ struct h2g_sam {
 	double smConst = 0.0, smCoeff = (double)(-0.2f);
 	h2g::HostSpliceDB ssdb;                               // h2g_sam_set_splice_sites: TLEN of concordant pairs leaves known introns out
 	uint32_t ssdb_window = 0;
+	int rna_strandness = 0;                               // --rna-strandness: 0 unknown, 1 F, 2 R, 3 FR, 4 RF (read.h:30)
 	bool collect_novel = false;                           // h2g_sam_collect_novel_sites
 	uint64_t first_read_id = 0;                           // Read::rdid of read 0 of the next format call
 };
@@ -447,7 +448,14 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	o += "\tYT:Z:";
 	o += fl.concordant() ? "CP" : fl.discordant() ? "DP" : fl.unpairedMate() ? "UP" : "UU";
 	if(!fl.lenfilt) o += "\tYF:Z:LN"; else if(!fl.nfilt) o += "\tYF:Z:NS";
-	{   // XS:A: sam.h:925-940 with AlnRes::spliced_whichsense_transcript aligner_result.h:1289 (unstranded library)
+	if(S.rna_strandness != 0) {   // a stranded library: the tag follows from the mate and the strand it aligned to (sam.h:940-966)
+		char strand = '+';
+		const bool m1 = fl.pairing == PAIR_UNPAIRED || fl.readMate1();   // unpaired reads are ALN_RES_TYPE_UNPAIRED_MATE1 (aln_sink.h:2368)
+		const int rs_ = S.rna_strandness;
+		if(m1) { if(rs->fw) { if(rs_ == 2 || rs_ == 4) strand = '-'; } else if(rs_ == 1 || rs_ == 3) strand = '-'; }
+		else   { if(rs->fw) { if(rs_ == 3) strand = '-'; } else if(rs_ == 4) strand = '-'; }
+		o += "\tXS:A:"; o.push_back(strand);
+	} else {   // XS:A: sam.h:925-940 with AlnRes::spliced_whichsense_transcript aligner_result.h:1289 (unstranded library)
 		uint32_t sense = 1;
 		for(uint32_t i = 0; i < rs->nedits; i++) {
 			if(rs->edits[i].type != EDIT_SPL) continue;
@@ -670,6 +678,7 @@ extern "C" void h2g_sam_set_splice_sites(h2g_sam* S, const h2g_splice_site* site
 	h2g::build_splice_db(sites, n, (uint32_t)S->refnames.size(), S->ssdb);
 	S->ssdb_window = window;
 }
+extern "C" void h2g_sam_set_rna_strandness(h2g_sam* S, int code) { if(S) S->rna_strandness = code; }
 extern "C" void h2g_sam_collect_novel_sites(h2g_sam* S, int on) { if(S) S->collect_novel = on != 0; }
 extern "C" void h2g_sam_set_first_read_id(h2g_sam* S, uint64_t id) { if(S) S->first_read_id = id; }
 extern "C" size_t h2g_sam_take_novel_sites(h2g_sam* S, h2g_splice_site* out, size_t cap) {

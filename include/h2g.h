@@ -290,6 +290,9 @@ typedef struct {
 	uint32_t first_read_id;                                     /* type as score_min_type; default G,-8,1.  first_read_id: Read::rdid of
 	                                                             * read 0 of the batch — the splice-site window compares read ids */
 	double   pen_canintronlen_const, pen_canintronlen_coeff, pen_noncanintronlen_const, pen_noncanintronlen_coeff;
+	/* TranscriptomePolicy (hisat2.cpp:4076-4084): anchor minima 7 / 14, with --dta (transcript assemblers) 15 / 20 and
+	 * --pen-noncanintronlen G,-8,2; xs_only (--dta-cufflinks): spliced alignments of unknown strand are not reported (hi_aligner.h:6101) */
+	uint32_t min_anchor_len, min_anchor_len_noncan, xs_only, pad2_;
 } h2g_align_params;
 /* number of visible HIP devices (0 without a GPU: the library has no CPU path) */
 H2G_EXPORT int        h2g_device_count(void);

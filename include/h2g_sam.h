@@ -40,6 +40,8 @@ H2G_EXPORT size_t     h2g_sam_read_splice_site_file(const h2g_sam*, const char* 
 /* the splice sites given to h2g_index_set_splice_sites: TLEN of a concordant pair leaves the longest database intron lying between
  * its mates out (AlnRes::setFragmentLength aligner_result.h:1669-1689, --no-templatelen-adjustment is not built) */
 H2G_EXPORT void       h2g_sam_set_splice_sites(h2g_sam*, const h2g_splice_site* sites, size_t n, uint32_t window);
+/* --rna-strandness: 0 unknown (XS:A from the splice directions), 1 F, 2 R, 3 FR, 4 RF (XS:A on every aligned line, sam.h:940-966) */
+H2G_EXPORT void       h2g_sam_set_rna_strandness(h2g_sam*, int code);
 /* Temporary splice sites (the reference's default mode; SpliceSiteDB::addSpliceSite splice_site.cpp:190, called for every line
  * written, aln_sink.h:1570): with collection on, the format calls record the junctions of the alignments they print, tagged with
  * the read's id = first_read_id + its index in the call.  h2g_sam_take_novel_sites hands them over in read order (returns the

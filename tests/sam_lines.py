@@ -49,6 +49,10 @@ def _score_min(L, h, options):
     if options and "--secondary" in options:
         L.h2g_sam_set_secondary.argtypes = [C.c_void_p, C.c_int]
         L.h2g_sam_set_secondary(h, 1)
+    if options and "--rna-strandness" in options:
+        code = {"F": 1, "R": 2, "FR": 3, "RF": 4}[options[list(options).index("--rna-strandness") + 1]]
+        L.h2g_sam_set_rna_strandness.argtypes = [C.c_void_p, C.c_int]
+        L.h2g_sam_set_rna_strandness(h, code)
     if options and "--known-splicesite-infile" in options:
         fn = options[list(options).index("--known-splicesite-infile") + 1].encode()
         L.h2g_sam_read_splice_site_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]

@@ -75,3 +75,20 @@ def test_temporary_splice_sites_on_snp_graph(tmp_path):
     rfa = os.path.join(tmp, "r.fa")
     synth.write_reads_fasta(rfa, reads)
     _compare(tmp, base, ["-U", rfa], ["-p", "3", "--reorder"], ["-p", "3"])
+
+
+@needs_ref
+def test_dta_and_stranded_library_command_line(tmp_path):
+    """--dta-cufflinks + --rna-strandness on a linear index: anchor minima 15 / 20, unknown-strand junctions dropped, XS:A from the strand"""
+    import fuzz_spliced_pairs as F
+    tmp = str(tmp_path)
+    contigs, m1, m2, _ = F.make_case(1041, 6000, sub=0.01)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    opts = ["--no-temp-splicesite", "--dta-cufflinks", "--rna-strandness", "RF"]
+    _compare(tmp, base, ["-1", f1, "-2", f2], ["-p", "1"] + opts, ["-p", "4"] + opts)
