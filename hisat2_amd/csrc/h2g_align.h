@@ -70,6 +70,7 @@ struct LGfm {
 	static constexpr uint32_t SYMS = 232, NCW = 8, F_OFF = 58, M_OFF = 87, HDR = 116, WSZ = 2;
 	H2G_HD uint32_t offs_at(uint32_t i) const { const uint32_t v = offs[i]; return v == 0xffffu ? H2G_MAX : v; }
 };
+H2G_HD bool local_is_linear(const DLocalDesc& d) { return d.len + 1 == d.gbwtLen || d.gbwtLen == 0; }   // GFMParams::linearFM gfm.h
 H2G_HD LGfm lgfm_of(const DLocalSet& ls, const DLocalDesc& d) {
 	LGfm x;
 	x.sides = ls.sides + d.sides_off; x.offs = ls.words + d.offs_off; x.zoffs = ls.zoffs + d.zoffs_off;
@@ -127,6 +128,39 @@ struct LIdx {
 	}
 	H2G_HD int rowL(uint32_t row) const {
 		uint32_t sideNum = row / 224u, charOff = row - sideNum * 224u;
+		const uint8_t* p = side_ptr(sideNum);
+		return (p[charOff >> 2] >> ((charOff & 3) * 2)) & 3;
+	}
+};
+
+// A local index without a variant in its interval is a LINEAR index even inside a graph index (GFMParams::linearFM gfm.h:149:
+// len + 1 == gbwtLen): it keeps the file's 128 B sides (lineRate 7) but lays them out linearly — 120 B payload (480 symbols)
+// + u16 occ[4] (GFMParams::init: sideGbwtSz = sideSz - 4 * sizeof(index_t)).
+struct LIdxW {
+	const DLocalSet* ls;
+	const DLocalDesc* d;
+	H2G_HD const uint8_t* side_ptr(uint32_t sideNum) const { return ls->sides + d->sides_off + (size_t)sideNum * 128; }
+	H2G_HD uint32_t ftab_at(uint32_t i) const { return ls->words[d->ftab_off + i]; }
+	H2G_HD uint32_t ftabChars() const { return ls->ftabChars; }
+	H2G_HD bool is_zoff(uint32_t row) const { return d->nZ && row == d->zoff; }
+	H2G_HD uint32_t side_of(uint32_t row) const { return row / 480u; }
+	H2G_HD uint32_t fh(uint32_t i) const { const uint32_t v = ftab_at(i); return v <= d->ftabLim ? v : ls->words[d->eftab_off + ((v ^ 0xffffu) * 2 + 1)]; }
+	H2G_HD uint32_t fl(uint32_t i) const { const uint32_t v = ftab_at(i); return v <= d->ftabLim ? v : ls->words[d->eftab_off + ((v ^ 0xffffu) * 2)]; }
+	H2G_HD void lohi(uint32_t fi, uint32_t* top, uint32_t* bot) const { *top = fh(fi); *bot = fl(fi + 1); }
+	H2G_HD uint32_t rank(uint32_t row, int c) const {   // countBt2Side gfm.h:2958 for index_t = uint16_t on a 128 B side
+		const uint32_t sideNum = row / 480u, charOff = row - sideNum * 480u;
+		const uint8_t* p = side_ptr(sideNum);
+		uint32_t cnt = 0;
+		for(int k = 0; k < 15; k++) { uint64_t w; memcpy(&w, p + 8 * k, 8); cnt += count_word(w, c, (int)charOff - 32 * k); }
+		if(c == 0 && d->nZ) {
+			const uint32_t zs = d->zoff / 480u, zc = d->zoff - zs * 480u;
+			if(zs == sideNum && zc < charOff) cnt--;
+		}
+		uint16_t occ; memcpy(&occ, p + 120 + 2 * c, 2);
+		return (uint32_t)occ + cnt + d->fchr[c];
+	}
+	H2G_HD int rowL(uint32_t row) const {
+		const uint32_t sideNum = row / 480u, charOff = row - sideNum * 480u;
 		const uint8_t* p = side_ptr(sideNum);
 		return (p[charOff >> 2] >> ((charOff & 3) * 2)) & 3;
 	}
@@ -194,7 +228,7 @@ H2G_HD uint32_t sa_walk_idx(const IDX& ix, uint32_t row, uint32_t offMask, uint3
 		}
 		int c = ix.rowL(row);
 		row = ix.rank(row, c);
-		jumps++;
+		if(++jumps > (1u << 22)) break;              // never reached on a well-formed index (the text is shorter): no endless walk on the device
 	}
 	*steps += jumps;
 	return jumps;
@@ -230,7 +264,8 @@ H2G_HD bool local_joff_to_coord(const DLocalSet& ls, const DLocalDesc* d, uint32
 }
 
 // getGenomeCoords_local hi_aligner.h:5861-5941 on a linear local index
-H2G_HD bool genome_coords_local(const LIdx& ix, uint32_t top, uint32_t bot, uint32_t rdoff, uint32_t rdlen, h2g_coord* coords,
+template <typename LX>
+H2G_HD bool genome_coords_local(const LX& ix, uint32_t top, uint32_t bot, uint32_t rdoff, uint32_t rdlen, h2g_coord* coords,
                                 uint32_t cap, uint32_t* ncoords, uint32_t* nsteps)
 {
 	const DLocalDesc* d = ix.d;
@@ -949,6 +984,14 @@ H2G_HD uint32_t al_local_search(const AlnCtx& C, AlignWS* ws, uint32_t lidx, con
 	const AlnParams& P = *C.P;
 	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
 	if(!C.graph) return gfm_search(lx, seq, extoff, extlen, top, bot, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true, &ws->nrank);
+	if(local_is_linear(*lx.d)) {
+		// a local index without a variant in its interval is a LINEAR index even inside a graph index (GFMParams::linearFM:
+		// len + 1 == gbwtLen; 64 B sides, no F / M bits): nodes are rows, no in-edges (localGFMSearch hi_aligner.h:6751 over mapLF)
+		LIdxW lw; lw.ls = C.ls; lw.d = lx.d;
+		const uint32_t nelt = gfm_search(lw, seq, extoff, extlen, top, bot, uniqueStop, P.minK_local, maxHitLen, P.kseeds, true, &ws->nrank);
+		C.gsl->node_top = *top; C.gsl->node_bot = *bot; C.gsl->ie.n = 0;
+		return nelt;
+	}
 	const LGfm x = lgfm_of(*C.ls, *lx.d);
 	GRange r;
 	r.top = *top; r.bot = *bot; r.node_top = r.node_bot = 0;
@@ -963,18 +1006,19 @@ H2G_HD void al_local_coords(const AlnCtx& C, AlignWS* ws, uint32_t lidx, uint32_
 {
 	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[lidx];
 	if(!C.graph) { genome_coords_local(lx, top, bot, rdoff, rdlen, coords, cap, ncoords, &ws->nsteps); return; }
+	if(local_is_linear(*lx.d)) { LIdxW lw; lw.ls = C.ls; lw.d = lx.d; genome_coords_local(lw, top, bot, rdoff, rdlen, coords, cap, ncoords, &ws->nsteps); return; }
 	const LGfm x = lgfm_of(*C.ls, *lx.d);
 	const uint32_t node_top = C.gsl->node_top, node_bot = C.gsl->node_bot;
 	uint32_t nelt = 0, n = 0;
 	*ncoords = 0;
-	if(!gw_resolve(x, &C.gws->gw, top, bot, node_top, node_bot, &C.gsl->ie, bot - top, &nelt)) { ws->overflow |= 512; return; }
+	if(!gw_resolve(x, &C.gws->gw, top, bot, node_top, node_bot, &C.gsl->ie, bot - top, &nelt)) { { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); } return; }
 	ws->nsteps += C.gws->gw.nsteps;
 	AL_TRACE("     lcoords top %u bot %u node %u %u -> nelt %u\n", top, bot, node_top, node_bot, nelt);
 	for(uint32_t e = 0; e < nelt; e++) {
 		h2g_coord c;
 		AL_TRACE("      off %u\n", C.gws->gw.offs[e]);
 		if(!local_joff_to_coord(*C.ls, lx.d, C.gws->gw.offs[e] & 0xffffu, rdoff, rdlen, &c)) continue;
-		if(n < cap) coords[n++] = c; else ws->overflow |= 512;
+		if(n < cap) coords[n++] = c; else { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); }
 	}
 	*ncoords = n;
 }
@@ -998,7 +1042,7 @@ H2G_HD uint32_t al_global_coords(const AlnCtx& C, AlignWS* ws, uint32_t top, uin
 	else {
 		genome_coords_graph_item(*C.g, &C.gws->gw, top, bot, C.gsl->node_top, C.gsl->node_bot, &C.gsl->ie, bot - top, extlen, true,
 		                         coords, cap, &res);
-		if(res.nsteps == H2G_MAX) { ws->overflow |= 512; res.nsteps = 0; }
+		if(res.nsteps == H2G_MAX) { { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); } res.nsteps = 0; }
 	}
 	ws->nsteps += res.nsteps;
 	return res.ncoords;

@@ -364,6 +364,12 @@ H2G_HDN void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32
 // merged when several rows lead into one node — merged-away duplicates get their own element index as the "offset"
 // (group_walk.h:1171, :1246), reproduced because that value reaches joinedToTextOff.  tryOffset (gfm.h:2719) samples by
 // node: (node & offMask) == node -> offs[node >> offRate].  Fixed capacities; exceeding one sets GwCtx::overflow.
+// a capacity of the group walk was hit (the read is flagged; -DH2G_TRACE builds of the host instantiation say where)
+#if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+#define GW_OVF(X) ((X)->overflow = 1, fprintf(stderr, "  group walk capacity hit at h2g_graph.h:%d\n", __LINE__))
+#else
+#define GW_OVF(X) ((X)->overflow = 1)
+#endif
 #ifndef H2G_GW_MAXELT             // the *_big units raise these (h2g_go_big.h)
 #define H2G_GW_MAXELT 24          // >= kseeds (20 on graph indexes)
 #define H2G_GW_MAXST 40
@@ -410,7 +416,7 @@ H2G_HDN void map_glf1_nochar(const X& g, uint32_t row, GRange* r) {
 	r->top = ft; r->bot = fb; r->node_top = node_top; r->node_bot = node_bot;
 }
 H2G_HD GwState* gw_new_state(GwCtx* x) {
-	if(x->nst >= H2G_GW_MAXST) { x->overflow = 1; return &x->st[H2G_GW_MAXST - 1]; }
+	if(x->nst >= H2G_GW_MAXST) { GW_OVF(x); return &x->st[H2G_GW_MAXST - 1]; }
 	GwState* s = &x->st[x->nst++];
 	s->top = s->bot = s->node_top = s->node_bot = s->step = s->mapi = s->nmap = s->nie = 0;
 	return s;
@@ -474,14 +480,14 @@ H2G_HDN void gw_init(const X& g, GwCtx* x, uint32_t range0) {
 		uint32_t zin[4], nz = 0;
 		for(uint32_t i = 0; i < g.nZ; i++) {
 			const uint32_t z = i == 0 ? g.zoff : g.zoffs[i];
-			if(z > s->top && z < s->bot) { if(nz < 4) zin[nz++] = z; else x->overflow = 1; }
+			if(z > s->top && z < s->bot) { if(nz < 4) zin[nz++] = z; else GW_OVF(x); }
 		}
 		if(nz == 0) continue;
 		uint32_t g2n[H2G_GW_MAXROWS], ng = 0, n = 0, ee = 0;
 		for(uint32_t r = 0; r < s->bot - s->top; r++) {
-			if(ng < H2G_GW_MAXROWS) g2n[ng++] = n; else x->overflow = 1;
+			if(ng < H2G_GW_MAXROWS) g2n[ng++] = n; else GW_OVF(x);
 			if(ee < s->nie && n == s->ie[ee].first) {
-				for(uint32_t a = 0; a < s->ie[ee].second; a++) { if(ng < H2G_GW_MAXROWS) g2n[ng++] = n; else x->overflow = 1; r++; }
+				for(uint32_t a = 0; a < s->ie[ee].second; a++) { if(ng < H2G_GW_MAXROWS) g2n[ng++] = n; else GW_OVF(x); r++; }
 				ee++;
 			}
 			n++;
@@ -507,17 +513,17 @@ H2G_HDN void gw_init(const X& g, GwCtx* x, uint32_t range0) {
 				while(j2 < new_bot - s->top) { if(nn != g2n[j2]) break; j2++; }
 				if(j + 1 < j2) {
 					if(ns->nie < H2G_GW_MAXELT) { ns->ie[ns->nie].first = nn - (new_node_top - s->node_top); ns->ie[ns->nie].second = j2 - j - 1; ns->nie++; }
-					else x->overflow = 1;
+					else GW_OVF(x);
 				}
 				j = j2;
 			}
 			ns->nmap = new_node_bot - new_node_top; ns->mapi = 0;
-			if(ns->nmap > H2G_GW_MAXELT) { x->overflow = 1; ns->nmap = H2G_GW_MAXELT; }
+			if(ns->nmap > H2G_GW_MAXELT) { GW_OVF(x); ns->nmap = H2G_GW_MAXELT; }
 			for(uint32_t j = 0; j < ns->nmap; j++) ns->map[j] = s->map[new_node_top + j - s->node_top + s->mapi];
 			ns->top = new_top; ns->bot = new_bot; ns->node_top = new_node_top; ns->node_bot = new_node_bot; ns->step = s->step;
 			// the reference initialises the new state right here (depth-first); deferring it is equivalent because the
 			// new states only touch their own elements' offs/fmap entries, which this state no longer owns
-			if(npend < H2G_GW_MAXST) pending[npend++] = x->nst - 1; else x->overflow = 1;
+			if(npend < H2G_GW_MAXST) pending[npend++] = x->nst - 1; else GW_OVF(x);
 		}
 		s->bot = zin[0];
 		s->node_bot = g2n[s->bot - s->top - 1] + s->node_top + 1;
@@ -580,7 +586,7 @@ H2G_HDN void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 				cur_node_bot = s->node_top + s->ie[e].first + 1;
 			}
 			uint32_t n = curbot - curtop;
-			if(n > H2G_GW_MAXROWS) { x->overflow = 1; return; }
+			if(n > H2G_GW_MAXROWS) { GW_OVF(x); return; }
 			uint64_t mask[4] = {0, 0, 0, 0};
 			for(uint32_t k = 0; k < n; k++) mask[rowL128(g, curtop + k)] |= 1ull << k;          // mapLFRange masks
 			for(int c = 0; c < 4; c++) {
@@ -588,14 +594,14 @@ H2G_HDN void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 				GRange r;
 				IEdges tie;
 				map_glf(g, curtop, curbot, c, cur_node_bot - cur_node_top, &r, &tie);
-				if(tie.n > H2G_GW_MAXELT) { x->overflow = 1; return; }
+				if(tie.n > H2G_GW_MAXELT) { GW_OVF(x); return; }
 				if(first) {
 					first = false;
 					newtop = r.top; newbot = r.bot; new_node_top = r.node_top; new_node_bot = r.node_bot;
 					backup.n = tie.n;
 					for(uint32_t k = 0; k < tie.n; k++) { backup.e[k][0] = tie.e[k][0]; backup.e[k][1] = tie.e[k][1]; }
 					for(uint32_t j = 0; j < n; j++) if((mask[c] >> j) & 1) {
-						if(ngmap < H2G_GW_MAXELT) gmap[ngmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)]; else x->overflow = 1;
+						if(ngmap < H2G_GW_MAXELT) gmap[ngmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)]; else GW_OVF(x);
 					}
 					if(new_node_bot - new_node_top < ngmap) gw_merge_dups(g, x, curtop, mask[c], n, c, gmap, &ngmap);
 				} else {
@@ -603,7 +609,7 @@ H2G_HDN void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 					if(x->overflow) return;
 					s = &x->st[range];
 					for(uint32_t j = 0; j < n; j++) if((mask[c] >> j) & 1) {
-						if(ns->nmap < H2G_GW_MAXELT) ns->map[ns->nmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)]; else x->overflow = 1;
+						if(ns->nmap < H2G_GW_MAXELT) ns->map[ns->nmap++] = s->map[j + s->mapi + (cur_node_top - s->node_top)]; else GW_OVF(x);
 					}
 					if(r.node_bot - r.node_top < ns->nmap) gw_merge_dups(g, x, curtop, mask[c], n, c, ns->map, &ns->nmap);
 					ns->top = r.top; ns->bot = r.bot; ns->node_top = r.node_top; ns->node_bot = r.node_bot;
@@ -653,7 +659,12 @@ H2G_HDN bool gw_resolve(const X& g, GwCtx* x, uint32_t top, uint32_t bot, uint32
 	for(uint32_t elt = 0; elt < nelt; elt++) {
 		uint32_t guard = 0;
 		while(x->offs[elt] == H2G_MAX) {                      // advanceElement :1491-1545
-			if(x->overflow || x->fmap[elt] == H2G_MAX || ++guard > 200000u) return false;
+			if(x->overflow || x->fmap[elt] == H2G_MAX || ++guard > 200000u) {
+#if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+				fprintf(stderr, "  gw_resolve gives up: overflow %u fmap %u guard %u (elt %u of %u, top %u bot %u nodes %u %u)\n", x->overflow, x->fmap[elt], guard, elt, nelt, top, bot, node_top, node_bot);
+#endif
+				return false;
+			}
 			gw_advance(g, x, x->fmap[elt]);
 		}
 	}
@@ -709,6 +720,9 @@ H2G_HDN uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, 
 	uint32_t top, bot;
 	ft.lohi(fi, &top, &bot);
 	dep += ftabLen;
+#if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+	if(local) fprintf(stderr, "      lsearch ftab key %u -> top %u bot %u\n", fi, top, bot);
+#endif
 	if(top >= bot) { *hitlen = ftabLen; return 0; }
 	uint32_t ntop = 0, nbot = 0;
 	IEdges tmp;
@@ -724,6 +738,9 @@ H2G_HDN uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, 
 				if(map_glf1(g, top, c, &r) && r.top + 1 < r.bot) { tmp.n = 1; tmp.e[0][0] = 0; tmp.e[0][1] = r.bot - r.top - 1; }
 			}
 		}
+#if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+		if(local) fprintf(stderr, "      lsearch step c %d: [%u,%u) -> [%u,%u) nodes [%u,%u)\n", c, top, bot, r.top, r.bot, r.node_top, r.node_bot);
+#endif
 		if(r.top >= r.bot) break;
 		top = r.top; bot = r.bot; ntop = r.node_top; nbot = r.node_bot;
 		ie_out->n = tmp.n;
@@ -750,6 +767,7 @@ struct DAlts {
 	// optional position index: bucket[b] = first ALT with pos >= b << H2G_ALT_BUCKET_SHIFT, so that the lower bound is one load
 	// plus a scan of the few ALTs of the bucket instead of ~log2(n) dependent loads (15 at E. coli scale, 24 at GRCh38+SNP scale)
 	const uint32_t* bucket = nullptr; uint32_t nbucket = 0;
+	uint32_t has_splice = 0;                                // ALTDB::hasSpliceSites(): the list holds splice-site ALTs (a --ss index)
 };
 #define H2G_ALT_BUCKET_SHIFT 7
 
@@ -817,7 +835,7 @@ H2G_HDN void replace_edits_with_alts(const DAlts& A, h2g_ghit* h) {
 }
 
 // alignWithALTs_recur (hi_aligner.h:2763-3550) for SNP ALTs (single / insertion / deletion), recursion turned into an
-// explicit stack.  Splice-site / exon ALTs are skipped (a --snp-only index has none) and haplotypes are unused
+// explicit stack, incl. the splice-site ALTs of --ss indexes (exon ALTs are skipped as in the reference); haplotypes are unused
 // (use_haplotype = false, hisat2.cpp:522).  The reference window needs no buffers: rfseq[i] is always the base of text
 // `tidx` at rfoff + i (4 outside the text), which RefCursor serves directly.
 #ifndef H2G_AWA_DEPTH
@@ -825,6 +843,7 @@ H2G_HDN void replace_edits_with_alts(const DAlts& A, h2g_ghit* h) {
 #endif
 struct AwaFrame {
 	uint32_t joinedOff, rdoff_add, rdoff, rdlen, rflen, tmp_numNs, orig_nedits, next_rdlen, rd_i, max_rd_i, dep;
+	uint32_t prev_alt_type, cur_alt_type;   // the ALT the parent frame went through; the one this frame is trying (splice sites search further, :3523)
 	int32_t  rfoff, a_first, a_second, min_rd_i;
 	uint32_t state;   // 0 entry, 1 loop, 2 after call
 };
@@ -867,7 +886,7 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 	{
 		AwaFrame& f = W->fr[0];
 		f.joinedOff = joinedOff0; f.rdoff_add = rdoff0 - base_rdoff; f.rdoff = rdoff0; f.rdlen = rdlen0; f.rfoff = rfoff0; f.rflen = rflen0;
-		f.tmp_numNs = 0; f.dep = 0; f.state = 0;
+		f.tmp_numNs = 0; f.dep = 0; f.state = 0; f.prev_alt_type = 0; f.cur_alt_type = 0;
 	}
 	while(sp >= 0) {
 		{
@@ -945,7 +964,11 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 					if(alt.type == H2G_ALT_SNP_DEL) { if(alt.seq & 0xff) continue; }
 					if(alt.pos > f.joinedOff + max_rd_i) break;
 				}
-				if(mm_max_rd_i == f.rdlen) AWA_RETURN(mm_max_rd_i);     // no splice-site ALTs to search further for
+				if(mm_max_rd_i == f.rdlen) {                            // the read ends here: only a forward splice site is worth trying (:3236-3245)
+					bool further = false;
+					for(uint32_t q = a1; q < a2; q++) if(A.a[q].type == H2G_ALT_SPLICESITE && A.a[q].pos < A.a[q].len) { further = true; break; }
+					if(!further) AWA_RETURN(mm_max_rd_i);
+				}
 				if(tmp_mm > 0) W->ntmp -= tmp_mm;
 				f.max_rd_i = max_rd_i;
 				f.a_first = (int)a1; f.a_second = (int)a2;
@@ -958,7 +981,12 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 				if(f.orig_nedits < W->ntmp) AWA_ERASE_FRONT(W->ntmp - f.orig_nedits);
 				f.a_second--;
 			} else {
-				if(ret > 0 && f.rd_i + ret == f.rdlen) AWA_RETURN(f.rd_i + ret);
+				if(ret > 0) {
+					bool search_further = false;                          // :3519-3535
+					if(f.cur_alt_type == H2G_ALT_SPLICESITE)
+						for(int q = f.a_first + 1; q < f.a_second; q++) if(A.a[q].type == H2G_ALT_SPLICESITE && A.a[q].pos < A.a[q].len) { search_further = true; break; }
+					if(!search_further && f.rd_i + ret == f.rdlen) AWA_RETURN(f.rd_i + ret);
+				}
 				if(f.orig_nedits < W->ntmp) W->ntmp = f.orig_nedits;
 				f.a_first++;
 			}
@@ -969,11 +997,15 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 			for(; f.a_second > f.a_first; f.a_second--) {
 				DAlt alt = A.a[f.a_second];
 				if(alt.pos >= f.joinedOff) continue;
-				if(alt.type == H2G_ALT_SPLICESITE || alt.type == H2G_ALT_EXON) continue;
+				if(alt.type == H2G_ALT_SPLICESITE) {                   // the mirrored copy (left > right) serves the leftward walk (:2946-2951)
+					if(alt.pos < alt.len) continue;
+					const uint32_t t_ = alt.pos; alt.pos = alt.len; alt.len = t_;
+				}
 				if(alt.type == H2G_ALT_SNP_DEL) {
 					if(!(alt.seq & 0xff)) continue;
 					alt.pos = alt.pos - alt.len + 1;
 				}
+				if(alt.type == H2G_ALT_EXON) continue;
 				bool alt_compatible = false;
 				int rf_i = (int)f.rflen - 1, rd_i = (int)f.rdoff, diff = 0;
 				if(alt.type == H2G_ALT_SNP_SGL) diff = (int)(f.joinedOff - alt.pos - 1);
@@ -981,6 +1013,7 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 					if(alt.pos + alt.len >= f.joinedOff) continue;
 					diff = (int)(f.joinedOff - (alt.pos + alt.len));
 				} else if(alt.type == H2G_ALT_SNP_INS) diff = (int)(f.joinedOff - alt.pos);
+				else if(alt.type == H2G_ALT_SPLICESITE) diff = (int)(f.joinedOff - (alt.len + 1));   // alt.len = right
 				else continue;
 				if(rf_i < diff || rd_i < diff) continue;
 				rf_i -= diff; rd_i -= diff;
@@ -1021,10 +1054,21 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 						if(same_seq) { rd_i -= (int)alt.len; alt_compatible = true; }
 					}
 				}
+				uint32_t next_joined = alt.pos;
+				int splice_shift = 0;
+				if(alt.type == H2G_ALT_SPLICESITE) {                    // :3083-3105
+					alt_compatible = false;
+					if(!(rd_i == (int)f.rdoff && f.prev_alt_type == H2G_ALT_SPLICESITE)) {
+						const uint32_t intronLen = alt.len - alt.pos + 1;
+						AWA_PUSH_FRONT(make_spl_edit((uint32_t)(rd_i + 1), intronLen, (alt.seq & 0xff) ? H2G_SPL_FW : H2G_SPL_RC, true, 0.0f));
+						alt_compatible = true;
+						next_joined = alt.pos; splice_shift = (int)intronLen;   // next_joinedOff = alt.left; the window moves across the intron
+					}
+				}
 				if(alt_compatible) {
 					numALTsTried++;
 					if(rd_i < 0) { best_rdoff = rd_i; AWA_COMMIT(); AWA_RETURN(f.rdlen); }
-					int next_rfoff = f.rfoff, next_rflen = rf_i + 1, next_rdlen = rd_i + 1;
+					int next_rfoff = f.rfoff - splice_shift, next_rflen = rf_i + 1, next_rdlen = rd_i + 1;
 					if(next_rflen < next_rdlen) {
 						int add_len = next_rdlen + 10 - next_rflen;
 						if(next_rfoff < add_len) add_len = next_rfoff;
@@ -1033,8 +1077,9 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 					if(sp + 1 >= H2G_AWA_DEPTH) { h->overflow = 1; }
 					else {
 						AwaFrame& nf = W->fr[sp + 1];
-						nf.joinedOff = alt.pos; nf.rdoff_add = f.rdoff_add; nf.rdoff = (uint32_t)rd_i; nf.rdlen = (uint32_t)next_rdlen;
+						nf.joinedOff = next_joined; nf.rdoff_add = f.rdoff_add; nf.rdoff = (uint32_t)rd_i; nf.rdlen = (uint32_t)next_rdlen;
 						nf.rfoff = next_rfoff; nf.rflen = (uint32_t)next_rflen; nf.tmp_numNs = f.tmp_numNs; nf.dep = f.dep + 1; nf.state = 0;
+						nf.prev_alt_type = alt.type; nf.cur_alt_type = 0;
 						f.next_rdlen = (uint32_t)next_rdlen;
 						f.state = 2;
 						sp++;
@@ -1047,7 +1092,8 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 		} else {
 			for(; f.a_first < f.a_second; f.a_first++) {
 				const DAlt alt = A.a[f.a_first];
-				if(alt.type == H2G_ALT_SPLICESITE || alt.type == H2G_ALT_EXON) continue;
+				if(alt.type == H2G_ALT_SPLICESITE) { if(alt.pos > alt.len) continue; }   // forward copies only (left < right)
+				if(alt.type == H2G_ALT_EXON) continue;
 				if(alt.type == H2G_ALT_SNP_DEL) { if(alt.seq & 0xff) continue; }
 				bool alt_compatible = false;
 				uint32_t rf_i, rd_i;
@@ -1086,6 +1132,13 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 						}
 						if(same_seq) { rd_i += alt.len; alt_compatible = true; }
 					}
+				} else if(alt.type == H2G_ALT_SPLICESITE) {             // :3425-3449
+					bool try_splice = rd_i > 0;
+					if(rd_i == 0 && f.dep > 0) { if(W->ntmp > 0 && W->tmp[W->ntmp - 1].type != H2G_EDIT_SPL) try_splice = true; }   // no consecutive introns
+					if(try_splice) {
+						AWA_PUSH_BACK(make_spl_edit(rd_i + f.rdoff_add, alt.len - alt.pos + 1, (alt.seq & 0xff) ? H2G_SPL_FW : H2G_SPL_RC, true, 0.0f));
+						alt_compatible = true;
+					}
 				}
 				if(alt_compatible) {
 					numALTsTried++;
@@ -1099,14 +1152,17 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 					const uint32_t next_rdlen = f.rdlen - rd_i;
 					if(alt.type == H2G_ALT_SNP_SGL) next_joinedOff = alt.pos + 1;
 					else if(alt.type == H2G_ALT_SNP_DEL) { next_joinedOff = alt.pos + alt.len; if(f.rflen <= rf_i) next_rflen = 0; }
+					else if(alt.type == H2G_ALT_SPLICESITE) next_joinedOff = alt.len + 1;            // alt.right + 1
 					else next_joinedOff = alt.pos;
+					const int splice_shift = alt.type == H2G_ALT_SPLICESITE ? (int)(alt.len - alt.pos + 1) : 0;
 					if(next_rflen < next_rdlen) next_rflen = next_rdlen + 10;
 					if(sp + 1 >= H2G_AWA_DEPTH) { h->overflow = 1; }
 					else {
 						AwaFrame& nf = W->fr[sp + 1];
 						nf.joinedOff = next_joinedOff; nf.rdoff_add = f.rdoff_add + rd_i; nf.rdoff = f.rdoff + rd_i; nf.rdlen = next_rdlen;
-						nf.rfoff = f.rfoff + (int)rf_i; nf.rflen = next_rflen; nf.tmp_numNs = f.tmp_numNs; nf.dep = f.dep + 1; nf.state = 0;
-						f.rd_i = rd_i;
+						nf.rfoff = f.rfoff + (int)rf_i + splice_shift; nf.rflen = next_rflen; nf.tmp_numNs = f.tmp_numNs; nf.dep = f.dep + 1; nf.state = 0;
+						nf.prev_alt_type = alt.type; nf.cur_alt_type = 0;
+						f.rd_i = rd_i; f.cur_alt_type = alt.type;
 						f.state = 2;
 						sp++;
 						goto next_frame;
@@ -1132,7 +1188,7 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 	if(extlen > 0 && ne > 0) {
 		const h2g_edit f = h->edits[0];
 		if(f.pos + extlen == base_rdoff + 1) {
-			if(is_gap(f.type)) extlen = 0;
+			if(is_gap(f.type) || f.type == H2G_EDIT_SPL) extlen = 0;       // :758-763 (the front test covers splices, the back test gaps only)
 			if(f.type == H2G_EDIT_MM && f.chr == 'N') extlen = 0;
 		}
 		const h2g_edit b = h->edits[ne - 1];
@@ -1175,6 +1231,7 @@ H2G_HDN bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& s
 			for(uint32_t i = 0; i < added; i++) {
 				if(h->edits[i].type == H2G_EDIT_REF_GAP) ref_ext--;
 				else if(h->edits[i].type == H2G_EDIT_READ_GAP) ref_ext++;
+				else if(h->edits[i].type == H2G_EDIT_SPL) ref_ext += (int)spl_len(h->edits[i]);     // hi_aligner.h:2121
 			}
 			h->rdoff -= best_ext;
 			h->toff -= (uint32_t)ref_ext;
@@ -1200,6 +1257,7 @@ H2G_HDN bool extend_item_alts(const DRef& ref, const DAlts& A, const DScoring& s
 				const h2g_edit e = h->edits[ei];
 				if(e.type == H2G_EDIT_REF_GAP) ref_ext--;
 				else if(e.type == H2G_EDIT_READ_GAP) ref_ext++;
+				else if(e.type == H2G_EDIT_SPL) ref_ext += (int)spl_len(e);                        // :2162
 				else if(e.type == H2G_EDIT_MM && e.chr == 'N') ref_ext--;
 			}
 			const uint32_t jr = h->joinedOff + (uint32_t)ref_ext;
@@ -1283,53 +1341,113 @@ H2G_HD bool ghit_equal(const h2g_ghit* a, const h2g_ghit* b) {
 	return true;
 }
 
-// static GenomeHit::adjustWithALT (hi_aligner.h:2239-2390) as getAnchorHits calls it (:5175); no splice-site ALTs, so
-// findSSOffs yields the single (0, 0).  Appends to hits[*nhits .. cap); returns whether any hit was added.
+// GenomeHit::findSSOffs (hi_aligner.h:2482-2540): by how much a coordinate found near splice-site ALTs may be off — an anchor
+// that ran through a splice edge of the graph is reported at the far side of the intron.  (0, 0) first, then sorted, unique.
+H2G_HDN uint32_t find_ss_offs(const DGfm& g, const DAlts& A, uint32_t start, uint32_t end, OffDiff* so, uint32_t* overflow) {
+	uint32_t n = 0;
+	so[n].first = 0; so[n].second = 0; n++;
+	if(g.linear || !A.has_splice) return n;
+	auto push = [&](uint32_t first, int second) { if(n < H2G_OFFDIFF_CAP) { so[n].first = first; so[n].second = second; n++; } else *overflow = 1; };
+	for(uint32_t i = alt_lobound(A, start); i < A.n; i++) {
+		const DAlt alt = A.a[i];
+		if(alt.pos >= end) break;
+		if(alt.type != H2G_ALT_SPLICESITE) continue;
+		if(alt.pos < alt.len) {                                  // left < right
+			push(alt.len - alt.pos + 1, 1);
+			const uint32_t relax = 5;
+			const uint32_t from = alt.len > relax ? alt.len - relax : 0;
+			for(uint32_t j = alt_lobound(A, from); j < A.n; j++) {
+				const DAlt alt2 = A.a[j];
+				if(alt2.type != H2G_ALT_SPLICESITE) continue;
+				if(alt2.pos < alt2.len) continue;
+				if((uint64_t)alt2.pos + alt2.len == (uint64_t)alt.pos + alt.len) continue;
+				if(alt2.pos > alt.len + relax) break;
+				if(alt2.len < alt.pos) push(alt.pos - alt2.len, -1);
+				else push(alt2.len - alt.pos, 1);
+			}
+		} else push(alt.pos - alt.len + 1, -1);
+	}
+	if(n > 1) {   // sort (pair order: first, then second) + unique
+		for(uint32_t i = 1; i < n; i++) {
+			const OffDiff x = so[i];
+			int j = (int)i - 1;
+			while(j >= 0 && (x.first != so[j].first ? x.first < so[j].first : x.second < so[j].second)) { so[j + 1] = so[j]; j--; }
+			so[j + 1] = x;
+		}
+		uint32_t w = 1;
+		for(uint32_t i = 1; i < n; i++) if(so[i].first != so[w - 1].first || so[i].second != so[w - 1].second) so[w++] = so[i];
+		n = w;
+	}
+	return n;
+}
+
+// static GenomeHit::adjustWithALT (hi_aligner.h:2239-2390) as getAnchorHits calls it (:5175): for every splice-site offset
+// (findSSOffs; the single (0, 0) without splice-site ALTs) and every indel offset (findOffDiffs) the hit is re-seated until the
+// ALT-aware comparison covers it.  Appends to hits[*nhits .. cap); returns whether any hit was added.
 H2G_HDN bool adjust_with_alt(const DGfm& g, const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t rdoff, uint32_t len,
-                            uint32_t tidx, uint32_t toff, uint32_t joinedOff, h2g_ghit* hits, uint32_t* nhits, uint32_t cap,
+                            uint32_t tidx, uint32_t toff0, uint32_t joinedOff0, h2g_ghit* hits, uint32_t* nhits, uint32_t cap,
                             AwaWS* W, uint32_t* overflow)
 {
 	const uint32_t n0 = *nhits;
-	if(*nhits >= cap) { *overflow = 1; return false; }
-	h2g_ghit* gh = &hits[*nhits];
-	gh->read = 1;   // _hitcount
-	gh->fw = seq.fw; gh->rdoff = rdoff; gh->len = len; gh->trim5 = 0; gh->trim3 = 0; gh->tidx = tidx; gh->toff = toff; gh->joinedOff = joinedOff;
-	gh->score = 0; gh->nedits = 0; gh->overflow = 0;
-	(*nhits)++;
-	if(g.linear) return true;
-	const uint32_t width = 1u << (g.offRate + 2);
-	OffDiff od[H2G_OFFDIFF_CAP];
-	uint32_t nod = 0;
-	const uint32_t single = find_off_diffs(A, joinedOff >= width ? joinedOff - width : 0, joinedOff + width, od, &nod, overflow);
-	const uint32_t max_od = (A.maxAltsTried / 4) > 4 ? (A.maxAltsTried / 4) : 4;
-	if(nod - single > max_od) nod = single + max_od;
-	bool found2 = false;
-	for(uint32_t o = 0; o < nod && !found2; o++) {
-		if(od[o].second >= 0) { gh->joinedOff = joinedOff + od[o].first; gh->toff = toff + od[o].first; }
-		else { if(toff < od[o].first) continue; gh->joinedOff = joinedOff - od[o].first; gh->toff = toff - od[o].first; }
-		gh->nedits = 0;
-		const uint32_t alignedLen = align_with_alts(ref, A, seq, gh->joinedOff, gh->rdoff, gh->rdoff, gh->len, gh->tidx, (int)gh->toff, gh->len + 10,
-		                                            false, gh, 0, nullptr, W, true);
-		if(gh->overflow) *overflow = 1;
-		if(alignedLen == gh->len) {
-			found2 = true;
-			for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], gh)) found2 = false;
-			if(found2) {
-				for(uint32_t e = 0; e < W->ncand; e++) {
-					if(*nhits >= cap) { *overflow = 1; break; }
-					h2g_ghit* c = &hits[*nhits];
-					const h2g_ghit* prev = &hits[*nhits - 1];
-					c->read = prev->read; c->fw = prev->fw; c->rdoff = prev->rdoff; c->len = prev->len; c->trim5 = prev->trim5; c->trim3 = prev->trim3;
-					c->tidx = prev->tidx; c->toff = prev->toff; c->joinedOff = prev->joinedOff; c->score = prev->score; c->overflow = 0;
-					c->nedits = W->cand_n[e];
-					for(uint32_t q = 0; q < c->nedits; q++) c->edits[q] = W->cand[e][q];
-					(*nhits)++;
-					for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], c)) { (*nhits)--; break; }
-				}
-			}
-		} else gh->nedits = 0;
+	if(g.linear) {
+		if(*nhits >= cap) { *overflow = 1; return false; }
+		h2g_ghit* gh = &hits[*nhits];
+		gh->read = 1;   // _hitcount
+		gh->fw = seq.fw; gh->rdoff = rdoff; gh->len = len; gh->trim5 = 0; gh->trim3 = 0; gh->tidx = tidx; gh->toff = toff0; gh->joinedOff = joinedOff0;
+		gh->score = 0; gh->nedits = 0; gh->overflow = 0; gh->splicescore = 0;
+		(*nhits)++;
+		return true;
 	}
-	if(!found2) (*nhits)--;
+	const uint32_t width = 1u << (g.offRate + 2);
+	OffDiff so[H2G_OFFDIFF_CAP];
+	const uint32_t nso = find_ss_offs(g, A, joinedOff0 >= width ? joinedOff0 - width : 0, joinedOff0 + width, so, overflow);
+	for(uint32_t si = 0; si < nso; si++) {
+		uint32_t toff = toff0, joinedOff = joinedOff0;
+		if(so[si].first > 0) {
+			if(so[si].second > 0) { toff += so[si].first; joinedOff += so[si].first; }
+			else { toff -= so[si].first; joinedOff -= so[si].first; }
+		}
+		if(*nhits >= cap) { *overflow = 1; break; }
+		h2g_ghit* gh = &hits[*nhits];
+		gh->read = 1;   // _hitcount
+		gh->fw = seq.fw; gh->rdoff = rdoff; gh->len = len; gh->trim5 = 0; gh->trim3 = 0; gh->tidx = tidx; gh->toff = toff; gh->joinedOff = joinedOff;
+		gh->score = 0; gh->nedits = 0; gh->overflow = 0; gh->splicescore = 0;
+		(*nhits)++;
+		OffDiff od[H2G_OFFDIFF_CAP];
+		uint32_t nod = 0;
+		const uint32_t single = find_off_diffs(A, joinedOff >= width ? joinedOff - width : 0, joinedOff + width, od, &nod, overflow);
+		const uint32_t max_od = (A.maxAltsTried / 4) > 4 ? (A.maxAltsTried / 4) : 4;
+		if(nod - single > max_od) nod = single + max_od;
+		bool found2 = false;
+		for(uint32_t o = 0; o < nod && !found2; o++) {
+			if(od[o].second >= 0) { gh->joinedOff = joinedOff + od[o].first; gh->toff = toff + od[o].first; }
+			else { if(toff < od[o].first) continue; gh->joinedOff = joinedOff - od[o].first; gh->toff = toff - od[o].first; }
+			gh->nedits = 0;
+			const uint32_t alignedLen = align_with_alts(ref, A, seq, gh->joinedOff, gh->rdoff, gh->rdoff, gh->len, gh->tidx, (int)gh->toff, gh->len + 10,
+			                                            false, gh, 0, nullptr, W, true);
+			if(gh->overflow) *overflow = 1;
+			if(alignedLen == gh->len) {
+				found2 = true;
+				for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], gh)) found2 = false;
+				if(found2) {
+					for(uint32_t e = 0; e < W->ncand; e++) {
+						if(*nhits >= cap) { *overflow = 1; break; }
+						h2g_ghit* c = &hits[*nhits];
+						const h2g_ghit* prev = &hits[*nhits - 1];
+						c->read = prev->read; c->fw = prev->fw; c->rdoff = prev->rdoff; c->len = prev->len; c->trim5 = prev->trim5; c->trim3 = prev->trim3;
+						c->tidx = prev->tidx; c->toff = prev->toff; c->joinedOff = prev->joinedOff; c->score = prev->score; c->overflow = 0; c->splicescore = 0;
+						c->nedits = W->cand_n[e];
+						for(uint32_t q = 0; q < c->nedits; q++) c->edits[q] = W->cand[e][q];
+						(*nhits)++;
+						for(uint32_t i = 0; i + 1 < *nhits; i++) if(ghit_equal(&hits[i], c)) { (*nhits)--; break; }
+					}
+				}
+			} else gh->nedits = 0;
+		}
+		if(!found2) {   // genomeHits.pop_back(): the entry this offset opened (candidates are only appended when it was kept)
+			(*nhits)--;
+		}
+	}
 	return *nhits > n0;
 }
 
@@ -1350,6 +1468,9 @@ H2G_HDN bool adjust_with_alt_member(const DGfm& g, const DRef& ref, const DAlts&
 		const uint32_t alignedLen = align_with_alts(ref, A, seq, gh->joinedOff, gh->rdoff, gh->rdoff, gh->len, gh->tidx, (int)gh->toff, gh->len + 10,
 		                                            false, gh, 0, nullptr, W, true);
 		if(gh->overflow) *overflow = 1;
+#if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+		fprintf(stderr, "      adjust(member) off %u/%d joff %u toff %u len %u -> aligned %u nedits %u\n", od[o].first, od[o].second, gh->joinedOff, gh->toff, gh->len, alignedLen, gh->nedits);
+#endif
 		if(alignedLen == gh->len) found = true;
 		else gh->nedits = 0;
 	}

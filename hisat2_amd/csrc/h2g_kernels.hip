@@ -42,6 +42,7 @@ struct h2g_index {
 	DAlts dalts;
 	bool has_local = false;
 	bool has_splice_alts = false;                         // the ALT list holds splice sites / exons (a _tran index)
+	std::vector<h2g_splice_site> alt_sites;               // splice-site ALTs of a --ss index: part of every database (SpliceSiteDB::read(gfm, alts))
 	DSpliceDB dssdb;                                       // h2g_index_set_splice_sites (device arrays; freed and replaced on every call)
 	void* d_ssdb[4] = {nullptr, nullptr, nullptr, nullptr};
 	const float* d_spl[3] = {nullptr, nullptr, nullptr};   // SpliceSiteDB::probscore tables (donor, acceptor halves), uploaded with the index
@@ -161,6 +162,9 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		alt_buckets(reinterpret_cast<const DAlt*>(ix->host.alts.data()), ix->dalts.n, bk);
 		const uint32_t* dbk = nullptr;
 		if(!bk.empty()) { if((s = upload(ix, bk, &dbk))) { h2g_index_free(ix); return s; } ix->dalts.bucket = dbk; ix->dalts.nbucket = (uint32_t)bk.size(); }
+		// a --ss index: its splice-site ALTs are graph edges AND known sites of the database (SpliceSiteDB::read(gfm, alts))
+		splice_sites_of_alts(reinterpret_cast<const uint32_t*>(ix->host.alts.data()), ix->host.alts.size(), sizeof(HostAlt) / 4, g.rstarts.data(), g.nFrag, g.p.len, ix->alt_sites);
+		for(const HostAlt& a : ix->host.alts) if(a.type == 5) ix->dalts.has_splice = 1;
 	}
 	memset(&ix->dls, 0, sizeof ix->dls);
 	if(o.load_local && !ix->host.local.empty()) {
@@ -179,6 +183,7 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		splice_tables(d, a1, a2);
 		if((s = upload(ix, d, &ix->d_spl[0])) || (s = upload(ix, a1, &ix->d_spl[1])) || (s = upload(ix, a2, &ix->d_spl[2]))) { h2g_index_free(ix); return s; }
 	}
+	if(!ix->alt_sites.empty()) { h2g_index* tmp_ = ix; const h2g_status rs_ = h2g_index_set_splice_sites(tmp_, nullptr, 0, 0); if(rs_ != H2G_OK) { h2g_index_free(ix); return rs_; } }
 	*out = ix;
 	return H2G_OK;
 }
@@ -201,9 +206,11 @@ extern "C" h2g_status h2g_index_set_splice_sites(h2g_index* ix, const h2g_splice
 	HIPCHK(hipDeviceSynchronize());
 	for(void*& p : ix->d_ssdb) { if(p) (void)hipFree(p); p = nullptr; }
 	ix->dssdb = DSpliceDB();
-	if(!n) return H2G_OK;
+	std::vector<h2g_splice_site> all(ix->alt_sites);      // the index's own sites first: of equal sites the first is kept
+	if(n) all.insert(all.end(), sites, sites + n);
+	if(all.empty()) return H2G_OK;
 	HostSpliceDB h;
-	build_splice_db(sites, n, ix->host.g.nPat, h);
+	build_splice_db(all.data(), all.size(), ix->host.g.nPat, h);
 	if(h.fw.empty()) return H2G_OK;
 	const void* src[4] = {h.fw.data(), h.bw.data(), h.fw_first.data(), h.bw_first.data()};
 	const size_t bytes[4] = {h.fw.size() * sizeof(DSpliceSite), h.bw.size() * sizeof(DSpliceSite), h.fw_first.size() * 4, h.bw_first.size() * 4};
@@ -1464,8 +1471,6 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		// sites are not shared (--no-temp-splicesite); the shared SpliceSiteDB of the default mode and graph indexes are not built
 		// no_temp_splicesite == 0 (the reference's default) is the CALLER's wave protocol: batches of <= window reads, the junctions of
 		// each batch's output merged into the database (h2g_index_set_splice_sites) before the next one; first_read_id carries the ids
-		// graph indexes: SNP / insertion / deletion ALTs; splice-site and exon ALTs (_tran indexes) are not read by this library
-		if(s->ix->has_splice_alts) { snprintf(g_err, sizeof g_err, "align: spliced alignment on an index with splice-site / exon ALTs (_tran) is not built"); return H2G_ERR_UNSUPPORTED; }
 		if(p->pen_canintronlen_type < 1 || p->pen_canintronlen_type > 4 || p->pen_noncanintronlen_type < 1 || p->pen_noncanintronlen_type > 4 ||
 		   p->min_intronlen < 20 || p->max_intronlen < p->min_intronlen || p->pen_cansplice < 0 || p->pen_noncansplice < 0 ||
 		   p->min_anchor_len < 1 || p->min_anchor_len_noncan < 1) {

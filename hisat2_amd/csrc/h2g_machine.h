@@ -296,7 +296,7 @@ again:
 		if(C.graph && hit.npartial < AL_MAX_PARTIAL) {
 			GraphPNode& pn = C.gsl->pnode[gv.mw_slot][fwi][hit.npartial];
 			pn.node_top = fh.node_top; pn.node_bot = fh.node_bot; pn.ie = C.gsl->ie;
-			if(pn.ie.n > H2G_IEDGE_CAP) ws->overflow |= 512;
+			if(pn.ie.n > H2G_IEDGE_CAP) { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); }
 		}
 		AL_TRACE("  psearch rdi %d fwi %d cur %u -> top %u bot %u len %u type %u cur %u done %u anchor %u\n", rdi, fwi, hit.cur, fh.top, fh.bot, fh.len, fh.hit_type, fh.cur, fh.done, fh.anchorStop);
 		ws->nrank += fh.nrank; ws->nside += fh.nside;
@@ -474,7 +474,7 @@ again:
 		M_GOTO(PC_GAH_SUB_LOOP);
 	}
 	case PC_GAH_FULL_AFTER: {
-		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		if(L.a1 == H2G_MAX) { { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); } L.a1 = 0; }
 		gv.gh_nco = L.a0;
 		ws->nsteps += L.a1;
 		M_GOTO(PC_GAH_HAVE);
@@ -514,7 +514,7 @@ again:
 		M_GOTO(PC_GAH_HAVE);
 	}
 	case PC_GAH_SUB_AFTER: {
-		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		if(L.a1 == H2G_MAX) { { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); } L.a1 = 0; }
 		gv.gh_nco += L.a0;
 		ws->nsteps += L.a1;
 		gv.gh_added++;
@@ -1119,7 +1119,7 @@ again:
 	}
 	case PC_L_GC_AFTER: {
 		Frame& f = FR;
-		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		if(L.a1 == H2G_MAX) { { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); } L.a1 = 0; }
 		ws->nsteps += L.a1;
 		f.ncoords = L.a0;
 		if(f.ncoords > 1) sort_coords(f.coords, f.ncoords);
@@ -1350,7 +1350,7 @@ again:
 	}
 	case PC_R_GC_AFTER: {
 		Frame& f = FR;
-		if(L.a1 == H2G_MAX) { ws->overflow |= 512; L.a1 = 0; }
+		if(L.a1 == H2G_MAX) { { ws->overflow |= 512; AL_TRACE("  cap512 at %s:%d\n", __FILE__, __LINE__); } L.a1 = 0; }
 		ws->nsteps += L.a1;
 		f.ncoords = L.a0;
 		sort_coords(f.coords, f.ncoords);

@@ -38,6 +38,7 @@ struct h2g_sam {
 	bool secondary = false;                               // --secondary: selectByScore keeps lower-scoring alignments too
 	uint32_t smType = 2;                                  // --score-min (MAPQ's scMin), default L,0,-0.2
 	double smConst = 0.0, smCoeff = (double)(-0.2f);
+	std::vector<h2g_splice_site> alt_sites;               // the splice-site ALTs of a --ss index (SpliceSiteDB::read(gfm, alts)): always in the database
 	h2g::HostSpliceDB ssdb;                               // h2g_sam_set_splice_sites: TLEN of concordant pairs leaves known introns out
 	uint32_t ssdb_window = 0;
 	int rna_strandness = 0;                               // --rna-strandness: 0 unknown, 1 F, 2 R, 3 FR, 4 RF (read.h:30)
@@ -556,6 +557,10 @@ extern "C" h2g_status h2g_sam_open(const char* base, h2g_sam** out) {
 	s->reflens.assign(ix.g.plen.begin(), ix.g.plen.end());
 	s->alts = ix.alts;
 	s->altnames = ix.alt_names;
+	if(!ix.alts.empty()) {
+		h2g::splice_sites_of_alts(reinterpret_cast<const uint32_t*>(ix.alts.data()), ix.alts.size(), sizeof(HostAlt) / 4, ix.g.rstarts.data(), ix.g.nFrag, ix.g.p.len, s->alt_sites);
+		if(!s->alt_sites.empty()) h2g::build_splice_db(s->alt_sites.data(), s->alt_sites.size(), (uint32_t)s->refnames.size(), s->ssdb);
+	}
 	*out = s;
 	return H2G_OK;
 }
@@ -675,7 +680,9 @@ extern "C" size_t h2g_sam_read_splice_site_file(const h2g_sam* S, const char* pa
 }
 extern "C" void h2g_sam_set_splice_sites(h2g_sam* S, const h2g_splice_site* sites, size_t n, uint32_t window) {
 	if(!S) return;
-	h2g::build_splice_db(sites, n, (uint32_t)S->refnames.size(), S->ssdb);
+	std::vector<h2g_splice_site> all(S->alt_sites);      // the index's own sites first: of equal sites the first is kept
+	if(n) all.insert(all.end(), sites, sites + n);
+	h2g::build_splice_db(all.data(), all.size(), (uint32_t)S->refnames.size(), S->ssdb);
 	S->ssdb_window = window;
 }
 extern "C" void h2g_sam_set_rna_strandness(h2g_sam* S, int code) { if(S) S->rna_strandness = code; }

@@ -46,4 +46,33 @@ inline void build_splice_db(const h2g_splice_site* sites, size_t n, uint32_t nPa
 	for(const E& e : u) db.bw.push_back(e.s);
 	db.bw_first = db.fw_first;
 }
+// SpliceSiteDB::read(gfm, alts) splice_site.cpp:653-725: the splice-site ALTs of a --ss index enter the database as known sites
+// read from a file (the forward copies only: left < right); joined coordinates become (text, offset), exon flanks = left - 1 / right + 1.
+// `rstarts` = GFM::rstarts() (nFrag triples), `len` = the joined length.
+inline void splice_sites_of_alts(const uint32_t* alts /* {pos, type, len, pad, seq lo, seq hi} x n */, size_t n, size_t stride_words,
+                                 const uint32_t* rstarts, uint32_t nFrag, uint32_t joined_len, std::vector<h2g_splice_site>& out) {
+	for(size_t i = 0; i < n; i++) {
+		const uint32_t* a = alts + i * stride_words;
+		const uint32_t left_j = a[0], type = a[1], right_j = a[2];
+		if(type != 5) continue;                                    // ALT_SPLICESITE (exons only matter under --avoid-pseudogene)
+		if(left_j > right_j) continue;
+		// joinedToTextOff(1, left, ..., rejectStraddle = true)
+		uint32_t top = 0, bot = nFrag, elt = 0xffffffffu, tidx = 0xffffffffu, toff = 0;
+		while(true) {
+			const uint32_t oldelt = elt;
+			elt = top + ((bot - top) >> 1);
+			if(oldelt == elt) break;
+			const uint32_t lower = rstarts[elt * 3], upper = (elt == nFrag - 1) ? joined_len : rstarts[(elt + 1) * 3];
+			if(lower <= left_j) {
+				if(upper > left_j) { if(left_j + 1 <= upper) { tidx = rstarts[elt * 3 + 1]; toff = (left_j - lower) + rstarts[elt * 3 + 2]; } break; }
+				top = elt;
+			} else bot = elt;
+		}
+		if(tidx == 0xffffffffu) continue;
+		h2g_splice_site x;
+		x.tidx = tidx; x.left = toff - 1; x.right = toff + (right_j - left_j) + 1; x.readid = 0;
+		x.dir = (a[4] & 0xff) ? 2 : 3; x.fromfile = 1; x.known = 1; x.pad_ = 0;   // SPL_FW : SPL_RC
+		out.push_back(x);
+	}
+}
 }  // namespace h2g

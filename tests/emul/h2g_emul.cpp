@@ -39,6 +39,7 @@ struct Emu {
 	h2g_align_params params;
 	std::vector<uint8_t> sw;
 	HostSpliceDB hssdb; DSpliceDB dssdb; uint32_t rdid_base = 0;
+	std::vector<h2g_splice_site> alt_sites;
 	DReads reads() const {
 		DReads r;
 		r.codes = codes.data(); r.offs = offs.data(); r.quals = has_quals ? quals.data() : nullptr;
@@ -48,6 +49,8 @@ struct Emu {
 };
 
 extern "C" {
+
+void h2gemu_set_splice_sites(Emu* e, const h2g_splice_site* sites, size_t n, uint32_t window);
 
 int h2gemu_load(const char* base, Emu** out) {
 	Emu* e = new Emu();
@@ -69,10 +72,15 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dr.nrefs = r.nrefs;
 	e->dalts.a = reinterpret_cast<const DAlt*>(e->host.alts.data()); e->dalts.n = g.p.linear ? 0 : (uint32_t)e->host.alts.size();
 	e->dalts.maxAltsTried = 16;
+	if(!g.p.linear) {
+		splice_sites_of_alts(reinterpret_cast<const uint32_t*>(e->host.alts.data()), e->host.alts.size(), sizeof(HostAlt) / 4, g.rstarts.data(), g.nFrag, g.p.len, e->alt_sites);
+		for(const HostAlt& a : e->host.alts) if(a.type == 5) e->dalts.has_splice = 1;
+	}
 	alt_buckets(e->dalts.a, e->dalts.n, e->alt_bk);
 	if(!e->alt_bk.empty()) { e->dalts.bucket = e->alt_bk.data(); e->dalts.nbucket = (uint32_t)e->alt_bk.size(); }
 	pack_local(e->host, e->lp);
 	e->dls = e->lp.view(e->lp.desc.data(), e->lp.sides.data(), e->lp.words.data(), e->lp.first.data(), e->lp.zoffs.data());
+	if(!e->alt_sites.empty()) h2gemu_set_splice_sites(e, nullptr, 0, 0);   // a --ss index: its splice sites are known sites of the database
 	*out = e;
 	return 0;
 }
@@ -262,7 +270,9 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 
 void h2gemu_set_rdid_base(Emu* e, uint32_t base) { e->rdid_base = base; }
 void h2gemu_set_splice_sites(Emu* e, const h2g_splice_site* sites, size_t n, uint32_t window) {
-	build_splice_db(sites, n, e->host.g.nPat, e->hssdb);
+	std::vector<h2g_splice_site> all(e->alt_sites);
+	if(n) all.insert(all.end(), sites, sites + n);
+	build_splice_db(all.data(), all.size(), e->host.g.nPat, e->hssdb);
 	e->dssdb = DSpliceDB();
 	if(e->hssdb.fw.empty()) return;
 	e->dssdb.fw = e->hssdb.fw.data(); e->dssdb.bw = e->hssdb.bw.data();

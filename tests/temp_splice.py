@@ -80,7 +80,10 @@ def run_case(seed, nreads, P=2, sub=0.005, show=6):
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
     snps = int(os.environ.get("H2G_FUZZ_SNPS", "0"))      # > 0: SNP-graph index (reads stay on the reference haplotype)
-    if snps:
+    if os.environ.get("H2G_FUZZ_TRAN"):                   # --ss / --exon index over every third planted intron (+ SNPs)
+        import fuzz_tran
+        fuzz_tran.build(tmp, contigs, introns, seed, snps, every=3)
+    elif snps:
         synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=snps))
         subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     else:

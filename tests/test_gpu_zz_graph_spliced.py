@@ -92,3 +92,17 @@ def test_dta_and_stranded_library_command_line(tmp_path):
     synth.write_reads_fasta(f2, m2)
     opts = ["--no-temp-splicesite", "--dta-cufflinks", "--rna-strandness", "RF"]
     _compare(tmp, base, ["-1", f1, "-2", f2], ["-p", "1"] + opts, ["-p", "4"] + opts)
+
+
+@needs_ref
+def test_splice_site_alt_index_command_line(tmp_path):
+    """a --ss / --exon / --snp index (the shape of genome_snp_tran) in the reference's default mode at -p 3"""
+    import fuzz_spliced as F
+    import fuzz_tran as T
+    tmp = str(tmp_path)
+    contigs, reads, introns = F.make_case(1051, 12000, sub=0.01)
+    base = T.build(tmp, contigs, introns, 1051, snps=200)
+    rfa = os.path.join(tmp, "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    want = _compare(tmp, base, ["-U", rfa], ["-p", "3", "--reorder"], ["-p", "3"])
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > 3000

@@ -251,3 +251,23 @@ def test_spliced_pairs_stranded_library(seed, extra):
     import fuzz_spliced_pairs as F
     bad, _ = F.run_case(seed, 1200, sub=0.01, show=3, extra=extra)
     assert bad == 0
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,snps", [(1231, 0), (1232, 150)])
+def test_splice_site_alt_index_lines_identical(seed, snps):
+    """--ss / --exon indexes (the reference's _tran indexes, here with and without --snp): splice sites are graph edges the FM search
+    and the ALT-aware extension run through (alignWithALTs_recur hi_aligner.h:3083 / :3425, findSSOffs :2482) and known sites of
+    the database (SpliceSiteDB::read(gfm, alts)); local indexes without a variant stay linear inside the graph index"""
+    import fuzz_tran as T
+    bad, _ = T.run_case(seed, 2000, 0.01, snps, verbose=3, lines=True)
+    assert bad == 0
+
+
+@needs_ref
+def test_splice_site_alt_index_pairs_and_waves(monkeypatch):
+    import fuzz_tran as T
+    import temp_splice as W
+    assert T.run_pairs(1233, 1000, 0.01, 200, show=3)[0] == 0
+    monkeypatch.setenv("H2G_FUZZ_TRAN", "1")
+    assert W.run_case(1234, 4500, P=2, show=3)[0] == 0
