@@ -996,6 +996,10 @@ __device__ __forceinline__ void ext_search_item(const DGfm& g, const DLocalSet& 
 		LIdx lx; lx.ls = &ls; lx.d = &ls.desc[qq.lidx]; lx.sbase = sbase; lx.fbase = fbase;
 		if(lx.d->len == 0) nelt = 0;
 		else if(!GRAPH) nelt = gfm_search(lx, sv, qq.rdoff, &hitlen, &top, &bot, &us, minK_local, qq.maxHitLen, kseeds, true, nr);
+		else if(local_is_linear(*lx.d)) {   // a local index without a variant is linear inside a graph index (128 B sides): h2g_align.h LIdxW
+			LIdxW lw; lw.ls = &ls; lw.d = lx.d;
+			nelt = gfm_search(lw, sv, qq.rdoff, &hitlen, &top, &bot, &us, minK_local, qq.maxHitLen, kseeds, true, nr);
+		}
 		else { const LGfm x = lgfm_of(ls, *lx.d); GRange r; r.top = top; r.bot = bot; r.node_top = r.node_bot = 0; IEdges ie;
 		       nelt = gfm_search_graph(x, lx, sv, qq.rdoff, &hitlen, &r, &ie, &us, minK_local, qq.maxHitLen, kseeds, true, kseeds, nr); top = r.top; bot = r.bot; }
 	}
