@@ -270,7 +270,10 @@ def main():
             shutil.rmtree(tmp, ignore_errors=True)
         st.close()
         if not a.no_extras:
-            out.update(extras(a, api, synth, ix, local, cache))
+            try:                                   # the extra legs never cost the headline its line
+                out.update(extras(a, api, synth, ix, local, cache))
+            except Exception as e:             # noqa: BLE001
+                out["extras_error"] = repr(e)[:400]
         print(json.dumps(out))
     else:
         st.close()

@@ -20,7 +20,7 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt_fn=None):
+def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt_fn=None, indel=0.0):
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, size=glen, dtype=np.uint8)
     # plant introns: [a, b) with GT at a and AG at b-2 (canonical); a few GC..AG / AT..AC / random (non-canonical)
@@ -52,6 +52,12 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt
             r = np.concatenate([g[a - left:a], g[b:b + rdlen - left]])
         m = rng.random(rdlen) < sub
         r = np.where(m, (r + rng.integers(1, 4, size=rdlen)) & 3, r).astype(np.uint8)
+        if indel > 0 and rng.random() < indel * rdlen:          # one short insertion or deletion somewhere in the read
+            at, k = int(rng.integers(5, rdlen - 5)), int(rng.integers(1, 3))
+            if rng.random() < 0.5:
+                r = np.concatenate([r[:at], rng.integers(0, 4, size=k, dtype=np.uint8), r[at:]])[:rdlen]
+            else:
+                r = np.concatenate([r[:at], r[at + k:], rng.integers(0, 4, size=k, dtype=np.uint8)])[:rdlen]
         if rng.random() < 0.5:
             r = (3 - r[::-1]).astype(np.uint8)
         reads[i] = r
@@ -67,7 +73,7 @@ def known_sites(introns, seed, frac):
     return sites
 
 
-def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=(), known=0.0):
+def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=(), known=0.0, indel=0.0):
     tmp = tempfile.mkdtemp(prefix="h2spl")
     snps = int(os.environ.get("H2G_FUZZ_SNPS", "0"))      # > 0: SNP-graph index with a seeded variant every ~snps bp
     var = []
@@ -75,7 +81,7 @@ def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=(), known=0
     def alt(g):                                           # every single-base variant applied (indels stay index-only)
         var.extend(synth.make_snps([g], seed + 5, every=snps))
         return synth.apply_snps([g], [v for v in var if v[1] == "single"])[0]
-    contigs, reads, introns = make_case(seed, nreads, sub=sub, alt_fn=alt if snps else None)
+    contigs, reads, introns = make_case(seed, nreads, sub=sub, alt_fn=alt if snps else None, indel=indel)
     sites = None
     if known > 0:
         sites = known_sites(introns, seed, known)
