@@ -149,7 +149,7 @@ class AlnRes(C.Structure):
 
 
 class SpliceSite(C.Structure):
-    _fields_ = [("tidx", u32), ("left", u32), ("right", u32), ("readid", u32), ("dir", u8), ("fromfile", u8), ("known", u8), ("pad_", u8)]
+    _fields_ = [("tidx", u32), ("left", u32), ("right", u32), ("readid", u32), ("dir", u8), ("fromfile", u8), ("known", u8), ("editdist", u8)]
 
 
 def splice_site_array(sites, known=True):
@@ -237,8 +237,10 @@ class AlignParams(C.Structure):
                 if o == "--dta-cufflinks":
                     self.xs_only = 1
                 i += 1
-            elif o == "--rna-strandness":   # output only (XS:A): h2g_sam_set_rna_strandness
+            elif o in ("--rna-strandness", "--novel-splicesite-outfile"):   # output only: h2g_sam_set_rna_strandness / h2g_sam_novel_splice_sites_text
                 i += 2
+            elif o == "--no-templatelen-adjustment":                       # output only (TLEN): h2g_sam_set_templatelen_adjustment
+                i += 1
             elif o == "--min-intronlen":
                 self.min_intronlen = int(v); i += 2
             elif o == "--max-intronlen":

@@ -216,7 +216,8 @@ int main(int argc, char** argv) {
 	std::string base, outfn, stats_fn;
 	std::vector<std::string> u, m1, m2;
 	bool fasta = false, nospliced = false, notempss = false, nohead = false, parse_only = false, no_unal = false;
-	std::string known_ss, novel_ss;
+	std::string known_ss, novel_ss, novel_out;
+	bool tlen_adjust = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
 	uint64_t skip = 0, upto = ~0ull;
@@ -251,6 +252,8 @@ int main(int argc, char** argv) {
 		}
 		else if(a == "--known-splicesite-infile") known_ss = need("--known-splicesite-infile");
 		else if(a == "--novel-splicesite-infile") novel_ss = need("--novel-splicesite-infile");
+		else if(a == "--novel-splicesite-outfile") novel_out = need("--novel-splicesite-outfile");
+		else if(a == "--no-templatelen-adjustment") tlen_adjust = false;
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
 		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min" ||
 		        a == "--min-intronlen" || a == "--max-intronlen" || a == "--pen-cansplice" || a == "--pen-noncansplice" ||
@@ -426,7 +429,15 @@ int main(int argc, char** argv) {
 		}
 		publish_sites();
 	}
-	if(temp_ss) h2g_sam_collect_novel_sites(sam, 1);
+	if(!temp_ss && !nospliced && !novel_out.empty() && h2g_sam_novel_splice_sites_text(sam, nullptr, 0) > 0) {
+		// write (the outfile) + read (a file's or the index's sites) without the temporary-site window: the reference then lets every read see
+		// the junctions of whichever reads its threads happened to finish first (window 0, hisat2.cpp:3687, :4092-4093) — not a function of the input
+		fprintf(stderr, "hisat2-align-amd: --novel-splicesite-outfile with --no-temp-splicesite and a splice-site database (file or --ss index) "
+		        "makes the reference's output depend on thread timing; drop --no-temp-splicesite (output == hisat2 -p <int> --reorder)\n");
+		return 1;
+	}
+	if(temp_ss || (!nospliced && !novel_out.empty())) h2g_sam_collect_novel_sites(sam, 1);   // SpliceSiteDB's `write` (hisat2.cpp:4092)
+	h2g_sam_set_templatelen_adjustment(sam, tlen_adjust);
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);
 	h2g_sam_set_rna_strandness(sam, strandness);
@@ -520,13 +531,13 @@ int main(int argc, char** argv) {
 			t_fmt += now() - tf;
 		}
 		fwrite(buf.data(), 1, used, out);
-		if(temp_ss) {   // the junctions of the lines just written join the database (SpliceSiteDB::addSpliceSite: smallest read id per site)
+		if(temp_ss || !novel_out.empty()) {   // the junctions of the lines just written join the database (SpliceSiteDB::addSpliceSite: smallest read id per site)
 			static std::vector<h2g_splice_site> novel;
 			const size_t k = h2g_sam_take_novel_sites(sam, nullptr, 0);
 			novel.resize(k);
 			if(k) h2g_sam_take_novel_sites(sam, novel.data(), k);
 			bool changed = false;
-			for(const h2g_splice_site& x : novel) {
+			if(temp_ss) for(const h2g_splice_site& x : novel) {
 				const std::array<uint32_t, 4> key = {x.tidx, x.left, x.right, (uint32_t)x.dir};
 				auto it = site_at.find(key);
 				if(it == site_at.end()) { site_at.emplace(key, sites.size()); sites.push_back(x); changed = true; }
@@ -589,6 +600,16 @@ int main(int argc, char** argv) {
 		}
 	}
 	if(out != stdout) fclose(out);
+	if(!novel_out.empty()) {                              // hisat2.cpp:4189-4197
+		FILE* nf = fopen(novel_out.c_str(), "w");
+		if(nf) {
+			const size_t need = h2g_sam_novel_splice_sites_text(sam, nullptr, 0);
+			std::vector<char> tb(need + 1);
+			h2g_sam_novel_splice_sites_text(sam, tb.data(), need);
+			fwrite(tb.data(), 1, need, nf);
+			fclose(nf);
+		}
+	}
 	const double t2 = now();
 	{   // the reference's alignment summary (aln_sink.h:1637), same text
 		const size_t need = h2g_sam_summary(sam, nullptr, 0);

@@ -8,6 +8,8 @@
 #include <math.h>
 #include <string>
 #include <vector>
+#include <map>
+#include <array>
 #include <algorithm>
 #include <thread>
 #include "../../include/h2g_sam.h"
@@ -43,6 +45,20 @@ struct h2g_sam {
 	uint32_t ssdb_window = 0;
 	int rna_strandness = 0;                               // --rna-strandness: 0 unknown, 1 F, 2 R, 3 FR, 4 RF (read.h:30)
 	bool collect_novel = false;                           // h2g_sam_collect_novel_sites
+	bool tlen_adjust = true;                              // --no-templatelen-adjustment clears it (aln_sink.h:2070-2076)
+	// what SpliceSiteDB keeps per site for --novel-splicesite-outfile (splice_site.cpp:243-276): the number of lines written across it
+	// and the smallest edit distance among them; file / index sites enter with 0 / 0 (SpliceSite::init splice_site.h:237)
+	struct SiteStat { uint64_t numreads = 0; uint32_t editdist = 0; };
+	mutable std::map<std::array<uint32_t, 4>, SiteStat> site_stats;   // (text, left, right, dir), the order SpliceSitePos sorts in
+	void count_sites(const std::vector<h2g_splice_site>& v) const {
+		for(const h2g_splice_site& x : v) {
+			auto r = site_stats.emplace(std::array<uint32_t, 4>{x.tidx, x.left, x.right, (uint32_t)x.dir}, SiteStat{1, x.editdist});
+			if(!r.second) { r.first->second.numreads++; if(x.editdist < r.first->second.editdist) r.first->second.editdist = x.editdist; }
+		}
+	}
+	void register_sites(const h2g_splice_site* v, size_t n) const {       // SpliceSiteDB::read: from the index or a file
+		for(size_t i = 0; i < n; i++) if(v[i].fromfile) site_stats.emplace(std::array<uint32_t, 4>{v[i].tidx, v[i].left, v[i].right, (uint32_t)v[i].dir}, SiteStat{0, 0});
+	}
 	uint64_t first_read_id = 0;                           // Read::rdid of read 0 of the next format call
 };
 
@@ -324,6 +340,8 @@ void add_splice_sites(const h2g_alnres& r, uint32_t rdlen, uint64_t rdid, std::v
 	if(!r.fw) { invert(ed, rdlen); std::reverse(dirs.begin(), dirs.end()); }
 	const uint32_t minAnchorLen = 15, SPL_UNKNOWN = 1;
 	auto is_mm_gap = [](const Ed& e) { return e.type == EDIT_MM || e.type == EDIT_READ_GAP || e.type == EDIT_REF_GAP; };
+	uint32_t editdist = 0;
+	for(const Ed& e : ed) editdist += is_mm_gap(e);
 	uint32_t refoff = r.toff, leftAnchor = 0, rightAnchor = 0, mm = 0;
 	size_t eidx = 0, last = 0;
 	bool inited = false;
@@ -346,7 +364,7 @@ void add_splice_sites(const h2g_alnres& r, uint32_t rdlen, uint64_t rdid, std::v
 					leftAnchor = rightAnchor; rightAnchor = 0;
 				} else leftAnchor = ed[eidx].pos;
 				ssp.tidx = r.tidx; ssp.left = refoff - 1; ssp.right = refoff + ed[eidx].skip; ssp.dir = (uint8_t)dirs[eidx];
-				ssp.readid = (uint32_t)rdid; ssp.fromfile = 0; ssp.known = 0; ssp.pad_ = 0;
+				ssp.readid = (uint32_t)rdid; ssp.fromfile = 0; ssp.known = 0; ssp.editdist = (uint8_t)std::min(editdist, 255u);
 				inited = true;
 				refoff += ed[eidx].skip;
 				last = eidx;
@@ -407,7 +425,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	else o.push_back('0');
 	o.push_back('\t');
 	// ISIZE: setMateParams computes it when the opposite mate is known and on the same reference (or concordant)
-	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1(), fl.concordant() ? &S : nullptr, tl_rdid));
+	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1(), fl.concordant() && S.tlen_adjust ? &S : nullptr, tl_rdid));
 	else o.push_back('0');
 	o.push_back('\t');
 	o += seq; o.push_back('\t');
@@ -559,6 +577,7 @@ extern "C" h2g_status h2g_sam_open(const char* base, h2g_sam** out) {
 	s->altnames = ix.alt_names;
 	if(!ix.alts.empty()) {
 		h2g::splice_sites_of_alts(reinterpret_cast<const uint32_t*>(ix.alts.data()), ix.alts.size(), sizeof(HostAlt) / 4, ix.g.rstarts.data(), ix.g.nFrag, ix.g.p.len, s->alt_sites);
+		s->register_sites(s->alt_sites.data(), s->alt_sites.size());
 		if(!s->alt_sites.empty()) h2g::build_splice_db(s->alt_sites.data(), s->alt_sites.size(), (uint32_t)s->refnames.size(), s->ssdb);
 	}
 	*out = s;
@@ -604,7 +623,7 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 	for(auto& p : parts) total += p.size();
 	*used = total;
 	if(total > cap || !out) return total <= cap && total == 0 ? H2G_OK : H2G_ERR_ARG;
-	for(auto& m : mets) S->met.add(m);                    // only a call that delivered its text counts
+	for(auto& m : mets) { S->count_sites(m.novel); S->met.add(m); }   // only a call that delivered its text counts
 	size_t off = 0;
 	for(auto& p : parts) { memcpy(out + off, p.data(), p.size()); off += p.size(); }
 	return H2G_OK;
@@ -672,7 +691,7 @@ extern "C" size_t h2g_sam_read_splice_site_file(const h2g_sam* S, const char* pa
 		if(n < cap && out) {
 			h2g_splice_site& x = out[n];
 			x.tidx = ref; x.left = (uint32_t)strtoul(l.c_str(), nullptr, 10); x.right = (uint32_t)strtoul(r.c_str(), nullptr, 10); x.readid = 0;
-			x.dir = d[0] == '+' ? 2 : 3; x.fromfile = 1; x.known = known ? 1 : 0; x.pad_ = 0;    // SPL_FW : SPL_RC
+			x.dir = d[0] == '+' ? 2 : 3; x.fromfile = 1; x.known = known ? 1 : 0; x.editdist = 0;    // SPL_FW : SPL_RC
 		}
 		n++;
 	}
@@ -684,8 +703,10 @@ extern "C" void h2g_sam_set_splice_sites(h2g_sam* S, const h2g_splice_site* site
 	if(n) all.insert(all.end(), sites, sites + n);
 	h2g::build_splice_db(all.data(), all.size(), (uint32_t)S->refnames.size(), S->ssdb);
 	S->ssdb_window = window;
+	S->register_sites(sites, n);
 }
 extern "C" void h2g_sam_set_rna_strandness(h2g_sam* S, int code) { if(S) S->rna_strandness = code; }
+extern "C" void h2g_sam_set_templatelen_adjustment(h2g_sam* S, int on) { if(S) S->tlen_adjust = on != 0; }
 extern "C" void h2g_sam_collect_novel_sites(h2g_sam* S, int on) { if(S) S->collect_novel = on != 0; }
 extern "C" void h2g_sam_set_first_read_id(h2g_sam* S, uint64_t id) { if(S) S->first_read_id = id; }
 extern "C" size_t h2g_sam_take_novel_sites(h2g_sam* S, h2g_splice_site* out, size_t cap) {
@@ -695,6 +716,49 @@ extern "C" size_t h2g_sam_take_novel_sites(h2g_sam* S, h2g_splice_site* out, siz
 	memcpy(out, S->met.novel.data(), n * sizeof(h2g_splice_site));
 	S->met.novel.clear();
 	return n;
+}
+// SpliceSiteDB::print splice_site.cpp:565-653 (--novel-splicesite-outfile, hisat2.cpp:4189-4197): the sites in SpliceSitePos order;
+// one is listed when enough lines crossed it — the 70 % point of the sites' read-count distribution — or, with no edits, 1e-5 of the
+// number of sites; of sites whose left ends are < 10 apart and whose shifts agree within 10 the one with more reads survives.
+extern "C" size_t h2g_sam_novel_splice_sites_text(const h2g_sam* S, char* out, size_t cap) {
+	if(!S) return 0;
+	struct Row { uint32_t ref, left, right, dir; uint64_t numreads; };
+	int64_t dist[100] = {0};
+	for(const auto& kv : S->site_stats) dist[kv.second.numreads < 100 ? kv.second.numreads : 99]++;
+	for(int i = 1; i < 100; i++) dist[i] += dist[i - 1];
+	uint32_t cutoff = 0;
+	for(int i = 0; i < 100; i++) { const float cmf = float(dist[i]) / dist[99]; if(cmf > 0.7) { cutoff = (uint32_t)i; break; } }
+	const uint32_t cutoff2 = (uint32_t)(S->site_stats.size() / 100000);
+	std::string o;
+	std::vector<Row> list;                               // sites waiting for a later, better neighbour
+	auto flush = [&](const Row* ss) {                    // print_impl
+		size_t i = 0;
+		while(i < list.size()) {
+			const Row t = list[i];
+			bool do_print = true;
+			if(ss && t.ref == ss->ref && ss->left < t.left + 10) {
+				do_print = false;
+				if(std::abs(((int)ss->left - (int)t.left) - ((int)ss->right - (int)t.right)) <= 10) {
+					if(t.numreads < ss->numreads) { list.erase(list.begin() + (long)i); list.push_back(*ss); }
+					return;
+				}
+			}
+			if(!do_print) { i++; continue; }
+			o += S->refnames[t.ref]; o.push_back('\t');
+			put(o, (int64_t)t.left); o.push_back('\t'); put(o, (int64_t)t.right); o.push_back('\t');
+			o.push_back(t.dir == 2 || t.dir == 4 ? '+' : t.dir == 3 || t.dir == 5 ? '-' : '.');
+			o.push_back('\n');
+			list.erase(list.begin() + (long)i);
+		}
+		if(ss) list.push_back(*ss);
+	};
+	for(const auto& kv : S->site_stats) {
+		const Row r = {kv.first[0], kv.first[1], kv.first[2], kv.first[3], kv.second.numreads};
+		if(r.numreads >= cutoff || (kv.second.editdist == 0 && r.numreads >= cutoff2)) flush(&r);
+	}
+	flush(nullptr);
+	if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
+	return o.size();
 }
 extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, double coeff) { if(S) { S->smType = type; S->smConst = c; S->smCoeff = coeff; } }
 

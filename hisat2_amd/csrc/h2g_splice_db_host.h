@@ -71,7 +71,7 @@ inline void splice_sites_of_alts(const uint32_t* alts /* {pos, type, len, pad, s
 		if(tidx == 0xffffffffu) continue;
 		h2g_splice_site x;
 		x.tidx = tidx; x.left = toff - 1; x.right = toff + (right_j - left_j) + 1; x.readid = 0;
-		x.dir = (a[4] & 0xff) ? 2 : 3; x.fromfile = 1; x.known = 1; x.pad_ = 0;   // SPL_FW : SPL_RC
+		x.dir = (a[4] & 0xff) ? 2 : 3; x.fromfile = 1; x.known = 1; x.editdist = 0;   // SPL_FW : SPL_RC
 		out.push_back(x);
 	}
 }

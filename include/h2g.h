@@ -70,7 +70,7 @@ H2G_EXPORT void       h2g_index_free(h2g_index*);
  * 1365-1496) and the SAM formatter leaves their introns out of TLEN (aligner_result.h:1669-1689).  Replaces the previous set;
  * n == 0 empties the database.  readid / fromfile: a site with fromfile == 0 is one found by read `readid` and is visible only to
  * reads readid + window and later (the reference's -p window, hisat2.cpp:3687). */
-typedef struct { uint32_t tidx, left, right, readid; uint8_t dir /* 2 = '+', 3 = '-' (SPL_FW / SPL_RC) */, fromfile, known, pad_; } h2g_splice_site;
+typedef struct { uint32_t tidx, left, right, readid; uint8_t dir /* 2 = '+', 3 = '-' (SPL_FW / SPL_RC) */, fromfile, known, editdist /* out of h2g_sam_take_novel_sites: mismatches + gaps of the line that crossed the site (<= 255); ignored on input */; } h2g_splice_site;
 H2G_EXPORT h2g_status h2g_index_set_splice_sites(h2g_index*, const h2g_splice_site* sites, size_t n, uint32_t window);
 
 H2G_EXPORT const char* h2g_last_error(void);

@@ -38,8 +38,10 @@ H2G_EXPORT void       h2g_sam_set_secondary(h2g_sam*, int on);
  * records of texts the index holds ((size_t)-1: cannot open), the first `cap` of them in out */
 H2G_EXPORT size_t     h2g_sam_read_splice_site_file(const h2g_sam*, const char* path, int known, h2g_splice_site* out, size_t cap);
 /* the splice sites given to h2g_index_set_splice_sites: TLEN of a concordant pair leaves the longest database intron lying between
- * its mates out (AlnRes::setFragmentLength aligner_result.h:1669-1689, --no-templatelen-adjustment is not built) */
+ * its mates out (AlnRes::setFragmentLength aligner_result.h:1669-1689) */
 H2G_EXPORT void       h2g_sam_set_splice_sites(h2g_sam*, const h2g_splice_site* sites, size_t n, uint32_t window);
+/* --no-templatelen-adjustment (on = 0): setMateParams without the database, TLEN keeps every intron (aln_sink.h:2070-2076) */
+H2G_EXPORT void       h2g_sam_set_templatelen_adjustment(h2g_sam*, int on);
 /* --rna-strandness: 0 unknown (XS:A from the splice directions), 1 F, 2 R, 3 FR, 4 RF (XS:A on every aligned line, sam.h:940-966) */
 H2G_EXPORT void       h2g_sam_set_rna_strandness(h2g_sam*, int code);
 /* Temporary splice sites (the reference's default mode; SpliceSiteDB::addSpliceSite splice_site.cpp:190, called for every line
@@ -50,6 +52,11 @@ H2G_EXPORT void       h2g_sam_set_rna_strandness(h2g_sam*, int code);
 H2G_EXPORT void       h2g_sam_collect_novel_sites(h2g_sam*, int on);
 H2G_EXPORT void       h2g_sam_set_first_read_id(h2g_sam*, uint64_t id);
 H2G_EXPORT size_t     h2g_sam_take_novel_sites(h2g_sam*, h2g_splice_site* out, size_t cap);
+/* --novel-splicesite-outfile (SpliceSiteDB::print splice_site.cpp:565, written at the end of a run hisat2.cpp:4189): the text of the
+ * file over every site this handle has seen — the index's and the files' (h2g_sam_set_splice_sites entries with fromfile) and those
+ * of the lines formatted while collection was on, with the reference's read-count cut-off and its merging of near-identical sites.
+ * Returns bytes needed; writes at most cap. */
+H2G_EXPORT size_t     h2g_sam_novel_splice_sites_text(const h2g_sam*, char* out, size_t cap);
 /* --score-min as given to the aligner (h2g_align_params.score_min_*): MAPQ is relative to it (unique.h:214-222) */
 H2G_EXPORT void       h2g_sam_set_score_min(h2g_sam*, uint32_t type, double constant, double coeff);
 

@@ -78,7 +78,7 @@ def emu_pairs(base, m1, m2, q1, q2, options=(), splice_sites=None):
     return outs, r1, r2
 
 
-def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0):
+def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0, novel_out=False):
     tmp = tempfile.mkdtemp(prefix="h2splpe")
     contigs, m1, m2, introns = make_case(seed, npairs, sub=sub)
     sites, sopt = None, []
@@ -102,7 +102,8 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0):
     synth.write_reads_fasta(f1, m1)
     synth.write_reads_fasta(f2, m2)
     sam = os.path.join(tmp, "ref.sam")
-    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-temp-splicesite", "-x", base, "-1", f1, "-2", f2, "-S", sam] + list(extra) + sopt,
+    nopt = ["--novel-splicesite-outfile", os.path.join(tmp, "ref.ss")] if novel_out else []
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-temp-splicesite", "-x", base, "-1", f1, "-2", f2, "-S", sam] + list(extra) + sopt + nopt,
                    check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
     q = [str(i) for i in range(npairs)]
     outs, r1, r2 = emu_pairs(base, m1, m2, q, q, options=extra, splice_sites=sites)
@@ -116,10 +117,14 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0):
             for k in range(min(outs[i].nres[m], api.PAIR_RES_CAP)):
                 C.memmove(C.byref(dst[i * api.PAIR_RES_CAP + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
     khits = int(extra[extra.index("-k") + 1]) if "-k" in extra else (10 if snps else 5)
-    got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra) + sopt)
+    nopt = ["--novel-splicesite-outfile", os.path.join(tmp, "our.ss")] if novel_out else []
+    got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra) + sopt + nopt)
     want = SL.body_lines(sam)
     from test_sam_lines import diff_lines
     bad = diff_lines(got, want, show=show)
+    if novel_out and open(os.path.join(tmp, "our.ss")).read() != open(os.path.join(tmp, "ref.ss")).read():
+        print("novel-splicesite-outfile differs:", os.path.join(tmp, "our.ss"), os.path.join(tmp, "ref.ss"))
+        bad += 1
     nspl = sum(1 for l in want if "N" in l.split("\t")[5])
     ovf = sum(1 for o in outs if o.overflow)
     print(f"seed {seed} pairs {npairs} sub {sub}: spliced lines(ref) {nspl}  differing lines {bad}  overflow {ovf}  summary {'same' if SL.LAST_SUMMARY == open(os.path.join(tmp, 'ref.err')).read() else 'DIFFERENT'}  tmp {tmp}")

@@ -62,6 +62,23 @@ def _score_min(L, h, options):
         L.h2g_sam_read_splice_site_file(h, fn, 1, a, n)
         L.h2g_sam_set_splice_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
         L.h2g_sam_set_splice_sites(h, a, n, 0)
+    if options and "--novel-splicesite-outfile" in options:
+        L.h2g_sam_collect_novel_sites.argtypes = [C.c_void_p, C.c_int]
+        L.h2g_sam_collect_novel_sites(h, 1)
+    if options and "--no-templatelen-adjustment" in options:
+        L.h2g_sam_set_templatelen_adjustment.argtypes = [C.c_void_p, C.c_int]
+        L.h2g_sam_set_templatelen_adjustment(h, 0)
+
+
+def _novel_out(L, h, options):
+    """--novel-splicesite-outfile <path>: written from the handle's site statistics, as the command line does at the end of a run"""
+    if options and "--novel-splicesite-outfile" in options:
+        L.h2g_sam_novel_splice_sites_text.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.h2g_sam_novel_splice_sites_text.restype = C.c_size_t
+        need = L.h2g_sam_novel_splice_sites_text(h, None, 0)
+        buf = C.create_string_buffer(need + 1)
+        L.h2g_sam_novel_splice_sites_text(h, buf, need)
+        open(options[list(options).index("--novel-splicesite-outfile") + 1], "wb").write(buf.raw[:need])
 
 
 def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):
@@ -86,6 +103,7 @@ def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):
     sb = C.create_string_buffer(4096)
     nsum = L.h2g_sam_summary(h, sb, 4096)
     LAST_SUMMARY = sb.raw[:nsum].decode()
+    _novel_out(L, h, options)
     L.h2g_sam_close(h)
     assert rc == 0, (rc, used.value, cap)
     return buf.raw[:used.value].decode().splitlines()
@@ -110,6 +128,7 @@ def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=()):
     sb = C.create_string_buffer(4096)
     nsum = L.h2g_sam_summary(h, sb, 4096)
     LAST_SUMMARY = sb.raw[:nsum].decode()
+    _novel_out(L, h, options)
     L.h2g_sam_close(h)
     assert rc == 0, (rc, used.value, cap)
     return buf.raw[:used.value].decode().splitlines()

@@ -106,3 +106,29 @@ def test_splice_site_alt_index_command_line(tmp_path):
     synth.write_reads_fasta(rfa, reads)
     want = _compare(tmp, base, ["-U", rfa], ["-p", "3", "--reorder"], ["-p", "3"])
     assert sum(1 for l in want if "N" in l.split("\t")[5]) > 3000
+
+
+@needs_ref
+def test_novel_splicesite_outfile_and_templatelen_command_line(tmp_path):
+    """pairs on a linear index in the default mode with a splice-site file: --novel-splicesite-outfile (SpliceSiteDB::print: read
+    counts per site, the 70 % cut-off, near-identical sites merged) equals the reference's file, and --no-templatelen-adjustment
+    (TLEN keeps the database introns between the mates) equals its lines"""
+    import fuzz_spliced as FS
+    import fuzz_spliced_pairs as F
+    tmp = str(tmp_path)
+    contigs, m1, m2, introns = F.make_case(1061, 9000, sub=0.01)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f1, f2, ss = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa"), os.path.join(tmp, "ss.txt")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    with open(ss, "w") as f:
+        for _, l, r, d in FS.known_sites(introns, 1061, 0.5):
+            f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
+    common = ["--known-splicesite-infile", ss, "--no-templatelen-adjustment", "--novel-splicesite-outfile"]
+    want = _compare(tmp, base, ["-1", f1, "-2", f2], ["-p", "3", "--reorder"] + common + [os.path.join(tmp, "ref.ss")], ["-p", "3"] + common + [os.path.join(tmp, "amd.ss")])
+    assert sum(1 for l in want if "N" in l.split("\t")[5]) > 2000
+    got_ss = open(os.path.join(tmp, "amd.ss")).read()
+    assert got_ss == open(os.path.join(tmp, "ref.ss")).read() and got_ss.count("\n") > 50

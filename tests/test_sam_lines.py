@@ -192,6 +192,35 @@ def test_temporary_splice_sites_wave_scheme():
 
 
 @needs_ref
+def test_temporary_splice_sites_with_known_file_and_outfile():
+    """default mode + --known-splicesite-infile: the file's sites stay visible to every read and are never replaced by a read's;
+    --novel-splicesite-outfile (SpliceSiteDB::print splice_site.cpp:565: per-site read counts, the 70 % cut-off, the merging of
+    near-identical sites) == the reference's file (temp_splice.run_case compares it in every case)"""
+    import temp_splice as T
+    bad, tmp = T.run_case(821, 5000, P=2, show=3, known=0.5)
+    assert bad == 0
+    assert sum(1 for _ in open(os.path.join(tmp, "ref.ss"))) > 50
+
+
+@needs_ref
+def test_novel_splicesite_outfile_pairs_no_database():
+    """--no-temp-splicesite --novel-splicesite-outfile without any database: the sites are written but never read (hisat2.cpp:4092);
+    both mates' lines count"""
+    import fuzz_spliced_pairs as F
+    bad, tmp = F.run_case(712, 1500, sub=0.01, show=3, novel_out=True)
+    assert bad == 0
+    assert sum(1 for _ in open(os.path.join(tmp, "ref.ss"))) > 50
+
+
+@needs_ref
+def test_no_templatelen_adjustment_pairs():
+    """--no-templatelen-adjustment: setMateParams without the database (aln_sink.h:2070-2076), TLEN keeps the introns between mates"""
+    import fuzz_spliced_pairs as F
+    bad, tmp = F.run_case(713, 1500, sub=0.01, show=3, known=0.8, extra=("--no-templatelen-adjustment",))
+    assert bad == 0
+
+
+@needs_ref
 def test_golden_spliced_default_mode_p1(tmp_path):
     """tests/golden/ref_se_spliced.sam.gz = `hisat2-align-s -p 1` in its default mode on the golden reads: at -p 1 the window is 0,
     every read sees the junctions of all reads before it, i.e. waves of ONE read (what only a test can afford)"""
