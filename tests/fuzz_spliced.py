@@ -20,8 +20,46 @@ from hisat2_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
+def rich():
+    """H2G_FUZZ_RICH: three contigs (the planted genes on the second), N runs, duplicated genes, processed pseudogenes"""
+    return bool(os.environ.get("H2G_FUZZ_RICH"))
+
+
+
+def contig_names(contigs):
+    """the contig with the planted introns is always called chr1 (the site files name it); RICH puts it second"""
+    return ["lead", "chr1", "tail"] if len(contigs) == 3 else None
+
+
+def enrich(g, introns, rng):
+    """RICH: N runs inside some exons, copies of whole genes (exon-intron-exon) on a leading contig, processed pseudogenes
+    (exon-exon, the intron removed) on a trailing one — spliced and contiguous placements compete for the same reads"""
+    g = g.copy()
+    for k in range(5, len(introns) - 1, 9):                 # 30 Ns in the middle of a long exon
+        e0, e1 = introns[k][1], introns[k + 1][0]
+        if e1 - e0 > 400:
+            m = (e0 + e1) // 2
+            g[m:m + 30] = 4
+    lead = [rng.integers(0, 4, size=3000, dtype=np.uint8)]
+    tail = [rng.integers(0, 4, size=3000, dtype=np.uint8)]
+    for k in range(2, len(introns) - 1, 5):
+        a, b = introns[k]
+        if b - a <= 1200 and k % 2 == 0:
+            lead += [g[a - 150:b + 150].copy(), rng.integers(0, 4, size=500, dtype=np.uint8)]
+        else:
+            tail += [g[a - 120:a].copy(), g[b:b + 120].copy(), rng.integers(0, 4, size=500, dtype=np.uint8)]
+    lead.insert(len(lead) // 2, np.full(200, 4, dtype=np.uint8))         # an N gap: two fragments in one contig
+    return [np.concatenate(lead), g, np.concatenate(tail)]
+
+
+def revcomp(r):
+    return np.where(r > 3, 4, 3 - r)[::-1].astype(np.uint8)
+
+
 def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt_fn=None, indel=0.0):
-    rng = np.random.default_rng(seed)
+    rdlen = int(os.environ.get("H2G_FUZZ_RDLEN", rdlen))
+    multi = float(os.environ.get("H2G_FUZZ_MULTI", "0"))   # > 0: that fraction of the exons is 20..90 bp long and the reads are drawn from
+    rng = np.random.default_rng(seed)                      # the spliced transcript, so one read crosses two or three junctions
     g = rng.integers(0, 4, size=glen, dtype=np.uint8)
     # plant introns: [a, b) with GT at a and AG at b-2 (canonical); a few GC..AG / AT..AC / random (non-canonical)
     introns = []
@@ -37,12 +75,34 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt
         elif kind == 8:
             g[a:a + 2] = [0, 3]; g[b - 2:b] = [0, 1]
         introns.append((a, b))
-        pos = b + int(rng.integers(150, 900))
+        pos = b + (int(rng.integers(20, 90)) if multi > 0 and rng.random() < multi else int(rng.integers(150, 900)))
+    extra = None
+    if rich():
+        extra = enrich(g, introns, rng)
+        g = extra[1]
     ref_g = g
     if alt_fn is not None:
         g = alt_fn(ref_g)                          # reads come from an alternate haplotype of the same length
     reads = np.zeros((nreads, rdlen), dtype=np.uint8)
+    if multi > 0:                                            # transcript = the genome with every planted intron spliced out
+        keep = np.ones(glen, dtype=bool)
+        for a, b in introns:
+            keep[a:b] = False
     for i in range(nreads):
+        if multi > 0 and alt_fn is None:
+            if rng.random() < 0.15:
+                s = int(rng.integers(1000, introns[-1][1]))
+                r = g[s:s + rdlen].copy()
+            else:
+                k = int(rng.integers(0, len(introns)))
+                s = introns[k][0] - int(rng.integers(1, rdlen))
+                r = g[s:s + 60000][keep[s:s + 60000]][:rdlen].copy()
+            m = rng.random(rdlen) < sub
+            r = np.where(m & (r < 4), (r + rng.integers(1, 4, size=rdlen)) & 3, r).astype(np.uint8)
+            if rng.random() < 0.5:
+                r = revcomp(r)
+            reads[i] = r
+            continue
         a, b = introns[int(rng.integers(0, len(introns)))]
         left = int(rng.integers(8, rdlen - 8)) if rng.random() < 0.8 else int(rng.integers(1, rdlen))   # bases before the intron
         if rng.random() < 0.15:                      # unspliced read nearby
@@ -51,7 +111,7 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt
         else:
             r = np.concatenate([g[a - left:a], g[b:b + rdlen - left]])
         m = rng.random(rdlen) < sub
-        r = np.where(m, (r + rng.integers(1, 4, size=rdlen)) & 3, r).astype(np.uint8)
+        r = np.where(m & (r < 4), (r + rng.integers(1, 4, size=rdlen)) & 3, r).astype(np.uint8)
         if indel > 0 and rng.random() < indel * rdlen:          # one short insertion or deletion somewhere in the read
             at, k = int(rng.integers(5, rdlen - 5)), int(rng.integers(1, 3))
             if rng.random() < 0.5:
@@ -59,17 +119,17 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, glen=400000, nintrons=400, alt
             else:
                 r = np.concatenate([r[:at], r[at + k:], rng.integers(0, 4, size=k, dtype=np.uint8)])[:rdlen]
         if rng.random() < 0.5:
-            r = (3 - r[::-1]).astype(np.uint8)
+            r = revcomp(r)
         reads[i] = r
-    return [ref_g], reads, introns
+    return ([extra[0], ref_g, extra[2]] if extra else [ref_g]), reads, introns
 
 
 def known_sites(introns, seed, frac):
     """a --known-splicesite-infile for a fraction of the planted introns plus some sites that do not exist in the reads"""
     rng = np.random.default_rng(seed + 77)
-    sites = [(0, a - 1, b, "+") for a, b in introns if rng.random() < frac]
+    sites = [(int(rich()), a - 1, b, "+") for a, b in introns if rng.random() < frac]
     for a, b in introns[::7]:
-        sites.append((0, a - 1 - int(rng.integers(3, 40)), b + int(rng.integers(3, 40)), "-" if rng.random() < 0.5 else "+"))
+        sites.append((int(rich()), a - 1 - int(rng.integers(3, 40)), b + int(rng.integers(3, 40)), "-" if rng.random() < 0.5 else "+"))
     return sites
 
 
@@ -90,7 +150,7 @@ def run_case(seed, nreads, sub=0.005, verbose=8, backend=None, extra=(), known=0
                 f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
         extra = list(extra) + ["--known-splicesite-infile", os.path.join(tmp, "ss.txt")]
     fa = os.path.join(tmp, "g.fa")
-    synth.write_fasta(fa, contigs)
+    synth.write_fasta(fa, contigs, names=contig_names(contigs))
     base = os.path.join(tmp, "g")
     if snps:
         synth.write_snps(os.path.join(tmp, "g.snp"), var)

@@ -24,6 +24,9 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 
 
 def make_case(seed, npairs, rdlen=101, sub=0.005, glen=400000, nintrons=300, frag_mean=280, frag_sd=40):
+    import fuzz_spliced as FS
+    rdlen = int(os.environ.get("H2G_FUZZ_RDLEN", rdlen))
+    multi = float(os.environ.get("H2G_FUZZ_MULTI", "0"))   # that fraction of the exons is 20..90 bp long
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, size=glen, dtype=np.uint8)
     introns = []
@@ -37,7 +40,11 @@ def make_case(seed, npairs, rdlen=101, sub=0.005, glen=400000, nintrons=300, fra
         elif kind == 8:
             g[a:a + 2] = [2, 1]; g[b - 2:b] = [0, 2]
         introns.append((a, b))
-        pos = b + int(rng.integers(120, 700))
+        pos = b + (int(rng.integers(20, 90)) if multi > 0 and rng.random() < multi else int(rng.integers(120, 700)))
+    extra = None
+    if FS.rich():                                    # three contigs, N runs, gene copies, processed pseudogenes (fuzz_spliced.enrich)
+        extra = FS.enrich(g, introns, rng)
+        g = extra[1]
     keep = np.ones(glen, dtype=bool)
     for a, b in introns:
         keep[a:b] = False
@@ -49,12 +56,12 @@ def make_case(seed, npairs, rdlen=101, sub=0.005, glen=400000, nintrons=300, fra
         s = int(rng.integers(0, len(tx) - fl))
         f = tx[s:s + fl].copy()
         m = rng.random(fl) < sub
-        f = np.where(m, (f + rng.integers(1, 4, size=fl)) & 3, f).astype(np.uint8)
+        f = np.where(m & (f < 4), (f + rng.integers(1, 4, size=fl)) & 3, f).astype(np.uint8)
         if rng.random() < 0.5:
-            f = (3 - f[::-1]).astype(np.uint8)
+            f = FS.revcomp(f)
         m1[i] = f[:rdlen]
-        m2[i] = 3 - f[::-1][:rdlen]
-    return [g], m1, m2, introns
+        m2[i] = FS.revcomp(f)[:rdlen]
+    return ([extra[0], g, extra[2]] if extra else [g]), m1, m2, introns
 
 
 def emu_pairs(base, m1, m2, q1, q2, options=(), splice_sites=None):
@@ -90,7 +97,8 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0, novel_out=Fal
                 f.write("chr1\t%d\t%d\t%s\n" % (l, r, d))
         sopt = ["--known-splicesite-infile", os.path.join(tmp, "ss.txt")]
     fa = os.path.join(tmp, "g.fa")
-    synth.write_fasta(fa, contigs)
+    import fuzz_spliced as FS
+    synth.write_fasta(fa, contigs, names=FS.contig_names(contigs))
     base = os.path.join(tmp, "g")
     snps = int(os.environ.get("H2G_FUZZ_SNPS", "0"))      # > 0: SNP-graph index (reads stay on the reference haplotype)
     if snps:

@@ -19,7 +19,7 @@ from hisat2_amd import synth  # noqa: E402
 
 def build(tmp, contigs, introns, seed, snps=0, every=2):
     fa = os.path.join(tmp, "g.fa")
-    synth.write_fasta(fa, contigs)
+    synth.write_fasta(fa, contigs, names=__import__('fuzz_spliced').contig_names(contigs))
     with open(os.path.join(tmp, "ss.txt"), "w") as f:
         for a, b in introns[::every]:
             f.write("chr1\t%d\t%d\t+\n" % (a - 1, b))

@@ -42,7 +42,7 @@ def flat_names(names):
 
 
 def _score_min(L, h, options):
-    if options and "--score-min" in options:
+    if options and any(o in options for o in ("--score-min", "--sensitive", "--very-sensitive")):   # the presets carry a --score-min
         p = api.AlignParams()
         p.apply_options(list(options))
         L.h2g_sam_set_score_min(h, p.score_min_type, p.score_min_const, p.score_min_coeff)

@@ -103,7 +103,7 @@ def run_case(seed, nreads, P=2, sub=0.005, show=6, known=0.0, ref_opts=()):
     tmp = tempfile.mkdtemp(prefix="h2tmpss")
     contigs, reads, introns = F.make_case(seed, nreads, sub=sub)
     fa = os.path.join(tmp, "g.fa")
-    synth.write_fasta(fa, contigs)
+    synth.write_fasta(fa, contigs, names=F.contig_names(contigs))
     base = os.path.join(tmp, "g")
     snps = int(os.environ.get("H2G_FUZZ_SNPS", "0"))      # > 0: SNP-graph index (reads stay on the reference haplotype)
     if os.environ.get("H2G_FUZZ_TRAN"):                   # --ss / --exon index over every third planted intron (+ SNPs)

@@ -175,6 +175,43 @@ def test_known_splice_sites_lines_identical(seed, sub, known):
 
 
 @needs_ref
+@pytest.mark.parametrize("seed,known", [(5101, 0.0), (5102, 0.5)])
+def test_spliced_lines_multi_junction_multi_contig(seed, known, monkeypatch):
+    """the rich generator: reads drawn from the spliced transcript over 20..90 bp exons (two or three junctions per read), the genes on
+    the SECOND of three contigs (site text ids > 0, a leading contig with an N gap = two fragments), N runs inside exons, whole-gene
+    copies and processed pseudogenes (the intron-less copy competes with the spliced placement) — every line byte-identical"""
+    monkeypatch.setenv("H2G_FUZZ_RICH", "1")
+    monkeypatch.setenv("H2G_FUZZ_MULTI", "0.5")
+    import fuzz_spliced as F
+    from h2gemu_align import emu_align
+    bad, tmp = F.run_case(seed, 3000, sub=0.01, verbose=2, known=known, indel=0.003)
+    assert bad == 0
+    names, reads = read_fa(os.path.join(tmp, "r.fa"))
+    sites, opts = None, []
+    if known:
+        sites = api.read_splice_site_file(os.path.join(tmp, "ss.txt"), ["lead", "chr1", "tail"])
+        opts = ["--known-splicesite-infile", os.path.join(tmp, "ss.txt")]
+    outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, no_spliced=0, splice_sites=sites)
+    res, aln = SL.emu_to_abi(outs, recs)
+    got = SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, options=opts)
+    want = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert sum(1 for l in want if l.split("\t")[5].count("N") >= 2) > 100            # reads across two junctions
+    assert len({l.split("\t")[2] for l in want}) == 4                                  # lead, chr1, tail and *
+    assert diff_lines(got, want) == 0
+    assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
+
+
+@needs_ref
+def test_temporary_splice_sites_multi_junction_multi_contig(monkeypatch):
+    """the default mode on the rich generator, at -p 3"""
+    monkeypatch.setenv("H2G_FUZZ_RICH", "1")
+    monkeypatch.setenv("H2G_FUZZ_MULTI", "0.4")
+    import temp_splice as T
+    bad, _ = T.run_case(5201, 7000, P=3, show=3, known=0.3)
+    assert bad == 0
+
+
+@needs_ref
 def test_known_splice_sites_pairs_lines_identical():
     """pairs with a splice-site database: TLEN leaves the longest database intron between the mates out (aligner_result.h:1669)"""
     import fuzz_spliced_pairs as F
