@@ -30,7 +30,7 @@ def build(tmp, contigs, introns, seed, snps=0, every=2):
     base = os.path.join(tmp, "g")
     cmd = [os.path.join(F.REF, "hisat2-build-s"), "-q", "--ss", os.path.join(tmp, "ss.txt"), "--exon", os.path.join(tmp, "exon.txt")]
     if snps:
-        synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=snps))
+        synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=snps, names=__import__('fuzz_spliced').contig_names(contigs)))
         cmd += ["--snp", os.path.join(tmp, "g.snp")]
     subprocess.run(cmd + [fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return base

@@ -110,7 +110,7 @@ def run_case(seed, nreads, P=2, sub=0.005, show=6, known=0.0, ref_opts=()):
         import fuzz_tran
         fuzz_tran.build(tmp, contigs, introns, seed, snps, every=3)
     elif snps:
-        synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=snps))
+        synth.write_snps(os.path.join(tmp, "g.snp"), synth.make_snps(contigs, seed + 5, every=snps, names=F.contig_names(contigs)))
         subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     else:
         subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
