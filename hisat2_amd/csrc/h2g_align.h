@@ -745,7 +745,7 @@ inline void align_params_defaults(h2g_align_params* p, bool linear) {
 	p->min_intronlen = 20; p->max_intronlen = 500000; p->pen_cansplice = 0; p->pen_noncansplice = 12;   // hisat2.cpp:493-499
 	p->pen_canintronlen_type = 4; p->pen_canintronlen_const = -8.0; p->pen_canintronlen_coeff = 1.0;
 	p->pen_noncanintronlen_type = 4; p->pen_noncanintronlen_const = -8.0; p->pen_noncanintronlen_coeff = 1.0;
-	p->min_anchor_len = 7; p->min_anchor_len_noncan = 14; p->xs_only = 0; p->pad2_ = 0;
+	p->min_anchor_len = 7; p->min_anchor_len_noncan = 14; p->xs_only = 0; p->use_haplotype = 0; p->max_alts_tried = 16; p->pad3_ = 0;
 }
 
 // One reported alignment = the arguments reportHit (hi_aligner.h:6064-6166) hands to AlnRes::init

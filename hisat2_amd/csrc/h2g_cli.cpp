@@ -217,7 +217,8 @@ int main(int argc, char** argv) {
 	std::vector<std::string> u, m1, m2;
 	bool fasta = false, nospliced = false, notempss = false, nohead = false, parse_only = false, no_unal = false;
 	std::string known_ss, novel_ss, novel_out;
-	bool tlen_adjust = true;
+	bool tlen_adjust = true, use_haplotype = false;
+	int max_alts_tried = 16;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
 	uint64_t skip = 0, upto = ~0ull;
@@ -254,6 +255,8 @@ int main(int argc, char** argv) {
 		else if(a == "--novel-splicesite-infile") novel_ss = need("--novel-splicesite-infile");
 		else if(a == "--novel-splicesite-outfile") novel_out = need("--novel-splicesite-outfile");
 		else if(a == "--no-templatelen-adjustment") tlen_adjust = false;
+		else if(a == "--max-altstried") { max_alts_tried = atoi(need("--max-altstried")); if(max_alts_tried < 8) { fprintf(stderr, "--max-altstried arg must be at least 8\n"); return 1; } }
+		else if(a == "--haplotype") use_haplotype = true;                      // hisat2.cpp:1749 (ARG_HAPLOTYPE)
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
 		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min" ||
 		        a == "--min-intronlen" || a == "--max-intronlen" || a == "--pen-cansplice" || a == "--pen-noncansplice" ||
@@ -389,6 +392,8 @@ int main(int argc, char** argv) {
 		P.pen_noncanintronlen_type = 4; P.pen_noncanintronlen_const = -8.0; P.pen_noncanintronlen_coeff = 2.0;
 	}
 	P.xs_only = xs_only ? 1 : 0;
+	P.use_haplotype = use_haplotype ? 1 : 0;
+	P.max_alts_tried = (uint32_t)max_alts_tried;
 	h2g_align_params_presets(&P, ix, saw_k ? 1 : 0, k_arg, max_seeds_arg, sensitive ? 1 : 0, very_sensitive ? 1 : 0);
 	if(P.min_intronlen > P.max_intronlen) {   // hisat2.cpp:4278
 		fprintf(stderr, "--min-intronlen(%u) should not be greater than --max-intronlen(%u)\n", P.min_intronlen, P.max_intronlen);

@@ -767,8 +767,37 @@ struct DAlts {
 	// optional position index: bucket[b] = first ALT with pos >= b << H2G_ALT_BUCKET_SHIFT, so that the lower bound is one load
 	// plus a scan of the few ALTs of the bucket instead of ~log2(n) dependent loads (15 at E. coli scale, 24 at GRCh38+SNP scale)
 	const uint32_t* bucket = nullptr; uint32_t nbucket = 0;
-	uint32_t has_splice = 0;                                // ALTDB::hasSpliceSites(): the list holds splice-site ALTs (a --ss index)
+	// bit 0: ALTDB::hasSpliceSites(), the list holds splice-site ALTs (a --ss index).  bit 1: --haplotype is on AND the haplotype table
+	// follows the ALT array in memory (pack_alts below) — kept out of this struct so that the kernel arguments of the units built without
+	// H2G_HAPLOTYPE stay what they were
+	uint32_t has_splice = 0;
 };
+// ALTDB::haplotypes() (alt.h:209) as laid out behind the ALTs: u32 {nhap, nids, 0, 0}, left[nhap], right[nhap], maxright[nhap],
+// first[nhap + 1], ids[nids].  [left, right] joined, sorted by (left, right); ids[first[h] .. first[h+1]) = positions in the ALT list of
+// the SNPs haplotype h carries; maxright[h] = max right over 0..h (gfm.h:907-921)
+struct DHaps { const uint32_t *left, *right, *maxright, *first, *ids; uint32_t n; };
+H2G_HD DHaps haps_of(const DAlts& A) {
+	const uint32_t* h = reinterpret_cast<const uint32_t*>(A.a + A.n);
+	DHaps H;
+	H.n = h[0]; H.left = h + 4; H.right = H.left + H.n; H.maxright = H.right + H.n; H.first = H.maxright + H.n; H.ids = H.first + H.n + 1;
+	return H;
+}
+// host: the ALT array followed by the haplotype table, one buffer (device upload and the host instantiation share it)
+template <class ALT_T>
+inline void pack_alts(const std::vector<ALT_T>& alts, const std::vector<uint32_t>& left, const std::vector<uint32_t>& right,
+                      const std::vector<uint32_t>& maxright, const std::vector<uint32_t>& first, const std::vector<uint32_t>& ids,
+                      std::vector<uint64_t>& out) {
+	static_assert(sizeof(ALT_T) == sizeof(DAlt) && sizeof(DAlt) % 8 == 0, "ALT records are 8-byte multiples");
+	const size_t nh = left.size();
+	std::vector<uint32_t> t = {(uint32_t)nh, (uint32_t)ids.size(), 0u, 0u};
+	t.insert(t.end(), left.begin(), left.end()); t.insert(t.end(), right.begin(), right.end()); t.insert(t.end(), maxright.begin(), maxright.end());
+	if(first.size() == nh + 1) t.insert(t.end(), first.begin(), first.end()); else t.insert(t.end(), nh + 1, 0u);
+	t.insert(t.end(), ids.begin(), ids.end());
+	if(t.size() & 1) t.push_back(0u);
+	out.assign((alts.size() * sizeof(DAlt) + t.size() * 4) / 8, 0);
+	if(!alts.empty()) memcpy(out.data(), alts.data(), alts.size() * sizeof(DAlt));
+	memcpy(reinterpret_cast<uint8_t*>(out.data()) + alts.size() * sizeof(DAlt), t.data(), t.size() * 4);
+}
 #define H2G_ALT_BUCKET_SHIFT 7
 
 H2G_HD uint32_t alt_lobound(const DAlts& A, uint32_t pos) {   // EList::bsearchLoBound with a type-NONE key: first pos >= key
@@ -850,15 +879,111 @@ struct AwaFrame {
 #ifndef H2G_AWA_CAND
 #define H2G_AWA_CAND 4
 #endif
+// --haplotype: compiled into the units that define H2G_SPLICE_DB 1 (and the host instantiation); the other units keep the code and
+// the workspace layout they were verified with (every unit reports its own layout, h2g_go_args.h).
+#ifndef H2G_HAPLOTYPE
+#ifdef H2G_SPLICE_DB
+#define H2G_HAPLOTYPE H2G_SPLICE_DB
+#else
+#define H2G_HAPLOTYPE 1
+#endif
+#endif
+#ifndef H2G_HT_CAP
+#define H2G_HT_CAP 16
+#endif
+// ht_llist[dep] (hi_aligner.h:410, :2899): the haplotypes still compatible with the ALTs taken so far, each with the position of the
+// next ALT it expects (walking left: counting down; right: counting up, == the haplotype's size once it is exhausted)
+struct HtList { uint32_t ht[H2G_HT_CAP]; uint16_t idx[H2G_HT_CAP]; uint32_t n; };
 struct AwaWS {
 	h2g_edit tmp[H2G_MAX_EDITS];
 	uint32_t ntmp;
 	AwaFrame fr[H2G_AWA_DEPTH];
+#if H2G_HAPLOTYPE
+	HtList ht[H2G_AWA_DEPTH];
+#endif
 	// candidate_edits (ELList<Edit,128,4>): other edit lists reaching the same best offset (adjustWithALT only)
 	h2g_edit cand[H2G_AWA_CAND][H2G_MAX_EDITS];
 	uint32_t cand_n[H2G_AWA_CAND], ncand;
 	h2g_ghit scratch;     // adjust_with_alt builds its candidate hit here
 };
+
+#if H2G_HAPLOTYPE
+// ALT::isSame alt.h:127-149 (reversed = the low byte of seq: set on the mirrored copy of a deletion)
+H2G_HD bool alt_is_same(const DAlt& a, const DAlt& o) {
+	if(a.type != o.type) return false;
+	if(a.type == H2G_ALT_SNP_SGL) return a.pos == o.pos && a.seq == o.seq;
+	if(a.type == H2G_ALT_SNP_INS && a.seq != o.seq) return false;
+	const bool ra = (a.seq & 0xff) != 0, ro = (o.seq & 0xff) != 0;
+	if(ra == ro) return a.pos == o.pos && a.len == o.len;
+	if(ra) return a.pos - a.len + 1 == o.pos && a.len == o.len;
+	return a.pos == o.pos - o.len + 1 && a.len == o.len;
+}
+H2G_HD bool ht_has(const HtList& L, uint32_t ht) { for(uint32_t h = 0; h < L.n; h++) if(L.ht[h] == ht) return true; return false; }
+H2G_HD void ht_push(HtList& L, uint32_t ht, uint32_t idx, uint32_t* ovf) {
+	if(L.n >= H2G_HT_CAP) { *ovf = 1; return; }
+	L.ht[L.n] = ht; L.idx[L.n] = (uint16_t)idx; L.n++;
+}
+// add_haplotypes hi_aligner.h:2648-2757: the haplotypes a walk arriving at cmp (= joinedOff) can still meet within one read length
+H2G_HD void add_haplotypes(const DAlts& A, const DHaps& H, uint32_t cmp, HtList& L, uint32_t rdlen, bool left_ext, bool initial, uint32_t* ovf) {
+	uint32_t lo = 0, hi = H.n;                                   // bsearchLoBound over (left, right) with key (cmp, cmp)
+	while(lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if(H.left[mid] < cmp || (H.left[mid] == cmp && H.right[mid] < cmp)) lo = mid + 1; else hi = mid;
+	}
+	if(lo >= H.n) return;
+	if(left_ext) {
+		for(int first = (int)lo; first >= 0; first--) {
+			const uint32_t right = H.right[first];
+			if(!initial && right >= cmp) continue;
+			if((uint32_t)(H.maxright[first] + rdlen - 1) < cmp) break;
+			const uint32_t o = H.first[first], nal = H.first[first + 1] - o;
+			if(nal == 0 || ht_has(L, (uint32_t)first)) continue;
+			if(right < cmp) ht_push(L, (uint32_t)first, nal - 1, ovf);
+			else {
+				uint32_t second = nal;
+				for(int a = (int)nal - 1; a >= 0; a--) {
+					const uint32_t alti = H.ids[o + (uint32_t)a];
+					second = (uint32_t)a;
+					if(alti < A.n && cmp > A.a[alti].pos) break;
+				}
+				if(second != nal) ht_push(L, (uint32_t)first, second, ovf);
+			}
+		}
+		return;
+	}
+	if(initial) {
+		for(int first = (int)lo; first >= 0; first--) {
+			if(H.maxright[first] < cmp) break;
+			if(H.right[first] < cmp || H.left[first] > cmp) continue;
+			const uint32_t o = H.first[first], nal = H.first[first + 1] - o;
+			if(nal == 0 || ht_has(L, (uint32_t)first)) continue;
+			uint32_t second = nal;
+			for(uint32_t a = 0; a < nal; a++) {
+				const uint32_t alti = H.ids[o + a];
+				second = a;
+				if(alti < A.n && cmp <= A.a[alti].pos) break;
+			}
+			if(second != nal) ht_push(L, (uint32_t)first, second, ovf);
+		}
+	}
+	for(uint32_t second = lo; second < H.n; second++) {
+		if(H.left[second] < cmp) continue;
+		if(H.left[second] >= cmp + rdlen) break;
+		if(H.first[second + 1] == H.first[second] || ht_has(L, second)) continue;
+		ht_push(L, second, 0, ovf);
+	}
+}
+// "Check to see if there is a haplotype that supports this alt" (:2981-2996 leftwards, :3314-3331 rightwards)
+H2G_HD bool ht_supports(const DAlts& A, const DHaps& H, const HtList& L, uint32_t alti) {
+	for(uint32_t h = 0; h < L.n; h++) {
+		const uint32_t o = H.first[L.ht[h]], nal = H.first[L.ht[h] + 1] - o;
+		if(L.idx[h] >= nal) continue;
+		const uint32_t hi = H.ids[o + L.idx[h]];
+		if(hi < A.n && alt_is_same(A.a[alti], A.a[hi])) return true;
+	}
+	return false;
+}
+#endif
 
 H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView& seq, uint32_t joinedOff0, uint32_t base_rdoff,
                                 uint32_t rdoff0, uint32_t rdlen0, uint32_t tidx, int rfoff0, uint32_t rflen0, bool left,
@@ -866,6 +991,11 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 {
 	if(numNs) *numNs = 0;
 	W->ncand = 0;
+#if H2G_HAPLOTYPE
+	const bool use_hap = (A.has_splice & 2u) != 0;         // --haplotype (GraphPolicy::useHaplotype gp.h:71) and the table is there
+	DHaps H; H.left = H.right = H.maxright = H.first = H.ids = nullptr; H.n = 0;
+	if(use_hap) H = haps_of(A);
+#endif
 	const uint32_t nedits0 = h->nedits;
 	W->ntmp = nedits0;
 	for(uint32_t k = 0; k < nedits0; k++) W->tmp[k] = h->edits[k];
@@ -935,6 +1065,25 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 						} else continue;
 					}
 				}
+#if H2G_HAPLOTYPE
+				{   // "Update and find Haplotypes" :2898-2939
+					HtList& L = W->ht[sp];
+					L.n = 0;
+					if(use_hap && H.n > 0) {
+						if(sp > 0 && W->ntmp > 0 && W->tmp[0].type != H2G_EDIT_SPL && W->tmp[0].snp < A.n) {   // (a splice-site ALT carries no ALT id: the reference indexes past its list there)
+							const HtList& P = W->ht[sp - 1];
+							const DAlt taken = A.a[W->tmp[0].snp];
+							for(uint32_t p = 0; p < P.n; p++) {
+								const uint32_t o = H.first[P.ht[p]], hi_ = H.ids[o + P.idx[p]];
+								if(hi_ >= A.n || !alt_is_same(taken, A.a[hi_])) continue;
+								if(P.idx[p] == 0) add_haplotypes(A, H, f.joinedOff, L, f.rdlen, true, false, &h->overflow);
+								else ht_push(L, P.ht[p], P.idx[p] - 1u, &h->overflow);
+							}
+						}
+						if(L.n == 0) add_haplotypes(A, H, f.joinedOff, L, f.rdlen, true, sp == 0, &h->overflow);
+					}
+				}
+#endif
 				f.orig_nedits = W->ntmp;
 				f.state = 1;
 			} else {
@@ -972,6 +1121,28 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 				if(tmp_mm > 0) W->ntmp -= tmp_mm;
 				f.max_rd_i = max_rd_i;
 				f.a_first = (int)a1; f.a_second = (int)a2;
+#if H2G_HAPLOTYPE
+				{   // "Update and find Haplotypes" :3251-3292
+					HtList& L = W->ht[sp];
+					L.n = 0;
+					if(use_hap && H.n > 0) {
+						if(sp > 0) {
+							const HtList& P = W->ht[sp - 1];
+							const uint32_t last = W->ntmp > 0 && W->tmp[W->ntmp - 1].type != H2G_EDIT_SPL ? W->tmp[W->ntmp - 1].snp : H2G_MAX;
+							for(uint32_t p = 0; p < P.n; p++) {
+								const uint32_t o = H.first[P.ht[p]], nal = H.first[P.ht[p] + 1] - o;
+								if(P.idx[p] < nal) {
+									const uint32_t hi_ = H.ids[o + P.idx[p]];
+									if(last >= A.n || hi_ >= A.n || !alt_is_same(A.a[last], A.a[hi_])) continue;
+								}
+								if(P.idx[p] + 1u >= nal && f.joinedOff > H.right[P.ht[p]]) add_haplotypes(A, H, f.joinedOff, L, f.rdlen, false, false, &h->overflow);
+								else ht_push(L, P.ht[p], P.idx[p] + 1u, &h->overflow);
+							}
+						}
+						if(L.n == 0) add_haplotypes(A, H, f.joinedOff, L, f.rdlen, false, sp == 0 && f.rdoff_add == 0, &h->overflow);
+					}
+				}
+#endif
 				f.orig_nedits = W->ntmp;
 				f.state = 1;
 			}
@@ -1022,6 +1193,9 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 					if(alt.type == H2G_ALT_SNP_INS) { if(rd_i + 1 >= f.min_rd_i) continue; }
 					break;
 				}
+#if H2G_HAPLOTYPE
+				if(W->ht[sp].n > 0 && alt.type != H2G_ALT_SPLICESITE && !ht_supports(A, H, W->ht[sp], (uint32_t)f.a_second)) continue;
+#endif
 				if(alt.type == H2G_ALT_SNP_SGL) {
 					if(rd_bp == (int)alt.seq) {
 						const int rf_bp = AWA_RF(f, rf_i);
@@ -1100,6 +1274,9 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 				rf_i = rd_i = alt.pos - f.joinedOff;
 				if(rd_i >= f.rdlen) continue;
 				int rf_bp = AWA_RF(f, rf_i), rd_bp = seq.at(f.rdoff + rd_i);
+#if H2G_HAPLOTYPE
+				if(W->ht[sp].n > 0 && alt.type != H2G_ALT_SPLICESITE && !ht_supports(A, H, W->ht[sp], (uint32_t)f.a_first)) continue;
+#endif
 				if(alt.type == H2G_ALT_SNP_SGL) {
 					if(rd_bp == (int)alt.seq) {
 						h2g_edit e; e.pos = rd_i + f.rdoff_add; e.chr = base_char(rf_bp); e.qchr = base_char(rd_bp); e.type = H2G_EDIT_MM; e.pad = 0; e.snp = (uint32_t)f.a_first;
@@ -1346,7 +1523,11 @@ H2G_HD bool ghit_equal(const h2g_ghit* a, const h2g_ghit* b) {
 H2G_HDN uint32_t find_ss_offs(const DGfm& g, const DAlts& A, uint32_t start, uint32_t end, OffDiff* so, uint32_t* overflow) {
 	uint32_t n = 0;
 	so[n].first = 0; so[n].second = 0; n++;
+#if H2G_HAPLOTYPE
+	if(g.linear || !(A.has_splice & 1u)) return n;
+#else
 	if(g.linear || !A.has_splice) return n;
+#endif
 	auto push = [&](uint32_t first, int second) { if(n < H2G_OFFDIFF_CAP) { so[n].first = first; so[n].second = second; n++; } else *overflow = 1; };
 	for(uint32_t i = alt_lobound(A, start); i < A.n; i++) {
 		const DAlt alt = A.a[i];

@@ -75,6 +75,10 @@ struct HostIndex {
 	std::vector<uint32_t> local_first;  // [nPat+1]
 	std::vector<std::string> names;
 	std::vector<std::string> alt_names;  // ALTDB::altnames() (.8.ht2), permuted like `alts`
+	// ALTDB::haplotypes() (.7.ht2 after the ALTs, gfm.h:779-793, :907-921): [left, right] in joined coordinates, sorted by (left, right);
+	// hap_ids[hap_first[h] .. hap_first[h+1]) = positions in `alts` of the SNPs the haplotype carries, in ascending order;
+	// hap_maxright[h] = max right of haplotypes 0..h.  An index built without --haplotype has one haplotype per SNP (gfm.h:1645).
+	std::vector<uint32_t> hap_left, hap_right, hap_maxright, hap_first, hap_ids;
 	uint32_t minK = 0;
 };
 
@@ -245,6 +249,20 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 			});
 			ix.alt_names.clear();
 			for(auto& e : v) { ix.alts.push_back(e.first); ix.alt_names.push_back(nm[e.second]); }
+			ix.hap_left.clear(); ix.hap_right.clear(); ix.hap_maxright.clear(); ix.hap_first.assign(1, 0); ix.hap_ids.clear();
+			if(b7.has(4)) {                                   // older indexes end after the ALTs
+				std::vector<uint32_t> to_alti(n0, 0xffffffffu);    // file order -> position after the sort
+				for(size_t i = 0; i < v.size(); i++) if(v[i].second < n0) to_alti[v[i].second] = (uint32_t)i;
+				const uint32_t nh = b7.u32();
+				for(uint32_t h = 0; h < nh && b7.has(12); h++) {
+					const uint32_t l = b7.u32(), r = b7.u32(), k = b7.u32();
+					if(!b7.has((size_t)k * 4)) break;
+					ix.hap_left.push_back(l); ix.hap_right.push_back(r);
+					ix.hap_maxright.push_back(h == 0 ? r : std::max(ix.hap_maxright.back(), r));
+					for(uint32_t q = 0; q < k; q++) { const uint32_t id = b7.u32(); ix.hap_ids.push_back(id < n0 ? to_alti[id] : 0xffffffffu); }
+					ix.hap_first.push_back((uint32_t)ix.hap_ids.size());
+				}
+			}
 		}
 	}
 	uint32_t gl = ix.g.p.len;

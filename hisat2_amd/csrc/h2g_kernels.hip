@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#define H2G_HAPLOTYPE 0     // the primitive kernels of this unit (k_extend_alts, k_adjust_alt) run without haplotype lists; go() units: h2g_graph.h
 #include "h2g_core.h"
 #include "h2g_host_index.h"
 #include "h2g_align.h"
@@ -154,8 +155,10 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	static_assert(sizeof(HostAlt) == sizeof(DAlt), "HostAlt mirrors DAlt");
 	ix->dalts.a = nullptr; ix->dalts.n = 0; ix->dalts.maxAltsTried = 16;      // --max-altstried default hisat2.cpp:521
 	if(!g.p.linear && !ix->host.alts.empty()) {
-		const HostAlt* da = nullptr;
-		if((s = upload(ix, ix->host.alts, &da))) { h2g_index_free(ix); return s; }
+		std::vector<uint64_t> packed;                      // the ALTs followed by the haplotype table (pack_alts, h2g_graph.h)
+		pack_alts(ix->host.alts, ix->host.hap_left, ix->host.hap_right, ix->host.hap_maxright, ix->host.hap_first, ix->host.hap_ids, packed);
+		const uint64_t* da = nullptr;
+		if((s = upload(ix, packed, &da))) { h2g_index_free(ix); return s; }
 		ix->dalts.a = reinterpret_cast<const DAlt*>(da);
 		ix->dalts.n = (uint32_t)ix->host.alts.size();
 		std::vector<uint32_t> bk;
@@ -1469,7 +1472,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(!s->ix->has_local) { snprintf(g_err, sizeof g_err, "align: index loaded without local (.5/.6) indexes"); return H2G_ERR_ARG; }
 	if(!s->has_names || (paired && !s->has_mates)) { snprintf(g_err, sizeof g_err, "align: read names (h2g_set_read_names)%s not set", paired ? " / mates (h2g_set_mates)" : ""); return H2G_ERR_ARG; }
 	const bool linear = s->ix->dg.linear != 0;
-	const bool spl = !p->no_spliced_alignment;
+	// --haplotype is compiled into the units that also carry the splice-site database (H2G_HAPLOTYPE, h2g_graph.h); they run either mode
+	const bool spl = !p->no_spliced_alignment || (p->use_haplotype && !linear);
 	if(!p->no_spliced_alignment) {
 		// spliced alignment: combineWith places introns (hi_aligner.h:1588-1739) and every read is independent when novel splice
 		// sites are not shared (--no-temp-splicesite); the shared SpliceSiteDB of the default mode and graph indexes are not built
@@ -1490,6 +1494,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		return H2G_ERR_ARG;
 	}
 	if(p->bowtie2_dp > 2) return H2G_ERR_ARG;
+	if(p->max_alts_tried && p->max_alts_tried < 8) { snprintf(g_err, sizeof g_err, "align: --max-altstried arg must be at least 8"); return H2G_ERR_ARG; }
 	if(p->bowtie2_dp) {
 		if(s->max_read_len == 0) return H2G_ERR_ARG;
 		// a read longer than H2G_SW_MAX_ROWS is flagged by the kernel (overflow bit 256) instead of run through the DP
@@ -1519,6 +1524,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	GoArgs A;
 	memset(&A, 0, sizeof A);
 	A.g = s->ix->dg; A.ref = s->ix->dr; A.ls = s->ix->dls; A.alts = s->ix->dalts;
+	if(p->max_alts_tried) A.alts.maxAltsTried = p->max_alts_tried;          // --max-altstried
+	if(p->use_haplotype && !linear && A.alts.n) A.alts.has_splice |= 2u;   // --haplotype: the table behind the ALTs is read (h2g_graph.h haps_of)
 	A.rd1 = dreads(s); A.rd2 = A.rd1;
 	if(paired) { A.rd2.codes = s->d_codes2; A.rd2.offs = s->d_offs2; A.rd2.quals = s->has_quals2 ? s->d_quals2 : nullptr; }
 	A.P = aln_params_from(*p, p->no_spliced_alignment != 0, linear);

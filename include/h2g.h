@@ -292,7 +292,13 @@ typedef struct {
 	double   pen_canintronlen_const, pen_canintronlen_coeff, pen_noncanintronlen_const, pen_noncanintronlen_coeff;
 	/* TranscriptomePolicy (hisat2.cpp:4076-4084): anchor minima 7 / 14, with --dta (transcript assemblers) 15 / 20 and
 	 * --pen-noncanintronlen G,-8,2; xs_only (--dta-cufflinks): spliced alignments of unknown strand are not reported (hi_aligner.h:6101) */
-	uint32_t min_anchor_len, min_anchor_len_noncan, xs_only, pad2_;
+	uint32_t min_anchor_len, min_anchor_len_noncan, xs_only;
+	/* --haplotype (graph indexes): an ALT is only tried when a haplotype of the index carries it together with the ALTs already taken
+	 * (GraphPolicy::useHaplotype gp.h:71, alignWithALTs_recur hi_aligner.h:2898-2996, :3251-3331) */
+	uint32_t use_haplotype;
+	/* --max-altstried (GraphPolicy::maxAltsTried, default 16, at least 8: hisat2.cpp:521, :1745): ALTs one extension may walk through
+	 * (hi_aligner.h:2794) and, / 4, the offset combinations adjustWithALT tries (:2313, :2423) */
+	uint32_t max_alts_tried, pad3_;
 } h2g_align_params;
 /* number of visible HIP devices (0 without a GPU: the library has no CPU path) */
 H2G_EXPORT int        h2g_device_count(void);

@@ -33,6 +33,7 @@ struct Emu {
 	LocalPack lp;
 	DLocalSet dls;
 	DAlts dalts;
+	std::vector<uint64_t> altbuf;                         // the ALTs followed by the haplotype table (pack_alts)
 	std::vector<uint32_t> alt_bk;
 	uint32_t bowtie2_dp = 0;
 	bool has_params = false;
@@ -70,7 +71,8 @@ int h2gemu_load(const char* base, Emu** out) {
 	e->dr.buf = r.buf.data(); e->dr.rec_start = r.rec_start.data(); e->dr.rec_len = r.rec_len.data();
 	e->dr.rec_bufoff = r.rec_bufoff.data(); e->dr.refRecOffs = r.refRecOffs.data(); e->dr.refLens = r.refLens.data();
 	e->dr.nrefs = r.nrefs;
-	e->dalts.a = reinterpret_cast<const DAlt*>(e->host.alts.data()); e->dalts.n = g.p.linear ? 0 : (uint32_t)e->host.alts.size();
+	pack_alts(e->host.alts, e->host.hap_left, e->host.hap_right, e->host.hap_maxright, e->host.hap_first, e->host.hap_ids, e->altbuf);
+	e->dalts.a = reinterpret_cast<const DAlt*>(e->altbuf.data()); e->dalts.n = g.p.linear ? 0 : (uint32_t)e->host.alts.size();
 	e->dalts.maxAltsTried = 16;
 	if(!g.p.linear) {
 		splice_sites_of_alts(reinterpret_cast<const uint32_t*>(e->host.alts.data()), e->host.alts.size(), sizeof(HostAlt) / 4, g.rstarts.data(), g.nFrag, g.p.len, e->alt_sites);
@@ -265,6 +267,8 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	static GraphSlot gsl_;
 	static int64_t sc_[2 * H2G_COMBINE_MAXLEN];
 	C->sc = sc_;
+	e->dalts.maxAltsTried = hp.max_alts_tried ? hp.max_alts_tried : 16;
+	e->dalts.has_splice = (e->dalts.has_splice & 1u) | (hp.use_haplotype && !e->dg.linear ? 2u : 0u);
 	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->gsl = e->dg.linear ? nullptr : &gsl_; C->graph = !e->dg.linear;
 }
 

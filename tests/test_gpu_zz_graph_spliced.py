@@ -132,3 +132,38 @@ def test_novel_splicesite_outfile_and_templatelen_command_line(tmp_path):
     assert sum(1 for l in want if "N" in l.split("\t")[5]) > 2000
     got_ss = open(os.path.join(tmp, "amd.ss")).read()
     assert got_ss == open(os.path.join(tmp, "ref.ss")).read() and got_ss.count("\n") > 50
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", [["--no-spliced-alignment"], ["--no-temp-splicesite"]])
+def test_haplotype_command_line(tmp_path, mode):
+    """--haplotype on an index built with --snp + --haplotype: ALT combinations no haplotype carries are not walked; lines and summary
+    equal the reference's (the go() units with H2G_HAPLOTYPE run both the spliced and the unspliced mode)"""
+    import numpy as np
+    import fuzz_haplotype as H
+    tmp = str(tmp_path)
+    rng = np.random.default_rng(1071)
+    contigs = [rng.integers(0, 4, size=300000, dtype=np.uint8), rng.integers(0, 4, size=90000, dtype=np.uint8)]
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    snps = synth.make_snps(contigs, 1076, every=25)
+    synth.write_snps(os.path.join(tmp, "g.snp"), snps)
+    lines, clusters, per = H.make_haplotypes(snps, rng)
+    with open(os.path.join(tmp, "g.haplotype"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "--snp", os.path.join(tmp, "g.snp"), "--haplotype", os.path.join(tmp, "g.haplotype"), fa, base],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    parts = []
+    for d in range(4):                                         # two donors carrying haplotypes of the index, two carrying arbitrary subsets
+        chosen = []
+        for c, hs in zip(clusters, per):
+            chosen += (hs[int(rng.integers(0, len(hs)))] if rng.random() < 0.8 else []) if d < 2 else [s for s in c if rng.random() < 0.5]
+        parts.append(synth.make_reads(synth.apply_snps(contigs, chosen), 5000, 101, 1080 + d, sub_rate=0.004, indel_rate=0.0, n_rate=0.0)[0])
+    rfa = os.path.join(tmp, "r.fa")
+    synth.write_reads_fasta(rfa, np.concatenate(parts))
+    want = _compare(tmp, base, ["-U", rfa], ["-p", "2", "--reorder", "--haplotype"] + mode, ["-p", "2", "--haplotype"] + mode)
+    nohap = os.path.join(tmp, "nohap.sam")
+    subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "2", "--reorder", "-x", base, "-U", rfa, "-S", nohap] + mode, check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert sum(1 for a, b in zip(want, SL.body_lines(nohap)) if a != b) > 100      # the option matters on this input

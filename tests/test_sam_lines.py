@@ -337,3 +337,20 @@ def test_splice_site_alt_index_pairs_and_waves(monkeypatch):
     assert T.run_pairs(1233, 1000, 0.01, 200, show=3)[0] == 0
     monkeypatch.setenv("H2G_FUZZ_TRAN", "1")
     assert W.run_case(1234, 4500, P=2, show=3)[0] == 0
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,every,kw", [(2101, 25, {}), (2102, 40, {"ht_file": False}), (2103, 15, {"extra": ("--spliced",)}),
+                                           (2104, 30, {"extra": ("-k", "10", "--secondary")})])
+def test_haplotype_option(seed, every, kw):
+    """--haplotype (GraphPolicy::useHaplotype): an index built with --snp + --haplotype (or without the file: one haplotype per SNP,
+    gfm.h:1645); reads from donors that carry the index's haplotypes or arbitrary SNP subsets.  An ALT is only walked when a
+    haplotype carries it together with the ALTs already taken (alignWithALTs_recur hi_aligner.h:2898-2996, :3251-3331) — equal to the
+    reference read for read, on an input where the option changes its output"""
+    import fuzz_haplotype as H
+    bad, tmp = H.run_case(seed, 3000, every=every, verbose=2, **kw)
+    assert bad == 0
+    import sam_util as SU
+    _, a = SU.parse_sam(os.path.join(tmp, "ref.sam"))
+    _, b = SU.parse_sam(os.path.join(tmp, "ref_nohap.sam"))
+    assert sum(1 for q in a if a[q] != b[q]) >= (5 if kw.get("ht_file", True) else 1)
