@@ -206,6 +206,22 @@ H2G_MACH_FN void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 		/* spliced_aligner.h:363-366: cushion = alignMate ? rdlen * 0.03 * sc.mm(255) : 0 (no_spliced_alignment only) */ \
 		gv.rc_cushion = (no_spliced && (MATE)) ? (int64_t)((double)mach_sv(M).len * 0.03 * (double)sc.mmpMax) : 0; \
 		M_GOTO(PC_RC_ENTRY); } while(0)
+// sink.bestSplicedUnp1/2() (aln_sink.h:2618-2637): the number of introns of the alignment that set bestUnp — the FIRST reported one with
+// that score, the update being a strict '>'.  nextBWT (hi_aligner.h:4680) and align (:5520) let a strand run that many more partial
+// searches before they give it up against the other strand's best alignment.  Unspliced units never hold a spliced record.
+#if H2G_SPLICE_DB
+H2G_HD uint32_t best_spliced_unp(const MateWS& mw) {
+	if(mw.bestUnp == INT64_MIN) return 0;
+	for(uint32_t i = 0; i < mw.nres; i++) if(mw.res[i].score == mw.bestUnp) {
+		uint32_t n = 0;
+		for(uint32_t k = 0; k < mw.res[i].nedits; k++) n += mw.res[i].edits[k].type == H2G_EDIT_SPL;
+		return n;
+	}
+	return 0;
+}
+#else
+#define best_spliced_unp(MW) 0u
+#endif
 #define MINSC_LIVE(MV) do { if(!P.secondary) { int64_t b_ = mw->bestUnp - gv.rc_cushion; if(b_ > (MV)) (MV) = b_; } } while(0)
 
 H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M);
@@ -273,7 +289,7 @@ again:
 			const int64_t bestScore = mw.bestUnp;
 			if(bestScore >= mw.minsc) {
 				const uint32_t maxmm = (uint32_t)((-bestScore + sc.mmpMax - 1) / sc.mmpMax);
-				if(numSearched > maxmm + 0 + 1) {
+				if(numSearched > maxmm + best_spliced_unp(mw) + 1) {
 					hit.done = 1;
 					if(gv.paired) { if(ow.bestUnp >= ow.minsc && ws->npairs > 0) M_GOTO(PC_GO_AFTER_LOOP); else M_GOTO(PC_NB_PICK); }
 					else M_GOTO(PC_GO_AFTER_LOOP);
@@ -322,7 +338,7 @@ again:
 		if(bestScore < mw->minsc) bestScore = mw->minsc;
 		const uint32_t maxmm = (uint32_t)((-bestScore + sc.mmpMax - 1) / sc.mmpMax);
 		const uint32_t nact = hit.numPartialSearch - hit.numUniqueSearch;
-		if(!P.secondary && nact > maxmm + 0 + 1) { gv.hs_found = 1; M_GOTO(PC_AFTER_ALIGN); }
+		if(!P.secondary && nact > maxmm + best_spliced_unp(*mw) + 1) { gv.hs_found = 1; M_GOTO(PC_AFTER_ALIGN); }
 		M_GOTO(PC_GAH_BEGIN);
 	}
 	case PC_AFTER_ALIGN: {

@@ -167,3 +167,20 @@ def test_haplotype_command_line(tmp_path, mode):
     subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "2", "--reorder", "-x", base, "-U", rfa, "-S", nohap] + mode, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert sum(1 for a, b in zip(want, SL.body_lines(nohap)) if a != b) > 100      # the option matters on this input
+
+
+@needs_ref
+def test_spliced_on_real_sequence_command_line(tmp_path):
+    """the default mode on the reference's own chr22 example contig with introns at its GT..AG pairs (tests/fuzz_real.py): reads whose
+    two strands both align, one of them spliced, in the inverted duplications of real sequence (bestSplicedUnp, hi_aligner.h:4680)"""
+    import fuzz_real as R
+    tmp = str(tmp_path)
+    contigs, reads, _ = R.make_case(9001, 12000)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    rfa = os.path.join(tmp, "r.fa")
+    synth.write_reads_fasta(rfa, reads)
+    want = _compare(tmp, base, ["-U", rfa], ["-p", "2", "--reorder"], ["-p", "2"])
+    assert sum(1 for l in want if "NH:i:1" not in l and "N" in l.split("\t")[5]) > 20      # spliced multi-mappers

@@ -354,3 +354,26 @@ def test_haplotype_option(seed, every, kw):
     _, a = SU.parse_sam(os.path.join(tmp, "ref.sam"))
     _, b = SU.parse_sam(os.path.join(tmp, "ref_nohap.sam"))
     assert sum(1 for q in a if a[q] != b[q]) >= (5 if kw.get("ht_file", True) else 1)
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", ["notemp", "temp", "tran"])
+def test_spliced_on_real_sequence(mode, monkeypatch):
+    """tests/fuzz_real.py: introns at GT..AG pairs of the reference's own chr22 example contig, reads from that transcript (two or three
+    junctions per read).  Real sequence has what random genomes lack — here inverted segmental duplications: a read whose reverse
+    complement aligns spliced and perfectly must still get its forward strand aligned, because nextBWT / align give a strand
+    bestSplicedUnp more partial searches (hi_aligner.h:4680, :5520; the term was a constant 0 until this case found it)"""
+    import fuzz_real as R
+    import fuzz_spliced as F
+    monkeypatch.setattr(F, "make_case", R.make_case)
+    if mode == "tran":
+        monkeypatch.setenv("H2G_FUZZ_TRAN", "1")
+    if mode == "notemp":
+        bad, tmp = F.run_case(9001, 4000, 0.005, known=0.0, verbose=2)
+        import sam_util as SU
+        _, want = SU.parse_sam(os.path.join(tmp, "ref.sam"))
+        assert sum(1 for q in want if len(want[q]) > 1) >= 5              # multi-mappers in the duplications
+    else:
+        import temp_splice as T
+        bad, _ = T.run_case(9001, 4000, P=2, show=3)
+    assert bad == 0
