@@ -46,13 +46,28 @@ def make_haplotypes(snps, rng, window=70, with_file=True):
     return lines, clusters, per
 
 
-def run_case(seed, nreads, every=40, rdlen=101, sub=0.004, verbose=6, extra=(), use=True, glen=200000, ht_file=True):
+def real_example():
+    """the reference's example: 1 Mbp of chr22 and its 3.5 k dbSNP variants (tests/golden)"""
+    import gzip
+    import fuzz_real
+    gold = os.path.join(HERE, "golden")
+    snps = []
+    for ln in gzip.open(os.path.join(gold, "example_22_20-21M.snp.gz"), "rt"):
+        f = ln.split()
+        snps.append((f[0], f[1], "chr1", int(f[3]), f[4]))
+    return [fuzz_real.real_contig()], snps
+
+
+def run_case(seed, nreads, every=40, rdlen=101, sub=0.004, verbose=6, extra=(), use=True, glen=200000, ht_file=True, real=False):
     tmp = tempfile.mkdtemp(prefix="h2hap")
     rng = np.random.default_rng(seed)
-    contigs = [rng.integers(0, 4, size=glen, dtype=np.uint8), rng.integers(0, 4, size=glen // 3, dtype=np.uint8)]
+    if real:
+        contigs, snps = real_example()
+    else:
+        contigs = [rng.integers(0, 4, size=glen, dtype=np.uint8), rng.integers(0, 4, size=glen // 3, dtype=np.uint8)]
+        snps = synth.make_snps(contigs, seed + 5, every=every)
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
-    snps = synth.make_snps(contigs, seed + 5, every=every)
     synth.write_snps(os.path.join(tmp, "g.snp"), snps)
     lines, clusters, per = make_haplotypes(snps, rng)
     with open(os.path.join(tmp, "g.haplotype"), "w") as f:
@@ -111,4 +126,4 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
     every = int(sys.argv[3]) if len(sys.argv) > 3 else 40
     extra = ("--spliced",) if len(sys.argv) > 4 and sys.argv[4] == "1" else ()
-    sys.exit(1 if run_case(seed, n, every, extra=extra)[0] else 0)
+    sys.exit(1 if run_case(seed, n, every, extra=extra, real=bool(os.environ.get("H2G_FUZZ_REAL")))[0] else 0)

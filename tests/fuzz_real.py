@@ -3,7 +3,7 @@
 introns chosen at GT..AG pairs that exist in it, reads drawn from the resulting transcript (short exons: two or three junctions per
 read), optionally over the dbSNP variants of the example (SNP-graph / --ss --exon index).  Installs itself as fuzz_spliced.make_case
 so that every harness (fuzz_spliced, temp_splice, fuzz_tran) runs on it.  usage: fuzz_real.py <seed> <nreads> <mode>, mode in
-notemp | temp | tran | snp | snptemp"""
+notemp | temp | tran | snp | snptemp | pairs | snppairs"""
 import gzip
 import os
 import sys
@@ -77,8 +77,38 @@ def make_case(seed, nreads, rdlen=101, sub=0.005, alt_fn=None, indel=0.0, **_):
     return [g], reads, introns
 
 
+def make_pairs_case(seed, npairs, rdlen=101, sub=0.005, frag_mean=280, frag_sd=40, **_):
+    """fuzz_spliced_pairs.make_case on the real contig: fragments of the transcript, --fr mates"""
+    rdlen = int(os.environ.get("H2G_FUZZ_RDLEN", rdlen))
+    contigs, _, introns = make_case(seed, 1, rdlen=rdlen)
+    g = contigs[0]
+    rng = np.random.default_rng(seed + 3)
+    keep = np.ones(len(g), dtype=bool)
+    for a, b in introns:
+        keep[a:b] = False
+    tx = g[keep]
+    m1 = np.zeros((npairs, rdlen), dtype=np.uint8)
+    m2 = np.zeros((npairs, rdlen), dtype=np.uint8)
+    for i in range(npairs):
+        while True:
+            fl = max(rdlen, int(rng.normal(frag_mean, frag_sd)))
+            s = int(rng.integers(0, len(tx) - fl))
+            f = tx[s:s + fl].copy()
+            if (f < 4).all():
+                break
+        m = rng.random(fl) < sub
+        f = np.where(m, (f + rng.integers(1, 4, size=fl)) & 3, f).astype(np.uint8)
+        if rng.random() < 0.5:
+            f = F.revcomp(f)
+        m1[i] = f[:rdlen]
+        m2[i] = F.revcomp(f)[:rdlen]
+    return [g], m1, m2, introns
+
+
 def install():
     F.make_case = make_case
+    import fuzz_spliced_pairs as FP
+    FP.make_case = make_pairs_case
 
 
 if __name__ == "__main__":
@@ -90,7 +120,12 @@ if __name__ == "__main__":
         os.environ["H2G_FUZZ_SNPS"] = "300"
     if mode == "tran":
         os.environ["H2G_FUZZ_TRAN"] = "1"
-    if mode in ("notemp", "snp"):
+    if mode in ("pairs", "snppairs"):
+        import fuzz_spliced_pairs as FP
+        if mode == "snppairs":
+            os.environ["H2G_FUZZ_SNPS"] = "300"
+        bad = FP.run_case(seed, n, 0.005, known=0.4, show=3)[0]
+    elif mode in ("notemp", "snp"):
         bad = F.run_case(seed, n, 0.005, known=0.5, verbose=3)[0]
     else:
         import temp_splice as T
