@@ -243,6 +243,8 @@ class AlignParams(C.Structure):
                 self.max_alts_tried = int(v); i += 2
             elif o == "--haplotype":
                 self.use_haplotype = 1; i += 1
+            elif o in ("--no-mixed", "--no-discordant"):                      # output only: h2g_sam_set_report_policy
+                i += 1
             elif o == "--no-templatelen-adjustment":                       # output only (TLEN): h2g_sam_set_templatelen_adjustment
                 i += 1
             elif o == "--min-intronlen":

@@ -219,6 +219,7 @@ int main(int argc, char** argv) {
 	std::string known_ss, novel_ss, novel_out;
 	bool tlen_adjust = true, use_haplotype = false;
 	int max_alts_tried = 16;
+	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
 	uint64_t skip = 0, upto = ~0ull;
@@ -256,6 +257,8 @@ int main(int argc, char** argv) {
 		else if(a == "--novel-splicesite-outfile") novel_out = need("--novel-splicesite-outfile");
 		else if(a == "--no-templatelen-adjustment") tlen_adjust = false;
 		else if(a == "--max-altstried") { max_alts_tried = atoi(need("--max-altstried")); if(max_alts_tried < 8) { fprintf(stderr, "--max-altstried arg must be at least 8\n"); return 1; } }
+		else if(a == "--no-mixed") report_mixed = false;                       // hisat2.cpp:1162
+		else if(a == "--no-discordant") report_discordant = false;             // hisat2.cpp:1161
 		else if(a == "--haplotype") use_haplotype = true;                      // hisat2.cpp:1749 (ARG_HAPLOTYPE)
 		else if(a == "--bowtie2-dp") dp = (uint32_t)atoi(need("--bowtie2-dp"));
 		else if(a == "-k" || a == "--max-seeds" || a == "--mp" || a == "--sp" || a == "--np" || a == "--rdg" || a == "--rfg" || a == "--score-min" ||
@@ -443,6 +446,7 @@ int main(int argc, char** argv) {
 	}
 	if(temp_ss || (!nospliced && !novel_out.empty())) h2g_sam_collect_novel_sites(sam, 1);   // SpliceSiteDB's `write` (hisat2.cpp:4092)
 	h2g_sam_set_templatelen_adjustment(sam, tlen_adjust);
+	h2g_sam_set_report_policy(sam, report_discordant, report_mixed);
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);
 	h2g_sam_set_rna_strandness(sam, strandness);

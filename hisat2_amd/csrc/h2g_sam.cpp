@@ -45,6 +45,7 @@ struct h2g_sam {
 	uint32_t ssdb_window = 0;
 	int rna_strandness = 0;                               // --rna-strandness: 0 unknown, 1 F, 2 R, 3 FR, 4 RF (read.h:30)
 	bool collect_novel = false;                           // h2g_sam_collect_novel_sites
+	bool report_discordant = true, report_mixed = true;   // --no-discordant / --no-mixed clear them (ReportingParams::discord / mixed aln_sink.h:272)
 	bool tlen_adjust = true;                              // --no-templatelen-adjustment clears it (aln_sink.h:2070-2076)
 	// what SpliceSiteDB keeps per site for --novel-splicesite-outfile (splice_site.cpp:243-276): the number of lines written across it
 	// and the smallest edit distance among them; file / index sites enter with 0 / 0 (SpliceSite::init splice_site.h:237)
@@ -666,6 +667,7 @@ extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
 	if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
 	return o.size();
 }
+extern "C" void h2g_sam_set_report_policy(h2g_sam* S, int discordant, int mixed) { if(S) { S->report_discordant = discordant != 0; S->report_mixed = mixed != 0; } }
 extern "C" void h2g_sam_set_no_unal(h2g_sam* S, int on) { if(S) S->no_unal = on != 0; }
 extern "C" void h2g_sam_set_secondary(h2g_sam* S, int on) { if(S) S->secondary = on != 0; }
 // SpliceSiteDB::read(ifstream&, known) splice_site.cpp:727-776: whitespace-separated (name, left, right, strand) records; names the
@@ -855,7 +857,7 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 				append_mate(*S, o, rd[0], &rd[1], a, b, summ, f1, sel.size());
 				append_mate(*S, o, rd[1], &rd[0], b, a, summ, f2, sel.size());
 			}
-		} else if(n1 == 1 && n2 == 1) {
+		} else if(S->report_discordant && n1 == 1 && n2 == 1) {
 			// discordant: one unpaired alignment per mate (ReportingState::finish -> convertUnpairedToDiscordant)
 			Summ summ;
 			summ.paired = true;
@@ -871,9 +873,10 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 		} else {
 			Summ s1, s2;
 			sel1.clear(); sel2.clear();
-			if(n1) { keys.clear(); for(size_t k = 0; k < n1; k++) keys.push_back(score_of(r1[k])); select_by_score(keys, std::min<size_t>(khits, n1), rnd, sel1, S->secondary); }
-			if(n2) { keys.clear(); for(size_t k = 0; k < n2; k++) keys.push_back(score_of(r2[k])); select_by_score(keys, std::min<size_t>(khits, n2), rnd, sel2, S->secondary); }
-			summ_unpaired(s1, 0, r1, n1); summ_unpaired(s1, 1, r2, n2);
+			const size_t u1 = S->report_mixed ? n1 : 0, u2 = S->report_mixed ? n2 : 0;                      // --no-mixed: ReportingState::getReport leaves the unpaired counts at 0 (aln_sink.cpp:280)
+			if(u1) { keys.clear(); for(size_t k = 0; k < u1; k++) keys.push_back(score_of(r1[k])); select_by_score(keys, std::min<size_t>(khits, u1), rnd, sel1, S->secondary); }
+			if(u2) { keys.clear(); for(size_t k = 0; k < u2; k++) keys.push_back(score_of(r2[k])); select_by_score(keys, std::min<size_t>(khits, u2), rnd, sel2, S->secondary); }
+			summ_unpaired(s1, 0, r1, u1); summ_unpaired(s1, 1, r2, u2);
 			s2 = s1;
 			met.nconcord_0++;
 			if(sel1.empty()) met.nunp_0_0++; else if(sel1.size() == 1) met.nunp_0_uni1++; else met.nunp_0_uni2++;

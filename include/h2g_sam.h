@@ -32,6 +32,10 @@ H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
 H2G_EXPORT size_t     h2g_sam_summary(const h2g_sam*, char* out, size_t cap);
 /* --no-unal: lines of reads / mates that failed to align are not printed (aln_sink.h:3040) */
 H2G_EXPORT void       h2g_sam_set_no_unal(h2g_sam*, int on);
+/* --no-discordant (discordant = 0): a pair with one alignment per mate that is not concordant is not converted into a discordant pair
+ * (ReportingState::nextRead aln_sink.cpp:38); --no-mixed (mixed = 0): mates of a pair without a paired alignment are reported unaligned
+ * (ReportingState::getReport aln_sink.cpp:280).  Both default to 1 (hisat2.cpp:353-354). */
+H2G_EXPORT void       h2g_sam_set_report_policy(h2g_sam*, int discordant, int mixed);
 /* --secondary: the sink's -k selection for pairs keeps lower-scoring alignments (aln_sink.h:2733-2745) */
 H2G_EXPORT void       h2g_sam_set_secondary(h2g_sam*, int on);
 /* reads a --known-splicesite-infile / --novel-splicesite-infile (SpliceSiteDB::read splice_site.cpp:727): returns the number of

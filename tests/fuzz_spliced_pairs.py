@@ -61,6 +61,9 @@ def make_case(seed, npairs, rdlen=101, sub=0.005, glen=400000, nintrons=300, fra
             f = FS.revcomp(f)
         m1[i] = f[:rdlen]
         m2[i] = FS.revcomp(f)[:rdlen]
+        if rng.random() < float(os.environ.get("H2G_FUZZ_CHIMERA", "0")):    # mate 2 from elsewhere (discordant pairs), sometimes same strand
+            s2 = int(rng.integers(0, len(tx) - rdlen))
+            m2[i] = tx[s2:s2 + rdlen] if rng.random() < 0.5 else FS.revcomp(tx[s2:s2 + rdlen])
     return ([extra[0], g, extra[2]] if extra else [g]), m1, m2, introns
 
 

@@ -65,6 +65,9 @@ def _score_min(L, h, options):
     if options and "--novel-splicesite-outfile" in options:
         L.h2g_sam_collect_novel_sites.argtypes = [C.c_void_p, C.c_int]
         L.h2g_sam_collect_novel_sites(h, 1)
+    if options and ("--no-mixed" in options or "--no-discordant" in options):
+        L.h2g_sam_set_report_policy.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.h2g_sam_set_report_policy(h, 0 if "--no-discordant" in options else 1, 0 if "--no-mixed" in options else 1)
     if options and "--no-templatelen-adjustment" in options:
         L.h2g_sam_set_templatelen_adjustment.argtypes = [C.c_void_p, C.c_int]
         L.h2g_sam_set_templatelen_adjustment(h, 0)

@@ -377,3 +377,16 @@ def test_spliced_on_real_sequence(mode, monkeypatch):
         import temp_splice as T
         bad, _ = T.run_case(9001, 4000, P=2, show=3)
     assert bad == 0
+
+
+@needs_ref
+@pytest.mark.parametrize("extra", [("--no-mixed",), ("--no-discordant",), ("--no-mixed", "--no-discordant", "-k", "3")])
+def test_no_mixed_no_discordant(extra, monkeypatch):
+    """--no-mixed / --no-discordant (ReportingParams::mixed / discord): mates without a paired alignment are reported unaligned; a pair
+    with one alignment per mate is not turned into a discordant pair — lines and summary equal the reference's on pairs of which 15 %
+    have their second mate drawn from elsewhere"""
+    monkeypatch.setenv("H2G_FUZZ_CHIMERA", "0.15")
+    import fuzz_spliced_pairs as F
+    bad, tmp = F.run_case(7301, 2000, sub=0.03, show=3, extra=extra)
+    assert bad == 0
+    assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
