@@ -648,14 +648,18 @@ extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
 		line("    ", m.nconcord_0, m.npaired, "aligned concordantly 0 times");
 		line("    ", m.nconcord_uni1, m.npaired, "aligned concordantly exactly 1 time");
 		line("    ", m.nconcord_uni2, m.npaired, "aligned concordantly >1 times");
-		o += "    ----\n    "; o += std::to_string(m.nconcord_0); o += " pairs aligned concordantly 0 times; of these:\n";
-		line("      ", m.ndiscord, m.nconcord_0, "aligned discordantly 1 time");
+		if(S->report_discordant) {                          // aln_sink.h:1724-1734
+			o += "    ----\n    "; o += std::to_string(m.nconcord_0); o += " pairs aligned concordantly 0 times; of these:\n";
+			line("      ", m.ndiscord, m.nconcord_0, "aligned discordantly 1 time");
+		}
 		const uint64_t n0 = m.nconcord_0 - m.ndiscord;
-		o += "    ----\n    "; o += std::to_string(n0); o += " pairs aligned 0 times concordantly or discordantly; of these:\n";
-		o += "      "; o += std::to_string(n0 * 2); o += " mates make up the pairs; of these:\n";
-		line("        ", m.nunp_0_0, n0 * 2, "aligned 0 times");
-		line("        ", m.nunp_0_uni1, n0 * 2, "aligned exactly 1 time");
-		line("        ", m.nunp_0_uni2, n0 * 2, "aligned >1 times");
+		if(S->report_mixed) {                               // :1736-1772
+			o += "    ----\n    "; o += std::to_string(n0); o += " pairs aligned 0 times concordantly or discordantly; of these:\n";
+			o += "      "; o += std::to_string(n0 * 2); o += " mates make up the pairs; of these:\n";
+			line("        ", m.nunp_0_0, n0 * 2, "aligned 0 times");
+			line("        ", m.nunp_0_uni1, n0 * 2, "aligned exactly 1 time");
+			line("        ", m.nunp_0_uni2, n0 * 2, "aligned >1 times");
+		}
 	}
 	if(m.nunpaired > 0) {
 		line("  ", m.nunpaired, m.nread, "were unpaired; of these:");
