@@ -186,7 +186,7 @@ class AlignParams(C.Structure):
                 ("pen_canintronlen_type", u32), ("pen_noncanintronlen_type", u32), ("first_read_id", u32),
                 ("pen_canintronlen_const", C.c_double), ("pen_canintronlen_coeff", C.c_double),
                 ("pen_noncanintronlen_const", C.c_double), ("pen_noncanintronlen_coeff", C.c_double),
-                ("min_anchor_len", u32), ("min_anchor_len_noncan", u32), ("xs_only", u32), ("use_haplotype", u32), ("max_alts_tried", u32), ("pad3_", u32)]
+                ("min_anchor_len", u32), ("min_anchor_len_noncan", u32), ("xs_only", u32), ("use_haplotype", u32), ("max_alts_tried", u32), ("max_frag_len", u32), ("min_frag_len", u32), ("pe_orientation", u32), ("nofw", u32), ("norc", u32)]
 
     def apply_options(self, opts, linear=None):
         """apply a list of reference command-line options (['-k', '3', '--mp', '4,2', ...]) to this block; returns leftovers.
@@ -239,6 +239,16 @@ class AlignParams(C.Structure):
                 i += 1
             elif o in ("--rna-strandness", "--novel-splicesite-outfile"):   # output only: h2g_sam_set_rna_strandness / h2g_sam_novel_splice_sites_text
                 i += 2
+            elif o in ("-I", "--minins"):
+                self.min_frag_len = int(v); i += 2
+            elif o in ("--fr", "--rf", "--ff"):
+                self.pe_orientation = {"--fr": 0, "--rf": 1, "--ff": 2}[o]; i += 1
+            elif o == "--nofw":
+                self.nofw = 1; i += 1
+            elif o == "--norc":
+                self.norc = 1; i += 1
+            elif o in ("-X", "--maxins"):
+                self.max_frag_len = int(v); i += 2
             elif o == "--max-altstried":
                 self.max_alts_tried = int(v); i += 2
             elif o == "--haplotype":

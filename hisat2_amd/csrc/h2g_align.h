@@ -697,6 +697,20 @@ H2G_HD bool hit_equal(const h2g_ghit* a, const h2g_ghit* b) {
 	return true;
 }
 
+// -I, --fr/--rf/--ff, --nofw/--norc: compiled into the units that define H2G_SPLICE_DB 1 (and the host instantiation), which run either mode;
+// the units built without them keep the code they were verified with.  pe_flags: bit 0 gMate1fw, bit 1 gMate2fw, bit 2 gNofw, bit 3 gNorc.
+#ifndef H2G_EXT_OPTS
+#ifdef H2G_SPLICE_DB
+#define H2G_EXT_OPTS H2G_SPLICE_DB
+#else
+#define H2G_EXT_OPTS 1
+#endif
+#endif
+#define H2G_PE_DEFAULT 1u
+H2G_HD uint32_t pe_flags_from(const h2g_align_params& p) {
+	const uint32_t m1 = p.pe_orientation == 1 ? 0u : 1u, m2 = p.pe_orientation == 0 ? 0u : 1u;   // fr: 1,0  rf: 0,1  ff: 1,1
+	return m1 | (m2 << 1) | (p.nofw ? 4u : 0u) | (p.norc ? 8u : 0u);
+}
 // ---------------------------------------------------------------------------------------- per-read workspace
 struct AlnParams {
 	uint32_t khits, kseeds, no_spliced, secondary;
@@ -723,8 +737,10 @@ inline AlnParams aln_params_from(const h2g_align_params& p, bool no_spliced, boo
 	AlnParams P;
 	P.khits = p.khits; P.kseeds = p.kseeds; P.no_spliced = no_spliced ? 1 : 0; P.secondary = p.secondary;
 	P.minIntronLen = p.min_intronlen; P.maxIntronLen = p.max_intronlen; P.minAnchorLen = p.min_anchor_len; P.minAnchorLen_noncan = p.min_anchor_len_noncan; P.minK_local = 8;
-	P.xs_only = p.xs_only;   // tp.h, hi_aligner.h:3986
-	P.pseudogeneStop = (linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = 1000;
+	// xs_only also carries the options of H2G_EXT_OPTS (ctx_ext_opts below): bits 1-4 = pe_flags ^ default, bits 8.. = -I.  The kernel argument
+	// block keeps its size and offsets that way, and with them the code of the units built without those options (which only ever see 0 / 1)
+	P.xs_only = (p.xs_only ? 1u : 0u) | ((pe_flags_from(p) ^ H2G_PE_DEFAULT) << 1) | (p.min_frag_len << 8);   // tp.h, hi_aligner.h:3986
+	P.pseudogeneStop = (linear && !no_spliced) ? 1 : 0; P.anchorStop = 1; P.maxFragLen = p.max_frag_len ? p.max_frag_len : 1000;
 	P.bowtie2_dp = p.bowtie2_dp;
 	P.scoreMinType = p.score_min_type; P.scoreMinConst = p.score_min_const; P.scoreMinCoeff = p.score_min_coeff;
 	P.sc.mmpMax = p.mm_max; P.sc.mmpMin = p.mm_min; P.sc.nPen = p.n_pen; P.sc.rdGapConst = p.rdg_const; P.sc.rdGapLinear = p.rdg_linear;
@@ -745,7 +761,7 @@ inline void align_params_defaults(h2g_align_params* p, bool linear) {
 	p->min_intronlen = 20; p->max_intronlen = 500000; p->pen_cansplice = 0; p->pen_noncansplice = 12;   // hisat2.cpp:493-499
 	p->pen_canintronlen_type = 4; p->pen_canintronlen_const = -8.0; p->pen_canintronlen_coeff = 1.0;
 	p->pen_noncanintronlen_type = 4; p->pen_noncanintronlen_const = -8.0; p->pen_noncanintronlen_coeff = 1.0;
-	p->min_anchor_len = 7; p->min_anchor_len_noncan = 14; p->xs_only = 0; p->use_haplotype = 0; p->max_alts_tried = 16; p->pad3_ = 0;
+	p->min_anchor_len = 7; p->min_anchor_len_noncan = 14; p->xs_only = 0; p->use_haplotype = 0; p->max_alts_tried = 16; p->max_frag_len = 1000; p->min_frag_len = 0; p->pe_orientation = 0; p->nofw = 0; p->norc = 0;
 }
 
 // One reported alignment = the arguments reportHit (hi_aligner.h:6064-6166) hands to AlnRes::init
@@ -936,7 +952,13 @@ struct AlnCtx {
 	struct GraphWS* gws = nullptr;    // graph index: this lane's scratch for one primitive (group walk, ALT extension)
 	struct GraphSlot* gsl = nullptr;  // graph index: the graph state of the read being worked on
 	bool graph = false;               // set from a kernel template constant so that the linear kernels carry no graph code
+#if H2G_EXT_OPTS
+	uint32_t pe_flags = H2G_PE_DEFAULT, min_frag_len = 0;
+#endif
 };
+#if H2G_EXT_OPTS
+H2G_HD void ctx_ext_opts(AlnCtx& C, const AlnParams& P) { C.pe_flags = ((P.xs_only >> 1) & 15u) ^ H2G_PE_DEFAULT; C.min_frag_len = P.xs_only >> 8; }
+#endif
 
 // Per-lane scratch of the graph paths (allocated only for graph indexes, so the linear workspace keeps its size):
 // group-walk state, ALT-extension state, and the node range + in-edge list of every partial hit (BWTHit::_node_top,
@@ -1118,8 +1140,37 @@ H2G_HD bool pe_concordant(int64_t off1, uint32_t len1, bool fw1, int64_t off2, u
 	return true;
 }
 
-// pairReads hi_aligner.h:5948-6055 (non-repeat alignments, gMate1fw = true, gMate2fw = false)
-H2G_HD void al_pair_reads(const AlnParams& P, AlignWS* ws, uint32_t rdlen1, uint32_t rdlen2) {
+#if H2G_EXT_OPTS
+// the same with the policy of --fr / --rf / --ff and -I (pe.cpp:38-133); (off1, len1, fw1) is the LEFT alignment (hi_aligner.h:6020-6029)
+H2G_HD bool pe_concordant_ext(int64_t off1, uint32_t len1, bool fw1, int64_t off2, uint32_t len2, bool fw2, uint32_t maxfrag_, uint32_t minfrag_, uint32_t pe_flags) {
+	uint64_t maxfrag = maxfrag_;
+	if(len1 > maxfrag) maxfrag = len1;
+	if(len2 > maxfrag) maxfrag = len2;
+	const uint64_t minfrag = minfrag_ < 1 ? 1 : minfrag_;
+	const bool m1fw = (pe_flags & 1u) != 0, m2fw = (pe_flags & 2u) != 0;
+	bool oneLeft;
+	if(m1fw == m2fw) { if(fw1 != fw2) return false; oneLeft = m1fw ? fw1 : !fw1; }   // PE_POLICY_FF / _RR
+	else { if(fw1 == fw2) return false; oneLeft = m1fw ? fw1 : !fw1; }              // PE_POLICY_FR / _RF
+	const int64_t fraglo = off1 < off2 ? off1 : off2;
+	const int64_t h1 = off1 + len1, h2 = off2 + len2;
+	const int64_t fraghi = h1 > h2 ? h1 : h2;
+	const uint64_t frag = (uint64_t)(fraghi - fraglo);
+	if(frag > maxfrag || frag < minfrag) return false;
+	const int64_t lo1 = off1, hi1 = off1 + len1 - 1, lo2 = off2, hi2 = off2 + len2 - 1;
+	const bool containment = (lo1 >= lo2 && hi1 <= hi2) || (lo2 >= lo1 && hi2 <= hi1);
+	const bool olap = (lo1 <= lo2 && hi1 >= lo2) || (lo1 <= hi2 && hi1 >= hi2) || containment;
+	if(!olap) { if((oneLeft && lo2 < lo1) || (!oneLeft && lo1 < lo2)) return false; }
+	if((oneLeft && (hi1 > hi2 || lo2 < lo1)) || (!oneLeft && (hi2 > hi1 || lo1 < lo2))) return false;   // dovetail not allowed
+	return true;
+}
+#endif
+
+// pairReads hi_aligner.h:5948-6055 (non-repeat alignments; without H2G_EXT_OPTS: gMate1fw = true, gMate2fw = false)
+H2G_HD void al_pair_reads(const AlnParams& P, AlignWS* ws, uint32_t rdlen1, uint32_t rdlen2
+#if H2G_EXT_OPTS
+                          , uint32_t pe_flags = H2G_PE_DEFAULT, uint32_t min_frag_len = 0
+#endif
+                          ) {
 	MateWS& m1 = ws->m[0];
 	MateWS& m2 = ws->m[1];
 	const uint32_t start_i = ws->insp_i, start_j = ws->insp_j;
@@ -1131,18 +1182,32 @@ H2G_HD void al_pair_reads(const AlnParams& P, AlignWS* ws, uint32_t rdlen1, uint
 			if(r1.tidx != r2.tidx) continue;
 			const uint32_t e1 = rec_ref_extent(r1), e2 = rec_ref_extent(r2);
 			int64_t l = r1.toff, r = (int64_t)r1.toff + e1 - 1, l2 = r2.toff, rr2 = (int64_t)r2.toff + e2 - 1;
+#if H2G_EXT_OPTS
+			const bool m1fw = (pe_flags & 1u) != 0, m2fw = (pe_flags & 2u) != 0;
+			if((r1.fw != 0) == m1fw) { if((r2.fw != 0) != m2fw) continue; }
+			else {
+				if((r2.fw != 0) == m2fw) continue;
+				int64_t t = l; l = l2; l2 = t; t = r; r = rr2; rr2 = t;
+			}
+#else
 			if(r1.fw) { if(r2.fw) continue; }
 			else {
 				if(!r2.fw) continue;
 				int64_t t = l; l = l2; l2 = t; t = r; r = rr2; rr2 = t;
 			}
+#endif
 			if(l > l2) continue;
 			if(r > rr2) continue;
 			if(r + (int64_t)P.maxIntronLen < l2) continue;
 			bool pass = true;
 			if(P.no_spliced) {
+#if H2G_EXT_OPTS
+				if(r1.toff < r2.toff) pass = pe_concordant_ext(r1.toff, e1, r1.fw != 0, r2.toff, e2, r2.fw != 0, P.maxFragLen, min_frag_len, pe_flags);
+				else                  pass = pe_concordant_ext(r2.toff, e2, r2.fw != 0, r1.toff, e1, r1.fw != 0, P.maxFragLen, min_frag_len, pe_flags);
+#else
 				if(r1.toff < r2.toff) pass = pe_concordant(r1.toff, e1, r1.fw != 0, r2.toff, e2, r2.fw != 0, P.maxFragLen);
 				else                  pass = pe_concordant(r2.toff, e2, r2.fw != 0, r1.toff, e1, r1.fw != 0, P.maxFragLen);
+#endif
 			}
 			if(!P.no_spliced || pass) {
 				int64_t threshold = ws->bestPair;

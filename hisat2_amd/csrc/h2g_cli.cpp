@@ -218,7 +218,8 @@ int main(int argc, char** argv) {
 	bool fasta = false, nospliced = false, notempss = false, nohead = false, parse_only = false, no_unal = false;
 	std::string known_ss, novel_ss, novel_out;
 	bool tlen_adjust = true, use_haplotype = false;
-	int max_alts_tried = 16;
+	int max_alts_tried = 16, max_frag_len = 1000, min_frag_len = 0, pe_orientation = 0;
+	bool nofw = false, norc = false;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -257,6 +258,13 @@ int main(int argc, char** argv) {
 		else if(a == "--novel-splicesite-outfile") novel_out = need("--novel-splicesite-outfile");
 		else if(a == "--no-templatelen-adjustment") tlen_adjust = false;
 		else if(a == "--max-altstried") { max_alts_tried = atoi(need("--max-altstried")); if(max_alts_tried < 8) { fprintf(stderr, "--max-altstried arg must be at least 8\n"); return 1; } }
+		else if(a == "-X" || a == "--maxins") { max_frag_len = atoi(need("-X")); if(max_frag_len < 1) { fprintf(stderr, "-X arg must be at least 1\n"); return 1; } }
+		else if(a == "-I" || a == "--minins") { min_frag_len = atoi(need("-I")); if(min_frag_len < 0) { fprintf(stderr, "-I arg must be positive\n"); return 1; } }
+		else if(a == "--fr") pe_orientation = 0;                               // hisat2.cpp:1166-1168
+		else if(a == "--rf") pe_orientation = 1;
+		else if(a == "--ff") pe_orientation = 2;
+		else if(a == "--nofw") nofw = true;                                    // hisat2.cpp:1337-1338
+		else if(a == "--norc") norc = true;
 		else if(a == "--no-mixed") report_mixed = false;                       // hisat2.cpp:1162
 		else if(a == "--no-discordant") report_discordant = false;             // hisat2.cpp:1161
 		else if(a == "--haplotype") use_haplotype = true;                      // hisat2.cpp:1749 (ARG_HAPLOTYPE)
@@ -397,6 +405,8 @@ int main(int argc, char** argv) {
 	P.xs_only = xs_only ? 1 : 0;
 	P.use_haplotype = use_haplotype ? 1 : 0;
 	P.max_alts_tried = (uint32_t)max_alts_tried;
+	P.max_frag_len = (uint32_t)max_frag_len;
+	P.min_frag_len = (uint32_t)min_frag_len; P.pe_orientation = (uint32_t)pe_orientation; P.nofw = nofw ? 1 : 0; P.norc = norc ? 1 : 0;
 	h2g_align_params_presets(&P, ix, saw_k ? 1 : 0, k_arg, max_seeds_arg, sensitive ? 1 : 0, very_sensitive ? 1 : 0);
 	if(P.min_intronlen > P.max_intronlen) {   // hisat2.cpp:4278
 		fprintf(stderr, "--min-intronlen(%u) should not be greater than --max-intronlen(%u)\n", P.min_intronlen, P.max_intronlen);

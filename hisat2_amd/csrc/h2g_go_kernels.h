@@ -137,6 +137,9 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	// combineWith temp_scores: one block per wave, lane-interleaved
 	C.sc = (int64_t*)(A.sc_base + (tid >> 6) * (size_t)(64 * 2 * H2G_COMBINE_MAXLEN * sizeof(int64_t))) + lane; C.sc_stride = 64;
 	C.ssdb = &A.ssdb; C.rdid_base = A.rdid_base;
+#if H2G_EXT_OPTS
+	ctx_ext_opts(C, A.P);
+#endif
 	C.alts = &A.alts; C.gws = A.gws_base ? (GraphWS*)(A.gws_base + tid * A.gws_stride) : nullptr; C.graph = GRAPH;
 	const size_t slot0 = (size_t)blockIdx.x * H2G_GO_SLOTS;
 	Mach M;

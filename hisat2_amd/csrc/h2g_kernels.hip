@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#define H2G_EXT_OPTS 0      // likewise -I / --fr --rf --ff / --nofw --norc (h2g_align.h): go() units only
 #define H2G_HAPLOTYPE 0     // the primitive kernels of this unit (k_extend_alts, k_adjust_alt) run without haplotype lists; go() units: h2g_graph.h
 #include "h2g_core.h"
 #include "h2g_host_index.h"
@@ -1473,7 +1474,9 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(!s->has_names || (paired && !s->has_mates)) { snprintf(g_err, sizeof g_err, "align: read names (h2g_set_read_names)%s not set", paired ? " / mates (h2g_set_mates)" : ""); return H2G_ERR_ARG; }
 	const bool linear = s->ix->dg.linear != 0;
 	// --haplotype is compiled into the units that also carry the splice-site database (H2G_HAPLOTYPE, h2g_graph.h); they run either mode
-	const bool spl = !p->no_spliced_alignment || (p->use_haplotype && !linear);
+	// ... and so are -I, --rf / --ff, --nofw / --norc (H2G_EXT_OPTS, h2g_align.h)
+	const bool ext_opts = pe_flags_from(*p) != H2G_PE_DEFAULT || p->min_frag_len != 0;
+	const bool spl = !p->no_spliced_alignment || (p->use_haplotype && !linear) || ext_opts;
 	if(!p->no_spliced_alignment) {
 		// spliced alignment: combineWith places introns (hi_aligner.h:1588-1739) and every read is independent when novel splice
 		// sites are not shared (--no-temp-splicesite); the shared SpliceSiteDB of the default mode and graph indexes are not built
@@ -1493,7 +1496,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		snprintf(g_err, sizeof g_err, "align: -k %u / --max-seeds %u outside the built range (-k 1..%u, --max-seeds <= %u)", p->khits, p->kseeds, (unsigned)H2G_SELECT_CAP, bcaps[0]);
 		return H2G_ERR_ARG;
 	}
-	if(p->bowtie2_dp > 2) return H2G_ERR_ARG;
+	if(p->bowtie2_dp > 2 || p->pe_orientation > 2 || p->min_frag_len >= (1u << 24)) return H2G_ERR_ARG;
 	if(p->max_alts_tried && p->max_alts_tried < 8) { snprintf(g_err, sizeof g_err, "align: --max-altstried arg must be at least 8"); return H2G_ERR_ARG; }
 	if(p->bowtie2_dp) {
 		if(s->max_read_len == 0) return H2G_ERR_ARG;

@@ -206,6 +206,11 @@ H2G_MACH_FN void mach_begin(Mach& M, uint32_t read, bool paired_input) {
 		/* spliced_aligner.h:363-366: cushion = alignMate ? rdlen * 0.03 * sc.mm(255) : 0 (no_spliced_alignment only) */ \
 		gv.rc_cushion = (no_spliced && (MATE)) ? (int64_t)((double)mach_sv(M).len * 0.03 * (double)sc.mmpMax) : 0; \
 		M_GOTO(PC_RC_ENTRY); } while(0)
+#if H2G_EXT_OPTS
+#define H2G_XS_ONLY(P_) (((P_).xs_only & 1u) != 0)      // the upper bits carry -I and the pair orientation (aln_params_from)
+#else
+#define H2G_XS_ONLY(P_) ((P_).xs_only != 0)
+#endif
 // sink.bestSplicedUnp1/2() (aln_sink.h:2618-2637): the number of introns of the alignment that set bestUnp — the FIRST reported one with
 // that score, the update being a strict '>'.  nextBWT (hi_aligner.h:4680) and align (:5520) let a strand run that many more partial
 // searches before they give it up against the other strand's best alignment.  Unspliced units never hold a spliced record.
@@ -273,6 +278,13 @@ again:
 		int rdi = -1, fwi = -1;
 		int64_t maxScore = INT64_MIN;
 		for(uint32_t r = 0; r < gv.nm; r++) for(int k = 0; k < 2; k++) {
+#if H2G_EXT_OPTS
+			{   // _nofw / _norc of the mate in this slot (hisat2.cpp:3449-3452, hi_aligner.h:4875)
+				const bool mfw = gv.rd_sel[1] != 1 || ((C.pe_flags >> (r ^ gv.slot0)) & 1u) != 0;   // paired input (also a lone mate of it): gMate1fw / gMate2fw
+				const bool gnofw = (C.pe_flags & 4u) != 0, gnorc = (C.pe_flags & 8u) != 0;
+				if(k == 0 ? (mfw ? gnofw : gnorc) : (mfw ? gnorc : gnofw)) continue;
+			}
+#endif
 			const RBHit& h = ws->m[r ^ gv.slot0].rb[k];
 			if(h.done) continue;
 			int64_t cs = rb_search_score(h, minK);
@@ -349,7 +361,11 @@ again:
 		M_GOTO(PC_NB_PICK);
 	}
 	case PC_PAIR_READS: {
+#if H2G_EXT_OPTS
+		al_pair_reads(P, ws, gv.rdlens[0], gv.rdlens[1], C.pe_flags, C.min_frag_len);
+#else
 		al_pair_reads(P, ws, gv.rdlens[0], gv.rdlens[1]);
+#endif
 		M_GOTO(gv.pr_ret_pc);
 	}
 	// no concordant pair: use each mate's alignments as anchors for the other mate (hi_aligner.h:4092-4148)
@@ -371,7 +387,11 @@ again:
 		AL_TRACE(" alignMate anchor mate %u res %u fw %d toff %u\n", gv.mp_i, gv.mp_j, (int)fw, r.toff);
 		// alignMate hi_aligner.h:5579-5770: anchor the OTHER mate near (tidx, toff) through the local index
 		gv.am_fw = fw; gv.am_tidx = r.tidx; gv.am_toff = r.toff;
+#if H2G_EXT_OPTS
+		gv.sv_rdi = 1 - gv.mp_i; gv.sv_fw = (fw == ((C.pe_flags & 2u) != 0)) ? (C.pe_flags & 1u) != 0 : (C.pe_flags & 2u) != 0;   // ofw = (fw == gMate2fw ? gMate1fw : gMate2fw) hi_aligner.h:5605
+#else
 		gv.sv_rdi = 1 - gv.mp_i; gv.sv_fw = !fw;                     // ofw = (fw == gMate2fw ? gMate1fw : gMate2fw) = !fw
+#endif
 		gv.mw_slot = 1 - gv.mp_i;
 		ws->nghits = 0;
 		gv.am_lidx = local_index_of(*C.ls, r.tidx, r.toff);
@@ -691,7 +711,7 @@ again:
 					M_GOTO(PC_FS_L_LOOP);
 				}
 #endif
-				al_report(ws, mw, &hit, rdlen, minsc, P.xs_only != 0);
+				al_report(ws, mw, &hit, rdlen, minsc, H2G_XS_ONLY(P));
 				if(hit.score > f.maxsc) f.maxsc = hit.score;
 			}
 			RC_RET(f.maxsc);
@@ -862,7 +882,7 @@ again:
 			if(!P.secondary && can->score < f.prev_score) continue;
 			if(i > 0 && !al_is_searched(mw, can)) al_add_searched(ws, mw, can);
 			if(!al_redundant(mw, can, rdlen)) {
-				al_report(ws, mw, can, rdlen, gv.rc_minsc, P.xs_only != 0);
+				al_report(ws, mw, can, rdlen, gv.rc_minsc, H2G_XS_ONLY(P));
 				if(can->score > f.maxsc) f.maxsc = can->score;
 			}
 		}

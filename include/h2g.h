@@ -298,7 +298,14 @@ typedef struct {
 	uint32_t use_haplotype;
 	/* --max-altstried (GraphPolicy::maxAltsTried, default 16, at least 8: hisat2.cpp:521, :1745): ALTs one extension may walk through
 	 * (hi_aligner.h:2794) and, / 4, the offset combinations adjustWithALT tries (:2313, :2423) */
-	uint32_t max_alts_tried, pad3_;
+	uint32_t max_alts_tried;
+	/* -X / --maxins (PairedEndPolicy::maxfrag, default 1000 hisat2.cpp:345): the longest fragment of a concordant pair (pe.cpp:38; checked
+	 * under --no-spliced-alignment, hi_aligner.h:6018) and half the window alignMate searches the other mate in (:5688) */
+	uint32_t max_frag_len;
+	/* -I / --minins (PairedEndPolicy::minfrag, default 0); --fr / --rf / --ff as pe_orientation 0 / 1 / 2 (gMate1fw, gMate2fw hisat2.cpp:1166-1168:
+	 * the strand pair a concordant pair has, hi_aligner.h:5605, :6003, pe.cpp:59-83); --nofw / --norc: the strand of the READ (of mate 1's
+	 * fragment strand for pairs, hisat2.cpp:3449-3452) that is not searched (hi_aligner.h:4875) */
+	uint32_t min_frag_len, pe_orientation, nofw, norc;
 } h2g_align_params;
 /* number of visible HIP devices (0 without a GPU: the library has no CPU path) */
 H2G_EXPORT int        h2g_device_count(void);

@@ -261,6 +261,7 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	}
 	C->g = &e->dg; C->ref = &e->dr; C->ls = &e->dls; C->P = P;
 	C->ssdb = no_spliced ? nullptr : &e->dssdb; C->rdid_base = e->rdid_base;
+	ctx_ext_opts(*C, *P);
 	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
 	C->sw = e->sw.data();
 	static GraphWS gws_;

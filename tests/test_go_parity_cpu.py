@@ -102,3 +102,30 @@ def test_live_reference_pairs_graph_index(monkeypatch):
     monkeypatch.setattr(F, "SNPS", 200)
     bad, _ = F.run_case(verbose=3, seed=108, npairs=800, rdlen=101, sub=0.01)
     assert bad == 0
+
+
+def _rc(m):
+    import numpy as np
+    return np.where(m[:, ::-1] > 3, 4, 3 - m[:, ::-1]).astype(np.uint8)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("opts,library", [(("--ff",), "ff"), (("--rf",), "rf"), (("--rf",), "fr"), (("-I", "250", "-X", "330"), "fr"),
+                                           (("--nofw",), "fr"), (("--norc", "--rf"), "rf"), (("-X", "2000"), "fr")])
+def test_live_reference_pair_policy_options(opts, library, monkeypatch):
+    """-I / -X (PairedEndPolicy min / max fragment), --fr / --rf / --ff (gMate1fw, gMate2fw: the other mate's strand in alignMate,
+    the orientation test of pairReads, the policy of peClassifyPair), --nofw / --norc (the strand pickNextReadToSearch skips, per
+    mate of a pair) on libraries of the matching and of the wrong orientation"""
+    import fuzz_pairs as F
+    monkeypatch.setattr(F, "OPTS", opts)
+    mut = {"fr": None, "ff": lambda a, b: (a, _rc(b)), "rf": lambda a, b: (_rc(a), _rc(b))}[library]
+    bad, _ = F.run_case(verbose=3, seed=7500 + len(opts) + len(library), npairs=2500, rdlen=101, sub=0.012, frag_mean=300, frag_sd=40, mutate=mut)
+    assert bad == 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("opt", ["--nofw", "--norc"])
+def test_live_reference_unpaired_strand_options(opt):
+    import fuzz_align as F
+    bad, _ = F.run_case(7601, 3000, 101, 0.01, 0.001, 0.0, extra=(opt,), verbose=2)
+    assert bad == 0

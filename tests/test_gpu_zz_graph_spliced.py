@@ -184,3 +184,30 @@ def test_spliced_on_real_sequence_command_line(tmp_path):
     synth.write_reads_fasta(rfa, reads)
     want = _compare(tmp, base, ["-U", rfa], ["-p", "2", "--reorder"], ["-p", "2"])
     assert sum(1 for l in want if "NH:i:1" not in l and "N" in l.split("\t")[5]) > 20      # spliced multi-mappers
+
+
+@needs_ref
+@pytest.mark.parametrize("opts,library", [(["--rf"], "rf"), (["--ff", "--no-mixed"], "ff"), (["-I", "250", "-X", "330", "--no-discordant"], "fr"),
+                                           (["--nofw"], "fr"), (["--norc", "--rf", "--no-spliced-alignment"], "rf")])
+def test_pair_policy_options_command_line(tmp_path, opts, library):
+    """-I / -X, --fr / --rf / --ff, --nofw / --norc, --no-mixed / --no-discordant through the command line, unspliced and spliced
+    (the options other than -X are compiled into the units that carry the splice-site database, which run either mode)"""
+    import numpy as np
+    tmp = str(tmp_path)
+    contigs = synth.make_genome([300000, 120000], 1091, n_gaps=2, gap_len=300, repeats=6, repeat_len=500)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    m1, m2 = synth.make_pairs(contigs, 8000, 101, 1092, frag_mean=300, frag_sd=40, sub_rate=0.012)
+    rc = lambda m: np.where(m[:, ::-1] > 3, 4, 3 - m[:, ::-1]).astype(np.uint8)
+    if library == "ff":
+        m2 = rc(m2)
+    elif library == "rf":
+        m1, m2 = rc(m1), rc(m2)
+    f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
+    synth.write_reads_fasta(f1, m1)
+    synth.write_reads_fasta(f2, m2)
+    mode = [] if "--no-spliced-alignment" in opts else ["--no-temp-splicesite"]
+    want = _compare(tmp, base, ["-1", f1, "-2", f2], ["-p", "2", "--reorder"] + mode + opts, ["-p", "2"] + mode + opts)
+    assert sum(1 for l in want if l.split("\t")[1] != "77" and l.split("\t")[1] != "141") > 4000
