@@ -253,6 +253,10 @@ class AlignParams(C.Structure):
                 self.max_alts_tried = int(v); i += 2
             elif o == "--haplotype":
                 self.use_haplotype = 1; i += 1
+            elif o in ("--rg-id", "--rg"):                                   # output only: h2g_sam_add_read_group
+                i += 2
+            elif o in ("--no-sq", "--omit-sec-seq"):                         # output only: h2g_sam_set_header_options
+                i += 1
             elif o in ("--no-mixed", "--no-discordant"):                      # output only: h2g_sam_set_report_policy
                 i += 1
             elif o == "--no-templatelen-adjustment":                       # output only (TLEN): h2g_sam_set_templatelen_adjustment

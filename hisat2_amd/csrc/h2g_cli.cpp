@@ -219,7 +219,8 @@ int main(int argc, char** argv) {
 	std::string known_ss, novel_ss, novel_out;
 	bool tlen_adjust = true, use_haplotype = false;
 	int max_alts_tried = 16, max_frag_len = 1000, min_frag_len = 0, pe_orientation = 0;
-	bool nofw = false, norc = false;
+	bool nofw = false, norc = false, no_sq = false, omit_sec_seq = false;
+	std::vector<std::pair<bool, std::string> > rg_args;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -265,6 +266,10 @@ int main(int argc, char** argv) {
 		else if(a == "--ff") pe_orientation = 2;
 		else if(a == "--nofw") nofw = true;                                    // hisat2.cpp:1337-1338
 		else if(a == "--norc") norc = true;
+		else if(a == "--rg-id") rg_args.push_back({true, need("--rg-id")});    // hisat2.cpp:1389-1407, in command-line order
+		else if(a == "--rg") rg_args.push_back({false, need("--rg")});
+		else if(a == "--no-sq" || a == "--sam-no-sq" || a == "--sam-nosq" || a == "--sam-noSQ") no_sq = true;
+		else if(a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") omit_sec_seq = true;
 		else if(a == "--no-mixed") report_mixed = false;                       // hisat2.cpp:1162
 		else if(a == "--no-discordant") report_discordant = false;             // hisat2.cpp:1161
 		else if(a == "--haplotype") use_haplotype = true;                      // hisat2.cpp:1749 (ARG_HAPLOTYPE)
@@ -457,6 +462,8 @@ int main(int argc, char** argv) {
 	if(temp_ss || (!nospliced && !novel_out.empty())) h2g_sam_collect_novel_sites(sam, 1);   // SpliceSiteDB's `write` (hisat2.cpp:4092)
 	h2g_sam_set_templatelen_adjustment(sam, tlen_adjust);
 	h2g_sam_set_report_policy(sam, report_discordant, report_mixed);
+	for(const auto& r : rg_args) h2g_sam_add_read_group(sam, r.first ? r.second.c_str() : nullptr, r.first ? nullptr : r.second.c_str());
+	h2g_sam_set_header_options(sam, no_sq, omit_sec_seq);
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);
 	h2g_sam_set_rna_strandness(sam, strandness);

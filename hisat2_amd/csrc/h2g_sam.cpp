@@ -45,6 +45,8 @@ struct h2g_sam {
 	uint32_t ssdb_window = 0;
 	int rna_strandness = 0;                               // --rna-strandness: 0 unknown, 1 F, 2 R, 3 FR, 4 RF (read.h:30)
 	bool collect_novel = false;                           // h2g_sam_collect_novel_sites
+	std::string rg_id, rg_fields, rg_optflag;             // --rg-id / --rg: "\tID:x", "\tSM:y...", "RG:Z:x" (hisat2.cpp:1389-1407)
+	bool no_sq = false, omit_sec_seq = false;             // --no-sq (hisat2.cpp:4130), --omit-sec-seq (aln_sink.h:3190)
 	bool report_discordant = true, report_mixed = true;   // --no-discordant / --no-mixed clear them (ReportingParams::discord / mixed aln_sink.h:272)
 	bool tlen_adjust = true;                              // --no-templatelen-adjustment clears it (aln_sink.h:2070-2076)
 	// what SpliceSiteDB keeps per site for --novel-splicesite-outfile (splice_site.cpp:243-276): the number of lines written across it
@@ -429,12 +431,13 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	if(rs && rso && summ.paired && (rs->tidx == rso->tidx || fl.concordant())) put(o, fragment_length(*rs, *rso, fl.readMate1(), fl.concordant() && S.tlen_adjust ? &S : nullptr, tl_rdid));
 	else o.push_back('0');
 	o.push_back('\t');
-	o += seq; o.push_back('\t');
-	o += qual; o.push_back('\t');
+	if(!fl.primary && S.omit_sec_seq) o += "*\t*\t";                     // aln_sink.h:3190, :3206
+	else { o += seq; o.push_back('\t'); o += qual; o.push_back('\t'); }
 	if(!rs) {                                                            // printEmptyOptFlags sam.h:1033-1100
 		o += "YT:Z:";
 		o += fl.concordant() ? "CP" : fl.discordant() ? "DP" : fl.unpairedMate() ? "UP" : "UU";
 		if(!fl.lenfilt) o += "\tYF:Z:LN"; else if(!fl.nfilt) o += "\tYF:Z:NS";
+		if(!S.rg_optflag.empty()) { o.push_back('\t'); o += S.rg_optflag; }   // sam.h:1102
 		o.push_back('\n');
 		return;
 	}
@@ -468,6 +471,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	o += "\tYT:Z:";
 	o += fl.concordant() ? "CP" : fl.discordant() ? "DP" : fl.unpairedMate() ? "UP" : "UU";
 	if(!fl.lenfilt) o += "\tYF:Z:LN"; else if(!fl.nfilt) o += "\tYF:Z:NS";
+	if(!S.rg_optflag.empty()) { o.push_back('\t'); o += S.rg_optflag; }       // sam.h:780
 	if(S.rna_strandness != 0) {   // a stranded library: the tag follows from the mate and the strand it aligned to (sam.h:940-966)
 		char strand = '+';
 		const bool m1 = fl.pairing == PAIR_UNPAIRED || fl.readMate1();   // unpaired reads are ALN_RES_TYPE_UNPAIRED_MATE1 (aln_sink.h:2368)
@@ -589,9 +593,10 @@ extern "C" void h2g_sam_close(h2g_sam* s) { delete s; }
 extern "C" size_t h2g_sam_header(const h2g_sam* S, const char* cmdline, char* out, size_t cap) {
 	if(!S) return 0;
 	std::string o = "@HD\tVN:1.0\tSO:unsorted\n";
-	for(size_t i = 0; i < S->refnames.size(); i++) {
+	if(!S->no_sq) for(size_t i = 0; i < S->refnames.size(); i++) {
 		o += "@SQ\tSN:"; put_ref_name(o, S->refnames[i]); o += "\tLN:"; put(o, i < S->reflens.size() ? S->reflens[i] : 0); o.push_back('\n');
 	}
+	if(!S->rg_id.empty()) { o += "@RG"; o += S->rg_id; o += S->rg_fields; o.push_back('\n'); }   // sam.h:456-461
 	o += "@PG\tID:hisat2\tPN:hisat2\tVN:2.2.3\tCL:\""; o += cmdline ? cmdline : ""; o += "\"\n";
 	if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
 	return o.size();
@@ -671,6 +676,17 @@ extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
 	if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
 	return o.size();
 }
+// --rg-id <text> (id != NULL) and --rg <text> (field != NULL; "ID:x" sets the id like --rg-id x), hisat2.cpp:1389-1407
+extern "C" void h2g_sam_add_read_group(h2g_sam* S, const char* id, const char* field) {
+	if(!S) return;
+	if(id) { S->rg_id = std::string("\tID:") + id; S->rg_optflag = std::string("RG:Z:") + id; }
+	if(field) {
+		const std::string f = field;
+		if(f.compare(0, 3, "ID:") == 0) { S->rg_id = "\t" + f; S->rg_optflag = "RG:Z:" + f.substr(3); }
+		else { S->rg_fields += '\t'; S->rg_fields += f; }
+	}
+}
+extern "C" void h2g_sam_set_header_options(h2g_sam* S, int no_sq, int omit_sec_seq) { if(S) { S->no_sq = no_sq != 0; S->omit_sec_seq = omit_sec_seq != 0; } }
 extern "C" void h2g_sam_set_report_policy(h2g_sam* S, int discordant, int mixed) { if(S) { S->report_discordant = discordant != 0; S->report_mixed = mixed != 0; } }
 extern "C" void h2g_sam_set_no_unal(h2g_sam* S, int on) { if(S) S->no_unal = on != 0; }
 extern "C" void h2g_sam_set_secondary(h2g_sam* S, int on) { if(S) S->secondary = on != 0; }

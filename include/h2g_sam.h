@@ -32,6 +32,11 @@ H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
 H2G_EXPORT size_t     h2g_sam_summary(const h2g_sam*, char* out, size_t cap);
 /* --no-unal: lines of reads / mates that failed to align are not printed (aln_sink.h:3040) */
 H2G_EXPORT void       h2g_sam_set_no_unal(h2g_sam*, int on);
+/* --rg-id <text> (id) / --rg <text> (field; "ID:x" acts like --rg-id x): the @RG header line, printed when an id is set, and RG:Z:<id> on
+ * every record (hisat2.cpp:1389-1407, sam.h:456, :780, :1102).  Either argument may be NULL. */
+H2G_EXPORT void       h2g_sam_add_read_group(h2g_sam*, const char* id, const char* field);
+/* --no-sq: the header without @SQ lines; --omit-sec-seq: SEQ and QUAL of secondary lines are '*' (aln_sink.h:3190) */
+H2G_EXPORT void       h2g_sam_set_header_options(h2g_sam*, int no_sq, int omit_sec_seq);
 /* --no-discordant (discordant = 0): a pair with one alignment per mate that is not concordant is not converted into a discordant pair
  * (ReportingState::nextRead aln_sink.cpp:38); --no-mixed (mixed = 0): mates of a pair without a paired alignment are reported unaligned
  * (ReportingState::getReport aln_sink.cpp:280).  Both default to 1 (hisat2.cpp:353-354). */

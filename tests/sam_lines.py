@@ -12,6 +12,7 @@ ROOT = os.path.dirname(HERE)
 
 
 LAST_SUMMARY = None   # alignment summary text of the last format_* call (h2g_sam_summary)
+LAST_HEADER = ""
 
 
 def load_sam_lib(path=None):
@@ -65,6 +66,17 @@ def _score_min(L, h, options):
     if options and "--novel-splicesite-outfile" in options:
         L.h2g_sam_collect_novel_sites.argtypes = [C.c_void_p, C.c_int]
         L.h2g_sam_collect_novel_sites(h, 1)
+    if options and ("--rg-id" in options or "--rg" in options):
+        L.h2g_sam_add_read_group.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        ol = list(options)
+        for k, o in enumerate(ol):
+            if o == "--rg-id":
+                L.h2g_sam_add_read_group(h, ol[k + 1].encode(), None)
+            elif o == "--rg":
+                L.h2g_sam_add_read_group(h, None, ol[k + 1].encode())
+    if options and ("--no-sq" in options or "--omit-sec-seq" in options):
+        L.h2g_sam_set_header_options.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.h2g_sam_set_header_options(h, 1 if "--no-sq" in options else 0, 1 if "--omit-sec-seq" in options else 0)
     if options and ("--no-mixed" in options or "--no-discordant" in options):
         L.h2g_sam_set_report_policy.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.h2g_sam_set_report_policy(h, 0 if "--no-discordant" in options else 1, 0 if "--no-mixed" in options else 1)
@@ -106,6 +118,12 @@ def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):
     sb = C.create_string_buffer(4096)
     nsum = L.h2g_sam_summary(h, sb, 4096)
     LAST_SUMMARY = sb.raw[:nsum].decode()
+    global LAST_HEADER
+    L.h2g_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.h2g_sam_header.restype = C.c_size_t
+    hb = C.create_string_buffer(1 << 16)
+    nhead = L.h2g_sam_header(h, b"", hb, 1 << 16)
+    LAST_HEADER = hb.raw[:nhead].decode()
     _novel_out(L, h, options)
     L.h2g_sam_close(h)
     assert rc == 0, (rc, used.value, cap)
@@ -131,6 +149,12 @@ def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=()):
     sb = C.create_string_buffer(4096)
     nsum = L.h2g_sam_summary(h, sb, 4096)
     LAST_SUMMARY = sb.raw[:nsum].decode()
+    global LAST_HEADER
+    L.h2g_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.h2g_sam_header.restype = C.c_size_t
+    hb = C.create_string_buffer(1 << 16)
+    nhead = L.h2g_sam_header(h, b"", hb, 1 << 16)
+    LAST_HEADER = hb.raw[:nhead].decode()
     _novel_out(L, h, options)
     L.h2g_sam_close(h)
     assert rc == 0, (rc, used.value, cap)

@@ -390,3 +390,18 @@ def test_no_mixed_no_discordant(extra, monkeypatch):
     bad, tmp = F.run_case(7301, 2000, sub=0.03, show=3, extra=extra)
     assert bad == 0
     assert SL.LAST_SUMMARY == open(os.path.join(tmp, "ref.err")).read()
+
+
+@needs_ref
+def test_read_group_no_sq_omit_sec_seq():
+    """--rg-id / --rg (the @RG header line and RG:Z: on aligned and unaligned records), --no-sq, --omit-sec-seq ('*' for SEQ / QUAL of
+    secondary lines) — header (up to @PG's command line) and every line equal the reference's; pairs with multi-mappers"""
+    import fuzz_spliced_pairs as F
+    extra = ("--rg-id", "grp1", "--rg", "SM:sample one", "--rg", "PL:ILLUMINA", "--no-sq", "--omit-sec-seq", "-k", "4")
+    bad, tmp = F.run_case(7701, 1500, sub=0.02, show=3, extra=extra)
+    assert bad == 0
+    ref_head = [l.rstrip("\n") for l in open(os.path.join(tmp, "ref.sam")) if l.startswith("@") and not l.startswith("@PG")]
+    got_head = [l for l in SL.LAST_HEADER.splitlines() if not l.startswith("@PG")]
+    assert got_head == ref_head and any(l.startswith("@RG\tID:grp1\tSM:sample one\tPL:ILLUMINA") for l in got_head)
+    body = SL.body_lines(os.path.join(tmp, "ref.sam"))
+    assert all("RG:Z:grp1" in l for l in body) and any(l.split("\t")[9] == "*" for l in body)
