@@ -393,9 +393,10 @@ def test_no_mixed_no_discordant(extra, monkeypatch):
 
 
 @needs_ref
-def test_read_group_no_sq_omit_sec_seq():
+def test_read_group_no_sq_omit_sec_seq(monkeypatch):
     """--rg-id / --rg (the @RG header line and RG:Z: on aligned and unaligned records), --no-sq, --omit-sec-seq ('*' for SEQ / QUAL of
     secondary lines) — header (up to @PG's command line) and every line equal the reference's; pairs with multi-mappers"""
+    monkeypatch.setenv("H2G_FUZZ_RICH", "1")              # gene copies: multi-mapping pairs, i.e. secondary lines
     import fuzz_spliced_pairs as F
     extra = ("--rg-id", "grp1", "--rg", "SM:sample one", "--rg", "PL:ILLUMINA", "--no-sq", "--omit-sec-seq", "-k", "4")
     bad, tmp = F.run_case(7701, 1500, sub=0.02, show=3, extra=extra)
