@@ -255,7 +255,9 @@ class AlignParams(C.Structure):
                 self.use_haplotype = 1; i += 1
             elif o in ("--rg-id", "--rg"):                                   # output only: h2g_sam_add_read_group
                 i += 2
-            elif o in ("--no-sq", "--omit-sec-seq"):                         # output only: h2g_sam_set_header_options
+            elif o == "--summary-file":
+                i += 2
+            elif o in ("--no-sq", "--omit-sec-seq", "--new-summary"):                         # output only: h2g_sam_set_header_options
                 i += 1
             elif o in ("--no-mixed", "--no-discordant"):                      # output only: h2g_sam_set_report_policy
                 i += 1

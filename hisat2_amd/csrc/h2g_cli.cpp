@@ -221,6 +221,8 @@ int main(int argc, char** argv) {
 	int max_alts_tried = 16, max_frag_len = 1000, min_frag_len = 0, pe_orientation = 0;
 	bool nofw = false, norc = false, no_sq = false, omit_sec_seq = false;
 	std::vector<std::pair<bool, std::string> > rg_args;
+	bool new_summary = false;
+	std::string summary_file;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -270,6 +272,8 @@ int main(int argc, char** argv) {
 		else if(a == "--rg") rg_args.push_back({false, need("--rg")});
 		else if(a == "--no-sq" || a == "--sam-no-sq" || a == "--sam-nosq" || a == "--sam-noSQ") no_sq = true;
 		else if(a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") omit_sec_seq = true;
+		else if(a == "--new-summary") new_summary = true;
+		else if(a == "--summary-file") summary_file = need("--summary-file");
 		else if(a == "--no-mixed") report_mixed = false;                       // hisat2.cpp:1162
 		else if(a == "--no-discordant") report_discordant = false;             // hisat2.cpp:1161
 		else if(a == "--haplotype") use_haplotype = true;                      // hisat2.cpp:1749 (ARG_HAPLOTYPE)
@@ -464,6 +468,7 @@ int main(int argc, char** argv) {
 	h2g_sam_set_report_policy(sam, report_discordant, report_mixed);
 	for(const auto& r : rg_args) h2g_sam_add_read_group(sam, r.first ? r.second.c_str() : nullptr, r.first ? nullptr : r.second.c_str());
 	h2g_sam_set_header_options(sam, no_sq, omit_sec_seq);
+	h2g_sam_set_new_summary(sam, new_summary);
 	h2g_sam_set_score_min(sam, P.score_min_type, P.score_min_const, P.score_min_coeff);
 	h2g_sam_set_secondary(sam, (int)P.secondary);
 	h2g_sam_set_rna_strandness(sam, strandness);
@@ -642,6 +647,7 @@ int main(int argc, char** argv) {
 		std::vector<char> sb(need + 1);
 		h2g_sam_summary(sam, sb.data(), need);
 		fwrite(sb.data(), 1, need, stderr);
+		if(!summary_file.empty()) { FILE* sf = fopen(summary_file.c_str(), "w"); if(sf) { fwrite(sb.data(), 1, need, sf); fclose(sf); } }   // hisat2.cpp:4175
 	}
 	(void)naligned; (void)nreads;
 	// Reads whose lists overflow the default device workspace are re-run on the device with the large one (h2g_align_run's

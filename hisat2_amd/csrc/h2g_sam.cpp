@@ -46,6 +46,7 @@ struct h2g_sam {
 	int rna_strandness = 0;                               // --rna-strandness: 0 unknown, 1 F, 2 R, 3 FR, 4 RF (read.h:30)
 	bool collect_novel = false;                           // h2g_sam_collect_novel_sites
 	std::string rg_id, rg_fields, rg_optflag;             // --rg-id / --rg: "\tID:x", "\tSM:y...", "RG:Z:x" (hisat2.cpp:1389-1407)
+	bool new_summary = false;                             // --new-summary (aln_sink.h:1659)
 	bool no_sq = false, omit_sec_seq = false;             // --no-sq (hisat2.cpp:4130), --omit-sec-seq (aln_sink.h:3190)
 	bool report_discordant = true, report_mixed = true;   // --no-discordant / --no-mixed clear them (ReportingParams::discord / mixed aln_sink.h:272)
 	bool tlen_adjust = true;                              // --no-templatelen-adjustment clears it (aln_sink.h:2070-2076)
@@ -647,6 +648,30 @@ extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
 	auto line = [&](const char* ind, uint64_t v, uint64_t den, const char* txt) { o += ind; o += std::to_string(v); o += " ("; pct(v, den); o += ") "; o += txt; o += "\n"; };
 	const uint64_t tot_al_cand = m.nunpaired + m.npaired * 2;
 	const uint64_t tot_al = (m.nconcord_uni1 + m.nconcord_uni2) * 2 + m.ndiscord * 2 + m.nunp_0_uni1 + m.nunp_0_uni2 + m.nunp_uni1 + m.nunp_uni2;
+	if(S->new_summary) {                                  // --new-summary: aln_sink.h:1659-1679
+		o += "HISAT2 summary stats:\n";
+		auto row = [&](const char* txt, uint64_t v, uint64_t den) { o += txt; o += std::to_string(v); o += " ("; pct(v, den); o += ")\n"; };
+		if(m.npaired > 0) {
+			const uint64_t n0 = m.nconcord_0 - m.ndiscord;
+			o += "\tTotal pairs: "; o += std::to_string(m.npaired); o += "\n";
+			row("\t\tAligned concordantly or discordantly 0 time: ", n0, m.npaired);
+			row("\t\tAligned concordantly 1 time: ", m.nconcord_uni1, m.npaired);
+			row("\t\tAligned concordantly >1 times: ", m.nconcord_uni2, m.npaired);
+			row("\t\tAligned discordantly 1 time: ", m.ndiscord, m.npaired);
+			o += "\tTotal unpaired reads: "; o += std::to_string(n0 * 2); o += "\n";
+			row("\t\tAligned 0 time: ", m.nunp_0_0, n0 * 2);
+			row("\t\tAligned 1 time: ", m.nunp_0_uni1, n0 * 2);
+			row("\t\tAligned >1 times: ", m.nunp_0_uni2, n0 * 2);
+		} else {
+			o += "\tTotal reads: "; o += std::to_string(m.nread); o += "\n";
+			row("\t\tAligned 0 time: ", m.nunp_0, m.nunpaired);
+			row("\t\tAligned 1 time: ", m.nunp_uni1, m.nunpaired);
+			row("\t\tAligned >1 times: ", m.nunp_uni2, m.nunpaired);
+		}
+		o += "\tOverall alignment rate: "; pct(tot_al, tot_al_cand); o += "\n";
+		if(out && cap) memcpy(out, o.data(), std::min(cap, o.size()));
+		return o.size();
+	}
 	o += std::to_string(m.nread); o += m.nread ? " reads; of these:\n" : " reads\n";
 	if(m.npaired > 0) {
 		line("  ", m.npaired, m.nread, "were paired; of these:");
@@ -686,6 +711,7 @@ extern "C" void h2g_sam_add_read_group(h2g_sam* S, const char* id, const char* f
 		else { S->rg_fields += '\t'; S->rg_fields += f; }
 	}
 }
+extern "C" void h2g_sam_set_new_summary(h2g_sam* S, int on) { if(S) S->new_summary = on != 0; }
 extern "C" void h2g_sam_set_header_options(h2g_sam* S, int no_sq, int omit_sec_seq) { if(S) { S->no_sq = no_sq != 0; S->omit_sec_seq = omit_sec_seq != 0; } }
 extern "C" void h2g_sam_set_report_policy(h2g_sam* S, int discordant, int mixed) { if(S) { S->report_discordant = discordant != 0; S->report_mixed = mixed != 0; } }
 extern "C" void h2g_sam_set_no_unal(h2g_sam* S, int on) { if(S) S->no_unal = on != 0; }

@@ -32,6 +32,8 @@ H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
 H2G_EXPORT size_t     h2g_sam_summary(const h2g_sam*, char* out, size_t cap);
 /* --no-unal: lines of reads / mates that failed to align are not printed (aln_sink.h:3040) */
 H2G_EXPORT void       h2g_sam_set_no_unal(h2g_sam*, int on);
+/* --new-summary: h2g_sam_summary returns the "HISAT2 summary stats:" text instead (aln_sink.h:1659-1679) */
+H2G_EXPORT void       h2g_sam_set_new_summary(h2g_sam*, int on);
 /* --rg-id <text> (id) / --rg <text> (field; "ID:x" acts like --rg-id x): the @RG header line, printed when an id is set, and RG:Z:<id> on
  * every record (hisat2.cpp:1389-1407, sam.h:456, :780, :1102).  Either argument may be NULL. */
 H2G_EXPORT void       h2g_sam_add_read_group(h2g_sam*, const char* id, const char* field);

@@ -77,6 +77,9 @@ def _score_min(L, h, options):
     if options and ("--no-sq" in options or "--omit-sec-seq" in options):
         L.h2g_sam_set_header_options.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.h2g_sam_set_header_options(h, 1 if "--no-sq" in options else 0, 1 if "--omit-sec-seq" in options else 0)
+    if options and "--new-summary" in options:
+        L.h2g_sam_set_new_summary.argtypes = [C.c_void_p, C.c_int]
+        L.h2g_sam_set_new_summary(h, 1)
     if options and ("--no-mixed" in options or "--no-discordant" in options):
         L.h2g_sam_set_report_policy.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.h2g_sam_set_report_policy(h, 0 if "--no-discordant" in options else 1, 0 if "--no-mixed" in options else 1)

@@ -406,3 +406,23 @@ def test_read_group_no_sq_omit_sec_seq(monkeypatch):
     assert got_head == ref_head and any(l.startswith("@RG\tID:grp1\tSM:sample one\tPL:ILLUMINA") for l in got_head)
     body = SL.body_lines(os.path.join(tmp, "ref.sam"))
     assert all("RG:Z:grp1" in l for l in body) and any(l.split("\t")[9] == "*" for l in body)
+
+
+@needs_ref
+@pytest.mark.parametrize("paired", [False, True])
+def test_new_summary(paired):
+    """--new-summary: the "HISAT2 summary stats:" text (aln_sink.h:1659-1679) equals the reference's stderr"""
+    if paired:
+        import fuzz_spliced_pairs as F
+        bad, tmp = F.run_case(7801, 1200, sub=0.03, show=3, extra=("--new-summary",))
+    else:
+        import fuzz_spliced as F
+        from h2gemu_align import emu_align
+        bad, tmp = F.run_case(7802, 2000, sub=0.02, verbose=2, extra=("--new-summary",))
+        names, reads = read_fa(os.path.join(tmp, "r.fa"))
+        outs, recs = emu_align(os.path.join(tmp, "g"), reads, names, no_spliced=0)
+        res, aln = SL.emu_to_abi(outs, recs)
+        SL.format_unpaired(SL.load_sam_lib(), os.path.join(tmp, "g"), reads, names, res, aln, options=["--new-summary"])
+    assert bad == 0
+    want = open(os.path.join(tmp, "ref.err")).read()
+    assert want.startswith("HISAT2 summary stats:") and SL.LAST_SUMMARY == want
