@@ -257,7 +257,7 @@ class AlignParams(C.Structure):
                 i += 2
             elif o == "--summary-file":
                 i += 2
-            elif o in ("--no-sq", "--omit-sec-seq", "--new-summary"):                         # output only: h2g_sam_set_header_options
+            elif o in ("--no-sq", "--omit-sec-seq", "--new-summary", "--add-chrname", "--remove-chrname"):                         # output only: h2g_sam_set_header_options
                 i += 1
             elif o in ("--no-mixed", "--no-discordant"):                      # output only: h2g_sam_set_report_policy
                 i += 1

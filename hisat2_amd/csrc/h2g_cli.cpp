@@ -223,6 +223,7 @@ int main(int argc, char** argv) {
 	std::vector<std::pair<bool, std::string> > rg_args;
 	bool new_summary = false;
 	std::string summary_file;
+	int chrname_mode = 0;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -272,6 +273,8 @@ int main(int argc, char** argv) {
 		else if(a == "--rg") rg_args.push_back({false, need("--rg")});
 		else if(a == "--no-sq" || a == "--sam-no-sq" || a == "--sam-nosq" || a == "--sam-noSQ") no_sq = true;
 		else if(a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") omit_sec_seq = true;
+		else if(a == "--remove-chrname") chrname_mode |= 1;
+		else if(a == "--add-chrname") chrname_mode |= 2;
 		else if(a == "--new-summary") new_summary = true;
 		else if(a == "--summary-file") summary_file = need("--summary-file");
 		else if(a == "--no-mixed") report_mixed = false;                       // hisat2.cpp:1162
@@ -354,6 +357,8 @@ int main(int argc, char** argv) {
 	h2g_index* ix = ixs[0];
 	h2g_sam* sam = nullptr;
 	if(h2g_sam_open(base.c_str(), &sam) != H2G_OK) die("cannot read reference names");
+	if(chrname_mode == 3) { fprintf(stderr, "Error: --remove-chrname and --add-chrname cannot be used at the same time\n"); return 1; }   // hisat2.cpp:3958
+	if(chrname_mode) h2g_sam_set_chrname_mode(sam, chrname_mode);
 	h2g_align_params P; h2g_align_params_init(&P, ix);
 	P.bowtie2_dp = dp;
 	P.no_spliced_alignment = nospliced ? 1 : 0; P.no_temp_splicesite = notempss ? 1 : 0;

@@ -711,6 +711,15 @@ extern "C" void h2g_sam_add_read_group(h2g_sam* S, const char* id, const char* f
 		else { S->rg_fields += '\t'; S->rg_fields += f; }
 	}
 }
+// --remove-chrname (mode 1) / --add-chrname (mode 2): hisat2.cpp:3962-3976, before anything else uses the names (@SQ, RNAME, the
+// splice-site files' names, --novel-splicesite-outfile)
+extern "C" void h2g_sam_set_chrname_mode(h2g_sam* S, int mode) {
+	if(!S) return;
+	for(std::string& n : S->refnames) {
+		if(mode == 1) { if(n.compare(0, 3, "chr") == 0) n = n.substr(3); }
+		else if(mode == 2) { if(n.compare(0, 3, "chr") != 0) n = "chr" + n; }
+	}
+}
 extern "C" void h2g_sam_set_new_summary(h2g_sam* S, int on) { if(S) S->new_summary = on != 0; }
 extern "C" void h2g_sam_set_header_options(h2g_sam* S, int no_sq, int omit_sec_seq) { if(S) { S->no_sq = no_sq != 0; S->omit_sec_seq = omit_sec_seq != 0; } }
 extern "C" void h2g_sam_set_report_policy(h2g_sam* S, int discordant, int mixed) { if(S) { S->report_discordant = discordant != 0; S->report_mixed = mixed != 0; } }

@@ -32,6 +32,8 @@ H2G_EXPORT void       h2g_sam_set_threads(h2g_sam*, int threads);
 H2G_EXPORT size_t     h2g_sam_summary(const h2g_sam*, char* out, size_t cap);
 /* --no-unal: lines of reads / mates that failed to align are not printed (aln_sink.h:3040) */
 H2G_EXPORT void       h2g_sam_set_no_unal(h2g_sam*, int on);
+/* --remove-chrname (1) / --add-chrname (2): the reference names lose / gain a leading "chr" (hisat2.cpp:3962-3976); call right after open */
+H2G_EXPORT void       h2g_sam_set_chrname_mode(h2g_sam*, int mode);
 /* --new-summary: h2g_sam_summary returns the "HISAT2 summary stats:" text instead (aln_sink.h:1659-1679) */
 H2G_EXPORT void       h2g_sam_set_new_summary(h2g_sam*, int on);
 /* --rg-id <text> (id) / --rg <text> (field; "ID:x" acts like --rg-id x): the @RG header line, printed when an id is set, and RG:Z:<id> on

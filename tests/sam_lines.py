@@ -77,6 +77,9 @@ def _score_min(L, h, options):
     if options and ("--no-sq" in options or "--omit-sec-seq" in options):
         L.h2g_sam_set_header_options.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.h2g_sam_set_header_options(h, 1 if "--no-sq" in options else 0, 1 if "--omit-sec-seq" in options else 0)
+    if options and ("--add-chrname" in options or "--remove-chrname" in options):
+        L.h2g_sam_set_chrname_mode.argtypes = [C.c_void_p, C.c_int]
+        L.h2g_sam_set_chrname_mode(h, 1 if "--remove-chrname" in options else 2)
     if options and "--new-summary" in options:
         L.h2g_sam_set_new_summary.argtypes = [C.c_void_p, C.c_int]
         L.h2g_sam_set_new_summary(h, 1)

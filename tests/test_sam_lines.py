@@ -426,3 +426,12 @@ def test_new_summary(paired):
     assert bad == 0
     want = open(os.path.join(tmp, "ref.err")).read()
     assert want.startswith("HISAT2 summary stats:") and SL.LAST_SUMMARY == want
+
+
+@needs_ref
+def test_remove_chrname():
+    """--remove-chrname: chr1 -> 1 in @SQ, RNAME / RNEXT and in --novel-splicesite-outfile (hisat2.cpp:3962)"""
+    import fuzz_spliced_pairs as F
+    bad, tmp = F.run_case(7901, 1200, sub=0.01, show=3, extra=("--remove-chrname",), novel_out=True)
+    assert bad == 0
+    assert "@SQ\tSN:1\t" in SL.LAST_HEADER and open(os.path.join(tmp, "ref.ss")).read().startswith("1\t")
