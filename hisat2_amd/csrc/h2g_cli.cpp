@@ -187,7 +187,16 @@ private:
 		while(q < end && *q != '\n' && *q != '\r') q++;
 		if((size_t)(q - ql) < Lraw) { fprintf(stderr, "Error: Read %.*s has more read characters than quality values.\n", (int)nlen, nm); exit(1); }
 		b.quals.append(ql + t5, L);
+		if(phred64_) {                                               // charToPhred33 qual.h:126-136
+			for(size_t k = b.quals.size() - L; k < b.quals.size(); k++) {
+				if(b.quals[k] < 64) { fprintf(stderr, "Saw ASCII character %d but expected 64-based Phred qual.\nTry not specifying --solexa1.3-quals/--phred64-quals.\n", (int)b.quals[k]); exit(1); }
+				b.quals[k] = (char)(b.quals[k] - 31);
+			}
+		}
 	}
+public:
+	bool phred64_ = false;
+private:
 	std::vector<std::string> files_;
 	bool fasta_;
 	int T_;
@@ -224,6 +233,7 @@ int main(int argc, char** argv) {
 	bool new_summary = false;
 	std::string summary_file;
 	int chrname_mode = 0;
+	bool phred64 = false;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -273,6 +283,8 @@ int main(int argc, char** argv) {
 		else if(a == "--rg") rg_args.push_back({false, need("--rg")});
 		else if(a == "--no-sq" || a == "--sam-no-sq" || a == "--sam-nosq" || a == "--sam-noSQ") no_sq = true;
 		else if(a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") omit_sec_seq = true;
+		else if(a == "--phred64" || a == "--phred64-quals" || a == "--solexa1.3-quals") phred64 = true;   // hisat2.cpp ARG_PHRED64
+		else if(a == "--phred33" || a == "--phred33-quals") phred64 = false;
 		else if(a == "--remove-chrname") chrname_mode |= 1;
 		else if(a == "--add-chrname") chrname_mode |= 2;
 		else if(a == "--new-summary") new_summary = true;
@@ -309,6 +321,7 @@ int main(int argc, char** argv) {
 	}
 	if(parse_only) {
 		Reader r(u.empty() ? m1 : u, fasta, threads);
+		r.phred64_ = phred64;
 		Batch b;
 		uint64_t n = 0, bases = 0, h = 1469598103934665603ull;
 		auto mix = [&](const void* p, size_t len) { const uint8_t* c = (const uint8_t*)p; for(size_t i = 0; i < len; i++) { h ^= c[i]; h *= 1099511628211ull; } };
@@ -492,6 +505,7 @@ int main(int argc, char** argv) {
 	h2g_sam_set_threads(sam, threads);
 	h2g_sam_set_no_unal(sam, no_unal ? 1 : 0);
 	Reader ra(paired ? m1 : u, fasta, threads, trim5, trim3), rb(m2, fasta, threads, trim5, trim3);
+	ra.phred64_ = rb.phred64_ = phred64;
 	if(skip) {   // -s: the skipped reads are parsed (their ids count) but not aligned
 		Batch junk;
 		for(uint64_t left = skip; left > 0;) { junk.clear(); const size_t g = ra.fill(junk, (size_t)std::min<uint64_t>(left, batch)); if(paired) { junk.clear(); rb.fill(junk, g); } if(!g) break; left -= g; }

@@ -68,3 +68,21 @@ def test_reader_is_thread_and_batch_invariant(tmp_path, fmt):
     out = subprocess.run([CLI, "--parse-only", "-f" if fmt != "fastq" else "-q", "-U", str(path) + ".gz", "-p", "4", "-x", "unused"], check=True,
                          capture_output=True, text=True).stdout.split()
     assert (int(out[0]), int(out[1]), int(out[2], 16)) == expected(names, seqs2, quals, 1 << 20)
+
+
+def test_phred64_input(tmp_path):
+    """--phred64: a FASTQ file with 64-based qualities parses to what its 33-based twin parses to (charToPhred33 qual.h:126)"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    p33, p64 = tmp_path / "a33.fq", tmp_path / "a64.fq"
+    with open(p33, "w") as f33, open(p64, "w") as f64:
+        for i in range(300):
+            L = int(rng.integers(30, 120))
+            seq = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=L))
+            q = rng.integers(0, 41, size=L)
+            f33.write(f"@r{i}\n{seq}\n+\n" + "".join(chr(33 + int(x)) for x in q) + "\n")
+            f64.write(f"@r{i}\n{seq}\n+\n" + "".join(chr(64 + int(x)) for x in q) + "\n")
+    run = lambda path, extra: subprocess.run([CLI, "--parse-only", "-q", "-U", str(path), "-x", "unused"] + extra, check=True, stdout=subprocess.PIPE).stdout
+    assert run(p64, ["--phred64"]) == run(p33, [])
+    assert run(p64, []) != run(p33, [])
+    assert subprocess.run([CLI, "--parse-only", "-q", "-U", str(p33), "-x", "unused", "--phred64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode != 0
