@@ -197,6 +197,7 @@ class AlignParams(C.Structure):
             linear = self.khits == 5
         rest, i = [], 0
         saw_k, k_arg, max_seeds, sensitive, very = False, 0, 0, False, False
+        ignore_quals = False
         dta = False
         while i < len(opts):
             o = opts[i]
@@ -255,6 +256,8 @@ class AlignParams(C.Structure):
                 self.use_haplotype = 1; i += 1
             elif o in ("--rg-id", "--rg"):                                   # output only: h2g_sam_add_read_group
                 i += 2
+            elif o == "--ignore-quals":
+                ignore_quals = True; i += 1
             elif o == "--summary-file":
                 i += 2
             elif o in ("--no-sq", "--omit-sec-seq", "--new-summary", "--add-chrname", "--remove-chrname"):                         # output only: h2g_sam_set_header_options
@@ -291,6 +294,8 @@ class AlignParams(C.Structure):
         if dta:                              # hisat2.cpp:3920, 4078: applied after every option was read
             self.min_anchor_len, self.min_anchor_len_noncan = 15, 20
             self.pen_noncanintronlen_type, self.pen_noncanintronlen_const, self.pen_noncanintronlen_coeff = 4, -8.0, 2.0
+        if ignore_quals and "--mp" not in opts:   # COST_MODEL_CONSTANT: every mismatch costs the maximum (aligner_seed_policy.cpp:279); --mp sets the quality model again (:418)
+            self.mm_min = self.mm_max
         self.presets(linear, saw_k, k_arg, max_seeds, sensitive, very)
         return rest
 

@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
 	bool new_summary = false;
 	std::string summary_file;
 	int chrname_mode = 0;
-	bool phred64 = false;
+	bool phred64 = false, ignore_quals = false;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -285,6 +285,7 @@ int main(int argc, char** argv) {
 		else if(a == "--omit-sec-seq" || a == "--sam-omit-sec-seq") omit_sec_seq = true;
 		else if(a == "--phred64" || a == "--phred64-quals" || a == "--solexa1.3-quals") phred64 = true;   // hisat2.cpp ARG_PHRED64
 		else if(a == "--phred33" || a == "--phred33-quals") phred64 = false;
+		else if(a == "--ignore-quals") ignore_quals = true;                    // hisat2.cpp:1434
 		else if(a == "--remove-chrname") chrname_mode |= 1;
 		else if(a == "--add-chrname") chrname_mode |= 2;
 		else if(a == "--new-summary") new_summary = true;
@@ -428,6 +429,11 @@ int main(int argc, char** argv) {
 	if(dta) {   // hisat2.cpp:3920, 4078-4079: after every option was read
 		P.min_anchor_len = 15; P.min_anchor_len_noncan = 20;
 		P.pen_noncanintronlen_type = 4; P.pen_noncanintronlen_const = -8.0; P.pen_noncanintronlen_coeff = 2.0;
+	}
+	{   // COST_MODEL_CONSTANT: every mismatch costs the maximum (aligner_seed_policy.cpp:279, scoring.h:129); a --mp sets the quality model again (:418)
+		bool saw_mp = false;
+		for(const std::string& o : opts) if(o == "--mp") saw_mp = true;
+		if(ignore_quals && !saw_mp) P.mm_min = P.mm_max;
 	}
 	P.xs_only = xs_only ? 1 : 0;
 	P.use_haplotype = use_haplotype ? 1 : 0;

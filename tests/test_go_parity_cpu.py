@@ -129,3 +129,13 @@ def test_live_reference_unpaired_strand_options(opt):
     import fuzz_align as F
     bad, _ = F.run_case(7601, 3000, 101, 0.01, 0.001, 0.0, extra=(opt,), verbose=2)
     assert bad == 0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("extra", [("--ignore-quals",), ("--ignore-quals", "--mp", "5,3")])
+def test_live_reference_ignore_quals(extra):
+    """--ignore-quals on FASTQ input: every mismatch costs --mp's maximum (COST_MODEL_CONSTANT); an explicit --mp brings the quality
+    model back (aligner_seed_policy.cpp:279, :418)"""
+    import fuzz_align as F
+    bad, _ = F.run_case(8001, 3000, 101, 0.02, 0.001, 0.0, extra=extra, verbose=2, fastq=True)
+    assert bad == 0
