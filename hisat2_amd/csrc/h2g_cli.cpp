@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
 	bool new_summary = false;
 	std::string summary_file;
 	int chrname_mode = 0;
-	bool phred64 = false, ignore_quals = false;
+	bool phred64 = false, ignore_quals = false, quiet = false;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -311,7 +311,9 @@ int main(int argc, char** argv) {
 		else if(a == "-5" || a == "--trim5") trim5 = (uint32_t)atoi(need("-5"));
 		else if(a == "-3" || a == "--trim3") trim3 = (uint32_t)atoi(need("-3"));
 		else if(a == "--no-unal") no_unal = true;
-		else if(a == "--reorder" || a == "-t" || a == "--time" || a == "--quiet") {}    // output is always in read order
+		else if(a == "--quiet") quiet = true;                                      // gQuiet: no alignment summary on stderr (hisat2.cpp:4165)
+		else if(a == "--version") { printf("hisat2-align-amd (h2g) — output format of HISAT2 2.2.3\n"); return 0; }
+		else if(a == "--reorder" || a == "-t" || a == "--time" || a == "--mm" || a == "--qc-filter") {}   // output is always in read order; --mm (index mapping) and --qc-filter (a QSEQ field) have nothing to act on here
 		else if(a == "--h2g-stats") stats_fn = need("--h2g-stats");               // writes {reads, second_pass, overflow} as JSON (tests, bench)
 		else if(a == "--parse-only") parse_only = true;                           // test hook: ingest the reads, print counts + checksums
 		else { fprintf(stderr, "hisat2-align-amd: option %s is not built (see DESIGN.md, scope)\n", a.c_str()); return 1; }
@@ -671,8 +673,8 @@ int main(int argc, char** argv) {
 		const size_t need = h2g_sam_summary(sam, nullptr, 0);
 		std::vector<char> sb(need + 1);
 		h2g_sam_summary(sam, sb.data(), need);
-		fwrite(sb.data(), 1, need, stderr);
-		if(!summary_file.empty()) { FILE* sf = fopen(summary_file.c_str(), "w"); if(sf) { fwrite(sb.data(), 1, need, sf); fclose(sf); } }   // hisat2.cpp:4175
+		if(!quiet) fwrite(sb.data(), 1, need, stderr);
+		if(!quiet && !summary_file.empty()) { FILE* sf = fopen(summary_file.c_str(), "w"); if(sf) { fwrite(sb.data(), 1, need, sf); fclose(sf); } }   // hisat2.cpp:4175
 	}
 	(void)naligned; (void)nreads;
 	// Reads whose lists overflow the default device workspace are re-run on the device with the large one (h2g_align_run's
