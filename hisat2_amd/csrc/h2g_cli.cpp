@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
 	bool new_summary = false;
 	std::string summary_file;
 	int chrname_mode = 0;
-	bool phred64 = false, ignore_quals = false, quiet = false;
+	bool phred64 = false, ignore_quals = false, quiet = false, raw_input = false, cmdline_input = false;
 	bool report_mixed = true, report_discordant = true;
 	bool dta = false, xs_only = false;
 	int strandness = 0;
@@ -255,6 +255,8 @@ int main(int argc, char** argv) {
 		else if(a == "-1") { auto v = split_commas(need("-1")); m1.insert(m1.end(), v.begin(), v.end()); }
 		else if(a == "-2") { auto v = split_commas(need("-2")); m2.insert(m2.end(), v.begin(), v.end()); }
 		else if(a == "-S") outfn = need("-S");
+		else if(a == "-r") raw_input = true;                                   // one sequence per line (RawPatternSource pat.h)
+		else if(a == "-c") cmdline_input = true;                               // -U / -1 / -2 are comma-separated sequences (VectorPatternSource)
 		else if(a == "-f") fasta = true;
 		else if(a == "-q") fasta = false;
 		else if(a == "-p" || a == "--threads") threads = atoi(need("-p"));        // host threads for parsing and SAM formatting
@@ -322,6 +324,35 @@ int main(int argc, char** argv) {
 		fprintf(stderr, "usage: hisat2-align-amd -x <ht2-base> {-U <r.fq> | -1 <m1.fq> -2 <m2.fq>} [-f|-q] --no-spliced-alignment [--bowtie2-dp 0|1|2] [-S out.sam]\n");
 		return 1;
 	}
+	// -c / -r: the reads have no names (the reference numbers them, like FASTA records with an empty name) and no qualities ('I'): they are
+	// handed to the FASTA reader as ">\n<sequence>\n" records through a temporary file
+	std::vector<std::string> tmp_inputs;
+	if(cmdline_input || raw_input) {
+		auto as_fasta = [&](std::vector<std::string>& list) {
+			if(list.empty()) return;
+			std::string text;
+			for(const std::string& item : list) {
+				if(cmdline_input) { text += ">\n"; text += item; text += "\n"; continue; }
+				FILE* f = fopen(item.c_str(), "rb");
+				if(!f) { fprintf(stderr, "Error: could not open %s\n", item.c_str()); exit(1); }
+				std::string line;
+				int c;
+				auto flush = [&]() { while(!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back(); if(!line.empty()) { text += ">\n"; text += line; text += "\n"; } line.clear(); };
+				while((c = fgetc(f)) != EOF) { if(c == '\n') flush(); else line.push_back((char)c); }
+				flush();
+				fclose(f);
+			}
+			char path[] = "/tmp/h2g_reads_XXXXXX";
+			const int fd = mkstemp(path);
+			if(fd < 0 || write(fd, text.data(), text.size()) != (ssize_t)text.size()) { fprintf(stderr, "Error: cannot write a temporary read file\n"); exit(1); }
+			close(fd);
+			list.assign(1, path);
+			tmp_inputs.push_back(path);
+		};
+		as_fasta(u); as_fasta(m1); as_fasta(m2);
+		fasta = true;
+	}
+	struct TmpGuard { std::vector<std::string>& v; ~TmpGuard() { for(const std::string& p : v) unlink(p.c_str()); } } tmp_guard{tmp_inputs};
 	if(parse_only) {
 		Reader r(u.empty() ? m1 : u, fasta, threads);
 		r.phred64_ = phred64;

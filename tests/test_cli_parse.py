@@ -86,3 +86,16 @@ def test_phred64_input(tmp_path):
     assert run(p64, ["--phred64"]) == run(p33, [])
     assert run(p64, []) != run(p33, [])
     assert subprocess.run([CLI, "--parse-only", "-q", "-U", str(p33), "-x", "unused", "--phred64"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode != 0
+
+
+def test_raw_and_command_line_reads(tmp_path):
+    """-r (one sequence per line, blank lines skipped) and -c (comma-separated sequences) parse to what the FASTA file with empty
+    record names parses to: reads numbered 0, 1, … , qualities 'I'"""
+    seqs = ["ACGTACGTACGTAGCTAGCTAGCATCGATCGATCGTAGCTAGCTAG", "GGGGACGTNNACGTAGCTAGCTAGCATCGATCGATCGTAGCTAGCTAG", "TTTTGGGGCCCCAAAA"]
+    fa, raw = tmp_path / "e.fa", tmp_path / "e.txt"
+    fa.write_text("".join(f">\n{s}\n" for s in seqs))
+    raw.write_text(seqs[0] + "\n\n" + seqs[1] + "\r\n" + seqs[2])
+    run = lambda args: subprocess.run([CLI, "--parse-only", "-x", "unused"] + args, check=True, stdout=subprocess.PIPE).stdout
+    want = run(["-f", "-U", str(fa)])
+    assert run(["-r", "-U", str(raw)]) == want
+    assert run(["-c", "-U", ",".join(seqs)]) == want

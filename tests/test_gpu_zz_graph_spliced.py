@@ -211,3 +211,25 @@ def test_pair_policy_options_command_line(tmp_path, opts, library):
     mode = [] if "--no-spliced-alignment" in opts else ["--no-temp-splicesite"]
     want = _compare(tmp, base, ["-1", f1, "-2", f2], ["-p", "2", "--reorder"] + mode + opts, ["-p", "2"] + mode + opts)
     assert sum(1 for l in want if l.split("\t")[1] != "77" and l.split("\t")[1] != "141") > 4000
+
+
+@needs_ref
+def test_command_line_and_raw_reads(tmp_path):
+    """-c (sequences on the command line, unpaired and paired) and -r (one sequence per line): names 0, 1, … and the lines of the reference"""
+    import numpy as np
+    tmp = str(tmp_path)
+    contigs = synth.make_genome([120000], 1101, n_gaps=0, gap_len=0, repeats=2, repeat_len=300)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    m1, m2 = synth.make_pairs(contigs, 40, 75, 1102, frag_mean=250, frag_sd=30, sub_rate=0.01)
+    txt = lambda m: ["".join("ACGTN"[int(x)] for x in r) for r in m]
+    s1, s2 = txt(m1), txt(m2)
+    for inputs in (["-c", "-U", ",".join(s1)], ["-c", "-1", ",".join(s1), "-2", ",".join(s2)]):
+        os.makedirs(os.path.join(tmp, "a"), exist_ok=True)
+        _compare(tmp, base, inputs, ["-p", "2", "--reorder", "--no-spliced-alignment"], ["-p", "2", "--no-spliced-alignment"])
+    raw = os.path.join(tmp, "r.txt")
+    open(raw, "w").write("\n".join(s1) + "\n")
+    want = _compare(tmp, base, ["-r", "-U", raw], ["-p", "2", "--reorder", "--no-spliced-alignment"], ["-p", "2", "--no-spliced-alignment"])
+    assert [l.split("\t")[0] for l in want[:3]] == ["0", "1", "2"]
