@@ -120,16 +120,20 @@ def run_case(seed, npairs, sub=0.005, extra=(), show=6, known=0.0, novel_out=Fal
     outs, r1, r2 = emu_pairs(base, m1, m2, q, q, options=extra, splice_sites=sites)
     n = npairs
     res = (api.PairResult * n)()
-    a1 = (api.AlnRes * (n * api.PAIR_RES_CAP))()
-    a2 = (api.AlnRes * (n * api.PAIR_RES_CAP))()
     C.memmove(res, outs, C.sizeof(res))
+    # every record the machine reported, back to back (the dense layout): a pair whose mate reports more than H2G_PAIR_RES_CAP alignments is
+    # flagged and re-run with more room on the device; the host instantiation already holds them all
+    cnt = [[min(int(outs[i].nres[m]), SU.AL_MAX_RESULTS) for i in range(n)] for m in range(2)]
+    offs = [np.concatenate([[0], np.cumsum(cnt[m])]).astype(np.uint64) for m in range(2)]
+    a1 = (api.AlnRes * max(1, int(offs[0][-1])))()
+    a2 = (api.AlnRes * max(1, int(offs[1][-1])))()
     for i in range(n):
         for m, (src, dst) in enumerate(((r1, a1), (r2, a2))):
-            for k in range(min(outs[i].nres[m], api.PAIR_RES_CAP)):
-                C.memmove(C.byref(dst[i * api.PAIR_RES_CAP + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
+            for k in range(cnt[m][i]):
+                C.memmove(C.byref(dst[int(offs[m][i]) + k]), C.byref(src[i * SU.AL_MAX_RESULTS + k]), C.sizeof(api.AlnRes))
     khits = int(extra[extra.index("-k") + 1]) if "-k" in extra else (10 if snps else 5)
     nopt = ["--novel-splicesite-outfile", os.path.join(tmp, "our.ss")] if novel_out else []
-    got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra) + sopt + nopt)
+    got = SL.format_paired(SL.load_sam_lib(), base, list(m1), list(m2), q, q, res, a1, a2, khits, options=list(extra) + sopt + nopt, dense=(offs[0], offs[1]))
     want = SL.body_lines(sam)
     from test_sam_lines import diff_lines
     bad = diff_lines(got, want, show=show)

@@ -22,6 +22,8 @@ def load_sam_lib(path=None):
     L.h2g_sam_format_unpaired.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.h2g_sam_format_paired.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
                                                                              C.POINTER(C.c_size_t)]
+    L.h2g_sam_format_paired_dense.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.h2g_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     L.h2g_sam_header.restype = C.c_size_t
     L.h2g_sam_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -136,7 +138,8 @@ def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):
     return buf.raw[:used.value].decode().splitlines()
 
 
-def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=()):
+def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=(), dense=None):
+    """dense = (offs1, offs2): a1 / a2 hold every pair's records back to back (h2g_align_pairs_fetch_dense's layout), uint64 offsets [n + 1]"""
     h = C.c_void_p()
     assert L.h2g_sam_open(base.encode(), C.byref(h)) == 0
     _score_min(L, h, options)
@@ -149,8 +152,12 @@ def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=()):
     buf = C.create_string_buffer(cap)
     used = C.c_size_t(0)
     ptr = lambda x: x.ctypes.data if isinstance(x, np.ndarray) else C.addressof(x)
-    rc = L.h2g_sam_format_paired(h, c1.ctypes.data, o1.ctypes.data, None, nb1, no1.ctypes.data, c2.ctypes.data, o2.ctypes.data, None, nb2,
-                                 no2.ctypes.data, n, ptr(res), ptr(a1), ptr(a2), khits, buf, cap, C.byref(used))
+    if dense is not None:
+        rc = L.h2g_sam_format_paired_dense(h, c1.ctypes.data, o1.ctypes.data, None, nb1, no1.ctypes.data, c2.ctypes.data, o2.ctypes.data, None, nb2,
+                                           no2.ctypes.data, n, ptr(res), ptr(a1), dense[0].ctypes.data, ptr(a2), dense[1].ctypes.data, khits, buf, cap, C.byref(used))
+    else:
+        rc = L.h2g_sam_format_paired(h, c1.ctypes.data, o1.ctypes.data, None, nb1, no1.ctypes.data, c2.ctypes.data, o2.ctypes.data, None, nb2,
+                                     no2.ctypes.data, n, ptr(res), ptr(a1), ptr(a2), khits, buf, cap, C.byref(used))
     global LAST_SUMMARY
     sb = C.create_string_buffer(4096)
     nsum = L.h2g_sam_summary(h, sb, 4096)
