@@ -180,12 +180,13 @@ struct SeqView {
 	bool           fw;
 	const uint32_t* pk = nullptr;
 	uint32_t       pk_stride = 0;
+	bool           pk_nomask = false;   // the packed read holds no N: no mask words behind the 2-bit words (h2g_fast.h)
 	H2G_HD int at(uint32_t i) const {
 		const uint32_t j = fw ? i : len - 1 - i;
 		int c;
 		if(pk) {
 			c = (int)((pk[(j >> 4) * pk_stride] >> ((j & 15) * 2)) & 3u);
-			if((pk[(H2G_PK_WORDS + (j >> 5)) * pk_stride] >> (j & 31)) & 1u) c = 4;
+			if(!pk_nomask && ((pk[(H2G_PK_WORDS + (j >> 5)) * pk_stride] >> (j & 31)) & 1u)) c = 4;
 		} else c = fwc[j];
 		if(fw) return c;
 		return c < 4 ? 3 - c : 4;

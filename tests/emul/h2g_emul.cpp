@@ -14,6 +14,7 @@
 #include "../../hisat2_amd/csrc/h2g_core.h"
 #include "../../hisat2_amd/csrc/h2g_host_index.h"
 #include "../../hisat2_amd/csrc/h2g_align.h"
+#include "../../hisat2_amd/csrc/h2g_fast.h"
 #include "../../hisat2_amd/csrc/h2g_graph.h"
 #include "../../hisat2_amd/csrc/h2g_sw.h"
 #include "../../hisat2_amd/csrc/h2g_local_pack.h"
@@ -94,6 +95,7 @@ void h2gemu_set_params(Emu* e, const h2g_align_params* p) { e->params = *p; e->h
 
 void h2gemu_set_reads(Emu* e, const uint8_t* codes, const uint32_t* offs, const char* quals, size_t n) {
 	e->codes.assign(codes, codes + offs[n]);
+	e->codes.resize((size_t)offs[n] + 8, 0);   // word-wise readers (fg_pack_read) may touch up to 3 bytes past the last read
 	e->offs.assign(offs, offs + n + 1);
 	e->has_quals = quals != nullptr;
 	if(quals) e->quals.assign(quals, quals + offs[n]);
@@ -324,6 +326,89 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 	delete ws;
 }
 
+
+// ---- the fast path (h2g_fast.h) against the general machine: every read / pair of the batch through both; for the ones the
+// fast path completes, its PairOut / ReadOut and records must equal the machine's.  stats[0] completed, [1] mismatching,
+// [2 + why] bails by reason; bad_ids (cap entries) = the first mismatching read ids.  codes2 == nullptr: unpaired.
+static bool rec_equal(const h2g_alnres& a, const AlnRec& b) {
+	if(a.fw != b.fw || a.tidx != b.tidx || a.toff != b.toff || a.len != b.len || a.trim5 != b.trim5 || a.trim3 != b.trim3 || a.nedits != b.nedits ||
+	   a.splicescore != b.splicescore || a.score != b.score) return false;
+	for(uint32_t k = 0; k < a.nedits; k++) {
+		const h2g_edit &x = a.edits[k], &y = b.edits[k];
+		if(x.pos != y.pos || x.chr != y.chr || x.qchr != y.qchr || x.type != y.type || x.pad != y.pad || x.snp != y.snp) return false;
+	}
+	return true;
+}
+void h2gemu_fast_check(Emu* e, const uint8_t* codes2, const uint32_t* offs2, const char* names1, const uint32_t* noffs1, const char* names2,
+                       const uint32_t* noffs2, uint64_t* stats, uint32_t* bad_ids, uint32_t cap, uint8_t* done_flags) {
+	AlnParams P; AlnCtx C;
+	emu_ctx(e, 1, &P, &C);
+	const bool paired = codes2 != nullptr;
+	AlignWS* ws = new AlignWS();
+	Mach M;
+	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
+	if(paired) { M.rd[1].codes = codes2; M.rd[1].offs = offs2; M.rd[1].quals = nullptr; }
+	const uint32_t n = M.rd[0].n, slots = 16;
+	std::vector<PairOut> mp(1), fp(n);
+	std::vector<ReadOut> mr(1), fr(n);
+	std::vector<h2g_alnres> f1((size_t)n * slots), f2((size_t)n * slots), m1(slots), m2(slots);
+	FCtx F;
+	F.g = &e->dg; F.ref = &e->dr; F.ls = &e->dls; F.P = &P;
+	F.rd[0] = M.rd[0]; F.rd[1] = M.rd[1];
+	uint32_t pk[2][H2G_PK_WORDS];
+	F.pk[0] = pk[0]; F.pk[1] = pk[1]; F.pk_stride = 1;
+	static int64_t sc_[2 * H2G_COMBINE_MAXLEN];
+	F.sc = sc_; F.sc_stride = 1;
+	F.O.rout = fr.data(); F.O.aln = f1.data(); F.O.aln_slots = slots; F.O.pout = fp.data(); F.O.paln[0] = f1.data(); F.O.paln[1] = f2.data(); F.O.pair_slots = slots;
+	uint32_t words[FW_TOTAL];
+	FWords W; W.hot = words; W.hot_stride = 1; W.cold = words + FW_HOT;
+	for(int k = 0; k < 2 + (int)FB_COUNT; k++) stats[k] = 0;
+	uint32_t nbad = 0;
+	for(uint32_t i = 0; i < n; i++) {
+		F.name[0] = names1 + noffs1[i]; F.namelen[0] = noffs1[i + 1] - noffs1[i];
+		F.name[1] = paired ? names2 + noffs2[i] : nullptr; F.namelen[1] = paired ? noffs2[i + 1] - noffs2[i] : 0;
+		memset(words, 0xa5, sizeof words);
+		bool ok = fg_pack_read(F.rd[0], i, pk[0], 1);
+		if(paired) ok = fg_pack_read(F.rd[1], i, pk[1], 1) && ok;
+		FState S;
+		memset(&S, 0xa5, sizeof S);
+		const bool done = fast_run_single(F, S, W, i, paired, ok);
+		if(done_flags) done_flags[i] = done ? 1 : 0;
+		if(!done) { stats[2 + (S.bail < FB_COUNT ? S.bail : FB_OTHER)]++; continue; }
+		stats[0]++;
+		// the machine on the same read
+		M.name[0] = F.name[0]; M.namelen[0] = F.namelen[0]; M.name[1] = F.name[1]; M.namelen[1] = F.namelen[1];
+		MachOut O; O.rout = nullptr; O.aln = nullptr; O.aln_slots = 0; O.pout = nullptr; O.paln[0] = O.paln[1] = nullptr; O.pair_slots = 0;
+		bool same = true;
+		if(paired) {
+			std::vector<PairOut> tmp(n ? 1 : 1);
+			// the machine writes pout[i]: give it a window that starts at -i
+			PairOut one; O.pout = &one - i; O.paln[0] = m1.data() - (size_t)i * slots; O.paln[1] = m2.data() - (size_t)i * slots; O.pair_slots = slots;
+			mach_run_single(C, M, i, true, O);
+			const PairOut& f = fp[i];
+			same = one.nres[0] == f.nres[0] && one.nres[1] == f.nres[1] && one.npairs == f.npairs && one.overflow == f.overflow && one.nrank == f.nrank &&
+			       one.nsteps == f.nsteps && one.depth == f.depth && one.nside == f.nside && one.rnd_state == f.rnd_state &&
+			       memcmp(one.pair_i, f.pair_i, sizeof one.pair_i) == 0 && memcmp(one.pair_j, f.pair_j, sizeof one.pair_j) == 0;
+			for(uint32_t k = 0; same && k < f.nres[0]; k++) same = rec_equal(f1[(size_t)i * slots + k], ws->m[0].res[k]);
+			for(uint32_t k = 0; same && k < f.nres[1]; k++) same = rec_equal(f2[(size_t)i * slots + k], ws->m[1].res[k]);
+		} else {
+			ReadOut one; O.rout = &one - i; O.aln = m1.data() - (size_t)i * slots; O.aln_slots = slots;
+			mach_run_single(C, M, i, false, O);
+			const ReadOut& f = fr[i];
+			same = one.nres == f.nres && one.nselect == f.nselect && one.overflow == f.overflow && one.nrank == f.nrank && one.nsteps == f.nsteps &&
+			       one.depth == f.depth && one.nside == f.nside && one.best == f.best && one.secbest == f.secbest && one.best_h2 == f.best_h2 &&
+			       one.secbest_h2 == f.secbest_h2;
+			for(uint32_t k = 0; same && k < f.nselect; k++) same = one.select[k] == f.select[k];
+			for(uint32_t k = 0; same && k < f.nselect; k++) {
+				const h2g_alnres &a = f1[(size_t)i * slots + k], &b = m1[k];
+				same = a.fw == b.fw && a.tidx == b.tidx && a.toff == b.toff && a.len == b.len && a.trim5 == b.trim5 && a.trim3 == b.trim3 && a.nedits == b.nedits &&
+				       a.splicescore == b.splicescore && a.score == b.score && memcmp(a.edits, b.edits, a.nedits * sizeof(h2g_edit)) == 0;
+			}
+		}
+		if(!same) { stats[1]++; if(nbad < cap) bad_ids[nbad++] = i; }
+	}
+	delete ws;
+}
 
 #ifdef H2G_MEMPROF
 void mp_report(unsigned nreads, const char** opnames, int nops);
