@@ -137,7 +137,7 @@ class Counters(C.Structure):
     _fields_ = [("n_rank", u64), ("n_side", u64), ("n_sa_steps", u64), ("n_ext", u64), ("n_ref_bytes", u64),
                 ("n_queries", u64), ("n_aligned", u64), ("n_overflow", u64), ("ms_search", C.c_float),
                 ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_align_kernel", C.c_float),
-                ("n_second_pass", u64)]
+                ("n_second_pass", u64), ("n_fast", u64), ("n_fast_bail", u64), ("ms_fast_kernel", C.c_float), ("pad_", C.c_float)]
 
 
 ALN_CAP = 10
@@ -364,6 +364,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    if os.environ.get("H2G_LIB"):          # development: a variant build of the library
+        LIB_PATH = os.environ["H2G_LIB"]
     if not os.path.exists(LIB_PATH):
         raise H2GError(f"{LIB_PATH} not built (run __graft_entry__.build()); hisat2_amd has no CPU path")
     L = C.CDLL(LIB_PATH)

@@ -61,9 +61,16 @@ enum : uint32_t {
 	FB_SEARCHED, FB_REDUNDANT, FB_MATE, FB_NPAIRS, FB_PARTIAL, FB_STRADDLE, FB_OTHER, FB_COUNT
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FG_LDS  __attribute__((address_space(3)))   // ds_read / ds_write instead of flat accesses
+#define FG_PRIV __attribute__((address_space(5)))
+#else
+#define FG_LDS
+#define FG_PRIV
+#endif
 struct FWords {                          // the lane's word store
-	uint32_t* hot; uint32_t hot_stride;  // LDS, lane-interleaved (host: stride 1)
-	uint32_t* cold;                      // private memory
+	FG_LDS uint32_t* hot; uint32_t hot_stride;  // LDS, lane-interleaved (host: stride 1)
+	FG_PRIV uint32_t* cold;                     // private memory
 	H2G_HD uint32_t ld(uint32_t i) const { return i < FW_HOT ? hot[i * hot_stride] : cold[i - FW_HOT]; }
 	H2G_HD void st(uint32_t i, uint32_t v) const { if(i < FW_HOT) hot[i * hot_stride] = v; else cold[i - FW_HOT] = v; }
 };
@@ -77,7 +84,7 @@ struct FState {                          // registers of one lane
 	uint32_t pc, op, bail;
 	uint32_t a0, a1, a2, a3, a4, a5;
 	uint32_t read, paired, nm;
-	uint32_t rl[2];
+	uint32_t rl[2], ro[2];                         // length / offset of the mates in their read sets
 	uint32_t rnd;
 	// ReadBWTHit x 4 (index = rdi * 2 + fwi): hi_aligner.h:216
 	uint32_t rb_cur[4], rb_nps[4], rb_nus[4], rb_np[4], rb_sumsq[4];
@@ -177,7 +184,7 @@ H2G_HD uint32_t fg_hit_hash(const h2g_ghit* h) {
 
 H2G_HD SeqView fg_view(const FCtx& C, const FState& S, uint32_t set, bool fw) {
 	const DReads& r = C.rd[set];
-	const uint32_t ro = r.offs[S.read];
+	const uint32_t ro = FG_GET2(S.ro, set);
 	SeqView s;
 	s.fwc = r.codes + ro; s.q = r.quals ? r.quals + ro : nullptr; s.len = FG_GET2(S.rl, set); s.fw = fw;
 	s.pk = C.pk[set]; s.pk_stride = C.pk_stride; s.pk_nomask = true;
@@ -217,16 +224,37 @@ H2G_HD bool fg_pack_read(const DReads& rd, uint32_t i, uint32_t* pk, uint32_t st
 // result summaries: tidx, toff, fw | nedits << 1 | extent << 4 | (score + 32768) << 16
 H2G_HD uint32_t fg_res_base(uint32_t m, uint32_t k) { return FW_RES + (m * FG_NRES + k) * 3; }
 
+// genRandSeed (pat.h:55-91, gen_rand_seed of h2g_align.h) of a read without N from its packed words: the 2-bit codes of 16 bases
+// XOR into the seed exactly as they lie in a packed word
+H2G_HD uint32_t fg_rand_seed(const FCtx& C, const FState& S, uint32_t set) {
+	uint32_t rseed = (0u + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
+	const uint32_t len = FG_GET2(S.rl, set);
+	for(uint32_t w = 0; w < H2G_PK_WORDS; w++) rseed ^= C.pk[set][w * C.pk_stride];
+	const DReads& r = C.rd[set];
+	if(r.quals) {
+		const char* q = r.quals + FG_GET2(S.ro, set);
+		for(uint32_t i = 0; i < len; i++) rseed ^= ((uint32_t)q[i] << ((i & 3) << 3));
+	} else {
+		for(uint32_t b = 0; b < 4; b++) if(((len + 3 - b) >> 2) & 1u) rseed ^= (uint32_t)'I' << (b << 3);
+	}
+	const char* name = C.name[set];
+	for(uint32_t i = 0; i < C.namelen[set]; i++) {
+		const int p = name[i];
+		if(p == '/') break;
+		rseed ^= ((uint32_t)p << ((i & 3) << 3));
+	}
+	return rseed;
+}
+
 // The worker-loop prelude (mach_begin; hisat2.cpp:3380-3530).  `ok0/ok1`: the mates were packed without an N and have 32..128 bases.
 H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, bool packed_ok) {
 	S.read = read; S.op = FOP_NONE; S.bail = FB_NONE; S.paired = paired ? 1u : 0u; S.nm = paired ? 2u : 1u;
-	for(int k = 0; k < 2; k++) { const DReads& r = C.rd[paired ? k : 0]; S.rl[k] = r.offs[read + 1] - r.offs[read]; }
+	for(int k = 0; k < 2; k++) { const DReads& r = C.rd[paired ? k : 0]; S.ro[k] = r.offs[read]; S.rl[k] = r.offs[read + 1] - S.ro[k]; }
 	if(!packed_ok || S.rl[0] < 32 || S.rl[0] > 128 || (paired && (S.rl[1] < 32 || S.rl[1] > 128))) { S.pc = FPC_BAIL; S.bail = FB_INPUT; return; }
 	// no N, length >= 2: both filters pass (read_passes_filters)
-	const SeqView v1 = fg_view(C, S, 0, true);
 	Rng rnd;
-	uint32_t seed = gen_rand_seed(v1, C.name[0], C.namelen[0], 0);
-	if(paired) { const SeqView v2 = fg_view(C, S, 1, true); seed ^= gen_rand_seed(v2, C.name[1], C.namelen[1], 0); }   // hisat2.cpp:3463-3468
+	uint32_t seed = fg_rand_seed(C, S, 0);
+	if(paired) seed ^= fg_rand_seed(C, S, 1);                  // hisat2.cpp:3463-3468
 	rnd.init(seed);
 	S.rnd = rnd.last;
 	S.pc = FPC_GO_INIT;

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "h2g_align.h"
+#include "h2g_fast.h"
 
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
 	for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -39,3 +40,20 @@ struct GoArgs {
 	extern "C" void h2g_go_caps_##NAME(uint32_t*); extern "C" int h2g_go_launch_##NAME(const GoArgs*, unsigned, hipStream_t);
 H2G_GO_DECLARE(linear) H2G_GO_DECLARE(graph) H2G_GO_DECLARE(linear_big) H2G_GO_DECLARE(graph_big)
 H2G_GO_DECLARE(linear_spl) H2G_GO_DECLARE(linear_spl_big) H2G_GO_DECLARE(graph_spl) H2G_GO_DECLARE(graph_spl_big)   // spliced alignment (linear indexes): with the splice-site database joins
+
+// ---- the fast pass (h2g_fast.h / h2g_k_go_fast.hip): one read / pair per lane, state on chip; what it cannot hold goes to `bail_list`
+struct FastArgs {
+	h2g::DGfm g; h2g::DRef ref; h2g::DLocalSet ls;
+	h2g::DReads rd1, rd2;
+	h2g::AlnParams P;
+	const char* names1; const uint32_t* noffs1;
+	const char* names2; const uint32_t* noffs2;
+	uint8_t* sc_base;                     // combineWith temp_scores per lane (as GoArgs::sc_base)
+	h2g::FastOut O;
+	unsigned long long* counters;         // [0] rank calls [1] sides [2] SA steps [4] aligned [6] completed [7] bailed, [96 + why] bails by reason
+	uint32_t* work;                       // next unclaimed read (zeroed before the launch)
+	uint32_t* bail_list; uint32_t* bail_count;
+	uint32_t total, paired;
+};
+extern "C" int h2g_go_fast_launch(const FastArgs*, unsigned grid, hipStream_t);
+extern "C" void h2g_go_fast_geometry(uint32_t* g);   // [0] threads per workgroup [1] LDS bytes per workgroup

@@ -76,6 +76,8 @@ struct h2g_stream {
 	} pool[2];
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
 	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
+	uint32_t* d_bail_list = nullptr;  // read ids the fast pass handed on to the general machine (+ their count behind the list)
+	bool ran_fast = false;
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
 	size_t paln_alloc = 0;
@@ -97,7 +99,7 @@ struct h2g_stream {
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t tmp_sz[4] = {0, 0, 0, 0};
-	hipEvent_t ev[10];
+	hipEvent_t ev[12];
 	bool ran_seed = false, ran_align = false;
 	h2g_counters last;
 };
@@ -348,9 +350,9 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	h2g_stream* s = new h2g_stream();
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-	for(int i = 0; i < 10; i++) HIPCHK(hipEventCreate(&s->ev[i]));
-	HIPCHK(hipMalloc((void**)&s->d_counters, 128 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(s->d_counters, 0, 128 * sizeof(unsigned long long)));
+	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
+	HIPCHK(hipMalloc((void**)&s->d_counters, 256 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->d_counters, 0, 256 * sizeof(unsigned long long)));
 	if(max_reads) {
 		HIPCHK(hipMalloc((void**)&s->d_codes, max_bases + 64));
 		HIPCHK(hipMalloc((void**)&s->d_quals, max_bases + 64));
@@ -371,7 +373,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
-	for(int i = 0; i < 10; i++) (void)hipEventDestroy(s->ev[i]);
+	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
 	(void)hipStreamDestroy(s->st);
 	delete s;
 }
@@ -1564,7 +1566,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	}
 	if(!s->d_ovf_list) HIPCHK(hipMalloc((void**)&s->d_ovf_list, (s->max_reads + 4) * 4));
 	(void)hipGetLastError();
-	HIPCHK(hipMemsetAsync(s->d_counters, 0, 128 * sizeof(unsigned long long), s->st));
+	HIPCHK(hipMemsetAsync(s->d_counters, 0, 256 * sizeof(unsigned long long), s->st));
 	HIPCHK(hipMemsetAsync(s->d_ovf_list + s->max_reads, 0, 16, s->st));
 	A.counters = s->d_counters;
 	A.work = reinterpret_cast<uint32_t*>(s->d_counters + 14);
@@ -1580,6 +1582,40 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	const bool second = !big_main && !no_second;
 	A.defer_overflow = second ? 1u : 0u;
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
+	// ---- the fast pass (h2g_fast.h): the dominant traces with the per-read state on chip.  What it completes is final; the reads
+	// it hands on (a device-side list, no host sync) are the general machine's batch.  Built for unspliced alignment on a linear
+	// index with the default pair policy; every other option set goes to the machine whole.
+	static const int fast_env = getenv("H2G_GO_FAST") ? atoi(getenv("H2G_GO_FAST")) : 1;
+	const bool fast = fast_env && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp && s->max_read_len != 0;
+	s->ran_fast = fast;
+	if(fast) {
+		uint32_t fgeo[2];
+		h2g_go_fast_geometry(fgeo);
+		size_t fwant = (s->n_reads + fgeo[0] - 1) / fgeo[0];
+		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > 256 ? 256 : fwant));      // one persistent workgroup per CU (LDS-bound)
+		h2g_stream::GoPool& pl = s->pool[0];
+		const size_t flanes = (size_t)fgrid * fgeo[0];
+		if(pl.sc_lanes < flanes) {
+			(void)hipFree(pl.sc); pl.sc = nullptr; pl.sc_lanes = 0;
+			HIPCHK(hipMalloc((void**)&pl.sc, flanes * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t))));
+			pl.sc_lanes = flanes;
+			A.sc_base = pl.sc;
+		}
+		if(!s->d_bail_list) HIPCHK(hipMalloc((void**)&s->d_bail_list, (s->max_reads + 4) * 4));
+		HIPCHK(hipMemsetAsync(s->d_bail_list + s->max_reads, 0, 16, s->st));
+		FastArgs F;
+		memset(&F, 0, sizeof F);
+		F.g = A.g; F.ref = A.ref; F.ls = A.ls; F.rd1 = A.rd1; F.rd2 = A.rd2; F.P = A.P;
+		F.names1 = A.names1; F.noffs1 = A.noffs1; F.names2 = A.names2; F.noffs2 = A.noffs2;
+		F.sc_base = pl.sc;
+		F.O.rout = A.O.rout; F.O.aln = A.O.aln; F.O.aln_slots = A.O.aln_slots; F.O.pout = A.O.pout; F.O.paln[0] = A.O.paln[0]; F.O.paln[1] = A.O.paln[1]; F.O.pair_slots = A.O.pair_slots;
+		F.counters = s->d_counters; F.work = reinterpret_cast<uint32_t*>(s->d_counters + 12);
+		F.bail_list = s->d_bail_list; F.bail_count = s->d_bail_list + s->max_reads;
+		F.total = (uint32_t)s->n_reads; F.paired = paired ? 1u : 0u;
+		if(h2g_go_fast_launch(&F, fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
+		A.list = s->d_bail_list; A.nlist = s->d_bail_list + s->max_reads;
+	}
+	HIPCHK(hipEventRecord(s->ev[10], s->st));
 	HIPCHK(hipEventRecord(s->ev[7], s->st));
 	if(U.launch(&A, grid, s->st) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], s->st));
@@ -1727,6 +1763,15 @@ extern "C" __attribute__((visibility("default"))) int h2g_go_prof(h2g_stream* s,
 	return H2G_OK;
 }
 
+// development hook (builds with -DH2G_GO_PROF): the wave-level time split of the last fast pass, 48 slots + 24 bail reasons (h2g_k_go_fast.hip)
+extern "C" __attribute__((visibility("default"))) int h2g_go_fast_prof(h2g_stream* s, unsigned long long* out72) {
+	if(!s || !out72) return H2G_ERR_ARG;
+	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(hipMemcpy(out72, s->d_counters + 128, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out72 + 48, s->d_counters + 96, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return H2G_OK;
+}
+
 extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	if(!s || !c) return H2G_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(s->st));
@@ -1747,7 +1792,14 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 		if(hipEventElapsedTime(&t, s->ev[3], s->ev[4]) == hipSuccess) s->last.ms_resolve_extend = t;
 	}
 	if(s->ran_align && hipEventElapsedTime(&t, s->ev[7], s->ev[6]) == hipSuccess) s->last.ms_align_kernel = t;
-	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[8]) == hipSuccess) s->last.ms_align = t;   // both passes
+	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[8]) == hipSuccess) s->last.ms_align = t;   // every pass
+	s->last.n_fast = 0; s->last.n_fast_bail = 0; s->last.ms_fast_kernel = 0; s->last.pad_ = 0;
+	if(s->ran_align && s->ran_fast) {
+		unsigned long long f[2];
+		HIPCHK(hipMemcpy(f, s->d_counters + 6, sizeof f, hipMemcpyDeviceToHost));
+		s->last.n_fast = f[0]; s->last.n_fast_bail = f[1];
+		if(hipEventElapsedTime(&t, s->ev[5], s->ev[10]) == hipSuccess) s->last.ms_fast_kernel = t;
+	}
 	(void)hipGetLastError();
 	*c = s->last;
 	return H2G_OK;

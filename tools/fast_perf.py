@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""go() timing with the fast pass on / off (env H2G_GO_FAST, read once per process) + a checksum of every result, so that the two
+settings can be compared for identical output.  usage: fast_perf.py se|pe [n] [genome bases]"""
+import os, sys, zlib, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import bench
+from hisat2_amd import api, synth
+
+ALN_DT = np.dtype([("fw", "<u4"), ("tidx", "<u4"), ("toff", "<u4"), ("len", "<u4"), ("trim5", "<u4"), ("trim3", "<u4"), ("nedits", "<u4"), ("spl", "<u4"),
+                   ("score", "<i8"), ("edits", [("pos", "<u4"), ("chr", "u1"), ("qchr", "u1"), ("type", "u1"), ("pad", "u1"), ("snp", "<u4")], 32)])
+
+
+def aln_crc(arr, n):
+    a = np.frombuffer(arr, dtype=ALN_DT, count=n).copy()
+    keep = np.arange(32)[None, :] < a["nedits"][:, None]
+    for f in ("pos", "chr", "qchr", "type", "pad", "snp"):
+        a["edits"][f][~keep] = 0
+    return zlib.crc32(a.tobytes())
+
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "pe"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+glen = int(float(sys.argv[3])) if len(sys.argv) > 3 else 4_900_000
+t0 = time.time()
+if glen < 10_000_000:
+    base, contigs = bench.build_index(os.path.join(ROOT, ".bench_cache"), glen)
+else:
+    import build_bench_index as BB
+    base, total, how = bench.headline_index(os.path.join(ROOT, ".bench_cache"), glen)
+    contigs = BB.genome(total)
+print("index ready in %.1f s" % (time.time() - t0), flush=True)
+ix = api.Index(base)
+if mode == "se":
+    reads, _ = synth.make_reads(contigs, n, 101, bench.SEED + 1000, sub_rate=0.005)
+    codes, offs = synth.flatten_reads(reads)
+    st = api.Stream(ix, max_reads=n, max_bases=codes.size)
+    st.set_reads(codes, offs); st.set_read_names([str(i) for i in range(n)])
+    run = st.align_run
+else:
+    m1, m2 = synth.make_pairs(contigs, n, 101, bench.SEED + 7, sub_rate=0.005)
+    c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
+    names = [str(i) for i in range(n)]
+    st = api.Stream(ix, max_reads=n, max_bases=c1.size)
+    st.set_reads(c1, o1); st.set_read_names(names); st.set_mates(c2, o2, names)
+    run = st.align_pairs_run
+ms = []
+for _ in range(4):
+    run(); st.sync()
+    c = st.counters()
+    ms.append((c.ms_align, c.ms_fast_kernel, c.ms_align_kernel))
+if mode == "se":
+    res, aln, offs_ = st.align_fetch_dense()
+    ck = zlib.crc32(res.tobytes()) ^ aln_crc(aln, int(offs_[n]))
+else:
+    res, a1, o1_, a2, o2_ = st.align_pairs_fetch_dense()
+    ck = zlib.crc32(bytes(res)) ^ aln_crc(a1, int(o1_[n])) ^ aln_crc(a2, int(o2_[n]))
+if os.environ.get("H2G_DUMP"):
+    np.save(os.environ["H2G_DUMP"], np.frombuffer(bytes(res) if mode != "se" else res.tobytes(), dtype=np.uint8))
+L = api.lib()
+if hasattr(L, "h2g_go_fast_prof"):
+    import ctypes as C
+    v = (C.c_ulonglong * 72)()
+    L.h2g_go_fast_prof.argtypes = [C.c_void_p, C.c_void_p]
+    if L.h2g_go_fast_prof(st.h, v) == 0:
+        reasons = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other".split()
+        print("  bails:", {reasons[k]: int(v[48 + k]) for k in range(len(reasons)) if v[48 + k]})
+        if v[47]:
+            ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE".split()
+            tot = sum(v[k] for k in range(0, 16))
+            print("  rounds %d (per wave %.0f), lanes per control step %.1f, wave-ticks %d" % (v[47], v[47] / 2048.0, v[40] / max(1, v[41]), tot))
+            for k, nm in ((0, "fetch"), (1, "control"), (2, "vote")):
+                print("  %-10s %5.1f %%" % (nm, 100.0 * v[k] / tot))
+            for op in range(1, 7):
+                if v[3 + op]:
+                    print("  %-10s %5.1f %%   executions %d: avg %.1f of 64 lanes" % (ops[op], 100.0 * v[3 + op] / tot, v[32 + op], v[20 + op] / max(1, v[32 + op])))
+print("%s n %d genome %d FAST=%s: align total/fast/machine ms %s | fast done %d bailed %d (%.1f %%) second %d overflow %d aligned %d | sides/unit %.1f steps/unit %.1f | crc %08x" % (
+    mode, n, glen, os.environ.get("H2G_GO_FAST", "1"), " ".join("%.2f/%.2f/%.2f" % m for m in ms), c.n_fast, c.n_fast_bail, 100.0 * c.n_fast_bail / n,
+    c.n_second_pass, c.n_overflow, c.n_aligned, c.n_side / n, c.n_sa_steps / n, ck))
