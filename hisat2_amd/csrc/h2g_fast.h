@@ -29,7 +29,7 @@ namespace h2g {
 #define FG_FRS    5                     // scalar words of a saved frame
 #define FG_FRW    (FG_FRS + FG_HW + 3 * FG_NCO)
 #define FG_NFRAME 3
-// word store of one lane: [0, FW_HOT) lives in LDS, [FW_HOT, FW_TOTAL) in private memory (touched by reads with a mismatch only)
+// word store of one read in flight: [0, FW_HOT) is staged in LDS while a wave works on it, [FW_HOT, FW_TOTAL) stays in HBM (touched by reads with a mismatch only)
 #define FW_LONG   0
 #define FW_G0     (FW_LONG + 3 * FG_NLONG)
 #define FW_FR0    (FW_G0 + FG_HW)
@@ -58,7 +58,7 @@ enum : uint32_t {
 // why a read left the fast path (statistics only)
 enum : uint32_t {
 	FB_NONE = 0, FB_INPUT, FB_LONGPOOL, FB_SUBSAMPLE, FB_COORDS, FB_NGHITS, FB_EDITS, FB_DEPTH, FB_LOCALHITS, FB_GSEARCH, FB_NRES,
-	FB_SEARCHED, FB_REDUNDANT, FB_MATE, FB_NPAIRS, FB_PARTIAL, FB_STRADDLE, FB_OTHER, FB_COUNT
+	FB_SEARCHED, FB_REDUNDANT, FB_MATE, FB_NPAIRS, FB_PARTIAL, FB_STRADDLE, FB_OTHER, FB_INDEL, FB_COUNT
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -70,7 +70,7 @@ enum : uint32_t {
 #endif
 struct FWords {                          // the lane's word store
 	FG_LDS uint32_t* hot; uint32_t hot_stride;  // LDS, lane-interleaved (host: stride 1)
-	FG_PRIV uint32_t* cold;                     // private memory
+	uint32_t* cold;                             // the slot's cold words in HBM (reads with a mismatch only)
 	H2G_HD uint32_t ld(uint32_t i) const { return i < FW_HOT ? hot[i * hot_stride] : cold[i - FW_HOT]; }
 	H2G_HD void st(uint32_t i, uint32_t v) const { if(i < FW_HOT) hot[i * hot_stride] = v; else cold[i - FW_HOT] = v; }
 };
@@ -80,36 +80,50 @@ struct FastOut {                         // where a completed read leaves its re
 	PairOut*    pout; h2g_alnres* paln[2]; uint32_t pair_slots;
 };
 
-struct FState {                          // registers of one lane
-	uint32_t pc, op, bail;
-	uint32_t a0, a1, a2, a3, a4, a5;
-	uint32_t read, paired, nm;
-	uint32_t rl[2], ro[2];                         // length / offset of the mates in their read sets
-	uint32_t rnd;
-	// ReadBWTHit x 4 (index = rdi * 2 + fwi): hi_aligner.h:216
-	uint32_t rb_cur[4], rb_nps[4], rb_nus[4], rb_np[4], rb_sumsq[4];
-	uint32_t rb_done, rb_nonempty, found;          // bit sets over the four (read, strand)s
-	int32_t  sel_r, sel_f, nb_rdi, nb_fwi;
-	uint32_t sv_rdi, sv_fw;
-	// per mate: the sink's unpaired lists (summaries in the word store) + HI_Aligner's searched list (hashes)
-	uint32_t nres[2], nsearched[2];
-	int32_t  bestUnp[2], best2Unp[2], minsc[2];
-	// concordant pairs
-	uint32_t npairs, pairs, insp_i, insp_j;      // pairs: 4 bits per pair (i | j << 2)
-	int32_t  bestPair, best2Pair;
-	uint32_t nrank, nside, nsteps, nframes_max;
-	// getAnchorHits / hybridSearch
-	uint32_t nghits, ghit_done, gh_hi, gh_hj, gh_nco, gh_rdoff, hs_hi, hs_hj, hs_found;
-	uint32_t localindexatts, max_localindexatts;
-	// hybridSearch_recur
-	int32_t  sp, rc_minsc, ret;
-	uint32_t rc_ret_pc, pr_ret_pc;
-	// the CURRENT frame (saved into the word store across a nested call)
-	uint32_t f_hitoff, f_hitlen, f_extoff, f_extlen, f_lidx, f_state, f_count, f_ncoords;
-	int32_t  f_ri, f_maxsc, f_prev;
-	uint32_t f_success, f_first, f_uselocal, f_unique;
-	uint32_t f_top, f_bot, f_nelt, f_noext, f_maxHitLen;    // locals of the local-search loop: dead across calls
+// The state of one read between (and during) two trips: FS_WORDS 32-bit words of bit-fields.  It is the slot's stored form as it
+// is (no packing step), and in a kernel it costs FS_WORDS registers instead of one per field — the control code of go() touches a
+// handful of fields per state, and a field access is a bit-field extract / insert.
+struct FState {
+	uint32_t pc : 8, op : 4, bail : 5, paired : 1, nm : 2, found : 4, rb_done : 4, rb_nonempty : 4;                                          // 0
+	uint32_t rl0 : 8, rl1 : 8, sel_r : 1, sel_f : 1, nb_rdi : 1, nb_fwi : 1, sv_rdi : 1, sv_fw : 1, nres0 : 2, nres1 : 2, nsearched0 : 2, nsearched1 : 2, hs_found : 1, pad1_ : 1;   // 1
+	uint32_t a0, a1, a2, a3, a4, a5;                                                                                                   // 2-7
+	uint32_t read, ro0, ro1, rnd;                                                                                                      // 8-11
+	uint32_t rb_cur, rb_nps, rb_nus, rb_np;          // ReadBWTHit x 4 (hi_aligner.h:216), 8 bits each, index = rdi * 2 + fwi          // 12-15
+	uint32_t rb_sumsq0, rb_sumsq1, rb_sumsq2, rb_sumsq3;                                                                               // 16-19
+	int32_t  bestUnp0 : 16, bestUnp1 : 16;           // the sink's per-mate bests; F_SMIN16 = none                                       // 20
+	int32_t  best2Unp0 : 16, best2Unp1 : 16;                                                                                            // 21
+	int32_t  minsc0 : 16, minsc1 : 16;               // F_SMAX16 = the mate is not there                                                // 22
+	uint32_t npairs : 3, pairs : 16, insp_i : 2, insp_j : 2, pad23_ : 9;                   // pairs: 4 bits per pair (i | j << 2)          // 23
+	int32_t  bestPair, best2Pair;                                                                                                      // 24, 25
+	uint32_t nrank : 16, nside : 16;                                                                                                    // 26
+	uint32_t nsteps : 16, nframes_max : 8, pad27_ : 8;                                                                                  // 27
+	uint32_t nghits : 2, ghit_done : 2, gh_hi : 5, gh_hj : 3, gh_nco : 2, gh_rdoff : 8, hs_hi : 2, hs_hj : 2, pad28_ : 6;                 // 28
+	uint32_t localindexatts : 16, max_localindexatts : 16;                                                                              // 29
+	int32_t  sp : 4; uint32_t rc_ret_pc : 8, pr_ret_pc : 8, pad30_ : 12;                                                                // 30
+	int32_t  rc_minsc, ret;                                                                                                            // 31, 32
+	// the CURRENT frame of hybridSearch_recur (saved into the word store across a nested call)
+	uint32_t f_hitoff : 8, f_hitlen : 8, f_extoff : 8, f_extlen : 8;                                                                     // 33
+	uint32_t f_lidx;                                                                                                                   // 34
+	uint32_t f_state : 8, f_count : 2, f_ncoords : 2; int32_t f_ri : 4; uint32_t f_success : 1, f_first : 1, f_uselocal : 1, f_unique : 1, f_noext : 1, pad35_ : 11;   // 35
+	int32_t  f_maxsc, f_prev;                                                                                                          // 36, 37
+	uint32_t f_top : 16, f_bot : 16;                 // rows of a local index (16-bit words); 0xffff stands for "none"                   // 38
+	uint32_t f_nelt : 16, f_maxHitLen : 16;                                                                                             // 39
 };
+#define FS_WORDS 40
+static_assert(sizeof(FState) == FS_WORDS * 4, "FState is FS_WORDS words");
+#define F_SMIN16 (-32768)
+#define F_SMAX16 32767
+// per-mate / per-strand fields by index
+H2G_HD uint32_t fs_rl(const FState& S, uint32_t m) { return m ? S.rl1 : S.rl0; }
+H2G_HD uint32_t fs_ro(const FState& S, uint32_t m) { return m ? S.ro1 : S.ro0; }
+H2G_HD uint32_t fs_nres(const FState& S, uint32_t m) { return m ? S.nres1 : S.nres0; }
+H2G_HD uint32_t fs_nsearched(const FState& S, uint32_t m) { return m ? S.nsearched1 : S.nsearched0; }
+H2G_HD int32_t fs_bestUnp(const FState& S, uint32_t m) { return m ? S.bestUnp1 : S.bestUnp0; }
+H2G_HD int32_t fs_minsc(const FState& S, uint32_t m) { return m ? S.minsc1 : S.minsc0; }
+H2G_HD uint32_t fs_b4(uint32_t w, uint32_t x) { return (w >> (8 * x)) & 0xffu; }
+H2G_HD uint32_t fs_b4_set(uint32_t w, uint32_t x, uint32_t v) { return (w & ~(0xffu << (8 * x))) | ((v & 0xffu) << (8 * x)); }
+H2G_HD uint32_t fs_sumsq(const FState& S, uint32_t x) { return x == 0 ? S.rb_sumsq0 : x == 1 ? S.rb_sumsq1 : x == 2 ? S.rb_sumsq2 : S.rb_sumsq3; }
+H2G_HD void fs_sumsq_add(FState& S, uint32_t x, uint32_t v) { if(x == 0) S.rb_sumsq0 += v; else if(x == 1) S.rb_sumsq1 += v; else if(x == 2) S.rb_sumsq2 += v; else S.rb_sumsq3 += v; }
 #define F_SMIN INT32_MIN
 
 struct FCtx {
@@ -137,57 +151,353 @@ H2G_HD void fg_hit_copy(const FWords& W, uint32_t dst, uint32_t src) {
 	for(uint32_t k = 0; k < 6; k++) W.st(dst + k, W.ld(src + k));
 	for(uint32_t k = 0; k < ne; k++) W.st(dst + 6 + k, W.ld(src + 6 + k));
 }
-H2G_HD void fg_hit_load(const FWords& W, uint32_t hb, h2g_ghit* h) {
-	h->tidx = W.ld(hb); h->toff = W.ld(hb + 1); h->joinedOff = W.ld(hb + 2); h->score = (int64_t)(int32_t)W.ld(hb + 3);
+// A hit in REGISTERS: what GenomeHit holds for an alignment with at most FG_FE mismatch / gap edits on a linear index (no ALT ids,
+// no splices).  Every loop over its edits is unrolled over FG_FE selects: nothing of it is ever indexed in private memory.
+struct FHit {
+	uint32_t tidx, toff, joff; int32_t score;
+	uint32_t rdoff, len, trim5, trim3, fw, nedits, hitcount;
+	uint32_t e0, e1, e2;                  // pos | chr << 8 | qchr << 16 | type << 24
+	uint32_t bad;                         // it stopped fitting (more than FG_FE edits): the read leaves the fast path
+};
+static_assert(FG_FE == 3, "FHit holds three edits");
+#define FE_GET(H, K) ((K) == 0 ? (H).e0 : (K) == 1 ? (H).e1 : (H).e2)
+#define FE_SET(H, K, V) do { const uint32_t v_ = (V); if((K) == 0) (H).e0 = v_; else if((K) == 1) (H).e1 = v_; else (H).e2 = v_; } while(0)
+#define FE_POS(E)  ((E) & 0xffu)
+#define FE_CHR(E)  (((E) >> 8) & 0xffu)
+#define FE_QCHR(E) (((E) >> 16) & 0xffu)
+#define FE_TYPE(E) ((E) >> 24)
+#define FE_MAKE(POS, CHR, QCHR, TYPE) ((uint32_t)(POS) | ((uint32_t)(CHR) << 8) | ((uint32_t)(QCHR) << 16) | ((uint32_t)(TYPE) << 24))
+H2G_HD bool fe_is_gap(uint32_t e) { const uint32_t t = FE_TYPE(e); return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
+
+H2G_HD FHit fh_load(const FWords& W, uint32_t hb) {
+	FHit h;
+	h.tidx = W.ld(hb); h.toff = W.ld(hb + 1); h.joff = W.ld(hb + 2); h.score = (int32_t)W.ld(hb + 3);
 	const uint32_t w4 = W.ld(hb + 4), w5 = W.ld(hb + 5);
-	h->rdoff = w4 & 0xffu; h->len = (w4 >> 8) & 0xffu; h->trim5 = (w4 >> 16) & 0xffu; h->trim3 = w4 >> 24;
-	h->fw = w5 & 1u; h->nedits = (w5 >> 1) & 7u; h->read = w5 >> 8;
-	h->overflow = 0; h->splicescore = 0;
-	for(uint32_t k = 0; k < h->nedits; k++) {
-		const uint32_t e = W.ld(hb + 6 + k);
-		h2g_edit& d = h->edits[k];
-		d.pos = e & 0xffu; d.chr = (uint8_t)(e >> 8); d.qchr = (uint8_t)(e >> 16); d.type = (uint8_t)(e >> 24); d.pad = 0; d.snp = H2G_MAX;
-	}
+	h.rdoff = w4 & 0xffu; h.len = (w4 >> 8) & 0xffu; h.trim5 = (w4 >> 16) & 0xffu; h.trim3 = w4 >> 24;
+	h.fw = w5 & 1u; h.nedits = (w5 >> 1) & 7u; h.hitcount = w5 >> 8;
+	h.e0 = h.nedits > 0 ? W.ld(hb + 6) : 0; h.e1 = h.nedits > 1 ? W.ld(hb + 7) : 0; h.e2 = h.nedits > 2 ? W.ld(hb + 8) : 0;
+	h.bad = 0;
+	return h;
 }
 // false: the hit does not fit the stored form (the caller bails)
-H2G_HD bool fg_hit_store(const FWords& W, uint32_t hb, const h2g_ghit* h) {
-	if(h->overflow || h->nedits > FG_FE || h->score < -(1 << 30) || h->score > (1 << 30) || h->read > 0xffffu) return false;
-	if(h->rdoff > 255 || h->len > 255 || h->trim5 > 255 || h->trim3 > 255) return false;
-	W.st(hb, h->tidx); W.st(hb + 1, h->toff); W.st(hb + 2, h->joinedOff); W.st(hb + 3, (uint32_t)(int32_t)h->score);
-	W.st(hb + 4, h->rdoff | (h->len << 8) | (h->trim5 << 16) | (h->trim3 << 24));
-	W.st(hb + 5, (h->fw ? 1u : 0u) | (h->nedits << 1) | (h->read << 8));
-	for(uint32_t k = 0; k < h->nedits; k++) {
-		const h2g_edit& e = h->edits[k];
-		if(e.pos > 255 || e.snp != H2G_MAX || e.pad != 0) return false;
-		W.st(hb + 6 + k, e.pos | ((uint32_t)e.chr << 8) | ((uint32_t)e.qchr << 16) | ((uint32_t)e.type << 24));
-	}
+H2G_HD bool fh_store(const FWords& W, uint32_t hb, const FHit& h) {
+	if(h.bad || h.nedits > FG_FE || h.score < -(1 << 30) || h.score > (1 << 30) || h.hitcount > 0xffffu) return false;
+	if(h.rdoff > 255 || h.len > 255 || h.trim5 > 255 || h.trim3 > 255) return false;
+	W.st(hb, h.tidx); W.st(hb + 1, h.toff); W.st(hb + 2, h.joff); W.st(hb + 3, (uint32_t)h.score);
+	W.st(hb + 4, h.rdoff | (h.len << 8) | (h.trim5 << 16) | (h.trim3 << 24));
+	W.st(hb + 5, (h.fw ? 1u : 0u) | (h.nedits << 1) | (h.hitcount << 8));
+	if(h.nedits > 0) W.st(hb + 6, h.e0);
+	if(h.nedits > 1) W.st(hb + 7, h.e1);
+	if(h.nedits > 2) W.st(hb + 8, h.e2);
 	return true;
 }
 // a hash of exactly what GenomeHit::operator== compares (hit_equal, hi_aligner.h:1156): equal hits => equal hashes
-H2G_HD uint32_t fg_hit_hash(const h2g_ghit* h) {
+H2G_HD uint32_t fh_hash(const FHit& h) {
 	uint32_t x = 0x9e3779b9u;
 #define FG_MIX(V) do { x ^= (uint32_t)(V); x *= 0x85ebca6bu; x ^= x >> 13; } while(0)
-	FG_MIX(h->fw); FG_MIX(h->rdoff); FG_MIX(h->len); FG_MIX(h->tidx); FG_MIX(h->toff); FG_MIX(h->trim5); FG_MIX(h->trim3); FG_MIX(h->nedits);
-	for(uint32_t i = 0; i < h->nedits; i++) {
-		const h2g_edit& e = h->edits[i];
-		if(e.type == H2G_EDIT_READ_GAP || e.type == H2G_EDIT_REF_GAP) FG_MIX(e.type);
-		else FG_MIX(e.pos | ((uint32_t)e.chr << 8) | ((uint32_t)e.qchr << 16) | ((uint32_t)e.type << 24));
+	FG_MIX(h.fw); FG_MIX(h.rdoff); FG_MIX(h.len); FG_MIX(h.tidx); FG_MIX(h.toff); FG_MIX(h.trim5); FG_MIX(h.trim3); FG_MIX(h.nedits);
+#pragma unroll
+	for(uint32_t i = 0; i < FG_FE; i++) if(i < h.nedits) {
+		const uint32_t e = FE_GET(h, i);
+		if(fe_is_gap(e)) FG_MIX(FE_TYPE(e)); else FG_MIX(e);
 	}
 #undef FG_MIX
 	return x;
 }
+// getRight hi_aligner.h:962-1000 (hit_get_right): the part behind the last gap
+H2G_HD void fh_get_right(const FHit& h, uint32_t* rdoff, uint32_t* len, uint32_t* toff) {
+	*rdoff = h.rdoff; *len = h.len; *toff = h.toff;
+	int last = -1;
+#pragma unroll
+	for(int i = 0; i < FG_FE; i++) if((uint32_t)i < h.nedits && fe_is_gap(FE_GET(h, i))) last = i;
+	if(last < 0) return;
+	const uint32_t e = FE_GET(h, last);
+	*rdoff = h.rdoff + FE_POS(e); *len = h.len - FE_POS(e);
+	if(FE_TYPE(e) == H2G_EDIT_REF_GAP) { (*rdoff)++; (*len)--; }
+	uint32_t roff = h.toff + h.len;
+#pragma unroll
+	for(uint32_t k = 0; k < FG_FE; k++) if(k < h.nedits) {
+		const uint32_t t = FE_TYPE(FE_GET(h, k));
+		if(t == H2G_EDIT_READ_GAP) roff++; else if(t == H2G_EDIT_REF_GAP) roff--;
+	}
+	*toff = roff - *len;
+}
+// getLeft :919-958 (hit_get_left): the part in front of the first gap
+H2G_HD void fh_get_left(const FHit& h, uint32_t* rdoff, uint32_t* len, uint32_t* toff) {
+	*toff = h.toff; *rdoff = h.rdoff; *len = h.len;
+	bool stop = false;
+#pragma unroll
+	for(uint32_t i = 0; i < FG_FE; i++) if(i < h.nedits && !stop && fe_is_gap(FE_GET(h, i))) { *len = FE_POS(FE_GET(h, i)); stop = true; }
+}
+// compatibleWith :1375-1413 (hit_compatible) without spliced alignment
+H2G_HD bool fh_compatible(const FHit& a, const FHit& b) {
+	if(a.fw != b.fw || a.tidx != b.tidx) return false;
+	if(a.rdoff > b.rdoff) return false;
+	if(a.rdoff + a.len > b.rdoff + b.len) return false;
+	if(a.toff > b.toff) return false;
+	uint32_t ar, al, at, br, bl, bt;
+	fh_get_right(a, &ar, &al, &at);
+	fh_get_left(b, &br, &bl, &bt);
+	if(ar > br) return false;
+	if(ar + al > br + bl) return false;
+	if(at > bt) return false;
+	return true;
+}
+// calculateScore :3711-3891 (calculate_score) for mismatch / gap edits and soft trims
+H2G_HD void fh_calc_score(const DScoring& sc, const SeqView& seq, FHit& h) {
+	int64_t score = 0;
+	uint32_t mm = 0, prev = 0;
+#pragma unroll
+	for(uint32_t i = 0; i < FG_FE; i++) if(i < h.nedits) {
+		const uint32_t e = FE_GET(h, i), t = FE_TYPE(e);
+		if(t == H2G_EDIT_MM) {
+			const int q = seq.qual(h.rdoff + FE_POS(e)) - 33;
+			if(FE_QCHR(e) == 'N') score -= sc.nPen;
+			else if(FE_CHR(e) == 'N') score += sc.matchBonus;
+			else score -= mm_penalty(sc, q);
+			mm++;
+		} else if(t == H2G_EDIT_READ_GAP) {
+			const bool open = !(i > 0 && FE_TYPE(prev) == H2G_EDIT_READ_GAP && FE_POS(prev) == FE_POS(e));
+			score -= open ? (sc.rdGapConst + sc.rdGapLinear) : sc.rdGapLinear;
+		} else if(t == H2G_EDIT_REF_GAP) {
+			const bool open = !(i > 0 && FE_TYPE(prev) == H2G_EDIT_REF_GAP && FE_POS(prev) + 1 == FE_POS(e));
+			score -= open ? (sc.rfGapConst + sc.rfGapLinear) : sc.rfGapLinear;
+		}
+		prev = e;
+	}
+	for(uint32_t i = 0; i < h.trim5; i++) score -= sc_penalty(sc, seq.qual(i));
+	for(uint32_t i = 0; i < h.trim3; i++) score -= sc_penalty(sc, seq.qual(i));
+	score += (int64_t)(h.len - mm) * sc.matchBonus;
+	if(score < -(1 << 30)) { h.bad = 1; score = -(1 << 30); }
+	h.score = (int32_t)score;
+}
+// alignWithALTs without ALTs (align_no_alts of h2g_core.h; hi_aligner.h:683-783, :2763-2853, :3168-3216): extends by up to `mm`
+// mismatches; the new edits are committed to the hit.  Returns the extension length.
+H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdoff, uint32_t rdoff, uint32_t rdlen, int rfoff, uint32_t rflen,
+                         bool left, FHit& h, uint32_t mm, uint32_t* numNs)
+{
+	if(numNs) *numNs = 0;
+	const uint32_t n_old = h.nedits;
+	uint32_t n0 = 0, n1 = 0, n2 = 0;                       // the first three new edits
+	uint32_t tmp_mm = 0, nNs = 0, extlen = 0;
+	bool updated = false;
+	const uint32_t contig_len = ref.refLens[h.tidx];
+	bool run = !(rfoff < -16) && !((int64_t)rfoff >= (int64_t)contig_len);
+	if(run) {
+		if(rfoff >= 0 && (uint64_t)rfoff + rflen > contig_len) rflen = contig_len - (uint32_t)rfoff;
+		else if(rfoff < 0 && rflen > contig_len) rflen = contig_len;
+		if(rflen == 0) run = false;
+	}
+	if(run) {
+		RefCursor rc;
+		rc.init(&ref, h.tidx);
+		const uint32_t rdoff_add = rdoff - base_rdoff;
+		if(left) {
+			int i = (int)rdoff;
+			for(int rf_i = (int)rflen - 1; rf_i >= 0 && i >= 0; rf_i--, i--) {
+				const int64_t p = (int64_t)rfoff + rf_i;
+				const int rf_bp = p < 0 ? 4 : rc.get(p), rd_bp = seq.at((uint32_t)i);
+				if(rf_bp != rd_bp || rd_bp == 4) {
+					if(tmp_mm >= mm) break;
+					const uint32_t e = FE_MAKE(i, base_char(rf_bp), base_char(rd_bp), H2G_EDIT_MM);
+					if(tmp_mm == 0) n0 = e; else if(tmp_mm == 1) n1 = e; else if(tmp_mm == 2) n2 = e;
+					tmp_mm++;
+				}
+				if(rf_bp == 4) nNs++;
+			}
+			if(i < (int)rdoff) { updated = true; extlen = rdoff - (uint32_t)i; if(numNs) *numNs = nNs; }
+		} else {
+			uint32_t i = 0;
+			for(uint32_t rf_i = 0; rf_i < rflen && i < rdlen; rf_i++, i++) {
+				const int64_t p = (int64_t)rfoff + rf_i;
+				const int rf_bp = p < 0 ? 4 : rc.get(p), rd_bp = seq.at(rdoff + i);
+				if(rf_bp != rd_bp || rd_bp == 4) {
+					if(tmp_mm >= mm) break;
+					const uint32_t e = FE_MAKE(i + rdoff_add, base_char(rf_bp), base_char(rd_bp), H2G_EDIT_MM);
+					if(tmp_mm == 0) n0 = e; else if(tmp_mm == 1) n1 = e; else if(tmp_mm == 2) n2 = e;
+					tmp_mm++;
+				}
+			}
+			if(i > 0) { updated = true; extlen = i; }
+		}
+	}
+	if(!updated) tmp_mm = 0;
+	const uint32_t total = n_old + tmp_mm;
+	if(tmp_mm > FG_FE) { h.bad = 1; return extlen; }       // (the new edits beyond the third were not kept)
+	const uint32_t nlast = tmp_mm == 0 ? 0u : (tmp_mm == 1 ? n0 : (tmp_mm == 2 ? n1 : n2));
+	if(extlen > 0 && total > 0) {   // :751-779: front() / back() of the list the reference would hold
+		const uint32_t old_first = h.e0, old_last = n_old == 0 ? 0u : FE_GET(h, n_old - 1);
+		uint32_t f, b;
+		if(left) { f = tmp_mm ? nlast : old_first; b = n_old ? old_last : n0; }
+		else     { f = n_old ? old_first : n0;     b = tmp_mm ? nlast : old_last; }
+		if(FE_POS(f) + extlen == base_rdoff + 1) {
+			if(fe_is_gap(f)) extlen = 0;
+			if(FE_TYPE(f) == H2G_EDIT_MM && FE_CHR(f) == 'N') extlen = 0;
+		}
+		if(extlen > 0 && FE_POS(b) == rdoff - base_rdoff + extlen - 1) { if(fe_is_gap(b)) extlen = 0; }
+	}
+	if(extlen > 0 && tmp_mm > 0) {   // commit the new edits
+		if(total > FG_FE) { h.bad = 1; return extlen; }
+		if(left) {                   // new edits go to the front, in increasing read position
+			// old edits move up by tmp_mm (total <= 3)
+			if(tmp_mm == 1) { h.e2 = h.e1; h.e1 = h.e0; h.e0 = n0; }
+			else if(tmp_mm == 2) { h.e2 = h.e0; h.e0 = n1; h.e1 = n0; }
+			else { h.e0 = n2; h.e1 = n1; h.e2 = n0; }
+		} else {
+			if(tmp_mm >= 1) FE_SET(h, n_old, n0);
+			if(tmp_mm >= 2) FE_SET(h, n_old + 1, n1);
+			if(tmp_mm >= 3) FE_SET(h, n_old + 2, n2);
+		}
+		h.nedits = total;
+	}
+	if(extlen == 0 && numNs) *numNs = updated ? nNs : 0;
+	return extlen;
+}
+// GenomeHit::extend hi_aligner.h:2031-2232 (extend_item)
+H2G_HD void fh_extend(const DRef& ref, const DScoring& sc, const SeqView& seq, FHit& h, uint32_t mm, uint32_t max_leftext, uint32_t max_rightext,
+                      uint32_t* leftext, uint32_t* rightext)
+{
+	const uint32_t rdlen = seq.len;
+	*leftext = 0; *rightext = 0;
+	if(max_leftext > 0 && h.rdoff > 0) {
+		if(h.toff <= 0) return;
+		int rl = (int)h.toff - (int)h.rdoff;
+		uint32_t reflen = h.rdoff + 10;
+		rl -= (int)(reflen - h.rdoff);
+		if(rl < 0) { reflen += rl; rl = 0; }
+		uint32_t numNs = 0;
+		const uint32_t n_prev = h.nedits;
+		const uint32_t best_ext = fh_align(ref, seq, h.rdoff - 1, h.rdoff - 1, h.rdoff, rl, reflen, true, h, mm, &numNs);
+		if(h.bad) return;
+		if(h.len == 0 && mm == 0 && h.nedits > 0) { h.nedits = 0; return; }
+		if(best_ext > 0) {
+			*leftext = best_ext;
+			const uint32_t added = h.nedits - n_prev;
+			h.rdoff -= best_ext; h.toff -= best_ext; h.len += best_ext; h.joff -= best_ext - numNs;   // (the new edits are mismatches: ref_ext == best_ext)
+#pragma unroll
+			for(uint32_t i = 0; i < FG_FE; i++) if(i < h.nedits) {
+				const uint32_t e = FE_GET(h, i);
+				const uint32_t pos = i < added ? FE_POS(e) - h.rdoff : FE_POS(e) + best_ext;
+				if(pos > 255) h.bad = 1;
+				FE_SET(h, i, (e & 0xffffff00u) | (pos & 0xffu));
+			}
+		}
+	}
+	if(max_rightext > 0 && h.rdoff + h.len < rdlen) {
+		uint32_t r_rdoff, r_len, r_toff;
+		fh_get_right(h, &r_rdoff, &r_len, &r_toff);
+		const uint32_t rl = r_toff + r_len;
+		const uint32_t rr = rdlen - (r_rdoff + r_len);
+		const uint32_t tlen = ref.refLens[h.tidx];
+		if(rl < tlen) {
+			uint32_t reflen = rr + 10;
+			if(rl + reflen > tlen) reflen = tlen - rl;
+			const uint32_t best_ext = fh_align(ref, seq, h.rdoff, h.rdoff + h.len, rdlen - (h.rdoff + h.len), (int)rl, reflen, false, h, mm, nullptr);
+			if(h.bad) return;
+			if(h.len == 0 && mm == 0 && h.nedits > 0) { h.nedits = 0; return; }
+			if(best_ext > 0) { *rightext = best_ext; h.len += best_ext; }
+		}
+	}
+	fh_calc_score(sc, seq, h);
+}
+// combineWith hi_aligner.h:1420-2025 (hit_combine) without spliced alignment, for two hits with the same read / reference offset
+// difference: concatenation (:1506-1525) or the rescan of the joint for mismatches (:1880-1931).  An insertion or deletion between
+// them is the general machine's: *indel is set and nothing else happens.
+// the mismatch scores getRight / getLeft return with their parts (hit_get_right_sc, hit_get_left): behind the last / before the first gap
+H2G_HD int64_t fh_part_score(const DScoring& sc, const SeqView& seq, const FHit& h, bool right) {
+	int first = -1, last = -1;
+#pragma unroll
+	for(int i = 0; i < FG_FE; i++) if((uint32_t)i < h.nedits && fe_is_gap(FE_GET(h, i))) { if(first < 0) first = i; last = i; }
+	int64_t score = 0;
+#pragma unroll
+	for(int i = 0; i < FG_FE; i++) if((uint32_t)i < h.nedits) {
+		const uint32_t e = FE_GET(h, i);
+		if(FE_TYPE(e) != H2G_EDIT_MM) continue;
+		if(right ? i > last : (first < 0 || i < first))
+			score += score_cell(sc, base_code((uint8_t)FE_QCHR(e)), base_code((uint8_t)FE_CHR(e)), seq.qual(h.rdoff + FE_POS(e)) - 33);
+	}
+	return score;
+}
+H2G_HD bool fh_combine(const DRef& ref, const DScoring& sc, const SeqView& seq, FHit& a, const FHit& b, int64_t minsc, bool* indel) {
+	*indel = false;
+	uint32_t this_rdoff, this_len, this_toff, other_rdoff, other_len, other_toff;
+	fh_get_right(a, &this_rdoff, &this_len, &this_toff);
+	fh_get_left(b, &other_rdoff, &other_len, &other_toff);
+	if(this_len != 0 && other_len != 0 && this_rdoff + this_len > other_rdoff + other_len) return false;
+	const uint32_t len = other_rdoff - this_rdoff + other_len;
+	const uint32_t reflen = ref.refLens[a.tidx];
+	if(this_toff + len > reflen) return false;
+	const uint32_t refdif = other_toff - this_toff, rddif = other_rdoff - this_rdoff;
+	if(refdif != rddif) {
+		// an insertion or a deletion: the gap budget decides first (:1539-1560); a join that survives it is the general machine's
+		int64_t remainsc = minsc - ((int64_t)a.score - fh_part_score(sc, seq, a, true)) - ((int64_t)b.score - fh_part_score(sc, seq, b, false));
+		if(remainsc > 0) remainsc = 0;
+		const int read_gaps = max_gaps(remainsc + sc.cp, sc.rdGapConst + sc.rdGapLinear, sc.rdGapLinear);
+		const int ref_gaps = max_gaps(remainsc + sc.cp, sc.rfGapConst + sc.rfGapLinear, sc.rfGapLinear);
+		if(refdif < rddif) { if((int64_t)refdif + ref_gaps < (int64_t)rddif) return false; }
+		else { if((int64_t)rddif + read_gaps < (int64_t)refdif) return false; }
+		*indel = true;
+		return false;
+	}
+	if(this_rdoff + this_len == other_rdoff) {
+		const uint32_t addoff = b.rdoff - a.rdoff;
+#pragma unroll
+		for(uint32_t i = 0; i < FG_FE; i++) if(i < b.nedits) {
+			const uint32_t e = FE_GET(b, i), pos = FE_POS(e) + addoff;
+			if(a.nedits >= FG_FE || pos > 255) { a.bad = 1; break; }
+			FE_SET(a, a.nedits, (e & 0xffffff00u) | pos); a.nedits++;
+		}
+		a.len += b.len;
+		fh_calc_score(sc, seq, a);
+		return true;
+	}
+	// keep this hit's edits up to (and including) its last gap; drop the mismatches after it (:1818-1831)
+	{
+		int last = -1;
+#pragma unroll
+		for(int i = 0; i < FG_FE; i++) if((uint32_t)i < a.nedits && fe_is_gap(FE_GET(a, i))) last = i;
+		a.nedits = (uint32_t)(last + 1);
+	}
+	{
+		RefCursor rc1;
+		rc1.init(&ref, a.tidx);
+		const uint32_t addoff = this_rdoff - a.rdoff;
+		for(uint32_t i = 0; i < len; i++) {
+			const int rdc = seq.at(this_rdoff + i), rfc = rc1.get((int64_t)this_toff + i);
+			if(rdc != rfc) {
+				if(a.nedits >= FG_FE || i + addoff > 255) { a.bad = 1; break; }
+				FE_SET(a, a.nedits, FE_MAKE(i + addoff, base_char(rfc), base_char(rdc), H2G_EDIT_MM)); a.nedits++;
+			}
+		}
+	}
+	if(!a.bad) {   // the other hit's edits from its first gap on
+		int fsi = -1;
+#pragma unroll
+		for(int i = FG_FE - 1; i >= 0; i--) if((uint32_t)i < b.nedits && fe_is_gap(FE_GET(b, i))) fsi = i;
+		const uint32_t addoff = b.rdoff - a.rdoff;
+#pragma unroll
+		for(int i = 0; i < FG_FE; i++) if(fsi >= 0 && i >= fsi && (uint32_t)i < b.nedits) {
+			const uint32_t e = FE_GET(b, i), pos = FE_POS(e) + addoff;
+			if(a.nedits >= FG_FE || pos > 255) { a.bad = 1; break; }
+			FE_SET(a, a.nedits, (e & 0xffffff00u) | pos); a.nedits++;
+		}
+	}
+	a.len = b.rdoff + b.len - a.rdoff;
+	a.trim3 += b.trim3;
+	fh_calc_score(sc, seq, a);
+	return true;
+}
 
 // small per-strand arrays by explicit selects (registers, no private-memory indexing)
-#define FG_GET4(A, I) ((I) == 0 ? (A)[0] : (I) == 1 ? (A)[1] : (I) == 2 ? (A)[2] : (A)[3])
-#define FG_SET4(A, I, V) do { const uint32_t v_ = (V); if((I) == 0) (A)[0] = v_; else if((I) == 1) (A)[1] = v_; else if((I) == 2) (A)[2] = v_; else (A)[3] = v_; } while(0)
-#define FG_GET2(A, I) ((I) == 0 ? (A)[0] : (A)[1])
 
 H2G_HD SeqView fg_view(const FCtx& C, const FState& S, uint32_t set, bool fw) {
-	const DReads& r = C.rd[set];
-	const uint32_t ro = FG_GET2(S.ro, set);
+	// (selects, not indexing: an indexed array member would pin the whole context in private memory)
+	const uint8_t* codes = set ? C.rd[1].codes : C.rd[0].codes;
+	const char* quals = set ? C.rd[1].quals : C.rd[0].quals;
+	const uint32_t ro = fs_ro(S, set);
 	SeqView s;
-	s.fwc = r.codes + ro; s.q = r.quals ? r.quals + ro : nullptr; s.len = FG_GET2(S.rl, set); s.fw = fw;
-	s.pk = C.pk[set]; s.pk_stride = C.pk_stride; s.pk_nomask = true;
+	s.fwc = codes + ro; s.q = quals ? quals + ro : nullptr; s.len = fs_rl(S, set); s.fw = fw;
+	s.pk = set ? C.pk[1] : C.pk[0]; s.pk_stride = C.pk_stride; s.pk_nomask = true;
 	return s;
 }
 H2G_HD SeqView fg_sv(const FCtx& C, const FState& S) { return fg_view(C, S, S.paired ? S.sv_rdi : 0u, S.sv_fw != 0); }
@@ -228,17 +538,19 @@ H2G_HD uint32_t fg_res_base(uint32_t m, uint32_t k) { return FW_RES + (m * FG_NR
 // XOR into the seed exactly as they lie in a packed word
 H2G_HD uint32_t fg_rand_seed(const FCtx& C, const FState& S, uint32_t set) {
 	uint32_t rseed = (0u + 101u) * 59u * 61u * 67u * 71u * 73u * 79u * 83u;
-	const uint32_t len = FG_GET2(S.rl, set);
-	for(uint32_t w = 0; w < H2G_PK_WORDS; w++) rseed ^= C.pk[set][w * C.pk_stride];
-	const DReads& r = C.rd[set];
-	if(r.quals) {
-		const char* q = r.quals + FG_GET2(S.ro, set);
+	const uint32_t len = fs_rl(S, set);
+	const uint32_t* pk = set ? C.pk[1] : C.pk[0];
+	for(uint32_t w = 0; w < H2G_PK_WORDS; w++) rseed ^= pk[w * C.pk_stride];
+	const char* quals = set ? C.rd[1].quals : C.rd[0].quals;
+	if(quals) {
+		const char* q = quals + fs_ro(S, set);
 		for(uint32_t i = 0; i < len; i++) rseed ^= ((uint32_t)q[i] << ((i & 3) << 3));
 	} else {
 		for(uint32_t b = 0; b < 4; b++) if(((len + 3 - b) >> 2) & 1u) rseed ^= (uint32_t)'I' << (b << 3);
 	}
-	const char* name = C.name[set];
-	for(uint32_t i = 0; i < C.namelen[set]; i++) {
+	const char* name = set ? C.name[1] : C.name[0];
+	const uint32_t namelen = set ? C.namelen[1] : C.namelen[0];
+	for(uint32_t i = 0; i < namelen; i++) {
 		const int p = name[i];
 		if(p == '/') break;
 		rseed ^= ((uint32_t)p << ((i & 3) << 3));
@@ -249,8 +561,23 @@ H2G_HD uint32_t fg_rand_seed(const FCtx& C, const FState& S, uint32_t set) {
 // The worker-loop prelude (mach_begin; hisat2.cpp:3380-3530).  `ok0/ok1`: the mates were packed without an N and have 32..128 bases.
 H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, bool packed_ok) {
 	S.read = read; S.op = FOP_NONE; S.bail = FB_NONE; S.paired = paired ? 1u : 0u; S.nm = paired ? 2u : 1u;
-	for(int k = 0; k < 2; k++) { const DReads& r = C.rd[paired ? k : 0]; S.ro[k] = r.offs[read]; S.rl[k] = r.offs[read + 1] - S.ro[k]; }
-	if(!packed_ok || S.rl[0] < 32 || S.rl[0] > 128 || (paired && (S.rl[1] < 32 || S.rl[1] > 128))) { S.pc = FPC_BAIL; S.bail = FB_INPUT; return; }
+	// every field has a defined value from here on: the packed form of the state (fs_pack) gives each its bits
+	S.a0 = S.a1 = S.a2 = S.a3 = S.a4 = S.a5 = 0;
+	S.sel_r = S.sel_f = S.nb_rdi = S.nb_fwi = 0; S.sv_rdi = S.sv_fw = 0;
+	S.gh_hi = S.gh_hj = S.gh_nco = S.gh_rdoff = S.hs_hi = S.hs_hj = S.hs_found = 0;
+	S.sp = -1; S.rc_minsc = 0; S.ret = 0; S.rc_ret_pc = S.pr_ret_pc = 0;
+	S.f_hitoff = S.f_hitlen = S.f_extoff = S.f_extlen = S.f_lidx = S.f_state = S.f_count = S.f_ncoords = 0; S.f_ri = 0; S.f_maxsc = S.f_prev = 0;
+	S.f_success = S.f_first = S.f_uselocal = S.f_unique = 0; S.f_top = S.f_bot = S.f_nelt = 0; S.f_noext = 0; S.f_maxHitLen = 0;
+	S.rb_cur = S.rb_nps = S.rb_nus = S.rb_np = 0; S.rb_sumsq0 = S.rb_sumsq1 = S.rb_sumsq2 = S.rb_sumsq3 = 0;
+	S.rb_done = S.rb_nonempty = S.found = 0; S.rnd = 0; S.ro0 = S.ro1 = 0; S.rl0 = S.rl1 = 0;
+	S.nres0 = S.nres1 = S.nsearched0 = S.nsearched1 = 0; S.bestUnp0 = S.bestUnp1 = S.best2Unp0 = S.best2Unp1 = F_SMIN16; S.minsc0 = S.minsc1 = F_SMAX16;
+	S.pad1_ = 0; S.pad23_ = 0; S.pad27_ = 0; S.pad28_ = 0; S.pad30_ = 0; S.pad35_ = 0;
+	S.npairs = S.pairs = S.insp_i = S.insp_j = 0; S.bestPair = S.best2Pair = F_SMIN;
+	S.nrank = S.nside = S.nsteps = S.nframes_max = 0; S.nghits = S.ghit_done = 0; S.localindexatts = S.max_localindexatts = 0;
+	S.ro0 = C.rd[0].offs[read]; S.ro1 = C.rd[1].offs[read];                     // (unpaired: rd[1] is rd[0])
+	const uint32_t len0 = C.rd[0].offs[read + 1] - S.ro0, len1 = C.rd[1].offs[read + 1] - S.ro1;
+	if(!packed_ok || len0 < 32 || len0 > 128 || (paired && (len1 < 32 || len1 > 128))) { S.pc = FPC_BAIL; S.bail = FB_INPUT; return; }
+	S.rl0 = len0; S.rl1 = len1;
 	// no N, length >= 2: both filters pass (read_passes_filters)
 	Rng rnd;
 	uint32_t seed = fg_rand_seed(C, S, 0);
@@ -271,7 +598,7 @@ H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, boo
 		fg_frame_save(W, S); fg_hit_copy(W, fg_frame_hit(S.sp + 1), (HB)); S.sp++; S.f_hitoff = hoff_; S.f_hitlen = hlen_; \
 		if((uint32_t)S.sp + 1 > S.nframes_max) S.nframes_max = (uint32_t)S.sp + 1; \
 		F_GOTO(FPC_RC_ENTRY); } while(0)
-#define F_MINSC_LIVE(MV) do { const int32_t b_ = FG_GET2(S.bestUnp, S.sv_rdi); if(b_ > (MV)) (MV) = b_; } while(0)
+#define F_MINSC_LIVE(MV) do { const int32_t b_ = fs_bestUnp(S, S.sv_rdi); if(b_ > (MV)) (MV) = b_; } while(0)
 
 H2G_HD void fg_frame_save(const FWords& W, const FState& S) {
 	const uint32_t b = fg_frame_base(S.sp);
@@ -290,23 +617,27 @@ H2G_HD void fg_frame_restore(const FWords& W, FState& S) {
 }
 
 // reportHit + AlnSinkWrap::report (al_report of h2g_align.h) for a full-length hit; the record goes straight to its output slot
-H2G_HD void fg_write_rec(h2g_alnres& d, const h2g_ghit* hit, uint32_t rdlen) {
-	d.fw = hit->fw; d.tidx = hit->tidx; d.toff = hit->toff; d.len = hit->len; d.trim5 = hit->trim5; d.trim3 = hit->trim3;
-	d.nedits = hit->nedits; d.splicescore = hit->splicescore; d.score = hit->score;
-	const uint32_t trim5p = hit->fw ? hit->trim5 : hit->trim3;
-	for(uint32_t k = 0; k < hit->nedits; k++) {
-		h2g_edit e;
-		if(hit->fw) { e = hit->edits[k]; e.pos += hit->trim5; }
-		else e = inverted_edit(hit, k, rdlen, hit->trim5);
-		e.pos -= trim5p;
-		d.edits[k] = e;
+H2G_HD void fg_write_rec(h2g_alnres& d, const FHit& hit, uint32_t rdlen) {
+	d.fw = hit.fw; d.tidx = hit.tidx; d.toff = hit.toff; d.len = hit.len; d.trim5 = hit.trim5; d.trim3 = hit.trim3;
+	d.nedits = hit.nedits; d.splicescore = 0; d.score = (int64_t)hit.score;
+	const uint32_t trim5p = hit.fw ? hit.trim5 : hit.trim3;
+#pragma unroll
+	for(uint32_t k = 0; k < FG_FE; k++) if(k < hit.nedits) {
+		const uint32_t e = hit.fw ? FE_GET(hit, k) : FE_GET(hit, hit.nedits - 1 - k);
+		uint32_t pos = FE_POS(e) + hit.trim5;
+		if(!hit.fw) pos = FE_TYPE(e) == H2G_EDIT_READ_GAP ? rdlen - pos : rdlen - pos - 1;   // Edit::invertPoss edit.cpp:70-111
+		pos -= trim5p;
+		h2g_edit o;
+		o.pos = pos; o.chr = (uint8_t)FE_CHR(e); o.qchr = (uint8_t)FE_QCHR(e); o.type = (uint8_t)FE_TYPE(e); o.pad = 0; o.snp = H2G_MAX;
+		d.edits[k] = o;
 	}
 }
-H2G_HD uint32_t fg_ref_extent(const h2g_ghit* h) {
-	uint32_t ext = h->len;
-	for(uint32_t k = 0; k < h->nedits; k++) {
-		if(h->edits[k].type == H2G_EDIT_READ_GAP) ext++;
-		else if(h->edits[k].type == H2G_EDIT_REF_GAP) ext--;
+H2G_HD uint32_t fg_ref_extent(const FHit& h) {
+	uint32_t ext = h.len;
+#pragma unroll
+	for(uint32_t k = 0; k < FG_FE; k++) if(k < h.nedits) {
+		const uint32_t t = FE_TYPE(FE_GET(h, k));
+		if(t == H2G_EDIT_READ_GAP) ext++; else if(t == H2G_EDIT_REF_GAP) ext--;
 	}
 	return ext;
 }
@@ -330,15 +661,13 @@ again:
 		S.npairs = 0; S.pairs = 0; S.insp_i = S.insp_j = 0; S.bestPair = F_SMIN; S.best2Pair = F_SMIN;
 		S.localindexatts = 0; S.max_localindexatts = 0;
 		S.nghits = 0; S.ghit_done = 0;
-		for(int r = 0; r < 2; r++) {
-			S.nres[r] = 0; S.nsearched[r] = 0; S.bestUnp[r] = F_SMIN; S.best2Unp[r] = F_SMIN; S.minsc[r] = INT32_MAX;
-			if((uint32_t)r < S.nm) {
-				const int64_t m = min_score_for(P, S.rl[r]);
-				if(m < -(1 << 24)) F_BAIL(FB_INPUT);
-				S.minsc[r] = (int32_t)m;
-			}
+		S.nres0 = S.nres1 = S.nsearched0 = S.nsearched1 = 0; S.bestUnp0 = S.bestUnp1 = S.best2Unp0 = S.best2Unp1 = F_SMIN16; S.minsc0 = S.minsc1 = F_SMAX16;
+		{
+			const int64_t m0 = min_score_for(P, S.rl0), m1 = S.nm > 1 ? min_score_for(P, S.rl1) : 0;
+			if(m0 < -30000 || m1 < -30000) F_BAIL(FB_INPUT);        // (the scores are kept in 16 bits)
+			S.minsc0 = (int32_t)m0; if(S.nm > 1) S.minsc1 = (int32_t)m1;
 		}
-		for(int k = 0; k < 4; k++) { S.rb_cur[k] = 0; S.rb_nps[k] = 0; S.rb_nus[k] = 0; S.rb_np[k] = 0; S.rb_sumsq[k] = 0; }
+		S.rb_cur = S.rb_nps = S.rb_nus = S.rb_np = 0; S.rb_sumsq0 = S.rb_sumsq1 = S.rb_sumsq2 = S.rb_sumsq3 = 0;
 		S.rb_done = 0; S.rb_nonempty = 0;
 		S.found = S.paired ? 15u : 3u;                           // found[0][0], [0][1], [1][0], [1][1]
 		for(uint32_t k = 0; k < FG_NLONG; k++) W.st(FW_LONG + 3 * k + 2, 0);
@@ -350,34 +679,34 @@ again:
 		for(uint32_t r = 0; r < S.nm; r++) for(int k = 0; k < 2; k++) {
 			const uint32_t x = r * 2 + (uint32_t)k;
 			if((S.rb_done >> x) & 1u) continue;
-			const uint32_t act = FG_GET4(S.rb_nps, x) - FG_GET4(S.rb_nus, x);
-			int64_t cs = (int64_t)FG_GET4(S.rb_sumsq, x) - (int64_t)act * minK * minK - ((int64_t)1 << (act << 1));   // ReadBWTHit::searchScore :320
-			if(FG_GET4(S.rb_cur, x) == 0) cs = INT64_MAX;
+			const uint32_t act = fs_b4(S.rb_nps, x) - fs_b4(S.rb_nus, x);
+			int64_t cs = (int64_t)fs_sumsq(S, x) - (int64_t)act * minK * minK - ((int64_t)1 << (act << 1));   // ReadBWTHit::searchScore :320
+			if(fs_b4(S.rb_cur, x) == 0) cs = INT64_MAX;
 			if(cs > maxScore) { maxScore = cs; rdi = (int)r; fwi = k; }
 		}
 		if(rdi < 0) F_GOTO(FPC_AFTER_LOOP);
 		const uint32_t x = (uint32_t)rdi * 2 + (uint32_t)fwi, xr = (uint32_t)rdi * 2 + (uint32_t)(1 - fwi);
 		{
-			const uint32_t numSearched = FG_GET4(S.rb_nps, x) - FG_GET4(S.rb_nus, x);
-			const int32_t bestScore = FG_GET2(S.bestUnp, rdi), msc = FG_GET2(S.minsc, rdi);
+			const uint32_t numSearched = fs_b4(S.rb_nps, x) - fs_b4(S.rb_nus, x);
+			const int32_t bestScore = fs_bestUnp(S, rdi), msc = fs_minsc(S, rdi);
 			if(bestScore >= msc) {
 				const uint32_t maxmm = (uint32_t)((-(int64_t)bestScore + sc.mmpMax - 1) / sc.mmpMax);
 				if(numSearched > maxmm + 1) {
 					S.rb_done |= 1u << x; fg_pool_free(W, x);
 					if(S.paired) {
-						const int32_t ob = FG_GET2(S.bestUnp, 1 - rdi), om = FG_GET2(S.minsc, 1 - rdi);
+						const int32_t ob = fs_bestUnp(S, 1 - rdi), om = fs_minsc(S, 1 - rdi);
 						if(ob >= om && S.npairs > 0) F_GOTO(FPC_AFTER_LOOP); else F_GOTO(FPC_NB_PICK);
 					} else F_GOTO(FPC_AFTER_LOOP);
 				}
 			}
 			if(((S.rb_done >> xr) & 1u) && bestScore < msc) {
-				const uint32_t rcs = FG_GET4(S.rb_nps, xr) - FG_GET4(S.rb_nus, xr);
+				const uint32_t rcs = fs_b4(S.rb_nps, xr) - fs_b4(S.rb_nus, xr);
 				if(numSearched > rcs + (P.anchorStop ? 1u : 0u)) { S.rb_done |= 1u << x; fg_pool_free(W, x); F_GOTO(FPC_AFTER_LOOP); }
 			}
 		}
 		S.nb_rdi = rdi; S.nb_fwi = fwi;
 		S.sv_rdi = (uint32_t)rdi; S.sv_fw = fwi == 0;
-		S.a0 = FG_GET4(S.rb_cur, x);
+		S.a0 = fs_b4(S.rb_cur, x);
 		F_OP(FOP_PSEARCH, FPC_NB_AFTER_PS);
 	}
 	case FPC_NB_AFTER_PS: {
@@ -385,11 +714,11 @@ again:
 		const int rdi = S.nb_rdi, fwi = S.nb_fwi;
 		const uint32_t x = (uint32_t)rdi * 2 + (uint32_t)fwi;
 		const uint32_t top = S.a0, bot = S.a1, len = S.a2 & 0xffu, type = (S.a2 >> 8) & 0xffu, done = (S.a2 >> 16) & 1u, anchor = (S.a2 >> 17) & 1u, nus = S.a2 >> 18;
-		S.nrank += S.a4 & 0xffffu; S.nside += S.a4 >> 16;
-		FG_SET4(S.rb_nps, x, FG_GET4(S.rb_nps, x) + 1); FG_SET4(S.rb_nus, x, FG_GET4(S.rb_nus, x) + nus); FG_SET4(S.rb_cur, x, S.a3);
-		const uint32_t np = FG_GET4(S.rb_np, x);
+		{ const uint32_t nr_ = S.nrank + (S.a4 & 0xffffu), ns_ = S.nside + (S.a4 >> 16); if(nr_ > 0xffffu || ns_ > 0xffffu) F_BAIL(FB_OTHER); S.nrank = nr_; S.nside = ns_; }
+		S.rb_nps = fs_b4_set(S.rb_nps, x, fs_b4(S.rb_nps, x) + 1); S.rb_nus = fs_b4_set(S.rb_nus, x, fs_b4(S.rb_nus, x) + nus); S.rb_cur = fs_b4_set(S.rb_cur, x, S.a3);
+		const uint32_t np = fs_b4(S.rb_np, x);
 		if(np >= 16) F_BAIL(FB_PARTIAL);                    // AL_MAX_PARTIAL of the default workspace
-		FG_SET4(S.rb_sumsq, x, FG_GET4(S.rb_sumsq, x) + len * len);
+		fs_sumsq_add(S, x, len * len);
 		if(bot > top && bot != H2G_MAX) {
 			S.rb_nonempty |= 1u << x;
 			if(len > minK + 2) {                            // getAnchorHits looks at these only (:5033)
@@ -400,9 +729,9 @@ again:
 				W.st(FW_LONG + 3 * k + 2, 0x80000000u | S.a5 | (len << 8) | (type << 16) | (x << 20) | (np << 24));   // bwoff, len, type, strand, index
 			}
 		}
-		FG_SET4(S.rb_np, x, np + 1);
+		S.rb_np = fs_b4_set(S.rb_np, x, np + 1);
 		if(done) { S.rb_done |= 1u << x; S.sel_r = rdi; S.sel_f = fwi; F_GOTO(FPC_ALIGN); }
-		{ const uint32_t cur = FG_GET4(S.rb_cur, x); if(cur + 1 < FG_GET2(S.rl, rdi)) FG_SET4(S.rb_cur, x, cur + 1); }   // !pseudogeneStop (never set without spliced alignment)
+		{ const uint32_t cur = fs_b4(S.rb_cur, x); if(cur + 1 < fs_rl(S, rdi)) S.rb_cur = fs_b4_set(S.rb_cur, x, cur + 1); }   // !pseudogeneStop (never set without spliced alignment)
 		if(anchor) { S.rb_done |= 1u << x; S.sel_r = rdi; S.sel_f = fwi; F_GOTO(FPC_ALIGN); }
 		F_GOTO(FPC_NB_PICK);
 	}
@@ -411,11 +740,11 @@ again:
 		S.sv_rdi = (uint32_t)S.sel_r; S.sv_fw = S.sel_f == 0;
 		const uint32_t x = (uint32_t)S.sel_r * 2 + (uint32_t)S.sel_f;
 		if(!((S.rb_nonempty >> x) & 1u)) { S.hs_found = 0; F_GOTO(FPC_AFTER_ALIGN); }
-		int32_t bestScore = FG_GET2(S.bestUnp, S.sel_r);
-		const int32_t msc = FG_GET2(S.minsc, S.sel_r);
+		int32_t bestScore = fs_bestUnp(S, S.sel_r);
+		const int32_t msc = fs_minsc(S, S.sel_r);
 		if(bestScore < msc) bestScore = msc;
 		const uint32_t maxmm = (uint32_t)((-(int64_t)bestScore + sc.mmpMax - 1) / sc.mmpMax);
-		const uint32_t nact = FG_GET4(S.rb_nps, x) - FG_GET4(S.rb_nus, x);
+		const uint32_t nact = fs_b4(S.rb_nps, x) - fs_b4(S.rb_nus, x);
 		if(nact > maxmm + 1) { S.hs_found = 1; F_GOTO(FPC_AFTER_ALIGN); }
 		S.nghits = 0; S.gh_hi = 0;
 		F_GOTO(FPC_GAH_LOOP);
@@ -433,9 +762,9 @@ again:
 	}
 	case FPC_PAIR_READS: {                                // pairReads hi_aligner.h:5948-6055 (al_pair_reads) over the summaries
 		const uint32_t start_i = S.insp_i, start_j = S.insp_j;
-		S.insp_i = S.nres[0]; S.insp_j = S.nres[1];
-		for(uint32_t i = 0; i < S.nres[0]; i++) {
-			for(uint32_t j = (i >= start_i ? 0 : start_j); j < S.nres[1]; j++) {
+		S.insp_i = S.nres0; S.insp_j = S.nres1;
+		for(uint32_t i = 0; i < S.nres0; i++) {
+			for(uint32_t j = (i >= start_i ? 0 : start_j); j < S.nres1; j++) {
 				const uint32_t b1 = fg_res_base(0, i), b2 = fg_res_base(1, j);
 				const uint32_t t1 = W.ld(b1), t2 = W.ld(b2);
 				if(t1 != t2) continue;
@@ -457,8 +786,8 @@ again:
 				else        pass = pe_concordant(o2, e2, fw2, o1, e1, fw1, P.maxFragLen);
 				if(pass) {
 					int64_t threshold = S.bestPair == F_SMIN ? INT64_MIN : (int64_t)S.bestPair;
-					if(S.bestUnp[0] >= S.minsc[0] && S.bestUnp[1] >= S.minsc[1]) {
-						const int64_t tmp = (int64_t)((double)((int64_t)S.bestUnp[0] + S.bestUnp[1]) - (double)(S.rl[0] + S.rl[1]) * 0.03 * (double)sc.mmpMax);
+					if(S.bestUnp0 != F_SMIN16 && S.bestUnp1 != F_SMIN16 && S.bestUnp0 >= S.minsc0 && S.bestUnp1 >= S.minsc1) {
+						const int64_t tmp = (int64_t)((double)((int64_t)S.bestUnp0 + S.bestUnp1) - (double)(S.rl0 + S.rl1) * 0.03 * (double)sc.mmpMax);
 						if(tmp > threshold) threshold = tmp;
 					}
 					const int32_t score = s1 + s2;
@@ -475,21 +804,29 @@ again:
 	}
 	case FPC_AFTER_LOOP: {
 		// no concordant pair but an aligned mate: alignMate (hi_aligner.h:4092-4148) is the general machine's
-		if(S.paired && S.npairs == 0 && (S.bestUnp[0] >= S.minsc[0] || S.bestUnp[1] >= S.minsc[1])) F_BAIL(FB_MATE);
+		if(S.paired && S.npairs == 0 && ((S.bestUnp0 != F_SMIN16 && S.bestUnp0 >= S.minsc0) || (S.bestUnp1 != F_SMIN16 && S.bestUnp1 >= S.minsc1))) F_BAIL(FB_MATE);
 		F_GOTO(FPC_FINISH);
 	}
 	// ======================================================================== getAnchorHits :5007-5193
 	case FPC_GAH_LOOP: {
 		const uint32_t x = (uint32_t)S.sel_r * 2 + (uint32_t)S.sel_f;
-		const uint32_t offsetSize = FG_GET4(S.rb_np, x);
+		const uint32_t offsetSize = fs_b4(S.rb_np, x);
 		if(S.gh_hi >= offsetSize) F_GOTO(FPC_GAH_END);
 		// candidates in index order: pool entries of this strand that were not resolved yet (bit 30 = has coordinates)
 		uint32_t hj = FG_NLONG, mj = 0, tj_top = 0, tj_bot = 0;
-		for(uint32_t idx = 0; idx < 16; idx++) {                  // by the hit's index in the strand's list
-			uint32_t k = 0, m = 0;
-			for(; k < FG_NLONG; k++) { m = W.ld(FW_LONG + 3 * k + 2); if(m && ((m >> 20) & 3u) == x && ((m >> 24) & 31u) == idx) break; }
-			if(k >= FG_NLONG) continue;
-			if(m & 0x40000000u) continue;                        // ncoords > 0
+		int last = -1;                                          // index of the candidate looked at last
+		for(uint32_t pass = 0; pass < FG_NLONG; pass++) {
+			// the unresolved entry of this strand with the smallest index above `last`
+			uint32_t k = FG_NLONG, m = 0;
+			int kidx = 1 << 20;
+#pragma unroll
+			for(uint32_t q = 0; q < FG_NLONG; q++) {
+				const uint32_t mq = W.ld(FW_LONG + 3 * q + 2);
+				const int iq = (int)((mq >> 24) & 31u);
+				if(mq && !(mq & 0x40000000u) && ((mq >> 20) & 3u) == x && iq > last && iq < kidx) { k = q; m = mq; kidx = iq; }
+			}
+			if(k == FG_NLONG) break;
+			last = kidx;
 			const uint32_t top = W.ld(FW_LONG + 3 * k), bot = W.ld(FW_LONG + 3 * k + 1);
 			if(hj == FG_NLONG) { hj = k; mj = m; tj_top = top; tj_bot = bot; continue; }
 			const uint32_t tj = (mj >> 16) & 15u, tk = (m >> 16) & 15u, lj = (mj >> 8) & 0xffu, lk = (m >> 8) & 0xffu;
@@ -504,20 +841,20 @@ again:
 		if(expected > remained) F_BAIL(FB_SUBSAMPLE);       // the random sub-sample of a repeat's rows (:5096-5136)
 		if(expected > FG_NCO) F_BAIL(FB_COORDS);
 		S.gh_hj = hj; S.gh_nco = 0;
-		S.gh_rdoff = FG_GET2(S.rl, S.sel_r) - bwoff - len;
+		S.gh_rdoff = fs_rl(S, S.sel_r) - bwoff - len;
 		S.a0 = tj_top; S.a1 = tj_bot; S.a2 = expected; S.a3 = len; S.a4 = 0; S.a5 = fg_frame_co(0);
 		F_OP(FOP_GCOORDS, FPC_GAH_FULL_AFTER);
 	}
 	case FPC_GAH_FULL_AFTER: {
 		const uint32_t nco = S.a0;
-		S.nsteps += S.a1;
+		{ const uint32_t nt_ = S.nsteps + S.a1; if(nt_ > 0xffffu) F_BAIL(FB_OTHER); S.nsteps = nt_; }
 		if(nco == 0) F_BAIL(FB_COORDS);                     // joinedToTextOff failed: the reference retries the same hit (:5140)
 		const uint32_t mslot = FW_LONG + 3 * S.gh_hj + 2;
 		const uint32_t m = W.ld(mslot);
 		W.st(mslot, m | 0x40000000u);                       // ph.ncoords = nco
 		const uint32_t len = (m >> 8) & 0xffu, type = (m >> 16) & 15u;
 		const uint32_t gsize = S.nghits;                    // gsize + nco <= maxsz: no shuffle (:5147)
-		const uint32_t rl = FG_GET2(S.rl, S.sel_r);
+		const uint32_t rl = fs_rl(S, S.sel_r);
 		for(uint32_t k = 0; k < nco; k++) {
 			const uint32_t cb = fg_frame_co(0) + 3 * k;
 			const uint32_t tidx = W.ld(cb), toff = W.ld(cb + 1), joff = W.ld(cb + 2);
@@ -545,7 +882,7 @@ again:
 	case FPC_GAH_END: {
 		const uint32_t numHits = S.nghits;
 		if(numHits == 0) { S.hs_found = 0; F_GOTO(FPC_AFTER_ALIGN); }
-		const uint64_t add = (uint64_t)((-(int64_t)FG_GET2(S.minsc, S.sel_r)) / sc.mmpMax) * numHits;
+		const uint64_t add = (uint64_t)((-(int64_t)fs_minsc(S, S.sel_r)) / sc.mmpMax) * numHits;
 		S.max_localindexatts = S.localindexatts + (uint32_t)(add > 10 ? add : 10);
 		S.hs_hi = 0;
 		F_GOTO(FPC_HS_EXT_LOOP);
@@ -574,60 +911,59 @@ again:
 		const uint32_t w4 = W.ld(gb + 4);
 		fg_hit_copy(W, fg_frame_hit(0), gb);
 		S.sp = 0; S.f_hitoff = w4 & 0xffu; S.f_hitlen = (w4 >> 8) & 0xffu;
-		S.rc_minsc = FG_GET2(S.minsc, S.sel_r); S.rc_ret_pc = FPC_HS_AFTER_REC1; S.ret = F_SMIN;
+		S.rc_minsc = fs_minsc(S, S.sel_r); S.rc_ret_pc = FPC_HS_AFTER_REC1; S.ret = F_SMIN;
 		F_GOTO(FPC_RC_ENTRY);
 	}
 	case FPC_HS_AFTER_REC1: { S.ghit_done |= 1u << S.hs_hj; S.hs_hi++; F_GOTO(FPC_HS_LOOP); }     // (no SwAligner pass: bowtie2_dp == 0)
 	// ======================================================================== hybridSearch_recur spliced_aligner.h:331-2052
 	case FPC_RC_ENTRY: {
-		h2g_ghit hit;
-		fg_hit_load(W, fg_frame_hit(S.sp), &hit);
-		const uint32_t hitoff = S.f_hitoff, hitlen = S.f_hitlen, rdlen = FG_GET2(S.rl, S.sv_rdi);
+		const FHit hit = fh_load(W, fg_frame_hit(S.sp));
+		const uint32_t hitoff = S.f_hitoff, hitlen = S.f_hitlen, rdlen = fs_rl(S, S.sv_rdi);
 		const int32_t minsc = S.rc_minsc;
 		S.f_maxsc = F_SMIN;
-		if(hit.score < (int64_t)minsc) F_RC_RET(S.f_maxsc);
+		if(hit.score < minsc) F_RC_RET(S.f_maxsc);
 		if(hitoff == hit.rdoff - hit.trim5 && hitlen == hit.len + hit.trim5 + hit.trim3) {
-			const uint32_t hsh = fg_hit_hash(&hit);
-			const uint32_t sb = FW_SRCH + S.sv_rdi * FG_NSRCH, ns = FG_GET2(S.nsearched, S.sv_rdi);
+			const uint32_t hsh = fh_hash(hit);
+			const uint32_t sb = FW_SRCH + S.sv_rdi * FG_NSRCH, ns = fs_nsearched(S, S.sv_rdi);
 			for(uint32_t i = 0; i < ns; i++) if(W.ld(sb + i) == hsh) F_BAIL(FB_SEARCHED);   // isSearched (or a collision): not ours to decide
 			if(ns >= FG_NSRCH) F_BAIL(FB_SEARCHED);
 			W.st(sb + ns, hsh);
-			if(S.sv_rdi == 0) S.nsearched[0] = ns + 1; else S.nsearched[1] = ns + 1;
+			if(S.sv_rdi == 0) S.nsearched0 = ns + 1; else S.nsearched1 = ns + 1;
 		}
 		if(hitoff == 0 && hitlen == rdlen) {
 			// redundant() :6311 over the summaries: same locus, strand and edit count => the general machine compares the edits
-			const uint32_t nr = FG_GET2(S.nres, S.sv_rdi);
+			const uint32_t nr = fs_nres(S, S.sv_rdi);
 			for(uint32_t i = 0; i < nr; i++) {
 				const uint32_t rb = fg_res_base(S.sv_rdi, i), m = W.ld(rb + 2);
 				if(W.ld(rb) == hit.tidx && W.ld(rb + 1) == hit.toff && (m & 1u) == (hit.fw ? 1u : 0u) && ((m >> 1) & 7u) == hit.nedits) F_BAIL(FB_REDUNDANT);
 			}
 			// reportHit :6064 (al_report)
-			if(!(hit.rdoff - hit.trim5 > 0 || hit.len + hit.trim5 + hit.trim3 < rdlen) && hit.score >= (int64_t)minsc) {
+			if(!(hit.rdoff - hit.trim5 > 0 || hit.len + hit.trim5 + hit.trim3 < rdlen) && hit.score >= minsc) {
 				if(nr >= FG_NRES) F_BAIL(FB_NRES);
-				const uint32_t ext = fg_ref_extent(&hit);
+				const uint32_t ext = fg_ref_extent(hit);
 				if(hit.score < -32000 || hit.score > 32000 || ext > 0xfffu) F_BAIL(FB_OTHER);
 				if(S.paired) {
 					if(nr >= C.O.pair_slots) F_BAIL(FB_NRES);
-					fg_write_rec(C.O.paln[S.sv_rdi][(size_t)S.read * C.O.pair_slots + nr], &hit, rdlen);
+					h2g_alnres* pl = S.sv_rdi ? C.O.paln[1] : C.O.paln[0];
+					fg_write_rec(pl[(size_t)S.read * C.O.pair_slots + nr], hit, rdlen);
 				} else {
 					if(nr >= C.O.aln_slots) F_BAIL(FB_NRES);
-					fg_write_rec(C.O.aln[(size_t)S.read * C.O.aln_slots + nr], &hit, rdlen);
+					fg_write_rec(C.O.aln[(size_t)S.read * C.O.aln_slots + nr], hit, rdlen);
 				}
 				const uint32_t rb = fg_res_base(S.sv_rdi, nr);
 				W.st(rb, hit.tidx); W.st(rb + 1, hit.toff);
-				W.st(rb + 2, (hit.fw ? 1u : 0u) | (hit.nedits << 1) | (ext << 4) | ((uint32_t)((int32_t)hit.score + 32768) << 16));
-				const int32_t s = (int32_t)hit.score;
+				W.st(rb + 2, (hit.fw ? 1u : 0u) | (hit.nedits << 1) | (ext << 4) | ((uint32_t)(hit.score + 32768) << 16));
+				const int32_t s = hit.score;
 				if(S.sv_rdi == 0) {
-					S.nres[0] = nr + 1;
-					if(S.bestUnp[0] == F_SMIN || s > S.bestUnp[0]) { S.best2Unp[0] = S.bestUnp[0]; S.bestUnp[0] = s; } else if(S.best2Unp[0] == F_SMIN || s > S.best2Unp[0]) S.best2Unp[0] = s;
+					S.nres0 = nr + 1;
+					if(S.bestUnp0 == F_SMIN16 || s > S.bestUnp0) { S.best2Unp0 = S.bestUnp0; S.bestUnp0 = s; } else if(S.best2Unp0 == F_SMIN16 || s > S.best2Unp0) S.best2Unp0 = s;
 				} else {
-					S.nres[1] = nr + 1;
-					if(S.bestUnp[1] == F_SMIN || s > S.bestUnp[1]) { S.best2Unp[1] = S.bestUnp[1]; S.bestUnp[1] = s; } else if(S.best2Unp[1] == F_SMIN || s > S.best2Unp[1]) S.best2Unp[1] = s;
+					S.nres1 = nr + 1;
+					if(S.bestUnp1 == F_SMIN16 || s > S.bestUnp1) { S.best2Unp1 = S.bestUnp1; S.bestUnp1 = s; } else if(S.best2Unp1 == F_SMIN16 || s > S.best2Unp1) S.best2Unp1 = s;
 				}
 			}
 			// (the frame's maximum follows the hit whether or not it was reported: spliced_aligner.h:676)
-			if(hit.score < -(1 << 30)) F_BAIL(FB_OTHER);
-			if(S.f_maxsc == F_SMIN || (int32_t)hit.score > S.f_maxsc) S.f_maxsc = (int32_t)hit.score;
+			if(S.f_maxsc == F_SMIN || hit.score > S.f_maxsc) S.f_maxsc = hit.score;
 			F_RC_RET(S.f_maxsc);
 		}
 		if(S.sp >= FG_NFRAME - 1) F_BAIL(FB_DEPTH);          // the deepest frame holds no lists: it may only report
@@ -648,7 +984,7 @@ again:
 	case FPC_RC_ENTRY_RX: {                                // extend to the right (:1496-2050)
 		const uint32_t hb = fg_frame_hit(S.sp);
 		const uint32_t w4 = W.ld(hb + 4), h_len = (w4 >> 8) & 0xffu;
-		const uint32_t rdlen = FG_GET2(S.rl, S.sv_rdi);
+		const uint32_t rdlen = fs_rl(S, S.sv_rdi);
 		S.f_uselocal = 1;
 		if(h_len == S.f_hitlen && S.f_hitoff + S.f_hitlen + minK > rdlen) {
 			fg_hit_copy(W, FW_T1, hb);
@@ -660,7 +996,7 @@ again:
 	case FPC_RC_ENTRY_L2: { if((W.ld(FW_T1 + 4) & 0xffu) == 0) S.f_uselocal = 0; F_GOTO(FPC_RC_ENTRY_L3); }
 	case FPC_RC_ENTRY_R2: {
 		const uint32_t w4 = W.ld(FW_T1 + 4);
-		if((w4 & 0xffu) + ((w4 >> 8) & 0xffu) == FG_GET2(S.rl, S.sv_rdi)) S.f_uselocal = 0;
+		if((w4 & 0xffu) + ((w4 >> 8) & 0xffu) == fs_rl(S, S.sv_rdi)) S.f_uselocal = 0;
 		F_GOTO(FPC_RC_ENTRY_R3);
 	}
 	case FPC_RC_ENTRY_L3:
@@ -690,7 +1026,7 @@ again:
 		F_GOTO(FPC_L_LS_LOOP);
 	}
 	case FPC_L_LS_LOOP: {
-		if(!(S.f_extoff < FG_GET2(S.rl, S.sv_rdi))) F_GOTO(FPC_L_LS_DONE);
+		if(!(S.f_extoff < fs_rl(S, S.sv_rdi))) F_GOTO(FPC_L_LS_DONE);
 		S.f_extlen = 0; S.f_unique = 1;
 		S.localindexatts++;
 		if(C.ls->desc[S.f_lidx].len == 0) { S.a0 = 0; S.a1 = 0; S.a2 = S.f_top; S.a3 = S.f_bot; S.a4 = 1; F_GOTO(FPC_L_LS_AFTER); }
@@ -729,9 +1065,7 @@ again:
 		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
 		fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, W.ld(cb), W.ld(cb + 1), W.ld(cb + 2));
-		h2g_ghit t, fh;
-		fg_hit_load(W, FW_T1, &t); fg_hit_load(W, hb, &fh);
-		if(!hit_compatible(&t, &fh, P.maxIntronLen, true)) {
+		if(!fh_compatible(fh_load(W, FW_T1), fh_load(W, hb))) {
 			if(S.f_count == 1) { S.f_ri--; F_GOTO(FPC_L_FOR_RI); }
 			F_GOTO(FPC_L_AFTER_FOR);
 		}
@@ -766,17 +1100,16 @@ again:
 		F_GOTO(FPC_L_TRIM);
 	}
 	case FPC_L_TRIM: {
-		h2g_ghit hit;
-		fg_hit_load(W, fg_frame_hit(S.sp), &hit);
+		FHit hit = fh_load(W, fg_frame_hit(S.sp));
 		const int64_t minsc = S.rc_minsc;
 		const int64_t floor_ = (S.f_maxsc != F_SMIN && (int64_t)S.f_maxsc > minsc) ? (int64_t)S.f_maxsc : minsc;
-		const int64_t tm = (hit.score - floor_) / sc_penalty(sc, 0);
+		const int64_t tm = ((int64_t)hit.score - floor_) / sc_penalty(sc, 0);
 		const uint32_t trimMax = (uint32_t)tm;
 		if(hit.rdoff < trimMax) {
 			hit.trim5 = hit.rdoff;                            // GenomeHit::trim5 hi_aligner.h:831
-			calculate_score(sc, fg_sv(C, S), &hit);
-			if((S.f_maxsc == F_SMIN || hit.score > (int64_t)S.f_maxsc) && hit.score >= minsc) {
-				if(!fg_hit_store(W, FW_T1, &hit)) F_BAIL(FB_EDITS);
+			fh_calc_score(sc, fg_sv(C, S), hit);
+			if((S.f_maxsc == F_SMIN || hit.score > S.f_maxsc) && (int64_t)hit.score >= minsc) {
+				if(!fh_store(W, FW_T1, hit)) F_BAIL(FB_EDITS);
 				F_RC_CALL(FW_T1, 0, hit.len + hit.trim5 + hit.trim3, FPC_L_R4);
 			}
 		}
@@ -815,7 +1148,7 @@ again:
 	case FPC_L_R5: { if(S.ret > S.f_maxsc) S.f_maxsc = S.ret; F_RC_RET(S.f_maxsc); }
 	// =============================== RIGHT ===============================
 	case FPC_R_WHILE: {
-		const uint32_t rdlen = FG_GET2(S.rl, S.sv_rdi);
+		const uint32_t rdlen = fs_rl(S, S.sv_rdi);
 		if(S.f_success) F_GOTO(FPC_R_AFTER_WHILE);
 		if(!(S.f_count++ < 2)) F_GOTO(FPC_R_AFTER_WHILE);
 		if(!S.f_uselocal) F_GOTO(FPC_R_AFTER_WHILE);
@@ -835,7 +1168,7 @@ again:
 		F_GOTO(FPC_R_LS_LOOP);
 	}
 	case FPC_R_LS_LOOP: {
-		if(!(S.f_maxHitLen < S.f_extoff + 1 && S.f_extoff < FG_GET2(S.rl, S.sv_rdi))) F_GOTO(FPC_R_LS_DONE);
+		if(!(S.f_maxHitLen < S.f_extoff + 1 && S.f_extoff < fs_rl(S, S.sv_rdi))) F_GOTO(FPC_R_LS_DONE);
 		S.f_extlen = 0; S.f_unique = 0;
 		S.localindexatts++;
 		if(C.ls->desc[S.f_lidx].len == 0) { S.a0 = 0; S.a1 = 0; S.a2 = S.f_top; S.a3 = S.f_bot; S.a4 = 0; F_GOTO(FPC_R_LS_AFTER); }
@@ -843,7 +1176,7 @@ again:
 		F_OP(FOP_LSEARCH, FPC_R_LS_AFTER);
 	}
 	case FPC_R_LS_AFTER: {
-		const uint32_t rdlen = FG_GET2(S.rl, S.sv_rdi);
+		const uint32_t rdlen = fs_rl(S, S.sv_rdi);
 		S.f_nelt = S.a0; S.f_extlen = S.a1; S.f_top = S.a2; S.f_bot = S.a3; S.f_unique = S.a4 & 1u;
 		if(S.f_extoff < S.f_hitoff + S.f_hitlen) { S.f_noext = 1; F_GOTO(FPC_R_LS_DONE); }
 		if(S.f_nelt <= 5) F_GOTO(FPC_R_LS_DONE);
@@ -865,9 +1198,7 @@ again:
 		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
 		fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, W.ld(cb), W.ld(cb + 1), W.ld(cb + 2));
-		h2g_ghit t, fh;
-		fg_hit_load(W, FW_T1, &t); fg_hit_load(W, hb, &fh);
-		if(!hit_compatible(&fh, &t, P.maxIntronLen, true)) {
+		if(!fh_compatible(fh_load(W, hb), fh_load(W, FW_T1))) {
 			if(S.f_count == 1) { S.f_ri++; F_GOTO(FPC_R_FOR_RI); }
 			F_GOTO(FPC_R_AFTER_FOR);
 		}
@@ -904,21 +1235,20 @@ again:
 	case FPC_R_AFTER_WHILE: {
 		if(S.f_success) F_RC_RET(S.f_maxsc);
 		S.f_ncoords = 0; S.f_ri = 0;
-		if(S.f_hitoff + S.f_hitlen + minK + 1 < FG_GET2(S.rl, S.sv_rdi) && S.localindexatts < S.max_localindexatts) F_BAIL(FB_GSEARCH);
+		if(S.f_hitoff + S.f_hitlen + minK + 1 < fs_rl(S, S.sv_rdi) && S.localindexatts < S.max_localindexatts) F_BAIL(FB_GSEARCH);
 		F_GOTO(FPC_R_TRIM);
 	}
 	case FPC_R_TRIM: {
-		h2g_ghit hit;
-		fg_hit_load(W, fg_frame_hit(S.sp), &hit);
+		FHit hit = fh_load(W, fg_frame_hit(S.sp));
 		const int64_t minsc = S.rc_minsc;
-		const uint32_t trimLen = FG_GET2(S.rl, S.sv_rdi) - S.f_hitoff - hit.len - hit.trim5;
+		const uint32_t trimLen = fs_rl(S, S.sv_rdi) - S.f_hitoff - hit.len - hit.trim5;
 		const int64_t floor_ = (S.f_maxsc != F_SMIN && (int64_t)S.f_maxsc > minsc) ? (int64_t)S.f_maxsc : minsc;
-		const uint32_t trimMax = (uint32_t)((hit.score - floor_) / sc_penalty(sc, 0));
+		const uint32_t trimMax = (uint32_t)(((int64_t)hit.score - floor_) / sc_penalty(sc, 0));
 		if(trimLen < trimMax) {
 			hit.trim3 = trimLen;                              // GenomeHit::trim3 hi_aligner.h:855
-			calculate_score(sc, fg_sv(C, S), &hit);
-			if((S.f_maxsc == F_SMIN || hit.score > (int64_t)S.f_maxsc) && hit.score >= minsc) {
-				if(!fg_hit_store(W, FW_T1, &hit)) F_BAIL(FB_EDITS);
+			fh_calc_score(sc, fg_sv(C, S), hit);
+			if((S.f_maxsc == F_SMIN || hit.score > S.f_maxsc) && (int64_t)hit.score >= minsc) {
+				if(!fh_store(W, FW_T1, hit)) F_BAIL(FB_EDITS);
 				F_RC_CALL(FW_T1, hit.rdoff - hit.trim5, hit.len + hit.trim5 + hit.trim3, FPC_R_R4);
 			}
 		}
@@ -928,7 +1258,7 @@ again:
 	case FPC_R_EXT: {
 		const uint32_t hb = fg_frame_hit(S.sp);
 		fg_hit_copy(W, FW_T1, hb);
-		const uint32_t rdlen = FG_GET2(S.rl, S.sv_rdi);
+		const uint32_t rdlen = fs_rl(S, S.sv_rdi);
 		const int32_t tscore = (int32_t)W.ld(hb + 3);
 		const uint32_t w4 = W.ld(hb + 4);
 		const uint32_t mm = (uint32_t)(((int64_t)tscore - S.rc_minsc) / sc.mmpMax);
@@ -942,7 +1272,7 @@ again:
 	}
 	case FPC_R_EXT_A: {
 		const uint32_t hb = fg_frame_hit(S.sp);
-		const uint32_t re = S.a1, hitoff = S.f_hitoff, hitlen = S.f_hitlen, rdlen = FG_GET2(S.rl, S.sv_rdi);
+		const uint32_t re = S.a1, hitoff = S.f_hitoff, hitlen = S.f_hitlen, rdlen = fs_rl(S, S.sv_rdi);
 		const uint32_t hw4 = W.ld(hb + 4), h_rdoff = hw4 & 0xffu, h_len = (hw4 >> 8) & 0xffu;
 		const int32_t hscore = (int32_t)W.ld(hb + 3), tscore = (int32_t)W.ld(FW_T1 + 3);
 		int32_t m = S.rc_minsc;
@@ -965,7 +1295,7 @@ again:
 		if(!S.paired) {
 			ReadOut o;
 			Rng rnd; rnd.last = S.rnd;
-			const uint32_t sz = S.nres[0];
+			const uint32_t sz = S.nres0;
 			o.nres = sz; o.overflow = 0; o.nrank = S.nrank; o.nsteps = S.nsteps; o.depth = S.nframes_max; o.nside = S.nside;
 			for(uint32_t k = 0; k < H2G_SELECT_CAP; k++) o.select[k] = 0;
 			// the records are in their slots in report order; selectByScore (al_select) over at most two of them
@@ -982,7 +1312,8 @@ again:
 				if(nsel == 2 && key[0] != key[1]) nsel = 1;
 			}
 			o.nselect = nsel;
-			for(uint32_t k = 0; k < nsel; k++) o.select[k] = (uint8_t)ord[k];
+			if(nsel >= 1) o.select[0] = (uint8_t)ord[0];
+			if(nsel >= 2) o.select[1] = (uint8_t)ord[1];
 			int64_t b = INT64_MIN, sb = INT64_MIN, bh = 0, sbh = 0;        // AlnSetSumm::init aligner_result.cpp:1209
 			for(uint32_t k = 0; k < sz; k++) {
 				const int64_t h = key[k], s = scv[k];
@@ -992,16 +1323,17 @@ again:
 			o.best = b == INT64_MIN ? INT32_MIN : (int32_t)b; o.secbest = sb == INT64_MIN ? INT32_MIN : (int32_t)sb;
 			o.best_h2 = (uint32_t)(uint64_t)bh; o.secbest_h2 = (uint32_t)(uint64_t)sbh;
 			// output slot k holds res[select[k]]
-			if(nsel >= 1 && ord[0] == 1) {
-				h2g_alnres r0 = recs[0], r1 = recs[1];
-				recs[0] = r1; if(nsel == 2) recs[1] = r0;
+			if(nsel >= 1 && ord[0] == 1) {                  // (word by word: no record-sized temporaries)
+				uint32_t* w0 = reinterpret_cast<uint32_t*>(&recs[0]);
+				uint32_t* w1 = reinterpret_cast<uint32_t*>(&recs[1]);
+				for(uint32_t k = 0; k < sizeof(h2g_alnres) / 4; k++) { const uint32_t t = w0[k]; w0[k] = w1[k]; w1[k] = t; }
 			}
 			C.O.rout[S.read] = o;
 			S.rnd = rnd.last;
 			S.a0 = nsel > 0;
 		} else {
 			PairOut o;
-			o.nres[0] = S.nres[0]; o.nres[1] = S.nres[1]; o.npairs = S.npairs; o.overflow = 0;
+			o.nres[0] = S.nres0; o.nres[1] = S.nres1; o.npairs = S.npairs; o.overflow = 0;
 			o.nrank = S.nrank; o.nsteps = S.nsteps; o.depth = S.nframes_max; o.nside = S.nside; o.rnd_state = S.rnd; o.pad = 0;
 			for(uint32_t k = 0; k < AL_MAX_PAIRS; k++) {
 				o.pair_i[k] = k < S.npairs ? (uint8_t)((S.pairs >> (4 * k)) & 3u) : 0;
@@ -1034,19 +1366,28 @@ H2G_HD void fast_op_psearch(const FCtx& C, FState& S) {
 	S.a2 = (fh.len & 0xffu) | (fh.hit_type << 8) | ((fh.done ? 1u : 0u) << 16) | ((fh.anchorStop ? 1u : 0u) << 17) | (fh.numUniqueSearch << 18);
 	S.a3 = fh.cur; S.a4 = (fh.nrank & 0xffffu) | (fh.nside << 16);
 }
-H2G_HD void fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
-	h2g_coord co[FG_NCO];
-	h2g_sa_result res;
-	genome_coords_item(*C.g, S.a0, S.a1, S.a2, S.a3, S.a4 != 0, co, FG_NCO, &res);
-	for(uint32_t k = 0; k < res.ncoords && k < FG_NCO; k++) { W.st(S.a5 + 3 * k, co[k].tidx); W.st(S.a5 + 3 * k + 1, co[k].toff); W.st(S.a5 + 3 * k + 2, co[k].joinedOff); }
-	S.a0 = res.ncoords; S.a1 = res.nsteps;
+H2G_HD void fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {   // getGenomeCoords :5774 (genome_coords_item), coordinates straight to the word store
+	const DGfm& g = *C.g;
+	uint32_t nelt = S.a1 - S.a0;
+	if(nelt > S.a2) nelt = S.a2;
+	if(nelt > FG_NCO) nelt = FG_NCO;
+	uint32_t n = 0, nsteps = 0;
+	for(uint32_t e = 0; e < nelt; e++) {
+		const uint32_t joff = sa_walk(g, S.a0 + e, &nsteps);
+		uint32_t tidx = 0, toff = 0;
+		bool st2 = false;
+		joined_to_text(g, S.a3, joff, &tidx, &toff, S.a4 != 0, &st2);
+		if(tidx == H2G_MAX) break;
+		W.st(S.a5 + 3 * e, st2 ? H2G_MAX : tidx); W.st(S.a5 + 3 * e + 1, toff); W.st(S.a5 + 3 * e + 2, joff);
+		n = e + 1;
+	}
+	S.a0 = n; S.a1 = nsteps;
 }
 H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
-	h2g_ghit h;
-	fg_hit_load(W, S.a3, &h);
+	FHit h = fh_load(W, S.a3);
 	uint32_t le = H2G_MAX, re = H2G_MAX;
-	extend_item(*C.ref, C.P->sc, fg_sv(C, S), &h, S.a0, S.a1, S.a2, &le, &re);
-	if(!fg_hit_store(W, S.a3, &h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
+	fh_extend(*C.ref, C.P->sc, fg_sv(C, S), h, S.a0, S.a1, S.a2, &le, &re);
+	if(!fh_store(W, S.a3, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
 	S.a0 = le; S.a1 = re;
 }
 H2G_HD void fast_op_lsearch(const FCtx& C, FState& S) {
@@ -1058,22 +1399,26 @@ H2G_HD void fast_op_lsearch(const FCtx& C, FState& S) {
 	S.nrank += nr[0]; S.nside += nr[1];
 	S.a0 = nelt; S.a1 = extlen; S.a2 = top; S.a3 = bot; S.a4 = uniqueStop ? 1u : 0u;
 }
-H2G_HD void fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
+H2G_HD void fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {   // getGenomeCoords_local :5861 (genome_coords_local)
 	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[S.a0];
-	h2g_coord co[FG_NCO];
+	const uint32_t offMask = (0xffffu << C.ls->offRate) & 0xffffu;
 	uint32_t n = 0, steps = 0;
-	genome_coords_local(lx, S.a1, S.a2, S.a3, S.a4, co, FG_NCO, &n, &steps);
+	for(uint32_t e = 0; e < S.a2 - S.a1; e++) {
+		const uint32_t joff = sa_walk_idx(lx, S.a1 + e, offMask, C.ls->offRate, C.ls->words + lx.d->offs_off, true, &steps);
+		h2g_coord c;
+		if(!local_joff_to_coord(*C.ls, lx.d, joff, S.a3, S.a4, &c)) continue;
+		if(n < FG_NCO) { W.st(S.a5 + 3 * n, c.tidx); W.st(S.a5 + 3 * n + 1, c.toff); W.st(S.a5 + 3 * n + 2, c.joinedOff); n++; }
+	}
 	S.nsteps += steps;
-	for(uint32_t k = 0; k < n; k++) { W.st(S.a5 + 3 * k, co[k].tidx); W.st(S.a5 + 3 * k + 1, co[k].toff); W.st(S.a5 + 3 * k + 2, co[k].joinedOff); }
 	S.a0 = n;
 }
 H2G_HD void fast_op_combine(const FCtx& C, FState& S, const FWords& W) {
-	const AlnParams& P = *C.P;
-	h2g_ghit a, b;
-	fg_hit_load(W, S.a3, &a); fg_hit_load(W, S.a4, &b);
-	const bool ok = hit_combine(*C.ref, P.sc, fg_sv(C, S), &a, &b, (int64_t)S.rc_minsc, P.minIntronLen, true,
-	                            ScVec{C.sc, C.sc_stride}, ScVec{C.sc + (size_t)H2G_COMBINE_MAXLEN * C.sc_stride, C.sc_stride}, nullptr);
-	if(!fg_hit_store(W, S.a3, &a)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
+	FHit a = fh_load(W, S.a3);
+	const FHit b = fh_load(W, S.a4);
+	bool indel = false;
+	const bool ok = fh_combine(*C.ref, C.P->sc, fg_sv(C, S), a, b, (int64_t)S.rc_minsc, &indel);
+	if(indel) { S.pc = FPC_BAIL; S.bail = FB_INDEL; }
+	else if(!fh_store(W, S.a3, a)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
 	S.a0 = ok ? 1u : 0u;
 }
 H2G_HD void fast_exec(const FCtx& C, FState& S, const FWords& W, uint32_t op) {
@@ -1089,12 +1434,70 @@ H2G_HD void fast_exec(const FCtx& C, FState& S, const FWords& W, uint32_t op) {
 	S.op = FOP_NONE;
 }
 
+// ---------------------------------------------------------------------------------------- the state between two trips
+// The state goes to / comes from its slot word by word.
+template <typename ST>   // st(i, v): store word i
+H2G_HD void fs_pack(const FState& S, ST&& st) {
+	uint32_t w[FS_WORDS];
+	memcpy(w, &S, sizeof S);
+#pragma unroll
+	for(uint32_t i = 0; i < FS_WORDS; i++) st(i, w[i]);
+}
+template <typename LD>   // ld(i): word i
+H2G_HD void fs_unpack(FState& S, LD&& ld) {
+	uint32_t w[FS_WORDS];
+#pragma unroll
+	for(uint32_t i = 0; i < FS_WORDS; i++) w[i] = ld(i);
+	memcpy(&S, w, sizeof S);
+}
+
+// Every place the fast machine requests a primitive: (primitive, pc it resumes at).  The queued kernel keeps one queue per site, so
+// the lanes of a wave resume at the same pc (as H2G_MACH_SITES of h2g_machine.h).
+#define FG_SITES(X) \
+	X(FOP_PSEARCH, FPC_NB_AFTER_PS) X(FOP_GCOORDS, FPC_GAH_FULL_AFTER) \
+	X(FOP_EXTEND, FPC_HS_EXT_AFTER) X(FOP_EXTEND, FPC_RC_ENTRY_L2) X(FOP_EXTEND, FPC_RC_ENTRY_R2) X(FOP_EXTEND, FPC_L_RI_B) X(FOP_EXTEND, FPC_R_RI_B) \
+	X(FOP_EXTEND, FPC_L_EXT_A) X(FOP_EXTEND, FPC_R_EXT_A) \
+	X(FOP_LSEARCH, FPC_L_LS_AFTER) X(FOP_LSEARCH, FPC_R_LS_AFTER) X(FOP_LCOORDS, FPC_L_LC_AFTER) X(FOP_LCOORDS, FPC_R_LC_AFTER) \
+	X(FOP_COMBINE, FPC_L_RI_C) X(FOP_COMBINE, FPC_R_RI_C)
+enum : uint32_t {
+#define X(OPC, PC) FSITE_##PC,
+	FSITE_FREE = 0, FG_SITES(X) FSITE_COUNT
+#undef X
+};
+H2G_HD uint32_t fg_site_of(uint32_t pc) {
+	switch(pc) {
+#define X(OPC, PC) case PC: return FSITE_##PC;
+	FG_SITES(X)
+#undef X
+	default: return 0;
+	}
+}
+H2G_HD uint32_t fg_site_op(uint32_t site) {
+	switch(site) {
+#define X(OPC, PC) case FSITE_##PC: return OPC;
+	FG_SITES(X)
+#undef X
+	default: return FOP_NONE;
+	}
+}
+
 // One read / pair on ONE lane until it completes or bails (tests/emul).  true = completed.
 H2G_HD bool fast_run_single(const FCtx& C, FState& S, const FWords& W, uint32_t read, bool paired, bool packed_ok) {
 	fast_begin(C, S, read, paired, packed_ok);
 	while(S.pc != FPC_DONE && S.pc != FPC_BAIL) {
 		fast_step(C, S, W);
-		if(S.op != FOP_NONE) fast_exec(C, S, W, S.op);
+		if(S.op != FOP_NONE) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+			// what the queued kernel does between two trips: the state through its packed form (and the site table must know the resume pc)
+			uint32_t pw[FS_WORDS];
+			const uint32_t op = S.op;
+			if(fg_site_of(S.pc) == 0 || fg_site_op(fg_site_of(S.pc)) != op) { S.pc = FPC_BAIL; S.bail = FB_OTHER; break; }
+			fs_pack(S, [&](uint32_t i, uint32_t v) { pw[i] = v; });
+			memset(&S, 0x5a, sizeof S);
+			fs_unpack(S, [&](uint32_t i) { return pw[i]; });
+#endif
+			fast_exec(C, S, W, S.op);
+		}
 	}
 	return S.pc == FPC_DONE;
 }

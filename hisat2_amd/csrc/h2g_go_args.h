@@ -48,7 +48,7 @@ struct FastArgs {
 	h2g::AlnParams P;
 	const char* names1; const uint32_t* noffs1;
 	const char* names2; const uint32_t* noffs2;
-	uint8_t* sc_base;                     // combineWith temp_scores per lane (as GoArgs::sc_base)
+	uint32_t* slots;                      // FG_SLOT_WORDS words per read in flight: packed state, hot words, packed reads, cold words
 	h2g::FastOut O;
 	unsigned long long* counters;         // [0] rank calls [1] sides [2] SA steps [4] aligned [6] completed [7] bailed, [96 + why] bails by reason
 	uint32_t* work;                       // next unclaimed read (zeroed before the launch)
@@ -56,4 +56,4 @@ struct FastArgs {
 	uint32_t total, paired;
 };
 extern "C" int h2g_go_fast_launch(const FastArgs*, unsigned grid, hipStream_t);
-extern "C" void h2g_go_fast_geometry(uint32_t* g);   // [0] threads per workgroup [1] LDS bytes per workgroup
+extern "C" void h2g_go_fast_geometry(uint32_t* g);   // [0] threads per workgroup [1] LDS bytes per workgroup [2] slots per workgroup [3] bytes per slot

@@ -1,46 +1,103 @@
-// go() fast pass: HI_Aligner::go of the dominant traces with the per-read state in registers + LDS (h2g_fast.h).
+// go() fast pass: HI_Aligner::go of the dominant traces with a COMPACT per-read state (h2g_fast.h).
 //
-// One read / pair per LANE, persistent lanes: a lane that completes (or bails) takes the next read of the batch.  Every round
-// each lane runs its control flow (registers + LDS words) up to its next primitive request; the wavefront then runs ONE primitive
-// — the one most lanes ask for, with ageing so that rare ones are not starved — at a single code site for all its requesters.
-// The only HBM traffic of a read is its index lines (the algorithmic bytes), its bases and its result records.
+// Reads in flight are slots of FG_SLOT_WORDS words (672 B: 40 state words, 59 hot words, the packed reads, 52 cold words),
+// contiguous in HBM.  A workgroup owns H2G_FAST_SLOTS of them and keeps, in LDS, one queue of slot ids per request site of the fast
+// machine (primitive + resume pc) plus the free queue.  Each wave loops: pop up to 64 slots of the longest queue, load their state
+// in one go (registers + a per-lane LDS staging area: 30 16-byte loads per lane, no dependent chain), run THAT primitive for all of
+// them at one code site, let every lane run its read's control flow on registers / LDS up to the next request, store the state and
+// push the slot to the queue of what it asked for.  The general machine's 23 scattered workspace lines per trip become 5 sequential
+// ones, and nothing of the control flow waits for HBM.  Reads that leave the fast path go to the general machine's list.
 #include "h2g_go_args.h"
 
 using namespace h2g;
 
 #ifndef H2G_FAST_THREADS
-#define H2G_FAST_THREADS 512
+#define H2G_FAST_THREADS 384
 #endif
-#define H2G_FAST_LDS_WORDS (FW_HOT + 2 * H2G_PK_WORDS)
+#ifndef H2G_FAST_SLOTS
+#define H2G_FAST_SLOTS 1024       // reads in flight per workgroup (power of two)
+#endif
+#define FG_STAGE_WORDS (FW_HOT + 2 * H2G_PK_WORDS)                     // staged in LDS per lane: hot words + packed reads
+#define FG_SLOT_WORDS  (((FS_WORDS + FW_HOT + 2 * H2G_PK_WORDS + FW_COLD) + 3) & ~3)   // 16-byte multiple
+#define FG_NQ ((int)FSITE_COUNT)
+#define FG_RING_EMPTY 0xffffu
+static_assert(FG_NQ <= 64, "the queue census is one lane per queue");
+static_assert(FS_WORDS % 4 == 0, "16-byte loads of the state");
+
+struct FastLds {
+	uint32_t head[FG_NQ], tail[FG_NQ];
+	uint16_t ring[FG_NQ][H2G_FAST_SLOTS];
+};
+
+__device__ __forceinline__ void fq_push(FastLds* Q, bool valid, uint32_t q, uint32_t slot, int lane) {
+	unsigned long long todo = __ballot(valid);
+	while(todo) {                                                  // one aggregated reservation per queue present in the wave
+		const int first = __ffsll((long long)todo) - 1;
+		const uint32_t k = (uint32_t)__shfl((int)q, first);
+		const unsigned long long m = __ballot(valid && q == k);
+		uint32_t base = 0;
+		if(lane == first) base = atomicAdd(&Q->tail[k], (uint32_t)__popcll(m));
+		base = (uint32_t)__shfl((int)base, first);
+		if(valid && q == k) {
+			const uint32_t pos = (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (H2G_FAST_SLOTS - 1);
+			__atomic_store_n(&Q->ring[k][pos], (uint16_t)slot, __ATOMIC_RELAXED);
+		}
+		todo &= ~m;
+	}
+}
+__device__ __forceinline__ uint32_t fq_pop(FastLds* Q, uint32_t q, int lane, uint32_t* slot) {
+	uint32_t n = 0, h = 0;
+	if(lane == 0) {
+		for(;;) {
+			h = __atomic_load_n(&Q->head[q], __ATOMIC_RELAXED);
+			const uint32_t t = __atomic_load_n(&Q->tail[q], __ATOMIC_RELAXED);
+			n = t - h;
+			if(n == 0) break;
+			if(n > 64) n = 64;
+			if(atomicCAS(&Q->head[q], h, h + n) == h) break;
+		}
+	}
+	n = (uint32_t)__shfl((int)n, 0); h = (uint32_t)__shfl((int)h, 0);
+	if((uint32_t)lane < n) {
+		const uint32_t pos = (h + (uint32_t)lane) & (H2G_FAST_SLOTS - 1);
+		uint16_t v;
+		while((v = __atomic_load_n(&Q->ring[q][pos], __ATOMIC_RELAXED)) == FG_RING_EMPTY) __builtin_amdgcn_s_sleep(1);   // reserved, being written
+		__atomic_store_n(&Q->ring[q][pos], (uint16_t)FG_RING_EMPTY, __ATOMIC_RELAXED);
+		*slot = v;
+	}
+	return n;
+}
 
 __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 {
 	extern __shared__ uint32_t s_mem[];
+	FastLds* Q = reinterpret_cast<FastLds*>(s_mem);
+	uint32_t* const stage = s_mem + (sizeof(FastLds) + 3) / 4 + threadIdx.x;      // word w of this lane at stage[w * H2G_FAST_THREADS]
 	const int lane = (int)(threadIdx.x & 63);
-	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
 	const bool paired = A.paired != 0;
-	uint32_t cold[FW_COLD];
-	FWords W; W.hot = (FG_LDS uint32_t*)(s_mem + threadIdx.x); W.hot_stride = H2G_FAST_THREADS; W.cold = (FG_PRIV uint32_t*)cold;
-	uint32_t* const pk0 = s_mem + FW_HOT * H2G_FAST_THREADS + threadIdx.x;
+	for(uint32_t k = threadIdx.x; k < (uint32_t)FG_NQ * H2G_FAST_SLOTS; k += blockDim.x) (&Q->ring[0][0])[k] = FG_RING_EMPTY;
+	if(threadIdx.x < (uint32_t)FG_NQ) { Q->head[threadIdx.x] = 0; Q->tail[threadIdx.x] = 0; }
+	__syncthreads();
+	for(uint32_t k = threadIdx.x; k < H2G_FAST_SLOTS; k += blockDim.x) Q->ring[0][k] = (uint16_t)k;   // every slot starts free
+	if(threadIdx.x == 0) Q->tail[0] = H2G_FAST_SLOTS;
+	__syncthreads();
+	FWords W; W.hot = (FG_LDS uint32_t*)stage; W.hot_stride = H2G_FAST_THREADS; W.cold = nullptr;
+	uint32_t* const pk0 = stage + FW_HOT * H2G_FAST_THREADS;
 	uint32_t* const pk1 = pk0 + H2G_PK_WORDS * H2G_FAST_THREADS;
 	FCtx C;
 	C.g = &A.g; C.ref = &A.ref; C.ls = &A.ls; C.P = &A.P;
 	C.rd[0] = A.rd1; C.rd[1] = paired ? A.rd2 : A.rd1;
 	C.pk[0] = pk0; C.pk[1] = paired ? pk1 : pk0; C.pk_stride = H2G_FAST_THREADS;
-	C.sc = (int64_t*)(A.sc_base + (tid >> 6) * (size_t)(64 * 2 * H2G_COMBINE_MAXLEN * sizeof(int64_t))) + lane; C.sc_stride = 64;
+	C.sc = nullptr; C.sc_stride = 0;
 	C.O = A.O;
 	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
-	FState S;
-	S.pc = FPC_DONE; S.op = FOP_NONE; S.bail = FB_NONE; S.read = 0;
+	uint32_t* const slots0 = A.slots + (size_t)blockIdx.x * H2G_FAST_SLOTS * FG_SLOT_WORDS;
 	unsigned long long nrank = 0, nside = 0, nsteps = 0, naln = 0, ndone = 0, nbail = 0;
-	const uint32_t FOP_FETCH = FOP_COUNT;                      // idle lanes "request" the next reads: refills compete (and age) like any primitive
-	uint32_t age[FOP_COUNT + 1];
-	for(int k = 0; k <= (int)FOP_COUNT; k++) age[k] = 0;
 	bool more = true;
 	const uint32_t total = A.total;
 #ifdef H2G_GO_PROF
-	// wave-level time split (shader clock): [0] fetch [1] control [2] vote [3+op] each primitive; [20+op] lanes executed; [32+op] executions;
-	// [40] lanes stepped [41] step calls [47] rounds
+	// wave-level time split (shader clock): [0] choose + pop + load [1] control [2] store [12] release fence [13] push [3+op] each primitive [15] new reads; [20+op] slots executed;
+	// [32+op] executions; [46] slots stepped [47] trips
 	unsigned long long prof[48];
 	for(int k = 0; k < 48; k++) prof[k] = 0;
 	unsigned long long tp0 = __builtin_readcyclecounter(), tp1;
@@ -49,36 +106,135 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 #define PROF(SLOT) do {} while(0)
 #endif
 	for(;;) {
-		// ---- control up to the next primitive request
-		{
-			const bool run = S.pc != FPC_DONE && S.pc != FPC_BAIL && S.op == FOP_NONE;
-#ifdef H2G_GO_PROF
-			{ const unsigned long long rm = __ballot(run); if(rm) { prof[40] += __popcll(rm); prof[41]++; } prof[47]++; }
-#endif
-			if(run) {
-				fast_step(C, S, W);
-				if(S.pc == FPC_DONE) { nrank += S.nrank; nside += S.nside; nsteps += S.nsteps; naln += S.a0 != 0; ndone++; }
+		// ---- choose: the site with the longest queue; free slots are refilled when reads remain and nothing is long
+		uint32_t cnt = 0;
+		if(lane < FG_NQ) cnt = __atomic_load_n(&Q->tail[lane], __ATOMIC_RELAXED) - __atomic_load_n(&Q->head[lane], __ATOMIC_RELAXED);
+		const uint32_t nfree = (uint32_t)__shfl((int)cnt, 0);
+		uint32_t bestc = (lane >= 1 && lane < FG_NQ) ? cnt : 0, bestq = (uint32_t)lane;
+		for(int o = 32; o > 0; o >>= 1) {
+			const uint32_t oc = (uint32_t)__shfl_xor((int)bestc, o), oq = (uint32_t)__shfl_xor((int)bestq, o);
+			if(oc > bestc || (oc == bestc && oq < bestq)) { bestc = oc; bestq = oq; }
+		}
+		bestc = (uint32_t)__shfl((int)bestc, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
+		const bool fetch = more && nfree > 0 && (bestc < 64 || nfree >= H2G_FAST_SLOTS / 4);
+		bool have = false;
+		uint32_t slot = 0;
+		uint32_t* sm = nullptr;                                   // this lane's slot in HBM
+		FState S;
+		S.pc = FPC_DONE; S.op = FOP_NONE; S.bail = FB_NONE;
+		if(fetch) {
+			const uint32_t n = fq_pop(Q, 0, lane, &slot);
+			if(n == 0) continue;
+			uint32_t base = 0;
+			if(lane == 0) base = atomicAdd(A.work, n);
+			base = (uint32_t)__shfl((int)base, 0);
+			if(base + n >= total) more = false;
+			const bool got = (uint32_t)lane < n && base + (uint32_t)lane < total;
+			fq_push(Q, (uint32_t)lane < n && !got, 0, slot, lane);      // slots without a read go back
+			if(got) {
+				have = true;
+				const uint32_t mine = base + (uint32_t)lane;
+				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
+				W.cold = sm + FS_WORDS + FG_STAGE_WORDS;
+				bool ok = fg_pack_read(A.rd1, mine, pk0, H2G_FAST_THREADS);
+				C.name[0] = A.names1 + A.noffs1[mine]; C.namelen[0] = A.noffs1[mine + 1] - A.noffs1[mine];
+				if(paired) {
+					ok = fg_pack_read(A.rd2, mine, pk1, H2G_FAST_THREADS) && ok;
+					C.name[1] = A.names2 + A.noffs2[mine]; C.namelen[1] = A.noffs2[mine + 1] - A.noffs2[mine];
+				}
+				// the packed reads are written to the slot once
+#pragma unroll
+				for(uint32_t k = 0; k < 2 * H2G_PK_WORDS; k++) sm[FS_WORDS + FW_HOT + k] = pk0[k * H2G_FAST_THREADS];
+				fast_begin(C, S, mine, paired, ok);
 			}
+			PROF(15);
+		} else {
+			if(bestc == 0) {
+				if(!more && nfree == H2G_FAST_SLOTS) break;           // the batch is exhausted and every slot is free again
+				__builtin_amdgcn_s_sleep(8);
+				if(more) { uint32_t w = 0; if(lane == 0) w = __atomic_load_n(A.work, __ATOMIC_RELAXED); if((uint32_t)__shfl((int)w, 0) >= total) more = false; }
+				continue;
+			}
+			const uint32_t op = fg_site_op(bestq);
+			const uint32_t n = fq_pop(Q, bestq, lane, &slot);
+			if(n == 0) continue;
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			have = (uint32_t)lane < n;
+			if(have) {
+				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
+				W.cold = sm + FS_WORDS + FG_STAGE_WORDS;
+				// what the primitive needs of the state: its arguments, the read's geometry, the strand (words 0-10, 31).  The rest is loaded
+				// behind the primitive, so that it is not live (= spilled) across the latency-bound loops
+				const uint4* src = reinterpret_cast<const uint4*>(sm);
+				const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
+#pragma unroll
+				for(uint32_t k = 0; k < FG_STAGE_WORDS / 4; k++) {
+					const uint4 v = hsrc[k];
+					stage[(4 * k) * H2G_FAST_THREADS] = v.x; stage[(4 * k + 1) * H2G_FAST_THREADS] = v.y; stage[(4 * k + 2) * H2G_FAST_THREADS] = v.z; stage[(4 * k + 3) * H2G_FAST_THREADS] = v.w;
+				}
+#pragma unroll
+				for(uint32_t k = FG_STAGE_WORDS & ~3u; k < FG_STAGE_WORDS; k++) stage[k * H2G_FAST_THREADS] = sm[FS_WORDS + k];
+				uint32_t w[FS_WORDS];
+#pragma unroll
+				for(uint32_t k = 0; k < FS_WORDS; k++) w[k] = 0;
+				{ const uint4 v0 = src[0], v1 = src[1], v2 = src[2]; w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w; w[8] = v2.x; w[9] = v2.y; w[10] = v2.z; }
+				w[31] = sm[31];
+				__builtin_memcpy(&S, w, sizeof S);
+				S.nrank = 0; S.nside = 0; S.nsteps = 0; S.pc = FPC_GO_INIT;
+			}
+#ifdef H2G_GO_PROF
+			prof[20 + op] += n; prof[32 + op]++;
+#endif
+			PROF(0);
+			if(have) {
+				fast_exec(C, S, W, op);
+				// results of the primitive; then the whole state (16-byte loads, nothing depends on anything)
+				const uint32_t r0 = S.a0, r1 = S.a1, r2 = S.a2, r3 = S.a3, r4 = S.a4, r5 = S.a5, dr = S.nrank, ds = S.nside, dt = S.nsteps;
+				const bool failed = S.pc == FPC_BAIL;
+				const uint32_t why = S.bail;
+				const uint4* src = reinterpret_cast<const uint4*>(sm);
+				uint32_t w[FS_WORDS];
+#pragma unroll
+				for(uint32_t k = 0; k < FS_WORDS / 4; k++) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+				__builtin_memcpy(&S, w, sizeof S);
+				S.op = FOP_NONE;
+				S.a0 = r0; S.a1 = r1; S.a2 = r2; S.a3 = r3; S.a4 = r4; S.a5 = r5;
+				const uint32_t nr_ = S.nrank + dr, ns_ = S.nside + ds, nt_ = S.nsteps + dt;
+				S.nrank = nr_; S.nside = ns_; S.nsteps = nt_;
+				if(failed) { S.pc = FPC_BAIL; S.bail = why; }
+				else if(nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
+			}
+			PROF(3 + op);
+		}
+		// ---- control flow of each read up to its next primitive request; then hand the slots on
+		uint32_t nextq = 0;
+#ifdef H2G_GO_PROF
+		prof[46] += __popcll(__ballot(have)); prof[47]++;
+#endif
+		if(have) {
+			if(S.pc != FPC_DONE && S.pc != FPC_BAIL) fast_step(C, S, W);
 		}
 		PROF(1);
-		// ---- one primitive (or the refill) for the wave: most requesters, aged
-		const bool idle = S.pc == FPC_DONE || S.pc == FPC_BAIL;
-		const uint32_t want = idle ? (more ? FOP_FETCH : (uint32_t)FOP_NONE) : S.op;
-		uint32_t bestop = FOP_NONE, bestscore = 0;
+		if(have) {
+			if(S.pc == FPC_DONE) { nrank += S.nrank; nside += S.nside; nsteps += S.nsteps; naln += S.a0 != 0; ndone++; }
+			else if(S.pc != FPC_BAIL) {
+				uint32_t w[FS_WORDS];
+				__builtin_memcpy(w, &S, sizeof S);
+				uint4* dst = reinterpret_cast<uint4*>(sm);
 #pragma unroll
-		for(uint32_t op = 1; op <= FOP_COUNT; op++) {
-			const uint32_t c = (uint32_t)__popcll(__ballot(want == op));
-			const uint32_t sc = c ? c + 6 * age[op] : 0;
-			if(sc > bestscore) { bestscore = sc; bestop = op; }
-			age[op] = c ? age[op] + 1 : 0;
+				for(uint32_t k = 0; k < FS_WORDS / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+				uint4* hdst = reinterpret_cast<uint4*>(sm + FS_WORDS);
+#pragma unroll
+				for(uint32_t k = 0; k < FW_HOT / 4; k++)
+					hdst[k] = make_uint4(stage[(4 * k) * H2G_FAST_THREADS], stage[(4 * k + 1) * H2G_FAST_THREADS], stage[(4 * k + 2) * H2G_FAST_THREADS], stage[(4 * k + 3) * H2G_FAST_THREADS]);
+#pragma unroll
+				for(uint32_t k = FW_HOT & ~3u; k < FW_HOT; k++) sm[FS_WORDS + k] = stage[k * H2G_FAST_THREADS];
+				nextq = fg_site_of(S.pc);
+			}
 		}
-		if(bestop == FOP_NONE) break;                            // nothing in flight, nothing left to fetch
-#pragma unroll
-		for(uint32_t op = 1; op <= FOP_COUNT; op++) if(op == bestop) age[op] = 0;
-		PROF(2);
-		if(bestop == FOP_FETCH) {
-			// reads that left the fast path: their ids go to the general machine's list
-			const bool b = S.pc == FPC_BAIL && S.bail != FB_NONE;
+		// reads that left the fast path: their ids go to the general machine's list
+		{
+			const bool b = have && S.pc == FPC_BAIL;
 			const unsigned long long bm = __ballot(b);
 			if(bm) {
 				uint32_t base = 0;
@@ -87,48 +243,15 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 				if(b) {
 					A.bail_list[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = S.read;
 					atomicAdd(A.counters + 96 + (S.bail < FB_COUNT ? S.bail : (uint32_t)FB_OTHER), 1ull);
-					nbail++; S.bail = FB_NONE;
+					nbail++;
 				}
 			}
-			const unsigned long long im = __ballot(idle);
-			const uint32_t n = (uint32_t)__popcll(im);
-			uint32_t base = 0;
-			if(lane == 0) base = atomicAdd(A.work, n);
-			base = (uint32_t)__shfl((int)base, 0);
-			if(base + n >= total) more = false;
-			const uint32_t mine = base + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
-			if(idle && mine < total) {
-				bool ok = fg_pack_read(A.rd1, mine, pk0, H2G_FAST_THREADS);
-				C.name[0] = A.names1 + A.noffs1[mine]; C.namelen[0] = A.noffs1[mine + 1] - A.noffs1[mine];
-				if(paired) {
-					ok = fg_pack_read(A.rd2, mine, pk1, H2G_FAST_THREADS) && ok;
-					C.name[1] = A.names2 + A.noffs2[mine]; C.namelen[1] = A.noffs2[mine + 1] - A.noffs2[mine];
-				}
-				fast_begin(C, S, mine, paired, ok);
-			}
-			PROF(0);
-		} else {
-#ifdef H2G_GO_PROF
-			prof[20 + bestop] += __popcll(__ballot(S.op == bestop)); prof[32 + bestop]++;
-#endif
-			if(S.op == bestop) fast_exec(C, S, W, bestop);
-			PROF(3 + bestop);
 		}
-	}
-	// bails not yet handed on (the batch ran out before another refill)
-	{
-		const bool b = S.pc == FPC_BAIL && S.bail != FB_NONE;
-		const unsigned long long bm = __ballot(b);
-		if(bm) {
-			uint32_t base = 0;
-			if(lane == 0) base = atomicAdd(A.bail_count, (uint32_t)__popcll(bm));
-			base = (uint32_t)__shfl((int)base, 0);
-			if(b) {
-				A.bail_list[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = S.read;
-				atomicAdd(A.counters + 96 + (S.bail < FB_COUNT ? S.bail : (uint32_t)FB_OTHER), 1ull);
-				nbail++;
-			}
-		}
+		PROF(2);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		PROF(12);
+		fq_push(Q, have, nextq, slot, lane);
+		PROF(13);
 	}
 #ifdef H2G_GO_PROF
 	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A.counters + 128 + k, prof[k]);
@@ -141,11 +264,11 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 	wave_add(A.counters + 7, nbail);
 }
 
-extern "C" void h2g_go_fast_geometry(uint32_t* g) { g[0] = H2G_FAST_THREADS; g[1] = H2G_FAST_LDS_WORDS * H2G_FAST_THREADS * 4u; }
+#define FG_LDS_BYTES ((unsigned)(((sizeof(FastLds) + 3) / 4 + (size_t)FG_STAGE_WORDS * H2G_FAST_THREADS) * 4))
+extern "C" void h2g_go_fast_geometry(uint32_t* g) { g[0] = H2G_FAST_THREADS; g[1] = FG_LDS_BYTES; g[2] = H2G_FAST_SLOTS; g[3] = FG_SLOT_WORDS * 4u; }
 extern "C" int h2g_go_fast_launch(const FastArgs* a, unsigned grid, hipStream_t st) {
-	const unsigned lds = H2G_FAST_LDS_WORDS * H2G_FAST_THREADS * 4u;
 	static bool lds_ok = false;   // more than 64 KB of dynamic LDS is an opt-in
 	if(!lds_ok) { if(hipFuncSetAttribute((const void*)k_go_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok = true; }
-	hipLaunchKernelGGL(k_go_fast, dim3(grid), dim3(H2G_FAST_THREADS), lds, st, *a);
+	hipLaunchKernelGGL(k_go_fast, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, *a);
 	return (int)hipGetLastError();
 }

@@ -77,6 +77,7 @@ struct h2g_stream {
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
 	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
 	uint32_t* d_bail_list = nullptr;  // read ids the fast pass handed on to the general machine (+ their count behind the list)
+	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
 	bool ran_fast = false;
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
@@ -369,7 +370,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_ovf_list); (void)hipFree(s->d_bail_list); (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -1589,17 +1590,15 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	const bool fast = fast_env && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp && s->max_read_len != 0;
 	s->ran_fast = fast;
 	if(fast) {
-		uint32_t fgeo[2];
+		uint32_t fgeo[4];
 		h2g_go_fast_geometry(fgeo);
-		size_t fwant = (s->n_reads + fgeo[0] - 1) / fgeo[0];
+		size_t fwant = (s->n_reads + fgeo[2] - 1) / fgeo[2];
 		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > 256 ? 256 : fwant));      // one persistent workgroup per CU (LDS-bound)
-		h2g_stream::GoPool& pl = s->pool[0];
-		const size_t flanes = (size_t)fgrid * fgeo[0];
-		if(pl.sc_lanes < flanes) {
-			(void)hipFree(pl.sc); pl.sc = nullptr; pl.sc_lanes = 0;
-			HIPCHK(hipMalloc((void**)&pl.sc, flanes * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t))));
-			pl.sc_lanes = flanes;
-			A.sc_base = pl.sc;
+		const size_t slot_bytes = (size_t)fgrid * fgeo[2] * fgeo[3];
+		if(s->fast_slot_bytes < slot_bytes) {
+			(void)hipFree(s->d_fast_slots); s->d_fast_slots = nullptr; s->fast_slot_bytes = 0;
+			HIPCHK(hipMalloc((void**)&s->d_fast_slots, slot_bytes));
+			s->fast_slot_bytes = slot_bytes;
 		}
 		if(!s->d_bail_list) HIPCHK(hipMalloc((void**)&s->d_bail_list, (s->max_reads + 4) * 4));
 		HIPCHK(hipMemsetAsync(s->d_bail_list + s->max_reads, 0, 16, s->st));
@@ -1607,7 +1606,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		memset(&F, 0, sizeof F);
 		F.g = A.g; F.ref = A.ref; F.ls = A.ls; F.rd1 = A.rd1; F.rd2 = A.rd2; F.P = A.P;
 		F.names1 = A.names1; F.noffs1 = A.noffs1; F.names2 = A.names2; F.noffs2 = A.noffs2;
-		F.sc_base = pl.sc;
+		F.slots = s->d_fast_slots;
 		F.O.rout = A.O.rout; F.O.aln = A.O.aln; F.O.aln_slots = A.O.aln_slots; F.O.pout = A.O.pout; F.O.paln[0] = A.O.paln[0]; F.O.paln[1] = A.O.paln[1]; F.O.pair_slots = A.O.pair_slots;
 		F.counters = s->d_counters; F.work = reinterpret_cast<uint32_t*>(s->d_counters + 12);
 		F.bail_list = s->d_bail_list; F.bail_count = s->d_bail_list + s->max_reads;

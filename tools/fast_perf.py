@@ -64,17 +64,17 @@ if hasattr(L, "h2g_go_fast_prof"):
     v = (C.c_ulonglong * 72)()
     L.h2g_go_fast_prof.argtypes = [C.c_void_p, C.c_void_p]
     if L.h2g_go_fast_prof(st.h, v) == 0:
-        reasons = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other".split()
+        reasons = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other indel".split()
         print("  bails:", {reasons[k]: int(v[48 + k]) for k in range(len(reasons)) if v[48 + k]})
         if v[47]:
             ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE".split()
             tot = sum(v[k] for k in range(0, 16))
-            print("  rounds %d (per wave %.0f), lanes per control step %.1f, wave-ticks %d" % (v[47], v[47] / 2048.0, v[40] / max(1, v[41]), tot))
-            for k, nm in ((0, "fetch"), (1, "control"), (2, "vote")):
-                print("  %-10s %5.1f %%" % (nm, 100.0 * v[k] / tot))
+            print("  trips %d, slots per trip %.1f, wave-ticks %d" % (v[47], v[46] / max(1, v[47]), tot))
+            for k, nm in ((0, "pop+load"), (1, "control"), (2, "store"), (12, "release fence"), (13, "push"), (15, "new reads")):
+                print("  %-20s %5.1f %%" % (nm, 100.0 * v[k] / tot))
             for op in range(1, 7):
                 if v[3 + op]:
-                    print("  %-10s %5.1f %%   executions %d: avg %.1f of 64 lanes" % (ops[op], 100.0 * v[3 + op] / tot, v[32 + op], v[20 + op] / max(1, v[32 + op])))
+                    print("  %-20s %5.1f %%   executions %d: avg %.1f of 64 lanes" % (ops[op], 100.0 * v[3 + op] / tot, v[32 + op], v[20 + op] / max(1, v[32 + op])))
 print("%s n %d genome %d FAST=%s: align total/fast/machine ms %s | fast done %d bailed %d (%.1f %%) second %d overflow %d aligned %d | sides/unit %.1f steps/unit %.1f | crc %08x" % (
     mode, n, glen, os.environ.get("H2G_GO_FAST", "1"), " ".join("%.2f/%.2f/%.2f" % m for m in ms), c.n_fast, c.n_fast_bail, 100.0 * c.n_fast_bail / n,
     c.n_second_pass, c.n_overflow, c.n_aligned, c.n_side / n, c.n_sa_steps / n, ck))
