@@ -22,37 +22,39 @@ namespace h2g {
 #define FG_FE     3                     // edits kept per hit (more: bail)
 #define FG_HW     (6 + FG_FE)           // words of a stored hit
 #define FG_NLONG  4                     // partial hits longer than minK + 2 waiting for getAnchorHits
-#define FG_NCO    2                     // coordinates per SA resolution
+#define FG_NCO    5                     // coordinates per SA resolution (the reference resolves at most 5 outside getAnchorHits)
 #define FG_NRES   2                     // reported alignments per mate
-#define FG_NSRCH  3                     // hybridSearch_recur roots per mate (hashes)
+#define FG_NSRCH  7                     // hybridSearch_recur roots per mate (_hits_searched: hash + hit)
 #define FG_NPAIR  4                     // concordant pairs
 #define FG_FRS    5                     // scalar words of a saved frame
-#define FG_FRW    (FG_FRS + FG_HW + 3 * FG_NCO)
-#define FG_NFRAME 3
-// word store of one read in flight: [0, FW_HOT) is staged in LDS while a wave works on it, [FW_HOT, FW_TOTAL) stays in HBM (touched by reads with a mismatch only)
+#define FG_NFRAME 5
+#define FG_NLOCAL 2                     // _local_genomeHits kept per frame
+// word store of one read in flight: [0, FW_HOT) is staged in LDS while a wave works on it, [FW_HOT, FW_TOTAL) stays in HBM (coordinate lists,
+// the searched list, everything only reads with a mismatch touch)
 #define FW_LONG   0
 #define FW_G0     (FW_LONG + 3 * FG_NLONG)
-#define FW_FR0    (FW_G0 + FG_HW)
-#define FW_RES    (FW_FR0 + FG_FRW)
-#define FW_SRCH   (FW_RES + 2 * FG_NRES * 3)
-#define FW_HOT    (FW_SRCH + 2 * FG_NSRCH)
+#define FW_FR0    (FW_G0 + FG_HW)                  // frame 0: scalars + hit
+#define FW_RES    (FW_FR0 + FG_FRS + FG_HW)
+#define FW_HOT    (FW_RES + 2 * FG_NRES * 3)
 #define FW_G1     FW_HOT
 #define FW_T1     (FW_G1 + FG_HW)
-#define FW_FR1    (FW_T1 + FG_HW)
-#define FW_FR2    (FW_FR1 + FG_FRW)       // the deepest frame: scalars + hit, no coordinate list (it may only report)
-#define FW_TOTAL  (FW_FR2 + FG_FRS + FG_HW)
+#define FW_SRCH   (FW_T1 + FG_HW)
+#define FW_CO     (FW_SRCH + 2 * FG_NSRCH * (1 + FG_HW))   // the coordinate list of every frame (frame 0's doubles as getAnchorHits'); before it: (hash, hit) per searched root
+#define FW_FRX    (FW_CO + FG_NFRAME * 3 * FG_NCO)  // frames 1 .. FG_NFRAME - 1: scalars + hit
+#define FW_LH     (FW_FRX + (FG_NFRAME - 1) * (FG_FRS + FG_HW))   // _local_genomeHits of every frame
+#define FW_TOTAL  (FW_LH + FG_NFRAME * FG_NLOCAL * FG_HW)
 #define FW_COLD   (FW_TOTAL - FW_HOT)
 
-enum : uint32_t { FOP_NONE = 0, FOP_PSEARCH, FOP_GCOORDS, FOP_EXTEND, FOP_LSEARCH, FOP_LCOORDS, FOP_COMBINE, FOP_COUNT };
+enum : uint32_t { FOP_NONE = 0, FOP_PSEARCH, FOP_GCOORDS, FOP_EXTEND, FOP_LSEARCH, FOP_LCOORDS, FOP_COMBINE, FOP_GSEARCH, FOP_COUNT };
 enum : uint32_t {
 	FPC_DONE = 0, FPC_BAIL,
 	FPC_GO_INIT, FPC_NB_PICK, FPC_NB_AFTER_PS, FPC_ALIGN, FPC_AFTER_ALIGN, FPC_PAIR_READS, FPC_AFTER_LOOP, FPC_FINISH,
 	FPC_GAH_LOOP, FPC_GAH_FULL_AFTER, FPC_GAH_END, FPC_HS_EXT_LOOP, FPC_HS_EXT_AFTER, FPC_HS_LOOP, FPC_HS_AFTER_REC1,
 	FPC_RC_ENTRY, FPC_RC_ENTRY_LX, FPC_RC_ENTRY_L2, FPC_RC_ENTRY_L3, FPC_RC_ENTRY_RX, FPC_RC_ENTRY_R2, FPC_RC_ENTRY_R3,
 	FPC_L_WHILE, FPC_L_LS_LOOP, FPC_L_LS_AFTER, FPC_L_LS_DONE, FPC_L_LC_AFTER, FPC_L_FOR_RI, FPC_L_RI_B, FPC_L_RI_B2, FPC_L_RI_C, FPC_L_R1,
-	FPC_L_AFTER_FOR, FPC_L_AFTER_WHILE, FPC_L_TRIM, FPC_L_R4, FPC_L_EXT, FPC_L_EXT_A, FPC_L_R5,
+	FPC_L_AFTER_FOR, FPC_L_FOR_TI, FPC_L_R2, FPC_L_AFTER_WHILE, FPC_L_GS_AFTER, FPC_L_GC_AFTER, FPC_L_FOR_G, FPC_L_G_B, FPC_L_G_C, FPC_L_R3, FPC_L_TRIM, FPC_L_R4, FPC_L_EXT, FPC_L_EXT_A, FPC_L_R5,
 	FPC_R_WHILE, FPC_R_LS_LOOP, FPC_R_LS_AFTER, FPC_R_LS_DONE, FPC_R_LC_AFTER, FPC_R_FOR_RI, FPC_R_RI_B, FPC_R_RI_C, FPC_R_R1,
-	FPC_R_AFTER_FOR, FPC_R_AFTER_WHILE, FPC_R_TRIM, FPC_R_R4, FPC_R_EXT, FPC_R_EXT_A, FPC_R_R5
+	FPC_R_AFTER_FOR, FPC_R_FOR_TI, FPC_R_R2, FPC_R_AFTER_WHILE, FPC_R_GS_AFTER, FPC_R_GC_AFTER, FPC_R_FOR_G, FPC_R_G_B, FPC_R_G_C, FPC_R_R3, FPC_R_TRIM, FPC_R_R4, FPC_R_EXT, FPC_R_EXT_A, FPC_R_R5
 };
 
 // why a read left the fast path (statistics only)
@@ -73,6 +75,28 @@ struct FWords {                          // the lane's word store
 	uint32_t* cold;                             // the slot's cold words in HBM (reads with a mismatch only)
 	H2G_HD uint32_t ld(uint32_t i) const { return i < FW_HOT ? hot[i * hot_stride] : cold[i - FW_HOT]; }
 	H2G_HD void st(uint32_t i, uint32_t v) const { if(i < FW_HOT) hot[i * hot_stride] = v; else cold[i - FW_HOT] = v; }
+	// N consecutive words of one object (objects never straddle the hot / cold boundary): ONE branch, then N independent accesses —
+	// a cold object costs one HBM latency instead of N
+	template <int N> H2G_HD void ldv(uint32_t i, uint32_t* o) const {
+		if(i < FW_HOT) {
+#pragma unroll
+			for(int k = 0; k < N; k++) o[k] = hot[(i + k) * hot_stride];
+		} else {
+			const uint32_t* c = cold + (i - FW_HOT);
+#pragma unroll
+			for(int k = 0; k < N; k++) o[k] = c[k];
+		}
+	}
+	template <int N> H2G_HD void stv(uint32_t i, const uint32_t* v) const {
+		if(i < FW_HOT) {
+#pragma unroll
+			for(int k = 0; k < N; k++) hot[(i + k) * hot_stride] = v[k];
+		} else {
+			uint32_t* c = cold + (i - FW_HOT);
+#pragma unroll
+			for(int k = 0; k < N; k++) c[k] = v[k];
+		}
+	}
 };
 
 struct FastOut {                         // where a completed read leaves its results (MachOut of h2g_machine.h)
@@ -85,7 +109,7 @@ struct FastOut {                         // where a completed read leaves its re
 // handful of fields per state, and a field access is a bit-field extract / insert.
 struct FState {
 	uint32_t pc : 8, op : 4, bail : 5, paired : 1, nm : 2, found : 4, rb_done : 4, rb_nonempty : 4;                                          // 0
-	uint32_t rl0 : 8, rl1 : 8, sel_r : 1, sel_f : 1, nb_rdi : 1, nb_fwi : 1, sv_rdi : 1, sv_fw : 1, nres0 : 2, nres1 : 2, nsearched0 : 2, nsearched1 : 2, hs_found : 1, pad1_ : 1;   // 1
+	uint32_t rl0 : 8, rl1 : 8, sel_r : 1, sel_f : 1, nb_rdi : 1, nb_fwi : 1, sv_rdi : 1, sv_fw : 1, nres0 : 2, nres1 : 2, nsearched0 : 3, nsearched1 : 3;   // 1
 	uint32_t a0, a1, a2, a3, a4, a5;                                                                                                   // 2-7
 	uint32_t read, ro0, ro1, rnd;                                                                                                      // 8-11
 	uint32_t rb_cur, rb_nps, rb_nus, rb_np;          // ReadBWTHit x 4 (hi_aligner.h:216), 8 bits each, index = rdi * 2 + fwi          // 12-15
@@ -93,18 +117,18 @@ struct FState {
 	int32_t  bestUnp0 : 16, bestUnp1 : 16;           // the sink's per-mate bests; F_SMIN16 = none                                       // 20
 	int32_t  best2Unp0 : 16, best2Unp1 : 16;                                                                                            // 21
 	int32_t  minsc0 : 16, minsc1 : 16;               // F_SMAX16 = the mate is not there                                                // 22
-	uint32_t npairs : 3, pairs : 16, insp_i : 2, insp_j : 2, pad23_ : 9;                   // pairs: 4 bits per pair (i | j << 2)          // 23
+	uint32_t npairs : 3, pairs : 16, insp_i : 2, insp_j : 2, hs_found : 1, pad23_ : 8;                   // pairs: 4 bits per pair (i | j << 2)          // 23
 	int32_t  bestPair, best2Pair;                                                                                                      // 24, 25
 	uint32_t nrank : 16, nside : 16;                                                                                                    // 26
 	uint32_t nsteps : 16, nframes_max : 8, pad27_ : 8;                                                                                  // 27
-	uint32_t nghits : 2, ghit_done : 2, gh_hi : 5, gh_hj : 3, gh_nco : 2, gh_rdoff : 8, hs_hi : 2, hs_hj : 2, pad28_ : 6;                 // 28
+	uint32_t nghits : 2, ghit_done : 2, gh_hi : 5, gh_hj : 3, gh_nco : 3, gh_rdoff : 8, hs_hi : 2, hs_hj : 2, pad28_ : 5;                 // 28
 	uint32_t localindexatts : 16, max_localindexatts : 16;                                                                              // 29
 	int32_t  sp : 4; uint32_t rc_ret_pc : 8, pr_ret_pc : 8, pad30_ : 12;                                                                // 30
 	int32_t  rc_minsc, ret;                                                                                                            // 31, 32
 	// the CURRENT frame of hybridSearch_recur (saved into the word store across a nested call)
 	uint32_t f_hitoff : 8, f_hitlen : 8, f_extoff : 8, f_extlen : 8;                                                                     // 33
 	uint32_t f_lidx;                                                                                                                   // 34
-	uint32_t f_state : 8, f_count : 2, f_ncoords : 2; int32_t f_ri : 4; uint32_t f_success : 1, f_first : 1, f_uselocal : 1, f_unique : 1, f_noext : 1, pad35_ : 11;   // 35
+	uint32_t f_state : 8, f_count : 2, f_ncoords : 3; int32_t f_ri : 4; uint32_t f_success : 1, f_first : 1, f_uselocal : 1, f_unique : 1, f_noext : 1, f_nlocal : 2, f_ti : 2, pad35_ : 6;   // 35
 	int32_t  f_maxsc, f_prev;                                                                                                          // 36, 37
 	uint32_t f_top : 16, f_bot : 16;                 // rows of a local index (16-bit words); 0xffff stands for "none"                   // 38
 	uint32_t f_nelt : 16, f_maxHitLen : 16;                                                                                             // 39
@@ -136,20 +160,21 @@ struct FCtx {
 };
 
 // ---------------------------------------------------------------------------------------- stored hits
-H2G_HD uint32_t fg_frame_base(int sp) { return sp == 0 ? (uint32_t)FW_FR0 : (sp == 1 ? (uint32_t)FW_FR1 : (uint32_t)FW_FR2); }
+H2G_HD uint32_t fg_frame_base(int sp) { return sp == 0 ? (uint32_t)FW_FR0 : (uint32_t)FW_FRX + (uint32_t)(sp - 1) * (FG_FRS + FG_HW); }
 H2G_HD uint32_t fg_frame_hit(int sp) { return fg_frame_base(sp) + FG_FRS; }
-H2G_HD uint32_t fg_frame_co(int sp) { return fg_frame_base(sp) + FG_FRS + FG_HW; }
+H2G_HD uint32_t fg_frame_lh(int sp, uint32_t k) { return (uint32_t)FW_LH + ((uint32_t)sp * FG_NLOCAL + k) * FG_HW; }
+H2G_HD uint32_t fg_frame_co(int sp) { return (uint32_t)FW_CO + (uint32_t)sp * 3 * FG_NCO; }
 
 // hit words: tidx, toff, joinedOff, score, rdoff | len << 8 | trim5 << 16 | trim3 << 24, fw | nedits << 1 | hitcount << 8, edits
 H2G_HD void fg_hit_init(const FWords& W, uint32_t hb, bool fw, uint32_t rdoff, uint32_t len, uint32_t tidx, uint32_t toff, uint32_t joff) {
-	W.st(hb, tidx); W.st(hb + 1, toff); W.st(hb + 2, joff); W.st(hb + 3, 0);
-	W.st(hb + 4, rdoff | (len << 8)); W.st(hb + 5, (fw ? 1u : 0u) | (1u << 8));
+	const uint32_t v[6] = {tidx, toff, joff, 0u, rdoff | (len << 8), (fw ? 1u : 0u) | (1u << 8)};
+	W.stv<6>(hb, v);
 }
 H2G_HD void fg_hit_copy(const FWords& W, uint32_t dst, uint32_t src) {
 	if(dst == src) return;
-	const uint32_t w5 = W.ld(src + 5), ne = (w5 >> 1) & 7u;
-	for(uint32_t k = 0; k < 6; k++) W.st(dst + k, W.ld(src + k));
-	for(uint32_t k = 0; k < ne; k++) W.st(dst + 6 + k, W.ld(src + 6 + k));
+	uint32_t v[FG_HW];
+	W.ldv<FG_HW>(src, v);
+	W.stv<FG_HW>(dst, v);
 }
 // A hit in REGISTERS: what GenomeHit holds for an alignment with at most FG_FE mismatch / gap edits on a linear index (no ALT ids,
 // no splices).  Every loop over its edits is unrolled over FG_FE selects: nothing of it is ever indexed in private memory.
@@ -170,12 +195,13 @@ static_assert(FG_FE == 3, "FHit holds three edits");
 H2G_HD bool fe_is_gap(uint32_t e) { const uint32_t t = FE_TYPE(e); return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
 
 H2G_HD FHit fh_load(const FWords& W, uint32_t hb) {
+	uint32_t v[FG_HW];
+	W.ldv<FG_HW>(hb, v);
 	FHit h;
-	h.tidx = W.ld(hb); h.toff = W.ld(hb + 1); h.joff = W.ld(hb + 2); h.score = (int32_t)W.ld(hb + 3);
-	const uint32_t w4 = W.ld(hb + 4), w5 = W.ld(hb + 5);
-	h.rdoff = w4 & 0xffu; h.len = (w4 >> 8) & 0xffu; h.trim5 = (w4 >> 16) & 0xffu; h.trim3 = w4 >> 24;
-	h.fw = w5 & 1u; h.nedits = (w5 >> 1) & 7u; h.hitcount = w5 >> 8;
-	h.e0 = h.nedits > 0 ? W.ld(hb + 6) : 0; h.e1 = h.nedits > 1 ? W.ld(hb + 7) : 0; h.e2 = h.nedits > 2 ? W.ld(hb + 8) : 0;
+	h.tidx = v[0]; h.toff = v[1]; h.joff = v[2]; h.score = (int32_t)v[3];
+	h.rdoff = v[4] & 0xffu; h.len = (v[4] >> 8) & 0xffu; h.trim5 = (v[4] >> 16) & 0xffu; h.trim3 = v[4] >> 24;
+	h.fw = v[5] & 1u; h.nedits = (v[5] >> 1) & 7u; h.hitcount = v[5] >> 8;
+	h.e0 = h.nedits > 0 ? v[6] : 0; h.e1 = h.nedits > 1 ? v[7] : 0; h.e2 = h.nedits > 2 ? v[8] : 0;
 	h.bad = 0;
 	return h;
 }
@@ -183,12 +209,9 @@ H2G_HD FHit fh_load(const FWords& W, uint32_t hb) {
 H2G_HD bool fh_store(const FWords& W, uint32_t hb, const FHit& h) {
 	if(h.bad || h.nedits > FG_FE || h.score < -(1 << 30) || h.score > (1 << 30) || h.hitcount > 0xffffu) return false;
 	if(h.rdoff > 255 || h.len > 255 || h.trim5 > 255 || h.trim3 > 255) return false;
-	W.st(hb, h.tidx); W.st(hb + 1, h.toff); W.st(hb + 2, h.joff); W.st(hb + 3, (uint32_t)h.score);
-	W.st(hb + 4, h.rdoff | (h.len << 8) | (h.trim5 << 16) | (h.trim3 << 24));
-	W.st(hb + 5, (h.fw ? 1u : 0u) | (h.nedits << 1) | (h.hitcount << 8));
-	if(h.nedits > 0) W.st(hb + 6, h.e0);
-	if(h.nedits > 1) W.st(hb + 7, h.e1);
-	if(h.nedits > 2) W.st(hb + 8, h.e2);
+	const uint32_t v[FG_HW] = {h.tidx, h.toff, h.joff, (uint32_t)h.score, h.rdoff | (h.len << 8) | (h.trim5 << 16) | (h.trim3 << 24),
+	                           (h.fw ? 1u : 0u) | (h.nedits << 1) | (h.hitcount << 8), h.e0, h.e1, h.e2};
+	W.stv<FG_HW>(hb, v);
 	return true;
 }
 // a hash of exactly what GenomeHit::operator== compares (hit_equal, hi_aligner.h:1156): equal hits => equal hashes
@@ -203,6 +226,19 @@ H2G_HD uint32_t fh_hash(const FHit& h) {
 	}
 #undef FG_MIX
 	return x;
+}
+// operator== hi_aligner.h:1156-1183 (hit_equal)
+H2G_HD bool fh_equal(const FHit& a, const FHit& b) {
+	if(a.fw != b.fw || a.rdoff != b.rdoff || a.len != b.len || a.tidx != b.tidx || a.toff != b.toff || a.trim5 != b.trim5 || a.trim3 != b.trim3) return false;
+	if(a.nedits != b.nedits) return false;
+	bool eq = true;
+#pragma unroll
+	for(uint32_t i = 0; i < FG_FE; i++) if(i < a.nedits) {
+		const uint32_t e = FE_GET(a, i), o = FE_GET(b, i);
+		if(fe_is_gap(e)) { if(FE_TYPE(o) != FE_TYPE(e)) eq = false; }
+		else if(e != o) eq = false;
+	}
+	return eq;
 }
 // getRight hi_aligner.h:962-1000 (hit_get_right): the part behind the last gap
 H2G_HD void fh_get_right(const FHit& h, uint32_t* rdoff, uint32_t* len, uint32_t* toff) {
@@ -567,11 +603,11 @@ H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, boo
 	S.gh_hi = S.gh_hj = S.gh_nco = S.gh_rdoff = S.hs_hi = S.hs_hj = S.hs_found = 0;
 	S.sp = -1; S.rc_minsc = 0; S.ret = 0; S.rc_ret_pc = S.pr_ret_pc = 0;
 	S.f_hitoff = S.f_hitlen = S.f_extoff = S.f_extlen = S.f_lidx = S.f_state = S.f_count = S.f_ncoords = 0; S.f_ri = 0; S.f_maxsc = S.f_prev = 0;
-	S.f_success = S.f_first = S.f_uselocal = S.f_unique = 0; S.f_top = S.f_bot = S.f_nelt = 0; S.f_noext = 0; S.f_maxHitLen = 0;
+	S.f_success = S.f_first = S.f_uselocal = S.f_unique = 0; S.f_top = S.f_bot = S.f_nelt = 0; S.f_noext = 0; S.f_maxHitLen = 0; S.f_nlocal = 0; S.f_ti = 0;
 	S.rb_cur = S.rb_nps = S.rb_nus = S.rb_np = 0; S.rb_sumsq0 = S.rb_sumsq1 = S.rb_sumsq2 = S.rb_sumsq3 = 0;
 	S.rb_done = S.rb_nonempty = S.found = 0; S.rnd = 0; S.ro0 = S.ro1 = 0; S.rl0 = S.rl1 = 0;
 	S.nres0 = S.nres1 = S.nsearched0 = S.nsearched1 = 0; S.bestUnp0 = S.bestUnp1 = S.best2Unp0 = S.best2Unp1 = F_SMIN16; S.minsc0 = S.minsc1 = F_SMAX16;
-	S.pad1_ = 0; S.pad23_ = 0; S.pad27_ = 0; S.pad28_ = 0; S.pad30_ = 0; S.pad35_ = 0;
+	S.pad23_ = 0; S.pad27_ = 0; S.pad28_ = 0; S.pad30_ = 0; S.pad35_ = 0;
 	S.npairs = S.pairs = S.insp_i = S.insp_j = 0; S.bestPair = S.best2Pair = F_SMIN;
 	S.nrank = S.nside = S.nsteps = S.nframes_max = 0; S.nghits = S.ghit_done = 0; S.localindexatts = S.max_localindexatts = 0;
 	S.ro0 = C.rd[0].offs[read]; S.ro1 = C.rd[1].offs[read];                     // (unpaired: rd[1] is rd[0])
@@ -601,21 +637,37 @@ H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, boo
 #define F_MINSC_LIVE(MV) do { const int32_t b_ = fs_bestUnp(S, S.sv_rdi); if(b_ > (MV)) (MV) = b_; } while(0)
 
 H2G_HD void fg_frame_save(const FWords& W, const FState& S) {
-	const uint32_t b = fg_frame_base(S.sp);
-	W.st(b, S.f_hitoff | (S.f_hitlen << 8) | (S.f_extoff << 16) | (S.f_extlen << 24));
-	W.st(b + 1, (uint32_t)S.f_maxsc); W.st(b + 2, (uint32_t)S.f_prev); W.st(b + 3, S.f_lidx);
-	W.st(b + 4, S.f_state | (S.f_count << 8) | (S.f_ncoords << 10) | ((uint32_t)(S.f_ri + 1) << 12) | (S.f_success << 15) | (S.f_first << 16) |
-	            (S.f_uselocal << 17) | (S.f_unique << 18));
+	const uint32_t w0 = (uint32_t)S.f_hitoff | ((uint32_t)S.f_hitlen << 8) | ((uint32_t)S.f_extoff << 16) | ((uint32_t)S.f_extlen << 24);
+	const uint32_t w4 = (uint32_t)S.f_state | ((uint32_t)S.f_count << 8) | ((uint32_t)S.f_ncoords << 10) | ((uint32_t)(S.f_ri + 1) << 13) | ((uint32_t)S.f_success << 17) |
+	                    ((uint32_t)S.f_first << 18) | ((uint32_t)S.f_uselocal << 19) | ((uint32_t)S.f_unique << 20) | ((uint32_t)S.f_nlocal << 21) | ((uint32_t)S.f_ti << 23);
+	const uint32_t v[FG_FRS] = {w0, (uint32_t)S.f_maxsc, (uint32_t)S.f_prev, S.f_lidx, w4};
+	W.stv<FG_FRS>(fg_frame_base(S.sp), v);
 }
 H2G_HD void fg_frame_restore(const FWords& W, FState& S) {
-	const uint32_t b = fg_frame_base(S.sp);
-	const uint32_t w0 = W.ld(b), w4 = W.ld(b + 4);
+	uint32_t v[FG_FRS];
+	W.ldv<FG_FRS>(fg_frame_base(S.sp), v);
+	const uint32_t w0 = v[0], w4 = v[4];
 	S.f_hitoff = w0 & 0xffu; S.f_hitlen = (w0 >> 8) & 0xffu; S.f_extoff = (w0 >> 16) & 0xffu; S.f_extlen = w0 >> 24;
-	S.f_maxsc = (int32_t)W.ld(b + 1); S.f_prev = (int32_t)W.ld(b + 2); S.f_lidx = W.ld(b + 3);
-	S.f_state = w4 & 0xffu; S.f_count = (w4 >> 8) & 3u; S.f_ncoords = (w4 >> 10) & 3u; S.f_ri = (int32_t)((w4 >> 12) & 7u) - 1;
-	S.f_success = (w4 >> 15) & 1u; S.f_first = (w4 >> 16) & 1u; S.f_uselocal = (w4 >> 17) & 1u; S.f_unique = (w4 >> 18) & 1u;
+	S.f_maxsc = (int32_t)v[1]; S.f_prev = (int32_t)v[2]; S.f_lidx = v[3];
+	S.f_state = w4 & 0xffu; S.f_count = (w4 >> 8) & 3u; S.f_ncoords = (w4 >> 10) & 7u; S.f_ri = (int32_t)((w4 >> 13) & 15u) - 1;
+	S.f_success = (w4 >> 17) & 1u; S.f_first = (w4 >> 18) & 1u; S.f_uselocal = (w4 >> 19) & 1u; S.f_unique = (w4 >> 20) & 1u;
+	S.f_nlocal = (w4 >> 21) & 3u; S.f_ti = (w4 >> 23) & 3u;
 }
 
+// sort_coords (Coord::operator< ref_coord.h:79: by text, then offset) over a frame's list
+H2G_HD void fg_sort_coords(const FWords& W, uint32_t cb, uint32_t n) {
+	for(uint32_t i = 1; i < n; i++) {
+		const uint32_t xt = W.ld(cb + 3 * i), xo = W.ld(cb + 3 * i + 1), xj = W.ld(cb + 3 * i + 2);
+		int j = (int)i - 1;
+		while(j >= 0) {
+			const uint32_t jt = W.ld(cb + 3 * j), jo = W.ld(cb + 3 * j + 1);
+			if(!(jt > xt || (jt == xt && jo > xo))) break;
+			W.st(cb + 3 * (j + 1), jt); W.st(cb + 3 * (j + 1) + 1, jo); W.st(cb + 3 * (j + 1) + 2, W.ld(cb + 3 * j + 2));
+			j--;
+		}
+		W.st(cb + 3 * (j + 1), xt); W.st(cb + 3 * (j + 1) + 1, xo); W.st(cb + 3 * (j + 1) + 2, xj);
+	}
+}
 // reportHit + AlnSinkWrap::report (al_report of h2g_align.h) for a full-length hit; the record goes straight to its output slot
 H2G_HD void fg_write_rec(h2g_alnres& d, const FHit& hit, uint32_t rdlen) {
 	d.fw = hit.fw; d.tidx = hit.tidx; d.toff = hit.toff; d.len = hit.len; d.trim5 = hit.trim5; d.trim3 = hit.trim3;
@@ -856,8 +908,9 @@ again:
 		const uint32_t gsize = S.nghits;                    // gsize + nco <= maxsz: no shuffle (:5147)
 		const uint32_t rl = fs_rl(S, S.sel_r);
 		for(uint32_t k = 0; k < nco; k++) {
-			const uint32_t cb = fg_frame_co(0) + 3 * k;
-			const uint32_t tidx = W.ld(cb), toff = W.ld(cb + 1), joff = W.ld(cb + 2);
+			uint32_t co3[3];
+			W.ldv<3>(fg_frame_co(0) + 3 * k, co3);
+			const uint32_t tidx = co3[0], toff = co3[1], joff = co3[2];
 			if(tidx == H2G_MAX) F_BAIL(FB_STRADDLE);
 			bool overlapped = false;
 			for(uint32_t l = 0; l < gsize; l++) {
@@ -924,10 +977,19 @@ again:
 		if(hit.score < minsc) F_RC_RET(S.f_maxsc);
 		if(hitoff == hit.rdoff - hit.trim5 && hitlen == hit.len + hit.trim5 + hit.trim3) {
 			const uint32_t hsh = fh_hash(hit);
-			const uint32_t sb = FW_SRCH + S.sv_rdi * FG_NSRCH, ns = fs_nsearched(S, S.sv_rdi);
-			for(uint32_t i = 0; i < ns; i++) if(W.ld(sb + i) == hsh) F_BAIL(FB_SEARCHED);   // isSearched (or a collision): not ours to decide
+			const uint32_t sb = FW_SRCH + S.sv_rdi * FG_NSRCH * (1 + FG_HW), ns = fs_nsearched(S, S.sv_rdi);
+			bool searched = false;
+			if(ns > 0) {
+				uint32_t hs[FG_NSRCH];
+#pragma unroll
+				for(uint32_t i = 0; i < FG_NSRCH; i++) hs[i] = W.cold[sb - FW_HOT + i * (1 + FG_HW)];      // (every hash at once: one HBM latency)
+#pragma unroll
+				for(uint32_t i = 0; i < FG_NSRCH; i++) if(!searched && i < ns && hs[i] == hsh && fh_equal(fh_load(W, sb + i * (1 + FG_HW) + 1), hit)) searched = true;
+			}
+			if(searched) F_RC_RET(S.f_maxsc);                   // isSearched :6898
 			if(ns >= FG_NSRCH) F_BAIL(FB_SEARCHED);
-			W.st(sb + ns, hsh);
+			W.st(sb + ns * (1 + FG_HW), hsh);
+			if(!fh_store(W, sb + ns * (1 + FG_HW) + 1, hit)) F_BAIL(FB_EDITS);
 			if(S.sv_rdi == 0) S.nsearched0 = ns + 1; else S.nsearched1 = ns + 1;
 		}
 		if(hitoff == 0 && hitlen == rdlen) {
@@ -1003,7 +1065,7 @@ again:
 	case FPC_RC_ENTRY_R3: {
 		const uint32_t hb = fg_frame_hit(S.sp);
 		S.f_lidx = local_index_of(*C.ls, W.ld(hb), W.ld(hb + 1));
-		S.f_success = 0; S.f_first = 1; S.f_count = 0; S.f_prev = (int32_t)W.ld(hb + 3); S.f_ncoords = 0; S.f_ri = 0;
+		S.f_success = 0; S.f_first = 1; S.f_count = 0; S.f_prev = (int32_t)W.ld(hb + 3); S.f_ncoords = 0; S.f_ri = 0; S.f_nlocal = 0; S.f_ti = 0;
 		if(S.pc == FPC_RC_ENTRY_L3) F_GOTO(FPC_L_WHILE);
 		F_GOTO(FPC_R_WHILE);
 	}
@@ -1052,11 +1114,7 @@ again:
 	case FPC_L_LC_AFTER:
 	case FPC_R_LC_AFTER: {
 		S.f_ncoords = S.a0;
-		if(S.f_ncoords == 2) {                              // sort_coords
-			const uint32_t cb = fg_frame_co(S.sp);
-			const uint32_t t0 = W.ld(cb), o0 = W.ld(cb + 1), j0 = W.ld(cb + 2), t1 = W.ld(cb + 3), o1 = W.ld(cb + 4), j1 = W.ld(cb + 5);
-			if(t0 > t1 || (t0 == t1 && o0 > o1)) { W.st(cb, t1); W.st(cb + 1, o1); W.st(cb + 2, j1); W.st(cb + 3, t0); W.st(cb + 4, o0); W.st(cb + 5, j0); }
-		}
+		if(S.f_ncoords > 1) fg_sort_coords(W, fg_frame_co(S.sp), S.f_ncoords);
 		if(S.pc == FPC_L_LC_AFTER) { S.f_ri = (int32_t)S.f_ncoords - 1; F_GOTO(FPC_L_FOR_RI); }
 		F_GOTO(FPC_R_FOR_RI);
 	}
@@ -1064,7 +1122,7 @@ again:
 		if(S.f_ri < 0) F_GOTO(FPC_L_AFTER_FOR);
 		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
-		fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, W.ld(cb), W.ld(cb + 1), W.ld(cb + 2));
+		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
 		if(!fh_compatible(fh_load(W, FW_T1), fh_load(W, hb))) {
 			if(S.f_count == 1) { S.f_ri--; F_GOTO(FPC_L_FOR_RI); }
 			F_GOTO(FPC_L_AFTER_FOR);
@@ -1084,21 +1142,90 @@ again:
 				const uint32_t w4 = W.ld(FW_T1 + 4);
 				F_RC_CALL(FW_T1, w4 & 0xffu, ((w4 >> 8) & 0xffu) + (w4 >> 24), FPC_L_R1);
 			}
-			F_BAIL(FB_LOCALHITS);                           // _local_genomeHits: kept for later by the general machine
+			if(S.f_nlocal >= FG_NLOCAL) F_BAIL(FB_LOCALHITS);   // _local_genomeHits: kept for later (:1040)
+			fg_hit_copy(W, fg_frame_lh(S.sp, S.f_nlocal), FW_T1); S.f_nlocal = S.f_nlocal + 1;
 		}
 		F_GOTO(FPC_L_FOR_RI);
 	}
 	case FPC_L_R1: { if(S.ret > S.f_maxsc) S.f_maxsc = S.ret; F_GOTO(FPC_L_FOR_RI); }
 	case FPC_L_AFTER_FOR: {
 		if(S.f_maxsc != F_SMIN && S.f_maxsc >= S.f_prev - sc.mmpMax) S.f_success = 1;
-		F_GOTO(FPC_L_WHILE);                                // (the loop over _local_genomeHits is empty: nlocal == 0)
+		S.f_ti = 0;
+		if(!S.f_success && S.f_nlocal > 0 && (S.localindexatts >= S.max_localindexatts || S.f_count == 2 ||
+		                                      (S.f_lidx == H2G_MAX || local_index_prev(*C.ls, S.f_lidx) == H2G_MAX)))
+			F_GOTO(FPC_L_FOR_TI);
+		F_GOTO(FPC_L_WHILE);
 	}
+	case FPC_L_FOR_TI: {
+		if(S.f_ti >= S.f_nlocal) F_GOTO(FPC_L_WHILE);
+		const uint32_t tb = fg_frame_lh(S.sp, S.f_ti);
+		S.f_ti = S.f_ti + 1;
+		int32_t m = S.rc_minsc;
+		F_MINSC_LIVE(m);
+		if((int32_t)W.ld(tb + 3) >= m) {
+			const uint32_t w4 = W.ld(tb + 4);
+			F_RC_CALL(tb, w4 & 0xffu, ((w4 >> 8) & 0xffu) + (w4 >> 24), FPC_L_R2);
+		}
+		F_GOTO(FPC_L_FOR_TI);
+	}
+	case FPC_L_R2: { if(S.ret > S.f_maxsc) S.f_maxsc = S.ret; F_GOTO(FPC_L_FOR_TI); }
 	case FPC_L_AFTER_WHILE: {
 		if(S.f_success) F_RC_RET(S.f_maxsc);
 		S.f_ncoords = 0; S.f_ri = -1;
-		if(S.f_hitoff > minK && S.localindexatts < S.max_localindexatts) F_BAIL(FB_GSEARCH);   // global search for long introns (:1085)
-		F_GOTO(FPC_L_TRIM);
+		if(S.f_hitoff > minK && S.localindexatts < S.max_localindexatts) {   // global search for long introns (:1085)
+			S.f_extoff = S.f_hitoff - 1; S.f_extlen = 0;
+			S.a1 = S.f_extoff; S.a3 = 1; S.a4 = H2G_MAX; S.a5 = H2G_MAX;
+			F_OP(FOP_GSEARCH, FPC_L_GS_AFTER);
+		}
+		F_GOTO(FPC_L_FOR_G);
 	}
+	case FPC_L_GS_AFTER:
+	case FPC_R_GS_AFTER: {
+		const uint32_t nelt = S.a0, top = S.a2, bot = S.a3;
+		const bool left = S.pc == FPC_L_GS_AFTER;
+		S.f_extlen = S.a1; S.f_unique = S.a4 & 1u;
+		if(nelt > 0 && nelt <= 5 && S.f_extlen >= minK) {
+			S.a0 = top; S.a1 = bot; S.a2 = bot - top; S.a3 = S.f_extlen; S.a4 = 1; S.a5 = fg_frame_co(S.sp);
+			if(left) F_OP(FOP_GCOORDS, FPC_L_GC_AFTER); else F_OP(FOP_GCOORDS, FPC_R_GC_AFTER);
+		}
+		if(left) F_GOTO(FPC_L_FOR_G);
+		F_GOTO(FPC_R_FOR_G);
+	}
+	case FPC_L_GC_AFTER:
+	case FPC_R_GC_AFTER: {
+		{ const uint32_t nt_ = S.nsteps + S.a1; if(nt_ > 0xffffu) F_BAIL(FB_OTHER); S.nsteps = nt_; }
+		S.f_ncoords = S.a0;
+		if(S.pc == FPC_L_GC_AFTER) {
+			if(S.f_ncoords > 1) fg_sort_coords(W, fg_frame_co(S.sp), S.f_ncoords);
+			S.f_ri = (int32_t)S.f_ncoords - 1;
+			F_GOTO(FPC_L_FOR_G);
+		}
+		fg_sort_coords(W, fg_frame_co(S.sp), S.f_ncoords);
+		F_GOTO(FPC_R_FOR_G);
+	}
+	case FPC_L_FOR_G: {
+		if(S.f_ri < 0) F_GOTO(FPC_L_TRIM);
+		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
+		S.f_ri--;
+		const bool fw = (W.ld(hb + 5) & 1u) != 0;
+		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
+		if(!fh_compatible(fh_load(W, FW_T1), fh_load(W, hb))) F_GOTO(FPC_L_FOR_G);
+		if(S.f_unique) { S.a0 = 0; S.a1 = H2G_MAX; S.a2 = 0; S.a3 = FW_T1; F_OP(FOP_EXTEND, FPC_L_G_B); }
+		F_GOTO(FPC_L_G_B);
+	}
+	case FPC_L_G_B: { S.a3 = FW_T1; S.a4 = fg_frame_hit(S.sp); F_OP(FOP_COMBINE, FPC_L_G_C); }
+	case FPC_L_G_C: {
+		const bool combined = S.a0 != 0;
+		const int32_t tscore = (int32_t)W.ld(FW_T1 + 3);
+		int32_t m = S.rc_minsc;
+		F_MINSC_LIVE(m);
+		if(combined && tscore >= m) {
+			const uint32_t w4 = W.ld(FW_T1 + 4);
+			F_RC_CALL(FW_T1, w4 & 0xffu, ((w4 >> 8) & 0xffu) + (w4 >> 24), FPC_L_R3);
+		}
+		F_GOTO(FPC_L_FOR_G);
+	}
+	case FPC_L_R3: { if(S.ret > S.f_maxsc) S.f_maxsc = S.ret; F_GOTO(FPC_L_FOR_G); }
 	case FPC_L_TRIM: {
 		FHit hit = fh_load(W, fg_frame_hit(S.sp));
 		const int64_t minsc = S.rc_minsc;
@@ -1197,7 +1324,7 @@ again:
 		if(S.f_ri >= (int32_t)S.f_ncoords) F_GOTO(FPC_R_AFTER_FOR);
 		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
-		fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, W.ld(cb), W.ld(cb + 1), W.ld(cb + 2));
+		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
 		if(!fh_compatible(fh_load(W, hb), fh_load(W, FW_T1))) {
 			if(S.f_count == 1) { S.f_ri++; F_GOTO(FPC_R_FOR_RI); }
 			F_GOTO(FPC_R_AFTER_FOR);
@@ -1223,21 +1350,72 @@ again:
 				const uint32_t w4 = W.ld(t2 + 4);
 				F_RC_CALL(t2, (w4 & 0xffu) - ((w4 >> 16) & 0xffu), ((w4 >> 8) & 0xffu) + ((w4 >> 16) & 0xffu), FPC_R_R1);
 			}
-			F_BAIL(FB_LOCALHITS);
+			if(S.f_nlocal >= FG_NLOCAL) F_BAIL(FB_LOCALHITS);
+			fg_hit_copy(W, fg_frame_lh(S.sp, S.f_nlocal), t2); S.f_nlocal = S.f_nlocal + 1;
 		}
 		F_GOTO(FPC_R_FOR_RI);
 	}
 	case FPC_R_R1: { if(S.ret > S.f_maxsc) S.f_maxsc = S.ret; F_GOTO(FPC_R_FOR_RI); }
 	case FPC_R_AFTER_FOR: {
 		if(S.f_maxsc != F_SMIN && S.f_maxsc >= S.f_prev - sc.mmpMax) S.f_success = 1;
-		F_GOTO(FPC_R_WHILE);                                // (the loop over _local_genomeHits is empty: nlocal == 0)
+		S.f_ti = 0;
+		if(!S.f_success && S.f_nlocal > 0 && (S.localindexatts >= S.max_localindexatts || S.f_count == 2 ||
+		                                      (S.f_lidx == H2G_MAX || local_index_next(*C.ls, S.f_lidx) == H2G_MAX)))
+			F_GOTO(FPC_R_FOR_TI);
+		F_GOTO(FPC_R_WHILE);
 	}
+	case FPC_R_FOR_TI: {
+		if(S.f_ti >= S.f_nlocal) F_GOTO(FPC_R_WHILE);
+		const uint32_t tb = fg_frame_lh(S.sp, S.f_ti);
+		S.f_ti = S.f_ti + 1;
+		int32_t m = S.rc_minsc;
+		F_MINSC_LIVE(m);
+		if((int32_t)W.ld(tb + 3) >= m) {
+			const uint32_t w4 = W.ld(tb + 4);
+			F_RC_CALL(tb, (w4 & 0xffu) - ((w4 >> 16) & 0xffu), ((w4 >> 8) & 0xffu) + ((w4 >> 16) & 0xffu), FPC_R_R2);
+		}
+		F_GOTO(FPC_R_FOR_TI);
+	}
+	case FPC_R_R2: { if(S.ret > S.f_maxsc) S.f_maxsc = S.ret; F_GOTO(FPC_R_FOR_TI); }
 	case FPC_R_AFTER_WHILE: {
 		if(S.f_success) F_RC_RET(S.f_maxsc);
 		S.f_ncoords = 0; S.f_ri = 0;
-		if(S.f_hitoff + S.f_hitlen + minK + 1 < fs_rl(S, S.sv_rdi) && S.localindexatts < S.max_localindexatts) F_BAIL(FB_GSEARCH);
-		F_GOTO(FPC_R_TRIM);
+		if(S.f_hitoff + S.f_hitlen + minK + 1 < fs_rl(S, S.sv_rdi) && S.localindexatts < S.max_localindexatts) {
+			S.f_extoff = S.f_hitoff + S.f_hitlen + minK + 1; S.f_extlen = 0;
+			S.a1 = S.f_extoff; S.a3 = 1; S.a4 = H2G_MAX; S.a5 = H2G_MAX;
+			F_OP(FOP_GSEARCH, FPC_R_GS_AFTER);
+		}
+		F_GOTO(FPC_R_FOR_G);
 	}
+	case FPC_R_FOR_G: {
+		if(S.f_ri >= (int32_t)S.f_ncoords) F_GOTO(FPC_R_TRIM);
+		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
+		S.f_ri++;
+		const bool fw = (W.ld(hb + 5) & 1u) != 0;
+		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
+		if(!fh_compatible(fh_load(W, hb), fh_load(W, FW_T1))) F_GOTO(FPC_R_FOR_G);
+		S.a0 = 0; S.a1 = 0; S.a2 = H2G_MAX; S.a3 = FW_T1;
+		F_OP(FOP_EXTEND, FPC_R_G_B);
+	}
+	case FPC_R_G_B: {
+		const uint32_t t2 = fg_frame_hit(S.sp + 1);            // tmp2 lives where the callee's hit goes
+		fg_hit_copy(W, t2, fg_frame_hit(S.sp));
+		S.a3 = t2; S.a4 = FW_T1;
+		F_OP(FOP_COMBINE, FPC_R_G_C);
+	}
+	case FPC_R_G_C: {
+		const uint32_t t2 = fg_frame_hit(S.sp + 1);
+		const bool combined = S.a0 != 0;
+		const int32_t cscore = (int32_t)W.ld(t2 + 3);
+		int32_t m = S.rc_minsc;
+		F_MINSC_LIVE(m);
+		if(combined && cscore >= m) {
+			const uint32_t w4 = W.ld(t2 + 4);
+			F_RC_CALL(t2, (w4 & 0xffu) - ((w4 >> 16) & 0xffu), ((w4 >> 8) & 0xffu) + ((w4 >> 16) & 0xffu), FPC_R_R3);
+		}
+		F_GOTO(FPC_R_FOR_G);
+	}
+	case FPC_R_R3: { if(S.ret > S.f_maxsc) S.f_maxsc = S.ret; F_GOTO(FPC_R_FOR_G); }
 	case FPC_R_TRIM: {
 		FHit hit = fh_load(W, fg_frame_hit(S.sp));
 		const int64_t minsc = S.rc_minsc;
@@ -1366,22 +1544,66 @@ H2G_HD void fast_op_psearch(const FCtx& C, FState& S) {
 	S.a2 = (fh.len & 0xffu) | (fh.hit_type << 8) | ((fh.done ? 1u : 0u) << 16) | ((fh.anchorStop ? 1u : 0u) << 17) | (fh.numUniqueSearch << 18);
 	S.a3 = fh.cur; S.a4 = (fh.nrank & 0xffffu) | (fh.nside << 16);
 }
-H2G_HD void fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {   // getGenomeCoords :5774 (genome_coords_item), coordinates straight to the word store
+// SA walks are chunked: in lock-step a wave waits for its longest walk (the walk length is geometric: mean 15, the longest of 60 about 65),
+// so a primitive gives up after FG_WALK_STEPS LF steps, keeps (element, row, steps so far) in its arguments and asks to be queued again.
+#ifndef FG_WALK_STEPS
+#define FG_WALK_STEPS 20
+#endif
+#ifndef FG_LWALK_STEPS
+#define FG_LWALK_STEPS 10
+#endif
+// getGenomeCoords :5774 (genome_coords_item), coordinates straight to the word store.  a0 top a1 bot a2 maxelt a3 len a4 rejectStraddle a5 dst;
+// while it is under way a1 = the row the walk stands at, a2 = elements | (1 | element << 1 | coordinates written << 4 | jumps << 7) << 8.
+// true: not finished
+H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
 	const DGfm& g = *C.g;
-	uint32_t nelt = S.a1 - S.a0;
-	if(nelt > S.a2) nelt = S.a2;
-	if(nelt > FG_NCO) nelt = FG_NCO;
-	uint32_t n = 0, nsteps = 0;
-	for(uint32_t e = 0; e < nelt; e++) {
-		const uint32_t joff = sa_walk(g, S.a0 + e, &nsteps);
+	const bool reject = (S.a4 & 1u) != 0;
+	const uint32_t prog = S.a2 >> 8;
+	uint32_t nelt, e = 0, n = 0, jumps = 0, row = 0;
+	bool resume = false;
+	if(prog & 1u) { nelt = S.a2 & 0xffu; e = (prog >> 1) & 7u; n = (prog >> 4) & 7u; jumps = prog >> 7; row = S.a1; resume = true; }
+	else {
+		nelt = S.a1 - S.a0;
+		if(nelt > (S.a2 & 0xffu)) nelt = S.a2 & 0xffu;
+		if(nelt > FG_NCO) nelt = FG_NCO;
+	}
+	uint32_t budget = FG_WALK_STEPS, nsteps = 0;
+	for(; e < nelt; e++) {
+		if(!resume) { row = S.a0 + e; jumps = 0; }
+		resume = false;
+		// sa_walk (h2g_core.h) with a step budget
+		uint32_t joff = 0;
+		bool found = false;
+		while(true) {
+			if(g.nZ && row == g.zoff) { joff = jumps; found = true; break; }
+			if((row & g.offMask) == row) {
+				const uint32_t off = g.offs[row >> g.offRate];
+				if(off != H2G_MAX) { joff = off + jumps; found = true; break; }
+			}
+			if(budget == 0) break;
+			const uint32_t s0 = row / 192u, c0 = row - s0 * 192u;
+			const Side64 sd = load_side64(g.sides + (size_t)s0 * 64);
+			const int c = rowL_in_side64(sd, c0);
+			row = rank_in_side64(g, sd, s0, c0, c);
+			jumps++; budget--; nsteps++;
+		}
+		if(!found) {                                            // out of budget: come back
+			if(jumps >= (1u << 16)) { S.pc = FPC_BAIL; S.bail = FB_OTHER; return false; }
+			S.a1 = row;
+			S.a2 = nelt | ((1u | (e << 1) | (n << 4) | (jumps << 7)) << 8);
+			S.nsteps += nsteps;
+			return true;
+		}
 		uint32_t tidx = 0, toff = 0;
 		bool st2 = false;
-		joined_to_text(g, S.a3, joff, &tidx, &toff, S.a4 != 0, &st2);
+		joined_to_text(g, S.a3, joff, &tidx, &toff, reject, &st2);
 		if(tidx == H2G_MAX) break;
-		W.st(S.a5 + 3 * e, st2 ? H2G_MAX : tidx); W.st(S.a5 + 3 * e + 1, toff); W.st(S.a5 + 3 * e + 2, joff);
+		{ const uint32_t co3[3] = {st2 ? H2G_MAX : tidx, toff, joff}; W.stv<3>(S.a5 + 3 * e, co3); }
 		n = e + 1;
 	}
-	S.a0 = n; S.a1 = nsteps;
+	S.nsteps += nsteps;
+	S.a0 = n; S.a1 = 0;
+	return false;
 }
 H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
 	FHit h = fh_load(W, S.a3);
@@ -1399,18 +1621,47 @@ H2G_HD void fast_op_lsearch(const FCtx& C, FState& S) {
 	S.nrank += nr[0]; S.nside += nr[1];
 	S.a0 = nelt; S.a1 = extlen; S.a2 = top; S.a3 = bot; S.a4 = uniqueStop ? 1u : 0u;
 }
-H2G_HD void fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {   // getGenomeCoords_local :5861 (genome_coords_local)
+// getGenomeCoords_local :5861 (genome_coords_local), chunked like fast_op_gcoords.  a0 lidx a1 top a2 bot a3 rdoff a4 rdlen a5 dst; under way:
+// a2 bits 16.. = 1 | element << 1 | coordinates written << 4 | jumps << 7, a4 bits 8.. = the row (16 bits)
+H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
 	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[S.a0];
-	const uint32_t offMask = (0xffffu << C.ls->offRate) & 0xffffu;
-	uint32_t n = 0, steps = 0;
-	for(uint32_t e = 0; e < S.a2 - S.a1; e++) {
-		const uint32_t joff = sa_walk_idx(lx, S.a1 + e, offMask, C.ls->offRate, C.ls->words + lx.d->offs_off, true, &steps);
+	const uint32_t offMask = (0xffffu << C.ls->offRate) & 0xffffu, offRate = C.ls->offRate;
+	const uint16_t* offs = C.ls->words + lx.d->offs_off;
+	const uint32_t top = S.a1, bot = S.a2 & 0xffffu, rdlen = S.a4 & 0xffu;
+	uint32_t prog = S.a2 >> 16, e = 0, n = 0, jumps = 0, row = 0;
+	bool resume = false;
+	if(prog & 1u) { e = (prog >> 1) & 7u; n = (prog >> 4) & 7u; jumps = prog >> 7; row = S.a4 >> 8; resume = true; }
+	uint32_t budget = FG_LWALK_STEPS, steps = 0;
+	for(; e < bot - top; e++) {
+		if(!resume) { row = top + e; jumps = 0; }
+		resume = false;
+		uint32_t joff = 0;
+		bool found = false;
+		while(true) {                                            // sa_walk_idx (h2g_align.h) with a step budget
+			if(lx.is_zoff(row)) { joff = jumps; found = true; break; }
+			if((row & offMask) == row) {
+				const uint32_t off = offs[row >> offRate];
+				if(off != 0xffffu) { joff = off + jumps; found = true; break; }
+			}
+			if(budget == 0) break;
+			const int c = lx.rowL(row);
+			row = lx.rank(row, c);
+			jumps++; budget--; steps++;
+			if(jumps > 500) { S.pc = FPC_BAIL; S.bail = FB_OTHER; return false; }
+		}
+		if(!found) {
+			S.a2 = bot | ((1u | (e << 1) | (n << 4) | (jumps << 7)) << 16);
+			S.a4 = rdlen | (row << 8);
+			S.nsteps += steps;
+			return true;
+		}
 		h2g_coord c;
-		if(!local_joff_to_coord(*C.ls, lx.d, joff, S.a3, S.a4, &c)) continue;
-		if(n < FG_NCO) { W.st(S.a5 + 3 * n, c.tidx); W.st(S.a5 + 3 * n + 1, c.toff); W.st(S.a5 + 3 * n + 2, c.joinedOff); n++; }
+		if(!local_joff_to_coord(*C.ls, lx.d, joff, S.a3, rdlen, &c)) continue;
+		if(n < FG_NCO) { const uint32_t co3[3] = {c.tidx, c.toff, c.joinedOff}; W.stv<3>(S.a5 + 3 * n, co3); n++; }
 	}
 	S.nsteps += steps;
 	S.a0 = n;
+	return false;
 }
 H2G_HD void fast_op_combine(const FCtx& C, FState& S, const FWords& W) {
 	FHit a = fh_load(W, S.a3);
@@ -1421,17 +1672,29 @@ H2G_HD void fast_op_combine(const FCtx& C, FState& S, const FWords& W) {
 	else if(!fh_store(W, S.a3, a)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
 	S.a0 = ok ? 1u : 0u;
 }
+H2G_HD void fast_op_gsearch(const FCtx& C, FState& S) {       // globalGFMSearch :6606 (al_global_search)
+	const AlnParams& P = *C.P;
+	uint32_t extlen = 0, top = S.a4, bot = S.a5, nr[2] = {0, 0};
+	bool uniqueStop = S.a3 != 0;
+	GIdx gx; gx.g = C.g;
+	const uint32_t nelt = gfm_search(gx, fg_sv(C, S), S.a1, &extlen, &top, &bot, &uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false, nr);
+	S.nrank += nr[0]; S.nside += nr[1];
+	S.a0 = nelt; S.a1 = extlen; S.a2 = top; S.a3 = bot; S.a4 = uniqueStop ? 1u : 0u;
+}
+// S.op stays set when the primitive is not finished (a chunked walk): the slot goes back to the same site's queue
 H2G_HD void fast_exec(const FCtx& C, FState& S, const FWords& W, uint32_t op) {
+	bool again = false;
 	switch(op) {
+	case FOP_GSEARCH: fast_op_gsearch(C, S); break;
 	case FOP_PSEARCH: fast_op_psearch(C, S); break;
-	case FOP_GCOORDS: fast_op_gcoords(C, S, W); break;
+	case FOP_GCOORDS: again = fast_op_gcoords(C, S, W); break;
 	case FOP_EXTEND:  fast_op_extend(C, S, W); break;
 	case FOP_LSEARCH: fast_op_lsearch(C, S); break;
-	case FOP_LCOORDS: fast_op_lcoords(C, S, W); break;
+	case FOP_LCOORDS: again = fast_op_lcoords(C, S, W); break;
 	case FOP_COMBINE: fast_op_combine(C, S, W); break;
 	default: break;
 	}
-	S.op = FOP_NONE;
+	S.op = again ? op : (uint32_t)FOP_NONE;
 }
 
 // ---------------------------------------------------------------------------------------- the state between two trips
@@ -1458,7 +1721,9 @@ H2G_HD void fs_unpack(FState& S, LD&& ld) {
 	X(FOP_EXTEND, FPC_HS_EXT_AFTER) X(FOP_EXTEND, FPC_RC_ENTRY_L2) X(FOP_EXTEND, FPC_RC_ENTRY_R2) X(FOP_EXTEND, FPC_L_RI_B) X(FOP_EXTEND, FPC_R_RI_B) \
 	X(FOP_EXTEND, FPC_L_EXT_A) X(FOP_EXTEND, FPC_R_EXT_A) \
 	X(FOP_LSEARCH, FPC_L_LS_AFTER) X(FOP_LSEARCH, FPC_R_LS_AFTER) X(FOP_LCOORDS, FPC_L_LC_AFTER) X(FOP_LCOORDS, FPC_R_LC_AFTER) \
-	X(FOP_COMBINE, FPC_L_RI_C) X(FOP_COMBINE, FPC_R_RI_C)
+	X(FOP_COMBINE, FPC_L_RI_C) X(FOP_COMBINE, FPC_R_RI_C) \
+	X(FOP_GSEARCH, FPC_L_GS_AFTER) X(FOP_GSEARCH, FPC_R_GS_AFTER) X(FOP_GCOORDS, FPC_L_GC_AFTER) X(FOP_GCOORDS, FPC_R_GC_AFTER) \
+	X(FOP_EXTEND, FPC_L_G_B) X(FOP_EXTEND, FPC_R_G_B) X(FOP_COMBINE, FPC_L_G_C) X(FOP_COMBINE, FPC_R_G_C)
 enum : uint32_t {
 #define X(OPC, PC) FSITE_##PC,
 	FSITE_FREE = 0, FG_SITES(X) FSITE_COUNT
@@ -1480,12 +1745,42 @@ H2G_HD uint32_t fg_site_op(uint32_t site) {
 	default: return FOP_NONE;
 	}
 }
+// The queues of the kernel: the two hot sites have their own, the other sites share one queue per primitive (their lanes resume at
+// different pcs, which the control loop handles anyway): 8 queues of slot ids instead of 25 (LDS: 16 KB instead of 50 KB).
+enum : uint32_t { FQ_FREE = 0, FQ_PSEARCH, FQ_GCOORDS, FQ_EXTEND_HS, FQ_EXTEND, FQ_LSEARCH, FQ_LCOORDS, FQ_COMBINE, FQ_GSEARCH, FQ_COUNT };
+H2G_HD uint32_t fg_queue_of(uint32_t pc) {
+	const uint32_t site = fg_site_of(pc);
+	if(site == 0) return 0;
+	if(pc == FPC_HS_EXT_AFTER) return FQ_EXTEND_HS;
+	switch(fg_site_op(site)) {
+	case FOP_PSEARCH: return FQ_PSEARCH;
+	case FOP_GCOORDS: return FQ_GCOORDS;
+	case FOP_EXTEND:  return FQ_EXTEND;
+	case FOP_LSEARCH: return FQ_LSEARCH;
+	case FOP_LCOORDS: return FQ_LCOORDS;
+	case FOP_COMBINE: return FQ_COMBINE;
+	case FOP_GSEARCH: return FQ_GSEARCH;
+	default: return 0;
+	}
+}
+H2G_HD uint32_t fg_queue_op(uint32_t q) {
+	switch(q) {
+	case FQ_PSEARCH: return FOP_PSEARCH;
+	case FQ_GCOORDS: return FOP_GCOORDS;
+	case FQ_EXTEND_HS: case FQ_EXTEND: return FOP_EXTEND;
+	case FQ_LSEARCH: return FOP_LSEARCH;
+	case FQ_LCOORDS: return FOP_LCOORDS;
+	case FQ_COMBINE: return FOP_COMBINE;
+	case FQ_GSEARCH: return FOP_GSEARCH;
+	default: return FOP_NONE;
+	}
+}
 
 // One read / pair on ONE lane until it completes or bails (tests/emul).  true = completed.
 H2G_HD bool fast_run_single(const FCtx& C, FState& S, const FWords& W, uint32_t read, bool paired, bool packed_ok) {
 	fast_begin(C, S, read, paired, packed_ok);
 	while(S.pc != FPC_DONE && S.pc != FPC_BAIL) {
-		fast_step(C, S, W);
+		if(S.op == FOP_NONE) fast_step(C, S, W);
 		if(S.op != FOP_NONE) {
 #if !defined(__HIP_DEVICE_COMPILE__)
 			// what the queued kernel does between two trips: the state through its packed form (and the site table must know the resume pc)

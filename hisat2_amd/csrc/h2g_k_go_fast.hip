@@ -12,14 +12,14 @@
 using namespace h2g;
 
 #ifndef H2G_FAST_THREADS
-#define H2G_FAST_THREADS 384
+#define H2G_FAST_THREADS 512
 #endif
 #ifndef H2G_FAST_SLOTS
 #define H2G_FAST_SLOTS 1024       // reads in flight per workgroup (power of two)
 #endif
 #define FG_STAGE_WORDS (FW_HOT + 2 * H2G_PK_WORDS)                     // staged in LDS per lane: hot words + packed reads
 #define FG_SLOT_WORDS  (((FS_WORDS + FW_HOT + 2 * H2G_PK_WORDS + FW_COLD) + 3) & ~3)   // 16-byte multiple
-#define FG_NQ ((int)FSITE_COUNT)
+#define FG_NQ ((int)FQ_COUNT)
 #define FG_RING_EMPTY 0xffffu
 static_assert(FG_NQ <= 64, "the queue census is one lane per queue");
 static_assert(FS_WORDS % 4 == 0, "16-byte loads of the state");
@@ -68,38 +68,103 @@ __device__ __forceinline__ uint32_t fq_pop(FastLds* Q, uint32_t q, int lane, uin
 	return n;
 }
 
-__global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
+#ifndef H2G_FAST_SPLIT
+#define H2G_FAST_SPLIT 0
+#endif
+#if H2G_FAST_SPLIT
+#define FK_PHASE __device__ __noinline__
+#else
+#define FK_PHASE __device__ __forceinline__
+#endif
+// The two phases of a trip are functions of their own (own register allocation: the primitives need ~90 registers, the control
+// flow ~250; inlined into one kernel body they spilled 220).  Both work on the slot in HBM: the phase loads what it needs, the
+// state goes back to the slot, the caller reads the few words it routes by.
+__device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint32_t* sm, FCtx& C, FWords& W) {
+	const bool paired = A->paired != 0;
+	W.hot = (FG_LDS uint32_t*)stage; W.hot_stride = H2G_FAST_THREADS; W.cold = sm + FS_WORDS + FG_STAGE_WORDS;
+	uint32_t* const pk0 = stage + FW_HOT * H2G_FAST_THREADS;
+	C.g = &A->g; C.ref = &A->ref; C.ls = &A->ls; C.P = &A->P;
+	C.rd[0] = A->rd1; C.rd[1] = paired ? A->rd2 : A->rd1;
+	C.pk[0] = pk0; C.pk[1] = paired ? pk0 + H2G_PK_WORDS * H2G_FAST_THREADS : pk0; C.pk_stride = H2G_FAST_THREADS;
+	C.sc = nullptr; C.sc_stride = 0;
+	C.O = A->O;
+	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
+}
+// one primitive for this lane's slot; its results (and the bail / not-finished marks) go to the slot's state words
+FK_PHASE void fk_exec(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t op) {
+	FCtx C; FWords W;
+	fk_ctx(A, stage, sm, C, W);
+	FState S;
+	uint32_t w[FS_WORDS];
+#pragma unroll
+	for(uint32_t k = 0; k < FS_WORDS; k++) w[k] = 0;
+	const uint4* src = reinterpret_cast<const uint4*>(sm);
+	{ const uint4 v0 = src[0], v1 = src[1], v2 = src[2]; w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w; w[8] = v2.x; w[9] = v2.y; w[10] = v2.z; }
+	w[31] = sm[31];
+	const uint32_t w26 = sm[26], w27 = sm[27];
+	__builtin_memcpy(&S, w, sizeof S);
+	S.nrank = 0; S.nside = 0; S.nsteps = 0;
+	fast_exec(C, S, W, op);
+	const uint32_t nr_ = (w26 & 0xffffu) + S.nrank, ns_ = (w26 >> 16) + S.nside, nt_ = (w27 & 0xffffu) + S.nsteps;
+	if(S.pc != FPC_BAIL && (nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu)) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
+	__builtin_memcpy(w, &S, sizeof S);
+	uint4* dst = reinterpret_cast<uint4*>(sm);
+	dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);   // pc / op / bail, a0 .. a5
+	sm[26] = (nr_ & 0xffffu) | (ns_ << 16); sm[27] = (w27 & 0xffff0000u) | (nt_ & 0xffffu);
+}
+// the control flow of this lane's slot up to its next primitive request (begin != H2G_MAX: the slot takes up read `begin` first).
+// Returns the state's word 0 (pc, op, bail); the whole state is in the slot.
+FK_PHASE uint32_t fk_step(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t begin, uint32_t packed_ok) {
+	FCtx C; FWords W;
+	fk_ctx(A, stage, sm, C, W);
+	FState S;
+	if(begin != H2G_MAX) {
+		const bool paired = A->paired != 0;
+		C.name[0] = A->names1 + A->noffs1[begin]; C.namelen[0] = A->noffs1[begin + 1] - A->noffs1[begin];
+		if(paired) { C.name[1] = A->names2 + A->noffs2[begin]; C.namelen[1] = A->noffs2[begin + 1] - A->noffs2[begin]; }
+		fast_begin(C, S, begin, paired, packed_ok != 0);
+	} else {
+		uint32_t w[FS_WORDS];
+		const uint4* src = reinterpret_cast<const uint4*>(sm);
+#pragma unroll
+		for(uint32_t k = 0; k < FS_WORDS / 4; k++) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+		__builtin_memcpy(&S, w, sizeof S);
+	}
+	if(S.pc != FPC_DONE && S.pc != FPC_BAIL && S.op == FOP_NONE) fast_step(C, S, W);
+	uint32_t w[FS_WORDS];
+	__builtin_memcpy(w, &S, sizeof S);
+	uint4* dst = reinterpret_cast<uint4*>(sm);
+#pragma unroll
+	for(uint32_t k = 0; k < FS_WORDS / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+	return w[0];
+}
+
+__global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __restrict__ A)
 {
 	extern __shared__ uint32_t s_mem[];
 	FastLds* Q = reinterpret_cast<FastLds*>(s_mem);
 	uint32_t* const stage = s_mem + (sizeof(FastLds) + 3) / 4 + threadIdx.x;      // word w of this lane at stage[w * H2G_FAST_THREADS]
 	const int lane = (int)(threadIdx.x & 63);
-	const bool paired = A.paired != 0;
+	const bool paired = A->paired != 0;
 	for(uint32_t k = threadIdx.x; k < (uint32_t)FG_NQ * H2G_FAST_SLOTS; k += blockDim.x) (&Q->ring[0][0])[k] = FG_RING_EMPTY;
 	if(threadIdx.x < (uint32_t)FG_NQ) { Q->head[threadIdx.x] = 0; Q->tail[threadIdx.x] = 0; }
 	__syncthreads();
 	for(uint32_t k = threadIdx.x; k < H2G_FAST_SLOTS; k += blockDim.x) Q->ring[0][k] = (uint16_t)k;   // every slot starts free
 	if(threadIdx.x == 0) Q->tail[0] = H2G_FAST_SLOTS;
 	__syncthreads();
-	FWords W; W.hot = (FG_LDS uint32_t*)stage; W.hot_stride = H2G_FAST_THREADS; W.cold = nullptr;
 	uint32_t* const pk0 = stage + FW_HOT * H2G_FAST_THREADS;
 	uint32_t* const pk1 = pk0 + H2G_PK_WORDS * H2G_FAST_THREADS;
-	FCtx C;
-	C.g = &A.g; C.ref = &A.ref; C.ls = &A.ls; C.P = &A.P;
-	C.rd[0] = A.rd1; C.rd[1] = paired ? A.rd2 : A.rd1;
-	C.pk[0] = pk0; C.pk[1] = paired ? pk1 : pk0; C.pk_stride = H2G_FAST_THREADS;
-	C.sc = nullptr; C.sc_stride = 0;
-	C.O = A.O;
-	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
-	uint32_t* const slots0 = A.slots + (size_t)blockIdx.x * H2G_FAST_SLOTS * FG_SLOT_WORDS;
+	uint32_t* const slots0 = A->slots + (size_t)blockIdx.x * H2G_FAST_SLOTS * FG_SLOT_WORDS;
 	unsigned long long nrank = 0, nside = 0, nsteps = 0, naln = 0, ndone = 0, nbail = 0;
 	bool more = true;
-	const uint32_t total = A.total;
+	const uint32_t total = A->total;
 #ifdef H2G_GO_PROF
 	// wave-level time split (shader clock): [0] choose + pop + load [1] control [2] store [12] release fence [13] push [3+op] each primitive [15] new reads; [20+op] slots executed;
 	// [32+op] executions; [46] slots stepped [47] trips
-	unsigned long long prof[48];
+	unsigned long long prof[48], prof_ctl[32], prof_n[32];
 	for(int k = 0; k < 48; k++) prof[k] = 0;
+	for(int k = 0; k < 32; k++) { prof_ctl[k] = 0; prof_n[k] = 0; }
+	uint32_t trip_site = 0;
 	unsigned long long tp0 = __builtin_readcyclecounter(), tp1;
 #define PROF(SLOT) do { tp1 = __builtin_readcyclecounter(); prof[SLOT] += tp1 - tp0; tp0 = tp1; } while(0)
 #else
@@ -118,54 +183,47 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 		bestc = (uint32_t)__shfl((int)bestc, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
 		const bool fetch = more && nfree > 0 && (bestc < 64 || nfree >= H2G_FAST_SLOTS / 4);
 		bool have = false;
-		uint32_t slot = 0;
+		uint32_t slot = 0, begin = H2G_MAX, packed_ok = 0;
 		uint32_t* sm = nullptr;                                   // this lane's slot in HBM
-		FState S;
-		S.pc = FPC_DONE; S.op = FOP_NONE; S.bail = FB_NONE;
 		if(fetch) {
 			const uint32_t n = fq_pop(Q, 0, lane, &slot);
 			if(n == 0) continue;
 			uint32_t base = 0;
-			if(lane == 0) base = atomicAdd(A.work, n);
+			if(lane == 0) base = atomicAdd(A->work, n);
 			base = (uint32_t)__shfl((int)base, 0);
 			if(base + n >= total) more = false;
 			const bool got = (uint32_t)lane < n && base + (uint32_t)lane < total;
 			fq_push(Q, (uint32_t)lane < n && !got, 0, slot, lane);      // slots without a read go back
 			if(got) {
 				have = true;
-				const uint32_t mine = base + (uint32_t)lane;
+				begin = base + (uint32_t)lane;
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
-				W.cold = sm + FS_WORDS + FG_STAGE_WORDS;
-				bool ok = fg_pack_read(A.rd1, mine, pk0, H2G_FAST_THREADS);
-				C.name[0] = A.names1 + A.noffs1[mine]; C.namelen[0] = A.noffs1[mine + 1] - A.noffs1[mine];
-				if(paired) {
-					ok = fg_pack_read(A.rd2, mine, pk1, H2G_FAST_THREADS) && ok;
-					C.name[1] = A.names2 + A.noffs2[mine]; C.namelen[1] = A.noffs2[mine + 1] - A.noffs2[mine];
-				}
+				bool ok = fg_pack_read(A->rd1, begin, pk0, H2G_FAST_THREADS);
+				if(paired) ok = fg_pack_read(A->rd2, begin, pk1, H2G_FAST_THREADS) && ok;
+				packed_ok = ok ? 1u : 0u;
 				// the packed reads are written to the slot once
 #pragma unroll
 				for(uint32_t k = 0; k < 2 * H2G_PK_WORDS; k++) sm[FS_WORDS + FW_HOT + k] = pk0[k * H2G_FAST_THREADS];
-				fast_begin(C, S, mine, paired, ok);
 			}
+#ifdef H2G_GO_PROF
+			trip_site = 0;
+#endif
 			PROF(15);
 		} else {
 			if(bestc == 0) {
 				if(!more && nfree == H2G_FAST_SLOTS) break;           // the batch is exhausted and every slot is free again
 				__builtin_amdgcn_s_sleep(8);
-				if(more) { uint32_t w = 0; if(lane == 0) w = __atomic_load_n(A.work, __ATOMIC_RELAXED); if((uint32_t)__shfl((int)w, 0) >= total) more = false; }
+				if(more) { uint32_t w = 0; if(lane == 0) w = __atomic_load_n(A->work, __ATOMIC_RELAXED); if((uint32_t)__shfl((int)w, 0) >= total) more = false; }
 				continue;
 			}
-			const uint32_t op = fg_site_op(bestq);
+			const uint32_t op = fg_queue_op(bestq);
 			const uint32_t n = fq_pop(Q, bestq, lane, &slot);
 			if(n == 0) continue;
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			have = (uint32_t)lane < n;
 			if(have) {
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
-				W.cold = sm + FS_WORDS + FG_STAGE_WORDS;
-				// what the primitive needs of the state: its arguments, the read's geometry, the strand (words 0-10, 31).  The rest is loaded
-				// behind the primitive, so that it is not live (= spilled) across the latency-bound loops
-				const uint4* src = reinterpret_cast<const uint4*>(sm);
+				// hot words + packed reads into this lane's LDS staging area: 16-byte loads, nothing depends on anything
 				const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
 #pragma unroll
 				for(uint32_t k = 0; k < FG_STAGE_WORDS / 4; k++) {
@@ -174,36 +232,12 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 				}
 #pragma unroll
 				for(uint32_t k = FG_STAGE_WORDS & ~3u; k < FG_STAGE_WORDS; k++) stage[k * H2G_FAST_THREADS] = sm[FS_WORDS + k];
-				uint32_t w[FS_WORDS];
-#pragma unroll
-				for(uint32_t k = 0; k < FS_WORDS; k++) w[k] = 0;
-				{ const uint4 v0 = src[0], v1 = src[1], v2 = src[2]; w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w; w[8] = v2.x; w[9] = v2.y; w[10] = v2.z; }
-				w[31] = sm[31];
-				__builtin_memcpy(&S, w, sizeof S);
-				S.nrank = 0; S.nside = 0; S.nsteps = 0; S.pc = FPC_GO_INIT;
 			}
 #ifdef H2G_GO_PROF
-			prof[20 + op] += n; prof[32 + op]++;
+			prof[20 + op] += n; prof[32 + op]++; trip_site = bestq;
 #endif
 			PROF(0);
-			if(have) {
-				fast_exec(C, S, W, op);
-				// results of the primitive; then the whole state (16-byte loads, nothing depends on anything)
-				const uint32_t r0 = S.a0, r1 = S.a1, r2 = S.a2, r3 = S.a3, r4 = S.a4, r5 = S.a5, dr = S.nrank, ds = S.nside, dt = S.nsteps;
-				const bool failed = S.pc == FPC_BAIL;
-				const uint32_t why = S.bail;
-				const uint4* src = reinterpret_cast<const uint4*>(sm);
-				uint32_t w[FS_WORDS];
-#pragma unroll
-				for(uint32_t k = 0; k < FS_WORDS / 4; k++) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-				__builtin_memcpy(&S, w, sizeof S);
-				S.op = FOP_NONE;
-				S.a0 = r0; S.a1 = r1; S.a2 = r2; S.a3 = r3; S.a4 = r4; S.a5 = r5;
-				const uint32_t nr_ = S.nrank + dr, ns_ = S.nside + ds, nt_ = S.nsteps + dt;
-				S.nrank = nr_; S.nside = ns_; S.nsteps = nt_;
-				if(failed) { S.pc = FPC_BAIL; S.bail = why; }
-				else if(nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
-			}
+			if(have) fk_exec(A, stage, sm, op);
 			PROF(3 + op);
 		}
 		// ---- control flow of each read up to its next primitive request; then hand the slots on
@@ -211,38 +245,36 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 #ifdef H2G_GO_PROF
 		prof[46] += __popcll(__ballot(have)); prof[47]++;
 #endif
-		if(have) {
-			if(S.pc != FPC_DONE && S.pc != FPC_BAIL) fast_step(C, S, W);
-		}
+		uint32_t w0 = 0;
+		if(have) w0 = fk_step(A, stage, sm, begin, packed_ok);
+#ifdef H2G_GO_PROF
+		{ const unsigned long long t_ = __builtin_readcyclecounter(); prof_ctl[trip_site & 31] += t_ - tp0; prof_n[trip_site & 31]++; }
+#endif
 		PROF(1);
+		const uint32_t pc = w0 & 0xffu, why = (w0 >> 12) & 0x1fu;
 		if(have) {
-			if(S.pc == FPC_DONE) { nrank += S.nrank; nside += S.nside; nsteps += S.nsteps; naln += S.a0 != 0; ndone++; }
-			else if(S.pc != FPC_BAIL) {
-				uint32_t w[FS_WORDS];
-				__builtin_memcpy(w, &S, sizeof S);
-				uint4* dst = reinterpret_cast<uint4*>(sm);
-#pragma unroll
-				for(uint32_t k = 0; k < FS_WORDS / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+			if(pc == FPC_DONE) { const uint32_t c26 = sm[26], c27 = sm[27]; nrank += c26 & 0xffffu; nside += c26 >> 16; nsteps += c27 & 0xffffu; naln += sm[2] != 0; ndone++; }
+			else if(pc != FPC_BAIL) {
 				uint4* hdst = reinterpret_cast<uint4*>(sm + FS_WORDS);
 #pragma unroll
 				for(uint32_t k = 0; k < FW_HOT / 4; k++)
 					hdst[k] = make_uint4(stage[(4 * k) * H2G_FAST_THREADS], stage[(4 * k + 1) * H2G_FAST_THREADS], stage[(4 * k + 2) * H2G_FAST_THREADS], stage[(4 * k + 3) * H2G_FAST_THREADS]);
 #pragma unroll
 				for(uint32_t k = FW_HOT & ~3u; k < FW_HOT; k++) sm[FS_WORDS + k] = stage[k * H2G_FAST_THREADS];
-				nextq = fg_site_of(S.pc);
+				nextq = fg_queue_of(pc);
 			}
 		}
 		// reads that left the fast path: their ids go to the general machine's list
 		{
-			const bool b = have && S.pc == FPC_BAIL;
+			const bool b = have && pc == FPC_BAIL;
 			const unsigned long long bm = __ballot(b);
 			if(bm) {
 				uint32_t base = 0;
-				if(lane == 0) base = atomicAdd(A.bail_count, (uint32_t)__popcll(bm));
+				if(lane == 0) base = atomicAdd(A->bail_count, (uint32_t)__popcll(bm));
 				base = (uint32_t)__shfl((int)base, 0);
 				if(b) {
-					A.bail_list[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = S.read;
-					atomicAdd(A.counters + 96 + (S.bail < FB_COUNT ? S.bail : (uint32_t)FB_OTHER), 1ull);
+					A->bail_list[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = sm[8];       // state word 8 = the read id
+					atomicAdd(A->counters + 96 + (why < FB_COUNT ? why : (uint32_t)FB_OTHER), 1ull);
 					nbail++;
 				}
 			}
@@ -254,21 +286,23 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(FastArgs A)
 		PROF(13);
 	}
 #ifdef H2G_GO_PROF
-	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A.counters + 128 + k, prof[k]);
+	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A->counters + 128 + k, prof[k]);
+	if(lane == 0) for(int k = 0; k < 32; k++) if(prof_n[k]) { atomicAdd(A->counters + 176 + k, prof_ctl[k]); atomicAdd(A->counters + 208 + k, prof_n[k]); }
 #endif
-	wave_add(A.counters + 0, nrank);
-	wave_add(A.counters + 1, nside);
-	wave_add(A.counters + 2, nsteps);
-	wave_add(A.counters + 4, naln);
-	wave_add(A.counters + 6, ndone);
-	wave_add(A.counters + 7, nbail);
+	wave_add(A->counters + 0, nrank);
+	wave_add(A->counters + 1, nside);
+	wave_add(A->counters + 2, nsteps);
+	wave_add(A->counters + 4, naln);
+	wave_add(A->counters + 6, ndone);
+	wave_add(A->counters + 7, nbail);
 }
 
 #define FG_LDS_BYTES ((unsigned)(((sizeof(FastLds) + 3) / 4 + (size_t)FG_STAGE_WORDS * H2G_FAST_THREADS) * 4))
 extern "C" void h2g_go_fast_geometry(uint32_t* g) { g[0] = H2G_FAST_THREADS; g[1] = FG_LDS_BYTES; g[2] = H2G_FAST_SLOTS; g[3] = FG_SLOT_WORDS * 4u; }
+// `a` is the argument block in DEVICE memory
 extern "C" int h2g_go_fast_launch(const FastArgs* a, unsigned grid, hipStream_t st) {
 	static bool lds_ok = false;   // more than 64 KB of dynamic LDS is an opt-in
 	if(!lds_ok) { if(hipFuncSetAttribute((const void*)k_go_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok = true; }
-	hipLaunchKernelGGL(k_go_fast, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, *a);
+	hipLaunchKernelGGL(k_go_fast, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, a);
 	return (int)hipGetLastError();
 }

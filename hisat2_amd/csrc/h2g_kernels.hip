@@ -77,6 +77,7 @@ struct h2g_stream {
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
 	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
 	uint32_t* d_bail_list = nullptr;  // read ids the fast pass handed on to the general machine (+ their count behind the list)
+	void* d_fast_args = nullptr;      // the fast pass's argument block (device copy)
 	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
 	bool ran_fast = false;
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -370,7 +371,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipStreamSynchronize(s->st);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list); (void)hipFree(s->d_bail_list); (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_ovf_list); (void)hipFree(s->d_bail_list); (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_args); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -1592,7 +1593,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(fast) {
 		uint32_t fgeo[4];
 		h2g_go_fast_geometry(fgeo);
-		size_t fwant = (s->n_reads + fgeo[2] - 1) / fgeo[2];
+		size_t fwant = (s->n_reads + 127) / 128;                                                // small batches spread over the chip
 		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > 256 ? 256 : fwant));      // one persistent workgroup per CU (LDS-bound)
 		const size_t slot_bytes = (size_t)fgrid * fgeo[2] * fgeo[3];
 		if(s->fast_slot_bytes < slot_bytes) {
@@ -1611,7 +1612,9 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		F.counters = s->d_counters; F.work = reinterpret_cast<uint32_t*>(s->d_counters + 12);
 		F.bail_list = s->d_bail_list; F.bail_count = s->d_bail_list + s->max_reads;
 		F.total = (uint32_t)s->n_reads; F.paired = paired ? 1u : 0u;
-		if(h2g_go_fast_launch(&F, fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
+		if(!s->d_fast_args) HIPCHK(hipMalloc((void**)&s->d_fast_args, sizeof(FastArgs)));
+		HIPCHK(hipMemcpyAsync(s->d_fast_args, &F, sizeof F, hipMemcpyHostToDevice, s->st));   // (pageable source: the copy is staged before the call returns)
+		if(h2g_go_fast_launch(reinterpret_cast<const FastArgs*>(s->d_fast_args), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
 		A.list = s->d_bail_list; A.nlist = s->d_bail_list + s->max_reads;
 	}
 	HIPCHK(hipEventRecord(s->ev[10], s->st));
@@ -1763,11 +1766,12 @@ extern "C" __attribute__((visibility("default"))) int h2g_go_prof(h2g_stream* s,
 }
 
 // development hook (builds with -DH2G_GO_PROF): the wave-level time split of the last fast pass, 48 slots + 24 bail reasons (h2g_k_go_fast.hip)
-extern "C" __attribute__((visibility("default"))) int h2g_go_fast_prof(h2g_stream* s, unsigned long long* out72) {
+extern "C" __attribute__((visibility("default"))) int h2g_go_fast_prof(h2g_stream* s, unsigned long long* out72 /* [136] */) {
 	if(!s || !out72) return H2G_ERR_ARG;
 	HIPCHK(hipStreamSynchronize(s->st));
 	HIPCHK(hipMemcpy(out72, s->d_counters + 128, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(out72 + 48, s->d_counters + 96, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out72 + 72, s->d_counters + 176, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // control time / trips by site
 	return H2G_OK;
 }
 

@@ -61,18 +61,20 @@ if os.environ.get("H2G_DUMP"):
 L = api.lib()
 if hasattr(L, "h2g_go_fast_prof"):
     import ctypes as C
-    v = (C.c_ulonglong * 72)()
+    v = (C.c_ulonglong * 136)()
     L.h2g_go_fast_prof.argtypes = [C.c_void_p, C.c_void_p]
     if L.h2g_go_fast_prof(st.h, v) == 0:
         reasons = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other indel".split()
         print("  bails:", {reasons[k]: int(v[48 + k]) for k in range(len(reasons)) if v[48 + k]})
         if v[47]:
-            ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE".split()
+            ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE GSEARCH".split()
             tot = sum(v[k] for k in range(0, 16))
             print("  trips %d, slots per trip %.1f, wave-ticks %d" % (v[47], v[46] / max(1, v[47]), tot))
             for k, nm in ((0, "pop+load"), (1, "control"), (2, "store"), (12, "release fence"), (13, "push"), (15, "new reads")):
                 print("  %-20s %5.1f %%" % (nm, 100.0 * v[k] / tot))
-            for op in range(1, 7):
+            sites = ["FETCH", "P", "G", "E:HS", "E", "l", "c", "C", "g"]
+            print("  control by site (us per trip, trips, %% of wave time):", "  ".join("%s %.1f/%d/%.1f%%" % (sites[k] if k < len(sites) else k, v[72 + k] / max(1, v[104 + k]) / 2400.0, v[104 + k], 100.0 * v[72 + k] / tot) for k in range(32) if v[104 + k]))
+            for op in range(1, 8):
                 if v[3 + op]:
                     print("  %-20s %5.1f %%   executions %d: avg %.1f of 64 lanes" % (ops[op], 100.0 * v[3 + op] / tot, v[32 + op], v[20 + op] / max(1, v[32 + op])))
 print("%s n %d genome %d FAST=%s: align total/fast/machine ms %s | fast done %d bailed %d (%.1f %%) second %d overflow %d aligned %d | sides/unit %.1f steps/unit %.1f | crc %08x" % (
