@@ -56,6 +56,13 @@ struct h2g_index {
 struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
+	hipStream_t st2 = nullptr;        // the general machine's pass over the fast pass's hand-ons runs here, next to the following batch's fast pass
+	bool st2_busy = false;
+	hipEvent_t ev_fast[2], ev_mach[2];
+	unsigned gen = 0;                 // go_run generation: bail list, counters and argument block are double-buffered by its parity
+	unsigned long long* cnt_cur = nullptr;   // the counter block of the last go_run
+	uint32_t last_bails = 0;
+	uint32_t* h_bails = nullptr;      // pinned: the hand-on count of the last two fast passes (sizes the machine's share of the CUs)
 	size_t max_reads = 0, max_bases = 0, n_reads = 0;
 	uint32_t max_read_len = 0;
 	uint8_t* d_codes = nullptr;
@@ -76,8 +83,8 @@ struct h2g_stream {
 	} pool[2];
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
 	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
-	uint32_t* d_bail_list = nullptr;  // read ids the fast pass handed on to the general machine (+ their count behind the list)
-	void* d_fast_args = nullptr;      // the fast pass's argument block (device copy)
+	uint32_t* d_bail_list[2] = {nullptr, nullptr};  // read ids the fast pass handed on to the general machine (+ their count behind the list)
+	void* d_fast_args[2] = {nullptr, nullptr};      // the fast pass's argument block (device copy)
 	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
 	bool ran_fast = false;
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -352,9 +359,13 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	h2g_stream* s = new h2g_stream();
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+	HIPCHK(hipHostMalloc((void**)&s->h_bails, 16)); s->h_bails[0] = s->h_bails[1] = 0;
+	for(int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
 	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
-	HIPCHK(hipMalloc((void**)&s->d_counters, 256 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(s->d_counters, 0, 256 * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&s->d_counters, 512 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->d_counters, 0, 512 * sizeof(unsigned long long)));
+	s->cnt_cur = s->d_counters;
 	if(max_reads) {
 		HIPCHK(hipMalloc((void**)&s->d_codes, max_bases + 64));
 		HIPCHK(hipMalloc((void**)&s->d_quals, max_bases + 64));
@@ -368,22 +379,28 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 
 extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
-	(void)hipStreamSynchronize(s->st);
+	(void)hipStreamSynchronize(s->st); (void)hipStreamSynchronize(s->st2);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list); (void)hipFree(s->d_bail_list); (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_args); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_ovf_list); for(int k = 0; k < 2; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
-	(void)hipStreamDestroy(s->st);
+	(void)hipStreamDestroy(s->st); (void)hipStreamDestroy(s->st2); (void)hipHostFree(s->h_bails);
 	delete s;
 }
 
+// both streams of a batch context (the second one only ever holds the machine pass behind a fast pass)
+static hipError_t sync_all(h2g_stream* s) {
+	hipError_t e = hipStreamSynchronize(s->st);
+	if(e == hipSuccess && s->st2_busy) { e = hipStreamSynchronize(s->st2); s->st2_busy = false; }
+	return e;
+}
 extern "C" void* h2g_stream_hip(h2g_stream* s) { return s ? (void*)s->st : nullptr; }
 extern "C" h2g_status h2g_stream_sync(h2g_stream* s) {
 	if(!s) return H2G_ERR_ARG;
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -399,6 +416,7 @@ static int tmp_buf(h2g_stream* s, int slot, size_t bytes, void** out) {
 }
 
 extern "C" h2g_status h2g_set_reads(h2g_stream* s, const uint8_t* codes, const uint32_t* offs, const char* quals, size_t n) {
+	if(s) HIPCHK(sync_all(s));        // (a machine pass of the previous batch may still read the buffers this call replaces)
 	if(!s || !codes || !offs || n > s->max_reads) return H2G_ERR_ARG;
 	size_t nb = offs[n];
 	if(nb > s->max_bases) return H2G_ERR_ARG;
@@ -409,7 +427,7 @@ extern "C" h2g_status h2g_set_reads(h2g_stream* s, const uint8_t* codes, const u
 	HIPCHK(hipMemcpyAsync(s->d_offs, offs, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
 	s->has_quals = quals != nullptr;
 	if(quals) HIPCHK(hipMemcpyAsync(s->d_quals, quals, nb, hipMemcpyHostToDevice, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	s->n_reads = n;
 	s->has_names = false;
 	s->has_mates = false;
@@ -647,7 +665,7 @@ static int launch_rank(h2g_stream* s, const uint32_t* d_rows, const uint8_t* d_c
 		} else return H2G_ERR_ARG;
 	}
 	HIPCHK(hipEventRecord(s->ev[1], s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	HIPCHK(hipGetLastError());
 	float t = 0;
 	HIPCHK(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
@@ -688,7 +706,7 @@ extern "C" h2g_status h2g_rank_bench_synth(h2g_stream* s, size_t n, uint64_t see
 		hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, s->st, (const uint32_t*)dout, n, s->d_counters + 7);
 		unsigned long long v = 0;
 		HIPCHK(hipMemcpyAsync(&v, s->d_counters + 7, 8, hipMemcpyDeviceToHost, s->st));
-		HIPCHK(hipStreamSynchronize(s->st));
+		HIPCHK(sync_all(s));
 		*checksum = v;
 	}
 	return H2G_OK;
@@ -889,7 +907,7 @@ extern "C" h2g_status h2g_graph_lf(h2g_stream* s, const h2g_glf_query* q, size_t
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
 	if(iedges) HIPCHK(hipMemcpyAsync(iedges, die, n * sizeof *iedges, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -909,7 +927,7 @@ extern "C" h2g_status h2g_adjust_with_alt(h2g_stream* s, const h2g_adjust_query*
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(hits, dh, n * cap * sizeof *hits, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipMemcpyAsync(nhits, dn, n * 4, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -938,7 +956,7 @@ extern "C" h2g_status h2g_sa_resolve_graph(h2g_stream* s, const h2g_gsa_query* q
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(coords, dco, n * cap * sizeof *coords, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -962,7 +980,7 @@ extern "C" h2g_status h2g_fm_search_graph(h2g_stream* s, const h2g_fm_query* q, 
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
 	if(iedges) HIPCHK(hipMemcpyAsync(iedges, die, n * sizeof *iedges, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -983,7 +1001,7 @@ extern "C" h2g_status h2g_fm_search(h2g_stream* s, const h2g_fm_query* q, size_t
 	hipLaunchKernelGGL(k_fm_search, dim3(grid_for(n, 256)), dim3(256), 0, s->st, s->ix->dg, dreads(s), (const h2g_fm_query*)dq, n, khits, (h2g_fm_hit*)dout);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -1131,7 +1149,7 @@ extern "C" h2g_status h2g_ext_search(h2g_stream* s, const h2g_ext_search_query* 
 	HIPCHK(hipEventRecord(s->ev[9], s->st));
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	float t = 0;
 	if(hipEventElapsedTime(&t, s->ev[0], s->ev[1]) == hipSuccess) st.ms_staged = t;
 	if(hipEventElapsedTime(&t, s->ev[1], s->ev[9]) == hipSuccess) st.ms_hbm = t;
@@ -1183,7 +1201,7 @@ extern "C" h2g_status h2g_sw_align(h2g_stream* s, const h2g_sw_query* q, size_t 
 	HIPCHK(hipEventRecord(s->ev[1], s->st));
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, dout, n * sizeof *out, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	float t = 0;
 	HIPCHK(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
 	if(kernel_ms) *kernel_ms = t / repeats;
@@ -1208,7 +1226,7 @@ extern "C" h2g_status h2g_sa_resolve(h2g_stream* s, const h2g_sa_query* q, size_
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(coords, dco, n * cap * sizeof *coords, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -1239,7 +1257,7 @@ extern "C" h2g_status h2g_extend(h2g_stream* s, h2g_ghit* hits, const h2g_ext_ar
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(hits, dh, n * sizeof *hits, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipMemcpyAsync(res, dres, n * sizeof *res, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -1309,7 +1327,7 @@ extern "C" h2g_status h2g_seed_extend_run(h2g_stream* s, const h2g_seed_params* 
 extern "C" h2g_status h2g_seed_extend_fetch(h2g_stream* s, h2g_seed_result* out, size_t first_read, size_t n_reads) {
 	if(!s || !out || first_read + n_reads > s->n_reads) return H2G_ERR_ARG;
 	HIPCHK(hipMemcpyAsync(out, s->d_seed + first_read * 2, n_reads * 2 * sizeof *out, hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -1349,6 +1367,7 @@ extern "C" void h2g_align_params_presets(h2g_align_params* p, const h2g_index* i
 }
 
 extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const uint32_t* offs, size_t n) {
+	if(s) HIPCHK(sync_all(s));        // (a machine pass of the previous batch may still read the buffers this call replaces)
 	if(!s || !bytes || !offs || n != s->n_reads || n == 0) return H2G_ERR_ARG;
 	HIPCHK(hipSetDevice(s->ix->device));
 	size_t nb = offs[n];
@@ -1361,7 +1380,7 @@ extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const
 	}
 	HIPCHK(hipMemcpyAsync(s->d_names, bytes, nb, hipMemcpyHostToDevice, s->st));
 	HIPCHK(hipMemcpyAsync(s->d_name_offs, offs, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	s->has_names = true;
 	return H2G_OK;
 }
@@ -1369,6 +1388,7 @@ extern "C" h2g_status h2g_set_read_names(h2g_stream* s, const char* bytes, const
 extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const uint32_t* offs2, const char* quals2,
                                     const char* nb2, const uint32_t* noffs2, size_t n)
 {
+	if(s) HIPCHK(sync_all(s));
 	if(!s || !codes2 || !offs2 || !nb2 || !noffs2 || n != s->n_reads || n == 0) return H2G_ERR_ARG;
 	if(offs2[n] > s->max_bases) return H2G_ERR_ARG;
 	for(size_t i = 0; i < n; i++) { const uint32_t l = offs2[i + 1] - offs2[i]; if(l > s->max_read_len) s->max_read_len = l; }
@@ -1387,7 +1407,7 @@ extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const 
 	if(quals2) HIPCHK(hipMemcpyAsync(s->d_quals2, quals2, offs2[n], hipMemcpyHostToDevice, s->st));
 	HIPCHK(hipMemcpyAsync(s->d_names2, nb2, noffs2[n], hipMemcpyHostToDevice, s->st));
 	HIPCHK(hipMemcpyAsync(s->d_name_offs2, noffs2, (n + 1) * 4, hipMemcpyHostToDevice, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	s->has_mates = true;
 	return H2G_OK;
 }
@@ -1568,10 +1588,14 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	}
 	if(!s->d_ovf_list) HIPCHK(hipMalloc((void**)&s->d_ovf_list, (s->max_reads + 4) * 4));
 	(void)hipGetLastError();
-	HIPCHK(hipMemsetAsync(s->d_counters, 0, 256 * sizeof(unsigned long long), s->st));
-	HIPCHK(hipMemsetAsync(s->d_ovf_list + s->max_reads, 0, 16, s->st));
-	A.counters = s->d_counters;
-	A.work = reinterpret_cast<uint32_t*>(s->d_counters + 14);
+	// the fast pass's hand-on list, the counters and its argument block are double-buffered by the parity of the run: the general
+	// machine's pass over run k's hand-ons goes to the second stream and may still be under way while run k + 1's fast pass runs
+	const unsigned gsel = s->gen & 1u;
+	unsigned long long* const cblk = s->d_counters + 256 * gsel;
+	HIPCHK(hipStreamWaitEvent(s->st, s->ev_mach[gsel], 0));          // run k - 2's machine pass: done with this parity's buffers
+	HIPCHK(hipMemsetAsync(cblk, 0, 256 * sizeof(unsigned long long), s->st));
+	A.counters = cblk;
+	A.work = reinterpret_cast<uint32_t*>(cblk + 14);
 	A.list = nullptr; A.nlist = nullptr;
 	if(getenv("H2G_GO_DBG_READ")) {
 		static uint32_t* dbg = nullptr;
@@ -1588,56 +1612,82 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	// it hands on (a device-side list, no host sync) are the general machine's batch.  Built for unspliced alignment on a linear
 	// index with the default pair policy; every other option set goes to the machine whole.
 	static const int fast_env = getenv("H2G_GO_FAST") ? atoi(getenv("H2G_GO_FAST")) : 1;
-	const bool fast = fast_env && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp && s->max_read_len != 0;
+	const bool fast = fast_env && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp;
 	s->ran_fast = fast;
+	unsigned fast_mgrid = 0;
+	if(!fast && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (the machine's pool is about to be used on the first stream)
 	if(fast) {
 		uint32_t fgeo[4];
 		h2g_go_fast_geometry(fgeo);
+		// CUs: one persistent fast workgroup each (LDS-bound), minus the few the machine pass of the PREVIOUS run may still hold
+		// (the machine takes ~150 hand-ons per workgroup in half the time of a fast pass; the count is the last finished fast pass's)
+		if(s->gen > 0 && hipEventQuery(s->ev_fast[gsel ^ 1u]) == hipSuccess) s->last_bails = s->h_bails[gsel ^ 1u];
+		else if(s->gen > 1 && hipEventQuery(s->ev_fast[gsel]) == hipSuccess) s->last_bails = s->h_bails[gsel];
+		(void)hipGetLastError();
+		unsigned mgrid = (unsigned)((s->last_bails + 149) / 150);
+		if(mgrid < 4) mgrid = 4;
+		if(mgrid > 96) mgrid = 96;
 		size_t fwant = (s->n_reads + 127) / 128;                                                // small batches spread over the chip
-		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > 256 ? 256 : fwant));      // one persistent workgroup per CU (LDS-bound)
-		const size_t slot_bytes = (size_t)fgrid * fgeo[2] * fgeo[3];
+		const unsigned fmax = 256 - mgrid;
+		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > fmax ? fmax : fwant));
+		const size_t slot_bytes = (size_t)256 * fgeo[2] * fgeo[3];
 		if(s->fast_slot_bytes < slot_bytes) {
 			(void)hipFree(s->d_fast_slots); s->d_fast_slots = nullptr; s->fast_slot_bytes = 0;
 			HIPCHK(hipMalloc((void**)&s->d_fast_slots, slot_bytes));
 			s->fast_slot_bytes = slot_bytes;
 		}
-		if(!s->d_bail_list) HIPCHK(hipMalloc((void**)&s->d_bail_list, (s->max_reads + 4) * 4));
-		HIPCHK(hipMemsetAsync(s->d_bail_list + s->max_reads, 0, 16, s->st));
+		if(!s->d_bail_list[gsel]) HIPCHK(hipMalloc((void**)&s->d_bail_list[gsel], (s->max_reads + 4) * 4));
+		uint32_t* const bl = s->d_bail_list[gsel];
+		HIPCHK(hipMemsetAsync(bl + s->max_reads, 0, 16, s->st));
 		FastArgs F;
 		memset(&F, 0, sizeof F);
 		F.g = A.g; F.ref = A.ref; F.ls = A.ls; F.rd1 = A.rd1; F.rd2 = A.rd2; F.P = A.P;
 		F.names1 = A.names1; F.noffs1 = A.noffs1; F.names2 = A.names2; F.noffs2 = A.noffs2;
 		F.slots = s->d_fast_slots;
 		F.O.rout = A.O.rout; F.O.aln = A.O.aln; F.O.aln_slots = A.O.aln_slots; F.O.pout = A.O.pout; F.O.paln[0] = A.O.paln[0]; F.O.paln[1] = A.O.paln[1]; F.O.pair_slots = A.O.pair_slots;
-		F.counters = s->d_counters; F.work = reinterpret_cast<uint32_t*>(s->d_counters + 12);
-		F.bail_list = s->d_bail_list; F.bail_count = s->d_bail_list + s->max_reads;
+		F.counters = cblk; F.work = reinterpret_cast<uint32_t*>(cblk + 12);
+		F.bail_list = bl; F.bail_count = bl + s->max_reads;
 		F.total = (uint32_t)s->n_reads; F.paired = paired ? 1u : 0u;
-		if(!s->d_fast_args) HIPCHK(hipMalloc((void**)&s->d_fast_args, sizeof(FastArgs)));
-		HIPCHK(hipMemcpyAsync(s->d_fast_args, &F, sizeof F, hipMemcpyHostToDevice, s->st));   // (pageable source: the copy is staged before the call returns)
-		if(h2g_go_fast_launch(reinterpret_cast<const FastArgs*>(s->d_fast_args), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
-		A.list = s->d_bail_list; A.nlist = s->d_bail_list + s->max_reads;
+		if(!s->d_fast_args[gsel]) HIPCHK(hipMalloc((void**)&s->d_fast_args[gsel], sizeof(FastArgs)));
+		HIPCHK(hipMemcpyAsync(s->d_fast_args[gsel], &F, sizeof F, hipMemcpyHostToDevice, s->st));   // (pageable source: the copy is staged before the call returns)
+		if(h2g_go_fast_launch(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
+		A.list = bl; A.nlist = bl + s->max_reads;
+		fast_mgrid = mgrid;
 	}
 	HIPCHK(hipEventRecord(s->ev[10], s->st));
-	HIPCHK(hipEventRecord(s->ev[7], s->st));
-	if(U.launch(&A, grid, s->st) != 0) return set_err("go() launch", hipGetLastError());
-	HIPCHK(hipEventRecord(s->ev[6], s->st));
+	// behind a fast pass the machine works on the second stream (a short list on few workgroups: the next run's fast pass does not wait for it)
+	hipStream_t ms = s->st;
+	unsigned mach_grid = grid;
+	if(fast) {
+		HIPCHK(hipMemcpyAsync(&s->h_bails[gsel], s->d_bail_list[gsel] + s->max_reads, 4, hipMemcpyDeviceToHost, s->st));
+		HIPCHK(hipEventRecord(s->ev_fast[gsel], s->st));
+		HIPCHK(hipStreamWaitEvent(s->st2, s->ev_fast[gsel], 0));
+		ms = s->st2; s->st2_busy = true;
+		if(fast_mgrid < mach_grid) mach_grid = fast_mgrid;
+	}
+	HIPCHK(hipMemsetAsync(s->d_ovf_list + s->max_reads, 0, 16, ms));
+	HIPCHK(hipEventRecord(s->ev[7], ms));
+	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
+	HIPCHK(hipEventRecord(s->ev[6], ms));
 	if(second) {
 		const GoUnit& B = go_unit(linear, true, spl);
 		uint32_t* cnt = s->d_ovf_list + s->max_reads;
-		hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st,
+		hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, ms,
 		                   paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, s->d_ovf_list, cnt);
 		const unsigned bgrid = 4;
 		uint32_t bgeo[4];
 		B.geometry(bgeo);
 		GoArgs A2 = A;
 		if((rc = go_pool_for(s, 1, B, (size_t)bgrid * bgeo[1], (size_t)bgrid * bgeo[0], p->bowtie2_dp, &A2))) return rc;
-		A2.counters = s->d_counters + 64;
-		A2.work = reinterpret_cast<uint32_t*>(s->d_counters + 15);
+		A2.counters = cblk + 64;
+		A2.work = reinterpret_cast<uint32_t*>(cblk + 15);
 		A2.list = s->d_ovf_list; A2.nlist = cnt;
 		A2.defer_overflow = 0;
-		if(B.launch(&A2, bgrid, s->st) != 0) return set_err("go() second pass launch", hipGetLastError());
+		if(B.launch(&A2, bgrid, ms) != 0) return set_err("go() second pass launch", hipGetLastError());
 	}
-	HIPCHK(hipEventRecord(s->ev[8], s->st));
+	HIPCHK(hipEventRecord(s->ev[8], ms));
+	if(fast) HIPCHK(hipEventRecord(s->ev_mach[gsel], s->st2));
+	s->cnt_cur = cblk; s->gen++;
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;
 	return H2G_OK;
@@ -1647,6 +1697,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) { 
 extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params* p) { return go_run(s, p, true); }
 
 extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t first, size_t n) {
+	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
 	std::vector<ReadOut> tmp(n);
 	HIPCHK(hipMemcpyAsync(tmp.data(), s->d_rout + first, n * sizeof(ReadOut), hipMemcpyDeviceToHost, s->st));
@@ -1655,7 +1706,7 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 		HIPCHK(hipMemcpy2DAsync(aln, (size_t)H2G_ALN_CAP * sizeof(h2g_alnres), s->d_aln + first * s->aln_slots, (size_t)s->aln_slots * sizeof(h2g_alnres),
 		                        (size_t)w * sizeof(h2g_alnres), n, hipMemcpyDeviceToHost, s->st));
 	}
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	for(size_t i = 0; i < n; i++) {
 		res[i].nres = tmp[i].nres; res[i].nselect = tmp[i].nselect; res[i].overflow = tmp[i].overflow;
 		res[i].nrank = tmp[i].nrank; res[i].nsteps = tmp[i].nsteps; res[i].depth = tmp[i].depth;
@@ -1666,6 +1717,7 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 
 // ------------------------------------------------------------------------------------------ paired go(): fetch
 extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) {
+	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
 	// device rows hold pair_slots records, the caller's rows H2G_PAIR_RES_CAP (the dense variant returns all of them)
@@ -1674,7 +1726,7 @@ extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res,
 		if(dst) HIPCHK(hipMemcpy2DAsync(dst, (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres), s->d_paln[m] + first * s->pair_slots, (size_t)s->pair_slots * sizeof(h2g_alnres),
 		                                (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres), n, hipMemcpyDeviceToHost, s->st));
 	}
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
@@ -1717,11 +1769,12 @@ static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, 
 	                   (const unsigned long long*)d_offs, n, (h2g_alnres*)d_dense);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, d_dense, tot * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	return H2G_OK;
 }
 
 extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t aln_cap, uint64_t* aln_offs, size_t first, size_t n) {
+	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || !aln || !aln_offs || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
 	const h2g_status rc = h2g_align_fetch(s, res, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
@@ -1734,6 +1787,7 @@ extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res,
 extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, size_t cap1, uint64_t* offs1,
                                                   h2g_alnres* aln2, size_t cap2, uint64_t* offs2, size_t first, size_t n)
 {
+	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || !aln1 || !aln2 || !offs1 || !offs2 || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	const h2g_status rc = h2g_align_pairs_fetch(s, res, nullptr, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
@@ -1751,8 +1805,9 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 
 // development hook (env H2G_GO_DBG_READ=<read id>): the primitive requests of that read in the last go() launch, 8 words each
 extern "C" __attribute__((visibility("default"))) int h2g_go_debug_trace(h2g_stream* s, uint32_t* out, uint32_t cap_words) {
+	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !out || !s->dbg_buf) return H2G_ERR_ARG;
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	HIPCHK(hipMemcpy(out, s->dbg_buf, (size_t)cap_words * 4, hipMemcpyDeviceToHost));
 	return H2G_OK;
 }
@@ -1760,27 +1815,28 @@ extern "C" __attribute__((visibility("default"))) int h2g_go_debug_trace(h2g_str
 // development hook (builds with -DH2G_GO_PROF): the wave-level time split of the last go() launch, 48 slots (h2g_go_kernels.h)
 extern "C" __attribute__((visibility("default"))) int h2g_go_prof(h2g_stream* s, unsigned long long* out48) {
 	if(!s || !out48) return H2G_ERR_ARG;
-	HIPCHK(hipStreamSynchronize(s->st));
-	HIPCHK(hipMemcpy(out48, s->d_counters + 16, 80 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // [0..47] split, [64..79] control by source ring
+	HIPCHK(sync_all(s));
+	HIPCHK(hipMemcpy(out48, s->cnt_cur + 16, 80 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // [0..47] split, [64..79] control by source ring
 	return H2G_OK;
 }
 
 // development hook (builds with -DH2G_GO_PROF): the wave-level time split of the last fast pass, 48 slots + 24 bail reasons (h2g_k_go_fast.hip)
 extern "C" __attribute__((visibility("default"))) int h2g_go_fast_prof(h2g_stream* s, unsigned long long* out72 /* [136] */) {
 	if(!s || !out72) return H2G_ERR_ARG;
-	HIPCHK(hipStreamSynchronize(s->st));
-	HIPCHK(hipMemcpy(out72, s->d_counters + 128, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(out72 + 48, s->d_counters + 96, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(out72 + 72, s->d_counters + 176, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // control time / trips by site
+	HIPCHK(sync_all(s));
+	HIPCHK(hipMemcpy(out72, s->cnt_cur + 128, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out72 + 48, s->cnt_cur + 96, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out72 + 72, s->cnt_cur + 176, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // control time / trips by site
 	return H2G_OK;
 }
 
 extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	if(!s || !c) return H2G_ERR_ARG;
-	HIPCHK(hipStreamSynchronize(s->st));
+	HIPCHK(sync_all(s));
 	unsigned long long v[16];
-	HIPCHK(hipMemcpy(v, s->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(v + 8, s->d_counters + 64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	unsigned long long* const cb = s->ran_align ? s->cnt_cur : s->d_counters;
+	HIPCHK(hipMemcpy(v, cb, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(v + 8, cb + 64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	// [0..7] the main pass, [8..15] <- slots 64..71: the second pass over its overflowed reads (go_run)
 	s->last.n_rank = v[0] + v[8]; s->last.n_side = v[1] + v[9]; s->last.n_sa_steps = v[2] + v[10]; s->last.n_ext = v[3];
 	s->last.n_aligned = v[4] + v[12];
@@ -1799,7 +1855,8 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	s->last.n_fast = 0; s->last.n_fast_bail = 0; s->last.ms_fast_kernel = 0; s->last.pad_ = 0;
 	if(s->ran_align && s->ran_fast) {
 		unsigned long long f[2];
-		HIPCHK(hipMemcpy(f, s->d_counters + 6, sizeof f, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(f, s->cnt_cur + 6, sizeof f, hipMemcpyDeviceToHost));
+		s->last_bails = (uint32_t)f[1];
 		s->last.n_fast = f[0]; s->last.n_fast_bail = f[1];
 		if(hipEventElapsedTime(&t, s->ev[5], s->ev[10]) == hipSuccess) s->last.ms_fast_kernel = t;
 	}
