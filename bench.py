@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the MI355X seed-and-extend hot path (BASELINE.json metric: reads/sec, 101 bp PE on a GRCh38-scale
+"""bench.py — throughput of the MI355X seed-and-extend hot path (BASELINE.json metric: reads/sec, 101 bp PE on a GRCh38-size
 linear index; achieved HBM GB/s on Occ-rank).
 
 One "step" = one pass of the hot path over one resident batch of synthetic read pairs = HI_Aligner::go for every pair
 (hi_aligner.h:4048: FM backward search of both mates on both strands, SA-offset resolution, ungapped extension, local-index
-search, indel joins, recursion, mate rescue, pairing, sink feedback) — h2g_align_pairs_run, both of its passes (the main pass
-and the second pass over reads whose default workspace overflowed).
+search, indel joins, recursion, mate rescue, pairing, sink feedback) — h2g_align_pairs_run: the fast pass (h2g_k_go_fast.hip:
+the dominant traces with a compact per-read state), the general machine's pass over the reads the fast pass handed on, and the
+large-workspace pass over what overflowed that.  The machine's pass of step k runs on a second stream next to the fast pass of
+step k + 1 (its own share of the CUs); the K timed steps are bracketed by a full synchronisation of both streams.
 
-Workload at N=1 = the shape of BASELINE.json configs[2]: linear index, 101 bp paired-end reads, --no-spliced-alignment.  The
-index is the reference builder's (oracle/_ref/hisat2-build-s) over a seeded uniform-random genome in 24 human-profile contigs
-(no network: GRCh38 itself cannot be fetched).  Its SIZE is what the box can obtain: a staged .bench_cache/grch38sim<len>_*
-index is used when present (largest first; the 3.1 Gbp one takes ~18 min to build and is 4.7 GB, more than a repo snapshot may
-carry); otherwise H2G_BENCH_GENOME bases (default 256 Mbp, ~2.5 min on the GPU box, 85 MB of sides: beyond the 4 MB of L2 per XCD) are built once and
-cached.  The size actually used is named in config.workload.  configs[1] (E. coli-size, single-end) runs as the extra leg
-"ecoli_se".
+Workload at N=1 = BASELINE.json configs[2]: GRCh38-SIZE linear index (3.1 Gbp, 4.7 GB resident), 101 bp paired-end reads,
+--no-spliced-alignment.  The index is the reference builder's (oracle/_ref/hisat2-build-s) over a seeded uniform-random genome in
+24 human-profile contigs (no network: GRCh38 itself cannot be fetched), built on the box (~18 min at -p 64) and cached in
+.bench_cache/; a staged grch38sim<len>_* index of at least the wanted size is used when present.  H2G_BENCH_GENOME overrides the
+size (e.g. 256e6 for a quick run); the size actually used is named in config.workload.  configs[1] (E. coli-size, single-end)
+runs as the extra leg "ecoli_se"; the extra legs are skipped when the run is past H2G_BENCH_DEADLINE seconds (default 1350).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]        (N>1 via torch.distributed.run, one rank per GPU)
 Prints ONE JSON line on rank 0.
@@ -96,17 +97,19 @@ def body(path):
 
 
 def main():
+    t_start = time.time()
+    deadline = float(os.environ.get("H2G_BENCH_DEADLINE", "1350"))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per GPU per step")
-    ap.add_argument("--genome", type=float, default=float(os.environ.get("H2G_BENCH_GENOME", "256e6")))
+    ap.add_argument("--genome", type=float, default=float(os.environ.get("H2G_BENCH_GENOME", "3.1e9")))
     ap.add_argument("--strong", action="store_true", help="one global batch of --pairs split over the ranks instead of --pairs per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (E. coli SE, graph index, micro-benchmarks)")
     ap.add_argument("--rank-queries", type=int, default=1 << 26)
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="pairs of the reference CPU run")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs available to the reference CPU runs (each thread count takes what ~6 s of it)")
     a = ap.parse_args()
 
     import torch
@@ -181,35 +184,44 @@ def main():
         out = {}
         total_reads = 2 * int(summ[0])
         value = total_reads * a.steps / dt
-        # dominant kernel = k_go (the whole go() machine), main pass.  Algorithmic bytes = 64 B x (unique sides
-        # visited by the search loops + SA-walk steps) of the LAST launch on this rank; duration = HIP events on the launch stream.
-        ms_kernel = float(cnt.ms_align_kernel)
-        ms_both = float(cnt.ms_align)
-        alg_bytes = (int(cnt.n_side) + int(cnt.n_sa_steps)) * 64
+        # dominant kernel = k_go_fast (the fast pass: every pair enters it, 99 % complete on it).  Algorithmic bytes =
+        # 64 B x (unique sides visited by its search loops + its SA-walk steps) of the LAST launch on this rank; duration = HIP events
+        # on the launch stream around that launch (h2g_counters.ms_fast_kernel)
+        ms_fast = float(cnt.ms_fast_kernel)
+        ms_machine = float(cnt.ms_align_kernel)
+        fast_on = ms_fast > 0 and int(cnt.n_fast) > 0
+        ms_kernel = ms_fast if fast_on else ms_machine
+        alg_bytes = ((int(cnt.n_fast_side) + int(cnt.n_fast_sa_steps)) if fast_on else (int(cnt.n_side) + int(cnt.n_sa_steps))) * 64
         achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+        alg_all = (int(cnt.n_side) + int(cnt.n_sa_steps)) * 64
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "k_go<false> (h2g_go_kernels.h)", "kernel_ms": ms_kernel, "both_passes_ms": ms_both,
-                    "algorithmic_bytes_per_launch": alg_bytes, "sides_per_pair": int(cnt.n_side) / npairs, "sa_steps_per_pair": int(cnt.n_sa_steps) / npairs,
-                    "note": "per-read control state lives in HBM: the kernel is bound by scattered workspace lines and divergent control, not by index bytes (DESIGN.md §3)"}
+                    "kernel": "k_go_fast (h2g_k_go_fast.hip)" if fast_on else "k_go<false> (h2g_go_kernels.h)", "kernel_ms": ms_kernel,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "pairs_completed_by_the_kernel": int(cnt.n_fast), "pairs_handed_on": int(cnt.n_fast_bail),
+                    "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs, on the second stream next to the following step's fast pass",
+                    "whole_step": {"algorithmic_bytes": alg_all, "GB/s": alg_all / (dt / a.steps) / 1e9, "frac": alg_all / (dt / a.steps) / 1e9 / HBM_PEAK_GBS},
+                    "sides_per_pair": int(cnt.n_side) / npairs, "sa_steps_per_pair": int(cnt.n_sa_steps) / npairs,
+                    "note": "latency chains over scattered 64 B index lines + per-read control; the per-read state is 672 B per trip in 5 sequential lines (DESIGN.md §3)"}
         # HBM traffic of the same kernel on the same workload from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
         # WRITE_SIZE need separate passes and cannot be collected inside this process); per launch like `achieved`
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            if pm.get("pairs_per_launch") == npairs and pm.get("genome") == total:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            if pm.get("pairs_per_launch") == npairs and pm.get("genome") == total and pm.get("kernel", "").startswith("k_go_fast") == fast_on:
                 roofline["traffic"] = int(pm["traffic_bytes_per_launch"])
                 roofline["traffic_source"] = pm.get("source")
         except (OSError, ValueError):
             pass
         out.update({
-            "metric": "reads/sec, 101 bp PE, linear index, --no-spliced-alignment (whole job): HI_Aligner::go per pair on the GPU, SAM-identical to hisat2",
+            "metric": "reads/sec, 101 bp PE, GRCh38-size linear index, --no-spliced-alignment: HI_Aligner::go per pair on the GPU (inputs and report events resident in HBM), SAM-identical to hisat2",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"configs[2] shape: GRCh38-PROFILE linear index over a seeded uniform-random {total} bp genome (24 contigs; {how}), "
+            "config": {"workload": f"configs[2]: GRCh38-{'SIZE' if total >= 3_000_000_000 else 'PROFILE (reduced size)'} linear index over a seeded uniform-random {total} bp genome (24 contigs; {how}), "
                                    f"{npairs} synthetic 101 bp --fr pairs per GPU per step, --no-spliced-alignment -k 5, 1xMI355X per rank",
                        "genome_bases": total, "index_device_bytes": int(ix.info.device_bytes), "pairs_per_gpu": npairs, "read_len": 101, "sub_rate": 0.005,
                        "fragment": "N(300, 30) clipped to [150, 600]",
                        "stage": "HI_Aligner::go for both mates + pairing; report events stay in HBM (finishRead / SAM text are host code, SURVEY §8(f) N1)",
+                       "pipelining": "the machine pass of step k overlaps the fast pass of step k+1 on a second stream; all K steps complete inside the timed region",
                        "sharding": f"pairs by id range across {world} GPU(s) ({'one global batch split' if a.strong else 'fixed work per GPU'}), index replicated; RCCL all-reduce of the summary counters only"},
             "roofline": roofline,
             "counters": {"pairs": int(summ[0]), "pairs_with_concordant": int(summ[1]), "pairs_still_flagged_overflow": int(summ[2]),
@@ -248,18 +260,37 @@ def main():
                              "against": "oracle/_ref/hisat2-align-s -p 1 (complete SAM lines, byte for byte)", **json.load(open(os.path.join(tmp, "stats.json")))}
             if ndiff:
                 raise SystemExit(f"bench.py: {ndiff} SAM lines of the parity sample differ from the reference")
-            # the reference on this box's host cores, same index, same reads (bounded sample); index load timed apart and subtracted
+            # the reference on this box's host cores, same index, same reads: thread counts 1 .. nproc, each on as many pairs
+            # as ~6 s of work at that width; wall time minus the index load (a `-u 1` run at the same width); median of 3 at the best width
             ncpu = os.cpu_count() or 1
+            widths = sorted({t for t in (1, 16, 32, 64, 128, ncpu) if t <= ncpu})
+            per_core = 12_000.0                          # pairs/s/core guess for sizing the first sample (corrected by what is measured)
             scan, best = {}, None
-            for pth in [t for t in (16, 64) if t <= ncpu] or [ncpu]:
+            for pth in widths:
+                if time.time() - t_start > deadline:
+                    break
+                nsamp = int(min(ns, max(20_000, 6.0 * per_core * min(pth, 48))))
                 t_load = reference_pairs(base, f1, f2, [], pth, upto=1)
-                t_run = max(reference_pairs(base, f1, f2, [], pth) - t_load, 1e-6)
-                scan[str(pth)] = 2 * ns / t_run
-                if best is None or 2 * ns / t_run > best[0]:
-                    best = (2 * ns / t_run, pth, t_run, t_load)
-            out["cpu_baseline"] = {"value": best[0], "unit": "reads/s", "cores": best[1], "kind": "reference", "host_cpus": ncpu, "threads_scan_reads_per_s": scan,
-                                   "sample": f"first {ns} pairs of the bench batch, oracle/_ref/hisat2-align-s -p {best[1]} --no-spliced-alignment -S /dev/null on the same index, "
-                                             f"{best[2]:.1f} s (index load {best[3]:.1f} s timed apart and subtracted); best of the thread counts scanned"}
+                t_run = max(reference_pairs(base, f1, f2, [], pth, upto=nsamp) - t_load, 1e-6)
+                rate = 2 * nsamp / t_run
+                scan[str(pth)] = {"reads_per_s": rate, "reads_per_s_per_core": rate / pth, "pairs": nsamp, "seconds": t_run, "index_load_s": t_load}
+                if pth == 1:
+                    per_core = max(2_000.0, nsamp / t_run)
+                if best is None or rate > best[0]:
+                    best = (rate, pth, t_run, t_load, nsamp)
+            reps = [best[0]]
+            for _ in range(2):
+                if time.time() - t_start > deadline:
+                    break
+                t_run = max(reference_pairs(base, f1, f2, [], best[1], upto=best[4]) - best[3], 1e-6)
+                reps.append(2 * best[4] / t_run)
+            med = sorted(reps)[len(reps) // 2]
+            out["cpu_baseline"] = {"value": med, "unit": "reads/s", "cores": best[1], "kind": "reference", "host_cpus": ncpu,
+                                   "reads_per_s_per_core_at_1_thread": scan.get("1", {}).get("reads_per_s_per_core"), "repeats_at_best_width": reps,
+                                   "threads_scan": scan,
+                                   "sample": f"first {best[4]} pairs of the bench batch, oracle/_ref/hisat2-align-s -p {best[1]} --no-spliced-alignment -S /dev/null on the same "
+                                             f"{total} bp index, {best[2]:.1f} s of alignment (index load {best[3]:.1f} s timed by a -u 1 run and subtracted); median of {len(reps)}; "
+                                             "every width's own sample is in threads_scan"}
             # end to end on the same sample: reads files -> SAM file, both programs
             t0c = time.perf_counter()
             r = subprocess.run([cli, "-f", "--no-spliced-alignment", "-p", "32", "-x", base, "-1", f1, "-2", f2, "-S", os.path.join(tmp, "e2e.sam")],
@@ -269,7 +300,9 @@ def main():
                                      "timing": r.stderr.strip().splitlines()[-1] if r.returncode == 0 and r.stderr.strip() else r.stderr[-300:]}
             shutil.rmtree(tmp, ignore_errors=True)
         st.close()
-        if not a.no_extras:
+        if not a.no_extras and time.time() - t_start > deadline:
+            out["extras_skipped"] = "past H2G_BENCH_DEADLINE = %.0f s (index build included)" % deadline
+        elif not a.no_extras:
             try:                                   # the extra legs never cost the headline its line
                 out.update(extras(a, api, synth, ix, local, cache))
             except Exception as e:             # noqa: BLE001
@@ -303,9 +336,11 @@ def extras(a, api, synth, ix_big, local, cache):
     dt = (time.perf_counter() - t0) / 5
     c = st.counters()
     leg = {"workload": "configs[1]: E. coli-size (4.9 Mbp seeded substitute) linear index, 1 M synthetic 101 bp SE reads", "reads": n,
-           "ms_per_step": dt * 1e3, "reads_per_s": n / dt, "kernel_ms": float(c.ms_align_kernel), "aligned": int(c.n_aligned),
+           "ms_per_step": dt * 1e3, "reads_per_s": n / dt, "kernel_ms": float(c.ms_fast_kernel) or float(c.ms_align_kernel), "machine_pass_ms": float(c.ms_align_kernel),
+           "aligned": int(c.n_aligned), "fast_pass_completed": int(c.n_fast), "handed_on": int(c.n_fast_bail),
            "second_pass": int(c.n_second_pass), "still_flagged": int(c.n_overflow),
-           "roofline_frac": (int(c.n_side) + int(c.n_sa_steps)) * 64 / (float(c.ms_align_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+           "roofline_frac": ((int(c.n_fast_side) + int(c.n_fast_sa_steps)) * 64 / (float(c.ms_fast_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS) if float(c.ms_fast_kernel) > 0
+                            else (int(c.n_side) + int(c.n_sa_steps)) * 64 / (float(c.ms_align_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if os.path.exists(exe) and not a.no_cpu_baseline:
         nv = 3000
         tmp = tempfile.mkdtemp(prefix="h2benchs")

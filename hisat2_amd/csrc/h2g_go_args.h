@@ -50,7 +50,7 @@ struct FastArgs {
 	const char* names2; const uint32_t* noffs2;
 	uint32_t* slots;                      // FG_SLOT_WORDS words per read in flight: packed state, hot words, packed reads, cold words
 	h2g::FastOut O;
-	unsigned long long* counters;         // [0] rank calls [1] sides [2] SA steps [4] aligned [6] completed [7] bailed, [96 + why] bails by reason
+	unsigned long long* counters;         // [120] rank calls [121] sides [122] SA steps [123] aligned [6] completed [7] bailed, [96 + why] bails by reason
 	uint32_t* work;                       // next unclaimed read (zeroed before the launch)
 	uint32_t* bail_list; uint32_t* bail_count;
 	uint32_t total, paired;

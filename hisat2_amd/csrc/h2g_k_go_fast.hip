@@ -289,10 +289,10 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A->counters + 128 + k, prof[k]);
 	if(lane == 0) for(int k = 0; k < 32; k++) if(prof_n[k]) { atomicAdd(A->counters + 176 + k, prof_ctl[k]); atomicAdd(A->counters + 208 + k, prof_n[k]); }
 #endif
-	wave_add(A->counters + 0, nrank);
-	wave_add(A->counters + 1, nside);
-	wave_add(A->counters + 2, nsteps);
-	wave_add(A->counters + 4, naln);
+	wave_add(A->counters + 120, nrank);     // (slots of its own: the general machine's passes count in 0..5 / 64..69)
+	wave_add(A->counters + 121, nside);
+	wave_add(A->counters + 122, nsteps);
+	wave_add(A->counters + 123, naln);
 	wave_add(A->counters + 6, ndone);
 	wave_add(A->counters + 7, nbail);
 }

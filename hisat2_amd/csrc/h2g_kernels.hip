@@ -1852,12 +1852,15 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	}
 	if(s->ran_align && hipEventElapsedTime(&t, s->ev[7], s->ev[6]) == hipSuccess) s->last.ms_align_kernel = t;
 	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[8]) == hipSuccess) s->last.ms_align = t;   // every pass
-	s->last.n_fast = 0; s->last.n_fast_bail = 0; s->last.ms_fast_kernel = 0; s->last.pad_ = 0;
+	s->last.n_fast = 0; s->last.n_fast_bail = 0; s->last.ms_fast_kernel = 0; s->last.pad_ = 0; s->last.n_fast_side = 0; s->last.n_fast_sa_steps = 0;
 	if(s->ran_align && s->ran_fast) {
-		unsigned long long f[2];
+		unsigned long long f[2], fc[4];
 		HIPCHK(hipMemcpy(f, s->cnt_cur + 6, sizeof f, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(fc, s->cnt_cur + 120, sizeof fc, hipMemcpyDeviceToHost));
 		s->last_bails = (uint32_t)f[1];
 		s->last.n_fast = f[0]; s->last.n_fast_bail = f[1];
+		s->last.n_fast_side = fc[1]; s->last.n_fast_sa_steps = fc[2];
+		s->last.n_rank += fc[0]; s->last.n_side += fc[1]; s->last.n_sa_steps += fc[2]; s->last.n_aligned += fc[3];
 		if(hipEventElapsedTime(&t, s->ev[5], s->ev[10]) == hipSuccess) s->last.ms_fast_kernel = t;
 	}
 	(void)hipGetLastError();

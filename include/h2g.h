@@ -359,8 +359,9 @@ typedef struct {
 	float    ms_align_kernel;                                   /* the main go() pass alone (ms_align includes the second pass) */
 	uint64_t n_second_pass;                                     /* reads whose default workspace overflowed and that were re-run with the
 	                                                             * large one; n_overflow = reads still flagged after that */
-	uint64_t n_fast, n_fast_bail;                               /* reads / pairs completed by the on-chip fast pass; handed on to the general machine */
+	uint64_t n_fast, n_fast_bail;                               /* reads / pairs completed by the fast pass; handed on to the general machine */
 	float    ms_fast_kernel, pad_;                              /* the fast pass alone (ms_align covers every pass) */
+	uint64_t n_fast_side, n_fast_sa_steps;                      /* sides / SA-walk steps of the fast pass alone (n_side, n_sa_steps cover every pass) */
 } h2g_counters;
 H2G_EXPORT h2g_status h2g_get_counters(h2g_stream*, h2g_counters*);
 

@@ -1,0 +1,74 @@
+"""The fast path of go() (hisat2_amd/csrc/h2g_fast.h) against the general machine, both instantiated on the host (tests/emul): every read
+/ pair runs through both; whatever the fast path completes must equal the machine's result bit for bit (PairOut / ReadOut incl. the PRNG
+state and the work counters, every record).  The machine itself is pinned to the reference binary by test_go_parity_cpu.py."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from hisat2_amd import synth
+import fast_check as FC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
+pytestmark = pytest.mark.skipif(not os.path.exists(BUILD), reason="needs oracle/_ref/hisat2-build-s")
+
+
+@pytest.fixture(scope="module")
+def genome():
+    tmp = tempfile.mkdtemp(prefix="h2fast")
+    contigs = synth.make_genome([400000, 150000, 60000], 9101, n_gaps=3, gap_len=300, repeats=40, repeat_len=500)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([BUILD, "-q", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return base, contigs
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=6000, rdlen=101, sub=0.005),
+    dict(n=4000, rdlen=101, sub=0.03, least=0.25),      # 3 mismatches per read on average: every other read needs a 4th edit
+    dict(n=3000, rdlen=75, sub=0.01, frag_mean=400, frag_sd=200),
+    dict(n=3000, rdlen=125, sub=0.02),
+    dict(n=2000, rdlen=40, sub=0.01, frag_mean=200, frag_sd=40),
+])
+def test_pairs_equal_the_machine(genome, case):
+    base, contigs = genome
+    m1, m2 = synth.make_pairs(contigs, case["n"], case["rdlen"], 77 + case["n"], frag_mean=case.get("frag_mean", 300), frag_sd=case.get("frag_sd", 30), sub_rate=case["sub"])
+    r = FC.fast_check(base, list(m1), list(m2))
+    assert r["mismatching"] == 0, r
+    assert r["completed"] > case.get("least", 0.5) * r["n"], r            # the fast path is the path: it must take most pairs even on a repeat-rich genome
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=8000, rdlen=101, sub=0.005),
+    dict(n=4000, rdlen=101, sub=0.02, indel=0.002),
+    dict(n=3000, rdlen=60, sub=0.02, nrate=0.01),
+    dict(n=3000, rdlen=128, sub=0.01),
+    dict(n=1000, rdlen=150, sub=0.01),                  # longer than the packed form: everything is handed on
+])
+def test_reads_equal_the_machine(genome, case):
+    base, contigs = genome
+    reads, _ = synth.make_reads(contigs, case["n"], case["rdlen"], 5 + case["n"], sub_rate=case["sub"], indel_rate=case.get("indel", 0.0), n_rate=case.get("nrate", 0.0))
+    r = FC.fast_check(base, list(reads))
+    assert r["mismatching"] == 0, r
+    if case["rdlen"] > 128:
+        assert r["completed"] == 0 and r["bails"].get("input") == case["n"], r
+    else:
+        assert r["completed"] > 0.4 * r["n"], r
+
+
+def test_qualities_and_scoring_options(genome):
+    base, contigs = genome
+    n = 4000
+    m1, m2 = synth.make_pairs(contigs, n, 101, 4242, sub_rate=0.02)
+    rng = np.random.default_rng(7)
+    quals = (33 + rng.integers(2, 41, size=n * 101)).astype(np.uint8)       # FASTQ: quality-aware mismatch penalties and PRNG seeds
+    r = FC.fast_check(base, list(m1), None, quals=quals)
+    assert r["mismatching"] == 0, r
+    for opts in (("--mp", "4,2", "--score-min", "L,0,-0.4"), ("-k", "2"), ("--no-softclip",), ("--sp", "3,1", "--np", "2")):
+        r = FC.fast_check(base, list(m1), list(m2), options=opts)
+        assert r["mismatching"] == 0, (opts, r)
+        assert r["completed"] > 0.4 * n, (opts, r)
