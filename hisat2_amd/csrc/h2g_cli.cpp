@@ -352,7 +352,11 @@ int main(int argc, char** argv) {
 		as_fasta(u); as_fasta(m1); as_fasta(m2);
 		fasta = true;
 	}
-	struct TmpGuard { std::vector<std::string>& v; ~TmpGuard() { for(const std::string& p : v) unlink(p.c_str()); } } tmp_guard{tmp_inputs};
+	// the -c / -r temporary read files go away on every way out, exit() included
+	static std::vector<std::string>* g_tmp_inputs = nullptr;
+	g_tmp_inputs = &tmp_inputs;
+	atexit([] { if(g_tmp_inputs) for(const std::string& p : *g_tmp_inputs) unlink(p.c_str()); });
+	struct TmpGuard { std::vector<std::string>& v; ~TmpGuard() { for(const std::string& p : v) unlink(p.c_str()); v.clear(); } } tmp_guard{tmp_inputs};
 	if(parse_only) {
 		Reader r(u.empty() ? m1 : u, fasta, threads);
 		r.phred64_ = phred64;
@@ -474,6 +478,10 @@ int main(int argc, char** argv) {
 	P.max_frag_len = (uint32_t)max_frag_len;
 	P.min_frag_len = (uint32_t)min_frag_len; P.pe_orientation = (uint32_t)pe_orientation; P.nofw = nofw ? 1 : 0; P.norc = norc ? 1 : 0;
 	h2g_align_params_presets(&P, ix, saw_k ? 1 : 0, k_arg, max_seeds_arg, sensitive ? 1 : 0, very_sensitive ? 1 : 0);
+	if(!P.no_spliced_alignment && P.max_intronlen > 0xfffffu) {
+		fprintf(stderr, "hisat2-align-amd: --max-intronlen %u is beyond the 1048575 bases a splice edit holds here\n", P.max_intronlen);
+		return 1;
+	}
 	if(P.min_intronlen > P.max_intronlen) {   // hisat2.cpp:4278
 		fprintf(stderr, "--min-intronlen(%u) should not be greater than --max-intronlen(%u)\n", P.min_intronlen, P.max_intronlen);
 		return 1;
@@ -666,6 +674,8 @@ int main(int argc, char** argv) {
 		const double tq0 = now();
 		if(h2g_set_reads(sg.st, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, n) != H2G_OK) die("h2g_set_reads");
 		if(h2g_set_read_names(sg.st, a.names.data(), a.noffs.data(), n) != H2G_OK) die("h2g_set_read_names");
+		// read ids are 32 bits in the splice-site window test (DSpliceSite::readid): past that the temporary sites' visibility would wrap silently
+		if(temp_ss && (uint64_t)next_id + n > 0xffffffffull) die("read ids beyond 2^32 with temporary splice sites (use --no-temp-splicesite or split the input)");
 		P.first_read_id = (uint32_t)next_id;
 		sg.first_id = next_id;
 		next_id += n;

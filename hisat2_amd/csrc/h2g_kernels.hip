@@ -223,6 +223,12 @@ extern "C" h2g_status h2g_index_set_splice_sites(h2g_index* ix, const h2g_splice
 	ix->dssdb = DSpliceDB();
 	std::vector<h2g_splice_site> all(ix->alt_sites);      // the index's own sites first: of equal sites the first is kept
 	if(n) all.insert(all.end(), sites, sites + n);
+	// an intron longer than a splice edit holds (20 bits) can never be placed by the aligner (max_intronlen is capped there): such sites
+	// are refused by name instead of being joined with a truncated length
+	for(const h2g_splice_site& x : all) if(x.right > x.left && x.right - x.left - 1 > H2G_SPL_MAXLEN) {
+		snprintf(g_err, sizeof g_err, "splice site %u:%u-%u: an intron of more than %u bases", x.tidx, x.left, x.right, (unsigned)H2G_SPL_MAXLEN);
+		return H2G_ERR_UNSUPPORTED;
+	}
 	if(all.empty()) return H2G_OK;
 	HostSpliceDB h;
 	build_splice_db(all.data(), all.size(), ix->host.g.nPat, h);
@@ -1511,6 +1517,11 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		   p->min_anchor_len < 1 || p->min_anchor_len_noncan < 1) {
 			snprintf(g_err, sizeof g_err, "align: splice scoring outside its range (intron-length function type 1..4, 20 <= min_intronlen <= max_intronlen, penalties >= 0)");
 			return H2G_ERR_ARG;
+		}
+		// a splice edit keeps its intron length in 20 bits (include/h2g.h): longer introns are refused by name, never truncated
+		if(p->max_intronlen > H2G_SPL_MAXLEN) {
+			snprintf(g_err, sizeof g_err, "align: --max-intronlen %u is beyond the %u bases a splice edit holds", p->max_intronlen, (unsigned)H2G_SPL_MAXLEN);
+			return H2G_ERR_UNSUPPORTED;
 		}
 	}
 	const uint32_t maxsz = p->khits > p->kseeds ? p->khits : p->kseeds;

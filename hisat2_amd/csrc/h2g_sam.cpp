@@ -801,7 +801,7 @@ extern "C" size_t h2g_sam_novel_splice_sites_text(const h2g_sam* S, char* out, s
 				}
 			}
 			if(!do_print) { i++; continue; }
-			o += S->refnames[t.ref]; o.push_back('\t');
+			put_ref_name(o, S->refnames[t.ref]); o.push_back('\t');   // first token of the header, as SpliceSiteDB keeps it (splice_site.cpp:135-144)
 			put(o, (int64_t)t.left); o.push_back('\t'); put(o, (int64_t)t.right); o.push_back('\t');
 			o.push_back(t.dir == 2 || t.dir == 4 ? '+' : t.dir == 3 || t.dir == 5 ? '-' : '.');
 			o.push_back('\n');
