@@ -326,7 +326,7 @@ int main(int argc, char** argv) {
 	}
 	// -c / -r: the reads have no names (the reference numbers them, like FASTA records with an empty name) and no qualities ('I'): they are
 	// handed to the FASTA reader as ">\n<sequence>\n" records through a temporary file
-	std::vector<std::string> tmp_inputs;
+	static std::vector<std::string> tmp_inputs;   // (static: the exit handler below outlives main's frame)
 	if(cmdline_input || raw_input) {
 		auto as_fasta = [&](std::vector<std::string>& list) {
 			if(list.empty()) return;
@@ -353,9 +353,7 @@ int main(int argc, char** argv) {
 		fasta = true;
 	}
 	// the -c / -r temporary read files go away on every way out, exit() included
-	static std::vector<std::string>* g_tmp_inputs = nullptr;
-	g_tmp_inputs = &tmp_inputs;
-	atexit([] { if(g_tmp_inputs) for(const std::string& p : *g_tmp_inputs) unlink(p.c_str()); });
+	atexit([] { for(const std::string& p : tmp_inputs) unlink(p.c_str()); tmp_inputs.clear(); });
 	struct TmpGuard { std::vector<std::string>& v; ~TmpGuard() { for(const std::string& p : v) unlink(p.c_str()); v.clear(); } } tmp_guard{tmp_inputs};
 	if(parse_only) {
 		Reader r(u.empty() ? m1 : u, fasta, threads);

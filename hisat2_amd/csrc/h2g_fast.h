@@ -21,7 +21,7 @@ namespace h2g {
 
 #define FG_FE     3                     // edits kept per hit (more: bail)
 #define FG_HW     (6 + FG_FE)           // words of a stored hit
-#define FG_NLONG  4                     // partial hits longer than minK + 2 waiting for getAnchorHits
+#define FG_NLONG  3                     // partial hits longer than minK + 2 waiting for getAnchorHits
 #define FG_NCO    5                     // coordinates per SA resolution (the reference resolves at most 5 outside getAnchorHits)
 #define FG_NRES   2                     // reported alignments per mate
 #define FG_NSRCH  7                     // hybridSearch_recur roots per mate (_hits_searched: hash + hit)
@@ -35,10 +35,10 @@ namespace h2g {
 #define FW_G0     (FW_LONG + 3 * FG_NLONG)
 #define FW_FR0    (FW_G0 + FG_HW)                  // frame 0: scalars + hit
 #define FW_RES    (FW_FR0 + FG_FRS + FG_HW)
-#define FW_HOT    (FW_RES + 2 * FG_NRES * 3)
+#define FW_T1     (FW_RES + 2 * FG_NRES * 3)       // the scratch hit of the extension branches (every read with a mismatch works through it)
+#define FW_HOT    (FW_T1 + FG_HW)
 #define FW_G1     FW_HOT
-#define FW_T1     (FW_G1 + FG_HW)
-#define FW_SRCH   (FW_T1 + FG_HW)
+#define FW_SRCH   (FW_G1 + FG_HW)
 #define FW_CO     (FW_SRCH + 2 * FG_NSRCH * (1 + FG_HW))   // the coordinate list of every frame (frame 0's doubles as getAnchorHits'); before it: (hash, hit) per searched root
 #define FW_FRX    (FW_CO + FG_NFRAME * 3 * FG_NCO)  // frames 1 .. FG_NFRAME - 1: scalars + hit
 #define FW_LH     (FW_FRX + (FG_NFRAME - 1) * (FG_FRS + FG_HW))   // _local_genomeHits of every frame
