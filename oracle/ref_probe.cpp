@@ -307,6 +307,40 @@ int main(int argc, char** argv) {
 		}
 		return 0;
 	}
+	if(cmd == "extsearch") {
+		// extsearch <base> <reads.fa> <queries.txt>: globalGFMSearch (hi_aligner.h:6606) / localGFMSearch (:6751) as hybridSearch_recur calls
+		// them.  Query line: read fw rdoff kind(0 global | 1 local) tidx toff maxHitLen uniqueStop; output line: nelt hitlen top bot uniqueStop
+		vector<Read*> rds;
+		loadReads(argv[3], rds);
+		SimpleFunc scoreMin, nCeil, canIL, noncanIL;
+		Scoring* sc = makeScoring(scoreMin, nCeil, canIL, noncanIL, true);
+		bool linear = gh.linearFM();
+		int khits = linear ? 5 : 10;
+		ReportingParams rp(khits, std::max(5, khits * 2), 0, 0, true, true, true, false, false, 0, false, false);
+		HI_Aligner<index_t, local_index_t> al(gfm, true, 0);
+		RandomSource rnd;
+		rnd.init(0);
+		ifstream qf(argv[4]);
+		unsigned ri, fwv, rdoff, kind, tidx, toff, maxHitLen, us;
+		while(qf >> ri >> fwv >> rdoff >> kind >> tidx >> toff >> maxHitLen >> us) {
+			Read& rd = *rds[ri];
+			bool uniqueStop = us != 0;
+			index_t hitlen = 0;
+			if(kind == 0) {
+				index_t top = (index_t)INDEX_MAX, bot = (index_t)INDEX_MAX, ntop = top, nbot = bot;
+				EList<pair<index_t, index_t> > ie;
+				index_t nelt = al.globalGFMSearch(gfm, rd, *sc, rp, fwv != 0, rdoff, hitlen, top, bot, ntop, nbot, ie, rnd, uniqueStop);
+				printf("%u %u %u %u %d\n", nelt, hitlen, top, bot, (int)uniqueStop);
+			} else {
+				const LocalGFM<local_index_t, index_t>* l = p.gfm->getLocalGFM(tidx, toff);
+				local_index_t top = (local_index_t)INDEX_MAX, bot = (local_index_t)INDEX_MAX, ntop = top, nbot = bot;
+				EList<pair<local_index_t, local_index_t> > lie;
+				index_t nelt = l == NULL ? 0 : al.localGFMSearch(*l, rd, *sc, rp, fwv != 0, rdoff, hitlen, top, bot, ntop, nbot, lie, rnd, uniqueStop, 8, (local_index_t)maxHitLen);
+				printf("%u %u %u %u %d\n", nelt, hitlen, (unsigned)top, (unsigned)bot, (int)uniqueStop);
+			}
+		}
+		return 0;
+	}
 	if(cmd == "psearch" || cmd == "lsearch" || cmd == "coords" || cmd == "extend" || cmd == "sw" || cmd == "adjust") {
 		// <cmd> <base> <reads.fa> <nospliced:0|1>
 		vector<Read*> rds;

@@ -169,6 +169,8 @@ void h2gemu_fm_search(Emu* e, const h2g_fm_query* q, size_t n, uint32_t khits, h
 	}
 }
 
+uint32_t h2gemu_local_index_of(Emu* e, uint32_t tidx, uint32_t toff) { return local_index_of(e->dls, tidx, toff); }
+
 // globalGFMSearch / localGFMSearch as h2g_ext_search runs them (linear index)
 void h2gemu_ext_search(Emu* e, const h2g_ext_search_query* q, size_t n, h2g_ext_search_hit* out) {
 	DReads rd = e->reads();

@@ -143,8 +143,50 @@ def main_sw():
     shutil.rmtree(tmp)
 
 
+def main_extsearch():
+    """probe_extsearch.txt.gz / probe_g1s_extsearch.txt.gz: globalGFMSearch (hi_aligner.h:6606) and localGFMSearch (:6751) of the REAL
+    classes as hybridSearch_recur calls them — on the local index under the read's true origin and its neighbours, from several read
+    offsets, with and without uniqueStop / a hit-length limit.  Line: read fw rdoff kind tidx toff maxHitLen uniqueStop nelt hitlen top bot uniqueStopOut"""
+    import numpy as np
+    tmp = tempfile.mkdtemp(prefix="h2goldx")
+    probe = os.path.join(REF, "ref_probe")
+    contigs = synth.make_genome([60000, 45000, 30000], SEED, n_gaps=1, gap_len=500, repeats=2, repeat_len=400)
+    snps = synth.make_snps(contigs, SEED + 11)
+    alt = synth.apply_snps(contigs, snps)
+    for tag, idx, src, rseed, nreads, rate, rname in (("", "g1", contigs, SEED + 1, 400, dict(sub_rate=0.01, indel_rate=0.0005, n_rate=0.0005), "reads_se.fa.gz"),
+                                                      ("g1s_", "g1s", alt, SEED + 12, 300, dict(sub_rate=0.004), "reads_snp.fa.gz")):
+        base = os.path.join(tmp, idx)
+        for k in range(1, 9):
+            open(f"{base}.{k}.ht2", "wb").write(gzip.open(os.path.join(GOLD, f"{idx}.{k}.ht2.gz")).read())
+        reads, truth = synth.make_reads(src, nreads, 101, rseed, **rate)          # the committed reads, with their origins
+        rfa = os.path.join(tmp, idx + "_reads.fa")
+        open(rfa, "wb").write(gzip.open(os.path.join(GOLD, rname)).read())
+        rng = np.random.default_rng(SEED + 77)
+        q = []
+        for i, (ci, pos, fw) in enumerate(truth):
+            ci, pos, fw = int(ci), int(pos), int(fw)
+            n = len(reads[i])
+            for rdoff in (n - 1, int(rng.integers(30, n - 1))):
+                q.append((i, fw, rdoff, 0, 0, 0, 0xffffffff, 1))
+            for _ in range(4):
+                rdoff = int(rng.integers(8, n))
+                shift = int(rng.choice([0, 0, -56320, 56320]))
+                toff = min(max(0, pos + shift), len(src[ci]) - 1)
+                q.append((i, fw if rng.integers(0, 8) else 1 - fw, rdoff, 1, ci, toff, 0xffff if rng.integers(0, 2) else int(rng.integers(8, 40)), int(rng.integers(0, 2))))
+        qf = os.path.join(tmp, "q.txt")
+        open(qf, "w").write("".join(" ".join(map(str, x)) + "\n" for x in q))
+        out = run([probe, "extsearch", base, rfa, qf]).stdout.decode().splitlines()
+        assert len(out) == len(q), (len(out), len(q))
+        body = "".join(" ".join(map(str, x)) + " " + o + "\n" for x, o in zip(q, out))
+        gz_write(os.path.join(GOLD, f"probe_{tag}extsearch.txt.gz"), body.encode())
+        print(tag + "extsearch", len(out), "lines,", sum(1 for o in out if not o.startswith("0 ")), "with elements")
+    shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "graph":
+    if len(sys.argv) > 1 and sys.argv[1] == "extsearch":
+        main_extsearch()
+    elif len(sys.argv) > 1 and sys.argv[1] == "graph":
         main_graph()
     elif len(sys.argv) > 1 and sys.argv[1] == "sw":
         main_sw()

@@ -351,3 +351,27 @@ def check_graph_adjust(be, golden_dir, fn):
                 edit_strings_snp(hits[i * cap + k].edits, hits[i * cap + k].nedits)) for k in range(nh[i])]
         assert got == want, (c[:7], got, want)
     return len(cases)
+
+
+def check_ext_search(search, local_index_of, golden_dir, fn):
+    """globalGFMSearch / localGFMSearch against the vectors of the real classes (tests/gen_golden.py extsearch).
+    search(queries) -> hits; local_index_of(tidx, toff) -> lidx"""
+    qs, want = [], []
+    for l in H.glines(golden_dir, fn):
+        v = list(map(int, l.split()))
+        q = api.ExtSearchQuery()
+        q.read, q.fw, q.rdoff = v[0], v[1], v[2]
+        q.lidx = 0xffffffff if v[3] == 0 else local_index_of(v[4], v[5])
+        q.maxHitLen, q.uniqueStop = (0xffffffff if v[3] == 0 else v[6]), v[7]
+        if v[3] == 1 and q.lidx == 0xffffffff:
+            assert v[8] == 0            # no local index there: the reference probe reports nothing
+            continue
+        qs.append(q); want.append(v[8:])
+    got = search(qs)
+    nel = 0
+    for q, g, w in zip(qs, got, want):
+        assert g.nelt == w[0] and bool(g.uniqueStop) == bool(w[4]), (q.read, q.fw, q.rdoff, q.lidx, g.nelt, g.uniqueStop, w)
+        if w[0] > 0:
+            nel += 1
+            assert (g.hitlen, g.top, g.bot) == (w[1], w[2], w[3]), (q.read, q.fw, q.rdoff, q.lidx, g.hitlen, g.top, g.bot, w)
+    return len(qs), nel

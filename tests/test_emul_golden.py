@@ -141,3 +141,21 @@ def test_sw_align(g1_index, golden_dir):
     reads, offs = PC.load_sw_reads(golden_dir)
     e.set_reads(reads.reshape(-1), offs)
     assert PC.check_sw(e, golden_dir) > 250
+
+
+def test_ext_search_golden(emu, golden_dir):
+    """globalGFMSearch / localGFMSearch (hi_aligner.h:6606 / :6751): the host instantiation against the real classes' vectors"""
+    import ctypes as C
+    from hisat2_amd import api
+    emu.L.h2gemu_local_index_of.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    emu.L.h2gemu_local_index_of.restype = C.c_uint32
+    emu.L.h2gemu_ext_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+
+    def search(qs):
+        n = len(qs)
+        arr = (api.ExtSearchQuery * n)(*qs)
+        out = (api.ExtSearchHit * n)()
+        emu.L.h2gemu_ext_search(emu.h, arr, n, out)
+        return out
+    n, nel = PC.check_ext_search(search, lambda t, o: emu.L.h2gemu_local_index_of(emu.h, t, o), golden_dir, "probe_extsearch.txt.gz")
+    assert n > 2000 and nel > 1500

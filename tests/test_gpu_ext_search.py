@@ -2,6 +2,7 @@
 local queries bucketed by local index and the fat buckets served from LDS (the index's sides + ftab staged once per workgroup).
 Staged, unstaged and the host instantiation of the same item function must agree on every field; the LDS hit-rate is reported."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -75,3 +76,21 @@ def test_ext_search_staged_equals_unstaged_equals_host(which, g1_index, g1s_inde
           f"unstaged all-HBM {s0.ms_hbm:.3f} ms")
     st.close()
     ix.close()
+
+
+@pytest.mark.parametrize("which", ["g1", "g1s"])
+def test_ext_search_equals_the_reference_classes(which, g1_index, g1s_index, golden_dir):
+    """staged and unstaged h2g_ext_search against vectors of the REAL HI_Aligner::globalGFMSearch / localGFMSearch (oracle/ref_probe.cpp
+    extsearch, tests/gen_golden.py extsearch): linear index and SNP-graph index (graph local indexes incl. the linear ones inside it)"""
+    import h2o_py as H
+    base, reads_fn, vec = (g1_index, "reads_se.fa.gz", "probe_extsearch.txt.gz") if which == "g1" else (g1s_index, "reads_snp.fa.gz", "probe_g1s_extsearch.txt.gz")
+    _, seqs = H.read_fasta_reads(os.path.join(golden_dir, reads_fn))
+    codes, offs = synth.flatten_reads(seqs)
+    ix = api.Index(base, device=0)
+    st = api.Stream(ix, max_reads=len(seqs), max_bases=codes.size)
+    st.set_reads(codes, offs)
+    L = api.lib()
+    for stage_min in (2, 0):
+        n, nel = PC.check_ext_search(lambda qs: st.ext_search((api.ExtSearchQuery * len(qs))(*qs), stage_min=stage_min)[0],
+                                     lambda t, o: L.h2g_local_index_of(ix.h, t, o), golden_dir, vec)
+        assert n > 1500 and nel > 1200
