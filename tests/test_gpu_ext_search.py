@@ -85,7 +85,8 @@ def test_ext_search_equals_the_reference_classes(which, g1_index, g1s_index, gol
     import h2o_py as H
     base, reads_fn, vec = (g1_index, "reads_se.fa.gz", "probe_extsearch.txt.gz") if which == "g1" else (g1s_index, "reads_snp.fa.gz", "probe_g1s_extsearch.txt.gz")
     _, seqs = H.read_fasta_reads(os.path.join(golden_dir, reads_fn))
-    codes, offs = synth.flatten_reads(seqs)
+    codes = np.concatenate(seqs).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.uint32)
     ix = api.Index(base, device=0)
     st = api.Stream(ix, max_reads=len(seqs), max_bases=codes.size)
     st.set_reads(codes, offs)
