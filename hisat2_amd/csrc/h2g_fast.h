@@ -19,8 +19,8 @@
 
 namespace h2g {
 
-#define FG_FE     3                     // edits kept per hit (more: bail)
-#define FG_HW     (6 + FG_FE)           // words of a stored hit
+#define FG_FE     4                     // edits kept per hit (more: bail), 16 bits each
+#define FG_HW     (6 + FG_FE / 2)       // words of a stored hit
 #define FG_NLONG  3                     // partial hits longer than minK + 2 waiting for getAnchorHits
 #define FG_NCO    5                     // coordinates per SA resolution (the reference resolves at most 5 outside getAnchorHits)
 #define FG_NRES   2                     // reported alignments per mate
@@ -181,17 +181,21 @@ H2G_HD void fg_hit_copy(const FWords& W, uint32_t dst, uint32_t src) {
 struct FHit {
 	uint32_t tidx, toff, joff; int32_t score;
 	uint32_t rdoff, len, trim5, trim3, fw, nedits, hitcount;
-	uint32_t e0, e1, e2;                  // pos | chr << 8 | qchr << 16 | type << 24
+	uint64_t e;                           // the edits, 16 bits each, in read order: pos | ref base << 8 | read base << 11 | type << 14 (bases 0..4 = ACGTN, 5 = '-')
 	uint32_t bad;                         // it stopped fitting (more than FG_FE edits): the read leaves the fast path
 };
-static_assert(FG_FE == 3, "FHit holds three edits");
-#define FE_GET(H, K) ((K) == 0 ? (H).e0 : (K) == 1 ? (H).e1 : (H).e2)
-#define FE_SET(H, K, V) do { const uint32_t v_ = (V); if((K) == 0) (H).e0 = v_; else if((K) == 1) (H).e1 = v_; else (H).e2 = v_; } while(0)
+static_assert(FG_FE == 4, "FHit holds four 16-bit edits in one 64-bit word");
+#define FE_GET(H, K) ((uint32_t)((H).e >> (16u * (uint32_t)(K))) & 0xffffu)
+#define FE_SET(H, K, V) do { const uint32_t sh_ = 16u * (uint32_t)(K); (H).e = ((H).e & ~(0xffffull << sh_)) | ((uint64_t)((V) & 0xffffu) << sh_); } while(0)
 #define FE_POS(E)  ((E) & 0xffu)
-#define FE_CHR(E)  (((E) >> 8) & 0xffu)
-#define FE_QCHR(E) (((E) >> 16) & 0xffu)
-#define FE_TYPE(E) ((E) >> 24)
-#define FE_MAKE(POS, CHR, QCHR, TYPE) ((uint32_t)(POS) | ((uint32_t)(CHR) << 8) | ((uint32_t)(QCHR) << 16) | ((uint32_t)(TYPE) << 24))
+#define FE_CCODE(E) (((E) >> 8) & 7u)
+#define FE_QCODE(E) (((E) >> 11) & 7u)
+#define FE_DEC(K)  ((uint32_t)(0x2d4e54474341ull >> (8u * (K))) & 0xffu)      // "ACGTN-"
+#define FE_CHR(E)  FE_DEC(FE_CCODE(E))
+#define FE_QCHR(E) FE_DEC(FE_QCODE(E))
+#define FE_TYPE(E) (((E) >> 14) & 3u)
+#define FE_MAKE_BP(POS, RFBP, RDBP, TYPE) ((uint32_t)(POS) | ((uint32_t)(RFBP) << 8) | ((uint32_t)(RDBP) << 11) | ((uint32_t)(TYPE) << 14))
+static_assert(H2G_EDIT_MM < 4 && H2G_EDIT_READ_GAP < 4 && H2G_EDIT_REF_GAP < 4, "edit types in two bits");
 H2G_HD bool fe_is_gap(uint32_t e) { const uint32_t t = FE_TYPE(e); return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
 
 H2G_HD FHit fh_load(const FWords& W, uint32_t hb) {
@@ -201,7 +205,8 @@ H2G_HD FHit fh_load(const FWords& W, uint32_t hb) {
 	h.tidx = v[0]; h.toff = v[1]; h.joff = v[2]; h.score = (int32_t)v[3];
 	h.rdoff = v[4] & 0xffu; h.len = (v[4] >> 8) & 0xffu; h.trim5 = (v[4] >> 16) & 0xffu; h.trim3 = v[4] >> 24;
 	h.fw = v[5] & 1u; h.nedits = (v[5] >> 1) & 7u; h.hitcount = v[5] >> 8;
-	h.e0 = h.nedits > 0 ? v[6] : 0; h.e1 = h.nedits > 1 ? v[7] : 0; h.e2 = h.nedits > 2 ? v[8] : 0;
+	h.e = (uint64_t)v[6] | (uint64_t)v[7] << 32;
+	h.e &= h.nedits >= 4 ? ~0ull : (1ull << (16u * h.nedits)) - 1ull;
 	h.bad = 0;
 	return h;
 }
@@ -210,7 +215,7 @@ H2G_HD bool fh_store(const FWords& W, uint32_t hb, const FHit& h) {
 	if(h.bad || h.nedits > FG_FE || h.score < -(1 << 30) || h.score > (1 << 30) || h.hitcount > 0xffffu) return false;
 	if(h.rdoff > 255 || h.len > 255 || h.trim5 > 255 || h.trim3 > 255) return false;
 	const uint32_t v[FG_HW] = {h.tidx, h.toff, h.joff, (uint32_t)h.score, h.rdoff | (h.len << 8) | (h.trim5 << 16) | (h.trim3 << 24),
-	                           (h.fw ? 1u : 0u) | (h.nedits << 1) | (h.hitcount << 8), h.e0, h.e1, h.e2};
+	                           (h.fw ? 1u : 0u) | (h.nedits << 1) | (h.hitcount << 8), (uint32_t)h.e, (uint32_t)(h.e >> 32)};
 	W.stv<FG_HW>(hb, v);
 	return true;
 }
@@ -288,8 +293,8 @@ H2G_HD void fh_calc_score(const DScoring& sc, const SeqView& seq, FHit& h) {
 		const uint32_t e = FE_GET(h, i), t = FE_TYPE(e);
 		if(t == H2G_EDIT_MM) {
 			const int q = seq.qual(h.rdoff + FE_POS(e)) - 33;
-			if(FE_QCHR(e) == 'N') score -= sc.nPen;
-			else if(FE_CHR(e) == 'N') score += sc.matchBonus;
+			if(FE_QCODE(e) == 4) score -= sc.nPen;
+			else if(FE_CCODE(e) == 4) score += sc.matchBonus;
 			else score -= mm_penalty(sc, q);
 			mm++;
 		} else if(t == H2G_EDIT_READ_GAP) {
@@ -314,7 +319,7 @@ H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdof
 {
 	if(numNs) *numNs = 0;
 	const uint32_t n_old = h.nedits;
-	uint32_t n0 = 0, n1 = 0, n2 = 0;                       // the first three new edits
+	uint64_t nw = 0;                                       // the first four new edits, in the order met
 	uint32_t tmp_mm = 0, nNs = 0, extlen = 0;
 	bool updated = false;
 	const uint32_t contig_len = ref.refLens[h.tidx];
@@ -335,8 +340,7 @@ H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdof
 				const int rf_bp = p < 0 ? 4 : rc.get(p), rd_bp = seq.at((uint32_t)i);
 				if(rf_bp != rd_bp || rd_bp == 4) {
 					if(tmp_mm >= mm) break;
-					const uint32_t e = FE_MAKE(i, base_char(rf_bp), base_char(rd_bp), H2G_EDIT_MM);
-					if(tmp_mm == 0) n0 = e; else if(tmp_mm == 1) n1 = e; else if(tmp_mm == 2) n2 = e;
+					if(tmp_mm < FG_FE) nw |= (uint64_t)FE_MAKE_BP(i, rf_bp, rd_bp, H2G_EDIT_MM) << (16u * tmp_mm);
 					tmp_mm++;
 				}
 				if(rf_bp == 4) nNs++;
@@ -349,8 +353,7 @@ H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdof
 				const int rf_bp = p < 0 ? 4 : rc.get(p), rd_bp = seq.at(rdoff + i);
 				if(rf_bp != rd_bp || rd_bp == 4) {
 					if(tmp_mm >= mm) break;
-					const uint32_t e = FE_MAKE(i + rdoff_add, base_char(rf_bp), base_char(rd_bp), H2G_EDIT_MM);
-					if(tmp_mm == 0) n0 = e; else if(tmp_mm == 1) n1 = e; else if(tmp_mm == 2) n2 = e;
+					if(tmp_mm < FG_FE) nw |= (uint64_t)FE_MAKE_BP(i + rdoff_add, rf_bp, rd_bp, H2G_EDIT_MM) << (16u * tmp_mm);
 					tmp_mm++;
 				}
 			}
@@ -359,30 +362,27 @@ H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdof
 	}
 	if(!updated) tmp_mm = 0;
 	const uint32_t total = n_old + tmp_mm;
-	if(tmp_mm > FG_FE) { h.bad = 1; return extlen; }       // (the new edits beyond the third were not kept)
-	const uint32_t nlast = tmp_mm == 0 ? 0u : (tmp_mm == 1 ? n0 : (tmp_mm == 2 ? n1 : n2));
+	if(tmp_mm > FG_FE) { h.bad = 1; return extlen; }       // (the new edits beyond the fourth were not kept)
+	const uint32_t n0 = (uint32_t)nw & 0xffffu;
+	const uint32_t nlast = tmp_mm == 0 ? 0u : (uint32_t)(nw >> (16u * (tmp_mm - 1))) & 0xffffu;
 	if(extlen > 0 && total > 0) {   // :751-779: front() / back() of the list the reference would hold
-		const uint32_t old_first = h.e0, old_last = n_old == 0 ? 0u : FE_GET(h, n_old - 1);
+		const uint32_t old_first = FE_GET(h, 0), old_last = n_old == 0 ? 0u : FE_GET(h, n_old - 1);
 		uint32_t f, b;
 		if(left) { f = tmp_mm ? nlast : old_first; b = n_old ? old_last : n0; }
 		else     { f = n_old ? old_first : n0;     b = tmp_mm ? nlast : old_last; }
 		if(FE_POS(f) + extlen == base_rdoff + 1) {
 			if(fe_is_gap(f)) extlen = 0;
-			if(FE_TYPE(f) == H2G_EDIT_MM && FE_CHR(f) == 'N') extlen = 0;
+			if(FE_TYPE(f) == H2G_EDIT_MM && FE_CCODE(f) == 4) extlen = 0;
 		}
 		if(extlen > 0 && FE_POS(b) == rdoff - base_rdoff + extlen - 1) { if(fe_is_gap(b)) extlen = 0; }
 	}
 	if(extlen > 0 && tmp_mm > 0) {   // commit the new edits
 		if(total > FG_FE) { h.bad = 1; return extlen; }
-		if(left) {                   // new edits go to the front, in increasing read position
-			// old edits move up by tmp_mm (total <= 3)
-			if(tmp_mm == 1) { h.e2 = h.e1; h.e1 = h.e0; h.e0 = n0; }
-			else if(tmp_mm == 2) { h.e2 = h.e0; h.e0 = n1; h.e1 = n0; }
-			else { h.e0 = n2; h.e1 = n1; h.e2 = n0; }
+		if(left) {                   // new edits go to the front, in increasing read position (they were met right to left); the old ones move up
+			const uint64_t rev = (nw << 48) | ((nw & 0xffff0000ull) << 16) | ((nw >> 16) & 0xffff0000ull) | (nw >> 48);
+			h.e = (tmp_mm >= FG_FE ? 0ull : h.e << (16u * tmp_mm)) | (rev >> (16u * (FG_FE - tmp_mm)));
 		} else {
-			if(tmp_mm >= 1) FE_SET(h, n_old, n0);
-			if(tmp_mm >= 2) FE_SET(h, n_old + 1, n1);
-			if(tmp_mm >= 3) FE_SET(h, n_old + 2, n2);
+			h.e |= nw << (16u * n_old);       // (n_old + tmp_mm <= FG_FE)
 		}
 		h.nedits = total;
 	}
@@ -502,7 +502,7 @@ H2G_HD bool fh_combine(const DRef& ref, const DScoring& sc, const SeqView& seq, 
 			const int rdc = seq.at(this_rdoff + i), rfc = rc1.get((int64_t)this_toff + i);
 			if(rdc != rfc) {
 				if(a.nedits >= FG_FE || i + addoff > 255) { a.bad = 1; break; }
-				FE_SET(a, a.nedits, FE_MAKE(i + addoff, base_char(rfc), base_char(rdc), H2G_EDIT_MM)); a.nedits++;
+				FE_SET(a, a.nedits, FE_MAKE_BP(i + addoff, rfc, rdc, H2G_EDIT_MM)); a.nedits++;
 			}
 		}
 	}

@@ -139,6 +139,43 @@ FK_PHASE uint32_t fk_step(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint
 	return w[0];
 }
 
+#ifndef H2G_FAST_ONESTATE
+#define H2G_FAST_ONESTATE 1
+#endif
+// One trip of this lane's slot with the state in registers from its load to its store: the primitive `op` (FOP_NONE: a slot taking up
+// read `begin`), then the control flow up to the next request.  Returns the state's word 0 (pc, op, bail); the whole state is in the slot.
+__device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t op, uint32_t begin, uint32_t packed_ok) {
+	FCtx C; FWords W;
+	fk_ctx(A, stage, sm, C, W);
+	FState S;
+	if(begin != H2G_MAX) {
+		const bool paired = A->paired != 0;
+		C.name[0] = A->names1 + A->noffs1[begin]; C.namelen[0] = A->noffs1[begin + 1] - A->noffs1[begin];
+		if(paired) { C.name[1] = A->names2 + A->noffs2[begin]; C.namelen[1] = A->noffs2[begin + 1] - A->noffs2[begin]; }
+		fast_begin(C, S, begin, paired, packed_ok != 0);
+	} else {
+		uint32_t w[FS_WORDS];
+		const uint4* src = reinterpret_cast<const uint4*>(sm);
+#pragma unroll
+		for(uint32_t k = 0; k < FS_WORDS / 4; k++) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+		__builtin_memcpy(&S, w, sizeof S);
+		// the work counters are 16-bit fields: the primitive counts from zero, a read that would wrap them leaves the fast path
+		const uint32_t nr0 = S.nrank, ns0 = S.nside, nt0 = S.nsteps;
+		S.nrank = 0; S.nside = 0; S.nsteps = 0;
+		fast_exec(C, S, W, op);
+		const uint32_t nr_ = nr0 + S.nrank, ns_ = ns0 + S.nside, nt_ = nt0 + S.nsteps;
+		if(S.pc != FPC_BAIL && (nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu)) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
+		S.nrank = nr_ & 0xffffu; S.nside = ns_ & 0xffffu; S.nsteps = nt_ & 0xffffu;
+	}
+	if(S.pc != FPC_DONE && S.pc != FPC_BAIL && S.op == FOP_NONE) fast_step(C, S, W);
+	uint32_t w[FS_WORDS];
+	__builtin_memcpy(w, &S, sizeof S);
+	uint4* dst = reinterpret_cast<uint4*>(sm);
+#pragma unroll
+	for(uint32_t k = 0; k < FS_WORDS / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+	return w[0];
+}
+
 __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __restrict__ A)
 {
 	extern __shared__ uint32_t s_mem[];
@@ -183,7 +220,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 		bestc = (uint32_t)__shfl((int)bestc, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
 		const bool fetch = more && nfree > 0 && (bestc < 64 || nfree >= H2G_FAST_SLOTS / 4);
 		bool have = false;
-		uint32_t slot = 0, begin = H2G_MAX, packed_ok = 0;
+		uint32_t slot = 0, begin = H2G_MAX, packed_ok = 0, trip_op = FOP_NONE;
 		uint32_t* sm = nullptr;                                   // this lane's slot in HBM
 		if(fetch) {
 			const uint32_t n = fq_pop(Q, 0, lane, &slot);
@@ -237,8 +274,12 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 			prof[20 + op] += n; prof[32 + op]++; trip_site = bestq;
 #endif
 			PROF(0);
+#if H2G_FAST_ONESTATE
+			trip_op = op;
+#else
 			if(have) fk_exec(A, stage, sm, op);
 			PROF(3 + op);
+#endif
 		}
 		// ---- control flow of each read up to its next primitive request; then hand the slots on
 		uint32_t nextq = 0;
@@ -246,7 +287,11 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 		prof[46] += __popcll(__ballot(have)); prof[47]++;
 #endif
 		uint32_t w0 = 0;
+#if H2G_FAST_ONESTATE
+		if(have) w0 = fk_trip(A, stage, sm, trip_op, begin, packed_ok);
+#else
 		if(have) w0 = fk_step(A, stage, sm, begin, packed_ok);
+#endif
 #ifdef H2G_GO_PROF
 		{ const unsigned long long t_ = __builtin_readcyclecounter(); prof_ctl[trip_site & 31] += t_ - tp0; prof_n[trip_site & 31]++; }
 #endif

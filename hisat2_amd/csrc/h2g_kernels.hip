@@ -53,13 +53,17 @@ struct h2g_index {
 	uint64_t device_bytes = 0;
 };
 
+#define H2G_NBUF 3
+#define H2G_MACH_MAXGRID 48u       // workgroups of a machine pass behind a fast pass (two such passes may be in flight)
 struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
-	hipStream_t st2 = nullptr;        // the general machine's pass over the fast pass's hand-ons runs here, next to the following batch's fast pass
-	bool st2_busy = false;
-	hipEvent_t ev_fast[2], ev_mach[2];
-	unsigned gen = 0;                 // go_run generation: bail list, counters and argument block are double-buffered by its parity
+	// the general machine's pass over a fast pass's hand-ons runs on one of these, next to the fast passes of the FOLLOWING two batches:
+	// its few reads are long latency chains (about a fast pass's duration whatever their number), so two such passes are kept in flight
+	hipStream_t mst[2] = {nullptr, nullptr};
+	bool st2_busy = false;            // a machine stream may hold work
+	hipEvent_t ev_fast[H2G_NBUF], ev_mach[H2G_NBUF];
+	unsigned gen = 0;                 // go_run generation: bail list, counters and argument block are buffered H2G_NBUF deep by gen % H2G_NBUF
 	unsigned long long* cnt_cur = nullptr;   // the counter block of the last go_run
 	uint32_t last_bails = 0;
 	uint32_t* h_bails = nullptr;      // pinned: the hand-on count of the last two fast passes (sizes the machine's share of the CUs)
@@ -80,11 +84,12 @@ struct h2g_stream {
 		uint8_t* gws = nullptr; size_t gws_bytes = 0;     // GraphWS x lanes (graph indexes only)
 		uint8_t* sw = nullptr;  size_t sw_stride = 0, sw_lanes = 0;   // Smith-Waterman scratch (only with bowtie2_dp != 0)
 		uint8_t* sc = nullptr;  size_t sc_lanes = 0;                  // combineWith temp_scores per lane
-	} pool[2];
+	} pool[4];                        // [2 * m + 0] main pass, [2 * m + 1] second pass of machine stream m (m = 0 also: passes on the first stream)
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
-	uint32_t* d_ovf_list = nullptr;   // read ids whose workspace overflowed in the main pass (+ their count behind the list)
-	uint32_t* d_bail_list[2] = {nullptr, nullptr};  // read ids the fast pass handed on to the general machine (+ their count behind the list)
-	void* d_fast_args[2] = {nullptr, nullptr};      // the fast pass's argument block (device copy)
+	uint32_t* d_ovf_list[2] = {nullptr, nullptr};   // per machine stream: read ids whose workspace overflowed in the main pass (+ their count behind the list)
+	unsigned ovf_cur = 0;             // the one the last run used
+	uint32_t* d_bail_list[H2G_NBUF] = {};  // read ids the fast pass handed on to the general machine (+ their count behind the list)
+	void* d_fast_args[H2G_NBUF] = {};      // the fast pass's argument block (device copy)
 	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
 	bool ran_fast = false;
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -105,6 +110,7 @@ struct h2g_stream {
 	bool has_mates = false, has_quals2 = false;
 	PairOut* d_pout = nullptr;
 	h2g_alnres* d_paln[2] = {nullptr, nullptr};
+	h2g_alnres* d_paln_ovf = nullptr; size_t paln_ovf_cap = 0;   // pairs with more records than pair_slots per mate (MachOut::ovf)
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t tmp_sz[4] = {0, 0, 0, 0};
@@ -365,12 +371,12 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	h2g_stream* s = new h2g_stream();
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
-	HIPCHK(hipHostMalloc((void**)&s->h_bails, 16)); s->h_bails[0] = s->h_bails[1] = 0;
-	for(int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
+	for(int k = 0; k < 2; k++) HIPCHK(hipStreamCreateWithFlags(&s->mst[k], hipStreamNonBlocking));
+	HIPCHK(hipHostMalloc((void**)&s->h_bails, 4 * H2G_NBUF)); for(int k = 0; k < H2G_NBUF; k++) s->h_bails[k] = 0;
+	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
 	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
-	HIPCHK(hipMalloc((void**)&s->d_counters, 512 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(s->d_counters, 0, 512 * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&s->d_counters, H2G_NBUF * 256 * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->d_counters, 0, H2G_NBUF * 256 * sizeof(unsigned long long)));
 	s->cnt_cur = s->d_counters;
 	if(max_reads) {
 		HIPCHK(hipMalloc((void**)&s->d_codes, max_bases + 64));
@@ -385,22 +391,25 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 
 extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
-	(void)hipStreamSynchronize(s->st); (void)hipStreamSynchronize(s->st2);
+	(void)hipStreamSynchronize(s->st); for(int k = 0; k < 2; k++) (void)hipStreamSynchronize(s->mst[k]);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list); for(int k = 0; k < 2; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 4; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
+	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
-	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]);
+	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
-	(void)hipStreamDestroy(s->st); (void)hipStreamDestroy(s->st2); (void)hipHostFree(s->h_bails);
+	(void)hipStreamDestroy(s->st); for(int k = 0; k < 2; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails);
 	delete s;
 }
 
 // both streams of a batch context (the second one only ever holds the machine pass behind a fast pass)
 static hipError_t sync_all(h2g_stream* s) {
 	hipError_t e = hipStreamSynchronize(s->st);
-	if(e == hipSuccess && s->st2_busy) { e = hipStreamSynchronize(s->st2); s->st2_busy = false; }
+	if(e == hipSuccess && s->st2_busy) {
+		for(int k = 0; k < 2 && e == hipSuccess; k++) e = hipStreamSynchronize(s->mst[k]);
+		s->st2_busy = false;
+	}
 	return e;
 }
 extern "C" void* h2g_stream_hip(h2g_stream* s) { return s ? (void*)s->st : nullptr; }
@@ -1544,6 +1553,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	HIPCHK(hipSetDevice(s->ix->device));
 	const bool big_main = maxsz > caps[0];
 	const GoUnit& U = go_unit(linear, big_main, spl);
+	static const int fast_env = getenv("H2G_GO_FAST") ? atoi(getenv("H2G_GO_FAST")) : 1;
+	const bool fast = fast_env && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp;
 	// geometry of the unit: workgroups of geo[0] threads own geo[1] reads in flight; resident workgroups per CU = what the
 	// unit's waves per SIMD and the LDS (rings + one packed-read region per mate) allow
 	uint32_t geo[4];
@@ -1571,7 +1582,11 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(!p->no_spliced_alignment) { A.P.sc.donor_sum = s->ix->d_spl[0]; A.P.sc.acc_sum1 = s->ix->d_spl[1]; A.P.sc.acc_sum2 = s->ix->d_spl[2]; }
 	A.names1 = s->d_names; A.noffs1 = s->d_name_offs; A.names2 = s->d_names2; A.noffs2 = s->d_name_offs2;
 	A.paired = paired ? 1u : 0u;
-	if((rc = go_pool_for(s, 0, U, (size_t)grid * geo[1], (size_t)grid * block, p->bowtie2_dp, &A))) return rc;
+	if(!fast && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (the machine streams' pools are about to be used on the first stream)
+	{	// behind a fast pass the machine works on stream gen & 1 with that stream's pools, on at most H2G_MACH_MAXGRID workgroups
+		const size_t pgrid = fast && grid > H2G_MACH_MAXGRID ? (size_t)H2G_MACH_MAXGRID : (size_t)grid;
+		if((rc = go_pool_for(s, fast ? 2 * (int)(s->gen & 1u) : 0, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &A))) return rc;
+	}
 	memset(&A.O, 0, sizeof A.O);
 	if(!paired) {
 		if(!s->d_rout) HIPCHK(hipMalloc((void**)&s->d_rout, s->max_reads * sizeof(ReadOut)));
@@ -1588,6 +1603,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		// a mate can report more alignments than -k before the pair is settled: 2 k + 4 slots, at least H2G_PAIR_RES_CAP
 		uint32_t pslots = p->khits * 2 + 4;
 		if(pslots < H2G_PAIR_RES_CAP) pslots = H2G_PAIR_RES_CAP;
+		if(const char* e = getenv("H2G_PAIR_SLOTS")) { const int v = atoi(e); if(v > 0) pslots = (uint32_t)v; }   // test knob: tiny rows push pairs through the overflow area (dense fetch only)
 		if(s->paln_alloc < s->max_reads * (size_t)pslots) {
 			for(int m = 0; m < 2; m++) { (void)hipFree(s->d_paln[m]); s->d_paln[m] = nullptr; }
 			s->paln_alloc = 0;
@@ -1596,17 +1612,24 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		}
 		s->pair_slots = pslots;
 		A.O.pout = s->d_pout; A.O.paln[0] = s->d_paln[0]; A.O.paln[1] = s->d_paln[1]; A.O.pair_slots = pslots;
+		const size_t ovf_cap = s->max_reads / 4 > 65536 ? s->max_reads / 4 : 65536;   // records
+		if(s->paln_ovf_cap < ovf_cap) {
+			(void)hipFree(s->d_paln_ovf); s->d_paln_ovf = nullptr; s->paln_ovf_cap = 0;
+			HIPCHK(hipMalloc((void**)&s->d_paln_ovf, ovf_cap * sizeof(h2g_alnres)));
+			s->paln_ovf_cap = ovf_cap;
+		}
+		A.O.ovf = s->d_paln_ovf; A.O.ovf_cap = (uint32_t)s->paln_ovf_cap;
 	}
-	if(!s->d_ovf_list) HIPCHK(hipMalloc((void**)&s->d_ovf_list, (s->max_reads + 4) * 4));
 	(void)hipGetLastError();
-	// the fast pass's hand-on list, the counters and its argument block are double-buffered by the parity of the run: the general
-	// machine's pass over run k's hand-ons goes to the second stream and may still be under way while run k + 1's fast pass runs
-	const unsigned gsel = s->gen & 1u;
+	// the fast pass's hand-on list, the counters and its argument block are buffered H2G_NBUF deep: the general machine's pass over
+	// run k's hand-ons goes to machine stream k & 1 and may still be under way while the fast passes of runs k + 1 and k + 2 run
+	const unsigned gsel = s->gen % H2G_NBUF, msel = s->gen & 1u;
 	unsigned long long* const cblk = s->d_counters + 256 * gsel;
-	HIPCHK(hipStreamWaitEvent(s->st, s->ev_mach[gsel], 0));          // run k - 2's machine pass: done with this parity's buffers
+	HIPCHK(hipStreamWaitEvent(s->st, s->ev_mach[gsel], 0));          // run k - H2G_NBUF's machine pass: done with this set of buffers
 	HIPCHK(hipMemsetAsync(cblk, 0, 256 * sizeof(unsigned long long), s->st));
 	A.counters = cblk;
 	A.work = reinterpret_cast<uint32_t*>(cblk + 14);
+	if(paired) A.O.ovf_cursor = reinterpret_cast<uint32_t*>(cblk + 124);      // (zeroed with the counter block)
 	A.list = nullptr; A.nlist = nullptr;
 	if(getenv("H2G_GO_DBG_READ")) {
 		static uint32_t* dbg = nullptr;
@@ -1622,24 +1645,25 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	// ---- the fast pass (h2g_fast.h): the dominant traces with the per-read state on chip.  What it completes is final; the reads
 	// it hands on (a device-side list, no host sync) are the general machine's batch.  Built for unspliced alignment on a linear
 	// index with the default pair policy; every other option set goes to the machine whole.
-	static const int fast_env = getenv("H2G_GO_FAST") ? atoi(getenv("H2G_GO_FAST")) : 1;
-	const bool fast = fast_env && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp;
 	s->ran_fast = fast;
 	unsigned fast_mgrid = 0;
-	if(!fast && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (the machine's pool is about to be used on the first stream)
 	if(fast) {
 		uint32_t fgeo[4];
 		h2g_go_fast_geometry(fgeo);
 		// CUs: one persistent fast workgroup each (LDS-bound), minus the few the machine pass of the PREVIOUS run may still hold
 		// (the machine takes ~150 hand-ons per workgroup in half the time of a fast pass; the count is the last finished fast pass's)
-		if(s->gen > 0 && hipEventQuery(s->ev_fast[gsel ^ 1u]) == hipSuccess) s->last_bails = s->h_bails[gsel ^ 1u];
-		else if(s->gen > 1 && hipEventQuery(s->ev_fast[gsel]) == hipSuccess) s->last_bails = s->h_bails[gsel];
+		for(unsigned back = 1; back < H2G_NBUF && back <= s->gen; back++) {                     // the latest fast pass that is over
+			const unsigned b = (s->gen - back) % H2G_NBUF;
+			if(hipEventQuery(s->ev_fast[b]) == hipSuccess) { s->last_bails = s->h_bails[b]; break; }
+		}
 		(void)hipGetLastError();
-		unsigned mgrid = (unsigned)((s->last_bails + 149) / 150);
-		if(mgrid < 4) mgrid = 4;
-		if(mgrid > 96) mgrid = 96;
+		static const unsigned mach_div = getenv("H2G_MACH_DIV") ? (unsigned)atoi(getenv("H2G_MACH_DIV")) : 400u;   // (tuning knobs; hand-ons per machine workgroup: latency chains, two passes in flight)
+		static const unsigned mach_min = getenv("H2G_MACH_MIN") ? (unsigned)atoi(getenv("H2G_MACH_MIN")) : 4u;
+		unsigned mgrid = (unsigned)((s->last_bails + mach_div - 1) / (mach_div ? mach_div : 1u));
+		if(mgrid < mach_min) mgrid = mach_min;
+		if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
 		size_t fwant = (s->n_reads + 127) / 128;                                                // small batches spread over the chip
-		const unsigned fmax = 256 - mgrid;
+		const unsigned fmax = 256 - 2 * mgrid;                                                  // (two machine passes may be in flight)
 		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > fmax ? fmax : fwant));
 		const size_t slot_bytes = (size_t)256 * fgeo[2] * fgeo[3];
 		if(s->fast_slot_bytes < slot_bytes) {
@@ -1672,32 +1696,36 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(fast) {
 		HIPCHK(hipMemcpyAsync(&s->h_bails[gsel], s->d_bail_list[gsel] + s->max_reads, 4, hipMemcpyDeviceToHost, s->st));
 		HIPCHK(hipEventRecord(s->ev_fast[gsel], s->st));
-		HIPCHK(hipStreamWaitEvent(s->st2, s->ev_fast[gsel], 0));
-		ms = s->st2; s->st2_busy = true;
+		HIPCHK(hipStreamWaitEvent(s->mst[msel], s->ev_fast[gsel], 0));
+		ms = s->mst[msel]; s->st2_busy = true;
 		if(fast_mgrid < mach_grid) mach_grid = fast_mgrid;
 	}
-	HIPCHK(hipMemsetAsync(s->d_ovf_list + s->max_reads, 0, 16, ms));
+	const unsigned psel = fast ? msel : 0u;          // workspace pools and the overflow list of this machine stream
+	s->ovf_cur = psel;
+	if(!s->d_ovf_list[psel]) HIPCHK(hipMalloc((void**)&s->d_ovf_list[psel], (s->max_reads + 4) * 4));
+	uint32_t* const ovl = s->d_ovf_list[psel];
+	HIPCHK(hipMemsetAsync(ovl + s->max_reads, 0, 16, ms));
 	HIPCHK(hipEventRecord(s->ev[7], ms));
 	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], ms));
 	if(second) {
 		const GoUnit& B = go_unit(linear, true, spl);
-		uint32_t* cnt = s->d_ovf_list + s->max_reads;
+		uint32_t* cnt = ovl + s->max_reads;
 		hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, ms,
-		                   paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, s->d_ovf_list, cnt);
+		                   paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, ovl, cnt);
 		const unsigned bgrid = 4;
 		uint32_t bgeo[4];
 		B.geometry(bgeo);
 		GoArgs A2 = A;
-		if((rc = go_pool_for(s, 1, B, (size_t)bgrid * bgeo[1], (size_t)bgrid * bgeo[0], p->bowtie2_dp, &A2))) return rc;
+		if((rc = go_pool_for(s, 2 * psel + 1, B, (size_t)bgrid * bgeo[1], (size_t)bgrid * bgeo[0], p->bowtie2_dp, &A2))) return rc;
 		A2.counters = cblk + 64;
 		A2.work = reinterpret_cast<uint32_t*>(cblk + 15);
-		A2.list = s->d_ovf_list; A2.nlist = cnt;
+		A2.list = ovl; A2.nlist = cnt;
 		A2.defer_overflow = 0;
 		if(B.launch(&A2, bgrid, ms) != 0) return set_err("go() second pass launch", hipGetLastError());
 	}
 	HIPCHK(hipEventRecord(s->ev[8], ms));
-	if(fast) HIPCHK(hipEventRecord(s->ev_mach[gsel], s->st2));
+	if(fast) HIPCHK(hipEventRecord(s->ev_mach[gsel], ms));
 	s->cnt_cur = cblk; s->gen++;
 	HIPCHK(hipGetLastError());
 	s->ran_align = true;
@@ -1708,7 +1736,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) { 
 extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params* p) { return go_run(s, p, true); }
 
 extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t first, size_t n) {
-	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
 	std::vector<ReadOut> tmp(n);
 	HIPCHK(hipMemcpyAsync(tmp.data(), s->d_rout + first, n * sizeof(ReadOut), hipMemcpyDeviceToHost, s->st));
@@ -1728,8 +1756,9 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 
 // ------------------------------------------------------------------------------------------ paired go(): fetch
 extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) {
-	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
+	if((aln1 || aln2) && s->pair_slots < H2G_PAIR_RES_CAP) return H2G_ERR_ARG;
 	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
 	// device rows hold pair_slots records, the caller's rows H2G_PAIR_RES_CAP (the dense variant returns all of them)
 	for(int m = 0; m < 2 && n; m++) {
@@ -1738,6 +1767,9 @@ extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res,
 		                                (size_t)H2G_PAIR_RES_CAP * sizeof(h2g_alnres), n, hipMemcpyDeviceToHost, s->st));
 	}
 	HIPCHK(sync_all(s));
+	// a pair kept in the overflow area has more records than these fixed rows return: flagged in the returned copy (the dense variant
+	// returns every record)
+	for(size_t i = 0; i < n; i++) if(res[i].pad) res[i].overflow |= 4;
 	return H2G_OK;
 }
 
@@ -1745,13 +1777,15 @@ extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res,
 // The slot layout of h2g_align_fetch moves H2G_ALN_CAP x 424 B per read over PCIe whatever was found; these variants gather
 // only the records that exist into one dense array on the device (one lane per read) and copy that.
 __global__ __launch_bounds__(256) void k_gather_aln(const h2g_alnres* src, uint32_t slots, const uint32_t* cnt, uint32_t cnt_stride,
-                                                    const unsigned long long* offs, size_t n, h2g_alnres* dst)
+                                                    const unsigned long long* offs, size_t n, h2g_alnres* dst,
+                                                    const PairOut* pout = nullptr, const h2g_alnres* ovf = nullptr, int mate = 0)
 {
 	const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
 	if(i >= n) return;
 	uint32_t c = cnt[i * cnt_stride];
-	if(c > slots) c = slots;
 	const h2g_alnres* a = src + i * slots;
+	if(pout && pout[i].pad) a = ovf + (pout[i].pad - 1u) + (mate ? pout[i].nres[0] : 0u);      // every record of the pair lives in its overflow block
+	else if(c > slots) c = slots;
 	h2g_alnres* d = dst + offs[i];
 	for(uint32_t k = 0; k < c; k++) {
 		d[k].fw = a[k].fw; d[k].tidx = a[k].tidx; d[k].toff = a[k].toff; d[k].len = a[k].len; d[k].trim5 = a[k].trim5; d[k].trim3 = a[k].trim3;
@@ -1760,15 +1794,15 @@ __global__ __launch_bounds__(256) void k_gather_aln(const h2g_alnres* src, uint3
 	}
 }
 // dense offsets of [first, first+n) of a slot array from the per-read record counts already on the host
-static uint64_t dense_offsets(const uint32_t* h_cnt, uint32_t h_stride, uint32_t slots, size_t n, uint64_t* offs) {
+static uint64_t dense_offsets(const uint32_t* h_cnt, uint32_t h_stride, uint32_t slots, size_t n, uint64_t* offs, const uint32_t* h_pad = nullptr) {
 	uint64_t tot = 0;
-	for(size_t i = 0; i < n; i++) { offs[i] = tot; const uint32_t c = h_cnt[i * h_stride]; tot += c < slots ? c : slots; }
+	for(size_t i = 0; i < n; i++) { offs[i] = tot; const uint32_t c = h_cnt[i * h_stride]; tot += (c < slots || (h_pad && h_pad[i * h_stride])) ? c : slots; }
 	offs[n] = tot;
 	return tot;
 }
 // gathers the records into `out` (host) at the offsets computed by dense_offsets
 static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, const uint32_t* d_cnt, uint32_t cnt_stride, size_t n, h2g_alnres* out,
-                        const uint64_t* offs, int tmp_slot)
+                        const uint64_t* offs, int tmp_slot, const PairOut* d_pout = nullptr, int mate = 0)
 {
 	const uint64_t tot = offs[n];
 	if(tot == 0) return H2G_OK;
@@ -1777,7 +1811,7 @@ static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, 
 	if((rc = tmp_buf(s, tmp_slot, (n + 1) * 8, &d_offs)) || (rc = tmp_buf(s, tmp_slot + 1, tot * sizeof(h2g_alnres), &d_dense))) return rc;
 	HIPCHK(hipMemcpyAsync(d_offs, offs, (n + 1) * 8, hipMemcpyHostToDevice, s->st));
 	hipLaunchKernelGGL(k_gather_aln, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->st, d_src, slots, d_cnt, cnt_stride,
-	                   (const unsigned long long*)d_offs, n, (h2g_alnres*)d_dense);
+	                   (const unsigned long long*)d_offs, n, (h2g_alnres*)d_dense, d_pout, (const h2g_alnres*)s->d_paln_ovf, mate);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, d_dense, tot * sizeof(h2g_alnres), hipMemcpyDeviceToHost, s->st));
 	HIPCHK(sync_all(s));
@@ -1785,7 +1819,7 @@ static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, 
 }
 
 extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t aln_cap, uint64_t* aln_offs, size_t first, size_t n) {
-	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || !aln || !aln_offs || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
 	const h2g_status rc = h2g_align_fetch(s, res, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
@@ -1798,25 +1832,27 @@ extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res,
 extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, size_t cap1, uint64_t* offs1,
                                                   h2g_alnres* aln2, size_t cap2, uint64_t* offs2, size_t first, size_t n)
 {
-	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || !aln1 || !aln2 || !offs1 || !offs2 || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	const h2g_status rc = h2g_align_pairs_fetch(s, res, nullptr, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
 	static_assert(offsetof(PairOut, nres) == 0, "PairOut layout");
 	// both totals are known before either capacity is judged, so a caller that has to grow its buffers learns both needs at once
-	const uint64_t t1 = dense_offsets(&res[0].nres[0], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs1);
-	const uint64_t t2 = dense_offsets(&res[0].nres[1], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs2);
+	static_assert(offsetof(h2g_pair_result, pad) == offsetof(PairOut, pad) && sizeof(h2g_pair_result) == sizeof(PairOut), "PairOut layout");
+	for(size_t i = 0; i < n; i++) if(res[i].pad) res[i].overflow &= ~4u;     // (h2g_align_pairs_fetch flagged what its fixed rows cannot return; here every record is returned)
+	const uint64_t t1 = dense_offsets(&res[0].nres[0], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs1, &res[0].pad);
+	const uint64_t t2 = dense_offsets(&res[0].nres[1], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs2, &res[0].pad);
 	if(t1 > cap1 || t2 > cap2) return H2G_ERR_ARG;
 	int r;
 	if((r = gather_dense(s, s->d_paln[0] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first), sizeof(PairOut) / 4,
-	                     n, aln1, offs1, 0))) return r;
+	                     n, aln1, offs1, 0, s->d_pout + first, 0))) return r;
 	return gather_dense(s, s->d_paln[1] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
-	                    n, aln2, offs2, 2);
+	                    n, aln2, offs2, 2, s->d_pout + first, 1);
 }
 
 // development hook (env H2G_GO_DBG_READ=<read id>): the primitive requests of that read in the last go() launch, 8 words each
 extern "C" __attribute__((visibility("default"))) int h2g_go_debug_trace(h2g_stream* s, uint32_t* out, uint32_t cap_words) {
-	if(s && s->st2_busy) { HIPCHK(hipStreamSynchronize(s->st2)); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !out || !s->dbg_buf) return H2G_ERR_ARG;
 	HIPCHK(sync_all(s));
 	HIPCHK(hipMemcpy(out, s->dbg_buf, (size_t)cap_words * 4, hipMemcpyDeviceToHost));
@@ -1852,7 +1888,7 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	s->last.n_rank = v[0] + v[8]; s->last.n_side = v[1] + v[9]; s->last.n_sa_steps = v[2] + v[10]; s->last.n_ext = v[3];
 	s->last.n_aligned = v[4] + v[12];
 	uint32_t nsecond = 0;
-	if(s->d_ovf_list && s->ran_align) HIPCHK(hipMemcpy(&nsecond, s->d_ovf_list + s->max_reads, 4, hipMemcpyDeviceToHost));
+	if(s->d_ovf_list[s->ovf_cur] && s->ran_align) HIPCHK(hipMemcpy(&nsecond, s->d_ovf_list[s->ovf_cur] + s->max_reads, 4, hipMemcpyDeviceToHost));
 	s->last.n_second_pass = nsecond;
 	s->last.n_overflow = nsecond ? v[13] : v[5];   // reads still flagged after the last pass that saw them
 	s->last.n_queries = s->n_reads * 2;

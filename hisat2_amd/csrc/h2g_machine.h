@@ -120,6 +120,11 @@ struct MachOut {
 	PairOut*    pout;      // paired: [n]
 	h2g_alnres* paln[2];   // paired: [n * pair_slots] each
 	uint32_t    pair_slots;
+	// a pair whose mates reported more than pair_slots alignments keeps ALL its records in a block of this area (mate 1's, then mate 2's),
+	// PairOut::pad = block start + 1 (the sink's lists grow on demand, aln_sink.h:2565; soft-clipped variants of a tandem duplicate's loci)
+	h2g_alnres* ovf = nullptr;
+	uint32_t*   ovf_cursor = nullptr;
+	uint32_t    ovf_cap = 0;
 };
 
 struct Lane {                 // the registers of one lane's machine
@@ -1625,15 +1630,29 @@ H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M) {
 	} else {
 		PairOut o;
 		o.nres[0] = ws->m[0].nres; o.nres[1] = ws->m[1].nres; o.npairs = ws->npairs; o.overflow = ws->overflow;
-		// the records beyond pair_slots are not returned: the pair is flagged so that no caller indexes past them
-		if(o.nres[0] > O.pair_slots || o.nres[1] > O.pair_slots) o.overflow |= 4;
-		o.nrank = ws->nrank; o.nsteps = ws->nsteps; o.depth = ws->nframes_max; o.nside = ws->nside; o.rnd_state = gv.rnd; o.pad = 0;
+		// more records than the fixed rows hold: the whole pair goes to a block of the overflow area; without room there the pair is
+		// flagged, so that no caller indexes past its rows
+		uint32_t blk = H2G_MAX;
+		if(o.nres[0] > O.pair_slots || o.nres[1] > O.pair_slots) {
+			const uint32_t need = o.nres[0] + o.nres[1];
+			if(O.ovf && O.ovf_cursor) {
+#if defined(__HIP_DEVICE_COMPILE__)
+				const uint32_t at = atomicAdd(O.ovf_cursor, need);
+#else
+				const uint32_t at = *O.ovf_cursor; *O.ovf_cursor += need;
+#endif
+				if(at + need <= O.ovf_cap) blk = at;
+			}
+			if(blk == H2G_MAX) o.overflow |= 4;
+		}
+		o.nrank = ws->nrank; o.nsteps = ws->nsteps; o.depth = ws->nframes_max; o.nside = ws->nside; o.rnd_state = gv.rnd; o.pad = blk == H2G_MAX ? 0u : blk + 1u;
 		for(uint32_t k = 0; k < AL_MAX_PAIRS; k++) { o.pair_i[k] = k < ws->npairs ? ws->pair_i[k] : 0; o.pair_j[k] = k < ws->npairs ? ws->pair_j[k] : 0; }
 		if(O.pout) O.pout[i] = o;
 		for(int m = 0; m < 2; m++) {
 			if(!O.paln[m]) continue;
 			const uint32_t n = o.nres[m] < O.pair_slots ? o.nres[m] : O.pair_slots;
 			for(uint32_t k = 0; k < n; k++) mach_copy_rec(O.paln[m][(size_t)i * O.pair_slots + k], ws->m[m].res[k]);
+			if(blk != H2G_MAX) for(uint32_t k = 0; k < o.nres[m]; k++) mach_copy_rec(O.ovf[(size_t)blk + (m ? o.nres[0] : 0u) + k], ws->m[m].res[k]);
 		}
 		M.L.a0 = o.npairs > 0; M.L.a1 = o.overflow != 0;
 	}

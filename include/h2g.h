@@ -339,7 +339,8 @@ typedef struct {
 	uint32_t npairs;               /* sink.report(r1, r2) events, in report order (rs1_/rs2_) */
 	uint32_t overflow, nrank, nsteps, depth, nside;
 	uint32_t rnd_state;            /* RandomSource::last after go(): the sink's selectByScore continues from it */
-	uint32_t pad;
+	uint32_t pad;                  /* device-side: != 0 when the pair's records live in the stream's growable area (a mate with more reports than its
+	                                * fixed rows); h2g_align_pairs_fetch_dense returns all of them, h2g_align_pairs_fetch sets overflow bit 4 for such a pair */
 	uint8_t  pair_i[H2G_PAIR_CAP], pair_j[H2G_PAIR_CAP];   /* indexes into the two per-mate lists */
 } h2g_pair_result;
 /* The concordant / discordant / unpaired decision, -k selection, MAPQ and SAM stay in the caller's AlnSinkWrap

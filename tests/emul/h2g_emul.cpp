@@ -329,6 +329,46 @@ void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, cons
 }
 
 
+static bool rec_equal(const h2g_alnres& a, const AlnRec& b);
+// paired go() with `slots` record rows per mate and an overflow area of `ovf_cap` records (MachOut::ovf): every pair's records, read the way
+// the dense fetch reads them (PairOut::pad -> its block, mate 2 behind mate 1; else its rows), must equal the workspace's lists.
+// stats[0] pairs kept in the area, [1] pairs with a wrong record, [2] pairs flagged (area full), [3] records the area holds at the end
+void h2gemu_pairs_overflow_check(Emu* e, const uint8_t* codes2, const uint32_t* offs2, const char* names1, const uint32_t* noffs1,
+                                 const char* names2, const uint32_t* noffs2, uint32_t slots, uint32_t ovf_cap, uint64_t* stats) {
+	AlnParams P; AlnCtx C;
+	emu_ctx(e, 1, &P, &C);
+	AlignWS* ws = new AlignWS();
+	Mach M;
+	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
+	M.rd[1].codes = codes2; M.rd[1].offs = offs2; M.rd[1].quals = nullptr;
+	const uint32_t n = M.rd[0].n;
+	std::vector<PairOut> outs(n);
+	std::vector<h2g_alnres> r1((size_t)n * slots), r2((size_t)n * slots), area(ovf_cap ? ovf_cap : 1);
+	uint32_t cursor = 0;
+	MachOut O; O.rout = nullptr; O.aln = nullptr; O.aln_slots = 0; O.pout = outs.data(); O.paln[0] = r1.data(); O.paln[1] = r2.data(); O.pair_slots = slots;
+	O.ovf = area.data(); O.ovf_cursor = &cursor; O.ovf_cap = ovf_cap;
+	stats[0] = stats[1] = stats[2] = stats[3] = 0;
+	for(uint32_t i = 0; i < n; i++) {
+		M.name[0] = names1 + noffs1[i]; M.namelen[0] = noffs1[i + 1] - noffs1[i];
+		M.name[1] = names2 + noffs2[i]; M.namelen[1] = noffs2[i + 1] - noffs2[i];
+		mach_run_single(C, M, i, true, O);
+		const PairOut& o = outs[i];
+		const bool big = o.nres[0] > slots || o.nres[1] > slots;
+		bool bad = (o.pad != 0 || (o.overflow & 4)) != big || (o.pad != 0 && (o.overflow & 4));
+		stats[0] += o.pad != 0; stats[2] += (o.overflow & 4) != 0;
+		for(int m = 0; m < 2 && !bad; m++) {
+			const h2g_alnres* a = o.pad ? area.data() + (o.pad - 1) + (m ? o.nres[0] : 0) : (m ? r2.data() : r1.data()) + (size_t)i * slots;
+			const uint32_t c = o.pad ? o.nres[m] : (o.nres[m] < slots ? o.nres[m] : slots);
+			if(o.nres[m] != ws->m[m].nres) bad = true;
+			for(uint32_t k = 0; k < c && !bad; k++) bad = !rec_equal(a[k], ws->m[m].res[k]);
+		}
+		stats[1] += bad;
+	}
+	stats[3] = cursor;
+	delete ws;
+}
+
+
 // ---- the fast path (h2g_fast.h) against the general machine: every read / pair of the batch through both; for the ones the
 // fast path completes, its PairOut / ReadOut and records must equal the machine's.  stats[0] completed, [1] mismatching,
 // [2 + why] bails by reason; bad_ids (cap entries) = the first mismatching read ids.  codes2 == nullptr: unpaired.

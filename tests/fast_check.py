@@ -40,6 +40,26 @@ def fast_check(base, reads1, reads2=None, names=None, quals=None, options=()):
             "bad": [int(x) for x in bad[:min(nbad, 64)]], "done": done}
 
 
+def pairs_overflow_check(base, reads1, reads2, slots, ovf_cap):
+    """paired go() on the host machine with `slots` record rows per mate and an overflow area of ovf_cap records (MachOut::ovf)
+    -> dict(in_area, mismatching, flagged, area_records)"""
+    e = Emu(base)
+    n = len(reads1)
+    codes = np.concatenate(reads1).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads1])]).astype(np.uint32)
+    e.set_reads(codes, offs, None)
+    names = [str(i) for i in range(n)]
+    nb = "".join(names).encode()
+    noffs = np.concatenate([[0], np.cumsum([len(q) for q in names])]).astype(np.uint32)
+    c2 = np.concatenate([np.concatenate(reads2).astype(np.uint8), np.zeros(8, np.uint8)])
+    o2 = np.concatenate([[0], np.cumsum([len(r) for r in reads2])]).astype(np.uint32)
+    stats = np.zeros(4, dtype=np.uint64)
+    vp = C.c_void_p
+    e.L.h2gemu_pairs_overflow_check.argtypes = [vp, vp, vp, C.c_char_p, vp, C.c_char_p, vp, C.c_uint32, C.c_uint32, vp]
+    e.L.h2gemu_pairs_overflow_check(e.h, c2.ctypes.data, o2.ctypes.data, nb, noffs.ctypes.data, nb, noffs.ctypes.data, slots, ovf_cap, stats.ctypes.data)
+    return {"n": n, "in_area": int(stats[0]), "mismatching": int(stats[1]), "flagged": int(stats[2]), "area_records": int(stats[3])}
+
+
 if __name__ == "__main__":
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 class Emu:
     def __init__(self, base):
         subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emul")], check=True)
-        self.L = C.CDLL(os.path.join(HERE, "emul", "libh2gemu.so"))
+        self.L = C.CDLL(os.environ.get("H2GEMU_LIB") or os.path.join(HERE, "emul", "libh2gemu.so"))
         vp = C.c_void_p
         self.L.h2gemu_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         self.L.h2gemu_set_reads.argtypes = [vp, vp, vp, vp, C.c_size_t]

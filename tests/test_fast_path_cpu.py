@@ -72,3 +72,14 @@ def test_qualities_and_scoring_options(genome):
         r = FC.fast_check(base, list(m1), list(m2), options=opts)
         assert r["mismatching"] == 0, (opts, r)
         assert r["completed"] > 0.4 * n, (opts, r)
+
+
+def test_pair_records_beyond_the_rows_go_to_the_overflow_area(genome):
+    """MachOut::ovf: a pair with more reports than a mate's fixed rows keeps all of them in a block of the area (PairOut::pad); only a
+    full area flags the pair (overflow bit 4) -- the sink's lists grow on demand (aln_sink.h:2565)"""
+    base, contigs = genome
+    m1, m2 = synth.make_pairs(contigs, 3000, 101, 4242, frag_mean=300, frag_sd=30, sub_rate=0.01)
+    r = FC.pairs_overflow_check(base, list(m1), list(m2), 1, 1 << 16)
+    assert r["mismatching"] == 0 and r["flagged"] == 0 and r["in_area"] > 20, r
+    small = FC.pairs_overflow_check(base, list(m1), list(m2), 1, 40)
+    assert small["mismatching"] == 0 and small["flagged"] > 0 and small["in_area"] + small["flagged"] == r["in_area"], (small, r)

@@ -86,3 +86,58 @@ def test_golden_pairs_sam(g1_index, golden_dir):
     for i in range(len(s1)):
         assert res[i].overflow == 0
         assert PS.finish_pair(res[i], a1, a2, i * api.PAIR_RES_CAP, refnames, (s1[i], s2[i])) == want[q[i]], i
+
+
+def test_pair_records_beyond_the_rows_are_all_returned(monkeypatch):
+    """a mate with more reports than its fixed device rows: the pair's records live in the stream's overflow area (MachOut::ovf,
+    PairOut::pad) and the dense fetch returns every one of them.  H2G_PAIR_SLOTS=1 pushes every multi-report pair through it."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    build = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
+    if not os.path.exists(build):
+        pytest.skip("needs oracle/_ref")
+    tmp = tempfile.mkdtemp(prefix="h2ovf")
+    contigs = synth.make_genome([300000, 100000], 515, n_gaps=2, gap_len=300, repeats=60, repeat_len=500)
+    synth.write_fasta(os.path.join(tmp, "g.fa"), contigs)
+    base = os.path.join(tmp, "g")
+    subprocess.run([build, "-q", os.path.join(tmp, "g.fa"), base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    m1, m2 = synth.make_pairs(contigs, 20000, 101, 516, frag_mean=300, frag_sd=30, sub_rate=0.01)
+    q = [str(i) for i in range(len(m1))]
+
+    def run():
+        c1, o1 = synth.flatten_reads(m1)
+        c2, o2 = synth.flatten_reads(m2)
+        ix = api.Index(base, device=0)
+        st = api.Stream(ix, max_reads=len(m1), max_bases=c1.size)
+        st.set_reads(c1, o1)
+        st.set_read_names(q)
+        st.set_mates(c2, o2, q)
+        p = st.align_params()
+        p.no_spliced_alignment = 1
+        st.align_pairs_run(p)
+        res, a1, f1, a2, f2 = st.align_pairs_fetch_dense()
+        n1, n2 = int(f1[len(m1)]), int(f2[len(m1)])
+        out = (bytes(res), bytes(a1)[:n1 * C.sizeof(api.AlnRes)], f1.copy(), bytes(a2)[:n2 * C.sizeof(api.AlnRes)], f2.copy(), [r.pad for r in res])
+        st.close()
+        ix.close()
+        return out
+
+    import ctypes as C
+    want = run()
+    assert not any(want[5])
+    monkeypatch.setenv("H2G_PAIR_SLOTS", "1")
+    got = run()
+    npad = sum(1 for x in got[5] if x)
+    print("pairs in the overflow area:", npad)
+    assert npad > 100
+    # everything but `pad` itself is identical: counts, flags, PRNG state, every record of both mates
+    rw = np.frombuffer(want[0], dtype=np.uint32).reshape(len(m1), -1).copy()
+    rg = np.frombuffer(got[0], dtype=np.uint32).reshape(len(m1), -1).copy()
+    k = api.PairResult.pad.offset // 4
+    rw[:, k] = 0
+    rg[:, k] = 0
+    assert (rw == rg).all()
+    assert (want[2] == got[2]).all() and (want[4] == got[4]).all()
+    assert want[1] == got[1] and want[3] == got[3]

@@ -50,6 +50,15 @@ for _ in range(4):
     run(); st.sync()
     c = st.counters()
     ms.append((c.ms_align, c.ms_fast_kernel, c.ms_align_kernel))
+# steady state: runs queued back to back (the machine pass of run k next to the fast pass of run k + 1), one sync at the end
+K = int(os.environ.get("H2G_STEADY", "10"))
+run(); st.sync()
+t1 = time.perf_counter()
+for _ in range(K):
+    run()
+st.sync()
+steady = (time.perf_counter() - t1) * 1e3 / K
+c = st.counters()
 if mode == "se":
     res, aln, offs_ = st.align_fetch_dense()
     ck = zlib.crc32(res.tobytes()) ^ aln_crc(aln, int(offs_[n]))
@@ -77,6 +86,6 @@ if hasattr(L, "h2g_go_fast_prof"):
             for op in range(1, 8):
                 if v[3 + op]:
                     print("  %-20s %5.1f %%   executions %d: avg %.1f of 64 lanes" % (ops[op], 100.0 * v[3 + op] / tot, v[32 + op], v[20 + op] / max(1, v[32 + op])))
-print("%s n %d genome %d FAST=%s: align total/fast/machine ms %s | fast done %d bailed %d (%.1f %%) second %d overflow %d aligned %d | sides/unit %.1f steps/unit %.1f | crc %08x" % (
-    mode, n, glen, os.environ.get("H2G_GO_FAST", "1"), " ".join("%.2f/%.2f/%.2f" % m for m in ms), c.n_fast, c.n_fast_bail, 100.0 * c.n_fast_bail / n,
+print("%s n %d genome %d FAST=%s: steady %.2f ms/run | align total/fast/machine ms %s | fast done %d bailed %d (%.1f %%) second %d overflow %d aligned %d | sides/unit %.1f steps/unit %.1f | crc %08x" % (
+    mode, n, glen, os.environ.get("H2G_GO_FAST", "1"), steady, " ".join("%.2f/%.2f/%.2f" % m for m in ms), c.n_fast, c.n_fast_bail, 100.0 * c.n_fast_bail / n,
     c.n_second_pass, c.n_overflow, c.n_aligned, c.n_side / n, c.n_sa_steps / n, ck))
