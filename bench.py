@@ -198,10 +198,10 @@ def main():
                     "kernel": "k_go_fast (h2g_k_go_fast.hip)" if fast_on else "k_go<false> (h2g_go_kernels.h)", "kernel_ms": ms_kernel,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "pairs_completed_by_the_kernel": int(cnt.n_fast), "pairs_handed_on": int(cnt.n_fast_bail),
-                    "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs, on the second stream next to the following step's fast pass",
+                    "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs (about 0.5 %: long latency chains), on one of two machine streams next to the fast passes of the following two steps",
                     "whole_step": {"algorithmic_bytes": alg_all, "GB/s": alg_all / (dt / a.steps) / 1e9, "frac": alg_all / (dt / a.steps) / 1e9 / HBM_PEAK_GBS},
                     "sides_per_pair": int(cnt.n_side) / npairs, "sa_steps_per_pair": int(cnt.n_sa_steps) / npairs,
-                    "note": "latency chains over scattered 64 B index lines + per-read control; the per-read state is 672 B per trip in 5 sequential lines (DESIGN.md §3)"}
+                    "note": "latency chains over scattered 64 B index lines + per-read control; per trip a read's 160 B state and 264 B of hot words + packed reads are loaded in one batch of 16 B loads and stored back (DESIGN.md §3.1)"}
         # HBM traffic of the same kernel on the same workload from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
         # WRITE_SIZE need separate passes and cannot be collected inside this process); per launch like `achieved`
         try:
@@ -221,7 +221,7 @@ def main():
                        "genome_bases": total, "index_device_bytes": int(ix.info.device_bytes), "pairs_per_gpu": npairs, "read_len": 101, "sub_rate": 0.005,
                        "fragment": "N(300, 30) clipped to [150, 600]",
                        "stage": "HI_Aligner::go for both mates + pairing; report events stay in HBM (finishRead / SAM text are host code, SURVEY §8(f) N1)",
-                       "pipelining": "the machine pass of step k overlaps the fast pass of step k+1 on a second stream; all K steps complete inside the timed region",
+                       "pipelining": "the machine pass of step k overlaps the fast passes of steps k+1 and k+2 (two machine streams, three buffer sets); all K steps complete inside the timed region",
                        "sharding": f"pairs by id range across {world} GPU(s) ({'one global batch split' if a.strong else 'fixed work per GPU'}), index replicated; RCCL all-reduce of the summary counters only"},
             "roofline": roofline,
             "counters": {"pairs": int(summ[0]), "pairs_with_concordant": int(summ[1]), "pairs_still_flagged_overflow": int(summ[2]),

@@ -89,7 +89,8 @@ struct h2g_stream {
 	uint32_t* d_ovf_list[2] = {nullptr, nullptr};   // per machine stream: read ids whose workspace overflowed in the main pass (+ their count behind the list)
 	unsigned ovf_cur = 0;             // the one the last run used
 	uint32_t* d_bail_list[H2G_NBUF] = {};  // read ids the fast pass handed on to the general machine (+ their count behind the list)
-	void* d_fast_args[H2G_NBUF] = {};      // the fast pass's argument block (device copy)
+	void* d_fast_args[H2G_NBUF] = {};
+	void* h_fast_args = nullptr;      // pinned staging of the argument blocks (H2G_NBUF of them): the upload never makes the host wait for the stream      // the fast pass's argument block (device copy)
 	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
 	bool ran_fast = false;
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -372,6 +373,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
 	for(int k = 0; k < 2; k++) HIPCHK(hipStreamCreateWithFlags(&s->mst[k], hipStreamNonBlocking));
+	HIPCHK(hipHostMalloc((void**)&s->h_fast_args, sizeof(FastArgs) * H2G_NBUF));
 	HIPCHK(hipHostMalloc((void**)&s->h_bails, 4 * H2G_NBUF)); for(int k = 0; k < H2G_NBUF; k++) s->h_bails[k] = 0;
 	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
 	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
@@ -399,7 +401,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
-	(void)hipStreamDestroy(s->st); for(int k = 0; k < 2; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails);
+	(void)hipStreamDestroy(s->st); for(int k = 0; k < 2; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails); (void)hipHostFree(s->h_fast_args);
 	delete s;
 }
 
@@ -1684,7 +1686,13 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		F.bail_list = bl; F.bail_count = bl + s->max_reads;
 		F.total = (uint32_t)s->n_reads; F.paired = paired ? 1u : 0u;
 		if(!s->d_fast_args[gsel]) HIPCHK(hipMalloc((void**)&s->d_fast_args[gsel], sizeof(FastArgs)));
-		HIPCHK(hipMemcpyAsync(s->d_fast_args[gsel], &F, sizeof F, hipMemcpyHostToDevice, s->st));   // (pageable source: the copy is staged before the call returns)
+		// through pinned memory: a pageable source would make this call wait for everything queued on the stream (the previous run's fast
+		// pass), and the chip would idle while the host queues this run.  The staging block of this buffer set was last read by the upload
+		// of run k - H2G_NBUF, which is over once that run's fast pass is
+		if(s->gen >= H2G_NBUF && hipEventQuery(s->ev_fast[gsel]) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipEventSynchronize(s->ev_fast[gsel])); }
+		FastArgs* const hF = reinterpret_cast<FastArgs*>(s->h_fast_args) + gsel;
+		*hF = F;
+		HIPCHK(hipMemcpyAsync(s->d_fast_args[gsel], hF, sizeof F, hipMemcpyHostToDevice, s->st));
 		if(h2g_go_fast_launch(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
 		A.list = bl; A.nlist = bl + s->max_reads;
 		fast_mgrid = mgrid;
