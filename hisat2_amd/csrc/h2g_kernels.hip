@@ -1504,6 +1504,17 @@ __global__ __launch_bounds__(256) void k_collect_overflow(const ReadOut* rout, c
 	if(ovf) list[atomicAdd(count, 1u)] = i;
 }
 
+// the same over the ids of a list (behind a fast pass only the reads it handed on can carry a flag); few workgroups, grid-stride: this
+// runs next to two persistent kernels
+__global__ __launch_bounds__(256) void k_collect_overflow_of(const uint32_t* ids, const uint32_t* nids, const ReadOut* rout, const PairOut* pout, uint32_t* list, uint32_t* count) {
+	const uint32_t n = *nids;
+	for(uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t i = ids[k];
+		const uint32_t ovf = rout ? rout[i].overflow : pout[i].overflow;
+		if(ovf) list[atomicAdd(count, 1u)] = i;
+	}
+}
+
 // HI_Aligner::go for every read (pair) of the resident batch.  Two passes, both asynchronous on the stream: the main pass
 // with the default workspace, then the reads it flagged (a list overflowed) once more through the large-workspace unit,
 // whose results replace theirs.  Reads still flagged after that keep `overflow` set (n_overflow counts them).
@@ -1719,8 +1730,10 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(second) {
 		const GoUnit& B = go_unit(linear, true, spl);
 		uint32_t* cnt = ovl + s->max_reads;
-		hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, ms,
-		                   paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, ovl, cnt);
+		if(fast) hipLaunchKernelGGL(k_collect_overflow_of, dim3(8), dim3(256), 0, ms, (const uint32_t*)A.list, (const uint32_t*)A.nlist,
+		                            paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, ovl, cnt);
+		else hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, ms,
+		                        paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, ovl, cnt);
 		const unsigned bgrid = 4;
 		uint32_t bgeo[4];
 		B.geometry(bgeo);
