@@ -342,7 +342,7 @@ SEED_RESULT_DTYPE = np.dtype([("hit", FM_HIT_DTYPE), ("ncoords", np.uint32), ("s
 assert SEED_RESULT_DTYPE.itemsize == C.sizeof(SeedResult)
 
 EXPORTS = [
-    "h2g_load_opts_init", "h2g_index_load", "h2g_index_get_info", "h2g_index_synth_sides", "h2g_index_free", "h2g_index_set_splice_sites",
+    "h2g_load_opts_init", "h2g_index_load", "h2g_index_get_info", "h2g_index_synth_sides", "h2g_index_free", "h2g_index_set_splice_sites", "h2g_index_add_splice_sites",
     "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_set_reads",
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",

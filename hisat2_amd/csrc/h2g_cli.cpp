@@ -242,6 +242,7 @@ int main(int argc, char** argv) {
 	uint32_t dp = 0;
 	size_t batch = 1u << 20;
 	int device = 0, threads = 1, gpus = 1;
+	uint32_t ss_window_opt = 0;
 	std::string cmdline;
 	std::vector<std::string> opts;                      // scoring / reporting options, applied once the index type is known
 	bool sensitive = false, very_sensitive = false, saw_k = false;
@@ -262,6 +263,7 @@ int main(int argc, char** argv) {
 		else if(a == "-p" || a == "--threads") threads = atoi(need("-p"));        // host threads for parsing and SAM formatting
 		else if(a == "--no-spliced-alignment") nospliced = true;
 		else if(a == "--no-temp-splicesite") notempss = true;
+		else if(a == "--ss-window") ss_window_opt = (uint32_t)strtoul(need("--ss-window"), nullptr, 10);   // reads a temporary splice site stays invisible for: 1000 x <-p> of the reference (hisat2.cpp:3687), decoupled from this program's host threads
 		else if(a == "--dta" || a == "--downstream-transcriptome-assembly") dta = true;
 		else if(a == "--dta-cufflinks") { dta = true; xs_only = true; }
 		else if(a == "--rna-strandness") {
@@ -377,12 +379,13 @@ int main(int argc, char** argv) {
 	const bool temp_ss = !nospliced && !notempss;
 	uint32_t ss_window = 0;
 	if(temp_ss) {
-		if(threads < 2) {
+		if(threads < 2 && !ss_window_opt) {
 			fprintf(stderr, "hisat2-align-amd: with temporary splice sites a read depends on the reads 1000 x <-p> before it; -p 1 would run the reads one by one. "
-			        "Pass -p >= 2 (output == hisat2 -p <int> --reorder), --no-temp-splicesite or --no-spliced-alignment\n");
+			        "Pass -p >= 2 (output == hisat2 -p <int> --reorder), --ss-window <int> (output == hisat2 -p <int>/1000 --reorder whatever -p is here), "
+			        "--no-temp-splicesite or --no-spliced-alignment\n");
 			return 1;
 		}
-		ss_window = 1000u * (uint32_t)threads;
+		ss_window = ss_window_opt ? ss_window_opt : 1000u * (uint32_t)threads;
 		if(batch > ss_window) batch = ss_window;
 	}
 	const bool paired = u.empty();
@@ -518,7 +521,7 @@ int main(int argc, char** argv) {
 			sites.swap(uniq);
 		}
 		publish_sites();
-	}
+	} else if(temp_ss) publish_sites();                    // (the window of the wave scheme; the sites arrive wave after wave)
 	if(!temp_ss && !nospliced && !novel_out.empty() && h2g_sam_novel_splice_sites_text(sam, nullptr, 0) > 0) {
 		// write (the outfile) + read (a file's or the index's sites) without the temporary-site window: the reference then lets every read see
 		// the junctions of whichever reads its threads happened to finish first (window 0, hisat2.cpp:3687, :4092-4093) — not a function of the input
@@ -631,14 +634,24 @@ int main(int argc, char** argv) {
 			const size_t k = h2g_sam_take_novel_sites(sam, nullptr, 0);
 			novel.resize(k);
 			if(k) h2g_sam_take_novel_sites(sam, novel.data(), k);
-			bool changed = false;
+			// only what is new (or whose smallest read id went down) goes to the devices and the formatter: they merge it into their sorted
+			// copies (h2g_index_add_splice_sites) — the cost of a wave is its own junctions, not the database's size
+			static std::vector<h2g_splice_site> delta;
+			delta.clear();
 			if(temp_ss) for(const h2g_splice_site& x : novel) {
 				const std::array<uint32_t, 4> key = {x.tidx, x.left, x.right, (uint32_t)x.dir};
 				auto it = site_at.find(key);
-				if(it == site_at.end()) { site_at.emplace(key, sites.size()); sites.push_back(x); changed = true; }
-				else if(!sites[it->second].fromfile && x.readid < sites[it->second].readid) { sites[it->second].readid = x.readid; changed = true; }
+				if(it == site_at.end()) { site_at.emplace(key, sites.size()); sites.push_back(x); delta.push_back(x); }
+				else if(!sites[it->second].fromfile && x.readid < sites[it->second].readid) { sites[it->second].readid = x.readid; delta.push_back(sites[it->second]); }
 			}
-			if(changed) publish_sites();
+			if(!delta.empty()) {
+				for(int g2 = 0; g2 < gpus; g2++) {
+					bool first = true;
+					for(int q = 0; q < g2; q++) if(ixs[(size_t)q] == ixs[(size_t)g2]) first = false;
+					if(first && h2g_index_add_splice_sites(ixs[(size_t)g2], delta.data(), delta.size()) != H2G_OK) die("cannot upload the splice sites");
+				}
+				h2g_sam_add_splice_sites(sam, delta.data(), delta.size());
+			}
 		}
 		{ h2g_counters hc; if(h2g_get_counters(st, &hc) == H2G_OK) nsecond += hc.n_second_pass; }
 		nreads += n;

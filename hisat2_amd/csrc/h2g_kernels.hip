@@ -47,6 +47,8 @@ struct h2g_index {
 	std::vector<h2g_splice_site> alt_sites;               // splice-site ALTs of a --ss index: part of every database (SpliceSiteDB::read(gfm, alts))
 	DSpliceDB dssdb;                                       // h2g_index_set_splice_sites (device arrays; freed and replaced on every call)
 	void* d_ssdb[4] = {nullptr, nullptr, nullptr, nullptr};
+	size_t ssdb_cap[4] = {0, 0, 0, 0};                     // bytes behind each (they grow by doubling: temporary splice sites arrive wave after wave)
+	HostSpliceDB h_ssdb;                                   // the host copy h2g_index_add_splice_sites merges into
 	const float* d_spl[3] = {nullptr, nullptr, nullptr};   // SpliceSiteDB::probscore tables (donor, acceptor halves), uploaded with the index
 	std::vector<DLocalDesc> h_ldesc;   // host copy of the local-index descriptors (bucketing of h2g_ext_search)
 	std::vector<void*> allocs;
@@ -222,12 +224,37 @@ extern "C" h2g_status h2g_index_get_info(const h2g_index* ix, h2g_index_info* o)
 	return H2G_OK;
 }
 
+static h2g_status upload_splice_db(h2g_index* ix) {
+	const HostSpliceDB& h = ix->h_ssdb;
+	const uint32_t window = ix->dssdb.window;
+	ix->dssdb = DSpliceDB();
+	ix->dssdb.window = window;
+	if(h.fw.empty()) return H2G_OK;
+	const void* src[4] = {h.fw.data(), h.bw.data(), h.fw_first.data(), h.bw_first.data()};
+	const size_t bytes[4] = {h.fw.size() * sizeof(DSpliceSite), h.bw.size() * sizeof(DSpliceSite), h.fw_first.size() * 4, h.bw_first.size() * 4};
+	for(int k = 0; k < 4; k++) {
+		if(ix->ssdb_cap[k] < bytes[k]) {
+			if(ix->d_ssdb[k]) (void)hipFree(ix->d_ssdb[k]);
+			ix->d_ssdb[k] = nullptr; ix->ssdb_cap[k] = 0;
+			const size_t cap = bytes[k] * 2 < 4096 ? 4096 : bytes[k] * 2;
+			HIPCHK(hipMalloc(&ix->d_ssdb[k], cap));
+			ix->ssdb_cap[k] = cap;
+		}
+		HIPCHK(hipMemcpy(ix->d_ssdb[k], src[k], bytes[k], hipMemcpyHostToDevice));
+	}
+	ix->dssdb.fw = (const DSpliceSite*)ix->d_ssdb[0]; ix->dssdb.bw = (const DSpliceSite*)ix->d_ssdb[1];
+	ix->dssdb.fw_first = (const uint32_t*)ix->d_ssdb[2]; ix->dssdb.bw_first = (const uint32_t*)ix->d_ssdb[3];
+	ix->dssdb.n = (uint32_t)h.fw.size();
+	return H2G_OK;
+}
+
 extern "C" h2g_status h2g_index_set_splice_sites(h2g_index* ix, const h2g_splice_site* sites, size_t n, uint32_t window) {
 	if(!ix || (n && !sites)) return H2G_ERR_ARG;
 	HIPCHK(hipSetDevice(ix->device));
 	HIPCHK(hipDeviceSynchronize());
-	for(void*& p : ix->d_ssdb) { if(p) (void)hipFree(p); p = nullptr; }
 	ix->dssdb = DSpliceDB();
+	ix->dssdb.window = window;
+	ix->h_ssdb = HostSpliceDB();
 	std::vector<h2g_splice_site> all(ix->alt_sites);      // the index's own sites first: of equal sites the first is kept
 	if(n) all.insert(all.end(), sites, sites + n);
 	// an intron longer than a splice edit holds (20 bits) can never be placed by the aligner (max_intronlen is capped there): such sites
@@ -237,19 +264,24 @@ extern "C" h2g_status h2g_index_set_splice_sites(h2g_index* ix, const h2g_splice
 		return H2G_ERR_UNSUPPORTED;
 	}
 	if(all.empty()) return H2G_OK;
-	HostSpliceDB h;
-	build_splice_db(all.data(), all.size(), ix->host.g.nPat, h);
-	if(h.fw.empty()) return H2G_OK;
-	const void* src[4] = {h.fw.data(), h.bw.data(), h.fw_first.data(), h.bw_first.data()};
-	const size_t bytes[4] = {h.fw.size() * sizeof(DSpliceSite), h.bw.size() * sizeof(DSpliceSite), h.fw_first.size() * 4, h.bw_first.size() * 4};
-	for(int k = 0; k < 4; k++) {
-		HIPCHK(hipMalloc(&ix->d_ssdb[k], bytes[k]));
-		HIPCHK(hipMemcpy(ix->d_ssdb[k], src[k], bytes[k], hipMemcpyHostToDevice));
+	build_splice_db(all.data(), all.size(), ix->host.g.nPat, ix->h_ssdb);
+	return upload_splice_db(ix);
+}
+
+// The sites met since the last call (or known ones whose smallest read id went down) join the database: a merge into the sorted host
+// copy and one upload into buffers that only ever grow — no sort of everything, no free / malloc per wave of reads.  The caller has
+// nothing in flight on this index (the waves of the temporary-splice-site scheme are synchronous by construction).
+extern "C" h2g_status h2g_index_add_splice_sites(h2g_index* ix, const h2g_splice_site* delta, size_t n) {
+	if(!ix || (n && !delta)) return H2G_ERR_ARG;
+	if(n == 0) return H2G_OK;
+	HIPCHK(hipSetDevice(ix->device));
+	for(size_t i = 0; i < n; i++) if(delta[i].right > delta[i].left && delta[i].right - delta[i].left - 1 > H2G_SPL_MAXLEN) {
+		snprintf(g_err, sizeof g_err, "splice site %u:%u-%u: an intron of more than %u bases", delta[i].tidx, delta[i].left, delta[i].right, (unsigned)H2G_SPL_MAXLEN);
+		return H2G_ERR_UNSUPPORTED;
 	}
-	ix->dssdb.fw = (const DSpliceSite*)ix->d_ssdb[0]; ix->dssdb.bw = (const DSpliceSite*)ix->d_ssdb[1];
-	ix->dssdb.fw_first = (const uint32_t*)ix->d_ssdb[2]; ix->dssdb.bw_first = (const uint32_t*)ix->d_ssdb[3];
-	ix->dssdb.n = (uint32_t)h.fw.size(); ix->dssdb.window = window;
-	return H2G_OK;
+	HIPCHK(hipDeviceSynchronize());
+	merge_splice_db(ix->h_ssdb, delta, n, ix->host.g.nPat);
+	return upload_splice_db(ix);
 }
 
 extern "C" void h2g_index_free(h2g_index* ix) {

@@ -762,6 +762,11 @@ extern "C" void h2g_sam_set_splice_sites(h2g_sam* S, const h2g_splice_site* site
 	S->ssdb_window = window;
 	S->register_sites(sites, n);
 }
+extern "C" void h2g_sam_add_splice_sites(h2g_sam* S, const h2g_splice_site* delta, size_t n) {
+	if(!S || !n) return;
+	h2g::merge_splice_db(S->ssdb, delta, n, (uint32_t)S->refnames.size());
+	S->register_sites(delta, n);
+}
 extern "C" void h2g_sam_set_rna_strandness(h2g_sam* S, int code) { if(S) S->rna_strandness = code; }
 extern "C" void h2g_sam_set_templatelen_adjustment(h2g_sam* S, int on) { if(S) S->tlen_adjust = on != 0; }
 extern "C" void h2g_sam_collect_novel_sites(h2g_sam* S, int on) { if(S) S->collect_novel = on != 0; }

@@ -46,6 +46,68 @@ inline void build_splice_db(const h2g_splice_site* sites, size_t n, uint32_t nPa
 	for(const E& e : u) db.bw.push_back(e.s);
 	db.bw_first = db.fw_first;
 }
+// The database plus `delta` (sites met since the last call, or known ones whose smallest read id went down) in O(sites + delta log delta):
+// what build_splice_db(all the sites in order of first appearance) would give, without sorting everything again per wave of reads.
+// A delta site equal to an existing one in (text, left, right, dir) only lowers that one's read id (SpliceSiteDB::addSpliceSite keeps
+// the smallest id per site, splice_site.cpp:243-276); a site read from a file or the index keeps its id.
+inline void merge_splice_db(HostSpliceDB& db, const h2g_splice_site* delta, size_t d, uint32_t nPat) {
+	if(db.fw_first.size() != (size_t)nPat + 1) { db.fw.clear(); db.bw.clear(); db.fw_first.assign(nPat + 1, 0); db.bw_first.assign(nPat + 1, 0); }
+	struct E { uint32_t tidx; DSpliceSite s; size_t order; };
+	std::vector<E> v;
+	v.reserve(d);
+	for(size_t i = 0; i < d; i++) {
+		if(delta[i].tidx >= nPat) continue;
+		E e; e.tidx = delta[i].tidx; e.order = i;
+		e.s.left = delta[i].left; e.s.right = delta[i].right; e.s.readid = delta[i].readid; e.s.dir = delta[i].dir;
+		e.s.fromfile = delta[i].fromfile; e.s.known = delta[i].known; e.s.pad = 0;
+		v.push_back(e);
+	}
+	if(v.empty()) return;
+	for(int side = 0; side < 2; side++) {
+		// fw: (text, left, right, dir); bw: (text, right, left, dir)
+		auto k1 = [side](const DSpliceSite& x) { return side == 0 ? x.left : x.right; };
+		auto k2 = [side](const DSpliceSite& x) { return side == 0 ? x.right : x.left; };
+		auto less = [&](uint32_t ta, const DSpliceSite& a, uint32_t tb, const DSpliceSite& b) {
+			if(ta != tb) return ta < tb;
+			if(k1(a) != k1(b)) return k1(a) < k1(b);
+			if(k2(a) != k2(b)) return k2(a) < k2(b);
+			return a.dir < b.dir;
+		};
+		std::sort(v.begin(), v.end(), [&](const E& a, const E& b) {
+			if(less(a.tidx, a.s, b.tidx, b.s)) return true;
+			if(less(b.tidx, b.s, a.tidx, a.s)) return false;
+			return a.order < b.order;
+		});
+		std::vector<DSpliceSite>& cur = side == 0 ? db.fw : db.bw;
+		const std::vector<uint32_t>& first = side == 0 ? db.fw_first : db.bw_first;
+		std::vector<DSpliceSite> out;
+		std::vector<uint32_t> nfirst(nPat + 1, 0);
+		out.reserve(cur.size() + v.size());
+		size_t j = 0;
+		for(uint32_t t = 0; t < nPat; t++) {
+			size_t i = first[t];
+			const size_t ie = first[t + 1];
+			const size_t at0 = out.size();
+			while(i < ie || (j < v.size() && v[j].tidx == t)) {
+				const bool have_d = j < v.size() && v[j].tidx == t;
+				if(i < ie && (!have_d || less(t, cur[i], t, v[j].s))) { out.push_back(cur[i++]); continue; }
+				if(i < ie && !less(t, v[j].s, t, cur[i])) {                 // equal keys: the known site stays, its read id may go down
+					DSpliceSite x = cur[i++];
+					while(j < v.size() && v[j].tidx == t && !less(t, x, t, v[j].s)) { if(!x.fromfile && v[j].s.readid < x.readid) x.readid = v[j].s.readid; j++; }
+					out.push_back(x);
+					continue;
+				}
+				DSpliceSite x = v[j++].s;                                  // a new site (of equal new ones the first, with the smallest id)
+				while(j < v.size() && v[j].tidx == t && !less(t, x, t, v[j].s)) { if(!x.fromfile && v[j].s.readid < x.readid) x.readid = v[j].s.readid; j++; }
+				out.push_back(x);
+			}
+			nfirst[t + 1] = (uint32_t)(out.size() - at0);
+		}
+		for(uint32_t t = 0; t < nPat; t++) nfirst[t + 1] += nfirst[t];
+		cur.swap(out);
+		(side == 0 ? db.fw_first : db.bw_first) = nfirst;
+	}
+}
 // SpliceSiteDB::read(gfm, alts) splice_site.cpp:653-725: the splice-site ALTs of a --ss index enter the database as known sites
 // read from a file (the forward copies only: left < right); joined coordinates become (text, offset), exon flanks = left - 1 / right + 1.
 // `rstarts` = GFM::rstarts() (nFrag triples), `len` = the joined length.

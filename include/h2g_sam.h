@@ -53,6 +53,7 @@ H2G_EXPORT size_t     h2g_sam_read_splice_site_file(const h2g_sam*, const char* 
 /* the splice sites given to h2g_index_set_splice_sites: TLEN of a concordant pair leaves the longest database intron lying between
  * its mates out (AlnRes::setFragmentLength aligner_result.h:1669-1689) */
 H2G_EXPORT void       h2g_sam_set_splice_sites(h2g_sam*, const h2g_splice_site* sites, size_t n, uint32_t window);
+H2G_EXPORT void       h2g_sam_add_splice_sites(h2g_sam*, const h2g_splice_site* delta, size_t n);   /* as h2g_index_add_splice_sites */
 /* --no-templatelen-adjustment (on = 0): setMateParams without the database, TLEN keeps every intron (aln_sink.h:2070-2076) */
 H2G_EXPORT void       h2g_sam_set_templatelen_adjustment(h2g_sam*, int on);
 /* --rna-strandness: 0 unknown (XS:A from the splice directions), 1 F, 2 R, 3 FR, 4 RF (XS:A on every aligned line, sam.h:940-966) */

@@ -461,3 +461,34 @@ void h2gemu_memprof_report(unsigned nreads) {
 #endif
 
 }
+
+// ---- the splice-site database kept up to date wave by wave (merge_splice_db) against the one built from scratch over the same sites
+// in order of first appearance (build_splice_db): `sites` arrive in `nwaves` slices; within a later slice a site may repeat an earlier
+// one with a smaller read id (the caller passes the updated entry, as h2g_cli.cpp does).  Returns the number of differing entries.
+extern "C" uint64_t h2gemu_splice_db_merge_check(const h2g_splice_site* sites, size_t n, uint32_t nPat, uint32_t nwaves) {
+	using namespace h2g;
+	std::vector<h2g_splice_site> seen;                                          // the caller's list: first appearance order, smallest id per temporary site
+	HostSpliceDB inc;
+	uint64_t bad = 0;
+	for(uint32_t w = 0; w < nwaves; w++) {
+		const size_t a = n * w / nwaves, b = n * (w + 1) / nwaves;
+		std::vector<h2g_splice_site> delta;
+		for(size_t i = a; i < b; i++) {
+			const h2g_splice_site& x = sites[i];
+			size_t at = seen.size();
+			for(size_t k = 0; k < seen.size(); k++) if(seen[k].tidx == x.tidx && seen[k].left == x.left && seen[k].right == x.right && seen[k].dir == x.dir) { at = k; break; }
+			if(at == seen.size()) { seen.push_back(x); delta.push_back(x); }
+			else if(!seen[at].fromfile && x.readid < seen[at].readid) { seen[at].readid = x.readid; delta.push_back(seen[at]); }
+		}
+		if(w == 0) build_splice_db(seen.data(), seen.size(), nPat, inc);                 // (h2g_index_set_splice_sites: the whole list)
+		else merge_splice_db(inc, delta.data(), delta.size(), nPat);
+		HostSpliceDB full;
+		build_splice_db(seen.data(), seen.size(), nPat, full);
+		if(inc.fw.size() != full.fw.size() || inc.bw.size() != full.bw.size() || inc.fw_first != full.fw_first || inc.bw_first != full.bw_first) { bad++; continue; }
+		for(size_t k = 0; k < full.fw.size(); k++) {
+			bad += memcmp(&inc.fw[k], &full.fw[k], sizeof(DSpliceSite)) != 0;
+			bad += memcmp(&inc.bw[k], &full.bw[k], sizeof(DSpliceSite)) != 0;
+		}
+	}
+	return bad;
+}

@@ -120,6 +120,10 @@ def test_temporary_splice_sites_command_line(tmp_path, seed, n, P, sub):
     want = SL.body_lines(ref_sam)
     assert diff_lines(SL.body_lines(amd_sam), want) == 0
     assert open(os.path.join(t, "amd.err")).read() == open(os.path.join(t, "ref.err")).read()
+    # the window is the reference's thread count, not this program's: --ss-window 1000 x P with any -p gives the same lines
+    subprocess.run([CLI, "-f", "-p", "1" if seed % 2 else "16", "--ss-window", str(1000 * P), "-x", base, "-U", rfa, "-S", amd_sam + "2"], check=True, stderr=open(os.path.join(t, "amd2.err"), "w"))
+    assert diff_lines(SL.body_lines(amd_sam + "2"), want) == 0
+    assert open(os.path.join(t, "amd2.err")).read() == open(os.path.join(t, "ref.err")).read()
     assert sum(1 for a, b in zip(want, SL.body_lines(nt_sam)) if a != b) > n // 20      # the database matters on this input
 
 
