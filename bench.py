@@ -400,6 +400,8 @@ def extras(a, api, synth, ix_big, local, cache):
                                 "pairs_with_concordant": int(gc_.n_aligned), "second_pass": int(gc_.n_second_pass), "still_flagged": int(gc_.n_overflow)}
         gst.close(); gix.close()
     ix.close()
+    if os.path.exists(builder) and os.path.exists(exe):
+        ex["spliced_pe"] = spliced_leg(a, api, synth, local, cache)
     # Occ-rank micro-kernel at GRCh38 scale: 0.98 GB of synthetic sides, uniform rows, one countBt2Side per query
     for graph, nsides, key in ((False, 15_300_000, "rank_microbench"), (True, 7_650_000, "rank_microbench_graph")):
         rix = api.Index(synth_sides=nsides, seed=SEED, device=local, graph=graph)
@@ -413,6 +415,114 @@ def extras(a, api, synth, ix_big, local, cache):
         rst.close(); rix.close()
         ex[key] = micro
     return ex
+
+
+def spliced_leg(a, api, synth, local, cache):
+    """BASELINE configs[4]'s shape (genome_snp_tran index, paired, the reference's default mode) at E. coli size: a seeded genome with an
+    intron planted about every 1.3 kb, an index built with --snp --ss --exon (a third of the introns as index splice sites), pairs drawn
+    from the spliced transcript.  Two figures: go() with spliced alignment on the device for one resident batch (--no-temp-splicesite:
+    the kernel's own rate and roofline line), and the command line in the default temporary-splice-site mode (waves of 1000 x -p reads,
+    each wave's junctions merged before the next) next to the reference at the same -p, with the SAM bodies compared."""
+    import hashlib
+    import numpy as np
+    exe = os.path.join(REF, "hisat2-align-s")
+    builder = os.path.join(REF, "hisat2-build-s")
+    glen, rdlen, npairs = 4_900_000, 101, 1_000_000
+    rng = np.random.default_rng(SEED + 99)
+    g = rng.integers(0, 4, size=glen, dtype=np.uint8)
+    introns, pos = [], 2000
+    while pos < glen - 12000:
+        L = int(rng.choice([60, 90, 150, 400, 1200, 5000, 9000]))
+        a0, b0 = pos, pos + L
+        kind = int(rng.integers(0, 10))
+        if kind < 8:
+            g[a0:a0 + 2] = [2, 3]; g[b0 - 2:b0] = [0, 2]          # GT..AG
+        elif kind == 8:
+            g[a0:a0 + 2] = [2, 1]; g[b0 - 2:b0] = [0, 2]          # GC..AG
+        introns.append((a0, b0))
+        pos = b0 + int(rng.integers(120, 700))
+    keep = np.ones(glen, dtype=bool)
+    for a0, b0 in introns:
+        keep[a0:b0] = False
+    tx = g[keep]
+    fl = np.maximum(rdlen, rng.normal(280, 40, size=npairs).astype(np.int64))
+    s0 = rng.integers(0, len(tx) - 1000, size=npairs)
+    ar = np.arange(rdlen)
+    left = tx[s0[:, None] + ar]
+    right = (3 - tx[(s0 + fl)[:, None] - 1 - ar])               # reverse complement of the fragment's other end
+    sub = rng.random((npairs, rdlen)) < 0.005
+    left = np.where(sub, (left + rng.integers(1, 4, size=left.shape)) & 3, left).astype(np.uint8)
+    sub = rng.random((npairs, rdlen)) < 0.005
+    right = np.where(sub, (right + rng.integers(1, 4, size=right.shape)) & 3, right).astype(np.uint8)
+    flip = rng.random(npairs) < 0.5
+    m1 = np.where(flip[:, None], right, left)
+    m2 = np.where(flip[:, None], left, right)
+    d = os.path.join(cache, f"spl{glen}_s{SEED}")
+    base = os.path.join(d, "g")
+    if not os.path.exists(base + ".8.ht2"):
+        os.makedirs(d, exist_ok=True)
+        synth.write_fasta(base + ".fa", [g], names=["chr1"])
+        with open(base + ".ss", "w") as f:
+            for a0, b0 in introns[::3]:
+                f.write("chr1\t%d\t%d\t+\n" % (a0 - 1, b0))
+        with open(base + ".exon", "w") as f:
+            prev = 0
+            for a0, b0 in introns:
+                f.write("chr1\t%d\t%d\n" % (max(prev, a0 - 400), a0 - 1)); prev = b0
+        synth.write_snps(base + ".snp", synth.make_snps([g], SEED + 5, every=400, names=["chr1"]))
+        subprocess.run([builder, "-q", "-p", str(min(os.cpu_count() or 1, 64)), "--snp", base + ".snp", "--ss", base + ".ss", "--exon", base + ".exon", base + ".fa", base],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    leg = {"workload": f"configs[4] shape at E. coli size: --snp --ss --exon index over a {glen} bp genome with {len(introns)} planted introns, {npairs} x 2 x {rdlen} bp pairs from the spliced transcript",
+           "pairs": npairs, "introns": len(introns)}
+    # (1) the device alone: one resident batch, spliced alignment, no temporary sites
+    ix = api.Index(base, device=local)
+    c1, o1 = synth.flatten_reads(m1)
+    c2, o2 = synth.flatten_reads(m2)
+    q = [str(i) for i in range(npairs)]
+    st = api.Stream(ix, max_reads=npairs, max_bases=c1.size)
+    st.set_reads(c1, o1); st.set_read_names(q); st.set_mates(c2, o2, q)
+    p = st.align_params()
+    p.no_spliced_alignment = 0; p.no_temp_splicesite = 1
+    st.align_pairs_run(p); st.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        st.align_pairs_run(p)
+    st.sync()
+    dt = (time.perf_counter() - t0) / 3
+    c = st.counters()
+    alg = (int(c.n_rank) + int(c.n_sa_steps)) * 128                           # graph sides are 128 B lines, one per rank query / walk step (the graph units count ranks)
+    leg["device_no_temp_splicesite"] = {"ms_per_step": dt * 1e3, "reads_per_s": 2 * npairs / dt, "kernel_ms": float(c.ms_align_kernel), "pairs_with_concordant": int(c.n_aligned),
+                                        "second_pass": int(c.n_second_pass), "still_flagged": int(c.n_overflow), "ranks_per_pair": int(c.n_rank) / npairs,
+                                        "sa_steps_per_pair": int(c.n_sa_steps) / npairs,
+                                        "roofline": {"bound": "hbm", "kernel": "k_go<true> spliced unit (h2g_go_kernels.h)", "achieved": alg / (float(c.ms_align_kernel) * 1e-3) / 1e9,
+                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (float(c.ms_align_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    st.close(); ix.close()
+    # (2) the command line in the reference's default mode against the reference at the same -p
+    tmp = tempfile.mkdtemp(prefix="h2benchspl")
+    ncli = npairs
+    f1, f2 = os.path.join(tmp, "r1.fa"), os.path.join(tmp, "r2.fa")
+    synth.write_reads_fasta(f1, m1[:ncli]); synth.write_reads_fasta(f2, m2[:ncli])
+    P = 16
+    cli = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+    t0 = time.perf_counter()
+    subprocess.run([cli, "-f", "-p", str(P), "-x", base, "-1", f1, "-2", f2, "-S", os.path.join(tmp, "amd.sam")], check=True, stderr=subprocess.DEVNULL)
+    t_amd = time.perf_counter() - t0
+    leg["default_mode_command_line"] = {"pairs": ncli, "p": P, "window_reads": 1000 * P, "wall_s": t_amd, "reads_per_s_wall": 2 * ncli / t_amd}
+    t0 = time.perf_counter()                                                  # the window is the reference's -p, not this program's: 64 000 reads == hisat2 -p 64
+    subprocess.run([cli, "-f", "-p", str(P), "--ss-window", "64000", "-x", base, "-1", f1, "-2", f2, "-S", os.path.join(tmp, "amd64.sam")], check=True, stderr=subprocess.DEVNULL)
+    t_amd64 = time.perf_counter() - t0
+    leg["default_mode_command_line_window_64000"] = {"pairs": ncli, "wall_s": t_amd64, "reads_per_s_wall": 2 * ncli / t_amd64}
+    if not a.no_cpu_baseline:
+        t0 = time.perf_counter()
+        subprocess.run([exe, "-f", "-p", str(P), "--reorder", "-x", base, "-1", f1, "-2", f2, "-S", os.path.join(tmp, "ref.sam")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_ref = time.perf_counter() - t0
+        same = hashlib.md5("".join(body(os.path.join(tmp, "amd.sam"))).encode()).hexdigest() == hashlib.md5("".join(body(os.path.join(tmp, "ref.sam"))).encode()).hexdigest()
+        leg["default_mode_command_line"].update({"reference_wall_s": t_ref, "reference_reads_per_s_wall": 2 * ncli / t_ref,
+                                                 "sam_identical_to": f"hisat2-align-s -p {P} --reorder" if same else None})
+        if not same:
+            raise SystemExit("bench.py: the spliced leg's SAM differs from the reference's")
+    shutil.rmtree(tmp, ignore_errors=True)
+    return leg
 
 
 if __name__ == "__main__":
