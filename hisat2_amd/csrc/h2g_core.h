@@ -195,6 +195,31 @@ struct SeqView {
 		if(q == nullptr) return 'I';
 		return fw ? q[i] : q[len - 1 - i];
 	}
+	// 32 bases of this strand's view from position i (packed reads without N only), base j at bits 2j .. 2j + 1; what lies past the
+	// read's end is not meaningful (the caller masks).  The word-wise comparison loops of h2g_fast.h read the read this way.
+	H2G_HD uint64_t pk64(uint32_t w) const {              // packed words w, w + 1 (16 bases each)
+		const uint32_t a = w < H2G_PK_WORDS ? pk[w * pk_stride] : 0u, b = w + 1 < H2G_PK_WORDS ? pk[(w + 1) * pk_stride] : 0u;
+		return (uint64_t)a | (uint64_t)b << 32;
+	}
+	H2G_HD uint64_t fwd_chunk32(uint32_t j) const {       // read positions j .. j + 31, forward strand
+		const uint32_t w = j >> 4, sh = (j & 15u) * 2u;
+		const uint64_t lo = pk64(w);
+		if(sh == 0) return lo;
+		const uint32_t c = w + 2 < H2G_PK_WORDS ? pk[(w + 2) * pk_stride] : 0u;
+		return (lo >> sh) | ((uint64_t)c << (64u - sh));
+	}
+	H2G_HD uint64_t chunk32(uint32_t i) const {
+		if(fw) return fwd_chunk32(i);
+		// view position i + j is the complement of read position len - 1 - i - j: the forward chunk ending at p = len - 1 - i, reversed
+		const uint32_t p = len - 1 - i;
+		uint64_t g = p >= 31 ? fwd_chunk32(p - 31) : fwd_chunk32(0) << ((31u - p) * 2u);
+		g = ((g >> 2) & 0x3333333333333333ull) | ((g & 0x3333333333333333ull) << 2);      // reverse the order of the 32 two-bit groups
+		g = ((g >> 4) & 0x0f0f0f0f0f0f0f0full) | ((g & 0x0f0f0f0f0f0f0f0full) << 4);
+		g = ((g >> 8) & 0x00ff00ff00ff00ffull) | ((g & 0x00ff00ff00ff00ffull) << 8);
+		g = ((g >> 16) & 0x0000ffff0000ffffull) | ((g & 0x0000ffff0000ffffull) << 16);
+		g = (g >> 32) | (g << 32);
+		return ~g;                                         // 3 - c
+	}
 };
 
 H2G_HD SeqView seq_view(const DReads& r, uint32_t read, bool fw) {
@@ -527,6 +552,23 @@ struct RefCursor {
 		const uint64_t blk = bo >> 5;
 		if(blk != cblk) { memcpy(&cw, r->buf + blk * 8, 8); cblk = blk; }   // buf is 256 B-aligned and padded
 		return (int)((cw >> ((bo & 31) << 1)) & 3);
+	}
+	// true: [pos, pos + n) lies inside one stretch of unambiguous bases (the cursor then stands on it)
+	H2G_HD bool covers(int64_t pos, uint32_t n) {
+		if(pos < lo || pos >= hi) locate(pos);
+		return inrec && pos + (int64_t)n <= hi;
+	}
+	// 32 bases from pos (inside the stretch the cursor stands on), base j at bits 2j .. 2j + 1; bases past the stretch are not meaningful.
+	// (buf is padded by 16 bytes: the second word is always readable)
+	H2G_HD uint64_t chunk32(int64_t pos) const {
+		const uint64_t bo = (uint64_t)bufbase + (uint64_t)(pos - lo);
+		const uint64_t blk = bo >> 5;
+		const uint32_t sh = (uint32_t)(bo & 31) * 2u;
+		uint64_t w0, w1;
+		memcpy(&w0, r->buf + blk * 8, 8);
+		if(sh == 0) return w0;
+		memcpy(&w1, r->buf + blk * 8 + 8, 8);
+		return (w0 >> sh) | (w1 << (64u - sh));
 	}
 };
 

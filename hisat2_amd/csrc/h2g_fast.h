@@ -312,6 +312,13 @@ H2G_HD void fh_calc_score(const DScoring& sc, const SeqView& seq, FHit& h) {
 	if(score < -(1 << 30)) { h.bad = 1; score = -(1 << 30); }
 	h.score = (int32_t)score;
 }
+// positions (bit 2j = position j, j < n <= 32) at which two 2-bit strings differ
+H2G_HD uint64_t fh_diff32(uint64_t r, uint64_t q, uint32_t n) {
+	const uint64_t x = r ^ q;
+	uint64_t m = (x | (x >> 1)) & 0x5555555555555555ull;
+	if(n < 32u) m &= (1ull << (2u * n)) - 1ull;
+	return m;
+}
 // alignWithALTs without ALTs (align_no_alts of h2g_core.h; hi_aligner.h:683-783, :2763-2853, :3168-3216): extends by up to `mm`
 // mismatches; the new edits are committed to the hit.  Returns the extension length.
 H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdoff, uint32_t rdoff, uint32_t rdlen, int rfoff, uint32_t rflen,
@@ -333,7 +340,46 @@ H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdof
 		RefCursor rc;
 		rc.init(&ref, h.tidx);
 		const uint32_t rdoff_add = rdoff - base_rdoff;
-		if(left) {
+		// 32 bases per step where the window lies inside one stretch of unambiguous reference bases (nearly always): the two 2-bit strings
+		// are XORed word-wise and only the mismatches are visited, in the order the base-by-base loops below meet them
+		const uint32_t limit = left ? (rflen < rdoff + 1 ? rflen : rdoff + 1) : (rflen < rdlen ? rflen : rdlen);
+		const bool wordwise = seq.pk != nullptr && seq.pk_nomask && limit > 0 && rc.covers(left ? (int64_t)rfoff + rflen - limit : (int64_t)rfoff, limit);
+		if(wordwise && left) {
+			uint32_t k0 = 0;
+			bool stop = false;
+			while(k0 < limit && !stop) {
+				uint32_t n = limit - k0 < 32u ? limit - k0 : 32u;
+				const uint32_t a = rdoff - k0 - n + 1;                               // the chunk's first view position (ascending inside the chunk)
+				const uint64_t R = rc.chunk32((int64_t)rfoff + rflen - k0 - n), Q = seq.chunk32(a);
+				uint64_t M = fh_diff32(R, Q, n);
+				while(M) {
+					const uint32_t j = (63u - (uint32_t)__builtin_clzll(M)) >> 1;     // the mismatch met first going left
+					if(tmp_mm >= mm) { n = n - 1 - j; stop = true; break; }
+					if(tmp_mm < FG_FE) nw |= (uint64_t)FE_MAKE_BP(a + j, (uint32_t)(R >> (2u * j)) & 3u, (uint32_t)(Q >> (2u * j)) & 3u, H2G_EDIT_MM) << (16u * tmp_mm);
+					tmp_mm++;
+					M &= ~(3ull << (2u * j));
+				}
+				k0 += n;
+			}
+			if(k0 > 0) { updated = true; extlen = k0; if(numNs) *numNs = 0; }
+		} else if(wordwise) {
+			uint32_t i = 0;
+			bool stop = false;
+			while(i < limit && !stop) {
+				uint32_t n = limit - i < 32u ? limit - i : 32u;
+				const uint64_t R = rc.chunk32((int64_t)rfoff + i), Q = seq.chunk32(rdoff + i);
+				uint64_t M = fh_diff32(R, Q, n);
+				while(M) {
+					const uint32_t j = (uint32_t)__builtin_ctzll(M) >> 1;
+					if(tmp_mm >= mm) { n = j; stop = true; break; }
+					if(tmp_mm < FG_FE) nw |= (uint64_t)FE_MAKE_BP(i + j + rdoff_add, (uint32_t)(R >> (2u * j)) & 3u, (uint32_t)(Q >> (2u * j)) & 3u, H2G_EDIT_MM) << (16u * tmp_mm);
+					tmp_mm++;
+					M &= M - 1;
+				}
+				i += n;
+			}
+			if(i > 0) { updated = true; extlen = i; }
+		} else if(left) {
 			int i = (int)rdoff;
 			for(int rf_i = (int)rflen - 1; rf_i >= 0 && i >= 0; rf_i--, i--) {
 				const int64_t p = (int64_t)rfoff + rf_i;
@@ -498,7 +544,19 @@ H2G_HD bool fh_combine(const DRef& ref, const DScoring& sc, const SeqView& seq, 
 		RefCursor rc1;
 		rc1.init(&ref, a.tidx);
 		const uint32_t addoff = this_rdoff - a.rdoff;
-		for(uint32_t i = 0; i < len; i++) {
+		if(seq.pk != nullptr && seq.pk_nomask && len > 0 && rc1.covers((int64_t)this_toff, len)) {   // word-wise, as in fh_align
+			for(uint32_t i = 0; i < len && !a.bad; i += 32) {
+				const uint32_t n = len - i < 32u ? len - i : 32u;
+				const uint64_t R = rc1.chunk32((int64_t)this_toff + i), Q = seq.chunk32(this_rdoff + i);
+				uint64_t M = fh_diff32(R, Q, n);
+				while(M) {
+					const uint32_t j = (uint32_t)__builtin_ctzll(M) >> 1;
+					if(a.nedits >= FG_FE || i + j + addoff > 255) { a.bad = 1; break; }
+					FE_SET(a, a.nedits, FE_MAKE_BP(i + j + addoff, (uint32_t)(R >> (2u * j)) & 3u, (uint32_t)(Q >> (2u * j)) & 3u, H2G_EDIT_MM)); a.nedits++;
+					M &= M - 1;
+				}
+			}
+		} else for(uint32_t i = 0; i < len; i++) {
 			const int rdc = seq.at(this_rdoff + i), rfc = rc1.get((int64_t)this_toff + i);
 			if(rdc != rfc) {
 				if(a.nedits >= FG_FE || i + addoff > 255) { a.bad = 1; break; }
