@@ -571,7 +571,15 @@ int main(int argc, char** argv) {
 	std::vector<h2g_alnres> aln, aln2;
 	std::vector<uint64_t> ao1, ao2;
 	std::string ovf_names;
-	auto want = [&]() { const size_t w = (size_t)std::min<uint64_t>(batch, budget); return w; };
+	// Temporary splice sites on G devices: a wave of W reads is cut into G shards that run side by side — a read never sees the junctions of
+	// its own wave (readid + W > its id), so the shards need nothing from one another; every shard's junctions join the database (on every
+	// device) before the next wave starts (the exchange between two waves is the junction list, tens of bytes per site).
+	size_t wave_left = ss_window;                         // reads the current wave still takes
+	auto want = [&]() {
+		size_t w = (size_t)std::min<uint64_t>(batch, budget);
+		if(temp_ss) { const size_t shard = (ss_window + (size_t)gpus - 1) / (size_t)gpus; w = std::min(w, std::min(shard, wave_left)); }
+		return w;
+	};
 	// fetch + format + write the batch that stream `g` carries
 	auto complete = [&](int g) {
 		Str& sg = S[(size_t)g];
@@ -668,8 +676,10 @@ int main(int argc, char** argv) {
 		if(n == 0) break;
 		const int g = (int)(k % G);
 		const double tg = now();
-		if(temp_ss) {                                  // a wave needs the sites of every earlier one: nothing stays in flight
-			for(long q = k - G; q < k; q++) if(q >= 0) complete((int)(q % G));
+		if(temp_ss) {                                  // a wave needs the sites of every earlier one: nothing of them stays in flight when it starts
+			if(wave_left == ss_window) for(long q = k - G; q < k; q++) if(q >= 0) complete((int)(q % G));
+			wave_left -= n;
+			if(wave_left == 0) wave_left = ss_window;
 		}
 		complete(g);                                   // the batch this stream still carries (k - G): the oldest one in flight
 		Str& sg = S[(size_t)g];

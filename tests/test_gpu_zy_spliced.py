@@ -124,6 +124,11 @@ def test_temporary_splice_sites_command_line(tmp_path, seed, n, P, sub):
     subprocess.run([CLI, "-f", "-p", "1" if seed % 2 else "16", "--ss-window", str(1000 * P), "-x", base, "-U", rfa, "-S", amd_sam + "2"], check=True, stderr=open(os.path.join(t, "amd2.err"), "w"))
     assert diff_lines(SL.body_lines(amd_sam + "2"), want) == 0
     assert open(os.path.join(t, "amd2.err")).read() == open(os.path.join(t, "ref.err")).read()
+    # --gpus 2: every wave is cut into two shards that run side by side (here on the one device), their junctions merged before the next wave
+    subprocess.run([CLI, "-f", "-p", str(P), "--gpus", "2", "-x", base, "-U", rfa, "-S", amd_sam + "3"], check=True, stderr=open(os.path.join(t, "amd3.err"), "w"),
+                   env=dict(os.environ, H2G_GPUS_SHARE_DEVICE="1"))
+    assert diff_lines(SL.body_lines(amd_sam + "3"), want) == 0
+    assert open(os.path.join(t, "amd3.err")).read() == open(os.path.join(t, "ref.err")).read()
     assert sum(1 for a, b in zip(want, SL.body_lines(nt_sam)) if a != b) > n // 20      # the database matters on this input
 
 

@@ -23,10 +23,7 @@ def body_md5(path):
     return h.hexdigest()
 
 
-variants = [("old", exes[0], {}, True)] if len(exes) > 1 else []
-new = exes[-1]
-variants += [("new async pinned", new, {}, True), ("new async pageable", new, {"H2G_CLI_PINNED": "0"}, False), ("new inline pinned", new, {"H2G_CLI_ASYNC": "0"}, False),
-             ("new inline pageable", new, {"H2G_CLI_ASYNC": "0", "H2G_CLI_PINNED": "0"}, False)]
+variants = [(os.path.basename(e), e, {}, True) for e in exes]
 for name, exe, env, check in variants:
     for dest in (os.path.join(tmp, "o.sam"), "/dev/null"):
         t0 = time.perf_counter()
