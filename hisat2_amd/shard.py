@@ -36,3 +36,34 @@ def all_reduce_sum(arr: np.ndarray, dist=None, device=None):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def all_gather_junctions(sites: np.ndarray, dist=None, device=None):
+    """Spliced alignment with temporary splice sites, sharded (hisat2.cpp:3687, splice_site.cpp:190-347): a wave of W reads
+    is cut into one shard per rank — a read never sees the junctions of its own wave — and between two waves every rank needs every
+    shard's new junctions.  `sites`: this rank's [k, 5] int64 rows (text, left, right, dir, read id).  Returns the rows of all ranks
+    concatenated in rank order (= read-id order of the shards); the caller merges them into its database keeping the smallest read id
+    per (text, left, right, dir), which is what SpliceSiteDB::addSpliceSite does whatever the arrival order.  Two collectives: the row
+    counts, then the padded rows (tens of bytes per junction)."""
+    sites = np.ascontiguousarray(sites, dtype=np.int64).reshape(-1, 5)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return sites
+    import torch
+    world = dist.get_world_size()
+    cnt = torch.tensor([sites.shape[0]], dtype=torch.int64)
+    if device is not None:
+        cnt = cnt.to(device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts) if counts else 0
+    if m == 0:
+        return sites
+    pad = np.zeros((m, 5), dtype=np.int64)
+    pad[:sites.shape[0]] = sites
+    t = torch.from_numpy(pad)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)], axis=0)

@@ -22,9 +22,12 @@ from hisat2_amd import api, synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def wave_run(base, reads, names, P, formatter, file_sites=()):
+def wave_run(base, reads, names, P, formatter, file_sites=(), rank=0, world=1, exchange=None):
     """formatter(lo, hi, outs, recs, sites_array, nsites, W) -> (lines, novel api.SpliceSite list); returns all lines.
-    file_sites: (tidx, left, right, '+'/'-') of a --known-splicesite-infile — always visible, never replaced by a read's"""
+    file_sites: (tidx, left, right, '+'/'-') of a --known-splicesite-infile — always visible, never replaced by a read's.
+    world > 1: this process runs shard `rank` of every wave (hisat2_amd.shard.shard_range inside the wave) and exchange(rows) returns
+    every rank's new junctions (shard.all_gather_junctions); the lines returned are this rank's, wave by wave: [(wave, lines), ...]"""
+    from hisat2_amd import shard
     W = 1000 * P if P > 1 else 0                    # -p 1: window 0, every read sees all the reads before it (hisat2.cpp:3687)
     step = W if W else 1
     db = {}                                          # (tidx, left, right, dir) -> smallest read id, in first-seen order
@@ -32,8 +35,12 @@ def wave_run(base, reads, names, P, formatter, file_sites=()):
     for t, l, r, d in file_sites:
         fixed.setdefault((t, l, r, 2 if d == "+" else 3), None)
     lines = []
-    for lo in range(0, len(reads), step):
-        hi = min(len(reads), lo + step)
+    for wave, wlo in enumerate(range(0, len(reads), step)):
+        whi = min(len(reads), wlo + step)
+        lo, hi = wlo, whi
+        if world > 1:
+            a, b = shard.shard_range(whi - wlo, rank, world)
+            lo, hi = wlo + a, wlo + b
         nall = len(fixed) + len(db)
         arr = (api.SpliceSite * max(1, nall))()
         for k, (t, l, r, d) in enumerate(fixed):
@@ -42,7 +49,12 @@ def wave_run(base, reads, names, P, formatter, file_sites=()):
             arr[k].tidx, arr[k].left, arr[k].right, arr[k].readid, arr[k].dir, arr[k].fromfile, arr[k].known = t, l, r, rid, d, 0, 0
         outs, recs = emu_align(base, reads[lo:hi], names[lo:hi], no_spliced=0, splice_sites=(arr, nall) if nall else None, window=W, rdid_base=lo)
         got, novel = formatter(lo, hi, outs, recs, arr, nall, W)
-        lines += got
+        if world > 1:
+            lines.append((wave, got))
+            rows = exchange(np.array([(s.tidx, s.left, s.right, s.dir, s.readid) for s in novel], dtype=np.int64).reshape(-1, 5))
+            novel = [api.SpliceSite(tidx=int(r[0]), left=int(r[1]), right=int(r[2]), dir=int(r[3]), readid=int(r[4])) for r in rows]
+        else:
+            lines += got
         for s in novel:
             key = (s.tidx, s.left, s.right, s.dir)
             if key in fixed:
