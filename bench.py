@@ -92,6 +92,21 @@ def reference_pairs(base, m1, m2, opts, threads, sam_path=None, upto=None):
     return time.perf_counter() - t0
 
 
+def host_cpu_limits():
+    """what bounds the reference's thread scaling on this box besides its own locks: the affinity mask and the cgroup CPU quota"""
+    lim = {"sched_affinity": len(os.sched_getaffinity(0))}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            lim[path] = open(path).read().strip()
+        except OSError:
+            pass
+    try:
+        lim["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except OSError:
+        pass
+    return lim
+
+
 def body(path):
     return [l for l in open(path) if not l.startswith("@")]
 
@@ -286,7 +301,7 @@ def main():
                 t_run = max(reference_pairs(base, f1, f2, [], best[1], upto=best[4]) - best[3], 1e-6)
                 reps.append(2 * best[4] / t_run)
             med = sorted(reps)[len(reps) // 2]
-            out["cpu_baseline"] = {"value": med, "unit": "reads/s", "cores": best[1], "kind": "reference", "host_cpus": ncpu,
+            out["cpu_baseline"] = {"value": med, "unit": "reads/s", "cores": best[1], "kind": "reference", "host_cpus": ncpu, "host_cpu_limits": host_cpu_limits(),
                                    "reads_per_s_per_core_at_1_thread": scan.get("1", {}).get("reads_per_s_per_core"), "repeats_at_best_width": reps,
                                    "threads_scan": scan,
                                    "sample": f"first {best[4]} pairs of the bench batch, oracle/_ref/hisat2-align-s -p {best[1]} --no-spliced-alignment -S /dev/null on the same "
