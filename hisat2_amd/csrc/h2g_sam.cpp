@@ -390,7 +390,11 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	static thread_local Stacked st;                       // scratch reused across lines (no per-line allocations)
 	static thread_local std::string seq, qual;
 	seq_ascii(rd, rs == nullptr || rs->fw, seq, qual);
-	if(rs) stack_alignment(*rs, seq, st);
+	// an alignment whose edits are all mismatches (nearly every line) needs no stacked form: its CIGAR is one M run between the soft
+	// clips and its MD:Z follows from the mismatch positions; what buildCigar / buildMdz would make of the stacked strings is written directly
+	bool simple = rs != nullptr;
+	if(rs) for(uint32_t i = 0; i < rs->nedits; i++) if(rs->edits[i].type != EDIT_MM) { simple = false; break; }
+	if(rs && !simple) stack_alignment(*rs, seq, st);
 	if(rs && S.collect_novel && tl_novel) add_splice_sites(*rs, rd.len, tl_rdid, *tl_novel);
 	put_read_name(o, rd, fl.partOfPair());
 	o.push_back('\t');
@@ -417,7 +421,11 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	if(rs) put(o, mapq_v2(S, summ, fl.pairing == PAIR_UNPAIRED || fl.readMate1(), rd.len, rdo ? rdo->len : 0));
 	else o.push_back('0');
 	o.push_back('\t');
-	if(rs) write_cigar(st, o); else o.push_back('*');
+	if(rs && simple) {
+		if(rs->trim5 > 0) { put(o, rs->trim5); o.push_back('S'); }
+		put(o, (int64_t)(rd.len - rs->trim5 - rs->trim3)); o.push_back('M');
+		if(rs->trim3 > 0) { put(o, rs->trim3); o.push_back('S'); }
+	} else if(rs) write_cigar(st, o); else o.push_back('*');
 	o.push_back('\t');
 	if(rs && fl.partOfPair()) {                                         // RNEXT
 		if(rso && rs->tidx != rso->tidx) put_ref_name(o, S.refnames[rso->tidx]); else o.push_back('=');
@@ -467,7 +475,19 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	o += "\tXO:i:"; put(o, (int64_t)num_go);
 	o += "\tXG:i:"; put(o, (int64_t)num_gx);
 	o += "\tNM:i:"; put(o, (int64_t)NM);
-	o += "\tMD:Z:"; write_mdz(st, o);
+	o += "\tMD:Z:";
+	if(simple) {   // writeMdz over '=' runs and 'X' cells only: a run length (0 between two mismatches and at either end), then the reference base
+		const uint32_t lt = rd.len - rs->trim5 - rs->trim3;
+		uint32_t at = 0;                                               // the next position of the aligned strand not yet accounted for
+		for(uint32_t k = 0; k < rs->nedits; k++) {
+			const h2g_edit& e = rs->edits[rs->fw ? k : rs->nedits - 1 - k];
+			const uint32_t pos = rs->fw ? e.pos : lt - 1 - e.pos;
+			if(pos > at) put(o, (int64_t)(pos - at)); else o.push_back('0');
+			o.push_back((char)e.chr);
+			at = pos + 1;
+		}
+		if(lt > at) put(o, (int64_t)(lt - at)); else o.push_back('0');
+	} else write_mdz(st, o);
 	if(summ.paired && rso) { o += "\tYS:i:"; put(o, rso->score); }
 	o += "\tYT:Z:";
 	o += fl.concordant() ? "CP" : fl.discordant() ? "DP" : fl.unpairedMate() ? "UP" : "UU";
