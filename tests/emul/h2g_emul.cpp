@@ -492,3 +492,40 @@ extern "C" uint64_t h2gemu_splice_db_merge_check(const h2g_splice_site* sites, s
 	}
 	return bad;
 }
+
+// ---- the 32-base chunk accessors of the word-wise comparison loops (SeqView::chunk32, RefCursor::chunk32) against the base-by-base
+// accessors they stand in for: every view position of every read on both strands, and `nref` seeded reference positions per contig.
+// Returns the number of differing bases.
+extern "C" uint64_t h2gemu_chunk_check(Emu* e, uint32_t nref, uint64_t seed) {
+	using namespace h2g;
+	uint64_t bad = 0;
+	DReads rd = e->reads();
+	for(uint32_t i = 0; i < rd.n; i++) {
+		uint32_t pk[H2G_PK_WORDS];
+		if(!fg_pack_read(rd, i, pk, 1)) continue;
+		for(int fw = 0; fw < 2; fw++) {
+			SeqView plain = seq_view(rd, i, fw != 0);
+			SeqView packed = plain;
+			packed.pk = pk; packed.pk_stride = 1; packed.pk_nomask = true;
+			for(uint32_t p = 0; p < plain.len; p++) {
+				const uint64_t c = packed.chunk32(p);
+				for(uint32_t j = 0; j < 32 && p + j < plain.len; j++) bad += (uint32_t)((c >> (2 * j)) & 3) != (uint32_t)plain.at(p + j);
+			}
+		}
+	}
+	uint64_t x = seed * 0x9e3779b97f4a7c15ull + 1;
+	for(uint32_t t = 0; t < e->dr.nrefs; t++) {
+		RefCursor rc, rc2;
+		rc.init(&e->dr, t); rc2.init(&e->dr, t);
+		const uint32_t len = e->dr.refLens[t];
+		for(uint32_t k = 0; k < nref && len > 0; k++) {
+			x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+			const int64_t pos = (int64_t)(x % len);
+			const uint32_t n = 1 + (uint32_t)((x >> 40) % 32);
+			if(!rc.covers(pos, n)) continue;                                   // (touches an ambiguous stretch or the contig's end: the loops take over)
+			const uint64_t c = rc.chunk32(pos);
+			for(uint32_t j = 0; j < n; j++) bad += (int)((c >> (2 * j)) & 3) != rc2.get(pos + j);
+		}
+	}
+	return bad;
+}

@@ -83,3 +83,20 @@ def test_pair_records_beyond_the_rows_go_to_the_overflow_area(genome):
     assert r["mismatching"] == 0 and r["flagged"] == 0 and r["in_area"] > 20, r
     small = FC.pairs_overflow_check(base, list(m1), list(m2), 1, 40)
     assert small["mismatching"] == 0 and small["flagged"] > 0 and small["in_area"] + small["flagged"] == r["in_area"], (small, r)
+
+
+def test_chunk_accessors_equal_the_base_accessors(genome):
+    """SeqView::chunk32 / RefCursor::chunk32 (32 bases per step in extend / combineWith) against SeqView::at / RefCursor::get: every view
+    position of reads of several lengths on both strands, and seeded reference windows incl. those next to N stretches and contig ends"""
+    import ctypes as C
+    from h2gemu_py import Emu
+    base, contigs = genome
+    e = Emu(base)
+    e.L.h2gemu_chunk_check.restype = C.c_uint64
+    e.L.h2gemu_chunk_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    for rdlen in (33, 64, 101, 127, 128):
+        reads, _ = synth.make_reads(contigs, 300, rdlen, 900 + rdlen, sub_rate=0.02)
+        codes = np.concatenate([np.concatenate(list(reads)).astype(np.uint8), np.zeros(8, np.uint8)])
+        offs = (np.arange(len(reads) + 1, dtype=np.uint64) * rdlen).astype(np.uint32)
+        e.set_reads(codes, offs, None)
+        assert e.L.h2gemu_chunk_check(e.h, 20000, rdlen) == 0
