@@ -1,12 +1,11 @@
 // go() fast pass: HI_Aligner::go of the dominant traces with a COMPACT per-read state (h2g_fast.h).
 //
-// Reads in flight are slots of FG_SLOT_WORDS words (672 B: 40 state words, 59 hot words, the packed reads, 52 cold words),
-// contiguous in HBM.  A workgroup owns H2G_FAST_SLOTS of them and keeps, in LDS, one queue of slot ids per request site of the fast
-// machine (primitive + resume pc) plus the free queue.  Each wave loops: pop up to 64 slots of the longest queue, load their state
-// in one go (registers + a per-lane LDS staging area: 30 16-byte loads per lane, no dependent chain), run THAT primitive for all of
-// them at one code site, let every lane run its read's control flow on registers / LDS up to the next request, store the state and
-// push the slot to the queue of what it asked for.  The general machine's 23 scattered workspace lines per trip become 5 sequential
-// ones, and nothing of the control flow waits for HBM.  Reads that leave the fast path go to the general machine's list.
+// Reads in flight are slots of FG_SLOT_WORDS words (about 1 KB: 40 state words, 50 hot words, the packed reads, the cold words), contiguous
+// in HBM.  A workgroup owns H2G_FAST_SLOTS of them and keeps, in LDS, one queue of slot ids per request site of the fast machine
+// (primitive + resume pc) plus the free queue.  Each wave loops: pop up to 64 slots of the longest queue, load their state in one go
+// (registers + a per-lane LDS staging area: 27 16-byte loads per lane, no dependent chain), run THAT primitive for all of them at one
+// code site, let every lane run its read's control flow on registers / LDS up to the next request, store the state and push the slot to
+// the queue of what it asked for.  Reads that leave the fast path go to the general machine's list.
 #include "h2g_go_args.h"
 
 using namespace h2g;
@@ -68,17 +67,6 @@ __device__ __forceinline__ uint32_t fq_pop(FastLds* Q, uint32_t q, int lane, uin
 	return n;
 }
 
-#ifndef H2G_FAST_SPLIT
-#define H2G_FAST_SPLIT 0
-#endif
-#if H2G_FAST_SPLIT
-#define FK_PHASE __device__ __noinline__
-#else
-#define FK_PHASE __device__ __forceinline__
-#endif
-// The two phases of a trip are functions of their own (own register allocation: the primitives need ~90 registers, the control
-// flow ~250; inlined into one kernel body they spilled 220).  Both work on the slot in HBM: the phase loads what it needs, the
-// state goes back to the slot, the caller reads the few words it routes by.
 __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint32_t* sm, FCtx& C, FWords& W) {
 	const bool paired = A->paired != 0;
 	W.hot = (FG_LDS uint32_t*)stage; W.hot_stride = H2G_FAST_THREADS; W.cold = sm + FS_WORDS + FG_STAGE_WORDS;
@@ -90,58 +78,6 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 	C.O = A->O;
 	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
 }
-// one primitive for this lane's slot; its results (and the bail / not-finished marks) go to the slot's state words
-FK_PHASE void fk_exec(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t op) {
-	FCtx C; FWords W;
-	fk_ctx(A, stage, sm, C, W);
-	FState S;
-	uint32_t w[FS_WORDS];
-#pragma unroll
-	for(uint32_t k = 0; k < FS_WORDS; k++) w[k] = 0;
-	const uint4* src = reinterpret_cast<const uint4*>(sm);
-	{ const uint4 v0 = src[0], v1 = src[1], v2 = src[2]; w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w; w[8] = v2.x; w[9] = v2.y; w[10] = v2.z; }
-	w[31] = sm[31];
-	const uint32_t w26 = sm[26], w27 = sm[27];
-	__builtin_memcpy(&S, w, sizeof S);
-	S.nrank = 0; S.nside = 0; S.nsteps = 0;
-	fast_exec(C, S, W, op);
-	const uint32_t nr_ = (w26 & 0xffffu) + S.nrank, ns_ = (w26 >> 16) + S.nside, nt_ = (w27 & 0xffffu) + S.nsteps;
-	if(S.pc != FPC_BAIL && (nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu)) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
-	__builtin_memcpy(w, &S, sizeof S);
-	uint4* dst = reinterpret_cast<uint4*>(sm);
-	dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);   // pc / op / bail, a0 .. a5
-	sm[26] = (nr_ & 0xffffu) | (ns_ << 16); sm[27] = (w27 & 0xffff0000u) | (nt_ & 0xffffu);
-}
-// the control flow of this lane's slot up to its next primitive request (begin != H2G_MAX: the slot takes up read `begin` first).
-// Returns the state's word 0 (pc, op, bail); the whole state is in the slot.
-FK_PHASE uint32_t fk_step(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t begin, uint32_t packed_ok) {
-	FCtx C; FWords W;
-	fk_ctx(A, stage, sm, C, W);
-	FState S;
-	if(begin != H2G_MAX) {
-		const bool paired = A->paired != 0;
-		C.name[0] = A->names1 + A->noffs1[begin]; C.namelen[0] = A->noffs1[begin + 1] - A->noffs1[begin];
-		if(paired) { C.name[1] = A->names2 + A->noffs2[begin]; C.namelen[1] = A->noffs2[begin + 1] - A->noffs2[begin]; }
-		fast_begin(C, S, begin, paired, packed_ok != 0);
-	} else {
-		uint32_t w[FS_WORDS];
-		const uint4* src = reinterpret_cast<const uint4*>(sm);
-#pragma unroll
-		for(uint32_t k = 0; k < FS_WORDS / 4; k++) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-		__builtin_memcpy(&S, w, sizeof S);
-	}
-	if(S.pc != FPC_DONE && S.pc != FPC_BAIL && S.op == FOP_NONE) fast_step(C, S, W);
-	uint32_t w[FS_WORDS];
-	__builtin_memcpy(w, &S, sizeof S);
-	uint4* dst = reinterpret_cast<uint4*>(sm);
-#pragma unroll
-	for(uint32_t k = 0; k < FS_WORDS / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-	return w[0];
-}
-
-#ifndef H2G_FAST_ONESTATE
-#define H2G_FAST_ONESTATE 1
-#endif
 // One trip of this lane's slot with the state in registers from its load to its store: the primitive `op` (FOP_NONE: a slot taking up
 // read `begin`), then the control flow up to the next request.  Returns the state's word 0 (pc, op, bail); the whole state is in the slot.
 __device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t op, uint32_t begin, uint32_t packed_ok) {
@@ -274,12 +210,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 			prof[20 + op] += n; prof[32 + op]++; trip_site = bestq;
 #endif
 			PROF(0);
-#if H2G_FAST_ONESTATE
 			trip_op = op;
-#else
-			if(have) fk_exec(A, stage, sm, op);
-			PROF(3 + op);
-#endif
 		}
 		// ---- control flow of each read up to its next primitive request; then hand the slots on
 		uint32_t nextq = 0;
@@ -287,11 +218,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 		prof[46] += __popcll(__ballot(have)); prof[47]++;
 #endif
 		uint32_t w0 = 0;
-#if H2G_FAST_ONESTATE
 		if(have) w0 = fk_trip(A, stage, sm, trip_op, begin, packed_ok);
-#else
-		if(have) w0 = fk_step(A, stage, sm, begin, packed_ok);
-#endif
 #ifdef H2G_GO_PROF
 		{ const unsigned long long t_ = __builtin_readcyclecounter(); prof_ctl[trip_site & 31] += t_ - tp0; prof_n[trip_site & 31]++; }
 #endif
