@@ -29,6 +29,9 @@ namespace h2g {
 #define FG_FRS    5                     // scalar words of a saved frame
 #define FG_NFRAME 5
 #define FG_NLOCAL 2                     // _local_genomeHits kept per frame
+#ifndef FG_ALIGN_MATE
+#define FG_ALIGN_MATE 0                 // 1: alignMate (hi_aligner.h:5579) in the fast path; 0: such pairs are handed on (the shipped build: DESIGN.md §3.1)
+#endif
 // word store of one read in flight: [0, FW_HOT) is staged in LDS while a wave works on it, [FW_HOT, FW_TOTAL) stays in HBM (coordinate lists,
 // the searched list, everything only reads with a mismatch touch)
 #define FW_LONG   0
@@ -42,7 +45,8 @@ namespace h2g {
 #define FW_CO     (FW_SRCH + 2 * FG_NSRCH * (1 + FG_HW))   // the coordinate list of every frame (frame 0's doubles as getAnchorHits'); before it: (hash, hit) per searched root
 #define FW_FRX    (FW_CO + FG_NFRAME * 3 * FG_NCO)  // frames 1 .. FG_NFRAME - 1: scalars + hit
 #define FW_LH     (FW_FRX + (FG_NFRAME - 1) * (FG_FRS + FG_HW))   // _local_genomeHits of every frame
-#define FW_TOTAL  (FW_LH + FG_NFRAME * FG_NLOCAL * FG_HW)
+#define FW_AM      (FW_LH + FG_NFRAME * FG_NLOCAL * FG_HW)   // alignMate's loop state (4 words; only pairs without a concordant alignment get there)
+#define FW_TOTAL  (FW_AM + 4 * FG_ALIGN_MATE)
 #define FW_COLD   (FW_TOTAL - FW_HOT)
 
 enum : uint32_t { FOP_NONE = 0, FOP_PSEARCH, FOP_GCOORDS, FOP_EXTEND, FOP_LSEARCH, FOP_LCOORDS, FOP_COMBINE, FOP_GSEARCH, FOP_COUNT };
@@ -54,7 +58,8 @@ enum : uint32_t {
 	FPC_L_WHILE, FPC_L_LS_LOOP, FPC_L_LS_AFTER, FPC_L_LS_DONE, FPC_L_LC_AFTER, FPC_L_FOR_RI, FPC_L_RI_B, FPC_L_RI_B2, FPC_L_RI_C, FPC_L_R1,
 	FPC_L_AFTER_FOR, FPC_L_FOR_TI, FPC_L_R2, FPC_L_AFTER_WHILE, FPC_L_GS_AFTER, FPC_L_GC_AFTER, FPC_L_FOR_G, FPC_L_G_B, FPC_L_G_C, FPC_L_R3, FPC_L_TRIM, FPC_L_R4, FPC_L_EXT, FPC_L_EXT_A, FPC_L_R5,
 	FPC_R_WHILE, FPC_R_LS_LOOP, FPC_R_LS_AFTER, FPC_R_LS_DONE, FPC_R_LC_AFTER, FPC_R_FOR_RI, FPC_R_RI_B, FPC_R_RI_C, FPC_R_R1,
-	FPC_R_AFTER_FOR, FPC_R_FOR_TI, FPC_R_R2, FPC_R_AFTER_WHILE, FPC_R_GS_AFTER, FPC_R_GC_AFTER, FPC_R_FOR_G, FPC_R_G_B, FPC_R_G_C, FPC_R_R3, FPC_R_TRIM, FPC_R_R4, FPC_R_EXT, FPC_R_EXT_A, FPC_R_R5
+	FPC_R_AFTER_FOR, FPC_R_FOR_TI, FPC_R_R2, FPC_R_AFTER_WHILE, FPC_R_GS_AFTER, FPC_R_GC_AFTER, FPC_R_FOR_G, FPC_R_G_B, FPC_R_G_C, FPC_R_R3, FPC_R_TRIM, FPC_R_R4, FPC_R_EXT, FPC_R_EXT_A, FPC_R_R5,
+	FPC_MP_LOOP, FPC_AM_WHILE, FPC_AM_INNER, FPC_AM_AFTER_LS, FPC_AM_AFTER_LC, FPC_AM_RI_LOOP, FPC_AM_ADV, FPC_AM_EXT_LOOP, FPC_AM_EXT_AFTER, FPC_AM_REC_AFTER
 };
 
 // why a read left the fast path (statistics only)
@@ -121,7 +126,7 @@ struct FState {
 	int32_t  bestPair, best2Pair;                                                                                                      // 24, 25
 	uint32_t nrank : 16, nside : 16;                                                                                                    // 26
 	uint32_t nsteps : 16, nframes_max : 8, pad27_ : 8;                                                                                  // 27
-	uint32_t nghits : 2, ghit_done : 2, gh_hi : 5, gh_hj : 3, gh_nco : 3, gh_rdoff : 8, hs_hi : 2, hs_hj : 2, pad28_ : 5;                 // 28
+	uint32_t nghits : 2, ghit_done : 2, gh_hi : 5, gh_hj : 3, gh_nco : 3, gh_rdoff : 8, hs_hi : 2, hs_hj : 2, rc_mate : 1, pad28_ : 4;                 // 28
 	uint32_t localindexatts : 16, max_localindexatts : 16;                                                                              // 29
 	int32_t  sp : 4; uint32_t rc_ret_pc : 8, pr_ret_pc : 8, pad30_ : 12;                                                                // 30
 	int32_t  rc_minsc, ret;                                                                                                            // 31, 32
@@ -665,7 +670,7 @@ H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, boo
 	S.rb_cur = S.rb_nps = S.rb_nus = S.rb_np = 0; S.rb_sumsq0 = S.rb_sumsq1 = S.rb_sumsq2 = S.rb_sumsq3 = 0;
 	S.rb_done = S.rb_nonempty = S.found = 0; S.rnd = 0; S.ro0 = S.ro1 = 0; S.rl0 = S.rl1 = 0;
 	S.nres0 = S.nres1 = S.nsearched0 = S.nsearched1 = 0; S.bestUnp0 = S.bestUnp1 = S.best2Unp0 = S.best2Unp1 = F_SMIN16; S.minsc0 = S.minsc1 = F_SMAX16;
-	S.pad23_ = 0; S.pad27_ = 0; S.pad28_ = 0; S.pad30_ = 0; S.pad35_ = 0;
+	S.pad23_ = 0; S.pad27_ = 0; S.pad28_ = 0; S.rc_mate = 0; S.pad30_ = 0; S.pad35_ = 0;
 	S.npairs = S.pairs = S.insp_i = S.insp_j = 0; S.bestPair = S.best2Pair = F_SMIN;
 	S.nrank = S.nside = S.nsteps = S.nframes_max = 0; S.nghits = S.ghit_done = 0; S.localindexatts = S.max_localindexatts = 0;
 	S.ro0 = C.rd[0].offs[read]; S.ro1 = C.rd[1].offs[read];                     // (unpaired: rd[1] is rd[0])
@@ -692,7 +697,15 @@ H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, boo
 		fg_frame_save(W, S); fg_hit_copy(W, fg_frame_hit(S.sp + 1), (HB)); S.sp++; S.f_hitoff = hoff_; S.f_hitlen = hlen_; \
 		if((uint32_t)S.sp + 1 > S.nframes_max) S.nframes_max = (uint32_t)S.sp + 1; \
 		F_GOTO(FPC_RC_ENTRY); } while(0)
+#if FG_ALIGN_MATE
+#define F_CUSHION() (S.rc_mate ? (int32_t)((double)fs_rl(S, S.sv_rdi) * 0.03 * (double)sc.mmpMax) : 0)     /* spliced_aligner.h:363-366 */
+// (with the mate cushion and no alignment of this mate yet the reference computes numeric_limits<TAlScore>::min() - cushion, which wraps
+// to a huge positive score: nothing passes that bar — spliced_aligner.h:960, :1106 as compiled; the general machine does the same in 64 bits)
+#define F_MINSC_LIVE(MV) do { const int32_t c_ = F_CUSHION(), u_ = fs_bestUnp(S, S.sv_rdi); const int32_t b_ = (u_ == F_SMIN16 && c_ > 0) ? 0x7fffffff : u_ - c_; if(b_ > (MV)) (MV) = b_; } while(0)
+#else
+#define F_CUSHION() 0
 #define F_MINSC_LIVE(MV) do { const int32_t b_ = fs_bestUnp(S, S.sv_rdi); if(b_ > (MV)) (MV) = b_; } while(0)
+#endif
 
 H2G_HD void fg_frame_save(const FWords& W, const FState& S) {
 	const uint32_t w0 = (uint32_t)S.f_hitoff | ((uint32_t)S.f_hitlen << 8) | ((uint32_t)S.f_extoff << 16) | ((uint32_t)S.f_extlen << 24);
@@ -914,9 +927,165 @@ again:
 	}
 	case FPC_AFTER_LOOP: {
 		// no concordant pair but an aligned mate: alignMate (hi_aligner.h:4092-4148) is the general machine's
-		if(S.paired && S.npairs == 0 && ((S.bestUnp0 != F_SMIN16 && S.bestUnp0 >= S.minsc0) || (S.bestUnp1 != F_SMIN16 && S.bestUnp1 >= S.minsc1))) F_BAIL(FB_MATE);
+		if(S.paired && S.npairs == 0 && ((S.bestUnp0 != F_SMIN16 && S.bestUnp0 >= S.minsc0) || (S.bestUnp1 != F_SMIN16 && S.bestUnp1 >= S.minsc1))) {
+#if FG_ALIGN_MATE
+			const uint32_t am[4] = {(uint32_t)fs_nres(S, 0) << 3 | (uint32_t)fs_nres(S, 1) << 5, H2G_MAX, 0u, 0u};   // mp_i = mp_j = 0, mate_found = 0
+			W.stv<4>(FW_AM, am);
+			F_GOTO(FPC_MP_LOOP);
+#else
+			F_BAIL(FB_MATE);
+#endif
+		}
 		F_GOTO(FPC_FINISH);
 	}
+#if FG_ALIGN_MATE
+	// ======================================================================== alignMate hi_aligner.h:4092-4148, :5579-5770
+	// Each alignment of a mate anchors a search for the OTHER mate near it: the local index at the anchor (and its neighbour in the
+	// anchor's direction), backward searches from the read's end, hits within 2 x maxFragLen of the anchor, hybridSearch_recur with
+	// the mate cushion.  Loop state (FAm) in four cold words: w0 = mp_i | mp_j << 1 | mp_rs0 << 3 | mp_rs1 << 5 | mate_found << 7 |
+	// first << 8 | count << 9 | hi << 11 | ri << 13 | nco << 16 | fw << 19; w1 = the local index; w2 = hitoff | hitlen << 8 | maxhitlen << 16.
+#define FAM_LOAD() uint32_t am[4]; W.ldv<4>(FW_AM, am)
+#define FAM_STORE() W.stv<4>(FW_AM, am)
+#define FAM_GET(WORD, SH, BITS) ((am[WORD] >> (SH)) & ((1u << (BITS)) - 1u))
+#define FAM_SET(WORD, SH, BITS, V) (am[WORD] = (am[WORD] & ~(((1u << (BITS)) - 1u) << (SH))) | (((uint32_t)(V) & ((1u << (BITS)) - 1u)) << (SH)))
+	case FPC_MP_LOOP: {
+		FAM_LOAD();
+		uint32_t mp_i = FAM_GET(0, 0, 1), mp_j = FAM_GET(0, 1, 2);
+		// (mp_i needs the value 2 as well: kept as mp_i | done << 20)
+		if(FAM_GET(0, 20, 1)) {
+			if(FAM_GET(0, 7, 1)) { S.pr_ret_pc = FPC_FINISH; F_GOTO(FPC_PAIR_READS); }
+			F_GOTO(FPC_FINISH);
+		}
+		const uint32_t rs = mp_i == 0 ? FAM_GET(0, 3, 2) : FAM_GET(0, 5, 2);
+		if(mp_j >= rs) {
+			if(mp_i == 1) FAM_SET(0, 20, 1, 1); else FAM_SET(0, 0, 1, 1);
+			FAM_SET(0, 1, 2, 0);
+			FAM_STORE();
+			F_GOTO(FPC_MP_LOOP);
+		}
+		const uint32_t rb = fg_res_base(mp_i, mp_j);
+		uint32_t r3[3];
+		W.ldv<3>(rb, r3);
+		const bool fw = (r3[2] & 1u) != 0;
+		FAM_SET(0, 19, 1, fw ? 1u : 0u);
+		S.sv_rdi = 1u - mp_i; S.sv_fw = fw ? 0u : 1u;               // ofw = (fw == gMate2fw ? gMate1fw : gMate2fw) = !fw with --fr (:5605)
+		S.nghits = 0; S.ghit_done = 0;
+		am[1] = local_index_of(*C.ls, r3[0], r3[1]);
+		FAM_SET(0, 8, 1, 1); FAM_SET(0, 9, 2, 0);
+		am[2] = 0;                                               // hitoff, hitlen, maxhitlen
+		FAM_STORE();
+		F_GOTO(FPC_AM_WHILE);
+	}
+	case FPC_AM_WHILE: {
+		FAM_LOAD();
+		const uint32_t count = FAM_GET(0, 9, 2);
+		FAM_SET(0, 9, 2, count < 3 ? count + 1 : 3);
+		bool ext = !(count < 2);
+		if(!ext) {
+			if(FAM_GET(0, 8, 1)) FAM_SET(0, 8, 1, 0);
+			else {
+				if(S.nghits > 0) ext = true;
+				else {
+					if(am[1] != H2G_MAX) am[1] = FAM_GET(0, 19, 1) ? local_index_next(*C.ls, am[1]) : local_index_prev(*C.ls, am[1]);
+					if(am[1] == H2G_MAX || C.ls->desc[am[1]].len == 0) ext = true;
+				}
+			}
+			if(!ext && am[1] == H2G_MAX) ext = true;
+		}
+		if(ext) { FAM_SET(0, 11, 2, 0); FAM_STORE(); F_GOTO(FPC_AM_EXT_LOOP); }
+		am[2] = (am[2] & ~0xffu) | ((fs_rl(S, S.sv_rdi) - 1u) & 0xffu);
+		FAM_STORE();
+		F_GOTO(FPC_AM_INNER);
+	}
+	case FPC_AM_INNER: {
+		FAM_LOAD();
+		const uint32_t hitoff = am[2] & 0xffu;
+		if(!(hitoff >= minK_local - 1)) F_GOTO(FPC_AM_WHILE);
+		if(C.ls->desc[am[1]].len == 0) { S.a0 = 0; S.a1 = 0; S.a2 = H2G_MAX; S.a3 = H2G_MAX; S.a4 = 0; F_GOTO(FPC_AM_AFTER_LS); }
+		S.a0 = am[1]; S.a1 = hitoff; S.a2 = 0xffffu; S.a3 = 0; S.a4 = H2G_MAX; S.a5 = H2G_MAX;
+		F_OP(FOP_LSEARCH, FPC_AM_AFTER_LS);
+	}
+	case FPC_AM_AFTER_LS: {
+		FAM_LOAD();
+		const uint32_t nelt = S.a0, hitlen = S.a1, top = S.a2, bot = S.a3, hitoff = am[2] & 0xffu, maxhitlen = (am[2] >> 16) & 0xffu;
+		if(hitlen > 255) F_BAIL(FB_OTHER);
+		am[2] = (am[2] & ~0xff00u) | (hitlen << 8);
+		FAM_STORE();
+		if(nelt > 0 && nelt <= P.kseeds && hitlen > maxhitlen) {
+			if(bot - top > FG_NCO) F_BAIL(FB_COORDS);
+			S.a0 = am[1]; S.a1 = top; S.a2 = bot; S.a3 = hitoff - hitlen + 1; S.a4 = hitlen; S.a5 = fg_frame_co(0);
+			F_OP(FOP_LCOORDS, FPC_AM_AFTER_LC);
+		}
+		F_GOTO(FPC_AM_ADV);
+	}
+	case FPC_AM_AFTER_LC: {
+		FAM_LOAD();
+		FAM_SET(0, 16, 3, S.a0); FAM_SET(0, 13, 3, 0);
+		FAM_STORE();
+		S.nghits = 0; S.ghit_done = 0;
+		F_GOTO(FPC_AM_RI_LOOP);
+	}
+	case FPC_AM_RI_LOOP: {
+		FAM_LOAD();
+		const uint32_t nco = FAM_GET(0, 16, 3), hitoff = am[2] & 0xffu, hitlen = (am[2] >> 8) & 0xffu;
+		const uint32_t mp_i = FAM_GET(0, 0, 1), mp_j = FAM_GET(0, 1, 2);
+		const uint32_t toff = W.ld(fg_res_base(mp_i, mp_j) + 1);
+		for(uint32_t ri = 0; ri < nco; ri++) {
+			uint32_t co3[3];
+			W.ldv<3>(fg_frame_co(0) + 3 * ri, co3);
+			if((uint64_t)co3[1] + (uint64_t)P.maxFragLen * 2 < toff || (uint64_t)toff + (uint64_t)P.maxFragLen * 2 < co3[1]) continue;   // (no_spliced_alignment :5683)
+			if(S.nghits >= 2) F_BAIL(FB_NGHITS);
+			fg_hit_init(W, S.nghits == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1, S.sv_fw != 0, hitoff - hitlen + 1, hitlen, co3[0], co3[1], co3[2]);
+			S.nghits++;
+		}
+		am[2] = (am[2] & ~0xff0000u) | (hitlen << 16);
+		FAM_STORE();
+		F_GOTO(FPC_AM_ADV);
+	}
+	case FPC_AM_ADV: {
+		FAM_LOAD();
+		uint32_t hitoff = am[2] & 0xffu;
+		const uint32_t hitlen = (am[2] >> 8) & 0xffu;
+		if(hitlen > 0) hitoff -= (hitlen - 1);
+		if(hitoff > 0) hitoff -= 1;
+		am[2] = (am[2] & ~0xffu) | (hitoff & 0xffu);
+		FAM_STORE();
+		F_GOTO(FPC_AM_INNER);
+	}
+	case FPC_AM_EXT_LOOP: {
+		FAM_LOAD();
+		const uint32_t hi = FAM_GET(0, 11, 2);
+		if(hi >= S.nghits) {
+			FAM_SET(0, 7, 1, 1);
+			FAM_SET(0, 1, 2, FAM_GET(0, 1, 2) + 1);
+			FAM_STORE();
+			F_GOTO(FPC_MP_LOOP);
+		}
+		S.a0 = 0; S.a1 = H2G_MAX; S.a2 = H2G_MAX; S.a3 = hi == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+		F_OP(FOP_EXTEND, FPC_AM_EXT_AFTER);
+	}
+	case FPC_AM_EXT_AFTER: {
+		FAM_LOAD();
+		const uint32_t hi = FAM_GET(0, 11, 2);
+		const uint32_t gb = hi == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+		const uint32_t w4 = W.ld(gb + 4);
+		fg_hit_copy(W, fg_frame_hit(0), gb);                    // RC_START(tmp2, rdoff, len, the mate's minimum score, alignMate = true)
+		S.sp = 0; S.f_hitoff = w4 & 0xffu; S.f_hitlen = (w4 >> 8) & 0xffu;
+		S.rc_minsc = fs_minsc(S, S.sv_rdi); S.rc_ret_pc = FPC_AM_REC_AFTER; S.ret = F_SMIN; S.rc_mate = 1;
+		F_GOTO(FPC_RC_ENTRY);
+	}
+	case FPC_AM_REC_AFTER: {
+		FAM_LOAD();
+		S.rc_mate = 0;
+		FAM_SET(0, 11, 2, FAM_GET(0, 11, 2) + 1);
+		FAM_STORE();
+		F_GOTO(FPC_AM_EXT_LOOP);
+	}
+#undef FAM_LOAD
+#undef FAM_STORE
+#undef FAM_GET
+#undef FAM_SET
+#endif
 	// ======================================================================== getAnchorHits :5007-5193
 	case FPC_GAH_LOOP: {
 		const uint32_t x = (uint32_t)S.sel_r * 2 + (uint32_t)S.sel_f;
@@ -1032,7 +1201,7 @@ again:
 		const uint32_t hitoff = S.f_hitoff, hitlen = S.f_hitlen, rdlen = fs_rl(S, S.sv_rdi);
 		const int32_t minsc = S.rc_minsc;
 		S.f_maxsc = F_SMIN;
-		if(hit.score < minsc) F_RC_RET(S.f_maxsc);
+		if(hit.score + F_CUSHION() < minsc) F_RC_RET(S.f_maxsc);    // (the cushion: alignMate only)
 		if(hitoff == hit.rdoff - hit.trim5 && hitlen == hit.len + hit.trim5 + hit.trim3) {
 			const uint32_t hsh = fh_hash(hit);
 			const uint32_t sb = FW_SRCH + S.sv_rdi * FG_NSRCH * (1 + FG_HW), ns = fs_nsearched(S, S.sv_rdi);
@@ -1772,6 +1941,11 @@ H2G_HD void fs_unpack(FState& S, LD&& ld) {
 	memcpy(&S, w, sizeof S);
 }
 
+#if FG_ALIGN_MATE
+#define FG_SITES_AM(X) X(FOP_LSEARCH, FPC_AM_AFTER_LS) X(FOP_LCOORDS, FPC_AM_AFTER_LC) X(FOP_EXTEND, FPC_AM_EXT_AFTER)
+#else
+#define FG_SITES_AM(X)
+#endif
 // Every place the fast machine requests a primitive: (primitive, pc it resumes at).  The queued kernel keeps one queue per site, so
 // the lanes of a wave resume at the same pc (as H2G_MACH_SITES of h2g_machine.h).
 #define FG_SITES(X) \
@@ -1781,7 +1955,7 @@ H2G_HD void fs_unpack(FState& S, LD&& ld) {
 	X(FOP_LSEARCH, FPC_L_LS_AFTER) X(FOP_LSEARCH, FPC_R_LS_AFTER) X(FOP_LCOORDS, FPC_L_LC_AFTER) X(FOP_LCOORDS, FPC_R_LC_AFTER) \
 	X(FOP_COMBINE, FPC_L_RI_C) X(FOP_COMBINE, FPC_R_RI_C) \
 	X(FOP_GSEARCH, FPC_L_GS_AFTER) X(FOP_GSEARCH, FPC_R_GS_AFTER) X(FOP_GCOORDS, FPC_L_GC_AFTER) X(FOP_GCOORDS, FPC_R_GC_AFTER) \
-	X(FOP_EXTEND, FPC_L_G_B) X(FOP_EXTEND, FPC_R_G_B) X(FOP_COMBINE, FPC_L_G_C) X(FOP_COMBINE, FPC_R_G_C)
+	X(FOP_EXTEND, FPC_L_G_B) X(FOP_EXTEND, FPC_R_G_B) X(FOP_COMBINE, FPC_L_G_C) X(FOP_COMBINE, FPC_R_G_C) FG_SITES_AM(X)
 enum : uint32_t {
 #define X(OPC, PC) FSITE_##PC,
 	FSITE_FREE = 0, FG_SITES(X) FSITE_COUNT
@@ -1844,6 +2018,7 @@ H2G_HD bool fast_run_single(const FCtx& C, FState& S, const FWords& W, uint32_t 
 			// what the queued kernel does between two trips: the state through its packed form (and the site table must know the resume pc)
 			uint32_t pw[FS_WORDS];
 			const uint32_t op = S.op;
+			AL_TRACE(" FAST op %u resume pc %u a %u %u %u %u %u %u sv %u/%u sp %d\n", op, (unsigned)S.pc, S.a0, S.a1, S.a2, S.a3, S.a4, S.a5, (unsigned)S.sv_rdi, (unsigned)S.sv_fw, (int)S.sp);
 			if(fg_site_of(S.pc) == 0 || fg_site_op(fg_site_of(S.pc)) != op) { S.pc = FPC_BAIL; S.bail = FB_OTHER; break; }
 			fs_pack(S, [&](uint32_t i, uint32_t v) { pw[i] = v; });
 			memset(&S, 0x5a, sizeof S);

@@ -447,7 +447,20 @@ void h2gemu_fast_check(Emu* e, const uint8_t* codes2, const uint32_t* offs2, con
 				       a.splicescore == b.splicescore && a.score == b.score && memcmp(a.edits, b.edits, a.nedits * sizeof(h2g_edit)) == 0;
 			}
 		}
-		if(!same) { stats[1]++; if(nbad < cap) bad_ids[nbad++] = i; }
+		if(!same) {
+			stats[1]++; if(nbad < cap) bad_ids[nbad++] = i;
+			if(getenv("H2GEMU_FAST_VERBOSE") && paired) {
+				const PairOut& f = fp[i];
+				PairOut one; MachOut O2; O2.rout = nullptr; O2.aln = nullptr; O2.aln_slots = 0; O2.pout = &one - i; O2.paln[0] = m1.data() - (size_t)i * slots; O2.paln[1] = m2.data() - (size_t)i * slots; O2.pair_slots = slots;
+				mach_run_single(C, M, i, true, O2);
+				fprintf(stderr, "pair %u: fast nres %u/%u npairs %u nrank %u nsteps %u depth %u nside %u rnd %08x | machine nres %u/%u npairs %u nrank %u nsteps %u depth %u nside %u rnd %08x\n", i,
+				        f.nres[0], f.nres[1], f.npairs, f.nrank, f.nsteps, f.depth, f.nside, f.rnd_state, one.nres[0], one.nres[1], one.npairs, one.nrank, one.nsteps, one.depth, one.nside, one.rnd_state);
+				for(int m = 0; m < 2; m++) {
+					for(uint32_t k = 0; k < f.nres[m]; k++) { const h2g_alnres& a = (m ? f2 : f1)[(size_t)i * slots + k]; fprintf(stderr, "   fast m%d r%u fw %u toff %u len %u trim %u/%u ned %u score %lld\n", m, k, a.fw, a.toff, a.len, a.trim5, a.trim3, a.nedits, (long long)a.score); }
+					for(uint32_t k = 0; k < one.nres[m]; k++) { const AlnRec& a = ws->m[m].res[k]; fprintf(stderr, "   mach m%d r%u fw %u toff %u len %u trim %u/%u ned %u score %lld\n", m, k, a.fw, a.toff, a.len, a.trim5, a.trim3, a.nedits, (long long)a.score); }
+				}
+			}
+		}
 	}
 	delete ws;
 }
