@@ -100,3 +100,21 @@ def test_chunk_accessors_equal_the_base_accessors(genome):
         offs = (np.arange(len(reads) + 1, dtype=np.uint64) * rdlen).astype(np.uint32)
         e.set_reads(codes, offs, None)
         assert e.L.h2gemu_chunk_check(e.h, 20000, rdlen) == 0
+
+
+def test_mate_rescue_in_the_fast_path(genome):
+    """alignMate (hi_aligner.h:5579) restated in the fast path (FG_ALIGN_MATE; compiled into this emulator, not yet into the shipped kernel):
+    pairs whose second mate carries too many mismatches for an end-to-end alignment are rescued through the local index next to the first
+    mate — the result, incl. the work counters and the wrap of the live minimum score for a mate without an alignment, equals the machine's"""
+    base, contigs = genome
+    n = 4000
+    m1, m2 = synth.make_pairs(contigs, n, 101, 5151, frag_mean=300, frag_sd=30, sub_rate=0.004)
+    rng = np.random.default_rng(11)
+    m2 = np.array(m2, dtype=np.uint8).copy()
+    for i in range(0, n, 2):                                      # every other pair: 5..8 extra mismatches in mate 2
+        pos = rng.choice(101, size=int(rng.integers(5, 9)), replace=False)
+        m2[i, pos] = (m2[i, pos] + rng.integers(1, 4, size=len(pos))) & 3
+    r = FC.fast_check(base, list(m1), list(m2))
+    assert r["mismatching"] == 0, r
+    assert "mate" not in r["bails"], r
+    assert r["completed"] > 0.8 * n, r
