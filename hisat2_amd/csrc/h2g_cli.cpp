@@ -386,7 +386,7 @@ int main(int argc, char** argv) {
 			return 1;
 		}
 		ss_window = ss_window_opt ? ss_window_opt : 1000u * (uint32_t)threads;
-		if(batch > ss_window) batch = ss_window;
+		batch = ss_window;   // a wave is exactly one shard per device (want()): a smaller --batch would complete shards (and merge their junctions) in the middle of a wave
 	}
 	const bool paired = u.empty();
 	const double t0 = now();

@@ -56,6 +56,7 @@ struct h2g_index {
 };
 
 #define H2G_NBUF 3
+#define H2G_CNT_BLOCK 512u          // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
 #define H2G_MACH_MAXGRID 48u       // workgroups of a machine pass behind a fast pass (two such passes may be in flight)
 struct h2g_stream {
 	h2g_index* ix = nullptr;
@@ -95,6 +96,7 @@ struct h2g_stream {
 	void* h_fast_args = nullptr;      // pinned staging of the argument blocks (H2G_NBUF of them): the upload never makes the host wait for the stream      // the fast pass's argument block (device copy)
 	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
 	bool ran_fast = false;
+	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
 	size_t paln_alloc = 0;
@@ -280,6 +282,9 @@ extern "C" h2g_status h2g_index_add_splice_sites(h2g_index* ix, const h2g_splice
 		return H2G_ERR_UNSUPPORTED;
 	}
 	HIPCHK(hipDeviceSynchronize());
+	// without a database yet (no h2g_index_set_splice_sites before this call) the index's own splice-site ALTs seed it, as they seed every
+	// database (SpliceSiteDB::read(gfm, alts), splice_site.cpp:653); the window stays what it was (0 until a set call names one)
+	if(ix->h_ssdb.fw.empty() && !ix->alt_sites.empty()) build_splice_db(ix->alt_sites.data(), ix->alt_sites.size(), ix->host.g.nPat, ix->h_ssdb);
 	merge_splice_db(ix->h_ssdb, delta, n, ix->host.g.nPat);
 	return upload_splice_db(ix);
 }
@@ -409,8 +414,8 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	HIPCHK(hipHostMalloc((void**)&s->h_bails, 4 * H2G_NBUF)); for(int k = 0; k < H2G_NBUF; k++) s->h_bails[k] = 0;
 	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
 	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
-	HIPCHK(hipMalloc((void**)&s->d_counters, H2G_NBUF * 256 * sizeof(unsigned long long)));
-	HIPCHK(hipMemset(s->d_counters, 0, H2G_NBUF * 256 * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void**)&s->d_counters, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
+	HIPCHK(hipMemset(s->d_counters, 0, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
 	s->cnt_cur = s->d_counters;
 	if(max_reads) {
 		HIPCHK(hipMalloc((void**)&s->d_codes, max_bases + 64));
@@ -1596,6 +1601,13 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if(min_score_for(Pq, swlen) < -254) { snprintf(g_err, sizeof g_err, "bowtie2_dp: --score-min gives %lld for %u-base reads; below -254 the reference runs its 16-bit DP, which is not built", (long long)min_score_for(Pq, s->max_read_len), s->max_read_len); return H2G_ERR_UNSUPPORTED; }
 	}
 	HIPCHK(hipSetDevice(s->ix->device));
+	// Runs queued back to back share the result arrays (rows per read, record stride): a machine pass still in flight may only meet a
+	// run over the same reads with the same options.  Anything else waits for the machine streams first.
+	if(s->st2_busy && (s->last_paired != (paired ? 1 : 0) || memcmp(&s->last_p, p, sizeof *p) != 0)) {
+		for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_]));
+		s->st2_busy = false;
+	}
+	s->last_p = *p; s->last_paired = paired ? 1 : 0;
 	const bool big_main = maxsz > caps[0];
 	const GoUnit& U = go_unit(linear, big_main, spl);
 	static const int fast_env = getenv("H2G_GO_FAST") ? atoi(getenv("H2G_GO_FAST")) : 1;
@@ -1657,24 +1669,31 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		}
 		s->pair_slots = pslots;
 		A.O.pout = s->d_pout; A.O.paln[0] = s->d_paln[0]; A.O.paln[1] = s->d_paln[1]; A.O.pair_slots = pslots;
-		const size_t ovf_cap = s->max_reads / 4 > 65536 ? s->max_reads / 4 : 65536;   // records
+		// Two halves, one per machine stream: the machine passes of two queued runs may be in flight together and each takes its blocks
+		// from its own cursor.  Block offsets (PairOut::pad) are relative to the whole area, so whichever pass wrote a pair last, its block is found.
+		const size_t ovf_cap = s->max_reads / 4 > 65536 ? s->max_reads / 4 : 65536;   // records per half
 		if(s->paln_ovf_cap < ovf_cap) {
 			(void)hipFree(s->d_paln_ovf); s->d_paln_ovf = nullptr; s->paln_ovf_cap = 0;
-			HIPCHK(hipMalloc((void**)&s->d_paln_ovf, ovf_cap * sizeof(h2g_alnres)));
+			HIPCHK(hipMalloc((void**)&s->d_paln_ovf, 2 * ovf_cap * sizeof(h2g_alnres)));
 			s->paln_ovf_cap = ovf_cap;
 		}
-		A.O.ovf = s->d_paln_ovf; A.O.ovf_cap = (uint32_t)s->paln_ovf_cap;
+		A.O.ovf = s->d_paln_ovf;
 	}
 	(void)hipGetLastError();
 	// the fast pass's hand-on list, the counters and its argument block are buffered H2G_NBUF deep: the general machine's pass over
 	// run k's hand-ons goes to machine stream k & 1 and may still be under way while the fast passes of runs k + 1 and k + 2 run
 	const unsigned gsel = s->gen % H2G_NBUF, msel = s->gen & 1u;
-	unsigned long long* const cblk = s->d_counters + 256 * gsel;
+	unsigned long long* const cblk = s->d_counters + H2G_CNT_BLOCK * gsel;
 	HIPCHK(hipStreamWaitEvent(s->st, s->ev_mach[gsel], 0));          // run k - H2G_NBUF's machine pass: done with this set of buffers
-	HIPCHK(hipMemsetAsync(cblk, 0, 256 * sizeof(unsigned long long), s->st));
+	HIPCHK(hipMemsetAsync(cblk, 0, H2G_CNT_BLOCK * sizeof(unsigned long long), s->st));
 	A.counters = cblk;
 	A.work = reinterpret_cast<uint32_t*>(cblk + 14);
-	if(paired) A.O.ovf_cursor = reinterpret_cast<uint32_t*>(cblk + 124);      // (zeroed with the counter block)
+	if(paired) {   // the cursor starts at this machine stream's half of the area
+		const uint32_t half = fast ? (s->gen & 1u) : 0u;
+		A.O.ovf_cursor = reinterpret_cast<uint32_t*>(cblk + 124);
+		A.O.ovf_cap = (uint32_t)((half + 1) * s->paln_ovf_cap);
+		if(half) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)A.O.ovf_cursor, (int)(half * s->paln_ovf_cap), 1, s->st));
+	}
 	A.list = nullptr; A.nlist = nullptr;
 	if(getenv("H2G_GO_DBG_READ")) {
 		static uint32_t* dbg = nullptr;
@@ -1771,7 +1790,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		B.geometry(bgeo);
 		GoArgs A2 = A;
 		if((rc = go_pool_for(s, 2 * psel + 1, B, (size_t)bgrid * bgeo[1], (size_t)bgrid * bgeo[0], p->bowtie2_dp, &A2))) return rc;
-		A2.counters = cblk + 64;
+		A2.counters = cblk + 256;           // (a region of its own: in H2G_GO_PROF builds a pass writes up to 96 words behind its counters)
 		A2.work = reinterpret_cast<uint32_t*>(cblk + 15);
 		A2.list = ovl; A2.nlist = cnt;
 		A2.defer_overflow = 0;
@@ -1936,8 +1955,8 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	unsigned long long v[16];
 	unsigned long long* const cb = s->ran_align ? s->cnt_cur : s->d_counters;
 	HIPCHK(hipMemcpy(v, cb, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(v + 8, cb + 64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-	// [0..7] the main pass, [8..15] <- slots 64..71: the second pass over its overflowed reads (go_run)
+	HIPCHK(hipMemcpy(v + 8, cb + (s->ran_align ? 256 : 64), 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	// [0..7] the main pass, [8..15] <- slots 256..263: the second pass over its overflowed reads (go_run)
 	s->last.n_rank = v[0] + v[8]; s->last.n_side = v[1] + v[9]; s->last.n_sa_steps = v[2] + v[10]; s->last.n_ext = v[3];
 	s->last.n_aligned = v[4] + v[12];
 	uint32_t nsecond = 0;

@@ -73,7 +73,11 @@ H2G_EXPORT void       h2g_index_free(h2g_index*);
 typedef struct { uint32_t tidx, left, right, readid; uint8_t dir /* 2 = '+', 3 = '-' (SPL_FW / SPL_RC) */, fromfile, known, editdist /* out of h2g_sam_take_novel_sites: mismatches + gaps of the line that crossed the site (<= 255); ignored on input */; } h2g_splice_site;
 H2G_EXPORT h2g_status h2g_index_set_splice_sites(h2g_index*, const h2g_splice_site* sites, size_t n, uint32_t window);
 /* the sites met since (new ones, or known ones whose smallest read id went down) join the database: O(sites + n log n), no re-allocation;
- * nothing may be in flight on the index (SpliceSiteDB::addSpliceSite, splice_site.cpp:243; the temporary-splice-site waves of the command line) */
+ * the call waits for the device first (a caller with shards of a wave still in flight pays that wait; the command line merges at wave
+ * boundaries only).  Without a h2g_index_set_splice_sites call before it the database starts from the index's own splice-site ALTs and
+ * the window is 0 (SpliceSiteDB::addSpliceSite, splice_site.cpp:243; the temporary-splice-site waves of the command line).
+ * Queued runs: h2g_align(_pairs)_run calls queued without a fetch between them share the result rows; a run whose options differ
+ * from the previous one's first waits for everything still in flight (go_run). */
 H2G_EXPORT h2g_status h2g_index_add_splice_sites(h2g_index*, const h2g_splice_site* delta, size_t n);
 
 H2G_EXPORT const char* h2g_last_error(void);

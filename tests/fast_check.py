@@ -11,9 +11,9 @@ BAIL_REASONS = ["none", "input", "longpool", "subsample", "coords", "nghits", "e
                 "redundant", "mate", "npairs", "partial", "straddle", "other", "indel"]
 
 
-def fast_check(base, reads1, reads2=None, names=None, quals=None, options=()):
+def fast_check(base, reads1, reads2=None, names=None, quals=None, options=(), variant=""):
     """-> dict(completed, mismatching, bails {reason: n}, bad [read ids], done flags)"""
-    e = Emu(base)
+    e = Emu(base, variant)
     if options:
         from h2gemu_align import set_options
         set_options(e, 0, options)

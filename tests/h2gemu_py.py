@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class Emu:
-    def __init__(self, base):
-        subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emul")], check=True)
-        self.L = C.CDLL(os.environ.get("H2GEMU_LIB") or os.path.join(HERE, "emul", "libh2gemu.so"))
+    def __init__(self, base, variant=""):
+        """variant "" = the shipped kernel's configuration; "am" = alignMate in the fast path (tests/emul/Makefile)"""
+        subprocess.run(["make", "-s", "-j2", "-C", os.path.join(HERE, "emul")], check=True)
+        self.L = C.CDLL(os.environ.get("H2GEMU_LIB") or os.path.join(HERE, "emul", "libh2gemu%s.so" % ("_" + variant if variant else "")))
         vp = C.c_void_p
         self.L.h2gemu_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         self.L.h2gemu_set_reads.argtypes = [vp, vp, vp, vp, C.c_size_t]

@@ -103,7 +103,7 @@ def test_chunk_accessors_equal_the_base_accessors(genome):
 
 
 def test_mate_rescue_in_the_fast_path(genome):
-    """alignMate (hi_aligner.h:5579) restated in the fast path (FG_ALIGN_MATE; compiled into this emulator, not yet into the shipped kernel):
+    """alignMate (hi_aligner.h:5579) restated in the fast path (FG_ALIGN_MATE; compiled into libh2gemu_am.so, not into the shipped kernel):
     pairs whose second mate carries too many mismatches for an end-to-end alignment are rescued through the local index next to the first
     mate — the result, incl. the work counters and the wrap of the live minimum score for a mate without an alignment, equals the machine's"""
     base, contigs = genome
@@ -114,7 +114,10 @@ def test_mate_rescue_in_the_fast_path(genome):
     for i in range(0, n, 2):                                      # every other pair: 5..8 extra mismatches in mate 2
         pos = rng.choice(101, size=int(rng.integers(5, 9)), replace=False)
         m2[i, pos] = (m2[i, pos] + rng.integers(1, 4, size=len(pos))) & 3
-    r = FC.fast_check(base, list(m1), list(m2))
+    r = FC.fast_check(base, list(m1), list(m2), variant="am")
     assert r["mismatching"] == 0, r
     assert "mate" not in r["bails"], r
     assert r["completed"] > 0.8 * n, r
+    # the shipped configuration hands exactly these pairs on (FB_MATE) and completes the rest equal to the machine
+    s = FC.fast_check(base, list(m1), list(m2))
+    assert s["mismatching"] == 0 and s["bails"].get("mate", 0) > 0.3 * n, s
