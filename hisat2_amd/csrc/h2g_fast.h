@@ -45,7 +45,8 @@ namespace h2g {
 #define FW_CO     (FW_SRCH + 2 * FG_NSRCH * (1 + FG_HW))   // the coordinate list of every frame (frame 0's doubles as getAnchorHits'); before it: (hash, hit) per searched root
 #define FW_FRX    (FW_CO + FG_NFRAME * 3 * FG_NCO)  // frames 1 .. FG_NFRAME - 1: scalars + hit
 #define FW_LH     (FW_FRX + (FG_NFRAME - 1) * (FG_FRS + FG_HW))   // _local_genomeHits of every frame
-#define FW_AM      (FW_LH + FG_NFRAME * FG_NLOCAL * FG_HW)   // alignMate's loop state (4 words; only pairs without a concordant alignment get there)
+#define FW_RH     (FW_LH + FG_NFRAME * FG_NLOCAL * FG_HW)   // the reported alignments themselves (hits), [mate][k]: their records are written once, by FPC_FINISH
+#define FW_AM      (FW_RH + 2 * FG_NRES * FG_HW)             // alignMate's loop state (4 words; only pairs without a concordant alignment get there)
 #define FW_TOTAL  (FW_AM + 4 * FG_ALIGN_MATE)
 #define FW_COLD   (FW_TOTAL - FW_HOT)
 
@@ -65,7 +66,7 @@ enum : uint32_t {
 // why a read left the fast path (statistics only)
 enum : uint32_t {
 	FB_NONE = 0, FB_INPUT, FB_LONGPOOL, FB_SUBSAMPLE, FB_COORDS, FB_NGHITS, FB_EDITS, FB_DEPTH, FB_LOCALHITS, FB_GSEARCH, FB_NRES,
-	FB_SEARCHED, FB_REDUNDANT, FB_MATE, FB_NPAIRS, FB_PARTIAL, FB_STRADDLE, FB_OTHER, FB_INDEL, FB_COUNT
+	FB_SEARCHED, FB_REDUNDANT, FB_MATE, FB_NPAIRS, FB_PARTIAL, FB_STRADDLE, FB_OTHER, FB_INDEL, FB_TAIL, FB_COUNT
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -632,6 +633,11 @@ H2G_HD bool fg_pack_read(const DReads& rd, uint32_t i, uint32_t* pk, uint32_t st
 }
 // result summaries: tidx, toff, fw | nedits << 1 | extent << 4 | (score + 32768) << 16
 H2G_HD uint32_t fg_res_base(uint32_t m, uint32_t k) { return FW_RES + (m * FG_NRES + k) * 3; }
+// ... and the hit behind each summary.  A completed read's output (records + ReadOut / PairOut) is written in ONE place, FPC_FINISH, as a pure
+// function of the read: runs queued back to back share the result rows, and a machine pass of an earlier run may write the same read's rows
+// at the same time — with identical bytes, as long as nobody reads rows back (profiles/r04_NOTES.md: the round-3 inequality was an in-place
+// swap of two rows here against exactly such a pass)
+H2G_HD uint32_t fg_res_hit(uint32_t m, uint32_t k) { return FW_RH + (m * FG_NRES + k) * FG_HW; }
 
 // genRandSeed (pat.h:55-91, gen_rand_seed of h2g_align.h) of a read without N from its packed words: the 2-bit codes of 16 bases
 // XOR into the seed exactly as they lie in a packed word
@@ -1231,14 +1237,8 @@ again:
 				if(nr >= FG_NRES) F_BAIL(FB_NRES);
 				const uint32_t ext = fg_ref_extent(hit);
 				if(hit.score < -32000 || hit.score > 32000 || ext > 0xfffu) F_BAIL(FB_OTHER);
-				if(S.paired) {
-					if(nr >= C.O.pair_slots) F_BAIL(FB_NRES);
-					h2g_alnres* pl = S.sv_rdi ? C.O.paln[1] : C.O.paln[0];
-					fg_write_rec(pl[(size_t)S.read * C.O.pair_slots + nr], hit, rdlen);
-				} else {
-					if(nr >= C.O.aln_slots) F_BAIL(FB_NRES);
-					fg_write_rec(C.O.aln[(size_t)S.read * C.O.aln_slots + nr], hit, rdlen);
-				}
+				if(nr >= (S.paired ? C.O.pair_slots : C.O.aln_slots)) F_BAIL(FB_NRES);
+				if(!fh_store(W, fg_res_hit(S.sv_rdi, nr), hit)) F_BAIL(FB_EDITS);      // (its record is written by FPC_FINISH)
 				const uint32_t rb = fg_res_base(S.sv_rdi, nr);
 				W.st(rb, hit.tidx); W.st(rb + 1, hit.toff);
 				W.st(rb + 2, (hit.fw ? 1u : 0u) | (hit.nedits << 1) | (ext << 4) | ((uint32_t)(hit.score + 32768) << 16));
@@ -1703,10 +1703,12 @@ again:
 			const uint32_t sz = S.nres0;
 			o.nres = sz; o.overflow = 0; o.nrank = S.nrank; o.nsteps = S.nsteps; o.depth = S.nframes_max; o.nside = S.nside;
 			for(uint32_t k = 0; k < H2G_SELECT_CAP; k++) o.select[k] = 0;
-			// the records are in their slots in report order; selectByScore (al_select) over at most two of them
-			int64_t key[FG_NRES]; int64_t scv[FG_NRES];
+			// selectByScore (al_select) over at most two reported hits
+			int64_t key[FG_NRES] = {0, 0}; int64_t scv[FG_NRES] = {0, 0};
 			h2g_alnres* recs = C.O.aln + (size_t)S.read * C.O.aln_slots;
-			for(uint32_t k = 0; k < sz; k++) { scv[k] = recs[k].score; key[k] = fg_hisat2_key(recs[k].score, recs[k].trim5 + recs[k].trim3); }
+			const FHit h0 = fh_load(W, fg_res_hit(0, 0)), h1 = fh_load(W, fg_res_hit(0, sz > 1 ? 1u : 0u));
+			if(sz >= 1) { scv[0] = h0.score; key[0] = fg_hisat2_key(h0.score, h0.trim5 + h0.trim3); }
+			if(sz >= 2) { scv[1] = h1.score; key[1] = fg_hisat2_key(h1.score, h1.trim5 + h1.trim3); }
 			uint32_t nsel = 0; uint32_t ord[FG_NRES] = {0, 1};
 			if(sz == 1) { nsel = 1; }
 			else if(sz == 2) {
@@ -1727,12 +1729,9 @@ again:
 			}
 			o.best = b == INT64_MIN ? INT32_MIN : (int32_t)b; o.secbest = sb == INT64_MIN ? INT32_MIN : (int32_t)sb;
 			o.best_h2 = (uint32_t)(uint64_t)bh; o.secbest_h2 = (uint32_t)(uint64_t)sbh;
-			// output slot k holds res[select[k]]
-			if(nsel >= 1 && ord[0] == 1) {                  // (word by word: no record-sized temporaries)
-				uint32_t* w0 = reinterpret_cast<uint32_t*>(&recs[0]);
-				uint32_t* w1 = reinterpret_cast<uint32_t*>(&recs[1]);
-				for(uint32_t k = 0; k < sizeof(h2g_alnres) / 4; k++) { const uint32_t t = w0[k]; w0[k] = w1[k]; w1[k] = t; }
-			}
+			// output slot k holds res[select[k]]: written here, once, in that order (nothing is read back from the rows)
+			if(sz >= 1) fg_write_rec(recs[0], ord[0] == 1 ? h1 : h0, S.rl0);
+			if(sz >= 2) fg_write_rec(recs[1], ord[1] == 1 ? h1 : h0, S.rl0);
 			C.O.rout[S.read] = o;
 			S.rnd = rnd.last;
 			S.a0 = nsel > 0;
@@ -1743,6 +1742,11 @@ again:
 			for(uint32_t k = 0; k < AL_MAX_PAIRS; k++) {
 				o.pair_i[k] = k < S.npairs ? (uint8_t)((S.pairs >> (4 * k)) & 3u) : 0;
 				o.pair_j[k] = k < S.npairs ? (uint8_t)((S.pairs >> (4 * k + 2)) & 3u) : 0;
+			}
+			for(uint32_t m = 0; m < 2; m++) {                   // the records, in report order
+				h2g_alnres* pl = (m ? C.O.paln[1] : C.O.paln[0]) + (size_t)S.read * C.O.pair_slots;
+				const uint32_t nr = fs_nres(S, m), rl = fs_rl(S, m);
+				for(uint32_t k = 0; k < nr; k++) fg_write_rec(pl[k], fh_load(W, fg_res_hit(m, k)), rl);
 			}
 			C.O.pout[S.read] = o;
 			S.a0 = S.npairs > 0;

@@ -18,6 +18,9 @@ using namespace h2g;
 #endif
 #define FG_STAGE_WORDS (FW_HOT + 2 * H2G_PK_WORDS)                     // staged in LDS per lane: hot words + packed reads
 #define FG_SLOT_WORDS  (((FS_WORDS + FW_HOT + 2 * H2G_PK_WORDS + FW_COLD) + 3) & ~3)   // 16-byte multiple
+#ifndef FG_TAIL
+#define FG_TAIL 0                 // > 0: a workgroup hands its last FG_TAIL reads in flight on to the general machine once the batch is exhausted (an experiment: profiles/r04_NOTES.md)
+#endif
 #define FG_NQ ((int)FQ_COUNT)
 #define FG_RING_EMPTY 0xffffu
 static_assert(FG_NQ <= 64, "the queue census is one lane per queue");
@@ -156,6 +159,9 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 		bestc = (uint32_t)__shfl((int)bestc, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
 		const bool fetch = more && nfree > 0 && (bestc < 64 || nfree >= H2G_FAST_SLOTS / 4);
 		bool have = false;
+#if FG_TAIL
+		bool tail = false;
+#endif
 		uint32_t slot = 0, begin = H2G_MAX, packed_ok = 0, trip_op = FOP_NONE;
 		uint32_t* sm = nullptr;                                   // this lane's slot in HBM
 		if(fetch) {
@@ -194,7 +200,13 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 			if(n == 0) continue;
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			have = (uint32_t)lane < n;
+#if FG_TAIL
+			tail = !more && H2G_FAST_SLOTS - nfree <= (uint32_t)FG_TAIL;
+			if(have && tail) sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
+			if(have && !tail) {
+#else
 			if(have) {
+#endif
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
 				// hot words + packed reads into this lane's LDS staging area: 16-byte loads, nothing depends on anything
 				const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
@@ -218,6 +230,10 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 		prof[46] += __popcll(__ballot(have)); prof[47]++;
 #endif
 		uint32_t w0 = 0;
+#if FG_TAIL
+		if(have && tail) w0 = (uint32_t)FPC_BAIL | ((uint32_t)FB_TAIL << 12);     // (pc, bail reason of state word 0; the read id is state word 8 in the slot)
+		else
+#endif
 		if(have) w0 = fk_trip(A, stage, sm, trip_op, begin, packed_ok);
 #ifdef H2G_GO_PROF
 		{ const unsigned long long t_ = __builtin_readcyclecounter(); prof_ctl[trip_site & 31] += t_ - tp0; prof_n[trip_site & 31]++; }

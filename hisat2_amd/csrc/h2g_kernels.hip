@@ -96,6 +96,8 @@ struct h2g_stream {
 	void* h_fast_args = nullptr;      // pinned staging of the argument blocks (H2G_NBUF of them): the upload never makes the host wait for the stream      // the fast pass's argument block (device copy)
 	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
 	bool ran_fast = false;
+	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
+	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 400, mach_min = 4; long dbg_read = -1; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
@@ -424,6 +426,12 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		HIPCHK(hipMalloc((void**)&s->d_seed, max_reads * 2 * sizeof(h2g_seed_result)));
 	}
 	memset(&s->last, 0, sizeof s->last);
+	{
+		auto env = [](const char* k, long d) { const char* e = getenv(k); return e ? atol(e) : d; };
+		s->tune.fast = (int)env("H2G_GO_FAST", 1); s->tune.blocks_per_cu = (int)env("H2G_GO_BLOCKS_PER_CU", 0); s->tune.pair_slots = (int)env("H2G_PAIR_SLOTS", 0);
+		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 400); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
+		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
+	}
 	*out = s;
 	return H2G_OK;
 }
@@ -1610,8 +1618,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	s->last_p = *p; s->last_paired = paired ? 1 : 0;
 	const bool big_main = maxsz > caps[0];
 	const GoUnit& U = go_unit(linear, big_main, spl);
-	static const int fast_env = getenv("H2G_GO_FAST") ? atoi(getenv("H2G_GO_FAST")) : 1;
-	const bool fast = fast_env && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp;
+	const bool fast = s->tune.fast && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp;
 	// geometry of the unit: workgroups of geo[0] threads own geo[1] reads in flight; resident workgroups per CU = what the
 	// unit's waves per SIMD and the LDS (rings + one packed-read region per mate) allow
 	uint32_t geo[4];
@@ -1621,8 +1628,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	const size_t lds_blocks = (160u * 1024u) / (geo[2] + (paired ? 2u : 1u) * geo[3]);
 	if(per_cu > lds_blocks) per_cu = lds_blocks;
 	if(per_cu < 1) per_cu = 1;
-	static const int grid_env = getenv("H2G_GO_BLOCKS_PER_CU") ? atoi(getenv("H2G_GO_BLOCKS_PER_CU")) : 0;
-	if(grid_env > 0) per_cu = (size_t)grid_env;
+	if(s->tune.blocks_per_cu > 0) per_cu = (size_t)s->tune.blocks_per_cu;
 	size_t want = (s->n_reads + geo[1] - 1) / geo[1];
 	size_t maxblocks = 256 * per_cu;
 	if(big_main && maxblocks > 32) maxblocks = 32;        // ~1.3 MB of workspace per read in flight
@@ -1660,7 +1666,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		// a mate can report more alignments than -k before the pair is settled: 2 k + 4 slots, at least H2G_PAIR_RES_CAP
 		uint32_t pslots = p->khits * 2 + 4;
 		if(pslots < H2G_PAIR_RES_CAP) pslots = H2G_PAIR_RES_CAP;
-		if(const char* e = getenv("H2G_PAIR_SLOTS")) { const int v = atoi(e); if(v > 0) pslots = (uint32_t)v; }   // test knob: tiny rows push pairs through the overflow area (dense fetch only)
+		if(s->tune.pair_slots > 0) pslots = (uint32_t)s->tune.pair_slots;   // test knob: tiny rows push pairs through the overflow area (dense fetch only)
 		if(s->paln_alloc < s->max_reads * (size_t)pslots) {
 			for(int m = 0; m < 2; m++) { (void)hipFree(s->d_paln[m]); s->d_paln[m] = nullptr; }
 			s->paln_alloc = 0;
@@ -1695,14 +1701,14 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if(half) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)A.O.ovf_cursor, (int)(half * s->paln_ovf_cap), 1, s->st));
 	}
 	A.list = nullptr; A.nlist = nullptr;
-	if(getenv("H2G_GO_DBG_READ")) {
+	if(s->tune.dbg_read >= 0) {
 		static uint32_t* dbg = nullptr;
 		if(!dbg) HIPCHK(hipMalloc((void**)&dbg, (1u << 20) * 4));
 		HIPCHK(hipMemsetAsync(dbg, 0, (1u << 20) * 4, s->st));
-		A.dbg_buf = dbg; A.dbg_read = (uint32_t)atoi(getenv("H2G_GO_DBG_READ"));
+		A.dbg_buf = dbg; A.dbg_read = (uint32_t)s->tune.dbg_read;
 		s->dbg_buf = dbg;
 	}
-	const int no_second = getenv("H2G_GO_NO_SECOND_PASS") ? atoi(getenv("H2G_GO_NO_SECOND_PASS")) : 0;   // measurement / debugging knob
+	const int no_second = s->tune.no_second_pass;   // measurement / debugging knob
 	const bool second = !big_main && !no_second;
 	A.defer_overflow = second ? 1u : 0u;
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
@@ -1721,8 +1727,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 			if(hipEventQuery(s->ev_fast[b]) == hipSuccess) { s->last_bails = s->h_bails[b]; break; }
 		}
 		(void)hipGetLastError();
-		static const unsigned mach_div = getenv("H2G_MACH_DIV") ? (unsigned)atoi(getenv("H2G_MACH_DIV")) : 400u;   // (tuning knobs; hand-ons per machine workgroup: latency chains, two passes in flight)
-		static const unsigned mach_min = getenv("H2G_MACH_MIN") ? (unsigned)atoi(getenv("H2G_MACH_MIN")) : 4u;
+		const unsigned mach_div = s->tune.mach_div, mach_min = s->tune.mach_min;   // (hand-ons per machine workgroup: latency chains, two passes in flight)
 		unsigned mgrid = (unsigned)((s->last_bails + mach_div - 1) / (mach_div ? mach_div : 1u));
 		if(mgrid < mach_min) mgrid = mach_min;
 		if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
@@ -1922,7 +1927,20 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 	                    n, aln2, offs2, 2, s->d_pout + first, 1);
 }
 
-// development hook (env H2G_GO_DBG_READ=<read id>): the primitive requests of that read in the last go() launch, 8 words each
+// development hook: measurement / debugging knobs of go_run by name.  Everything in flight is waited for first, so a change never meets a
+// queued run.  "fast" 0/1, "blocks_per_cu", "pair_slots", "no_second_pass", "mach_div", "mach_min", "dbg_read" (-1 = off)
+extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream* s, const char* key, long v) {
+	if(!s || !key) return H2G_ERR_ARG;
+	HIPCHK(sync_all(s));
+	for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_]));
+	const std::string k(key);
+	if(k == "fast") s->tune.fast = (int)v; else if(k == "blocks_per_cu") s->tune.blocks_per_cu = (int)v; else if(k == "pair_slots") s->tune.pair_slots = (int)v;
+	else if(k == "no_second_pass") s->tune.no_second_pass = (int)v; else if(k == "mach_div") s->tune.mach_div = (unsigned)v; else if(k == "mach_min") s->tune.mach_min = (unsigned)v;
+	else if(k == "dbg_read") s->tune.dbg_read = v; else return H2G_ERR_ARG;
+	return H2G_OK;
+}
+
+// development hook (h2g_stream_tune "dbg_read" / env H2G_GO_DBG_READ=<read id>): the primitive requests of that read in the last go() launch, 8 words each
 extern "C" __attribute__((visibility("default"))) int h2g_go_debug_trace(h2g_stream* s, uint32_t* out, uint32_t cap_words) {
 	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !out || !s->dbg_buf) return H2G_ERR_ARG;
