@@ -14,13 +14,26 @@
 //
 // Built for: linear index, --no-spliced-alignment, no --secondary, --bowtie2-dp 0, default pair policy (--fr, -I 0), reads of
 // 32..128 bases without N.  Everything else never enters (go_run) or bails at the first state.
+//
+// FG_GRAPH = 1 (round 4) is the same state machine over a GRAPH index (SNP / indel ALTs): a partial hit carries its node range and in-edge
+// list, a coordinate is re-seated by adjustWithALT before it becomes a hit, and a hit's edits carry ALT ids.  The graph primitives are the
+// general machine's item functions (h2g_graph.h: mapGLF searches, the group walk, alignWithALTs) run on per-LANE scratch; what is compact is
+// the state a read keeps between two of them.  One translation unit sees one setting (the kernels h2g_k_go_fast.hip / h2g_k_go_fast_graph.hip,
+// the test libraries tests/emul/libh2gemu.so / libh2gemu_g.so).
 #pragma once
 #include "h2g_align.h"
+#ifndef FG_GRAPH
+#define FG_GRAPH 0
+#endif
+#if FG_GRAPH
+#include "h2g_graph.h"
+#endif
 
 namespace h2g {
 
 #define FG_FE     4                     // edits kept per hit (more: bail), 16 bits each
-#define FG_HW     (6 + FG_FE / 2)       // words of a stored hit
+#define FG_HW     (6 + FG_FE / 2 + FG_GRAPH * FG_FE)   // words of a stored hit (graph: + the ALT id of each edit)
+#define FG_LW     (3 + 3 * FG_GRAPH)    // words of a long partial hit in the pool (graph: + node range, in-edge list)
 #define FG_NLONG  3                     // partial hits longer than minK + 2 waiting for getAnchorHits
 #define FG_NCO    5                     // coordinates per SA resolution (the reference resolves at most 5 outside getAnchorHits)
 #define FG_NRES   2                     // reported alignments per mate
@@ -35,7 +48,7 @@ namespace h2g {
 // word store of one read in flight: [0, FW_HOT) is staged in LDS while a wave works on it, [FW_HOT, FW_TOTAL) stays in HBM (coordinate lists,
 // the searched list, everything only reads with a mismatch touch)
 #define FW_LONG   0
-#define FW_G0     (FW_LONG + 3 * FG_NLONG)
+#define FW_G0     (FW_LONG + FG_LW * FG_NLONG)
 #define FW_FR0    (FW_G0 + FG_HW)                  // frame 0: scalars + hit
 #define FW_RES    (FW_FR0 + FG_FRS + FG_HW)
 #define FW_T1     (FW_RES + 2 * FG_NRES * 3)       // the scratch hit of the extension branches (every read with a mismatch works through it)
@@ -50,7 +63,7 @@ namespace h2g {
 #define FW_TOTAL  (FW_AM + 4 * FG_ALIGN_MATE)
 #define FW_COLD   (FW_TOTAL - FW_HOT)
 
-enum : uint32_t { FOP_NONE = 0, FOP_PSEARCH, FOP_GCOORDS, FOP_EXTEND, FOP_LSEARCH, FOP_LCOORDS, FOP_COMBINE, FOP_GSEARCH, FOP_COUNT };
+enum : uint32_t { FOP_NONE = 0, FOP_PSEARCH, FOP_GCOORDS, FOP_EXTEND, FOP_LSEARCH, FOP_LCOORDS, FOP_COMBINE, FOP_GSEARCH, FOP_ADJUST, FOP_ADJMEMBER, FOP_COUNT };
 enum : uint32_t {
 	FPC_DONE = 0, FPC_BAIL,
 	FPC_GO_INIT, FPC_NB_PICK, FPC_NB_AFTER_PS, FPC_ALIGN, FPC_AFTER_ALIGN, FPC_PAIR_READS, FPC_AFTER_LOOP, FPC_FINISH,
@@ -60,13 +73,14 @@ enum : uint32_t {
 	FPC_L_AFTER_FOR, FPC_L_FOR_TI, FPC_L_R2, FPC_L_AFTER_WHILE, FPC_L_GS_AFTER, FPC_L_GC_AFTER, FPC_L_FOR_G, FPC_L_G_B, FPC_L_G_C, FPC_L_R3, FPC_L_TRIM, FPC_L_R4, FPC_L_EXT, FPC_L_EXT_A, FPC_L_R5,
 	FPC_R_WHILE, FPC_R_LS_LOOP, FPC_R_LS_AFTER, FPC_R_LS_DONE, FPC_R_LC_AFTER, FPC_R_FOR_RI, FPC_R_RI_B, FPC_R_RI_C, FPC_R_R1,
 	FPC_R_AFTER_FOR, FPC_R_FOR_TI, FPC_R_R2, FPC_R_AFTER_WHILE, FPC_R_GS_AFTER, FPC_R_GC_AFTER, FPC_R_FOR_G, FPC_R_G_B, FPC_R_G_C, FPC_R_R3, FPC_R_TRIM, FPC_R_R4, FPC_R_EXT, FPC_R_EXT_A, FPC_R_R5,
+	FPC_GAH_K_LOOP, FPC_GAH_K_AFTER, FPC_L_RI_A, FPC_L_G_A, FPC_R_RI_A, FPC_R_G_A,     // graph: adjustWithALT of an anchor's coordinates / of a local hit
 	FPC_MP_LOOP, FPC_AM_WHILE, FPC_AM_INNER, FPC_AM_AFTER_LS, FPC_AM_AFTER_LC, FPC_AM_RI_LOOP, FPC_AM_ADV, FPC_AM_EXT_LOOP, FPC_AM_EXT_AFTER, FPC_AM_REC_AFTER
 };
 
 // why a read left the fast path (statistics only)
 enum : uint32_t {
 	FB_NONE = 0, FB_INPUT, FB_LONGPOOL, FB_SUBSAMPLE, FB_COORDS, FB_NGHITS, FB_EDITS, FB_DEPTH, FB_LOCALHITS, FB_GSEARCH, FB_NRES,
-	FB_SEARCHED, FB_REDUNDANT, FB_MATE, FB_NPAIRS, FB_PARTIAL, FB_STRADDLE, FB_OTHER, FB_INDEL, FB_TAIL, FB_COUNT
+	FB_SEARCHED, FB_REDUNDANT, FB_MATE, FB_NPAIRS, FB_PARTIAL, FB_STRADDLE, FB_OTHER, FB_INDEL, FB_TAIL, FB_IEDGES, FB_GWALK, FB_COUNT
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -138,8 +152,15 @@ struct FState {
 	int32_t  f_maxsc, f_prev;                                                                                                          // 36, 37
 	uint32_t f_top : 16, f_bot : 16;                 // rows of a local index (16-bit words); 0xffff stands for "none"                   // 38
 	uint32_t f_nelt : 16, f_maxHitLen : 16;                                                                                             // 39
+#if FG_GRAPH
+	uint32_t a6, a7, a8;                             // node range + packed in-edge list of the last search (BWTHit::_node_top/_node_bot/_node_iedge_count)   // 40-42
+	uint32_t gh_k : 3, gh_gsize : 2, pad43_ : 27;    // getAnchorHits' loop over an anchor's coordinates (each goes through adjustWithALT)                  // 43
+	uint32_t f_ntop : 16, f_nbot : 16;               // node range of the frame's local search                                                           // 44
+	uint32_t f_ie;                                   // ... and its in-edge list                                                                        // 45
+	uint32_t pad46_, pad47_;                                                                                                                         // 46, 47
+#endif
 };
-#define FS_WORDS 40
+#define FS_WORDS (40 + 8 * FG_GRAPH)
 static_assert(sizeof(FState) == FS_WORDS * 4, "FState is FS_WORDS words");
 #define F_SMIN16 (-32768)
 #define F_SMAX16 32767
@@ -163,7 +184,28 @@ struct FCtx {
 	const char* name[2]; uint32_t namelen[2];
 	int64_t* sc; uint32_t sc_stride;               // combineWith temp_scores of this lane
 	FastOut O;
+#if FG_GRAPH
+	const DAlts* alts;                             // the ALT database
+	GraphWS* gws;                                  // this LANE's scratch of one primitive (group walk, ALT-aware extension): nothing in it outlives a trip
+#endif
 };
+#if FG_GRAPH
+// BWTHit::_node_iedge_count in one word: n (2 bits), then (node index, extra in-edges) 7 + 7 bits each, at most two entries; a list that does
+// not fit is FG_IE_NOFIT (the read leaves the fast path the moment that list is needed)
+#define FG_IE_NOFIT 0xffffffffu
+H2G_HD uint32_t fg_ie_pack(const IEdges& ie) {
+	if(ie.n > 2) return FG_IE_NOFIT;
+	uint32_t w = ie.n;
+	if(ie.n > 0) { if(ie.e[0][0] > 127 || ie.e[0][1] > 127) return FG_IE_NOFIT; w |= (ie.e[0][0] << 2) | (ie.e[0][1] << 9); }
+	if(ie.n > 1) { if(ie.e[1][0] > 127 || ie.e[1][1] > 127) return FG_IE_NOFIT; w |= (ie.e[1][0] << 16) | (ie.e[1][1] << 23); }
+	return w;
+}
+H2G_HD void fg_ie_unpack(uint32_t w, IEdges* ie) {
+	ie->n = w & 3u;
+	ie->e[0][0] = (w >> 2) & 127u; ie->e[0][1] = (w >> 9) & 127u;
+	ie->e[1][0] = (w >> 16) & 127u; ie->e[1][1] = (w >> 23) & 127u;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------- stored hits
 H2G_HD uint32_t fg_frame_base(int sp) { return sp == 0 ? (uint32_t)FW_FR0 : (uint32_t)FW_FRX + (uint32_t)(sp - 1) * (FG_FRS + FG_HW); }
@@ -188,6 +230,9 @@ struct FHit {
 	uint32_t tidx, toff, joff; int32_t score;
 	uint32_t rdoff, len, trim5, trim3, fw, nedits, hitcount;
 	uint64_t e;                           // the edits, 16 bits each, in read order: pos | ref base << 8 | read base << 11 | type << 14 (bases 0..4 = ACGTN, 5 = '-')
+#if FG_GRAPH
+	uint32_t snp[FG_FE];                  // Edit::snpID of each edit: index into the ALT list, H2G_MAX = not through a known variant
+#endif
 	uint32_t bad;                         // it stopped fitting (more than FG_FE edits): the read leaves the fast path
 };
 static_assert(FG_FE == 4, "FHit holds four 16-bit edits in one 64-bit word");
@@ -203,6 +248,15 @@ static_assert(FG_FE == 4, "FHit holds four 16-bit edits in one 64-bit word");
 #define FE_MAKE_BP(POS, RFBP, RDBP, TYPE) ((uint32_t)(POS) | ((uint32_t)(RFBP) << 8) | ((uint32_t)(RDBP) << 11) | ((uint32_t)(TYPE) << 14))
 static_assert(H2G_EDIT_MM < 4 && H2G_EDIT_READ_GAP < 4 && H2G_EDIT_REF_GAP < 4, "edit types in two bits");
 H2G_HD bool fe_is_gap(uint32_t e) { const uint32_t t = FE_TYPE(e); return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
+// the edits getLeft / getRight stop at (is_stop_edit of h2g_core.h; hi_aligner.h:937-940, :981-984): gaps, and on a graph index every edit
+// through a known variant
+#if FG_GRAPH
+#define FH_STOP(H, K) (fe_is_gap(FE_GET(H, K)) || (H).snp[K] != H2G_MAX)
+#define FH_ALT(H, K)  ((H).snp[K] != H2G_MAX)
+#else
+#define FH_STOP(H, K) fe_is_gap(FE_GET(H, K))
+#define FH_ALT(H, K)  false
+#endif
 
 H2G_HD FHit fh_load(const FWords& W, uint32_t hb) {
 	uint32_t v[FG_HW];
@@ -213,6 +267,10 @@ H2G_HD FHit fh_load(const FWords& W, uint32_t hb) {
 	h.fw = v[5] & 1u; h.nedits = (v[5] >> 1) & 7u; h.hitcount = v[5] >> 8;
 	h.e = (uint64_t)v[6] | (uint64_t)v[7] << 32;
 	h.e &= h.nedits >= 4 ? ~0ull : (1ull << (16u * h.nedits)) - 1ull;
+#if FG_GRAPH
+#pragma unroll
+	for(uint32_t k = 0; k < FG_FE; k++) h.snp[k] = k < h.nedits ? v[8 + k] : H2G_MAX;
+#endif
 	h.bad = 0;
 	return h;
 }
@@ -221,7 +279,11 @@ H2G_HD bool fh_store(const FWords& W, uint32_t hb, const FHit& h) {
 	if(h.bad || h.nedits > FG_FE || h.score < -(1 << 30) || h.score > (1 << 30) || h.hitcount > 0xffffu) return false;
 	if(h.rdoff > 255 || h.len > 255 || h.trim5 > 255 || h.trim3 > 255) return false;
 	const uint32_t v[FG_HW] = {h.tidx, h.toff, h.joff, (uint32_t)h.score, h.rdoff | (h.len << 8) | (h.trim5 << 16) | (h.trim3 << 24),
-	                           (h.fw ? 1u : 0u) | (h.nedits << 1) | (h.hitcount << 8), (uint32_t)h.e, (uint32_t)(h.e >> 32)};
+	                           (h.fw ? 1u : 0u) | (h.nedits << 1) | (h.hitcount << 8), (uint32_t)h.e, (uint32_t)(h.e >> 32)
+#if FG_GRAPH
+	                           , h.snp[0], h.snp[1], h.snp[2], h.snp[3]
+#endif
+	};
 	W.stv<FG_HW>(hb, v);
 	return true;
 }
@@ -256,11 +318,11 @@ H2G_HD void fh_get_right(const FHit& h, uint32_t* rdoff, uint32_t* len, uint32_t
 	*rdoff = h.rdoff; *len = h.len; *toff = h.toff;
 	int last = -1;
 #pragma unroll
-	for(int i = 0; i < FG_FE; i++) if((uint32_t)i < h.nedits && fe_is_gap(FE_GET(h, i))) last = i;
+	for(int i = 0; i < FG_FE; i++) if((uint32_t)i < h.nedits && FH_STOP(h, i)) last = i;
 	if(last < 0) return;
 	const uint32_t e = FE_GET(h, last);
 	*rdoff = h.rdoff + FE_POS(e); *len = h.len - FE_POS(e);
-	if(FE_TYPE(e) == H2G_EDIT_REF_GAP) { (*rdoff)++; (*len)--; }
+	if(FE_TYPE(e) == H2G_EDIT_REF_GAP || FE_TYPE(e) == H2G_EDIT_MM) { (*rdoff)++; (*len)--; }     // (a mismatch stops the part on a graph index only: hit_get_right)
 	uint32_t roff = h.toff + h.len;
 #pragma unroll
 	for(uint32_t k = 0; k < FG_FE; k++) if(k < h.nedits) {
@@ -274,7 +336,7 @@ H2G_HD void fh_get_left(const FHit& h, uint32_t* rdoff, uint32_t* len, uint32_t*
 	*toff = h.toff; *rdoff = h.rdoff; *len = h.len;
 	bool stop = false;
 #pragma unroll
-	for(uint32_t i = 0; i < FG_FE; i++) if(i < h.nedits && !stop && fe_is_gap(FE_GET(h, i))) { *len = FE_POS(FE_GET(h, i)); stop = true; }
+	for(uint32_t i = 0; i < FG_FE; i++) if(i < h.nedits && !stop && FH_STOP(h, i)) { *len = FE_POS(FE_GET(h, i)); stop = true; }
 }
 // compatibleWith :1375-1413 (hit_compatible) without spliced alignment
 H2G_HD bool fh_compatible(const FHit& a, const FHit& b) {
@@ -297,6 +359,7 @@ H2G_HD void fh_calc_score(const DScoring& sc, const SeqView& seq, FHit& h) {
 #pragma unroll
 	for(uint32_t i = 0; i < FG_FE; i++) if(i < h.nedits) {
 		const uint32_t e = FE_GET(h, i), t = FE_TYPE(e);
+		if(FH_ALT(h, i)) { prev = e; continue; }           // edits through known variants cost nothing (calculate_score of h2g_core.h; hi_aligner.h:3737, :3846, :3858)
 		if(t == H2G_EDIT_MM) {
 			const int q = seq.qual(h.rdoff + FE_POS(e)) - 33;
 			if(FE_QCODE(e) == 4) score -= sc.nPen;
@@ -318,6 +381,7 @@ H2G_HD void fh_calc_score(const DScoring& sc, const SeqView& seq, FHit& h) {
 	if(score < -(1 << 30)) { h.bad = 1; score = -(1 << 30); }
 	h.score = (int32_t)score;
 }
+#if !FG_GRAPH      // (on a graph index extension and joins are the ALT-aware item functions of h2g_graph.h / h2g_align.h over an unpacked hit)
 // positions (bit 2j = position j, j < n <= 32) at which two 2-bit strings differ
 H2G_HD uint64_t fh_diff32(uint64_t r, uint64_t q, uint32_t n) {
 	const uint64_t x = r ^ q;
@@ -587,6 +651,39 @@ H2G_HD bool fh_combine(const DRef& ref, const DScoring& sc, const SeqView& seq, 
 	fh_calc_score(sc, seq, a);
 	return true;
 }
+#else
+// a register hit <-> the general GenomeHit record the ALT-aware item functions work on
+H2G_HD void fh_to_ghit(const FHit& h, h2g_ghit* g) {
+	g->read = h.hitcount; g->fw = h.fw; g->rdoff = h.rdoff; g->len = h.len; g->trim5 = h.trim5; g->trim3 = h.trim3; g->tidx = h.tidx; g->toff = h.toff; g->joinedOff = h.joff;
+	g->splicescore = 0; g->score = h.score; g->nedits = h.nedits; g->overflow = 0;
+#pragma unroll
+	for(uint32_t k = 0; k < FG_FE; k++) if(k < h.nedits) {
+		const uint32_t e = FE_GET(h, k);
+		h2g_edit o;
+		o.pos = FE_POS(e); o.chr = (uint8_t)FE_CHR(e); o.qchr = (uint8_t)FE_QCHR(e); o.type = (uint8_t)FE_TYPE(e); o.pad = 0; o.snp = h.snp[k];
+		g->edits[k] = o;
+	}
+}
+H2G_HD uint32_t fe_code_of(uint8_t ch) { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 4u : ch == '-' ? 5u : 7u; }
+// (h.bad: the record does not fit the register form — more than FG_FE edits, an edit type / position / base outside it, a flagged record)
+H2G_HD void ghit_to_fh(const h2g_ghit& g, FHit& h) {
+	h.tidx = g.tidx; h.toff = g.toff; h.joff = g.joinedOff; h.rdoff = g.rdoff; h.len = g.len; h.trim5 = g.trim5; h.trim3 = g.trim3; h.fw = g.fw ? 1u : 0u;
+	h.hitcount = g.read; h.nedits = g.nedits; h.e = 0; h.bad = 0;
+	if(g.overflow || g.nedits > FG_FE || g.splicescore != 0 || g.score < -(int64_t)(1 << 30) || g.score > (int64_t)(1 << 30)) { h.bad = 1; h.nedits = 0; h.score = 0; }
+	else h.score = (int32_t)g.score;
+#pragma unroll
+	for(uint32_t k = 0; k < FG_FE; k++) {
+		h.snp[k] = H2G_MAX;
+		if(k < h.nedits) {
+			const h2g_edit o = g.edits[k];
+			const uint32_t cc = fe_code_of(o.chr), qc = fe_code_of(o.qchr);
+			if(o.pos > 255 || cc > 5 || qc > 5 || o.pad != 0 || !(o.type == H2G_EDIT_MM || o.type == H2G_EDIT_READ_GAP || o.type == H2G_EDIT_REF_GAP)) h.bad = 1;
+			FE_SET(h, k, FE_MAKE_BP(o.pos & 0xffu, cc & 7u, qc & 7u, o.type & 3u));
+			h.snp[k] = o.snp;
+		}
+	}
+}
+#endif
 
 // small per-strand arrays by explicit selects (registers, no private-memory indexing)
 
@@ -604,7 +701,7 @@ H2G_HD SeqView fg_sv(const FCtx& C, const FState& S) { return fg_view(C, S, S.pa
 
 // the long partial hits of strand x leave the pool (the strand is done)
 H2G_HD void fg_pool_free(const FWords& W, uint32_t x) {
-	for(uint32_t k = 0; k < FG_NLONG; k++) { const uint32_t m = W.ld(FW_LONG + 3 * k + 2); if(m && ((m >> 20) & 3u) == x) W.st(FW_LONG + 3 * k + 2, 0); }
+	for(uint32_t k = 0; k < FG_NLONG; k++) { const uint32_t m = W.ld(FW_LONG + FG_LW * k + 2); if(m && ((m >> 20) & 3u) == x) W.st(FW_LONG + FG_LW * k + 2, 0); }
 }
 // packs read i of `rd` for the fast path: 8 words of 2-bit codes (word k of this lane at pk[k * stride]).  false: an N, or longer than 128 bases.
 H2G_HD bool fg_pack_read(const DReads& rd, uint32_t i, uint32_t* pk, uint32_t stride) {
@@ -677,6 +774,9 @@ H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, boo
 	S.rb_done = S.rb_nonempty = S.found = 0; S.rnd = 0; S.ro0 = S.ro1 = 0; S.rl0 = S.rl1 = 0;
 	S.nres0 = S.nres1 = S.nsearched0 = S.nsearched1 = 0; S.bestUnp0 = S.bestUnp1 = S.best2Unp0 = S.best2Unp1 = F_SMIN16; S.minsc0 = S.minsc1 = F_SMAX16;
 	S.pad23_ = 0; S.pad27_ = 0; S.pad28_ = 0; S.rc_mate = 0; S.pad30_ = 0; S.pad35_ = 0;
+#if FG_GRAPH
+	S.a6 = S.a7 = S.a8 = 0; S.gh_k = S.gh_gsize = 0; S.pad43_ = 0; S.f_ntop = S.f_nbot = 0; S.f_ie = 0; S.pad46_ = S.pad47_ = 0;
+#endif
 	S.npairs = S.pairs = S.insp_i = S.insp_j = 0; S.bestPair = S.best2Pair = F_SMIN;
 	S.nrank = S.nside = S.nsteps = S.nframes_max = 0; S.nghits = S.ghit_done = 0; S.localindexatts = S.max_localindexatts = 0;
 	S.ro0 = C.rd[0].offs[read]; S.ro1 = C.rd[1].offs[read];                     // (unpaired: rd[1] is rd[0])
@@ -758,6 +858,9 @@ H2G_HD void fg_write_rec(h2g_alnres& d, const FHit& hit, uint32_t rdlen) {
 		pos -= trim5p;
 		h2g_edit o;
 		o.pos = pos; o.chr = (uint8_t)FE_CHR(e); o.qchr = (uint8_t)FE_QCHR(e); o.type = (uint8_t)FE_TYPE(e); o.pad = 0; o.snp = H2G_MAX;
+#if FG_GRAPH
+		o.snp = hit.fw ? hit.snp[k] : hit.snp[hit.nedits - 1 - k];
+#endif
 		d.edits[k] = o;
 	}
 }
@@ -799,7 +902,7 @@ again:
 		S.rb_cur = S.rb_nps = S.rb_nus = S.rb_np = 0; S.rb_sumsq0 = S.rb_sumsq1 = S.rb_sumsq2 = S.rb_sumsq3 = 0;
 		S.rb_done = 0; S.rb_nonempty = 0;
 		S.found = S.paired ? 15u : 3u;                           // found[0][0], [0][1], [1][0], [1][1]
-		for(uint32_t k = 0; k < FG_NLONG; k++) W.st(FW_LONG + 3 * k + 2, 0);
+		for(uint32_t k = 0; k < FG_NLONG; k++) W.st(FW_LONG + FG_LW * k + 2, 0);
 		F_GOTO(FPC_NB_PICK);
 	}
 	case FPC_NB_PICK: {                                   // one iteration of nextBWT's loop (:4644-4760)
@@ -852,10 +955,14 @@ again:
 			S.rb_nonempty |= 1u << x;
 			if(len > minK + 2) {                            // getAnchorHits looks at these only (:5033)
 				uint32_t k = 0;
-				for(; k < FG_NLONG; k++) if(W.ld(FW_LONG + 3 * k + 2) == 0) break;
+				for(; k < FG_NLONG; k++) if(W.ld(FW_LONG + FG_LW * k + 2) == 0) break;
 				if(k >= FG_NLONG) F_BAIL(FB_LONGPOOL);
-				W.st(FW_LONG + 3 * k, top); W.st(FW_LONG + 3 * k + 1, bot);
-				W.st(FW_LONG + 3 * k + 2, 0x80000000u | S.a5 | (len << 8) | (type << 16) | (x << 20) | (np << 24));   // bwoff, len, type, strand, index
+				W.st(FW_LONG + FG_LW * k, top); W.st(FW_LONG + FG_LW * k + 1, bot);
+#if FG_GRAPH
+				if(S.a8 == FG_IE_NOFIT) F_BAIL(FB_IEDGES);
+				W.st(FW_LONG + FG_LW * k + 3, S.a6); W.st(FW_LONG + FG_LW * k + 4, S.a7); W.st(FW_LONG + FG_LW * k + 5, S.a8);   // pnode: node range, in-edges
+#endif
+				W.st(FW_LONG + FG_LW * k + 2, 0x80000000u | S.a5 | (len << 8) | (type << 16) | (x << 20) | (np << 24));   // bwoff, len, type, strand, index
 			}
 		}
 		S.rb_np = fs_b4_set(S.rb_np, x, np + 1);
@@ -1106,13 +1213,13 @@ again:
 			int kidx = 1 << 20;
 #pragma unroll
 			for(uint32_t q = 0; q < FG_NLONG; q++) {
-				const uint32_t mq = W.ld(FW_LONG + 3 * q + 2);
+				const uint32_t mq = W.ld(FW_LONG + FG_LW * q + 2);
 				const int iq = (int)((mq >> 24) & 31u);
 				if(mq && !(mq & 0x40000000u) && ((mq >> 20) & 3u) == x && iq > last && iq < kidx) { k = q; m = mq; kidx = iq; }
 			}
 			if(k == FG_NLONG) break;
 			last = kidx;
-			const uint32_t top = W.ld(FW_LONG + 3 * k), bot = W.ld(FW_LONG + 3 * k + 1);
+			const uint32_t top = W.ld(FW_LONG + FG_LW * k), bot = W.ld(FW_LONG + FG_LW * k + 1);
 			if(hj == FG_NLONG) { hj = k; mj = m; tj_top = top; tj_bot = bot; continue; }
 			const uint32_t tj = (mj >> 16) & 15u, tk = (m >> 16) & 15u, lj = (mj >> 8) & 0xffu, lk = (m >> 8) & 0xffu;
 			const uint32_t sj = tj_bot - tj_top, sk = bot - top;
@@ -1122,21 +1229,71 @@ again:
 		if(hj == FG_NLONG) F_GOTO(FPC_GAH_END);
 		const uint32_t remained = maxsz - S.nghits;
 		if(remained == 0) F_GOTO(FPC_GAH_END);
-		const uint32_t expected = tj_bot - tj_top, len = (mj >> 8) & 0xffu, bwoff = mj & 0xffu;
+		const uint32_t len = (mj >> 8) & 0xffu, bwoff = mj & 0xffu;
+#if FG_GRAPH
+		uint32_t pn[3];                                     // the hit's node range and in-edge list: the elements are NODES
+		W.ldv<3>(FW_LONG + FG_LW * hj + 3, pn);
+		const uint32_t expected = pn[1] - pn[0];
+#else
+		const uint32_t expected = tj_bot - tj_top;
+#endif
 		if(expected > remained) F_BAIL(FB_SUBSAMPLE);       // the random sub-sample of a repeat's rows (:5096-5136)
 		if(expected > FG_NCO) F_BAIL(FB_COORDS);
 		S.gh_hj = hj; S.gh_nco = 0;
 		S.gh_rdoff = fs_rl(S, S.sel_r) - bwoff - len;
 		S.a0 = tj_top; S.a1 = tj_bot; S.a2 = expected; S.a3 = len; S.a4 = 0; S.a5 = fg_frame_co(0);
+#if FG_GRAPH
+		S.a6 = pn[0]; S.a7 = pn[1]; S.a8 = pn[2];
+#endif
 		F_OP(FOP_GCOORDS, FPC_GAH_FULL_AFTER);
 	}
 	case FPC_GAH_FULL_AFTER: {
 		const uint32_t nco = S.a0;
 		{ const uint32_t nt_ = S.nsteps + S.a1; if(nt_ > 0xffffu) F_BAIL(FB_OTHER); S.nsteps = nt_; }
 		if(nco == 0) F_BAIL(FB_COORDS);                     // joinedToTextOff failed: the reference retries the same hit (:5140)
-		const uint32_t mslot = FW_LONG + 3 * S.gh_hj + 2;
+		const uint32_t mslot = FW_LONG + FG_LW * S.gh_hj + 2;
 		const uint32_t m = W.ld(mslot);
 		W.st(mslot, m | 0x40000000u);                       // ph.ncoords = nco
+#if FG_GRAPH
+		S.gh_nco = nco; S.gh_gsize = S.nghits; S.gh_k = 0;  // gsize + nco <= maxsz: no shuffle (:5147)
+		F_GOTO(FPC_GAH_K_LOOP);
+	}
+	case FPC_GAH_K_LOOP: {                                // each coordinate goes through adjustWithALT, which may yield several hits or none (:5175)
+		const uint32_t m = W.ld(FW_LONG + FG_LW * S.gh_hj + 2);
+		const uint32_t len = (m >> 8) & 0xffu, type = (m >> 16) & 15u;
+		const uint32_t rl = fs_rl(S, S.sel_r);
+		while(S.gh_k < S.gh_nco) {
+			uint32_t co3[3];
+			W.ldv<3>(fg_frame_co(0) + 3 * S.gh_k, co3);
+			const uint32_t tidx = co3[0], toff = co3[1], joff = co3[2];
+			if(tidx == H2G_MAX) F_BAIL(FB_STRADDLE);
+			bool overlapped = false;
+			for(uint32_t l = 0; l < S.gh_gsize; l++) {
+				const uint32_t gb = l == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+				const uint32_t w5 = W.ld(gb + 5);
+				if(W.ld(gb) != tidx || ((w5 & 1u) != 0) != (S.sv_fw != 0)) continue;
+				const uint32_t g_rdoff = W.ld(gb + 4) & 0xffu;
+				const uint32_t hitoff = W.ld(gb + 1) + rl - g_rdoff, hitoff2 = toff + rl - S.gh_rdoff;
+				if(hitoff == hitoff2) { overlapped = true; W.st(gb + 5, w5 + (1u << 8)); break; }   // _hitcount++
+			}
+			if(!overlapped) {
+				S.a0 = S.gh_rdoff; S.a1 = len; S.a2 = tidx; S.a3 = toff; S.a4 = joff;
+				F_OP(FOP_ADJUST, FPC_GAH_K_AFTER);
+			}
+			if(type == H2G_CANDIDATE_HIT && S.nghits >= maxsz) break;
+			S.gh_k = S.gh_k + 1;
+		}
+		if(type == H2G_CANDIDATE_HIT && S.nghits >= maxsz) F_GOTO(FPC_GAH_END);
+		S.gh_hi++;
+		F_GOTO(FPC_GAH_LOOP);
+	}
+	case FPC_GAH_K_AFTER: {
+		const uint32_t type = (W.ld(FW_LONG + FG_LW * S.gh_hj + 2) >> 16) & 15u;
+		if(type == H2G_CANDIDATE_HIT && S.nghits >= maxsz) F_GOTO(FPC_GAH_END);
+		S.gh_k = S.gh_k + 1;
+		F_GOTO(FPC_GAH_K_LOOP);
+	}
+#else
 		const uint32_t len = (m >> 8) & 0xffu, type = (m >> 16) & 15u;
 		const uint32_t gsize = S.nghits;                    // gsize + nco <= maxsz: no shuffle (:5147)
 		const uint32_t rl = fs_rl(S, S.sel_r);
@@ -1165,6 +1322,7 @@ again:
 		S.gh_hi++;
 		F_GOTO(FPC_GAH_LOOP);
 	}
+#endif
 	case FPC_GAH_END: {
 		const uint32_t numHits = S.nghits;
 		if(numHits == 0) { S.hs_found = 0; F_GOTO(FPC_AFTER_ALIGN); }
@@ -1318,12 +1476,20 @@ again:
 		if(!(S.f_extoff < fs_rl(S, S.sv_rdi))) F_GOTO(FPC_L_LS_DONE);
 		S.f_extlen = 0; S.f_unique = 1;
 		S.localindexatts++;
-		if(C.ls->desc[S.f_lidx].len == 0) { S.a0 = 0; S.a1 = 0; S.a2 = S.f_top; S.a3 = S.f_bot; S.a4 = 1; F_GOTO(FPC_L_LS_AFTER); }
+		if(C.ls->desc[S.f_lidx].len == 0) {
+#if FG_GRAPH
+			S.a6 = S.f_ntop; S.a7 = S.f_nbot; S.a8 = S.f_ie;
+#endif
+			S.a0 = 0; S.a1 = 0; S.a2 = S.f_top; S.a3 = S.f_bot; S.a4 = 1; F_GOTO(FPC_L_LS_AFTER);
+		}
 		S.a0 = S.f_lidx; S.a1 = S.f_extoff; S.a2 = 0xffffu; S.a3 = 1; S.a4 = S.f_top; S.a5 = S.f_bot;
 		F_OP(FOP_LSEARCH, FPC_L_LS_AFTER);
 	}
 	case FPC_L_LS_AFTER: {
 		S.f_nelt = S.a0; S.f_extlen = S.a1; S.f_top = S.a2; S.f_bot = S.a3; S.f_unique = S.a4 & 1u;
+#if FG_GRAPH
+		S.f_ntop = S.a6; S.f_nbot = S.a7; S.f_ie = S.a8;
+#endif
 		if(S.f_extoff + 1 - S.f_extlen >= S.f_hitoff) { S.f_noext = 1; F_GOTO(FPC_L_LS_DONE); }
 		if(S.f_nelt <= 5) F_GOTO(FPC_L_LS_DONE);
 		S.f_extoff++;
@@ -1332,7 +1498,13 @@ again:
 	case FPC_L_LS_DONE: {
 		S.f_ncoords = 0; S.f_ri = -1;
 		if(S.f_nelt > 0 && S.f_nelt <= 5 && S.f_extlen >= P.minAnchorLen && !S.f_noext) {
+#if FG_GRAPH
+			if(S.f_nbot - S.f_ntop > FG_NCO || S.f_bot - S.f_top > 255) F_BAIL(FB_COORDS);      // (the elements are nodes)
+			if(S.f_ie == FG_IE_NOFIT) F_BAIL(FB_IEDGES);
+			S.a6 = S.f_ntop; S.a7 = S.f_nbot; S.a8 = S.f_ie;
+#else
 			if(S.f_bot - S.f_top > FG_NCO) F_BAIL(FB_COORDS);
+#endif
 			S.a0 = S.f_lidx; S.a1 = S.f_top; S.a2 = S.f_bot; S.a3 = S.f_extoff + 1 - S.f_extlen; S.a4 = S.f_extlen; S.a5 = fg_frame_co(S.sp);
 			F_OP(FOP_LCOORDS, FPC_L_LC_AFTER);
 		}
@@ -1350,6 +1522,13 @@ again:
 		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
 		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
+#if FG_GRAPH
+		S.a3 = FW_T1; F_OP(FOP_ADJMEMBER, FPC_L_RI_A);      // tempHit.adjustWithALT (spliced_aligner.h:946)
+	}
+	case FPC_L_RI_A: {
+		if(!S.a0) { S.f_ri--; F_GOTO(FPC_L_FOR_RI); }
+		const uint32_t hb = fg_frame_hit(S.sp);
+#endif
 		if(!fh_compatible(fh_load(W, FW_T1), fh_load(W, hb))) {
 			if(S.f_count == 1) { S.f_ri--; F_GOTO(FPC_L_FOR_RI); }
 			F_GOTO(FPC_L_AFTER_FOR);
@@ -1412,6 +1591,9 @@ again:
 		const bool left = S.pc == FPC_L_GS_AFTER;
 		S.f_extlen = S.a1; S.f_unique = S.a4 & 1u;
 		if(nelt > 0 && nelt <= 5 && S.f_extlen >= minK) {
+#if FG_GRAPH
+			if(S.a8 == FG_IE_NOFIT) F_BAIL(FB_IEDGES);          // (a6 .. a8: the search's node range and in-edge list, as it left them)
+#endif
 			S.a0 = top; S.a1 = bot; S.a2 = bot - top; S.a3 = S.f_extlen; S.a4 = 1; S.a5 = fg_frame_co(S.sp);
 			if(left) F_OP(FOP_GCOORDS, FPC_L_GC_AFTER); else F_OP(FOP_GCOORDS, FPC_R_GC_AFTER);
 		}
@@ -1436,6 +1618,13 @@ again:
 		S.f_ri--;
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
 		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
+#if FG_GRAPH
+		S.a3 = FW_T1; F_OP(FOP_ADJMEMBER, FPC_L_G_A);       // (:1139)
+	}
+	case FPC_L_G_A: {
+		if(!S.a0) F_GOTO(FPC_L_FOR_G);
+		const uint32_t hb = fg_frame_hit(S.sp);
+#endif
 		if(!fh_compatible(fh_load(W, FW_T1), fh_load(W, hb))) F_GOTO(FPC_L_FOR_G);
 		if(S.f_unique) { S.a0 = 0; S.a1 = H2G_MAX; S.a2 = 0; S.a3 = FW_T1; F_OP(FOP_EXTEND, FPC_L_G_B); }
 		F_GOTO(FPC_L_G_B);
@@ -1525,13 +1714,21 @@ again:
 		if(!(S.f_maxHitLen < S.f_extoff + 1 && S.f_extoff < fs_rl(S, S.sv_rdi))) F_GOTO(FPC_R_LS_DONE);
 		S.f_extlen = 0; S.f_unique = 0;
 		S.localindexatts++;
-		if(C.ls->desc[S.f_lidx].len == 0) { S.a0 = 0; S.a1 = 0; S.a2 = S.f_top; S.a3 = S.f_bot; S.a4 = 0; F_GOTO(FPC_R_LS_AFTER); }
+		if(C.ls->desc[S.f_lidx].len == 0) {
+#if FG_GRAPH
+			S.a6 = S.f_ntop; S.a7 = S.f_nbot; S.a8 = S.f_ie;
+#endif
+			S.a0 = 0; S.a1 = 0; S.a2 = S.f_top; S.a3 = S.f_bot; S.a4 = 0; F_GOTO(FPC_R_LS_AFTER);
+		}
 		S.a0 = S.f_lidx; S.a1 = S.f_extoff; S.a2 = S.f_maxHitLen; S.a3 = 0; S.a4 = S.f_top; S.a5 = S.f_bot;
 		F_OP(FOP_LSEARCH, FPC_R_LS_AFTER);
 	}
 	case FPC_R_LS_AFTER: {
 		const uint32_t rdlen = fs_rl(S, S.sv_rdi);
 		S.f_nelt = S.a0; S.f_extlen = S.a1; S.f_top = S.a2; S.f_bot = S.a3; S.f_unique = S.a4 & 1u;
+#if FG_GRAPH
+		S.f_ntop = S.a6; S.f_nbot = S.a7; S.f_ie = S.a8;
+#endif
 		if(S.f_extoff < S.f_hitoff + S.f_hitlen) { S.f_noext = 1; F_GOTO(FPC_R_LS_DONE); }
 		if(S.f_nelt <= 5) F_GOTO(FPC_R_LS_DONE);
 		if(S.f_extoff + 1 < rdlen) S.f_extoff++;
@@ -1541,7 +1738,13 @@ again:
 	case FPC_R_LS_DONE: {
 		S.f_ncoords = 0; S.f_ri = 0;
 		if(S.f_nelt > 0 && S.f_nelt <= 5 && S.f_extlen >= P.minAnchorLen && !S.f_noext) {
+#if FG_GRAPH
+			if(S.f_nbot - S.f_ntop > FG_NCO || S.f_bot - S.f_top > 255) F_BAIL(FB_COORDS);      // (the elements are nodes)
+			if(S.f_ie == FG_IE_NOFIT) F_BAIL(FB_IEDGES);
+			S.a6 = S.f_ntop; S.a7 = S.f_nbot; S.a8 = S.f_ie;
+#else
 			if(S.f_bot - S.f_top > FG_NCO) F_BAIL(FB_COORDS);
+#endif
 			S.a0 = S.f_lidx; S.a1 = S.f_top; S.a2 = S.f_bot; S.a3 = S.f_extoff + 1 - S.f_extlen; S.a4 = S.f_extlen; S.a5 = fg_frame_co(S.sp);
 			F_OP(FOP_LCOORDS, FPC_R_LC_AFTER);
 		}
@@ -1552,6 +1755,13 @@ again:
 		const uint32_t cb = fg_frame_co(S.sp) + 3 * (uint32_t)S.f_ri, hb = fg_frame_hit(S.sp);
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
 		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
+#if FG_GRAPH
+		S.a3 = FW_T1; F_OP(FOP_ADJMEMBER, FPC_R_RI_A);      // (:1635)
+	}
+	case FPC_R_RI_A: {
+		if(!S.a0) { S.f_ri++; F_GOTO(FPC_R_FOR_RI); }
+		const uint32_t hb = fg_frame_hit(S.sp);
+#endif
 		if(!fh_compatible(fh_load(W, hb), fh_load(W, FW_T1))) {
 			if(S.f_count == 1) { S.f_ri++; F_GOTO(FPC_R_FOR_RI); }
 			F_GOTO(FPC_R_AFTER_FOR);
@@ -1620,6 +1830,13 @@ again:
 		S.f_ri++;
 		const bool fw = (W.ld(hb + 5) & 1u) != 0;
 		{ uint32_t co3[3]; W.ldv<3>(cb, co3); fg_hit_init(W, FW_T1, fw, S.f_extoff + 1 - S.f_extlen, S.f_extlen, co3[0], co3[1], co3[2]); }
+#if FG_GRAPH
+		S.a3 = FW_T1; F_OP(FOP_ADJMEMBER, FPC_R_G_A);       // (:1826)
+	}
+	case FPC_R_G_A: {
+		if(!S.a0) F_GOTO(FPC_R_FOR_G);
+		const uint32_t hb = fg_frame_hit(S.sp);
+#endif
 		if(!fh_compatible(fh_load(W, hb), fh_load(W, FW_T1))) F_GOTO(FPC_R_FOR_G);
 		S.a0 = 0; S.a1 = 0; S.a2 = H2G_MAX; S.a3 = FW_T1;
 		F_OP(FOP_EXTEND, FPC_R_G_B);
@@ -1769,7 +1986,13 @@ again:
 H2G_HD void fast_op_psearch(const FCtx& C, FState& S) {
 	const AlnParams& P = *C.P;
 	h2g_fm_hit fh;
+#if FG_GRAPH
+	IEdges ie;
+	partial_search_graph_item(*C.g, fg_sv(C, S), S.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, P.kseeds, &fh, &ie);
+	S.a6 = fh.node_top; S.a7 = fh.node_bot; S.a8 = fg_ie_pack(ie);
+#else
 	partial_search_item(*C.g, fg_sv(C, S), S.a0, P.pseudogeneStop != 0, P.anchorStop != 0, P.khits, &fh);
+#endif
 	S.a5 = S.a0;
 	S.a0 = fh.top; S.a1 = fh.bot;
 	S.a2 = (fh.len & 0xffu) | (fh.hit_type << 8) | ((fh.done ? 1u : 0u) << 16) | ((fh.anchorStop ? 1u : 0u) << 17) | (fh.numUniqueSearch << 18);
@@ -1786,6 +2009,23 @@ H2G_HD void fast_op_psearch(const FCtx& C, FState& S) {
 // getGenomeCoords :5774 (genome_coords_item), coordinates straight to the word store.  a0 top a1 bot a2 maxelt a3 len a4 rejectStraddle a5 dst;
 // while it is under way a1 = the row the walk stands at, a2 = elements | (1 | element << 1 | coordinates written << 4 | jumps << 7) << 8.
 // true: not finished
+#if FG_GRAPH
+// getGenomeCoords on a graph index: the node-based group walk (genome_coords_graph_item) on this lane's scratch, in one go.
+// a0 top a1 bot a2 maxelt a3 len a4 rejectStraddle a5 dst a6 / a7 node range a8 in-edges
+H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
+	IEdges ie;
+	fg_ie_unpack(S.a8, &ie);
+	h2g_coord co[FG_NCO];
+	h2g_sa_result res;
+	genome_coords_graph_item(*C.g, &C.gws->gw, S.a0, S.a1, S.a6, S.a7, &ie, S.a2, S.a3, (S.a4 & 1u) != 0, co, FG_NCO, &res);
+	if(res.nsteps == H2G_MAX) { S.pc = FPC_BAIL; S.bail = FB_GWALK; return false; }       // a capacity of the group walk
+#pragma unroll
+	for(uint32_t e = 0; e < FG_NCO; e++) if(e < res.ncoords) { const uint32_t co3[3] = {co[e].tidx, co[e].toff, co[e].joinedOff}; W.stv<3>(S.a5 + 3 * e, co3); }
+	S.nsteps += res.nsteps;
+	S.a0 = res.ncoords; S.a1 = 0;
+	return false;
+}
+#else
 H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
 	const DGfm& g = *C.g;
 	const bool reject = (S.a4 & 1u) != 0;
@@ -1836,6 +2076,72 @@ H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
 	S.a0 = n; S.a1 = 0;
 	return false;
 }
+#endif
+#if FG_GRAPH
+// GenomeHit::extend on a graph index: alignWithALTs through the ALT database (extend_item_alts) over the unpacked hit
+H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
+	FHit h = fh_load(W, S.a3);
+	h2g_ghit g;
+	fh_to_ghit(h, &g);
+	uint32_t le = H2G_MAX, re = H2G_MAX;
+	extend_item_alts(*C.ref, *C.alts, C.P->sc, fg_sv(C, S), &g, S.a0, S.a1, S.a2, &le, &re, &C.gws->awa);
+	ghit_to_fh(g, h);
+	if(!fh_store(W, S.a3, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
+	S.a0 = le; S.a1 = re;
+}
+// static adjustWithALT (hi_aligner.h:2239; adjust_with_alt): the anchor (a0 rdoff, a1 len) placed at (a2 tidx, a3 toff, a4 joinedOff) becomes the
+// genome hits it yields.  It compares what it adds with the hits already there, so those go in first.
+H2G_HD void fast_op_adjust(const FCtx& C, FState& S, const FWords& W) {
+	h2g_ghit arr[2];
+	uint32_t n = S.nghits, ovf = 0;
+	if(n >= 1) fh_to_ghit(fh_load(W, FW_G0), &arr[0]);
+	if(n >= 2) fh_to_ghit(fh_load(W, FW_G1), &arr[1]);
+	adjust_with_alt(*C.g, *C.ref, *C.alts, fg_sv(C, S), S.a0, S.a1, S.a2, S.a3, S.a4, arr, &n, 2, &C.gws->awa, &ovf);
+	if(ovf) { S.pc = FPC_BAIL; S.bail = FB_NGHITS; return; }
+	for(uint32_t k = S.nghits; k < n && k < 2; k++) {
+		FHit h;
+		ghit_to_fh(arr[k], h);
+		if(!fh_store(W, k == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; return; }
+	}
+	S.nghits = n;
+	S.a0 = 0;
+}
+// member adjustWithALT (hi_aligner.h:2395; adjust_with_alt_member) of the hit at a3: re-seated, or a0 = 0
+H2G_HD void fast_op_adjmember(const FCtx& C, FState& S, const FWords& W) {
+	FHit h = fh_load(W, S.a3);
+	h2g_ghit g;
+	fh_to_ghit(h, &g);
+	uint32_t ovf = 0;
+	const bool ok = adjust_with_alt_member(*C.g, *C.ref, *C.alts, fg_sv(C, S), &g, &C.gws->awa, &ovf);
+	if(ovf) { S.pc = FPC_BAIL; S.bail = FB_OTHER; return; }
+	ghit_to_fh(g, h);
+	if(ok && !fh_store(W, S.a3, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; return; }
+	S.a0 = ok ? 1u : 0u;
+}
+// localGFMSearch on the three kinds of local index a graph index holds (al_local_search)
+H2G_HD void fast_op_lsearch(const FCtx& C, FState& S) {
+	const AlnParams& P = *C.P;
+	uint32_t extlen = 0, top = S.a4, bot = S.a5, nr[2] = {0, 0};
+	bool uniqueStop = S.a3 != 0;
+	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[S.a0];
+	uint32_t nelt;
+	if(local_is_linear(*lx.d)) {
+		LIdxW lw; lw.ls = C.ls; lw.d = lx.d;
+		nelt = gfm_search(lw, fg_sv(C, S), S.a1, &extlen, &top, &bot, &uniqueStop, P.minK_local, S.a2, P.kseeds, true, nr);
+		S.a6 = top; S.a7 = bot; S.a8 = 0;
+	} else {
+		const LGfm x = lgfm_of(*C.ls, *lx.d);
+		GRange r;
+		r.top = top; r.bot = bot; r.node_top = r.node_bot = 0;
+		IEdges ie;
+		nelt = gfm_search_graph(x, lx, fg_sv(C, S), S.a1, &extlen, &r, &ie, &uniqueStop, P.minK_local, S.a2, P.kseeds, true, P.kseeds, nr);
+		top = r.top; bot = r.bot;
+		S.a6 = r.node_top; S.a7 = r.node_bot; S.a8 = fg_ie_pack(ie);
+	}
+	S.nrank += nr[0]; S.nside += nr[1];
+	S.a0 = nelt; S.a1 = extlen; S.a2 = top; S.a3 = bot; S.a4 = uniqueStop ? 1u : 0u;
+}
+#else
 H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
 	FHit h = fh_load(W, S.a3);
 	uint32_t le = H2G_MAX, re = H2G_MAX;
@@ -1852,10 +2158,11 @@ H2G_HD void fast_op_lsearch(const FCtx& C, FState& S) {
 	S.nrank += nr[0]; S.nside += nr[1];
 	S.a0 = nelt; S.a1 = extlen; S.a2 = top; S.a3 = bot; S.a4 = uniqueStop ? 1u : 0u;
 }
+#endif
 // getGenomeCoords_local :5861 (genome_coords_local), chunked like fast_op_gcoords.  a0 lidx a1 top a2 bot a3 rdoff a4 rdlen a5 dst; under way:
 // a2 bits 16.. = 1 | element << 1 | coordinates written << 4 | jumps << 7, a4 bits 8.. = the row (16 bits)
-H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
-	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[S.a0];
+template <typename LX>
+H2G_HD bool fast_op_lcoords_walk(const FCtx& C, FState& S, const FWords& W, const LX& lx) {
 	const uint32_t offMask = (0xffffu << C.ls->offRate) & 0xffffu, offRate = C.ls->offRate;
 	const uint16_t* offs = C.ls->words + lx.d->offs_off;
 	const uint32_t top = S.a1, bot = S.a2 & 0xffffu, rdlen = S.a4 & 0xffu;
@@ -1894,6 +2201,60 @@ H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
 	S.a0 = n;
 	return false;
 }
+#if FG_GRAPH
+// getGenomeCoords_local on whichever kind of local index this is (al_local_coords): a linear one inside the graph index walks as on a
+// linear index (chunked), a graph one through the group walk.  a6 / a7 node range, a8 in-edges of the search that found the rows
+H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
+	const DLocalDesc* d = &C.ls->desc[S.a0];
+	if(local_is_linear(*d)) { LIdxW lw; lw.ls = C.ls; lw.d = d; return fast_op_lcoords_walk(C, S, W, lw); }
+	const LGfm x = lgfm_of(*C.ls, *d);
+	const uint32_t top = S.a1, bot = S.a2 & 0xffffu, rdlen = S.a4 & 0xffu;
+	IEdges ie;
+	fg_ie_unpack(S.a8, &ie);
+	uint32_t nelt = 0, n = 0;
+	if(!gw_resolve(x, &C.gws->gw, top, bot, S.a6, S.a7, &ie, bot - top, &nelt) || nelt > FG_NCO) { S.pc = FPC_BAIL; S.bail = FB_GWALK; return false; }
+	S.nsteps += C.gws->gw.nsteps;
+	for(uint32_t e = 0; e < nelt; e++) {
+		h2g_coord c;
+		if(!local_joff_to_coord(*C.ls, d, C.gws->gw.offs[e] & 0xffffu, S.a3, rdlen, &c)) continue;
+		{ const uint32_t co3[3] = {c.tidx, c.toff, c.joinedOff}; W.stv<3>(S.a5 + 3 * n, co3); n++; }
+	}
+	S.a0 = n;
+	return false;
+}
+// combineWith through hit_combine of h2g_align.h (the rescan of the joint looks mismatches up in the ALT database; insertions and deletions
+// between the two hits are placed there as well) over the unpacked hits
+H2G_HD void fast_op_combine(const FCtx& C, FState& S, const FWords& W) {
+	FHit a = fh_load(W, S.a3);
+	h2g_ghit ga, gb;
+	fh_to_ghit(a, &ga);
+	fh_to_ghit(fh_load(W, S.a4), &gb);
+	const AlnParams& P = *C.P;
+	const bool ok = hit_combine(*C.ref, P.sc, fg_sv(C, S), &ga, &gb, (int64_t)S.rc_minsc, P.minIntronLen, true,
+	                            ScVec{C.sc, C.sc_stride}, ScVec{C.sc + (size_t)H2G_COMBINE_MAXLEN * C.sc_stride, C.sc_stride}, C.alts, nullptr, 0u, 0u);
+	ghit_to_fh(ga, a);
+	if(!fh_store(W, S.a3, a)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
+	S.a0 = ok ? 1u : 0u;
+}
+H2G_HD void fast_op_gsearch(const FCtx& C, FState& S) {       // globalGFMSearch :6606 (al_global_search)
+	const AlnParams& P = *C.P;
+	uint32_t extlen = 0, nr[2] = {0, 0};
+	bool uniqueStop = S.a3 != 0;
+	GIdx gx; gx.g = C.g;
+	GRange r;
+	r.top = S.a4; r.bot = S.a5; r.node_top = r.node_bot = 0;
+	IEdges ie;
+	const uint32_t nelt = gfm_search_graph(*C.g, gx, fg_sv(C, S), S.a1, &extlen, &r, &ie, &uniqueStop, C.g->minK, H2G_MAX, P.kseeds, false, P.kseeds, nr);
+	S.nrank += nr[0]; S.nside += nr[1];
+	S.a0 = nelt; S.a1 = extlen; S.a4 = uniqueStop ? 1u : 0u;
+	if(nelt > 0) { S.a2 = r.top; S.a3 = r.bot; } else { S.a2 = S.a3 = H2G_MAX; }      // (top / bot stay what the caller passed: none)
+	S.a6 = r.node_top; S.a7 = r.node_bot; S.a8 = fg_ie_pack(ie);
+}
+#else
+H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
+	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[S.a0];
+	return fast_op_lcoords_walk(C, S, W, lx);
+}
 H2G_HD void fast_op_combine(const FCtx& C, FState& S, const FWords& W) {
 	FHit a = fh_load(W, S.a3);
 	const FHit b = fh_load(W, S.a4);
@@ -1912,6 +2273,7 @@ H2G_HD void fast_op_gsearch(const FCtx& C, FState& S) {       // globalGFMSearch
 	S.nrank += nr[0]; S.nside += nr[1];
 	S.a0 = nelt; S.a1 = extlen; S.a2 = top; S.a3 = bot; S.a4 = uniqueStop ? 1u : 0u;
 }
+#endif
 // S.op stays set when the primitive is not finished (a chunked walk): the slot goes back to the same site's queue
 H2G_HD void fast_exec(const FCtx& C, FState& S, const FWords& W, uint32_t op) {
 	bool again = false;
@@ -1923,6 +2285,10 @@ H2G_HD void fast_exec(const FCtx& C, FState& S, const FWords& W, uint32_t op) {
 	case FOP_LSEARCH: fast_op_lsearch(C, S); break;
 	case FOP_LCOORDS: again = fast_op_lcoords(C, S, W); break;
 	case FOP_COMBINE: fast_op_combine(C, S, W); break;
+#if FG_GRAPH
+	case FOP_ADJUST:    fast_op_adjust(C, S, W); break;
+	case FOP_ADJMEMBER: fast_op_adjmember(C, S, W); break;
+#endif
 	default: break;
 	}
 	S.op = again ? op : (uint32_t)FOP_NONE;
@@ -1952,6 +2318,11 @@ H2G_HD void fs_unpack(FState& S, LD&& ld) {
 #endif
 // Every place the fast machine requests a primitive: (primitive, pc it resumes at).  The queued kernel keeps one queue per site, so
 // the lanes of a wave resume at the same pc (as H2G_MACH_SITES of h2g_machine.h).
+#if FG_GRAPH
+#define FG_SITES_GR(X) X(FOP_ADJUST, FPC_GAH_K_AFTER) X(FOP_ADJMEMBER, FPC_L_RI_A) X(FOP_ADJMEMBER, FPC_L_G_A) X(FOP_ADJMEMBER, FPC_R_RI_A) X(FOP_ADJMEMBER, FPC_R_G_A)
+#else
+#define FG_SITES_GR(X)
+#endif
 #define FG_SITES(X) \
 	X(FOP_PSEARCH, FPC_NB_AFTER_PS) X(FOP_GCOORDS, FPC_GAH_FULL_AFTER) \
 	X(FOP_EXTEND, FPC_HS_EXT_AFTER) X(FOP_EXTEND, FPC_RC_ENTRY_L2) X(FOP_EXTEND, FPC_RC_ENTRY_R2) X(FOP_EXTEND, FPC_L_RI_B) X(FOP_EXTEND, FPC_R_RI_B) \
@@ -1959,7 +2330,7 @@ H2G_HD void fs_unpack(FState& S, LD&& ld) {
 	X(FOP_LSEARCH, FPC_L_LS_AFTER) X(FOP_LSEARCH, FPC_R_LS_AFTER) X(FOP_LCOORDS, FPC_L_LC_AFTER) X(FOP_LCOORDS, FPC_R_LC_AFTER) \
 	X(FOP_COMBINE, FPC_L_RI_C) X(FOP_COMBINE, FPC_R_RI_C) \
 	X(FOP_GSEARCH, FPC_L_GS_AFTER) X(FOP_GSEARCH, FPC_R_GS_AFTER) X(FOP_GCOORDS, FPC_L_GC_AFTER) X(FOP_GCOORDS, FPC_R_GC_AFTER) \
-	X(FOP_EXTEND, FPC_L_G_B) X(FOP_EXTEND, FPC_R_G_B) X(FOP_COMBINE, FPC_L_G_C) X(FOP_COMBINE, FPC_R_G_C) FG_SITES_AM(X)
+	X(FOP_EXTEND, FPC_L_G_B) X(FOP_EXTEND, FPC_R_G_B) X(FOP_COMBINE, FPC_L_G_C) X(FOP_COMBINE, FPC_R_G_C) FG_SITES_AM(X) FG_SITES_GR(X)
 enum : uint32_t {
 #define X(OPC, PC) FSITE_##PC,
 	FSITE_FREE = 0, FG_SITES(X) FSITE_COUNT
@@ -1983,7 +2354,11 @@ H2G_HD uint32_t fg_site_op(uint32_t site) {
 }
 // The queues of the kernel: the two hot sites have their own, the other sites share one queue per primitive (their lanes resume at
 // different pcs, which the control loop handles anyway): 8 queues of slot ids instead of 25 (LDS: 16 KB instead of 50 KB).
-enum : uint32_t { FQ_FREE = 0, FQ_PSEARCH, FQ_GCOORDS, FQ_EXTEND_HS, FQ_EXTEND, FQ_LSEARCH, FQ_LCOORDS, FQ_COMBINE, FQ_GSEARCH, FQ_COUNT };
+enum : uint32_t { FQ_FREE = 0, FQ_PSEARCH, FQ_GCOORDS, FQ_EXTEND_HS, FQ_EXTEND, FQ_LSEARCH, FQ_LCOORDS, FQ_COMBINE, FQ_GSEARCH,
+#if FG_GRAPH
+	FQ_ADJUST, FQ_ADJMEMBER,
+#endif
+	FQ_COUNT };
 H2G_HD uint32_t fg_queue_of(uint32_t pc) {
 	const uint32_t site = fg_site_of(pc);
 	if(site == 0) return 0;
@@ -1996,6 +2371,10 @@ H2G_HD uint32_t fg_queue_of(uint32_t pc) {
 	case FOP_LCOORDS: return FQ_LCOORDS;
 	case FOP_COMBINE: return FQ_COMBINE;
 	case FOP_GSEARCH: return FQ_GSEARCH;
+#if FG_GRAPH
+	case FOP_ADJUST: return FQ_ADJUST;
+	case FOP_ADJMEMBER: return FQ_ADJMEMBER;
+#endif
 	default: return 0;
 	}
 }
@@ -2008,6 +2387,10 @@ H2G_HD uint32_t fg_queue_op(uint32_t q) {
 	case FQ_LCOORDS: return FOP_LCOORDS;
 	case FQ_COMBINE: return FOP_COMBINE;
 	case FQ_GSEARCH: return FOP_GSEARCH;
+#if FG_GRAPH
+	case FQ_ADJUST: return FOP_ADJUST;
+	case FQ_ADJMEMBER: return FOP_ADJMEMBER;
+#endif
 	default: return FOP_NONE;
 	}
 }

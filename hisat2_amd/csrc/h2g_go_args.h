@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "h2g_align.h"
+#include "h2g_graph.h"
 #include "h2g_fast.h"
 
 __device__ __forceinline__ void wave_add(unsigned long long* dst, unsigned long long v) {
@@ -54,6 +55,12 @@ struct FastArgs {
 	uint32_t* work;                       // next unclaimed read (zeroed before the launch)
 	uint32_t* bail_list; uint32_t* bail_count;
 	uint32_t total, paired;
+	// graph indexes only (h2g_k_go_fast_graph.hip): the ALT database and the per-LANE scratch of one primitive
+	h2g::DAlts alts;
+	uint8_t* gws_base; size_t gws_stride;     // GraphWS per lane (group walk, ALT-aware extension)
+	uint8_t* sc_base;                         // combineWith temp_scores per lane: 2 x H2G_COMBINE_MAXLEN int64, lane-interleaved per wave
 };
 extern "C" int h2g_go_fast_launch(const FastArgs*, unsigned grid, hipStream_t);
 extern "C" void h2g_go_fast_geometry(uint32_t* g);   // [0] threads per workgroup [1] LDS bytes per workgroup [2] slots per workgroup [3] bytes per slot
+extern "C" int h2g_go_fast_graph_launch(const FastArgs*, unsigned grid, hipStream_t);
+extern "C" void h2g_go_fast_graph_geometry(uint32_t* g);   // ... [4] bytes of GraphWS per lane

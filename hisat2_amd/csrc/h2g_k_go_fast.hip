@@ -6,9 +6,16 @@
 // (registers + a per-lane LDS staging area: 27 16-byte loads per lane, no dependent chain), run THAT primitive for all of them at one
 // code site, let every lane run its read's control flow on registers / LDS up to the next request, store the state and push the slot to
 // the queue of what it asked for.  Reads that leave the fast path go to the general machine's list.
+// h2g_k_go_fast_graph.hip compiles this file once more with FG_GRAPH = 1 (graph indexes: h2g_fast.h) under its own symbol names.
 #include "h2g_go_args.h"
 
 using namespace h2g;
+
+#ifndef FG_KERNEL
+#define FG_KERNEL   k_go_fast
+#define FG_LAUNCH   h2g_go_fast_launch
+#define FG_GEOMETRY h2g_go_fast_geometry
+#endif
 
 #ifndef H2G_FAST_THREADS
 #define H2G_FAST_THREADS 512
@@ -78,6 +85,14 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 	C.rd[0] = A->rd1; C.rd[1] = paired ? A->rd2 : A->rd1;
 	C.pk[0] = pk0; C.pk[1] = paired ? pk0 + H2G_PK_WORDS * H2G_FAST_THREADS : pk0; C.pk_stride = H2G_FAST_THREADS;
 	C.sc = nullptr; C.sc_stride = 0;
+#if FG_GRAPH
+	{
+		const size_t tid = (size_t)blockIdx.x * H2G_FAST_THREADS + threadIdx.x;
+		C.alts = &A->alts;
+		C.gws = reinterpret_cast<GraphWS*>(A->gws_base + tid * A->gws_stride);
+		C.sc = reinterpret_cast<int64_t*>(A->sc_base + (tid >> 6) * (size_t)(64 * 2 * H2G_COMBINE_MAXLEN * sizeof(int64_t))) + (threadIdx.x & 63); C.sc_stride = 64;
+	}
+#endif
 	C.O = A->O;
 	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
 }
@@ -115,7 +130,7 @@ __device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, 
 	return w[0];
 }
 
-__global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __restrict__ A)
+__global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __restrict__ A)
 {
 	extern __shared__ uint32_t s_mem[];
 	FastLds* Q = reinterpret_cast<FastLds*>(s_mem);
@@ -286,11 +301,16 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void k_go_fast(const FastArgs* __
 }
 
 #define FG_LDS_BYTES ((unsigned)(((sizeof(FastLds) + 3) / 4 + (size_t)FG_STAGE_WORDS * H2G_FAST_THREADS) * 4))
-extern "C" void h2g_go_fast_geometry(uint32_t* g) { g[0] = H2G_FAST_THREADS; g[1] = FG_LDS_BYTES; g[2] = H2G_FAST_SLOTS; g[3] = FG_SLOT_WORDS * 4u; }
+extern "C" void FG_GEOMETRY(uint32_t* g) {
+	g[0] = H2G_FAST_THREADS; g[1] = FG_LDS_BYTES; g[2] = H2G_FAST_SLOTS; g[3] = FG_SLOT_WORDS * 4u;
+#if FG_GRAPH
+	g[4] = (uint32_t)sizeof(GraphWS);
+#endif
+}
 // `a` is the argument block in DEVICE memory
-extern "C" int h2g_go_fast_launch(const FastArgs* a, unsigned grid, hipStream_t st) {
+extern "C" int FG_LAUNCH(const FastArgs* a, unsigned grid, hipStream_t st) {
 	static bool lds_ok = false;   // more than 64 KB of dynamic LDS is an opt-in
-	if(!lds_ok) { if(hipFuncSetAttribute((const void*)k_go_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok = true; }
-	hipLaunchKernelGGL(k_go_fast, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, a);
+	if(!lds_ok) { if(hipFuncSetAttribute((const void*)FG_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok = true; }
+	hipLaunchKernelGGL(FG_KERNEL, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, a);
 	return (int)hipGetLastError();
 }

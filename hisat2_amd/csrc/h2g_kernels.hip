@@ -95,6 +95,8 @@ struct h2g_stream {
 	void* d_fast_args[H2G_NBUF] = {};
 	void* h_fast_args = nullptr;      // pinned staging of the argument blocks (H2G_NBUF of them): the upload never makes the host wait for the stream      // the fast pass's argument block (device copy)
 	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
+	uint8_t* d_fast_gws = nullptr; size_t fast_gws_bytes = 0;       // graph indexes: GraphWS per lane of the fast kernel (scratch of one primitive)
+	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
 	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 400, mach_min = 4; long dbg_read = -1; } tune;
@@ -441,7 +443,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipStreamSynchronize(s->st); for(int k = 0; k < 2; k++) (void)hipStreamSynchronize(s->mst[k]);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 4; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -1618,7 +1620,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	s->last_p = *p; s->last_paired = paired ? 1 : 0;
 	const bool big_main = maxsz > caps[0];
 	const GoUnit& U = go_unit(linear, big_main, spl);
-	const bool fast = s->tune.fast && linear && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp;
+	// (graph indexes: h2g_k_go_fast_graph.hip, the same pass over the graph form of the compact state; --haplotype and the pair-policy options are `spl`)
+	const bool fast = s->tune.fast && !spl && !big_main && p->no_spliced_alignment && !p->secondary && !p->bowtie2_dp;
 	// geometry of the unit: workgroups of geo[0] threads own geo[1] reads in flight; resident workgroups per CU = what the
 	// unit's waves per SIMD and the LDS (rings + one packed-read region per mate) allow
 	uint32_t geo[4];
@@ -1718,8 +1721,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	s->ran_fast = fast;
 	unsigned fast_mgrid = 0;
 	if(fast) {
-		uint32_t fgeo[4];
-		h2g_go_fast_geometry(fgeo);
+		uint32_t fgeo[5] = {0, 0, 0, 0, 0};
+		if(linear) h2g_go_fast_geometry(fgeo); else h2g_go_fast_graph_geometry(fgeo);
 		// CUs: one persistent fast workgroup each (LDS-bound), minus the few the machine pass of the PREVIOUS run may still hold
 		// (the machine takes ~150 hand-ons per workgroup in half the time of a fast pass; the count is the last finished fast pass's)
 		for(unsigned back = 1; back < H2G_NBUF && back <= s->gen; back++) {                     // the latest fast pass that is over
@@ -1752,6 +1755,22 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		F.counters = cblk; F.work = reinterpret_cast<uint32_t*>(cblk + 12);
 		F.bail_list = bl; F.bail_count = bl + s->max_reads;
 		F.total = (uint32_t)s->n_reads; F.paired = paired ? 1u : 0u;
+		F.alts = A.alts; F.gws_base = nullptr; F.gws_stride = 0; F.sc_base = nullptr;
+		if(!linear) {   // per-lane scratch of the graph primitives (every CU may hold a workgroup)
+			const size_t lanes = (size_t)256 * fgeo[0];
+			const size_t gws_bytes = lanes * fgeo[4], sc_bytes = lanes * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t));
+			if(s->fast_gws_bytes < gws_bytes) {
+				(void)hipFree(s->d_fast_gws); s->d_fast_gws = nullptr; s->fast_gws_bytes = 0;
+				HIPCHK(hipMalloc((void**)&s->d_fast_gws, gws_bytes));
+				s->fast_gws_bytes = gws_bytes;
+			}
+			if(s->fast_sc_bytes < sc_bytes) {
+				(void)hipFree(s->d_fast_sc); s->d_fast_sc = nullptr; s->fast_sc_bytes = 0;
+				HIPCHK(hipMalloc((void**)&s->d_fast_sc, sc_bytes));
+				s->fast_sc_bytes = sc_bytes;
+			}
+			F.gws_base = s->d_fast_gws; F.gws_stride = fgeo[4]; F.sc_base = s->d_fast_sc;
+		}
 		if(!s->d_fast_args[gsel]) HIPCHK(hipMalloc((void**)&s->d_fast_args[gsel], sizeof(FastArgs)));
 		// through pinned memory: a pageable source would make this call wait for everything queued on the stream (the previous run's fast
 		// pass), and the chip would idle while the host queues this run.  The staging block of this buffer set was last read by the upload
@@ -1760,7 +1779,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		FastArgs* const hF = reinterpret_cast<FastArgs*>(s->h_fast_args) + gsel;
 		*hF = F;
 		HIPCHK(hipMemcpyAsync(s->d_fast_args[gsel], hF, sizeof F, hipMemcpyHostToDevice, s->st));
-		if(h2g_go_fast_launch(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
+		if((linear ? h2g_go_fast_launch : h2g_go_fast_graph_launch)(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
 		A.list = bl; A.nlist = bl + s->max_reads;
 		fast_mgrid = mgrid;
 	}

@@ -401,6 +401,12 @@ void h2gemu_fast_check(Emu* e, const uint8_t* codes2, const uint32_t* offs2, con
 	F.pk[0] = pk[0]; F.pk[1] = pk[1]; F.pk_stride = 1;
 	static int64_t sc_[2 * H2G_COMBINE_MAXLEN];
 	F.sc = sc_; F.sc_stride = 1;
+	for(int k = 0; k < 2 + (int)FB_COUNT; k++) stats[k] = 0;
+	if((e->dg.linear != 0) == (FG_GRAPH != 0)) { stats[1] = ~0ull; delete ws; return; }      // this library's fast path is built for the other kind of index
+#if FG_GRAPH
+	static GraphWS fgws_;
+	F.alts = &e->dalts; F.gws = &fgws_;
+#endif
 	F.O.rout = fr.data(); F.O.aln = f1.data(); F.O.aln_slots = slots; F.O.pout = fp.data(); F.O.paln[0] = f1.data(); F.O.paln[1] = f2.data(); F.O.pair_slots = slots;
 	uint32_t words[FW_TOTAL];
 	FWords W; W.hot = words; W.hot_stride = 1; W.cold = words + FW_HOT;

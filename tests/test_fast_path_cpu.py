@@ -121,3 +121,54 @@ def test_mate_rescue_in_the_fast_path(genome):
     # the shipped configuration hands exactly these pairs on (FB_MATE) and completes the rest equal to the machine
     s = FC.fast_check(base, list(m1), list(m2))
     assert s["mismatching"] == 0 and s["bails"].get("mate", 0) > 0.3 * n, s
+
+
+@pytest.fixture(scope="module")
+def graph_genome():
+    """a SNP-graph index (single-base variants, deletions, insertions about every 200 bp) and the alternate haplotype that carries all of them"""
+    tmp = tempfile.mkdtemp(prefix="h2fastg")
+    contigs = synth.make_genome([400000, 150000, 60000], 9102, n_gaps=3, gap_len=300, repeats=20, repeat_len=500)
+    var = synth.make_snps(contigs, 78, every=200)
+    fa = os.path.join(tmp, "g.fa")
+    synth.write_fasta(fa, contigs)
+    synth.write_snps(os.path.join(tmp, "g.snp"), var)
+    base = os.path.join(tmp, "g")
+    subprocess.run([BUILD, "-q", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return base, contigs, synth.apply_snps(contigs, var)
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=6000, rdlen=101, sub=0.005, alt=True),
+    dict(n=3000, rdlen=101, sub=0.005, alt=False),             # reads from the reference haplotype: the graph paths without ALT edits
+    dict(n=3000, rdlen=101, sub=0.03, alt=True, least=0.2),
+    dict(n=2000, rdlen=60, sub=0.01, alt=True, frag_mean=200, frag_sd=40),
+    dict(n=2000, rdlen=125, sub=0.01, alt=True),
+])
+def test_graph_pairs_equal_the_machine(graph_genome, case):
+    """the fast path over a graph index (FG_GRAPH = 1, tests/emul/libh2gemu_g.so = the configuration of h2g_k_go_fast_graph.hip): node ranges and
+    in-edge lists of the partial hits, adjustWithALT of every coordinate, ALT-aware extension and joins, ALT ids in the reported edits"""
+    base, ref, alt = graph_genome
+    m1, m2 = synth.make_pairs(alt if case["alt"] else ref, case["n"], case["rdlen"], 177 + case["n"], frag_mean=case.get("frag_mean", 300), frag_sd=case.get("frag_sd", 30), sub_rate=case["sub"])
+    r = FC.fast_check(base, list(m1), list(m2), variant="g")
+    assert r["mismatching"] == 0, r
+    assert r["completed"] > case.get("least", 0.5) * r["n"], r
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=6000, rdlen=101, sub=0.005),
+    dict(n=3000, rdlen=101, sub=0.02, indel=0.002),
+    dict(n=2000, rdlen=50, sub=0.01),
+])
+def test_graph_reads_equal_the_machine(graph_genome, case):
+    base, ref, alt = graph_genome
+    reads, _ = synth.make_reads(alt, case["n"], case["rdlen"], 15 + case["n"], sub_rate=case["sub"], indel_rate=case.get("indel", 0.0))
+    r = FC.fast_check(base, list(reads), variant="g")
+    assert r["mismatching"] == 0, r
+    assert r["completed"] > 0.4 * r["n"], r
+
+
+def test_the_graph_library_refuses_a_linear_index(genome):
+    base, contigs = genome
+    reads, _ = synth.make_reads(contigs, 10, 101, 5)
+    r = FC.fast_check(base, list(reads), variant="g")
+    assert r["mismatching"] > 10 ** 9          # (the library says so instead of running the wrong fast path)

@@ -22,6 +22,8 @@ BUILD = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
 @pytest.mark.parametrize("case", [
     dict(seed=71, npairs=150000, nreads=150000, rdlen=101, sub=0.005),
     dict(seed=72, npairs=60000, nreads=60000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25),   # hard reads: half are handed on
+    dict(seed=73, npairs=100000, nreads=100000, rdlen=101, sub=0.005, snps=250),                            # SNP-graph index (h2g_k_go_fast_graph.hip), reads from the alternate haplotype
+    dict(seed=74, npairs=40000, nreads=40000, rdlen=90, sub=0.02, indel=0.002, snps=120, least=0.25),        # ... dense variants, harder reads
 ])
 def test_fast_pass_equals_the_machine(case):
     tmp = tempfile.mkdtemp(prefix="h2fp")
@@ -29,7 +31,13 @@ def test_fast_pass_equals_the_machine(case):
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
-    subprocess.run([BUILD, "-q", "-p", "16", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if case.get("snps"):
+        var = synth.make_snps(contigs, case["seed"] + 9, every=case["snps"])
+        synth.write_snps(os.path.join(tmp, "g.snp"), var)
+        subprocess.run([BUILD, "-q", "-p", "16", "--snp", os.path.join(tmp, "g.snp"), fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        contigs = synth.apply_snps(contigs, var)
+    else:
+        subprocess.run([BUILD, "-q", "-p", "16", fa, base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     m1, m2 = synth.make_pairs(contigs, case["npairs"], case["rdlen"], case["seed"] + 1, frag_mean=300, frag_sd=40, sub_rate=case["sub"])
     reads, _ = synth.make_reads(contigs, case["nreads"], case["rdlen"], case["seed"] + 2, sub_rate=case["sub"], indel_rate=case.get("indel", 0.0), n_rate=case.get("nrate", 0.0))
     npz = os.path.join(tmp, "reads.npz")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """go() timing with the fast pass on / off (env H2G_GO_FAST, read once per process) + a checksum of every result, so that the two
-settings can be compared for identical output.  usage: fast_perf.py se|pe [n] [genome bases]"""
+settings can be compared for identical output.  usage: fast_perf.py se|pe|gpe [n] [genome bases]   (gpe: pairs from the alternate haplotype
+on the SNP-graph index of bench.py's graph leg, a variant every ~250 bp)"""
 import os, sys, zlib, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -30,6 +31,17 @@ else:
     import build_bench_index as BB
     base, total, how = bench.headline_index(os.path.join(ROOT, ".bench_cache"), glen)
     contigs = BB.genome(total)
+if mode == "gpe":
+    import subprocess
+    gtmp = os.path.join(ROOT, ".bench_cache", f"rnd{glen}_s{bench.SEED}_snp")
+    gbase = os.path.join(gtmp, "g")
+    var = synth.make_snps(contigs, bench.SEED + 5, every=250, names=["ecoli_substitute"])
+    if not os.path.exists(gbase + ".8.ht2"):
+        os.makedirs(gtmp, exist_ok=True)
+        synth.write_fasta(gbase + ".fa", contigs, names=["ecoli_substitute"]); synth.write_snps(gbase + ".snp", var)
+        subprocess.run([os.path.join(bench.REF, "hisat2-build-s"), "-q", "-p", "16", "--snp", gbase + ".snp", gbase + ".fa", gbase], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    contigs = synth.apply_snps(contigs, var, names=["ecoli_substitute"])
+    base = gbase
 print("index ready in %.1f s" % (time.time() - t0), flush=True)
 ix = api.Index(base)
 if mode == "se":
@@ -39,7 +51,7 @@ if mode == "se":
     st.set_reads(codes, offs); st.set_read_names([str(i) for i in range(n)])
     run = st.align_run
 else:
-    m1, m2 = synth.make_pairs(contigs, n, 101, bench.SEED + 7, sub_rate=0.005)
+    m1, m2 = synth.make_pairs(contigs, n, 101, bench.SEED + (4343 if mode == "gpe" else 7), frag_mean=300, frag_sd=30, sub_rate=0.005) if mode == "gpe" else synth.make_pairs(contigs, n, 101, bench.SEED + 7, sub_rate=0.005)
     c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
     names = [str(i) for i in range(n)]
     st = api.Stream(ix, max_reads=n, max_bases=c1.size)
@@ -73,7 +85,7 @@ if hasattr(L, "h2g_go_fast_prof"):
     v = (C.c_ulonglong * 136)()
     L.h2g_go_fast_prof.argtypes = [C.c_void_p, C.c_void_p]
     if L.h2g_go_fast_prof(st.h, v) == 0:
-        reasons = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other indel".split()
+        reasons = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other indel tail iedges gwalk".split()
         print("  bails:", {reasons[k]: int(v[48 + k]) for k in range(len(reasons)) if v[48 + k]})
         if v[47]:
             ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE GSEARCH".split()
