@@ -33,7 +33,7 @@ namespace h2g {
 
 #define FG_FE     4                     // edits kept per hit (more: bail), 16 bits each
 #define FG_HW     (6 + FG_FE / 2 + FG_GRAPH * FG_FE)   // words of a stored hit (graph: + the ALT id of each edit)
-#define FG_LW     (3 + 3 * FG_GRAPH)    // words of a long partial hit in the pool (graph: + node range, in-edge list)
+#define FG_LW     3                     // words of a long partial hit in the pool (graph: + 3 cold words at FW_LONGX: node range, in-edge list)
 #define FG_NLONG  3                     // partial hits longer than minK + 2 waiting for getAnchorHits
 #define FG_NCO    5                     // coordinates per SA resolution (the reference resolves at most 5 outside getAnchorHits)
 #define FG_NRES   2                     // reported alignments per mate
@@ -50,10 +50,19 @@ namespace h2g {
 #define FW_LONG   0
 #define FW_G0     (FW_LONG + FG_LW * FG_NLONG)
 #define FW_FR0    (FW_G0 + FG_HW)                  // frame 0: scalars + hit
+#if FG_GRAPH
+// (the graph form of a hit is 12 words: to keep 8 waves per workgroup inside the LDS the result summaries and the pool's graph words are cold)
+#define FW_T1     (FW_FR0 + FG_FRS + FG_HW)        // the scratch hit of the extension branches (every read with a mismatch works through it)
+#define FW_HOT    (FW_T1 + FG_HW)
+#define FW_RES    FW_HOT
+#define FW_LONGX  (FW_RES + 2 * FG_NRES * 3)       // node range + in-edge list of each long partial hit
+#define FW_G1     (FW_LONGX + 3 * FG_NLONG)
+#else
 #define FW_RES    (FW_FR0 + FG_FRS + FG_HW)
 #define FW_T1     (FW_RES + 2 * FG_NRES * 3)       // the scratch hit of the extension branches (every read with a mismatch works through it)
 #define FW_HOT    (FW_T1 + FG_HW)
 #define FW_G1     FW_HOT
+#endif
 #define FW_SRCH   (FW_G1 + FG_HW)
 #define FW_CO     (FW_SRCH + 2 * FG_NSRCH * (1 + FG_HW))   // the coordinate list of every frame (frame 0's doubles as getAnchorHits'); before it: (hash, hit) per searched root
 #define FW_FRX    (FW_CO + FG_NFRAME * 3 * FG_NCO)  // frames 1 .. FG_NFRAME - 1: scalars + hit
@@ -960,7 +969,7 @@ again:
 				W.st(FW_LONG + FG_LW * k, top); W.st(FW_LONG + FG_LW * k + 1, bot);
 #if FG_GRAPH
 				if(S.a8 == FG_IE_NOFIT) F_BAIL(FB_IEDGES);
-				W.st(FW_LONG + FG_LW * k + 3, S.a6); W.st(FW_LONG + FG_LW * k + 4, S.a7); W.st(FW_LONG + FG_LW * k + 5, S.a8);   // pnode: node range, in-edges
+				{ const uint32_t pn[3] = {S.a6, S.a7, S.a8}; W.stv<3>(FW_LONGX + 3 * k, pn); }   // pnode: node range, in-edges
 #endif
 				W.st(FW_LONG + FG_LW * k + 2, 0x80000000u | S.a5 | (len << 8) | (type << 16) | (x << 20) | (np << 24));   // bwoff, len, type, strand, index
 			}
@@ -1232,7 +1241,7 @@ again:
 		const uint32_t len = (mj >> 8) & 0xffu, bwoff = mj & 0xffu;
 #if FG_GRAPH
 		uint32_t pn[3];                                     // the hit's node range and in-edge list: the elements are NODES
-		W.ldv<3>(FW_LONG + FG_LW * hj + 3, pn);
+		W.ldv<3>(FW_LONGX + 3 * hj, pn);
 		const uint32_t expected = pn[1] - pn[0];
 #else
 		const uint32_t expected = tj_bot - tj_top;
@@ -1265,7 +1274,7 @@ again:
 		while(S.gh_k < S.gh_nco) {
 			uint32_t co3[3];
 			W.ldv<3>(fg_frame_co(0) + 3 * S.gh_k, co3);
-			const uint32_t tidx = co3[0], toff = co3[1], joff = co3[2];
+			const uint32_t tidx = co3[0], toff = co3[1];
 			if(tidx == H2G_MAX) F_BAIL(FB_STRADDLE);
 			bool overlapped = false;
 			for(uint32_t l = 0; l < S.gh_gsize; l++) {
@@ -1277,7 +1286,10 @@ again:
 				if(hitoff == hitoff2) { overlapped = true; W.st(gb + 5, w5 + (1u << 8)); break; }   // _hitcount++
 			}
 			if(!overlapped) {
-				S.a0 = S.gh_rdoff; S.a1 = len; S.a2 = tidx; S.a3 = toff; S.a4 = joff;
+				// (the coordinate's third word is fetched HERE, not before the loop above: hipcc 7.2 at -O2 / -O3 loses a value that lives across
+				// that divergent loop with a break — the joined offset arrived as the stale a4 whenever the loop had run; -O1 keeps it.  Measured on
+				// the device with a per-trip trace of one read: profiles/r04_NOTES.md §2)
+				S.a0 = S.gh_rdoff; S.a1 = len; S.a2 = tidx; S.a3 = toff; S.a4 = W.ld(fg_frame_co(0) + 3 * S.gh_k + 2);
 				F_OP(FOP_ADJUST, FPC_GAH_K_AFTER);
 			}
 			if(type == H2G_CANDIDATE_HIT && S.nghits >= maxsz) break;
@@ -2010,9 +2022,33 @@ H2G_HD void fast_op_psearch(const FCtx& C, FState& S) {
 // while it is under way a1 = the row the walk stands at, a2 = elements | (1 | element << 1 | coordinates written << 4 | jumps << 7) << 8.
 // true: not finished
 #if FG_GRAPH
-// getGenomeCoords on a graph index: the node-based group walk (genome_coords_graph_item) on this lane's scratch, in one go.
-// a0 top a1 bot a2 maxelt a3 len a4 rejectStraddle a5 dst a6 / a7 node range a8 in-edges
+// getGenomeCoords on a graph index.  a0 top a1 bot a2 maxelt a3 len a4 rejectStraddle a5 dst a6 / a7 node range a8 in-edges.
+// The common anchor is ONE node reached through ONE row: its walk is a row walk (gw_walk_single), kept in registers and chunked like the
+// linear one — under way: a4 bit 1 set, a0 = the row, a6 = the node, a2 = steps so far.  Everything else (several nodes, a node with
+// extra in-edges) is the node-based group walk (genome_coords_graph_item) on this lane's scratch, in one go.
 H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
+	if(!(S.a4 & 2u)) {
+		uint32_t nelt = S.a7 - S.a6;
+		if(nelt > S.a2) nelt = S.a2;
+		if(nelt == 1 && S.a1 - S.a0 == 1) { S.a4 |= 2u; S.a2 = 0; }
+	}
+	if(S.a4 & 2u) {
+		uint32_t row = S.a0, node = S.a6, steps = S.a2, off = 0;
+		const uint32_t before = steps;
+		const bool found = gw_walk_single(*C.g, &row, &node, &steps, FG_WALK_STEPS, &off);
+		S.nsteps += steps - before;
+		if(!found) {
+			if(steps > 60000u) { S.pc = FPC_BAIL; S.bail = FB_GWALK; return false; }
+			S.a0 = row; S.a6 = node; S.a2 = steps;
+			return true;
+		}
+		uint32_t tidx = 0, toff = 0, n = 0;
+		bool st2 = false;
+		joined_to_text(*C.g, S.a3, off, &tidx, &toff, (S.a4 & 1u) != 0, &st2);
+		if(tidx != H2G_MAX) { const uint32_t co3[3] = {st2 ? H2G_MAX : tidx, toff, off}; W.stv<3>(S.a5, co3); n = 1; }
+		S.a0 = n; S.a1 = 0;
+		return false;
+	}
 	IEdges ie;
 	fg_ie_unpack(S.a8, &ie);
 	h2g_coord co[FG_NCO];
@@ -2208,7 +2244,26 @@ H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
 	const DLocalDesc* d = &C.ls->desc[S.a0];
 	if(local_is_linear(*d)) { LIdxW lw; lw.ls = C.ls; lw.d = d; return fast_op_lcoords_walk(C, S, W, lw); }
 	const LGfm x = lgfm_of(*C.ls, *d);
-	const uint32_t top = S.a1, bot = S.a2 & 0xffffu, rdlen = S.a4 & 0xffu;
+	const uint32_t rdlen = S.a4 & 0xffu;
+	// one node through one row: the row walk, chunked (under way: a2 bit 31 set, a1 = the row, a6 = the node, a7 = steps so far)
+	if(!(S.a2 & 0x80000000u) && S.a7 - S.a6 == 1 && (S.a2 & 0xffffu) - S.a1 == 1) { S.a2 |= 0x80000000u; S.a7 = 0; }
+	if(S.a2 & 0x80000000u) {
+		uint32_t row = S.a1, node = S.a6, steps = S.a7, off = 0;
+		const uint32_t before = steps;
+		const bool found = gw_walk_single(x, &row, &node, &steps, FG_LWALK_STEPS, &off);
+		S.nsteps += steps - before;
+		if(!found) {
+			if(steps > 60000u) { S.pc = FPC_BAIL; S.bail = FB_GWALK; return false; }
+			S.a1 = row; S.a6 = node; S.a7 = steps;
+			return true;
+		}
+		h2g_coord c;
+		uint32_t n1 = 0;
+		if(local_joff_to_coord(*C.ls, d, off & 0xffffu, S.a3, rdlen, &c)) { const uint32_t co3[3] = {c.tidx, c.toff, c.joinedOff}; W.stv<3>(S.a5, co3); n1 = 1; }
+		S.a0 = n1;
+		return false;
+	}
+	const uint32_t top = S.a1, bot = S.a2 & 0xffffu;
 	IEdges ie;
 	fg_ie_unpack(S.a8, &ie);
 	uint32_t nelt = 0, n = 0;

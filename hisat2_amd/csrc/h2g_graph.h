@@ -212,6 +212,136 @@ H2G_GLF void in_edge_count(const X& g, uint32_t top, uint32_t bot, IEdges* ie) {
 
 struct GRange { uint32_t top, bot, node_top, node_bot; };
 
+// ---- one LF step of ONE row with the bit vectors taken from sides held in registers (round 4) -------------------------------
+// mapGLF1 without a required character (gfm.h:4029-4095), reduced to what a single-row walk needs: the incoming row and the node
+// the step arrives at.  Equal to map_glf1_nochar's (top, node_top) — the host test h2gemu_glf_fused_check holds it to that — but
+// with one 128 B load per side touched (the row's side; the side of t + 1 for its M bits, F_loc and M_occ; the side select_F lands
+// in when that is another one) instead of a dependent load per field: 2-3 latencies per step instead of 5-6.
+template <class X>
+H2G_HD Bits256 bits_of_side(const Side128& s, uint32_t off) {       // load_bits over a side in registers
+	const uint32_t i = off >> 3, sh = (off & 7u) * 8u;
+	Bits256 b;
+#pragma unroll
+	for(uint32_t k = 0; k < 4; k++) {
+		const uint64_t lo = s.w[i + k] >> sh;
+		const uint64_t hi = sh ? (s.w[i + k + 1] << (64u - sh)) : 0ull;
+		b.w[k] = lo | hi;
+	}
+	b.w[3] &= (1ull << (X::SYMS - 192)) - 1ull;
+	return b;
+}
+template <class X> H2G_HD uint32_t side_hdr_reg(const Side128& s, int k) {   // {F_loc, M_occ} of a side in registers (side_hdr_mem)
+	if(X::WSZ == 4) return k == 0 ? (uint32_t)s.w[13] : (uint32_t)(s.w[13] >> 32);           // u32 at byte 104 / 108
+	return k == 0 ? (uint32_t)((s.w[14] >> 32) & 0xffffu) : (uint32_t)(s.w[14] >> 48);      // u16 at byte 116 / 118
+}
+// the c1-th and the c2-th F one at or after row F_loc (select_F twice over one scan; a count of 0 stands for "F_loc itself", as mapGLF1 uses
+// it), starting in registers when F_loc lies in the side `cur` holds (side number *sideNum)
+template <class X>
+H2G_HD void select_F2_reg(const X& g, Side128& cur, uint32_t& sideNum, uint32_t F_loc, uint32_t c1, uint32_t c2, uint32_t* p1, uint32_t* p2) {
+	*p1 = c1 == 0 ? F_loc : g.gbwtLen;
+	*p2 = c2 == 0 ? F_loc : g.gbwtLen;
+	if(c1 == 0 && c2 == 0) return;
+	uint32_t fs = F_loc / X::SYMS, off = F_loc - fs * X::SYMS;
+	const uint32_t lastSide = (g.gbwtLen - 1) / X::SYMS;
+	while(true) {
+		if(fs != sideNum) { cur = load_side128(g.sides + (size_t)fs * 128); sideNum = fs; }
+		const Bits256 f = bits_of_side<X>(cur, X::F_OFF);
+#pragma unroll
+		for(int k = 0; k < 4; k++) {
+			const uint64_t w = f.w[k] & ~low_mask((int)off - 64 * k);
+			const uint32_t pc = (uint32_t)__builtin_popcountll(w);
+			if(c1 > 0) { if(c1 <= pc) { *p1 = fs * X::SYMS + 64u * k + select_in_word(w, c1); c1 = 0; } else c1 -= pc; }
+			if(c2 > 0) { if(c2 <= pc) { *p2 = fs * X::SYMS + 64u * k + select_in_word(w, c2); c2 = 0; } else c2 -= pc; }
+		}
+		if((c1 == 0 && c2 == 0) || fs >= lastSide) return;
+		fs++;
+		off = 0;
+	}
+}
+// mapGLF1 with a required character (gfm.h:3957-4021; map_glf1) from sides held in registers: the searches' step once a range is one row
+template <class X>
+H2G_HD bool map_glf1_fused(const X& g, uint32_t row, int c, GRange* r) {
+	r->top = r->bot = r->node_top = r->node_bot = 0;
+	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
+	const Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
+	if(rowL_in_side128(sd, c0) != c || is_zoff(g, row)) return false;
+	const uint32_t t = rank_in_side128(g, sd, s0, c0, c);
+	const uint32_t r1 = t + 1, s1 = r1 / X::SYMS, o1 = r1 - s1 * X::SYMS;
+	Side128 cur = sd;
+	if(s1 != s0) cur = load_side128(g.sides + (size_t)s1 * 128);
+	uint32_t node;
+	{
+		const Bits256 m = bits_of_side<X>(cur, X::M_OFF);
+		uint32_t cnt = side_hdr_reg<X>(cur, 1);
+#pragma unroll
+		for(int k = 0; k < 4; k++) cnt += (uint32_t)__builtin_popcountll(m.w[k] & low_mask((int)o1 - 64 * k));
+		node = cnt - 1;
+	}
+	uint32_t sideNum = s1, F_loc = side_hdr_reg<X>(cur, 0), M_occ = side_hdr_reg<X>(cur, 1);
+	while(!(M_occ <= node || sideNum == 0)) {
+		sideNum--;
+		cur = load_side128(g.sides + (size_t)sideNum * 128);
+		F_loc = side_hdr_reg<X>(cur, 0); M_occ = side_hdr_reg<X>(cur, 1);
+	}
+	if(M_occ > 0) F_loc++;
+	const uint32_t node_bot = node + 1;
+	uint32_t ft, fb;
+	select_F2_reg(g, cur, sideNum, F_loc, node + 1 > M_occ ? node + 1 - M_occ : 0u, node_bot + 1 > M_occ ? node_bot + 1 - M_occ : 0u, &ft, &fb);
+	r->top = ft; r->bot = fb; r->node_top = node; r->node_bot = node_bot;
+	return true;
+}
+template <class X>
+H2G_HD void glf1_top_fused(const X& g, uint32_t row, uint32_t* top_out, uint32_t* node_out) {
+	const uint32_t s0 = row / X::SYMS, c0 = row - s0 * X::SYMS;
+	const Side128 sd = load_side128(g.sides + (size_t)s0 * 128);
+	const int c = rowL_in_side128(sd, c0);
+	const uint32_t t = rank_in_side128(g, sd, s0, c0, c);
+	// rank_M(t + 1) - 1
+	const uint32_t r1 = t + 1, s1 = r1 / X::SYMS, o1 = r1 - s1 * X::SYMS;
+	Side128 cur = sd;
+	if(s1 != s0) cur = load_side128(g.sides + (size_t)s1 * 128);
+	uint32_t node;
+	{
+		const Bits256 m = bits_of_side<X>(cur, X::M_OFF);
+		uint32_t cnt = side_hdr_reg<X>(cur, 1);
+#pragma unroll
+		for(int k = 0; k < 4; k++) cnt += (uint32_t)__builtin_popcountll(m.w[k] & low_mask((int)o1 - 64 * k));
+		node = cnt - 1;
+	}
+	// node_to_Frow(t + 1, node): backward scan over the side headers
+	uint32_t sideNum = s1, F_loc = side_hdr_reg<X>(cur, 0), M_occ = side_hdr_reg<X>(cur, 1);
+	while(!(M_occ <= node || sideNum == 0)) {
+		sideNum--;
+		cur = load_side128(g.sides + (size_t)sideNum * 128);
+		F_loc = side_hdr_reg<X>(cur, 0); M_occ = side_hdr_reg<X>(cur, 1);
+	}
+	if(M_occ > 0) F_loc++;
+	uint32_t ft = F_loc;
+	if(node + 1 > M_occ) {                                   // select_F(F_loc, node + 1 - M_occ), starting in registers when F_loc lies in `cur`'s side
+		uint32_t count = node + 1 - M_occ;
+		uint32_t fs = F_loc / X::SYMS, off = F_loc - fs * X::SYMS;
+		const uint32_t lastSide = (g.gbwtLen - 1) / X::SYMS;
+		ft = g.gbwtLen;
+		while(true) {
+			if(fs != sideNum) { cur = load_side128(g.sides + (size_t)fs * 128); sideNum = fs; }
+			const Bits256 f = bits_of_side<X>(cur, X::F_OFF);
+			bool hit = false;
+#pragma unroll
+			for(int k = 0; k < 4; k++) {
+				if(hit) continue;
+				const uint64_t w = f.w[k] & ~low_mask((int)off - 64 * k);
+				const uint32_t pc = (uint32_t)__builtin_popcountll(w);
+				if(count <= pc) { ft = fs * X::SYMS + 64u * k + select_in_word(w, count); hit = true; }
+				else count -= pc;
+			}
+			if(hit || fs >= lastSide) break;
+			fs++;
+			off = 0;
+		}
+	}
+	*top_out = ft; *node_out = node;
+}
+
 // mapGLF (gfm.h:3759-3837): LF of a row range + translation of the outgoing-edge rows back to incoming rows
 // through M-rank / F-select.  false = empty range.  `ie` may be null.
 template <class X>
@@ -306,7 +436,7 @@ H2G_HDN void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32
 					map_glf(g, top, bot, c, kseeds, &r, &tmp_ie);
 				} else {
 					h.nrank += 1;
-					if(map_glf1(g, top, c, &r) && r.top + 1 < r.bot) {   // :6476-6482
+					if(map_glf1_fused(g, top, c, &r) && r.top + 1 < r.bot) {   // :6476-6482 (map_glf1 with one load per side touched)
 						tmp_ie.n = 1; tmp_ie.e[0][0] = 0; tmp_ie.e[0][1] = r.bot - r.top - 1;
 					}
 				}
@@ -628,13 +758,30 @@ H2G_HDN void gw_advance(const X& g, GwCtx* x, uint32_t range) {
 		if(ngmap > 0) { for(uint32_t k = 0; k < ngmap; k++) s->map[k] = gmap[k]; s->nmap = ngmap; }
 	} else {
 		GRange r;
-		map_glf1_nochar(g, s->top, &r);
+		if(is_zoff(g, s->top)) map_glf1_nochar(g, s->top, &r);       // (not reached: GWState::init resolves a '$' row before it is advanced)
+		else { glf1_top_fused(g, s->top, &r.top, &r.node_top); r.node_bot = r.node_top + 1; }   // map_glf1_nochar's (top, node range) with one load per side touched
 		s->top = r.top; s->bot = r.top + 1; s->node_top = r.node_top; s->node_bot = r.node_bot;
 		if(s->mapi > 0) { s->map[0] = s->map[s->mapi]; s->mapi = 0; }
 		s->nmap = 1;
 	}
 	s->step++;
 	gw_init(g, x, range);
+}
+
+// The group walk of ONE element that is ONE row (no in-edges): GWState::advance's single-row branch (group_walk.h:1290-1336) and
+// GWState::init's tryOffset, nothing else — a row stays a row.  Advances (*row, *node, *steps) by at most `budget` LF steps; true = the
+// offset was found (*off = tryOffset + steps, what gw_resolve leaves in offs[0]; *steps = its nsteps).
+template <class X>
+H2G_HD bool gw_walk_single(const X& g, uint32_t* row, uint32_t* node, uint32_t* steps, uint32_t budget, uint32_t* off) {
+	while(true) {
+		const uint32_t toff = gw_try_offset(g, *row, *node);
+		if(toff != H2G_MAX) { *off = toff + *steps; return true; }
+		if(budget == 0) return false;
+		budget--;
+		uint32_t r, n;
+		glf1_top_fused(g, *row, &r, &n);
+		*row = r; *node = n; (*steps)++;
+	}
 }
 
 // GroupWalk2S::init + advanceElement for every element (group_walk.h:1430-1545): fills x->offs[0 .. *nelt) with the joined
@@ -735,7 +882,7 @@ H2G_HDN uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, 
 			if(bot - top > 1) { nrank[0] += 2; map_glf(g, top, bot, c, kseeds, &r, &tmp); }
 			else {
 				nrank[0] += 1;
-				if(map_glf1(g, top, c, &r) && r.top + 1 < r.bot) { tmp.n = 1; tmp.e[0][0] = 0; tmp.e[0][1] = r.bot - r.top - 1; }
+				if(map_glf1_fused(g, top, c, &r) && r.top + 1 < r.bot) { tmp.n = 1; tmp.e[0][0] = 0; tmp.e[0][1] = r.bot - r.top - 1; }
 			}
 		}
 #if defined(H2G_TRACE) && !defined(__HIP_DEVICE_COMPILE__)

@@ -121,7 +121,20 @@ __device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, 
 		if(S.pc != FPC_BAIL && (nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu)) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
 		S.nrank = nr_ & 0xffffu; S.nside = ns_ & 0xffffu; S.nsteps = nt_ & 0xffffu;
 	}
+#ifdef FG_DBG_TRACE
+	const uint32_t dbg_a[6] = {S.a0, S.a1, S.a2, S.a3, S.a4, S.a5};
+	const uint32_t dbg_pc0 = S.pc, dbg_op0 = S.op;
+#endif
 	if(S.pc != FPC_DONE && S.pc != FPC_BAIL && S.op == FOP_NONE) fast_step(C, S, W);
+#ifdef FG_DBG_TRACE
+	if(A->dbg_buf && S.read == A->dbg_read) {
+		const uint32_t at = atomicAdd(A->dbg_buf, 12u);
+		if(at + 13 < (1u << 20)) {
+			uint32_t* d = A->dbg_buf + 1 + at;
+			d[0] = op; d[1] = dbg_pc0 | (dbg_op0 << 8); for(int k = 0; k < 6; k++) d[2 + k] = dbg_a[k]; d[8] = S.pc | (S.op << 8) | ((uint32_t)(S.sp & 15) << 16); d[9] = S.nrank | (S.nsteps << 16); d[10] = W.ld(FW_CO + 2); d[11] = S.a4;
+		}
+	}
+#endif
 	uint32_t w[FS_WORDS];
 	__builtin_memcpy(w, &S, sizeof S);
 	uint4* dst = reinterpret_cast<uint4*>(sm);
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 	bool more = true;
 	const uint32_t total = A->total;
 #ifdef H2G_GO_PROF
-	// wave-level time split (shader clock): [0] choose + pop + load [1] control [2] store [12] release fence [13] push [3+op] each primitive [15] new reads; [20+op] slots executed;
+	// wave-level time split (shader clock): [0] choose + pop + load [1] control [2] store [16] release fence [17] push [3+op] each primitive [15] new reads; [20+op] slots executed;
 	// [32+op] executions; [46] slots stepped [47] trips
 	unsigned long long prof[48], prof_ctl[32], prof_n[32];
 	for(int k = 0; k < 48; k++) prof[k] = 0;
@@ -284,9 +297,9 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 		}
 		PROF(2);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		PROF(12);
+		PROF(16);
 		fq_push(Q, have, nextq, slot, lane);
-		PROF(13);
+		PROF(17);
 	}
 #ifdef H2G_GO_PROF
 	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A->counters + 128 + k, prof[k]);

@@ -1756,6 +1756,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		F.bail_list = bl; F.bail_count = bl + s->max_reads;
 		F.total = (uint32_t)s->n_reads; F.paired = paired ? 1u : 0u;
 		F.alts = A.alts; F.gws_base = nullptr; F.gws_stride = 0; F.sc_base = nullptr;
+		F.dbg_read = A.dbg_read; F.dbg_buf = A.dbg_buf;
 		if(!linear) {   // per-lane scratch of the graph primitives (every CU may hold a workgroup)
 			const size_t lanes = (size_t)256 * fgeo[0];
 			const size_t gws_bytes = lanes * fgeo[4], sc_bytes = lanes * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t));

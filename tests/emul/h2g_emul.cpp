@@ -471,6 +471,61 @@ void h2gemu_fast_check(Emu* e, const uint8_t* codes2, const uint32_t* offs2, con
 	delete ws;
 }
 
+// glf1_top_fused (one LF step of one row from sides held in registers) against map_glf1_nochar, and gw_walk_single against gw_resolve,
+// on `n` seeded rows of the global graph index and of the graph local indexes.  Returns the number of differing rows.
+uint64_t h2gemu_glf_fused_check(Emu* e, uint32_t n, uint64_t seed) {
+	if(e->dg.linear) return ~0ull;
+	uint64_t bad = 0, x = seed * 0x9e3779b97f4a7c15ull + 1;
+	auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+	static GraphWS gws;
+	for(uint32_t i = 0; i < n; i++) {
+		const uint32_t row = (uint32_t)(rnd() % e->dg.gbwtLen);
+		if(is_zoff(e->dg, row)) continue;
+		GRange r;
+		map_glf1_nochar(e->dg, row, &r);
+		uint32_t t = 0, nd = 0;
+		glf1_top_fused(e->dg, row, &t, &nd);
+		if(t != r.top || nd != r.node_top) { bad++; continue; }
+		for(int c = 0; c < 4; c++) {                                  // map_glf1_fused == map_glf1, whatever character is asked for
+			GRange a, b;
+			const bool oa = map_glf1(e->dg, row, c, &a), ob = map_glf1_fused(e->dg, row, c, &b);
+			if(oa != ob || a.top != b.top || a.bot != b.bot || a.node_top != b.node_top || a.node_bot != b.node_bot) { bad++; break; }
+		}
+		// a walk from (row r.top, node r.node_top)
+		uint32_t nelt = 0;
+		const bool ok = gw_resolve(e->dg, &gws.gw, r.top, r.top + 1, r.node_top, r.node_top + 1, nullptr, 1, &nelt);
+		uint32_t wr = r.top, wn = r.node_top, steps = 0, off = 0;
+		bool found = false;
+		for(int chunk = 0; chunk < 100000 && !found; chunk++) found = gw_walk_single(e->dg, &wr, &wn, &steps, 7, &off);
+		if(!ok || !found || off != gws.gw.offs[0] || steps != gws.gw.nsteps) bad++;
+	}
+	for(uint32_t i = 0; i < n; i++) {
+		const uint32_t li = (uint32_t)(rnd() % e->dls.n);
+		const DLocalDesc& d = e->dls.desc[li];
+		if(d.len == 0 || local_is_linear(d)) continue;
+		const LGfm lx = lgfm_of(e->dls, d);
+		const uint32_t row = (uint32_t)(rnd() % d.gbwtLen);
+		if(is_zoff(lx, row)) continue;
+		GRange r;
+		map_glf1_nochar(lx, row, &r);
+		uint32_t t = 0, nd = 0;
+		glf1_top_fused(lx, row, &t, &nd);
+		if(t != r.top || nd != r.node_top) { bad++; continue; }
+		for(int c = 0; c < 4; c++) {
+			GRange a, b;
+			const bool oa = map_glf1(lx, row, c, &a), ob = map_glf1_fused(lx, row, c, &b);
+			if(oa != ob || a.top != b.top || a.bot != b.bot || a.node_top != b.node_top || a.node_bot != b.node_bot) { bad++; break; }
+		}
+		uint32_t nelt = 0;
+		const bool ok = gw_resolve(lx, &gws.gw, r.top, r.top + 1, r.node_top, r.node_top + 1, nullptr, 1, &nelt);
+		uint32_t wr = r.top, wn = r.node_top, steps = 0, off = 0;
+		bool found = false;
+		for(int chunk = 0; chunk < 100000 && !found; chunk++) found = gw_walk_single(lx, &wr, &wn, &steps, 5, &off);
+		if(!ok || !found || off != gws.gw.offs[0] || steps != gws.gw.nsteps) bad++;
+	}
+	return bad;
+}
+
 #ifdef H2G_MEMPROF
 void mp_report(unsigned nreads, const char** opnames, int nops);
 void h2gemu_memprof_report(unsigned nreads) {

@@ -65,6 +65,20 @@ def differing(ref, got, n):
 def describe(ref, got, i):
     """what differs for read i: the struct, the records, or only the records' order"""
     d = {"id": i, "struct": not np.array_equal(ref[0][i], got[0][i])}
+    if d["struct"]:
+        w = np.flatnonzero(ref[0][i] != got[0][i])
+        d["struct_bytes"] = [int(x) for x in w[:12]]
+        d["struct_ref"] = [int(x) for x in ref[0][i].view(np.uint32)[:12]]; d["struct_got"] = [int(x) for x in got[0][i].view(np.uint32)[:12]]
+    for k in range(1, len(ref)):
+        a, b = ref[k][i], got[k][i]
+        if a != b and len(a) == len(b):
+            ra, rb = np.frombuffer(a, dtype=ALN_DT), np.frombuffer(b, dtype=ALN_DT)
+            for q in range(len(ra)):
+                if ra[q].tobytes() != rb[q].tobytes():
+                    d["rec%d_%d" % (k, q)] = {f: (ra[q][f].tolist(), rb[q][f].tolist()) for f in ("fw", "tidx", "toff", "len", "trim5", "trim3", "nedits", "score") if ra[q][f] != rb[q][f]}
+                    ne = int(max(ra[q]["nedits"], rb[q]["nedits"]))
+                    d["rec%d_%d_edits" % (k, q)] = ([tuple(int(x) if not isinstance(x, bytes) else x for x in e.tolist()) for e in ra[q]["edits"][:ne]], [tuple(e.tolist()) for e in rb[q]["edits"][:ne]])
+                    break
     for k in range(1, len(ref)):
         a, b = ref[k][i], got[k][i]
         if a != b:

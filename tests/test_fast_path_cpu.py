@@ -172,3 +172,16 @@ def test_the_graph_library_refuses_a_linear_index(genome):
     reads, _ = synth.make_reads(contigs, 10, 101, 5)
     r = FC.fast_check(base, list(reads), variant="g")
     assert r["mismatching"] > 10 ** 9          # (the library says so instead of running the wrong fast path)
+
+
+def test_fused_graph_lf_and_single_row_walk(graph_genome):
+    """glf1_top_fused (one LF step of one row with the M / F bits and side headers taken from sides held in registers) == map_glf1_nochar,
+    and gw_walk_single (a one-node, one-row walk in chunks) == gw_resolve's offset and step count, on seeded rows of the global graph
+    index and of its graph local indexes"""
+    import ctypes as C
+    from h2gemu_py import Emu
+    base, ref, alt = graph_genome
+    e = Emu(base, "g")
+    e.L.h2gemu_glf_fused_check.restype = C.c_uint64
+    e.L.h2gemu_glf_fused_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    assert e.L.h2gemu_glf_fused_check(e.h, 100000, 11) == 0

@@ -88,14 +88,14 @@ if hasattr(L, "h2g_go_fast_prof"):
         reasons = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other indel tail iedges gwalk".split()
         print("  bails:", {reasons[k]: int(v[48 + k]) for k in range(len(reasons)) if v[48 + k]})
         if v[47]:
-            ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE GSEARCH".split()
-            tot = sum(v[k] for k in range(0, 16))
+            ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE GSEARCH ADJUST ADJMEMBER".split()
+            tot = sum(v[k] for k in range(0, 18))
             print("  trips %d, slots per trip %.1f, wave-ticks %d; state transitions per slot-trip %.2f, longest lane's per wave-trip %.2f" % (v[47], v[46] / max(1, v[47]), tot, v[44] / max(1, v[46]), v[45] / max(1, v[47])))
-            for k, nm in ((0, "pop+load"), (1, "control"), (2, "store"), (12, "release fence"), (13, "push"), (15, "new reads")):
+            for k, nm in ((0, "pop+load"), (1, "control"), (2, "store"), (16, "release fence"), (17, "push"), (15, "new reads")):
                 print("  %-20s %5.1f %%" % (nm, 100.0 * v[k] / tot))
-            sites = ["FETCH", "P", "G", "E:HS", "E", "l", "c", "C", "g"]
+            sites = ["FETCH", "P", "G", "E:HS", "E", "l", "c", "C", "g", "A", "a"]
             print("  control by site (us per trip, trips, %% of wave time):", "  ".join("%s %.1f/%d/%.1f%%" % (sites[k] if k < len(sites) else k, v[72 + k] / max(1, v[104 + k]) / 2400.0, v[104 + k], 100.0 * v[72 + k] / tot) for k in range(32) if v[104 + k]))
-            for op in range(1, 8):
+            for op in range(1, 10):
                 if v[3 + op]:
                     print("  %-20s %5.1f %%   executions %d: avg %.1f of 64 lanes" % (ops[op], 100.0 * v[3 + op] / tot, v[32 + op], v[20 + op] / max(1, v[32 + op])))
 print("%s n %d genome %d FAST=%s: steady %.2f ms/run | align total/fast/machine ms %s | fast done %d bailed %d (%.1f %%) second %d overflow %d aligned %d | sides/unit %.1f steps/unit %.1f | crc %08x" % (
