@@ -111,6 +111,19 @@ def body(path):
     return [l for l in open(path) if not l.startswith("@")]
 
 
+KERNEL_SOURCES = ("h2g_k_go_fast.hip", "h2g_k_go_fast_am.hip", "h2g_fast.h", "h2g_core.h", "h2g_align.h", "h2g_graph.h", "h2g_go_args.h", "Makefile")
+
+
+def kernel_sources_sha16():
+    """what the dominant kernel is compiled from (hisat2_amd/csrc: the fast pass's sources, the headers they include, the build flags).  A PMC
+    record is only attached to the line when it was taken on exactly these bytes; otherwise `traffic` is null (a stale figure is no figure)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(f.encode()); h.update(open(os.path.join(ROOT, "hisat2_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     t_start = time.time()
     deadline = float(os.environ.get("H2G_BENCH_DEADLINE", "1350"))
@@ -124,6 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (E. coli SE, graph index, micro-benchmarks)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
+    ap.add_argument("--only-legs", default="", help="comma-separated big legs (repeat_pe, graph256_pe) to run INSTEAD of the headline: prints {leg: ...} and exits")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs available to the reference CPU runs (each thread count takes what ~6 s of it)")
     a = ap.parse_args()
 
@@ -145,6 +159,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
 
     cache = os.path.join(ROOT, ".bench_cache")
+    if a.only_legs:
+        out = {}
+        for name in a.only_legs.split(","):
+            t0 = time.time()
+            out[name] = BIG_LEGS[name][0](a, api, synth, local, cache)
+            out[name]["leg_seconds"] = time.time() - t0
+        print(json.dumps(out))
+        return
     want_total = int(a.genome)
     how = None
     if rank == 0:
@@ -210,7 +232,8 @@ def main():
         achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
         alg_all = (int(cnt.n_side) + int(cnt.n_sa_steps)) * 64
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "k_go_fast (h2g_k_go_fast.hip)" if fast_on else "k_go<false> (h2g_go_kernels.h)", "kernel_ms": ms_kernel,
+                    "kernel": ("k_go_fast_am (h2g_k_go_fast_am.hip: alignMate in the pass)" if int(os.environ.get("H2G_FAST_AM", api.DEFAULT_ALIGN_MATE)) else "k_go_fast (h2g_k_go_fast.hip)") if fast_on else "k_go<false> (h2g_go_kernels.h)", "kernel_ms": ms_kernel,
+                    "tail_hand_off": int(os.environ.get("H2G_FAST_TAIL", api.DEFAULT_TAIL)),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "pairs_completed_by_the_kernel": int(cnt.n_fast), "pairs_handed_on": int(cnt.n_fast_bail),
                     "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs (about 0.5 %: long latency chains), on one of two machine streams next to the fast passes of the following two steps",
@@ -219,13 +242,19 @@ def main():
                     "note": "latency chains over scattered 64 B index lines + per-read control; per trip a read's 160 B state and 264 B of hot words + packed reads are loaded in one batch of 16 B loads and stored back (DESIGN.md §3.1)"}
         # HBM traffic of the same kernel on the same workload from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
         # WRITE_SIZE need separate passes and cannot be collected inside this process); per launch like `achieved`
+        roofline["kernel_sources_sha16"] = kernel_sources_sha16()
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
-            if pm.get("pairs_per_launch") == npairs and pm.get("genome") == total and pm.get("kernel", "").startswith("k_go_fast") == fast_on:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            same_run = pm.get("pairs_per_launch") == npairs and pm.get("genome") == total and pm.get("kernel", "").startswith("k_go_fast") == fast_on
+            if same_run and pm.get("kernel_sources_sha16") == roofline["kernel_sources_sha16"]:
                 roofline["traffic"] = int(pm["traffic_bytes_per_launch"])
                 roofline["traffic_source"] = pm.get("source")
+                roofline["traffic_calibration"] = pm.get("calibration")
+            else:
+                roofline["traffic_note"] = ("profiles/r04_pmc_traffic.json was taken on kernel sources %s / %s pairs / %s bp; this run is %s / %d / %d: not attached"
+                                            % (pm.get("kernel_sources_sha16"), pm.get("pairs_per_launch"), pm.get("genome"), roofline["kernel_sources_sha16"], npairs, total))
         except (OSError, ValueError):
-            pass
+            roofline["traffic_note"] = "no PMC record (profiles/r04_pmc_traffic.json)"
         out.update({
             "metric": "reads/sec, 101 bp PE, GRCh38-size linear index, --no-spliced-alignment: HI_Aligner::go per pair on the GPU (inputs and report events resident in HBM), SAM-identical to hisat2",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -323,6 +352,17 @@ def main():
                 out.update(extras(a, api, synth, ix, local, cache))
             except Exception as e:             # noqa: BLE001
                 out["extras_error"] = repr(e)[:400]
+            # the two legs with an index build of their own run while the budget lasts (H2G_BENCH_BIG_DEADLINE seconds since the start; both
+            # are measured with --only-legs in profiles/r04_legs.json whether or not this run reaches them)
+            big_deadline = float(os.environ.get("H2G_BENCH_BIG_DEADLINE", "1500"))
+            for name, (fn, need) in BIG_LEGS.items():
+                if time.time() - t_start + need > big_deadline:
+                    out.setdefault("big_legs_skipped", []).append(name)
+                    continue
+                try:
+                    out[name] = fn(a, api, synth, local, cache)
+                except Exception as e:         # noqa: BLE001
+                    out[name] = {"error": repr(e)[:400]}
         print(json.dumps(out))
     else:
         st.close()
@@ -414,10 +454,11 @@ def extras(a, api, synth, ix_big, local, cache):
                                 "pairs": gnp, "variants": len(var), "ms_per_step": gdt * 1e3, "reads_per_s": 2 * gnp / gdt, "kernel_ms": float(gc_.ms_align_kernel),
                                 "pairs_with_concordant": int(gc_.n_aligned), "second_pass": int(gc_.n_second_pass), "still_flagged": int(gc_.n_overflow),
                                 "ranks_per_pair": int(gc_.n_rank) / gnp, "sa_steps_per_pair": int(gc_.n_sa_steps) / gnp,
-                                "roofline": {"bound": "hbm", "kernel": "k_go<true> (h2g_go_kernels.h; graph indexes run the general machine, no fast pass yet)",
-                                             "achieved": (int(gc_.n_rank) + int(gc_.n_sa_steps)) * 128 / (float(gc_.ms_align_kernel) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": (int(gc_.n_rank) + int(gc_.n_sa_steps)) * 128 / (float(gc_.ms_align_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                             "algorithmic": "(rank queries + SA-walk steps) x 128 B graph sides"}}
+                                "pairs_completed_by_the_fast_pass": int(gc_.n_fast), "pairs_handed_on": int(gc_.n_fast_bail), "fast_kernel_ms": float(gc_.ms_fast_kernel),
+                                "roofline": {"bound": "hbm", "kernel": "k_go_fast_graph (h2g_k_go_fast_graph.hip: the compact-state pass over the graph form of the state) + k_go<true> over the pairs it hands on",
+                                             "achieved": (int(gc_.n_rank) + int(gc_.n_sa_steps)) * 128 / (gdt) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": (int(gc_.n_rank) + int(gc_.n_sa_steps)) * 128 / (gdt) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                             "algorithmic": "(rank queries + SA-walk steps) x 128 B graph sides of the whole step, over the steady-state step time (fast pass and machine pass overlap across steps)"}}
         gst.close(); gix.close()
     ix.close()
     if os.path.exists(builder) and os.path.exists(exe):
@@ -437,6 +478,117 @@ def extras(a, api, synth, ix_big, local, cache):
         rst.close(); rix.close()
         ex[key] = micro
     return ex
+
+
+BAIL_REASONS = "none input longpool subsample coords nghits edits depth localhits gsearch nres searched redundant mate npairs partial straddle other indel tail iedges gwalk".split()
+
+
+def fast_bail_reasons(api, st):
+    """hand-ons of the last fast pass by reason (h2g_fast.h FB_*): the development hook reads the counter block of the last run"""
+    import ctypes as C
+    v = (C.c_ulonglong * 136)()
+    L = api.lib()
+    L.h2g_go_fast_prof.argtypes = [C.c_void_p, C.c_void_p]
+    if L.h2g_go_fast_prof(st.h, v) != 0:
+        return None
+    return {BAIL_REASONS[k]: int(v[48 + k]) for k in range(len(BAIL_REASONS)) if v[48 + k]}
+
+
+def sam_parity(base, f1, f2, nv, tmp, opts=()):
+    """the first nv pairs through the drop-in command line and through the reference: differing SAM lines (bodies)"""
+    exe = os.path.join(REF, "hisat2-align-s")
+    cli = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+    ref_sam, amd_sam = os.path.join(tmp, "ref.sam"), os.path.join(tmp, "amd.sam")
+    subprocess.run([exe, "-f", "--no-spliced-alignment", "-p", "8", "--reorder", "-x", base, "-1", f1, "-2", f2, "-u", str(nv), "-S", ref_sam] + list(opts), check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([cli, "-f", "--no-spliced-alignment", "-p", "8", "-x", base, "-1", f1, "-2", f2, "-u", str(nv), "-S", amd_sam, "--h2g-stats", os.path.join(tmp, "stats.json")] + list(opts),
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"error": "hisat2-align-amd rc %d: %s" % (r.returncode, r.stderr[-600:])}
+    wa, wb = body(amd_sam), body(ref_sam)
+    return {"pairs_checked": nv, "sam_lines": len(wb), "sam_lines_differing": sum(1 for x, y in zip(wa, wb) if x != y) + abs(len(wa) - len(wb)),
+            "against": "oracle/_ref/hisat2-align-s -p 8 --reorder (complete SAM lines)", **json.load(open(os.path.join(tmp, "stats.json")))}
+
+
+def timed_pairs(api, synth, base, local, m1, m2, steps=5):
+    c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
+    n = len(m1)
+    names = [str(i) for i in range(n)]
+    ix = api.Index(base, device=local)
+    st = api.Stream(ix, max_reads=n, max_bases=c1.size)
+    st.set_reads(c1, o1); st.set_read_names(names); st.set_mates(c2, o2, names)
+    st.align_pairs_run(); st.align_pairs_run(); st.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.align_pairs_run()
+    st.sync()
+    dt = (time.perf_counter() - t0) / steps
+    c = st.counters()
+    leg = {"pairs": n, "ms_per_step": dt * 1e3, "reads_per_s": 2 * n / dt, "fast_kernel_ms": float(c.ms_fast_kernel), "machine_pass_ms": float(c.ms_align_kernel),
+           "pairs_completed_by_the_fast_pass": int(c.n_fast), "pairs_handed_on": int(c.n_fast_bail), "hand_on_rate": int(c.n_fast_bail) / n,
+           "hand_ons_by_reason": fast_bail_reasons(api, st), "pairs_second_pass": int(c.n_second_pass), "second_pass_rate": int(c.n_second_pass) / n,
+           "pairs_still_flagged_overflow": int(c.n_overflow), "pairs_with_concordant": int(c.n_aligned),
+           "ranks_per_pair": int(c.n_rank) / n, "sides_per_pair": int(c.n_side) / n, "sa_steps_per_pair": int(c.n_sa_steps) / n,
+           "index_device_bytes": int(ix.info.device_bytes)}
+    st.close(); ix.close()
+    return leg
+
+
+def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, nparity=20_000):
+    """The headline's companion on a genome WITH repeats: synth.make_repeat_genome — Alu-like and LINE-like families at 8-20 %
+    divergence in a quarter of the bases, tandem arrays, segmental duplications — 24 human-profile contigs, linear index built on the box,
+    1 M x 2 x 101 bp pairs: the step time, how many pairs the fast pass hands on and why, the second-pass rate, and the SAM of 20 000 pairs
+    against the reference."""
+    import build_bench_index as BB
+    d = os.path.join(cache, f"rep{glen}_s{SEED}")
+    base = os.path.join(d, "g")
+    contigs = synth.make_repeat_genome(BB.contig_lens(glen), SEED + 77)
+    t_build = None
+    if not os.path.exists(base + ".8.ht2"):
+        os.makedirs(d, exist_ok=True)
+        synth.write_fasta(base + ".fa", contigs)
+        t0 = time.time()
+        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "-p", str(min(os.cpu_count() or 1, 64)), base + ".fa", base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_build = time.time() - t0
+        os.remove(base + ".fa")
+    m1, m2 = synth.make_pairs(contigs, npairs, 101, SEED + 78, sub_rate=0.005)
+    leg = {"workload": f"repeat-structured {glen} bp genome (interspersed families of ~300 bp and 1-6 kbp at 8-20 % divergence in a quarter of the bases, tandem arrays, segmental "
+                       f"duplications; 24 contigs), linear index, {npairs} x 2 x 101 bp pairs, --no-spliced-alignment -k 5", "index_build_s": t_build}
+    leg.update(timed_pairs(api, synth, base, local, m1, m2))
+    tmp = tempfile.mkdtemp(prefix="h2rep")
+    f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
+    synth.write_reads_fasta(f1, m1[:nparity]); synth.write_reads_fasta(f2, m2[:nparity])
+    leg["parity"] = sam_parity(base, f1, f2, nparity, tmp)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return leg
+
+
+def graph256_leg(a, api, synth, local, cache, glen=256_000_000, every=250, npairs=1_000_000, nparity=20_000):
+    """configs[3]'s shape beyond toy size: a SNP-graph index over a 256 Mbp genome (a variant about every 250 bp: ~1 M single-base variants,
+    deletions and insertions; built on the box by the reference's builder, ~18 GB of builder memory), 1 M pairs from the alternate haplotype."""
+    import build_graph_bench_index as GB
+    import build_bench_index as BB
+    base, info = GB.build(glen, every, cache=cache)
+    if info is None and os.path.exists(base + ".build.json"):
+        info = json.load(open(base + ".build.json"))
+    contigs = BB.genome(glen)
+    alt = synth.apply_snps(contigs, GB.variants(glen, every, contigs), names=GB.names(glen))
+    m1, m2 = synth.make_pairs(alt, npairs, 101, SEED + 79, frag_mean=300, frag_sd=30, sub_rate=0.005)
+    leg = {"workload": f"configs[3] shape: SNP-graph index over a seeded {glen} bp genome, a variant every ~{every} bp, {npairs} x 2 x 101 bp pairs from the alternate haplotype, --no-spliced-alignment",
+           "index_build": info}
+    leg.update(timed_pairs(api, synth, base, local, m1, m2))
+    alg = (leg["ranks_per_pair"] + leg["sa_steps_per_pair"]) * npairs * 128
+    leg["roofline"] = {"bound": "hbm", "kernel": "k_go_fast_graph + k_go<true> over the hand-ons (whole step)", "achieved": alg / (leg["ms_per_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": alg / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic": "(rank queries + SA-walk steps) x 128 B graph sides"}
+    tmp = tempfile.mkdtemp(prefix="h2g256")
+    f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
+    synth.write_reads_fasta(f1, m1[:nparity]); synth.write_reads_fasta(f2, m2[:nparity])
+    leg["parity"] = sam_parity(base, f1, f2, nparity, tmp)
+    shutil.rmtree(tmp, ignore_errors=True)
+    return leg
+
+
+BIG_LEGS = {"repeat_pe": (repeat_leg, 330.0), "graph256_pe": (graph256_leg, 520.0)}      # name -> (function, seconds it needs on a 16-core box incl. its index build)
 
 
 def spliced_leg(a, api, synth, local, cache):

@@ -377,16 +377,14 @@ int main(int argc, char** argv) {
 	// Temporary splice sites (the reference's default): a read sees the junctions of reads at least W = 1000 * p ids before it
 	// (hisat2.cpp:3687; -p 1 means W = 0, every read after the other).  The batches are waves of <= W reads run one after the other.
 	const bool temp_ss = !nospliced && !notempss;
-	uint32_t ss_window = 0;
+	uint32_t ss_window = 0, ss_wave = 0;      // the reference's visibility window, and the reads of one wave here (the window, or ONE read when it is 0)
 	if(temp_ss) {
-		if(threads < 2 && !ss_window_opt) {
-			fprintf(stderr, "hisat2-align-amd: with temporary splice sites a read depends on the reads 1000 x <-p> before it; -p 1 would run the reads one by one. "
-			        "Pass -p >= 2 (output == hisat2 -p <int> --reorder), --ss-window <int> (output == hisat2 -p <int>/1000 --reorder whatever -p is here), "
-			        "--no-temp-splicesite or --no-spliced-alignment\n");
-			return 1;
-		}
-		ss_window = ss_window_opt ? ss_window_opt : 1000u * (uint32_t)threads;
-		batch = ss_window;   // a wave is exactly one shard per device (want()): a smaller --batch would complete shards (and merge their junctions) in the middle of a wave
+		// -p 1 (and no --ss-window): the reference's window is 0 (hisat2.cpp:3687) — a read sees the junctions of EVERY read before it, a strict
+		// chain.  It runs as waves of one read: exact, and as slow as a chain is (a device round trip per read); meant for small inputs — the
+		// reference's bare default invocation `hisat2 -x idx -U reads` then simply works.  -p >= 2 / --ss-window are the throughput modes.
+		ss_window = ss_window_opt ? ss_window_opt : (threads < 2 ? 0u : 1000u * (uint32_t)threads);
+		ss_wave = ss_window ? ss_window : 1u;
+		batch = ss_wave;   // a wave is exactly one shard per device (want()): a smaller --batch would complete shards (and merge their junctions) in the middle of a wave
 	}
 	const bool paired = u.empty();
 	const double t0 = now();
@@ -574,10 +572,10 @@ int main(int argc, char** argv) {
 	// Temporary splice sites on G devices: a wave of W reads is cut into G shards that run side by side — a read never sees the junctions of
 	// its own wave (readid + W > its id), so the shards need nothing from one another; every shard's junctions join the database (on every
 	// device) before the next wave starts (the exchange between two waves is the junction list, tens of bytes per site).
-	size_t wave_left = ss_window;                         // reads the current wave still takes
+	size_t wave_left = ss_wave;                           // reads the current wave still takes
 	auto want = [&]() {
 		size_t w = (size_t)std::min<uint64_t>(batch, budget);
-		if(temp_ss) { const size_t shard = (ss_window + (size_t)gpus - 1) / (size_t)gpus; w = std::min(w, std::min(shard, wave_left)); }
+		if(temp_ss) { const size_t shard = (ss_wave + (size_t)gpus - 1) / (size_t)gpus; w = std::min(w, std::min(shard, wave_left)); }
 		return w;
 	};
 	// fetch + format + write the batch that stream `g` carries
@@ -677,9 +675,9 @@ int main(int argc, char** argv) {
 		const int g = (int)(k % G);
 		const double tg = now();
 		if(temp_ss) {                                  // a wave needs the sites of every earlier one: nothing of them stays in flight when it starts
-			if(wave_left == ss_window) for(long q = k - G; q < k; q++) if(q >= 0) complete((int)(q % G));
+			if(wave_left == ss_wave) for(long q = k - G; q < k; q++) if(q >= 0) complete((int)(q % G));
 			wave_left -= n;
-			if(wave_left == 0) wave_left = ss_window;
+			if(wave_left == 0) wave_left = ss_wave;
 		}
 		complete(g);                                   // the batch this stream still carries (k - G): the oldest one in flight
 		Str& sg = S[(size_t)g];

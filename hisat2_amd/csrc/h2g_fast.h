@@ -390,7 +390,6 @@ H2G_HD void fh_calc_score(const DScoring& sc, const SeqView& seq, FHit& h) {
 	if(score < -(1 << 30)) { h.bad = 1; score = -(1 << 30); }
 	h.score = (int32_t)score;
 }
-#if !FG_GRAPH      // (on a graph index extension and joins are the ALT-aware item functions of h2g_graph.h / h2g_align.h over an unpacked hit)
 // positions (bit 2j = position j, j < n <= 32) at which two 2-bit strings differ
 H2G_HD uint64_t fh_diff32(uint64_t r, uint64_t q, uint32_t n) {
 	const uint64_t x = r ^ q;
@@ -506,6 +505,20 @@ H2G_HD uint32_t fh_align(const DRef& ref, const SeqView& seq, uint32_t base_rdof
 		if(left) {                   // new edits go to the front, in increasing read position (they were met right to left); the old ones move up
 			const uint64_t rev = (nw << 48) | ((nw & 0xffff0000ull) << 16) | ((nw >> 16) & 0xffff0000ull) | (nw >> 48);
 			h.e = (tmp_mm >= FG_FE ? 0ull : h.e << (16u * tmp_mm)) | (rev >> (16u * (FG_FE - tmp_mm)));
+#if FG_GRAPH
+			{   // ... and their ALT ids with them (the new edits are plain mismatches)
+				uint32_t o[FG_FE];
+#pragma unroll
+				for(uint32_t k = 0; k < FG_FE; k++) o[k] = h.snp[k];
+#pragma unroll
+				for(uint32_t k = 0; k < FG_FE; k++) {
+					uint32_t v = H2G_MAX;
+#pragma unroll
+					for(uint32_t j = 0; j < FG_FE; j++) if(j + tmp_mm == k) v = o[j];
+					h.snp[k] = v;
+				}
+			}
+#endif
 		} else {
 			h.e |= nw << (16u * n_old);       // (n_old + tmp_mm <= FG_FE)
 		}
@@ -561,6 +574,7 @@ H2G_HD void fh_extend(const DRef& ref, const DScoring& sc, const SeqView& seq, F
 	}
 	fh_calc_score(sc, seq, h);
 }
+#if !FG_GRAPH      // (on a graph index joins are hit_combine of h2g_align.h over the unpacked hits: the rescan looks mismatches up in the ALT database)
 // combineWith hi_aligner.h:1420-2025 (hit_combine) without spliced alignment, for two hits with the same read / reference offset
 // difference: concatenation (:1506-1525) or the rescan of the joint for mismatches (:1880-1931).  An insertion or deletion between
 // them is the general machine's: *indel is set and nothing else happens.
@@ -2117,6 +2131,35 @@ H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
 // GenomeHit::extend on a graph index: alignWithALTs through the ALT database (extend_item_alts) over the unpacked hit
 H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
 	FHit h = fh_load(W, S.a3);
+	{
+		// No ALT within reach of either extension (extend_item_alts' own tests; the right end of a hit does not move when it grows to the left):
+		// alignWithALTs degenerates to the mismatch scan of a linear index — the word-wise register code, no unpacked record
+		const DAlts& A = *C.alts;
+		const SeqView sv = fg_sv(C, S);
+		bool plain = true;
+		if(S.a1 > 0 && h.rdoff > 0) {
+			const uint32_t wlo = h.joff > h.rdoff + 16 ? h.joff - h.rdoff - 16 : 0;
+			if(alt_lobound(A, wlo) != alt_lobound(A, h.joff + 2)) plain = false;
+		}
+		if(plain && S.a2 > 0 && h.rdoff + h.len < sv.len) {
+			int ref_ext = (int)h.len;
+#pragma unroll
+			for(uint32_t k = 0; k < FG_FE; k++) if(k < h.nedits) {
+				const uint32_t e = FE_GET(h, k), t = FE_TYPE(e);
+				if(t == H2G_EDIT_REF_GAP) ref_ext--; else if(t == H2G_EDIT_READ_GAP) ref_ext++; else if(t == H2G_EDIT_MM && FE_CCODE(e) == 4) ref_ext--;
+			}
+			const uint32_t jr = h.joff + (uint32_t)ref_ext, rr = sv.len - (h.rdoff + h.len);
+			// (a left extension of up to rdoff bases can add mismatches against reference Ns, which move jr by nothing; the window is taken 16 wider on both sides all the same)
+			if(alt_lobound(A, jr > 18 ? jr - 18 : 0) != alt_lobound(A, jr + rr + 32)) plain = false;
+		}
+		if(plain) {
+			uint32_t le = H2G_MAX, re = H2G_MAX;
+			fh_extend(*C.ref, C.P->sc, sv, h, S.a0, S.a1, S.a2, &le, &re);
+			if(!fh_store(W, S.a3, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
+			S.a0 = le; S.a1 = re;
+			return;
+		}
+	}
 	h2g_ghit g;
 	fh_to_ghit(h, &g);
 	uint32_t le = H2G_MAX, re = H2G_MAX;

@@ -59,9 +59,12 @@ struct FastArgs {
 	h2g::DAlts alts;
 	uint8_t* gws_base; size_t gws_stride;     // GraphWS per lane (group walk, ALT-aware extension)
 	uint8_t* sc_base;                         // combineWith temp_scores per lane: 2 x H2G_COMBINE_MAXLEN int64, lane-interleaved per wave
+	uint32_t tail;                            // > 0: a workgroup hands its last `tail` reads in flight on to the general machine once the batch is exhausted
 	uint32_t dbg_read; uint32_t* dbg_buf;     // development hook (-DFG_DBG_TRACE builds, h2g_stream_tune "dbg_read"): the trips of one read id, 10 words each behind a word count
 };
 extern "C" int h2g_go_fast_launch(const FastArgs*, unsigned grid, hipStream_t);
 extern "C" void h2g_go_fast_geometry(uint32_t* g);   // [0] threads per workgroup [1] LDS bytes per workgroup [2] slots per workgroup [3] bytes per slot
+extern "C" int h2g_go_fast_am_launch(const FastArgs*, unsigned grid, hipStream_t);         // h2g_k_go_fast_am.hip: alignMate in the pass (FG_ALIGN_MATE = 1)
+extern "C" void h2g_go_fast_am_geometry(uint32_t* g);
 extern "C" int h2g_go_fast_graph_launch(const FastArgs*, unsigned grid, hipStream_t);
 extern "C" void h2g_go_fast_graph_geometry(uint32_t* g);   // ... [4] bytes of GraphWS per lane

@@ -13,6 +13,7 @@
 #include <string>
 #include <algorithm>
 #include <vector>
+#include <thread>
 
 namespace h2g {
 
@@ -130,8 +131,13 @@ inline bool read_gfm_body(Reader& b, HostGfm& g) {
 // returns 0 ok, -1 io, -2 format
 inline int load_host_index(const std::string& base, bool load_local, HostIndex& ix) {
 	Reader b1, b2, b3, b4;
-	if(!b1.open(base + ".1.ht2") || !b2.open(base + ".2.ht2") || !b3.open(base + ".3.ht2") ||
-	   !b4.open(base + ".4.ht2")) return -1;
+	{   // the three large files are read side by side (a human-size index: 1.0 + 0.8 + 0.8 GB)
+		bool ok1 = false, ok2 = false, ok4 = false;
+		std::thread t2([&]() { ok2 = b2.open(base + ".2.ht2"); }), t4([&]() { ok4 = b4.open(base + ".4.ht2"); });
+		ok1 = b1.open(base + ".1.ht2");
+		t2.join(); t4.join();
+		if(!ok1 || !ok2 || !ok4 || !b3.open(base + ".3.ht2")) return -1;
+	}
 	if(b1.u32() != 1) return -2;
 	b1.u32();  // version
 	uint32_t len = b1.u32(), gbwtLen = b1.u32(), numNodes = b1.u32();

@@ -25,9 +25,6 @@ using namespace h2g;
 #endif
 #define FG_STAGE_WORDS (FW_HOT + 2 * H2G_PK_WORDS)                     // staged in LDS per lane: hot words + packed reads
 #define FG_SLOT_WORDS  (((FS_WORDS + FW_HOT + 2 * H2G_PK_WORDS + FW_COLD) + 3) & ~3)   // 16-byte multiple
-#ifndef FG_TAIL
-#define FG_TAIL 0                 // > 0: a workgroup hands its last FG_TAIL reads in flight on to the general machine once the batch is exhausted (an experiment: profiles/r04_NOTES.md)
-#endif
 #define FG_NQ ((int)FQ_COUNT)
 #define FG_RING_EMPTY 0xffffu
 static_assert(FG_NQ <= 64, "the queue census is one lane per queue");
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 	uint32_t* const slots0 = A->slots + (size_t)blockIdx.x * H2G_FAST_SLOTS * FG_SLOT_WORDS;
 	unsigned long long nrank = 0, nside = 0, nsteps = 0, naln = 0, ndone = 0, nbail = 0;
 	bool more = true;
-	const uint32_t total = A->total;
+	const uint32_t total = A->total, tail_n = A->tail;
 #ifdef H2G_GO_PROF
 	// wave-level time split (shader clock): [0] choose + pop + load [1] control [2] store [16] release fence [17] push [3+op] each primitive [15] new reads; [20+op] slots executed;
 	// [32+op] executions; [46] slots stepped [47] trips
@@ -187,9 +184,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 		bestc = (uint32_t)__shfl((int)bestc, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
 		const bool fetch = more && nfree > 0 && (bestc < 64 || nfree >= H2G_FAST_SLOTS / 4);
 		bool have = false;
-#if FG_TAIL
 		bool tail = false;
-#endif
 		uint32_t slot = 0, begin = H2G_MAX, packed_ok = 0, trip_op = FOP_NONE;
 		uint32_t* sm = nullptr;                                   // this lane's slot in HBM
 		if(fetch) {
@@ -228,13 +223,11 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 			if(n == 0) continue;
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			have = (uint32_t)lane < n;
-#if FG_TAIL
-			tail = !more && H2G_FAST_SLOTS - nfree <= (uint32_t)FG_TAIL;
+			// (FastArgs::tail: the last reads in flight of an exhausted batch are a few latency chains per workgroup; they can go to the general
+			// machine's pass, which is in flight anyway — profiles/r04_NOTES.md §1, §4)
+			tail = !more && H2G_FAST_SLOTS - nfree <= tail_n;
 			if(have && tail) sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
 			if(have && !tail) {
-#else
-			if(have) {
-#endif
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
 				// hot words + packed reads into this lane's LDS staging area: 16-byte loads, nothing depends on anything
 				const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
@@ -258,11 +251,8 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 		prof[46] += __popcll(__ballot(have)); prof[47]++;
 #endif
 		uint32_t w0 = 0;
-#if FG_TAIL
 		if(have && tail) w0 = (uint32_t)FPC_BAIL | ((uint32_t)FB_TAIL << 12);     // (pc, bail reason of state word 0; the read id is state word 8 in the slot)
-		else
-#endif
-		if(have) w0 = fk_trip(A, stage, sm, trip_op, begin, packed_ok);
+		else if(have) w0 = fk_trip(A, stage, sm, trip_op, begin, packed_ok);
 #ifdef H2G_GO_PROF
 		{ const unsigned long long t_ = __builtin_readcyclecounter(); prof_ctl[trip_site & 31] += t_ - tp0; prof_n[trip_site & 31]++; }
 #endif

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <thread>
 #include <algorithm>
 #define H2G_EXT_OPTS 0      // likewise -I / --fr --rf --ff / --nofw --norc (h2g_align.h): go() units only
 #define H2G_HAPLOTYPE 0     // the primitive kernels of this unit (k_extend_alts, k_adjust_alt) run without haplotype lists; go() units: h2g_graph.h
@@ -56,8 +57,14 @@ struct h2g_index {
 };
 
 #define H2G_NBUF 3
+// the fast pass's two scheduling choices for PAIRED batches on a linear index (measured at GRCh38 size: profiles/r04_NOTES.md §4): reads a
+// workgroup hands on at the tail of an exhausted batch, and whether alignMate runs inside the pass (k_go_fast_am) or in the machine's pass
+#define H2G_DEFAULT_TAIL 0
+#define H2G_DEFAULT_ALIGN_MATE 0
 #define H2G_CNT_BLOCK 512u          // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
-#define H2G_MACH_MAXGRID 48u       // workgroups of a machine pass behind a fast pass (two such passes may be in flight)
+#define H2G_MACH_MAXGRID 100u      // workgroups of a machine pass behind a fast pass (two such passes may be in flight): its workspace pools are sized for this
+#define H2G_MACH_LATGRID 48u       // ... while its hand-ons are few (a latency chain: more workgroups buy nothing)
+#define H2G_MACH_WORK_BAILS 8000u  // hand-ons from which the machine pass is throughput-bound and its share of the CUs follows the measured work
 struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
@@ -66,6 +73,8 @@ struct h2g_stream {
 	hipStream_t mst[2] = {nullptr, nullptr};
 	bool st2_busy = false;            // a machine stream may hold work
 	hipEvent_t ev_fast[H2G_NBUF], ev_mach[H2G_NBUF];
+	hipEvent_t ev_f0[H2G_NBUF], ev_m0[H2G_NBUF];     // start of that generation's fast / machine pass (their durations x workgroups = the work that balances the CUs)
+	unsigned fgrid_of[H2G_NBUF] = {}, mgrid_of[H2G_NBUF] = {};
 	unsigned gen = 0;                 // go_run generation: bail list, counters and argument block are buffered H2G_NBUF deep by gen % H2G_NBUF
 	unsigned long long* cnt_cur = nullptr;   // the counter block of the last go_run
 	uint32_t last_bails = 0;
@@ -99,7 +108,8 @@ struct h2g_stream {
 	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
-	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 400, mach_min = 4; long dbg_read = -1; } tune;
+	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 400, mach_min = 4; long dbg_read = -1;
+	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
@@ -165,8 +175,15 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	HIPCHK(hipSetDevice(o.device));
 	h2g_index* ix = new h2g_index();
 	ix->device = o.device;
-	int rc = load_host_index(base, o.load_local != 0, ix->host);
-	if(rc != 0) { delete ix; snprintf(g_err, sizeof g_err, "cannot read index %s", base); return rc == -1 ? H2G_ERR_IO : H2G_ERR_FORMAT; }
+	// the local indexes (.5 / .6: 2.1 GB of a human-size index) are packed on a thread of their own, straight from the files, while the global
+	// index is read, parsed and uploaded here
+	LocalPack lp;
+	int lrc = 1;                                             // 1: no local files (an index built without them loads for rank / search only)
+	std::thread tlocal;
+	if(o.load_local) tlocal = std::thread([&]() { lrc = load_local_pack(base, 0, lp); });
+	struct Joiner { std::thread& t; ~Joiner() { if(t.joinable()) t.join(); } } joiner{tlocal};      // (every early return below waits for it)
+	int rc = load_host_index(base, false, ix->host);
+	if(rc != 0) { if(tlocal.joinable()) tlocal.join(); delete ix; snprintf(g_err, sizeof g_err, "cannot read index %s", base); return rc == -1 ? H2G_ERR_IO : H2G_ERR_FORMAT; }
 	const HostGfm& g = ix->host.g;
 	fill_dgfm(g, ix->host.minK, &ix->dg);
 	int s = H2G_OK;
@@ -197,9 +214,10 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		for(const HostAlt& a : ix->host.alts) if(a.type == 5) ix->dalts.has_splice = 1;
 	}
 	memset(&ix->dls, 0, sizeof ix->dls);
-	if(o.load_local && !ix->host.local.empty()) {
-		LocalPack lp;
-		pack_local(ix->host, lp);
+	if(tlocal.joinable()) tlocal.join();
+	if(lrc == -2) { h2g_index_free(ix); snprintf(g_err, sizeof g_err, "cannot read the local indexes of %s", base); return H2G_ERR_FORMAT; }
+	if(o.load_local && lrc == 0 && !lp.desc.empty()) {
+		while(lp.first.size() <= g.nPat) lp.first.push_back((uint32_t)lp.desc.size());
 		const DLocalDesc* dd; const uint8_t* ds; const uint16_t* dw; const uint32_t* df; const uint32_t* dz;
 		if((s = upload(ix, lp.desc, &dd)) || (s = upload(ix, lp.sides, &ds, 256)) || (s = upload(ix, lp.words, &dw)) ||
 		   (s = upload(ix, lp.first, &df)) || (s = upload(ix, lp.zoffs, &dz))) { h2g_index_free(ix); return s; }
@@ -416,7 +434,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	for(int k = 0; k < 2; k++) HIPCHK(hipStreamCreateWithFlags(&s->mst[k], hipStreamNonBlocking));
 	HIPCHK(hipHostMalloc((void**)&s->h_fast_args, sizeof(FastArgs) * H2G_NBUF));
 	HIPCHK(hipHostMalloc((void**)&s->h_bails, 4 * H2G_NBUF)); for(int k = 0; k < H2G_NBUF; k++) s->h_bails[k] = 0;
-	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
+	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreate(&s->ev_fast[k])); HIPCHK(hipEventCreate(&s->ev_mach[k])); HIPCHK(hipEventCreate(&s->ev_f0[k])); HIPCHK(hipEventCreate(&s->ev_m0[k])); }
 	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
 	HIPCHK(hipMalloc((void**)&s->d_counters, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(s->d_counters, 0, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
@@ -433,6 +451,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.fast = (int)env("H2G_GO_FAST", 1); s->tune.blocks_per_cu = (int)env("H2G_GO_BLOCKS_PER_CU", 0); s->tune.pair_slots = (int)env("H2G_PAIR_SLOTS", 0);
 		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 400); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
+		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
 	}
 	*out = s;
 	return H2G_OK;
@@ -443,7 +462,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipStreamSynchronize(s->st); for(int k = 0; k < 2; k++) (void)hipStreamSynchronize(s->mst[k]);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 4; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); (void)hipEventDestroy(s->ev_f0[k]); (void)hipEventDestroy(s->ev_m0[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -1715,6 +1734,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	const bool second = !big_main && !no_second;
 	A.defer_overflow = second ? 1u : 0u;
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
+	HIPCHK(hipEventRecord(s->ev_f0[gsel], s->st));
 	// ---- the fast pass (h2g_fast.h): the dominant traces with the per-read state on chip.  What it completes is final; the reads
 	// it hands on (a device-side list, no host sync) are the general machine's batch.  Built for unspliced alignment on a linear
 	// index with the default pair policy; every other option set goes to the machine whole.
@@ -1722,7 +1742,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	unsigned fast_mgrid = 0;
 	if(fast) {
 		uint32_t fgeo[5] = {0, 0, 0, 0, 0};
-		if(linear) h2g_go_fast_geometry(fgeo); else h2g_go_fast_graph_geometry(fgeo);
+		const bool use_am = linear && paired && s->tune.align_mate != 0;
+		if(!linear) h2g_go_fast_graph_geometry(fgeo); else if(use_am) h2g_go_fast_am_geometry(fgeo); else h2g_go_fast_geometry(fgeo);
 		// CUs: one persistent fast workgroup each (LDS-bound), minus the few the machine pass of the PREVIOUS run may still hold
 		// (the machine takes ~150 hand-ons per workgroup in half the time of a fast pass; the count is the last finished fast pass's)
 		for(unsigned back = 1; back < H2G_NBUF && back <= s->gen; back++) {                     // the latest fast pass that is over
@@ -1733,7 +1754,25 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		const unsigned mach_div = s->tune.mach_div, mach_min = s->tune.mach_min;   // (hand-ons per machine workgroup: latency chains, two passes in flight)
 		unsigned mgrid = (unsigned)((s->last_bails + mach_div - 1) / (mach_div ? mach_div : 1u));
 		if(mgrid < mach_min) mgrid = mach_min;
-		if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
+		if(mgrid > H2G_MACH_LATGRID) mgrid = H2G_MACH_LATGRID;
+		// Many hand-ons (repeat-rich sequence: 3-4 % of the pairs): the machine pass is no latency chain any more but WORK, and the step time is
+		// what the slower of the two kernels needs on its share of the CUs.  Two machine passes are in flight next to one fast pass, so the shares
+		// balance at  M / m = 2 F / (256 - 2 m)  <=>  m = 128 M / (F + M),  with F, M the workgroup-milliseconds of the latest finished generation.
+		if(s->last_bails > H2G_MACH_WORK_BAILS) {
+			for(unsigned back = 1; back < H2G_NBUF && back <= s->gen; back++) {
+				const unsigned b = (s->gen - back) % H2G_NBUF;
+				float tf = 0, tm = 0;
+				if(s->fgrid_of[b] && s->mgrid_of[b] && hipEventQuery(s->ev_mach[b]) == hipSuccess && hipEventElapsedTime(&tf, s->ev_f0[b], s->ev_fast[b]) == hipSuccess &&
+				   hipEventElapsedTime(&tm, s->ev_m0[b], s->ev_mach[b]) == hipSuccess && tf > 0 && tm > 0) {
+					const double F = (double)tf * s->fgrid_of[b], M = (double)tm * s->mgrid_of[b];
+					const unsigned m = (unsigned)(128.0 * M / (F + M) + 0.5);
+					if(m > mgrid) mgrid = m;
+					break;
+				}
+			}
+			(void)hipGetLastError();
+			if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
+		}
 		size_t fwant = (s->n_reads + 127) / 128;                                                // small batches spread over the chip
 		const unsigned fmax = 256 - 2 * mgrid;                                                  // (two machine passes may be in flight)
 		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > fmax ? fmax : fwant));
@@ -1757,6 +1796,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		F.total = (uint32_t)s->n_reads; F.paired = paired ? 1u : 0u;
 		F.alts = A.alts; F.gws_base = nullptr; F.gws_stride = 0; F.sc_base = nullptr;
 		F.dbg_read = A.dbg_read; F.dbg_buf = A.dbg_buf;
+		F.tail = paired && s->tune.tail > 0 ? (uint32_t)s->tune.tail : 0u;      // (single-end batches: the machine's pass would become the longer of the two, §1)
 		if(!linear) {   // per-lane scratch of the graph primitives (every CU may hold a workgroup)
 			const size_t lanes = (size_t)256 * fgeo[0];
 			const size_t gws_bytes = lanes * fgeo[4], sc_bytes = lanes * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t));
@@ -1780,9 +1820,10 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		FastArgs* const hF = reinterpret_cast<FastArgs*>(s->h_fast_args) + gsel;
 		*hF = F;
 		HIPCHK(hipMemcpyAsync(s->d_fast_args[gsel], hF, sizeof F, hipMemcpyHostToDevice, s->st));
-		if((linear ? h2g_go_fast_launch : h2g_go_fast_graph_launch)(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
+		if((!linear ? h2g_go_fast_graph_launch : use_am ? h2g_go_fast_am_launch : h2g_go_fast_launch)(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
 		A.list = bl; A.nlist = bl + s->max_reads;
 		fast_mgrid = mgrid;
+		s->fgrid_of[gsel] = fgrid; s->mgrid_of[gsel] = mgrid;
 	}
 	HIPCHK(hipEventRecord(s->ev[10], s->st));
 	// behind a fast pass the machine works on the second stream (a short list on few workgroups: the next run's fast pass does not wait for it)
@@ -1801,6 +1842,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	uint32_t* const ovl = s->d_ovf_list[psel];
 	HIPCHK(hipMemsetAsync(ovl + s->max_reads, 0, 16, ms));
 	HIPCHK(hipEventRecord(s->ev[7], ms));
+	if(fast) HIPCHK(hipEventRecord(s->ev_m0[gsel], ms));
 	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], ms));
 	if(second) {
@@ -1948,7 +1990,7 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 }
 
 // development hook: measurement / debugging knobs of go_run by name.  Everything in flight is waited for first, so a change never meets a
-// queued run.  "fast" 0/1, "blocks_per_cu", "pair_slots", "no_second_pass", "mach_div", "mach_min", "dbg_read" (-1 = off)
+// queued run.  "fast" 0/1, "blocks_per_cu", "pair_slots", "no_second_pass", "mach_div", "mach_min", "dbg_read" (-1 = off), "tail", "align_mate"
 extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream* s, const char* key, long v) {
 	if(!s || !key) return H2G_ERR_ARG;
 	HIPCHK(sync_all(s));
@@ -1956,7 +1998,7 @@ extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream
 	const std::string k(key);
 	if(k == "fast") s->tune.fast = (int)v; else if(k == "blocks_per_cu") s->tune.blocks_per_cu = (int)v; else if(k == "pair_slots") s->tune.pair_slots = (int)v;
 	else if(k == "no_second_pass") s->tune.no_second_pass = (int)v; else if(k == "mach_div") s->tune.mach_div = (unsigned)v; else if(k == "mach_min") s->tune.mach_min = (unsigned)v;
-	else if(k == "dbg_read") s->tune.dbg_read = v; else return H2G_ERR_ARG;
+	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") s->tune.tail = (int)v; else if(k == "align_mate") s->tune.align_mate = (int)v; else return H2G_ERR_ARG;
 	return H2G_OK;
 }
 

@@ -33,6 +33,59 @@ def make_genome(contig_lens, seed, n_gaps=0, gap_len=500, repeats=0, repeat_len=
     return contigs
 
 
+def make_repeat_genome(contig_lens, seed, alu_frac=0.10, line_frac=0.15, n_tandem_per_mbp=0.8, n_segdup_per_100mbp=12):
+    """A genome with HUMAN-LIKE repeat structure (what a uniform-random genome lacks: VERDICT r3 item 5), codes 0..3 per contig:
+    * interspersed families — 6 short (~300 bp, Alu-like: many copies) and 6 long (1-6 kbp consensus, LINE-like: copies 5'-truncated to a
+      random suffix) — every copy mutated from its family's consensus at a per-copy divergence drawn from U(8 %, 20 %), random strand,
+      pasted at a random position; `alu_frac` / `line_frac` of the bases end up in them (human: ~10 % / ~17 %);
+    * tandem arrays: a 5-170 bp unit repeated 20-400 times, 2-6 % divergence between units;
+    * segmental duplications: 10-100 kbp segments copied elsewhere (also to other contigs) at 1-3 % divergence.
+    A pure function of the seed."""
+    rng = np.random.default_rng(seed)
+    contigs = [rng.integers(0, 4, size=L, dtype=np.uint8) for L in contig_lens]
+    total = sum(contig_lens)
+    cum = np.cumsum([0] + list(contig_lens))
+
+    def mutate(seq, div):
+        out = seq.copy()
+        m = rng.random(len(out)) < div
+        out[m] = (out[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+        return out
+
+    def paste(seq):
+        ci = int(np.searchsorted(cum, rng.integers(0, total), side="right") - 1)
+        g = contigs[ci]
+        if len(seq) + 2 >= len(g):
+            return
+        at = int(rng.integers(0, len(g) - len(seq)))
+        g[at:at + len(seq)] = seq if rng.random() < 0.5 else (3 - seq[::-1])
+
+    short = [rng.integers(0, 4, size=int(rng.integers(280, 320)), dtype=np.uint8) for _ in range(6)]
+    long_ = [rng.integers(0, 4, size=int(rng.integers(1000, 6000)), dtype=np.uint8) for _ in range(6)]
+    placed = 0
+    while placed < alu_frac * total:
+        c = short[int(rng.integers(0, len(short)))]
+        paste(mutate(c, rng.uniform(0.08, 0.20))); placed += len(c)
+    placed = 0
+    while placed < line_frac * total:
+        c = long_[int(rng.integers(0, len(long_)))]
+        keep = int(rng.integers(300, len(c) + 1))                 # 5'-truncated: a suffix of the consensus
+        paste(mutate(c[len(c) - keep:], rng.uniform(0.08, 0.20))); placed += keep
+    for _ in range(int(n_tandem_per_mbp * total / 1e6)):
+        unit = rng.integers(0, 4, size=int(rng.integers(5, 171)), dtype=np.uint8)
+        n = int(rng.integers(20, 401))
+        paste(np.concatenate([mutate(unit, rng.uniform(0.02, 0.06)) for _ in range(n)])[:40000])
+    for _ in range(max(1, int(n_segdup_per_100mbp * total / 1e8))):
+        ci = int(np.searchsorted(cum, rng.integers(0, total), side="right") - 1)
+        g = contigs[ci]
+        L = int(min(rng.integers(10_000, 100_001), len(g) // 4))
+        if L < 1000:
+            continue
+        a = int(rng.integers(0, len(g) - L))
+        paste(mutate(g[a:a + L], rng.uniform(0.01, 0.03)))
+    return contigs
+
+
 def make_snps(contigs, seed, every=250, names=None):
     """Seeded variant set for a graph index (hisat2-build --snp): list of
     (id, type, chrom, pos, data) with type in single|deletion|insertion, >= 12 bp apart, away from Ns."""

@@ -526,6 +526,22 @@ uint64_t h2gemu_glf_fused_check(Emu* e, uint32_t n, uint64_t seed) {
 	return bad;
 }
 
+// load_local_pack (straight from the files, threaded) against pack_local(load_host_index(..)): 0 = byte-identical
+int h2gemu_local_pack_check(Emu* e, const char* base) {
+	LocalPack a;
+	const int rc = load_local_pack(base, e->host.g.nPat, a, 3);
+	if(e->host.local.empty()) return rc == -1 ? 0 : 100;          // an index without local files
+	if(rc != 0) return 1;
+	const LocalPack& b = e->lp;
+	if(a.desc.size() != b.desc.size() || memcmp(a.desc.data(), b.desc.data(), a.desc.size() * sizeof(DLocalDesc)) != 0) return 2;
+	if(a.sides != b.sides) return 3;
+	if(a.words != b.words) return 4;
+	if(a.first != b.first) return 5;
+	if(a.zoffs != b.zoffs) return 6;
+	if(a.ftabChars != b.ftabChars || a.offRate != b.offRate) return 7;
+	return 0;
+}
+
 #ifdef H2G_MEMPROF
 void mp_report(unsigned nreads, const char** opnames, int nops);
 void h2gemu_memprof_report(unsigned nreads) {

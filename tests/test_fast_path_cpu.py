@@ -185,3 +185,14 @@ def test_fused_graph_lf_and_single_row_walk(graph_genome):
     e.L.h2gemu_glf_fused_check.restype = C.c_uint64
     e.L.h2gemu_glf_fused_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     assert e.L.h2gemu_glf_fused_check(e.h, 100000, 11) == 0
+
+
+def test_local_indexes_packed_straight_from_the_files(genome, graph_genome):
+    """load_local_pack (h2g_local_pack.h: one walk over the local headers, then threaded copies of the sides and the 16-bit words — what
+    h2g_index_load uses) == pack_local over the per-index host objects, byte for byte, on a linear and on a graph index"""
+    import ctypes as C
+    from h2gemu_py import Emu
+    for base in (genome[0], graph_genome[0]):
+        e = Emu(base)
+        e.L.h2gemu_local_pack_check.argtypes = [C.c_void_p, C.c_char_p]
+        assert e.L.h2gemu_local_pack_check(e.h, base.encode()) == 0

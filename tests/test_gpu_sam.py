@@ -97,9 +97,6 @@ def test_command_line_skip_upto_trim_no_unal():
 
 
 def test_command_line_refuses_what_is_not_built(tmp_path):
-    # temporary splice sites at -p 1 mean one read after the other: refused before anything is loaded
-    r = subprocess.run([CLI, "-x", "nonexistent", "-U", "x.fq"], capture_output=True, text=True)
-    assert r.returncode != 0 and "--no-temp-splicesite" in r.stderr
     r = subprocess.run([CLI, "-x", "nonexistent", "-U", "x.fq", "--no-spliced-alignment", "--un", "y.fq"], capture_output=True, text=True)
     assert r.returncode != 0 and "is not built" in r.stderr
 

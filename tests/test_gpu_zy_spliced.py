@@ -146,3 +146,20 @@ def test_temporary_splice_sites_pairs_command_line(tmp_path):
     subprocess.run([CLI, "-f", "-p", "3", "-x", base, "-1", f1, "-2", f2, "-S", os.path.join(t, "amd.sam")], check=True, stderr=open(os.path.join(t, "amd.err"), "w"))
     assert diff_lines(SL.body_lines(os.path.join(t, "amd.sam")), SL.body_lines(os.path.join(t, "ref.sam"))) == 0
     assert open(os.path.join(t, "amd.err")).read() == open(os.path.join(t, "ref.err")).read()
+
+
+def test_bare_default_invocation_equals_the_reference(tmp_path):
+    """`hisat2 -f -x idx -U reads` with no other option: the reference's defaults are -p 1 and temporary splice sites, i.e. window 0 — every
+    read sees the junctions of all reads before it (hisat2.cpp:3687).  The command line runs that as waves of one read; the SAM equals the
+    committed output of `hisat2-align-s -f -p 1` (tests/golden/ref_se_spliced.sam.gz) byte for byte."""
+    import gzip
+    gold = os.path.join(ROOT, "tests", "golden")
+    t = str(tmp_path)
+    for k in range(1, 9):
+        open(os.path.join(t, f"g1.{k}.ht2"), "wb").write(gzip.open(os.path.join(gold, f"g1.{k}.ht2.gz")).read())
+    rfa = os.path.join(t, "r.fa")
+    open(rfa, "wb").write(gzip.open(os.path.join(gold, "reads_se.fa.gz")).read())
+    subprocess.run([CLI, "-f", "-x", os.path.join(t, "g1"), "-U", rfa, "-S", os.path.join(t, "amd.sam")], check=True, stderr=open(os.path.join(t, "amd.err"), "w"), timeout=600)
+    got = [l for l in open(os.path.join(t, "amd.sam")).read().splitlines() if not l.startswith("@")]
+    want = [l for l in gzip.open(os.path.join(gold, "ref_se_spliced.sam.gz"), "rt").read().splitlines() if not l.startswith("@")]
+    assert len(want) > 100 and got == want

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""command-line throughput on a multi-batch input: cli_perf.py npairs [exe ...]  (E. coli-size cached index, --no-spliced-alignment)"""
+"""command-line throughput on a multi-batch input: cli_perf.py npairs [exe ...]  (E. coli-size cached index, --no-spliced-alignment;
+H2G_CLI_GENOME=<bases> takes the staged / built GRCh38-profile index of that size instead)"""
 import os, sys, time, subprocess, tempfile, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -8,7 +9,12 @@ import bench
 from hisat2_amd import synth
 n = int(sys.argv[1])
 exes = sys.argv[2:] or [os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")]
-base, contigs = bench.build_index(os.path.join(ROOT, ".bench_cache"), 4_900_000)
+if os.environ.get("H2G_CLI_GENOME"):
+    import build_bench_index as BB
+    base, total, how = bench.headline_index(os.path.join(ROOT, ".bench_cache"), int(float(os.environ["H2G_CLI_GENOME"])))
+    contigs = BB.genome(total)
+else:
+    base, contigs = bench.build_index(os.path.join(ROOT, ".bench_cache"), 4_900_000)
 t0 = time.time()
 m1, m2 = synth.make_pairs(contigs, n, 101, bench.SEED + 7, sub_rate=0.005)
 tmp = tempfile.mkdtemp(prefix="h2cli")

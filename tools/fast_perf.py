@@ -30,7 +30,7 @@ if glen < 10_000_000:
 else:
     import build_bench_index as BB
     base, total, how = bench.headline_index(os.path.join(ROOT, ".bench_cache"), glen)
-    contigs = BB.genome(total)
+    contigs = (lambda: BB.genome(total))        # generated only when the reads are not cached
 if mode == "gpe":
     import subprocess
     gtmp = os.path.join(ROOT, ".bench_cache", f"rnd{glen}_s{bench.SEED}_snp")
@@ -45,13 +45,20 @@ if mode == "gpe":
 print("index ready in %.1f s" % (time.time() - t0), flush=True)
 ix = api.Index(base)
 if mode == "se":
+    if callable(contigs): contigs = contigs()
     reads, _ = synth.make_reads(contigs, n, 101, bench.SEED + 1000, sub_rate=0.005)
     codes, offs = synth.flatten_reads(reads)
     st = api.Stream(ix, max_reads=n, max_bases=codes.size)
     st.set_reads(codes, offs); st.set_read_names([str(i) for i in range(n)])
     run = st.align_run
 else:
-    m1, m2 = synth.make_pairs(contigs, n, 101, bench.SEED + (4343 if mode == "gpe" else 7), frag_mean=300, frag_sd=30, sub_rate=0.005) if mode == "gpe" else synth.make_pairs(contigs, n, 101, bench.SEED + 7, sub_rate=0.005)
+    pc = os.path.join("/tmp", "fast_perf_pairs_%s_%d_%d.npz" % (mode, n, glen))       # (several variant libraries are timed on the same reads: one process each)
+    if os.path.exists(pc):
+        d_ = np.load(pc); m1, m2 = d_["m1"], d_["m2"]
+    else:
+        if callable(contigs): contigs = contigs()
+        m1, m2 = synth.make_pairs(contigs, n, 101, bench.SEED + (4343 if mode == "gpe" else 7), frag_mean=300, frag_sd=30, sub_rate=0.005) if mode == "gpe" else synth.make_pairs(contigs, n, 101, bench.SEED + 7, sub_rate=0.005)
+        np.savez(pc, m1=np.stack(m1), m2=np.stack(m2))
     c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
     names = [str(i) for i in range(n)]
     st = api.Stream(ix, max_reads=n, max_bases=c1.size)
