@@ -443,12 +443,14 @@ def extras(a, api, synth, ix_big, local, cache):
         gix = api.Index(gbase, device=local)
         gst = api.Stream(gix, max_reads=gnp, max_bases=gc1.size)
         gst.set_reads(gc1, go1); gst.set_read_names(gq); gst.set_mates(gc2, go2, gq)
-        gst.align_pairs_run(); gst.sync()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(3):                                  # (the two machine streams' workspaces are allocated by the first two runs)
             gst.align_pairs_run()
         gst.sync()
-        gdt = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gst.align_pairs_run()
+        gst.sync()
+        gdt = (time.perf_counter() - t0) / 5
         gc_ = gst.counters()
         ex["graph_index_pe"] = {"workload": "configs[3] shape at E. coli size: SNP-graph index (a variant every ~250 bp), 500 k pairs from the alternate haplotype",
                                 "pairs": gnp, "variants": len(var), "ms_per_step": gdt * 1e3, "reads_per_s": 2 * gnp / gdt, "kernel_ms": float(gc_.ms_align_kernel),
@@ -517,14 +519,18 @@ def timed_pairs(api, synth, base, local, m1, m2, steps=5):
     ix = api.Index(base, device=local)
     st = api.Stream(ix, max_reads=n, max_bases=c1.size)
     st.set_reads(c1, o1); st.set_read_names(names); st.set_mates(c2, o2, names)
-    st.align_pairs_run(); st.align_pairs_run(); st.sync()
+    st.align_pairs_run(); st.align_pairs_run(); st.align_pairs_run(); st.sync()      # (the two machine streams' workspaces are allocated by the first two runs)
     t0 = time.perf_counter()
     for _ in range(steps):
         st.align_pairs_run()
     st.sync()
     dt = (time.perf_counter() - t0) / steps
+    # the counters of ONE run on its own: in a queue of runs the machine pass of run k - 1 may finish a deferred read that run k also deferred, and
+    # run k's count of aligned pairs then misses it (the result itself is the same either way; the headline's workload has no second pass)
+    st.align_pairs_run(); st.sync()
     c = st.counters()
     leg = {"pairs": n, "ms_per_step": dt * 1e3, "reads_per_s": 2 * n / dt, "fast_kernel_ms": float(c.ms_fast_kernel), "machine_pass_ms": float(c.ms_align_kernel),
+           "kernel_times_are": "of one run on its own (the step time above is the steady state of queued runs)",
            "pairs_completed_by_the_fast_pass": int(c.n_fast), "pairs_handed_on": int(c.n_fast_bail), "hand_on_rate": int(c.n_fast_bail) / n,
            "hand_ons_by_reason": fast_bail_reasons(api, st), "pairs_second_pass": int(c.n_second_pass), "second_pass_rate": int(c.n_second_pass) / n,
            "pairs_still_flagged_overflow": int(c.n_overflow), "pairs_with_concordant": int(c.n_aligned),

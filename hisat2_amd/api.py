@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_TAIL, DEFAULT_ALIGN_MATE = 0, 0     # H2G_DEFAULT_TAIL / H2G_DEFAULT_ALIGN_MATE of csrc/h2g_kernels.hip (what a stream does without H2G_FAST_TAIL / H2G_FAST_AM)
+DEFAULT_TAIL, DEFAULT_ALIGN_MATE = 16, 0     # H2G_DEFAULT_TAIL / H2G_DEFAULT_ALIGN_MATE of csrc/h2g_kernels.hip (what a stream does without H2G_FAST_TAIL / H2G_FAST_AM)
 LIB_PATH = os.environ.get("H2G_LIBPATH") or os.path.join(_HERE, "libh2g.so")   # H2G_LIBPATH: development builds (tools/)
 MAX = 0xFFFFFFFF
 MAX_EDITS = 32

@@ -44,6 +44,7 @@ struct h2g_index {
 	DLocalSet dls;
 	DAlts dalts;
 	bool has_local = false;
+	uint32_t n_local = 0;                                  // local indexes loaded (their per-index host objects are not kept: load_local_pack)
 	bool has_splice_alts = false;                         // the ALT list holds splice sites / exons (a _tran index)
 	std::vector<h2g_splice_site> alt_sites;               // splice-site ALTs of a --ss index: part of every database (SpliceSiteDB::read(gfm, alts))
 	DSpliceDB dssdb;                                       // h2g_index_set_splice_sites (device arrays; freed and replaced on every call)
@@ -59,12 +60,10 @@ struct h2g_index {
 #define H2G_NBUF 3
 // the fast pass's two scheduling choices for PAIRED batches on a linear index (measured at GRCh38 size: profiles/r04_NOTES.md §4): reads a
 // workgroup hands on at the tail of an exhausted batch, and whether alignMate runs inside the pass (k_go_fast_am) or in the machine's pass
-#define H2G_DEFAULT_TAIL 0
+#define H2G_DEFAULT_TAIL 16
 #define H2G_DEFAULT_ALIGN_MATE 0
 #define H2G_CNT_BLOCK 512u          // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
-#define H2G_MACH_MAXGRID 100u      // workgroups of a machine pass behind a fast pass (two such passes may be in flight): its workspace pools are sized for this
-#define H2G_MACH_LATGRID 48u       // ... while its hand-ons are few (a latency chain: more workgroups buy nothing)
-#define H2G_MACH_WORK_BAILS 8000u  // hand-ons from which the machine pass is throughput-bound and its share of the CUs follows the measured work
+#define H2G_MACH_MAXGRID 48u       // workgroups of a machine pass behind a fast pass (two such passes may be in flight)
 struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
@@ -73,8 +72,6 @@ struct h2g_stream {
 	hipStream_t mst[2] = {nullptr, nullptr};
 	bool st2_busy = false;            // a machine stream may hold work
 	hipEvent_t ev_fast[H2G_NBUF], ev_mach[H2G_NBUF];
-	hipEvent_t ev_f0[H2G_NBUF], ev_m0[H2G_NBUF];     // start of that generation's fast / machine pass (their durations x workgroups = the work that balances the CUs)
-	unsigned fgrid_of[H2G_NBUF] = {}, mgrid_of[H2G_NBUF] = {};
 	unsigned gen = 0;                 // go_run generation: bail list, counters and argument block are buffered H2G_NBUF deep by gen % H2G_NBUF
 	unsigned long long* cnt_cur = nullptr;   // the counter block of the last go_run
 	uint32_t last_bails = 0;
@@ -223,6 +220,8 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		   (s = upload(ix, lp.first, &df)) || (s = upload(ix, lp.zoffs, &dz))) { h2g_index_free(ix); return s; }
 		ix->dls = lp.view(dd, ds, dw, df, dz);
 		ix->h_ldesc = lp.desc;
+		ix->host.local_first = lp.first;                     // (h2g_local_index_of)
+		ix->n_local = (uint32_t)lp.desc.size();
 		ix->has_local = true;
 		for(const HostAlt& a : ix->host.alts) if(a.type >= 5) ix->has_splice_alts = true;   // ALT_SPLICESITE / ALT_EXON alt.h:38-39
 	}
@@ -243,7 +242,7 @@ extern "C" h2g_status h2g_index_get_info(const h2g_index* ix, h2g_index_info* o)
 	o->ftabChars = p.ftabChars; o->eftabLen = p.eftabLen; o->linear = p.linear; o->sideSz = p.sideSz;
 	o->sideGbwtSz = p.sideGbwtSz; o->sideGbwtLen = p.sideGbwtLen; o->numSides = p.numSides; o->offsLen = p.offsLen;
 	o->ftabLen = p.ftabLen; o->nPat = ix->host.g.nPat; o->nFrag = ix->host.g.nFrag; o->nZ = (uint32_t)ix->host.g.zOffs.size();
-	o->minK = ix->host.minK; o->nLocal = (uint32_t)ix->host.local.size(); o->nRefRecs = (uint32_t)ix->host.r.rec_len.size();
+	o->minK = ix->host.minK; o->nLocal = ix->n_local; o->nRefRecs = (uint32_t)ix->host.r.rec_len.size();
 	o->device_bytes = ix->device_bytes;
 	return H2G_OK;
 }
@@ -434,7 +433,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	for(int k = 0; k < 2; k++) HIPCHK(hipStreamCreateWithFlags(&s->mst[k], hipStreamNonBlocking));
 	HIPCHK(hipHostMalloc((void**)&s->h_fast_args, sizeof(FastArgs) * H2G_NBUF));
 	HIPCHK(hipHostMalloc((void**)&s->h_bails, 4 * H2G_NBUF)); for(int k = 0; k < H2G_NBUF; k++) s->h_bails[k] = 0;
-	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreate(&s->ev_fast[k])); HIPCHK(hipEventCreate(&s->ev_mach[k])); HIPCHK(hipEventCreate(&s->ev_f0[k])); HIPCHK(hipEventCreate(&s->ev_m0[k])); }
+	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
 	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
 	HIPCHK(hipMalloc((void**)&s->d_counters, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(s->d_counters, 0, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
@@ -462,7 +461,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipStreamSynchronize(s->st); for(int k = 0; k < 2; k++) (void)hipStreamSynchronize(s->mst[k]);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 4; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); (void)hipEventDestroy(s->ev_f0[k]); (void)hipEventDestroy(s->ev_m0[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
@@ -1734,7 +1733,6 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	const bool second = !big_main && !no_second;
 	A.defer_overflow = second ? 1u : 0u;
 	HIPCHK(hipEventRecord(s->ev[5], s->st));
-	HIPCHK(hipEventRecord(s->ev_f0[gsel], s->st));
 	// ---- the fast pass (h2g_fast.h): the dominant traces with the per-read state on chip.  What it completes is final; the reads
 	// it hands on (a device-side list, no host sync) are the general machine's batch.  Built for unspliced alignment on a linear
 	// index with the default pair policy; every other option set goes to the machine whole.
@@ -1754,25 +1752,10 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		const unsigned mach_div = s->tune.mach_div, mach_min = s->tune.mach_min;   // (hand-ons per machine workgroup: latency chains, two passes in flight)
 		unsigned mgrid = (unsigned)((s->last_bails + mach_div - 1) / (mach_div ? mach_div : 1u));
 		if(mgrid < mach_min) mgrid = mach_min;
-		if(mgrid > H2G_MACH_LATGRID) mgrid = H2G_MACH_LATGRID;
-		// Many hand-ons (repeat-rich sequence: 3-4 % of the pairs): the machine pass is no latency chain any more but WORK, and the step time is
-		// what the slower of the two kernels needs on its share of the CUs.  Two machine passes are in flight next to one fast pass, so the shares
-		// balance at  M / m = 2 F / (256 - 2 m)  <=>  m = 128 M / (F + M),  with F, M the workgroup-milliseconds of the latest finished generation.
-		if(s->last_bails > H2G_MACH_WORK_BAILS) {
-			for(unsigned back = 1; back < H2G_NBUF && back <= s->gen; back++) {
-				const unsigned b = (s->gen - back) % H2G_NBUF;
-				float tf = 0, tm = 0;
-				if(s->fgrid_of[b] && s->mgrid_of[b] && hipEventQuery(s->ev_mach[b]) == hipSuccess && hipEventElapsedTime(&tf, s->ev_f0[b], s->ev_fast[b]) == hipSuccess &&
-				   hipEventElapsedTime(&tm, s->ev_m0[b], s->ev_mach[b]) == hipSuccess && tf > 0 && tm > 0) {
-					const double F = (double)tf * s->fgrid_of[b], M = (double)tm * s->mgrid_of[b];
-					const unsigned m = (unsigned)(128.0 * M / (F + M) + 0.5);
-					if(m > mgrid) mgrid = m;
-					break;
-				}
-			}
-			(void)hipGetLastError();
-			if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
-		}
+		if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
+		// (Tried on repeat-rich sequence, 27 000 hand-ons: a share that follows the measured work of the two passes, m = 128 M / (F + M) — the machine's
+		// pass stayed a latency chain, 78 -> 66 ms on twice the workgroups, while the fast pass went 14.5 -> 49 ms on what was left; and the second pass
+		// on a stream of its own — the extra queues cost the common case 13 -> 20 ms per run.  Neither ships: profiles/r04_NOTES.md §6.)
 		size_t fwant = (s->n_reads + 127) / 128;                                                // small batches spread over the chip
 		const unsigned fmax = 256 - 2 * mgrid;                                                  // (two machine passes may be in flight)
 		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > fmax ? fmax : fwant));
@@ -1823,7 +1806,6 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if((!linear ? h2g_go_fast_graph_launch : use_am ? h2g_go_fast_am_launch : h2g_go_fast_launch)(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
 		A.list = bl; A.nlist = bl + s->max_reads;
 		fast_mgrid = mgrid;
-		s->fgrid_of[gsel] = fgrid; s->mgrid_of[gsel] = mgrid;
 	}
 	HIPCHK(hipEventRecord(s->ev[10], s->st));
 	// behind a fast pass the machine works on the second stream (a short list on few workgroups: the next run's fast pass does not wait for it)
@@ -1842,7 +1824,6 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	uint32_t* const ovl = s->d_ovf_list[psel];
 	HIPCHK(hipMemsetAsync(ovl + s->max_reads, 0, 16, ms));
 	HIPCHK(hipEventRecord(s->ev[7], ms));
-	if(fast) HIPCHK(hipEventRecord(s->ev_m0[gsel], ms));
 	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], ms));
 	if(second) {

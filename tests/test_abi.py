@@ -70,3 +70,13 @@ def test_no_cpu_fallback(g1_index):
     assert "-3" in str(e.value)   # H2G_ERR_DEVICE
     with pytest.raises(api.H2GError):
         api.Index(synth_sides=1024)
+
+
+def test_stream_defaults_are_what_the_python_mirror_says():
+    """H2G_DEFAULT_TAIL / H2G_DEFAULT_ALIGN_MATE of csrc/h2g_kernels.hip (what go_run does without H2G_FAST_TAIL / H2G_FAST_AM) == api.DEFAULT_*,
+    which bench.py names in its line"""
+    import re
+    from hisat2_amd import api
+    src = open(os.path.join(ROOT, "hisat2_amd", "csrc", "h2g_kernels.hip")).read()
+    assert int(re.search(r"#define H2G_DEFAULT_TAIL (\d+)", src).group(1)) == api.DEFAULT_TAIL
+    assert int(re.search(r"#define H2G_DEFAULT_ALIGN_MATE (\d+)", src).group(1)) == api.DEFAULT_ALIGN_MATE

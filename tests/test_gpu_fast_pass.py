@@ -24,10 +24,16 @@ BUILD = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
     dict(seed=72, npairs=60000, nreads=60000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25),   # hard reads: half are handed on
     dict(seed=73, npairs=100000, nreads=100000, rdlen=101, sub=0.005, snps=250),                            # SNP-graph index (h2g_k_go_fast_graph.hip), reads from the alternate haplotype
     dict(seed=74, npairs=40000, nreads=40000, rdlen=90, sub=0.02, indel=0.002, snps=120, least=0.25),        # ... dense variants, harder reads
+    dict(seed=75, npairs=120000, nreads=60000, rdlen=101, sub=0.005, repeat_genome=True),                    # human-like repeat structure: the cold genome hits / pool entries
+    dict(seed=76, npairs=100000, nreads=20000, rdlen=101, sub=0.01, repeat_genome=True, env={"H2G_FAST_AM": "1", "H2G_FAST_TAIL": "16"}),   # k_go_fast_am + tail hand-off
+    dict(seed=72, npairs=60000, nreads=20000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_AM": "1"}),         # alignMate in the pass on hard reads
 ])
 def test_fast_pass_equals_the_machine(case):
     tmp = tempfile.mkdtemp(prefix="h2fp")
-    contigs = synth.make_genome([1500000, 400000, 100000], case["seed"], n_gaps=3, gap_len=300, repeats=80, repeat_len=600)
+    if case.get("repeat_genome"):
+        contigs = synth.make_repeat_genome([5000000, 2000000, 1000000], case["seed"])
+    else:
+        contigs = synth.make_genome([1500000, 400000, 100000], case["seed"], n_gaps=3, gap_len=300, repeats=80, repeat_len=600)
     fa = os.path.join(tmp, "g.fa")
     synth.write_fasta(fa, contigs)
     base = os.path.join(tmp, "g")
@@ -44,7 +50,7 @@ def test_fast_pass_equals_the_machine(case):
     np.savez(npz, m1=np.stack(m1), m2=np.stack(m2), reads=np.asarray(reads))
     got = {}
     for fast in ("0", "1"):
-        env = dict(os.environ, H2G_GO_FAST=fast, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+        env = dict(os.environ, H2G_GO_FAST=fast, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"), **(case.get("env", {}) if fast == "1" else {}))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fast_digest.py"), base, npz], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         got[fast] = json.loads(r.stdout.strip().splitlines()[-1])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """go() timing with the fast pass on / off (env H2G_GO_FAST, read once per process) + a checksum of every result, so that the two
-settings can be compared for identical output.  usage: fast_perf.py se|pe|gpe [n] [genome bases]   (gpe: pairs from the alternate haplotype
+settings can be compared for identical output.  usage: fast_perf.py se|pe|gpe|rpe [n] [genome bases]   (gpe: pairs from the alternate haplotype
 on the SNP-graph index of bench.py's graph leg, a variant every ~250 bp)"""
 import os, sys, zlib, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,12 +25,25 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "pe"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 glen = int(float(sys.argv[3])) if len(sys.argv) > 3 else 4_900_000
 t0 = time.time()
-if glen < 10_000_000:
+if mode == "rpe":
+    base, contigs = None, None
+elif glen < 10_000_000:
     base, contigs = bench.build_index(os.path.join(ROOT, ".bench_cache"), glen)
 else:
     import build_bench_index as BB
     base, total, how = bench.headline_index(os.path.join(ROOT, ".bench_cache"), glen)
     contigs = (lambda: BB.genome(total))        # generated only when the reads are not cached
+if mode == "rpe":     # pairs on a repeat-structured genome (synth.make_repeat_genome), linear index built here
+    import subprocess, tempfile
+    import build_bench_index as BB
+    glen = max(glen, 20_000_000)
+    contigs = synth.make_repeat_genome(BB.contig_lens(glen), bench.SEED + 77)
+    rdir = os.path.join("/tmp", "fast_perf_rep%d" % glen)
+    base = os.path.join(rdir, "g")
+    if not os.path.exists(base + ".8.ht2"):
+        os.makedirs(rdir, exist_ok=True)
+        synth.write_fasta(base + ".fa", contigs)
+        subprocess.run([os.path.join(bench.REF, "hisat2-build-s"), "-q", "-p", "16", base + ".fa", base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 if mode == "gpe":
     import subprocess
     gtmp = os.path.join(ROOT, ".bench_cache", f"rnd{glen}_s{bench.SEED}_snp")
