@@ -114,13 +114,42 @@ def body(path):
 KERNEL_SOURCES = ("h2g_k_go_fast.hip", "h2g_k_go_fast_am.hip", "h2g_fast.h", "h2g_core.h", "h2g_align.h", "h2g_graph.h", "h2g_go_args.h", "Makefile")
 
 
+def _strip_comments(src):
+    """C / C++ / make source without comments, blank lines and leading / trailing blanks: what the compiler sees of it"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c in "\"'":                                           # string / character literal: copied as it is
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1]); i = j + 1
+        elif src.startswith("//", i):
+            while i < n and src[i] != "\n":
+                i += 1
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    lines = [l.strip() for l in "".join(out).splitlines()]
+    return "\n".join(l for l in lines if l)
+
+
 def kernel_sources_sha16():
-    """what the dominant kernel is compiled from (hisat2_amd/csrc: the fast pass's sources, the headers they include, the build flags).  A PMC
-    record is only attached to the line when it was taken on exactly these bytes; otherwise `traffic` is null (a stale figure is no figure)."""
+    """what the dominant kernel is compiled from (hisat2_amd/csrc: the fast pass's sources, the headers they include, the build flags), comments and
+    blank space apart.  A PMC record is only attached to the line when it was taken on exactly this code; otherwise `traffic` is null (a stale
+    figure is no figure)."""
     import hashlib
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        h.update(f.encode()); h.update(open(os.path.join(ROOT, "hisat2_amd", "csrc", f), "rb").read())
+        txt = open(os.path.join(ROOT, "hisat2_amd", "csrc", f), "r", errors="replace").read()
+        if f == "Makefile":
+            txt = "\n".join(l.split("#")[0].rstrip() for l in txt.splitlines() if l.split("#")[0].strip())
+        else:
+            txt = _strip_comments(txt)
+        h.update(f.encode()); h.update(txt.encode())
     return h.hexdigest()[:16]
 
 

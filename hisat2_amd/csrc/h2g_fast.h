@@ -1,19 +1,20 @@
-// h2g_fast.h — HI_Aligner::go for the DOMINANT traces with the per-read state on chip.
+// h2g_fast.h — HI_Aligner::go for the DOMINANT traces with a compact per-read state.
 //
-// The general machine (h2g_machine.h) keeps a read's state in a ~115 KB workspace in HBM and pays for it: 47 KB of HBM
-// traffic per read, control bound by scattered workspace lines.  On the benchmark's reads 85 % of the pairs only ever walk
-//   partialSearch* -> getGenomeCoords -> extend -> [localGFMSearch -> getGenomeCoords_local -> extend -> combineWith] -> report
-// with one or two genome hits, at most two reported alignments per mate and a recursion of depth <= 3.  This file restates
-// exactly that part of go() (same reference lines as h2g_machine.h, cited per state) over a state of ~60 registers and
-// ~75 words of LDS per pair (+ 50 rarely touched words in private memory), and gives up ("bail") the moment a read leaves
-// it: anything it cannot hold, anything rare (random sub-sampling of repeats, mate rescue, global re-search, soft-clip and
-// list overflows, hash matches in the searched / redundant tests).  A bailed read is re-run FROM SCRATCH by the general
-// machine, so the only obligation of this file is: a read it completes has exactly the machine's results.  tests/ hold it to
-// that on the host (the same source, one lane at a time) over every read of the fuzz sets; on the device the kernel of
-// h2g_k_go_fast.hip runs one pair per lane, primitives by wave-level majority vote.
+// The general machine (h2g_machine.h) keeps a read's state in a ~115 KB workspace in HBM and pays for it: 47 KB of HBM traffic per read,
+// control bound by scattered workspace lines.  On the benchmark's reads 99.5 % of the pairs only ever walk
+//   partialSearch* -> getGenomeCoords -> extend -> [localGFMSearch -> getGenomeCoords_local -> extend -> combineWith | globalGFMSearch ..] -> report
+// with at most two genome hits, two reported alignments per mate, four edits per hit and a recursion of depth <= 5.  This file restates exactly that
+// part of go() (same reference lines as h2g_machine.h, cited per state) over a state of 40 words of bit-fields (FState: its own stored form), 50 hot
+// words staged in LDS during a trip and the cold words of a ~1 KB slot in HBM, and gives up ("bail") the moment a read leaves it: anything it cannot
+// hold, the random sub-sampling of a repeat's rows, mate rescue (restated too, behind FG_ALIGN_MATE: h2g_k_go_fast_am.hip), an insertion or deletion
+// that survives combineWith's gap budget.  A bailed read is re-run FROM SCRATCH by the general machine, so the only obligation of this file is: a read
+// it completes has exactly the machine's results (PairOut / ReadOut incl. the PRNG state and the work counters, every record).  tests/ hold it to
+// that on the host (the same source, one lane at a time, every read through both) and on the device (pass on == pass off, queued-run stress).  The
+// kernel (h2g_k_go_fast.hip) is the slot-queue scheme: a workgroup owns 1024 slots and one queue of slot ids per primitive; a wave pops <= 64 slots
+// of the longest queue, loads them in one go, runs THAT primitive at one code site, lets each lane run its control flow to the next request.
 //
-// Built for: linear index, --no-spliced-alignment, no --secondary, --bowtie2-dp 0, default pair policy (--fr, -I 0), reads of
-// 32..128 bases without N.  Everything else never enters (go_run) or bails at the first state.
+// Built for: --no-spliced-alignment, no --secondary, --bowtie2-dp 0, default pair policy (--fr, -I 0), reads of 32..128 bases without N.
+// Everything else never enters (go_run) or bails at the first state.
 //
 // FG_GRAPH = 1 (round 4) is the same state machine over a GRAPH index (SNP / indel ALTs): a partial hit carries its node range and in-edge
 // list, a coordinate is re-seated by adjustWithALT before it becomes a hit, and a hit's edits carry ALT ids.  The graph primitives are the

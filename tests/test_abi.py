@@ -80,3 +80,16 @@ def test_stream_defaults_are_what_the_python_mirror_says():
     src = open(os.path.join(ROOT, "hisat2_amd", "csrc", "h2g_kernels.hip")).read()
     assert int(re.search(r"#define H2G_DEFAULT_TAIL (\d+)", src).group(1)) == api.DEFAULT_TAIL
     assert int(re.search(r"#define H2G_DEFAULT_ALIGN_MATE (\d+)", src).group(1)) == api.DEFAULT_ALIGN_MATE
+
+
+def test_pmc_record_was_taken_on_the_shipped_kernel_sources():
+    """profiles/r04_pmc_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE of the headline kernel at GRCh38 size) carries the hash of the kernel sources
+    it was taken on; bench.py attaches `roofline.traffic` only while that equals the hash of the sources in the tree (comments and blank space
+    apart).  A kernel change after the profile shows up here, not as a stale figure in the bench line."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+    assert rec["kernel_sources_sha16"] == bench.kernel_sources_sha16()
+    assert bench._strip_comments('a = "//x"; // c\n/* d */ b /* e\n f */ c\n\n') == 'a = "//x";\nb   c'
