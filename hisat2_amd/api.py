@@ -500,7 +500,7 @@ class Stream:
         return out, st
 
     def sw_align(self, queries, repeats=1):
-        """SwAligner call site of hybridSearch (frame + u8 end-to-end DP + gather + first backtrace) -> (results, kernel ms)"""
+        """SwAligner call site of hybridSearch (frame + end-to-end DP, 8-bit cells or 16-bit for minsc < -254, + gather + first backtrace) -> (results, kernel ms)"""
         n = len(queries)
         q = (SwQuery * n)(*queries)
         out = (SwResult * n)()

@@ -14,6 +14,10 @@
 #include <algorithm>
 #include <vector>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace h2g {
 
@@ -83,20 +87,35 @@ struct HostIndex {
 	uint32_t minK = 0;
 };
 
+// A file of the index, mapped read-only: what is parsed is read, what is copied out is copied once, what a caller has no use for (the SAM
+// formatter needs names, lengths and ALTs, not a gigabyte of sides) is never touched.
+struct FileView {
+	const uint8_t* p = nullptr; size_t n = 0;
+	size_t size() const { return n; }
+	const uint8_t& operator[](size_t i) const { return p[i]; }
+	const uint8_t* begin() const { return p; }
+	~FileView() { if(p) munmap((void*)p, n); }
+	FileView() {}
+	FileView(const FileView&) = delete;
+	FileView& operator=(const FileView&) = delete;
+};
 class Reader {
 public:
-	std::vector<uint8_t> d;
+	FileView d;
 	size_t pos = 0;
 	bool open(const std::string& fn) {
-		FILE* f = fopen(fn.c_str(), "rb");
-		if(!f) return false;
-		fseek(f, 0, SEEK_END);
-		long n = ftell(f);
-		fseek(f, 0, SEEK_SET);
-		d.resize((size_t)n);
-		bool ok = n == 0 || fread(d.data(), 1, (size_t)n, f) == (size_t)n;
-		fclose(f);
-		return ok;
+		const int fd = ::open(fn.c_str(), O_RDONLY);
+		if(fd < 0) return false;
+		struct stat st;
+		if(fstat(fd, &st) != 0) { ::close(fd); return false; }
+		d.n = (size_t)st.st_size;
+		if(d.n) {
+			void* m = mmap(nullptr, d.n, PROT_READ, MAP_PRIVATE, fd, 0);
+			if(m == MAP_FAILED) { ::close(fd); d.n = 0; return false; }
+			d.p = (const uint8_t*)m;
+		}
+		::close(fd);
+		return true;
 	}
 	bool has(size_t n) const { return pos + n <= d.size(); }
 	uint32_t u32() { uint32_t v = 0; if(has(4)) memcpy(&v, &d[pos], 4); else bad = true; pos += 4; return v; }
@@ -111,33 +130,29 @@ public:
 	bool bad = false;
 };
 
-inline bool read_gfm_body(Reader& b, HostGfm& g) {
+inline bool read_gfm_body(Reader& b, HostGfm& g, bool light = false) {
 	const int wsz = g.p.wsz;
 	g.nPat = b.w(wsz);
 	b.arr(g.plen, wsz, g.nPat);
 	g.nFrag = b.w(wsz);
 	b.arr(g.rstarts, wsz, (size_t)g.nFrag * 3);
 	if(!b.has(g.p.gbwtTotLen)) return false;
-	g.sides.assign(b.d.begin() + b.pos, b.d.begin() + b.pos + g.p.gbwtTotLen);
+	if(!light) g.sides.assign(b.d.begin() + b.pos, b.d.begin() + b.pos + g.p.gbwtTotLen);
 	b.pos += g.p.gbwtTotLen;
 	uint32_t nZ = b.w(wsz);
 	b.arr(g.zOffs, wsz, nZ);
 	for(int i = 0; i < 5; i++) g.fchr[i] = b.w(wsz);
+	if(light) { b.pos += ((size_t)g.p.ftabLen + g.p.eftabLen) * wsz; if(b.pos > b.d.size()) b.bad = true; return !b.bad; }
 	b.arr(g.ftab, wsz, g.p.ftabLen);
 	b.arr(g.eftab, wsz, g.p.eftabLen);
 	return !b.bad;
 }
 
-// returns 0 ok, -1 io, -2 format
-inline int load_host_index(const std::string& base, bool load_local, HostIndex& ix) {
+// returns 0 ok, -1 io, -2 format.  light: names, lengths, fragment table, reference records and ALTs only (no sides, SA sample, ftab or
+// reference bases: the SAM formatter's view of an index)
+inline int load_host_index(const std::string& base, bool load_local, HostIndex& ix, bool light = false) {
 	Reader b1, b2, b3, b4;
-	{   // the three large files are read side by side (a human-size index: 1.0 + 0.8 + 0.8 GB)
-		bool ok1 = false, ok2 = false, ok4 = false;
-		std::thread t2([&]() { ok2 = b2.open(base + ".2.ht2"); }), t4([&]() { ok4 = b4.open(base + ".4.ht2"); });
-		ok1 = b1.open(base + ".1.ht2");
-		t2.join(); t4.join();
-		if(!ok1 || !ok2 || !ok4 || !b3.open(base + ".3.ht2")) return -1;
-	}
+	if(!b1.open(base + ".1.ht2") || !b2.open(base + ".2.ht2") || !b3.open(base + ".3.ht2") || !b4.open(base + ".4.ht2")) return -1;
 	if(b1.u32() != 1) return -2;
 	b1.u32();  // version
 	uint32_t len = b1.u32(), gbwtLen = b1.u32(), numNodes = b1.u32();
@@ -146,7 +161,7 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 	uint32_t eftabLen = b1.u32(); b1.u32();
 	if(lineRate < 6 || lineRate > 8 || ftabChars < 1 || ftabChars > 14 || offRate < 0 || offRate > 16) return -2;
 	ix.g.p.init(len, gbwtLen, numNodes, lineRate, offRate, ftabChars, eftabLen, 4);
-	if(!read_gfm_body(b1, ix.g)) return -2;
+	if(!read_gfm_body(b1, ix.g, light)) return -2;
 	{   // reference names, '\n'-separated, '\0'-terminated
 		std::string cur;
 		while(b1.pos < b1.d.size()) {
@@ -155,9 +170,17 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 			if(c == '\n') { ix.names.push_back(cur); cur.clear(); } else cur.push_back(c);
 		}
 	}
-	b2.u32();
-	b2.arr(ix.g.offs, 4, ix.g.p.offsLen);
-	if(b2.bad) return -2;
+	// the SA sample (0.8 GB of a human-size index) and the reference bases (0.8 GB) are copied on threads of their own while this one parses on
+	std::thread t_offs, t_buf;
+	struct Join { std::thread &a, &b; ~Join() { if(a.joinable()) a.join(); if(b.joinable()) b.join(); } } join_{t_offs, t_buf};
+	if(!light) {
+		b2.u32();
+		if(!b2.has((size_t)ix.g.p.offsLen * 4)) return -2;
+		ix.g.offs.resize(ix.g.p.offsLen);
+		t_offs = std::thread([&]() { if(ix.g.p.offsLen) memcpy(ix.g.offs.data(), &b2.d[b2.pos], (size_t)ix.g.p.offsLen * 4); });
+		ix.r.buf.resize(b4.d.size() + 16, 0);
+		t_buf = std::thread([&]() { if(b4.d.size()) memcpy(ix.r.buf.data(), b4.d.begin(), b4.d.size()); });
+	}
 	// reference records
 	if(b3.u32() != 1) return -2;
 	uint32_t nrecs = b3.u32();
@@ -183,8 +206,6 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 	if(b3.bad || r.nrefs == 0) return -2;
 	r.refRecOffs.push_back(nrecs);
 	r.refLens.push_back((uint32_t)cumlen);
-	r.buf.swap(b4.d);
-	r.buf.resize(r.buf.size() + 16, 0);
 	if(load_local) {
 		Reader b5, b6;
 		if(b5.open(base + ".5.ht2") && b6.open(base + ".6.ht2")) {

@@ -902,10 +902,10 @@ __global__ __launch_bounds__(256) void k_fm_search_graph(DGfm g, DReads rd, cons
 // ------------------------------------------------------------------------------------------ Smith-Waterman
 static_assert(sizeof(h2g_sw_result) == sizeof(SwOut), "h2g_sw_result must mirror SwOut");
 // Two kernels.  k_sw_fill: one wavefront per problem, register-resident systolic fill (sw_fill_wave), H/E/F streamed to an
-// HBM workspace in anti-diagonal-major order (64 contiguous bytes per step and matrix).  k_sw_backtrace: one LANE per
+// HBM workspace in anti-diagonal-major order (64 contiguous cells per step and matrix; 8-bit cells, 16-bit for a problem with minsc < -254).  k_sw_backtrace: one LANE per
 // problem walks the reference's sequential gather/backtrace over that workspace, so 64 backtraces share a wavefront
 // instead of 63 lanes idling behind one.
-struct SwWs { uint8_t* base; size_t stride, mat_bytes; };   // per problem: H | E | F (mat_bytes each) | rf
+struct SwWs { uint8_t* base; size_t stride, mat_bytes, rf_bytes; };   // per problem: H | E | F (mat_bytes each) | rf (rf_bytes) | mask matrix of the rare second walk (SwMaskTab::direct)
 __global__ __launch_bounds__(64) void k_sw_fill(DRef ref, DReads rd, SwParams P, const h2g_sw_query* q, size_t n, SwWs ws)
 {
 	__shared__ uint8_t s_rf[H2G_SW_MAX_COLS + 8];
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(64) void k_sw_fill(DRef ref, DReads rd, SwParams P,
 		const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
 		uint8_t* w = ws.base + p * ws.stride;
 		SwMats m;
-		m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1;
+		m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1; m.wide = sw_wide_for(qq.minsc);
 		m.H = w; m.E = w + ws.mat_bytes; m.F = w + 2 * ws.mat_bytes; m.rf = s_rf;
 		{   // reference window: BitPairReference::getStretch semantics (N / outside the sequence = 4)
 			RefCursor rc;
@@ -945,10 +945,10 @@ __global__ __launch_bounds__(256) void k_sw_backtrace(DRef ref, DReads rd, SwPar
 		const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
 		uint8_t* w = ws.base + p * ws.stride;
 		SwMats m;
-		m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1;
+		m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1; m.wide = sw_wide_for(qq.minsc);
 		m.H = w; m.E = w + ws.mat_bytes; m.F = w + 2 * ws.mat_bytes; m.rf = w + 3 * ws.mat_bytes;
 		uint32_t rnd = qq.rnd;
-		const SwOut* o = sw_finish(m, P, sv, rect, qq.minsc, &rnd, ls);
+		const SwOut* o = sw_finish(m, P, sv, rect, qq.minsc, &rnd, ls, reinterpret_cast<uint16_t*>(w + 3 * ws.mat_bytes + ws.rf_bytes));
 		SwOut* dst = reinterpret_cast<SwOut*>(&out[p]);
 		dst->found_align = o->found_align; dst->found = o->found; dst->best = o->best; dst->score = o->score; dst->off = o->off;
 		dst->nedits = o->nedits; dst->gaps = o->gaps; dst->overflow = o->overflow; dst->rnd = o->rnd; dst->refl = o->refl; dst->refr = o->refr;
@@ -1250,8 +1250,11 @@ extern "C" h2g_status h2g_sw_align(h2g_stream* s, const h2g_sw_query* q, size_t 
 	HIPCHK(hipSetDevice(s->ix->device));
 	const size_t ncolmax = maxlen + 4 * H2G_SW_MAXGAP, ndmax = maxlen + ncolmax - 1;
 	SwWs ws;
-	ws.mat_bytes = (size_t)((maxlen + 63) / 64) * ndmax * 64;
-	ws.stride = 3 * ws.mat_bytes + ((ncolmax + 255) & ~(size_t)255);
+	bool any_wide = false;                                        // 16-bit cells for the problems with minsc < -254 (aligner_sw.cpp:496)
+	for(size_t i = 0; i < n && !any_wide; i++) any_wide = sw_wide_for(q[i].minsc);
+	ws.mat_bytes = ((size_t)((maxlen + 63) / 64) * ndmax * 64) << (any_wide ? 1 : 0);
+	ws.rf_bytes = (ncolmax + 255) & ~(size_t)255;
+	ws.stride = 3 * ws.mat_bytes + ws.rf_bytes + (((size_t)maxlen * ncolmax * 2 + 255) & ~(size_t)255);
 	const size_t batch = n < 32768 ? n : 32768;                   // 32 k problems x ~93 KB = 3 GB of HBM workspace
 	const size_t bt_threads = ((batch + 255) / 256) * 256;
 	if(s->sw_ws_bytes < batch * ws.stride) {
@@ -1549,7 +1552,10 @@ static int go_pool_for(h2g_stream* s, int which, const GoUnit& u, size_t slots, 
 	a->sc_base = pl.sc;
 	a->sw_base = nullptr; a->sw_stride = 0;
 	if(bowtie2_dp) {
-		const size_t stride = (sw_scratch_bytes(s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len) + 255) & ~(size_t)255;
+		const uint32_t swlen = s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len;
+		bool wide = false;                                        // some read length of the batch may put minsc below -254: 16-bit cells
+		for(uint32_t l = 1; l <= swlen && !wide; l++) wide = sw_wide_for(min_score_for(a->P, l));
+		const size_t stride = (sw_scratch_bytes(swlen, wide) + 255) & ~(size_t)255;
 		if(pl.sw_stride < stride || pl.sw_lanes < lanes) {
 			(void)hipFree(pl.sw); pl.sw = nullptr; pl.sw_stride = 0; pl.sw_lanes = 0;
 			HIPCHK(hipMalloc((void**)&pl.sw, stride * lanes));
@@ -1623,10 +1629,6 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(p->bowtie2_dp) {
 		if(s->max_read_len == 0) return H2G_ERR_ARG;
 		// a read longer than H2G_SW_MAX_ROWS is flagged by the kernel (overflow bit 256) instead of run through the DP
-		// SwAligner::align switches to 16-bit scores when minsc < -254 (aligner_sw.cpp:494-504); only the 8-bit fill is built
-		const AlnParams Pq = aln_params_from(*p, p->no_spliced_alignment != 0, linear);
-		const uint32_t swlen = s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len;
-		if(min_score_for(Pq, swlen) < -254) { snprintf(g_err, sizeof g_err, "bowtie2_dp: --score-min gives %lld for %u-base reads; below -254 the reference runs its 16-bit DP, which is not built", (long long)min_score_for(Pq, s->max_read_len), s->max_read_len); return H2G_ERR_UNSUPPORTED; }
 	}
 	HIPCHK(hipSetDevice(s->ix->device));
 	// Runs queued back to back share the result arrays (rows per read, record stride): a machine pass still in flight may only meet a

@@ -594,7 +594,7 @@ void summ_unpaired(Summ& s, int m, const h2g_alnres* lst, size_t n) {   // the r
 extern "C" h2g_status h2g_sam_open(const char* base, h2g_sam** out) {
 	if(!base || !out) return H2G_ERR_ARG;
 	HostIndex ix;
-	const int rc = load_host_index(base, false, ix);
+	const int rc = load_host_index(base, false, ix, true);       // (light: names, lengths, fragment table, ALTs — no sides / SA sample / reference bases)
 	if(rc != 0) return (h2g_status)rc;
 	h2g_sam* s = new h2g_sam();
 	s->refnames = ix.names;

@@ -1,4 +1,4 @@
-// h2g_sw.h — the 8-bit end-to-end Smith-Waterman of SwAligner as HISAT2 uses it.
+// h2g_sw.h — the end-to-end Smith-Waterman of SwAligner as HISAT2 uses it, 8-bit and 16-bit cells.
 //
 // Reference: frameSeedExtensionRect dp_framer.cpp:81-130; SwAligner::initRef aligner_sw.cpp:137-253;
 // alignNucleotidesEnd2EndSseU8 aligner_swsse_ee_u8.cpp:791-1172; gatherCellsNucleotidesEnd2EndSseU8 :1202-1234;
@@ -15,6 +15,14 @@
 // still hand the reference's backtrace byte-identical matrices.  The backtrace itself (deterministic `#if 1`
 // tie-breaks, branch stack, reported-through masks) is sequential and runs on lane 0.
 //
+// 16-bit cells (row a24).  SwAligner::align takes the 8-bit fill when minsc >= -254 and alignNucleotidesEnd2EndSseI16 (aligner_swsse_ee_i16.cpp,
+// with its own gather :1216-1249 and backtrace :1324-1915) otherwise (aligner_sw.cpp:496); nothing else selects between them in an end-to-end
+// run (readSse16_ is never set).  The i16 cells are signed with saturating adds: 0x7fff = score 0, 0x8000 = "minus infinity", the gap barrier
+// is 0x8000 added twice (forces 0x8000).  Read as unsigned after + 0x8000 that is the recurrence above with 0xffff for 0xff — the same code
+// at another cell width (SwMats::wide), gather and backtrace decoding with - 0xffff.  One difference outside the matrices: after a candidate the
+// 16-bit branch of nextAlignment re-seeds the PRNG with `reseed`, the 8-bit branch with `reseed + 1` (aligner_sw.cpp:906 / :840).
+// Pinned by tests/golden/probe_sw16.txt.gz (the reference at --score-min -450 / -900, scores down to -407).
+//
 // All functions are `__host__ __device__`; tests/emul instantiates them on the host with one "lane".
 #pragma once
 #include "h2g_core.h"
@@ -25,8 +33,8 @@ namespace h2g {
 #define H2G_SW_NCH ((H2G_SW_MAX_ROWS + 63) / 64)   // row chunks of 64 per lane in the wave-systolic fill
 #define H2G_SW_MAXGAP 10                    // readGaps = refGaps = maxhalf = 10 (spliced_aligner.h:222)
 #define H2G_SW_MAX_COLS (H2G_SW_MAX_ROWS + 4 * H2G_SW_MAXGAP)
-#define H2G_SW_STACK 96                     // branch frames (the reference's list is unbounded; overflow is flagged)
 #define H2G_SW_CELLS (H2G_SW_MAX_ROWS + 2 * H2G_SW_MAXGAP + 8)
+#define H2G_SW_STACK H2G_SW_CELLS             // branch frames: at most one per cell of the current path (the reference's list is unbounded; overflow is flagged)
 
 struct SwParams {   // Scoring (scoring.h) + the constants of the call site
 	DScoring sc;
@@ -40,13 +48,17 @@ struct SwFrame { uint16_t nedsz, celsz, row, col, gaps; int16_t ns; int32_t scor
 // backtraced paths (a few hundred cells of 14 k), so it is kept as a small open-addressing table instead of a matrix.
 // Entry = generation << 32 | (row << 8 | col) << 16 | mask; a new problem bumps the generation instead of clearing.
 #define H2G_SW_MASK_SLOTS 1024
+// A walk that touches more cells than the table holds (many failing candidates of a poor placement: every one of them marks its path) is
+// run again over `direct`, a plain matrix of masks (nrow x ncol uint16, cleared first) — sw_finish; without one it ends flagged (`full`).
 struct SwMaskTab {
 	uint64_t* e;      // [H2G_SW_MASK_SLOTS], zero-initialised once
 	uint32_t  gen;    // > 0
-	uint32_t  full;   // set when an insert found no slot (reported as overflow)
+	uint32_t  full;   // set when an insert found no slot
+	uint16_t* direct = nullptr; uint32_t dcols = 0;
 	H2G_HD uint32_t slot(uint32_t key) const { return (key * 40503u >> 4) & (H2G_SW_MASK_SLOTS - 1); }
 	// entry = generation (30 bits) | key (18 bits: row << 10 | col; col < 1024 covers 256 rows + 4 * maxgap columns) | mask (16 bits)
 	H2G_HD uint32_t get(uint32_t row, uint32_t col) const {
+		if(direct) return direct[(size_t)row * dcols + col];
 		const uint32_t key = (row << 10) | col;
 		uint32_t h = slot(key);
 		for(uint32_t n = 0; n < H2G_SW_MASK_SLOTS; n++, h = (h + 1) & (H2G_SW_MASK_SLOTS - 1)) {
@@ -57,6 +69,7 @@ struct SwMaskTab {
 		return 0;
 	}
 	H2G_HD void set(uint32_t row, uint32_t col, uint32_t mask) {
+		if(direct) { direct[(size_t)row * dcols + col] = (uint16_t)mask; return; }
 		const uint32_t key = (row << 10) | col;
 		uint32_t h = slot(key);
 		for(uint32_t n = 0; n < H2G_SW_MASK_SLOTS; n++, h = (h + 1) & (H2G_SW_MASK_SLOTS - 1)) {
@@ -72,17 +85,22 @@ struct SwMaskTab {
 //   layout 1: anti-diagonal-major [((i >> 6) * nd + i + j) << 6 | (i & 63)], nd = nrow + ncol - 1
 //             — what the wavefront fill writes: the 64 cells of one step are 64 contiguous bytes
 struct SwMats {
-	uint8_t*  H; uint8_t* E; uint8_t* F;
+	uint8_t*  H; uint8_t* E; uint8_t* F;   // cells: uint8_t, or uint16_t when `wide`
 	uint8_t*  rf;                          // reference chars 0..4 for the ncol columns
 	uint32_t  nrow, ncol, nd, layout;
-	H2G_HD size_t at(uint32_t i, uint32_t j) const {
+	uint32_t  wide = 0;                    // 1: 16-bit cells (minsc < -254)
+	H2G_HD size_t at(uint32_t i, uint32_t j) const {   // cell index (not a byte offset)
 		return layout ? ((((size_t)(i >> 6) * nd + i + j) << 6) | (i & 63u)) : ((size_t)i * ncol + j);
 	}
-	H2G_HD size_t bytes() const { return layout ? ((size_t)((nrow + 63) >> 6) * nd) << 6 : (size_t)nrow * ncol; }
+	H2G_HD size_t bytes() const { return (layout ? ((size_t)((nrow + 63) >> 6) * nd) << 6 : (size_t)nrow * ncol) << wide; }
+	H2G_HD uint32_t top() const { return wide ? 0xffffu : 0xffu; }   // the cell value of score 0
+	H2G_HD uint32_t ld(const uint8_t* M, size_t k) const { return wide ? (uint32_t)reinterpret_cast<const uint16_t*>(M)[k] : (uint32_t)M[k]; }
+	H2G_HD void st(uint8_t* M, size_t k, uint32_t v) const { if(wide) reinterpret_cast<uint16_t*>(M)[k] = (uint16_t)v; else M[k] = (uint8_t)v; }
 };
+H2G_HD bool sw_wide_for(int64_t minsc) { return minsc < -254; }   // aligner_sw.cpp:496
 
-H2G_HD uint8_t subs8(uint32_t a, uint32_t b) { return (uint8_t)(a > b ? a - b : 0u); }
-H2G_HD uint8_t max8(uint32_t a, uint32_t b) { return (uint8_t)(a > b ? a : b); }
+H2G_HD uint32_t subs8(uint32_t a, uint32_t b) { return a > b ? a - b : 0u; }   // unsigned saturating subtract; cells never exceed SwMats::top()
+H2G_HD uint32_t max8(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // DPRect of frameSeedExtensionRect with maxns = 0, trimToRef = false (dp_framer.cpp:81-130)
 struct SwRect { int64_t refl, refr, refl_pretrim, refr_pretrim, triml, trimr, corel, corer; };
@@ -107,19 +125,19 @@ H2G_HD uint32_t sw_pen(const DScoring& sc, int readc, int refc, int q) {
 
 // One DP cell.  Reads only cells of the two previous anti-diagonals.
 H2G_HD void sw_cell(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t i, uint32_t j) {
-	const uint32_t nrow = m.nrow;
-	const uint32_t gb = (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar) ? 0xffu : 0u;
+	const uint32_t nrow = m.nrow, top = m.top();
+	const uint32_t gb = (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar) ? top : 0u;
 	const uint32_t rdgapo = (uint32_t)(P.sc.rdGapConst + P.sc.rdGapLinear), rdgape = (uint32_t)P.sc.rdGapLinear;
 	const uint32_t rfgapo = (uint32_t)(P.sc.rfGapConst + P.sc.rfGapLinear), rfgape = (uint32_t)P.sc.rfGapLinear;
 	uint32_t e = 0, f = 0, diag;
-	if(j > 0) { const size_t l = m.at(i, j - 1); e = max8(subs8(m.E[l], rdgape), subs8(subs8(m.H[l], rdgapo), gb)); }
-	if(i > 0) { const size_t u = m.at(i - 1, j); f = subs8(max8(subs8(m.F[u], rfgape), subs8(m.H[u], rfgapo)), gb); }
-	diag = i == 0 ? 0xffu : (j == 0 ? 0u : m.H[m.at(i - 1, j - 1)]);
+	if(j > 0) { const size_t l = m.at(i, j - 1); e = max8(subs8(m.ld(m.E, l), rdgape), subs8(subs8(m.ld(m.H, l), rdgapo), gb)); }
+	if(i > 0) { const size_t u = m.at(i - 1, j); f = subs8(max8(subs8(m.ld(m.F, u), rfgape), subs8(m.ld(m.H, u), rfgapo)), gb); }
+	diag = i == 0 ? top : (j == 0 ? 0u : m.ld(m.H, m.at(i - 1, j - 1)));
 	const uint32_t pen = sw_pen(P.sc, seq.at(i), m.rf[j], seq.qual(i) - 33);
 	const size_t at = m.at(i, j);
-	m.E[at] = (uint8_t)e;
-	m.F[at] = (uint8_t)f;
-	m.H[at] = max8(max8(subs8(diag, pen), e), f);
+	m.st(m.E, at, e);
+	m.st(m.F, at, f);
+	m.st(m.H, at, max8(max8(subs8(diag, pen), e), f));
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -143,15 +161,28 @@ H2G_HD void sw_fill(const SwMats& m, const SwParams& P, const SeqView& seq, uint
 #if defined(__HIPCC__)
 // Wavefront fill (layout 1): lane l owns rows l, 64 + l, 128 + l.  At step d it computes cell (i, d - i) of each of its
 // rows from its own previous cell (H/E to the left) and the previous cells of the lane above (H/F up, H diagonal), which
-// arrive by one 32-bit __shfl_up per chunk — the packed word also conveys the reference character down the diagonal.
-// No LDS, no barriers; the three result bytes of a step are 64 contiguous bytes per matrix (coalesced stores).
-//   packed word: h_cur | h_old << 8 | f_cur << 16 | refc << 24
-__device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t lane) {
+// arrive by one __shfl_up per chunk — the packed word also conveys the reference character down the diagonal.
+// No LDS, no barriers; the three result cells of a step are 64 contiguous cells per matrix (coalesced stores).
+//   packed word (CELL = uint8_t):  h_cur | h_old << 8  | f_cur << 16 | refc << 24      (32 bits)
+//   packed word (CELL = uint16_t): h_cur | h_old << 16 | f_cur << 32 | refc << 48      (64 bits: two 32-bit shuffles)
+template <typename CELL> struct SwPack;
+template <> struct SwPack<uint8_t>  { typedef uint32_t W; static constexpr int B = 8;  static constexpr uint32_t TOP = 0xffu; };
+template <> struct SwPack<uint16_t> { typedef uint64_t W; static constexpr int B = 16; static constexpr uint32_t TOP = 0xffffu; };
+__device__ inline uint32_t sw_shfl_up1(uint32_t v) { return __shfl_up(v, 1); }
+__device__ inline uint64_t sw_shfl_up1(uint64_t v) { return (uint64_t)__shfl_up((uint32_t)v, 1) | ((uint64_t)__shfl_up((uint32_t)(v >> 32), 1) << 32); }
+__device__ inline uint32_t sw_shfl_63(uint32_t v) { return __shfl(v, 63); }
+__device__ inline uint64_t sw_shfl_63(uint64_t v) { return (uint64_t)__shfl((uint32_t)v, 63) | ((uint64_t)__shfl((uint32_t)(v >> 32), 63) << 32); }
+template <typename CELL>
+__device__ inline void sw_fill_wave_t(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t lane) {
+	typedef typename SwPack<CELL>::W W;
+	constexpr int B = SwPack<CELL>::B;
+	constexpr uint32_t TOP = SwPack<CELL>::TOP;
+	CELL* const mH = reinterpret_cast<CELL*>(m.H); CELL* const mE = reinterpret_cast<CELL*>(m.E); CELL* const mF = reinterpret_cast<CELL*>(m.F);
 	const uint32_t nrow = m.nrow, ncol = m.ncol, nd = m.nd;
 	const uint32_t nch = (nrow + 63) >> 6;
 	const uint32_t rdgapo = (uint32_t)(P.sc.rdGapConst + P.sc.rdGapLinear), rdgape = (uint32_t)P.sc.rdGapLinear;
 	const uint32_t rfgapo = (uint32_t)(P.sc.rfGapConst + P.sc.rfGapLinear), rfgape = (uint32_t)P.sc.rfGapLinear;
-	uint32_t pk[H2G_SW_NCH], e_cur[H2G_SW_NCH];
+	W pk[H2G_SW_NCH]; uint32_t e_cur[H2G_SW_NCH];
 	int readc[H2G_SW_NCH]; uint32_t mmpen[H2G_SW_NCH], gb[H2G_SW_NCH];
 #pragma unroll
 	for(int c = 0; c < H2G_SW_NCH; c++) {
@@ -160,17 +191,17 @@ __device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const Se
 		const bool in = i < nrow;
 		readc[c] = in ? seq.at(i) : 4;
 		mmpen[c] = in ? (uint32_t)mm_penalty(P.sc, seq.qual(i) - 33) : 0u;
-		gb[c] = (in && (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar)) ? 0xffu : 0u;
+		gb[c] = (in && (i < (uint32_t)P.gapbar || (nrow - i - 1) < (uint32_t)P.gapbar)) ? TOP : 0u;
 	}
 	for(uint32_t d = 0; d < nd; d++) {
-		uint32_t up[H2G_SW_NCH];
+		W up[H2G_SW_NCH];
 		const uint32_t fresh = d < ncol ? (uint32_t)m.rf[d] : 4u;     // row 0 meets column d at step d
 #pragma unroll
 		for(int c = 0; c < H2G_SW_NCH; c++) {
 			if((uint32_t)c >= nch) break;
-			uint32_t u = __shfl_up(pk[c], 1);
-			if(c > 0) { const uint32_t w = __shfl(pk[c - 1], 63); if(lane == 0) u = w; }
-			else if(lane == 0) u = fresh << 24;
+			W u = sw_shfl_up1(pk[c]);
+			if(c > 0) { const W w = sw_shfl_63(pk[c - 1]); if(lane == 0) u = w; }
+			else if(lane == 0) u = (W)fresh << (3 * B);
 			up[c] = u;
 		}
 #pragma unroll
@@ -179,20 +210,23 @@ __device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const Se
 			const uint32_t i = (uint32_t)c * 64 + lane;
 			const int32_t j = (int32_t)d - (int32_t)i;
 			if(i < nrow && j >= 0 && j < (int32_t)ncol) {
-				const uint32_t h_left = pk[c] & 0xffu, e_left = e_cur[c];
-				const uint32_t up_h = up[c] & 0xffu, up_hold = (up[c] >> 8) & 0xffu, up_f = (up[c] >> 16) & 0xffu, refc = up[c] >> 24;
+				const uint32_t h_left = (uint32_t)pk[c] & TOP, e_left = e_cur[c];
+				const uint32_t up_h = (uint32_t)up[c] & TOP, up_hold = (uint32_t)(up[c] >> B) & TOP, up_f = (uint32_t)(up[c] >> (2 * B)) & TOP, refc = (uint32_t)(up[c] >> (3 * B));
 				const uint32_t e = j == 0 ? 0u : max8(subs8(e_left, rdgape), subs8(subs8(h_left, rdgapo), gb[c]));
 				const uint32_t f = i == 0 ? 0u : subs8(max8(subs8(up_f, rfgape), subs8(up_h, rfgapo)), gb[c]);
-				const uint32_t diag = i == 0 ? 0xffu : (j == 0 ? 0u : up_hold);
+				const uint32_t diag = i == 0 ? TOP : (j == 0 ? 0u : up_hold);
 				const uint32_t pen = (readc[c] > 3 || refc > 3) ? (uint32_t)P.sc.nPen : ((uint32_t)readc[c] == refc ? 0u : mmpen[c]);
 				const uint32_t h = max8(max8(subs8(diag, pen), e), f);
 				const size_t at = ((((size_t)c * nd + d) << 6) | lane);
-				m.H[at] = (uint8_t)h; m.E[at] = (uint8_t)e; m.F[at] = (uint8_t)f;
-				pk[c] = h | (h_left << 8) | (f << 16) | (refc << 24);
+				mH[at] = (CELL)h; mE[at] = (CELL)e; mF[at] = (CELL)f;
+				pk[c] = (W)h | ((W)h_left << B) | ((W)f << (2 * B)) | ((W)refc << (3 * B));
 				e_cur[c] = e;
 			}
 		}
 	}
+}
+__device__ inline void sw_fill_wave(const SwMats& m, const SwParams& P, const SeqView& seq, uint32_t lane) {
+	if(m.wide) sw_fill_wave_t<uint16_t>(m, P, seq, lane); else sw_fill_wave_t<uint8_t>(m, P, seq, lane);
 }
 #endif
 
@@ -224,22 +258,23 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 	const uint32_t nrow = m.nrow, ncol = m.ncol;
 	const int64_t rdgapo = P.sc.rdGapConst + P.sc.rdGapLinear, rdgape = P.sc.rdGapLinear;
 	const int64_t rfgapo = P.sc.rfGapConst + P.sc.rfGapLinear, rfgape = P.sc.rfGapLinear;
+	const int64_t top = (int64_t)m.top();
 	uint32_t lrmax = 0;
-	for(uint32_t j = 0; j < ncol; j++) { const uint32_t v = m.H[m.at(nrow - 1, j)]; if(v > lrmax) lrmax = v; }
-	o->best = (int32_t)lrmax - 0xff;
+	for(uint32_t j = 0; j < ncol; j++) { const uint32_t v = m.ld(m.H, m.at(nrow - 1, j)); if(v > lrmax) lrmax = v; }
+	o->best = (int32_t)((int64_t)lrmax - top);
 	o->found_align = 0; o->found = 0; o->score = 0; o->off = 0; o->nedits = 0; o->gaps = 0; o->overflow = 0;
 	if((int64_t)o->best < minsc || lrmax == 0) return;         // flag -1 / -2 (:1140-1165)
 	// Candidates = last-row cells with score >= minsc, visited best score first, then rightmost column first.
 	// Instead of sorting a list, repeatedly take the next (score, col) in that order: O(ncol) per candidate.
-	uint32_t prev_v = 256, prev_col = 0;
+	uint32_t prev_v = m.top() + 1, prev_col = 0;
 	bool any = false;
 	while(true) {
 		// next candidate strictly after (prev_v, prev_col) in (score desc, col desc) order
 		uint32_t best_v = 0, best_col = 0;
 		bool have = false;
 		for(uint32_t j = 0; j < ncol; j++) {
-			const uint32_t v = m.H[m.at(nrow - 1, j)];
-			if((int64_t)v - 0xff < minsc) continue;
+			const uint32_t v = m.ld(m.H, m.at(nrow - 1, j));
+			if((int64_t)v - top < minsc) continue;
 			any = true;
 			const bool after = v < prev_v || (v == prev_v && j < prev_col);
 			if(!after) continue;
@@ -266,10 +301,10 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 			else if(row > 0) {
 				const bool gapsAllowed = !(row < (uint32_t)P.gapbar || (nrow - row - 1) < (uint32_t)P.gapbar);
 				if(ct == 1) {                                  // E: gap open from H-left or extension from E-left
-					const int64_t sc_cur = (int64_t)m.E[m.at(row, col)] - 0xff;
+					const int64_t sc_cur = (int64_t)m.ld(m.E, m.at(row, col)) - top;
 					int mask = 0;
-					if((int64_t)m.H[m.at(row, col - 1)] - 0xff - rdgapo == sc_cur) mask |= 1;
-					if((int64_t)m.E[m.at(row, col - 1)] - 0xff - rdgape == sc_cur) mask |= 2;
+					if((int64_t)m.ld(m.H, m.at(row, col - 1)) - top - rdgapo == sc_cur) mask |= 1;
+					if((int64_t)m.ld(m.E, m.at(row, col - 1)) - top - rdgape == sc_cur) mask |= 2;
 					const int origMask = mask;
 					if(mk & (1 << 7)) mask = (mk >> 8) & 3;
 					int nm = -1;
@@ -279,10 +314,10 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 					else { empty = true; canMoveThru = (origMask == 0); }
 					if(nm >= 0) mk = (uint16_t)((mk & ~(7 << 7)) | (1 << 7) | (nm << 8));
 				} else if(ct == 2) {                           // F: gap open from H-up or extension from F-up
-					const int64_t sc_cur = (int64_t)m.F[m.at(row, col)] - 0xff;
+					const int64_t sc_cur = (int64_t)m.ld(m.F, m.at(row, col)) - top;
 					int mask = 0;
-					if((int64_t)m.H[m.at(row - 1, col)] - 0xff - rfgapo == sc_cur) mask |= 1;
-					if((int64_t)m.F[m.at(row - 1, col)] - 0xff - rfgape == sc_cur) mask |= 2;
+					if((int64_t)m.ld(m.H, m.at(row - 1, col)) - top - rfgapo == sc_cur) mask |= 1;
+					if((int64_t)m.ld(m.F, m.at(row - 1, col)) - top - rfgape == sc_cur) mask |= 2;
 					const int origMask = mask;
 					if(mk & (1 << 10)) mask = (mk >> 11) & 3;
 					int nm = -1;
@@ -292,19 +327,19 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 					else { empty = true; canMoveThru = (origMask == 0); }
 					if(nm >= 0) mk = (uint16_t)((mk & ~(7 << 10)) | (1 << 10) | (nm << 11));
 				} else {
-					const int64_t sc_cur = (int64_t)m.H[m.at(row, col)] - 0xff;
+					const int64_t sc_cur = (int64_t)m.ld(m.H, m.at(row, col)) - top;
 					const bool hasl = col > 0;
 					int64_t sc_diag;                           // Scoring::score scoring.h:259
 					if(readc > 3 || refm > 15) sc_diag = -P.sc.nPen;
 					else sc_diag = (refm & (1 << readc)) ? 0 : -mm_penalty(P.sc, seq.qual(row) - 33);
 					int mask = 0;
 					if(gapsAllowed) {
-						if(sc_cur == (int64_t)m.H[m.at(row - 1, col)] - 0xff - rfgapo) mask |= 1;
-						if(hasl && sc_cur == (int64_t)m.H[m.at(row, col - 1)] - 0xff - rdgapo) mask |= 2;
-						if(sc_cur == (int64_t)m.F[m.at(row - 1, col)] - 0xff - rfgape) mask |= 4;
-						if(hasl && sc_cur == (int64_t)m.E[m.at(row, col - 1)] - 0xff - rdgape) mask |= 8;
+						if(sc_cur == (int64_t)m.ld(m.H, m.at(row - 1, col)) - top - rfgapo) mask |= 1;
+						if(hasl && sc_cur == (int64_t)m.ld(m.H, m.at(row, col - 1)) - top - rdgapo) mask |= 2;
+						if(sc_cur == (int64_t)m.ld(m.F, m.at(row - 1, col)) - top - rfgape) mask |= 4;
+						if(hasl && sc_cur == (int64_t)m.ld(m.E, m.at(row, col - 1)) - top - rdgape) mask |= 8;
 					}
-					if(hasl && sc_cur == (int64_t)m.H[m.at(row - 1, col - 1)] - 0xff + sc_diag) mask |= 16;
+					if(hasl && sc_cur == (int64_t)m.ld(m.H, m.at(row - 1, col - 1)) - top + sc_diag) mask |= 16;
 					const int origMask = mask;
 					if(mk & (1 << 1)) mask = (mk >> 2) & 31;
 					const int opts = __builtin_popcount((unsigned)mask);
@@ -323,6 +358,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 				}
 			}
 			mt.set(row, col, (uint32_t)mk | 1u);                     // setReportedThrough
+			if(mt.full) { o->overflow = 1; return; }               // the table is full: without the marks the walk would not terminate (sw_finish runs it again over a mask matrix)
 			if(!canMoveThru) {
 				if(nstack == 0) break;                         // give up on this candidate
 				const SwFrame& fr = stack[--nstack];
@@ -366,7 +402,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 				col--; ct = cur == 3 ? 0 : 1; score -= cur == 3 ? rdgapo : rdgape; gaps++;
 			}
 			if(has_edit) {
-				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed; else o->overflow = 1;
+				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed;        // (more edits than a record holds: flagged below, if this walk is the one reported)
 				ned++;
 			}
 		}
@@ -384,15 +420,16 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 			if(mt != 1) {
 				h2g_edit ed;
 				ed.pad = 0; ed.snp = H2G_MAX; ed.pos = row; ed.chr = (uint8_t)sw_mask2dna(refm); ed.qchr = (uint8_t)"ACGTN"[readc]; ed.type = H2G_EDIT_MM;
-				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed; else o->overflow = 1;
+				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed;
 				ned++;
 				score -= (readc > 3 || refm > 15) ? P.sc.nPen : mm_penalty(P.sc, seq.qual(row) - 33);
 			}
 			if(mt == -1) ns++;
 			if(ns > nceil) ok = false;
 		}
-		*rnd = reseed + 1;                                     // aligner_sw.cpp:840
+		*rnd = m.wide ? reseed : reseed + 1;                   // aligner_sw.cpp:840 (8-bit branch) / :906 (16-bit branch: rnd.init(reseed))
 		if(ok) {
+			if(ned > H2G_MAX_EDITS) o->overflow = 1;
 			const uint32_t n = ned < H2G_MAX_EDITS ? ned : H2G_MAX_EDITS;
 			for(uint32_t a = 0; a < n / 2; a++) { h2g_edit t = o->edits[a]; o->edits[a] = o->edits[n - 1 - a]; o->edits[n - 1 - a] = t; }   // res.reverse()
 			o->found = 1; o->score = (int32_t)score; o->nedits = n; o->off = (int64_t)col + rect.refl; o->gaps = gaps;
@@ -410,43 +447,57 @@ struct SwLaneState {
 	uint16_t cells[2 * H2G_SW_CELLS];
 	SwOut    out;
 };
-H2G_HD size_t sw_cell_bytes(uint32_t nrow, uint32_t ncol) { return ((size_t)nrow * ncol + 15) & ~(size_t)15; }
-// in-go() scratch of one lane for reads up to `maxlen`: SwLaneState + row-major H/E/F + the reference window
-H2G_HD size_t sw_scratch_bytes(uint32_t maxlen) {
+H2G_HD size_t sw_cell_bytes(uint32_t nrow, uint32_t ncol, bool wide) { return ((((size_t)nrow * ncol) << (wide ? 1 : 0)) + 15) & ~(size_t)15; }
+// in-go() scratch of one lane for reads up to `maxlen`: SwLaneState + row-major H/E/F (16-bit cells when `wide`) + the reference window +
+// the mask matrix of the rare second walk (SwMaskTab::direct)
+H2G_HD size_t sw_scratch_bytes(uint32_t maxlen, bool wide) {
 	const uint32_t ncol = maxlen + 4 * H2G_SW_MAXGAP;
-	return ((sizeof(SwLaneState) + 15) & ~(size_t)15) + 3 * sw_cell_bytes(maxlen, ncol) + ((ncol + 15) & ~15u);
+	return ((sizeof(SwLaneState) + 15) & ~(size_t)15) + 3 * sw_cell_bytes(maxlen, ncol, wide) + ((ncol + 15) & ~15u) + sw_cell_bytes(maxlen, ncol, true);
 }
 
-// gather + backtrace of one filled problem on the calling lane, using its persistent SwLaneState (zero-initialised once)
-H2G_HD SwOut* sw_finish(const SwMats& m, const SwParams& P, const SeqView& sv, const SwRect& rect, int64_t minsc, uint32_t* rnd, SwLaneState* ls) {
+// gather + backtrace of one filled problem on the calling lane, using its persistent SwLaneState (zero-initialised once).
+// `direct`: nrow * ncol uint16 of scratch (contents arbitrary) for the walk that outgrows the mask table, or nullptr (such a walk ends flagged).
+H2G_HD SwOut* sw_finish(const SwMats& m, const SwParams& P, const SeqView& sv, const SwRect& rect, int64_t minsc, uint32_t* rnd, SwLaneState* ls,
+                        uint16_t* direct) {
 	SwMaskTab mt;
 	if(++ls->gen >= (1u << 30)) { for(uint32_t k = 0; k < H2G_SW_MASK_SLOTS; k++) ls->mask[k] = 0; ls->gen = 1; }   // generation field is 30 bits
 	mt.e = ls->mask; mt.gen = ls->gen; mt.full = 0;
 	SwOut* o = &ls->out;
 	o->refl = rect.refl; o->refr = rect.refr;
-	sw_gather_backtrace(m, P, sv, rect, minsc, (int)((double)P.nceil_pct * 0.01 * (double)m.nrow), rnd, mt, ls->stack, ls->cells, o);
+	const uint32_t rnd0 = *rnd;
+	const int nceil = (int)((double)P.nceil_pct * 0.01 * (double)m.nrow);
+	sw_gather_backtrace(m, P, sv, rect, minsc, nceil, rnd, mt, ls->stack, ls->cells, o);
+	if(mt.full && direct) {
+		const size_t n = (size_t)m.nrow * m.ncol;
+		for(size_t k = 0; k < n; k++) direct[k] = 0;
+		mt.direct = direct; mt.dcols = m.ncol; mt.full = 0;
+		*rnd = rnd0;
+		sw_gather_backtrace(m, P, sv, rect, minsc, nceil, rnd, mt, ls->stack, ls->cells, o);
+	}
 	o->rnd = *rnd;
 	return o;
 }
 
-// The whole call site (spliced_aligner.h:209-262 without genomeHit bookkeeping) run by ONE lane over scratch memory.
+// The whole call site (spliced_aligner.h:209-262 without genomeHit bookkeeping) run by ONE lane over scratch memory
+// (sw_scratch_bytes(read length, sw_wide_for(minsc))).
 H2G_HD void sw_align_single(const DRef& ref, const SwParams& P, const SeqView& sv, uint32_t tidx, uint32_t refoff, int64_t minsc,
                             uint32_t* rnd, uint8_t* scratch, SwOut** out)
 {
 	const uint32_t nrow = sv.len;
 	const SwRect rect = sw_frame(refoff, nrow, ref.refLens[tidx]);
 	const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
-	const size_t cs = sw_cell_bytes(nrow, ncol);
+	const bool wide = sw_wide_for(minsc);
+	const size_t cs = sw_cell_bytes(nrow, ncol, wide);
 	SwLaneState* ls = reinterpret_cast<SwLaneState*>(scratch);
 	uint8_t* p = scratch + ((sizeof(SwLaneState) + 15) & ~(size_t)15);
 	SwMats m;
-	m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 0;
+	m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 0; m.wide = wide;
 	m.H = p; m.E = p + cs; m.F = p + 2 * cs; m.rf = p + 3 * cs;
 	RefCursor rc;
 	rc.init(&ref, tidx);
 	for(uint32_t j = 0; j < ncol; j++) m.rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
 	sw_fill<false>(m, P, sv, 0, 1);
-	*out = sw_finish(m, P, sv, rect, minsc, rnd, ls);
+	*out = sw_finish(m, P, sv, rect, minsc, rnd, ls, reinterpret_cast<uint16_t*>(p + 3 * cs + ((ncol + 15) & ~15u)));
 }
 
 }  // namespace h2g

@@ -206,7 +206,8 @@ H2G_EXPORT h2g_status h2g_adjust_with_alt(h2g_stream*, const h2g_adjust_query* q
 /* ---- Smith-Waterman extension (opt-in in the reference: --bowtie2-dp / --sensitive) ---------------------------- */
 /* One problem = the SwAligner call site of hybridSearch (spliced_aligner.h:209-262) for one seed hit of one read:
  * DynProgFramer::frameSeedExtensionRect (dp_framer.cpp:81) around refoff = hit.refoff - hit.rdoff, SwAligner::initRef
- * (aligner_sw.cpp:137), the 8-bit end-to-end fill alignNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:791),
+ * (aligner_sw.cpp:137), the end-to-end fill — 8-bit cells, alignNucleotidesEnd2EndSseU8 (aligner_swsse_ee_u8.cpp:791), or for
+ * minsc < -254 16-bit cells, alignNucleotidesEnd2EndSseI16 (aligner_swsse_ee_i16.cpp:793): SwAligner::align's rule, aligner_sw.cpp:496 —,
  * gatherCells (:1202), and the first SwAligner::nextAlignment (aligner_sw.cpp:709) with its backtrace (:1309) and PRNG
  * reseeding.  Edits are in the coordinates of the aligned strand (fw: patFw, !fw: patRc), ascending. */
 typedef struct {

@@ -1366,14 +1366,15 @@ uint64_t h2o_seed_extend_batch(const h2o_index* ix, const uint8_t* seqs, const u
 }
 
 /* ------------------------------------------------------------------ Smith-Waterman (a23-a25) */
-/* The 8-bit end-to-end DP of SwAligner as HISAT2 calls it from hybridSearch (spliced_aligner.h:209-262):
+/* The end-to-end DP of SwAligner as HISAT2 calls it from hybridSearch (spliced_aligner.h:209-262), 8-bit and (minsc < -254,
+ * alignNucleotidesEnd2EndSseI16 aligner_swsse_ee_i16.cpp:793-1170 with its gather :1216 and backtrace :1324) 16-bit cells:
  *   frameSeedExtensionRect dp_framer.cpp:81-130; initRef aligner_sw.cpp:137-253;
  *   alignNucleotidesEnd2EndSseU8 aligner_swsse_ee_u8.cpp:791-1172 (Farrar striped fill + lazy-F fix-up; the
  *   H/E/F bytes it leaves in SSEMatrix equal the plain saturating recurrences below);
  *   gatherCellsNucleotidesEnd2EndSseU8 :1202-1234; SwAligner::nextAlignment aligner_sw.cpp:709-870;
  *   backtraceNucleotidesEnd2EndSseU8 :1309-1900 (tie-breaks are the deterministic `#if 1` branches). */
-static inline uint8_t subs8(uint8_t a, uint8_t b) { return a > b ? (uint8_t)(a - b) : 0; }
-static inline uint8_t max8(uint8_t a, uint8_t b) { return a > b ? a : b; }
+static inline uint32_t subsu(uint32_t a, uint32_t b) { return a > b ? a - b : 0; }   /* unsigned saturating subtract (cells are <= TOP) */
+static inline uint32_t maxu(uint32_t a, uint32_t b) { return a > b ? a : b; }
 static uint32_t lcg_next(uint32_t* last) { /* RandomSource::nextU32 random_source.h:52-61 */
 	*last = 1664525u * *last + 1013904223u;
 	uint32_t ret = *last >> 16;
@@ -1405,32 +1406,37 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 	const uint32_t ncol = (uint32_t)(o->refr - o->refl + 1), nrow = rdlen;
 	uint8_t* rf = (uint8_t*)malloc(ncol + 1);
 	h2o_get_stretch(&ix->r, tidx, rfi, ncol, rf);           /* 0..3, 4 = N / outside */
-	uint8_t* H = (uint8_t*)calloc((size_t)nrow * ncol, 1);
-	uint8_t* E = (uint8_t*)calloc((size_t)nrow * ncol, 1);
-	uint8_t* F = (uint8_t*)calloc((size_t)nrow * ncol, 1);
+	/* cell width: SwAligner::align takes the 8-bit fill when minsc >= -254, else the 16-bit one (aligner_sw.cpp:496;
+	 * alignNucleotidesEnd2EndSseI16 aligner_swsse_ee_i16.cpp + its gather / backtrace).  The i16 cells (signed saturating, 0x7fff = score 0,
+	 * 0x8000 = "minus infinity", the gap barrier added twice = forced to 0x8000) are the u8 recurrences at 16 bits: with the cell + 0x8000
+	 * read as unsigned, TOP = 0xffff is score 0 and every subtraction saturates at 0 */
+	const uint32_t TOP = minsc >= -254 ? 0xffu : 0xffffu;
+	uint16_t* H = (uint16_t*)calloc((size_t)nrow * ncol, 2);
+	uint16_t* E = (uint16_t*)calloc((size_t)nrow * ncol, 2);
+	uint16_t* F = (uint16_t*)calloc((size_t)nrow * ncol, 2);
 	uint16_t* M = (uint16_t*)calloc((size_t)nrow * ncol, 2);
-	const uint8_t rdgapo = (uint8_t)(sc->rdGapConst + sc->rdGapLinear), rdgape = (uint8_t)sc->rdGapLinear;
-	const uint8_t rfgapo = (uint8_t)(sc->rfGapConst + sc->rfGapLinear), rfgape = (uint8_t)sc->rfGapLinear;
+	const uint32_t rdgapo = (uint32_t)(sc->rdGapConst + sc->rdGapLinear), rdgape = (uint32_t)sc->rdGapLinear;
+	const uint32_t rfgapo = (uint32_t)(sc->rfGapConst + sc->rfGapLinear), rfgape = (uint32_t)sc->rfGapLinear;
 #define AT(m, i, j) m[(size_t)(i) * ncol + (j)]
-	uint8_t lrmax = 0;
+	uint32_t lrmax = 0;
 	for(uint32_t j = 0; j < ncol; j++) {
 		const int refc = rf[j];
 		for(uint32_t i = 0; i < nrow; i++) {
-			const uint8_t gb = (i < (uint32_t)gapbar || (nrow - i - 1) < (uint32_t)gapbar) ? 0xff : 0;
+			const uint32_t gb = (i < (uint32_t)gapbar || (nrow - i - 1) < (uint32_t)gapbar) ? TOP : 0;
 			const int readc = seq[i], q = (qual ? qual[i] : 'I') - 33;
-			uint8_t pen;                                   /* query profile :76-147 == -Scoring::score scoring.h:259 */
-			if(readc > 3 || refc > 3) pen = (uint8_t)sc->nPen;
-			else pen = readc == refc ? 0 : (uint8_t)mmpen_q(sc, q);
-			const uint8_t e = j == 0 ? 0 : max8(subs8(AT(E, i, j - 1), rdgape), subs8(subs8(AT(H, i, j - 1), rdgapo), gb));
-			const uint8_t f = i == 0 ? 0 : subs8(max8(subs8(AT(F, i - 1, j), rfgape), subs8(AT(H, i - 1, j), rfgapo)), gb);
-			const uint8_t diag = i == 0 ? 0xff : (j == 0 ? 0 : AT(H, i - 1, j - 1));
-			AT(E, i, j) = e;
-			AT(F, i, j) = f;
-			AT(H, i, j) = max8(max8(subs8(diag, pen), e), f);
+			uint32_t pen;                                   /* query profile :76-147 == -Scoring::score scoring.h:259 */
+			if(readc > 3 || refc > 3) pen = (uint32_t)sc->nPen;
+			else pen = readc == refc ? 0 : (uint32_t)mmpen_q(sc, q);
+			const uint32_t e = j == 0 ? 0 : maxu(subsu(AT(E, i, j - 1), rdgape), subsu(subsu(AT(H, i, j - 1), rdgapo), gb));
+			const uint32_t f = i == 0 ? 0 : subsu(maxu(subsu(AT(F, i - 1, j), rfgape), subsu(AT(H, i - 1, j), rfgapo)), gb);
+			const uint32_t diag = i == 0 ? TOP : (j == 0 ? 0 : AT(H, i - 1, j - 1));
+			AT(E, i, j) = (uint16_t)e;
+			AT(F, i, j) = (uint16_t)f;
+			AT(H, i, j) = (uint16_t)maxu(maxu(subsu(diag, pen), e), f);
 		}
 		if(AT(H, nrow - 1, j) > lrmax) lrmax = AT(H, nrow - 1, j);
 	}
-	int64_t best = (int64_t)lrmax - 0xff;
+	int64_t best = (int64_t)lrmax - (int64_t)TOP;
 	o->best = best;
 	int found = !(best < minsc) && lrmax != 0;
 	o->found_align = 0;
@@ -1438,7 +1444,7 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 		/* gather :1202-1234 + sort (DpBtCandidate::operator< aligner_sw_nuc.h:149: score desc, row desc, col desc) */
 		uint32_t ncand = 0;
 		uint32_t* cand = (uint32_t*)malloc(4 * ncol);
-		for(uint32_t j = 0; j < ncol; j++) if((int64_t)AT(H, nrow - 1, j) - 0xff >= minsc) cand[ncand++] = j;
+		for(uint32_t j = 0; j < ncol; j++) if((int64_t)AT(H, nrow - 1, j) - (int64_t)TOP >= minsc) cand[ncand++] = j;
 		for(uint32_t a = 1; a < ncand; a++) {            /* insertion sort: score desc, then col desc */
 			uint32_t c = cand[a]; int b = (int)a - 1;
 			while(b >= 0 && (AT(H, nrow - 1, cand[b]) < AT(H, nrow - 1, c) ||
@@ -1452,7 +1458,7 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 		uint32_t* cells = (uint32_t*)malloc(8 * 4096);
 		for(uint32_t ci = 0; ci < ncand && !o->found; ci++) {
 			uint32_t row = nrow - 1, col = cand[ci];
-			const int64_t escore = (int64_t)AT(H, row, col) - 0xff;
+			const int64_t escore = (int64_t)AT(H, row, col) - (int64_t)TOP;
 			if(escore < minsc) continue;
 			if(AT(M, row, col) & 1) continue;                /* BT_CAND_FATE_FILT_START */
 			uint32_t reseed = lcg_next(rnd) + 1;
@@ -1473,9 +1479,9 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 				else if(row > 0) {
 					const int gapsAllowed = !(row < (uint32_t)gapbar || (nrow - row - 1) < (uint32_t)gapbar);
 					if(ct == 1) {                            /* E: came from the left */
-						const int64_t sc_cur = (int64_t)AT(E, row, col) - 0xff;
+						const int64_t sc_cur = (int64_t)AT(E, row, col) - (int64_t)TOP;
 						int mask = 0, origMask;
-						const int64_t sc_h_left = (int64_t)AT(H, row, col - 1) - 0xff, sc_e_left = (int64_t)AT(E, row, col - 1) - 0xff;
+						const int64_t sc_h_left = (int64_t)AT(H, row, col - 1) - (int64_t)TOP, sc_e_left = (int64_t)AT(E, row, col - 1) - (int64_t)TOP;
 						if(sc_h_left - rdgapo == sc_cur) mask |= 1;
 						if(sc_e_left - rdgape == sc_cur) mask |= 2;
 						origMask = mask;
@@ -1488,8 +1494,8 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 						else if(mask == 1) { cur = 3; EMASK(0); }
 						else { empty = 1; canMoveThru = (origMask == 0); }
 					} else if(ct == 2) {                     /* F: came from above */
-						const int64_t sc_h_up = (int64_t)AT(H, row - 1, col) - 0xff, sc_f_up = (int64_t)AT(F, row - 1, col) - 0xff;
-						const int64_t sc_cur = (int64_t)AT(F, row, col) - 0xff;
+						const int64_t sc_h_up = (int64_t)AT(H, row - 1, col) - (int64_t)TOP, sc_f_up = (int64_t)AT(F, row - 1, col) - (int64_t)TOP;
+						const int64_t sc_cur = (int64_t)AT(F, row, col) - (int64_t)TOP;
 						int mask = 0, origMask;
 						if(sc_h_up - rfgapo == sc_cur) mask |= 1;
 						if(sc_f_up - rfgape == sc_cur) mask |= 2;
@@ -1500,12 +1506,12 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 						else if(mask == 1) { cur = 1; FMASK(0); }
 						else { empty = 1; canMoveThru = (origMask == 0); }
 					} else {
-						const int64_t sc_cur = (int64_t)AT(H, row, col) - 0xff;
-						const int64_t sc_f_up = (int64_t)AT(F, row - 1, col) - 0xff, sc_h_up = (int64_t)AT(H, row - 1, col) - 0xff;
+						const int64_t sc_cur = (int64_t)AT(H, row, col) - (int64_t)TOP;
+						const int64_t sc_f_up = (int64_t)AT(F, row - 1, col) - (int64_t)TOP, sc_h_up = (int64_t)AT(H, row - 1, col) - (int64_t)TOP;
 						const int hasl = col > 0;
-						const int64_t sc_h_left = hasl ? (int64_t)AT(H, row, col - 1) - 0xff : 0;
-						const int64_t sc_e_left = hasl ? (int64_t)AT(E, row, col - 1) - 0xff : 0;
-						const int64_t sc_h_upleft = hasl ? (int64_t)AT(H, row - 1, col - 1) - 0xff : 0;
+						const int64_t sc_h_left = hasl ? (int64_t)AT(H, row, col - 1) - (int64_t)TOP : 0;
+						const int64_t sc_e_left = hasl ? (int64_t)AT(E, row, col - 1) - (int64_t)TOP : 0;
+						const int64_t sc_h_upleft = hasl ? (int64_t)AT(H, row - 1, col - 1) - (int64_t)TOP : 0;
 						const int q = (qual ? qual[row] : 'I') - 33;
 						int64_t sc_diag;                         /* Scoring::score(readc, refm, q) */
 						if(readc > 3 || refm > 15) sc_diag = -sc->nPen;
@@ -1601,7 +1607,7 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 				o->found = 1; o->score = score; o->nedits = ned; o->off = (int64_t)col + rfi; o->gaps = gaps;
 				(void)origCol; (void)fail; (void)refGaps; (void)readGaps;
 			}
-			*rnd = reseed + 1;
+			*rnd = TOP == 0xffu ? reseed + 1 : reseed;      /* aligner_sw.cpp:840 (8-bit branch: rnd.init(reseed + 1)) / :906 (16-bit branch: rnd.init(reseed)) */
 		}
 		free(stack); free(cells); free(cand);
 	}

@@ -151,7 +151,7 @@ int  h2o_adjust_with_alt(const h2o_index*, const uint8_t* seq, int fw, uint32_t 
                          uint32_t joinedOff, h2o_ghit* hits, uint32_t* nhits, uint32_t cap);
 int64_t h2o_calculate_score(const h2o_scoring*, const char* qual, h2o_ghit* hit);
 
-/* SwAligner as called from hybridSearch (spliced_aligner.h:209-262): frame + 8-bit end-to-end fill + gather + the first
+/* SwAligner as called from hybridSearch (spliced_aligner.h:209-262): frame + end-to-end fill (8-bit cells; 16-bit when minsc < -254) + gather + the first
  * nextAlignment.  seq/qual in the aligned orientation; refoff = hit.refoff - hit.rdoff (or 0); *rnd = RandomSource::last */
 typedef struct {
 	int64_t  refl, refr, refl_pretrim, refr_pretrim, corel, corer;   /* DPRect dp_framer.h */

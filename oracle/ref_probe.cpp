@@ -370,6 +370,7 @@ int main(int argc, char** argv) {
 			index_t rdlen = (index_t)rd.length();
 			TAlScore minsc = (TAlScore)scoreMin.f<double>((double)rdlen);
 			if(minsc > 0) minsc = 0;
+			if(cmd == "sw" && argc > 5) minsc = (TAlScore)atoll(argv[5]);   // sw <base> <reads> <nospliced> <minsc>: below -254 SwAligner::align takes its 16-bit path (aligner_sw.cpp:496)
 			for(int fwi = 0; fwi < 2; fwi++) {
 				bool fw = fwi == 0;
 				ReadBWTHit<index_t> hit;
@@ -463,24 +464,30 @@ int main(int argc, char** argv) {
 					// seed hit, fill (8-bit end-to-end SSE), gather, one nextAlignment.  Output: the rectangle, whether an
 					// alignment was found, its score, reference offset, edits (read coordinates of the aligned strand,
 					// i.e. before invertEdits) and the next PRNG draw (nextAlignment reseeds rnd).
-					for(size_t k = 0; k < coords.size(); k++) {
+					// sw <base> <reads> <nospliced> <minsc> <shift>: with a shift, every coordinate is also tried `shift` bases to the right
+					// (an unrelated placement: deep scores, many equal choices in the backtrace); those lines carry k + 100
+					const size_t swshift = argc > 6 ? (size_t)atoll(argv[6]) : 0;
+					for(size_t kk = 0; kk < coords.size() * (swshift ? 2 : 1); kk++) {
+						const size_t k = kk % coords.size();
+						const bool shifted = kk >= coords.size();
 						if(coords[k].ref() == (TRefId)std::numeric_limits<index_t>::max()) continue;
 						swa.initRead(rd.patFw, rd.patRc, rd.qual, rd.qualRev, 0, rd.length(), *sc);
 						DynProgFramer dpframe(false);
 						size_t tlen = p.ref->approxLen(coords[k].ref());
 						size_t readGaps = 10, refGaps = 10, nceil = 0, maxhalf = 10;
-						index_t hit_refoff = (index_t)coords[k].off();
+						index_t hit_refoff = (index_t)coords[k].off() + (shifted ? (index_t)swshift : 0);
+						if(shifted && (size_t)hit_refoff + rd.length() + 64 > tlen) continue;
 						index_t refoff = hit_refoff > rdoff ? hit_refoff - rdoff : 0;
 						DPRect rect;
 						dpframe.frameSeedExtensionRect(refoff, rd.length(), tlen, readGaps, refGaps, nceil, maxhalf, rect);
 						size_t cminlen = 2000, cpow2 = 4, nwindow = 10, nsInLeftShift = 0;
 						swa.initRef(fw, coords[k].ref(), rect, *p.ref, tlen, *sc, minsc, true, cminlen, cpow2, false, true,
 						            nwindow, nsInLeftShift);
-						rnd.init((uint32_t)(rd.rdid * 7 + k + 1));
+						rnd.init((uint32_t)(rd.rdid * 7 + k + (shifted ? 100 : 0) + 1));
 						TAlScore bestCell = std::numeric_limits<TAlScore>::min();
 						bool found = swa.align(rnd, bestCell);
 						printf("%llu %d %u %u %u %lld | %lld %lld %lld %lld %lld %lld | %d %lld",
-						       (unsigned long long)rd.rdid, (int)fw, (unsigned)k, (unsigned)coords[k].ref(), refoff, (long long)minsc,
+						       (unsigned long long)rd.rdid, (int)fw, (unsigned)(k + (shifted ? 100 : 0)), (unsigned)coords[k].ref(), refoff, (long long)minsc,
 						       (long long)rect.refl, (long long)rect.refr, (long long)rect.refl_pretrim, (long long)rect.refr_pretrim,
 						       (long long)rect.corel, (long long)rect.corer, (int)found,
 						       bestCell == std::numeric_limits<TAlScore>::min() ? -99999LL : (long long)bestCell);

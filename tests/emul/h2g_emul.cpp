@@ -192,7 +192,7 @@ void h2gemu_sw_align(Emu* e, const h2g_sw_query* q, size_t n, h2g_sw_result* out
 	// wavefront kernel (filled here cell by cell), even ones the row-major layout of the in-go() path
 	DReads rd = e->reads();
 	SwParams P;
-	std::vector<uint8_t> scratch(sw_scratch_bytes(H2G_SW_MAX_ROWS));
+	std::vector<uint8_t> scratch(sw_scratch_bytes(H2G_SW_MAX_ROWS, true));
 	SwLaneState* ls = new SwLaneState();
 	memset(ls, 0, sizeof *ls);
 	for(size_t p = 0; p < n; p++) {
@@ -205,14 +205,15 @@ void h2gemu_sw_align(Emu* e, const h2g_sw_query* q, size_t n, h2g_sw_result* out
 			const SwRect rect = sw_frame(q[p].refoff, nrow, e->dr.refLens[q[p].tidx]);
 			const uint32_t ncol = (uint32_t)(rect.refr - rect.refl + 1);
 			SwMats m;
-			m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1;
+			m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = 1; m.wide = sw_wide_for(q[p].minsc);
 			std::vector<uint8_t> H(m.bytes()), E(H.size()), F(H.size()), rf(ncol);
 			m.H = H.data(); m.E = E.data(); m.F = F.data(); m.rf = rf.data();
 			RefCursor rc;
 			rc.init(&e->dr, q[p].tidx);
 			for(uint32_t j = 0; j < ncol; j++) rf[j] = (uint8_t)rc.get(rect.refl + (int64_t)j);
 			sw_fill<false>(m, P, sv, 0, 1);
-			o = sw_finish(m, P, sv, rect, q[p].minsc, &rnd, ls);
+			std::vector<uint16_t> direct((size_t)nrow * ncol, 0xabcd);
+			o = sw_finish(m, P, sv, rect, q[p].minsc, &rnd, ls, direct.data());
 		}
 		memcpy(&out[p], o, sizeof(SwOut));
 	}
@@ -266,7 +267,7 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	C->g = &e->dg; C->ref = &e->dr; C->ls = &e->dls; C->P = P;
 	C->ssdb = no_spliced ? nullptr : &e->dssdb; C->rdid_base = e->rdid_base;
 	ctx_ext_opts(*C, *P);
-	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS));
+	e->sw.resize(sw_scratch_bytes(H2G_SW_MAX_ROWS, true));
 	C->sw = e->sw.data();
 	static GraphWS gws_;
 	static GraphSlot gsl_;

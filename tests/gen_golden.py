@@ -10,7 +10,7 @@ for a small seeded genome ("g1"):
   ref_se_nospliced.sam.gz         hisat2-align-s -f -p 1 --no-spliced-alignment (minus @PG)
   ref_se_spliced.sam.gz           hisat2-align-s -f -p 1 (default), minus @PG
   reads_pe_{1,2}.fa.gz, ref_pe_nospliced.sam.gz   300 pairs and their -1/-2 --no-spliced-alignment SAM
-`gen_golden.py sw` adds reads_sw.fa.gz + probe_sw.txt.gz (SwAligner call-site vectors); `gen_golden.py graph` adds the GRAPH index fixtures without touching the above:
+`gen_golden.py sw` adds reads_sw.fa.gz + probe_sw.txt.gz (SwAligner call-site vectors), `gen_golden.py sw16` reads_sw16.fa.gz + probe_sw16.txt.gz (its 16-bit path); `gen_golden.py graph` adds the GRAPH index fixtures without touching the above:
   g1s.snp.gz, g1s.{1..8}.ht2.gz   ~500 seeded variants of g1 and the hisat2-build-s --snp graph index
   reads_snp.fa.gz                 300 reads drawn from the alternate haplotype (all variants applied)
   probe_g1s_{params,rank,glf,glf1,psearch,psearch_spliced,coords,coords_short,extend,adjust,adjust_short,lglf}.txt.gz   reference GFM graph-LF / group-walk outputs
@@ -22,6 +22,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -183,6 +184,27 @@ def main_extsearch():
     shutil.rmtree(tmp)
 
 
+def main_sw16():
+    """reads_sw16.fa.gz (150-base reads of g1 at 2 / 7 / 18 / 30 % substitutions, an indel each) + probe_sw16.txt.gz: the same call site with
+    --score-min below -254, where SwAligner::align takes its 16-bit path (aligner_sw.cpp:496: alignNucleotidesEnd2EndSseI16 + the I16
+    gather / backtrace).  Two runs of the probe: minsc -450, and minsc -900 with every seed coordinate also tried 777 bases to the right (unrelated placements:
+    deep scores, many equal choices in the backtrace).  Alignments with more than H2G_MAX_EDITS edits are part of the vectors (score and
+    offset are checked; the records flag the overflow)."""
+    tmp = tempfile.mkdtemp(prefix="h2goldsw16")
+    base = os.path.join(tmp, "g1")
+    for k in range(1, 9):
+        open(f"{base}.{k}.ht2", "wb").write(gzip.open(os.path.join(GOLD, f"g1.{k}.ht2.gz")).read())
+    contigs = synth.make_genome([60000, 45000, 30000], SEED, n_gaps=1, gap_len=500, repeats=2, repeat_len=400)
+    reads = np.concatenate([synth.make_reads(contigs, 150, 150, SEED + 31 + g, sub_rate=r, indel_rate=0.01, n_rate=0.002)[0] for g, r in enumerate((0.02, 0.07, 0.18, 0.30))])
+    rfa = os.path.join(tmp, "reads_sw16.fa")
+    synth.write_reads_fasta(rfa, reads)
+    gz_write(os.path.join(GOLD, "reads_sw16.fa.gz"), open(rfa, "rb").read())
+    out = b"".join(run([os.path.join(REF, "ref_probe"), "sw", base, rfa, "1", str(m), str(sh)]).stdout for m, sh in ((-450, 0), (-900, 777)))
+    gz_write(os.path.join(GOLD, "probe_sw16.txt.gz"), out)
+    print("sw16", len(out.splitlines()), "lines")
+    shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extsearch":
         main_extsearch()
@@ -190,5 +212,7 @@ if __name__ == "__main__":
         main_graph()
     elif len(sys.argv) > 1 and sys.argv[1] == "sw":
         main_sw()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sw16":
+        main_sw16()
     else:
         main()

@@ -140,7 +140,16 @@ def test_sw_align(g1_index, golden_dir):
     e = Emu(g1_index)
     reads, offs = PC.load_sw_reads(golden_dir)
     e.set_reads(reads.reshape(-1), offs)
-    assert PC.check_sw(e, golden_dir) > 250
+    assert PC.check_sw(e, golden_dir)[0] > 250
+
+
+def test_sw_align_16bit_cells(g1_index, golden_dir):
+    """--score-min below -254: SwAligner's 16-bit path (aligner_sw.cpp:496); both matrix layouts (even / odd problems)"""
+    e = Emu(g1_index)
+    reads, offs = PC.load_sw_reads(golden_dir, "reads_sw16.fa.gz")
+    e.set_reads(reads.reshape(-1), offs)
+    n, nbig = PC.check_sw(e, golden_dir, rdlen=150, fn="probe_sw16.txt.gz")
+    assert n > 700 and nbig > 100
 
 
 def test_ext_search_golden(emu, golden_dir):

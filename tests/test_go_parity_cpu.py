@@ -54,6 +54,9 @@ def test_golden_sam(g1_index, golden_dir):
     # SwAligner pass on reads up to 256 bp (4 row chunks; mask-table keys hold 10-bit columns)
     dict(seed=771, nreads=3000, rdlen=250, sub=0.02, indel=0.006, nrate=0.002, extra=("--bowtie2-dp", "1"), bowtie2_dp=1),
     dict(seed=773, nreads=3000, rdlen=230, sub=0.03, indel=0.008, nrate=0.002, extra=("--sensitive",)),
+    # --score-min below -254: SwAligner runs its 16-bit DP (aligner_sw.cpp:496); linear and graph index
+    dict(seed=1604, nreads=1500, rdlen=101, sub=0.02, indel=0.008, nrate=0.001, extra=("--bowtie2-dp", "2", "--score-min", "L,0,-3"), bowtie2_dp=2),
+    dict(seed=1606, nreads=1500, rdlen=101, sub=0.02, indel=0.008, nrate=0.001, snps=60, extra=("--bowtie2-dp", "2", "--score-min", "L,0,-2.6"), bowtie2_dp=2),
 ])
 def test_live_reference(case):
     """Fresh genome + reads, index by the reference's builder, SAM by the reference's aligner."""

@@ -33,6 +33,24 @@ def have(base):
     return all(os.path.exists(f"{base}.{k}.ht2") for k in range(1, 9))
 
 
+def usable_cpus():
+    """CPUs this process can actually run on: the affinity mask capped by the cgroup CPU quota.  The reference's builder slows down when it
+    is given more threads than that (200 Mbp on 8 CPUs: 61 s with -p 8, 115 s with -p 32), and the GPU boxes show 256 CPUs under a 16-CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
 def build(total, threads=None, timeout=None, cache=None):
     base = index_base(total, cache)
     if have(base):
@@ -43,7 +61,7 @@ def build(total, threads=None, timeout=None, cache=None):
         raise RuntimeError("oracle/_ref/hisat2-build-s is missing")
     fa = base + ".fa"
     synth.write_fasta(fa, genome(total))
-    threads = threads or min(os.cpu_count() or 1, 64)
+    threads = threads or usable_cpus()
     try:
         subprocess.run([builder, "-q", "-p", str(threads), fa, base + ".tmp"], check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, timeout=timeout)

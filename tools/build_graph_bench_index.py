@@ -37,14 +37,14 @@ def build(total, every=250, threads=None, cache=None):
     synth.write_fasta(base + ".fa", contigs, names=names(total))
     synth.write_snps(base + ".snp", var)
     t0 = time.time()
-    subprocess.run([builder, "-q", "-p", str(threads or min(os.cpu_count() or 1, 64)), "--snp", base + ".snp", base + ".fa", base + ".tmp"], check=True,
+    subprocess.run([builder, "-q", "-p", str(threads or BB.usable_cpus()), "--snp", base + ".snp", base + ".fa", base + ".tmp"], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     dt = time.time() - t0
     for k in range(1, 9):
         os.replace(f"{base}.tmp.{k}.ht2", f"{base}.{k}.ht2")
     os.remove(base + ".fa")
     peak = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6
-    info = {"genome_bases": total, "variants": len(var), "build_seconds": dt, "builder_peak_rss_GB": peak, "threads": threads or min(os.cpu_count() or 1, 64),
+    info = {"genome_bases": total, "variants": len(var), "build_seconds": dt, "builder_peak_rss_GB": peak, "threads": threads or BB.usable_cpus(),
             "index_bytes": sum(os.path.getsize(f"{base}.{k}.ht2") for k in range(1, 9))}
     import json
     json.dump(info, open(base + ".build.json", "w"))
