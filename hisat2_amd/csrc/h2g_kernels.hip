@@ -105,7 +105,7 @@ struct h2g_stream {
 	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
-	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 400, mach_min = 4; long dbg_read = -1;
+	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4; long dbg_read = -1;
 	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -448,7 +448,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	{
 		auto env = [](const char* k, long d) { const char* e = getenv(k); return e ? atol(e) : d; };
 		s->tune.fast = (int)env("H2G_GO_FAST", 1); s->tune.blocks_per_cu = (int)env("H2G_GO_BLOCKS_PER_CU", 0); s->tune.pair_slots = (int)env("H2G_PAIR_SLOTS", 0);
-		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 400); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
+		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 0); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
 		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
 	}
@@ -1751,7 +1751,22 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 			if(hipEventQuery(s->ev_fast[b]) == hipSuccess) { s->last_bails = s->h_bails[b]; break; }
 		}
 		(void)hipGetLastError();
-		const unsigned mach_div = s->tune.mach_div, mach_min = s->tune.mach_min;   // (hand-ons per machine workgroup: latency chains, two passes in flight)
+		// hand-ons per machine workgroup (latency chains, two passes in flight).  Linear index: 400 — the fast pass is short and the machine's pass bounds the
+		// step.  Graph index: the fast pass bounds the step and every machine workgroup costs it two of its 256 (one per CU), while the machine's pass only
+		// has to end within two steps — so large batches give the machine less: 400 per workgroup up to 500 k batch units (pairs, or two unpaired reads), rising
+		// to 1600 at 1 M and beyond.  Measured steady steps, SNP graphs over 8-256 Mbp (profiles/r04_graph_scale.jsonl, r04_graph_scale2.jsonl):
+		//   500 k pairs: machine alone 55.3 ms | 400: 51.0 | 800: 55.2 | 1600: 70.6        1 M pairs (32 Mbp): alone 103.1 | 200: 110.0 | 400: 106.1 | 1600: 94.7 | 3200: 129.4
+		//   2 M pairs: alone 194.6 | 1600: 171.1 | 3200: 176.4                               1 M pairs, 128 / 256 Mbp: alone 110.6 / 119.6 | 400: 113.7 / 122.7 | 1600: 101.5 / 109.2
+		unsigned mach_div = s->tune.mach_div;
+		if(mach_div == 0) {
+			mach_div = 400;
+			if(!linear) {
+				const size_t units = paired ? (size_t)s->n_reads : (size_t)s->n_reads / 2;
+				if(units >= 1000000) mach_div = 1600;
+				else if(units > 500000) mach_div = 400 + (unsigned)((units - 500000) * 1200 / 500000);
+			}
+		}
+		const unsigned mach_min = s->tune.mach_min;
 		unsigned mgrid = (unsigned)((s->last_bails + mach_div - 1) / (mach_div ? mach_div : 1u));
 		if(mgrid < mach_min) mgrid = mach_min;
 		if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
