@@ -458,14 +458,14 @@ H2G_HD size_t sw_scratch_bytes(uint32_t maxlen, bool wide) {
 // gather + backtrace of one filled problem on the calling lane, using its persistent SwLaneState (zero-initialised once).
 // `direct`: nrow * ncol uint16 of scratch (contents arbitrary) for the walk that outgrows the mask table, or nullptr (such a walk ends flagged).
 H2G_HD SwOut* sw_finish(const SwMats& m, const SwParams& P, const SeqView& sv, const SwRect& rect, int64_t minsc, uint32_t* rnd, SwLaneState* ls,
-                        uint16_t* direct) {
+                        uint16_t* direct, int nceil_given = -1 /* >= 0: instead of nCeil(read length): tests */) {
 	SwMaskTab mt;
 	if(++ls->gen >= (1u << 30)) { for(uint32_t k = 0; k < H2G_SW_MASK_SLOTS; k++) ls->mask[k] = 0; ls->gen = 1; }   // generation field is 30 bits
 	mt.e = ls->mask; mt.gen = ls->gen; mt.full = 0;
 	SwOut* o = &ls->out;
 	o->refl = rect.refl; o->refr = rect.refr;
 	const uint32_t rnd0 = *rnd;
-	const int nceil = (int)((double)P.nceil_pct * 0.01 * (double)m.nrow);
+	const int nceil = nceil_given >= 0 ? nceil_given : (int)((double)P.nceil_pct * 0.01 * (double)m.nrow);
 	sw_gather_backtrace(m, P, sv, rect, minsc, nceil, rnd, mt, ls->stack, ls->cells, o);
 	if(mt.full && direct) {
 		const size_t n = (size_t)m.nrow * m.ncol;

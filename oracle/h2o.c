@@ -2,7 +2,8 @@
  * h2o.c — CPU ORACLE (test infrastructure; see h2o.h).  Plain C restatement of the
  * HISAT2 2.2.3 seed-and-extend hot path; every function cites the reference lines it
  * follows.  Pinned by tests/test_oracle_golden.py against vectors produced by the real
- * reference classes (oracle/ref_probe.cpp).
+ * reference classes (oracle/ref_probe.cpp) and against the reference's own SwAligner
+ * known-answer cases (aligner_sw.cpp:1470-2727, lifted into tests/golden/sw_kat.json).
  */
 #include "h2o.h"
 #include <stdio.h>
@@ -1389,6 +1390,11 @@ static int mmpen_q(const h2o_scoring* sc, int q) { /* Scoring::initPens COST_MOD
 }
 static const char MASK2DNA[] = "?ACMGRSVTWYHKDBNN";   /* alphabet.cpp:71-89 */
 
+/* fill + gather + first nextAlignment over the rectangle whose columns are rf[0..ncol) (0..3, 4 = N; owned: freed here), column 0 at reference
+ * offset o->refl, `triml` columns trimmed on the left, core diagonals o->corel..o->corer; *ns_out = Ns of the reported alignment */
+static int sw_rect(const h2o_scoring* sc, const uint8_t* seq, const char* qual, uint32_t nrow, uint8_t* rf, uint32_t ncol, int64_t triml,
+                   int64_t minsc, int nceil, int gapbar, uint32_t* rnd, h2o_sw_result* o, int* ns_out);
+
 int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq, const char* qual, uint32_t rdlen,
                  uint32_t tidx, uint32_t refoff, int64_t minsc, int nceil, int gapbar, uint32_t* rnd, h2o_sw_result* o)
 {
@@ -1402,10 +1408,35 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 	if(refl < 0) triml = -refl;
 	o->refl = refl + triml; o->refr = refr - trimr; o->refl_pretrim = refl; o->refr_pretrim = refr;
 	o->corel = maxgap; o->corer = maxgap + 2 * maxgap;
-	const int64_t rfi = o->refl;
-	const uint32_t ncol = (uint32_t)(o->refr - o->refl + 1), nrow = rdlen;
+	const uint32_t ncol = (uint32_t)(o->refr - o->refl + 1);
 	uint8_t* rf = (uint8_t*)malloc(ncol + 1);
-	h2o_get_stretch(&ix->r, tidx, rfi, ncol, rf);           /* 0..3, 4 = N / outside */
+	h2o_get_stretch(&ix->r, tidx, o->refl, ncol, rf);       /* 0..3, 4 = N / outside */
+	int ns;
+	return sw_rect(sc, seq, qual, rdlen, rf, ncol, triml, minsc, nceil, gapbar, rnd, o, &ns);
+}
+
+/* The same DP over a window of a plain reference string: columns refl..refr of ref[0..reflen) (codes 0..4), N outside the string (the padding
+ * of the reference's own SwAligner test driver, aligner_sw.cpp:1230-1245), nothing trimmed, core diagonals corel..corer (col - row, as DPRect
+ * counts them).  For the known-answer cases of aligner_sw.cpp:1470-2727 (tests/golden/sw_kat.json). */
+int h2o_sw_align_window(const h2o_scoring* sc, const uint8_t* seq, const char* qual, uint32_t rdlen, const uint8_t* ref, uint32_t reflen,
+                        int64_t refl, int64_t refr, int64_t corel, int64_t corer, int64_t minsc, int nceil, int gapbar, uint32_t* rnd,
+                        h2o_sw_result* o, int* ns_out)
+{
+	memset(o, 0, sizeof *o);
+	o->best = -99999;
+	o->refl = o->refl_pretrim = refl; o->refr = o->refr_pretrim = refr;
+	o->corel = corel; o->corer = corer;
+	const uint32_t ncol = (uint32_t)(refr - refl + 1);
+	uint8_t* rf = (uint8_t*)malloc(ncol + 1);
+	for(uint32_t j = 0; j < ncol; j++) { const int64_t p = refl + (int64_t)j; rf[j] = (p < 0 || p >= (int64_t)reflen) ? 4 : ref[p]; }
+	return sw_rect(sc, seq, qual, rdlen, rf, ncol, 0, minsc, nceil, gapbar, rnd, o, ns_out);
+}
+
+static int sw_rect(const h2o_scoring* sc, const uint8_t* seq, const char* qual, uint32_t nrow, uint8_t* rf, uint32_t ncol, int64_t triml,
+                   int64_t minsc, int nceil, int gapbar, uint32_t* rnd, h2o_sw_result* o, int* ns_out)
+{
+	const int64_t rfi = o->refl;
+	*ns_out = 0;
 	/* cell width: SwAligner::align takes the 8-bit fill when minsc >= -254, else the 16-bit one (aligner_sw.cpp:496;
 	 * alignNucleotidesEnd2EndSseI16 aligner_swsse_ee_i16.cpp + its gather / backtrace).  The i16 cells (signed saturating, 0x7fff = score 0,
 	 * 0x8000 = "minus infinity", the gap barrier added twice = forced to 0x8000) are the u8 recurrences at 16 bits: with the cell + 0x8000
@@ -1604,7 +1635,7 @@ int h2o_sw_align(const h2o_index* ix, const h2o_scoring* sc, const uint8_t* seq,
 			if(ok) {
 				if(ned > H2O_MAX_EDITS) { o->overflow = 1; ned = H2O_MAX_EDITS; }
 				for(uint32_t a = 0; a < ned / 2; a++) { h2o_edit t = o->edits[a]; o->edits[a] = o->edits[ned - 1 - a]; o->edits[ned - 1 - a] = t; }
-				o->found = 1; o->score = score; o->nedits = ned; o->off = (int64_t)col + rfi; o->gaps = gaps;
+				o->found = 1; o->score = score; o->nedits = ned; o->off = (int64_t)col + rfi; o->gaps = gaps; *ns_out = ns;
 				(void)origCol; (void)fail; (void)refGaps; (void)readGaps;
 			}
 			*rnd = TOP == 0xffu ? reseed + 1 : reseed;      /* aligner_sw.cpp:840 (8-bit branch: rnd.init(reseed + 1)) / :906 (16-bit branch: rnd.init(reseed)) */

@@ -164,6 +164,11 @@ typedef struct {
 } h2o_sw_result;
 int h2o_sw_align(const h2o_index*, const h2o_scoring*, const uint8_t* seq, const char* qual, uint32_t rdlen,
                  uint32_t tidx, uint32_t refoff, int64_t minsc, int nceil, int gapbar, uint32_t* rnd, h2o_sw_result* out);
+/* the same DP over columns refl..refr of a plain reference string (codes 0..4; N outside it), core diagonals corel..corer: the setting of the
+ * reference's own known-answer cases (aligner_sw.cpp:1470-2727) */
+int h2o_sw_align_window(const h2o_scoring*, const uint8_t* seq, const char* qual, uint32_t rdlen, const uint8_t* ref, uint32_t reflen,
+                        int64_t refl, int64_t refr, int64_t corel, int64_t corer, int64_t minsc, int nceil, int gapbar, uint32_t* rnd,
+                        h2o_sw_result* out, int* ns_out);
 
 /* whole-batch CPU baseline of the stage timed by bench.py: both strands' partialSearch +
  * coordinate resolution + 0-mismatch extension, returns a checksum */

@@ -220,6 +220,34 @@ void h2gemu_sw_align(Emu* e, const h2g_sw_query* q, size_t n, h2g_sw_result* out
 	delete ls;
 }
 
+// The reference's own SwAligner known-answer cases (tests/golden/sw_kat.json, aligner_sw.cpp:1470-2727) through the product's DP: read `read` of
+// the batch over columns refl..refr of a plain reference string (N outside it), core diagonals corel..corer, a scoring of the case's own.
+// scoring = mmpMax mmpMin nPen rdGapConst rdGapLinear rfGapConst rfGapLinear; layout 0 = row-major cells, 1 = the wave kernel's anti-diagonal-major.
+void h2gemu_sw_align_window(Emu* e, uint32_t read, const uint8_t* ref, uint32_t reflen, int64_t refl, int64_t refr, int64_t corel, int64_t corer,
+                            const int* scoring, int gapbar, int64_t minsc, int nceil, uint32_t layout, uint32_t rnd, h2g_sw_result* out) {
+	DReads rd = e->reads();
+	SeqView sv = seq_view(rd, read, true);
+	SwParams P;
+	P.sc.mmpMax = scoring[0]; P.sc.mmpMin = scoring[1]; P.sc.nPen = scoring[2];
+	P.sc.rdGapConst = scoring[3]; P.sc.rdGapLinear = scoring[4]; P.sc.rfGapConst = scoring[5]; P.sc.rfGapLinear = scoring[6];
+	P.gapbar = gapbar;
+	SwRect rect;
+	rect.refl = rect.refl_pretrim = refl; rect.refr = rect.refr_pretrim = refr; rect.triml = rect.trimr = 0; rect.corel = corel; rect.corer = corer;
+	const uint32_t nrow = sv.len, ncol = (uint32_t)(refr - refl + 1);
+	SwMats m;
+	m.nrow = nrow; m.ncol = ncol; m.nd = nrow + ncol - 1; m.layout = layout; m.wide = sw_wide_for(minsc);
+	std::vector<uint8_t> H(m.bytes()), E(H.size()), F(H.size()), rf(ncol);
+	m.H = H.data(); m.E = E.data(); m.F = F.data(); m.rf = rf.data();
+	for(uint32_t j = 0; j < ncol; j++) { const int64_t p = refl + (int64_t)j; rf[j] = (p < 0 || p >= (int64_t)reflen) ? 4 : ref[p]; }
+	sw_fill<false>(m, P, sv, 0, 1);
+	SwLaneState* ls = new SwLaneState();
+	memset(ls, 0, sizeof *ls);
+	std::vector<uint16_t> direct((size_t)nrow * ncol);
+	const SwOut* o = sw_finish(m, P, sv, rect, minsc, &rnd, ls, direct.data(), nceil);
+	memcpy(out, o, sizeof *out);
+	delete ls;
+}
+
 void h2gemu_sa_resolve(Emu* e, const h2g_sa_query* q, size_t n, uint32_t cap, h2g_coord* coords, h2g_sa_result* res) {
 	for(size_t i = 0; i < n; i++)
 		genome_coords_item(e->dg, q[i].top, q[i].bot, q[i].maxelt, q[i].len, q[i].rejectStraddle != 0, coords + i * cap, cap, &res[i]);

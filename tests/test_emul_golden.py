@@ -168,3 +168,37 @@ def test_ext_search_golden(emu, golden_dir):
         return out
     n, nel = PC.check_ext_search(search, lambda t, o: emu.L.h2gemu_local_index_of(emu.h, t, o), golden_dir, "probe_extsearch.txt.gz")
     assert n > 2000 and nel > 1500
+
+
+def test_sw_reference_known_answer_cases(g1_index, golden_dir):
+    """the reference's own SwAligner known-answer cases (aligner_sw.cpp:1470-2727, tests/golden/sw_kat.json) through the product's DP code (h2g_sw.h:
+    fill, gather, backtrace), both cell layouts; the last case runs on 16-bit cells (minsc -260)"""
+    import ctypes as C
+    import numpy as np
+    import sw_kat as K
+    from hisat2_amd import api
+    e = Emu(g1_index)
+    cases = K.load(golden_dir)
+    reads = [K.codes(c["read"]) for c in cases]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint32)
+    e.set_reads(np.concatenate(reads), offs, quals="".join(c["qual"] for c in cases).encode())
+    f = e.L.h2gemu_sw_align_window
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_uint32,
+                  C.c_uint32, C.c_void_p]
+    nfound = 0
+    for i, case in enumerate(cases):
+        s = case["scoring"]
+        mx, mn = K.mm_range(s)
+        sc = (C.c_int * 7)(mx, mn, s["npen"], s["rdGapConst"], s["rdGapLinear"], s["rfGapConst"], s["rfGapLinear"])
+        ref = K.codes(case["ref"])
+        refl, refr, corel, corer = K.window(case)
+        for layout in (0, 1):
+            o = api.SwResult()
+            f(e.h, i, ref.ctypes.data, len(ref), refl, refr, corel, corer, sc, s["gapbar"], case["minsc"], 10 ** 6 if case["nceil"] is None else case["nceil"], layout, 1,
+              C.byref(o))
+            assert not o.overflow
+            eds = [(o.edits[k].type, o.edits[k].pos) for k in range(o.nedits)]
+            ns = sum(1 for k in range(o.nedits) if o.edits[k].type == 3 and (chr(o.edits[k].chr) == "N" or chr(o.edits[k].qchr) == "N"))
+            K.check(case, dict(found=o.found, score=o.score, off=o.off, gaps=o.gaps, ns=ns, edits=eds))
+        nfound += o.found
+    assert len(cases) == 105 and nfound > 60

@@ -364,3 +364,28 @@ def test_local_graph_lf(oracle_lib, g1s_index, golden_dir):
                 nie += bool(ie)
         n += 1
     assert n == 6000 and nie >= 3
+
+
+def test_sw_reference_known_answer_cases(oracle_lib, golden_dir):
+    """the reference's own SwAligner end-to-end known-answer cases (aligner_sw.cpp:1470-2727; not runnable there any more, lifted into
+    tests/golden/sw_kat.json by tests/gen_sw_kat.py): score, reference offset, extent, gaps and Ns of the first alignment"""
+    import sw_kat as K
+    oracle_lib.h2o_sw_align_window.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int64, C.c_int64, C.c_int64,
+                                               C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    cases = K.load(golden_dir)
+    nfound = nwide = 0
+    for case in cases:
+        s = case["scoring"]
+        sc = H.Scoring()
+        oracle_lib.h2o_scoring_default(C.byref(sc))
+        sc.mmpMax, sc.mmpMin = K.mm_range(s)
+        sc.nPen, sc.rdGapConst, sc.rdGapLinear, sc.rfGapConst, sc.rfGapLinear = s["npen"], s["rdGapConst"], s["rdGapLinear"], s["rfGapConst"], s["rfGapLinear"]
+        seq, ref = K.codes(case["read"]), K.codes(case["ref"])
+        refl, refr, corel, corer = K.window(case)
+        rnd, ns, o = C.c_uint32(1), C.c_int(0), H.SwResult()
+        oracle_lib.h2o_sw_align_window(C.byref(sc), seq.ctypes.data, case["qual"].encode(), len(seq), ref.ctypes.data, len(ref), refl, refr, corel, corer, case["minsc"],
+                                       10 ** 6 if case["nceil"] is None else case["nceil"], s["gapbar"], C.byref(rnd), C.byref(o), C.byref(ns))
+        K.check(case, dict(found=o.found, score=o.score, off=o.off, gaps=o.gaps, ns=ns.value, edits=[(o.edits[k].type, o.edits[k].pos) for k in range(o.nedits)]))
+        nfound += o.found
+        nwide += case["minsc"] < -254
+    assert len(cases) == 105 and nfound > 60 and nwide == 1
