@@ -1,5 +1,7 @@
 """CPU tests of the *device* item functions (hisat2_amd/csrc/h2g_core.h) instantiated on the host by
 tests/emul — same golden vectors as the oracle, plus emul == oracle on fresh seeded inputs."""
+import os
+
 import pytest
 
 import h2o_py as H
@@ -202,3 +204,71 @@ def test_sw_reference_known_answer_cases(g1_index, golden_dir):
             K.check(case, dict(found=o.found, score=o.score, off=o.off, gaps=o.gaps, ns=ns, edits=eds))
         nfound += o.found
     assert len(cases) == 105 and nfound > 60
+
+
+def test_sw_align_vs_oracle_random_both_widths(oracle_lib, g1_index, golden_dir):
+    """fresh indel-rich reads (60-250 bases, Ns, hits at the contig ends, unrelated placements), minsc from the default down to -3 per base: the
+    product's DP code against the C oracle, 8-bit and 16-bit cells, both matrix layouts (even / odd problems)"""
+    import ctypes as C
+    import numpy as np
+    import h2o_py as H
+    from hisat2_amd import api, synth
+    contigs = PC.load_contigs(golden_dir)
+    rng = np.random.default_rng(11)
+    reads, truth = [], []
+    for L in (60, 101, 150, 200, 250):
+        for sub in (0.02, 0.12):
+            r, t = synth.make_reads(contigs, 60, L, 3000 + L + int(sub * 100), sub_rate=sub, indel_rate=0.01, n_rate=0.003)
+            reads += [x for x in r]
+            truth += [tuple(int(v) for v in x) for x in t]
+    codes = np.concatenate(reads).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint32)
+    e = Emu(g1_index)
+    e.set_reads(codes, offs)
+    oix = H.load_index(oracle_lib, g1_index)
+    sc = H.Scoring()
+    oracle_lib.h2o_scoring_default(C.byref(sc))
+    qs = []
+    for i, (ci, pos, fw) in enumerate(truth):
+        L = len(reads[i])
+        minsc = int(-float(rng.choice([0.2, 1.0, 2.0, 3.0])) * L)
+        off = pos + int(rng.integers(-3, 4))
+        if i % 7 == 0:
+            off = int(rng.integers(0, 30))
+        if i % 11 == 0:
+            off = len(contigs[ci]) - L - int(rng.integers(0, 25))
+        if i % 13 == 0:
+            off = int(rng.integers(1000, len(contigs[ci]) - 1000))      # an unrelated placement
+        qs.append(api.SwQuery(i, fw, ci, max(off, 0), minsc, i * 977 + 1))
+    out, _ = e.sw_align(qs)
+    nfound = nwide = 0
+    for q, o in zip(qs, out):
+        seq = np.ascontiguousarray(reads[q.read] if q.fw else H.revcomp(reads[q.read]))
+        rnd = C.c_uint32(q.rnd)
+        w = H.SwResult()
+        oracle_lib.h2o_sw_align(oix, C.byref(sc), seq.ctypes.data, None, len(seq), q.tidx, q.refoff, q.minsc, int(0.15 * len(seq)), 4, C.byref(rnd), C.byref(w))
+        assert (o.refl, o.refr, o.found_align, o.best, o.found, o.rnd) == (w.refl, w.refr, w.found_align, w.best, w.found, rnd.value), (q.read, q.refoff, q.minsc)
+        if w.found and (w.nedits > api.MAX_EDITS or w.overflow):
+            assert o.overflow and (o.score, o.off) == (w.score, w.off)
+        elif w.found:
+            assert not o.overflow and (o.score, o.off, o.nedits) == (w.score, w.off, w.nedits)
+            for k in range(w.nedits):
+                assert (o.edits[k].pos, o.edits[k].chr, o.edits[k].qchr, o.edits[k].type) == (w.edits[k].pos, w.edits[k].chr, w.edits[k].qchr, w.edits[k].type)
+        nfound += w.found
+        nwide += q.minsc < -254
+    assert nfound > 300 and nwide > 200
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_probe")), reason="needs oracle/_ref")
+@pytest.mark.parametrize("case", [
+    dict(seed=5, nreads=400, rdlen=101, sub=0.03, minsc=-303),                 # --score-min L,0,-3: every problem on 16-bit cells
+    dict(seed=6, nreads=300, rdlen=150, sub=0.1, minsc=-450, shift=333),       # + unrelated placements
+    dict(seed=7, nreads=300, rdlen=250, sub=0.05, minsc=-700),                 # four row chunks
+    dict(seed=9, nreads=300, rdlen=101, sub=0.2, minsc=-254, shift=555),       # the last 8-bit minsc ...
+    dict(seed=10, nreads=300, rdlen=101, sub=0.2, minsc=-255, shift=555),      # ... and the first 16-bit one
+])
+def test_sw_align_live_reference(golden_dir, case):
+    """fresh reads through the reference's own SwAligner (oracle/_ref/ref_probe sw) and through h2g_sw.h, problem by problem"""
+    import fuzz_sw as F
+    n, bad = F.run_case(F.emu_backend, golden_dir, **case)
+    assert n > 50 and bad == 0
