@@ -106,7 +106,13 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam] + (["--bowtie2-dp", str(DP)] if DP else []) + list(OPTS),
                    check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
     refnames, want = parse_pe_sam(sam)
-    khits = int(OPTS[OPTS.index("-k") + 1]) if "-k" in OPTS else (10 if SNPS else 5)
+    khits = int(OPTS[OPTS.index("-k") + 1]) if "-k" in OPTS else None
+    if "--sensitive" in OPTS:                                  # the presets raise -k (hisat2.cpp:1891-1907)
+        khits = max(khits or 0, 10)
+    elif "--very-sensitive" in OPTS:
+        khits = max(khits or 0, 30)
+    if khits is None:
+        khits = 10 if SNPS else 5
     secondary = "--secondary" in OPTS
     q = [str(i) for i in range(npairs)]
     outs, r1, r2 = (backend or emu_pairs)(base, m1, m2, q, q)
