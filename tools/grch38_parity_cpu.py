@@ -3,7 +3,7 @@
 seeded 3.1 Gbp genome, seed SEED + 7) through the host instantiation of the device sources (tests/emul) and through oracle/_ref/hisat2-align-s on the
 staged .bench_cache index, compared pair by pair (FLAG, RNAME, POS, CIGAR, AS:i of every line, in order); then the same pairs through the fast pass and the general machine
 (tests/fast_check.py: bit for bit).  Needs the staged index (build_bench_index.py)
-and ~15 GB of memory.  usage: grch38_parity_cpu.py [n=20000] [first=0] [genome=3.1e9]"""
+and ~15 GB of memory.  usage: grch38_parity_cpu.py [n=20000] [first=0] [genome=3.1e9] [sub_rate=0.005: another rate draws another batch, seed SEED + 8]"""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -24,7 +24,8 @@ def main():
     assert BB.have(base), "stage the index first: tools/build_bench_index.py"
     t0 = time.time()
     contigs = BB.genome(total)
-    m1, m2 = synth.make_pairs(contigs, 1_000_000, 101, bench.SEED + 7, sub_rate=0.005)     # exactly rank 0's batch of the default run (seed SEED + 7 + 1000 * rank)
+    sub = float(sys.argv[4]) if len(sys.argv) > 4 else 0.005
+    m1, m2 = synth.make_pairs(contigs, 1_000_000, 101, bench.SEED + (7 if sub == 0.005 else 8), sub_rate=sub)   # 0.005: exactly rank 0's batch of the default run (seed SEED + 7 + 1000 * rank)
     m1, m2 = m1[first:first + n], m2[first:first + n]
     del contigs
     print("reads ready %.0f s" % (time.time() - t0), flush=True)
