@@ -33,16 +33,24 @@ def main():
     f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
     synth.write_reads_fasta(f1, m1, start_id=first); synth.write_reads_fasta(f2, m2, start_id=first)
     sam = os.path.join(tmp, "ref.sam")
-    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s"), "-f", "-p", "8", "--reorder", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam],
-                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    opts = os.environ.get("H2G_PARITY_OPTS", "").split()          # extra reference options for both sides, e.g. "-k 10 --secondary"; --bowtie2-dp N is taken out
+    dp = 0
+    if "--bowtie2-dp" in opts:
+        k = opts.index("--bowtie2-dp"); dp = int(opts[k + 1]); del opts[k:k + 2]
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "hisat2-align-s"), "-f", "-p", "8", "--reorder", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam]
+                   + opts + (["--bowtie2-dp", str(dp)] if dp else []), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refnames, want = F.parse_pe_sam(sam)
     print("reference done %.0f s" % (time.time() - t0), flush=True)
     q = [str(first + i) for i in range(n)]
+    F.OPTS, F.DP = tuple(opts), dp
     outs, r1, r2 = F.emu_pairs(base, m1, m2, q, q)
     print("emulator done %.0f s" % (time.time() - t0), flush=True)
     bad = ovf = ncon = 0
+    khits = int(opts[opts.index("-k") + 1]) if "-k" in opts else 5
+    if "--sensitive" in opts:
+        khits = max(khits if "-k" in opts else 0, 10)
     for i in range(n):
-        got = PS.finish_pair(outs[i], r1, r2, i * SU.AL_MAX_RESULTS, refnames, (m1[i], m2[i]), khits=5, secondary=False)
+        got = PS.finish_pair(outs[i], r1, r2, i * SU.AL_MAX_RESULTS, refnames, (m1[i], m2[i]), khits=khits, secondary="--secondary" in opts)
         w = want[q[i]]
         ncon += 1 if (w[0][0] & 2) else 0
         ovf += 1 if outs[i].overflow else 0
@@ -50,11 +58,11 @@ def main():
             bad += 1
             if bad <= 5:
                 print(" pair", q[i], "ovf%d" % outs[i].overflow, "\n   GOT ", got, "\n   WANT", w)
-    res = {"genome": total, "pairs": n, "first": first, "concordant_in_reference": ncon, "pairs_differing": bad, "flagged_overflow": ovf}
+    res = {"genome": total, "options": " ".join(opts) + (" --bowtie2-dp %d" % dp if dp else ""), "sub_rate": sub, "pairs": n, "first": first, "concordant_in_reference": ncon, "pairs_differing": bad, "flagged_overflow": ovf}
     del outs, r1, r2
     # the fast pass against the general machine on the same pairs (both on the host): what the pass completes must be the machine's result bit for bit
     import fast_check as FC
-    fc = FC.fast_check(base, [m1[i] for i in range(n)], [m2[i] for i in range(n)], names=q, options=("--no-spliced-alignment",))
+    fc = FC.fast_check(base, [m1[i] for i in range(n)], [m2[i] for i in range(n)], names=q, options=("--no-spliced-alignment",) + tuple(opts)) if not dp and "--secondary" not in opts else {"completed": 0, "mismatching": 0, "bails": {"(go_run does not route --bowtie2-dp / --secondary runs through the fast pass)": n}}
     res["fast_pass"] = {"completed": fc["completed"], "mismatching_the_machine": fc["mismatching"], "handed_on": fc["bails"]}
     res["seconds"] = round(time.time() - t0)
     print(res)
