@@ -794,6 +794,91 @@ extern "C" h2g_status h2g_rank_bench_synth(h2g_stream* s, size_t n, uint64_t see
 	return H2G_OK;
 }
 
+// ---- chains of dependent rank queries (measurement only: tools/chain_bench.py) ----------------------------------------
+// What the search loops of go() are made of is not a stream of independent rank queries (k_rank_*) but CHAINS: the row of step i + 1 comes out of
+// the rank of step i.  This kernel runs C independent chains per lane — chain k of lane t starts at splitmix64(seed + t * C + k) and walks
+// row' = splitmix64(rank << 32 | row) % gbwtLen — so that one can measure, at the occupancy of the compact-state pass (512-thread workgroups, one per
+// CU: `lds_bytes` of dynamic LDS bound them the same way the pass's staging area does), what several chains in flight per lane are worth against the
+// same number of chains spread over more lanes.  The sum of out[] depends only on (seed, number of chains, steps).
+template <int C, bool GRAPH>
+__global__ __launch_bounds__(512) void k_rank_chain(DGfm g, uint64_t seed, int steps, size_t nlanes, unsigned long long* sum)
+{
+	extern __shared__ uint32_t chain_pad[];
+	const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	unsigned long long acc = 0;
+	if(t < nlanes) {
+		uint32_t row[C]; int c[C];
+#pragma unroll
+		for(int k = 0; k < C; k++) { const uint64_t h = splitmix64(seed + t * C + k); row[k] = (uint32_t)(h % g.gbwtLen); c[k] = (int)((h >> 40) & 3); }
+		for(int i = 0; i < steps; i++) {
+			// every chain's side is requested before any of them is counted (the counting has data-dependent branches: left to itself the compiler
+			// finishes chain k before it issues chain k + 1's loads)
+			uint32_t r[C], sn[C], co[C];
+			if constexpr(GRAPH) {
+				Side128 sd[C];
+#pragma unroll
+				for(int k = 0; k < C; k++) { sn[k] = row[k] / DGfm::SYMS; co[k] = row[k] - sn[k] * DGfm::SYMS; sd[k] = load_side128(g.sides + (size_t)sn[k] * 128); }
+#pragma unroll
+				for(int k = 0; k < C; k++) r[k] = rank_in_side128(g, sd[k], sn[k], co[k], c[k]);
+			} else {
+				Side64 sd[C];
+#pragma unroll
+				for(int k = 0; k < C; k++) { sn[k] = row[k] / 192u; co[k] = row[k] - sn[k] * 192u; sd[k] = load_side64(g.sides + (size_t)sn[k] * 64); }
+#pragma unroll
+				for(int k = 0; k < C; k++) r[k] = rank_in_side64(g, sd[k], sn[k], co[k], c[k]);
+			}
+#pragma unroll
+			for(int k = 0; k < C; k++) {
+				const uint64_t h = splitmix64(((uint64_t)r[k] << 32) | row[k]);
+				row[k] = (uint32_t)(h % g.gbwtLen); c[k] = (int)((h >> 40) & 3);
+				acc += r[k];
+			}
+		}
+	}
+	if(threadIdx.x == 0 && steps < 0) chain_pad[0] = (uint32_t)acc;   // (keeps the dynamic allocation alive; never taken)
+	for(int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+	if((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
+}
+
+// nchains chains of `steps` dependent rank queries, chains_per_lane (1, 2, 4 or 8) of them in each lane, workgroups of `block` threads (64..512) with
+// `lds_bytes` of dynamic LDS each.  *checksum = the sum of all rank results (the same for every chains_per_lane at equal seed, nchains and steps).
+extern "C" H2G_EXPORT h2g_status h2g_rank_chain_bench(h2g_stream* s, size_t nchains, int chains_per_lane, int steps, int block, int lds_bytes, uint64_t seed,
+                                                      int repeats, float* kernel_ms, uint64_t* checksum)
+{
+	if(!s || nchains == 0 || steps < 1 || block < 64 || block > 512 || (block & 63) || lds_bytes < 0 || lds_bytes > 160 * 1024) return H2G_ERR_ARG;
+	if(chains_per_lane != 1 && chains_per_lane != 2 && chains_per_lane != 4 && chains_per_lane != 8) return H2G_ERR_ARG;
+	if(nchains % (size_t)chains_per_lane) return H2G_ERR_ARG;
+	const DGfm& g = s->ix->dg;
+	const bool graph = !g.linear && g.lineRate == 7;
+	if(!graph && (!g.linear || g.lineRate != 6)) { snprintf(g_err, sizeof g_err, "rank kernels: 64 B linear or 128 B graph sides only"); return H2G_ERR_UNSUPPORTED; }
+	HIPCHK(hipSetDevice(s->ix->device));
+	const size_t nlanes = nchains / (size_t)chains_per_lane;
+	const unsigned grid = (unsigned)((nlanes + (size_t)block - 1) / (size_t)block);
+	if(repeats < 1) repeats = 1;
+	const void* fn = nullptr;
+#define H2G_CHAIN_CASE(CC) case CC: fn = graph ? (const void*)k_rank_chain<CC, true> : (const void*)k_rank_chain<CC, false>; break;
+	switch(chains_per_lane) { H2G_CHAIN_CASE(1) H2G_CHAIN_CASE(2) H2G_CHAIN_CASE(4) H2G_CHAIN_CASE(8) }
+#undef H2G_CHAIN_CASE
+	if(lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) (void)hipGetLastError();
+	unsigned long long* dsum = s->d_counters + 7;
+	HIPCHK(hipEventRecord(s->ev[0], s->st));
+	for(int r = 0; r < repeats; r++) {
+		HIPCHK(hipMemsetAsync(dsum, 0, 8, s->st));
+		void* args[] = {(void*)&g, (void*)&seed, (void*)&steps, (void*)&nlanes, (void*)&dsum};
+		HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3((unsigned)block), args, (size_t)lds_bytes, s->st));
+	}
+	HIPCHK(hipEventRecord(s->ev[1], s->st));
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpyAsync(&v, dsum, 8, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(sync_all(s));
+	HIPCHK(hipGetLastError());
+	float t = 0;
+	HIPCHK(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+	if(kernel_ms) *kernel_ms = t / repeats;
+	if(checksum) *checksum = v;
+	return H2G_OK;
+}
+
 // ------------------------------------------------------------------------------------------ primitive kernels
 __global__ __launch_bounds__(256) void k_fm_search(DGfm g, DReads rd, const h2g_fm_query* q, size_t n, uint32_t khits,
                                                    h2g_fm_hit* out)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# first measurement of the next round (~1 GPU-minute): chains of dependent rank queries per lane at the compact-state pass's occupancy (tools/chain_bench.py)
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+timeout 300 python tools/chain_bench.py > gpurun_out/r05_chain_bench.json 2> gpurun_out/r05_chain_bench.err; echo rc $?
+python - <<'P'
+import json
+d = json.load(open('gpurun_out/r05_chain_bench.json'))
+for k in ('linear_64B', 'graph_128B'):
+    print(k, 'checksums equal:', d[k]['checksums_equal'])
+    for label, r in d[k].items():
+        if isinstance(r, dict) and 'ms' in r:
+            print('  %-20s %8.3f ms  %7.1f GB/s  %.3f of 8 TB/s' % (label, r['ms'], r['GB/s'], r['frac_of_8TBs']))
+P
