@@ -17,6 +17,7 @@
 #include "h2g_align.h"
 #include "h2g_graph.h"
 #include "h2g_sw.h"
+#include "h2g_graph_staged.h"
 #include "h2g_local_pack.h"
 #include "h2g_splice_host.h"
 #include "h2g_splice_db_host.h"
@@ -865,6 +866,82 @@ extern "C" H2G_EXPORT h2g_status h2g_rank_chain_bench(h2g_stream* s, size_t ncha
 	for(int r = 0; r < repeats; r++) {
 		HIPCHK(hipMemsetAsync(dsum, 0, 8, s->st));
 		void* args[] = {(void*)&g, (void*)&seed, (void*)&steps, (void*)&nlanes, (void*)&dsum};
+		HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3((unsigned)block), args, (size_t)lds_bytes, s->st));
+	}
+	HIPCHK(hipEventRecord(s->ev[1], s->st));
+	unsigned long long v = 0;
+	HIPCHK(hipMemcpyAsync(&v, dsum, 8, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(sync_all(s));
+	HIPCHK(hipGetLastError());
+	float t = 0;
+	HIPCHK(hipEventElapsedTime(&t, s->ev[0], s->ev[1]));
+	if(kernel_ms) *kernel_ms = t / repeats;
+	if(checksum) *checksum = v;
+	return H2G_OK;
+}
+
+// The same for whole graph LF steps on a REAL graph index (glf1_top_fused: the step of a coordinate walk — rank, rank_M, select_F: two or three dependent
+// 128 B lines): C walks per lane, either one after the other (staged = 0: what a lane of the pass does today, C times) or stage by stage over all C
+// (h2g_graph_staged.h: every walk's next line is requested before any of them is consumed).  A walk that runs into a '$' row starts over somewhere else.
+template <int C>
+__global__ __launch_bounds__(512) void k_glf_chain(DGfm g, uint64_t seed, int steps, size_t nlanes, int staged, unsigned long long* sum)
+{
+	extern __shared__ uint32_t chain_pad[];
+	const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	unsigned long long acc = 0;
+	if(t < nlanes) {
+		uint32_t row[C];
+#pragma unroll
+		for(int k = 0; k < C; k++) { uint64_t h = splitmix64(seed + t * C + k); row[k] = (uint32_t)(h % g.gbwtLen); while(is_zoff(g, row[k])) { h = splitmix64(h); row[k] = (uint32_t)(h % g.gbwtLen); } }
+		for(int i = 0; i < steps; i++) {
+			uint32_t top[C], node[C];
+			if(staged) {
+				GlfStage st[C];
+#pragma unroll
+				for(int k = 0; k < C; k++) glf_stage_a(g, row[k], st[k]);
+#pragma unroll
+				for(int k = 0; k < C; k++) glf_stage_b(g, st[k]);
+#pragma unroll
+				for(int k = 0; k < C; k++) glf_stage_c(g, st[k]);
+#pragma unroll
+				for(int k = 0; k < C; k++) glf_stage_d(g, st[k], &top[k], &node[k]);
+			} else {
+#pragma unroll
+				for(int k = 0; k < C; k++) glf1_top_fused(g, row[k], &top[k], &node[k]);
+			}
+#pragma unroll
+			for(int k = 0; k < C; k++) {
+				acc += (unsigned long long)top[k] + node[k];
+				uint32_t nr = top[k];
+				if(nr >= g.gbwtLen || is_zoff(g, nr)) { uint64_t h = splitmix64(((uint64_t)top[k] << 32) | row[k]); nr = (uint32_t)(h % g.gbwtLen); while(is_zoff(g, nr)) { h = splitmix64(h); nr = (uint32_t)(h % g.gbwtLen); } }
+				row[k] = nr;
+			}
+		}
+	}
+	if(threadIdx.x == 0 && steps < 0) chain_pad[0] = (uint32_t)acc;
+	for(int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+	if((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
+}
+
+extern "C" H2G_EXPORT h2g_status h2g_glf_chain_bench(h2g_stream* s, size_t nchains, int chains_per_lane, int steps, int block, int lds_bytes, uint64_t seed,
+                                                     int staged, int repeats, float* kernel_ms, uint64_t* checksum)
+{
+	if(!s || nchains == 0 || steps < 1 || block < 64 || block > 512 || (block & 63) || lds_bytes < 0 || lds_bytes > 160 * 1024) return H2G_ERR_ARG;
+	if(chains_per_lane != 1 && chains_per_lane != 2 && chains_per_lane != 4) return H2G_ERR_ARG;
+	if(nchains % (size_t)chains_per_lane) return H2G_ERR_ARG;
+	if(s->ix->synthetic || s->ix->dg.linear || s->ix->dg.lineRate != 7) { snprintf(g_err, sizeof g_err, "h2g_glf_chain_bench: needs a real graph (GFM, 128 B side) index"); return H2G_ERR_ARG; }
+	const DGfm& g = s->ix->dg;
+	HIPCHK(hipSetDevice(s->ix->device));
+	const size_t nlanes = nchains / (size_t)chains_per_lane;
+	const unsigned grid = (unsigned)((nlanes + (size_t)block - 1) / (size_t)block);
+	if(repeats < 1) repeats = 1;
+	const void* fn = chains_per_lane == 1 ? (const void*)k_glf_chain<1> : chains_per_lane == 2 ? (const void*)k_glf_chain<2> : (const void*)k_glf_chain<4>;
+	if(lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) (void)hipGetLastError();
+	unsigned long long* dsum = s->d_counters + 7;
+	HIPCHK(hipEventRecord(s->ev[0], s->st));
+	for(int r = 0; r < repeats; r++) {
+		HIPCHK(hipMemsetAsync(dsum, 0, 8, s->st));
+		void* args[] = {(void*)&g, (void*)&seed, (void*)&steps, (void*)&nlanes, (void*)&staged, (void*)&dsum};
 		HIPCHK(hipLaunchKernel(fn, dim3(grid), dim3((unsigned)block), args, (size_t)lds_bytes, s->st));
 	}
 	HIPCHK(hipEventRecord(s->ev[1], s->st));

@@ -17,6 +17,7 @@
 #include "../../hisat2_amd/csrc/h2g_fast.h"
 #include "../../hisat2_amd/csrc/h2g_graph.h"
 #include "../../hisat2_amd/csrc/h2g_sw.h"
+#include "../../hisat2_amd/csrc/h2g_graph_staged.h"
 #include "../../hisat2_amd/csrc/h2g_local_pack.h"
 #include "../../hisat2_amd/csrc/h2g_splice_host.h"
 #include "../../hisat2_amd/csrc/h2g_splice_db_host.h"
@@ -551,6 +552,47 @@ uint64_t h2gemu_glf_fused_check(Emu* e, uint32_t n, uint64_t seed) {
 		bool found = false;
 		for(int chunk = 0; chunk < 100000 && !found; chunk++) found = gw_walk_single(lx, &wr, &wn, &steps, 5, &off);
 		if(!ok || !found || off != gws.gw.offs[0] || steps != gws.gw.nsteps) bad++;
+	}
+	return bad;
+}
+
+// the staged LF step (h2g_graph_staged.h) against glf1_top_fused: random rows of the global and of the local graph indexes, and walks of `steps` steps
+// with four rows in flight (the stages of all four issued stage by stage, as k_glf_chain does); returns the number of differences
+uint64_t h2gemu_glf_staged_check(Emu* e, uint32_t n, uint32_t steps, uint64_t seed) {
+	if(e->dg.linear) return ~0ull;
+	uint64_t bad = 0, x = seed * 0x9e3779b97f4a7c15ull + 1;
+	auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+	for(uint32_t i = 0; i < n; i++) {
+		uint32_t row[4], ref[4];
+		for(int k = 0; k < 4; k++) { do row[k] = (uint32_t)(rnd() % e->dg.gbwtLen); while(is_zoff(e->dg, row[k])); ref[k] = row[k]; }
+		for(uint32_t s = 0; s < steps; s++) {
+			GlfStage st[4];
+			uint32_t t[4], nd[4];
+			for(int k = 0; k < 4; k++) glf_stage_a(e->dg, row[k], st[k]);
+			for(int k = 0; k < 4; k++) glf_stage_b(e->dg, st[k]);
+			for(int k = 0; k < 4; k++) glf_stage_c(e->dg, st[k]);
+			for(int k = 0; k < 4; k++) glf_stage_d(e->dg, st[k], &t[k], &nd[k]);
+			for(int k = 0; k < 4; k++) {
+				uint32_t rt = 0, rn = 0;
+				glf1_top_fused(e->dg, ref[k], &rt, &rn);
+				if(rt != t[k] || rn != nd[k]) bad++;
+				row[k] = ref[k] = (rt < e->dg.gbwtLen && !is_zoff(e->dg, rt)) ? rt : (uint32_t)(rnd() % e->dg.gbwtLen);
+				while(is_zoff(e->dg, row[k])) row[k] = ref[k] = (uint32_t)(rnd() % e->dg.gbwtLen);
+			}
+		}
+	}
+	for(uint32_t i = 0; i < n; i++) {
+		const uint32_t li = (uint32_t)(rnd() % e->dls.n);
+		const DLocalDesc& d = e->dls.desc[li];
+		if(d.len == 0 || local_is_linear(d)) continue;
+		const LGfm lx = lgfm_of(e->dls, d);
+		const uint32_t row = (uint32_t)(rnd() % d.gbwtLen);
+		if(is_zoff(lx, row)) continue;
+		GlfStage st;
+		uint32_t t = 0, nd = 0, rt = 0, rn = 0;
+		glf_stage_a(lx, row, st); glf_stage_b(lx, st); glf_stage_c(lx, st); glf_stage_d(lx, st, &t, &nd);
+		glf1_top_fused(lx, row, &rt, &rn);
+		if(rt != t || rn != nd) bad++;
 	}
 	return bad;
 }

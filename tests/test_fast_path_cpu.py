@@ -196,3 +196,14 @@ def test_local_indexes_packed_straight_from_the_files(genome, graph_genome):
         e = Emu(base)
         e.L.h2gemu_local_pack_check.argtypes = [C.c_void_p, C.c_char_p]
         assert e.L.h2gemu_local_pack_check(e.h, base.encode()) == 0
+
+
+def test_staged_graph_lf_step_equals_the_fused_one(g1s_index):
+    """h2g_graph_staged.h (the LF step of one row cut at its dependent loads, four rows in flight stage by stage: measurement kernel k_glf_chain and the
+    groundwork of several rows per lane) against glf1_top_fused: 50 000 x 4 walks of 12 steps on the global index, 50 000 rows of local indexes"""
+    import ctypes as C
+    from h2gemu_py import Emu
+    e = Emu(g1s_index)
+    e.L.h2gemu_glf_staged_check.restype = C.c_uint64
+    e.L.h2gemu_glf_staged_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    assert e.L.h2gemu_glf_staged_check(e.h, 50000, 12, 5) == 0

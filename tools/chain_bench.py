@@ -4,6 +4,7 @@ the occupancy of the compact-state pass.  The search loops of go() are chains â€
 512 lanes per CU (256 VGPRs: two waves per SIMD), one chain each.  For synthetic linear (64 B) and graph (128 B) sides at GRCh38 scale (0.98 GB), the same
 number of chains is walked (a) at full occupancy, one chain per lane; (b) one 512-thread workgroup per CU (dynamic LDS bounds it as the pass's staging area
 does), with 1, 2, 4, 8 chains per lane.  Reported: steps per second, the algorithmic GB/s (64 or 128 B per step), the checksum (must not depend on the split).
+Then whole graph LF steps (k_glf_chain) on a real SNP-graph index: 1, 2, 4 walks per lane, one after the other or stage by stage.
 
 usage: chain_bench.py [chains=2^21] [steps=64]   -> one JSON line"""
 import ctypes as C, json, sys
@@ -40,8 +41,34 @@ def main():
         rows["checksums_equal"] = len(sums) == 1
         out[name] = rows
         st.close(); ix.close()
+    # whole graph LF steps (rank, rank_M, select_F: two or three dependent lines) on a REAL SNP-graph index (built here: ~15 s for 32 Mbp), walks of `steps` steps:
+    # C walks per lane one after the other (what a lane of the pass does, C times) against C walks stage by stage (h2g_graph_staged.h)
+    glen = int(float(os.environ.get("H2G_CHAIN_GRAPH_GENOME", "32e6")))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_graph_bench_index as GB
+    base, _ = GB.build(glen, 250)
+    f2 = api.lib().h2g_glf_chain_bench
+    f2.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    f2.restype = C.c_int
+    ix = api.Index(base, device=0)
+    st = api.Stream(ix)
+    rows, sums = {"genome": glen, "index_device_bytes": int(ix.info.device_bytes)}, set()
+    for occ, block, lds in (("pass_occupancy", 512, 96 * 1024), ("full_occupancy", 256, 0)):
+        for per_lane in (1, 2, 4):
+            for staged in ((0,) if per_lane == 1 else (0, 1)):
+                ms, cs = C.c_float(0), C.c_uint64(0)
+                rc = f2(st.h, nchains, per_lane, steps, block, lds, 12345, staged, 3, C.byref(ms), C.byref(cs))
+                label = "%s_%d_%s" % (occ, per_lane, "staged" if staged else "one_after_the_other")
+                if rc != 0:
+                    rows[label] = {"error": rc}
+                    continue
+                rows[label] = {"ms": round(ms.value, 3), "lf_steps_per_s": nchains * steps / (ms.value * 1e-3), "checksum": cs.value}
+                sums.add(cs.value)
+    rows["checksums_equal"] = len(sums) == 1
+    out["graph_lf_walks"] = rows
+    st.close(); ix.close()
     print(json.dumps(out))
-    return 0 if all(out[k]["checksums_equal"] for k in ("linear_64B", "graph_128B")) else 1
+    return 0 if all(out[k]["checksums_equal"] for k in ("linear_64B", "graph_128B", "graph_lf_walks")) else 1
 
 
 if __name__ == "__main__":

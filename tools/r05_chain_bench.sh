@@ -10,4 +10,9 @@ for k in ('linear_64B', 'graph_128B'):
     for label, r in d[k].items():
         if isinstance(r, dict) and 'ms' in r:
             print('  %-20s %8.3f ms  %7.1f GB/s  %.3f of 8 TB/s' % (label, r['ms'], r['GB/s'], r['frac_of_8TBs']))
+g = d['graph_lf_walks']
+print('graph LF walks, checksums equal:', g['checksums_equal'])
+for label, r in g.items():
+    if isinstance(r, dict) and 'ms' in r:
+        print('  %-44s %8.3f ms  %.2f G LF steps/s' % (label, r['ms'], r['lf_steps_per_s'] / 1e9))
 P
