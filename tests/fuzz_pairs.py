@@ -106,12 +106,14 @@ def run_case(seed, npairs, rdlen, sub, lens=(300000, 120000, 60000), repeats=6, 
     subprocess.run([os.path.join(REF, "hisat2-align-s"), "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-1", f1, "-2", f2, "-S", sam] + (["--bowtie2-dp", str(DP)] if DP else []) + list(OPTS),
                    check=True, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "ref.err"), "w"))
     refnames, want = parse_pe_sam(sam)
-    khits = int(OPTS[OPTS.index("-k") + 1]) if "-k" in OPTS else None
-    if "--sensitive" in OPTS:                                  # the presets raise -k (hisat2.cpp:1891-1907)
-        khits = max(khits or 0, 10)
-    elif "--very-sensitive" in OPTS:
-        khits = max(khits or 0, 30)
-    if khits is None:
+    # -k as the sink sees it (hisat2.cpp:336 default 10, :1891-1907 the presets raise a smaller one, :3903 no -k seen: 5 on a linear index, 10 on a graph)
+    saw_k = "-k" in OPTS
+    khits = int(OPTS[OPTS.index("-k") + 1]) if saw_k else 10
+    if "--sensitive" in OPTS and khits < 10:
+        khits, saw_k = 10, True
+    elif "--very-sensitive" in OPTS and "--sensitive" not in OPTS and khits < 30:
+        khits, saw_k = 30, True
+    if not saw_k:
         khits = 10 if SNPS else 5
     secondary = "--secondary" in OPTS
     q = [str(i) for i in range(npairs)]

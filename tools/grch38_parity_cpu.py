@@ -46,9 +46,9 @@ def main():
     outs, r1, r2 = F.emu_pairs(base, m1, m2, q, q)
     print("emulator done %.0f s" % (time.time() - t0), flush=True)
     bad = ovf = ncon = 0
-    khits = int(opts[opts.index("-k") + 1]) if "-k" in opts else 5
-    if "--sensitive" in opts:
-        khits = max(khits if "-k" in opts else 0, 10)
+    khits = int(opts[opts.index("-k") + 1]) if "-k" in opts else 5          # (--sensitive raises a -k below 10 and leaves the linear default of 5 alone: hisat2.cpp:1891-1907, :3903)
+    if "--sensitive" in opts and "-k" in opts and khits < 10:
+        khits = 10
     for i in range(n):
         got = PS.finish_pair(outs[i], r1, r2, i * SU.AL_MAX_RESULTS, refnames, (m1[i], m2[i]), khits=khits, secondary="--secondary" in opts)
         w = want[q[i]]
