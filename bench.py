@@ -411,13 +411,13 @@ def main():
                     out[name] = fn(a, api, synth, local, cache)
                 except Exception as e:         # noqa: BLE001
                     out[name] = {"error": repr(e)[:400]}
-        if not a.no_extras and time.time() - t_start < float(os.environ.get("H2G_BENCH_CHAIN_DEADLINE", "1600")):
+        if not a.no_extras and time.time() - t_start < float(os.environ.get("H2G_BENCH_CHAIN_DEADLINE", "1500")):
             # last key of the line: chains of dependent rank queries / graph LF steps with 1-8 chains per lane at the occupancy of the compact-state pass
             # (k_rank_chain, k_glf_chain; tools/chain_bench.py) — in a process of its own with a time limit: measurement kernels never cost the headline its line
             try:
                 gbase = os.path.join(cache, f"rnd4900000_s{SEED}_snp", "g")
-                cmd = [sys.executable, os.path.join(ROOT, "tools", "chain_bench.py"), str(1 << 21), "64", gbase if os.path.exists(gbase + ".8.ht2") else "-", "compact"]
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
+                cmd = [sys.executable, os.path.join(ROOT, "tools", "chain_bench.py"), str(1 << 21), "64", gbase if os.path.exists(gbase + ".8.ht2") else "none", "compact"]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
                 out["chain_microbench"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {"error": (r.stderr or "no output")[-300:]}
             except Exception as e:             # noqa: BLE001
                 out["chain_microbench"] = {"error": repr(e)[:300]}

@@ -6,7 +6,7 @@ number of chains is walked (a) at full occupancy, one chain per lane; (b) one 51
 does), with 1, 2, 4, 8 chains per lane.  Reported: steps per second, the algorithmic GB/s (64 or 128 B per step), the checksum (must not depend on the split).
 Then whole graph LF steps (k_glf_chain) on a real SNP-graph index: 1, 2, 4 walks per lane, one after the other or stage by stage.
 
-usage: chain_bench.py [chains=2^21] [steps=64] [graph index base (default: a 32 Mbp SNP graph built here)] [compact]   -> one JSON line
+usage: chain_bench.py [chains=2^21] [steps=64] [graph index base (default: a 32 Mbp SNP graph built here; "none": skip the graph LF walks)] [compact]   -> one JSON line
 (compact: label -> [ms, GB/s or G LF steps/s] only — the form bench.py's extras carry as their last key)"""
 import ctypes as C, json, sys
 import os
@@ -45,6 +45,14 @@ def main():
     # whole graph LF steps (rank, rank_M, select_F: two or three dependent lines) on a REAL SNP-graph index (built here: ~15 s for 32 Mbp), walks of `steps` steps:
     # C walks per lane one after the other (what a lane of the pass does, C times) against C walks stage by stage (h2g_graph_staged.h)
     glen = int(float(os.environ.get("H2G_CHAIN_GRAPH_GENOME", "32e6")))
+    compact = len(sys.argv) > 4 and sys.argv[4] == "compact"
+    if len(sys.argv) > 3 and sys.argv[3] == "none":               # no graph index at hand and no time to build one: the rank chains only
+        ok = all(out[k]["checksums_equal"] for k in ("linear_64B", "graph_128B"))
+        if compact:
+            out = {"chains": nchains, "steps": steps, "checksums_equal": ok,
+                   **{k: {lab: ([r["ms"], round(r["GB/s"], 1)] if "ms" in r else r) for lab, r in out[k].items() if isinstance(r, dict)} for k in ("linear_64B", "graph_128B")}}
+        print(json.dumps(out))
+        return 0 if ok else 1
     if len(sys.argv) > 3 and sys.argv[3] not in ("", "-"):
         base, glen = sys.argv[3], None
     else:
@@ -72,7 +80,7 @@ def main():
     out["graph_lf_walks"] = rows
     st.close(); ix.close()
     ok = all(out[k]["checksums_equal"] for k in ("linear_64B", "graph_128B", "graph_lf_walks"))
-    if len(sys.argv) > 4 and sys.argv[4] == "compact":
+    if compact:
         c = {"chains": nchains, "steps": steps, "checksums_equal": ok}
         for k in ("linear_64B", "graph_128B"):
             c[k] = {lab: ([r["ms"], round(r["GB/s"], 1)] if "ms" in r else r) for lab, r in out[k].items() if isinstance(r, dict)}
