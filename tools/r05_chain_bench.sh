@@ -1,7 +1,8 @@
 #!/bin/bash
-# first measurement of the next round (~1 GPU-minute): chains of dependent rank queries per lane at the compact-state pass's occupancy (tools/chain_bench.py)
+# first measurement of the next round (~2 GPU-minutes): chains of dependent rank queries per lane at the compact-state pass's occupancy (tools/chain_bench.py)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-timeout 300 python tools/chain_bench.py > gpurun_out/r05_chain_bench.json 2> gpurun_out/r05_chain_bench.err; echo rc $?
+# (a 128 Mbp SNP graph: 308 MB of index, beyond the 256 MB MALL; ~40 s to build on the box)
+H2G_CHAIN_GRAPH_GENOME=128e6 timeout 400 python tools/chain_bench.py > gpurun_out/r05_chain_bench.json 2> gpurun_out/r05_chain_bench.err; echo rc $?
 python - <<'P'
 import json
 d = json.load(open('gpurun_out/r05_chain_bench.json'))
