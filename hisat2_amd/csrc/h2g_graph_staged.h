@@ -83,4 +83,30 @@ template <class X> H2G_HD void glf_stage_d(const X& g, GlfStage& st, uint32_t* t
 	*top_out = st.ft; *node_out = st.node;
 }
 
+// C single-row walks (gw_walk_single: a coordinate walk of one node and one row, group_walk.h:1430-1545 reduced to that case) advanced TOGETHER, stage by
+// stage, by at most `budget` LF steps each: walk k stops for good once its offset is found (done bit k; off[k] = tryOffset + its step count).  Returns the done
+// mask.  A walk that is done, or was done on entry (bit set in `done`), costs nothing further.
+template <int C, class X>
+H2G_HD uint32_t gw_walk_multi(const X& g, uint32_t* row, uint32_t* node, uint32_t* steps, uint32_t budget, uint32_t* off, uint32_t done) {
+	while(true) {
+#pragma unroll
+		for(int k = 0; k < C; k++) {
+			if(done & (1u << k)) continue;
+			const uint32_t toff = gw_try_offset(g, row[k], node[k]);
+			if(toff != H2G_MAX) { off[k] = toff + steps[k]; done |= 1u << k; }
+		}
+		if(done == (1u << C) - 1u || budget == 0) return done;
+		budget--;
+		GlfStage st[C];
+#pragma unroll
+		for(int k = 0; k < C; k++) if(!(done & (1u << k))) glf_stage_a(g, row[k], st[k]);
+#pragma unroll
+		for(int k = 0; k < C; k++) if(!(done & (1u << k))) glf_stage_b(g, st[k]);
+#pragma unroll
+		for(int k = 0; k < C; k++) if(!(done & (1u << k))) glf_stage_c(g, st[k]);
+#pragma unroll
+		for(int k = 0; k < C; k++) if(!(done & (1u << k))) { glf_stage_d(g, st[k], &row[k], &node[k]); steps[k]++; }
+	}
+}
+
 }  // namespace h2g

@@ -581,6 +581,26 @@ uint64_t h2gemu_glf_staged_check(Emu* e, uint32_t n, uint32_t steps, uint64_t se
 			}
 		}
 	}
+	// four coordinate walks advanced together (gw_walk_multi, in chunks of 5 steps) against four gw_walk_single
+	for(uint32_t i = 0; i < n / 8; i++) {
+		uint32_t row[4], node[4], steps[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};
+		uint32_t r1[4], n1[4];
+		for(int k = 0; k < 4; k++) {
+			uint32_t r0;
+			do r0 = (uint32_t)(rnd() % e->dg.gbwtLen); while(is_zoff(e->dg, r0));
+			glf1_top_fused(e->dg, r0, &row[k], &node[k]);             // a (row, node) pair that belongs together
+			if(row[k] >= e->dg.gbwtLen) { k--; continue; }
+			r1[k] = row[k]; n1[k] = node[k];
+		}
+		uint32_t done = 0;
+		for(int chunk = 0; chunk < 100000 && done != 15u; chunk++) done = gw_walk_multi<4>(e->dg, row, node, steps, 5, off, done);
+		for(int k = 0; k < 4; k++) {
+			uint32_t s1 = 0, o1 = 0;
+			bool found = false;
+			for(int chunk = 0; chunk < 100000 && !found; chunk++) found = gw_walk_single(e->dg, &r1[k], &n1[k], &s1, 7, &o1);
+			if(done != 15u || !found || o1 != off[k] || s1 != steps[k]) bad++;
+		}
+	}
 	for(uint32_t i = 0; i < n; i++) {
 		const uint32_t li = (uint32_t)(rnd() % e->dls.n);
 		const DLocalDesc& d = e->dls.desc[li];
