@@ -83,6 +83,50 @@ template <class X> H2G_HD void glf_stage_d(const X& g, GlfStage& st, uint32_t* t
 	*top_out = st.ft; *node_out = st.node;
 }
 
+// ---- map_glf1_fused (the searches' step once a range is one row: mapGLF1 WITH a required character, gfm.h:3957-4021) in the same stages.
+// A is glf_stage_a; B fails the step when the row's character is another one (no further line is requested); C and D produce the GRange.
+struct GlfSearchStage { GlfStage s; uint32_t c1, c2, F_loc, fail; };
+template <class X> H2G_HD void glf_search_stage_b(const X& g, uint32_t row, int c, GlfSearchStage& q) {
+	q.fail = (rowL_in_side128(q.s.cur, q.s.c0) != c || is_zoff(g, row)) ? 1u : 0u;
+	if(q.fail) return;
+	const uint32_t t = rank_in_side128(g, q.s.cur, q.s.s0, q.s.c0, c);
+	const uint32_t r1 = t + 1;
+	q.s.s1 = r1 / X::SYMS; q.s.o1 = r1 - q.s.s1 * X::SYMS;
+	if(q.s.s1 != q.s.s0) q.s.cur = load_side128(g.sides + (size_t)q.s.s1 * 128);
+}
+template <class X> H2G_HD void glf_search_stage_c(const X& g, GlfSearchStage& q) {
+	if(q.fail) return;
+	GlfStage& st = q.s;
+	{
+		const Bits256 m = bits_of_side<X>(st.cur, X::M_OFF);
+		uint32_t cnt = side_hdr_reg<X>(st.cur, 1);
+#pragma unroll
+		for(int k = 0; k < 4; k++) cnt += (uint32_t)__builtin_popcountll(m.w[k] & low_mask((int)st.o1 - 64 * k));
+		st.node = cnt - 1;
+	}
+	uint32_t sideNum = st.s1, F_loc = side_hdr_reg<X>(st.cur, 0), M_occ = side_hdr_reg<X>(st.cur, 1);
+	while(!(M_occ <= st.node || sideNum == 0)) {
+		sideNum--;
+		st.cur = load_side128(g.sides + (size_t)sideNum * 128);
+		F_loc = side_hdr_reg<X>(st.cur, 0); M_occ = side_hdr_reg<X>(st.cur, 1);
+	}
+	if(M_occ > 0) F_loc++;
+	st.sideNum = sideNum;
+	q.F_loc = F_loc;
+	q.c1 = st.node + 1 > M_occ ? st.node + 1 - M_occ : 0u;
+	q.c2 = st.node + 2 > M_occ ? st.node + 2 - M_occ : 0u;
+	const uint32_t fs = F_loc / X::SYMS;
+	if((q.c1 || q.c2) && fs != st.sideNum) { st.cur = load_side128(g.sides + (size_t)fs * 128); st.sideNum = fs; }
+}
+template <class X> H2G_HD bool glf_search_stage_d(const X& g, GlfSearchStage& q, GRange* r) {
+	r->top = r->bot = r->node_top = r->node_bot = 0;
+	if(q.fail) return false;
+	uint32_t ft, fb;
+	select_F2_reg(g, q.s.cur, q.s.sideNum, q.F_loc, q.c1, q.c2, &ft, &fb);
+	r->top = ft; r->bot = fb; r->node_top = q.s.node; r->node_bot = q.s.node + 1;
+	return true;
+}
+
 // C single-row walks (gw_walk_single: a coordinate walk of one node and one row, group_walk.h:1430-1545 reduced to that case) advanced TOGETHER, stage by
 // stage, by at most `budget` LF steps each: walk k stops for good once its offset is found (done bit k; off[k] = tryOffset + its step count).  Returns the done
 // mask.  A walk that is done, or was done on entry (bit set in `done`), costs nothing further.

@@ -581,6 +581,25 @@ uint64_t h2gemu_glf_staged_check(Emu* e, uint32_t n, uint32_t steps, uint64_t se
 			}
 		}
 	}
+	// the searches' step (a required character) in stages, four rows at a time, every character
+	for(uint32_t i = 0; i < n / 4; i++) {
+		uint32_t row[4];
+		for(int k = 0; k < 4; k++) row[k] = (uint32_t)(rnd() % e->dg.gbwtLen);      // ('$' rows included: the step must fail on them)
+		for(int c = 0; c < 4; c++) {
+			GlfSearchStage q[4];
+			GRange a[4];
+			bool oa[4];
+			for(int k = 0; k < 4; k++) glf_stage_a(e->dg, row[k], q[k].s);
+			for(int k = 0; k < 4; k++) glf_search_stage_b(e->dg, row[k], c, q[k]);
+			for(int k = 0; k < 4; k++) glf_search_stage_c(e->dg, q[k]);
+			for(int k = 0; k < 4; k++) oa[k] = glf_search_stage_d(e->dg, q[k], &a[k]);
+			for(int k = 0; k < 4; k++) {
+				GRange b;
+				const bool ob = map_glf1_fused(e->dg, row[k], c, &b);
+				if(oa[k] != ob || a[k].top != b.top || a[k].bot != b.bot || a[k].node_top != b.node_top || a[k].node_bot != b.node_bot) bad++;
+			}
+		}
+	}
 	// four coordinate walks advanced together (gw_walk_multi, in chunks of 5 steps) against four gw_walk_single
 	for(uint32_t i = 0; i < n / 8; i++) {
 		uint32_t row[4], node[4], steps[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};

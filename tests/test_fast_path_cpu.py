@@ -200,7 +200,8 @@ def test_local_indexes_packed_straight_from_the_files(genome, graph_genome):
 
 def test_staged_graph_lf_step_equals_the_fused_one(g1s_index):
     """h2g_graph_staged.h (the LF step of one row cut at its dependent loads, four rows in flight stage by stage: measurement kernel k_glf_chain and the
-    groundwork of several rows per lane) against glf1_top_fused: 50 000 x 4 walks of 12 steps on the global index, 50 000 rows of local indexes"""
+    groundwork of several rows per lane) against glf1_top_fused: 50 000 x 4 walks of 12 steps on the global index, 50 000 rows of local indexes; the searches' step with a required character in stages
+    against map_glf1_fused (every character, '$' rows included); four coordinate walks advanced together (gw_walk_multi) against gw_walk_single"""
     import ctypes as C
     from h2gemu_py import Emu
     e = Emu(g1s_index)
