@@ -129,6 +129,90 @@ def body(path):
     return [l for l in open(path) if not l.startswith("@")]
 
 
+def whole_batch_parity(api, base, st, codes1, offs1, codes2, offs2, names, khits, f1, f2, ref_opts=(), threads=None, tmp=None, paired=True):
+    """Device-side parity at the size that is timed: EVERY record the device produced for the batch the steps ran on — the dense
+    fetch of the stream the timed region used, h2g_align_pairs_fetch_dense / h2g_align_fetch_dense — through the product's sink + SAM text
+    (include/h2g_sam.h), against the SAM of oracle/_ref/hisat2-align-s over the same read files, complete lines byte for byte.  The reference binary is
+    the checker; nothing here is inside a timed region.  -> dict(pairs_checked | reads_checked, sam_lines, sam_lines_differing,
+    digest_equal, sha256 of both bodies)."""
+    import hashlib
+    L = api.lib()
+    vp = C.c_void_p
+    L.h2g_sam_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.h2g_sam_close.argtypes = [vp]
+    L.h2g_sam_set_threads.argtypes = [vp, C.c_int]
+    L.h2g_sam_format_paired_dense.argtypes = [vp] + [vp] * 10 + [C.c_size_t, vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.h2g_sam_format_unpaired_dense.argtypes = [vp] + [vp] * 5 + [C.c_size_t, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = len(names)
+    threads = threads or min(32, os.cpu_count() or 1)
+    exe = os.path.join(REF, "hisat2-align-s")
+    ref_sam = os.path.join(tmp, "whole_ref.sam")
+    t0 = time.perf_counter()
+    cmd = [exe, "-f", "--no-spliced-alignment", "-p", str(min(threads, 16)), "--reorder", "-x", base] + (["-1", f1, "-2", f2] if paired else ["-U", f1]) + ["-S", ref_sam] + list(ref_opts)
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    t_ref = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nb = "".join(names).encode()
+    noffs = np.concatenate([[0], np.cumsum([len(q) for q in names])]).astype(np.uint32)
+    h = vp()
+    if L.h2g_sam_open(base.encode(), C.byref(h)) != 0:
+        return {"error": "h2g_sam_open"}
+    L.h2g_sam_set_threads(h, threads)
+    used = C.c_size_t(0)
+    ptr = lambda x: x.ctypes.data if isinstance(x, np.ndarray) else C.addressof(x)
+    if paired:
+        res, a1, o1, a2, o2 = st.align_pairs_fetch_dense()
+        nrec = int(o1[-1] + o2[-1])
+        cap = n * 1400 + 6 * int(codes1.size + codes2.size) + 4096
+        for _ in range(2):
+            buf = np.empty(cap, dtype=np.uint8)
+            rc = L.h2g_sam_format_paired_dense(h, codes1.ctypes.data, offs1.ctypes.data, None, nb, noffs.ctypes.data, codes2.ctypes.data, offs2.ctypes.data, None, nb, noffs.ctypes.data,
+                                               n, ptr(res), ptr(a1), o1.ctypes.data, ptr(a2), o2.ctypes.data, khits, buf.ctypes.data, cap, C.byref(used))
+            if rc == 0:
+                break
+            cap = used.value + 16
+        del a1, a2
+    else:
+        res, a1, o1 = st.align_fetch_dense()
+        nrec = int(o1[-1])
+        cap = n * 700 + 3 * int(codes1.size) + 4096
+        for _ in range(2):
+            buf = np.empty(cap, dtype=np.uint8)
+            rc = L.h2g_sam_format_unpaired_dense(h, codes1.ctypes.data, offs1.ctypes.data, None, nb, noffs.ctypes.data, n, ptr(res), ptr(a1), o1.ctypes.data, buf.ctypes.data, cap, C.byref(used))
+            if rc == 0:
+                break
+            cap = used.value + 16
+        del a1
+    L.h2g_sam_close(h)
+    if rc != 0:
+        return {"error": "h2g_sam_format_*_dense rc %d" % rc}
+    got = buf[:used.value].tobytes()
+    del buf
+    t_fmt = time.perf_counter() - t0
+    with open(ref_sam, "rb") as f:
+        want = f.read()
+    k = 0
+    while want.startswith(b"@", k):                      # the header lines (@HD @SQ @PG) are the file's, not the batch's
+        k = want.index(b"\n", k) + 1
+    want = want[k:]
+    os.remove(ref_sam)
+    dg, dw = hashlib.sha256(got).hexdigest(), hashlib.sha256(want).hexdigest()
+    out = {("pairs_checked" if paired else "reads_checked"): n, "records_fetched": nrec, "sam_bytes": len(want), "digest_equal": dg == dw, "sha256_device_path": dg, "sha256_reference": dw,
+           "against": "oracle/_ref/hisat2-align-s -p %d --reorder over the whole timed batch (complete SAM lines, byte for byte); device side = the dense fetch of the stream the timed steps ran on, "
+                      "formatted by h2g_sam_format_%s_dense" % (min(threads, 16), "paired" if paired else "unpaired"),
+           "reference_wall_s": t_ref, "fetch_and_format_s": t_fmt}
+    if dg == dw:
+        out["sam_lines"] = want.count(b"\n"); out["sam_lines_differing"] = 0
+    else:
+        gl, wl = got.split(b"\n"), want.split(b"\n")
+        out["sam_lines"] = len(wl) - 1
+        out["sam_lines_differing"] = sum(1 for x, y in zip(gl, wl) if x != y) + abs(len(gl) - len(wl))
+        bad = [y.split(b"\t", 1)[0].decode() for x, y in zip(gl, wl) if x != y][:8]
+        out["first_differing_reads"] = bad
+    return out
+
+
+
 KERNEL_SOURCES = ("h2g_k_go_fast.hip", "h2g_k_go_fast_am.hip", "h2g_fast.h", "h2g_core.h", "h2g_align.h", "h2g_graph.h", "h2g_go_args.h", "Makefile")
 
 
@@ -171,6 +255,93 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def newest_pmc_record():
+    """(path, record) of the newest profiles/rNN_pmc_traffic.json, or (None, None)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        return files[-1], json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return files[-1], None
+
+
+def attach_pmc_traffic(roofline, npairs, total, fast_on):
+    """HBM traffic of the dominant kernel from the newest committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be
+    collected inside this process), per launch like `achieved` — attached ONLY when the record was taken on exactly the kernel sources of this tree and
+    on this workload; otherwise `traffic` stays null and the line says why (a stale figure is no figure)."""
+    roofline["kernel_sources_sha16"] = kernel_sources_sha16()
+    path, pm = newest_pmc_record()
+    if pm is None:
+        roofline["traffic_note"] = "no PMC record under profiles/"
+        return False
+    name = os.path.relpath(path, ROOT)
+    same_run = pm.get("pairs_per_launch") == npairs and pm.get("genome") == total and pm.get("kernel", "").startswith("k_go_fast") == fast_on
+    if same_run and pm.get("kernel_sources_sha16") == roofline["kernel_sources_sha16"]:
+        roofline["traffic"] = int(pm["traffic_bytes_per_launch"])
+        roofline["traffic_source"] = pm.get("source")
+        roofline["traffic_calibration"] = pm.get("calibration")
+        roofline["traffic_record"] = name
+        return True
+    roofline["traffic_note"] = ("%s was taken on kernel sources %s / %s pairs / %s bp; this run is %s / %d / %d: not attached"
+                                % (name, pm.get("kernel_sources_sha16"), pm.get("pairs_per_launch"), pm.get("genome"), roofline["kernel_sources_sha16"], npairs, total))
+    return False
+
+
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def spawn_ranks(a, torch):
+    """`python bench.py --gpus N` started on its own: re-launches itself as N ranks (torch.distributed.run, rendezvous on 127.0.0.1), the same command
+    the driver uses.  Refuses when fewer than N devices are visible (a dry run needs none).  Returns the launcher's exit code."""
+    if not a.dry_run:
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < a.gpus:
+            print("bench.py: %d GPUs requested (--gpus %d), %d visible: refusing to run fewer ranks than asked for" % (a.gpus, a.gpus, ndev), file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(a, torch, shard, world, rank):
+    """The launch path without a device: rendezvous (gloo), the id-range shards, the max-over-ranks timing and the one collective of the path (the
+    counter sum), with synthetic per-rank counters.  tests/test_bench_launch.py runs it with --gpus 2 here."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_global = a.pairs if a.strong else a.pairs * world
+    lo, hi = shard.shard_range(n_global, rank, world)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(lo), float(hi)], dtype=torch.float64)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, t)
+    else:
+        parts = [t]
+    summ = shard.all_reduce_sum(np.array([hi - lo, rank + 1], dtype=np.int64), dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": world, "backend": "gloo" if world > 1 else None, "scaling": "strong" if a.strong else "weak",
+                          "pairs_global": int(summ[0]), "rank_sum": int(summ[1]), "shards": [[int(x[1]), int(x[2])] for x in parts],
+                          "max_over_ranks_s": max(float(x[0]) for x in parts)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     t_start = time.time()
     deadline = float(os.environ.get("H2G_BENCH_DEADLINE", "1350"))
@@ -182,21 +353,36 @@ def main():
     ap.add_argument("--genome", type=float, default=float(os.environ.get("H2G_BENCH_GENOME", "3.1e9")))
     ap.add_argument("--strong", action="store_true", help="one global batch of --pairs split over the ranks instead of --pairs per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-whole-parity", action="store_true", help="skip the whole-batch device-vs-reference SAM comparison of each leg (the 3 000 / 20 000-pair command-line samples stay)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (E. coli SE, graph index, micro-benchmarks)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--only-legs", default="", help="comma-separated big legs (repeat_pe, graph256_pe) to run INSTEAD of the headline: prints {leg: ...} and exits")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs available to the reference CPU runs (each thread count takes what ~6 s of it)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises the launch path only (spawn, rendezvous over gloo, shard ranges, the counter all-reduce) and prints a line marked dry_run")
     a = ap.parse_args()
 
     import torch
-    from hisat2_amd import api, synth, shard
-    import build_bench_index as BB
+    from hisat2_amd import shard
 
+    # --gpus N is the launch contract: either this process is one of N ranks started by torch.distributed.run (WORLD_SIZE == N), or — started on its
+    # own with N > 1 — it becomes that launch: N ranks over 127.0.0.1, one per device.  N ranks on fewer visible devices is an error, never a silent N = 1.
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a, torch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (a.gpus, world))
+    if a.dry_run:
+        return dry_run(a, torch, shard, world, rank)
+    from hisat2_amd import api, synth
+    import build_bench_index as BB
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if torch.cuda.device_count() < world or local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: %d GPUs requested (--gpus / WORLD_SIZE), %d visible: one rank per device, no sharing" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -290,22 +476,10 @@ def main():
                     "note": "latency chains over scattered 64 B index lines + per-read control; per trip a read's 160 B state and 264 B of hot words + packed reads are loaded in one batch of 16 B loads and stored back (DESIGN.md §3.1)"}
         # HBM traffic of the same kernel on the same workload from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
         # WRITE_SIZE need separate passes and cannot be collected inside this process); per launch like `achieved`
-        roofline["kernel_sources_sha16"] = kernel_sources_sha16()
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-            same_run = pm.get("pairs_per_launch") == npairs and pm.get("genome") == total and pm.get("kernel", "").startswith("k_go_fast") == fast_on
-            if same_run and pm.get("kernel_sources_sha16") == roofline["kernel_sources_sha16"]:
-                roofline["traffic"] = int(pm["traffic_bytes_per_launch"])
-                roofline["traffic_source"] = pm.get("source")
-                roofline["traffic_calibration"] = pm.get("calibration")
-            else:
-                roofline["traffic_note"] = ("profiles/r04_pmc_traffic.json was taken on kernel sources %s / %s pairs / %s bp; this run is %s / %d / %d: not attached"
-                                            % (pm.get("kernel_sources_sha16"), pm.get("pairs_per_launch"), pm.get("genome"), roofline["kernel_sources_sha16"], npairs, total))
-        except (OSError, ValueError):
-            roofline["traffic_note"] = "no PMC record (profiles/r04_pmc_traffic.json)"
+        attach_pmc_traffic(roofline, npairs, total, fast_on)
         out.update({
             "metric": "reads/sec, 101 bp PE, " + ("GRCh38-size" if total >= 3_000_000_000 else "REDUCED-SIZE (%d bp, GRCh38 contig profile)" % total) + " linear index, --no-spliced-alignment: HI_Aligner::go per pair on the GPU (inputs and report events resident in HBM), SAM-identical to hisat2",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "reads/s", "n_gpus": world, "rccl_world_size": (dist.get_world_size() if dist is not None else 1), "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"configs[2]: GRCh38-{'SIZE' if total >= 3_000_000_000 else 'PROFILE (reduced size)'} linear index over a seeded uniform-random {total} bp genome (24 contigs; {how}), "
@@ -320,6 +494,17 @@ def main():
                          "pairs_second_pass": int(summ[3]), "second_pass_rate": float(summ[3]) / max(1, int(summ[0])),
                          "sides_per_pair": float(summ[4]) / int(summ[0]), "sa_steps_per_pair": float(summ[5]) / int(summ[0])},
         })
+        exe = os.path.join(REF, "hisat2-align-s")
+        cli = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
+        tmp = tempfile.mkdtemp(prefix="h2bench")
+        f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
+        parity_failed = False
+        if os.path.exists(exe) and not a.no_cpu_baseline:
+            synth.write_reads_fasta(f1, m1, start_id=lo); synth.write_reads_fasta(f2, m2, start_id=lo)
+            if not a.no_whole_parity:
+                # every record of the batch the timed steps ran on (the stream still holds the last step's results) against the reference binary
+                out["parity_whole_batch"] = whole_batch_parity(api, base, st, c1, o1, c2, o2, names, int(params.khits), f1, f2, tmp=tmp)
+                parity_failed = not out["parity_whole_batch"].get("digest_equal", False)
         # host buffers in, host buffers out: upload + both passes + dense fetch of the report events (never `value`)
         t1 = time.perf_counter()
         st.set_reads(c1, o1); st.set_read_names(names); st.set_mates(c2, o2, names)
@@ -330,13 +515,8 @@ def main():
                                  "records_fetched": int(po1[-1] + po2[-1]),
                                  "note": "h2g_set_reads + h2g_set_mates + h2g_align_pairs_run + h2g_align_pairs_fetch_dense from pageable host memory, single thread"}
         del pres, pa1, pa2
-        exe = os.path.join(REF, "hisat2-align-s")
-        cli = os.path.join(ROOT, "hisat2_amd", "hisat2-align-amd")
         if os.path.exists(exe) and not a.no_cpu_baseline:
-            tmp = tempfile.mkdtemp(prefix="h2bench")
-            ns = min(a.cpu_sample, npairs)
-            f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
-            synth.write_reads_fasta(f1, m1[:ns], start_id=lo); synth.write_reads_fasta(f2, m2[:ns], start_id=lo)
+            ns = npairs
             # parity on THIS config: the first pairs through the whole drop-in path (reads file -> hisat2-align-amd -> SAM) must be
             # byte-identical to the reference's SAM
             nv = min(3000, ns)
@@ -391,7 +571,7 @@ def main():
             t_cli = time.perf_counter() - t0c
             out["cli_end_to_end"] = {"pairs": ns, "wall_s": t_cli, "reads_per_s_wall": 2 * ns / t_cli, "host_threads": 32,
                                      "timing": r.stderr.strip().splitlines()[-1] if r.returncode == 0 and r.stderr.strip() else r.stderr[-300:]}
-            shutil.rmtree(tmp, ignore_errors=True)
+        shutil.rmtree(tmp, ignore_errors=True)
         st.close()
         if not a.no_extras and time.time() - t_start > deadline:
             out["extras_skipped"] = "past H2G_BENCH_DEADLINE = %.0f s (index build included)" % deadline
@@ -421,7 +601,13 @@ def main():
                 out["chain_microbench"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {"error": (r.stderr or "no output")[-300:]}
             except Exception as e:             # noqa: BLE001
                 out["chain_microbench"] = {"error": repr(e)[:300]}
+        legs_failed = [k for k, v in out.items() if isinstance(v, dict) and isinstance(v.get("parity_whole_batch"), dict) and not v["parity_whole_batch"].get("digest_equal", False)]
+        if parity_failed or legs_failed:
+            out["parity_failed"] = (["headline"] if parity_failed else []) + legs_failed
         print(json.dumps(out), flush=True)
+        if parity_failed or legs_failed:      # the line is printed (it says what differs), and the run FAILS: a fast kernel whose results differ from the reference's is not done
+            ix.close()
+            raise SystemExit("bench.py: the device's records differ from the reference's SAM on the whole batch: %s" % out["parity_failed"])
     else:
         st.close()
     ix.close()
@@ -456,20 +642,25 @@ def extras(a, api, synth, ix_big, local, cache):
            "roofline_frac": ((int(c.n_fast_side) + int(c.n_fast_sa_steps)) * 64 / (float(c.ms_fast_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS) if float(c.ms_fast_kernel) > 0
                             else (int(c.n_side) + int(c.n_sa_steps)) * 64 / (float(c.ms_align_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if os.path.exists(exe) and not a.no_cpu_baseline:
-        nv = 3000
         tmp = tempfile.mkdtemp(prefix="h2benchs")
-        synth.write_reads_fasta(os.path.join(tmp, "r.fa"), reads[:nv])
-        subprocess.run([exe, "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-U", os.path.join(tmp, "r.fa"), "-S", os.path.join(tmp, "r.sam")],
-                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        rn, want = SU.parse_sam(os.path.join(tmp, "r.sam"))
-        res, aln = st.align_fetch(0, nv)
-        qn = [str(i) for i in range(nv)]
-        got = SU.render_selected(res, aln, rn, [reads[i] for i in range(nv)], qn)
-        leg["sam_checked_reads"] = nv
-        leg["sam_mismatching_reads"] = sum(1 for q in qn if got[q] != want[q])
+        if a.no_whole_parity:
+            nv = 3000
+            synth.write_reads_fasta(os.path.join(tmp, "r.fa"), reads[:nv])
+            subprocess.run([exe, "-f", "-p", "1", "--no-spliced-alignment", "-x", base, "-U", os.path.join(tmp, "r.fa"), "-S", os.path.join(tmp, "r.sam")],
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            rn, want = SU.parse_sam(os.path.join(tmp, "r.sam"))
+            res, aln = st.align_fetch(0, nv)
+            qn = [str(i) for i in range(nv)]
+            got = SU.render_selected(res, aln, rn, [reads[i] for i in range(nv)], qn)
+            leg["sam_checked_reads"] = nv
+            leg["sam_mismatching_reads"] = sum(1 for q in qn if got[q] != want[q])
+            if leg["sam_mismatching_reads"]:
+                raise SystemExit("bench.py: the E. coli-size leg differs from the reference SAM")
+        else:      # all 1 000 000 reads of the timed batch: the device's records -> SAM against the reference binary
+            synth.write_reads_fasta(os.path.join(tmp, "r.fa"), reads)
+            leg["parity_whole_batch"] = whole_batch_parity(api, base, st, codes, offs, None, None, [str(i) for i in range(n)], int(st.align_params().khits),
+                                                           os.path.join(tmp, "r.fa"), None, tmp=tmp, paired=False)
         shutil.rmtree(tmp, ignore_errors=True)
-        if leg["sam_mismatching_reads"]:
-            raise SystemExit("bench.py: the E. coli-size leg differs from the reference SAM")
     ex["ecoli_se"] = leg
     # Smith-Waterman kernels (a23-a25, opt-in path of the reference): the first 65536 reads framed around their true position
     nsw = 65536
@@ -570,7 +761,7 @@ def sam_parity(base, f1, f2, nv, tmp, opts=()):
             "against": "oracle/_ref/hisat2-align-s -p 8 --reorder (complete SAM lines)", **json.load(open(os.path.join(tmp, "stats.json")))}
 
 
-def timed_pairs(api, synth, base, local, m1, m2, steps=5):
+def timed_pairs(api, synth, base, local, m1, m2, steps=5, whole_parity=True):
     c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
     n = len(m1)
     names = [str(i) for i in range(n)]
@@ -594,6 +785,13 @@ def timed_pairs(api, synth, base, local, m1, m2, steps=5):
            "pairs_still_flagged_overflow": int(c.n_overflow), "pairs_with_concordant": int(c.n_aligned),
            "ranks_per_pair": int(c.n_rank) / n, "sides_per_pair": int(c.n_side) / n, "sa_steps_per_pair": int(c.n_sa_steps) / n,
            "index_device_bytes": int(ix.info.device_bytes)}
+    if whole_parity and os.path.exists(os.path.join(REF, "hisat2-align-s")):
+        # the whole batch on the device (the stream's results of the run above) against the reference binary, every SAM line
+        tmp = tempfile.mkdtemp(prefix="h2whole")
+        f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
+        synth.write_reads_fasta(f1, m1); synth.write_reads_fasta(f2, m2)
+        leg["parity_whole_batch"] = whole_batch_parity(api, base, st, c1, o1, c2, o2, names, int(st.align_params().khits), f1, f2, tmp=tmp)
+        shutil.rmtree(tmp, ignore_errors=True)
     st.close(); ix.close()
     return leg
 
@@ -618,7 +816,7 @@ def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, 
     m1, m2 = synth.make_pairs(contigs, npairs, 101, SEED + 78, sub_rate=0.005)
     leg = {"workload": f"repeat-structured {glen} bp genome (interspersed families of ~300 bp and 1-6 kbp at 8-20 % divergence in a quarter of the bases, tandem arrays, segmental "
                        f"duplications; 24 contigs), linear index, {npairs} x 2 x 101 bp pairs, --no-spliced-alignment -k 5", "index_build_s": t_build}
-    leg.update(timed_pairs(api, synth, base, local, m1, m2))
+    leg.update(timed_pairs(api, synth, base, local, m1, m2, whole_parity=not a.no_whole_parity and not a.no_cpu_baseline))
     tmp = tempfile.mkdtemp(prefix="h2rep")
     f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
     synth.write_reads_fasta(f1, m1[:nparity]); synth.write_reads_fasta(f2, m2[:nparity])
@@ -640,7 +838,7 @@ def graph256_leg(a, api, synth, local, cache, glen=256_000_000, every=250, npair
     m1, m2 = synth.make_pairs(alt, npairs, 101, SEED + 79, frag_mean=300, frag_sd=30, sub_rate=0.005)
     leg = {"workload": f"configs[3] shape: SNP-graph index over a seeded {glen} bp genome, a variant every ~{every} bp, {npairs} x 2 x 101 bp pairs from the alternate haplotype, --no-spliced-alignment",
            "index_build": info}
-    leg.update(timed_pairs(api, synth, base, local, m1, m2))
+    leg.update(timed_pairs(api, synth, base, local, m1, m2, whole_parity=not a.no_whole_parity and not a.no_cpu_baseline))
     alg = (leg["ranks_per_pair"] + leg["sa_steps_per_pair"]) * npairs * 128
     leg["roofline"] = {"bound": "hbm", "kernel": "k_go_fast_graph + k_go<true> over the hand-ons (whole step)", "achieved": alg / (leg["ms_per_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": alg / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic": "(rank queries + SA-walk steps) x 128 B graph sides"}

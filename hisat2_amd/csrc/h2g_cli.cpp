@@ -384,6 +384,15 @@ int main(int argc, char** argv) {
 		// reference's bare default invocation `hisat2 -x idx -U reads` then simply works.  -p >= 2 / --ss-window are the throughput modes.
 		ss_window = ss_window_opt ? ss_window_opt : (threads < 2 ? 0u : 1000u * (uint32_t)threads);
 		ss_wave = ss_window ? ss_window : 1u;
+		// a wave sizes the streams and the result rows (one shard per device): bound it — the reference's own window at its largest useful
+		// -p (1000 x 256 threads) is far below this, and an absurd value would only be an allocation failure later
+		const uint32_t ss_wave_max = 4u * 1024u * 1024u;
+		if(ss_wave > ss_wave_max) {
+			fprintf(stderr, "hisat2-align-amd: --ss-window %u (or 1000 x -p) makes waves of more than %u reads; a wave is one resident batch per device "
+			                "(streams and result rows are sized by it, --batch does not apply to the temporary-splice-site mode): use --ss-window <= %u, "
+			                "or --no-temp-splicesite with --batch\n", ss_wave, ss_wave_max, ss_wave_max);
+			return 1;
+		}
 		batch = ss_wave;   // a wave is exactly one shard per device (want()): a smaller --batch would complete shards (and merge their junctions) in the middle of a wave
 	}
 	const bool paired = u.empty();
@@ -698,6 +707,12 @@ int main(int argc, char** argv) {
 		P.first_read_id = (uint32_t)next_id;
 		sg.first_id = next_id;
 		next_id += n;
+		// the chain mode (window 0: waves of ONE read) is exact and meant for small inputs; an input that turns out not to be small is told so,
+		// loudly and once (a small run's stderr stays the reference's summary, byte for byte)
+		if(temp_ss && ss_window == 0 && next_id - skip >= 20000 && next_id - skip - n < 20000 && !getenv("H2G_QUIET_CHAIN_WARNING"))
+			fprintf(stderr, "Warning: hisat2-align-amd: -p 1 with temporary splice sites is the reference's strict read-after-read chain (window 0, hisat2.cpp:3687): "
+			                "it runs as waves of ONE read - a device round trip and a database merge per read; 20000 reads in, this input is not small. "
+			                "Use -p >= 2 or --ss-window W (output == hisat2 -p W/1000 --reorder), or --no-temp-splicesite, for throughput.\n");
 		if(paired) {
 			if(h2g_set_mates(sg.st, b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n) != H2G_OK) die("h2g_set_mates");
 			if(h2g_align_pairs_run(sg.st, &P) != H2G_OK) die("h2g_align_pairs_run");

@@ -14,6 +14,7 @@
 // default capacities).  h2g_kernels.hip sees only GoArgs and the extern "C" launchers of H2G_GO_UNIT.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "h2g_core.h"
 #include "h2g_align.h"
 #include "h2g_go_args.h"
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	extern "C" void h2g_go_caps_##NAME(uint32_t* c) { c[0] = AL_MAX_GHITS; c[1] = AL_MAX_RESULTS; c[2] = AL_MAX_SEARCHED; c[3] = AL_MAX_DEPTH; c[4] = AL_MAX_PARTIAL; } \
 	extern "C" int h2g_go_launch_##NAME(const GoArgs* a, unsigned grid, hipStream_t st) { \
 		const unsigned lds = (unsigned)((sizeof(GoLds) + 3) / 4 * 4) + (a->paired ? 2u : 1u) * H2G_PK_LANE_WORDS * H2G_GO_THREADS * 4u; \
-		static bool lds_ok = false;   /* more than 64 KB of dynamic LDS is an opt-in */ \
-		if(!lds_ok) { if(hipFuncSetAttribute((const void*)k_go<GRAPH, WAVES, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok = true; } \
+		static std::atomic<unsigned long long> lds_ok{0};   /* more than 64 KB of dynamic LDS is an opt-in, per device: a mask over device ids */ \
+		int dev_ = 0; (void)hipGetDevice(&dev_); const unsigned long long bit_ = 1ull << (dev_ & 63); \
+		if(!(lds_ok.load(std::memory_order_relaxed) & bit_)) { if(hipFuncSetAttribute((const void*)k_go<GRAPH, WAVES, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok.fetch_or(bit_, std::memory_order_relaxed); } \
 		hipLaunchKernelGGL((k_go<GRAPH, WAVES, UNIT>), dim3(grid), dim3(H2G_GO_THREADS), lds, st, *a); \
 		return (int)hipGetLastError(); }

@@ -7,6 +7,7 @@
 // code site, let every lane run its read's control flow on registers / LDS up to the next request, store the state and push the slot to
 // the queue of what it asked for.  Reads that leave the fast path go to the general machine's list.
 // h2g_k_go_fast_graph.hip compiles this file once more with FG_GRAPH = 1 (graph indexes: h2g_fast.h) under its own symbol names.
+#include <atomic>
 #include "h2g_go_args.h"
 
 using namespace h2g;
@@ -312,8 +313,11 @@ extern "C" void FG_GEOMETRY(uint32_t* g) {
 }
 // `a` is the argument block in DEVICE memory
 extern "C" int FG_LAUNCH(const FastArgs* a, unsigned grid, hipStream_t st) {
-	static bool lds_ok = false;   // more than 64 KB of dynamic LDS is an opt-in
-	if(!lds_ok) { if(hipFuncSetAttribute((const void*)FG_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok = true; }
+	// more than 64 KB of dynamic LDS is an opt-in — per DEVICE (a process may drive several: hisat2-align-amd --gpus N), so the flag is a mask over device ids
+	static std::atomic<unsigned long long> lds_ok{0};
+	int dev = 0; (void)hipGetDevice(&dev);
+	const unsigned long long bit = 1ull << (dev & 63);
+	if(!(lds_ok.load(std::memory_order_relaxed) & bit)) { if(hipFuncSetAttribute((const void*)FG_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok.fetch_or(bit, std::memory_order_relaxed); }
 	hipLaunchKernelGGL(FG_KERNEL, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, a);
 	return (int)hipGetLastError();
 }

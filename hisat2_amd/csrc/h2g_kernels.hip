@@ -58,19 +58,29 @@ struct h2g_index {
 	uint64_t device_bytes = 0;
 };
 
-#define H2G_NBUF 3
+// The general machine's pass over run k's hand-ons is a LATENCY CHAIN: its length is its longest reads' (hundreds of dependent trips of
+// 60-100 us on a 115 KB workspace), not their number — 30 ms behind a 14.5 ms fast pass on the random GRCh38-size genome, 118 ms behind a 25 ms
+// fast pass on repeat-structured sequence (profiles/r04_NOTES.md §4-§6).  The stream therefore keeps up to H2G_MSTREAMS_MAX such passes in flight,
+// one per machine stream, next to the fast passes of the following runs: run k's pass goes to machine stream k % M and the hand-on list, the
+// counters and the argument block are buffered M + 1 deep.  M is a property of the stream (h2g_stream_tune "mstreams", H2G_MSTREAMS; default
+// H2G_MSTREAMS_DEFAULT).  A caller sees no difference: results are complete when a fetch / sync returns.
+#define H2G_MSTREAMS_MAX 8
+#define H2G_MSTREAMS_DEFAULT 4
+#define H2G_NBUF (H2G_MSTREAMS_MAX + 1)
 // the fast pass's two scheduling choices for PAIRED batches on a linear index (measured at GRCh38 size: profiles/r04_NOTES.md §4): reads a
 // workgroup hands on at the tail of an exhausted batch, and whether alignMate runs inside the pass (k_go_fast_am) or in the machine's pass
 #define H2G_DEFAULT_TAIL 16
 #define H2G_DEFAULT_ALIGN_MATE 0
 #define H2G_CNT_BLOCK 512u          // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
-#define H2G_MACH_MAXGRID 48u       // workgroups of a machine pass behind a fast pass (two such passes may be in flight)
+#define H2G_MACH_MAXGRID 48u       // workgroups of ONE machine pass behind a fast pass
+#define H2G_MACH_TOTAL 96u         // ... and of all machine passes in flight together (the CUs the fast pass leaves them; "mach_total")
 struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
 	// the general machine's pass over a fast pass's hand-ons runs on one of these, next to the fast passes of the FOLLOWING two batches:
 	// its few reads are long latency chains (about a fast pass's duration whatever their number), so two such passes are kept in flight
-	hipStream_t mst[2] = {nullptr, nullptr};
+	hipStream_t mst[H2G_MSTREAMS_MAX] = {};
+	unsigned mstreams = H2G_MSTREAMS_DEFAULT;   // machine passes kept in flight (1 .. H2G_MSTREAMS_MAX)
 	bool st2_busy = false;            // a machine stream may hold work
 	hipEvent_t ev_fast[H2G_NBUF], ev_mach[H2G_NBUF];
 	unsigned gen = 0;                 // go_run generation: bail list, counters and argument block are buffered H2G_NBUF deep by gen % H2G_NBUF
@@ -94,9 +104,9 @@ struct h2g_stream {
 		uint8_t* gws = nullptr; size_t gws_bytes = 0;     // GraphWS x lanes (graph indexes only)
 		uint8_t* sw = nullptr;  size_t sw_stride = 0, sw_lanes = 0;   // Smith-Waterman scratch (only with bowtie2_dp != 0)
 		uint8_t* sc = nullptr;  size_t sc_lanes = 0;                  // combineWith temp_scores per lane
-	} pool[4];                        // [2 * m + 0] main pass, [2 * m + 1] second pass of machine stream m (m = 0 also: passes on the first stream)
+	} pool[2 * H2G_MSTREAMS_MAX];     // [2 * m + 0] main pass, [2 * m + 1] second pass of machine stream m (m = 0 also: passes on the first stream)
 	uint32_t* dbg_buf = nullptr;      // development hook (H2G_GO_DBG_READ)
-	uint32_t* d_ovf_list[2] = {nullptr, nullptr};   // per machine stream: read ids whose workspace overflowed in the main pass (+ their count behind the list)
+	uint32_t* d_ovf_list[H2G_MSTREAMS_MAX] = {};   // per machine stream: read ids whose workspace overflowed in the main pass (+ their count behind the list)
 	unsigned ovf_cur = 0;             // the one the last run used
 	uint32_t* d_bail_list[H2G_NBUF] = {};  // read ids the fast pass handed on to the general machine (+ their count behind the list)
 	void* d_fast_args[H2G_NBUF] = {};
@@ -106,7 +116,7 @@ struct h2g_stream {
 	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
-	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4; long dbg_read = -1;
+	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int fast_reserve = -1; long dbg_read = -1;
 	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -127,7 +137,7 @@ struct h2g_stream {
 	bool has_mates = false, has_quals2 = false;
 	PairOut* d_pout = nullptr;
 	h2g_alnres* d_paln[2] = {nullptr, nullptr};
-	h2g_alnres* d_paln_ovf = nullptr; size_t paln_ovf_cap = 0;   // pairs with more records than pair_slots per mate (MachOut::ovf)
+	h2g_alnres* d_paln_ovf = nullptr; size_t paln_ovf_cap = 0; unsigned paln_ovf_parts = 0;   // pairs with more records than pair_slots per mate (MachOut::ovf): one part of paln_ovf_cap records per machine stream
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
 	size_t tmp_sz[4] = {0, 0, 0, 0};
@@ -178,9 +188,10 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	LocalPack lp;
 	int lrc = 1;                                             // 1: no local files (an index built without them loads for rank / search only)
 	std::thread tlocal;
-	if(o.load_local) tlocal = std::thread([&]() { lrc = load_local_pack(base, 0, lp); });
+	if(o.load_local) tlocal = std::thread([&]() { try { lrc = load_local_pack(base, 0, lp); } catch(...) { lrc = -2; } });   // (bad_alloc / length_error on a corrupt file must not escape the thread)
 	struct Joiner { std::thread& t; ~Joiner() { if(t.joinable()) t.join(); } } joiner{tlocal};      // (every early return below waits for it)
-	int rc = load_host_index(base, false, ix->host);
+	int rc;
+	try { rc = load_host_index(base, false, ix->host); } catch(...) { rc = -2; }   // a length read from a corrupt file: an allocation failure is a format error, not std::terminate across the C ABI
 	if(rc != 0) { if(tlocal.joinable()) tlocal.join(); delete ix; snprintf(g_err, sizeof g_err, "cannot read index %s", base); return rc == -1 ? H2G_ERR_IO : H2G_ERR_FORMAT; }
 	const HostGfm& g = ix->host.g;
 	fill_dgfm(g, ix->host.minK, &ix->dg);
@@ -431,7 +442,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	h2g_stream* s = new h2g_stream();
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-	for(int k = 0; k < 2; k++) HIPCHK(hipStreamCreateWithFlags(&s->mst[k], hipStreamNonBlocking));
+	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) HIPCHK(hipStreamCreateWithFlags(&s->mst[k], hipStreamNonBlocking));
 	HIPCHK(hipHostMalloc((void**)&s->h_fast_args, sizeof(FastArgs) * H2G_NBUF));
 	HIPCHK(hipHostMalloc((void**)&s->h_bails, 4 * H2G_NBUF)); for(int k = 0; k < H2G_NBUF; k++) s->h_bails[k] = 0;
 	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
@@ -452,6 +463,8 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 0); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
 		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
+		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", -1);
+		{ const long m = env("H2G_MSTREAMS", H2G_MSTREAMS_DEFAULT); s->mstreams = (unsigned)(m < 1 ? 1 : m > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : m); }
 	}
 	*out = s;
 	return H2G_OK;
@@ -459,15 +472,16 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 
 extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
-	(void)hipStreamSynchronize(s->st); for(int k = 0; k < 2; k++) (void)hipStreamSynchronize(s->mst[k]);
+	(void)hipStreamSynchronize(s->st); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamSynchronize(s->mst[k]);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
-	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 4; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	(void)hipFree(s->d_ovf_list[0]); (void)hipFree(s->d_ovf_list[1]); for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states);
+	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2 * H2G_MSTREAMS_MAX; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
+	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipFree(s->d_ovf_list[k]);
+	for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->dbg_buf);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
-	(void)hipStreamDestroy(s->st); for(int k = 0; k < 2; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails); (void)hipHostFree(s->h_fast_args);
+	(void)hipStreamDestroy(s->st); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails); (void)hipHostFree(s->h_fast_args);
 	delete s;
 }
 
@@ -475,7 +489,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 static hipError_t sync_all(h2g_stream* s) {
 	hipError_t e = hipStreamSynchronize(s->st);
 	if(e == hipSuccess && s->st2_busy) {
-		for(int k = 0; k < 2 && e == hipSuccess; k++) e = hipStreamSynchronize(s->mst[k]);
+		for(int k = 0; k < H2G_MSTREAMS_MAX && e == hipSuccess; k++) e = hipStreamSynchronize(s->mst[k]);
 		s->st2_busy = false;
 	}
 	return e;
@@ -1417,7 +1431,13 @@ extern "C" h2g_status h2g_sw_align(h2g_stream* s, const h2g_sw_query* q, size_t 
 	ws.mat_bytes = ((size_t)((maxlen + 63) / 64) * ndmax * 64) << (any_wide ? 1 : 0);
 	ws.rf_bytes = (ncolmax + 255) & ~(size_t)255;
 	ws.stride = 3 * ws.mat_bytes + ws.rf_bytes + (((size_t)maxlen * ncolmax * 2 + 255) & ~(size_t)255);
-	const size_t batch = n < 32768 ? n : 32768;                   // 32 k problems x ~93 KB = 3 GB of HBM workspace
+	// the batch is sized by BYTES, not by a problem count: a problem's stride runs from ~135 KB (101 rows, 8-bit cells: three H/E/F matrices + the
+	// second walk's mask matrix) to ~1 MB (256 rows, 16-bit cells), and the workspace sits next to a human-size index
+	const size_t ws_budget = (size_t)6 << 30;
+	size_t batch = ws_budget / ws.stride;
+	if(batch > 32768) batch = 32768;
+	if(batch < 256) batch = 256;
+	if(batch > n) batch = n;
 	const size_t bt_threads = ((batch + 255) / 256) * 256;
 	if(s->sw_ws_bytes < batch * ws.stride) {
 		(void)hipFree(s->d_sw_ws); s->d_sw_ws = nullptr; s->sw_ws_bytes = 0;
@@ -1796,7 +1816,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	// Runs queued back to back share the result arrays (rows per read, record stride): a machine pass still in flight may only meet a
 	// run over the same reads with the same options.  Anything else waits for the machine streams first.
 	if(s->st2_busy && (s->last_paired != (paired ? 1 : 0) || memcmp(&s->last_p, p, sizeof *p) != 0)) {
-		for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_]));
+		for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_]));
 		s->st2_busy = false;
 	}
 	s->last_p = *p; s->last_paired = paired ? 1 : 0;
@@ -1830,10 +1850,14 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(!p->no_spliced_alignment) { A.P.sc.donor_sum = s->ix->d_spl[0]; A.P.sc.acc_sum1 = s->ix->d_spl[1]; A.P.sc.acc_sum2 = s->ix->d_spl[2]; }
 	A.names1 = s->d_names; A.noffs1 = s->d_name_offs; A.names2 = s->d_names2; A.noffs2 = s->d_name_offs2;
 	A.paired = paired ? 1u : 0u;
-	if(!fast && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (the machine streams' pools are about to be used on the first stream)
-	{	// behind a fast pass the machine works on stream gen & 1 with that stream's pools, on at most H2G_MACH_MAXGRID workgroups
-		const size_t pgrid = fast && grid > H2G_MACH_MAXGRID ? (size_t)H2G_MACH_MAXGRID : (size_t)grid;
-		if((rc = go_pool_for(s, fast ? 2 * (int)(s->gen & 1u) : 0, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &A))) return rc;
+	if(!fast && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (the machine streams' pools are about to be used on the first stream)
+	const unsigned M = s->mstreams, NB = M + 1;                    // machine passes in flight, and the depth of the per-run buffers
+	unsigned mach_cap = s->tune.mach_total / M;                  // workgroups of one machine pass behind a fast pass
+	if(mach_cap > H2G_MACH_MAXGRID) mach_cap = H2G_MACH_MAXGRID;
+	if(mach_cap < 1) mach_cap = 1;
+	{	// behind a fast pass the machine works on stream gen % M with that stream's pools, on at most mach_cap workgroups
+		const size_t pgrid = fast && grid > mach_cap ? (size_t)mach_cap : (size_t)grid;
+		if((rc = go_pool_for(s, fast ? 2 * (int)(s->gen % M) : 0, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &A))) return rc;
 	}
 	memset(&A.O, 0, sizeof A.O);
 	if(!paired) {
@@ -1860,38 +1884,38 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		}
 		s->pair_slots = pslots;
 		A.O.pout = s->d_pout; A.O.paln[0] = s->d_paln[0]; A.O.paln[1] = s->d_paln[1]; A.O.pair_slots = pslots;
-		// Two halves, one per machine stream: the machine passes of two queued runs may be in flight together and each takes its blocks
+		// One part per machine stream: the machine passes of M queued runs may be in flight together and each takes its blocks
 		// from its own cursor.  Block offsets (PairOut::pad) are relative to the whole area, so whichever pass wrote a pair last, its block is found.
-		const size_t ovf_cap = s->max_reads / 4 > 65536 ? s->max_reads / 4 : 65536;   // records per half
-		if(s->paln_ovf_cap < ovf_cap) {
-			(void)hipFree(s->d_paln_ovf); s->d_paln_ovf = nullptr; s->paln_ovf_cap = 0;
-			HIPCHK(hipMalloc((void**)&s->d_paln_ovf, 2 * ovf_cap * sizeof(h2g_alnres)));
-			s->paln_ovf_cap = ovf_cap;
+		const size_t ovf_cap = s->max_reads / 4 > 65536 ? s->max_reads / 4 : 65536;   // records per part
+		if(s->paln_ovf_cap < ovf_cap || s->paln_ovf_parts < M) {
+			if(s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }
+			HIPCHK(hipStreamSynchronize(s->st));
+			(void)hipFree(s->d_paln_ovf); s->d_paln_ovf = nullptr; s->paln_ovf_cap = 0; s->paln_ovf_parts = 0;
+			HIPCHK(hipMalloc((void**)&s->d_paln_ovf, M * ovf_cap * sizeof(h2g_alnres)));
+			s->paln_ovf_cap = ovf_cap; s->paln_ovf_parts = M;
 		}
 		A.O.ovf = s->d_paln_ovf;
 	}
 	(void)hipGetLastError();
 	// the fast pass's hand-on list, the counters and its argument block are buffered H2G_NBUF deep: the general machine's pass over
 	// run k's hand-ons goes to machine stream k & 1 and may still be under way while the fast passes of runs k + 1 and k + 2 run
-	const unsigned gsel = s->gen % H2G_NBUF, msel = s->gen & 1u;
+	const unsigned gsel = s->gen % NB, msel = s->gen % M;
 	unsigned long long* const cblk = s->d_counters + H2G_CNT_BLOCK * gsel;
-	HIPCHK(hipStreamWaitEvent(s->st, s->ev_mach[gsel], 0));          // run k - H2G_NBUF's machine pass: done with this set of buffers
+	HIPCHK(hipStreamWaitEvent(s->st, s->ev_mach[gsel], 0));          // run k - NB's machine pass: done with this set of buffers
 	HIPCHK(hipMemsetAsync(cblk, 0, H2G_CNT_BLOCK * sizeof(unsigned long long), s->st));
 	A.counters = cblk;
 	A.work = reinterpret_cast<uint32_t*>(cblk + 14);
 	if(paired) {   // the cursor starts at this machine stream's half of the area
-		const uint32_t half = fast ? (s->gen & 1u) : 0u;
+		const uint32_t half = fast ? msel : 0u;
 		A.O.ovf_cursor = reinterpret_cast<uint32_t*>(cblk + 124);
 		A.O.ovf_cap = (uint32_t)((half + 1) * s->paln_ovf_cap);
 		if(half) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)A.O.ovf_cursor, (int)(half * s->paln_ovf_cap), 1, s->st));
 	}
 	A.list = nullptr; A.nlist = nullptr;
 	if(s->tune.dbg_read >= 0) {
-		static uint32_t* dbg = nullptr;
-		if(!dbg) HIPCHK(hipMalloc((void**)&dbg, (1u << 20) * 4));
-		HIPCHK(hipMemsetAsync(dbg, 0, (1u << 20) * 4, s->st));
-		A.dbg_buf = dbg; A.dbg_read = (uint32_t)s->tune.dbg_read;
-		s->dbg_buf = dbg;
+		if(!s->dbg_buf) HIPCHK(hipMalloc((void**)&s->dbg_buf, (1u << 20) * 4));      // (the stream's own: a device's memory, not the process's)
+		HIPCHK(hipMemsetAsync(s->dbg_buf, 0, (1u << 20) * 4, s->st));
+		A.dbg_buf = s->dbg_buf; A.dbg_read = (uint32_t)s->tune.dbg_read;
 	}
 	const int no_second = s->tune.no_second_pass;   // measurement / debugging knob
 	const bool second = !big_main && !no_second;
@@ -1908,8 +1932,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if(!linear) h2g_go_fast_graph_geometry(fgeo); else if(use_am) h2g_go_fast_am_geometry(fgeo); else h2g_go_fast_geometry(fgeo);
 		// CUs: one persistent fast workgroup each (LDS-bound), minus the few the machine pass of the PREVIOUS run may still hold
 		// (the machine takes ~150 hand-ons per workgroup in half the time of a fast pass; the count is the last finished fast pass's)
-		for(unsigned back = 1; back < H2G_NBUF && back <= s->gen; back++) {                     // the latest fast pass that is over
-			const unsigned b = (s->gen - back) % H2G_NBUF;
+		for(unsigned back = 1; back < NB && back <= s->gen; back++) {                           // the latest fast pass that is over
+			const unsigned b = (s->gen - back) % NB;
 			if(hipEventQuery(s->ev_fast[b]) == hipSuccess) { s->last_bails = s->h_bails[b]; break; }
 		}
 		(void)hipGetLastError();
@@ -1931,12 +1955,14 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		const unsigned mach_min = s->tune.mach_min;
 		unsigned mgrid = (unsigned)((s->last_bails + mach_div - 1) / (mach_div ? mach_div : 1u));
 		if(mgrid < mach_min) mgrid = mach_min;
-		if(mgrid > H2G_MACH_MAXGRID) mgrid = H2G_MACH_MAXGRID;
+		if(mgrid > mach_cap) mgrid = mach_cap;
 		// (Tried on repeat-rich sequence, 27 000 hand-ons: a share that follows the measured work of the two passes, m = 128 M / (F + M) — the machine's
 		// pass stayed a latency chain, 78 -> 66 ms on twice the workgroups, while the fast pass went 14.5 -> 49 ms on what was left; and the second pass
 		// on a stream of its own — the extra queues cost the common case 13 -> 20 ms per run.  Neither ships: profiles/r04_NOTES.md §6.)
 		size_t fwant = (s->n_reads + 127) / 128;                                                // small batches spread over the chip
-		const unsigned fmax = 256 - 2 * mgrid;                                                  // (two machine passes may be in flight)
+		unsigned reserve = s->tune.fast_reserve >= 0 ? (unsigned)s->tune.fast_reserve : M * mgrid;  // (M machine passes may be in flight)
+		if(reserve > 192) reserve = 192;
+		const unsigned fmax = 256 - reserve;
 		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > fmax ? fmax : fwant));
 		const size_t slot_bytes = (size_t)256 * fgeo[2] * fgeo[3];
 		if(s->fast_slot_bytes < slot_bytes) {
@@ -1979,7 +2005,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		// through pinned memory: a pageable source would make this call wait for everything queued on the stream (the previous run's fast
 		// pass), and the chip would idle while the host queues this run.  The staging block of this buffer set was last read by the upload
 		// of run k - H2G_NBUF, which is over once that run's fast pass is
-		if(s->gen >= H2G_NBUF && hipEventQuery(s->ev_fast[gsel]) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipEventSynchronize(s->ev_fast[gsel])); }
+		if(s->gen >= NB && hipEventQuery(s->ev_fast[gsel]) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipEventSynchronize(s->ev_fast[gsel])); }
 		FastArgs* const hF = reinterpret_cast<FastArgs*>(s->h_fast_args) + gsel;
 		*hF = F;
 		HIPCHK(hipMemcpyAsync(s->d_fast_args[gsel], hF, sizeof F, hipMemcpyHostToDevice, s->st));
@@ -2036,7 +2062,7 @@ extern "C" h2g_status h2g_align_run(h2g_stream* s, const h2g_align_params* p) { 
 extern "C" h2g_status h2g_align_pairs_run(h2g_stream* s, const h2g_align_params* p) { return go_run(s, p, true); }
 
 extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t first, size_t n) {
-	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
 	std::vector<ReadOut> tmp(n);
 	HIPCHK(hipMemcpyAsync(tmp.data(), s->d_rout + first, n * sizeof(ReadOut), hipMemcpyDeviceToHost, s->st));
@@ -2056,7 +2082,7 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 
 // ------------------------------------------------------------------------------------------ paired go(): fetch
 extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) {
-	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	if((aln1 || aln2) && s->pair_slots < H2G_PAIR_RES_CAP) return H2G_ERR_ARG;
 	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
@@ -2119,7 +2145,7 @@ static int gather_dense(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, 
 }
 
 extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res, h2g_alnres* aln, size_t aln_cap, uint64_t* aln_offs, size_t first, size_t n) {
-	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || !aln || !aln_offs || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
 	const h2g_status rc = h2g_align_fetch(s, res, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
@@ -2132,7 +2158,7 @@ extern "C" h2g_status h2g_align_fetch_dense(h2g_stream* s, h2g_read_result* res,
 extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, size_t cap1, uint64_t* offs1,
                                                   h2g_alnres* aln2, size_t cap2, uint64_t* offs2, size_t first, size_t n)
 {
-	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || !aln1 || !aln2 || !offs1 || !offs2 || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	const h2g_status rc = h2g_align_pairs_fetch(s, res, nullptr, nullptr, first, n);
 	if(rc != H2G_OK) return rc;
@@ -2151,21 +2177,26 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 }
 
 // development hook: measurement / debugging knobs of go_run by name.  Everything in flight is waited for first, so a change never meets a
-// queued run.  "fast" 0/1, "blocks_per_cu", "pair_slots", "no_second_pass", "mach_div", "mach_min", "dbg_read" (-1 = off), "tail", "align_mate"
+// queued run.  "fast" 0/1, "blocks_per_cu", "pair_slots", "no_second_pass", "mach_div", "mach_min", "dbg_read" (-1 = off), "tail", "align_mate",
+// "mstreams" (machine passes kept in flight, 1..H2G_MSTREAMS_MAX), "mach_total" (workgroups of all of them together), "fast_reserve" (CUs the fast pass leaves
+// free: -1 = as many as the machine passes in flight may hold)
 extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream* s, const char* key, long v) {
 	if(!s || !key) return H2G_ERR_ARG;
 	HIPCHK(sync_all(s));
-	for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_]));
+	for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_]));
 	const std::string k(key);
 	if(k == "fast") s->tune.fast = (int)v; else if(k == "blocks_per_cu") s->tune.blocks_per_cu = (int)v; else if(k == "pair_slots") s->tune.pair_slots = (int)v;
 	else if(k == "no_second_pass") s->tune.no_second_pass = (int)v; else if(k == "mach_div") s->tune.mach_div = (unsigned)v; else if(k == "mach_min") s->tune.mach_min = (unsigned)v;
-	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") s->tune.tail = (int)v; else if(k == "align_mate") s->tune.align_mate = (int)v; else return H2G_ERR_ARG;
+	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") s->tune.tail = (int)v; else if(k == "align_mate") s->tune.align_mate = (int)v;
+	else if(k == "mach_total") s->tune.mach_total = (unsigned)(v < 1 ? 1 : v); else if(k == "fast_reserve") s->tune.fast_reserve = (int)v;
+	else if(k == "mstreams") { s->mstreams = (unsigned)(v < 1 ? 1 : v > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : v); s->gen = 0; }   // (nothing is in flight: every buffer set is free)
+	else return H2G_ERR_ARG;
 	return H2G_OK;
 }
 
 // development hook (h2g_stream_tune "dbg_read" / env H2G_GO_DBG_READ=<read id>): the primitive requests of that read in the last go() launch, 8 words each
 extern "C" __attribute__((visibility("default"))) int h2g_go_debug_trace(h2g_stream* s, uint32_t* out, uint32_t cap_words) {
-	if(s && s->st2_busy) { for(int k_ = 0; k_ < 2; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !out || !s->dbg_buf) return H2G_ERR_ARG;
 	HIPCHK(sync_all(s));
 	HIPCHK(hipMemcpy(out, s->dbg_buf, (size_t)cap_words * 4, hipMemcpyDeviceToHost));

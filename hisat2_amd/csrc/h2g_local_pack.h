@@ -87,6 +87,7 @@ inline int load_local_pack(const std::string& base, uint32_t nPat, LocalPack& lp
 	const int32_t lor = (int32_t)u32at(f5, p5, &bad); p5 += 4;
 	const int32_t lfc = (int32_t)u32at(f5, p5, &bad); p5 += 8;
 	if(bad) return -2;
+	if((size_t)nlocal > f5.n / 20) return -2;                // every local-index header is at least 20 bytes: a count beyond that is a corrupt / truncated file (never reserve() on it)
 	struct Job { size_t src_sides, dst_sides, nsides, src_w[4], dst_w, nw[4]; };   // word arrays in packed order: ftab, eftab, offs (file 6), rstarts
 	std::vector<Job> jobs;
 	lp.desc.clear(); lp.zoffs.clear(); lp.first.clear();

@@ -501,6 +501,40 @@ void h2gemu_fast_check(Emu* e, const uint8_t* codes2, const uint32_t* offs2, con
 	delete ws;
 }
 
+// development: trips (primitive requests) of the general machine per read, by primitive — the length of a hard read's latency chain.
+// out[nids * 16]: [op] = requests of that primitive, [15] = control phases (mach_step calls)
+void h2gemu_pair_trips(Emu* e, const uint8_t* codes2, const uint32_t* offs2, const char* names1, const uint32_t* noffs1, const char* names2,
+                       const uint32_t* noffs2, const uint32_t* ids, size_t nids, uint32_t* out) {
+	AlnParams P; AlnCtx C;
+	emu_ctx(e, 1, &P, &C);
+	const bool paired = codes2 != nullptr;
+	AlignWS* ws = new AlignWS();
+	Mach M;
+	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
+	if(paired) { M.rd[1].codes = codes2; M.rd[1].offs = offs2; M.rd[1].quals = nullptr; }
+	std::vector<h2g_alnres> m1(64), m2(64);
+	for(size_t k = 0; k < nids; k++) {
+		const uint32_t i = ids[k];
+		uint32_t* o = out + k * 16;
+		for(int j = 0; j < 16; j++) o[j] = 0;
+		M.name[0] = names1 + noffs1[i]; M.namelen[0] = noffs1[i + 1] - noffs1[i];
+		M.name[1] = paired ? names2 + noffs2[i] : nullptr; M.namelen[1] = paired ? noffs2[i + 1] - noffs2[i] : 0;
+		MachOut O; O.rout = nullptr; O.aln = nullptr; O.aln_slots = 0; O.pout = nullptr; O.paln[0] = O.paln[1] = nullptr; O.pair_slots = 0;
+		PairOut onep; ReadOut oner;
+		if(paired) { O.pout = &onep - i; O.paln[0] = m1.data() - (size_t)i * 64; O.paln[1] = m2.data() - (size_t)i * 64; O.pair_slots = 64; }
+		else { O.rout = &oner - i; O.aln = m1.data() - (size_t)i * 64; O.aln_slots = 64; }
+		M.out = &O; M.paired_input = paired;
+		mach_begin(M, i, paired);
+		while(M.L.pc != PC_FINISHED || M.L.op != OP_NONE) {
+			mach_step(C, M);
+			o[15]++;
+			if(M.L.op != OP_NONE) { if(M.L.op < 15) o[M.L.op]++; mach_exec(C, M, M.L.op); }
+		}
+		M.L.pc = PC_IDLE;
+	}
+	delete ws;
+}
+
 // glf1_top_fused (one LF step of one row from sides held in registers) against map_glf1_nochar, and gw_walk_single against gw_resolve,
 // on `n` seeded rows of the global graph index and of the graph local indexes.  Returns the number of differing rows.
 uint64_t h2gemu_glf_fused_check(Emu* e, uint32_t n, uint64_t seed) {

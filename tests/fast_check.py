@@ -8,7 +8,7 @@ import numpy as np
 from h2gemu_py import Emu
 
 BAIL_REASONS = ["none", "input", "longpool", "subsample", "coords", "nghits", "edits", "depth", "localhits", "gsearch", "nres", "searched",
-                "redundant", "mate", "npairs", "partial", "straddle", "other", "indel", "tail"]
+                "redundant", "mate", "npairs", "partial", "straddle", "other", "indel", "tail", "iedges", "gwalk"]    # == h2g_fast.h FB_* (FB_COUNT entries: tests/test_fast_path_cpu.py checks it)
 
 
 def fast_check(base, reads1, reads2=None, names=None, quals=None, options=(), variant=""):

@@ -82,14 +82,22 @@ def test_stream_defaults_are_what_the_python_mirror_says():
     assert int(re.search(r"#define H2G_DEFAULT_ALIGN_MATE (\d+)", src).group(1)) == api.DEFAULT_ALIGN_MATE
 
 
-def test_pmc_record_was_taken_on_the_shipped_kernel_sources():
-    """profiles/r04_pmc_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE of the headline kernel at GRCh38 size) carries the hash of the kernel sources
-    it was taken on; bench.py attaches `roofline.traffic` only while that equals the hash of the sources in the tree (comments and blank space
-    apart).  A kernel change after the profile shows up here, not as a stale figure in the bench line."""
-    import json
+def test_pmc_record_is_attached_only_to_the_sources_it_was_taken_on():
+    """The newest profiles/rNN_pmc_traffic.json (rocprofv3 FETCH_SIZE / WRITE_SIZE of the headline kernel at GRCh38 size) carries the hash of the kernel
+    sources it was taken on; bench.py attaches `roofline.traffic` only while that equals the hash of the sources in the tree (comments and blank space
+    apart) and the workload is the record's.  A kernel change after the profile yields `traffic: null` + a note — never a stale figure in the bench line."""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-    assert rec["kernel_sources_sha16"] == bench.kernel_sources_sha16()
+    path, rec = bench.newest_pmc_record()
+    assert rec is not None and rec["kernel"].startswith("k_go_fast")
+    fresh = rec["kernel_sources_sha16"] == bench.kernel_sources_sha16()
+    r = {"traffic": None}
+    assert bench.attach_pmc_traffic(r, rec["pairs_per_launch"], rec["genome"], True) == fresh
+    if fresh:
+        assert r["traffic"] == rec["traffic_bytes_per_launch"] and r["traffic_record"].startswith("profiles/")
+    else:
+        assert r["traffic"] is None and "not attached" in r["traffic_note"]
+    r = {"traffic": None}                                           # another workload: never attached
+    assert not bench.attach_pmc_traffic(r, rec["pairs_per_launch"] // 2, rec["genome"], True) and r["traffic"] is None
     assert bench._strip_comments('a = "//x"; // c\n/* d */ b /* e\n f */ c\n\n') == 'a = "//x";\nb   c'

@@ -208,3 +208,17 @@ def test_staged_graph_lf_step_equals_the_fused_one(g1s_index):
     e.L.h2gemu_glf_staged_check.restype = C.c_uint64
     e.L.h2gemu_glf_staged_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
     assert e.L.h2gemu_glf_staged_check(e.h, 50000, 12, 5) == 0
+
+
+def test_bail_reason_names_cover_the_fb_enum():
+    """h2gemu_fast_check writes 2 + FB_COUNT words and bench.py reads FB_COUNT counters: both name lists must be the FB_* enum of h2g_fast.h,
+    entry for entry (a reason added to the enum alone would overflow the stats buffer / drop out of the report)"""
+    import re
+    import fast_check as FC
+    import bench
+    src = open(os.path.join(ROOT, "hisat2_amd", "csrc", "h2g_fast.h")).read()
+    body = src[src.index("FB_NONE = 0"):]
+    body = body[:body.index("FB_COUNT")]
+    names = [m.lower() for m in re.findall(r"FB_([A-Z]+)", body)]
+    assert names == FC.BAIL_REASONS
+    assert names == bench.BAIL_REASONS
