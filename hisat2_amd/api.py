@@ -348,7 +348,7 @@ EXPORTS = [
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_device_count", "h2g_ext_search", "h2g_local_index_of", "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
-    "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense",
+    "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense", "h2g_align_fetch_long_edits",
     "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph", "h2g_adjust_with_alt",
 ]
 
@@ -639,6 +639,18 @@ class Stream:
             if int(o1[n]) <= c1 and int(o2[n]) <= c2:
                 _chk(rc, "h2g_align_pairs_fetch_dense")
             c1, c2 = max(c1, int(o1[n])), max(c2, int(o2[n]))
+
+    def align_fetch_long_edits(self):
+        """the used prefix of the stream's long-edit area (records with nedits > MAX_EDITS: edits[0].pos is their offset in it) -> (Edit array or None, n)"""
+        n = C.c_size_t(0)
+        f = lib().h2g_align_fetch_long_edits
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        f(self.h, None, 0, C.byref(n))
+        if n.value == 0:
+            return None, 0
+        a = (Edit * n.value)()
+        _chk(f(self.h, a, n.value, C.byref(n)), "h2g_align_fetch_long_edits")
+        return a, n.value
 
     def align_pairs_run(self, params=None):
         params = params or self.align_params()

@@ -416,7 +416,7 @@ H2G_HD void hit_left_align(h2g_ghit* h, const SeqView& seq) {
 }
 
 H2G_HD void hit_push_edit(h2g_ghit* h, uint32_t pos, uint8_t chr, uint8_t qchr, uint8_t type) {
-	if(h->nedits >= H2G_MAX_EDITS) { h->overflow = 1; return; }
+	if(h->nedits >= H2G_GHIT_EDITS) { h->overflow = 1; return; }
 	h2g_edit& e = h->edits[h->nedits++];
 	e.pos = pos; e.chr = chr; e.qchr = qchr; e.type = type; e.pad = 0; e.snp = H2G_MAX;
 }
@@ -621,7 +621,7 @@ H2G_HD bool hit_combine(const DRef& ref, const DScoring& sc_in, const SeqView& s
 			if(i == maxscorei) {
 				const uint32_t left = this_toff + i + 1, right = other_toff + other_len - (len - i - 1);
 				const uint32_t skipLen = right - left;
-				if(a->nedits >= H2G_MAX_EDITS) a->overflow = 1;
+				if(a->nedits >= H2G_GHIT_EDITS) a->overflow = 1;
 				else a->edits[a->nedits++] = make_spl_edit(i + 1 + addoff, skipLen, maxspldir, site != nullptr, spl_probstore);
 			}
 		}
@@ -768,7 +768,7 @@ inline void align_params_defaults(h2g_align_params* p, bool linear) {
 struct AlnRec {
 	uint32_t fw, tidx, toff, len, trim5, trim3, nedits, splicescore;
 	int64_t  score;
-	h2g_edit edits[H2G_MAX_EDITS];   // as stored in the AlnRes: 5'-to-3' positions of the ORIGINAL read relative to the first aligned base
+	h2g_edit edits[H2G_GHIT_EDITS];  // as stored in the AlnRes: 5'-to-3' positions of the ORIGINAL read relative to the first aligned base
 };
 
 struct Frame {                 // one activation of hybridSearch_recur (spliced_aligner.h:331); `state` = the machine pc to resume at

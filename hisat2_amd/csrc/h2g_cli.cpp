@@ -597,6 +597,14 @@ int main(int argc, char** argv) {
 		size_t used = 0;
 		const double tq0 = now();
 		h2g_sam_set_first_read_id(sam, sg.first_id);
+		{	// records with more than H2G_MAX_EDITS edits (long deletions: one edit per base) keep their lists in the stream's long-edit area
+			static std::vector<h2g_edit> long_edits;
+			size_t nl = 0;
+			h2g_status lrc = h2g_align_fetch_long_edits(st, nullptr, 0, &nl);
+			if(nl) { long_edits.resize(nl); lrc = h2g_align_fetch_long_edits(st, long_edits.data(), long_edits.size(), &nl); }
+			if(lrc != H2G_OK) die("h2g_align_fetch_long_edits");
+			h2g_sam_set_long_edits(sam, nl ? long_edits.data() : nullptr, nl);
+		}
 		if(paired) {
 			pres.resize(n); ao1.assign(n + 1, 0); ao2.assign(n + 1, 0);
 			if(aln.size() < 2 * n + 64) aln.resize(2 * n + 64);

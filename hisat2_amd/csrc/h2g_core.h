@@ -663,7 +663,9 @@ H2G_HD int64_t calculate_score(const DScoring& sc, const SeqView& seq, h2g_ghit*
 }
 
 // ------------------------------------------------------------------------------------------ extend (a18)
+#ifndef H2G_NEW_EDITS           // edits ONE extension may add (the *_big units raise it with H2G_GHIT_EDITS: h2g_go_big.h)
 #define H2G_NEW_EDITS 24
+#endif
 H2G_HD uint8_t base_char(int c) { return (uint8_t)("ACGTN"[c]); }
 H2G_HD bool is_gap(uint8_t t) { return t == H2G_EDIT_READ_GAP || t == H2G_EDIT_REF_GAP; }
 // the edits getLeft / getRight / combineWith stop at: gaps and mismatches through a known SNP (hi_aligner.h:937-940, :981-984)
@@ -742,7 +744,7 @@ H2G_HD uint32_t align_no_alts(const DRef& ref, const SeqView& seq, uint32_t base
 		}
 	}
 	if(extlen > 0 && tmp_mm > 0) {   // commit the new edits
-		if(total > H2G_MAX_EDITS) { h->overflow = 1; return extlen; }
+		if(total > H2G_GHIT_EDITS) { h->overflow = 1; return extlen; }
 		if(left) {                   // new edits go to the front, in increasing read position
 			for(int k = (int)n_old - 1; k >= 0; k--) h->edits[k + tmp_mm] = h->edits[k];
 			for(uint32_t k = 0; k < tmp_mm; k++) h->edits[k] = ne[tmp_mm - 1 - k];

@@ -2,6 +2,20 @@
 // sets beyond the default capacities (-k up to 30 = --very-sensitive, --max-seeds up to 64).  Depth 128 is the reference's
 // own recursion limit (spliced_aligner.h:369).
 #pragma once
+// ... and the reference's edit lists are unbounded (hi_aligner.h:421 LinkedEList<EList<Edit>>; a deletion of n bases is n edits, edit.h): the working hit of
+// these units holds H2G_GHIT_EDITS of them (include/h2g.h: a per-translation-unit capacity; 32 in the default units, whose flagged reads come here).  A
+// record beyond the 32 inline entries of h2g_alnres leaves through the long-edit area (MachOut::ledits).  160 edits = a 101-base read at --score-min L,0,-4.8
+// all in deletions, or every base of a 160-base read mismatching.
+#ifndef H2G_GHIT_EDITS
+#define H2G_GHIT_EDITS 160
+#endif
+#ifndef H2G_NEW_EDITS
+#define H2G_NEW_EDITS 96
+#endif
+// (a slot of these units is ~5 MB: 256 reads in flight per workgroup keep the second pass's pool at its former size)
+#ifndef H2G_GO_SLOTS
+#define H2G_GO_SLOTS 256
+#endif
 #define AL_MAX_GHITS     64
 #define AL_MAX_SEARCHED  512
 #define AL_MAX_RESULTS   128

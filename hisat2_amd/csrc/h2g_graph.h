@@ -1042,14 +1042,14 @@ struct AwaFrame {
 // next ALT it expects (walking left: counting down; right: counting up, == the haplotype's size once it is exhausted)
 struct HtList { uint32_t ht[H2G_HT_CAP]; uint16_t idx[H2G_HT_CAP]; uint32_t n; };
 struct AwaWS {
-	h2g_edit tmp[H2G_MAX_EDITS];
+	h2g_edit tmp[H2G_GHIT_EDITS];
 	uint32_t ntmp;
 	AwaFrame fr[H2G_AWA_DEPTH];
 #if H2G_HAPLOTYPE
 	HtList ht[H2G_AWA_DEPTH];
 #endif
 	// candidate_edits (ELList<Edit,128,4>): other edit lists reaching the same best offset (adjustWithALT only)
-	h2g_edit cand[H2G_AWA_CAND][H2G_MAX_EDITS];
+	h2g_edit cand[H2G_AWA_CAND][H2G_GHIT_EDITS];
 	uint32_t cand_n[H2G_AWA_CAND], ncand;
 	h2g_ghit scratch;     // adjust_with_alt builds its candidate hit here
 };
@@ -1152,8 +1152,8 @@ H2G_HDN uint32_t align_with_alts(const DRef& ref, const DAlts& A, const SeqView&
 	RefCursor rc;
 	rc.init(&ref, tidx);
 #define AWA_RF(F, I) ((int64_t)(F).rfoff + (int64_t)(I) < 0 ? 4 : rc.get((int64_t)(F).rfoff + (int64_t)(I)))
-#define AWA_PUSH_FRONT(E) do { if(W->ntmp >= H2G_MAX_EDITS) h->overflow = 1; else { for(int q_ = (int)W->ntmp - 1; q_ >= 0; q_--) W->tmp[q_ + 1] = W->tmp[q_]; W->tmp[0] = (E); W->ntmp++; } } while(0)
-#define AWA_PUSH_BACK(E) do { if(W->ntmp >= H2G_MAX_EDITS) h->overflow = 1; else W->tmp[W->ntmp++] = (E); } while(0)
+#define AWA_PUSH_FRONT(E) do { if(W->ntmp >= H2G_GHIT_EDITS) h->overflow = 1; else { for(int q_ = (int)W->ntmp - 1; q_ >= 0; q_--) W->tmp[q_ + 1] = W->tmp[q_]; W->tmp[0] = (E); W->ntmp++; } } while(0)
+#define AWA_PUSH_BACK(E) do { if(W->ntmp >= H2G_GHIT_EDITS) h->overflow = 1; else W->tmp[W->ntmp++] = (E); } while(0)
 #define AWA_ERASE_FRONT(N) do { const uint32_t n_ = (N); for(uint32_t q_ = n_; q_ < W->ntmp; q_++) W->tmp[q_ - n_] = W->tmp[q_]; W->ntmp -= n_; } while(0)
 #define AWA_COMMIT() do { for(uint32_t q_ = 0; q_ < W->ntmp; q_++) h->edits[q_] = W->tmp[q_]; h->nedits = W->ntmp; } while(0)
 #define AWA_RETURN(V) do { ret = (V); sp--; goto next_frame; } while(0)

@@ -137,6 +137,8 @@ struct h2g_stream {
 	bool has_mates = false, has_quals2 = false;
 	PairOut* d_pout = nullptr;
 	h2g_alnres* d_paln[2] = {nullptr, nullptr};
+	// records with more than H2G_MAX_EDITS edits keep their lists here (MachOut::ledits): one part of ledits_cap edits and one cursor per machine stream
+	h2g_edit* d_ledits = nullptr; uint32_t* d_ledits_cur = nullptr; size_t ledits_cap = 0; unsigned ledits_parts = 0;
 	h2g_alnres* d_paln_ovf = nullptr; size_t paln_ovf_cap = 0; unsigned paln_ovf_parts = 0;   // pairs with more records than pair_slots per mate (MachOut::ovf): one part of paln_ovf_cap records per machine stream
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -478,7 +480,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipFree(s->d_ovf_list[k]);
 	for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->dbg_buf);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
-	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf);
+	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf); (void)hipFree(s->d_ledits); (void)hipFree(s->d_ledits_cur);
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
 	(void)hipStreamDestroy(s->st); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails); (void)hipHostFree(s->h_fast_args);
@@ -2029,6 +2031,21 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(!s->d_ovf_list[psel]) HIPCHK(hipMalloc((void**)&s->d_ovf_list[psel], (s->max_reads + 4) * 4));
 	uint32_t* const ovl = s->d_ovf_list[psel];
 	HIPCHK(hipMemsetAsync(ovl + s->max_reads, 0, 16, ms));
+	{	// the long-edit area: part psel and its cursor belong to this machine stream (the pass that used them last is over: same stream)
+		const size_t lcap = s->max_reads > (1u << 20) ? s->max_reads : (size_t)(1u << 20);
+		if(s->ledits_cap < lcap || s->ledits_parts < M) {
+			if(s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); }
+			HIPCHK(hipStreamSynchronize(s->st));
+			(void)hipFree(s->d_ledits); s->d_ledits = nullptr; s->ledits_cap = 0; s->ledits_parts = 0;
+			HIPCHK(hipMalloc((void**)&s->d_ledits, M * lcap * sizeof(h2g_edit)));
+			if(!s->d_ledits_cur) HIPCHK(hipMalloc((void**)&s->d_ledits_cur, H2G_MSTREAMS_MAX * 4));
+			s->ledits_cap = lcap; s->ledits_parts = M;
+			for(unsigned m_ = 0; m_ < H2G_MSTREAMS_MAX; m_++) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(s->d_ledits_cur + m_), (int)(m_ < M ? m_ * lcap : 0), 1, s->st));
+			HIPCHK(hipStreamSynchronize(s->st));
+		}
+		A.O.ledits = s->d_ledits; A.O.ledits_cursor = s->d_ledits_cur + psel; A.O.ledits_cap = (uint32_t)((psel + 1) * s->ledits_cap);
+		HIPCHK(hipMemsetD32Async((hipDeviceptr_t)A.O.ledits_cursor, (int)(psel * s->ledits_cap), 1, ms));
+	}
 	HIPCHK(hipEventRecord(s->ev[7], ms));
 	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], ms));
@@ -2174,6 +2191,34 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 	                     n, aln1, offs1, 0, s->d_pout + first, 0))) return r;
 	return gather_dense(s, s->d_paln[1] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
 	                    n, aln2, offs2, 2, s->d_pout + first, 1);
+}
+
+// The edit lists of the records with more than H2G_MAX_EDITS edits of the resident batch (include/h2g.h): the used prefix of the stream's long-edit
+// area, offsets as the records carry them in edits[0].pos.  *n = edits the prefix spans (0: no such record); H2G_ERR_ARG when cap is smaller.
+extern "C" h2g_status h2g_align_fetch_long_edits(h2g_stream* s, h2g_edit* out, size_t cap, size_t* n) {
+	if(!s || !n) return H2G_ERR_ARG;
+	*n = 0;
+	if(!s->ran_align || !s->d_ledits || !s->d_ledits_cur) return H2G_OK;
+	HIPCHK(hipSetDevice(s->ix->device));
+	if(s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }
+	HIPCHK(hipStreamSynchronize(s->st));
+	uint32_t cur[H2G_MSTREAMS_MAX];
+	HIPCHK(hipMemcpy(cur, s->d_ledits_cur, sizeof cur, hipMemcpyDeviceToHost));
+	size_t hi = 0;
+	for(unsigned m = 0; m < s->ledits_parts; m++) {
+		size_t end = cur[m]; const size_t lo = m * s->ledits_cap, top = (m + 1) * s->ledits_cap;
+		if(end > top) end = top;                       // (a full part: the reads that found no room are flagged)
+		if(end > lo) hi = end;
+	}
+	*n = hi;
+	if(hi == 0) return H2G_OK;
+	if(!out || cap < hi) return H2G_ERR_ARG;
+	for(unsigned m = 0; m < s->ledits_parts; m++) {
+		size_t end = cur[m]; const size_t lo = m * s->ledits_cap, top = (m + 1) * s->ledits_cap;
+		if(end > top) end = top;
+		if(end > lo) HIPCHK(hipMemcpy(out + lo, s->d_ledits + lo, (end - lo) * sizeof(h2g_edit), hipMemcpyDeviceToHost));
+	}
+	return H2G_OK;
 }
 
 // development hook: measurement / debugging knobs of go_run by name.  Everything in flight is waited for first, so a change never meets a

@@ -125,7 +125,14 @@ struct MachOut {
 	h2g_alnres* ovf = nullptr;
 	uint32_t*   ovf_cursor = nullptr;
 	uint32_t    ovf_cap = 0;
+	// a record with more edits than the H2G_MAX_EDITS inline entries of h2g_alnres (the units with the large workspace hold H2G_GHIT_EDITS of them:
+	// the reference's lists are unbounded, reportHit hi_aligner.h:6129-6166) keeps its whole list in this area: nedits says how many, edits[0].pos
+	// where they start, edits[0].snp == H2G_LONG_EDITS_TAG.  No room: the read is flagged (overflow bit 1, the edit capacity's).
+	h2g_edit*   ledits = nullptr;
+	uint32_t*   ledits_cursor = nullptr;
+	uint32_t    ledits_cap = 0;
 };
+#define H2G_LONG_EDITS_TAG 0x4c4f4e47u
 
 struct Lane {                 // the registers of one lane's machine
 	uint32_t pc, op;
@@ -1597,10 +1604,29 @@ H2G_MACH_FN void mach_op_sw(const AlnCtx& C, Mach& M) {
 	}
 }
 
-H2G_HD void mach_copy_rec(h2g_alnres& d, const AlnRec& r) {
+// returns false when a long record found no room in the long-edit area (the caller flags the read)
+H2G_HD bool mach_copy_rec(h2g_alnres& d, const AlnRec& r, const MachOut& O) {
 	d.fw = r.fw; d.tidx = r.tidx; d.toff = r.toff; d.len = r.len; d.trim5 = r.trim5; d.trim3 = r.trim3;
 	d.nedits = r.nedits; d.splicescore = r.splicescore; d.score = r.score;
+#if H2G_GHIT_EDITS > H2G_MAX_EDITS
+	if(r.nedits > H2G_MAX_EDITS) {
+		uint32_t at = H2G_MAX;
+		if(O.ledits && O.ledits_cursor) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			at = atomicAdd(O.ledits_cursor, r.nedits);
+#else
+			at = *O.ledits_cursor; *O.ledits_cursor += r.nedits;
+#endif
+			if(at + r.nedits > O.ledits_cap) at = H2G_MAX;
+		}
+		if(at == H2G_MAX) { d.nedits = 0; return false; }
+		for(uint32_t e = 0; e < r.nedits; e++) O.ledits[(size_t)at + e] = r.edits[e];
+		d.edits[0].pos = at; d.edits[0].chr = d.edits[0].qchr = d.edits[0].type = d.edits[0].pad = 0; d.edits[0].snp = H2G_LONG_EDITS_TAG;
+		return true;
+	}
+#endif
 	for(uint32_t e = 0; e < r.nedits; e++) d.edits[e] = r.edits[e];
+	return true;
 }
 
 H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M) {
@@ -1624,8 +1650,8 @@ H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M) {
 		}
 		o.best = b == INT64_MIN ? INT32_MIN : (int32_t)b; o.secbest = sb == INT64_MIN ? INT32_MIN : (int32_t)sb;
 		o.best_h2 = (uint32_t)(uint64_t)bh; o.secbest_h2 = (uint32_t)(uint64_t)sbh;
+		if(O.aln) for(uint32_t k = 0; k < o.nselect && k < O.aln_slots; k++) if(!mach_copy_rec(O.aln[(size_t)i * O.aln_slots + k], ws->m[0].res[o.select[k]], O)) o.overflow |= 1;
 		if(O.rout) O.rout[i] = o;
-		if(O.aln) for(uint32_t k = 0; k < o.nselect && k < O.aln_slots; k++) mach_copy_rec(O.aln[(size_t)i * O.aln_slots + k], ws->m[0].res[o.select[k]]);
 		M.L.a0 = o.nselect > 0; M.L.a1 = o.overflow != 0;
 	} else {
 		PairOut o;
@@ -1647,13 +1673,13 @@ H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M) {
 		}
 		o.nrank = ws->nrank; o.nsteps = ws->nsteps; o.depth = ws->nframes_max; o.nside = ws->nside; o.rnd_state = gv.rnd; o.pad = blk == H2G_MAX ? 0u : blk + 1u;
 		for(uint32_t k = 0; k < AL_MAX_PAIRS; k++) { o.pair_i[k] = k < ws->npairs ? ws->pair_i[k] : 0; o.pair_j[k] = k < ws->npairs ? ws->pair_j[k] : 0; }
-		if(O.pout) O.pout[i] = o;
 		for(int m = 0; m < 2; m++) {
 			if(!O.paln[m]) continue;
 			const uint32_t n = o.nres[m] < O.pair_slots ? o.nres[m] : O.pair_slots;
-			for(uint32_t k = 0; k < n; k++) mach_copy_rec(O.paln[m][(size_t)i * O.pair_slots + k], ws->m[m].res[k]);
-			if(blk != H2G_MAX) for(uint32_t k = 0; k < o.nres[m]; k++) mach_copy_rec(O.ovf[(size_t)blk + (m ? o.nres[0] : 0u) + k], ws->m[m].res[k]);
+			for(uint32_t k = 0; k < n; k++) if(!mach_copy_rec(O.paln[m][(size_t)i * O.pair_slots + k], ws->m[m].res[k], O)) o.overflow |= 1;
+			if(blk != H2G_MAX) for(uint32_t k = 0; k < o.nres[m]; k++) if(!mach_copy_rec(O.ovf[(size_t)blk + (m ? o.nres[0] : 0u) + k], ws->m[m].res[k], O)) o.overflow |= 1;
 		}
+		if(O.pout) O.pout[i] = o;
 		M.L.a0 = o.npairs > 0; M.L.a1 = o.overflow != 0;
 	}
 }

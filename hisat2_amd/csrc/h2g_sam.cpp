@@ -50,6 +50,7 @@ struct h2g_sam {
 	bool no_sq = false, omit_sec_seq = false;             // --no-sq (hisat2.cpp:4130), --omit-sec-seq (aln_sink.h:3190)
 	bool report_discordant = true, report_mixed = true;   // --no-discordant / --no-mixed clear them (ReportingParams::discord / mixed aln_sink.h:272)
 	bool tlen_adjust = true;                              // --no-templatelen-adjustment clears it (aln_sink.h:2070-2076)
+	const h2g_edit* long_edits = nullptr; size_t n_long_edits = 0;   // h2g_sam_set_long_edits: the caller's buffer (not owned), of the batch being formatted
 	// what SpliceSiteDB keeps per site for --novel-splicesite-outfile (splice_site.cpp:243-276): the number of lines written across it
 	// and the smallest edit distance among them; file / index sites enter with 0 / 0 (SpliceSite::init splice_site.h:237)
 	struct SiteStat { uint64_t numreads = 0; uint32_t editdist = 0; };
@@ -83,6 +84,16 @@ struct Score {        // AlnScore (aligner_result.h:44-330): score, then hisat2_
 };
 // AlnScore::calculate_hisat2_score aligner_result.h:322-350: score, repeat (never), transcript (1 = spliced: near splice sites,
 // reportHit hi_aligner.h:6100-6143), splice score (mean intron length of the short-anchored splices / 100), trimmed bases
+// A record with more edits than its H2G_MAX_EDITS inline entries (a long deletion: one edit per base, edit.h) keeps them in the long-edit area
+// of its batch (h2g_align_fetch_long_edits -> h2g_sam_set_long_edits): edits[0].pos is their offset there.  Every reader goes through ED().
+thread_local const h2g_edit* tl_long_edits = nullptr;
+thread_local size_t tl_long_edits_n = 0;
+inline const h2g_edit* ED(const h2g_alnres& r) {
+	if(r.nedits <= H2G_MAX_EDITS) return r.edits;
+	static const h2g_edit none[1] = {};
+	if(!tl_long_edits || (size_t)r.edits[0].pos + r.nedits > tl_long_edits_n) return none;      // (format_* refuses such a batch before any line is written)
+	return tl_long_edits + r.edits[0].pos;
+}
 int64_t hisat2_score(int64_t sc, uint32_t trim, int transcript = 0, uint32_t splicescore = 0) {
 	if(sc > INT32_MAX) sc = INT32_MAX; else if(sc < INT32_MIN) sc = INT32_MIN;
 	const int64_t t = trim > 0xFFFF ? 0 : 0xFFFF - (int64_t)trim;
@@ -94,7 +105,7 @@ Score score_of(const h2g_alnres& r) {
 	Score s; s.valid = true; s.score = r.score;
 	int transcript = 0;                  // 2: every splice is a database site, 1: spliced (GenomeHit::spliced hi_aligner.h:1086)
 	bool all_known = true;
-	for(uint32_t i = 0; i < r.nedits; i++) if(r.edits[i].type == EDIT_SPL) { transcript = 1; all_known = all_known && (r.edits[i].pad >> 7) != 0; }
+	for(uint32_t i = 0; i < r.nedits; i++) if(ED(r)[i].type == EDIT_SPL) { transcript = 1; all_known = all_known && (ED(r)[i].pad >> 7) != 0; }
 	if(transcript && all_known) transcript = 2;
 	s.h2 = hisat2_score(r.score, r.trim5 + r.trim3, transcript, r.splicescore);
 	return s;
@@ -182,7 +193,7 @@ struct Stacked { std::string ref, rel, read; std::vector<uint8_t> snp; std::vect
 void stack_alignment(const h2g_alnres& r, const std::string& seq /* aligned strand, ASCII */, Stacked& st) {
 	static thread_local std::vector<Ed> ed;
 	ed.resize(r.nedits);
-	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = r.edits[i].pos; ed[i].chr = (char)r.edits[i].chr; ed[i].qchr = (char)r.edits[i].qchr; ed[i].type = r.edits[i].type; ed[i].snp = r.edits[i].snp; ed[i].skip = r.edits[i].type == EDIT_SPL ? spl_len(r.edits[i]) : 0; }
+	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = ED(r)[i].pos; ed[i].chr = (char)ED(r)[i].chr; ed[i].qchr = (char)ED(r)[i].qchr; ed[i].type = ED(r)[i].type; ed[i].snp = ED(r)[i].snp; ed[i].skip = ED(r)[i].type == EDIT_SPL ? spl_len(ED(r)[i]) : 0; }
 	// h2g_alnres trims are those of the GenomeHit (left / right of the aligned strand) == trimLS / trimRS after the swap
 	st.trimLS = r.trim5; st.trimRS = r.trim3;
 	const uint32_t len_trimmed = (uint32_t)seq.size() - st.trimLS - st.trimRS;
@@ -289,8 +300,8 @@ int64_t fragment_length(const h2g_alnres& me, const h2g_alnres& o, bool meMate1,
 	auto coords = [](const h2g_alnres& r, int64_t& st, int64_t& en, int64_t& st2, int64_t& en2) {
 		int64_t ext = r.len, spl = 0;
 		for(uint32_t i = 0; i < r.nedits; i++) {
-			if(r.edits[i].type == EDIT_REF_GAP) ext--; else if(r.edits[i].type == EDIT_READ_GAP) ext++;
-			else if(r.edits[i].type == EDIT_SPL) spl += spl_len(r.edits[i]);
+			if(ED(r)[i].type == EDIT_REF_GAP) ext--; else if(ED(r)[i].type == EDIT_READ_GAP) ext++;
+			else if(ED(r)[i].type == EDIT_SPL) spl += spl_len(ED(r)[i]);
 		}
 		st = (int64_t)r.toff - r.trim5; en = (int64_t)r.toff + ext - 1 + r.trim3;
 		st2 = st + spl; en2 = en + spl;
@@ -338,9 +349,9 @@ void add_splice_sites(const h2g_alnres& r, uint32_t rdlen, uint64_t rdid, std::v
 	if(r.trim5 + r.trim3 > 0) return;
 	static thread_local std::vector<Ed> ed;
 	ed.resize(r.nedits);
-	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = r.edits[i].pos; ed[i].chr = (char)r.edits[i].chr; ed[i].qchr = (char)r.edits[i].qchr; ed[i].type = r.edits[i].type; ed[i].snp = r.edits[i].snp; ed[i].skip = r.edits[i].type == EDIT_SPL ? spl_len(r.edits[i]) : 0; }
+	for(uint32_t i = 0; i < r.nedits; i++) { ed[i].pos = ED(r)[i].pos; ed[i].chr = (char)ED(r)[i].chr; ed[i].qchr = (char)ED(r)[i].qchr; ed[i].type = ED(r)[i].type; ed[i].snp = ED(r)[i].snp; ed[i].skip = ED(r)[i].type == EDIT_SPL ? spl_len(ED(r)[i]) : 0; }
 	std::vector<uint32_t> dirs(r.nedits);
-	for(uint32_t i = 0; i < r.nedits; i++) dirs[i] = spl_dir(r.edits[i]);
+	for(uint32_t i = 0; i < r.nedits; i++) dirs[i] = spl_dir(ED(r)[i]);
 	if(!r.fw) { invert(ed, rdlen); std::reverse(dirs.begin(), dirs.end()); }
 	const uint32_t minAnchorLen = 15, SPL_UNKNOWN = 1;
 	auto is_mm_gap = [](const Ed& e) { return e.type == EDIT_MM || e.type == EDIT_READ_GAP || e.type == EDIT_REF_GAP; };
@@ -393,7 +404,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	// an alignment whose edits are all mismatches (nearly every line) needs no stacked form: its CIGAR is one M run between the soft
 	// clips and its MD:Z follows from the mismatch positions; what buildCigar / buildMdz would make of the stacked strings is written directly
 	bool simple = rs != nullptr;
-	if(rs) for(uint32_t i = 0; i < rs->nedits; i++) if(rs->edits[i].type != EDIT_MM) { simple = false; break; }
+	if(rs) for(uint32_t i = 0; i < rs->nedits; i++) if(ED(*rs)[i].type != EDIT_MM) { simple = false; break; }
 	if(rs && !simple) stack_alignment(*rs, seq, st);
 	if(rs && S.collect_novel && tl_novel) add_splice_sites(*rs, rd.len, tl_rdid, *tl_novel);
 	put_read_name(o, rd, fl.partOfPair());
@@ -459,7 +470,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	const size_t nalts = S.alts.size();
 	size_t num_mm = 0, num_go = 0, num_gx = 0, NM = 0;
 	for(uint32_t i = 0; i < rs->nedits; i++) {                            // on the edits as stored (5'-relative)
-		const h2g_edit* e = rs->edits;
+		const h2g_edit* e = ED(*rs);
 		if(e[i].type == EDIT_SPL) continue;
 		if(e[i].type == EDIT_MM) { if(e[i].snp >= nalts) num_mm++; }
 		else if(e[i].type == EDIT_READ_GAP) {
@@ -470,7 +481,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 			while(i + 1 < rs->nedits && e[i + 1].pos == e[i].pos + 1 && e[i + 1].type == EDIT_REF_GAP) { i++; if(e[i].snp >= nalts) num_gx++; }
 		}
 	}
-	for(uint32_t i = 0; i < rs->nedits; i++) if(rs->edits[i].type != EDIT_SPL && rs->edits[i].snp >= nalts) NM++;
+	for(uint32_t i = 0; i < rs->nedits; i++) if(ED(*rs)[i].type != EDIT_SPL && ED(*rs)[i].snp >= nalts) NM++;
 	o += "\tXM:i:"; put(o, (int64_t)num_mm);
 	o += "\tXO:i:"; put(o, (int64_t)num_go);
 	o += "\tXG:i:"; put(o, (int64_t)num_gx);
@@ -480,7 +491,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 		const uint32_t lt = rd.len - rs->trim5 - rs->trim3;
 		uint32_t at = 0;                                               // the next position of the aligned strand not yet accounted for
 		for(uint32_t k = 0; k < rs->nedits; k++) {
-			const h2g_edit& e = rs->edits[rs->fw ? k : rs->nedits - 1 - k];
+			const h2g_edit& e = ED(*rs)[rs->fw ? k : rs->nedits - 1 - k];
 			const uint32_t pos = rs->fw ? e.pos : lt - 1 - e.pos;
 			if(pos > at) put(o, (int64_t)(pos - at)); else o.push_back('0');
 			o.push_back((char)e.chr);
@@ -503,8 +514,8 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	} else {   // XS:A: sam.h:925-940 with AlnRes::spliced_whichsense_transcript aligner_result.h:1289 (unstranded library)
 		uint32_t sense = 1;
 		for(uint32_t i = 0; i < rs->nedits; i++) {
-			if(rs->edits[i].type != EDIT_SPL) continue;
-			const uint32_t d = spl_dir(rs->edits[i]);
+			if(ED(*rs)[i].type != EDIT_SPL) continue;
+			const uint32_t d = spl_dir(ED(*rs)[i]);
 			if(sense == 1) sense = d;
 			else if(d != 1) {
 				if((sense == 2 || sense == 4) && d != 2 && d != 4) { sense = 1; break; }
@@ -518,7 +529,7 @@ void append_mate(const h2g_sam& S, std::string& o, const Rd& rd, const Rd* rdo, 
 	{
 		static thread_local std::vector<Ed> ed;
 		ed.resize(rs->nedits);
-		for(uint32_t i = 0; i < rs->nedits; i++) { ed[i].pos = rs->edits[i].pos; ed[i].type = rs->edits[i].type; ed[i].snp = rs->edits[i].type == EDIT_SPL ? 0xffffffffu : rs->edits[i].snp /* a splice edit keeps its probscore there */; ed[i].chr = ed[i].qchr = 0; }
+		for(uint32_t i = 0; i < rs->nedits; i++) { ed[i].pos = ED(*rs)[i].pos; ed[i].type = ED(*rs)[i].type; ed[i].snp = ED(*rs)[i].type == EDIT_SPL ? 0xffffffffu : ED(*rs)[i].snp /* a splice edit keeps its probscore there */; ed[i].chr = ed[i].qchr = 0; }
 		const uint32_t len_trimmed = rd.len - rs->trim5 - rs->trim3;
 		if(!rs->fw) invert(ed, len_trimmed);
 		bool snp_first = true;
@@ -636,8 +647,9 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 		std::string& o = parts[t];
 		o.reserve((e - b) * 760);                       // (two lines of a 101 bp pair; longer reads grow it)
 		tl_novel = &mets[t].novel;
+		tl_long_edits = S->long_edits; tl_long_edits_n = S->n_long_edits;
 		for(size_t i = b; i < e; i++) { tl_rdid = S->first_read_id + i; one(i, o, mets[t]); }
-		tl_novel = nullptr;
+		tl_novel = nullptr; tl_long_edits = nullptr; tl_long_edits_n = 0;
 	};
 	if(T == 1) work(0);
 	else {
@@ -666,6 +678,14 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 }
 }  // namespace
 
+extern "C" void h2g_sam_set_long_edits(h2g_sam* S, const h2g_edit* area, size_t n) { if(S) { S->long_edits = n ? area : nullptr; S->n_long_edits = area ? n : 0; } }
+namespace {
+// every long record of a batch must point inside the area the caller set: checked before a line is written (H2G_ERR_ARG otherwise)
+bool long_records_ok(const h2g_sam* S, const h2g_alnres* a, size_t n) {
+	for(size_t i = 0; i < n; i++) if(a[i].nedits > H2G_MAX_EDITS && (!S->long_edits || (size_t)a[i].edits[0].pos + a[i].nedits > S->n_long_edits)) return false;
+	return true;
+}
+}  // namespace
 extern "C" void h2g_sam_set_threads(h2g_sam* S, int threads) { if(S) S->threads = threads < 1 ? 1 : threads; }
 // AlnSink::printAlSumm aln_sink.h:1637-1815 (old-style summary, -k mode: no repeat threshold, discordant + mixed reporting on)
 extern "C" size_t h2g_sam_summary(const h2g_sam* S, char* out, size_t cap) {
@@ -885,7 +905,11 @@ extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* c
 extern "C" h2g_status h2g_sam_format_unpaired_dense(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
                                                     const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
                                                     const h2g_alnres* aln, const uint64_t* aln_offs, char* out, size_t cap, size_t* used)
-{ return aln_offs ? format_unpaired(S, codes, offs, quals, nb, noffs, n, res, aln, aln_offs, out, cap, used) : H2G_ERR_ARG; }
+{
+	if(!aln_offs || !S || !aln) return H2G_ERR_ARG;
+	if(!long_records_ok(S, aln, aln_offs[n])) return H2G_ERR_ARG;     // a long record without its area (h2g_sam_set_long_edits)
+	return format_unpaired(S, codes, offs, quals, nb, noffs, n, res, aln, aln_offs, out, cap, used);
+}
 
 static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
                                 const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
@@ -1013,6 +1037,7 @@ extern "C" h2g_status h2g_sam_format_paired_dense(const h2g_sam* S, const uint8_
                                                   const h2g_pair_result* res, const h2g_alnres* aln1, const uint64_t* aln_offs1,
                                                   const h2g_alnres* aln2, const uint64_t* aln_offs2, uint32_t khits, char* out, size_t cap, size_t* used)
 {
-	if(!aln_offs1 || !aln_offs2) return H2G_ERR_ARG;
+	if(!aln_offs1 || !aln_offs2 || !S || !aln1 || !aln2) return H2G_ERR_ARG;
+	if(!long_records_ok(S, aln1, aln_offs1[n]) || !long_records_ok(S, aln2, aln_offs2[n])) return H2G_ERR_ARG;   // a long record without its area (h2g_sam_set_long_edits)
 	return format_paired(S, codes1, offs1, quals1, nb1, noffs1, codes2, offs2, quals2, nb2, noffs2, n, res, aln1, aln_offs1, aln2, aln_offs2, khits, out, cap, used);
 }

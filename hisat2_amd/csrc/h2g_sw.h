@@ -236,7 +236,7 @@ struct SwOut {   // mirrors h2g_sw_result
 	int64_t  off;                // refcoord().off()
 	uint32_t nedits, gaps, overflow, rnd;
 	int64_t  refl, refr;
-	h2g_edit edits[H2G_MAX_EDITS];
+	h2g_edit edits[H2G_GHIT_EDITS];   // (== H2G_MAX_EDITS wherever the struct crosses the C ABI: h2g_kernels.hip)
 };
 
 H2G_HD uint32_t sw_lcg_next(uint32_t* last) {   // RandomSource::nextU32 random_source.h:52-61
@@ -402,7 +402,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 				col--; ct = cur == 3 ? 0 : 1; score -= cur == 3 ? rdgapo : rdgape; gaps++;
 			}
 			if(has_edit) {
-				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed;        // (more edits than a record holds: flagged below, if this walk is the one reported)
+				if(ned < H2G_GHIT_EDITS) o->edits[ned] = ed;        // (more edits than a record holds: flagged below, if this walk is the one reported)
 				ned++;
 			}
 		}
@@ -420,7 +420,7 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 			if(mt != 1) {
 				h2g_edit ed;
 				ed.pad = 0; ed.snp = H2G_MAX; ed.pos = row; ed.chr = (uint8_t)sw_mask2dna(refm); ed.qchr = (uint8_t)"ACGTN"[readc]; ed.type = H2G_EDIT_MM;
-				if(ned < H2G_MAX_EDITS) o->edits[ned] = ed;
+				if(ned < H2G_GHIT_EDITS) o->edits[ned] = ed;
 				ned++;
 				score -= (readc > 3 || refm > 15) ? P.sc.nPen : mm_penalty(P.sc, seq.qual(row) - 33);
 			}
@@ -429,8 +429,8 @@ H2G_HD void sw_gather_backtrace(const SwMats& m, const SwParams& P, const SeqVie
 		}
 		*rnd = m.wide ? reseed : reseed + 1;                   // aligner_sw.cpp:840 (8-bit branch) / :906 (16-bit branch: rnd.init(reseed))
 		if(ok) {
-			if(ned > H2G_MAX_EDITS) o->overflow = 1;
-			const uint32_t n = ned < H2G_MAX_EDITS ? ned : H2G_MAX_EDITS;
+			if(ned > H2G_GHIT_EDITS) o->overflow = 1;
+			const uint32_t n = ned < H2G_GHIT_EDITS ? ned : H2G_GHIT_EDITS;
 			for(uint32_t a = 0; a < n / 2; a++) { h2g_edit t = o->edits[a]; o->edits[a] = o->edits[n - 1 - a]; o->edits[n - 1 - a] = t; }   // res.reverse()
 			o->found = 1; o->score = (int32_t)score; o->nedits = n; o->off = (int64_t)col + rect.refl; o->gaps = gaps;
 			break;

@@ -182,6 +182,12 @@ enum { H2G_EDIT_READ_GAP = 1, H2G_EDIT_REF_GAP = 2, H2G_EDIT_MM = 3, H2G_EDIT_SP
  * splLen = chr | qchr << 8 | (pad & 15) << 16 (introns up to 2^20), splDir = (pad >> 4) & 7 (splice_site.h:37-43: 1 unknown, 2 +, 3 -,
  * 4 semi +, 5 semi -), knownSpl = pad >> 7; `snp` holds the float bits of SpliceSiteDB::probscore(donor_seq, acceptor_seq). */
 typedef struct { uint32_t pos; uint8_t chr, qchr, type, pad; uint32_t snp; /* Edit::snpID: index into the ALT list, H2G_MAX = none */ } h2g_edit;   /* Edit, edit.h */
+/* h2g_ghit is also the WORKING hit of the go() kernels.  The go() units with the large workspace (the second pass, h2g_go_big.h) are compiled with
+ * longer edit lists in it (H2G_GHIT_EDITS, set before this header is read): the reference's lists are unbounded (hi_aligner.h:421), and a deletion of
+ * n bases is n edits.  Every entry point of this header sees the default, H2G_MAX_EDITS. */
+#ifndef H2G_GHIT_EDITS
+#define H2G_GHIT_EDITS H2G_MAX_EDITS
+#endif
 typedef struct {
 	uint32_t read;
 	uint32_t fw, rdoff, len, trim5, trim3, tidx, toff, joinedOff;
@@ -189,7 +195,7 @@ typedef struct {
 	int64_t  score;
 	uint32_t nedits;
 	uint32_t overflow;         /* edit list exceeded H2G_MAX_EDITS: caller must take its own path */
-	h2g_edit edits[H2G_MAX_EDITS];
+	h2g_edit edits[H2G_GHIT_EDITS];
 } h2g_ghit;
 typedef struct { uint32_t mm, max_leftext, max_rightext; } h2g_ext_args;
 typedef struct { uint32_t extended, leftext, rightext; } h2g_ext_result;
@@ -360,6 +366,14 @@ H2G_EXPORT h2g_status h2g_align_pairs_fetch(h2g_stream*, h2g_pair_result* res /*
 /* Dense variant: the nres[m] report events of each mate back to back (see h2g_align_fetch_dense) */
 H2G_EXPORT h2g_status h2g_align_pairs_fetch_dense(h2g_stream*, h2g_pair_result* res /* [n] */, h2g_alnres* aln1, size_t cap1, uint64_t* aln_offs1 /* [n+1] */,
                                                   h2g_alnres* aln2, size_t cap2, uint64_t* aln_offs2 /* [n+1] */, size_t first_read, size_t n_reads);
+
+/* Records beyond H2G_MAX_EDITS edits.  The reference's edit lists are unbounded (hi_aligner.h:421, reportHit :6129-6166) and a deletion of n bases
+ * is n edits (edit.h).  A record whose list does not fit its H2G_MAX_EDITS inline entries says so with nedits > H2G_MAX_EDITS: its edits live in the
+ * stream's long-edit area, at offset edits[0].pos (edits[0].snp == 0x4c4f4e47 marks it; the other inline entries are unspecified).  This call returns
+ * the used prefix of that area for the resident batch: *n = edits it spans (0 when the batch has no such record); H2G_ERR_ARG with *n set when cap is
+ * smaller.  include/h2g_sam.h: h2g_sam_set_long_edits hands it to the formatter.  Capacity of the working lists: 160 edits per alignment (the units with
+ * the large workspace, which the flagged reads of the default units are re-run by); beyond that a read keeps overflow bit 1. */
+H2G_EXPORT h2g_status h2g_align_fetch_long_edits(h2g_stream*, h2g_edit* out, size_t cap, size_t* n);
 
 /* ---- counters (roofline numerators) ------------------------------------------------- */
 typedef struct {

@@ -74,6 +74,11 @@ H2G_EXPORT size_t     h2g_sam_novel_splice_sites_text(const h2g_sam*, char* out,
 /* --score-min as given to the aligner (h2g_align_params.score_min_*): MAPQ is relative to it (unique.h:214-222) */
 H2G_EXPORT void       h2g_sam_set_score_min(h2g_sam*, uint32_t type, double constant, double coeff);
 
+/* Records with more than H2G_MAX_EDITS edits (nedits > H2G_MAX_EDITS: a long deletion is one edit per base, edit.h) keep their edit list in the
+ * long-edit area of their batch (h2g_align_fetch_long_edits, include/h2g.h).  Hand the area of the batch about to be formatted to the handle (not
+ * copied: it must stay valid through the format call; n = 0 clears it).  A dense format call over such a record without its area is H2G_ERR_ARG. */
+H2G_EXPORT void       h2g_sam_set_long_edits(h2g_sam*, const h2g_edit* area, size_t n);
+
 /* "@HD / @SQ / @PG" header as the reference prints it (sam.h printHeader: VN:1.0 SO:unsorted, one @SQ per reference,
  * @PG ID:hisat2 PN:hisat2 VN:<version> CL:"<cmdline>").  Returns bytes needed; writes at most cap. */
 H2G_EXPORT size_t     h2g_sam_header(const h2g_sam*, const char* cmdline, char* out, size_t cap);
