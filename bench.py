@@ -31,6 +31,9 @@ import time
 
 import numpy as np
 
+# (before torch / HIP initialise: one h2g stream is 1 + M HIP streams that must run side by side; ROCclr's default 4 hardware queues would serialise them)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

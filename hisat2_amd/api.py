@@ -11,6 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_TAIL, DEFAULT_ALIGN_MATE = 16, 0     # H2G_DEFAULT_TAIL / H2G_DEFAULT_ALIGN_MATE of csrc/h2g_kernels.hip (what a stream does without H2G_FAST_TAIL / H2G_FAST_AM)
+# one h2g stream = 1 + up to 8 HIP streams that must run side by side; ROCclr's default of 4 hardware queues would serialise them (h2g_kernels.hip).
+# Read at HIP runtime initialisation: set before anything touches the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = os.environ.get("H2G_LIBPATH") or os.path.join(_HERE, "libh2g.so")   # H2G_LIBPATH: development builds (tools/)
 MAX = 0xFFFFFFFF
 MAX_EDITS = 32

@@ -222,6 +222,7 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 }  // namespace
 
 int main(int argc, char** argv) {
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);   // before the HIP runtime initialises: the streams of one h2g stream run side by side (h2g_kernels.hip)
 	std::string base, outfn, stats_fn;
 	std::vector<std::string> u, m1, m2;
 	bool fasta = false, nospliced = false, notempss = false, nohead = false, parse_only = false, no_unal = false;

@@ -117,6 +117,41 @@ __device__ __forceinline__ uint32_t ring_pop(GoLds* Q, uint32_t q, int lane, uin
 	return n;
 }
 
+// as ring_pop, for the lanes [at, at + room) of the wave: tops a thin trip up from another ring of the same primitive.  Returns the count popped.
+__device__ __forceinline__ uint32_t ring_pop_at(GoLds* Q, uint32_t q, int lane, uint32_t at, uint32_t room, uint32_t* slot) {
+	uint32_t n = 0, h = 0;
+	if(lane == 0) {
+		for(;;) {
+			h = __atomic_load_n(&Q->head[q], __ATOMIC_RELAXED);
+			const uint32_t t = __atomic_load_n(&Q->tail[q], __ATOMIC_RELAXED);
+			n = t - h;
+			if(n == 0) break;
+			if(n > room) n = room;
+			if(atomicCAS(&Q->head[q], h, h + n) == h) break;
+		}
+	}
+	n = (uint32_t)__shfl((int)n, 0); h = (uint32_t)__shfl((int)h, 0);
+	if((uint32_t)lane >= at && (uint32_t)lane < at + n) {
+		const uint32_t pos = (h + (uint32_t)lane - at) & (H2G_GO_SLOTS - 1);
+		uint16_t v;
+		while((v = __atomic_load_n(&Q->ring[q][pos], __ATOMIC_RELAXED)) == H2G_RING_EMPTY) __builtin_amdgcn_s_sleep(1);
+		__atomic_store_n(&Q->ring[q][pos], (uint16_t)H2G_RING_EMPTY, __ATOMIC_RELAXED);
+		*slot = v;
+	}
+	return n;
+}
+// the rings (request sites) that wait for primitive `op`, as a bit set over ring ids
+__device__ __forceinline__ unsigned long long mach_rings_of_op(uint32_t op) {
+	unsigned long long m = 0;
+#define X(OPC, PC) if(op == OPC) m |= 1ull << SITE_##PC;
+	H2G_MACH_SITES(X)
+#undef X
+	return m;
+}
+#ifndef H2G_GO_TOPUP
+#define H2G_GO_TOPUP 40      // a trip that popped fewer slots than this from the longest ring is topped up from the other rings of the same primitive
+#endif
+
 // UNIT tells the builds of different translation units (capacities) apart: same template arguments would be ONE symbol
 template <bool GRAPH, int WAVES_PER_SIMD, int UNIT>
 __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
@@ -225,8 +260,19 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 				continue;
 			}
 			const uint32_t op = mach_site_op(bestq);      // the ring is a request site: one primitive, one resume pc
-			const uint32_t n = ring_pop(Q, bestq, lane, &slot);
+			uint32_t n = ring_pop(Q, bestq, lane, &slot);
 			if(n == 0) continue;
+			// A thin trip (the machine behind a fast pass works on the hard reads only: a few hundred slots over ~34 rings) is topped up from the
+			// other request sites of the SAME primitive: the primitive still runs at one code site for every lane, the control flow behind it
+			// resumes at a few pcs instead of one.  Measured on the repeat-structured leg: profiles/r05_NOTES.md.
+			if(n < H2G_GO_TOPUP) {
+				unsigned long long cand = __ballot(cnt > 0 && lane >= 1 && lane < H2G_GO_NQ) & mach_rings_of_op(op) & ~(1ull << bestq);
+				while(cand && n < 64) {
+					const uint32_t q2 = (uint32_t)__ffsll((long long)cand) - 1u;
+					cand &= cand - 1ull;
+					n += ring_pop_at(Q, q2, lane, n, 64u - n, &slot);
+				}
+			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			have = (uint32_t)lane < n;
 			if(have) {

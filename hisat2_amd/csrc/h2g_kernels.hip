@@ -65,15 +65,18 @@ struct h2g_index {
 // counters and the argument block are buffered M + 1 deep.  M is a property of the stream (h2g_stream_tune "mstreams", H2G_MSTREAMS; default
 // H2G_MSTREAMS_DEFAULT).  A caller sees no difference: results are complete when a fetch / sync returns.
 #define H2G_MSTREAMS_MAX 8
-#define H2G_MSTREAMS_DEFAULT 4
+#define H2G_MSTREAMS_DEFAULT 8
 #define H2G_NBUF (H2G_MSTREAMS_MAX + 1)
+// CUs the fast pass's persistent grid leaves free for the machine passes: -1 = as many as M passes may hold; 0 = none — the fast pass asks for every
+// CU and the hardware dispatcher places machine workgroups as CUs come free (the fast pass draws its reads from one counter, so a late workgroup costs nothing)
+#define H2G_FAST_RESERVE_DEFAULT 0
 // the fast pass's two scheduling choices for PAIRED batches on a linear index (measured at GRCh38 size: profiles/r04_NOTES.md §4): reads a
 // workgroup hands on at the tail of an exhausted batch, and whether alignMate runs inside the pass (k_go_fast_am) or in the machine's pass
 #define H2G_DEFAULT_TAIL 16
 #define H2G_DEFAULT_ALIGN_MATE 0
 #define H2G_CNT_BLOCK 512u          // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
 #define H2G_MACH_MAXGRID 48u       // workgroups of ONE machine pass behind a fast pass
-#define H2G_MACH_TOTAL 96u         // ... and of all machine passes in flight together (the CUs the fast pass leaves them; "mach_total")
+#define H2G_MACH_TOTAL 128u        // ... and of all machine passes in flight together ("mach_total": a pass gets at most mach_total / mstreams workgroups)
 struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
@@ -116,7 +119,7 @@ struct h2g_stream {
 	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
-	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int fast_reserve = -1; long dbg_read = -1;
+	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int fast_reserve = H2G_FAST_RESERVE_DEFAULT; long dbg_read = -1;
 	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -438,6 +441,13 @@ extern "C" h2g_status h2g_index_synth_graph_sides(uint64_t num_sides, uint64_t s
 }
 
 // ------------------------------------------------------------------------------------------ stream
+// A stream of this library is 1 + H2G_MSTREAMS_MAX HIP streams whose kernels must be able to run side by side.  ROCclr maps HIP streams onto
+// GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue serialise — measured: four machine passes "in flight" on the
+// default 4 queues ran one after the other (repeat-structured leg: 127 ms per step against 78 ms with 16 queues; profiles/r05_NOTES.md).  The variable is
+// read when the HIP runtime initialises, so it is set when this library is loaded (never overriding the caller's own setting); a process that
+// initialises HIP before loading libh2g.so sets it itself (bench.py, hisat2-align-amd and hisat2_amd/api.py do).
+__attribute__((constructor)) static void h2g_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t max_bases, h2g_stream** out) {
 	if(!ix || !out) return H2G_ERR_ARG;
 	HIPCHK(hipSetDevice(ix->device));
@@ -465,7 +475,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 0); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
 		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
-		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", -1);
+		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", H2G_FAST_RESERVE_DEFAULT);
 		{ const long m = env("H2G_MSTREAMS", H2G_MSTREAMS_DEFAULT); s->mstreams = (unsigned)(m < 1 ? 1 : m > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : m); }
 	}
 	*out = s;
@@ -1751,24 +1761,7 @@ static int go_pool_for(h2g_stream* s, int which, const GoUnit& u, size_t slots, 
 	return H2G_OK;
 }
 
-// read ids whose main-pass workspace overflowed -> list (the count lands behind the list's n slots)
-__global__ __launch_bounds__(256) void k_collect_overflow(const ReadOut* rout, const PairOut* pout, uint32_t n, uint32_t* list, uint32_t* count) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if(i >= n) return;
-	const uint32_t ovf = rout ? rout[i].overflow : pout[i].overflow;
-	if(ovf) list[atomicAdd(count, 1u)] = i;
-}
-
-// the same over the ids of a list (behind a fast pass only the reads it handed on can carry a flag); few workgroups, grid-stride: this
-// runs next to two persistent kernels
-__global__ __launch_bounds__(256) void k_collect_overflow_of(const uint32_t* ids, const uint32_t* nids, const ReadOut* rout, const PairOut* pout, uint32_t* list, uint32_t* count) {
-	const uint32_t n = *nids;
-	for(uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-		const uint32_t i = ids[k];
-		const uint32_t ovf = rout ? rout[i].overflow : pout[i].overflow;
-		if(ovf) list[atomicAdd(count, 1u)] = i;
-	}
-}
+// (the reads whose main-pass workspace overflowed are listed by the pass itself — MachOut::defer_list — and their rows left alone until the second pass writes them)
 
 // HI_Aligner::go for every read (pair) of the resident batch.  Two passes, both asynchronous on the stream: the main pass
 // with the default workspace, then the reads it flagged (a list overflowed) once more through the large-workspace unit,
@@ -2046,16 +2039,13 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		A.O.ledits = s->d_ledits; A.O.ledits_cursor = s->d_ledits_cur + psel; A.O.ledits_cap = (uint32_t)((psel + 1) * s->ledits_cap);
 		HIPCHK(hipMemsetD32Async((hipDeviceptr_t)A.O.ledits_cursor, (int)(psel * s->ledits_cap), 1, ms));
 	}
+	if(second) { A.O.defer_list = ovl; A.O.defer_count = ovl + s->max_reads; }     // overflowed reads: listed for the second pass, their rows untouched
 	HIPCHK(hipEventRecord(s->ev[7], ms));
 	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], ms));
 	if(second) {
 		const GoUnit& B = go_unit(linear, true, spl);
-		uint32_t* cnt = ovl + s->max_reads;
-		if(fast) hipLaunchKernelGGL(k_collect_overflow_of, dim3(8), dim3(256), 0, ms, (const uint32_t*)A.list, (const uint32_t*)A.nlist,
-		                            paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, ovl, cnt);
-		else hipLaunchKernelGGL(k_collect_overflow, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, ms,
-		                        paired ? nullptr : s->d_rout, paired ? s->d_pout : nullptr, (uint32_t)s->n_reads, ovl, cnt);
+		uint32_t* cnt = ovl + s->max_reads;       // (filled by the main pass itself: MachOut::defer_list)
 		const unsigned bgrid = 4;
 		uint32_t bgeo[4];
 		B.geometry(bgeo);
@@ -2064,7 +2054,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		A2.counters = cblk + 256;           // (a region of its own: in H2G_GO_PROF builds a pass writes up to 96 words behind its counters)
 		A2.work = reinterpret_cast<uint32_t*>(cblk + 15);
 		A2.list = ovl; A2.nlist = cnt;
-		A2.defer_overflow = 0;
+		A2.defer_overflow = 0; A2.O.defer_list = nullptr; A2.O.defer_count = nullptr;
 		if(B.launch(&A2, bgrid, ms) != 0) return set_err("go() second pass launch", hipGetLastError());
 	}
 	HIPCHK(hipEventRecord(s->ev[8], ms));

@@ -131,6 +131,11 @@ struct MachOut {
 	h2g_edit*   ledits = nullptr;
 	uint32_t*   ledits_cursor = nullptr;
 	uint32_t    ledits_cap = 0;
+	// A pass that is followed by a second pass over the reads whose lists overflowed its workspace (go_run) does not write such a read's partial
+	// result: it appends the read to this list and leaves the rows alone.  Every store into the result rows is then FINAL content — runs queued
+	// back to back over the same reads (fast passes and several machine passes in flight) write identical bytes, whatever their order.
+	uint32_t*   defer_list = nullptr;
+	uint32_t*   defer_count = nullptr;
 };
 #define H2G_LONG_EDITS_TAG 0x4c4f4e47u
 
@@ -1635,6 +1640,15 @@ H2G_MACH_FN void mach_finish(const AlnCtx& C, Mach& M) {
 	AlignWS* ws = M.ws;
 	GoVars& gv = ws->gv;
 	const uint32_t i = M.read;
+	if(O.defer_list && ws->overflow) {           // the second pass re-runs this read from scratch with the large workspace
+#if defined(__HIP_DEVICE_COMPILE__)
+		O.defer_list[atomicAdd(O.defer_count, 1u)] = i;
+#else
+		O.defer_list[(*O.defer_count)++] = i;
+#endif
+		M.L.a0 = 0; M.L.a1 = 1;
+		return;
+	}
 	if(!paired_input) {
 		ReadOut o;
 		Rng rnd; rnd.last = gv.rnd;

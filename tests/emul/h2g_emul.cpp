@@ -337,6 +337,28 @@ void h2gemu_align(Emu* e, uint32_t no_spliced, const char* names, const uint32_t
 }
 
 
+// go() with the result rows of the C ABI (h2g_align_fetch's layout: `slots` h2g_alnres per read, the selected alignments in order) and the long-edit
+// area (MachOut::ledits): the path a record with more than H2G_MAX_EDITS edits takes out of the large-workspace units.  *ledits_used = edits written.
+void h2gemu_align_abi(Emu* e, uint32_t no_spliced, const char* names, const uint32_t* name_offs, ReadOut* outs, h2g_alnres* rows, uint32_t slots,
+                      h2g_edit* ledits, uint32_t ledits_cap, uint32_t* ledits_used) {
+	AlnParams P; AlnCtx C;
+	emu_ctx(e, no_spliced, &P, &C);
+	AlignWS* ws = new AlignWS();
+	Mach M;
+	M.ws = ws; M.rd[0] = e->reads(); M.rd[1] = M.rd[0];
+	uint32_t cursor = 0;
+	MachOut O; O.rout = outs; O.aln = rows; O.aln_slots = slots; O.pout = nullptr; O.paln[0] = O.paln[1] = nullptr; O.pair_slots = 0;
+	O.ledits = ledits; O.ledits_cursor = &cursor; O.ledits_cap = ledits_cap;
+	for(uint32_t i = 0; i < M.rd[0].n; i++) {
+		M.name[0] = names + name_offs[i]; M.namelen[0] = name_offs[i + 1] - name_offs[i];
+		M.name[1] = nullptr; M.namelen[1] = 0;
+		mach_run_single(C, M, i, false, O);
+	}
+	*ledits_used = cursor;
+	delete ws;
+}
+uint32_t h2gemu_ghit_edits() { return H2G_GHIT_EDITS; }
+
 // paired go(): mate 2 passed separately; names1/names2 as in the FASTA files
 void h2gemu_align_pairs(Emu* e, uint32_t no_spliced, const uint8_t* codes2, const uint32_t* offs2, const char* names1,
                         const uint32_t* noffs1, const char* names2, const uint32_t* noffs2, PairOut* outs, AlnRec* recs1, AlnRec* recs2) {

@@ -104,11 +104,15 @@ def _novel_out(L, h, options):
         open(options[list(options).index("--novel-splicesite-outfile") + 1], "wb").write(buf.raw[:need])
 
 
-def format_unpaired(L, base, reads, names, res, aln, quals=None, options=()):
-    """res: array of api.ReadResult (or same-layout numpy), aln: api.AlnRes * (n*ALN_CAP) -> list of SAM lines"""
+def format_unpaired(L, base, reads, names, res, aln, quals=None, options=(), long_edits=None):
+    """res: array of api.ReadResult (or same-layout numpy), aln: api.AlnRes * (n*ALN_CAP) -> list of SAM lines.
+    long_edits = (api.Edit array, n): the batch's long-edit area (records with nedits > MAX_EDITS, h2g_align_fetch_long_edits)"""
     h = C.c_void_p()
     assert L.h2g_sam_open(base.encode(), C.byref(h)) == 0
     _score_min(L, h, options)
+    if long_edits is not None and long_edits[1]:
+        L.h2g_sam_set_long_edits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.h2g_sam_set_long_edits(h, long_edits[0], long_edits[1])
     codes, offs = flat(reads)
     nb, noffs = flat_names(names)
     n = len(reads)

@@ -64,8 +64,6 @@ OPTS = {"default": [], "sensitive": ["--sensitive"], "k10sec": ["-k", "10", "--s
 @pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("index", ["lin", "snp"])
 def test_real_sequence_sam_identical(chr22, index, paired, reads, opt):
-    if opt == "verysensitive" and reads == "drawn":
-        pytest.skip("--score-min L,0,-1 lets a handful of the drawn reads exceed the 32-edit / 64-record capacities: the command line names them and exits 3 (by design); covered on the example reads")
     d = chr22
     tag = f"{index}_{'pe' if paired else 'se'}_{reads}_{opt}"
     if paired:
