@@ -35,7 +35,9 @@ namespace h2g {
 #define FG_FE     4                     // edits kept per hit (more: bail), 16 bits each
 #define FG_HW     (6 + FG_FE / 2 + FG_GRAPH * FG_FE)   // words of a stored hit (graph: + the ALT id of each edit)
 #define FG_LW     3                     // words of a long partial hit in the pool (graph: + 3 cold words at FW_LONGX: node range, in-edge list)
-#define FG_NLONG  3                     // partial hits longer than minK + 2 waiting for getAnchorHits
+#define FG_NLONG  3                     // partial hits longer than minK + 2 waiting for getAnchorHits: the hot ones ...
+#define FG_NLONGC 3                     // ... and the cold ones behind them (repeat-rich reads; FState::pool_x says which are taken, so the common read never looks)
+#define FG_NLONGT (FG_NLONG + FG_NLONGC)
 #define FG_NCO    5                     // coordinates per SA resolution (the reference resolves at most 5 outside getAnchorHits)
 #define FG_NRES   2                     // reported alignments per mate
 #define FG_NSRCH  7                     // hybridSearch_recur roots per mate (_hits_searched: hash + hit)
@@ -43,6 +45,7 @@ namespace h2g {
 #define FG_FRS    5                     // scalar words of a saved frame
 #define FG_NFRAME 5
 #define FG_NLOCAL 2                     // _local_genomeHits kept per frame
+#define FG_NGH    4                     // genome hits of one strand (getAnchorHits); the first is hot, the others cold
 #ifndef FG_ALIGN_MATE
 #define FG_ALIGN_MATE 0                 // 1: alignMate (hi_aligner.h:5579) in the fast path; 0: such pairs are handed on (the shipped build: DESIGN.md §3.1)
 #endif
@@ -57,14 +60,16 @@ namespace h2g {
 #define FW_HOT    (FW_T1 + FG_HW)
 #define FW_RES    FW_HOT
 #define FW_LONGX  (FW_RES + 2 * FG_NRES * 3)       // node range + in-edge list of each long partial hit
-#define FW_G1     (FW_LONGX + 3 * FG_NLONG)
+#define FW_LONGC  (FW_LONGX + 3 * FG_NLONGT)       // the cold pool entries
+#define FW_G1     (FW_LONGC + FG_LW * FG_NLONGC)
 #else
 #define FW_RES    (FW_FR0 + FG_FRS + FG_HW)
 #define FW_T1     (FW_RES + 2 * FG_NRES * 3)       // the scratch hit of the extension branches (every read with a mismatch works through it)
 #define FW_HOT    (FW_T1 + FG_HW)
-#define FW_G1     FW_HOT
+#define FW_LONGC  FW_HOT                           // the cold pool entries
+#define FW_G1     (FW_LONGC + FG_LW * FG_NLONGC)
 #endif
-#define FW_SRCH   (FW_G1 + FG_HW)
+#define FW_SRCH   (FW_G1 + (FG_NGH - 1) * FG_HW)
 #define FW_CO     (FW_SRCH + 2 * FG_NSRCH * (1 + FG_HW))   // the coordinate list of every frame (frame 0's doubles as getAnchorHits'); before it: (hash, hit) per searched root
 #define FW_FRX    (FW_CO + FG_NFRAME * 3 * FG_NCO)  // frames 1 .. FG_NFRAME - 1: scalars + hit
 #define FW_LH     (FW_FRX + (FG_NFRAME - 1) * (FG_FRS + FG_HW))   // _local_genomeHits of every frame
@@ -147,11 +152,11 @@ struct FState {
 	int32_t  bestUnp0 : 16, bestUnp1 : 16;           // the sink's per-mate bests; F_SMIN16 = none                                       // 20
 	int32_t  best2Unp0 : 16, best2Unp1 : 16;                                                                                            // 21
 	int32_t  minsc0 : 16, minsc1 : 16;               // F_SMAX16 = the mate is not there                                                // 22
-	uint32_t npairs : 3, pairs : 16, insp_i : 2, insp_j : 2, hs_found : 1, pad23_ : 8;                   // pairs: 4 bits per pair (i | j << 2)          // 23
+	uint32_t npairs : 3, pairs : 16, insp_i : 2, insp_j : 2, hs_found : 1, rc_mate : 1, pool_x : 3, pad23_ : 4;                   // pairs: 4 bits per pair (i | j << 2)          // 23
 	int32_t  bestPair, best2Pair;                                                                                                      // 24, 25
 	uint32_t nrank : 16, nside : 16;                                                                                                    // 26
 	uint32_t nsteps : 16, nframes_max : 8, pad27_ : 8;                                                                                  // 27
-	uint32_t nghits : 2, ghit_done : 2, gh_hi : 5, gh_hj : 3, gh_nco : 3, gh_rdoff : 8, hs_hi : 2, hs_hj : 2, rc_mate : 1, pad28_ : 4;                 // 28
+	uint32_t nghits : 3, ghit_done : 4, gh_hi : 5, gh_hj : 3, gh_nco : 3, gh_rdoff : 8, hs_hi : 3, hs_hj : 3;                 // 28
 	uint32_t localindexatts : 16, max_localindexatts : 16;                                                                              // 29
 	int32_t  sp : 4; uint32_t rc_ret_pc : 8, pr_ret_pc : 8, pad30_ : 12;                                                                // 30
 	int32_t  rc_minsc, ret;                                                                                                            // 31, 32
@@ -164,7 +169,7 @@ struct FState {
 	uint32_t f_nelt : 16, f_maxHitLen : 16;                                                                                             // 39
 #if FG_GRAPH
 	uint32_t a6, a7, a8;                             // node range + packed in-edge list of the last search (BWTHit::_node_top/_node_bot/_node_iedge_count)   // 40-42
-	uint32_t gh_k : 3, gh_gsize : 2, pad43_ : 27;    // getAnchorHits' loop over an anchor's coordinates (each goes through adjustWithALT)                  // 43
+	uint32_t gh_k : 3, gh_gsize : 3, pad43_ : 26;    // getAnchorHits' loop over an anchor's coordinates (each goes through adjustWithALT)                  // 43
 	uint32_t f_ntop : 16, f_nbot : 16;               // node range of the frame's local search                                                           // 44
 	uint32_t f_ie;                                   // ... and its in-edge list                                                                        // 45
 	uint32_t pad46_, pad47_;                                                                                                                         // 46, 47
@@ -218,6 +223,8 @@ H2G_HD void fg_ie_unpack(uint32_t w, IEdges* ie) {
 #endif
 
 // ---------------------------------------------------------------------------------------- stored hits
+H2G_HD uint32_t fg_pool(uint32_t k) { return k < FG_NLONG ? (uint32_t)FW_LONG + FG_LW * k : (uint32_t)FW_LONGC + FG_LW * (k - FG_NLONG); }   // long partial hit k of the pool
+H2G_HD uint32_t fg_gbase(uint32_t k) { return k == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1 + (k - 1) * FG_HW; }      // genome hit k of the strand
 H2G_HD uint32_t fg_frame_base(int sp) { return sp == 0 ? (uint32_t)FW_FR0 : (uint32_t)FW_FRX + (uint32_t)(sp - 1) * (FG_FRS + FG_HW); }
 H2G_HD uint32_t fg_frame_hit(int sp) { return fg_frame_base(sp) + FG_FRS; }
 H2G_HD uint32_t fg_frame_lh(int sp, uint32_t k) { return (uint32_t)FW_LH + ((uint32_t)sp * FG_NLOCAL + k) * FG_HW; }
@@ -724,8 +731,12 @@ H2G_HD SeqView fg_view(const FCtx& C, const FState& S, uint32_t set, bool fw) {
 H2G_HD SeqView fg_sv(const FCtx& C, const FState& S) { return fg_view(C, S, S.paired ? S.sv_rdi : 0u, S.sv_fw != 0); }
 
 // the long partial hits of strand x leave the pool (the strand is done)
-H2G_HD void fg_pool_free(const FWords& W, uint32_t x) {
+H2G_HD void fg_pool_free(const FWords& W, FState& S, uint32_t x) {
 	for(uint32_t k = 0; k < FG_NLONG; k++) { const uint32_t m = W.ld(FW_LONG + FG_LW * k + 2); if(m && ((m >> 20) & 3u) == x) W.st(FW_LONG + FG_LW * k + 2, 0); }
+	if(S.pool_x) for(uint32_t k = FG_NLONG; k < FG_NLONGT; k++) if((S.pool_x >> (k - FG_NLONG)) & 1u) {
+		const uint32_t m = W.ld(fg_pool(k) + 2);
+		if(((m >> 20) & 3u) == x) { W.st(fg_pool(k) + 2, 0); S.pool_x = S.pool_x & ~(1u << (k - FG_NLONG)); }
+	}
 }
 // packs read i of `rd` for the fast path: 8 words of 2-bit codes (word k of this lane at pk[k * stride]).  false: an N, or longer than 128 bases.
 H2G_HD bool fg_pack_read(const DReads& rd, uint32_t i, uint32_t* pk, uint32_t stride) {
@@ -797,7 +808,7 @@ H2G_HD void fast_begin(const FCtx& C, FState& S, uint32_t read, bool paired, boo
 	S.rb_cur = S.rb_nps = S.rb_nus = S.rb_np = 0; S.rb_sumsq0 = S.rb_sumsq1 = S.rb_sumsq2 = S.rb_sumsq3 = 0;
 	S.rb_done = S.rb_nonempty = S.found = 0; S.rnd = 0; S.ro0 = S.ro1 = 0; S.rl0 = S.rl1 = 0;
 	S.nres0 = S.nres1 = S.nsearched0 = S.nsearched1 = 0; S.bestUnp0 = S.bestUnp1 = S.best2Unp0 = S.best2Unp1 = F_SMIN16; S.minsc0 = S.minsc1 = F_SMAX16;
-	S.pad23_ = 0; S.pad27_ = 0; S.pad28_ = 0; S.rc_mate = 0; S.pad30_ = 0; S.pad35_ = 0;
+	S.pad23_ = 0; S.pad27_ = 0; S.rc_mate = 0; S.pool_x = 0; S.pad30_ = 0; S.pad35_ = 0;
 #if FG_GRAPH
 	S.a6 = S.a7 = S.a8 = 0; S.gh_k = S.gh_gsize = 0; S.pad43_ = 0; S.f_ntop = S.f_nbot = 0; S.f_ie = 0; S.pad46_ = S.pad47_ = 0;
 #endif
@@ -927,6 +938,7 @@ again:
 		S.rb_done = 0; S.rb_nonempty = 0;
 		S.found = S.paired ? 15u : 3u;                           // found[0][0], [0][1], [1][0], [1][1]
 		for(uint32_t k = 0; k < FG_NLONG; k++) W.st(FW_LONG + FG_LW * k + 2, 0);
+		S.pool_x = 0;
 		F_GOTO(FPC_NB_PICK);
 	}
 	case FPC_NB_PICK: {                                   // one iteration of nextBWT's loop (:4644-4760)
@@ -948,7 +960,7 @@ again:
 			if(bestScore >= msc) {
 				const uint32_t maxmm = (uint32_t)((-(int64_t)bestScore + sc.mmpMax - 1) / sc.mmpMax);
 				if(numSearched > maxmm + 1) {
-					S.rb_done |= 1u << x; fg_pool_free(W, x);
+					S.rb_done |= 1u << x; fg_pool_free(W, S, x);
 					if(S.paired) {
 						const int32_t ob = fs_bestUnp(S, 1 - rdi), om = fs_minsc(S, 1 - rdi);
 						if(ob >= om && S.npairs > 0) F_GOTO(FPC_AFTER_LOOP); else F_GOTO(FPC_NB_PICK);
@@ -957,7 +969,7 @@ again:
 			}
 			if(((S.rb_done >> xr) & 1u) && bestScore < msc) {
 				const uint32_t rcs = fs_b4(S.rb_nps, xr) - fs_b4(S.rb_nus, xr);
-				if(numSearched > rcs + (P.anchorStop ? 1u : 0u)) { S.rb_done |= 1u << x; fg_pool_free(W, x); F_GOTO(FPC_AFTER_LOOP); }
+				if(numSearched > rcs + (P.anchorStop ? 1u : 0u)) { S.rb_done |= 1u << x; fg_pool_free(W, S, x); F_GOTO(FPC_AFTER_LOOP); }
 			}
 		}
 		S.nb_rdi = rdi; S.nb_fwi = fwi;
@@ -980,13 +992,17 @@ again:
 			if(len > minK + 2) {                            // getAnchorHits looks at these only (:5033)
 				uint32_t k = 0;
 				for(; k < FG_NLONG; k++) if(W.ld(FW_LONG + FG_LW * k + 2) == 0) break;
-				if(k >= FG_NLONG) F_BAIL(FB_LONGPOOL);
-				W.st(FW_LONG + FG_LW * k, top); W.st(FW_LONG + FG_LW * k + 1, bot);
+				if(k >= FG_NLONG) {                             // the hot entries are taken: a cold one
+					for(; k < FG_NLONGT; k++) if(!((S.pool_x >> (k - FG_NLONG)) & 1u)) break;
+					if(k >= FG_NLONGT) F_BAIL(FB_LONGPOOL);
+					S.pool_x = S.pool_x | (1u << (k - FG_NLONG));
+				}
+				W.st(fg_pool(k), top); W.st(fg_pool(k) + 1, bot);
 #if FG_GRAPH
 				if(S.a8 == FG_IE_NOFIT) F_BAIL(FB_IEDGES);
 				{ const uint32_t pn[3] = {S.a6, S.a7, S.a8}; W.stv<3>(FW_LONGX + 3 * k, pn); }   // pnode: node range, in-edges
 #endif
-				W.st(FW_LONG + FG_LW * k + 2, 0x80000000u | S.a5 | (len << 8) | (type << 16) | (x << 20) | (np << 24));   // bwoff, len, type, strand, index
+				W.st(fg_pool(k) + 2, 0x80000000u | S.a5 | (len << 8) | (type << 16) | (x << 20) | (np << 24));   // bwoff, len, type, strand, index
 			}
 		}
 		S.rb_np = fs_b4_set(S.rb_np, x, np + 1);
@@ -1013,7 +1029,7 @@ again:
 		// the strand is done for good (align() runs once per strand): its long partial hits leave the pool
 		{
 			const uint32_t x = (uint32_t)S.sel_r * 2 + (uint32_t)S.sel_f;
-			fg_pool_free(W, x);
+			fg_pool_free(W, S, x);
 			if(S.hs_found) S.found |= 1u << x; else S.found &= ~(1u << x);
 		}
 		if(S.found == 0) F_GOTO(FPC_AFTER_LOOP);
@@ -1171,8 +1187,8 @@ again:
 			uint32_t co3[3];
 			W.ldv<3>(fg_frame_co(0) + 3 * ri, co3);
 			if((uint64_t)co3[1] + (uint64_t)P.maxFragLen * 2 < toff || (uint64_t)toff + (uint64_t)P.maxFragLen * 2 < co3[1]) continue;   // (no_spliced_alignment :5683)
-			if(S.nghits >= 2) F_BAIL(FB_NGHITS);
-			fg_hit_init(W, S.nghits == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1, S.sv_fw != 0, hitoff - hitlen + 1, hitlen, co3[0], co3[1], co3[2]);
+			if(S.nghits >= FG_NGH) F_BAIL(FB_NGHITS);
+			fg_hit_init(W, fg_gbase(S.nghits), S.sv_fw != 0, hitoff - hitlen + 1, hitlen, co3[0], co3[1], co3[2]);
 			S.nghits++;
 		}
 		am[2] = (am[2] & ~0xff0000u) | (hitlen << 16);
@@ -1198,13 +1214,13 @@ again:
 			FAM_STORE();
 			F_GOTO(FPC_MP_LOOP);
 		}
-		S.a0 = 0; S.a1 = H2G_MAX; S.a2 = H2G_MAX; S.a3 = hi == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+		S.a0 = 0; S.a1 = H2G_MAX; S.a2 = H2G_MAX; S.a3 = fg_gbase(hi);
 		F_OP(FOP_EXTEND, FPC_AM_EXT_AFTER);
 	}
 	case FPC_AM_EXT_AFTER: {
 		FAM_LOAD();
 		const uint32_t hi = FAM_GET(0, 11, 2);
-		const uint32_t gb = hi == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+		const uint32_t gb = fg_gbase(hi);
 		const uint32_t w4 = W.ld(gb + 4);
 		fg_hit_copy(W, fg_frame_hit(0), gb);                    // RC_START(tmp2, rdoff, len, the mate's minimum score, alignMate = true)
 		S.sp = 0; S.f_hitoff = w4 & 0xffu; S.f_hitlen = (w4 >> 8) & 0xffu;
@@ -1229,28 +1245,30 @@ again:
 		const uint32_t offsetSize = fs_b4(S.rb_np, x);
 		if(S.gh_hi >= offsetSize) F_GOTO(FPC_GAH_END);
 		// candidates in index order: pool entries of this strand that were not resolved yet (bit 30 = has coordinates)
-		uint32_t hj = FG_NLONG, mj = 0, tj_top = 0, tj_bot = 0;
+		uint32_t hj = FG_NLONGT, mj = 0, tj_top = 0, tj_bot = 0;
+		const uint32_t npool = S.pool_x ? (uint32_t)FG_NLONGT : (uint32_t)FG_NLONG;
 		int last = -1;                                          // index of the candidate looked at last
-		for(uint32_t pass = 0; pass < FG_NLONG; pass++) {
+		for(uint32_t pass = 0; pass < npool; pass++) {
 			// the unresolved entry of this strand with the smallest index above `last`
-			uint32_t k = FG_NLONG, m = 0;
+			uint32_t k = FG_NLONGT, m = 0;
 			int kidx = 1 << 20;
 #pragma unroll
-			for(uint32_t q = 0; q < FG_NLONG; q++) {
-				const uint32_t mq = W.ld(FW_LONG + FG_LW * q + 2);
+			for(uint32_t q = 0; q < FG_NLONGT; q++) {
+				if(q >= FG_NLONG && !((S.pool_x >> (q - FG_NLONG)) & 1u)) continue;
+				const uint32_t mq = W.ld(fg_pool(q) + 2);
 				const int iq = (int)((mq >> 24) & 31u);
 				if(mq && !(mq & 0x40000000u) && ((mq >> 20) & 3u) == x && iq > last && iq < kidx) { k = q; m = mq; kidx = iq; }
 			}
-			if(k == FG_NLONG) break;
+			if(k == FG_NLONGT) break;
 			last = kidx;
-			const uint32_t top = W.ld(FW_LONG + FG_LW * k), bot = W.ld(FW_LONG + FG_LW * k + 1);
-			if(hj == FG_NLONG) { hj = k; mj = m; tj_top = top; tj_bot = bot; continue; }
+			const uint32_t top = W.ld(fg_pool(k)), bot = W.ld(fg_pool(k) + 1);
+			if(hj == FG_NLONGT) { hj = k; mj = m; tj_top = top; tj_bot = bot; continue; }
 			const uint32_t tj = (mj >> 16) & 15u, tk = (m >> 16) & 15u, lj = (mj >> 8) & 0xffu, lk = (m >> 8) & 0xffu;
 			const uint32_t sj = tj_bot - tj_top, sk = bot - top;
 			const bool better = tj == tk ? (sj > sk || (sj == sk && lj < lk)) : (tk > tj);
 			if(better) { hj = k; mj = m; tj_top = top; tj_bot = bot; }
 		}
-		if(hj == FG_NLONG) F_GOTO(FPC_GAH_END);
+		if(hj == FG_NLONGT) F_GOTO(FPC_GAH_END);
 		const uint32_t remained = maxsz - S.nghits;
 		if(remained == 0) F_GOTO(FPC_GAH_END);
 		const uint32_t len = (mj >> 8) & 0xffu, bwoff = mj & 0xffu;
@@ -1275,7 +1293,7 @@ again:
 		const uint32_t nco = S.a0;
 		{ const uint32_t nt_ = S.nsteps + S.a1; if(nt_ > 0xffffu) F_BAIL(FB_OTHER); S.nsteps = nt_; }
 		if(nco == 0) F_BAIL(FB_COORDS);                     // joinedToTextOff failed: the reference retries the same hit (:5140)
-		const uint32_t mslot = FW_LONG + FG_LW * S.gh_hj + 2;
+		const uint32_t mslot = fg_pool(S.gh_hj) + 2;
 		const uint32_t m = W.ld(mslot);
 		W.st(mslot, m | 0x40000000u);                       // ph.ncoords = nco
 #if FG_GRAPH
@@ -1283,7 +1301,7 @@ again:
 		F_GOTO(FPC_GAH_K_LOOP);
 	}
 	case FPC_GAH_K_LOOP: {                                // each coordinate goes through adjustWithALT, which may yield several hits or none (:5175)
-		const uint32_t m = W.ld(FW_LONG + FG_LW * S.gh_hj + 2);
+		const uint32_t m = W.ld(fg_pool(S.gh_hj) + 2);
 		const uint32_t len = (m >> 8) & 0xffu, type = (m >> 16) & 15u;
 		const uint32_t rl = fs_rl(S, S.sel_r);
 		while(S.gh_k < S.gh_nco) {
@@ -1293,7 +1311,7 @@ again:
 			if(tidx == H2G_MAX) F_BAIL(FB_STRADDLE);
 			bool overlapped = false;
 			for(uint32_t l = 0; l < S.gh_gsize; l++) {
-				const uint32_t gb = l == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+				const uint32_t gb = fg_gbase(l);
 				const uint32_t w5 = W.ld(gb + 5);
 				if(W.ld(gb) != tidx || ((w5 & 1u) != 0) != (S.sv_fw != 0)) continue;
 				const uint32_t g_rdoff = W.ld(gb + 4) & 0xffu;
@@ -1315,7 +1333,7 @@ again:
 		F_GOTO(FPC_GAH_LOOP);
 	}
 	case FPC_GAH_K_AFTER: {
-		const uint32_t type = (W.ld(FW_LONG + FG_LW * S.gh_hj + 2) >> 16) & 15u;
+		const uint32_t type = (W.ld(fg_pool(S.gh_hj) + 2) >> 16) & 15u;
 		if(type == H2G_CANDIDATE_HIT && S.nghits >= maxsz) F_GOTO(FPC_GAH_END);
 		S.gh_k = S.gh_k + 1;
 		F_GOTO(FPC_GAH_K_LOOP);
@@ -1331,7 +1349,7 @@ again:
 			if(tidx == H2G_MAX) F_BAIL(FB_STRADDLE);
 			bool overlapped = false;
 			for(uint32_t l = 0; l < gsize; l++) {
-				const uint32_t gb = l == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+				const uint32_t gb = fg_gbase(l);
 				const uint32_t w5 = W.ld(gb + 5);
 				if(W.ld(gb) != tidx || ((w5 & 1u) != 0) != (S.sv_fw != 0)) continue;
 				const uint32_t g_rdoff = W.ld(gb + 4) & 0xffu;
@@ -1339,8 +1357,8 @@ again:
 				if(hitoff == hitoff2) { overlapped = true; W.st(gb + 5, w5 + (1u << 8)); break; }   // _hitcount++
 			}
 			if(!overlapped) {
-				if(S.nghits >= 2) F_BAIL(FB_NGHITS);
-				fg_hit_init(W, S.nghits == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1, S.sv_fw != 0, S.gh_rdoff, len, tidx, toff, joff);
+				if(S.nghits >= FG_NGH) F_BAIL(FB_NGHITS);
+				fg_hit_init(W, fg_gbase(S.nghits), S.sv_fw != 0, S.gh_rdoff, len, tidx, toff, joff);
 				S.nghits++;
 			}
 			if(type == H2G_CANDIDATE_HIT && S.nghits >= maxsz) break;
@@ -1361,7 +1379,7 @@ again:
 	// ======================================================================== hybridSearch spliced_aligner.h:112-322
 	case FPC_HS_EXT_LOOP: {
 		if(S.hs_hi >= S.nghits) { S.hs_hi = 0; F_GOTO(FPC_HS_LOOP); }
-		S.a0 = 0; S.a1 = H2G_MAX; S.a2 = H2G_MAX; S.a3 = S.hs_hi == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+		S.a0 = 0; S.a1 = H2G_MAX; S.a2 = H2G_MAX; S.a3 = fg_gbase(S.hs_hi);
 		F_OP(FOP_EXTEND, FPC_HS_EXT_AFTER);
 	}
 	case FPC_HS_EXT_AFTER: { S.ghit_done &= ~(1u << S.hs_hi); S.hs_hi++; F_GOTO(FPC_HS_EXT_LOOP); }
@@ -1372,12 +1390,12 @@ again:
 		if(hj >= S.nghits) { S.hs_found = 1; F_GOTO(FPC_AFTER_ALIGN); }
 		for(uint32_t hk = hj + 1; hk < S.nghits; hk++) {
 			if((S.ghit_done >> hk) & 1u) continue;
-			const uint32_t bj = hj == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1, bk = hk == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+			const uint32_t bj = fg_gbase(hj), bk = fg_gbase(hk);
 			const uint32_t ar = W.ld(bj + 5) >> 8, al = (W.ld(bj + 4) >> 8) & 0xffu, br = W.ld(bk + 5) >> 8, bl = (W.ld(bk + 4) >> 8) & 0xffu;
 			if(br > ar || (br == ar && bl > al)) hj = hk;
 		}
 		S.hs_hj = hj;
-		const uint32_t gb = hj == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1;
+		const uint32_t gb = fg_gbase(hj);
 		// hybridSearch_recur(root) (RC_START): frame 0
 		const uint32_t w4 = W.ld(gb + 4);
 		fg_hit_copy(W, fg_frame_hit(0), gb);
@@ -2172,16 +2190,15 @@ H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
 // static adjustWithALT (hi_aligner.h:2239; adjust_with_alt): the anchor (a0 rdoff, a1 len) placed at (a2 tidx, a3 toff, a4 joinedOff) becomes the
 // genome hits it yields.  It compares what it adds with the hits already there, so those go in first.
 H2G_HD void fast_op_adjust(const FCtx& C, FState& S, const FWords& W) {
-	h2g_ghit arr[2];
+	h2g_ghit arr[FG_NGH];
 	uint32_t n = S.nghits, ovf = 0;
-	if(n >= 1) fh_to_ghit(fh_load(W, FW_G0), &arr[0]);
-	if(n >= 2) fh_to_ghit(fh_load(W, FW_G1), &arr[1]);
-	adjust_with_alt(*C.g, *C.ref, *C.alts, fg_sv(C, S), S.a0, S.a1, S.a2, S.a3, S.a4, arr, &n, 2, &C.gws->awa, &ovf);
+	for(uint32_t k = 0; k < n && k < FG_NGH; k++) fh_to_ghit(fh_load(W, fg_gbase(k)), &arr[k]);
+	adjust_with_alt(*C.g, *C.ref, *C.alts, fg_sv(C, S), S.a0, S.a1, S.a2, S.a3, S.a4, arr, &n, FG_NGH, &C.gws->awa, &ovf);
 	if(ovf) { S.pc = FPC_BAIL; S.bail = FB_NGHITS; return; }
-	for(uint32_t k = S.nghits; k < n && k < 2; k++) {
+	for(uint32_t k = S.nghits; k < n && k < FG_NGH; k++) {
 		FHit h;
 		ghit_to_fh(arr[k], h);
-		if(!fh_store(W, k == 0 ? (uint32_t)FW_G0 : (uint32_t)FW_G1, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; return; }
+		if(!fh_store(W, fg_gbase(k), h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; return; }
 	}
 	S.nghits = n;
 	S.a0 = 0;
