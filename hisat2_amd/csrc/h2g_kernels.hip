@@ -2183,6 +2183,139 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 	                    n, aln2, offs2, 2, s->d_pout + first, 1);
 }
 
+// ------------------------------------------------------------------------------------------ compact result fetch
+// The dense fetch still moves 424 B per record (40 B of fields + 32 edit entries of which an alignment of a 101 bp read uses one or two) and needs the
+// result headers on the host before it can size anything (two round trips).  The compact fetch sizes, scans and gathers on the device: a record travels as its
+// 40 B of fields + 12 B per edit it holds (a long record: its marker entry), 8-byte aligned — a tenth of the bytes — and the host gets byte offsets per read.
+// A compact record is a PREFIX of an h2g_alnres: read it through a `const h2g_alnres*`, never copy the struct.
+__device__ __forceinline__ uint32_t compact_rec_bytes(uint32_t nedits) { const uint32_t e = nedits > H2G_MAX_EDITS ? 1u : nedits; return (40u + 12u * e + 7u) & ~7u; }
+__device__ __forceinline__ const h2g_alnres* compact_src(const h2g_alnres* src, uint32_t slots, size_t i, uint32_t* c, const PairOut* pout, const h2g_alnres* ovf, int mate) {
+	const h2g_alnres* a = src + i * slots;
+	if(pout && pout[i].pad) a = ovf + (pout[i].pad - 1u) + (mate ? pout[i].nres[0] : 0u);      // every record of the pair lives in its overflow block
+	else if(*c > slots) *c = slots;
+	return a;
+}
+__global__ __launch_bounds__(256) void k_compact_sizes(const h2g_alnres* src, uint32_t slots, const uint32_t* cnt, uint32_t cnt_stride, size_t n, unsigned long long* sizes,
+                                                       const PairOut* pout, const h2g_alnres* ovf, int mate)
+{
+	const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	if(i > n) return;
+	if(i == n) { sizes[n] = 0; return; }
+	uint32_t c = cnt[i * cnt_stride];
+	const h2g_alnres* a = compact_src(src, slots, i, &c, pout, ovf, mate);
+	unsigned long long b = 0;
+	for(uint32_t k = 0; k < c; k++) b += compact_rec_bytes(a[k].nedits);
+	sizes[i] = b;
+}
+// exclusive prefix sum of v[0 .. n] in place (n + 1 entries: v[n] becomes the total), one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan_u64(unsigned long long* v, size_t n1) {
+	__shared__ unsigned long long part[1024];
+	const size_t per = (n1 + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n1 ? lo + per : n1;
+	unsigned long long sum = 0;
+	for(size_t k = lo; k < hi; k++) sum += v[k];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for(unsigned d = 1; d < 1024; d <<= 1) {
+		unsigned long long t = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+		__syncthreads();
+		part[threadIdx.x] += t;
+		__syncthreads();
+	}
+	unsigned long long run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+	for(size_t k = lo; k < hi; k++) { const unsigned long long x = v[k]; v[k] = run; run += x; }
+}
+__global__ __launch_bounds__(256) void k_compact_gather(const h2g_alnres* src, uint32_t slots, const uint32_t* cnt, uint32_t cnt_stride, const unsigned long long* offs, size_t n,
+                                                        uint8_t* dst, const PairOut* pout, const h2g_alnres* ovf, int mate)
+{
+	const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	uint32_t c = cnt[i * cnt_stride];
+	const h2g_alnres* a = compact_src(src, slots, i, &c, pout, ovf, mate);
+	uint8_t* d = dst + offs[i];
+	for(uint32_t k = 0; k < c; k++) {
+		const uint32_t ne = a[k].nedits, e = ne > H2G_MAX_EDITS ? 1u : ne, bytes = compact_rec_bytes(ne);
+		const unsigned long long* sw = reinterpret_cast<const unsigned long long*>(&a[k]);
+		unsigned long long* dw = reinterpret_cast<unsigned long long*>(d);
+		for(uint32_t w = 0; w < 5; w++) dw[w] = sw[w];                       // fw .. score: 40 bytes
+		const uint32_t* se = reinterpret_cast<const uint32_t*>(a[k].edits);
+		uint32_t* de = reinterpret_cast<uint32_t*>(d + 40);
+		for(uint32_t w = 0; w < 3 * e; w++) de[w] = se[w];
+		if(e & 1u) de[3 * e] = 0;                                            // the alignment pad: never stale bytes
+		d += bytes;
+	}
+}
+static_assert(offsetof(h2g_alnres, edits) == 40 && sizeof(h2g_edit) == 12, "compact records are prefixes of h2g_alnres");
+
+// sizes + scan for one mate into tmp slot `slot` (-> device offsets [n + 1], exclusive, in bytes)
+static int compact_offsets(h2g_stream* s, const h2g_alnres* d_src, uint32_t slots, const uint32_t* d_cnt, uint32_t cnt_stride, size_t n, int slot, const PairOut* d_pout, int mate, void** d_offs) {
+	int rc;
+	if((rc = tmp_buf(s, slot, (n + 1) * 8, d_offs))) return rc;
+	hipLaunchKernelGGL(k_compact_sizes, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s->st, d_src, slots, d_cnt, cnt_stride, n, (unsigned long long*)*d_offs, d_pout, (const h2g_alnres*)s->d_paln_ovf, mate);
+	hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s->st, (unsigned long long*)*d_offs, n + 1);
+	HIPCHK(hipGetLastError());
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_align_pairs_fetch_compact(h2g_stream* s, h2g_pair_result* res, uint8_t* rec1, size_t cap1, uint64_t* boffs1, uint8_t* rec2, size_t cap2, uint64_t* boffs2,
+                                                    size_t first, size_t n)
+{
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }
+	if(!s || !res || !rec1 || !rec2 || !boffs1 || !boffs2 || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
+	if(n == 0) { boffs1[0] = boffs2[0] = 0; return H2G_OK; }
+	HIPCHK(hipSetDevice(s->ix->device));
+	static_assert(offsetof(PairOut, nres) == 0 && sizeof(h2g_pair_result) == sizeof(PairOut), "PairOut layout");
+	const uint32_t* cnt = reinterpret_cast<const uint32_t*>(s->d_pout + first);
+	void *d_o1 = nullptr, *d_o2 = nullptr, *d_b1 = nullptr, *d_b2 = nullptr;
+	int rc;
+	if((rc = compact_offsets(s, s->d_paln[0] + first * s->pair_slots, s->pair_slots, cnt, sizeof(PairOut) / 4, n, 0, s->d_pout + first, 0, &d_o1)) ||
+	   (rc = compact_offsets(s, s->d_paln[1] + first * s->pair_slots, s->pair_slots, cnt + 1, sizeof(PairOut) / 4, n, 2, s->d_pout + first, 1, &d_o2))) return (h2g_status)rc;
+	HIPCHK(hipMemcpyAsync(boffs1, d_o1, (n + 1) * 8, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipMemcpyAsync(boffs2, d_o2, (n + 1) * 8, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	for(size_t i = 0; i < n; i++) if(res[i].pad) res[i].overflow &= ~4u;      // (every record is returned)
+	if(boffs1[n] > cap1 || boffs2[n] > cap2) return H2G_ERR_ARG;              // (boffs[n] = the bytes needed)
+	if((rc = tmp_buf(s, 1, boffs1[n] + 8, &d_b1)) || (rc = tmp_buf(s, 3, boffs2[n] + 8, &d_b2))) return (h2g_status)rc;
+	const unsigned g = (unsigned)((n + 255) / 256);
+	if(boffs1[n]) hipLaunchKernelGGL(k_compact_gather, dim3(g), dim3(256), 0, s->st, s->d_paln[0] + first * s->pair_slots, s->pair_slots, cnt, (uint32_t)(sizeof(PairOut) / 4),
+	                                 (const unsigned long long*)d_o1, n, (uint8_t*)d_b1, s->d_pout + first, (const h2g_alnres*)s->d_paln_ovf, 0);
+	if(boffs2[n]) hipLaunchKernelGGL(k_compact_gather, dim3(g), dim3(256), 0, s->st, s->d_paln[1] + first * s->pair_slots, s->pair_slots, cnt + 1, (uint32_t)(sizeof(PairOut) / 4),
+	                                 (const unsigned long long*)d_o2, n, (uint8_t*)d_b2, s->d_pout + first, (const h2g_alnres*)s->d_paln_ovf, 1);
+	HIPCHK(hipGetLastError());
+	if(boffs1[n]) HIPCHK(hipMemcpyAsync(rec1, d_b1, boffs1[n], hipMemcpyDeviceToHost, s->st));
+	if(boffs2[n]) HIPCHK(hipMemcpyAsync(rec2, d_b2, boffs2[n], hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+extern "C" h2g_status h2g_align_fetch_compact(h2g_stream* s, h2g_read_result* res, uint8_t* rec, size_t cap, uint64_t* boffs, size_t first, size_t n) {
+	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }
+	if(!s || !res || !rec || !boffs || first + n > s->n_reads || !s->d_rout) return H2G_ERR_ARG;
+	if(n == 0) { boffs[0] = 0; return H2G_OK; }
+	HIPCHK(hipSetDevice(s->ix->device));
+	static_assert(offsetof(ReadOut, nselect) == 4, "ReadOut layout");
+	const uint32_t* cnt = reinterpret_cast<const uint32_t*>(s->d_rout + first) + 1;
+	void *d_o = nullptr, *d_b = nullptr;
+	int rc;
+	if((rc = compact_offsets(s, s->d_aln + first * s->aln_slots, s->aln_slots, cnt, sizeof(ReadOut) / 4, n, 0, nullptr, 0, &d_o))) return (h2g_status)rc;
+	HIPCHK(hipMemcpyAsync(boffs, d_o, (n + 1) * 8, hipMemcpyDeviceToHost, s->st));
+	const h2g_status hr = h2g_align_fetch(s, res, nullptr, first, n);           // (the headers; syncs the stream)
+	if(hr != H2G_OK) return hr;
+	if(boffs[n] > cap) return H2G_ERR_ARG;
+	if(boffs[n] == 0) return H2G_OK;
+	if((rc = tmp_buf(s, 1, boffs[n] + 8, &d_b))) return (h2g_status)rc;
+	hipLaunchKernelGGL(k_compact_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->st, s->d_aln + first * s->aln_slots, s->aln_slots, cnt, (uint32_t)(sizeof(ReadOut) / 4),
+	                   (const unsigned long long*)d_o, n, (uint8_t*)d_b, (const PairOut*)nullptr, (const h2g_alnres*)nullptr, 0);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(rec, d_b, boffs[n], hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipStreamSynchronize(s->st));
+	return H2G_OK;
+}
+
+// page-locked host memory for the buffers a caller hands to the set_* / fetch_* entry points: copies from / to it run at the link's rate and asynchronously
+extern "C" void* h2g_host_alloc(size_t bytes) { void* p = nullptr; if(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+extern "C" void h2g_host_free(void* p) { if(p) (void)hipHostFree(p); }
+
 // The edit lists of the records with more than H2G_MAX_EDITS edits of the resident batch (include/h2g.h): the used prefix of the stream's long-edit
 // area, offsets as the records carry them in edits[0].pos.  *n = edits the prefix spans (0: no such record); H2G_ERR_ARG when cap is smaller.
 extern "C" h2g_status h2g_align_fetch_long_edits(h2g_stream* s, h2g_edit* out, size_t cap, size_t* n) {

@@ -367,6 +367,20 @@ H2G_EXPORT h2g_status h2g_align_pairs_fetch(h2g_stream*, h2g_pair_result* res /*
 H2G_EXPORT h2g_status h2g_align_pairs_fetch_dense(h2g_stream*, h2g_pair_result* res /* [n] */, h2g_alnres* aln1, size_t cap1, uint64_t* aln_offs1 /* [n+1] */,
                                                   h2g_alnres* aln2, size_t cap2, uint64_t* aln_offs2 /* [n+1] */, size_t first_read, size_t n_reads);
 
+/* Compact variants — what a caller on the other side of PCIe wants: sized, scanned and gathered on the device in one go.  A record travels as its 40 bytes
+ * of fields + 12 bytes per edit it holds (a record beyond H2G_MAX_EDITS: its one marker entry), rounded up to 8: read i's records lie back to back in
+ * rec[boffs[i] .. boffs[i + 1]) (byte offsets).  A compact record is a PREFIX of an h2g_alnres: read it through a `const h2g_alnres*` up to edits[nedits), never
+ * copy the struct; the next record starts H2G_COMPACT_BYTES(nedits) further.  H2G_ERR_ARG when a capacity is too small (boffs[n] then holds the bytes needed).
+ * include/h2g_sam.h formats this layout directly (h2g_sam_format_*_compact). */
+#define H2G_COMPACT_BYTES(nedits) ((40u + 12u * ((nedits) > H2G_MAX_EDITS ? 1u : (uint32_t)(nedits)) + 7u) & ~7u)
+H2G_EXPORT h2g_status h2g_align_fetch_compact(h2g_stream*, h2g_read_result* res /* [n] */, uint8_t* rec, size_t cap, uint64_t* boffs /* [n+1] */, size_t first_read, size_t n_reads);
+H2G_EXPORT h2g_status h2g_align_pairs_fetch_compact(h2g_stream*, h2g_pair_result* res /* [n] */, uint8_t* rec1, size_t cap1, uint64_t* boffs1 /* [n+1] */,
+                                                    uint8_t* rec2, size_t cap2, uint64_t* boffs2 /* [n+1] */, size_t first_read, size_t n_reads);
+/* Page-locked host memory for the buffers handed to h2g_set_* / h2g_*_fetch_*: copies from / to it run at the link's rate (pageable memory is staged by the
+ * runtime at a fraction of it).  NULL when the allocation fails. */
+H2G_EXPORT void*      h2g_host_alloc(size_t bytes);
+H2G_EXPORT void       h2g_host_free(void*);
+
 /* Records beyond H2G_MAX_EDITS edits.  The reference's edit lists are unbounded (hi_aligner.h:421, reportHit :6129-6166) and a deletion of n bases
  * is n edits (edit.h).  A record whose list does not fit its H2G_MAX_EDITS inline entries says so with nedits > H2G_MAX_EDITS: its edits live in the
  * stream's long-edit area, at offset edits[0].pos (edits[0].snp == 0x4c4f4e47 marks it; the other inline entries are unspecified).  This call returns
