@@ -352,6 +352,7 @@ EXPORTS = [
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_device_count", "h2g_ext_search", "h2g_local_index_of", "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
     "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense", "h2g_align_fetch_long_edits",
+    "h2g_align_fetch_compact", "h2g_align_pairs_fetch_compact", "h2g_host_alloc", "h2g_host_free",
     "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph", "h2g_adjust_with_alt",
 ]
 
@@ -448,6 +449,34 @@ class Index:
         if self.h:
             lib().h2g_index_free(self.h)
             self.h = C.c_void_p()
+
+
+class PinnedPool:
+    """page-locked host buffers by key (h2g_host_alloc), grown on demand, handed out as numpy views: what a caller moving results over PCIe allocates once"""
+    def __init__(self):
+        L = lib()
+        L.h2g_host_alloc.restype = C.c_void_p
+        L.h2g_host_alloc.argtypes = [C.c_size_t]
+        L.h2g_host_free.argtypes = [C.c_void_p]
+        self._b = {}
+
+    def array(self, key, nbytes, dtype=np.uint8):
+        p, cap = self._b.get(key, (None, 0))
+        if cap < nbytes:
+            if p:
+                lib().h2g_host_free(p)
+            cap = nbytes + nbytes // 4 + 4096
+            p = lib().h2g_host_alloc(cap)
+            if not p:
+                raise H2GError("h2g_host_alloc(%d) failed" % cap)
+            self._b[key] = (p, cap)
+        raw = (C.c_uint8 * cap).from_address(p)
+        return np.frombuffer(raw, dtype=dtype, count=nbytes // np.dtype(dtype).itemsize)
+
+    def close(self):
+        for p, _ in self._b.values():
+            lib().h2g_host_free(p)
+        self._b = {}
 
 
 class Stream:
@@ -583,10 +612,14 @@ class Stream:
         _chk(lib().h2g_get_counters(self.h, C.byref(c)), "h2g_get_counters")
         return c
 
+    @staticmethod
+    def pack_names(qnames):
+        """-> (bytes, uint32 offsets [n + 1]): the form the C ABI takes (a caller that uploads a batch more than once packs once)"""
+        return "".join(qnames).encode(), np.concatenate([[0], np.cumsum([len(q) for q in qnames])]).astype(np.uint32)
+
     def set_read_names(self, qnames):
-        nb = "".join(qnames).encode()
-        offs = np.concatenate([[0], np.cumsum([len(q) for q in qnames])]).astype(np.uint32)
-        _chk(lib().h2g_set_read_names(self.h, nb, offs.ctypes.data, len(qnames)), "h2g_set_read_names")
+        nb, offs = qnames if isinstance(qnames, tuple) else self.pack_names(qnames)
+        _chk(lib().h2g_set_read_names(self.h, nb, offs.ctypes.data, len(offs) - 1), "h2g_set_read_names")
 
     def align_params(self):
         p = AlignParams()
@@ -607,8 +640,7 @@ class Stream:
     def set_mates(self, codes2, offs2, qnames2, quals2=None):
         codes2 = np.ascontiguousarray(codes2, dtype=np.uint8)
         offs2 = np.ascontiguousarray(offs2, dtype=np.uint32)
-        nb = "".join(qnames2).encode()
-        noffs = np.concatenate([[0], np.cumsum([len(q) for q in qnames2])]).astype(np.uint32)
+        nb, noffs = qnames2 if isinstance(qnames2, tuple) else self.pack_names(qnames2)
         q = None if quals2 is None else np.ascontiguousarray(quals2, dtype=np.uint8).ctypes.data
         _chk(lib().h2g_set_mates(self.h, codes2.ctypes.data, offs2.ctypes.data, q, nb, noffs.ctypes.data, len(offs2) - 1), "h2g_set_mates")
 
@@ -642,6 +674,47 @@ class Stream:
             if int(o1[n]) <= c1 and int(o2[n]) <= c2:
                 _chk(rc, "h2g_align_pairs_fetch_dense")
             c1, c2 = max(c1, int(o1[n])), max(c2, int(o2[n]))
+
+    def tune(self, key, value):
+        """development / measurement knobs of go_run by name (h2g_stream_tune: "mstreams", "mach_total", "fast_reserve", "pair_slots", "fast", ...)"""
+        f = lib().h2g_stream_tune
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        _chk(f(self.h, key.encode(), int(value)), "h2g_stream_tune " + key)
+
+    def align_pairs_fetch_compact(self, first=0, n=None, pinned=None):
+        """-> (res, rec1, boffs1, rec2, boffs2): compact records (40 bytes + 12 per edit held, 8-aligned) as uint8 arrays, byte offsets [n + 1] per mate.
+        pinned: a PinnedPool whose page-locked buffers the results land in (valid until its next use)"""
+        n = self.n_reads - first if n is None else n
+        f = lib().h2g_align_pairs_fetch_compact
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]
+        alloc = pinned.array if pinned is not None else (lambda key, nbytes, dtype=np.uint8: np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype))
+        res = alloc("res", n * C.sizeof(PairResult))
+        o1 = alloc("o1", (n + 1) * 8, np.uint64); o2 = alloc("o2", (n + 1) * 8, np.uint64)
+        c1 = c2 = n * 64 + 4096
+        while True:
+            r1 = alloc("r1", c1); r2 = alloc("r2", c2)
+            rc = f(self.h, res.ctypes.data, r1.ctypes.data, r1.size, o1.ctypes.data, r2.ctypes.data, r2.size, o2.ctypes.data, first, n)
+            if rc == 0:
+                return res, r1, o1, r2, o2
+            if int(o1[n]) <= r1.size and int(o2[n]) <= r2.size:
+                _chk(rc, "h2g_align_pairs_fetch_compact")
+            c1, c2 = max(c1, int(o1[n]) + 8), max(c2, int(o2[n]) + 8)
+
+    def align_fetch_compact(self, first=0, n=None):
+        n = self.n_reads - first if n is None else n
+        f = lib().h2g_align_fetch_compact
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]
+        res = np.zeros(n, dtype=READ_RESULT_DTYPE)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        cap = n * 64 + 4096
+        while True:
+            rec = np.empty(cap, dtype=np.uint8)
+            rc = f(self.h, res.ctypes.data, rec.ctypes.data, cap, offs.ctypes.data, first, n)
+            if rc == 0:
+                return res, rec, offs
+            if int(offs[n]) <= cap:
+                _chk(rc, "h2g_align_fetch_compact")
+            cap = int(offs[n]) + 8
 
     def align_fetch_long_edits(self):
         """the used prefix of the stream's long-edit area (records with nedits > MAX_EDITS: edits[0].pos is their offset in it) -> (Edit array or None, n)"""

@@ -574,10 +574,14 @@ int main(int argc, char** argv) {
 	std::vector<Str> S((size_t)G);
 	uint64_t nreads = 0, naligned = 0, novf = 0, nsecond = 0;
 	double t_gpu = 0, t_fmt = 0, t_parse = 0, t_up = 0, t_fetch = 0, t_stream = 0;
-	std::vector<h2g_read_result> res;
-	std::vector<h2g_pair_result> pres;
-	std::vector<h2g_alnres> aln, aln2;
-	std::vector<uint64_t> ao1, ao2;
+	// what comes back from the device lands in page-locked memory (h2g_host_alloc): the copies run at the link's rate.  The records travel compact
+	// (h2g_align_*_fetch_compact: 40 bytes + 12 per edit held instead of 424 per record) and are formatted in that layout.
+	struct Pinned {
+		uint8_t* p = nullptr; size_t cap = 0;
+		void need(size_t n) { if(n <= cap) return; h2g_host_free(p); cap = n + n / 4 + 4096; p = (uint8_t*)h2g_host_alloc(cap); if(!p) { fprintf(stderr, "hisat2-align-amd: cannot allocate %zu bytes of page-locked memory\n", cap); exit(1); } }
+		~Pinned() { h2g_host_free(p); }
+	};
+	Pinned pin_res, pin_rec1, pin_rec2, pin_o1, pin_o2;
 	std::string ovf_names;
 	// Temporary splice sites on G devices: a wave of W reads is cut into G shards that run side by side — a read never sees the junctions of
 	// its own wave (readid + W > its id), so the shards need nothing from one another; every shard's junctions join the database (on every
@@ -607,47 +611,47 @@ int main(int argc, char** argv) {
 			h2g_sam_set_long_edits(sam, nl ? long_edits.data() : nullptr, nl);
 		}
 		if(paired) {
-			pres.resize(n); ao1.assign(n + 1, 0); ao2.assign(n + 1, 0);
-			if(aln.size() < 2 * n + 64) aln.resize(2 * n + 64);
-			if(aln2.size() < 2 * n + 64) aln2.resize(2 * n + 64);
-			// dense fetch: only the records that exist cross PCIe
-			if(h2g_align_pairs_fetch_dense(st, pres.data(), aln.data(), aln.size(), ao1.data(), aln2.data(), aln2.size(), ao2.data(), 0, n) != H2G_OK) {
-				if(aln.size() < ao1[n]) aln.resize(ao1[n]);
-				if(aln2.size() < ao2[n]) aln2.resize(ao2[n]);
-				if(h2g_align_pairs_fetch_dense(st, pres.data(), aln.data(), aln.size(), ao1.data(), aln2.data(), aln2.size(), ao2.data(), 0, n) != H2G_OK) die("h2g_align_pairs_fetch_dense");
+			pin_res.need(n * sizeof(h2g_pair_result)); pin_o1.need((n + 1) * 8); pin_o2.need((n + 1) * 8);
+			pin_rec1.need(n * 64 + 4096); pin_rec2.need(n * 64 + 4096);
+			h2g_pair_result* pres = (h2g_pair_result*)pin_res.p;
+			uint64_t *ao1 = (uint64_t*)pin_o1.p, *ao2 = (uint64_t*)pin_o2.p;
+			if(h2g_align_pairs_fetch_compact(st, pres, pin_rec1.p, pin_rec1.cap, ao1, pin_rec2.p, pin_rec2.cap, ao2, 0, n) != H2G_OK) {
+				pin_rec1.need(ao1[n] + 8); pin_rec2.need(ao2[n] + 8);                 // (boffs[n] = the bytes needed)
+				if(h2g_align_pairs_fetch_compact(st, pres, pin_rec1.p, pin_rec1.cap, ao1, pin_rec2.p, pin_rec2.cap, ao2, 0, n) != H2G_OK) die("h2g_align_pairs_fetch_compact");
 			}
 			t_fetch += now() - tq0;
 			const double tf = now();
 			buf.resize(n * 1400 + 6 * (a.codes.size() + b.codes.size()) + 4096);
-			h2g_status rc = h2g_sam_format_paired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
+			h2g_status rc = h2g_sam_format_paired_compact(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
 			                                      b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n,
-			                                      pres.data(), aln.data(), ao1.data(), aln2.data(), ao2.data(), P.khits, buf.data(), buf.size(), &used);
+			                                      pres, pin_rec1.p, ao1, pin_rec2.p, ao2, P.khits, buf.data(), buf.size(), &used);
 			if(rc != H2G_OK) {
 				buf.resize(used + 16);
-				rc = h2g_sam_format_paired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
+				rc = h2g_sam_format_paired_compact(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(),
 				                           b.codes.data(), b.offs.data(), b.have_quals ? b.quals.data() : nullptr, b.names.data(), b.noffs.data(), n,
-				                           pres.data(), aln.data(), ao1.data(), aln2.data(), ao2.data(), P.khits, buf.data(), buf.size(), &used);
-				if(rc != H2G_OK) die("h2g_sam_format_paired");
+				                           pres, pin_rec1.p, ao1, pin_rec2.p, ao2, P.khits, buf.data(), buf.size(), &used);
+				if(rc != H2G_OK) die("h2g_sam_format_paired_compact");
 			}
 			for(size_t i = 0; i < n; i++) { naligned += pres[i].npairs > 0; if(pres[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names += " (bits " + std::to_string(pres[i].overflow) + ")\n"; } } }
 			t_fmt += now() - tf;
 		} else {
-			res.resize(n); ao1.assign(n + 1, 0);
-			if(aln.size() < n + n / 4 + 64) aln.resize(n + n / 4 + 64);
-			if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) {
-				if(aln.size() < ao1[n]) aln.resize(ao1[n]);
-				if(h2g_align_fetch_dense(st, res.data(), aln.data(), aln.size(), ao1.data(), 0, n) != H2G_OK) die("h2g_align_fetch_dense");
+			pin_res.need(n * sizeof(h2g_read_result)); pin_o1.need((n + 1) * 8); pin_rec1.need(n * 64 + 4096);
+			h2g_read_result* res = (h2g_read_result*)pin_res.p;
+			uint64_t* ao1 = (uint64_t*)pin_o1.p;
+			if(h2g_align_fetch_compact(st, res, pin_rec1.p, pin_rec1.cap, ao1, 0, n) != H2G_OK) {
+				pin_rec1.need(ao1[n] + 8);
+				if(h2g_align_fetch_compact(st, res, pin_rec1.p, pin_rec1.cap, ao1, 0, n) != H2G_OK) die("h2g_align_fetch_compact");
 			}
 			t_fetch += now() - tq0;
 			const double tf = now();
 			buf.resize(n * 700 + 3 * a.codes.size() + 4096);
-			h2g_status rc = h2g_sam_format_unpaired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
-			                                        res.data(), aln.data(), ao1.data(), buf.data(), buf.size(), &used);
+			h2g_status rc = h2g_sam_format_unpaired_compact(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
+			                                        res, pin_rec1.p, ao1, buf.data(), buf.size(), &used);
 			if(rc != H2G_OK) {
 				buf.resize(used + 16);
-				rc = h2g_sam_format_unpaired_dense(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
-				                             res.data(), aln.data(), ao1.data(), buf.data(), buf.size(), &used);
-				if(rc != H2G_OK) die("h2g_sam_format_unpaired");
+				rc = h2g_sam_format_unpaired_compact(sam, a.codes.data(), a.offs.data(), a.have_quals ? a.quals.data() : nullptr, a.names.data(), a.noffs.data(), n,
+				                             res, pin_rec1.p, ao1, buf.data(), buf.size(), &used);
+				if(rc != H2G_OK) die("h2g_sam_format_unpaired_compact");
 			}
 			for(size_t i = 0; i < n; i++) { naligned += res[i].nselect > 0; if(res[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names += " (bits " + std::to_string(res[i].overflow) + ")\n"; } } }
 			t_fmt += now() - tf;

@@ -21,9 +21,6 @@
 
 using namespace h2g;
 
-#ifndef H2G_GWS_PRIVATE
-#define H2G_GWS_PRIVATE 0
-#endif
 #ifndef H2G_GO_THREADS
 #define H2G_GO_THREADS 512
 #endif
@@ -180,10 +177,6 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	ctx_ext_opts(C, A.P);
 #endif
 	C.alts = &A.alts; C.gws = A.gws_base ? (GraphWS*)(A.gws_base + tid * A.gws_stride) : nullptr; C.graph = GRAPH;
-#if H2G_GWS_PRIVATE
-	GraphWS gws_priv;                  // (see h2g_k_go_fast.hip: the per-lane scratch of the graph primitives in the wave's private segment)
-	if(GRAPH) C.gws = &gws_priv;
-#endif
 	const size_t slot0 = (size_t)blockIdx.x * H2G_GO_SLOTS;
 	Mach M;
 	M.rd[0] = A.rd1; M.rd[1] = paired ? A.rd2 : A.rd1;

@@ -18,9 +18,6 @@ using namespace h2g;
 #define FG_GEOMETRY h2g_go_fast_geometry
 #endif
 
-#ifndef H2G_GWS_PRIVATE
-#define H2G_GWS_PRIVATE 0
-#endif
 #ifndef H2G_FAST_THREADS
 #define H2G_FAST_THREADS 512
 #endif
@@ -102,13 +99,6 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 __device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t op, uint32_t begin, uint32_t packed_ok) {
 	FCtx C; FWords W;
 	fk_ctx(A, stage, sm, C, W);
-#if FG_GRAPH && H2G_GWS_PRIVATE
-	// the graph primitives' scratch as PRIVATE memory: the hardware interleaves a wave's private segment lane by lane, dword by dword, so the lanes of a
-	// wave running the same primitive touch one 256-byte row per access instead of 64 lines 17 KB apart (the per-lane global scratch: 40 GB of write
-	// traffic per 1 M pairs, profiles/r05_a)
-	GraphWS gws_priv;
-	C.gws = &gws_priv;
-#endif
 	FState S;
 	if(begin != H2G_MAX) {
 		const bool paired = A->paired != 0;

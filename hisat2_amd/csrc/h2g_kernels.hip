@@ -2088,7 +2088,7 @@ extern "C" h2g_status h2g_align_fetch(h2g_stream* s, h2g_read_result* res, h2g_a
 }
 
 // ------------------------------------------------------------------------------------------ paired go(): fetch
-extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) {
+static h2g_status pairs_fetch_rows(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n, bool callers_view) {
 	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
 	if((aln1 || aln2) && s->pair_slots < H2G_PAIR_RES_CAP) return H2G_ERR_ARG;
@@ -2102,9 +2102,10 @@ extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res,
 	HIPCHK(sync_all(s));
 	// a pair kept in the overflow area has more records than these fixed rows return: flagged in the returned copy (the dense variant
 	// returns every record)
-	for(size_t i = 0; i < n; i++) if(res[i].pad) res[i].overflow |= 4;
+	if(callers_view) for(size_t i = 0; i < n; i++) if(res[i].pad) { res[i].overflow |= 4; res[i].pad = 0; }      // (the block offset itself is the device's business: allocation order, i.e. timing)
 	return H2G_OK;
 }
+extern "C" h2g_status h2g_align_pairs_fetch(h2g_stream* s, h2g_pair_result* res, h2g_alnres* aln1, h2g_alnres* aln2, size_t first, size_t n) { return pairs_fetch_rows(s, res, aln1, aln2, first, n, true); }
 
 // ------------------------------------------------------------------------------------------ dense result fetch
 // The slot layout of h2g_align_fetch moves H2G_ALN_CAP x 424 B per read over PCIe whatever was found; these variants gather
@@ -2167,20 +2168,22 @@ extern "C" h2g_status h2g_align_pairs_fetch_dense(h2g_stream* s, h2g_pair_result
 {
 	if(s && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (results of the machine pass on the second stream)
 	if(!s || !res || !aln1 || !aln2 || !offs1 || !offs2 || first + n > s->n_reads || !s->d_pout) return H2G_ERR_ARG;
-	const h2g_status rc = h2g_align_pairs_fetch(s, res, nullptr, nullptr, first, n);
+	const h2g_status rc = pairs_fetch_rows(s, res, nullptr, nullptr, first, n, false);       // (the headers as the device holds them: `pad` says where a pair's records are)
 	if(rc != H2G_OK) return rc;
 	static_assert(offsetof(PairOut, nres) == 0, "PairOut layout");
 	// both totals are known before either capacity is judged, so a caller that has to grow its buffers learns both needs at once
 	static_assert(offsetof(h2g_pair_result, pad) == offsetof(PairOut, pad) && sizeof(h2g_pair_result) == sizeof(PairOut), "PairOut layout");
-	for(size_t i = 0; i < n; i++) if(res[i].pad) res[i].overflow &= ~4u;     // (h2g_align_pairs_fetch flagged what its fixed rows cannot return; here every record is returned)
 	const uint64_t t1 = dense_offsets(&res[0].nres[0], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs1, &res[0].pad);
 	const uint64_t t2 = dense_offsets(&res[0].nres[1], sizeof(h2g_pair_result) / 4, s->pair_slots, n, offs2, &res[0].pad);
 	if(t1 > cap1 || t2 > cap2) return H2G_ERR_ARG;
 	int r;
 	if((r = gather_dense(s, s->d_paln[0] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first), sizeof(PairOut) / 4,
 	                     n, aln1, offs1, 0, s->d_pout + first, 0))) return r;
-	return gather_dense(s, s->d_paln[1] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
-	                    n, aln2, offs2, 2, s->d_pout + first, 1);
+	r = gather_dense(s, s->d_paln[1] + first * s->pair_slots, s->pair_slots, reinterpret_cast<const uint32_t*>(s->d_pout + first) + 1, sizeof(PairOut) / 4,
+	                 n, aln2, offs2, 2, s->d_pout + first, 1);
+	// `pad` is where the device kept the pair's records (a block offset in the overflow area: allocation order, i.e. timing) — nothing a caller may see
+	for(size_t i = 0; i < n; i++) res[i].pad = 0;
+	return r;
 }
 
 // ------------------------------------------------------------------------------------------ compact result fetch
@@ -2273,7 +2276,7 @@ extern "C" h2g_status h2g_align_pairs_fetch_compact(h2g_stream* s, h2g_pair_resu
 	HIPCHK(hipMemcpyAsync(boffs2, d_o2, (n + 1) * 8, hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipMemcpyAsync(res, s->d_pout + first, n * sizeof(PairOut), hipMemcpyDeviceToHost, s->st));
 	HIPCHK(hipStreamSynchronize(s->st));
-	for(size_t i = 0; i < n; i++) if(res[i].pad) res[i].overflow &= ~4u;      // (every record is returned)
+	for(size_t i = 0; i < n; i++) if(res[i].pad) { res[i].overflow &= ~4u; res[i].pad = 0; }      // (every record is returned; the block offset is the device's business)
 	if(boffs1[n] > cap1 || boffs2[n] > cap2) return H2G_ERR_ARG;              // (boffs[n] = the bytes needed)
 	if((rc = tmp_buf(s, 1, boffs1[n] + 8, &d_b1)) || (rc = tmp_buf(s, 3, boffs2[n] + 8, &d_b2))) return (h2g_status)rc;
 	const unsigned g = (unsigned)((n + 255) / 256);
@@ -2313,7 +2316,7 @@ extern "C" h2g_status h2g_align_fetch_compact(h2g_stream* s, h2g_read_result* re
 }
 
 // page-locked host memory for the buffers a caller hands to the set_* / fetch_* entry points: copies from / to it run at the link's rate and asynchronously
-extern "C" void* h2g_host_alloc(size_t bytes) { void* p = nullptr; if(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+extern "C" void* h2g_host_alloc(size_t bytes) { void* p = nullptr; if(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
 extern "C" void h2g_host_free(void* p) { if(p) (void)hipHostFree(p); }
 
 // The edit lists of the records with more than H2G_MAX_EDITS edits of the resident batch (include/h2g.h): the used prefix of the stream's long-edit

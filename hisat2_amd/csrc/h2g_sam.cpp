@@ -591,7 +591,39 @@ void select_by_score(const std::vector<Score>& keys, size_t num, Rng& rnd, std::
 	if(!secondary) for(size_t i = 0; i + 1 < sel.size(); i++) if(!buf[i].first.eq(buf[i + 1].first)) { sel.resize(i + 1); break; }
 }
 
-void summ_unpaired(Summ& s, int m, const h2g_alnres* lst, size_t n) {   // the rs1u_/rs2u_ loop of AlnSetSumm::init
+// The records of one read / mate: rows of h2g_alnres (fixed-stride and dense layouts), or compact records (h2g_align_*_fetch_compact: prefixes of
+// h2g_alnres of H2G_COMPACT_BYTES(nedits) bytes, back to back) found through a table of pointers built once per read.
+struct Recs {
+	const h2g_alnres* base = nullptr;
+	const h2g_alnres* const* tab = nullptr;
+	const h2g_alnres& operator[](size_t k) const { return tab ? *tab[k] : base[k]; }
+};
+// walks `n` compact records from `p` (at most to `end`) into tab; false = the bytes do not hold n records
+inline bool compact_table(const uint8_t* p, const uint8_t* end, size_t n, std::vector<const h2g_alnres*>& tab) {
+	tab.resize(n);
+	for(size_t k = 0; k < n; k++) {
+		if(p + 40 > end) return false;
+		const h2g_alnres* r = reinterpret_cast<const h2g_alnres*>(p);
+		const size_t b = H2G_COMPACT_BYTES(r->nedits);
+		if(p + b > end) return false;
+		tab[k] = r;
+		p += b;
+	}
+	return true;
+}
+// walks every compact record in [p, end) into tab; returns their count (a truncated tail ends the walk)
+inline size_t compact_walk(const uint8_t* p, const uint8_t* end, std::vector<const h2g_alnres*>& tab) {
+	tab.clear();
+	while(p + 40 <= end) {
+		const h2g_alnres* r = reinterpret_cast<const h2g_alnres*>(p);
+		const size_t b = H2G_COMPACT_BYTES(r->nedits);
+		if(p + b > end) break;
+		tab.push_back(r);
+		p += b;
+	}
+	return tab.size();
+}
+void summ_unpaired(Summ& s, int m, const Recs& lst, size_t n) {   // the rs1u_/rs2u_ loop of AlnSetSumm::init
 	for(size_t i = 0; i < n; i++) {
 		const Score sc = score_of(lst[i]);
 		if(sc.gt(s.best[m])) { s.secbest[m] = s.best[m]; s.best[m] = sc; }
@@ -875,8 +907,9 @@ extern "C" void h2g_sam_set_score_min(h2g_sam* S, uint32_t type, double c, doubl
 
 static h2g_status format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
                                   const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
-                                  const h2g_alnres* aln, const uint64_t* aln_offs, char* out, size_t cap, size_t* used)
+                                  const h2g_alnres* aln, const uint64_t* aln_offs, char* out, size_t cap, size_t* used, const uint8_t* compact = nullptr)
 {
+	if(compact) aln = reinterpret_cast<const h2g_alnres*>(compact);       // (aln_offs are byte offsets then)
 	if(!S || !codes || !offs || !nb || !noffs || !res || !aln || !used) return H2G_ERR_ARG;
 	auto one = [&](size_t i, std::string& o, Met& met) {
 		Rd rd = {nb + noffs[i], noffs[i + 1] - noffs[i], codes + offs[i], offs[i + 1] - offs[i], quals ? quals + offs[i] : nullptr};
@@ -890,9 +923,13 @@ static h2g_status format_unpaired(const h2g_sam* S, const uint8_t* codes, const 
 		met.nread++; met.nunpaired++;
 		if(nsel == 0) met.nunp_0++; else if(nsel == 1) met.nunp_uni1++; else met.nunp_uni2++;
 		if(nsel == 0) append_mate(*S, o, rd, nullptr, nullptr, nullptr, summ, fl, 0);
+		static thread_local std::vector<const h2g_alnres*> tab;
+		Recs R;
+		if(compact) { if(!compact_table(compact + aln_offs[i], compact + aln_offs[i + 1], nsel, tab)) return; R.tab = tab.data(); }
+		else R.base = aln_offs ? aln + aln_offs[i] : aln + i * H2G_ALN_CAP;
 		for(uint32_t k = 0; k < nsel; k++) {
 			fl.primary = k == 0;
-			append_mate(*S, o, rd, nullptr, (aln_offs ? aln + aln_offs[i] : aln + i * H2G_ALN_CAP) + k, nullptr, summ, fl, nsel);
+			append_mate(*S, o, rd, nullptr, &R[k], nullptr, summ, fl, nsel);
 		}
 	};
 	return drive(S, n, one, out, cap, used);
@@ -915,8 +952,9 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
                                 const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
                                 const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
                                 const h2g_pair_result* res, const h2g_alnres* aln1, const uint64_t* ao1, const h2g_alnres* aln2, const uint64_t* ao2,
-                                uint32_t khits, char* out, size_t cap, size_t* used)
+                                uint32_t khits, char* out, size_t cap, size_t* used, const uint8_t* compact1 = nullptr, const uint8_t* compact2 = nullptr)
 {
+	if(compact1) { aln1 = reinterpret_cast<const h2g_alnres*>(compact1); aln2 = reinterpret_cast<const h2g_alnres*>(compact2); }   // (ao1 / ao2 are byte offsets then)
 	if(!S || !codes1 || !offs1 || !nb1 || !noffs1 || !codes2 || !offs2 || !nb2 || !noffs2 || !res || !aln1 || !aln2 || !used) return H2G_ERR_ARG;
 	auto one = [&](size_t i, std::string& o, Met& met) {
 		std::vector<size_t> sel, sel1, sel2;
@@ -925,11 +963,19 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 		const h2g_pair_result& pr = res[i];
 		Rd rd[2] = {{nb1 + noffs1[i], noffs1[i + 1] - noffs1[i], codes1 + offs1[i], offs1[i + 1] - offs1[i], quals1 ? quals1 + offs1[i] : nullptr},
 		            {nb2 + noffs2[i], noffs2[i + 1] - noffs2[i], codes2 + offs2[i], offs2[i + 1] - offs2[i], quals2 ? quals2 + offs2[i] : nullptr}};
-		const h2g_alnres* r1 = ao1 ? aln1 + ao1[i] : aln1 + i * H2G_PAIR_RES_CAP;
-		const h2g_alnres* r2 = ao2 ? aln2 + ao2[i] : aln2 + i * H2G_PAIR_RES_CAP;
-		// records available: the dense layout carries every record the device kept, the slot layout H2G_PAIR_RES_CAP per mate
-		const size_t n1 = ao1 ? (size_t)(ao1[i + 1] - ao1[i]) : std::min<size_t>(pr.nres[0], H2G_PAIR_RES_CAP);
-		const size_t n2 = ao2 ? (size_t)(ao2[i + 1] - ao2[i]) : std::min<size_t>(pr.nres[1], H2G_PAIR_RES_CAP);
+		Recs r1, r2;
+		size_t n1, n2;
+		if(compact1) {   // every record the device kept, found by walking the read's bytes
+			static thread_local std::vector<const h2g_alnres*> t1, t2;
+			n1 = compact_walk(compact1 + ao1[i], compact1 + ao1[i + 1], t1); n2 = compact_walk(compact2 + ao2[i], compact2 + ao2[i + 1], t2);
+			r1.tab = t1.data(); r2.tab = t2.data();
+		} else {
+			r1.base = ao1 ? aln1 + ao1[i] : aln1 + i * H2G_PAIR_RES_CAP;
+			r2.base = ao2 ? aln2 + ao2[i] : aln2 + i * H2G_PAIR_RES_CAP;
+			// records available: the dense layout carries every record the device kept, the slot layout H2G_PAIR_RES_CAP per mate
+			n1 = ao1 ? (size_t)(ao1[i + 1] - ao1[i]) : std::min<size_t>(pr.nres[0], H2G_PAIR_RES_CAP);
+			n2 = ao2 ? (size_t)(ao2[i + 1] - ao2[i]) : std::min<size_t>(pr.nres[1], H2G_PAIR_RES_CAP);
+		}
 		Flags f1, f2;
 		read_filters(rd[0], &f1.lenfilt, &f1.nfilt);
 		read_filters(rd[1], &f2.lenfilt, &f2.nfilt);
@@ -1025,6 +1071,22 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 	return drive(S, n, one, out, cap, used);
 }
 
+extern "C" h2g_status h2g_sam_format_paired_compact(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                                    const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
+                                                    const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
+                                                    const h2g_pair_result* res, const uint8_t* rec1, const uint64_t* boffs1,
+                                                    const uint8_t* rec2, const uint64_t* boffs2, uint32_t khits, char* out, size_t cap, size_t* used)
+{
+	if(!boffs1 || !boffs2 || !S || !rec1 || !rec2) return H2G_ERR_ARG;
+	return format_paired(S, codes1, offs1, quals1, nb1, noffs1, codes2, offs2, quals2, nb2, noffs2, n, res, nullptr, boffs1, nullptr, boffs2, khits, out, cap, used, rec1, rec2);
+}
+extern "C" h2g_status h2g_sam_format_unpaired_compact(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                                      const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
+                                                      const uint8_t* rec, const uint64_t* boffs, char* out, size_t cap, size_t* used)
+{
+	if(!boffs || !S || !rec) return H2G_ERR_ARG;
+	return format_unpaired(S, codes, offs, quals, nb, noffs, n, res, nullptr, boffs, out, cap, used, rec);
+}
 extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
                                             const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
                                             const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,

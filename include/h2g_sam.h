@@ -112,6 +112,18 @@ H2G_EXPORT h2g_status h2g_sam_format_paired_dense(const h2g_sam*, const uint8_t*
                                                   const uint32_t* name_offs2, size_t n_pairs, const h2g_pair_result* res,
                                                   const h2g_alnres* aln1, const uint64_t* aln_offs1, const h2g_alnres* aln2,
                                                   const uint64_t* aln_offs2, uint32_t khits, char* out, size_t cap, size_t* used);
+/* Same, over the compact layout of h2g_align_fetch_compact / h2g_align_pairs_fetch_compact (byte offsets; records are prefixes of h2g_alnres).  A record
+ * beyond H2G_MAX_EDITS edits needs its batch's long-edit area (h2g_sam_set_long_edits), as in every layout. */
+H2G_EXPORT h2g_status h2g_sam_format_unpaired_compact(const h2g_sam*, const uint8_t* codes, const uint32_t* offs, const char* quals,
+                                                      const char* name_bytes, const uint32_t* name_offs, size_t n_reads,
+                                                      const h2g_read_result* res, const uint8_t* rec, const uint64_t* boffs /* [n+1] */,
+                                                      char* out, size_t cap, size_t* used);
+H2G_EXPORT h2g_status h2g_sam_format_paired_compact(const h2g_sam*, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
+                                                    const char* name_bytes1, const uint32_t* name_offs1, const uint8_t* codes2,
+                                                    const uint32_t* offs2, const char* quals2, const char* name_bytes2,
+                                                    const uint32_t* name_offs2, size_t n_pairs, const h2g_pair_result* res,
+                                                    const uint8_t* rec1, const uint64_t* boffs1, const uint8_t* rec2, const uint64_t* boffs2,
+                                                    uint32_t khits, char* out, size_t cap, size_t* used);
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,37 @@ def _novel_out(L, h, options):
         open(options[list(options).index("--novel-splicesite-outfile") + 1], "wb").write(buf.raw[:need])
 
 
+def to_compact(aln, starts, counts):
+    """records aln[starts[i] .. starts[i] + counts[i]) of every read -> (bytes, uint64 byte offsets [n + 1]) in the layout of h2g_align_*_fetch_compact:
+    40 bytes of fields + 12 per edit held (a record beyond MAX_EDITS: its marker entry), rounded up to 8, the pad zeroed"""
+    rs = C.sizeof(api.AlnRes)
+    raw = bytes(aln) if not isinstance(aln, np.ndarray) else aln.tobytes()
+    out = bytearray()
+    offs = np.zeros(len(starts) + 1, dtype=np.uint64)
+    for i, (s0, c) in enumerate(zip(starts, counts)):
+        for k in range(int(c)):
+            at = (int(s0) + k) * rs
+            ne = int.from_bytes(raw[at + 24:at + 28], "little")
+            e = 1 if ne > api.MAX_EDITS else ne
+            out += raw[at:at + 40 + 12 * e]
+            if e & 1:
+                out += b"\0\0\0\0"
+        offs[i + 1] = len(out)
+    return bytes(out) + b"\0" * 8, offs
+
+
+def _check_compact_unpaired(L, h, codes, offs, qp, nb, noffs, n, res, rp, aln, want_text):
+    """the compact formatter over a host-compacted copy of the same records must write the same text (every SAM-line test is also its test)"""
+    nsel = np.array([min(int(res[i].nselect) if not isinstance(res, np.ndarray) else int(res["nselect"][i]), api.ALN_CAP) for i in range(n)])
+    rec, boffs = to_compact(aln, np.arange(n) * api.ALN_CAP, nsel)
+    L.h2g_sam_format_unpaired_compact.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    cap = len(want_text) + 64
+    buf = C.create_string_buffer(cap)
+    used = C.c_size_t(0)
+    rc = L.h2g_sam_format_unpaired_compact(h, codes.ctypes.data, offs.ctypes.data, qp, nb, noffs.ctypes.data, n, rp, rec, boffs.ctypes.data, buf, cap, C.byref(used))
+    assert rc == 0 and buf.raw[:used.value] == want_text, "compact formatter differs from the row formatter"
+
+
 def format_unpaired(L, base, reads, names, res, aln, quals=None, options=(), long_edits=None):
     """res: array of api.ReadResult (or same-layout numpy), aln: api.AlnRes * (n*ALN_CAP) -> list of SAM lines.
     long_edits = (api.Edit array, n): the batch's long-edit area (records with nedits > MAX_EDITS, h2g_align_fetch_long_edits)"""
@@ -126,6 +157,14 @@ def format_unpaired(L, base, reads, names, res, aln, quals=None, options=(), lon
         quals = np.ascontiguousarray(quals, dtype=np.uint8)
         qp = quals.ctypes.data
     rc = L.h2g_sam_format_unpaired(h, codes.ctypes.data, offs.ctypes.data, qp, nb, noffs.ctypes.data, n, rp, ap, buf, cap, C.byref(used))
+    if rc == 0 and not (options and ("--novel-splicesite-outfile" in options or "--new-summary" in options)) and n <= 20000:
+        h2 = C.c_void_p()                                  # (a handle of its own: the summary / site statistics of `h` count every line once)
+        assert L.h2g_sam_open(base.encode(), C.byref(h2)) == 0
+        _score_min(L, h2, options)
+        if long_edits is not None and long_edits[1]:
+            L.h2g_sam_set_long_edits(h2, long_edits[0], long_edits[1])
+        _check_compact_unpaired(L, h2, codes, offs, qp, nb, noffs, n, res, rp, aln, buf.raw[:used.value])
+        L.h2g_sam_close(h2)
     global LAST_SUMMARY
     sb = C.create_string_buffer(4096)
     nsum = L.h2g_sam_summary(h, sb, 4096)
@@ -162,6 +201,26 @@ def format_paired(L, base, m1, m2, n1, n2, res, a1, a2, khits, options=(), dense
     else:
         rc = L.h2g_sam_format_paired(h, c1.ctypes.data, o1.ctypes.data, None, nb1, no1.ctypes.data, c2.ctypes.data, o2.ctypes.data, None, nb2,
                                      no2.ctypes.data, n, ptr(res), ptr(a1), ptr(a2), khits, buf, cap, C.byref(used))
+    if rc == 0 and not (options and ("--novel-splicesite-outfile" in options or "--new-summary" in options)) and n <= 20000:
+        # the compact formatter over a host-compacted copy of the same records must write the same text
+        cnt = lambda r, m: int(r.nres[m])
+        if dense is not None:
+            s1, c1_ = dense[0][:-1], np.diff(dense[0].astype(np.int64)); s2, c2_ = dense[1][:-1], np.diff(dense[1].astype(np.int64))
+        else:
+            s1 = s2 = np.arange(n) * api.PAIR_RES_CAP
+            c1_ = np.array([min(cnt(res[i], 0), api.PAIR_RES_CAP) for i in range(n)]); c2_ = np.array([min(cnt(res[i], 1), api.PAIR_RES_CAP) for i in range(n)])
+        rec1, bo1 = to_compact(a1, s1, c1_); rec2, bo2 = to_compact(a2, s2, c2_)
+        h2 = C.c_void_p()
+        assert L.h2g_sam_open(base.encode(), C.byref(h2)) == 0
+        _score_min(L, h2, options)
+        L.h2g_sam_format_paired_compact.argtypes = [C.c_void_p] + [C.c_void_p] * 10 + [C.c_size_t, C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t,
+                                                     C.POINTER(C.c_size_t)]
+        buf2 = C.create_string_buffer(used.value + 64)
+        u2 = C.c_size_t(0)
+        rc2 = L.h2g_sam_format_paired_compact(h2, c1.ctypes.data, o1.ctypes.data, None, nb1, no1.ctypes.data, c2.ctypes.data, o2.ctypes.data, None, nb2, no2.ctypes.data, n, ptr(res),
+                                              rec1, bo1.ctypes.data, rec2, bo2.ctypes.data, khits, buf2, used.value + 64, C.byref(u2))
+        L.h2g_sam_close(h2)
+        assert rc2 == 0 and buf2.raw[:u2.value] == buf.raw[:used.value], "compact formatter differs from the row formatter"
     global LAST_SUMMARY
     sb = C.create_string_buffer(4096)
     nsum = L.h2g_sam_summary(h, sb, 4096)

@@ -21,7 +21,7 @@ def _declared(hdr=HDR):
 def test_library_exports_the_sam_emitter():
     """include/h2g_sam.h (host-side SAM emission) lives in the same library"""
     names = _declared(os.path.join(ROOT, "include", "h2g_sam.h"))
-    assert sorted(names) == ["h2g_sam_add_read_group", "h2g_sam_add_splice_sites", "h2g_sam_close", "h2g_sam_collect_novel_sites", "h2g_sam_format_paired", "h2g_sam_format_paired_dense", "h2g_sam_format_unpaired", "h2g_sam_format_unpaired_dense", "h2g_sam_header", "h2g_sam_novel_splice_sites_text", "h2g_sam_open", "h2g_sam_read_splice_site_file", "h2g_sam_set_chrname_mode", "h2g_sam_set_first_read_id", "h2g_sam_set_header_options", "h2g_sam_set_long_edits", "h2g_sam_set_new_summary", "h2g_sam_set_no_unal", "h2g_sam_set_report_policy", "h2g_sam_set_rna_strandness", "h2g_sam_set_score_min", "h2g_sam_set_secondary", "h2g_sam_set_splice_sites", "h2g_sam_set_templatelen_adjustment", "h2g_sam_set_threads", "h2g_sam_summary", "h2g_sam_take_novel_sites"]
+    assert sorted(names) == ["h2g_sam_add_read_group", "h2g_sam_add_splice_sites", "h2g_sam_close", "h2g_sam_collect_novel_sites", "h2g_sam_format_paired", "h2g_sam_format_paired_compact", "h2g_sam_format_paired_dense", "h2g_sam_format_unpaired", "h2g_sam_format_unpaired_compact", "h2g_sam_format_unpaired_dense", "h2g_sam_header", "h2g_sam_novel_splice_sites_text", "h2g_sam_open", "h2g_sam_read_splice_site_file", "h2g_sam_set_chrname_mode", "h2g_sam_set_first_read_id", "h2g_sam_set_header_options", "h2g_sam_set_long_edits", "h2g_sam_set_new_summary", "h2g_sam_set_no_unal", "h2g_sam_set_report_policy", "h2g_sam_set_rna_strandness", "h2g_sam_set_score_min", "h2g_sam_set_secondary", "h2g_sam_set_splice_sites", "h2g_sam_set_templatelen_adjustment", "h2g_sam_set_threads", "h2g_sam_summary", "h2g_sam_take_novel_sites"]
     L = api.lib()
     for n in names:
         assert hasattr(L, n), n
