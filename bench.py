@@ -473,7 +473,7 @@ def main():
                     "tail_hand_off": int(os.environ.get("H2G_FAST_TAIL", api.DEFAULT_TAIL)),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "pairs_completed_by_the_kernel": int(cnt.n_fast), "pairs_handed_on": int(cnt.n_fast_bail),
-                    "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs (about 0.5 %: long latency chains), on one of two machine streams next to the fast passes of the following two steps",
+                    "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs (about 0.8 %), on one of 8 machine streams next to the fast passes of the following steps",
                     "whole_step": {"algorithmic_bytes": alg_all, "GB/s": alg_all / (dt / a.steps) / 1e9, "frac": alg_all / (dt / a.steps) / 1e9 / HBM_PEAK_GBS},
                     "sides_per_pair": int(cnt.n_side) / npairs, "sa_steps_per_pair": int(cnt.n_sa_steps) / npairs,
                     "note": "latency chains over scattered 64 B index lines + per-read control; per trip a read's 160 B state and 264 B of hot words + packed reads are loaded in one batch of 16 B loads and stored back (DESIGN.md §3.1)"}
@@ -490,7 +490,7 @@ def main():
                        "genome_bases": total, "index_device_bytes": int(ix.info.device_bytes), "pairs_per_gpu": npairs, "read_len": 101, "sub_rate": 0.005,
                        "fragment": "N(300, 30) clipped to [150, 600]",
                        "stage": "HI_Aligner::go for both mates + pairing; report events stay in HBM (finishRead / SAM text are host code, SURVEY §8(f) N1)",
-                       "pipelining": "the machine pass of step k overlaps the fast passes of steps k+1 and k+2 (two machine streams, three buffer sets); all K steps complete inside the timed region",
+                       "pipelining": "the general machine's pass over step k's hand-ons runs on machine stream k mod 8 next to the fast passes of the following steps (up to 8 such passes in flight, buffers 9 deep, 16 hardware queues); all K steps complete inside the timed region",
                        "sharding": f"pairs by id range across {world} GPU(s) ({'one global batch split' if a.strong else 'fixed work per GPU'}), index replicated; RCCL all-reduce of the summary counters only"},
             "roofline": roofline,
             "counters": {"pairs": int(summ[0]), "pairs_with_concordant": int(summ[1]), "pairs_still_flagged_overflow": int(summ[2]),

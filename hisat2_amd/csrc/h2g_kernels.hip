@@ -1850,8 +1850,22 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	unsigned mach_cap = s->tune.mach_total / M;                  // workgroups of one machine pass behind a fast pass
 	if(mach_cap > H2G_MACH_MAXGRID) mach_cap = H2G_MACH_MAXGRID;
 	if(mach_cap < 1) mach_cap = 1;
+	const unsigned bgrid = fast ? 2u : 4u;                        // workgroups of a second pass (large workspace: ~5 MB per read in flight)
 	{	// behind a fast pass the machine works on stream gen % M with that stream's pools, on at most mach_cap workgroups
 		const size_t pgrid = fast && grid > mach_cap ? (size_t)mach_cap : (size_t)grid;
+		if(fast && s->n_reads >= 200000) {
+			// large batches (a streaming caller's): every machine stream's pools exist before the first pass that could need them — an allocation
+			// in the middle of a queue of runs (gigabytes, synchronous) would stall all of them; the first run of a stream pays for it once.
+			// (Small batches keep allocating a machine stream's pools when it is first used.)
+			const GoUnit& Bp = go_unit(linear, true, spl);
+			uint32_t bgeo_[4];
+			Bp.geometry(bgeo_);
+			GoArgs scratch = A;
+			for(unsigned m_ = 0; m_ < M; m_++) {
+				if((rc = go_pool_for(s, 2 * (int)m_, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &scratch))) return rc;
+				if(!big_main && !s->tune.no_second_pass && (rc = go_pool_for(s, 2 * (int)m_ + 1, Bp, (size_t)bgrid * bgeo_[1], (size_t)bgrid * bgeo_[0], p->bowtie2_dp, &scratch))) return rc;
+			}
+		}
 		if((rc = go_pool_for(s, fast ? 2 * (int)(s->gen % M) : 0, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &A))) return rc;
 	}
 	memset(&A.O, 0, sizeof A.O);
@@ -2046,7 +2060,6 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	if(second) {
 		const GoUnit& B = go_unit(linear, true, spl);
 		uint32_t* cnt = ovl + s->max_reads;       // (filled by the main pass itself: MachOut::defer_list)
-		const unsigned bgrid = 4;
 		uint32_t bgeo[4];
 		B.geometry(bgeo);
 		GoArgs A2 = A;
