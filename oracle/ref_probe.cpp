@@ -341,6 +341,55 @@ int main(int argc, char** argv) {
 		}
 		return 0;
 	}
+	if(cmd == "combine") {
+		// combine <base> <reads.fa> <nospliced:0|1>: GenomeHit::combineWith (hi_aligner.h:1420-2025) on two partial alignments of a read whose
+		// names carry them: ">id|fw|tidx|rdoffA|lenA|toffA|rdoffB|lenB|toffB".  Both hits are GenomeHit::init'ed exact anchors (the generator keeps
+		// them free of mismatches); what lies between them on the read — mismatches, an insertion, a deletion, an intron — is combineWith's to place.
+		vector<Read*> rds;
+		loadReads(argv[3], rds);
+		bool nospliced = (argc > 4) ? atoi(argv[4]) != 0 : true;
+		SimpleFunc scoreMin, nCeil, canIL, noncanIL;
+		Scoring* sc = makeScoring(scoreMin, nCeil, canIL, noncanIL, nospliced);
+		RandomSource rnd;
+		EList<string> refnames;
+		SpliceSiteDB ssdb(*p.ref, refnames, false, false, false);
+		SwAligner swa;
+		SwMetrics swm;
+		SharedTempVars<index_t> sharedVars;
+		init_junction_prob();
+		for(size_t ri = 0; ri < rds.size(); ri++) {
+			Read& rd = *rds[ri];
+			unsigned id, fw, tidx, roA, lenA, toA, roB, lenB, toB;
+			if(sscanf(rd.name.toZBuf(), "%u|%u|%u|%u|%u|%u|%u|%u|%u", &id, &fw, &tidx, &roA, &lenA, &toA, &roB, &lenB, &toB) != 9) continue;
+			index_t rdlen = (index_t)rd.length();
+			TAlScore minsc = (TAlScore)scoreMin.f<double>((double)rdlen);
+			if(minsc > 0) minsc = 0;
+			// joined offsets of the two anchors (rstarts: joined start, text id, text offset of every fragment)
+			auto joined = [&](index_t t, index_t off) -> index_t {
+				const index_t* rs = gfm.rstarts();
+				for(index_t f = 0; f < gfm.nFrag(); f++) {
+					if(rs[f * 3 + 1] != t || rs[f * 3 + 2] > off) continue;
+					index_t flen = (f + 1 < gfm.nFrag() ? rs[(f + 1) * 3] : gh._len) - rs[f * 3];
+					if(off - rs[f * 3 + 2] < flen) return rs[f * 3] + (off - rs[f * 3 + 2]);
+				}
+				return 0;
+			};
+			GenomeHit<index_t> a, b;
+			a.init(fw != 0, roA, lenA, 0, 0, tidx, toA, joined(tidx, toA), sharedVars);
+			b.init(fw != 0, roB, lenB, 0, 0, tidx, toB, joined(tidx, toB), sharedVars);
+			rnd.init((uint32_t)(id * 13 + 1));
+			bool ok = a.combineWith(b, rd, gfm, *p.ref, *p.altdb, *p.repeatdb, ssdb, swa, swm, *sc, minsc, rnd, (index_t)8,
+			                        (index_t)20, (index_t)500000, (index_t)7, (index_t)14, (index_t)16, NULL, nospliced);
+			printf("%u %d %lld -> %d %u %u %u %lld %u", id, (int)fw, (long long)minsc, (int)ok, a.rdoff(), a.len(), a.refoff(), (long long)a.score(), (unsigned)a.edits().size());
+			for(size_t e = 0; e < a.edits().size(); e++) {
+				const Edit& ed = a.edits()[e];
+				if(ed.type == EDIT_TYPE_SPL) printf(" %u:S:%u:%d:%d", ed.pos, ed.splLen, (int)ed.splDir, (int)ed.knownSpl);
+				else printf(" %u:%c>%c:%d", ed.pos, (char)ed.chr, (char)ed.qchr, (int)ed.type);
+			}
+			putchar('\n');
+		}
+		return 0;
+	}
 	if(cmd == "psearch" || cmd == "lsearch" || cmd == "coords" || cmd == "extend" || cmd == "sw" || cmd == "adjust") {
 		// <cmd> <base> <reads.fa> <nospliced:0|1>
 		vector<Read*> rds;

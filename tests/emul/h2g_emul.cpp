@@ -307,6 +307,19 @@ static void emu_ctx(Emu* e, uint32_t no_spliced, AlnParams* P, AlnCtx* C) {
 	C->alts = &e->dalts; C->gws = e->dg.linear ? nullptr : &gws_; C->gsl = e->dg.linear ? nullptr : &gsl_; C->graph = !e->dg.linear;
 }
 
+// GenomeHit::combineWith (hit_combine) on n pairs of partial alignments of the resident reads: a[i] is combined with b[i] in place; ok[i] = its return value.
+// minsc[i] as the reference passes it (scoreMin.f(read length)).
+void h2gemu_combine(Emu* e, uint32_t no_spliced, h2g_ghit* a, const h2g_ghit* b, const int64_t* minsc, size_t n, uint32_t* ok) {
+	AlnParams P; AlnCtx C;
+	emu_ctx(e, no_spliced, &P, &C);
+	DReads rd = e->reads();
+	static int64_t t1[H2G_COMBINE_MAXLEN], t2[H2G_COMBINE_MAXLEN];
+	for(size_t i = 0; i < n; i++) {
+		SeqView sv = seq_view(rd, a[i].read, a[i].fw != 0);
+		ok[i] = hit_combine(e->dr, P.sc, sv, &a[i], &b[i], minsc[i], P.minIntronLen, P.no_spliced != 0, ScVec{t1, 1}, ScVec{t2, 1}, C.alts) ? 1u : 0u;
+	}
+}
+
 void h2gemu_set_rdid_base(Emu* e, uint32_t base) { e->rdid_base = base; }
 void h2gemu_set_splice_sites(Emu* e, const h2g_splice_site* sites, size_t n, uint32_t window) {
 	std::vector<h2g_splice_site> all(e->alt_sites);

@@ -205,8 +205,75 @@ def main_sw16():
     shutil.rmtree(tmp)
 
 
+def combine_reads(contigs, n, seed, rdlen=101):
+    """reads made of two exact anchors of the genome with something for GenomeHit::combineWith to place between them: nothing (a plain join), mismatches,
+    an insertion, a deletion, an intron (a jump of 20 ... 3000 reference bases).  Names = "id|fw|tidx|rdoffA|lenA|toffA|rdoffB|lenB|toffB" in the coordinates of
+    the aligned strand.  -> (names, read arrays)"""
+    rng = np.random.default_rng(seed)
+    names, reads = [], []
+    k = 0
+    while k < n:
+        tidx = int(rng.integers(0, len(contigs)))
+        c = contigs[tidx]
+        kind = int(rng.integers(0, 6))                       # 0 join, 1 mismatches, 2 insertion, 3 deletion, 4 intron, 5 deletion + mismatches
+        lenA = int(rng.integers(18, 45)); lenB = int(rng.integers(18, 45))
+        mid = rdlen - lenA - lenB                            # bases of the read between the anchors
+        ins = int(rng.integers(1, 4)) if kind == 2 else 0
+        skip = int(rng.integers(1, 16)) if kind in (3, 5) else int(rng.integers(20, 3000)) if kind == 4 else 0
+        cut = int(rng.integers(1, mid)) if mid > 1 else 0   # where in the middle the event sits
+        span = rdlen - ins + skip
+        s0 = int(rng.integers(0, len(c) - span - 1))
+        ref = c[s0:s0 + span]
+        if (ref > 3).any():
+            continue
+        left = ref[:lenA + cut]
+        right = ref[lenA + cut + skip:]
+        strand = np.concatenate([left, rng.integers(0, 4, size=ins).astype(np.uint8), right])[:rdlen]
+        if len(strand) != rdlen:
+            continue
+        if kind in (1, 5) and mid > 4:                       # substitutions strictly between the anchors
+            for pos in rng.choice(np.arange(lenA + 1, lenA + mid - 1), size=min(2, mid - 2), replace=False):
+                strand[pos] = (strand[pos] + int(rng.integers(1, 4))) & 3
+        toA = s0
+        roB = rdlen - lenB
+        toB = s0 + span - lenB
+        if not (np.array_equal(strand[:lenA], c[toA:toA + lenA]) and np.array_equal(strand[roB:], c[toB:toB + lenB])):
+            continue
+        fw = int(rng.integers(0, 2))
+        rd = strand if fw else (3 - strand[::-1]).astype(np.uint8)
+        names.append("%d|%d|%d|%d|%d|%d|%d|%d|%d" % (k, fw, tidx, 0, lenA, toA, roB, lenB, toB))
+        reads.append(rd.astype(np.uint8))
+        k += 1
+    return names, reads
+
+
+def main_combine():
+    """probe_combine{,_spliced}.txt.gz + reads_combine.fa.gz: GenomeHit::combineWith of the reference on the g1 index (SURVEY §8 a20)"""
+    import parity_cases as PC
+    tmp = tempfile.mkdtemp(prefix="h2goldc")
+    for k in range(1, 9):
+        with gzip.open(os.path.join(GOLD, f"g1.{k}.ht2.gz"), "rb") as f, open(os.path.join(tmp, f"g1.{k}.ht2"), "wb") as o:
+            shutil.copyfileobj(f, o)
+    contigs = PC.load_contigs(GOLD)
+    names, reads = combine_reads(contigs, 1500, SEED + 77)
+    rfa = os.path.join(tmp, "reads_combine.fa")
+    with open(rfa, "wb") as f:
+        for nm, r in zip(names, reads):
+            f.write(b">" + nm.encode() + b"\n" + synth._ALPHA[r].tobytes() + b"\n")
+    gz_write(os.path.join(GOLD, "reads_combine.fa.gz"), open(rfa, "rb").read())
+    for nosp, out in ((1, "probe_combine.txt.gz"), (0, "probe_combine_spliced.txt.gz")):
+        txt = run([os.path.join(REF, "ref_probe"), "combine", os.path.join(tmp, "g1"), rfa, str(nosp)]).stdout
+        gz_write(os.path.join(GOLD, out), txt)
+        ok = sum(1 for l in txt.splitlines() if b"-> 1" in l)
+        print(out, len(txt.splitlines()), "lines,", ok, "combined")
+    shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "extsearch":
+    if len(sys.argv) > 1 and sys.argv[1] == "combine":
+        sys.path.insert(0, HERE)
+        main_combine()
+    elif len(sys.argv) > 1 and sys.argv[1] == "extsearch":
         main_extsearch()
     elif len(sys.argv) > 1 and sys.argv[1] == "graph":
         main_graph()
