@@ -71,3 +71,27 @@ def test_unpaired_compact_equals_dense(g1_index, golden_dir):
     assert np.array_equal(woffs, b) and rec[:int(b[n])].tobytes() == want[:int(woffs[n])]
     assert int(f[n]) > n // 2
     st.close(); ix.close()
+
+
+def test_compact_offsets_over_many_scan_tiles(g1_index, golden_dir):
+    """30 011 pairs: the prefix sum behind the compact fetch runs over 15 tiles of 2048 entries (tile scan, scan of the tile sums, add back) — offsets and bytes
+    against the host compaction of the dense fetch"""
+    import parity_cases as PC
+    contigs = PC.load_contigs(golden_dir)
+    n = 30011
+    m1, m2 = synth.make_pairs(contigs, n, 101, 4711, frag_mean=300, frag_sd=30, sub_rate=0.02)
+    c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
+    q = [str(i) for i in range(n)]
+    ix = api.Index(g1_index, device=0)
+    st = api.Stream(ix, max_reads=n, max_bases=c1.size)
+    st.set_reads(c1, o1); st.set_read_names(q); st.set_mates(c2, o2, q)
+    st.align_pairs_run()
+    res, a1, f1, a2, f2 = st.align_pairs_fetch_dense()
+    cres, r1, b1, r2, b2 = st.align_pairs_fetch_compact()
+    assert bytes(res) == cres.tobytes()
+    for a, f, r, b in ((a1, f1, r1, b1), (a2, f2, r2, b2)):
+        want, woffs = SL.to_compact(a, f[:-1], np.diff(f.astype(np.int64)))
+        assert np.array_equal(woffs, b)
+        assert r[:int(b[n])].tobytes() == want[:int(woffs[n])]
+    assert int(f1[n]) > n // 2
+    st.close(); ix.close()
