@@ -798,7 +798,7 @@ def timed_pairs(api, synth, base, local, m1, m2, steps=5, whole_parity=True):
            "hand_ons_by_reason": fast_bail_reasons(api, st), "pairs_second_pass": int(c.n_second_pass), "second_pass_rate": int(c.n_second_pass) / n,
            "pairs_still_flagged_overflow": int(c.n_overflow), "pairs_with_concordant": int(c.n_aligned),
            "ranks_per_pair": int(c.n_rank) / n, "sides_per_pair": int(c.n_side) / n, "sa_steps_per_pair": int(c.n_sa_steps) / n,
-           "index_device_bytes": int(ix.info.device_bytes)}
+           "index_device_bytes": int(ix.info.device_bytes), "_fast_alg_bytes": (int(c.n_fast_side) + int(c.n_fast_sa_steps)) * 64}
     if whole_parity and os.path.exists(os.path.join(REF, "hisat2-align-s")):
         # the whole batch on the device (the stream's results of the run above) against the reference binary, every SAM line
         tmp = tempfile.mkdtemp(prefix="h2whole")
@@ -831,6 +831,22 @@ def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, 
     leg = {"workload": f"repeat-structured {glen} bp genome (interspersed families of ~300 bp and 1-6 kbp at 8-20 % divergence in a quarter of the bases, tandem arrays, segmental "
                        f"duplications; 24 contigs), linear index, {npairs} x 2 x 101 bp pairs, --no-spliced-alignment -k 5", "index_build_s": t_build}
     leg.update(timed_pairs(api, synth, base, local, m1, m2, whole_parity=not a.no_whole_parity and not a.no_cpu_baseline))
+    # roofline of this leg: the fast kernel over its own algorithmic bytes, and the whole step (fast + machine passes, steady state)
+    alg_fast = leg.pop("_fast_alg_bytes")
+    alg_all = (leg["sides_per_pair"] + leg["sa_steps_per_pair"]) * npairs * 64
+    pm_rep = None
+    try:
+        pm_rep = json.load(open(os.path.join(ROOT, "profiles", "r05_rep_pmc_traffic.json")))
+    except (OSError, ValueError):
+        pass
+    leg["roofline"] = {"bound": "hbm", "kernel": "k_go_fast (h2g_k_go_fast.hip) over the pairs it completes", "kernel_ms": leg["fast_kernel_ms"],
+                       "achieved": alg_fast / (leg["fast_kernel_ms"] * 1e-3) / 1e9 if leg["fast_kernel_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg_fast / (leg["fast_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["fast_kernel_ms"] > 0 else 0.0,
+                       "traffic": (int(pm_rep["traffic_bytes_per_launch"]) if pm_rep and pm_rep.get("kernel_sources_sha16") == kernel_sources_sha16() and pm_rep.get("pairs_per_launch") == npairs else None),
+                       "traffic_record": "profiles/r05_rep_pmc_traffic.json (lease A: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this leg's fast kernel; attached only on the sources it was taken on)",
+                       "algorithmic": "64 B x (unique sides + SA-walk steps) of the fast kernel's own searches and walks",
+                       "whole_step": {"algorithmic_bytes": alg_all, "GB/s": alg_all / (leg["ms_per_step"] * 1e-3) / 1e9, "frac": alg_all / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "fast pass + the general machine's passes over the hand-ons (8 in flight) + second passes, steady state of queued runs"}}
     tmp = tempfile.mkdtemp(prefix="h2rep")
     f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
     synth.write_reads_fasta(f1, m1[:nparity]); synth.write_reads_fasta(f2, m2[:nparity])
@@ -853,9 +869,19 @@ def graph256_leg(a, api, synth, local, cache, glen=256_000_000, every=250, npair
     leg = {"workload": f"configs[3] shape: SNP-graph index over a seeded {glen} bp genome, a variant every ~{every} bp, {npairs} x 2 x 101 bp pairs from the alternate haplotype, --no-spliced-alignment",
            "index_build": info}
     leg.update(timed_pairs(api, synth, base, local, m1, m2, whole_parity=not a.no_whole_parity and not a.no_cpu_baseline))
+    leg.pop("_fast_alg_bytes", None)
     alg = (leg["ranks_per_pair"] + leg["sa_steps_per_pair"]) * npairs * 128
+    pm_g = None
+    try:
+        pm_g = json.load(open(os.path.join(ROOT, "profiles", "r05_graph_pmc_traffic.json")))
+    except (OSError, ValueError):
+        pass
     leg["roofline"] = {"bound": "hbm", "kernel": "k_go_fast_graph + k_go<true> over the hand-ons (whole step)", "achieved": alg / (leg["ms_per_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": alg / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic": "(rank queries + SA-walk steps) x 128 B graph sides"}
+                       "unit": "GB/s", "frac": alg / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "traffic": (int(pm_g["traffic_bytes_per_launch"]) if pm_g and pm_g.get("kernel_sources_sha16") == kernel_sources_sha16() and pm_g.get("pairs_per_launch") == npairs else None),
+                       "traffic_record": "profiles/r05_graph_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of k_go_fast_graph per launch (a LOWER bound: the counter tallies a 128 B side request at 64 B, profiles/r04_rank_pmc.json; "
+                                         "the record also holds 2 x FETCH_SIZE + WRITE_SIZE); attached only on the sources it was taken on",
+                       "algorithmic": "(rank queries + SA-walk steps) x 128 B graph sides (the graph units count rank queries: an upper bound of the unique sides SURVEY §8(d) asks for)"}
     tmp = tempfile.mkdtemp(prefix="h2g256")
     f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
     synth.write_reads_fasta(f1, m1[:nparity]); synth.write_reads_fasta(f2, m2[:nparity])
