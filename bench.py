@@ -395,6 +395,11 @@ def main():
         import datetime
         dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(hours=2))   # "nccl" == RCCL on ROCm; (rank 0 may build the index behind the first barrier)
 
+    if world > 1:
+        # N > 1 measures the sharded hot path only: the CPU baseline, the whole-batch parity against the reference binary, the command-line figures and the companion legs are
+        # single-GPU items (they run at N = 1: SURVEY §8(d)) and would only keep N - 1 ranks waiting at the last barrier
+        a.no_extras = True
+        a.no_cpu_baseline = True
     cache = os.path.join(ROOT, ".bench_cache")
     if a.only_legs:
         out = {}
@@ -508,7 +513,9 @@ def main():
                 # every record of the batch the timed steps ran on (the stream still holds the last step's results) against the reference binary
                 out["parity_whole_batch"] = whole_batch_parity(api, base, st, c1, o1, c2, o2, names, int(params.khits), f1, f2, tmp=tmp)
                 parity_failed = not out["parity_whole_batch"].get("digest_equal", False)
-        # host buffers in, host buffers out: upload + both passes + dense fetch of the report events (never `value`)
+        if world > 1:
+            out["single_gpu_items"] = "cpu_baseline, parity_whole_batch, cli_end_to_end and the companion legs are measured by the N = 1 run"
+        # host buffers in, host buffers out: upload + both passes + compact fetch of the report events (never `value`)
         pool = api.PinnedPool()
         pc1 = pool.array("c1", c1.size); pc1[:] = c1
         pc2 = pool.array("c2", c2.size); pc2[:] = c2
