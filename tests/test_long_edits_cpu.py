@@ -28,7 +28,7 @@ def deletion_reads(contigs, n, rdlen, seed, dmin=26, dmax=70, sub=0.01):
     while k < n:
         c = contigs[int(rng.integers(0, len(contigs)))]
         D = int(rng.integers(dmin, dmax + 1))
-        left = int(rng.integers(30, rdlen - 30))
+        left = int(rng.integers(min(30, rdlen // 3), max(min(30, rdlen // 3) + 1, rdlen - 30)))
         s = int(rng.integers(0, len(c) - rdlen - D - 1))
         w = np.concatenate([c[s:s + left], c[s + left + D:s + rdlen + D]])
         if (w > 3).any():
