@@ -6,8 +6,13 @@ One "step" = one pass of the hot path over one resident batch of synthetic read 
 (hi_aligner.h:4048: FM backward search of both mates on both strands, SA-offset resolution, ungapped extension, local-index
 search, indel joins, recursion, mate rescue, pairing, sink feedback) — h2g_align_pairs_run: the fast pass (h2g_k_go_fast.hip:
 the dominant traces with a compact per-read state), the general machine's pass over the reads the fast pass handed on, and the
-large-workspace pass over what overflowed that.  The machine's pass of step k runs on a second stream next to the fast pass of
-step k + 1 (its own share of the CUs); the K timed steps are bracketed by a full synchronisation of both streams.
+large-workspace pass over what overflowed that.  The machine's pass of step k runs on machine stream k mod 8 next to the fast passes of
+the following steps (up to eight in flight; the process asks for 16 hardware queues); the K timed steps are bracketed by a full
+synchronisation of every stream, so the drain of the last machine passes is inside the timed region.
+
+Parity at the size that is timed: every record of the batch the timed steps ran on goes through the product's sink + SAM text and is
+compared with oracle/_ref/hisat2-align-s over the same reads, byte for byte (`parity_whole_batch`; a mismatch prints the line and fails
+the run) — the reference binary is the checker, never inside a timed region.
 
 Workload at N=1 = BASELINE.json configs[2]: GRCh38-SIZE linear index (3.1 Gbp, 4.7 GB resident), 101 bp paired-end reads,
 --no-spliced-alignment.  The index is the reference builder's (oracle/_ref/hisat2-build-s) over a seeded uniform-random genome in
@@ -16,7 +21,8 @@ Workload at N=1 = BASELINE.json configs[2]: GRCh38-SIZE linear index (3.1 Gbp, 4
 size (e.g. 256e6 for a quick run); the size actually used is named in config.workload.  configs[1] (E. coli-size, single-end)
 runs as the extra leg "ecoli_se"; the extra legs are skipped when the run is past H2G_BENCH_DEADLINE seconds (default 1350).
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]        (N>1 via torch.distributed.run, one rank per GPU)
+Launch:  python bench.py [--gpus N --steps K --warmup W]        (N > 1: N ranks, one per GPU — under torch.distributed.run, or spawned by this
+program when it is started on its own; fewer than N visible devices is an error, never a silent N = 1)
 Prints ONE JSON line on rank 0.
 """
 import argparse

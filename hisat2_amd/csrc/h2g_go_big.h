@@ -4,15 +4,15 @@
 #pragma once
 // ... and the reference's edit lists are unbounded (hi_aligner.h:421 LinkedEList<EList<Edit>>; a deletion of n bases is n edits, edit.h): the working hit of
 // these units holds H2G_GHIT_EDITS of them (include/h2g.h: a per-translation-unit capacity; 32 in the default units, whose flagged reads come here).  A
-// record beyond the 32 inline entries of h2g_alnres leaves through the long-edit area (MachOut::ledits).  160 edits = a 101-base read at --score-min L,0,-4.8
-// all in deletions, or every base of a 160-base read mismatching.
+// record beyond the 32 inline entries of h2g_alnres leaves through the long-edit area (MachOut::ledits).  192 edits = a 101-base read at --score-min L,0,-5.7
+// all in deletions; one extension may add 160 (H2G_NEW_EDITS: the mismatches --score-min L,0,-3 buys a 250-base read).
 #ifndef H2G_GHIT_EDITS
-#define H2G_GHIT_EDITS 160
+#define H2G_GHIT_EDITS 192
 #endif
 #ifndef H2G_NEW_EDITS
-#define H2G_NEW_EDITS 96
+#define H2G_NEW_EDITS 160
 #endif
-// (a slot of these units is ~5 MB: 256 reads in flight per workgroup keep the second pass's pool at its former size)
+// (a slot of these units is 6.1 MB: 256 reads in flight per workgroup keep the second pass's pool near its former size)
 #ifndef H2G_GO_SLOTS
 #define H2G_GO_SLOTS 256
 #endif

@@ -385,7 +385,7 @@ H2G_EXPORT void       h2g_host_free(void*);
  * is n edits (edit.h).  A record whose list does not fit its H2G_MAX_EDITS inline entries says so with nedits > H2G_MAX_EDITS: its edits live in the
  * stream's long-edit area, at offset edits[0].pos (edits[0].snp == 0x4c4f4e47 marks it; the other inline entries are unspecified).  This call returns
  * the used prefix of that area for the resident batch: *n = edits it spans (0 when the batch has no such record); H2G_ERR_ARG with *n set when cap is
- * smaller.  include/h2g_sam.h: h2g_sam_set_long_edits hands it to the formatter.  Capacity of the working lists: 160 edits per alignment (the units with
+ * smaller.  include/h2g_sam.h: h2g_sam_set_long_edits hands it to the formatter.  Capacity of the working lists: 192 edits per alignment (the units with
  * the large workspace, which the flagged reads of the default units are re-run by); beyond that a read keeps overflow bit 1. */
 H2G_EXPORT h2g_status h2g_align_fetch_long_edits(h2g_stream*, h2g_edit* out, size_t cap, size_t* n);
 

@@ -1,5 +1,5 @@
 """Campaign behind tests/test_long_edits_cpu.py: random genomes, reads of 60-250 bases with substitutions, short indels AND a long deletion in a third of them,
---score-min L,0,-1 ... L,0,-3, single-end — the host instantiation of the large-workspace configuration (libh2gemu_long.so: 160 edits per working hit, records through the
+--score-min L,0,-1 ... L,0,-3, single-end — the host instantiation of the large-workspace configuration (libh2gemu_long.so: 192 edits per working hit, records through the
 long-edit area) against oracle/_ref/hisat2-align-s, every SAM line; counts the reads still flagged.   usage: fuzz_long_edits.py [cases] [seed0]"""
 import ctypes as C
 import os

@@ -1,5 +1,5 @@
 """Records beyond 32 edits on the device: reads carrying a 26-70-base deletion at --score-min L,0,-2.4 (a deletion of n bases is n edits,
-edit.h; the reference's lists are unbounded, hi_aligner.h:421) through hisat2-align-amd — default units flag them, the large-workspace units (160 edits per
+edit.h; the reference's lists are unbounded, hi_aligner.h:421) through hisat2-align-amd — default units flag them, the large-workspace units (192 edits per
 working hit) align them, the records leave through the long-edit area (h2g_align_fetch_long_edits) — against the reference binary, every SAM line + summary."""
 import json
 import os

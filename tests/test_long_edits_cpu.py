@@ -1,5 +1,5 @@
 """Alignments with more edits than a record's 32 inline entries (the reference's edit lists are unbounded, hi_aligner.h:421, and a
-deletion of n bases is n edits, edit.h): the units with the large workspace hold 160 edits per working hit (H2G_GHIT_EDITS, h2g_go_big.h) and such a
+deletion of n bases is n edits, edit.h): the units with the large workspace hold 192 edits per working hit (H2G_GHIT_EDITS, h2g_go_big.h) and such a
 record leaves through the long-edit area (MachOut::ledits -> h2g_align_fetch_long_edits -> h2g_sam_set_long_edits).  Host instantiation of exactly that
 configuration (tests/emul/libh2gemu_long.so) against the reference binary: reads carrying a 26-70-base deletion at --score-min L,0,-2.4 — every SAM line."""
 import ctypes as C
@@ -60,7 +60,7 @@ def test_records_beyond_32_edits_equal_the_reference(case):
     want = SL.body_lines(sam)
     e = Emu(base, "long")
     e.L.h2gemu_ghit_edits.restype = C.c_uint32
-    assert e.L.h2gemu_ghit_edits() == 160                          # the *_big units' own configuration
+    assert e.L.h2gemu_ghit_edits() == 192                          # the *_big units' own configuration
     p = set_options(e, 0, opts)
     codes, offs = SL.flat([reads[i] for i in range(n)])
     e.set_reads(codes, offs, None)
