@@ -19,7 +19,9 @@ Workload at N=1 = BASELINE.json configs[2]: GRCh38-SIZE linear index (3.1 Gbp, 4
 24 human-profile contigs (no network: GRCh38 itself cannot be fetched), built on the box (~18 min at -p 64) and cached in
 .bench_cache/; a staged grch38sim<len>_* index of at least the wanted size is used when present.  H2G_BENCH_GENOME overrides the
 size (e.g. 256e6 for a quick run); the size actually used is named in config.workload.  configs[1] (E. coli-size, single-end)
-runs as the extra leg "ecoli_se"; the extra legs are skipped when the run is past H2G_BENCH_DEADLINE seconds (default 1350).
+runs as the extra leg "ecoli_se"; the extra legs are skipped when the run is past H2G_BENCH_DEADLINE seconds (default 1150), the two
+companion legs with an index build of their own (repeat_pe, graph256_pe) when they would end past H2G_BENCH_BIG_DEADLINE (1250): both are measured by
+`bench.py --only-legs` / tools/r05_mstreams.py in profiles/ whether or not a run reaches them.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]        (N > 1: N ranks, one per GPU — under torch.distributed.run, or spawned by this
 program when it is started on its own; fewer than N visible devices is an error, never a silent N = 1)
@@ -353,7 +355,7 @@ def dry_run(a, torch, shard, world, rank):
 
 def main():
     t_start = time.time()
-    deadline = float(os.environ.get("H2G_BENCH_DEADLINE", "1350"))
+    deadline = float(os.environ.get("H2G_BENCH_DEADLINE", "1150"))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -609,7 +611,7 @@ def main():
                 out["extras_error"] = repr(e)[:400]
             # the two legs with an index build of their own run while the budget lasts (H2G_BENCH_BIG_DEADLINE seconds since the start; both
             # are measured with --only-legs in profiles/r04_legs.json whether or not this run reaches them)
-            big_deadline = float(os.environ.get("H2G_BENCH_BIG_DEADLINE", "1500"))
+            big_deadline = float(os.environ.get("H2G_BENCH_BIG_DEADLINE", "1250"))
             for name, (fn, need) in BIG_LEGS.items():
                 if time.time() - t_start + need > big_deadline:
                     out.setdefault("big_legs_skipped", []).append(name)
@@ -618,7 +620,7 @@ def main():
                     out[name] = fn(a, api, synth, local, cache)
                 except Exception as e:         # noqa: BLE001
                     out[name] = {"error": repr(e)[:400]}
-        if not a.no_extras and time.time() - t_start < float(os.environ.get("H2G_BENCH_CHAIN_DEADLINE", "1500")):
+        if not a.no_extras and time.time() - t_start < float(os.environ.get("H2G_BENCH_CHAIN_DEADLINE", "1250")):
             # last key of the line: chains of dependent rank queries / graph LF steps with 1-8 chains per lane at the occupancy of the compact-state pass
             # (k_rank_chain, k_glf_chain; tools/chain_bench.py) — in a process of its own with a time limit: measurement kernels never cost the headline its line
             try:
@@ -903,7 +905,7 @@ def graph256_leg(a, api, synth, local, cache, glen=256_000_000, every=250, npair
     return leg
 
 
-BIG_LEGS = {"repeat_pe": (repeat_leg, 330.0), "graph256_pe": (graph256_leg, 520.0)}      # name -> (function, seconds it needs on a 16-core box incl. its index build)
+BIG_LEGS = {"repeat_pe": (repeat_leg, 200.0), "graph256_pe": (graph256_leg, 260.0)}      # name -> (function, seconds it needs on a 16-core box incl. its index build)
 
 
 def spliced_leg(a, api, synth, local, cache):
