@@ -13,6 +13,9 @@
 #include <array>
 #include <vector>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
 #include <chrono>
 #include <algorithm>
 #include <fcntl.h>
@@ -549,7 +552,9 @@ int main(int argc, char** argv) {
 	FILE* out = outfn.empty() ? stdout : fopen(outfn.c_str(), "wb");
 	if(!out) { fprintf(stderr, "cannot open %s\n", outfn.c_str()); return 1; }
 	// output text buffer: raw storage, grown without value-initialising hundreds of MB per batch
-	struct RawBuf { char* p = nullptr; size_t n = 0; void resize(size_t m) { if(m > n) { free(p); p = (char*)malloc(m); n = m; if(!p) { fprintf(stderr, "out of memory\n"); exit(1); } } } char* data() { return p; } size_t size() const { return n; } ~RawBuf() { free(p); } } buf;
+	struct RawBuf { char* p = nullptr; size_t n = 0; void resize(size_t m) { if(m > n) { free(p); p = (char*)malloc(m); n = m; if(!p) { fprintf(stderr, "out of memory\n"); exit(1); } } } char* data() { return p; } size_t size() const { return n; } ~RawBuf() { free(p); } };
+	RawBuf hdr_buf;
+	RawBuf& buf = hdr_buf;          // (the header; the batches' text goes through the writer's ring below)
 	buf.resize(1 << 20);
 	if(!nohead) {
 		const size_t need = h2g_sam_header(sam, cmdline.c_str(), nullptr, 0);
@@ -567,8 +572,8 @@ int main(int argc, char** argv) {
 		for(uint64_t left = skip; left > 0;) { junk.clear(); const size_t g = ra.fill(junk, (size_t)std::min<uint64_t>(left, batch)); if(paired) { junk.clear(); rb.fill(junk, g); } if(!g) break; left -= g; }
 	}
 	uint64_t budget = upto;                               // -u counts the reads after the skipped ones (qUpto += skipReads, hisat2.cpp:1959-1963)
-	const int G = gpus, H = gpus + 1;                    // G streams (one per device) in flight, H host batch buffers: batch k is
-	std::vector<Batch> A((size_t)H), B((size_t)H);     // parsed into buffer k mod H while up to G earlier ones are on the GPUs
+	const int G = gpus, H = gpus + 2;                    // G streams (one per device) in flight, H host batch buffers: batch k + 1 is parsed
+	std::vector<Batch> A((size_t)H), B((size_t)H);     // (on a thread of its own) into buffer (k + 1) mod H while batch k is uploaded and up to G earlier ones are on the GPUs / being written
 	struct Str { h2g_stream* st = nullptr; size_t reads = 0, bases = 0; long batch = -1; size_t n = 0; uint64_t first_id = 0; };
 	uint64_t next_id = skip;                              // Read::rdid of the next read (the skipped ones count, hisat2.cpp:3319)
 	std::vector<Str> S((size_t)G);
@@ -587,11 +592,31 @@ int main(int argc, char** argv) {
 	// its own wave (readid + W > its id), so the shards need nothing from one another; every shard's junctions join the database (on every
 	// device) before the next wave starts (the exchange between two waves is the junction list, tens of bytes per site).
 	size_t wave_left = ss_wave;                           // reads the current wave still takes
-	auto want = [&]() {
-		size_t w = (size_t)std::min<uint64_t>(batch, budget);
-		if(temp_ss) { const size_t shard = (ss_wave + (size_t)gpus - 1) / (size_t)gpus; w = std::min(w, std::min(shard, wave_left)); }
-		return w;
-	};
+	// ---- the writer: the text of a batch goes to the output on a thread of its own (6 GB of SAM per 10 M pairs: a third of the run when the main thread wrote it).
+	// Three text buffers go round; the batches are written in the order they were formatted (one writer, a FIFO).
+	RawBuf wtext[3];
+	size_t wused[3] = {0, 0, 0};
+	std::mutex wm; std::condition_variable wcv;
+	std::deque<int> wqueue, wfree = {0, 1, 2};
+	bool wdone = false, werr = false;
+	std::thread writer([&]() {
+		for(;;) {
+			int i;
+			{ std::unique_lock<std::mutex> lk(wm); wcv.wait(lk, [&] { return !wqueue.empty() || wdone; }); if(wqueue.empty()) return; i = wqueue.front(); wqueue.pop_front(); }
+			if(wused[i] && fwrite(wtext[i].data(), 1, wused[i], out) != wused[i]) werr = true;
+			{ std::lock_guard<std::mutex> lk(wm); wfree.push_back(i); }
+			wcv.notify_all();
+		}
+	});
+	auto wacquire = [&]() { std::unique_lock<std::mutex> lk(wm); wcv.wait(lk, [&] { return !wfree.empty(); }); const int i = wfree.front(); wfree.pop_front(); return i; };
+	auto wsubmit = [&](int i, size_t used_) { { std::lock_guard<std::mutex> lk(wm); wused[i] = used_; wqueue.push_back(i); } wcv.notify_all(); };
+	auto wfinish = [&]() { { std::lock_guard<std::mutex> lk(wm); wdone = true; } wcv.notify_all(); writer.join(); };
+	// ---- the parser: batch j is read into buffer j mod H as soon as that buffer is free (batch j - H is written), ahead of the main thread
+	std::mutex pm; std::condition_variable pcv;
+	long parsed = 0, completed_cnt = 0;
+	std::vector<size_t> pn((size_t)H, 0);
+	bool perr = false;
+	double t_parse_busy = 0;
 	// fetch + format + write the batch that stream `g` carries
 	auto complete = [&](int g) {
 		Str& sg = S[(size_t)g];
@@ -600,6 +625,8 @@ int main(int argc, char** argv) {
 		h2g_stream* st = sg.st;
 		const size_t n = sg.n;
 		size_t used = 0;
+		const int wi = wacquire();
+		RawBuf& buf = wtext[wi];
 		const double tq0 = now();
 		h2g_sam_set_first_read_id(sam, sg.first_id);
 		{	// records with more than H2G_MAX_EDITS edits (long deletions: one edit per base) keep their lists in the stream's long-edit area
@@ -656,7 +683,7 @@ int main(int argc, char** argv) {
 			for(size_t i = 0; i < n; i++) { naligned += res[i].nselect > 0; if(res[i].overflow) { novf++; if(ovf_names.size() < 4096) { ovf_names.append(a.names.data() + a.noffs[i], a.noffs[i + 1] - a.noffs[i]); ovf_names += " (bits " + std::to_string(res[i].overflow) + ")\n"; } } }
 			t_fmt += now() - tf;
 		}
-		fwrite(buf.data(), 1, used, out);
+		wsubmit(wi, used);
 		if(temp_ss || !novel_out.empty()) {   // the junctions of the lines just written join the database (SpliceSiteDB::addSpliceSite: smallest read id per site)
 			static std::vector<h2g_splice_site> novel;
 			const size_t k = h2g_sam_take_novel_sites(sam, nullptr, 0);
@@ -684,15 +711,37 @@ int main(int argc, char** argv) {
 		{ h2g_counters hc; if(h2g_get_counters(st, &hc) == H2G_OK) nsecond += hc.n_second_pass; }
 		nreads += n;
 		sg.batch = -1;
+		{ std::lock_guard<std::mutex> lk(pm); completed_cnt++; }      // (its read buffers are free for the parser)
+		pcv.notify_all();
 	};
+	std::thread parser([&]() {
+		uint64_t pbudget = budget;
+		size_t pwave_left = ss_wave;
+		for(long j = 0;; j++) {
+			{ std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return j < completed_cnt + H; }); }
+			Batch& a = A[(size_t)(j % H)]; Batch& b = B[(size_t)(j % H)];
+			a.clear(); b.clear();
+			const double tp = now();
+			size_t w = (size_t)std::min<uint64_t>(batch, pbudget);
+			if(temp_ss) { const size_t shard = (ss_wave + (size_t)gpus - 1) / (size_t)gpus; w = std::min(w, std::min(shard, pwave_left)); }
+			const size_t n = pbudget ? ra.fill(a, w) : 0;
+			pbudget -= std::min<uint64_t>(pbudget, n);
+			const bool bad = paired && rb.fill(b, n) != n;
+			if(temp_ss) { pwave_left -= n; if(pwave_left == 0) pwave_left = ss_wave; }
+			t_parse_busy += now() - tp;
+			{ std::lock_guard<std::mutex> lk(pm); pn[(size_t)(j % H)] = n; perr = perr || bad; parsed = j + 1; }
+			pcv.notify_all();
+			if(n == 0 || bad) return;
+		}
+	});
+	struct Joiner { std::thread& t; ~Joiner() { if(t.joinable()) t.detach(); } } pjoin{parser}, wjoin{writer};      // (an early `return` / exit leaves no joinable thread behind)
 	for(long k = 0;; k++) {
 		Batch& a = A[(size_t)(k % H)]; Batch& b = B[(size_t)(k % H)];
-		a.clear(); b.clear();
 		double tp = now();
-		const size_t n = budget ? ra.fill(a, want()) : 0;
-		budget -= std::min<uint64_t>(budget, n);
-		if(paired && rb.fill(b, n) != n) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
-		t_parse += now() - tp;
+		size_t n;
+		{ std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return parsed > k; }); n = pn[(size_t)(k % H)]; }
+		if(perr) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
+		t_parse += now() - tp;                         // (what the main thread waited for the parser)
 		if(n == 0) break;
 		const int g = (int)(k % G);
 		const double tg = now();
@@ -745,7 +794,10 @@ int main(int argc, char** argv) {
 			t_gpu += now() - tg;
 		}
 	}
-	if(out != stdout) fclose(out);
+	if(parser.joinable()) parser.join();
+	wfinish();
+	if(werr) { fprintf(stderr, "Error: writing the SAM output failed\n"); return 1; }
+	if(out != stdout) fclose(out); else fflush(out);
 	if(!novel_out.empty()) {                              // hisat2.cpp:4189-4197
 		FILE* nf = fopen(novel_out.c_str(), "w");
 		if(nf) {
@@ -769,8 +821,8 @@ int main(int argc, char** argv) {
 	// second pass).  What is still flagged after that is NOT known to equal the reference's output: name it and fail.
 	if(novf) fprintf(stderr, "Error: %llu %s exceeded even the large device workspace (h2g overflow bit); their SAM records are not verified "
 	                 "against hisat2 -- rerun these with the reference aligner:\n%s", (unsigned long long)novf, paired ? "pairs" : "reads", ovf_names.c_str());
-	if(getenv("H2G_CLI_TIMING")) fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (includes overlapped parsing %.2f s), SAM formatting %.2f s, total %.2f s [stream create %.2f, upload+launch %.2f, wait+fetch %.2f]\n", t1 - t0, t_gpu,
-	        t_parse, t_fmt, t2 - t0, t_stream, t_up, t_fetch);
+	if(getenv("H2G_CLI_TIMING")) fprintf(stderr, "time: index load %.2f s, align+fetch %.2f s (waited for the parser thread %.2f s; it parsed for %.2f s), SAM formatting %.2f s, total %.2f s [stream create %.2f, upload+launch %.2f, wait+fetch %.2f]\n", t1 - t0, t_gpu,
+	        t_parse, t_parse_busy, t_fmt, t2 - t0, t_stream, t_up, t_fetch);
 	if(!stats_fn.empty()) {
 		FILE* sf = fopen(stats_fn.c_str(), "w");
 		if(sf) { fprintf(sf, "{\"reads\": %llu, \"second_pass\": %llu, \"overflow\": %llu}\n", (unsigned long long)nreads, (unsigned long long)nsecond, (unsigned long long)novf); fclose(sf); }

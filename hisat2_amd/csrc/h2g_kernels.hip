@@ -1864,6 +1864,12 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 			for(unsigned m_ = 0; m_ < M; m_++) {
 				if((rc = go_pool_for(s, 2 * (int)m_, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &scratch))) return rc;
 				if(!big_main && !s->tune.no_second_pass && (rc = go_pool_for(s, 2 * (int)m_ + 1, Bp, (size_t)bgrid * bgeo_[1], (size_t)bgrid * bgeo_[0], p->bowtie2_dp, &scratch))) return rc;
+				// ... and its overflow list, and the stream itself (a HIP stream gets its hardware queue when it is first used)
+				if(!s->d_ovf_list[m_]) { HIPCHK(hipMalloc((void**)&s->d_ovf_list[m_], (s->max_reads + 4) * 4)); HIPCHK(hipMemsetAsync(s->d_ovf_list[m_] + s->max_reads, 0, 16, s->mst[m_])); }
+			}
+			for(unsigned b_ = 0; b_ < M + 1; b_++) {      // the per-run buffers of every generation
+				if(!s->d_bail_list[b_]) HIPCHK(hipMalloc((void**)&s->d_bail_list[b_], (s->max_reads + 4) * 4));
+				if(!s->d_fast_args[b_]) HIPCHK(hipMalloc((void**)&s->d_fast_args[b_], sizeof(FastArgs)));
 			}
 		}
 		if((rc = go_pool_for(s, fast ? 2 * (int)(s->gen % M) : 0, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &A))) return rc;

@@ -99,3 +99,13 @@ def test_raw_and_command_line_reads(tmp_path):
     want = run(["-f", "-U", str(fa)])
     assert run(["-r", "-U", str(raw)]) == want
     assert run(["-c", "-U", ",".join(seqs)]) == want
+
+
+def test_absurd_splice_site_window_is_refused_by_name(tmp_path):
+    """in the temporary-splice-site mode a wave (the window, or 1000 x -p) sizes the streams and the result rows whatever --batch says; a window beyond
+    what one resident batch can be is refused with an error that names --ss-window and --batch — before any device or index is touched (no GPU needed)."""
+    r = tmp_path / "r.fa"
+    r.write_text(">0\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    p = subprocess.run([CLI, "-f", "-x", str(tmp_path / "no_such_index"), "-U", str(r), "--ss-window", "5000000", "-S", str(tmp_path / "o.sam")], capture_output=True, text=True)
+    assert p.returncode == 1
+    assert "--ss-window" in p.stderr and "--batch" in p.stderr and "4194304" in p.stderr
