@@ -771,6 +771,11 @@ static int launch_rank(h2g_stream* s, const uint32_t* d_rows, const uint8_t* d_c
 			hipLaunchKernelGGL(k_rank_exp<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed);
 		} else if(variant == 5 && synth) {
 			hipLaunchKernelGGL(k_rank_exp<5>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed);
+		} else if(variant >= 6 && variant <= 9) {
+			// variant 0's kernel at a fraction of the chip's occupancy (measurement: the chain kernel sustains more random 64 B requests per second at one 512-thread
+			// workgroup per CU than at full occupancy — profiles/r05_NOTES.md): 6: 16 waves per CU, 7: 8, 8: 4, 9: 2
+			const unsigned blocks = variant == 6 ? 1024u : variant == 7 ? 512u : variant == 8 ? 256u : 128u;
+			hipLaunchKernelGGL(k_rank_v0, dim3(blocks), dim3(256), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
 		} else return H2G_ERR_ARG;
 	}
 	HIPCHK(hipEventRecord(s->ev[1], s->st));
