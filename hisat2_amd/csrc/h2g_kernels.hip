@@ -119,7 +119,7 @@ struct h2g_stream {
 	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
-	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int fast_reserve = H2G_FAST_RESERVE_DEFAULT; long dbg_read = -1;
+	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int mach_total_auto = 1; int fast_reserve = H2G_FAST_RESERVE_DEFAULT; long dbg_read = -1;
 	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
@@ -475,7 +475,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 0); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
 		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
-		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", H2G_FAST_RESERVE_DEFAULT);
+		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.mach_total_auto = getenv("H2G_MACH_TOTAL") ? 0 : 1; s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", H2G_FAST_RESERVE_DEFAULT);
 		{ const long m = env("H2G_MSTREAMS", H2G_MSTREAMS_DEFAULT); s->mstreams = (unsigned)(m < 1 ? 1 : m > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : m); }
 	}
 	*out = s;
@@ -1852,12 +1852,21 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	A.paired = paired ? 1u : 0u;
 	if(!fast && s->st2_busy) { for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_])); s->st2_busy = false; }   // (the machine streams' pools are about to be used on the first stream)
 	const unsigned M = s->mstreams, NB = M + 1;                    // machine passes in flight, and the depth of the per-run buffers
-	unsigned mach_cap = s->tune.mach_total / M;                  // workgroups of one machine pass behind a fast pass
+	// workgroups of one machine pass behind a fast pass: mach_total / M.  The default policy follows the batch: when the fast pass hands on more than 1.5 % of a linear index's
+	// batch (repeat-structured sequence: the machine's passes, not the fast pass, are the step) the passes get 192 workgroups in all instead of 128 — measured on the repeat-structured
+	// leg 44.7 -> 40.3 ms per step, while the fast-pass-bound legs (0.8 % handed on) lose 3 % with it (profiles/r05_NOTES.md §6).  The pools are sized for the larger share from the start.
+	const bool mt_auto = s->tune.mach_total_auto != 0 && linear;
+	const size_t units_ = paired ? s->n_reads : (s->n_reads + 1) / 2;
+	const unsigned mach_total_now = mt_auto && (size_t)s->last_bails * 1000 > units_ * 15 ? 192u : s->tune.mach_total;
+	unsigned mach_cap = mach_total_now / M;
 	if(mach_cap > H2G_MACH_MAXGRID) mach_cap = H2G_MACH_MAXGRID;
 	if(mach_cap < 1) mach_cap = 1;
+	unsigned pool_cap = (mt_auto ? 192u : s->tune.mach_total) / M;      // what the pools are sized for
+	if(pool_cap > H2G_MACH_MAXGRID) pool_cap = H2G_MACH_MAXGRID;
+	if(pool_cap < mach_cap) pool_cap = mach_cap;
 	const unsigned bgrid = fast ? 2u : 4u;                        // workgroups of a second pass (large workspace: ~5 MB per read in flight)
 	{	// behind a fast pass the machine works on stream gen % M with that stream's pools, on at most mach_cap workgroups
-		const size_t pgrid = fast && grid > mach_cap ? (size_t)mach_cap : (size_t)grid;
+		const size_t pgrid = fast && grid > pool_cap ? (size_t)pool_cap : (size_t)grid;
 		if(fast && s->n_reads >= 200000) {
 			// large batches (a streaming caller's): every machine stream's pools exist before the first pass that could need them — an allocation
 			// in the middle of a queue of runs (gigabytes, synchronous) would stall all of them; the first run of a stream pays for it once.
@@ -2415,7 +2424,8 @@ extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream
 	if(k == "fast") s->tune.fast = (int)v; else if(k == "blocks_per_cu") s->tune.blocks_per_cu = (int)v; else if(k == "pair_slots") s->tune.pair_slots = (int)v;
 	else if(k == "no_second_pass") s->tune.no_second_pass = (int)v; else if(k == "mach_div") s->tune.mach_div = (unsigned)v; else if(k == "mach_min") s->tune.mach_min = (unsigned)v;
 	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") s->tune.tail = (int)v; else if(k == "align_mate") s->tune.align_mate = (int)v;
-	else if(k == "mach_total") s->tune.mach_total = (unsigned)(v < 1 ? 1 : v); else if(k == "fast_reserve") s->tune.fast_reserve = (int)v;
+	else if(k == "mach_total") { s->tune.mach_total_auto = v <= 0; s->tune.mach_total = v <= 0 ? H2G_MACH_TOTAL : (unsigned)v; }      // (0 = the default policy)
+	else if(k == "fast_reserve") s->tune.fast_reserve = (int)v;
 	else if(k == "mstreams") { s->mstreams = (unsigned)(v < 1 ? 1 : v > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : v); s->gen = 0; }   // (nothing is in flight: every buffer set is free)
 	else return H2G_ERR_ARG;
 	return H2G_OK;
