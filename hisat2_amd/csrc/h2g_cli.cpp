@@ -409,10 +409,19 @@ int main(int argc, char** argv) {
 	int ndev = h2g_device_count();
 	if(ndev < 1) die("no GPU");
 	if(gpus > ndev && !getenv("H2G_GPUS_SHARE_DEVICE")) { fprintf(stderr, "hisat2-align-amd: --gpus %d but %d device(s) visible\n", gpus, ndev); return 1; }
+	// Two streams per device when the batches are independent (no temporary splice sites): while the main thread fetches, formats and hands batch k - 2 to the writer,
+	// batch k - 1 is on the device — its kernels and its wait are off the main thread's path.  (A wave of the temporary-splice-site mode ends before the next one
+	// starts: one stream per device there.)  H2G_STREAMS_PER_DEVICE overrides.
+	const int ndevs_asked = gpus;
+	{
+		const char* e = getenv("H2G_STREAMS_PER_DEVICE");
+		const int per = e ? atoi(e) : (temp_ss ? 1 : 2);
+		if(per > 1) gpus *= per;
+	}
 	std::vector<h2g_index*> ixs((size_t)gpus, nullptr);
 	for(int g = 0; g < gpus; g++) {
-		const int dev = (device + g) % ndev;
-		for(int q = 0; q < g; q++) if((device + q) % ndev == dev) ixs[g] = ixs[q];      // shared device: share the replica
+		const int dev = (device + g % ndevs_asked) % ndev;
+		for(int q = 0; q < g; q++) if((device + q % ndevs_asked) % ndev == dev) ixs[g] = ixs[q];      // shared device: share the replica
 		if(ixs[g]) continue;
 		lo.device = dev;
 		if(h2g_index_load(base.c_str(), &lo, &ixs[g]) != H2G_OK) die("cannot load the index onto the GPU");
