@@ -409,13 +409,12 @@ int main(int argc, char** argv) {
 	int ndev = h2g_device_count();
 	if(ndev < 1) die("no GPU");
 	if(gpus > ndev && !getenv("H2G_GPUS_SHARE_DEVICE")) { fprintf(stderr, "hisat2-align-amd: --gpus %d but %d device(s) visible\n", gpus, ndev); return 1; }
-	// Two streams per device when the batches are independent (no temporary splice sites): while the main thread fetches, formats and hands batch k - 2 to the writer,
-	// batch k - 1 is on the device — its kernels and its wait are off the main thread's path.  (A wave of the temporary-splice-site mode ends before the next one
-	// starts: one stream per device there.)  H2G_STREAMS_PER_DEVICE overrides.
+	// One stream per device.  (H2G_STREAMS_PER_DEVICE=2 puts batch k - 1 on the device while the main thread fetches and formats batch k - 2: measured on 10 M pairs, E. coli-size
+	// index — 2.77 s against 2.74 s to /dev/null, and slower to a file: the kernels are 0.16 s of the run, there is nothing to hide; profiles/r05_NOTES.md §12.)
 	const int ndevs_asked = gpus;
 	{
 		const char* e = getenv("H2G_STREAMS_PER_DEVICE");
-		const int per = e ? atoi(e) : (temp_ss ? 1 : 2);
+		const int per = e && !temp_ss ? atoi(e) : 1;
 		if(per > 1) gpus *= per;
 	}
 	std::vector<h2g_index*> ixs((size_t)gpus, nullptr);
