@@ -539,7 +539,7 @@ def main():
             reps.append((time.perf_counter() - t1, t_up))
         t_e2e, t_up = sorted(reps)[1]
         out["pcie_inclusive"] = {"pairs": npairs, "seconds": t_e2e, "reads_per_s": 2 * npairs / t_e2e, "upload_s": t_up, "upload_s_first_pageable": t_upload,
-                                 "compact_record_bytes": int(pb1[-1] + pb2[-1]), "dense_record_bytes_would_be": None,
+                                 "compact_record_bytes": int(pb1[-1] + pb2[-1]),
                                  "note": "h2g_set_reads + h2g_set_read_names + h2g_set_mates + h2g_align_pairs_run + h2g_align_pairs_fetch_compact (40 B + 12 B per edit held "
                                          "per record instead of 424 B), base codes and results in page-locked host memory (h2g_host_alloc), one host thread, nothing overlapped: median of 3"}
         del pres, pr1, pr2
