@@ -569,7 +569,8 @@ void select_by_score(const std::vector<Score>& keys, size_t num, Rng& rnd, std::
 	const size_t sz = keys.size();
 	if(sz < 1) return;
 	if(num > sz) num = sz;
-	std::vector<std::pair<Score, size_t> > buf(sz);
+	static thread_local std::vector<std::pair<Score, size_t> > buf;      // (reused: no allocation per read)
+	buf.resize(sz);
 	for(size_t i = 0; i < sz; i++) buf[i] = std::make_pair(keys[i], i);
 	// EList::sort of pair<AlnScore, size_t> descending: (score, h2) then index
 	std::sort(buf.begin(), buf.end(), [](const std::pair<Score, size_t>& a, const std::pair<Score, size_t>& b) {
@@ -672,8 +673,14 @@ template <class F>
 h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_t* used) {
 	size_t T = S->threads < 1 ? 1 : (size_t)S->threads;
 	if(T > n / 2048 + 1) T = n / 2048 + 1;
-	std::vector<std::string> parts(T);
-	std::vector<Met> mets(T);
+	// per-thread text and counters, each on cache lines of its own: a std::string's size field changes with every append, and two of them (or two threads' counters) in
+	// one line made eight formatter threads as slow as one (measured: 0.176 s for 60 000 pairs on 1 thread, 0.164 s on 8)
+	struct alignas(128) Part { std::string o; char pad[128 - sizeof(std::string) % 128]; };
+	struct alignas(128) PMet { Met m; };
+	std::vector<Part> parts_(T);
+	std::vector<PMet> mets_(T);
+	struct PartsView { std::vector<Part>& v; std::string& operator[](size_t t) { return v[t].o; } size_t size() const { return v.size(); } } parts{parts_};
+	struct MetsView { std::vector<PMet>& v; Met& operator[](size_t t) { return v[t].m; } } mets{mets_};
 	auto work = [&](size_t t) {
 		const size_t b = n * t / T, e = n * (t + 1) / T;
 		std::string& o = parts[t];
@@ -691,10 +698,10 @@ h2g_status drive(const h2g_sam* S, size_t n, F one, char* out, size_t cap, size_
 		for(auto& x : th) x.join();
 	}
 	size_t total = 0;
-	for(auto& p : parts) total += p.size();
+	for(size_t t = 0; t < T; t++) total += parts[t].size();
 	*used = total;
 	if(total > cap || !out) return total <= cap && total == 0 ? H2G_OK : H2G_ERR_ARG;
-	for(auto& m : mets) { S->count_sites(m.novel); S->met.add(m); }   // only a call that delivered its text counts
+	for(size_t t = 0; t < T; t++) { S->count_sites(mets[t].novel); S->met.add(mets[t]); }   // only a call that delivered its text counts
 	// the parts go to the caller's buffer side by side (hundreds of MB per batch: one thread would spend a third of the call here)
 	std::vector<size_t> at(T + 1, 0);
 	for(size_t t = 0; t < T; t++) at[t + 1] = at[t] + parts[t].size();
@@ -957,9 +964,10 @@ static h2g_status format_paired(const h2g_sam* S, const uint8_t* codes1, const u
 	if(compact1) { aln1 = reinterpret_cast<const h2g_alnres*>(compact1); aln2 = reinterpret_cast<const h2g_alnres*>(compact2); }   // (ao1 / ao2 are byte offsets then)
 	if(!S || !codes1 || !offs1 || !nb1 || !noffs1 || !codes2 || !offs2 || !nb2 || !noffs2 || !res || !aln1 || !aln2 || !used) return H2G_ERR_ARG;
 	auto one = [&](size_t i, std::string& o, Met& met) {
-		std::vector<size_t> sel, sel1, sel2;
+		static thread_local std::vector<size_t> sel, sel1, sel2;         // (reused: the formatter allocates nothing per pair)
+		static thread_local std::vector<Score> keys;
+		sel.clear(); sel1.clear(); sel2.clear(); keys.clear();
 		met.nread++; met.npaired++;
-		std::vector<Score> keys;
 		const h2g_pair_result& pr = res[i];
 		Rd rd[2] = {{nb1 + noffs1[i], noffs1[i + 1] - noffs1[i], codes1 + offs1[i], offs1[i + 1] - offs1[i], quals1 ? quals1 + offs1[i] : nullptr},
 		            {nb2 + noffs2[i], noffs2[i + 1] - noffs2[i], codes2 + offs2[i], offs2[i + 1] - offs2[i], quals2 ? quals2 + offs2[i] : nullptr}};
