@@ -747,8 +747,16 @@ int main(int argc, char** argv) {
 		Batch& a = A[(size_t)(k % H)]; Batch& b = B[(size_t)(k % H)];
 		double tp = now();
 		size_t n;
-		{ std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return parsed > k; }); n = pn[(size_t)(k % H)]; }
-		if(perr) { fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n"); return 1; }
+		bool perr_now;
+		{ std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return parsed > k; }); n = pn[(size_t)(k % H)]; perr_now = perr; }
+		if(perr_now) {
+			// the parser has returned (it stops at the short file); the writer waits on a condition variable that lives in this frame: both threads are
+			// joined before the frame goes (a detached waiter would block the variable's destructor for ever)
+			fprintf(stderr, "Error, fewer reads in file specified with -2 than in file specified with -1\n");
+			parser.join();
+			wfinish();
+			return 1;
+		}
 		t_parse += now() - tp;                         // (what the main thread waited for the parser)
 		if(n == 0) break;
 		const int g = (int)(k % G);

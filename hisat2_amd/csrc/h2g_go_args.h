@@ -37,7 +37,7 @@ struct GoArgs {
 
 #define H2G_GO_DECLARE(NAME) \
 	extern "C" size_t h2g_go_ws_bytes_##NAME(); extern "C" size_t h2g_go_gws_bytes_##NAME(); extern "C" int h2g_go_waves_##NAME(); \
-	extern "C" size_t h2g_go_slot_off_##NAME(); extern "C" size_t h2g_go_gsl_off_##NAME(); extern "C" void h2g_go_geometry_##NAME(uint32_t*); \
+	extern "C" size_t h2g_go_slot_off_##NAME(); extern "C" size_t h2g_go_gsl_off_##NAME(); extern "C" void h2g_go_geometry_##NAME(uint32_t*); extern "C" size_t h2g_go_sw_bytes_##NAME(uint32_t, int); \
 	extern "C" void h2g_go_caps_##NAME(uint32_t*); extern "C" int h2g_go_launch_##NAME(const GoArgs*, unsigned, hipStream_t);
 H2G_GO_DECLARE(linear) H2G_GO_DECLARE(graph) H2G_GO_DECLARE(linear_big) H2G_GO_DECLARE(graph_big)
 H2G_GO_DECLARE(linear_spl) H2G_GO_DECLARE(linear_spl_big) H2G_GO_DECLARE(graph_spl) H2G_GO_DECLARE(graph_spl_big)   // spliced alignment (linear indexes): with the splice-site database joins

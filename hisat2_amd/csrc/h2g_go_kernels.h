@@ -337,6 +337,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	extern "C" size_t h2g_go_slot_off_##NAME() { return H2G_GO_ALIGN256(sizeof(AlignWS)); } \
 	extern "C" size_t h2g_go_gsl_off_##NAME() { return H2G_GO_ALIGN256(sizeof(AlignWS)) + H2G_GO_ALIGN256(sizeof(GoSlot)); } \
 	extern "C" size_t h2g_go_gws_bytes_##NAME() { return (GRAPH) ? H2G_GO_ALIGN256(sizeof(GraphWS)) : 0; } \
+	extern "C" size_t h2g_go_sw_bytes_##NAME(uint32_t maxlen, int wide) { return sw_scratch_bytes(maxlen, wide != 0); }   /* SwLaneState holds H2G_GHIT_EDITS of THIS unit */ \
 	extern "C" int h2g_go_waves_##NAME() { return (WAVES); } \
 	extern "C" void h2g_go_geometry_##NAME(uint32_t* g) { g[0] = H2G_GO_THREADS; g[1] = H2G_GO_SLOTS; \
 		g[2] = (uint32_t)((sizeof(GoLds) + 3) / 4 * 4); g[3] = H2G_PK_LANE_WORDS * H2G_GO_THREADS * 4u; /* LDS: rings + one pack region per mate */ } \

@@ -1709,18 +1709,18 @@ static int need_alignable(h2g_stream* s) {
 // the go() units: [linear?][big?]
 struct GoUnit {
 	size_t (*ws_bytes)(); size_t (*gws_bytes)(); int (*waves)(); void (*caps)(uint32_t*); int (*launch)(const GoArgs*, unsigned, hipStream_t);
-	size_t (*slot_off)(); size_t (*gsl_off)(); void (*geometry)(uint32_t*);
+	size_t (*slot_off)(); size_t (*gsl_off)(); void (*geometry)(uint32_t*); size_t (*sw_bytes)(uint32_t, int);
 };
 static const GoUnit& go_unit(bool linear, bool big, bool spliced = false) {
 	// spliced alignment: the units whose machine carries the splice-site database joins
-#define H2G_UNIT_ROW(N) {h2g_go_ws_bytes_##N, h2g_go_gws_bytes_##N, h2g_go_waves_##N, h2g_go_caps_##N, h2g_go_launch_##N, h2g_go_slot_off_##N, h2g_go_gsl_off_##N, h2g_go_geometry_##N}
+#define H2G_UNIT_ROW(N) {h2g_go_ws_bytes_##N, h2g_go_gws_bytes_##N, h2g_go_waves_##N, h2g_go_caps_##N, h2g_go_launch_##N, h2g_go_slot_off_##N, h2g_go_gsl_off_##N, h2g_go_geometry_##N, h2g_go_sw_bytes_##N}
 	static const GoUnit spl[2][2] = {{H2G_UNIT_ROW(graph_spl), H2G_UNIT_ROW(graph_spl_big)}, {H2G_UNIT_ROW(linear_spl), H2G_UNIT_ROW(linear_spl_big)}};
 	if(spliced) return spl[linear ? 1 : 0][big ? 1 : 0];
 	static const GoUnit u[2][2] = {
-		{{h2g_go_ws_bytes_graph, h2g_go_gws_bytes_graph, h2g_go_waves_graph, h2g_go_caps_graph, h2g_go_launch_graph, h2g_go_slot_off_graph, h2g_go_gsl_off_graph, h2g_go_geometry_graph},
-		 {h2g_go_ws_bytes_graph_big, h2g_go_gws_bytes_graph_big, h2g_go_waves_graph_big, h2g_go_caps_graph_big, h2g_go_launch_graph_big, h2g_go_slot_off_graph_big, h2g_go_gsl_off_graph_big, h2g_go_geometry_graph_big}},
-		{{h2g_go_ws_bytes_linear, h2g_go_gws_bytes_linear, h2g_go_waves_linear, h2g_go_caps_linear, h2g_go_launch_linear, h2g_go_slot_off_linear, h2g_go_gsl_off_linear, h2g_go_geometry_linear},
-		 {h2g_go_ws_bytes_linear_big, h2g_go_gws_bytes_linear_big, h2g_go_waves_linear_big, h2g_go_caps_linear_big, h2g_go_launch_linear_big, h2g_go_slot_off_linear_big, h2g_go_gsl_off_linear_big, h2g_go_geometry_linear_big}}};
+		{{h2g_go_ws_bytes_graph, h2g_go_gws_bytes_graph, h2g_go_waves_graph, h2g_go_caps_graph, h2g_go_launch_graph, h2g_go_slot_off_graph, h2g_go_gsl_off_graph, h2g_go_geometry_graph, h2g_go_sw_bytes_graph},
+		 {h2g_go_ws_bytes_graph_big, h2g_go_gws_bytes_graph_big, h2g_go_waves_graph_big, h2g_go_caps_graph_big, h2g_go_launch_graph_big, h2g_go_slot_off_graph_big, h2g_go_gsl_off_graph_big, h2g_go_geometry_graph_big, h2g_go_sw_bytes_graph_big}},
+		{{h2g_go_ws_bytes_linear, h2g_go_gws_bytes_linear, h2g_go_waves_linear, h2g_go_caps_linear, h2g_go_launch_linear, h2g_go_slot_off_linear, h2g_go_gsl_off_linear, h2g_go_geometry_linear, h2g_go_sw_bytes_linear},
+		 {h2g_go_ws_bytes_linear_big, h2g_go_gws_bytes_linear_big, h2g_go_waves_linear_big, h2g_go_caps_linear_big, h2g_go_launch_linear_big, h2g_go_slot_off_linear_big, h2g_go_gsl_off_linear_big, h2g_go_geometry_linear_big, h2g_go_sw_bytes_linear_big}}};
 	return u[linear ? 1 : 0][big ? 1 : 0];
 }
 
@@ -1754,7 +1754,7 @@ static int go_pool_for(h2g_stream* s, int which, const GoUnit& u, size_t slots, 
 		const uint32_t swlen = s->max_read_len > H2G_SW_MAX_ROWS ? (uint32_t)H2G_SW_MAX_ROWS : s->max_read_len;
 		bool wide = false;                                        // some read length of the batch may put minsc below -254: 16-bit cells
 		for(uint32_t l = 1; l <= swlen && !wide; l++) wide = sw_wide_for(min_score_for(a->P, l));
-		const size_t stride = (sw_scratch_bytes(swlen, wide) + 255) & ~(size_t)255;
+		const size_t stride = (u.sw_bytes(swlen, wide ? 1 : 0) + 255) & ~(size_t)255;   // the unit's own SwLaneState (the large-workspace units hold 192-edit records)
 		if(pl.sw_stride < stride || pl.sw_lanes < lanes) {
 			(void)hipFree(pl.sw); pl.sw = nullptr; pl.sw_stride = 0; pl.sw_lanes = 0;
 			HIPCHK(hipMalloc((void**)&pl.sw, stride * lanes));

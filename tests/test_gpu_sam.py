@@ -219,6 +219,14 @@ def test_command_line_paired_fastq_unequal_mates(monkeypatch, snps):
     want = SL.body_lines(os.path.join(tmp, "ref4.sam"))
     assert diff_lines(SL.body_lines(os.path.join(tmp, "amd4.sam")), want) == 0
     assert open(os.path.join(tmp, "amd4.err")).read() == "".join(l for l in open(os.path.join(tmp, "ref4.err")) if not l.startswith("Warning"))
+    if snps == 0:
+        # -2 shorter than -1: the reference's message and exit status 1 (pat.cpp:420), and the process ENDS (the threaded pipeline used to
+        # hang here, a detached writer waiting on a condition variable of the frame being left)
+        with open(os.path.join(tmp, "q2short.fq"), "w") as f:
+            f.writelines(open(os.path.join(tmp, "q2.fq")).readlines()[:4 * 3100])
+        r = subprocess.run([CLI, "-p", "4", "--batch", "2500", "-q", "--no-spliced-alignment", "-x", os.path.join(tmp, "g"), "-1", os.path.join(tmp, "q1.fq"),
+                            "-2", os.path.join(tmp, "q2short.fq"), "-S", os.path.join(tmp, "short.sam")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "fewer reads in file specified with -2" in r.stderr
 
 
 @needs_ref
