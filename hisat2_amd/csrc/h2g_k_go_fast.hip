@@ -24,6 +24,14 @@ using namespace h2g;
 #ifndef H2G_FAST_SLOTS
 #define H2G_FAST_SLOTS 1024       // reads in flight per workgroup (power of two)
 #endif
+// The scratch of the graph primitives (GraphWS: group walk + ALT-aware extension) lives in the lane's PRIVATE segment (round 6): the hardware interleaves a
+// wave's private memory dword by dword, so a wave-wide access to one field is 256 contiguous bytes.  In global memory at one GraphWS per lane the same access
+// was 64 lines, 17 KB apart: 40 GB written per million pairs (profiles/r05_g_graph_pmc_traffic.json).  Round 5's attempt at the default capacities (20 KB per
+// lane) was refused by the runtime; h2g_k_go_fast_graph.hip sets the capacities a read of the fast path can use (it holds four edits per hit and five
+// coordinates per resolution: everything beyond is a bail as before).
+#ifndef FG_GWS_PRIVATE
+#define FG_GWS_PRIVATE FG_GRAPH
+#endif
 #define FG_STAGE_WORDS (FW_HOT + 2 * H2G_PK_WORDS)                     // staged in LDS per lane: hot words + packed reads
 #define FG_SLOT_WORDS  (((FS_WORDS + FW_HOT + 2 * H2G_PK_WORDS + FW_COLD) + 3) & ~3)   // 16-byte multiple
 #define FG_NQ ((int)FQ_COUNT)
@@ -87,7 +95,9 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 	{
 		const size_t tid = (size_t)blockIdx.x * H2G_FAST_THREADS + threadIdx.x;
 		C.alts = &A->alts;
+#if !FG_GWS_PRIVATE
 		C.gws = reinterpret_cast<GraphWS*>(A->gws_base + tid * A->gws_stride);
+#endif
 		C.sc = reinterpret_cast<int64_t*>(A->sc_base + (tid >> 6) * (size_t)(64 * 2 * H2G_COMBINE_MAXLEN * sizeof(int64_t))) + (threadIdx.x & 63); C.sc_stride = 64;
 	}
 #endif
@@ -99,6 +109,10 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 __device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t op, uint32_t begin, uint32_t packed_ok) {
 	FCtx C; FWords W;
 	fk_ctx(A, stage, sm, C, W);
+#if FG_GRAPH && FG_GWS_PRIVATE
+	GraphWS gws_private;
+	C.gws = &gws_private;
+#endif
 	FState S;
 	if(begin != H2G_MAX) {
 		const bool paired = A->paired != 0;
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 extern "C" void FG_GEOMETRY(uint32_t* g) {
 	g[0] = H2G_FAST_THREADS; g[1] = FG_LDS_BYTES; g[2] = H2G_FAST_SLOTS; g[3] = FG_SLOT_WORDS * 4u;
 #if FG_GRAPH
-	g[4] = (uint32_t)sizeof(GraphWS);
+	g[4] = FG_GWS_PRIVATE ? 0u : (uint32_t)sizeof(GraphWS);
 #endif
 }
 // `a` is the argument block in DEVICE memory
