@@ -9,6 +9,7 @@
 // h2g_k_go_fast_graph.hip compiles this file once more with FG_GRAPH = 1 (graph indexes: h2g_fast.h) under its own symbol names.
 #include <atomic>
 #include "h2g_go_args.h"
+#include "h2g_fast_prof.h"
 
 using namespace h2g;
 
@@ -60,7 +61,11 @@ __device__ __forceinline__ void fq_push(FastLds* Q, bool valid, uint32_t q, uint
 		todo &= ~m;
 	}
 }
-__device__ __forceinline__ uint32_t fq_pop(FastLds* Q, uint32_t q, int lane, uint32_t* slot) {
+// Pops up to one slot of queue `q` for every lane with `want` set (in lane order).  Returns whether THIS lane got one.
+__device__ __forceinline__ bool fq_pop_into(FastLds* Q, uint32_t q, int lane, bool want, uint32_t* slot) {
+	const unsigned long long wm = __ballot(want);
+	if(wm == 0) return false;
+	const uint32_t nwant = (uint32_t)__popcll(wm);
 	uint32_t n = 0, h = 0;
 	if(lane == 0) {
 		for(;;) {
@@ -68,19 +73,21 @@ __device__ __forceinline__ uint32_t fq_pop(FastLds* Q, uint32_t q, int lane, uin
 			const uint32_t t = __atomic_load_n(&Q->tail[q], __ATOMIC_RELAXED);
 			n = t - h;
 			if(n == 0) break;
-			if(n > 64) n = 64;
+			if(n > nwant) n = nwant;
 			if(atomicCAS(&Q->head[q], h, h + n) == h) break;
 		}
 	}
 	n = (uint32_t)__shfl((int)n, 0); h = (uint32_t)__shfl((int)h, 0);
-	if((uint32_t)lane < n) {
-		const uint32_t pos = (h + (uint32_t)lane) & (H2G_FAST_SLOTS - 1);
+	const uint32_t r = (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+	const bool got = want && r < n;
+	if(got) {
+		const uint32_t pos = (h + r) & (H2G_FAST_SLOTS - 1);
 		uint16_t v;
 		while((v = __atomic_load_n(&Q->ring[q][pos], __ATOMIC_RELAXED)) == FG_RING_EMPTY) __builtin_amdgcn_s_sleep(1);   // reserved, being written
 		__atomic_store_n(&Q->ring[q][pos], (uint16_t)FG_RING_EMPTY, __ATOMIC_RELAXED);
 		*slot = v;
 	}
-	return n;
+	return got;
 }
 
 __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint32_t* sm, FCtx& C, FWords& W) {
@@ -104,27 +111,36 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 	C.O = A->O;
 	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
 }
-// One trip of this lane's slot with the state in registers from its load to its store: the primitive `op` (FOP_NONE: a slot taking up
-// read `begin`), then the control flow up to the next request.  Returns the state's word 0 (pc, op, bail); the whole state is in the slot.
-__device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, uint32_t* sm, uint32_t op, uint32_t begin, uint32_t packed_ok) {
+// the state <-> its slot (16-byte accesses, nothing depends on anything)
+__device__ __forceinline__ void fk_load_state(FState& S, const uint32_t* sm) {
+	uint32_t w[FS_WORDS];
+	const uint4* src = reinterpret_cast<const uint4*>(sm);
+#pragma unroll
+	for(uint32_t k = 0; k < FS_WORDS / 4; k++) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+	__builtin_memcpy(&S, w, sizeof S);
+}
+__device__ __forceinline__ void fk_store_state(const FState& S, uint32_t* sm) {
+	uint32_t w[FS_WORDS];
+	__builtin_memcpy(w, &S, sizeof S);
+	uint4* dst = reinterpret_cast<uint4*>(sm);
+#pragma unroll
+	for(uint32_t k = 0; k < FS_WORDS / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+// One trip of this lane's read with the state in registers: the primitive `op` (FOP_NONE: a slot taking up read `begin`), then the control flow up to
+// the next request.
+__device__ __forceinline__ void fk_trip(const FastArgs* A, uint32_t* stage, uint32_t* sm, FState& S, uint32_t op, uint32_t begin, uint32_t packed_ok) {
 	FCtx C; FWords W;
 	fk_ctx(A, stage, sm, C, W);
 #if FG_GRAPH && FG_GWS_PRIVATE
 	GraphWS gws_private;
 	C.gws = &gws_private;
 #endif
-	FState S;
 	if(begin != H2G_MAX) {
 		const bool paired = A->paired != 0;
 		C.name[0] = A->names1 + A->noffs1[begin]; C.namelen[0] = A->noffs1[begin + 1] - A->noffs1[begin];
 		if(paired) { C.name[1] = A->names2 + A->noffs2[begin]; C.namelen[1] = A->noffs2[begin + 1] - A->noffs2[begin]; }
 		fast_begin(C, S, begin, paired, packed_ok != 0);
 	} else {
-		uint32_t w[FS_WORDS];
-		const uint4* src = reinterpret_cast<const uint4*>(sm);
-#pragma unroll
-		for(uint32_t k = 0; k < FS_WORDS / 4; k++) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-		__builtin_memcpy(&S, w, sizeof S);
 		// the work counters are 16-bit fields: the primitive counts from zero, a read that would wrap them leaves the fast path
 		const uint32_t nr0 = S.nrank, ns0 = S.nside, nt0 = S.nsteps;
 		S.nrank = 0; S.nside = 0; S.nsteps = 0;
@@ -133,34 +149,22 @@ __device__ __forceinline__ uint32_t fk_trip(const FastArgs* A, uint32_t* stage, 
 		if(S.pc != FPC_BAIL && (nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu)) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
 		S.nrank = nr_ & 0xffffu; S.nside = ns_ & 0xffffu; S.nsteps = nt_ & 0xffffu;
 	}
-#ifdef FG_DBG_TRACE
-	const uint32_t dbg_a[6] = {S.a0, S.a1, S.a2, S.a3, S.a4, S.a5};
-	const uint32_t dbg_pc0 = S.pc, dbg_op0 = S.op;
-#endif
 	if(S.pc != FPC_DONE && S.pc != FPC_BAIL && S.op == FOP_NONE) fast_step(C, S, W);
-#ifdef FG_DBG_TRACE
-	if(A->dbg_buf && S.read == A->dbg_read) {
-		const uint32_t at = atomicAdd(A->dbg_buf, 12u);
-		if(at + 13 < (1u << 20)) {
-			uint32_t* d = A->dbg_buf + 1 + at;
-			d[0] = op; d[1] = dbg_pc0 | (dbg_op0 << 8); for(int k = 0; k < 6; k++) d[2 + k] = dbg_a[k]; d[8] = S.pc | (S.op << 8) | ((uint32_t)(S.sp & 15) << 16); d[9] = S.nrank | (S.nsteps << 16); d[10] = W.ld(FW_CO + 2); d[11] = S.a4;
-		}
-	}
-#endif
-	uint32_t w[FS_WORDS];
-	__builtin_memcpy(w, &S, sizeof S);
-	uint4* dst = reinterpret_cast<uint4*>(sm);
-#pragma unroll
-	for(uint32_t k = 0; k < FS_WORDS / 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-	return w[0];
 }
 
+#define FG_Q_NONE 0xffffffffu
+// The loop of one wave (round 6: reads stay in their lane).  A lane that has run a read's control flow up to its next request KEEPS the read — state in
+// registers, hot words in its LDS staging area — and the wave looks at what its own lanes ask for next to the queues: it runs the site that fills most of
+// its lanes (own lanes first: they cost no load).  Only the lanes that do not take part in that trip store their read (state + hot words; the packed reads
+// never change) and push its slot; free lanes pop from the site's queue.  Through round 5 every trip stored and re-loaded every read: half of the kernel's
+// fabric requests.  Which reads run together changes; what a read computes does not (every read is a function of itself).
 __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __restrict__ A)
 {
 	extern __shared__ uint32_t s_mem[];
 	FastLds* Q = reinterpret_cast<FastLds*>(s_mem);
 	uint32_t* const stage = s_mem + (sizeof(FastLds) + 3) / 4 + threadIdx.x;      // word w of this lane at stage[w * H2G_FAST_THREADS]
 	const int lane = (int)(threadIdx.x & 63);
+	const unsigned long long lt = (1ull << lane) - 1ull;
 	const bool paired = A->paired != 0;
 	for(uint32_t k = threadIdx.x; k < (uint32_t)FG_NQ * H2G_FAST_SLOTS; k += blockDim.x) (&Q->ring[0][0])[k] = FG_RING_EMPTY;
 	if(threadIdx.x < (uint32_t)FG_NQ) { Q->head[threadIdx.x] = 0; Q->tail[threadIdx.x] = 0; }
@@ -174,46 +178,75 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 	unsigned long long nrank = 0, nside = 0, nsteps = 0, naln = 0, ndone = 0, nbail = 0;
 	bool more = true;
 	const uint32_t total = A->total, tail_n = A->tail;
-#ifdef H2G_GO_PROF
-	// wave-level time split (shader clock): [0] choose + pop + load [1] control [2] store [16] release fence [17] push [3+op] each primitive [15] new reads; [20+op] slots executed;
-	// [32+op] executions; [46] slots stepped [47] trips
-	unsigned long long prof[48], prof_ctl[32], prof_n[32];
-	for(int k = 0; k < 48; k++) prof[k] = 0;
-	for(int k = 0; k < 32; k++) { prof_ctl[k] = 0; prof_n[k] = 0; }
-	uint32_t trip_site = 0;
-	unsigned long long tp0 = __builtin_readcyclecounter(), tp1;
-#define PROF(SLOT) do { tp1 = __builtin_readcyclecounter(); prof[SLOT] += tp1 - tp0; tp0 = tp1; } while(0)
-#else
-#define PROF(SLOT) do {} while(0)
-#endif
+	FPROF_DECL;
+	// what this lane holds between two trips
+	FState S;
+	bool keep = false;              // a slot is in this lane: a read up to its next request (myq >= 1) or a slot whose read is over (myq == FQ_FREE)
+	uint32_t slot = 0, myq = 0;
+	uint32_t* sm = nullptr;         // the slot in HBM
+	__builtin_memset(&S, 0, sizeof S);
 	for(;;) {
-		// ---- choose: the site with the longest queue; free slots are refilled when reads remain and nothing is long
-		uint32_t cnt = 0;
+		// ---- choose: per site, the lanes a trip would fill = this wave's own lanes waiting for it + its queue
+		uint32_t cnt = 0, own = 0;
 		if(lane < FG_NQ) cnt = __atomic_load_n(&Q->tail[lane], __ATOMIC_RELAXED) - __atomic_load_n(&Q->head[lane], __ATOMIC_RELAXED);
-		const uint32_t nfree = (uint32_t)__shfl((int)cnt, 0);
-		uint32_t bestc = (lane >= 1 && lane < FG_NQ) ? cnt : 0, bestq = (uint32_t)lane;
+#pragma unroll
+		for(uint32_t q = 0; q < (uint32_t)FG_NQ; q++) { const uint32_t c = (uint32_t)__popcll(__ballot(keep && myq == q)); if((uint32_t)lane == q) own = c; }
+		const uint32_t nfree = (uint32_t)__shfl((int)cnt, 0), own_free = (uint32_t)__shfl((int)own, 0);
+		uint32_t key = 0, bestq = (uint32_t)lane;
+		if(lane >= 1 && lane < FG_NQ) { const uint32_t act = own + cnt > 64u ? 64u : own + cnt; key = act ? ((act << 8) | own) : 0u; }
 		for(int o = 32; o > 0; o >>= 1) {
-			const uint32_t oc = (uint32_t)__shfl_xor((int)bestc, o), oq = (uint32_t)__shfl_xor((int)bestq, o);
-			if(oc > bestc || (oc == bestc && oq < bestq)) { bestc = oc; bestq = oq; }
+			const uint32_t ok = (uint32_t)__shfl_xor((int)key, o), oq = (uint32_t)__shfl_xor((int)bestq, o);
+			if(ok > key || (ok == key && oq < bestq)) { key = ok; bestq = oq; }
 		}
-		bestc = (uint32_t)__shfl((int)bestc, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
-		const bool fetch = more && nfree > 0 && (bestc < 64 || nfree >= H2G_FAST_SLOTS / 4);
-		bool have = false;
-		bool tail = false;
-		uint32_t slot = 0, begin = H2G_MAX, packed_ok = 0, trip_op = FOP_NONE;
-		uint32_t* sm = nullptr;                                   // this lane's slot in HBM
+		key = (uint32_t)__shfl((int)key, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
+		const uint32_t bestact = key >> 8, avail = nfree + own_free;
+		// new reads: when that trip would fill more lanes than any site's, or a quarter of the slots lie free
+		const bool fetch = more && avail > 0 && ((avail > 64u ? 64u : avail) > bestact || nfree >= H2G_FAST_SLOTS / 4);
+		const uint32_t qstar = fetch ? (uint32_t)FQ_FREE : (bestact ? bestq : FG_Q_NONE);
+		// ---- the lanes that do not take part hand their slots on
+		{
+			const bool out = keep && myq != qstar;
+			if(out && myq != FQ_FREE) {
+				fk_store_state(S, sm);
+				uint4* hdst = reinterpret_cast<uint4*>(sm + FS_WORDS);
+#pragma unroll
+				for(uint32_t k = 0; k < FW_HOT / 4; k++)
+					hdst[k] = make_uint4(stage[(4 * k) * H2G_FAST_THREADS], stage[(4 * k + 1) * H2G_FAST_THREADS], stage[(4 * k + 2) * H2G_FAST_THREADS], stage[(4 * k + 3) * H2G_FAST_THREADS]);
+#pragma unroll
+				for(uint32_t k = FW_HOT & ~3u; k < FW_HOT; k++) sm[FS_WORDS + k] = stage[k * H2G_FAST_THREADS];
+			}
+			FPROF(2);
+			if(__ballot(out)) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				fq_push(Q, out, myq, slot, lane);
+			}
+			if(out) keep = false;
+			FPROF(17);
+		}
+		if(qstar == FG_Q_NONE) {
+			if(!more && nfree == H2G_FAST_SLOTS) break;           // the batch is exhausted and every slot is free again
+			__builtin_amdgcn_s_sleep(8);
+			if(more) { uint32_t w = 0; if(lane == 0) w = __atomic_load_n(A->work, __ATOMIC_RELAXED); if((uint32_t)__shfl((int)w, 0) >= total) more = false; }
+			continue;
+		}
+		bool active = false, tail = false, fresh = false;
+		uint32_t begin = H2G_MAX, packed_ok = 0, trip_op = FOP_NONE;
 		if(fetch) {
-			const uint32_t n = fq_pop(Q, 0, lane, &slot);
+			const bool got = fq_pop_into(Q, FQ_FREE, lane, !keep, &slot);    // (a lane whose read is over re-uses its slot without the queue)
+			const bool has = keep || got;
+			const unsigned long long hm = __ballot(has);
+			const uint32_t n = (uint32_t)__popcll(hm);
 			if(n == 0) continue;
 			uint32_t base = 0;
 			if(lane == 0) base = atomicAdd(A->work, n);
 			base = (uint32_t)__shfl((int)base, 0);
 			if(base + n >= total) more = false;
-			const bool got = (uint32_t)lane < n && base + (uint32_t)lane < total;
-			fq_push(Q, (uint32_t)lane < n && !got, 0, slot, lane);      // slots without a read go back
-			if(got) {
-				have = true;
-				begin = base + (uint32_t)lane;
+			const uint32_t r = (uint32_t)__popcll(hm & lt);
+			active = has && base + r < total;
+			if(has && !active) { keep = true; myq = FQ_FREE; }        // a slot without a read goes back with the next trip's hand-ons
+			if(active) {
+				keep = false;
+				begin = base + r;
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
 				bool ok = fg_pack_read(A->rd1, begin, pk0, H2G_FAST_THREADS);
 				if(paired) ok = fg_pack_read(A->rd2, begin, pk1, H2G_FAST_THREADS) && ok;
@@ -222,94 +255,68 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 #pragma unroll
 				for(uint32_t k = 0; k < 2 * H2G_PK_WORDS; k++) sm[FS_WORDS + FW_HOT + k] = pk0[k * H2G_FAST_THREADS];
 			}
-#ifdef H2G_GO_PROF
-			trip_site = 0;
-#endif
-			PROF(15);
+			FPROF_SITE(0);
+			FPROF(15);
 		} else {
-			if(bestc == 0) {
-				if(!more && nfree == H2G_FAST_SLOTS) break;           // the batch is exhausted and every slot is free again
-				__builtin_amdgcn_s_sleep(8);
-				if(more) { uint32_t w = 0; if(lane == 0) w = __atomic_load_n(A->work, __ATOMIC_RELAXED); if((uint32_t)__shfl((int)w, 0) >= total) more = false; }
-				continue;
-			}
-			const uint32_t op = fg_queue_op(bestq);
-			const uint32_t n = fq_pop(Q, bestq, lane, &slot);
-			if(n == 0) continue;
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			have = (uint32_t)lane < n;
+			trip_op = fg_queue_op(qstar);
+			fresh = fq_pop_into(Q, qstar, lane, !keep, &slot);
+			if(__ballot(fresh)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			active = keep || fresh;
 			// (FastArgs::tail: the last reads in flight of an exhausted batch are a few latency chains per workgroup; they can go to the general
 			// machine's pass, which is in flight anyway — profiles/r04_NOTES.md §1, §4)
 			tail = !more && H2G_FAST_SLOTS - nfree <= tail_n;
-			if(have && tail) sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
-			if(have && !tail) {
+			if(fresh) {
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
-				// hot words + packed reads into this lane's LDS staging area: 16-byte loads, nothing depends on anything
-				const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
+				if(tail) S.read = sm[8];                              // (state word 8 = the read id)
+				else {
+					fk_load_state(S, sm);
+					// hot words + packed reads into this lane's LDS staging area: 16-byte loads, nothing depends on anything
+					const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
 #pragma unroll
-				for(uint32_t k = 0; k < FG_STAGE_WORDS / 4; k++) {
-					const uint4 v = hsrc[k];
-					stage[(4 * k) * H2G_FAST_THREADS] = v.x; stage[(4 * k + 1) * H2G_FAST_THREADS] = v.y; stage[(4 * k + 2) * H2G_FAST_THREADS] = v.z; stage[(4 * k + 3) * H2G_FAST_THREADS] = v.w;
+					for(uint32_t k = 0; k < FG_STAGE_WORDS / 4; k++) {
+						const uint4 v = hsrc[k];
+						stage[(4 * k) * H2G_FAST_THREADS] = v.x; stage[(4 * k + 1) * H2G_FAST_THREADS] = v.y; stage[(4 * k + 2) * H2G_FAST_THREADS] = v.z; stage[(4 * k + 3) * H2G_FAST_THREADS] = v.w;
+					}
+#pragma unroll
+					for(uint32_t k = FG_STAGE_WORDS & ~3u; k < FG_STAGE_WORDS; k++) stage[k * H2G_FAST_THREADS] = sm[FS_WORDS + k];
 				}
-#pragma unroll
-				for(uint32_t k = FG_STAGE_WORDS & ~3u; k < FG_STAGE_WORDS; k++) stage[k * H2G_FAST_THREADS] = sm[FS_WORDS + k];
 			}
-#ifdef H2G_GO_PROF
-			prof[20 + op] += n; prof[32 + op]++; trip_site = bestq;
-#endif
-			PROF(0);
-			trip_op = op;
+			FPROF_EXEC(trip_op, __popcll(__ballot(active)), __popcll(__ballot(fresh)));
+			FPROF_SITE(qstar);
+			FPROF(0);
 		}
-		// ---- control flow of each read up to its next primitive request; then hand the slots on
-		uint32_t nextq = 0;
-#ifdef H2G_GO_PROF
-		prof[46] += __popcll(__ballot(have)); prof[47]++;
-#endif
-		uint32_t w0 = 0;
-		if(have && tail) w0 = (uint32_t)FPC_BAIL | ((uint32_t)FB_TAIL << 12);     // (pc, bail reason of state word 0; the read id is state word 8 in the slot)
-		else if(have) w0 = fk_trip(A, stage, sm, trip_op, begin, packed_ok);
-#ifdef H2G_GO_PROF
-		{ const unsigned long long t_ = __builtin_readcyclecounter(); prof_ctl[trip_site & 31] += t_ - tp0; prof_n[trip_site & 31]++; }
-#endif
-		PROF(1);
-		const uint32_t pc = w0 & 0xffu, why = (w0 >> 12) & 0x1fu;
-		if(have) {
-			if(pc == FPC_DONE) { const uint32_t c26 = sm[26], c27 = sm[27]; nrank += c26 & 0xffffu; nside += c26 >> 16; nsteps += c27 & 0xffffu; naln += sm[2] != 0; ndone++; }
-			else if(pc != FPC_BAIL) {
-				uint4* hdst = reinterpret_cast<uint4*>(sm + FS_WORDS);
-#pragma unroll
-				for(uint32_t k = 0; k < FW_HOT / 4; k++)
-					hdst[k] = make_uint4(stage[(4 * k) * H2G_FAST_THREADS], stage[(4 * k + 1) * H2G_FAST_THREADS], stage[(4 * k + 2) * H2G_FAST_THREADS], stage[(4 * k + 3) * H2G_FAST_THREADS]);
-#pragma unroll
-				for(uint32_t k = FW_HOT & ~3u; k < FW_HOT; k++) sm[FS_WORDS + k] = stage[k * H2G_FAST_THREADS];
-				nextq = fg_queue_of(pc);
-			}
+		// ---- control flow of each read up to its next primitive request
+		FPROF_TRIP(__popcll(__ballot(active)));
+		if(active && tail) { S.pc = FPC_BAIL; S.bail = FB_TAIL; }
+		else if(active) fk_trip(A, stage, sm, S, trip_op, begin, packed_ok);
+		FPROF_CTL();
+		FPROF(1);
+		const uint32_t pc = S.pc;
+		if(active) {
+			keep = true;
+			if(pc == FPC_DONE) { nrank += S.nrank; nside += S.nside; nsteps += S.nsteps; naln += S.a0 != 0; ndone++; myq = FQ_FREE; }
+			else if(pc == FPC_BAIL) myq = FQ_FREE;
+			else myq = fg_queue_of(pc);
 		}
 		// reads that left the fast path: their ids go to the general machine's list
 		{
-			const bool b = have && pc == FPC_BAIL;
+			const bool b = active && pc == FPC_BAIL;
 			const unsigned long long bm = __ballot(b);
 			if(bm) {
 				uint32_t base = 0;
 				if(lane == 0) base = atomicAdd(A->bail_count, (uint32_t)__popcll(bm));
 				base = (uint32_t)__shfl((int)base, 0);
 				if(b) {
-					A->bail_list[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = sm[8];       // state word 8 = the read id
+					const uint32_t why = S.bail;
+					A->bail_list[base + (uint32_t)__popcll(bm & lt)] = S.read;
 					atomicAdd(A->counters + 96 + (why < FB_COUNT ? why : (uint32_t)FB_OTHER), 1ull);
 					nbail++;
 				}
 			}
 		}
-		PROF(2);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		PROF(16);
-		fq_push(Q, have, nextq, slot, lane);
-		PROF(17);
+		FPROF(16);
 	}
-#ifdef H2G_GO_PROF
-	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A->counters + 128 + k, prof[k]);
-	if(lane == 0) for(int k = 0; k < 32; k++) if(prof_n[k]) { atomicAdd(A->counters + 176 + k, prof_ctl[k]); atomicAdd(A->counters + 208 + k, prof_n[k]); }
-#endif
+	FPROF_FLUSH(A->counters);
 	wave_add(A->counters + 120, nrank);     // (slots of its own: the general machine's passes count in 0..5 / 64..69)
 	wave_add(A->counters + 121, nside);
 	wave_add(A->counters + 122, nsteps);
