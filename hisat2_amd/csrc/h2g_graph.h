@@ -431,11 +431,13 @@ H2G_HDN void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32
 			r.top = r.bot = r.node_top = r.node_bot = 0;
 			tmp_ie.n = 0;
 			if(c <= 3) {
+				// nside: the sides of the BWT rows themselves (as on a linear index: one when top and bot share a side).  The sides the M / F bit vectors and the
+				// header back-scan add are NOT counted — a lower bound of the unique sides SURVEY §8(d) asks for (round 6; it was 0 through round 5)
 				if(bot - top > 1) {
-					h.nrank += 2;
+					h.nrank += 2; h.nside += top / DGfm::SYMS == bot / DGfm::SYMS ? 1 : 2;
 					map_glf(g, top, bot, c, kseeds, &r, &tmp_ie);
 				} else {
-					h.nrank += 1;
+					h.nrank += 1; h.nside += 1;
 					if(map_glf1_fused(g, top, c, &r) && r.top + 1 < r.bot) {   // :6476-6482 (map_glf1 with one load per side touched)
 						tmp_ie.n = 1; tmp_ie.e[0][0] = 0; tmp_ie.e[0][1] = r.bot - r.top - 1;
 					}
@@ -879,9 +881,9 @@ H2G_HDN uint32_t gfm_search_graph(const X& g, const FT& ft, const SeqView& seq, 
 		r.top = r.bot = r.node_top = r.node_bot = 0;
 		tmp.n = 0;
 		if(c <= 3) {
-			if(bot - top > 1) { nrank[0] += 2; map_glf(g, top, bot, c, kseeds, &r, &tmp); }
+			if(bot - top > 1) { nrank[0] += 2; nrank[1] += top / X::SYMS == bot / X::SYMS ? 1 : 2; map_glf(g, top, bot, c, kseeds, &r, &tmp); }   // (sides of the rows only: partial_search_graph_item)
 			else {
-				nrank[0] += 1;
+				nrank[0] += 1; nrank[1] += 1;
 				if(map_glf1_fused(g, top, c, &r) && r.top + 1 < r.bot) { tmp.n = 1; tmp.e[0][0] = 0; tmp.e[0][1] = r.bot - r.top - 1; }
 			}
 		}
