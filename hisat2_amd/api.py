@@ -347,7 +347,7 @@ assert SEED_RESULT_DTYPE.itemsize == C.sizeof(SeedResult)
 
 EXPORTS = [
     "h2g_load_opts_init", "h2g_index_load", "h2g_index_get_info", "h2g_index_synth_sides", "h2g_index_free", "h2g_index_set_splice_sites", "h2g_index_add_splice_sites",
-    "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_set_reads",
+    "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_stream_select_batch", "h2g_set_reads",
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_device_count", "h2g_ext_search", "h2g_local_index_of", "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
@@ -388,6 +388,7 @@ def lib():
     L.h2g_stream_hip.argtypes = [vp]
     L.h2g_stream_hip.restype = vp
     L.h2g_stream_sync.argtypes = [vp]
+    L.h2g_stream_select_batch.argtypes = [vp, C.c_uint]
     L.h2g_set_reads.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.h2g_rank_bench.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     L.h2g_rank_bench_synth.argtypes = [vp, C.c_size_t, u64, C.c_int, C.c_int, P(C.c_float), P(u64)]
@@ -485,6 +486,15 @@ class Stream:
         self.h = C.c_void_p()
         _chk(lib().h2g_stream_create(index.h, max_reads, max_bases, C.byref(self.h)), "h2g_stream_create")
         self.n_reads = 0
+        self._batch = 0
+        self._batch_n = {}
+
+    def select_batch(self, k: int):
+        """resident batch k (h2g_stream_select_batch): the set_* calls, runs and fetches that follow are its own; runs over other batches stay in flight"""
+        self._batch_n[self._batch] = self.n_reads
+        _chk(lib().h2g_stream_select_batch(self.h, k), "h2g_stream_select_batch")
+        self._batch = k
+        self.n_reads = self._batch_n.get(k, 0)
 
     def close(self):
         if self.h:

@@ -77,6 +77,21 @@ struct h2g_index {
 #define H2G_CNT_BLOCK 512u          // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
 #define H2G_MACH_MAXGRID 48u       // workgroups of ONE machine pass behind a fast pass
 #define H2G_MACH_TOTAL 128u        // ... and of all machine passes in flight together ("mach_total": a pass gets at most mach_total / mstreams workgroups)
+// Resident batches (round 6): a stream holds up to H2G_MAX_BATCHES read sets WITH their result rows (h2g_stream_select_batch).  The named fields of h2g_stream are the
+// selected batch's; the others are parked in h2g_stream::parked.  A run captures its batch's pointers in its argument block when it is queued, so runs over different batches
+// are in flight together — fast passes and up to eight machine passes — each writing its own rows (a streaming caller's steady state: SURVEY §8(d) configs[2] is 10 M pairs, not one
+// million ten times).
+#define H2G_MAX_BATCHES 16
+#define H2G_BATCH_FIELDS(X) X(n_reads) X(max_read_len) X(d_codes) X(d_offs) X(d_quals) X(has_quals) X(d_names) X(d_name_offs) X(names_cap) X(has_names) \
+	X(d_codes2) X(d_offs2) X(d_quals2) X(d_names2) X(d_name_offs2) X(has_mates) X(has_quals2) X(d_rout) X(d_aln) X(aln_alloc) X(aln_slots) X(d_pout) X(paln_alloc) X(pair_slots)
+struct BatchCtx {
+	size_t n_reads = 0; uint32_t max_read_len = 0;
+	uint8_t* d_codes = nullptr; uint32_t* d_offs = nullptr; char* d_quals = nullptr; bool has_quals = false;
+	char* d_names = nullptr; uint32_t* d_name_offs = nullptr; size_t names_cap = 0; bool has_names = false;
+	uint8_t* d_codes2 = nullptr; uint32_t* d_offs2 = nullptr; char* d_quals2 = nullptr; char* d_names2 = nullptr; uint32_t* d_name_offs2 = nullptr; bool has_mates = false, has_quals2 = false;
+	ReadOut* d_rout = nullptr; h2g_alnres* d_aln = nullptr; size_t aln_alloc = 0; uint32_t aln_slots = 0;
+	PairOut* d_pout = nullptr; h2g_alnres* d_paln[2] = {nullptr, nullptr}; size_t paln_alloc = 0; uint32_t pair_slots = 0;
+};
 struct h2g_stream {
 	h2g_index* ix = nullptr;
 	hipStream_t st = nullptr;
@@ -149,6 +164,8 @@ struct h2g_stream {
 	hipEvent_t ev[12];
 	bool ran_seed = false, ran_align = false;
 	h2g_counters last;
+	BatchCtx parked[H2G_MAX_BATCHES];   // the batches that are not selected ([cur_batch] is unused: its fields are the stream's own)
+	unsigned cur_batch = 0;
 };
 
 template <typename T>
@@ -491,6 +508,11 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->dbg_buf);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf); (void)hipFree(s->d_ledits); (void)hipFree(s->d_ledits_cur);
+	for(unsigned b = 0; b < H2G_MAX_BATCHES; b++) if(b != s->cur_batch) {
+		BatchCtx& B = s->parked[b];
+		(void)hipFree(B.d_codes); (void)hipFree(B.d_offs); (void)hipFree(B.d_quals); (void)hipFree(B.d_names); (void)hipFree(B.d_name_offs); (void)hipFree(B.d_codes2); (void)hipFree(B.d_offs2);
+		(void)hipFree(B.d_quals2); (void)hipFree(B.d_names2); (void)hipFree(B.d_name_offs2); (void)hipFree(B.d_rout); (void)hipFree(B.d_aln); (void)hipFree(B.d_pout); (void)hipFree(B.d_paln[0]); (void)hipFree(B.d_paln[1]);
+	}
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
 	(void)hipStreamDestroy(s->st); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails); (void)hipHostFree(s->h_fast_args);
@@ -510,6 +532,32 @@ extern "C" void* h2g_stream_hip(h2g_stream* s) { return s ? (void*)s->st : nullp
 extern "C" h2g_status h2g_stream_sync(h2g_stream* s) {
 	if(!s) return H2G_ERR_ARG;
 	HIPCHK(sync_all(s));
+	return H2G_OK;
+}
+
+// Selects resident batch k: the h2g_set_* calls that follow fill it, the runs that follow work on it and write its rows, the fetches read them.  Nothing waits: runs queued
+// over other batches go on.
+extern "C" h2g_status h2g_stream_select_batch(h2g_stream* s, unsigned k) {
+	if(!s || k >= H2G_MAX_BATCHES) return H2G_ERR_ARG;
+	if(k == s->cur_batch) return H2G_OK;
+	HIPCHK(hipSetDevice(s->ix->device));
+	BatchCtx& out = s->parked[s->cur_batch];
+#define X(F) out.F = s->F;
+	H2G_BATCH_FIELDS(X)
+#undef X
+	out.d_paln[0] = s->d_paln[0]; out.d_paln[1] = s->d_paln[1];
+	BatchCtx& in = s->parked[k];
+	if(!in.d_codes && s->max_reads) {      // first use: the read buffers h2g_stream_create gives batch 0
+		HIPCHK(hipMalloc((void**)&in.d_codes, s->max_bases + 64));
+		HIPCHK(hipMalloc((void**)&in.d_quals, s->max_bases + 64));
+		HIPCHK(hipMalloc((void**)&in.d_offs, (s->max_reads + 1) * 4));
+	}
+#define X(F) s->F = in.F;
+	H2G_BATCH_FIELDS(X)
+#undef X
+	s->d_paln[0] = in.d_paln[0]; s->d_paln[1] = in.d_paln[1];
+	in = BatchCtx();
+	s->cur_batch = k;
 	return H2G_OK;
 }
 

@@ -87,6 +87,11 @@ H2G_EXPORT h2g_status h2g_stream_create(h2g_index*, size_t max_reads, size_t max
 H2G_EXPORT void       h2g_stream_free(h2g_stream*);
 H2G_EXPORT void*      h2g_stream_hip(h2g_stream*);   /* the hipStream_t every kernel of this context runs on */
 H2G_EXPORT h2g_status h2g_stream_sync(h2g_stream*);
+/* Resident batches: a stream holds up to 16 read sets, each with result rows of its own.  Batch 0 is selected when the stream is created.  After a selection the
+ * h2g_set_* calls fill that batch, h2g_align_*run works on it and the fetches read its rows; runs queued over other batches stay in flight (their machine passes next
+ * to this batch's fast pass), which is a streaming caller's steady state — the reference's worker threads likewise hold different reads at any moment
+ * (hisat2.cpp:3276-3644).  The call itself never waits. */
+H2G_EXPORT h2g_status h2g_stream_select_batch(h2g_stream*, unsigned batch);
 
 /* Reads as the worker loop holds them after parsing (read.h:325, Read::patFw): one byte per base,
  * codes A,C,G,T,N = 0..4; read i = codes[offs[i] .. offs[i+1]).  quals = ASCII (phred+33) or NULL for
