@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per GPU per step")
+    ap.add_argument("--batches", type=int, default=10, help="distinct resident batches of --pairs pairs the timed steps walk over (1..16)")
     ap.add_argument("--genome", type=float, default=float(os.environ.get("H2G_BENCH_GENOME", "3.1e9")))
     ap.add_argument("--strong", action="store_true", help="one global batch of --pairs split over the ranks instead of --pairs per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -432,15 +433,26 @@ def main():
     n_global = a.pairs if a.strong else a.pairs * world
     lo, hi = shard.shard_range(n_global, rank, world)
     npairs = hi - lo
-    m1, m2 = synth.make_pairs(contigs, npairs, 101, SEED + 7 + 1000 * rank, sub_rate=0.005)
-    c1, o1 = synth.flatten_reads(m1)
-    c2, o2 = synth.flatten_reads(m2)
-    names = [str(lo + i) for i in range(npairs)]           # FASTA names = decimal ids (they feed genRandSeed, pat.h:55)
+    # configs[2] is 10 M pairs: the timed region walks over `--batches` DISTINCT batches of --pairs pairs (default 10), all resident in HBM before it starts
+    # (h2g_stream_select_batch: read sets with result rows of their own on one stream), step i on batch i mod B — not one batch K times.  Batch b holds the global
+    # ids [b x n_global + lo, b x n_global + hi) of a read set of B x n_global pairs.
+    nbatch = max(1, min(int(a.batches), 16))
     ix = api.Index(base, device=local)
-    st = api.Stream(ix, max_reads=npairs, max_bases=c1.size)
-    t_up0 = time.perf_counter()
-    st.set_reads(c1, o1); st.set_read_names(names); st.set_mates(c2, o2, names)   # inputs resident in HBM before the timed region
-    t_upload = time.perf_counter() - t_up0
+    st = api.Stream(ix, max_reads=npairs, max_bases=npairs * 101)
+    last_b = (a.warmup + a.steps - 1) % nbatch                     # the batch of the last timed step: the one whose records the parity check reads
+    t_upload = 0.0
+    for b in range(nbatch):
+        bm1, bm2 = synth.make_pairs(contigs, npairs, 101, SEED + 7 + 1000 * rank + 100003 * b, sub_rate=0.005)
+        bc1, bo1 = synth.flatten_reads(bm1)
+        bc2, bo2 = synth.flatten_reads(bm2)
+        bnames = [str(b * n_global + lo + i) for i in range(npairs)]   # FASTA names = decimal ids (they feed genRandSeed, pat.h:55)
+        st.select_batch(b)
+        t_up0 = time.perf_counter()
+        st.set_reads(bc1, bo1); st.set_read_names(bnames); st.set_mates(bc2, bo2, bnames)   # inputs resident in HBM before the timed region
+        t_upload = time.perf_counter() - t_up0
+        if b == last_b:
+            m1, m2, c1, o1, c2, o2, names, id0 = bm1, bm2, bc1, bo1, bc2, bo2, bnames, b * n_global + lo
+    del bm1, bm2, bc1, bc2, bnames
     params = st.align_params()
 
     def barrier():
@@ -450,12 +462,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    step_no = 0
     for _ in range(a.warmup):
-        st.align_pairs_run(params)
+        st.select_batch(step_no % nbatch); st.align_pairs_run(params); step_no += 1
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        st.align_pairs_run(params)
+        st.select_batch(step_no % nbatch); st.align_pairs_run(params); step_no += 1
     barrier()
     dt = time.perf_counter() - t0
     cnt = st.counters()                        # counters + HIP-event kernel times (stream events) of the LAST step
@@ -499,7 +512,8 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"configs[2]: GRCh38-{'SIZE' if total >= 3_000_000_000 else 'PROFILE (reduced size)'} linear index over a seeded uniform-random {total} bp genome (24 contigs; {how}), "
-                                   f"{npairs} synthetic 101 bp --fr pairs per GPU per step, --no-spliced-alignment -k 5, 1xMI355X per rank",
+                                   f"{nbatch} distinct batches of {npairs} synthetic 101 bp --fr pairs per GPU resident in HBM ({nbatch * npairs} pairs; step i runs batch i mod {nbatch}), --no-spliced-alignment -k 5, 1xMI355X per rank",
+                       "distinct_batches": nbatch,
                        "genome_bases": total, "index_device_bytes": int(ix.info.device_bytes), "pairs_per_gpu": npairs, "read_len": 101, "sub_rate": 0.005,
                        "fragment": "N(300, 30) clipped to [150, 600]",
                        "stage": "HI_Aligner::go for both mates + pairing; report events stay in HBM (finishRead / SAM text are host code, SURVEY §8(f) N1)",
@@ -516,7 +530,7 @@ def main():
         f1, f2 = os.path.join(tmp, "1.fa"), os.path.join(tmp, "2.fa")
         parity_failed = False
         if os.path.exists(exe) and not a.no_cpu_baseline:
-            synth.write_reads_fasta(f1, m1, start_id=lo); synth.write_reads_fasta(f2, m2, start_id=lo)
+            synth.write_reads_fasta(f1, m1, start_id=id0); synth.write_reads_fasta(f2, m2, start_id=id0)
             if not a.no_whole_parity:
                 # every record of the batch the timed steps ran on (the stream still holds the last step's results) against the reference binary
                 out["parity_whole_batch"] = whole_batch_parity(api, base, st, c1, o1, c2, o2, names, int(params.khits), f1, f2, tmp=tmp)

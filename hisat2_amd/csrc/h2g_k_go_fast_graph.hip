@@ -4,6 +4,7 @@
 // four edits and a resolution five coordinates, every capacity hit is flagged by the primitive and the read handed on: smaller lists change which reads the
 // pass completes, never what it writes.
 #define H2G_GHIT_EDITS 12
+#define H2G_IEDGE_CAP  4       // a read of this pass keeps in-edge lists of at most two entries (fg_ie_pack); a longer one is counted, not stored
 #define H2G_NEW_EDITS  8
 #define H2G_GW_MAXELT  8
 #define H2G_GW_MAXST   12

@@ -148,7 +148,9 @@ H2G_EXPORT uint32_t   h2g_local_index_of(const h2g_index*, uint32_t tidx, uint32
 
 /* ---- graph (GFM) index primitives: 128 B sides with F/M bit vectors (gfm.h:160-176) ------------------- */
 /* BWTHit::_node_iedge_count (hi_aligner.h:199): nodes of a range with more than one incoming edge */
+#ifndef H2G_IEDGE_CAP       /* (a per-translation-unit capacity like H2G_GHIT_EDITS: the graph fast pass keeps lists of two entries and sets 4) */
 #define H2G_IEDGE_CAP 24
+#endif
 typedef struct {
 	uint32_t n;                        /* true count; only the first H2G_IEDGE_CAP entries are stored */
 	uint32_t e[H2G_IEDGE_CAP][2];      /* {node index relative to node_top, extra in-edges} */
