@@ -452,6 +452,10 @@ def main():
         t_upload = time.perf_counter() - t_up0
         if b == last_b:
             m1, m2, c1, o1, c2, o2, names, id0 = bm1, bm2, bc1, bo1, bc2, bo2, bnames, b * n_global + lo
+        if b == 0 and a.warmup > 0:
+            # the first of the W warm-up steps runs here, on batch 0, before the other batches are selected: a stream's first run allocates its pools and this batch's
+            # result rows, and a batch selected afterwards gets rows of the same size at selection (h2g_stream_select_batch) — nothing is allocated inside the timed region
+            st.align_pairs_run(st.align_params()); st.sync()
     del bm1, bm2, bc1, bc2, bnames
     params = st.align_params()
 
@@ -462,8 +466,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    step_no = 0
-    for _ in range(a.warmup):
+    step_no = 1 if a.warmup > 0 else 0
+    for _ in range(a.warmup - step_no):
         st.select_batch(step_no % nbatch); st.align_pairs_run(params); step_no += 1
     barrier()
     t0 = time.perf_counter()
@@ -644,6 +648,24 @@ def main():
                 out["chain_microbench"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {"error": (r.stderr or "no output")[-300:]}
             except Exception as e:             # noqa: BLE001
                 out["chain_microbench"] = {"error": repr(e)[:300]}
+        if not a.no_extras and total >= 1_000_000_000:
+            # the headline's companion AT THE METRIC'S SIZE on a genome with repeats: same contig profile and size, synth.make_repeat_genome, linear index built
+            # here by the reference's builder — only when the time this run has left covers that build (measured: 1.5 x the random genome's; H2G_BENCH_HARD_LIMIT seconds in all);
+            # the 256 Mbp repeat leg above is the figure that is always there
+            hard = float(os.environ.get("H2G_BENCH_HARD_LIMIT", "1680"))
+            try:
+                built = float(how.split("built in ")[1].split(" s")[0]) if how and "built in " in how else 600.0
+            except (IndexError, ValueError):
+                built = 600.0
+            left = hard - (time.time() - t_start)
+            need = 1.6 * built + 100.0 + 150.0       # genome + FASTA, the build, reads + timed runs + the reference over one batch
+            if left < need:
+                out["repeat_grch38size_pe"] = {"skipped": "%.0f s left of %.0f, about %.0f needed (the random genome's index took %.0f s on this box)" % (left, hard, need, built)}
+            else:
+                try:
+                    out["repeat_grch38size_pe"] = repeat_leg(a, api, synth, local, cache, glen=total, build_timeout=left - 250.0, nbatch=min(4, max(1, int(a.batches))))
+                except Exception as e:         # noqa: BLE001
+                    out["repeat_grch38size_pe"] = {"error": repr(e)[:400]}
         legs_failed = [k for k, v in out.items() if isinstance(v, dict) and isinstance(v.get("parity_whole_batch"), dict) and not v["parity_whole_batch"].get("digest_equal", False)]
         if parity_failed or legs_failed:
             out["parity_failed"] = (["headline"] if parity_failed else []) + legs_failed
@@ -771,6 +793,22 @@ def extras(a, api, synth, ix_big, local, cache):
             # second denominator: the measured copy bandwidth of the chip (MI355X guide: 6.29 TB/s); a 64 B side is half a 128 B
             # sector pair, so the linear kernel's ceiling in these units is half of that
             micro[name] = {"ms": ms, "GB/s": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "frac_of_copy_6.29TBs": gbs / 6290.0, "checksum": int(ck)}
+            if not graph and v == 0 and a.rank_queries >= (1 << 20):
+                # 2^20 sampled outputs of THIS run against GFM::mapLF on the CPU — the oracle's own h2o_rank over the same side array, rebuilt on the host
+                # (tests/rank_synth_check.py; the oracle is the checker here, nothing it computes is measured)
+                try:
+                    import rank_synth_check as RC
+                    import h2o_py as HO
+                    stride = a.rank_queries >> 20
+                    got = rst.rank_synth_sample(stride, 1 << 20)
+                    ncmp, nbad = RC.sampled_check(HO.load(), got, nsides, SEED, a.rank_queries, stride)
+                    micro["sampled_vs_oracle_mapLF"] = {"samples": ncmp, "differing": nbad, "every": stride, "against": "oracle/h2o.c h2o_rank (SideLocus::initFromRow gfm.h:376 + countBt2Side :2958 + fchr)"}
+                    if nbad:
+                        raise SystemExit("bench.py: %d of %d sampled rank outputs differ from the oracle's mapLF" % (nbad, ncmp))
+                except SystemExit:
+                    raise
+                except Exception as e:         # noqa: BLE001
+                    micro["sampled_vs_oracle_mapLF"] = {"error": repr(e)[:300]}
         rst.close(); rix.close()
         ex[key] = micro
     return ex
@@ -806,26 +844,36 @@ def sam_parity(base, f1, f2, nv, tmp, opts=()):
             "against": "oracle/_ref/hisat2-align-s -p 8 --reorder (complete SAM lines)", **json.load(open(os.path.join(tmp, "stats.json")))}
 
 
-def timed_pairs(api, synth, base, local, m1, m2, steps=32, whole_parity=True):
+def timed_pairs(api, synth, base, local, m1, m2, steps=32, whole_parity=True, more=()):
+    """steady-state step of queued runs over (m1, m2) and the batches of `more` ((m1, m2) tuples of the same size): all resident (h2g_stream_select_batch), step i on batch
+    i mod B; the counters and the whole-batch parity are batch 0's, run once more on its own"""
     c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
     n = len(m1)
     names = [str(i) for i in range(n)]
     ix = api.Index(base, device=local)
     st = api.Stream(ix, max_reads=n, max_bases=c1.size)
     st.set_reads(c1, o1); st.set_read_names(names); st.set_mates(c2, o2, names)
+    nb = 1 + len(more)
+    for b, (x1, x2) in enumerate(more, start=1):
+        d1, p1 = synth.flatten_reads(x1); d2, p2 = synth.flatten_reads(x2)
+        xn = [str(b * n + i) for i in range(n)]
+        st.select_batch(b)
+        st.set_reads(d1, p1); st.set_read_names(xn); st.set_mates(d2, p2, xn)
+    k = 0
     for _ in range(10):                                # (the pipeline is 8 machine passes deep: filled before the clock starts)
-        st.align_pairs_run()
+        st.select_batch(k % nb); st.align_pairs_run(); k += 1
     st.sync()
     t0 = time.perf_counter()
     for _ in range(steps):                             # 32 steps: the drain of the last machine passes (inside the timed region) weighs 1 / 32
-        st.align_pairs_run()
+        st.select_batch(k % nb); st.align_pairs_run(); k += 1
     st.sync()
     dt = (time.perf_counter() - t0) / steps
     # the counters of ONE run on its own: in a queue of runs the machine pass of run k - 1 may finish a deferred read that run k also deferred, and
     # run k's count of aligned pairs then misses it (the result itself is the same either way; the headline's workload has no second pass)
+    st.select_batch(0)
     st.align_pairs_run(); st.sync()
     c = st.counters()
-    leg = {"pairs": n, "ms_per_step": dt * 1e3, "reads_per_s": 2 * n / dt, "fast_kernel_ms": float(c.ms_fast_kernel), "machine_pass_ms": float(c.ms_align_kernel),
+    leg = {"pairs": n, "distinct_batches": nb, "ms_per_step": dt * 1e3, "reads_per_s": 2 * n / dt, "fast_kernel_ms": float(c.ms_fast_kernel), "machine_pass_ms": float(c.ms_align_kernel),
            "kernel_times_are": "of one run on its own (the step time above is the steady state of queued runs)",
            "pairs_completed_by_the_fast_pass": int(c.n_fast), "pairs_handed_on": int(c.n_fast_bail), "hand_on_rate": int(c.n_fast_bail) / n,
            "hand_ons_by_reason": fast_bail_reasons(api, st), "pairs_second_pass": int(c.n_second_pass), "second_pass_rate": int(c.n_second_pass) / n,
@@ -843,7 +891,7 @@ def timed_pairs(api, synth, base, local, m1, m2, steps=32, whole_parity=True):
     return leg
 
 
-def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, nparity=20_000):
+def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, nparity=20_000, build_timeout=None, nbatch=1):
     """The headline's companion on a genome WITH repeats: synth.make_repeat_genome — Alu-like and LINE-like families at 8-20 %
     divergence in a quarter of the bases, tandem arrays, segmental duplications — 24 human-profile contigs, linear index built on the box,
     1 M x 2 x 101 bp pairs: the step time, how many pairs the fast pass hands on and why, the second-pass rate, and the SAM of 20 000 pairs
@@ -857,13 +905,24 @@ def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, 
         os.makedirs(d, exist_ok=True)
         synth.write_fasta(base + ".fa", contigs)
         t0 = time.time()
-        subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "-p", str(_builder_threads()), base + ".fa", base], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        try:
+            subprocess.run([os.path.join(REF, "hisat2-build-s"), "-q", "-p", str(_builder_threads()), base + ".fa", base + ".tmp"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=build_timeout)
+            for k in range(1, 9):
+                os.replace(f"{base}.tmp.{k}.ht2", f"{base}.{k}.ht2")
+        except subprocess.TimeoutExpired:
+            return {"skipped": "the reference's builder did not finish the %d bp repeat-structured index within the %.0f s this run had left for it" % (glen, build_timeout)}
+        finally:
+            for p_ in [base + ".fa"] + [f"{base}.tmp.{k}.ht2" for k in range(1, 9)]:
+                if os.path.exists(p_):
+                    os.remove(p_)
         t_build = time.time() - t0
-        os.remove(base + ".fa")
     m1, m2 = synth.make_pairs(contigs, npairs, 101, SEED + 78, sub_rate=0.005)
+    more = [synth.make_pairs(contigs, npairs, 101, SEED + 78 + 100003 * b, sub_rate=0.005) for b in range(1, nbatch)]
     leg = {"workload": f"repeat-structured {glen} bp genome (interspersed families of ~300 bp and 1-6 kbp at 8-20 % divergence in a quarter of the bases, tandem arrays, segmental "
                        f"duplications; 24 contigs), linear index, {npairs} x 2 x 101 bp pairs, --no-spliced-alignment -k 5", "index_build_s": t_build}
-    leg.update(timed_pairs(api, synth, base, local, m1, m2, whole_parity=not a.no_whole_parity and not a.no_cpu_baseline))
+    leg.update(timed_pairs(api, synth, base, local, m1, m2, whole_parity=not a.no_whole_parity and not a.no_cpu_baseline, more=more))
+    del more
     # roofline of this leg: the fast kernel over its own algorithmic bytes, and the whole step (fast + machine passes, steady state)
     alg_fast = leg.pop("_fast_alg_bytes")
     alg_all = (leg["sides_per_pair"] + leg["sa_steps_per_pair"]) * npairs * 64
@@ -875,7 +934,7 @@ def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, 
     leg["roofline"] = {"bound": "hbm", "kernel": "k_go_fast (h2g_k_go_fast.hip) over the pairs it completes", "kernel_ms": leg["fast_kernel_ms"],
                        "achieved": alg_fast / (leg["fast_kernel_ms"] * 1e-3) / 1e9 if leg["fast_kernel_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": alg_fast / (leg["fast_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["fast_kernel_ms"] > 0 else 0.0,
-                       "traffic": (int(pm_rep["traffic_bytes_per_launch"]) if pm_rep and pm_rep.get("kernel_sources_sha16") == kernel_sources_sha16() and pm_rep.get("pairs_per_launch") == npairs else None),
+                       "traffic": (int(pm_rep["traffic_bytes_per_launch"]) if pm_rep and pm_rep.get("kernel_sources_sha16") == kernel_sources_sha16() and pm_rep.get("pairs_per_launch") == npairs and int(pm_rep.get("genome", 256000000)) == glen else None),
                        "traffic_record": "profiles/r05_rep_pmc_traffic.json (lease A: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this leg's fast kernel; attached only on the sources it was taken on)",
                        "algorithmic": "64 B x (unique sides + SA-walk steps) of the fast kernel's own searches and walks",
                        "whole_step": {"algorithmic_bytes": alg_all, "GB/s": alg_all / (leg["ms_per_step"] * 1e-3) / 1e9, "frac": alg_all / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -348,7 +348,7 @@ assert SEED_RESULT_DTYPE.itemsize == C.sizeof(SeedResult)
 EXPORTS = [
     "h2g_load_opts_init", "h2g_index_load", "h2g_index_get_info", "h2g_index_synth_sides", "h2g_index_free", "h2g_index_set_splice_sites", "h2g_index_add_splice_sites",
     "h2g_last_error", "h2g_stream_create", "h2g_stream_free", "h2g_stream_hip", "h2g_stream_sync", "h2g_stream_select_batch", "h2g_set_reads",
-    "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
+    "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_rank_bench_synth_sample", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_device_count", "h2g_ext_search", "h2g_local_index_of", "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
     "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense", "h2g_align_fetch_long_edits",
@@ -392,6 +392,7 @@ def lib():
     L.h2g_set_reads.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.h2g_rank_bench.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     L.h2g_rank_bench_synth.argtypes = [vp, C.c_size_t, u64, C.c_int, C.c_int, P(C.c_float), P(u64)]
+    L.h2g_rank_bench_synth_sample.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
     L.h2g_fm_search.argtypes = [vp, vp, C.c_size_t, u32, vp]
     L.h2g_sa_resolve.argtypes = [vp, vp, C.c_size_t, u32, vp, vp]
     L.h2g_sw_align.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, P(C.c_float)]
@@ -524,6 +525,12 @@ class Stream:
         ms, ck = C.c_float(0), u64(0)
         _chk(lib().h2g_rank_bench_synth(self.h, n, seed, variant, repeats, C.byref(ms), C.byref(ck)), "h2g_rank_bench_synth")
         return ms.value, ck.value
+
+    def rank_synth_sample(self, stride, nsample):
+        """results j * stride (j < nsample) of the last rank_synth run"""
+        out = np.empty(nsample, dtype=np.uint32)
+        _chk(lib().h2g_rank_bench_synth_sample(self.h, stride, nsample, out.ctypes.data), "h2g_rank_bench_synth_sample")
+        return out
 
     def fm_search(self, queries, khits=5):
         n = len(queries)

@@ -11,6 +11,8 @@
 #define H2G_GW_MAXROWS 64      // fixed: the row masks of the group walk are 64-bit words
 #define H2G_AWA_CAND   4
 #define H2G_AWA_DEPTH  12
+#define H2G_HAPLOTYPE  0       // --haplotype runs on the graph_spl units (go_run: `spl`), never through this pass
+#define H2G_INLINE_GLF         // the graph LF leaf functions inline in this unit's search loops (lease C: 75.8 -> 74.2 ms per million pairs)
 #define FG_KERNEL   k_go_fast_graph
 #define FG_LAUNCH   h2g_go_fast_graph_launch
 #define FG_GEOMETRY h2g_go_fast_graph_geometry

@@ -552,6 +552,18 @@ extern "C" h2g_status h2g_stream_select_batch(h2g_stream* s, unsigned k) {
 		HIPCHK(hipMalloc((void**)&in.d_quals, s->max_bases + 64));
 		HIPCHK(hipMalloc((void**)&in.d_offs, (s->max_reads + 1) * 4));
 	}
+	// ... and result rows as large as the rows of the batch that is leaving (the option set a streaming caller runs every batch with): a batch's first run then
+	// allocates nothing — an allocation of gigabytes in the middle of a queue of runs waits for all of them
+	if(!in.d_pout && out.d_pout && out.paln_alloc) {
+		HIPCHK(hipMalloc((void**)&in.d_pout, s->max_reads * sizeof(PairOut)));
+		for(int m = 0; m < 2; m++) HIPCHK(hipMalloc((void**)&in.d_paln[m], out.paln_alloc * sizeof(h2g_alnres)));
+		in.paln_alloc = out.paln_alloc; in.pair_slots = out.pair_slots;
+	}
+	if(!in.d_rout && out.d_rout && out.aln_alloc) {
+		HIPCHK(hipMalloc((void**)&in.d_rout, s->max_reads * sizeof(ReadOut)));
+		HIPCHK(hipMalloc((void**)&in.d_aln, out.aln_alloc * sizeof(h2g_alnres)));
+		in.aln_alloc = out.aln_alloc; in.aln_slots = out.aln_slots;
+	}
 #define X(F) s->F = in.F;
 	H2G_BATCH_FIELDS(X)
 #undef X
@@ -922,6 +934,15 @@ __global__ __launch_bounds__(512) void k_rank_chain(DGfm g, uint64_t seed, int s
 
 // nchains chains of `steps` dependent rank queries, chains_per_lane (1, 2, 4 or 8) of them in each lane, workgroups of `block` threads (64..512) with
 // `lds_bytes` of dynamic LDS each.  *checksum = the sum of all rank results (the same for every chains_per_lane at equal seed, nchains and steps).
+// out[j] = result j * stride of the LAST h2g_rank_bench_synth run of this stream (its device buffer is still there): what a sampled comparison with the
+// CPU's mapLF needs of a 2^28-query run
+extern "C" h2g_status h2g_rank_bench_synth_sample(h2g_stream* s, size_t stride, size_t nsample, uint32_t* out) {
+	if(!s || !out || stride == 0 || nsample == 0 || !s->d_tmp[2] || s->tmp_sz[2] < ((nsample - 1) * stride + 1) * 4) return H2G_ERR_ARG;
+	HIPCHK(hipSetDevice(s->ix->device));
+	HIPCHK(sync_all(s));
+	HIPCHK(hipMemcpy2D(out, 4, s->d_tmp[2], stride * 4, 4, nsample, hipMemcpyDeviceToHost));
+	return H2G_OK;
+}
 extern "C" H2G_EXPORT h2g_status h2g_rank_chain_bench(h2g_stream* s, size_t nchains, int chains_per_lane, int steps, int block, int lds_bytes, uint64_t seed,
                                                       int repeats, float* kernel_ms, uint64_t* checksum)
 {

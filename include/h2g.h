@@ -110,6 +110,8 @@ H2G_EXPORT h2g_status h2g_rank_bench(h2g_stream*, const uint32_t* rows, const ui
 /* generates the SURVEY §8(d) query set on device: row ~ U[0,gbwtLen) from splitmix64(seed), c = hash&3 */
 H2G_EXPORT h2g_status h2g_rank_bench_synth(h2g_stream*, size_t n, uint64_t seed, int variant, int repeats,
                                            float* kernel_ms, uint64_t* checksum);
+/* out[j] = result j * stride of this stream's last h2g_rank_bench_synth run: the sampled comparison with GFM::mapLF on the CPU */
+H2G_EXPORT h2g_status h2g_rank_bench_synth_sample(h2g_stream*, size_t stride, size_t nsample, uint32_t* out);
 
 enum { H2G_FM_PARTIAL = 0, H2G_FM_GLOBAL = 1, H2G_FM_LOCAL = 2 };
 enum { H2G_CANDIDATE_HIT = 1, H2G_PSEUDOGENE_HIT = 2, H2G_ANCHOR_HIT = 3 };   /* hi_aligner.h:96-100 */

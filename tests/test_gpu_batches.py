@@ -37,12 +37,12 @@ def test_batches_in_flight_keep_their_rows(g1_index, g1s_index, golden_dir, grap
     orders = [np.arange(n), np.arange(n)[::-1].copy(), np.repeat(np.arange(0, n, 2), 2)[:n]]
     sets = []
     for k, o in enumerate(orders):
-        m1 = [s1[i] for i in o]; m2 = [s2[i] for i in o]
+        m1 = np.stack([s1[i] for i in o]); m2 = np.stack([s2[i] for i in o])
         names = ["b%d_%d" % (k, i) for i in range(len(o))]          # (names feed genRandSeed: each batch has its own)
         sets.append((m1, m2, names))
     want = [_one(ix, m1, m2, names, _dense) for m1, m2, names in sets]
     assert want[0] != want[1]
-    cmax = max(sum(len(r) for r in m1) for m1, _, _ in sets)
+    cmax = max(m1.size for m1, _, _ in sets)
     st = api.Stream(ix, max_reads=n, max_bases=cmax + 64)
     for k, (m1, m2, names) in enumerate(sets):
         st.select_batch(k)

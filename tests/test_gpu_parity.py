@@ -283,3 +283,18 @@ def test_graph_rank_variants_agree_on_large_synthetic_sides():
     assert np.array_equal(tot, rows.astype(np.uint64) + np.uint64(base))
     st.close()
     ix.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_rank_synth_sampled_vs_oracle(oracle_lib, variant):
+    """the micro-benchmark's own query stream (h2g_rank_bench_synth: rows drawn on the device) on the synthetic side array, sampled every 64th output, against the
+    ORACLE's mapLF over the same array rebuilt on the host (SURVEY §8(d)'s sampled check; bench.py does the same at 2^28 queries / 2^20 samples)"""
+    import rank_synth_check as RC
+    nsides, seed, n, stride = 300_000, 20260925, 1 << 22, 64
+    ix = api.Index(synth_sides=nsides, seed=seed, device=0)
+    st = api.Stream(ix)
+    st.rank_synth(n, seed, variant=variant, repeats=1)
+    got = st.rank_synth_sample(stride, n // stride)
+    ncmp, nbad = RC.sampled_check(oracle_lib, got, nsides, seed, n, stride)
+    assert ncmp == n // stride and nbad == 0
+    st.close(); ix.close()
