@@ -793,7 +793,7 @@ def extras(a, api, synth, ix_big, local, cache):
             # second denominator: the measured copy bandwidth of the chip (MI355X guide: 6.29 TB/s); a 64 B side is half a 128 B
             # sector pair, so the linear kernel's ceiling in these units is half of that
             micro[name] = {"ms": ms, "GB/s": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS, "frac_of_copy_6.29TBs": gbs / 6290.0, "checksum": int(ck)}
-            if not graph and v == 0 and a.rank_queries >= (1 << 20):
+            if not graph and v == 0 and a.rank_queries >= (1 << 28):
                 # 2^20 sampled outputs of THIS run against GFM::mapLF on the CPU — the oracle's own h2o_rank over the same side array, rebuilt on the host
                 # (tests/rank_synth_check.py; the oracle is the checker here, nothing it computes is measured)
                 try:
@@ -801,10 +801,19 @@ def extras(a, api, synth, ix_big, local, cache):
                     import h2o_py as HO
                     stride = a.rank_queries >> 20
                     got = rst.rank_synth_sample(stride, 1 << 20)
-                    ncmp, nbad = RC.sampled_check(HO.load(), got, nsides, SEED, a.rank_queries, stride)
-                    micro["sampled_vs_oracle_mapLF"] = {"samples": ncmp, "differing": nbad, "every": stride, "against": "oracle/h2o.c h2o_rank (SideLocus::initFromRow gfm.h:376 + countBt2Side :2958 + fchr)"}
-                    if nbad:
-                        raise SystemExit("bench.py: %d of %d sampled rank outputs differ from the oracle's mapLF" % (nbad, ncmp))
+                    want = RC.sampled_expect(HO.load(), nsides, SEED, a.rank_queries, stride, 1 << 20)
+                    nbad = int((want != got).sum())
+                    micro["sampled_vs_oracle_mapLF"] = {"samples": int(len(want)), "differing": nbad, "every": stride, "against": "oracle/h2o.c h2o_rank (SideLocus::initFromRow gfm.h:376 + countBt2Side :2958 + fchr)"}
+                    # the same kernel without the micro-benchmark's own output stream (k_rank_v0_sampled: every result into the checksum, every 256th stored)
+                    rst.rank_synth(a.rank_queries, SEED, variant=10, repeats=1)
+                    ms10, ck10 = rst.rank_synth(a.rank_queries, SEED, variant=10, repeats=3)
+                    got10 = rst.rank_synth_sample(256, a.rank_queries >> 8)[::max(1, stride // 256)][:1 << 20]
+                    gbs10 = a.rank_queries * 64 / (ms10 * 1e-3) / 1e9
+                    micro["lane_per_side_no_output_stream"] = {"ms": ms10, "GB/s": gbs10, "frac_of_8TBs": gbs10 / HBM_PEAK_GBS, "checksum": int(ck10), "checksum_equals_lane_per_side": int(ck10) == int(ck),
+                                                               "sampled_differing": int((want != got10).sum()),
+                                                               "note": "a rank in the aligner feeds the next step of its chain; 4 B per query written back is the micro-benchmark's own traffic"}
+                    if nbad or micro["lane_per_side_no_output_stream"]["sampled_differing"] or int(ck10) != int(ck):
+                        raise SystemExit("bench.py: the rank micro-benchmark's outputs differ from the oracle's mapLF (%d of %d sampled; checksums %s / %s)" % (nbad, len(want), ck, ck10))
                 except SystemExit:
                     raise
                 except Exception as e:         # noqa: BLE001

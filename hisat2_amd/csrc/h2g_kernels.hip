@@ -629,6 +629,23 @@ __global__ __launch_bounds__(256) void k_rank_v0(DGfm g, const uint32_t* rows, c
 	}
 }
 
+// variant 10: variant 0 without the OUTPUT STREAM (round 6).  In the aligner a rank feeds the next step of its own chain; the 4 bytes per query the micro-benchmark writes
+// are its own artefact (2^28 queries: 1 GB of stores next to 17 GB of side lines).  Here every result goes into the run's checksum (the k_checksum function of the full
+// output, so the two variants must agree) and every 256th is stored — the samples the comparison with the CPU's mapLF reads.
+__global__ __launch_bounds__(256) void k_rank_v0_sampled(DGfm g, uint32_t* out, size_t n, uint64_t seed, unsigned long long* sum)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	unsigned long long acc = 0;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		const uint64_t h = splitmix64(seed + i);
+		const uint32_t r = rank64(g, (uint32_t)(h % g.gbwtLen), (int)((h >> 40) & 3));
+		if((i & 255) == 0) out[i] = r;
+		acc += (unsigned long long)r * (unsigned long long)((i & 1023) + 1);
+	}
+	for(int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+	if((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
 // variant 1: four lanes per side — one dwordx4 per lane => one fully coalesced 64 B request per query;
 // lanes 0-2 popcount two payload words each, lane 3 holds the four Occ words; 2-step butterfly reduce.
 template <int UNROLL>
@@ -831,6 +848,9 @@ static int launch_rank(h2g_stream* s, const uint32_t* d_rows, const uint8_t* d_c
 			hipLaunchKernelGGL(k_rank_exp<4>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed);
 		} else if(variant == 5 && synth) {
 			hipLaunchKernelGGL(k_rank_exp<5>, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed);
+		} else if(variant == 10 && synth) {
+			HIPCHK(hipMemsetAsync(s->d_counters + 6, 0, 8, s->st));
+			hipLaunchKernelGGL(k_rank_v0_sampled, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed, s->d_counters + 6);
 		} else if(variant >= 6 && variant <= 9) {
 			// variant 0's kernel at a fraction of the chip's occupancy (measurement: the chain kernel sustains more random 64 B requests per second at one 512-thread
 			// workgroup per CU than at full occupancy — profiles/r05_NOTES.md): 6: 16 waves per CU, 7: 8, 8: 4, 9: 2
@@ -877,9 +897,9 @@ extern "C" h2g_status h2g_rank_bench_synth(h2g_stream* s, size_t n, uint64_t see
 	if(rc) return rc;
 	if(checksum) {
 		HIPCHK(hipMemsetAsync(s->d_counters + 7, 0, 8, s->st));
-		hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, s->st, (const uint32_t*)dout, n, s->d_counters + 7);
+		if(variant != 10) hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, s->st, (const uint32_t*)dout, n, s->d_counters + 7);
 		unsigned long long v = 0;
-		HIPCHK(hipMemcpyAsync(&v, s->d_counters + 7, 8, hipMemcpyDeviceToHost, s->st));
+		HIPCHK(hipMemcpyAsync(&v, s->d_counters + (variant == 10 ? 6 : 7), 8, hipMemcpyDeviceToHost, s->st));   // (variant 10 sums on the fly: the last repeat's)
 		HIPCHK(sync_all(s));
 		*checksum = v;
 	}

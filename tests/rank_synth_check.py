@@ -64,11 +64,16 @@ def oracle_map_lf(olib, sides, fchr, nsides, rows, cs):
     return np.fromiter((f(gp, int(r), int(c)) for r, c in zip(rows, cs)), dtype=np.uint32, count=len(rows))
 
 
-def sampled_check(olib, device_samples, nsides, seed, n, stride):
-    """device_samples[j] = output of query j * stride of an n-query run over h2g_index_synth_sides(nsides, seed); returns (number compared, number differing)"""
+def sampled_expect(olib, nsides, seed, n, stride, nsample):
+    """the oracle's mapLF for queries 0, stride, 2 stride, ... of an n-query run over h2g_index_synth_sides(nsides, seed)"""
     sides, fchr = synth_linear_sides(nsides, seed)
-    idx = np.arange(len(device_samples), dtype=np.uint64) * np.uint64(stride)
+    idx = np.arange(nsample, dtype=np.uint64) * np.uint64(stride)
     assert int(idx[-1]) < n
     rows, cs = queries(seed, idx, nsides * 192)
-    want = oracle_map_lf(olib, sides, fchr, nsides, rows, cs)
+    return oracle_map_lf(olib, sides, fchr, nsides, rows, cs)
+
+
+def sampled_check(olib, device_samples, nsides, seed, n, stride):
+    """device_samples[j] = output of query j * stride; returns (number compared, number differing)"""
+    want = sampled_expect(olib, nsides, seed, n, stride, len(device_samples))
     return len(want), int((want != np.asarray(device_samples, dtype=np.uint32)).sum())

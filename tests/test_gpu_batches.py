@@ -21,9 +21,22 @@ def _one(ix, m1, m2, names, fetch):
     return out
 
 
+ALN_DT = np.dtype([("fw", "<u4"), ("tidx", "<u4"), ("toff", "<u4"), ("len", "<u4"), ("trim5", "<u4"), ("trim3", "<u4"), ("nedits", "<u4"), ("spl", "<u4"),
+                   ("score", "<i8"), ("edits", [("pos", "<u4"), ("chr", "u1"), ("qchr", "u1"), ("type", "u1"), ("pad", "u1"), ("snp", "<u4")], 32)])
+
+
+def _recs(arr, n):
+    """n dense records with the edit entries a record does not use zeroed (they are whatever the row held before)"""
+    a = np.frombuffer(arr, dtype=ALN_DT, count=n).copy()
+    keep = np.arange(32)[None, :] < a["nedits"][:, None]
+    for f in ("pos", "chr", "qchr", "type", "pad", "snp"):
+        a["edits"][f][~keep] = 0
+    return a.tobytes()
+
+
 def _dense(st):
     res, a1, f1, a2, f2 = st.align_pairs_fetch_dense()
-    return bytes(res), bytes(a1)[:int(f1[-1]) * 424], f1.tobytes(), bytes(a2)[:int(f2[-1]) * 424], f2.tobytes()
+    return bytes(res), _recs(a1, int(f1[-1])), f1.tobytes(), _recs(a2, int(f2[-1])), f2.tobytes()
 
 
 @pytest.mark.parametrize("graph", [False, True])
