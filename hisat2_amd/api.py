@@ -351,7 +351,7 @@ EXPORTS = [
     "h2g_rank_bench", "h2g_rank_bench_synth", "h2g_rank_bench_synth_sample", "h2g_fm_search", "h2g_sa_resolve", "h2g_extend",
     "h2g_seed_params_init", "h2g_seed_extend_run", "h2g_seed_extend_fetch", "h2g_get_counters",
     "h2g_device_count", "h2g_ext_search", "h2g_local_index_of", "h2g_align_params_init", "h2g_align_params_presets", "h2g_set_read_names", "h2g_align_run", "h2g_align_fetch",
-    "h2g_set_mates", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense", "h2g_align_fetch_long_edits",
+    "h2g_set_mates", "h2g_combine_with", "h2g_align_pairs_run", "h2g_align_pairs_fetch", "h2g_align_fetch_dense", "h2g_align_pairs_fetch_dense", "h2g_align_fetch_long_edits",
     "h2g_align_fetch_compact", "h2g_align_pairs_fetch_compact", "h2g_host_alloc", "h2g_host_free",
     "h2g_graph_lf", "h2g_fm_search_graph", "h2g_index_synth_graph_sides", "h2g_sw_align", "h2g_sa_resolve_graph", "h2g_adjust_with_alt",
 ]

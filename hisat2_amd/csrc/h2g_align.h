@@ -131,6 +131,54 @@ struct LIdx {
 		const uint8_t* p = side_ptr(sideNum);
 		return (p[charOff >> 2] >> ((charOff & 3) * 2)) & 3;
 	}
+	H2G_HD uint32_t lf(uint32_t row) const { return rank(row, rowL(row)); }      // one step of an SA walk: mapLF(row, rowL(row))
+};
+// The same local index with its descriptor IN REGISTERS (round 6: the fast pass's local searches and walks).  LIdx reads DLocalDesc fields from HBM at every rank — the side
+// array's offset, the '$' row, fchr[c] indexed by a character that is only known once the row's own symbol has come back — and an SA-walk step is a byte load (rowL) followed
+// by the side load (rank).  Here the descriptor is read once per primitive and a walk step is ONE side load: the symbol is taken from the side in registers.  Same arithmetic.
+struct LIdxR {
+	const uint8_t*  sides;
+	const uint16_t* ftab; const uint16_t* eftab;
+	uint32_t nZ, zoff, ftabLim, fchr0, fchr1, fchr2, fchr3, ftab_chars;
+	H2G_HD void init(const DLocalSet* ls, const DLocalDesc* d) {
+		sides = ls->sides + d->sides_off; ftab = ls->words + d->ftab_off; eftab = ls->words + d->eftab_off;
+		nZ = d->nZ; zoff = d->zoff; ftabLim = d->ftabLim; fchr0 = d->fchr[0]; fchr1 = d->fchr[1]; fchr2 = d->fchr[2]; fchr3 = d->fchr[3]; ftab_chars = ls->ftabChars;
+	}
+	H2G_HD uint32_t ftabChars() const { return ftab_chars; }
+	H2G_HD bool is_zoff(uint32_t row) const { return nZ && row == zoff; }
+	H2G_HD uint32_t side_of(uint32_t row) const { return row / 224u; }
+	H2G_HD uint32_t fh(uint32_t i) const { const uint32_t v = ftab[i]; return v <= ftabLim ? v : eftab[(v ^ 0xffffu) * 2 + 1]; }
+	H2G_HD uint32_t fl(uint32_t i) const { const uint32_t v = ftab[i]; return v <= ftabLim ? v : eftab[(v ^ 0xffffu) * 2]; }
+	H2G_HD void lohi(uint32_t fi, uint32_t* top, uint32_t* bot) const { *top = fh(fi); *bot = fl(fi + 1); }
+	H2G_HD uint32_t fchr_of(int c) const { return c == 0 ? fchr0 : c == 1 ? fchr1 : c == 2 ? fchr2 : fchr3; }
+	H2G_HD uint32_t rank_in(const Side64& s, uint32_t sideNum, uint32_t charOff, int c) const {
+		uint32_t cnt = 0;
+#pragma unroll
+		for(int k = 0; k < 7; k++) cnt += count_word(s.w[k], c, (int)charOff - 32 * k);
+		if(c == 0 && nZ) {
+			const uint32_t zs = zoff / 224u, zc = zoff - zs * 224u;
+			if(zs == sideNum && zc < charOff) cnt--;
+		}
+		return (uint32_t)((s.w[7] >> (16 * c)) & 0xffffu) + cnt + fchr_of(c);
+	}
+	H2G_HD uint32_t rank(uint32_t row, int c) const {
+		const uint32_t sideNum = row / 224u, charOff = row - sideNum * 224u;
+		return rank_in(load_side64(sides + (size_t)sideNum * 64), sideNum, charOff, c);
+	}
+	H2G_HD int rowL(uint32_t row) const {
+		const uint32_t sideNum = row / 224u, charOff = row - sideNum * 224u;
+		return (sides[(size_t)sideNum * 64 + (charOff >> 2)] >> ((charOff & 3) * 2)) & 3;
+	}
+	H2G_HD uint32_t lf(uint32_t row) const {
+		const uint32_t sideNum = row / 224u, charOff = row - sideNum * 224u;
+		const Side64 s = load_side64(sides + (size_t)sideNum * 64);
+		// (224 symbols: words 0 .. 6, picked by selects — an index into the array would put the side into private memory)
+		const uint32_t k = charOff >> 5;
+		const uint64_t a = (k & 1) ? s.w[1] : s.w[0], b = (k & 1) ? s.w[3] : s.w[2], d = (k & 1) ? s.w[5] : s.w[4];
+		const uint64_t w = k >= 6 ? s.w[6] : (k >= 4 ? d : (k >= 2 ? b : a));
+		const int c = (int)((w >> ((charOff & 31u) * 2u)) & 3u);
+		return rank_in(s, sideNum, charOff, c);
+	}
 };
 
 // A local index without a variant in its interval is a LINEAR index even inside a graph index (GFMParams::linearFM gfm.h:149:
@@ -164,6 +212,7 @@ struct LIdxW {
 		const uint8_t* p = side_ptr(sideNum);
 		return (p[charOff >> 2] >> ((charOff & 3) * 2)) & 3;
 	}
+	H2G_HD uint32_t lf(uint32_t row) const { return rank(row, rowL(row)); }
 };
 
 // globalGFMSearch hi_aligner.h:6606-6744 / localGFMSearch :6751-6892 on a linear index.

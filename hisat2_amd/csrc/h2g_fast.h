@@ -2250,7 +2250,7 @@ H2G_HD void fast_op_lsearch(const FCtx& C, FState& S) {
 	const AlnParams& P = *C.P;
 	uint32_t extlen = 0, top = S.a4, bot = S.a5, nr[2] = {0, 0};
 	bool uniqueStop = S.a3 != 0;
-	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[S.a0];
+	LIdxR lx; lx.init(C.ls, &C.ls->desc[S.a0]);
 	const uint32_t nelt = gfm_search(lx, fg_sv(C, S), S.a1, &extlen, &top, &bot, &uniqueStop, P.minK_local, S.a2, P.kseeds, true, nr);
 	S.nrank += nr[0]; S.nside += nr[1];
 	S.a0 = nelt; S.a1 = extlen; S.a2 = top; S.a3 = bot; S.a4 = uniqueStop ? 1u : 0u;
@@ -2279,8 +2279,7 @@ H2G_HD bool fast_op_lcoords_walk(const FCtx& C, FState& S, const FWords& W, cons
 				if(off != 0xffffu) { joff = off + jumps; found = true; break; }
 			}
 			if(budget == 0) break;
-			const int c = lx.rowL(row);
-			row = lx.rank(row, c);
+			row = lx.lf(row);
 			jumps++; budget--; steps++;
 			if(jumps > 500) { S.pc = FPC_BAIL; S.bail = FB_OTHER; return false; }
 		}
@@ -2367,8 +2366,10 @@ H2G_HD void fast_op_gsearch(const FCtx& C, FState& S) {       // globalGFMSearch
 	S.a6 = r.node_top; S.a7 = r.node_bot; S.a8 = fg_ie_pack(ie);
 }
 #else
+// (LIdxR needs the descriptor pointer for local_joff_to_coord and the offs array: fast_op_lcoords_walk reads lx.d)
+struct LIdxRD : LIdxR { const DLocalDesc* d; };
 H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
-	LIdx lx; lx.ls = C.ls; lx.d = &C.ls->desc[S.a0];
+	LIdxRD lx; lx.d = &C.ls->desc[S.a0]; lx.init(C.ls, lx.d);
 	return fast_op_lcoords_walk(C, S, W, lx);
 }
 H2G_HD void fast_op_combine(const FCtx& C, FState& S, const FWords& W) {

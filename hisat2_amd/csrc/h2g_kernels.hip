@@ -1126,6 +1126,17 @@ __global__ __launch_bounds__(256) void k_extend_alts(DRef ref, DAlts alts, DRead
 	}
 }
 
+// GenomeHit::combineWith (hi_aligner.h:1420-2025) per lane: a[i] <- a[i] + b[i] (hit_combine of h2g_align.h, the function OP_COMBINE / FOP_COMBINE run inside go())
+__global__ __launch_bounds__(256) void k_combine(DRef ref, DAlts alts, DReads rd, AlnParams P, h2g_ghit* a, const h2g_ghit* b, const int64_t* minsc, size_t n, uint32_t* ok, int64_t* scratch)
+{
+	const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	int64_t* const t1 = scratch + tid * (size_t)(2 * H2G_COMBINE_MAXLEN);
+	for(size_t i = tid; i < n; i += stride) {
+		const SeqView sv = seq_view(rd, a[i].read, a[i].fw != 0);
+		ok[i] = hit_combine(ref, P.sc, sv, &a[i], &b[i], minsc[i], P.minIntronLen, P.no_spliced != 0, ScVec{t1, 1}, ScVec{t1 + H2G_COMBINE_MAXLEN, 1}, &alts) ? 1u : 0u;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_adjust_alt(DGfm g, DRef ref, DAlts alts, DReads rd, const h2g_adjust_query* q, size_t n, uint32_t cap,
                                                     h2g_ghit* hits, uint32_t* nhits, AwaWS* scratch)
 {
@@ -1786,6 +1797,41 @@ extern "C" h2g_status h2g_set_mates(h2g_stream* s, const uint8_t* codes2, const 
 }
 
 // go() on a graph index: the index must be a SNP graph (ALT database present)
+// GenomeHit::combineWith as a primitive of its own: a[i] becomes the combination of a[i] (the left hit) and b[i] on the resident reads, ok[i] the
+// function's return value.  Scoring and splice policy: `p` (nullptr: the defaults of the index).
+extern "C" h2g_status h2g_combine_with(h2g_stream* s, const h2g_align_params* p, h2g_ghit* a, const h2g_ghit* b, const int64_t* minsc, size_t n, uint32_t* ok) {
+	if(!s || !a || !b || !minsc || !ok || n == 0) return H2G_ERR_ARG;
+	int rc;
+	if((rc = need_reads(s))) return rc;
+	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
+	const bool linear = s->ix->dg.linear != 0;
+	for(size_t i = 0; i < n; i++) {
+		if(a[i].read >= s->n_reads || b[i].read != a[i].read || a[i].tidx >= s->ix->dr.nrefs || b[i].tidx >= s->ix->dr.nrefs || a[i].nedits > H2G_MAX_EDITS || b[i].nedits > H2G_MAX_EDITS) return H2G_ERR_ARG;
+	}
+	if(s->max_read_len > H2G_COMBINE_MAXLEN) return H2G_ERR_ARG;      // (the joint's prefix / suffix score arrays)
+	h2g_align_params hp;
+	if(p) hp = *p; else align_params_defaults(&hp, linear);
+	AlnParams P = aln_params_from(hp, hp.no_spliced_alignment != 0, linear);
+	if(!hp.no_spliced_alignment) { P.sc.donor_sum = s->ix->d_spl[0]; P.sc.acc_sum1 = s->ix->d_spl[1]; P.sc.acc_sum2 = s->ix->d_spl[2]; }
+	HIPCHK(hipSetDevice(s->ix->device));
+	unsigned grid = grid_for(n, 256);
+	if(grid > 64) grid = 64;
+	void *da, *db, *dm, *dscr;
+	const size_t ab = n * sizeof(h2g_ghit);
+	if((rc = tmp_buf(s, 0, 2 * ab, &da)) || (rc = tmp_buf(s, 1, n * 8, &dm)) || (rc = tmp_buf(s, 2, n * 4, &db)) ||
+	   (rc = tmp_buf(s, 3, (size_t)grid * 256 * 2 * H2G_COMBINE_MAXLEN * sizeof(int64_t), &dscr))) return rc;
+	h2g_ghit* const d_a = (h2g_ghit*)da; h2g_ghit* const d_b = d_a + n;
+	HIPCHK(hipMemcpyAsync(d_a, a, ab, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(d_b, b, ab, hipMemcpyHostToDevice, s->st));
+	HIPCHK(hipMemcpyAsync(dm, minsc, n * 8, hipMemcpyHostToDevice, s->st));
+	hipLaunchKernelGGL(k_combine, dim3(grid), dim3(256), 0, s->st, s->ix->dr, s->ix->dalts, dreads(s), P, d_a, (const h2g_ghit*)d_b, (const int64_t*)dm, n, (uint32_t*)db, (int64_t*)dscr);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(a, d_a, ab, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(hipMemcpyAsync(ok, db, n * 4, hipMemcpyDeviceToHost, s->st));
+	HIPCHK(sync_all(s));
+	return H2G_OK;
+}
+
 static int need_alignable(h2g_stream* s) {
 	if(s->ix->synthetic) { snprintf(g_err, sizeof g_err, "synthetic index: rank only"); return H2G_ERR_ARG; }
 	const DGfm& g = s->ix->dg;

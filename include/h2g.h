@@ -341,6 +341,10 @@ H2G_EXPORT void       h2g_align_params_presets(h2g_align_params* p, const h2g_in
                                                int sensitive, int very_sensitive);
 /* read names (needed by genRandSeed): name i = bytes[offs[i] .. offs[i+1]) */
 H2G_EXPORT h2g_status h2g_set_read_names(h2g_stream*, const char* bytes, const uint32_t* offs, size_t n_reads);
+/* GenomeHit::combineWith (hi_aligner.h:1420-2025) as a primitive of its own: a[i] (the left hit) absorbs b[i] — concatenation, the mismatch rescan of the joint,
+ * an insertion or deletion, or (spliced alignment) an intron placed by the donor / acceptor scan — over the resident reads; ok[i] = the function's return value.  `p` carries
+ * scoring and splice policy (NULL: h2g_align_params_init's defaults for this index).  Inside go() the same device function runs as OP_COMBINE. */
+H2G_EXPORT h2g_status h2g_combine_with(h2g_stream*, const h2g_align_params* p, h2g_ghit* a /* in/out */, const h2g_ghit* b, const int64_t* minsc, size_t n, uint32_t* ok);
 H2G_EXPORT h2g_status h2g_align_run(h2g_stream*, const h2g_align_params*);           /* async on the stream */
 H2G_EXPORT h2g_status h2g_align_fetch(h2g_stream*, h2g_read_result* res /* [n] */, h2g_alnres* aln /* [n*H2G_ALN_CAP] or NULL */,
                                       size_t first_read, size_t n_reads);

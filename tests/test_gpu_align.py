@@ -141,3 +141,58 @@ def test_align_requires_names_and_valid_splice_scoring(g1_index, golden_dir):
         st.align_run(p)                     # splice scoring outside its range: refused, not approximated
     st.close()
     ix.close()
+
+
+@pytest.mark.parametrize("spliced", [False, True])
+def test_combine_with_golden_on_the_device(g1_index, golden_dir, spliced):
+    """GenomeHit::combineWith (hi_aligner.h:1420-2025; SURVEY §8 a20) through the C ABI ON THE DEVICE (h2g_combine_with -> k_combine -> hit_combine): the 1 500 anchor pairs of
+    the reference's own class (tests/gen_golden.py combine; oracle/ref_probe.cpp `combine`) — return value, extent, score and every edit.  Round 5 held only the host
+    instantiation to these vectors (tests/test_emul_golden.py::test_combine_with_golden); hipcc and g++ have differed on these sources before."""
+    import ctypes as C
+    names, seqs = H.read_fasta_reads(os.path.join(golden_dir, "reads_combine.fa.gz"))
+    n = len(seqs)
+    codes = np.concatenate(seqs).astype(np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint32)
+    ix = api.Index(g1_index, device=0)
+    st = api.Stream(ix, max_reads=n, max_bases=codes.size)
+    st.set_reads(codes, offs)
+    a = (api.GHit * n)()
+    b = (api.GHit * n)()
+    minsc = np.zeros(n, dtype=np.int64)
+    lines = list(H.glines(golden_dir, "probe_combine_spliced.txt.gz" if spliced else "probe_combine.txt.gz"))
+    assert len(lines) == n
+    for i, nm in enumerate(names):
+        rid, fw, tidx, roA, lenA, toA, roB, lenB, toB = (int(x) for x in nm.split("|"))
+        assert rid == i
+        for h, (ro, ln, to) in ((a[i], (roA, lenA, toA)), (b[i], (roB, lenB, toB))):
+            h.read, h.fw, h.rdoff, h.len, h.trim5, h.trim3, h.tidx, h.toff, h.joinedOff, h.score, h.nedits, h.overflow = i, fw, ro, ln, 0, 0, tidx, to, 0, 0, 0, 0
+        minsc[i] = int(lines[i].split()[2])
+    p = st.align_params()
+    p.no_spliced_alignment = 0 if spliced else 1
+    ok = np.zeros(n, dtype=np.uint32)
+    L = api.lib()
+    L.h2g_combine_with.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    assert L.h2g_combine_with(st.h, C.byref(p), a, b, minsc.ctypes.data, n, ok.ctypes.data) == 0, L.h2g_last_error()
+    kinds, ncomb = set(), 0
+    for i, l in enumerate(lines):
+        t = l.split()
+        want_ok = int(t[4])
+        assert int(ok[i]) == want_ok, (i, l)
+        if not want_ok:
+            continue
+        ncomb += 1
+        h = a[i]
+        assert not h.overflow
+        assert (h.rdoff, h.len, h.toff, h.score, h.nedits) == (int(t[5]), int(t[6]), int(t[7]), int(t[8]), int(t[9])), (i, l, (h.rdoff, h.len, h.toff, h.score, h.nedits))
+        for k, tok in enumerate(t[10:]):
+            ed = h.edits[k]
+            f = tok.split(":")
+            if f[1] == "S":                                   # intron: splLen, splDir, knownSpl in chr | qchr << 8 | (pad & 15) << 16, (pad >> 4) & 7, pad >> 7
+                assert ed.type == 5 and ed.pos == int(f[0]), (i, l)
+                assert (ed.chr | (ed.qchr << 8) | ((ed.pad & 15) << 16), (ed.pad >> 4) & 7, ed.pad >> 7) == (int(f[2]), int(f[3]), int(f[4])), (i, l)
+            else:
+                chr_, qchr = f[1].split(">")
+                assert (ed.pos, chr(ed.chr), chr(ed.qchr), ed.type) == (int(f[0]), chr_, qchr, int(f[2])), (i, l, k)
+            kinds.add(ed.type)
+    assert ncomb > 700 and kinds >= ({1, 2, 3, 5} if spliced else {1, 2, 3})
+    st.close(); ix.close()
