@@ -46,6 +46,7 @@ class FmHit(C.Structure):
 
 
 H2G_IEDGE_CAP = 24
+H2G_ERR_ARG = -4          # include/h2g.h: bad argument / capacity exceeded
 
 
 class IEdges(C.Structure):           # h2g_iedges
@@ -708,12 +709,13 @@ class Stream:
         res = alloc("res", n * C.sizeof(PairResult))
         o1 = alloc("o1", (n + 1) * 8, np.uint64); o2 = alloc("o2", (n + 1) * 8, np.uint64)
         c1 = c2 = n * 64 + 4096
-        while True:
+        for attempt in range(2):           # at most one retry, and only on "buffer too small" (H2G_ERR_ARG with the needed size in boffs[n]: buffers may be uninitialised memory)
             r1 = alloc("r1", c1); r2 = alloc("r2", c2)
+            o1[n] = 0; o2[n] = 0
             rc = f(self.h, res.ctypes.data, r1.ctypes.data, r1.size, o1.ctypes.data, r2.ctypes.data, r2.size, o2.ctypes.data, first, n)
             if rc == 0:
                 return res, r1, o1, r2, o2
-            if int(o1[n]) <= r1.size and int(o2[n]) <= r2.size:
+            if attempt or rc != H2G_ERR_ARG or (int(o1[n]) <= r1.size and int(o2[n]) <= r2.size):
                 _chk(rc, "h2g_align_pairs_fetch_compact")
             c1, c2 = max(c1, int(o1[n]) + 8), max(c2, int(o2[n]) + 8)
 
@@ -724,12 +726,13 @@ class Stream:
         res = np.zeros(n, dtype=READ_RESULT_DTYPE)
         offs = np.zeros(n + 1, dtype=np.uint64)
         cap = n * 64 + 4096
-        while True:
+        for attempt in range(2):           # (as align_pairs_fetch_compact: one retry, on "buffer too small" only)
             rec = np.empty(cap, dtype=np.uint8)
+            offs[n] = 0
             rc = f(self.h, res.ctypes.data, rec.ctypes.data, cap, offs.ctypes.data, first, n)
             if rc == 0:
                 return res, rec, offs
-            if int(offs[n]) <= cap:
+            if attempt or rc != H2G_ERR_ARG or int(offs[n]) <= cap:
                 _chk(rc, "h2g_align_fetch_compact")
             cap = int(offs[n]) + 8
 

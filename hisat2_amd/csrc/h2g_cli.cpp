@@ -650,8 +650,11 @@ int main(int argc, char** argv) {
 			pin_rec1.need(n * 64 + 4096); pin_rec2.need(n * 64 + 4096);
 			h2g_pair_result* pres = (h2g_pair_result*)pin_res.p;
 			uint64_t *ao1 = (uint64_t*)pin_o1.p, *ao2 = (uint64_t*)pin_o2.p;
-			if(h2g_align_pairs_fetch_compact(st, pres, pin_rec1.p, pin_rec1.cap, ao1, pin_rec2.p, pin_rec2.cap, ao2, 0, n) != H2G_OK) {
-				pin_rec1.need(ao1[n] + 8); pin_rec2.need(ao2[n] + 8);                 // (boffs[n] = the bytes needed)
+			ao1[n] = 0; ao2[n] = 0;
+			if(const h2g_status frc = h2g_align_pairs_fetch_compact(st, pres, pin_rec1.p, pin_rec1.cap, ao1, pin_rec2.p, pin_rec2.cap, ao2, 0, n); frc != H2G_OK) {
+				// one retry, and only for "buffer too small": H2G_ERR_ARG with the bytes needed in boffs[n] (zeroed above: page-locked memory starts uninitialised)
+				if(frc != H2G_ERR_ARG || (ao1[n] <= pin_rec1.cap && ao2[n] <= pin_rec2.cap)) die("h2g_align_pairs_fetch_compact");
+				pin_rec1.need(ao1[n] + 8); pin_rec2.need(ao2[n] + 8);
 				if(h2g_align_pairs_fetch_compact(st, pres, pin_rec1.p, pin_rec1.cap, ao1, pin_rec2.p, pin_rec2.cap, ao2, 0, n) != H2G_OK) die("h2g_align_pairs_fetch_compact");
 			}
 			t_fetch += now() - tq0;
@@ -673,7 +676,9 @@ int main(int argc, char** argv) {
 			pin_res.need(n * sizeof(h2g_read_result)); pin_o1.need((n + 1) * 8); pin_rec1.need(n * 64 + 4096);
 			h2g_read_result* res = (h2g_read_result*)pin_res.p;
 			uint64_t* ao1 = (uint64_t*)pin_o1.p;
-			if(h2g_align_fetch_compact(st, res, pin_rec1.p, pin_rec1.cap, ao1, 0, n) != H2G_OK) {
+			ao1[n] = 0;
+			if(const h2g_status frc = h2g_align_fetch_compact(st, res, pin_rec1.p, pin_rec1.cap, ao1, 0, n); frc != H2G_OK) {
+				if(frc != H2G_ERR_ARG || ao1[n] <= pin_rec1.cap) die("h2g_align_fetch_compact");
 				pin_rec1.need(ao1[n] + 8);
 				if(h2g_align_fetch_compact(st, res, pin_rec1.p, pin_rec1.cap, ao1, 0, n) != H2G_OK) die("h2g_align_fetch_compact");
 			}

@@ -157,6 +157,7 @@ struct h2g_stream {
 	h2g_alnres* d_paln[2] = {nullptr, nullptr};
 	// records with more than H2G_MAX_EDITS edits keep their lists here (MachOut::ledits): one part of ledits_cap edits and one cursor per machine stream
 	h2g_edit* d_ledits = nullptr; uint32_t* d_ledits_cur = nullptr; size_t ledits_cap = 0; unsigned ledits_parts = 0;
+	unsigned ledits_touched = 0;   // parts a run has written to since the last h2g_set_reads (bit per machine stream): the span h2g_align_fetch_long_edits reports
 	h2g_alnres* d_paln_ovf = nullptr; size_t paln_ovf_cap = 0; unsigned paln_ovf_parts = 0;   // pairs with more records than pair_slots per mate (MachOut::ovf): one part of paln_ovf_cap records per machine stream
 	unsigned long long* d_counters = nullptr;   // [8]
 	void* d_tmp[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -600,6 +601,7 @@ extern "C" h2g_status h2g_set_reads(h2g_stream* s, const uint8_t* codes, const u
 	s->n_reads = n;
 	s->has_names = false;
 	s->has_mates = false;
+	s->ledits_touched = 0;            // (long-edit lists of the batch this one replaces are nobody's any more)
 	return H2G_OK;
 }
 
@@ -2207,6 +2209,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		}
 		A.O.ledits = s->d_ledits; A.O.ledits_cursor = s->d_ledits_cur + psel; A.O.ledits_cap = (uint32_t)((psel + 1) * s->ledits_cap);
 		HIPCHK(hipMemsetD32Async((hipDeviceptr_t)A.O.ledits_cursor, (int)(psel * s->ledits_cap), 1, ms));
+		s->ledits_touched |= 1u << psel;
 	}
 	if(second) { A.O.defer_list = ovl; A.O.defer_count = ovl + s->max_reads; }     // overflowed reads: listed for the second pass, their rows untouched
 	HIPCHK(hipEventRecord(s->ev[7], ms));
@@ -2531,6 +2534,8 @@ extern "C" h2g_status h2g_align_fetch_long_edits(h2g_stream* s, h2g_edit* out, s
 	uint32_t cur[H2G_MSTREAMS_MAX];
 	HIPCHK(hipMemcpy(cur, s->d_ledits_cur, sizeof cur, hipMemcpyDeviceToHost));
 	size_t hi = 0;
+	// (only the parts the runs since the last upload wrote to: a part left over from an earlier batch keeps its cursor until its machine stream is used again — ADVICE r5)
+	for(unsigned m = 0; m < s->ledits_parts; m++) if(!((s->ledits_touched >> m) & 1u)) cur[m] = (uint32_t)(m * s->ledits_cap);
 	for(unsigned m = 0; m < s->ledits_parts; m++) {
 		size_t end = cur[m]; const size_t lo = m * s->ledits_cap, top = (m + 1) * s->ledits_cap;
 		if(end > top) end = top;                       // (a full part: the reads that found no room are flagged)

@@ -724,6 +724,29 @@ bool long_records_ok(const h2g_sam* S, const h2g_alnres* a, size_t n) {
 	for(size_t i = 0; i < n; i++) if(a[i].nedits > H2G_MAX_EDITS && (!S->long_edits || (size_t)a[i].edits[0].pos + a[i].nedits > S->n_long_edits)) return false;
 	return true;
 }
+inline bool long_record_ok(const h2g_sam* S, const h2g_alnres& r) {
+	return r.nedits <= H2G_MAX_EDITS || (S->long_edits && (size_t)r.edits[0].pos + r.nedits <= S->n_long_edits);
+}
+// the compact layout of n reads: every read's bytes [boffs[i], boffs[i + 1]) must be whole records (at least `need(i)` of them) and every long record must point inside
+// the area — checked before a line is written, so that the formatter itself never meets a malformed buffer (ED() handed out a one-entry list, a failed
+// table dropped the read's lines silently)
+template <typename NEED>
+bool compact_ok(const h2g_sam* S, const uint8_t* rec, const uint64_t* boffs, size_t n, NEED&& need) {
+	for(size_t i = 0; i < n; i++) {
+		if(boffs[i + 1] < boffs[i]) return false;
+		const uint8_t* p = rec + boffs[i]; const uint8_t* const end = rec + boffs[i + 1];
+		size_t k = 0;
+		while(p < end) {
+			if(p + 40 > end) return false;
+			const h2g_alnres* r = reinterpret_cast<const h2g_alnres*>(p);
+			const size_t b = H2G_COMPACT_BYTES(r->nedits);
+			if(p + b > end || !long_record_ok(S, *r)) return false;
+			p += b; k++;
+		}
+		if(k < need(i)) return false;
+	}
+	return true;
+}
 }  // namespace
 extern "C" void h2g_sam_set_threads(h2g_sam* S, int threads) { if(S) S->threads = threads < 1 ? 1 : threads; }
 // AlnSink::printAlSumm aln_sink.h:1637-1815 (old-style summary, -k mode: no repeat threshold, discordant + mixed reporting on)
@@ -945,7 +968,11 @@ static h2g_status format_unpaired(const h2g_sam* S, const uint8_t* codes, const 
 extern "C" h2g_status h2g_sam_format_unpaired(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
                                               const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
                                               const h2g_alnres* aln, char* out, size_t cap, size_t* used)
-{ return format_unpaired(S, codes, offs, quals, nb, noffs, n, res, aln, nullptr, out, cap, used); }
+{
+	if(!S || !res || !aln) return H2G_ERR_ARG;
+	for(size_t i = 0; i < n; i++) for(uint32_t k = 0; k < res[i].nselect && k < H2G_ALN_CAP; k++) if(!long_record_ok(S, aln[i * H2G_ALN_CAP + k])) return H2G_ERR_ARG;
+	return format_unpaired(S, codes, offs, quals, nb, noffs, n, res, aln, nullptr, out, cap, used);
+}
 extern "C" h2g_status h2g_sam_format_unpaired_dense(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
                                                     const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
                                                     const h2g_alnres* aln, const uint64_t* aln_offs, char* out, size_t cap, size_t* used)
@@ -1085,14 +1112,16 @@ extern "C" h2g_status h2g_sam_format_paired_compact(const h2g_sam* S, const uint
                                                     const h2g_pair_result* res, const uint8_t* rec1, const uint64_t* boffs1,
                                                     const uint8_t* rec2, const uint64_t* boffs2, uint32_t khits, char* out, size_t cap, size_t* used)
 {
-	if(!boffs1 || !boffs2 || !S || !rec1 || !rec2) return H2G_ERR_ARG;
+	if(!boffs1 || !boffs2 || !S || !rec1 || !rec2 || !res) return H2G_ERR_ARG;
+	if(!compact_ok(S, rec1, boffs1, n, [](size_t) { return (size_t)0; }) || !compact_ok(S, rec2, boffs2, n, [](size_t) { return (size_t)0; })) return H2G_ERR_ARG;
 	return format_paired(S, codes1, offs1, quals1, nb1, noffs1, codes2, offs2, quals2, nb2, noffs2, n, res, nullptr, boffs1, nullptr, boffs2, khits, out, cap, used, rec1, rec2);
 }
 extern "C" h2g_status h2g_sam_format_unpaired_compact(const h2g_sam* S, const uint8_t* codes, const uint32_t* offs, const char* quals,
                                                       const char* nb, const uint32_t* noffs, size_t n, const h2g_read_result* res,
                                                       const uint8_t* rec, const uint64_t* boffs, char* out, size_t cap, size_t* used)
 {
-	if(!boffs || !S || !rec) return H2G_ERR_ARG;
+	if(!boffs || !S || !rec || !res) return H2G_ERR_ARG;
+	if(!compact_ok(S, rec, boffs, n, [&](size_t i) { return (size_t)(res[i].nselect < H2G_ALN_CAP ? res[i].nselect : H2G_ALN_CAP); })) return H2G_ERR_ARG;
 	return format_unpaired(S, codes, offs, quals, nb, noffs, n, res, nullptr, boffs, out, cap, used, rec);
 }
 extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
@@ -1100,7 +1129,12 @@ extern "C" h2g_status h2g_sam_format_paired(const h2g_sam* S, const uint8_t* cod
                                             const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,
                                             const h2g_pair_result* res, const h2g_alnres* aln1, const h2g_alnres* aln2,
                                             uint32_t khits, char* out, size_t cap, size_t* used)
-{ return format_paired(S, codes1, offs1, quals1, nb1, noffs1, codes2, offs2, quals2, nb2, noffs2, n, res, aln1, nullptr, aln2, nullptr, khits, out, cap, used); }
+{
+	if(!S || !res || !aln1 || !aln2) return H2G_ERR_ARG;
+	for(size_t i = 0; i < n; i++) for(int m = 0; m < 2; m++) for(uint32_t k = 0; k < res[i].nres[m] && k < H2G_PAIR_RES_CAP; k++)
+		if(!long_record_ok(S, (m ? aln2 : aln1)[i * H2G_PAIR_RES_CAP + k])) return H2G_ERR_ARG;
+	return format_paired(S, codes1, offs1, quals1, nb1, noffs1, codes2, offs2, quals2, nb2, noffs2, n, res, aln1, nullptr, aln2, nullptr, khits, out, cap, used);
+}
 extern "C" h2g_status h2g_sam_format_paired_dense(const h2g_sam* S, const uint8_t* codes1, const uint32_t* offs1, const char* quals1,
                                                   const char* nb1, const uint32_t* noffs1, const uint8_t* codes2, const uint32_t* offs2,
                                                   const char* quals2, const char* nb2, const uint32_t* noffs2, size_t n,

@@ -435,3 +435,34 @@ def test_remove_chrname():
     bad, tmp = F.run_case(7901, 1200, sub=0.01, show=3, extra=("--remove-chrname",), novel_out=True)
     assert bad == 0
     assert "@SQ\tSN:1\t" in SL.LAST_HEADER and open(os.path.join(tmp, "ref.ss")).read().startswith("1\t")
+
+
+def test_compact_layout_is_checked_before_a_line_is_written(g1_index):
+    """the compact and the fixed-row formatters must refuse a long record (nedits > 32) whose long-edit area is missing or too short, and a compact buffer
+    whose bytes are not whole records — H2G_ERR_ARG, never an out-of-bounds read or a silently missing read"""
+    import ctypes as C
+    from hisat2_amd import api
+    L = SL.load_sam_lib()
+    h = C.c_void_p()
+    assert L.h2g_sam_open(g1_index.encode(), C.byref(h)) == 0
+    codes = np.zeros(50, dtype=np.uint8); offs = np.array([0, 50], dtype=np.uint32)
+    nb, noffs = SL.flat_names(["r0"])
+    res = np.zeros(1, dtype=api.READ_RESULT_DTYPE)
+    res["nres"] = 1; res["nselect"] = 1; res["best"] = -6; res["secbest"] = -(2 ** 31)
+    rec = (api.AlnRes * 1)()
+    rec[0].fw, rec[0].tidx, rec[0].toff, rec[0].len, rec[0].nedits, rec[0].score = 1, 0, 100, 50, 0, -6
+    out = C.create_string_buffer(1 << 16); used = C.c_size_t(0)
+    fc = L.h2g_sam_format_unpaired_compact
+    fc.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    raw = bytes(rec)[:40]
+    buf = np.frombuffer(raw, dtype=np.uint8).copy()
+    boffs = np.array([0, 40], dtype=np.uint64)
+    args = lambda b, bo: (h, codes.ctypes.data, offs.ctypes.data, None, nb, noffs.ctypes.data, 1, res.ctypes.data, b.ctypes.data, bo.ctypes.data, out, 1 << 16, C.byref(used))
+    assert fc(*args(buf, boffs)) == 0 and used.value > 0                              # a well-formed record prints
+    assert fc(*args(buf, np.array([0, 32], dtype=np.uint64))) != 0                    # the read's bytes end inside its record
+    assert fc(*args(buf[:0].copy() if False else buf, np.array([0, 0], dtype=np.uint64))) != 0   # nselect = 1 but no record in the read's bytes
+    rec[0].nedits = 40; rec[0].edits[0].pos = 0                                         # a long record: one marker entry inline, the list in the long-edit area
+    buf2 = np.frombuffer(bytes(rec)[:56], dtype=np.uint8).copy()
+    assert fc(*args(buf2, np.array([0, 56], dtype=np.uint64))) != 0                   # ... which was never set
+    assert L.h2g_sam_format_unpaired(h, codes.ctypes.data, offs.ctypes.data, None, nb, noffs.ctypes.data, 1, res.ctypes.data, C.byref(rec), out, 1 << 16, C.byref(used)) != 0
+    L.h2g_sam_close(h)
