@@ -21,7 +21,7 @@ Workload at N=1 = BASELINE.json configs[2]: GRCh38-SIZE linear index (3.1 Gbp, 4
 size (e.g. 256e6 for a quick run); the size actually used is named in config.workload.  configs[1] (E. coli-size, single-end)
 runs as the extra leg "ecoli_se"; the extra legs are skipped when the run is past H2G_BENCH_DEADLINE seconds (default 1150), the two
 companion legs with an index build of their own (repeat_pe, graph256_pe) when they would end past H2G_BENCH_BIG_DEADLINE (1250): both are measured by
-`bench.py --only-legs` / tools/r05_mstreams.py in profiles/ whether or not a run reaches them.
+`bench.py --only-legs` / tools/queued_steps.py in profiles/ whether or not a run reaches them.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]        (N > 1: N ranks, one per GPU — under torch.distributed.run, or spawned by this
 program when it is started on its own; fewer than N visible devices is an error, never a silent N = 1)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One resident batch run K times against B distinct resident batches (h2g_stream_select_batch), same stream, same process, alternating: the steady-state step of queued runs.
-usage: r06_batches.py GENOME_BP [pairs=1000000] [B=10] [rounds=3]   -> one JSON line per measurement"""
+usage: batches_ab.py GENOME_BP [pairs=1000000] [B=10] [rounds=3]   -> one JSON line per measurement"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -55,7 +55,7 @@ except Exception as e:
     print("pmc record failed:", repr(e))
 PY
 # (5)
-timeout 500 python tools/r05_mstreams.py rnd 3.1e9 1000000 "8,128,0,0;2,96,-1,0;4,128,0,0;8,128,-1,0" > $OUT/mstreams_grch38.jsonl 2> $OUT/mstreams_grch38.err; cut -c1-330 $OUT/mstreams_grch38.jsonl; tail -2 $OUT/mstreams_grch38.err
+timeout 500 python tools/queued_steps.py rnd 3.1e9 1000000 "8,128,0,0;2,96,-1,0;4,128,0,0;8,128,-1,0" > $OUT/mstreams_grch38.jsonl 2> $OUT/mstreams_grch38.err; cut -c1-330 $OUT/mstreams_grch38.jsonl; tail -2 $OUT/mstreams_grch38.err
 echo "sweep after $(( $(date +%s) - T0 )) s" | tee -a $OUT/timeline.txt
 # (6)
 H2G_LIB=$PWD/hisat2_amd/csrc/obj_prof/libh2g_prof.so timeout 500 python tools/fast_perf.py pe 1000000 3.1e9 > $OUT/fast_prof_grch38.log 2>&1; tail -24 $OUT/fast_prof_grch38.log | cut -c1-300

@@ -8,7 +8,7 @@ T0=$(date +%s)
 timeout 1200 python -m pytest tests -m gpu -q > $OUT/gputests.log 2>&1; tail -4 $OUT/gputests.log | cut -c1-300
 echo "tests after $(( $(date +%s) - T0 )) s"
 for leg in rep graph; do
-  CMD="python tools/r05_mstreams.py $leg 256e6 1000000 8,128,0,0"
+  CMD="python tools/queued_steps.py $leg 256e6 1000000 8,128,0,0"
   if [ $leg = rep ]; then
     rm -rf /tmp/bp_trace
     timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/bp_trace -- $CMD > $OUT/${leg}_traced.jsonl 2> /tmp/bp_trace.err
@@ -37,7 +37,7 @@ for leg, kern in (("rep", "k_go_fast"), ("graph", "k_go_fast_graph")):
         f = mean(OUT + "/%s_pmc_FETCH_SIZE.txt" % leg, "FETCH_SIZE", kern); w = mean(OUT + "/%s_pmc_WRITE_SIZE.txt" % leg, "WRITE_SIZE", kern)
         rec = {"leg": leg, "pairs_per_launch": 1000000, "genome": 256000000, "kernel": kern, "kernel_sources_sha16": bench.kernel_sources_sha16(), "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                "traffic_bytes_per_launch": int((f + w) * 1024), "traffic_upper_bound_bytes": int((2 * f + w) * 1024),
-               "source": "profiles/r05_g_%s_pmc_FETCH_SIZE.txt + r05_g_%s_pmc_WRITE_SIZE.txt: rocprofv3 --pmc, separate passes of `python tools/r05_mstreams.py %s 256e6 1000000 8,128,0,0`, mean per launch" % (leg, leg, leg),
+               "source": "profiles/r05_g_%s_pmc_FETCH_SIZE.txt + r05_g_%s_pmc_WRITE_SIZE.txt: rocprofv3 --pmc, separate passes of `python tools/queued_steps.py %s 256e6 1000000 8,128,0,0`, mean per launch" % (leg, leg, leg),
                "calibration": "FETCH_SIZE counts fabric read requests x 64 B (exact for 64 B sides, half for 128 B graph sides: profiles/r04_rank_pmc.json); traffic = FETCH_SIZE + WRITE_SIZE is a lower bound"}
         json.dump(rec, open(OUT + "/%s_pmc_traffic.json" % leg, "w"), indent=1)
         print(json.dumps(rec)[:400])
@@ -46,6 +46,6 @@ for leg, kern in (("rep", "k_go_fast"), ("graph", "k_go_fast_graph")):
 PY
 for cfg in "16 0" "0 0" "16 1" "0 1"; do
   set -- $cfg
-  H2G_FAST_TAIL=$1 H2G_FAST_AM=$2 timeout 300 python tools/r05_mstreams.py rnd 256e6 1000000 "8,128,0,0" > $OUT/rnd256_tail$1_am$2.jsonl 2> $OUT/rnd256_tail$1_am$2.err; echo "tail=$1 am=$2: $(tail -1 $OUT/rnd256_tail$1_am$2.jsonl | cut -c1-330)"
+  H2G_FAST_TAIL=$1 H2G_FAST_AM=$2 timeout 300 python tools/queued_steps.py rnd 256e6 1000000 "8,128,0,0" > $OUT/rnd256_tail$1_am$2.jsonl 2> $OUT/rnd256_tail$1_am$2.err; echo "tail=$1 am=$2: $(tail -1 $OUT/rnd256_tail$1_am$2.jsonl | cut -c1-330)"
 done
 echo "done after $(( $(date +%s) - T0 )) s"

@@ -9,17 +9,17 @@ timeout 900 python -m pytest tests/test_gpu_fast_pass.py tests/test_gpu_fast_str
 echo "tests after $(( $(date +%s) - T0 )) s"
 for lib in r5base gwspriv new; do
   if [ $lib = new ]; then unset H2G_LIB; else export H2G_LIB=$PWD/hisat2_amd/variants/libh2g_$lib.so; fi
-  timeout 600 python tools/r05_mstreams.py graph 256e6 1000000 "8,128,0,0" > $OUT/graph_$lib.jsonl 2> $OUT/graph_$lib.err; echo "graph $lib: $(tail -1 $OUT/graph_$lib.jsonl | cut -c1-420)"
+  timeout 600 python tools/queued_steps.py graph 256e6 1000000 "8,128,0,0" > $OUT/graph_$lib.jsonl 2> $OUT/graph_$lib.err; echo "graph $lib: $(tail -1 $OUT/graph_$lib.jsonl | cut -c1-420)"
 done
 echo "graph after $(( $(date +%s) - T0 )) s"
 for lib in r5base new; do
   if [ $lib = new ]; then unset H2G_LIB; else export H2G_LIB=$PWD/hisat2_amd/variants/libh2g_$lib.so; fi
-  timeout 600 python tools/r05_mstreams.py rnd 256e6 1000000 "8,128,0,0" > $OUT/rnd_$lib.jsonl 2> $OUT/rnd_$lib.err; echo "rnd $lib: $(tail -1 $OUT/rnd_$lib.jsonl | cut -c1-420)"
+  timeout 600 python tools/queued_steps.py rnd 256e6 1000000 "8,128,0,0" > $OUT/rnd_$lib.jsonl 2> $OUT/rnd_$lib.err; echo "rnd $lib: $(tail -1 $OUT/rnd_$lib.jsonl | cut -c1-420)"
 done
 unset H2G_LIB
 echo "rnd after $(( $(date +%s) - T0 )) s"
 for leg in graph rnd; do
-  CMD="python tools/r05_mstreams.py $leg 256e6 1000000 8,128,0,0"
+  CMD="python tools/queued_steps.py $leg 256e6 1000000 8,128,0,0"
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/bp_pmc
     timeout 400 rocprofv3 --pmc $c -d /tmp/bp_pmc -- $CMD > $OUT/${leg}_pmc_run.jsonl 2> /tmp/bp_pmc.err

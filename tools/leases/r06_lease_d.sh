@@ -9,7 +9,7 @@ timeout 900 python -m pytest tests/test_gpu_batches.py tests/test_gpu_parity.py 
 echo "tests after $(( $(date +%s) - T0 )) s"
 for lib in new gnosink gos; do
   if [ $lib = new ]; then unset H2G_LIB; else export H2G_LIB=$PWD/hisat2_amd/csrc/obj/libh2g_$lib.so; fi
-  timeout 600 python tools/r05_mstreams.py graph 256e6 1000000 "8,128,0,0" > $OUT/graph_$lib.jsonl 2> $OUT/graph_$lib.err; echo "graph $lib: $(tail -1 $OUT/graph_$lib.jsonl | cut -c1-420)"
+  timeout 600 python tools/queued_steps.py graph 256e6 1000000 "8,128,0,0" > $OUT/graph_$lib.jsonl 2> $OUT/graph_$lib.err; echo "graph $lib: $(tail -1 $OUT/graph_$lib.jsonl | cut -c1-420)"
 done
 unset H2G_LIB
 echo "graph after $(( $(date +%s) - T0 )) s"

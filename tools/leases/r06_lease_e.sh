@@ -5,12 +5,12 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 export PYTHONPATH=$PWD:$PWD/tests:$PWD/tools
 OUT=gpurun_out/r06_e; mkdir -p $OUT
 T0=$(date +%s)
-timeout 900 python tools/r06_batches.py 256e6 1000000 10 3 > $OUT/batches_ab.jsonl 2> $OUT/batches_ab.err; cat $OUT/batches_ab.jsonl | cut -c1-300; tail -3 $OUT/batches_ab.err
+timeout 900 python tools/batches_ab.py 256e6 1000000 10 3 > $OUT/batches_ab.jsonl 2> $OUT/batches_ab.err; cat $OUT/batches_ab.jsonl | cut -c1-300; tail -3 $OUT/batches_ab.err
 echo "batches after $(( $(date +%s) - T0 )) s"
 timeout 900 python -m pytest tests/test_gpu_batches.py tests/test_gpu_parity.py -m gpu -x -q > $OUT/gputests_new.log 2>&1; tail -4 $OUT/gputests_new.log | cut -c1-300
 echo "tests after $(( $(date +%s) - T0 )) s"
 for leg in rnd rep; do for am in 0 1; do
-  H2G_FAST_AM=$am timeout 600 python tools/r05_mstreams.py $leg 256e6 1000000 "8,128,0,0" > $OUT/${leg}_am$am.jsonl 2> $OUT/${leg}_am$am.err; echo "$leg am=$am: $(tail -1 $OUT/${leg}_am$am.jsonl | cut -c1-420)"
+  H2G_FAST_AM=$am timeout 600 python tools/queued_steps.py $leg 256e6 1000000 "8,128,0,0" > $OUT/${leg}_am$am.jsonl 2> $OUT/${leg}_am$am.err; echo "$leg am=$am: $(tail -1 $OUT/${leg}_am$am.jsonl | cut -c1-420)"
 done; done
 echo "am after $(( $(date +%s) - T0 )) s"
 python - <<'PY' > gpurun_out/r06_e/rank_variants.json 2> gpurun_out/r06_e/rank_variants.err

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wave-level time split of the general machine's pass over the reads the fast pass hands on (library built with -DH2G_GO_PROF, tools/build_prof_lib.sh,
 loaded through H2G_LIB): one run on its own on the repeat-structured / graph leg, then h2g_go_prof of that run's machine pass.
-usage: H2G_LIB=hisat2_amd/csrc/obj_prof/libh2g_prof.so r05_mach_prof.py rep|graph|rnd GENOME_BP [pairs]"""
+usage: H2G_LIB=hisat2_amd/csrc/obj_prof/libh2g_prof.so mach_prof.py rep|graph|rnd GENOME_BP [pairs]"""
 import ctypes as C, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random option sets against the live reference on the host instantiation of this round's device sources (the emulator, default configuration): single-end and paired cases on fresh
-genomes, linear and SNP-graph indexes.  usage: r05_option_campaign.py [cases per kind] [seed0]"""
+genomes, linear and SNP-graph indexes.  usage: option_campaign.py [cases per kind] [seed0]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,7 +3,7 @@
 of queued runs for several (mstreams, mach_total, fast_reserve, mach_div) settings of h2g_stream_tune, with a checksum of every result record per setting
 (it must not move) and the kernels' own times.  One JSON line per setting.
 
-usage: r05_mstreams.py rep|rnd|graph GENOME_BP [pairs=1000000] [settings "M,total,reserve,div;..."]"""
+usage: queued_steps.py rep|rnd|graph GENOME_BP [pairs=1000000] [settings "M,total,reserve,div;..."]"""
 import ctypes as C, json, os, subprocess, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
