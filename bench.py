@@ -938,15 +938,17 @@ def repeat_leg(a, api, synth, local, cache, glen=256_000_000, npairs=1_000_000, 
     alg_fast = leg.pop("_fast_alg_bytes")
     alg_all = (leg["sides_per_pair"] + leg["sa_steps_per_pair"]) * npairs * 64
     pm_rep = None
-    try:
-        pm_rep = json.load(open(os.path.join(ROOT, "profiles", "r05_rep_pmc_traffic.json")))
-    except (OSError, ValueError):
-        pass
+    for rec in ("r06_rep_pmc_traffic.json", "r05_rep_pmc_traffic.json"):
+        try:
+            pm_rep = json.load(open(os.path.join(ROOT, "profiles", rec)))
+            break
+        except (OSError, ValueError):
+            pass
     leg["roofline"] = {"bound": "hbm", "kernel": "k_go_fast (h2g_k_go_fast.hip) over the pairs it completes", "kernel_ms": leg["fast_kernel_ms"],
                        "achieved": alg_fast / (leg["fast_kernel_ms"] * 1e-3) / 1e9 if leg["fast_kernel_ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": alg_fast / (leg["fast_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if leg["fast_kernel_ms"] > 0 else 0.0,
                        "traffic": (int(pm_rep["traffic_bytes_per_launch"]) if pm_rep and pm_rep.get("kernel_sources_sha16") == kernel_sources_sha16() and pm_rep.get("pairs_per_launch") == npairs and int(pm_rep.get("genome", 256000000)) == glen else None),
-                       "traffic_record": "profiles/r05_rep_pmc_traffic.json (lease A: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this leg's fast kernel; attached only on the sources it was taken on)",
+                       "traffic_record": "profiles/r06_rep_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this leg's fast kernel; attached only on the sources it was taken on)",
                        "algorithmic": "64 B x (unique sides + SA-walk steps) of the fast kernel's own searches and walks",
                        "whole_step": {"algorithmic_bytes": alg_all, "GB/s": alg_all / (leg["ms_per_step"] * 1e-3) / 1e9, "frac": alg_all / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "note": "fast pass + the general machine's passes over the hand-ons (8 in flight) + second passes, steady state of queued runs"}}
