@@ -165,6 +165,8 @@ struct h2g_stream {
 	hipEvent_t ev[12];
 	bool ran_seed = false, ran_align = false;
 	h2g_counters last;
+	bool mstreams_warm = false;          // every machine stream has run its two kernels once (go_run, large batches)
+	unsigned long long* d_warm_cnt = nullptr;   // counter block of those empty launches
 	BatchCtx parked[H2G_MAX_BATCHES];   // the batches that are not selected ([cur_batch] is unused: its fields are the stream's own)
 	unsigned cur_batch = 0;
 };
@@ -508,7 +510,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipFree(s->d_ovf_list[k]);
 	for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->dbg_buf);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
-	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf); (void)hipFree(s->d_ledits); (void)hipFree(s->d_ledits_cur);
+	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf); (void)hipFree(s->d_ledits); (void)hipFree(s->d_ledits_cur); (void)hipFree(s->d_warm_cnt);
 	for(unsigned b = 0; b < H2G_MAX_BATCHES; b++) if(b != s->cur_batch) {
 		BatchCtx& B = s->parked[b];
 		(void)hipFree(B.d_codes); (void)hipFree(B.d_offs); (void)hipFree(B.d_quals); (void)hipFree(B.d_names); (void)hipFree(B.d_name_offs); (void)hipFree(B.d_codes2); (void)hipFree(B.d_offs2);
@@ -2218,6 +2220,34 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		s->ledits_touched |= 1u << psel;
 	}
 	if(second) { A.O.defer_list = ovl; A.O.defer_count = ovl + s->max_reads; }     // overflowed reads: listed for the second pass, their rows untouched
+	if(fast && s->n_reads >= 200000 && !s->mstreams_warm) {
+		// A machine stream's FIRST kernels cost it ~64 ms on top of their own time (lease I of round 6, `profiles/r06_i_batches_first.jsonl`: runs 1-7 of a stream 94 ms, every
+		// later one 30; the kernels' own events read 10 + 20 ms throughout — the queue's scratch memory and code objects are set up when a queue first needs them).  A streaming
+		// caller's first run therefore runs both machine kernels once on every OTHER machine stream, over an empty list: with the pools, lists and per-run buffers above this is
+		// everything a stream does for the first time (a bench that warms up for 5 steps then timed the first use of streams 5-7: 18.5 ms per step where the steady state is 12-13).
+		if(!s->d_warm_cnt) { HIPCHK(hipMalloc((void**)&s->d_warm_cnt, H2G_CNT_BLOCK * sizeof(unsigned long long))); HIPCHK(hipMemset(s->d_warm_cnt, 0, H2G_CNT_BLOCK * sizeof(unsigned long long))); }
+		const GoUnit& Bw = go_unit(linear, true, spl);
+		uint32_t wgeo[4];
+		Bw.geometry(wgeo);
+		for(unsigned m_ = 0; m_ < M; m_++) {
+			if(m_ == msel || !s->d_ovf_list[m_]) continue;
+			GoArgs W1 = A;
+			if((rc = go_pool_for(s, 2 * (int)m_, U, (size_t)geo[1], (size_t)block, p->bowtie2_dp, &W1))) return rc;      // (the stream's pools exist: nothing is allocated here)
+			W1.counters = s->d_warm_cnt; W1.work = reinterpret_cast<uint32_t*>(s->d_warm_cnt + 14);
+			W1.list = s->d_ovf_list[m_]; W1.nlist = s->d_ovf_list[m_] + s->max_reads;                                       // a count of zero (memset on this stream above)
+			W1.O.ovf_cursor = reinterpret_cast<uint32_t*>(s->d_warm_cnt + 124); W1.O.ledits_cursor = reinterpret_cast<uint32_t*>(s->d_warm_cnt + 126);
+			W1.defer_overflow = 0; W1.O.defer_list = nullptr; W1.O.defer_count = nullptr;
+			if(U.launch(&W1, 1, s->mst[m_]) != 0) return set_err("go() warm-up launch", hipGetLastError());
+			if(second) {
+				GoArgs W2 = W1;
+				if((rc = go_pool_for(s, 2 * (int)m_ + 1, Bw, (size_t)wgeo[1], (size_t)wgeo[0], p->bowtie2_dp, &W2))) return rc;
+				W2.work = reinterpret_cast<uint32_t*>(s->d_warm_cnt + 15);
+				if(Bw.launch(&W2, 1, s->mst[m_]) != 0) return set_err("go() warm-up launch", hipGetLastError());
+			}
+		}
+		s->st2_busy = true;
+		s->mstreams_warm = true;
+	}
 	HIPCHK(hipEventRecord(s->ev[7], ms));
 	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev[6], ms));
