@@ -2014,13 +2014,14 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		const size_t pgrid = fast && grid > pool_cap ? (size_t)pool_cap : (size_t)grid;
 		if(fast && s->n_reads >= 200000) {
 			// large batches (a streaming caller's): every machine stream's pools exist before the first pass that could need them — an allocation
-			// in the middle of a queue of runs (gigabytes, synchronous) would stall all of them; the first run of a stream pays for it once.
+			// in the middle of a queue of runs (gigabytes, synchronous) would stall all of them.  The stream's SECOND run pays for it, once (round 6: a caller with one
+			// batch — a command line over a million pairs — never needs streams 1 .. M - 1: their 30 GB of pools were a second of its three).
 			// (Small batches keep allocating a machine stream's pools when it is first used.)
 			const GoUnit& Bp = go_unit(linear, true, spl);
 			uint32_t bgeo_[4];
 			Bp.geometry(bgeo_);
 			GoArgs scratch = A;
-			for(unsigned m_ = 0; m_ < M; m_++) {
+			for(unsigned m_ = 0; m_ < M && s->gen >= 1; m_++) {
 				if((rc = go_pool_for(s, 2 * (int)m_, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &scratch))) return rc;
 				if(!big_main && !s->tune.no_second_pass && (rc = go_pool_for(s, 2 * (int)m_ + 1, Bp, (size_t)bgrid * bgeo_[1], (size_t)bgrid * bgeo_[0], p->bowtie2_dp, &scratch))) return rc;
 				// ... and its overflow list, and the stream itself (a HIP stream gets its hardware queue when it is first used)
@@ -2220,10 +2221,10 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		s->ledits_touched |= 1u << psel;
 	}
 	if(second) { A.O.defer_list = ovl; A.O.defer_count = ovl + s->max_reads; }     // overflowed reads: listed for the second pass, their rows untouched
-	if(fast && s->n_reads >= 200000 && !s->mstreams_warm) {
+	if(fast && s->n_reads >= 200000 && s->gen >= 1 && !s->mstreams_warm) {
 		// A machine stream's FIRST kernels cost it ~64 ms on top of their own time (lease I of round 6, `profiles/r06_i_batches_first.jsonl`: runs 1-7 of a stream 94 ms, every
 		// later one 30; the kernels' own events read 10 + 20 ms throughout — the queue's scratch memory and code objects are set up when a queue first needs them).  A streaming
-		// caller's first run therefore runs both machine kernels once on every OTHER machine stream, over an empty list: with the pools, lists and per-run buffers above this is
+		// caller's SECOND run therefore runs both machine kernels once on every other machine stream (the first run may be the only one), over an empty list: with the pools, lists and per-run buffers above this is
 		// everything a stream does for the first time (a bench that warms up for 5 steps then timed the first use of streams 5-7: 18.5 ms per step where the steady state is 12-13).
 		if(!s->d_warm_cnt) { HIPCHK(hipMalloc((void**)&s->d_warm_cnt, H2G_CNT_BLOCK * sizeof(unsigned long long))); HIPCHK(hipMemset(s->d_warm_cnt, 0, H2G_CNT_BLOCK * sizeof(unsigned long long))); }
 		const GoUnit& Bw = go_unit(linear, true, spl);
