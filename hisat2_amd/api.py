@@ -142,7 +142,8 @@ class Counters(C.Structure):
     _fields_ = [("n_rank", u64), ("n_side", u64), ("n_sa_steps", u64), ("n_ext", u64), ("n_ref_bytes", u64),
                 ("n_queries", u64), ("n_aligned", u64), ("n_overflow", u64), ("ms_search", C.c_float),
                 ("ms_resolve_extend", C.c_float), ("ms_rank", C.c_float), ("ms_align", C.c_float), ("ms_align_kernel", C.c_float),
-                ("n_second_pass", u64), ("n_fast", u64), ("n_fast_bail", u64), ("ms_fast_kernel", C.c_float), ("pad_", C.c_float), ("n_fast_side", u64), ("n_fast_sa_steps", u64)]
+                ("n_second_pass", u64), ("n_fast", u64), ("n_fast_bail", u64), ("ms_fast_kernel", C.c_float), ("pad_", C.c_float), ("n_fast_side", u64), ("n_fast_sa_steps", u64),
+                ("ms_drain_kernel", C.c_float), ("pad2_", C.c_float), ("n_drain_side", u64), ("n_drain_sa_steps", u64), ("n_adopted", u64)]
 
 
 ALN_CAP = 10

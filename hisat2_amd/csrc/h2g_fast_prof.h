@@ -10,11 +10,18 @@
 	for(int k_ = 0; k_ < 48; k_++) prof[k_] = 0; \
 	for(int k_ = 0; k_ < 32; k_++) { prof_ctl[k_] = 0; prof_n[k_] = 0; } \
 	uint32_t trip_site = 0; \
+	const unsigned long long prof_t0 = wall_clock64(); \
 	unsigned long long tp0 = __builtin_readcyclecounter(), tp1
 #define FPROF(SLOT) do { tp1 = __builtin_readcyclecounter(); prof[SLOT] += tp1 - tp0; tp0 = tp1; } while(0)
 #define FPROF_SITE(Q) do { trip_site = (Q); } while(0)
 #define FPROF_EXEC(OP, NACTIVE, NFRESH) do { prof[20 + (OP)] += (NACTIVE); prof[32 + (OP)]++; prof[44] += (NFRESH); } while(0)
 #define FPROF_TRIP(NACTIVE) do { prof[46] += (NACTIVE); prof[47]++; } while(0)
+// time-resolved: per bin of 2^FPROF_BIN_SHIFT ticks of the 100 MHz clock since the wave started: [512 + 4 bin] trips, [+1] lanes that ran, [+2] slots in flight in the workgroup (summed per trip)
+#ifndef FPROF_BIN_SHIFT
+#define FPROF_BIN_SHIFT (FG_GRAPH ? 18 : 15)
+#endif
+#define FPROF_TBIN(CNT, NACTIVE, NINFLIGHT) do { const unsigned long long na_ = (unsigned long long)(NACTIVE); if(lane == 0) { unsigned long long b_ = (wall_clock64() - prof_t0) >> FPROF_BIN_SHIFT; if(b_ > 63) b_ = 63; \
+	atomicAdd((CNT) + 512 + 4 * b_, 1ull); atomicAdd((CNT) + 513 + 4 * b_, na_); atomicAdd((CNT) + 514 + 4 * b_, (unsigned long long)(NINFLIGHT)); } } while(0)
 #define FPROF_CTL() do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_ctl[trip_site & 31] += t_ - tp0; prof_n[trip_site & 31]++; } while(0)
 #define FPROF_FLUSH(CNT) do { \
 	if(lane == 0) for(int k_ = 0; k_ < 48; k_++) if(prof[k_]) atomicAdd((CNT) + 128 + k_, prof[k_]); \
@@ -26,5 +33,6 @@
 #define FPROF_EXEC(OP, NACTIVE, NFRESH) do {} while(0)
 #define FPROF_TRIP(NACTIVE) do {} while(0)
 #define FPROF_CTL() do {} while(0)
+#define FPROF_TBIN(CNT, NACTIVE, NINFLIGHT) do {} while(0)
 #define FPROF_FLUSH(CNT) do {} while(0)
 #endif

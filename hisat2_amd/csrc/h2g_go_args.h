@@ -61,8 +61,16 @@ struct FastArgs {
 	uint8_t* sc_base;                         // combineWith temp_scores per lane: 2 x H2G_COMBINE_MAXLEN int64, lane-interleaved per wave
 	uint32_t tail;                            // > 0: a workgroup hands its last `tail` reads in flight on to the general machine once the batch is exhausted
 	uint32_t dbg_read; uint32_t* dbg_buf;     // development hook (-DFG_DBG_TRACE builds, h2g_stream_tune "dbg_read"): the trips of one read id, 10 words each behind a word count
+	// the end of a batch (h2g_k_go_fast.hip, fk_loop): a launch with orphan_T > 0 lists the slots (workgroup x slots per workgroup + slot) of the reads its workgroups still held
+	// when they could fetch no more and had thinned out to orphan_T reads; the drain launch (..._launch_drain) resumes the reads of `adopt_list` out of `adopt_slots`
+	uint32_t orphan_T; uint32_t* orphan_list; uint32_t* orphan_count;
+	const uint32_t* adopt_list; const uint32_t* adopt_count; const uint32_t* adopt_slots;
+	uint32_t cnt_off;                         // this launch's rank / side / step / aligned counters are counters[120 + cnt_off ..]
 };
 extern "C" int h2g_go_fast_launch(const FastArgs*, unsigned grid, hipStream_t);
+extern "C" int h2g_go_fast_launch_drain(const FastArgs*, unsigned grid, hipStream_t);
+extern "C" int h2g_go_fast_am_launch_drain(const FastArgs*, unsigned grid, hipStream_t);
+extern "C" int h2g_go_fast_graph_launch_drain(const FastArgs*, unsigned grid, hipStream_t);
 extern "C" void h2g_go_fast_geometry(uint32_t* g);   // [0] threads per workgroup [1] LDS bytes per workgroup [2] slots per workgroup [3] bytes per slot
 extern "C" int h2g_go_fast_am_launch(const FastArgs*, unsigned grid, hipStream_t);         // h2g_k_go_fast_am.hip: alignMate in the pass (FG_ALIGN_MATE = 1)
 extern "C" void h2g_go_fast_am_geometry(uint32_t* g);

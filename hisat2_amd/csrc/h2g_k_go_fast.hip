@@ -18,6 +18,10 @@ using namespace h2g;
 #define FG_LAUNCH   h2g_go_fast_launch
 #define FG_GEOMETRY h2g_go_fast_geometry
 #endif
+#define FG_CAT_(a, b) a##b
+#define FG_CAT(a, b) FG_CAT_(a, b)
+#define FG_KERNEL_DRAIN FG_CAT(FG_KERNEL, _drain)      // the same loop over the reads a launch of FG_KERNEL left in flight (FastArgs::adopt_list)
+#define FG_LAUNCH_DRAIN FG_CAT(FG_LAUNCH, _drain)
 
 #ifndef H2G_FAST_THREADS
 #define H2G_FAST_THREADS 512
@@ -42,6 +46,7 @@ static_assert(FS_WORDS % 4 == 0, "16-byte loads of the state");
 
 struct FastLds {
 	uint32_t head[FG_NQ], tail[FG_NQ];
+	uint32_t quit;                      // the workgroup hands its reads in flight on (FastArgs::orphan_T)
 	uint16_t ring[FG_NQ][H2G_FAST_SLOTS];
 };
 
@@ -152,15 +157,52 @@ __device__ __forceinline__ void fk_trip(const FastArgs* A, uint32_t* stage, uint
 	if(S.pc != FPC_DONE && S.pc != FPC_BAIL && S.op == FOP_NONE) fast_step(C, S, W);
 }
 
+// a read that leaves its lane: state + hot words to its slot (the packed reads and the cold words are there already)
+__device__ __forceinline__ void fk_store_read(const FState& S, uint32_t* sm, const uint32_t* stage) {
+	fk_store_state(S, sm);
+	uint4* hdst = reinterpret_cast<uint4*>(sm + FS_WORDS);
+#pragma unroll
+	for(uint32_t k = 0; k < FW_HOT / 4; k++)
+		hdst[k] = make_uint4(stage[(4 * k) * H2G_FAST_THREADS], stage[(4 * k + 1) * H2G_FAST_THREADS], stage[(4 * k + 2) * H2G_FAST_THREADS], stage[(4 * k + 3) * H2G_FAST_THREADS]);
+#pragma unroll
+	for(uint32_t k = FW_HOT & ~3u; k < FW_HOT; k++) sm[FS_WORDS + k] = stage[k * H2G_FAST_THREADS];
+}
+// ... and a read that enters one: state into registers, hot words + packed reads into this lane's LDS staging area (16-byte loads, nothing depends on anything)
+__device__ __forceinline__ void fk_load_read(FState& S, const uint32_t* sm, uint32_t* stage) {
+	fk_load_state(S, sm);
+	const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
+#pragma unroll
+	for(uint32_t k = 0; k < FG_STAGE_WORDS / 4; k++) {
+		const uint4 v = hsrc[k];
+		stage[(4 * k) * H2G_FAST_THREADS] = v.x; stage[(4 * k + 1) * H2G_FAST_THREADS] = v.y; stage[(4 * k + 2) * H2G_FAST_THREADS] = v.z; stage[(4 * k + 3) * H2G_FAST_THREADS] = v.w;
+	}
+#pragma unroll
+	for(uint32_t k = FG_STAGE_WORDS & ~3u; k < FG_STAGE_WORDS; k++) stage[k * H2G_FAST_THREADS] = sm[FS_WORDS + k];
+}
+// appends the slots of the lanes with `valid` set to the launch's orphan list (one reservation per wave)
+__device__ __forceinline__ void fk_orphan(const FastArgs* A, bool valid, uint32_t slot, int lane) {
+	const unsigned long long m = __ballot(valid);
+	if(m == 0) return;
+	uint32_t base = 0;
+	if(lane == 0) base = atomicAdd(A->orphan_count, (uint32_t)__popcll(m));
+	base = (uint32_t)__shfl((int)base, 0);
+	if(valid) A->orphan_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = blockIdx.x * H2G_FAST_SLOTS + slot;
+}
+
 #define FG_Q_NONE 0xffffffffu
 // The loop of one wave (round 6: reads stay in their lane).  A lane that has run a read's control flow up to its next request KEEPS the read — state in
 // registers, hot words in its LDS staging area — and the wave looks at what its own lanes ask for next to the queues: it runs the site that fills most of
 // its lanes (own lanes first: they cost no load).  Only the lanes that do not take part in that trip store their read (state + hot words; the packed reads
 // never change) and push its slot; free lanes pop from the site's queue.  Through round 5 every trip stored and re-loaded every read: half of the kernel's
 // fabric requests.  Which reads run together changes; what a read computes does not (every read is a function of itself).
-__global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __restrict__ A)
+//
+// The end of a batch (round 6, lease L: `profiles/r06_l_*`): once the batch is exhausted a workgroup's population decays with the reads' own latency chains — a third of the
+// kernel's time went by with 256 workgroups holding a few dozen reads each.  With FastArgs::orphan_T set, a workgroup that can fetch no more and holds at most that many reads
+// stores them and lists their slots (`orphan_list`), and leaves; FG_KERNEL_DRAIN — this loop with ADOPT — takes the listed reads up on a few workgroups next to the following
+// batch's launch: slots copied into its own pool, resumed at the request they were waiting at.  A read is a function of itself: which launch finishes it changes nothing it writes.
+template <bool ADOPT>
+__device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t* s_mem)
 {
-	extern __shared__ uint32_t s_mem[];
 	FastLds* Q = reinterpret_cast<FastLds*>(s_mem);
 	uint32_t* const stage = s_mem + (sizeof(FastLds) + 3) / 4 + threadIdx.x;      // word w of this lane at stage[w * H2G_FAST_THREADS]
 	const int lane = (int)(threadIdx.x & 63);
@@ -168,6 +210,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 	const bool paired = A->paired != 0;
 	for(uint32_t k = threadIdx.x; k < (uint32_t)FG_NQ * H2G_FAST_SLOTS; k += blockDim.x) (&Q->ring[0][0])[k] = FG_RING_EMPTY;
 	if(threadIdx.x < (uint32_t)FG_NQ) { Q->head[threadIdx.x] = 0; Q->tail[threadIdx.x] = 0; }
+	if(threadIdx.x == 0) Q->quit = 0;
 	__syncthreads();
 	for(uint32_t k = threadIdx.x; k < H2G_FAST_SLOTS; k += blockDim.x) Q->ring[0][k] = (uint16_t)k;   // every slot starts free
 	if(threadIdx.x == 0) Q->tail[0] = H2G_FAST_SLOTS;
@@ -176,8 +219,10 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 	uint32_t* const pk1 = pk0 + H2G_PK_WORDS * H2G_FAST_THREADS;
 	uint32_t* const slots0 = A->slots + (size_t)blockIdx.x * H2G_FAST_SLOTS * FG_SLOT_WORDS;
 	unsigned long long nrank = 0, nside = 0, nsteps = 0, naln = 0, ndone = 0, nbail = 0;
-	bool more = true;
-	const uint32_t total = A->total, tail_n = A->tail;
+	const uint32_t total = ADOPT ? *A->adopt_count : A->total, tail_n = A->tail;
+	const uint32_t orphan_T = ADOPT ? 0u : A->orphan_T;
+	unsigned long long* const cnt = A->counters + A->cnt_off;
+	bool more = total != 0;
 	FPROF_DECL;
 	// what this lane holds between two trips
 	FState S;
@@ -203,18 +248,24 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 		// new reads: when that trip would fill more lanes than any site's, or a quarter of the slots lie free
 		const bool fetch = more && avail > 0 && ((avail > 64u ? 64u : avail) > bestact || nfree >= H2G_FAST_SLOTS / 4);
 		const uint32_t qstar = fetch ? (uint32_t)FQ_FREE : (bestact ? bestq : FG_Q_NONE);
+		// ---- the batch is exhausted and the workgroup has thinned out: every read in flight goes to the drain launch (this wave's here, the queued ones behind the loop)
+		if(!ADOPT && orphan_T) {
+			uint32_t quit = 0;
+			if(lane == 0) {
+				quit = __atomic_load_n(&Q->quit, __ATOMIC_RELAXED);
+				if(!quit && !more && H2G_FAST_SLOTS - nfree <= orphan_T) { __atomic_store_n(&Q->quit, 1u, __ATOMIC_RELAXED); quit = 1; }
+			}
+			if(__shfl((int)quit, 0)) {
+				const bool out = keep && myq != FQ_FREE;
+				if(out) fk_store_read(S, sm, stage);
+				fk_orphan(A, out, slot, lane);
+				break;
+			}
+		}
 		// ---- the lanes that do not take part hand their slots on
 		{
 			const bool out = keep && myq != qstar;
-			if(out && myq != FQ_FREE) {
-				fk_store_state(S, sm);
-				uint4* hdst = reinterpret_cast<uint4*>(sm + FS_WORDS);
-#pragma unroll
-				for(uint32_t k = 0; k < FW_HOT / 4; k++)
-					hdst[k] = make_uint4(stage[(4 * k) * H2G_FAST_THREADS], stage[(4 * k + 1) * H2G_FAST_THREADS], stage[(4 * k + 2) * H2G_FAST_THREADS], stage[(4 * k + 3) * H2G_FAST_THREADS]);
-#pragma unroll
-				for(uint32_t k = FW_HOT & ~3u; k < FW_HOT; k++) sm[FS_WORDS + k] = stage[k * H2G_FAST_THREADS];
-			}
+			if(out && myq != FQ_FREE) fk_store_read(S, sm, stage);
 			FPROF(2);
 			if(__ballot(out)) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -244,7 +295,18 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 			const uint32_t r = (uint32_t)__popcll(hm & lt);
 			active = has && base + r < total;
 			if(has && !active) { keep = true; myq = FQ_FREE; }        // a slot without a read goes back with the next trip's hand-ons
-			if(active) {
+			if(ADOPT && active) {
+				// a read another launch left in flight: its slot into this workgroup's pool, the read into this lane — it waits for the request it was stored at
+				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
+				const uint32_t* const src = A->adopt_slots + (size_t)A->adopt_list[base + r] * FG_SLOT_WORDS;
+				const uint4* s4 = reinterpret_cast<const uint4*>(src); uint4* d4 = reinterpret_cast<uint4*>(sm);
+#pragma unroll 8
+				for(uint32_t k = 0; k < FG_SLOT_WORDS / 4; k++) d4[k] = s4[k];
+				fk_load_read(S, src, stage);
+				keep = true; myq = fg_queue_of(S.pc);
+				active = false;
+			}
+			if(!ADOPT && active) {
 				keep = false;
 				begin = base + r;
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
@@ -268,18 +330,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 			if(fresh) {
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
 				if(tail) S.read = sm[8];                              // (state word 8 = the read id)
-				else {
-					fk_load_state(S, sm);
-					// hot words + packed reads into this lane's LDS staging area: 16-byte loads, nothing depends on anything
-					const uint4* hsrc = reinterpret_cast<const uint4*>(sm + FS_WORDS);
-#pragma unroll
-					for(uint32_t k = 0; k < FG_STAGE_WORDS / 4; k++) {
-						const uint4 v = hsrc[k];
-						stage[(4 * k) * H2G_FAST_THREADS] = v.x; stage[(4 * k + 1) * H2G_FAST_THREADS] = v.y; stage[(4 * k + 2) * H2G_FAST_THREADS] = v.z; stage[(4 * k + 3) * H2G_FAST_THREADS] = v.w;
-					}
-#pragma unroll
-					for(uint32_t k = FG_STAGE_WORDS & ~3u; k < FG_STAGE_WORDS; k++) stage[k * H2G_FAST_THREADS] = sm[FS_WORDS + k];
-				}
+				else fk_load_read(S, sm, stage);
 			}
 			FPROF_EXEC(trip_op, __popcll(__ballot(active)), __popcll(__ballot(fresh)));
 			FPROF_SITE(qstar);
@@ -287,6 +338,7 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 		}
 		// ---- control flow of each read up to its next primitive request
 		FPROF_TRIP(__popcll(__ballot(active)));
+		FPROF_TBIN(A->counters, __popcll(__ballot(active)), H2G_FAST_SLOTS - nfree);
 		if(active && tail) { S.pc = FPC_BAIL; S.bail = FB_TAIL; }
 		else if(active) fk_trip(A, stage, sm, S, trip_op, begin, packed_ok);
 		FPROF_CTL();
@@ -316,13 +368,36 @@ __global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __
 		}
 		FPROF(16);
 	}
+	if(!ADOPT && orphan_T) {
+		// the reads that wait in the queues: listed once every wave has left the loop (a workgroup that ran dry has empty queues)
+		__syncthreads();
+		if(Q->quit) {
+			for(uint32_t q = 1 + (threadIdx.x >> 6); q < (uint32_t)FG_NQ; q += H2G_FAST_THREADS / 64) {
+				const uint32_t h = Q->head[q], n = Q->tail[q] - h;
+				for(uint32_t i0 = 0; i0 < n; i0 += 64) {
+					const bool v = i0 + (uint32_t)lane < n;
+					fk_orphan(A, v, v ? (uint32_t)Q->ring[q][(h + i0 + (uint32_t)lane) & (H2G_FAST_SLOTS - 1)] : 0u, lane);
+				}
+			}
+		}
+	}
 	FPROF_FLUSH(A->counters);
-	wave_add(A->counters + 120, nrank);     // (slots of its own: the general machine's passes count in 0..5 / 64..69)
-	wave_add(A->counters + 121, nside);
-	wave_add(A->counters + 122, nsteps);
-	wave_add(A->counters + 123, naln);
+	wave_add(cnt + 120, nrank);     // (slots of its own: the general machine's passes count in 0..5 / 64..69; the drain launch's cnt_off moves its four)
+	wave_add(cnt + 121, nside);
+	wave_add(cnt + 122, nsteps);
+	wave_add(cnt + 123, naln);
 	wave_add(A->counters + 6, ndone);
 	wave_add(A->counters + 7, nbail);
+}
+__global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL(const FastArgs* __restrict__ A)
+{
+	extern __shared__ uint32_t s_mem[];
+	fk_loop<false>(A, s_mem);
+}
+__global__ __launch_bounds__(H2G_FAST_THREADS) void FG_KERNEL_DRAIN(const FastArgs* __restrict__ A)
+{
+	extern __shared__ uint32_t s_mem[];
+	fk_loop<true>(A, s_mem);
 }
 
 #define FG_LDS_BYTES ((unsigned)(((sizeof(FastLds) + 3) / 4 + (size_t)FG_STAGE_WORDS * H2G_FAST_THREADS) * 4))
@@ -340,5 +415,13 @@ extern "C" int FG_LAUNCH(const FastArgs* a, unsigned grid, hipStream_t st) {
 	const unsigned long long bit = 1ull << (dev & 63);
 	if(!(lds_ok.load(std::memory_order_relaxed) & bit)) { if(hipFuncSetAttribute((const void*)FG_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok.fetch_or(bit, std::memory_order_relaxed); }
 	hipLaunchKernelGGL(FG_KERNEL, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, a);
+	return (int)hipGetLastError();
+}
+extern "C" int FG_LAUNCH_DRAIN(const FastArgs* a, unsigned grid, hipStream_t st) {
+	static std::atomic<unsigned long long> lds_ok{0};
+	int dev = 0; (void)hipGetDevice(&dev);
+	const unsigned long long bit = 1ull << (dev & 63);
+	if(!(lds_ok.load(std::memory_order_relaxed) & bit)) { if(hipFuncSetAttribute((const void*)FG_KERNEL_DRAIN, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); lds_ok.fetch_or(bit, std::memory_order_relaxed); }
+	hipLaunchKernelGGL(FG_KERNEL_DRAIN, dim3(grid), dim3(H2G_FAST_THREADS), FG_LDS_BYTES, st, a);
 	return (int)hipGetLastError();
 }

@@ -73,8 +73,20 @@ struct h2g_index {
 // the fast pass's two scheduling choices for PAIRED batches on a linear index (measured at GRCh38 size: profiles/r04_NOTES.md §4): reads a
 // workgroup hands on at the tail of an exhausted batch, and whether alignMate runs inside the pass (k_go_fast_am) or in the machine's pass
 #define H2G_DEFAULT_TAIL 16
+// The end of a batch (h2g_k_go_fast.hip, fk_loop): workgroups of a fast launch that can fetch no more and hold at most H2G_ORPHAN_T reads list them and leave; the drain launch
+// (H2G_DRAIN_GRID workgroups, on the run's machine stream in front of the machine's pass) finishes them next to the following run's fast launch.  Batches below
+// H2G_ORPHAN_MIN_UNITS keep the single launch (h2g_stream_tune "orphan": -1 this policy, 0 off, n the threshold; "drain_grid").
+#define H2G_ORPHAN_T 512
+#define H2G_ORPHAN_MIN_UNITS 200000
+#define H2G_DRAIN_GRID 32
+#define H2G_FAST_POOLS 3
 #define H2G_DEFAULT_ALIGN_MATE 0
-#define H2G_CNT_BLOCK 512u          // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
+#ifdef H2G_GO_PROF
+#define H2G_CNT_BLOCK 1024u         // (+ the time-resolved bins of h2g_fast_prof.h at [512, 768))
+#else
+#define H2G_CNT_BLOCK 512u
+#endif
+//                            // counter words per go_run generation: [0, 256) the main / fast pass (+ their profiling slots), [256, 512) the second pass
 #define H2G_MACH_MAXGRID 48u       // workgroups of ONE machine pass behind a fast pass
 #define H2G_MACH_TOTAL 128u        // ... and of all machine passes in flight together ("mach_total": a pass gets at most mach_total / mstreams workgroups)
 // Resident batches (round 6): a stream holds up to H2G_MAX_BATCHES read sets WITH their result rows (h2g_stream_select_batch).  The named fields of h2g_stream are the
@@ -127,15 +139,28 @@ struct h2g_stream {
 	uint32_t* d_ovf_list[H2G_MSTREAMS_MAX] = {};   // per machine stream: read ids whose workspace overflowed in the main pass (+ their count behind the list)
 	unsigned ovf_cur = 0;             // the one the last run used
 	uint32_t* d_bail_list[H2G_NBUF] = {};  // read ids the fast pass handed on to the general machine (+ their count behind the list)
-	void* d_fast_args[H2G_NBUF] = {};
+	void* d_fast_args[2 * H2G_NBUF] = {};  // [gen % NBUF] the fast launch's, [NBUF + gen % NBUF] its drain launch's
 	void* h_fast_args = nullptr;      // pinned staging of the argument blocks (H2G_NBUF of them): the upload never makes the host wait for the stream      // the fast pass's argument block (device copy)
-	uint32_t* d_fast_slots = nullptr; size_t fast_slot_bytes = 0;   // the fast pass's reads in flight (h2g_k_go_fast.hip)
+	// the fast pass's reads in flight (h2g_k_go_fast.hip): pool gen % 3 — the drain launch of run k reads run k's pool while the fast passes of runs k + 1 and k + 2 run
+	uint32_t* d_fast_slots[H2G_FAST_POOLS] = {}; size_t fast_slot_bytes[H2G_FAST_POOLS] = {};
+	hipEvent_t ev_pool[H2G_FAST_POOLS];                              // the drain launch that last read pool p is over
+	uint32_t* d_orphans[H2G_NBUF] = {};                              // slots a fast launch left in flight (+ their count behind the list)
+	size_t orphan_cap = 0;
+	hipStream_t dst = nullptr;                                       // the drain launches' stream: one after the other, each next to the following run's fast launch
+	uint32_t* d_drain_slots = nullptr; size_t drain_slot_bytes = 0;  // the drain launch's own pool
+	uint8_t* d_drain_sc = nullptr; size_t drain_sc_bytes = 0;        // graph indexes: its combineWith scores per lane
+	hipEvent_t ev_drain[H2G_NBUF];                                   // run k's drain launch is over (its machine pass waits for it)
+	bool dst_busy = false;
+	hipEvent_t ev_bails[H2G_NBUF];                                   // h_bails[gen % NBUF] has arrived
+	hipEvent_t ev_dr[2];                                             // (timed) around the last drain launch
+	bool ran_drain = false;
+	const uint32_t* orph_cur = nullptr;                              // the orphan count of the last run
 	uint8_t* d_fast_gws = nullptr; size_t fast_gws_bytes = 0;       // graph indexes: GraphWS per lane of the fast kernel (scratch of one primitive)
 	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
 	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int mach_total_auto = 1; int fast_reserve = H2G_FAST_RESERVE_DEFAULT; long dbg_read = -1;
-	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; } tune;
+	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; int orphan = -1 /* auto */, drain_grid = H2G_DRAIN_GRID; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
@@ -475,9 +500,12 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 	s->ix = ix; s->max_reads = max_reads; s->max_bases = max_bases;
 	HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
 	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) HIPCHK(hipStreamCreateWithFlags(&s->mst[k], hipStreamNonBlocking));
-	HIPCHK(hipHostMalloc((void**)&s->h_fast_args, sizeof(FastArgs) * H2G_NBUF));
+	HIPCHK(hipStreamCreateWithFlags(&s->dst, hipStreamNonBlocking));
+	HIPCHK(hipHostMalloc((void**)&s->h_fast_args, sizeof(FastArgs) * 2 * H2G_NBUF));
 	HIPCHK(hipHostMalloc((void**)&s->h_bails, 4 * H2G_NBUF)); for(int k = 0; k < H2G_NBUF; k++) s->h_bails[k] = 0;
-	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); }
+	for(int k = 0; k < H2G_NBUF; k++) { HIPCHK(hipEventCreateWithFlags(&s->ev_fast[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_mach[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_bails[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&s->ev_drain[k], hipEventDisableTiming)); }
+	for(int k = 0; k < H2G_FAST_POOLS; k++) HIPCHK(hipEventCreateWithFlags(&s->ev_pool[k], hipEventDisableTiming));
+	for(int k = 0; k < 2; k++) HIPCHK(hipEventCreate(&s->ev_dr[k]));
 	for(int i = 0; i < 12; i++) HIPCHK(hipEventCreate(&s->ev[i]));
 	HIPCHK(hipMalloc((void**)&s->d_counters, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
 	HIPCHK(hipMemset(s->d_counters, 0, H2G_NBUF * H2G_CNT_BLOCK * sizeof(unsigned long long)));
@@ -495,6 +523,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 0); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
 		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
+		s->tune.orphan = (int)env("H2G_FAST_ORPHAN", -1); s->tune.drain_grid = (int)env("H2G_DRAIN_GRID", H2G_DRAIN_GRID);
 		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.mach_total_auto = getenv("H2G_MACH_TOTAL") ? 0 : 1; s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", H2G_FAST_RESERVE_DEFAULT);
 		{ const long m = env("H2G_MSTREAMS", H2G_MSTREAMS_DEFAULT); s->mstreams = (unsigned)(m < 1 ? 1 : m > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : m); }
 	}
@@ -504,11 +533,15 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 
 extern "C" void h2g_stream_free(h2g_stream* s) {
 	if(!s) return;
-	(void)hipStreamSynchronize(s->st); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamSynchronize(s->mst[k]);
+	(void)hipStreamSynchronize(s->st); (void)hipStreamSynchronize(s->dst); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamSynchronize(s->mst[k]);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2 * H2G_MSTREAMS_MAX; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
 	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipFree(s->d_ovf_list[k]);
-	for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); } (void)hipFree(s->d_fast_slots); (void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->dbg_buf);
+	for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipFree(s->d_fast_args[H2G_NBUF + k]); (void)hipFree(s->d_orphans[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); (void)hipEventDestroy(s->ev_bails[k]); (void)hipEventDestroy(s->ev_drain[k]); }
+	for(int k = 0; k < H2G_FAST_POOLS; k++) { (void)hipFree(s->d_fast_slots[k]); (void)hipEventDestroy(s->ev_pool[k]); }
+	(void)hipFree(s->d_drain_slots); (void)hipFree(s->d_drain_sc);
+	for(int k = 0; k < 2; k++) (void)hipEventDestroy(s->ev_dr[k]);
+	(void)hipFree(s->d_fast_gws); (void)hipFree(s->d_fast_sc); (void)hipFree(s->d_sw_ws); (void)hipFree(s->d_sw_states); (void)hipFree(s->dbg_buf);
 	(void)hipFree(s->d_rout); (void)hipFree(s->d_aln); (void)hipFree(s->d_codes2); (void)hipFree(s->d_offs2); (void)hipFree(s->d_quals2);
 	(void)hipFree(s->d_names2); (void)hipFree(s->d_name_offs2); (void)hipFree(s->d_pout); (void)hipFree(s->d_paln[0]); (void)hipFree(s->d_paln[1]); (void)hipFree(s->d_paln_ovf); (void)hipFree(s->d_ledits); (void)hipFree(s->d_ledits_cur); (void)hipFree(s->d_warm_cnt);
 	for(unsigned b = 0; b < H2G_MAX_BATCHES; b++) if(b != s->cur_batch) {
@@ -518,13 +551,14 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	}
 	for(int i = 0; i < 4; i++) (void)hipFree(s->d_tmp[i]);
 	for(int i = 0; i < 12; i++) (void)hipEventDestroy(s->ev[i]);
-	(void)hipStreamDestroy(s->st); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails); (void)hipHostFree(s->h_fast_args);
+	(void)hipStreamDestroy(s->st); (void)hipStreamDestroy(s->dst); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamDestroy(s->mst[k]); (void)hipHostFree(s->h_bails); (void)hipHostFree(s->h_fast_args);
 	delete s;
 }
 
 // both streams of a batch context (the second one only ever holds the machine pass behind a fast pass)
 static hipError_t sync_all(h2g_stream* s) {
 	hipError_t e = hipStreamSynchronize(s->st);
+	if(e == hipSuccess && s->dst_busy) { e = hipStreamSynchronize(s->dst); s->dst_busy = false; }
 	if(e == hipSuccess && s->st2_busy) {
 		for(int k = 0; k < H2G_MSTREAMS_MAX && e == hipSuccess; k++) e = hipStreamSynchronize(s->mst[k]);
 		s->st2_busy = false;
@@ -2030,6 +2064,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 			for(unsigned b_ = 0; b_ < M + 1; b_++) {      // the per-run buffers of every generation
 				if(!s->d_bail_list[b_]) HIPCHK(hipMalloc((void**)&s->d_bail_list[b_], (s->max_reads + 4) * 4));
 				if(!s->d_fast_args[b_]) HIPCHK(hipMalloc((void**)&s->d_fast_args[b_], sizeof(FastArgs)));
+				if(!s->d_fast_args[H2G_NBUF + b_]) HIPCHK(hipMalloc((void**)&s->d_fast_args[H2G_NBUF + b_], sizeof(FastArgs)));
 			}
 		}
 		if((rc = go_pool_for(s, fast ? 2 * (int)(s->gen % M) : 0, U, pgrid * geo[1], pgrid * block, p->bowtie2_dp, &A))) return rc;
@@ -2100,7 +2135,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	// it hands on (a device-side list, no host sync) are the general machine's batch.  Built for unspliced alignment on a linear
 	// index with the default pair policy; every other option set goes to the machine whole.
 	s->ran_fast = fast;
-	unsigned fast_mgrid = 0;
+	unsigned fast_mgrid = 0, fast_orphan = 0, fast_dgrid = 0, fast_pool = 0;
 	if(fast) {
 		uint32_t fgeo[5] = {0, 0, 0, 0, 0};
 		const bool use_am = linear && paired && s->tune.align_mate != 0;
@@ -2109,7 +2144,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		// (the machine takes ~150 hand-ons per workgroup in half the time of a fast pass; the count is the last finished fast pass's)
 		for(unsigned back = 1; back < NB && back <= s->gen; back++) {                           // the latest fast pass that is over
 			const unsigned b = (s->gen - back) % NB;
-			if(hipEventQuery(s->ev_fast[b]) == hipSuccess) { s->last_bails = s->h_bails[b]; break; }
+			if(hipEventQuery(s->ev_bails[b]) == hipSuccess) { s->last_bails = s->h_bails[b]; break; }
 		}
 		(void)hipGetLastError();
 		// hand-ons per machine workgroup (latency chains, two passes in flight).  Linear index: 400 — the fast pass is short and the machine's pass bounds the
@@ -2140,11 +2175,46 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		const unsigned fmax = 256 - reserve;
 		const unsigned fgrid = (unsigned)(fwant < 1 ? 1 : (fwant > fmax ? fmax : fwant));
 		const size_t slot_bytes = (size_t)256 * fgeo[2] * fgeo[3];
-		if(s->fast_slot_bytes < slot_bytes) {
-			(void)hipFree(s->d_fast_slots); s->d_fast_slots = nullptr; s->fast_slot_bytes = 0;
-			HIPCHK(hipMalloc((void**)&s->d_fast_slots, slot_bytes));
-			s->fast_slot_bytes = slot_bytes;
+		// the end of the batch goes to a drain launch (h2g_k_go_fast.hip) when the batch is large enough to have one
+		const size_t units_f = paired ? (size_t)s->n_reads : ((size_t)s->n_reads + 1) / 2;
+		uint32_t orphan_T = s->tune.orphan >= 0 ? (uint32_t)s->tune.orphan : (units_f >= H2G_ORPHAN_MIN_UNITS ? (uint32_t)H2G_ORPHAN_T : 0u);
+		if(orphan_T > fgeo[2]) orphan_T = fgeo[2];
+		if(!linear && fgeo[4] != 0) orphan_T = 0;                     // (a graph unit with GraphWS in global memory: its scratch is sized for one launch)
+		const unsigned dgrid = (unsigned)(s->tune.drain_grid < 1 ? 1 : s->tune.drain_grid);
+		const unsigned psel_f = orphan_T ? s->gen % H2G_FAST_POOLS : 0u;
+		{	// every buffer of the two launches exists (and has been written once: fresh device memory costs its first writer the mapping) before the first run that could need it
+			const size_t ocap = (size_t)256 * fgeo[2], dbytes = (size_t)dgrid * fgeo[2] * fgeo[3];
+			const size_t dsc = linear ? 0 : (size_t)dgrid * fgeo[0] * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t));
+			bool need = s->fast_slot_bytes[psel_f] < slot_bytes;
+			if(orphan_T) {
+				for(unsigned p_ = 0; p_ < H2G_FAST_POOLS; p_++) need = need || s->fast_slot_bytes[p_] < slot_bytes;
+				need = need || s->drain_slot_bytes < dbytes || s->drain_sc_bytes < dsc;
+				for(unsigned b_ = 0; b_ < NB; b_++) need = need || !s->d_orphans[b_] || !s->d_fast_args[H2G_NBUF + b_];
+				need = need || s->orphan_cap < ocap;
+			}
+			if(need) {
+				HIPCHK(hipStreamSynchronize(s->st)); HIPCHK(hipStreamSynchronize(s->dst)); for(int k_ = 0; k_ < H2G_MSTREAMS_MAX; k_++) HIPCHK(hipStreamSynchronize(s->mst[k_]));
+				auto grow = [&](void** ptr, size_t* have, size_t want_) -> int {
+					if(*have >= want_) return H2G_OK;
+					(void)hipFree(*ptr); *ptr = nullptr; *have = 0;
+					if(want_) { HIPCHK(hipMalloc(ptr, want_)); HIPCHK(hipMemsetAsync(*ptr, 0, want_, s->st)); }
+					*have = want_;
+					return H2G_OK;
+				};
+				for(unsigned p_ = 0; p_ < (orphan_T ? (unsigned)H2G_FAST_POOLS : 1u); p_++) if((rc = grow((void**)&s->d_fast_slots[orphan_T ? p_ : psel_f], &s->fast_slot_bytes[orphan_T ? p_ : psel_f], slot_bytes))) return rc;
+				if(orphan_T) {
+					if(s->orphan_cap < ocap) { for(int b_ = 0; b_ < H2G_NBUF; b_++) { (void)hipFree(s->d_orphans[b_]); s->d_orphans[b_] = nullptr; } s->orphan_cap = ocap; }
+					for(unsigned b_ = 0; b_ < NB; b_++) {
+						if(!s->d_orphans[b_]) { HIPCHK(hipMalloc((void**)&s->d_orphans[b_], (s->orphan_cap + 4) * 4)); HIPCHK(hipMemsetAsync(s->d_orphans[b_], 0, (s->orphan_cap + 4) * 4, s->st)); }
+						if(!s->d_fast_args[H2G_NBUF + b_]) HIPCHK(hipMalloc((void**)&s->d_fast_args[H2G_NBUF + b_], sizeof(FastArgs)));
+					}
+					if((rc = grow((void**)&s->d_drain_slots, &s->drain_slot_bytes, dbytes))) return rc;
+					if((rc = grow((void**)&s->d_drain_sc, &s->drain_sc_bytes, dsc))) return rc;
+				}
+				HIPCHK(hipStreamSynchronize(s->st));
+			}
 		}
+		if(orphan_T) HIPCHK(hipStreamWaitEvent(s->st, s->ev_pool[psel_f], 0));  // run k - 3's drain launch: done with this pool
 		if(!s->d_bail_list[gsel]) HIPCHK(hipMalloc((void**)&s->d_bail_list[gsel], (s->max_reads + 4) * 4));
 		uint32_t* const bl = s->d_bail_list[gsel];
 		HIPCHK(hipMemsetAsync(bl + s->max_reads, 0, 16, s->st));
@@ -2152,7 +2222,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		memset(&F, 0, sizeof F);
 		F.g = A.g; F.ref = A.ref; F.ls = A.ls; F.rd1 = A.rd1; F.rd2 = A.rd2; F.P = A.P;
 		F.names1 = A.names1; F.noffs1 = A.noffs1; F.names2 = A.names2; F.noffs2 = A.noffs2;
-		F.slots = s->d_fast_slots;
+		F.slots = s->d_fast_slots[psel_f];
 		F.O.rout = A.O.rout; F.O.aln = A.O.aln; F.O.aln_slots = A.O.aln_slots; F.O.pout = A.O.pout; F.O.paln[0] = A.O.paln[0]; F.O.paln[1] = A.O.paln[1]; F.O.pair_slots = A.O.pair_slots;
 		F.counters = cblk; F.work = reinterpret_cast<uint32_t*>(cblk + 12);
 		F.bail_list = bl; F.bail_count = bl + s->max_reads;
@@ -2177,6 +2247,19 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 			F.gws_base = s->d_fast_gws; F.gws_stride = fgeo[4]; F.sc_base = s->d_fast_sc;
 		}
 		if(!s->d_fast_args[gsel]) HIPCHK(hipMalloc((void**)&s->d_fast_args[gsel], sizeof(FastArgs)));
+		FastArgs D = F;
+		if(orphan_T) {
+			uint32_t* const ol = s->d_orphans[gsel];
+			HIPCHK(hipMemsetAsync(ol + s->orphan_cap, 0, 16, s->st));
+			F.orphan_T = orphan_T; F.orphan_list = ol; F.orphan_count = ol + s->orphan_cap;
+			D.slots = s->d_drain_slots;
+			D.adopt_list = ol; D.adopt_count = ol + s->orphan_cap; D.adopt_slots = F.slots;
+			D.work = reinterpret_cast<uint32_t*>(cblk + 13);
+			D.cnt_off = 120;                                             // its own rank / side / step / aligned counters: [240..243]
+			D.total = 0;
+			if(!linear) D.sc_base = s->d_drain_sc;
+			s->orph_cur = ol + s->orphan_cap;
+		}
 		// through pinned memory: a pageable source would make this call wait for everything queued on the stream (the previous run's fast
 		// pass), and the chip would idle while the host queues this run.  The staging block of this buffer set was last read by the upload
 		// of run k - H2G_NBUF, which is over once that run's fast pass is
@@ -2184,20 +2267,43 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		FastArgs* const hF = reinterpret_cast<FastArgs*>(s->h_fast_args) + gsel;
 		*hF = F;
 		HIPCHK(hipMemcpyAsync(s->d_fast_args[gsel], hF, sizeof F, hipMemcpyHostToDevice, s->st));
+		if(orphan_T) {
+			FastArgs* const hD = reinterpret_cast<FastArgs*>(s->h_fast_args) + H2G_NBUF + gsel;
+			*hD = D;
+			HIPCHK(hipMemcpyAsync(s->d_fast_args[H2G_NBUF + gsel], hD, sizeof D, hipMemcpyHostToDevice, s->st));
+		}
 		if((!linear ? h2g_go_fast_graph_launch : use_am ? h2g_go_fast_am_launch : h2g_go_fast_launch)(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
 		A.list = bl; A.nlist = bl + s->max_reads;
 		fast_mgrid = mgrid;
+		fast_orphan = orphan_T; fast_dgrid = dgrid; fast_pool = psel_f;
 	}
 	HIPCHK(hipEventRecord(s->ev[10], s->st));
 	// behind a fast pass the machine works on the second stream (a short list on few workgroups: the next run's fast pass does not wait for it)
 	hipStream_t ms = s->st;
 	unsigned mach_grid = grid;
+	s->ran_drain = false;
 	if(fast) {
-		HIPCHK(hipMemcpyAsync(&s->h_bails[gsel], s->d_bail_list[gsel] + s->max_reads, 4, hipMemcpyDeviceToHost, s->st));
 		HIPCHK(hipEventRecord(s->ev_fast[gsel], s->st));
-		HIPCHK(hipStreamWaitEvent(s->mst[msel], s->ev_fast[gsel], 0));
 		ms = s->mst[msel]; s->st2_busy = true;
 		if(fast_mgrid < mach_grid) mach_grid = fast_mgrid;
+		if(fast_orphan) {
+			// the drain launch: the reads the fast launch's workgroups left in flight, on the drain stream next to the following run's fast launch; the machine's pass needs its hand-ons too
+			const bool use_am = linear && paired && s->tune.align_mate != 0;
+			HIPCHK(hipStreamWaitEvent(s->dst, s->ev_fast[gsel], 0));
+			HIPCHK(hipEventRecord(s->ev_dr[0], s->dst));
+			if((!linear ? h2g_go_fast_graph_launch_drain : use_am ? h2g_go_fast_am_launch_drain : h2g_go_fast_launch_drain)(reinterpret_cast<const FastArgs*>(s->d_fast_args[H2G_NBUF + gsel]), fast_dgrid, s->dst) != 0) return set_err("go() drain launch", hipGetLastError());
+			HIPCHK(hipEventRecord(s->ev_dr[1], s->dst));
+			HIPCHK(hipEventRecord(s->ev_pool[fast_pool], s->dst));
+			HIPCHK(hipMemcpyAsync(&s->h_bails[gsel], s->d_bail_list[gsel] + s->max_reads, 4, hipMemcpyDeviceToHost, s->dst));
+			HIPCHK(hipEventRecord(s->ev_drain[gsel], s->dst));
+			HIPCHK(hipEventRecord(s->ev_bails[gsel], s->dst));
+			HIPCHK(hipStreamWaitEvent(ms, s->ev_drain[gsel], 0));
+			s->ran_drain = true; s->dst_busy = true;
+		} else {
+			HIPCHK(hipMemcpyAsync(&s->h_bails[gsel], s->d_bail_list[gsel] + s->max_reads, 4, hipMemcpyDeviceToHost, s->st));
+			HIPCHK(hipEventRecord(s->ev_bails[gsel], s->st));
+			HIPCHK(hipStreamWaitEvent(ms, s->ev_fast[gsel], 0));
+		}
 	}
 	const unsigned psel = fast ? msel : 0u;          // workspace pools and the overflow list of this machine stream
 	s->ovf_cur = psel;
@@ -2603,6 +2709,7 @@ extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream
 	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") s->tune.tail = (int)v; else if(k == "align_mate") s->tune.align_mate = (int)v;
 	else if(k == "mach_total") { s->tune.mach_total_auto = v <= 0; s->tune.mach_total = v <= 0 ? H2G_MACH_TOTAL : (unsigned)v; }      // (0 = the default policy)
 	else if(k == "fast_reserve") s->tune.fast_reserve = (int)v;
+	else if(k == "orphan") s->tune.orphan = (int)v; else if(k == "drain_grid") s->tune.drain_grid = (int)(v < 1 ? 1 : v > 128 ? 128 : v);
 	else if(k == "mstreams") { s->mstreams = (unsigned)(v < 1 ? 1 : v > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : v); s->gen = 0; }   // (nothing is in flight: every buffer set is free)
 	else return H2G_ERR_ARG;
 	return H2G_OK;
@@ -2634,6 +2741,14 @@ extern "C" __attribute__((visibility("default"))) int h2g_go_fast_prof(h2g_strea
 	HIPCHK(hipMemcpy(out72 + 72, s->cnt_cur + 176, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));   // control time / trips by site
 	return H2G_OK;
 }
+#ifdef H2G_GO_PROF
+extern "C" __attribute__((visibility("default"))) int h2g_go_fast_prof_bins(h2g_stream* s, unsigned long long* out256) {
+	if(!s || !out256) return H2G_ERR_ARG;
+	HIPCHK(sync_all(s));
+	HIPCHK(hipMemcpy(out256, s->cnt_cur + 512, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return H2G_OK;
+}
+#endif
 
 extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	if(!s || !c) return H2G_ERR_ARG;
@@ -2658,6 +2773,7 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 	if(s->ran_align && hipEventElapsedTime(&t, s->ev[7], s->ev[6]) == hipSuccess) s->last.ms_align_kernel = t;
 	if(s->ran_align && hipEventElapsedTime(&t, s->ev[5], s->ev[8]) == hipSuccess) s->last.ms_align = t;   // every pass
 	s->last.n_fast = 0; s->last.n_fast_bail = 0; s->last.ms_fast_kernel = 0; s->last.pad_ = 0; s->last.n_fast_side = 0; s->last.n_fast_sa_steps = 0;
+	s->last.ms_drain_kernel = 0; s->last.pad2_ = 0; s->last.n_drain_side = 0; s->last.n_drain_sa_steps = 0; s->last.n_adopted = 0;
 	if(s->ran_align && s->ran_fast) {
 		unsigned long long f[2], fc[4];
 		HIPCHK(hipMemcpy(f, s->cnt_cur + 6, sizeof f, hipMemcpyDeviceToHost));
@@ -2667,6 +2783,14 @@ extern "C" h2g_status h2g_get_counters(h2g_stream* s, h2g_counters* c) {
 		s->last.n_fast_side = fc[1]; s->last.n_fast_sa_steps = fc[2];
 		s->last.n_rank += fc[0]; s->last.n_side += fc[1]; s->last.n_sa_steps += fc[2]; s->last.n_aligned += fc[3];
 		if(hipEventElapsedTime(&t, s->ev[5], s->ev[10]) == hipSuccess) s->last.ms_fast_kernel = t;
+		if(s->ran_drain) {
+			unsigned long long dc[4]; uint32_t nad = 0;
+			HIPCHK(hipMemcpy(dc, s->cnt_cur + 240, sizeof dc, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpy(&nad, s->orph_cur, 4, hipMemcpyDeviceToHost));
+			s->last.n_drain_side = dc[1]; s->last.n_drain_sa_steps = dc[2]; s->last.n_adopted = nad;
+			s->last.n_rank += dc[0]; s->last.n_side += dc[1]; s->last.n_sa_steps += dc[2]; s->last.n_aligned += dc[3];
+			if(hipEventElapsedTime(&t, s->ev_dr[0], s->ev_dr[1]) == hipSuccess) s->last.ms_drain_kernel = t;
+		}
 	}
 	(void)hipGetLastError();
 	*c = s->last;

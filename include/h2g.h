@@ -412,6 +412,8 @@ typedef struct {
 	uint64_t n_fast, n_fast_bail;                               /* reads / pairs completed by the fast pass; handed on to the general machine */
 	float    ms_fast_kernel, pad_;                              /* the fast pass alone (ms_align covers every pass) */
 	uint64_t n_fast_side, n_fast_sa_steps;                      /* sides / SA-walk steps of the fast pass alone (n_side, n_sa_steps cover every pass) */
+	float    ms_drain_kernel, pad2_;                            /* the drain launch of the fast pass: the reads its workgroups still held when the batch was exhausted ... */
+	uint64_t n_drain_side, n_drain_sa_steps, n_adopted;         /* ... its sides / SA-walk steps (NOT in n_fast_side / n_fast_sa_steps) and how many reads it took up */
 } h2g_counters;
 H2G_EXPORT h2g_status h2g_get_counters(h2g_stream*, h2g_counters*);
 

@@ -39,7 +39,7 @@ def main():
     h = hashlib.sha256()
     h.update(bytes(res)); h.update(f1.tobytes()); h.update(f2.tobytes()); h.update(aln_bytes(a1, int(f1[n]))); h.update(aln_bytes(a2, int(f2[n])))
     c = st.counters()
-    out["pairs"] = {"sha": h.hexdigest(), "fast": int(c.n_fast), "handed_on": int(c.n_fast_bail), "aligned": int(c.n_aligned), "overflow": int(c.n_overflow)}
+    out["pairs"] = {"sha": h.hexdigest(), "fast": int(c.n_fast), "handed_on": int(c.n_fast_bail), "aligned": int(c.n_aligned), "overflow": int(c.n_overflow), "adopted": int(c.n_adopted)}
     rc, ro = synth.flatten_reads(rd)
     st.set_reads(rc, ro); st.set_read_names([str(i) for i in range(len(rd))])
     for rep in range(3):
@@ -48,7 +48,7 @@ def main():
     h = hashlib.sha256()
     h.update(res.tobytes()); h.update(offs.tobytes()); h.update(aln_bytes(aln, int(offs[len(rd)])))
     c = st.counters()
-    out["reads"] = {"sha": h.hexdigest(), "fast": int(c.n_fast), "handed_on": int(c.n_fast_bail), "aligned": int(c.n_aligned), "overflow": int(c.n_overflow)}
+    out["reads"] = {"sha": h.hexdigest(), "fast": int(c.n_fast), "handed_on": int(c.n_fast_bail), "aligned": int(c.n_aligned), "overflow": int(c.n_overflow), "adopted": int(c.n_adopted)}
     st.close(); ix.close()
     print(json.dumps(out))
 

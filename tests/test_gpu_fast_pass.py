@@ -27,6 +27,11 @@ BUILD = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
     dict(seed=75, npairs=120000, nreads=60000, rdlen=101, sub=0.005, repeat_genome=True),                    # human-like repeat structure: the cold genome hits / pool entries
     dict(seed=76, npairs=100000, nreads=20000, rdlen=101, sub=0.01, repeat_genome=True, env={"H2G_FAST_AM": "1", "H2G_FAST_TAIL": "16"}),   # k_go_fast_am + tail hand-off
     dict(seed=72, npairs=60000, nreads=20000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_AM": "1"}),         # alignMate in the pass on hard reads
+    # the end of the batch through the drain launch (k_go_fast_drain: workgroups that hold <= H2G_FAST_ORPHAN reads list them and leave; a small batch needs the knob)
+    dict(seed=71, npairs=150000, nreads=150000, rdlen=101, sub=0.005, env={"H2G_FAST_ORPHAN": "64", "H2G_DRAIN_GRID": "8"}, adopted=True),
+    dict(seed=72, npairs=60000, nreads=60000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_ORPHAN": "512", "H2G_DRAIN_GRID": "32"}, adopted=True),
+    dict(seed=73, npairs=100000, nreads=100000, rdlen=101, sub=0.005, snps=250, env={"H2G_FAST_ORPHAN": "100", "H2G_DRAIN_GRID": "16"}, adopted=True),   # k_go_fast_graph_drain
+    dict(seed=76, npairs=100000, nreads=20000, rdlen=101, sub=0.01, repeat_genome=True, env={"H2G_FAST_AM": "1", "H2G_FAST_TAIL": "16", "H2G_FAST_ORPHAN": "200", "H2G_DRAIN_GRID": "4"}, adopted=True),
 ])
 def test_fast_pass_equals_the_machine(case):
     tmp = tempfile.mkdtemp(prefix="h2fp")
@@ -62,3 +67,4 @@ def test_fast_pass_equals_the_machine(case):
         assert got["0"][k]["overflow"] == 0 and got["1"][k]["overflow"] == 0
         assert got["0"][k]["aligned"] == got["1"][k]["aligned"]
         assert got["0"][k]["sha"] == got["1"][k]["sha"], k
+        if case.get("adopted"): assert got["1"][k]["adopted"] > 0, got["1"][k]

@@ -118,6 +118,20 @@ if hasattr(L, "h2g_go_fast_prof"):
             for op in range(1, 10):
                 if v[3 + op]:
                     print("  %-20s %5.1f %%   executions %d: avg %.1f of 64 lanes" % (ops[op], 100.0 * v[3 + op] / tot, v[32 + op], v[20 + op] / max(1, v[32 + op])))
+if hasattr(L, "h2g_go_fast_prof_bins"):
+    import ctypes as C
+    vb = (C.c_ulonglong * 256)()
+    L.h2g_go_fast_prof_bins.argtypes = [C.c_void_p, C.c_void_p]
+    if L.h2g_go_fast_prof_bins(st.h, vb) == 0:
+        shift = 18 if mode == "gpe" else 15
+        print("  per %.2f ms since the wave started: trips / lanes per trip / slots in flight per workgroup" % ((1 << shift) / 1e5))
+        print("   ", "  ".join("%d/%.0f/%.0f" % (vb[4 * b], vb[4 * b + 1] / max(1, vb[4 * b]), vb[4 * b + 2] / max(1, vb[4 * b])) for b in range(64) if vb[4 * b]))
+print("  drain launch: %.2f ms, adopted %d, sides %d steps %d" % (c.ms_drain_kernel, c.n_adopted, c.n_drain_side, c.n_drain_sa_steps))
 print("%s n %d genome %d FAST=%s: steady %.2f ms/run | align total/fast/machine ms %s | fast done %d bailed %d (%.1f %%) second %d overflow %d aligned %d | sides/unit %.1f steps/unit %.1f | crc %08x" % (
     mode, n, glen, os.environ.get("H2G_GO_FAST", "1"), steady, " ".join("%.2f/%.2f/%.2f" % m for m in ms), c.n_fast, c.n_fast_bail, 100.0 * c.n_fast_bail / n,
     c.n_second_pass, c.n_overflow, c.n_aligned, c.n_side / n, c.n_sa_steps / n, ck))
+if os.environ.get("H2G_JSONL"):
+    import json
+    with open(os.environ["H2G_JSONL"], "a") as f_:
+        f_.write(json.dumps({"tag": os.environ.get("H2G_TAG", ""), "mode": mode, "n": n, "genome": glen, "steady_ms": steady, "runs_ms": ms, "fast_done": int(c.n_fast), "handed_on": int(c.n_fast_bail),
+                             "drain_ms": float(c.ms_drain_kernel), "adopted": int(c.n_adopted), "aligned": int(c.n_aligned), "crc": "%08x" % ck}) + "\n")
