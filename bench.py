@@ -503,10 +503,18 @@ def main():
                     "tail_hand_off": int(os.environ.get("H2G_FAST_TAIL", api.DEFAULT_TAIL)),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "pairs_completed_by_the_kernel": int(cnt.n_fast), "pairs_handed_on": int(cnt.n_fast_bail),
-                    "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs (about 0.8 %), on one of 8 machine streams next to the fast passes of the following steps",
+                    "machine_pass_ms": ms_machine, "machine_pass_note": "k_go<false> over the handed-on pairs (%.2f %%), on one of 8 machine streams next to the fast passes of the following steps" % (100.0 * int(cnt.n_fast_bail) / max(1, npairs)),
                     "whole_step": {"algorithmic_bytes": alg_all, "GB/s": alg_all / (dt / a.steps) / 1e9, "frac": alg_all / (dt / a.steps) / 1e9 / HBM_PEAK_GBS},
                     "sides_per_pair": int(cnt.n_side) / npairs, "sa_steps_per_pair": int(cnt.n_sa_steps) / npairs,
-                    "note": "latency chains over scattered 64 B index lines + per-read control; per trip a read's 160 B state and 264 B of hot words + packed reads are loaded in one batch of 16 B loads and stored back (DESIGN.md §3.1)"}
+                    "note": "latency chains over scattered 64 B index lines + per-read control; a read stays in its lane between trips (state in registers, hot words in LDS), 44 % of the slot-trips load their slot (DESIGN.md §3.1c)"}
+        if fast_on and float(cnt.ms_drain_kernel) > 0:
+            # the end of the batch: the fast launch's workgroups leave once they can fetch no more and hold <= 512 reads; what they held (and the pairs that need alignMate) is finished by the
+            # drain launch next to the FOLLOWING step's fast launch — its own kernel, its own counters (not in algorithmic_bytes_per_launch above)
+            d_bytes = (int(cnt.n_drain_side) + int(cnt.n_drain_sa_steps)) * 64
+            roofline["drain_launch"] = {"kernel": "k_go_fast_am_drain (h2g_k_go_fast_am.hip, the loop of h2g_k_go_fast.hip with ADOPT; alignMate in it)" if int(os.environ.get("H2G_FAST_MATE_HANDOVER", "1")) else "k_go_fast_drain",
+                                        "kernel_ms": float(cnt.ms_drain_kernel), "reads_taken_up": int(cnt.n_adopted), "algorithmic_bytes_per_launch": d_bytes,
+                                        "GB/s": d_bytes / (float(cnt.ms_drain_kernel) * 1e-3) / 1e9, "workgroups": int(os.environ.get("H2G_DRAIN_GRID", "64")),
+                                        "note": "runs on the drain stream beside the next step's fast launch; the machine's pass over this step's hand-ons waits for it (DESIGN.md §3.1d)"}
         # HBM traffic of the same kernel on the same workload from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
         # WRITE_SIZE need separate passes and cannot be collected inside this process); per launch like `achieved`
         attach_pmc_traffic(roofline, npairs, total, fast_on)
@@ -658,14 +666,23 @@ def main():
             except (IndexError, ValueError):
                 built = 600.0
             left = hard - (time.time() - t_start)
-            need = 1.2 * built + 100.0 + 150.0       # genome + FASTA, the build (measured: the repeat-structured 256 Mbp index builds in 0.9-1.5 x the random one's time), reads + timed runs + the reference over one batch
-            if left < need:
-                out["repeat_grch38size_pe"] = {"skipped": "%.0f s left of %.0f, about %.0f needed (the random genome's index took %.0f s on this box)" % (left, hard, need, built)}
+            # genome + FASTA, the build (measured: the repeat-structured 256 Mbp index builds in 0.9-1.5 x the random one's time), reads + timed runs + the reference over one batch;
+            # when the metric's size does not fit the time left, the companion runs at the LARGEST size that does (build time is linear in the genome: multiples of 0.25 Gbp,
+            # at least 1 Gbp) and its workload says so — a repeat-structured figure four times the 256 Mbp leg's size instead of none
+            need = lambda g: (1.2 * built + 100.0) * g / total + 150.0
+            glen_c = total
+            if left < need(total):
+                glen_c = int(max(0.0, (left - 150.0) / ((1.2 * built + 100.0) / total)) // 250_000_000) * 250_000_000
+            if glen_c < 1_000_000_000:
+                out["repeat_grch38size_pe"] = {"skipped": "%.0f s left of %.0f, about %.0f needed at the metric's size, %.0f at 1 Gbp (the random genome's index took %.0f s on this box)" % (left, hard, need(total), need(1e9), built)}
             else:
+                name = "repeat_grch38size_pe" if glen_c == total else "repeat_%dMbp_pe" % (glen_c // 1_000_000)
+                if glen_c != total:
+                    out["repeat_grch38size_pe"] = {"skipped": "%.0f s left of %.0f, about %.0f needed at the metric's size: run at %d bp instead (%s)" % (left, hard, need(total), glen_c, name)}
                 try:
-                    out["repeat_grch38size_pe"] = repeat_leg(a, api, synth, local, cache, glen=total, build_timeout=left - 250.0, nbatch=min(4, max(1, int(a.batches))))
+                    out[name] = repeat_leg(a, api, synth, local, cache, glen=glen_c, build_timeout=left - 250.0, nbatch=min(4, max(1, int(a.batches))))
                 except Exception as e:         # noqa: BLE001
-                    out["repeat_grch38size_pe"] = {"error": repr(e)[:400]}
+                    out[name] = {"error": repr(e)[:400]}
         legs_failed = [k for k, v in out.items() if isinstance(v, dict) and isinstance(v.get("parity_whole_batch"), dict) and not v["parity_whole_batch"].get("digest_equal", False)]
         if parity_failed or legs_failed:
             out["parity_failed"] = (["headline"] if parity_failed else []) + legs_failed

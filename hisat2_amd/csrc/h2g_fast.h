@@ -79,6 +79,8 @@ namespace h2g {
 #define FW_COLD   (FW_TOTAL - FW_HOT)
 
 enum : uint32_t { FOP_NONE = 0, FOP_PSEARCH, FOP_GCOORDS, FOP_EXTEND, FOP_LSEARCH, FOP_LCOORDS, FOP_COMBINE, FOP_GSEARCH, FOP_ADJUST, FOP_ADJMEMBER, FOP_COUNT };
+// not a primitive: the read stands at a state only the alignMate build of this file can run (FCtx::mate_handover) — the kernel parks its slot for that build's drain launch
+#define FOP_HANDOVER 15u
 enum : uint32_t {
 	FPC_DONE = 0, FPC_BAIL,
 	FPC_GO_INIT, FPC_NB_PICK, FPC_NB_AFTER_PS, FPC_ALIGN, FPC_AFTER_ALIGN, FPC_PAIR_READS, FPC_AFTER_LOOP, FPC_FINISH,
@@ -199,6 +201,7 @@ struct FCtx {
 	const char* name[2]; uint32_t namelen[2];
 	int64_t* sc; uint32_t sc_stride;               // combineWith temp_scores of this lane
 	FastOut O;
+	uint32_t mate_handover = 0;                    // 1 (a build without alignMate): a pair that needs alignMate stops at FPC_AFTER_LOOP with FOP_HANDOVER instead of leaving the fast path
 #if FG_GRAPH
 	const DAlts* alts;                             // the ALT database
 	GraphWS* gws;                                  // this LANE's scratch of one primitive (group walk, ALT-aware extension): nothing in it outlives a trip
@@ -1086,6 +1089,7 @@ again:
 			W.stv<4>(FW_AM, am);
 			F_GOTO(FPC_MP_LOOP);
 #else
+			if(C.mate_handover) F_OP(FOP_HANDOVER, FPC_AFTER_LOOP);      // (the alignMate build re-enters this state and takes the branch above)
 			F_BAIL(FB_MATE);
 #endif
 		}

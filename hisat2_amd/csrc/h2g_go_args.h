@@ -66,6 +66,8 @@ struct FastArgs {
 	uint32_t orphan_T; uint32_t* orphan_list; uint32_t* orphan_count;
 	const uint32_t* adopt_list; const uint32_t* adopt_count; const uint32_t* adopt_slots;
 	uint32_t cnt_off;                         // this launch's rank / side / step / aligned counters are counters[120 + cnt_off ..]
+	uint32_t adopt_slot_words;                // words per slot of `adopt_slots` (the launch that left them may be another build of the pass: same layout, a shorter cold tail)
+	uint32_t mate_handover;                   // 1 (with orphan_T > 0, a build without alignMate): pairs that need alignMate are parked in their slots and listed for the drain launch — the alignMate build's
 };
 extern "C" int h2g_go_fast_launch(const FastArgs*, unsigned grid, hipStream_t);
 extern "C" int h2g_go_fast_launch_drain(const FastArgs*, unsigned grid, hipStream_t);

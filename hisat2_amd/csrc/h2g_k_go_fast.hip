@@ -47,6 +47,7 @@ static_assert(FS_WORDS % 4 == 0, "16-byte loads of the state");
 struct FastLds {
 	uint32_t head[FG_NQ], tail[FG_NQ];
 	uint32_t quit;                      // the workgroup hands its reads in flight on (FastArgs::orphan_T)
+	uint32_t parked;                    // slots that hold a read listed for the drain launch already (FastArgs::mate_handover): not free, not in flight
 	uint16_t ring[FG_NQ][H2G_FAST_SLOTS];
 };
 
@@ -114,6 +115,7 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 	}
 #endif
 	C.O = A->O;
+	C.mate_handover = FG_ALIGN_MATE ? 0u : A->mate_handover;
 	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
 }
 // the state <-> its slot (16-byte accesses, nothing depends on anything)
@@ -210,7 +212,7 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 	const bool paired = A->paired != 0;
 	for(uint32_t k = threadIdx.x; k < (uint32_t)FG_NQ * H2G_FAST_SLOTS; k += blockDim.x) (&Q->ring[0][0])[k] = FG_RING_EMPTY;
 	if(threadIdx.x < (uint32_t)FG_NQ) { Q->head[threadIdx.x] = 0; Q->tail[threadIdx.x] = 0; }
-	if(threadIdx.x == 0) Q->quit = 0;
+	if(threadIdx.x == 0) { Q->quit = 0; Q->parked = 0; }
 	__syncthreads();
 	for(uint32_t k = threadIdx.x; k < H2G_FAST_SLOTS; k += blockDim.x) Q->ring[0][k] = (uint16_t)k;   // every slot starts free
 	if(threadIdx.x == 0) Q->tail[0] = H2G_FAST_SLOTS;
@@ -245,6 +247,8 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 		}
 		key = (uint32_t)__shfl((int)key, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
 		const uint32_t bestact = key >> 8, avail = nfree + own_free;
+		uint32_t parked = 0;
+		if(!ADOPT && !FG_ALIGN_MATE && orphan_T) { if(lane == 0) parked = __atomic_load_n(&Q->parked, __ATOMIC_RELAXED); parked = (uint32_t)__shfl((int)parked, 0); }
 		// new reads: when that trip would fill more lanes than any site's, or a quarter of the slots lie free
 		const bool fetch = more && avail > 0 && ((avail > 64u ? 64u : avail) > bestact || nfree >= H2G_FAST_SLOTS / 4);
 		const uint32_t qstar = fetch ? (uint32_t)FQ_FREE : (bestact ? bestq : FG_Q_NONE);
@@ -253,7 +257,7 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 			uint32_t quit = 0;
 			if(lane == 0) {
 				quit = __atomic_load_n(&Q->quit, __ATOMIC_RELAXED);
-				if(!quit && !more && H2G_FAST_SLOTS - nfree <= orphan_T) { __atomic_store_n(&Q->quit, 1u, __ATOMIC_RELAXED); quit = 1; }
+				if(!quit && !more && H2G_FAST_SLOTS - nfree - parked <= orphan_T) { __atomic_store_n(&Q->quit, 1u, __ATOMIC_RELAXED); quit = 1; }
 			}
 			if(__shfl((int)quit, 0)) {
 				const bool out = keep && myq != FQ_FREE;
@@ -275,7 +279,7 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 			FPROF(17);
 		}
 		if(qstar == FG_Q_NONE) {
-			if(!more && nfree == H2G_FAST_SLOTS) break;           // the batch is exhausted and every slot is free again
+			if(!more && nfree + parked == H2G_FAST_SLOTS) break;  // the batch is exhausted and every slot is free again (or parked for the drain launch)
 			__builtin_amdgcn_s_sleep(8);
 			if(more) { uint32_t w = 0; if(lane == 0) w = __atomic_load_n(A->work, __ATOMIC_RELAXED); if((uint32_t)__shfl((int)w, 0) >= total) more = false; }
 			continue;
@@ -298,13 +302,15 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 			if(ADOPT && active) {
 				// a read another launch left in flight: its slot into this workgroup's pool, the read into this lane — it waits for the request it was stored at
 				sm = slots0 + (size_t)slot * FG_SLOT_WORDS;
-				const uint32_t* const src = A->adopt_slots + (size_t)A->adopt_list[base + r] * FG_SLOT_WORDS;
+				const uint32_t sw = A->adopt_slot_words;               // (16-byte multiples both; the other build's slot ends 4 words earlier or later)
+				const uint32_t* const src = A->adopt_slots + (size_t)A->adopt_list[base + r] * sw;
 				const uint4* s4 = reinterpret_cast<const uint4*>(src); uint4* d4 = reinterpret_cast<uint4*>(sm);
+				const uint32_t nq = (sw < (uint32_t)FG_SLOT_WORDS ? sw : (uint32_t)FG_SLOT_WORDS) / 4;
 #pragma unroll 8
-				for(uint32_t k = 0; k < FG_SLOT_WORDS / 4; k++) d4[k] = s4[k];
+				for(uint32_t k = 0; k < nq; k++) d4[k] = s4[k];
 				fk_load_read(S, src, stage);
-				keep = true; myq = fg_queue_of(S.pc);
-				active = false;
+				if(S.op == FOP_NONE) trip_op = FOP_NONE;                // parked between two states (FOP_HANDOVER): its control flow runs now, below
+				else { keep = true; myq = fg_queue_of(S.pc); active = false; }
 			}
 			if(!ADOPT && active) {
 				keep = false;
@@ -343,6 +349,24 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 		else if(active) fk_trip(A, stage, sm, S, trip_op, begin, packed_ok);
 		FPROF_CTL();
 		FPROF(1);
+		if(!ADOPT && !FG_ALIGN_MATE) {
+			// a pair that needs alignMate: parked in its slot and listed for the drain launch (the alignMate build of this loop) — up to a quarter of the workgroup's slots, then handed on
+			const bool ho = active && S.op == FOP_HANDOVER;
+			const unsigned long long hm = __ballot(ho);
+			if(hm) {
+				uint32_t old = 0;
+				if(lane == 0) old = atomicAdd(&Q->parked, (uint32_t)__popcll(hm));
+				old = (uint32_t)__shfl((int)old, 0);
+				const bool ok = ho && old + (uint32_t)__popcll(hm & lt) < H2G_FAST_SLOTS / 4;
+				const uint32_t nfail = (uint32_t)__popcll(hm) - (uint32_t)__popcll(__ballot(ok));
+				if(lane == 0 && nfail) atomicSub(&Q->parked, nfail);
+				if(ho) S.op = FOP_NONE;
+				if(ok) fk_store_read(S, sm, stage);
+				fk_orphan(A, ok, slot, lane);
+				if(ok) { active = false; keep = false; }
+				else if(ho) { S.pc = FPC_BAIL; S.bail = FB_MATE; }
+			}
+		}
 		const uint32_t pc = S.pc;
 		if(active) {
 			keep = true;

@@ -74,11 +74,12 @@ struct h2g_index {
 // workgroup hands on at the tail of an exhausted batch, and whether alignMate runs inside the pass (k_go_fast_am) or in the machine's pass
 #define H2G_DEFAULT_TAIL 16
 // The end of a batch (h2g_k_go_fast.hip, fk_loop): workgroups of a fast launch that can fetch no more and hold at most H2G_ORPHAN_T reads list them and leave; the drain launch
-// (H2G_DRAIN_GRID workgroups, on the run's machine stream in front of the machine's pass) finishes them next to the following run's fast launch.  Batches below
-// H2G_ORPHAN_MIN_UNITS keep the single launch (h2g_stream_tune "orphan": -1 this policy, 0 off, n the threshold; "drain_grid").
+// (H2G_DRAIN_GRID workgroups on the stream's drain stream; the machine's pass waits for it) finishes them next to the following run's fast launch.  Drain launches run one after
+// the other, so one has to be shorter than a step: 64 workgroups (lease Q: with 32 and the alignMate pairs in it the drain launch, 10 ms, became the step).  Batches below
+// H2G_ORPHAN_MIN_UNITS keep the single launch (h2g_stream_tune "orphan": -1 this policy, 0 off, n the threshold; "drain_grid"; "mate_handover").
 #define H2G_ORPHAN_T 512
 #define H2G_ORPHAN_MIN_UNITS 200000
-#define H2G_DRAIN_GRID 32
+#define H2G_DRAIN_GRID 64
 #define H2G_FAST_POOLS 3
 #define H2G_DEFAULT_ALIGN_MATE 0
 #ifdef H2G_GO_PROF
@@ -160,7 +161,7 @@ struct h2g_stream {
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
 	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int mach_total_auto = 1; int fast_reserve = H2G_FAST_RESERVE_DEFAULT; long dbg_read = -1;
-	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; int orphan = -1 /* auto */, drain_grid = H2G_DRAIN_GRID; } tune;
+	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; int orphan = -1 /* auto */, drain_grid = H2G_DRAIN_GRID, mate_handover = -1 /* auto */; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
@@ -523,7 +524,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 0); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
 		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
-		s->tune.orphan = (int)env("H2G_FAST_ORPHAN", -1); s->tune.drain_grid = (int)env("H2G_DRAIN_GRID", H2G_DRAIN_GRID);
+		s->tune.orphan = (int)env("H2G_FAST_ORPHAN", -1); s->tune.drain_grid = (int)env("H2G_DRAIN_GRID", H2G_DRAIN_GRID); s->tune.mate_handover = (int)env("H2G_FAST_MATE_HANDOVER", -1);
 		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.mach_total_auto = getenv("H2G_MACH_TOTAL") ? 0 : 1; s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", H2G_FAST_RESERVE_DEFAULT);
 		{ const long m = env("H2G_MSTREAMS", H2G_MSTREAMS_DEFAULT); s->mstreams = (unsigned)(m < 1 ? 1 : m > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : m); }
 	}
@@ -2135,7 +2136,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 	// it hands on (a device-side list, no host sync) are the general machine's batch.  Built for unspliced alignment on a linear
 	// index with the default pair policy; every other option set goes to the machine whole.
 	s->ran_fast = fast;
-	unsigned fast_mgrid = 0, fast_orphan = 0, fast_dgrid = 0, fast_pool = 0;
+	unsigned fast_mgrid = 0, fast_orphan = 0, fast_dgrid = 0, fast_pool = 0; bool fast_mate_ho = false;
 	if(fast) {
 		uint32_t fgeo[5] = {0, 0, 0, 0, 0};
 		const bool use_am = linear && paired && s->tune.align_mate != 0;
@@ -2181,9 +2182,14 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if(orphan_T > fgeo[2]) orphan_T = fgeo[2];
 		if(!linear && fgeo[4] != 0) orphan_T = 0;                     // (a graph unit with GraphWS in global memory: its scratch is sized for one launch)
 		const unsigned dgrid = (unsigned)(s->tune.drain_grid < 1 ? 1 : s->tune.drain_grid);
+		// pairs that need alignMate (hi_aligner.h:5579): with a drain launch there, the fast launch parks them and the drain launch is the alignMate build of the pass (k_go_fast_am_drain)
+		// — the hot loop keeps the lighter build, the machine sees neither them nor the tail (h2g_stream_tune "mate_handover": -1 this policy, 0 off, 1 on)
+		const bool mate_ho = orphan_T != 0 && linear && paired && !use_am && s->tune.mate_handover != 0;
+		uint32_t dgeo[5] = {fgeo[0], fgeo[1], fgeo[2], fgeo[3], fgeo[4]};
+		if(mate_ho) h2g_go_fast_am_geometry(dgeo);
 		const unsigned psel_f = orphan_T ? s->gen % H2G_FAST_POOLS : 0u;
 		{	// every buffer of the two launches exists (and has been written once: fresh device memory costs its first writer the mapping) before the first run that could need it
-			const size_t ocap = (size_t)256 * fgeo[2], dbytes = (size_t)dgrid * fgeo[2] * fgeo[3];
+			const size_t ocap = (size_t)256 * fgeo[2], dbytes = (size_t)dgrid * dgeo[2] * dgeo[3];
 			const size_t dsc = linear ? 0 : (size_t)dgrid * fgeo[0] * (size_t)(2 * H2G_COMBINE_MAXLEN * sizeof(int64_t));
 			bool need = s->fast_slot_bytes[psel_f] < slot_bytes;
 			if(orphan_T) {
@@ -2251,7 +2257,8 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if(orphan_T) {
 			uint32_t* const ol = s->d_orphans[gsel];
 			HIPCHK(hipMemsetAsync(ol + s->orphan_cap, 0, 16, s->st));
-			F.orphan_T = orphan_T; F.orphan_list = ol; F.orphan_count = ol + s->orphan_cap;
+			F.orphan_T = orphan_T; F.orphan_list = ol; F.orphan_count = ol + s->orphan_cap; F.mate_handover = mate_ho ? 1u : 0u;
+			D.adopt_slot_words = fgeo[3] / 4;
 			D.slots = s->d_drain_slots;
 			D.adopt_list = ol; D.adopt_count = ol + s->orphan_cap; D.adopt_slots = F.slots;
 			D.work = reinterpret_cast<uint32_t*>(cblk + 13);
@@ -2275,7 +2282,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if((!linear ? h2g_go_fast_graph_launch : use_am ? h2g_go_fast_am_launch : h2g_go_fast_launch)(reinterpret_cast<const FastArgs*>(s->d_fast_args[gsel]), fgrid, s->st) != 0) return set_err("go() fast pass launch", hipGetLastError());
 		A.list = bl; A.nlist = bl + s->max_reads;
 		fast_mgrid = mgrid;
-		fast_orphan = orphan_T; fast_dgrid = dgrid; fast_pool = psel_f;
+		fast_orphan = orphan_T; fast_dgrid = dgrid; fast_pool = psel_f; fast_mate_ho = mate_ho;
 	}
 	HIPCHK(hipEventRecord(s->ev[10], s->st));
 	// behind a fast pass the machine works on the second stream (a short list on few workgroups: the next run's fast pass does not wait for it)
@@ -2288,7 +2295,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		if(fast_mgrid < mach_grid) mach_grid = fast_mgrid;
 		if(fast_orphan) {
 			// the drain launch: the reads the fast launch's workgroups left in flight, on the drain stream next to the following run's fast launch; the machine's pass needs its hand-ons too
-			const bool use_am = linear && paired && s->tune.align_mate != 0;
+			const bool use_am = (linear && paired && s->tune.align_mate != 0) || fast_mate_ho;
 			HIPCHK(hipStreamWaitEvent(s->dst, s->ev_fast[gsel], 0));
 			HIPCHK(hipEventRecord(s->ev_dr[0], s->dst));
 			if((!linear ? h2g_go_fast_graph_launch_drain : use_am ? h2g_go_fast_am_launch_drain : h2g_go_fast_launch_drain)(reinterpret_cast<const FastArgs*>(s->d_fast_args[H2G_NBUF + gsel]), fast_dgrid, s->dst) != 0) return set_err("go() drain launch", hipGetLastError());
@@ -2709,6 +2716,7 @@ extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream
 	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") s->tune.tail = (int)v; else if(k == "align_mate") s->tune.align_mate = (int)v;
 	else if(k == "mach_total") { s->tune.mach_total_auto = v <= 0; s->tune.mach_total = v <= 0 ? H2G_MACH_TOTAL : (unsigned)v; }      // (0 = the default policy)
 	else if(k == "fast_reserve") s->tune.fast_reserve = (int)v;
+	else if(k == "mate_handover") s->tune.mate_handover = (int)v;
 	else if(k == "orphan") s->tune.orphan = (int)v; else if(k == "drain_grid") s->tune.drain_grid = (int)(v < 1 ? 1 : v > 128 ? 128 : v);
 	else if(k == "mstreams") { s->mstreams = (unsigned)(v < 1 ? 1 : v > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : v); s->gen = 0; }   // (nothing is in flight: every buffer set is free)
 	else return H2G_ERR_ARG;

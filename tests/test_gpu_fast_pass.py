@@ -28,10 +28,14 @@ BUILD = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
     dict(seed=76, npairs=100000, nreads=20000, rdlen=101, sub=0.01, repeat_genome=True, env={"H2G_FAST_AM": "1", "H2G_FAST_TAIL": "16"}),   # k_go_fast_am + tail hand-off
     dict(seed=72, npairs=60000, nreads=20000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_AM": "1"}),         # alignMate in the pass on hard reads
     # the end of the batch through the drain launch (k_go_fast_drain: workgroups that hold <= H2G_FAST_ORPHAN reads list them and leave; a small batch needs the knob)
-    dict(seed=71, npairs=150000, nreads=150000, rdlen=101, sub=0.005, env={"H2G_FAST_ORPHAN": "64", "H2G_DRAIN_GRID": "8"}, adopted=True),
-    dict(seed=72, npairs=60000, nreads=60000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_ORPHAN": "512", "H2G_DRAIN_GRID": "32"}, adopted=True),
+    dict(seed=71, npairs=150000, nreads=150000, rdlen=101, sub=0.005, env={"H2G_FAST_ORPHAN": "64", "H2G_DRAIN_GRID": "8", "H2G_FAST_MATE_HANDOVER": "0"}, adopted=True),
+    dict(seed=72, npairs=60000, nreads=60000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_ORPHAN": "512", "H2G_DRAIN_GRID": "32", "H2G_FAST_MATE_HANDOVER": "0"}, adopted=True),
     dict(seed=73, npairs=100000, nreads=100000, rdlen=101, sub=0.005, snps=250, env={"H2G_FAST_ORPHAN": "100", "H2G_DRAIN_GRID": "16"}, adopted=True),   # k_go_fast_graph_drain
     dict(seed=76, npairs=100000, nreads=20000, rdlen=101, sub=0.01, repeat_genome=True, env={"H2G_FAST_AM": "1", "H2G_FAST_TAIL": "16", "H2G_FAST_ORPHAN": "200", "H2G_DRAIN_GRID": "4"}, adopted=True),
+    # ... and with the pairs that need alignMate parked for it (the drain launch is then the alignMate build: k_go_fast_am_drain behind k_go_fast) — the policy of large batches
+    dict(seed=76, npairs=100000, nreads=20000, rdlen=101, sub=0.01, repeat_genome=True, env={"H2G_FAST_ORPHAN": "200", "H2G_DRAIN_GRID": "8", "H2G_FAST_MATE_HANDOVER": "1"}, adopted=True),
+    dict(seed=72, npairs=60000, nreads=20000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_ORPHAN": "64", "H2G_DRAIN_GRID": "16", "H2G_FAST_MATE_HANDOVER": "1"}, adopted=True),
+    dict(seed=77, npairs=150000, nreads=20000, rdlen=101, sub=0.005, env={"H2G_FAST_ORPHAN": "512", "H2G_DRAIN_GRID": "32", "H2G_FAST_MATE_HANDOVER": "1", "H2G_FAST_TAIL": "16"}, adopted=True),
 ])
 def test_fast_pass_equals_the_machine(case):
     tmp = tempfile.mkdtemp(prefix="h2fp")
