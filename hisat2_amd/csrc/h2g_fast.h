@@ -81,6 +81,8 @@ namespace h2g {
 enum : uint32_t { FOP_NONE = 0, FOP_PSEARCH, FOP_GCOORDS, FOP_EXTEND, FOP_LSEARCH, FOP_LCOORDS, FOP_COMBINE, FOP_GSEARCH, FOP_ADJUST, FOP_ADJMEMBER, FOP_COUNT };
 // not a primitive: the read stands at a state only the alignMate build of this file can run (FCtx::mate_handover) — the kernel parks its slot for that build's drain launch
 #define FOP_HANDOVER 15u
+// ... and not one either: the trip of a queue whose lanes wait for different primitives (FQ_WALK_SLOW) runs each lane's own S.op
+#define FOP_PER_LANE 14u
 enum : uint32_t {
 	FPC_DONE = 0, FPC_BAIL,
 	FPC_GO_INIT, FPC_NB_PICK, FPC_NB_AFTER_PS, FPC_ALIGN, FPC_AFTER_ALIGN, FPC_PAIR_READS, FPC_AFTER_LOOP, FPC_FINISH,
@@ -201,6 +203,10 @@ struct FCtx {
 	const char* name[2]; uint32_t namelen[2];
 	int64_t* sc; uint32_t sc_stride;               // combineWith temp_scores of this lane
 	FastOut O;
+	// 1 (graph indexes, the queued kernel): a primitive whose read turns out to need its slow form — the ALT-aware extension over the unpacked hit, the node-based group walk on the
+	// lane's scratch: 300-900 us where the common form takes 30-170 — marks its arguments and asks to be queued again, on a queue of such requests (FQ_EXTEND_SLOW / FQ_WALK_SLOW):
+	// a wave waits for its slowest lane, and with a third of the reads near a variant every trip had one (lease P: E:HS 308 us per trip against 29 on a linear index)
+	uint32_t defer_slow = 0;
 	uint32_t mate_handover = 0;                    // 1 (a build without alignMate): a pair that needs alignMate stops at FPC_AFTER_LOOP with FOP_HANDOVER instead of leaving the fast path
 #if FG_GRAPH
 	const DAlts* alts;                             // the ALT database
@@ -2086,6 +2092,8 @@ H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
 		S.a0 = n; S.a1 = 0;
 		return false;
 	}
+	if(C.defer_slow && !(S.a4 & 4u)) { S.a4 |= 4u; return true; }                          // the group walk: on the queue of slow walks
+	S.a4 &= ~4u;
 	IEdges ie;
 	fg_ie_unpack(S.a8, &ie);
 	h2g_coord co[FG_NCO];
@@ -2152,9 +2160,11 @@ H2G_HD bool fast_op_gcoords(const FCtx& C, FState& S, const FWords& W) {
 #endif
 #if FG_GRAPH
 // GenomeHit::extend on a graph index: alignWithALTs through the ALT database (extend_item_alts) over the unpacked hit
-H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
+H2G_HD bool fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
+	const bool deferred = (S.a3 >> 31) != 0;         // (asked again from the queue of slow extensions: the tests below said so already)
+	S.a3 &= 0x7fffffffu;
 	FHit h = fh_load(W, S.a3);
-	{
+	if(!deferred) {
 		// No ALT within reach of either extension (extend_item_alts' own tests; the right end of a hit does not move when it grows to the left):
 		// alignWithALTs degenerates to the mismatch scan of a linear index — the word-wise register code, no unpacked record
 		const DAlts& A = *C.alts;
@@ -2180,8 +2190,9 @@ H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
 			fh_extend(*C.ref, C.P->sc, sv, h, S.a0, S.a1, S.a2, &le, &re);
 			if(!fh_store(W, S.a3, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
 			S.a0 = le; S.a1 = re;
-			return;
+			return false;
 		}
+		if(C.defer_slow) { S.a3 |= 0x80000000u; return true; }
 	}
 	h2g_ghit g;
 	fh_to_ghit(h, &g);
@@ -2190,6 +2201,7 @@ H2G_HD void fast_op_extend(const FCtx& C, FState& S, const FWords& W) {
 	ghit_to_fh(g, h);
 	if(!fh_store(W, S.a3, h)) { S.pc = FPC_BAIL; S.bail = FB_EDITS; }
 	S.a0 = le; S.a1 = re;
+	return false;
 }
 // static adjustWithALT (hi_aligner.h:2239; adjust_with_alt): the anchor (a0 rdoff, a1 len) placed at (a2 tidx, a3 toff, a4 joinedOff) becomes the
 // genome hits it yields.  It compares what it adds with the hits already there, so those go in first.
@@ -2327,6 +2339,8 @@ H2G_HD bool fast_op_lcoords(const FCtx& C, FState& S, const FWords& W) {
 		S.a0 = n1;
 		return false;
 	}
+	if(C.defer_slow && !(S.a2 & 0x40000000u)) { S.a2 |= 0x40000000u; return true; }      // the group walk: on the queue of slow walks
+	S.a2 &= ~0x40000000u;
 	const uint32_t top = S.a1, bot = S.a2 & 0xffffu;
 	IEdges ie;
 	fg_ie_unpack(S.a8, &ie);
@@ -2402,7 +2416,11 @@ H2G_HD void fast_exec(const FCtx& C, FState& S, const FWords& W, uint32_t op) {
 	case FOP_GSEARCH: fast_op_gsearch(C, S); break;
 	case FOP_PSEARCH: fast_op_psearch(C, S); break;
 	case FOP_GCOORDS: again = fast_op_gcoords(C, S, W); break;
+#if FG_GRAPH
+	case FOP_EXTEND:  again = fast_op_extend(C, S, W); break;
+#else
 	case FOP_EXTEND:  fast_op_extend(C, S, W); break;
+#endif
 	case FOP_LSEARCH: fast_op_lsearch(C, S); break;
 	case FOP_LCOORDS: again = fast_op_lcoords(C, S, W); break;
 	case FOP_COMBINE: fast_op_combine(C, S, W); break;
@@ -2478,6 +2496,7 @@ H2G_HD uint32_t fg_site_op(uint32_t site) {
 enum : uint32_t { FQ_FREE = 0, FQ_PSEARCH, FQ_GCOORDS, FQ_EXTEND_HS, FQ_EXTEND, FQ_LSEARCH, FQ_LCOORDS, FQ_COMBINE, FQ_GSEARCH,
 #if FG_GRAPH
 	FQ_ADJUST, FQ_ADJMEMBER,
+	FQ_EXTEND_SLOW, FQ_WALK_SLOW,       // requests that turned out to need a primitive's slow form (FCtx::defer_slow): FOP_EXTEND; FOP_LCOORDS / FOP_GCOORDS, each lane its own
 #endif
 	FQ_COUNT };
 H2G_HD uint32_t fg_queue_of(uint32_t pc) {
@@ -2511,9 +2530,20 @@ H2G_HD uint32_t fg_queue_op(uint32_t q) {
 #if FG_GRAPH
 	case FQ_ADJUST: return FOP_ADJUST;
 	case FQ_ADJMEMBER: return FOP_ADJMEMBER;
+	case FQ_EXTEND_SLOW: return FOP_EXTEND;
+	case FQ_WALK_SLOW: return FOP_PER_LANE;
 #endif
 	default: return FOP_NONE;
 	}
+}
+// the queue a read waits in: that of its request site — or, when its primitive asked to be queued again for its slow form, the queue of such requests
+H2G_HD uint32_t fg_queue_of_state(const FState& S) {
+#if FG_GRAPH
+	if(S.op == FOP_EXTEND && (S.a3 >> 31)) return FQ_EXTEND_SLOW;
+	if(S.op == FOP_LCOORDS && (S.a2 & 0x40000000u)) return FQ_WALK_SLOW;
+	if(S.op == FOP_GCOORDS && (S.a4 & 4u)) return FQ_WALK_SLOW;
+#endif
+	return fg_queue_of(S.pc);
 }
 
 // One read / pair on ONE lane until it completes or bails (tests/emul).  true = completed.

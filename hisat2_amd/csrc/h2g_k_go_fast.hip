@@ -116,6 +116,7 @@ __device__ __forceinline__ void fk_ctx(const FastArgs* A, uint32_t* stage, uint3
 #endif
 	C.O = A->O;
 	C.mate_handover = FG_ALIGN_MATE ? 0u : A->mate_handover;
+	C.defer_slow = FG_GRAPH ? 1u : 0u;
 	C.name[0] = C.name[1] = nullptr; C.namelen[0] = C.namelen[1] = 0;
 }
 // the state <-> its slot (16-byte accesses, nothing depends on anything)
@@ -151,7 +152,7 @@ __device__ __forceinline__ void fk_trip(const FastArgs* A, uint32_t* stage, uint
 		// the work counters are 16-bit fields: the primitive counts from zero, a read that would wrap them leaves the fast path
 		const uint32_t nr0 = S.nrank, ns0 = S.nside, nt0 = S.nsteps;
 		S.nrank = 0; S.nside = 0; S.nsteps = 0;
-		fast_exec(C, S, W, op);
+		fast_exec(C, S, W, op == FOP_PER_LANE ? (uint32_t)S.op : op);
 		const uint32_t nr_ = nr0 + S.nrank, ns_ = ns0 + S.nside, nt_ = nt0 + S.nsteps;
 		if(S.pc != FPC_BAIL && (nr_ > 0xffffu || ns_ > 0xffffu || nt_ > 0xffffu)) { S.pc = FPC_BAIL; S.bail = FB_OTHER; }
 		S.nrank = nr_ & 0xffffu; S.nside = ns_ & 0xffffu; S.nsteps = nt_ & 0xffffu;
@@ -310,7 +311,7 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 				for(uint32_t k = 0; k < nq; k++) d4[k] = s4[k];
 				fk_load_read(S, src, stage);
 				if(S.op == FOP_NONE) trip_op = FOP_NONE;                // parked between two states (FOP_HANDOVER): its control flow runs now, below
-				else { keep = true; myq = fg_queue_of(S.pc); active = false; }
+				else { keep = true; myq = fg_queue_of_state(S); active = false; }
 			}
 			if(!ADOPT && active) {
 				keep = false;
@@ -338,7 +339,7 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 				if(tail) S.read = sm[8];                              // (state word 8 = the read id)
 				else fk_load_read(S, sm, stage);
 			}
-			FPROF_EXEC(trip_op, __popcll(__ballot(active)), __popcll(__ballot(fresh)));
+			FPROF_EXEC(trip_op > 11u ? 11u : trip_op, __popcll(__ballot(active)), __popcll(__ballot(fresh)));
 			FPROF_SITE(qstar);
 			FPROF(0);
 		}
@@ -372,7 +373,7 @@ __device__ __forceinline__ void fk_loop(const FastArgs* __restrict__ A, uint32_t
 			keep = true;
 			if(pc == FPC_DONE) { nrank += S.nrank; nside += S.nside; nsteps += S.nsteps; naln += S.a0 != 0; ndone++; myq = FQ_FREE; }
 			else if(pc == FPC_BAIL) myq = FQ_FREE;
-			else myq = fg_queue_of(pc);
+			else myq = fg_queue_of_state(S);
 		}
 		// reads that left the fast path: their ids go to the general machine's list
 		{
