@@ -390,6 +390,7 @@ H2G_GLF bool map_glf1(const X& g, uint32_t row, int c, GRange* r) {
 // ------------------------------------------------------------------------------------------ partialSearch (a11)
 // hi_aligner.h:6361-6600 on a graph index: mapGLF / mapGLF1 per base, node ranges drive the stop rules,
 // the in-edge list of the last step rides along (:6522-6527) and gates reporting (:6551-6553).
+// (inline in the fast unit it was measured slower: 73.2 -> 74.9 ms per step on the 256 Mbp SNP graph, lease T of round 6)
 H2G_HDN void partial_search_graph_item(const DGfm& g, const SeqView& seq, uint32_t cur_in, bool pseudogeneStopIn,
                                       bool anchorStopIn, uint32_t khits, uint32_t kseeds, h2g_fm_hit* o, IEdges* ie_out)
 {
