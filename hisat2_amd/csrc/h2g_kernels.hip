@@ -487,7 +487,7 @@ extern "C" h2g_status h2g_index_synth_graph_sides(uint64_t num_sides, uint64_t s
 }
 
 // ------------------------------------------------------------------------------------------ stream
-// A stream of this library is 1 + H2G_MSTREAMS_MAX HIP streams whose kernels must be able to run side by side.  ROCclr maps HIP streams onto
+// A stream of this library is 2 + H2G_MSTREAMS_MAX HIP streams (the fast launches', the drain launches', one per machine pass in flight) whose kernels must be able to run side by side.  ROCclr maps HIP streams onto
 // GPU_MAX_HW_QUEUES hardware queues (4 by default) and streams that share a queue serialise — measured: four machine passes "in flight" on the
 // default 4 queues ran one after the other (repeat-structured leg: 127 ms per step against 78 ms with 16 queues; profiles/r05_NOTES.md).  The variable is
 // read when the HIP runtime initialises, so it is set when this library is loaded (never overriding the caller's own setting); a process that
