@@ -32,10 +32,6 @@ struct GoArgs {
 	uint32_t dbg_read; uint32_t* dbg_buf; // development hook: trace of one read id (H2G_GO_DBG_READ): [0] = words used, then 8 words per primitive request
 	uint32_t rdid_base;                   // Read::rdid of read 0 of the batch (splice-site visibility window)
 	uint32_t defer_overflow;              // 1: a second pass follows; overflowed reads are not counted as aligned here
-	// the end of a pass (h2g_go_kernels.h): a launch with orphan_T > 0 lists the pool entries of the reads its workgroups still held when they could fetch no more and had thinned
-	// out to orphan_T reads, and a drain launch (adopt_list) of the same kernel over the same pool takes them up in place
-	uint32_t orphan_T; uint32_t* orphan_list; uint32_t* orphan_count;
-	const uint32_t* adopt_list; const uint32_t* adopt_count;
 };
 #define H2G_PK_LANE_WORDS_HOST (H2G_PK_WORDS + H2G_PK_WORDS / 2)
 

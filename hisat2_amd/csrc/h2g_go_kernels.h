@@ -72,8 +72,6 @@ __device__ __forceinline__ bool pack_read(const DReads& rd, uint32_t i, uint32_t
 static_assert(H2G_GO_NQ <= 64, "the ring census is one lane per ring");
 struct GoLds {
 	uint32_t head[H2G_GO_NQ], tail[H2G_GO_NQ];
-	uint32_t quit;                              // the workgroup hands its reads in flight on (GoArgs::orphan_T)
-	uint32_t gslot[H2G_GO_SLOTS];               // where slot k's state lives in the pool: the workgroup's own k-th entry, or — in a drain launch — the entry of the read it took up
 	uint16_t ring[H2G_GO_NQ][H2G_GO_SLOTS];
 };
 
@@ -167,8 +165,8 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	for(uint32_t k = threadIdx.x; k < (uint32_t)H2G_GO_NQ * H2G_GO_SLOTS; k += blockDim.x) (&Q->ring[0][0])[k] = H2G_RING_EMPTY;
 	if(threadIdx.x < (uint32_t)H2G_GO_NQ) { Q->head[threadIdx.x] = 0; Q->tail[threadIdx.x] = 0; }
 	__syncthreads();
-	for(uint32_t k = threadIdx.x; k < H2G_GO_SLOTS; k += blockDim.x) { Q->ring[0][k] = (uint16_t)k; Q->gslot[k] = blockIdx.x * H2G_GO_SLOTS + k; }   // every slot starts free
-	if(threadIdx.x == 0) { Q->tail[0] = H2G_GO_SLOTS; Q->quit = 0; }
+	for(uint32_t k = threadIdx.x; k < H2G_GO_SLOTS; k += blockDim.x) Q->ring[0][k] = (uint16_t)k;   // every slot starts free
+	if(threadIdx.x == 0) Q->tail[0] = H2G_GO_SLOTS;
 	__syncthreads();
 	AlnCtx C; C.g = &A.g; C.ref = &A.ref; C.ls = &A.ls; C.P = &A.P;
 	C.sw = A.sw_base ? A.sw_base + tid * A.sw_stride : nullptr;
@@ -179,12 +177,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	ctx_ext_opts(C, A.P);
 #endif
 	C.alts = &A.alts; C.gws = A.gws_base ? (GraphWS*)(A.gws_base + tid * A.gws_stride) : nullptr; C.graph = GRAPH;
-	// The end of a pass (round 6).  The machine's pass behind a fast pass is one long decay: its few hundred reads per workgroup are all in flight at once and leave
-	// one by one, the last after ten times the mean.  With GoArgs::orphan_T a workgroup whose population has thinned out lists the pool entries of what it still holds and leaves;
-	// a drain launch of this kernel (GoArgs::adopt_list) takes them up IN PLACE on a quarter of the workgroups — an entry of `gslot` per read, nothing is copied — so the tail holds
-	// a few CUs instead of the pass's whole share.
-	const bool adopt = A.adopt_list != nullptr;
-	const uint32_t orphan_T = adopt ? 0u : A.orphan_T;
+	const size_t slot0 = (size_t)blockIdx.x * H2G_GO_SLOTS;
 	Mach M;
 	M.rd[0] = A.rd1; M.rd[1] = paired ? A.rd2 : A.rd1;
 	uint32_t* const my_pk0 = s_pk + threadIdx.x;
@@ -194,7 +187,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 	M.name[0] = M.name[1] = nullptr; M.namelen[0] = M.namelen[1] = 0; M.read = 0;
 	M.ws = nullptr;
 	M.out = &A.O; M.paired_input = paired;
-	const uint32_t total = adopt ? *A.adopt_count : (A.list ? *A.nlist : A.rd1.n);
+	const uint32_t total = A.list ? *A.nlist : A.rd1.n;
 	unsigned long long nrank = 0, nsteps = 0, naln = 0, novf = 0, nside = 0;
 	bool more = true;                                         // reads left in the batch (wave-local view)
 #ifdef H2G_GO_PROF
@@ -220,16 +213,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 			if(oc > bestc || (oc == bestc && oq < bestq)) { bestc = oc; bestq = oq; }
 		}
 		bestc = (uint32_t)__shfl((int)bestc, 0); bestq = (uint32_t)__shfl((int)bestq, 0);
-		if(orphan_T) {
-			uint32_t quit = 0;
-			if(lane == 0) {
-				quit = __atomic_load_n(&Q->quit, __ATOMIC_RELAXED);
-				if(!quit && !more && H2G_GO_SLOTS - nfree <= orphan_T) { __atomic_store_n(&Q->quit, 1u, __ATOMIC_RELAXED); quit = 1; }
-			}
-			if(__shfl((int)quit, 0)) break;       // (a wave holds no slot between two trips: everything in flight waits in the rings, listed behind the loop)
-		}
 		const bool fetch = more && nfree > 0 && (bestc < 64 || nfree >= H2G_GO_SLOTS / 4);
-		bool taken_up = false;      // (drain launch) this lane's slot was filled with a read another launch left in flight: it goes to the ring of its request as it is
 		bool have = false;          // this lane carries a slot in this trip
 		uint32_t slot = 0;
 		GoSlot* gs = nullptr;
@@ -246,17 +230,10 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 			if(base + n >= total) more = false;
 			const bool got = (uint32_t)lane < n && base + (uint32_t)lane < total;
 			ring_push(Q, (uint32_t)lane < n && !got, 0, slot, lane);      // slots without a read go back
-			if(got && adopt) {
-				have = true; taken_up = true;
-				const uint32_t gi = A.adopt_list[base + (uint32_t)lane];
-				Q->gslot[slot] = gi;
-				M.ws = (AlignWS*)(A.pool + (size_t)gi * A.ws_stride);
-				gs = (GoSlot*)((uint8_t*)M.ws + A.slot_off);
-				M.L = gs->L;
-			} else if(got) {
+			if(got) {
 				have = true;
 				const uint32_t i = A.list ? A.list[base + (uint32_t)lane] : base + (uint32_t)lane;
-				M.ws = (AlignWS*)(A.pool + (size_t)Q->gslot[slot] * A.ws_stride);
+				M.ws = (AlignWS*)(A.pool + (slot0 + slot) * A.ws_stride);
 				gs = (GoSlot*)((uint8_t*)M.ws + A.slot_off);
 				C.gsl = GRAPH ? (GraphSlot*)((uint8_t*)M.ws + A.gsl_off) : nullptr;
 				gs->read = i;
@@ -299,7 +276,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			have = (uint32_t)lane < n;
 			if(have) {
-				M.ws = (AlignWS*)(A.pool + (size_t)Q->gslot[slot] * A.ws_stride);
+				M.ws = (AlignWS*)(A.pool + (slot0 + slot) * A.ws_stride);
 				gs = (GoSlot*)((uint8_t*)M.ws + A.slot_off);
 				C.gsl = GRAPH ? (GraphSlot*)((uint8_t*)M.ws + A.gsl_off) : nullptr;
 				M.L = gs->L;
@@ -321,8 +298,7 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 		}
 		// ---- control flow of each read up to its next primitive request; then hand the slots on
 		uint32_t nextq = 0;
-		if(have && taken_up) nextq = mach_site_of(M.L.pc);
-		else if(have) {
+		if(have) {
 			if(M.L.pc != PC_FINISHED) mach_step(C, M);
 			if(M.L.pc == PC_FINISHED && M.L.op == OP_NONE) {       // OP_FINISH ran: account, the slot is free
 				nrank += M.ws->nrank; nsteps += M.ws->nsteps; nside += M.ws->nside;
@@ -342,23 +318,6 @@ __global__ __launch_bounds__(H2G_GO_THREADS, WAVES_PER_SIMD) void k_go(GoArgs A)
 #ifdef H2G_GO_PROF
 		tp1 = __builtin_readcyclecounter(); prof[1] += tp1 - tp0; prof_ctl[trip_op] += tp1 - tp0; tp0 = tp1;
 #endif
-	}
-	if(orphan_T) {
-		// what waits in the rings: listed (pool entries) once every wave has left the loop; a workgroup that ran dry has empty rings
-		__syncthreads();
-		if(Q->quit) {
-			for(uint32_t q = 1 + (threadIdx.x >> 6); q < (uint32_t)H2G_GO_NQ; q += H2G_GO_THREADS / 64) {
-				const uint32_t h = Q->head[q], n = Q->tail[q] - h;
-				for(uint32_t i0 = 0; i0 < n; i0 += 64) {
-					const bool v = i0 + (uint32_t)lane < n;
-					const unsigned long long m = __ballot(v);
-					uint32_t base = 0;
-					if(lane == 0) base = atomicAdd(A.orphan_count, (uint32_t)__popcll(m));
-					base = (uint32_t)__shfl((int)base, 0);
-					if(v) A.orphan_list[base + (uint32_t)lane] = Q->gslot[Q->ring[q][(h + i0 + (uint32_t)lane) & (H2G_GO_SLOTS - 1)]];
-				}
-			}
-		}
 	}
 #ifdef H2G_GO_PROF
 	if(lane == 0) for(int k = 0; k < 48; k++) if(prof[k]) atomicAdd(A.counters + 16 + k, prof[k]);

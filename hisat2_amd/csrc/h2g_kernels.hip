@@ -81,11 +81,6 @@ struct h2g_index {
 #define H2G_ORPHAN_MIN_UNITS 200000
 #define H2G_DRAIN_GRID 64
 #define H2G_FAST_POOLS 3
-// ... and of a machine pass (h2g_go_kernels.h): its workgroups leave at H2G_MACH_ORPHAN_T reads in flight, a drain launch of the same kernel on a quarter of them (at least two) takes
-// the listed reads up in place (h2g_stream_tune "mach_orphan": -1 this policy for batches of H2G_ORPHAN_MIN_UNITS and more, 0 off, n the threshold; "mach_drain_div")
-#define H2G_MACH_ORPHAN_T 256
-#define H2G_MACH_DRAIN_DIV 4
-#define H2G_MACH_ORPH_CAP (256u * 1024u)
 #define H2G_DEFAULT_ALIGN_MATE 0
 #ifdef H2G_GO_PROF
 #define H2G_CNT_BLOCK 1024u         // (+ the time-resolved bins of h2g_fast_prof.h at [512, 768))
@@ -160,14 +155,13 @@ struct h2g_stream {
 	hipEvent_t ev_bails[H2G_NBUF];                                   // h_bails[gen % NBUF] has arrived
 	hipEvent_t ev_dr[2];                                             // (timed) around the last drain launch
 	bool ran_drain = false;
-	uint32_t* d_mach_orph[H2G_MSTREAMS_MAX] = {};                    // per machine stream: pool entries a machine launch left in flight (+ their count behind the list)
 	const uint32_t* orph_cur = nullptr;                              // the orphan count of the last run
 	uint8_t* d_fast_gws = nullptr; size_t fast_gws_bytes = 0;       // graph indexes: GraphWS per lane of the fast kernel (scratch of one primitive)
 	uint8_t* d_fast_sc = nullptr; size_t fast_sc_bytes = 0;         // ... and combineWith's temp_scores per lane
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
 	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int mach_total_auto = 1; int fast_reserve = H2G_FAST_RESERVE_DEFAULT; long dbg_read = -1;
-	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; int orphan = -1 /* auto */, drain_grid = H2G_DRAIN_GRID, mate_handover = -1 /* auto */, mach_orphan = -1 /* auto */, mach_drain_div = H2G_MACH_DRAIN_DIV; } tune;
+	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; int orphan = -1 /* auto */, drain_grid = H2G_DRAIN_GRID, mate_handover = -1 /* auto */; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
@@ -531,7 +525,6 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
 		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
 		s->tune.orphan = (int)env("H2G_FAST_ORPHAN", -1); s->tune.drain_grid = (int)env("H2G_DRAIN_GRID", H2G_DRAIN_GRID); s->tune.mate_handover = (int)env("H2G_FAST_MATE_HANDOVER", -1);
-		s->tune.mach_orphan = (int)env("H2G_MACH_ORPHAN", -1); s->tune.mach_drain_div = (int)env("H2G_MACH_DRAIN_DIV", H2G_MACH_DRAIN_DIV);
 		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.mach_total_auto = getenv("H2G_MACH_TOTAL") ? 0 : 1; s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", H2G_FAST_RESERVE_DEFAULT);
 		{ const long m = env("H2G_MSTREAMS", H2G_MSTREAMS_DEFAULT); s->mstreams = (unsigned)(m < 1 ? 1 : m > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : m); }
 	}
@@ -544,7 +537,7 @@ extern "C" void h2g_stream_free(h2g_stream* s) {
 	(void)hipStreamSynchronize(s->st); (void)hipStreamSynchronize(s->dst); for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipStreamSynchronize(s->mst[k]);
 	(void)hipFree(s->d_codes); (void)hipFree(s->d_quals); (void)hipFree(s->d_offs); (void)hipFree(s->d_seed);
 	(void)hipFree(s->d_counters); (void)hipFree(s->d_names); (void)hipFree(s->d_name_offs); for(int k = 0; k < 2 * H2G_MSTREAMS_MAX; k++) { (void)hipFree(s->pool[k].ws); (void)hipFree(s->pool[k].gws); (void)hipFree(s->pool[k].sw); (void)hipFree(s->pool[k].sc); }
-	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) { (void)hipFree(s->d_ovf_list[k]); (void)hipFree(s->d_mach_orph[k]); }
+	for(int k = 0; k < H2G_MSTREAMS_MAX; k++) (void)hipFree(s->d_ovf_list[k]);
 	for(int k = 0; k < H2G_NBUF; k++) { (void)hipFree(s->d_bail_list[k]); (void)hipFree(s->d_fast_args[k]); (void)hipFree(s->d_fast_args[H2G_NBUF + k]); (void)hipFree(s->d_orphans[k]); (void)hipEventDestroy(s->ev_fast[k]); (void)hipEventDestroy(s->ev_mach[k]); (void)hipEventDestroy(s->ev_bails[k]); (void)hipEventDestroy(s->ev_drain[k]); }
 	for(int k = 0; k < H2G_FAST_POOLS; k++) { (void)hipFree(s->d_fast_slots[k]); (void)hipEventDestroy(s->ev_pool[k]); }
 	(void)hipFree(s->d_drain_slots); (void)hipFree(s->d_drain_sc);
@@ -2068,7 +2061,6 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 				if(!big_main && !s->tune.no_second_pass && (rc = go_pool_for(s, 2 * (int)m_ + 1, Bp, (size_t)bgrid * bgeo_[1], (size_t)bgrid * bgeo_[0], p->bowtie2_dp, &scratch))) return rc;
 				// ... and its overflow list, and the stream itself (a HIP stream gets its hardware queue when it is first used)
 				if(!s->d_ovf_list[m_]) { HIPCHK(hipMalloc((void**)&s->d_ovf_list[m_], (s->max_reads + 4) * 4)); HIPCHK(hipMemsetAsync(s->d_ovf_list[m_] + s->max_reads, 0, 16, s->mst[m_])); }
-				if(!s->d_mach_orph[m_]) { HIPCHK(hipMalloc((void**)&s->d_mach_orph[m_], ((size_t)H2G_MACH_ORPH_CAP + 4) * 4)); HIPCHK(hipMemsetAsync(s->d_mach_orph[m_], 0, ((size_t)H2G_MACH_ORPH_CAP + 4) * 4, s->mst[m_])); }
 			}
 			for(unsigned b_ = 0; b_ < M + 1; b_++) {      // the per-run buffers of every generation
 				if(!s->d_bail_list[b_]) HIPCHK(hipMalloc((void**)&s->d_bail_list[b_], (s->max_reads + 4) * 4));
@@ -2371,27 +2363,7 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 		s->mstreams_warm = true;
 	}
 	HIPCHK(hipEventRecord(s->ev[7], ms));
-	// the end of the machine's pass: its workgroups leave when they have thinned out, a drain launch of the same kernel takes what they held up in place (h2g_go_kernels.h)
-	const size_t units_m = paired ? (size_t)s->n_reads : ((size_t)s->n_reads + 1) / 2;
-	const uint32_t m_orphan = s->tune.mach_orphan >= 0 ? (uint32_t)s->tune.mach_orphan : (units_m >= H2G_ORPHAN_MIN_UNITS ? (uint32_t)H2G_MACH_ORPHAN_T : 0u);
-	if(m_orphan && mach_grid >= 2 && (size_t)mach_grid * geo[1] <= H2G_MACH_ORPH_CAP) {
-		if(!s->d_mach_orph[psel]) HIPCHK(hipMalloc((void**)&s->d_mach_orph[psel], ((size_t)H2G_MACH_ORPH_CAP + 4) * 4));
-		uint32_t* const ml = s->d_mach_orph[psel];
-		HIPCHK(hipMemsetAsync(ml + H2G_MACH_ORPH_CAP, 0, 16, ms));
-		A.orphan_T = m_orphan > geo[1] ? geo[1] : m_orphan; A.orphan_list = ml; A.orphan_count = ml + H2G_MACH_ORPH_CAP;
-	}
 	if(U.launch(&A, mach_grid, ms) != 0) return set_err("go() launch", hipGetLastError());
-	if(A.orphan_T) {
-		GoArgs A3 = A;
-		A3.orphan_T = 0; A3.orphan_list = nullptr; A3.orphan_count = nullptr;
-		A3.adopt_list = A.orphan_list; A3.adopt_count = A.orphan_count;
-		A3.work = reinterpret_cast<uint32_t*>(cblk + 9);
-		unsigned dg = mach_grid / (unsigned)(s->tune.mach_drain_div < 1 ? 1 : s->tune.mach_drain_div);
-		if(dg < 2) dg = 2;
-		if(dg > mach_grid) dg = mach_grid;
-		if(U.launch(&A3, dg, ms) != 0) return set_err("go() machine drain launch", hipGetLastError());
-		A.orphan_T = 0; A.orphan_list = nullptr; A.orphan_count = nullptr;       // (the second pass below copies A)
-	}
 	HIPCHK(hipEventRecord(s->ev[6], ms));
 	if(second) {
 		const GoUnit& B = go_unit(linear, true, spl);
@@ -2745,7 +2717,6 @@ extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream
 	else if(k == "mach_total") { s->tune.mach_total_auto = v <= 0; s->tune.mach_total = v <= 0 ? H2G_MACH_TOTAL : (unsigned)v; }      // (0 = the default policy)
 	else if(k == "fast_reserve") s->tune.fast_reserve = (int)v;
 	else if(k == "mate_handover") s->tune.mate_handover = (int)v;
-	else if(k == "mach_orphan") s->tune.mach_orphan = (int)v; else if(k == "mach_drain_div") s->tune.mach_drain_div = (int)(v < 1 ? 1 : v);
 	else if(k == "orphan") s->tune.orphan = (int)v; else if(k == "drain_grid") s->tune.drain_grid = (int)(v < 1 ? 1 : v > 128 ? 128 : v);
 	else if(k == "mstreams") { s->mstreams = (unsigned)(v < 1 ? 1 : v > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : v); s->gen = 0; }   // (nothing is in flight: every buffer set is free)
 	else return H2G_ERR_ARG;

@@ -36,10 +36,6 @@ BUILD = os.path.join(ROOT, "oracle", "_ref", "hisat2-build-s")
     dict(seed=76, npairs=100000, nreads=20000, rdlen=101, sub=0.01, repeat_genome=True, env={"H2G_FAST_ORPHAN": "200", "H2G_DRAIN_GRID": "8", "H2G_FAST_MATE_HANDOVER": "1"}, adopted=True),
     dict(seed=72, npairs=60000, nreads=20000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_FAST_ORPHAN": "64", "H2G_DRAIN_GRID": "16", "H2G_FAST_MATE_HANDOVER": "1"}, adopted=True),
     dict(seed=77, npairs=150000, nreads=20000, rdlen=101, sub=0.005, env={"H2G_FAST_ORPHAN": "512", "H2G_DRAIN_GRID": "32", "H2G_FAST_MATE_HANDOVER": "1", "H2G_FAST_TAIL": "16"}, adopted=True),
-    # the end of the MACHINE's pass: its workgroups leave at <= H2G_MACH_ORPHAN reads in flight, a drain launch of the same kernel takes them up in place (h2g_go_kernels.h)
-    dict(seed=72, npairs=60000, nreads=60000, rdlen=76, sub=0.03, indel=0.002, nrate=0.002, least=0.25, env={"H2G_MACH_ORPHAN": "100", "H2G_MACH_DRAIN_DIV": "2"}),
-    dict(seed=74, npairs=40000, nreads=40000, rdlen=90, sub=0.02, indel=0.002, snps=120, least=0.25, env={"H2G_MACH_ORPHAN": "300", "H2G_MACH_DRAIN_DIV": "4", "H2G_FAST_ORPHAN": "128", "H2G_DRAIN_GRID": "8"}),
-    dict(seed=75, npairs=120000, nreads=60000, rdlen=101, sub=0.005, repeat_genome=True, env={"H2G_MACH_ORPHAN": "32", "H2G_MACH_DRAIN_DIV": "8", "H2G_FAST_ORPHAN": "256", "H2G_DRAIN_GRID": "16", "H2G_FAST_MATE_HANDOVER": "1"}),
 ])
 def test_fast_pass_equals_the_machine(case):
     tmp = tempfile.mkdtemp(prefix="h2fp")

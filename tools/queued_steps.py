@@ -3,7 +3,7 @@
 of queued runs for several (mstreams, mach_total, fast_reserve, mach_div) settings of h2g_stream_tune, with a checksum of every result record per setting
 (it must not move) and the kernels' own times.  One JSON line per setting.
 
-usage: queued_steps.py rep|rnd|graph GENOME_BP [pairs=1000000] [settings "M,total,reserve,div[,orphan[,drain_grid[,mate_handover[,mach_orphan[,mach_drain_div]]]]];..."]"""
+usage: queued_steps.py rep|rnd|graph GENOME_BP [pairs=1000000] [settings "M,total,reserve,div[,orphan[,drain_grid]];..."]"""
 import ctypes as C, json, os, subprocess, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -71,8 +71,7 @@ def main():
         f_ = [int(x) for x in sset.split(",")]
         M, total, reserve, div = f_[:4]
         orphan, dgrid = (f_[4] if len(f_) > 4 else -1), (f_[5] if len(f_) > 5 else 32)
-        tune(st, "mate_handover", f_[6] if len(f_) > 6 else -1)
-        tune(st, "mach_orphan", f_[7] if len(f_) > 7 else -1); tune(st, "mach_drain_div", f_[8] if len(f_) > 8 else 4)      # (the end of a machine pass: h2g_go_kernels.h)      # (the end of the batch: h2g_stream_tune "orphan" -1 = the default policy, 0 = off; "drain_grid")
+        tune(st, "mate_handover", f_[6] if len(f_) > 6 else -1)      # (the end of the batch: h2g_stream_tune "orphan" -1 = the default policy, 0 = off; "drain_grid")
         tune(st, "mstreams", M); tune(st, "mach_total", total); tune(st, "fast_reserve", reserve); tune(st, "mach_div", div); tune(st, "orphan", orphan); tune(st, "drain_grid", dgrid)
         for _ in range(M + 2):                      # (each machine stream allocates its workspace on its first pass)
             st.align_pairs_run()
@@ -91,7 +90,7 @@ def main():
         del a1, a2, res
         if first_ck is None:
             first_ck = ck
-        print(json.dumps({"mstreams": M, "mach_total": total, "fast_reserve": reserve, "mach_div": div, "orphan": orphan, "drain_grid": dgrid, "mate_handover": (f_[6] if len(f_) > 6 else -1), "mach_orphan": (f_[7] if len(f_) > 7 else -1), "mach_drain_div": (f_[8] if len(f_) > 8 else 4), "drain_ms_solo": round(float(c.ms_drain_kernel), 2), "adopted": int(c.n_adopted), "ms_per_step": round(dt * 1e3, 2), "reads_per_s": round(2 * n / dt),
+        print(json.dumps({"mstreams": M, "mach_total": total, "fast_reserve": reserve, "mach_div": div, "orphan": orphan, "drain_grid": dgrid, "mate_handover": (f_[6] if len(f_) > 6 else -1), "drain_ms_solo": round(float(c.ms_drain_kernel), 2), "adopted": int(c.n_adopted), "ms_per_step": round(dt * 1e3, 2), "reads_per_s": round(2 * n / dt),
                           "fast_kernel_ms_solo": round(float(c.ms_fast_kernel), 2), "machine_pass_ms_solo": round(float(c.ms_align_kernel), 2), "handed_on": int(c.n_fast_bail),
                           "second_pass": int(c.n_second_pass), "flagged": int(c.n_overflow), "concordant": int(c.n_aligned), "records_crc": "%08x" % ck, "crc_same_as_first": ck == first_ck}), flush=True)
     st.close(); ix.close()
