@@ -111,7 +111,7 @@ if hasattr(L, "h2g_go_fast_prof"):
             ops = "NONE PSEARCH GCOORDS EXTEND LSEARCH LCOORDS COMBINE GSEARCH ADJUST ADJMEMBER".split()
             tot = sum(v[k] for k in range(0, 18))
             print("  trips %d, slots per trip %.1f, wave-ticks %d; slots LOADED from their slot per slot-trip %.2f (the others stayed in their lane), - %.2f" % (v[47], v[46] / max(1, v[47]), tot, v[44] / max(1, v[46]), v[45] / max(1, v[47])))
-            for k, nm in ((0, "pop+load"), (1, "control"), (2, "store"), (16, "release fence"), (17, "push"), (15, "new reads")):
+            for k, nm in ((0, "pop+load"), (1, "control"), (2, "store"), (16, "hand-on list"), (17, "release fence + push"), (15, "new reads")):
                 print("  %-20s %5.1f %%" % (nm, 100.0 * v[k] / tot))
             sites = ["FETCH", "P", "G", "E:HS", "E", "l", "c", "C", "g", "A", "a", "E:slow", "walk:slow"]
             print("  control by site (us per trip, trips, %% of wave time):", "  ".join("%s %.1f/%d/%.1f%%" % (sites[k] if k < len(sites) else k, v[72 + k] / max(1, v[104 + k]) / 2400.0, v[104 + k], 100.0 * v[72 + k] / tot) for k in range(32) if v[104 + k]))
