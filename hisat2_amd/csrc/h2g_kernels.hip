@@ -662,13 +662,28 @@ static unsigned grid_for(size_t n, unsigned block) {
 
 // ------------------------------------------------------------------------------------------ rank kernels
 // variant 0: one lane per query, 4 x dwordx4 per side
+// The row of a synthetic query: the high word of the hash scaled into [0, gbwtLen) — ONE v_mul_hi.  Through round 6 this was `h % gbwtLen`: a 64-bit modulo, ~45 vector and ~55 scalar
+// instructions per query next to the rank's own ~120 — the micro-benchmark was measuring its own generator (issue time 3.3 of its 5.8 ms: that, not the request pattern, was the gap to the
+// chain kernel's 3.5 TB/s).  tests/rank_synth_check.py draws the same rows on the host.
+__device__ __forceinline__ uint32_t synth_row(uint64_t h, uint32_t n) { return (uint32_t)(((h >> 32) * (uint64_t)n) >> 32); }
 __global__ __launch_bounds__(256) void k_rank_v0(DGfm g, const uint32_t* rows, const uint8_t* cs, uint32_t* out,
                                                  size_t n, uint64_t seed, int synth)
 {
 	size_t stride = (size_t)gridDim.x * blockDim.x;
 	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
 		uint32_t row; int c;
-		if(synth) { uint64_t h = splitmix64(seed + i); row = (uint32_t)(h % g.gbwtLen); c = (int)((h >> 40) & 3); }
+		if(synth) { uint64_t h = splitmix64(seed + i); row = synth_row(h, g.gbwtLen); c = (int)((h >> 40) & 3); }
+		else { row = rows[i]; c = cs[i]; }
+		out[i] = rank64(g, row, c);
+	}
+}
+
+__global__ __launch_bounds__(512) void k_rank_v0_512(DGfm g, const uint32_t* rows, const uint8_t* cs, uint32_t* out, size_t n, uint64_t seed, int synth)
+{
+	size_t stride = (size_t)gridDim.x * blockDim.x;
+	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+		uint32_t row; int c;
+		if(synth) { uint64_t h = splitmix64(seed + i); row = synth_row(h, g.gbwtLen); c = (int)((h >> 40) & 3); }
 		else { row = rows[i]; c = cs[i]; }
 		out[i] = rank64(g, row, c);
 	}
@@ -683,7 +698,7 @@ __global__ __launch_bounds__(256) void k_rank_v0_sampled(DGfm g, uint32_t* out, 
 	unsigned long long acc = 0;
 	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
 		const uint64_t h = splitmix64(seed + i);
-		const uint32_t r = rank64(g, (uint32_t)(h % g.gbwtLen), (int)((h >> 40) & 3));
+		const uint32_t r = rank64(g, synth_row(h, g.gbwtLen), (int)((h >> 40) & 3));
 		if((i & 255) == 0) out[i] = r;
 		acc += (unsigned long long)r * (unsigned long long)((i & 1023) + 1);
 	}
@@ -706,7 +721,7 @@ __global__ __launch_bounds__(256) void k_rank_v1(DGfm g, const uint32_t* rows, c
 		for(int u = 0; u < UNROLL; u++) {
 			size_t i = base + u;
 			bool ok = i < n;
-			if(synth) { uint64_t h = splitmix64(seed + (ok ? i : 0)); row[u] = (uint32_t)(h % g.gbwtLen); c[u] = (int)((h >> 40) & 3); }
+			if(synth) { uint64_t h = splitmix64(seed + (ok ? i : 0)); row[u] = synth_row(h, g.gbwtLen); c[u] = (int)((h >> 40) & 3); }
 			else { row[u] = ok ? rows[i] : 0; c[u] = ok ? cs[i] : 0; }
 			sideNum[u] = row[u] / 192u; charOff[u] = row[u] - sideNum[u] * 192u;
 			v[u] = reinterpret_cast<const uint4*>(g.sides + (size_t)sideNum[u] * 64)[sub];
@@ -743,7 +758,7 @@ __global__ __launch_bounds__(256) void k_rank_v2(DGfm g, const uint32_t* rows, c
 		for(int u = 0; u < UNROLL; u++) {
 			size_t i = base + u;
 			bool ok = i < n;
-			if(synth) { uint64_t h = splitmix64(seed + (ok ? i : 0)); row[u] = (uint32_t)(h % g.gbwtLen); c[u] = (int)((h >> 40) & 3); }
+			if(synth) { uint64_t h = splitmix64(seed + (ok ? i : 0)); row[u] = synth_row(h, g.gbwtLen); c[u] = (int)((h >> 40) & 3); }
 			else { row[u] = ok ? rows[i] : 0; c[u] = ok ? cs[i] : 0; }
 			sideNum[u] = row[u] / 192u; charOff[u] = row[u] - sideNum[u] * 192u;
 			w[u] = reinterpret_cast<const uint64_t*>(g.sides + (size_t)sideNum[u] * 64)[sub];
@@ -773,7 +788,7 @@ __global__ __launch_bounds__(256) void k_rank_exp(DGfm g, uint32_t* out, size_t 
 	size_t stride = (size_t)gridDim.x * blockDim.x;
 	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride * (MODE == 5 ? 2 : 1)) {
 		uint64_t h = splitmix64(seed + i);
-		uint32_t row = (uint32_t)(h % g.gbwtLen); int c = (int)((h >> 40) & 3);
+		uint32_t row = synth_row(h, g.gbwtLen); int c = (int)((h >> 40) & 3);
 		if(MODE == 3) {
 			uint32_t sideNum = row / 192u;
 			const uint4* q = reinterpret_cast<const uint4*>(g.sides + (size_t)(sideNum ^ 1u) * 64);
@@ -790,7 +805,7 @@ __global__ __launch_bounds__(256) void k_rank_exp(DGfm g, uint32_t* out, size_t 
 		} else {
 			size_t j = i + stride;
 			uint64_t h2 = splitmix64(seed + (j < n ? j : i));
-			uint32_t row2 = (uint32_t)(h2 % g.gbwtLen); int c2 = (int)((h2 >> 40) & 3);
+			uint32_t row2 = synth_row(h2, g.gbwtLen); int c2 = (int)((h2 >> 40) & 3);
 			uint32_t s1 = row / 192u, s2 = row2 / 192u;
 			Side64 a = load_side64(g.sides + (size_t)s1 * 64), b = load_side64(g.sides + (size_t)s2 * 64);
 			out[i] = rank_in_side64(g, a, s1, row - s1 * 192u, c);
@@ -807,7 +822,7 @@ __global__ __launch_bounds__(256) void k_rank_g0(DGfm g, const uint32_t* rows, c
 	size_t stride = (size_t)gridDim.x * blockDim.x;
 	for(size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
 		uint32_t row; int c;
-		if(synth) { uint64_t h = splitmix64(seed + i); row = (uint32_t)(h % g.gbwtLen); c = (int)((h >> 40) & 3); }
+		if(synth) { uint64_t h = splitmix64(seed + i); row = synth_row(h, g.gbwtLen); c = (int)((h >> 40) & 3); }
 		else { row = rows[i]; c = cs[i]; }
 		out[i] = rank128(g, row, c);
 	}
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(256) void k_rank_g1(DGfm g, const uint32_t* rows, c
 			ok[u] = i < n;
 			uint32_t row = 0; int c = 0;
 			if(ok[u]) {
-				if(synth) { uint64_t h = splitmix64(seed + i); row = (uint32_t)(h % g.gbwtLen); c = (int)((h >> 40) & 3); }
+				if(synth) { uint64_t h = splitmix64(seed + i); row = synth_row(h, g.gbwtLen); c = (int)((h >> 40) & 3); }
 				else { row = rows[i]; c = cs[i]; }
 			}
 			sn[u] = row / H2G_GSIDE_SYMS; off[u] = row - sn[u] * H2G_GSIDE_SYMS; cc[u] = c;
@@ -896,6 +911,9 @@ static int launch_rank(h2g_stream* s, const uint32_t* d_rows, const uint8_t* d_c
 		} else if(variant == 10 && synth) {
 			HIPCHK(hipMemsetAsync(s->d_counters + 6, 0, 8, s->st));
 			hipLaunchKernelGGL(k_rank_v0_sampled, dim3(grid_for(n, 256)), dim3(256), 0, s->st, g, d_out, n, seed, s->d_counters + 6);
+		} else if(variant == 11 || variant == 12) {
+			// variant 0's loop in the chain kernel's geometry: ONE 512-thread workgroup per CU (11), two (12)
+			hipLaunchKernelGGL(k_rank_v0_512, dim3(variant == 11 ? 256u : 512u), dim3(512), 0, s->st, g, d_rows, d_cs, d_out, n, seed, synth);
 		} else if(variant >= 6 && variant <= 9) {
 			// variant 0's kernel at a fraction of the chip's occupancy (measurement: the chain kernel sustains more random 64 B requests per second at one 512-thread
 			// workgroup per CU than at full occupancy — profiles/r05_NOTES.md): 6: 16 waves per CU, 7: 8, 8: 4, 9: 2

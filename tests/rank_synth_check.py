@@ -43,10 +43,10 @@ def synth_linear_sides(nsides, seed, chunk=1 << 20):
 
 
 def queries(seed, idx, gbwt_len):
-    """(row, c) of query i as the rank kernels draw it: h = splitmix64(seed + i), row = h % gbwtLen, c = (h >> 40) & 3"""
+    """(row, c) of query i as the rank kernels draw it: h = splitmix64(seed + i), row = ((h >> 32) * gbwtLen) >> 32 (synth_row of h2g_kernels.hip), c = (h >> 40) & 3"""
     with np.errstate(over="ignore"):
         h = splitmix64((np.uint64(seed) + idx.astype(np.uint64)) & M64)
-    return (h % np.uint64(gbwt_len)).astype(np.uint32), ((h >> np.uint64(40)) & np.uint64(3)).astype(np.int32)
+    return (((h >> np.uint64(32)) * np.uint64(gbwt_len)) >> np.uint64(32)).astype(np.uint32), ((h >> np.uint64(40)) & np.uint64(3)).astype(np.int32)
 
 
 def oracle_map_lf(olib, sides, fchr, nsides, rows, cs):
