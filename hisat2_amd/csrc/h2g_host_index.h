@@ -98,6 +98,15 @@ struct FileView {
 	FileView() {}
 	FileView(const FileView&) = delete;
 	FileView& operator=(const FileView&) = delete;
+	void take(FileView& o) { if(p) munmap((void*)p, n); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+};
+// The three big arrays of the global index — sides, SA sample, reference bases: 2.6 GB of a human-size index — left WHERE THEY ARE in the mapped files (load_host_index with a
+// BigViews*): a loader that only hands them on to a device has no use for a copy in host vectors (1 GB of memcpy and 1.6 GB of zero-fill + memcpy on the loading thread, round 6).
+struct BigViews {
+	FileView f1, f2, f4;                 // keep the mappings alive
+	const uint8_t* sides = nullptr; size_t sides_n = 0;
+	const uint8_t* offs = nullptr;  size_t offs_n = 0;     // bytes (u32 entries)
+	const uint8_t* buf = nullptr;   size_t buf_n = 0;
 };
 class Reader {
 public:
@@ -130,14 +139,15 @@ public:
 	bool bad = false;
 };
 
-inline bool read_gfm_body(Reader& b, HostGfm& g, bool light = false) {
+inline bool read_gfm_body(Reader& b, HostGfm& g, bool light = false, const uint8_t** sides_view = nullptr) {
 	const int wsz = g.p.wsz;
 	g.nPat = b.w(wsz);
 	b.arr(g.plen, wsz, g.nPat);
 	g.nFrag = b.w(wsz);
 	b.arr(g.rstarts, wsz, (size_t)g.nFrag * 3);
 	if(!b.has(g.p.gbwtTotLen)) return false;
-	if(!light) g.sides.assign(b.d.begin() + b.pos, b.d.begin() + b.pos + g.p.gbwtTotLen);
+	if(sides_view) *sides_view = b.d.begin() + b.pos;
+	else if(!light) g.sides.assign(b.d.begin() + b.pos, b.d.begin() + b.pos + g.p.gbwtTotLen);
 	b.pos += g.p.gbwtTotLen;
 	uint32_t nZ = b.w(wsz);
 	b.arr(g.zOffs, wsz, nZ);
@@ -150,7 +160,7 @@ inline bool read_gfm_body(Reader& b, HostGfm& g, bool light = false) {
 
 // returns 0 ok, -1 io, -2 format.  light: names, lengths, fragment table, reference records and ALTs only (no sides, SA sample, ftab or
 // reference bases: the SAM formatter's view of an index)
-inline int load_host_index(const std::string& base, bool load_local, HostIndex& ix, bool light = false) {
+inline int load_host_index(const std::string& base, bool load_local, HostIndex& ix, bool light = false, BigViews* bv = nullptr) {
 	Reader b1, b2, b3, b4;
 	if(!b1.open(base + ".1.ht2") || !b2.open(base + ".2.ht2") || !b3.open(base + ".3.ht2") || !b4.open(base + ".4.ht2")) return -1;
 	if(b1.u32() != 1) return -2;
@@ -161,7 +171,8 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 	uint32_t eftabLen = b1.u32(); b1.u32();
 	if(lineRate < 6 || lineRate > 8 || ftabChars < 1 || ftabChars > 14 || offRate < 0 || offRate > 16) return -2;
 	ix.g.p.init(len, gbwtLen, numNodes, lineRate, offRate, ftabChars, eftabLen, 4);
-	if(!read_gfm_body(b1, ix.g, light)) return -2;
+	if(!read_gfm_body(b1, ix.g, light, bv ? &bv->sides : nullptr)) return -2;
+	if(bv) bv->sides_n = (size_t)ix.g.p.gbwtTotLen;
 	{   // reference names, '\n'-separated, '\0'-terminated
 		std::string cur;
 		while(b1.pos < b1.d.size()) {
@@ -173,7 +184,12 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 	// the SA sample (0.8 GB of a human-size index) and the reference bases (0.8 GB) are copied on threads of their own while this one parses on
 	std::thread t_offs, t_buf;
 	struct Join { std::thread &a, &b; ~Join() { if(a.joinable()) a.join(); if(b.joinable()) b.join(); } } join_{t_offs, t_buf};
-	if(!light) {
+	if(!light && bv) {
+		b2.u32();
+		if(!b2.has((size_t)ix.g.p.offsLen * 4)) return -2;
+		bv->offs = &b2.d[b2.pos]; bv->offs_n = (size_t)ix.g.p.offsLen * 4;
+		bv->buf = b4.d.begin(); bv->buf_n = b4.d.size();
+	} else if(!light) {
 		b2.u32();
 		if(!b2.has((size_t)ix.g.p.offsLen * 4)) return -2;
 		ix.g.offs.resize(ix.g.p.offsLen);
@@ -292,6 +308,7 @@ inline int load_host_index(const std::string& base, bool load_local, HostIndex& 
 			}
 		}
 	}
+	if(bv) { bv->f1.take(b1.d); bv->f2.take(b2.d); bv->f4.take(b4.d); }      // (the views point into these mappings)
 	uint32_t gl = ix.g.p.len;
 	ix.minK = 0;
 	while(gl > 0) { gl >>= 2; ix.minK++; }   // hi_aligner.h:3979-3984

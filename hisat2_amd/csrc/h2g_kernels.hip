@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <atomic>
+#include <chrono>
 #include <algorithm>
 #define H2G_EXT_OPTS 0      // likewise -I / --fr --rf --ff / --nofw --norc (h2g_align.h): go() units only
 #define H2G_HAPLOTYPE 0     // the primitive kernels of this unit (k_extend_alts, k_adjust_alt) run without haplotype lists; go() units: h2g_graph.h
@@ -197,17 +199,70 @@ struct h2g_stream {
 	unsigned cur_batch = 0;
 };
 
-template <typename T>
-static int upload(h2g_index* ix, const std::vector<T>& v, const T** out, size_t pad = 64) {
+// Large arrays travel through page-locked staging buffers filled by several threads: a pageable hipMemcpy of a human-size index (4.7 GB) was most of its 1.2 s load (round 6).
+// Chunk k of a copy is thread k mod T's: wait for its staging buffer, memcpy (from a host vector or straight from a mapped index file: the page faults spread over the threads
+// too), hipMemcpyAsync on the thread's own stream.
+struct Stager {
+	enum { T = 6, NB = 2 };
+	static constexpr size_t CH = (size_t)16 << 20;
+	uint8_t* buf[T][NB] = {}; hipStream_t st[T] = {}; hipEvent_t ev[T][NB] = {};
+	int device = 0; bool ok = false;
+	bool init(int dev) {
+		device = dev; ok = true;
+		for(int t = 0; t < T && ok; t++) {
+			ok = hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking) == hipSuccess;
+			for(int b = 0; b < NB && ok; b++) ok = hipHostMalloc((void**)&buf[t][b], CH, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[t][b], hipEventDisableTiming) == hipSuccess;
+		}
+		if(!ok) (void)hipGetLastError();
+		return ok;
+	}
+	~Stager() { for(int t = 0; t < T; t++) { for(int b = 0; b < NB; b++) { if(buf[t][b]) (void)hipHostFree(buf[t][b]); if(ev[t][b]) (void)hipEventDestroy(ev[t][b]); } if(st[t]) (void)hipStreamDestroy(st[t]); } }
+	bool copy(void* dst, const void* src, size_t bytes) {
+		return gather(dst, bytes, [src](uint8_t* out, size_t off, size_t len) { memcpy(out, (const uint8_t*)src + off, len); });
+	}
+	// the same pipeline with the staging buffers filled by `fill(out, off, len)`: bytes [off, off + len) of an array that exists nowhere on the host in one piece
+	template <class F>
+	bool gather(void* dst, size_t bytes, F fill) {
+		std::atomic<bool> good{true};
+		std::thread th[T];
+		const size_t nch = (bytes + CH - 1) / CH;
+		for(int t = 0; t < T; t++) th[t] = std::thread([&, t]() {
+			if(hipSetDevice(device) != hipSuccess) { good = false; return; }
+			size_t n = 0;
+			for(size_t k = (size_t)t; k < nch; k += T, n++) {
+				const int b = (int)(n % NB);
+				const size_t off = k * CH, len = bytes - off < CH ? bytes - off : CH;
+				if(n >= NB && hipEventSynchronize(ev[t][b]) != hipSuccess) { good = false; return; }
+				fill(buf[t][b], off, len);
+				if(hipMemcpyAsync((uint8_t*)dst + off, buf[t][b], len, hipMemcpyHostToDevice, st[t]) != hipSuccess || hipEventRecord(ev[t][b], st[t]) != hipSuccess) { good = false; return; }
+			}
+			if(hipStreamSynchronize(st[t]) != hipSuccess) good = false;
+		});
+		for(int t = 0; t < T; t++) th[t].join();
+		if(!good) (void)hipGetLastError();
+		return good;
+	}
+};
+static int upload_raw(h2g_index* ix, const void* src, size_t n, const void** out, size_t pad, Stager* sg) {
 	void* p = nullptr;
-	size_t bytes = v.size() * sizeof(T) + pad;
+	const size_t bytes = n + pad;
 	HIPCHK(hipMalloc(&p, bytes));
-	HIPCHK(hipMemset(p, 0, bytes));
-	if(!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
 	ix->allocs.push_back(p);
 	ix->device_bytes += bytes;
-	*out = (const T*)p;
+	HIPCHK(hipMemset((uint8_t*)p + n, 0, pad));                       // (the padding only: the rest is about to be written)
+	if(n) {
+		if(sg && sg->ok && n >= ((size_t)32 << 20)) { if(!sg->copy(p, src, n)) { snprintf(g_err, sizeof g_err, "index upload through the staging buffers failed"); return H2G_ERR_DEVICE; } }
+		else HIPCHK(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+	}
+	*out = p;
 	return H2G_OK;
+}
+template <typename T>
+static int upload(h2g_index* ix, const std::vector<T>& v, const T** out, size_t pad = 64, Stager* sg = nullptr) {
+	const void* p = nullptr;
+	const int rc = upload_raw(ix, v.data(), v.size() * sizeof(T), &p, pad ? pad : 64, sg);
+	*out = (const T*)p;
+	return rc;
 }
 
 extern "C" void h2g_load_opts_init(h2g_load_opts* o) { o->device = 0; o->load_local = 1; }
@@ -237,23 +292,42 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	// the local indexes (.5 / .6: 2.1 GB of a human-size index) are packed on a thread of their own, straight from the files, while the global
 	// index is read, parsed and uploaded here
 	LocalPack lp;
+	LocalPlan lpl;                                           // the local indexes' pieces in the mapped files: streamed to the device below, never assembled on the host
 	int lrc = 1;                                             // 1: no local files (an index built without them loads for rank / search only)
 	std::thread tlocal;
-	if(o.load_local) tlocal = std::thread([&]() { try { lrc = load_local_pack(base, 0, lp); } catch(...) { lrc = -2; } });   // (bad_alloc / length_error on a corrupt file must not escape the thread)
+	if(o.load_local) tlocal = std::thread([&]() { try { lrc = plan_local_pack(base, 0, lp, lpl); if(lrc == -1) lrc = 1; } catch(...) { lrc = -2; } });   // (bad_alloc / length_error on a corrupt file must not escape the thread)
 	struct Joiner { std::thread& t; ~Joiner() { if(t.joinable()) t.join(); } } joiner{tlocal};      // (every early return below waits for it)
 	int rc;
-	try { rc = load_host_index(base, false, ix->host); } catch(...) { rc = -2; }   // a length read from a corrupt file: an allocation failure is a format error, not std::terminate across the C ABI
+	const bool ltime = getenv("H2G_LOAD_TIMING") != nullptr;
+	const auto tl0 = std::chrono::steady_clock::now();
+	auto lsec = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count(); };
+	BigViews bv;                                             // sides, SA sample and reference bases stay in the mapped files until they are on the device
+	Stager sg;
+	sg.init(o.device);
+	try { rc = load_host_index(base, false, ix->host, false, &bv); } catch(...) { rc = -2; }
+	const double t_parse = lsec();   // a length read from a corrupt file: an allocation failure is a format error, not std::terminate across the C ABI
 	if(rc != 0) { if(tlocal.joinable()) tlocal.join(); delete ix; snprintf(g_err, sizeof g_err, "cannot read index %s", base); return rc == -1 ? H2G_ERR_IO : H2G_ERR_FORMAT; }
 	const HostGfm& g = ix->host.g;
 	fill_dgfm(g, ix->host.minK, &ix->dg);
 	int s = H2G_OK;
-	if((s = upload(ix, g.sides, &ix->dg.sides, 256)) || (s = upload(ix, g.ftab, &ix->dg.ftab)) ||
-	   (s = upload(ix, g.eftab, &ix->dg.eftab)) || (s = upload(ix, g.offs, &ix->dg.offs)) ||
+	{
+		const void *ds_ = nullptr, *do_ = nullptr;
+		if((s = upload_raw(ix, bv.sides, bv.sides_n, &ds_, 256, &sg)) || (s = upload_raw(ix, bv.offs, bv.offs_n, &do_, 64, &sg))) { h2g_index_free(ix); return s; }
+		ix->dg.sides = (const uint8_t*)ds_; ix->dg.offs = (const uint32_t*)do_;
+	}
+	if((s = upload(ix, g.ftab, &ix->dg.ftab)) ||
+	   (s = upload(ix, g.eftab, &ix->dg.eftab)) ||
 	   (s = upload(ix, g.rstarts, &ix->dg.rstarts)) || (s = upload(ix, g.plen, &ix->dg.plen)) ||
 	   (s = upload(ix, g.zOffs, &ix->dg.zoffs))) { h2g_index_free(ix); return s; }
 	const HostRef& r = ix->host.r;
 	ix->dr.nrefs = r.nrefs;
-	if((s = upload(ix, r.buf, &ix->dr.buf)) || (s = upload(ix, r.rec_start, &ix->dr.rec_start)) ||
+	{
+		const void* db_ = nullptr;
+		if((s = upload_raw(ix, bv.buf, bv.buf_n, &db_, 64, &sg))) { h2g_index_free(ix); return s; }
+		ix->dr.buf = (const uint8_t*)db_;
+	}
+	const double t_global = lsec();
+	if((s = upload(ix, r.rec_start, &ix->dr.rec_start)) ||
 	   (s = upload(ix, r.rec_len, &ix->dr.rec_len)) || (s = upload(ix, r.rec_bufoff, &ix->dr.rec_bufoff)) ||
 	   (s = upload(ix, r.refRecOffs, &ix->dr.refRecOffs)) || (s = upload(ix, r.refLens, &ix->dr.refLens))) { h2g_index_free(ix); return s; }
 	static_assert(sizeof(HostAlt) == sizeof(DAlt), "HostAlt mirrors DAlt");
@@ -275,12 +349,28 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 	}
 	memset(&ix->dls, 0, sizeof ix->dls);
 	if(tlocal.joinable()) tlocal.join();
+	const double t_join = lsec();
 	if(lrc == -2) { h2g_index_free(ix); snprintf(g_err, sizeof g_err, "cannot read the local indexes of %s", base); return H2G_ERR_FORMAT; }
 	if(o.load_local && lrc == 0 && !lp.desc.empty()) {
 		while(lp.first.size() <= g.nPat) lp.first.push_back((uint32_t)lp.desc.size());
-		const DLocalDesc* dd; const uint8_t* ds; const uint16_t* dw; const uint32_t* df; const uint32_t* dz;
-		if((s = upload(ix, lp.desc, &dd)) || (s = upload(ix, lp.sides, &ds, 256)) || (s = upload(ix, lp.words, &dw)) ||
-		   (s = upload(ix, lp.first, &df)) || (s = upload(ix, lp.zoffs, &dz))) { h2g_index_free(ix); return s; }
+		const DLocalDesc* dd; const uint8_t* ds = nullptr; const uint16_t* dw = nullptr; const uint32_t* df; const uint32_t* dz;
+		{	// the two packed arrays (sides: 128-byte aligned per index, 256 bytes of padding behind; 16-bit words: 64 entries of padding), gathered chunk by chunk out of the files
+			const size_t sb = lpl.nsides_tot + 256, wb = (lpl.nwords_tot + 64) * 2;
+			void *ps = nullptr, *pw = nullptr;
+			HIPCHK(hipMalloc(&ps, sb + 64)); ix->allocs.push_back(ps); ix->device_bytes += sb + 64;
+			HIPCHK(hipMalloc(&pw, wb + 64)); ix->allocs.push_back(pw); ix->device_bytes += wb + 64;
+			HIPCHK(hipMemset((uint8_t*)ps + sb, 0, 64)); HIPCHK(hipMemset((uint8_t*)pw + wb, 0, 64));
+			bool okc = sg.ok;
+			if(okc) okc = sg.gather(ps, sb, [&](uint8_t* out_, size_t off_, size_t len_) { local_fill_sides(lpl, out_, off_, len_); }) &&
+			              sg.gather(pw, wb, [&](uint8_t* out_, size_t off_, size_t len_) { local_fill_words(lpl, out_, off_, len_); });
+			if(!okc) {   // (no staging buffers: through one host chunk at a time)
+				std::vector<uint8_t> tmp((size_t)16 << 20);
+				for(size_t off_ = 0; off_ < sb; off_ += tmp.size()) { const size_t len_ = sb - off_ < tmp.size() ? sb - off_ : tmp.size(); local_fill_sides(lpl, tmp.data(), off_, len_); HIPCHK(hipMemcpy((uint8_t*)ps + off_, tmp.data(), len_, hipMemcpyHostToDevice)); }
+				for(size_t off_ = 0; off_ < wb; off_ += tmp.size()) { const size_t len_ = wb - off_ < tmp.size() ? wb - off_ : tmp.size(); local_fill_words(lpl, tmp.data(), off_, len_); HIPCHK(hipMemcpy((uint8_t*)pw + off_, tmp.data(), len_, hipMemcpyHostToDevice)); }
+			}
+			ds = (const uint8_t*)ps; dw = (const uint16_t*)pw;
+		}
+		if((s = upload(ix, lp.desc, &dd)) || (s = upload(ix, lp.first, &df)) || (s = upload(ix, lp.zoffs, &dz))) { h2g_index_free(ix); return s; }
 		ix->dls = lp.view(dd, ds, dw, df, dz);
 		ix->h_ldesc = lp.desc;
 		ix->host.local_first = lp.first;                     // (h2g_local_index_of)
@@ -294,6 +384,7 @@ extern "C" h2g_status h2g_index_load(const char* base, const h2g_load_opts* opts
 		if((s = upload(ix, d, &ix->d_spl[0])) || (s = upload(ix, a1, &ix->d_spl[1])) || (s = upload(ix, a2, &ix->d_spl[2]))) { h2g_index_free(ix); return s; }
 	}
 	if(!ix->alt_sites.empty()) { h2g_index* tmp_ = ix; const h2g_status rs_ = h2g_index_set_splice_sites(tmp_, nullptr, 0, 0); if(rs_ != H2G_OK) { h2g_index_free(ix); return rs_; } }
+	if(ltime) fprintf(stderr, "index load: parse %.3f s, global arrays on the device %.3f s, local pack joined %.3f s, all %.3f s (%.2f GB)\n", t_parse, t_global, t_join, lsec(), ix->device_bytes / 1e9);
 	*out = ix;
 	return H2G_OK;
 }

@@ -75,8 +75,13 @@ struct MappedFile {
 	}
 	~MappedFile() { if(p) munmap((void*)p, n); }
 };
-inline int load_local_pack(const std::string& base, uint32_t nPat, LocalPack& lp, unsigned nthreads = 8) {
-	MappedFile f5, f6;
+// one local index's pieces: where they lie in the files and where they go in the packed arrays (word arrays in packed order: ftab, eftab, offs (file 6), rstarts)
+struct LocalJob { size_t src_sides, dst_sides, nsides, src_w[4], dst_w, nw[4]; };
+// The walk over the headers alone: descriptors, '$' rows, first-index table, the jobs (ascending destinations) and the sizes of the two packed arrays without their padding.
+// load_local_pack copies the jobs into host vectors; the device loader (h2g_kernels.hip) streams them through its staging buffers instead and never builds the 2.1 GB of host arrays.
+struct LocalPlan { MappedFile f5, f6; std::vector<LocalJob> jobs; size_t nsides_tot = 0, nwords_tot = 0; };
+inline int plan_local_pack(const std::string& base, uint32_t nPat, LocalPack& lp, LocalPlan& pl) {
+	MappedFile& f5 = pl.f5; MappedFile& f6 = pl.f6;
 	if(!f5.open(base + ".5.ht2") || !f6.open(base + ".6.ht2")) return -1;
 	auto u32at = [](const MappedFile& f, size_t at, bool* bad) { uint32_t v = 0; if(at + 4 <= f.n) memcpy(&v, f.p + at, 4); else *bad = true; return v; };
 	auto u16at = [](const MappedFile& f, size_t at, bool* bad) { uint16_t v = 0; if(at + 2 <= f.n) memcpy(&v, f.p + at, 2); else *bad = true; return (uint32_t)v; };
@@ -88,8 +93,9 @@ inline int load_local_pack(const std::string& base, uint32_t nPat, LocalPack& lp
 	const int32_t lfc = (int32_t)u32at(f5, p5, &bad); p5 += 8;
 	if(bad) return -2;
 	if((size_t)nlocal > f5.n / 20) return -2;                // every local-index header is at least 20 bytes: a count beyond that is a corrupt / truncated file (never reserve() on it)
-	struct Job { size_t src_sides, dst_sides, nsides, src_w[4], dst_w, nw[4]; };   // word arrays in packed order: ftab, eftab, offs (file 6), rstarts
-	std::vector<Job> jobs;
+	typedef LocalJob Job;
+	std::vector<Job>& jobs = pl.jobs;
+	jobs.clear();
 	lp.desc.clear(); lp.zoffs.clear(); lp.first.clear();
 	lp.desc.reserve(nlocal); jobs.reserve(nlocal);
 	size_t nsides_tot = 0, nwords_tot = 0;
@@ -132,9 +138,48 @@ inline int load_local_pack(const std::string& base, uint32_t nPat, LocalPack& lp
 	}
 	while(lp.first.size() <= nPat) lp.first.push_back(nlocal);
 	if(lp.first.empty()) lp.first.assign(nPat + 1, 0);
-	lp.sides.assign(nsides_tot + 256, 0);
-	lp.words.assign(nwords_tot + 64, 0);
 	lp.zoffs.resize(lp.zoffs.size() + 4, H2G_MAX);
+	pl.nsides_tot = nsides_tot; pl.nwords_tot = nwords_tot;
+	return 0;
+}
+// bytes [off, off + len) of the packed SIDES array (LocalPlan) into `out`: the pieces of the jobs that overlap the range, zeros in the alignment gaps and behind the last job
+inline void local_fill_sides(const LocalPlan& pl, uint8_t* out, size_t off, size_t len) {
+	memset(out, 0, len);
+	const std::vector<LocalJob>& J = pl.jobs;
+	size_t lo = 0, hi = J.size();
+	while(lo < hi) { const size_t m = (lo + hi) / 2; if(J[m].dst_sides + J[m].nsides <= off) lo = m + 1; else hi = m; }
+	for(size_t k = lo; k < J.size() && J[k].dst_sides < off + len; k++) {
+		const size_t a = J[k].dst_sides > off ? J[k].dst_sides : off, b = J[k].dst_sides + J[k].nsides < off + len ? J[k].dst_sides + J[k].nsides : off + len;
+		if(b > a) memcpy(out + (a - off), pl.f5.p + J[k].src_sides + (a - J[k].dst_sides), b - a);
+	}
+}
+// ... and of the packed 16-bit WORD array (byte offsets)
+inline void local_fill_words(const LocalPlan& pl, uint8_t* out, size_t off, size_t len) {
+	memset(out, 0, len);
+	const std::vector<LocalJob>& J = pl.jobs;
+	auto jend = [&](const LocalJob& j) { return (j.dst_w + j.nw[0] + j.nw[1] + j.nw[2] + j.nw[3]) * 2; };
+	size_t lo = 0, hi = J.size();
+	while(lo < hi) { const size_t m = (lo + hi) / 2; if(jend(J[m]) <= off) lo = m + 1; else hi = m; }
+	for(size_t k = lo; k < J.size() && J[k].dst_w * 2 < off + len; k++) {
+		size_t w = J[k].dst_w * 2;
+		for(int a = 0; a < 4; a++) {
+			const size_t nb = J[k].nw[a] * 2;
+			const uint8_t* src = (a == 2 ? pl.f6.p : pl.f5.p) + J[k].src_w[a];
+			const size_t x = w > off ? w : off, y = w + nb < off + len ? w + nb : off + len;
+			if(y > x) memcpy(out + (x - off), src + (x - w), y - x);
+			w += nb;
+		}
+	}
+}
+inline int load_local_pack(const std::string& base, uint32_t nPat, LocalPack& lp, unsigned nthreads = 8) {
+	LocalPlan pl;
+	const int prc = plan_local_pack(base, nPat, lp, pl);
+	if(prc) return prc;
+	const MappedFile& f5 = pl.f5; const MappedFile& f6 = pl.f6;
+	typedef LocalJob Job;
+	const std::vector<Job>& jobs = pl.jobs;
+	lp.sides.assign(pl.nsides_tot + 256, 0);
+	lp.words.assign(pl.nwords_tot + 64, 0);
 	if(nthreads < 1) nthreads = 1;
 	std::vector<std::thread> th;
 	for(unsigned t = 0; t < nthreads; t++) th.emplace_back([&, t]() {

@@ -36,4 +36,4 @@ for name, exe, env, check in variants:
         r = subprocess.run([exe, "-f", "--no-spliced-alignment", "-p", "32", "-x", base, "-1", f1, "-2", f2, "-S", dest], env=dict(os.environ, H2G_CLI_TIMING="1", **env), capture_output=True, text=True)
         dt = time.perf_counter() - t0
         h = body_md5(dest) if (check and dest != "/dev/null") else ""
-        print("%-22s -> %-9s rc %d wall %.2f s = %.2f M reads/s %s | %s" % (name, "file" if dest != "/dev/null" else dest, r.returncode, dt, 2 * n / dt / 1e6, h, [l for l in r.stderr.splitlines() if l.startswith("time:")]), flush=True)
+        print("%-22s -> %-9s rc %d wall %.2f s = %.2f M reads/s %s | %s" % (name, "file" if dest != "/dev/null" else dest, r.returncode, dt, 2 * n / dt / 1e6, h, [l for l in r.stderr.splitlines() if l.startswith("time:") or l.startswith("index load:")]), flush=True)
