@@ -44,6 +44,26 @@ inline bool is_read_char(int c) {
 	return c == '-';
 }
 inline uint8_t base_code(int c) { switch(c | 0x20) { case 'c': return 1; case 'g': return 2; case 't': return 3; case 'n': return 4; } return 0; }
+// the two per-character tests as tables (0xff = not a base of the record): FASTA keeps is_read_char() characters, FASTQ keeps '.' (as N) and every isalpha() character
+struct BaseTables {
+	uint8_t fa[256], fq[256];
+	BaseTables() {
+		for(int c = 0; c < 256; c++) {
+			fa[c] = is_read_char(c) ? base_code(c) : 0xff;
+			const int d = c == '.' ? 'N' : c;
+			fq[c] = isalpha(d) ? base_code(d) : 0xff;
+		}
+	}
+};
+inline const BaseTables& base_tables() { static const BaseTables t; return t; }
+// appends the bases of [q, e) to `codes` through table `tb`: written unconditionally, kept when they are bases (no branch per character, no push_back)
+inline void append_bases(std::vector<uint8_t>& codes, const char* q, const char* e, const uint8_t* tb) {
+	const size_t at = codes.size();
+	codes.resize(at + (size_t)(e - q));
+	uint8_t* o = codes.data() + at;
+	for(; q < e; q++) { const uint8_t v = tb[(unsigned char)*q]; *o = v; o += v != 0xff; }
+	codes.resize((size_t)(o - codes.data()));
+}
 
 // Sequential stream of reads over a list of FASTA / FASTQ files (pat.cpp FastaPatternSource / FastqPatternSource), parsed
 // in parallel: a file is mapped, the record starts are found by all threads (FASTA: lines beginning with '>'; FASTQ: every
@@ -169,7 +189,7 @@ private:
 			return t5;
 		};
 		if(fasta_) {
-			for(; q < end; q++) if(is_read_char((unsigned char)*q)) b.codes.push_back(base_code(*q));
+			append_bases(b.codes, q, end, base_tables().fa);
 			trim();
 			b.offs.push_back((uint32_t)b.codes.size());
 			return;
@@ -177,7 +197,7 @@ private:
 		// FastqPatternSource::read (pat.cpp:932-945): '.' is N, every isalpha() character is a base through asc2dna
 		// (alphabet.cpp:298: A C G T N, every other letter reads as A); anything else is skipped
 		if(*(nm - 1) != '@') { fprintf(stderr, "Error: reads file does not look like a FASTQ file (record %llu does not start with '@'; wrapped records are not supported)\n", (unsigned long long)(count_ + (r - cur_))); exit(1); }
-		for(; q < end && *q != '\n'; q++) { int c = (unsigned char)*q; if(c == '.') c = 'N'; if(isalpha(c)) b.codes.push_back(base_code(c)); }
+		{ const char* le = (const char*)memchr(q, '\n', (size_t)(end - q)); if(!le) le = end; append_bases(b.codes, q, le, base_tables().fq); q = le; }
 		if(q + 1 < end && q[1] != '+') { fprintf(stderr, "Error: FASTQ record %.*s: the line after the sequence does not start with '+' (sequences wrapped over several lines are not supported)\n", (int)nlen, nm); exit(1); }
 		const size_t Lraw = b.codes.size() - c0;
 		const size_t t5 = trim();
