@@ -669,10 +669,12 @@ def main():
             # genome + FASTA, the build (measured: the repeat-structured 256 Mbp index builds in 0.9-1.5 x the random one's time), reads + timed runs + the reference over one batch;
             # when the metric's size does not fit the time left, the companion runs at the LARGEST size that does (build time is linear in the genome: multiples of 0.25 Gbp,
             # at least 1 Gbp) and its workload says so — a repeat-structured figure four times the 256 Mbp leg's size instead of none
-            need = lambda g: (1.2 * built + 100.0) * g / total + 150.0
+            # (1.5 x: on one box the repeat-structured 3.1 Gbp index built in 0.94 x the random genome's time, on another it was not done after 1.29 x — a shared host's load — and a
+            # build that runs into its time limit costs the run ten minutes and leaves nothing: profiles/r06_last/)
+            need = lambda g: (1.5 * built + 100.0) * g / total + 150.0
             glen_c = total
             if left < need(total):
-                glen_c = int(max(0.0, (left - 150.0) / ((1.2 * built + 100.0) / total)) // 250_000_000) * 250_000_000
+                glen_c = int(max(0.0, (left - 150.0) / ((1.5 * built + 100.0) / total)) // 250_000_000) * 250_000_000
             if glen_c < 1_000_000_000:
                 out["repeat_grch38size_pe"] = {"skipped": "%.0f s left of %.0f, about %.0f needed at the metric's size, %.0f at 1 Gbp (the random genome's index took %.0f s on this box)" % (left, hard, need(total), need(1e9), built)}
             else:
@@ -680,7 +682,7 @@ def main():
                 if glen_c != total:
                     out["repeat_grch38size_pe"] = {"skipped": "%.0f s left of %.0f, about %.0f needed at the metric's size: run at %d bp instead (%s)" % (left, hard, need(total), glen_c, name)}
                 try:
-                    out[name] = repeat_leg(a, api, synth, local, cache, glen=glen_c, build_timeout=left - 250.0, nbatch=min(4, max(1, int(a.batches))))
+                    out[name] = repeat_leg(a, api, synth, local, cache, glen=glen_c, build_timeout=left - 200.0, nbatch=min(4, max(1, int(a.batches))))
                 except Exception as e:         # noqa: BLE001
                     out[name] = {"error": repr(e)[:400]}
         legs_failed = [k for k, v in out.items() if isinstance(v, dict) and isinstance(v.get("parity_whole_batch"), dict) and not v["parity_whole_batch"].get("digest_equal", False)]

@@ -2329,7 +2329,9 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 				HIPCHK(hipStreamSynchronize(s->st));
 			}
 		}
-		if(orphan_T) HIPCHK(hipStreamWaitEvent(s->st, s->ev_pool[psel_f], 0));  // run k - 3's drain launch: done with this pool
+		// run k - 3's drain launch is done with this pool — and a run WITHOUT a drain launch (a small resident batch queued behind a large one) uses pool 0, which the drain launch
+		// of an earlier run may still be reading: every fast launch waits for the last reader of its pool
+		HIPCHK(hipStreamWaitEvent(s->st, s->ev_pool[psel_f], 0));
 		if(!s->d_bail_list[gsel]) HIPCHK(hipMalloc((void**)&s->d_bail_list[gsel], (s->max_reads + 4) * 4));
 		uint32_t* const bl = s->d_bail_list[gsel];
 		HIPCHK(hipMemsetAsync(bl + s->max_reads, 0, 16, s->st));

@@ -70,3 +70,35 @@ def test_batches_in_flight_keep_their_rows(g1_index, g1s_index, golden_dir, grap
         st.select_batch(k)
         assert _dense(st) == want[k], "batch %d" % k
     st.close(); ix.close()
+
+
+def test_a_small_batch_behind_a_large_one(g1_index, golden_dir):
+    """Two resident batches of different sizes queued alternately without a sync: the large one ends in a drain launch (the policy of >= 200 000 pairs), the small one does not —
+    its fast launch uses slot pool 0, which the large batch's drain launch may still be reading (go_run: every fast launch waits for the last reader of its pool)."""
+    _, s1 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_1.fa.gz"))
+    _, s2 = H.read_fasta_reads(os.path.join(golden_dir, "reads_pe_2.fa.gz"))
+    n = len(s1)
+    ix = api.Index(g1_index, device=0)
+    big_n, small_n = 220_000, 3 * n
+    sets = []
+    for k, cnt in enumerate((big_n, small_n)):
+        o = (np.arange(cnt) * (7 + 4 * k)) % n
+        m1 = np.stack([s1[i] for i in o]); m2 = np.stack([s2[i] for i in o])
+        sets.append((m1, m2, ["m%d_%d" % (k, i) for i in range(cnt)]))
+    want = [_one(ix, m1, m2, names, _dense) for m1, m2, names in sets]
+    st = api.Stream(ix, max_reads=big_n, max_bases=sets[0][0].size + 64)
+    for k, (m1, m2, names) in enumerate(sets):
+        st.select_batch(k)
+        c1, o1 = synth.flatten_reads(m1); c2, o2 = synth.flatten_reads(m2)
+        st.set_reads(c1, o1); st.set_read_names(names); st.set_mates(c2, o2, names)
+    for rep in range(6):
+        for k in (0, 1):
+            st.select_batch(k)
+            st.align_pairs_run()
+    st.sync()
+    st.select_batch(0)
+    assert int(st.counters().n_adopted) >= 0
+    for k in (1, 0):
+        st.select_batch(k)
+        assert _dense(st) == want[k], "batch %d" % k
+    st.close(); ix.close()
