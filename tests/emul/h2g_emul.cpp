@@ -721,6 +721,46 @@ int h2gemu_local_pack_check(Emu* e, const char* base) {
 	return 0;
 }
 
+// What the device loader does since round 6 — plan_local_pack + local_fill_sides / local_fill_words: any byte range of the two packed arrays straight out of the files, nothing
+// assembled on the host — against load_local_pack's arrays, in chunks of several (odd) sizes; and the global index's three big arrays as views into the mapped files (BigViews)
+// against the copies a plain load_host_index makes.  0 = byte-identical.
+int h2gemu_local_fill_check(Emu* e, const char* base) {
+	LocalPack a;
+	if(!e->host.local.empty()) {
+		if(load_local_pack(base, e->host.g.nPat, a, 3) != 0) return 1;
+		LocalPack b; LocalPlan pl;
+		if(plan_local_pack(base, e->host.g.nPat, b, pl) != 0) return 2;
+		if(a.desc.size() != b.desc.size() || memcmp(a.desc.data(), b.desc.data(), a.desc.size() * sizeof(DLocalDesc)) != 0) return 3;
+		if(a.first != b.first || a.zoffs != b.zoffs || a.ftabChars != b.ftabChars || a.offRate != b.offRate) return 4;
+		if(a.sides.size() != pl.nsides_tot + 256 || a.words.size() != pl.nwords_tot + 64) return 5;
+		const size_t chunks[4] = {(size_t)1 << 20, 999983, 4096 + 7, (size_t)16 << 20};
+		std::vector<uint8_t> tmp((size_t)16 << 20);
+		for(size_t ch : chunks) {
+			for(size_t off = 0; off < a.sides.size(); off += ch) {
+				const size_t len = a.sides.size() - off < ch ? a.sides.size() - off : ch;
+				local_fill_sides(pl, tmp.data(), off, len);
+				if(memcmp(tmp.data(), a.sides.data() + off, len) != 0) return 6;
+			}
+			const size_t wb = a.words.size() * 2;
+			for(size_t off = 0; off < wb; off += ch) {
+				const size_t len = wb - off < ch ? wb - off : ch;
+				local_fill_words(pl, tmp.data(), off, len);
+				if(memcmp(tmp.data(), (const uint8_t*)a.words.data() + off, len) != 0) return 7;
+			}
+		}
+	}
+	HostIndex h2;
+	BigViews bv;
+	if(load_host_index(base, false, h2, false, &bv) != 0) return 8;
+	const HostIndex& h1 = e->host;
+	if(bv.sides_n != h1.g.sides.size() || memcmp(bv.sides, h1.g.sides.data(), bv.sides_n) != 0) return 9;
+	if(bv.offs_n != h1.g.offs.size() * 4 || memcmp(bv.offs, h1.g.offs.data(), bv.offs_n) != 0) return 10;
+	if(bv.buf_n + 16 != h1.r.buf.size() || memcmp(bv.buf, h1.r.buf.data(), bv.buf_n) != 0) return 11;
+	if(!h2.g.sides.empty() || !h2.g.offs.empty() || !h2.r.buf.empty()) return 12;          // (nothing was copied)
+	if(h2.g.ftab != h1.g.ftab || h2.names != h1.names || h2.r.rec_start != h1.r.rec_start || h2.g.rstarts != h1.g.rstarts) return 13;
+	return 0;
+}
+
 #ifdef H2G_MEMPROF
 void mp_report(unsigned nreads, const char** opnames, int nops);
 void h2gemu_memprof_report(unsigned nreads) {

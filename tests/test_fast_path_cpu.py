@@ -198,6 +198,17 @@ def test_local_indexes_packed_straight_from_the_files(genome, graph_genome):
         assert e.L.h2gemu_local_pack_check(e.h, base.encode()) == 0
 
 
+def test_index_arrays_straight_from_the_mapped_files(genome, graph_genome):
+    """the device loader's host side (round 6): any byte range of the packed local-index arrays gathered out of the files (plan_local_pack + local_fill_*) == load_local_pack's
+    arrays, and the global index's sides / SA sample / reference bases as views into the mapped files (BigViews) == the copies a plain load makes — linear and graph index"""
+    import ctypes as C
+    from h2gemu_py import Emu
+    for base in (genome[0], graph_genome[0]):
+        e = Emu(base)
+        e.L.h2gemu_local_fill_check.argtypes = [C.c_void_p, C.c_char_p]
+        assert e.L.h2gemu_local_fill_check(e.h, base.encode()) == 0
+
+
 def test_staged_graph_lf_step_equals_the_fused_one(g1s_index):
     """h2g_graph_staged.h (the LF step of one row cut at its dependent loads, four rows in flight stage by stage: measurement kernel k_glf_chain and the
     groundwork of several rows per lane) against glf1_top_fused: 50 000 x 4 walks of 12 steps on the global index, 50 000 rows of local indexes; the searches' step with a required character in stages
