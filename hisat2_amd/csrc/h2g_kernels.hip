@@ -163,7 +163,7 @@ struct h2g_stream {
 	bool ran_fast = false;
 	// development / measurement knobs (h2g_stream_tune; their H2G_* environment names are read ONCE, when the stream is created)
 	struct Tune { int fast = 1, blocks_per_cu = 0, pair_slots = 0, no_second_pass = 0; unsigned mach_div = 0 /* auto */, mach_min = 4, mach_total = H2G_MACH_TOTAL; int mach_total_auto = 1; int fast_reserve = H2G_FAST_RESERVE_DEFAULT; long dbg_read = -1;
-	              int tail = H2G_DEFAULT_TAIL, align_mate = H2G_DEFAULT_ALIGN_MATE; int orphan = -1 /* auto */, drain_grid = H2G_DRAIN_GRID, mate_handover = -1 /* auto */; } tune;
+	              int tail = H2G_DEFAULT_TAIL, tail_auto = 1, align_mate = H2G_DEFAULT_ALIGN_MATE; int orphan = -1 /* auto */, drain_grid = H2G_DRAIN_GRID, mate_handover = -1 /* auto */; } tune;
 	h2g_align_params last_p; int last_paired = -1;   // the option set of the last go_run (a different one waits for the machine streams)
 	uint32_t aln_slots = 0;           // alignment records kept per unpaired read in d_aln (>= -k of the last run)
 	uint32_t pair_slots = 0;          // report events kept per mate in d_paln (>= H2G_PAIR_RES_CAP; grows with -k)
@@ -614,7 +614,7 @@ extern "C" h2g_status h2g_stream_create(h2g_index* ix, size_t max_reads, size_t 
 		s->tune.fast = (int)env("H2G_GO_FAST", 1); s->tune.blocks_per_cu = (int)env("H2G_GO_BLOCKS_PER_CU", 0); s->tune.pair_slots = (int)env("H2G_PAIR_SLOTS", 0);
 		s->tune.no_second_pass = (int)env("H2G_GO_NO_SECOND_PASS", 0); s->tune.mach_div = (unsigned)env("H2G_MACH_DIV", 0); s->tune.mach_min = (unsigned)env("H2G_MACH_MIN", 4);
 		s->tune.dbg_read = env("H2G_GO_DBG_READ", -1);
-		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
+		s->tune.tail = (int)env("H2G_FAST_TAIL", H2G_DEFAULT_TAIL); s->tune.tail_auto = getenv("H2G_FAST_TAIL") ? 0 : 1; s->tune.align_mate = (int)env("H2G_FAST_AM", H2G_DEFAULT_ALIGN_MATE);
 		s->tune.orphan = (int)env("H2G_FAST_ORPHAN", -1); s->tune.drain_grid = (int)env("H2G_DRAIN_GRID", H2G_DRAIN_GRID); s->tune.mate_handover = (int)env("H2G_FAST_MATE_HANDOVER", -1);
 		s->tune.mach_total = (unsigned)env("H2G_MACH_TOTAL", H2G_MACH_TOTAL); s->tune.mach_total_auto = getenv("H2G_MACH_TOTAL") ? 0 : 1; s->tune.fast_reserve = (int)env("H2G_FAST_RESERVE", H2G_FAST_RESERVE_DEFAULT);
 		{ const long m = env("H2G_MSTREAMS", H2G_MSTREAMS_DEFAULT); s->mstreams = (unsigned)(m < 1 ? 1 : m > H2G_MSTREAMS_MAX ? H2G_MSTREAMS_MAX : m); }
@@ -2370,6 +2370,11 @@ static h2g_status go_run(h2g_stream* s, const h2g_align_params* p, bool paired) 
 			HIPCHK(hipMemsetAsync(ol + s->orphan_cap, 0, 16, s->st));
 			F.orphan_T = orphan_T; F.orphan_list = ol; F.orphan_count = ol + s->orphan_cap; F.mate_handover = mate_ho ? 1u : 0u;
 			D.adopt_slot_words = fgeo[3] / 4;
+			// The drain launch's own tail (the last reads of each of its workgroups go to the machine).  With few hand-ons the machine's passes are short and the tail is a third of
+			// what they get: the drain launch finishes its reads itself (lease ZE, random genome: 11.48 -> 11.16 ms per step, hand-ons 2 830 -> 1 880); where the machine's passes are
+			// the step (more than 1.5 % handed on: the policy of mach_total) they absorb the tail for nothing and a drain launch that runs to its last read would be the longer one
+			// (repeat-structured: 37.8 -> 39.0 ms with it): the tail stays.  A caller's own setting (H2G_FAST_TAIL, "tail") is kept as it is.
+			if(s->tune.tail_auto) D.tail = linear && paired && (size_t)s->last_bails * 1000 > units_f * 15 ? (uint32_t)H2G_DEFAULT_TAIL : 0u;
 			D.slots = s->d_drain_slots;
 			D.adopt_list = ol; D.adopt_count = ol + s->orphan_cap; D.adopt_slots = F.slots;
 			D.work = reinterpret_cast<uint32_t*>(cblk + 13);
@@ -2824,7 +2829,7 @@ extern "C" __attribute__((visibility("default"))) int h2g_stream_tune(h2g_stream
 	const std::string k(key);
 	if(k == "fast") s->tune.fast = (int)v; else if(k == "blocks_per_cu") s->tune.blocks_per_cu = (int)v; else if(k == "pair_slots") s->tune.pair_slots = (int)v;
 	else if(k == "no_second_pass") s->tune.no_second_pass = (int)v; else if(k == "mach_div") s->tune.mach_div = (unsigned)v; else if(k == "mach_min") s->tune.mach_min = (unsigned)v;
-	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") s->tune.tail = (int)v; else if(k == "align_mate") s->tune.align_mate = (int)v;
+	else if(k == "dbg_read") s->tune.dbg_read = v; else if(k == "tail") { s->tune.tail = (int)v; s->tune.tail_auto = 0; } else if(k == "align_mate") s->tune.align_mate = (int)v;
 	else if(k == "mach_total") { s->tune.mach_total_auto = v <= 0; s->tune.mach_total = v <= 0 ? H2G_MACH_TOTAL : (unsigned)v; }      // (0 = the default policy)
 	else if(k == "fast_reserve") s->tune.fast_reserve = (int)v;
 	else if(k == "mate_handover") s->tune.mate_handover = (int)v;
